@@ -1,0 +1,448 @@
+/*
+ * oracle/orc_dec.c -- CPU ORACLE (test infrastructure only).
+ * NAL layer (7.3.1, 7.4.1.2.4), picture order count (8.2.1), reference list
+ * construction (8.2.4), reference marking (8.2.5), DPB output/bumping (C.4.5)
+ * and the reference wrapper's display-area crop.
+ * Restates: cuvidParseVideoData + the three parser callbacks
+ * (/root/reference/nv_dec/nv_dec.cpp:23-52, :394), the EOS flush (:389-392)
+ * and nvdec_create_decoder's target rectangle (:513-519).
+ */
+#include "orc_internal.h"
+
+/* ------------------------------ DPB helpers ------------------------------ */
+static int level_max_dpb_mbs(int level_idc, int constraint_flags) {
+    switch (level_idc) {
+    case 9: case 10: return 396;
+    case 11: return (constraint_flags & 0x10) ? 396 : 900;   /* level 1b signalled via constraint_set3 */
+    case 12: case 13: case 20: return 2376;
+    case 21: return 4752;
+    case 22: case 30: return 8100;
+    case 31: return 18000;
+    case 32: return 20480;
+    case 40: case 41: return 32768;
+    case 42: return 34816;
+    case 50: return 110400;
+    default: return 184320;
+    }
+}
+
+static void free_pictures(OrcDec *d) {
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        free(d->dpb[i].y); free(d->dpb[i].u); free(d->dpb[i].v); free(d->dpb[i].mbs);
+        memset(&d->dpb[i], 0, sizeof d->dpb[i]);
+    }
+    d->cur = NULL;
+}
+
+static void emit(OrcDec *d, Picture *p) {
+    const Sps *s = d->asps;
+    OrcFrame f;
+    int cw = d->mb_w * 16, ch = d->mb_h * 16;
+    int dw = cw - 2 * (s->crop_left + s->crop_right), dh = ch - 2 * (s->crop_top + s->crop_bottom);
+    if (dw <= 0 || dh <= 0) { dw = cw; dh = ch; }
+    /* nv_dec.cpp:513-519: target size = display_area size, display_area origin forced to (0,0) */
+    f.y = p->y; f.u = p->u; f.v = p->v;
+    f.width = dw; f.height = dh; f.stride_y = p->stride_y; f.stride_c = p->stride_c;
+    f.poc = p->poc; f.frame_type = p->frame_type; f.decode_index = p->decode_index;
+    p->needed_for_output = 0;
+    if (d->cb) d->cb(d->user, &f);
+}
+
+static Picture *smallest_poc_waiting(OrcDec *d, const Picture *exclude) {
+    Picture *best = NULL;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (!p->in_use || p == exclude || !p->needed_for_output) continue;
+        if (!best || p->poc < best->poc) best = p;
+    }
+    return best;
+}
+static void release_unused(OrcDec *d) {
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (p->in_use && p != d->cur && !p->is_ref && !p->needed_for_output) p->in_use = 0;
+    }
+}
+void orc_output_all(OrcDec *d) {
+    Picture *p;
+    while ((p = smallest_poc_waiting(d, d->cur)) != NULL) emit(d, p);
+    release_unused(d);
+}
+
+static int activate(OrcDec *d, const Sps *sps, const Pps *pps) {
+    int changed = !d->asps || d->mb_w != sps->mb_width || d->mb_h != sps->mb_height;
+    d->asps = sps; d->apps = pps;
+    int frame_mbs = sps->mb_width * sps->mb_height;
+    int size = level_max_dpb_mbs(sps->level_idc, sps->constraint_flags) / frame_mbs;
+    if (size > 16) size = 16;
+    if (sps->max_dec_frame_buffering >= 0) size = sps->max_dec_frame_buffering;
+    if (size < sps->max_num_ref_frames) size = sps->max_num_ref_frames;
+    if (size < 1) size = 1;
+    if (size > 16) size = 16;
+    d->dpb_size = size;
+    if (changed) {
+        free_pictures(d);
+        d->mb_w = sps->mb_width; d->mb_h = sps->mb_height;
+        d->width = d->mb_w * 16; d->height = d->mb_h * 16;
+        for (int i = 0; i <= ORC_MAX_DPB; i++) {
+            Picture *p = &d->dpb[i];
+            p->stride_y = d->width; p->stride_c = d->width / 2;
+            p->y = (uint8_t *)malloc((size_t)d->width * d->height);
+            p->u = (uint8_t *)malloc((size_t)d->width * d->height / 4);
+            p->v = (uint8_t *)malloc((size_t)d->width * d->height / 4);
+            p->mbs = (MbInfo *)malloc(sizeof(MbInfo) * frame_mbs);
+            if (!p->y || !p->u || !p->v || !p->mbs) ORC_FAIL(d, "out of memory");
+        }
+    }
+    return 0;
+}
+
+/* 8.2.1 decoding process for picture order count (frames only) */
+static int compute_poc(OrcDec *d, const SliceHdr *sh) {
+    const Sps *s = d->asps;
+    int max_frame_num = 1 << s->log2_max_frame_num;
+    if (s->poc_type == 0) {
+        int max_lsb = 1 << s->log2_max_poc_lsb, prev_msb, prev_lsb;
+        if (sh->idr) { prev_msb = 0; prev_lsb = 0; }
+        else if (d->prev_ref_has_mmco5) { prev_msb = 0; prev_lsb = 0; /* frame: tempPicOrderCnt of a frame after mmco5 is 0 */ }
+        else { prev_msb = d->prev_poc_msb; prev_lsb = d->prev_poc_lsb; }
+        int msb;
+        if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+        else if (sh->poc_lsb > prev_lsb && sh->poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+        else msb = prev_msb;
+        int top = msb + sh->poc_lsb, bot = top + sh->delta_poc_bottom;
+        if (sh->nal_ref_idc) { d->prev_poc_msb = msb; d->prev_poc_lsb = sh->poc_lsb; }
+        return orc_min(top, bot);
+    }
+    int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset;
+    int prev_fn = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num;
+    int off = sh->idr ? 0 : (prev_fn > sh->frame_num ? prev_off + max_frame_num : prev_off);
+    d->prev_frame_num_offset = off;
+    if (s->poc_type == 2) {
+        if (sh->idr) return 0;
+        return sh->nal_ref_idc ? 2 * (off + sh->frame_num) : 2 * (off + sh->frame_num) - 1;
+    }
+    /* type 1 */
+    int abs_fn = s->num_ref_frames_in_poc_cycle ? off + sh->frame_num : 0;
+    if (!sh->nal_ref_idc && abs_fn > 0) abs_fn--;
+    int expected = 0, cycle_sum = 0;
+    for (int i = 0; i < s->num_ref_frames_in_poc_cycle; i++) cycle_sum += s->offset_for_ref_frame[i];
+    if (abs_fn > 0) {
+        int cnt = (abs_fn - 1) / s->num_ref_frames_in_poc_cycle, in_cycle = (abs_fn - 1) % s->num_ref_frames_in_poc_cycle;
+        expected = cnt * cycle_sum;
+        for (int i = 0; i <= in_cycle; i++) expected += s->offset_for_ref_frame[i];
+    }
+    if (!sh->nal_ref_idc) expected += s->offset_for_non_ref_pic;
+    int top = expected + sh->delta_poc[0], bot = top + s->offset_for_top_to_bottom + sh->delta_poc[1];
+    return orc_min(top, bot);
+}
+
+int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
+    const Pps *pps = &d->pps[sh->pps_id];
+    const Sps *sps = &d->sps[pps->sps_id];
+    if (sh->idr || !d->asps) {
+        /* new coded video sequence: output everything that is waiting (no_output_of_prior_pics
+         * would discard instead; the reference's CUVID parser displays them, so do we) */
+        if (d->asps) {
+            for (int i = 0; i <= ORC_MAX_DPB; i++) d->dpb[i].is_ref = 0;
+            orc_output_all(d);
+        }
+        if (activate(d, sps, pps) < 0) return -1;
+    } else {
+        if (sps != d->asps && (sps->mb_width != d->mb_w || sps->mb_height != d->mb_h)) ORC_FAIL(d, "SPS change without IDR");
+        d->asps = sps; d->apps = pps;
+    }
+    release_unused(d);
+    Picture *cur = NULL;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) if (!d->dpb[i].in_use) { cur = &d->dpb[i]; break; }
+    if (!cur) ORC_FAIL(d, "DPB overflow (no free picture)");
+    cur->in_use = 1; cur->is_ref = 0; cur->needed_for_output = 0; cur->has_mmco5 = 0;
+    cur->id = d->next_pic_id++; cur->decode_index = d->decode_count++;
+    cur->frame_num = sh->frame_num; cur->is_idr = sh->idr; cur->long_term_frame_idx = -1;
+    cur->frame_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? 1 : 2);
+    cur->poc = compute_poc(d, sh);
+    int n = d->mb_w * d->mb_h;
+    for (int i = 0; i < n; i++) cur->mbs[i].slice_num = -1;
+    /* missing macroblocks stay visible as mid-grey rather than stale data */
+    memset(cur->y, 128, (size_t)d->width * d->height);
+    memset(cur->u, 128, (size_t)d->width * d->height / 4);
+    memset(cur->v, 128, (size_t)d->width * d->height / 4);
+    d->cur = cur; d->cur_mb_count = 0; d->slice_num = 0;
+    d->first_sh = *sh;
+    return 0;
+}
+
+/* 8.2.4.1 + 8.2.4.2.1 + 8.2.4.3: RefPicList0 for P slices of frames */
+int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
+    d->ref_count[0] = d->ref_count[1] = 0;
+    memset(d->ref_list, 0, sizeof d->ref_list);
+    if (sh->slice_type == SLICE_I) return 0;
+    int max_frame_num = 1 << d->asps->log2_max_frame_num;
+    Picture *st[ORC_MAX_DPB + 1], *lt[ORC_MAX_DPB + 1]; int nst = 0, nlt = 0;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (!p->in_use || p == d->cur) continue;
+        if (p->is_ref == 1) {
+            p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
+            p->pic_num = p->frame_num_wrap; st[nst++] = p;
+        } else if (p->is_ref == 2) { p->long_term_pic_num = p->long_term_frame_idx; lt[nlt++] = p; }
+    }
+    for (int i = 0; i < nst; i++) for (int j = i + 1; j < nst; j++) if (st[j]->pic_num > st[i]->pic_num) { Picture *t = st[i]; st[i] = st[j]; st[j] = t; }
+    for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_pic_num < lt[i]->long_term_pic_num) { Picture *t = lt[i]; lt[i] = lt[j]; lt[j] = t; }
+    Picture *list[34]; memset(list, 0, sizeof list);
+    int n = 0, nact = sh->num_ref_idx[0];
+    for (int i = 0; i < nst && n < 33; i++) list[n++] = st[i];
+    for (int i = 0; i < nlt && n < 33; i++) list[n++] = lt[i];
+    if (n > nact) for (int i = nact; i < 34; i++) list[i] = NULL;
+    if (sh->rplm_flag[0]) {
+        int pred = sh->frame_num, idx = 0;
+        for (int k = 0; k < sh->n_rplm[0]; k++) {
+            const RplmOp *op = &sh->rplm[0][k];
+            Picture *target = NULL;
+            if (op->idc < 2) {
+                int nowrap;
+                if (op->idc == 0) { nowrap = pred - (op->val + 1); if (nowrap < 0) nowrap += max_frame_num; }
+                else { nowrap = pred + (op->val + 1); if (nowrap >= max_frame_num) nowrap -= max_frame_num; }
+                pred = nowrap;
+                int pic_num = nowrap > sh->frame_num ? nowrap - max_frame_num : nowrap;
+                for (int i = 0; i < nst; i++) if (st[i]->pic_num == pic_num) target = st[i];
+            } else {
+                for (int i = 0; i < nlt; i++) if (lt[i]->long_term_pic_num == op->val) target = lt[i];
+            }
+            if (!target) ORC_FAIL(d, "ref_pic_list_modification names a missing picture");
+            if (idx >= nact) ORC_FAIL(d, "too many ref_pic_list_modification operations");
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+        }
+    }
+    for (int i = 0; i < nact; i++) d->ref_list[0][i] = list[i];
+    d->ref_count[0] = nact;
+    return 0;
+}
+
+/* 8.2.5 decoded reference picture marking */
+static void mark_current(OrcDec *d) {
+    Picture *cur = d->cur; const SliceHdr *sh = &d->first_sh;
+    int max_frame_num = 1 << d->asps->log2_max_frame_num;
+    if (!sh->nal_ref_idc) return;
+    if (sh->idr) {
+        for (int i = 0; i <= ORC_MAX_DPB; i++) if (&d->dpb[i] != cur) d->dpb[i].is_ref = 0;
+        if (sh->long_term_reference_flag) { cur->is_ref = 2; cur->long_term_frame_idx = 0; d->max_long_term_frame_idx = 0; }
+        else { cur->is_ref = 1; d->max_long_term_frame_idx = -1; }
+        return;
+    }
+    /* refresh PicNum of short-term pictures relative to the current frame_num */
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (p->in_use && p != cur && p->is_ref == 1) {
+            p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
+            p->pic_num = p->frame_num_wrap;
+        }
+    }
+    int made_long = 0;
+    if (sh->adaptive_marking) {
+        for (int k = 0; k < sh->n_mmco; k++) {
+            const Mmco *m = &sh->mmco[k];
+            int pic_num_x = sh->frame_num - (m->diff_pic_nums_minus1 + 1);
+            for (int i = 0; i <= ORC_MAX_DPB; i++) {
+                Picture *p = &d->dpb[i];
+                if (!p->in_use || p == cur) continue;
+                switch (m->op) {
+                case 1: if (p->is_ref == 1 && p->pic_num == pic_num_x) p->is_ref = 0; break;
+                case 2: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_pic_num) p->is_ref = 0; break;
+                case 3:
+                    if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx && !(p->pic_num == pic_num_x && 0)) p->is_ref = 0;
+                    break;
+                case 4: if (p->is_ref == 2 && p->long_term_frame_idx > m->max_long_term_frame_idx_plus1 - 1) p->is_ref = 0; break;
+                case 5: p->is_ref = 0; break;
+                case 6: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx) p->is_ref = 0; break;
+                }
+            }
+            if (m->op == 3)
+                for (int i = 0; i <= ORC_MAX_DPB; i++) {
+                    Picture *p = &d->dpb[i];
+                    if (p->in_use && p != cur && p->is_ref == 1 && p->pic_num == pic_num_x) { p->is_ref = 2; p->long_term_frame_idx = m->long_term_frame_idx; }
+                }
+            if (m->op == 4) d->max_long_term_frame_idx = m->max_long_term_frame_idx_plus1 - 1;
+            if (m->op == 5) { d->max_long_term_frame_idx = -1; cur->has_mmco5 = 1; }
+            if (m->op == 6) { cur->is_ref = 2; cur->long_term_frame_idx = m->long_term_frame_idx; made_long = 1; }
+        }
+    } else {
+        int nst = 0, nlt = 0; Picture *oldest = NULL;
+        for (int i = 0; i <= ORC_MAX_DPB; i++) {
+            Picture *p = &d->dpb[i];
+            if (!p->in_use || p == cur) continue;
+            if (p->is_ref == 1) { nst++; if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p; }
+            else if (p->is_ref == 2) nlt++;
+        }
+        if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) oldest->is_ref = 0;
+    }
+    if (!made_long) cur->is_ref = 1;
+}
+
+void orc_finish_picture(OrcDec *d) {
+    Picture *cur = d->cur;
+    if (!cur) return;
+    orc_deblock_picture(d, cur);
+    mark_current(d);
+    d->prev_frame_num = cur->frame_num;
+    d->prev_ref_has_mmco5 = 0;
+    if (cur->has_mmco5) {
+        /* 8.2.1: after mmco5 the picture is inferred to have had frame_num 0 and POC relative to itself */
+        d->prev_ref_has_mmco5 = 1; cur->frame_num = 0;
+        Picture *p; while ((p = smallest_poc_waiting(d, cur)) != NULL) emit(d, p);
+        cur->poc = 0;
+    }
+    /* C.4.5.2 / C.4.5.3 */
+    d->cur = NULL;
+    Picture *w = smallest_poc_waiting(d, cur);
+    if (!cur->is_ref && (!w || w->poc > cur->poc)) { cur->needed_for_output = 1; emit(d, cur); cur->in_use = 0; release_unused(d); return; }
+    cur->needed_for_output = 1;
+    for (;;) {
+        int used = 0;
+        for (int i = 0; i <= ORC_MAX_DPB; i++) { Picture *p = &d->dpb[i]; if (p->in_use && (p->is_ref || p->needed_for_output)) used++; }
+        if (used <= d->dpb_size) break;
+        Picture *p = smallest_poc_waiting(d, NULL);
+        if (!p) break;                       /* DPB full of references: non-conformant, keep going */
+        emit(d, p);
+    }
+    release_unused(d);
+}
+
+/* ------------------------------- NAL layer ------------------------------- */
+static int same_picture(const SliceHdr *a, const SliceHdr *b) {       /* 7.4.1.2.4 */
+    if (a->frame_num != b->frame_num || a->pps_id != b->pps_id) return 0;
+    if ((a->nal_ref_idc == 0) != (b->nal_ref_idc == 0)) return 0;
+    if (a->poc_lsb != b->poc_lsb || a->delta_poc_bottom != b->delta_poc_bottom) return 0;
+    if (a->delta_poc[0] != b->delta_poc[0] || a->delta_poc[1] != b->delta_poc[1]) return 0;
+    if (a->idr != b->idr) return 0;
+    if (a->idr && a->idr_pic_id != b->idr_pic_id) return 0;
+    return 1;
+}
+
+OrcDec *orc_open(orc_frame_cb cb, void *user) {
+    OrcDec *d = (OrcDec *)calloc(1, sizeof(OrcDec));
+    if (!d) return NULL;
+    d->cb = cb; d->user = user; d->max_long_term_frame_idx = -1;
+    return d;
+}
+void orc_close(OrcDec *d) {
+    if (!d) return;
+    free_pictures(d); free(d->rbsp); free(d);
+}
+const char *orc_last_error(const OrcDec *d) { return d->err; }
+
+int orc_stream_info(const OrcDec *d, int *dw, int *dh, int *cw, int *ch) {
+    if (!d->asps) return -1;
+    const Sps *s = d->asps;
+    int w = d->mb_w * 16, h = d->mb_h * 16;
+    if (cw) *cw = w;
+    if (ch) *ch = h;
+    int x = w - 2 * (s->crop_left + s->crop_right), y = h - 2 * (s->crop_top + s->crop_bottom);
+    if (x <= 0 || y <= 0) { x = w; y = h; }
+    if (dw) *dw = x;
+    if (dh) *dh = y;
+    return 0;
+}
+
+int orc_decode_nal(OrcDec *d, const uint8_t *nal, size_t len) {
+    if (len < 1) return 0;
+    d->err[0] = 0;
+    if (nal[0] & 0x80) ORC_FAIL(d, "forbidden_zero_bit set");
+    int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
+    if (len > d->rbsp_cap) { free(d->rbsp); d->rbsp = (uint8_t *)malloc(len + 16); d->rbsp_cap = len; if (!d->rbsp) ORC_FAIL(d, "out of memory"); }
+    size_t n = 0; int zeros = 0;
+    for (size_t i = 1; i < len; i++) {                /* 7.4.1: drop emulation_prevention_three_byte */
+        if (zeros >= 2 && nal[i] == 3) { zeros = 0; continue; }
+        d->rbsp[n++] = nal[i];
+        zeros = nal[i] == 0 ? zeros + 1 : 0;
+    }
+    Bits b; bits_init(&b, d->rbsp, n);
+    switch (type) {
+    case 7: return orc_parse_sps(d, &b);
+    case 8: return orc_parse_pps(d, &b);
+    case 1: case 5: {
+        SliceHdr sh;
+        if (orc_parse_slice_header(d, &b, type, ref_idc, &sh) < 0) return -1;
+        if (d->cur && !same_picture(&d->first_sh, &sh)) orc_finish_picture(d);
+        if (!d->cur) { if (orc_start_picture(d, &sh) < 0) return -1; }
+        else d->slice_num++;
+        d->sh = sh;
+        if (sh.first_mb >= d->mb_w * d->mb_h) ORC_FAIL(d, "first_mb_in_slice out of range");
+        if (orc_build_ref_lists(d, &sh) < 0) return -1;
+        return orc_decode_slice_data(d, &b);
+    }
+    case 10: case 11:
+        if (d->cur) orc_finish_picture(d);
+        return 0;
+    default: return 0;                                 /* SEI, AUD, filler, ... */
+    }
+}
+
+int orc_decode_annexb(OrcDec *d, const uint8_t *buf, size_t len) {
+    size_t i = 0; int count = 0;
+    /* locate first start code */
+    while (i + 3 <= len && !(buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1)) i++;
+    if (i + 3 > len) return 0;
+    while (i + 3 <= len) {
+        size_t start = i + 3, j = start;
+        while (j + 3 <= len && !(buf[j] == 0 && buf[j + 1] == 0 && buf[j + 2] == 1)) j++;
+        size_t end = (j + 3 <= len) ? j : len;
+        size_t e = end;
+        while (e > start && buf[e - 1] == 0) e--;      /* trailing_zero_8bits / 4-byte start code zero */
+        if (e > start) { if (orc_decode_nal(d, buf + start, e - start) < 0) return -1; count++; }
+        if (j + 3 > len) break;
+        i = j;
+    }
+    return count;
+}
+
+void orc_flush(OrcDec *d) {
+    if (d->cur) orc_finish_picture(d);
+    for (int i = 0; i <= ORC_MAX_DPB; i++) d->dpb[i].is_ref = 0;
+    if (d->asps) orc_output_all(d);
+}
+
+/* ------------------------- buffer convenience API ------------------------ */
+typedef struct { uint8_t *buf; size_t len, cap; int n, w, h, fmt, oom; } Sink;
+static void sink_cb(void *user, const OrcFrame *f) {
+    Sink *s = (Sink *)user;
+    size_t fs = (size_t)f->width * f->height * 3 / 2;
+    if (s->len + fs > s->cap) {
+        size_t nc = s->cap ? s->cap * 2 : fs * 8;
+        while (nc < s->len + fs) nc *= 2;
+        uint8_t *nb = (uint8_t *)realloc(s->buf, nc);
+        if (!nb) { s->oom = 1; return; }
+        s->buf = nb; s->cap = nc;
+    }
+    uint8_t *o = s->buf + s->len;
+    for (int y = 0; y < f->height; y++) memcpy(o + (size_t)y * f->width, f->y + (size_t)y * f->stride_y, f->width);
+    o += (size_t)f->width * f->height;
+    int cw = f->width / 2, ch = f->height / 2;
+    if (s->fmt == 1) {
+        for (int y = 0; y < ch; y++) memcpy(o + (size_t)y * cw, f->u + (size_t)y * f->stride_c, cw);
+        o += (size_t)cw * ch;
+        for (int y = 0; y < ch; y++) memcpy(o + (size_t)y * cw, f->v + (size_t)y * f->stride_c, cw);
+    } else {
+        for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) {
+            o[(size_t)y * f->width + 2 * x] = f->u[(size_t)y * f->stride_c + x];
+            o[(size_t)y * f->width + 2 * x + 1] = f->v[(size_t)y * f->stride_c + x];
+        }
+    }
+    s->len += fs; s->n++; s->w = f->width; s->h = f->height;
+}
+int orc_decode_stream_to_buffer(const uint8_t *buf, size_t len, int out_fmt, uint8_t **out, size_t *out_len, int *w, int *h) {
+    Sink s; memset(&s, 0, sizeof s); s.fmt = out_fmt;
+    OrcDec *d = orc_open(sink_cb, &s);
+    if (!d) return -1;
+    int rc = orc_decode_annexb(d, buf, len);
+    if (rc < 0) fprintf(stderr, "orc: %s\n", orc_last_error(d));
+    orc_flush(d);
+    orc_close(d);
+    if (rc < 0 || s.oom) { free(s.buf); return -1; }
+    *out = s.buf; *out_len = s.len; if (w) *w = s.w; if (h) *h = s.h;
+    return s.n;
+}
+void orc_free(void *p) { free(p); }

@@ -1,0 +1,788 @@
+/*
+ * oracle/orc_slice.c -- CPU ORACLE (test infrastructure only).
+ * Slice data: CAVLC macroblock parsing (7.3.4, 7.3.5, 9.2), intra prediction
+ * (8.3), inter prediction (8.4) and the transform / reconstruction path (8.5).
+ * This is the restatement of the closed picture reconstruction performed by
+ * cuvidDecodePicture (/root/reference/nv_dec/nv_dec.cpp:37) for progressive
+ * 8-bit 4:2:0 I/P slices.
+ */
+#include "orc_internal.h"
+#include "orc_tables.h"
+
+typedef struct {
+    OrcDec *d; Bits *b; Picture *pic; const Sps *sps; const Pps *pps; const SliceHdr *sh;
+    int mb_x, mb_y, mb_addr;
+    int qp;                          /* running QP_Y                                  */
+    MbInfo *mb;
+    /* parsed residual of the current MB */
+    int16_t luma[16][16];            /* per 4x4 raster block index, coefficient raster */
+    int16_t luma8[4][64];            /* per 8x8 block, raster                          */
+    int16_t i16dc[16];               /* raster 4x4 matrix c                            */
+    int16_t cdc[2][4];
+    int16_t cac[2][4][16];
+    int i16_pred_mode, chroma_pred_mode;
+    int decoded_mask;                /* 4x4 blocks (raster bit) whose MVs are decoded  */
+} Sl;
+
+/* ------------------------------------------------------------------------ */
+static MbInfo *mb_at(Sl *s, int mx, int my) {
+    if (mx < 0 || my < 0 || mx >= s->d->mb_w || my >= s->d->mb_h) return NULL;
+    MbInfo *m = &s->pic->mbs[my * s->d->mb_w + mx];
+    return m->slice_num == s->d->slice_num ? m : NULL;     /* 6.4.x availability */
+}
+static int intra_usable(Sl *s, MbInfo *m) {               /* for intra prediction */
+    if (!m) return 0;
+    if (s->pps->constrained_intra_pred && !m->is_intra) return 0;
+    return 1;
+}
+
+/* ------------------------------- CAVLC ---------------------------------- */
+static int vlc_match(Bits *b, const uint8_t *len, const uint8_t *bits, int n) {
+    /* read one bit at a time until the prefix equals exactly one codeword */
+    unsigned v = 0;
+    for (int l = 1; l <= 16; l++) {
+        v = (v << 1) | bits_u1(b);
+        if (b->err) return -1;
+        for (int i = 0; i < n; i++) if (len[i] == l && bits[i] == v) return i;
+    }
+    return -1;
+}
+
+/* 9.2.1: returns total_coeff; fills coef[0..max_num-1] in scan order */
+static int residual_block_cavlc(Sl *s, int nC, int max_num, int16_t *coef) {
+    Bits *b = s->b;
+    int idx;
+    memset(coef, 0, sizeof(int16_t) * max_num);
+    if (nC == -1) idx = vlc_match(b, orc_chroma_dc_token_len, orc_chroma_dc_token_bits, 20);
+    else {
+        int t = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+        idx = vlc_match(b, orc_coeff_token_len[t], orc_coeff_token_bits[t], 68);
+    }
+    if (idx < 0) return -1;
+    int total = idx >> 2, t1 = idx & 3;
+    if (total == 0) return 0;
+    if (total > max_num) return -1;
+    int level[16], run[16];
+    int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1) level[i] = 1 - 2 * (int)bits_u1(b);
+        else {
+            int prefix = 0;
+            while (!bits_u1(b)) { if (b->err || ++prefix > 32) return -1; }
+            int code = orc_min(15, prefix) << suffix_len;
+            if (suffix_len > 0 || prefix >= 14) {
+                int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+                if (size > 0) code += (int)bits_u(b, size);
+            }
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1 && t1 < 3) code += 2;
+            level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            if (suffix_len == 0) suffix_len = 1;
+            if (orc_abs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+    }
+    int zeros_left = 0;
+    if (total < max_num) {
+        int tz;
+        if (max_num == 4) tz = vlc_match(b, orc_cdc_total_zeros_len[total - 1], orc_cdc_total_zeros_bits[total - 1], 4 - total + 1);
+        else tz = vlc_match(b, orc_total_zeros_len[total - 1], orc_total_zeros_bits[total - 1], 16 - total + 1);
+        if (tz < 0) return -1;
+        zeros_left = tz;
+    }
+    for (int i = 0; i < total - 1; i++) {
+        if (zeros_left > 0) {
+            int t = orc_min(zeros_left, 7) - 1;
+            int r = vlc_match(b, orc_run_len[t], orc_run_bits[t], orc_run_count[t]);
+            if (r < 0 || r > zeros_left) return -1;
+            run[i] = r; zeros_left -= r;
+        } else run[i] = 0;
+    }
+    run[total - 1] = zeros_left;
+    int pos = -1;
+    for (int i = total - 1; i >= 0; i--) {
+        pos += run[i] + 1;
+        if (pos >= max_num) return -1;
+        coef[pos] = (int16_t)level[i];
+    }
+    return b->err ? -1 : total;
+}
+
+/* 9.2.1 nC for a luma 4x4 block at raster (bx,by) / chroma block (plane 1,2) */
+static int nc_luma(Sl *s, int bx, int by) {
+    int availA = 0, availB = 0, nA = 0, nB = 0;
+    if (bx > 0) { availA = 1; nA = s->mb->total_coeff[by * 4 + bx - 1]; }
+    else { MbInfo *m = mb_at(s, s->mb_x - 1, s->mb_y); if (m) { availA = 1; nA = m->total_coeff[by * 4 + 3]; } }
+    if (by > 0) { availB = 1; nB = s->mb->total_coeff[(by - 1) * 4 + bx]; }
+    else { MbInfo *m = mb_at(s, s->mb_x, s->mb_y - 1); if (m) { availB = 1; nB = m->total_coeff[12 + bx]; } }
+    if (availA && availB) return (nA + nB + 1) >> 1;
+    return availA ? nA : (availB ? nB : 0);
+}
+static int nc_chroma(Sl *s, int pl, int bx, int by) {
+    int o = 16 + 4 * pl, availA = 0, availB = 0, nA = 0, nB = 0;
+    if (bx > 0) { availA = 1; nA = s->mb->total_coeff[o + by * 2 + bx - 1]; }
+    else { MbInfo *m = mb_at(s, s->mb_x - 1, s->mb_y); if (m) { availA = 1; nA = m->total_coeff[o + by * 2 + 1]; } }
+    if (by > 0) { availB = 1; nB = s->mb->total_coeff[o + (by - 1) * 2 + bx]; }
+    else { MbInfo *m = mb_at(s, s->mb_x, s->mb_y - 1); if (m) { availB = 1; nB = m->total_coeff[o + 2 + bx]; } }
+    if (availA && availB) return (nA + nB + 1) >> 1;
+    return availA ? nA : (availB ? nB : 0);
+}
+
+static inline int blk_x(int blk) { return (blk & 1) + 2 * ((blk >> 2) & 1); }
+static inline int blk_y(int blk) { return ((blk >> 1) & 1) + 2 * (blk >> 3); }
+
+/* 7.3.5.3 residual() with CAVLC */
+static int parse_residual(Sl *s, int cbp) {
+    MbInfo *mb = s->mb;
+    int16_t tmp[16];
+    if (mb->is_i16) {
+        int n = residual_block_cavlc(s, nc_luma(s, 0, 0), 16, tmp);
+        if (n < 0) return -1;
+        for (int i = 0; i < 16; i++) s->i16dc[orc_zigzag4[i]] = tmp[i];
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        for (int k = 0; k < 4; k++) {
+            int blk = b8 * 4 + k, bx = blk_x(blk), by = blk_y(blk), r = by * 4 + bx;
+            if (!(cbp & (1 << b8))) { mb->total_coeff[r] = 0; continue; }
+            int nC = nc_luma(s, bx, by), n;
+            if (mb->is_i16) {
+                n = residual_block_cavlc(s, nC, 15, tmp);
+                if (n < 0) return -1;
+                for (int i = 0; i < 15; i++) s->luma[r][orc_zigzag4[i + 1]] = tmp[i];
+            } else {
+                n = residual_block_cavlc(s, nC, 16, tmp);
+                if (n < 0) return -1;
+                if (mb->t8x8) {   /* 7.3.5.3.2: 4x4 block k carries 8x8 scan positions 4*i+k */
+                    for (int i = 0; i < 16; i++) s->luma8[b8][orc_zigzag8[4 * i + k]] = tmp[i];
+                } else
+                    for (int i = 0; i < 16; i++) s->luma[r][orc_zigzag4[i]] = tmp[i];
+            }
+            mb->total_coeff[r] = (uint8_t)n;
+        }
+    }
+    if (cbp & 0x30) {
+        for (int pl = 0; pl < 2; pl++)
+            if (residual_block_cavlc(s, -1, 4, s->cdc[pl]) < 0) return -1;
+    }
+    for (int pl = 0; pl < 2; pl++)
+        for (int k = 0; k < 4; k++) {
+            if (!(cbp & 0x20)) { mb->total_coeff[16 + 4 * pl + k] = 0; continue; }
+            int n = residual_block_cavlc(s, nc_chroma(s, pl, k & 1, k >> 1), 15, tmp);
+            if (n < 0) return -1;
+            for (int i = 0; i < 15; i++) s->cac[pl][k][orc_zigzag4[i + 1]] = tmp[i];
+            mb->total_coeff[16 + 4 * pl + k] = (uint8_t)n;
+        }
+    return 0;
+}
+
+/* ----------------------------- transforms -------------------------------- */
+static int chroma_qp(const Pps *pps, int qpy, int pl) {
+    int off = pl == 0 ? pps->chroma_qp_index_offset : pps->second_chroma_qp_index_offset;
+    int qpi = orc_clip3(0, 51, qpy + off);
+    return qpi < 30 ? qpi : orc_qpc_tab[qpi - 30];
+}
+/* LevelScale4x4(m,i,j) = weightScale4x4 * normAdjust4x4 (8.5.9); list in zig-zag order */
+static int level_scale4(const uint8_t *list_zz, int m, int raster) {
+    int w = 16;
+    for (int k = 0; k < 16; k++) if (orc_zigzag4[k] == raster) { w = list_zz[k]; break; }
+    int i = raster >> 2, j = raster & 3;
+    int cls = (!(i & 1) && !(j & 1)) ? 0 : ((i & 1) && (j & 1)) ? 1 : 2;
+    return w * orc_norm4[m][cls];
+}
+static int level_scale8(const uint8_t *list_zz, int m, int raster) {
+    int w = 16;
+    for (int k = 0; k < 64; k++) if (orc_zigzag8[k] == raster) { w = list_zz[k]; break; }
+    int i = raster >> 3, j = raster & 7, cls;
+    if (i % 4 == 0 && j % 4 == 0) cls = 0;
+    else if (i % 2 == 1 && j % 2 == 1) cls = 1;
+    else if (i % 4 == 2 && j % 4 == 2) cls = 2;
+    else if ((i % 4 == 0 && j % 2 == 1) || (i % 2 == 1 && j % 4 == 0)) cls = 3;
+    else if ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) cls = 4;
+    else cls = 5;
+    return w * orc_norm8[m][cls];
+}
+
+/* 8.5.12.1 scaling of a 4x4 residual block; dc_done: element 0 already scaled */
+static void scale4x4(const int16_t *c, int *dq, const uint8_t *list, int qp, int dc_done) {
+    for (int k = 0; k < 16; k++) {
+        if (k == 0 && dc_done) { dq[0] = c[0]; continue; }
+        int ls = level_scale4(list, qp % 6, k);
+        if (qp >= 24) dq[k] = (c[k] * ls) << (qp / 6 - 4);
+        else dq[k] = (c[k] * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6);
+    }
+}
+/* 8.5.12.2 inverse 4x4 transform -> residual r (before the >>6 already applied) */
+static void idct4x4(const int *dq, int *r) {
+    int f[16];
+    for (int i = 0; i < 4; i++) {                 /* rows */
+        const int *d = dq + 4 * i;
+        int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+        f[4 * i + 0] = e0 + e3; f[4 * i + 1] = e1 + e2; f[4 * i + 2] = e1 - e2; f[4 * i + 3] = e0 - e3;
+    }
+    for (int j = 0; j < 4; j++) {                 /* columns */
+        int g0 = f[j] + f[8 + j], g1 = f[j] - f[8 + j], g2 = (f[4 + j] >> 1) - f[12 + j], g3 = f[4 + j] + (f[12 + j] >> 1);
+        r[j] = (g0 + g3 + 32) >> 6; r[4 + j] = (g1 + g2 + 32) >> 6;
+        r[8 + j] = (g1 - g2 + 32) >> 6; r[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+static void idct8_1d(const int *d, int *o, int stride_in, int stride_out) {
+    int d0 = d[0], d1 = d[stride_in], d2 = d[2 * stride_in], d3 = d[3 * stride_in];
+    int d4 = d[4 * stride_in], d5 = d[5 * stride_in], d6 = d[6 * stride_in], d7 = d[7 * stride_in];
+    int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
+    int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
+    int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+    int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+    o[0] = f0 + f7; o[stride_out] = f2 + f5; o[2 * stride_out] = f4 + f3; o[3 * stride_out] = f6 + f1;
+    o[4 * stride_out] = f6 - f1; o[5 * stride_out] = f4 - f3; o[6 * stride_out] = f2 - f5; o[7 * stride_out] = f0 - f7;
+}
+static void idct8x8(const int *dq, int *r) {
+    int t[64];
+    for (int i = 0; i < 8; i++) idct8_1d(dq + 8 * i, t + 8 * i, 1, 1);
+    for (int j = 0; j < 8; j++) idct8_1d(t + j, r + j, 8, 8);
+    for (int k = 0; k < 64; k++) r[k] = (r[k] + 32) >> 6;
+}
+static void add_block(uint8_t *dst, int stride, const int *r, int n) {
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) dst[y * stride + x] = (uint8_t)orc_clip1(dst[y * stride + x] + r[y * n + x]);
+}
+
+/* ----------------------------- intra prediction -------------------------- */
+/* gather neighbours of a 4x4 block at pixel (px,py) of plane; T[-1]=corner */
+static void pred4x4(Sl *s, int blk, int mode, uint8_t *dst, int stride) {
+    int bx = blk_x(blk), by = blk_y(blk);
+    MbInfo *mA = bx > 0 ? s->mb : mb_at(s, s->mb_x - 1, s->mb_y);
+    MbInfo *mB = by > 0 ? s->mb : mb_at(s, s->mb_x, s->mb_y - 1);
+    MbInfo *mD = (bx > 0 && by > 0) ? s->mb : (bx > 0 ? mb_at(s, s->mb_x, s->mb_y - 1)
+                 : (by > 0 ? mb_at(s, s->mb_x - 1, s->mb_y) : mb_at(s, s->mb_x - 1, s->mb_y - 1)));
+    int availA = bx > 0 || intra_usable(s, mA), availB = by > 0 || intra_usable(s, mB);
+    int availD = (bx > 0 && by > 0) || intra_usable(s, mD);
+    int availC;
+    if (by == 0) {
+        MbInfo *mC = bx < 3 ? mb_at(s, s->mb_x, s->mb_y - 1) : mb_at(s, s->mb_x + 1, s->mb_y - 1);
+        availC = intra_usable(s, mC);
+    } else availC = !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
+    int Tbuf[9], Lbuf[5], *T = Tbuf + 1, *L = Lbuf + 1;
+    for (int i = 0; i < 4; i++) { T[i] = availB ? dst[-stride + i] : 128; L[i] = availA ? dst[i * stride - 1] : 128; }
+    for (int i = 4; i < 8; i++) T[i] = (availB && availC) ? dst[-stride + i] : T[3];
+    T[-1] = L[-1] = availD ? dst[-stride - 1] : 128;
+    int p[16];
+    switch (mode) {
+    case 0: for (int k = 0; k < 16; k++) p[k] = T[k & 3]; break;
+    case 1: for (int k = 0; k < 16; k++) p[k] = L[k >> 2]; break;
+    case 2: {
+        int dc;
+        if (availA && availB) dc = (T[0] + T[1] + T[2] + T[3] + L[0] + L[1] + L[2] + L[3] + 4) >> 3;
+        else if (availA) dc = (L[0] + L[1] + L[2] + L[3] + 2) >> 2;
+        else if (availB) dc = (T[0] + T[1] + T[2] + T[3] + 2) >> 2;
+        else dc = 128;
+        for (int k = 0; k < 16; k++) p[k] = dc;
+        break; }
+    case 3: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
+                p[y * 4 + x] = (x == 3 && y == 3) ? (T[6] + 3 * T[7] + 2) >> 2
+                                                  : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2;
+            break;
+    case 4: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+                if (x > y) p[y * 4 + x] = (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2;
+                else if (x < y) p[y * 4 + x] = (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2;
+                else p[y * 4 + x] = (T[0] + 2 * T[-1] + L[0] + 2) >> 2;
+            } break;
+    case 5: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+                int z = 2 * x - y, i = x - (y >> 1);
+                if (z >= 0 && !(z & 1)) p[y * 4 + x] = (T[i - 1] + T[i] + 1) >> 1;
+                else if (z >= 0) p[y * 4 + x] = (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2;
+                else if (z == -1) p[y * 4 + x] = (L[0] + 2 * T[-1] + T[0] + 2) >> 2;
+                else p[y * 4 + x] = (L[y - 1] + 2 * L[y - 2] + L[y - 3] + 2) >> 2;
+            } break;
+    case 6: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+                int z = 2 * y - x, i = y - (x >> 1);
+                if (z >= 0 && !(z & 1)) p[y * 4 + x] = (L[i - 1] + L[i] + 1) >> 1;
+                else if (z >= 0) p[y * 4 + x] = (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2;
+                else if (z == -1) p[y * 4 + x] = (L[0] + 2 * T[-1] + T[0] + 2) >> 2;
+                else p[y * 4 + x] = (T[x - 1] + 2 * T[x - 2] + T[x - 3] + 2) >> 2;
+            } break;
+    case 7: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+                int i = x + (y >> 1);
+                p[y * 4 + x] = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1;
+            } break;
+    default: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+                int z = x + 2 * y, i = y + (x >> 1);
+                if (z > 5) p[y * 4 + x] = L[3];
+                else if (z == 5) p[y * 4 + x] = (L[2] + 3 * L[3] + 2) >> 2;
+                else if (z & 1) p[y * 4 + x] = (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2;
+                else p[y * 4 + x] = (L[i] + L[i + 1] + 1) >> 1;
+            } break;
+    }
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) dst[y * stride + x] = (uint8_t)p[y * 4 + x];
+}
+
+/* 8.3.3 Intra16x16 / 8.3.4 chroma (n = 16 or 8) */
+static void pred_plane_block(uint8_t *dst, int stride, int n) {
+    int H = 0, V = 0, half = n / 2;
+    for (int k = 0; k < half; k++) {
+        int t0 = dst[-stride + half + k], t1 = (half - 2 - k) >= 0 ? dst[-stride + half - 2 - k] : dst[-stride - 1];
+        int l0 = dst[(half + k) * stride - 1], l1 = (half - 2 - k) >= 0 ? dst[(half - 2 - k) * stride - 1] : dst[-stride - 1];
+        H += (k + 1) * (t0 - t1); V += (k + 1) * (l0 - l1);
+    }
+    int a = 16 * (dst[(n - 1) * stride - 1] + dst[-stride + n - 1]);
+    int bb = n == 16 ? (5 * H + 32) >> 6 : (34 * H + 32) >> 6;
+    int cc = n == 16 ? (5 * V + 32) >> 6 : (34 * V + 32) >> 6;
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++)
+        dst[y * stride + x] = (uint8_t)orc_clip1((a + bb * (x - (half - 1)) + cc * (y - (half - 1)) + 16) >> 5);
+}
+static int pred16x16(Sl *s, int mode, uint8_t *dst, int stride) {
+    int availA = intra_usable(s, mb_at(s, s->mb_x - 1, s->mb_y));
+    int availB = intra_usable(s, mb_at(s, s->mb_x, s->mb_y - 1));
+    int availD = intra_usable(s, mb_at(s, s->mb_x - 1, s->mb_y - 1));
+    switch (mode) {
+    case 0: if (!availB) return -1;
+        for (int y = 0; y < 16; y++) memcpy(dst + y * stride, dst - stride, 16); break;
+    case 1: if (!availA) return -1;
+        for (int y = 0; y < 16; y++) memset(dst + y * stride, dst[y * stride - 1], 16); break;
+    case 2: {
+        int st = 0, sl = 0, dc;
+        for (int i = 0; i < 16; i++) { if (availB) st += dst[-stride + i]; if (availA) sl += dst[i * stride - 1]; }
+        if (availA && availB) dc = (st + sl + 16) >> 5;
+        else if (availA) dc = (sl + 8) >> 4; else if (availB) dc = (st + 8) >> 4; else dc = 128;
+        for (int y = 0; y < 16; y++) memset(dst + y * stride, dc, 16);
+        break; }
+    default: if (!availA || !availB || !availD) return -1;
+        pred_plane_block(dst, stride, 16); break;
+    }
+    return 0;
+}
+static int pred_chroma(Sl *s, int mode, uint8_t *dst, int stride) {
+    int availA = intra_usable(s, mb_at(s, s->mb_x - 1, s->mb_y));
+    int availB = intra_usable(s, mb_at(s, s->mb_x, s->mb_y - 1));
+    int availD = intra_usable(s, mb_at(s, s->mb_x - 1, s->mb_y - 1));
+    switch (mode) {
+    case 0:
+        for (int by = 0; by < 2; by++) for (int bx = 0; bx < 2; bx++) {
+            int st = 0, sl = 0, dc;
+            for (int i = 0; i < 4; i++) { if (availB) st += dst[-stride + bx * 4 + i]; if (availA) sl += dst[(by * 4 + i) * stride - 1]; }
+            if (bx == by) {                       /* (0,0) and (1,1) */
+                if (availA && availB) dc = (st + sl + 4) >> 3;
+                else if (availA) dc = (sl + 2) >> 2; else if (availB) dc = (st + 2) >> 2; else dc = 128;
+            } else if (bx == 1) {                 /* (1,0): prefer top */
+                if (availB) dc = (st + 2) >> 2; else if (availA) dc = (sl + 2) >> 2; else dc = 128;
+            } else {                              /* (0,1): prefer left */
+                if (availA) dc = (sl + 2) >> 2; else if (availB) dc = (st + 2) >> 2; else dc = 128;
+            }
+            for (int y = 0; y < 4; y++) memset(dst + (by * 4 + y) * stride + bx * 4, dc, 4);
+        }
+        break;
+    case 1: if (!availA) return -1;
+        for (int y = 0; y < 8; y++) memset(dst + y * stride, dst[y * stride - 1], 8); break;
+    case 2: if (!availB) return -1;
+        for (int y = 0; y < 8; y++) memcpy(dst + y * stride, dst - stride, 8); break;
+    default: if (!availA || !availB || !availD) return -1;
+        pred_plane_block(dst, stride, 8); break;
+    }
+    return 0;
+}
+
+/* ----------------------------- inter prediction -------------------------- */
+typedef struct { int avail; int ref; int mv[2]; } Nb;
+
+/* neighbour partition covering 4x4 block (bx,by) relative to the current MB */
+static Nb nb_get(Sl *s, int bx, int by) {
+    Nb n = {0, -1, {0, 0}};
+    MbInfo *m; int rx, ry;
+    if (by < 0) {
+        if (bx < 0) { m = mb_at(s, s->mb_x - 1, s->mb_y - 1); rx = 3; }
+        else if (bx > 3) { m = mb_at(s, s->mb_x + 1, s->mb_y - 1); rx = bx - 4; }
+        else { m = mb_at(s, s->mb_x, s->mb_y - 1); rx = bx; }
+        ry = 3;
+    } else if (bx < 0) { m = mb_at(s, s->mb_x - 1, s->mb_y); rx = 3; ry = by; }
+    else if (bx > 3) return n;
+    else {
+        if (!(s->decoded_mask & (1 << (by * 4 + bx)))) return n;
+        m = s->mb; rx = bx; ry = by;
+    }
+    if (!m) return n;
+    n.avail = 1;
+    if (m->is_intra) return n;
+    n.ref = m->ref_idx[(ry >> 1) * 2 + (rx >> 1)];
+    if (n.ref >= 0) { n.mv[0] = m->mv[ry * 4 + rx][0]; n.mv[1] = m->mv[ry * 4 + rx][1]; }
+    return n;
+}
+static int median3(int a, int b, int c) {
+    int mx = orc_max(a, orc_max(b, c)), mn = orc_min(a, orc_min(b, c));
+    return a + b + c - mx - mn;
+}
+/* 8.4.1.3: mv prediction for a partition at 4x4 (bx,by) size (bw,bh) in 4x4 units */
+static void predict_mv(Sl *s, int bx, int by, int bw, int bh, int ref, int shape, int part, int mvp[2]) {
+    Nb A = nb_get(s, bx - 1, by), B = nb_get(s, bx, by - 1), C = nb_get(s, bx + bw, by - 1);
+    if (!C.avail) C = nb_get(s, bx - 1, by - 1);
+    (void)bh;
+    if (shape == 1) {            /* 16x8 */
+        if (part == 0 && B.ref == ref) { mvp[0] = B.mv[0]; mvp[1] = B.mv[1]; return; }
+        if (part == 1 && A.ref == ref) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; return; }
+    } else if (shape == 2) {     /* 8x16 */
+        if (part == 0 && A.ref == ref) { mvp[0] = A.mv[0]; mvp[1] = A.mv[1]; return; }
+        if (part == 1 && C.ref == ref) { mvp[0] = C.mv[0]; mvp[1] = C.mv[1]; return; }
+    }
+    if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
+    int ma = A.ref == ref, mb = B.ref == ref, mc = C.ref == ref;
+    if (ma + mb + mc == 1) {
+        const Nb *n = ma ? &A : (mb ? &B : &C);
+        mvp[0] = n->mv[0]; mvp[1] = n->mv[1];
+    } else {
+        mvp[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
+        mvp[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
+    }
+}
+static void set_mv(Sl *s, int bx, int by, int bw, int bh, int mvx, int mvy) {
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
+        s->mb->mv[y * 4 + x][0] = (int16_t)mvx; s->mb->mv[y * 4 + x][1] = (int16_t)mvy;
+        s->decoded_mask |= 1 << (y * 4 + x);
+    }
+}
+
+static inline int ref_px(const uint8_t *pl, int stride, int w, int h, int x, int y) {
+    return pl[orc_clip3(0, h - 1, y) * stride + orc_clip3(0, w - 1, x)];
+}
+static inline int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+/* 8.4.2.2.1 luma sample interpolation for one sample */
+static int luma_sample(const Picture *r, int W, int H, int xi, int yi, int fx, int fy) {
+    const uint8_t *p = r->y; int st = r->stride_y;
+#define P(dx, dy) ref_px(p, st, W, H, xi + (dx), yi + (dy))
+#define HB1(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))   /* b1 at row dy */
+#define VH1(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))   /* h1 at col dx */
+    int G = P(0, 0);
+    if (!fx && !fy) return G;
+    int b = orc_clip1((HB1(0) + 16) >> 5), h = orc_clip1((VH1(0) + 16) >> 5);
+    if (fy == 0) return fx == 2 ? b : (fx == 1 ? (G + b + 1) >> 1 : (P(1, 0) + b + 1) >> 1);
+    if (fx == 0) return fy == 2 ? h : (fy == 1 ? (G + h + 1) >> 1 : (P(0, 1) + h + 1) >> 1);
+    int j1 = tap6(HB1(-2), HB1(-1), HB1(0), HB1(1), HB1(2), HB1(3));
+    int j = orc_clip1((j1 + 512) >> 10);
+    int s_ = orc_clip1((HB1(1) + 16) >> 5), m = orc_clip1((VH1(1) + 16) >> 5);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) return fy == 1 ? (b + j + 1) >> 1 : (j + s_ + 1) >> 1;          /* f, q */
+    if (fy == 2) return fx == 1 ? (h + j + 1) >> 1 : (j + m + 1) >> 1;           /* i, k */
+    if (fx == 1 && fy == 1) return (b + h + 1) >> 1;                             /* e */
+    if (fx == 3 && fy == 1) return (b + m + 1) >> 1;                             /* g */
+    if (fx == 1 && fy == 3) return (h + s_ + 1) >> 1;                            /* p */
+    return (m + s_ + 1) >> 1;                                                    /* r */
+#undef P
+#undef HB1
+#undef VH1
+}
+/* motion-compensate one partition (luma px rect x,y,w,h inside the MB) */
+static void mc_part(Sl *s, const Picture *ref, int refidx, int px, int py, int w, int h, int mvx, int mvy) {
+    OrcDec *d = s->d; Picture *pic = s->pic;
+    int W = d->mb_w * 16, H = d->mb_h * 16;
+    int x0 = s->mb_x * 16 + px, y0 = s->mb_y * 16 + py;
+    const SliceHdr *sh = s->sh;
+    int wp = s->pps->weighted_pred && sh->slice_type == SLICE_P;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        int v = luma_sample(ref, W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
+        if (wp) {
+            int lw = sh->luma_log2_wd, wt = sh->luma_weight[0][refidx], of = sh->luma_offset[0][refidx];
+            v = orc_clip1((lw >= 1 ? ((v * wt + (1 << (lw - 1))) >> lw) : v * wt) + of);
+        }
+        pic->y[(y0 + y) * pic->stride_y + x0 + x] = (uint8_t)v;
+    }
+    int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
+    for (int pl = 0; pl < 2; pl++) {
+        const uint8_t *rp = pl ? ref->v : ref->u; uint8_t *dp = pl ? pic->v : pic->u;
+        for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
+            int xi = cx0 + x + (mvx >> 3), yi = cy0 + y + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
+            int A = ref_px(rp, ref->stride_c, cw, ch, xi, yi), B = ref_px(rp, ref->stride_c, cw, ch, xi + 1, yi);
+            int C = ref_px(rp, ref->stride_c, cw, ch, xi, yi + 1), D = ref_px(rp, ref->stride_c, cw, ch, xi + 1, yi + 1);
+            int v = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
+            if (wp) {
+                int lw = sh->chroma_log2_wd, wt = sh->chroma_weight[0][refidx][pl], of = sh->chroma_offset[0][refidx][pl];
+                v = orc_clip1((lw >= 1 ? ((v * wt + (1 << (lw - 1))) >> lw) : v * wt) + of);
+            }
+            dp[(cy0 + y) * pic->stride_c + cx0 + x] = (uint8_t)v;
+        }
+    }
+}
+static int inter_recon(Sl *s) {
+    MbInfo *mb = s->mb;
+    /* walk the 4x4 grid, merging nothing: per-4x4 MC gives identical samples */
+    for (int b8 = 0; b8 < 4; b8++) {
+        int ri = mb->ref_idx[b8];
+        if (ri < 0 || ri >= s->d->ref_count[0] || !s->d->ref_list[0][ri]) {
+            snprintf(s->d->err, sizeof s->d->err, "missing reference picture (ref_idx %d)", ri); return -1;
+        }
+        const Picture *ref = s->d->ref_list[0][ri];
+        mb->ref_pic_id[b8] = ref->id;
+        for (int k = 0; k < 4; k++) {
+            int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1);
+            mc_part(s, ref, ri, bx * 4, by * 4, 4, 4, mb->mv[by * 4 + bx][0], mb->mv[by * 4 + bx][1]);
+        }
+    }
+    return 0;
+}
+
+/* ----------------------------- residual add ------------------------------ */
+static void recon_chroma_residual(Sl *s, int cbp) {
+    Picture *pic = s->pic; MbInfo *mb = s->mb;
+    if (!(cbp & 0x30)) return;
+    for (int pl = 0; pl < 2; pl++) {
+        uint8_t *dst = (pl ? pic->v : pic->u) + (s->mb_y * 8) * pic->stride_c + s->mb_x * 8;
+        int qpc = mb->qpc[pl];
+        const uint8_t *list = s->pps->scaling4[(mb->is_intra ? 0 : 3) + 1 + pl];
+        /* 8.5.11.1/2: 2x2 chroma DC transform + scaling */
+        const int16_t *c = s->cdc[pl];
+        int f[4] = { c[0] + c[1] + c[2] + c[3], c[0] - c[1] + c[2] - c[3], c[0] + c[1] - c[2] - c[3], c[0] - c[1] - c[2] + c[3] };
+        int ls0 = level_scale4(list, qpc % 6, 0);
+        for (int k = 0; k < 4; k++) {
+            int dc = ((f[k] * ls0) << (qpc / 6)) >> 5;
+            int16_t blk[16]; int dq[16], r[16];
+            memcpy(blk, s->cac[pl][k], sizeof blk);
+            blk[0] = 0;
+            scale4x4(blk, dq, list, qpc, 0);
+            dq[0] = dc;
+            idct4x4(dq, r);
+            add_block(dst + (k >> 1) * 4 * pic->stride_c + (k & 1) * 4, pic->stride_c, r, 4);
+        }
+    }
+}
+
+/* ----------------------------- macroblock layer -------------------------- */
+static void mb_reset(Sl *s) {
+    MbInfo *mb = s->mb;
+    memset(mb, 0, sizeof *mb);
+    mb->slice_num = (int16_t)s->d->slice_num;
+    for (int i = 0; i < 4; i++) { mb->ref_idx[i] = -1; mb->ref_pic_id[i] = -1; }
+    memset(mb->i4mode, 2, 16);
+    mb->disable_deblock = (uint8_t)s->sh->disable_deblock;
+    mb->alpha_off = (int8_t)s->sh->alpha_c0_offset; mb->beta_off = (int8_t)s->sh->beta_offset;
+    memset(s->luma, 0, sizeof s->luma); memset(s->luma8, 0, sizeof s->luma8);
+    memset(s->i16dc, 0, sizeof s->i16dc); memset(s->cdc, 0, sizeof s->cdc); memset(s->cac, 0, sizeof s->cac);
+    s->decoded_mask = 0;
+}
+static void mb_set_qp(Sl *s) {
+    s->mb->qp = (uint8_t)s->qp;
+    s->mb->qpc[0] = (uint8_t)chroma_qp(s->pps, s->qp, 0);
+    s->mb->qpc[1] = (uint8_t)chroma_qp(s->pps, s->qp, 1);
+}
+
+static int decode_skip_mb(Sl *s) {
+    mb_reset(s);
+    MbInfo *mb = s->mb;
+    mb->is_skip = 1; mb->mb_type_p = 0;
+    mb_set_qp(s);
+    int mvp[2] = {0, 0};
+    MbInfo *mA = mb_at(s, s->mb_x - 1, s->mb_y), *mB = mb_at(s, s->mb_x, s->mb_y - 1);
+    if (mA && mB) {
+        Nb A = nb_get(s, -1, 0), B = nb_get(s, 0, -1);
+        if (!((A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) || (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
+            predict_mv(s, 0, 0, 4, 4, 0, 0, 0, mvp);
+    }
+    for (int i = 0; i < 4; i++) mb->ref_idx[i] = 0;
+    set_mv(s, 0, 0, 4, 4, mvp[0], mvp[1]);
+    return inter_recon(s);
+}
+
+static int decode_mb(Sl *s) {
+    Bits *b = s->b; Picture *pic = s->pic; const SliceHdr *sh = s->sh;
+    mb_reset(s);
+    MbInfo *mb = s->mb;
+    int mb_type = bits_ue(b);
+    int is_intra_type = -1;                /* I-slice numbering when intra */
+    if (sh->slice_type == SLICE_I) is_intra_type = mb_type;
+    else if (sh->slice_type == SLICE_P) { if (mb_type >= 5) is_intra_type = mb_type - 5; }
+    else { snprintf(s->d->err, sizeof s->d->err, "B slices unsupported by the round-1 oracle"); return -1; }
+    if (is_intra_type > 25 || mb_type > 30) { snprintf(s->d->err, sizeof s->d->err, "bad mb_type %d", mb_type); return -1; }
+
+    uint8_t *dy = pic->y + (s->mb_y * 16) * pic->stride_y + s->mb_x * 16;
+    uint8_t *du = pic->u + (s->mb_y * 8) * pic->stride_c + s->mb_x * 8;
+    uint8_t *dv = pic->v + (s->mb_y * 8) * pic->stride_c + s->mb_x * 8;
+
+    if (is_intra_type == 25) {             /* I_PCM, 7.3.5 */
+        mb->is_intra = 1; mb->is_pcm = 1;
+        while (!bits_aligned(b)) if (bits_u1(b)) { snprintf(s->d->err, sizeof s->d->err, "pcm_alignment_zero_bit != 0"); return -1; }
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) dy[y * pic->stride_y + x] = (uint8_t)bits_u(b, 8);
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) du[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) dv[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);
+        memset(mb->total_coeff, 16, sizeof mb->total_coeff);
+        mb->qp = 0;                        /* 8.7.2.2: qPp = 0 for I_PCM in the deblocking filter */
+        mb->qpc[0] = (uint8_t)chroma_qp(s->pps, 0, 0); mb->qpc[1] = (uint8_t)chroma_qp(s->pps, 0, 1);
+        mb->cbp = 0x2f;
+        return b->err ? -1 : 0;
+    }
+
+    int cbp = 0;
+    if (is_intra_type >= 0) {
+        mb->is_intra = 1;
+        if (is_intra_type == 0) {          /* I_NxN */
+            if (s->pps->transform_8x8_mode) mb->t8x8 = (uint8_t)bits_u1(b);
+            if (mb->t8x8) { snprintf(s->d->err, sizeof s->d->err, "Intra8x8 unsupported by the round-1 oracle"); return -1; }
+            for (int blk = 0; blk < 16; blk++) {
+                int bx = blk_x(blk), by = blk_y(blk);
+                /* 8.3.1.1 predIntra4x4PredMode */
+                MbInfo *mA = bx > 0 ? mb : mb_at(s, s->mb_x - 1, s->mb_y);
+                MbInfo *mB = by > 0 ? mb : mb_at(s, s->mb_x, s->mb_y - 1);
+                int modeA, modeB, dc_pred = 0;
+                if (!mA || !mB) dc_pred = 1;
+                if ((mA && !mA->is_intra && s->pps->constrained_intra_pred) || (mB && !mB->is_intra && s->pps->constrained_intra_pred)) dc_pred = 1;
+                modeA = (mA && mA->is_intra && !mA->is_i16 && !mA->is_pcm) ? (bx > 0 ? mb->i4mode[by * 4 + bx - 1] : mA->i4mode[by * 4 + 3]) : 2;
+                modeB = (mB && mB->is_intra && !mB->is_i16 && !mB->is_pcm) ? (by > 0 ? mb->i4mode[(by - 1) * 4 + bx] : mB->i4mode[12 + bx]) : 2;
+                int pred = dc_pred ? 2 : orc_min(modeA, modeB);
+                int mode;
+                if (bits_u1(b)) mode = pred;
+                else { int rem = bits_u(b, 3); mode = rem < pred ? rem : rem + 1; }
+                mb->i4mode[by * 4 + bx] = (uint8_t)mode;
+            }
+        } else {                           /* I_16x16: Table 7-11 */
+            int k = is_intra_type - 1;
+            mb->is_i16 = 1;
+            s->i16_pred_mode = k % 4;
+            cbp = ((k / 4) % 3) << 4 | (k >= 12 ? 15 : 0);
+        }
+        s->chroma_pred_mode = bits_ue(b);
+        if (s->chroma_pred_mode > 3) { snprintf(s->d->err, sizeof s->d->err, "bad intra_chroma_pred_mode"); return -1; }
+    } else {
+        /* ---- P macroblock: 7.3.5.1 mb_pred / 7.3.5.2 sub_mb_pred ---- */
+        int nref = sh->num_ref_idx[0];
+        mb->mb_type_p = (uint8_t)(mb_type > 3 ? 3 : mb_type);
+        if (mb_type <= 2) {
+            int nparts = mb_type == 0 ? 1 : 2, refs[2] = {0, 0};
+            for (int p = 0; p < nparts; p++) if (nref > 1) { refs[p] = bits_te(b, nref - 1); if (refs[p] >= nref) return -1; }
+            for (int p = 0; p < nparts; p++) {
+                int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0;
+                int bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
+                for (int y = by; y < by + bh; y += 2) for (int x = bx; x < bx + bw; x += 2) mb->ref_idx[(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[p];
+                int mvp[2]; predict_mv(s, bx, by, bw, bh, refs[p], mb_type, p, mvp);
+                int mvx = mvp[0] + bits_se(b), mvy = mvp[1] + bits_se(b);
+                set_mv(s, bx, by, bw, bh, mvx, mvy);
+            }
+        } else {
+            int sub[4], refs[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) { sub[i] = bits_ue(b); if (sub[i] > 3) return -1; }
+            for (int i = 0; i < 4; i++) if (nref > 1 && mb_type != 4) { refs[i] = bits_te(b, nref - 1); if (refs[i] >= nref) return -1; }
+            for (int i = 0; i < 4; i++) mb->ref_idx[i] = (int8_t)refs[i];
+            for (int i = 0; i < 4; i++) {
+                int ox = (i & 1) * 2, oy = (i >> 1) * 2;
+                int nsp = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
+                int bw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1, bh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;
+                for (int p = 0; p < nsp; p++) {
+                    int bx = ox + (sub[i] == 1 ? 0 : (sub[i] == 2 ? p : (p & 1)));
+                    int by = oy + (sub[i] == 1 ? p : (sub[i] == 2 ? 0 : (p >> 1)));
+                    int mvp[2]; predict_mv(s, bx, by, bw, bh, refs[i], 0, 0, mvp);
+                    int mvx = mvp[0] + bits_se(b), mvy = mvp[1] + bits_se(b);
+                    set_mv(s, bx, by, bw, bh, mvx, mvy);
+                }
+            }
+        }
+    }
+    if (!mb->is_i16) {
+        unsigned code = bits_ue(b);
+        if (code > 47) { snprintf(s->d->err, sizeof s->d->err, "bad coded_block_pattern"); return -1; }
+        cbp = mb->is_intra ? orc_cbp_intra[code] : orc_cbp_inter[code];
+        if ((cbp & 15) && s->pps->transform_8x8_mode && !mb->is_intra) {
+            snprintf(s->d->err, sizeof s->d->err, "transform_8x8 inter unsupported by the round-1 oracle"); return -1;
+        }
+    }
+    mb->cbp = (uint16_t)cbp;
+    if (cbp > 0 || mb->is_i16) {
+        int dqp = bits_se(b);
+        if (dqp < -26 || dqp > 25) { snprintf(s->d->err, sizeof s->d->err, "mb_qp_delta out of range"); return -1; }
+        s->qp = (s->qp + dqp + 52) % 52;
+    }
+    mb_set_qp(s);
+    if (cbp > 0 || mb->is_i16) { if (parse_residual(s, cbp) < 0) { if (!s->d->err[0]) snprintf(s->d->err, sizeof s->d->err, "CAVLC residual error at MB %d", s->mb_addr); return -1; } }
+    if (b->err) return -1;
+
+    /* ------------------------- reconstruction ------------------------- */
+    int qp = s->qp;
+    if (!mb->is_intra) {
+        if (inter_recon(s) < 0) return -1;
+        const uint8_t *list = s->pps->scaling4[3];
+        for (int r = 0; r < 16; r++) {
+            if (!mb->total_coeff[r]) continue;
+            int dq[16], res[16];
+            scale4x4(s->luma[r], dq, list, qp, 0);
+            idct4x4(dq, res);
+            add_block(dy + (r >> 2) * 4 * pic->stride_y + (r & 3) * 4, pic->stride_y, res, 4);
+        }
+    } else if (mb->is_i16) {
+        if (pred16x16(s, s->i16_pred_mode, dy, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra16x16 mode needs unavailable neighbour"); return -1; }
+        const uint8_t *list = s->pps->scaling4[0];
+        /* 8.5.10: 4x4 luma DC Hadamard + scaling */
+        int f[16], g[16];
+        const int16_t *c = s->i16dc;
+        for (int i = 0; i < 4; i++) {
+            int a0 = c[4 * i] + c[4 * i + 1] + c[4 * i + 2] + c[4 * i + 3], a1 = c[4 * i] + c[4 * i + 1] - c[4 * i + 2] - c[4 * i + 3];
+            int a2 = c[4 * i] - c[4 * i + 1] - c[4 * i + 2] + c[4 * i + 3], a3 = c[4 * i] - c[4 * i + 1] + c[4 * i + 2] - c[4 * i + 3];
+            f[4 * i] = a0; f[4 * i + 1] = a1; f[4 * i + 2] = a2; f[4 * i + 3] = a3;
+        }
+        for (int j = 0; j < 4; j++) {
+            g[j] = f[j] + f[4 + j] + f[8 + j] + f[12 + j]; g[4 + j] = f[j] + f[4 + j] - f[8 + j] - f[12 + j];
+            g[8 + j] = f[j] - f[4 + j] - f[8 + j] + f[12 + j]; g[12 + j] = f[j] - f[4 + j] + f[8 + j] - f[12 + j];
+        }
+        int ls0 = level_scale4(list, qp % 6, 0);
+        for (int r = 0; r < 16; r++) {
+            int dc = qp >= 36 ? (g[r] * ls0) << (qp / 6 - 6) : (g[r] * ls0 + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+            int dq[16], res[16];
+            scale4x4(s->luma[r], dq, list, qp, 0);
+            dq[0] = dc;
+            idct4x4(dq, res);
+            add_block(dy + (r >> 2) * 4 * pic->stride_y + (r & 3) * 4, pic->stride_y, res, 4);
+        }
+    } else {                               /* Intra 4x4: predict + residual per block in decode order */
+        const uint8_t *list = s->pps->scaling4[0];
+        for (int blk = 0; blk < 16; blk++) {
+            int bx = blk_x(blk), by = blk_y(blk), r = by * 4 + bx;
+            uint8_t *dst = dy + by * 4 * pic->stride_y + bx * 4;
+            int mode = mb->i4mode[r];
+            /* modes that require unavailable samples are a bitstream error */
+            int availA = bx > 0 || intra_usable(s, mb_at(s, s->mb_x - 1, s->mb_y));
+            int availB = by > 0 || intra_usable(s, mb_at(s, s->mb_x, s->mb_y - 1));
+            if (((mode == 0 || mode == 3 || mode == 7) && !availB) || ((mode == 1 || mode == 8) && !availA) ||
+                ((mode == 4 || mode == 5 || mode == 6) && !(availA && availB))) {
+                snprintf(s->d->err, sizeof s->d->err, "Intra4x4 mode %d needs unavailable neighbour", mode); return -1;
+            }
+            pred4x4(s, blk, mode, dst, pic->stride_y);
+            if (mb->total_coeff[r]) {
+                int dq[16], res[16];
+                scale4x4(s->luma[r], dq, list, qp, 0);
+                idct4x4(dq, res);
+                add_block(dst, pic->stride_y, res, 4);
+            }
+        }
+    }
+    if (mb->is_intra) {
+        if (pred_chroma(s, s->chroma_pred_mode, du, pic->stride_c) < 0 || pred_chroma(s, s->chroma_pred_mode, dv, pic->stride_c) < 0) {
+            snprintf(s->d->err, sizeof s->d->err, "chroma intra mode needs unavailable neighbour"); return -1;
+        }
+    }
+    recon_chroma_residual(s, cbp);
+    return 0;
+}
+
+/* 7.3.4 slice_data() */
+int orc_decode_slice_data(OrcDec *d, Bits *b) {
+    Sl *s = (Sl *)calloc(1, sizeof(Sl));
+    if (!s) return -1;
+    s->d = d; s->b = b; s->pic = d->cur; s->sps = d->asps; s->pps = d->apps; s->sh = &d->sh;
+    s->qp = d->sh.qp;
+    int n_mbs = d->mb_w * d->mb_h, addr = d->sh.first_mb, rc = 0;
+    if (s->pps->entropy_coding_mode) { snprintf(d->err, sizeof d->err, "CABAC unsupported by the round-1 oracle"); free(s); return -1; }
+    int more = 1;
+    while (more) {
+        if (d->sh.slice_type != SLICE_I) {
+            unsigned run = bits_ue(b);
+            if (b->err || run > (unsigned)(n_mbs - addr)) { snprintf(d->err, sizeof d->err, "bad mb_skip_run"); rc = -1; break; }
+            for (unsigned i = 0; i < run; i++) {
+                s->mb_addr = addr; s->mb_x = addr % d->mb_w; s->mb_y = addr / d->mb_w; s->mb = &s->pic->mbs[addr];
+                if (decode_skip_mb(s) < 0) { rc = -1; break; }
+                addr++; d->cur_mb_count++;
+            }
+            if (rc < 0) break;
+            if (run > 0) more = bits_more_rbsp(b);
+            if (!more) break;
+        }
+        if (addr >= n_mbs) { snprintf(d->err, sizeof d->err, "slice runs past the end of the picture"); rc = -1; break; }
+        s->mb_addr = addr; s->mb_x = addr % d->mb_w; s->mb_y = addr / d->mb_w; s->mb = &s->pic->mbs[addr];
+        if (decode_mb(s) < 0) { if (!d->err[0]) snprintf(d->err, sizeof d->err, "macroblock %d decode error", addr); rc = -1; break; }
+        addr++; d->cur_mb_count++;
+        more = bits_more_rbsp(b);
+    }
+    if (rc == 0 && b->err) { snprintf(d->err, sizeof d->err, "slice data truncated"); rc = -1; }
+    free(s);
+    return rc;
+}

@@ -1,0 +1,1119 @@
+/*
+ * tools/h264gen.c -- seeded synthetic H.264 Annex-B stream generator.
+ *
+ * The reference repository ships no bitstreams, fixtures or golden YUV
+ *  and this image has no encoder, so every test and bench
+ * input is produced here: a small closed-loop Constrained-Baseline encoder
+ * (CAVLC, I/P, I_PCM, Intra16x16 / Intra4x4, P16x16/16x8/8x16/8x8 with
+ * 8x4/4x8/4x4 sub-partitions, quarter-pel MVs that may point outside the
+ * picture, multiple reference frames, multiple slices, in-loop deblocking)
+ * with its OWN reconstruction loop.  The reconstruction it writes with
+ * --recon must equal what any conforming decoder outputs for the stream, which
+ * gives the CPU oracle and the HIP decoder a second, independently written
+ * code path to agree with (tests/test_oracle_vs_generator.py).
+ *
+ * Not derived from the reference (which contains no codec arithmetic).
+ * Content is procedural and integer-only so that streams are bit-identical on
+ * every machine:  seed = 0x4A4D0000 + config_id*256 + stream_id.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PAD 48
+#define CLIP3(lo, hi, v) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+#define CLIP1(v) CLIP3(0, 255, v)
+#define ABS(v) ((v) < 0 ? -(v) : (v))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+
+typedef struct {
+    int width, height;          /* display size (cropped)                     */
+    int frames, qp, gop, seed;
+    int mode;                   /* 0 = "real" (SAD decisions), 1 = fuzz       */
+    int deblock;                /* 1 = on (idc 0), 0 = off (idc 1), 2 = idc 2 */
+    int num_ref;                /* max_num_ref_frames 1..4                    */
+    int slices;                 /* slices per picture (split by MB rows)      */
+    int pcm_only;               /* every MB I_PCM (known-answer streams)      */
+    int poc_type;               /* 0 or 2                                     */
+    int nonref_period;          /* >0: every n-th P picture is non-reference  */
+    int alpha_off, beta_off;    /* slice_alpha_c0_offset_div2, beta_offset_div2 */
+    int chroma_qp_off;
+    int level_idc;
+    int cip;                    /* constrained_intra_pred_flag                */
+    int search;                 /* integer search range                       */
+} GenParams;
+
+/* ------------------------------ RNG --------------------------------------- */
+typedef struct { uint64_t s; } Rng;
+static uint32_t rnd(Rng *r) { r->s = r->s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(r->s >> 33); }
+static int rnd_n(Rng *r, int n) { return (int)(rnd(r) % (uint32_t)n); }
+
+/* ------------------------------ bit writer -------------------------------- */
+typedef struct { uint8_t *buf; size_t cap, len; uint32_t cur; int nbits; } BitW;
+static void bw_reserve(BitW *w, size_t extra) {
+    if (w->len + extra > w->cap) { w->cap = (w->len + extra) * 2 + 1024; w->buf = (uint8_t *)realloc(w->buf, w->cap); }
+}
+static void bw_put(BitW *w, int n, uint32_t v) {
+    for (int i = n - 1; i >= 0; i--) {
+        w->cur = (w->cur << 1) | ((v >> i) & 1);
+        if (++w->nbits == 8) { bw_reserve(w, 1); w->buf[w->len++] = (uint8_t)w->cur; w->cur = 0; w->nbits = 0; }
+    }
+}
+static void bw_ue(BitW *w, uint32_t v) {
+    uint32_t x = v + 1; int n = 0;
+    while ((x >> n) > 1) n++;
+    bw_put(w, n, 0); bw_put(w, n + 1, x);
+}
+static void bw_se(BitW *w, int v) { bw_ue(w, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+static void bw_te(BitW *w, int range_max, int v) { if (range_max > 1) bw_ue(w, v); else bw_put(w, 1, !v); }
+static void bw_trailing(BitW *w) { bw_put(w, 1, 1); while (w->nbits) bw_put(w, 1, 0); }
+static int bw_bitpos(const BitW *w) { return (int)w->len * 8 + w->nbits; }
+
+typedef struct { uint8_t *buf; size_t cap, len; } Out;
+static void out_nal(Out *o, int ref_idc, int type, const BitW *w, int long_sc) {
+    size_t need = w->len * 3 / 2 + 16;
+    if (o->len + need > o->cap) { o->cap = (o->len + need) * 2; o->buf = (uint8_t *)realloc(o->buf, o->cap); }
+    uint8_t *p = o->buf + o->len;
+    if (long_sc) *p++ = 0;
+    *p++ = 0; *p++ = 0; *p++ = 1;
+    *p++ = (uint8_t)((ref_idc << 5) | type);
+    int zeros = 0;
+    for (size_t i = 0; i < w->len; i++) {
+        uint8_t b = w->buf[i];
+        if (zeros >= 2 && b <= 3) { *p++ = 3; zeros = 0; }
+        *p++ = b;
+        zeros = b == 0 ? zeros + 1 : 0;
+    }
+    o->len = (size_t)(p - o->buf);
+}
+
+/* ------------------------------ tables (own copy) -------------------------- */
+static const uint8_t ct_len[4][68] = {
+{ 1,0,0,0, 6,2,0,0, 8,6,3,0, 9,8,7,5, 10,9,8,6, 11,10,9,7, 13,11,10,8, 13,13,11,9, 13,13,13,10,
+ 14,14,13,11, 14,14,14,13, 15,15,14,14, 15,15,15,14, 16,15,15,15, 16,16,16,15, 16,16,16,16, 16,16,16,16 },
+{ 2,0,0,0, 6,2,0,0, 6,5,3,0, 7,6,6,4, 8,6,6,4, 8,7,7,5, 9,8,8,6, 11,9,9,6, 11,11,11,7,
+ 12,11,11,9, 12,12,12,11, 12,12,12,11, 13,13,13,12, 13,13,13,13, 13,14,13,13, 14,14,14,13, 14,14,14,14 },
+{ 4,0,0,0, 6,4,0,0, 6,5,4,0, 6,5,5,4, 7,5,5,4, 7,5,5,4, 7,6,6,4, 7,6,6,4, 8,7,7,5,
+ 8,8,7,6, 9,8,8,7, 9,9,8,8, 9,9,9,8, 10,9,9,9, 10,10,10,10, 10,10,10,10, 10,10,10,10 },
+{ 6,0,0,0, 6,6,0,0, 6,6,6,0, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6,
+ 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6, 6,6,6,6 } };
+static const uint8_t ct_bits[4][68] = {
+{ 1,0,0,0, 5,1,0,0, 7,4,1,0, 7,6,5,3, 7,6,5,3, 7,6,5,4, 15,6,5,4, 11,14,5,4, 8,10,13,4,
+ 15,14,9,4, 11,10,13,12, 15,14,9,12, 11,10,13,8, 15,1,9,12, 11,14,13,8, 7,10,9,12, 4,6,5,8 },
+{ 3,0,0,0, 11,2,0,0, 7,7,3,0, 7,10,9,5, 7,6,5,4, 4,6,5,6, 7,6,5,8, 15,6,5,4, 11,14,13,4,
+ 15,10,9,4, 11,14,13,12, 8,10,9,8, 15,14,13,12, 11,10,9,12, 7,11,6,8, 9,8,10,1, 7,6,5,4 },
+{ 15,0,0,0, 15,14,0,0, 11,15,13,0, 8,12,14,12, 15,10,11,11, 11,8,9,10, 9,14,13,9, 8,10,9,8, 15,14,13,13,
+ 11,14,10,12, 15,10,13,12, 11,14,9,12, 8,10,13,8, 13,7,9,12, 9,12,11,10, 5,8,7,6, 1,4,3,2 },
+{ 3,0,0,0, 0,1,0,0, 4,5,6,0, 8,9,10,11, 12,13,14,15, 16,17,18,19, 20,21,22,23, 24,25,26,27, 28,29,30,31,
+ 32,33,34,35, 36,37,38,39, 40,41,42,43, 44,45,46,47, 48,49,50,51, 52,53,54,55, 56,57,58,59, 60,61,62,63 } };
+static const uint8_t cdc_len[20] = { 2,0,0,0, 6,1,0,0, 6,6,3,0, 6,7,7,6, 6,8,8,7 };
+static const uint8_t cdc_bits[20] = { 1,0,0,0, 7,1,0,0, 4,6,1,0, 3,3,2,5, 2,3,2,0 };
+static const uint8_t tz_len[15][16] = {
+ {1,3,3,4,4,5,5,6,6,7,7,8,8,9,9,9},{3,3,3,3,3,4,4,4,4,5,5,6,6,6,6,0},{4,3,3,3,4,4,3,3,4,5,5,6,5,6,0,0},
+ {5,3,4,4,3,3,3,4,3,4,5,5,5,0,0,0},{4,4,4,3,3,3,3,3,4,5,4,5,0,0,0,0},{6,5,3,3,3,3,3,3,4,3,6,0,0,0,0,0},
+ {6,5,3,3,3,2,3,4,3,6,0,0,0,0,0,0},{6,4,5,3,2,2,3,3,6,0,0,0,0,0,0,0},{6,6,4,2,2,3,2,5,0,0,0,0,0,0,0,0},
+ {5,5,3,2,2,2,4,0,0,0,0,0,0,0,0,0},{4,4,3,3,1,3,0,0,0,0,0,0,0,0,0,0},{4,4,2,1,3,0,0,0,0,0,0,0,0,0,0,0},
+ {3,3,1,2,0,0,0,0,0,0,0,0,0,0,0,0},{2,2,1,0,0,0,0,0,0,0,0,0,0,0,0,0},{1,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0} };
+static const uint8_t tz_bits[15][16] = {
+ {1,3,2,3,2,3,2,3,2,3,2,3,2,3,2,1},{7,6,5,4,3,5,4,3,2,3,2,3,2,1,0,0},{5,7,6,5,4,3,4,3,2,3,2,1,1,0,0,0},
+ {3,7,5,4,6,5,4,3,3,2,2,1,0,0,0,0},{5,4,3,7,6,5,4,3,2,1,1,0,0,0,0,0},{1,1,7,6,5,4,3,2,1,1,0,0,0,0,0,0},
+ {1,1,5,4,3,3,2,1,1,0,0,0,0,0,0,0},{1,1,1,3,3,2,2,1,0,0,0,0,0,0,0,0},{1,0,1,3,2,1,1,1,0,0,0,0,0,0,0,0},
+ {1,0,1,3,2,1,1,0,0,0,0,0,0,0,0,0},{0,1,1,2,1,3,0,0,0,0,0,0,0,0,0,0},{0,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0},
+ {0,1,1,1,0,0,0,0,0,0,0,0,0,0,0,0},{0,1,1,0,0,0,0,0,0,0,0,0,0,0,0,0},{0,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0} };
+static const uint8_t ctz_len[3][4] = { {1,2,3,3},{1,2,2,0},{1,1,0,0} };
+static const uint8_t ctz_bits[3][4] = { {1,1,1,0},{1,1,0,0},{1,0,0,0} };
+static const uint8_t rb_len[7][15] = {
+ {1,1},{1,2,2},{2,2,2,2},{2,2,2,3,3},{2,2,3,3,3,3},{2,3,3,3,3,3,3},{3,3,3,3,3,3,3,4,5,6,7,8,9,10,11} };
+static const uint8_t rb_bits[7][15] = {
+ {1,0},{1,1,0},{3,2,1,0},{3,2,1,1,0},{3,2,3,2,1,0},{3,0,1,3,2,5,4},{7,6,5,4,3,2,1,1,1,1,1,1,1,1,1} };
+static const uint8_t cbp_intra_tab[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
+static const uint8_t cbp_inter_tab[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
+static const uint8_t zz4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
+static const uint8_t qpc_tab[22] = {29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39};
+static const int norm4[6][3] = { {10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23} };
+static const int quant_mf[6][3] = { {13107,5243,8066},{11916,4660,7490},{10082,4194,6554},{9362,3647,5825},{8192,3355,5243},{7282,2893,4559} };
+static const uint8_t alpha_tab[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
+static const uint8_t beta_tab[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
+static const uint8_t tc0_tab[52][3] = {
+ {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+ {0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},
+ {2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
+ {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
+
+/* ------------------------------ frames ------------------------------------- */
+typedef struct {
+    uint8_t *y, *u, *v;            /* origin pointers inside padded buffers      */
+    uint8_t *by, *bu, *bv;
+    int sy, sc;                    /* strides                                    */
+    uint8_t *hb, *hh, *hj;         /* luma half-pel planes (origin pointers)     */
+    uint8_t *bhb, *bhh, *bhj;
+    int frame_num, poc, id;
+} Frame;
+
+typedef struct {
+    int8_t ref[4]; int16_t mv[16][2]; int refid[4];
+    uint8_t tc[24]; uint8_t intra, pcm, i16, qp, qpc[2]; uint8_t i4[16];
+    int slice; uint8_t skip;
+    int8_t dis_db, a_off, b_off;
+} MbE;
+
+typedef struct {
+    GenParams p;
+    int W, H, mbw, mbh;            /* coded size                                 */
+    Frame src, cur, refs[5]; int nrefs;
+    MbE *mbs;
+    Rng rng;
+    BitW bw; Out out;
+    int frame_num, idr_id, log2_max_fn, poc_lsb_bits;
+    int slice_id, slice_type, qp_run;
+    Frame *list0[5]; int nlist0;
+    int16_t tex[256][256];
+    int next_id;
+    int decoded_mask;
+    FILE *recon;
+    long stat_bits_mb[8];
+} Enc;
+
+static void frame_alloc(Frame *f, int W, int H, int hp) {
+    memset(f, 0, sizeof *f);
+    f->sy = W + 2 * PAD; f->sc = W / 2 + PAD;
+    f->by = (uint8_t *)calloc((size_t)f->sy * (H + 2 * PAD), 1);
+    f->bu = (uint8_t *)calloc((size_t)f->sc * (H / 2 + PAD), 1);
+    f->bv = (uint8_t *)calloc((size_t)f->sc * (H / 2 + PAD), 1);
+    f->y = f->by + PAD * f->sy + PAD; f->u = f->bu + (PAD / 2) * f->sc + PAD / 2; f->v = f->bv + (PAD / 2) * f->sc + PAD / 2;
+    if (hp) {
+        f->bhb = (uint8_t *)calloc((size_t)f->sy * (H + 2 * PAD), 1); f->bhh = (uint8_t *)calloc((size_t)f->sy * (H + 2 * PAD), 1);
+        f->bhj = (uint8_t *)calloc((size_t)f->sy * (H + 2 * PAD), 1);
+        f->hb = f->bhb + PAD * f->sy + PAD; f->hh = f->bhh + PAD * f->sy + PAD; f->hj = f->bhj + PAD * f->sy + PAD;
+    }
+}
+static void frame_free(Frame *f) { free(f->by); free(f->bu); free(f->bv); free(f->bhb); free(f->bhh); free(f->bhj); }
+static void pad_plane(uint8_t *o, int stride, int w, int h, int pad) {
+    for (int y = 0; y < h; y++) { memset(o + y * stride - pad, o[y * stride], pad); memset(o + y * stride + w, o[y * stride + w - 1], pad); }
+    for (int y = 1; y <= pad; y++) { memcpy(o - y * stride - pad, o - pad, w + 2 * pad); memcpy(o + (h - 1 + y) * stride - pad, o + (h - 1) * stride - pad, w + 2 * pad); }
+}
+static inline int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+/* pad the reconstructed frame and build the three half-sample planes used by motion search */
+static void frame_finish_ref(Frame *f, int W, int H) {
+    pad_plane(f->y, f->sy, W, H, PAD); pad_plane(f->u, f->sc, W / 2, H / 2, PAD / 2); pad_plane(f->v, f->sc, W / 2, H / 2, PAD / 2);
+    int m = PAD - 4, st = f->sy;
+    int tw = W + 2 * m, th = H + 2 * m + 5;
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)tw * th);     /* unclipped horizontal 6-tap, rows -m-2 .. H+m+2 */
+    for (int y = -m - 2; y < H + m + 3; y++) for (int x = -m; x < W + m; x++) {
+        const uint8_t *p = f->y + y * st + x;
+        tmp[(y + m + 2) * tw + x + m] = (int16_t)tap6(p[-2], p[-1], p[0], p[1], p[2], p[3]);
+    }
+    for (int y = -m; y < H + m; y++) for (int x = -m; x < W + m; x++) {
+        const uint8_t *p = f->y + y * st + x; const int16_t *t = tmp + (y + m + 2) * tw + x + m;
+        f->hb[y * st + x] = (uint8_t)CLIP1((t[0] + 16) >> 5);
+        f->hh[y * st + x] = (uint8_t)CLIP1((tap6(p[-2 * st], p[-st], p[0], p[st], p[2 * st], p[3 * st]) + 16) >> 5);
+        f->hj[y * st + x] = (uint8_t)CLIP1((tap6(t[-2 * tw], t[-tw], t[0], t[tw], t[2 * tw], t[3 * tw]) + 512) >> 10);
+    }
+    free(tmp);
+}
+
+/* ------------------------------ content ------------------------------------ */
+static int tri(int p) { p &= 1023; int q = p < 512 ? p : 1023 - p; int x = q - 256; return (x * (512 - ABS(x))) >> 8; /* [-256,256] smooth */ }
+static void make_texture(Enc *e) {
+    Rng r = { (uint64_t)e->p.seed * 77 + 5 };
+    static int16_t n0[64][64];
+    for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++) n0[y][x] = (int16_t)(rnd_n(&r, 65) - 32);
+    for (int y = 0; y < 256; y++) for (int x = 0; x < 256; x++) {      /* bilinear-upsampled noise + fine grain */
+        int x0 = (x >> 2) & 63, y0 = (y >> 2) & 63, x1 = (x0 + 1) & 63, y1 = (y0 + 1) & 63, fx = x & 3, fy = y & 3;
+        int v = (n0[y0][x0] * (4 - fx) * (4 - fy) + n0[y0][x1] * fx * (4 - fy) + n0[y1][x0] * (4 - fx) * fy + n0[y1][x1] * fx * fy) >> 4;
+        e->tex[y][x] = (int16_t)(v + rnd_n(&r, 9) - 4);
+    }
+}
+static void render_source(Enc *e, int t) {
+    Frame *f = &e->src; int W = e->p.width, H = e->p.height, s = e->p.seed & 0xffff;
+    /* background pans at 3/4 px/frame horizontally, 1/4 px/frame vertically (quarter-pel units) */
+    int panx4 = 3 * t + (s & 7), pany4 = t + ((s >> 3) & 7);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+        int X4 = 4 * x - panx4, Y4 = 4 * y - pany4;
+        int v = 128 + ((70 * tri(2 * X4 + Y4 / 2 + s) + 45 * tri(Y4 * 3 - X4 / 2 + 300)) >> 8);
+        int tx = (X4 >> 2) & 255, ty = (Y4 >> 2) & 255, fx = X4 & 3, fy = Y4 & 3;
+        int t00 = e->tex[ty][tx], t01 = e->tex[ty][(tx + 1) & 255], t10 = e->tex[(ty + 1) & 255][tx], t11 = e->tex[(ty + 1) & 255][(tx + 1) & 255];
+        v += (t00 * (4 - fx) * (4 - fy) + t01 * fx * (4 - fy) + t10 * (4 - fx) * fy + t11 * fx * fy) >> 4;
+        f->y[y * f->sy + x] = (uint8_t)CLIP1(v);
+    }
+    /* translating objects with their own texture and velocity */
+    for (int k = 0; k < 6; k++) {
+        int bw = 32 + 24 * k, bh = 24 + 16 * ((k * 5) % 4);
+        int vx4 = (k * 7 + s) % 19 - 9, vy4 = (k * 11 + s) % 13 - 6;
+        int ox = (((k * 97 + s * 3) % (W + bw)) * 4 + vx4 * t) >> 2, oy = (((k * 61 + s) % (H + bh)) * 4 + vy4 * t) >> 2;
+        ox = ((ox % (W + bw)) + (W + bw)) % (W + bw) - bw; oy = ((oy % (H + bh)) + (H + bh)) % (H + bh) - bh;
+        for (int y = MAX(0, oy); y < MIN(H, oy + bh); y++) for (int x = MAX(0, ox); x < MIN(W, ox + bw); x++) {
+            int v = 60 + 30 * k + ((40 * tri((x - ox) * 24 + (y - oy) * 9 * (k + 1))) >> 8) + e->tex[(y - oy + 40 * k) & 255][(x - ox + 13 * k) & 255] / 2;
+            f->y[y * f->sy + x] = (uint8_t)CLIP1(v);
+        }
+    }
+    for (int y = 0; y < H / 2; y++) for (int x = 0; x < W / 2; x++) {
+        int X4 = 8 * x - panx4, Y4 = 8 * y - pany4;
+        f->u[y * f->sc + x] = (uint8_t)CLIP1(128 + ((50 * tri(X4 / 2 + Y4 + 100 + s)) >> 8) + e->tex[(Y4 >> 3) & 255][(X4 >> 3) & 255] / 4);
+        f->v[y * f->sc + x] = (uint8_t)CLIP1(128 + ((50 * tri(Y4 - X4 / 3 + 700)) >> 8) - e->tex[(X4 >> 3) & 255][(Y4 >> 3) & 255] / 4);
+    }
+    /* replicate into the coded-size area beyond the display size */
+    for (int y = 0; y < e->H; y++) { int yy = MIN(y, H - 1);
+        if (yy != y) memcpy(f->y + y * f->sy, f->y + yy * f->sy, W);
+        for (int x = W; x < e->W; x++) f->y[y * f->sy + x] = f->y[y * f->sy + W - 1]; }
+    for (int y = 0; y < e->H / 2; y++) { int yy = MIN(y, H / 2 - 1);
+        if (yy != y) { memcpy(f->u + y * f->sc, f->u + yy * f->sc, W / 2); memcpy(f->v + y * f->sc, f->v + yy * f->sc, W / 2); }
+        for (int x = W / 2; x < e->W / 2; x++) { f->u[y * f->sc + x] = f->u[y * f->sc + W / 2 - 1]; f->v[y * f->sc + x] = f->v[y * f->sc + W / 2 - 1]; } }
+}
+
+/* ------------------------------ prediction helpers -------------------------- */
+static MbE *mb_avail(Enc *e, int mx, int my) {
+    if (mx < 0 || my < 0 || mx >= e->mbw || my >= e->mbh) return NULL;
+    MbE *m = &e->mbs[my * e->mbw + mx];
+    return m->slice == e->slice_id ? m : NULL;
+}
+static int intra_ok(Enc *e, MbE *m) { return m && (!e->p.cip || m->intra); }
+
+static inline int refpx(const uint8_t *p, int st, int w, int h, int x, int y) { return p[CLIP3(0, h - 1, y) * st + CLIP3(0, w - 1, x)]; }
+/* spec-literal luma sample (8.4.2.2.1), coordinate clamping */
+static int luma_sample(const Frame *r, int W, int H, int xi, int yi, int fx, int fy) {
+#define P(dx, dy) refpx(r->y, r->sy, W, H, xi + (dx), yi + (dy))
+#define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
+#define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
+    int G = P(0, 0);
+    if (!fx && !fy) return G;
+    int b = CLIP1((HB(0) + 16) >> 5), h = CLIP1((VH(0) + 16) >> 5);
+    if (!fy) return fx == 2 ? b : (fx == 1 ? (G + b + 1) >> 1 : (P(1, 0) + b + 1) >> 1);
+    if (!fx) return fy == 2 ? h : (fy == 1 ? (G + h + 1) >> 1 : (P(0, 1) + h + 1) >> 1);
+    int j = CLIP1((tap6(HB(-2), HB(-1), HB(0), HB(1), HB(2), HB(3)) + 512) >> 10);
+    int s = CLIP1((HB(1) + 16) >> 5), m = CLIP1((VH(1) + 16) >> 5);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) return fy == 1 ? (b + j + 1) >> 1 : (j + s + 1) >> 1;
+    if (fy == 2) return fx == 1 ? (h + j + 1) >> 1 : (j + m + 1) >> 1;
+    if (fx == 1 && fy == 1) return (b + h + 1) >> 1;
+    if (fx == 3 && fy == 1) return (b + m + 1) >> 1;
+    if (fx == 1 && fy == 3) return (h + s + 1) >> 1;
+    return (m + s + 1) >> 1;
+#undef P
+#undef HB
+#undef VH
+}
+/* fast quarter-sample fetch from the half-pel planes (motion search only) */
+static inline int qpel_fast(const Frame *r, int x, int y, int fx, int fy) {
+    int st = r->sy; const uint8_t *G = r->y + y * st + x, *b = r->hb + y * st + x, *h = r->hh + y * st + x, *j = r->hj + y * st + x;
+    switch (fy * 4 + fx) {
+    case 0: return G[0]; case 2: return b[0]; case 8: return h[0]; case 10: return j[0];
+    case 1: return (G[0] + b[0] + 1) >> 1; case 3: return (G[1] + b[0] + 1) >> 1;
+    case 4: return (G[0] + h[0] + 1) >> 1; case 12: return (G[st] + h[0] + 1) >> 1;
+    case 5: return (b[0] + h[0] + 1) >> 1; case 7: return (b[0] + h[1] + 1) >> 1;
+    case 13: return (h[0] + b[st] + 1) >> 1; case 15: return (h[1] + b[st] + 1) >> 1;
+    case 6: return (b[0] + j[0] + 1) >> 1; case 14: return (j[0] + b[st] + 1) >> 1;
+    case 9: return (h[0] + j[0] + 1) >> 1; default: return (j[0] + h[1] + 1) >> 1;
+    }
+}
+static int sad_inter(Enc *e, const Frame *r, int px, int py, int w, int h, int mvx, int mvy) {
+    int sad = 0, x0 = px + (mvx >> 2), y0 = py + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
+    const Frame *s = &e->src;
+    if (!fx && !fy) { for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) sad += ABS(s->y[(py + y) * s->sy + px + x] - r->y[(y0 + y) * r->sy + x0 + x]); }
+    else for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) sad += ABS(s->y[(py + y) * s->sy + px + x] - qpel_fast(r, x0 + x, y0 + y, fx, fy));
+    return sad;
+}
+static int mv_legal(Enc *e, int px, int py, int w, int h, int mvx, int mvy) {
+    int lim = PAD - 8;
+    int x0 = px + (mvx >> 2), y0 = py + (mvy >> 2);
+    return x0 >= -lim && y0 >= -lim && x0 + w <= e->W + lim && y0 + h <= e->H + lim && ABS(mvx) < 4 * 120 && ABS(mvy) < 4 * 120;
+}
+static void mc_block(Enc *e, const Frame *r, int px, int py, int w, int h, int mvx, int mvy) {
+    Frame *c = &e->cur;
+    static int check = -1; if (check < 0) check = getenv("H264GEN_CHECK") != NULL;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        int v = qpel_fast(r, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
+        if (check && v != luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3)) { fprintf(stderr, "h264gen: fast/literal MC mismatch\n"); abort(); }
+        c->y[(py + y) * c->sy + px + x] = (uint8_t)v;
+    }
+    int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
+    for (int pl = 0; pl < 2; pl++) {
+        const uint8_t *rp = pl ? r->v : r->u; uint8_t *dp = pl ? c->v : c->u;
+        for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
+            int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
+            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1), D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
+            dp[(py / 2 + y) * c->sc + px / 2 + x] = (uint8_t)(((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6);
+        }
+    }
+}
+
+/* neighbour motion data (8.4.1.3.2) */
+typedef struct { int avail, ref, mv[2]; } Nbr;
+static Nbr nbr_get(Enc *e, int mx, int my, MbE *cur, int bx, int by) {
+    Nbr n = {0, -1, {0, 0}}; MbE *m; int rx, ry;
+    if (by < 0) { ry = 3;
+        if (bx < 0) { m = mb_avail(e, mx - 1, my - 1); rx = 3; }
+        else if (bx > 3) { m = mb_avail(e, mx + 1, my - 1); rx = bx - 4; }
+        else { m = mb_avail(e, mx, my - 1); rx = bx; } }
+    else if (bx < 0) { m = mb_avail(e, mx - 1, my); rx = 3; ry = by; }
+    else if (bx > 3) return n;
+    else { if (!(e->decoded_mask >> (by * 4 + bx) & 1)) return n; m = cur; rx = bx; ry = by; }
+    if (!m) return n;
+    n.avail = 1;
+    if (m->intra) return n;
+    n.ref = m->ref[(ry >> 1) * 2 + (rx >> 1)];
+    if (n.ref >= 0) { n.mv[0] = m->mv[ry * 4 + rx][0]; n.mv[1] = m->mv[ry * 4 + rx][1]; }
+    return n;
+}
+static int med3(int a, int b, int c) { return a + b + c - MAX(a, MAX(b, c)) - MIN(a, MIN(b, c)); }
+static void pred_mv(Enc *e, int mx, int my, MbE *cur, int bx, int by, int bw, int ref, int shape, int part, int out[2]) {
+    Nbr A = nbr_get(e, mx, my, cur, bx - 1, by), B = nbr_get(e, mx, my, cur, bx, by - 1), C = nbr_get(e, mx, my, cur, bx + bw, by - 1);
+    if (!C.avail) C = nbr_get(e, mx, my, cur, bx - 1, by - 1);
+    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } }
+    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0]; out[1] = C.mv[1]; return; } }
+    if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
+    int ma = A.ref == ref, mb = B.ref == ref, mc = C.ref == ref;
+    if (ma + mb + mc == 1) { Nbr *n = ma ? &A : (mb ? &B : &C); out[0] = n->mv[0]; out[1] = n->mv[1]; }
+    else { out[0] = med3(A.mv[0], B.mv[0], C.mv[0]); out[1] = med3(A.mv[1], B.mv[1], C.mv[1]); }
+}
+static void skip_mv(Enc *e, int mx, int my, MbE *cur, int out[2]) {
+    out[0] = out[1] = 0;
+    if (!mb_avail(e, mx - 1, my) || !mb_avail(e, mx, my - 1)) return;
+    Nbr A = nbr_get(e, mx, my, cur, -1, 0), B = nbr_get(e, mx, my, cur, 0, -1);
+    if ((A.ref == 0 && !A.mv[0] && !A.mv[1]) || (B.ref == 0 && !B.mv[0] && !B.mv[1])) return;
+    pred_mv(e, mx, my, cur, 0, 0, 4, 0, 0, 0, out);
+}
+static void store_mv(Enc *e, MbE *m, int bx, int by, int bw, int bh, int mvx, int mvy) {
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mv[y * 4 + x][0] = (int16_t)mvx; m->mv[y * 4 + x][1] = (int16_t)mvy; e->decoded_mask |= 1 << (y * 4 + x); }
+}
+
+/* ------------------------------ intra prediction ---------------------------- */
+static inline int bX(int blk) { return (blk & 1) + 2 * ((blk >> 2) & 1); }
+static inline int bY(int blk) { return ((blk >> 1) & 1) + 2 * (blk >> 3); }
+/* which Intra4x4 modes are usable for block blk; fills edge arrays */
+static void i4_edges(Enc *e, int mx, int my, int blk, int *T, int *L, int *aA, int *aB) {
+    Frame *c = &e->cur; int bx = bX(blk), by = bY(blk);
+    uint8_t *d = c->y + (my * 16 + by * 4) * c->sy + mx * 16 + bx * 4; int st = c->sy;
+    int availA = bx > 0 || intra_ok(e, mb_avail(e, mx - 1, my)), availB = by > 0 || intra_ok(e, mb_avail(e, mx, my - 1));
+    int availD = (bx > 0 && by > 0) ? 1 : (bx > 0 ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by > 0 ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e, mb_avail(e, mx - 1, my - 1))));
+    int availC;
+    if (by == 0) availC = intra_ok(e, bx < 3 ? mb_avail(e, mx, my - 1) : mb_avail(e, mx + 1, my - 1));
+    else availC = !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
+    for (int i = 0; i < 4; i++) { T[i] = availB ? d[-st + i] : 128; L[i] = availA ? d[i * st - 1] : 128; }
+    for (int i = 4; i < 8; i++) T[i] = (availB && availC) ? d[-st + i] : T[3];
+    T[-1] = L[-1] = availD ? d[-st - 1] : 128;
+    *aA = availA; *aB = availB;
+}
+static int i4_mode_ok(int mode, int aA, int aB) {
+    if (mode == 2) return 1;
+    if (mode == 0 || mode == 3 || mode == 7) return aB;
+    if (mode == 1 || mode == 8) return aA;
+    return aA && aB;
+}
+static void i4_predict(int mode, const int *T, const int *L, int aA, int aB, int *p) {
+    switch (mode) {
+    case 0: for (int k = 0; k < 16; k++) p[k] = T[k & 3]; break;
+    case 1: for (int k = 0; k < 16; k++) p[k] = L[k >> 2]; break;
+    case 2: { int dc = aA && aB ? (T[0] + T[1] + T[2] + T[3] + L[0] + L[1] + L[2] + L[3] + 4) >> 3 : aA ? (L[0] + L[1] + L[2] + L[3] + 2) >> 2 : aB ? (T[0] + T[1] + T[2] + T[3] + 2) >> 2 : 128;
+        for (int k = 0; k < 16; k++) p[k] = dc; break; }
+    case 3: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = (x == 3 && y == 3) ? (T[6] + 3 * T[7] + 2) >> 2 : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2; break;
+    case 4: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ? (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 : (T[0] + 2 * T[-1] + L[0] + 2) >> 2; break;
+    case 5: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = 2 * x - y, i = x - (y >> 1);
+            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (L[y - 1] + 2 * L[y - 2] + L[y - 3] + 2) >> 2; } break;
+    case 6: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = 2 * y - x, i = y - (x >> 1);
+            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (T[x - 1] + 2 * T[x - 2] + T[x - 3] + 2) >> 2; } break;
+    case 7: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int i = x + (y >> 1); p[y * 4 + x] = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1; } break;
+    default: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = x + 2 * y, i = y + (x >> 1);
+            p[y * 4 + x] = z > 5 ? L[3] : z == 5 ? (L[2] + 3 * L[3] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 : (L[i] + L[i + 1] + 1) >> 1; } break;
+    }
+}
+/* n x n block prediction for Intra16x16 (n=16, modes V,H,DC,Plane) and chroma (n=8, modes DC,H,V,Plane mapped by caller) */
+static void big_predict(const uint8_t *d, int st, int n, int kind /*0 V 1 H 2 DC 3 plane*/, int aA, int aB, int *p) {
+    if (kind == 0) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) p[y * n + x] = d[-st + x]; }
+    else if (kind == 1) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) p[y * n + x] = d[y * st - 1]; }
+    else if (kind == 3) {
+        int Hh = 0, V = 0, h2 = n / 2;
+        for (int k = 0; k < h2; k++) { Hh += (k + 1) * (d[-st + h2 + k] - d[-st + h2 - 2 - k]); V += (k + 1) * (d[(h2 + k) * st - 1] - d[(h2 - 2 - k) * st - 1]); }
+        int a = 16 * (d[(n - 1) * st - 1] + d[-st + n - 1]);
+        int b = n == 16 ? (5 * Hh + 32) >> 6 : (34 * Hh + 32) >> 6, c = n == 16 ? (5 * V + 32) >> 6 : (34 * V + 32) >> 6;
+        for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) p[y * n + x] = CLIP1((a + b * (x - (h2 - 1)) + c * (y - (h2 - 1)) + 16) >> 5);
+    } else if (n == 16) {
+        int s1 = 0, s2 = 0; for (int i = 0; i < 16; i++) { if (aB) s1 += d[-st + i]; if (aA) s2 += d[i * st - 1]; }
+        int dc = aA && aB ? (s1 + s2 + 16) >> 5 : aA ? (s2 + 8) >> 4 : aB ? (s1 + 8) >> 4 : 128;
+        for (int k = 0; k < 256; k++) p[k] = dc;
+    } else {
+        for (int by = 0; by < 2; by++) for (int bx = 0; bx < 2; bx++) {
+            int s1 = 0, s2 = 0, dc; for (int i = 0; i < 4; i++) { if (aB) s1 += d[-st + bx * 4 + i]; if (aA) s2 += d[(by * 4 + i) * st - 1]; }
+            if (bx == by) dc = aA && aB ? (s1 + s2 + 4) >> 3 : aA ? (s2 + 2) >> 2 : aB ? (s1 + 2) >> 2 : 128;
+            else if (bx == 1) dc = aB ? (s1 + 2) >> 2 : aA ? (s2 + 2) >> 2 : 128;
+            else dc = aA ? (s2 + 2) >> 2 : aB ? (s1 + 2) >> 2 : 128;
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[(by * 4 + y) * 8 + bx * 4 + x] = dc;
+        }
+    }
+}
+
+/* ------------------------------ transform / quant --------------------------- */
+static void fdct4(const int *x, int *w) {
+    int t[16];
+    for (int i = 0; i < 4; i++) { const int *r = x + 4 * i; int a = r[0] + r[3], b = r[1] + r[2], c = r[1] - r[2], d = r[0] - r[3];
+        t[4 * i] = a + b; t[4 * i + 1] = 2 * d + c; t[4 * i + 2] = a - b; t[4 * i + 3] = d - 2 * c; }
+    for (int j = 0; j < 4; j++) { int a = t[j] + t[12 + j], b = t[4 + j] + t[8 + j], c = t[4 + j] - t[8 + j], d = t[j] - t[12 + j];
+        w[j] = a + b; w[4 + j] = 2 * d + c; w[8 + j] = a - b; w[12 + j] = d - 2 * c; }
+}
+static inline int pos_class(int k) { int i = k >> 2, j = k & 3; return (!(i & 1) && !(j & 1)) ? 0 : ((i & 1) && (j & 1)) ? 1 : 2; }
+static int quant1(int w, int mf, int f, int shift) { int z = (ABS(w) * mf + f) >> shift; z = MIN(z, 2000); return w < 0 ? -z : z; }
+static void idct4_add(const int *dq, uint8_t *dst, int st) {
+    int f[16];
+    for (int i = 0; i < 4; i++) { const int *d = dq + 4 * i; int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+        f[4 * i] = e0 + e3; f[4 * i + 1] = e1 + e2; f[4 * i + 2] = e1 - e2; f[4 * i + 3] = e0 - e3; }
+    for (int j = 0; j < 4; j++) { int g0 = f[j] + f[8 + j], g1 = f[j] - f[8 + j], g2 = (f[4 + j] >> 1) - f[12 + j], g3 = f[4 + j] + (f[12 + j] >> 1);
+        int r0 = (g0 + g3 + 32) >> 6, r1 = (g1 + g2 + 32) >> 6, r2 = (g1 - g2 + 32) >> 6, r3 = (g0 - g3 + 32) >> 6;
+        dst[j] = (uint8_t)CLIP1(dst[j] + r0); dst[st + j] = (uint8_t)CLIP1(dst[st + j] + r1); dst[2 * st + j] = (uint8_t)CLIP1(dst[2 * st + j] + r2); dst[3 * st + j] = (uint8_t)CLIP1(dst[3 * st + j] + r3); }
+}
+static inline int dequant_ac(int c, int qp, int k) { int ls = 16 * norm4[qp % 6][pos_class(k)]; return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
+
+/* ------------------------------ CAVLC writer -------------------------------- */
+static void put_level_code(BitW *w, int code, int sl) {
+    if (sl == 0) {
+        if (code < 14) { bw_put(w, code, 0); bw_put(w, 1, 1); }
+        else if (code < 30) { bw_put(w, 14, 0); bw_put(w, 1, 1); bw_put(w, 4, code - 14); }
+        else { bw_put(w, 15, 0); bw_put(w, 1, 1); bw_put(w, 12, code - 30); }
+    } else {
+        if (code < (15 << sl)) { bw_put(w, code >> sl, 0); bw_put(w, 1, 1); bw_put(w, sl, code & ((1 << sl) - 1)); }
+        else { bw_put(w, 15, 0); bw_put(w, 1, 1); bw_put(w, 12, code - (15 << sl)); }
+    }
+}
+/* coef: scan-order coefficients; returns total_coeff */
+static int write_block(BitW *w, const int *coef, int max_num, int nC) {
+    int lev[16], pos[16], total = 0;
+    for (int i = max_num - 1; i >= 0; i--) if (coef[i]) { lev[total] = coef[i]; pos[total] = i; total++; }
+    int t1 = 0;
+    while (t1 < total && t1 < 3 && ABS(lev[t1]) == 1) t1++;
+    int idx = 4 * total + t1;
+    if (nC == -1) bw_put(w, cdc_len[idx], cdc_bits[idx]);
+    else { int t = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3; bw_put(w, ct_len[t][idx], ct_bits[t][idx]); }
+    if (!total) return 0;
+    int sl = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1) { bw_put(w, 1, lev[i] < 0); continue; }
+        int code = lev[i] > 0 ? 2 * lev[i] - 2 : -2 * lev[i] - 1;
+        if (i == t1 && t1 < 3) code -= 2;
+        put_level_code(w, code, sl);
+        if (sl == 0) sl = 1;
+        if (ABS(lev[i]) > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    int zeros = pos[0] + 1 - total;
+    if (total < max_num) {
+        if (max_num == 4) bw_put(w, ctz_len[total - 1][zeros], ctz_bits[total - 1][zeros]);
+        else bw_put(w, tz_len[total - 1][zeros], tz_bits[total - 1][zeros]);
+    }
+    int left = zeros;
+    for (int i = 0; i < total - 1 && left > 0; i++) {
+        int run = pos[i] - pos[i + 1] - 1, t = MIN(left, 7) - 1;
+        bw_put(w, rb_len[t][run], rb_bits[t][run]);
+        left -= run;
+    }
+    return total;
+}
+
+/* ------------------------------ MB coding state ------------------------------ */
+typedef struct {
+    int type;                 /* 0 P16x16 1 P16x8 2 P8x16 3 P8x8 4 skip 5 I4x4 6 I16x16 7 PCM */
+    int sub[4];
+    int refs[4];
+    int i16mode, cmode;
+    int i4modes[16];
+    int cbp;
+    int luma[16][16];         /* quantised levels per raster 4x4 block, raster coefficient order */
+    int dc16[16];
+    int cdc[2][4], cac[2][4][16];
+    int dqp;
+} MbCode;
+
+static int nC_luma(Enc *e, int mx, int my, MbE *cur, int bx, int by) {
+    int aA = 0, aB = 0, nA = 0, nB = 0; MbE *m;
+    if (bx > 0) { aA = 1; nA = cur->tc[by * 4 + bx - 1]; } else if ((m = mb_avail(e, mx - 1, my))) { aA = 1; nA = m->tc[by * 4 + 3]; }
+    if (by > 0) { aB = 1; nB = cur->tc[(by - 1) * 4 + bx]; } else if ((m = mb_avail(e, mx, my - 1))) { aB = 1; nB = m->tc[12 + bx]; }
+    return aA && aB ? (nA + nB + 1) >> 1 : aA ? nA : aB ? nB : 0;
+}
+static int nC_chroma(Enc *e, int mx, int my, MbE *cur, int pl, int bx, int by) {
+    int o = 16 + 4 * pl, aA = 0, aB = 0, nA = 0, nB = 0; MbE *m;
+    if (bx > 0) { aA = 1; nA = cur->tc[o + by * 2]; } else if ((m = mb_avail(e, mx - 1, my))) { aA = 1; nA = m->tc[o + by * 2 + 1]; }
+    if (by > 0) { aB = 1; nB = cur->tc[o + bx]; } else if ((m = mb_avail(e, mx, my - 1))) { aB = 1; nB = m->tc[o + 2 + bx]; }
+    return aA && aB ? (nA + nB + 1) >> 1 : aA ? nA : aB ? nB : 0;
+}
+static int chroma_qp_of(Enc *e, int qp) { int q = CLIP3(0, 51, qp + e->p.chroma_qp_off); return q < 30 ? q : qpc_tab[q - 30]; }
+
+/* transform+quantise+reconstruct one luma 4x4 block (pred already in cur frame). returns nonzero count */
+static int code_luma4(Enc *e, int px, int py, int qp, int intra, int *levels /*raster*/) {
+    Frame *c = &e->cur, *s = &e->src; int x[16], w[16], nz = 0;
+    for (int k = 0; k < 16; k++) x[k] = s->y[(py + (k >> 2)) * s->sy + px + (k & 3)] - c->y[(py + (k >> 2)) * c->sy + px + (k & 3)];
+    fdct4(x, w);
+    int shift = 15 + qp / 6, f = (1 << shift) / (intra ? 3 : 6);
+    for (int k = 0; k < 16; k++) { levels[k] = quant1(w[k], quant_mf[qp % 6][pos_class(k)], f, shift); nz += levels[k] != 0; }
+    if (nz) { int dq[16]; for (int k = 0; k < 16; k++) dq[k] = dequant_ac(levels[k], qp, k); idct4_add(dq, c->y + py * c->sy + px, c->sy); }
+    return nz;
+}
+
+/* chroma residual for one plane; pred in cur. fills cdc/cac; returns flags: bit0 dc nonzero, bit1 ac nonzero */
+static int code_chroma(Enc *e, int mx, int my, int pl, int qpc, int intra, MbCode *mc) {
+    Frame *c = &e->cur, *s = &e->src; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8; const uint8_t *sp = (pl ? s->v : s->u) + my * 8 * s->sc + mx * 8;
+    int w[4][16], dcs[4], flags = 0;
+    int shift = 15 + qpc / 6, f = (1 << shift) / (intra ? 3 : 6);
+    for (int k = 0; k < 4; k++) {
+        int x[16]; int ox = (k & 1) * 4, oy = (k >> 1) * 4;
+        for (int i = 0; i < 16; i++) x[i] = sp[(oy + (i >> 2)) * s->sc + ox + (i & 3)] - cp[(oy + (i >> 2)) * c->sc + ox + (i & 3)];
+        fdct4(x, w[k]); dcs[k] = w[k][0];
+        mc->cac[pl][k][0] = 0;
+        for (int i = 1; i < 16; i++) { mc->cac[pl][k][i] = quant1(w[k][i], quant_mf[qpc % 6][pos_class(i)], f, shift); if (mc->cac[pl][k][i]) flags |= 2; }
+    }
+    int h[4] = { dcs[0] + dcs[1] + dcs[2] + dcs[3], dcs[0] - dcs[1] + dcs[2] - dcs[3], dcs[0] + dcs[1] - dcs[2] - dcs[3], dcs[0] - dcs[1] - dcs[2] + dcs[3] };
+    for (int k = 0; k < 4; k++) { mc->cdc[pl][k] = quant1(h[k], quant_mf[qpc % 6][0], 2 * f, shift + 1); if (mc->cdc[pl][k]) flags |= 1; }
+    return flags;
+}
+static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *mc, int use_dc, int use_ac) {
+    Frame *c = &e->cur; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
+    if (!use_dc && !use_ac) return;
+    const int *d = mc->cdc[pl];
+    int f[4] = { d[0] + d[1] + d[2] + d[3], d[0] - d[1] + d[2] - d[3], d[0] + d[1] - d[2] - d[3], d[0] - d[1] - d[2] + d[3] };
+    for (int k = 0; k < 4; k++) {
+        int dq[16];
+        for (int i = 1; i < 16; i++) dq[i] = use_ac ? dequant_ac(mc->cac[pl][k][i], qpc, i) : 0;
+        dq[0] = use_dc ? ((f[k] * 16 * norm4[qpc % 6][0]) << (qpc / 6)) >> 5 : 0;
+        idct4_add(dq, cp + (k >> 1) * 4 * c->sc + (k & 1) * 4, c->sc);
+    }
+}
+
+/* ------------------------------ deblocking (own implementation) --------------- */
+static int edge_bs(const MbE *p, int bp, const MbE *q, int bq, int mbedge) {
+    if (p->intra || q->intra) return mbedge ? 4 : 3;
+    if (p->tc[bp] || q->tc[bq]) return 2;
+    if (p->refid[(bp >> 3) * 2 + ((bp & 3) >> 1)] != q->refid[(bq >> 3) * 2 + ((bq & 3) >> 1)]) return 1;
+    return (ABS(p->mv[bp][0] - q->mv[bq][0]) >= 4 || ABS(p->mv[bp][1] - q->mv[bq][1]) >= 4) ? 1 : 0;
+}
+static void db_luma(uint8_t *q, int s, int bS, int a, int b, int ia) {
+    int p0 = q[-s], p1 = q[-2 * s], p2 = q[-3 * s], q0 = q[0], q1 = q[s], q2 = q[2 * s];
+    if (ABS(p0 - q0) >= a || ABS(p1 - p0) >= b || ABS(q1 - q0) >= b) return;
+    int ap = ABS(p2 - p0) < b, aq = ABS(q2 - q0) < b;
+    if (bS == 4) {
+        int small = ABS(p0 - q0) < (a >> 2) + 2;
+        if (ap && small) { int p3 = q[-4 * s]; q[-s] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3); q[-2 * s] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2); q[-3 * s] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
+        else q[-s] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+        if (aq && small) { int q3 = q[3 * s]; q[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3); q[s] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2); q[2 * s] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3); }
+        else q[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    } else {
+        int t0 = tc0_tab[ia][bS - 1], tc = t0 + ap + aq;
+        int dl = CLIP3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+        q[-s] = (uint8_t)CLIP1(p0 + dl); q[0] = (uint8_t)CLIP1(q0 - dl);
+        if (ap) q[-2 * s] = (uint8_t)(p1 + CLIP3(-t0, t0, (p2 + ((p0 + q0 + 1) >> 1) - 2 * p1) >> 1));
+        if (aq) q[s] = (uint8_t)(q1 + CLIP3(-t0, t0, (q2 + ((p0 + q0 + 1) >> 1) - 2 * q1) >> 1));
+    }
+}
+static void db_chroma(uint8_t *q, int s, int bS, int a, int b, int ia) {
+    int p0 = q[-s], p1 = q[-2 * s], q0 = q[0], q1 = q[s];
+    if (ABS(p0 - q0) >= a || ABS(p1 - p0) >= b || ABS(q1 - q0) >= b) return;
+    if (bS == 4) { q[-s] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2); q[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2); }
+    else { int tc = tc0_tab[ia][bS - 1] + 1, dl = CLIP3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3); q[-s] = (uint8_t)CLIP1(p0 + dl); q[0] = (uint8_t)CLIP1(q0 - dl); }
+}
+static void deblock_frame(Enc *e) {
+    Frame *c = &e->cur;
+    for (int my = 0; my < e->mbh; my++) for (int mx = 0; mx < e->mbw; mx++) {
+        MbE *q = &e->mbs[my * e->mbw + mx];
+        if (q->dis_db == 1) continue;
+        for (int dir = 0; dir < 2; dir++) for (int ed = 0; ed < 4; ed++) {
+            const MbE *p = q;
+            if (ed == 0) { int nx = mx - !dir, ny = my - dir; if (nx < 0 || ny < 0) continue; p = &e->mbs[ny * e->mbw + nx]; if (q->dis_db == 2 && p->slice != q->slice) continue; }
+            int bs[4], any = 0;
+            for (int k = 0; k < 4; k++) { int bq = dir ? ed * 4 + k : k * 4 + ed; int bp = ed ? (dir ? bq - 4 : bq - 1) : (dir ? 12 + k : k * 4 + 3); bs[k] = edge_bs(p, bp, q, bq, ed == 0); any |= bs[k]; }
+            if (!any) continue;
+            int qa = (p->qp + q->qp + 1) >> 1, ia = CLIP3(0, 51, qa + q->a_off), ib = CLIP3(0, 51, qa + q->b_off);
+            for (int i = 0; i < 16; i++) if (bs[i >> 2]) {
+                uint8_t *px = dir ? c->y + (my * 16 + ed * 4) * c->sy + mx * 16 + i : c->y + (my * 16 + i) * c->sy + mx * 16 + ed * 4;
+                db_luma(px, dir ? c->sy : 1, bs[i >> 2], alpha_tab[ia], beta_tab[ib], ia);
+            }
+            if (ed & 1) continue;
+            for (int pl = 0; pl < 2; pl++) {
+                uint8_t *base = pl ? c->v : c->u;
+                int qc = (p->qpc[pl] + q->qpc[pl] + 1) >> 1, ca = CLIP3(0, 51, qc + q->a_off), cb = CLIP3(0, 51, qc + q->b_off);
+                for (int i = 0; i < 8; i++) if (bs[i >> 1]) {
+                    uint8_t *px = dir ? base + (my * 8 + ed * 2) * c->sc + mx * 8 + i : base + (my * 8 + i) * c->sc + mx * 8 + ed * 2;
+                    db_chroma(px, dir ? c->sc : 1, bs[i >> 1], alpha_tab[ca], beta_tab[cb], ca);
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------ macroblock encode ---------------------------- */
+static int sad16_pred(Enc *e, int mx, int my, const int *p) {
+    const Frame *s = &e->src; int sad = 0;
+    for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) sad += ABS(s->y[(my * 16 + y) * s->sy + mx * 16 + x] - p[y * 16 + x]);
+    return sad;
+}
+
+static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) {
+    BitW *w = &e->bw; int sc[16];
+    if (mc->type == 6) {
+        for (int i = 0; i < 16; i++) sc[i] = mc->dc16[zz4[i]];
+        write_block(w, sc, 16, nC_luma(e, mx, my, m, 0, 0));
+    }
+    for (int b8 = 0; b8 < 4; b8++) for (int k = 0; k < 4; k++) {
+        int blk = b8 * 4 + k, bx = bX(blk), by = bY(blk), r = by * 4 + bx;
+        if (!(mc->cbp & (1 << b8))) { m->tc[r] = 0; continue; }
+        int nC = nC_luma(e, mx, my, m, bx, by);
+        if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]]; m->tc[r] = (uint8_t)write_block(w, sc, 15, nC); }
+        else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; m->tc[r] = (uint8_t)write_block(w, sc, 16, nC); }
+    }
+    if (mc->cbp & 0x30) for (int pl = 0; pl < 2; pl++) write_block(w, mc->cdc[pl], 4, -1);
+    for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
+        if (!(mc->cbp & 0x20)) { m->tc[16 + 4 * pl + k] = 0; continue; }
+        for (int i = 0; i < 15; i++) sc[i] = mc->cac[pl][k][zz4[i + 1]];
+        m->tc[16 + 4 * pl + k] = (uint8_t)write_block(w, sc, 15, nC_chroma(e, mx, my, m, pl, k & 1, k >> 1));
+    }
+}
+
+/* Intra4x4 predicted mode (8.3.1.1) */
+static int i4_pred_mode(Enc *e, int mx, int my, MbE *m, int bx, int by) {
+    MbE *mA = bx > 0 ? m : mb_avail(e, mx - 1, my), *mB = by > 0 ? m : mb_avail(e, mx, my - 1);
+    if (!mA || !mB) return 2;
+    if (e->p.cip && (!mA->intra || !mB->intra)) return 2;
+    int a = (mA->intra && !mA->i16 && !mA->pcm) ? (bx > 0 ? m->i4[by * 4 + bx - 1] : mA->i4[by * 4 + 3]) : 2;
+    int b = (mB->intra && !mB->i16 && !mB->pcm) ? (by > 0 ? m->i4[(by - 1) * 4 + bx] : mB->i4[12 + bx]) : 2;
+    return MIN(a, b);
+}
+
+static void mb_init(Enc *e, MbE *m) {
+    memset(m, 0, sizeof *m);
+    m->slice = e->slice_id; for (int i = 0; i < 4; i++) { m->ref[i] = -1; m->refid[i] = -1; }
+    memset(m->i4, 2, 16);
+    m->dis_db = (int8_t)(e->p.deblock == 1 ? 0 : (e->p.deblock == 0 ? 1 : 2)); m->a_off = (int8_t)(2 * e->p.alpha_off); m->b_off = (int8_t)(2 * e->p.beta_off);
+    e->decoded_mask = 0;
+}
+
+/* encode one intra MB (decision + recon + syntax). in P slices mb_type is offset by 5 */
+static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,5 I4,6 I16,7 PCM*/) {
+    Frame *c = &e->cur, *s = &e->src; BitW *w = &e->bw; int fuzz = e->p.mode == 1;
+    int off = e->slice_type == 0 ? 5 : 0;
+    uint8_t *dy = c->y + my * 16 * c->sy + mx * 16;
+    m->intra = 1;
+    if (force == 7) {
+        m->pcm = 1; m->qp = 0; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, 0);
+        bw_ue(w, 25 + off);
+        while (w->nbits) bw_put(w, 1, 0);
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) { int v = s->y[(my * 16 + y) * s->sy + mx * 16 + x]; dy[y * c->sy + x] = (uint8_t)v; bw_put(w, 8, v); }
+        for (int pl = 0; pl < 2; pl++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
+            int v = (pl ? s->v : s->u)[(my * 8 + y) * s->sc + mx * 8 + x]; (pl ? c->v : c->u)[(my * 8 + y) * c->sc + mx * 8 + x] = (uint8_t)v; bw_put(w, 8, v); }
+        memset(m->tc, 16, 24);
+        return;
+    }
+    int aA = intra_ok(e, mb_avail(e, mx - 1, my)), aB = intra_ok(e, mb_avail(e, mx, my - 1)), aD = intra_ok(e, mb_avail(e, mx - 1, my - 1));
+    static MbCode mc; memset(&mc, 0, sizeof mc);
+    /* QP for this MB */
+    int dqp = 0;
+    if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
+    int qp = CLIP3(10, 48, e->qp_run + dqp); dqp = qp - e->qp_run;
+    /* ---- Intra16x16 candidate ---- */
+    int best16 = -1, best16sad = 1 << 30, p16[256];
+    { int cand[4], nc = 0; cand[nc++] = 2; if (aB) cand[nc++] = 0; if (aA) cand[nc++] = 1; if (aA && aB && aD) cand[nc++] = 3;
+      if (fuzz) { best16 = cand[rnd_n(&e->rng, nc)]; }
+      else for (int i = 0; i < nc; i++) { big_predict(dy, c->sy, 16, cand[i], aA, aB, p16); int sd = sad16_pred(e, mx, my, p16); if (sd < best16sad) { best16sad = sd; best16 = cand[i]; } } }
+    /* ---- decide I4x4 vs I16x16 ---- */
+    int use_i4;
+    if (force == 5) use_i4 = 1; else if (force == 6) use_i4 = 0;
+    else if (fuzz) use_i4 = rnd_n(&e->rng, 2);
+    else {   /* estimate I4x4 cost with source neighbours replaced by recon progressively: do a trial encode below and compare SAD */
+        use_i4 = best16sad > 16 * 16 * 3;
+    }
+    int cbp_l = 0;
+    if (use_i4) {
+        mc.type = 5;
+        bw_ue(w, 0 + off);
+        /* choose, reconstruct and remember modes; syntax needs all modes before residual so buffer decisions */
+        for (int blk = 0; blk < 16; blk++) {
+            int bx = bX(blk), by = bY(blk), r = by * 4 + bx, Tb[9], Lb[5], *T = Tb + 1, *L = Lb + 1, a, b, p[16];
+            i4_edges(e, mx, my, blk, T, L, &a, &b);
+            int best = 2, bests = 1 << 30;
+            if (fuzz) { do best = rnd_n(&e->rng, 9); while (!i4_mode_ok(best, a, b)); }
+            else for (int md = 0; md < 9; md++) if (i4_mode_ok(md, a, b)) {
+                i4_predict(md, T, L, a, b, p); int sd = 0;
+                for (int k = 0; k < 16; k++) sd += ABS(s->y[(my * 16 + by * 4 + (k >> 2)) * s->sy + mx * 16 + bx * 4 + (k & 3)] - p[k]);
+                if (sd < bests) { bests = sd; best = md; } }
+            i4_predict(best, T, L, a, b, p);
+            uint8_t *d = dy + by * 4 * c->sy + bx * 4;
+            for (int k = 0; k < 16; k++) d[(k >> 2) * c->sy + (k & 3)] = (uint8_t)p[k];
+            mc.i4modes[r] = best; m->i4[r] = (uint8_t)best;
+            if (code_luma4(e, mx * 16 + bx * 4, my * 16 + by * 4, qp, 1, mc.luma[r])) cbp_l |= 1 << (blk >> 2);
+        }
+        /* blocks in an 8x8 whose cbp bit is clear must have been all-zero: true by construction of cbp_l */
+        for (int blk = 0; blk < 16; blk++) {
+            int bx = bX(blk), by = bY(blk), r = by * 4 + bx, pm = i4_pred_mode(e, mx, my, m, bx, by), md = mc.i4modes[r];
+            /* i4_pred_mode reads m->i4 of already-coded blocks only (left/top), all set above */
+            if (md == pm) bw_put(w, 1, 1); else { bw_put(w, 1, 0); bw_put(w, 3, md < pm ? md : md - 1); }
+        }
+    } else {
+        mc.type = 6; m->i16 = 1; mc.i16mode = best16;
+        big_predict(dy, c->sy, 16, best16, aA, aB, p16);
+        for (int k = 0; k < 256; k++) dy[(k >> 4) * c->sy + (k & 15)] = (uint8_t)p16[k];
+        int dcw[16], any_ac = 0, wblk[16][16];
+        int shift = 15 + qp / 6, f = (1 << shift) / 3;
+        for (int r = 0; r < 16; r++) {
+            int x[16]; int px = mx * 16 + (r & 3) * 4, py = my * 16 + (r >> 2) * 4;
+            for (int k = 0; k < 16; k++) x[k] = s->y[(py + (k >> 2)) * s->sy + px + (k & 3)] - c->y[(py + (k >> 2)) * c->sy + px + (k & 3)];
+            fdct4(x, wblk[r]); dcw[r] = wblk[r][0]; mc.luma[r][0] = 0;
+            for (int k = 1; k < 16; k++) { mc.luma[r][k] = quant1(wblk[r][k], quant_mf[qp % 6][pos_class(k)], f, shift); any_ac |= mc.luma[r][k] != 0; }
+        }
+        /* forward 4x4 Hadamard of the DCs, /2, quantise */
+        int t[16], h[16];
+        for (int i = 0; i < 4; i++) { int *r = dcw + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
+        for (int j = 0; j < 4; j++) { h[j] = (t[j] + t[4 + j] + t[8 + j] + t[12 + j]) >> 1; h[4 + j] = (t[j] + t[4 + j] - t[8 + j] - t[12 + j]) >> 1; h[8 + j] = (t[j] - t[4 + j] - t[8 + j] + t[12 + j]) >> 1; h[12 + j] = (t[j] - t[4 + j] + t[8 + j] - t[12 + j]) >> 1; }
+        for (int k = 0; k < 16; k++) mc.dc16[k] = quant1(h[k], quant_mf[qp % 6][0], 2 * f, shift + 1);
+        if (!any_ac) for (int r = 0; r < 16; r++) for (int k = 1; k < 16; k++) mc.luma[r][k] = 0;
+        cbp_l = any_ac ? 15 : 0;
+        /* reconstruct: inverse Hadamard + scaling of DCs (8.5.10) */
+        int g[16]; const int *cq = mc.dc16;
+        for (int i = 0; i < 4; i++) { const int *r = cq + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
+        for (int j = 0; j < 4; j++) { g[j] = t[j] + t[4 + j] + t[8 + j] + t[12 + j]; g[4 + j] = t[j] + t[4 + j] - t[8 + j] - t[12 + j]; g[8 + j] = t[j] - t[4 + j] - t[8 + j] + t[12 + j]; g[12 + j] = t[j] - t[4 + j] + t[8 + j] - t[12 + j]; }
+        int ls0 = 16 * norm4[qp % 6][0];
+        for (int r = 0; r < 16; r++) {
+            int dq[16];
+            dq[0] = qp >= 36 ? (g[r] * ls0) << (qp / 6 - 6) : (g[r] * ls0 + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+            for (int k = 1; k < 16; k++) dq[k] = dequant_ac(mc.luma[r][k], qp, k);
+            idct4_add(dq, dy + (r >> 2) * 4 * c->sy + (r & 3) * 4, c->sy);
+        }
+    }
+    /* ---- chroma ---- */
+    int cand[4], nc = 0, cmode = 0; cand[nc++] = 0; if (aA) cand[nc++] = 1; if (aB) cand[nc++] = 2; if (aA && aB && aD) cand[nc++] = 3;
+    if (fuzz) cmode = cand[rnd_n(&e->rng, nc)];
+    else { int bests = 1 << 30; for (int i = 0; i < nc; i++) { int sd = 0, pu[64], pv[64], kind = cand[i] == 0 ? 2 : cand[i] == 1 ? 1 : cand[i] == 2 ? 0 : 3;
+            big_predict(c->u + my * 8 * c->sc + mx * 8, c->sc, 8, kind, aA, aB, pu); big_predict(c->v + my * 8 * c->sc + mx * 8, c->sc, 8, kind, aA, aB, pv);
+            for (int k = 0; k < 64; k++) sd += ABS(s->u[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pu[k]) + ABS(s->v[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pv[k]);
+            if (sd < bests) { bests = sd; cmode = cand[i]; } } }
+    int qpc = chroma_qp_of(e, qp), cflags = 0;
+    for (int pl = 0; pl < 2; pl++) { int pc[64], kind = cmode == 0 ? 2 : cmode == 1 ? 1 : cmode == 2 ? 0 : 3; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
+        big_predict(cp, c->sc, 8, kind, aA, aB, pc); for (int k = 0; k < 64; k++) cp[(k >> 3) * c->sc + (k & 7)] = (uint8_t)pc[k]; }
+    for (int pl = 0; pl < 2; pl++) cflags |= code_chroma(e, mx, my, pl, qpc, 1, &mc);
+    int cbp_c = (cflags & 2) ? 2 : (cflags & 1) ? 1 : 0;
+    for (int pl = 0; pl < 2; pl++) recon_chroma(e, mx, my, pl, qpc, &mc, cbp_c >= 1, cbp_c == 2);
+    mc.cbp = cbp_l | (cbp_c << 4); mc.cmode = cmode;
+    /* ---- syntax ---- */
+    if (mc.type == 6) bw_ue(w, off + 1 + mc.i16mode + 4 * cbp_c + (cbp_l ? 12 : 0));
+    bw_ue(w, cmode);
+    if (mc.type == 5) { int code = 0; for (int i = 0; i < 48; i++) if (cbp_intra_tab[i] == mc.cbp) code = i; bw_ue(w, code); }
+    if (mc.cbp > 0 || mc.type == 6) { bw_se(w, dqp); e->qp_run = qp; } else qp = e->qp_run;
+    m->qp = (uint8_t)qp; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, qp);
+    if (mc.cbp > 0 || mc.type == 6) write_mb_residual(e, mx, my, m, &mc);
+    /* note: when cbp==0 for I4x4 we quantised with a QP that is never signalled, but all levels are zero so recon is unaffected */
+}
+
+typedef struct { int mvx, mvy, cost; } MvRes;
+static int mv_bits(int d) { int a = ABS(d) * 2 + 1, n = 0; while (a >> n) n++; return 2 * n - 1; }
+static MvRes search_block(Enc *e, const Frame *r, int px, int py, int w, int h, const int mvp[2], int cx, int cy, int range) {
+    MvRes qbest = { 0, 0, 1 << 30 }; int have_q = 0;
+    MvRes best = { 0, 0, 1 << 30 }; int lambda = 4;
+    if (mv_legal(e, px, py, w, h, mvp[0], mvp[1])) {          /* constant-velocity content: the predictor is usually exact */
+        int c = sad_inter(e, r, px, py, w, h, mvp[0], mvp[1]);
+        if (c < w * h * 5 / 2) { best.mvx = mvp[0]; best.mvy = mvp[1]; best.cost = c; return best; }
+        best.mvx = mvp[0]; best.mvy = mvp[1]; best.cost = c;
+    }
+    int cands[3][2] = { { mvp[0] & ~3, mvp[1] & ~3 }, { 0, 0 }, { cx & ~3, cy & ~3 } };
+    for (int i = 0; i < 3; i++) { int mx = cands[i][0], my = cands[i][1]; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
+        int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; } }
+    if (best.cost == 1 << 30) { best.mvx = best.mvy = 0; best.cost = sad_inter(e, r, px, py, w, h, 0, 0); }
+    best.mvx &= ~3; best.mvy &= ~3; best.cost = sad_inter(e, r, px, py, w, h, best.mvx, best.mvy) + lambda * (mv_bits(best.mvx - mvp[0]) + mv_bits(best.mvy - mvp[1]));
+    { int c = sad_inter(e, r, px, py, w, h, mvp[0], mvp[1]); if (mv_legal(e, px, py, w, h, mvp[0], mvp[1]) && c <= best.cost) { MvRes q = { mvp[0], mvp[1], c }; qbest = q; have_q = 1; } }
+    for (int step = range; step >= 1; step >>= 1) {          /* integer: shrinking-step pattern search */
+        int improved = 1;
+        while (improved) { improved = 0; int bx = best.mvx, by = best.mvy;
+            static const int dx[8] = { -1, 1, 0, 0, -1, 1, -1, 1 }, dy[8] = { 0, 0, -1, 1, -1, -1, 1, 1 };
+            for (int k = 0; k < 8; k++) { int mx = bx + dx[k] * step * 4, my = by + dy[k] * step * 4; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
+                int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; improved = 1; } } }
+    }
+    for (int step = 2; step >= 1; step--) {                  /* half then quarter */
+        int bx = best.mvx, by = best.mvy;
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) { if (!dx && !dy) continue; int mx = bx + dx * step, my = by + dy * step; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
+            int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; } }
+    }
+    if (have_q && qbest.cost <= best.cost) return qbest;
+    return best;
+}
+static void random_mv(Enc *e, int px, int py, int w, int h, const int mvp[2], int out[2]) {
+    for (int tries = 0; tries < 50; tries++) {
+        int k = rnd_n(&e->rng, 10), mx, my;
+        if (k < 4) { mx = mvp[0] + rnd_n(&e->rng, 9) - 4; my = mvp[1] + rnd_n(&e->rng, 9) - 4; }
+        else if (k < 8) { mx = rnd_n(&e->rng, 65) - 32; my = rnd_n(&e->rng, 65) - 32; }
+        else { mx = rnd_n(&e->rng, 4 * 161) - 4 * 80; my = rnd_n(&e->rng, 4 * 161) - 4 * 80; }
+        if (mv_legal(e, px, py, w, h, mx, my)) { out[0] = mx; out[1] = my; return; }
+    }
+    out[0] = out[1] = 0;
+}
+
+static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
+    Frame *c = &e->cur; BitW *w = &e->bw; int fuzz = e->p.mode == 1;
+    int px = mx * 16, py = my * 16, nref = e->nlist0;
+    /* ---- decide intra vs inter ---- */
+    int want_intra = 0, force_intra = -1;
+    if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1; force_intra = 7; } }
+    static MbCode mc; memset(&mc, 0, sizeof mc);
+    int try_skip = fuzz && !want_intra && rnd_n(&e->rng, 8) < 2;
+    int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {0, 0, 0, 0};
+    int mvs[16][2]; memset(mvs, 0, sizeof mvs);
+    int skipmv[2]; skip_mv(e, mx, my, m, skipmv);
+    if (!want_intra) {
+        if (fuzz) {
+            type = rnd_n(&e->rng, 4);
+            for (int i = 0; i < 4; i++) { sub[i] = rnd_n(&e->rng, 4); refs[i] = nref > 1 ? rnd_n(&e->rng, nref) : 0; }
+            if (type == 0) refs[1] = refs[2] = refs[3] = refs[0];
+            else if (type == 1) { refs[1] = refs[0]; refs[3] = refs[2]; }
+            else if (type == 2) { refs[2] = refs[0]; refs[3] = refs[1]; }
+            if (try_skip) { type = 0; refs[0] = refs[1] = refs[2] = refs[3] = 0; }
+        } else {
+            int mvp[2]; pred_mv(e, mx, my, m, 0, 0, 4, 0, 0, 0, mvp);
+            MvRes r16 = search_block(e, e->list0[0], px, py, 16, 16, mvp, skipmv[0], skipmv[1], e->p.search);
+            for (int k = 0; k < 16; k++) { mvs[k][0] = r16.mvx; mvs[k][1] = r16.mvy; }
+            type = 0;
+            if (r16.cost > 16 * 16 * 4) {
+                /* try an 8x8 split around the 16x16 vector */
+                MvRes r8[4]; int tot = 0, c8[2] = { r16.mvx, r16.mvy };
+                for (int i = 0; i < 4; i++) { r8[i] = search_block(e, e->list0[0], px + (i & 1) * 8, py + (i >> 1) * 8, 8, 8, c8, r16.mvx, r16.mvy, 2); tot += r8[i].cost; }
+                if (tot + 16 * 12 < r16.cost) {
+                    int same_h = r8[0].mvx == r8[1].mvx && r8[0].mvy == r8[1].mvy && r8[2].mvx == r8[3].mvx && r8[2].mvy == r8[3].mvy;
+                    int same_v = r8[0].mvx == r8[2].mvx && r8[0].mvy == r8[2].mvy && r8[1].mvx == r8[3].mvx && r8[1].mvy == r8[3].mvy;
+                    type = same_h ? 1 : same_v ? 2 : 3;
+                    for (int i = 0; i < 4; i++) {
+                        int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                        for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r8[i].mvx; mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r8[i].mvy; }
+                        if (type == 3 && r8[i].cost > 8 * 8 * 6) {     /* 4x4 split of a still-poor 8x8 */
+                            int c4[2] = { r8[i].mvx, r8[i].mvy }, t4 = 0; MvRes r4[4];
+                            for (int k = 0; k < 4; k++) { r4[k] = search_block(e, e->list0[0], px + bx * 4 + (k & 1) * 4, py + by * 4 + (k >> 1) * 4, 4, 4, c4, c4[0], c4[1], 1); t4 += r4[k].cost; }
+                            if (t4 + 40 < r8[i].cost) {
+                                int sh = r4[0].mvx == r4[1].mvx && r4[0].mvy == r4[1].mvy && r4[2].mvx == r4[3].mvx && r4[2].mvy == r4[3].mvy;
+                                int sv = r4[0].mvx == r4[2].mvx && r4[0].mvy == r4[2].mvy && r4[1].mvx == r4[3].mvx && r4[1].mvy == r4[3].mvy;
+                                sub[i] = sh ? 1 : sv ? 2 : 3;
+                                for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r4[k].mvx; mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r4[k].mvy; }
+                            }
+                        }
+                    }
+                }
+            }
+            /* intra fallback when inter prediction is poor */
+            int best_cost = 0;
+            for (int k = 0; k < 16; k++) best_cost += sad_inter(e, e->list0[0], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, mvs[k][0], mvs[k][1]);
+            if (best_cost > 16 * 16 * 10) {
+                int aA = intra_ok(e, mb_avail(e, mx - 1, my)), aB = intra_ok(e, mb_avail(e, mx, my - 1)), p16[256];
+                big_predict(c->y + py * c->sy + px, c->sy, 16, 2, aA, aB, p16);
+                if (sad16_pred(e, mx, my, p16) < best_cost) want_intra = 1;
+            }
+        }
+    }
+    if (want_intra) {
+        if (*skip_run >= 0) { bw_ue(w, *skip_run); *skip_run = 0; }
+        encode_intra_mb(e, mx, my, m, force_intra);
+        return;
+    }
+    /* ---- finalise motion: walk partitions in syntax order, computing mvd against the running prediction ---- */
+    int mvd[16][2], nmvd = 0;
+    e->decoded_mask = 0;
+    for (int i = 0; i < 4; i++) m->ref[i] = (int8_t)refs[i];
+    if (type <= 2) {
+        int np = type == 0 ? 1 : 2;
+        for (int p = 0; p < np; p++) {
+            int bx = type == 2 ? p * 2 : 0, by = type == 1 ? p * 2 : 0, bw = type == 2 ? 2 : 4, bh = type == 1 ? 2 : 4;
+            int ref = refs[(by >> 1) * 2 + (bx >> 1)], mvp[2], mv[2];
+            pred_mv(e, mx, my, m, bx, by, bw, ref, type, p, mvp);
+            if (try_skip && mv_legal(e, px, py, 16, 16, skipmv[0], skipmv[1])) { mv[0] = skipmv[0]; mv[1] = skipmv[1]; }
+            else if (fuzz) random_mv(e, px + bx * 4, py + by * 4, bw * 4, bh * 4, mvp, mv); else { mv[0] = mvs[by * 4 + bx][0]; mv[1] = mvs[by * 4 + bx][1]; }
+            mvd[nmvd][0] = mv[0] - mvp[0]; mvd[nmvd][1] = mv[1] - mvp[1]; nmvd++;
+            store_mv(e, m, bx, by, bw, bh, mv[0], mv[1]);
+        }
+    } else {
+        for (int i = 0; i < 4; i++) {
+            int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i], nsp = st == 0 ? 1 : st == 3 ? 4 : 2, bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
+            for (int p = 0; p < nsp; p++) {
+                int bx = ox + (st == 1 ? 0 : st == 2 ? p : (p & 1)), by = oy + (st == 1 ? p : st == 2 ? 0 : (p >> 1)), mvp[2], mv[2];
+                pred_mv(e, mx, my, m, bx, by, bw, refs[i], 0, 0, mvp);
+                if (fuzz) random_mv(e, px + bx * 4, py + by * 4, bw * 4, bh * 4, mvp, mv); else { mv[0] = mvs[by * 4 + bx][0]; mv[1] = mvs[by * 4 + bx][1]; }
+                mvd[nmvd][0] = mv[0] - mvp[0]; mvd[nmvd][1] = mv[1] - mvp[1]; nmvd++;
+                store_mv(e, m, bx, by, bw, bh, mv[0], mv[1]);
+            }
+        }
+    }
+    for (int i = 0; i < 4; i++) m->refid[i] = e->list0[refs[i]]->id;
+    /* ---- prediction + residual ---- */
+    for (int k = 0; k < 16; k++) mc_block(e, e->list0[refs[(k >> 3) * 2 + ((k & 3) >> 1)]], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, m->mv[k][0], m->mv[k][1]);
+    int dqp = 0;
+    if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
+    int qp = CLIP3(10, 48, e->qp_run + dqp); dqp = qp - e->qp_run;
+    int cbp_l = 0;
+    if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    int qpc = chroma_qp_of(e, qp), cflags = 0;
+    if (!try_skip) for (int pl = 0; pl < 2; pl++) cflags |= code_chroma(e, mx, my, pl, qpc, 0, &mc);
+    int cbp_c = (cflags & 2) ? 2 : (cflags & 1) ? 1 : 0;
+    for (int pl = 0; pl < 2; pl++) recon_chroma(e, mx, my, pl, qpc, &mc, cbp_c >= 1, cbp_c == 2);
+    mc.cbp = cbp_l | (cbp_c << 4); mc.type = type;
+    /* ---- P_Skip ---- */
+    if (type == 0 && refs[0] == 0 && mc.cbp == 0 && m->mv[0][0] == skipmv[0] && m->mv[0][1] == skipmv[1] && !(fuzz && rnd_n(&e->rng, 4) == 0)) {
+        m->skip = 1; m->qp = (uint8_t)e->qp_run; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, e->qp_run);
+        (*skip_run)++;
+        return;
+    }
+    bw_ue(w, *skip_run); *skip_run = 0;
+    int p8ref0 = type == 3 && nref > 1 && refs[0] == 0 && refs[1] == 0 && refs[2] == 0 && refs[3] == 0 && (fuzz ? rnd_n(&e->rng, 2) : 1);
+    bw_ue(w, type == 3 && p8ref0 ? 4 : type);
+    if (type <= 2) {
+        int np = type == 0 ? 1 : 2;
+        if (nref > 1) for (int p = 0; p < np; p++) bw_te(w, nref - 1, refs[type == 1 ? p * 2 : p]);
+    } else {
+        for (int i = 0; i < 4; i++) bw_ue(w, sub[i]);
+        if (nref > 1 && !p8ref0) for (int i = 0; i < 4; i++) bw_te(w, nref - 1, refs[i]);
+    }
+    for (int i = 0; i < nmvd; i++) { bw_se(w, mvd[i][0]); bw_se(w, mvd[i][1]); }
+    { int code = 0; for (int i = 0; i < 48; i++) if (cbp_inter_tab[i] == mc.cbp) code = i; bw_ue(w, code); }
+    if (mc.cbp > 0) { bw_se(w, dqp); e->qp_run = qp; } else qp = e->qp_run;
+    m->qp = (uint8_t)qp; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, qp);
+    if (mc.cbp > 0) write_mb_residual(e, mx, my, m, &mc);
+}
+
+/* ------------------------------ headers -------------------------------------- */
+static void write_sps_pps(Enc *e) {
+    BitW *w = &e->bw; GenParams *p = &e->p;
+    w->len = 0; w->nbits = 0; w->cur = 0;
+    bw_put(w, 8, 66); bw_put(w, 8, 0xC0); bw_put(w, 8, p->level_idc);     /* Baseline, constraint_set0/1 */
+    bw_ue(w, 0);
+    bw_ue(w, e->log2_max_fn - 4);
+    bw_ue(w, p->poc_type);
+    if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
+    bw_ue(w, p->num_ref); bw_put(w, 1, 0);
+    bw_ue(w, e->mbw - 1); bw_ue(w, e->mbh - 1);
+    bw_put(w, 1, 1); bw_put(w, 1, 1);                                     /* frame_mbs_only, direct_8x8_inference */
+    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / 2;
+    if (cr || cb) { bw_put(w, 1, 1); bw_ue(w, 0); bw_ue(w, cr); bw_ue(w, 0); bw_ue(w, cb); } else bw_put(w, 1, 0);
+    bw_put(w, 1, 0);                                                      /* no VUI */
+    bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
+    w->len = 0;
+    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, 0); bw_ue(w, 0);
+    bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
+    bw_put(w, 1, 0); bw_put(w, 2, 0);
+    bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
+    bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
+    bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
+}
+
+static void encode_frame(Enc *e, int t) {
+    GenParams *p = &e->p; BitW *w = &e->bw;
+    int idr = (t % p->gop) == 0;
+    int is_ref = idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0);
+    render_source(e, t);
+    if (idr) { e->frame_num = 0; e->nrefs = 0; write_sps_pps(e); }
+    e->slice_type = idr ? 2 : 0;
+    if (!idr && p->mode == 1 && rnd_n(&e->rng, 12) == 0) e->slice_type = 2;   /* occasional non-IDR I picture */
+    /* RefPicList0: short-term refs by descending PicNum == most recent first */
+    e->nlist0 = MIN(e->nrefs, p->num_ref);
+    for (int i = 0; i < e->nlist0; i++) e->list0[i] = &e->refs[i];
+    e->cur.id = e->next_id++;
+    int mbs_total = e->mbw * e->mbh, rows_per = (e->mbh + p->slices - 1) / p->slices;
+    for (int i = 0; i < mbs_total; i++) e->mbs[i].slice = -1;
+    for (int sl = 0, first_row = 0; first_row < e->mbh; sl++, first_row += rows_per) {
+        int last_row = MIN(e->mbh, first_row + rows_per);
+        e->slice_id = sl; e->qp_run = p->qp;
+        w->len = 0; w->nbits = 0; w->cur = 0;
+        bw_ue(w, first_row * e->mbw);
+        bw_ue(w, e->slice_type + ((sl & 1) ? 0 : 5));                     /* alternate slice_type / slice_type+5 spelling */
+        bw_ue(w, 0);
+        bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
+        if (idr) bw_ue(w, e->idr_id & 0xffff);
+        if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (2 * (t % p->gop)) & ((1 << e->poc_lsb_bits) - 1));
+        if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); bw_put(w, 1, 0); }
+        if (is_ref) { if (idr) { bw_put(w, 1, 0); bw_put(w, 1, 0); } else bw_put(w, 1, 0); }
+        bw_se(w, 0);                                                      /* slice_qp_delta */
+        int idc = p->deblock == 1 ? 0 : (p->deblock == 0 ? 1 : 2);
+        bw_ue(w, idc); if (idc != 1) { bw_se(w, p->alpha_off); bw_se(w, p->beta_off); }
+        int skip_run = e->slice_type == 0 ? 0 : -1;
+        for (int my = first_row; my < last_row; my++) for (int mx = 0; mx < e->mbw; mx++) {
+            MbE *m = &e->mbs[my * e->mbw + mx];
+            mb_init(e, m);
+            int before = bw_bitpos(w);
+            if (p->pcm_only) { if (skip_run >= 0) { bw_ue(w, skip_run); skip_run = 0; } encode_intra_mb(e, mx, my, m, 7); }
+            else if (e->slice_type == 2) { int force = -1; if (p->mode == 1 && rnd_n(&e->rng, 40) == 0) force = 7; encode_intra_mb(e, mx, my, m, force); }
+            else encode_p_mb(e, mx, my, m, &skip_run);
+            e->stat_bits_mb[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)] += bw_bitpos(w) - before;
+        }
+        if (skip_run > 0) bw_ue(w, skip_run);
+        bw_trailing(w);
+        out_nal(&e->out, is_ref ? (idr ? 3 : 2) : 0, idr ? 5 : 1, w, sl == 0);
+    }
+    if (p->deblock != 0) deblock_frame(e);
+    if (getenv("H264GEN_STATS")) {
+        double se = 0; int cnt[6] = {0}, nzmv = 0, qmv = 0;
+        for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x]; se += d * d; }
+        for (int i = 0; i < mbs_total; i++) { MbE *m = &e->mbs[i]; cnt[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)]++; if (!m->intra) for (int k = 0; k < 16; k++) { nzmv += m->mv[k][0] || m->mv[k][1]; qmv += (m->mv[k][0] & 3) || (m->mv[k][1] & 3); } }
+        double mse = se / (p->width * p->height);
+        fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t, idr ? 'I' : (e->slice_type == 2 ? 'i' : 'P'), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
+    }
+    if (e->recon) {
+        for (int y = 0; y < p->height; y++) fwrite(e->cur.y + y * e->cur.sy, 1, p->width, e->recon);
+        for (int y = 0; y < p->height / 2; y++) fwrite(e->cur.u + y * e->cur.sc, 1, p->width / 2, e->recon);
+        for (int y = 0; y < p->height / 2; y++) fwrite(e->cur.v + y * e->cur.sc, 1, p->width / 2, e->recon);
+    }
+    if (is_ref) {
+        frame_finish_ref(&e->cur, e->W, e->H);
+        /* sliding window: newest first */
+        Frame tmp = e->refs[p->num_ref - 1 >= 0 ? MIN(e->nrefs, p->num_ref - 1) : 0];
+        int n = MIN(e->nrefs, p->num_ref - 1);
+        Frame last = e->refs[n];
+        for (int i = n; i > 0; i--) e->refs[i] = e->refs[i - 1];
+        e->refs[0] = e->cur; e->cur = last; (void)tmp;
+        e->nrefs = MIN(e->nrefs + 1, p->num_ref);
+        e->frame_num++;
+    }
+    if (idr) e->idr_id++;
+}
+
+/* library entry: returns malloc'ed Annex-B stream */
+int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const char *recon_path) {
+    Enc *e = (Enc *)calloc(1, sizeof(Enc));
+    e->p = *gp;
+    GenParams *p = &e->p;
+    if (p->width < 16 || p->height < 16 || (p->width & 1) || (p->height & 1)) { free(e); return -1; }
+    if (p->gop < 1) p->gop = 30;
+    if (p->num_ref < 1) p->num_ref = 1;
+    if (p->num_ref > 4) p->num_ref = 4;
+    if (p->slices < 1) p->slices = 1;
+    if (p->search < 1) p->search = 4;
+    if (!p->level_idc) p->level_idc = 40;
+    if (p->poc_type != 0) p->poc_type = 2;
+    if (p->nonref_period == 1) p->nonref_period = 2;
+    e->mbw = (p->width + 15) / 16; e->mbh = (p->height + 15) / 16; e->W = e->mbw * 16; e->H = e->mbh * 16;
+    if (p->slices > e->mbh) p->slices = e->mbh;
+    e->log2_max_fn = 4 + (p->seed & 3); e->poc_lsb_bits = 6 + (p->seed & 1) * 2;
+    e->rng.s = (uint64_t)p->seed * 0x9E3779B97F4A7C15ull + 12345;
+    frame_alloc(&e->src, e->W, e->H, 0); frame_alloc(&e->cur, e->W, e->H, 1);
+    for (int i = 0; i < 5; i++) frame_alloc(&e->refs[i], e->W, e->H, 1);
+    e->mbs = (MbE *)calloc((size_t)e->mbw * e->mbh, sizeof(MbE));
+    make_texture(e);
+    if (recon_path) e->recon = fopen(recon_path, "wb");
+    for (int t = 0; t < p->frames; t++) encode_frame(e, t);
+    if (e->recon) fclose(e->recon);
+    *out = e->out.buf; *out_len = e->out.len;
+    frame_free(&e->src); frame_free(&e->cur); for (int i = 0; i < 5; i++) frame_free(&e->refs[i]);
+    free(e->mbs); free(e->bw.buf); free(e);
+    return 0;
+}
+void h264gen_free(void *p) { free(p); }
+
+#ifndef H264GEN_NO_MAIN
+int main(int argc, char **argv) {
+    GenParams p; memset(&p, 0, sizeof p);
+    p.width = 1920; p.height = 1080; p.frames = 30; p.qp = 28; p.gop = 30; p.seed = 0x4A4D0100; p.deblock = 1; p.num_ref = 1; p.slices = 1; p.search = 4;
+    const char *outp = NULL, *recon = NULL;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i]; const char *v = i + 1 < argc ? argv[i + 1] : "0";
+#define OPT(name, field) if (!strcmp(a, name)) { p.field = (int)strtol(v, NULL, 0); i++; continue; }
+        OPT("--width", width) OPT("--height", height) OPT("--frames", frames) OPT("--qp", qp) OPT("--gop", gop) OPT("--seed", seed)
+        OPT("--mode", mode) OPT("--deblock", deblock) OPT("--refs", num_ref) OPT("--slices", slices) OPT("--pcm", pcm_only)
+        OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
+        OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
+        if (!strcmp(a, "-o")) { outp = v; i++; continue; }
+        if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
+        fprintf(stderr, "unknown option %s\n", a); return 2;
+    }
+    if (!outp) { fprintf(stderr, "usage: h264gen [--width W --height H --frames N --qp Q --gop G --seed S --mode 0|1 --deblock 0|1|2 --refs N --slices N --pcm 1 ...] -o out.h264 [--recon recon.yuv]\n"); return 2; }
+    uint8_t *buf; size_t len;
+    if (h264gen_generate(&p, &buf, &len, recon) < 0) { fprintf(stderr, "bad parameters\n"); return 1; }
+    FILE *f = fopen(outp, "wb"); fwrite(buf, 1, len, f); fclose(f);
+    fprintf(stderr, "wrote %zu bytes, %d frames (%.1f kbit/frame)\n", len, p.frames, len * 8.0 / 1000 / p.frames);
+    free(buf);
+    return 0;
+}
+#endif
