@@ -1,0 +1,74 @@
+/*
+ * include/jm_amd_dec.h -- C ABI of the MI355X-native decode backend (libjm_amd_dec.so).
+ *
+ * Every entry point mirrors one function of the reference's public decode API
+ * (/root/reference/nv_dec/jm_nv_dec.h) 1:1 -- same argument order, meaning and
+ * return conventions -- with plain C types so that any FFI can bind it.  The
+ * same library ALSO exports the reference's own C++-mangled jm_nvdec_* symbols
+ * (jmcodec_amd/csrc/jm_nv_dec_api.cpp) so that test_nv_dec.cpp links unchanged.
+ *
+ *   jm_amddec_create_handle   <- jm_nvdec_create_handle   jm_nv_dec.h:27   (nv_dec.cpp:695-698)
+ *   jm_amddec_init            <- jm_nvdec_init            jm_nv_dec.h:39   (nv_dec.cpp:710-713)
+ *   jm_amddec_deinit          <- jm_nvdec_deinit          jm_nv_dec.h:47   (nv_dec.cpp:721-724)
+ *   jm_amddec_decode_frame    <- jm_nvdec_decode_frame    jm_nv_dec.h:58   (nv_dec.cpp:735-739)
+ *   jm_amddec_output_frame    <- jm_nvdec_output_frame    jm_nv_dec.h:68   (nv_dec.cpp:750-828)
+ *   jm_amddec_stream_info     <- jm_nvdec_stream_info     jm_nv_dec.h:79   (nv_dec.cpp:838-845)
+ *   jm_amddec_set_eof         <- jm_nvdec_set_eof         jm_nv_dec.h:82   (nv_dec.cpp:848-851)
+ *   jm_amddec_is_exit         <- jm_nvdec_is_exit         jm_nv_dec.h:84   (nv_dec.cpp:853-856)
+ *   jm_amddec_show_dec_info   <- jm_nvdec_show_dec_info   jm_nv_dec.h:86   (nv_dec.cpp:858-861)
+ *   jm_amddec_is_hw_support   <- jm_nvdec_is_hw_support   jm_nv_dec.h:88   (nv_dec.cpp:863-870)
+ *
+ * Differences from the reference, all deliberate:
+ *   - init/decode_frame return -1 (and log to stderr) when no HIP device can be
+ *     used or the stream is unsupported; the reference returns 0 unconditionally
+ *     (nv_dec.cpp:79,493).  There is no CPU fallback.
+ *   - handles are independent: N handles may be driven from N threads.
+ *   - the device is chosen by JM_AMD_DEC_DEVICE, jm_amddec_set_option("device")
+ *     before init, or round-robin over visible devices (reference: device 0,
+ *     nv_dec.cpp:209).
+ */
+#ifndef JM_AMD_DEC_H
+#define JM_AMD_DEC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *jm_amddec_handle;
+
+jm_amddec_handle jm_amddec_create_handle(void);
+/* codec_type: 0 = H.264 (1 = H.265 reserved); out_fmt: 0 = NV12, 1 = "YV12" = planar Y,U,V */
+int  jm_amddec_init(int codec_type, int out_fmt, char *extra_data, int len, jm_amddec_handle h);
+int  jm_amddec_deinit(jm_amddec_handle h);
+/* in_buf may hold any chunk of an Annex-B stream; (NULL, 0) signals end of stream and then
+ * drains one display-order frame per call.  *got_frame = 1 when a frame is ready. */
+int  jm_amddec_decode_frame(unsigned char *in_buf, int in_data_len, int *got_frame, jm_amddec_handle h);
+/* *out_len: capacity in, bytes out.  Returns the frame size (>0), -1 no frame, -2 buffer too small. */
+int  jm_amddec_output_frame(unsigned char *out_buf, int *out_len, jm_amddec_handle h);
+int  jm_amddec_stream_info(int *disp_width, int *disp_height, jm_amddec_handle h);
+void jm_amddec_set_eof(int is_eof, jm_amddec_handle h);
+int  jm_amddec_is_exit(jm_amddec_handle h);
+char *jm_amddec_show_dec_info(jm_amddec_handle h);
+int  jm_amddec_is_hw_support(void);
+
+/* ---- additions (no reference counterpart) ---- */
+/* keys: "device" (before init), "sync" (1 = every call waits for the pipeline; deterministic),
+ *       "parse_only" (1 = host bitstream stages only, frames carry no pixels; for host-side tests),
+ *       "digest" (1 = accumulate the macroblock syntax digest; implies sync) */
+int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
+/* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
+ *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",
+ *       "threads", "elapsed_us", "display_poc:<n>" */
+long long jm_amddec_get_stat(jm_amddec_handle h, const char *key);
+const char *jm_amddec_last_error(jm_amddec_handle h);
+
+/* Stand-alone pack-out of one pitch-linear NV12 surface that already lives in device memory
+ * (device pointers).  Same semantics as jm_nvdec_output_frame's repack (nv_dec.cpp:782-820).
+ * stream: a hipStream_t or NULL.  Returns 0 or a negative hipError. */
+int  jm_amddec_packout_device(const void *d_src, int pitch, int width, int height, int out_fmt,
+                              void *d_dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+"""ctypes binding of ``include/jm_amd_dec.h`` plus a Python mirror of the reference API.
+
+Mirrors /root/reference/nv_dec/jm_nv_dec.h:27-88 (``jm_nvdec_*``) and the call loop of
+/root/reference/test_nv_dec/test_nv_dec.cpp:163-259.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libjm_amd_dec.so")
+
+
+def build(force=False):
+    """Compile the HIP/C++ sources in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(lib_path()) or _stale():
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+    return lib_path()
+
+
+def _stale():
+    try:
+        t = os.path.getmtime(lib_path())
+        src = os.path.join(_HERE, "csrc")
+        return any(os.path.getmtime(os.path.join(src, f)) > t for f in os.listdir(src))
+    except OSError:
+        return True
+
+
+def lib():
+    """Load libjm_amd_dec.so; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run jmcodec_amd.build() / __graft_entry__.build() first "
+                           "(the HIP backend is mandatory, there is no CPU fallback)")
+    L = C.CDLL(path)
+    vp, cp, ip = C.c_void_p, C.c_char_p, C.POINTER(C.c_int)
+    L.jm_amddec_create_handle.restype = vp
+    L.jm_amddec_init.argtypes = [C.c_int, C.c_int, cp, C.c_int, vp]
+    L.jm_amddec_deinit.argtypes = [vp]
+    L.jm_amddec_decode_frame.argtypes = [vp, C.c_int, ip, vp]
+    L.jm_amddec_output_frame.argtypes = [vp, ip, vp]
+    L.jm_amddec_stream_info.argtypes = [ip, ip, vp]
+    L.jm_amddec_set_eof.argtypes = [C.c_int, vp]
+    L.jm_amddec_set_eof.restype = None
+    L.jm_amddec_is_exit.argtypes = [vp]
+    L.jm_amddec_show_dec_info.argtypes = [vp]
+    L.jm_amddec_show_dec_info.restype = cp
+    L.jm_amddec_set_option.argtypes = [vp, cp, C.c_longlong]
+    L.jm_amddec_get_stat.argtypes = [vp, cp]
+    L.jm_amddec_get_stat.restype = C.c_longlong
+    L.jm_amddec_last_error.argtypes = [vp]
+    L.jm_amddec_last_error.restype = cp
+    L.jm_amddec_packout_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    _LIB = L
+    return L
+
+
+# ---- the reference's ten functions, same names and argument order -------------------------
+def jm_nvdec_is_hw_support():
+    return bool(lib().jm_amddec_is_hw_support())
+
+
+def jm_nvdec_create_handle():
+    return lib().jm_amddec_create_handle()
+
+
+def jm_nvdec_init(codec_type, out_fmt, extra_data, length, handle):
+    return lib().jm_amddec_init(codec_type, out_fmt, extra_data, length, handle)
+
+
+def jm_nvdec_deinit(handle):
+    return lib().jm_amddec_deinit(handle)
+
+
+def jm_nvdec_decode_frame(in_buf, in_data_len, handle):
+    """Returns (ret, got_frame).  in_buf: bytes / ctypes buffer / None."""
+    got = C.c_int(0)
+    if in_buf is None or in_data_len == 0:
+        ret = lib().jm_amddec_decode_frame(None, 0, C.byref(got), handle)
+    else:
+        if isinstance(in_buf, (bytes, bytearray)):
+            in_buf = C.cast(C.c_char_p(bytes(in_buf)), C.c_void_p)
+        ret = lib().jm_amddec_decode_frame(in_buf, in_data_len, C.byref(got), handle)
+    return ret, got.value
+
+
+def jm_nvdec_output_frame(out_buf, out_len, handle):
+    """out_buf: writable ctypes buffer; out_len: its capacity.  Returns (ret, bytes_written)."""
+    n = C.c_int(out_len)
+    ret = lib().jm_amddec_output_frame(C.cast(out_buf, C.c_void_p), C.byref(n), handle)
+    return ret, n.value
+
+
+def jm_nvdec_stream_info(handle):
+    w, h = C.c_int(0), C.c_int(0)
+    lib().jm_amddec_stream_info(C.byref(w), C.byref(h), handle)
+    return w.value, h.value
+
+
+def jm_nvdec_set_eof(is_eof, handle):
+    lib().jm_amddec_set_eof(1 if is_eof else 0, handle)
+
+
+def jm_nvdec_is_exit(handle):
+    return bool(lib().jm_amddec_is_exit(handle))
+
+
+def jm_nvdec_show_dec_info(handle):
+    return lib().jm_amddec_show_dec_info(handle).decode()
+
+
+# ---- the reference harness's NAL scanner (test_nv_dec.cpp:30-86), vectorised -----------------
+def split_nalus(data):
+    """Split an Annex-B buffer into chunks exactly as test_nv_dec's find_nalu does: each chunk
+    starts at a start code (00 00 01 or 00 00 00 01) and runs up to the next one."""
+    import numpy as np
+    a = np.frombuffer(data, dtype=np.uint8)
+    if len(a) < 4:
+        return [bytes(data)]
+    m = (a[:-2] == 0) & (a[1:-1] == 0) & (a[2:] == 1)
+    idx = np.flatnonzero(m)
+    starts = []
+    for i in idx:
+        s = int(i)
+        if s > 0 and a[s - 1] == 0:
+            s -= 1                      # 4-byte start code: find_nalu_prefix matches it one byte earlier
+        if not starts or s > starts[-1]:
+            starts.append(s)
+    out = []
+    for k, s in enumerate(starts):
+        e = starts[k + 1] if k + 1 < len(starts) else len(a)
+        out.append(bytes(data[s:e]))
+    return out
+
+
+class JmAmdDec:
+    """Convenience wrapper reproducing test_nv_dec's main loop (test_nv_dec.cpp:163-259)."""
+
+    def __init__(self, codec_type=0, out_fmt=1, options=None):
+        self.h = jm_nvdec_create_handle()
+        for k, v in (options or {}).items():
+            lib().jm_amddec_set_option(self.h, k.encode(), int(v))
+        rc = jm_nvdec_init(codec_type, out_fmt, None, 0, self.h)
+        if rc != 0:
+            err = lib().jm_amddec_last_error(self.h).decode()
+            jm_nvdec_deinit(self.h)
+            self.h = None
+            raise RuntimeError(f"jm_nvdec_init failed: {err}")
+        self.out_buf = None
+        self.nalu_count = 0
+
+    def stat(self, key):
+        return lib().jm_amddec_get_stat(self.h, key.encode())
+
+    def _pull(self, frames):
+        if self.out_buf is None:
+            w, h = jm_nvdec_stream_info(self.h)
+            self.out_buf = C.create_string_buffer(max(w * h * 3 // 2, 16))
+        ret, n = jm_nvdec_output_frame(self.out_buf, len(self.out_buf), self.h)
+        if n > 0 and frames is not None:
+            frames.append(self.out_buf.raw[:n])
+        return n > 0
+
+    def decode_stream(self, data, keep=True, chunks=None):
+        """Feed one NAL per call, then drain with (NULL, 0) until is_exit.  Returns list of frames
+        (bytes) when keep, else the frame count."""
+        frames = [] if keep else None
+        count = 0
+        for nal in (chunks if chunks is not None else split_nalus(data)):
+            self.nalu_count += 1
+            _, got = jm_nvdec_decode_frame(nal, len(nal), self.h)
+            if got == 1 and self._pull(frames):
+                count += 1
+        while not jm_nvdec_is_exit(self.h):
+            self.nalu_count += 1
+            ret, got = jm_nvdec_decode_frame(None, 0, self.h)
+            if ret != 0:
+                raise RuntimeError(lib().jm_amddec_last_error(self.h).decode())
+            if got == 1 and self._pull(frames):
+                count += 1
+        return frames if keep else count
+
+    def close(self):
+        if self.h:
+            jm_nvdec_deinit(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

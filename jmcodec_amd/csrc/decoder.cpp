@@ -1,0 +1,717 @@
+// jmcodec_amd/csrc/decoder.cpp -- see decoder.h.
+#include "decoder.h"
+#include "kernels.h"
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace jmamd {
+
+#define HIP_OK(expr) ((expr) == hipSuccess)
+
+// =============================================================================================
+// parse worker pool (process wide, one queue)
+// =============================================================================================
+namespace {
+struct Pool {
+    std::mutex m; std::condition_variable cv;
+    std::deque<std::pair<Decoder *, PicTask *>> q;
+    std::vector<std::thread> threads;
+    int n = 0;
+    Pool() {
+        const char *e = getenv("JM_AMD_DEC_THREADS");
+        n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
+        for (int i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+        for (auto &t : threads) t.detach();
+    }
+    void run() {
+        ParseScratch scratch;
+        for (;;) {
+            std::pair<Decoder *, PicTask *> job;
+            { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); job = q.front(); q.pop_front(); }
+            job.first->parse_task(job.second, scratch);
+        }
+    }
+};
+Pool &pool() { static Pool *p = new Pool(); return *p; }   // intentionally leaked: workers outlive static destruction
+std::atomic<int> g_handle_counter{0};
+}  // namespace
+
+void pool_submit(Decoder *d, PicTask *t) { Pool &p = pool(); { std::lock_guard<std::mutex> lk(p.m); p.q.emplace_back(d, t); } p.cv.notify_one(); }
+int pool_threads() { return pool().n; }
+
+// =============================================================================================
+Decoder::Decoder() { memset(info_, 0, sizeof info_); }
+
+Decoder::~Decoder() {
+    // wait until no worker still references this object
+    { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
+    { std::lock_guard<std::mutex> lk(submit_mtx_); }
+    gpu_close();
+}
+
+void Decoder::fail(const std::string &msg) {
+    if (!failed_) { error_ = msg; fprintf(stderr, "jm_amd_dec: %s\n", msg.c_str()); }
+    failed_ = true;
+}
+
+int Decoder::set_option(const char *key, long long v) {
+    std::string k(key);
+    if (k == "parse_only") parse_only_ = v != 0;
+    else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
+    else if (k == "sync") sync_mode_ = v != 0;
+    else if (k == "device") device_ = (int)v;
+    else return -1;
+    return 0;
+}
+long long Decoder::get_stat(const char *key) const {
+    std::string k(key);
+    if (k == "frames") return num_frames_;
+    if (k == "pictures") return stat_pictures_;
+    if (k == "job_bytes") return stat_job_bytes_;
+    if (k == "errors") return stat_errors_;
+    if (k == "intra_mbs") return stat_intra_mbs_;
+    if (k == "coef_int16") return stat_coef_;
+    if (k == "syntax_digest") return (long long)digest_.h;
+    if (k == "digest_mbs") return (long long)digest_.mbs;
+    if (k == "i_pictures") return stat_i_;
+    if (k == "p_pictures") return stat_p_;
+    if (k == "coded_width") return mb_w_ * 16;
+    if (k == "coded_height") return mb_h_ * 16;
+    if (k == "pitch") return pitch_;
+    if (k == "device") return device_;
+    if (k == "threads") return pool_threads();
+    if (k == "elapsed_us") return (long long)(elapsed_ms_ * 1000.0);
+    if (k.rfind("display_poc:", 0) == 0) { size_t i = (size_t)atoll(k.c_str() + 12); return i < display_pocs_.size() ? display_pocs_[i] : -1; }
+    return -1;
+}
+
+// nvdec_decode_init (nv_dec.cpp:62-80): the reference always returns 0; we return <0 when no
+// MI355X-class device can be opened, because silently continuing would mean a CPU fallback.
+int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
+    codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
+    if (codec_type != 0) { fail("only codec_type 0 (H.264) is implemented"); return -1; }
+    if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
+    cavlc_init_tables();
+    if (!parse_only_ && !gpu_open()) return -1;
+    inited_ = true;
+    // optional SPS/PPS given up front (nv_dec.cpp:334-360)
+    if (extra && len > 0) { feed(extra, (size_t)len); static const uint8_t sc[4] = {0, 0, 0, 1}; feed(sc, 4); in_.clear(); scan_ = 0; have_start_ = false; }
+    return 0;
+}
+
+// =============================================================================================
+// device resources
+// =============================================================================================
+bool Decoder::gpu_open() {
+    int n = 0;
+    if (!HIP_OK(hipGetDeviceCount(&n)) || n <= 0) { fail("no HIP device available (the HIP backend is mandatory; there is no CPU fallback)"); return false; }
+    if (device_ < 0) {
+        const char *e = getenv("JM_AMD_DEC_DEVICE");
+        device_ = e ? atoi(e) : (g_handle_counter++ % n);
+    }
+    if (device_ >= n) device_ %= n;
+    if (!HIP_OK(hipSetDevice(device_))) { fail("hipSetDevice failed"); return false; }
+    hipStream_t st;
+    if (!HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) { fail("hipStreamCreate failed"); return false; }
+    stream_ = st;
+    gpu_open_ = true;
+    return true;
+}
+
+void Decoder::gpu_free_sequence() {
+    if (!gpu_open_) return;
+    hipSetDevice(device_);
+    hipStreamSynchronize(stream_);
+    for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+    for (auto &j : jobs_) {
+        if (j.host) hipHostFree(j.host);
+        if (j.dev) hipFree(j.dev);
+        if (j.done) hipEventDestroy(j.done);
+        j = JobSlot();
+    }
+    for (OutSlot *o : all_out_) {
+        if (o->host) hipHostFree(o->host);
+        if (o->dev) hipFree(o->dev);
+        if (o->done) hipEventDestroy(o->done);
+        delete o;
+    }
+    all_out_.clear(); free_out_.clear(); ready_.clear(); cur_out_ = nullptr;
+}
+void Decoder::gpu_close() {
+    if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); for (auto &j : jobs_) { free(j.host); j.host = nullptr; } return; }
+    gpu_free_sequence();
+    hipStreamDestroy(stream_);
+    gpu_open_ = false;
+}
+
+// nvdec_create_decoder (nv_dec.cpp:496-540): surfaces sized by the coded picture, NV12
+bool Decoder::gpu_alloc_sequence() {
+    size_t n_mbs = (size_t)mb_w_ * mb_h_;
+    frame_bytes_ = (size_t)disp_w_ * disp_h_ * 3 / 2;
+    job_cap_ = n_mbs * (sizeof(MbRec) + 816 + 64) + 256 * sizeof(SliceRec) + 4096;
+    if (parse_only_) {
+        for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
+        return true;
+    }
+    hipSetDevice(device_);
+    pitch_ = (mb_w_ * 16 + 127) & ~127;
+    chroma_off_ = pitch_ * mb_h_ * 16;
+    surf_bytes_ = (size_t)pitch_ * mb_h_ * 16 * 3 / 2;
+    for (int i = 0; i < n_surf_; i++) {
+        if (!HIP_OK(hipMalloc((void **)&surf_[i], surf_bytes_))) { fail("hipMalloc(surface) failed"); return false; }
+        hipMemsetAsync(surf_[i], 128, surf_bytes_, stream_);
+    }
+    for (auto &j : jobs_) {
+        if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
+            !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
+        j.cap = job_cap_;
+    }
+    return true;
+}
+
+OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
+    if (!free_out_.empty()) { OutSlot *o = free_out_.back(); free_out_.pop_back(); return o; }
+    OutSlot *o = new OutSlot();
+    if (!parse_only_) {
+        hipSetDevice(device_);
+        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_)) ||
+            !HIP_OK(hipEventCreateWithFlags(&o->done, hipEventDisableTiming))) { fail("output buffer allocation failed"); }
+    }
+    all_out_.push_back(o);
+    return o;
+}
+
+// =============================================================================================
+// front end: Annex-B splitting (replaces the NAL scanning half of cuvidParseVideoData, nv_dec.cpp:394)
+// =============================================================================================
+void Decoder::feed(const uint8_t *buf, size_t len) {
+    in_.insert(in_.end(), buf, buf + len);
+    const uint8_t *p = in_.data();
+    size_t n = in_.size();
+    for (;;) {
+        // find next start code 00 00 01 at or after scan_
+        size_t pos = std::string::npos;
+        for (size_t i = scan_; i + 3 <= n;) {
+            const uint8_t *q = (const uint8_t *)memchr(p + i + 2, 1, n - (i + 2));
+            if (!q) { i = n; break; }
+            size_t k = (size_t)(q - p);
+            if (p[k - 1] == 0 && p[k - 2] == 0) { pos = k - 2; break; }
+            i = k - 1;
+        }
+        if (pos == std::string::npos) { scan_ = n >= 2 ? n - 2 : 0; if (have_start_ && scan_ < nal_start_) scan_ = nal_start_; break; }
+        if (have_start_) {
+            size_t end = pos;
+            while (end > nal_start_ && p[end - 1] == 0) end--;
+            if (end > nal_start_) handle_nal(p + nal_start_, end - nal_start_);
+        }
+        have_start_ = true; nal_start_ = pos + 3; scan_ = pos + 3;
+    }
+    // drop consumed bytes
+    if (have_start_ && nal_start_ > (1u << 16)) {
+        size_t drop = nal_start_ - 3;
+        in_.erase(in_.begin(), in_.begin() + (long)drop);
+        nal_start_ -= drop; scan_ = scan_ > drop ? scan_ - drop : 0;
+        if (scan_ < nal_start_) scan_ = nal_start_;
+    } else if (!have_start_ && in_.size() > 4) {
+        in_.erase(in_.begin(), in_.end() - 3); scan_ = 0;
+    }
+}
+
+// ENDOFSTREAM packet (nv_dec.cpp:389-392)
+void Decoder::flush_stream() {
+    if (have_start_) {
+        size_t end = in_.size();
+        while (end > nal_start_ && in_[end - 1] == 0) end--;
+        if (end > nal_start_) handle_nal(in_.data() + nal_start_, end - nal_start_);
+    }
+    in_.clear(); have_start_ = false; scan_ = 0;
+    dispatch_pending();
+    auto t = std::make_unique<PicTask>();
+    t->out_before = std::move(carry_out_); carry_out_.clear();
+    flush_dpb(t->out_before);
+    push_task(std::move(t));
+}
+
+static bool same_picture(const SliceHeader &a, const SliceHeader &b) {      // 7.4.1.2.4
+    if (a.frame_num != b.frame_num || a.pps_id != b.pps_id) return false;
+    if ((a.nal_ref_idc == 0) != (b.nal_ref_idc == 0)) return false;
+    if (a.poc_lsb != b.poc_lsb || a.delta_poc_bottom != b.delta_poc_bottom) return false;
+    if (a.delta_poc[0] != b.delta_poc[0] || a.delta_poc[1] != b.delta_poc[1]) return false;
+    if (a.idr != b.idr) return false;
+    if (a.idr && a.idr_pic_id != b.idr_pic_id) return false;
+    return true;
+}
+
+void Decoder::handle_nal(const uint8_t *nal, size_t len) {
+    if (failed_ || len < 1 || (nal[0] & 0x80)) return;
+    int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
+    if (type != 1 && type != 5 && type != 7 && type != 8) {
+        if (type == 9 || type == 6 || type == 10 || type == 11) dispatch_pending();
+        return;
+    }
+    std::vector<uint8_t> rbsp(len + Rbsp::kSlack);
+    size_t n = Rbsp::unescape(nal + 1, len - 1, rbsp.data());
+    BitReader br(rbsp.data(), n);
+    if (type == 7 || type == 8) {
+        dispatch_pending();
+        std::string e = type == 7 ? ps_.parse_sps(br) : ps_.parse_pps(br);
+        if (!e.empty()) { stat_errors_++; error_ = e; }
+        return;
+    }
+    SliceHeader sh;
+    std::string e = ps_.parse_slice_header(br, type, ref_idc, sh);
+    if (!e.empty()) { stat_errors_++; error_ = e; return; }
+    const PicParamSet &pps = ps_.pps[sh.pps_id];
+    const SeqParams &sps = ps_.sps[pps.sps_id];
+    if (pending_ && !same_picture(first_sh_, sh)) dispatch_pending();
+    if (!pending_) { if (!start_picture(sh, sps, pps)) return; }
+    add_slice(sh, std::move(rbsp), n);
+}
+
+// =============================================================================================
+// sequence activation, POC, DPB
+// =============================================================================================
+bool Decoder::activate(const SeqParams &sps) {
+    bool changed = !seq_active_ || sps.mb_w != mb_w_ || sps.mb_h != mb_h_;
+    seq_ = sps;
+    dpb_size_ = sps.dpb_frames();
+    // display order == decode order when POC type 2 (8.2.1.3): no bumping delay needed
+    reorder_depth_ = sps.poc_type == 2 ? 0 : (sps.max_num_reorder_frames >= 0 ? sps.max_num_reorder_frames : dpb_size_);
+    if (!changed) return true;
+    if (seq_active_) {
+        // resolution change: drain everything that still refers to the old surfaces
+        auto t = std::make_unique<PicTask>();
+        t->out_before = std::move(carry_out_); carry_out_.clear();
+        push_task(std::move(t));
+        { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
+        fail("resolution change inside a stream is not supported yet");
+        return false;
+    }
+    mb_w_ = sps.mb_w; mb_h_ = sps.mb_h; disp_w_ = sps.disp_w(); disp_h_ = sps.disp_h();
+    n_surf_ = 18;                                  // 16 (max DPB) + current + one spare; also covers later SPSs with a larger DPB
+    for (auto &d : dpb_) d = DpbPic();
+    if (!gpu_alloc_sequence()) return false;
+    seq_active_ = true;
+    if (!timer_started_) { t0_ = std::chrono::steady_clock::now(); timer_started_ = true; }   // nv_dec.cpp:537
+    return true;
+}
+
+int Decoder::compute_poc(const SliceHeader &sh) {                                   // 8.2.1
+    const SeqParams &s = seq_;
+    int max_fn = 1 << s.log2_max_frame_num;
+    if (s.poc_type == 0) {
+        int max_lsb = 1 << s.log2_max_poc_lsb;
+        int prev_msb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_msb_, prev_lsb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_lsb_;
+        int msb = prev_msb;
+        if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+        else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+        if (sh.nal_ref_idc) { prev_poc_msb_ = msb; prev_poc_lsb_ = sh.poc_lsb; }
+        int top = msb + sh.poc_lsb;
+        return std::min(top, top + sh.delta_poc_bottom);
+    }
+    int prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
+    int off = sh.idr ? 0 : (prev_fn > sh.frame_num ? prev_off + max_fn : prev_off);
+    prev_frame_num_offset_ = off;
+    if (s.poc_type == 2) return sh.idr ? 0 : (sh.nal_ref_idc ? 2 * (off + sh.frame_num) : 2 * (off + sh.frame_num) - 1);
+    int abs_fn = s.num_ref_frames_in_poc_cycle ? off + sh.frame_num : 0;
+    if (!sh.nal_ref_idc && abs_fn > 0) abs_fn--;
+    int expected = 0, cycle = 0;
+    for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) cycle += s.offset_for_ref_frame[i];
+    if (abs_fn > 0) {
+        int cnt = (abs_fn - 1) / s.num_ref_frames_in_poc_cycle, in_cycle = (abs_fn - 1) % s.num_ref_frames_in_poc_cycle;
+        expected = cnt * cycle;
+        for (int i = 0; i <= in_cycle; i++) expected += s.offset_for_ref_frame[i];
+    }
+    if (!sh.nal_ref_idc) expected += s.offset_for_non_ref_pic;
+    int top = expected + sh.delta_poc[0];
+    return std::min(top, top + s.offset_for_top_to_bottom + sh.delta_poc[1]);
+}
+
+void Decoder::flush_dpb(std::vector<int> &out) {
+    for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
+        if (best < 0) break;
+        out.push_back(best); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc);
+    }
+    for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
+}
+
+bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const PicParamSet &pps) {
+    if (sh.idr || !seq_active_) {
+        // pfnSequenceCallback moment (nv_dec.cpp:23-30): a new coded video sequence starts.
+        if (seq_active_) flush_dpb(carry_out_);
+        if (!activate(sps)) return false;
+    } else if (sps.mb_w != mb_w_ || sps.mb_h != mb_h_) { stat_errors_++; return false; }
+    int slot = -1;
+    for (int i = 0; i < n_surf_; i++) if (!dpb_[i].in_use) { slot = i; break; }
+    if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
+        int best = -1;
+        for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
+        if (best < 0) { for (int i = 0; i < n_surf_; i++) if (best < 0 || dpb_[i].frame_num_wrap < dpb_[best].frame_num_wrap) best = i; dpb_[best].ref = 0; }
+        else { carry_out_.push_back(best); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false; dpb_[best].ref = 0; }
+        dpb_[best].in_use = false; slot = best; stat_errors_++;
+    }
+    cur_ = slot;
+    DpbPic &c = dpb_[slot];
+    c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
+    c.poc = compute_poc(sh);
+    pending_ = std::make_unique<PicTask>();
+    pending_->has_picture = true; pending_->cur_slot = slot; pending_->sps = sps; pending_->pps = pps;
+    pending_->out_before = std::move(carry_out_); carry_out_.clear();
+    first_sh_ = sh;
+    if (sh.type == SL_I) stat_i_++; else stat_p_++;
+    return true;
+}
+
+// 8.2.4.2.1 + 8.2.4.3: RefPicList0 of a P slice, expressed as surface slots
+void Decoder::build_ref_list(const SliceHeader &sh, int8_t *ref_slot) {
+    memset(ref_slot, -1, 32);
+    if (sh.type == SL_I) return;
+    int max_fn = 1 << seq_.log2_max_frame_num;
+    int st[kMaxSurfaces], lt[kMaxSurfaces], nst = 0, nlt = 0;
+    for (int i = 0; i < n_surf_; i++) {
+        DpbPic &p = dpb_[i];
+        if (!p.in_use || i == cur_) continue;
+        if (p.ref == 1) { p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; st[nst++] = i; }
+        else if (p.ref == 2) lt[nlt++] = i;
+    }
+    std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].pic_num > dpb_[b].pic_num; });
+    std::sort(lt, lt + nlt, [&](int a, int b) { return dpb_[a].lt_idx < dpb_[b].lt_idx; });
+    int list[34]; for (int &v : list) v = -1;
+    int n = 0, nact = sh.num_ref_idx[0];
+    for (int i = 0; i < nst && n < 33; i++) list[n++] = st[i];
+    for (int i = 0; i < nlt && n < 33; i++) list[n++] = lt[i];
+    for (int i = nact; i < 34; i++) list[i] = -1;
+    int pred = sh.frame_num, idx = 0;
+    for (int k = 0; k < sh.n_mod[0]; k++) {
+        const RefMod &m = sh.mod[0][k];
+        int target = -1;
+        if (m.idc < 2) {
+            int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
+            if (nowrap < 0) nowrap += max_fn;
+            if (nowrap >= max_fn) nowrap -= max_fn;
+            pred = nowrap;
+            int pic_num = nowrap > sh.frame_num ? nowrap - max_fn : nowrap;
+            for (int i = 0; i < nst; i++) if (dpb_[st[i]].pic_num == pic_num) target = st[i];
+        } else for (int i = 0; i < nlt; i++) if (dpb_[lt[i]].lt_idx == (int)m.val) target = lt[i];
+        if (target < 0 || idx >= nact) { stat_errors_++; break; }
+        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+        list[idx++] = target;
+        int nidx = idx;
+        for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+    }
+    for (int i = 0; i < nact && i < 32; i++) ref_slot[i] = (int8_t)list[i];
+}
+
+void Decoder::add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size_t rbsp_len) {
+    if (pending_->slices.size() >= 255) { stat_errors_++; return; }
+    pending_->slices.emplace_back();
+    SliceTask &s = pending_->slices.back();
+    s.sh = sh; s.rbsp = std::move(rbsp); s.rbsp_len = rbsp_len;
+    build_ref_list(sh, s.ref_slot);
+}
+
+void Decoder::mark_current(const SliceHeader &sh) {                                 // 8.2.5
+    DpbPic &cur = dpb_[cur_];
+    if (!sh.nal_ref_idc) return;
+    int max_fn = 1 << seq_.log2_max_frame_num;
+    if (sh.idr) {
+        for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
+        if (sh.long_term_reference) { cur.ref = 2; cur.lt_idx = 0; max_lt_idx_ = 0; } else { cur.ref = 1; max_lt_idx_ = -1; }
+        return;
+    }
+    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1) { p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; } }
+    bool made_long = false;
+    if (sh.adaptive_marking) {
+        for (int k = 0; k < sh.n_mark; k++) {
+            const MarkOp &m = sh.mark[k];
+            int pic_num_x = sh.frame_num - (int)(m.a + 1);
+            for (int i = 0; i < n_surf_; i++) {
+                DpbPic &p = dpb_[i];
+                if (!p.in_use || i == cur_) continue;
+                switch (m.op) {
+                case 1: if (p.ref == 1 && p.pic_num == pic_num_x) p.ref = 0; break;
+                case 2: if (p.ref == 2 && p.lt_idx == (int)m.a) p.ref = 0; break;
+                case 3: if (p.ref == 2 && p.lt_idx == (int)m.b) p.ref = 0; break;
+                case 4: if (p.ref == 2 && p.lt_idx > (int)m.a - 1) p.ref = 0; break;
+                case 5: p.ref = 0; break;
+                case 6: if (p.ref == 2 && p.lt_idx == (int)m.b) p.ref = 0; break;
+                }
+            }
+            if (m.op == 3) for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1 && p.pic_num == pic_num_x) { p.ref = 2; p.lt_idx = (int)m.b; } }
+            if (m.op == 4) max_lt_idx_ = (int)m.a - 1;
+            if (m.op == 5) { max_lt_idx_ = -1; cur.mmco5 = true; }
+            if (m.op == 6) { cur.ref = 2; cur.lt_idx = (int)m.b; made_long = true; }
+        }
+    } else {
+        int nst = 0, nlt = 0, oldest = -1;
+        for (int i = 0; i < n_surf_; i++) {
+            DpbPic &p = dpb_[i];
+            if (!p.in_use || i == cur_) continue;
+            if (p.ref == 1) { nst++; if (oldest < 0 || p.frame_num_wrap < dpb_[oldest].frame_num_wrap) oldest = i; }
+            else if (p.ref == 2) nlt++;
+        }
+        if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].ref = 0;
+    }
+    if (!made_long) cur.ref = 1;
+}
+
+// C.4.5.2 / C.4.5.3 with the display delay of the reference replaced by the minimum that keeps
+// display order (the YUV file only records ORDER; nv_dec.cpp:341 ulMaxDisplayDelay=2 only adds latency)
+void Decoder::bump_after_current(std::vector<int> &out) {
+    DpbPic &cur = dpb_[cur_];
+    auto smallest = [&](int exclude) { int b = -1; for (int i = 0; i < n_surf_; i++) if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i; return b; };
+    if (cur.mmco5) { int b; while ((b = smallest(cur_)) >= 0) { out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; } cur.poc = 0; cur.frame_num = 0; }
+    int w = smallest(cur_);
+    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.in_use = false; }
+    else {
+        cur.wait_output = true;
+        for (;;) {
+            int used = 0, waiting = 0;
+            for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use) { if (dpb_[i].ref || dpb_[i].wait_output) used++; if (dpb_[i].wait_output) waiting++; }
+            if (used <= dpb_size_ && waiting <= reorder_depth_) break;
+            int b = smallest(-1);
+            if (b < 0) break;
+            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false;
+        }
+    }
+    for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
+}
+
+void Decoder::dispatch_pending() {
+    if (!pending_) return;
+    std::unique_ptr<PicTask> t = std::move(pending_);
+    mark_current(first_sh_);
+    prev_frame_num_ = dpb_[cur_].frame_num;
+    prev_mmco5_ = dpb_[cur_].mmco5;
+    int poc = dpb_[cur_].poc;
+    (void)poc;
+    bump_after_current(t->out_after);
+    cur_ = -1;
+    t->job_slot = acquire_job_slot();
+    push_task(std::move(t));
+}
+
+int Decoder::acquire_job_slot() {
+    std::unique_lock<std::mutex> lk(mtx_);
+    for (;;) {
+        for (int i = 0; i < kJobSlots; i++) {
+            JobSlot &j = jobs_[i];
+            if (j.busy && j.submitted && (parse_only_ || hipEventQuery(j.done) == hipSuccess)) { j.busy = false; j.submitted = false; }
+            if (!j.busy) { j.busy = true; j.submitted = false; return i; }
+        }
+        // all busy: wait for the device (if something is submitted) or for a worker
+        int sub = -1;
+        for (int i = 0; i < kJobSlots; i++) if (jobs_[i].submitted) { sub = i; break; }
+        if (sub >= 0 && !parse_only_) { hipEvent_t ev = jobs_[sub].done; lk.unlock(); hipSetDevice(device_); hipEventSynchronize(ev); lk.lock(); }
+        else cv_.wait(lk);
+    }
+}
+
+void Decoder::push_task(std::unique_ptr<PicTask> t) {
+    PicTask *raw = t.get();
+    {
+        std::lock_guard<std::mutex> lk(mtx_);
+        raw->seq = next_seq_++;
+        outstanding_++;
+        inflight_.push_back(std::move(t));
+    }
+    if (raw->has_picture) pool_submit(this, raw);
+    else { raw->state.store(1, std::memory_order_release); submit_ready(); }
+}
+
+// =============================================================================================
+// worker: entropy decode one picture into its job buffer
+// =============================================================================================
+void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
+    JobSlot &js = jobs_[t->job_slot];
+    const int n_mbs = t->sps.mb_w * t->sps.mb_h;
+    scratch.resize(t->sps.mb_w, t->sps.mb_h);
+    scratch.begin_picture();
+    // job buffer layout: MbRec[n_mbs] | SliceRec[256] | coef ... | mv_ext (appended after parsing)
+    MbRec *mbs = (MbRec *)js.host;
+    SliceRec *srec = (SliceRec *)(js.host + (size_t)n_mbs * sizeof(MbRec));
+    int16_t *coef = (int16_t *)(srec + 256);
+    static thread_local std::vector<int16_t> mv_ext_buf;
+    mv_ext_buf.resize((size_t)n_mbs * 32);
+    // default record = concealment (grey, not decoded)
+    MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER; blank.ref[0] = blank.ref[1] = blank.ref[2] = blank.ref[3] = -1;
+    for (int i = 0; i < n_mbs; i++) mbs[i] = blank;
+    JobWriter w;
+    w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * 16;
+    w.coef = coef;
+    size_t fixed = (size_t)n_mbs * sizeof(MbRec) + 256 * sizeof(SliceRec);
+    w.coef_cap = (uint32_t)((js.cap - fixed - (size_t)n_mbs * 64) / 2);
+    SyntaxDigest dg = digest_;
+    for (size_t si = 0; si < t->slices.size(); si++) {
+        SliceTask &s = t->slices[si];
+        srec[si].alpha_off = (int8_t)s.sh.alpha_off; srec[si].beta_off = (int8_t)s.sh.beta_off; srec[si].disable = (uint8_t)s.sh.disable_deblock; srec[si].pad = 0;
+        if (s.sh.disable_deblock != 1) t->any_deblock = true;
+        BitReader br(s.rbsp.data(), s.rbsp_len);
+        br.set_end_from_trailing();
+        br.skip_bytes(s.sh.data_bit_offset >> 3); br.skip((int)(s.sh.data_bit_offset & 7));
+        if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
+        SliceParseResult r = parse_slice_cavlc(t->sps, t->pps, s.sh, br, (int)si, s.ref_slot, scratch, w, want_digest_ ? &dg : nullptr);
+        t->n_intra += r.n_intra;
+        if (r.error) { t->error = r.error; stat_errors_++; }
+    }
+    if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)
+    t->n_slices = (int)t->slices.size();
+    // append mv_ext behind the coefficients (4-byte aligned)
+    if (w.coef_count & 1) w.coef[w.coef_count++] = 0;
+    memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
+    t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count;
+    t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
+    stat_pictures_++; stat_job_bytes_ += (long long)t->upload_bytes; stat_intra_mbs_ += t->n_intra; stat_coef_ += w.coef_count;
+    for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
+    t->state.store(1, std::memory_order_release);
+    submit_ready();
+}
+
+// =============================================================================================
+// device submission, strictly in decode order
+// =============================================================================================
+void Decoder::submit_ready() {
+    std::lock_guard<std::mutex> sl(submit_mtx_);
+    for (;;) {
+        PicTask *t = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mtx_);
+            if (inflight_.empty() || inflight_.front()->state.load(std::memory_order_acquire) != 1) break;
+            t = inflight_.front().get();
+        }
+        submit_task(t);
+        {
+            std::lock_guard<std::mutex> lk(mtx_);
+            if (t->job_slot >= 0) jobs_[t->job_slot].submitted = true;
+            inflight_.pop_front();
+            outstanding_--;
+        }
+        cv_.notify_all();
+    }
+}
+
+void Decoder::enqueue_output(int slot) {
+    OutSlot *o;
+    { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); }
+    if (!parse_only_ && !failed_) {
+        launch_packout(surf_[slot], pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, o->dev, stream_);
+        hipMemcpyAsync(o->host, o->dev, frame_bytes_, hipMemcpyDeviceToHost, stream_);
+        hipEventRecord(o->done, stream_);
+        o->has_data = true;
+    }
+    { std::lock_guard<std::mutex> lk(mtx_); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
+}
+
+void Decoder::submit_task(PicTask *t) {
+    if (!parse_only_) hipSetDevice(device_);
+    for (int s : t->out_before) enqueue_output(s);
+    if (t->has_picture && !parse_only_ && !failed_) {
+        JobSlot &js = jobs_[t->job_slot];
+        hipMemcpyAsync(js.dev, js.host, t->upload_bytes, hipMemcpyHostToDevice, stream_);
+        const int n_mbs = t->sps.mb_w * t->sps.mb_h;
+        PicParams pp;
+        memset(&pp, 0, sizeof pp);
+        pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = pitch_; pp.chroma_offset = chroma_off_;
+        pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
+        pp.n_slices = t->n_slices; pp.cur = t->cur_slot;
+        for (int i = 0; i < kMaxSurfaces; i++) pp.surf[i] = surf_[i];
+        pp.mbs = (const MbRec *)js.dev;
+        pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
+        pp.coef = (const int16_t *)(pp.slices + 256);
+        pp.mv_ext = pp.coef + t->coef_count;
+        launch_recon_inter(pp, stream_);
+        if (t->n_intra > 0) launch_recon_intra(pp, stream_);
+        if (t->any_deblock) launch_deblock(pp, stream_);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+        hipEventRecord(js.done, stream_);
+    }
+    for (int s : t->out_after) enqueue_output(s);
+}
+
+// =============================================================================================
+// API-level flow: nvdec_decode_frame (nv_dec.cpp:481-494) = feed packet, then pop <= 1 display frame
+// =============================================================================================
+int Decoder::pop_output(bool block) {
+    std::unique_lock<std::mutex> lk(mtx_);
+    if (cur_out_) { free_out_.push_back(cur_out_); cur_out_ = nullptr; }
+    for (;;) {
+        if (!ready_.empty()) {
+            OutSlot *o = ready_.front();
+            if (o->has_data) {
+                if (block) { lk.unlock(); hipSetDevice(device_); hipEventSynchronize(o->done); lk.lock(); }
+                else if (hipEventQuery(o->done) != hipSuccess) return 0;
+            }
+            ready_.pop_front();
+            cur_out_ = o;
+            return 1;
+        }
+        if (!block || outstanding_ == 0) return 0;
+        cv_.wait(lk);
+    }
+}
+
+int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {
+    *got_frame = 0;
+    if (!inited_ || failed_) return -1;
+    if (!eos_sent_) {                                       // nvdec_decode_packet: ignored once EOS was sent (nv_dec.cpp:374-375)
+        // jm_nvdec_set_eof(true) stops input in the reference without flushing the parser (frames held for
+        // display delay would be stranded); here it is treated as end of stream so that nothing is lost.
+        if (buf && len > 0 && !eof_flag_) feed(buf, (size_t)len);
+        else { eos_sent_ = true; flush_stream(); }
+    }
+    if (failed_) return -1;
+    bool block = eos_sent_ || sync_mode_;
+    if (sync_mode_ && !eos_sent_) { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
+    int got = pop_output(block);
+    *got_frame = got;
+    if (!got && (eos_sent_ || eof_flag_)) {
+        bool drained;
+        { std::lock_guard<std::mutex> lk(mtx_); drained = outstanding_ == 0 && ready_.empty(); }
+        if (drained && eos_sent_ && !is_exit_) {            // nv_dec.cpp:460-466
+            elapsed_ms_ = timer_started_ ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count() : 0.0;
+            is_exit_ = true;
+            snprintf(info_, sizeof info_,
+                     "==========================================\n"
+                     "Codec:\t\t%s\n"
+                     "Display:\t%d x %d\n"
+                     "Pixel Format:\t%s\n"
+                     "Frame Count:\t%d\n"
+                     "Elapsed Time:\t%d ms\n"
+                     "Decode FPS:\t%f fps\n"
+                     "==========================================\n",
+                     codec_ == 0 ? "H.264" : "H.265", disp_w_, disp_h_, out_fmt_ == 0 ? "NV12" : "YV12", (int)num_frames_,
+                     (int)elapsed_ms_, elapsed_ms_ > 0 ? (double)num_frames_ * 1000.0 / elapsed_ms_ : 0.0);
+        }
+    }
+    return 0;
+}
+
+// jm_nvdec_output_frame (nv_dec.cpp:750-828): the pitch strip / de-interleave already happened on the
+// device (k_packout), so what is left of it on the host is one tight memcpy.
+int Decoder::output(uint8_t *out, int *out_len) {
+    if (!cur_out_ || (!cur_out_->has_data && !parse_only_)) return -1;
+    int need = disp_w_ * disp_h_ * 3 / 2;
+    if (*out_len < need) return -2;
+    *out_len = 0;
+    if (cur_out_->has_data) memcpy(out, cur_out_->host, (size_t)need);
+    else memset(out, 0, (size_t)need);
+    *out_len = need;
+    return need;
+}
+
+int Decoder::stream_info(int *w, int *h) const {
+    *w = disp_w_; *h = disp_h_;
+    return 0;
+}
+
+}  // namespace jmamd

@@ -1,0 +1,170 @@
+// jmcodec_amd/csrc/decoder.h -- per-handle decode pipeline behind the jm_nvdec_* API.
+//
+// Re-implements nvdec_ctx and its call flow (/root/reference/nv_dec/nv_dec.h:69-126,
+// nv_dec.cpp:62-80, :368-478, :496-540) without CUVID:
+//   caller thread : Annex-B splitter -> SPS/PPS/slice headers -> POC, DPB, ref lists, display order
+//   worker pool   : CAVLC slice_data() -> macroblock job list in a pinned buffer      (h264_cavlc.cpp)
+//   HIP stream    : H2D job list -> k_recon_inter -> k_recon_intra -> k_deblock -> k_packout -> D2H
+//   caller thread : jm_nvdec_output_frame = one memcpy out of the pinned output slot
+#pragma once
+#include "h264_cavlc.h"
+#include "h264_syntax.h"
+#include "jobs.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct ihipStream_t; struct ihipEvent_t;
+
+namespace jmamd {
+
+constexpr int kJobSlots = 8;
+
+struct DpbPic {
+    bool in_use = false; int ref = 0;          // 0 none, 1 short-term, 2 long-term
+    bool wait_output = false;
+    int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
+    int decode_idx = 0; bool mmco5 = false;
+};
+
+struct SliceTask {
+    SliceHeader sh;
+    std::vector<uint8_t> rbsp;                 // unescaped NAL payload (+ slack)
+    size_t rbsp_len = 0;
+    int8_t ref_slot[32];
+};
+
+struct PicTask {
+    uint64_t seq = 0;
+    bool has_picture = false;
+    int cur_slot = -1, job_slot = -1;
+    SeqParams sps; PicParamSet pps;
+    std::vector<SliceTask> slices;
+    std::vector<int> out_before, out_after;    // DPB slots to display before / after this picture
+    // written by the parse worker
+    std::atomic<int> state{0};                 // 0 queued, 1 parsed
+    int n_intra = 0, n_slices = 0; bool any_deblock = false;
+    uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0;
+    std::string error;
+};
+
+struct JobSlot {
+    uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
+    ihipEvent_t *done = nullptr;
+    bool busy = false, submitted = false;
+};
+struct OutSlot {
+    uint8_t *host = nullptr, *dev = nullptr;
+    ihipEvent_t *done = nullptr;
+    bool has_data = false;
+};
+
+class Decoder {
+public:
+    Decoder();
+    ~Decoder();
+    int  init(int codec_type, int out_fmt, const uint8_t *extra, int len);
+    int  decode(const uint8_t *buf, int len, int *got_frame);
+    int  output(uint8_t *out, int *out_len);
+    int  stream_info(int *w, int *h) const;
+    void set_eof(bool e) { eof_flag_ = e; }
+    bool is_exit() const { return is_exit_; }
+    char *info() { return info_; }
+    const char *last_error() const { return error_.c_str(); }
+    int  set_option(const char *key, long long v);
+    long long get_stat(const char *key) const;
+    void set_device(int d) { device_ = d; }
+
+    // worker-pool entry
+    void parse_task(PicTask *t, ParseScratch &scratch);
+
+private:
+    // ---- front end (caller thread) ----
+    void feed(const uint8_t *buf, size_t len);
+    void flush_stream();
+    void handle_nal(const uint8_t *nal, size_t len);
+    bool start_picture(const SliceHeader &sh, const SeqParams &sps, const PicParamSet &pps);
+    void add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size_t rbsp_len);
+    void dispatch_pending();
+    void build_ref_list(const SliceHeader &sh, int8_t *ref_slot);
+    void mark_current(const SliceHeader &sh);
+    int  compute_poc(const SliceHeader &sh);
+    void bump_after_current(std::vector<int> &out);
+    void flush_dpb(std::vector<int> &out);
+    void push_task(std::unique_ptr<PicTask> t);
+    bool activate(const SeqParams &sps);
+    int  acquire_job_slot();
+    int  pop_output(bool block);
+    void fail(const std::string &msg);
+    // ---- device side ----
+    bool gpu_open();
+    bool gpu_alloc_sequence();
+    void gpu_free_sequence();
+    void gpu_close();
+    void submit_ready();
+    void submit_task(PicTask *t);
+    void enqueue_output(int slot);
+    OutSlot *alloc_out_slot();
+
+    // configuration
+    int codec_ = 0, out_fmt_ = 1, device_ = -1;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false;
+    std::string error_;
+    bool failed_ = false, inited_ = false;
+
+    // splitter
+    std::vector<uint8_t> in_; size_t scan_ = 0; bool have_start_ = false; size_t nal_start_ = 0;
+
+    // parameter sets / sequence
+    ParamSets ps_;
+    bool seq_active_ = false; SeqParams seq_;
+    int mb_w_ = 0, mb_h_ = 0, disp_w_ = 0, disp_h_ = 0, dpb_size_ = 1, reorder_depth_ = 0, n_surf_ = 0;
+
+    // DPB / picture state (front end only)
+    DpbPic dpb_[kMaxSurfaces];
+    int cur_ = -1;
+    std::unique_ptr<PicTask> pending_;
+    SliceHeader first_sh_;
+    int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0, prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;
+    int decode_count_ = 0, max_lt_idx_ = -1;
+    uint64_t next_seq_ = 0;
+    std::vector<int> carry_out_;               // outputs decided before the next picture starts (IDR flush)
+
+    // task pipeline
+    std::mutex mtx_;                           // guards inflight_, job slots, out queue
+    std::condition_variable cv_;
+    std::deque<std::unique_ptr<PicTask>> inflight_;
+    std::mutex submit_mtx_;
+    JobSlot jobs_[kJobSlots];
+    std::deque<OutSlot *> ready_;              // display order
+    std::vector<OutSlot *> free_out_, all_out_;
+    OutSlot *cur_out_ = nullptr;
+    int outstanding_ = 0;                      // tasks pushed and not yet submitted
+
+    // device
+    ihipStream_t *stream_ = nullptr;
+    uint8_t *surf_[kMaxSurfaces] = {nullptr};
+    int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
+    bool gpu_open_ = false;
+
+    // status / stats
+    bool eof_flag_ = false, eos_sent_ = false, is_exit_ = false;
+    uint32_t num_frames_ = 0;
+    std::chrono::steady_clock::time_point t0_; bool timer_started_ = false; double elapsed_ms_ = 0;
+    char info_[1024];
+    std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0};
+    SyntaxDigest digest_;
+    long long stat_i_ = 0, stat_p_ = 0;
+    std::vector<int> display_pocs_;            // diagnostic (get via stats)
+};
+
+// process-wide parse worker pool
+void pool_submit(Decoder *d, PicTask *t);
+int  pool_threads();
+
+}  // namespace jmamd

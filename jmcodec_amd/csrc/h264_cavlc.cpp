@@ -1,0 +1,483 @@
+// jmcodec_amd/csrc/h264_cavlc.cpp -- CAVLC macroblock layer parser producing the device job list.
+// H.264 7.3.4 (slice_data), 7.3.5 (macroblock_layer), 9.2 (CAVLC), 8.3.1.1 (intra mode
+// prediction), 8.4.1 (motion vector prediction).  See h264_cavlc.h for what it replaces.
+#include "h264_cavlc.h"
+#include <mutex>
+
+namespace jmamd {
+
+// ----------------------------------------------------------------------------------------
+// VLC tables: {length, codeword} source arrays (Table 9-5, 9-7..9-10) -> lookup tables
+// ----------------------------------------------------------------------------------------
+static const uint8_t kTokLen[3][68] = {
+{ 1,0,0,0, 6,2,0,0, 8,6,3,0, 9,8,7,5, 10,9,8,6, 11,10,9,7, 13,11,10,8, 13,13,11,9, 13,13,13,10,
+ 14,14,13,11, 14,14,14,13, 15,15,14,14, 15,15,15,14, 16,15,15,15, 16,16,16,15, 16,16,16,16, 16,16,16,16 },
+{ 2,0,0,0, 6,2,0,0, 6,5,3,0, 7,6,6,4, 8,6,6,4, 8,7,7,5, 9,8,8,6, 11,9,9,6, 11,11,11,7,
+ 12,11,11,9, 12,12,12,11, 12,12,12,11, 13,13,13,12, 13,13,13,13, 13,14,13,13, 14,14,14,13, 14,14,14,14 },
+{ 4,0,0,0, 6,4,0,0, 6,5,4,0, 6,5,5,4, 7,5,5,4, 7,5,5,4, 7,6,6,4, 7,6,6,4, 8,7,7,5,
+ 8,8,7,6, 9,8,8,7, 9,9,8,8, 9,9,9,8, 10,9,9,9, 10,10,10,10, 10,10,10,10, 10,10,10,10 } };
+static const uint8_t kTokBits[3][68] = {
+{ 1,0,0,0, 5,1,0,0, 7,4,1,0, 7,6,5,3, 7,6,5,3, 7,6,5,4, 15,6,5,4, 11,14,5,4, 8,10,13,4,
+ 15,14,9,4, 11,10,13,12, 15,14,9,12, 11,10,13,8, 15,1,9,12, 11,14,13,8, 7,10,9,12, 4,6,5,8 },
+{ 3,0,0,0, 11,2,0,0, 7,7,3,0, 7,10,9,5, 7,6,5,4, 4,6,5,6, 7,6,5,8, 15,6,5,4, 11,14,13,4,
+ 15,10,9,4, 11,14,13,12, 8,10,9,8, 15,14,13,12, 11,10,9,12, 7,11,6,8, 9,8,10,1, 7,6,5,4 },
+{ 15,0,0,0, 15,14,0,0, 11,15,13,0, 8,12,14,12, 15,10,11,11, 11,8,9,10, 9,14,13,9, 8,10,9,8, 15,14,13,13,
+ 11,14,10,12, 15,10,13,12, 11,14,9,12, 8,10,13,8, 13,7,9,12, 9,12,11,10, 5,8,7,6, 1,4,3,2 } };
+static const uint8_t kCdcLen[20] = { 2,0,0,0, 6,1,0,0, 6,6,3,0, 6,7,7,6, 6,8,8,7 };
+static const uint8_t kCdcBits[20] = { 1,0,0,0, 7,1,0,0, 4,6,1,0, 3,3,2,5, 2,3,2,0 };
+static const uint8_t kTzLen[15][16] = {
+ {1,3,3,4,4,5,5,6,6,7,7,8,8,9,9,9},{3,3,3,3,3,4,4,4,4,5,5,6,6,6,6,0},{4,3,3,3,4,4,3,3,4,5,5,6,5,6,0,0},
+ {5,3,4,4,3,3,3,4,3,4,5,5,5,0,0,0},{4,4,4,3,3,3,3,3,4,5,4,5,0,0,0,0},{6,5,3,3,3,3,3,3,4,3,6,0,0,0,0,0},
+ {6,5,3,3,3,2,3,4,3,6,0,0,0,0,0,0},{6,4,5,3,2,2,3,3,6,0,0,0,0,0,0,0},{6,6,4,2,2,3,2,5,0,0,0,0,0,0,0,0},
+ {5,5,3,2,2,2,4,0,0,0,0,0,0,0,0,0},{4,4,3,3,1,3,0,0,0,0,0,0,0,0,0,0},{4,4,2,1,3,0,0,0,0,0,0,0,0,0,0,0},
+ {3,3,1,2,0,0,0,0,0,0,0,0,0,0,0,0},{2,2,1,0,0,0,0,0,0,0,0,0,0,0,0,0},{1,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0} };
+static const uint8_t kTzBits[15][16] = {
+ {1,3,2,3,2,3,2,3,2,3,2,3,2,3,2,1},{7,6,5,4,3,5,4,3,2,3,2,3,2,1,0,0},{5,7,6,5,4,3,4,3,2,3,2,1,1,0,0,0},
+ {3,7,5,4,6,5,4,3,3,2,2,1,0,0,0,0},{5,4,3,7,6,5,4,3,2,1,1,0,0,0,0,0},{1,1,7,6,5,4,3,2,1,1,0,0,0,0,0,0},
+ {1,1,5,4,3,3,2,1,1,0,0,0,0,0,0,0},{1,1,1,3,3,2,2,1,0,0,0,0,0,0,0,0},{1,0,1,3,2,1,1,1,0,0,0,0,0,0,0,0},
+ {1,0,1,3,2,1,1,0,0,0,0,0,0,0,0,0},{0,1,1,2,1,3,0,0,0,0,0,0,0,0,0,0},{0,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0},
+ {0,1,1,1,0,0,0,0,0,0,0,0,0,0,0,0},{0,1,1,0,0,0,0,0,0,0,0,0,0,0,0,0},{0,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0} };
+static const uint8_t kCtzLen[3][4] = { {1,2,3,3},{1,2,2,0},{1,1,0,0} };
+static const uint8_t kCtzBits[3][4] = { {1,1,1,0},{1,1,0,0},{1,0,0,0} };
+static const uint8_t kRunLen[6][7] = { {1,1,0,0,0,0,0},{1,2,2,0,0,0,0},{2,2,2,2,0,0,0},{2,2,2,3,3,0,0},{2,2,3,3,3,3,0},{2,3,3,3,3,3,3} };
+static const uint8_t kRunBits[6][7] = { {1,0,0,0,0,0,0},{1,1,0,0,0,0,0},{3,2,1,0,0,0,0},{3,2,1,1,0,0,0},{3,2,3,2,1,0,0},{3,0,1,3,2,5,4} };
+static const uint8_t kCbpIntra[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
+static const uint8_t kCbpInter[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
+static const uint8_t kZigzag4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
+
+// two-level table for coeff_token: primary on the top 8 bits, secondary on the next 8
+struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ; len 0xFF => sym = subtable number
+static TokTable g_tok[3];
+static uint16_t g_tok_flc[64];                        // nC >= 8: 6-bit FLC
+static uint16_t g_cdc[256];                           // chroma DC token, max 8 bits
+static uint16_t g_tz[15][512];                        // total_zeros, max 9 bits
+static uint8_t  g_ctz[3][8];                          // chroma DC total_zeros, max 3 bits: val << 4 | len
+static uint8_t  g_run[6][8];                          // run_before for zerosLeft 1..6: val << 4 | len
+static std::once_flag g_once;
+
+static void build_tok(TokTable &T, const uint8_t *len, const uint8_t *bits) {
+    memset(T.t, 0, sizeof T.t);
+    int nsub = 0;
+    for (int s = 0; s < 68; s++) {
+        int l = len[s]; if (!l) continue;
+        uint32_t code = bits[s];
+        if (l <= 8) {
+            uint32_t base = code << (8 - l);
+            for (uint32_t k = 0; k < (1u << (8 - l)); k++) T.t[base + k] = (uint16_t)(s << 8 | l);
+        } else {
+            uint32_t top = code >> (l - 8);
+            int sub;
+            if ((T.t[top] & 0xff) == 0xff) sub = T.t[top] >> 8;
+            else { sub = ++nsub; T.t[top] = (uint16_t)(sub << 8 | 0xff); }
+            uint32_t low = (code & ((1u << (l - 8)) - 1)) << (16 - l);
+            for (uint32_t k = 0; k < (1u << (16 - l)); k++) T.t[256 * sub + low + k] = (uint16_t)(s << 8 | l);
+        }
+    }
+}
+void cavlc_init_tables() {
+    std::call_once(g_once, [] {
+        for (int i = 0; i < 3; i++) build_tok(g_tok[i], kTokLen[i], kTokBits[i]);
+        // nC >= 8: 0000 11 -> (0,0); else total_coeff = (code >> 2) + 1, trailing_ones = code & 3
+        for (int c = 0; c < 64; c++) { int tc = (c >> 2) + 1, t1 = c & 3; if (c == 3) { tc = 0; t1 = 0; } g_tok_flc[c] = (uint16_t)((4 * tc + t1) << 8 | 6); }
+        memset(g_cdc, 0, sizeof g_cdc);
+        for (int s = 0; s < 20; s++) if (kCdcLen[s]) { int l = kCdcLen[s]; uint32_t b = (uint32_t)kCdcBits[s] << (8 - l); for (uint32_t k = 0; k < (1u << (8 - l)); k++) g_cdc[b + k] = (uint16_t)(s << 8 | l); }
+        memset(g_tz, 0, sizeof g_tz);
+        for (int t = 0; t < 15; t++) for (int z = 0; z < 16 - t; z++) { int l = kTzLen[t][z]; uint32_t b = (uint32_t)kTzBits[t][z] << (9 - l); for (uint32_t k = 0; k < (1u << (9 - l)); k++) g_tz[t][b + k] = (uint16_t)(z << 8 | l); }
+        memset(g_ctz, 0, sizeof g_ctz);
+        for (int t = 0; t < 3; t++) for (int z = 0; z < 4 - t; z++) { int l = kCtzLen[t][z]; uint32_t b = (uint32_t)kCtzBits[t][z] << (3 - l); for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_ctz[t][b + k] = (uint8_t)(z << 4 | l); }
+        memset(g_run, 0, sizeof g_run);
+        for (int t = 0; t < 6; t++) for (int r = 0; r <= t + 1; r++) { int l = kRunLen[t][r]; uint32_t b = (uint32_t)kRunBits[t][r] << (3 - l); for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_run[t][b + k] = (uint8_t)(r << 4 | l); }
+    });
+}
+
+void ParseScratch::resize(int w, int h) {
+    if (w == mb_w && h == mb_h) return;
+    mb_w = w; mb_h = h;
+    size_t n = (size_t)w * h;
+    tc.assign(n * 24, 0); mv.assign(n * 32, 0); refidx.assign(n * 4, -1); i4.assign(n * 16, 2); info.assign(n, 0); slice_of.assign(n, -1);
+}
+void ParseScratch::begin_picture() { std::fill(slice_of.begin(), slice_of.end(), (int16_t)-1); }
+
+// ----------------------------------------------------------------------------------------
+namespace {
+
+struct Canon {                     // canonical per-MB serialisation for SyntaxDigest
+    uint32_t addr; uint8_t kind, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4]; int16_t mv[16][2];
+    int16_t i16dc[16], luma[16][16], cdc[2][4], cac[2][4][16];
+};
+static_assert(sizeof(Canon) == 4 + 4 + 16 + 4 + 64 + 32 + 512 + 16 + 256, "Canon must be packed");
+
+struct P {
+    const SeqParams &sps; const PicParamSet &pps; const SliceHeader &sh;
+    BitReader &br; ParseScratch &cx; JobWriter &out; SyntaxDigest *dg;
+    int slice_num; const int8_t *ref_slot;
+    int mb_w, mb_x = 0, mb_y = 0, addr = 0, qp;
+    // neighbour MB indices or -1
+    int nA = -1, nB = -1, nC = -1, nD = -1;
+    uint8_t *tc; int16_t *mv; int8_t *ref; uint8_t *i4m;
+    uint32_t decoded_mask = 0;
+    Canon *canon = nullptr;
+    const char *err = nullptr;
+
+    void locate(int a) {
+        addr = a; mb_x = a % mb_w; mb_y = a / mb_w;
+        auto av = [&](int x, int y) -> int {
+            if (x < 0 || y < 0 || x >= mb_w || y >= cx.mb_h) return -1;
+            int i = y * mb_w + x; return cx.slice_of[i] == slice_num ? i : -1; };
+        nA = av(mb_x - 1, mb_y); nB = av(mb_x, mb_y - 1); nC = av(mb_x + 1, mb_y - 1); nD = av(mb_x - 1, mb_y - 1);
+        tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16];
+    }
+    bool intra_usable(int n) const { return n >= 0 && (!pps.constrained_intra || (cx.info[n] & 1)); }
+
+    // ---- 9.2.1 -------------------------------------------------------------------------
+    int nc_luma(int bx, int by) const {
+        int a = -1, b = -1;
+        if (bx > 0) a = tc[by * 4 + bx - 1]; else if (nA >= 0) a = cx.tc[(size_t)nA * 24 + by * 4 + 3];
+        if (by > 0) b = tc[(by - 1) * 4 + bx]; else if (nB >= 0) b = cx.tc[(size_t)nB * 24 + 12 + bx];
+        if (a >= 0 && b >= 0) return (a + b + 1) >> 1;
+        return a >= 0 ? a : (b >= 0 ? b : 0);
+    }
+    int nc_chroma(int pl, int bx, int by) const {
+        int o = 16 + 4 * pl, a = -1, b = -1;
+        if (bx > 0) a = tc[o + by * 2]; else if (nA >= 0) a = cx.tc[(size_t)nA * 24 + o + by * 2 + 1];
+        if (by > 0) b = tc[o + bx]; else if (nB >= 0) b = cx.tc[(size_t)nB * 24 + o + 2 + bx];
+        if (a >= 0 && b >= 0) return (a + b + 1) >> 1;
+        return a >= 0 ? a : (b >= 0 ? b : 0);
+    }
+
+    // residual_block_cavlc: levels written at dst[map[scan_pos + first]]; returns total_coeff or -1
+    int residual_block(int nCtx, int max_num, int first, int16_t *dst, const uint8_t *map) {
+        uint32_t e;
+        if (nCtx < 0) { e = g_cdc[br.peek(8)]; }
+        else if (nCtx >= 8) { e = g_tok_flc[br.peek(6)]; }
+        else {
+            const TokTable &T = g_tok[nCtx < 2 ? 0 : (nCtx < 4 ? 1 : 2)];
+            uint32_t v = br.peek(16);
+            e = T.t[v >> 8];
+            if ((e & 0xff) == 0xff) e = T.t[256 * (e >> 8) + (v & 0xff)];
+        }
+        int len = e & 0xff;
+        if (len == 0) return -1;
+        br.skip(len);
+        int total = (int)(e >> 10), t1 = (e >> 8) & 3;
+        if (total == 0) return 0;
+        if (total > max_num) return -1;
+        int level[16];
+        int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+        int i = 0;
+        if (t1) { uint32_t s = br.u(t1); for (; i < t1; i++) level[i] = 1 - 2 * (int)((s >> (t1 - 1 - i)) & 1); }
+        for (; i < total; i++) {
+            uint32_t w = br.peek(32);
+            if (w == 0) return -1;
+            int prefix = __builtin_clz(w);
+            br.skip(prefix + 1);
+            int code = (prefix < 15 ? prefix : 15) << suffix_len;
+            if (suffix_len > 0 || prefix >= 14) {
+                int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+                if (size > 0) code += (int)br.u(size);
+            }
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1 && t1 < 3) code += 2;
+            int lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            level[i] = lv;
+            if (suffix_len == 0) suffix_len = 1;
+            int a = lv < 0 ? -lv : lv;
+            if (a > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+        int zeros_left = 0;
+        if (total < max_num) {
+            if (max_num == 4) { uint8_t z = g_ctz[total - 1][br.peek(3)]; if (!(z & 15)) return -1; br.skip(z & 15); zeros_left = z >> 4; }
+            else { uint16_t z = g_tz[total - 1][br.peek(9)]; if (!(z & 0xff)) return -1; br.skip(z & 0xff); zeros_left = z >> 8; }
+            if (zeros_left + total > max_num) return -1;
+        }
+        int pos = zeros_left + total - 1;                 // scan position of the first (highest) level
+        for (i = 0; i < total; i++) {
+            dst[map[pos + first]] = (int16_t)level[i];
+            if (i == total - 1) break;
+            int run = 0;
+            if (zeros_left > 0) {
+                if (zeros_left <= 6) { uint8_t r = g_run[zeros_left - 1][br.peek(3)]; br.skip(r & 15); run = r >> 4; }
+                else {
+                    uint32_t w3 = br.peek(3);
+                    if (w3) { run = 7 - (int)w3; br.skip(3); }
+                    else { uint32_t w = br.peek(16); if (!w) return -1; int lz = __builtin_clz(w) - 16; run = lz + 4; br.skip(lz + 1); }
+                }
+                if (run > zeros_left) return -1;
+                zeros_left -= run;
+            }
+            pos -= run + 1;
+        }
+        return total;
+    }
+
+    // ---- motion vector prediction (8.4.1.3) ---------------------------------------------
+    struct Nb { bool avail; int ref; int mvx, mvy; };
+    Nb nb(int bx, int by) const {
+        Nb n{false, -1, 0, 0};
+        int m, rx, ry;
+        if (by < 0) { ry = 3; if (bx < 0) { m = nD; rx = 3; } else if (bx > 3) { m = nC; rx = bx - 4; } else { m = nB; rx = bx; } }
+        else if (bx < 0) { m = nA; rx = 3; ry = by; }
+        else if (bx > 3) return n;
+        else { if (!((decoded_mask >> (by * 4 + bx)) & 1)) return n; m = addr; rx = bx; ry = by; }
+        if (m < 0) return n;
+        n.avail = true;
+        n.ref = cx.refidx[(size_t)m * 4 + (ry >> 1) * 2 + (rx >> 1)];
+        if (n.ref >= 0) { const int16_t *q = &cx.mv[(size_t)m * 32 + (ry * 4 + rx) * 2]; n.mvx = q[0]; n.mvy = q[1]; }
+        return n;
+    }
+    static int med(int a, int b, int c) { int mx = a > b ? a : b, mn = a < b ? a : b; return c > mx ? mx : (c < mn ? mn : c); }
+    void predict(int bx, int by, int bw, int refi, int shape, int part, int &px, int &py) const {
+        Nb A = nb(bx - 1, by), B = nb(bx, by - 1), C = nb(bx + bw, by - 1);
+        if (!C.avail) C = nb(bx - 1, by - 1);
+        if (shape == 1) { if (part == 0) { if (B.ref == refi) { px = B.mvx; py = B.mvy; return; } } else if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } }
+        else if (shape == 2) { if (part == 0) { if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } } else if (C.ref == refi) { px = C.mvx; py = C.mvy; return; } }
+        if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
+        int ma = A.ref == refi, mb = B.ref == refi, mc = C.ref == refi;
+        if (ma + mb + mc == 1) { const Nb &n = ma ? A : (mb ? B : C); px = n.mvx; py = n.mvy; }
+        else { px = med(A.mvx, B.mvx, C.mvx); py = med(A.mvy, B.mvy, C.mvy); }
+    }
+    void set_mv(int bx, int by, int bw, int bh, int x, int y) {
+        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mv[(j * 4 + i) * 2] = (int16_t)x; mv[(j * 4 + i) * 2 + 1] = (int16_t)y; decoded_mask |= 1u << (j * 4 + i); }
+    }
+
+    // ---- macroblock start / finish -------------------------------------------------------
+    MbRec *begin_mb() {
+        MbRec *r = &out.mbs[addr];
+        memset(r, 0, sizeof *r);
+        r->flags = MBF_DECODED; r->slice = (uint8_t)slice_num; r->coef_off = out.coef_count;
+        r->ref[0] = r->ref[1] = r->ref[2] = r->ref[3] = -1;
+        cx.slice_of[addr] = (int16_t)slice_num;
+        memset(tc, 0, 24); ref[0] = ref[1] = ref[2] = ref[3] = -1; memset(mv, 0, 64); memset(i4m, 2, 16);
+        cx.info[addr] = 0; decoded_mask = 0;
+        if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; }
+        return r;
+    }
+    void finish_mb(const MbRec *r) {
+        if (!dg) return;
+        canon->kind = r->kind; canon->qp = r->qp;
+        if (r->kind == MB_INTER) { for (int i = 0; i < 4; i++) canon->ref[i] = ref[i]; memcpy(canon->mv, mv, 64); }
+        const uint8_t *p = (const uint8_t *)canon;
+        uint64_t h = dg->h;
+        for (size_t i = 0; i < sizeof(Canon); i++) { h ^= p[i]; h *= 1099511628211ull; }
+        dg->h = h; dg->mbs++;
+    }
+    int16_t *alloc_coef(int n) {
+        if (out.coef_count + (uint32_t)n > out.coef_cap) { err = "coefficient buffer overflow"; return nullptr; }
+        int16_t *p = out.coef + out.coef_count; out.coef_count += n;
+        memset(p, 0, sizeof(int16_t) * n);
+        return p;
+    }
+    void write_motion(MbRec *r, bool sub8) {
+        for (int i = 0; i < 4; i++) r->ref[i] = ref[i] >= 0 ? ref_slot[ref[i]] : (int8_t)-1;
+        if (!sub8) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; r->u.mv[i][0] = mv[b * 2]; r->u.mv[i][1] = mv[b * 2 + 1]; } }
+        else {
+            if (out.mv_ext_count + 16 > out.mv_ext_cap) { err = "mv_ext overflow"; return; }
+            r->flags |= MBF_MV_EXT; r->u.mv_ext = out.mv_ext_count;
+            memcpy(out.mv_ext + (size_t)out.mv_ext_count * 2, mv, 64); out.mv_ext_count += 16;
+        }
+    }
+
+    bool skip_mb() {
+        MbRec *r = begin_mb();
+        r->kind = MB_INTER; r->qp = (uint8_t)qp;
+        int px = 0, py = 0;
+        if (nA >= 0 && nB >= 0) {
+            Nb A = nb(-1, 0), B = nb(0, -1);
+            if (!((A.ref == 0 && !A.mvx && !A.mvy) || (B.ref == 0 && !B.mvx && !B.mvy))) predict(0, 0, 4, 0, 0, 0, px, py);
+        }
+        ref[0] = ref[1] = ref[2] = ref[3] = 0;
+        set_mv(0, 0, 4, 4, px, py);
+        write_motion(r, false);
+        finish_mb(r);
+        return err == nullptr;
+    }
+
+    // residual(): luma + chroma blocks into the coefficient stream
+    bool residual(MbRec *r, int cbp, bool i16) {
+        static const uint8_t ident[16] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15};
+        (void)ident;
+        if (i16) {
+            int16_t *d = alloc_coef(16); if (!d) return false;
+            if (residual_block(nc_luma(0, 0), 16, 0, d, kZigzag4) < 0) { err = "CAVLC error (Intra16x16 DC)"; return false; }
+            if (canon) memcpy(canon->i16dc, d, 32);
+        }
+        uint32_t bits = 0;
+        for (int blk = 0; blk < 16; blk++) {
+            if (!(cbp & (1 << (blk >> 2)))) continue;
+            int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+            // parse into the stream tail; keep the 16 slots only if the block turns out non-empty
+            if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+            int16_t *d = out.coef + out.coef_count;
+            memset(d, 0, 32);
+            int n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
+            if (n < 0) { err = "CAVLC error (luma block)"; return false; }
+            tc[by * 4 + bx] = (uint8_t)n;
+            if (n) { bits |= 1u << blk; out.coef_count += 16; if (canon) memcpy(canon->luma[by * 4 + bx], d, 32); }
+        }
+        r->cbp_blk = (uint16_t)bits;
+        if (cbp & 0x30) {
+            for (int pl = 0; pl < 2; pl++) {
+                if (out.coef_count + 4 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                int16_t *d = out.coef + out.coef_count; memset(d, 0, 8);
+                int n = residual_block(-1, 4, 0, d, ident);
+                if (n < 0) { err = "CAVLC error (chroma DC)"; return false; }
+                if (n) { r->flags |= pl ? MBF_CR_DC : MBF_CB_DC; out.coef_count += 4; if (canon) memcpy(canon->cdc[pl], d, 8); }
+            }
+        }
+        if (cbp & 0x20) {
+            uint32_t cb = 0;
+            for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
+                if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                int16_t *d = out.coef + out.coef_count; memset(d, 0, 32);
+                int n = residual_block(nc_chroma(pl, k & 1, k >> 1), 15, 1, d, kZigzag4);
+                if (n < 0) { err = "CAVLC error (chroma AC)"; return false; }
+                tc[16 + 4 * pl + k] = (uint8_t)n;
+                if (n) { cb |= 1u << (4 * pl + k); out.coef_count += 16; if (canon) memcpy(canon->cac[pl][k], d, 32); }
+            }
+            r->cbp_cac = (uint8_t)cb;
+        }
+        return true;
+    }
+
+    bool macroblock(int &n_intra) {
+        MbRec *r = begin_mb();
+        uint32_t mb_type = br.ue();
+        int itype = -1;
+        if (sh.type == SL_I) itype = (int)mb_type;
+        else if (sh.type == SL_P) { if (mb_type >= 5) itype = (int)mb_type - 5; }
+        else { err = "B slices are not supported yet"; return false; }
+        if (mb_type > 30 || itype > 25) { err = "bad mb_type"; return false; }
+
+        if (itype == 25) {                                     // I_PCM
+            r->kind = MB_PCM; r->qp = 0;
+            br.align_zero();
+            if (br.overrun() || (br.bitpos() >> 3) + 384 > br.size()) { err = "I_PCM runs past the slice"; return false; }
+            int16_t *d = alloc_coef(192); if (!d) return false;
+            memcpy(d, br.byte_ptr(), 384); br.skip_bytes(384);
+            memset(tc, 16, 24); cx.info[addr] = 1;
+            finish_mb(r);
+            return true;
+        }
+        int cbp = 0; bool i16 = false;
+        if (itype >= 0) {
+            cx.info[addr] = 1;
+            if (intra_usable(nA)) r->flags |= MBF_AVAIL_A;
+            if (intra_usable(nB)) r->flags |= MBF_AVAIL_B;
+            if (intra_usable(nC)) r->flags |= MBF_AVAIL_C;
+            if (intra_usable(nD)) r->flags |= MBF_AVAIL_D;
+            n_intra++;
+            if (itype == 0) {
+                r->kind = MB_I4; cx.info[addr] = 3;
+                if (pps.transform8x8 && br.u1()) { err = "Intra8x8 is not supported yet"; return false; }
+                for (int blk = 0; blk < 16; blk++) {
+                    int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+                    int mA = bx > 0 ? addr : nA, mB = by > 0 ? addr : nB, pred;
+                    if (mA < 0 || mB < 0) pred = 2;
+                    else if (pps.constrained_intra && (!(cx.info[mA] & 1) || !(cx.info[mB] & 1))) pred = 2;
+                    else {
+                        int a = bx > 0 ? i4m[by * 4 + bx - 1] : ((cx.info[mA] & 2) ? cx.i4[(size_t)mA * 16 + by * 4 + 3] : 2);
+                        int b = by > 0 ? i4m[(by - 1) * 4 + bx] : ((cx.info[mB] & 2) ? cx.i4[(size_t)mB * 16 + 12 + bx] : 2);
+                        pred = a < b ? a : b;
+                    }
+                    int mode;
+                    if (br.u1()) mode = pred; else { int rem = (int)br.u(3); mode = rem < pred ? rem : rem + 1; }
+                    i4m[by * 4 + bx] = (uint8_t)mode;
+                }
+                for (int k = 0; k < 8; k++) r->u.i4[k] = (uint8_t)(i4m[2 * k] | (i4m[2 * k + 1] << 4));
+                if (canon) memcpy(canon->i4, i4m, 16);
+            } else {
+                r->kind = MB_I16; i16 = true;
+                int k = itype - 1;
+                r->modes = (uint8_t)((k & 3) << 2);
+                cbp = (((k >> 2) % 3) << 4) | (k >= 12 ? 15 : 0);
+                if (canon) canon->i16mode = (uint8_t)(k & 3);
+            }
+            uint32_t cm = br.ue();
+            if (cm > 3) { err = "bad intra_chroma_pred_mode"; return false; }
+            r->modes |= (uint8_t)cm;
+            if (canon) canon->cmode = (uint8_t)cm;
+        } else {
+            r->kind = MB_INTER;
+            int nref = sh.num_ref_idx[0];
+            bool sub8 = false;
+            if (mb_type <= 2) {
+                int np = mb_type == 0 ? 1 : 2, rf[2] = {0, 0};
+                if (nref > 1) for (int p = 0; p < np; p++) { rf[p] = br.te(nref - 1); if (rf[p] >= nref) { err = "ref_idx out of range"; return false; } }
+                for (int p = 0; p < np; p++) {
+                    int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0, bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
+                    for (int j = by; j < by + bh; j += 2) for (int i = bx; i < bx + bw; i += 2) ref[(j >> 1) * 2 + (i >> 1)] = (int8_t)rf[p];
+                    int px, py; predict(bx, by, bw, rf[p], (int)mb_type, p, px, py);
+                    int mx = px + br.se(), my = py + br.se();
+                    set_mv(bx, by, bw, bh, mx, my);
+                }
+            } else {
+                int sub[4], rf[4] = {0, 0, 0, 0};
+                for (int i = 0; i < 4; i++) { sub[i] = (int)br.ue(); if (sub[i] > 3) { err = "bad sub_mb_type"; return false; } if (sub[i]) sub8 = true; }
+                if (nref > 1 && mb_type != 4) for (int i = 0; i < 4; i++) { rf[i] = br.te(nref - 1); if (rf[i] >= nref) { err = "ref_idx out of range"; return false; } }
+                for (int i = 0; i < 4; i++) ref[i] = (int8_t)rf[i];
+                for (int i = 0; i < 4; i++) {
+                    int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i];
+                    int nsp = st == 0 ? 1 : (st == 3 ? 4 : 2), bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
+                    for (int p = 0; p < nsp; p++) {
+                        int bx = ox + (st == 1 ? 0 : (st == 2 ? p : (p & 1))), by = oy + (st == 1 ? p : (st == 2 ? 0 : (p >> 1)));
+                        int px, py; predict(bx, by, bw, rf[i], 0, 0, px, py);
+                        int mx = px + br.se(), my = py + br.se();
+                        set_mv(bx, by, bw, bh, mx, my);
+                    }
+                }
+            }
+            write_motion(r, sub8);
+            if (err) return false;
+        }
+        if (!i16) {
+            uint32_t code = br.ue();
+            if (code > 47) { err = "bad coded_block_pattern"; return false; }
+            cbp = itype >= 0 ? kCbpIntra[code] : kCbpInter[code];
+            if ((cbp & 15) && pps.transform8x8 && itype < 0) { err = "8x8 transform is not supported yet"; return false; }
+        }
+        if (cbp > 0 || i16) {
+            int dqp = br.se();
+            if (dqp < -26 || dqp > 25) { err = "mb_qp_delta out of range"; return false; }
+            qp = (qp + dqp + 52) % 52;
+        }
+        r->qp = (uint8_t)qp;
+        if (cbp > 0 || i16) { if (!residual(r, cbp, i16)) return false; }
+        if (br.overrun()) { err = "macroblock data truncated"; return false; }
+        finish_mb(r);
+        return true;
+    }
+};
+
+}  // namespace
+
+SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
+                                   BitReader &br, int slice_num, const int8_t *ref_slot,
+                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest) {
+    cavlc_init_tables();
+    SliceParseResult res;
+    Canon canon;
+    P p{sps, pps, sh, br, cx, out, digest, slice_num, ref_slot, sps.mb_w};
+    p.qp = sh.qp;
+    p.canon = digest ? &canon : nullptr;
+    int n_mbs = sps.mb_w * sps.mb_h, addr = sh.first_mb;
+    if (pps.cabac) { res.error = "CABAC is not supported yet"; return res; }
+    bool more = true;
+    while (more) {
+        if (sh.type != SL_I) {
+            uint32_t run = br.ue();
+            if (br.overrun() || run > (uint32_t)(n_mbs - addr)) { res.error = "bad mb_skip_run"; return res; }
+            for (uint32_t i = 0; i < run; i++) { p.locate(addr); if (!p.skip_mb()) { res.error = p.err; return res; } addr++; res.mbs_decoded++; }
+            if (run > 0) more = br.more_rbsp_data();
+            if (!more) break;
+        }
+        if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; return res; }
+        p.locate(addr);
+        if (!p.macroblock(res.n_intra)) { res.error = p.err ? p.err : "macroblock error"; return res; }
+        addr++; res.mbs_decoded++;
+        more = br.more_rbsp_data();
+    }
+    return res;
+}
+
+}  // namespace jmamd

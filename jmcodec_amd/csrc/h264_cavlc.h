@@ -1,0 +1,51 @@
+// jmcodec_amd/csrc/h264_cavlc.h -- host entropy stage: CAVLC slice_data() -> macroblock job list.
+//
+// This is the "entropy decode stays on the host and feeds a per-macroblock job
+// list" half of the replacement for cuvidDecodePicture
+// (/root/reference/nv_dec/nv_dec.cpp:33-41).  No pixel is touched here.
+#pragma once
+#include "h264_syntax.h"
+#include "jobs.h"
+#include <vector>
+
+namespace jmamd {
+
+// Destination of one picture's job list (pointers into a pinned JobBuffer).
+struct JobWriter {
+    MbRec   *mbs = nullptr;
+    int16_t *mv_ext = nullptr;  uint32_t mv_ext_count = 0, mv_ext_cap = 0;   // in MVs (int16 pairs)
+    int16_t *coef = nullptr;    uint32_t coef_count = 0, coef_cap = 0;       // in int16
+};
+
+// Per-worker scratch: neighbour context of the picture being parsed.
+struct ParseScratch {
+    int mb_w = 0, mb_h = 0;
+    std::vector<uint8_t> tc;       // [mb][24] total_coeff per 4x4 (16 luma raster, 4 Cb, 4 Cr)
+    std::vector<int16_t> mv;       // [mb][16][2]
+    std::vector<int8_t>  refidx;   // [mb][4]
+    std::vector<uint8_t> i4;       // [mb][16] Intra4x4PredMode (2 when not I4x4)
+    std::vector<uint8_t> info;     // [mb] bit0 intra, bit1 Intra4x4
+    std::vector<int16_t> slice_of; // [mb] slice number or -1
+    void resize(int w, int h);
+    void begin_picture();
+};
+
+// Optional syntax digest (tests): FNV-1a over a canonical serialisation of every macroblock,
+// comparable with the CPU oracle's digest of the same stream (tests/test_host_parser.py).
+struct SyntaxDigest { uint64_t h = 1469598103934665603ull; uint64_t mbs = 0; };
+
+struct SliceParseResult {
+    int mbs_decoded = 0;
+    int n_intra = 0;            // I4x4 + I16x16 macroblocks (need the wavefront kernel)
+    const char *error = nullptr;
+};
+
+// Parses slice_data() of one slice.  br must be positioned at sh.data_bit_offset with
+// set_end_from_trailing() already called.  ref_slot[i] = DPB surface slot of RefPicList0[i].
+SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
+                                   BitReader &br, int slice_num, const int8_t *ref_slot,
+                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest);
+
+void cavlc_init_tables();   // idempotent, thread-safe
+
+}  // namespace jmamd

@@ -1,0 +1,231 @@
+// jmcodec_amd/csrc/h264_syntax.cpp -- see h264_syntax.h.
+#include "h264_syntax.h"
+
+namespace jmamd {
+
+static const uint8_t kDef4Intra[16] = {6,13,13,20,20,20,28,28,28,28,32,32,32,37,37,42};
+static const uint8_t kDef4Inter[16] = {10,14,14,20,20,20,24,24,24,24,27,27,27,30,30,34};
+static const uint8_t kDef8Intra[64] = {
+  6,10,10,13,11,13,16,16,16,16,18,18,18,18,18,23,23,23,23,23,23,25,25,25,25,25,25,25,27,27,27,27,
+  27,27,27,27,29,29,29,29,29,29,29,31,31,31,31,31,31,33,33,33,33,33,36,36,36,36,38,38,38,40,40,42};
+static const uint8_t kDef8Inter[64] = {
+  9,13,13,15,13,15,17,17,17,17,19,19,19,19,19,21,21,21,21,21,21,22,22,22,22,22,22,22,24,24,24,24,
+  24,24,24,24,25,25,25,25,25,25,25,27,27,27,27,27,27,28,28,28,28,28,30,30,30,30,32,32,32,33,33,35};
+
+static bool read_scaling_list(BitReader &br, uint8_t *dst, int n) {   // returns useDefaultScalingMatrixFlag
+    int last = 8, next = 8; bool use_default = false;
+    for (int j = 0; j < n; j++) {
+        if (next) { next = (last + br.se() + 256) & 255; if (j == 0 && next == 0) use_default = true; }
+        dst[j] = (uint8_t)(next ? next : last);
+        last = dst[j];
+    }
+    return use_default;
+}
+static void read_scaling_matrix(BitReader &br, uint8_t s4[6][16], uint8_t s8[2][64], int count,
+                                const uint8_t (*fb4)[16], const uint8_t (*fb8)[64]) {
+    for (int i = 0; i < count; i++) {
+        bool present = br.u1();
+        if (i < 6) {
+            const uint8_t *dflt = i < 3 ? kDef4Intra : kDef4Inter;
+            if (present) { if (read_scaling_list(br, s4[i], 16)) memcpy(s4[i], dflt, 16); }
+            else if (i == 0 || i == 3) memcpy(s4[i], fb4 ? fb4[i] : dflt, 16);
+            else memcpy(s4[i], s4[i - 1], 16);
+        } else {
+            int k = i - 6; const uint8_t *dflt = k ? kDef8Inter : kDef8Intra;
+            if (k > 1) { if (present) { uint8_t tmp[64]; read_scaling_list(br, tmp, 64); } continue; }
+            if (present) { if (read_scaling_list(br, s8[k], 64)) memcpy(s8[k], dflt, 64); }
+            else memcpy(s8[k], fb8 ? fb8[k] : dflt, 64);
+        }
+    }
+}
+
+int SeqParams::dpb_frames() const {
+    int mbs;
+    switch (level_idc) {
+    case 9: case 10: mbs = 396; break;
+    case 11: mbs = (constraint_flags & 0x10) ? 396 : 900; break;
+    case 12: case 13: case 20: mbs = 2376; break;
+    case 21: mbs = 4752; break;
+    case 22: case 30: mbs = 8100; break;
+    case 31: mbs = 18000; break;
+    case 32: mbs = 20480; break;
+    case 40: case 41: mbs = 32768; break;
+    case 42: mbs = 34816; break;
+    case 50: mbs = 110400; break;
+    default: mbs = 184320; break;
+    }
+    int n = mbs / (mb_w * mb_h);
+    if (n > 16) n = 16;
+    if (max_dec_frame_buffering >= 0) n = max_dec_frame_buffering;
+    if (n < max_num_ref_frames) n = max_num_ref_frames;
+    if (n < 1) n = 1;
+    if (n > 16) n = 16;
+    return n;
+}
+
+static void skip_hrd(BitReader &br) {
+    int n = (int)br.ue() + 1;
+    br.u(4); br.u(4);
+    for (int i = 0; i < n && !br.overrun(); i++) { br.ue(); br.ue(); br.u1(); }
+    br.u(5); br.u(5); br.u(5); br.u(5);
+}
+
+std::string ParamSets::parse_sps(BitReader &br) {
+    SeqParams s;
+    memset(s.scaling4, 16, sizeof s.scaling4); memset(s.scaling8, 16, sizeof s.scaling8);
+    s.profile_idc = br.u(8); s.constraint_flags = br.u(8); s.level_idc = br.u(8);
+    s.id = br.ue();
+    if (s.id > 31) return "sps id out of range";
+    switch (s.profile_idc) {
+    case 100: case 110: case 122: case 244: case 44: case 83: case 86: case 118: case 128: case 138: case 139: case 134: case 135:
+        s.chroma_format_idc = br.ue();
+        if (s.chroma_format_idc == 3) br.u1();
+        s.bit_depth_luma = 8 + br.ue(); s.bit_depth_chroma = 8 + br.ue();
+        br.u1();
+        s.scaling_matrix_present = br.u1();
+        if (s.scaling_matrix_present) read_scaling_matrix(br, s.scaling4, s.scaling8, s.chroma_format_idc != 3 ? 8 : 12, nullptr, nullptr);
+        break;
+    default: break;
+    }
+    s.log2_max_frame_num = 4 + br.ue();
+    s.poc_type = br.ue();
+    if (s.poc_type == 0) s.log2_max_poc_lsb = 4 + br.ue();
+    else if (s.poc_type == 1) {
+        s.delta_pic_order_always_zero = br.u1();
+        s.offset_for_non_ref_pic = br.se(); s.offset_for_top_to_bottom = br.se();
+        s.num_ref_frames_in_poc_cycle = br.ue();
+        if (s.num_ref_frames_in_poc_cycle > 255) return "bad num_ref_frames_in_pic_order_cnt_cycle";
+        for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) s.offset_for_ref_frame[i] = br.se();
+    } else if (s.poc_type != 2) return "bad pic_order_cnt_type";
+    s.max_num_ref_frames = br.ue();
+    s.gaps_allowed = br.u1();
+    s.mb_w = br.ue() + 1; s.mb_h = br.ue() + 1;
+    s.frame_mbs_only = br.u1();
+    if (!s.frame_mbs_only) br.u1();
+    s.direct_8x8_inference = br.u1();
+    if (br.u1()) { s.crop_l = br.ue(); s.crop_r = br.ue(); s.crop_t = br.ue(); s.crop_b = br.ue(); }
+    if (br.u1()) {   // VUI (E.1.1); only the bitstream restriction matters to us
+        if (br.u1()) { if (br.u(8) == 255) { br.u(16); br.u(16); } }
+        if (br.u1()) br.u1();
+        if (br.u1()) { br.u(3); br.u1(); if (br.u1()) { br.u(8); br.u(8); br.u(8); } }
+        if (br.u1()) { br.ue(); br.ue(); }
+        if (br.u1()) { br.u(32); br.u(32); br.u1(); }
+        bool nal_hrd = br.u1(); if (nal_hrd) skip_hrd(br);
+        bool vcl_hrd = br.u1(); if (vcl_hrd) skip_hrd(br);
+        if (nal_hrd || vcl_hrd) br.u1();
+        br.u1();
+        if (br.u1()) { br.u1(); br.ue(); br.ue(); br.ue(); br.ue(); s.max_num_reorder_frames = br.ue(); s.max_dec_frame_buffering = br.ue(); }
+    }
+    if (br.overrun()) return "SPS truncated";
+    if (s.chroma_format_idc != 1 || s.bit_depth_luma != 8 || s.bit_depth_chroma != 8) return "only 8-bit 4:2:0 is supported";
+    if (!s.frame_mbs_only) return "interlaced streams are not supported";
+    if (s.mb_w > 1024 || s.mb_h > 1024) return "picture too large";
+    s.valid = true;
+    sps[s.id] = s;
+    return "";
+}
+
+std::string ParamSets::parse_pps(BitReader &br) {
+    PicParamSet p;
+    p.id = br.ue(); p.sps_id = br.ue();
+    if (p.id > 255 || p.sps_id > 31) return "pps/sps id out of range";
+    p.cabac = br.u1(); p.bottom_field_poc_present = br.u1();
+    if (br.ue() != 0) return "slice groups (FMO) are not supported";
+    p.num_ref_idx_default[0] = br.ue() + 1; p.num_ref_idx_default[1] = br.ue() + 1;
+    p.weighted_pred = br.u1(); p.weighted_bipred_idc = br.u(2);
+    p.init_qp = 26 + br.se(); br.se();
+    p.chroma_qp_off = br.se();
+    p.deblock_ctrl_present = br.u1(); p.constrained_intra = br.u1(); p.redundant_pic_cnt_present = br.u1();
+    p.second_chroma_qp_off = p.chroma_qp_off;
+    const SeqParams *s = sps[p.sps_id].valid ? &sps[p.sps_id] : nullptr;
+    if (s) { memcpy(p.scaling4, s->scaling4, sizeof p.scaling4); memcpy(p.scaling8, s->scaling8, sizeof p.scaling8); }
+    else { memset(p.scaling4, 16, sizeof p.scaling4); memset(p.scaling8, 16, sizeof p.scaling8); }
+    br.set_end_from_trailing();
+    if (br.more_rbsp_data()) {
+        p.transform8x8 = br.u1();
+        p.scaling_matrix_present = br.u1();
+        if (p.scaling_matrix_present) {
+            bool sps_has = s && s->scaling_matrix_present;
+            read_scaling_matrix(br, p.scaling4, p.scaling8, 6 + 2 * (int)p.transform8x8, sps_has ? s->scaling4 : nullptr, sps_has ? s->scaling8 : nullptr);
+        }
+        p.second_chroma_qp_off = br.se();
+    }
+    if (br.overrun()) return "PPS truncated";
+    p.valid = true;
+    pps[p.id] = p;
+    return "";
+}
+
+std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_ref_idc, SliceHeader &sh) const {
+    sh.nal_ref_idc = nal_ref_idc; sh.idr = nal_type == 5;
+    sh.first_mb = br.ue();
+    uint32_t st = br.ue();
+    if (st > 9) return "bad slice_type";
+    sh.type = st % 5;
+    if (sh.type > SL_I) return "SP/SI slices are not supported";
+    sh.pps_id = br.ue();
+    if (sh.pps_id > 255 || !pps[sh.pps_id].valid) return "slice refers to a missing PPS";
+    const PicParamSet &p = pps[sh.pps_id];
+    if (!sps[p.sps_id].valid) return "slice refers to a missing SPS";
+    const SeqParams &s = sps[p.sps_id];
+    sh.frame_num = br.u(s.log2_max_frame_num);
+    if (sh.idr) sh.idr_pic_id = br.ue();
+    if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present) sh.delta_poc_bottom = br.se(); }
+    else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (p.bottom_field_poc_present) sh.delta_poc[1] = br.se(); }
+    if (p.redundant_pic_cnt_present) br.ue();
+    if (sh.type == SL_B) br.u1();
+    sh.num_ref_idx[0] = p.num_ref_idx_default[0]; sh.num_ref_idx[1] = p.num_ref_idx_default[1];
+    if (sh.type != SL_I && br.u1()) { sh.num_ref_idx[0] = br.ue() + 1; if (sh.type == SL_B) sh.num_ref_idx[1] = br.ue() + 1; }
+    if (sh.num_ref_idx[0] > 32 || sh.num_ref_idx[1] > 32) return "num_ref_idx_active out of range";
+    if (sh.type != SL_B) sh.num_ref_idx[1] = 0;
+    if (sh.type == SL_I) sh.num_ref_idx[0] = 0;
+    int lists = sh.type == SL_I ? 0 : (sh.type == SL_B ? 2 : 1);
+    for (int l = 0; l < lists; l++) {
+        if (!br.u1()) continue;
+        for (;;) {
+            uint32_t idc = br.ue();
+            if (idc == 3) break;
+            if (idc > 3 || sh.n_mod[l] >= 66 || br.overrun()) return "bad ref_pic_list_modification";
+            sh.mod[l][sh.n_mod[l]++] = RefMod{(uint8_t)idc, br.ue()};
+        }
+    }
+    if ((p.weighted_pred && sh.type == SL_P) || (p.weighted_bipred_idc == 1 && sh.type == SL_B)) {
+        sh.explicit_wp = true;
+        sh.luma_log2_wd = br.ue(); sh.chroma_log2_wd = br.ue();
+        for (int l = 0; l < lists; l++) for (int i = 0; i < sh.num_ref_idx[l]; i++) {
+            int lw = 1 << sh.luma_log2_wd, lo = 0, cw[2] = {1 << sh.chroma_log2_wd, 1 << sh.chroma_log2_wd}, co[2] = {0, 0};
+            if (br.u1()) { lw = br.se(); lo = br.se(); }
+            if (br.u1()) for (int j = 0; j < 2; j++) { cw[j] = br.se(); co[j] = br.se(); }
+            if (l == 0) { sh.luma_w[i] = (int16_t)lw; sh.luma_o[i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[i][j] = (int16_t)cw[j]; sh.chroma_o[i][j] = (int16_t)co[j]; } }
+        }
+    }
+    if (nal_ref_idc) {
+        if (sh.idr) { br.u1(); sh.long_term_reference = br.u1(); }
+        else if ((sh.adaptive_marking = br.u1())) {
+            for (;;) {
+                uint32_t op = br.ue();
+                if (!op) break;
+                if (op > 6 || sh.n_mark >= 66 || br.overrun()) return "bad memory_management_control_operation";
+                MarkOp m{(uint8_t)op, 0, 0};
+                if (op == 1 || op == 3) m.a = br.ue();
+                if (op == 2) m.a = br.ue();
+                if (op == 3 || op == 6) m.b = br.ue();
+                if (op == 4) m.a = br.ue();
+                sh.mark[sh.n_mark++] = m;
+            }
+        }
+    }
+    if (p.cabac && sh.type != SL_I) br.ue();
+    sh.qp = p.init_qp + br.se();
+    if (sh.qp < 0 || sh.qp > 51) return "slice QP out of range";
+    if (p.deblock_ctrl_present) {
+        sh.disable_deblock = br.ue();
+        if (sh.disable_deblock > 2) return "bad disable_deblocking_filter_idc";
+        if (sh.disable_deblock != 1) { sh.alpha_off = 2 * br.se(); sh.beta_off = 2 * br.se(); }
+    }
+    if (br.overrun()) return "slice header truncated";
+    sh.data_bit_offset = br.bitpos();
+    return "";
+}
+
+}  // namespace jmamd

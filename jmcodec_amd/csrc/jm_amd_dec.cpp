@@ -1,0 +1,44 @@
+// jmcodec_amd/csrc/jm_amd_dec.cpp -- C ABI (include/jm_amd_dec.h) over jmamd::Decoder.
+#include "../../include/jm_amd_dec.h"
+#include "decoder.h"
+#include "kernels.h"
+#include <hip/hip_runtime_api.h>
+
+using jmamd::Decoder;
+#define D(h) (reinterpret_cast<Decoder *>(h))
+
+extern "C" {
+
+__attribute__((visibility("default"))) jm_amddec_handle jm_amddec_create_handle(void) { return new Decoder(); }
+__attribute__((visibility("default"))) int jm_amddec_init(int codec_type, int out_fmt, char *extra, int len, jm_amddec_handle h) {
+    if (!h) return -1;
+    return D(h)->init(codec_type, out_fmt, reinterpret_cast<const uint8_t *>(extra), len);
+}
+__attribute__((visibility("default"))) int jm_amddec_deinit(jm_amddec_handle h) { delete D(h); return 0; }
+__attribute__((visibility("default"))) int jm_amddec_decode_frame(unsigned char *in_buf, int n, int *got, jm_amddec_handle h) {
+    int dummy = 0;
+    if (!h) return -1;
+    return D(h)->decode(in_buf, n, got ? got : &dummy);
+}
+__attribute__((visibility("default"))) int jm_amddec_output_frame(unsigned char *out, int *out_len, jm_amddec_handle h) {
+    if (!h || !out || !out_len) return -1;
+    return D(h)->output(out, out_len);
+}
+__attribute__((visibility("default"))) int jm_amddec_stream_info(int *w, int *hh, jm_amddec_handle h) { return D(h)->stream_info(w, hh); }
+__attribute__((visibility("default"))) void jm_amddec_set_eof(int e, jm_amddec_handle h) { D(h)->set_eof(e != 0); }
+__attribute__((visibility("default"))) int jm_amddec_is_exit(jm_amddec_handle h) { return D(h)->is_exit() ? 1 : 0; }
+__attribute__((visibility("default"))) char *jm_amddec_show_dec_info(jm_amddec_handle h) { return D(h)->info(); }
+__attribute__((visibility("default"))) int jm_amddec_is_hw_support(void) {      // nvdec_cuda_hw_support: device count > 0 (nv_dec.cpp:188-200)
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+__attribute__((visibility("default"))) int jm_amddec_set_option(jm_amddec_handle h, const char *key, long long v) { return D(h)->set_option(key, v); }
+__attribute__((visibility("default"))) long long jm_amddec_get_stat(jm_amddec_handle h, const char *key) { return D(h)->get_stat(key); }
+__attribute__((visibility("default"))) const char *jm_amddec_last_error(jm_amddec_handle h) { return D(h)->last_error(); }
+__attribute__((visibility("default"))) int jm_amddec_packout_device(const void *src, int pitch, int w, int hgt, int fmt, void *dst, void *stream) {
+    jmamd::launch_packout(static_cast<const uint8_t *>(src), pitch, pitch * hgt, w, hgt, fmt, static_cast<uint8_t *>(dst), static_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // extern "C"

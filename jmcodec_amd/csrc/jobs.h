@@ -1,0 +1,81 @@
+// jmcodec_amd/csrc/jobs.h -- the host->device contract: one picture's macroblock job list.
+//
+// Replaces the CUVIDPICPARAMS hand-off of the reference
+// (/root/reference/nv_dec/nv_dec.cpp:33-41 -> cuvidDecodePicture;
+//  struct at nv_sdk/inc/dynlink_cuviddec.h:635-663).  There the slice bytes go
+// to a fixed-function ASIC; here entropy decoding stays on the host and the
+// device receives, per picture:
+//   PicParams   (kernel argument, by value)
+//   MbRec[n_mbs]            fixed 32-byte record per macroblock
+//   SliceRec[n_slices]      deblocking parameters per slice
+//   int16 mv_ext[]          16 MVs for macroblocks with sub-8x8 partitions
+//   int16 coef[]            raw (un-scaled) levels, 16 per CODED 4x4 block
+// packed into one pinned buffer so that a single hipMemcpyAsync uploads it.
+#pragma once
+#include <stdint.h>
+
+namespace jmamd {
+
+enum : uint8_t { MB_INTER = 0, MB_I4 = 1, MB_I16 = 2, MB_PCM = 3 };
+
+// MbRec.flags
+enum : uint8_t {
+    MBF_AVAIL_A = 1,      // left  MB usable for intra prediction
+    MBF_AVAIL_B = 2,      // top
+    MBF_AVAIL_C = 4,      // top-right
+    MBF_AVAIL_D = 8,      // top-left
+    MBF_CB_DC   = 16,     // chroma DC block present for Cb
+    MBF_CR_DC   = 32,     // ... Cr
+    MBF_MV_EXT  = 64,     // sub-8x8 partitions: u.mv_ext indexes 16 MVs in mv_ext[]
+    MBF_DECODED = 128,    // macroblock was present in the bitstream (else concealment)
+};
+
+struct MbRec {            // 32 bytes
+    uint8_t  kind;        // MB_*
+    uint8_t  qp;          // QP_Y of the macroblock (0 for I_PCM: 8.7.2.2)
+    uint8_t  modes;       // bits 0-1 intra_chroma_pred_mode, bits 2-3 Intra16x16PredMode
+    uint8_t  flags;       // MBF_*
+    uint16_t cbp_blk;     // bit r set: luma 4x4 block r (raster) has coded levels
+    uint8_t  cbp_cac;     // bits 0-3 Cb AC blocks, 4-7 Cr AC blocks
+    uint8_t  slice;       // index into SliceRec[]
+    uint32_t coef_off;    // first int16 of this macroblock in coef[]
+    int8_t   ref[4];      // DPB surface slot per 8x8 (inter), -1 otherwise
+    union {
+        int16_t  mv[4][2];    // one MV per 8x8 (quarter-sample units)
+        uint8_t  i4[8];       // Intra4x4PredMode, two per byte (low nibble = even raster index)
+        uint32_t mv_ext;      // MBF_MV_EXT: index (in MVs) of 16 per-4x4 MVs in mv_ext[]
+    } u;
+};
+static_assert(sizeof(MbRec) == 32, "MbRec must stay 32 bytes");
+
+// Coefficient stream layout of one macroblock, starting at coef_off (int16 units):
+//   MB_I16 : 16 DC levels (4x4 matrix, raster)              always
+//   luma   : 16 levels (raster) for every set bit of cbp_blk, ascending bit order
+//   chroma : 4 Cb DC levels if MBF_CB_DC, then 4 Cr DC levels if MBF_CR_DC
+//   chroma : 16 levels (raster, [0] unused) per set bit of cbp_cac, ascending
+//   MB_PCM : 384 raw bytes (256 Y, 64 Cb, 64 Cr) = 192 int16 slots, nothing else
+
+struct SliceRec {         // 4 bytes
+    int8_t  alpha_off;    // FilterOffsetA
+    int8_t  beta_off;     // FilterOffsetB
+    uint8_t disable;      // disable_deblocking_filter_idc
+    uint8_t pad;
+};
+
+constexpr int kMaxSurfaces = 20;
+
+struct PicParams {
+    int mb_w, mb_h;
+    int pitch;                    // bytes per luma row == bytes per interleaved chroma row
+    int chroma_offset;            // byte offset of the UV plane inside a surface = pitch * coded_h
+    int cb_qp_off, cr_qp_off;     // chroma_qp_index_offset, second_chroma_qp_index_offset
+    int n_slices;
+    int cur;                      // surface slot being written
+    uint8_t *surf[kMaxSurfaces];  // device pointers of the DPB surfaces
+    const MbRec *mbs;
+    const SliceRec *slices;
+    const int16_t *mv_ext;
+    const int16_t *coef;
+};
+
+}  // namespace jmamd

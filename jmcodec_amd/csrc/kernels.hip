@@ -1,0 +1,707 @@
+// jmcodec_amd/csrc/kernels.hip -- gfx950 reconstruction kernels of the jm_amd_dec backend.
+//
+// Together these kernels are the device half of what the reference delegates to the NVDEC ASIC
+// through cuvidDecodePicture (/root/reference/nv_dec/nv_dec.cpp:33-41) plus the host repack of
+// jm_nvdec_output_frame (nv_dec.cpp:750-828):
+//   k_recon_inter   sub-pel motion compensation + dequant/inverse transform + I_PCM   (fully parallel)
+//   k_recon_intra   Intra4x4 / Intra16x16 / chroma intra prediction + residual        (MB wavefront)
+//   k_deblock       in-loop deblocking filter, clause 8.7 order                        (MB wavefront)
+//   k_packout       pitch NV12 surface -> tight NV12 / I420 display frame              (fully parallel)
+// All arithmetic is 8-bit integer pixel work: HBM/LDS bound, no MFMA.
+#include <hip/hip_runtime.h>
+#include "jobs.h"
+#include "kernels.h"
+
+namespace jmamd {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clip1(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+
+__device__ const uint8_t kNorm4[6][3] = { {10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23} };
+__device__ const uint8_t kQpcTab[22] = {29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39};
+__device__ const uint8_t kAlpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,
+    32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
+__device__ const uint8_t kBeta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,
+    9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
+__device__ const uint8_t kTc0[52][3] = {
+ {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+ {0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},
+ {2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
+ {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
+
+__device__ __forceinline__ int chroma_qp(int qpy, int off) {
+    int q = clip3(0, 51, qpy + off);
+    return q < 30 ? q : kQpcTab[q - 30];
+}
+// LevelScale4x4 with the flat (16) weight matrix: 16 * normAdjust4x4 (8.5.9)
+__device__ __forceinline__ int level_scale4(int qp_rem, int pos) {
+    int i = pos >> 2, j = pos & 3;
+    int cls = (!(i & 1) && !(j & 1)) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
+    return 16 * kNorm4[qp_rem][cls];
+}
+// 8.5.12.1 scaling of one residual coefficient (not the separately handled DC ones)
+__device__ __forceinline__ int dequant4(int c, int qp, int pos) {
+    int ls = level_scale4(qp % 6, pos), s = qp / 6;
+    return s >= 4 ? (c * ls) << (s - 4) : (c * ls + (1 << (3 - s))) >> (4 - s);
+}
+// 8.5.12.2 inverse 4x4 transform, in place on d[16] (raster), result already >> 6
+__device__ __forceinline__ void idct4x4(int *d) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int a = d[4 * i], b = d[4 * i + 1], c = d[4 * i + 2], e = d[4 * i + 3];
+        int e0 = a + c, e1 = a - c, e2 = (b >> 1) - e, e3 = b + (e >> 1);
+        d[4 * i] = e0 + e3; d[4 * i + 1] = e1 + e2; d[4 * i + 2] = e1 - e2; d[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int a = d[j], b = d[4 + j], c = d[8 + j], e = d[12 + j];
+        int g0 = a + c, g1 = a - c, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+        d[j] = (g0 + g3 + 32) >> 6; d[4 + j] = (g1 + g2 + 32) >> 6; d[8 + j] = (g1 - g2 + 32) >> 6; d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+// blkIdx (coding order) <-> raster position of a luma 4x4 block inside the macroblock
+__device__ __forceinline__ int blk_to_raster(int blk) { return ((((blk >> 1) & 1) + 2 * (blk >> 3)) << 2) | ((blk & 1) + 2 * ((blk >> 2) & 1)); }
+__device__ __forceinline__ int raster_to_blk(int r) { int bx = r & 3, by = r >> 2; return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
+
+// LDS residual scratch of one wave: 16x16 luma + 2 x 8x8 chroma, int16
+struct ResTile { short y[256]; short c[2][64]; };
+
+// Residual of one macroblock into LDS.  Lanes 0..15: luma blocks (blkIdx order), lanes 16..23: chroma blocks.
+// For MB_I16 the luma DC path (8.5.10) is applied.  Must be called by all 64 lanes of the wave.
+__device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile &rt, int lane) {
+    const short *coef = pp.coef + r.coef_off;
+    int qp = r.qp;
+    int n_luma = __popc((unsigned)r.cbp_blk);
+    int base_luma = r.kind == MB_I16 ? 16 : 0;
+    if (lane < 16) {
+        int blk = lane, rpos = blk_to_raster(blk);
+        int d[16];
+        bool coded = (r.cbp_blk >> blk) & 1;
+        if (coded) {
+            const short *c = coef + base_luma + 16 * __popc((unsigned)r.cbp_blk & ((1u << blk) - 1));
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = dequant4(c[k], qp, k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = 0;
+        }
+        bool any = coded;
+        if (r.kind == MB_I16) {
+            // 8.5.10: f = H c H over the 4x4 DC matrix, element (row i, col j) belongs to the block at (x=j, y=i)
+            int c[16], f[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) c[k] = coef[k];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int a = c[4 * i], b = c[4 * i + 1], cc = c[4 * i + 2], e = c[4 * i + 3];
+                f[4 * i] = a + b + cc + e; f[4 * i + 1] = a + b - cc - e; f[4 * i + 2] = a - b - cc + e; f[4 * i + 3] = a - b + cc - e;
+            }
+            int j = rpos & 3, i = rpos >> 2;
+            int a = f[j], b = f[4 + j], cc = f[8 + j], e = f[12 + j];
+            int g = i == 0 ? a + b + cc + e : (i == 1 ? a + b - cc - e : (i == 2 ? a - b - cc + e : a - b + cc - e));
+            int ls0 = level_scale4(qp % 6, 0), s = qp / 6;
+            d[0] = s >= 6 ? (g * ls0) << (s - 6) : (g * ls0 + (1 << (5 - s))) >> (6 - s);
+            any = true;
+        }
+        if (any) idct4x4(d);
+        int bx = rpos & 3, by = rpos >> 2;
+#pragma unroll
+        for (int k = 0; k < 16; k++) rt.y[(by * 4 + (k >> 2)) * 16 + bx * 4 + (k & 3)] = (short)d[k];
+    } else if (lane < 24) {
+        int pl = (lane - 16) >> 2, k4 = (lane - 16) & 3;
+        int qpc = chroma_qp(qp, pl ? pp.cr_qp_off : pp.cb_qp_off);
+        const short *cdc = coef + base_luma + 16 * n_luma;
+        int has_cb = (r.flags & MBF_CB_DC) ? 1 : 0, has_cr = (r.flags & MBF_CR_DC) ? 1 : 0;
+        const short *cac = cdc + 4 * (has_cb + has_cr);
+        int d[16];
+        bool coded = (r.cbp_cac >> (lane - 16)) & 1;
+        if (coded) {
+            const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 16)) - 1));
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = dequant4(c[k], qpc, k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = 0;
+        }
+        bool has_dc = pl ? has_cr : has_cb;
+        if (has_dc) {
+            const short *c = cdc + (pl ? 4 * has_cb : 0);
+            int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            int f = k4 == 0 ? c0 + c1 + c2 + c3 : (k4 == 1 ? c0 - c1 + c2 - c3 : (k4 == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
+            d[0] = ((f * level_scale4(qpc % 6, 0)) << (qpc / 6)) >> 5;
+        } else d[0] = 0;
+        if (coded || has_dc) idct4x4(d);
+        int bx = k4 & 1, by = k4 >> 1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) rt.c[pl][(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)] = (short)d[k];
+    }
+}
+
+__device__ __forceinline__ bool mb_has_residual(const MbRec &r) {
+    return r.kind == MB_I16 || r.cbp_blk || r.cbp_cac || (r.flags & (MBF_CB_DC | MBF_CR_DC));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_recon_inter: one wave per macroblock, 4 macroblocks per workgroup
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ref_luma(const uint8_t *s, int pitch, int W, int H, int x, int y) {
+    return s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)];
+}
+// 8.4.2.2.1 luma sample interpolation (literal form)
+__device__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
+#define P(dx, dy) ref_luma(s, pitch, W, H, xi + (dx), yi + (dy))
+#define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
+#define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
+    int G = P(0, 0);
+    if (!fx && !fy) return G;
+    if (!fy) { int b = clip1((HB(0) + 16) >> 5); return fx == 2 ? b : (fx == 1 ? (G + b + 1) >> 1 : (P(1, 0) + b + 1) >> 1); }
+    if (!fx) { int h = clip1((VH(0) + 16) >> 5); return fy == 2 ? h : (fy == 1 ? (G + h + 1) >> 1 : (P(0, 1) + h + 1) >> 1); }
+    if (fx == 2 || fy == 2) {
+        int j = clip1((tap6(HB(-2), HB(-1), HB(0), HB(1), HB(2), HB(3)) + 512) >> 10);
+        if (fx == 2 && fy == 2) return j;
+        if (fx == 2) { int q = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5); return (q + j + 1) >> 1; }
+        int q = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);
+        return (q + j + 1) >> 1;
+    }
+    int bq = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5);   // b or s
+    int hq = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);   // h or m
+    return (bq + hq + 1) >> 1;
+#undef P
+#undef HB
+#undef VH
+}
+
+__global__ __launch_bounds__(256) void k_recon_inter(PicParams pp) {
+    __shared__ ResTile tiles[4];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int n_mbs = pp.mb_w * pp.mb_h;
+    int mb = blockIdx.x * 4 + wave;
+    bool valid = mb < n_mbs;
+    MbRec r;
+    if (valid) r = pp.mbs[mb]; else { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
+    bool inter = valid && r.kind == MB_INTER;
+    bool has_res = inter && mb_has_residual(r);
+    if (has_res) mb_residual_to_lds(pp, r, tiles[wave], lane);
+    __syncthreads();
+    if (!valid) return;
+    int mbx = mb % pp.mb_w, mby = mb / pp.mb_w;
+    int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
+    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst_c = dst + pp.chroma_offset;
+    if (r.kind == MB_PCM) {
+        const uint8_t *pcm = (const uint8_t *)(pp.coef + r.coef_off);
+        int row = lane >> 2, xq = lane & 3;
+        *(uint32_t *)(dst + (size_t)(mby * 16 + row) * pitch + mbx * 16 + xq * 4) =
+            pcm[row * 16 + xq * 4] | (pcm[row * 16 + xq * 4 + 1] << 8) | (pcm[row * 16 + xq * 4 + 2] << 16) | (pcm[row * 16 + xq * 4 + 3] << 24);
+        int cx = lane & 7, cy = lane >> 3;
+        *(uint16_t *)(dst_c + (size_t)(mby * 8 + cy) * pitch + mbx * 16 + cx * 2) = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
+        return;
+    }
+    if (!inter) return;
+    // ---- luma: lane -> (raster 4x4 block, row inside it), 4 pixels per lane ----
+    {
+        int rb = lane >> 2, row = lane & 3;
+        int bx = rb & 3, by = rb >> 2;
+        int b8 = (by >> 1) * 2 + (bx >> 1);
+        int mvx, mvy;
+        if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
+        else { mvx = r.u.mv[b8][0]; mvy = r.u.mv[b8][1]; }
+        int slot = r.ref[b8];
+        int x0 = mbx * 16 + bx * 4, y = mby * 16 + by * 4 + row;
+        int v[4];
+        if (slot < 0) { v[0] = v[1] = v[2] = v[3] = 128; }
+        else {
+            const uint8_t *ref = pp.surf[slot];
+            int xi = x0 + (mvx >> 2), yi = y + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = luma_sample(ref, pitch, W, H, xi + k, yi, fx, fy);
+        }
+        if (has_res) {
+            const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
+        }
+        *(uint32_t *)(dst + (size_t)y * pitch + x0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    }
+    // ---- chroma: lane -> chroma position (cx, cy), both planes ----
+    {
+        int cx = lane & 7, cy = lane >> 3;
+        int rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
+        int mvx, mvy;
+        if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
+        else { mvx = r.u.mv[b8][0]; mvy = r.u.mv[b8][1]; }
+        int slot = r.ref[b8];
+        int u, v;
+        if (slot < 0) { u = v = 128; }
+        else {
+            const uint8_t *rc = pp.surf[slot] + pp.chroma_offset;
+            int CW = W >> 1, CH = H >> 1;
+            int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
+            int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
+            const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
+            int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
+            u = (w00 * r0[2 * xa] + w01 * r0[2 * xb] + w10 * r1[2 * xa] + w11 * r1[2 * xb] + 32) >> 6;
+            v = (w00 * r0[2 * xa + 1] + w01 * r0[2 * xb + 1] + w10 * r1[2 * xa + 1] + w11 * r1[2 * xb + 1] + 32) >> 6;
+        }
+        if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
+        *(uint16_t *)(dst_c + (size_t)(mby * 8 + cy) * pitch + mbx * 16 + cx * 2) = (uint16_t)(u | (v << 8));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wavefront plumbing shared by k_recon_intra and k_deblock: one workgroup of kWaves waves, wave w
+// walks macroblock rows w, w+kWaves, ...; progress[row] = number of finished macroblocks in that row.
+// A macroblock (x, y) may start once row y-1 has finished min(x+2, mb_w) macroblocks
+// (left neighbour is the same wave; top, top-left and top-right are covered by the count).
+// ------------------------------------------------------------------------------------------
+constexpr int kWaves = 16;
+constexpr int kMaxRows = 512;
+
+__device__ __forceinline__ void wait_row(volatile int *progress, int row, int need) {
+    if (row < 0) return;
+    while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void publish_row(volatile int *progress, int row, int done, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) progress[row] = done;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_recon_intra
+// ------------------------------------------------------------------------------------------
+struct IntraTile {
+    uint8_t y[17][24];        // [0] = row above; column 0 = left neighbour, columns 1..16 MB, 17..20 top-right
+    uint8_t c[2][9][12];      // per plane: [0] = row above, column 0 = left neighbour, 1..8 MB
+};
+
+__device__ void intra4x4_block(IntraTile &t, const ResTile &rt, int blk, int mode, bool availA, bool availB, bool availC, bool availD, int lane) {
+    // lanes 0..15: pixel (px, py) of the 4x4 block
+    if (lane >= 16) return;
+    int rpos = blk_to_raster(blk), bx = rpos & 3, by = rpos >> 2;
+    int px = lane & 3, py = lane >> 2;
+    int ox = 1 + bx * 4, oy = 1 + by * 4;              // tile coordinates of the block origin
+    int T[9], L[5];                                    // T[k+1] = p[k,-1] for k=-1..7 ; L[k+1] = p[-1,k] for k=-1..3
+#pragma unroll
+    for (int k = 0; k < 4; k++) { T[k + 1] = availB ? t.y[oy - 1][ox + k] : 128; L[k + 1] = availA ? t.y[oy + k][ox - 1] : 128; }
+#pragma unroll
+    for (int k = 4; k < 8; k++) T[k + 1] = (availB && availC) ? t.y[oy - 1][ox + k] : T[4];
+    T[0] = L[0] = availD ? t.y[oy - 1][ox - 1] : 128;
+#define TT(k) T[(k) + 1]
+#define LL(k) L[(k) + 1]
+    int p;
+    switch (mode) {
+    case 0: p = TT(px); break;
+    case 1: p = LL(py); break;
+    case 2:
+        if (availA && availB) p = (TT(0) + TT(1) + TT(2) + TT(3) + LL(0) + LL(1) + LL(2) + LL(3) + 4) >> 3;
+        else if (availA) p = (LL(0) + LL(1) + LL(2) + LL(3) + 2) >> 2;
+        else if (availB) p = (TT(0) + TT(1) + TT(2) + TT(3) + 2) >> 2;
+        else p = 128;
+        break;
+    case 3: p = (px == 3 && py == 3) ? (TT(6) + 3 * TT(7) + 2) >> 2 : (TT(px + py) + 2 * TT(px + py + 1) + TT(px + py + 2) + 2) >> 2; break;
+    case 4:
+        if (px > py) p = (TT(px - py - 2) + 2 * TT(px - py - 1) + TT(px - py) + 2) >> 2;
+        else if (px < py) p = (LL(py - px - 2) + 2 * LL(py - px - 1) + LL(py - px) + 2) >> 2;
+        else p = (TT(0) + 2 * TT(-1) + LL(0) + 2) >> 2;
+        break;
+    case 5: { int z = 2 * px - py, i = px - (py >> 1);
+        if (z >= 0) p = (z & 1) ? (TT(i - 2) + 2 * TT(i - 1) + TT(i) + 2) >> 2 : (TT(i - 1) + TT(i) + 1) >> 1;
+        else if (z == -1) p = (LL(0) + 2 * TT(-1) + TT(0) + 2) >> 2;
+        else p = (LL(py - 1) + 2 * LL(py - 2) + LL(py - 3) + 2) >> 2;
+        break; }
+    case 6: { int z = 2 * py - px, i = py - (px >> 1);
+        if (z >= 0) p = (z & 1) ? (LL(i - 2) + 2 * LL(i - 1) + LL(i) + 2) >> 2 : (LL(i - 1) + LL(i) + 1) >> 1;
+        else if (z == -1) p = (LL(0) + 2 * TT(-1) + TT(0) + 2) >> 2;
+        else p = (TT(px - 1) + 2 * TT(px - 2) + TT(px - 3) + 2) >> 2;
+        break; }
+    case 7: { int i = px + (py >> 1); p = (py & 1) ? (TT(i) + 2 * TT(i + 1) + TT(i + 2) + 2) >> 2 : (TT(i) + TT(i + 1) + 1) >> 1; break; }
+    default: { int z = px + 2 * py, i = py + (px >> 1);
+        if (z > 5) p = LL(3);
+        else if (z == 5) p = (LL(2) + 3 * LL(3) + 2) >> 2;
+        else p = (z & 1) ? (LL(i) + 2 * LL(i + 1) + LL(i + 2) + 2) >> 2 : (LL(i) + LL(i + 1) + 1) >> 1;
+        break; }
+    }
+#undef TT
+#undef LL
+    p = clip1(p + rt.y[(by * 4 + py) * 16 + bx * 4 + px]);
+    t.y[oy + py][ox + px] = (uint8_t)p;
+}
+
+// plane prediction (8.3.3.4 / 8.3.4.4) for an n x n block whose neighbours sit in a tile with the given row stride
+__device__ __forceinline__ int plane_pred(const uint8_t *tile, int stride, int n, int x, int y) {
+    // tile points at the MB origin inside the tile (tile[-stride] = row above, tile[-1] = left column)
+    int h2 = n >> 1, Hs = 0, Vs = 0;
+    for (int k = 0; k < h2; k++) {
+        Hs += (k + 1) * (tile[-stride + h2 + k] - tile[-stride + h2 - 2 - k]);
+        Vs += (k + 1) * (tile[(h2 + k) * stride - 1] - tile[(h2 - 2 - k) * stride - 1]);
+    }
+    int a = 16 * (tile[(n - 1) * stride - 1] + tile[-stride + n - 1]);
+    int b = n == 16 ? (5 * Hs + 32) >> 6 : (34 * Hs + 32) >> 6;
+    int c = n == 16 ? (5 * Vs + 32) >> 6 : (34 * Vs + 32) >> 6;
+    return clip1((a + b * (x - (h2 - 1)) + c * (y - (h2 - 1)) + 16) >> 5);
+}
+
+__device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, IntraTile &t, ResTile &rt, int lane) {
+    int pitch = pp.pitch, W = pp.mb_w * 16, H = pp.mb_h * 16;
+    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst_c = dst + pp.chroma_offset;
+    bool availA = r.flags & MBF_AVAIL_A, availB = r.flags & MBF_AVAIL_B, availC = r.flags & MBF_AVAIL_C, availD = r.flags & MBF_AVAIL_D;
+    // ---- residual (zeros when absent) ----
+    if (mb_has_residual(r)) mb_residual_to_lds(pp, r, rt, lane);
+    else { for (int k = lane; k < 256; k += 64) rt.y[k] = 0; for (int k = lane; k < 128; k += 64) (&rt.c[0][0])[k] = 0; }
+    // ---- neighbours into the tile (clamped addresses; unavailable ones are never used) ----
+    {
+        int x0 = mbx * 16, y0 = mby * 16;
+        if (lane < 21) { int x = clip3(0, W - 1, x0 - 1 + lane), y = clip3(0, H - 1, y0 - 1); t.y[0][lane] = dst[(size_t)y * pitch + x]; }
+        else if (lane >= 32 && lane < 48) { int i = lane - 32; int x = clip3(0, W - 1, x0 - 1); t.y[1 + i][0] = dst[(size_t)(y0 + i) * pitch + x]; }
+        int cx0 = mbx * 8, cy0 = mby * 8, CW = W >> 1, CH = H >> 1;
+        if (lane < 18) { int pl = lane / 9, i = lane % 9; int x = clip3(0, CW - 1, cx0 - 1 + i), y = clip3(0, CH - 1, cy0 - 1); t.c[pl][0][i] = dst_c[(size_t)y * pitch + 2 * x + pl]; }
+        else if (lane >= 32 && lane < 48) { int pl = (lane - 32) >> 3, i = (lane - 32) & 7; int x = clip3(0, CW - 1, cx0 - 1); t.c[pl][1 + i][0] = dst_c[(size_t)(cy0 + i) * pitch + 2 * x + pl]; }
+    }
+    // ---- luma ----
+    if (r.kind == MB_I4) {
+        for (int blk = 0; blk < 16; blk++) {
+            int rpos = blk_to_raster(blk), bx = rpos & 3, by = rpos >> 2;
+            int mode = (r.u.i4[rpos >> 1] >> ((rpos & 1) * 4)) & 15;
+            bool a = bx > 0 || availA, b = by > 0 || availB, d = (bx > 0 && by > 0) ? true : (bx > 0 ? availB : (by > 0 ? availA : availD));
+            bool c;
+            if (by == 0) c = bx < 3 ? availB : availC;
+            else c = !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
+            intra4x4_block(t, rt, blk, mode, a, b, c, d, lane);
+        }
+    } else {
+        int mode = (r.modes >> 2) & 3;
+        int rb = lane >> 2, row = lane & 3, bx = rb & 3, by = rb >> 2, y = by * 4 + row;
+        int dc = 128;
+        if (mode == 2) {
+            int st = 0, sl = 0;
+            for (int i = 0; i < 16; i++) { st += t.y[0][1 + i]; sl += t.y[1 + i][0]; }
+            dc = (availA && availB) ? (st + sl + 16) >> 5 : (availA ? (sl + 8) >> 4 : (availB ? (st + 8) >> 4 : 128));
+        }
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int x = bx * 4 + k, p;
+            if (mode == 0) p = t.y[0][1 + x];
+            else if (mode == 1) p = t.y[1 + y][0];
+            else if (mode == 2) p = dc;
+            else p = plane_pred(&t.y[1][1], 24, 16, x, y);
+            v[k] = clip1(p + rt.y[y * 16 + x]);
+        }
+        // all lanes read the borders before anyone overwrites the tile interior (interior is not read for I16)
+#pragma unroll
+        for (int k = 0; k < 4; k++) t.y[1 + y][1 + bx * 4 + k] = (uint8_t)v[k];
+    }
+    // ---- chroma: lane -> (cx, cy), both planes ----
+    {
+        int cmode = r.modes & 3, cx = lane & 7, cy = lane >> 3;
+        int out[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            int p;
+            if (cmode == 0) {
+                int bx = cx >> 2, by = cy >> 2, st = 0, sl = 0;
+                for (int i = 0; i < 4; i++) { st += t.c[pl][0][1 + bx * 4 + i]; sl += t.c[pl][1 + by * 4 + i][0]; }
+                if (bx == by) p = (availA && availB) ? (st + sl + 4) >> 3 : (availA ? (sl + 2) >> 2 : (availB ? (st + 2) >> 2 : 128));
+                else if (bx == 1) p = availB ? (st + 2) >> 2 : (availA ? (sl + 2) >> 2 : 128);
+                else p = availA ? (sl + 2) >> 2 : (availB ? (st + 2) >> 2 : 128);
+            } else if (cmode == 1) p = t.c[pl][1 + cy][0];
+            else if (cmode == 2) p = t.c[pl][0][1 + cx];
+            else p = plane_pred(&t.c[pl][1][1], 12, 8, cx, cy);
+            out[pl] = clip1(p + rt.c[pl][cy * 8 + cx]);
+        }
+        *(uint16_t *)(dst_c + (size_t)(mby * 8 + cy) * pitch + mbx * 16 + cx * 2) = (uint16_t)(out[0] | (out[1] << 8));
+    }
+    // ---- store luma tile ----
+    {
+        int row = lane >> 2, xq = lane & 3;
+        const uint8_t *s = &t.y[1 + row][1 + xq * 4];
+        *(uint32_t *)(dst + (size_t)(mby * 16 + row) * pitch + mbx * 16 + xq * 4) = s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_recon_intra(PicParams pp) {
+    __shared__ volatile int progress[kMaxRows];
+    __shared__ IntraTile tiles[kWaves];
+    __shared__ ResTile res[kWaves];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kMaxRows; i += blockDim.x) progress[i] = 0;
+    __syncthreads();
+    // progress[row] = x of the first macroblock of the row that is NOT yet reconstructed; inter / I_PCM
+    // macroblocks were finished by k_recon_inter, so only Intra4x4 / Intra16x16 ones hold the count back.
+    for (int row = wave; row < pp.mb_h; row += kWaves) {
+        const MbRec *recs = pp.mbs + (size_t)row * pp.mb_w;
+        for (int c0 = 0; c0 < pp.mb_w; c0 += 64) {
+            int x = c0 + lane;
+            int kind = x < pp.mb_w ? recs[x].kind : MB_INTER;
+            unsigned long long m = __ballot(kind == MB_I4 || kind == MB_I16);
+            while (m) {
+                int xi = c0 + __builtin_ctzll(m);
+                m &= m - 1;
+                publish_row(progress, row, xi, lane);
+                int need = xi + 2 < pp.mb_w ? xi + 2 : pp.mb_w;
+                wait_row(progress, row - 1, need);
+                MbRec r = recs[xi];
+                intra_mb(pp, r, xi, row, tiles[wave], res[wave], lane);
+            }
+        }
+        publish_row(progress, row, pp.mb_w, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_deblock
+// ------------------------------------------------------------------------------------------
+struct MbView {                     // what bS derivation needs from one macroblock
+    bool intra; uint16_t cbp_blk; int8_t ref[4]; const short *mv; bool ext;
+};
+__device__ __forceinline__ void mv_of(const PicParams &pp, const MbRec &r, int rpos, int &mx, int &my) {
+    if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rpos) * 2; mx = m[0]; my = m[1]; }
+    else { int b8 = (rpos >> 3) * 2 + ((rpos & 3) >> 1); mx = r.u.mv[b8][0]; my = r.u.mv[b8][1]; }
+}
+__device__ int boundary_strength(const PicParams &pp, const MbRec &p, int rp, const MbRec &q, int rq, bool mb_edge) {
+    if (p.kind != MB_INTER || q.kind != MB_INTER) return mb_edge ? 4 : 3;
+    if (((p.cbp_blk >> raster_to_blk(rp)) & 1) || ((q.cbp_blk >> raster_to_blk(rq)) & 1)) return 2;
+    if (p.ref[(rp >> 3) * 2 + ((rp & 3) >> 1)] != q.ref[(rq >> 3) * 2 + ((rq & 3) >> 1)]) return 1;
+    int px, py, qx, qy; mv_of(pp, p, rp, px, py); mv_of(pp, q, rq, qx, qy);
+    return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
+}
+
+// filter one line across an edge; s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (luma) in registers
+__device__ __forceinline__ void filter_luma(int *s, int bS, int alpha, int beta, int ia) {
+    int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    int ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    if (bS < 4) {
+        int tc0 = kTc0[ia][bS - 1], tc = tc0 + ap + aq;
+        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        s[3] = clip1(p0 + delta); s[4] = clip1(q0 - delta);
+        if (ap) s[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
+        if (aq) s[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
+    } else {
+        bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap && strong) { s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; s[2] = (p2 + p1 + p0 + q0 + 2) >> 2; s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; }
+        else s[3] = (2 * p1 + p0 + q1 + 2) >> 2;
+        if (aq && strong) { s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; s[5] = (p0 + q0 + q1 + q2 + 2) >> 2; s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3; }
+        else s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
+}
+// chroma: s[0..3] = p1 p0 q0 q1
+__device__ __forceinline__ void filter_chroma(int *s, int bS, int alpha, int beta, int ia) {
+    int p1 = s[0], p0 = s[1], q0 = s[2], q1 = s[3];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (bS < 4) {
+        int tc = kTc0[ia][bS - 1] + 1;
+        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        s[1] = clip1(p0 + delta); s[2] = clip1(q0 - delta);
+    } else { s[1] = (2 * p1 + p0 + q1 + 2) >> 2; s[2] = (2 * q1 + q0 + p1 + 2) >> 2; }
+}
+
+struct DbTile {
+    uint8_t y[20][24];      // rows -4..15, cols -4..15 (+pad)
+    uint8_t c[10][24];      // interleaved UV: rows -2..7, byte cols -4..15 (chroma cols -2..7)
+    uint8_t bs[2][4][4];    // [dir][edge][segment]
+};
+
+__device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int lane) {
+    int pitch = pp.pitch, mbw = pp.mb_w;
+    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst_c = dst + pp.chroma_offset;
+    const MbRec q = pp.mbs[mby * mbw + mbx];
+    const SliceRec sl = pp.slices[q.slice];
+    if (sl.disable == 1) return;
+    bool has_left = mbx > 0, has_top = mby > 0;
+    MbRec pl_ = q, pt_ = q;
+    if (has_left) { pl_ = pp.mbs[mby * mbw + mbx - 1]; if (sl.disable == 2 && pl_.slice != q.slice) has_left = false; }
+    if (has_top) { pt_ = pp.mbs[(mby - 1) * mbw + mbx]; if (sl.disable == 2 && pt_.slice != q.slice) has_top = false; }
+    // ---- boundary strengths: lanes 0..31 -> (dir, edge, segment) ----
+    if (lane < 32) {
+        int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
+        int rq = dir == 0 ? k * 4 + e : e * 4 + k;
+        int bs;
+        if (e == 0) {
+            bool have = dir == 0 ? has_left : has_top;
+            if (!have) bs = 0;
+            else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, dir == 0 ? pl_ : pt_, rp, q, rq, true); }
+        } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
+        t.bs[dir][e][k] = (uint8_t)bs;
+    }
+    // ---- load tiles ----
+    int x0 = mbx * 16, y0 = mby * 16;
+    {   // luma 20 rows x 5 dwords = 100 dwords; rows above the picture / left of it are never used
+        for (int i = lane; i < 100; i += 64) {
+            int row = i / 5, dw = i % 5;
+            int y = y0 - 4 + row, x = x0 - 4 + dw * 4;
+            uint32_t v = 0;
+            if (y >= 0 && x >= 0) v = *(const uint32_t *)(dst + (size_t)y * pitch + x);
+            *(uint32_t *)&t.y[row][dw * 4] = v;
+        }
+        for (int i = lane; i < 50; i += 64) {   // chroma 10 rows x 5 dwords
+            int row = i / 5, dw = i % 5;
+            int y = mby * 8 - 2 + row, x = x0 - 4 + dw * 4;
+            uint32_t v = 0;
+            if (y >= 0 && x >= 0) v = *(const uint32_t *)(dst_c + (size_t)y * pitch + x);
+            *(uint32_t *)&t.c[row][dw * 4] = v;
+        }
+    }
+    // ---- luma vertical edges: lane = pixel row ----
+    int qp_q = q.qp;
+    if (lane < 16) {
+        for (int e = 0; e < 4; e++) {
+            int bs = t.bs[0][e][lane >> 2];
+            if (!bs) continue;
+            int qp_p = e == 0 ? pl_.qp : qp_q;
+            int qpav = (qp_p + qp_q + 1) >> 1;
+            int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+            int s[8];
+            uint8_t *px = &t.y[4 + lane][e * 4];          // p3 is at tile col e*4 (= MB col e*4-4)
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = px[k];
+            filter_luma(s, bs, kAlpha[ia], kBeta[ib], ia);
+#pragma unroll
+            for (int k = 1; k < 7; k++) px[k] = (uint8_t)s[k];
+        }
+    }
+    // ---- luma horizontal edges: lane = pixel column ----
+    if (lane < 16) {
+        for (int e = 0; e < 4; e++) {
+            int bs = t.bs[1][e][lane >> 2];
+            if (!bs) continue;
+            int qp_p = e == 0 ? pt_.qp : qp_q;
+            int qpav = (qp_p + qp_q + 1) >> 1;
+            int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+            int s[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = t.y[e * 4 + k][4 + lane];
+            filter_luma(s, bs, kAlpha[ia], kBeta[ib], ia);
+#pragma unroll
+            for (int k = 1; k < 7; k++) t.y[e * 4 + k][4 + lane] = (uint8_t)s[k];
+        }
+    }
+    // ---- chroma vertical edges (chroma x = 0, 4 <-> luma edges 0, 2): lane = (plane, chroma row) ----
+    if (lane < 16) {
+        int plane = lane >> 3, row = lane & 7;
+        int qc_q = chroma_qp(q.qp, plane ? pp.cr_qp_off : pp.cb_qp_off);
+        for (int e = 0; e < 4; e += 2) {
+            int bs = t.bs[0][e][row >> 1];
+            if (!bs) continue;
+            int qc_p = e == 0 ? chroma_qp(pl_.qp, plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
+            int qpav = (qc_p + qc_q + 1) >> 1;
+            int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+            int s[4];
+            uint8_t *px = &t.c[2 + row][4 + (e * 2) * 2 + plane];     // q0 of this plane at chroma col e*2
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = px[(k - 2) * 2];
+            filter_chroma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            px[-2] = (uint8_t)s[1]; px[0] = (uint8_t)s[2];
+        }
+    }
+    // ---- chroma horizontal edges: lane = interleaved byte column (plane = lane & 1) ----
+    if (lane < 16) {
+        int plane = lane & 1, ccol = lane >> 1;
+        int qc_q = chroma_qp(q.qp, plane ? pp.cr_qp_off : pp.cb_qp_off);
+        for (int e = 0; e < 4; e += 2) {
+            int bs = t.bs[1][e][ccol >> 1];
+            if (!bs) continue;
+            int qc_p = e == 0 ? chroma_qp(pt_.qp, plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
+            int qpav = (qc_p + qc_q + 1) >> 1;
+            int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+            int s[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = t.c[e * 2 + k][4 + lane];          // rows (e*2-2 .. e*2+1) + 2
+            filter_chroma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            t.c[e * 2 + 1][4 + lane] = (uint8_t)s[1]; t.c[e * 2 + 2][4 + lane] = (uint8_t)s[2];
+        }
+    }
+    // ---- write back (rows -3..15 luma, -1..7 chroma; whole 20-byte rows where they exist) ----
+    for (int i = lane; i < 100; i += 64) {
+        int row = i / 5, dw = i % 5;
+        int y = y0 - 4 + row, x = x0 - 4 + dw * 4;
+        if (row >= 1 && y >= 0 && x >= 0) *(uint32_t *)(dst + (size_t)y * pitch + x) = *(const uint32_t *)&t.y[row][dw * 4];
+    }
+    for (int i = lane; i < 50; i += 64) {
+        int row = i / 5, dw = i % 5;
+        int y = mby * 8 - 2 + row, x = x0 - 4 + dw * 4;
+        if (row >= 1 && y >= 0 && x >= 0) *(uint32_t *)(dst_c + (size_t)y * pitch + x) = *(const uint32_t *)&t.c[row][dw * 4];
+    }
+}
+
+__global__ __launch_bounds__(kWaves * 64) void k_deblock(PicParams pp) {
+    __shared__ volatile int progress[kMaxRows];
+    __shared__ DbTile tiles[kWaves];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kMaxRows; i += blockDim.x) progress[i] = 0;
+    __syncthreads();
+    for (int row = wave; row < pp.mb_h; row += kWaves) {
+        for (int x = 0; x < pp.mb_w; x++) {
+            int need = x + 2 < pp.mb_w ? x + 2 : pp.mb_w;
+            wait_row(progress, row - 1, need);
+            deblock_mb(pp, x, row, tiles[wave], lane);
+            publish_row(progress, row, x + 1, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_packout: restates jm_nvdec_output_frame (nv_dec.cpp:782-820) on the device.
+// out_fmt 0: tight NV12; out_fmt 1: Y plane, U plane, V plane ("YV12" in the reference's words, I420 order).
+// One thread moves 16 source bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_packout(const uint8_t *src, int pitch, int chroma_offset, int width, int height,
+                                                 int out_fmt, uint8_t *dst) {
+    int chunks_per_row = (width + 15) >> 4;
+    int luma_chunks = chunks_per_row * height;
+    int h2 = height >> 1, w2 = width >> 1;
+    int total = luma_chunks + chunks_per_row * h2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        bool chroma = i >= luma_chunks;
+        int j = chroma ? i - luma_chunks : i;
+        int row = j / chunks_per_row, x = (j % chunks_per_row) * 16;
+        const uint8_t *s = src + (chroma ? chroma_offset : 0) + (size_t)row * pitch + x;
+        int n = width - x < 16 ? width - x : 16;
+        if (!chroma || out_fmt == 0) {
+            uint8_t *d = dst + (chroma ? (size_t)width * height : 0) + (size_t)row * width + x;
+            if (n == 16 && ((((uintptr_t)d) & 15) == 0)) *(uint4 *)d = *(const uint4 *)s;
+            else for (int k = 0; k < n; k++) d[k] = s[k];
+        } else {
+            uint8_t *du = dst + (size_t)width * height + (size_t)row * w2 + (x >> 1);
+            uint8_t *dv = du + (size_t)w2 * h2;
+            if (n == 16 && ((((uintptr_t)du) & 7) == 0) && ((((uintptr_t)dv) & 7) == 0)) {
+                uint4 v = *(const uint4 *)s;
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t u[2], vv[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    uint32_t a = w[2 * k], b = w[2 * k + 1];
+                    u[k] = (a & 0xff) | ((a >> 8) & 0xff00) | ((b & 0xff) << 16) | ((b << 8) & 0xff000000u);
+                    vv[k] = ((a >> 8) & 0xff) | ((a >> 16) & 0xff00) | ((b << 8) & 0xff0000) | (b & 0xff000000u);
+                }
+                *(uint2 *)du = make_uint2(u[0], u[1]); *(uint2 *)dv = make_uint2(vv[0], vv[1]);
+            } else for (int k = 0; k < n / 2; k++) { du[k] = s[2 * k]; dv[k] = s[2 * k + 1]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void launch_recon_inter(const PicParams &pp, hipStream_t st) {
+    int n = pp.mb_w * pp.mb_h;
+    hipLaunchKernelGGL(k_recon_inter, dim3((n + 3) / 4), dim3(256), 0, st, pp);
+}
+void launch_recon_intra(const PicParams &pp, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1), dim3(kWaves * 64), 0, st, pp); }
+void launch_deblock(const PicParams &pp, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1), dim3(kWaves * 64), 0, st, pp); }
+void launch_packout(const uint8_t *src, int pitch, int chroma_offset, int width, int height, int out_fmt, uint8_t *dst, hipStream_t st) {
+    int chunks = ((width + 15) >> 4) * (height + (height >> 1));
+    int blocks = (chunks + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_packout, dim3(blocks), dim3(256), 0, st, src, pitch, chroma_offset, width, height, out_fmt, dst);
+}
+
+}  // namespace jmamd

@@ -1,0 +1,117 @@
+"""Seeded synthetic Annex-B streams (tools/h264gen.c) and the CPU-oracle binding used by tests/bench.
+
+Neither is part of the decode product: the generator makes inputs (the reference ships none,
+SURVEY.md section 4) and ``Oracle`` wraps oracle/ for the checker / cpu_baseline legs only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class GenParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "width", "height", "frames", "qp", "gop", "seed", "mode", "deblock", "num_ref", "slices",
+        "pcm_only", "poc_type", "nonref_period", "alpha_off", "beta_off", "chroma_qp_off", "level_idc",
+        "cip", "search")]
+
+
+def build_tools():
+    subprocess.check_call(["make", "-C", os.path.join(_ROOT, "tools")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+_gen = None
+
+
+def _genlib():
+    global _gen
+    if _gen is None:
+        p = os.path.join(_ROOT, "tools", "_build", "libh264gen.so")
+        if not os.path.exists(p):
+            build_tools()
+        _gen = C.CDLL(p)
+        _gen.h264gen_generate.argtypes = [C.POINTER(GenParams), C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t), C.c_char_p]
+        _gen.h264gen_free.argtypes = [C.c_void_p]
+    return _gen
+
+
+def generate(width=64, height=48, frames=4, qp=28, gop=30, seed=0x4A4D0100, mode=0, deblock=1, num_ref=1,
+             slices=1, pcm_only=0, poc_type=2, nonref_period=0, alpha_off=0, beta_off=0, chroma_qp_off=0,
+             level_idc=0, cip=0, search=4, recon_path=None):
+    """Returns the Annex-B stream as bytes (optionally writing the encoder's own reconstruction)."""
+    p = GenParams(width, height, frames, qp, gop, seed, mode, deblock, num_ref, slices, pcm_only, poc_type,
+                  nonref_period, alpha_off, beta_off, chroma_qp_off, level_idc, cip, search)
+    buf = C.POINTER(C.c_ubyte)()
+    n = C.c_size_t(0)
+    rc = _genlib().h264gen_generate(C.byref(p), C.byref(buf), C.byref(n), recon_path.encode() if recon_path else None)
+    if rc != 0:
+        raise ValueError("h264gen: bad parameters")
+    data = C.string_at(buf, n.value)
+    _genlib().h264gen_free(buf)
+    return data
+
+
+# BASELINE.json configs restated as generator parameters; seed = 0x4A4D0000 + config*256 + stream
+def config_c1(stream_id=0, frames=300, width=1920, height=1080):
+    return dict(width=width, height=height, frames=frames, qp=28, gop=30, seed=0x4A4D0000 + 1 * 256 + stream_id,
+                mode=0, deblock=1, num_ref=1, level_idc=40)
+
+
+class Oracle:
+    """ctypes binding of oracle/_build/liborc.so (CPU oracle -- checker / cpu_baseline only)."""
+
+    def __init__(self):
+        p = os.path.join(_ROOT, "oracle", "_build", "liborc.so")
+        if not os.path.exists(p):
+            build_tools()
+        L = C.CDLL(p)
+        L.orc_decode_stream_to_buffer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)),
+                                                  C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_open.restype = C.c_void_p
+        L.orc_open.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_close.argtypes = [C.c_void_p]
+        L.orc_decode_annexb.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.orc_flush.argtypes = [C.c_void_p]
+        L.orc_digest_enable.argtypes = [C.c_void_p]
+        L.orc_digest_value.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orc_digest_value.restype = C.c_uint64
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_packout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        self.L = L
+
+    def decode(self, data, out_fmt=1):
+        """Returns (frames_bytes, n_frames, width, height): all display-order frames concatenated."""
+        buf = C.POINTER(C.c_ubyte)()
+        n = C.c_size_t(0)
+        w, h = C.c_int(0), C.c_int(0)
+        cnt = self.L.orc_decode_stream_to_buffer(data, len(data), out_fmt, C.byref(buf), C.byref(n), C.byref(w), C.byref(h))
+        if cnt < 0:
+            raise RuntimeError("oracle decode failed")
+        out = C.string_at(buf, n.value) if n.value else b""
+        self.L.orc_free(buf)
+        return out, cnt, w.value, h.value
+
+    def syntax_digest(self, data):
+        """(digest, n_macroblocks) of the parsed syntax elements (see oracle/orc_slice.c digest_mb)."""
+        d = self.L.orc_open(None, None)
+        self.L.orc_digest_enable(d)
+        rc = self.L.orc_decode_annexb(d, data, len(data))
+        err = self.L.orc_last_error(d).decode()
+        self.L.orc_flush(d)
+        n = C.c_uint64(0)
+        v = self.L.orc_digest_value(d, C.byref(n))
+        self.L.orc_close(d)
+        if rc < 0:
+            raise RuntimeError("oracle: " + err)
+        return v, n.value
+
+    def packout(self, src, pitch, width, height, out_fmt):
+        cap = width * height * 3 // 2
+        dst = C.create_string_buffer(cap)
+        n = C.c_int(cap)
+        rc = self.L.orc_packout(src, pitch, width, height, out_fmt, dst, C.byref(n))
+        return rc, dst.raw[:n.value]

@@ -333,6 +333,8 @@ void orc_close(OrcDec *d) {
     free_pictures(d); free(d->rbsp); free(d);
 }
 const char *orc_last_error(const OrcDec *d) { return d->err; }
+void orc_digest_enable(OrcDec *d) { d->digest_on = 1; d->digest = 1469598103934665603ull; d->digest_mbs = 0; }
+uint64_t orc_digest_value(const OrcDec *d, uint64_t *n) { if (n) *n = d->digest_mbs; return d->digest; }
 
 int orc_stream_info(const OrcDec *d, int *dw, int *dh, int *cw, int *ch) {
     if (!d->asps) return -1;

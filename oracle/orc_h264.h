@@ -76,6 +76,10 @@ int  orc_decode_stream_to_buffer(const uint8_t *buf, size_t len, int out_fmt,
                                  uint8_t **out, size_t *out_len, int *w, int *h);
 void orc_free(void *p);
 
+/* Syntax digest (tests only): FNV-1a over every parsed macroblock's syntax elements. */
+void orc_digest_enable(OrcDec *d);
+uint64_t orc_digest_value(const OrcDec *d, uint64_t *n_mbs);
+
 /* ---- pack-out restatement (orc_packout.c) ------------------------------ */
 /* Byte-for-byte restatement of jm_nvdec_output_frame (nv_dec.cpp:750-828):
  * src is pitch-linear NV12 (luma pitch*height, then interleaved UV rows at

@@ -169,6 +169,7 @@ struct OrcDec {
     uint8_t *rbsp; size_t rbsp_cap;
     int last_poc_out;
     uint8_t *outbuf; /* crop scratch */
+    int digest_on; uint64_t digest; uint64_t digest_mbs;
 };
 
 /* orc_parse.c */
