@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded frames/sec @1080p H.264 on N x MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one pass of the hot path over one batch: S independent 1080p Baseline I/P streams
+(BASELINE config 1 / SURVEY 8d "C1", the per-GPU slice of config C4) of F frames each, decoded
+concurrently by S jm_nvdec handles on this rank's GPU, fed NAL-by-NAL exactly like the reference
+harness (test_nv_dec.cpp:184-250).  `value` = frames displayed by all ranks / wall time of the K timed
+steps (barrier + device sync on both sides, max over ranks).
+
+The boundary hands over HOST buffers (Annex-B bytes in, tight YUV out), so `value` is the end-to-end rate:
+host entropy decode + H2D job lists + kernels + pack-out + D2H + the memcpy into the caller's buffer.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("JM_BENCH_STREAMS", "8")))
+    ap.add_argument("--frames", type=int, default=60, help="frames per stream per step (multiple of the GOP, 30)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "jmcodec_amd", "lib", "libjm_amd_dec.so")):
+        ge.build()
+    import jmcodec_amd
+    from jmcodec_amd import streams
+    L = jmcodec_amd.lib()
+    if not jmcodec_amd.jm_nvdec_is_hw_support():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+
+    # ---- synthetic input: SURVEY 8d C1, seed = 0x4A4D0000 + 1*256 + stream_id (stream_id = rank) ----
+    cfg = streams.config_c1(stream_id=rank, frames=args.frames, width=args.width, height=args.height)
+    data = streams.generate(**cfg)
+    nalus = jmcodec_amd.split_nalus(data)
+    S, F, K, W = args.streams, args.frames, args.steps, args.warmup
+    mb_w, mb_h = (args.width + 15) // 16, (args.height + 15) // 16
+    frame_bytes = args.width * args.height * 3 // 2
+
+    handles = []
+    for _ in range(S):
+        h = jmcodec_amd.jm_nvdec_create_handle()
+        L.jm_amddec_set_option(h, b"profile", 1)
+        if jmcodec_amd.jm_nvdec_init(0, 1, None, 0, h) != 0:
+            raise SystemExit("init failed: " + L.jm_amddec_last_error(h).decode())
+        handles.append(h)
+
+    counts = [0] * S
+
+    def run_passes(i, passes):
+        """test_nv_dec's hot loop: one NAL per jm_nvdec_decode_frame call, pull a frame whenever got_frame == 1."""
+        h = handles[i]
+        out = C.create_string_buffer(frame_bytes)
+        got = C.c_int(0)
+        n = C.c_int(0)
+        cnt = 0
+        for _ in range(passes):
+            for nal in nalus:
+                L.jm_amddec_decode_frame(C.cast(C.c_char_p(nal), C.c_void_p), len(nal), C.byref(got), h)
+                if got.value == 1:
+                    n.value = frame_bytes
+                    if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
+                        cnt += 1
+        # let the pipeline run dry (no EOS: the handle keeps its DPB) and collect what it finished
+        L.jm_amddec_set_option(h, b"wait_idle", 1)
+        sc = b"\x00\x00\x01\x09\x10"          # an access-unit delimiter: carries no picture, lets us poll for frames
+        while True:
+            L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
+            if got.value != 1:
+                break
+            n.value = frame_bytes
+            if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
+                cnt += 1
+        counts[i] += cnt
+
+    def batch(passes):
+        ts = [threading.Thread(target=run_passes, args=(i, passes)) for i in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if W > 0:
+        batch(W)
+    prof0 = [[L.jm_amddec_get_stat(h, f"k_{k}_{s}".encode()) for k in ("inter", "intra", "deblock", "packout") for s in ("ns", "n")] for h in handles]
+    jb0 = [L.jm_amddec_get_stat(h, b"job_bytes") for h in handles]
+    pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
+    for i in range(S):
+        counts[i] = 0
+    sync()
+    t0 = time.perf_counter()
+    batch(K)
+    sync()
+    dt = time.perf_counter() - t0
+    frames_local = sum(counts)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        f = torch.tensor([frames_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        frames_total = int(f.item())
+    else:
+        dt_max, frames_total = dt, frames_local
+
+    # ---- per-kernel device time (HIP events on each handle's own decode stream, timed region only) ----
+    names = ("inter", "intra", "deblock", "packout")
+    tot_ns = {k: 0 for k in names}
+    tot_n = {k: 0 for k in names}
+    for hi, h in enumerate(handles):
+        for ki, k in enumerate(names):
+            tot_ns[k] += L.jm_amddec_get_stat(h, f"k_{k}_ns".encode()) - prof0[hi][2 * ki]
+            tot_n[k] += L.jm_amddec_get_stat(h, f"k_{k}_n".encode()) - prof0[hi][2 * ki + 1]
+    job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
+    pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
+    errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
+    threads = L.jm_amddec_get_stat(handles[0], b"threads")
+
+    # algorithmic bytes per launch (DESIGN.md "Kernels"): Wc x Hc coded, Wd x Hd display
+    surf = 1.5 * mb_w * 16 * mb_h * 16
+    J = job_bytes / max(pictures, 1)
+    p_frac = (F - F // 30) / F if F >= 30 else 1.0
+    alg = {
+        "inter": p_frac * (2 * surf) + J,          # each reference sample read once + each sample written once (P pictures) + job list
+        "intra": (1.0 - p_frac) * surf,            # samples of intra pictures written once
+        "deblock": 2 * surf,                       # every sample read once and written once
+        "packout": surf + frame_bytes,             # surface read once, tight frame written once
+    }
+    dominant = max(names, key=lambda k: tot_ns[k])
+    avg_s = {k: (tot_ns[k] * 1e-9 / tot_n[k]) if tot_n[k] else 0.0 for k in names}
+    peak = 8000.0
+    achieved = alg[dominant] / avg_s[dominant] / 1e9 if avg_s[dominant] > 0 else 0.0
+    # frame-level contract figure of SURVEY 8(d): A = 1.5*Wc*Hc*(n_ref+1) + 1.5*Wd*Hd + J per frame
+    A = surf * (p_frac * 2 + (1 - p_frac) * 1) + frame_bytes + J
+    kernel_s_per_frame = sum(tot_ns[k] for k in names) * 1e-9 / max(pictures, 1)
+
+    # drain + tear down (outside the timed region)
+    for h in handles:
+        L.jm_amddec_decode_frame(None, 0, C.byref(C.c_int(0)), h)
+        jmcodec_amd.jm_nvdec_deinit(h)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the build's own scalar CPU oracle (NOT libmfx: unobtainable),
+        # one core, on a bounded sample of the same workload.
+        o = streams.Oracle()
+        sample_frames = min(F, 90)
+        sample = streams.generate(**dict(cfg, frames=sample_frames)) if sample_frames != F else data
+        reps, c0, n_dec = 0, time.perf_counter(), 0
+        while True:
+            _, n, _, _ = o.decode(sample, 1)
+            n_dec += n
+            reps += 1
+            if time.perf_counter() - c0 > 10.0 or reps >= 8:
+                break
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(n_dec / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} x the first {sample_frames} frames of the same {args.width}x{args.height} stream, "
+                         f"build CPU oracle (scalar, spec-literal; not libmfx), {cdt:.1f}s of CPU work",
+               "host_cpus": os.cpu_count()}
+
+    value = frames_total / dt_max
+    line = {
+        "metric": "decoded frames/sec @1080p H.264 + bit-exact YUV",
+        "value": round(value, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(dt_max * 1000.0 / K, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"H.264 Baseline {args.width}x{args.height} I/P-only (CAVLC, IDR every 30, QP 28, deblock on), "
+                               f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
+                   "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
+                   "host_parse_threads": int(threads), "includes": "host CAVLC + H2D + kernels + packout + D2H + memcpy to caller"},
+        "frames": frames_total,
+        "decode_errors": int(errors),
+        "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
+                     "frac": round(achieved / peak, 6), "traffic": None,
+                     "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
+                     "launches": int(tot_n[dominant])},
+        "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2),
+                                 "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
+        "roofline_frame": {"alg_bytes_per_frame": int(A), "job_bytes_per_frame": int(J),
+                           "end_to_end_GBps": round(value / world * A / 1e9, 3), "end_to_end_frac": round(value / world * A / 1e9 / peak, 6),
+                           "kernel_time_GBps": round(A / kernel_s_per_frame / 1e9, 3) if kernel_s_per_frame > 0 else None},
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

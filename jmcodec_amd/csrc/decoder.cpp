@@ -66,6 +66,12 @@ int Decoder::set_option(const char *key, long long v) {
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
     else if (k == "sync") sync_mode_ = v != 0;
     else if (k == "device") device_ = (int)v;
+    else if (k == "profile") profile_ = v != 0;
+    else if (k == "wait_idle") {      // block until every dispatched picture has been executed by the device (no flush)
+        dispatch_pending();
+        { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
+        if (!parse_only_ && gpu_open_) { hipSetDevice(device_); hipStreamSynchronize(stream_); }
+    }
     else return -1;
     return 0;
 }
@@ -87,6 +93,11 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "device") return device_;
     if (k == "threads") return pool_threads();
     if (k == "elapsed_us") return (long long)(elapsed_ms_ * 1000.0);
+    static const char *kn[4] = {"inter", "intra", "deblock", "packout"};
+    for (int i = 0; i < 4; i++) {
+        if (k == std::string("k_") + kn[i] + "_ns") return (long long)(prof_us_[i] * 1000.0);
+        if (k == std::string("k_") + kn[i] + "_n") return prof_n_[i];
+    }
     if (k.rfind("display_poc:", 0) == 0) { size_t i = (size_t)atoll(k.c_str() + 12); return i < display_pocs_.size() ? display_pocs_[i] : -1; }
     return -1;
 }
@@ -133,12 +144,14 @@ void Decoder::gpu_free_sequence() {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
         if (j.done) hipEventDestroy(j.done);
+        for (auto e : j.pev) if (e) hipEventDestroy(e);
         j = JobSlot();
     }
     for (OutSlot *o : all_out_) {
         if (o->host) hipHostFree(o->host);
         if (o->dev) hipFree(o->dev);
         if (o->done) hipEventDestroy(o->done);
+        for (auto e : o->pev) if (e) hipEventDestroy(e);
         delete o;
     }
     all_out_.clear(); free_out_.clear(); ready_.clear(); cur_out_ = nullptr;
@@ -171,6 +184,7 @@ bool Decoder::gpu_alloc_sequence() {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
             !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
+        if (profile_) for (auto &e : j.pev) hipEventCreate(&e);
     }
     return true;
 }
@@ -182,6 +196,7 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
         hipSetDevice(device_);
         if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_)) ||
             !HIP_OK(hipEventCreateWithFlags(&o->done, hipEventDisableTiming))) { fail("output buffer allocation failed"); }
+        if (profile_) for (auto &e : o->pev) hipEventCreate(&e);
     }
     all_out_.push_back(o);
     return o;
@@ -500,12 +515,27 @@ void Decoder::dispatch_pending() {
     push_task(std::move(t));
 }
 
+// profile option: per-kernel device time from HIP events recorded on the decode stream itself
+void Decoder::harvest_job(JobSlot &j) {                  // mtx_ held, j.done known complete
+    if (!profile_ || !j.pev[0]) return;
+    for (int k = 0; k < 3; k++) if (j.pmask & (1 << k)) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, j.pev[k], j.pev[k + 1]) == hipSuccess) { prof_us_[k] += ms * 1000.0; prof_n_[k]++; }
+    }
+    j.pmask = 0;
+}
+void Decoder::harvest_out(OutSlot &o) {
+    if (!profile_ || !o.pev[0]) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, o.pev[0], o.pev[1]) == hipSuccess) { prof_us_[3] += ms * 1000.0; prof_n_[3]++; }
+}
+
 int Decoder::acquire_job_slot() {
     std::unique_lock<std::mutex> lk(mtx_);
     for (;;) {
         for (int i = 0; i < kJobSlots; i++) {
             JobSlot &j = jobs_[i];
-            if (j.busy && j.submitted && (parse_only_ || hipEventQuery(j.done) == hipSuccess)) { j.busy = false; j.submitted = false; }
+            if (j.busy && j.submitted && (parse_only_ || hipEventQuery(j.done) == hipSuccess)) { harvest_job(j); j.busy = false; j.submitted = false; }
             if (!j.busy) { j.busy = true; j.submitted = false; return i; }
         }
         // all busy: wait for the device (if something is submitted) or for a worker
@@ -603,7 +633,9 @@ void Decoder::enqueue_output(int slot) {
     OutSlot *o;
     { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); }
     if (!parse_only_ && !failed_) {
+        if (profile_) hipEventRecord(o->pev[0], stream_);
         launch_packout(surf_[slot], pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, o->dev, stream_);
+        if (profile_) hipEventRecord(o->pev[1], stream_);
         hipMemcpyAsync(o->host, o->dev, frame_bytes_, hipMemcpyDeviceToHost, stream_);
         hipEventRecord(o->done, stream_);
         o->has_data = true;
@@ -628,9 +660,14 @@ void Decoder::submit_task(PicTask *t) {
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
+        js.pmask = 1 | (t->n_intra > 0 ? 2 : 0) | (t->any_deblock ? 4 : 0);
+        if (profile_) hipEventRecord(js.pev[0], stream_);
         launch_recon_inter(pp, stream_);
+        if (profile_) hipEventRecord(js.pev[1], stream_);
         if (t->n_intra > 0) launch_recon_intra(pp, stream_);
+        if (profile_) hipEventRecord(js.pev[2], stream_);
         if (t->any_deblock) launch_deblock(pp, stream_);
+        if (profile_) hipEventRecord(js.pev[3], stream_);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
         hipEventRecord(js.done, stream_);
@@ -652,6 +689,7 @@ int Decoder::pop_output(bool block) {
                 else if (hipEventQuery(o->done) != hipSuccess) return 0;
             }
             ready_.pop_front();
+            if (o->has_data) harvest_out(*o);
             cur_out_ = o;
             return 1;
         }
@@ -678,6 +716,7 @@ int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {
         bool drained;
         { std::lock_guard<std::mutex> lk(mtx_); drained = outstanding_ == 0 && ready_.empty(); }
         if (drained && eos_sent_ && !is_exit_) {            // nv_dec.cpp:460-466
+            if (profile_ && !parse_only_) { hipSetDevice(device_); hipStreamSynchronize(stream_); std::lock_guard<std::mutex> lk(mtx_); for (auto &j : jobs_) if (j.busy && j.submitted) { harvest_job(j); j.busy = false; j.submitted = false; } }
             elapsed_ms_ = timer_started_ ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count() : 0.0;
             is_exit_ = true;
             snprintf(info_, sizeof info_,

@@ -56,11 +56,14 @@ struct PicTask {
 struct JobSlot {
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
     ihipEvent_t *done = nullptr;
+    ihipEvent_t *pev[4] = {nullptr, nullptr, nullptr, nullptr};   // profile option: before inter / intra / deblock, after deblock
+    int pmask = 0;                                                // bit k: kernel k was launched for the picture in this slot
     bool busy = false, submitted = false;
 };
 struct OutSlot {
     uint8_t *host = nullptr, *dev = nullptr;
     ihipEvent_t *done = nullptr;
+    ihipEvent_t *pev[2] = {nullptr, nullptr};                     // profile option: around k_packout
     bool has_data = false;
 };
 
@@ -113,7 +116,10 @@ private:
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1;
-    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false;
+    void harvest_job(JobSlot &j);
+    void harvest_out(OutSlot &o);
+    double prof_us_[4] = {0, 0, 0, 0}; long long prof_n_[4] = {0, 0, 0, 0};   // inter, intra, deblock, packout
     std::string error_;
     bool failed_ = false, inited_ = false;
 
