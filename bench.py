@@ -87,9 +87,17 @@ def main():
                     n.value = frame_bytes
                     if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
                         cnt += 1
-        # let the pipeline run dry (no EOS: the handle keeps its DPB) and collect what it finished
+        # let the pipeline run dry (no EOS: the handle keeps its DPB) and collect what it finished.
+        # An access-unit delimiter carries no picture; two of them push the last slice NAL out of the
+        # splitter (a NAL ends at the next start code) and close the picture (7.4.1.2.3).
+        sc = b"\x00\x00\x01\x09\x10"
+        for _ in range(2):
+            L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
+            if got.value == 1:
+                n.value = frame_bytes
+                if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
+                    cnt += 1
         L.jm_amddec_set_option(h, b"wait_idle", 1)
-        sc = b"\x00\x00\x01\x09\x10"          # an access-unit delimiter: carries no picture, lets us poll for frames
         while True:
             L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
             if got.value != 1:

@@ -22,8 +22,22 @@ __device__ __forceinline__ int clip1(int v) { return v < 0 ? 0 : (v > 255 ? 255 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 
-__device__ const uint8_t kNorm4[6][3] = { {10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23} };
-__device__ const uint8_t kQpcTab[22] = {29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39};
+// Small tables are packed into 64-bit immediates so that a lookup is a shift, not a dependent memory
+// access inside the serial wavefront chains.
+// normAdjust4x4 (8.5.9) by qP%6: class 0 (even,even) {10,11,13,14,16,18}, class 1 (odd,odd) {16,18,20,23,25,29}, class 2 {13,14,16,18,20,23}
+__device__ __forceinline__ int norm4(int qp_rem, int cls) {
+    unsigned long long t = cls == 0 ? 0x12100E0D0B0AULL : (cls == 1 ? 0x1D1917141210ULL : 0x171412100E0DULL);
+    return (int)((t >> (8 * qp_rem)) & 0xff);
+}
+// Table 8-15: QPc for qPI = 30..51 : 29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39 (stored minus 29, 4 bits each)
+__device__ __forceinline__ int qpc_from_qpi(int qpi) {
+    if (qpi < 30) return qpi;
+    int k = qpi - 30;
+    unsigned long long lo = 0x9888776655433210ULL;                   // entries 0..15, 4 bits each
+    unsigned int hi = 0xAAAA99u;                                     // entries 16..21
+    int v = k < 16 ? (int)((lo >> (4 * k)) & 15) : (int)((hi >> (4 * (k - 16))) & 15);
+    return 29 + v;
+}
 __device__ const uint8_t kAlpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,
     32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
 __device__ const uint8_t kBeta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,
@@ -35,14 +49,13 @@ __device__ const uint8_t kTc0[52][3] = {
  {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
 
 __device__ __forceinline__ int chroma_qp(int qpy, int off) {
-    int q = clip3(0, 51, qpy + off);
-    return q < 30 ? q : kQpcTab[q - 30];
+    return qpc_from_qpi(clip3(0, 51, qpy + off));
 }
 // LevelScale4x4 with the flat (16) weight matrix: 16 * normAdjust4x4 (8.5.9)
 __device__ __forceinline__ int level_scale4(int qp_rem, int pos) {
     int i = pos >> 2, j = pos & 3;
     int cls = (!(i & 1) && !(j & 1)) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
-    return 16 * kNorm4[qp_rem][cls];
+    return 16 * norm4(qp_rem, cls);
 }
 // 8.5.12.1 scaling of one residual coefficient (not the separately handled DC ones)
 __device__ __forceinline__ int dequant4(int c, int qp, int pos) {
@@ -474,12 +487,12 @@ __device__ int boundary_strength(const PicParams &pp, const MbRec &p, int rp, co
 }
 
 // filter one line across an edge; s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (luma) in registers
-__device__ __forceinline__ void filter_luma(int *s, int bS, int alpha, int beta, int ia) {
+__device__ __forceinline__ void filter_luma(int *s, int bS, int alpha, int beta, const uint8_t *tc0_row) {
     int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
     if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
     int ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
     if (bS < 4) {
-        int tc0 = kTc0[ia][bS - 1], tc = tc0 + ap + aq;
+        int tc0 = tc0_row[bS - 1], tc = tc0 + ap + aq;
         int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         s[3] = clip1(p0 + delta); s[4] = clip1(q0 - delta);
         if (ap) s[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
@@ -493,23 +506,24 @@ __device__ __forceinline__ void filter_luma(int *s, int bS, int alpha, int beta,
     }
 }
 // chroma: s[0..3] = p1 p0 q0 q1
-__device__ __forceinline__ void filter_chroma(int *s, int bS, int alpha, int beta, int ia) {
+__device__ __forceinline__ void filter_chroma(int *s, int bS, int alpha, int beta, const uint8_t *tc0_row) {
     int p1 = s[0], p0 = s[1], q0 = s[2], q1 = s[3];
     if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
     if (bS < 4) {
-        int tc = kTc0[ia][bS - 1] + 1;
+        int tc = tc0_row[bS - 1] + 1;
         int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         s[1] = clip1(p0 + delta); s[2] = clip1(q0 - delta);
     } else { s[1] = (2 * p1 + p0 + q1 + 2) >> 2; s[2] = (2 * q1 + q0 + p1 + 2) >> 2; }
 }
 
+struct DbTables { uint8_t alpha[52], beta[52], tc0[52][3]; };   // LDS copy of Tables 8-16 / 8-17
 struct DbTile {
     uint8_t y[20][24];      // rows -4..15, cols -4..15 (+pad)
     uint8_t c[10][24];      // interleaved UV: rows -2..7, byte cols -4..15 (chroma cols -2..7)
     uint8_t bs[2][4][4];    // [dir][edge][segment]
 };
 
-__device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int lane) {
+__device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, const DbTables &tb, int lane) {
     int pitch = pp.pitch, mbw = pp.mb_w;
     uint8_t *dst = pp.surf[pp.cur];
     uint8_t *dst_c = dst + pp.chroma_offset;
@@ -563,7 +577,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int
             uint8_t *px = &t.y[4 + lane][e * 4];          // p3 is at tile col e*4 (= MB col e*4-4)
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = px[k];
-            filter_luma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            filter_luma(s, bs, tb.alpha[ia], tb.beta[ib], tb.tc0[ia]);
 #pragma unroll
             for (int k = 1; k < 7; k++) px[k] = (uint8_t)s[k];
         }
@@ -579,7 +593,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int
             int s[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = t.y[e * 4 + k][4 + lane];
-            filter_luma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            filter_luma(s, bs, tb.alpha[ia], tb.beta[ib], tb.tc0[ia]);
 #pragma unroll
             for (int k = 1; k < 7; k++) t.y[e * 4 + k][4 + lane] = (uint8_t)s[k];
         }
@@ -598,7 +612,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int
             uint8_t *px = &t.c[2 + row][4 + (e * 2) * 2 + plane];     // q0 of this plane at chroma col e*2
 #pragma unroll
             for (int k = 0; k < 4; k++) s[k] = px[(k - 2) * 2];
-            filter_chroma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            filter_chroma(s, bs, tb.alpha[ia], tb.beta[ib], tb.tc0[ia]);
             px[-2] = (uint8_t)s[1]; px[0] = (uint8_t)s[2];
         }
     }
@@ -615,7 +629,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int
             int s[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) s[k] = t.c[e * 2 + k][4 + lane];          // rows (e*2-2 .. e*2+1) + 2
-            filter_chroma(s, bs, kAlpha[ia], kBeta[ib], ia);
+            filter_chroma(s, bs, tb.alpha[ia], tb.beta[ib], tb.tc0[ia]);
             t.c[e * 2 + 1][4 + lane] = (uint8_t)s[1]; t.c[e * 2 + 2][4 + lane] = (uint8_t)s[2];
         }
     }
@@ -635,14 +649,17 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, int
 __global__ __launch_bounds__(kWaves * 64) void k_deblock(PicParams pp) {
     __shared__ volatile int progress[kMaxRows];
     __shared__ DbTile tiles[kWaves];
+    __shared__ DbTables tb;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < kMaxRows; i += blockDim.x) progress[i] = 0;
+    if (threadIdx.x < 52) { tb.alpha[threadIdx.x] = kAlpha[threadIdx.x]; tb.beta[threadIdx.x] = kBeta[threadIdx.x]; }
+    if (threadIdx.x < 156) (&tb.tc0[0][0])[threadIdx.x] = (&kTc0[0][0])[threadIdx.x];
     __syncthreads();
     for (int row = wave; row < pp.mb_h; row += kWaves) {
         for (int x = 0; x < pp.mb_w; x++) {
             int need = x + 2 < pp.mb_w ? x + 2 : pp.mb_w;
             wait_row(progress, row - 1, need);
-            deblock_mb(pp, x, row, tiles[wave], lane);
+            deblock_mb(pp, x, row, tiles[wave], tb, lane);
             publish_row(progress, row, x + 1, lane);
         }
     }

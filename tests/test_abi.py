@@ -1,0 +1,74 @@
+"""The drop-in boundary: the library loads, exports every symbol include/jm_amd_dec.h declares plus the ten
+C++-mangled jm_nvdec_* names of the reference header, and the reference's own harness links against it."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from jmcodec_amd import api
+from util import ROOT
+
+MANGLED = ["_Z22jm_nvdec_create_handlev", "_Z13jm_nvdec_initiiPciPv", "_Z15jm_nvdec_deinitPv", "_Z21jm_nvdec_decode_framePhiPiPv",
+           "_Z21jm_nvdec_output_framePhPiPv", "_Z20jm_nvdec_stream_infoPiS_Pv", "_Z16jm_nvdec_set_eofbPv", "_Z16jm_nvdec_is_exitPv",
+           "_Z22jm_nvdec_show_dec_infoPv", "_Z22jm_nvdec_is_hw_supportv"]
+
+
+def _exports():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.lib_path()], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "jm_amd_dec.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(jm_amddec_\w+)\s*\(", hdr))
+    assert len(declared) >= 14
+    exp = _exports()
+    assert declared <= exp, declared - exp
+    assert set(MANGLED) <= exp, set(MANGLED) - exp
+    L = api.lib()
+    for name in declared:
+        assert getattr(L, name)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a HIP device init must fail (the reference would return 0); nothing decodes on the CPU."""
+    if api.jm_nvdec_is_hw_support():
+        pytest.skip("a GPU is present")
+    h = api.jm_nvdec_create_handle()
+    assert api.jm_nvdec_init(0, 1, None, 0, h) != 0
+    assert b"no HIP device" in api.lib().jm_amddec_last_error(h)
+    assert api.jm_nvdec_decode_frame(b"\x00\x00\x01\x09\x10", 5, h)[0] != 0
+    api.jm_nvdec_deinit(h)
+
+
+def test_product_does_not_link_the_oracle():
+    out = subprocess.check_output(["nm", "-D", api.lib_path()], text=True)
+    assert "orc_" not in out
+    for f in os.listdir(os.path.join(ROOT, "jmcodec_amd", "csrc")):
+        src = open(os.path.join(ROOT, "jmcodec_amd", "csrc", f)).read()
+        assert "oracle/" not in src and "orc_h264" not in src, f
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/test_nv_dec/test_nv_dec.cpp"), reason="reference sources only exist in the build container")
+def test_reference_harness_links_against_the_library():
+    """Compile /root/reference/test_nv_dec/test_nv_dec.cpp IN PLACE (never copied) with a two-file shim for
+    <Windows.h>/<conio.h> and link it against libjm_amd_dec.so: every jm_nvdec_* symbol it uses must resolve."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ missing")
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "Windows.h"), "w").write("#include <string.h>\n#include <stdlib.h>\n")
+        open(os.path.join(td, "conio.h"), "w").write("static inline int _kbhit(void){return 0;}\nstatic inline int getch(void){return 0;}\n")
+        exe = os.path.join(td, "test_nv_dec")
+        cmd = ["g++", "-w", "-fpermissive", "-I" + td, "-I/root/reference/nv_dec",
+               "-DJMDLL_FUNC=__attribute__((visibility(\"default\")))", "-DJMDLL_API=",
+               "/root/reference/test_nv_dec/test_nv_dec.cpp", "-o", exe,
+               "-L" + os.path.dirname(api.lib_path()), "-ljm_amd_dec", "-Wl,-rpath," + os.path.dirname(api.lib_path())]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        und = subprocess.check_output(["nm", "-u", exe], text=True)
+        used = set(re.findall(r"_Z\d+jm_nvdec_\w+", und))
+        assert len(used) == 8 and used <= set(MANGLED)

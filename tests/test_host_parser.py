@@ -1,0 +1,103 @@
+"""Host side of the product (no GPU needed): Annex-B splitting, header parsing, DPB / display order and the CAVLC
+job builder, compared with the CPU oracle through the macroblock syntax digest (parse_only mode produces no pixels)."""
+import random
+
+import pytest
+
+from jmcodec_amd import api, streams
+from util import PARITY_CASES, golden_meta, golden_stream
+
+
+def _product_digest(data, chunks=None):
+    with api.JmAmdDec(0, 1, options={"parse_only": 1, "digest": 1}) as d:
+        n = d.decode_stream(data, keep=False, chunks=chunks)
+        pocs = [d.stat(f"display_poc:{i}") for i in range(n)]
+        return d.stat("syntax_digest") & (2 ** 64 - 1), d.stat("digest_mbs"), n, d.stat("errors"), pocs, d.stat("job_bytes")
+
+
+@pytest.mark.parametrize("name", sorted(PARITY_CASES))
+def test_syntax_digest_matches_oracle(oracle, name):
+    data = streams.generate(**PARITY_CASES[name])
+    od, on = oracle.syntax_digest(data)
+    pd, pn, frames, errors, _, job_bytes = _product_digest(data)
+    assert errors == 0
+    assert frames == PARITY_CASES[name]["frames"]
+    assert (pd, pn) == (od, on)
+    assert job_bytes > 0
+
+
+@pytest.mark.parametrize("name", sorted(golden_meta()))
+def test_golden_streams_parse(oracle, name):
+    data = golden_stream(name)
+    od, on = oracle.syntax_digest(data)
+    pd, pn, frames, errors, _, _ = _product_digest(data)
+    assert (pd, pn, frames, errors) == (od, on, golden_meta()[name]["frames"], 0)
+
+
+def test_chunking_does_not_matter(oracle):
+    """jm_nvdec_decode_frame accepts any chunk: one NAL per call (test_nv_dec.cpp:186-215), whole access units
+    (test_player.cpp:253), the whole file, or arbitrary byte runs must all give the same pictures."""
+    data = golden_stream("ip_fuzz_crop_90x70")
+    ref = _product_digest(data)
+    assert _product_digest(data, chunks=[data])[:4] == ref[:4]
+    rng = random.Random(1)
+    for _ in range(3):
+        cuts, i = [], 0
+        while i < len(data):
+            n = rng.choice([1, 2, 3, 5, 17, 100, 1000])
+            cuts.append(data[i:i + n]); i += n
+        assert _product_digest(data, chunks=cuts)[:4] == ref[:4]
+
+
+def test_display_order_is_poc_order_within_each_idr_period(oracle):
+    kw = dict(width=96, height=80, frames=12, gop=6, mode=1, num_ref=4, slices=3, seed=78, poc_type=0, nonref_period=3, deblock=2)
+    _, _, n, _, pocs, _ = _product_digest(streams.generate(**kw))
+    assert n == 12
+    assert pocs[:6] == sorted(pocs[:6]) and pocs[6:] == sorted(pocs[6:])
+    assert pocs[0] == 0 and pocs[6] == 0
+
+
+def test_empty_and_garbage_input():
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        assert d.decode_stream(b"", keep=False) == 0
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        assert d.decode_stream(bytes(range(256)) * 8, keep=False) == 0
+    # a truncated stream must not crash and must still display the complete pictures before the cut
+    data = golden_stream("ip_real_96x80")
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        n = d.decode_stream(data[:len(data) * 2 // 3], keep=False)
+        assert 1 <= n <= 6
+
+
+def test_api_protocol_and_info_block():
+    """got_frame / is_exit / output_frame conventions of nv_dec.cpp:406-478 and :750-828, info block of :663-683."""
+    import ctypes as C
+    import re
+    data = golden_stream("ip_real_96x80")
+    h = api.jm_nvdec_create_handle()
+    api.lib().jm_amddec_set_option(h, b"parse_only", 1)
+    api.lib().jm_amddec_set_option(h, b"sync", 1)
+    assert api.jm_nvdec_init(0, 1, None, 0, h) == 0
+    buf = C.create_string_buffer(96 * 80 * 3 // 2)
+    assert api.jm_nvdec_output_frame(buf, len(buf), h)[0] == -1            # no frame yet
+    frames = 0
+    for nal in api.split_nalus(data):
+        ret, got = api.jm_nvdec_decode_frame(nal, len(nal), h)
+        assert ret == 0 and got in (0, 1)
+        if got:
+            frames += 1
+            assert api.jm_nvdec_output_frame(buf, 10, h)[0] == -2           # buffer too small
+            ret, n = api.jm_nvdec_output_frame(buf, len(buf), h)
+            assert ret == n == 96 * 80 * 3 // 2                             # returns the size, not 0 (nv_dec.cpp:827)
+    assert api.jm_nvdec_stream_info(h) == (96, 80)
+    assert not api.jm_nvdec_is_exit(h)
+    while not api.jm_nvdec_is_exit(h):
+        ret, got = api.jm_nvdec_decode_frame(None, 0, h)
+        frames += got
+    assert frames == 6
+    info = api.jm_nvdec_show_dec_info(h)
+    assert re.fullmatch(r"=+\nCodec:\t\tH\.264\nDisplay:\t96 x 80\nPixel Format:\tYV12\nFrame Count:\t6\nElapsed Time:\t\d+ ms\nDecode FPS:\t[\d.]+ fps\n=+\n", info), info
+    # once EOS was sent further input is ignored (nv_dec.cpp:374-375)
+    ret, got = api.jm_nvdec_decode_frame(data, len(data), h)
+    assert (ret, got) == (0, 0)
+    api.jm_nvdec_deinit(h)

@@ -1,0 +1,52 @@
+"""Multi-GPU path: streams shard across ranks with no data-path collective; only the timing / frame
+count reduction of bench.py uses torch.distributed.  Exercised here with 2 gloo ranks on the CPU (parse_only)."""
+import os
+import socket
+
+import pytest
+
+from jmcodec_amd import shard
+
+
+def test_assignment_is_a_partition():
+    for total in (1, 7, 8, 64):
+        for world in (1, 2, 4, 8):
+            parts = [shard.streams_of_rank(total, r, world) for r in range(world)]
+            flat = sorted(s for p in parts for s in p)
+            assert flat == list(range(total))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard.streams_of_rank(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]     # stream i -> GPU i mod n
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jmcodec_amd import api, streams
+    mine = shard.streams_of_rank(6, rank, world)
+    frames = 0
+    for sid in mine:
+        data = streams.generate(width=64, height=48, frames=3 + sid % 2, gop=4, seed=100 + sid)
+        with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+            frames += d.decode_stream(data, keep=False)
+    total, tmax = shard.reduce_result(dist, frames, 1.0 + rank, device="cpu")
+    q.put((rank, frames, total, tmax))
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduction_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want_total = sum(3 + sid % 2 for sid in range(6))
+    assert [r[2] for r in res] == [want_total, want_total]
+    assert [r[3] for r in res] == [2.0, 2.0]                     # max over ranks
+    assert res[0][1] + res[1][1] == want_total

@@ -1,0 +1,72 @@
+import hashlib
+import json
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def golden_meta():
+    return json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def golden_stream(name):
+    return open(os.path.join(GOLDEN, name + ".h264"), "rb").read()
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def c_array(path, name):
+    """Extract a (possibly nested) integer array initialiser called `name` from a C/C++ source as a flat list."""
+    src = open(path).read()
+    m = re.search(r"\b" + re.escape(name) + r"\s*(\[[^\]]*\]\s*)+=\s*\{", src)
+    assert m, f"{name} not found in {path}"
+    i = m.end() - 1
+    depth, j = 0, i
+    while True:
+        if src[j] == "{":
+            depth += 1
+        elif src[j] == "}":
+            depth -= 1
+            if depth == 0:
+                break
+        j += 1
+    body = re.sub(r"/\*.*?\*/", "", src[i:j + 1], flags=re.S)
+    return [int(x, 0) for x in re.findall(r"-?\b(?:0x[0-9a-fA-F]+|\d+)\b", body)]
+
+
+def unescape(nal):
+    out = bytearray()
+    z = 0
+    for b in nal:
+        if z >= 2 and b == 3:
+            z = 0
+            continue
+        out.append(b)
+        z = z + 1 if b == 0 else 0
+    return bytes(out)
+
+
+# the cases every parity test runs (generator keyword arguments)
+PARITY_CASES = {
+    "pcm": dict(width=64, height=48, frames=2, pcm_only=1, gop=2, deblock=0),
+    "intra_nodb": dict(width=64, height=48, frames=1, gop=1, deblock=0),
+    "intra_db": dict(width=64, height=48, frames=2, gop=1, deblock=1),
+    "p_nodb": dict(width=64, height=48, frames=4, gop=4, deblock=0),
+    "p_db": dict(width=64, height=48, frames=4, gop=4, deblock=1),
+    "fuzz_nodb": dict(width=96, height=80, frames=6, gop=6, mode=1, deblock=0, seed=77),
+    "fuzz_multiref_slices": dict(width=96, height=80, frames=8, gop=4, mode=1, deblock=1, num_ref=3, slices=2, seed=77),
+    "fuzz_poc0_nonref_idc2": dict(width=96, height=80, frames=12, gop=6, mode=1, num_ref=4, slices=3, seed=78, poc_type=0, nonref_period=3, deblock=2),
+    "fuzz_cip_offsets": dict(width=176, height=144, frames=8, gop=8, mode=1, num_ref=2, seed=79, cip=1, chroma_qp_off=-3, alpha_off=2, beta_off=-2),
+    "fuzz_crop_odd_mbs": dict(width=90, height=70, frames=6, gop=3, mode=1, num_ref=2, seed=80),
+    "real_qvga": dict(width=320, height=240, frames=10, gop=10, seed=5),
+    "real_lowqp": dict(width=128, height=96, frames=5, gop=5, seed=6, qp=12),
+    "real_highqp": dict(width=128, height=96, frames=5, gop=5, seed=7, qp=44),
+    "one_mb": dict(width=16, height=16, frames=4, gop=2, mode=1, seed=81),
+    "wide_strip": dict(width=640, height=16, frames=3, gop=3, mode=1, seed=82),
+    "tall_strip": dict(width=16, height=400, frames=3, gop=3, mode=1, seed=83),
+}
