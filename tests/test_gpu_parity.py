@@ -155,15 +155,26 @@ def test_api_protocol_on_device():
 @pytest.mark.parametrize("w,h,pitch", [(16, 16, 128), (90, 70, 128), (1920, 1080, 1920), (3840, 2160, 3840)])
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_packout_kernel_vs_oracle(oracle, w, h, pitch, fmt):
-    """k_packout alone (jm_amddec_packout_device) against the restatement of nv_dec.cpp:782-820."""
-    import torch
+    """k_packout alone (jm_amddec_packout_device) against the restatement of nv_dec.cpp:782-820.
+    Device memory comes straight from the HIP runtime the library is linked to (no torch in this process:
+    torch bundles its own libamdhip64 and two HIP runtimes cannot share one process)."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     rng = np.random.default_rng(w + h + fmt)
     src = rng.integers(0, 256, size=pitch * h * 3 // 2, dtype=np.uint8)
-    d_src = torch.from_numpy(src).cuda()
-    d_dst = torch.zeros(w * h * 3 // 2, dtype=torch.uint8, device="cuda")
-    rc = api.lib().jm_amddec_packout_device(d_src.data_ptr(), pitch, w, h, fmt, d_dst.data_ptr(), None)
-    assert rc == 0
-    torch.cuda.synchronize()
+    n_out = w * h * 3 // 2
+    d_src, d_dst = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_src), src.size) == 0 and hip.hipMalloc(C.byref(d_dst), n_out) == 0
+    try:
+        assert hip.hipMemcpy(d_src, src.ctypes.data_as(C.c_void_p), src.size, 1) == 0          # hipMemcpyHostToDevice
+        assert api.lib().jm_amddec_packout_device(d_src, pitch, w, h, fmt, d_dst, None) == 0
+        assert hip.hipDeviceSynchronize() == 0
+        out = np.zeros(n_out, np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d_dst, n_out, 2) == 0             # hipMemcpyDeviceToHost
+    finally:
+        hip.hipFree(d_src); hip.hipFree(d_dst)
     rc, want = oracle.packout(src.tobytes(), pitch, w, h, fmt)
-    assert rc == w * h * 3 // 2
-    assert d_dst.cpu().numpy().tobytes() == want
+    assert rc == n_out
+    assert out.tobytes() == want
