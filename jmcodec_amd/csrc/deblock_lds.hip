@@ -1,0 +1,347 @@
+// jmcodec_amd/csrc/deblock_lds.hip -- in-loop deblocking (H.264 8.7), LDS-resident lockstep wavefront.
+//
+// Part of the replacement for cuvidDecodePicture (/root/reference/nv_dec/nv_dec.cpp:33-41).
+//
+// Clause 8.7 filters macroblocks in raster order, per macroblock the vertical edges and then the
+// horizontal edges, and every filter reads samples its predecessors already changed.  The exact
+// dependencies are: MB(x,y) after MB(x-1,y), MB(x,y-1) and MB(x+1,y-1).  So all macroblocks with the same
+// s = x + 2y are independent ("step s") and the steps must run in order.
+//
+//   k_deblock_prep   fully parallel: boundary strengths (8.7.2.1) and the alpha/beta/tC0 of every edge class
+//                    of every macroblock -> one 64-byte DbRec.  All divergent, table-driven work lives here.
+//   k_deblock_lds    ONE workgroup (16 waves) walks the steps in lockstep, one __syncthreads() per step.
+//                    Waves 0-7 filter luma, waves 8-15 chroma; 16 lanes per macroblock (lane = pixel row
+//                    for vertical edges, = pixel column for horizontal edges), so a whole edge chain of a
+//                    macroblock stays in registers.  Everything a neighbour still needs lives in LDS:
+//                      tile[row][x&1]   the macroblock's 16 rows after its own filtering (right 4 columns are
+//                                       the next macroblock's left border)
+//                      ring[row][x&3]   its bottom 4 rows (the macroblock below filters and finally stores them)
+//                    HBM traffic is the algorithmic minimum: every sample is read once (prefetched one step
+//                    ahead) and written once, as whole 16-byte row segments of a (-4,-4)-shifted 16x16 block.
+#include <hip/hip_runtime.h>
+#include "jobs.h"
+#include "kernels.h"
+#include "kernel_common.h"
+
+namespace jmamd {
+
+struct DbRec {                 // 64 bytes per macroblock
+    uint8_t bs[16];            // 32 nibbles, index dir*16 + edge*4 + segment   (dir 0 = vertical edges)
+    uint8_t lp[3][5];          // luma   [0 left MB edge, 1 internal edges, 2 top MB edge][alpha, beta, tC0(bS=1..3)]
+    uint8_t cp[2][3][5];       // chroma [plane][same classes]
+    uint8_t pad[3];
+};
+static_assert(sizeof(DbRec) == 64, "DbRec must be 64 bytes");
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deblock_prep(PicParams pp, DbRec *out) {
+    int mb = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+    int n_mbs = pp.mb_w * pp.mb_h;
+    if (mb >= n_mbs) return;
+    int mbx = mb % pp.mb_w, mby = mb / pp.mb_w;
+    const MbRec q = pp.mbs[mb];
+    const SliceRec sl = pp.slices[q.slice];
+    bool has_left = mbx > 0, has_top = mby > 0;
+    MbRec pl = q, pt = q;
+    if (has_left) { pl = pp.mbs[mb - 1]; if (sl.disable == 2 && pl.slice != q.slice) has_left = false; }
+    if (has_top) { pt = pp.mbs[mb - pp.mb_w]; if (sl.disable == 2 && pt.slice != q.slice) has_top = false; }
+    // lanes 0..31 of the half-wave: one boundary strength each
+    int dir = t >> 4, e = (t >> 2) & 3, k = t & 3;
+    int rq = dir == 0 ? k * 4 + e : e * 4 + k;
+    int bs;
+    if (sl.disable == 1) bs = 0;
+    else if (e == 0) {
+        bool have = dir == 0 ? has_left : has_top;
+        bs = have ? boundary_strength(pp, dir == 0 ? pl : pt, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true) : 0;
+    } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
+    // pack two nibbles per byte: partner lane t^1 holds the other half
+    int other = __shfl_xor(bs, 1);
+    uint8_t *o = (uint8_t *)&out[mb];
+    if (!(t & 1)) o[t >> 1] = (uint8_t)(bs | (other << 4));
+    // filter parameters: 9 classes (3 luma + 2 x 3 chroma), one per lane
+    if (t < 9) {
+        int plane = t < 3 ? -1 : (t - 3) / 3, cls = t < 3 ? t : (t - 3) % 3;
+        int qp_p = cls == 0 ? pl.qp : (cls == 2 ? pt.qp : q.qp), qp_q = q.qp;
+        if (plane >= 0) { int off = plane ? pp.cr_qp_off : pp.cb_qp_off; qp_p = chroma_qp(qp_p, off); qp_q = chroma_qp(qp_q, off); }
+        int qpav = (qp_p + qp_q + 1) >> 1;
+        int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+        uint8_t *p = o + 16 + 5 * t;
+        p[0] = kAlpha[ia]; p[1] = kBeta[ib]; p[2] = kTc0[ia][0]; p[3] = kTc0[ia][1]; p[4] = kTc0[ia][2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sample filters on register arrays
+// ------------------------------------------------------------------------------------------
+// s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3
+__device__ __forceinline__ void flt_luma(int *s, int bS, int alpha, int beta, int tc0) {
+    int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    int ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    if (bS < 4) {
+        int tc = tc0 + ap + aq;
+        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        s[3] = clip1(p0 + delta); s[4] = clip1(q0 - delta);
+        if (ap) s[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
+        if (aq) s[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
+    } else {
+        bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap && strong) { s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; s[2] = (p2 + p1 + p0 + q0 + 2) >> 2; s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; }
+        else s[3] = (2 * p1 + p0 + q1 + 2) >> 2;
+        if (aq && strong) { s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; s[5] = (p0 + q0 + q1 + q2 + 2) >> 2; s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3; }
+        else s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
+}
+// chroma: p1 p0 q0 q1 by reference
+__device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int bS, int alpha, int beta, int tc0) {
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (bS < 4) {
+        int tc = tc0 + 1;
+        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        p0 = clip1(p0 + delta); q0 = clip1(q0 - delta);
+    } else { int np = (2 * p1 + p0 + q1 + 2) >> 2, nq = (2 * q1 + q0 + p1 + 2) >> 2; p0 = np; q0 = nq; }
+}
+
+__device__ __forceinline__ int nib(const uint32_t *w, int idx) { return (w[idx >> 3] >> ((idx & 7) * 4)) & 15; }
+__device__ __forceinline__ int byt(const uint32_t *w, int idx) { return (w[idx >> 2] >> ((idx & 3) * 8)) & 255; }
+__device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
+
+// LDS layout (dynamic): per macroblock row
+//   lumaTile  [2][16][16]   = 512 B        chromaTile [2][8][16] = 256 B
+//   lumaRing  [4][4][16]    = 256 B        chromaRing [4][2][16] = 128 B
+// then 64 x 64 B staging for the DbRec of the macroblock each group is working on.
+constexpr int kLdsPerRow = 512 + 256 + 256 + 128;
+constexpr int kGroups = 32;              // macroblock rows in flight per plane type: 8 waves x 4 groups
+constexpr int kMaxSlots = 3;             // rows g, g+32, g+64 -> pictures up to 96 MB rows (1536 lines)
+
+struct Lds {
+    uint8_t *base; int mb_h;
+    __device__ uint8_t *luma_tile(int row, int par) const { return base + (size_t)row * 512 + par * 256; }
+    __device__ uint8_t *luma_ring(int row, int slot) const { return base + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
+    __device__ uint8_t *chroma_tile(int row, int par) const { return base + (size_t)mb_h * 768 + (size_t)row * 256 + par * 128; }
+    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + (size_t)mb_h * 1024 + (size_t)row * 128 + slot * 32; }
+    __device__ uint8_t *rec(int group) const { return base + (size_t)mb_h * kLdsPerRow + group * 64; }
+};
+
+// ------------------------------------------------------------------------------------------
+// luma: one macroblock, 16 lanes (l = 0..15)
+// ------------------------------------------------------------------------------------------
+__device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int l, int group, uint4 own, uint32_t recdw) {
+    uint8_t *tc = lds.luma_tile(row, x & 1), *tp = lds.luma_tile(row, (x - 1) & 1);
+    uint8_t *ring_up = row > 0 ? lds.luma_ring(row - 1, x & 3) : nullptr;
+    uint8_t *ring_up_l = row > 0 ? lds.luma_ring(row - 1, (x - 1) & 3) : nullptr;
+    uint8_t *ring_dn = lds.luma_ring(row, x & 3), *ring_dn_l = lds.luma_ring(row, (x - 1) & 3);
+    uint32_t *rec = (uint32_t *)lds.rec(group);
+    rec[l] = recdw;
+    uint32_t rw[8];
+    { uint4 a = *(const uint4 *)rec, b = *(const uint4 *)(rec + 4); rw[0] = a.x; rw[1] = a.y; rw[2] = a.z; rw[3] = a.w; rw[4] = b.x; rw[5] = b.y; rw[6] = b.z; rw[7] = b.w; }
+    const uint32_t *bsw = rw, *lpw = rw + 4;                  // bs nibbles ; lp bytes [3][5]
+    // ---- vertical edges: lane = pixel row l ----
+    uint32_t left = x > 0 ? *(const uint32_t *)(tp + l * 16 + 12) : 0;
+    int p[20];
+    { uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
+#pragma unroll
+      for (int i = 0; i < 20; i++) p[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255; }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        int bs = nib(bsw, e * 4 + (l >> 2));
+        if (bs) { int c = e ? 1 : 0; flt_luma(p + 4 * e, bs, byt(lpw, c * 5), byt(lpw, c * 5 + 1), bs < 4 ? byt(lpw, c * 5 + 1 + bs) : 0); }
+    }
+    uint32_t left_after = pack4(p);
+    if (x > 0) *(uint32_t *)(tp + l * 16 + 12) = left_after;
+    *(uint4 *)(tc + l * 16) = make_uint4(pack4(p + 4), pack4(p + 8), pack4(p + 12), pack4(p + 16));
+    // the left neighbour's bottom rows (its ring slot) get our edge-0 result for columns 12..15
+    if (x > 0 && l >= 12) *(uint32_t *)(ring_dn_l + (l - 12) * 16 + 12) = left_after;
+    // ---- horizontal edges: lane = pixel column l ----
+    int c[20];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = ring_up ? ring_up[j * 16 + l] : 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) c[4 + j] = tc[j * 16 + l];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        int bs = nib(bsw, 16 + e * 4 + (l >> 2));
+        if (bs) { int k = e ? 1 : 2; flt_luma(c + 4 * e, bs, byt(lpw, k * 5), byt(lpw, k * 5 + 1), bs < 4 ? byt(lpw, k * 5 + 1 + bs) : 0); }
+    }
+    if (ring_up) {
+#pragma unroll
+        for (int j = 1; j < 4; j++) ring_up[j * 16 + l] = (uint8_t)c[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) tc[j * 16 + l] = (uint8_t)c[4 + j];
+#pragma unroll
+    for (int j = 12; j < 16; j++) { tc[j * 16 + l] = (uint8_t)c[4 + j]; ring_dn[(j - 12) * 16 + l] = (uint8_t)c[4 + j]; }
+    // ---- store the final (-4,-4)-shifted 16x16 block: lane -> row R = l - 4 ----
+    uint8_t *dst = pp.surf[pp.cur];
+    int x0 = x * 16, y0 = row * 16, pitch = pp.pitch;
+    bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
+    {
+        int R = l - 4;
+        const uint8_t *src, *srcl;
+        if (R < 0) { src = ring_up ? ring_up + (R + 4) * 16 : nullptr; srcl = ring_up_l ? ring_up_l + (R + 4) * 16 + 12 : nullptr; }
+        else { src = tc + R * 16; srcl = tp + R * 16 + 12; }
+        if (src) {
+            uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+            uint4 v = *(const uint4 *)src;
+            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
+            else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
+            if (right) *(uint32_t *)(d + 12) = v.w;
+        }
+    }
+    if (bottom && l < 4) {
+        int R = 12 + l;
+        uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+        uint4 v = *(const uint4 *)(tc + R * 16);
+        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
+        else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
+        if (right) *(uint32_t *)(d + 12) = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// chroma (NV12 interleaved UV): one macroblock, 16 lanes
+// ------------------------------------------------------------------------------------------
+__device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, int l, int group, uint4 own, uint32_t recdw) {
+    uint8_t *tc = lds.chroma_tile(row, x & 1), *tp = lds.chroma_tile(row, (x - 1) & 1);
+    uint8_t *ring_up = row > 0 ? lds.chroma_ring(row - 1, x & 3) : nullptr;
+    uint8_t *ring_up_l = row > 0 ? lds.chroma_ring(row - 1, (x - 1) & 3) : nullptr;
+    uint8_t *ring_dn = lds.chroma_ring(row, x & 3), *ring_dn_l = lds.chroma_ring(row, (x - 1) & 3);
+    uint32_t *rec = (uint32_t *)lds.rec(32 + group);
+    rec[l] = recdw;
+    uint32_t rw[16];
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { uint4 a = *(const uint4 *)(rec + 4 * i); rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
+    }
+    const uint32_t *bsw = rw;                 // cp bytes start at byte 31 of the record
+    // ---- vertical edges (chroma columns 0 and 4 <-> luma edges 0 and 2): lane = (plane, chroma row) ----
+    {
+        int plane = l >> 3, r = l & 7;
+        // `own` of lane l is row (l & 7) of the macroblock (both lane halves prefetch the same 16 bytes)
+        uint32_t left = x > 0 ? *(const uint32_t *)(tp + r * 16 + 12) : 0;
+        if (plane == 0) *(uint4 *)(tc + r * 16) = own;
+        uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
+        int b[20];
+#pragma unroll
+        for (int i = 0; i < 20; i++) b[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255;
+        int cbase = 31 + plane * 15;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            int bs = nib(bsw, e * 4 + (r >> 1));
+            if (!bs) continue;
+            int k = e ? 1 : 0, o = 4 * e + plane;                       // p1 = b[o], p0 = b[o+2], q0 = b[o+4], q1 = b[o+6]
+            int p0 = b[o + 2], q0 = b[o + 4];
+            flt_chroma(b[o], p0, q0, b[o + 6], bs, byt(rw, cbase + k * 5), byt(rw, cbase + k * 5 + 1), bs < 4 ? byt(rw, cbase + k * 5 + 1 + bs) : 0);
+            if (e == 0) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
+            else { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
+        }
+    }
+    // left neighbour's bottom rows: columns 12..15 (bytes) of rows 6, 7 after our edge 0
+    if (x > 0 && l < 2) *(uint32_t *)(ring_dn_l + l * 16 + 12) = *(const uint32_t *)(tp + (6 + l) * 16 + 12);
+    // ---- horizontal edges (chroma rows 0 and 4): lane = interleaved byte column ----
+    {
+        int plane = l & 1, cbase = 31 + plane * 15;
+        int c[10];
+        c[0] = ring_up ? ring_up[l] : 0; c[1] = ring_up ? ring_up[16 + l] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[2 + j] = tc[j * 16 + l];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            int bs = nib(bsw, 16 + e * 4 + (l >> 2));
+            if (!bs) continue;
+            int k = e ? 1 : 2, o = 2 * e;                                 // p1 = c[o], p0 = c[o+1], q0 = c[o+2], q1 = c[o+3]
+            flt_chroma(c[o], c[o + 1], c[o + 2], c[o + 3], bs, byt(rw, cbase + k * 5), byt(rw, cbase + k * 5 + 1), bs < 4 ? byt(rw, cbase + k * 5 + 1 + bs) : 0);
+        }
+        if (ring_up) ring_up[16 + l] = (uint8_t)c[1];
+        tc[l] = (uint8_t)c[2]; tc[3 * 16 + l] = (uint8_t)c[5]; tc[4 * 16 + l] = (uint8_t)c[6];
+        ring_dn[l] = (uint8_t)c[8]; ring_dn[16 + l] = (uint8_t)c[9];
+    }
+    // ---- store the (-2 px, -2 rows)-shifted 8 x 16-byte block: lanes 0..7 -> row R = l - 2 ----
+    uint8_t *dst = pp.surf[pp.cur] + pp.chroma_offset;
+    int x0 = x * 16, y0 = row * 8, pitch = pp.pitch;
+    bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
+    if (l < 8) {
+        int R = l - 2;
+        const uint8_t *src, *srcl;
+        if (R < 0) { src = ring_up ? ring_up + (R + 2) * 16 : nullptr; srcl = ring_up_l ? ring_up_l + (R + 2) * 16 + 12 : nullptr; }
+        else { src = tc + R * 16; srcl = tp + R * 16 + 12; }
+        if (src) {
+            uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+            uint4 v = *(const uint4 *)src;
+            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
+            else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
+            if (right) *(uint32_t *)(d + 12) = v.w;
+        }
+    } else if (bottom && l < 10) {
+        int R = 6 + (l - 8);
+        uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+        uint4 v = *(const uint4 *)(tc + R * 16);
+        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
+        else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
+        if (right) *(uint32_t *)(d + 12) = v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_deblock_lds(PicParams pp, const DbRec *recs) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    Lds lds{smem, pp.mb_h};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool is_chroma = wave >= 8;
+    const int group = (wave & 7) * 4 + (lane >> 4), l = lane & 15;
+    const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
+    const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
+    const int rows_per_mb = is_chroma ? 8 : 16;
+    const int my_row = is_chroma ? (l & 7) : l;
+    uint4 pre_pix[kMaxSlots]; uint32_t pre_rec[kMaxSlots];
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; k++) { pre_pix[k] = make_uint4(0, 0, 0, 0); pre_rec[k] = 0; }
+    const int n_steps = mb_w + 2 * (mb_h - 1);
+    // prefetch for step 0
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; k++) {
+        int row = group + kGroups * k;
+        if (row < mb_h && 2 * row == 0) {
+            pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch);
+            pre_rec[k] = ((const uint32_t *)&recs[row * mb_w])[l];
+        }
+    }
+    for (int s = 0; s < n_steps; s++) {
+#pragma unroll
+        for (int k = 0; k < kMaxSlots; k++) {
+            int row = group + kGroups * k;
+            if (row >= mb_h) continue;
+            int x = s - 2 * row;
+            uint4 own = pre_pix[k]; uint32_t rdw = pre_rec[k];
+            int xn = x + 1;                                   // macroblock of the next step: prefetch now
+            if (xn >= 0 && xn < mb_w) {
+                pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
+                pre_rec[k] = ((const uint32_t *)&recs[row * mb_w + xn])[l];
+            }
+            if (x >= 0 && x < mb_w) {
+                if (is_chroma) chroma_mb(pp, lds, x, row, l, group, own, rdw);
+                else luma_mb(pp, lds, x, row, l, group, own, rdw);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+size_t deblock_lds_bytes(int mb_h) { return (size_t)mb_h * kLdsPerRow + 64 * 64; }
+bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
+
+void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        hipFuncSetAttribute((const void *)k_deblock_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        attr_set[dev] = true;
+    }
+    int n = pp.mb_w * pp.mb_h;
+    hipLaunchKernelGGL(k_deblock_prep, dim3((n + 7) / 8), dim3(256), 0, st, pp, (DbRec *)dbrec_scratch);
+    hipLaunchKernelGGL(k_deblock_lds, dim3(1), dim3(1024), deblock_lds_bytes(pp.mb_h), st, pp, (const DbRec *)dbrec_scratch);
+}
+
+}  // namespace jmamd

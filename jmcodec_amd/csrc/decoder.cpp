@@ -140,6 +140,7 @@ void Decoder::gpu_free_sequence() {
     hipSetDevice(device_);
     hipStreamSynchronize(stream_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+    if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
     for (auto &j : jobs_) {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
@@ -180,6 +181,8 @@ bool Decoder::gpu_alloc_sequence() {
         if (!HIP_OK(hipMalloc((void **)&surf_[i], surf_bytes_))) { fail("hipMalloc(surface) failed"); return false; }
         hipMemsetAsync(surf_[i], 128, surf_bytes_, stream_);
     }
+    use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
+    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 64))) { fail("hipMalloc(dbrec) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
             !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
@@ -666,7 +669,7 @@ void Decoder::submit_task(PicTask *t) {
         if (profile_) hipEventRecord(js.pev[1], stream_);
         if (t->n_intra > 0) launch_recon_intra(pp, stream_);
         if (profile_) hipEventRecord(js.pev[2], stream_);
-        if (t->any_deblock) launch_deblock(pp, stream_);
+        if (t->any_deblock) { if (use_lds_deblock_) launch_deblock_lds(pp, dbrec_, stream_); else launch_deblock(pp, stream_); }
         if (profile_) hipEventRecord(js.pev[3], stream_);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) fail(std::string("kernel launch failed: ") + hipGetErrorString(le));

@@ -155,6 +155,7 @@ private:
     // device
     ihipStream_t *stream_ = nullptr;
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
+    uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
     bool gpu_open_ = false;
 

@@ -1,0 +1,91 @@
+// jmcodec_amd/csrc/kernel_common.h -- device helpers shared by kernels.hip and deblock_lds.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "jobs.h"
+
+namespace jmamd {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clip1(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+
+// Small tables are packed into 64-bit immediates so that a lookup is a shift, not a dependent memory
+// access inside the serial wavefront chains.
+// normAdjust4x4 (8.5.9) by qP%6: class 0 (even,even) {10,11,13,14,16,18}, class 1 (odd,odd) {16,18,20,23,25,29}, class 2 {13,14,16,18,20,23}
+__device__ __forceinline__ int norm4(int qp_rem, int cls) {
+    unsigned long long t = cls == 0 ? 0x12100E0D0B0AULL : (cls == 1 ? 0x1D1917141210ULL : 0x171412100E0DULL);
+    return (int)((t >> (8 * qp_rem)) & 0xff);
+}
+// Table 8-15: QPc for qPI = 30..51 : 29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39 (stored minus 29, 4 bits each)
+__device__ __forceinline__ int qpc_from_qpi(int qpi) {
+    if (qpi < 30) return qpi;
+    int k = qpi - 30;
+    unsigned long long lo = 0x9888776655433210ULL;                   // entries 0..15, 4 bits each
+    unsigned int hi = 0xAAAA99u;                                     // entries 16..21
+    int v = k < 16 ? (int)((lo >> (4 * k)) & 15) : (int)((hi >> (4 * (k - 16))) & 15);
+    return 29 + v;
+}
+static __device__ const uint8_t kAlpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,
+    32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
+static __device__ const uint8_t kBeta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,
+    9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
+static __device__ const uint8_t kTc0[52][3] = {
+ {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+ {0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},
+ {2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
+ {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
+
+__device__ __forceinline__ int chroma_qp(int qpy, int off) {
+    return qpc_from_qpi(clip3(0, 51, qpy + off));
+}
+// LevelScale4x4 with the flat (16) weight matrix: 16 * normAdjust4x4 (8.5.9)
+__device__ __forceinline__ int level_scale4(int qp_rem, int pos) {
+    int i = pos >> 2, j = pos & 3;
+    int cls = (!(i & 1) && !(j & 1)) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
+    return 16 * norm4(qp_rem, cls);
+}
+// 8.5.12.1 scaling of one residual coefficient (not the separately handled DC ones)
+__device__ __forceinline__ int dequant4(int c, int qp, int pos) {
+    int ls = level_scale4(qp % 6, pos), s = qp / 6;
+    return s >= 4 ? (c * ls) << (s - 4) : (c * ls + (1 << (3 - s))) >> (4 - s);
+}
+// 8.5.12.2 inverse 4x4 transform, in place on d[16] (raster), result already >> 6
+__device__ __forceinline__ void idct4x4(int *d) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int a = d[4 * i], b = d[4 * i + 1], c = d[4 * i + 2], e = d[4 * i + 3];
+        int e0 = a + c, e1 = a - c, e2 = (b >> 1) - e, e3 = b + (e >> 1);
+        d[4 * i] = e0 + e3; d[4 * i + 1] = e1 + e2; d[4 * i + 2] = e1 - e2; d[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int a = d[j], b = d[4 + j], c = d[8 + j], e = d[12 + j];
+        int g0 = a + c, g1 = a - c, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+        d[j] = (g0 + g3 + 32) >> 6; d[4 + j] = (g1 + g2 + 32) >> 6; d[8 + j] = (g1 - g2 + 32) >> 6; d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+// blkIdx (coding order) <-> raster position of a luma 4x4 block inside the macroblock
+__device__ __forceinline__ int blk_to_raster(int blk) { return ((((blk >> 1) & 1) + 2 * (blk >> 3)) << 2) | ((blk & 1) + 2 * ((blk >> 2) & 1)); }
+__device__ __forceinline__ int raster_to_blk(int r) { int bx = r & 3, by = r >> 2; return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
+
+struct MbView {                     // what bS derivation needs from one macroblock
+    bool intra; uint16_t cbp_blk; int8_t ref[4]; const short *mv; bool ext;
+};
+__device__ __forceinline__ void mv_of(const PicParams &pp, const MbRec &r, int rpos, int &mx, int &my) {
+    if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rpos) * 2; mx = m[0]; my = m[1]; }
+    else { int b8 = (rpos >> 3) * 2 + ((rpos & 3) >> 1); mx = r.u.mv[b8][0]; my = r.u.mv[b8][1]; }
+}
+__device__ inline int boundary_strength(const PicParams &pp, const MbRec &p, int rp, const MbRec &q, int rq, bool mb_edge) {
+    if (p.kind != MB_INTER || q.kind != MB_INTER) return mb_edge ? 4 : 3;
+    if (((p.cbp_blk >> raster_to_blk(rp)) & 1) || ((q.cbp_blk >> raster_to_blk(rq)) & 1)) return 2;
+    if (p.ref[(rp >> 3) * 2 + ((rp & 3) >> 1)] != q.ref[(rq >> 3) * 2 + ((rq & 3) >> 1)]) return 1;
+    int px, py, qx, qy; mv_of(pp, p, rp, px, py); mv_of(pp, q, rq, qx, qy);
+    return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
+}
+
+
+}  // namespace jmamd
