@@ -25,13 +25,15 @@
 
 namespace jmamd {
 
-struct DbRec {                 // 64 bytes per macroblock
-    uint8_t bs[16];            // 32 nibbles, index dir*16 + edge*4 + segment   (dir 0 = vertical edges)
-    uint8_t lp[3][5];          // luma   [0 left MB edge, 1 internal edges, 2 top MB edge][alpha, beta, tC0(bS=1..3)]
-    uint8_t cp[2][3][5];       // chroma [plane][same classes]
-    uint8_t pad[3];
+struct DbRec {                 // 96 bytes per macroblock: 48 for the luma workgroup, 48 for the chroma workgroup
+    uint8_t y_bs[32];          // index dir*16 + edge*4 + segment : bS | tC0 << 3   (dir 0 = vertical edges)
+    uint8_t y_ab[3][2];        // alpha, beta of [0 left MB edge, 1 internal edges, 2 top MB edge]
+    uint8_t y_pad[10];
+    uint8_t c_bs[2][16];       // [plane][dir*8 + (edge/2)*4 + segment] : bS | tC0 << 3
+    uint8_t c_ab[2][3][2];     // [plane][class][alpha, beta]
+    uint8_t c_pad[4];
 };
-static_assert(sizeof(DbRec) == 64, "DbRec must be 64 bytes");
+static_assert(sizeof(DbRec) == 96, "DbRec must be 96 bytes");
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deblock_prep(PicParams pp, DbRec *out) {
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void k_deblock_prep(PicParams pp, DbRec *out) 
     MbRec pl = q, pt = q;
     if (has_left) { pl = pp.mbs[mb - 1]; if (sl.disable == 2 && pl.slice != q.slice) has_left = false; }
     if (has_top) { pt = pp.mbs[mb - pp.mb_w]; if (sl.disable == 2 && pt.slice != q.slice) has_top = false; }
-    // lanes 0..31 of the half-wave: one boundary strength each
+    // lane t: one boundary strength (8.7.2.1)
     int dir = t >> 4, e = (t >> 2) & 3, k = t & 3;
     int rq = dir == 0 ? k * 4 + e : e * 4 + k;
     int bs;
@@ -54,19 +56,27 @@ __global__ __launch_bounds__(256) void k_deblock_prep(PicParams pp, DbRec *out) 
         bool have = dir == 0 ? has_left : has_top;
         bs = have ? boundary_strength(pp, dir == 0 ? pl : pt, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true) : 0;
     } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
-    // pack two nibbles per byte: partner lane t^1 holds the other half
-    int other = __shfl_xor(bs, 1);
-    uint8_t *o = (uint8_t *)&out[mb];
-    if (!(t & 1)) o[t >> 1] = (uint8_t)(bs | (other << 4));
-    // filter parameters: 9 classes (3 luma + 2 x 3 chroma), one per lane
-    if (t < 9) {
-        int plane = t < 3 ? -1 : (t - 3) / 3, cls = t < 3 ? t : (t - 3) % 3;
-        int qp_p = cls == 0 ? pl.qp : (cls == 2 ? pt.qp : q.qp), qp_q = q.qp;
-        if (plane >= 0) { int off = plane ? pp.cr_qp_off : pp.cb_qp_off; qp_p = chroma_qp(qp_p, off); qp_q = chroma_qp(qp_q, off); }
+    // edge class of this lane: 0 left MB edge, 1 internal, 2 top MB edge; qPp is the neighbour's QP on MB edges
+    int cls = e ? 1 : (dir ? 2 : 0);
+    int qp_p = cls == 0 ? pl.qp : (cls == 2 ? pt.qp : q.qp), qp_q = q.qp;
+    DbRec *o = &out[mb];
+    {
         int qpav = (qp_p + qp_q + 1) >> 1;
         int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
-        uint8_t *p = o + 16 + 5 * t;
-        p[0] = kAlpha[ia]; p[1] = kBeta[ib]; p[2] = kTc0[ia][0]; p[3] = kTc0[ia][1]; p[4] = kTc0[ia][2];
+        int tc0 = (bs >= 1 && bs <= 3) ? kTc0[ia][bs - 1] : 0;
+        o->y_bs[t] = (uint8_t)(bs | (tc0 << 3));
+        if (k == 0 && (e == 0 || (e == 1 && dir == 0))) { o->y_ab[cls][0] = kAlpha[ia]; o->y_ab[cls][1] = kBeta[ib]; }
+    }
+    if (!(e & 1)) {
+#pragma unroll
+        for (int plane = 0; plane < 2; plane++) {
+            int off = plane ? pp.cr_qp_off : pp.cb_qp_off;
+            int qpav = (chroma_qp(qp_p, off) + chroma_qp(qp_q, off) + 1) >> 1;
+            int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
+            int tc0 = (bs >= 1 && bs <= 3) ? kTc0[ia][bs - 1] : 0;
+            o->c_bs[plane][dir * 8 + (e >> 1) * 4 + k] = (uint8_t)(bs | (tc0 << 3));
+            if (k == 0 && (e == 0 || (e == 2 && dir == 0))) { o->c_ab[plane][cls][0] = kAlpha[ia]; o->c_ab[plane][cls][1] = kBeta[ib]; }
+        }
     }
 }
 
@@ -102,25 +112,24 @@ __device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int
     } else { int np = (2 * p1 + p0 + q1 + 2) >> 2, nq = (2 * q1 + q0 + p1 + 2) >> 2; p0 = np; q0 = nq; }
 }
 
-__device__ __forceinline__ int nib(const uint32_t *w, int idx) { return (w[idx >> 3] >> ((idx & 7) * 4)) & 15; }
-__device__ __forceinline__ int byt(const uint32_t *w, int idx) { return (w[idx >> 2] >> ((idx & 3) * 8)) & 255; }
 __device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
 
 // LDS layout (dynamic): per macroblock row
 //   lumaTile  [2][16][16]   = 512 B        chromaTile [2][8][16] = 256 B
 //   lumaRing  [4][4][16]    = 256 B        chromaRing [4][2][16] = 128 B
 // then 64 x 64 B staging for the DbRec of the macroblock each group is working on.
-constexpr int kLdsPerRow = 512 + 256 + 256 + 128;
 constexpr int kGroups = 32;              // macroblock rows in flight per plane type: 8 waves x 4 groups
-constexpr int kMaxSlots = 3;             // rows g, g+32, g+64 -> pictures up to 96 MB rows (1536 lines)
+constexpr int kMaxSlots = 5;             // rows g, g+32, ... g+128 -> pictures up to 160 MB rows (2560 lines)
 
+// Workgroup 0 (luma) and workgroup 1 (chroma) each own a private LDS image laid out the same way:
+// 32 x 64 B DbRec staging, then per macroblock row the tile pair, then per row the ring.
 struct Lds {
     uint8_t *base; int mb_h;
-    __device__ uint8_t *luma_tile(int row, int par) const { return base + (size_t)row * 512 + par * 256; }
-    __device__ uint8_t *luma_ring(int row, int slot) const { return base + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
-    __device__ uint8_t *chroma_tile(int row, int par) const { return base + (size_t)mb_h * 768 + (size_t)row * 256 + par * 128; }
-    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + (size_t)mb_h * 1024 + (size_t)row * 128 + slot * 32; }
-    __device__ uint8_t *rec(int group) const { return base + (size_t)mb_h * kLdsPerRow + group * 64; }
+    __device__ uint8_t *rec(int group) const { return base + group * 64; }
+    __device__ uint8_t *luma_tile(int row, int par) const { return base + 2048 + (size_t)row * 512 + par * 256; }
+    __device__ uint8_t *luma_ring(int row, int slot) const { return base + 2048 + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
+    __device__ uint8_t *chroma_tile(int row, int par) const { return base + 2048 + (size_t)row * 256 + par * 128; }
+    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + 2048 + (size_t)mb_h * 256 + (size_t)row * 128 + slot * 32; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -131,11 +140,14 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
     uint8_t *ring_up = row > 0 ? lds.luma_ring(row - 1, x & 3) : nullptr;
     uint8_t *ring_up_l = row > 0 ? lds.luma_ring(row - 1, (x - 1) & 3) : nullptr;
     uint8_t *ring_dn = lds.luma_ring(row, x & 3), *ring_dn_l = lds.luma_ring(row, (x - 1) & 3);
-    uint32_t *rec = (uint32_t *)lds.rec(group);
-    rec[l] = recdw;
-    uint32_t rw[8];
-    { uint4 a = *(const uint4 *)rec, b = *(const uint4 *)(rec + 4); rw[0] = a.x; rw[1] = a.y; rw[2] = a.z; rw[3] = a.w; rw[4] = b.x; rw[5] = b.y; rw[6] = b.z; rw[7] = b.w; }
-    const uint32_t *bsw = rw, *lpw = rw + 4;                  // bs nibbles ; lp bytes [3][5]
+    uint8_t *rec = lds.rec(group);
+    if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte luma half of the DbRec
+    // this lane's four vertical-edge and four horizontal-edge strengths (bS | tC0 << 3), and the class parameters
+    int vb[4], hb[4], ab[6];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { vb[e] = rec[e * 4 + (l >> 2)]; hb[e] = rec[16 + e * 4 + (l >> 2)]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) ab[i] = rec[32 + i];
     // ---- vertical edges: lane = pixel row l ----
     uint32_t left = x > 0 ? *(const uint32_t *)(tp + l * 16 + 12) : 0;
     int p[20];
@@ -144,8 +156,8 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
       for (int i = 0; i < 20; i++) p[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255; }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        int bs = nib(bsw, e * 4 + (l >> 2));
-        if (bs) { int c = e ? 1 : 0; flt_luma(p + 4 * e, bs, byt(lpw, c * 5), byt(lpw, c * 5 + 1), bs < 4 ? byt(lpw, c * 5 + 1 + bs) : 0); }
+        int bs = vb[e] & 7;
+        if (bs) { const int c = e ? 1 : 0; flt_luma(p + 4 * e, bs, ab[2 * c], ab[2 * c + 1], vb[e] >> 3); }
     }
     uint32_t left_after = pack4(p);
     if (x > 0) *(uint32_t *)(tp + l * 16 + 12) = left_after;
@@ -160,8 +172,8 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
     for (int j = 0; j < 16; j++) c[4 + j] = tc[j * 16 + l];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        int bs = nib(bsw, 16 + e * 4 + (l >> 2));
-        if (bs) { int k = e ? 1 : 2; flt_luma(c + 4 * e, bs, byt(lpw, k * 5), byt(lpw, k * 5 + 1), bs < 4 ? byt(lpw, k * 5 + 1 + bs) : 0); }
+        int bs = hb[e] & 7;
+        if (bs) { const int k = e ? 1 : 2; flt_luma(c + 4 * e, bs, ab[2 * k], ab[2 * k + 1], hb[e] >> 3); }
     }
     if (ring_up) {
 #pragma unroll
@@ -206,14 +218,8 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
     uint8_t *ring_up = row > 0 ? lds.chroma_ring(row - 1, x & 3) : nullptr;
     uint8_t *ring_up_l = row > 0 ? lds.chroma_ring(row - 1, (x - 1) & 3) : nullptr;
     uint8_t *ring_dn = lds.chroma_ring(row, x & 3), *ring_dn_l = lds.chroma_ring(row, (x - 1) & 3);
-    uint32_t *rec = (uint32_t *)lds.rec(32 + group);
-    rec[l] = recdw;
-    uint32_t rw[16];
-    {
-#pragma unroll
-        for (int i = 0; i < 4; i++) { uint4 a = *(const uint4 *)(rec + 4 * i); rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
-    }
-    const uint32_t *bsw = rw;                 // cp bytes start at byte 31 of the record
+    uint8_t *rec = lds.rec(group);
+    if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte chroma half of the DbRec
     // ---- vertical edges (chroma columns 0 and 4 <-> luma edges 0 and 2): lane = (plane, chroma row) ----
     {
         int plane = l >> 3, r = l & 7;
@@ -224,14 +230,16 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
         int b[20];
 #pragma unroll
         for (int i = 0; i < 20; i++) b[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255;
-        int cbase = 31 + plane * 15;
+        int vb[2] = { rec[plane * 16 + (r >> 1)], rec[plane * 16 + 4 + (r >> 1)] };
+        int ab[4] = { rec[32 + plane * 6], rec[32 + plane * 6 + 1], rec[32 + plane * 6 + 2], rec[32 + plane * 6 + 3] };
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-            int bs = nib(bsw, e * 4 + (r >> 1));
+            int bs = vb[e >> 1] & 7;
             if (!bs) continue;
-            int k = e ? 1 : 0, o = 4 * e + plane;                       // p1 = b[o], p0 = b[o+2], q0 = b[o+4], q1 = b[o+6]
+            const int k = e ? 1 : 0;
+            int o = 4 * e + plane;                                        // p1 = b[o], p0 = b[o+2], q0 = b[o+4], q1 = b[o+6]
             int p0 = b[o + 2], q0 = b[o + 4];
-            flt_chroma(b[o], p0, q0, b[o + 6], bs, byt(rw, cbase + k * 5), byt(rw, cbase + k * 5 + 1), bs < 4 ? byt(rw, cbase + k * 5 + 1 + bs) : 0);
+            flt_chroma(b[o], p0, q0, b[o + 6], bs, ab[2 * k], ab[2 * k + 1], vb[e >> 1] >> 3);
             if (e == 0) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
             else { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
         }
@@ -240,17 +248,20 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
     if (x > 0 && l < 2) *(uint32_t *)(ring_dn_l + l * 16 + 12) = *(const uint32_t *)(tp + (6 + l) * 16 + 12);
     // ---- horizontal edges (chroma rows 0 and 4): lane = interleaved byte column ----
     {
-        int plane = l & 1, cbase = 31 + plane * 15;
+        int plane = l & 1;
+        int hb[2] = { rec[plane * 16 + 8 + (l >> 2)], rec[plane * 16 + 12 + (l >> 2)] };
+        int ab[4] = { rec[32 + plane * 6 + 4], rec[32 + plane * 6 + 5], rec[32 + plane * 6 + 2], rec[32 + plane * 6 + 3] };   // top class, internal class
         int c[10];
         c[0] = ring_up ? ring_up[l] : 0; c[1] = ring_up ? ring_up[16 + l] : 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) c[2 + j] = tc[j * 16 + l];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-            int bs = nib(bsw, 16 + e * 4 + (l >> 2));
+            int bs = hb[e >> 1] & 7;
             if (!bs) continue;
-            int k = e ? 1 : 2, o = 2 * e;                                 // p1 = c[o], p0 = c[o+1], q0 = c[o+2], q1 = c[o+3]
-            flt_chroma(c[o], c[o + 1], c[o + 2], c[o + 3], bs, byt(rw, cbase + k * 5), byt(rw, cbase + k * 5 + 1), bs < 4 ? byt(rw, cbase + k * 5 + 1 + bs) : 0);
+            const int k = e ? 1 : 0;                                      // ab[0..1] top class, ab[2..3] internal
+            const int o = 2 * e;                                          // p1 = c[o], p0 = c[o+1], q0 = c[o+2], q1 = c[o+3]
+            flt_chroma(c[o], c[o + 1], c[o + 2], c[o + 3], bs, ab[2 * k], ab[2 * k + 1], hb[e >> 1] >> 3);
         }
         if (ring_up) ring_up[16 + l] = (uint8_t)c[1];
         tc[l] = (uint8_t)c[2]; tc[3 * 16 + l] = (uint8_t)c[5]; tc[4 * 16 + l] = (uint8_t)c[6];
@@ -283,16 +294,19 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_deblock_lds(PicParams pp, const DbRec *recs) {
+// grid = 2 workgroups of 512 threads: block 0 filters luma, block 1 chroma (independent planes, no exchange).
+// 512 threads = 2 waves per SIMD, so each lane may use up to 256 VGPRs: the edge chains never spill.
+__global__ __launch_bounds__(512) void k_deblock_lds(PicParams pp, const DbRec *recs) {
     extern __shared__ __align__(16) uint8_t smem[];
     Lds lds{smem, pp.mb_h};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_chroma = wave >= 8;
-    const int group = (wave & 7) * 4 + (lane >> 4), l = lane & 15;
+    const bool is_chroma = blockIdx.x == 1;
+    const int group = wave * 4 + (lane >> 4), l = lane & 15;
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
     const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
     const int rows_per_mb = is_chroma ? 8 : 16;
     const int my_row = is_chroma ? (l & 7) : l;
+    const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
     uint4 pre_pix[kMaxSlots]; uint32_t pre_rec[kMaxSlots];
 #pragma unroll
     for (int k = 0; k < kMaxSlots; k++) { pre_pix[k] = make_uint4(0, 0, 0, 0); pre_rec[k] = 0; }
@@ -303,32 +317,46 @@ __global__ __launch_bounds__(1024) void k_deblock_lds(PicParams pp, const DbRec 
         int row = group + kGroups * k;
         if (row < mb_h && 2 * row == 0) {
             pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch);
-            pre_rec[k] = ((const uint32_t *)&recs[row * mb_w])[l];
+            pre_rec[k] = ((const uint32_t *)&recs[row * mb_w])[rec_dw];
         }
     }
     for (int s = 0; s < n_steps; s++) {
+        // (1) take delivery of what was prefetched during the previous step.  The empty asm "uses" the
+        //     registers, so the compiler's s_waitcnt lands HERE, before this step's loads are issued.
+        uint4 own[kMaxSlots]; uint32_t rdw[kMaxSlots];
+#pragma unroll
+        for (int k = 0; k < kMaxSlots; k++) {
+            own[k] = pre_pix[k]; rdw[k] = pre_rec[k];
+            asm volatile("" : "+v"(own[k].x), "+v"(own[k].y), "+v"(own[k].z), "+v"(own[k].w), "+v"(rdw[k]));
+        }
+        // (2) prefetch the macroblocks of the next step
 #pragma unroll
         for (int k = 0; k < kMaxSlots; k++) {
             int row = group + kGroups * k;
-            if (row >= mb_h) continue;
-            int x = s - 2 * row;
-            uint4 own = pre_pix[k]; uint32_t rdw = pre_rec[k];
-            int xn = x + 1;                                   // macroblock of the next step: prefetch now
-            if (xn >= 0 && xn < mb_w) {
+            int xn = s + 1 - 2 * row;
+            if (row < mb_h && xn >= 0 && xn < mb_w) {
                 pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
-                pre_rec[k] = ((const uint32_t *)&recs[row * mb_w + xn])[l];
-            }
-            if (x >= 0 && x < mb_w) {
-                if (is_chroma) chroma_mb(pp, lds, x, row, l, group, own, rdw);
-                else luma_mb(pp, lds, x, row, l, group, own, rdw);
+                pre_rec[k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
             }
         }
-        __syncthreads();
+        // (3) filter this step's macroblocks out of registers + LDS
+#pragma unroll
+        for (int k = 0; k < kMaxSlots; k++) {
+            int row = group + kGroups * k;
+            int x = s - 2 * row;
+            if (row < mb_h && x >= 0 && x < mb_w) {
+                if (is_chroma) chroma_mb(pp, lds, x, row, l, group, own[k], rdw[k]);
+                else luma_mb(pp, lds, x, row, l, group, own[k], rdw[k]);
+            }
+        }
+        // (4) step barrier: only LDS traffic has to be complete (a __syncthreads() would also drain vmcnt,
+        //     i.e. wait for the prefetch that was just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
 // ------------------------------------------------------------------------------------------
-size_t deblock_lds_bytes(int mb_h) { return (size_t)mb_h * kLdsPerRow + 64 * 64; }
+size_t deblock_lds_bytes(int mb_h) { return 2048 + (size_t)mb_h * 768; }      // luma workgroup's need (chroma needs half)
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
 
 void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st) {
@@ -341,7 +369,7 @@ void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st
     }
     int n = pp.mb_w * pp.mb_h;
     hipLaunchKernelGGL(k_deblock_prep, dim3((n + 7) / 8), dim3(256), 0, st, pp, (DbRec *)dbrec_scratch);
-    hipLaunchKernelGGL(k_deblock_lds, dim3(1), dim3(1024), deblock_lds_bytes(pp.mb_h), st, pp, (const DbRec *)dbrec_scratch);
+    hipLaunchKernelGGL(k_deblock_lds, dim3(2), dim3(512), deblock_lds_bytes(pp.mb_h), st, pp, (const DbRec *)dbrec_scratch);
 }
 
 }  // namespace jmamd

@@ -182,7 +182,7 @@ bool Decoder::gpu_alloc_sequence() {
         hipMemsetAsync(surf_[i], 128, surf_bytes_, stream_);
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
-    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 64))) { fail("hipMalloc(dbrec) failed"); return false; }
+    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96))) { fail("hipMalloc(dbrec) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
             !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }

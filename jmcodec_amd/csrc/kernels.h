@@ -7,7 +7,7 @@ namespace jmamd {
 void launch_recon_inter(const PicParams &pp, hipStream_t st);
 void launch_recon_intra(const PicParams &pp, hipStream_t st);
 void launch_deblock(const PicParams &pp, hipStream_t st);            // spin-wait wavefront (any picture height)
-// LDS-resident lockstep wavefront (deblock_lds.hip); dbrec_scratch: device buffer of 64 B per macroblock
+// LDS-resident lockstep wavefront (deblock_lds.hip); dbrec_scratch: device buffer of 96 B per macroblock
 bool deblock_lds_supported(int mb_w, int mb_h);
 void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st);
 // src: pitch-linear NV12 surface; dst: tight frame (out_fmt 0 = NV12, 1 = I420 order) of width x height
