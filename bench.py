@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -52,7 +53,7 @@ def main():
     import jmcodec_amd
     from jmcodec_amd import streams
     L = jmcodec_amd.lib()
-    if not jmcodec_amd.jm_nvdec_is_hw_support():
+    if not jmcodec_amd.jm_nvdec_is_hw_support() and not args.parse_only:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
 
     # ---- synthetic input: SURVEY 8d C1, seed = 0x4A4D0000 + 1*256 + stream_id (stream_id = rank) ----
@@ -67,6 +68,8 @@ def main():
     for _ in range(S):
         h = jmcodec_amd.jm_nvdec_create_handle()
         L.jm_amddec_set_option(h, b"profile", 1)
+        if args.parse_only:
+            L.jm_amddec_set_option(h, b"parse_only", 1)
         if jmcodec_amd.jm_nvdec_init(0, 1, None, 0, h) != 0:
             raise SystemExit("init failed: " + L.jm_amddec_last_error(h).decode())
         handles.append(h)
@@ -115,7 +118,8 @@ def main():
             t.join()
 
     def sync():
-        torch.cuda.synchronize()
+        if not args.parse_only:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -155,6 +159,8 @@ def main():
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
     threads = L.jm_amddec_get_stat(handles[0], b"threads")
+    host_diag = {k: round(sum(L.jm_amddec_get_stat(h, k.encode()) for h in handles) / 1e6 / max(1, sum(L.jm_amddec_get_stat(h, b"pictures") for h in handles)), 4)
+                 for k in ("submit_ns", "wait_slot_ns", "parse_ns_i", "parse_ns_p")}   # ms per picture, whole run
 
     # algorithmic bytes per launch (DESIGN.md "Kernels"): Wc x Hc coded, Wd x Hd display
     surf = 1.5 * mb_w * 16 * mb_h * 16
@@ -224,6 +230,7 @@ def main():
                    "host_parse_threads": int(threads), "includes": "host CAVLC + H2D + kernels + packout + D2H + memcpy to caller"},
         "frames": frames_total,
         "decode_errors": int(errors),
+        "host_ms_per_picture": host_diag,
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": None,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),

@@ -93,6 +93,10 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "device") return device_;
     if (k == "threads") return pool_threads();
     if (k == "elapsed_us") return (long long)(elapsed_ms_ * 1000.0);
+    if (k == "parse_ns_i") return stat_parse_ns_i_;
+    if (k == "submit_ns") return stat_submit_ns_;
+    if (k == "wait_slot_ns") return stat_wait_slot_ns_;
+    if (k == "parse_ns_p") return stat_parse_ns_p_;
     static const char *kn[4] = {"inter", "intra", "deblock", "packout"};
     for (int i = 0; i < 4; i++) {
         if (k == std::string("k_") + kn[i] + "_ns") return (long long)(prof_us_[i] * 1000.0);
@@ -141,6 +145,7 @@ void Decoder::gpu_free_sequence() {
     hipStreamSynchronize(stream_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
     if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
+    if (resid_) { hipFree(resid_); resid_ = nullptr; }
     for (auto &j : jobs_) {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
@@ -183,13 +188,23 @@ bool Decoder::gpu_alloc_sequence() {
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
     if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96))) { fail("hipMalloc(dbrec) failed"); return false; }
+    use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
+    if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(resid) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
             !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
         if (profile_) for (auto &e : j.pev) hipEventCreate(&e);
     }
-    return true;
+    // output slots: allocate the steady-state population now (hipHostMalloc costs milliseconds and serialises
+    // inside the runtime; it must never happen while pictures are in flight)
+    {
+        std::lock_guard<std::mutex> lk(mtx_);
+        std::vector<OutSlot *> tmp;
+        for (int i = 0; i < kJobSlots + 4; i++) tmp.push_back(alloc_out_slot());
+        for (OutSlot *o : tmp) free_out_.push_back(o);
+    }
+    return !failed_;
 }
 
 OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
@@ -534,6 +549,8 @@ void Decoder::harvest_out(OutSlot &o) {
 }
 
 int Decoder::acquire_job_slot() {
+    auto w0 = std::chrono::steady_clock::now();
+    struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{stat_wait_slot_ns_, w0};
     std::unique_lock<std::mutex> lk(mtx_);
     for (;;) {
         for (int i = 0; i < kJobSlots; i++) {
@@ -565,6 +582,7 @@ void Decoder::push_task(std::unique_ptr<PicTask> t) {
 // worker: entropy decode one picture into its job buffer
 // =============================================================================================
 void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
+    auto pt0 = std::chrono::steady_clock::now();
     JobSlot &js = jobs_[t->job_slot];
     const int n_mbs = t->sps.mb_w * t->sps.mb_h;
     scratch.resize(t->sps.mb_w, t->sps.mb_h);
@@ -605,6 +623,11 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
     stat_pictures_++; stat_job_bytes_ += (long long)t->upload_bytes; stat_intra_mbs_ += t->n_intra; stat_coef_ += w.coef_count;
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
+    {
+        long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
+        bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
+        (is_i ? stat_parse_ns_i_ : stat_parse_ns_p_) += ns;
+    }
     t->state.store(1, std::memory_order_release);
     submit_ready();
 }
@@ -647,6 +670,7 @@ void Decoder::enqueue_output(int slot) {
 }
 
 void Decoder::submit_task(PicTask *t) {
+    auto st0 = std::chrono::steady_clock::now();
     if (!parse_only_) hipSetDevice(device_);
     for (int s : t->out_before) enqueue_output(s);
     if (t->has_picture && !parse_only_ && !failed_) {
@@ -663,11 +687,14 @@ void Decoder::submit_task(PicTask *t) {
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
+        // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
+        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs;
+        pp.resid = (int16_t *)resid_; pp.want_intra_resid = lds_intra ? 1 : 0;
         js.pmask = 1 | (t->n_intra > 0 ? 2 : 0) | (t->any_deblock ? 4 : 0);
         if (profile_) hipEventRecord(js.pev[0], stream_);
         launch_recon_inter(pp, stream_);
         if (profile_) hipEventRecord(js.pev[1], stream_);
-        if (t->n_intra > 0) launch_recon_intra(pp, stream_);
+        if (t->n_intra > 0) { if (lds_intra) launch_intra_lds(pp, resid_, stream_); else launch_recon_intra(pp, stream_); }
         if (profile_) hipEventRecord(js.pev[2], stream_);
         if (t->any_deblock) { if (use_lds_deblock_) launch_deblock_lds(pp, dbrec_, stream_); else launch_deblock(pp, stream_); }
         if (profile_) hipEventRecord(js.pev[3], stream_);
@@ -676,6 +703,7 @@ void Decoder::submit_task(PicTask *t) {
         hipEventRecord(js.done, stream_);
     }
     for (int s : t->out_after) enqueue_output(s);
+    stat_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - st0).count();
 }
 
 // =============================================================================================

@@ -23,7 +23,7 @@ struct ihipStream_t; struct ihipEvent_t;
 
 namespace jmamd {
 
-constexpr int kJobSlots = 8;
+constexpr int kJobSlots = 24;   // pictures in flight per handle (parse + device); deep enough to hide an I picture's entropy decode behind a GOP of device work
 
 struct DpbPic {
     bool in_use = false; int ref = 0;          // 0 none, 1 short-term, 2 long-term
@@ -156,6 +156,7 @@ private:
     ihipStream_t *stream_ = nullptr;
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
+    uint8_t *resid_ = nullptr; bool use_lds_intra_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
     bool gpu_open_ = false;
 
@@ -164,6 +165,7 @@ private:
     uint32_t num_frames_ = 0;
     std::chrono::steady_clock::time_point t0_; bool timer_started_ = false; double elapsed_ms_ = 0;
     char info_[1024];
+    std::atomic<long long> stat_parse_ns_i_{0}, stat_parse_ns_p_{0}, stat_submit_ns_{0}, stat_wait_slot_ns_{0};
     std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0};
     SyntaxDigest digest_;
     long long stat_i_ = 0, stat_p_ = 0;

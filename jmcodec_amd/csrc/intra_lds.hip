@@ -1,0 +1,348 @@
+// jmcodec_amd/csrc/intra_lds.hip -- intra prediction + reconstruction (H.264 8.3), LDS-resident lockstep wavefront.
+//
+// Part of the replacement for cuvidDecodePicture (/root/reference/nv_dec/nv_dec.cpp:33-41).
+//
+// Intra prediction of MB(x,y) needs the UNFILTERED reconstructed samples of its left, top-left, top and
+// top-right neighbours, so macroblocks with equal s = x + 2y are independent and steps run in order
+// (the same diagonal as deblock_lds.hip).  Residuals do not depend on prediction: k_recon_inter computes them
+// for intra macroblocks too (dequant + DC Hadamard + inverse transform) into a per-MB int16 buffer, so the
+// serial part here is prediction + add only.
+//
+// grid = 2 workgroups x 512 threads: block 0 luma, block 1 chroma; 16 lanes per macroblock, 32 macroblock rows
+// in flight per block, one raw s_barrier per step.  Neighbour samples never come from HBM: each macroblock
+// row keeps in LDS the right column of its last macroblock and a 4-slot ring of bottom rows; macroblocks that
+// are not intra (inter / I_PCM, already reconstructed by k_recon_inter) just refresh those from prefetched
+// samples.  Intra4x4 is branch-free: every mode is "copy / 2-tap / 3-tap around centre c" on the 15-entry edge
+// path  L3' L3 L2 L1 L0 TL T0..T7 T7'  and (c, kind) comes from a 9x16 table built in LDS at kernel start.
+#include <hip/hip_runtime.h>
+#include "jobs.h"
+#include "kernels.h"
+#include "kernel_common.h"
+
+namespace jmamd {
+
+constexpr int kIGroups = 32;
+constexpr int kISlots = 5;
+
+// (c, kind) of Intra4x4 mode `mode` for pixel (x, y); kind 0 copy P[c], 1 two-tap (P[c]+P[c+1]+1)>>1,
+// 2 three-tap (P[c-1]+2P[c]+P[c+1]+2)>>2, 3 DC.  Edge path index: 0 L3' 1 L3 2 L2 3 L1 4 L0 5 TL 6..13 T0..T7 14 T7'
+__device__ int i4_table_entry(int mode, int x, int y) {
+    int c = 0, kind = 0;
+    switch (mode) {
+    case 0: c = 6 + x; kind = 0; break;
+    case 1: c = 4 - y; kind = 0; break;
+    case 2: c = 0; kind = 3; break;
+    case 3: c = 7 + x + y; kind = 2; break;
+    case 4: c = 5 + x - y; kind = 2; break;
+    case 5: { int z = 2 * x - y, i = x - (y >> 1);
+        if (z >= 0) { c = 5 + i; kind = (z & 1) ? 2 : 1; }
+        else if (z == -1) { c = 5; kind = 2; }
+        else { c = 6 - y; kind = 2; }
+        break; }
+    case 6: { int z = 2 * y - x, i = y - (x >> 1);
+        if (z >= 0) { if (z & 1) { c = 5 - i; kind = 2; } else { c = 4 - i; kind = 1; } }
+        else if (z == -1) { c = 5; kind = 2; }
+        else { c = 4 + x; kind = 2; }
+        break; }
+    case 7: { int i = x + (y >> 1); if (y & 1) { c = 7 + i; kind = 2; } else { c = 6 + i; kind = 1; } break; }
+    default: { int z = x + 2 * y, i = y + (x >> 1);
+        if (z > 5) { c = 1; kind = 0; }
+        else if (z == 5) { c = 1; kind = 2; }
+        else if (z & 1) { c = 3 - i; kind = 2; }
+        else { c = 3 - i; kind = 1; }
+        break; }
+    }
+    return c | (kind << 4);
+}
+
+// LDS image of one workgroup
+struct ILds {
+    uint8_t *base; int mb_h;
+    // common
+    __device__ uint8_t *i4tab() const { return base; }                                            // 144 B
+    __device__ uint8_t *rec(int g) const { return base + 256 + g * 32; }                          // MbRec staging, 32 groups
+    // luma: tile[17][24] per group (408 -> 416), residual [16][16] int16 per group (512)
+    __device__ uint8_t *ltile(int g) const { return base + 1280 + g * 416; }
+    __device__ short *lres(int g) const { return (short *)(base + 1280 + 32 * 416 + g * 512); }
+    __device__ uint8_t *lrcol(int row) const { return base + 1280 + 32 * 928 + row * 16; }
+    __device__ uint8_t *lring(int row, int slot) const { return base + 1280 + 32 * 928 + mb_h * 16 + row * 64 + slot * 16; }
+    // chroma: tile [8][16] interleaved per group (128), right column [8][2] per row, ring 4 x 16 B per row
+    __device__ uint8_t *ctile(int g) const { return base + 1280 + g * 128; }
+    __device__ uint8_t *crcol(int row) const { return base + 1280 + 32 * 128 + row * 16; }
+    __device__ uint8_t *cring(int row, int slot) const { return base + 1280 + 32 * 128 + mb_h * 16 + row * 64 + slot * 16; }
+};
+
+// sum over the 16 (or n) lanes of a group
+__device__ __forceinline__ int group_sum16(int v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ int sum8(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+__device__ __forceinline__ int sum4(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+
+// ------------------------------------------------------------------------------------------
+// luma, one macroblock, 16 lanes.  res0/res1: this lane's residual row (16 int16); right4/bottom: prefetched
+// samples of an already reconstructed (non-intra) macroblock: columns 12..15 of row l, and the whole row 15.
+// ------------------------------------------------------------------------------------------
+__device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int row, int l, int g,
+                              uint32_t recdw, uint4 res0, uint4 res1, uint32_t right4, uint4 bottom) {
+    uint8_t *rcol = lds.lrcol(row);
+    uint8_t *ring_dn = lds.lring(row, x & 3);
+    // MbRec through LDS (8 dwords); every lane needs kind / modes / flags / i4 modes
+    uint32_t *rec = (uint32_t *)lds.rec(g);
+    if (l < 8) rec[l] = recdw;
+    uint32_t r0 = rec[0];
+    int kind = r0 & 255, modes = (r0 >> 16) & 255, flags = r0 >> 24;
+    if (kind != MB_I4 && kind != MB_I16) {
+        // reconstructed earlier: publish its right column and bottom row for the neighbours
+        rcol[l] = (uint8_t)(right4 >> 24);
+        if (l < 4) ((uint32_t *)ring_dn)[l] = l == 0 ? bottom.x : (l == 1 ? bottom.y : (l == 2 ? bottom.z : bottom.w));
+        return;
+    }
+    bool availA = flags & MBF_AVAIL_A, availB = flags & MBF_AVAIL_B, availC = flags & MBF_AVAIL_C, availD = flags & MBF_AVAIL_D;
+    uint8_t *dst = pp.surf[pp.cur] + (size_t)(row * 16 + l) * pp.pitch + x * 16;
+    const uint8_t *ring_up = row > 0 ? lds.lring(row - 1, x & 3) : ring_dn;           // only read when availB
+    const uint8_t *ring_ur = row > 0 ? lds.lring(row - 1, (x + 1) & 3) : ring_dn;
+    const uint8_t *ring_ul = row > 0 ? lds.lring(row - 1, (x - 1) & 3) : ring_dn;
+    int rs[16];
+    { uint32_t w[8] = {res0.x, res0.y, res0.z, res0.w, res1.x, res1.y, res1.z, res1.w};
+#pragma unroll
+      for (int i = 0; i < 16; i++) rs[i] = (int)(short)(w[i >> 1] >> ((i & 1) * 16)); }
+    int left = rcol[l], corner = ring_ul[15];
+    int out[16];
+    if (kind == MB_I16) {
+        int mode = (modes >> 2) & 3;
+        uint4 tv = *(const uint4 *)ring_up;
+        int T[16];
+        { uint32_t w[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+          for (int i = 0; i < 16; i++) T[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255; }
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = T[i];
+        } else if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = left;
+        } else if (mode == 2) {
+            int st = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) st += T[i];
+            int sl = group_sum16(left);
+            int dc = (availA && availB) ? (st + sl + 16) >> 5 : (availA ? (sl + 8) >> 4 : (availB ? (st + 8) >> 4 : 128));
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = dc;
+        } else {
+            int Hs = -8 * corner;
+#pragma unroll
+            for (int i = 0; i < 16; i++) Hs += (i - 7) * T[i];
+            int Vs = group_sum16((l - 7) * left) - 8 * corner;
+            int l15 = __shfl(left, (threadIdx.x & 48) | 15);
+            int a = 16 * (l15 + T[15]), b = (5 * Hs + 32) >> 6, c = (5 * Vs + 32) >> 6;
+            int base = a + c * (l - 7) + 16;
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = clip1((base + b * (i - 7)) >> 5);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = clip1(out[i] + rs[i]);
+    } else {
+        // ---- Intra4x4: work tile in LDS: tile[0] = row above (col 0 corner, 1..16, 17..20 top-right), col 0 = left ----
+        uint8_t *tile = lds.ltile(g);
+        short *res = lds.lres(g);
+        *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
+        tile[(1 + l) * 24] = (uint8_t)left;
+        tile[1 + l] = ring_up[l];
+        if (l < 4) tile[17 + l] = ring_ur[l];
+        if (l == 0) tile[0] = (uint8_t)corner;
+        const uint8_t *tab = lds.i4tab();
+        uint32_t m0 = rec[4], m1 = rec[5];                         // u.i4[8]: two 4-bit modes per byte, raster order
+        int px = l & 3, py = l >> 2;
+        // everything that does not depend on earlier blocks is fetched up front: table entries and this lane's residuals
+        int ent[16], rsd[16];
+#pragma unroll
+        for (int blk = 0; blk < 16; blk++) {
+            const int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3), rpos = by * 4 + bx;
+            int mode = ((rpos < 8 ? m0 : m1) >> ((rpos & 7) * 4)) & 15;
+            ent[blk] = tab[mode * 16 + l];
+            rsd[blk] = res[(by * 4 + py) * 16 + bx * 4 + px];
+        }
+#pragma unroll
+        for (int blk = 0; blk < 16; blk++) {
+            const int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+            const bool a = bx > 0 || availA, b = by > 0 || availB;
+            const bool cavail = by == 0 ? (bx < 3 ? availB : availC) : !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
+            const int c = ent[blk] & 15, kd = ent[blk] >> 4;
+            uint8_t *org = tile + (by * 4) * 24 + bx * 4;     // corner sample of this block
+            // offset of edge-path entry k relative to org: k<=4 left column (row 5-k), k==5 corner, k>=6 row above
+            int off[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                int k = c - 1 + t;
+                k = k < 1 ? 1 : (k > 13 ? 13 : k);
+                int xx = k - 6;
+                if (!cavail && xx > 3) xx = 3;
+                off[t] = k <= 4 ? (5 - k) * 24 : (k == 5 ? 0 : 1 + xx);
+            }
+            int pred;
+            if (kd == 3) {
+                int st = org[1] + org[2] + org[3] + org[4], sl = org[24] + org[48] + org[72] + org[96];
+                pred = (a && b) ? (st + sl + 4) >> 3 : (a ? (sl + 2) >> 2 : (b ? (st + 2) >> 2 : 128));
+            } else {
+                int v0 = org[off[0]], v1 = org[off[1]], v2 = org[off[2]];
+                pred = kd == 2 ? (v0 + 2 * v1 + v2 + 2) >> 2 : (kd == 1 ? (v1 + v2 + 1) >> 1 : v1);
+            }
+            org[(1 + py) * 24 + 1 + px] = (uint8_t)clip1(pred + rsd[blk]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * 24 + 1 + i];
+    }
+    uint32_t o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24), o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+    uint32_t o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24), o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
+    *(uint4 *)dst = make_uint4(o0, o1, o2, o3);
+    rcol[l] = (uint8_t)out[15];
+    if (l == 15) *(uint4 *)ring_dn = make_uint4(o0, o1, o2, o3);
+}
+
+// ------------------------------------------------------------------------------------------
+// chroma, one macroblock, 16 lanes: lane = (plane, row).  res: 8 int16 of this lane's row; right2/bottom:
+// prefetched samples of an already reconstructed macroblock (UV pair of column 7 in row r; whole row 7).
+// ------------------------------------------------------------------------------------------
+__device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int row, int l, int g,
+                                uint32_t recdw, uint4 res, uint32_t right2, uint4 bottom) {
+    uint8_t *rcol = lds.crcol(row);                // [8 rows][2 planes]
+    uint8_t *ring_dn = lds.cring(row, x & 3);      // 16 B interleaved bottom row
+    uint32_t *rec = (uint32_t *)lds.rec(g);
+    if (l < 8) rec[l] = recdw;
+    uint32_t r0 = rec[0];
+    int kind = r0 & 255, modes = (r0 >> 16) & 255, flags = r0 >> 24;
+    int plane = l >> 3, r = l & 7;
+    if (kind != MB_I4 && kind != MB_I16) {
+        rcol[r * 2 + plane] = (uint8_t)(right2 >> (16 + 8 * plane));      // bytes 14, 15 of the row = column 7 (U, V)
+        if (l < 4) ((uint32_t *)ring_dn)[l] = l == 0 ? bottom.x : (l == 1 ? bottom.y : (l == 2 ? bottom.z : bottom.w));
+        return;
+    }
+    bool availA = flags & MBF_AVAIL_A, availB = flags & MBF_AVAIL_B;
+    int cmode = modes & 3;
+    const uint8_t *ring_up = row > 0 ? lds.cring(row - 1, x & 3) : ring_dn;
+    const uint8_t *ring_ul = row > 0 ? lds.cring(row - 1, (x - 1) & 3) : ring_dn;
+    int rs[8];
+    { uint32_t w[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) rs[i] = (int)(short)(w[i >> 1] >> ((i & 1) * 16)); }
+    int left = rcol[r * 2 + plane], corner = ring_ul[14 + plane];
+    uint4 tv = *(const uint4 *)ring_up;
+    int T[8];
+    { uint32_t w[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) T[i] = (w[i >> 1] >> (((i & 1) * 2 + plane) * 8)) & 255; }
+    int out[8];
+    if (cmode == 0) {
+        int by = r >> 2;
+        int sl = sum4(left);                                 // left sum of this lane's 4-row band (same plane: lanes differ in bits 0,1)
+        int st0 = T[0] + T[1] + T[2] + T[3], st1 = T[4] + T[5] + T[6] + T[7];
+        int dc0, dc1;                                        // blocks (0,by) and (1,by)
+        if (by == 0) {
+            dc0 = (availA && availB) ? (st0 + sl + 4) >> 3 : (availA ? (sl + 2) >> 2 : (availB ? (st0 + 2) >> 2 : 128));
+            dc1 = availB ? (st1 + 2) >> 2 : (availA ? (sl + 2) >> 2 : 128);
+        } else {
+            dc0 = availA ? (sl + 2) >> 2 : (availB ? (st0 + 2) >> 2 : 128);
+            dc1 = (availA && availB) ? (st1 + sl + 4) >> 3 : (availA ? (sl + 2) >> 2 : (availB ? (st1 + 2) >> 2 : 128));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = i < 4 ? dc0 : dc1;
+    } else if (cmode == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = left;
+    } else if (cmode == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = T[i];
+    } else {
+        int Hs = -4 * corner;
+#pragma unroll
+        for (int i = 0; i < 8; i++) Hs += (i - 3) * T[i];
+        int Vs = sum8((r - 3) * left) - 4 * corner;
+        int l7 = __shfl(left, (threadIdx.x & 56) | 7);
+        int a = 16 * (l7 + T[7]), b = (34 * Hs + 32) >> 6, c = (34 * Vs + 32) >> 6;
+        int base = a + c * (r - 3) + 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = clip1((base + b * (i - 3)) >> 5);
+    }
+    uint8_t *tile = lds.ctile(g);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { out[i] = clip1(out[i] + rs[i]); tile[r * 16 + 2 * i + plane] = (uint8_t)out[i]; }
+    rcol[r * 2 + plane] = (uint8_t)out[7];
+    if (l < 8) {
+        uint4 v = *(const uint4 *)(tile + l * 16);
+        *(uint4 *)(pp.surf[pp.cur] + pp.chroma_offset + (size_t)(row * 8 + l) * pp.pitch + x * 16) = v;
+        if (l == 7) *(uint4 *)ring_dn = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_intra_lds(PicParams pp, const short *resid) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    ILds lds{smem, pp.mb_h};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool is_chroma = blockIdx.x == 1;
+    const int g = wave * 4 + (lane >> 4), l = lane & 15;
+    const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
+    if (threadIdx.x < 144) lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
+    const int rows_per_mb = is_chroma ? 8 : 16, my_row = is_chroma ? (l & 7) : l;
+    uint32_t p_rec[kISlots], p_right[kISlots]; uint4 p_res0[kISlots], p_res1[kISlots], p_bot[kISlots];
+#pragma unroll
+    for (int k = 0; k < kISlots; k++) { p_rec[k] = 0; p_right[k] = 0; p_res0[k] = p_res1[k] = p_bot[k] = make_uint4(0, 0, 0, 0); }
+    const int n_steps = mb_w + 2 * (mb_h - 1);
+    auto prefetch = [&](int k, int row, int xn) {
+        int mb = row * mb_w + xn;
+        p_rec[k] = ((const uint32_t *)&pp.mbs[mb])[l & 7];
+        const uint8_t *px = plane_base + (size_t)(row * rows_per_mb) * pitch + xn * 16;
+        p_right[k] = *(const uint32_t *)(px + (size_t)my_row * pitch + 12);
+        p_bot[k] = *(const uint4 *)(px + (size_t)(rows_per_mb - 1) * pitch);
+        const short *rs = resid + (size_t)mb * 384;
+        if (is_chroma) p_res0[k] = *(const uint4 *)(rs + 256 + l * 8);               // plane (l>>3), row (l&7): 8 int16
+        else { p_res0[k] = *(const uint4 *)(rs + l * 16); p_res1[k] = *(const uint4 *)(rs + l * 16 + 8); }
+    };
+#pragma unroll
+    for (int k = 0; k < kISlots; k++) { int row = g + kIGroups * k; if (row == 0) prefetch(k, 0, 0); }
+    for (int s = 0; s < n_steps; s++) {
+        uint32_t c_rec[kISlots], c_right[kISlots]; uint4 c_res0[kISlots], c_res1[kISlots], c_bot[kISlots];
+#pragma unroll
+        for (int k = 0; k < kISlots; k++) {
+            c_rec[k] = p_rec[k]; c_right[k] = p_right[k]; c_res0[k] = p_res0[k]; c_res1[k] = p_res1[k]; c_bot[k] = p_bot[k];
+            asm volatile("" : "+v"(c_rec[k]), "+v"(c_right[k]), "+v"(c_res0[k].x), "+v"(c_res0[k].y), "+v"(c_res0[k].z), "+v"(c_res0[k].w),
+                              "+v"(c_res1[k].x), "+v"(c_res1[k].y), "+v"(c_res1[k].z), "+v"(c_res1[k].w),
+                              "+v"(c_bot[k].x), "+v"(c_bot[k].y), "+v"(c_bot[k].z), "+v"(c_bot[k].w));
+        }
+#pragma unroll
+        for (int k = 0; k < kISlots; k++) {
+            int row = g + kIGroups * k, xn = s + 1 - 2 * row;
+            if (row < mb_h && xn >= 0 && xn < mb_w) prefetch(k, row, xn);
+        }
+#pragma unroll
+        for (int k = 0; k < kISlots; k++) {
+            int row = g + kIGroups * k, x = s - 2 * row;
+            if (row < mb_h && x >= 0 && x < mb_w) {
+                if (is_chroma) intra_chroma_mb(pp, lds, x, row, l, g, c_rec[k], c_res0[k], c_right[k], c_bot[k]);
+                else intra_luma_mb(pp, lds, x, row, l, g, c_rec[k], c_res0[k], c_res1[k], c_right[k], c_bot[k]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+size_t intra_lds_bytes(int mb_h) { return 1280 + 32 * 928 + (size_t)mb_h * 80 + 64; }
+bool intra_lds_supported(int mb_w, int mb_h) { return mb_h <= kIGroups * kISlots && intra_lds_bytes(mb_h) <= 150 * 1024; }
+
+void launch_intra_lds(const PicParams &pp, const void *resid, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        hipFuncSetAttribute((const void *)k_intra_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_intra_lds, dim3(2), dim3(512), intra_lds_bytes(pp.mb_h), st, pp, (const short *)resid);
+}
+
+}  // namespace jmamd

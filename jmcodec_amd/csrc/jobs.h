@@ -76,6 +76,8 @@ struct PicParams {
     const SliceRec *slices;
     const int16_t *mv_ext;
     const int16_t *coef;
+    int16_t *resid;               // per-handle scratch: residual of intra macroblocks, 384 int16 per MB (Y 16x16, Cb 8x8, Cr 8x8)
+    int want_intra_resid;         // 1: k_recon_inter also writes the residual of Intra4x4/16x16 macroblocks to resid
 };
 
 }  // namespace jmamd

@@ -132,10 +132,19 @@ __global__ __launch_bounds__(256) void k_recon_inter(PicParams pp) {
     MbRec r;
     if (valid) r = pp.mbs[mb]; else { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
     bool inter = valid && r.kind == MB_INTER;
-    bool has_res = inter && mb_has_residual(r);
+    bool intra_res = valid && pp.want_intra_resid && (r.kind == MB_I4 || r.kind == MB_I16);
+    bool has_res = (inter || intra_res) && mb_has_residual(r);
     if (has_res) mb_residual_to_lds(pp, r, tiles[wave], lane);
     __syncthreads();
     if (!valid) return;
+    if (intra_res) {
+        // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
+        if (lane < 48) {
+            uint4 v = has_res ? *(const uint4 *)((const short *)&tiles[wave] + lane * 8) : make_uint4(0, 0, 0, 0);
+            *(uint4 *)(pp.resid + (size_t)mb * 384 + lane * 8) = v;
+        }
+        return;
+    }
     int mbx = mb % pp.mb_w, mby = mb / pp.mb_w;
     int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
     uint8_t *dst = pp.surf[pp.cur];

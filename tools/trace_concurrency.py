@@ -1,0 +1,24 @@
+"""Developer script: kernel-level concurrency histogram + per-kernel busy time from a rocprofv3 kernel trace CSV."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+t_first = min(int(r["Start_Timestamp"]) for r in rows if "k_recon_inter" in r["Kernel_Name"])
+rows = [r for r in rows if int(r["Start_Timestamp"]) >= t_first]      # decode phase only (skip allocation memsets)
+qbusy = collections.Counter()
+ev = []
+per = collections.defaultdict(lambda: [0, 0])
+qs = set()
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    ev.append((s, 1)); ev.append((e, -1)); qs.add(r["Queue_Id"])
+    n = r["Kernel_Name"].split("(")[0]; per[n][0] += e - s; per[n][1] += 1; qbusy[r["Queue_Id"]] += e - s
+ev.sort()
+cur, last, hist = 0, ev[0][0], collections.Counter()
+for t, d in ev:
+    hist[cur] += t - last; last = t; cur += d
+tot = sum(hist.values())
+print("kernels", len(rows), "queues", len(qs), "span ms %.1f" % (tot / 1e6))
+print("concurrency histogram (% of span):", {k: round(100 * v / tot, 1) for k, v in sorted(hist.items())})
+print("mean concurrency %.2f" % (sum(k * v for k, v in hist.items()) / tot))
+for n, (t, c) in sorted(per.items(), key=lambda x: -x[1][0]):
+    print("  %-40s calls %6d total ms %9.1f avg us %9.1f" % (n[-40:], c, t / 1e6, t / c / 1e3))
+print("per-queue busy % of span:", sorted(round(100 * v / tot, 1) for v in qbusy.values()))
