@@ -46,13 +46,19 @@ void pool_submit(Decoder *d, PicTask *t) { Pool &p = pool(); { std::lock_guard<s
 int pool_threads() { return pool().n; }
 
 // =============================================================================================
-Decoder::Decoder() { memset(info_, 0, sizeof info_); }
+static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+Decoder::Decoder() { memset(info_, 0, sizeof info_); trace_on_ = getenv("JM_AMD_DEC_TRACE") != nullptr; }
 
 Decoder::~Decoder() {
     // wait until no worker still references this object
     { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
     { std::lock_guard<std::mutex> lk(submit_mtx_); }
     gpu_close();
+    if (trace_on_ && !trace_.empty()) {
+        char name[256]; snprintf(name, sizeof name, "%s.%p.csv", getenv("JM_AMD_DEC_TRACE"), (void *)this);
+        if (FILE *f = fopen(name, "w")) { fprintf(f, "seq,is_i,dispatch,parsed,submit0,submit1\n"); for (auto &r : trace_) fprintf(f, "%llu,%d,%lld,%lld,%lld,%lld\n", (unsigned long long)r.seq, r.is_i, r.t_dispatch, r.t_parsed, r.t_submit0, r.t_submit1); fclose(f); }
+    }
 }
 
 void Decoder::fail(const std::string &msg) {
@@ -135,6 +141,9 @@ bool Decoder::gpu_open() {
     hipStream_t st;
     if (!HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) { fail("hipStreamCreate failed"); return false; }
     stream_ = st;
+    hipStream_t cs;
+    if (!HIP_OK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking))) { fail("hipStreamCreate failed"); return false; }
+    copy_stream_ = cs;
     gpu_open_ = true;
     return true;
 }
@@ -143,6 +152,7 @@ void Decoder::gpu_free_sequence() {
     if (!gpu_open_) return;
     hipSetDevice(device_);
     hipStreamSynchronize(stream_);
+    hipStreamSynchronize(copy_stream_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
     if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
@@ -150,6 +160,7 @@ void Decoder::gpu_free_sequence() {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
         if (j.done) hipEventDestroy(j.done);
+        if (j.uploaded) hipEventDestroy(j.uploaded);
         for (auto e : j.pev) if (e) hipEventDestroy(e);
         j = JobSlot();
     }
@@ -166,6 +177,7 @@ void Decoder::gpu_close() {
     if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); for (auto &j : jobs_) { free(j.host); j.host = nullptr; } return; }
     gpu_free_sequence();
     hipStreamDestroy(stream_);
+    hipStreamDestroy(copy_stream_);
     gpu_open_ = false;
 }
 
@@ -192,7 +204,7 @@ bool Decoder::gpu_alloc_sequence() {
     if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(resid) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
-            !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
+            !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming)) || !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
         if (profile_) for (auto &e : j.pev) hipEventCreate(&e);
     }
@@ -212,7 +224,7 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     OutSlot *o = new OutSlot();
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_)) ||
+        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault)) ||
             !HIP_OK(hipEventCreateWithFlags(&o->done, hipEventDisableTiming))) { fail("output buffer allocation failed"); }
         if (profile_) for (auto &e : o->pev) hipEventCreate(&e);
     }
@@ -568,6 +580,7 @@ int Decoder::acquire_job_slot() {
 
 void Decoder::push_task(std::unique_ptr<PicTask> t) {
     PicTask *raw = t.get();
+    raw->t_dispatch = now_ns();
     {
         std::lock_guard<std::mutex> lk(mtx_);
         raw->seq = next_seq_++;
@@ -623,11 +636,18 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
     stat_pictures_++; stat_job_bytes_ += (long long)t->upload_bytes; stat_intra_mbs_ += t->n_intra; stat_coef_ += w.coef_count;
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
+    if (!parse_only_ && !failed_) {
+        // upload now, out of decode order: the device copy of the job list only has to exist before this picture's kernels
+        hipSetDevice(device_);
+        hipMemcpyAsync(js.dev, js.host, t->upload_bytes, hipMemcpyHostToDevice, copy_stream_);
+        hipEventRecord(js.uploaded, copy_stream_);
+    }
     {
         long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
         bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
         (is_i ? stat_parse_ns_i_ : stat_parse_ns_p_) += ns;
     }
+    t->t_parsed = now_ns();
     t->state.store(1, std::memory_order_release);
     submit_ready();
 }
@@ -644,7 +664,9 @@ void Decoder::submit_ready() {
             if (inflight_.empty() || inflight_.front()->state.load(std::memory_order_acquire) != 1) break;
             t = inflight_.front().get();
         }
+        long long ts0 = now_ns();
         submit_task(t);
+        if (trace_on_ && t->has_picture) trace_.push_back(TraceRec{t->seq, t->t_dispatch, t->t_parsed, ts0, now_ns(), (!t->slices.empty() && t->slices[0].sh.type == SL_I) ? 1 : 0});
         {
             std::lock_guard<std::mutex> lk(mtx_);
             if (t->job_slot >= 0) jobs_[t->job_slot].submitted = true;
@@ -660,9 +682,10 @@ void Decoder::enqueue_output(int slot) {
     { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); }
     if (!parse_only_ && !failed_) {
         if (profile_) hipEventRecord(o->pev[0], stream_);
-        launch_packout(surf_[slot], pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, o->dev, stream_);
+        // k_packout stores the tight frame straight into the pinned host slot (PCIe writes from the kernel): no copy-engine
+        // hop, so nothing of this stream can queue behind another stream's transfer
+        launch_packout(surf_[slot], pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, o->host, stream_);
         if (profile_) hipEventRecord(o->pev[1], stream_);
-        hipMemcpyAsync(o->host, o->dev, frame_bytes_, hipMemcpyDeviceToHost, stream_);
         hipEventRecord(o->done, stream_);
         o->has_data = true;
     }
@@ -675,7 +698,7 @@ void Decoder::submit_task(PicTask *t) {
     for (int s : t->out_before) enqueue_output(s);
     if (t->has_picture && !parse_only_ && !failed_) {
         JobSlot &js = jobs_[t->job_slot];
-        hipMemcpyAsync(js.dev, js.host, t->upload_bytes, hipMemcpyHostToDevice, stream_);
+        hipStreamWaitEvent(stream_, js.uploaded, 0);
         const int n_mbs = t->sps.mb_w * t->sps.mb_h;
         PicParams pp;
         memset(&pp, 0, sizeof pp);

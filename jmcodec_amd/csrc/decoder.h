@@ -51,11 +51,13 @@ struct PicTask {
     int n_intra = 0, n_slices = 0; bool any_deblock = false;
     uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0;
     std::string error;
+    long long t_dispatch = 0, t_parsed = 0;    // host steady-clock ns (JM_AMD_DEC_TRACE)
 };
 
 struct JobSlot {
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
     ihipEvent_t *done = nullptr;
+    ihipEvent_t *uploaded = nullptr;                              // job list is in device memory (recorded on the copy stream)
     ihipEvent_t *pev[4] = {nullptr, nullptr, nullptr, nullptr};   // profile option: before inter / intra / deblock, after deblock
     int pmask = 0;                                                // bit k: kernel k was launched for the picture in this slot
     bool busy = false, submitted = false;
@@ -154,6 +156,7 @@ private:
 
     // device
     ihipStream_t *stream_ = nullptr;
+    ihipStream_t *copy_stream_ = nullptr;      // job-list uploads run ahead of the decode stream, ordered only by events
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false;
@@ -170,6 +173,8 @@ private:
     SyntaxDigest digest_;
     long long stat_i_ = 0, stat_p_ = 0;
     std::vector<int> display_pocs_;            // diagnostic (get via stats)
+    struct TraceRec { uint64_t seq; long long t_dispatch, t_parsed, t_submit0, t_submit1; int is_i; };
+    std::vector<TraceRec> trace_; bool trace_on_ = false;
 };
 
 // process-wide parse worker pool
