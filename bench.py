@@ -25,9 +25,9 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("JM_BENCH_STREAMS", "8")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("JM_BENCH_STREAMS", "32")))
     ap.add_argument("--frames", type=int, default=60, help="frames per stream per step (multiple of the GOP, 30)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -67,7 +67,7 @@ def main():
     handles = []
     for _ in range(S):
         h = jmcodec_amd.jm_nvdec_create_handle()
-        L.jm_amddec_set_option(h, b"profile", 1)
+        L.jm_amddec_set_option(h, b"profile", 1)          # the engine records HIP events around each batched launch
         if args.parse_only:
             L.jm_amddec_set_option(h, b"parse_only", 1)
         if jmcodec_amd.jm_nvdec_init(0, 1, None, 0, h) != 0:
@@ -125,7 +125,11 @@ def main():
 
     if W > 0:
         batch(W)
-    prof0 = [[L.jm_amddec_get_stat(h, f"k_{k}_{s}".encode()) for k in ("inter", "intra", "deblock", "packout") for s in ("ns", "n")] for h in handles]
+    KN = ("inter", "intra", "deblock", "packout")
+    def eng():      # engine-wide counters (one engine per device serves every handle)
+        return {k: {f: L.jm_amddec_get_stat(handles[0], f"k_{k}_{f}".encode()) for f in ("ns", "n", "pics", "alg_bytes")} for k in KN}
+    e0 = eng()
+    b0 = (L.jm_amddec_get_stat(handles[0], b"eng_batches"), L.jm_amddec_get_stat(handles[0], b"eng_batch_pics"))
     jb0 = [L.jm_amddec_get_stat(h, b"job_bytes") for h in handles]
     pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
     for i in range(S):
@@ -147,14 +151,15 @@ def main():
     else:
         dt_max, frames_total = dt, frames_local
 
-    # ---- per-kernel device time (HIP events on each handle's own decode stream, timed region only) ----
-    names = ("inter", "intra", "deblock", "packout")
-    tot_ns = {k: 0 for k in names}
-    tot_n = {k: 0 for k in names}
-    for hi, h in enumerate(handles):
-        for ki, k in enumerate(names):
-            tot_ns[k] += L.jm_amddec_get_stat(h, f"k_{k}_ns".encode()) - prof0[hi][2 * ki]
-            tot_n[k] += L.jm_amddec_get_stat(h, f"k_{k}_n".encode()) - prof0[hi][2 * ki + 1]
+    # ---- per-kernel device time: HIP events recorded by the engine on ITS stream around every batched launch, timed region only ----
+    names = KN
+    e1 = eng()
+    tot_ns = {k: e1[k]["ns"] - e0[k]["ns"] for k in names}
+    tot_n = {k: e1[k]["n"] - e0[k]["n"] for k in names}
+    tot_pics = {k: e1[k]["pics"] - e0[k]["pics"] for k in names}
+    tot_alg = {k: e1[k]["alg_bytes"] - e0[k]["alg_bytes"] for k in names}
+    batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
+    batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
@@ -162,16 +167,11 @@ def main():
     host_diag = {k: round(sum(L.jm_amddec_get_stat(h, k.encode()) for h in handles) / 1e6 / max(1, sum(L.jm_amddec_get_stat(h, b"pictures") for h in handles)), 4)
                  for k in ("submit_ns", "wait_slot_ns", "parse_ns_i", "parse_ns_p")}   # ms per picture, whole run
 
-    # algorithmic bytes per launch (DESIGN.md "Kernels"): Wc x Hc coded, Wd x Hd display
+    # algorithmic bytes per launch: summed by the engine over the pictures each batched launch processed
     surf = 1.5 * mb_w * 16 * mb_h * 16
     J = job_bytes / max(pictures, 1)
     p_frac = (F - F // 30) / F if F >= 30 else 1.0
-    alg = {
-        "inter": p_frac * (2 * surf) + J,          # each reference sample read once + each sample written once (P pictures) + job list
-        "intra": (1.0 - p_frac) * surf,            # samples of intra pictures written once
-        "deblock": 2 * surf,                       # every sample read once and written once
-        "packout": surf + frame_bytes,             # surface read once, tight frame written once
-    }
+    alg = {k: (tot_alg[k] / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     dominant = max(names, key=lambda k: tot_ns[k])
     avg_s = {k: (tot_ns[k] * 1e-9 / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     peak = 8000.0
@@ -234,8 +234,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": None,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
-                     "launches": int(tot_n[dominant])},
-        "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2),
+                     "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
+        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2)},
+        "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
         "roofline_frame": {"alg_bytes_per_frame": int(A), "job_bytes_per_frame": int(J),
                            "end_to_end_GBps": round(value / world * A / 1e9, 3), "end_to_end_frac": round(value / world * A / 1e9 / peak, 6),

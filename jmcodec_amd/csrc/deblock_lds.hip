@@ -36,7 +36,10 @@ struct DbRec {                 // 96 bytes per macroblock: 48 for the luma workg
 static_assert(sizeof(DbRec) == 96, "DbRec must be 96 bytes");
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_deblock_prep(PicParams pp, DbRec *out) {
+__global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_DEBLOCK_LDS)) return;
+    DbRec *out = (DbRec *)pp.dbrec;
     int mb = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
     int n_mbs = pp.mb_w * pp.mb_h;
     if (mb >= n_mbs) return;
@@ -296,8 +299,11 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
 // ------------------------------------------------------------------------------------------
 // grid = 2 workgroups of 512 threads: block 0 filters luma, block 1 chroma (independent planes, no exchange).
 // 512 threads = 2 waves per SIMD, so each lane may use up to 256 VGPRs: the edge chains never spill.
-__global__ __launch_bounds__(512) void k_deblock_lds(PicParams pp, const DbRec *recs) {
+__global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
     extern __shared__ __align__(16) uint8_t smem[];
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_DEBLOCK_LDS)) return;
+    const DbRec *recs = (const DbRec *)pp.dbrec;
     Lds lds{smem, pp.mb_h};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_chroma = blockIdx.x == 1;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(512) void k_deblock_lds(PicParams pp, const DbRec *
 size_t deblock_lds_bytes(int mb_h) { return 2048 + (size_t)mb_h * 768; }      // luma workgroup's need (chroma needs half)
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
 
-void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st) {
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     hipGetDevice(&dev);
@@ -367,9 +373,8 @@ void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st
         hipFuncSetAttribute((const void *)k_deblock_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set[dev] = true;
     }
-    int n = pp.mb_w * pp.mb_h;
-    hipLaunchKernelGGL(k_deblock_prep, dim3((n + 7) / 8), dim3(256), 0, st, pp, (DbRec *)dbrec_scratch);
-    hipLaunchKernelGGL(k_deblock_lds, dim3(2), dim3(512), deblock_lds_bytes(pp.mb_h), st, pp, (const DbRec *)dbrec_scratch);
+    hipLaunchKernelGGL(k_deblock_prep, dim3((max_mbs + 7) / 8, n), dim3(256), 0, st, d_pics);
+    hipLaunchKernelGGL(k_deblock_lds, dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
 }
 
 }  // namespace jmamd

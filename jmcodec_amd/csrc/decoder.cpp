@@ -1,5 +1,6 @@
 // jmcodec_amd/csrc/decoder.cpp -- see decoder.h.
 #include "decoder.h"
+#include "engine.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
@@ -72,11 +73,10 @@ int Decoder::set_option(const char *key, long long v) {
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
     else if (k == "sync") sync_mode_ = v != 0;
     else if (k == "device") device_ = (int)v;
-    else if (k == "profile") profile_ = v != 0;
+    else if (k == "profile") { profile_ = v != 0; if (engine_) engine_->set_profile(profile_); }
     else if (k == "wait_idle") {      // block until every dispatched picture has been executed by the device (no flush)
         dispatch_pending();
         { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
-        if (!parse_only_ && gpu_open_) { hipSetDevice(device_); hipStreamSynchronize(stream_); }
     }
     else return -1;
     return 0;
@@ -103,10 +103,19 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "submit_ns") return stat_submit_ns_;
     if (k == "wait_slot_ns") return stat_wait_slot_ns_;
     if (k == "parse_ns_p") return stat_parse_ns_p_;
-    static const char *kn[4] = {"inter", "intra", "deblock", "packout"};
-    for (int i = 0; i < 4; i++) {
-        if (k == std::string("k_") + kn[i] + "_ns") return (long long)(prof_us_[i] * 1000.0);
-        if (k == std::string("k_") + kn[i] + "_n") return prof_n_[i];
+    if (k.rfind("k_", 0) == 0 || k.rfind("eng_", 0) == 0) {          // engine-wide (all handles on this device), profile option
+        static const char *kn[4] = {"inter", "intra", "deblock", "packout"};
+        if (!engine_) return 0;
+        EngineStats es = engine_->stats();
+        for (int i = 0; i < 4; i++) {
+            if (k == std::string("k_") + kn[i] + "_ns") return (long long)es.ns[i];
+            if (k == std::string("k_") + kn[i] + "_n") return es.launches[i];
+            if (k == std::string("k_") + kn[i] + "_pics") return es.pics[i];
+            if (k == std::string("k_") + kn[i] + "_alg_bytes") return es.alg_bytes[i];
+        }
+        if (k == "eng_batches") return es.batches;
+        if (k == "eng_batch_pics") return es.batch_pics;
+        return -1;
     }
     if (k.rfind("display_poc:", 0) == 0) { size_t i = (size_t)atoll(k.c_str() + 12); return i < display_pocs_.size() ? display_pocs_[i] : -1; }
     return -1;
@@ -120,6 +129,7 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
+    if (engine_) engine_->set_profile(profile_);
     inited_ = true;
     // optional SPS/PPS given up front (nv_dec.cpp:334-360)
     if (extra && len > 0) { feed(extra, (size_t)len); static const uint8_t sc[4] = {0, 0, 0, 1}; feed(sc, 4); in_.clear(); scan_ = 0; have_start_ = false; }
@@ -127,7 +137,7 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
 }
 
 // =============================================================================================
-// device resources
+// device resources (all device WORK is issued by the per-device Engine; the decoder only owns memory)
 // =============================================================================================
 bool Decoder::gpu_open() {
     int n = 0;
@@ -138,12 +148,8 @@ bool Decoder::gpu_open() {
     }
     if (device_ >= n) device_ %= n;
     if (!HIP_OK(hipSetDevice(device_))) { fail("hipSetDevice failed"); return false; }
-    hipStream_t st;
-    if (!HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) { fail("hipStreamCreate failed"); return false; }
-    stream_ = st;
-    hipStream_t cs;
-    if (!HIP_OK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking))) { fail("hipStreamCreate failed"); return false; }
-    copy_stream_ = cs;
+    engine_ = Engine::get(device_);
+    if (!engine_) { fail("could not start the device engine (stream / buffer creation failed)"); return false; }
     gpu_open_ = true;
     return true;
 }
@@ -151,33 +157,20 @@ bool Decoder::gpu_open() {
 void Decoder::gpu_free_sequence() {
     if (!gpu_open_) return;
     hipSetDevice(device_);
-    hipStreamSynchronize(stream_);
-    hipStreamSynchronize(copy_stream_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
     if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
     for (auto &j : jobs_) {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
-        if (j.done) hipEventDestroy(j.done);
-        if (j.uploaded) hipEventDestroy(j.uploaded);
-        for (auto e : j.pev) if (e) hipEventDestroy(e);
         j = JobSlot();
     }
-    for (OutSlot *o : all_out_) {
-        if (o->host) hipHostFree(o->host);
-        if (o->dev) hipFree(o->dev);
-        if (o->done) hipEventDestroy(o->done);
-        for (auto e : o->pev) if (e) hipEventDestroy(e);
-        delete o;
-    }
+    for (OutSlot *o : all_out_) { if (o->host) hipHostFree(o->host); delete o; }
     all_out_.clear(); free_out_.clear(); ready_.clear(); cur_out_ = nullptr;
 }
 void Decoder::gpu_close() {
     if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); for (auto &j : jobs_) { free(j.host); j.host = nullptr; } return; }
     gpu_free_sequence();
-    hipStreamDestroy(stream_);
-    hipStreamDestroy(copy_stream_);
     gpu_open_ = false;
 }
 
@@ -196,17 +189,14 @@ bool Decoder::gpu_alloc_sequence() {
     surf_bytes_ = (size_t)pitch_ * mb_h_ * 16 * 3 / 2;
     for (int i = 0; i < n_surf_; i++) {
         if (!HIP_OK(hipMalloc((void **)&surf_[i], surf_bytes_))) { fail("hipMalloc(surface) failed"); return false; }
-        hipMemsetAsync(surf_[i], 128, surf_bytes_, stream_);
+        hipMemset(surf_[i], 128, surf_bytes_);
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
-    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96))) { fail("hipMalloc(dbrec) failed"); return false; }
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
-    if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(resid) failed"); return false; }
+    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
-        if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
-            !HIP_OK(hipEventCreateWithFlags(&j.done, hipEventDisableTiming)) || !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
+        if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
-        if (profile_) for (auto &e : j.pev) hipEventCreate(&e);
     }
     // output slots: allocate the steady-state population now (hipHostMalloc costs milliseconds and serialises
     // inside the runtime; it must never happen while pictures are in flight)
@@ -220,13 +210,11 @@ bool Decoder::gpu_alloc_sequence() {
 }
 
 OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
-    if (!free_out_.empty()) { OutSlot *o = free_out_.back(); free_out_.pop_back(); return o; }
+    if (!free_out_.empty()) { OutSlot *o = free_out_.back(); free_out_.pop_back(); o->ready = false; o->has_data = false; return o; }
     OutSlot *o = new OutSlot();
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault)) ||
-            !HIP_OK(hipEventCreateWithFlags(&o->done, hipEventDisableTiming))) { fail("output buffer allocation failed"); }
-        if (profile_) for (auto &e : o->pev) hipEventCreate(&e);
+        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
     }
     all_out_.push_back(o);
     return o;
@@ -384,7 +372,7 @@ void Decoder::flush_dpb(std::vector<int> &out) {
         int best = -1;
         for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
         if (best < 0) break;
-        out.push_back(best); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc);
+        out.push_back(best); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc); dpb_[best].out_at = decode_count_ - 1;
     }
     for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
 }
@@ -395,8 +383,12 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
         if (seq_active_) flush_dpb(carry_out_);
         if (!activate(sps)) return false;
     } else if (sps.mb_w != mb_w_ || sps.mb_h != mb_h_) { stat_errors_++; return false; }
-    int slot = -1;
-    for (int i = 0; i < n_surf_; i++) if (!dpb_[i].in_use) { slot = i; break; }
+    // Surface for the new picture.  A surface that was displayed after picture n is still being packed out while picture
+    // n+1 decodes (the engine overlaps pack-out with the next batch), so prefer one that has "cooled" for a picture.
+    int slot = -1, warm = -1;
+    bool wait_pack = false;
+    for (int i = 0; i < n_surf_; i++) if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i; break; } if (warm < 0) warm = i; }
+    if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
     if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
         int best = -1;
         for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
@@ -409,7 +401,7 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
     c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
     c.poc = compute_poc(sh);
     pending_ = std::make_unique<PicTask>();
-    pending_->has_picture = true; pending_->cur_slot = slot; pending_->sps = sps; pending_->pps = pps;
+    pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack; pending_->sps = sps; pending_->pps = pps;
     pending_->out_before = std::move(carry_out_); carry_out_.clear();
     first_sh_ = sh;
     if (sh.type == SL_I) stat_i_++; else stat_p_++;
@@ -514,9 +506,9 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
 void Decoder::bump_after_current(std::vector<int> &out) {
     DpbPic &cur = dpb_[cur_];
     auto smallest = [&](int exclude) { int b = -1; for (int i = 0; i < n_surf_; i++) if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i; return b; };
-    if (cur.mmco5) { int b; while ((b = smallest(cur_)) >= 0) { out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; } cur.poc = 0; cur.frame_num = 0; }
+    if (cur.mmco5) { int b; while ((b = smallest(cur_)) >= 0) { out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; dpb_[b].out_at = decode_count_ - 1; } cur.poc = 0; cur.frame_num = 0; }
     int w = smallest(cur_);
-    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.in_use = false; }
+    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.out_at = decode_count_ - 1; cur.in_use = false; }
     else {
         cur.wait_output = true;
         for (;;) {
@@ -525,7 +517,7 @@ void Decoder::bump_after_current(std::vector<int> &out) {
             if (used <= dpb_size_ && waiting <= reorder_depth_) break;
             int b = smallest(-1);
             if (b < 0) break;
-            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false;
+            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; dpb_[b].out_at = decode_count_ - 1;
         }
     }
     for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
@@ -545,37 +537,14 @@ void Decoder::dispatch_pending() {
     push_task(std::move(t));
 }
 
-// profile option: per-kernel device time from HIP events recorded on the decode stream itself
-void Decoder::harvest_job(JobSlot &j) {                  // mtx_ held, j.done known complete
-    if (!profile_ || !j.pev[0]) return;
-    for (int k = 0; k < 3; k++) if (j.pmask & (1 << k)) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, j.pev[k], j.pev[k + 1]) == hipSuccess) { prof_us_[k] += ms * 1000.0; prof_n_[k]++; }
-    }
-    j.pmask = 0;
-}
-void Decoder::harvest_out(OutSlot &o) {
-    if (!profile_ || !o.pev[0]) return;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, o.pev[0], o.pev[1]) == hipSuccess) { prof_us_[3] += ms * 1000.0; prof_n_[3]++; }
-}
-
 int Decoder::acquire_job_slot() {
     auto w0 = std::chrono::steady_clock::now();
-    struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{stat_wait_slot_ns_, w0};
     std::unique_lock<std::mutex> lk(mtx_);
-    for (;;) {
-        for (int i = 0; i < kJobSlots; i++) {
-            JobSlot &j = jobs_[i];
-            if (j.busy && j.submitted && (parse_only_ || hipEventQuery(j.done) == hipSuccess)) { harvest_job(j); j.busy = false; j.submitted = false; }
-            if (!j.busy) { j.busy = true; j.submitted = false; return i; }
-        }
-        // all busy: wait for the device (if something is submitted) or for a worker
-        int sub = -1;
-        for (int i = 0; i < kJobSlots; i++) if (jobs_[i].submitted) { sub = i; break; }
-        if (sub >= 0 && !parse_only_) { hipEvent_t ev = jobs_[sub].done; lk.unlock(); hipSetDevice(device_); hipEventSynchronize(ev); lk.lock(); }
-        else cv_.wait(lk);
-    }
+    int got = -1;
+    cv_.wait(lk, [&] { for (int i = 0; i < kJobSlots; i++) if (!jobs_[i].busy) { got = i; return true; } return false; });
+    jobs_[got].busy = true;
+    stat_wait_slot_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+    return got;
 }
 
 void Decoder::push_task(std::unique_ptr<PicTask> t) {
@@ -638,9 +607,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
     if (!parse_only_ && !failed_) {
         // upload now, out of decode order: the device copy of the job list only has to exist before this picture's kernels
-        hipSetDevice(device_);
-        hipMemcpyAsync(js.dev, js.host, t->upload_bytes, hipMemcpyHostToDevice, copy_stream_);
-        hipEventRecord(js.uploaded, copy_stream_);
+        engine_->upload(js.dev, js.host, t->upload_bytes);
     }
     {
         long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
@@ -653,55 +620,46 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
 }
 
 // =============================================================================================
-// device submission, strictly in decode order
+// hand-over to the device engine, strictly in decode order per handle
 // =============================================================================================
 void Decoder::submit_ready() {
     std::lock_guard<std::mutex> sl(submit_mtx_);
     for (;;) {
-        PicTask *t = nullptr;
+        std::unique_ptr<PicTask> t;
         {
             std::lock_guard<std::mutex> lk(mtx_);
             if (inflight_.empty() || inflight_.front()->state.load(std::memory_order_acquire) != 1) break;
-            t = inflight_.front().get();
+            t = std::move(inflight_.front());
+            inflight_.pop_front();
         }
         long long ts0 = now_ns();
-        submit_task(t);
+        submit_task(t.get());
         if (trace_on_ && t->has_picture) trace_.push_back(TraceRec{t->seq, t->t_dispatch, t->t_parsed, ts0, now_ns(), (!t->slices.empty() && t->slices[0].sh.type == SL_I) ? 1 : 0});
-        {
-            std::lock_guard<std::mutex> lk(mtx_);
-            if (t->job_slot >= 0) jobs_[t->job_slot].submitted = true;
-            inflight_.pop_front();
-            outstanding_--;
-        }
-        cv_.notify_all();
     }
 }
 
-void Decoder::enqueue_output(int slot) {
+// a display frame leaves the DPB: reserve an output slot (display order) and describe the pack-out for the engine
+void Decoder::enqueue_output(int slot, std::vector<PackJob> &jobs, std::vector<OutSlot *> &slots) {
     OutSlot *o;
-    { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); }
-    if (!parse_only_ && !failed_) {
-        if (profile_) hipEventRecord(o->pev[0], stream_);
-        // k_packout stores the tight frame straight into the pinned host slot (PCIe writes from the kernel): no copy-engine
-        // hop, so nothing of this stream can queue behind another stream's transfer
-        launch_packout(surf_[slot], pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, o->host, stream_);
-        if (profile_) hipEventRecord(o->pev[1], stream_);
-        hipEventRecord(o->done, stream_);
-        o->has_data = true;
-    }
-    { std::lock_guard<std::mutex> lk(mtx_); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
+    { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
+    if (parse_only_ || failed_) { std::lock_guard<std::mutex> lk(mtx_); o->ready = true; return; }
+    // k_packout stores the tight frame straight into the pinned host slot (PCIe writes from the kernel, no copy-engine hop)
+    jobs.push_back(PackJob{surf_[slot], o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, 0});
+    slots.push_back(o);
+    o->has_data = true;
 }
 
 void Decoder::submit_task(PicTask *t) {
     auto st0 = std::chrono::steady_clock::now();
-    if (!parse_only_) hipSetDevice(device_);
-    for (int s : t->out_before) enqueue_output(s);
-    if (t->has_picture && !parse_only_ && !failed_) {
+    EnginePic ep;
+    ep.dec = this; ep.has_picture = t->has_picture && !parse_only_ && !failed_; ep.job_slot = t->job_slot;
+    ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
+    for (int s : t->out_before) enqueue_output(s, ep.out_before, ep.slots_before);
+    memset(&ep.pp, 0, sizeof ep.pp);
+    if (ep.has_picture) {
         JobSlot &js = jobs_[t->job_slot];
-        hipStreamWaitEvent(stream_, js.uploaded, 0);
         const int n_mbs = t->sps.mb_w * t->sps.mb_h;
-        PicParams pp;
-        memset(&pp, 0, sizeof pp);
+        PicParams &pp = ep.pp;
         pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = pitch_; pp.chroma_offset = chroma_off_;
         pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
         pp.n_slices = t->n_slices; pp.cur = t->cur_slot;
@@ -710,23 +668,37 @@ void Decoder::submit_task(PicTask *t) {
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
+        pp.resid = (int16_t *)resid_; pp.dbrec = dbrec_;
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
         bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs;
-        pp.resid = (int16_t *)resid_; pp.want_intra_resid = lds_intra ? 1 : 0;
-        js.pmask = 1 | (t->n_intra > 0 ? 2 : 0) | (t->any_deblock ? 4 : 0);
-        if (profile_) hipEventRecord(js.pev[0], stream_);
-        launch_recon_inter(pp, stream_);
-        if (profile_) hipEventRecord(js.pev[1], stream_);
-        if (t->n_intra > 0) { if (lds_intra) launch_intra_lds(pp, resid_, stream_); else launch_recon_intra(pp, stream_); }
-        if (profile_) hipEventRecord(js.pev[2], stream_);
-        if (t->any_deblock) { if (use_lds_deblock_) launch_deblock_lds(pp, dbrec_, stream_); else launch_deblock(pp, stream_); }
-        if (profile_) hipEventRecord(js.pev[3], stream_);
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
-        hipEventRecord(js.done, stream_);
+        pp.want_intra_resid = lds_intra ? 1 : 0;
+        pp.stages = PS_RECON;
+        if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;
+        if (t->any_deblock) pp.stages |= use_lds_deblock_ ? PS_DEBLOCK_LDS : PS_DEBLOCK_V1;
+        // algorithmic bytes of this picture per kernel class
+        long long S = (long long)surf_bytes_;
+        bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
+        ep.alg_bytes[0] = (is_i ? 0 : 2 * S) + (long long)t->upload_bytes;
+        ep.alg_bytes[1] = is_i ? S : (long long)t->n_intra * 384;
+        ep.alg_bytes[2] = 2 * S;
     }
-    for (int s : t->out_after) enqueue_output(s);
+    ep.alg_bytes[3] = (long long)surf_bytes_ + (long long)frame_bytes_;
+    for (int s : t->out_after) enqueue_output(s, ep.out_after, ep.slots_after);
     stat_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - st0).count();
+    if (parse_only_ || failed_ || !engine_) { on_engine_done(ep); return; }
+    engine_->submit(std::move(ep));
+}
+
+// called by the engine thread when the batch containing this picture has finished on the device
+void Decoder::on_engine_done(const EnginePic &p) {
+    {
+        std::lock_guard<std::mutex> lk(mtx_);
+        if (p.job_slot >= 0) jobs_[p.job_slot].busy = false;
+        for (OutSlot *o : p.slots_before) o->ready = true;
+        for (OutSlot *o : p.slots_after) o->ready = true;
+        outstanding_--;
+    }
+    cv_.notify_all();
 }
 
 // =============================================================================================
@@ -738,12 +710,8 @@ int Decoder::pop_output(bool block) {
     for (;;) {
         if (!ready_.empty()) {
             OutSlot *o = ready_.front();
-            if (o->has_data) {
-                if (block) { lk.unlock(); hipSetDevice(device_); hipEventSynchronize(o->done); lk.lock(); }
-                else if (hipEventQuery(o->done) != hipSuccess) return 0;
-            }
+            if (!o->ready) { if (!block) return 0; cv_.wait(lk); continue; }
             ready_.pop_front();
-            if (o->has_data) harvest_out(*o);
             cur_out_ = o;
             return 1;
         }
@@ -770,7 +738,6 @@ int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {
         bool drained;
         { std::lock_guard<std::mutex> lk(mtx_); drained = outstanding_ == 0 && ready_.empty(); }
         if (drained && eos_sent_ && !is_exit_) {            // nv_dec.cpp:460-466
-            if (profile_ && !parse_only_) { hipSetDevice(device_); hipStreamSynchronize(stream_); std::lock_guard<std::mutex> lk(mtx_); for (auto &j : jobs_) if (j.busy && j.submitted) { harvest_job(j); j.busy = false; j.submitted = false; } }
             elapsed_ms_ = timer_started_ ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count() : 0.0;
             is_exit_ = true;
             snprintf(info_, sizeof info_,

@@ -30,6 +30,7 @@ struct DpbPic {
     bool wait_output = false;
     int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
     int decode_idx = 0; bool mmco5 = false;
+    int out_at = -100;                         // decode index of the picture after which this surface was displayed (cooling)
 };
 
 struct SliceTask {
@@ -46,6 +47,7 @@ struct PicTask {
     SeqParams sps; PicParamSet pps;
     std::vector<SliceTask> slices;
     std::vector<int> out_before, out_after;    // DPB slots to display before / after this picture
+    bool wait_prev_pack = false;               // current surface was displayed by the previous picture (no cooling slack)
     // written by the parse worker
     std::atomic<int> state{0};                 // 0 queued, 1 parsed
     int n_intra = 0, n_slices = 0; bool any_deblock = false;
@@ -54,19 +56,13 @@ struct PicTask {
     long long t_dispatch = 0, t_parsed = 0;    // host steady-clock ns (JM_AMD_DEC_TRACE)
 };
 
-struct JobSlot {
+struct JobSlot {                       // one picture's job list: pinned host buffer (parse target) + its device copy
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
-    ihipEvent_t *done = nullptr;
-    ihipEvent_t *uploaded = nullptr;                              // job list is in device memory (recorded on the copy stream)
-    ihipEvent_t *pev[4] = {nullptr, nullptr, nullptr, nullptr};   // profile option: before inter / intra / deblock, after deblock
-    int pmask = 0;                                                // bit k: kernel k was launched for the picture in this slot
-    bool busy = false, submitted = false;
+    bool busy = false;                 // from dispatch until the engine reports the picture done
 };
-struct OutSlot {
-    uint8_t *host = nullptr, *dev = nullptr;
-    ihipEvent_t *done = nullptr;
-    ihipEvent_t *pev[2] = {nullptr, nullptr};                     // profile option: around k_packout
-    bool has_data = false;
+struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
+    uint8_t *host = nullptr;
+    bool has_data = false, ready = false;
 };
 
 class Decoder {
@@ -87,6 +83,8 @@ public:
 
     // worker-pool entry
     void parse_task(PicTask *t, ParseScratch &scratch);
+    // engine completion callback
+    void on_engine_done(const struct EnginePic &p);
 
 private:
     // ---- front end (caller thread) ----
@@ -113,15 +111,12 @@ private:
     void gpu_close();
     void submit_ready();
     void submit_task(PicTask *t);
-    void enqueue_output(int slot);
+    void enqueue_output(int slot, std::vector<PackJob> &jobs, std::vector<OutSlot *> &slots);
     OutSlot *alloc_out_slot();
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false;
-    void harvest_job(JobSlot &j);
-    void harvest_out(OutSlot &o);
-    double prof_us_[4] = {0, 0, 0, 0}; long long prof_n_[4] = {0, 0, 0, 0};   // inter, intra, deblock, packout
     std::string error_;
     bool failed_ = false, inited_ = false;
 
@@ -155,8 +150,7 @@ private:
     int outstanding_ = 0;                      // tasks pushed and not yet submitted
 
     // device
-    ihipStream_t *stream_ = nullptr;
-    ihipStream_t *copy_stream_ = nullptr;      // job-list uploads run ahead of the decode stream, ordered only by events
+    class Engine *engine_ = nullptr;          // per-device executor (engine.h): the only place device work is issued
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false;

@@ -278,8 +278,11 @@ __device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_intra_lds(PicParams pp, const short *resid) {
+__global__ __launch_bounds__(512) void k_intra_lds(const PicParams *pics) {
     extern __shared__ __align__(16) uint8_t smem[];
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_INTRA_LDS)) return;
+    const short *resid = pp.resid;
     ILds lds{smem, pp.mb_h};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_chroma = blockIdx.x == 1;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(512) void k_intra_lds(PicParams pp, const short *re
 size_t intra_lds_bytes(int mb_h) { return 1280 + 32 * 928 + (size_t)mb_h * 80 + 64; }
 bool intra_lds_supported(int mb_w, int mb_h) { return mb_h <= kIGroups * kISlots && intra_lds_bytes(mb_h) <= 150 * 1024; }
 
-void launch_intra_lds(const PicParams &pp, const void *resid, hipStream_t st) {
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     hipGetDevice(&dev);
@@ -342,7 +345,7 @@ void launch_intra_lds(const PicParams &pp, const void *resid, hipStream_t st) {
         hipFuncSetAttribute((const void *)k_intra_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_intra_lds, dim3(2), dim3(512), intra_lds_bytes(pp.mb_h), st, pp, (const short *)resid);
+    hipLaunchKernelGGL(k_intra_lds, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
 }
 
 }  // namespace jmamd

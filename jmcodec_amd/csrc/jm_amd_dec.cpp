@@ -36,8 +36,15 @@ __attribute__((visibility("default"))) int jm_amddec_set_option(jm_amddec_handle
 __attribute__((visibility("default"))) long long jm_amddec_get_stat(jm_amddec_handle h, const char *key) { return D(h)->get_stat(key); }
 __attribute__((visibility("default"))) const char *jm_amddec_last_error(jm_amddec_handle h) { return D(h)->last_error(); }
 __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *src, int pitch, int w, int hgt, int fmt, void *dst, void *stream) {
-    jmamd::launch_packout(static_cast<const uint8_t *>(src), pitch, pitch * hgt, w, hgt, fmt, static_cast<uint8_t *>(dst), static_cast<hipStream_t>(stream));
+    jmamd::PackJob job{static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), pitch, pitch * hgt, w, hgt, fmt, 0};
+    jmamd::PackJob *d_job = nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMalloc((void **)&d_job, sizeof job) != hipSuccess) return -1;
+    hipMemcpyAsync(d_job, &job, sizeof job, hipMemcpyHostToDevice, st);
+    jmamd::launch_packout(d_job, 1, w, hgt, st);
     hipError_t e = hipGetLastError();
+    hipStreamSynchronize(st);
+    hipFree(d_job);
     return e == hipSuccess ? 0 : -(int)e;
 }
 

@@ -77,7 +77,18 @@ struct PicParams {
     const int16_t *mv_ext;
     const int16_t *coef;
     int16_t *resid;               // per-handle scratch: residual of intra macroblocks, 384 int16 per MB (Y 16x16, Cb 8x8, Cr 8x8)
+    void *dbrec;                  // per-handle scratch: 96 B per macroblock written by k_deblock_prep
     int want_intra_resid;         // 1: k_recon_inter also writes the residual of Intra4x4/16x16 macroblocks to resid
+    int stages;                   // PS_* : which kernels of a batched launch act on this picture
+};
+
+// One launch works on a BATCH of pictures (one per stream): kernels take an array of PicParams in device memory
+// and use blockIdx.y as the picture index.
+enum : int { PS_RECON = 1, PS_INTRA_LDS = 2, PS_INTRA_V1 = 4, PS_DEBLOCK_LDS = 8, PS_DEBLOCK_V1 = 16 };
+
+struct PackJob {                  // one display frame to pack out (k_packout, blockIdx.y = job)
+    const uint8_t *src; uint8_t *dst;
+    int pitch, chroma_offset, width, height, out_fmt, pad;
 };
 
 }  // namespace jmamd

@@ -1,19 +1,18 @@
-// jmcodec_amd/csrc/kernels.h -- host-callable launchers of the gfx950 kernels in kernels.hip.
+// jmcodec_amd/csrc/kernels.h -- host-callable launchers of the gfx950 kernels (kernels.hip, intra_lds.hip, deblock_lds.hip).
+// Every launch processes a BATCH: d_pics / d_jobs are device arrays, blockIdx.y selects the picture; a picture takes part in a
+// kernel only if the matching PS_* bit is set in PicParams::stages.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include "jobs.h"
 
 namespace jmamd {
-void launch_recon_inter(const PicParams &pp, hipStream_t st);
-void launch_recon_intra(const PicParams &pp, hipStream_t st);
-void launch_deblock(const PicParams &pp, hipStream_t st);            // spin-wait wavefront (any picture height)
-// LDS-resident lockstep intra wavefront (intra_lds.hip); resid: 768 B per macroblock written by k_recon_inter
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t st);
+void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st);          // spin-wait wavefront (sparse intra, any height)
+void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);              // spin-wait wavefront (any height)
 bool intra_lds_supported(int mb_w, int mb_h);
-void launch_intra_lds(const PicParams &pp, const void *resid, hipStream_t st);
-// LDS-resident lockstep wavefront (deblock_lds.hip); dbrec_scratch: device buffer of 96 B per macroblock
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st);
 bool deblock_lds_supported(int mb_w, int mb_h);
-void launch_deblock_lds(const PicParams &pp, void *dbrec_scratch, hipStream_t st);
-// src: pitch-linear NV12 surface; dst: tight frame (out_fmt 0 = NV12, 1 = I420 order) of width x height
-void launch_packout(const uint8_t *src, int pitch, int chroma_offset, int width, int height, int out_fmt,
-                    uint8_t *dst, hipStream_t st);
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st);   // prep + LDS wavefront
+// pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
+void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
 }  // namespace jmamd

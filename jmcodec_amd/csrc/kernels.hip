@@ -123,7 +123,9 @@ __device__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, in
 #undef VH
 }
 
-__global__ __launch_bounds__(256) void k_recon_inter(PicParams pp) {
+__global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_RECON) || (int)blockIdx.x * 4 >= pp.mb_w * pp.mb_h) return;
     __shared__ ResTile tiles[4];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int n_mbs = pp.mb_w * pp.mb_h;
@@ -382,7 +384,9 @@ __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, 
     }
 }
 
-__global__ __launch_bounds__(kWaves * 64) void k_recon_intra(PicParams pp) {
+__global__ __launch_bounds__(kWaves * 64) void k_recon_intra(const PicParams *pics) {
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_INTRA_V1)) return;
     __shared__ volatile int progress[kMaxRows];
     __shared__ IntraTile tiles[kWaves];
     __shared__ ResTile res[kWaves];
@@ -574,7 +578,9 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
     }
 }
 
-__global__ __launch_bounds__(kWaves * 64) void k_deblock(PicParams pp) {
+__global__ __launch_bounds__(kWaves * 64) void k_deblock(const PicParams *pics) {
+    const PicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & PS_DEBLOCK_V1)) return;
     __shared__ volatile int progress[kMaxRows];
     __shared__ DbTile tiles[kWaves];
     __shared__ DbTables tb;
@@ -598,8 +604,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_deblock(PicParams pp) {
 // out_fmt 0: tight NV12; out_fmt 1: Y plane, U plane, V plane ("YV12" in the reference's words, I420 order).
 // One thread moves 16 source bytes.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_packout(const uint8_t *src, int pitch, int chroma_offset, int width, int height,
-                                                 int out_fmt, uint8_t *dst) {
+__global__ __launch_bounds__(256) void k_packout(const PackJob *jobs) {
+    const PackJob jb = jobs[blockIdx.y];
+    const uint8_t *src = jb.src; uint8_t *dst = jb.dst;
+    const int pitch = jb.pitch, chroma_offset = jb.chroma_offset, width = jb.width, height = jb.height, out_fmt = jb.out_fmt;
     int chunks_per_row = (width + 15) >> 4;
     int luma_chunks = chunks_per_row * height;
     int h2 = height >> 1, w2 = width >> 1;
@@ -634,19 +642,22 @@ __global__ __launch_bounds__(256) void k_packout(const uint8_t *src, int pitch, 
 }
 
 // ------------------------------------------------------------------------------------------
-// launchers
+// launchers: d_pics / d_jobs are device arrays of n entries; max_* size the grid for the largest picture
 // ------------------------------------------------------------------------------------------
-void launch_recon_inter(const PicParams &pp, hipStream_t st) {
-    int n = pp.mb_w * pp.mb_h;
-    hipLaunchKernelGGL(k_recon_inter, dim3((n + 3) / 4), dim3(256), 0, st, pp);
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {
+    hipLaunchKernelGGL(k_recon_inter, dim3((max_mbs + 3) / 4, n), dim3(256), 0, st, d_pics);
 }
-void launch_recon_intra(const PicParams &pp, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1), dim3(kWaves * 64), 0, st, pp); }
-void launch_deblock(const PicParams &pp, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1), dim3(kWaves * 64), 0, st, pp); }
-void launch_packout(const uint8_t *src, int pitch, int chroma_offset, int width, int height, int out_fmt, uint8_t *dst, hipStream_t st) {
-    int chunks = ((width + 15) >> 4) * (height + (height >> 1));
+void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
+void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
+void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st) {
+    int chunks = ((max_width + 15) >> 4) * (max_height + (max_height >> 1));
     int blocks = (chunks + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_packout, dim3(blocks), dim3(256), 0, st, src, pitch, chroma_offset, width, height, out_fmt, dst);
+    // The destination is pinned HOST memory: the kernel is PCIe-bound (~55 GB/s), not CU-bound.  A small grid is enough to
+    // keep the link full and leaves the CUs to the decode kernels of the next batch that run concurrently.
+    int cap = 160 / (n > 0 ? n : 1);
+    if (cap < 2) cap = 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_packout, dim3(blocks, n), dim3(256), 0, st, d_jobs);
 }
 
 }  // namespace jmamd

@@ -104,7 +104,7 @@ def test_three_copies_of_the_tables_agree():
     assert c_array(PROD, "kCbpIntra") == c_array(ORC, "orc_cbp_intra") == c_array(GEN, "cbp_intra_tab")
     assert c_array(PROD, "kCbpInter") == c_array(ORC, "orc_cbp_inter") == c_array(GEN, "cbp_inter_tab")
     assert c_array(PROD, "kZigzag4") == c_array(ORC, "orc_zigzag4") == c_array(GEN, "zz4")
-    kern = os.path.join(ROOT, "jmcodec_amd", "csrc", "kernels.hip")
+    kern = os.path.join(ROOT, "jmcodec_amd", "csrc", "kernel_common.h")
     assert c_array(kern, "kAlpha") == c_array(ORC, "orc_alpha") == c_array(GEN, "alpha_tab")
     assert c_array(kern, "kBeta") == c_array(ORC, "orc_beta") == c_array(GEN, "beta_tab")
     assert c_array(kern, "kTc0") == c_array(ORC, "orc_tc0") == c_array(GEN, "tc0_tab")
