@@ -41,6 +41,7 @@ struct Pool {
 };
 Pool &pool() { static Pool *p = new Pool(); return *p; }   // intentionally leaked: workers outlive static destruction
 std::atomic<int> g_handle_counter{0};
+std::atomic<int> g_handle_index{0};
 }  // namespace
 
 void pool_submit(Decoder *d, PicTask *t) { Pool &p = pool(); { std::lock_guard<std::mutex> lk(p.m); p.q.emplace_back(d, t); } p.cv.notify_one(); }
@@ -49,13 +50,14 @@ int pool_threads() { return pool().n; }
 // =============================================================================================
 static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-Decoder::Decoder() { memset(info_, 0, sizeof info_); trace_on_ = getenv("JM_AMD_DEC_TRACE") != nullptr; }
+Decoder::Decoder() { memset(info_, 0, sizeof info_); trace_on_ = getenv("JM_AMD_DEC_TRACE") != nullptr; eng_state_ = new EngineDecoderState(); }
 
 Decoder::~Decoder() {
     // wait until no worker still references this object
     { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
     { std::lock_guard<std::mutex> lk(submit_mtx_); }
     gpu_close();
+    delete eng_state_;
     if (trace_on_ && !trace_.empty()) {
         char name[256]; snprintf(name, sizeof name, "%s.%p.csv", getenv("JM_AMD_DEC_TRACE"), (void *)this);
         if (FILE *f = fopen(name, "w")) { fprintf(f, "seq,is_i,dispatch,parsed,submit0,submit1\n"); for (auto &r : trace_) fprintf(f, "%llu,%d,%lld,%lld,%lld,%lld\n", (unsigned long long)r.seq, r.is_i, r.t_dispatch, r.t_parsed, r.t_submit0, r.t_submit1); fclose(f); }
@@ -148,6 +150,7 @@ bool Decoder::gpu_open() {
     }
     if (device_ >= n) device_ %= n;
     if (!HIP_OK(hipSetDevice(device_))) { fail("hipSetDevice failed"); return false; }
+    handle_index_ = g_handle_index++;
     engine_ = Engine::get(device_);
     if (!engine_) { fail("could not start the device engine (stream / buffer creation failed)"); return false; }
     gpu_open_ = true;
@@ -163,6 +166,7 @@ void Decoder::gpu_free_sequence() {
     for (auto &j : jobs_) {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
+        if (j.uploaded) hipEventDestroy(j.uploaded);
         j = JobSlot();
     }
     for (OutSlot *o : all_out_) { if (o->host) hipHostFree(o->host); delete o; }
@@ -195,7 +199,8 @@ bool Decoder::gpu_alloc_sequence() {
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
     if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
-        if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_))) { fail("job buffer allocation failed"); return false; }
+        if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
+            !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
     }
     // output slots: allocate the steady-state population now (hipHostMalloc costs milliseconds and serialises
@@ -607,7 +612,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
     if (!parse_only_ && !failed_) {
         // upload now, out of decode order: the device copy of the job list only has to exist before this picture's kernels
-        engine_->upload(js.dev, js.host, t->upload_bytes);
+        t->upload_seq = engine_->upload(js.dev, js.host, t->upload_bytes, js.uploaded);
     }
     {
         long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
@@ -653,6 +658,7 @@ void Decoder::submit_task(PicTask *t) {
     auto st0 = std::chrono::steady_clock::now();
     EnginePic ep;
     ep.dec = this; ep.has_picture = t->has_picture && !parse_only_ && !failed_; ep.job_slot = t->job_slot;
+    ep.p_lane = handle_index_ % kPLanes;
     ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
     for (int s : t->out_before) enqueue_output(s, ep.out_before, ep.slots_before);
     memset(&ep.pp, 0, sizeof ep.pp);
@@ -660,6 +666,7 @@ void Decoder::submit_task(PicTask *t) {
         JobSlot &js = jobs_[t->job_slot];
         const int n_mbs = t->sps.mb_w * t->sps.mb_h;
         PicParams &pp = ep.pp;
+        ep.uploaded = js.uploaded; ep.upload_seq = t->upload_seq;
         pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = pitch_; pp.chroma_offset = chroma_off_;
         pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
         pp.n_slices = t->n_slices; pp.cur = t->cur_slot;

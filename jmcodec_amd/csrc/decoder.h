@@ -52,12 +52,14 @@ struct PicTask {
     std::atomic<int> state{0};                 // 0 queued, 1 parsed
     int n_intra = 0, n_slices = 0; bool any_deblock = false;
     uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0;
+    unsigned long long upload_seq = 0;
     std::string error;
     long long t_dispatch = 0, t_parsed = 0;    // host steady-clock ns (JM_AMD_DEC_TRACE)
 };
 
 struct JobSlot {                       // one picture's job list: pinned host buffer (parse target) + its device copy
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
+    ihipEvent_t *uploaded = nullptr;   // recorded behind the H2D copy on the engine's copy stream
     bool busy = false;                 // from dispatch until the engine reports the picture done
 };
 struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
@@ -83,8 +85,9 @@ public:
 
     // worker-pool entry
     void parse_task(PicTask *t, ParseScratch &scratch);
-    // engine completion callback
+    // engine completion callback + engine-private per-decoder state
     void on_engine_done(const struct EnginePic &p);
+    struct EngineDecoderState &engine_state() { return *eng_state_; }
 
 private:
     // ---- front end (caller thread) ----
@@ -115,7 +118,7 @@ private:
     OutSlot *alloc_out_slot();
 
     // configuration
-    int codec_ = 0, out_fmt_ = 1, device_ = -1;
+    int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false;
     std::string error_;
     bool failed_ = false, inited_ = false;
@@ -150,6 +153,7 @@ private:
     int outstanding_ = 0;                      // tasks pushed and not yet submitted
 
     // device
+    struct EngineDecoderState *eng_state_ = nullptr;
     class Engine *engine_ = nullptr;          // per-device executor (engine.h): the only place device work is issued
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -25,28 +26,34 @@ Engine *Engine::get(int device) {
 
 Engine::Engine(int device) : device_(device) {
     if (hipSetDevice(device_) != hipSuccess) return;
-    hipStream_t s, c, p;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return;
-    stream_ = s; copy_stream_ = c; pack_stream_ = p;
-    for (auto &b : ring_) {
-        if (hipHostMalloc((void **)&b.h_pics, sizeof(PicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
-        if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
-        if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
-        if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&b.upl, hipEventDisableTiming) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming) != hipSuccess) return;
-        for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
+    hipStream_t c;
+    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
+    copy_stream_ = c;
+    for (auto &ln : lanes_) {
+        hipStream_t s, p;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return;
+        ln.stream = s; ln.pack_stream = p;
+        for (auto &b : ln.ring) {
+            if (hipHostMalloc((void **)&b.h_pics, sizeof(PicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
+            if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming) != hipSuccess) return;
+            for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
+        }
     }
     ok_ = true;
     th_ = std::thread([this] { run(); });
     th_.detach();
 }
 
-void Engine::upload(uint8_t *dev, const uint8_t *host, size_t n) {
+unsigned long long Engine::upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev) {
+    std::lock_guard<std::mutex> lk(um_);              // keeps (copy, event, sequence number) consistent with stream order
     hipSetDevice(device_);
     hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, copy_stream_);
+    hipEventRecord(ev, copy_stream_);
+    return ++upload_seq_;
 }
 
 void Engine::submit(EnginePic &&p) {
@@ -56,11 +63,31 @@ void Engine::submit(EnginePic &&p) {
 
 EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 
-// one batched launch per stage; everything on the engine's single in-order stream
-void Engine::launch(Batch &b) {
+// Take the first pending picture of every decoder (arrival order) that belongs to this lane and may run now.
+bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
+    b.pics.clear();
+    std::vector<Decoder *> seen;
+    for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
+        Decoder *d = it->dec;
+        if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
+        seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
+        EngineDecoderState &es = d->engine_state();
+        bool ok = it->lane() == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        if (!ok) { ++it; continue; }
+        es.lane = lane_idx; es.inflight++;
+        b.pics.push_back(std::move(*it));
+        it = pending_.erase(it);
+    }
+    (void)ln;
+    return !b.pics.empty();
+}
+
+// one batched launch per stage on the lane's in-order stream; pack-out on the lane's second stream
+void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size();
     int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0, stages = 0;
     bool wait_pack = false;
+    const EnginePic *last_upload = nullptr;
     b.n_pre = b.n_post = 0; b.pmask = 0;
     for (int k = 0; k < 4; k++) { b.alg[k] = 0; b.npics[k] = 0; }
     // pack jobs: [0, n_pre) before the decode kernels, [2*kMaxBatch, 2*kMaxBatch + n_post) after them
@@ -69,7 +96,10 @@ void Engine::launch(Batch &b) {
         b.h_pics[i] = p.pp;
         if (!p.has_picture) b.h_pics[i].stages = 0;
         stages |= b.h_pics[i].stages;
-        if (p.has_picture) { max_mbs = std::max(max_mbs, p.mb_w * p.mb_h); max_mb_h = std::max(max_mb_h, p.mb_h); }
+        if (p.has_picture) {
+            max_mbs = std::max(max_mbs, p.mb_w * p.mb_h); max_mb_h = std::max(max_mb_h, p.mb_h);
+            if (p.uploaded && (!last_upload || p.upload_seq > last_upload->upload_seq)) last_upload = &p;
+        }
         if (p.wait_prev_pack) wait_pack = true;
         for (auto &j : p.out_before) if (b.n_pre < 2 * kMaxBatch) b.h_jobs[b.n_pre++] = j;
         for (auto &j : p.out_after) if (b.n_post < 2 * kMaxBatch) b.h_jobs[2 * kMaxBatch + b.n_post++] = j;
@@ -81,39 +111,39 @@ void Engine::launch(Batch &b) {
         b.alg[3] += p.alg_bytes[3] * (long long)(p.out_before.size() + p.out_after.size());
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
-    hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, stream_);
-    if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, stream_);
-    if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, stream_);
-    // job lists were copied on the copy stream when the pictures were parsed: one event covers them all
-    hipEventRecord(b.upl, copy_stream_);
-    hipStreamWaitEvent(stream_, b.upl, 0);
+    hipStream_t st = ln.stream, pst = ln.pack_stream;
+    hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
+    if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, st);
+    if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, st);
+    // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
+    // issued one of this batch covers them all without waiting for uploads of later pictures
+    if (last_upload) hipStreamWaitEvent(st, last_upload->uploaded, 0);
     // Pack-out of batch k runs on its own stream and overlaps the decode kernels of batch k+1 (PCIe writes vs. compute).
     // The decoder never reuses a displayed surface for the very next picture (DPB cooling, decoder.cpp), so the decode
     // kernels of this batch only have to wait for the pack-out launched TWO batches ago.
-    if (pack_hist_[1]) hipStreamWaitEvent(stream_, pack_hist_[1], 0);
-    if ((wait_pack || b.n_pre) && pack_hist_[0]) hipStreamWaitEvent(stream_, pack_hist_[0], 0);
+    if (ln.pack_hist[1]) hipStreamWaitEvent(st, ln.pack_hist[1], 0);
+    if ((wait_pack || b.n_pre) && ln.pack_hist[0]) hipStreamWaitEvent(st, ln.pack_hist[0], 0);
     auto mark = [&](int i, hipStream_t s) { if (profile_) hipEventRecord(b.pev[i], s); };
-    mark(0, stream_);
-    if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, stream_); b.pmask |= 1; }
-    mark(1, stream_);
-    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, stream_); b.pmask |= 2; }
-    mark(2, stream_);
-    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, stream_); b.pmask |= 4; }
-    if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, stream_); b.pmask |= 4; }
-    mark(3, stream_);
-    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, stream_); b.pmask |= 8; }
-    if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, stream_); b.pmask |= 8; }
-    mark(4, stream_);
-    hipEventRecord(b.kdone, stream_);
-    hipStreamWaitEvent(pack_stream_, b.kdone, 0);
-    mark(5, pack_stream_);
-    if (b.n_post) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pack_stream_); b.pmask |= 16; }
-    mark(6, pack_stream_);
+    mark(0, st);
+    if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; }
+    mark(1, st);
+    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
+    mark(2, st);
+    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, st); b.pmask |= 4; }
+    if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
+    mark(3, st);
+    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, st); b.pmask |= 8; }
+    if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
+    mark(4, st);
+    hipEventRecord(b.kdone, st);
+    hipStreamWaitEvent(pst, b.kdone, 0);
+    mark(5, pst);
+    if (b.n_post) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pst); b.pmask |= 16; }
+    mark(6, pst);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) fprintf(stderr, "jm_amd_dec: kernel launch failed: %s\n", hipGetErrorString(le));
-    hipEventRecord(b.done, pack_stream_);
-    pack_hist_[1] = pack_hist_[0]; pack_hist_[0] = b.done;
-    b.busy = true;
+    hipEventRecord(b.done, pst);
+    ln.pack_hist[1] = ln.pack_hist[0]; ln.pack_hist[0] = b.done;
 }
 
 void Engine::complete(Batch &b) {
@@ -128,43 +158,41 @@ void Engine::complete(Batch &b) {
         for (int k = 0; k < 4; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
+    { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
     for (auto &p : b.pics) p.dec->on_engine_done(p);
     b.pics.clear();
-    b.busy = false;
 }
 
 void Engine::run() {
     hipSetDevice(device_);
     for (;;) {
-        Batch *next = nullptr;
-        {
-            std::unique_lock<std::mutex> lk(m_);
-            if (pending_.empty() && inflight_ == 0) cv_.wait(lk, [&] { return !pending_.empty(); });
-            if (!pending_.empty() && inflight_ < kBatchRing - 1) {
-                // one picture per decoder, in arrival order
-                next = &ring_[head_];
-                next->pics.clear();
-                std::vector<Decoder *> seen;
-                for (auto it = pending_.begin(); it != pending_.end() && (int)next->pics.size() < kMaxBatch;) {
-                    if (std::find(seen.begin(), seen.end(), it->dec) != seen.end()) { ++it; continue; }
-                    seen.push_back(it->dec);
-                    next->pics.push_back(std::move(*it));
-                    it = pending_.erase(it);
-                }
+        bool progressed = false;
+        // 1. retire finished batches (oldest first per lane)
+        for (auto &ln : lanes_) {
+            while (ln.inflight > 0 && hipEventQuery(ln.ring[ln.tail].done) == hipSuccess) {
+                complete(ln.ring[ln.tail]);
+                ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
+                progressed = true;
             }
         }
-        if (next) {
-            launch(*next);
-            head_ = (head_ + 1) % kBatchRing; inflight_++;
-            // keep at most two batches queued on the device: while they run, new pictures pile up and the next batch is full
-            if (inflight_ < 2) continue;
+        // 2. launch: at most two batches queued per lane, so that while they run new pictures pile up and batches stay full
+        for (int li = 0; li < kLanes; li++) {
+            Lane &ln = lanes_[li];
+            if (ln.inflight >= 2) continue;
+            Batch &b = ln.ring[ln.head];
+            bool have;
+            { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
+            if (!have) continue;
+            launch(ln, b);
+            ln.head = (ln.head + 1) % kBatchRing; ln.inflight++;
+            progressed = true;
         }
-        if (inflight_ > 0) {
-            Batch &old = ring_[tail_];
-            hipEventSynchronize(old.done);
-            complete(old);
-            tail_ = (tail_ + 1) % kBatchRing; inflight_--;
-        }
+        if (progressed) continue;
+        // 3. nothing to do right now
+        bool busy = false;
+        for (auto &ln : lanes_) busy |= ln.inflight > 0;
+        if (busy) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        else { std::unique_lock<std::mutex> lk(m_); cv_.wait_for(lk, std::chrono::milliseconds(2), [&] { return !pending_.empty(); }); }
     }
 }
 

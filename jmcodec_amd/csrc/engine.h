@@ -2,10 +2,16 @@
 //
 // Why: single-picture kernels of the serial stages (intra / deblock wavefronts) occupy 2 CUs for ~1 ms, and the GPU
 // front end only keeps a handful of HW queues running concurrently, so "one HIP stream per decoder" tops out at ~5
-// pictures in flight on a 256-CU part.  The engine instead owns ONE in-order stream per device; each round it takes the
-// next ready picture of every decoder (pictures of one stream depend on each other, pictures of different streams do
-// not -- SURVEY.md 8e), uploads nothing (job lists were copied when parsed) and issues one batched launch per stage with
-// blockIdx.y = picture.  A 16-stream batch is 16x the work per launch at the same latency.
+// pictures in flight on a 256-CU part.  The engine instead owns the device: each round it takes the next ready picture
+// of every decoder (pictures of one stream depend on each other, pictures of different streams do not -- SURVEY.md 8e)
+// and issues ONE batched launch per stage with blockIdx.y = picture.  A 32-stream batch is 32x the work per launch at
+// the same latency.
+//
+// Lanes, each an in-order HIP stream with its own pack-out stream: lanes 0..kPLanes-1 take ordinary pictures (P, sparse
+// intra; decoders are split between them), the last lane pictures whose macroblocks are mostly intra (I pictures:
+// +3 ms of intra wavefront).  Without the split
+// one I picture would hold up every other stream's round.  A decoder may only change lane when its previous pictures
+// have completed, so decode order per stream is preserved by stream order inside a lane.
 // There is no reference counterpart: the reference drives one NVDEC session synchronously (nv_dec.cpp:33-41).
 #pragma once
 #include "jobs.h"
@@ -22,32 +28,41 @@ namespace jmamd {
 class Decoder;
 struct OutSlot;
 
+constexpr int kMaxBatch = 64;
+constexpr int kBatchRing = 4;
+constexpr int kPLanes = 1;                          // lanes for ordinary pictures: while one group's batch sits in the serial deblock
+                                                    // wavefront (2 CUs per picture) the other group's fully parallel kernels use the idle CUs
+constexpr int kLanes = kPLanes + 1;                 // + one lane for intra-dense pictures
+
 struct EnginePic {
     Decoder *dec = nullptr;
     bool has_picture = false;
     PicParams pp;                                   // device pointers already resolved by the decoder
     int job_slot = -1;
-    uint8_t *job_host = nullptr, *job_dev = nullptr; size_t upload_bytes = 0;
+    ihipEvent_t *uploaded = nullptr; unsigned long long upload_seq = 0;   // job list copy (copy stream), see Engine::upload
     std::vector<PackJob> out_before, out_after;     // display frames to pack before / after this picture's kernels
     std::vector<OutSlot *> slots_before, slots_after;
     int mb_w = 0, mb_h = 0, disp_w = 0, disp_h = 0;
     bool wait_prev_pack = false;                    // this picture reuses a surface whose pack-out may still be running
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
+    int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
+    int lane() const { return (has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane; }
 };
-
-constexpr int kMaxBatch = 64;
-constexpr int kBatchRing = 4;
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout
     double ns[4] = {0, 0, 0, 0}; long long launches[4] = {0, 0, 0, 0}, pics[4] = {0, 0, 0, 0}, alg_bytes[4] = {0, 0, 0, 0};
     long long batches = 0, batch_pics = 0;
 };
 
+// engine-private state kept inside each Decoder (touched only by the engine thread)
+struct EngineDecoderState { int lane = -1, inflight = 0; };
+
 class Engine {
 public:
     static Engine *get(int device);                 // creates the engine (and its thread) on first use; nullptr on HIP failure
     void submit(EnginePic &&p);                     // decode order per decoder; thread-safe
-    void upload(uint8_t *dev, const uint8_t *host, size_t n);   // async H2D on the engine's copy stream (called when a picture is parsed)
+    // async H2D of a parsed job list on the engine's copy stream; records `ev` behind it and returns its sequence number
+    unsigned long long upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev);
     void set_profile(bool on) { profile_ = on; }
     EngineStats stats();
     int device() const { return device_; }
@@ -58,21 +73,27 @@ private:
     struct Batch {
         PicParams *h_pics = nullptr, *d_pics = nullptr;       // pinned host / device, kMaxBatch entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
-        ihipEvent_t *done = nullptr, *kdone = nullptr, *upl = nullptr, *pev[8] = {nullptr};
+        ihipEvent_t *done = nullptr, *kdone = nullptr, *pev[8] = {nullptr};
         std::vector<EnginePic> pics;
-        int n_pre = 0, n_post = 0; bool busy = false; unsigned pmask = 0;
+        int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[4] = {0, 0, 0, 0}; int npics[4] = {0, 0, 0, 0};
     };
-    void launch(Batch &b);
+    struct Lane {
+        ihipStream_t *stream = nullptr, *pack_stream = nullptr;
+        ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // done events of the two most recently launched batches
+        Batch ring[kBatchRing];
+        int head = 0, tail = 0, inflight = 0;
+    };
+    bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
+    void launch(Lane &ln, Batch &b);
     void complete(Batch &b);
 
     int device_;
-    ihipStream_t *stream_ = nullptr, *copy_stream_ = nullptr, *pack_stream_ = nullptr;   // decode kernels | job uploads | pack-out (PCIe writes)
-    ihipEvent_t *pack_hist_[2] = {nullptr, nullptr};   // done events of the two most recently launched batches
+    ihipStream_t *copy_stream_ = nullptr;
+    std::mutex um_; unsigned long long upload_seq_ = 0;
+    Lane lanes_[kLanes];
     std::mutex m_; std::condition_variable cv_;
     std::deque<EnginePic> pending_;
-    Batch ring_[kBatchRing];
-    int head_ = 0, tail_ = 0, inflight_ = 0;
     bool profile_ = false, ok_ = false;
     std::mutex sm_; EngineStats st_;
     std::thread th_;
