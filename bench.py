@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the engine's streams need distinct HW queues (must precede HIP init, incl. torch's)
 
 
 def main():
@@ -32,6 +33,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
     args = ap.parse_args()
 
@@ -67,7 +69,7 @@ def main():
     handles = []
     for _ in range(S):
         h = jmcodec_amd.jm_nvdec_create_handle()
-        L.jm_amddec_set_option(h, b"profile", 1)          # the engine records HIP events around each batched launch
+        L.jm_amddec_set_option(h, b"profile", 0 if args.no_profile else 1)   # the engine records HIP events around each batched launch
         if args.parse_only:
             L.jm_amddec_set_option(h, b"parse_only", 1)
         if jmcodec_amd.jm_nvdec_init(0, 1, None, 0, h) != 0:

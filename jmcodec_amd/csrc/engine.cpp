@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace jmamd {
 
@@ -117,7 +118,8 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, st);
     // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
     // issued one of this batch covers them all without waiting for uploads of later pictures
-    if (last_upload) hipStreamWaitEvent(st, last_upload->uploaded, 0);
+    static const bool no_upl_wait = getenv("JM_AMD_DEC_EXP_NOUPLWAIT") != nullptr;   // experiment only
+    if (last_upload && !no_upl_wait) hipStreamWaitEvent(st, last_upload->uploaded, 0);
     // Pack-out of batch k runs on its own stream and overlaps the decode kernels of batch k+1 (PCIe writes vs. compute).
     // The decoder never reuses a displayed surface for the very next picture (DPB cooling, decoder.cpp), so the decode
     // kernels of this batch only have to wait for the pack-out launched TWO batches ago.

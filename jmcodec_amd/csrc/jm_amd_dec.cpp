@@ -3,8 +3,14 @@
 #include "decoder.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
+#include <cstdlib>
 
 using jmamd::Decoder;
+
+// The engine drives several HIP streams (per lane: decode + pack-out, plus one copy stream) that must map to distinct
+// hardware queues to run concurrently; ROCm's default is 4 queues per process.  Must be set before the runtime initialises.
+__attribute__((constructor)) static void jm_amddec_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 #define D(h) (reinterpret_cast<Decoder *>(h))
 
 extern "C" {

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_RECON) || (int)blockIdx.x * 4 >= pp.mb_w * pp.mb_h) return;
     __shared__ ResTile tiles[4];
+    __shared__ uint32_t wins[4][4][13 * 5 + 3];            // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int n_mbs = pp.mb_w * pp.mb_h;
     int mb = blockIdx.x * 4 + wave;
@@ -161,8 +162,87 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         return;
     }
     if (!inter) return;
-    // ---- luma: lane -> (raster 4x4 block, row inside it), 4 pixels per lane ----
+    // ---- luma ----
+    // Fast path (one MV per 8x8 block, i.e. 16x16 / 16x8 / 8x16 / 8x8 partitions): 16 lanes per 8x8 block stage its
+    // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
+    // The fractional position is uniform inside a block, so the 6-tap paths do not diverge within the 16 lanes.
+    // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
+    bool fast;
     {
+        int g = lane >> 4;                                  // 8x8 block of this lane in the fast-path mapping
+        int mvx = r.u.mv[g][0], mvy = r.u.mv[g][1];
+        int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2;
+        bool ok = !(r.flags & MBF_MV_EXT) && r.ref[g] >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
+        fast = __all(ok);                                   // wave-uniform: the whole macroblock takes one path
+    }
+    if (fast) {
+        int g = lane >> 4, l = lane & 15;
+        int mvx = r.u.mv[g][0], mvy = r.u.mv[g][1], fx = mvx & 3, fy = mvy & 3;
+        int bx0 = mbx * 16 + (g & 1) * 8, by0 = mby * 16 + (g >> 1) * 8;
+        int xi = bx0 + (mvx >> 2) - 2, yi = by0 + (mvy >> 2) - 2;
+        const uint8_t *ref = pp.surf[r.ref[g]];
+        uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
+        int xa = xi & ~3, sh = xi & 3;
+        for (int i = l; i < 65; i += 16) {
+            int row = i / 5, dw = i % 5;
+            win[row * 5 + dw] = *(const uint32_t *)(ref + (size_t)(yi + row) * pitch + xa + dw * 4);
+        }
+        // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
+        int rr = l >> 1, hh = l & 1;
+        // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
+        auto row9 = [&](int wr, int *t) {
+            const uint32_t *p = win + wr * 5 + hh;           // dword containing byte 4hh
+            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+            uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
+            t[4] = a1 & 255; t[5] = (a1 >> 8) & 255; t[6] = (a1 >> 16) & 255; t[7] = a1 >> 24; t[8] = a2 & 255;
+        };
+        int v[4];
+        if (fy == 0) {
+            int t[9]; row9(rr + 2, t);
+            if (fx == 0) { v[0] = t[2]; v[1] = t[3]; v[2] = t[4]; v[3] = t[5]; }
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int b = clip1((tap6(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5]) + 16) >> 5);
+                    v[k] = fx == 2 ? b : ((fx == 1 ? t[k + 2] : t[k + 3]) + b + 1) >> 1;
+                }
+            }
+        } else {
+            int t[6][9];
+#pragma unroll
+            for (int j = 0; j < 6; j++) row9(rr + j, t[j]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // vertical half samples at column k (h) and k+1 (m); horizontal half samples at row 0 (b) and row 1 (s)
+                int c = k + 2;
+                if (fx == 0) {
+                    int h = clip1((tap6(t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]) + 16) >> 5);
+                    v[k] = fy == 2 ? h : ((fy == 1 ? t[2][c] : t[3][c]) + h + 1) >> 1;
+                } else if (fx == 2 || fy == 2) {
+                    int hb[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) hb[j] = tap6(t[j][k], t[j][k + 1], t[j][k + 2], t[j][k + 3], t[j][k + 4], t[j][k + 5]);
+                    int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
+                    if (fx == 2 && fy == 2) v[k] = jv;
+                    else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
+                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
+                } else {
+                    int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
+                    int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
+                    int hq = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
+                    v[k] = (bq + hq + 1) >> 1;
+                }
+            }
+        }
+        int px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;     // position inside the macroblock
+        if (has_res) {
+            const short *rs = &tiles[wave].y[py * 16 + px];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
+        }
+        *(uint32_t *)(dst + (size_t)(mby * 16 + py) * pitch + mbx * 16 + px) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    } else {
         int rb = lane >> 2, row = lane & 3;
         int bx = rb & 3, by = rb >> 2;
         int b8 = (by >> 1) * 2 + (bx >> 1);
