@@ -40,16 +40,20 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_DEBLOCK_LDS)) return;
     DbRec *out = (DbRec *)pp.dbrec;
-    int mb = blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+    const int per_xcd = ((int)gridDim.x + 7) >> 3;         // XCD-aware: one contiguous band of macroblocks per XCD (see k_recon_inter)
+    const int blk = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    __shared__ __align__(16) uint8_t stage[8][96];         // records are assembled in LDS and written as 16-byte stores
+    int sub = threadIdx.x >> 5, t = threadIdx.x & 31;
+    int mb = blk * 8 + sub;
     int n_mbs = pp.mb_w * pp.mb_h;
     if (mb >= n_mbs) return;
     int mbx = mb % pp.mb_w, mby = mb / pp.mb_w;
-    const MbRec q = pp.mbs[mb];
-    const SliceRec sl = pp.slices[q.slice];
+    const MbW q = load_mbw(&pp.mbs[mb]);
+    const SliceRec sl = pp.slices[mbw_slice(q)];
     bool has_left = mbx > 0, has_top = mby > 0;
-    MbRec pl = q, pt = q;
-    if (has_left) { pl = pp.mbs[mb - 1]; if (sl.disable == 2 && pl.slice != q.slice) has_left = false; }
-    if (has_top) { pt = pp.mbs[mb - pp.mb_w]; if (sl.disable == 2 && pt.slice != q.slice) has_top = false; }
+    MbW pl = q, pt = q;
+    if (has_left) { pl = load_mbw(&pp.mbs[mb - 1]); if (sl.disable == 2 && mbw_slice(pl) != mbw_slice(q)) has_left = false; }
+    if (has_top) { pt = load_mbw(&pp.mbs[mb - pp.mb_w]); if (sl.disable == 2 && mbw_slice(pt) != mbw_slice(q)) has_top = false; }
     // lane t: one boundary strength (8.7.2.1)
     int dir = t >> 4, e = (t >> 2) & 3, k = t & 3;
     int rq = dir == 0 ? k * 4 + e : e * 4 + k;
@@ -57,12 +61,13 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
     if (sl.disable == 1) bs = 0;
     else if (e == 0) {
         bool have = dir == 0 ? has_left : has_top;
-        bs = have ? boundary_strength(pp, dir == 0 ? pl : pt, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true) : 0;
+        const MbW pn = select_mbw(dir == 0, pl, pt);
+        bs = have ? boundary_strength(pp, pn, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true) : 0;
     } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
     // edge class of this lane: 0 left MB edge, 1 internal, 2 top MB edge; qPp is the neighbour's QP on MB edges
     int cls = e ? 1 : (dir ? 2 : 0);
-    int qp_p = cls == 0 ? pl.qp : (cls == 2 ? pt.qp : q.qp), qp_q = q.qp;
-    DbRec *o = &out[mb];
+    int qp_p = cls == 0 ? mbw_qp(pl) : (cls == 2 ? mbw_qp(pt) : mbw_qp(q)), qp_q = mbw_qp(q);
+    DbRec *o = (DbRec *)stage[sub];
     {
         int qpav = (qp_p + qp_q + 1) >> 1;
         int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
@@ -81,6 +86,8 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
             if (k == 0 && (e == 0 || (e == 2 && dir == 0))) { o->c_ab[plane][cls][0] = kAlpha[ia]; o->c_ab[plane][cls][1] = kBeta[ib]; }
         }
     }
+    // the 32 lanes of this macroblock are one half-wave: LDS writes above are visible to the reads below (same wave)
+    if (t < 6) ((uint4 *)&out[mb])[t] = ((const uint4 *)stage[sub])[t];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -373,7 +380,7 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_
         hipFuncSetAttribute((const void *)k_deblock_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_deblock_prep, dim3((max_mbs + 7) / 8, n), dim3(256), 0, st, d_pics);
+    hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)
     hipLaunchKernelGGL(k_deblock_lds, dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
 }
 

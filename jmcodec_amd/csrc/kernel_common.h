@@ -72,20 +72,42 @@ __device__ __forceinline__ void idct4x4(int *d) {
 __device__ __forceinline__ int blk_to_raster(int blk) { return ((((blk >> 1) & 1) + 2 * (blk >> 3)) << 2) | ((blk & 1) + 2 * ((blk >> 2) & 1)); }
 __device__ __forceinline__ int raster_to_blk(int r) { int bx = r & 3, by = r >> 2; return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
 
-struct MbView {                     // what bS derivation needs from one macroblock
-    bool intra; uint16_t cbp_blk; int8_t ref[4]; const short *mv; bool ext;
-};
-__device__ __forceinline__ void mv_of(const PicParams &pp, const MbRec &r, int rpos, int &mx, int &my) {
-    if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rpos) * 2; mx = m[0]; my = m[1]; }
-    else { int b8 = (rpos >> 3) * 2 + ((rpos & 3) >> 1); mx = r.u.mv[b8][0]; my = r.u.mv[b8][1]; }
+// A MbRec as eight dwords in registers.  All dynamically indexed fields are extracted with shifts / selects so the
+// record never has to live in scratch memory.
+struct MbW { uint32_t w[8]; };
+__device__ __forceinline__ MbW load_mbw(const MbRec *p) {
+    const uint4 *q = (const uint4 *)p;
+    uint4 a = q[0], b = q[1];
+    MbW m; m.w[0] = a.x; m.w[1] = a.y; m.w[2] = a.z; m.w[3] = a.w; m.w[4] = b.x; m.w[5] = b.y; m.w[6] = b.z; m.w[7] = b.w;
+    return m;
 }
-__device__ inline int boundary_strength(const PicParams &pp, const MbRec &p, int rp, const MbRec &q, int rq, bool mb_edge) {
-    if (p.kind != MB_INTER || q.kind != MB_INTER) return mb_edge ? 4 : 3;
-    if (((p.cbp_blk >> raster_to_blk(rp)) & 1) || ((q.cbp_blk >> raster_to_blk(rq)) & 1)) return 2;
-    if (p.ref[(rp >> 3) * 2 + ((rp & 3) >> 1)] != q.ref[(rq >> 3) * 2 + ((rq & 3) >> 1)]) return 1;
-    int px, py, qx, qy; mv_of(pp, p, rp, px, py); mv_of(pp, q, rq, qx, qy);
+__device__ __forceinline__ MbW select_mbw(bool c, const MbW &a, const MbW &b) {
+    MbW m;
+#pragma unroll
+    for (int i = 0; i < 8; i++) m.w[i] = c ? a.w[i] : b.w[i];
+    return m;
+}
+__device__ __forceinline__ int mbw_kind(const MbW &m) { return m.w[0] & 255; }
+__device__ __forceinline__ int mbw_qp(const MbW &m) { return (m.w[0] >> 8) & 255; }
+__device__ __forceinline__ int mbw_flags(const MbW &m) { return m.w[0] >> 24; }
+__device__ __forceinline__ int mbw_cbp_blk(const MbW &m) { return m.w[1] & 0xffff; }
+__device__ __forceinline__ int mbw_slice(const MbW &m) { return m.w[1] >> 24; }
+__device__ __forceinline__ int mbw_ref(const MbW &m, int b8) { return (int)(int8_t)(m.w[3] >> (8 * b8)); }
+__device__ __forceinline__ void mbw_mv(const PicParams &pp, const MbW &m, int rpos, int &mx, int &my) {
+    if (mbw_flags(m) & MBF_MV_EXT) { const short *v = pp.mv_ext + ((size_t)m.w[4] + rpos) * 2; mx = v[0]; my = v[1]; }
+    else {
+        int b8 = (rpos >> 3) * 2 + ((rpos & 3) >> 1);
+        uint32_t w = b8 == 0 ? m.w[4] : (b8 == 1 ? m.w[5] : (b8 == 2 ? m.w[6] : m.w[7]));
+        mx = (int)(int16_t)(w & 0xffff); my = (int)(int16_t)(w >> 16);
+    }
+}
+// 8.7.2.1 boundary strength between 4x4 luma blocks rp (in macroblock p) and rq (in macroblock q), raster indices
+__device__ __forceinline__ int boundary_strength(const PicParams &pp, const MbW &p, int rp, const MbW &q, int rq, bool mb_edge) {
+    if (mbw_kind(p) != MB_INTER || mbw_kind(q) != MB_INTER) return mb_edge ? 4 : 3;
+    if (((mbw_cbp_blk(p) >> raster_to_blk(rp)) & 1) || ((mbw_cbp_blk(q) >> raster_to_blk(rq)) & 1)) return 2;
+    if (mbw_ref(p, (rp >> 3) * 2 + ((rp & 3) >> 1)) != mbw_ref(q, (rq >> 3) * 2 + ((rq & 3) >> 1))) return 1;
+    int px, py, qx, qy; mbw_mv(pp, p, rp, px, py); mbw_mv(pp, q, rq, qx, qy);
     return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
 }
-
 
 }  // namespace jmamd

@@ -89,6 +89,18 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
     }
 }
 
+// dynamically indexed fields of a MbRec held in registers: select with shifts instead of indexing an array (which would
+// force the record into scratch memory -- 18 MB of extra HBM writes per 1080p picture, measured with WRITE_SIZE)
+__device__ __forceinline__ int rec_ref(const MbRec &r, int b8) {
+    uint32_t w = (uint32_t)(uint8_t)r.ref[0] | ((uint32_t)(uint8_t)r.ref[1] << 8) | ((uint32_t)(uint8_t)r.ref[2] << 16) | ((uint32_t)(uint8_t)r.ref[3] << 24);
+    return (int)(int8_t)(w >> (8 * b8));
+}
+__device__ __forceinline__ void rec_mv8(const MbRec &r, int b8, int &mx, int &my) {
+    uint32_t w0 = (uint16_t)r.u.mv[0][0] | ((uint32_t)(uint16_t)r.u.mv[0][1] << 16), w1 = (uint16_t)r.u.mv[1][0] | ((uint32_t)(uint16_t)r.u.mv[1][1] << 16);
+    uint32_t w2 = (uint16_t)r.u.mv[2][0] | ((uint32_t)(uint16_t)r.u.mv[2][1] << 16), w3 = (uint16_t)r.u.mv[3][0] | ((uint32_t)(uint16_t)r.u.mv[3][1] << 16);
+    uint32_t w = b8 == 0 ? w0 : (b8 == 1 ? w1 : (b8 == 2 ? w2 : w3));
+    mx = (int)(int16_t)(w & 0xffff); my = (int)(int16_t)(w >> 16);
+}
 __device__ __forceinline__ bool mb_has_residual(const MbRec &r) {
     return r.kind == MB_I16 || r.cbp_blk || r.cbp_cac || (r.flags & (MBF_CB_DC | MBF_CR_DC));
 }
@@ -125,12 +137,17 @@ __device__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, in
 
 __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & PS_RECON) || (int)blockIdx.x * 4 >= pp.mb_w * pp.mb_h) return;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give every XCD one
+    // contiguous band of the picture; neighbouring macroblocks, whose reference windows overlap, then share an L2.
+    const int per_xcd = ((int)gridDim.x + 7) >> 3;
+    const int blk = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (!(pp.stages & PS_RECON) || blk * 4 >= pp.mb_w * pp.mb_h) return;
     __shared__ ResTile tiles[4];
+    __shared__ uint32_t outt[4][96];                        // per wave: reconstructed MB, 16 luma rows + 8 interleaved chroma rows of 16 B
     __shared__ uint32_t wins[4][4][13 * 5 + 3];            // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int n_mbs = pp.mb_w * pp.mb_h;
-    int mb = blockIdx.x * 4 + wave;
+    int mb = blk * 4 + wave;
     bool valid = mb < n_mbs;
     MbRec r;
     if (valid) r = pp.mbs[mb]; else { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
@@ -152,16 +169,16 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
     uint8_t *dst = pp.surf[pp.cur];
     uint8_t *dst_c = dst + pp.chroma_offset;
+    uint32_t *ot = outt[wave];
     if (r.kind == MB_PCM) {
         const uint8_t *pcm = (const uint8_t *)(pp.coef + r.coef_off);
         int row = lane >> 2, xq = lane & 3;
-        *(uint32_t *)(dst + (size_t)(mby * 16 + row) * pitch + mbx * 16 + xq * 4) =
-            pcm[row * 16 + xq * 4] | (pcm[row * 16 + xq * 4 + 1] << 8) | (pcm[row * 16 + xq * 4 + 2] << 16) | (pcm[row * 16 + xq * 4 + 3] << 24);
+        ot[row * 4 + xq] = pcm[row * 16 + xq * 4] | (pcm[row * 16 + xq * 4 + 1] << 8) | (pcm[row * 16 + xq * 4 + 2] << 16) | (pcm[row * 16 + xq * 4 + 3] << 24);
         int cx = lane & 7, cy = lane >> 3;
-        *(uint16_t *)(dst_c + (size_t)(mby * 8 + cy) * pitch + mbx * 16 + cx * 2) = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
-        return;
+        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
     }
-    if (!inter) return;
+    if (!inter && r.kind != MB_PCM) return;
+    if (inter) {
     // ---- luma ----
     // Fast path (one MV per 8x8 block, i.e. 16x16 / 16x8 / 8x16 / 8x8 partitions): 16 lanes per 8x8 block stage its
     // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
@@ -170,17 +187,18 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     bool fast;
     {
         int g = lane >> 4;                                  // 8x8 block of this lane in the fast-path mapping
-        int mvx = r.u.mv[g][0], mvy = r.u.mv[g][1];
+        int mvx, mvy; rec_mv8(r, g, mvx, mvy);
         int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2;
-        bool ok = !(r.flags & MBF_MV_EXT) && r.ref[g] >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
+        bool ok = !(r.flags & MBF_MV_EXT) && rec_ref(r, g) >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
         fast = __all(ok);                                   // wave-uniform: the whole macroblock takes one path
     }
     if (fast) {
         int g = lane >> 4, l = lane & 15;
-        int mvx = r.u.mv[g][0], mvy = r.u.mv[g][1], fx = mvx & 3, fy = mvy & 3;
+        int mvx, mvy; rec_mv8(r, g, mvx, mvy);
+        int fx = mvx & 3, fy = mvy & 3;
         int bx0 = mbx * 16 + (g & 1) * 8, by0 = mby * 16 + (g >> 1) * 8;
         int xi = bx0 + (mvx >> 2) - 2, yi = by0 + (mvy >> 2) - 2;
-        const uint8_t *ref = pp.surf[r.ref[g]];
+        const uint8_t *ref = pp.surf[rec_ref(r, g)];
         uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
         int xa = xi & ~3, sh = xi & 3;
         for (int i = l; i < 65; i += 16) {
@@ -241,15 +259,15 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
         }
-        *(uint32_t *)(dst + (size_t)(mby * 16 + py) * pitch + mbx * 16 + px) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        ot[py * 4 + (px >> 2)] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     } else {
         int rb = lane >> 2, row = lane & 3;
         int bx = rb & 3, by = rb >> 2;
         int b8 = (by >> 1) * 2 + (bx >> 1);
         int mvx, mvy;
         if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
-        else { mvx = r.u.mv[b8][0]; mvy = r.u.mv[b8][1]; }
-        int slot = r.ref[b8];
+        else rec_mv8(r, b8, mvx, mvy);
+        int slot = rec_ref(r, b8);
         int x0 = mbx * 16 + bx * 4, y = mby * 16 + by * 4 + row;
         int v[4];
         if (slot < 0) { v[0] = v[1] = v[2] = v[3] = 128; }
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
         }
-        *(uint32_t *)(dst + (size_t)y * pitch + x0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     }
     // ---- chroma: lane -> chroma position (cx, cy), both planes ----
     {
@@ -272,8 +290,8 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         int rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
         int mvx, mvy;
         if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
-        else { mvx = r.u.mv[b8][0]; mvy = r.u.mv[b8][1]; }
-        int slot = r.ref[b8];
+        else rec_mv8(r, b8, mvx, mvy);
+        int slot = rec_ref(r, b8);
         int u, v;
         if (slot < 0) { u = v = 128; }
         else {
@@ -287,8 +305,12 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
             v = (w00 * r0[2 * xa + 1] + w01 * r0[2 * xb + 1] + w10 * r1[2 * xa + 1] + w11 * r1[2 * xb + 1] + 32) >> 6;
         }
         if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
-        *(uint16_t *)(dst_c + (size_t)(mby * 8 + cy) * pitch + mbx * 16 + cx * 2) = (uint16_t)(u | (v << 8));
+        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
     }
+    }   // inter
+    // ---- store: whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments ----
+    if (lane < 16) *(uint4 *)(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16) = *(const uint4 *)(ot + lane * 4);
+    else if (lane < 24) *(uint4 *)(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16) = *(const uint4 *)(ot + 64 + (lane - 16) * 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -539,13 +561,13 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
     int pitch = pp.pitch, mbw = pp.mb_w;
     uint8_t *dst = pp.surf[pp.cur];
     uint8_t *dst_c = dst + pp.chroma_offset;
-    const MbRec q = pp.mbs[mby * mbw + mbx];
-    const SliceRec sl = pp.slices[q.slice];
+    const MbW q = load_mbw(&pp.mbs[mby * mbw + mbx]);
+    const SliceRec sl = pp.slices[mbw_slice(q)];
     if (sl.disable == 1) return;
     bool has_left = mbx > 0, has_top = mby > 0;
-    MbRec pl_ = q, pt_ = q;
-    if (has_left) { pl_ = pp.mbs[mby * mbw + mbx - 1]; if (sl.disable == 2 && pl_.slice != q.slice) has_left = false; }
-    if (has_top) { pt_ = pp.mbs[(mby - 1) * mbw + mbx]; if (sl.disable == 2 && pt_.slice != q.slice) has_top = false; }
+    MbW pl_ = q, pt_ = q;
+    if (has_left) { pl_ = load_mbw(&pp.mbs[mby * mbw + mbx - 1]); if (sl.disable == 2 && mbw_slice(pl_) != mbw_slice(q)) has_left = false; }
+    if (has_top) { pt_ = load_mbw(&pp.mbs[(mby - 1) * mbw + mbx]); if (sl.disable == 2 && mbw_slice(pt_) != mbw_slice(q)) has_top = false; }
     // ---- boundary strengths: lanes 0..31 -> (dir, edge, segment) ----
     if (lane < 32) {
         int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
@@ -554,7 +576,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
         if (e == 0) {
             bool have = dir == 0 ? has_left : has_top;
             if (!have) bs = 0;
-            else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, dir == 0 ? pl_ : pt_, rp, q, rq, true); }
+            else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, select_mbw(dir == 0, pl_, pt_), rp, q, rq, true); }
         } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
         t.bs[dir][e][k] = (uint8_t)bs;
     }
@@ -577,12 +599,12 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
         }
     }
     // ---- luma vertical edges: lane = pixel row ----
-    int qp_q = q.qp;
+    int qp_q = mbw_qp(q);
     if (lane < 16) {
         for (int e = 0; e < 4; e++) {
             int bs = t.bs[0][e][lane >> 2];
             if (!bs) continue;
-            int qp_p = e == 0 ? pl_.qp : qp_q;
+            int qp_p = e == 0 ? mbw_qp(pl_) : qp_q;
             int qpav = (qp_p + qp_q + 1) >> 1;
             int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
             int s[8];
@@ -599,7 +621,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
         for (int e = 0; e < 4; e++) {
             int bs = t.bs[1][e][lane >> 2];
             if (!bs) continue;
-            int qp_p = e == 0 ? pt_.qp : qp_q;
+            int qp_p = e == 0 ? mbw_qp(pt_) : qp_q;
             int qpav = (qp_p + qp_q + 1) >> 1;
             int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
             int s[8];
@@ -613,11 +635,11 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
     // ---- chroma vertical edges (chroma x = 0, 4 <-> luma edges 0, 2): lane = (plane, chroma row) ----
     if (lane < 16) {
         int plane = lane >> 3, row = lane & 7;
-        int qc_q = chroma_qp(q.qp, plane ? pp.cr_qp_off : pp.cb_qp_off);
+        int qc_q = chroma_qp(qp_q, plane ? pp.cr_qp_off : pp.cb_qp_off);
         for (int e = 0; e < 4; e += 2) {
             int bs = t.bs[0][e][row >> 1];
             if (!bs) continue;
-            int qc_p = e == 0 ? chroma_qp(pl_.qp, plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
+            int qc_p = e == 0 ? chroma_qp(mbw_qp(pl_), plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
             int qpav = (qc_p + qc_q + 1) >> 1;
             int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
             int s[4];
@@ -631,11 +653,11 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
     // ---- chroma horizontal edges: lane = interleaved byte column (plane = lane & 1) ----
     if (lane < 16) {
         int plane = lane & 1, ccol = lane >> 1;
-        int qc_q = chroma_qp(q.qp, plane ? pp.cr_qp_off : pp.cb_qp_off);
+        int qc_q = chroma_qp(qp_q, plane ? pp.cr_qp_off : pp.cb_qp_off);
         for (int e = 0; e < 4; e += 2) {
             int bs = t.bs[1][e][ccol >> 1];
             if (!bs) continue;
-            int qc_p = e == 0 ? chroma_qp(pt_.qp, plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
+            int qc_p = e == 0 ? chroma_qp(mbw_qp(pt_), plane ? pp.cr_qp_off : pp.cb_qp_off) : qc_q;
             int qpav = (qc_p + qc_q + 1) >> 1;
             int ia = clip3(0, 51, qpav + sl.alpha_off), ib = clip3(0, 51, qpav + sl.beta_off);
             int s[4];
@@ -725,7 +747,8 @@ __global__ __launch_bounds__(256) void k_packout(const PackJob *jobs) {
 // launchers: d_pics / d_jobs are device arrays of n entries; max_* size the grid for the largest picture
 // ------------------------------------------------------------------------------------------
 void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {
-    hipLaunchKernelGGL(k_recon_inter, dim3((max_mbs + 3) / 4, n), dim3(256), 0, st, d_pics);
+    int nblk = ((max_mbs + 3) / 4 + 7) & ~7;              // multiple of 8: the XCD band mapping must be a bijection
+    hipLaunchKernelGGL(k_recon_inter, dim3(nblk, n), dim3(256), 0, st, d_pics);
 }
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
