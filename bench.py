@@ -174,10 +174,21 @@ def main():
     J = job_bytes / max(pictures, 1)
     p_frac = (F - F // 30) / F if F >= 30 else 1.0
     alg = {k: (tot_alg[k] / tot_n[k]) if tot_n[k] else 0.0 for k in names}
-    dominant = max(names, key=lambda k: tot_ns[k])
+    # dominant kernel among the HBM-side stages; k_packout writes to pinned HOST memory, so it is priced against PCIe below
+    dominant = max(("inter", "intra", "deblock"), key=lambda k: tot_ns[k])
     avg_s = {k: (tot_ns[k] * 1e-9 / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     peak = 8000.0
     achieved = alg[dominant] / avg_s[dominant] / 1e9 if avg_s[dominant] > 0 else 0.0
+    # HBM traffic from PMC counters (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, per picture) x pictures per launch
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc["k_intra_lds"]["traffic_upper"],
+                   "deblock": pmc["k_deblock_lds"]["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
+        if (args.width, args.height) == (1920, 1080):
+            traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
+    except Exception:
+        traffic = None
     # frame-level contract figure of SURVEY 8(d): A = 1.5*Wc*Hc*(n_ref+1) + 1.5*Wd*Hd + J per frame
     A = surf * (p_frac * 2 + (1 - p_frac) * 1) + frame_bytes + J
     kernel_s_per_frame = sum(tot_ns[k] for k in names) * 1e-9 / max(pictures, 1)
@@ -234,10 +245,12 @@ def main():
         "decode_errors": int(errors),
         "host_ms_per_picture": host_diag,
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 6), "traffic": None,
+                     "frac": round(achieved / peak, 6), "traffic": traffic,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2)},
+        "pcie_out": {"kernel": "k_packout", "bound": "pcie", "achieved": round(tot_pics["packout"] * frame_bytes / (tot_ns["packout"] * 1e-9) / 1e9, 2) if tot_ns["packout"] else None,
+                     "peak": 63.0, "unit": "GB/s", "note": "tight frames written by the kernel straight into pinned host memory"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
         "roofline_frame": {"alg_bytes_per_frame": int(A), "job_bytes_per_frame": int(J),
