@@ -43,11 +43,17 @@ def main():
 
     import torch
     dist = None
+    backend = os.environ.get("JM_BENCH_BACKEND", "nccl")      # "gloo" lets the multi-process path be exercised on a 1-GPU box
+    n_dev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank % max(n_dev, 1))
+    red_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
 
     import __graft_entry__ as ge
     if not os.path.exists(os.path.join(ROOT, "jmcodec_amd", "lib", "libjm_amd_dec.so")):
@@ -120,7 +126,7 @@ def main():
             t.join()
 
     def sync():
-        if not args.parse_only:
+        if not args.parse_only and n_dev > 0:
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -143,15 +149,8 @@ def main():
     dt = time.perf_counter() - t0
     frames_local = sum(counts)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        f = torch.tensor([frames_local], dtype=torch.float64, device="cuda")
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        frames_total = int(f.item())
-    else:
-        dt_max, frames_total = dt, frames_local
+    from jmcodec_amd import shard
+    frames_total, dt_max = shard.reduce_result(dist, frames_local, dt, device=red_dev)     # SUM of frames, MAX of seconds over ranks
 
     # ---- per-kernel device time: HIP events recorded by the engine on ITS stream around every batched launch, timed region only ----
     names = KN

@@ -178,3 +178,52 @@ def test_packout_kernel_vs_oracle(oracle, w, h, pitch, fmt):
     rc, want = oracle.packout(src.tobytes(), pitch, w, h, fmt)
     assert rc == n_out
     assert out.tobytes() == want
+
+
+def test_4k_picture_size(oracle):
+    """3840x2160 (240 x 135 macroblocks, 5 wavefront slots, 106 KB of LDS in the deblock kernel)."""
+    data = streams.generate(width=3840, height=2160, frames=2, gop=2, seed=0x4A4D0200, level_idc=51)
+    want, n, w, h = oracle.decode(data, 1)
+    assert (n, w, h) == (2, 3840, 2160)
+    frames = gpu_decode(data)
+    fs = w * h * 3 // 2
+    assert len(frames) == 2
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+
+
+def test_mixed_resolutions_share_batches(oracle):
+    """Handles of different picture sizes run concurrently: the engine puts their pictures into the same launches."""
+    kws = [dict(width=1920, height=1080, frames=6, gop=3, seed=1), dict(width=176, height=144, frames=12, gop=4, mode=1, num_ref=2, seed=2),
+           dict(width=640, height=360, frames=10, gop=5, seed=3), dict(width=90, height=70, frames=12, gop=6, mode=1, seed=4),
+           dict(width=1280, height=720, frames=8, gop=4, mode=1, slices=2, seed=5), dict(width=16, height=16, frames=20, gop=5, mode=1, seed=6)]
+    datas = [streams.generate(**kw) for kw in kws]
+    wants = [oracle.decode(d, 1)[0] for d in datas]
+    got = [None] * len(kws)
+
+    def run(i):
+        got[i] = b"".join(gpu_decode(datas[i]))
+    for _ in range(2):
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(len(kws))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for i in range(len(kws)):
+            assert got[i] == wants[i], kws[i]
+
+
+def test_corrupt_streams_do_not_crash_or_hang():
+    """Damaged input must never crash or dead-lock the pipeline (reference policy: errors are swallowed, nv_dec.cpp:394-402)."""
+    base = golden_stream("ip_fuzz_96x80")
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        b = bytearray(base)
+        for _ in range(1 + trial % 4):
+            p = int(rng.integers(40, len(b)))
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        if trial % 3 == 0:
+            b = b[:int(rng.integers(100, len(b)))]
+        with api.JmAmdDec(0, 1) as d:
+            frames = d.decode_stream(bytes(b))
+            assert len(frames) <= 8
+            for f in frames:
+                assert len(f) == 96 * 80 * 3 // 2
