@@ -53,6 +53,9 @@ def main():
         else:
             dist.init_process_group("gloo")
     os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank % max(n_dev, 1))
+    if world > 1 and "JM_AMD_DEC_THREADS" not in os.environ:      # share the host cores between the ranks of this node
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ["JM_AMD_DEC_THREADS"] = str(max(8, min(64, (os.cpu_count() or 8) // max(local_world, 1))))
     red_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
 
     import __graft_entry__ as ge
