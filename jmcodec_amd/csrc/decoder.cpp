@@ -554,6 +554,8 @@ int Decoder::acquire_job_slot() {
 
 void Decoder::push_task(std::unique_ptr<PicTask> t) {
     PicTask *raw = t.get();
+    // sync / digest mode: strictly one picture in flight (the end-of-stream flush can dispatch two pictures in one call)
+    if (sync_mode_) { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
     raw->t_dispatch = now_ns();
     {
         std::lock_guard<std::mutex> lk(mtx_);

@@ -109,6 +109,27 @@ class Oracle:
             raise RuntimeError("oracle: " + err)
         return v, n.value
 
+    def tools(self, data):
+        """Which coding tools the stream exercises: {counter name: macroblocks / slices} (non-zero entries)."""
+        L = self.L
+        L.orc_tool_name.restype = C.c_char_p
+        L.orc_tool_name.argtypes = [C.c_int]
+        L.orc_tool_count.restype = C.c_long
+        L.orc_tool_count.argtypes = [C.c_void_p, C.c_int]
+        d = L.orc_open(None, None)
+        rc = L.orc_decode_annexb(d, data, len(data))
+        err = L.orc_last_error(d).decode()
+        L.orc_flush(d)
+        out, i = {}, 0
+        while L.orc_tool_name(i):
+            if L.orc_tool_count(d, i):
+                out[L.orc_tool_name(i).decode()] = L.orc_tool_count(d, i)
+            i += 1
+        L.orc_close(d)
+        if rc < 0:
+            raise RuntimeError("oracle: " + err)
+        return out
+
     def packout(self, src, pitch, width, height, out_fmt):
         cap = width * height * 3 // 2
         dst = C.create_string_buffer(cap)

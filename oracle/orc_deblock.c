@@ -20,9 +20,9 @@ static int bs_of(const MbInfo *mp, int bp, const MbInfo *mq, int bq, int mb_edge
         nzq = mq->total_coeff[o] | mq->total_coeff[o + 1] | mq->total_coeff[o + 4] | mq->total_coeff[o + 5]; }
     else nzq = mq->total_coeff[bq];
     if (nzp || nzq) return 2;
-    int rp = mp->ref_pic_id[(bp >> 3) * 2 + ((bp & 3) >> 1)], rq = mq->ref_pic_id[(bq >> 3) * 2 + ((bq & 3) >> 1)];
+    int rp = mp->ref_pic_id[0][(bp >> 3) * 2 + ((bp & 3) >> 1)], rq = mq->ref_pic_id[0][(bq >> 3) * 2 + ((bq & 3) >> 1)];
     if (rp != rq) return 1;
-    if (orc_abs(mp->mv[bp][0] - mq->mv[bq][0]) >= 4 || orc_abs(mp->mv[bp][1] - mq->mv[bq][1]) >= 4) return 1;
+    if (orc_abs(mp->mv[0][bp][0] - mq->mv[0][bq][0]) >= 4 || orc_abs(mp->mv[0][bp][1] - mq->mv[0][bq][1]) >= 4) return 1;
     return 0;
 }
 

@@ -333,6 +333,13 @@ void orc_close(OrcDec *d) {
     free_pictures(d); free(d->rbsp); free(d);
 }
 const char *orc_last_error(const OrcDec *d) { return d->err; }
+/* which coding tools the decoded stream exercised (macroblock / slice counts) */
+const char *orc_tool_name(int i) {
+    static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
+        "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter"};
+    return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
+}
+long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }
 void orc_digest_enable(OrcDec *d) { d->digest_on = 1; d->digest = 1469598103934665603ull; d->digest_mbs = 0; }
 uint64_t orc_digest_value(const OrcDec *d, uint64_t *n) { if (n) *n = d->digest_mbs; return d->digest; }
 
@@ -442,6 +449,11 @@ int orc_decode_stream_to_buffer(const uint8_t *buf, size_t len, int out_fmt, uin
     int rc = orc_decode_annexb(d, buf, len);
     if (rc < 0) fprintf(stderr, "orc: %s\n", orc_last_error(d));
     orc_flush(d);
+    if (getenv("ORC_STATS")) {
+        fprintf(stderr, "orc tools:");
+        for (int i = 0; orc_tool_name(i); i++) if (orc_tool_count(d, i)) fprintf(stderr, " %s=%ld", orc_tool_name(i), orc_tool_count(d, i));
+        fprintf(stderr, "\n");
+    }
     orc_close(d);
     if (rc < 0 || s.oom) { free(s.buf); return -1; }
     *out = s.buf; *out_len = s.len; if (w) *w = s.w; if (h) *h = s.h;

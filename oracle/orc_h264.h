@@ -65,6 +65,9 @@ void orc_flush(OrcDec *d);
 
 /* Last error string (static storage inside the decoder). */
 const char *orc_last_error(const OrcDec *d);
+/* tool-usage counters of the stream decoded so far: name of counter i (NULL past the end) and its value */
+const char *orc_tool_name(int i);
+long orc_tool_count(const OrcDec *d, int i);
 
 /* Stream info valid after the first SPS is activated (nv_dec.cpp:838-845). */
 int orc_stream_info(const OrcDec *d, int *disp_w, int *disp_h, int *coded_w, int *coded_h);

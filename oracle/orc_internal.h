@@ -120,13 +120,18 @@ typedef struct {
 
 /* ---------------- pictures -------------------------------------------------- */
 typedef struct {
-    int8_t  ref_idx[4];        /* per 8x8, list0 ; -1 = none/intra            */
-    int16_t mv[16][2];         /* per 4x4 (raster within MB), list0           */
-    int     ref_pic_id[4];     /* picture identity of the l0 reference per 8x8 (for deblock bS) */
-    uint8_t total_coeff[16 + 4 + 4]; /* luma 16 (raster) + Cb 4 + Cr 4          */
+    int8_t  ref_idx[2][4];     /* [list] per 8x8 ; -1 = list not used / intra                    */
+    int16_t mv[2][16][2];      /* [list] per 4x4 (raster within MB)                              */
+    int     ref_pic_id[2][4];  /* picture identity of the reference per 8x8 (deblock bS, direct) */
+    uint16_t mvd[2][16][2];    /* |mvd| per 4x4, CABAC ctxIdxInc of mvd (9.3.3.1.1.7)            */
+    uint8_t total_coeff[16 + 4 + 4]; /* luma 16 (raster) + Cb 4 + Cr 4                          */
+    uint32_t cbf;              /* CABAC coded_block_flag: bits 0-15 luma raster, 16 I16 DC, 17/18 Cb/Cr DC, 19-22 Cb AC, 23-26 Cr AC */
     uint8_t is_intra, is_pcm, is_i16, is_skip, t8x8;
+    uint8_t direct8;           /* bit b8: 8x8 quadrant predicted in direct mode (B_Skip / B_Direct_16x16: 0xF) */
+    uint8_t b_direct16;        /* B_Skip or B_Direct_16x16 */
+    uint8_t chroma_pred_mode;
     uint8_t qp, qpc[2];
-    uint8_t i4mode[16];        /* Intra4x4PredMode per 4x4 raster (or 2 = DC) */
+    uint8_t i4mode[16];        /* Intra4x4PredMode per 4x4 raster (Intra8x8PredMode replicated over its four 4x4s; 2 = DC default) */
     int16_t slice_num;         /* slice this MB belongs to; -1 = not decoded  */
     uint8_t disable_deblock; int8_t alpha_off, beta_off;
     uint16_t cbp;
@@ -170,6 +175,7 @@ struct OrcDec {
     int last_poc_out;
     uint8_t *outbuf; /* crop scratch */
     int digest_on; uint64_t digest; uint64_t digest_mbs;
+    long stats[24];       /* ORC_ST_* tool-usage counters (which coding tools a stream exercised) */
 };
 
 /* orc_parse.c */
@@ -185,6 +191,9 @@ int  orc_start_picture(OrcDec *d, const SliceHdr *sh);
 void orc_finish_picture(OrcDec *d);
 int  orc_build_ref_lists(OrcDec *d, const SliceHdr *sh);
 void orc_output_all(OrcDec *d);
+
+enum { ORC_ST_I4, ORC_ST_I8, ORC_ST_I16, ORC_ST_PCM, ORC_ST_PSKIP, ORC_ST_P16, ORC_ST_P16x8, ORC_ST_P8x16, ORC_ST_P8x8, ORC_ST_SUB_SMALL,
+       ORC_ST_T8_INTER, ORC_ST_CABAC_SLICES, ORC_ST_CAVLC_SLICES, ORC_ST_IDC0, ORC_ST_IDC1, ORC_ST_IDC2, ORC_ST_MULTIREF, ORC_ST_BSKIP, ORC_ST_BDIRECT, ORC_ST_BINTER, ORC_ST_N };
 
 #define ORC_FAIL(d, ...) do { snprintf((d)->err, sizeof((d)->err), __VA_ARGS__); return -1; } while (0)
 

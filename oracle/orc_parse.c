@@ -258,6 +258,7 @@ int orc_parse_slice_header(OrcDec *d, Bits *b, int nal_unit_type, int nal_ref_id
         }
     }
     if (pps->entropy_coding_mode && sh->slice_type != SLICE_I) sh->cabac_init_idc = bits_ue(b);
+    if (sh->cabac_init_idc > 2) ORC_FAIL(d, "bad cabac_init_idc");
     sh->slice_qp_delta = bits_se(b);
     sh->qp = pps->pic_init_qp + sh->slice_qp_delta;
     if (sh->qp < 0 || sh->qp > 51) ORC_FAIL(d, "slice QP out of range");

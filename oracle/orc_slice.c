@@ -6,30 +6,16 @@
  * cuvidDecodePicture (/root/reference/nv_dec/nv_dec.cpp:37) for progressive
  * 8-bit 4:2:0 I/P slices.
  */
-#include "orc_internal.h"
+#include "orc_slice.h"
 #include "orc_tables.h"
 
-typedef struct {
-    OrcDec *d; Bits *b; Picture *pic; const Sps *sps; const Pps *pps; const SliceHdr *sh;
-    int mb_x, mb_y, mb_addr;
-    int qp;                          /* running QP_Y                                  */
-    MbInfo *mb;
-    /* parsed residual of the current MB */
-    int16_t luma[16][16];            /* per 4x4 raster block index, coefficient raster */
-    int16_t luma8[4][64];            /* per 8x8 block, raster                          */
-    int16_t i16dc[16];               /* raster 4x4 matrix c                            */
-    int16_t cdc[2][4];
-    int16_t cac[2][4][16];
-    int i16_pred_mode, chroma_pred_mode;
-    int decoded_mask;                /* 4x4 blocks (raster bit) whose MVs are decoded  */
-} Sl;
-
 /* ------------------------------------------------------------------------ */
-static MbInfo *mb_at(Sl *s, int mx, int my) {
+MbInfo *orc_sl_mb_at(Sl *s, int mx, int my) {
     if (mx < 0 || my < 0 || mx >= s->d->mb_w || my >= s->d->mb_h) return NULL;
     MbInfo *m = &s->pic->mbs[my * s->d->mb_w + mx];
     return m->slice_num == s->d->slice_num ? m : NULL;     /* 6.4.x availability */
 }
+#define mb_at orc_sl_mb_at
 static int intra_usable(Sl *s, MbInfo *m) {               /* for intra prediction */
     if (!m) return 0;
     if (s->pps->constrained_intra_pred && !m->is_intra) return 0;
@@ -401,8 +387,8 @@ static Nb nb_get(Sl *s, int bx, int by) {
     if (!m) return n;
     n.avail = 1;
     if (m->is_intra) return n;
-    n.ref = m->ref_idx[(ry >> 1) * 2 + (rx >> 1)];
-    if (n.ref >= 0) { n.mv[0] = m->mv[ry * 4 + rx][0]; n.mv[1] = m->mv[ry * 4 + rx][1]; }
+    n.ref = m->ref_idx[0][(ry >> 1) * 2 + (rx >> 1)];
+    if (n.ref >= 0) { n.mv[0] = m->mv[0][ry * 4 + rx][0]; n.mv[1] = m->mv[0][ry * 4 + rx][1]; }
     return n;
 }
 static int median3(int a, int b, int c) {
@@ -433,7 +419,7 @@ static void predict_mv(Sl *s, int bx, int by, int bw, int bh, int ref, int shape
 }
 static void set_mv(Sl *s, int bx, int by, int bw, int bh, int mvx, int mvy) {
     for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
-        s->mb->mv[y * 4 + x][0] = (int16_t)mvx; s->mb->mv[y * 4 + x][1] = (int16_t)mvy;
+        s->mb->mv[0][y * 4 + x][0] = (int16_t)mvx; s->mb->mv[0][y * 4 + x][1] = (int16_t)mvy;
         s->decoded_mask |= 1 << (y * 4 + x);
     }
 }
@@ -502,15 +488,15 @@ static int inter_recon(Sl *s) {
     MbInfo *mb = s->mb;
     /* walk the 4x4 grid, merging nothing: per-4x4 MC gives identical samples */
     for (int b8 = 0; b8 < 4; b8++) {
-        int ri = mb->ref_idx[b8];
+        int ri = mb->ref_idx[0][b8];
         if (ri < 0 || ri >= s->d->ref_count[0] || !s->d->ref_list[0][ri]) {
             snprintf(s->d->err, sizeof s->d->err, "missing reference picture (ref_idx %d)", ri); return -1;
         }
         const Picture *ref = s->d->ref_list[0][ri];
-        mb->ref_pic_id[b8] = ref->id;
+        mb->ref_pic_id[0][b8] = ref->id;
         for (int k = 0; k < 4; k++) {
             int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1);
-            mc_part(s, ref, ri, bx * 4, by * 4, 4, 4, mb->mv[by * 4 + bx][0], mb->mv[by * 4 + bx][1]);
+            mc_part(s, ref, ri, bx * 4, by * 4, 4, 4, mb->mv[0][by * 4 + bx][0], mb->mv[0][by * 4 + bx][1]);
         }
     }
     return 0;
@@ -542,6 +528,102 @@ static void recon_chroma_residual(Sl *s, int cbp) {
 }
 
 
+/* ----------------------------- Intra 8x8 (8.3.2) ------------------------- */
+/* reference sample filtering 8.3.2.2.1 + the nine modes 8.3.2.2.2-10 for 8x8 block b8 */
+static int pred8x8l(Sl *s, int b8, int mode, uint8_t *dst, int stride) {
+    int bx = b8 & 1, by = b8 >> 1;
+    MbInfo *mA = bx ? s->mb : mb_at(s, s->mb_x - 1, s->mb_y);
+    MbInfo *mB = by ? s->mb : mb_at(s, s->mb_x, s->mb_y - 1);
+    MbInfo *mD = (bx && by) ? s->mb : (bx ? mb_at(s, s->mb_x, s->mb_y - 1) : (by ? mb_at(s, s->mb_x - 1, s->mb_y) : mb_at(s, s->mb_x - 1, s->mb_y - 1)));
+    int availA = bx || intra_usable(s, mA), availB = by || intra_usable(s, mB), availD = (bx && by) || intra_usable(s, mD), availC;
+    if (b8 == 0) availC = intra_usable(s, mb_at(s, s->mb_x, s->mb_y - 1));
+    else if (b8 == 1) availC = intra_usable(s, mb_at(s, s->mb_x + 1, s->mb_y - 1));
+    else availC = b8 == 2;
+    int t[16], l[8], c = 128, ft[16], fl[8], fc = 128;       /* raw p[x,-1], p[-1,y], p[-1,-1] and the filtered p' */
+    for (int i = 0; i < 8; i++) { t[i] = availB ? dst[-stride + i] : 128; l[i] = availA ? dst[i * stride - 1] : 128; }
+    for (int i = 8; i < 16; i++) t[i] = availB ? (availC ? dst[-stride + i] : t[7]) : 128;
+    if (availD) c = dst[-stride - 1];
+    if (availB) {
+        ft[0] = availD ? (c + 2 * t[0] + t[1] + 2) >> 2 : (3 * t[0] + t[1] + 2) >> 2;
+        for (int i = 1; i < 15; i++) ft[i] = (t[i - 1] + 2 * t[i] + t[i + 1] + 2) >> 2;
+        ft[15] = (t[14] + 3 * t[15] + 2) >> 2;
+    } else for (int i = 0; i < 16; i++) ft[i] = 128;
+    if (availD) {
+        if (availA && availB) fc = (t[0] + 2 * c + l[0] + 2) >> 2;
+        else if (availB) fc = (3 * c + t[0] + 2) >> 2;
+        else if (availA) fc = (3 * c + l[0] + 2) >> 2;
+        else fc = c;
+    }
+    if (availA) {
+        fl[0] = availD ? (c + 2 * l[0] + l[1] + 2) >> 2 : (3 * l[0] + l[1] + 2) >> 2;
+        for (int i = 1; i < 7; i++) fl[i] = (l[i - 1] + 2 * l[i] + l[i + 1] + 2) >> 2;
+        fl[7] = (l[6] + 3 * l[7] + 2) >> 2;
+    } else for (int i = 0; i < 8; i++) fl[i] = 128;
+    if (((mode == 0 || mode == 3 || mode == 7) && !availB) || ((mode == 1 || mode == 8) && !availA) ||
+        ((mode == 4 || mode == 5 || mode == 6) && !(availA && availB && availD))) return -1;
+#define T(i) ((i) < 0 ? fc : ft[i])
+#define L(i) ((i) < 0 ? fc : fl[i])
+    int p[64];
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
+        int v;
+        switch (mode) {
+        case 0: v = ft[x]; break;
+        case 1: v = fl[y]; break;
+        case 2: {
+            int st = 0, sl = 0;
+            for (int i = 0; i < 8; i++) { st += ft[i]; sl += fl[i]; }
+            v = (availA && availB) ? (st + sl + 8) >> 4 : availA ? (sl + 4) >> 3 : availB ? (st + 4) >> 3 : 128;
+            break; }
+        case 3: v = (x == 7 && y == 7) ? (ft[14] + 3 * ft[15] + 2) >> 2 : (ft[x + y] + 2 * ft[x + y + 1] + ft[x + y + 2] + 2) >> 2; break;
+        case 4:
+            if (x > y) v = (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
+            else if (x < y) v = (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
+            else v = (ft[0] + 2 * fc + fl[0] + 2) >> 2;
+            break;
+        case 5: {
+            int z = 2 * x - y, i = x - (y >> 1);
+            if (z >= 0 && !(z & 1)) v = (T(i - 1) + T(i) + 1) >> 1;
+            else if (z >= 0) v = (T(i - 2) + 2 * T(i - 1) + T(i) + 2) >> 2;
+            else if (z == -1) v = (fl[0] + 2 * fc + ft[0] + 2) >> 2;
+            else v = (L(y - 2 * x - 1) + 2 * L(y - 2 * x - 2) + L(y - 2 * x - 3) + 2) >> 2;
+            break; }
+        case 6: {
+            int z = 2 * y - x, i = y - (x >> 1);
+            if (z >= 0 && !(z & 1)) v = (L(i - 1) + L(i) + 1) >> 1;
+            else if (z >= 0) v = (L(i - 2) + 2 * L(i - 1) + L(i) + 2) >> 2;
+            else if (z == -1) v = (fl[0] + 2 * fc + ft[0] + 2) >> 2;
+            else v = (T(x - 2 * y - 1) + 2 * T(x - 2 * y - 2) + T(x - 2 * y - 3) + 2) >> 2;
+            break; }
+        case 7: {
+            int i = x + (y >> 1);
+            v = (y & 1) ? (ft[i] + 2 * ft[i + 1] + ft[i + 2] + 2) >> 2 : (ft[i] + ft[i + 1] + 1) >> 1;
+            break; }
+        default: {
+            int z = x + 2 * y, i = y + (x >> 1);
+            if (z > 13) v = fl[7];
+            else if (z == 13) v = (fl[6] + 3 * fl[7] + 2) >> 2;
+            else if (z & 1) v = (fl[i] + 2 * fl[i + 1] + fl[i + 2] + 2) >> 2;
+            else v = (fl[i] + fl[i + 1] + 1) >> 1;
+            break; }
+        }
+        p[y * 8 + x] = v;
+    }
+#undef T
+#undef L
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) dst[y * stride + x] = (uint8_t)p[y * 8 + x];
+    return 0;
+}
+/* 8.5.13: scaling + inverse transform of one 8x8 residual block, added to dst */
+static void recon8x8(Sl *s, int b8, const uint8_t *list, int qp, uint8_t *dst, int stride) {
+    int dq[64], res[64];
+    for (int k = 0; k < 64; k++) {
+        int ls = level_scale8(list, qp % 6, k), c = s->luma8[b8][k];
+        dq[k] = qp >= 36 ? (c * ls) << (qp / 6 - 6) : (c * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+    }
+    idct8x8(dq, res);
+    add_block(dst, stride, res, 8);
+}
+
 /* ----------------------------- syntax digest ------------------------------ */
 /* FNV-1a over a canonical serialisation of the parsed macroblock, used by
  * tests/test_host_parser.py to compare the product's host entropy decoder with
@@ -554,16 +636,17 @@ static void digest_mb(Sl *s) {
     memset(buf, 0, sizeof buf);
     uint32_t addr = (uint32_t)s->mb_addr; memcpy(buf, &addr, 4); n = 4;
     int kind = !mb->is_intra ? 0 : (mb->is_pcm ? 3 : (mb->is_i16 ? 2 : 1));
-    buf[n++] = (uint8_t)kind; buf[n++] = mb->qp;
+    buf[n++] = (uint8_t)(kind | (mb->t8x8 ? 16 : 0)); buf[n++] = mb->qp;
     buf[n++] = (uint8_t)((kind == 1 || kind == 2) ? s->chroma_pred_mode : 0);
     buf[n++] = (uint8_t)(kind == 2 ? s->i16_pred_mode : 0);
     if (kind == 1) memcpy(buf + n, mb->i4mode, 16);
     n += 16;
-    for (int i = 0; i < 4; i++) buf[n++] = (uint8_t)(kind == 0 ? mb->ref_idx[i] : -1);
-    if (kind == 0) memcpy(buf + n, mb->mv, 64);
+    for (int i = 0; i < 4; i++) buf[n++] = (uint8_t)(kind == 0 ? mb->ref_idx[0][i] : -1);
+    if (kind == 0) memcpy(buf + n, mb->mv[0], 64);
     n += 64;
     if (kind != 3) {
-        memcpy(buf + n, s->i16dc, 32); memcpy(buf + n + 32, s->luma, 512);
+        memcpy(buf + n, s->i16dc, 32);
+        if (mb->t8x8) memcpy(buf + n + 32, s->luma8, 512); else memcpy(buf + n + 32, s->luma, 512);
         memcpy(buf + n + 544, s->cdc, 16); memcpy(buf + n + 560, s->cac, 256);
     }
     n += 816;
@@ -577,7 +660,7 @@ static void mb_reset(Sl *s) {
     MbInfo *mb = s->mb;
     memset(mb, 0, sizeof *mb);
     mb->slice_num = (int16_t)s->d->slice_num;
-    for (int i = 0; i < 4; i++) { mb->ref_idx[i] = -1; mb->ref_pic_id[i] = -1; }
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 4; i++) { mb->ref_idx[l][i] = -1; mb->ref_pic_id[l][i] = -1; }
     memset(mb->i4mode, 2, 16);
     mb->disable_deblock = (uint8_t)s->sh->disable_deblock;
     mb->alpha_off = (int8_t)s->sh->alpha_c0_offset; mb->beta_off = (int8_t)s->sh->beta_offset;
@@ -595,7 +678,9 @@ static int decode_skip_mb(Sl *s) {
     mb_reset(s);
     MbInfo *mb = s->mb;
     mb->is_skip = 1; mb->mb_type_p = 0;
+    s->d->stats[ORC_ST_PSKIP]++;
     mb_set_qp(s);
+    s->last_dqp_nonzero = 0;
     int mvp[2] = {0, 0};
     MbInfo *mA = mb_at(s, s->mb_x - 1, s->mb_y), *mB = mb_at(s, s->mb_x, s->mb_y - 1);
     if (mA && mB) {
@@ -603,21 +688,98 @@ static int decode_skip_mb(Sl *s) {
         if (!((A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) || (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
             predict_mv(s, 0, 0, 4, 4, 0, 0, 0, mvp);
     }
-    for (int i = 0; i < 4; i++) mb->ref_idx[i] = 0;
+    for (int i = 0; i < 4; i++) mb->ref_idx[0][i] = 0;
     set_mv(s, 0, 0, 4, 4, mvp[0], mvp[1]);
     digest_mb(s);
     return inter_recon(s);
 }
 
+/* entropy-mode dispatch of the 7.3.5 descriptors: ue(v)|ae(v), te(v)|ae(v), se(v)|ae(v), me(v)|ae(v) */
+static int rd_ref_idx(Sl *s, int bx, int by, int nref) {
+    if (s->cabac_on) return orc_cabac_ref_idx(s, 0, bx, by);
+    return bits_te(s->b, nref - 1);
+}
+static void rd_mvd(Sl *s, int bx, int by, int bw, int bh, int mvd[2]) {
+    if (s->cabac_on) { mvd[0] = orc_cabac_mvd(s, 0, bx, by, 0); mvd[1] = orc_cabac_mvd(s, 0, bx, by, 1); }
+    else { mvd[0] = bits_se(s->b); mvd[1] = bits_se(s->b); }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
+        s->mb->mvd[0][y * 4 + x][0] = (uint16_t)orc_min(orc_abs(mvd[0]), 65535);
+        s->mb->mvd[0][y * 4 + x][1] = (uint16_t)orc_min(orc_abs(mvd[1]), 65535);
+    }
+}
+
+/* 7.3.5.3 residual() with CABAC */
+static int parse_residual_cabac(Sl *s, int cbp) {
+    MbInfo *mb = s->mb;
+    int16_t tmp[64];
+    if (mb->is_i16) {
+        if (orc_cabac_residual_block(s, 0, 0, tmp, 16) < 0) return -1;
+        for (int i = 0; i < 16; i++) s->i16dc[orc_zigzag4[i]] = tmp[i];
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!(cbp & (1 << b8))) continue;
+        if (mb->t8x8) {
+            int n = orc_cabac_residual_block(s, 5, b8, tmp, 64);
+            if (n < 0) return -1;
+            for (int i = 0; i < 64; i++) s->luma8[b8][orc_zigzag8[i]] = tmp[i];
+            for (int k = 0; k < 4; k++) {
+                int r = ((b8 >> 1) * 2 + (k >> 1)) * 4 + (b8 & 1) * 2 + (k & 1);
+                mb->total_coeff[r] = (uint8_t)orc_min(n, 16);
+                mb->cbf |= 1u << r;                 /* 7.4.5.3.3: coded_block_flag of an 8x8 block is inferred to be 1 */
+            }
+            continue;
+        }
+        for (int k = 0; k < 4; k++) {
+            int blk = b8 * 4 + k, bx = blk_x(blk), by = blk_y(blk), r = by * 4 + bx, n;
+            if (mb->is_i16) {
+                n = orc_cabac_residual_block(s, 1, r, tmp, 15);
+                if (n < 0) return -1;
+                for (int i = 0; i < 15; i++) s->luma[r][orc_zigzag4[i + 1]] = tmp[i];
+            } else {
+                n = orc_cabac_residual_block(s, 2, r, tmp, 16);
+                if (n < 0) return -1;
+                for (int i = 0; i < 16; i++) s->luma[r][orc_zigzag4[i]] = tmp[i];
+            }
+            mb->total_coeff[r] = (uint8_t)n;
+        }
+    }
+    if (cbp & 0x30)
+        for (int pl = 0; pl < 2; pl++)
+            if (orc_cabac_residual_block(s, 3, pl, s->cdc[pl], 4) < 0) return -1;
+    if (cbp & 0x20)
+        for (int pl = 0; pl < 2; pl++)
+            for (int k = 0; k < 4; k++) {
+                int n = orc_cabac_residual_block(s, 4, pl * 4 + k, tmp, 15);
+                if (n < 0) return -1;
+                for (int i = 0; i < 15; i++) s->cac[pl][k][orc_zigzag4[i + 1]] = tmp[i];
+                mb->total_coeff[16 + 4 * pl + k] = (uint8_t)n;
+            }
+    return 0;
+}
+
+/* 8.3.1.1 / 8.3.2.1: predicted Intra4x4 / Intra8x8 mode for the block whose top-left 4x4 is (bx,by) */
+static int pred_intra_mode(Sl *s, int bx, int by) {
+    MbInfo *mb = s->mb;
+    MbInfo *mA = bx > 0 ? mb : mb_at(s, s->mb_x - 1, s->mb_y);
+    MbInfo *mB = by > 0 ? mb : mb_at(s, s->mb_x, s->mb_y - 1);
+    if (!mA || !mB) return 2;
+    if ((!mA->is_intra || !mB->is_intra) && s->pps->constrained_intra_pred) return 2;
+    /* neighbour not coded as I4x4 / I8x8 -> DC; modes of I8x8 macroblocks are stored replicated over their 4x4 blocks */
+    int modeA = (mA->is_intra && !mA->is_i16 && !mA->is_pcm) ? (bx > 0 ? mb->i4mode[by * 4 + bx - 1] : mA->i4mode[by * 4 + 3]) : 2;
+    int modeB = (mB->is_intra && !mB->is_i16 && !mB->is_pcm) ? (by > 0 ? mb->i4mode[(by - 1) * 4 + bx] : mB->i4mode[12 + bx]) : 2;
+    return orc_min(modeA, modeB);
+}
+
 static int decode_mb(Sl *s) {
     Bits *b = s->b; Picture *pic = s->pic; const SliceHdr *sh = s->sh;
+    const int cab = s->cabac_on;
     mb_reset(s);
     MbInfo *mb = s->mb;
-    int mb_type = bits_ue(b);
+    int mb_type = cab ? orc_cabac_mb_type(s) : (int)bits_ue(b);
     int is_intra_type = -1;                /* I-slice numbering when intra */
     if (sh->slice_type == SLICE_I) is_intra_type = mb_type;
     else if (sh->slice_type == SLICE_P) { if (mb_type >= 5) is_intra_type = mb_type - 5; }
-    else { snprintf(s->d->err, sizeof s->d->err, "B slices unsupported by the round-1 oracle"); return -1; }
+    else { snprintf(s->d->err, sizeof s->d->err, "B slices unsupported by the oracle"); return -1; }
     if (is_intra_type > 25 || mb_type > 30) { snprintf(s->d->err, sizeof s->d->err, "bad mb_type %d", mb_type); return -1; }
 
     uint8_t *dy = pic->y + (s->mb_y * 16) * pic->stride_y + s->mb_x * 16;
@@ -626,14 +788,19 @@ static int decode_mb(Sl *s) {
 
     if (is_intra_type == 25) {             /* I_PCM, 7.3.5 */
         mb->is_intra = 1; mb->is_pcm = 1;
-        while (!bits_aligned(b)) if (bits_u1(b)) { snprintf(s->d->err, sizeof s->d->err, "pcm_alignment_zero_bit != 0"); return -1; }
+        s->d->stats[ORC_ST_PCM]++;
+        if (cab) b->pos = (b->pos / 8 + 1) * 8;   /* 9.3.1.2: the terminate bin left 9 bits read ahead; the encoder's flush wrote 10 (9.3.4.5) */
+        else while (!bits_aligned(b)) if (bits_u1(b)) { snprintf(s->d->err, sizeof s->d->err, "pcm_alignment_zero_bit != 0"); return -1; }
         for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) dy[y * pic->stride_y + x] = (uint8_t)bits_u(b, 8);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) du[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) dv[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);
         memset(mb->total_coeff, 16, sizeof mb->total_coeff);
+        mb->cbf = 0x7FFFFFF;
         mb->qp = 0;                        /* 8.7.2.2: qPp = 0 for I_PCM in the deblocking filter */
         mb->qpc[0] = (uint8_t)chroma_qp(s->pps, 0, 0); mb->qpc[1] = (uint8_t)chroma_qp(s->pps, 0, 1);
         mb->cbp = 0x2f;
+        s->last_dqp_nonzero = 0;
+        if (cab && orc_cabac_init_engine(&s->c, b) < 0) return -1;
         digest_mb(s);
         return b->err ? -1 : 0;
     }
@@ -642,23 +809,16 @@ static int decode_mb(Sl *s) {
     if (is_intra_type >= 0) {
         mb->is_intra = 1;
         if (is_intra_type == 0) {          /* I_NxN */
-            if (s->pps->transform_8x8_mode) mb->t8x8 = (uint8_t)bits_u1(b);
-            if (mb->t8x8) { snprintf(s->d->err, sizeof s->d->err, "Intra8x8 unsupported by the round-1 oracle"); return -1; }
-            for (int blk = 0; blk < 16; blk++) {
-                int bx = blk_x(blk), by = blk_y(blk);
-                /* 8.3.1.1 predIntra4x4PredMode */
-                MbInfo *mA = bx > 0 ? mb : mb_at(s, s->mb_x - 1, s->mb_y);
-                MbInfo *mB = by > 0 ? mb : mb_at(s, s->mb_x, s->mb_y - 1);
-                int modeA, modeB, dc_pred = 0;
-                if (!mA || !mB) dc_pred = 1;
-                if ((mA && !mA->is_intra && s->pps->constrained_intra_pred) || (mB && !mB->is_intra && s->pps->constrained_intra_pred)) dc_pred = 1;
-                modeA = (mA && mA->is_intra && !mA->is_i16 && !mA->is_pcm) ? (bx > 0 ? mb->i4mode[by * 4 + bx - 1] : mA->i4mode[by * 4 + 3]) : 2;
-                modeB = (mB && mB->is_intra && !mB->is_i16 && !mB->is_pcm) ? (by > 0 ? mb->i4mode[(by - 1) * 4 + bx] : mB->i4mode[12 + bx]) : 2;
-                int pred = dc_pred ? 2 : orc_min(modeA, modeB);
-                int mode;
-                if (bits_u1(b)) mode = pred;
+            if (s->pps->transform_8x8_mode) mb->t8x8 = (uint8_t)(cab ? orc_cabac_transform8x8_flag(s) : (int)bits_u1(b));
+            int nblk = mb->t8x8 ? 4 : 16;
+            for (int blk = 0; blk < nblk; blk++) {
+                int bx = mb->t8x8 ? (blk & 1) * 2 : blk_x(blk), by = mb->t8x8 ? (blk >> 1) * 2 : blk_y(blk);
+                int pred = pred_intra_mode(s, bx, by), mode;
+                if (cab) { int rem = orc_cabac_intra_pred_mode(s); mode = rem < 0 ? pred : (rem < pred ? rem : rem + 1); }
+                else if (bits_u1(b)) mode = pred;
                 else { int rem = bits_u(b, 3); mode = rem < pred ? rem : rem + 1; }
-                mb->i4mode[by * 4 + bx] = (uint8_t)mode;
+                if (mb->t8x8) { mb->i4mode[by * 4 + bx] = mb->i4mode[by * 4 + bx + 1] = mb->i4mode[by * 4 + bx + 4] = mb->i4mode[by * 4 + bx + 5] = (uint8_t)mode; }
+                else mb->i4mode[by * 4 + bx] = (uint8_t)mode;
             }
         } else {                           /* I_16x16: Table 7-11 */
             int k = is_intra_type - 1;
@@ -666,58 +826,86 @@ static int decode_mb(Sl *s) {
             s->i16_pred_mode = k % 4;
             cbp = ((k / 4) % 3) << 4 | (k >= 12 ? 15 : 0);
         }
-        s->chroma_pred_mode = bits_ue(b);
+        s->chroma_pred_mode = cab ? orc_cabac_chroma_pred_mode(s) : (int)bits_ue(b);
         if (s->chroma_pred_mode > 3) { snprintf(s->d->err, sizeof s->d->err, "bad intra_chroma_pred_mode"); return -1; }
+        mb->chroma_pred_mode = (uint8_t)s->chroma_pred_mode;
     } else {
         /* ---- P macroblock: 7.3.5.1 mb_pred / 7.3.5.2 sub_mb_pred ---- */
         int nref = sh->num_ref_idx[0];
         mb->mb_type_p = (uint8_t)(mb_type > 3 ? 3 : mb_type);
         if (mb_type <= 2) {
             int nparts = mb_type == 0 ? 1 : 2, refs[2] = {0, 0};
-            for (int p = 0; p < nparts; p++) if (nref > 1) { refs[p] = bits_te(b, nref - 1); if (refs[p] >= nref) return -1; }
             for (int p = 0; p < nparts; p++) {
                 int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0;
                 int bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
-                for (int y = by; y < by + bh; y += 2) for (int x = bx; x < bx + bw; x += 2) mb->ref_idx[(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[p];
-                int mvp[2]; predict_mv(s, bx, by, bw, bh, refs[p], mb_type, p, mvp);
-                int mvx = mvp[0] + bits_se(b), mvy = mvp[1] + bits_se(b);
-                set_mv(s, bx, by, bw, bh, mvx, mvy);
+                if (nref > 1) { refs[p] = rd_ref_idx(s, bx, by, nref); if (refs[p] < 0 || refs[p] >= nref) return -1; }
+                for (int y = by; y < by + bh; y += 2) for (int x = bx; x < bx + bw; x += 2) mb->ref_idx[0][(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[p];
+            }
+            for (int p = 0; p < nparts; p++) {
+                int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0;
+                int bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
+                int mvp[2], mvd[2]; predict_mv(s, bx, by, bw, bh, refs[p], mb_type, p, mvp);
+                rd_mvd(s, bx, by, bw, bh, mvd);
+                set_mv(s, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
             }
         } else {
             int sub[4], refs[4] = {0, 0, 0, 0};
-            for (int i = 0; i < 4; i++) { sub[i] = bits_ue(b); if (sub[i] > 3) return -1; }
-            for (int i = 0; i < 4; i++) if (nref > 1 && mb_type != 4) { refs[i] = bits_te(b, nref - 1); if (refs[i] >= nref) return -1; }
-            for (int i = 0; i < 4; i++) mb->ref_idx[i] = (int8_t)refs[i];
+            for (int i = 0; i < 4; i++) { sub[i] = cab ? orc_cabac_sub_mb_type(s) : (int)bits_ue(b); if (sub[i] > 3) return -1; }
+            for (int i = 0; i < 4; i++) {
+                if (nref > 1 && mb_type != 4) { refs[i] = rd_ref_idx(s, (i & 1) * 2, (i >> 1) * 2, nref); if (refs[i] < 0 || refs[i] >= nref) return -1; }
+                mb->ref_idx[0][i] = (int8_t)refs[i];
+            }
             for (int i = 0; i < 4; i++) {
                 int ox = (i & 1) * 2, oy = (i >> 1) * 2;
                 int nsp = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
                 int bw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1, bh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;
+                if (sub[i] != 0) mb->mb_type_p |= 4;     /* a sub-macroblock partition smaller than 8x8: no 8x8 transform */
                 for (int p = 0; p < nsp; p++) {
                     int bx = ox + (sub[i] == 1 ? 0 : (sub[i] == 2 ? p : (p & 1)));
                     int by = oy + (sub[i] == 1 ? p : (sub[i] == 2 ? 0 : (p >> 1)));
-                    int mvp[2]; predict_mv(s, bx, by, bw, bh, refs[i], 0, 0, mvp);
-                    int mvx = mvp[0] + bits_se(b), mvy = mvp[1] + bits_se(b);
-                    set_mv(s, bx, by, bw, bh, mvx, mvy);
+                    int mvp[2], mvd[2]; predict_mv(s, bx, by, bw, bh, refs[i], 0, 0, mvp);
+                    rd_mvd(s, bx, by, bw, bh, mvd);
+                    set_mv(s, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
                 }
             }
         }
     }
     if (!mb->is_i16) {
-        unsigned code = bits_ue(b);
-        if (code > 47) { snprintf(s->d->err, sizeof s->d->err, "bad coded_block_pattern"); return -1; }
-        cbp = mb->is_intra ? orc_cbp_intra[code] : orc_cbp_inter[code];
-        if ((cbp & 15) && s->pps->transform_8x8_mode && !mb->is_intra) {
-            snprintf(s->d->err, sizeof s->d->err, "transform_8x8 inter unsupported by the round-1 oracle"); return -1;
+        if (cab) cbp = orc_cabac_cbp(s);
+        else {
+            unsigned code = bits_ue(b);
+            if (code > 47) { snprintf(s->d->err, sizeof s->d->err, "bad coded_block_pattern"); return -1; }
+            cbp = mb->is_intra ? orc_cbp_intra[code] : orc_cbp_inter[code];
+        }
+        /* 7.3.5: transform_size_8x8_flag of a non-intra macroblock (noSubMbPartSizeLessThan8x8Flag) */
+        if ((cbp & 15) && s->pps->transform_8x8_mode && !mb->is_intra && !(mb->mb_type_p & 4))
+            mb->t8x8 = (uint8_t)(cab ? orc_cabac_transform8x8_flag(s) : (int)bits_u1(b));
+    }
+    {
+        long *st = s->d->stats;
+        if (mb->is_intra) st[mb->is_i16 ? ORC_ST_I16 : (mb->t8x8 ? ORC_ST_I8 : ORC_ST_I4)]++;
+        else {
+            st[ORC_ST_P16 + (mb->mb_type_p & 3)]++;
+            if (mb->mb_type_p & 4) st[ORC_ST_SUB_SMALL]++;
+            if (mb->t8x8) st[ORC_ST_T8_INTER]++;
+            if (mb->ref_idx[0][0] > 0 || mb->ref_idx[0][1] > 0 || mb->ref_idx[0][2] > 0 || mb->ref_idx[0][3] > 0) st[ORC_ST_MULTIREF]++;
         }
     }
+    mb->mb_type_p &= 3;
     mb->cbp = (uint16_t)cbp;
     if (cbp > 0 || mb->is_i16) {
-        int dqp = bits_se(b);
+        int dqp = cab ? orc_cabac_qp_delta(s) : bits_se(b);
         if (dqp < -26 || dqp > 25) { snprintf(s->d->err, sizeof s->d->err, "mb_qp_delta out of range"); return -1; }
         s->qp = (s->qp + dqp + 52) % 52;
-    }
+        s->last_dqp_nonzero = dqp != 0;
+    } else s->last_dqp_nonzero = 0;
     mb_set_qp(s);
-    if (cbp > 0 || mb->is_i16) { if (parse_residual(s, cbp) < 0) { if (!s->d->err[0]) snprintf(s->d->err, sizeof s->d->err, "CAVLC residual error at MB %d", s->mb_addr); return -1; } }
+    if (cbp > 0 || mb->is_i16) {
+        if ((cab ? parse_residual_cabac(s, cbp) : parse_residual(s, cbp)) < 0) {
+            if (!s->d->err[0]) snprintf(s->d->err, sizeof s->d->err, "%s residual error at MB %d", cab ? "CABAC" : "CAVLC", s->mb_addr);
+            return -1;
+        }
+    }
     if (b->err) return -1;
     digest_mb(s);
 
@@ -725,13 +913,18 @@ static int decode_mb(Sl *s) {
     int qp = s->qp;
     if (!mb->is_intra) {
         if (inter_recon(s) < 0) return -1;
-        const uint8_t *list = s->pps->scaling4[3];
-        for (int r = 0; r < 16; r++) {
-            if (!mb->total_coeff[r]) continue;
-            int dq[16], res[16];
-            scale4x4(s->luma[r], dq, list, qp, 0);
-            idct4x4(dq, res);
-            add_block(dy + (r >> 2) * 4 * pic->stride_y + (r & 3) * 4, pic->stride_y, res, 4);
+        if (mb->t8x8) {
+            for (int b8 = 0; b8 < 4; b8++)
+                if (cbp & (1 << b8)) recon8x8(s, b8, s->pps->scaling8[1], qp, dy + (b8 >> 1) * 8 * pic->stride_y + (b8 & 1) * 8, pic->stride_y);
+        } else {
+            const uint8_t *list = s->pps->scaling4[3];
+            for (int r = 0; r < 16; r++) {
+                if (!mb->total_coeff[r]) continue;
+                int dq[16], res[16];
+                scale4x4(s->luma[r], dq, list, qp, 0);
+                idct4x4(dq, res);
+                add_block(dy + (r >> 2) * 4 * pic->stride_y + (r & 3) * 4, pic->stride_y, res, 4);
+            }
         }
     } else if (mb->is_i16) {
         if (pred16x16(s, s->i16_pred_mode, dy, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra16x16 mode needs unavailable neighbour"); return -1; }
@@ -756,6 +949,13 @@ static int decode_mb(Sl *s) {
             dq[0] = dc;
             idct4x4(dq, res);
             add_block(dy + (r >> 2) * 4 * pic->stride_y + (r & 3) * 4, pic->stride_y, res, 4);
+        }
+    } else if (mb->t8x8) {                 /* Intra 8x8: predict + residual per 8x8 block */
+        for (int b8 = 0; b8 < 4; b8++) {
+            uint8_t *dst = dy + (b8 >> 1) * 8 * pic->stride_y + (b8 & 1) * 8;
+            int mode = mb->i4mode[(b8 >> 1) * 8 + (b8 & 1) * 2];
+            if (pred8x8l(s, b8, mode, dst, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra8x8 mode %d needs unavailable neighbour", mode); return -1; }
+            if (cbp & (1 << b8)) recon8x8(s, b8, s->pps->scaling8[0], qp, dst, pic->stride_y);
         }
     } else {                               /* Intra 4x4: predict + residual per block in decode order */
         const uint8_t *list = s->pps->scaling4[0];
@@ -795,7 +995,25 @@ int orc_decode_slice_data(OrcDec *d, Bits *b) {
     s->d = d; s->b = b; s->pic = d->cur; s->sps = d->asps; s->pps = d->apps; s->sh = &d->sh;
     s->qp = d->sh.qp;
     int n_mbs = d->mb_w * d->mb_h, addr = d->sh.first_mb, rc = 0;
-    if (s->pps->entropy_coding_mode) { snprintf(d->err, sizeof d->err, "CABAC unsupported by the round-1 oracle"); free(s); return -1; }
+    s->cabac_on = s->pps->entropy_coding_mode;
+    d->stats[s->cabac_on ? ORC_ST_CABAC_SLICES : ORC_ST_CAVLC_SLICES]++;
+    if (s->cabac_on && d->sh.slice_type != SLICE_I && d->sh.cabac_init_idc <= 2) d->stats[ORC_ST_IDC0 + d->sh.cabac_init_idc]++;
+    if (s->cabac_on) {
+        while (!bits_aligned(b)) if (!bits_u1(b)) { snprintf(d->err, sizeof d->err, "cabac_alignment_one_bit != 1"); free(s); return -1; }
+        orc_cabac_init_contexts(&s->c, d->sh.slice_type == SLICE_I, d->sh.cabac_init_idc, d->sh.qp);
+        if (d->sh.cabac_init_idc > 2 || orc_cabac_init_engine(&s->c, b) < 0) { snprintf(d->err, sizeof d->err, "bad CABAC slice start"); free(s); return -1; }
+        for (;;) {
+            if (addr >= n_mbs) { snprintf(d->err, sizeof d->err, "slice runs past the end of the picture"); rc = -1; break; }
+            s->mb_addr = addr; s->mb_x = addr % d->mb_w; s->mb_y = addr / d->mb_w; s->mb = &s->pic->mbs[addr];
+            int skip = d->sh.slice_type != SLICE_I ? orc_cabac_mb_skip_flag(s) : 0;
+            if ((skip ? decode_skip_mb(s) : decode_mb(s)) < 0) { if (!d->err[0]) snprintf(d->err, sizeof d->err, "macroblock %d decode error", addr); rc = -1; break; }
+            addr++; d->cur_mb_count++;
+            if (b->err) { snprintf(d->err, sizeof d->err, "slice data truncated"); rc = -1; break; }
+            if (orc_cabac_terminate(&s->c)) break;             /* end_of_slice_flag */
+        }
+        free(s);
+        return rc;
+    }
     int more = 1;
     while (more) {
         if (d->sh.slice_type != SLICE_I) {

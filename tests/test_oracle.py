@@ -1,5 +1,6 @@
 """Pins the CPU oracle: I_PCM known answers, agreement with the generator's independent reconstruction loop,
 committed golden vectors, and the pack-out restatement of nv_dec.cpp:750-828."""
+import json
 import os
 import tempfile
 
@@ -102,3 +103,27 @@ def test_packout_error_codes(oracle):
     n = C.c_int(10)
     assert oracle.L.orc_packout(src, 64, 64, 48, 1, dst, C.byref(n)) == -2      # nv_dec.cpp:773-774
     assert oracle.L.orc_packout(None, 64, 64, 48, 1, dst, C.byref(n)) == -1     # nv_dec.cpp:768-771
+
+
+def test_thirdparty_high_profile_stream(oracle):
+    """The only third-party-encoded H.264 in the image that a 4:2:0 decoder can take: imageio's public sample clip
+    realshort.mp4 (High profile, CABAC, 8x8 transform, Intra8x8, I/P, 320x240, 36 pictures, IDR at 0 and 30), extracted
+    to Annex-B by tools/mp4_to_annexb.py.  No reference YUV exists for it, so it pins the oracle three ways:
+    (1) every slice decodes to its exact end (a wrong CABAC context table entry, binarisation or ctxIdxInc desynchronises the
+    arithmetic decoder within a few macroblocks); (2) the tools it exercises are the ones listed; (3) the picture at the end of
+    a 29-picture P chain is as close to the following, independently coded IDR picture as neighbouring pictures are to each
+    other -- reconstruction errors (transform, prediction, deblocking) accumulate over a P chain and would show as drift."""
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "thirdparty_realshort.h264"), "rb").read()
+    out, n, w, h = oracle.decode(data, 1)
+    assert (n, w, h) == (36, 320, 240)
+    m = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "thirdparty.json")))["realshort"]
+    assert md5(out) == m["md5_i420"]
+    t = oracle.tools(data)
+    assert t["cabac-slices"] == 36 and t["idc0"] == 34 and "cavlc-slices" not in t
+    for k in ("I4x4", "I8x8", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "T8x8-inter"):
+        assert t[k] > 50, k
+    fs = w * h * 3 // 2
+    Y = [np.frombuffer(out, np.uint8, w * h, i * fs).astype(np.int32) for i in range(n)]
+    step = [float(np.abs(Y[i + 1] - Y[i]).mean()) for i in range(n - 1)]
+    assert max(step) < 12.0                                  # natural video, no broken pictures
+    assert step[29] < 1.25 * float(np.median(step))          # P-chain end vs. fresh IDR: no drift
