@@ -197,6 +197,7 @@ bool Decoder::gpu_alloc_sequence() {
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
+    lds_intra8_ = false;                           // Intra8x8 runs in the v1 wavefront kernel until k_intra_lds learns it
     if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
@@ -307,6 +308,18 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
     if (!e.empty()) { stat_errors_++; error_ = e; return; }
     const PicParamSet &pps = ps_.pps[sh.pps_id];
     const SeqParams &sps = ps_.sps[pps.sps_id];
+    {   // tools this build does not decode yet are refused, never decoded wrongly
+        const char *why = nullptr;
+        if (sh.type == SL_B) why = "B slices are not supported yet";
+        else if (sh.wp_nondefault) why = "explicit weighted prediction is not supported yet";
+        else if (pps.scaling_matrix_present || sps.scaling_matrix_present) {
+            bool flat = true;
+            for (int i = 0; i < 6 && flat; i++) for (int k = 0; k < 16; k++) if (pps.scaling4[i][k] != 16) { flat = false; break; }
+            for (int i = 0; i < 2 && flat; i++) for (int k = 0; k < 64; k++) if (pps.scaling8[i][k] != 16) { flat = false; break; }
+            if (!flat) why = "scaling matrices are not supported yet";
+        }
+        if (why) { stat_errors_++; error_ = why; return; }
+    }
     if (pending_ && !same_picture(first_sh_, sh)) dispatch_pending();
     if (!pending_) { if (!start_picture(sh, sps, pps)) return; }
     add_slice(sh, std::move(rbsp), n);
@@ -599,8 +612,8 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         br.set_end_from_trailing();
         br.skip_bytes(s.sh.data_bit_offset >> 3); br.skip((int)(s.sh.data_bit_offset & 7));
         if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
-        SliceParseResult r = parse_slice_cavlc(t->sps, t->pps, s.sh, br, (int)si, s.ref_slot, scratch, w, want_digest_ ? &dg : nullptr);
-        t->n_intra += r.n_intra;
+        SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.ref_slot, scratch, w, want_digest_ ? &dg : nullptr);
+        t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
         if (r.error) { t->error = r.error; stat_errors_++; }
     }
     if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)
@@ -679,7 +692,7 @@ void Decoder::submit_task(PicTask *t) {
         pp.mv_ext = pp.coef + t->coef_count;
         pp.resid = (int16_t *)resid_; pp.dbrec = dbrec_;
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
-        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs;
+        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_);
         pp.want_intra_resid = lds_intra ? 1 : 0;
         pp.stages = PS_RECON;
         if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;

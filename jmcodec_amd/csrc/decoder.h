@@ -50,7 +50,7 @@ struct PicTask {
     bool wait_prev_pack = false;               // current surface was displayed by the previous picture (no cooling slack)
     // written by the parse worker
     std::atomic<int> state{0};                 // 0 queued, 1 parsed
-    int n_intra = 0, n_slices = 0; bool any_deblock = false;
+    int n_intra = 0, n_i8x8 = 0, n_slices = 0; bool any_deblock = false;
     uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0;
     unsigned long long upload_seq = 0;
     std::string error;
@@ -157,7 +157,7 @@ private:
     class Engine *engine_ = nullptr;          // per-device executor (engine.h): the only place device work is issued
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
-    uint8_t *resid_ = nullptr; bool use_lds_intra_ = false;
+    uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
     bool gpu_open_ = false;
 

@@ -2,6 +2,7 @@
 // H.264 7.3.4 (slice_data), 7.3.5 (macroblock_layer), 9.2 (CAVLC), 8.3.1.1 (intra mode
 // prediction), 8.4.1 (motion vector prediction).  See h264_cavlc.h for what it replaces.
 #include "h264_cavlc.h"
+#include "h264_cabac.h"
 #include <mutex>
 
 namespace jmamd {
@@ -44,6 +45,9 @@ static const uint8_t kRunBits[6][7] = { {1,0,0,0,0,0,0},{1,1,0,0,0,0,0},{3,2,1,0
 static const uint8_t kCbpIntra[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
 static const uint8_t kCbpInter[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
 static const uint8_t kZigzag4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
+static const uint8_t kZigzag8[64] = {   // 8x8 zig-zag scan, frame macroblocks (Table 8-? / Figure 6-... 8x8): scan position -> raster
+    0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
+   35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
 
 // two-level table for coeff_token: primary on the top 8 bits, secondary on the next 8
 struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ; len 0xFF => sym = subtable number
@@ -95,6 +99,7 @@ void ParseScratch::resize(int w, int h) {
     mb_w = w; mb_h = h;
     size_t n = (size_t)w * h;
     tc.assign(n * 24, 0); mv.assign(n * 32, 0); refidx.assign(n * 4, -1); i4.assign(n * 16, 2); info.assign(n, 0); slice_of.assign(n, -1);
+    cbp.assign(n, 0); cmode.assign(n, 0); cbf.assign(n, 0); mvd.assign(n * 32, 0);
 }
 void ParseScratch::begin_picture() { std::fill(slice_of.begin(), slice_of.end(), (int16_t)-1); }
 
@@ -102,7 +107,7 @@ void ParseScratch::begin_picture() { std::fill(slice_of.begin(), slice_of.end(),
 namespace {
 
 struct Canon {                     // canonical per-MB serialisation for SyntaxDigest
-    uint32_t addr; uint8_t kind, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4]; int16_t mv[16][2];
+    uint32_t addr; uint8_t kind /* | 16 when transform_size_8x8_flag: luma[] then holds 4 x 64 levels */, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4]; int16_t mv[16][2];
     int16_t i16dc[16], luma[16][16], cdc[2][4], cac[2][4][16];
 };
 static_assert(sizeof(Canon) == 4 + 4 + 16 + 4 + 64 + 32 + 512 + 16 + 256, "Canon must be packed");
@@ -117,6 +122,9 @@ struct P {
     uint8_t *tc; int16_t *mv; int8_t *ref; uint8_t *i4m;
     uint32_t decoded_mask = 0;
     Canon *canon = nullptr;
+    Cabac *cb = nullptr;                 // non-null: entropy_coding_mode_flag = 1
+    bool last_dqp = false;               // mb_qp_delta of the previous macroblock in decoding order != 0
+    uint8_t *mvd = nullptr;              // |mvd| per 4x4 and component of the current macroblock (CABAC ctxIdxInc)
     const char *err = nullptr;
 
     void locate(int a) {
@@ -125,7 +133,7 @@ struct P {
             if (x < 0 || y < 0 || x >= mb_w || y >= cx.mb_h) return -1;
             int i = y * mb_w + x; return cx.slice_of[i] == slice_num ? i : -1; };
         nA = av(mb_x - 1, mb_y); nB = av(mb_x, mb_y - 1); nC = av(mb_x + 1, mb_y - 1); nD = av(mb_x - 1, mb_y - 1);
-        tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16];
+        tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16]; mvd = &cx.mvd[(size_t)a * 32];
     }
     bool intra_usable(int n) const { return n >= 0 && (!pps.constrained_intra || (cx.info[n] & 1)); }
 
@@ -250,13 +258,14 @@ struct P {
         cx.slice_of[addr] = (int16_t)slice_num;
         memset(tc, 0, 24); ref[0] = ref[1] = ref[2] = ref[3] = -1; memset(mv, 0, 64); memset(i4m, 2, 16);
         cx.info[addr] = 0; decoded_mask = 0;
+        if (cb) { cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0; memset(mvd, 0, 32); }
         if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; }
         return r;
     }
     void finish_mb(const MbRec *r) {
         if (!dg) return;
         canon->kind = r->kind; canon->qp = r->qp;
-        if (r->kind == MB_INTER) { for (int i = 0; i < 4; i++) canon->ref[i] = ref[i]; memcpy(canon->mv, mv, 64); }
+        if ((r->kind & 15) == MB_INTER) { for (int i = 0; i < 4; i++) canon->ref[i] = ref[i]; memcpy(canon->mv, mv, 64); }
         const uint8_t *p = (const uint8_t *)canon;
         uint64_t h = dg->h;
         for (size_t i = 0; i < sizeof(Canon); i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -281,6 +290,7 @@ struct P {
     bool skip_mb() {
         MbRec *r = begin_mb();
         r->kind = MB_INTER; r->qp = (uint8_t)qp;
+        cx.info[addr] = 4; last_dqp = false;
         int px = 0, py = 0;
         if (nA >= 0 && nB >= 0) {
             Nb A = nb(-1, 0), B = nb(0, -1);
@@ -293,56 +303,253 @@ struct P {
         return err == nullptr;
     }
 
+    // ---- CABAC syntax elements (9.3.2 binarisation, 9.3.3.1 ctxIdxInc) ------------------------
+    // macroblock holding the 4x4 block left of / above block (bx,by) and that block's raster index; -1 = not available
+    int nb4(int bx, int by, bool left, int &r) const {
+        if (left) { if (bx > 0) { r = by * 4 + bx - 1; return addr; } r = by * 4 + 3; return nA; }
+        if (by > 0) { r = (by - 1) * 4 + bx; return addr; }
+        r = 12 + bx; return nB;
+    }
+    int ae_mb_skip() { return cb->decision(11 + (nA >= 0 && !(cx.info[nA] & 4)) + (nB >= 0 && !(cx.info[nB] & 4))); }
+    int ae_intra_mb_type(int base, bool in_i) {
+        if (in_i) {
+            int inc = (nA >= 0 && !(cx.info[nA] & 2)) + (nB >= 0 && !(cx.info[nB] & 2));       // neighbour not I_NxN
+            if (!cb->decision(base + inc)) return 0;
+            base += 2;
+        } else if (!cb->decision(base)) return 0;
+        if (cb->terminate()) return 25;
+        int k = in_i ? 1 : 0, t = 1;
+        t += 12 * cb->decision(base + 1);
+        if (cb->decision(base + 2)) t += 4 + 4 * cb->decision(base + 2 + k);
+        t += 2 * cb->decision(base + 3 + k);
+        t += cb->decision(base + 3 + 2 * k);
+        return t;
+    }
+    int ae_mb_type() {
+        if (sh.type == SL_I) return ae_intra_mb_type(3, true);
+        if (!cb->decision(14)) {
+            if (!cb->decision(15)) return 3 * cb->decision(16);
+            return 2 - cb->decision(17);
+        }
+        return 5 + ae_intra_mb_type(17, false);
+    }
+    int ae_sub_mb_type() {
+        if (cb->decision(21)) return 0;
+        if (!cb->decision(22)) return 1;
+        return cb->decision(23) ? 2 : 3;
+    }
+    int ae_t8x8() { return cb->decision(399 + (nA >= 0 && (cx.info[nA] & 8)) + (nB >= 0 && (cx.info[nB] & 8))); }
+    int ae_intra_mode(int pred) {
+        if (cb->decision(68)) return pred;
+        int rem = cb->decision(69); rem |= cb->decision(69) << 1; rem |= cb->decision(69) << 2;
+        return rem < pred ? rem : rem + 1;
+    }
+    int ae_chroma_mode() {
+        int inc = (nA >= 0 && cx.cmode[nA] != 0) + (nB >= 0 && cx.cmode[nB] != 0);     // cmode stays 0 for inter / I_PCM macroblocks
+        if (!cb->decision(64 + inc)) return 0;
+        if (!cb->decision(64 + 3)) return 1;
+        return 2 + cb->decision(64 + 3);
+    }
+    int ae_ref_idx(int bx, int by) {
+        int inc = 0;
+        for (int k = 0; k < 2; k++) {
+            int r, m = nb4(bx, by, k == 0, r);
+            if (m < 0 || (cx.info[m] & 1)) continue;
+            if (cx.refidx[(size_t)m * 4 + (r >> 3) * 2 + ((r & 3) >> 1)] > 0) inc += k == 0 ? 1 : 2;
+        }
+        int v = 0, ctx = 54 + inc;
+        while (cb->decision(ctx)) { v++; ctx = 54 + (v == 1 ? 4 : 5); if (v > 32) { err = "ref_idx out of range"; return 0; } }
+        return v;
+    }
+    int ae_mvd(int bx, int by, int comp) {
+        int sum = 0;
+        for (int k = 0; k < 2; k++) { int r, m = nb4(bx, by, k == 0, r); if (m >= 0) sum += cx.mvd[(size_t)m * 32 + r * 2 + comp]; }
+        int base = comp ? 47 : 40;
+        if (!cb->decision(base + (sum < 3 ? 0 : (sum > 32 ? 2 : 1)))) return 0;
+        int v = 1, ctx = 3;
+        while (v < 9 && cb->decision(base + ctx)) { v++; if (ctx < 6) ctx++; }
+        if (v == 9) {
+            int k = 3;
+            while (cb->bypass()) { v += 1 << k; k++; if (k > 24) { err = "mvd out of range"; return 0; } }
+            while (k--) v += cb->bypass() << k;
+        }
+        return cb->bypass() ? -v : v;
+    }
+    void read_mvd(int bx, int by, int bw, int bh, int &dx, int &dy) {
+        if (!cb) { dx = br.se(); dy = br.se(); return; }
+        dx = ae_mvd(bx, by, 0); dy = ae_mvd(bx, by, 1);
+        int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+        uint8_t cx8 = (uint8_t)(ax > 255 ? 255 : ax), cy8 = (uint8_t)(ay > 255 ? 255 : ay);     // only sums <3 / >32 matter
+        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvd[(j * 4 + i) * 2] = cx8; mvd[(j * 4 + i) * 2 + 1] = cy8; }
+    }
+    int ae_cbp() {
+        int cbp = 0;
+        int ca4 = nA >= 0 ? cx.cbp[nA] : -1, cb4 = nB >= 0 ? cx.cbp[nB] : -1;
+        for (int b8 = 0; b8 < 4; b8++) {
+            int a = (b8 & 1) ? !((cbp >> (b8 - 1)) & 1) : (ca4 >= 0 ? !((ca4 >> (b8 + 1)) & 1) : 0);
+            int b = (b8 & 2) ? !((cbp >> (b8 - 2)) & 1) : (cb4 >= 0 ? !((cb4 >> (b8 + 2)) & 1) : 0);
+            cbp |= cb->decision(73 + a + 2 * b) << b8;
+        }
+        int a = ca4 >= 0 && (ca4 >> 4) != 0, b = cb4 >= 0 && (cb4 >> 4) != 0;
+        if (cb->decision(77 + a + 2 * b)) {
+            a = ca4 >= 0 && (ca4 >> 4) == 2; b = cb4 >= 0 && (cb4 >> 4) == 2;
+            cbp |= (1 + cb->decision(77 + 4 + a + 2 * b)) << 4;
+        }
+        return cbp;
+    }
+    int ae_qp_delta() {
+        int ctx = 60 + (last_dqp ? 1 : 0), k = 0;
+        while (cb->decision(ctx)) { k++; ctx = 60 + (k == 1 ? 2 : 3); if (k > 104) { err = "mb_qp_delta out of range"; return 0; } }
+        return (k & 1) ? (k + 1) >> 1 : -(k >> 1);
+    }
+    // residual_block_cabac (7.3.5.3.3): levels written at dst[map[scan_pos + first]]; returns number of non-zero levels.
+    // cat = ctxBlockCat, bit = this block's bit in cbf (or -1 for cat 5), fa / fb = coded_block_flag of the neighbouring
+    // blocks (-1: neighbour macroblock not available)
+    int residual_block_ae(int cat, int bit, int fa, int fb, int maxnum, int first, int16_t *dst, const uint8_t *map, bool intra) {
+        static const int cbf_off[5] = {0, 4, 8, 12, 16}, sig_off[5] = {0, 15, 29, 44, 47}, abs_off[5] = {0, 10, 20, 30, 39};
+        if (cat != 5) {
+            if (fa < 0) fa = intra; if (fb < 0) fb = intra;
+            if (!cb->decision(85 + cbf_off[cat] + fa + 2 * fb)) return 0;
+            cx.cbf[addr] |= 1u << bit;
+        }
+        const int sig_base = cat == 5 ? 402 : 105 + sig_off[cat], last_base = cat == 5 ? 417 : 166 + sig_off[cat];
+        const int abs_base = cat == 5 ? 426 : 227 + abs_off[cat];
+        uint8_t pos[64]; int n = 0, i;
+        for (i = 0; i < maxnum - 1; i++) {
+            int si = cat == 5 ? cabac_sig8_inc[i] : (cat == 3 ? (i < 2 ? i : 2) : i);
+            if (cb->decision(sig_base + si)) {
+                pos[n++] = (uint8_t)i;
+                int li = cat == 5 ? cabac_last8_inc[i] : (cat == 3 ? (i < 2 ? i : 2) : i);
+                if (cb->decision(last_base + li)) break;
+            }
+        }
+        if (i == maxnum - 1) pos[n++] = (uint8_t)(maxnum - 1);
+        int gt1 = 0, eq1 = 0;
+        const int gt1_max = 4 - (cat == 3);
+        for (int k = n - 1; k >= 0; k--) {
+            int v = 0;
+            if (cb->decision(abs_base + (gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4)))) {
+                v = 1;
+                int ctx = abs_base + 5 + (gt1 < gt1_max ? gt1 : gt1_max);
+                while (v < 14 && cb->decision(ctx)) v++;
+                if (v == 14) {
+                    int e = 0;
+                    while (cb->bypass()) { v += 1 << e; e++; if (e > 20) { err = "coefficient level out of range"; return -1; } }
+                    while (e--) v += cb->bypass() << e;
+                }
+            }
+            int level = v + 1;
+            if (level == 1) eq1++; else gt1++;
+            if (level > 32767) level = 32767;
+            dst[map[pos[k] + first]] = (int16_t)(cb->bypass() ? -level : level);
+        }
+        return n;
+    }
+    // coded_block_flag of the 4x4 luma block left of / above (bx,by): -1 when the neighbouring macroblock is not available
+    int cbf_luma_nb(int bx, int by, bool left) const {
+        int r, m = nb4(bx, by, left, r);
+        if (m < 0) return -1;
+        return (int)((cx.cbf[m] >> r) & 1);
+    }
+
     // residual(): luma + chroma blocks into the coefficient stream
-    bool residual(MbRec *r, int cbp, bool i16) {
+    bool residual(MbRec *r, int cbp, bool i16, bool t8, bool intra) {
         static const uint8_t ident[16] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15};
-        (void)ident;
         if (i16) {
             int16_t *d = alloc_coef(16); if (!d) return false;
-            if (residual_block(nc_luma(0, 0), 16, 0, d, kZigzag4) < 0) { err = "CAVLC error (Intra16x16 DC)"; return false; }
+            int n;
+            if (cb) n = residual_block_ae(0, 16, nA >= 0 ? (int)((cx.cbf[nA] >> 16) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> 16) & 1) : -1, 16, 0, d, kZigzag4, intra);
+            else n = residual_block(nc_luma(0, 0), 16, 0, d, kZigzag4);
+            if (n < 0) { if (!err) err = "entropy error (Intra16x16 DC)"; return false; }
             if (canon) memcpy(canon->i16dc, d, 32);
         }
         uint32_t bits = 0;
-        for (int blk = 0; blk < 16; blk++) {
-            if (!(cbp & (1 << (blk >> 2)))) continue;
-            int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
-            // parse into the stream tail; keep the 16 slots only if the block turns out non-empty
-            if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
-            int16_t *d = out.coef + out.coef_count;
-            memset(d, 0, 32);
-            int n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
-            if (n < 0) { err = "CAVLC error (luma block)"; return false; }
-            tc[by * 4 + bx] = (uint8_t)n;
-            if (n) { bits |= 1u << blk; out.coef_count += 16; if (canon) memcpy(canon->luma[by * 4 + bx], d, 32); }
+        if (t8) {
+            for (int b8 = 0; b8 < 4; b8++) {
+                if (!(cbp & (1 << b8))) continue;
+                if (out.coef_count + 64 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                int16_t *d = out.coef + out.coef_count;
+                memset(d, 0, 128);
+                int ox = (b8 & 1) * 2, oy = (b8 >> 1) * 2, total = 0;
+                if (cb) {
+                    total = residual_block_ae(5, -1, 0, 0, 64, 0, d, kZigzag8, intra);
+                    if (total < 0) return false;
+                    // 7.4.5.3.3: coded_block_flag of an 8x8 luma block is inferred to be 1 (4:2:0)
+                    for (int k = 0; k < 4; k++) cx.cbf[addr] |= 1u << ((oy + (k >> 1)) * 4 + ox + (k & 1));
+                } else {
+                    for (int k = 0; k < 4; k++) {                       // 7.3.5.3.2: block k carries every fourth level of the 8x8 scan
+                        int bx = ox + (k & 1), by = oy + (k >> 1);
+                        int16_t tmp[16]; memset(tmp, 0, sizeof tmp);
+                        int n = residual_block(nc_luma(bx, by), 16, 0, tmp, ident);
+                        if (n < 0) { err = "CAVLC error (luma 8x8 block)"; return false; }
+                        tc[by * 4 + bx] = (uint8_t)n; total += n;
+                        for (int i = 0; i < 16; i++) if (tmp[i]) d[kZigzag8[4 * i + k]] = tmp[i];
+                    }
+                }
+                if (total) { bits |= 15u << (4 * b8); out.coef_count += 64; if (canon) memcpy(&canon->luma[0][0] + 64 * b8, d, 128); }
+            }
+        } else {
+            for (int blk = 0; blk < 16; blk++) {
+                if (!(cbp & (1 << (blk >> 2)))) continue;
+                int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+                // parse into the stream tail; keep the 16 slots only if the block turns out non-empty
+                if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                int16_t *d = out.coef + out.coef_count;
+                memset(d, 0, 32);
+                int n;
+                if (cb) n = residual_block_ae(i16 ? 1 : 2, by * 4 + bx, cbf_luma_nb(bx, by, true), cbf_luma_nb(bx, by, false), i16 ? 15 : 16, i16 ? 1 : 0, d, kZigzag4, intra);
+                else n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
+                if (n < 0) { if (!err) err = "entropy error (luma block)"; return false; }
+                tc[by * 4 + bx] = (uint8_t)n;
+                if (n) { bits |= 1u << blk; out.coef_count += 16; if (canon) memcpy(canon->luma[by * 4 + bx], d, 32); }
+            }
         }
         r->cbp_blk = (uint16_t)bits;
         if (cbp & 0x30) {
             for (int pl = 0; pl < 2; pl++) {
                 if (out.coef_count + 4 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
                 int16_t *d = out.coef + out.coef_count; memset(d, 0, 8);
-                int n = residual_block(-1, 4, 0, d, ident);
-                if (n < 0) { err = "CAVLC error (chroma DC)"; return false; }
+                int n;
+                if (cb) n = residual_block_ae(3, 17 + pl, nA >= 0 ? (int)((cx.cbf[nA] >> (17 + pl)) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> (17 + pl)) & 1) : -1, 4, 0, d, ident, intra);
+                else n = residual_block(-1, 4, 0, d, ident);
+                if (n < 0) { if (!err) err = "entropy error (chroma DC)"; return false; }
                 if (n) { r->flags |= pl ? MBF_CR_DC : MBF_CB_DC; out.coef_count += 4; if (canon) memcpy(canon->cdc[pl], d, 8); }
             }
         }
         if (cbp & 0x20) {
-            uint32_t cb = 0;
+            uint32_t cbm = 0;
             for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
                 if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
                 int16_t *d = out.coef + out.coef_count; memset(d, 0, 32);
-                int n = residual_block(nc_chroma(pl, k & 1, k >> 1), 15, 1, d, kZigzag4);
-                if (n < 0) { err = "CAVLC error (chroma AC)"; return false; }
+                int n;
+                if (cb) {
+                    int bx = k & 1, by = k >> 1, b0 = 19 + pl * 4, fa, fb;
+                    if (bx) fa = (int)((cx.cbf[addr] >> (b0 + by * 2)) & 1); else fa = nA >= 0 ? (int)((cx.cbf[nA] >> (b0 + by * 2 + 1)) & 1) : -1;
+                    if (by) fb = (int)((cx.cbf[addr] >> (b0 + bx)) & 1); else fb = nB >= 0 ? (int)((cx.cbf[nB] >> (b0 + 2 + bx)) & 1) : -1;
+                    n = residual_block_ae(4, b0 + k, fa, fb, 15, 1, d, kZigzag4, intra);
+                } else n = residual_block(nc_chroma(pl, k & 1, k >> 1), 15, 1, d, kZigzag4);
+                if (n < 0) { if (!err) err = "entropy error (chroma AC)"; return false; }
                 tc[16 + 4 * pl + k] = (uint8_t)n;
-                if (n) { cb |= 1u << (4 * pl + k); out.coef_count += 16; if (canon) memcpy(canon->cac[pl][k], d, 32); }
+                if (n) { cbm |= 1u << (4 * pl + k); out.coef_count += 16; if (canon) memcpy(canon->cac[pl][k], d, 32); }
             }
-            r->cbp_cac = (uint8_t)cb;
+            r->cbp_cac = (uint8_t)cbm;
         }
         return true;
     }
 
-    bool macroblock(int &n_intra) {
+    // 8.3.1.1 / 8.3.2.1: predicted Intra4x4 / Intra8x8 mode of the block whose top-left 4x4 is (bx,by)
+    int pred_intra_mode(int bx, int by) const {
+        int mA = bx > 0 ? addr : nA, mB = by > 0 ? addr : nB;
+        if (mA < 0 || mB < 0) return 2;
+        if (pps.constrained_intra && (!(cx.info[mA] & 1) || !(cx.info[mB] & 1))) return 2;
+        int a = bx > 0 ? i4m[by * 4 + bx - 1] : ((cx.info[mA] & 2) ? cx.i4[(size_t)mA * 16 + by * 4 + 3] : 2);
+        int b = by > 0 ? i4m[(by - 1) * 4 + bx] : ((cx.info[mB] & 2) ? cx.i4[(size_t)mB * 16 + 12 + bx] : 2);
+        return a < b ? a : b;
+    }
+
+    bool macroblock(int &n_intra, int &n_i8x8) {
         MbRec *r = begin_mb();
-        uint32_t mb_type = br.ue();
+        uint32_t mb_type = cb ? (uint32_t)ae_mb_type() : br.ue();
         int itype = -1;
         if (sh.type == SL_I) itype = (int)mb_type;
         else if (sh.type == SL_P) { if (mb_type >= 5) itype = (int)mb_type - 5; }
@@ -351,15 +558,17 @@ struct P {
 
         if (itype == 25) {                                     // I_PCM
             r->kind = MB_PCM; r->qp = 0;
-            br.align_zero();
+            // CABAC: the terminate bin left 9 bits read ahead of the arithmetic code; the encoder's flush wrote 10 (9.3.4.5)
+            if (cb) br.skip((int)(8 - (br.bitpos() & 7))); else br.align_zero();
             if (br.overrun() || (br.bitpos() >> 3) + 384 > br.size()) { err = "I_PCM runs past the slice"; return false; }
             int16_t *d = alloc_coef(192); if (!d) return false;
             memcpy(d, br.byte_ptr(), 384); br.skip_bytes(384);
-            memset(tc, 16, 24); cx.info[addr] = 1;
+            memset(tc, 16, 24); cx.info[addr] = 1 | 16;
+            if (cb) { cx.cbp[addr] = 0x2f; cx.cbf[addr] = 0x7FFFFFF; last_dqp = false; cb->init_engine(&br); }
             finish_mb(r);
             return true;
         }
-        int cbp = 0; bool i16 = false;
+        int cbp = 0; bool i16 = false, t8 = false;
         if (itype >= 0) {
             cx.info[addr] = 1;
             if (intra_usable(nA)) r->flags |= MBF_AVAIL_A;
@@ -369,22 +578,27 @@ struct P {
             n_intra++;
             if (itype == 0) {
                 r->kind = MB_I4; cx.info[addr] = 3;
-                if (pps.transform8x8 && br.u1()) { err = "Intra8x8 is not supported yet"; return false; }
-                for (int blk = 0; blk < 16; blk++) {
-                    int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
-                    int mA = bx > 0 ? addr : nA, mB = by > 0 ? addr : nB, pred;
-                    if (mA < 0 || mB < 0) pred = 2;
-                    else if (pps.constrained_intra && (!(cx.info[mA] & 1) || !(cx.info[mB] & 1))) pred = 2;
-                    else {
-                        int a = bx > 0 ? i4m[by * 4 + bx - 1] : ((cx.info[mA] & 2) ? cx.i4[(size_t)mA * 16 + by * 4 + 3] : 2);
-                        int b = by > 0 ? i4m[(by - 1) * 4 + bx] : ((cx.info[mB] & 2) ? cx.i4[(size_t)mB * 16 + 12 + bx] : 2);
-                        pred = a < b ? a : b;
+                if (pps.transform8x8) t8 = cb ? ae_t8x8() : br.u1();
+                if (t8) {
+                    cx.info[addr] |= 8; n_i8x8++;
+                    for (int b8 = 0; b8 < 4; b8++) {
+                        int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2, pred = pred_intra_mode(bx, by), mode;
+                        if (cb) mode = ae_intra_mode(pred);
+                        else if (br.u1()) mode = pred; else { int rem = (int)br.u(3); mode = rem < pred ? rem : rem + 1; }
+                        i4m[by * 4 + bx] = i4m[by * 4 + bx + 1] = i4m[by * 4 + bx + 4] = i4m[by * 4 + bx + 5] = (uint8_t)mode;
                     }
-                    int mode;
-                    if (br.u1()) mode = pred; else { int rem = (int)br.u(3); mode = rem < pred ? rem : rem + 1; }
-                    i4m[by * 4 + bx] = (uint8_t)mode;
+                    // Intra8x8PredMode of block b8 in nibble b8
+                    r->u.i4[0] = (uint8_t)(i4m[0] | (i4m[2] << 4)); r->u.i4[1] = (uint8_t)(i4m[8] | (i4m[10] << 4));
+                } else {
+                    for (int blk = 0; blk < 16; blk++) {
+                        int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+                        int pred = pred_intra_mode(bx, by), mode;
+                        if (cb) mode = ae_intra_mode(pred);
+                        else if (br.u1()) mode = pred; else { int rem = (int)br.u(3); mode = rem < pred ? rem : rem + 1; }
+                        i4m[by * 4 + bx] = (uint8_t)mode;
+                    }
+                    for (int k = 0; k < 8; k++) r->u.i4[k] = (uint8_t)(i4m[2 * k] | (i4m[2 * k + 1] << 4));
                 }
-                for (int k = 0; k < 8; k++) r->u.i4[k] = (uint8_t)(i4m[2 * k] | (i4m[2 * k + 1] << 4));
                 if (canon) memcpy(canon->i4, i4m, 16);
             } else {
                 r->kind = MB_I16; i16 = true;
@@ -393,9 +607,10 @@ struct P {
                 cbp = (((k >> 2) % 3) << 4) | (k >= 12 ? 15 : 0);
                 if (canon) canon->i16mode = (uint8_t)(k & 3);
             }
-            uint32_t cm = br.ue();
+            uint32_t cm = cb ? (uint32_t)ae_chroma_mode() : br.ue();
             if (cm > 3) { err = "bad intra_chroma_pred_mode"; return false; }
             r->modes |= (uint8_t)cm;
+            if (cb) cx.cmode[addr] = (uint8_t)cm;
             if (canon) canon->cmode = (uint8_t)cm;
         } else {
             r->kind = MB_INTER;
@@ -403,57 +618,72 @@ struct P {
             bool sub8 = false;
             if (mb_type <= 2) {
                 int np = mb_type == 0 ? 1 : 2, rf[2] = {0, 0};
-                if (nref > 1) for (int p = 0; p < np; p++) { rf[p] = br.te(nref - 1); if (rf[p] >= nref) { err = "ref_idx out of range"; return false; } }
                 for (int p = 0; p < np; p++) {
                     int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0, bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
+                    if (nref > 1) { rf[p] = cb ? ae_ref_idx(bx, by) : br.te(nref - 1); if (rf[p] >= nref) { err = "ref_idx out of range"; return false; } }
                     for (int j = by; j < by + bh; j += 2) for (int i = bx; i < bx + bw; i += 2) ref[(j >> 1) * 2 + (i >> 1)] = (int8_t)rf[p];
-                    int px, py; predict(bx, by, bw, rf[p], (int)mb_type, p, px, py);
-                    int mx = px + br.se(), my = py + br.se();
-                    set_mv(bx, by, bw, bh, mx, my);
+                }
+                for (int p = 0; p < np; p++) {
+                    int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0, bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
+                    int px, py, dx, dy; predict(bx, by, bw, rf[p], (int)mb_type, p, px, py);
+                    read_mvd(bx, by, bw, bh, dx, dy);
+                    set_mv(bx, by, bw, bh, px + dx, py + dy);
                 }
             } else {
                 int sub[4], rf[4] = {0, 0, 0, 0};
-                for (int i = 0; i < 4; i++) { sub[i] = (int)br.ue(); if (sub[i] > 3) { err = "bad sub_mb_type"; return false; } if (sub[i]) sub8 = true; }
-                if (nref > 1 && mb_type != 4) for (int i = 0; i < 4; i++) { rf[i] = br.te(nref - 1); if (rf[i] >= nref) { err = "ref_idx out of range"; return false; } }
-                for (int i = 0; i < 4; i++) ref[i] = (int8_t)rf[i];
+                for (int i = 0; i < 4; i++) { sub[i] = cb ? ae_sub_mb_type() : (int)br.ue(); if (sub[i] > 3) { err = "bad sub_mb_type"; return false; } if (sub[i]) sub8 = true; }
+                for (int i = 0; i < 4; i++) {
+                    if (nref > 1 && mb_type != 4) { rf[i] = cb ? ae_ref_idx((i & 1) * 2, (i >> 1) * 2) : br.te(nref - 1); if (rf[i] >= nref) { err = "ref_idx out of range"; return false; } }
+                    ref[i] = (int8_t)rf[i];
+                }
                 for (int i = 0; i < 4; i++) {
                     int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i];
                     int nsp = st == 0 ? 1 : (st == 3 ? 4 : 2), bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
                     for (int p = 0; p < nsp; p++) {
                         int bx = ox + (st == 1 ? 0 : (st == 2 ? p : (p & 1))), by = oy + (st == 1 ? p : (st == 2 ? 0 : (p >> 1)));
-                        int px, py; predict(bx, by, bw, rf[i], 0, 0, px, py);
-                        int mx = px + br.se(), my = py + br.se();
-                        set_mv(bx, by, bw, bh, mx, my);
+                        int px, py, dx, dy; predict(bx, by, bw, rf[i], 0, 0, px, py);
+                        read_mvd(bx, by, bw, bh, dx, dy);
+                        set_mv(bx, by, bw, bh, px + dx, py + dy);
                     }
                 }
             }
+            if (err) return false;
             write_motion(r, sub8);
             if (err) return false;
+            if (!i16) {
+                if (cb) cbp = ae_cbp();
+                else { uint32_t code = br.ue(); if (code > 47) { err = "bad coded_block_pattern"; return false; } cbp = kCbpInter[code]; }
+                if ((cbp & 15) && pps.transform8x8 && !sub8) { t8 = cb ? ae_t8x8() : br.u1(); if (t8) cx.info[addr] |= 8; }
+            }
         }
-        if (!i16) {
-            uint32_t code = br.ue();
-            if (code > 47) { err = "bad coded_block_pattern"; return false; }
-            cbp = itype >= 0 ? kCbpIntra[code] : kCbpInter[code];
-            if ((cbp & 15) && pps.transform8x8 && itype < 0) { err = "8x8 transform is not supported yet"; return false; }
+        if (itype >= 0 && !i16) {
+            if (cb) cbp = ae_cbp();
+            else { uint32_t code = br.ue(); if (code > 47) { err = "bad coded_block_pattern"; return false; } cbp = kCbpIntra[code]; }
         }
+        if (cb) cx.cbp[addr] = (uint8_t)cbp;
+        if (t8) r->modes |= MBM_T8X8;
         if (cbp > 0 || i16) {
-            int dqp = br.se();
+            int dqp = cb ? ae_qp_delta() : br.se();
             if (dqp < -26 || dqp > 25) { err = "mb_qp_delta out of range"; return false; }
             qp = (qp + dqp + 52) % 52;
-        }
+            last_dqp = dqp != 0;
+        } else last_dqp = false;
         r->qp = (uint8_t)qp;
-        if (cbp > 0 || i16) { if (!residual(r, cbp, i16)) return false; }
+        if (cbp > 0 || i16) { if (!residual(r, cbp, i16, t8, itype >= 0)) return false; }
+        if (err) return false;
         if (br.overrun()) { err = "macroblock data truncated"; return false; }
+        if (canon && t8) r->kind |= 16;                        // digest only: restored below
         finish_mb(r);
+        r->kind &= 15;
         return true;
     }
 };
 
 }  // namespace
 
-SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
-                                   BitReader &br, int slice_num, const int8_t *ref_slot,
-                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest) {
+SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
+                                  BitReader &br, int slice_num, const int8_t *ref_slot,
+                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest) {
     cavlc_init_tables();
     SliceParseResult res;
     Canon canon;
@@ -461,7 +691,27 @@ SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps,
     p.qp = sh.qp;
     p.canon = digest ? &canon : nullptr;
     int n_mbs = sps.mb_w * sps.mb_h, addr = sh.first_mb;
-    if (pps.cabac) { res.error = "CABAC is not supported yet"; return res; }
+    if (pps.cabac) {
+        static thread_local Cabac cabac;
+        // 7.3.4: cabac_alignment_one_bit up to the byte boundary, then the arithmetic code (9.3.1.2)
+        while (!br.aligned()) if (!br.u1()) { res.error = "cabac_alignment_one_bit is not 1"; return res; }
+        if (sh.cabac_init_idc > 2) { res.error = "bad cabac_init_idc"; return res; }
+        cabac.init_contexts(sh.type == SL_I ? 0 : 1 + sh.cabac_init_idc, sh.qp);
+        cabac.init_engine(&br);
+        p.cb = &cabac;
+        for (;;) {
+            if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; return res; }
+            p.locate(addr);
+            bool ok;
+            if (sh.type != SL_I && p.ae_mb_skip()) ok = p.skip_mb();
+            else ok = p.macroblock(res.n_intra, res.n_i8x8);
+            if (!ok) { res.error = p.err ? p.err : "macroblock error"; return res; }
+            addr++; res.mbs_decoded++;
+            if (br.overrun()) { res.error = "slice data truncated"; return res; }
+            if (cabac.terminate()) break;                     // end_of_slice_flag
+        }
+        return res;
+    }
     bool more = true;
     while (more) {
         if (sh.type != SL_I) {
@@ -473,7 +723,7 @@ SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps,
         }
         if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; return res; }
         p.locate(addr);
-        if (!p.macroblock(res.n_intra)) { res.error = p.err ? p.err : "macroblock error"; return res; }
+        if (!p.macroblock(res.n_intra, res.n_i8x8)) { res.error = p.err ? p.err : "macroblock error"; return res; }
         addr++; res.mbs_decoded++;
         more = br.more_rbsp_data();
     }

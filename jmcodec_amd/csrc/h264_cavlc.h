@@ -1,4 +1,4 @@
-// jmcodec_amd/csrc/h264_cavlc.h -- host entropy stage: CAVLC slice_data() -> macroblock job list.
+// jmcodec_amd/csrc/h264_cavlc.h -- host entropy stage: slice_data() (CAVLC 9.2 or CABAC 9.3) -> macroblock job list.
 //
 // This is the "entropy decode stays on the host and feeds a per-macroblock job
 // list" half of the replacement for cuvidDecodePicture
@@ -24,8 +24,11 @@ struct ParseScratch {
     std::vector<int16_t> mv;       // [mb][16][2]
     std::vector<int8_t>  refidx;   // [mb][4]
     std::vector<uint8_t> i4;       // [mb][16] Intra4x4PredMode (2 when not I4x4)
-    std::vector<uint8_t> info;     // [mb] bit0 intra, bit1 Intra4x4
+    std::vector<uint8_t> info;     // [mb] bit0 intra, bit1 I_NxN (Intra4x4 / Intra8x8), bit2 skipped, bit3 transform_size_8x8_flag, bit4 I_PCM
     std::vector<int16_t> slice_of; // [mb] slice number or -1
+    // CABAC neighbour context (9.3.3.1.1): coded_block_pattern (luma bits 0-3, chroma << 4), intra_chroma_pred_mode,
+    // coded_block_flag bits (0-15 luma raster, 16 Intra16x16 DC, 17/18 Cb/Cr DC, 19-22 Cb AC, 23-26 Cr AC), |mvd| per 4x4
+    std::vector<uint8_t> cbp, cmode; std::vector<uint32_t> cbf; std::vector<uint8_t> mvd;
     void resize(int w, int h);
     void begin_picture();
 };
@@ -36,15 +39,16 @@ struct SyntaxDigest { uint64_t h = 1469598103934665603ull; uint64_t mbs = 0; };
 
 struct SliceParseResult {
     int mbs_decoded = 0;
-    int n_intra = 0;            // I4x4 + I16x16 macroblocks (need the wavefront kernel)
+    int n_intra = 0;            // I4x4 + I8x8 + I16x16 macroblocks (need the wavefront kernel)
+    int n_i8x8 = 0;             // of which Intra8x8
     const char *error = nullptr;
 };
 
 // Parses slice_data() of one slice.  br must be positioned at sh.data_bit_offset with
 // set_end_from_trailing() already called.  ref_slot[i] = DPB surface slot of RefPicList0[i].
-SliceParseResult parse_slice_cavlc(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
-                                   BitReader &br, int slice_num, const int8_t *ref_slot,
-                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest);
+SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
+                                  BitReader &br, int slice_num, const int8_t *ref_slot,
+                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest);
 
 void cavlc_init_tables();   // idempotent, thread-safe
 

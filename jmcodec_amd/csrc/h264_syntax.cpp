@@ -173,7 +173,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present) sh.delta_poc_bottom = br.se(); }
     else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (p.bottom_field_poc_present) sh.delta_poc[1] = br.se(); }
     if (p.redundant_pic_cnt_present) br.ue();
-    if (sh.type == SL_B) br.u1();
+    if (sh.type == SL_B) sh.direct_spatial_mv_pred = br.u1();
     sh.num_ref_idx[0] = p.num_ref_idx_default[0]; sh.num_ref_idx[1] = p.num_ref_idx_default[1];
     if (sh.type != SL_I && br.u1()) { sh.num_ref_idx[0] = br.ue() + 1; if (sh.type == SL_B) sh.num_ref_idx[1] = br.ue() + 1; }
     if (sh.num_ref_idx[0] > 32 || sh.num_ref_idx[1] > 32) return "num_ref_idx_active out of range";
@@ -196,6 +196,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
             int lw = 1 << sh.luma_log2_wd, lo = 0, cw[2] = {1 << sh.chroma_log2_wd, 1 << sh.chroma_log2_wd}, co[2] = {0, 0};
             if (br.u1()) { lw = br.se(); lo = br.se(); }
             if (br.u1()) for (int j = 0; j < 2; j++) { cw[j] = br.se(); co[j] = br.se(); }
+            if (lw != (1 << sh.luma_log2_wd) || lo != 0 || cw[0] != (1 << sh.chroma_log2_wd) || cw[1] != cw[0] || co[0] != 0 || co[1] != 0) sh.wp_nondefault = true;
             if (l == 0) { sh.luma_w[i] = (int16_t)lw; sh.luma_o[i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[i][j] = (int16_t)cw[j]; sh.chroma_o[i][j] = (int16_t)co[j]; } }
         }
     }
@@ -215,7 +216,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
             }
         }
     }
-    if (p.cabac && sh.type != SL_I) br.ue();
+    if (p.cabac && sh.type != SL_I) { sh.cabac_init_idc = (int)br.ue(); if (sh.cabac_init_idc > 2) return "bad cabac_init_idc"; }
     sh.qp = p.init_qp + br.se();
     if (sh.qp < 0 || sh.qp > 51) return "slice QP out of range";
     if (p.deblock_ctrl_present) {

@@ -30,10 +30,13 @@ enum : uint8_t {
     MBF_DECODED = 128,    // macroblock was present in the bitstream (else concealment)
 };
 
+// MbRec.modes bit 4: transform_size_8x8_flag -- luma residual is four 8x8 blocks; with MB_I4 the prediction is Intra8x8
+enum : uint8_t { MBM_T8X8 = 16 };
+
 struct MbRec {            // 32 bytes
     uint8_t  kind;        // MB_*
     uint8_t  qp;          // QP_Y of the macroblock (0 for I_PCM: 8.7.2.2)
-    uint8_t  modes;       // bits 0-1 intra_chroma_pred_mode, bits 2-3 Intra16x16PredMode
+    uint8_t  modes;       // bits 0-1 intra_chroma_pred_mode, bits 2-3 Intra16x16PredMode, bit 4 MBM_T8X8
     uint8_t  flags;       // MBF_*
     uint16_t cbp_blk;     // bit r set: luma 4x4 block r (raster) has coded levels
     uint8_t  cbp_cac;     // bits 0-3 Cb AC blocks, 4-7 Cr AC blocks
@@ -42,7 +45,8 @@ struct MbRec {            // 32 bytes
     int8_t   ref[4];      // DPB surface slot per 8x8 (inter), -1 otherwise
     union {
         int16_t  mv[4][2];    // one MV per 8x8 (quarter-sample units)
-        uint8_t  i4[8];       // Intra4x4PredMode, two per byte (low nibble = even raster index)
+        uint8_t  i4[8];       // Intra4x4PredMode, two per byte (low nibble = even raster index);
+                              // MBM_T8X8: Intra8x8PredMode of 8x8 block b in nibble b of i4[0..1]
         uint32_t mv_ext;      // MBF_MV_EXT: index (in MVs) of 16 per-4x4 MVs in mv_ext[]
     } u;
 };
@@ -50,7 +54,8 @@ static_assert(sizeof(MbRec) == 32, "MbRec must stay 32 bytes");
 
 // Coefficient stream layout of one macroblock, starting at coef_off (int16 units):
 //   MB_I16 : 16 DC levels (4x4 matrix, raster)              always
-//   luma   : 16 levels (raster) for every set bit of cbp_blk, ascending bit order
+//   luma   : 16 levels (raster) for every set bit of cbp_blk, ascending bit order;
+//            MBM_T8X8: a coded 8x8 block b sets the four bits 4b..4b+3 and stores 64 levels (8x8 raster) in their place
 //   chroma : 4 Cb DC levels if MBF_CB_DC, then 4 Cr DC levels if MBF_CR_DC
 //   chroma : 16 levels (raster, [0] unused) per set bit of cbp_cac, ascending
 //   MB_PCM : 384 raw bytes (256 Y, 64 Cb, 64 Cr) = 192 int16 slots, nothing else

@@ -89,6 +89,7 @@ __device__ __forceinline__ MbW select_mbw(bool c, const MbW &a, const MbW &b) {
 }
 __device__ __forceinline__ int mbw_kind(const MbW &m) { return m.w[0] & 255; }
 __device__ __forceinline__ int mbw_qp(const MbW &m) { return (m.w[0] >> 8) & 255; }
+__device__ __forceinline__ int mbw_modes(const MbW &m) { return (m.w[0] >> 16) & 255; }
 __device__ __forceinline__ int mbw_flags(const MbW &m) { return m.w[0] >> 24; }
 __device__ __forceinline__ int mbw_cbp_blk(const MbW &m) { return m.w[1] & 0xffff; }
 __device__ __forceinline__ int mbw_slice(const MbW &m) { return m.w[1] >> 24; }

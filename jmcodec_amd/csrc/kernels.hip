@@ -16,16 +16,61 @@
 namespace jmamd {
 
 // LDS residual scratch of one wave: 16x16 luma + 2 x 8x8 chroma, int16
-struct ResTile { short y[256]; short c[2][64]; };
+struct ResTile { short y[256]; short c[2][64]; int t8[256]; };    // t8: row-transformed 8x8 blocks between the two 1-D passes
 
-// Residual of one macroblock into LDS.  Lanes 0..15: luma blocks (blkIdx order), lanes 16..23: chroma blocks.
+// 8.5.13 one-dimensional 8-point inverse transform (in place)
+__device__ __forceinline__ void idct8_1d(int *d) {
+    int e0 = d[0] + d[4], e1 = -d[3] + d[5] - d[7] - (d[7] >> 1), e2 = d[0] - d[4], e3 = d[1] + d[7] - d[3] - (d[3] >> 1);
+    int e4 = (d[2] >> 1) - d[6], e5 = -d[1] + d[7] + d[5] + (d[5] >> 1), e6 = d[2] + (d[6] >> 1), e7 = d[3] + d[5] + d[1] + (d[1] >> 1);
+    int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2), f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+    d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1; d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
+}
+// LevelScale8x8 with the flat weight matrix: 16 * normAdjust8x8(m, i, j) (8.5.9, Table of v_m0..v_m5), six 6-bit fields per m
+__device__ __forceinline__ int level_scale8(int m, int i, int j) {
+    const unsigned long long packed = m == 0 ? 0x6194E0494ull : (m == 1 ? 0x69C5634D6ull : (m == 2 ? 0x7E162A5DAull : (m == 3 ? 0x8636AD65Cull : (m == 4 ? 0x9A87B3720ull : 0xAEE8BA824ull))));
+    int ti = (i & 1) ? 1 : ((i & 2) ? 2 : 0), tj = (j & 1) ? 1 : ((j & 2) ? 2 : 0);
+    int cls = ti == tj ? ti : (ti + tj == 1 ? 3 : (ti + tj == 2 ? 4 : 5));
+    return 16 * (int)((packed >> (6 * cls)) & 63);
+}
+
+// Residual of one macroblock into LDS.  Lanes 0..15: luma 4x4 blocks (blkIdx order) -- or lanes 0..31: (8x8 block, row / column)
+// when the macroblock uses the 8x8 transform -- and lanes 32..39: chroma blocks.
 // For MB_I16 the luma DC path (8.5.10) is applied.  Must be called by all 64 lanes of the wave.
 __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile &rt, int lane) {
     const short *coef = pp.coef + r.coef_off;
     int qp = r.qp;
     int n_luma = __popc((unsigned)r.cbp_blk);
     int base_luma = r.kind == MB_I16 ? 16 : 0;
-    if (lane < 16) {
+    if (r.modes & MBM_T8X8) {
+        if (lane < 32) {
+            int b8 = lane >> 3, i = lane & 7;
+            bool coded = (r.cbp_blk >> (4 * b8)) & 1;
+            int d[8];
+            if (coded) {
+                const short *c = coef + 16 * __popc((unsigned)r.cbp_blk & ((1u << (4 * b8)) - 1)) + i * 8;
+                int m = qp % 6, s = qp / 6;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { int v = c[k] * level_scale8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
+                idct8_1d(d);
+#pragma unroll
+                for (int k = 0; k < 8; k++) rt.t8[b8 * 64 + i * 8 + k] = d[k];
+            }
+            // second pass: lane = (block, column); same wave, LDS keeps program order
+            if (coded) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = rt.t8[b8 * 64 + k * 8 + i];
+                idct8_1d(d);
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = (d[k] + 32) >> 6;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = 0;
+            }
+            int ox = (b8 & 1) * 8 + i, oy = (b8 >> 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rt.y[(oy + k) * 16 + ox] = (short)d[k];
+        }
+    } else if (lane < 16) {
         int blk = lane, rpos = blk_to_raster(blk);
         int d[16];
         bool coded = (r.cbp_blk >> blk) & 1;
@@ -59,16 +104,17 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
         int bx = rpos & 3, by = rpos >> 2;
 #pragma unroll
         for (int k = 0; k < 16; k++) rt.y[(by * 4 + (k >> 2)) * 16 + bx * 4 + (k & 3)] = (short)d[k];
-    } else if (lane < 24) {
-        int pl = (lane - 16) >> 2, k4 = (lane - 16) & 3;
+    }
+    if (lane >= 32 && lane < 40) {
+        int pl = (lane - 32) >> 2, k4 = (lane - 32) & 3;
         int qpc = chroma_qp(qp, pl ? pp.cr_qp_off : pp.cb_qp_off);
         const short *cdc = coef + base_luma + 16 * n_luma;
         int has_cb = (r.flags & MBF_CB_DC) ? 1 : 0, has_cr = (r.flags & MBF_CR_DC) ? 1 : 0;
         const short *cac = cdc + 4 * (has_cb + has_cr);
         int d[16];
-        bool coded = (r.cbp_cac >> (lane - 16)) & 1;
+        bool coded = (r.cbp_cac >> (lane - 32)) & 1;
         if (coded) {
-            const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 16)) - 1));
+            const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 32)) - 1));
 #pragma unroll
             for (int k = 0; k < 16; k++) d[k] = dequant4(c[k], qpc, k);
         } else {
@@ -336,7 +382,8 @@ __device__ __forceinline__ void publish_row(volatile int *progress, int row, int
 // k_recon_intra
 // ------------------------------------------------------------------------------------------
 struct IntraTile {
-    uint8_t y[17][24];        // [0] = row above; column 0 = left neighbour, columns 1..16 MB, 17..20 top-right
+    uint8_t y[17][28];        // [0] = row above; column 0 = left neighbour, columns 1..16 MB, 17..24 top-right (4 for Intra4x4, 8 for Intra8x8)
+    uint8_t e8[2][32];        // Intra8x8: raw / filtered reference samples, index 0 corner, 1..16 p[0..15,-1], 17..24 p[-1,0..7]
     uint8_t c[2][9][12];      // per plane: [0] = row above, column 0 = left neighbour, 1..8 MB
 };
 
@@ -393,6 +440,67 @@ __device__ void intra4x4_block(IntraTile &t, const ResTile &rt, int blk, int mod
     t.y[oy + py][ox + px] = (uint8_t)p;
 }
 
+// Intra8x8 (8.3.2): reference sample filtering 8.3.2.2.1 and the nine modes 8.3.2.2.2-10 for 8x8 block b8; lane = pixel
+__device__ void intra8x8_block(IntraTile &t, const ResTile &rt, int b8, int mode, bool availA, bool availB, bool availC, bool availD, int lane) {
+    int ox = 1 + (b8 & 1) * 8, oy = 1 + (b8 >> 1) * 8;
+    uint8_t *raw = t.e8[0], *fe = t.e8[1];
+    if (lane == 0) raw[0] = availD ? t.y[oy - 1][ox - 1] : 128;
+    else if (lane <= 16) { int k = lane - 1; raw[lane] = availB ? t.y[oy - 1][ox + ((k >= 8 && !availC) ? 7 : k)] : 128; }
+    else if (lane <= 24) raw[lane] = availA ? t.y[oy + lane - 17][ox - 1] : 128;
+    // same wave: LDS keeps program order
+    if (lane == 0) {
+        int c = raw[0], t0 = raw[1], l0 = raw[17];
+        fe[0] = (uint8_t)(!availD ? 128 : ((availA && availB) ? (t0 + 2 * c + l0 + 2) >> 2 : (availB ? (3 * c + t0 + 2) >> 2 : (availA ? (3 * c + l0 + 2) >> 2 : c))));
+    } else if (lane <= 16) {
+        int k = lane - 1, c = raw[lane];
+        int lo = k == 0 ? (availD ? raw[0] : c) : raw[lane - 1], hi = k == 15 ? c : raw[lane + 1];
+        fe[lane] = (uint8_t)((lo + 2 * c + hi + 2) >> 2);
+    } else if (lane <= 24) {
+        int k = lane - 17, c = raw[lane];
+        int lo = k == 0 ? (availD ? raw[0] : c) : raw[lane - 1], hi = k == 7 ? c : raw[lane + 1];
+        fe[lane] = (uint8_t)((lo + 2 * c + hi + 2) >> 2);
+    }
+    int x = lane & 7, y = lane >> 3;
+#define TT(i) ((i) < 0 ? fe[0] : fe[1 + (i)])
+#define LL(i) ((i) < 0 ? fe[0] : fe[17 + (i)])
+    int p;
+    switch (mode) {
+    case 0: p = TT(x); break;
+    case 1: p = LL(y); break;
+    case 2: {
+        int st = 0, sl = 0;
+        for (int i = 0; i < 8; i++) { st += TT(i); sl += LL(i); }
+        p = (availA && availB) ? (st + sl + 8) >> 4 : (availA ? (sl + 4) >> 3 : (availB ? (st + 4) >> 3 : 128));
+        break; }
+    case 3: p = (x == 7 && y == 7) ? (TT(14) + 3 * TT(15) + 2) >> 2 : (TT(x + y) + 2 * TT(x + y + 1) + TT(x + y + 2) + 2) >> 2; break;
+    case 4:
+        if (x > y) p = (TT(x - y - 2) + 2 * TT(x - y - 1) + TT(x - y) + 2) >> 2;
+        else if (x < y) p = (LL(y - x - 2) + 2 * LL(y - x - 1) + LL(y - x) + 2) >> 2;
+        else p = (TT(0) + 2 * TT(-1) + LL(0) + 2) >> 2;
+        break;
+    case 5: { int z = 2 * x - y, i = x - (y >> 1);
+        if (z >= 0) p = (z & 1) ? (TT(i - 2) + 2 * TT(i - 1) + TT(i) + 2) >> 2 : (TT(i - 1) + TT(i) + 1) >> 1;
+        else if (z == -1) p = (LL(0) + 2 * TT(-1) + TT(0) + 2) >> 2;
+        else p = (LL(y - 2 * x - 1) + 2 * LL(y - 2 * x - 2) + LL(y - 2 * x - 3) + 2) >> 2;
+        break; }
+    case 6: { int z = 2 * y - x, i = y - (x >> 1);
+        if (z >= 0) p = (z & 1) ? (LL(i - 2) + 2 * LL(i - 1) + LL(i) + 2) >> 2 : (LL(i - 1) + LL(i) + 1) >> 1;
+        else if (z == -1) p = (LL(0) + 2 * TT(-1) + TT(0) + 2) >> 2;
+        else p = (TT(x - 2 * y - 1) + 2 * TT(x - 2 * y - 2) + TT(x - 2 * y - 3) + 2) >> 2;
+        break; }
+    case 7: { int i = x + (y >> 1); p = (y & 1) ? (TT(i) + 2 * TT(i + 1) + TT(i + 2) + 2) >> 2 : (TT(i) + TT(i + 1) + 1) >> 1; break; }
+    default: { int z = x + 2 * y, i = y + (x >> 1);
+        if (z > 13) p = LL(7);
+        else if (z == 13) p = (LL(6) + 3 * LL(7) + 2) >> 2;
+        else p = (z & 1) ? (LL(i) + 2 * LL(i + 1) + LL(i + 2) + 2) >> 2 : (LL(i) + LL(i + 1) + 1) >> 1;
+        break; }
+    }
+#undef TT
+#undef LL
+    p = clip1(p + rt.y[((b8 >> 1) * 8 + y) * 16 + (b8 & 1) * 8 + x]);
+    t.y[oy + y][ox + x] = (uint8_t)p;
+}
+
 // plane prediction (8.3.3.4 / 8.3.4.4) for an n x n block whose neighbours sit in a tile with the given row stride
 __device__ __forceinline__ int plane_pred(const uint8_t *tile, int stride, int n, int x, int y) {
     // tile points at the MB origin inside the tile (tile[-stride] = row above, tile[-1] = left column)
@@ -418,14 +526,22 @@ __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, 
     // ---- neighbours into the tile (clamped addresses; unavailable ones are never used) ----
     {
         int x0 = mbx * 16, y0 = mby * 16;
-        if (lane < 21) { int x = clip3(0, W - 1, x0 - 1 + lane), y = clip3(0, H - 1, y0 - 1); t.y[0][lane] = dst[(size_t)y * pitch + x]; }
+        if (lane < 25) { int x = clip3(0, W - 1, x0 - 1 + lane), y = clip3(0, H - 1, y0 - 1); t.y[0][lane] = dst[(size_t)y * pitch + x]; }
         else if (lane >= 32 && lane < 48) { int i = lane - 32; int x = clip3(0, W - 1, x0 - 1); t.y[1 + i][0] = dst[(size_t)(y0 + i) * pitch + x]; }
         int cx0 = mbx * 8, cy0 = mby * 8, CW = W >> 1, CH = H >> 1;
         if (lane < 18) { int pl = lane / 9, i = lane % 9; int x = clip3(0, CW - 1, cx0 - 1 + i), y = clip3(0, CH - 1, cy0 - 1); t.c[pl][0][i] = dst_c[(size_t)y * pitch + 2 * x + pl]; }
         else if (lane >= 32 && lane < 48) { int pl = (lane - 32) >> 3, i = (lane - 32) & 7; int x = clip3(0, CW - 1, cx0 - 1); t.c[pl][1 + i][0] = dst_c[(size_t)(cy0 + i) * pitch + 2 * x + pl]; }
     }
     // ---- luma ----
-    if (r.kind == MB_I4) {
+    if (r.kind == MB_I4 && (r.modes & MBM_T8X8)) {
+        for (int b8 = 0; b8 < 4; b8++) {
+            int bx = b8 & 1, by = b8 >> 1;
+            int mode = (r.u.i4[b8 >> 1] >> ((b8 & 1) * 4)) & 15;
+            bool a = bx > 0 || availA, b = by > 0 || availB, d = (bx > 0 && by > 0) ? true : (bx > 0 ? availB : (by > 0 ? availA : availD));
+            bool c = b8 == 0 ? availB : (b8 == 1 ? availC : b8 == 2);
+            intra8x8_block(t, rt, b8, mode, a, b, c, d, lane);
+        }
+    } else if (r.kind == MB_I4) {
         for (int blk = 0; blk < 16; blk++) {
             int rpos = blk_to_raster(blk), bx = rpos & 3, by = rpos >> 2;
             int mode = (r.u.i4[rpos >> 1] >> ((rpos & 1) * 4)) & 15;
@@ -451,7 +567,7 @@ __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, 
             if (mode == 0) p = t.y[0][1 + x];
             else if (mode == 1) p = t.y[1 + y][0];
             else if (mode == 2) p = dc;
-            else p = plane_pred(&t.y[1][1], 24, 16, x, y);
+            else p = plane_pred(&t.y[1][1], 28, 16, x, y);
             v[k] = clip1(p + rt.y[y * 16 + x]);
         }
         // all lanes read the borders before anyone overwrites the tile interior (interior is not read for I16)
@@ -578,6 +694,7 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
             if (!have) bs = 0;
             else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, select_mbw(dir == 0, pl_, pt_), rp, q, rq, true); }
         } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
+        if ((e & 1) && (mbw_modes(q) & MBM_T8X8)) bs = 0;    // 8x8 transform: inner 4x4 edges are not filtered
         t.bs[dir][e][k] = (uint8_t)bs;
     }
     // ---- load tiles ----

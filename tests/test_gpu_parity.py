@@ -227,3 +227,19 @@ def test_corrupt_streams_do_not_crash_or_hang():
             assert len(frames) <= 8
             for f in frames:
                 assert len(f) == 96 * 80 * 3 // 2
+
+
+def test_thirdparty_high_profile_stream(oracle):
+    """High profile (CABAC, 8x8 transform, Intra8x8) on the device: bit-exact with the oracle on the third-party clip."""
+    import json, os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    data = open(os.path.join(g, "thirdparty_realshort.h264"), "rb").read()
+    m = json.load(open(os.path.join(g, "thirdparty.json")))["realshort"]
+    want, n, w, h = oracle.decode(data, 1)
+    frames = gpu_decode(data)
+    fs = w * h * 3 // 2
+    assert len(frames) == n == m["frames"]
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+    assert md5(b"".join(frames)) == m["md5_i420"]
+    assert md5(b"".join(gpu_decode(data, out_fmt=0))) == m["md5_nv12"]

@@ -101,3 +101,14 @@ def test_api_protocol_and_info_block():
     ret, got = api.jm_nvdec_decode_frame(data, len(data), h)
     assert (ret, got) == (0, 0)
     api.jm_nvdec_deinit(h)
+
+
+def test_thirdparty_cabac_stream_parses_like_the_oracle(oracle):
+    """High profile / CABAC / 8x8 transform: the host entropy decoder and the oracle agree on every syntax element of the
+    third-party clip (tests/golden/README.md)."""
+    import os
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "thirdparty_realshort.h264"), "rb").read()
+    od, on = oracle.syntax_digest(data)
+    pd, pn, frames, errors, pocs, _ = _product_digest(data)
+    assert (pd, pn, frames, errors) == (od, on, 36, 0)
+    assert on == 36 * 20 * 15
