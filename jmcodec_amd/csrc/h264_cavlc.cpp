@@ -558,8 +558,9 @@ struct P {
 
         if (itype == 25) {                                     // I_PCM
             r->kind = MB_PCM; r->qp = 0;
-            // CABAC: the terminate bin left 9 bits read ahead of the arithmetic code; the encoder's flush wrote 10 (9.3.4.5)
-            if (cb) br.skip((int)(8 - (br.bitpos() & 7))); else br.align_zero();
+            // CABAC: the 9 bits the arithmetic decoder has read ahead end exactly with the last bit of the encoder's flush (9.3.4.5),
+            // so in both entropy modes only pcm_alignment_zero_bits remain before the samples
+            br.align_zero();
             if (br.overrun() || (br.bitpos() >> 3) + 384 > br.size()) { err = "I_PCM runs past the slice"; return false; }
             int16_t *d = alloc_coef(192); if (!d) return false;
             memcpy(d, br.byte_ptr(), 384); br.skip_bytes(384);

@@ -789,7 +789,7 @@ static int decode_mb(Sl *s) {
     if (is_intra_type == 25) {             /* I_PCM, 7.3.5 */
         mb->is_intra = 1; mb->is_pcm = 1;
         s->d->stats[ORC_ST_PCM]++;
-        if (cab) b->pos = (b->pos / 8 + 1) * 8;   /* 9.3.1.2: the terminate bin left 9 bits read ahead; the encoder's flush wrote 10 (9.3.4.5) */
+        if (cab) b->pos = (b->pos + 7) & ~(size_t)7;   /* the 9 bits read ahead end exactly with the last bit of the encoder's flush (9.3.4.5): only the pcm_alignment_zero_bits remain */
         else while (!bits_aligned(b)) if (bits_u1(b)) { snprintf(s->d->err, sizeof s->d->err, "pcm_alignment_zero_bit != 0"); return -1; }
         for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) dy[y * pic->stride_y + x] = (uint8_t)bits_u(b, 8);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) du[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);

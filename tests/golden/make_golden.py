@@ -24,6 +24,9 @@ CASES = {
     "ip_fuzz_96x80": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=3, slices=2, seed=15),
     "ip_fuzz_crop_90x70": dict(width=90, height=70, frames=6, gop=6, mode=1, num_ref=2, seed=16, poc_type=0, nonref_period=3, deblock=2, slices=3),
     "ip_fuzz_cip_80x64": dict(width=80, height=64, frames=6, gop=6, mode=1, num_ref=4, seed=17, cip=1, chroma_qp_off=-4, alpha_off=3, beta_off=-3),
+    "main_cabac_fuzz_96x80": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=3, slices=2, seed=18, cabac=1, cabac_idc=1),
+    "high_cabac_fuzz_96x80": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=2, seed=19, cabac=1, cabac_idc=2, t8x8=1),
+    "high_cavlc_real_96x80": dict(width=96, height=80, frames=6, gop=6, seed=20, t8x8=1),
 }
 
 

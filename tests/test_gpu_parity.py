@@ -68,6 +68,20 @@ def test_full_size_1080p_baseline(oracle):
         assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
 
 
+def test_full_size_1080p_high_cabac(oracle):
+    """1920x1080 High profile: CABAC, 8x8 transform, Intra8x8 (the tools of BASELINE config 2 that I/P streams use)."""
+    kw = streams.config_c1(frames=5)
+    kw.update(cabac=1, t8x8=1, qp=30, seed=0x4A4D0200)
+    data = streams.generate(**kw)
+    want, n, w, h = oracle.decode(data, 1)
+    assert (w, h, n) == (1920, 1080, 5)
+    frames = gpu_decode(data)
+    fs = w * h * 3 // 2
+    assert len(frames) == n
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+
+
 def test_full_size_properties_300_frames():
     """Size-independent properties at BASELINE's full stream length where the scalar oracle would take too long:
     the same stream decoded twice, fed in different chunkings and by concurrent handles, gives identical frames;

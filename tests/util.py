@@ -69,4 +69,13 @@ PARITY_CASES = {
     "one_mb": dict(width=16, height=16, frames=4, gop=2, mode=1, seed=81),
     "wide_strip": dict(width=640, height=16, frames=3, gop=3, mode=1, seed=82),
     "tall_strip": dict(width=16, height=400, frames=3, gop=3, mode=1, seed=83),
+    # Main / High profile: CABAC (all three cabac_init_idc tables), 8x8 transform, Intra8x8
+    "cabac_pcm": dict(width=48, height=32, frames=2, pcm_only=1, gop=2, cabac=1, seed=3),
+    "cabac_real": dict(width=176, height=144, frames=6, gop=6, seed=21, cabac=1),
+    "cabac_fuzz_idc1_multiref": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=3, slices=2, seed=84, cabac=1, cabac_idc=1),
+    "cabac_fuzz_idc2_cip": dict(width=96, height=80, frames=8, gop=8, mode=1, num_ref=2, slices=3, seed=85, cabac=1, cabac_idc=2, cip=1, deblock=2, chroma_qp_off=2),
+    "high_cabac_fuzz": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=2, seed=86, cabac=1, t8x8=1),
+    "high_cavlc_fuzz": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=2, seed=87, t8x8=1, poc_type=0),
+    "high_real_qvga": dict(width=320, height=240, frames=8, gop=8, seed=22, cabac=1, t8x8=1, qp=30),
+    "high_crop_odd_mbs": dict(width=90, height=70, frames=6, gop=3, mode=1, seed=88, cabac=1, cabac_idc=1, t8x8=1, slices=2),
 }

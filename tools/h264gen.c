@@ -43,6 +43,9 @@ typedef struct {
     int level_idc;
     int cip;                    /* constrained_intra_pred_flag                */
     int search;                 /* integer search range                       */
+    int cabac;                  /* entropy_coding_mode_flag                   */
+    int cabac_idc;              /* cabac_init_idc 0..2                        */
+    int t8x8;                   /* transform_8x8_mode_flag: 8x8 transform + Intra8x8 (High profile) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -70,6 +73,58 @@ static void bw_se(BitW *w, int v) { bw_ue(w, v > 0 ? (uint32_t)(2 * v - 1) : (ui
 static void bw_te(BitW *w, int range_max, int v) { if (range_max > 1) bw_ue(w, v); else bw_put(w, 1, !v); }
 static void bw_trailing(BitW *w) { bw_put(w, 1, 1); while (w->nbits) bw_put(w, 1, 0); }
 static int bw_bitpos(const BitW *w) { return (int)w->len * 8 + w->nbits; }
+
+/* ---------------- CABAC encoder (9.3.4) ------------------------------------- */
+#include "../oracle/orc_cabac_tables.h"     /* context init (m,n), rangeTabLPS, transIdxLPS: data tables shared with the oracle */
+typedef struct { uint8_t st[ORC_CABAC_N_CTX]; uint32_t low, range; int outstanding, first; BitW *w; } CabEnc;
+static void cab_init_ctx(CabEnc *c, int table, int qp) {
+    for (int i = 0; i < ORC_CABAC_N_CTX; i++) {
+        int pre = CLIP3(1, 126, ((orc_cabac_init_mn[table][i][0] * CLIP3(0, 51, qp)) >> 4) + orc_cabac_init_mn[table][i][1]);
+        c->st[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)(((pre - 64) << 1) | 1);
+    }
+}
+static void cab_start(CabEnc *c, BitW *w) { c->w = w; c->low = 0; c->range = 510; c->outstanding = 0; c->first = 1; }
+static void cab_put(CabEnc *c, int b) {
+    if (c->first) c->first = 0; else bw_put(c->w, 1, (uint32_t)b);
+    while (c->outstanding > 0) { bw_put(c->w, 1, (uint32_t)(1 - b)); c->outstanding--; }
+}
+static void cab_renorm(CabEnc *c) {
+    while (c->range < 256) {
+        if (c->low < 256) cab_put(c, 0);
+        else if (c->low >= 512) { c->low -= 512; cab_put(c, 1); }
+        else { c->low -= 256; c->outstanding++; }
+        c->range <<= 1; c->low <<= 1;
+    }
+}
+static void cab_enc(CabEnc *c, int ctx, int bin) {
+    uint32_t st = c->st[ctx] >> 1, mps = c->st[ctx] & 1, lps = orc_cabac_range_lps[st][(c->range >> 6) & 3];
+    c->range -= lps;
+    if ((uint32_t)bin != mps) { c->low += c->range; c->range = lps; if (st == 0) mps ^= 1; st = orc_cabac_trans_lps[st]; }
+    else if (st < 62) st++;
+    c->st[ctx] = (uint8_t)((st << 1) | mps);
+    cab_renorm(c);
+}
+static void cab_byp(CabEnc *c, int bin) {
+    c->low <<= 1;
+    if (bin) c->low += c->range;
+    if (c->low >= 1024) { cab_put(c, 1); c->low -= 1024; }
+    else if (c->low < 512) cab_put(c, 0);
+    else { c->low -= 512; c->outstanding++; }
+}
+static void cab_term(CabEnc *c, int bin) {
+    c->range -= 2;
+    if (bin) {
+        c->low += c->range;
+        c->range = 2; cab_renorm(c);                          /* EncodeFlush */
+        cab_put(c, (int)((c->low >> 9) & 1));
+        bw_put(c->w, 2, ((c->low >> 7) & 3) | 1);
+    } else cab_renorm(c);
+}
+static void cab_ueg(CabEnc *c, int v, int k) {               /* Exp-Golomb order k suffix, bypass coded */
+    while (v >= (1 << k)) { cab_byp(c, 1); v -= 1 << k; k++; }
+    cab_byp(c, 0);
+    while (k--) cab_byp(c, (v >> k) & 1);
+}
 
 typedef struct { uint8_t *buf; size_t cap, len; } Out;
 static void out_nal(Out *o, int ref_idc, int type, const BitW *w, int long_sc) {
@@ -157,6 +212,7 @@ typedef struct {
     uint8_t tc[24]; uint8_t intra, pcm, i16, qp, qpc[2]; uint8_t i4[16];
     int slice; uint8_t skip;
     int8_t dis_db, a_off, b_off;
+    uint8_t cbp, cmode, t8; uint32_t cbf; uint8_t mvd[16][2]; uint16_t nzmask;   /* CABAC context state / 8x8 transform / deblock non-zero map */
 } MbE;
 
 typedef struct {
@@ -174,6 +230,7 @@ typedef struct {
     int decoded_mask;
     FILE *recon;
     long stat_bits_mb[8];
+    int cabac; CabEnc cab; int last_dqp;   /* entropy_coding_mode_flag; mb_qp_delta of the previous MB != 0 */
 } Enc;
 
 static void frame_alloc(Frame *f, int W, int H, int hp) {
@@ -520,6 +577,7 @@ typedef struct {
     int dc16[16];
     int cdc[2][4], cac[2][4][16];
     int dqp;
+    int t8; int luma8[4][64]; /* transform_size_8x8_flag; levels per 8x8 block, raster */
 } MbCode;
 
 static int nC_luma(Enc *e, int mx, int my, MbE *cur, int bx, int by) {
@@ -579,7 +637,7 @@ static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *
 /* ------------------------------ deblocking (own implementation) --------------- */
 static int edge_bs(const MbE *p, int bp, const MbE *q, int bq, int mbedge) {
     if (p->intra || q->intra) return mbedge ? 4 : 3;
-    if (p->tc[bp] || q->tc[bq]) return 2;
+    if (((p->nzmask >> bp) & 1) || ((q->nzmask >> bq) & 1)) return 2;
     if (p->refid[(bp >> 3) * 2 + ((bp & 3) >> 1)] != q->refid[(bq >> 3) * 2 + ((bq & 3) >> 1)]) return 1;
     return (ABS(p->mv[bp][0] - q->mv[bq][0]) >= 4 || ABS(p->mv[bp][1] - q->mv[bq][1]) >= 4) ? 1 : 0;
 }
@@ -614,6 +672,7 @@ static void deblock_frame(Enc *e) {
         if (q->dis_db == 1) continue;
         for (int dir = 0; dir < 2; dir++) for (int ed = 0; ed < 4; ed++) {
             const MbE *p = q;
+            if ((ed & 1) && q->t8) continue;                /* 8x8 transform: only 8x8 block edges are filtered */
             if (ed == 0) { int nx = mx - !dir, ny = my - dir; if (nx < 0 || ny < 0) continue; p = &e->mbs[ny * e->mbw + nx]; if (q->dis_db == 2 && p->slice != q->slice) continue; }
             int bs[4], any = 0;
             for (int k = 0; k < 4; k++) { int bq = dir ? ed * 4 + k : k * 4 + ed; int bp = ed ? (dir ? bq - 4 : bq - 1) : (dir ? 12 + k : k * 4 + 3); bs[k] = edge_bs(p, bp, q, bq, ed == 0); any |= bs[k]; }
@@ -643,24 +702,318 @@ static int sad16_pred(Enc *e, int mx, int my, const int *p) {
     return sad;
 }
 
+/* ------------------------------ 8x8 transform (own implementation) ---------- */
+static const uint8_t zz8[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,
+    35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
+static const int norm8[6][6] = { {20,18,32,19,25,24},{22,19,35,21,28,26},{26,23,42,24,33,31},{28,25,45,26,35,33},{32,28,51,30,40,38},{36,32,58,34,46,43} };
+static int cls8(int i, int j) {
+    int a = (i & 1) ? 1 : ((i & 3) ? 2 : 0), b = (j & 1) ? 1 : ((j & 3) ? 2 : 0);
+    if (a == b) return a;
+    if (a + b == 1) return 3;
+    return a + b == 2 ? 4 : 5;
+}
+/* 8.5.13 written with the standard's intermediate names a[], b[] */
+static void inv8_1d(const int *in, int *out) {
+    int a[8], b[8];
+    a[0] = in[0] + in[4]; a[1] = -in[3] + in[5] - in[7] - (in[7] >> 1); a[2] = in[0] - in[4]; a[3] = in[1] + in[7] - in[3] - (in[3] >> 1);
+    a[4] = (in[2] >> 1) - in[6]; a[5] = -in[1] + in[7] + in[5] + (in[5] >> 1); a[6] = in[2] + (in[6] >> 1); a[7] = in[3] + in[5] + in[1] + (in[1] >> 1);
+    b[0] = a[0] + a[6]; b[1] = a[1] + (a[7] >> 2); b[2] = a[2] + a[4]; b[3] = a[3] + (a[5] >> 2);
+    b[4] = a[2] - a[4]; b[5] = (a[3] >> 2) - a[5]; b[6] = a[0] - a[6]; b[7] = a[7] - (a[1] >> 2);
+    out[0] = b[0] + b[7]; out[1] = b[2] + b[5]; out[2] = b[4] + b[3]; out[3] = b[6] + b[1];
+    out[4] = b[6] - b[1]; out[5] = b[4] - b[3]; out[6] = b[2] - b[5]; out[7] = b[0] - b[7];
+}
+static void recon8(const int *lev /*raster*/, int qp, uint8_t *dst, int st) {
+    int d[64], g[64], col[8], o[8];
+    for (int k = 0; k < 64; k++) { int ls = 16 * norm8[qp % 6][cls8(k >> 3, k & 7)]; d[k] = qp >= 36 ? (lev[k] * ls) << (qp / 6 - 6) : (lev[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6); }
+    for (int i = 0; i < 8; i++) inv8_1d(d + 8 * i, g + 8 * i);
+    for (int j = 0; j < 8; j++) {
+        for (int i = 0; i < 8; i++) col[i] = g[8 * i + j];
+        inv8_1d(col, o);
+        for (int i = 0; i < 8; i++) dst[i * st + j] = (uint8_t)CLIP1(dst[i * st + j] + ((o[i] + 32) >> 6));
+    }
+}
+/* forward side: projection on the decoder's (orthogonal) reconstruction basis, computed in floating point per QP */
+static float *basis8(int qp) {
+    static float *tab[52];
+    if (tab[qp]) return tab[qp];
+    float *B = (float *)malloc(sizeof(float) * 64 * 65);
+    for (int k = 0; k < 64; k++) {
+        double d[64], g[64];
+        for (int i = 0; i < 64; i++) d[i] = 0;
+        d[k] = 16.0 * norm8[qp % 6][cls8(k >> 3, k & 7)] * (double)(1 << (qp / 6)) / 64.0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int r = 0; r < 8; r++) {
+                double in[8], a[8], b[8], *src = pass ? g : d;
+                for (int i = 0; i < 8; i++) in[i] = pass ? src[8 * i + r] : src[8 * r + i];
+                a[0] = in[0] + in[4]; a[1] = -in[3] + in[5] - in[7] - in[7] / 2; a[2] = in[0] - in[4]; a[3] = in[1] + in[7] - in[3] - in[3] / 2;
+                a[4] = in[2] / 2 - in[6]; a[5] = -in[1] + in[7] + in[5] + in[5] / 2; a[6] = in[2] + in[6] / 2; a[7] = in[3] + in[5] + in[1] + in[1] / 2;
+                b[0] = a[0] + a[6]; b[1] = a[1] + a[7] / 4; b[2] = a[2] + a[4]; b[3] = a[3] + a[5] / 4; b[4] = a[2] - a[4]; b[5] = a[3] / 4 - a[5]; b[6] = a[0] - a[6]; b[7] = a[7] - a[1] / 4;
+                double o[8] = { b[0] + b[7], b[2] + b[5], b[4] + b[3], b[6] + b[1], b[6] - b[1], b[4] - b[3], b[2] - b[5], b[0] - b[7] };
+                for (int i = 0; i < 8; i++) { if (pass) d[8 * i + r] = o[i]; else g[8 * r + i] = o[i]; }
+            }
+        }
+        double nn = 0;
+        for (int i = 0; i < 64; i++) { B[k * 65 + i] = (float)(d[i] / 64.0); nn += (d[i] / 64.0) * (d[i] / 64.0); }
+        B[k * 65 + 64] = (float)nn;
+    }
+    return tab[qp] = B;
+}
+/* transform+quantise+reconstruct one luma 8x8 block (pred already in cur frame); returns nonzero count */
+static int code_luma8(Enc *e, int px, int py, int qp, int intra, int *levels /*raster*/) {
+    Frame *c = &e->cur, *s = &e->src; float x[64]; int nz = 0;
+    const float *B = basis8(qp);
+    for (int k = 0; k < 64; k++) x[k] = (float)(s->y[(py + (k >> 3)) * s->sy + px + (k & 7)] - c->y[(py + (k >> 3)) * c->sy + px + (k & 7)]);
+    float dz = intra ? 0.33f : 0.17f;
+    for (int k = 0; k < 64; k++) {
+        float acc = 0; const float *b = B + k * 65;
+        for (int i = 0; i < 64; i++) acc += x[i] * b[i];
+        float v = acc / b[64]; int z = (int)((v < 0 ? -v : v) + dz); z = MIN(z, 2000);
+        levels[k] = v < 0 ? -z : z; nz += z != 0;
+    }
+    if (nz) recon8(levels, qp, c->y + py * c->sy + px, c->sy);
+    return nz;
+}
+/* Intra8x8 (8.3.2): raw + filtered reference samples of 8x8 block b8; T/L index -1 = corner */
+static void i8_edges(Enc *e, int mx, int my, int b8, int *T /*[-1..15]*/, int *L /*[-1..7]*/, int *aA, int *aB, int *aD) {
+    Frame *c = &e->cur; int bx = b8 & 1, by = b8 >> 1;
+    uint8_t *d = c->y + (my * 16 + by * 8) * c->sy + mx * 16 + bx * 8; int st = c->sy;
+    int availA = bx || intra_ok(e, mb_avail(e, mx - 1, my)), availB = by || intra_ok(e, mb_avail(e, mx, my - 1));
+    int availD = (bx && by) ? 1 : (bx ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e, mb_avail(e, mx - 1, my - 1))));
+    int availC = b8 == 0 ? intra_ok(e, mb_avail(e, mx, my - 1)) : (b8 == 1 ? intra_ok(e, mb_avail(e, mx + 1, my - 1)) : b8 == 2);
+    int rt[17], rl[9], *t = rt + 1, *l = rl + 1;
+    for (int i = 0; i < 16; i++) t[i] = availB ? d[-st + ((i >= 8 && !availC) ? 7 : i)] : 128;
+    for (int i = 0; i < 8; i++) l[i] = availA ? d[i * st - 1] : 128;
+    t[-1] = l[-1] = availD ? d[-st - 1] : 128;
+    for (int i = 0; i < 16; i++) {
+        int lo = i == 0 ? (availD ? t[-1] : t[0]) : t[i - 1], hi = i == 15 ? t[15] : t[i + 1];
+        T[i] = (lo + 2 * t[i] + hi + 2) >> 2;
+    }
+    for (int i = 0; i < 8; i++) {
+        int lo = i == 0 ? (availD ? l[-1] : l[0]) : l[i - 1], hi = i == 7 ? l[7] : l[i + 1];
+        L[i] = (lo + 2 * l[i] + hi + 2) >> 2;
+    }
+    if (!availD) T[-1] = L[-1] = 128;
+    else if (availA && availB) T[-1] = L[-1] = (t[0] + 2 * t[-1] + l[0] + 2) >> 2;
+    else if (availB) T[-1] = L[-1] = (3 * t[-1] + t[0] + 2) >> 2;
+    else if (availA) T[-1] = L[-1] = (3 * t[-1] + l[0] + 2) >> 2;
+    else T[-1] = L[-1] = t[-1];
+    *aA = availA; *aB = availB; *aD = availD;
+}
+static int i8_mode_ok(int mode, int aA, int aB, int aD) {
+    if (mode == 2) return 1;
+    if (mode == 0 || mode == 3 || mode == 7) return aB;
+    if (mode == 1 || mode == 8) return aA;
+    return aA && aB && aD;
+}
+static void i8_predict(int mode, const int *T, const int *L, int aA, int aB, int *p) {
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
+        int v;
+        if (mode == 0) v = T[x];
+        else if (mode == 1) v = L[y];
+        else if (mode == 2) { int s1 = 0, s2 = 0; for (int i = 0; i < 8; i++) { s1 += T[i]; s2 += L[i]; } v = aA && aB ? (s1 + s2 + 8) >> 4 : aA ? (s2 + 4) >> 3 : aB ? (s1 + 4) >> 3 : 128; }
+        else if (mode == 3) v = (x == 7 && y == 7) ? (T[14] + 3 * T[15] + 2) >> 2 : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2;
+        else if (mode == 4) v = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ? (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 : (T[0] + 2 * T[-1] + L[0] + 2) >> 2;
+        else if (mode == 5) { int z = 2 * x - y, i = x - (y >> 1);
+            v = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (L[y - 2 * x - 1] + 2 * L[y - 2 * x - 2] + L[y - 2 * x - 3] + 2) >> 2; }
+        else if (mode == 6) { int z = 2 * y - x, i = y - (x >> 1);
+            v = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (T[x - 2 * y - 1] + 2 * T[x - 2 * y - 2] + T[x - 2 * y - 3] + 2) >> 2; }
+        else if (mode == 7) { int i = x + (y >> 1); v = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1; }
+        else { int z = x + 2 * y, i = y + (x >> 1); v = z > 13 ? L[7] : z == 13 ? (L[6] + 3 * L[7] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 : (L[i] + L[i + 1] + 1) >> 1; }
+        p[y * 8 + x] = v;
+    }
+}
+
+/* ------------------------------ syntax elements: CAVLC or CABAC --------------- */
+static int mb_inxn(const MbE *m) { return m->intra && !m->i16 && !m->pcm; }
+static MbE *nb4(Enc *e, int mx, int my, MbE *cur, int bx, int by, int left, int *r) {
+    if (left) { if (bx > 0) { *r = by * 4 + bx - 1; return cur; } *r = by * 4 + 3; return mb_avail(e, mx - 1, my); }
+    if (by > 0) { *r = (by - 1) * 4 + bx; return cur; }
+    *r = 12 + bx; return mb_avail(e, mx, my - 1);
+}
+static void se_skip_flag(Enc *e, int mx, int my, int skip) {
+    MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+    cab_enc(&e->cab, 11 + (a && !a->skip) + (b && !b->skip), skip);
+}
+/* called before every non-skipped macroblock */
+static void se_begin_mb(Enc *e, int mx, int my, int *skip_run) {
+    if (e->cabac) { if (e->slice_type == 0) se_skip_flag(e, mx, my, 0); }
+    else if (*skip_run >= 0) { bw_ue(&e->bw, *skip_run); *skip_run = 0; }
+}
+/* itype: 0 I_NxN, 1..24 I_16x16 (Table 7-11), 25 I_PCM */
+static void se_mb_type_intra(Enc *e, int mx, int my, int itype) {
+    int off = e->slice_type == 0 ? 5 : 0;
+    if (!e->cabac) { bw_ue(&e->bw, itype + off); return; }
+    CabEnc *c = &e->cab; int base, in_i = e->slice_type != 0;
+    if (in_i) {
+        MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+        cab_enc(c, 3 + (a && !mb_inxn(a)) + (b && !mb_inxn(b)), itype != 0);
+        base = 5;
+    } else { cab_enc(c, 14, 1); cab_enc(c, 17, itype != 0); base = 17; }
+    if (itype == 0) return;
+    cab_term(c, itype == 25);
+    if (itype == 25) return;
+    int k = itype - 1, cbp_l = k >= 12, cc = (k / 4) % 3, md = k & 3;
+    cab_enc(c, base + 1, cbp_l);
+    cab_enc(c, base + 2, cc != 0);
+    if (cc) cab_enc(c, base + 2 + in_i, cc == 2);
+    cab_enc(c, base + 3 + in_i, md >> 1);
+    cab_enc(c, base + 3 + 2 * in_i, md & 1);
+}
+static void se_mb_type_p(Enc *e, int type, int p8ref0) {
+    if (!e->cabac) { bw_ue(&e->bw, type == 3 && p8ref0 ? 4 : type); return; }
+    CabEnc *c = &e->cab;
+    cab_enc(c, 14, 0);
+    if (type == 0 || type == 3) { cab_enc(c, 15, 0); cab_enc(c, 16, type == 3); }
+    else { cab_enc(c, 15, 1); cab_enc(c, 17, type == 1); }
+}
+static void se_sub_mb_type(Enc *e, int st) {
+    if (!e->cabac) { bw_ue(&e->bw, st); return; }
+    CabEnc *c = &e->cab;
+    if (st == 0) { cab_enc(c, 21, 1); return; }
+    cab_enc(c, 21, 0);
+    if (st == 1) { cab_enc(c, 22, 0); return; }
+    cab_enc(c, 22, 1); cab_enc(c, 23, st == 2);
+}
+static void se_ref_idx(Enc *e, int mx, int my, MbE *m, int bx, int by, int nref, int v) {
+    if (!e->cabac) { bw_te(&e->bw, nref - 1, v); return; }
+    int inc = 0;
+    for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r); if (n && !n->intra && n->ref[(r >> 3) * 2 + ((r & 3) >> 1)] > 0) inc += k == 0 ? 1 : 2; }
+    int ctx = 54 + inc;
+    for (int i = 0; i < v; i++) { cab_enc(&e->cab, ctx, 1); ctx = 54 + (i == 0 ? 4 : 5); }
+    cab_enc(&e->cab, ctx, 0);
+}
+static void se_mvd(Enc *e, int mx, int my, MbE *m, int bx, int by, int bw, int bh, int dx, int dy) {
+    if (!e->cabac) { bw_se(&e->bw, dx); bw_se(&e->bw, dy); return; }
+    CabEnc *c = &e->cab;
+    for (int comp = 0; comp < 2; comp++) {
+        int d = comp ? dy : dx, a = ABS(d), sum = 0, base = comp ? 47 : 40;
+        for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r); if (n && !n->intra) sum += n->mvd[r][comp]; }
+        cab_enc(c, base + (sum < 3 ? 0 : sum > 32 ? 2 : 1), a > 0);
+        if (!a) continue;
+        int v = 1, ctx = 3;
+        while (v < 9) { int bin = a > v; cab_enc(c, base + ctx, bin); if (!bin) break; v++; if (ctx < 6) ctx++; }
+        if (a >= 9) cab_ueg(c, a - 9, 3);
+        cab_byp(c, d < 0);
+    }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mvd[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255); m->mvd[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
+}
+static void se_t8_flag(Enc *e, int mx, int my, int v) {
+    if (!e->cabac) { bw_put(&e->bw, 1, (uint32_t)v); return; }
+    MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+    cab_enc(&e->cab, 399 + (a && a->t8) + (b && b->t8), v);
+}
+static void se_intra_mode(Enc *e, int pred, int mode) {
+    if (!e->cabac) { if (mode == pred) bw_put(&e->bw, 1, 1); else { bw_put(&e->bw, 1, 0); bw_put(&e->bw, 3, (uint32_t)(mode < pred ? mode : mode - 1)); } return; }
+    CabEnc *c = &e->cab;
+    cab_enc(c, 68, mode == pred);
+    if (mode != pred) { int rem = mode < pred ? mode : mode - 1; cab_enc(c, 69, rem & 1); cab_enc(c, 69, (rem >> 1) & 1); cab_enc(c, 69, rem >> 2); }
+}
+static void se_chroma_mode(Enc *e, int mx, int my, int cm) {
+    if (!e->cabac) { bw_ue(&e->bw, cm); return; }
+    MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1); CabEnc *c = &e->cab;
+    cab_enc(c, 64 + (a && a->cmode != 0) + (b && b->cmode != 0), cm > 0);
+    if (cm > 0) { cab_enc(c, 67, cm > 1); if (cm > 1) cab_enc(c, 67, cm > 2); }
+}
+static void se_cbp(Enc *e, int mx, int my, int cbp, int intra) {
+    if (!e->cabac) { const uint8_t *tab = intra ? cbp_intra_tab : cbp_inter_tab; int code = 0; for (int i = 0; i < 48; i++) if (tab[i] == cbp) code = i; bw_ue(&e->bw, code); return; }
+    MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1); CabEnc *c = &e->cab;
+    for (int b8 = 0; b8 < 4; b8++) {
+        int ca = (b8 & 1) ? !((cbp >> (b8 - 1)) & 1) : (a ? !((a->cbp >> (b8 + 1)) & 1) : 0);
+        int cb = (b8 & 2) ? !((cbp >> (b8 - 2)) & 1) : (b ? !((b->cbp >> (b8 + 2)) & 1) : 0);
+        cab_enc(c, 73 + ca + 2 * cb, (cbp >> b8) & 1);
+    }
+    int cc = cbp >> 4, ca = a && (a->cbp >> 4) != 0, cb = b && (b->cbp >> 4) != 0;
+    cab_enc(c, 77 + ca + 2 * cb, cc != 0);
+    if (cc) { ca = a && (a->cbp >> 4) == 2; cb = b && (b->cbp >> 4) == 2; cab_enc(c, 81 + ca + 2 * cb, cc == 2); }
+}
+static void se_dqp(Enc *e, int dqp) {
+    if (!e->cabac) { bw_se(&e->bw, dqp); return; }
+    int k = dqp > 0 ? 2 * dqp - 1 : -2 * dqp, ctx = 60 + (e->last_dqp ? 1 : 0);
+    for (int i = 0; i < k; i++) { cab_enc(&e->cab, ctx, 1); ctx = 60 + (i == 0 ? 2 : 3); }
+    cab_enc(&e->cab, ctx, 0);
+    e->last_dqp = dqp != 0;
+}
+/* residual_block_cabac: coef in scan order (maxnum entries); bit = coded_block_flag bit (-1 for 8x8 blocks); fa/fb neighbours' flags (-1 n/a) */
+static int cab_block(Enc *e, MbE *m, int cat, int bit, int fa, int fb, const int *coef, int maxnum) {
+    static const int cbf_off[5] = {0, 4, 8, 12, 16}, sig_off[5] = {0, 15, 29, 44, 47}, abs_off[5] = {0, 10, 20, 30, 39};
+    CabEnc *c = &e->cab; int n = 0, last = -1;
+    for (int i = 0; i < maxnum; i++) if (coef[i]) { n++; last = i; }
+    if (cat != 5) {
+        if (fa < 0) fa = m->intra; if (fb < 0) fb = m->intra;
+        cab_enc(c, 85 + cbf_off[cat] + fa + 2 * fb, n != 0);
+        if (!n) return 0;
+        m->cbf |= 1u << bit;
+    }
+    int sb = cat == 5 ? 402 : 105 + sig_off[cat], lb = cat == 5 ? 417 : 166 + sig_off[cat], ab = cat == 5 ? 426 : 227 + abs_off[cat];
+    for (int i = 0; i < maxnum - 1; i++) {
+        int si = cat == 5 ? orc_cabac_sig8_inc[i] : cat == 3 ? MIN(i, 2) : i, li = cat == 5 ? orc_cabac_last8_inc[i] : cat == 3 ? MIN(i, 2) : i;
+        cab_enc(c, sb + si, coef[i] != 0);
+        if (coef[i]) { cab_enc(c, lb + li, i == last); if (i == last) break; }
+    }
+    int gt1 = 0, eq1 = 0;
+    for (int i = last; i >= 0; i--) {
+        if (!coef[i]) continue;
+        int v = ABS(coef[i]) - 1;
+        cab_enc(c, ab + (gt1 ? 0 : MIN(4, 1 + eq1)), v > 0);
+        if (v > 0) {
+            int ctx = ab + 5 + MIN(4 - (cat == 3), gt1);
+            for (int k = 1; k < MIN(v, 14); k++) cab_enc(c, ctx, 1);
+            if (v < 14) cab_enc(c, ctx, 0); else cab_ueg(c, v - 14, 0);
+        }
+        if (v == 0) eq1++; else gt1++;
+        cab_byp(c, coef[i] < 0);
+    }
+    return n;
+}
+
 static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) {
-    BitW *w = &e->bw; int sc[16];
+    BitW *w = &e->bw; int sc[64];
+    MbE *mA = mb_avail(e, mx - 1, my), *mB = mb_avail(e, mx, my - 1);
     if (mc->type == 6) {
         for (int i = 0; i < 16; i++) sc[i] = mc->dc16[zz4[i]];
-        write_block(w, sc, 16, nC_luma(e, mx, my, m, 0, 0));
+        if (e->cabac) cab_block(e, m, 0, 16, mA ? (int)((mA->cbf >> 16) & 1) : -1, mB ? (int)((mB->cbf >> 16) & 1) : -1, sc, 16);
+        else write_block(w, sc, 16, nC_luma(e, mx, my, m, 0, 0));
     }
-    for (int b8 = 0; b8 < 4; b8++) for (int k = 0; k < 4; k++) {
-        int blk = b8 * 4 + k, bx = bX(blk), by = bY(blk), r = by * 4 + bx;
-        if (!(mc->cbp & (1 << b8))) { m->tc[r] = 0; continue; }
-        int nC = nC_luma(e, mx, my, m, bx, by);
-        if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]]; m->tc[r] = (uint8_t)write_block(w, sc, 15, nC); }
-        else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; m->tc[r] = (uint8_t)write_block(w, sc, 16, nC); }
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (mc->t8) {
+            int ox = (b8 & 1) * 2, oy = (b8 >> 1) * 2, total = 0;
+            if (!(mc->cbp & (1 << b8))) { for (int k = 0; k < 4; k++) m->tc[(oy + (k >> 1)) * 4 + ox + (k & 1)] = 0; continue; }
+            if (e->cabac) {
+                for (int i = 0; i < 64; i++) sc[i] = mc->luma8[b8][zz8[i]];
+                total = cab_block(e, m, 5, -1, 0, 0, sc, 64);
+                for (int k = 0; k < 4; k++) { int r = (oy + (k >> 1)) * 4 + ox + (k & 1); m->tc[r] = (uint8_t)MIN(total, 16); m->cbf |= 1u << r; }
+            } else for (int k = 0; k < 4; k++) {
+                int bx = ox + (k & 1), by = oy + (k >> 1);
+                for (int i = 0; i < 16; i++) sc[i] = mc->luma8[b8][zz8[4 * i + k]];
+                int n = write_block(w, sc, 16, nC_luma(e, mx, my, m, bx, by));
+                m->tc[by * 4 + bx] = (uint8_t)n; total += n;
+            }
+            if (total) for (int k = 0; k < 4; k++) m->nzmask |= (uint16_t)(1u << ((oy + (k >> 1)) * 4 + ox + (k & 1)));
+            continue;
+        }
+        for (int k = 0; k < 4; k++) {
+            int blk = b8 * 4 + k, bx = bX(blk), by = bY(blk), r = by * 4 + bx, n, fa = -1, fb = -1;
+            if (!(mc->cbp & (1 << b8))) { m->tc[r] = 0; continue; }
+            if (e->cabac) { int q; MbE *nn = nb4(e, mx, my, m, bx, by, 1, &q); if (nn) fa = (int)((nn->cbf >> q) & 1); nn = nb4(e, mx, my, m, bx, by, 0, &q); if (nn) fb = (int)((nn->cbf >> q) & 1); }
+            if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]]; n = e->cabac ? cab_block(e, m, 1, r, fa, fb, sc, 15) : write_block(w, sc, 15, nC_luma(e, mx, my, m, bx, by)); }
+            else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; n = e->cabac ? cab_block(e, m, 2, r, fa, fb, sc, 16) : write_block(w, sc, 16, nC_luma(e, mx, my, m, bx, by)); }
+            m->tc[r] = (uint8_t)n;
+            if (n) m->nzmask |= (uint16_t)(1u << r);
+        }
     }
-    if (mc->cbp & 0x30) for (int pl = 0; pl < 2; pl++) write_block(w, mc->cdc[pl], 4, -1);
+    if (mc->cbp & 0x30) for (int pl = 0; pl < 2; pl++) {
+        if (e->cabac) cab_block(e, m, 3, 17 + pl, mA ? (int)((mA->cbf >> (17 + pl)) & 1) : -1, mB ? (int)((mB->cbf >> (17 + pl)) & 1) : -1, mc->cdc[pl], 4);
+        else write_block(w, mc->cdc[pl], 4, -1);
+    }
     for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
         if (!(mc->cbp & 0x20)) { m->tc[16 + 4 * pl + k] = 0; continue; }
         for (int i = 0; i < 15; i++) sc[i] = mc->cac[pl][k][zz4[i + 1]];
-        m->tc[16 + 4 * pl + k] = (uint8_t)write_block(w, sc, 15, nC_chroma(e, mx, my, m, pl, k & 1, k >> 1));
+        if (e->cabac) {
+            int bx = k & 1, by = k >> 1, b0 = 19 + pl * 4, fa, fb;
+            if (bx) fa = (int)((m->cbf >> (b0 + by * 2)) & 1); else fa = mA ? (int)((mA->cbf >> (b0 + by * 2 + 1)) & 1) : -1;
+            if (by) fb = (int)((m->cbf >> (b0 + bx)) & 1); else fb = mB ? (int)((mB->cbf >> (b0 + 2 + bx)) & 1) : -1;
+            m->tc[16 + 4 * pl + k] = (uint8_t)cab_block(e, m, 4, b0 + k, fa, fb, sc, 15);
+        } else m->tc[16 + 4 * pl + k] = (uint8_t)write_block(w, sc, 15, nC_chroma(e, mx, my, m, pl, k & 1, k >> 1));
     }
 }
 
@@ -685,17 +1038,18 @@ static void mb_init(Enc *e, MbE *m) {
 /* encode one intra MB (decision + recon + syntax). in P slices mb_type is offset by 5 */
 static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,5 I4,6 I16,7 PCM*/) {
     Frame *c = &e->cur, *s = &e->src; BitW *w = &e->bw; int fuzz = e->p.mode == 1;
-    int off = e->slice_type == 0 ? 5 : 0;
     uint8_t *dy = c->y + my * 16 * c->sy + mx * 16;
     m->intra = 1;
     if (force == 7) {
         m->pcm = 1; m->qp = 0; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, 0);
-        bw_ue(w, 25 + off);
+        se_mb_type_intra(e, mx, my, 25);                      /* CABAC: the terminate bin flushes the arithmetic code (9.3.4.5) */
         while (w->nbits) bw_put(w, 1, 0);
         for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) { int v = s->y[(my * 16 + y) * s->sy + mx * 16 + x]; dy[y * c->sy + x] = (uint8_t)v; bw_put(w, 8, v); }
         for (int pl = 0; pl < 2; pl++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
             int v = (pl ? s->v : s->u)[(my * 8 + y) * s->sc + mx * 8 + x]; (pl ? c->v : c->u)[(my * 8 + y) * c->sc + mx * 8 + x] = (uint8_t)v; bw_put(w, 8, v); }
         memset(m->tc, 16, 24);
+        m->cbp = 0x2f; m->cbf = 0x7FFFFFF; e->last_dqp = 0;
+        if (e->cabac) cab_start(&e->cab, w);
         return;
     }
     int aA = intra_ok(e, mb_avail(e, mx - 1, my)), aB = intra_ok(e, mb_avail(e, mx, my - 1)), aD = intra_ok(e, mb_avail(e, mx - 1, my - 1));
@@ -719,7 +1073,30 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
     int cbp_l = 0;
     if (use_i4) {
         mc.type = 5;
-        bw_ue(w, 0 + off);
+        se_mb_type_intra(e, mx, my, 0);
+        int use_i8 = e->p.t8x8 && rnd_n(&e->rng, 2);
+        if (e->p.t8x8) se_t8_flag(e, mx, my, use_i8);
+        mc.t8 = use_i8; m->t8 = (uint8_t)use_i8;
+        if (use_i8) {
+            for (int b8 = 0; b8 < 4; b8++) {
+                int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2, Tb[17], Lb[9], *T = Tb + 1, *L = Lb + 1, a, b, d, p[64];
+                i8_edges(e, mx, my, b8, T, L, &a, &b, &d);
+                int best = 2, bests = 1 << 30;
+                if (fuzz) { do best = rnd_n(&e->rng, 9); while (!i8_mode_ok(best, a, b, d)); }
+                else for (int md = 0; md < 9; md++) if (i8_mode_ok(md, a, b, d)) {
+                    i8_predict(md, T, L, a, b, p); int sd = 0;
+                    for (int k = 0; k < 64; k++) sd += ABS(s->y[(my * 16 + by * 4 + (k >> 3)) * s->sy + mx * 16 + bx * 4 + (k & 7)] - p[k]);
+                    if (sd < bests) { bests = sd; best = md; } }
+                i8_predict(best, T, L, a, b, p);
+                uint8_t *dd = dy + by * 4 * c->sy + bx * 4;
+                for (int k = 0; k < 64; k++) dd[(k >> 3) * c->sy + (k & 7)] = (uint8_t)p[k];
+                int pm = i4_pred_mode(e, mx, my, m, bx, by);           /* neighbours' modes only: known before this block's own mode is stored */
+                mc.i4modes[b8] = best; mc.i4modes[4 + b8] = pm;
+                m->i4[by * 4 + bx] = m->i4[by * 4 + bx + 1] = m->i4[by * 4 + bx + 4] = m->i4[by * 4 + bx + 5] = (uint8_t)best;
+                if (code_luma8(e, mx * 16 + bx * 4, my * 16 + by * 4, qp, 1, mc.luma8[b8])) cbp_l |= 1 << b8;
+            }
+            for (int b8 = 0; b8 < 4; b8++) se_intra_mode(e, mc.i4modes[4 + b8], mc.i4modes[b8]);
+        } else {
         /* choose, reconstruct and remember modes; syntax needs all modes before residual so buffer decisions */
         for (int blk = 0; blk < 16; blk++) {
             int bx = bX(blk), by = bY(blk), r = by * 4 + bx, Tb[9], Lb[5], *T = Tb + 1, *L = Lb + 1, a, b, p[16];
@@ -740,7 +1117,8 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
         for (int blk = 0; blk < 16; blk++) {
             int bx = bX(blk), by = bY(blk), r = by * 4 + bx, pm = i4_pred_mode(e, mx, my, m, bx, by), md = mc.i4modes[r];
             /* i4_pred_mode reads m->i4 of already-coded blocks only (left/top), all set above */
-            if (md == pm) bw_put(w, 1, 1); else { bw_put(w, 1, 0); bw_put(w, 3, md < pm ? md : md - 1); }
+            se_intra_mode(e, pm, md);
+        }
         }
     } else {
         mc.type = 6; m->i16 = 1; mc.i16mode = best16;
@@ -788,10 +1166,11 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
     for (int pl = 0; pl < 2; pl++) recon_chroma(e, mx, my, pl, qpc, &mc, cbp_c >= 1, cbp_c == 2);
     mc.cbp = cbp_l | (cbp_c << 4); mc.cmode = cmode;
     /* ---- syntax ---- */
-    if (mc.type == 6) bw_ue(w, off + 1 + mc.i16mode + 4 * cbp_c + (cbp_l ? 12 : 0));
-    bw_ue(w, cmode);
-    if (mc.type == 5) { int code = 0; for (int i = 0; i < 48; i++) if (cbp_intra_tab[i] == mc.cbp) code = i; bw_ue(w, code); }
-    if (mc.cbp > 0 || mc.type == 6) { bw_se(w, dqp); e->qp_run = qp; } else qp = e->qp_run;
+    if (mc.type == 6) se_mb_type_intra(e, mx, my, 1 + mc.i16mode + 4 * cbp_c + (cbp_l ? 12 : 0));
+    se_chroma_mode(e, mx, my, cmode); m->cmode = (uint8_t)cmode;
+    if (mc.type == 5) se_cbp(e, mx, my, mc.cbp, 1);
+    m->cbp = (uint8_t)mc.cbp;
+    if (mc.cbp > 0 || mc.type == 6) { se_dqp(e, dqp); e->qp_run = qp; } else { qp = e->qp_run; e->last_dqp = 0; }
     m->qp = (uint8_t)qp; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, qp);
     if (mc.cbp > 0 || mc.type == 6) write_mb_residual(e, mx, my, m, &mc);
     /* note: when cbp==0 for I4x4 we quantised with a QP that is never signalled, but all levels are zero so recon is unaffected */
@@ -898,12 +1277,12 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
         }
     }
     if (want_intra) {
-        if (*skip_run >= 0) { bw_ue(w, *skip_run); *skip_run = 0; }
+        se_begin_mb(e, mx, my, skip_run);
         encode_intra_mb(e, mx, my, m, force_intra);
         return;
     }
     /* ---- finalise motion: walk partitions in syntax order, computing mvd against the running prediction ---- */
-    int mvd[16][2], nmvd = 0;
+    int mvd[16][2], mvdpos[16][4], nmvd = 0;
     e->decoded_mask = 0;
     for (int i = 0; i < 4; i++) m->ref[i] = (int8_t)refs[i];
     if (type <= 2) {
@@ -914,6 +1293,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
             pred_mv(e, mx, my, m, bx, by, bw, ref, type, p, mvp);
             if (try_skip && mv_legal(e, px, py, 16, 16, skipmv[0], skipmv[1])) { mv[0] = skipmv[0]; mv[1] = skipmv[1]; }
             else if (fuzz) random_mv(e, px + bx * 4, py + by * 4, bw * 4, bh * 4, mvp, mv); else { mv[0] = mvs[by * 4 + bx][0]; mv[1] = mvs[by * 4 + bx][1]; }
+            mvdpos[nmvd][0] = bx; mvdpos[nmvd][1] = by; mvdpos[nmvd][2] = bw; mvdpos[nmvd][3] = bh;
             mvd[nmvd][0] = mv[0] - mvp[0]; mvd[nmvd][1] = mv[1] - mvp[1]; nmvd++;
             store_mv(e, m, bx, by, bw, bh, mv[0], mv[1]);
         }
@@ -924,6 +1304,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
                 int bx = ox + (st == 1 ? 0 : st == 2 ? p : (p & 1)), by = oy + (st == 1 ? p : st == 2 ? 0 : (p >> 1)), mvp[2], mv[2];
                 pred_mv(e, mx, my, m, bx, by, bw, refs[i], 0, 0, mvp);
                 if (fuzz) random_mv(e, px + bx * 4, py + by * 4, bw * 4, bh * 4, mvp, mv); else { mv[0] = mvs[by * 4 + bx][0]; mv[1] = mvs[by * 4 + bx][1]; }
+                mvdpos[nmvd][0] = bx; mvdpos[nmvd][1] = by; mvdpos[nmvd][2] = bw; mvdpos[nmvd][3] = bh;
                 mvd[nmvd][0] = mv[0] - mvp[0]; mvd[nmvd][1] = mv[1] - mvp[1]; nmvd++;
                 store_mv(e, m, bx, by, bw, bh, mv[0], mv[1]);
             }
@@ -936,7 +1317,12 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
     int qp = CLIP3(10, 48, e->qp_run + dqp); dqp = qp - e->qp_run;
     int cbp_l = 0;
-    if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    int t8_ok = e->p.t8x8 && (type != 3 || (sub[0] | sub[1] | sub[2] | sub[3]) == 0);     /* noSubMbPartSizeLessThan8x8Flag */
+    int use_t8 = t8_ok && (fuzz ? rnd_n(&e->rng, 2) : 1);
+    if (!try_skip && use_t8) { for (int b8 = 0; b8 < 4; b8++) if (code_luma8(e, px + (b8 & 1) * 8, py + (b8 >> 1) * 8, qp, 0, mc.luma8[b8])) cbp_l |= 1 << b8; }
+    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    if (!cbp_l) use_t8 = 0;
+    mc.t8 = use_t8;
     int qpc = chroma_qp_of(e, qp), cflags = 0;
     if (!try_skip) for (int pl = 0; pl < 2; pl++) cflags |= code_chroma(e, mx, my, pl, qpc, 0, &mc);
     int cbp_c = (cflags & 2) ? 2 : (cflags & 1) ? 1 : 0;
@@ -945,22 +1331,26 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     /* ---- P_Skip ---- */
     if (type == 0 && refs[0] == 0 && mc.cbp == 0 && m->mv[0][0] == skipmv[0] && m->mv[0][1] == skipmv[1] && !(fuzz && rnd_n(&e->rng, 4) == 0)) {
         m->skip = 1; m->qp = (uint8_t)e->qp_run; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, e->qp_run);
-        (*skip_run)++;
+        if (e->cabac) { se_skip_flag(e, mx, my, 1); e->last_dqp = 0; } else (*skip_run)++;
         return;
     }
-    bw_ue(w, *skip_run); *skip_run = 0;
-    int p8ref0 = type == 3 && nref > 1 && refs[0] == 0 && refs[1] == 0 && refs[2] == 0 && refs[3] == 0 && (fuzz ? rnd_n(&e->rng, 2) : 1);
-    bw_ue(w, type == 3 && p8ref0 ? 4 : type);
+    se_begin_mb(e, mx, my, skip_run);
+    int p8ref0 = !e->cabac && type == 3 && nref > 1 && refs[0] == 0 && refs[1] == 0 && refs[2] == 0 && refs[3] == 0 && (fuzz ? rnd_n(&e->rng, 2) : 1);
+    se_mb_type_p(e, type, p8ref0);
+    /* the CABAC contexts of ref_idx look at m->ref of earlier partitions only; the final values are already stored, which is
+       equivalent because partitions later in syntax order are never the left / upper neighbour of an earlier one */
     if (type <= 2) {
         int np = type == 0 ? 1 : 2;
-        if (nref > 1) for (int p = 0; p < np; p++) bw_te(w, nref - 1, refs[type == 1 ? p * 2 : p]);
+        if (nref > 1) for (int p = 0; p < np; p++) se_ref_idx(e, mx, my, m, type == 2 ? p * 2 : 0, type == 1 ? p * 2 : 0, nref, refs[type == 1 ? p * 2 : p]);
     } else {
-        for (int i = 0; i < 4; i++) bw_ue(w, sub[i]);
-        if (nref > 1 && !p8ref0) for (int i = 0; i < 4; i++) bw_te(w, nref - 1, refs[i]);
+        for (int i = 0; i < 4; i++) se_sub_mb_type(e, sub[i]);
+        if (nref > 1 && !p8ref0) for (int i = 0; i < 4; i++) se_ref_idx(e, mx, my, m, (i & 1) * 2, (i >> 1) * 2, nref, refs[i]);
     }
-    for (int i = 0; i < nmvd; i++) { bw_se(w, mvd[i][0]); bw_se(w, mvd[i][1]); }
-    { int code = 0; for (int i = 0; i < 48; i++) if (cbp_inter_tab[i] == mc.cbp) code = i; bw_ue(w, code); }
-    if (mc.cbp > 0) { bw_se(w, dqp); e->qp_run = qp; } else qp = e->qp_run;
+    for (int i = 0; i < nmvd; i++) se_mvd(e, mx, my, m, mvdpos[i][0], mvdpos[i][1], mvdpos[i][2], mvdpos[i][3], mvd[i][0], mvd[i][1]);
+    se_cbp(e, mx, my, mc.cbp, 0); m->cbp = (uint8_t)mc.cbp;
+    if (cbp_l && t8_ok) se_t8_flag(e, mx, my, use_t8);
+    m->t8 = (uint8_t)use_t8;
+    if (mc.cbp > 0) { se_dqp(e, dqp); e->qp_run = qp; } else { qp = e->qp_run; e->last_dqp = 0; }
     m->qp = (uint8_t)qp; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, qp);
     if (mc.cbp > 0) write_mb_residual(e, mx, my, m, &mc);
 }
@@ -969,8 +1359,12 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
 static void write_sps_pps(Enc *e) {
     BitW *w = &e->bw; GenParams *p = &e->p;
     w->len = 0; w->nbits = 0; w->cur = 0;
-    bw_put(w, 8, 66); bw_put(w, 8, 0xC0); bw_put(w, 8, p->level_idc);     /* Baseline, constraint_set0/1 */
+    if (p->t8x8) { bw_put(w, 8, 100); bw_put(w, 8, 0); }                  /* High */
+    else if (p->cabac) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
+    else { bw_put(w, 8, 66); bw_put(w, 8, 0xC0); }                        /* Baseline, constraint_set0/1 */
+    bw_put(w, 8, p->level_idc);
     bw_ue(w, 0);
+    if (p->t8x8) { bw_ue(w, 1); bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, 0); }   /* 4:2:0, 8 bit, no bypass, no scaling matrix */
     bw_ue(w, e->log2_max_fn - 4);
     bw_ue(w, p->poc_type);
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
@@ -982,11 +1376,12 @@ static void write_sps_pps(Enc *e) {
     bw_put(w, 1, 0);                                                      /* no VUI */
     bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
     w->len = 0;
-    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, 0); bw_ue(w, 0);
+    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, 0); bw_ue(w, 0);
     bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
     bw_put(w, 1, 0); bw_put(w, 2, 0);
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
     bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
+    if (p->t8x8) { bw_put(w, 1, 1); bw_put(w, 1, 0); bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, no scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
 }
 
@@ -1016,21 +1411,28 @@ static void encode_frame(Enc *e, int t) {
         if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (2 * (t % p->gop)) & ((1 << e->poc_lsb_bits) - 1));
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); bw_put(w, 1, 0); }
         if (is_ref) { if (idr) { bw_put(w, 1, 0); bw_put(w, 1, 0); } else bw_put(w, 1, 0); }
+        if (e->cabac && e->slice_type != 2) bw_ue(w, p->cabac_idc);
         bw_se(w, 0);                                                      /* slice_qp_delta */
         int idc = p->deblock == 1 ? 0 : (p->deblock == 0 ? 1 : 2);
         bw_ue(w, idc); if (idc != 1) { bw_se(w, p->alpha_off); bw_se(w, p->beta_off); }
         int skip_run = e->slice_type == 0 ? 0 : -1;
+        if (e->cabac) {
+            while (w->nbits) bw_put(w, 1, 1);                             /* cabac_alignment_one_bit */
+            cab_init_ctx(&e->cab, e->slice_type == 2 ? 0 : 1 + p->cabac_idc, p->qp);
+            cab_start(&e->cab, w); e->last_dqp = 0;
+        }
         for (int my = first_row; my < last_row; my++) for (int mx = 0; mx < e->mbw; mx++) {
             MbE *m = &e->mbs[my * e->mbw + mx];
             mb_init(e, m);
             int before = bw_bitpos(w);
-            if (p->pcm_only) { if (skip_run >= 0) { bw_ue(w, skip_run); skip_run = 0; } encode_intra_mb(e, mx, my, m, 7); }
+            if (p->pcm_only) { se_begin_mb(e, mx, my, &skip_run); encode_intra_mb(e, mx, my, m, 7); }
             else if (e->slice_type == 2) { int force = -1; if (p->mode == 1 && rnd_n(&e->rng, 40) == 0) force = 7; encode_intra_mb(e, mx, my, m, force); }
             else encode_p_mb(e, mx, my, m, &skip_run);
+            if (e->cabac) cab_term(&e->cab, my == last_row - 1 && mx == e->mbw - 1);      /* end_of_slice_flag */
             e->stat_bits_mb[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)] += bw_bitpos(w) - before;
         }
-        if (skip_run > 0) bw_ue(w, skip_run);
-        bw_trailing(w);
+        if (e->cabac) { while (w->nbits) bw_put(w, 1, 0); }              /* the flush ended with the rbsp_stop_one_bit */
+        else { if (skip_run > 0) bw_ue(w, skip_run); bw_trailing(w); }
         out_nal(&e->out, is_ref ? (idr ? 3 : 2) : 0, idr ? 5 : 1, w, sl == 0);
     }
     if (p->deblock != 0) deblock_frame(e);
@@ -1073,6 +1475,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (p->search < 1) p->search = 4;
     if (!p->level_idc) p->level_idc = 40;
     if (p->poc_type != 0) p->poc_type = 2;
+    p->cabac = p->cabac != 0; p->t8x8 = p->t8x8 != 0; p->cabac_idc = CLIP3(0, 2, p->cabac_idc);
+    e->cabac = p->cabac;
     if (p->nonref_period == 1) p->nonref_period = 2;
     e->mbw = (p->width + 15) / 16; e->mbh = (p->height + 15) / 16; e->W = e->mbw * 16; e->H = e->mbh * 16;
     if (p->slices > e->mbh) p->slices = e->mbh;
@@ -1104,6 +1508,7 @@ int main(int argc, char **argv) {
         OPT("--mode", mode) OPT("--deblock", deblock) OPT("--refs", num_ref) OPT("--slices", slices) OPT("--pcm", pcm_only)
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
+        OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
