@@ -45,7 +45,8 @@ static const uint8_t kRunBits[6][7] = { {1,0,0,0,0,0,0},{1,1,0,0,0,0,0},{3,2,1,0
 static const uint8_t kCbpIntra[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
 static const uint8_t kCbpInter[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
 static const uint8_t kZigzag4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
-static const uint8_t kZigzag8[64] = {   // 8x8 zig-zag scan, frame macroblocks (Table 8-? / Figure 6-... 8x8): scan position -> raster
+// zig-zag scan of a luma block coded with the large transform, frame macroblocks (8.5.7): scan position -> raster index
+static const uint8_t kZigzag8[64] = {
     0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
    35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
 

@@ -108,3 +108,50 @@ def test_three_copies_of_the_tables_agree():
     assert c_array(kern, "kAlpha") == c_array(ORC, "orc_alpha") == c_array(GEN, "alpha_tab")
     assert c_array(kern, "kBeta") == c_array(ORC, "orc_beta") == c_array(GEN, "beta_tab")
     assert c_array(kern, "kTc0") == c_array(ORC, "orc_tc0") == c_array(GEN, "tc0_tab")
+
+
+def test_8x8_scan_and_scaling_tables_agree():
+    """zig-zag 8x8 scan: a permutation, each step moves to a neighbouring anti-diagonal position; three typed copies agree."""
+    z = c_array(ORC, "orc_zigzag8")
+    assert sorted(z) == list(range(64))
+    assert z == c_array(PROD, "kZigzag8") == c_array(GEN, "zz8")
+    for a, b in zip(z, z[1:]):
+        da, db = (a >> 3) + (a & 7), (b >> 3) + (b & 7)
+        assert db - da in (0, 1)                      # stays on the anti-diagonal or steps to the next one
+    n8 = c_array(ORC, "orc_norm8")
+    assert n8 == c_array(GEN, "norm8") and len(n8) == 36
+    # normAdjust8x8 grows by 2^(1/6) per qP step: row m+... doubles every 6 (checked across the two ends)
+    for c in range(6):
+        assert 1.7 < n8[30 + c] / n8[c] < 1.9
+
+
+def test_cabac_tables_structure():
+    """CABAC data tables (generated once from tools/make_cabac_tables.py into the oracle and product headers)."""
+    orc = os.path.join(ROOT, "oracle", "orc_cabac_tables.h")
+    prod = os.path.join(ROOT, "jmcodec_amd", "csrc", "cabac_tables.h")
+    for name_o, name_p in (("orc_cabac_init_mn", "cabac_init_mn"), ("orc_cabac_range_lps", "cabac_range_lps"),
+                           ("orc_cabac_trans_lps", "cabac_trans_lps"), ("orc_cabac_sig8_inc", "cabac_sig8_inc"),
+                           ("orc_cabac_last8_inc", "cabac_last8_inc")):
+        assert c_array(orc, name_o) == c_array(prod, name_p)
+    lps = c_array(orc, "orc_cabac_range_lps")
+    assert len(lps) == 256
+    for s in range(63):                                # LPS range shrinks with the state index and grows with the range quarter
+        row, nxt = lps[4 * s:4 * s + 4], lps[4 * s + 4:4 * s + 8]
+        assert row == sorted(row) and all(a >= b for a, b in zip(row, nxt))
+    # rangeTabLPS follows alpha^s with alpha = (0.01875 / 0.5)^(1/63) within rounding
+    alpha = (0.01875 / 0.5) ** (1 / 63)
+    for s in range(63):
+        for q in range(4):
+            ideal = (256 + 64 * q + 32) * 0.5 * alpha ** s          # probability of state s times the middle of range quarter q
+            if q == 0:
+                ideal = min(ideal, 128.0)
+            assert abs(lps[4 * s + q] - ideal) <= max(2.0, 0.03 * ideal), (s, q, lps[4 * s + q], ideal)
+    tl = c_array(orc, "orc_cabac_trans_lps")
+    assert len(tl) == 64 and tl[0] == 0 and tl[63] == 63 and all(tl[i] <= tl[i + 1] for i in range(62)) and all(tl[i] < i for i in range(1, 63))
+    sig8, last8 = c_array(orc, "orc_cabac_sig8_inc"), c_array(orc, "orc_cabac_last8_inc")
+    assert len(sig8) == len(last8) == 63 and max(sig8) == 14 and max(last8) == 8 and last8 == sorted(last8)
+    mn = c_array(orc, "orc_cabac_init_mn")
+    assert len(mn) == 4 * 436 * 2
+    for t in range(4):                                 # contexts shared by all slice types start identically
+        for ctx in list(range(0, 11)) + list(range(60, 70)):
+            assert mn[(t * 436 + ctx) * 2:(t * 436 + ctx) * 2 + 2] == mn[ctx * 2:ctx * 2 + 2]
