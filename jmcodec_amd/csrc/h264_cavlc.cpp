@@ -110,8 +110,9 @@ namespace {
 struct Canon {                     // canonical per-MB serialisation for SyntaxDigest
     uint32_t addr; uint8_t kind /* | 16 when transform_size_8x8_flag: luma[] then holds 4 x 64 levels */, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4]; int16_t mv[16][2];
     int16_t i16dc[16], luma[16][16], cdc[2][4], cac[2][4][16];
+    int8_t ref1[4]; int16_t mv1[16][2];          // list 1 (B slices)
 };
-static_assert(sizeof(Canon) == 4 + 4 + 16 + 4 + 64 + 32 + 512 + 16 + 256, "Canon must be packed");
+static_assert(sizeof(Canon) == 4 + 4 + 16 + 4 + 64 + 32 + 512 + 16 + 256 + 4 + 64, "Canon must be packed");
 
 struct P {
     const SeqParams &sps; const PicParamSet &pps; const SliceHeader &sh;
@@ -260,7 +261,7 @@ struct P {
         memset(tc, 0, 24); ref[0] = ref[1] = ref[2] = ref[3] = -1; memset(mv, 0, 64); memset(i4m, 2, 16);
         cx.info[addr] = 0; decoded_mask = 0;
         if (cb) { cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0; memset(mvd, 0, 32); }
-        if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; }
+        if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; canon->ref1[0] = canon->ref1[1] = canon->ref1[2] = canon->ref1[3] = -1; }
         return r;
     }
     void finish_mb(const MbRec *r) {

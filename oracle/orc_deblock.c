@@ -20,10 +20,26 @@ static int bs_of(const MbInfo *mp, int bp, const MbInfo *mq, int bq, int mb_edge
         nzq = mq->total_coeff[o] | mq->total_coeff[o + 1] | mq->total_coeff[o + 4] | mq->total_coeff[o + 5]; }
     else nzq = mq->total_coeff[bq];
     if (nzp || nzq) return 2;
-    int rp = mp->ref_pic_id[0][(bp >> 3) * 2 + ((bp & 3) >> 1)], rq = mq->ref_pic_id[0][(bq >> 3) * 2 + ((bq & 3) >> 1)];
-    if (rp != rq) return 1;
-    if (orc_abs(mp->mv[0][bp][0] - mq->mv[0][bq][0]) >= 4 || orc_abs(mp->mv[0][bp][1] - mq->mv[0][bq][1]) >= 4) return 1;
-    return 0;
+    /* different reference pictures or a different number of motion vectors; the lists themselves do not matter */
+    int pb8 = (bp >> 3) * 2 + ((bp & 3) >> 1), qb8 = (bq >> 3) * 2 + ((bq & 3) >> 1);
+    int p0 = mp->ref_idx[0][pb8] >= 0 ? mp->ref_pic_id[0][pb8] : -1, p1 = mp->ref_idx[1][pb8] >= 0 ? mp->ref_pic_id[1][pb8] : -1;
+    int q0 = mq->ref_idx[0][qb8] >= 0 ? mq->ref_pic_id[0][qb8] : -1, q1 = mq->ref_idx[1][qb8] >= 0 ? mq->ref_pic_id[1][qb8] : -1;
+    const int16_t *pm0 = mp->mv[0][bp], *pm1 = mp->mv[1][bp], *qm0 = mq->mv[0][bq], *qm1 = mq->mv[1][bq];
+#define FAR(a, b) (orc_abs((a)[0] - (b)[0]) >= 4 || orc_abs((a)[1] - (b)[1]) >= 4)
+    int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
+    if (np != nq) return 1;
+    if (np == 1) {
+        int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
+        if (rp != rq) return 1;
+        return FAR(p0 >= 0 ? pm0 : pm1, q0 >= 0 ? qm0 : qm1);
+    }
+    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+    if (p0 != p1) {
+        if (p0 == q0) return FAR(pm0, qm0) || FAR(pm1, qm1);
+        return FAR(pm0, qm1) || FAR(pm1, qm0);
+    }
+    return (FAR(pm0, qm0) || FAR(pm1, qm1)) && (FAR(pm0, qm1) || FAR(pm1, qm0));
+#undef FAR
 }
 
 /* 8.7.2.3 / 8.7.2.4: filter one line of samples across an edge.

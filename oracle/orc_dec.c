@@ -189,36 +189,57 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
     }
     for (int i = 0; i < nst; i++) for (int j = i + 1; j < nst; j++) if (st[j]->pic_num > st[i]->pic_num) { Picture *t = st[i]; st[i] = st[j]; st[j] = t; }
     for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_pic_num < lt[i]->long_term_pic_num) { Picture *t = lt[i]; lt[i] = lt[j]; lt[j] = t; }
-    Picture *list[34]; memset(list, 0, sizeof list);
-    int n = 0, nact = sh->num_ref_idx[0];
-    for (int i = 0; i < nst && n < 33; i++) list[n++] = st[i];
-    for (int i = 0; i < nlt && n < 33; i++) list[n++] = lt[i];
-    if (n > nact) for (int i = nact; i < 34; i++) list[i] = NULL;
-    if (sh->rplm_flag[0]) {
-        int pred = sh->frame_num, idx = 0;
-        for (int k = 0; k < sh->n_rplm[0]; k++) {
-            const RplmOp *op = &sh->rplm[0][k];
-            Picture *target = NULL;
-            if (op->idc < 2) {
-                int nowrap;
-                if (op->idc == 0) { nowrap = pred - (op->val + 1); if (nowrap < 0) nowrap += max_frame_num; }
-                else { nowrap = pred + (op->val + 1); if (nowrap >= max_frame_num) nowrap -= max_frame_num; }
-                pred = nowrap;
-                int pic_num = nowrap > sh->frame_num ? nowrap - max_frame_num : nowrap;
-                for (int i = 0; i < nst; i++) if (st[i]->pic_num == pic_num) target = st[i];
-            } else {
-                for (int i = 0; i < nlt; i++) if (lt[i]->long_term_pic_num == op->val) target = lt[i];
-            }
-            if (!target) ORC_FAIL(d, "ref_pic_list_modification names a missing picture");
-            if (idx >= nact) ORC_FAIL(d, "too many ref_pic_list_modification operations");
-            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
-            list[idx++] = target;
-            int nidx = idx;
-            for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
-        }
+    int nlists = sh->slice_type == SLICE_B ? 2 : 1;
+    Picture *init[2][34]; int ninit[2] = {0, 0};
+    memset(init, 0, sizeof init);
+    if (sh->slice_type == SLICE_P) {                       /* 8.2.4.2.1: descending PicNum, then ascending LongTermPicNum */
+        for (int i = 0; i < nst && ninit[0] < 33; i++) init[0][ninit[0]++] = st[i];
+    } else {                                               /* 8.2.4.2.3: by POC distance around the current picture */
+        Picture *before[ORC_MAX_DPB + 1], *after[ORC_MAX_DPB + 1]; int nb = 0, na = 0;
+        for (int i = 0; i < nst; i++) { if (st[i]->poc < d->cur->poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j]; before[j] = t; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j]; after[j] = t; }
+        for (int i = 0; i < nb; i++) init[0][ninit[0]++] = before[i];
+        for (int i = 0; i < na; i++) init[0][ninit[0]++] = after[i];
+        for (int i = 0; i < na; i++) init[1][ninit[1]++] = after[i];
+        for (int i = 0; i < nb; i++) init[1][ninit[1]++] = before[i];
     }
-    for (int i = 0; i < nact; i++) d->ref_list[0][i] = list[i];
-    d->ref_count[0] = nact;
+    for (int l = 0; l < nlists; l++) for (int i = 0; i < nlt && ninit[l] < 33; i++) init[l][ninit[l]++] = lt[i];
+    if (nlists == 2 && ninit[1] > 1 && ninit[0] == ninit[1]) {
+        int same = 1;
+        for (int i = 0; i < ninit[0]; i++) if (init[0][i] != init[1][i]) same = 0;
+        if (same) { Picture *t = init[1][0]; init[1][0] = init[1][1]; init[1][1] = t; }
+    }
+    for (int l = 0; l < nlists; l++) {
+        Picture **list = init[l];
+        int nact = sh->num_ref_idx[l];
+        for (int i = nact; i < 34; i++) list[i] = NULL;
+        if (sh->rplm_flag[l]) {
+            int pred = sh->frame_num, idx = 0;
+            for (int k = 0; k < sh->n_rplm[l]; k++) {
+                const RplmOp *op = &sh->rplm[l][k];
+                Picture *target = NULL;
+                if (op->idc < 2) {
+                    int nowrap;
+                    if (op->idc == 0) { nowrap = pred - (op->val + 1); if (nowrap < 0) nowrap += max_frame_num; }
+                    else { nowrap = pred + (op->val + 1); if (nowrap >= max_frame_num) nowrap -= max_frame_num; }
+                    pred = nowrap;
+                    int pic_num = nowrap > sh->frame_num ? nowrap - max_frame_num : nowrap;
+                    for (int i = 0; i < nst; i++) if (st[i]->pic_num == pic_num) target = st[i];
+                } else {
+                    for (int i = 0; i < nlt; i++) if (lt[i]->long_term_pic_num == op->val) target = lt[i];
+                }
+                if (!target) ORC_FAIL(d, "ref_pic_list_modification names a missing picture");
+                if (idx >= nact) ORC_FAIL(d, "too many ref_pic_list_modification operations");
+                for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+                list[idx++] = target;
+                int nidx = idx;
+                for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+            }
+        }
+        for (int i = 0; i < nact; i++) d->ref_list[l][i] = list[i];
+        d->ref_count[l] = nact;
+    }
     return 0;
 }
 

@@ -370,7 +370,7 @@ static int pred_chroma(Sl *s, int mode, uint8_t *dst, int stride) {
 typedef struct { int avail; int ref; int mv[2]; } Nb;
 
 /* neighbour partition covering 4x4 block (bx,by) relative to the current MB */
-static Nb nb_get(Sl *s, int bx, int by) {
+static Nb nb_get(Sl *s, int list, int bx, int by) {
     Nb n = {0, -1, {0, 0}};
     MbInfo *m; int rx, ry;
     if (by < 0) {
@@ -387,8 +387,8 @@ static Nb nb_get(Sl *s, int bx, int by) {
     if (!m) return n;
     n.avail = 1;
     if (m->is_intra) return n;
-    n.ref = m->ref_idx[0][(ry >> 1) * 2 + (rx >> 1)];
-    if (n.ref >= 0) { n.mv[0] = m->mv[0][ry * 4 + rx][0]; n.mv[1] = m->mv[0][ry * 4 + rx][1]; }
+    n.ref = m->ref_idx[list][(ry >> 1) * 2 + (rx >> 1)];
+    if (n.ref >= 0) { n.mv[0] = m->mv[list][ry * 4 + rx][0]; n.mv[1] = m->mv[list][ry * 4 + rx][1]; }
     return n;
 }
 static int median3(int a, int b, int c) {
@@ -396,9 +396,9 @@ static int median3(int a, int b, int c) {
     return a + b + c - mx - mn;
 }
 /* 8.4.1.3: mv prediction for a partition at 4x4 (bx,by) size (bw,bh) in 4x4 units */
-static void predict_mv(Sl *s, int bx, int by, int bw, int bh, int ref, int shape, int part, int mvp[2]) {
-    Nb A = nb_get(s, bx - 1, by), B = nb_get(s, bx, by - 1), C = nb_get(s, bx + bw, by - 1);
-    if (!C.avail) C = nb_get(s, bx - 1, by - 1);
+static void predict_mv(Sl *s, int list, int bx, int by, int bw, int bh, int ref, int shape, int part, int mvp[2]) {
+    Nb A = nb_get(s, list, bx - 1, by), B = nb_get(s, list, bx, by - 1), C = nb_get(s, list, bx + bw, by - 1);
+    if (!C.avail) C = nb_get(s, list, bx - 1, by - 1);
     (void)bh;
     if (shape == 1) {            /* 16x8 */
         if (part == 0 && B.ref == ref) { mvp[0] = B.mv[0]; mvp[1] = B.mv[1]; return; }
@@ -417,9 +417,9 @@ static void predict_mv(Sl *s, int bx, int by, int bw, int bh, int ref, int shape
         mvp[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
     }
 }
-static void set_mv(Sl *s, int bx, int by, int bw, int bh, int mvx, int mvy) {
+static void set_mv(Sl *s, int list, int bx, int by, int bw, int bh, int mvx, int mvy) {
     for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
-        s->mb->mv[0][y * 4 + x][0] = (int16_t)mvx; s->mb->mv[0][y * 4 + x][1] = (int16_t)mvy;
+        s->mb->mv[list][y * 4 + x][0] = (int16_t)mvx; s->mb->mv[list][y * 4 + x][1] = (int16_t)mvy;
         s->decoded_mask |= 1 << (y * 4 + x);
     }
 }
@@ -453,53 +453,173 @@ static int luma_sample(const Picture *r, int W, int H, int xi, int yi, int fx, i
 #undef HB1
 #undef VH1
 }
-/* motion-compensate one partition (luma px rect x,y,w,h inside the MB) */
-static void mc_part(Sl *s, const Picture *ref, int refidx, int px, int py, int w, int h, int mvx, int mvy) {
-    OrcDec *d = s->d; Picture *pic = s->pic;
+/* 8.4.2.2: prediction samples of one 4x4 block (luma 4x4 + chroma 2x2 per plane) from one reference picture */
+static void pred_block(Sl *s, const Picture *ref, int px, int py, int mvx, int mvy, int *yl, int *cu, int *cv) {
+    OrcDec *d = s->d;
     int W = d->mb_w * 16, H = d->mb_h * 16;
     int x0 = s->mb_x * 16 + px, y0 = s->mb_y * 16 + py;
-    const SliceHdr *sh = s->sh;
-    int wp = s->pps->weighted_pred && sh->slice_type == SLICE_P;
-    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
-        int v = luma_sample(ref, W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
-        if (wp) {
-            int lw = sh->luma_log2_wd, wt = sh->luma_weight[0][refidx], of = sh->luma_offset[0][refidx];
-            v = orc_clip1((lw >= 1 ? ((v * wt + (1 << (lw - 1))) >> lw) : v * wt) + of);
-        }
-        pic->y[(y0 + y) * pic->stride_y + x0 + x] = (uint8_t)v;
-    }
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
+        yl[y * 4 + x] = luma_sample(ref, W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
     int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
     for (int pl = 0; pl < 2; pl++) {
-        const uint8_t *rp = pl ? ref->v : ref->u; uint8_t *dp = pl ? pic->v : pic->u;
-        for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
+        const uint8_t *rp = pl ? ref->v : ref->u; int *o = pl ? cv : cu;
+        for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
             int xi = cx0 + x + (mvx >> 3), yi = cy0 + y + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
             int A = ref_px(rp, ref->stride_c, cw, ch, xi, yi), B = ref_px(rp, ref->stride_c, cw, ch, xi + 1, yi);
             int C = ref_px(rp, ref->stride_c, cw, ch, xi, yi + 1), D = ref_px(rp, ref->stride_c, cw, ch, xi + 1, yi + 1);
-            int v = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
-            if (wp) {
-                int lw = sh->chroma_log2_wd, wt = sh->chroma_weight[0][refidx][pl], of = sh->chroma_offset[0][refidx][pl];
-                v = orc_clip1((lw >= 1 ? ((v * wt + (1 << (lw - 1))) >> lw) : v * wt) + of);
-            }
-            dp[(cy0 + y) * pic->stride_c + cx0 + x] = (uint8_t)v;
+            o[y * 2 + x] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
         }
     }
 }
+/* 8.4.2.3: weighted sample prediction of n samples; p1 == NULL: one list */
+static void weight_samples(int *out, const int *p0, const int *p1, int n, int mode /*0 default 1 explicit 2 implicit*/,
+                           int logwd, int w0, int w1, int o0, int o1) {
+    for (int i = 0; i < n; i++) {
+        int v;
+        if (!p1) v = mode == 1 ? orc_clip1((logwd >= 1 ? ((p0[i] * w0 + (1 << (logwd - 1))) >> logwd) : p0[i] * w0) + o0) : p0[i];
+        else if (mode == 0) v = (p0[i] + p1[i] + 1) >> 1;
+        else v = orc_clip1(((p0[i] * w0 + p1[i] * w1 + (1 << logwd)) >> (logwd + 1)) + ((o0 + o1 + 1) >> 1));
+        out[i] = v;
+    }
+}
+/* 8.4.2.3.1 implicit bi-prediction weights of the pair (ref0, ref1) */
+static void implicit_weights(const OrcDec *d, const Picture *r0, const Picture *r1, int *w0, int *w1) {
+    int tb = orc_clip3(-128, 127, d->cur->poc - r0->poc), td = orc_clip3(-128, 127, r1->poc - r0->poc);
+    *w0 = *w1 = 32;
+    if (td == 0 || r0->is_ref == 2 || r1->is_ref == 2) return;
+    int tx = (16384 + orc_abs(td / 2)) / td, dsf = orc_clip3(-1024, 1023, (tb * tx + 32) >> 6);
+    if ((dsf >> 2) < -64 || (dsf >> 2) > 128) return;
+    *w0 = 64 - (dsf >> 2); *w1 = dsf >> 2;
+}
 static int inter_recon(Sl *s) {
-    MbInfo *mb = s->mb;
+    MbInfo *mb = s->mb; OrcDec *d = s->d; Picture *pic = s->pic; const SliceHdr *sh = s->sh;
+    int mode = sh->slice_type == SLICE_P ? (s->pps->weighted_pred ? 1 : 0) : s->pps->weighted_bipred_idc;
     /* walk the 4x4 grid, merging nothing: per-4x4 MC gives identical samples */
     for (int b8 = 0; b8 < 4; b8++) {
-        int ri = mb->ref_idx[0][b8];
-        if (ri < 0 || ri >= s->d->ref_count[0] || !s->d->ref_list[0][ri]) {
-            snprintf(s->d->err, sizeof s->d->err, "missing reference picture (ref_idx %d)", ri); return -1;
+        const Picture *ref[2] = {NULL, NULL}; int ri[2];
+        for (int l = 0; l < 2; l++) {
+            ri[l] = mb->ref_idx[l][b8];
+            if (ri[l] < 0) continue;
+            if (ri[l] >= d->ref_count[l] || !d->ref_list[l][ri[l]]) { snprintf(d->err, sizeof d->err, "missing reference picture (list %d ref_idx %d)", l, ri[l]); return -1; }
+            ref[l] = d->ref_list[l][ri[l]];
+            mb->ref_pic_id[l][b8] = ref[l]->id;
         }
-        const Picture *ref = s->d->ref_list[0][ri];
-        mb->ref_pic_id[0][b8] = ref->id;
+        if (!ref[0] && !ref[1]) { snprintf(d->err, sizeof d->err, "inter block without a reference"); return -1; }
         for (int k = 0; k < 4; k++) {
-            int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1);
-            mc_part(s, ref, ri, bx * 4, by * 4, 4, 4, mb->mv[0][by * 4 + bx][0], mb->mv[0][by * 4 + bx][1]);
+            int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1), r = by * 4 + bx;
+            int y[2][16], cu[2][4], cv[2][4], oy[16], ou[4], ov[4];
+            for (int l = 0; l < 2; l++) if (ref[l]) pred_block(s, ref[l], bx * 4, by * 4, mb->mv[l][r][0], mb->mv[l][r][1], y[l], cu[l], cv[l]);
+            if (ref[0] && ref[1]) {
+                int m = mode, w0 = 32, w1 = 32;
+                if (m == 2) { implicit_weights(d, ref[0], ref[1], &w0, &w1); }
+                if (m == 1) {
+                    weight_samples(oy, y[0], y[1], 16, 1, sh->luma_log2_wd, sh->luma_weight[0][ri[0]], sh->luma_weight[1][ri[1]], sh->luma_offset[0][ri[0]], sh->luma_offset[1][ri[1]]);
+                    weight_samples(ou, cu[0], cu[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][0], sh->chroma_weight[1][ri[1]][0], sh->chroma_offset[0][ri[0]][0], sh->chroma_offset[1][ri[1]][0]);
+                    weight_samples(ov, cv[0], cv[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][1], sh->chroma_weight[1][ri[1]][1], sh->chroma_offset[0][ri[0]][1], sh->chroma_offset[1][ri[1]][1]);
+                } else {
+                    weight_samples(oy, y[0], y[1], 16, m, 5, w0, w1, 0, 0);
+                    weight_samples(ou, cu[0], cu[1], 4, m, 5, w0, w1, 0, 0);
+                    weight_samples(ov, cv[0], cv[1], 4, m, 5, w0, w1, 0, 0);
+                }
+            } else {
+                int l = ref[0] ? 0 : 1, m = mode == 1 ? 1 : 0;
+                weight_samples(oy, y[l], NULL, 16, m, sh->luma_log2_wd, sh->luma_weight[l][ri[l]], 0, sh->luma_offset[l][ri[l]], 0);
+                weight_samples(ou, cu[l], NULL, 4, m, sh->chroma_log2_wd, sh->chroma_weight[l][ri[l]][0], 0, sh->chroma_offset[l][ri[l]][0], 0);
+                weight_samples(ov, cv[l], NULL, 4, m, sh->chroma_log2_wd, sh->chroma_weight[l][ri[l]][1], 0, sh->chroma_offset[l][ri[l]][1], 0);
+            }
+            int x0 = s->mb_x * 16 + bx * 4, y0 = s->mb_y * 16 + by * 4;
+            for (int i = 0; i < 16; i++) pic->y[(y0 + (i >> 2)) * pic->stride_y + x0 + (i & 3)] = (uint8_t)oy[i];
+            for (int i = 0; i < 4; i++) {
+                pic->u[(y0 / 2 + (i >> 1)) * pic->stride_c + x0 / 2 + (i & 1)] = (uint8_t)ou[i];
+                pic->v[(y0 / 2 + (i >> 1)) * pic->stride_c + x0 / 2 + (i & 1)] = (uint8_t)ov[i];
+            }
         }
     }
     return 0;
+}
+
+/* ----------------------------- direct prediction (8.4.1.2) ---------------- */
+static int min_positive(int a, int b) { return (a >= 0 && b >= 0) ? orc_min(a, b) : orc_max(a, b); }
+/* colocated 4x4 block (8.4.1.2.1, frame pictures): motion of block r of the same macroblock in RefPicList1[0] */
+static void colocated(Sl *s, int r, int *ref_col, int mv_col[2], int *ref_pic_col) {
+    const Picture *col = s->d->ref_list[1][0];
+    const MbInfo *m = &col->mbs[s->mb_addr];
+    int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
+    *ref_col = -1; mv_col[0] = mv_col[1] = 0; *ref_pic_col = -1;
+    if (m->is_intra || m->slice_num < 0) return;
+    int l = m->ref_idx[0][b8] >= 0 ? 0 : 1;
+    if (m->ref_idx[l][b8] < 0) return;
+    *ref_col = m->ref_idx[l][b8]; mv_col[0] = m->mv[l][r][0]; mv_col[1] = m->mv[l][r][1]; *ref_pic_col = m->ref_pic_id[l][b8];
+}
+/* derive refIdx / mv of the 8x8 quadrants in `mask` (bit b8) by direct prediction; marks them in direct8 */
+static int direct_pred(Sl *s, int mask) {
+    MbInfo *mb = s->mb; OrcDec *d = s->d;
+    if (d->ref_count[1] < 1 || !d->ref_list[1][0]) { snprintf(d->err, sizeof d->err, "direct prediction without RefPicList1[0]"); return -1; }
+    int inf8 = s->sps->direct_8x8_inference;
+    if (s->sh->direct_spatial_mv_pred) {
+        int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
+        for (int l = 0; l < 2; l++) {                          /* neighbours of the macroblock as one 16x16 partition */
+            Nb A = nb_get(s, l, -1, 0), B = nb_get(s, l, 0, -1), C = nb_get(s, l, 4, -1);
+            if (!C.avail) C = nb_get(s, l, -1, -1);
+            ref[l] = min_positive(A.ref, min_positive(B.ref, C.ref));
+        }
+        int zero = ref[0] < 0 && ref[1] < 0;
+        if (zero) ref[0] = ref[1] = 0;
+        else for (int l = 0; l < 2; l++) if (ref[l] >= 0) {
+            int saved = s->decoded_mask; s->decoded_mask = 0;  /* only neighbouring macroblocks take part (mbPartIdx 0 of a 16x16 partition) */
+            predict_mv(s, l, 0, 0, 4, 4, ref[l], 0, 0, mvp[l]);
+            s->decoded_mask = saved;
+        }
+        int col_short = d->ref_list[1][0]->is_ref != 2;
+        for (int b8 = 0; b8 < 4; b8++) {
+            if (!(mask & (1 << b8))) continue;
+            mb->ref_idx[0][b8] = (int8_t)ref[0]; mb->ref_idx[1][b8] = (int8_t)ref[1];
+            for (int k = 0; k < 4; k++) {
+                int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1), r = by * 4 + bx;
+                int rc = inf8 ? ((b8 >> 1) * 3) * 4 + (b8 & 1) * 3 : r;       /* corner block of the quadrant when direct_8x8_inference */
+                int ref_col, mv_col[2], pid;
+                colocated(s, rc, &ref_col, mv_col, &pid);
+                int col_zero = col_short && ref_col == 0 && mv_col[0] >= -1 && mv_col[0] <= 1 && mv_col[1] >= -1 && mv_col[1] <= 1;
+                for (int l = 0; l < 2; l++) {
+                    int z = zero || ref[l] < 0 || (ref[l] == 0 && col_zero);
+                    mb->mv[l][r][0] = (int16_t)(z ? 0 : mvp[l][0]); mb->mv[l][r][1] = (int16_t)(z ? 0 : mvp[l][1]);
+                }
+            }
+        }
+    } else {
+        for (int b8 = 0; b8 < 4; b8++) {
+            if (!(mask & (1 << b8))) continue;
+            for (int k = 0; k < 4; k++) {
+                int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1), r = by * 4 + bx;
+                int rc = inf8 ? ((b8 >> 1) * 3) * 4 + (b8 & 1) * 3 : r;
+                int ref_col, mv_col[2], pid, ref0 = 0;
+                colocated(s, rc, &ref_col, mv_col, &pid);
+                if (ref_col >= 0) {
+                    ref0 = -1;
+                    for (int i = 0; i < d->ref_count[0]; i++) if (d->ref_list[0][i] && d->ref_list[0][i]->id == pid) { ref0 = i; break; }
+                    if (ref0 < 0) { snprintf(d->err, sizeof d->err, "temporal direct: colocated reference is not in RefPicList0"); return -1; }
+                }
+                const Picture *p0 = d->ref_list[0][ref0], *p1 = d->ref_list[1][0];
+                if (!p0) { snprintf(d->err, sizeof d->err, "temporal direct without RefPicList0[%d]", ref0); return -1; }
+                int mv0[2], mv1[2];
+                int tb = orc_clip3(-128, 127, d->cur->poc - p0->poc), td = orc_clip3(-128, 127, p1->poc - p0->poc);
+                if (p0->is_ref == 2 || td == 0) { mv0[0] = mv_col[0]; mv0[1] = mv_col[1]; mv1[0] = mv1[1] = 0; }
+                else {
+                    int tx = (16384 + orc_abs(td / 2)) / td, dsf = orc_clip3(-1024, 1023, (tb * tx + 32) >> 6);
+                    for (int c = 0; c < 2; c++) { mv0[c] = (dsf * mv_col[c] + 128) >> 8; mv1[c] = mv0[c] - mv_col[c]; }
+                }
+                mb->ref_idx[0][b8] = (int8_t)ref0; mb->ref_idx[1][b8] = 0;
+                mb->mv[0][r][0] = (int16_t)mv0[0]; mb->mv[0][r][1] = (int16_t)mv0[1];
+                mb->mv[1][r][0] = (int16_t)mv1[0]; mb->mv[1][r][1] = (int16_t)mv1[1];
+            }
+        }
+    }
+    mb->direct8 |= (uint8_t)mask;
+    return 0;
+}
+static void mark_decoded8(Sl *s, int b8) {
+    int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
+    s->decoded_mask |= (1 << (by * 4 + bx)) | (1 << (by * 4 + bx + 1)) | (1 << (by * 4 + bx + 4)) | (1 << (by * 4 + bx + 5));
 }
 
 /* ----------------------------- residual add ------------------------------ */
@@ -632,7 +752,7 @@ static void recon8x8(Sl *s, int b8, const uint8_t *list, int qp, uint8_t *dst, i
 static void digest_mb(Sl *s) {
     OrcDec *d = s->d; MbInfo *mb = s->mb;
     if (!d->digest_on) return;
-    uint8_t buf[908]; size_t n = 0;
+    uint8_t buf[976]; size_t n = 0;
     memset(buf, 0, sizeof buf);
     uint32_t addr = (uint32_t)s->mb_addr; memcpy(buf, &addr, 4); n = 4;
     int kind = !mb->is_intra ? 0 : (mb->is_pcm ? 3 : (mb->is_i16 ? 2 : 1));
@@ -650,6 +770,9 @@ static void digest_mb(Sl *s) {
         memcpy(buf + n + 544, s->cdc, 16); memcpy(buf + n + 560, s->cac, 256);
     }
     n += 816;
+    for (int i = 0; i < 4; i++) buf[n++] = (uint8_t)(kind == 0 ? mb->ref_idx[1][i] : -1);
+    if (kind == 0) memcpy(buf + n, mb->mv[1], 64);
+    n += 64;
     uint64_t h = d->digest;
     for (size_t i = 0; i < n; i++) { h ^= buf[i]; h *= 1099511628211ull; }
     d->digest = h; d->digest_mbs++;
@@ -678,33 +801,40 @@ static int decode_skip_mb(Sl *s) {
     mb_reset(s);
     MbInfo *mb = s->mb;
     mb->is_skip = 1; mb->mb_type_p = 0;
-    s->d->stats[ORC_ST_PSKIP]++;
     mb_set_qp(s);
     s->last_dqp_nonzero = 0;
+    if (s->sh->slice_type == SLICE_B) {                       /* B_Skip: direct prediction, no residual */
+        s->d->stats[ORC_ST_BSKIP]++;
+        mb->b_direct16 = 1;
+        if (direct_pred(s, 15) < 0) return -1;
+        digest_mb(s);
+        return inter_recon(s);
+    }
+    s->d->stats[ORC_ST_PSKIP]++;
     int mvp[2] = {0, 0};
     MbInfo *mA = mb_at(s, s->mb_x - 1, s->mb_y), *mB = mb_at(s, s->mb_x, s->mb_y - 1);
     if (mA && mB) {
-        Nb A = nb_get(s, -1, 0), B = nb_get(s, 0, -1);
+        Nb A = nb_get(s, 0, -1, 0), B = nb_get(s, 0, 0, -1);
         if (!((A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) || (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
-            predict_mv(s, 0, 0, 4, 4, 0, 0, 0, mvp);
+            predict_mv(s, 0, 0, 0, 4, 4, 0, 0, 0, mvp);
     }
     for (int i = 0; i < 4; i++) mb->ref_idx[0][i] = 0;
-    set_mv(s, 0, 0, 4, 4, mvp[0], mvp[1]);
+    set_mv(s, 0, 0, 0, 4, 4, mvp[0], mvp[1]);
     digest_mb(s);
     return inter_recon(s);
 }
 
 /* entropy-mode dispatch of the 7.3.5 descriptors: ue(v)|ae(v), te(v)|ae(v), se(v)|ae(v), me(v)|ae(v) */
-static int rd_ref_idx(Sl *s, int bx, int by, int nref) {
-    if (s->cabac_on) return orc_cabac_ref_idx(s, 0, bx, by);
+static int rd_ref_idx(Sl *s, int list, int bx, int by, int nref) {
+    if (s->cabac_on) return orc_cabac_ref_idx(s, list, bx, by);
     return bits_te(s->b, nref - 1);
 }
-static void rd_mvd(Sl *s, int bx, int by, int bw, int bh, int mvd[2]) {
-    if (s->cabac_on) { mvd[0] = orc_cabac_mvd(s, 0, bx, by, 0); mvd[1] = orc_cabac_mvd(s, 0, bx, by, 1); }
+static void rd_mvd(Sl *s, int list, int bx, int by, int bw, int bh, int mvd[2]) {
+    if (s->cabac_on) { mvd[0] = orc_cabac_mvd(s, list, bx, by, 0); mvd[1] = orc_cabac_mvd(s, list, bx, by, 1); }
     else { mvd[0] = bits_se(s->b); mvd[1] = bits_se(s->b); }
     for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) {
-        s->mb->mvd[0][y * 4 + x][0] = (uint16_t)orc_min(orc_abs(mvd[0]), 65535);
-        s->mb->mvd[0][y * 4 + x][1] = (uint16_t)orc_min(orc_abs(mvd[1]), 65535);
+        s->mb->mvd[list][y * 4 + x][0] = (uint16_t)orc_min(orc_abs(mvd[0]), 65535);
+        s->mb->mvd[list][y * 4 + x][1] = (uint16_t)orc_min(orc_abs(mvd[1]), 65535);
     }
 }
 
@@ -779,8 +909,8 @@ static int decode_mb(Sl *s) {
     int is_intra_type = -1;                /* I-slice numbering when intra */
     if (sh->slice_type == SLICE_I) is_intra_type = mb_type;
     else if (sh->slice_type == SLICE_P) { if (mb_type >= 5) is_intra_type = mb_type - 5; }
-    else { snprintf(s->d->err, sizeof s->d->err, "B slices unsupported by the oracle"); return -1; }
-    if (is_intra_type > 25 || mb_type > 30) { snprintf(s->d->err, sizeof s->d->err, "bad mb_type %d", mb_type); return -1; }
+    else if (mb_type >= 23) is_intra_type = mb_type - 23;
+    if (is_intra_type > 25 || mb_type > 48) { snprintf(s->d->err, sizeof s->d->err, "bad mb_type %d", mb_type); return -1; }
 
     uint8_t *dy = pic->y + (s->mb_y * 16) * pic->stride_y + s->mb_x * 16;
     uint8_t *du = pic->u + (s->mb_y * 8) * pic->stride_c + s->mb_x * 8;
@@ -830,42 +960,83 @@ static int decode_mb(Sl *s) {
         if (s->chroma_pred_mode > 3) { snprintf(s->d->err, sizeof s->d->err, "bad intra_chroma_pred_mode"); return -1; }
         mb->chroma_pred_mode = (uint8_t)s->chroma_pred_mode;
     } else {
-        /* ---- P macroblock: 7.3.5.1 mb_pred / 7.3.5.2 sub_mb_pred ---- */
-        int nref = sh->num_ref_idx[0];
-        mb->mb_type_p = (uint8_t)(mb_type > 3 ? 3 : mb_type);
-        if (mb_type <= 2) {
-            int nparts = mb_type == 0 ? 1 : 2, refs[2] = {0, 0};
-            for (int p = 0; p < nparts; p++) {
-                int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0;
-                int bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
-                if (nref > 1) { refs[p] = rd_ref_idx(s, bx, by, nref); if (refs[p] < 0 || refs[p] >= nref) return -1; }
-                for (int y = by; y < by + bh; y += 2) for (int x = bx; x < bx + bw; x += 2) mb->ref_idx[0][(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[p];
+        /* ---- P / B macroblock: 7.3.5.1 mb_pred / 7.3.5.2 sub_mb_pred ---- */
+        static const uint8_t b_pair[9][2] = {{0, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 2}, {1, 2}, {2, 0}, {2, 1}, {2, 2}};   /* Table 7-14: 0 L0 1 L1 2 Bi */
+        static const uint8_t b_sub_pred[13] = {3, 0, 1, 2, 0, 0, 1, 1, 2, 2, 0, 1, 2};                                   /* Table 7-18: 3 direct */
+        static const uint8_t b_sub_shape[13] = {0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};                                  /* 0 8x8 1 8x4 2 4x8 3 4x4 */
+        const int is_b = sh->slice_type == SLICE_B;
+        int shape, pred[4] = {0, 0, 0, 0};   /* shape 0 16x16 1 16x8 2 8x16 3 8x8; pred per partition / sub-macroblock */
+        int sub_shape[4] = {0, 0, 0, 0};
+        if (!is_b) { shape = mb_type > 3 ? 3 : mb_type; }
+        else if (mb_type == 0) shape = 4;                                   /* B_Direct_16x16 */
+        else if (mb_type <= 3) { shape = 0; pred[0] = mb_type - 1; }
+        else if (mb_type == 22) shape = 3;
+        else { shape = (mb_type & 1) ? 2 : 1; pred[0] = b_pair[(mb_type - 4) >> 1][0]; pred[1] = b_pair[(mb_type - 4) >> 1][1]; }
+        mb->mb_type_p = (uint8_t)(shape & 3);
+        if (shape == 4) {
+            mb->b_direct16 = 1; s->d->stats[ORC_ST_BDIRECT]++;
+            if (direct_pred(s, 15) < 0) return -1;
+            if (!s->sps->direct_8x8_inference) mb->mb_type_p |= 4;          /* no 8x8 transform without direct_8x8_inference */
+        } else if (shape <= 2) {
+            int nparts = shape == 0 ? 1 : 2, refs[2][2] = {{-1, -1}, {-1, -1}};
+            if (is_b) s->d->stats[ORC_ST_BINTER]++;
+            for (int l = 0; l < (is_b ? 2 : 1); l++) {
+                int nref = sh->num_ref_idx[l];
+                for (int p = 0; p < nparts; p++) {
+                    if (!(pred[p] == 2 || pred[p] == l)) continue;
+                    int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0;
+                    int bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
+                    refs[l][p] = 0;
+                    if (nref > 1) { refs[l][p] = rd_ref_idx(s, l, bx, by, nref); if (refs[l][p] < 0 || refs[l][p] >= nref) return -1; }
+                    for (int y = by; y < by + bh; y += 2) for (int x = bx; x < bx + bw; x += 2) mb->ref_idx[l][(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[l][p];
+                }
             }
-            for (int p = 0; p < nparts; p++) {
-                int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0;
-                int bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
-                int mvp[2], mvd[2]; predict_mv(s, bx, by, bw, bh, refs[p], mb_type, p, mvp);
-                rd_mvd(s, bx, by, bw, bh, mvd);
-                set_mv(s, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
+            for (int l = 0; l < (is_b ? 2 : 1); l++) {
+                s->decoded_mask = 0;
+                for (int p = 0; p < nparts; p++) {
+                    int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0;
+                    int bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
+                    if (refs[l][p] < 0) { for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) s->decoded_mask |= 1 << (y * 4 + x); continue; }
+                    int mvp[2], mvd[2]; predict_mv(s, l, bx, by, bw, bh, refs[l][p], shape, p, mvp);
+                    rd_mvd(s, l, bx, by, bw, bh, mvd);
+                    set_mv(s, l, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
+                }
             }
         } else {
-            int sub[4], refs[4] = {0, 0, 0, 0};
-            for (int i = 0; i < 4; i++) { sub[i] = cab ? orc_cabac_sub_mb_type(s) : (int)bits_ue(b); if (sub[i] > 3) return -1; }
+            int sub[4], refs[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}}, dmask = 0;
+            if (is_b) s->d->stats[ORC_ST_BINTER]++;
             for (int i = 0; i < 4; i++) {
-                if (nref > 1 && mb_type != 4) { refs[i] = rd_ref_idx(s, (i & 1) * 2, (i >> 1) * 2, nref); if (refs[i] < 0 || refs[i] >= nref) return -1; }
-                mb->ref_idx[0][i] = (int8_t)refs[i];
+                sub[i] = cab ? orc_cabac_sub_mb_type(s) : (int)bits_ue(b);
+                if (sub[i] > (is_b ? 12 : 3)) return -1;
+                if (is_b) { pred[i] = b_sub_pred[sub[i]]; sub_shape[i] = b_sub_shape[sub[i]]; if (pred[i] == 3) dmask |= 1 << i; }
+                else { pred[i] = 0; sub_shape[i] = sub[i]; }
+                if (sub_shape[i] != 0 || (pred[i] == 3 && !s->sps->direct_8x8_inference)) mb->mb_type_p |= 4;   /* noSubMbPartSizeLessThan8x8Flag = 0 */
             }
-            for (int i = 0; i < 4; i++) {
-                int ox = (i & 1) * 2, oy = (i >> 1) * 2;
-                int nsp = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
-                int bw = (sub[i] == 0 || sub[i] == 1) ? 2 : 1, bh = (sub[i] == 0 || sub[i] == 2) ? 2 : 1;
-                if (sub[i] != 0) mb->mb_type_p |= 4;     /* a sub-macroblock partition smaller than 8x8: no 8x8 transform */
-                for (int p = 0; p < nsp; p++) {
-                    int bx = ox + (sub[i] == 1 ? 0 : (sub[i] == 2 ? p : (p & 1)));
-                    int by = oy + (sub[i] == 1 ? p : (sub[i] == 2 ? 0 : (p >> 1)));
-                    int mvp[2], mvd[2]; predict_mv(s, bx, by, bw, bh, refs[i], 0, 0, mvp);
-                    rd_mvd(s, bx, by, bw, bh, mvd);
-                    set_mv(s, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
+            /* direct sub-macroblocks: derived from neighbouring macroblocks / the colocated picture only */
+            if (dmask && direct_pred(s, dmask) < 0) return -1;
+            for (int l = 0; l < (is_b ? 2 : 1); l++) {
+                int nref = sh->num_ref_idx[l];
+                for (int i = 0; i < 4; i++) {
+                    if (!(pred[i] == 2 || pred[i] == l)) continue;
+                    refs[l][i] = 0;
+                    if (nref > 1 && !(!is_b && mb_type == 4)) { refs[l][i] = rd_ref_idx(s, l, (i & 1) * 2, (i >> 1) * 2, nref); if (refs[l][i] < 0 || refs[l][i] >= nref) return -1; }
+                    mb->ref_idx[l][i] = (int8_t)refs[l][i];
+                }
+            }
+            for (int l = 0; l < (is_b ? 2 : 1); l++) {
+                s->decoded_mask = 0;
+                for (int i = 0; i < 4; i++) {
+                    int ox = (i & 1) * 2, oy = (i >> 1) * 2, sp = sub_shape[i];
+                    if (refs[l][i] < 0) { mark_decoded8(s, i); continue; }   /* direct, or this list unused: values are in place */
+                    int nsp = sp == 0 ? 1 : (sp == 3 ? 4 : 2);
+                    int bw = (sp == 0 || sp == 1) ? 2 : 1, bh = (sp == 0 || sp == 2) ? 2 : 1;
+                    for (int p = 0; p < nsp; p++) {
+                        int bx = ox + (sp == 1 ? 0 : (sp == 2 ? p : (p & 1)));
+                        int by = oy + (sp == 1 ? p : (sp == 2 ? 0 : (p >> 1)));
+                        int mvp[2], mvd[2]; predict_mv(s, l, bx, by, bw, bh, refs[l][i], 0, 0, mvp);
+                        rd_mvd(s, l, bx, by, bw, bh, mvd);
+                        set_mv(s, l, bx, by, bw, bh, mvp[0] + mvd[0], mvp[1] + mvd[1]);
+                    }
                 }
             }
         }
@@ -885,7 +1056,7 @@ static int decode_mb(Sl *s) {
         long *st = s->d->stats;
         if (mb->is_intra) st[mb->is_i16 ? ORC_ST_I16 : (mb->t8x8 ? ORC_ST_I8 : ORC_ST_I4)]++;
         else {
-            st[ORC_ST_P16 + (mb->mb_type_p & 3)]++;
+            if (sh->slice_type == SLICE_P) st[ORC_ST_P16 + (mb->mb_type_p & 3)]++;
             if (mb->mb_type_p & 4) st[ORC_ST_SUB_SMALL]++;
             if (mb->t8x8) st[ORC_ST_T8_INTER]++;
             if (mb->ref_idx[0][0] > 0 || mb->ref_idx[0][1] > 0 || mb->ref_idx[0][2] > 0 || mb->ref_idx[0][3] > 0) st[ORC_ST_MULTIREF]++;
