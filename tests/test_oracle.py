@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from jmcodec_amd import api, streams
-from util import PARITY_CASES, golden_meta, golden_stream, md5, unescape
+from util import ALL_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
 
 
 def _recon(kw):
@@ -17,12 +17,12 @@ def _recon(kw):
         return data, open(tf.name, "rb").read()
 
 
-@pytest.mark.parametrize("name", sorted(PARITY_CASES))
+@pytest.mark.parametrize("name", sorted(ALL_CASES))
 def test_oracle_equals_generator_reconstruction(oracle, name):
-    data, recon = _recon(PARITY_CASES[name])
+    data, recon = _recon(ALL_CASES[name])
     out, n, w, h = oracle.decode(data, 1)
-    assert n == PARITY_CASES[name]["frames"]
-    assert (w, h) == (PARITY_CASES[name]["width"], PARITY_CASES[name]["height"])
+    assert n == ALL_CASES[name]["frames"]
+    assert (w, h) == (ALL_CASES[name]["width"], ALL_CASES[name]["height"])
     assert out == recon
 
 

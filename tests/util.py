@@ -79,3 +79,21 @@ PARITY_CASES = {
     "high_real_qvga": dict(width=320, height=240, frames=8, gop=8, seed=22, cabac=1, t8x8=1, qp=30),
     "high_crop_odd_mbs": dict(width=90, height=70, frames=6, gop=3, mode=1, seed=88, cabac=1, cabac_idc=1, t8x8=1, slices=2),
 }
+
+# B pictures (Main / High): direct spatial / temporal, bi-prediction, implicit and explicit weights, CAVLC and CABAC
+B_CASES = {
+    # explicit weighted prediction in P slices
+    "wp_explicit_p": dict(width=96, height=80, frames=8, gop=8, mode=1, num_ref=3, seed=89, wp=1),
+    "wp_explicit_p_cabac": dict(width=96, height=80, frames=6, gop=6, mode=1, num_ref=2, seed=90, wp=1, cabac=1, t8x8=1),
+    "b_real_spatial": dict(width=176, height=144, frames=10, gop=10, seed=91, bframes=2),
+    "b_real_temporal_cabac": dict(width=176, height=144, frames=10, gop=10, seed=92, bframes=2, direct_temporal=1, cabac=1),
+    "b_fuzz_cavlc": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=93, bframes=2, num_ref=3),
+    "b_fuzz_cabac_high": dict(width=96, height=80, frames=12, gop=6, mode=1, seed=94, bframes=3, num_ref=4, cabac=1, t8x8=1, slices=2),
+    "b_fuzz_temporal_noinf8": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=95, bframes=2, num_ref=3, direct_temporal=1, dinf8=0, cabac=1, cabac_idc=1),
+    "b_fuzz_spatial_noinf8": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=96, bframes=1, dinf8=0, deblock=2, slices=3, cip=1),
+    "b_fuzz_implicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=97, bframes=2, num_ref=3, wp=2, cabac=1, cabac_idc=2),
+    "b_fuzz_explicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=98, bframes=2, num_ref=2, wp=1, t8x8=1),
+    "b_crop_odd_mbs": dict(width=90, height=70, frames=8, gop=8, mode=1, seed=99, bframes=3, num_ref=2, cabac=1),
+}
+ALL_CASES = dict(PARITY_CASES)
+ALL_CASES.update(B_CASES)

@@ -46,6 +46,10 @@ typedef struct {
     int cabac;                  /* entropy_coding_mode_flag                   */
     int cabac_idc;              /* cabac_init_idc 0..2                        */
     int t8x8;                   /* transform_8x8_mode_flag: 8x8 transform + Intra8x8 (High profile) */
+    int bframes;                /* B pictures between anchors (0..3); forces pic_order_cnt_type 0 */
+    int direct_temporal;        /* 0: direct_spatial_mv_pred_flag = 1, 1: temporal direct */
+    int wp;                     /* 0 none, 1 explicit weights (P and B), 2 implicit (B)          */
+    int dinf8;                  /* direct_8x8_inference_flag (default 1 when 0 is passed with bframes == 0) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -205,6 +209,7 @@ typedef struct {
     uint8_t *hb, *hh, *hj;         /* luma half-pel planes (origin pointers)     */
     uint8_t *bhb, *bhh, *bhj;
     int frame_num, poc, id;
+    void *mf;                      /* MbE[] motion field of the picture (colocated data for direct prediction) */
 } Frame;
 
 typedef struct {
@@ -212,6 +217,7 @@ typedef struct {
     uint8_t tc[24]; uint8_t intra, pcm, i16, qp, qpc[2]; uint8_t i4[16];
     int slice; uint8_t skip;
     int8_t dis_db, a_off, b_off;
+    int8_t ref1[4]; int16_t mv1[16][2]; int refid1[4]; uint8_t mvd1[16][2]; uint8_t direct8, bdirect16;   /* list 1 / direct prediction (B) */
     uint8_t cbp, cmode, t8; uint32_t cbf; uint8_t mvd[16][2]; uint16_t nzmask;   /* CABAC context state / 8x8 transform / deblock non-zero map */
 } MbE;
 
@@ -225,6 +231,9 @@ typedef struct {
     int frame_num, idr_id, log2_max_fn, poc_lsb_bits;
     int slice_id, slice_type, qp_run;
     Frame *list0[5]; int nlist0;
+    Frame *list1[5]; int nlist1; int cur_poc;
+    int wlog[2], ww[2][5][3], wo[2][5][3];   /* explicit weighted prediction: log2 denominators (luma, chroma), weight / offset [list][ref][Y,Cb,Cr] */
+    uint8_t *recon_buf; int recon_frames;
     int16_t tex[256][256];
     int next_id;
     int decoded_mask;
@@ -635,11 +644,23 @@ static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *
 }
 
 /* ------------------------------ deblocking (own implementation) --------------- */
+static int mv_far(const int16_t *a, const int16_t *b) { return ABS(a[0] - b[0]) >= 4 || ABS(a[1] - b[1]) >= 4; }
 static int edge_bs(const MbE *p, int bp, const MbE *q, int bq, int mbedge) {
     if (p->intra || q->intra) return mbedge ? 4 : 3;
     if (((p->nzmask >> bp) & 1) || ((q->nzmask >> bq) & 1)) return 2;
-    if (p->refid[(bp >> 3) * 2 + ((bp & 3) >> 1)] != q->refid[(bq >> 3) * 2 + ((bq & 3) >> 1)]) return 1;
-    return (ABS(p->mv[bp][0] - q->mv[bq][0]) >= 4 || ABS(p->mv[bp][1] - q->mv[bq][1]) >= 4) ? 1 : 0;
+    int pq = (bp >> 3) * 2 + ((bp & 3) >> 1), qq = (bq >> 3) * 2 + ((bq & 3) >> 1);
+    /* reference pictures actually used by each side (as a set of at most two), with their vectors */
+    int pr[2], qr[2], np = 0, nq = 0; const int16_t *pv[2], *qv[2];
+    if (p->ref[pq] >= 0) { pr[np] = p->refid[pq]; pv[np++] = p->mv[bp]; }
+    if (p->ref1[pq] >= 0) { pr[np] = p->refid1[pq]; pv[np++] = p->mv1[bp]; }
+    if (q->ref[qq] >= 0) { qr[nq] = q->refid[qq]; qv[nq++] = q->mv[bq]; }
+    if (q->ref1[qq] >= 0) { qr[nq] = q->refid1[qq]; qv[nq++] = q->mv1[bq]; }
+    if (np != nq) return 1;
+    if (np == 1) return pr[0] != qr[0] || mv_far(pv[0], qv[0]);
+    int straight = pr[0] == qr[0] && pr[1] == qr[1], crossed = pr[0] == qr[1] && pr[1] == qr[0];
+    if (!straight && !crossed) return 1;
+    if (pr[0] != pr[1]) return straight ? (mv_far(pv[0], qv[0]) || mv_far(pv[1], qv[1])) : (mv_far(pv[0], qv[1]) || mv_far(pv[1], qv[0]));
+    return (mv_far(pv[0], qv[0]) || mv_far(pv[1], qv[1])) && (mv_far(pv[0], qv[1]) || mv_far(pv[1], qv[0]));
 }
 static void db_luma(uint8_t *q, int s, int bS, int a, int b, int ia) {
     int p0 = q[-s], p1 = q[-2 * s], p2 = q[-3 * s], q0 = q[0], q1 = q[s], q2 = q[2 * s];
@@ -834,21 +855,24 @@ static void se_skip_flag(Enc *e, int mx, int my, int skip) {
     MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
     cab_enc(&e->cab, 11 + (a && !a->skip) + (b && !b->skip), skip);
 }
+static void se_skip_flag_b(Enc *e, int mx, int my, int skip);
+static void se_mb_type_b_intra_prefix(Enc *e, int mx, int my);
 /* called before every non-skipped macroblock */
 static void se_begin_mb(Enc *e, int mx, int my, int *skip_run) {
-    if (e->cabac) { if (e->slice_type == 0) se_skip_flag(e, mx, my, 0); }
+    if (e->cabac) { if (e->slice_type == 0) se_skip_flag(e, mx, my, 0); else if (e->slice_type == 1) se_skip_flag_b(e, mx, my, 0); }
     else if (*skip_run >= 0) { bw_ue(&e->bw, *skip_run); *skip_run = 0; }
 }
 /* itype: 0 I_NxN, 1..24 I_16x16 (Table 7-11), 25 I_PCM */
 static void se_mb_type_intra(Enc *e, int mx, int my, int itype) {
-    int off = e->slice_type == 0 ? 5 : 0;
+    int off = e->slice_type == 0 ? 5 : (e->slice_type == 1 ? 23 : 0);
     if (!e->cabac) { bw_ue(&e->bw, itype + off); return; }
-    CabEnc *c = &e->cab; int base, in_i = e->slice_type != 0;
+    CabEnc *c = &e->cab; int base, in_i = e->slice_type == 2;
     if (in_i) {
         MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
         cab_enc(c, 3 + (a && !mb_inxn(a)) + (b && !mb_inxn(b)), itype != 0);
         base = 5;
-    } else { cab_enc(c, 14, 1); cab_enc(c, 17, itype != 0); base = 17; }
+    } else if (e->slice_type == 0) { cab_enc(c, 14, 1); cab_enc(c, 17, itype != 0); base = 17; }
+    else { se_mb_type_b_intra_prefix(e, mx, my); cab_enc(c, 32, itype != 0); base = 32; }
     if (itype == 0) return;
     cab_term(c, itype == 25);
     if (itype == 25) return;
@@ -1029,7 +1053,7 @@ static int i4_pred_mode(Enc *e, int mx, int my, MbE *m, int bx, int by) {
 
 static void mb_init(Enc *e, MbE *m) {
     memset(m, 0, sizeof *m);
-    m->slice = e->slice_id; for (int i = 0; i < 4; i++) { m->ref[i] = -1; m->refid[i] = -1; }
+    m->slice = e->slice_id; for (int i = 0; i < 4; i++) { m->ref[i] = -1; m->refid[i] = -1; m->ref1[i] = -1; m->refid1[i] = -1; }
     memset(m->i4, 2, 16);
     m->dis_db = (int8_t)(e->p.deblock == 1 ? 0 : (e->p.deblock == 0 ? 1 : 2)); m->a_off = (int8_t)(2 * e->p.alpha_off); m->b_off = (int8_t)(2 * e->p.beta_off);
     e->decoded_mask = 0;
@@ -1218,6 +1242,7 @@ static void random_mv(Enc *e, int px, int py, int w, int h, const int mvp[2], in
     out[0] = out[1] = 0;
 }
 
+static void mc_mb(Enc *e, int mx, int my, MbE *m);
 static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     Frame *c = &e->cur; BitW *w = &e->bw; int fuzz = e->p.mode == 1;
     int px = mx * 16, py = my * 16, nref = e->nlist0;
@@ -1313,6 +1338,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     for (int i = 0; i < 4; i++) m->refid[i] = e->list0[refs[i]]->id;
     /* ---- prediction + residual ---- */
     for (int k = 0; k < 16; k++) mc_block(e, e->list0[refs[(k >> 3) * 2 + ((k & 3) >> 1)]], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, m->mv[k][0], m->mv[k][1]);
+    if (e->p.wp == 1) mc_mb(e, mx, my, m);                               /* explicit weighted prediction (8.4.2.3) */
     int dqp = 0;
     if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
     int qp = CLIP3(10, 48, e->qp_run + dqp); dqp = qp - e->qp_run;
@@ -1355,12 +1381,335 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     if (mc.cbp > 0) write_mb_residual(e, mx, my, m, &mc);
 }
 
+/* ------------------------------ B pictures ----------------------------------- */
+static int8_t *mb_ref(MbE *m, int l) { return l ? m->ref1 : m->ref; }
+static int16_t (*mb_mv(MbE *m, int l))[2] { return l ? m->mv1 : m->mv; }
+static Nbr nbr_get_l(Enc *e, int mx, int my, MbE *cur, int l, int bx, int by) {
+    Nbr n = {0, -1, {0, 0}}; MbE *m; int rx, ry;
+    if (by < 0) { ry = 3;
+        if (bx < 0) { m = mb_avail(e, mx - 1, my - 1); rx = 3; }
+        else if (bx > 3) { m = mb_avail(e, mx + 1, my - 1); rx = bx - 4; }
+        else { m = mb_avail(e, mx, my - 1); rx = bx; } }
+    else if (bx < 0) { m = mb_avail(e, mx - 1, my); rx = 3; ry = by; }
+    else if (bx > 3) return n;
+    else { if (!(e->decoded_mask >> (by * 4 + bx) & 1)) return n; m = cur; rx = bx; ry = by; }
+    if (!m) return n;
+    n.avail = 1;
+    if (m->intra) return n;
+    n.ref = mb_ref(m, l)[(ry >> 1) * 2 + (rx >> 1)];
+    if (n.ref >= 0) { n.mv[0] = mb_mv(m, l)[ry * 4 + rx][0]; n.mv[1] = mb_mv(m, l)[ry * 4 + rx][1]; }
+    return n;
+}
+static void pred_mv_l(Enc *e, int mx, int my, MbE *cur, int l, int bx, int by, int bw, int ref, int shape, int part, int out[2]) {
+    Nbr A = nbr_get_l(e, mx, my, cur, l, bx - 1, by), B = nbr_get_l(e, mx, my, cur, l, bx, by - 1), C = nbr_get_l(e, mx, my, cur, l, bx + bw, by - 1);
+    if (!C.avail) C = nbr_get_l(e, mx, my, cur, l, bx - 1, by - 1);
+    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } }
+    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0]; out[1] = C.mv[1]; return; } }
+    if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
+    int ma = A.ref == ref, mb = B.ref == ref, mc = C.ref == ref;
+    if (ma + mb + mc == 1) { Nbr *n = ma ? &A : (mb ? &B : &C); out[0] = n->mv[0]; out[1] = n->mv[1]; }
+    else { out[0] = med3(A.mv[0], B.mv[0], C.mv[0]); out[1] = med3(A.mv[1], B.mv[1], C.mv[1]); }
+}
+static void store_mv_l(Enc *e, MbE *m, int l, int bx, int by, int bw, int bh, int mvx, int mvy) {
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { mb_mv(m, l)[y * 4 + x][0] = (int16_t)mvx; mb_mv(m, l)[y * 4 + x][1] = (int16_t)mvy; e->decoded_mask |= 1 << (y * 4 + x); }
+}
+/* colocated motion (8.4.1.2.1) of 4x4 block r in the first picture of list 1 */
+static void col_motion(Enc *e, int mx, int my, int r, int *refidx, int mv[2], int *refid) {
+    const MbE *cm = &((const MbE *)e->list1[0]->mf)[my * e->mbw + mx];
+    int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
+    *refidx = -1; mv[0] = mv[1] = 0; *refid = -1;
+    if (cm->intra) return;
+    if (cm->ref[b8] >= 0) { *refidx = cm->ref[b8]; mv[0] = cm->mv[r][0]; mv[1] = cm->mv[r][1]; *refid = cm->refid[b8]; }
+    else if (cm->ref1[b8] >= 0) { *refidx = cm->ref1[b8]; mv[0] = cm->mv1[r][0]; mv[1] = cm->mv1[r][1]; *refid = cm->refid1[b8]; }
+}
+/* 8.4.1.2.2 / 8.4.1.2.3: fill refs and motion vectors of the 8x8 quadrants in mask */
+static void b_direct(Enc *e, int mx, int my, MbE *m, int mask) {
+    int inf8 = e->p.dinf8;
+    if (!e->p.direct_temporal) {
+        int ref[2], mvp[2][2] = {{0, 0}, {0, 0}}, saved = e->decoded_mask;
+        e->decoded_mask = 0;
+        for (int l = 0; l < 2; l++) {
+            Nbr n[3] = { nbr_get_l(e, mx, my, m, l, -1, 0), nbr_get_l(e, mx, my, m, l, 0, -1), nbr_get_l(e, mx, my, m, l, 4, -1) };
+            if (!n[2].avail) n[2] = nbr_get_l(e, mx, my, m, l, -1, -1);
+            ref[l] = -1;
+            for (int i = 0; i < 3; i++) if (n[i].ref >= 0 && (ref[l] < 0 || n[i].ref < ref[l])) ref[l] = n[i].ref;   /* smallest non-negative reference index */
+        }
+        int both_missing = ref[0] < 0 && ref[1] < 0;
+        if (both_missing) ref[0] = ref[1] = 0;
+        else for (int l = 0; l < 2; l++) if (ref[l] >= 0) pred_mv_l(e, mx, my, m, l, 0, 0, 4, ref[l], 0, 0, mvp[l]);
+        e->decoded_mask = saved;
+        for (int q = 0; q < 4; q++) if (mask & (1 << q)) {
+            m->ref[q] = (int8_t)ref[0]; m->ref1[q] = (int8_t)ref[1];
+            for (int k = 0; k < 4; k++) {
+                int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
+                int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid;
+                col_motion(e, mx, my, rc, &cref, cmv, &cid);
+                int still = cref == 0 && ABS(cmv[0]) <= 1 && ABS(cmv[1]) <= 1;     /* colZeroFlag (the list-1 picture is never long-term here) */
+                for (int l = 0; l < 2; l++) {
+                    int zero = both_missing || ref[l] < 0 || (ref[l] == 0 && still);
+                    mb_mv(m, l)[r][0] = (int16_t)(zero ? 0 : mvp[l][0]); mb_mv(m, l)[r][1] = (int16_t)(zero ? 0 : mvp[l][1]);
+                }
+            }
+        }
+    } else {
+        for (int q = 0; q < 4; q++) if (mask & (1 << q)) for (int k = 0; k < 4; k++) {
+            int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
+            int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid, r0 = 0;
+            col_motion(e, mx, my, rc, &cref, cmv, &cid);
+            if (cref >= 0) { r0 = 0; for (int i = e->nlist0 - 1; i >= 0; i--) if (e->list0[i]->id == cid) r0 = i; }
+            int pd = e->list1[0]->poc - e->list0[r0]->poc, pb = e->cur_poc - e->list0[r0]->poc;
+            int td = CLIP3(-128, 127, pd), tb = CLIP3(-128, 127, pb), v0[2], v1[2];
+            if (td == 0) { v0[0] = cmv[0]; v0[1] = cmv[1]; v1[0] = v1[1] = 0; }
+            else {
+                int tx = (16384 + ABS(td / 2)) / td, scale = CLIP3(-1024, 1023, (tb * tx + 32) >> 6);
+                for (int c = 0; c < 2; c++) { v0[c] = (scale * cmv[c] + 128) >> 8; v1[c] = v0[c] - cmv[c]; }
+            }
+            m->ref[q] = (int8_t)r0; m->ref1[q] = 0;
+            m->mv[r][0] = (int16_t)v0[0]; m->mv[r][1] = (int16_t)v0[1]; m->mv1[r][0] = (int16_t)v1[0]; m->mv1[r][1] = (int16_t)v1[1];
+        }
+    }
+    m->direct8 |= (uint8_t)mask;
+}
+/* temporal direct needs the colocated block's reference in list 0; the generator only emits it when that holds for every block */
+static int temporal_direct_ok(Enc *e, int mx, int my) {
+    for (int r = 0; r < 16; r++) { int cref, cmv[2], cid, found = 0; col_motion(e, mx, my, r, &cref, cmv, &cid); if (cref < 0) continue;
+        for (int i = 0; i < e->nlist0; i++) if (e->list0[i]->id == cid) found = 1;
+        if (!found) return 0; }
+    return 1;
+}
+/* prediction samples of one 4x4 block from one reference (literal, clamped: direct vectors may point anywhere) */
+static void sample4(Enc *e, const Frame *r, int px, int py, int mvx, int mvy, int *yl, int *cu, int *cv) {
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
+    int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
+    for (int pl = 0; pl < 2; pl++) { const uint8_t *rp = pl ? r->v : r->u; int *o = pl ? cv : cu;
+        for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
+            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1), D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
+            o[y * 2 + x] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6; } }
+}
+/* 8.4.2.3 for one colour component cmp (0 Y, 1 Cb, 2 Cr) of a block predicted from list entries r0 / r1 (-1 = unused) */
+static void weigh(Enc *e, int cmp, int r0, int r1, const int *a, const int *b, int n, int *out) {
+    int mode = e->slice_type == 0 ? (e->p.wp == 1) : e->p.wp, lg = e->wlog[cmp != 0];
+    for (int i = 0; i < n; i++) {
+        int v;
+        if (r0 >= 0 && r1 >= 0) {
+            if (mode == 0) v = (a[i] + b[i] + 1) >> 1;
+            else {
+                int w0, w1, o = 0, sh = 5;
+                if (mode == 1) { w0 = e->ww[0][r0][cmp]; w1 = e->ww[1][r1][cmp]; o = (e->wo[0][r0][cmp] + e->wo[1][r1][cmp] + 1) >> 1; sh = lg; }
+                else {
+                    int td = CLIP3(-128, 127, e->list1[r1]->poc - e->list0[r0]->poc), tb = CLIP3(-128, 127, e->cur_poc - e->list0[r0]->poc);
+                    w0 = w1 = 32;
+                    if (td != 0) { int tx = (16384 + ABS(td / 2)) / td, sc = CLIP3(-1024, 1023, (tb * tx + 32) >> 6) >> 2; if (sc >= -64 && sc <= 128) { w1 = sc; w0 = 64 - sc; } }
+                }
+                v = CLIP1(((a[i] * w0 + b[i] * w1 + (1 << sh)) >> (sh + 1)) + o);
+            }
+        } else {
+            int l = r0 >= 0 ? 0 : 1, r = l ? r1 : r0; const int *p = l ? b : a;
+            if (mode == 1) v = CLIP1((lg >= 1 ? ((p[i] * e->ww[l][r][cmp] + (1 << (lg - 1))) >> lg) : p[i] * e->ww[l][r][cmp]) + e->wo[l][r][cmp]);
+            else v = p[i];
+        }
+        out[i] = v;
+    }
+}
+/* motion compensation of the whole macroblock from m's refs / vectors (both lists, weights) into the current frame */
+static void mc_mb(Enc *e, int mx, int my, MbE *m) {
+    Frame *c = &e->cur;
+    for (int r = 0; r < 16; r++) {
+        int q = (r >> 3) * 2 + ((r & 3) >> 1), px = mx * 16 + (r & 3) * 4, py = my * 16 + (r >> 2) * 4;
+        int r0 = m->ref[q], r1 = m->ref1[q], y0[16], y1[16], u0[4], u1[4], v0[4], v1[4], oy[16], ou[4], ov[4];
+        if (r0 >= 0) sample4(e, e->list0[r0], px, py, m->mv[r][0], m->mv[r][1], y0, u0, v0);
+        if (r1 >= 0) sample4(e, e->list1[r1], px, py, m->mv1[r][0], m->mv1[r][1], y1, u1, v1);
+        weigh(e, 0, r0, r1, y0, y1, 16, oy); weigh(e, 1, r0, r1, u0, u1, 4, ou); weigh(e, 2, r0, r1, v0, v1, 4, ov);
+        for (int i = 0; i < 16; i++) c->y[(py + (i >> 2)) * c->sy + px + (i & 3)] = (uint8_t)oy[i];
+        for (int i = 0; i < 4; i++) { c->u[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ou[i]; c->v[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ov[i]; }
+    }
+}
+static int sad_mb(Enc *e, int mx, int my) {
+    const Frame *s = &e->src, *c = &e->cur; int sad = 0;
+    for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) sad += ABS(s->y[(my * 16 + y) * s->sy + mx * 16 + x] - c->y[(my * 16 + y) * c->sy + mx * 16 + x]);
+    return sad;
+}
+/* B-slice syntax elements (Tables 7-14, 7-18, 9-37) */
+static void se_skip_flag_b(Enc *e, int mx, int my, int skip) {
+    MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+    cab_enc(&e->cab, 24 + (a && !a->skip) + (b && !b->skip), skip);
+}
+static void se_mb_type_b(Enc *e, int mx, int my, int t) {            /* t: 0..22 inter types */
+    if (!e->cabac) { bw_ue(&e->bw, t); return; }
+    CabEnc *c = &e->cab; MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+    cab_enc(c, 27 + (a && !a->bdirect16) + (b && !b->bdirect16), t != 0);
+    if (t == 0) return;
+    if (t <= 2) { cab_enc(c, 30, 0); cab_enc(c, 32, t == 2); return; }
+    cab_enc(c, 30, 1);
+    int bits, extra = -1;                                                /* 4 bins, then one more for types 12..21 */
+    if (t <= 10) bits = t - 3; else if (t == 11) bits = 14; else if (t == 22) bits = 15; else { bits = (t + 4) >> 1; extra = (t + 4) & 1; }
+    cab_enc(c, 31, (bits >> 3) & 1); cab_enc(c, 32, (bits >> 2) & 1); cab_enc(c, 32, (bits >> 1) & 1); cab_enc(c, 32, bits & 1);
+    if (extra >= 0) cab_enc(c, 32, extra);
+}
+static void se_mb_type_b_intra_prefix(Enc *e, int mx, int my) {        /* prefix 1 1 1 1 0 1 (bits == 13) before the intra suffix */
+    CabEnc *c = &e->cab; MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1);
+    cab_enc(c, 27 + (a && !a->bdirect16) + (b && !b->bdirect16), 1);
+    cab_enc(c, 30, 1); cab_enc(c, 31, 1); cab_enc(c, 32, 1); cab_enc(c, 32, 0); cab_enc(c, 32, 1);
+}
+static void se_sub_mb_type_b(Enc *e, int st) {
+    if (!e->cabac) { bw_ue(&e->bw, st); return; }
+    CabEnc *c = &e->cab;
+    if (st == 0) { cab_enc(c, 36, 0); return; }
+    cab_enc(c, 36, 1);
+    if (st <= 2) { cab_enc(c, 37, 0); cab_enc(c, 39, st == 2); return; }
+    cab_enc(c, 37, 1);
+    if (st >= 11) { cab_enc(c, 38, 1); cab_enc(c, 39, 1); cab_enc(c, 39, st == 12); return; }
+    if (st >= 7) { cab_enc(c, 38, 1); cab_enc(c, 39, 0); st -= 4; } else cab_enc(c, 38, 0);
+    cab_enc(c, 39, ((st - 3) >> 1) & 1); cab_enc(c, 39, (st - 3) & 1);
+}
+static void se_ref_idx_l(Enc *e, int mx, int my, MbE *m, int l, int bx, int by, int nref, int v) {
+    if (!e->cabac) { bw_te(&e->bw, nref - 1, v); return; }
+    int inc = 0;
+    for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r); int q = (r >> 3) * 2 + ((r & 3) >> 1);
+        if (n && !n->intra && !(n->direct8 & (1 << q)) && mb_ref(n, l)[q] > 0) inc += k == 0 ? 1 : 2; }
+    int ctx = 54 + inc;
+    for (int i = 0; i < v; i++) { cab_enc(&e->cab, ctx, 1); ctx = 54 + (i == 0 ? 4 : 5); }
+    cab_enc(&e->cab, ctx, 0);
+}
+static void se_mvd_l(Enc *e, int mx, int my, MbE *m, int l, int bx, int by, int bw, int bh, int dx, int dy) {
+    if (!e->cabac) { bw_se(&e->bw, dx); bw_se(&e->bw, dy); return; }
+    CabEnc *c = &e->cab;
+    for (int comp = 0; comp < 2; comp++) {
+        int d = comp ? dy : dx, a = ABS(d), sum = 0, base = comp ? 47 : 40;
+        for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r); if (n && !n->intra) sum += (l ? n->mvd1 : n->mvd)[r][comp]; }
+        cab_enc(c, base + (sum < 3 ? 0 : sum > 32 ? 2 : 1), a > 0);
+        if (!a) continue;
+        int v = 1, ctx = 3;
+        while (v < 9) { int bin = a > v; cab_enc(c, base + ctx, bin); if (!bin) break; v++; if (ctx < 6) ctx++; }
+        if (a >= 9) cab_ueg(c, a - 9, 3);
+        cab_byp(c, d < 0);
+    }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { (l ? m->mvd1 : m->mvd)[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255); (l ? m->mvd1 : m->mvd)[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
+}
+
+typedef struct { int bx, by, bw, bh, pred /*0 L0 1 L1 2 Bi 3 direct*/, shape, part, q; } BPart;
+
+static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
+    static const uint8_t pair[9][2] = {{0, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 2}, {1, 2}, {2, 0}, {2, 1}, {2, 2}};
+    static const uint8_t sub_pred[13] = {3, 0, 1, 2, 0, 0, 1, 1, 2, 2, 0, 1, 2}, sub_shape[13] = {0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};
+    int fuzz = e->p.mode == 1, px = mx * 16, py = my * 16;
+    int nref[2] = { e->nlist0, e->nlist1 };
+    int direct_ok = e->p.direct_temporal ? temporal_direct_ok(e, mx, my) : 1;
+    static MbCode mc; memset(&mc, 0, sizeof mc);
+    /* ---- choose the macroblock type ---- */
+    int mbt, sub[4] = {0, 0, 0, 0};
+    if (fuzz) {
+        int k = rnd_n(&e->rng, 24);
+        if (k == 0) { se_begin_mb(e, mx, my, skip_run); encode_intra_mb(e, mx, my, m, rnd_n(&e->rng, 12) == 0 ? 7 : -1); return; }
+        if (k < 6) mbt = 0; else if (k < 11) mbt = 1 + rnd_n(&e->rng, 3); else if (k < 17) mbt = 4 + rnd_n(&e->rng, 18); else mbt = 22;
+        if (mbt == 22) for (int i = 0; i < 4; i++) sub[i] = rnd_n(&e->rng, 13);
+        if (!direct_ok) { if (mbt == 0) mbt = 3; for (int i = 0; i < 4; i++) if (sub[i] == 0) sub[i] = 3; }
+    } else mbt = -1;                                                     /* decided below by SAD */
+    BPart parts[16]; int np = 0, dmask = 0;
+    int want[2][16][2]; memset(want, 0, sizeof want);                    /* real mode: vectors found by the search, per 4x4 */
+    if (!fuzz) {
+        int best = 1 << 30, cand = 0, mvp[2], r16[2][2] = {{0, 0}, {0, 0}}, cost[4];
+        for (int l = 0; l < 2; l++) {                                   /* 16x16 search per list around that list's predictor */
+            e->decoded_mask = 0; pred_mv_l(e, mx, my, m, l, 0, 0, 4, 0, 0, 0, mvp);
+            MvRes r = search_block(e, l ? e->list1[0] : e->list0[0], px, py, 16, 16, mvp, mvp[0], mvp[1], e->p.search);
+            r16[l][0] = r.mvx; r16[l][1] = r.mvy; cost[1 + l] = r.cost;
+        }
+        mb_init(e, m);
+        if (direct_ok) { b_direct(e, mx, my, m, 15); mc_mb(e, mx, my, m); cost[0] = sad_mb(e, mx, my) - 64; } else cost[0] = 1 << 30;
+        mb_init(e, m);
+        for (int i = 0; i < 4; i++) { m->ref[i] = 0; m->ref1[i] = 0; }
+        for (int r = 0; r < 16; r++) { m->mv[r][0] = (int16_t)r16[0][0]; m->mv[r][1] = (int16_t)r16[0][1]; m->mv1[r][0] = (int16_t)r16[1][0]; m->mv1[r][1] = (int16_t)r16[1][1]; }
+        mc_mb(e, mx, my, m); cost[3] = sad_mb(e, mx, my) + 32;
+        mb_init(e, m);
+        for (int i = 0; i < 4; i++) if (cost[i] < best) { best = cost[i]; cand = i; }
+        mbt = cand;
+        for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) { want[l][r][0] = r16[l][0]; want[l][r][1] = r16[l][1]; }
+        if (best > 16 * 16 * 12) { se_begin_mb(e, mx, my, skip_run); encode_intra_mb(e, mx, my, m, -1); return; }
+    }
+    /* ---- partitions in syntax order ---- */
+    if (mbt == 0) { dmask = 15; m->bdirect16 = 1; }
+    else if (mbt <= 3) { BPart p = {0, 0, 4, 4, mbt - 1, 0, 0, 0}; parts[np++] = p; }
+    else if (mbt <= 21) { int sh = (mbt & 1) ? 2 : 1; for (int i = 0; i < 2; i++) { BPart p = { sh == 2 ? i * 2 : 0, sh == 1 ? i * 2 : 0, sh == 2 ? 2 : 4, sh == 1 ? 2 : 4, pair[(mbt - 4) >> 1][i], sh, i, 0 }; parts[np++] = p; } }
+    else for (int q = 0; q < 4; q++) {
+        int pr = sub_pred[sub[q]], sp = sub_shape[sub[q]], ox = (q & 1) * 2, oy = (q >> 1) * 2;
+        if (pr == 3) { dmask |= 1 << q; BPart p = {ox, oy, 2, 2, 3, 0, 0, q}; parts[np++] = p; continue; }
+        int n = sp == 0 ? 1 : sp == 3 ? 4 : 2, bw = (sp == 0 || sp == 1) ? 2 : 1, bh = (sp == 0 || sp == 2) ? 2 : 1;
+        for (int i = 0; i < n; i++) { BPart p = { ox + (sp == 1 ? 0 : sp == 2 ? i : (i & 1)), oy + (sp == 1 ? i : sp == 2 ? 0 : (i >> 1)), bw, bh, pr, 0, 0, q }; parts[np++] = p; }
+    }
+    if (dmask) b_direct(e, mx, my, m, dmask);
+    /* reference indices */
+    int refs[2][16];
+    for (int l = 0; l < 2; l++) for (int i = 0; i < np; i++) {
+        BPart *p = &parts[i]; refs[l][i] = -1;
+        if (p->pred == 3 || !(p->pred == 2 || p->pred == l)) continue;
+        if (mbt == 22 && i > 0 && parts[i - 1].q == p->q && parts[i - 1].pred != 3) refs[l][i] = refs[l][i - 1];   /* one ref_idx per sub-macroblock */
+        else refs[l][i] = (fuzz && nref[l] > 1) ? rnd_n(&e->rng, nref[l]) : 0;
+        for (int y = p->by; y < p->by + p->bh; y++) for (int x = p->bx; x < p->bx + p->bw; x++) mb_ref(m, l)[(y >> 1) * 2 + (x >> 1)] = (int8_t)refs[l][i];
+    }
+    /* motion vectors, list by list in syntax order */
+    int mvd[2][16][2]; memset(mvd, 0, sizeof mvd);
+    for (int l = 0; l < 2; l++) {
+        e->decoded_mask = 0;
+        for (int i = 0; i < np; i++) {
+            BPart *p = &parts[i];
+            if (refs[l][i] < 0) { for (int y = p->by; y < p->by + p->bh; y++) for (int x = p->bx; x < p->bx + p->bw; x++) e->decoded_mask |= 1 << (y * 4 + x); continue; }
+            int mvp[2], mv[2];
+            pred_mv_l(e, mx, my, m, l, p->bx, p->by, p->bw, refs[l][i], p->shape, p->part, mvp);
+            if (fuzz) random_mv(e, px + p->bx * 4, py + p->by * 4, p->bw * 4, p->bh * 4, mvp, mv); else { mv[0] = want[l][p->by * 4 + p->bx][0]; mv[1] = want[l][p->by * 4 + p->bx][1]; }
+            mvd[l][i][0] = mv[0] - mvp[0]; mvd[l][i][1] = mv[1] - mvp[1];
+            store_mv_l(e, m, l, p->bx, p->by, p->bw, p->bh, mv[0], mv[1]);
+        }
+    }
+    for (int q = 0; q < 4; q++) { m->refid[q] = m->ref[q] >= 0 ? e->list0[m->ref[q]]->id : -1; m->refid1[q] = m->ref1[q] >= 0 ? e->list1[m->ref1[q]]->id : -1; }
+    /* ---- prediction + residual ---- */
+    mc_mb(e, mx, my, m);
+    int try_skip = mbt == 0 && (fuzz ? rnd_n(&e->rng, 3) != 0 : 0);
+    int dqp = 0;
+    if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
+    int qp = CLIP3(10, 48, e->qp_run + dqp); dqp = qp - e->qp_run;
+    int small = 0;                                                       /* a partition below 8x8, or direct without direct_8x8_inference */
+    for (int i = 0; i < np; i++) if (parts[i].bw < 2 || parts[i].bh < 2 || (parts[i].pred == 3 && !e->p.dinf8)) small = 1;
+    if (mbt == 0 && !e->p.dinf8) small = 1;
+    int t8_ok = e->p.t8x8 && !small, use_t8 = t8_ok && (fuzz ? rnd_n(&e->rng, 2) : 1), cbp_l = 0;
+    if (!try_skip && use_t8) { for (int b8 = 0; b8 < 4; b8++) if (code_luma8(e, px + (b8 & 1) * 8, py + (b8 >> 1) * 8, qp, 0, mc.luma8[b8])) cbp_l |= 1 << b8; }
+    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    if (!cbp_l) use_t8 = 0;
+    mc.t8 = use_t8;
+    int qpc = chroma_qp_of(e, qp), cflags = 0;
+    if (!try_skip) for (int pl = 0; pl < 2; pl++) cflags |= code_chroma(e, mx, my, pl, qpc, 0, &mc);
+    int cbp_c = (cflags & 2) ? 2 : (cflags & 1) ? 1 : 0;
+    for (int pl = 0; pl < 2; pl++) recon_chroma(e, mx, my, pl, qpc, &mc, cbp_c >= 1, cbp_c == 2);
+    mc.cbp = cbp_l | (cbp_c << 4); mc.type = 0;
+    /* ---- B_Skip ---- */
+    if (mbt == 0 && mc.cbp == 0 && !(fuzz && rnd_n(&e->rng, 4) == 0)) {
+        m->skip = 1; m->qp = (uint8_t)e->qp_run; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, e->qp_run);
+        if (e->cabac) { se_skip_flag_b(e, mx, my, 1); e->last_dqp = 0; } else (*skip_run)++;
+        return;
+    }
+    if (e->cabac) se_skip_flag_b(e, mx, my, 0); else { bw_ue(&e->bw, *skip_run); *skip_run = 0; }
+    se_mb_type_b(e, mx, my, mbt);
+    if (mbt == 22) for (int q = 0; q < 4; q++) se_sub_mb_type_b(e, sub[q]);
+    for (int l = 0; l < 2; l++) for (int i = 0; i < np; i++) {
+        BPart *p = &parts[i];
+        if (refs[l][i] < 0 || nref[l] <= 1) continue;
+        if (mbt == 22 && i > 0 && parts[i - 1].q == p->q) continue;       /* ref_idx once per sub-macroblock */
+        se_ref_idx_l(e, mx, my, m, l, mbt == 22 ? (p->q & 1) * 2 : p->bx, mbt == 22 ? (p->q >> 1) * 2 : p->by, nref[l], refs[l][i]);
+    }
+    for (int l = 0; l < 2; l++) for (int i = 0; i < np; i++) if (refs[l][i] >= 0) se_mvd_l(e, mx, my, m, l, parts[i].bx, parts[i].by, parts[i].bw, parts[i].bh, mvd[l][i][0], mvd[l][i][1]);
+    se_cbp(e, mx, my, mc.cbp, 0); m->cbp = (uint8_t)mc.cbp;
+    if (cbp_l && t8_ok) se_t8_flag(e, mx, my, use_t8);
+    m->t8 = (uint8_t)use_t8;
+    if (mc.cbp > 0) { se_dqp(e, dqp); e->qp_run = qp; } else { qp = e->qp_run; e->last_dqp = 0; }
+    m->qp = (uint8_t)qp; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, qp);
+    if (mc.cbp > 0) write_mb_residual(e, mx, my, m, &mc);
+}
+
 /* ------------------------------ headers -------------------------------------- */
 static void write_sps_pps(Enc *e) {
     BitW *w = &e->bw; GenParams *p = &e->p;
     w->len = 0; w->nbits = 0; w->cur = 0;
     if (p->t8x8) { bw_put(w, 8, 100); bw_put(w, 8, 0); }                  /* High */
-    else if (p->cabac) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
+    else if (p->cabac || p->bframes || p->wp) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
     else { bw_put(w, 8, 66); bw_put(w, 8, 0xC0); }                        /* Baseline, constraint_set0/1 */
     bw_put(w, 8, p->level_idc);
     bw_ue(w, 0);
@@ -1370,7 +1719,7 @@ static void write_sps_pps(Enc *e) {
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
     bw_ue(w, p->num_ref); bw_put(w, 1, 0);
     bw_ue(w, e->mbw - 1); bw_ue(w, e->mbh - 1);
-    bw_put(w, 1, 1); bw_put(w, 1, 1);                                     /* frame_mbs_only, direct_8x8_inference */
+    bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)p->dinf8);                    /* frame_mbs_only, direct_8x8_inference */
     int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / 2;
     if (cr || cb) { bw_put(w, 1, 1); bw_ue(w, 0); bw_ue(w, cr); bw_ue(w, 0); bw_ue(w, cb); } else bw_put(w, 1, 0);
     bw_put(w, 1, 0);                                                      /* no VUI */
@@ -1378,24 +1727,55 @@ static void write_sps_pps(Enc *e) {
     w->len = 0;
     bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, 0); bw_ue(w, 0);
     bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
-    bw_put(w, 1, 0); bw_put(w, 2, 0);
+    bw_put(w, 1, (uint32_t)(p->wp == 1)); bw_put(w, 2, (uint32_t)(p->bframes ? p->wp : 0));   /* weighted_pred_flag, weighted_bipred_idc */
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
     bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
     if (p->t8x8) { bw_put(w, 1, 1); bw_put(w, 1, 0); bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, no scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
 }
 
-static void encode_frame(Enc *e, int t) {
+/* t = display index; kind: 0 P (or IDR/I when t starts a GOP), 1 B (non-reference, coded after its following anchor) */
+static void encode_frame(Enc *e, int t, int is_b) {
     GenParams *p = &e->p; BitW *w = &e->bw;
-    int idr = (t % p->gop) == 0;
-    int is_ref = idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0);
+    int idr = !is_b && (t % p->gop) == 0;
+    int is_ref = !is_b && (idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0));
+    if (p->bframes) is_ref = !is_b;
     render_source(e, t);
     if (idr) { e->frame_num = 0; e->nrefs = 0; write_sps_pps(e); }
-    e->slice_type = idr ? 2 : 0;
-    if (!idr && p->mode == 1 && rnd_n(&e->rng, 12) == 0) e->slice_type = 2;   /* occasional non-IDR I picture */
-    /* RefPicList0: short-term refs by descending PicNum == most recent first */
-    e->nlist0 = MIN(e->nrefs, p->num_ref);
-    for (int i = 0; i < e->nlist0; i++) e->list0[i] = &e->refs[i];
+    e->slice_type = idr ? 2 : (is_b ? 1 : 0);
+    if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0) e->slice_type = 2;   /* occasional non-IDR I picture */
+    e->cur_poc = 2 * (t % p->gop); e->cur.poc = e->cur_poc;
+    if (!is_b) {
+        /* RefPicList0: short-term refs by descending PicNum == most recent first */
+        e->nlist0 = MIN(e->nrefs, p->num_ref); e->nlist1 = 0;
+        for (int i = 0; i < e->nlist0; i++) e->list0[i] = &e->refs[i];
+    } else {
+        /* 8.2.4.2.3: list 0 = earlier pictures by descending POC then later ones ascending; list 1 the other way round */
+        Frame *before[5], *after[5]; int nb = 0, na = 0, n = MIN(e->nrefs, p->num_ref);
+        for (int i = 0; i < n; i++) { if (e->refs[i].poc < e->cur_poc) before[nb++] = &e->refs[i]; else after[na++] = &e->refs[i]; }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Frame *x = before[i]; before[i] = before[j]; before[j] = x; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Frame *x = after[i]; after[i] = after[j]; after[j] = x; }
+        e->nlist0 = e->nlist1 = 0;
+        for (int i = 0; i < nb; i++) e->list0[e->nlist0++] = before[i];
+        for (int i = 0; i < na; i++) e->list0[e->nlist0++] = after[i];
+        for (int i = 0; i < na; i++) e->list1[e->nlist1++] = after[i];
+        for (int i = 0; i < nb; i++) e->list1[e->nlist1++] = before[i];
+        if (e->nlist1 > 1) { int same = 1; for (int i = 0; i < e->nlist0; i++) if (e->list0[i] != e->list1[i]) same = 0; if (same) { Frame *x = e->list1[0]; e->list1[0] = e->list1[1]; e->list1[1] = x; } }
+        if (p->mode == 1) { e->nlist0 = 1 + rnd_n(&e->rng, e->nlist0); e->nlist1 = 1 + rnd_n(&e->rng, e->nlist1); }   /* num_ref_idx_active override */
+    }
+    /* explicit weights of this picture (8.4.2.3); the same table is sent in every slice */
+    e->wlog[0] = 5; e->wlog[1] = 5;
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) for (int c = 0; c < 3; c++) { e->ww[l][i][c] = 32; e->wo[l][i][c] = 0; }
+    int use_wp = (e->slice_type == 0 && p->wp == 1) || (e->slice_type == 1 && p->wp == 1);
+    if (use_wp) {
+        e->wlog[0] = 3 + rnd_n(&e->rng, 4); e->wlog[1] = 2 + rnd_n(&e->rng, 4);
+        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) for (int c = 0; c < 3; c++) {
+            int one = 1 << e->wlog[c != 0];
+            e->ww[l][i][c] = one; e->wo[l][i][c] = 0;
+            if (rnd_n(&e->rng, 3)) { e->ww[l][i][c] = one + rnd_n(&e->rng, one / 2 + 1) - one / 4; e->wo[l][i][c] = rnd_n(&e->rng, 13) - 6; }
+        }
+        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) if (e->ww[l][i][1] == (1 << e->wlog[1]) && e->wo[l][i][1] == 0 && (e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0)) e->wo[l][i][1] = 1;   /* one chroma flag covers Cb and Cr */
+    }
     e->cur.id = e->next_id++;
     int mbs_total = e->mbw * e->mbh, rows_per = (e->mbh + p->slices - 1) / p->slices;
     for (int i = 0; i < mbs_total; i++) e->mbs[i].slice = -1;
@@ -1408,14 +1788,25 @@ static void encode_frame(Enc *e, int t) {
         bw_ue(w, 0);
         bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
         if (idr) bw_ue(w, e->idr_id & 0xffff);
-        if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (2 * (t % p->gop)) & ((1 << e->poc_lsb_bits) - 1));
+        if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_poc & ((1u << e->poc_lsb_bits) - 1));
+        if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); bw_put(w, 1, 0); }
+        if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); bw_put(w, 1, 0); bw_put(w, 1, 0); }   /* override, no list modification */
+        if (use_wp) {                                                     /* pred_weight_table() */
+            bw_ue(w, e->wlog[0]); bw_ue(w, e->wlog[1]);
+            for (int l = 0; l < (e->slice_type == 1 ? 2 : 1); l++) for (int i = 0; i < (l ? e->nlist1 : e->nlist0); i++) {
+                int fy = e->ww[l][i][0] != (1 << e->wlog[0]) || e->wo[l][i][0] != 0;
+                int fc = e->ww[l][i][1] != (1 << e->wlog[1]) || e->wo[l][i][1] != 0 || e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0;
+                bw_put(w, 1, (uint32_t)fy); if (fy) { bw_se(w, e->ww[l][i][0]); bw_se(w, e->wo[l][i][0]); }
+                bw_put(w, 1, (uint32_t)fc); if (fc) for (int c = 1; c < 3; c++) { bw_se(w, e->ww[l][i][c]); bw_se(w, e->wo[l][i][c]); }
+            }
+        }
         if (is_ref) { if (idr) { bw_put(w, 1, 0); bw_put(w, 1, 0); } else bw_put(w, 1, 0); }
         if (e->cabac && e->slice_type != 2) bw_ue(w, p->cabac_idc);
         bw_se(w, 0);                                                      /* slice_qp_delta */
         int idc = p->deblock == 1 ? 0 : (p->deblock == 0 ? 1 : 2);
         bw_ue(w, idc); if (idc != 1) { bw_se(w, p->alpha_off); bw_se(w, p->beta_off); }
-        int skip_run = e->slice_type == 0 ? 0 : -1;
+        int skip_run = e->slice_type != 2 ? 0 : -1;
         if (e->cabac) {
             while (w->nbits) bw_put(w, 1, 1);                             /* cabac_alignment_one_bit */
             cab_init_ctx(&e->cab, e->slice_type == 2 ? 0 : 1 + p->cabac_idc, p->qp);
@@ -1427,6 +1818,7 @@ static void encode_frame(Enc *e, int t) {
             int before = bw_bitpos(w);
             if (p->pcm_only) { se_begin_mb(e, mx, my, &skip_run); encode_intra_mb(e, mx, my, m, 7); }
             else if (e->slice_type == 2) { int force = -1; if (p->mode == 1 && rnd_n(&e->rng, 40) == 0) force = 7; encode_intra_mb(e, mx, my, m, force); }
+            else if (e->slice_type == 1) encode_b_mb(e, mx, my, m, &skip_run);
             else encode_p_mb(e, mx, my, m, &skip_run);
             if (e->cabac) cab_term(&e->cab, my == last_row - 1 && mx == e->mbw - 1);      /* end_of_slice_flag */
             e->stat_bits_mb[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)] += bw_bitpos(w) - before;
@@ -1441,21 +1833,25 @@ static void encode_frame(Enc *e, int t) {
         for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x]; se += d * d; }
         for (int i = 0; i < mbs_total; i++) { MbE *m = &e->mbs[i]; cnt[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)]++; if (!m->intra) for (int k = 0; k < 16; k++) { nzmv += m->mv[k][0] || m->mv[k][1]; qmv += (m->mv[k][0] & 3) || (m->mv[k][1] & 3); } }
         double mse = se / (p->width * p->height);
-        fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t, idr ? 'I' : (e->slice_type == 2 ? 'i' : 'P'), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
+        fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t, idr ? 'I' : (e->slice_type == 2 ? 'i' : (is_b ? 'B' : 'P')), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
     }
-    if (e->recon) {
-        for (int y = 0; y < p->height; y++) fwrite(e->cur.y + y * e->cur.sy, 1, p->width, e->recon);
-        for (int y = 0; y < p->height / 2; y++) fwrite(e->cur.u + y * e->cur.sc, 1, p->width / 2, e->recon);
-        for (int y = 0; y < p->height / 2; y++) fwrite(e->cur.v + y * e->cur.sc, 1, p->width / 2, e->recon);
+    if (e->recon_buf && t < e->recon_frames) {                           /* display order */
+        uint8_t *o = e->recon_buf + (size_t)t * (p->width * p->height * 3 / 2);
+        for (int y = 0; y < p->height; y++) memcpy(o + (size_t)y * p->width, e->cur.y + y * e->cur.sy, p->width);
+        o += (size_t)p->width * p->height;
+        for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), e->cur.u + y * e->cur.sc, p->width / 2);
+        o += (size_t)(p->width / 2) * (p->height / 2);
+        for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), e->cur.v + y * e->cur.sc, p->width / 2);
     }
     if (is_ref) {
         frame_finish_ref(&e->cur, e->W, e->H);
+        if (!e->cur.mf) e->cur.mf = malloc(sizeof(MbE) * (size_t)mbs_total);
+        memcpy(e->cur.mf, e->mbs, sizeof(MbE) * (size_t)mbs_total);
         /* sliding window: newest first */
-        Frame tmp = e->refs[p->num_ref - 1 >= 0 ? MIN(e->nrefs, p->num_ref - 1) : 0];
         int n = MIN(e->nrefs, p->num_ref - 1);
         Frame last = e->refs[n];
         for (int i = n; i > 0; i--) e->refs[i] = e->refs[i - 1];
-        e->refs[0] = e->cur; e->cur = last; (void)tmp;
+        e->refs[0] = e->cur; e->cur = last;
         e->nrefs = MIN(e->nrefs + 1, p->num_ref);
         e->frame_num++;
     }
@@ -1475,6 +1871,9 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (p->search < 1) p->search = 4;
     if (!p->level_idc) p->level_idc = 40;
     if (p->poc_type != 0) p->poc_type = 2;
+    p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
+    if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
+    else { p->poc_type = 0; p->nonref_period = 0; if (p->num_ref < 2) p->num_ref = 2; p->dinf8 = p->dinf8 != 0; }
     p->cabac = p->cabac != 0; p->t8x8 = p->t8x8 != 0; p->cabac_idc = CLIP3(0, 2, p->cabac_idc);
     e->cabac = p->cabac;
     if (p->nonref_period == 1) p->nonref_period = 2;
@@ -1486,10 +1885,20 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     for (int i = 0; i < 5; i++) frame_alloc(&e->refs[i], e->W, e->H, 1);
     e->mbs = (MbE *)calloc((size_t)e->mbw * e->mbh, sizeof(MbE));
     make_texture(e);
-    if (recon_path) e->recon = fopen(recon_path, "wb");
-    for (int t = 0; t < p->frames; t++) encode_frame(e, t);
-    if (e->recon) fclose(e->recon);
+    if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames; e->recon_buf = (uint8_t *)calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
+    for (int g0 = 0; g0 < p->frames; g0 += p->gop) {                      /* coding order: every anchor before the B pictures that precede it in display order */
+        int g1 = MIN(p->frames, g0 + p->gop), prev = g0;
+        encode_frame(e, g0, 0);
+        while (prev + 1 < g1) {
+            int anchor = MIN(g1 - 1, prev + p->bframes + 1);
+            encode_frame(e, anchor, 0);
+            for (int t = prev + 1; t < anchor; t++) encode_frame(e, t, 1);
+            prev = anchor;
+        }
+    }
+    if (e->recon) { fwrite(e->recon_buf, 1, (size_t)p->frames * ((size_t)p->width * p->height * 3 / 2), e->recon); fclose(e->recon); free(e->recon_buf); }
     *out = e->out.buf; *out_len = e->out.len;
+    free(e->cur.mf); for (int i = 0; i < 5; i++) free(e->refs[i].mf);
     frame_free(&e->src); frame_free(&e->cur); for (int i = 0; i < 5; i++) frame_free(&e->refs[i]);
     free(e->mbs); free(e->bw.buf); free(e);
     return 0;
@@ -1499,7 +1908,7 @@ void h264gen_free(void *p) { free(p); }
 #ifndef H264GEN_NO_MAIN
 int main(int argc, char **argv) {
     GenParams p; memset(&p, 0, sizeof p);
-    p.width = 1920; p.height = 1080; p.frames = 30; p.qp = 28; p.gop = 30; p.seed = 0x4A4D0100; p.deblock = 1; p.num_ref = 1; p.slices = 1; p.search = 4;
+    p.width = 1920; p.height = 1080; p.frames = 30; p.qp = 28; p.gop = 30; p.seed = 0x4A4D0100; p.deblock = 1; p.num_ref = 1; p.slices = 1; p.search = 4; p.dinf8 = 1;
     const char *outp = NULL, *recon = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i]; const char *v = i + 1 < argc ? argv[i + 1] : "0";
@@ -1509,6 +1918,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
