@@ -95,6 +95,7 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "digest_mbs") return (long long)digest_.mbs;
     if (k == "i_pictures") return stat_i_;
     if (k == "p_pictures") return stat_p_;
+    if (k == "b_pictures") return stat_b_;
     if (k == "coded_width") return mb_w_ * 16;
     if (k == "coded_height") return mb_h_ * 16;
     if (k == "pitch") return pitch_;
@@ -182,7 +183,8 @@ void Decoder::gpu_close() {
 bool Decoder::gpu_alloc_sequence() {
     size_t n_mbs = (size_t)mb_w_ * mb_h_;
     frame_bytes_ = (size_t)disp_w_ * disp_h_ * 3 / 2;
-    job_cap_ = n_mbs * (sizeof(MbRec) + 816 + 64) + 256 * sizeof(SliceRec) + 4096;
+    // MbRec + worst-case coefficients + motion records (16 vectors; 72 int16 for B / weighted slices) + slice tables
+    job_cap_ = n_mbs * (sizeof(MbRec) + 816 + (seq_.profile_idc == 66 ? 64 : kBiRecInt16 * 2)) + 256 * (sizeof(SliceRec) + (seq_.profile_idc == 66 ? 0 : sizeof(SliceWp))) + 4096;
     if (parse_only_) {
         for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
         return true;
@@ -310,9 +312,7 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
     const SeqParams &sps = ps_.sps[pps.sps_id];
     {   // tools this build does not decode yet are refused, never decoded wrongly
         const char *why = nullptr;
-        if (sh.type == SL_B) why = "B slices are not supported yet";
-        else if (sh.wp_nondefault) why = "explicit weighted prediction is not supported yet";
-        else if (pps.scaling_matrix_present || sps.scaling_matrix_present) {
+        if (pps.scaling_matrix_present || sps.scaling_matrix_present) {
             bool flat = true;
             for (int i = 0; i < 6 && flat; i++) for (int k = 0; k < 16; k++) if (pps.scaling4[i][k] != 16) { flat = false; break; }
             for (int i = 0; i < 2 && flat; i++) for (int k = 0; k < 64; k++) if (pps.scaling8[i][k] != 16) { flat = false; break; }
@@ -418,17 +418,23 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
     DpbPic &c = dpb_[slot];
     c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
     c.poc = compute_poc(sh);
+    if (sps.profile_idc != 66 && sh.nal_ref_idc) c.mf = std::make_shared<MotionField>();   // a later B picture may use this one as its colocated picture
     pending_ = std::make_unique<PicTask>();
+    pending_->mf = c.mf;
     pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack; pending_->sps = sps; pending_->pps = pps;
     pending_->out_before = std::move(carry_out_); carry_out_.clear();
     first_sh_ = sh;
-    if (sh.type == SL_I) stat_i_++; else stat_p_++;
+    if (sh.type == SL_I) stat_i_++; else if (sh.type == SL_B) stat_b_++; else stat_p_++;
     return true;
 }
 
-// 8.2.4.2.1 + 8.2.4.3: RefPicList0 of a P slice, expressed as surface slots
-void Decoder::build_ref_list(const SliceHeader &sh, int8_t *ref_slot) {
-    memset(ref_slot, -1, 32);
+// 8.2.4.2 + 8.2.4.3: RefPicList0 / RefPicList1 of a slice, expressed as surface slots (+ what direct / weighted prediction need)
+void Decoder::build_ref_lists(const SliceHeader &sh, SliceTask &task) {
+    SliceRefs &rf = task.refs;
+    memset(rf.slot, -1, sizeof rf.slot); memset(rf.uid, -1, sizeof rf.uid); memset(rf.poc, 0, sizeof rf.poc); memset(rf.is_long, 0, sizeof rf.is_long);
+    rf.cur_poc = dpb_[cur_].poc;
+    rf.track_uid = seq_.profile_idc != 66;                   // Baseline has no B slices: nothing will ever ask for this picture's motion
+    rf.bipred_rec = sh.type == SL_B || sh.explicit_wp;
     if (sh.type == SL_I) return;
     int max_fn = 1 << seq_.log2_max_frame_num;
     int st[kMaxSurfaces], lt[kMaxSurfaces], nst = 0, nlt = 0;
@@ -438,32 +444,78 @@ void Decoder::build_ref_list(const SliceHeader &sh, int8_t *ref_slot) {
         if (p.ref == 1) { p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; st[nst++] = i; }
         else if (p.ref == 2) lt[nlt++] = i;
     }
-    std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].pic_num > dpb_[b].pic_num; });
     std::sort(lt, lt + nlt, [&](int a, int b) { return dpb_[a].lt_idx < dpb_[b].lt_idx; });
-    int list[34]; for (int &v : list) v = -1;
-    int n = 0, nact = sh.num_ref_idx[0];
-    for (int i = 0; i < nst && n < 33; i++) list[n++] = st[i];
-    for (int i = 0; i < nlt && n < 33; i++) list[n++] = lt[i];
-    for (int i = nact; i < 34; i++) list[i] = -1;
-    int pred = sh.frame_num, idx = 0;
-    for (int k = 0; k < sh.n_mod[0]; k++) {
-        const RefMod &m = sh.mod[0][k];
-        int target = -1;
-        if (m.idc < 2) {
-            int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
-            if (nowrap < 0) nowrap += max_fn;
-            if (nowrap >= max_fn) nowrap -= max_fn;
-            pred = nowrap;
-            int pic_num = nowrap > sh.frame_num ? nowrap - max_fn : nowrap;
-            for (int i = 0; i < nst; i++) if (dpb_[st[i]].pic_num == pic_num) target = st[i];
-        } else for (int i = 0; i < nlt; i++) if (dpb_[lt[i]].lt_idx == (int)m.val) target = lt[i];
-        if (target < 0 || idx >= nact) { stat_errors_++; break; }
-        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
-        list[idx++] = target;
-        int nidx = idx;
-        for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+    const int nlists = sh.type == SL_B ? 2 : 1;
+    int init[2][34], ninit[2] = {0, 0};
+    for (auto &row : init) for (int &v : row) v = -1;
+    if (sh.type == SL_P) {
+        std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].pic_num > dpb_[b].pic_num; });
+        for (int i = 0; i < nst && ninit[0] < 33; i++) init[0][ninit[0]++] = st[i];
+    } else {                                                // 8.2.4.2.3: by POC around the current picture
+        int before[kMaxSurfaces], after[kMaxSurfaces], nb = 0, na = 0, cp = dpb_[cur_].poc;
+        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].poc < cp) before[nb++] = st[i]; else after[na++] = st[i]; }
+        std::sort(before, before + nb, [&](int a, int b) { return dpb_[a].poc > dpb_[b].poc; });
+        std::sort(after, after + na, [&](int a, int b) { return dpb_[a].poc < dpb_[b].poc; });
+        for (int i = 0; i < nb; i++) init[0][ninit[0]++] = before[i];
+        for (int i = 0; i < na; i++) init[0][ninit[0]++] = after[i];
+        for (int i = 0; i < na; i++) init[1][ninit[1]++] = after[i];
+        for (int i = 0; i < nb; i++) init[1][ninit[1]++] = before[i];
     }
-    for (int i = 0; i < nact && i < 32; i++) ref_slot[i] = (int8_t)list[i];
+    for (int l = 0; l < nlists; l++) for (int i = 0; i < nlt && ninit[l] < 33; i++) init[l][ninit[l]++] = lt[i];
+    if (nlists == 2 && ninit[1] > 1 && ninit[0] == ninit[1] && std::equal(init[0], init[0] + ninit[0], init[1])) std::swap(init[1][0], init[1][1]);
+    if (sh.type == SL_P) std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].pic_num > dpb_[b].pic_num; });
+    for (int l = 0; l < nlists; l++) {
+        int *list = init[l];
+        int nact = sh.num_ref_idx[l];
+        for (int i = nact; i < 34; i++) list[i] = -1;
+        int pred = sh.frame_num, idx = 0;
+        for (int k = 0; k < sh.n_mod[l]; k++) {
+            const RefMod &m = sh.mod[l][k];
+            int target = -1;
+            if (m.idc < 2) {
+                int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
+                if (nowrap < 0) nowrap += max_fn;
+                if (nowrap >= max_fn) nowrap -= max_fn;
+                pred = nowrap;
+                int pic_num = nowrap > sh.frame_num ? nowrap - max_fn : nowrap;
+                for (int i = 0; i < nst; i++) if (dpb_[st[i]].pic_num == pic_num) target = st[i];
+            } else for (int i = 0; i < nlt; i++) if (dpb_[lt[i]].lt_idx == (int)m.val) target = lt[i];
+            if (target < 0 || idx >= nact) { stat_errors_++; break; }
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+        }
+        for (int i = 0; i < nact && i < 32; i++) {
+            rf.slot[l][i] = (int8_t)list[i];
+            if (list[i] >= 0) { rf.uid[l][i] = dpb_[list[i]].decode_idx; rf.poc[l][i] = dpb_[list[i]].poc; rf.is_long[l][i] = dpb_[list[i]].ref == 2; }
+        }
+    }
+    if (sh.type == SL_B && rf.slot[1][0] >= 0) { task.col = dpb_[rf.slot[1][0]].mf; rf.col = task.col.get(); }
+    // weighted prediction tables (8.4.2.3)
+    const PicParamSet &pps = ps_.pps[sh.pps_id];
+    int mode = sh.type == SL_P ? (sh.explicit_wp ? 1 : 0) : pps.weighted_bipred_idc;
+    task.has_wp = mode != 0;
+    if (task.has_wp) {
+        SliceWp &wp = task.wp;
+        memset(&wp, 0, sizeof wp);
+        wp.mode = (uint8_t)mode; wp.logwd_y = (uint8_t)sh.luma_log2_wd; wp.logwd_c = (uint8_t)sh.chroma_log2_wd;
+        if (mode == 1) {
+            for (int l = 0; l < nlists; l++) for (int i = 0; i < 16 && i < sh.num_ref_idx[l]; i++) {
+                wp.w[l][i][0] = (int8_t)sh.luma_w[l][i]; wp.o[l][i][0] = (int8_t)sh.luma_o[l][i];
+                for (int c = 0; c < 2; c++) { wp.w[l][i][1 + c] = (int8_t)sh.chroma_w[l][i][c]; wp.o[l][i][1 + c] = (int8_t)sh.chroma_o[l][i][c]; }
+            }
+        } else {
+            for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
+                int w1 = 32;
+                if (rf.slot[0][i] >= 0 && rf.slot[1][j] >= 0 && !rf.is_long[0][i] && !rf.is_long[1][j]) {
+                    int tb = std::clamp(rf.cur_poc - rf.poc[0][i], -128, 127), td = std::clamp(rf.poc[1][j] - rf.poc[0][i], -128, 127);
+                    if (td != 0) { int tx = (16384 + std::abs(td / 2)) / td, dsf = std::clamp((tb * tx + 32) >> 6, -1024, 1023) >> 2; if (dsf >= -64 && dsf <= 128) w1 = dsf; }
+                }
+                wp.imp_w1[i][j] = (uint8_t)(64 + w1);
+            }
+        }
+    }
 }
 
 void Decoder::add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size_t rbsp_len) {
@@ -471,7 +523,7 @@ void Decoder::add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size
     pending_->slices.emplace_back();
     SliceTask &s = pending_->slices.back();
     s.sh = sh; s.rbsp = std::move(rbsp); s.rbsp_len = rbsp_len;
-    build_ref_list(sh, s.ref_slot);
+    build_ref_lists(sh, s);
 }
 
 void Decoder::mark_current(const SliceHeader &sh) {                                 // 8.2.5
@@ -594,15 +646,16 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     SliceRec *srec = (SliceRec *)(js.host + (size_t)n_mbs * sizeof(MbRec));
     int16_t *coef = (int16_t *)(srec + 256);
     static thread_local std::vector<int16_t> mv_ext_buf;
-    mv_ext_buf.resize((size_t)n_mbs * 32);
+    const bool big_rec = t->sps.profile_idc != 66;
+    mv_ext_buf.resize((size_t)n_mbs * (big_rec ? kBiRecInt16 : 32));
     // default record = concealment (grey, not decoded)
     MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER; blank.ref[0] = blank.ref[1] = blank.ref[2] = blank.ref[3] = -1;
     for (int i = 0; i < n_mbs; i++) mbs[i] = blank;
     JobWriter w;
-    w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * 16;
+    w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * (big_rec ? kBiRecInt16 / 2 : 16);
     w.coef = coef;
     size_t fixed = (size_t)n_mbs * sizeof(MbRec) + 256 * sizeof(SliceRec);
-    w.coef_cap = (uint32_t)((js.cap - fixed - (size_t)n_mbs * 64) / 2);
+    w.coef_cap = (uint32_t)((js.cap - fixed - (size_t)n_mbs * (big_rec ? kBiRecInt16 * 2 : 64) - (big_rec ? 256 * sizeof(SliceWp) : 0)) / 2);
     SyntaxDigest dg = digest_;
     for (size_t si = 0; si < t->slices.size(); si++) {
         SliceTask &s = t->slices[si];
@@ -612,17 +665,33 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         br.set_end_from_trailing();
         br.skip_bytes(s.sh.data_bit_offset >> 3); br.skip((int)(s.sh.data_bit_offset & 7));
         if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
-        SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.ref_slot, scratch, w, want_digest_ ? &dg : nullptr);
+        if (s.col) s.col->wait();                            // direct prediction reads RefPicList1[0]'s motion: that picture was dispatched earlier
+        if (s.has_wp) t->any_wp = true;
+        SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr);
         t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
         if (r.error) { t->error = r.error; stat_errors_++; }
     }
     if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)
     t->n_slices = (int)t->slices.size();
-    // append mv_ext behind the coefficients (4-byte aligned)
+    if (t->mf) {                                             // publish this picture's motion for direct prediction in later B pictures
+        MotionField &f = *t->mf;
+        size_t n = (size_t)n_mbs;
+        f.mv[0].assign(scratch.mv.begin(), scratch.mv.begin() + n * 32); f.mv[1].assign(scratch.mv1.begin(), scratch.mv1.begin() + n * 32);
+        f.ref[0].assign(scratch.refidx.begin(), scratch.refidx.begin() + n * 4); f.ref[1].assign(scratch.refidx1.begin(), scratch.refidx1.begin() + n * 4);
+        f.uid[0].assign(scratch.uid0.begin(), scratch.uid0.begin() + n * 4); f.uid[1].assign(scratch.uid1.begin(), scratch.uid1.begin() + n * 4);
+        f.intra.resize(n);
+        for (size_t i = 0; i < n; i++) f.intra[i] = scratch.slice_of[i] < 0 || (scratch.info[i] & 1);
+        f.publish();
+    }
+    // append mv_ext behind the coefficients (4-byte aligned), then the weighted-prediction tables of the slices
     if (w.coef_count & 1) w.coef[w.coef_count++] = 0;
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
     t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count;
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
+    if (t->any_wp) {
+        t->wp_offset = t->upload_bytes;
+        for (auto &s : t->slices) { if (!s.has_wp) memset(&s.wp, 0, sizeof s.wp); memcpy(js.host + t->upload_bytes, &s.wp, sizeof(SliceWp)); t->upload_bytes += sizeof(SliceWp); }
+    }
     stat_pictures_++; stat_job_bytes_ += (long long)t->upload_bytes; stat_intra_mbs_ += t->n_intra; stat_coef_ += w.coef_count;
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
     if (!parse_only_ && !failed_) {
@@ -691,6 +760,7 @@ void Decoder::submit_task(PicTask *t) {
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
         pp.resid = (int16_t *)resid_; pp.dbrec = dbrec_;
+        pp.wp = t->any_wp ? (const SliceWp *)(js.dev + t->wp_offset) : nullptr;
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
         bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_);
         pp.want_intra_resid = lds_intra ? 1 : 0;

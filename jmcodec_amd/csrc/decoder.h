@@ -30,6 +30,7 @@ struct DpbPic {
     bool wait_output = false;
     int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
     int decode_idx = 0; bool mmco5 = false;
+    std::shared_ptr<MotionField> mf;
     int out_at = -100;                         // decode index of the picture after which this surface was displayed (cooling)
 };
 
@@ -37,13 +38,16 @@ struct SliceTask {
     SliceHeader sh;
     std::vector<uint8_t> rbsp;                 // unescaped NAL payload (+ slack)
     size_t rbsp_len = 0;
-    int8_t ref_slot[32];
+    SliceRefs refs;
+    std::shared_ptr<MotionField> col;          // keeps RefPicList1[0]'s motion field alive (B slices)
+    SliceWp wp; bool has_wp = false;           // weighted prediction tables of this slice
 };
 
 struct PicTask {
     uint64_t seq = 0;
     bool has_picture = false;
     int cur_slot = -1, job_slot = -1;
+    std::shared_ptr<MotionField> mf;           // this picture's motion field (reference pictures of streams that may hold B pictures)
     SeqParams sps; PicParamSet pps;
     std::vector<SliceTask> slices;
     std::vector<int> out_before, out_after;    // DPB slots to display before / after this picture
@@ -51,7 +55,7 @@ struct PicTask {
     // written by the parse worker
     std::atomic<int> state{0};                 // 0 queued, 1 parsed
     int n_intra = 0, n_i8x8 = 0, n_slices = 0; bool any_deblock = false;
-    uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0;
+    uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0, wp_offset = 0; bool any_wp = false;
     unsigned long long upload_seq = 0;
     std::string error;
     long long t_dispatch = 0, t_parsed = 0;    // host steady-clock ns (JM_AMD_DEC_TRACE)
@@ -97,7 +101,7 @@ private:
     bool start_picture(const SliceHeader &sh, const SeqParams &sps, const PicParamSet &pps);
     void add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size_t rbsp_len);
     void dispatch_pending();
-    void build_ref_list(const SliceHeader &sh, int8_t *ref_slot);
+    void build_ref_lists(const SliceHeader &sh, SliceTask &st);
     void mark_current(const SliceHeader &sh);
     int  compute_poc(const SliceHeader &sh);
     void bump_after_current(std::vector<int> &out);
@@ -169,7 +173,7 @@ private:
     std::atomic<long long> stat_parse_ns_i_{0}, stat_parse_ns_p_{0}, stat_submit_ns_{0}, stat_wait_slot_ns_{0};
     std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0};
     SyntaxDigest digest_;
-    long long stat_i_ = 0, stat_p_ = 0;
+    long long stat_i_ = 0, stat_p_ = 0, stat_b_ = 0;
     std::vector<int> display_pocs_;            // diagnostic (get via stats)
     struct TraceRec { uint64_t seq; long long t_dispatch, t_parsed, t_submit0, t_submit1; int is_i; };
     std::vector<TraceRec> trace_; bool trace_on_ = false;

@@ -101,6 +101,7 @@ void ParseScratch::resize(int w, int h) {
     size_t n = (size_t)w * h;
     tc.assign(n * 24, 0); mv.assign(n * 32, 0); refidx.assign(n * 4, -1); i4.assign(n * 16, 2); info.assign(n, 0); slice_of.assign(n, -1);
     cbp.assign(n, 0); cmode.assign(n, 0); cbf.assign(n, 0); mvd.assign(n * 32, 0);
+    mv1.assign(n * 32, 0); refidx1.assign(n * 4, -1); mvd1.assign(n * 32, 0); direct8.assign(n, 0); uid0.assign(n * 4, -1); uid1.assign(n * 4, -1);
 }
 void ParseScratch::begin_picture() { std::fill(slice_of.begin(), slice_of.end(), (int16_t)-1); }
 
@@ -117,11 +118,12 @@ static_assert(sizeof(Canon) == 4 + 4 + 16 + 4 + 64 + 32 + 512 + 16 + 256 + 4 + 6
 struct P {
     const SeqParams &sps; const PicParamSet &pps; const SliceHeader &sh;
     BitReader &br; ParseScratch &cx; JobWriter &out; SyntaxDigest *dg;
-    int slice_num; const int8_t *ref_slot;
+    int slice_num; const SliceRefs &rf;
     int mb_w, mb_x = 0, mb_y = 0, addr = 0, qp;
     // neighbour MB indices or -1
     int nA = -1, nB = -1, nC = -1, nD = -1;
     uint8_t *tc; int16_t *mv; int8_t *ref; uint8_t *i4m;
+    int16_t *mvl[2]; int8_t *refl[2]; uint8_t *mvdl[2];      // per list: [0] aliases mv / ref / mvd
     uint32_t decoded_mask = 0;
     Canon *canon = nullptr;
     Cabac *cb = nullptr;                 // non-null: entropy_coding_mode_flag = 1
@@ -136,6 +138,7 @@ struct P {
             int i = y * mb_w + x; return cx.slice_of[i] == slice_num ? i : -1; };
         nA = av(mb_x - 1, mb_y); nB = av(mb_x, mb_y - 1); nC = av(mb_x + 1, mb_y - 1); nD = av(mb_x - 1, mb_y - 1);
         tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16]; mvd = &cx.mvd[(size_t)a * 32];
+        mvl[0] = mv; mvl[1] = &cx.mv1[(size_t)a * 32]; refl[0] = ref; refl[1] = &cx.refidx1[(size_t)a * 4]; mvdl[0] = mvd; mvdl[1] = &cx.mvd1[(size_t)a * 32];
     }
     bool intra_usable(int n) const { return n >= 0 && (!pps.constrained_intra || (cx.info[n] & 1)); }
 
@@ -223,7 +226,7 @@ struct P {
 
     // ---- motion vector prediction (8.4.1.3) ---------------------------------------------
     struct Nb { bool avail; int ref; int mvx, mvy; };
-    Nb nb(int bx, int by) const {
+    Nb nb(int bx, int by, int l = 0) const {
         Nb n{false, -1, 0, 0};
         int m, rx, ry;
         if (by < 0) { ry = 3; if (bx < 0) { m = nD; rx = 3; } else if (bx > 3) { m = nC; rx = bx - 4; } else { m = nB; rx = bx; } }
@@ -232,14 +235,14 @@ struct P {
         else { if (!((decoded_mask >> (by * 4 + bx)) & 1)) return n; m = addr; rx = bx; ry = by; }
         if (m < 0) return n;
         n.avail = true;
-        n.ref = cx.refidx[(size_t)m * 4 + (ry >> 1) * 2 + (rx >> 1)];
-        if (n.ref >= 0) { const int16_t *q = &cx.mv[(size_t)m * 32 + (ry * 4 + rx) * 2]; n.mvx = q[0]; n.mvy = q[1]; }
+        n.ref = (l ? cx.refidx1 : cx.refidx)[(size_t)m * 4 + (ry >> 1) * 2 + (rx >> 1)];
+        if (n.ref >= 0) { const int16_t *q = &(l ? cx.mv1 : cx.mv)[(size_t)m * 32 + (ry * 4 + rx) * 2]; n.mvx = q[0]; n.mvy = q[1]; }
         return n;
     }
     static int med(int a, int b, int c) { int mx = a > b ? a : b, mn = a < b ? a : b; return c > mx ? mx : (c < mn ? mn : c); }
-    void predict(int bx, int by, int bw, int refi, int shape, int part, int &px, int &py) const {
-        Nb A = nb(bx - 1, by), B = nb(bx, by - 1), C = nb(bx + bw, by - 1);
-        if (!C.avail) C = nb(bx - 1, by - 1);
+    void predict(int bx, int by, int bw, int refi, int shape, int part, int &px, int &py, int l = 0) const {
+        Nb A = nb(bx - 1, by, l), B = nb(bx, by - 1, l), C = nb(bx + bw, by - 1, l);
+        if (!C.avail) C = nb(bx - 1, by - 1, l);
         if (shape == 1) { if (part == 0) { if (B.ref == refi) { px = B.mvx; py = B.mvy; return; } } else if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } }
         else if (shape == 2) { if (part == 0) { if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } } else if (C.ref == refi) { px = C.mvx; py = C.mvy; return; } }
         if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
@@ -247,8 +250,8 @@ struct P {
         if (ma + mb + mc == 1) { const Nb &n = ma ? A : (mb ? B : C); px = n.mvx; py = n.mvy; }
         else { px = med(A.mvx, B.mvx, C.mvx); py = med(A.mvy, B.mvy, C.mvy); }
     }
-    void set_mv(int bx, int by, int bw, int bh, int x, int y) {
-        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mv[(j * 4 + i) * 2] = (int16_t)x; mv[(j * 4 + i) * 2 + 1] = (int16_t)y; decoded_mask |= 1u << (j * 4 + i); }
+    void set_mv(int bx, int by, int bw, int bh, int x, int y, int l = 0) {
+        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvl[l][(j * 4 + i) * 2] = (int16_t)x; mvl[l][(j * 4 + i) * 2 + 1] = (int16_t)y; decoded_mask |= 1u << (j * 4 + i); }
     }
 
     // ---- macroblock start / finish -------------------------------------------------------
@@ -260,6 +263,7 @@ struct P {
         cx.slice_of[addr] = (int16_t)slice_num;
         memset(tc, 0, 24); ref[0] = ref[1] = ref[2] = ref[3] = -1; memset(mv, 0, 64); memset(i4m, 2, 16);
         cx.info[addr] = 0; decoded_mask = 0;
+        if (sh.type == SL_B || rf.track_uid) { refl[1][0] = refl[1][1] = refl[1][2] = refl[1][3] = -1; memset(mvl[1], 0, 64); memset(mvdl[1], 0, 32); cx.direct8[addr] = 0; }
         if (cb) { cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0; memset(mvd, 0, 32); }
         if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; canon->ref1[0] = canon->ref1[1] = canon->ref1[2] = canon->ref1[3] = -1; }
         return r;
@@ -267,7 +271,8 @@ struct P {
     void finish_mb(const MbRec *r) {
         if (!dg) return;
         canon->kind = r->kind; canon->qp = r->qp;
-        if ((r->kind & 15) == MB_INTER) { for (int i = 0; i < 4; i++) canon->ref[i] = ref[i]; memcpy(canon->mv, mv, 64); }
+        if ((r->kind & 15) == MB_INTER) { for (int i = 0; i < 4; i++) canon->ref[i] = ref[i]; memcpy(canon->mv, mv, 64);
+            if (sh.type == SL_B) { for (int i = 0; i < 4; i++) canon->ref1[i] = refl[1][i]; memcpy(canon->mv1, mvl[1], 64); } }
         const uint8_t *p = (const uint8_t *)canon;
         uint64_t h = dg->h;
         for (size_t i = 0; i < sizeof(Canon); i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -280,7 +285,18 @@ struct P {
         return p;
     }
     void write_motion(MbRec *r, bool sub8) {
-        for (int i = 0; i < 4; i++) r->ref[i] = ref[i] >= 0 ? ref_slot[ref[i]] : (int8_t)-1;
+        for (int i = 0; i < 4; i++) r->ref[i] = ref[i] >= 0 ? rf.slot[0][ref[i]] : (int8_t)-1;
+        if (rf.track_uid) for (int l = 0; l < 2; l++) { int32_t *u = &(l ? cx.uid1 : cx.uid0)[(size_t)addr * 4]; for (int i = 0; i < 4; i++) u[i] = refl[l][i] >= 0 ? rf.uid[l][refl[l][i]] : -1; }
+        if (rf.bipred_rec) {                                   // B slice / weighted prediction: full motion record (jobs.h MBM_BIPRED)
+            if (out.mv_ext_count + kBiRecInt16 / 2 > out.mv_ext_cap) { err = "mv_ext overflow"; return; }
+            r->modes |= MBM_BIPRED; r->u.mv_ext = out.mv_ext_count;
+            int16_t *d = out.mv_ext + (size_t)out.mv_ext_count * 2;
+            memcpy(d, mvl[0], 64); memcpy(d + 32, mvl[1], 64);
+            int8_t *t = (int8_t *)(d + 64);
+            for (int i = 0; i < 4; i++) { t[i] = refl[1][i] >= 0 ? rf.slot[1][refl[1][i]] : (int8_t)-1; t[4 + i] = ref[i]; t[8 + i] = refl[1][i]; t[12 + i] = 0; }
+            out.mv_ext_count += kBiRecInt16 / 2;
+            return;
+        }
         if (!sub8) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; r->u.mv[i][0] = mv[b * 2]; r->u.mv[i][1] = mv[b * 2 + 1]; } }
         else {
             if (out.mv_ext_count + 16 > out.mv_ext_cap) { err = "mv_ext overflow"; return; }
@@ -289,10 +305,91 @@ struct P {
         }
     }
 
+    // ---- direct prediction (8.4.1.2) of the 8x8 quadrants in mask -------------------------------------
+    static int min_pos(int a, int b) { return (a >= 0 && b >= 0) ? (a < b ? a : b) : (a > b ? a : b); }
+    void col_block(int r, int &refc, int &mx, int &my, int32_t &uid) const {
+        const MotionField &c = *rf.col;
+        refc = -1; mx = my = 0; uid = -1;
+        if (c.intra[addr]) return;
+        int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
+        int l = c.ref[0][(size_t)addr * 4 + b8] >= 0 ? 0 : 1;
+        refc = c.ref[l][(size_t)addr * 4 + b8];
+        if (refc < 0) return;
+        mx = c.mv[l][(size_t)addr * 32 + r * 2]; my = c.mv[l][(size_t)addr * 32 + r * 2 + 1]; uid = c.uid[l][(size_t)addr * 4 + b8];
+    }
+    bool direct_pred(int mask) {
+        if (!rf.col || rf.slot[1][0] < 0) { err = "direct prediction without RefPicList1[0]"; return false; }
+        const bool inf8 = sps.direct_8x8_inference;
+        if (sh.direct_spatial_mv_pred) {
+            int rr[2], mvp[2][2] = {{0, 0}, {0, 0}};
+            uint32_t saved = decoded_mask; decoded_mask = 0;          // only neighbouring macroblocks take part
+            for (int l = 0; l < 2; l++) {
+                Nb A = nb(-1, 0, l), B = nb(0, -1, l), C = nb(4, -1, l);
+                if (!C.avail) C = nb(-1, -1, l);
+                rr[l] = min_pos(A.ref, min_pos(B.ref, C.ref));
+            }
+            bool zero = rr[0] < 0 && rr[1] < 0;
+            if (zero) rr[0] = rr[1] = 0;
+            else for (int l = 0; l < 2; l++) if (rr[l] >= 0) predict(0, 0, 4, rr[l], 0, 0, mvp[l][0], mvp[l][1], l);
+            decoded_mask = saved;
+            const bool col_short = !rf.is_long[1][0];
+            for (int q = 0; q < 4; q++) {
+                if (!(mask & (1 << q))) continue;
+                refl[0][q] = (int8_t)rr[0]; refl[1][q] = (int8_t)rr[1];
+                for (int k = 0; k < 4; k++) {
+                    int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
+                    int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cx_, cy_; int32_t uid;
+                    col_block(rc, refc, cx_, cy_, uid);
+                    bool col_zero = col_short && refc == 0 && cx_ >= -1 && cx_ <= 1 && cy_ >= -1 && cy_ <= 1;
+                    for (int l = 0; l < 2; l++) {
+                        bool z = zero || rr[l] < 0 || (rr[l] == 0 && col_zero);
+                        mvl[l][r * 2] = (int16_t)(z ? 0 : mvp[l][0]); mvl[l][r * 2 + 1] = (int16_t)(z ? 0 : mvp[l][1]);
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < 4; q++) {
+                if (!(mask & (1 << q))) continue;
+                for (int k = 0; k < 4; k++) {
+                    int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
+                    int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cmx, cmy, r0 = 0; int32_t uid;
+                    col_block(rc, refc, cmx, cmy, uid);
+                    if (refc >= 0) {
+                        r0 = -1;
+                        for (int i = 0; i < sh.num_ref_idx[0]; i++) if (rf.slot[0][i] >= 0 && rf.uid[0][i] == uid) { r0 = i; break; }
+                        if (r0 < 0) { err = "temporal direct: colocated reference is not in RefPicList0"; return false; }
+                    }
+                    if (rf.slot[0][r0] < 0) { err = "temporal direct without its list-0 reference"; return false; }
+                    int tb = rf.cur_poc - rf.poc[0][r0], td = rf.poc[1][0] - rf.poc[0][r0];
+                    tb = tb < -128 ? -128 : (tb > 127 ? 127 : tb); td = td < -128 ? -128 : (td > 127 ? 127 : td);
+                    int m0x, m0y, m1x, m1y;
+                    if (rf.is_long[0][r0] || td == 0) { m0x = cmx; m0y = cmy; m1x = m1y = 0; }
+                    else {
+                        int tx = (16384 + (td < 0 ? -td : td) / 2) / td, dsf = (tb * tx + 32) >> 6;
+                        dsf = dsf < -1024 ? -1024 : (dsf > 1023 ? 1023 : dsf);
+                        m0x = (dsf * cmx + 128) >> 8; m0y = (dsf * cmy + 128) >> 8; m1x = m0x - cmx; m1y = m0y - cmy;
+                    }
+                    refl[0][q] = (int8_t)r0; refl[1][q] = 0;
+                    mvl[0][r * 2] = (int16_t)m0x; mvl[0][r * 2 + 1] = (int16_t)m0y; mvl[1][r * 2] = (int16_t)m1x; mvl[1][r * 2 + 1] = (int16_t)m1y;
+                }
+            }
+        }
+        cx.direct8[addr] |= (uint8_t)mask;
+        return true;
+    }
+    void mark8(int q) { int bx = (q & 1) * 2, by = (q >> 1) * 2; decoded_mask |= (1u << (by * 4 + bx)) | (1u << (by * 4 + bx + 1)) | (1u << (by * 4 + bx + 4)) | (1u << (by * 4 + bx + 5)); }
+
     bool skip_mb() {
         MbRec *r = begin_mb();
         r->kind = MB_INTER; r->qp = (uint8_t)qp;
         cx.info[addr] = 4; last_dqp = false;
+        if (sh.type == SL_B) {                                  // B_Skip: direct prediction, no residual
+            cx.direct8[addr] = 16;                               // bit 4: B_Skip / B_Direct_16x16 (mb_type context); direct_pred adds the quadrant bits
+            if (!direct_pred(15)) return false;
+            write_motion(r, true);
+            finish_mb(r);
+            return err == nullptr;
+        }
         int px = 0, py = 0;
         if (nA >= 0 && nB >= 0) {
             Nb A = nb(-1, 0), B = nb(0, -1);
@@ -312,7 +409,7 @@ struct P {
         if (by > 0) { r = (by - 1) * 4 + bx; return addr; }
         r = 12 + bx; return nB;
     }
-    int ae_mb_skip() { return cb->decision(11 + (nA >= 0 && !(cx.info[nA] & 4)) + (nB >= 0 && !(cx.info[nB] & 4))); }
+    int ae_mb_skip() { return cb->decision((sh.type == SL_B ? 24 : 11) + (nA >= 0 && !(cx.info[nA] & 4)) + (nB >= 0 && !(cx.info[nB] & 4))); }
     int ae_intra_mb_type(int base, bool in_i) {
         if (in_i) {
             int inc = (nA >= 0 && !(cx.info[nA] & 2)) + (nB >= 0 && !(cx.info[nB] & 2));       // neighbour not I_NxN
@@ -329,16 +426,39 @@ struct P {
     }
     int ae_mb_type() {
         if (sh.type == SL_I) return ae_intra_mb_type(3, true);
-        if (!cb->decision(14)) {
-            if (!cb->decision(15)) return 3 * cb->decision(16);
-            return 2 - cb->decision(17);
+        if (sh.type == SL_P) {
+            if (!cb->decision(14)) {
+                if (!cb->decision(15)) return 3 * cb->decision(16);
+                return 2 - cb->decision(17);
+            }
+            return 5 + ae_intra_mb_type(17, false);
         }
-        return 5 + ae_intra_mb_type(17, false);
+        // B slice (Table 9-37 b): neighbours coded as B_Skip / B_Direct_16x16 count 0
+        int inc = (nA >= 0 && !(cx.direct8[nA] & 16)) + (nB >= 0 && !(cx.direct8[nB] & 16));
+        if (!cb->decision(27 + inc)) return 0;
+        if (!cb->decision(27 + 3)) return 1 + cb->decision(27 + 5);
+        int bits = cb->decision(27 + 4) << 3;
+        bits |= cb->decision(27 + 5) << 2; bits |= cb->decision(27 + 5) << 1; bits |= cb->decision(27 + 5);
+        if (bits < 8) return bits + 3;
+        if (bits == 13) return 23 + ae_intra_mb_type(32, false);
+        if (bits == 14) return 11;
+        if (bits == 15) return 22;
+        bits = (bits << 1) | cb->decision(27 + 5);
+        return bits - 4;
     }
     int ae_sub_mb_type() {
-        if (cb->decision(21)) return 0;
-        if (!cb->decision(22)) return 1;
-        return cb->decision(23) ? 2 : 3;
+        if (sh.type == SL_P) {
+            if (cb->decision(21)) return 0;
+            if (!cb->decision(22)) return 1;
+            return cb->decision(23) ? 2 : 3;
+        }
+        if (!cb->decision(36)) return 0;
+        if (!cb->decision(37)) return 1 + cb->decision(39);
+        int t = 3;
+        if (cb->decision(38)) { if (cb->decision(39)) return 11 + cb->decision(39); t += 4; }
+        t += 2 * cb->decision(39);
+        t += cb->decision(39);
+        return t;
     }
     int ae_t8x8() { return cb->decision(399 + (nA >= 0 && (cx.info[nA] & 8)) + (nB >= 0 && (cx.info[nB] & 8))); }
     int ae_intra_mode(int pred) {
@@ -352,20 +472,22 @@ struct P {
         if (!cb->decision(64 + 3)) return 1;
         return 2 + cb->decision(64 + 3);
     }
-    int ae_ref_idx(int bx, int by) {
+    int ae_ref_idx(int bx, int by, int l = 0) {
         int inc = 0;
         for (int k = 0; k < 2; k++) {
             int r, m = nb4(bx, by, k == 0, r);
             if (m < 0 || (cx.info[m] & 1)) continue;
-            if (cx.refidx[(size_t)m * 4 + (r >> 3) * 2 + ((r & 3) >> 1)] > 0) inc += k == 0 ? 1 : 2;
+            int q = (r >> 3) * 2 + ((r & 3) >> 1);
+            if (sh.type == SL_B && ((cx.direct8[m] >> q) & 1)) continue;      // direct-predicted: refIdx was not parsed
+            if ((l ? cx.refidx1 : cx.refidx)[(size_t)m * 4 + q] > 0) inc += k == 0 ? 1 : 2;
         }
         int v = 0, ctx = 54 + inc;
         while (cb->decision(ctx)) { v++; ctx = 54 + (v == 1 ? 4 : 5); if (v > 32) { err = "ref_idx out of range"; return 0; } }
         return v;
     }
-    int ae_mvd(int bx, int by, int comp) {
+    int ae_mvd(int bx, int by, int comp, int l = 0) {
         int sum = 0;
-        for (int k = 0; k < 2; k++) { int r, m = nb4(bx, by, k == 0, r); if (m >= 0) sum += cx.mvd[(size_t)m * 32 + r * 2 + comp]; }
+        for (int k = 0; k < 2; k++) { int r, m = nb4(bx, by, k == 0, r); if (m >= 0) sum += (l ? cx.mvd1 : cx.mvd)[(size_t)m * 32 + r * 2 + comp]; }
         int base = comp ? 47 : 40;
         if (!cb->decision(base + (sum < 3 ? 0 : (sum > 32 ? 2 : 1)))) return 0;
         int v = 1, ctx = 3;
@@ -377,9 +499,10 @@ struct P {
         }
         return cb->bypass() ? -v : v;
     }
-    void read_mvd(int bx, int by, int bw, int bh, int &dx, int &dy) {
+    void read_mvd(int bx, int by, int bw, int bh, int &dx, int &dy, int l = 0) {
         if (!cb) { dx = br.se(); dy = br.se(); return; }
-        dx = ae_mvd(bx, by, 0); dy = ae_mvd(bx, by, 1);
+        uint8_t *mvd = mvdl[l];
+        dx = ae_mvd(bx, by, 0, l); dy = ae_mvd(bx, by, 1, l);
         int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
         uint8_t cx8 = (uint8_t)(ax > 255 ? 255 : ax), cy8 = (uint8_t)(ay > 255 ? 255 : ay);     // only sums <3 / >32 matter
         for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvd[(j * 4 + i) * 2] = cx8; mvd[(j * 4 + i) * 2 + 1] = cy8; }
@@ -555,8 +678,8 @@ struct P {
         int itype = -1;
         if (sh.type == SL_I) itype = (int)mb_type;
         else if (sh.type == SL_P) { if (mb_type >= 5) itype = (int)mb_type - 5; }
-        else { err = "B slices are not supported yet"; return false; }
-        if (mb_type > 30 || itype > 25) { err = "bad mb_type"; return false; }
+        else if (mb_type >= 23) itype = (int)mb_type - 23;
+        if (mb_type > 48 || itype > 25) { err = "bad mb_type"; return false; }
 
         if (itype == 25) {                                     // I_PCM
             r->kind = MB_PCM; r->qp = 0;
@@ -617,36 +740,75 @@ struct P {
             if (canon) canon->cmode = (uint8_t)cm;
         } else {
             r->kind = MB_INTER;
-            int nref = sh.num_ref_idx[0];
-            bool sub8 = false;
-            if (mb_type <= 2) {
-                int np = mb_type == 0 ? 1 : 2, rf[2] = {0, 0};
-                for (int p = 0; p < np; p++) {
-                    int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0, bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
-                    if (nref > 1) { rf[p] = cb ? ae_ref_idx(bx, by) : br.te(nref - 1); if (rf[p] >= nref) { err = "ref_idx out of range"; return false; } }
-                    for (int j = by; j < by + bh; j += 2) for (int i = bx; i < bx + bw; i += 2) ref[(j >> 1) * 2 + (i >> 1)] = (int8_t)rf[p];
+            static const uint8_t b_pair[9][2] = {{0, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 2}, {1, 2}, {2, 0}, {2, 1}, {2, 2}};   // Table 7-14: 0 L0, 1 L1, 2 Bi
+            static const uint8_t b_sub_pred[13] = {3, 0, 1, 2, 0, 0, 1, 1, 2, 2, 0, 1, 2};                                   // Table 7-18: 3 = direct
+            static const uint8_t b_sub_shape[13] = {0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};                                  // 0 8x8, 1 8x4, 2 4x8, 3 4x4
+            const bool is_b = sh.type == SL_B;
+            const int nl = is_b ? 2 : 1;
+            bool sub8 = false;                              // a partition smaller than 8x8 (or direct without direct_8x8_inference): no 8x8 transform
+            int shape, pred[4] = {0, 0, 0, 0};
+            if (!is_b) shape = mb_type > 3 ? 3 : (int)mb_type;
+            else if (mb_type == 0) shape = 4;
+            else if (mb_type <= 3) { shape = 0; pred[0] = (int)mb_type - 1; }
+            else if (mb_type == 22) shape = 3;
+            else { shape = (mb_type & 1) ? 2 : 1; pred[0] = b_pair[(mb_type - 4) >> 1][0]; pred[1] = b_pair[(mb_type - 4) >> 1][1]; }
+            if (shape == 4) {                               // B_Direct_16x16
+                cx.direct8[addr] = 16;
+                if (!direct_pred(15)) return false;
+                if (!sps.direct_8x8_inference) sub8 = true;
+            } else if (shape <= 2) {
+                int np = shape == 0 ? 1 : 2, rf_[2][2] = {{-1, -1}, {-1, -1}};
+                for (int l = 0; l < nl; l++) {
+                    int nref = sh.num_ref_idx[l];
+                    for (int p = 0; p < np; p++) {
+                        if (!(pred[p] == 2 || pred[p] == l)) continue;
+                        int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0, bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
+                        rf_[l][p] = 0;
+                        if (nref > 1) { rf_[l][p] = cb ? ae_ref_idx(bx, by, l) : br.te(nref - 1); if (rf_[l][p] >= nref) { err = "ref_idx out of range"; return false; } }
+                        for (int j = by; j < by + bh; j += 2) for (int i = bx; i < bx + bw; i += 2) refl[l][(j >> 1) * 2 + (i >> 1)] = (int8_t)rf_[l][p];
+                    }
                 }
-                for (int p = 0; p < np; p++) {
-                    int bx = mb_type == 2 ? p * 2 : 0, by = mb_type == 1 ? p * 2 : 0, bw = mb_type == 2 ? 2 : 4, bh = mb_type == 1 ? 2 : 4;
-                    int px, py, dx, dy; predict(bx, by, bw, rf[p], (int)mb_type, p, px, py);
-                    read_mvd(bx, by, bw, bh, dx, dy);
-                    set_mv(bx, by, bw, bh, px + dx, py + dy);
+                for (int l = 0; l < nl; l++) {
+                    decoded_mask = 0;
+                    for (int p = 0; p < np; p++) {
+                        int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0, bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
+                        if (rf_[l][p] < 0) { for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) decoded_mask |= 1u << (j * 4 + i); continue; }
+                        int px, py, dx, dy; predict(bx, by, bw, rf_[l][p], shape, p, px, py, l);
+                        read_mvd(bx, by, bw, bh, dx, dy, l);
+                        set_mv(bx, by, bw, bh, px + dx, py + dy, l);
+                    }
                 }
             } else {
-                int sub[4], rf[4] = {0, 0, 0, 0};
-                for (int i = 0; i < 4; i++) { sub[i] = cb ? ae_sub_mb_type() : (int)br.ue(); if (sub[i] > 3) { err = "bad sub_mb_type"; return false; } if (sub[i]) sub8 = true; }
+                int sub[4], sshape[4], rf_[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}}, dmask = 0;
                 for (int i = 0; i < 4; i++) {
-                    if (nref > 1 && mb_type != 4) { rf[i] = cb ? ae_ref_idx((i & 1) * 2, (i >> 1) * 2) : br.te(nref - 1); if (rf[i] >= nref) { err = "ref_idx out of range"; return false; } }
-                    ref[i] = (int8_t)rf[i];
+                    sub[i] = cb ? ae_sub_mb_type() : (int)br.ue();
+                    if (sub[i] > (is_b ? 12 : 3)) { err = "bad sub_mb_type"; return false; }
+                    if (is_b) { pred[i] = b_sub_pred[sub[i]]; sshape[i] = b_sub_shape[sub[i]]; if (pred[i] == 3) dmask |= 1 << i; }
+                    else { pred[i] = 0; sshape[i] = sub[i]; }
+                    if (sshape[i] != 0 || (pred[i] == 3 && !sps.direct_8x8_inference)) sub8 = true;
                 }
-                for (int i = 0; i < 4; i++) {
-                    int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i];
-                    int nsp = st == 0 ? 1 : (st == 3 ? 4 : 2), bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
-                    for (int p = 0; p < nsp; p++) {
-                        int bx = ox + (st == 1 ? 0 : (st == 2 ? p : (p & 1))), by = oy + (st == 1 ? p : (st == 2 ? 0 : (p >> 1)));
-                        int px, py, dx, dy; predict(bx, by, bw, rf[i], 0, 0, px, py);
-                        read_mvd(bx, by, bw, bh, dx, dy);
-                        set_mv(bx, by, bw, bh, px + dx, py + dy);
+                if (dmask && !direct_pred(dmask)) return false;     // from neighbouring macroblocks / the colocated picture only
+                for (int l = 0; l < nl; l++) {
+                    int nref = sh.num_ref_idx[l];
+                    for (int i = 0; i < 4; i++) {
+                        if (!(pred[i] == 2 || pred[i] == l)) continue;
+                        rf_[l][i] = 0;
+                        if (nref > 1 && !(!is_b && mb_type == 4)) { rf_[l][i] = cb ? ae_ref_idx((i & 1) * 2, (i >> 1) * 2, l) : br.te(nref - 1); if (rf_[l][i] >= nref) { err = "ref_idx out of range"; return false; } }
+                        refl[l][i] = (int8_t)rf_[l][i];
+                    }
+                }
+                for (int l = 0; l < nl; l++) {
+                    decoded_mask = 0;
+                    for (int i = 0; i < 4; i++) {
+                        int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sshape[i];
+                        if (rf_[l][i] < 0) { mark8(i); continue; }       // direct, or this list unused
+                        int nsp = st == 0 ? 1 : (st == 3 ? 4 : 2), bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
+                        for (int p = 0; p < nsp; p++) {
+                            int bx = ox + (st == 1 ? 0 : (st == 2 ? p : (p & 1))), by = oy + (st == 1 ? p : (st == 2 ? 0 : (p >> 1)));
+                            int px, py, dx, dy; predict(bx, by, bw, rf_[l][i], 0, 0, px, py, l);
+                            read_mvd(bx, by, bw, bh, dx, dy, l);
+                            set_mv(bx, by, bw, bh, px + dx, py + dy, l);
+                        }
                     }
                 }
             }
@@ -685,12 +847,12 @@ struct P {
 }  // namespace
 
 SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
-                                  BitReader &br, int slice_num, const int8_t *ref_slot,
+                                  BitReader &br, int slice_num, const SliceRefs &refs,
                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest) {
     cavlc_init_tables();
     SliceParseResult res;
     Canon canon;
-    P p{sps, pps, sh, br, cx, out, digest, slice_num, ref_slot, sps.mb_w};
+    P p{sps, pps, sh, br, cx, out, digest, slice_num, refs, sps.mb_w};
     p.qp = sh.qp;
     p.canon = digest ? &canon : nullptr;
     int n_mbs = sps.mb_w * sps.mb_h, addr = sh.first_mb;

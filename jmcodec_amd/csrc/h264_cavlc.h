@@ -6,6 +6,8 @@
 #pragma once
 #include "h264_syntax.h"
 #include "jobs.h"
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 namespace jmamd {
@@ -29,8 +31,34 @@ struct ParseScratch {
     // CABAC neighbour context (9.3.3.1.1): coded_block_pattern (luma bits 0-3, chroma << 4), intra_chroma_pred_mode,
     // coded_block_flag bits (0-15 luma raster, 16 Intra16x16 DC, 17/18 Cb/Cr DC, 19-22 Cb AC, 23-26 Cr AC), |mvd| per 4x4
     std::vector<uint8_t> cbp, cmode; std::vector<uint32_t> cbf; std::vector<uint8_t> mvd;
+    // list 1 (B slices), direct-predicted 8x8 quadrants (bit b8; bit 4: B_Skip / B_Direct_16x16), referenced picture ids
+    std::vector<int16_t> mv1; std::vector<int8_t> refidx1; std::vector<uint8_t> mvd1, direct8; std::vector<int32_t> uid0, uid1;
     void resize(int w, int h);
     void begin_picture();
+};
+
+// Motion field of a decoded picture kept for direct prediction in later B pictures (8.4.1.2): written once by the
+// worker that parsed the picture, read by workers parsing B pictures whose RefPicList1[0] it is.
+struct MotionField {
+    std::vector<int16_t> mv[2];    // [mb][16][2]
+    std::vector<int8_t>  ref[2];   // [mb][4] reference index (-1 unused)
+    std::vector<int32_t> uid[2];   // [mb][4] unique id of the referenced picture
+    std::vector<uint8_t> intra;    // [mb]
+    std::mutex m; std::condition_variable cv; bool done = false;
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done; }); }
+    void publish() { { std::lock_guard<std::mutex> lk(m); done = true; } cv.notify_all(); }
+};
+
+// What a slice knows about its reference picture lists (built by the decoder front end, 8.2.4)
+struct SliceRefs {
+    int8_t  slot[2][32];           // DPB surface of RefPicListX[i], -1 = missing
+    int32_t uid[2][32];            // unique picture id
+    int32_t poc[2][32];
+    uint8_t is_long[2][32];
+    int32_t cur_poc = 0;
+    const MotionField *col = nullptr;   // motion of RefPicList1[0] (B slices)
+    bool track_uid = false;        // the stream may contain B pictures: remember which picture every block refers to
+    bool bipred_rec = false;       // every inter macroblock of this slice uses the MBM_BIPRED motion record (B slice / weighted prediction)
 };
 
 // Optional syntax digest (tests): FNV-1a over a canonical serialisation of every macroblock,
@@ -45,9 +73,9 @@ struct SliceParseResult {
 };
 
 // Parses slice_data() of one slice.  br must be positioned at sh.data_bit_offset with
-// set_end_from_trailing() already called.  ref_slot[i] = DPB surface slot of RefPicList0[i].
+// set_end_from_trailing() already called.
 SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
-                                  BitReader &br, int slice_num, const int8_t *ref_slot,
+                                  BitReader &br, int slice_num, const SliceRefs &refs,
                                   ParseScratch &cx, JobWriter &out, SyntaxDigest *digest);
 
 void cavlc_init_tables();   // idempotent, thread-safe

@@ -197,7 +197,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
             if (br.u1()) { lw = br.se(); lo = br.se(); }
             if (br.u1()) for (int j = 0; j < 2; j++) { cw[j] = br.se(); co[j] = br.se(); }
             if (lw != (1 << sh.luma_log2_wd) || lo != 0 || cw[0] != (1 << sh.chroma_log2_wd) || cw[1] != cw[0] || co[0] != 0 || co[1] != 0) sh.wp_nondefault = true;
-            if (l == 0) { sh.luma_w[i] = (int16_t)lw; sh.luma_o[i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[i][j] = (int16_t)cw[j]; sh.chroma_o[i][j] = (int16_t)co[j]; } }
+            sh.luma_w[l][i] = (int16_t)lw; sh.luma_o[l][i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[l][i][j] = (int16_t)cw[j]; sh.chroma_o[l][i][j] = (int16_t)co[j]; }
         }
     }
     if (nal_ref_idc) {

@@ -56,7 +56,7 @@ struct SliceHeader {
     int num_ref_idx[2] = {0, 0};
     int n_mod[2] = {0, 0}; RefMod mod[2][66];
     bool explicit_wp = false, wp_nondefault = false; int luma_log2_wd = 0, chroma_log2_wd = 0;
-    int16_t luma_w[32], luma_o[32], chroma_w[32][2], chroma_o[32][2];
+    int16_t luma_w[2][32], luma_o[2][32], chroma_w[2][32][2], chroma_o[2][32][2];     // [list][ref_idx]
     bool long_term_reference = false, adaptive_marking = false; int n_mark = 0; MarkOp mark[66];
     int cabac_init_idc = 0; bool direct_spatial_mv_pred = false;
     int qp = 26, disable_deblock = 0, alpha_off = 0, beta_off = 0;     // offsets already doubled

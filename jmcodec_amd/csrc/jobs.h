@@ -31,7 +31,14 @@ enum : uint8_t {
 };
 
 // MbRec.modes bit 4: transform_size_8x8_flag -- luma residual is four 8x8 blocks; with MB_I4 the prediction is Intra8x8
-enum : uint8_t { MBM_T8X8 = 16 };
+// MbRec.modes bit 5: the motion of this macroblock (B slices, slices with weighted prediction) is a 72-int16 record at
+// mv_ext[u.mv_ext] (index in int16 pairs):
+//   int16 mv[2][16][2]   list 0 then list 1, one vector per 4x4 block (raster)
+//   int8  slot1[4]       DPB surface per 8x8 for list 1, -1 = list not used (MbRec.ref[] holds list 0 the same way)
+//   int8  idx0[4], idx1[4]  reference indices per 8x8 (they select the weights in SliceWp)
+//   int8  pad[4]
+enum : uint8_t { MBM_T8X8 = 16, MBM_BIPRED = 32 };
+constexpr int kBiRecInt16 = 72;
 
 struct MbRec {            // 32 bytes
     uint8_t  kind;        // MB_*
@@ -67,6 +74,16 @@ struct SliceRec {         // 4 bytes
     uint8_t pad;
 };
 
+// Weighted prediction tables of one slice (8.4.2.3); present (PicParams.wp != nullptr) only when a slice of the picture needs them.
+struct SliceWp {
+    uint8_t mode;             // 0 default, 1 explicit, 2 implicit (bi-predicted blocks only)
+    uint8_t logwd_y, logwd_c, pad;
+    int8_t  w[2][16][3];      // explicit weights [list][ref_idx][Y, Cb, Cr]
+    int8_t  o[2][16][3];      // explicit offsets
+    uint8_t imp_w1[16][16];   // implicit: 64 + w1 of the pair (ref_idx_l0, ref_idx_l1), w1 in [-64, 128]; w0 = 64 - w1
+};
+static_assert(sizeof(SliceWp) == 4 + 96 + 96 + 256, "SliceWp layout");
+
 constexpr int kMaxSurfaces = 20;
 
 struct PicParams {
@@ -85,6 +102,7 @@ struct PicParams {
     void *dbrec;                  // per-handle scratch: 96 B per macroblock written by k_deblock_prep
     int want_intra_resid;         // 1: k_recon_inter also writes the residual of Intra4x4/16x16 macroblocks to resid
     int stages;                   // PS_* : which kernels of a batched launch act on this picture
+    const SliceWp *wp;            // [n_slices] or nullptr
 };
 
 // One launch works on a BATCH of pictures (one per stream): kernels take an array of PicParams in device memory

@@ -102,13 +102,40 @@ __device__ __forceinline__ void mbw_mv(const PicParams &pp, const MbW &m, int rp
         mx = (int)(int16_t)(w & 0xffff); my = (int)(int16_t)(w >> 16);
     }
 }
+// reference surfaces (s0, s1; -1 = list unused) and vectors of 4x4 block rpos, for either motion representation
+__device__ __forceinline__ void mbw_motion(const PicParams &pp, const MbW &m, int rpos, int &s0, int &s1, int &x0, int &y0, int &x1, int &y1) {
+    int b8 = (rpos >> 3) * 2 + ((rpos & 3) >> 1);
+    s0 = mbw_ref(m, b8); s1 = -1; x1 = y1 = 0;
+    if (mbw_modes(m) & MBM_BIPRED) {
+        const short *rec = pp.mv_ext + (size_t)m.w[4] * 2;
+        x0 = rec[rpos * 2]; y0 = rec[rpos * 2 + 1]; x1 = rec[32 + rpos * 2]; y1 = rec[32 + rpos * 2 + 1];
+        s1 = ((const int8_t *)(rec + 64))[b8];
+    } else mbw_mv(pp, m, rpos, x0, y0);
+}
 // 8.7.2.1 boundary strength between 4x4 luma blocks rp (in macroblock p) and rq (in macroblock q), raster indices
 __device__ __forceinline__ int boundary_strength(const PicParams &pp, const MbW &p, int rp, const MbW &q, int rq, bool mb_edge) {
     if (mbw_kind(p) != MB_INTER || mbw_kind(q) != MB_INTER) return mb_edge ? 4 : 3;
     if (((mbw_cbp_blk(p) >> raster_to_blk(rp)) & 1) || ((mbw_cbp_blk(q) >> raster_to_blk(rq)) & 1)) return 2;
-    if (mbw_ref(p, (rp >> 3) * 2 + ((rp & 3) >> 1)) != mbw_ref(q, (rq >> 3) * 2 + ((rq & 3) >> 1))) return 1;
-    int px, py, qx, qy; mbw_mv(pp, p, rp, px, py); mbw_mv(pp, q, rq, qx, qy);
-    return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
+    if (!((mbw_modes(p) | mbw_modes(q)) & MBM_BIPRED)) {       // one list on both sides (P slices)
+        if (mbw_ref(p, (rp >> 3) * 2 + ((rp & 3) >> 1)) != mbw_ref(q, (rq >> 3) * 2 + ((rq & 3) >> 1))) return 1;
+        int px, py, qx, qy; mbw_mv(pp, p, rp, px, py); mbw_mv(pp, q, rq, qx, qy);
+        return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
+    }
+    // B slices: compare the SETS of reference pictures and the vectors that go with them
+    int p0, p1, q0, q1, px0, py0, px1, py1, qx0, qy0, qx1, qy1;
+    mbw_motion(pp, p, rp, p0, p1, px0, py0, px1, py1); mbw_motion(pp, q, rq, q0, q1, qx0, qy0, qx1, qy1);
+    int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
+    if (np != nq) return 1;
+    auto far = [](int ax, int ay, int bx, int by) { return iabs(ax - bx) >= 4 || iabs(ay - by) >= 4; };
+    if (np == 1) {
+        bool pl1 = p0 < 0, ql1 = q0 < 0;
+        if ((pl1 ? p1 : p0) != (ql1 ? q1 : q0)) return 1;
+        return far(pl1 ? px1 : px0, pl1 ? py1 : py0, ql1 ? qx1 : qx0, ql1 ? qy1 : qy0) ? 1 : 0;
+    }
+    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+    bool straight = far(px0, py0, qx0, qy0) || far(px1, py1, qx1, qy1), crossed = far(px0, py0, qx1, qy1) || far(px1, py1, qx0, qy0);
+    if (p0 != p1) return (p0 == q0 ? straight : crossed) ? 1 : 0;
+    return (straight && crossed) ? 1 : 0;
 }
 
 }  // namespace jmamd

@@ -224,7 +224,65 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
     }
     if (!inter && r.kind != MB_PCM) return;
-    if (inter) {
+    if (inter && (r.modes & MBM_BIPRED)) {
+        // B slices / weighted prediction: one or two references per 8x8, one vector per 4x4, weights of 8.4.2.3.  Literal sampling.
+        const short *rec = pp.mv_ext + (size_t)r.u.mv_ext * 2;
+        const int8_t *tail = (const int8_t *)(rec + 64);
+        const SliceWp *wp = pp.wp ? &pp.wp[r.slice] : nullptr;
+        const int mode = wp ? wp->mode : 0;
+        auto combine = [&](int a, int b, bool use0, bool use1, int i0, int i1, int cmp) -> int {
+            if (use0 && use1) {
+                if (mode == 0) return (a + b + 1) >> 1;
+                int w0, w1, o = 0, lg = 5;
+                if (mode == 1) { w0 = wp->w[0][i0 & 15][cmp]; w1 = wp->w[1][i1 & 15][cmp]; o = (wp->o[0][i0 & 15][cmp] + wp->o[1][i1 & 15][cmp] + 1) >> 1; lg = cmp ? wp->logwd_c : wp->logwd_y; }
+                else { w1 = (int)wp->imp_w1[i0 & 15][i1 & 15] - 64; w0 = 64 - w1; }
+                return clip1(((a * w0 + b * w1 + (1 << lg)) >> (lg + 1)) + o);
+            }
+            if (!use0 && !use1) return 128;
+            int v = use0 ? a : b;
+            if (mode != 1) return v;
+            int l = use0 ? 0 : 1, i = (use0 ? i0 : i1) & 15, lg = cmp ? wp->logwd_c : wp->logwd_y, w = wp->w[l][i][cmp], o = wp->o[l][i][cmp];
+            return clip1((lg >= 1 ? ((v * w + (1 << (lg - 1))) >> lg) : v * w) + o);
+        };
+        {   // luma: lane -> (4x4 block, row)
+            int rb = lane >> 2, row = lane & 3, bx = rb & 3, by = rb >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
+            int s0 = rec_ref(r, b8), s1 = tail[b8], i0 = tail[4 + b8], i1 = tail[8 + b8];
+            int x0 = mbx * 16 + bx * 4, y = mby * 16 + by * 4 + row;
+            int m0x = rec[rb * 2], m0y = rec[rb * 2 + 1], m1x = rec[32 + rb * 2], m1y = rec[32 + rb * 2 + 1];
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int a = 0, b = 0;
+                if (s0 >= 0) a = luma_sample(pp.surf[s0], pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
+                if (s1 >= 0) b = luma_sample(pp.surf[s1], pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
+                v[k] = combine(a, b, s0 >= 0, s1 >= 0, i0, i1, 0);
+            }
+            if (has_res) { const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]); }
+            ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        }
+        {   // chroma: lane -> (cx, cy), both planes
+            int cx = lane & 7, cy = lane >> 3, rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
+            int s[2] = { rec_ref(r, b8), tail[b8] }, i0 = tail[4 + b8], i1 = tail[8 + b8];
+            int CW = W >> 1, CH = H >> 1, pu[2] = {0, 0}, pv[2] = {0, 0};
+#pragma unroll
+            for (int l = 0; l < 2; l++) {
+                if (s[l] < 0) continue;
+                int mvx = rec[l * 32 + rb * 2], mvy = rec[l * 32 + rb * 2 + 1];
+                const uint8_t *rc = pp.surf[s[l]] + pp.chroma_offset;
+                int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
+                int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
+                const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
+                int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
+                pu[l] = (w00 * r0[2 * xa] + w01 * r0[2 * xb] + w10 * r1[2 * xa] + w11 * r1[2 * xb] + 32) >> 6;
+                pv[l] = (w00 * r0[2 * xa + 1] + w01 * r0[2 * xb + 1] + w10 * r1[2 * xa + 1] + w11 * r1[2 * xb + 1] + 32) >> 6;
+            }
+            int u = combine(pu[0], pu[1], s[0] >= 0, s[1] >= 0, i0, i1, 1), v = combine(pv[0], pv[1], s[0] >= 0, s[1] >= 0, i0, i1, 2);
+            if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
+            ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
+        }
+    } else if (inter) {
     // ---- luma ----
     // Fast path (one MV per 8x8 block, i.e. 16x16 / 16x8 / 8x16 / 8x8 partitions): 16 lanes per 8x8 block stage its
     // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.

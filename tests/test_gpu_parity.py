@@ -8,7 +8,7 @@ import pytest
 
 import jmcodec_amd
 from jmcodec_amd import api, streams
-from util import PARITY_CASES, golden_meta, golden_stream, md5
+from util import ALL_CASES as PARITY_CASES, golden_meta, golden_stream, md5
 
 pytestmark = pytest.mark.gpu
 

@@ -5,7 +5,7 @@ import random
 import pytest
 
 from jmcodec_amd import api, streams
-from util import PARITY_CASES, golden_meta, golden_stream
+from util import ALL_CASES as PARITY_CASES, golden_meta, golden_stream
 
 
 def _product_digest(data, chunks=None):
