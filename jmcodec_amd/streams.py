@@ -61,6 +61,12 @@ def config_c1(stream_id=0, frames=300, width=1920, height=1080):
                 mode=0, deblock=1, num_ref=1, level_idc=40)
 
 
+def config_c2(stream_id=0, frames=120, width=3840, height=2160):
+    """BASELINE config 2: H.264 High 4K, CABAC, 8x8 transform, I B B P with two references."""
+    return dict(width=width, height=height, frames=frames, qp=30, gop=30, seed=0x4A4D0000 + 2 * 256 + stream_id,
+                mode=0, deblock=1, num_ref=2, level_idc=52, cabac=1, t8x8=1, bframes=2, poc_type=0)
+
+
 class Oracle:
     """ctypes binding of oracle/_build/liborc.so (CPU oracle -- checker / cpu_baseline only)."""
 

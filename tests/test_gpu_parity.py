@@ -82,6 +82,38 @@ def test_full_size_1080p_high_cabac(oracle):
         assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
 
 
+def test_full_size_4k_high_ibbp(oracle):
+    """BASELINE config 2 at full size (3840x2160 High: CABAC, 8x8 transform, I B B P, two references), first pictures."""
+    data = streams.generate(**streams.config_c2(frames=4))
+    want, n, w, h = oracle.decode(data, 1)
+    assert (w, h, n) == (3840, 2160, 4)
+    with api.JmAmdDec(0, 1) as d:
+        frames = d.decode_stream(data)
+        assert d.stat("errors") == 0 and d.stat("b_pictures") == 2
+    fs = w * h * 3 // 2
+    assert len(frames) == n
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+
+
+def test_b_streams_concurrently(oracle):
+    """Several B-picture streams at once: direct prediction waits for the colocated picture's motion across the worker pool."""
+    from util import B_CASES
+    names = sorted(B_CASES)[:6]
+    datas = [streams.generate(**B_CASES[n]) for n in names]
+    wants = [oracle.decode(d, 1)[0] for d in datas]
+    got = [None] * len(names)
+
+    def run(i):
+        got[i] = b"".join(gpu_decode(datas[i]))
+    for _ in range(3):
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(len(names))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for i in range(len(names)):
+            assert got[i] == wants[i], names[i]
+
+
 def test_full_size_properties_300_frames():
     """Size-independent properties at BASELINE's full stream length where the scalar oracle would take too long:
     the same stream decoded twice, fed in different chunkings and by concurrent handles, gives identical frames;
