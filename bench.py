@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--frames", type=int, default=60, help="frames per stream per step (multiple of the GOP, 30)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--tools", default="baseline", choices=["baseline", "high", "high_b"],
+                    help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
@@ -69,6 +71,13 @@ def main():
 
     # ---- synthetic input: SURVEY 8d C1, seed = 0x4A4D0000 + 1*256 + stream_id (stream_id = rank) ----
     cfg = streams.config_c1(stream_id=rank, frames=args.frames, width=args.width, height=args.height)
+    tools_desc = "Baseline, I/P-only (CAVLC"
+    if args.tools != "baseline":
+        cfg.update(cabac=1, t8x8=1)
+        tools_desc = "High, I/P-only (CABAC, 8x8 transform"
+    if args.tools == "high_b":
+        cfg.update(bframes=2, num_ref=2, poc_type=0)
+        tools_desc = "High, I B B P (CABAC, 8x8 transform"
     data = streams.generate(**cfg)
     nalus = jmcodec_amd.split_nalus(data)
     S, F, K, W = args.streams, args.frames, args.steps, args.warmup
@@ -239,7 +248,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"H.264 Baseline {args.width}x{args.height} I/P-only (CAVLC, IDR every 30, QP 28, deblock on), "
+        "config": {"workload": f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) {args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
                    "host_parse_threads": int(threads), "includes": "host CAVLC + H2D + kernels + packout + D2H + memcpy to caller"},
