@@ -54,7 +54,7 @@ Decoder::Decoder() { memset(info_, 0, sizeof info_); trace_on_ = getenv("JM_AMD_
 
 Decoder::~Decoder() {
     // wait until no worker still references this object
-    { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
+    { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0 && parse_pending_ == 0; }); }
     { std::lock_guard<std::mutex> lk(submit_mtx_); }
     gpu_close();
     delete eng_state_;
@@ -626,6 +626,7 @@ void Decoder::push_task(std::unique_ptr<PicTask> t) {
         std::lock_guard<std::mutex> lk(mtx_);
         raw->seq = next_seq_++;
         outstanding_++;
+        if (raw->has_picture) parse_pending_++;
         inflight_.push_back(std::move(t));
     }
     if (raw->has_picture) pool_submit(this, raw);
@@ -706,6 +707,9 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     t->t_parsed = now_ns();
     t->state.store(1, std::memory_order_release);
     submit_ready();
+    // last touch of *this by this worker: another worker may already have submitted the task (and the caller may be waiting in the
+    // destructor), so the count is dropped and the waiter is woken while the lock is still held
+    { std::lock_guard<std::mutex> lk(mtx_); parse_pending_--; cv_.notify_all(); }
 }
 
 // =============================================================================================
@@ -789,8 +793,8 @@ void Decoder::on_engine_done(const EnginePic &p) {
         for (OutSlot *o : p.slots_before) o->ready = true;
         for (OutSlot *o : p.slots_after) o->ready = true;
         outstanding_--;
+        cv_.notify_all();                  // under the lock: the handle may be destroyed as soon as the count reaches zero
     }
-    cv_.notify_all();
 }
 
 // =============================================================================================

@@ -154,7 +154,7 @@ private:
     std::deque<OutSlot *> ready_;              // display order
     std::vector<OutSlot *> free_out_, all_out_;
     OutSlot *cur_out_ = nullptr;
-    int outstanding_ = 0;                      // tasks pushed and not yet submitted
+    int outstanding_ = 0, parse_pending_ = 0;                      // tasks pushed and not yet submitted
 
     // device
     struct EngineDecoderState *eng_state_ = nullptr;

@@ -192,10 +192,12 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if ((p.weighted_pred && sh.type == SL_P) || (p.weighted_bipred_idc == 1 && sh.type == SL_B)) {
         sh.explicit_wp = true;
         sh.luma_log2_wd = br.ue(); sh.chroma_log2_wd = br.ue();
+        if (sh.luma_log2_wd > 7 || sh.chroma_log2_wd > 7) return "bad weight denominator";
         for (int l = 0; l < lists; l++) for (int i = 0; i < sh.num_ref_idx[l]; i++) {
             int lw = 1 << sh.luma_log2_wd, lo = 0, cw[2] = {1 << sh.chroma_log2_wd, 1 << sh.chroma_log2_wd}, co[2] = {0, 0};
             if (br.u1()) { lw = br.se(); lo = br.se(); }
             if (br.u1()) for (int j = 0; j < 2; j++) { cw[j] = br.se(); co[j] = br.se(); }
+            if (lw < -128 || lw > 127 || lo < -128 || lo > 127 || cw[0] < -128 || cw[0] > 127 || cw[1] < -128 || cw[1] > 127 || co[0] < -128 || co[0] > 127 || co[1] < -128 || co[1] > 127) return "weight out of range";
             if (lw != (1 << sh.luma_log2_wd) || lo != 0 || cw[0] != (1 << sh.chroma_log2_wd) || cw[1] != cw[0] || co[0] != 0 || co[1] != 0) sh.wp_nondefault = true;
             sh.luma_w[l][i] = (int16_t)lw; sh.luma_o[l][i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[l][i][j] = (int16_t)cw[j]; sh.chroma_o[l][i][j] = (int16_t)co[j]; }
         }

@@ -226,6 +226,7 @@ int orc_parse_slice_header(OrcDec *d, Bits *b, int nal_unit_type, int nal_ref_id
         (pps->weighted_bipred_idc == 1 && sh->slice_type == SLICE_B)) {
         sh->luma_log2_wd = bits_ue(b);
         sh->chroma_log2_wd = bits_ue(b);
+        if (sh->luma_log2_wd > 7 || sh->chroma_log2_wd > 7) ORC_FAIL(d, "bad weight denominator");
         for (int l = 0; l < nlists; l++)
             for (int i = 0; i < sh->num_ref_idx[l]; i++) {
                 sh->luma_weight[l][i] = 1 << sh->luma_log2_wd;

@@ -258,21 +258,25 @@ def test_mixed_resolutions_share_batches(oracle):
 
 
 def test_corrupt_streams_do_not_crash_or_hang():
-    """Damaged input must never crash or dead-lock the pipeline (reference policy: errors are swallowed, nv_dec.cpp:394-402)."""
-    base = golden_stream("ip_fuzz_96x80")
+    """Damaged input must never crash or dead-lock the pipeline (reference policy: errors are swallowed, nv_dec.cpp:394-402).
+    Covers CAVLC, CABAC / 8x8 transform and B pictures (direct prediction waits on another picture's motion field)."""
+    from util import B_CASES
+    bases = [golden_stream("ip_fuzz_96x80"), golden_stream("high_cabac_fuzz_96x80"), streams.generate(**B_CASES["b_fuzz_cabac_high"]),
+             streams.generate(**B_CASES["b_fuzz_temporal_noinf8"])]
     rng = np.random.default_rng(7)
-    for trial in range(12):
-        b = bytearray(base)
-        for _ in range(1 + trial % 4):
-            p = int(rng.integers(40, len(b)))
-            b[p] ^= 1 << int(rng.integers(0, 8))
-        if trial % 3 == 0:
-            b = b[:int(rng.integers(100, len(b)))]
-        with api.JmAmdDec(0, 1) as d:
-            frames = d.decode_stream(bytes(b))
-            assert len(frames) <= 8
-            for f in frames:
-                assert len(f) == 96 * 80 * 3 // 2
+    for base in bases:
+        for trial in range(10):
+            b = bytearray(base)
+            for _ in range(1 + trial % 4):
+                p = int(rng.integers(40, len(b)))
+                b[p] ^= 1 << int(rng.integers(0, 8))
+            if trial % 3 == 0:
+                b = b[:int(rng.integers(100, len(b)))]
+            with api.JmAmdDec(0, 1) as d:
+                frames = d.decode_stream(bytes(b))
+                assert len(frames) <= 12
+                for f in frames:
+                    assert len(f) == 96 * 80 * 3 // 2
 
 
 def test_thirdparty_high_profile_stream(oracle):
