@@ -199,7 +199,7 @@ bool Decoder::gpu_alloc_sequence() {
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
-    lds_intra8_ = false;                           // Intra8x8 runs in the v1 wavefront kernel until k_intra_lds learns it
+    lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
     if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||

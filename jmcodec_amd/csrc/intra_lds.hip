@@ -23,6 +23,8 @@ namespace jmamd {
 
 constexpr int kIGroups = 32;
 constexpr int kISlots = 5;
+constexpr int kTS = 28;              // row stride of the luma work tile: corner + 16 + 8 top-right samples
+constexpr int kTileBase = 3904;      // tables, record staging and Intra8x8 edge buffers come first
 
 // (c, kind) of Intra4x4 mode `mode` for pixel (x, y); kind 0 copy P[c], 1 two-tap (P[c]+P[c+1]+1)>>1,
 // 2 three-tap (P[c-1]+2P[c]+P[c+1]+2)>>2, 3 DC.  Edge path index: 0 L3' 1 L3 2 L2 3 L1 4 L0 5 TL 6..13 T0..T7 14 T7'
@@ -55,21 +57,53 @@ __device__ int i4_table_entry(int mode, int x, int y) {
     return c | (kind << 4);
 }
 
+// Same idea for Intra8x8 on the FILTERED 25-entry edge path  L7..L0 (0..7)  TL (8)  T0..T15 (9..24): entry = c | kind << 5
+__device__ int i8_table_entry(int mode, int x, int y) {
+    int c = 0, kind = 0;
+    switch (mode) {
+    case 0: c = 9 + x; break;
+    case 1: c = 7 - y; break;
+    case 2: kind = 3; break;
+    case 3: c = 10 + x + y; kind = 2; break;
+    case 4: c = 8 + x - y; kind = 2; break;
+    case 5: { int z = 2 * x - y, i = x - (y >> 1);
+        if (z >= 0) { c = 8 + i; kind = (z & 1) ? 2 : 1; }
+        else if (z == -1) { c = 8; kind = 2; }
+        else { c = 9 - y + 2 * x; kind = 2; }
+        break; }
+    case 6: { int z = 2 * y - x, i = y - (x >> 1);
+        if (z >= 0) { if (z & 1) { c = 8 - i; kind = 2; } else { c = 7 - i; kind = 1; } }
+        else if (z == -1) { c = 8; kind = 2; }
+        else { c = 7 + x - 2 * y; kind = 2; }
+        break; }
+    case 7: { int i = x + (y >> 1); if (y & 1) { c = 10 + i; kind = 2; } else { c = 9 + i; kind = 1; } break; }
+    default: { int z = x + 2 * y, i = y + (x >> 1);
+        if (z > 13) { c = 0; kind = 0; }
+        else if (z == 13) { c = 0; kind = 2; }
+        else if (z & 1) { c = 6 - i; kind = 2; }
+        else { c = 6 - i; kind = 1; }
+        break; }
+    }
+    return c | (kind << 5);
+}
+
 // LDS image of one workgroup
 struct ILds {
     uint8_t *base; int mb_h;
     // common
     __device__ uint8_t *i4tab() const { return base; }                                            // 144 B
     __device__ uint8_t *rec(int g) const { return base + 256 + g * 32; }                          // MbRec staging, 32 groups
-    // luma: tile[17][24] per group (408 -> 416), residual [16][16] int16 per group (512)
-    __device__ uint8_t *ltile(int g) const { return base + 1280 + g * 416; }
-    __device__ short *lres(int g) const { return (short *)(base + 1280 + 32 * 416 + g * 512); }
-    __device__ uint8_t *lrcol(int row) const { return base + 1280 + 32 * 928 + row * 16; }
-    __device__ uint8_t *lring(int row, int slot) const { return base + 1280 + 32 * 928 + mb_h * 16 + row * 64 + slot * 16; }
+    __device__ uint8_t *i8tab() const { return base + 1280; }                                     // 576 B
+    __device__ uint8_t *e8(int g) const { return base + 1856 + g * 64; }                          // Intra8x8: raw [32] + filtered [32] edge path
+    // luma: tile[17][kTS] per group (476 -> 480), residual [16][16] int16 per group (512)
+    __device__ uint8_t *ltile(int g) const { return base + kTileBase + g * 480; }
+    __device__ short *lres(int g) const { return (short *)(base + kTileBase + 32 * 480 + g * 512); }
+    __device__ uint8_t *lrcol(int row) const { return base + kTileBase + 32 * 992 + row * 16; }
+    __device__ uint8_t *lring(int row, int slot) const { return base + kTileBase + 32 * 992 + mb_h * 16 + row * 64 + slot * 16; }
     // chroma: tile [8][16] interleaved per group (128), right column [8][2] per row, ring 4 x 16 B per row
-    __device__ uint8_t *ctile(int g) const { return base + 1280 + g * 128; }
-    __device__ uint8_t *crcol(int row) const { return base + 1280 + 32 * 128 + row * 16; }
-    __device__ uint8_t *cring(int row, int slot) const { return base + 1280 + 32 * 128 + mb_h * 16 + row * 64 + slot * 16; }
+    __device__ uint8_t *ctile(int g) const { return base + kTileBase + g * 128; }
+    __device__ uint8_t *crcol(int row) const { return base + kTileBase + 32 * 128 + row * 16; }
+    __device__ uint8_t *cring(int row, int slot) const { return base + kTileBase + 32 * 128 + mb_h * 16 + row * 64 + slot * 16; }
 };
 
 // sum over the 16 (or n) lanes of a group
@@ -144,12 +178,71 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) out[i] = clip1(out[i] + rs[i]);
+    } else if (modes & MBM_T8X8) {
+        // ---- Intra8x8 (8.3.2): four 8x8 blocks in order; per block the 25 reference samples are gathered and filtered
+        //      (8.3.2.2.1) into LDS by the 16 lanes, then every lane predicts 4 pixels of one row from the (c, kind) table ----
+        uint8_t *tile = lds.ltile(g);
+        short *res = lds.lres(g);
+        uint8_t *raw = lds.e8(g), *fe = raw + 32;
+        *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
+        tile[(1 + l) * kTS] = (uint8_t)left;
+        tile[1 + l] = ring_up[l];
+        if (l < 8) tile[17 + l] = ring_ur[l];
+        if (l == 0) tile[0] = (uint8_t)corner;
+        const uint8_t *tab8 = lds.i8tab();
+        const uint32_t m0 = rec[4];                                   // Intra8x8PredMode of block b in nibble b
+        const int y8 = l >> 1, x8 = (l & 1) * 4;
+#pragma nounroll
+        for (int b8 = 0; b8 < 4; b8++) {
+            const int bx8 = b8 & 1, by8 = b8 >> 1;
+            const bool a = bx8 || availA, b = by8 || availB;
+            const bool d = (bx8 && by8) ? true : (bx8 ? availB : (by8 ? availA : availD));
+            const bool c = b8 == 0 ? availB : (b8 == 1 ? availC : b8 == 2);
+            const int mode = (m0 >> (4 * b8)) & 15;
+            uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8;          // corner sample of this block
+            // edge path k: 0..7 = p[-1,7]..p[-1,0], 8 = p[-1,-1], 9..24 = p[0..15,-1] (top-right replaced by p[7,-1] when unavailable)
+            auto edge = [&](int k) -> int { return k <= 7 ? org[(8 - k) * kTS] : (k == 8 ? org[0] : org[1 + ((k - 9 > 7 && !c) ? 7 : k - 9)]); };
+            raw[l] = (uint8_t)edge(l);
+            if (l < 9) raw[16 + l] = (uint8_t)edge(16 + l);
+            auto filt = [&](int k) -> int {
+                int lo = k - 1, hi = k + 1;
+                if (k == 0) lo = 0;
+                if (k == 7) hi = d ? 8 : 7;
+                if (k == 8) { lo = a ? 7 : 8; hi = b ? 9 : 8; }
+                if (k == 9) lo = d ? 8 : 9;
+                if (k == 24) hi = 24;
+                return (raw[lo] + 2 * raw[k] + raw[hi] + 2) >> 2;
+            };
+            int f1 = filt(l), f2 = l < 9 ? filt(16 + l) : 0;
+            fe[l] = (uint8_t)f1;
+            if (l < 9) fe[16 + l] = (uint8_t)f2;
+            int dc = 0;
+            if (mode == 2) {
+                int st = 0, sl = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { sl += fe[i]; st += fe[9 + i]; }
+                dc = (a && b) ? (st + sl + 8) >> 4 : (a ? (sl + 4) >> 3 : (b ? (st + 4) >> 3 : 128));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ent = tab8[mode * 64 + y8 * 8 + x8 + j], cc = ent & 31, kd = ent >> 5;
+                int pred;
+                if (kd == 3) pred = dc;
+                else {
+                    int v0 = fe[cc > 0 ? cc - 1 : 0], v1 = fe[cc], v2 = fe[cc < 24 ? cc + 1 : 24];
+                    pred = kd == 2 ? (v0 + 2 * v1 + v2 + 2) >> 2 : (kd == 1 ? (v1 + v2 + 1) >> 1 : v1);
+                }
+                org[(1 + y8) * kTS + 1 + x8 + j] = (uint8_t)clip1(pred + res[(by8 * 8 + y8) * 16 + bx8 * 8 + x8 + j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * kTS + 1 + i];
     } else {
         // ---- Intra4x4: work tile in LDS: tile[0] = row above (col 0 corner, 1..16, 17..20 top-right), col 0 = left ----
         uint8_t *tile = lds.ltile(g);
         short *res = lds.lres(g);
         *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
-        tile[(1 + l) * 24] = (uint8_t)left;
+        tile[(1 + l) * kTS] = (uint8_t)left;
         tile[1 + l] = ring_up[l];
         if (l < 4) tile[17 + l] = ring_ur[l];
         if (l == 0) tile[0] = (uint8_t)corner;
@@ -171,7 +264,7 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
             const bool a = bx > 0 || availA, b = by > 0 || availB;
             const bool cavail = by == 0 ? (bx < 3 ? availB : availC) : !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
             const int c = ent[blk] & 15, kd = ent[blk] >> 4;
-            uint8_t *org = tile + (by * 4) * 24 + bx * 4;     // corner sample of this block
+            uint8_t *org = tile + (by * 4) * kTS + bx * 4;    // corner sample of this block
             // offset of edge-path entry k relative to org: k<=4 left column (row 5-k), k==5 corner, k>=6 row above
             int off[3];
 #pragma unroll
@@ -180,20 +273,20 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
                 k = k < 1 ? 1 : (k > 13 ? 13 : k);
                 int xx = k - 6;
                 if (!cavail && xx > 3) xx = 3;
-                off[t] = k <= 4 ? (5 - k) * 24 : (k == 5 ? 0 : 1 + xx);
+                off[t] = k <= 4 ? (5 - k) * kTS : (k == 5 ? 0 : 1 + xx);
             }
             int pred;
             if (kd == 3) {
-                int st = org[1] + org[2] + org[3] + org[4], sl = org[24] + org[48] + org[72] + org[96];
+                int st = org[1] + org[2] + org[3] + org[4], sl = org[kTS] + org[2 * kTS] + org[3 * kTS] + org[4 * kTS];
                 pred = (a && b) ? (st + sl + 4) >> 3 : (a ? (sl + 2) >> 2 : (b ? (st + 2) >> 2 : 128));
             } else {
                 int v0 = org[off[0]], v1 = org[off[1]], v2 = org[off[2]];
                 pred = kd == 2 ? (v0 + 2 * v1 + v2 + 2) >> 2 : (kd == 1 ? (v1 + v2 + 1) >> 1 : v1);
             }
-            org[(1 + py) * 24 + 1 + px] = (uint8_t)clip1(pred + rsd[blk]);
+            org[(1 + py) * kTS + 1 + px] = (uint8_t)clip1(pred + rsd[blk]);
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * 24 + 1 + i];
+        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * kTS + 1 + i];
     }
     uint32_t o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24), o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
     uint32_t o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24), o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
@@ -278,6 +371,9 @@ __device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int
 }
 
 // ------------------------------------------------------------------------------------------
+// NSLOTS macroblock rows per 16-lane group: 3 covers pictures up to 96 macroblock rows (1080p: 68) with far fewer live prefetch
+// registers (no spills); 5 covers up to 160 rows (4K: 135)
+template <int NSLOTS>
 __global__ __launch_bounds__(512) void k_intra_lds(const PicParams *pics) {
     extern __shared__ __align__(16) uint8_t smem[];
     const PicParams &pp = pics[blockIdx.y];
@@ -289,41 +385,43 @@ __global__ __launch_bounds__(512) void k_intra_lds(const PicParams *pics) {
     const int g = wave * 4 + (lane >> 4), l = lane & 15;
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
     if (threadIdx.x < 144) lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
+    for (int i = threadIdx.x; i < 576; i += 512) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
     const int rows_per_mb = is_chroma ? 8 : 16, my_row = is_chroma ? (l & 7) : l;
-    uint32_t p_rec[kISlots], p_right[kISlots]; uint4 p_res0[kISlots], p_res1[kISlots], p_bot[kISlots];
+    uint32_t p_rec[NSLOTS], p_right[NSLOTS]; uint4 p_res0[NSLOTS], p_res1[NSLOTS], p_bot[NSLOTS];
 #pragma unroll
-    for (int k = 0; k < kISlots; k++) { p_rec[k] = 0; p_right[k] = 0; p_res0[k] = p_res1[k] = p_bot[k] = make_uint4(0, 0, 0, 0); }
+    for (int k = 0; k < NSLOTS; k++) { p_rec[k] = 0; p_right[k] = 0; p_res0[k] = p_res1[k] = p_bot[k] = make_uint4(0, 0, 0, 0); }
     const int n_steps = mb_w + 2 * (mb_h - 1);
-    auto prefetch = [&](int k, int row, int xn) {
-        int mb = row * mb_w + xn;
-        p_rec[k] = ((const uint32_t *)&pp.mbs[mb])[l & 7];
-        const uint8_t *px = plane_base + (size_t)(row * rows_per_mb) * pitch + xn * 16;
-        p_right[k] = *(const uint32_t *)(px + (size_t)my_row * pitch + 12);
-        p_bot[k] = *(const uint4 *)(px + (size_t)(rows_per_mb - 1) * pitch);
-        const short *rs = resid + (size_t)mb * 384;
-        if (is_chroma) p_res0[k] = *(const uint4 *)(rs + 256 + l * 8);               // plane (l>>3), row (l&7): 8 int16
-        else { p_res0[k] = *(const uint4 *)(rs + l * 16); p_res1[k] = *(const uint4 *)(rs + l * 16 + 8); }
-    };
+    // (a macro, not a lambda: capturing the per-slot arrays by reference kept them in scratch memory)
+#define JM_PREFETCH(k, row, xn) do { \
+        int mb_ = (row) * mb_w + (xn); \
+        p_rec[k] = ((const uint32_t *)&pp.mbs[mb_])[l & 7]; \
+        const uint8_t *px_ = plane_base + (size_t)((row) * rows_per_mb) * pitch + (xn) * 16; \
+        p_right[k] = *(const uint32_t *)(px_ + (size_t)my_row * pitch + 12); \
+        p_bot[k] = *(const uint4 *)(px_ + (size_t)(rows_per_mb - 1) * pitch); \
+        const short *rs_ = resid + (size_t)mb_ * 384; \
+        if (is_chroma) p_res0[k] = *(const uint4 *)(rs_ + 256 + l * 8);               /* plane (l>>3), row (l&7): 8 int16 */ \
+        else { p_res0[k] = *(const uint4 *)(rs_ + l * 16); p_res1[k] = *(const uint4 *)(rs_ + l * 16 + 8); } \
+    } while (0)
 #pragma unroll
-    for (int k = 0; k < kISlots; k++) { int row = g + kIGroups * k; if (row == 0) prefetch(k, 0, 0); }
+    for (int k = 0; k < NSLOTS; k++) { int row = g + kIGroups * k; if (row == 0) JM_PREFETCH(k, 0, 0); }
     for (int s = 0; s < n_steps; s++) {
-        uint32_t c_rec[kISlots], c_right[kISlots]; uint4 c_res0[kISlots], c_res1[kISlots], c_bot[kISlots];
+        uint32_t c_rec[NSLOTS], c_right[NSLOTS]; uint4 c_res0[NSLOTS], c_res1[NSLOTS], c_bot[NSLOTS];
 #pragma unroll
-        for (int k = 0; k < kISlots; k++) {
+        for (int k = 0; k < NSLOTS; k++) {
             c_rec[k] = p_rec[k]; c_right[k] = p_right[k]; c_res0[k] = p_res0[k]; c_res1[k] = p_res1[k]; c_bot[k] = p_bot[k];
             asm volatile("" : "+v"(c_rec[k]), "+v"(c_right[k]), "+v"(c_res0[k].x), "+v"(c_res0[k].y), "+v"(c_res0[k].z), "+v"(c_res0[k].w),
                               "+v"(c_res1[k].x), "+v"(c_res1[k].y), "+v"(c_res1[k].z), "+v"(c_res1[k].w),
                               "+v"(c_bot[k].x), "+v"(c_bot[k].y), "+v"(c_bot[k].z), "+v"(c_bot[k].w));
         }
 #pragma unroll
-        for (int k = 0; k < kISlots; k++) {
+        for (int k = 0; k < NSLOTS; k++) {
             int row = g + kIGroups * k, xn = s + 1 - 2 * row;
-            if (row < mb_h && xn >= 0 && xn < mb_w) prefetch(k, row, xn);
+            if (row < mb_h && xn >= 0 && xn < mb_w) JM_PREFETCH(k, row, xn);
         }
 #pragma unroll
-        for (int k = 0; k < kISlots; k++) {
+        for (int k = 0; k < NSLOTS; k++) {
             int row = g + kIGroups * k, x = s - 2 * row;
             if (row < mb_h && x >= 0 && x < mb_w) {
                 if (is_chroma) intra_chroma_mb(pp, lds, x, row, l, g, c_rec[k], c_res0[k], c_right[k], c_bot[k]);
@@ -332,9 +430,10 @@ __global__ __launch_bounds__(512) void k_intra_lds(const PicParams *pics) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+#undef JM_PREFETCH
 }
 
-size_t intra_lds_bytes(int mb_h) { return 1280 + 32 * 928 + (size_t)mb_h * 80 + 64; }
+size_t intra_lds_bytes(int mb_h) { return kTileBase + 32 * 992 + (size_t)mb_h * 80 + 64; }
 bool intra_lds_supported(int mb_w, int mb_h) { return mb_h <= kIGroups * kISlots && intra_lds_bytes(mb_h) <= 150 * 1024; }
 
 void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st) {
@@ -342,10 +441,12 @@ void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t 
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void *)k_intra_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)k_intra_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void *)k_intra_lds<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_intra_lds, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
+    if (max_mb_h <= 3 * kIGroups) hipLaunchKernelGGL(k_intra_lds<3>, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
+    else hipLaunchKernelGGL(k_intra_lds<5>, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
 }
 
 }  // namespace jmamd
