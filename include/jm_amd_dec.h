@@ -55,6 +55,8 @@ int  jm_amddec_is_hw_support(void);
 /* keys: "device" (before init), "sync" (1 = every call waits for the pipeline; deterministic),
  *       "parse_only" (1 = host bitstream stages only, frames carry no pixels; for host-side tests),
  *       "digest" (1 = accumulate the macroblock syntax digest; implies sync) */
+/* like jm_amddec_decode_frame without input: *got_frame = 1 when a display-order frame became ready (never signals end of stream) */
+int  jm_amddec_poll_frame(int *got_frame, jm_amddec_handle h);
 int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
 /* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
  *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",

@@ -142,14 +142,36 @@ def split_nalus(data):
     return out
 
 
+def annexb_to_avcc(data, length_size=4):
+    """(avcC record, [length-prefixed packets]) of an Annex-B stream: what a demuxer hands test_player for an MP4 source when no
+    h264_mp4toannexb filter is in the way (test_player.cpp:221-226).  One packet per access unit (split before each first slice)."""
+    nalus = [n.lstrip(b"\x00")[1:] for n in split_nalus(data)]              # strip start codes
+    sps = [n for n in nalus if n and (n[0] & 31) == 7]
+    pps = [n for n in nalus if n and (n[0] & 31) == 8]
+    rec = bytes([1, sps[0][1], sps[0][2], sps[0][3], 0xFC | (length_size - 1), 0xE0 | 1]) + len(sps[0]).to_bytes(2, "big") + sps[0]
+    rec += bytes([1]) + len(pps[0]).to_bytes(2, "big") + pps[0]
+    packets, cur = [], b""
+    for n in nalus:
+        t = n[0] & 31
+        if t in (7, 8):
+            continue
+        if t in (1, 5) and (n[1] & 0x80) and cur:                            # first_mb_in_slice == 0: a new picture starts
+            packets.append(cur)
+            cur = b""
+        cur += len(n).to_bytes(length_size, "big") + n
+    if cur:
+        packets.append(cur)
+    return rec, packets
+
+
 class JmAmdDec:
     """Convenience wrapper reproducing test_nv_dec's main loop (test_nv_dec.cpp:163-259)."""
 
-    def __init__(self, codec_type=0, out_fmt=1, options=None):
+    def __init__(self, codec_type=0, out_fmt=1, options=None, extra_data=None):
         self.h = jm_nvdec_create_handle()
         for k, v in (options or {}).items():
             lib().jm_amddec_set_option(self.h, k.encode(), int(v))
-        rc = jm_nvdec_init(codec_type, out_fmt, None, 0, self.h)
+        rc = jm_nvdec_init(codec_type, out_fmt, extra_data, len(extra_data) if extra_data else 0, self.h)
         if rc != 0:
             err = lib().jm_amddec_last_error(self.h).decode()
             jm_nvdec_deinit(self.h)

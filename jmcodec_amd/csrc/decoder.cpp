@@ -130,12 +130,28 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
     if (codec_type != 0) { fail("only codec_type 0 (H.264) is implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
+    if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
     if (engine_) engine_->set_profile(profile_);
     inited_ = true;
-    // optional SPS/PPS given up front (nv_dec.cpp:334-360)
-    if (extra && len > 0) { feed(extra, (size_t)len); static const uint8_t sc[4] = {0, 0, 0, 1}; feed(sc, 4); in_.clear(); scan_ = 0; have_start_ = false; }
+    // optional SPS/PPS given up front (nv_dec.cpp:334-360).  FFmpeg hands test_player either Annex-B parameter sets or, for MP4 /
+    // MKV sources, an AVCDecoderConfigurationRecord ("avcC", ISO/IEC 14496-15 5.2.4.1); with avcC the packets that follow are
+    // length-prefixed NAL units unless a bitstream filter already converted them (test_player.cpp:221-226 uses h264_mp4toannexb).
+    if (extra && len > 0) {
+        if (len >= 7 && extra[0] == 1) {
+            avcc_len_size_ = (extra[4] & 3) + 1;
+            int o = 5, n_sps = extra[o++] & 31;
+            for (int pass = 0; pass < 2; pass++) {
+                int n = pass == 0 ? n_sps : (o < len ? extra[o++] : 0);
+                for (int i = 0; i < n && o + 2 <= len; i++) {
+                    int l = (extra[o] << 8) | extra[o + 1]; o += 2;
+                    if (l <= 0 || o + l > len) { o = len; break; }
+                    handle_nal(extra + o, (size_t)l); o += l;
+                }
+            }
+        } else { feed(extra, (size_t)len); static const uint8_t sc[4] = {0, 0, 0, 1}; feed(sc, 4); in_.clear(); scan_ = 0; have_start_ = false; }
+    }
     return 0;
 }
 
@@ -232,6 +248,21 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
 // front end: Annex-B splitting (replaces the NAL scanning half of cuvidParseVideoData, nv_dec.cpp:394)
 // =============================================================================================
 void Decoder::feed(const uint8_t *buf, size_t len) {
+    if (avcc_len_size_ && !have_start_ && in_.empty()) {
+        // avcC mode: a packet is a whole number of length-prefixed NAL units -- unless it starts with a start code (already converted)
+        bool annexb = len >= 4 && buf[0] == 0 && buf[1] == 0 && (buf[2] == 1 || (buf[2] == 0 && buf[3] == 1));
+        if (!annexb) {
+            size_t o = 0;
+            while (o + (size_t)avcc_len_size_ <= len) {
+                size_t l = 0;
+                for (int i = 0; i < avcc_len_size_; i++) l = (l << 8) | buf[o + i];
+                o += (size_t)avcc_len_size_;
+                if (l == 0 || l > len - o) break;
+                handle_nal(buf + o, l); o += l;
+            }
+            return;
+        }
+    }
     in_.insert(in_.end(), buf, buf + len);
     const uint8_t *p = in_.data();
     size_t n = in_.size();
@@ -814,6 +845,13 @@ int Decoder::pop_output(bool block) {
         if (!block || outstanding_ == 0) return 0;
         cv_.wait(lk);
     }
+}
+
+int Decoder::poll(int *got_frame) {
+    *got_frame = 0;
+    if (!inited_ || failed_) return -1;
+    *got_frame = pop_output(false);
+    return 0;
 }
 
 int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {

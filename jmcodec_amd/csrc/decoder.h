@@ -77,6 +77,7 @@ public:
     ~Decoder();
     int  init(int codec_type, int out_fmt, const uint8_t *extra, int len);
     int  decode(const uint8_t *buf, int len, int *got_frame);
+    int  poll(int *got_frame);                 // pop a finished display frame without feeding input
     int  output(uint8_t *out, int *out_len);
     int  stream_info(int *w, int *h) const;
     void set_eof(bool e) { eof_flag_ = e; }
@@ -129,6 +130,7 @@ private:
 
     // splitter
     std::vector<uint8_t> in_; size_t scan_ = 0; bool have_start_ = false; size_t nal_start_ = 0;
+    int avcc_len_size_ = 0;                    // > 0: init got an avcC record; packets are length-prefixed NAL units of this many bytes
 
     // parameter sets / sequence
     ParamSets ps_;

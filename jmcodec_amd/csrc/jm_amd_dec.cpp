@@ -26,6 +26,11 @@ __attribute__((visibility("default"))) int jm_amddec_decode_frame(unsigned char 
     if (!h) return -1;
     return D(h)->decode(in_buf, n, got ? got : &dummy);
 }
+__attribute__((visibility("default"))) int jm_amddec_poll_frame(int *got, jm_amddec_handle h) {
+    int dummy = 0;
+    if (!h) return -1;
+    return D(h)->poll(got ? got : &dummy);
+}
 __attribute__((visibility("default"))) int jm_amddec_output_frame(unsigned char *out, int *out_len, jm_amddec_handle h) {
     if (!h || !out || !out_len) return -1;
     return D(h)->output(out, out_len);

@@ -112,3 +112,24 @@ def test_thirdparty_cabac_stream_parses_like_the_oracle(oracle):
     pd, pn, frames, errors, pocs, _ = _product_digest(data)
     assert (pd, pn, frames, errors) == (od, on, 36, 0)
     assert on == 36 * 20 * 15
+
+
+def test_avcc_extradata_and_length_prefixed_packets(oracle):
+    """parameter sets through jm_nvdec_init(extra_data) as an avcC record, packets as length-prefixed NAL units
+    (what FFmpeg hands test_player for MP4 input, test_player.cpp:221-226, nv_dec.cpp:334-360) == the Annex-B decode."""
+    import os
+    for data in (golden_stream("ip_fuzz_96x80"), open(os.path.join(os.path.dirname(__file__), "golden", "thirdparty_realshort.h264"), "rb").read()):
+        want = oracle.syntax_digest(data)
+        for ls in (4, 2):
+            rec, packets = api.annexb_to_avcc(data, ls)
+            with api.JmAmdDec(0, 1, options={"parse_only": 1, "digest": 1}, extra_data=rec) as d:
+                n = d.decode_stream(b"", keep=False, chunks=packets)
+                assert (d.stat("syntax_digest") & (2 ** 64 - 1), d.stat("digest_mbs")) == want
+                assert d.stat("errors") == 0 and n > 0
+        # Annex-B parameter sets as extra_data, slices afterwards
+        nal = api.split_nalus(data)
+        head = b"".join(x for x in nal if (x.lstrip(b"\x00")[1] & 31) in (7, 8))
+        rest = [x for x in nal if (x.lstrip(b"\x00")[1] & 31) not in (7, 8)]
+        with api.JmAmdDec(0, 1, options={"parse_only": 1, "digest": 1}, extra_data=head) as d:
+            d.decode_stream(b"", keep=False, chunks=rest)
+            assert (d.stat("syntax_digest") & (2 ** 64 - 1), d.stat("digest_mbs")) == want
