@@ -341,16 +341,6 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
     if (!e.empty()) { stat_errors_++; error_ = e; return; }
     const PicParamSet &pps = ps_.pps[sh.pps_id];
     const SeqParams &sps = ps_.sps[pps.sps_id];
-    {   // tools this build does not decode yet are refused, never decoded wrongly
-        const char *why = nullptr;
-        if (pps.scaling_matrix_present || sps.scaling_matrix_present) {
-            bool flat = true;
-            for (int i = 0; i < 6 && flat; i++) for (int k = 0; k < 16; k++) if (pps.scaling4[i][k] != 16) { flat = false; break; }
-            for (int i = 0; i < 2 && flat; i++) for (int k = 0; k < 64; k++) if (pps.scaling8[i][k] != 16) { flat = false; break; }
-            if (!flat) why = "scaling matrices are not supported yet";
-        }
-        if (why) { stat_errors_++; error_ = why; return; }
-    }
     if (pending_ && !same_picture(first_sh_, sh)) dispatch_pending();
     if (!pending_) { if (!start_picture(sh, sps, pps)) return; }
     add_slice(sh, std::move(rbsp), n);
@@ -796,6 +786,15 @@ void Decoder::submit_task(PicTask *t) {
         pp.mv_ext = pp.coef + t->coef_count;
         pp.resid = (int16_t *)resid_; pp.dbrec = dbrec_;
         pp.wp = t->any_wp ? (const SliceWp *)(js.dev + t->wp_offset) : nullptr;
+        {   // scaling matrices: transmitted in zig-zag order (7.3.2.1.1.1), the kernels index them in raster order
+            static const uint8_t zz4[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+            static const uint8_t zz8[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            bool flat = true;
+            for (int i = 0; i < 6; i++) for (int k = 0; k < 16; k++) { pp.wscale4[i][zz4[k]] = t->pps.scaling4[i][k]; flat &= t->pps.scaling4[i][k] == 16; }
+            for (int i = 0; i < 2; i++) for (int k = 0; k < 64; k++) { pp.wscale8[i][zz8[k]] = t->pps.scaling8[i][k]; flat &= t->pps.scaling8[i][k] == 16; }
+            pp.flat_scaling = flat ? 1 : 0;
+        }
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
         bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_);
         pp.want_intra_resid = lds_intra ? 1 : 0;

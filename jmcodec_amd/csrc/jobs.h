@@ -103,6 +103,10 @@ struct PicParams {
     int want_intra_resid;         // 1: k_recon_inter also writes the residual of Intra4x4/16x16 macroblocks to resid
     int stages;                   // PS_* : which kernels of a batched launch act on this picture
     const SliceWp *wp;            // [n_slices] or nullptr
+    // scaling matrices (8.5.9) in RASTER order: 4x4 lists Intra Y/Cb/Cr, Inter Y/Cb/Cr; 8x8 lists Intra Y, Inter Y
+    int flat_scaling;             // 1: every weight is 16 (Flat_4x4_16 / Flat_8x8_16): kernels skip the table reads
+    uint8_t wscale4[6][16];
+    uint8_t wscale8[2][64];
 };
 
 // One launch works on a BATCH of pictures (one per stream): kernels take an array of PicParams in device memory

@@ -48,6 +48,13 @@ __device__ __forceinline__ int level_scale4(int qp_rem, int pos) {
     int cls = (!(i & 1) && !(j & 1)) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
     return 16 * norm4(qp_rem, cls);
 }
+// 8.5.12.1 with a weight w from a scaling matrix: LevelScale4x4 = w * normAdjust4x4
+__device__ __forceinline__ int dequant4w(int c, int qp, int pos, int w) {
+    int i = pos >> 2, j = pos & 3;
+    int cls = (!(i & 1) && !(j & 1)) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
+    int ls = w * norm4(qp % 6, cls), s = qp / 6;
+    return s >= 4 ? (c * ls) << (s - 4) : (c * ls + (1 << (3 - s))) >> (4 - s);
+}
 // 8.5.12.1 scaling of one residual coefficient (not the separately handled DC ones)
 __device__ __forceinline__ int dequant4(int c, int qp, int pos) {
     int ls = level_scale4(qp % 6, pos), s = qp / 6;

@@ -25,12 +25,12 @@ __device__ __forceinline__ void idct8_1d(int *d) {
     int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2), f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
     d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1; d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
 }
-// LevelScale8x8 with the flat weight matrix: 16 * normAdjust8x8(m, i, j) (8.5.9, Table of v_m0..v_m5), six 6-bit fields per m
-__device__ __forceinline__ int level_scale8(int m, int i, int j) {
+// normAdjust8x8(m, i, j) (8.5.9, v_m0..v_m5), six 6-bit fields per m; LevelScale8x8 = weight * this
+__device__ __forceinline__ int norm_adjust8(int m, int i, int j) {
     const unsigned long long packed = m == 0 ? 0x6194E0494ull : (m == 1 ? 0x69C5634D6ull : (m == 2 ? 0x7E162A5DAull : (m == 3 ? 0x8636AD65Cull : (m == 4 ? 0x9A87B3720ull : 0xAEE8BA824ull))));
     int ti = (i & 1) ? 1 : ((i & 2) ? 2 : 0), tj = (j & 1) ? 1 : ((j & 2) ? 2 : 0);
     int cls = ti == tj ? ti : (ti + tj == 1 ? 3 : (ti + tj == 2 ? 4 : 5));
-    return 16 * (int)((packed >> (6 * cls)) & 63);
+    return (int)((packed >> (6 * cls)) & 63);
 }
 
 // Residual of one macroblock into LDS.  Lanes 0..15: luma 4x4 blocks (blkIdx order) -- or lanes 0..31: (8x8 block, row / column)
@@ -41,6 +41,8 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
     int qp = r.qp;
     int n_luma = __popc((unsigned)r.cbp_blk);
     int base_luma = r.kind == MB_I16 ? 16 : 0;
+    const bool flat = pp.flat_scaling != 0;
+    const int wl = r.kind == MB_INTER ? 3 : 0;                 // scaling list of this macroblock's luma; chroma lists follow it
     if (r.modes & MBM_T8X8) {
         if (lane < 32) {
             int b8 = lane >> 3, i = lane & 7;
@@ -50,7 +52,7 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
                 const short *c = coef + 16 * __popc((unsigned)r.cbp_blk & ((1u << (4 * b8)) - 1)) + i * 8;
                 int m = qp % 6, s = qp / 6;
 #pragma unroll
-                for (int k = 0; k < 8; k++) { int v = c[k] * level_scale8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
+                for (int k = 0; k < 8; k++) { int wgt = flat ? 16 : pp.wscale8[r.kind == MB_INTER ? 1 : 0][i * 8 + k]; int v = c[k] * wgt * norm_adjust8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
                 idct8_1d(d);
 #pragma unroll
                 for (int k = 0; k < 8; k++) rt.t8[b8 * 64 + i * 8 + k] = d[k];
@@ -77,7 +79,7 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
         if (coded) {
             const short *c = coef + base_luma + 16 * __popc((unsigned)r.cbp_blk & ((1u << blk) - 1));
 #pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = dequant4(c[k], qp, k);
+            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qp, k) : dequant4w(c[k], qp, k, pp.wscale4[wl][k]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) d[k] = 0;
@@ -96,7 +98,7 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
             int j = rpos & 3, i = rpos >> 2;
             int a = f[j], b = f[4 + j], cc = f[8 + j], e = f[12 + j];
             int g = i == 0 ? a + b + cc + e : (i == 1 ? a + b - cc - e : (i == 2 ? a - b - cc + e : a - b + cc - e));
-            int ls0 = level_scale4(qp % 6, 0), s = qp / 6;
+            int ls0 = flat ? level_scale4(qp % 6, 0) : pp.wscale4[0][0] * norm4(qp % 6, 0), s = qp / 6;
             d[0] = s >= 6 ? (g * ls0) << (s - 6) : (g * ls0 + (1 << (5 - s))) >> (6 - s);
             any = true;
         }
@@ -116,7 +118,7 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
         if (coded) {
             const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 32)) - 1));
 #pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = dequant4(c[k], qpc, k);
+            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qpc, k) : dequant4w(c[k], qpc, k, pp.wscale4[wl + 1 + pl][k]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) d[k] = 0;
@@ -126,7 +128,7 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
             const short *c = cdc + (pl ? 4 * has_cb : 0);
             int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
             int f = k4 == 0 ? c0 + c1 + c2 + c3 : (k4 == 1 ? c0 - c1 + c2 - c3 : (k4 == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
-            d[0] = ((f * level_scale4(qpc % 6, 0)) << (qpc / 6)) >> 5;
+            d[0] = ((f * (flat ? level_scale4(qpc % 6, 0) : pp.wscale4[wl + 1 + pl][0] * norm4(qpc % 6, 0))) << (qpc / 6)) >> 5;
         } else d[0] = 0;
         if (coded || has_dc) idct4x4(d);
         int bx = k4 & 1, by = k4 >> 1;

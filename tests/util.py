@@ -94,6 +94,11 @@ B_CASES = {
     "b_fuzz_implicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=97, bframes=2, num_ref=3, wp=2, cabac=1, cabac_idc=2),
     "b_fuzz_explicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=98, bframes=2, num_ref=2, wp=1, t8x8=1),
     "b_crop_odd_mbs": dict(width=90, height=70, frames=8, gop=8, mode=1, seed=99, bframes=3, num_ref=2, cabac=1),
+    # scaling matrices (SPS / PPS lists, fall-back rules, default tables)
+    "scaling_sps_cavlc": dict(width=96, height=80, frames=6, gop=6, mode=1, seed=100, scaling=1),
+    "scaling_pps_high_cabac": dict(width=96, height=80, frames=8, gop=4, mode=1, seed=101, scaling=2, t8x8=1, cabac=1, num_ref=2),
+    "scaling_sps_high_b": dict(width=96, height=80, frames=8, gop=8, mode=1, seed=102, scaling=1, t8x8=1, cabac=1, bframes=2),
+    "scaling_real_qvga": dict(width=320, height=240, frames=6, gop=6, seed=103, scaling=1, t8x8=1, cabac=1),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

@@ -50,6 +50,7 @@ typedef struct {
     int direct_temporal;        /* 0: direct_spatial_mv_pred_flag = 1, 1: temporal direct */
     int wp;                     /* 0 none, 1 explicit weights (P and B), 2 implicit (B)          */
     int dinf8;                  /* direct_8x8_inference_flag (default 1 when 0 is passed with bframes == 0) */
+    int scaling;                /* 0 flat, 1 scaling lists in the SPS, 2 in the PPS (forces High profile)             */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -528,7 +529,9 @@ static void idct4_add(const int *dq, uint8_t *dst, int st) {
         int r0 = (g0 + g3 + 32) >> 6, r1 = (g1 + g2 + 32) >> 6, r2 = (g1 - g2 + 32) >> 6, r3 = (g0 - g3 + 32) >> 6;
         dst[j] = (uint8_t)CLIP1(dst[j] + r0); dst[st + j] = (uint8_t)CLIP1(dst[st + j] + r1); dst[2 * st + j] = (uint8_t)CLIP1(dst[2 * st + j] + r2); dst[3 * st + j] = (uint8_t)CLIP1(dst[3 * st + j] + r3); }
 }
-static inline int dequant_ac(int c, int qp, int k) { int ls = 16 * norm4[qp % 6][pos_class(k)]; return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
+/* scaling matrices in effect (8.5.9), raster order: 4x4 lists Intra Y/Cb/Cr, Inter Y/Cb/Cr; 8x8 lists Intra Y, Inter Y */
+static int g_w4[6][16], g_w8[2][64], g_wlist;          /* g_wlist: list used by the block being coded */
+static inline int dequant_ac(int c, int qp, int k) { int ls = g_w4[g_wlist][k] * norm4[qp % 6][pos_class(k)]; return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
 
 /* ------------------------------ CAVLC writer -------------------------------- */
 static void put_level_code(BitW *w, int code, int sl) {
@@ -609,7 +612,8 @@ static int code_luma4(Enc *e, int px, int py, int qp, int intra, int *levels /*r
     for (int k = 0; k < 16; k++) x[k] = s->y[(py + (k >> 2)) * s->sy + px + (k & 3)] - c->y[(py + (k >> 2)) * c->sy + px + (k & 3)];
     fdct4(x, w);
     int shift = 15 + qp / 6, f = (1 << shift) / (intra ? 3 : 6);
-    for (int k = 0; k < 16; k++) { levels[k] = quant1(w[k], quant_mf[qp % 6][pos_class(k)], f, shift); nz += levels[k] != 0; }
+    g_wlist = intra ? 0 : 3;
+    for (int k = 0; k < 16; k++) { levels[k] = quant1(w[k], quant_mf[qp % 6][pos_class(k)] * 16 / g_w4[g_wlist][k], f, shift); nz += levels[k] != 0; }
     if (nz) { int dq[16]; for (int k = 0; k < 16; k++) dq[k] = dequant_ac(levels[k], qp, k); idct4_add(dq, c->y + py * c->sy + px, c->sy); }
     return nz;
 }
@@ -624,21 +628,22 @@ static int code_chroma(Enc *e, int mx, int my, int pl, int qpc, int intra, MbCod
         for (int i = 0; i < 16; i++) x[i] = sp[(oy + (i >> 2)) * s->sc + ox + (i & 3)] - cp[(oy + (i >> 2)) * c->sc + ox + (i & 3)];
         fdct4(x, w[k]); dcs[k] = w[k][0];
         mc->cac[pl][k][0] = 0;
-        for (int i = 1; i < 16; i++) { mc->cac[pl][k][i] = quant1(w[k][i], quant_mf[qpc % 6][pos_class(i)], f, shift); if (mc->cac[pl][k][i]) flags |= 2; }
+        for (int i = 1; i < 16; i++) { mc->cac[pl][k][i] = quant1(w[k][i], quant_mf[qpc % 6][pos_class(i)] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][i], f, shift); if (mc->cac[pl][k][i]) flags |= 2; }
     }
     int h[4] = { dcs[0] + dcs[1] + dcs[2] + dcs[3], dcs[0] - dcs[1] + dcs[2] - dcs[3], dcs[0] + dcs[1] - dcs[2] - dcs[3], dcs[0] - dcs[1] - dcs[2] + dcs[3] };
-    for (int k = 0; k < 4; k++) { mc->cdc[pl][k] = quant1(h[k], quant_mf[qpc % 6][0], 2 * f, shift + 1); if (mc->cdc[pl][k]) flags |= 1; }
+    for (int k = 0; k < 4; k++) { mc->cdc[pl][k] = quant1(h[k], quant_mf[qpc % 6][0] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][0], 2 * f, shift + 1); if (mc->cdc[pl][k]) flags |= 1; }
     return flags;
 }
 static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *mc, int use_dc, int use_ac) {
     Frame *c = &e->cur; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
     if (!use_dc && !use_ac) return;
+    g_wlist = (e->mbs[my * e->mbw + mx].intra ? 0 : 3) + 1 + pl;
     const int *d = mc->cdc[pl];
     int f[4] = { d[0] + d[1] + d[2] + d[3], d[0] - d[1] + d[2] - d[3], d[0] + d[1] - d[2] - d[3], d[0] - d[1] - d[2] + d[3] };
     for (int k = 0; k < 4; k++) {
         int dq[16];
         for (int i = 1; i < 16; i++) dq[i] = use_ac ? dequant_ac(mc->cac[pl][k][i], qpc, i) : 0;
-        dq[0] = use_dc ? ((f[k] * 16 * norm4[qpc % 6][0]) << (qpc / 6)) >> 5 : 0;
+        dq[0] = use_dc ? ((f[k] * g_w4[g_wlist][0] * norm4[qpc % 6][0]) << (qpc / 6)) >> 5 : 0;
         idct4_add(dq, cp + (k >> 1) * 4 * c->sc + (k & 1) * 4, c->sc);
     }
 }
@@ -743,9 +748,9 @@ static void inv8_1d(const int *in, int *out) {
     out[0] = b[0] + b[7]; out[1] = b[2] + b[5]; out[2] = b[4] + b[3]; out[3] = b[6] + b[1];
     out[4] = b[6] - b[1]; out[5] = b[4] - b[3]; out[6] = b[2] - b[5]; out[7] = b[0] - b[7];
 }
-static void recon8(const int *lev /*raster*/, int qp, uint8_t *dst, int st) {
+static void recon8(const int *lev /*raster*/, int qp, int list, uint8_t *dst, int st) {
     int d[64], g[64], col[8], o[8];
-    for (int k = 0; k < 64; k++) { int ls = 16 * norm8[qp % 6][cls8(k >> 3, k & 7)]; d[k] = qp >= 36 ? (lev[k] * ls) << (qp / 6 - 6) : (lev[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6); }
+    for (int k = 0; k < 64; k++) { int ls = g_w8[list][k] * norm8[qp % 6][cls8(k >> 3, k & 7)]; d[k] = qp >= 36 ? (lev[k] * ls) << (qp / 6 - 6) : (lev[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6); }
     for (int i = 0; i < 8; i++) inv8_1d(d + 8 * i, g + 8 * i);
     for (int j = 0; j < 8; j++) {
         for (int i = 0; i < 8; i++) col[i] = g[8 * i + j];
@@ -754,14 +759,16 @@ static void recon8(const int *lev /*raster*/, int qp, uint8_t *dst, int st) {
     }
 }
 /* forward side: projection on the decoder's (orthogonal) reconstruction basis, computed in floating point per QP */
-static float *basis8(int qp) {
-    static float *tab[52];
-    if (tab[qp]) return tab[qp];
+static int g_w8_version;
+static float *basis8(int qp, int list) {
+    static float *tab[2][52]; static int version[2][52];
+    if (tab[list][qp] && version[list][qp] == g_w8_version) return tab[list][qp];
+    free(tab[list][qp]);
     float *B = (float *)malloc(sizeof(float) * 64 * 65);
     for (int k = 0; k < 64; k++) {
         double d[64], g[64];
         for (int i = 0; i < 64; i++) d[i] = 0;
-        d[k] = 16.0 * norm8[qp % 6][cls8(k >> 3, k & 7)] * (double)(1 << (qp / 6)) / 64.0;
+        d[k] = (double)g_w8[list][k] * norm8[qp % 6][cls8(k >> 3, k & 7)] * (double)(1 << (qp / 6)) / 64.0;
         for (int pass = 0; pass < 2; pass++) {
             for (int r = 0; r < 8; r++) {
                 double in[8], a[8], b[8], *src = pass ? g : d;
@@ -777,12 +784,13 @@ static float *basis8(int qp) {
         for (int i = 0; i < 64; i++) { B[k * 65 + i] = (float)(d[i] / 64.0); nn += (d[i] / 64.0) * (d[i] / 64.0); }
         B[k * 65 + 64] = (float)nn;
     }
-    return tab[qp] = B;
+    version[list][qp] = g_w8_version;
+    return tab[list][qp] = B;
 }
 /* transform+quantise+reconstruct one luma 8x8 block (pred already in cur frame); returns nonzero count */
 static int code_luma8(Enc *e, int px, int py, int qp, int intra, int *levels /*raster*/) {
     Frame *c = &e->cur, *s = &e->src; float x[64]; int nz = 0;
-    const float *B = basis8(qp);
+    const float *B = basis8(qp, intra ? 0 : 1);
     for (int k = 0; k < 64; k++) x[k] = (float)(s->y[(py + (k >> 3)) * s->sy + px + (k & 7)] - c->y[(py + (k >> 3)) * c->sy + px + (k & 7)]);
     float dz = intra ? 0.33f : 0.17f;
     for (int k = 0; k < 64; k++) {
@@ -791,7 +799,7 @@ static int code_luma8(Enc *e, int px, int py, int qp, int intra, int *levels /*r
         float v = acc / b[64]; int z = (int)((v < 0 ? -v : v) + dz); z = MIN(z, 2000);
         levels[k] = v < 0 ? -z : z; nz += z != 0;
     }
-    if (nz) recon8(levels, qp, c->y + py * c->sy + px, c->sy);
+    if (nz) recon8(levels, qp, intra ? 0 : 1, c->y + py * c->sy + px, c->sy);
     return nz;
 }
 /* Intra8x8 (8.3.2): raw + filtered reference samples of 8x8 block b8; T/L index -1 = corner */
@@ -1154,20 +1162,20 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
             int x[16]; int px = mx * 16 + (r & 3) * 4, py = my * 16 + (r >> 2) * 4;
             for (int k = 0; k < 16; k++) x[k] = s->y[(py + (k >> 2)) * s->sy + px + (k & 3)] - c->y[(py + (k >> 2)) * c->sy + px + (k & 3)];
             fdct4(x, wblk[r]); dcw[r] = wblk[r][0]; mc.luma[r][0] = 0;
-            for (int k = 1; k < 16; k++) { mc.luma[r][k] = quant1(wblk[r][k], quant_mf[qp % 6][pos_class(k)], f, shift); any_ac |= mc.luma[r][k] != 0; }
+            for (int k = 1; k < 16; k++) { mc.luma[r][k] = quant1(wblk[r][k], quant_mf[qp % 6][pos_class(k)] * 16 / g_w4[0][k], f, shift); any_ac |= mc.luma[r][k] != 0; }
         }
         /* forward 4x4 Hadamard of the DCs, /2, quantise */
         int t[16], h[16];
         for (int i = 0; i < 4; i++) { int *r = dcw + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
         for (int j = 0; j < 4; j++) { h[j] = (t[j] + t[4 + j] + t[8 + j] + t[12 + j]) >> 1; h[4 + j] = (t[j] + t[4 + j] - t[8 + j] - t[12 + j]) >> 1; h[8 + j] = (t[j] - t[4 + j] - t[8 + j] + t[12 + j]) >> 1; h[12 + j] = (t[j] - t[4 + j] + t[8 + j] - t[12 + j]) >> 1; }
-        for (int k = 0; k < 16; k++) mc.dc16[k] = quant1(h[k], quant_mf[qp % 6][0], 2 * f, shift + 1);
+        for (int k = 0; k < 16; k++) mc.dc16[k] = quant1(h[k], quant_mf[qp % 6][0] * 16 / g_w4[0][0], 2 * f, shift + 1);
         if (!any_ac) for (int r = 0; r < 16; r++) for (int k = 1; k < 16; k++) mc.luma[r][k] = 0;
         cbp_l = any_ac ? 15 : 0;
         /* reconstruct: inverse Hadamard + scaling of DCs (8.5.10) */
         int g[16]; const int *cq = mc.dc16;
         for (int i = 0; i < 4; i++) { const int *r = cq + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
         for (int j = 0; j < 4; j++) { g[j] = t[j] + t[4 + j] + t[8 + j] + t[12 + j]; g[4 + j] = t[j] + t[4 + j] - t[8 + j] - t[12 + j]; g[8 + j] = t[j] - t[4 + j] - t[8 + j] + t[12 + j]; g[12 + j] = t[j] - t[4 + j] + t[8 + j] - t[12 + j]; }
-        int ls0 = 16 * norm4[qp % 6][0];
+        int ls0 = g_w4[0][0] * norm4[qp % 6][0]; g_wlist = 0;
         for (int r = 0; r < 16; r++) {
             int dq[16];
             dq[0] = qp >= 36 ? (g[r] * ls0) << (qp / 6 - 6) : (g[r] * ls0 + (1 << (5 - qp / 6))) >> (6 - qp / 6);
@@ -1705,15 +1713,53 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
 }
 
 /* ------------------------------ headers -------------------------------------- */
+static const uint8_t dflt4_intra[16] = {6,13,13,20,20,20,28,28,28,28,32,32,32,37,37,42}, dflt4_inter[16] = {10,14,14,20,20,20,24,24,24,24,27,27,27,30,30,34};
+static const uint8_t dflt8_intra[64] = {6,10,10,13,11,13,16,16,16,16,18,18,18,18,18,23,23,23,23,23,23,25,25,25,25,25,25,25,27,27,27,27,
+    27,27,27,27,29,29,29,29,29,29,29,31,31,31,31,31,31,33,33,33,33,33,36,36,36,36,38,38,38,40,40,42};
+static const uint8_t dflt8_inter[64] = {9,13,13,15,13,15,17,17,17,17,19,19,19,19,19,21,21,21,21,21,21,22,22,22,22,22,22,22,24,24,24,24,
+    24,24,24,24,25,25,25,25,25,25,25,27,27,27,27,27,27,28,28,28,28,28,30,30,30,30,32,32,32,33,33,35};
+/* scaling_matrix syntax (7.3.2.1.1 / 7.3.2.2) with fall-back rule A; chooses per list: absent, use-default, full list, truncated list.
+ * Leaves the effective matrices in g_w4 / g_w8 (raster order). */
+static void write_scaling_matrix(Enc *e, BitW *w, int n_lists) {
+    uint8_t eff[8][64]; Rng r; r.s = (uint64_t)e->p.seed * 0x51ED27ull + 99;      /* own generator: identical matrices in every SPS / PPS of the stream */
+    for (int i = 0; i < 8; i++) {
+        int n = i < 6 ? 16 : 64;
+        const uint8_t *dflt = i < 6 ? (i < 3 ? dflt4_intra : dflt4_inter) : (i == 6 ? dflt8_intra : dflt8_inter);
+        int choice = rnd_n(&r, 4);
+        if (i >= n_lists) { memcpy(eff[i], dflt, n); memset(eff[i], 16, n); continue; }   /* 8x8 lists not sent: flat (transform_8x8_mode off) */
+        if (choice == 0) {                                                 /* not present: fall-back rule A */
+            bw_put(w, 1, 0);
+            if (i == 0 || i == 3 || i >= 6) memcpy(eff[i], dflt, n); else memcpy(eff[i], eff[i - 1], n);
+            continue;
+        }
+        bw_put(w, 1, 1);
+        if (choice == 1) { bw_se(w, -8); memcpy(eff[i], dflt, n); continue; }          /* useDefaultScalingMatrixFlag */
+        int last = 8, stop = choice == 3 ? 1 + rnd_n(&r, n - 1) : n;
+        for (int j = 0; j < n; j++) {
+            if (j == stop) { bw_se(w, -last <= -128 ? 256 - last : -last); for (int k = j; k < n; k++) eff[i][k] = (uint8_t)last; break; }
+            int v = 8 + rnd_n(&r, 41);                                     /* 8..48 */
+            if (j > 0 && rnd_n(&r, 3)) v = CLIP3(8, 48, last + rnd_n(&r, 9) - 4);
+            int d = v - last; bw_se(w, d);
+            eff[i][j] = (uint8_t)v; last = v;
+        }
+    }
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 16; k++) g_w4[i][zz4[k]] = eff[i][k];
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 64; k++) g_w8[i][zz8[k]] = eff[6 + i][k];
+    g_w8_version++;
+}
 static void write_sps_pps(Enc *e) {
     BitW *w = &e->bw; GenParams *p = &e->p;
     w->len = 0; w->nbits = 0; w->cur = 0;
-    if (p->t8x8) { bw_put(w, 8, 100); bw_put(w, 8, 0); }                  /* High */
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 16; k++) g_w4[i][k] = 16;
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 64; k++) g_w8[i][k] = 16;
+    g_w8_version++;
+    int high = p->t8x8 || p->scaling;
+    if (high) { bw_put(w, 8, 100); bw_put(w, 8, 0); }                  /* High */
     else if (p->cabac || p->bframes || p->wp) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
     else { bw_put(w, 8, 66); bw_put(w, 8, 0xC0); }                        /* Baseline, constraint_set0/1 */
     bw_put(w, 8, p->level_idc);
     bw_ue(w, 0);
-    if (p->t8x8) { bw_ue(w, 1); bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, 0); }   /* 4:2:0, 8 bit, no bypass, no scaling matrix */
+    if (high) { bw_ue(w, 1); bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, (uint32_t)(p->scaling == 1)); if (p->scaling == 1) write_scaling_matrix(e, w, 8); }   /* 4:2:0, 8 bit, no bypass, scaling matrix */
     bw_ue(w, e->log2_max_fn - 4);
     bw_ue(w, p->poc_type);
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
@@ -1730,7 +1776,7 @@ static void write_sps_pps(Enc *e) {
     bw_put(w, 1, (uint32_t)(p->wp == 1)); bw_put(w, 2, (uint32_t)(p->bframes ? p->wp : 0));   /* weighted_pred_flag, weighted_bipred_idc */
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
     bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
-    if (p->t8x8) { bw_put(w, 1, 1); bw_put(w, 1, 0); bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, no scaling matrix, second_chroma_qp_index_offset */
+    if (high) { bw_put(w, 1, (uint32_t)p->t8x8); bw_put(w, 1, (uint32_t)(p->scaling == 2)); if (p->scaling == 2) write_scaling_matrix(e, w, 6 + 2 * p->t8x8); bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
 }
 
@@ -1871,6 +1917,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (p->search < 1) p->search = 4;
     if (!p->level_idc) p->level_idc = 40;
     if (p->poc_type != 0) p->poc_type = 2;
+    p->scaling = CLIP3(0, 2, p->scaling);
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
     else { p->poc_type = 0; p->nonref_period = 0; if (p->num_ref < 2) p->num_ref = 2; p->dinf8 = p->dinf8 != 0; }
@@ -1918,7 +1965,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
