@@ -19,6 +19,7 @@
 //                    HBM traffic is the algorithmic minimum: every sample is read once (prefetched one step
 //                    ahead) and written once, as whole 16-byte row segments of a (-4,-4)-shifted 16x16 block.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "jobs.h"
 #include "kernels.h"
 #include "kernel_common.h"
@@ -135,12 +136,12 @@ constexpr int kMaxSlots = 5;             // rows g, g+32, ... g+128 -> pictures 
 // Workgroup 0 (luma) and workgroup 1 (chroma) each own a private LDS image laid out the same way:
 // 32 x 64 B DbRec staging, then per macroblock row the tile pair, then per row the ring.
 struct Lds {
-    uint8_t *base; int mb_h;
+    uint8_t *base; int mb_h; int hdr;     // hdr = bytes of DbRec staging in front (64 per group)
     __device__ uint8_t *rec(int group) const { return base + group * 64; }
-    __device__ uint8_t *luma_tile(int row, int par) const { return base + 2048 + (size_t)row * 512 + par * 256; }
-    __device__ uint8_t *luma_ring(int row, int slot) const { return base + 2048 + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
-    __device__ uint8_t *chroma_tile(int row, int par) const { return base + 2048 + (size_t)row * 256 + par * 128; }
-    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + 2048 + (size_t)mb_h * 256 + (size_t)row * 128 + slot * 32; }
+    __device__ uint8_t *luma_tile(int row, int par) const { return base + hdr + (size_t)row * 512 + par * 256; }
+    __device__ uint8_t *luma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
+    __device__ uint8_t *chroma_tile(int row, int par) const { return base + hdr + (size_t)row * 256 + par * 128; }
+    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * 256 + (size_t)row * 128 + slot * 32; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -307,12 +308,16 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
 // ------------------------------------------------------------------------------------------
 // grid = 2 workgroups of 512 threads: block 0 filters luma, block 1 chroma (independent planes, no exchange).
 // 512 threads = 2 waves per SIMD, so each lane may use up to 256 VGPRs: the edge chains never spill.
-__global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
+// GROUPS 16-lane groups per workgroup (one macroblock row each per slot), NSLOTS rows per group.  (64, 3): 1024 threads = 4 waves
+// per SIMD hide the latency of the dependent filter chains, and at most one macroblock per group is active in a step for pictures
+// up to 64 rows tall / two up to 128 (instead of two / three with 32 groups); needs <= 128 VGPRs.  (32, 5): the 512-thread form.
+template <int GROUPS, int NSLOTS>
+__global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pics) {
     extern __shared__ __align__(16) uint8_t smem[];
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_DEBLOCK_LDS)) return;
     const DbRec *recs = (const DbRec *)pp.dbrec;
-    Lds lds{smem, pp.mb_h};
+    Lds lds{smem, pp.mb_h, GROUPS * 64};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_chroma = blockIdx.x == 1;
     const int group = wave * 4 + (lane >> 4), l = lane & 15;
@@ -321,14 +326,14 @@ __global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
     const int rows_per_mb = is_chroma ? 8 : 16;
     const int my_row = is_chroma ? (l & 7) : l;
     const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
-    uint4 pre_pix[kMaxSlots]; uint32_t pre_rec[kMaxSlots];
+    uint4 pre_pix[NSLOTS]; uint32_t pre_rec[NSLOTS];
 #pragma unroll
-    for (int k = 0; k < kMaxSlots; k++) { pre_pix[k] = make_uint4(0, 0, 0, 0); pre_rec[k] = 0; }
+    for (int k = 0; k < NSLOTS; k++) { pre_pix[k] = make_uint4(0, 0, 0, 0); pre_rec[k] = 0; }
     const int n_steps = mb_w + 2 * (mb_h - 1);
     // prefetch for step 0
 #pragma unroll
-    for (int k = 0; k < kMaxSlots; k++) {
-        int row = group + kGroups * k;
+    for (int k = 0; k < NSLOTS; k++) {
+        int row = group + GROUPS * k;
         if (row < mb_h && 2 * row == 0) {
             pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch);
             pre_rec[k] = ((const uint32_t *)&recs[row * mb_w])[rec_dw];
@@ -337,16 +342,16 @@ __global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
     for (int s = 0; s < n_steps; s++) {
         // (1) take delivery of what was prefetched during the previous step.  The empty asm "uses" the
         //     registers, so the compiler's s_waitcnt lands HERE, before this step's loads are issued.
-        uint4 own[kMaxSlots]; uint32_t rdw[kMaxSlots];
+        uint4 own[NSLOTS]; uint32_t rdw[NSLOTS];
 #pragma unroll
-        for (int k = 0; k < kMaxSlots; k++) {
+        for (int k = 0; k < NSLOTS; k++) {
             own[k] = pre_pix[k]; rdw[k] = pre_rec[k];
             asm volatile("" : "+v"(own[k].x), "+v"(own[k].y), "+v"(own[k].z), "+v"(own[k].w), "+v"(rdw[k]));
         }
         // (2) prefetch the macroblocks of the next step
 #pragma unroll
-        for (int k = 0; k < kMaxSlots; k++) {
-            int row = group + kGroups * k;
+        for (int k = 0; k < NSLOTS; k++) {
+            int row = group + GROUPS * k;
             int xn = s + 1 - 2 * row;
             if (row < mb_h && xn >= 0 && xn < mb_w) {
                 pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
         }
         // (3) filter this step's macroblocks out of registers + LDS
 #pragma unroll
-        for (int k = 0; k < kMaxSlots; k++) {
-            int row = group + kGroups * k;
+        for (int k = 0; k < NSLOTS; k++) {
+            int row = group + GROUPS * k;
             int x = s - 2 * row;
             if (row < mb_h && x >= 0 && x < mb_w) {
                 if (is_chroma) chroma_mb(pp, lds, x, row, l, group, own[k], rdw[k]);
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void k_deblock_lds(const PicParams *pics) {
 }
 
 // ------------------------------------------------------------------------------------------
-size_t deblock_lds_bytes(int mb_h) { return 2048 + (size_t)mb_h * 768; }      // luma workgroup's need (chroma needs half)
+size_t deblock_lds_bytes(int mb_h) { return 4096 + (size_t)mb_h * 768; }      // luma workgroup's need (chroma needs half)
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
 
 void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st) {
@@ -378,11 +383,14 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void *)k_deblock_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipFuncSetAttribute((const void *)k_deblock_lds<32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipFuncSetAttribute((const void *)k_deblock_lds<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)
-    hipLaunchKernelGGL(k_deblock_lds, dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
+    static const bool wide = !getenv("JM_AMD_DEC_DEBLOCK_512");
+    if (wide) hipLaunchKernelGGL((k_deblock_lds<64, 3>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
+    else hipLaunchKernelGGL((k_deblock_lds<32, 5>), dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
 }
 
 }  // namespace jmamd

@@ -130,7 +130,8 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
     if (codec_type != 0) { fail("only codec_type 0 (H.264) is implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
-    if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
+    if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;
+    out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
     if (engine_) engine_->set_profile(profile_);
@@ -186,7 +187,7 @@ void Decoder::gpu_free_sequence() {
         if (j.uploaded) hipEventDestroy(j.uploaded);
         j = JobSlot();
     }
-    for (OutSlot *o : all_out_) { if (o->host) hipHostFree(o->host); delete o; }
+    for (OutSlot *o : all_out_) { if (o->host) hipHostFree(o->host); if (o->dev) hipFree(o->dev); delete o; }
     all_out_.clear(); free_out_.clear(); ready_.clear(); cur_out_ = nullptr;
 }
 void Decoder::gpu_close() {
@@ -239,6 +240,8 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     if (!parse_only_) {
         hipSetDevice(device_);
         if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if (out_via_copy_engine_ && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
+        o->bytes = frame_bytes_;
     }
     all_out_.push_back(o);
     return o;
@@ -757,8 +760,9 @@ void Decoder::enqueue_output(int slot, std::vector<PackJob> &jobs, std::vector<O
     OutSlot *o;
     { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
     if (parse_only_ || failed_) { std::lock_guard<std::mutex> lk(mtx_); o->ready = true; return; }
-    // k_packout stores the tight frame straight into the pinned host slot (PCIe writes from the kernel, no copy-engine hop)
-    jobs.push_back(PackJob{surf_[slot], o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, 0});
+    // k_packout packs the tight frame into device staging and a copy engine moves it to the pinned slot -- or, in direct mode,
+    // the kernel stores straight into the pinned host slot (see Engine::launch for why the copy engine is the default)
+    jobs.push_back(PackJob{surf_[slot], o->dev ? o->dev : o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, 0});
     slots.push_back(o);
     o->has_data = true;
 }

@@ -68,6 +68,8 @@ struct JobSlot {                       // one picture's job list: pinned host bu
 };
 struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
     uint8_t *host = nullptr;
+    uint8_t *dev = nullptr;            // device staging of the packed frame (copy-engine mode, see Engine::launch)
+    size_t bytes = 0;
     bool has_data = false, ready = false;
 };
 
@@ -124,7 +126,7 @@ private:
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
-    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true;
     std::string error_;
     bool failed_ = false, inited_ = false;
 

@@ -41,6 +41,7 @@ Engine::Engine(int device) : device_(device) {
             if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&b.packed, hipEventDisableTiming) != hipSuccess) return;
             for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
         }
     }
@@ -127,7 +128,11 @@ void Engine::launch(Lane &ln, Batch &b) {
     if ((wait_pack || b.n_pre) && ln.pack_hist[0]) hipStreamWaitEvent(st, ln.pack_hist[0], 0);
     auto mark = [&](int i, hipStream_t s) { if (profile_) hipEventRecord(b.pev[i], s); };
     mark(0, st);
-    if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; }
+    // Pack-out: k_packout writes the tight frames into device staging and a copy engine (SDMA) moves them to the pinned slots.
+    // Letting the kernel store into host memory directly saves that hop but its PCIe-bound stores share the L2 / fabric write
+    // queues with everything else: k_recon_inter of the next batch ran 4x slower next to it (0.56 -> 2.3 ms for 32 pictures).
+    auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
+    if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; for (auto &p : b.pics) copy_out(p.slots_before, st); }
     mark(1, st);
     if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
     mark(2, st);
@@ -140,12 +145,15 @@ void Engine::launch(Lane &ln, Batch &b) {
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
     mark(5, pst);
-    if (b.n_post) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pst); b.pmask |= 16; }
+    static const bool no_pack = getenv("JM_AMD_DEC_EXP_NOPACK") != nullptr;           // experiment only: frames are not written
+    if (b.n_post && !no_pack) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pst); b.pmask |= 16; }
     mark(6, pst);
+    hipEventRecord(b.packed, pst);                            // from here on the displayed surfaces may be decoded into again
+    if (!no_pack) for (auto &p : b.pics) copy_out(p.slots_after, pst);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) fprintf(stderr, "jm_amd_dec: kernel launch failed: %s\n", hipGetErrorString(le));
     hipEventRecord(b.done, pst);
-    ln.pack_hist[1] = ln.pack_hist[0]; ln.pack_hist[0] = b.done;
+    ln.pack_hist[1] = ln.pack_hist[0]; ln.pack_hist[0] = b.packed;
 }
 
 void Engine::complete(Batch &b) {

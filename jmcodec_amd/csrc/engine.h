@@ -73,14 +73,14 @@ private:
     struct Batch {
         PicParams *h_pics = nullptr, *d_pics = nullptr;       // pinned host / device, kMaxBatch entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
-        ihipEvent_t *done = nullptr, *kdone = nullptr, *pev[8] = {nullptr};
+        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[4] = {0, 0, 0, 0}; int npics[4] = {0, 0, 0, 0};
     };
     struct Lane {
         ihipStream_t *stream = nullptr, *pack_stream = nullptr;
-        ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // done events of the two most recently launched batches
+        ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // 'packed' events of the two most recently launched batches
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
     };

@@ -9,6 +9,7 @@
 //   k_packout       pitch NV12 surface -> tight NV12 / I420 display frame              (fully parallel)
 // All arithmetic is 8-bit integer pixel work: HBM/LDS bound, no MFMA.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "jobs.h"
 #include "kernels.h"
 #include "kernel_common.h"
@@ -202,8 +203,54 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     bool inter = valid && r.kind == MB_INTER;
     bool intra_res = valid && pp.want_intra_resid && (r.kind == MB_I4 || r.kind == MB_I16);
     bool has_res = (inter || intra_res) && mb_has_residual(r);
+    const int mbx = valid ? mb % pp.mb_w : 0, mby = valid ? mb / pp.mb_w : 0;
+    const int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
+    // Everything an ordinary inter macroblock reads from its reference pictures depends only on the record, not on the residual:
+    // issue those loads first so that their latency overlaps the coefficient loads and the inverse transform (the kernel is
+    // latency bound: SQ_WAIT_ANY was 65 % of SQ_WAVE_CYCLES with the loads issued where they were consumed).
+    const bool plain = inter && !(r.modes & MBM_BIPRED);
+    bool fast = false;
+    uint32_t wv[5] = {0, 0, 0, 0, 0};                       // this lane's dwords of the 13x13 reference window (fast path)
+    int c_smp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // chroma: the four neighbours of (cx, cy), U then V
+    int c_slot = -1, c_fx = 0, c_fy = 0;
+    if (plain) {
+        {
+            int g = lane >> 4;                              // 8x8 block of this lane in the fast-path mapping
+            int mvx, mvy; rec_mv8(r, g, mvx, mvy);
+            int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2;
+            bool ok = !(r.flags & MBF_MV_EXT) && rec_ref(r, g) >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
+            fast = __all(ok);                               // wave-uniform: the whole macroblock takes one path
+            if (fast) {
+                const uint8_t *ref = pp.surf[rec_ref(r, g)];
+                int l = lane & 15, xa = xi & ~3;
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    int i = l + 16 * t;
+                    if (i < 65) { int row = i / 5, dw = i % 5; wv[t] = *(const uint32_t *)(ref + (size_t)(yi + row) * pitch + xa + dw * 4); }
+                }
+            }
+        }
+        {
+            int cx = lane & 7, cy = lane >> 3;
+            int rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
+            int mvx, mvy;
+            if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
+            else rec_mv8(r, b8, mvx, mvy);
+            c_slot = rec_ref(r, b8); c_fx = mvx & 7; c_fy = mvy & 7;
+            if (c_slot >= 0) {
+                const uint8_t *rc = pp.surf[c_slot] + pp.chroma_offset;
+                int CW = W >> 1, CH = H >> 1;
+                int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3);
+                int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
+                const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
+                c_smp[0] = r0[2 * xa]; c_smp[1] = r0[2 * xb]; c_smp[2] = r1[2 * xa]; c_smp[3] = r1[2 * xb];
+                c_smp[4] = r0[2 * xa + 1]; c_smp[5] = r0[2 * xb + 1]; c_smp[6] = r1[2 * xa + 1]; c_smp[7] = r1[2 * xb + 1];
+            }
+        }
+    }
     if (has_res) mb_residual_to_lds(pp, r, tiles[wave], lane);
-    __syncthreads();
+    // the residual tile is private to this wave and LDS operations of one wave complete in order: no workgroup barrier needed
+    __builtin_amdgcn_wave_barrier();
     if (!valid) return;
     if (intra_res) {
         // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
@@ -213,8 +260,6 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         }
         return;
     }
-    int mbx = mb % pp.mb_w, mby = mb / pp.mb_w;
-    int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
     uint8_t *dst = pp.surf[pp.cur];
     uint8_t *dst_c = dst + pp.chroma_offset;
     uint32_t *ot = outt[wave];
@@ -290,27 +335,16 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
     // The fractional position is uniform inside a block, so the 6-tap paths do not diverge within the 16 lanes.
     // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
-    bool fast;
-    {
-        int g = lane >> 4;                                  // 8x8 block of this lane in the fast-path mapping
-        int mvx, mvy; rec_mv8(r, g, mvx, mvy);
-        int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2;
-        bool ok = !(r.flags & MBF_MV_EXT) && rec_ref(r, g) >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
-        fast = __all(ok);                                   // wave-uniform: the whole macroblock takes one path
-    }
     if (fast) {
         int g = lane >> 4, l = lane & 15;
         int mvx, mvy; rec_mv8(r, g, mvx, mvy);
         int fx = mvx & 3, fy = mvy & 3;
         int bx0 = mbx * 16 + (g & 1) * 8, by0 = mby * 16 + (g >> 1) * 8;
-        int xi = bx0 + (mvx >> 2) - 2, yi = by0 + (mvy >> 2) - 2;
-        const uint8_t *ref = pp.surf[rec_ref(r, g)];
+        int xi = bx0 + (mvx >> 2) - 2;
         uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
-        int xa = xi & ~3, sh = xi & 3;
-        for (int i = l; i < 65; i += 16) {
-            int row = i / 5, dw = i % 5;
-            win[row * 5 + dw] = *(const uint32_t *)(ref + (size_t)(yi + row) * pitch + xa + dw * 4);
-        }
+        int sh = xi & 3;
+#pragma unroll
+        for (int t = 0; t < 5; t++) { int i = l + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
         // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
         int rr = l >> 1, hh = l & 1;
         // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
@@ -390,25 +424,15 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         }
         ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     }
-    // ---- chroma: lane -> chroma position (cx, cy), both planes ----
+    // ---- chroma: lane -> chroma position (cx, cy), both planes; the four neighbours were loaded up front ----
     {
         int cx = lane & 7, cy = lane >> 3;
-        int rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
-        int mvx, mvy;
-        if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
-        else rec_mv8(r, b8, mvx, mvy);
-        int slot = rec_ref(r, b8);
         int u, v;
-        if (slot < 0) { u = v = 128; }
+        if (c_slot < 0) { u = v = 128; }
         else {
-            const uint8_t *rc = pp.surf[slot] + pp.chroma_offset;
-            int CW = W >> 1, CH = H >> 1;
-            int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
-            int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
-            const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
-            int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
-            u = (w00 * r0[2 * xa] + w01 * r0[2 * xb] + w10 * r1[2 * xa] + w11 * r1[2 * xb] + 32) >> 6;
-            v = (w00 * r0[2 * xa + 1] + w01 * r0[2 * xb + 1] + w10 * r1[2 * xa + 1] + w11 * r1[2 * xb + 1] + 32) >> 6;
+            int w00 = (8 - c_fx) * (8 - c_fy), w01 = c_fx * (8 - c_fy), w10 = (8 - c_fx) * c_fy, w11 = c_fx * c_fy;
+            u = (w00 * c_smp[0] + w01 * c_smp[1] + w10 * c_smp[2] + w11 * c_smp[3] + 32) >> 6;
+            v = (w00 * c_smp[4] + w01 * c_smp[5] + w10 * c_smp[6] + w11 * c_smp[7] + 32) >> 6;
         }
         if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
@@ -934,8 +958,9 @@ void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height,
     int blocks = (chunks + 255) / 256;
     // The destination is pinned HOST memory: the kernel is PCIe-bound (~55 GB/s), not CU-bound.  A small grid is enough to
     // keep the link full and leaves the CUs to the decode kernels of the next batch that run concurrently.
-    int cap = 160 / (n > 0 ? n : 1);
-    if (cap < 2) cap = 2;
+    static const int total = getenv("JM_AMD_DEC_PACK_WGS") ? atoi(getenv("JM_AMD_DEC_PACK_WGS")) : 160;
+    int cap = total / (n > 0 ? n : 1);
+    if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_packout, dim3(blocks, n), dim3(256), 0, st, d_jobs);
 }
