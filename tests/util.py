@@ -99,6 +99,14 @@ B_CASES = {
     "scaling_pps_high_cabac": dict(width=96, height=80, frames=8, gop=4, mode=1, seed=101, scaling=2, t8x8=1, cabac=1, num_ref=2),
     "scaling_sps_high_b": dict(width=96, height=80, frames=8, gop=8, mode=1, seed=102, scaling=1, t8x8=1, cabac=1, bframes=2),
     "scaling_real_qvga": dict(width=320, height=240, frames=6, gop=6, seed=103, scaling=1, t8x8=1, cabac=1),
+    # reference list modification (8.2.4.3), memory management control operations and long-term references (8.2.5.4)
+    "rplm_p": dict(width=96, height=80, frames=14, gop=14, mode=1, seed=104, rplm=1, num_ref=4),
+    "rplm_b_cabac": dict(width=96, height=80, frames=14, gop=14, mode=1, seed=105, rplm=1, num_ref=4, bframes=2, cabac=1),
+    "rplm_b_temporal": dict(width=96, height=80, frames=12, gop=12, mode=1, seed=106, rplm=1, num_ref=3, bframes=1, direct_temporal=1),
+    "mmco_longterm": dict(width=96, height=80, frames=20, gop=20, mode=1, seed=107, mmco=1, num_ref=4),
+    "mmco_longterm_rplm_cabac": dict(width=96, height=80, frames=20, gop=10, mode=1, seed=108, mmco=1, rplm=1, num_ref=3, cabac=1, t8x8=1),
+    "mmco_two_refs_poc0": dict(width=96, height=80, frames=20, gop=20, mode=1, seed=17, mmco=1, num_ref=2, poc_type=0, slices=2),
+    "mmco_one_ref": dict(width=96, height=80, frames=16, gop=16, mode=1, seed=109, mmco=1, num_ref=1),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

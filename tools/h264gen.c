@@ -51,6 +51,8 @@ typedef struct {
     int wp;                     /* 0 none, 1 explicit weights (P and B), 2 implicit (B)          */
     int dinf8;                  /* direct_8x8_inference_flag (default 1 when 0 is passed with bframes == 0) */
     int scaling;                /* 0 flat, 1 scaling lists in the SPS, 2 in the PPS (forces High profile)             */
+    int rplm;                   /* 1: random ref_pic_list_modification() in P / B slices (fuzz)                       */
+    int mmco;                   /* 1: random memory_management_control_operations, long-term references (P-only streams) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -210,6 +212,7 @@ typedef struct {
     uint8_t *hb, *hh, *hj;         /* luma half-pel planes (origin pointers)     */
     uint8_t *bhb, *bhh, *bhj;
     int frame_num, poc, id;
+    int is_long, lt_idx;           /* long-term reference with LongTermFrameIdx lt_idx */
     void *mf;                      /* MbE[] motion field of the picture (colocated data for direct prediction) */
 } Frame;
 
@@ -235,6 +238,9 @@ typedef struct {
     Frame *list1[5]; int nlist1; int cur_poc;
     int wlog[2], ww[2][5][3], wo[2][5][3];   /* explicit weighted prediction: log2 denominators (luma, chroma), weight / offset [list][ref][Y,Cb,Cr] */
     uint8_t *recon_buf; int recon_frames;
+    int max_lt_idx;                         /* MaxLongTermFrameIdx, -1 = "no long-term frame indices" */
+    int n_mod[2], mod_idc[2][8], mod_val[2][8];   /* ref_pic_list_modification of the current picture */
+    int n_mmco, mmco_op[12], mmco_a[12], mmco_b[12], idr_long;   /* dec_ref_pic_marking of the current picture */
     int16_t tex[256][256];
     int next_id;
     int decoded_mask;
@@ -1791,10 +1797,20 @@ static void encode_frame(Enc *e, int t, int is_b) {
     e->slice_type = idr ? 2 : (is_b ? 1 : 0);
     if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0) e->slice_type = 2;   /* occasional non-IDR I picture */
     e->cur_poc = 2 * (t % p->gop); e->cur.poc = e->cur_poc;
+    const int maxfn = 1 << e->log2_max_fn, curfn = e->frame_num & (maxfn - 1);
+    e->cur.frame_num = curfn; e->cur.is_long = 0; e->cur.lt_idx = -1;
+#define PICNUM(f) ((f)->frame_num > curfn ? (f)->frame_num - maxfn : (f)->frame_num)
+    Frame *init[2][5]; int ninit[2] = {0, 0};
     if (!is_b) {
-        /* RefPicList0: short-term refs by descending PicNum == most recent first */
-        e->nlist0 = MIN(e->nrefs, p->num_ref); e->nlist1 = 0;
-        for (int i = 0; i < e->nlist0; i++) e->list0[i] = &e->refs[i];
+        /* 8.2.4.2.1: short-term references by descending PicNum (most recent first), then long-term by ascending LongTermPicNum */
+        Frame *sh[5], *lg[5]; int ns = 0, nl = 0;
+        for (int i = 0; i < e->nrefs; i++) { if (e->refs[i].is_long) lg[nl++] = &e->refs[i]; else sh[ns++] = &e->refs[i]; }
+        for (int i = 0; i < ns; i++) for (int j = i + 1; j < ns; j++) if (PICNUM(sh[j]) > PICNUM(sh[i])) { Frame *x = sh[i]; sh[i] = sh[j]; sh[j] = x; }
+        for (int i = 0; i < nl; i++) for (int j = i + 1; j < nl; j++) if (lg[j]->lt_idx < lg[i]->lt_idx) { Frame *x = lg[i]; lg[i] = lg[j]; lg[j] = x; }
+        for (int i = 0; i < ns; i++) init[0][ninit[0]++] = sh[i];
+        for (int i = 0; i < nl; i++) init[0][ninit[0]++] = lg[i];
+        e->nlist0 = MIN(ninit[0], p->num_ref); e->nlist1 = 0;
+        for (int i = 0; i < e->nlist0; i++) e->list0[i] = init[0][i];
     } else {
         /* 8.2.4.2.3: list 0 = earlier pictures by descending POC then later ones ascending; list 1 the other way round */
         Frame *before[5], *after[5]; int nb = 0, na = 0, n = MIN(e->nrefs, p->num_ref);
@@ -1807,7 +1823,62 @@ static void encode_frame(Enc *e, int t, int is_b) {
         for (int i = 0; i < na; i++) e->list1[e->nlist1++] = after[i];
         for (int i = 0; i < nb; i++) e->list1[e->nlist1++] = before[i];
         if (e->nlist1 > 1) { int same = 1; for (int i = 0; i < e->nlist0; i++) if (e->list0[i] != e->list1[i]) same = 0; if (same) { Frame *x = e->list1[0]; e->list1[0] = e->list1[1]; e->list1[1] = x; } }
+        for (int i = 0; i < e->nlist0; i++) init[0][ninit[0]++] = e->list0[i];
+        for (int i = 0; i < e->nlist1; i++) init[1][ninit[1]++] = e->list1[i];
         if (p->mode == 1) { e->nlist0 = 1 + rnd_n(&e->rng, e->nlist0); e->nlist1 = 1 + rnd_n(&e->rng, e->nlist1); }   /* num_ref_idx_active override */
+    }
+    /* 8.2.4.3: random modification of the initial lists (fuzz).  The final list is computed with the clause's own insertion rule */
+    e->n_mod[0] = e->n_mod[1] = 0;
+    if (p->rplm && e->slice_type != 2) for (int l = 0; l < (is_b ? 2 : 1); l++) {
+        int nact = l ? e->nlist1 : e->nlist0;
+        if (nact < 1 || rnd_n(&e->rng, 2)) continue;
+        Frame *list[8]; for (int i = 0; i < 8; i++) list[i] = i < ninit[l] && i < nact ? init[l][i] : NULL;
+        int m = 1 + rnd_n(&e->rng, MIN(nact, 3)), pred = curfn, idx = 0;
+        for (int k = 0; k < m; k++) {
+            Frame *tg = init[l][rnd_n(&e->rng, ninit[l])];
+            if (tg->is_long) { e->mod_idc[l][k] = 2; e->mod_val[l][k] = tg->lt_idx; }
+            else {
+                int pn = PICNUM(tg), nowrap = pn < 0 ? pn + maxfn : pn, diff = nowrap - pred;
+                if (diff > 0) { e->mod_idc[l][k] = 1; e->mod_val[l][k] = diff - 1; }
+                else if (diff < 0) { e->mod_idc[l][k] = 0; e->mod_val[l][k] = -diff - 1; }
+                else { e->mod_idc[l][k] = 0; e->mod_val[l][k] = maxfn - 1; }            /* a full turn lands on the same PicNum */
+                pred = nowrap;
+            }
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = tg;
+            int n = idx;
+            for (int c = idx; c <= nact; c++) if (list[c] != tg) list[n++] = list[c];
+        }
+        e->n_mod[l] = m;
+        int cnt = 0;
+        for (int i = 0; i < nact; i++) if (list[i]) { (l ? e->list1 : e->list0)[cnt++] = list[i]; } else break;
+        if (l) e->nlist1 = cnt; else e->nlist0 = cnt;
+    }
+    /* 8.2.5: marking of this picture (decided before the slices are written; applied after the picture is coded) */
+    e->n_mmco = 0; e->idr_long = 0;
+    if (p->mmco && is_ref && !is_b) {
+        if (idr) e->idr_long = rnd_n(&e->rng, 3) == 0;
+        else {
+            int st_fn[5], st_n = 0, lt_ix[5], lt_n = 0, maxlt = e->max_lt_idx, cur_long = 0;      /* simulated state */
+            for (int i = 0; i < e->nrefs; i++) { if (e->refs[i].is_long) lt_ix[lt_n++] = e->refs[i].lt_idx; else st_fn[st_n++] = PICNUM(&e->refs[i]); }
+            /* the sliding window needs a short-term picture to drop (8.2.5.3): with only long-term pictures in a full buffer the
+               stream MUST use memory management operations */
+            int must = st_n == 0 && lt_n >= p->num_ref;
+            if (must || rnd_n(&e->rng, 3) == 0) {
+#define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
+#define DROP_LT(ix) do { for (int q_ = 0; q_ < lt_n; q_++) if (lt_ix[q_] == (ix)) { lt_ix[q_] = lt_ix[--lt_n]; break; } } while (0)
+            if (maxlt < 1 && rnd_n(&e->rng, 2)) { ADD_OP(4, 2, 0); maxlt = 1; }
+            if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1); ADD_OP(3, curfn - st_fn[k] - 1, ix); DROP_LT(ix); lt_ix[lt_n++] = ix; st_fn[k] = st_fn[--st_n]; }
+            if (st_n > 0 && rnd_n(&e->rng, 3) == 0) { int k = rnd_n(&e->rng, st_n); ADD_OP(1, curfn - st_fn[k] - 1, 0); st_fn[k] = st_fn[--st_n]; }
+            if (lt_n > 0 && rnd_n(&e->rng, 4) == 0) { int k = rnd_n(&e->rng, lt_n); ADD_OP(2, lt_ix[k], 0); lt_ix[k] = lt_ix[--lt_n]; }
+            if (maxlt >= 0 && rnd_n(&e->rng, 4) == 0) { int ix = rnd_n(&e->rng, maxlt + 1); ADD_OP(6, 0, ix); DROP_LT(ix); cur_long = 1; }
+            (void)cur_long;
+            while (st_n + lt_n + 1 > p->num_ref) {                       /* room for the current picture */
+                if (st_n > 0) { int k = 0; for (int i = 1; i < st_n; i++) if (st_fn[i] < st_fn[k]) k = i; ADD_OP(1, curfn - st_fn[k] - 1, 0); st_fn[k] = st_fn[--st_n]; }
+                else { ADD_OP(2, lt_ix[0], 0); lt_ix[0] = lt_ix[--lt_n]; }
+            }
+            }
+        }
     }
     /* explicit weights of this picture (8.4.2.3); the same table is sent in every slice */
     e->wlog[0] = 5; e->wlog[1] = 5;
@@ -1836,8 +1907,12 @@ static void encode_frame(Enc *e, int t, int is_b) {
         if (idr) bw_ue(w, e->idr_id & 0xffff);
         if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_poc & ((1u << e->poc_lsb_bits) - 1));
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
-        if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); bw_put(w, 1, 0); }
-        if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); bw_put(w, 1, 0); bw_put(w, 1, 0); }   /* override, no list modification */
+        if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); }
+        if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); }
+        for (int l = 0; l < (e->slice_type == 2 ? 0 : (e->slice_type == 1 ? 2 : 1)); l++) {                       /* ref_pic_list_modification() */
+            bw_put(w, 1, (uint32_t)(e->n_mod[l] > 0));
+            if (e->n_mod[l]) { for (int k = 0; k < e->n_mod[l]; k++) { bw_ue(w, e->mod_idc[l][k]); bw_ue(w, e->mod_val[l][k]); } bw_ue(w, 3); }
+        }
         if (use_wp) {                                                     /* pred_weight_table() */
             bw_ue(w, e->wlog[0]); bw_ue(w, e->wlog[1]);
             for (int l = 0; l < (e->slice_type == 1 ? 2 : 1); l++) for (int i = 0; i < (l ? e->nlist1 : e->nlist0); i++) {
@@ -1847,7 +1922,12 @@ static void encode_frame(Enc *e, int t, int is_b) {
                 bw_put(w, 1, (uint32_t)fc); if (fc) for (int c = 1; c < 3; c++) { bw_se(w, e->ww[l][i][c]); bw_se(w, e->wo[l][i][c]); }
             }
         }
-        if (is_ref) { if (idr) { bw_put(w, 1, 0); bw_put(w, 1, 0); } else bw_put(w, 1, 0); }
+        if (is_ref) {                                                     /* dec_ref_pic_marking() */
+            if (idr) { bw_put(w, 1, 0); bw_put(w, 1, (uint32_t)e->idr_long); }
+            else { bw_put(w, 1, (uint32_t)(e->n_mmco > 0));
+                for (int k = 0; k < e->n_mmco; k++) { int o = e->mmco_op[k]; bw_ue(w, o); if (o == 1 || o == 3) bw_ue(w, e->mmco_a[k]); if (o == 2) bw_ue(w, e->mmco_a[k]); if (o == 3 || o == 6) bw_ue(w, e->mmco_b[k]); if (o == 4) bw_ue(w, e->mmco_a[k]); }
+                if (e->n_mmco) bw_ue(w, 0); }
+        }
         if (e->cabac && e->slice_type != 2) bw_ue(w, p->cabac_idc);
         bw_se(w, 0);                                                      /* slice_qp_delta */
         int idc = p->deblock == 1 ? 0 : (p->deblock == 0 ? 1 : 2);
@@ -1879,6 +1959,7 @@ static void encode_frame(Enc *e, int t, int is_b) {
         for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x]; se += d * d; }
         for (int i = 0; i < mbs_total; i++) { MbE *m = &e->mbs[i]; cnt[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)]++; if (!m->intra) for (int k = 0; k < 16; k++) { nzmv += m->mv[k][0] || m->mv[k][1]; qmv += (m->mv[k][0] & 3) || (m->mv[k][1] & 3); } }
         double mse = se / (p->width * p->height);
+        if (e->n_mmco || e->n_mod[0] || e->n_mod[1]) { fprintf(stderr, "  frame %d fn %d:", t, e->frame_num); for (int k = 0; k < e->n_mmco; k++) fprintf(stderr, " mmco%d(%d,%d)", e->mmco_op[k], e->mmco_a[k], e->mmco_b[k]); for (int l = 0; l < 2; l++) for (int k = 0; k < e->n_mod[l]; k++) fprintf(stderr, " mod%d(%d,%d)", l, e->mod_idc[l][k], e->mod_val[l][k]); fprintf(stderr, " list0:"); for (int i = 0; i < e->nlist0; i++) fprintf(stderr, " %s%d", e->list0[i]->is_long ? "L" : "fn", e->list0[i]->is_long ? e->list0[i]->lt_idx : e->list0[i]->frame_num); fprintf(stderr, "\n"); }
         fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t, idr ? 'I' : (e->slice_type == 2 ? 'i' : (is_b ? 'B' : 'P')), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
     }
     if (e->recon_buf && t < e->recon_frames) {                           /* display order */
@@ -1893,12 +1974,30 @@ static void encode_frame(Enc *e, int t, int is_b) {
         frame_finish_ref(&e->cur, e->W, e->H);
         if (!e->cur.mf) e->cur.mf = malloc(sizeof(MbE) * (size_t)mbs_total);
         memcpy(e->cur.mf, e->mbs, sizeof(MbE) * (size_t)mbs_total);
-        /* sliding window: newest first */
-        int n = MIN(e->nrefs, p->num_ref - 1);
-        Frame last = e->refs[n];
-        for (int i = n; i > 0; i--) e->refs[i] = e->refs[i - 1];
-        e->refs[0] = e->cur; e->cur = last;
-        e->nrefs = MIN(e->nrefs + 1, p->num_ref);
+        /* 8.2.5 marking; e->refs[] is the set of reference frames, refs[nrefs..4] + cur are free frame stores */
+#define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; for (int q_ = (i_); q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; e->nrefs--; e->refs[e->nrefs] = t_; } while (0)
+        if (idr) { e->max_lt_idx = e->idr_long ? 0 : -1; e->cur.is_long = e->idr_long; e->cur.lt_idx = e->idr_long ? 0 : -1; }
+        else if (e->n_mmco) {
+            for (int k = 0; k < e->n_mmco; k++) {
+                int o = e->mmco_op[k], a = e->mmco_a[k], b = e->mmco_b[k];
+                if (o == 1 || o == 3) {
+                    int pn = curfn - (a + 1), found = -1;
+                    for (int i = 0; i < e->nrefs; i++) if (!e->refs[i].is_long && PICNUM(&e->refs[i]) == pn) found = i;
+                    if (found < 0) { fprintf(stderr, "h264gen: MMCO names a missing picture\n"); abort(); }
+                    if (o == 1) REMOVE_REF(found);
+                    else { for (int i = 0; i < e->nrefs; i++) if (i != found && e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); if (i < found) found--; break; }
+                           e->refs[found].is_long = 1; e->refs[found].lt_idx = b; }
+                } else if (o == 2) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == a) { REMOVE_REF(i); break; } }
+                else if (o == 4) { e->max_lt_idx = a - 1; for (int i = e->nrefs - 1; i >= 0; i--) if (e->refs[i].is_long && e->refs[i].lt_idx > e->max_lt_idx) REMOVE_REF(i); }
+                else if (o == 6) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); break; } e->cur.is_long = 1; e->cur.lt_idx = b; }
+            }
+        } else if (e->nrefs >= p->num_ref) {                              /* sliding window: drop the oldest short-term picture */
+            int old = -1;
+            for (int i = 0; i < e->nrefs; i++) if (!e->refs[i].is_long && (old < 0 || PICNUM(&e->refs[i]) < PICNUM(&e->refs[old]))) old = i;
+            if (old < 0) old = 0;
+            REMOVE_REF(old);
+        }
+        { Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = e->cur; e->cur = t_; e->nrefs++; }
         e->frame_num++;
     }
     if (idr) e->idr_id++;
@@ -1918,6 +2017,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (!p->level_idc) p->level_idc = 40;
     if (p->poc_type != 0) p->poc_type = 2;
     p->scaling = CLIP3(0, 2, p->scaling);
+    if (p->bframes) p->mmco = 0;
+    e->max_lt_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
     else { p->poc_type = 0; p->nonref_period = 0; if (p->num_ref < 2) p->num_ref = 2; p->dinf8 = p->dinf8 != 0; }
@@ -1965,7 +2066,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
