@@ -311,7 +311,10 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
 // GROUPS 16-lane groups per workgroup (one macroblock row each per slot), NSLOTS rows per group.  (64, 3): 1024 threads = 4 waves
 // per SIMD hide the latency of the dependent filter chains, and at most one macroblock per group is active in a step for pictures
 // up to 64 rows tall / two up to 128 (instead of two / three with 32 groups); needs <= 128 VGPRs.  (32, 5): the 512-thread form.
-template <int GROUPS, int NSLOTS>
+__device__ int g_dbg_noload = 0;     // experiment: skip the per-step global loads (timing only, output is wrong)
+// DEPTH = how many steps ahead samples and records are fetched: a step is shorter than a loaded HBM round trip, so with DEPTH 1 every
+// step waited for its own prefetch (0.71 ms without the loads against 1.11 ms with them, 32 x 1080p).
+template <int GROUPS, int NSLOTS, int DEPTH>
 __global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pics) {
     extern __shared__ __align__(16) uint8_t smem[];
     const PicParams &pp = pics[blockIdx.y];
@@ -326,36 +329,45 @@ __global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pi
     const int rows_per_mb = is_chroma ? 8 : 16;
     const int my_row = is_chroma ? (l & 7) : l;
     const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
-    uint4 pre_pix[NSLOTS]; uint32_t pre_rec[NSLOTS];
+    uint4 pre_pix[DEPTH][NSLOTS]; uint32_t pre_rec[DEPTH][NSLOTS];
 #pragma unroll
-    for (int k = 0; k < NSLOTS; k++) { pre_pix[k] = make_uint4(0, 0, 0, 0); pre_rec[k] = 0; }
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int k = 0; k < NSLOTS; k++) { pre_pix[d][k] = make_uint4(0, 0, 0, 0); pre_rec[d][k] = 0; }
     const int n_steps = mb_w + 2 * (mb_h - 1);
-    // prefetch for step 0
+    const bool loads_on = !g_dbg_noload;
+    // stage d holds what step (s + d) needs; fill stages 0 .. DEPTH-1 for steps 0 .. DEPTH-1
 #pragma unroll
-    for (int k = 0; k < NSLOTS; k++) {
-        int row = group + GROUPS * k;
-        if (row < mb_h && 2 * row == 0) {
-            pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch);
-            pre_rec[k] = ((const uint32_t *)&recs[row * mb_w])[rec_dw];
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int k = 0; k < NSLOTS; k++) {
+            int row = group + GROUPS * k, xn = d - 2 * row;
+            if (row < mb_h && xn >= 0 && xn < mb_w && loads_on) {
+                pre_pix[d][k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
+                pre_rec[d][k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
+            }
         }
-    }
     for (int s = 0; s < n_steps; s++) {
-        // (1) take delivery of what was prefetched during the previous step.  The empty asm "uses" the
-        //     registers, so the compiler's s_waitcnt lands HERE, before this step's loads are issued.
+        // (1) take delivery of stage 0 (fetched DEPTH steps ago).  The empty asm "uses" the registers, so the compiler's s_waitcnt
+        //     for exactly these loads lands HERE, before this step's loads are issued; younger stages stay in flight.
         uint4 own[NSLOTS]; uint32_t rdw[NSLOTS];
 #pragma unroll
         for (int k = 0; k < NSLOTS; k++) {
-            own[k] = pre_pix[k]; rdw[k] = pre_rec[k];
+            own[k] = pre_pix[0][k]; rdw[k] = pre_rec[0][k];
             asm volatile("" : "+v"(own[k].x), "+v"(own[k].y), "+v"(own[k].z), "+v"(own[k].w), "+v"(rdw[k]));
         }
-        // (2) prefetch the macroblocks of the next step
+        // (2) shift the stages and fetch for step s + DEPTH
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; d++)
+#pragma unroll
+            for (int k = 0; k < NSLOTS; k++) { pre_pix[d][k] = pre_pix[d + 1][k]; pre_rec[d][k] = pre_rec[d + 1][k]; }
 #pragma unroll
         for (int k = 0; k < NSLOTS; k++) {
             int row = group + GROUPS * k;
-            int xn = s + 1 - 2 * row;
-            if (row < mb_h && xn >= 0 && xn < mb_w) {
-                pre_pix[k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
-                pre_rec[k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
+            int xn = s + DEPTH - 2 * row;
+            if (row < mb_h && xn >= 0 && xn < mb_w && loads_on) {
+                pre_pix[DEPTH - 1][k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
+                pre_rec[DEPTH - 1][k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
             }
         }
         // (3) filter this step's macroblocks out of registers + LDS
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pi
             }
         }
         // (4) step barrier: only LDS traffic has to be complete (a __syncthreads() would also drain vmcnt,
-        //     i.e. wait for the prefetch that was just issued)
+        //     i.e. wait for the prefetches that are in flight)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
@@ -383,14 +395,18 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void *)k_deblock_lds<32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        hipFuncSetAttribute((const void *)k_deblock_lds<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipFuncSetAttribute((const void *)k_deblock_lds<32, 5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipFuncSetAttribute((const void *)k_deblock_lds<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        hipFuncSetAttribute((const void *)k_deblock_lds<64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         attr_set[dev] = true;
+        if (getenv("JM_AMD_DEC_EXP_NOLOAD")) { int one = 1; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_noload), &one, sizeof one); }
     }
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)
     static const bool wide = !getenv("JM_AMD_DEC_DEBLOCK_512");
-    if (wide) hipLaunchKernelGGL((k_deblock_lds<64, 3>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
-    else hipLaunchKernelGGL((k_deblock_lds<32, 5>), dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
+    static const bool deep = !getenv("JM_AMD_DEC_DEBLOCK_DEPTH1");
+    if (wide && deep && max_mb_h <= 128) hipLaunchKernelGGL((k_deblock_lds<64, 2, 2>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
+    else if (wide) hipLaunchKernelGGL((k_deblock_lds<64, 3, 1>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
+    else hipLaunchKernelGGL((k_deblock_lds<32, 5, 1>), dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
 }
 
 }  // namespace jmamd

@@ -188,7 +188,8 @@ void Engine::run() {
         // 2. launch: at most two batches queued per lane, so that while they run new pictures pile up and batches stay full
         for (int li = 0; li < kLanes; li++) {
             Lane &ln = lanes_[li];
-            if (ln.inflight >= 2) continue;
+            static const int max_inflight = getenv("JM_AMD_DEC_INFLIGHT") ? atoi(getenv("JM_AMD_DEC_INFLIGHT")) : 2;
+            if (ln.inflight >= max_inflight) continue;
             Batch &b = ln.ring[ln.head];
             bool have;
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
