@@ -52,7 +52,7 @@ char *jm_amddec_show_dec_info(jm_amddec_handle h);
 int  jm_amddec_is_hw_support(void);
 
 /* ---- additions (no reference counterpart) ---- */
-/* keys: "device" (before init), "sync" (1 = every call waits for the pipeline; deterministic),
+/* keys: "device" (before init), "device_output" (before init, see below), "sync" (1 = every call waits for the pipeline; deterministic),
  *       "parse_only" (1 = host bitstream stages only, frames carry no pixels; for host-side tests),
  *       "digest" (1 = accumulate the macroblock syntax digest; implies sync) */
 /* like jm_amddec_decode_frame without input: *got_frame = 1 when a display-order frame became ready (never signals end of stream) */
@@ -67,6 +67,14 @@ const char *jm_amddec_last_error(jm_amddec_handle h);
 /* Stand-alone pack-out of one pitch-linear NV12 surface that already lives in device memory
  * (device pointers).  Same semantics as jm_nvdec_output_frame's repack (nv_dec.cpp:782-820).
  * stream: a hipStream_t or NULL.  Returns 0 or a negative hipError. */
+/* SURVEY 8f f3 -- device-resident output, the path the reference stubbed out (nv_dec.h:98-107, nv_dec.cpp:244-265 under "#if 0").
+ * With option "device_output" = 1 (before init) display frames are not copied to the host at all:
+ *   jm_amddec_output_frame_device: *dev = device pointer of the current frame (tight NV12 / I420 as chosen at init), *len = its
+ *     size; valid until the next jm_amddec_decode_frame call.  Works in the default mode too (the staging copy of the frame).
+ *   jm_amddec_output_argb_device: converts the current frame to ARGB32 (memory bytes B,G,R,A; BT.601 limited range) into a device
+ *     buffer of `pitch` bytes per row (>= 4 * width).  Returns 0, or -1 when no frame is current. */
+int  jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h);
+int  jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h);
 int  jm_amddec_packout_device(const void *d_src, int pitch, int width, int height, int out_fmt,
                               void *d_dst, void *stream);
 

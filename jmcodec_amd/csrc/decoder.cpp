@@ -74,6 +74,7 @@ int Decoder::set_option(const char *key, long long v) {
     if (k == "parse_only") parse_only_ = v != 0;
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
     else if (k == "sync") sync_mode_ = v != 0;
+    else if (k == "device_output") device_output_ = v != 0;        // frames stay in device memory (no D2H); see output_device()
     else if (k == "device") device_ = (int)v;
     else if (k == "profile") { profile_ = v != 0; if (engine_) engine_->set_profile(profile_); }
     else if (k == "wait_idle") {      // block until every dispatched picture has been executed by the device (no flush)
@@ -239,8 +240,8 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     OutSlot *o = new OutSlot();
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
-        if (out_via_copy_engine_ && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
+        if (!device_output_ && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if ((out_via_copy_engine_ || device_output_) && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
         o->bytes = frame_bytes_;
     }
     all_out_.push_back(o);
@@ -900,10 +901,24 @@ int Decoder::output(uint8_t *out, int *out_len) {
     int need = disp_w_ * disp_h_ * 3 / 2;
     if (*out_len < need) return -2;
     *out_len = 0;
-    if (cur_out_->has_data) memcpy(out, cur_out_->host, (size_t)need);
+    if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);
+    else if (cur_out_->has_data) { hipSetDevice(device_); if (hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess) return -1; }   // device_output mode: convenience copy
     else memset(out, 0, (size_t)need);
     *out_len = need;
     return need;
+}
+
+// the current display frame as it sits in device memory (tight NV12 / I420), valid until the next decode call
+int Decoder::output_device(void **dev, int *len) {
+    if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev) return -1;
+    *dev = cur_out_->dev; *len = disp_w_ * disp_h_ * 3 / 2;
+    return *len;
+}
+int Decoder::output_argb_device(void *dev_dst, int pitch) {
+    if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev || pitch < disp_w_ * 4) return -1;
+    hipSetDevice(device_);
+    launch_frame_to_argb(cur_out_->dev, disp_w_, disp_h_, out_fmt_, (uint8_t *)dev_dst, pitch, nullptr);
+    return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : -1;
 }
 
 int Decoder::stream_info(int *w, int *h) const {

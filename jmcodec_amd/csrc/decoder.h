@@ -81,6 +81,8 @@ public:
     int  decode(const uint8_t *buf, int len, int *got_frame);
     int  poll(int *got_frame);                 // pop a finished display frame without feeding input
     int  output(uint8_t *out, int *out_len);
+    int  output_device(void **dev, int *len);
+    int  output_argb_device(void *dev_dst, int pitch);
     int  stream_info(int *w, int *h) const;
     void set_eof(bool e) { eof_flag_ = e; }
     bool is_exit() const { return is_exit_; }
@@ -126,7 +128,7 @@ private:
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
-    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false;
     std::string error_;
     bool failed_ = false, inited_ = false;
 

@@ -46,6 +46,8 @@ __attribute__((visibility("default"))) int jm_amddec_is_hw_support(void) {      
 __attribute__((visibility("default"))) int jm_amddec_set_option(jm_amddec_handle h, const char *key, long long v) { return D(h)->set_option(key, v); }
 __attribute__((visibility("default"))) long long jm_amddec_get_stat(jm_amddec_handle h, const char *key) { return D(h)->get_stat(key); }
 __attribute__((visibility("default"))) const char *jm_amddec_last_error(jm_amddec_handle h) { return D(h)->last_error(); }
+__attribute__((visibility("default"))) int jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h) { return (h && dev && len) ? D(h)->output_device(dev, len) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h) { return (h && dev_dst) ? D(h)->output_argb_device(dev_dst, pitch) : -1; }
 __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *src, int pitch, int w, int hgt, int fmt, void *dst, void *stream) {
     jmamd::PackJob job{static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), pitch, pitch * hgt, w, hgt, fmt, 0};
     jmamd::PackJob *d_job = nullptr;

@@ -15,4 +15,6 @@ bool deblock_lds_supported(int mb_w, int mb_h);
 void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st);   // prep + LDS wavefront
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
+// tight I420 (fmt 1) / NV12 (fmt 0) frame in device memory -> ARGB32 in device memory
+void launch_frame_to_argb(const uint8_t *d_src, int w, int h, int fmt, uint8_t *d_dst, int dst_pitch, hipStream_t st);
 }  // namespace jmamd

@@ -953,6 +953,29 @@ void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t
 }
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
+// Tight I420 / NV12 frame -> 32-bit ARGB (bytes B, G, R, A), BT.601 limited range, the conversion the reference left behind
+// "#if 0" (nv_dec.h:98-107, nv_dec.cpp:244-265).  One thread per pixel pair.
+__global__ __launch_bounds__(256) void k_frame_to_argb(const uint8_t *src, int w, int h, int fmt, uint8_t *dst, int dst_pitch) {
+    int x2 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
+    if (x2 >= w || y >= h) return;
+    const uint8_t *Y = src + (size_t)y * w + x2;
+    int u, v;
+    if (fmt == 0) { const uint8_t *c = src + (size_t)w * h + (size_t)(y >> 1) * w + (x2 & ~1); u = c[0]; v = c[1]; }
+    else { int cw = w >> 1; const uint8_t *pu = src + (size_t)w * h + (size_t)(y >> 1) * cw + (x2 >> 1); u = pu[0]; v = pu[(size_t)cw * (h >> 1)]; }
+    int d = u - 128, e = v - 128;
+    uint32_t *o = (uint32_t *)(dst + (size_t)y * dst_pitch) + x2;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (x2 + k >= w) break;
+        int c = 298 * (Y[k] - 16) + 128;
+        int r = clip1((c + 409 * e) >> 8), g = clip1((c - 100 * d - 208 * e) >> 8), b = clip1((c + 516 * d) >> 8);
+        o[k] = 0xFF000000u | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+    }
+}
+void launch_frame_to_argb(const uint8_t *d_src, int w, int h, int fmt, uint8_t *d_dst, int dst_pitch, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_to_argb, dim3((w / 2 + 255) / 256, h), dim3(256), 0, st, d_src, w, h, fmt, d_dst, dst_pitch);
+}
+
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st) {
     int chunks = ((max_width + 15) >> 4) * (max_height + (max_height >> 1));
     int blocks = (chunks + 255) / 256;

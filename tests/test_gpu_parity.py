@@ -339,3 +339,54 @@ def test_intel_push_pull_api(oracle):
         L.jm_amdintel_deinit(hd)
         assert len(got) == n
         assert b"".join(got) == want
+
+
+def test_device_resident_output_and_argb(oracle):
+    """with option device_output frames never cross PCIe; the device copy must hold the same bytes as the normal
+    output, and the ARGB conversion (BT.601 limited range, integer) must match a numpy restatement of the same formula."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    L = api.lib()
+    L.jm_amddec_output_frame_device.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]
+    L.jm_amddec_output_argb_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    data = golden_stream("high_cabac_fuzz_96x80")
+    for fmt in (1, 0):
+        want, n, w, h = oracle.decode(data, fmt)
+        fs = w * h * 3 // 2
+        pitch = w * 4 + 64
+        d_argb = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d_argb), pitch * h) == 0
+        try:
+            with api.JmAmdDec(0, fmt, options={"device_output": 1}) as d:
+                count = 0
+                for nal in api.split_nalus(data) + [None] * 64:
+                    if api.jm_nvdec_is_exit(d.h):
+                        break
+                    _, got = api.jm_nvdec_decode_frame(nal, len(nal) if nal else 0, d.h)
+                    if not got:
+                        continue
+                    dev, ln = C.c_void_p(), C.c_int(0)
+                    assert L.jm_amddec_output_frame_device(C.byref(dev), C.byref(ln), d.h) == fs and ln.value == fs
+                    host = np.zeros(fs, np.uint8)
+                    assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), dev, fs, 2) == 0
+                    ref = np.frombuffer(want, np.uint8, fs, count * fs)
+                    assert np.array_equal(host, ref), f"fmt {fmt} frame {count}"
+                    assert L.jm_amddec_output_argb_device(d_argb, pitch, d.h) == 0
+                    argb = np.zeros(pitch * h, np.uint8)
+                    assert hip.hipMemcpy(argb.ctypes.data_as(C.c_void_p), d_argb, pitch * h, 2) == 0
+                    argb = argb.reshape(h, pitch)[:, :w * 4].reshape(h, w, 4).astype(np.int32)
+                    Y = ref[:w * h].reshape(h, w).astype(np.int32)
+                    if fmt == 1:
+                        U = ref[w * h:w * h + w * h // 4].reshape(h // 2, w // 2); V = ref[w * h + w * h // 4:].reshape(h // 2, w // 2)
+                    else:
+                        uv = ref[w * h:].reshape(h // 2, w // 2, 2); U, V = uv[:, :, 0], uv[:, :, 1]
+                    D = U.astype(np.int32).repeat(2, 0).repeat(2, 1) - 128; E = V.astype(np.int32).repeat(2, 0).repeat(2, 1) - 128
+                    c = 298 * (Y - 16) + 128
+                    R, G, B = np.clip((c + 409 * E) >> 8, 0, 255), np.clip((c - 100 * D - 208 * E) >> 8, 0, 255), np.clip((c + 516 * D) >> 8, 0, 255)
+                    assert np.array_equal(argb[:, :, 0], B) and np.array_equal(argb[:, :, 1], G) and np.array_equal(argb[:, :, 2], R) and (argb[:, :, 3] == 255).all()
+                    count += 1
+                assert count == n
+        finally:
+            hip.hipFree(d_argb)

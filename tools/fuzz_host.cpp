@@ -45,3 +45,4 @@ void launch_recon_intra(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_deblock_lds(const PicParams *, int, int, int, ihipStream_t *) { abort(); }
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 }
+namespace jmamd { void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); } }
