@@ -4,6 +4,11 @@
 // (/root/reference/nv_dec/nv_dec.cpp:33-41; entropy_coding_mode_flag travels in CUVIDH264PICPARAMS,
 // nv_sdk/inc/dynlink_cuviddec.h:243-298).  Syntax-element binarisations and ctxIdxInc derivations live with the
 // macroblock layer in h264_cavlc.cpp; this file is only the engine.
+//
+// Representation: `val` holds codIOffset followed by look-ahead bits of the stream, `pos` is the bit index of the offset's least
+// significant bit inside `val` (codIOffset == val >> pos).  Renormalising by n bits is `pos -= n` (no shift of val); 32 more bits
+// are appended when pos drops below 16.  Comparisons use codIRange << pos.  Exactly the decisions of 9.3.3.2 (the oracle's
+// bit-serial restatement decodes the same bins), just without touching the bitstream per bin.
 #pragma once
 #include "bitreader.h"
 #include "cabac_tables.h"
@@ -11,8 +16,10 @@
 namespace jmamd {
 
 struct Cabac {
-    BitReader *br = nullptr;
-    uint32_t range = 510, offset = 0;
+    uint64_t val = 0; int pos = 0;
+    uint32_t range = 510;
+    const uint8_t *ptr = nullptr, *start = nullptr, *end = nullptr;
+    bool overrun = false;                    // the arithmetic decoder ran past the end of the slice data
     uint8_t state[CABAC_N_CTX];              // pStateIdx << 1 | valMPS
 
     // 9.3.1.1: context variables from (m, n) and SliceQPY; table 0 = I slices, 1 + cabac_init_idc otherwise
@@ -24,33 +31,53 @@ struct Cabac {
             state[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)(((pre - 64) << 1) | 1);
         }
     }
-    // 9.3.1.2: the reader must be byte aligned at the first byte of the arithmetic code
-    void init_engine(BitReader *b) { br = b; range = 510; offset = br->u(9); }
+    inline void refill() {
+        uint32_t w;
+        if (ptr + 4 <= end) { w = ((uint32_t)ptr[0] << 24) | ((uint32_t)ptr[1] << 16) | ((uint32_t)ptr[2] << 8) | ptr[3]; }
+        else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (ptr + i < end ? ptr[i] : 0); if (ptr >= end + 8) overrun = true; }   // a few bytes of look-ahead past the end are normal
+        ptr += 4;
+        val = (val << 32) | w; pos += 32;
+    }
+    // 9.3.1.2: `p` is the first byte of the arithmetic code (byte aligned), `e` the end of the slice data
+    void init_engine(const uint8_t *p, const uint8_t *e) {
+        start = ptr = p; end = e; val = 0; pos = -9; range = 510; overrun = false;
+        refill();                                              // val = first 32 bits, pos = 23: codIOffset = first 9 bits
+    }
+    // bits the arithmetic decoder of 9.3.1.2 / 9.3.3.2 has read so far (9 at initialisation + 1 per renormalisation shift)
+    inline size_t bits_consumed() const { return (size_t)(ptr - start) * 8 - (size_t)pos; }
 
     inline int decision(int ctx) {
         uint32_t s = state[ctx], st = s >> 1, mps = s & 1;
         uint32_t lps = cabac_range_lps[st][(range >> 6) & 3];
         range -= lps;
-        if (offset < range) {                                  // most probable symbol
+        uint64_t scaled = (uint64_t)range << pos;
+        int bin;
+        if (val < scaled) {                                     // most probable symbol
             state[ctx] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
-            if (range < 256) { range <<= 1; offset = (offset << 1) | br->u1(); }
-            return (int)mps;
+            if (range < 256) { range <<= 1; pos--; }
+            bin = (int)mps;
+        } else {
+            val -= scaled; range = lps;
+            state[ctx] = (uint8_t)((cabac_trans_lps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
+            int sh = __builtin_clz(range) - 23;                 // range in [6, 240] -> shift that brings it back into [256, 511]
+            range <<= sh; pos -= sh;
+            bin = (int)(mps ^ 1);
         }
-        offset -= range; range = lps;
-        state[ctx] = (uint8_t)((cabac_trans_lps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
-        int sh = __builtin_clz(range) - 23;                    // range in [6, 240] -> shift to bring it into [256, 511]
-        range <<= sh; offset = (offset << sh) | br->u(sh);
-        return (int)(mps ^ 1);
+        if (pos < 16) refill();
+        return bin;
     }
     inline int bypass() {
-        offset = (offset << 1) | br->u1();
-        if (offset >= range) { offset -= range; return 1; }
-        return 0;
+        pos--;
+        uint64_t scaled = (uint64_t)range << pos;
+        int bin = 0;
+        if (val >= scaled) { val -= scaled; bin = 1; }
+        if (pos < 16) refill();
+        return bin;
     }
     inline int terminate() {
         range -= 2;
-        if (offset >= range) return 1;
-        if (range < 256) { range <<= 1; offset = (offset << 1) | br->u1(); }
+        if (val >= ((uint64_t)range << pos)) return 1;          // no renormalisation: parsing of the slice / before I_PCM ends
+        if (range < 256) { range <<= 1; pos--; if (pos < 16) refill(); }
         return 0;
     }
 };

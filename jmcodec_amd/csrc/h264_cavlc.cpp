@@ -683,14 +683,21 @@ struct P {
 
         if (itype == 25) {                                     // I_PCM
             r->kind = MB_PCM; r->qp = 0;
-            // CABAC: the 9 bits the arithmetic decoder has read ahead end exactly with the last bit of the encoder's flush (9.3.4.5),
-            // so in both entropy modes only pcm_alignment_zero_bits remain before the samples
-            br.align_zero();
-            if (br.overrun() || (br.bitpos() >> 3) + 384 > br.size()) { err = "I_PCM runs past the slice"; return false; }
             int16_t *d = alloc_coef(192); if (!d) return false;
-            memcpy(d, br.byte_ptr(), 384); br.skip_bytes(384);
+            if (cb) {
+                // the 9 bits the arithmetic decoder has read ahead end exactly with the last bit of the encoder's flush (9.3.4.5), so only
+                // pcm_alignment_zero_bits remain before the samples; the engine restarts behind them (9.3.1.2)
+                const uint8_t *pcm = cb->start + ((cb->bits_consumed() + 7) >> 3);
+                if (cb->overrun || pcm + 384 > cb->end) { err = "I_PCM runs past the slice"; return false; }
+                memcpy(d, pcm, 384);
+                cx.cbp[addr] = 0x2f; cx.cbf[addr] = 0x7FFFFFF; last_dqp = false;
+                cb->init_engine(pcm + 384, cb->end);
+            } else {
+                br.align_zero();
+                if (br.overrun() || (br.bitpos() >> 3) + 384 > br.size()) { err = "I_PCM runs past the slice"; return false; }
+                memcpy(d, br.byte_ptr(), 384); br.skip_bytes(384);
+            }
             memset(tc, 16, 24); cx.info[addr] = 1 | 16;
-            if (cb) { cx.cbp[addr] = 0x2f; cx.cbf[addr] = 0x7FFFFFF; last_dqp = false; cb->init_engine(&br); }
             finish_mb(r);
             return true;
         }
@@ -836,7 +843,7 @@ struct P {
         r->qp = (uint8_t)qp;
         if (cbp > 0 || i16) { if (!residual(r, cbp, i16, t8, itype >= 0)) return false; }
         if (err) return false;
-        if (br.overrun()) { err = "macroblock data truncated"; return false; }
+        if (cb ? cb->overrun : br.overrun()) { err = "macroblock data truncated"; return false; }
         if (canon && t8) r->kind |= 16;                        // digest only: restored below
         finish_mb(r);
         r->kind &= 15;
@@ -862,7 +869,7 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
         while (!br.aligned()) if (!br.u1()) { res.error = "cabac_alignment_one_bit is not 1"; return res; }
         if (sh.cabac_init_idc > 2) { res.error = "bad cabac_init_idc"; return res; }
         cabac.init_contexts(sh.type == SL_I ? 0 : 1 + sh.cabac_init_idc, sh.qp);
-        cabac.init_engine(&br);
+        cabac.init_engine(br.byte_ptr(), br.base() + br.size());
         p.cb = &cabac;
         for (;;) {
             if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; return res; }
@@ -872,7 +879,7 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
             else ok = p.macroblock(res.n_intra, res.n_i8x8);
             if (!ok) { res.error = p.err ? p.err : "macroblock error"; return res; }
             addr++; res.mbs_decoded++;
-            if (br.overrun()) { res.error = "slice data truncated"; return res; }
+            if (cabac.overrun || cabac.bits_consumed() > (size_t)(cabac.end - cabac.start) * 8 + 16) { res.error = "slice data truncated"; return res; }
             if (cabac.terminate()) break;                     // end_of_slice_flag
         }
         return res;
