@@ -184,8 +184,8 @@ class JmAmdDec:
         return lib().jm_amddec_get_stat(self.h, key.encode())
 
     def _pull(self, frames):
-        if self.out_buf is None:
-            w, h = jm_nvdec_stream_info(self.h)
+        w, h = jm_nvdec_stream_info(self.h)                    # size of the frame about to be fetched (it can change at an IDR picture)
+        if self.out_buf is None or len(self.out_buf) < w * h * 3 // 2:
             self.out_buf = C.create_string_buffer(max(w * h * 3 // 2, 16))
         ret, n = jm_nvdec_output_frame(self.out_buf, len(self.out_buf), self.h)
         if n > 0 and frames is not None:

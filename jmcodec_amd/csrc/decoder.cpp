@@ -188,8 +188,22 @@ void Decoder::gpu_free_sequence() {
         if (j.uploaded) hipEventDestroy(j.uploaded);
         j = JobSlot();
     }
-    for (OutSlot *o : all_out_) { if (o->host) hipHostFree(o->host); if (o->dev) hipFree(o->dev); delete o; }
-    all_out_.clear(); free_out_.clear(); ready_.clear(); cur_out_ = nullptr;
+    free_out_slots(true);
+}
+// releases output slots: every one (teardown) or only those the application is not waiting for (resolution change: frames of the
+// old size that were decoded but not fetched yet stay valid; their slots are freed when they come back)
+void Decoder::free_out_slots(bool all) {
+    std::lock_guard<std::mutex> lk(mtx_);
+    std::vector<OutSlot *> keep;
+    for (OutSlot *o : all_out_) {
+        bool pending = !all && (o == cur_out_ || std::find(ready_.begin(), ready_.end(), o) != ready_.end());
+        if (pending) { keep.push_back(o); continue; }
+        if (o->host) hipHostFree(o->host);
+        if (o->dev) hipFree(o->dev);
+        delete o;
+    }
+    all_out_ = keep; free_out_.clear();
+    if (all) { ready_.clear(); cur_out_ = nullptr; }
 }
 void Decoder::gpu_close() {
     if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); for (auto &j : jobs_) { free(j.host); j.host = nullptr; } return; }
@@ -236,8 +250,17 @@ bool Decoder::gpu_alloc_sequence() {
 }
 
 OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
-    if (!free_out_.empty()) { OutSlot *o = free_out_.back(); free_out_.pop_back(); o->ready = false; o->has_data = false; return o; }
+    while (!free_out_.empty()) {
+        OutSlot *o = free_out_.back(); free_out_.pop_back();
+        if (o->bytes == frame_bytes_ || parse_only_) { o->ready = false; o->has_data = false; o->w = disp_w_; o->h = disp_h_; return o; }
+        // a slot of the previous resolution came back: release it
+        all_out_.erase(std::remove(all_out_.begin(), all_out_.end(), o), all_out_.end());
+        if (o->host) hipHostFree(o->host);
+        if (o->dev) hipFree(o->dev);
+        delete o;
+    }
     OutSlot *o = new OutSlot();
+    o->w = disp_w_; o->h = disp_h_;
     if (!parse_only_) {
         hipSetDevice(device_);
         if (!device_output_ && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
@@ -365,9 +388,17 @@ bool Decoder::activate(const SeqParams &sps) {
         auto t = std::make_unique<PicTask>();
         t->out_before = std::move(carry_out_); carry_out_.clear();
         push_task(std::move(t));
-        { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0; }); }
-        fail("resolution change inside a stream is not supported yet");
-        return false;
+        { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0 && parse_pending_ == 0; }); }
+        // a new coded video sequence with another picture size (cuvid_handle_video_sequence re-creates the decoder, nv_dec.cpp:23-30):
+        // nothing is in flight any more, so surfaces, job rings and scratch are rebuilt; frames already decoded keep their slots
+        if (gpu_open_) {
+            hipSetDevice(device_);
+            for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+            if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
+            if (resid_) { hipFree(resid_); resid_ = nullptr; }
+            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
+            free_out_slots(false);
+        } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
     }
     mb_w_ = sps.mb_w; mb_h_ = sps.mb_h; disp_w_ = sps.disp_w(); disp_h_ = sps.disp_h();
     n_surf_ = 18;                                  // 16 (max DPB) + current + one spare; also covers later SPSs with a larger DPB
@@ -898,7 +929,7 @@ int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {
 // device (k_packout), so what is left of it on the host is one tight memcpy.
 int Decoder::output(uint8_t *out, int *out_len) {
     if (!cur_out_ || (!cur_out_->has_data && !parse_only_)) return -1;
-    int need = disp_w_ * disp_h_ * 3 / 2;
+    int need = cur_out_->w * cur_out_->h * 3 / 2;
     if (*out_len < need) return -2;
     *out_len = 0;
     if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);
@@ -911,17 +942,19 @@ int Decoder::output(uint8_t *out, int *out_len) {
 // the current display frame as it sits in device memory (tight NV12 / I420), valid until the next decode call
 int Decoder::output_device(void **dev, int *len) {
     if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev) return -1;
-    *dev = cur_out_->dev; *len = disp_w_ * disp_h_ * 3 / 2;
+    *dev = cur_out_->dev; *len = cur_out_->w * cur_out_->h * 3 / 2;
     return *len;
 }
 int Decoder::output_argb_device(void *dev_dst, int pitch) {
-    if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev || pitch < disp_w_ * 4) return -1;
+    if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev || pitch < cur_out_->w * 4) return -1;
     hipSetDevice(device_);
-    launch_frame_to_argb(cur_out_->dev, disp_w_, disp_h_, out_fmt_, (uint8_t *)dev_dst, pitch, nullptr);
+    launch_frame_to_argb(cur_out_->dev, cur_out_->w, cur_out_->h, out_fmt_, (uint8_t *)dev_dst, pitch, nullptr);
     return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : -1;
 }
 
 int Decoder::stream_info(int *w, int *h) const {
+    // the frame the caller is about to fetch, else the current sequence (they differ only around a resolution change)
+    if (cur_out_) { *w = cur_out_->w; *h = cur_out_->h; return 0; }
     *w = disp_w_; *h = disp_h_;
     return 0;
 }

@@ -70,6 +70,7 @@ struct OutSlot {                       // one display frame in pinned host memor
     uint8_t *host = nullptr;
     uint8_t *dev = nullptr;            // device staging of the packed frame (copy-engine mode, see Engine::launch)
     size_t bytes = 0;
+    int w = 0, h = 0;                  // display size of the frame held (a stream may change resolution at an IDR picture)
     bool has_data = false, ready = false;
 };
 
@@ -120,6 +121,7 @@ private:
     bool gpu_open();
     bool gpu_alloc_sequence();
     void gpu_free_sequence();
+    void free_out_slots(bool all);
     void gpu_close();
     void submit_ready();
     void submit_task(PicTask *t);

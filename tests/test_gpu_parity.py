@@ -390,3 +390,17 @@ def test_device_resident_output_and_argb(oracle):
                 assert count == n
         finally:
             hip.hipFree(d_argb)
+
+
+def test_resolution_change_between_sequences(oracle):
+    """Three coded video sequences of different picture sizes and tool sets in one stream: surfaces, job rings and scratch are rebuilt
+    at each new SPS, frames already decoded are still delivered, every frame is bit-exact."""
+    a = streams.generate(width=96, height=80, frames=5, gop=5, mode=1, seed=1, num_ref=2)
+    b = streams.generate(width=320, height=240, frames=4, gop=4, seed=2, cabac=1, t8x8=1)
+    c = streams.generate(width=64, height=48, frames=6, gop=6, mode=1, seed=3, bframes=2)
+    want = b"".join(oracle.decode(x, 1)[0] for x in (a, b, c))
+    assert oracle.decode(a + b + c, 1)[0] == want
+    for _ in range(2):
+        frames = gpu_decode(a + b + c)
+        assert [len(f) for f in frames] == [96 * 80 * 3 // 2] * 5 + [320 * 240 * 3 // 2] * 4 + [64 * 48 * 3 // 2] * 6
+        assert b"".join(frames) == want

@@ -133,3 +133,15 @@ def test_avcc_extradata_and_length_prefixed_packets(oracle):
         with api.JmAmdDec(0, 1, options={"parse_only": 1, "digest": 1}, extra_data=head) as d:
             d.decode_stream(b"", keep=False, chunks=rest)
             assert (d.stat("syntax_digest") & (2 ** 64 - 1), d.stat("digest_mbs")) == want
+
+
+def test_resolution_change_between_sequences_host_side():
+    """A new SPS with another picture size at an IDR picture starts a new coded video sequence (the reference re-creates its decoder in
+    the sequence callback, nv_dec.cpp:23-30): all frames of all sequences come out, in order, none lost."""
+    a = streams.generate(width=96, height=80, frames=5, gop=5, mode=1, seed=1, num_ref=2)
+    b = streams.generate(width=176, height=144, frames=4, gop=4, mode=1, seed=2, cabac=1)
+    c = streams.generate(width=64, height=48, frames=3, gop=3, mode=1, seed=3, bframes=1)
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        frames = d.decode_stream(a + b + c)
+        assert [len(f) for f in frames] == [96 * 80 * 3 // 2] * 5 + [176 * 144 * 3 // 2] * 4 + [64 * 48 * 3 // 2] * 3
+        assert d.stat("errors") == 0
