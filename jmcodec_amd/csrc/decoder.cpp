@@ -132,7 +132,8 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     if (codec_type != 0) { fail("only codec_type 0 (H.264) is implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
     if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;
-    out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
+    out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");
+    if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
     if (engine_) engine_->set_profile(profile_);
