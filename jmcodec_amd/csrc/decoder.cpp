@@ -706,8 +706,11 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     static thread_local std::vector<int16_t> mv_ext_buf;
     const bool big_rec = t->sps.profile_idc != 66;
     mv_ext_buf.resize((size_t)n_mbs * (big_rec ? kBiRecInt16 : 32));
-    // default record = concealment (grey, not decoded)
-    MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER; blank.ref[0] = blank.ref[1] = blank.ref[2] = blank.ref[3] = -1;
+    // default record = concealment for macroblocks no slice delivers (lost / damaged slices): copy the colocated macroblock of the
+    // first list-0 reference (zero motion, no residual); grey when the picture has no reference (ref -1 -> 128 in k_recon_inter)
+    MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER;
+    { int8_t c = -1; for (auto &s : t->slices) if (s.sh.type != SL_I && s.refs.slot[0][0] >= 0) { c = s.refs.slot[0][0]; break; }
+      blank.ref[0] = blank.ref[1] = blank.ref[2] = blank.ref[3] = c; }
     for (int i = 0; i < n_mbs; i++) mbs[i] = blank;
     JobWriter w;
     w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * (big_rec ? kBiRecInt16 / 2 : 16);
