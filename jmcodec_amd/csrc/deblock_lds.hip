@@ -136,12 +136,15 @@ constexpr int kMaxSlots = 5;             // rows g, g+32, ... g+128 -> pictures 
 // Workgroup 0 (luma) and workgroup 1 (chroma) each own a private LDS image laid out the same way:
 // 32 x 64 B DbRec staging, then per macroblock row the tile pair, then per row the ring.
 struct Lds {
-    uint8_t *base; int mb_h; int hdr;     // hdr = bytes of DbRec staging in front (64 per group)
-    __device__ uint8_t *rec(int group) const { return base + group * 64; }
-    __device__ uint8_t *luma_tile(int row, int par) const { return base + hdr + (size_t)row * 512 + par * 256; }
-    __device__ uint8_t *luma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * 512 + (size_t)row * 256 + slot * 64; }
-    __device__ uint8_t *chroma_tile(int row, int par) const { return base + hdr + (size_t)row * 256 + par * 128; }
-    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * 256 + (size_t)row * 128 + slot * 32; }
+    // Row strides are padded by 16 bytes (4 banks): the four macroblock rows one wave works on would otherwise sit exactly
+    // 512 / 256 / 128 bytes apart, i.e. in the same LDS banks, and every byte-column access would be a 4-way bank conflict.
+    uint8_t *base; int mb_h; int hdr;     // hdr = bytes of DbRec staging in front (kRecStride per group)
+    static constexpr int kRecStride = 80, kLT = 528, kLR = 272, kCT = 272, kCR = 144;
+    __device__ uint8_t *rec(int group) const { return base + group * kRecStride; }
+    __device__ uint8_t *luma_tile(int row, int par) const { return base + hdr + (size_t)row * kLT + par * 256; }
+    __device__ uint8_t *luma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * kLT + (size_t)row * kLR + slot * 64; }
+    __device__ uint8_t *chroma_tile(int row, int par) const { return base + hdr + (size_t)row * kCT + par * 128; }
+    __device__ uint8_t *chroma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * kCT + (size_t)row * kCR + slot * 32; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pi
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_DEBLOCK_LDS)) return;
     const DbRec *recs = (const DbRec *)pp.dbrec;
-    Lds lds{smem, pp.mb_h, GROUPS * 64};
+    Lds lds{smem, pp.mb_h, GROUPS * Lds::kRecStride};
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_chroma = blockIdx.x == 1;
     const int group = wave * 4 + (lane >> 4), l = lane & 15;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pi
 }
 
 // ------------------------------------------------------------------------------------------
-size_t deblock_lds_bytes(int mb_h) { return 4096 + (size_t)mb_h * 768; }      // luma workgroup's need (chroma needs half)
+size_t deblock_lds_bytes(int mb_h) { return 64 * Lds::kRecStride + (size_t)mb_h * (Lds::kLT + Lds::kLR); }      // luma workgroup's need (chroma needs half)
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
 
 void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st) {
