@@ -144,3 +144,122 @@ class Oracle:
         n = C.c_int(cap)
         rc = self.L.orc_packout(src, pitch, width, height, out_fmt, dst, C.byref(n))
         return rc, dst.raw[:n.value]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# HEVC: tools/hevcgen.c (stream generator) and oracle/orc_hevc_*.c (CPU oracle) -- test infrastructure
+# ---------------------------------------------------------------------------------------------------------
+HEVC_FIELDS = ("width", "height", "frames", "qp", "seed", "intra_period", "gop", "num_ref", "ctb_log2", "min_cb_log2", "max_tb_log2", "min_tb_log2",
+               "depth_inter", "depth_intra", "mode", "amp", "sao", "deblock", "tskip", "sdh", "dqp", "pcm", "bypass", "cip", "strong_intra", "tmvp", "wp",
+               "rplm", "lt_ref", "scaling", "wpp", "tile_cols", "tile_rows", "slice_ctus", "dep_slices", "merge_cand", "cabac_init", "par_mrg", "rps_sps",
+               "cb_qp_off", "cr_qp_off", "search")
+
+
+class HevcGenParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in HEVC_FIELDS]
+
+
+_hgen = None
+
+
+def generate_hevc(recon_path=None, **kw):
+    """HEVC Annex-B stream as bytes (tools/hevcgen.c).  Defaults: 176x144, 8 frames, QP 32, CTB 64, SAO + deblocking + TMVP + AMP on."""
+    global _hgen
+    if _hgen is None:
+        p = os.path.join(_ROOT, "tools", "_build", "libhevcgen.so")
+        if not os.path.exists(p):
+            build_tools()
+        _hgen = C.CDLL(p)
+        _hgen.hevcgen_generate.argtypes = [C.POINTER(HevcGenParams), C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t), C.c_char_p]
+        _hgen.hevcgen_free.argtypes = [C.c_void_p]
+    d = dict(width=176, height=144, frames=8, qp=32, seed=0x4A4D0300, intra_period=32, deblock=1, sao=1, tmvp=1, amp=1, strong_intra=1, depth_inter=2, depth_intra=2)
+    d.update(kw)
+    unknown = set(d) - set(HEVC_FIELDS)
+    if unknown:
+        raise TypeError(f"generate_hevc: unknown parameters {sorted(unknown)}")
+    p = HevcGenParams(*[int(d.get(n, 0)) for n in HEVC_FIELDS])
+    buf = C.POINTER(C.c_ubyte)()
+    n = C.c_size_t(0)
+    if _hgen.hevcgen_generate(C.byref(p), C.byref(buf), C.byref(n), recon_path.encode() if recon_path else None) != 0:
+        raise ValueError("hevcgen: bad parameters")
+    out = C.string_at(buf, n.value)
+    _hgen.hevcgen_free(buf)
+    return out
+
+
+def config_c3(frames=120, width=3840, height=2160, stream_id=0):
+    """HEVC Main 4K60, 64x64 CTU, min CU 8, SAO + deblocking, random-access GOP 8, QP 32."""
+    return dict(width=width, height=height, frames=frames, qp=32, seed=0x4A4D0000 + 3 * 256 + stream_id, intra_period=32, gop=8, num_ref=2,
+                ctb_log2=6, min_cb_log2=3, sao=1, deblock=1, tmvp=1, amp=1, strong_intra=1, depth_inter=2, depth_intra=2, sdh=1)
+
+
+class OracleHevc:
+    """ctypes binding of oracle/_build/liborc_hevc.so (CPU oracle -- checker only)."""
+
+    def __init__(self):
+        p = os.path.join(_ROOT, "oracle", "_build", "liborc_hevc.so")
+        if not os.path.exists(p):
+            build_tools()
+        L = C.CDLL(p)
+        L.orch_decode_stream_to_buffer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orch_free.argtypes = [C.c_void_p]
+        L.orch_open.restype = C.c_void_p
+        L.orch_open.argtypes = [C.c_void_p, C.c_void_p]
+        L.orch_close.argtypes = [C.c_void_p]
+        L.orch_decode_annexb.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.orch_flush.argtypes = [C.c_void_p]
+        L.orch_digest_enable.argtypes = [C.c_void_p]
+        L.orch_digest_value.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orch_digest_value.restype = C.c_uint64
+        L.orch_last_error.argtypes = [C.c_void_p]
+        L.orch_last_error.restype = C.c_char_p
+        L.orch_tool_name.restype = C.c_char_p
+        L.orch_tool_name.argtypes = [C.c_int]
+        L.orch_tool_count.restype = C.c_long
+        L.orch_tool_count.argtypes = [C.c_void_p, C.c_int]
+        self.L = L
+
+    def decode(self, data, out_fmt=1):
+        buf = C.POINTER(C.c_ubyte)()
+        n = C.c_size_t(0)
+        w, h = C.c_int(0), C.c_int(0)
+        cnt = self.L.orch_decode_stream_to_buffer(data, len(data), out_fmt, C.byref(buf), C.byref(n), C.byref(w), C.byref(h))
+        if cnt < 0:
+            raise RuntimeError("HEVC oracle decode failed")
+        out = C.string_at(buf, n.value) if n.value else b""
+        self.L.orch_free(buf)
+        return out, cnt, w.value, h.value
+
+    def _run(self, data, digest=False):
+        d = self.L.orch_open(None, None)
+        if digest:
+            self.L.orch_digest_enable(d)
+        rc = self.L.orch_decode_annexb(d, data, len(data))
+        err = self.L.orch_last_error(d).decode()
+        self.L.orch_flush(d)
+        return d, rc, err
+
+    def syntax_digest(self, data):
+        d, rc, err = self._run(data, True)
+        n = C.c_uint64(0)
+        v = self.L.orch_digest_value(d, C.byref(n))
+        self.L.orch_close(d)
+        if rc < 0:
+            raise RuntimeError("HEVC oracle: " + err)
+        return v, n.value
+
+    def tools(self, data):
+        d, rc, err = self._run(data)
+        out, i = {}, 0
+        while True:
+            name = self.L.orch_tool_name(i)
+            if name is None:
+                break
+            c = self.L.orch_tool_count(d, i)
+            if c:
+                out[name.decode()] = c
+            i += 1
+        self.L.orch_close(d)
+        if rc < 0:
+            raise RuntimeError("HEVC oracle: " + err)
+        return out

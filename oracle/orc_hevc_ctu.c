@@ -873,7 +873,8 @@ static int coding_unit(Sx *s, int x0, int y0, int log2) {
     if (s->cu_intra && !pcm && !rqt_root_cbf) { s->err = 1; return -1; }
     /* 8.6.1: QpY of the coding unit (after a cu_qp_delta inside it took effect) */
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) d->qp_y[I4(d, x, y)] = (int8_t)s->qp_y;
-    d->last_cu_qp = s->qp_y;
+    d->last_cu_qp = s->qp_y; s->qg_started = 1;
+    TRACE("CU %d %d %d qp %d\n", x0, y0, log2, s->qp_y);
     if (d->digest_on) dg(d, 0x4800 | s->qp_y);
     return s->err ? -1 : 0;
 }
@@ -890,8 +891,7 @@ static int coding_quadtree(Sx *s, int x0, int y0, int log2, int depth) {
     } else split = log2 > sps->log2_min_cb;
     if (s->pps->cu_qp_delta && log2 >= sps->log2_ctb - s->pps->diff_cu_qp_delta_depth) {       /* start of a quantization group */
         s->is_dqp_coded = 0; s->dqp = 0;
-        if (s->qg_started) { s->qp_y_prev = d->last_cu_qp; s->first_qg = 0; }
-        s->qg_started = 1;
+        if (s->qg_started) { s->qp_y_prev = d->last_cu_qp; s->first_qg = 0; }     /* qg_started: a coding unit was decoded since the last reset */
     }
     if (split) {
         int h = n >> 1;
@@ -902,7 +902,6 @@ static int coding_quadtree(Sx *s, int x0, int y0, int log2, int depth) {
         return 0;
     }
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) d->ct_depth[I4(d, x, y)] = (uint8_t)depth;
-    if (!s->pps->cu_qp_delta) { if (s->qg_started) { s->qp_y_prev = d->last_cu_qp; s->first_qg = 0; } s->qg_started = 1; }   /* every CU is its own group: QpY = SliceQpY throughout */
     derive_qp(s, x0, y0);
     return coding_unit(s, x0, y0, log2);
 }

@@ -237,7 +237,7 @@ int orch_parse_pps(OrchDec *d, Bits *b) {
 static int parse_pwt(Bits *b, HSlice *sh) {
     sh->wp_log2_denom_l = (int)bits_ue(b);
     sh->wp_log2_denom_c = sh->wp_log2_denom_l + bits_se(b);
-    if (sh->wp_log2_denom_l > 7 || sh->wp_log2_denom_c < 0 || sh->wp_log2_denom_c > 7) return -1;
+    if (sh->wp_log2_denom_l > 7 || sh->wp_log2_denom_c < 0 || sh->wp_log2_denom_c > 7) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt denom %d %d type %d nref %d %d\n", sh->wp_log2_denom_l, sh->wp_log2_denom_c, sh->type, sh->n_ref[0], sh->n_ref[1]); return -1; }
     for (int l = 0; l < (sh->type == H_SLICE_B ? 2 : 1); l++) {
         uint8_t lf[16], cf[16];
         for (int i = 0; i < sh->n_ref[l]; i++) lf[i] = (uint8_t)bits_u1(b);
@@ -247,12 +247,12 @@ static int parse_pwt(Bits *b, HSlice *sh) {
             sh->wp_w[l][i][1] = sh->wp_w[l][i][2] = (int16_t)(1 << sh->wp_log2_denom_c); sh->wp_o[l][i][1] = sh->wp_o[l][i][2] = 0;
             if (lf[i]) {
                 int dw = bits_se(b), o = bits_se(b);
-                if (dw < -128 || dw > 127 || o < -128 || o > 127) return -1;
+                if (dw < -128 || dw > 127 || o < -128 || o > 127) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt luma l%d i%d dw %d o %d denom %d %d nref %d %d\n", l, i, dw, o, sh->wp_log2_denom_l, sh->wp_log2_denom_c, sh->n_ref[0], sh->n_ref[1]); return -1; }
                 sh->wp_w[l][i][0] = (int16_t)(sh->wp_w[l][i][0] + dw); sh->wp_o[l][i][0] = (int16_t)o;
             }
             if (cf[i]) for (int j = 1; j < 3; j++) {
                 int dw = bits_se(b), dofs = bits_se(b);
-                if (dw < -128 || dw > 127 || dofs < -512 || dofs > 511) return -1;
+                if (dw < -128 || dw > 127 || dofs < -512 || dofs > 511) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt chroma l%d i%d j%d dw %d dofs %d\n", l, i, j, dw, dofs); return -1; }
                 int w = (1 << sh->wp_log2_denom_c) + dw;
                 sh->wp_w[l][i][j] = (int16_t)w;
                 sh->wp_o[l][i][j] = (int16_t)h_clip3(-128, 127, (128 + dofs) - ((128 * w) >> sh->wp_log2_denom_c));
@@ -260,6 +260,7 @@ static int parse_pwt(Bits *b, HSlice *sh) {
         }
     }
     sh->has_wp = 1;
+    if (b->err && getenv("ORCH_DBG")) fprintf(stderr, "pwt ran out of bits\n");
     return b->err ? -1 : 0;
 }
 

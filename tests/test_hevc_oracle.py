@@ -1,0 +1,165 @@
+"""HEVC CPU oracle (oracle/orc_hevc_*.c) against the generator's independently written reconstruction (tools/hevcgen.c), the
+committed golden vectors and structural properties of the constant tables.  CPU only.
+
+PARITY NOTE (oracle/orc_hevc.h): the reference ships no HEVC fixture and this image holds no third-party HEVC stream or
+decoder, so these tests pin the oracle against the second code path and against regressions -- "parity unpinned" w.r.t. the
+standard's tables.
+"""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from jmcodec_amd import streams
+from util import GOLDEN, ROOT, c_array, md5
+
+HEVC_CASES = {
+    "intra": dict(width=64, height=64, frames=1),
+    "intra_ctb16_fuzz": dict(width=80, height=48, frames=2, intra_period=1, ctb_log2=4, mode=1, seed=2),
+    "p_real": dict(width=96, height=80, frames=4, num_ref=2),
+    "p_fuzz_refs": dict(width=96, height=80, frames=6, num_ref=4, mode=1, seed=3, merge_cand=2),
+    "b_gop2": dict(width=96, height=80, frames=7, gop=2, num_ref=2, mode=1, seed=4),
+    "b_gop8": dict(width=128, height=96, frames=17, gop=8, num_ref=2, seed=5),
+    "crop_ctb32": dict(width=90, height=70, frames=3, ctb_log2=5, mode=1, seed=6),
+    "min_cb16": dict(width=96, height=80, frames=3, ctb_log2=5, min_cb_log2=4, mode=1, seed=7),
+    "no_filters": dict(width=96, height=80, frames=3, sao=0, deblock=0, tmvp=0, amp=0, mode=1, seed=8),
+    "deblock_override": dict(width=96, height=80, frames=3, deblock=2, slice_ctus=3, ctb_log2=4, mode=1, seed=9),
+    "tskip_sdh": dict(width=96, height=80, frames=3, tskip=1, sdh=1, mode=1, seed=10, qp=22),
+    "dqp_depths": dict(width=128, height=96, frames=3, dqp=4, mode=1, seed=11, cb_qp_off=-5, cr_qp_off=7),
+    "pcm_bypass": dict(width=96, height=80, frames=3, pcm=1, bypass=1, mode=1, seed=12),
+    "pcm_filtered": dict(width=96, height=80, frames=2, pcm=2, mode=1, seed=13),
+    "cip": dict(width=96, height=80, frames=4, cip=1, mode=1, seed=14),
+    "wp_b": dict(width=96, height=80, frames=7, gop=2, num_ref=2, wp=1, mode=1, seed=15),
+    "rplm": dict(width=96, height=80, frames=6, num_ref=3, rplm=1, mode=1, seed=16),
+    "long_term": dict(width=64, height=64, frames=40, num_ref=2, lt_ref=1, seed=17),
+    "scaling_default": dict(width=96, height=80, frames=3, scaling=1, mode=1, seed=18),
+    "scaling_sps": dict(width=96, height=80, frames=3, scaling=2, mode=1, seed=19),
+    "scaling_pps": dict(width=96, height=80, frames=3, scaling=3, mode=1, seed=20),
+    "wpp": dict(width=128, height=96, frames=3, wpp=1, ctb_log2=4, mode=1, seed=21),
+    "tiles": dict(width=128, height=96, frames=3, tile_cols=3, tile_rows=2, ctb_log2=4, mode=1, seed=22),
+    "tiles_no_lf": dict(width=128, height=96, frames=3, tile_cols=2, tile_rows=2, ctb_log2=4, mode=1, seed=23),
+    "slices_dep": dict(width=128, height=96, frames=3, slice_ctus=5, dep_slices=1, ctb_log2=4, mode=1, seed=24),
+    "slices_wpp_dep": dict(width=128, height=96, frames=3, slice_ctus=8, dep_slices=1, wpp=1, ctb_log2=4, mode=1, seed=25),
+    "cabac_init": dict(width=96, height=80, frames=5, gop=1, cabac_init=2, mode=1, seed=26),
+    "par_merge": dict(width=96, height=80, frames=4, par_mrg=4, mode=1, seed=27),
+    "small_tb": dict(width=96, height=80, frames=3, max_tb_log2=3, depth_inter=1, depth_intra=0, mode=1, seed=28),
+}
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return streams.OracleHevc()
+
+
+@pytest.mark.parametrize("name", sorted(HEVC_CASES))
+def test_oracle_equals_generator_reconstruction(oracle, name):
+    """Two separately written code paths (decoder from the syntax, encoder's own reconstruction loop) must agree bit-exactly."""
+    with tempfile.NamedTemporaryFile(suffix=".yuv") as tf:
+        data = streams.generate_hevc(recon_path=tf.name, **HEVC_CASES[name])
+        recon = open(tf.name, "rb").read()
+    out, n, w, h = oracle.decode(data, 1)
+    assert n == HEVC_CASES[name]["frames"] and (w, h) == (HEVC_CASES[name]["width"], HEVC_CASES[name]["height"])
+    assert out == recon, f"{name}: oracle output differs from the generator's reconstruction"
+
+
+def test_cases_cover_the_tools(oracle):
+    seen = {}
+    for name in ("b_gop2", "tskip_sdh", "pcm_bypass", "wp_b", "rplm", "long_term", "wpp", "tiles", "slices_dep", "dqp_depths", "b_gop8", "cip"):
+        for k, v in oracle.tools(streams.generate_hevc(**HEVC_CASES[name])).items():
+            seen[k] = seen.get(k, 0) + v
+    for tool in ("intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst", "sign_hiding", "transform_skip", "tq_bypass", "pcm",
+                 "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "wpp_rows", "tiles", "dependent_slices", "long_term_ref", "rplm", "b_slices"):
+        assert seen.get(tool, 0) > 0, f"no test stream exercises {tool}"
+
+
+def test_golden_vectors(oracle):
+    meta = json.load(open(os.path.join(GOLDEN, "golden_hevc.json")))
+    assert len(meta) >= 6
+    for name, m in meta.items():
+        data = open(os.path.join(GOLDEN, name + ".h265"), "rb").read()
+        out, n, w, h = oracle.decode(data, 1)
+        assert (n, w, h) == (m["frames"], m["width"], m["height"])
+        assert md5(out) == m["md5_i420"], name
+        nv12, _, _, _ = oracle.decode(data, 0)
+        assert md5(nv12) == m["md5_nv12"], name
+        dig, ncu = oracle.syntax_digest(data)
+        assert "%016x" % dig == m["syntax_digest"] and ncu == m["coding_units"], name
+        assert streams.generate_hevc(**m["params"]) == data, f"{name}: the generator no longer reproduces the committed stream"
+
+
+def test_nv12_and_i420_outputs_hold_the_same_samples(oracle):
+    data = streams.generate_hevc(**HEVC_CASES["crop_ctb32"])
+    i420, n, w, h = oracle.decode(data, 1)
+    nv12, _, _, _ = oracle.decode(data, 0)
+    fs = w * h * 3 // 2
+    for k in range(n):
+        a = np.frombuffer(i420[k * fs:(k + 1) * fs], np.uint8); b = np.frombuffer(nv12[k * fs:(k + 1) * fs], np.uint8)
+        assert (a[:w * h] == b[:w * h]).all()
+        uv = b[w * h:].reshape(h // 2, w // 2, 2)
+        assert (uv[:, :, 0].ravel() == a[w * h:w * h + w * h // 4]).all() and (uv[:, :, 1].ravel() == a[w * h + w * h // 4:]).all()
+
+
+def test_corrupt_streams_fail_cleanly(oracle):
+    data = bytearray(streams.generate_hevc(**HEVC_CASES["b_gop2"]))
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        b = bytearray(data)
+        for p in rng.integers(60, len(b), size=3):
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        try:
+            oracle.decode(bytes(b), 1)
+        except RuntimeError:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+# structure of the constant tables (tools/make_hevc_tables.py): the only checks available without a third-party stream
+# ---------------------------------------------------------------------------------------------------------
+TABLES = os.path.join(ROOT, "oracle", "orc_hevc_tables.h")
+
+
+def test_transform_basis_structure():
+    t = np.array(c_array(TABLES, "orch_trans")).reshape(32, 32)
+    assert (t[0] == 64).all()
+    for k in range(32):                                   # even / odd symmetry of the DCT-II basis functions
+        assert (t[k] == (-1) ** k * t[k][::-1]).all()
+    g = t @ t.T
+    assert np.abs(g - np.diag(g.diagonal())).max() < 400 and abs(g.diagonal() - 64 * 64 * 32).max() < 400     # near-orthogonal, norm 2^17
+    for n in (4, 8, 16):                                  # the smaller transforms are the even rows of the larger
+        sub = t[::32 // n, :n]
+        gs = sub @ sub.T
+        assert np.abs(gs - np.diag(gs.diagonal())).max() < 400
+    d = np.array(c_array(TABLES, "orch_dst")).reshape(4, 4)
+    gd = d @ d.T
+    assert np.abs(gd - np.diag(gd.diagonal())).max() <= 16 and abs(gd.diagonal() - 128 * 128).max() < 100        # DST-VII basis, norm 2^14
+
+
+def test_filters_and_loop_filter_tables():
+    lf = np.array(c_array(TABLES, "orch_luma_filter")).reshape(4, 8)
+    cf = np.array(c_array(TABLES, "orch_chroma_filter")).reshape(8, 4)
+    assert (lf.sum(1) == 64).all() and (cf.sum(1) == 64).all()
+    assert (lf[1] == lf[3][::-1]).all() and (lf[2] == lf[2][::-1]).all()
+    for k in range(1, 8):
+        assert (cf[k] == cf[8 - k][::-1]).all()
+    beta, tc = c_array(TABLES, "orch_beta_tab"), c_array(TABLES, "orch_tc_tab")
+    assert len(beta) == 52 and len(tc) == 54 and beta == sorted(beta) and tc == sorted(tc) and beta[15] == 0 and beta[16] == 6 and beta[51] == 64 and tc[17] == 0 and tc[18] == 1 and tc[53] == 24
+    qpc = c_array(TABLES, "orch_qpc_tab")
+    assert qpc[:30] == list(range(30)) and qpc[43] == 37 and qpc[44] == 38 and qpc[57] == 51 and qpc == sorted(qpc)
+    ang = c_array(TABLES, "orch_intra_angle")
+    assert ang[2] == 32 and ang[10] == 0 and ang[18] == -32 and ang[26] == 0 and ang[34] == 32 and all(ang[18 + k] == ang[18 - k] for k in range(17))
+    inv = c_array(TABLES, "orch_inv_angle")
+    for m in range(11, 26):
+        assert abs(inv[m] - round(256 * 32 / ang[m])) <= 1
+
+
+def test_cabac_tables_shape_and_identity_between_copies():
+    init = np.array(c_array(TABLES, "orch_ctx_init")).reshape(3, 154)
+    assert init.min() >= 0 and init.max() <= 255
+    # the three copies (oracle, generator, product) come from one script and must stay identical
+    for path, prefix in ((os.path.join(ROOT, "tools", "hevcgen_tables.h"), "hg_"), (os.path.join(ROOT, "jmcodec_amd", "csrc", "hevc_tables.h"), "hevc_")):
+        assert c_array(path, prefix + "ctx_init") == init.ravel().tolist()
+        assert c_array(path, prefix + "trans") == c_array(TABLES, "orch_trans")
+    h264 = os.path.join(ROOT, "oracle", "orc_cabac_tables.h")
+    assert c_array(TABLES, "orch_range_lps") == c_array(h264, "orc_cabac_range_lps") and c_array(TABLES, "orch_trans_lps") == c_array(h264, "orc_cabac_trans_lps")

@@ -767,7 +767,7 @@ static void decide_pu(Enc *e, Cu *cu, Pu *pu, int part_idx, int force_merge) {
             int16_t cand[2][2]; amvp_list(e, cu->x, cu->y, 1 << cu->log2, pu->x, pu->y, pu->w, pu->h, part_idx, l, ri, cand);
             pu->ref[l] = ri; am.ref[l] = (int8_t)ri; am.pf |= (uint8_t)(1 << l);
             int16_t mv[2];
-            if (fuzz) { int k = rnd_n(r, 2); pu->mvp[l] = k; int big = rnd_n(r, 16) == 0; for (int d = 0; d < 2; d++) mv[d] = (int16_t)CLIP3(-2048, 2047, cand[k][d] + (big ? rnd_n(r, 1025) - 512 : rnd_n(r, 33) - 16)); }
+            if (fuzz) { int k = rnd_n(r, 2); pu->mvp[l] = k; int big = rnd_n(r, 16) == 0; for (int d = 0; d < 2; d++) { int t = cand[k][d] + (big ? rnd_n(r, 1025) - 512 : rnd_n(r, 33) - 16); mv[d] = (int16_t)CLIP3(-2048, 2047, t); }; }
             else {
                 /* true motion of the panning texture relative to the reference, plus a small search */
                 int dpoc = e->cur->poc - s->ref_poc[l][ri], gx = 0, gy = 0;
@@ -968,7 +968,8 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
     }
     if (p->dqp && !e->dqp_coded) cu->qp = pred;                          /* the delta was not sent after all */
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->qpmap[I4(e, x, y)] = (int8_t)cu->qp;
-    e->last_cu_qp = cu->qp;
+    e->last_cu_qp = cu->qp; e->qg_open = 1;
+    TRACE("CU %d %d %d qp %d\n", x0, y0, log2, cu->qp);
 }
 
 /* ------------------------------ coding quadtree, SAO syntax, CTU ------------------------------ */
@@ -985,7 +986,7 @@ static void encode_cqt(Enc *e, int x0, int y0, int log2, int depth) {
         int inc = (avail(e, x0, y0, x0 - 1, y0) && e->depth[I4(e, x0 - 1, y0)] > depth) + (avail(e, x0, y0, x0, y0 - 1) && e->depth[I4(e, x0, y0 - 1)] > depth);
         cab_enc(&e->cab, HG_CTX_SPLIT_CU + inc, split);
     } else split = log2 > p->min_cb_log2;
-    if (p->dqp && log2 >= p->ctb_log2 - (p->dqp - 1)) { e->dqp_coded = 0; e->dqp_val = 0; if (e->qg_open) { e->qp_prev = e->last_cu_qp; e->first_qg = 0; } e->qg_open = 1; }
+    if (p->dqp && log2 >= p->ctb_log2 - (p->dqp - 1)) { e->dqp_coded = 0; e->dqp_val = 0; if (e->qg_open) { e->qp_prev = e->last_cu_qp; e->first_qg = 0; } }   /* qg_open: a coding unit was coded since the last reset */
     if (split) {
         int h = n >> 1;
         for (int k = 0; k < 4; k++) { int x = x0 + (k & 1) * h, y = y0 + (k >> 1) * h; if (x < e->W && y < e->H) encode_cqt(e, x, y, log2 - 1, depth + 1); }
@@ -1180,7 +1181,7 @@ static void write_scaling_list_data(Enc *e, BitW *w) {
             bw_put(w, 1, 1);
             int next = 8;
             if (size > 1) { int d = 4 + rnd_n(r, 60); bw_se(w, d - 8); next = d; *dc = (uint8_t)d; }
-            for (int i = 0; i < n; i++) { int v = choice == 1 ? CLIP3(1, 255, 8 + i / 2 + rnd_n(r, 9)) : 1 + rnd_n(r, 255); int dl = v - next; if (dl > 127) dl -= 256; if (dl < -128) dl += 256; bw_se(w, dl); next = v; list[i] = (uint8_t)v; }
+            for (int i = 0; i < n; i++) { int v = choice == 1 ? 8 + i / 2 + rnd_n(r, 9) : 1 + rnd_n(r, 255); int dl = v - next; if (dl > 127) dl -= 256; if (dl < -128) dl += 256; bw_se(w, dl); next = v; list[i] = (uint8_t)v; }
         }
     }
 }
@@ -1312,6 +1313,7 @@ static Pic *find_poc(Enc *e, int poc) { for (int i = 0; i < 10; i++) if (e->dpb[
 
 static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int first, int dependent, int seg_addr, const size_t *sizes, int n_entry) {
     const HevcGenParams *p = &e->p;
+    if (getenv("HG_DBG")) fprintf(stderr, "SH type %d poc %d nref %d %d tmvp %d col %d %d mvdl1z %d cabac_init %d wp %d denom %d %d rpsneg %d pos %d nl %d ntotal %d\n", s->type, pp->poc, s->n_ref[0], s->n_ref[1], s->tmvp, s->col_l0, s->col_idx, s->mvd_l1_zero, s->cabac_init, s->wp_on, s->wp_denom[0], s->wp_denom[1], pp->n_neg, pp->n_pos, pp->nl, pp->n_total);
     bw_put(w, 1, (uint32_t)first);
     if (pp->nal >= 16 && pp->nal <= 23) bw_put(w, 1, 0);
     bw_ue(w, 0);
@@ -1407,7 +1409,7 @@ static void begin_slice(Enc *e, const PicPlan *pp, const Sched *sc, int addr) {
     s->col_l0 = s->type == 0 ? rnd_n(r, 2) : 1;
     s->col_idx = rnd_n(r, s->col_l0 ? s->n_ref[0] : s->n_ref[1]);
     if (p->wp) {
-        s->wp_on = 1; s->wp_denom[0] = rnd_n(r, 8); s->wp_denom[1] = CLIP3(0, 7, s->wp_denom[0] + rnd_n(r, 5) - 2);
+        s->wp_on = 1; s->wp_denom[0] = rnd_n(r, 8); { int t = s->wp_denom[0] + rnd_n(r, 5) - 2; s->wp_denom[1] = CLIP3(0, 7, t); }
         for (int l = 0; l < 2; l++) for (int i = 0; i < s->n_ref[l]; i++) for (int c = 0; c < 3; c++) {
             int dn = s->wp_denom[c ? 1 : 0], plain = rnd_n(r, 3) == 0;
             if (c == 2 && (s->wp_w[l][i][1] == (1 << s->wp_denom[1]) && s->wp_o[l][i][1] == 0)) plain = rnd_n(r, 2);
@@ -1611,6 +1613,8 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     free(sched);
     return 0;
 }
+
+void hevcgen_free(void *p) { free(p); }
 
 #ifndef HEVCGEN_LIB
 int main(int argc, char **argv) {
