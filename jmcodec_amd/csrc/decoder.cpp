@@ -92,8 +92,8 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "errors") return stat_errors_;
     if (k == "intra_mbs") return stat_intra_mbs_;
     if (k == "coef_int16") return stat_coef_;
-    if (k == "syntax_digest") return (long long)digest_.h;
-    if (k == "digest_mbs") return (long long)digest_.mbs;
+    if (k == "syntax_digest") return codec_ == 1 ? (long long)hdigest_.h : (long long)digest_.h;
+    if (k == "digest_mbs") return codec_ == 1 ? (long long)hdigest_.n_cu : (long long)digest_.mbs;
     if (k == "i_pictures") return stat_i_;
     if (k == "p_pictures") return stat_p_;
     if (k == "b_pictures") return stat_b_;
@@ -129,7 +129,7 @@ long long Decoder::get_stat(const char *key) const {
 // MI355X-class device can be opened, because silently continuing would mean a CPU fallback.
 int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
-    if (codec_type != 0) { fail("only codec_type 0 (H.264) is implemented"); return -1; }
+    if (codec_type != 0 && codec_type != 1) { fail("only codec_type 0 (H.264) and 1 (HEVC) are implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
     if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;
     out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");
@@ -218,6 +218,7 @@ bool Decoder::gpu_alloc_sequence() {
     frame_bytes_ = (size_t)disp_w_ * disp_h_ * 3 / 2;
     // MbRec + worst-case coefficients + motion records (16 vectors; 72 int16 for B / weighted slices) + slice tables
     job_cap_ = n_mbs * (sizeof(MbRec) + 816 + (seq_.profile_idc == 66 ? 64 : kBiRecInt16 * 2)) + 256 * (sizeof(SliceRec) + (seq_.profile_idc == 66 ? 0 : sizeof(SliceWp))) + 4096;
+    if (codec_ == 1) job_cap_ = n_mbs * 128 + (1u << 20);            // HEVC job lists vary a lot in size: start small, grow on demand (ensure_job_cap)
     if (parse_only_) {
         for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
         return true;
@@ -226,7 +227,7 @@ bool Decoder::gpu_alloc_sequence() {
     pitch_ = (mb_w_ * 16 + 127) & ~127;
     chroma_off_ = pitch_ * mb_h_ * 16;
     surf_bytes_ = (size_t)pitch_ * mb_h_ * 16 * 3 / 2;
-    for (int i = 0; i < n_surf_; i++) {
+    for (int i = 0; i < n_surf_ + extra_surf_; i++) {
         if (!HIP_OK(hipMalloc((void **)&surf_[i], surf_bytes_))) { fail("hipMalloc(surface) failed"); return false; }
         hipMemset(surf_[i], 128, surf_bytes_);
     }
@@ -349,6 +350,7 @@ static bool same_picture(const SliceHeader &a, const SliceHeader &b) {      // 7
 }
 
 void Decoder::handle_nal(const uint8_t *nal, size_t len) {
+    if (codec_ == 1) { hevc_handle_nal(nal, len); return; }
     if (failed_ || len < 1 || (nal[0] & 0x80)) return;
     int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
     if (type != 1 && type != 5 && type != 7 && type != 8) {
@@ -442,6 +444,7 @@ int Decoder::compute_poc(const SliceHeader &sh) {                               
 }
 
 void Decoder::flush_dpb(std::vector<int> &out) {
+    if (codec_ == 1) { for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0; hevc_bump(out, true, true); for (int i = 0; i < n_surf_; i++) if (i != cur_ && !dpb_[i].wait_output) dpb_[i].in_use = false; return; }
     for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
     for (;;) {
         int best = -1;
@@ -651,6 +654,7 @@ void Decoder::bump_after_current(std::vector<int> &out) {
 }
 
 void Decoder::dispatch_pending() {
+    if (codec_ == 1) { hevc_dispatch_pending(); return; }
     if (!pending_) return;
     std::unique_ptr<PicTask> t = std::move(pending_);
     mark_current(first_sh_);
@@ -694,6 +698,7 @@ void Decoder::push_task(std::unique_ptr<PicTask> t) {
 // worker: entropy decode one picture into its job buffer
 // =============================================================================================
 void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
+    if (t->hevc) { hevc_parse_task(t); return; }
     auto pt0 = std::chrono::steady_clock::now();
     JobSlot &js = jobs_[t->job_slot];
     const int n_mbs = t->sps.mb_w * t->sps.mb_h;
@@ -811,7 +816,8 @@ void Decoder::submit_task(PicTask *t) {
     ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
     for (int s : t->out_before) enqueue_output(s, ep.out_before, ep.slots_before);
     memset(&ep.pp, 0, sizeof ep.pp);
-    if (ep.has_picture) {
+    if (ep.has_picture && t->hevc) hevc_fill_engine_pic(t, ep);
+    else if (ep.has_picture) {
         JobSlot &js = jobs_[t->job_slot];
         const int n_mbs = t->sps.mb_w * t->sps.mb_h;
         PicParams &pp = ep.pp;

@@ -9,6 +9,7 @@
 #pragma once
 #include "h264_cavlc.h"
 #include "h264_syntax.h"
+#include "hevc_slice.h"
 #include "jobs.h"
 #include <atomic>
 #include <chrono>
@@ -31,6 +32,7 @@ struct DpbPic {
     int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
     int decode_idx = 0; bool mmco5 = false;
     std::shared_ptr<MotionField> mf;
+    std::shared_ptr<HevcColMotion> hcol;       // HEVC: motion of this picture for temporal prediction
     int out_at = -100;                         // decode index of the picture after which this surface was displayed (cooling)
 };
 
@@ -43,6 +45,16 @@ struct SliceTask {
     SliceWp wp; bool has_wp = false;           // weighted prediction tables of this slice
 };
 
+// HEVC picture: the slice segments with their reference lists, and where the packed job lists sit in the job buffer
+struct HevcSliceTask { HevcSliceHeader sh; HevcSliceRefs refs; std::vector<uint8_t> rbsp; size_t len = 0; };
+struct HevcTask {
+    HevcSps sps; HevcPps pps; int poc = 0, work_slot = -1;
+    std::vector<HevcSliceTask> slices;
+    std::shared_ptr<HevcColMotion> col_out;
+    size_t off_ctbs = 0, off_qp8 = 0, off_bsv = 0, off_bsh = 0, off_pus = 0, off_tbs = 0, off_itbs = 0, off_coefs = 0, off_wps = 0;
+    int n_pus = 0, n_tbs = 0, n_itbs = 0; bool any_sao = false, any_deblock = false;
+};
+
 struct PicTask {
     uint64_t seq = 0;
     bool has_picture = false;
@@ -50,6 +62,7 @@ struct PicTask {
     std::shared_ptr<MotionField> mf;           // this picture's motion field (reference pictures of streams that may hold B pictures)
     SeqParams sps; PicParamSet pps;
     std::vector<SliceTask> slices;
+    std::unique_ptr<HevcTask> hevc;            // codec_type 1
     std::vector<int> out_before, out_after;    // DPB slots to display before / after this picture
     bool wait_prev_pack = false;               // current surface was displayed by the previous picture (no cooling slack)
     // written by the parse worker
@@ -122,6 +135,16 @@ private:
     bool gpu_alloc_sequence();
     void gpu_free_sequence();
     void free_out_slots(bool all);
+    // ---- HEVC front end (hevc_decoder.cpp) ----
+    void hevc_handle_nal(const uint8_t *nal, size_t len);
+    bool hevc_start_picture(const HevcSliceHeader &sh, int nal_type, int tid);
+    bool hevc_activate(const HevcSps &sps);
+    bool hevc_build_refs(const HevcSliceHeader &sh, HevcSliceRefs &refs);
+    void hevc_dispatch_pending();
+    void hevc_bump(std::vector<int> &out, bool all, bool use_fullness);
+    void hevc_parse_task(PicTask *t);
+    void hevc_fill_engine_pic(PicTask *t, struct EnginePic &ep);
+    bool ensure_job_cap(JobSlot &js, size_t bytes);
     void gpu_close();
     void submit_ready();
     void submit_task(PicTask *t);
@@ -181,6 +204,11 @@ private:
     std::atomic<long long> stat_parse_ns_i_{0}, stat_parse_ns_p_{0}, stat_submit_ns_{0}, stat_wait_slot_ns_{0};
     std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0};
     SyntaxDigest digest_;
+    // HEVC state (front end only unless noted)
+    HevcParamSets hps_; HevcSps hsps_; HevcPps hpps_;
+    int h_poc_tid0_ = 0, h_max_dpb_ = 1, h_reorder_ = 0, extra_surf_ = 0; bool h_first_picture_ = true, h_no_rasl_output_ = false, h_seen_eos_ = false;
+    HevcSliceHeader h_last_sh_; bool h_have_last_sh_ = false;
+    HevcDigest hdigest_;                       // written by the parse worker (sync option)
     long long stat_i_ = 0, stat_p_ = 0, stat_b_ = 0;
     std::vector<int> display_pocs_;            // diagnostic (get via stats)
     struct TraceRec { uint64_t seq; long long t_dispatch, t_parsed, t_submit0, t_submit1; int is_i; };

@@ -2,6 +2,7 @@
 #include "engine.h"
 #include "decoder.h"
 #include "kernels.h"
+#include "hevc_kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <chrono>
@@ -37,6 +38,8 @@ Engine::Engine(int device) : device_(device) {
         for (auto &b : ln.ring) {
             if (hipHostMalloc((void **)&b.h_pics, sizeof(PicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
+            if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
@@ -88,16 +91,24 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
 void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size();
     int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0, stages = 0;
-    bool wait_pack = false;
+    bool wait_pack = false, any_hevc = false;
+    HevcBatchDims hd;
     const EnginePic *last_upload = nullptr;
     b.n_pre = b.n_post = 0; b.pmask = 0;
     for (int k = 0; k < 4; k++) { b.alg[k] = 0; b.npics[k] = 0; }
     // pack jobs: [0, n_pre) before the decode kernels, [2*kMaxBatch, 2*kMaxBatch + n_post) after them
     for (int i = 0; i < n; i++) {
         EnginePic &p = b.pics[i];
+        const bool hevc = p.codec == 1;
+        if (hevc) { b.h_hpics[i] = p.hp; if (!p.has_picture) b.h_hpics[i].stages = 0; any_hevc = true; }
         b.h_pics[i] = p.pp;
-        if (!p.has_picture) b.h_pics[i].stages = 0;
+        if (!p.has_picture || hevc) b.h_pics[i].stages = 0;
         stages |= b.h_pics[i].stages;
+        if (hevc && p.has_picture) {
+            const HevcPicParams &h = p.hp;
+            hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
+            hd.max_w = std::max(hd.max_w, h.w); hd.max_h = std::max(hd.max_h, h.h); hd.any_intra |= (h.stages & HPS_INTRA) != 0; hd.any_deblock |= (h.stages & HPS_DEBLOCK) != 0; hd.any_sao |= (h.stages & HPS_SAO) != 0;
+        }
         if (p.has_picture) {
             max_mbs = std::max(max_mbs, p.mb_w * p.mb_h); max_mb_h = std::max(max_mb_h, p.mb_h);
             if (p.uploaded && (!last_upload || p.upload_seq > last_upload->upload_seq)) last_upload = &p;
@@ -107,6 +118,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         for (auto &j : p.out_after) if (b.n_post < 2 * kMaxBatch) b.h_jobs[2 * kMaxBatch + b.n_post++] = j;
         if (!p.out_before.empty() || !p.out_after.empty()) { max_w = std::max(max_w, p.disp_w); max_h = std::max(max_h, p.disp_h); }
         int st = b.h_pics[i].stages;
+        if (hevc && p.has_picture) { const int hs = p.hp.stages; if (hs & (HPS_MC | HPS_RESID)) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; } if (hs & HPS_INTRA) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; } if (hs & (HPS_DEBLOCK | HPS_SAO)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; } }
         if (st & PS_RECON) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
         if (st & (PS_INTRA_LDS | PS_INTRA_V1)) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; }
         if (st & (PS_DEBLOCK_LDS | PS_DEBLOCK_V1)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; }
@@ -114,7 +126,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
     hipStream_t st = ln.stream, pst = ln.pack_stream;
-    hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
+    if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, st);
+    else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, st);
     if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, st);
     // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
@@ -134,14 +147,22 @@ void Engine::launch(Lane &ln, Batch &b) {
     auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev && o->host) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
     if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; for (auto &p : b.pics) copy_out(p.slots_before, st); }
     mark(1, st);
+    if (any_hevc && (hd.max_pus || hd.max_tbs || hd.any_intra || hd.any_deblock || hd.any_sao)) {
+        // HEVC batch (its own lane, so never mixed with H.264 pictures): MC + residual | intra diagonals | deblocking + SAO
+        hipEvent_t ev[4] = {b.pev[1], b.pev[2], b.pev[3], b.pev[4]};
+        launch_hevc_picture_batch(b.d_hpics, n, hd, st, profile_ ? ev : nullptr);
+        if (hd.max_pus || hd.max_tbs) b.pmask |= 2;
+        if (hd.any_intra) b.pmask |= 4;
+        if (hd.any_deblock || hd.any_sao) b.pmask |= 8;
+    }
     if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
-    mark(2, st);
+    if (!any_hevc) mark(2, st);
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
-    mark(3, st);
+    if (!any_hevc) mark(3, st);
     if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
-    mark(4, st);
+    if (!any_hevc) mark(4, st);
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
     mark(5, pst);

@@ -15,6 +15,7 @@
 // There is no reference counterpart: the reference drives one NVDEC session synchronously (nv_dec.cpp:33-41).
 #pragma once
 #include "jobs.h"
+#include "hevc_jobs.h"
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -32,12 +33,15 @@ constexpr int kMaxBatch = 64;
 constexpr int kBatchRing = 4;
 constexpr int kPLanes = 1;                          // lanes for ordinary pictures: while one group's batch sits in the serial deblock
                                                     // wavefront (2 CUs per picture) the other group's fully parallel kernels use the idle CUs
-constexpr int kLanes = kPLanes + 1;                 // + one lane for intra-dense pictures
+constexpr int kLanes = kPLanes + 2;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures
+constexpr int kHevcLane = kPLanes + 1;
 
 struct EnginePic {
     Decoder *dec = nullptr;
     bool has_picture = false;
     PicParams pp;                                   // device pointers already resolved by the decoder
+    int codec = 0;                                  // 0 = H.264 (pp), 1 = HEVC (hp)
+    HevcPicParams hp;
     int job_slot = -1;
     ihipEvent_t *uploaded = nullptr; unsigned long long upload_seq = 0;   // job list copy (copy stream), see Engine::upload
     std::vector<PackJob> out_before, out_after;     // display frames to pack before / after this picture's kernels
@@ -46,7 +50,7 @@ struct EnginePic {
     bool wait_prev_pack = false;                    // this picture reuses a surface whose pack-out may still be running
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
-    int lane() const { return (has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane; }
+    int lane() const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane); }
 };
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout
@@ -72,6 +76,7 @@ private:
     void run();
     struct Batch {
         PicParams *h_pics = nullptr, *d_pics = nullptr;       // pinned host / device, kMaxBatch entries
+        HevcPicParams *h_hpics = nullptr, *d_hpics = nullptr; // the same for HEVC batches
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;
@@ -86,6 +91,7 @@ private:
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     void launch(Lane &ln, Batch &b);
+    void launch_hevc(Lane &ln, Batch &b);
     void complete(Batch &b);
 
     int device_;

@@ -1,0 +1,84 @@
+// jmcodec_amd/csrc/hevc_jobs.h -- the host->device contract of one HEVC picture.
+//
+// Replaces the CUVIDHEVCPICPARAMS hand-off of the reference (/root/reference/nv_dec/nv_dec.cpp:33-41 -> cuvidDecodePicture with
+// nv_sdk/inc/dynlink_cuviddec.h:428-530): there the slice bytes go to the NVDEC ASIC; here CABAC decoding, motion vector
+// prediction (merge / AMVP / temporal), de-quantisation and the boundary-strength decisions stay on the host and the device gets
+//   HevcCtb[ctbs]        SAO parameters, deblocking offsets, the CTB's intra blocks
+//   qp8[]                QpY per 8x8 (bit 7: samples exempt from the loop filters: pcm_loop_filter_disabled / transquant bypass)
+//   bs_v[], bs_h[]       boundary strength per 4-sample edge segment of the 8x8 grid (0 = not filtered)
+//   HevcPu[]             motion-compensated blocks of at most 16x16 luma samples
+//   HevcTb[]             transform blocks of inter coding units that carry coefficients
+//   HevcIntraTb[]        intra-predicted transform blocks in decoding order, grouped per CTB
+//   coefs[]              scaled (de-quantised) coefficients, sparse: position | value << 16
+//   HevcWp[]             explicit weighted-prediction tables per slice
+// in one pinned buffer, uploaded with a single copy.
+#pragma once
+#include <stdint.h>
+#include "jobs.h"
+
+namespace jmamd {
+
+struct HevcCtb {                  // 32 bytes
+    uint8_t  sao_type[3];         // 0 off, 1 band offset, 2 edge offset
+    uint8_t  sao_pos[3];          // band position / edge class
+    int8_t   sao_off[3][4];
+    int8_t   beta_off, tc_off;    // slice_beta_offset_div2 / slice_tc_offset_div2 of the CTB's slice
+    uint8_t  nb_mask;             // bit k set: SAO edge offset may use samples of neighbouring CTB k (L, R, T, B, TL, TR, BL, BR)
+    uint8_t  pad;
+    uint32_t intra_first, intra_count;
+};
+static_assert(sizeof(HevcCtb) == 32, "HevcCtb layout");
+
+struct HevcPu {                   // 20 bytes
+    uint16_t x, y;                // luma position
+    uint8_t  w, h;                // luma size (4..16)
+    int8_t   slot0, slot1;        // DPB surface of list 0 / list 1, -1 = list unused
+    int16_t  mv0[2], mv1[2];      // quarter-sample units
+    uint8_t  ridx0, ridx1;        // reference indices (select the weights)
+    uint16_t wp;                  // 0 = default weighted prediction, else 1 + index into HevcWp[]
+};
+static_assert(sizeof(HevcPu) == 20, "HevcPu layout");
+
+enum : uint8_t { HTB_TSKIP = 1, HTB_BYPASS = 2, HTB_DST = 4, HTB_CORNER = 8 };
+constexpr uint8_t kHevcModePcm = 255;
+
+struct HevcTb {                   // 16 bytes
+    uint16_t x, y;                // position in samples of its plane
+    uint8_t  log2, plane, flags, pad;
+    uint32_t coef_off, coef_n;
+};
+struct HevcIntraTb {              // 20 bytes
+    uint16_t x, y;
+    uint8_t  log2, plane, mode, flags;   // mode: 0..34, kHevcModePcm = samples are the "coefficients"; flags: HTB_*
+    uint32_t avail;               // bit i (0..15): left neighbour unit i (top to bottom, 4 luma rows each) available; bit 16 + i: top unit i (left to right)
+    uint32_t coef_off, coef_n;    // coef_n == 0: prediction only
+};
+static_assert(sizeof(HevcTb) == 16 && sizeof(HevcIntraTb) == 20, "transform block record layout");
+
+struct HevcWp {                   // explicit weighted prediction of one slice (8.5.3.3.4.3)
+    int16_t log2wd[2];            // luma, chroma: denominator + 14 - bitDepth
+    int16_t w[2][16][3], o[2][16][3];
+};
+
+enum : int { HPS_MC = 1, HPS_RESID = 2, HPS_INTRA = 4, HPS_DEBLOCK = 8, HPS_SAO = 16 };
+
+struct HevcPicParams {
+    int w, h;                     // coded luma size
+    int pitch, chroma_offset;     // NV12 surfaces, as for H.264
+    int ctb_log2, ctb_w, ctb_h;
+    int w8;                       // qp8 row stride = w / 8
+    int cb_qp_off, cr_qp_off;     // pps_cb_qp_offset / pps_cr_qp_offset (chroma deblocking)
+    int strong_intra;
+    int stages;                   // HPS_*
+    int cur, work;                // surface the finished picture lands in / surface reconstruction and deblocking run in (== cur without SAO)
+    uint8_t *surf[kMaxSurfaces];
+    const HevcCtb *ctbs;
+    const uint8_t *qp8, *bs_v, *bs_h;
+    const HevcPu *pus; int n_pus;
+    const HevcTb *tbs; int n_tbs;
+    const HevcIntraTb *itbs; int n_itbs;
+    const uint32_t *coefs;
+    const HevcWp *wps;
+};
+
+}  // namespace jmamd

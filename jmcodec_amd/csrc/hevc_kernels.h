@@ -1,0 +1,11 @@
+// jmcodec_amd/csrc/hevc_kernels.h -- host-callable launcher of the HEVC kernels (hevc_kernels.hip); one call = one batch of pictures.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "hevc_jobs.h"
+
+namespace jmamd {
+struct HevcBatchDims { int max_pus = 0, max_tbs = 0, max_ctb_w = 0, max_ctb_h = 0, max_w = 0, max_h = 0; bool any_intra = false, any_deblock = false, any_sao = false; };
+// marks (optional, 4 events): before MC, after residual, after intra, after the loop filters
+void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBatchDims &m, hipStream_t st, hipEvent_t *marks);
+void hevc_kernels_init();
+}  // namespace jmamd

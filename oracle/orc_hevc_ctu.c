@@ -20,8 +20,10 @@ typedef struct {
     int err;
 } Sx;
 
+static void dg_trace(int v);
 static void dg(OrchDec *d, int v) {
     if (!d->digest_on) return;
+    dg_trace(v);
     for (int i = 0; i < 4; i++) { d->digest ^= (uint8_t)((uint32_t)v >> (8 * i)); d->digest *= 0x100000001b3ULL; }
 }
 
@@ -39,6 +41,7 @@ static void cabac_init_ctx(Sx *s) {                                     /* 9.3.2
 static void cabac_init_engine(Sx *s) { s->range = 510; s->offset = bits_u(&s->b, 9); }      /* 9.3.2.5 */
 static FILE *g_trace; static int g_trace_init;
 #define TRACE(...) do { if (!g_trace_init) { g_trace_init = 1; if (getenv("ORCH_TRACE")) g_trace = fopen(getenv("ORCH_TRACE"), "w"); } if (g_trace) fprintf(g_trace, __VA_ARGS__); } while (0)
+static void dg_trace(int v) { TRACE("D %d\n", v); }
 static int ae_(Sx *s, int ctx);
 static int ae(Sx *s, int ctx) { int b = ae_(s, ctx); TRACE("c%d %d\n", ctx, b); return b; }
 static int ae_(Sx *s, int ctx) {                                         /* 9.3.4.3.2 */

@@ -1,0 +1,95 @@
+"""HEVC on the GPU: the HIP path behind the jm_nvdec_* C ABI (codec_type 1) against the CPU oracle, bit-exact.
+
+Small seeded streams for every tool the generator can produce, the committed golden vectors, and -- at BASELINE.json's sizes
+(1080p, 4K) -- a few frames of the C3 configuration (64x64 CTBs, SAO + deblocking, random-access GOP 8)."""
+import json
+import os
+import threading
+
+import pytest
+
+import jmcodec_amd
+from jmcodec_amd import streams
+from test_hevc_oracle import HEVC_CASES
+from util import GOLDEN, md5
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return streams.OracleHevc()
+
+
+def gpu_decode(data, out_fmt=1, options=None):
+    with jmcodec_amd.JmAmdDec(1, out_fmt, options=dict({"device": 0}, **(options or {}))) as d:
+        frames = d.decode_stream(data)
+        return frames, d.stat("errors")
+
+
+@pytest.mark.parametrize("name", sorted(HEVC_CASES))
+def test_bit_exact_vs_oracle(oracle, name):
+    data = streams.generate_hevc(**HEVC_CASES[name])
+    want, n, w, h = oracle.decode(data, 1)
+    frames, errors = gpu_decode(data)
+    assert errors == 0 and len(frames) == n
+    fs = w * h * 3 // 2
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"{name}: frame {i} differs from the oracle"
+
+
+def test_golden_vectors_i420_and_nv12():
+    meta = json.load(open(os.path.join(GOLDEN, "golden_hevc.json")))
+    for name, m in meta.items():
+        data = open(os.path.join(GOLDEN, name + ".h265"), "rb").read()
+        for fmt, key in ((1, "md5_i420"), (0, "md5_nv12")):
+            frames, errors = gpu_decode(data, fmt)
+            assert errors == 0 and len(frames) == m["frames"]
+            assert md5(b"".join(frames)) == m[key], (name, key)
+
+
+def test_c3_configuration_1080p_and_4k(oracle):
+    for w, h, frames in ((1920, 1080, 9), (3840, 2160, 3)):
+        data = streams.generate_hevc(**streams.config_c3(frames=frames, width=w, height=h))
+        want, n, ww, hh = oracle.decode(data, 1)
+        got, errors = gpu_decode(data)
+        assert errors == 0 and len(got) == n == frames and (ww, hh) == (w, h)
+        assert b"".join(got) == want, f"{w}x{h}"
+
+
+def test_concurrent_hevc_and_h264_streams(oracle):
+    """independent handles of both codecs on one device (the per-device engine batches them in separate lanes)"""
+    o264 = streams.Oracle()
+    jobs = []
+    for i in range(6):
+        if i % 2:
+            data = streams.generate(width=96, height=80, frames=8, gop=4, seed=100 + i, cabac=1, bframes=1, num_ref=2, poc_type=0)
+            jobs.append((0, data, o264.decode(data, 1)[0]))
+        else:
+            data = streams.generate_hevc(**dict(HEVC_CASES["b_gop2"], seed=200 + i))
+            jobs.append((1, data, oracle.decode(data, 1)[0]))
+    results = [None] * len(jobs)
+
+    def run(k):
+        codec, data, _ = jobs[k]
+        with jmcodec_amd.JmAmdDec(codec, 1, options={"device": 0}) as d:
+            results[k] = b"".join(d.decode_stream(data))
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(len(jobs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k, (_, _, want) in enumerate(jobs):
+        assert results[k] == want, f"stream {k}"
+
+
+def test_corrupt_hevc_streams_do_not_hang():
+    import numpy as np
+    data = streams.generate_hevc(**HEVC_CASES["b_gop2"])
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        b = bytearray(data)
+        for p in rng.integers(60, len(b), size=2):
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        with jmcodec_amd.JmAmdDec(1, 1, options={"device": 0}) as d:
+            d.decode_stream(bytes(b), keep=False)
