@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tools", default="baseline", choices=["baseline", "high", "high_b"],
                     help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P)")
+    ap.add_argument("--codec", default="h264", choices=["h264", "hevc"], help="diagnostic: hevc = SURVEY 8d config C3 (HEVC Main, 64x64 CTB, SAO + deblocking, random-access GOP 8) at --width x --height")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
@@ -78,7 +79,12 @@ def main():
     if args.tools == "high_b":
         cfg.update(bframes=2, num_ref=2, poc_type=0)
         tools_desc = "High, I B B P (CABAC, 8x8 transform"
-    data = streams.generate(**cfg)
+    if args.codec == "hevc":
+        cfg = streams.config_c3(frames=args.frames, width=args.width, height=args.height, stream_id=rank)
+        tools_desc = "Main, random-access GOP 8 (CABAC, 64x64 CTB, SAO"
+        data = streams.generate_hevc(**cfg)
+    else:
+        data = streams.generate(**cfg)
     nalus = jmcodec_amd.split_nalus(data)
     S, F, K, W = args.streams, args.frames, args.steps, args.warmup
     mb_w, mb_h = (args.width + 15) // 16, (args.height + 15) // 16
@@ -90,7 +96,7 @@ def main():
         L.jm_amddec_set_option(h, b"profile", 0 if args.no_profile else 1)   # the engine records HIP events around each batched launch
         if args.parse_only:
             L.jm_amddec_set_option(h, b"parse_only", 1)
-        if jmcodec_amd.jm_nvdec_init(0, 1, None, 0, h) != 0:
+        if jmcodec_amd.jm_nvdec_init(1 if args.codec == "hevc" else 0, 1, None, 0, h) != 0:
             raise SystemExit("init failed: " + L.jm_amddec_last_error(h).decode())
         handles.append(h)
 
@@ -113,7 +119,7 @@ def main():
         # let the pipeline run dry (no EOS: the handle keeps its DPB) and collect what it finished.
         # An access-unit delimiter carries no picture; two of them push the last slice NAL out of the
         # splitter (a NAL ends at the next start code) and close the picture (7.4.1.2.3).
-        sc = b"\x00\x00\x01\x09\x10"
+        sc = b"\x00\x00\x01\x46\x01\x50" if args.codec == "hevc" else b"\x00\x00\x01\x09\x10"
         for _ in range(2):
             L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
             if got.value == 1:
@@ -218,9 +224,10 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the build's own scalar CPU oracle (NOT libmfx: unobtainable),
         # one core, on a bounded sample of the same workload.
-        o = streams.Oracle()
-        sample_frames = min(F, 90)
-        sample = streams.generate(**dict(cfg, frames=sample_frames)) if sample_frames != F else data
+        o = streams.OracleHevc() if args.codec == "hevc" else streams.Oracle()
+        sample_frames = min(F, 90 if args.codec == "h264" else 16)
+        gen = streams.generate_hevc if args.codec == "hevc" else streams.generate
+        sample = gen(**dict(cfg, frames=sample_frames)) if sample_frames != F else data
         reps, c0, n_dec = 0, time.perf_counter(), 0
         while True:
             _, n, _, _ = o.decode(sample, 1)
@@ -236,7 +243,7 @@ def main():
 
     value = frames_total / dt_max
     line = {
-        "metric": "decoded frames/sec @1080p H.264 + bit-exact YUV",
+        "metric": "decoded frames/sec @1080p H.264 + bit-exact YUV" if args.codec == "h264" else f"decoded frames/sec HEVC {args.width}x{args.height} (diagnostic, SURVEY 8d C3)",
         "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -248,7 +255,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) {args.width}x{args.height}, "
+        "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) ") + f"{args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
                    "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H + memcpy to caller"},
