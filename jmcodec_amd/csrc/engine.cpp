@@ -40,6 +40,7 @@ Engine::Engine(int device) : device_(device) {
             if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
@@ -150,7 +151,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (any_hevc && (hd.max_pus || hd.max_tbs || hd.any_intra || hd.any_deblock || hd.any_sao)) {
         // HEVC batch (its own lane, so never mixed with H.264 pictures): MC + residual | intra diagonals | deblocking + SAO
         hipEvent_t ev[4] = {b.pev[1], b.pev[2], b.pev[3], b.pev[4]};
-        launch_hevc_picture_batch(b.d_hpics, n, hd, st, profile_ ? ev : nullptr);
+        launch_hevc_picture_batch(b.d_hpics, n, hd, b.d_progress, st, profile_ ? ev : nullptr);
         if (hd.max_pus || hd.max_tbs) b.pmask |= 2;
         if (hd.any_intra) b.pmask |= 4;
         if (hd.any_deblock || hd.any_sao) b.pmask |= 8;

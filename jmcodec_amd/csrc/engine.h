@@ -77,6 +77,7 @@ private:
     struct Batch {
         PicParams *h_pics = nullptr, *d_pics = nullptr;       // pinned host / device, kMaxBatch entries
         HevcPicParams *h_hpics = nullptr, *d_hpics = nullptr; // the same for HEVC batches
+        int *d_progress = nullptr;                            // CTB row progress counters of k_hevc_intra
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;

@@ -6,7 +6,7 @@
 // (blockIdx.y = picture), as for H.264.
 //   k_hevc_mc        one wavefront per block of <= 16x16 luma samples: 8-tap / 4-tap separable interpolation through LDS, weighting
 //   k_hevc_resid     one wavefront per transform block of an inter CU: sparse coefficients -> inverse transform -> add
-//   k_hevc_intra     one wavefront per coding tree block of a wavefront diagonal (x + 2y = d): its intra blocks in decoding order
+//   k_hevc_intra     one workgroup per CTB row, rows chained by progress counters: the CTB's intra blocks in decoding order, CTB held in LDS
 //   k_hevc_deblock   one lane per 4-sample edge segment; all vertical edges of the picture, then all horizontal edges (8.7.2)
 //   k_hevc_sao       one lane per sample, deblocked surface -> final surface (8.7.3)
 // All integer arithmetic on 8-bit samples; surfaces are pitch-linear NV12 like the H.264 path's.
@@ -106,34 +106,38 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
 // ------------------------------------------------------------------------------------------------------------
 // 8.6.4.2: residual of one transform block from its sparse scaled coefficients; result in res[y * n + x]
 // ------------------------------------------------------------------------------------------------------------
-__device__ void residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, int lane) {
+// Callers make sure nobody still reads d / res (a barrier since their last use).  Returns the buffer that holds the residual.
+// tm: the 32x32 core transform matrix in LDS; ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the rest).
+// WAVE: the caller is a single wavefront (LDS operations of one wave execute in order, so a scheduling barrier replaces s_barrier).
+template <bool WAVE>
+__device__ const int16_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, const int8_t *tm, int *ext, int lane, int nt) {
+    auto sync = [] { if (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
     const int n = 1 << log2, nn = n * n;
-    __syncthreads();
-    for (int k = lane; k < nn; k += 64) d[k] = 0;
-    __syncthreads();
-    for (int k = lane; k < count; k += 64) { const uint32_t e = coefs[k]; d[e & 1023] = (int16_t)(e >> 16); }
-    __syncthreads();
-    if (flags & HTB_BYPASS) { for (int k = lane; k < nn; k += 64) res[k] = d[k]; __syncthreads(); return; }
-    if (flags & HTB_TSKIP) { for (int k = lane; k < nn; k += 64) res[k] = (int16_t)(((d[k] << 7) + 2048) >> 12); __syncthreads(); return; }
-    const int step = 32 >> log2, dst = flags & HTB_DST;
-    // columns: g[y][x] = clip16((sum_k M[k][y] * d[k][x] + 64) >> 7), kept in res
-    for (int k = lane; k < nn; k += 64) {
-        const int y = k >> log2, x = k & (n - 1);
+    for (int k = lane; k < nn; k += nt) d[k] = 0;
+    if (lane < 2) ext[lane] = 0;
+    sync();
+    for (int k = lane; k < count; k += nt) { const uint32_t e = coefs[k]; const int pos = e & 1023; d[pos] = (int16_t)(e >> 16); atomicMax(&ext[0], pos >> log2); atomicMax(&ext[1], pos & (n - 1)); }
+    sync();
+    if (flags & HTB_BYPASS) return d;
+    if (flags & HTB_TSKIP) { for (int k = lane; k < nn; k += nt) res[k] = (int16_t)(((d[k] << 7) + 2048) >> 12); sync(); return res; }
+    const int step = 32 >> log2, dst = flags & HTB_DST, jmax = ext[0], xw = ext[1] + 1;
+    // columns: g[y][x] = clip16((sum_j M[j][y] * d[j][x] + 64) >> 7) for the columns that hold coefficients, kept in res
+    for (int k = lane; k < n * xw; k += nt) {
+        const int y = k / xw, x = k - y * xw;
         int v = 0;
-        for (int j = 0; j < n; j++) { const int dj = d[j * n + x]; if (dj) v += (dst ? c_dst[j][y] : c_trans[j * step][y]) * dj; }
-        res[k] = (int16_t)clip3(-32768, 32767, (v + 64) >> 7);
+        for (int j = 0; j <= jmax; j++) v += (dst ? c_dst[j][y] : tm[j * step * 32 + y]) * d[j * n + x];
+        res[y * n + x] = (int16_t)clip3(-32768, 32767, (v + 64) >> 7);
     }
-    __syncthreads();
-    // rows: r[y][x] = (sum_k M[k][x] * g[y][k] + 2048) >> 12, back into d, then copied to res
-    for (int k = lane; k < nn; k += 64) {
+    sync();
+    // rows: r[y][x] = (sum_k M[k][x] * g[y][k] + 2048) >> 12, into d
+    for (int k = lane; k < nn; k += nt) {
         const int y = k >> log2, x = k & (n - 1);
         int v = 0;
-        for (int j = 0; j < n; j++) v += (dst ? c_dst[j][x] : c_trans[j * step][x]) * res[y * n + j];
+        for (int j = 0; j < xw; j++) v += (dst ? c_dst[j][x] : tm[j * step * 32 + x]) * res[y * n + j];
         d[k] = (int16_t)((v + 2048) >> 12);
     }
-    __syncthreads();
-    for (int k = lane; k < nn; k += 64) res[k] = d[k];
-    __syncthreads();
+    sync();
+    return d;
 }
 
 __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
@@ -141,64 +145,140 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     if (!(pp.stages & HPS_RESID) || (int)blockIdx.x >= pp.n_tbs) return;
     const HevcTb tb = pp.tbs[blockIdx.x];
     __shared__ int16_t d[32 * 32], res[32 * 32];
+    __shared__ __align__(16) int8_t tm[32 * 32];
+    __shared__ int ext[2];
     const int lane = threadIdx.x, n = 1 << tb.log2;
-    residual_block(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, lane);
+    for (int k = lane; k < 256; k += 64) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
+    const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
     uint8_t *dst = pp.surf[pp.work];
     for (int k = lane; k < n * n; k += 64) {
         const int y = k >> tb.log2, x = k & (n - 1);
         uint8_t *p = sample_ptr(dst, pp, tb.plane, tb.x + x, tb.y + y);
-        *p = (uint8_t)clip1(*p + res[k]);
+        *p = (uint8_t)clip1(*p + r[k]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // 8.4.4.2: intra prediction (+ residual) of the intra blocks of one coding tree block, in decoding order
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int load_recon(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // written by this workgroup moments ago
+constexpr int kIntraThreads = 256;
+constexpr int kYS = 132, kCS = 68;              // LDS row strides of the luma / chroma tiles
+constexpr int kIntraMaxTbs = 448, kIntraMaxCoefs = 6144;   // 64x64 CTB: <= 256 + 128 4x4 blocks (+ PCM planes); <= 64 * 64 * 1.5 coefficients
 
-__global__ __launch_bounds__(64) void k_hevc_intra(const HevcPicParams *pics, int diag) {
+// The coding tree block lives in LDS while its intra blocks are reconstructed: tile row 0 / column 0 hold the samples above / left
+// of the CTB (row 0 continues over the CTB to the right: above-right neighbours), so every neighbour a block may use (8.4.4.2.2) is
+// an LDS read, whether it was produced by this CTB's earlier blocks, by the inter kernels or by a CTB of an earlier diagonal.
+//
+// One workgroup per CTB row walks its row left to right; CTB (x, y) may start when row y - 1 has finished x + 2 CTBs (its above and
+// above-right neighbours).  Progress counters in device memory carry that dependency between workgroups: row y only ever waits for
+// row y - 1, whose workgroup has the smaller block index and is therefore already running or finished -- no deadlock whatever the
+// occupancy.  (A launch per wavefront diagonal, the first version, cost the sum of the slowest CTB of every diagonal: 23 ms for a
+// batch of 4K pictures; this form follows the real dependency chain.)
+__global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParams *pics, int *progress, int prog_stride) {
     const HevcPicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & HPS_INTRA)) return;
-    int ymin = diag - (pp.ctb_w - 1); ymin = ymin > 0 ? (ymin + 1) >> 1 : 0;
-    const int cy = ymin + (int)blockIdx.x, cx = diag - 2 * cy;
-    if (cy >= pp.ctb_h || cx < 0 || cx >= pp.ctb_w) return;
+    const int cy = blockIdx.x;
+    if (cy >= pp.ctb_h) return;
+    int *prog = progress + (size_t)blockIdx.y * prog_stride;
+    for (int cx = 0; cx < pp.ctb_w; cx++) {
     const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
-    if (!ctb.intra_count) return;
-    __shared__ int16_t edge[2][132];           // [0] raw, [1] filtered: 0 .. 2n-1 left column bottom-to-top, 2n corner, 2n+1 .. 4n top row left-to-right
-    __shared__ uint8_t ok[132];
-    __shared__ int16_t refa[32 * 3 + 8];       // main reference of the angular modes, index 0 at refa[32]
-    __shared__ int16_t d[32 * 32], res[32 * 32];
-    __shared__ int s_first;
-    const int lane = threadIdx.x;
+    if (ctb.intra_count) {
+    if (cy > 0) {
+        if (threadIdx.x == 0) {
+            const int need = cx + 2 < pp.ctb_w ? cx + 2 : pp.ctb_w;
+            int spins = 0;
+            while (__hip_atomic_load(&prog[cy - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __shared__ uint8_t ty[65 * kYS];            // luma tile
+    __shared__ uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
+    // per colour plane (= per wavefront of the block loop):
+    __shared__ int16_t edge_[3][2][132];        // [0] raw, [1] filtered: 0 .. 2n-1 left column bottom-to-top, 2n corner, 2n+1 .. 4n top row left-to-right
+    __shared__ int16_t refa_[3][32 * 3 + 8];    // main reference of the angular modes, index 0 at refa[32]
+    __shared__ int16_t d_[3][32 * 32], res_[3][32 * 32];
+    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records and coefficients, fetched once: the block loop touches no global memory
+    __shared__ uint32_t s_coefs[kIntraMaxCoefs];
+    __shared__ __align__(16) int8_t tm[32 * 32];
+    __shared__ int ext_[3][2];
+    int lane = threadIdx.x, nt = kIntraThreads;
+    for (int k = lane; k < 256; k += nt) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
     uint8_t *surf = pp.surf[pp.work];
-    for (uint32_t ti = 0; ti < ctb.intra_count; ti++) {
-        const HevcIntraTb tb = pp.itbs[ctb.intra_first + ti];
+    const int cs = 1 << pp.ctb_log2, x0 = cx << pp.ctb_log2, y0 = cy << pp.ctb_log2;
+    const int n_tbs = (int)ctb.intra_count;
+    const bool tbs_in_lds = n_tbs <= kIntraMaxTbs;
+    uint32_t coef_base = 0; bool coefs_in_lds = false;
+    if (tbs_in_lds) {
+        const uint32_t *src = (const uint32_t *)(pp.itbs + ctb.intra_first); uint32_t *dstw = (uint32_t *)s_tbs;      // 20-byte records, 4-byte aligned
+        for (int k = lane; k < n_tbs * 5; k += nt) dstw[k] = src[k];
+        const HevcIntraTb first = pp.itbs[ctb.intra_first], last = pp.itbs[ctb.intra_first + n_tbs - 1];
+        coef_base = first.coef_off;
+        const uint32_t len = last.coef_off + last.coef_n - coef_base;
+        coefs_in_lds = len <= (uint32_t)kIntraMaxCoefs;
+        if (coefs_in_lds) for (uint32_t k = lane; k < len; k += nt) s_coefs[k] = pp.coefs[coef_base + k];
+    }
+    // ---- load: CTB + the row above (two CTB widths) + the column to the left ----
+    for (int k = lane; k < (cs + 1) * (2 * cs + 1); k += nt) {
+        const int r = k / (2 * cs + 1), c = k - r * (2 * cs + 1), x = x0 + c - 1, y = y0 + r - 1;
+        if ((r > 0 && c > cs) || x < 0 || y < 0 || x >= pp.w || y >= pp.h) continue;
+        ty[r * kYS + c] = surf[(size_t)y * pp.pitch + x];
+    }
+    { const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1;
+      for (int k = lane; k < (hc + 1) * (2 * hc + 1); k += nt) {
+          const int r = k / (2 * hc + 1), c = k - r * (2 * hc + 1), x = xc0 + c - 1, y = yc0 + r - 1;
+          if ((r > 0 && c > hc) || x < 0 || y < 0 || x >= (pp.w >> 1) || y >= (pp.h >> 1)) continue;
+          const uint8_t *p = surf + pp.chroma_offset + (size_t)y * pp.pitch + 2 * x;
+          tc[0][r * kCS + c] = p[0]; tc[1][r * kCS + c] = p[1];
+      } }
+    __syncthreads();
+    // ---- block loop: the three colour planes are independent, so wavefront w runs the blocks of plane w on its own (wave-synchronous:
+    //      no s_barrier, the phases of a block only cost LDS latency) ----
+    const int wave = threadIdx.x >> 6;
+    lane = threadIdx.x & 63; nt = 64;
+    if (wave < 3) {
+    int16_t (*edge)[132] = edge_[wave]; int16_t *refa = refa_[wave], *d = d_[wave], *res = res_[wave]; int *ext = ext_[wave];
+    for (int ti = 0; ti < n_tbs; ti++) {
+        const HevcIntraTb tb = tbs_in_lds ? s_tbs[ti] : pp.itbs[ctb.intra_first + ti];
+        if (tb.plane != wave) continue;
         const int log2 = tb.log2, n = 1 << log2, c = tb.plane, N = 4 * n, unit = c ? 2 : 4;
         const bool pcm = tb.mode == kHevcModePcm;
-        if (tb.coef_n) residual_block(pp.coefs + tb.coef_off, (int)tb.coef_n, log2, tb.flags, d, res, lane); else __syncthreads();
+        uint8_t *tile = c ? tc[c - 1] : ty; const int ts = c ? kCS : kYS;
+        const int lx = tb.x - (c ? x0 >> 1 : x0) + 1, ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
+        const uint32_t *cf = coefs_in_lds ? s_coefs + (tb.coef_off - coef_base) : pp.coefs + tb.coef_off;
+        const int16_t *rr = tb.coef_n ? residual_block<true>(cf, (int)tb.coef_n, log2, tb.flags, d, res, tm, ext, lane, nt) : nullptr;
         const int16_t *e = edge[0];
         if (!pcm) {
-            // ---- neighbouring samples (8.4.4.2.2) ----
-            for (int i = lane; i <= N; i += 64) {
-                int a, v = 0;
-                if (i < 2 * n) { const int row = 2 * n - 1 - i; a = (tb.avail >> (row / unit)) & 1; if (a) v = load_recon(sample_ptr(surf, pp, c, tb.x - 1, tb.y + row)); }
-                else if (i == 2 * n) { a = (tb.flags & HTB_CORNER) != 0; if (a) v = load_recon(sample_ptr(surf, pp, c, tb.x - 1, tb.y - 1)); }
-                else { const int col = i - 2 * n - 1; a = (tb.avail >> (16 + col / unit)) & 1; if (a) v = load_recon(sample_ptr(surf, pp, c, tb.x + col, tb.y - 1)); }
-                ok[i] = (uint8_t)a; edge[0][i] = (int16_t)v;
+            // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
+            //      samples, so the substitute of an unavailable entry is found with bit scans over a mask of <= 33 segments ----
+            const int U = 2 * n / unit;
+            uint64_t mask = 0;
+            for (int j = 0; j < U; j++) if ((tb.avail >> (U - 1 - j)) & 1) mask |= 1ull << j;
+            if (tb.flags & HTB_CORNER) mask |= 1ull << U;
+            mask |= (uint64_t)((tb.avail >> 16) & ((1u << U) - 1)) << (U + 1);
+            for (int i = lane; i <= N; i += nt) {
+                int v = 128;
+                if (mask) {
+                    const int sgm = i < 2 * n ? i / unit : (i == 2 * n ? U : U + 1 + (i - 2 * n - 1) / unit);
+                    int src = i;
+                    if (!((mask >> sgm) & 1)) {
+                        const uint64_t below = mask & ((1ull << sgm) - 1);
+                        if (below) { const int t = 63 - __clzll((long long)below); src = t < U ? t * unit + unit - 1 : (t == U ? 2 * n : 2 * n + 1 + (t - U - 1) * unit + unit - 1); }
+                        else { const int f = __ffsll((long long)mask) - 1; src = f < U ? f * unit : (f == U ? 2 * n : 2 * n + 1 + (f - U - 1) * unit); }
+                    }
+                    if (src < 2 * n) v = tile[(ly + 2 * n - 1 - src) * ts + lx - 1];
+                    else if (src == 2 * n) v = tile[(ly - 1) * ts + lx - 1];
+                    else v = tile[(ly - 1) * ts + lx + src - 2 * n - 1];
+                }
+                edge[0][i] = (int16_t)v;
             }
-            __syncthreads();
-            if (lane == 0) { int f = -1; for (int i = 0; i <= N; i++) if (ok[i]) { f = i; break; } s_first = f; }
-            __syncthreads();
-            const int first = s_first;
-            if (first < 0) { for (int i = lane; i <= N; i += 64) edge[0][i] = 128; }
-            else if (lane == 0) { for (int i = 0; i < first; i++) edge[0][i] = edge[0][first]; for (int i = first + 1; i <= N; i++) if (!ok[i]) edge[0][i] = edge[0][i - 1]; }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             // ---- filtering (8.4.4.2.3) ----
             if (c == 0 && tb.mode != 1 && n > 4) {
                 const int dv = iabs(tb.mode - 26), dh = iabs(tb.mode - 10), md = dv < dh ? dv : dh, thr = n == 8 ? 7 : (n == 16 ? 1 : 0);
                 if (md > thr) {
                     const bool strong = pp.strong_intra && n == 32 && iabs(edge[0][64] + edge[0][128] - 2 * edge[0][96]) < 8 && iabs(edge[0][64] + edge[0][0] - 2 * edge[0][32]) < 8;
-                    for (int i = lane; i <= N; i += 64) {
+                    for (int i = lane; i <= N; i += nt) {
                         int v;
                         if (i == 0 || i == N) v = edge[0][i];
                         else if (strong) v = i == 64 ? edge[0][64] : (i < 64 ? (i * edge[0][64] + (64 - i) * edge[0][0] + 32) >> 6 : ((128 - i) * edge[0][64] + (i - 64) * edge[0][128] + 32) >> 6);
@@ -208,7 +288,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra(const HevcPicParams *pics, in
                     e = edge[1];
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
         const int16_t *L = e + 2 * n - 1, *T = e + 2 * n + 1;      // L[-y] = left sample of row y, T[x] = top sample of column x, T[-1] = corner
         int ang = 0; bool vert = false;
@@ -217,16 +297,16 @@ __global__ __launch_bounds__(64) void k_hevc_intra(const HevcPicParams *pics, in
         if (!pcm && tb.mode >= 2) {
             ang = c_angle[tb.mode]; vert = tb.mode >= 18;
             const int inv = c_inv_angle[tb.mode], lo = ang < 0 ? (n * ang) >> 5 : 0;
-            for (int i = lo + lane; i <= 2 * n; i += 64) {
+            for (int i = lo + lane; i <= 2 * n; i += nt) {
                 int v;
                 if (i >= 0) v = vert ? T[i - 1] : L[-(i - 1)];
                 else { const int k = (i * inv + 128) >> 8; v = vert ? L[-(k - 1)] : T[k - 1]; }
                 refa[32 + i] = (int16_t)v;
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
         const int16_t *ref = refa + 32;
-        for (int k = lane; k < n * n; k += 64) {
+        for (int k = lane; k < n * n; k += nt) {
             const int y = k >> log2, x = k & (n - 1);
             int v;
             if (pcm) v = 0;
@@ -239,12 +319,29 @@ __global__ __launch_bounds__(64) void k_hevc_intra(const HevcPicParams *pics, in
                 v = fr ? ((32 - fr) * ref[b + idx + 1] + fr * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
                 if (c == 0 && n < 32 && ang == 0 && b == 0) v = clip1((vert ? T[0] : L[0]) + (((vert ? L[-a] : T[a]) - T[-1]) >> 1));
             }
-            if (tb.coef_n) v = clip1(v + res[k]);
-            *sample_ptr(surf, pp, c, tb.x + x, tb.y + y) = (uint8_t)v;
+            if (rr) v = clip1(v + rr[k]);
+            tile[(ly + y) * ts + lx + x] = (uint8_t)v;
         }
-        __threadfence();
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    }   // wave < 3
+    __syncthreads();
+    lane = threadIdx.x; nt = kIntraThreads;
+    // ---- store the CTB (its intra blocks changed; the other samples are written back unchanged) ----
+    for (int k = lane; k < cs * cs; k += nt) {
+        const int r = k >> pp.ctb_log2, c = k & (cs - 1), x = x0 + c, y = y0 + r;
+        if (x < pp.w && y < pp.h) surf[(size_t)y * pp.pitch + x] = ty[(r + 1) * kYS + c + 1];
+    }
+    { const int hc = cs >> 1, lg = pp.ctb_log2 - 1, xc0 = x0 >> 1, yc0 = y0 >> 1;
+      for (int k = lane; k < hc * hc; k += nt) {
+          const int r = k >> lg, c = k & (hc - 1), x = xc0 + c, y = yc0 + r;
+          if (x < (pp.w >> 1) && y < (pp.h >> 1)) { uint8_t *p = surf + pp.chroma_offset + (size_t)y * pp.pitch + 2 * x; p[0] = tc[0][(r + 1) * kCS + c + 1]; p[1] = tc[1][(r + 1) * kCS + c + 1]; }
+      } }
+    __threadfence();
+    __syncthreads();
+    }   // ctb.intra_count
+    if (threadIdx.x == 0) __hip_atomic_store(&prog[cy], cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }   // cx
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -362,15 +459,15 @@ static void upload_tables() {
 }
 void hevc_kernels_init() { upload_tables(); }
 
-void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBatchDims &m, hipStream_t st, hipEvent_t *marks) {
+void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBatchDims &m, int *progress, hipStream_t st, hipEvent_t *marks) {
     upload_tables();
     if (marks) hipEventRecord(marks[0], st);
     if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3(m.max_pus, n), dim3(64), 0, st, d_pics);
     if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3(m.max_tbs, n), dim3(64), 0, st, d_pics);
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
-        const int n_diag = m.max_ctb_w + 2 * (m.max_ctb_h - 1), per = m.max_ctb_w < (m.max_ctb_h * 2) ? (m.max_ctb_w + 1) / 2 + 1 : m.max_ctb_h;
-        for (int d = 0; d < n_diag; d++) hipLaunchKernelGGL(k_hevc_intra, dim3(per > m.max_ctb_h ? m.max_ctb_h : per, n), dim3(64), 0, st, d_pics, d);
+        hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kHevcProgressStride, st);
+        hipLaunchKernelGGL(k_hevc_intra, dim3(m.max_ctb_h, n), dim3(kIntraThreads), 0, st, d_pics, progress, kHevcProgressStride);
     }
     if (marks) hipEventRecord(marks[2], st);
     if (m.any_deblock) {

@@ -683,7 +683,7 @@ static int decide_tt(Enc *e, Cu *cu, int x0, int y0, int xb, int yb, int log2, i
     memset(t, 0, sizeof *t); t->x = x0; t->y = y0; t->log2 = log2; t->depth = depth; t->blk = blk; t->xb = xb; t->yb = yb;
     const HevcGenParams *p = &e->p;
     int inter_split = p->depth_inter == 0 && !cu->intra && cu->part != 0 && depth == 0;
-    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) t->split = rnd_n(&e->rng, p->mode ? 2 : 3) == 0;
+    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) t->split = rnd_n(&e->rng, p->mode ? 2 : 5) == 0;
     else t->split = log2 > p->max_tb_log2 || (cu->intra_split && depth == 0) || inter_split;
     if (t->split) {
         int h = 1 << (log2 - 1);
@@ -981,7 +981,7 @@ static void encode_cqt(Enc *e, int x0, int y0, int log2, int depth) {
         else {                                                          /* split where the source is busy */
             const uint8_t *sp = e->src.pl[0] + y0 * e->src.stride[0] + x0; int act = 0;
             for (int y = 0; y < n; y += 2) for (int x = 0; x + 2 < n; x += 2) act += ABS(sp[y * e->src.stride[0] + x] - sp[y * e->src.stride[0] + x + 2]);
-            split = act * 4 > n * n * (3 + depth) || rnd_n(r, 6) == 0;
+            split = act * 4 > n * n * (4 + 2 * depth) || rnd_n(r, 8) == 0;
         }
         int inc = (avail(e, x0, y0, x0 - 1, y0) && e->depth[I4(e, x0 - 1, y0)] > depth) + (avail(e, x0, y0, x0, y0 - 1) && e->depth[I4(e, x0, y0 - 1)] > depth);
         cab_enc(&e->cab, HG_CTX_SPLIT_CU + inc, split);
