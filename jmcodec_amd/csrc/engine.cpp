@@ -107,7 +107,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         stages |= b.h_pics[i].stages;
         if (hevc && p.has_picture) {
             const HevcPicParams &h = p.hp;
-            hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
+            hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
             hd.max_w = std::max(hd.max_w, h.w); hd.max_h = std::max(hd.max_h, h.h); hd.any_intra |= (h.stages & HPS_INTRA) != 0; hd.any_deblock |= (h.stages & HPS_DEBLOCK) != 0; hd.any_sao |= (h.stages & HPS_SAO) != 0;
         }
         if (p.has_picture) {

@@ -290,7 +290,7 @@ void Decoder::hevc_fill_engine_pic(PicTask *t, EnginePic &ep) {
     for (int i = 0; i < kMaxSurfaces; i++) hp.surf[i] = surf_[i];
     hp.ctbs = (const HevcCtb *)(js.dev + ht.off_ctbs); hp.qp8 = js.dev + ht.off_qp8; hp.bs_v = js.dev + ht.off_bsv; hp.bs_h = js.dev + ht.off_bsh;
     hp.pus = (const HevcPu *)(js.dev + ht.off_pus); hp.n_pus = ht.n_pus; hp.tbs = (const HevcTb *)(js.dev + ht.off_tbs); hp.n_tbs = ht.n_tbs;
-    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs); hp.wps = (const HevcWp *)(js.dev + ht.off_wps);
+    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs); hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)resid_;
     hp.stages = (ht.n_pus ? HPS_MC : 0) | (ht.n_tbs ? HPS_RESID : 0) | (ht.n_itbs ? HPS_INTRA : 0) | (ht.any_deblock ? HPS_DEBLOCK : 0) | (ht.any_sao ? HPS_SAO : 0);
     const long long S = (long long)surf_bytes_;
     ep.alg_bytes[0] = (ht.n_pus ? 2 * S : 0) + (long long)t->upload_bytes; ep.alg_bytes[1] = ht.n_itbs ? S : 0; ep.alg_bytes[2] = (ht.any_deblock ? 2 * S : 0) + (ht.any_sao ? 2 * S : 0);

@@ -79,6 +79,7 @@ struct HevcPicParams {
     const HevcIntraTb *itbs; int n_itbs;
     const uint32_t *coefs;
     const HevcWp *wps;
+    int16_t *resid;               // per-handle scratch: residual of the intra blocks, planar (Y w x h, Cb, Cr), written by k_hevc_iresid
 };
 
 }  // namespace jmamd

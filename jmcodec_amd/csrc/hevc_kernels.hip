@@ -14,6 +14,7 @@
 #include "hevc_jobs.h"
 #include "hevc_kernels.h"
 #include "hevc_tables.h"
+#include <cstdlib>
 
 namespace jmamd {
 
@@ -158,12 +159,32 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     }
 }
 
+// residual of the intra blocks, computed ahead of the (sequential) intra pass: it does not depend on the prediction.  Planar int16
+// scratch: Y (w x h), Cb, Cr.
+__global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
+    const HevcPicParams &pp = pics[blockIdx.y];
+    if (!(pp.stages & HPS_INTRA) || (int)blockIdx.x >= pp.n_itbs) return;
+    const HevcIntraTb tb = pp.itbs[blockIdx.x];
+    if (!tb.coef_n) return;
+    __shared__ int16_t d[32 * 32], res[32 * 32];
+    __shared__ __align__(16) int8_t tm[32 * 32];
+    __shared__ int ext[2];
+    const int lane = threadIdx.x, n = 1 << tb.log2;
+    for (int k = lane; k < 256; k += 64) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
+    const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
+    const int pw = tb.plane ? pp.w >> 1 : pp.w;
+    int16_t *dst = pp.resid + (tb.plane == 0 ? 0 : (size_t)pp.w * pp.h + (tb.plane == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
+    for (int k = lane; k < n * n; k += 64) dst[(size_t)(tb.y + (k >> tb.log2)) * pw + tb.x + (k & (n - 1))] = r[k];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 8.4.4.2: intra prediction (+ residual) of the intra blocks of one coding tree block, in decoding order
 // ------------------------------------------------------------------------------------------------------------
+__device__ int g_hevc_exp = 0;                  // experiments (timing only, wrong output): 1 no block loop, 2 no waiting on the row above, 4 no tile load / store
 constexpr int kIntraThreads = 256;
-constexpr int kYS = 132, kCS = 68;              // LDS row strides of the luma / chroma tiles
-constexpr int kIntraMaxTbs = 448, kIntraMaxCoefs = 6144;   // 64x64 CTB: <= 256 + 128 4x4 blocks (+ PCM planes); <= 64 * 64 * 1.5 coefficients
+constexpr int kYS = 160, kCS = 80;              // LDS row strides of the luma / chroma tiles
+constexpr int kYO = 16, kCO = 8;                // column of the CTB's first sample inside a tile row (the left neighbour column sits just before): keeps 16- / 8-byte accesses aligned
+constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 blocks (+ PCM planes)
 
 // The coding tree block lives in LDS while its intra blocks are reconstructed: tile row 0 / column 0 hold the samples above / left
 // of the CTB (row 0 continues over the CTB to the right: above-right neighbours), so every neighbour a block may use (8.4.4.2.2) is
@@ -183,7 +204,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     for (int cx = 0; cx < pp.ctb_w; cx++) {
     const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
     if (ctb.intra_count) {
-    if (cy > 0) {
+    const int exp_ = g_hevc_exp;
+    if (cy > 0 && !(exp_ & 2)) {
         if (threadIdx.x == 0) {
             const int need = cx + 2 < pp.ctb_w ? cx + 2 : pp.ctb_w;
             int spins = 0;
@@ -192,61 +214,64 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         __syncthreads();
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
-    __shared__ uint8_t ty[65 * kYS];            // luma tile
-    __shared__ uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
+    __shared__ __align__(16) uint8_t ty[65 * kYS];            // luma tile
+    __shared__ __align__(16) uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
     // per colour plane (= per wavefront of the block loop):
     __shared__ int16_t edge_[3][2][132];        // [0] raw, [1] filtered: 0 .. 2n-1 left column bottom-to-top, 2n corner, 2n+1 .. 4n top row left-to-right
     __shared__ int16_t refa_[3][32 * 3 + 8];    // main reference of the angular modes, index 0 at refa[32]
-    __shared__ int16_t d_[3][32 * 32], res_[3][32 * 32];
-    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records and coefficients, fetched once: the block loop touches no global memory
-    __shared__ uint32_t s_coefs[kIntraMaxCoefs];
-    __shared__ __align__(16) int8_t tm[32 * 32];
-    __shared__ int ext_[3][2];
+    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records and residual (k_hevc_iresid), fetched once: the block loop touches no global memory
     int lane = threadIdx.x, nt = kIntraThreads;
-    for (int k = lane; k < 256; k += nt) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
     uint8_t *surf = pp.surf[pp.work];
     const int cs = 1 << pp.ctb_log2, x0 = cx << pp.ctb_log2, y0 = cy << pp.ctb_log2;
     const int n_tbs = (int)ctb.intra_count;
     const bool tbs_in_lds = n_tbs <= kIntraMaxTbs;
-    uint32_t coef_base = 0; bool coefs_in_lds = false;
     if (tbs_in_lds) {
         const uint32_t *src = (const uint32_t *)(pp.itbs + ctb.intra_first); uint32_t *dstw = (uint32_t *)s_tbs;      // 20-byte records, 4-byte aligned
         for (int k = lane; k < n_tbs * 5; k += nt) dstw[k] = src[k];
-        const HevcIntraTb first = pp.itbs[ctb.intra_first], last = pp.itbs[ctb.intra_first + n_tbs - 1];
-        coef_base = first.coef_off;
-        const uint32_t len = last.coef_off + last.coef_n - coef_base;
-        coefs_in_lds = len <= (uint32_t)kIntraMaxCoefs;
-        if (coefs_in_lds) for (uint32_t k = lane; k < len; k += nt) s_coefs[k] = pp.coefs[coef_base + k];
     }
-    // ---- load: CTB + the row above (two CTB widths) + the column to the left ----
-    for (int k = lane; k < (cs + 1) * (2 * cs + 1); k += nt) {
-        const int r = k / (2 * cs + 1), c = k - r * (2 * cs + 1), x = x0 + c - 1, y = y0 + r - 1;
-        if ((r > 0 && c > cs) || x < 0 || y < 0 || x >= pp.w || y >= pp.h) continue;
-        ty[r * kYS + c] = surf[(size_t)y * pp.pitch + x];
+    // ---- load: CTB body with 16-byte accesses, the row above (two CTB widths), the column to the left ----
+    if (!(exp_ & 4)) {
+        const int q = cs >> 4;                                          // 16-byte groups per CTB row
+        for (int k = lane; k < cs * q; k += nt) {                       // 64x64: one group per thread
+            const int r = k / q, g = k - r * q, y = y0 + r;
+            if (y < pp.h && x0 + 16 * g < pp.w) *(uint4 *)&ty[(r + 1) * kYS + kYO + 16 * g] = *(const uint4 *)(surf + (size_t)y * pp.pitch + x0 + 16 * g);
+        }
+        if (y0 > 0) for (int k = lane; k < 2 * q; k += nt) if (x0 + 16 * k < pp.w) *(uint4 *)&ty[kYO + 16 * k] = *(const uint4 *)(surf + (size_t)(y0 - 1) * pp.pitch + x0 + 16 * k);
+        if (x0 > 0) for (int k = lane; k <= cs; k += nt) { const int y = y0 + k - 1; if (y >= 0 && y < pp.h) ty[k * kYS + kYO - 1] = surf[(size_t)y * pp.pitch + x0 - 1]; }
+        const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1, qc = cs >> 4;      // a 16-byte group holds 8 Cb/Cr pairs
+        const uint8_t *cpl = surf + pp.chroma_offset;
+        for (int k = lane; k < (hc + 1) * 2 * qc; k += nt) {            // rows -1 .. hc-1; row -1 spans two CTB widths
+            const int r = k / (2 * qc), g = k - r * 2 * qc, y = yc0 + r - 1, x = xc0 + 8 * g;
+            if ((r > 0 && g >= qc) || y < 0 || y >= ph || x >= pw) continue;
+            const uint4 v = *(const uint4 *)(cpl + (size_t)y * pp.pitch + 2 * x);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            uint32_t cb[2], cr[2];
+            for (int h2 = 0; h2 < 2; h2++) { const uint32_t a = w4[2 * h2], b = w4[2 * h2 + 1];
+                cb[h2] = (a & 255) | ((a >> 16 & 255) << 8) | ((b & 255) << 16) | ((b >> 16 & 255) << 24);
+                cr[h2] = (a >> 8 & 255) | ((a >> 24) << 8) | ((b >> 8 & 255) << 16) | ((b >> 24) << 24); }
+            *(uint2 *)&tc[0][r * kCS + kCO + 8 * g] = make_uint2(cb[0], cb[1]); *(uint2 *)&tc[1][r * kCS + kCO + 8 * g] = make_uint2(cr[0], cr[1]);
+        }
+        if (x0 > 0) for (int k = lane; k <= hc; k += nt) { const int y = yc0 + k - 1; if (y >= 0 && y < ph) { const uint8_t *p = cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1); tc[0][k * kCS + kCO - 1] = p[0]; tc[1][k * kCS + kCO - 1] = p[1]; } }
     }
-    { const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1;
-      for (int k = lane; k < (hc + 1) * (2 * hc + 1); k += nt) {
-          const int r = k / (2 * hc + 1), c = k - r * (2 * hc + 1), x = xc0 + c - 1, y = yc0 + r - 1;
-          if ((r > 0 && c > hc) || x < 0 || y < 0 || x >= (pp.w >> 1) || y >= (pp.h >> 1)) continue;
-          const uint8_t *p = surf + pp.chroma_offset + (size_t)y * pp.pitch + 2 * x;
-          tc[0][r * kCS + c] = p[0]; tc[1][r * kCS + c] = p[1];
-      } }
     __syncthreads();
     // ---- block loop: the three colour planes are independent, so wavefront w runs the blocks of plane w on its own (wave-synchronous:
     //      no s_barrier, the phases of a block only cost LDS latency) ----
     const int wave = threadIdx.x >> 6;
     lane = threadIdx.x & 63; nt = 64;
-    if (wave < 3) {
-    int16_t (*edge)[132] = edge_[wave]; int16_t *refa = refa_[wave], *d = d_[wave], *res = res_[wave]; int *ext = ext_[wave];
+    if (wave < 3 && !(exp_ & 1)) {
+    int16_t (*edge)[132] = edge_[wave]; int16_t *refa = refa_[wave];
+    const int rpw = wave ? pp.w >> 1 : pp.w;
+    const int16_t *rplane = pp.resid + (wave == 0 ? 0 : (size_t)pp.w * pp.h + (wave == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
     for (int ti = 0; ti < n_tbs; ti++) {
         const HevcIntraTb tb = tbs_in_lds ? s_tbs[ti] : pp.itbs[ctb.intra_first + ti];
         if (tb.plane != wave) continue;
         const int log2 = tb.log2, n = 1 << log2, c = tb.plane, N = 4 * n, unit = c ? 2 : 4;
         const bool pcm = tb.mode == kHevcModePcm;
         uint8_t *tile = c ? tc[c - 1] : ty; const int ts = c ? kCS : kYS;
-        const int lx = tb.x - (c ? x0 >> 1 : x0) + 1, ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
-        const uint32_t *cf = coefs_in_lds ? s_coefs + (tb.coef_off - coef_base) : pp.coefs + tb.coef_off;
-        const int16_t *rr = tb.coef_n ? residual_block<true>(cf, (int)tb.coef_n, log2, tb.flags, d, res, tm, ext, lane, nt) : nullptr;
+        const int lx = tb.x - (c ? x0 >> 1 : x0) + (c ? kCO : kYO), ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
+        // the block's residual (k_hevc_iresid) is fetched now and used at the end: its latency hides behind the prediction
+        int rv[16];
+        if (tb.coef_n) for (int i = 0; i < 16; i++) { const int k = lane + 64 * i; if (k < n * n) rv[i] = rplane[(size_t)(tb.y + (k >> log2)) * rpw + tb.x + (k & (n - 1))]; }
         const int16_t *e = edge[0];
         if (!pcm) {
             // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
@@ -306,7 +331,9 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             __builtin_amdgcn_wave_barrier();
         }
         const int16_t *ref = refa + 32;
-        for (int k = lane; k < n * n; k += nt) {
+        for (int i = 0; i < 16; i++) {
+            const int k = lane + 64 * i;
+            if (k >= n * n) break;
             const int y = k >> log2, x = k & (n - 1);
             int v;
             if (pcm) v = 0;
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                 v = fr ? ((32 - fr) * ref[b + idx + 1] + fr * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
                 if (c == 0 && n < 32 && ang == 0 && b == 0) v = clip1((vert ? T[0] : L[0]) + (((vert ? L[-a] : T[a]) - T[-1]) >> 1));
             }
-            if (rr) v = clip1(v + rr[k]);
+            if (tb.coef_n) v = clip1(v + rv[i]);
             tile[(ly + y) * ts + lx + x] = (uint8_t)v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -328,15 +355,27 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     __syncthreads();
     lane = threadIdx.x; nt = kIntraThreads;
     // ---- store the CTB (its intra blocks changed; the other samples are written back unchanged) ----
-    for (int k = lane; k < cs * cs; k += nt) {
-        const int r = k >> pp.ctb_log2, c = k & (cs - 1), x = x0 + c, y = y0 + r;
-        if (x < pp.w && y < pp.h) surf[(size_t)y * pp.pitch + x] = ty[(r + 1) * kYS + c + 1];
+    if (!(exp_ & 4)) {
+        const int q = cs >> 4;
+        for (int k = lane; k < cs * q; k += nt) {
+            const int r = k / q, g = k - r * q, y = y0 + r;
+            if (y < pp.h && x0 + 16 * g < pp.w) *(uint4 *)(surf + (size_t)y * pp.pitch + x0 + 16 * g) = *(const uint4 *)&ty[(r + 1) * kYS + kYO + 16 * g];
+        }
+        const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1, qc = cs >> 4;
+        uint8_t *cpl = surf + pp.chroma_offset;
+        for (int k = lane; k < hc * qc; k += nt) {
+            const int r = k / qc, g = k - r * qc, y = yc0 + r, x = xc0 + 8 * g;
+            if (y >= ph || x >= pw) continue;
+            const uint2 cb = *(const uint2 *)&tc[0][(r + 1) * kCS + kCO + 8 * g], cr = *(const uint2 *)&tc[1][(r + 1) * kCS + kCO + 8 * g];
+            const uint32_t bw[2] = {cb.x, cb.y}, rw[2] = {cr.x, cr.y};
+            uint32_t o[4];
+            for (int h2 = 0; h2 < 2; h2++) {
+                o[2 * h2] = (bw[h2] & 255) | ((rw[h2] & 255) << 8) | ((bw[h2] >> 8 & 255) << 16) | ((rw[h2] >> 8 & 255) << 24);
+                o[2 * h2 + 1] = (bw[h2] >> 16 & 255) | ((rw[h2] >> 16 & 255) << 8) | ((bw[h2] >> 24) << 16) | ((rw[h2] >> 24) << 24);
+            }
+            *(uint4 *)(cpl + (size_t)y * pp.pitch + 2 * x) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
-    { const int hc = cs >> 1, lg = pp.ctb_log2 - 1, xc0 = x0 >> 1, yc0 = y0 >> 1;
-      for (int k = lane; k < hc * hc; k += nt) {
-          const int r = k >> lg, c = k & (hc - 1), x = xc0 + c, y = yc0 + r;
-          if (x < (pp.w >> 1) && y < (pp.h >> 1)) { uint8_t *p = surf + pp.chroma_offset + (size_t)y * pp.pitch + 2 * x; p[0] = tc[0][(r + 1) * kCS + c + 1]; p[1] = tc[1][(r + 1) * kCS + c + 1]; }
-      } }
     __threadfence();
     __syncthreads();
     }   // ctb.intra_count
@@ -455,6 +494,7 @@ static void upload_tables() {
     hipMemcpyToSymbol(HIP_SYMBOL(c_lf), hevc_luma_filter, sizeof c_lf); hipMemcpyToSymbol(HIP_SYMBOL(c_cf), hevc_chroma_filter, sizeof c_cf);
     hipMemcpyToSymbol(HIP_SYMBOL(c_angle), hevc_intra_angle, sizeof c_angle); hipMemcpyToSymbol(HIP_SYMBOL(c_inv_angle), hevc_inv_angle, sizeof c_inv_angle);
     hipMemcpyToSymbol(HIP_SYMBOL(c_beta), hevc_beta_tab, sizeof c_beta); hipMemcpyToSymbol(HIP_SYMBOL(c_tc), hevc_tc_tab, sizeof c_tc); hipMemcpyToSymbol(HIP_SYMBOL(c_qpc), hevc_qpc_tab, sizeof c_qpc);
+    if (getenv("JM_AMD_DEC_EXP_HEVC")) { int v = atoi(getenv("JM_AMD_DEC_EXP_HEVC")); hipMemcpyToSymbol(HIP_SYMBOL(g_hevc_exp), &v, sizeof v); }
     done[dev] = true;
 }
 void hevc_kernels_init() { upload_tables(); }
@@ -464,6 +504,7 @@ void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBat
     if (marks) hipEventRecord(marks[0], st);
     if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3(m.max_pus, n), dim3(64), 0, st, d_pics);
     if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3(m.max_tbs, n), dim3(64), 0, st, d_pics);
+    if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3(m.max_itbs, n), dim3(64), 0, st, d_pics);
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
         hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kHevcProgressStride, st);
