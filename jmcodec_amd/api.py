@@ -164,6 +164,33 @@ def annexb_to_avcc(data, length_size=4):
     return rec, packets
 
 
+def annexb_to_hvcc(data, length_size=4):
+    """(hvcC record, [length-prefixed packets]) of an HEVC Annex-B stream: the MP4 / MKV form of the same stream (one packet per access
+    unit, parameter sets only in the record)."""
+    nalus = [n.lstrip(b"\x00")[1:] for n in split_nalus(data)]
+    ps = {32: [], 33: [], 34: []}
+    for n in nalus:
+        t = (n[0] >> 1) & 63
+        if t in ps and n not in ps[t]:
+            ps[t].append(n)
+    rec = bytes([1]) + bytes(20) + bytes([0xFC | (length_size - 1), sum(1 for t in ps if ps[t])])
+    for t in (32, 33, 34):
+        if ps[t]:
+            rec += bytes([0x80 | t]) + len(ps[t]).to_bytes(2, "big") + b"".join(len(n).to_bytes(2, "big") + n for n in ps[t])
+    packets, cur = [], b""
+    for n in nalus:
+        t = (n[0] >> 1) & 63
+        if t in ps:
+            continue
+        if (t <= 9 or 16 <= t <= 21) and (n[2] & 0x80) and cur:            # first_slice_segment_in_pic_flag: a new picture starts
+            packets.append(cur)
+            cur = b""
+        cur += len(n).to_bytes(length_size, "big") + n
+    if cur:
+        packets.append(cur)
+    return rec, packets
+
+
 class JmAmdDec:
     """Convenience wrapper reproducing test_nv_dec's main loop (test_nv_dec.cpp:163-259)."""
 

@@ -141,7 +141,19 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     // optional SPS/PPS given up front (nv_dec.cpp:334-360).  FFmpeg hands test_player either Annex-B parameter sets or, for MP4 /
     // MKV sources, an AVCDecoderConfigurationRecord ("avcC", ISO/IEC 14496-15 5.2.4.1); with avcC the packets that follow are
     // length-prefixed NAL units unless a bitstream filter already converted them (test_player.cpp:221-226 uses h264_mp4toannexb).
-    if (extra && len > 0) {
+    if (extra && len > 0 && codec_ == 1 && len >= 23 && extra[0] == 1) {
+        // HEVCDecoderConfigurationRecord ("hvcC", ISO/IEC 14496-15 8.3.3.1): what a demuxer hands test_player for HEVC in MP4 / MKV
+        avcc_len_size_ = (extra[21] & 3) + 1;
+        int o = 23;
+        for (int a = 0, n_arrays = extra[22]; a < n_arrays && o + 3 <= len; a++) {
+            int n = (extra[o + 1] << 8) | extra[o + 2]; o += 3;
+            for (int i = 0; i < n && o + 2 <= len; i++) {
+                int l = (extra[o] << 8) | extra[o + 1]; o += 2;
+                if (l <= 0 || o + l > len) { o = len; break; }
+                handle_nal(extra + o, (size_t)l); o += l;
+            }
+        }
+    } else if (extra && len > 0) {
         if (len >= 7 && extra[0] == 1) {
             avcc_len_size_ = (extra[4] & 3) + 1;
             int o = 5, n_sps = extra[o++] & 31;

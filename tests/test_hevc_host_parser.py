@@ -86,3 +86,14 @@ def test_h264_and_hevc_handles_side_by_side():
         assert a.decode_stream(h264, keep=False) == 4
         assert b.decode_stream(hevc, keep=False) == HEVC_CASES["p_real"]["frames"]
         assert "H.265" in jmcodec_amd.jm_nvdec_show_dec_info(b.h) and "H.264" in jmcodec_amd.jm_nvdec_show_dec_info(a.h)
+
+
+def test_hvcc_record_and_length_prefixed_packets(oracle):
+    """SURVEY 8f f2 for HEVC: parameter sets through extra_data as an hvcC record, then one length-prefixed packet per access unit"""
+    data = streams.generate_hevc(**HEVC_CASES["b_gop2"])
+    want, ncu = oracle.syntax_digest(data)
+    from jmcodec_amd import api
+    rec, packets = api.annexb_to_hvcc(data)
+    with jmcodec_amd.JmAmdDec(1, 1, options=OPTS, extra_data=rec) as d:
+        n = d.decode_stream(None, keep=False, chunks=packets)
+        assert (d.stat("syntax_digest") & 0xFFFFFFFFFFFFFFFF, d.stat("digest_mbs"), n) == (want, ncu, HEVC_CASES["b_gop2"]["frames"])

@@ -1,6 +1,6 @@
 // tools/fuzz_host.cpp -- developer tool: feeds (corrupted) Annex-B streams through the product's host pipeline in parse-only
 // mode (no GPU work) so that it can be run under AddressSanitizer / UBSan on the CPU build:
-//   make -C tools fuzz_host_asan && tools/_build/fuzz_host_asan stream.h264 [seed] [trials]
+//   make -C tools fuzz_host_asan && tools/_build/fuzz_host_asan stream.h264 [seed] [trials] [codec_type: 0 H.264, 1 HEVC]
 #include "../include/jm_amd_dec.h"
 #include <cstdio>
 #include <cstdlib>
@@ -12,9 +12,9 @@ static std::vector<unsigned char> read_all(const char *p) {
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); v.resize(n); if (fread(v.data(), 1, n, f) != (size_t)n) v.clear(); fclose(f); return v;
 }
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s stream.h264 [seed] [trials]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s stream.h264|stream.h265 [seed] [trials] [codec_type]\n", argv[0]); return 2; }
     std::vector<unsigned char> base = read_all(argv[1]);
-    unsigned long long s = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1; int trials = argc > 3 ? atoi(argv[3]) : 100;
+    unsigned long long s = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1; int trials = argc > 3 ? atoi(argv[3]) : 100; const int codec = argc > 4 ? atoi(argv[4]) : 0;
     auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(s >> 33); };
     long frames = 0;
     for (int t = 0; t < trials; t++) {
@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
         void *h = jm_amddec_create_handle();
         jm_amddec_set_option(h, "parse_only", 1);
         if (t % 2) jm_amddec_set_option(h, "digest", 1);
-        jm_amddec_init(0, 1, nullptr, 0, h);
+        jm_amddec_init(codec, 1, nullptr, 0, h);
         size_t pos = 0; int got = 0;
         while (pos < b.size()) { size_t n = 1 + rnd() % 4096; if (n > b.size() - pos) n = b.size() - pos; jm_amddec_decode_frame(b.data() + pos, (int)n, &got, h); frames += got; pos += n; }
         for (int i = 0; i < 100000 && !jm_amddec_is_exit(h); i++) { jm_amddec_decode_frame(nullptr, 0, &got, h); frames += got; }
@@ -46,3 +46,8 @@ void launch_deblock_lds(const PicParams *, int, int, int, ihipStream_t *) { abor
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 }
 namespace jmamd { void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); } }
+#include "../jmcodec_amd/csrc/hevc_kernels.h"
+namespace jmamd {
+void launch_hevc_picture_batch(const HevcPicParams *, int, const HevcBatchDims &, int *, ihipStream_t *, ihipEvent_t **) { abort(); }
+void hevc_kernels_init() {}
+}
