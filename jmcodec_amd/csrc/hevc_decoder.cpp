@@ -35,7 +35,10 @@ void Decoder::hevc_handle_nal(const uint8_t *nal, size_t len) {
     const bool is_slice = type <= 9 || (type >= 16 && type <= 21);
     if (!is_slice && type != 33 && type != 34) {
         if (type == 32 || type == 35 || type == 39) hevc_dispatch_pending();            // VPS, AUD, prefix SEI: a new access unit starts
-        if (type == 36 || type == 37) { hevc_dispatch_pending(); h_seen_eos_ = true; }
+        if (type == 36 || type == 37) {                                              // end of sequence / bitstream: everything decoded so far is output
+            hevc_dispatch_pending(); h_seen_eos_ = true;
+            if (seq_active_) { for (int i = 0; i < n_surf_; i++) dpb_[i].ref = 0; hevc_bump(carry_out_, true, true); for (int i = 0; i < n_surf_; i++) if (!dpb_[i].wait_output) dpb_[i].in_use = false; }
+        }
         return;
     }
     std::vector<uint8_t> rbsp(len + Rbsp::kSlack);

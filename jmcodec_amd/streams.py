@@ -152,7 +152,7 @@ class Oracle:
 HEVC_FIELDS = ("width", "height", "frames", "qp", "seed", "intra_period", "gop", "num_ref", "ctb_log2", "min_cb_log2", "max_tb_log2", "min_tb_log2",
                "depth_inter", "depth_intra", "mode", "amp", "sao", "deblock", "tskip", "sdh", "dqp", "pcm", "bypass", "cip", "strong_intra", "tmvp", "wp",
                "rplm", "lt_ref", "scaling", "wpp", "tile_cols", "tile_rows", "slice_ctus", "dep_slices", "merge_cand", "cabac_init", "par_mrg", "rps_sps",
-               "cb_qp_off", "cr_qp_off", "search")
+               "cb_qp_off", "cr_qp_off", "search", "open_gop")
 
 
 class HevcGenParams(C.Structure):

@@ -302,7 +302,9 @@ int orch_decode_nal(OrchDec *d, const uint8_t *nal, size_t len) {
     int rc = 0;
     if (type == 33) { finish_picture(d); rc = orch_parse_sps(d, &b); }
     else if (type == 34) { finish_picture(d); rc = orch_parse_pps(d, &b); }
-    else if (type == 36 || type == 37) { finish_picture(d); d->seen_eos = 1; }
+    else if (type == 36 || type == 37) {                               /* end of sequence / bitstream: everything decoded so far is output (as at the end of the stream) */
+        finish_picture(d); while (bump(d)) {} for (int i = 0; i < H_MAX_DPB; i++) d->dpb[i].is_ref = 0; release_unused(d); d->seen_eos = 1;
+    }
     else if (type == 35 || type == 32 || type == 39) { finish_picture(d); }
     else if (type <= 9 || (type >= 16 && type <= 21)) {
         static HSlice sh;

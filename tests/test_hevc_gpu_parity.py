@@ -132,3 +132,13 @@ def test_hevc_through_the_intel_push_pull_api_and_hvcc(oracle):
     with jmcodec_amd.JmAmdDec(1, 1, options={"device": 0}, extra_data=rec) as d:
         frames = d.decode_stream(None, chunks=packets)
     assert b"".join(frames) == want
+
+
+def test_cra_start_and_end_of_sequence_on_gpu(oracle):
+    from test_hevc_oracle import cut_at_second_irap
+    data = streams.generate_hevc(**HEVC_CASES["open_gop"])
+    head, tail = cut_at_second_irap(data)
+    for s in (tail, head + b"\x00\x00\x01\x48\x01" + tail):
+        want, n, _, _ = oracle.decode(s, 1)
+        frames, errors = gpu_decode(s)
+        assert errors == 0 and len(frames) == n and b"".join(frames) == want

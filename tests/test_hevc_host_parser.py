@@ -97,3 +97,14 @@ def test_hvcc_record_and_length_prefixed_packets(oracle):
     with jmcodec_amd.JmAmdDec(1, 1, options=OPTS, extra_data=rec) as d:
         n = d.decode_stream(None, keep=False, chunks=packets)
         assert (d.stat("syntax_digest") & 0xFFFFFFFFFFFFFFFF, d.stat("digest_mbs"), n) == (want, ncu, HEVC_CASES["b_gop2"]["frames"])
+
+
+def test_start_at_cra_and_end_of_sequence(oracle):
+    """the product drops the RASL pictures of a CRA that starts decoding (or follows an end-of-sequence NAL) exactly like the oracle"""
+    from test_hevc_oracle import cut_at_second_irap
+    data = streams.generate_hevc(**HEVC_CASES["open_gop"])
+    head, tail = cut_at_second_irap(data)
+    for s in (tail, head + b"\x00\x00\x01\x48\x01" + tail):
+        want, ncu = oracle.syntax_digest(s)
+        got, cus, n, errors, _ = product_digest(s)
+        assert errors == 0 and (got, cus) == (want, ncu) and n == oracle.decode(s, 1)[1]

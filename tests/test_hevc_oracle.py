@@ -44,6 +44,9 @@ HEVC_CASES = {
     "slices_wpp_dep": dict(width=128, height=96, frames=3, slice_ctus=8, dep_slices=1, wpp=1, ctb_log2=4, mode=1, seed=25),
     "cabac_init": dict(width=96, height=80, frames=5, gop=1, cabac_init=2, mode=1, seed=26),
     "par_merge": dict(width=96, height=80, frames=4, par_mrg=4, mode=1, seed=27),
+    "rps_sps_gop8": dict(width=96, height=80, frames=17, gop=8, num_ref=2, rps_sps=1, mode=1, seed=29),
+    "rps_sps_p": dict(width=96, height=80, frames=9, num_ref=3, rps_sps=1, mode=1, seed=30),
+    "open_gop": dict(width=96, height=80, frames=20, gop=2, num_ref=2, open_gop=1, intra_period=6, rps_sps=1, seed=31),
     "small_tb": dict(width=96, height=80, frames=3, max_tb_log2=3, depth_inter=1, depth_intra=0, mode=1, seed=28),
 }
 
@@ -163,3 +166,44 @@ def test_cabac_tables_shape_and_identity_between_copies():
         assert c_array(path, prefix + "trans") == c_array(TABLES, "orch_trans")
     h264 = os.path.join(ROOT, "oracle", "orc_cabac_tables.h")
     assert c_array(TABLES, "orch_range_lps") == c_array(h264, "orc_cabac_range_lps") and c_array(TABLES, "orch_trans_lps") == c_array(h264, "orc_cabac_trans_lps")
+
+
+def nal_types(data):
+    import jmcodec_amd
+    return [(n.lstrip(b"\x00")[1] >> 1) & 63 for n in jmcodec_amd.split_nalus(data)]
+
+
+def cut_at_second_irap(data):
+    """the stream from its second IRAP picture on (with the parameter sets the generator repeats there)"""
+    import jmcodec_amd
+    nalus = jmcodec_amd.split_nalus(data)
+    types = [(n.lstrip(b"\x00")[1] >> 1) & 63 for n in nalus]
+    iraps = [i for i, t in enumerate(types) if 16 <= t <= 21]
+    k = iraps[1]
+    while types[k - 1] in (32, 33, 34):
+        k -= 1
+    return b"".join(nalus[:k]), b"".join(nalus[k:])
+
+
+def test_open_gop_stream_has_cra_and_rasl_pictures(oracle):
+    data = streams.generate_hevc(**HEVC_CASES["open_gop"])
+    t = nal_types(data)
+    assert t.count(21) >= 2 and t.count(8) >= 4 and t.count(19) == 1
+
+
+def test_decoding_from_a_cra_drops_its_rasl_pictures(oracle):
+    """8.1.3: NoRaslOutputFlag = 1 for a CRA picture that starts the bitstream; its RASL pictures are not output."""
+    kw = HEVC_CASES["open_gop"]
+    data = streams.generate_hevc(**kw)
+    full, n_full, w, h = oracle.decode(data, 1)
+    head, tail = cut_at_second_irap(data)
+    out, n, _, _ = oracle.decode(tail, 1)
+    fs = w * h * 3 // 2
+    # pictures of the tail in display order: the CRA is frame 6; frames 4, 5 (its RASL pictures) are gone, everything from 6 on stays identical
+    assert n == kw["frames"] - 6
+    assert out == full[6 * fs:]
+    # end of sequence NAL in front of the CRA: same effect inside one stream (POC MSB restarts, RASL pictures dropped)
+    eos = b"\x00\x00\x01\x48\x01"
+    out2, n2, _, _ = oracle.decode(head + eos + tail, 1)
+    n_head = oracle.decode(head, 1)[1]
+    assert n2 == n_head + n and out2[n_head * fs:] == out

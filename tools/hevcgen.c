@@ -50,6 +50,7 @@ typedef struct {
     int rps_sps;                /* 1: reference picture sets live in the SPS (inter RPS prediction where expressible) */
     int cb_qp_off, cr_qp_off;
     int search;                 /* integer search range (mode 0)                                            */
+    int open_gop;               /* 1: intra periods after the first start with a CRA picture whose leading B pictures are RASL (gop 1..3, period a multiple of gop + 1); parameter sets are repeated there */
 } HevcGenParams;
 
 /* ------------------------------ RNG ------------------------------ */
@@ -157,6 +158,7 @@ typedef struct {
     Mot *col; int *col_poc; uint8_t *col_lt, *col_intra;          /* 16x16 compressed motion of the picture (temporal candidates) */
 } Pic;
 
+typedef struct { int n_neg, n_pos, dneg[16], uneg[16], dpos[16], upos[16]; } RpsSet;
 typedef struct { int type[3], band[3], eo[3], off[3][4]; } Sao;
 typedef struct {                                                    /* one slice (independent segment): what later derivations need */
     int addr, type, qp, deblock_off, beta, tc, lf_across, n_ref[2];
@@ -187,6 +189,7 @@ typedef struct Enc {
     int decode_count;
     uint8_t *dbk[3];
     int lf_across_tiles;
+    RpsSet sps_sets[64]; int n_sps_sets;                               /* short-term reference picture sets carried by the SPS (rps_sps) */
     uint8_t sl4[6][16], sl8[6][64], sl16[6][64], sl32[6][64], dc16[6], dc32[6];   /* coded scaling lists (diagonal order) */
 } Enc;
 #define I4(e, x, y) (((y) >> 2) * (e)->w4 + ((x) >> 2))
@@ -1187,21 +1190,33 @@ static void write_scaling_list_data(Enc *e, BitW *w) {
 }
 
 /* ------------------------------ coded video sequence plan ------------------------------ */
-typedef struct { int t, poc, type /* 0 B 1 P 2 I */, is_ref, idr, n[2], l[2][4], lt; } Sched;
+typedef struct { int t, poc, type /* 0 B 1 P 2 I */, is_ref, idr, n[2], l[2][4], lt, cra, rasl; } Sched;
 
 static void plan_sequence(const HevcGenParams *p, Sched *sc, int *count) {
-    int n = 0;
+    int n = 0, last_idr_t = 0, carry_prev = -1;
     for (int t0 = 0; t0 < p->frames; t0 += p->intra_period) {
         int end = MIN(p->frames, t0 + p->intra_period);
-        Sched *s = &sc[n++]; memset(s, 0, sizeof *s); s->t = t0; s->type = 2; s->is_ref = 1; s->idr = 1;
-        int g = p->gop == 8 ? 8 : p->gop + 1, last_anchor = t0;
+        int g = p->gop == 8 ? 8 : p->gop + 1;
+        int open = p->open_gop && t0 > 0 && p->gop >= 1 && p->gop <= 3 && carry_prev >= 0;
+        Sched *s = &sc[n++]; memset(s, 0, sizeof *s); s->t = t0; s->type = 2; s->is_ref = 1; s->idr = !open; s->cra = open;
+        if (!open) last_idr_t = t0;
+        if (open) for (int t = carry_prev + 1; t < t0; t++) {          /* leading pictures: displayed before the CRA, decoded after it */
+            Sched *b = &sc[n++]; memset(b, 0, sizeof *b); b->t = t; b->type = 0; b->is_ref = 0; b->rasl = 1;
+            b->l[0][b->n[0]++] = carry_prev; if (p->num_ref > 1) b->l[0][b->n[0]++] = t0;
+            b->l[1][b->n[1]++] = t0; if (p->num_ref > 1) b->l[1][b->n[1]++] = carry_prev;
+        }
+        carry_prev = -1;
+        int last_anchor = t0;
         int anchors[4] = { t0, -1, -1, -1 };
         for (int a = t0 + g; ; a += g) {
-            if (a >= end) {                                             /* tail: plain P pictures in display order */
-                for (int t = last_anchor + 1; t < end; t++) {
+            if (a >= end) {
+                /* the next period opens with a CRA at `end`: the pictures between the last anchor and it wait for that CRA */
+                if (p->open_gop && p->gop >= 1 && p->gop <= 3 && end < p->frames && end - last_anchor == g) { carry_prev = last_anchor; break; }
+                for (int t = last_anchor + 1; t < end; t++) {           /* tail: plain P pictures in display order */
                     s = &sc[n++]; memset(s, 0, sizeof *s); s->t = t; s->type = 1; s->is_ref = 1;
-                    for (int k = 0; k < p->num_ref && s->n[0] < 4; k++) { int rt = k == 0 ? t - 1 : anchors[k]; if (k == 0 || (rt >= t0 && rt != t - 1 && rt < t - 1)) { if (rt >= t0) s->l[0][s->n[0]++] = rt; } }
-                    for (int k = 3; k > 0; k--) anchors[k] = anchors[k - 1]; anchors[0] = t;
+                    for (int k = 0; k < p->num_ref && k < 4; k++) if (anchors[k] >= 0) s->l[0][s->n[0]++] = anchors[k];
+                    for (int k = 3; k > 0; k--) anchors[k] = anchors[k - 1];
+                    anchors[0] = t;
                 }
                 break;
             }
@@ -1209,7 +1224,8 @@ static void plan_sequence(const HevcGenParams *p, Sched *sc, int *count) {
             for (int k = 0; k < p->num_ref && k < 4; k++) if (anchors[k] >= 0) s->l[0][s->n[0]++] = anchors[k];
             if (p->lt_ref && p->gop == 0 && a >= t0 + 3 && s->n[0] < 4) { int dup = 0; for (int k = 0; k < s->n[0]; k++) dup |= s->l[0][k] == t0; if (!dup) { s->l[0][s->n[0]++] = t0; s->lt = 1; } }
             int prev = anchors[0];
-            for (int k = 3; k > 0; k--) anchors[k] = anchors[k - 1]; anchors[0] = a;
+            for (int k = 3; k > 0; k--) anchors[k] = anchors[k - 1];
+            anchors[0] = a;
             last_anchor = a;
             if (p->gop >= 1 && p->gop <= 3) for (int t = prev + 1; t < a; t++) {
                 s = &sc[n++]; memset(s, 0, sizeof *s); s->t = t; s->type = 0; s->is_ref = 0;
@@ -1224,9 +1240,71 @@ static void plan_sequence(const HevcGenParams *p, Sched *sc, int *count) {
                 }
             }
         }
-        for (int i = 0; i < n; i++) if (sc[i].t >= t0 && sc[i].t < end) sc[i].poc = sc[i].t - t0;
+        (void)last_idr_t;
     }
+    /* POC: display distance from the last IDR picture (decoding order: an IDR precedes everything of its period) */
+    for (int i = 0, idr_t = 0; i < n; i++) { if (sc[i].idr) idr_t = sc[i].t; sc[i].poc = sc[i].t - idr_t; }
     *count = n;
+}
+
+/* short-term RPS of picture idx: every earlier reference picture (since the last IDR) that this or a later picture still lists */
+static void plan_rps(const Sched *sched, int n_sched, int idx, RpsSet *o) {
+    memset(o, 0, sizeof *o);
+    const Sched *sc = &sched[idx];
+    int period0 = idx; while (!sched[period0].idr) period0--;
+    for (int pass = 0; pass < 2; pass++) for (int dist = 1; dist < 64; dist++) for (int j = period0; j < idx; j++) {
+        if (!sched[j].is_ref || (sc->lt && sched[j].idr)) continue;
+        int d = sched[j].poc - sc->poc;
+        if ((pass == 0 ? -d : d) != dist) continue;
+        int needed = 0, used = 0;
+        for (int k = idx; k < n_sched && !sched[k].idr; k++) for (int l = 0; l < 2; l++) for (int i = 0; i < sched[k].n[l]; i++) if (sched[k].l[l][i] == sched[j].t) { needed = 1; if (k == idx) used = 1; }
+        if (!needed) continue;
+        if (pass == 0) { o->dneg[o->n_neg] = d; o->uneg[o->n_neg++] = used; } else { o->dpos[o->n_pos] = d; o->upos[o->n_pos++] = used; }
+    }
+}
+static int rps_equal(const RpsSet *a, const RpsSet *b) {
+    if (a->n_neg != b->n_neg || a->n_pos != b->n_pos) return 0;
+    for (int i = 0; i < a->n_neg; i++) if (a->dneg[i] != b->dneg[i] || a->uneg[i] != b->uneg[i]) return 0;
+    for (int i = 0; i < a->n_pos; i++) if (a->dpos[i] != b->dpos[i] || a->upos[i] != b->upos[i]) return 0;
+    return 1;
+}
+static void rps_write_explicit(BitW *w, const RpsSet *t) {
+    bw_ue(w, (uint32_t)t->n_neg); bw_ue(w, (uint32_t)t->n_pos);
+    for (int i = 0, prev = 0; i < t->n_neg; i++) { bw_ue(w, (uint32_t)(prev - t->dneg[i] - 1)); bw_put(w, 1, (uint32_t)t->uneg[i]); prev = t->dneg[i]; }
+    for (int i = 0, prev = 0; i < t->n_pos; i++) { bw_ue(w, (uint32_t)(t->dpos[i] - prev - 1)); bw_put(w, 1, (uint32_t)t->upos[i]); prev = t->dpos[i]; }
+}
+/* inter RPS prediction (7.3.7 / 7.4.8) of set t from set r: returns 1 and writes delta_rps + flags when t can be expressed that way */
+static int rps_write_inter(BitW *w, const RpsSet *t, const RpsSet *r) {
+    int nr = r->n_neg + r->n_pos, rd[33];
+    for (int j = 0; j < r->n_neg; j++) rd[j] = r->dneg[j];
+    for (int j = 0; j < r->n_pos; j++) rd[r->n_neg + j] = r->dpos[j];
+    rd[nr] = 0;
+    int nt = t->n_neg + t->n_pos, td[32], tu[32];
+    for (int j = 0; j < t->n_neg; j++) { td[j] = t->dneg[j]; tu[j] = t->uneg[j]; }
+    for (int j = 0; j < t->n_pos; j++) { td[t->n_neg + j] = t->dpos[j]; tu[t->n_neg + j] = t->upos[j]; }
+    for (int a = 0; a < nt; a++) for (int b = 0; b <= nr; b++) {
+        int d = td[a] - rd[b];
+        if (d == 0 || d < -32768 || d > 32767) continue;
+        int used[33], keep[33], hit = 0;
+        for (int j = 0; j <= nr; j++) { used[j] = keep[j] = 0; for (int k = 0; k < nt; k++) if (td[k] == rd[j] + d) { keep[j] = 1; used[j] = tu[k]; hit++; } }
+        if (hit != nt) continue;
+        /* derive exactly as a decoder would (the order of the result matters) and compare */
+        RpsSet o; memset(&o, 0, sizeof o);
+        int i = 0;
+        for (int j = r->n_pos - 1; j >= 0; j--) { int dp = r->dpos[j] + d; if (dp < 0 && keep[r->n_neg + j]) { o.dneg[i] = dp; o.uneg[i++] = used[r->n_neg + j]; } }
+        if (d < 0 && keep[nr]) { o.dneg[i] = d; o.uneg[i++] = used[nr]; }
+        for (int j = 0; j < r->n_neg; j++) { int dp = r->dneg[j] + d; if (dp < 0 && keep[j]) { o.dneg[i] = dp; o.uneg[i++] = used[j]; } }
+        o.n_neg = i; i = 0;
+        for (int j = r->n_neg - 1; j >= 0; j--) { int dp = r->dneg[j] + d; if (dp > 0 && keep[j]) { o.dpos[i] = dp; o.upos[i++] = used[j]; } }
+        if (d > 0 && keep[nr]) { o.dpos[i] = d; o.upos[i++] = used[nr]; }
+        for (int j = 0; j < r->n_pos; j++) { int dp = r->dpos[j] + d; if (dp > 0 && keep[r->n_neg + j]) { o.dpos[i] = dp; o.upos[i++] = used[r->n_neg + j]; } }
+        o.n_pos = i;
+        if (!rps_equal(&o, t)) continue;
+        bw_put(w, 1, d < 0); bw_ue(w, (uint32_t)(ABS(d) - 1));
+        for (int j = 0; j <= nr; j++) { bw_put(w, 1, (uint32_t)(keep[j] && used[j])); if (!(keep[j] && used[j])) bw_put(w, 1, (uint32_t)keep[j]); }
+        return 1;
+    }
+    return 0;
 }
 
 /* ------------------------------ parameter sets (7.3.2) ------------------------------ */
@@ -1246,6 +1324,8 @@ static void write_vps(Enc *e, BitW *out, int max_dpb, int reorder) {
     bw_trailing(&w);
     write_nal(out, 32, 0, w.buf, w.len, NULL, 0); free(w.buf);
 }
+static void rps_write_explicit(BitW *w, const RpsSet *t);
+static int rps_write_inter(BitW *w, const RpsSet *t, const RpsSet *r);
 static void write_sps(Enc *e, BitW *out, int max_dpb, int reorder) {
     const HevcGenParams *p = &e->p; BitW w; memset(&w, 0, sizeof w);
     bw_put(&w, 4, 0); bw_put(&w, 3, 0); bw_put(&w, 1, 1);
@@ -1265,7 +1345,15 @@ static void write_sps(Enc *e, BitW *out, int max_dpb, int reorder) {
     if (p->scaling) { bw_put(&w, 1, p->scaling == 2); if (p->scaling == 2) write_scaling_list_data(e, &w); }
     bw_put(&w, 1, (uint32_t)p->amp); bw_put(&w, 1, (uint32_t)p->sao); bw_put(&w, 1, p->pcm != 0);
     if (p->pcm) { bw_put(&w, 4, 6); bw_put(&w, 4, 5); bw_ue(&w, (uint32_t)(p->min_cb_log2 - 3)); bw_ue(&w, (uint32_t)(MIN(5, p->ctb_log2) - p->min_cb_log2)); bw_put(&w, 1, p->pcm == 1); }
-    bw_ue(&w, 0);                                                      /* num_short_term_ref_pic_sets: sets are sent in the slice headers */
+    bw_ue(&w, (uint32_t)e->n_sps_sets);                                /* short-term reference picture sets (none: every slice header carries its own) */
+    for (int i = 0; i < e->n_sps_sets; i++) {
+        if (i == 0) { rps_write_explicit(&w, &e->sps_sets[0]); continue; }
+        BitW t; memset(&t, 0, sizeof t);                                /* try inter prediction from the previous set (7.3.7) */
+        size_t len0 = w.len; int nb0 = w.nbits; uint32_t cur0 = w.cur;
+        bw_put(&w, 1, 1);
+        if (!rps_write_inter(&w, &e->sps_sets[i], &e->sps_sets[i - 1])) { w.len = len0; w.nbits = nb0; w.cur = cur0; bw_put(&w, 1, 0); rps_write_explicit(&w, &e->sps_sets[i]); }
+        (void)t;
+    }
     bw_put(&w, 1, (uint32_t)p->lt_ref);
     if (p->lt_ref) bw_ue(&w, 0);
     bw_put(&w, 1, (uint32_t)p->tmvp); bw_put(&w, 1, (uint32_t)p->strong_intra);
@@ -1322,10 +1410,32 @@ static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int f
         bw_ue(w, (uint32_t)s->type);
         if (!pp->idr) {
             bw_put(w, e->poc_bits, (uint32_t)(pp->poc & ((1 << e->poc_bits) - 1)));
-            bw_put(w, 1, 0);                                            /* short_term_ref_pic_set_sps_flag = 0: explicit set (idx == num sets == 0, so no inter prediction flag) */
-            bw_ue(w, (uint32_t)pp->n_neg); bw_ue(w, (uint32_t)pp->n_pos);
-            for (int i = 0, prev = 0; i < pp->n_neg; i++) { bw_ue(w, (uint32_t)(prev - pp->dneg[i] - 1)); bw_put(w, 1, (uint32_t)pp->uneg[i]); prev = pp->dneg[i]; }
-            for (int i = 0, prev = 0; i < pp->n_pos; i++) { bw_ue(w, (uint32_t)(pp->dpos[i] - prev - 1)); bw_put(w, 1, (uint32_t)pp->upos[i]); prev = pp->dpos[i]; }
+            {
+                RpsSet t; memset(&t, 0, sizeof t);
+                t.n_neg = pp->n_neg; t.n_pos = pp->n_pos;
+                for (int i = 0; i < t.n_neg; i++) { t.dneg[i] = pp->dneg[i]; t.uneg[i] = pp->uneg[i]; }
+                for (int i = 0; i < t.n_pos; i++) { t.dpos[i] = pp->dpos[i]; t.upos[i] = pp->upos[i]; }
+                int match = -1;
+                for (int i = 0; i < e->n_sps_sets; i++) if (rps_equal(&e->sps_sets[i], &t)) match = i;
+                if (match >= 0 && rnd_n(&e->rng, 4) != 0) {             /* a set of the SPS, by index */
+                    bw_put(w, 1, 1);
+                    if (e->n_sps_sets > 1) bw_put(w, ceil_log2(e->n_sps_sets), (uint32_t)match);
+                } else {
+                    bw_put(w, 1, 0);                                    /* st_ref_pic_set(num_short_term_ref_pic_sets) in the slice header */
+                    int done = 0;
+                    if (e->n_sps_sets > 0) {                            /* its index is not 0, so the inter prediction flag is present */
+                        int start = rnd_n(&e->rng, e->n_sps_sets);
+                        for (int k = 0; k < e->n_sps_sets && !done; k++) {
+                            int ref = (start + k) % e->n_sps_sets;
+                            size_t len0 = w->len; int nb0 = w->nbits; uint32_t cur0 = w->cur;
+                            bw_put(w, 1, 1); bw_ue(w, (uint32_t)(e->n_sps_sets - 1 - ref));      /* delta_idx_minus1 */
+                            if (rps_write_inter(w, &t, &e->sps_sets[ref])) done = 1; else { w->len = len0; w->nbits = nb0; w->cur = cur0; }
+                        }
+                        if (!done) bw_put(w, 1, 0);
+                    }
+                    if (!done) rps_write_explicit(w, &t);
+                }
+            }
             if (p->lt_ref) {
                 bw_ue(w, (uint32_t)pp->nl);
                 for (int i = 0; i < pp->nl; i++) { bw_put(w, e->poc_bits, (uint32_t)pp->lt_poc_lsb[i]); bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)pp->lt_msb[i]); if (pp->lt_msb[i]) bw_ue(w, (uint32_t)pp->lt_cycle[i]); }
@@ -1440,47 +1550,28 @@ static void tables_init(Enc *e) {                                       /* 6.5.1
 static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, int idx) {
     const HevcGenParams *p = &e->p; const Sched *sc = &sched[idx]; Rng *r = &e->rng;
     PicPlan pp; memset(&pp, 0, sizeof pp);
-    pp.type = sc->type; pp.idr = sc->idr; pp.poc = sc->poc; pp.nal = sc->idr ? 19 : (sc->is_ref ? 1 : 0);
+    pp.type = sc->type; pp.idr = sc->idr; pp.poc = sc->poc; pp.nal = sc->idr ? 19 : (sc->cra ? 21 : (sc->rasl ? 8 : (sc->is_ref ? 1 : 0)));
     if (sc->idr) for (int i = 0; i < 10; i++) e->dpb[i].used = 0;
     /* reference picture set: every earlier reference picture of this period that this or a later picture still needs */
     int period0 = idx; while (!sched[period0].idr) period0--;
-    int base_t = sched[period0].t;
     if (!sc->idr) {
-        int cand[32], nc = 0;
-        for (int j = period0; j < idx; j++) if (sched[j].is_ref) {
-            int needed = 0, used = 0, lt = 0;
-            for (int k = idx; k < n_sched && !sched[k].idr; k++) for (int l = 0; l < 2; l++) for (int i = 0; i < sched[k].n[l]; i++) if (sched[k].l[l][i] == sched[j].t) { needed = 1; if (k == idx) used = 1; }
-            if (!needed) continue;
-            Pic *pic = find_poc(e, sched[j].poc);
-            if (!pic) continue;
-            if (p->lt_ref && sched[j].idr && (pic->is_ref == 2 || sc->lt)) lt = 1;
-            if (lt) {
-                pic->is_ref = 2;
-                if (used) {
-                    int max = 1 << e->poc_bits;
-                    pp.ltc[pp.nl] = pic; pp.lt_poc_lsb[pp.nl] = pic->poc & (max - 1);
-                    pp.lt_msb[pp.nl] = (sc->poc - pic->poc) >= max / 2 || rnd_n(r, 2);
-                    pp.lt_cycle[pp.nl] = ((sc->poc & ~(max - 1)) - (pic->poc & ~(max - 1))) >> e->poc_bits; pp.nl++;
-                }
-                continue;
-            }
-            cand[nc++] = j; (void)used;
-        }
-        /* order: negative deltas closest first, then positive closest first */
-        for (int pass = 0; pass < 2; pass++) for (int dist = 1; dist < 64; dist++) for (int k = 0; k < nc; k++) {
-            int d = sched[cand[k]].poc - sc->poc;
-            if ((pass == 0 ? -d : d) != dist) continue;
-            int used = 0; for (int l = 0; l < 2; l++) for (int i = 0; i < sc->n[l]; i++) if (sc->l[l][i] == sched[cand[k]].t) used = 1;
-            Pic *pic = find_poc(e, sched[cand[k]].poc);
-            if (pass == 0) { pp.dneg[pp.n_neg] = d; pp.uneg[pp.n_neg++] = used; if (used) pp.before[pp.nb++] = pic; }
-            else { pp.dpos[pp.n_pos] = d; pp.upos[pp.n_pos++] = used; if (used) pp.after[pp.na++] = pic; }
+        RpsSet rs; plan_rps(sched, n_sched, idx, &rs);
+        pp.n_neg = rs.n_neg; pp.n_pos = rs.n_pos;
+        for (int i = 0; i < rs.n_neg; i++) { pp.dneg[i] = rs.dneg[i]; pp.uneg[i] = rs.uneg[i]; if (rs.uneg[i]) pp.before[pp.nb++] = find_poc(e, sc->poc + rs.dneg[i]); }
+        for (int i = 0; i < rs.n_pos; i++) { pp.dpos[i] = rs.dpos[i]; pp.upos[i] = rs.upos[i]; if (rs.upos[i]) pp.after[pp.na++] = find_poc(e, sc->poc + rs.dpos[i]); }
+        if (sc->lt) {                                                   /* the IDR picture of the period serves as a long-term reference */
+            Pic *pic = find_poc(e, sched[period0].poc);
+            int max = 1 << e->poc_bits;
+            pic->is_ref = 2;
+            pp.ltc[pp.nl] = pic; pp.lt_poc_lsb[pp.nl] = pic->poc & (max - 1);
+            pp.lt_msb[pp.nl] = (sc->poc - pic->poc) >= max / 2 || rnd_n(r, 2);
+            pp.lt_cycle[pp.nl] = ((sc->poc & ~(max - 1)) - (pic->poc & ~(max - 1))) >> e->poc_bits; pp.nl++;
         }
         /* pictures that fell out of the set are no longer references */
         for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 1) { int keep = 0; for (int k = 0; k < pp.n_neg; k++) keep |= e->dpb[i].poc == sc->poc + pp.dneg[k]; for (int k = 0; k < pp.n_pos; k++) keep |= e->dpb[i].poc == sc->poc + pp.dpos[k]; if (!keep) e->dpb[i].is_ref = 0; }
         for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 2) { int keep = 0; for (int k = 0; k < pp.nl; k++) keep |= pp.ltc[k] == &e->dpb[i]; if (!keep) e->dpb[i].is_ref = 0; }
         pp.n_total = pp.nb + pp.na + pp.nl;
     }
-    (void)base_t;
     Pic *cur = NULL;
     for (int i = 0; i < 10 && !cur; i++) if (!e->dpb[i].used || !e->dpb[i].is_ref) cur = &e->dpb[i];
     cur->used = 1; cur->is_ref = 0; cur->poc = sc->poc; cur->type = sc->type; e->cur = cur;
@@ -1603,11 +1694,23 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     int max_dpb = MIN(16, keep_max + reorder + 1);
     BitW outw; memset(&outw, 0, sizeof outw);
     lists_default(e); lists_expand(e); e->sf_on = p->scaling != 0;
+    if (p->rps_sps && !p->lt_ref) {                                     /* the distinct reference picture sets of the plan go into the SPS (some are left out on purpose) */
+        for (int i = 0; i < n_sched && e->n_sps_sets < 64; i++) {
+            if (sched[i].idr) continue;
+            RpsSet t; plan_rps(sched, n_sched, i, &t);
+            int known = 0; for (int k = 0; k < e->n_sps_sets; k++) known |= rps_equal(&e->sps_sets[k], &t);
+            if (!known && rnd_n(&e->rng, 4) != 0) e->sps_sets[e->n_sps_sets++] = t;
+        }
+    }
     write_vps(e, &outw, max_dpb, reorder);
     write_sps(e, &outw, max_dpb, reorder);
     write_pps(e, &outw);
+    size_t ps_len = outw.len;
     if (p->scaling >= 2) lists_expand(e);
-    for (int i = 0; i < n_sched; i++) encode_picture(e, &outw, sched, n_sched, i);
+    for (int i = 0; i < n_sched; i++) {
+        if (sched[i].cra) { uint8_t *copy = (uint8_t *)malloc(ps_len); memcpy(copy, outw.buf, ps_len); bw_bytes(&outw, copy, ps_len); free(copy); }   /* parameter sets again: decoding may start here */
+        encode_picture(e, &outw, sched, n_sched, i);
+    }
     if (e->recon) { fwrite(e->recon_buf, 1, (size_t)p->frames * ((size_t)p->width * p->height * 3 / 2), e->recon); fclose(e->recon); }
     *out = outw.buf; *out_len = outw.len;
     free(sched);
@@ -1626,7 +1729,7 @@ int main(int argc, char **argv) {
         {"--depth-intra", &p.depth_intra}, {"--mode", &p.mode}, {"--amp", &p.amp}, {"--sao", &p.sao}, {"--deblock", &p.deblock}, {"--tskip", &p.tskip}, {"--sdh", &p.sdh}, {"--dqp", &p.dqp}, {"--pcm", &p.pcm},
         {"--bypass", &p.bypass}, {"--cip", &p.cip}, {"--strong-intra", &p.strong_intra}, {"--tmvp", &p.tmvp}, {"--wp", &p.wp}, {"--rplm", &p.rplm}, {"--lt-ref", &p.lt_ref}, {"--scaling", &p.scaling},
         {"--wpp", &p.wpp}, {"--tile-cols", &p.tile_cols}, {"--tile-rows", &p.tile_rows}, {"--slice-ctus", &p.slice_ctus}, {"--dep-slices", &p.dep_slices}, {"--merge-cand", &p.merge_cand},
-        {"--cabac-init", &p.cabac_init}, {"--par-mrg", &p.par_mrg}, {"--cb-qp-off", &p.cb_qp_off}, {"--cr-qp-off", &p.cr_qp_off}, {"--search", &p.search} };
+        {"--cabac-init", &p.cabac_init}, {"--par-mrg", &p.par_mrg}, {"--cb-qp-off", &p.cb_qp_off}, {"--cr-qp-off", &p.cr_qp_off}, {"--search", &p.search}, {"--rps-sps", &p.rps_sps}, {"--open-gop", &p.open_gop} };
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-o") && i + 1 < argc) { outp = argv[++i]; continue; }
         if (!strcmp(argv[i], "--recon") && i + 1 < argc) { recon = argv[++i]; continue; }
