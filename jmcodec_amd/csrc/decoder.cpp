@@ -291,8 +291,11 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
 void Decoder::feed(const uint8_t *buf, size_t len) {
     if (avcc_len_size_ && !have_start_ && in_.empty()) {
         // avcC mode: a packet is a whole number of length-prefixed NAL units -- unless it starts with a start code (already converted)
-        bool annexb = len >= 4 && buf[0] == 0 && buf[1] == 0 && (buf[2] == 1 || (buf[2] == 0 && buf[3] == 1));
-        if (!annexb) {
+        // (a 4-byte length of 256..511 reads 00 00 01 xx, so the first bytes alone cannot tell the two forms apart: the packet is
+        //  length-prefixed exactly when its length fields chain to its end)
+        bool prefixed = false;
+        { size_t o = 0; while (o + (size_t)avcc_len_size_ <= len) { size_t l = 0; for (int i = 0; i < avcc_len_size_; i++) l = (l << 8) | buf[o + i]; o += (size_t)avcc_len_size_; if (l == 0 || l > len - o) { o = len + 1; break; } o += l; } prefixed = o == len; }
+        if (prefixed) {
             size_t o = 0;
             while (o + (size_t)avcc_len_size_ <= len) {
                 size_t l = 0;

@@ -90,13 +90,14 @@ def test_h264_and_hevc_handles_side_by_side():
 
 def test_hvcc_record_and_length_prefixed_packets(oracle):
     """SURVEY 8f f2 for HEVC: parameter sets through extra_data as an hvcC record, then one length-prefixed packet per access unit"""
-    data = streams.generate_hevc(**HEVC_CASES["b_gop2"])
-    want, ncu = oracle.syntax_digest(data)
     from jmcodec_amd import api
-    rec, packets = api.annexb_to_hvcc(data)
-    with jmcodec_amd.JmAmdDec(1, 1, options=OPTS, extra_data=rec) as d:
-        n = d.decode_stream(None, keep=False, chunks=packets)
-        assert (d.stat("syntax_digest") & 0xFFFFFFFFFFFFFFFF, d.stat("digest_mbs"), n) == (want, ncu, HEVC_CASES["b_gop2"]["frames"])
+    for name in ("b_gop2", "b_gop8"):          # b_gop8: access units of 256..511 bytes, whose 4-byte length reads 00 00 01 xx like a start code
+        data = streams.generate_hevc(**HEVC_CASES[name])
+        want, ncu = oracle.syntax_digest(data)
+        rec, packets = api.annexb_to_hvcc(data)
+        with jmcodec_amd.JmAmdDec(1, 1, options=OPTS, extra_data=rec) as d:
+            n = d.decode_stream(None, keep=False, chunks=packets)
+            assert (d.stat("syntax_digest") & 0xFFFFFFFFFFFFFFFF, d.stat("digest_mbs"), n) == (want, ncu, HEVC_CASES[name]["frames"])
 
 
 def test_start_at_cra_and_end_of_sequence(oracle):
