@@ -74,6 +74,17 @@ struct Cabac {
         if (pos < 16) refill();
         return bin;
     }
+    // n bypass bins at once (1 <= n <= 16), first bin in the most significant bit: the n compare-and-subtract steps of 9.3.3.2.3 are one
+    // division of the offset by the (scaled) range
+    inline uint32_t bypass_bits(int n) {
+        if (pos < 16) refill();
+        pos -= n;
+        const uint64_t scaled = (uint64_t)range << pos;
+        const uint64_t q = val / scaled;
+        val -= q * scaled;
+        if (pos < 16) refill();
+        return (uint32_t)q;
+    }
     inline int terminate() {
         range -= 2;
         if (val >= ((uint64_t)range << pos)) return 1;          // no renormalisation: parsing of the slice / before I_PCM ends

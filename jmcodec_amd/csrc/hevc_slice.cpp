@@ -14,11 +14,13 @@ enum { PART_2Nx2N, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_
 // scan tables (6.5.3 - 6.5.5): [scanIdx][log2 size 1..3][position] -> x | y << 4
 struct ScanTables {
     uint8_t t[3][4][64];
+    uint8_t inv[3][4][64];            // position x | y << 3 -> scan index
     ScanTables() {
         for (int l = 0; l <= 3; l++) {
             int n = 1 << l, k = 0;
             for (int s = 0; s <= 2 * (n - 1); s++) for (int x = 0; x <= s; x++) { int y = s - x; if (x < n && y < n) t[0][l][k++] = (uint8_t)(x | (y << 4)); }
             for (int i = 0; i < n * n; i++) { t[1][l][i] = (uint8_t)((i & (n - 1)) | ((i >> l) << 4)); t[2][l][i] = (uint8_t)((i >> l) | ((i & (n - 1)) << 4)); }
+            for (int sidx = 0; sidx < 3; sidx++) for (int i = 0; i < n * n; i++) inv[sidx][l][(t[sidx][l][i] & 15) | ((t[sidx][l][i] >> 4) << 3)] = (uint8_t)i;
         }
     }
 };
@@ -43,11 +45,21 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     w_ = sps.width; h_ = sps.height; w4_ = w_ >> 2; h4_ = h_ >> 2; ctb_size_ = 1 << sps.log2_ctb;
     ctb_w_ = (w_ + ctb_size_ - 1) >> sps.log2_ctb; ctb_h_ = (h_ + ctb_size_ - 1) >> sps.log2_ctb;
     const size_t n4 = (size_t)w4_ * h4_, nc = (size_t)ctb_w_ * ctb_h_;
-    pm_.assign(n4, 0); skip_.assign(n4, 0); depth_.assign(n4, 0); ipm_.assign(n4, 1); nofilter_.assign(n4, 0); edge_.assign(n4, 0); cbf_.assign(n4, 0);
-    qp_.assign(n4, 26); mot_.assign(n4, HevcMotion()); slice_of_.assign(n4, 0);
-    ctb_slice_.assign(nc, -1); rs2ts_.resize(nc); ts2rs_.resize(nc); tile_id_.resize(nc);
+    // The per-4x4 maps need no clearing between pictures: every read is guarded by the availability process (6.4.1), i.e. only touches
+    // units this picture has already decoded, and coding_unit() rewrites every map for all units of the CU; finish_picture() fills in
+    // coding tree blocks that no slice delivered.
+    if (pm_.size() != n4) {
+        pm_.assign(n4, 0); skip_.assign(n4, 0); depth_.assign(n4, 0); ipm_.assign(n4, 1); nofilter_.assign(n4, 0); edge_.assign(n4, 0); cbf_.assign(n4, 0);
+        qp_.assign(n4, 26); mot_.assign(n4, HevcMotion()); slice_of_.assign(n4, 0);
+    }
+    ctb_slice_.assign(nc, -1);
     slices_.clear(); wpp_valid_ = dep_valid_ = false; last_cu_qp_ = 26; err_ = false;
-    // 6.5.1: raster <-> tile scan
+    // 6.5.1 raster <-> tile scan and 6.5.2 z-scan order: only when the layout changed
+    uint64_t key = ((uint64_t)w_ << 48) ^ ((uint64_t)h_ << 32) ^ ((uint64_t)sps.log2_ctb << 28) ^ ((uint64_t)sps.log2_min_tb << 24) ^ ((uint64_t)pps.tile_cols << 16) ^ ((uint64_t)pps.tile_rows << 8) ^ (pps.uniform ? 1 : 0);
+    if (!pps.uniform) for (int i = 0; i < 20; i++) key = key * 1099511628211ULL + (uint64_t)(pps.col_w[i % 20] * 131 + pps.row_h[i % 22]);
+    if (key != layout_key_ || rs2ts_.size() != nc) {
+    layout_key_ = key;
+    rs2ts_.resize(nc); ts2rs_.resize(nc); tile_id_.resize(nc);
     int colb[21], rowb[23];
     const int nc_t = pps.tile_cols, nr_t = pps.tile_rows;
     colb[0] = rowb[0] = 0;
@@ -57,8 +69,7 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     int ts = 0;
     for (int tr = 0; tr < nr_t; tr++) for (int tc = 0; tc < nc_t; tc++)
         for (int y = rowb[tr]; y < rowb[tr + 1]; y++) for (int x = colb[tc]; x < colb[tc + 1]; x++) { int rs = y * ctb_w_ + x; rs2ts_[rs] = ts; ts2rs_[ts] = rs; tile_id_[ts] = tr * nc_t + tc; ts++; }
-    if (ts != (int)nc) err_ = true;                                   // tile boundaries that do not cover the picture
-    // 6.5.2: z-scan order of the minimum transform blocks
+    layout_bad_ = ts != (int)nc;                                       // tile boundaries that do not cover the picture
     const int sh = sps.log2_ctb - sps.log2_min_tb;
     tb_w_ = ctb_w_ << sh;
     zs_.resize((size_t)tb_w_ * (ctb_h_ << sh));
@@ -67,6 +78,8 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
         for (int i = 0; i < sh; i++) v |= (uint32_t)(((x >> i) & 1) << (2 * i)) | (uint32_t)(((y >> i) & 1) << (2 * i + 1));
         zs_[(size_t)y * tb_w_ + x] = v;
     }
+    }
+    if (layout_bad_) err_ = true;
     jobs->clear();
     jobs->ctbs.assign(nc, HevcCtb());
 }
@@ -301,12 +314,10 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     const uint8_t *sb_scan = kScan.t[scan][nsl], *pos_scan = kScan.t[scan][2];
     // locate the last position in scan order
     int last_sb = -1, last_pos = -1;
-    { const int sx = lx >> 2, sy = ly >> 2, px = lx & 3, py = ly & 3;
-      for (int i = 0; i < nsb * nsb; i++) if (sb_scan[i] == (sx | (sy << 4))) { last_sb = i; break; }
-      for (int i = 0; i < 16; i++) if (pos_scan[i] == (px | (py << 4))) { last_pos = i; break; } }
+    last_sb = kScan.inv[scan][nsl][(lx >> 2) | ((ly >> 2) << 3)]; last_pos = kScan.inv[scan][2][(lx & 3) | ((ly & 3) << 3)];
     uint8_t csbf[8][8]; memset(csbf, 0, sizeof csbf);
     int g1ctx = 1; bool first_group = true;
-    memset(lev_, 0, sizeof(int16_t) * (size_t)(n * n));
+    for (int k = 0; k < nz_n_; k++) lev_[nz_pos_[k]] = 0;             // lev_ is all zero between calls
     nz_n_ = 0;
     for (int i = last_sb; i >= 0; i--) {
         const int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
@@ -346,10 +357,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         if (last_g1 >= 0 && cb_.decision(HEVC_CTX_G2 + cset + (c ? 4 : 0))) absv[last_g1] = 3;
         const bool hide = pps_->sign_hiding && !tq_bypass_ && pos[0] - pos[np - 1] > 3;
         const int nsign = np - (hide ? 1 : 0);
-        uint32_t signs = 0;
-        for (int m = 0; m < nsign; m++) signs = (signs << 1) | (uint32_t)cb_.bypass();
-        signs <<= 32 - nsign > 31 ? 0 : 32 - nsign;                   // first sign in bit 31 (nsign >= 1 whenever it is used)
-        if (nsign == 0) signs = 0;
+        uint32_t signs = nsign ? cb_.bypass_bits(nsign) << (32 - nsign) : 0;      // first sign in bit 31
         int rice = 0, sum = 0;
         for (int m = 0; m < np; m++) {
             const int thr = m < 8 ? (m == last_g1 ? 3 : 2) : 1;
@@ -359,8 +367,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
                 while (q < 32 && cb_.bypass()) q++;
                 if (q >= 32) return false;
                 int rem;
-                if (q < 4) { rem = q << rice; for (int b = rice - 1; b >= 0; b--) rem |= cb_.bypass() << b; }
-                else { int nb = q - 3 + rice; if (nb > 30) return false; int s = 0; for (int b = 0; b < nb; b++) s = (s << 1) | cb_.bypass(); rem = (((1 << (q - 3)) + 2) << rice) + s; }
+                if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb_.bypass_bits(rice); }
+                else { int nb = q - 3 + rice; if (nb > 30) return false; int s = nb > 16 ? (int)(cb_.bypass_bits(nb - 16) << 16 | cb_.bypass_bits(16)) : (int)cb_.bypass_bits(nb); rem = (((1 << (q - 3)) + 2) << rice) + s; }
                 a += rem;
                 if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
             }
@@ -737,6 +745,8 @@ void HevcPicParser::finish_picture(HevcColMotion *col) {
         for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y); pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; slice_of_[i] = 0; }
     }
     if (slices_.empty()) { SliceInfo si; memset(&si, 0, sizeof si); si.deblock_disabled = true; slices_.push_back(si); }
+    // (after a damaged slice a unit may hold the slice index of an earlier picture: clamp)
+    auto slice_at = [&](int i) -> const SliceInfo & { size_t k = slice_of_[i]; return slices_[k < slices_.size() ? k : slices_.size() - 1]; };
     const int w8 = w_ >> 3, h8 = h_ >> 3;
     jobs_->qp8.resize((size_t)w8 * h8);
     for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8); jobs_->qp8[(size_t)y * w8 + x] = (uint8_t)((qp_[i] & 63) | (nofilter_[i] ? 128 : 0)); }
@@ -746,7 +756,7 @@ void HevcPicParser::finish_picture(HevcColMotion *col) {
         const int xp = dir ? xq : xq - 1, yp = dir ? yq - 1 : yq, q = i4(xq, yq), p = i4(xp, yp);
         const int tu = edge_[q] & (dir ? 2 : 1), pu = edge_[q] & (dir ? 8 : 4);
         if (!tu && !pu) return 0;
-        const SliceInfo &sq = slices_[slice_of_[q]], &sp = slices_[slice_of_[p]];
+        const SliceInfo &sq = slice_at(q), &sp = slice_at(p);
         if (sq.deblock_disabled) return 0;
         if (sq.addr != sp.addr && !sq.lf_across) return 0;
         if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc); if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
@@ -764,20 +774,20 @@ void HevcPicParser::finish_picture(HevcColMotion *col) {
         return straight && crossed ? (ds && dc) : (straight ? ds : dc);
     };
     if (jobs_->any_deblock) {
-        for (int y = 0; y < h_; y += 4) for (int x = 8; x < w_; x += 8) { int bs = strength(x, y, 0); if (bs) jobs_->bs_v[(size_t)(y >> 2) * w8 + (x >> 3)] = (uint8_t)(bs | (nofilter_[i4(x - 1, y)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
-        for (int y = 8; y < h_; y += 8) for (int x = 0; x < w_; x += 4) { int bs = strength(x, y, 1); if (bs) jobs_->bs_h[(size_t)(y >> 3) * w4_ + (x >> 2)] = (uint8_t)(bs | (nofilter_[i4(x, y - 1)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
+        for (int y = 0; y < h_; y += 4) for (int x = 8; x < w_; x += 8) { if (!(edge_[i4(x, y)] & 5)) continue; int bs = strength(x, y, 0); if (bs) jobs_->bs_v[(size_t)(y >> 2) * w8 + (x >> 3)] = (uint8_t)(bs | (nofilter_[i4(x - 1, y)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
+        for (int y = 8; y < h_; y += 8) for (int x = 0; x < w_; x += 4) { if (!(edge_[i4(x, y)] & 10)) continue; int bs = strength(x, y, 1); if (bs) jobs_->bs_h[(size_t)(y >> 3) * w4_ + (x >> 2)] = (uint8_t)(bs | (nofilter_[i4(x, y - 1)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
     }
     // SAO: which neighbouring CTBs the edge offset of a CTB may read (8.7.3: slice and tile boundaries)
     if (jobs_->any_sao) {
         static const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
         for (int rs = 0; rs < ctb_w_ * ctb_h_; rs++) {
             const int cx = rs % ctb_w_, cy = rs / ctb_w_; uint8_t mask = 0;
-            const SliceInfo &sc = slices_[slice_of_[i4(cx << lc, cy << lc)]];
+            const SliceInfo &sc = slice_at(i4(cx << lc, cy << lc));
             for (int k = 0; k < 8; k++) {
                 const int nx = cx + dx[k], ny = cy + dy[k];
                 if (nx < 0 || ny < 0 || nx >= ctb_w_ || ny >= ctb_h_) continue;
                 const int nrs = ny * ctb_w_ + nx;
-                const SliceInfo &sn = slices_[slice_of_[i4(nx << lc, ny << lc)]];
+                const SliceInfo &sn = slice_at(i4(nx << lc, ny << lc));
                 bool ok = true;
                 if (sn.addr != sc.addr) ok = rs2ts_[nrs] < rs2ts_[rs] ? sc.lf_across : sn.lf_across;
                 if (ok && !pps_->lf_across_tiles && tile_id_[rs2ts_[nrs]] != tile_id_[rs2ts_[rs]]) ok = false;
@@ -793,7 +803,7 @@ void HevcPicParser::finish_picture(HevcColMotion *col) {
         for (int y = 0; y < col->h16; y++) for (int x = 0; x < col->w16; x++) {
             const int i = i4(x * 16, y * 16); const size_t e = (size_t)y * col->w16 + x;
             col->intra[e] = pm_[i] != 1; col->mot[e] = mot_[i];
-            const SliceInfo &s = slices_[slice_of_[i]];
+            const SliceInfo &s = slice_at(i);
             for (int l = 0; l < 2; l++) if ((mot_[i].pf >> l) & 1) { col->ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]]; col->lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
         }
     }

@@ -88,7 +88,8 @@ private:
     int cu_x_ = 0, cu_y_ = 0, part_mode_ = 0, ipm_c_ = 0, max_tr_depth_ = 0;
     uint16_t wp_index_ = 0;
     int16_t lev_[32 * 32]; uint16_t nz_pos_[32 * 32]; int nz_n_ = 0;
-    bool err_ = false;
+    bool err_ = false, layout_bad_ = false;
+    uint64_t layout_key_ = 0;
 };
 
 }  // namespace jmamd

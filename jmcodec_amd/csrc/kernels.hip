@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
         int g = lane >> 4, l = lane & 15;
         int mvx, mvy; rec_mv8(r, g, mvx, mvy);
         int fx = mvx & 3, fy = mvy & 3;
-        int bx0 = mbx * 16 + (g & 1) * 8, by0 = mby * 16 + (g >> 1) * 8;
+        int bx0 = mbx * 16 + (g & 1) * 8;
         int xi = bx0 + (mvx >> 2) - 2;
         uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
         int sh = xi & 3;
