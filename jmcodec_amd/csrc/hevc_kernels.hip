@@ -68,8 +68,11 @@ __device__ void interp_block(const uint8_t *plane, int pitch, int step, int pw, 
 
 __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & HPS_MC) || (int)blockIdx.x >= pp.n_pus) return;
-    const HevcPu pu = pp.pus[blockIdx.x];
+    // XCD-aware: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); give every XCD one contiguous run of blocks
+    // (blocks are in decoding order, i.e. spatially coherent), so that a reference window is fetched into one L2 instead of eight
+    const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (!(pp.stages & HPS_MC) || job >= pp.n_pus) return;
+    const HevcPu pu = pp.pus[job];
     const int lane = threadIdx.x;
     __shared__ uint8_t tile[23 * 23 + 3];
     __shared__ int16_t hbuf[23 * 16];
@@ -143,8 +146,9 @@ __device__ const int16_t *residual_block(const uint32_t *coefs, int count, int l
 
 __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & HPS_RESID) || (int)blockIdx.x >= pp.n_tbs) return;
-    const HevcTb tb = pp.tbs[blockIdx.x];
+    const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD-aware, see k_hevc_mc
+    if (!(pp.stages & HPS_RESID) || job >= pp.n_tbs) return;
+    const HevcTb tb = pp.tbs[job];
     __shared__ int16_t d[32 * 32], res[32 * 32];
     __shared__ __align__(16) int8_t tm[32 * 32];
     __shared__ int ext[2];
@@ -502,8 +506,8 @@ void hevc_kernels_init() { upload_tables(); }
 void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBatchDims &m, int *progress, hipStream_t st, hipEvent_t *marks) {
     upload_tables();
     if (marks) hipEventRecord(marks[0], st);
-    if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3(m.max_pus, n), dim3(64), 0, st, d_pics);
-    if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3(m.max_tbs, n), dim3(64), 0, st, d_pics);
+    if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3((m.max_pus + 7) & ~7, n), dim3(64), 0, st, d_pics);
+    if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3((m.max_tbs + 7) & ~7, n), dim3(64), 0, st, d_pics);
     if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3(m.max_itbs, n), dim3(64), 0, st, d_pics);
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
