@@ -109,13 +109,12 @@ def main():
         got = C.c_int(0)
         n = C.c_int(0)
         cnt = 0
-        for _ in range(passes):
-            for nal in nalus:
-                L.jm_amddec_decode_frame(C.cast(C.c_char_p(nal), C.c_void_p), len(nal), C.byref(got), h)
-                if got.value == 1:
-                    n.value = frame_bytes
-                    if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
-                        cnt += 1
+        # test_nv_dec's hot loop (one NAL per jm_nvdec_decode_frame call, fetch a frame whenever got_frame == 1) runs in the library:
+        # a Python loop would measure the interpreter's per-call overhead and the GIL hand-off between the S feeder threads
+        got_n = L.jm_amddec_feed_annexb(data, len(data), passes, C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
+        if got_n < 0:
+            raise SystemExit("feed failed: " + L.jm_amddec_last_error(h).decode())
+        cnt += got_n
         # let the pipeline run dry (no EOS: the handle keeps its DPB) and collect what it finished.
         # An access-unit delimiter carries no picture; two of them push the last slice NAL out of the
         # splitter (a NAL ends at the next start code) and close the picture (7.4.1.2.3).
@@ -156,6 +155,7 @@ def main():
         return {k: {f: L.jm_amddec_get_stat(handles[0], f"k_{k}_{f}".encode()) for f in ("ns", "n", "pics", "alg_bytes")} for k in KN}
     e0 = eng()
     b0 = (L.jm_amddec_get_stat(handles[0], b"eng_batches"), L.jm_amddec_get_stat(handles[0], b"eng_batch_pics"))
+    et0 = (L.jm_amddec_get_stat(handles[0], b"eng_launch_ns"), L.jm_amddec_get_stat(handles[0], b"eng_complete_ns"))
     jb0 = [L.jm_amddec_get_stat(h, b"job_bytes") for h in handles]
     pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
     for i in range(S):
@@ -179,6 +179,7 @@ def main():
     tot_alg = {k: e1[k]["alg_bytes"] - e0[k]["alg_bytes"] for k in names}
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
+    eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4), "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
@@ -271,7 +272,7 @@ def main():
                      "frac": round(achieved / peak, 6), "traffic": traffic,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
-        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2)},
+        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms},
         "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 63.0, "unit": "GB/s",
                      "note": "tight frames: k_packout -> device staging, copy engine -> pinned host slot (overlaps the next batch); rate = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),

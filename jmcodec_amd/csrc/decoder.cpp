@@ -119,6 +119,8 @@ long long Decoder::get_stat(const char *key) const {
         }
         if (k == "eng_batches") return es.batches;
         if (k == "eng_batch_pics") return es.batch_pics;
+        if (k == "eng_launch_ns") return es.launch_ns;
+        if (k == "eng_complete_ns") return es.complete_ns;
         return -1;
     }
     if (k.rfind("display_poc:", 0) == 0) { size_t i = (size_t)atoll(k.c_str() + 12); return i < display_pocs_.size() ? display_pocs_[i] : -1; }

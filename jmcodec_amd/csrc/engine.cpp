@@ -202,7 +202,7 @@ void Engine::run() {
         // 1. retire finished batches (oldest first per lane)
         for (auto &ln : lanes_) {
             while (ln.inflight > 0 && hipEventQuery(ln.ring[ln.tail].done) == hipSuccess) {
-                complete(ln.ring[ln.tail]);
+                { auto t0 = std::chrono::steady_clock::now(); complete(ln.ring[ln.tail]); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
                 progressed = true;
             }
@@ -216,7 +216,7 @@ void Engine::run() {
             bool have;
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
             if (!have) continue;
-            launch(ln, b);
+            { auto t0 = std::chrono::steady_clock::now(); launch(ln, b); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.launch_ns += ns; }
             ln.head = (ln.head + 1) % kBatchRing; ln.inflight++;
             progressed = true;
         }

@@ -56,6 +56,7 @@ struct EnginePic {
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout
     double ns[4] = {0, 0, 0, 0}; long long launches[4] = {0, 0, 0, 0}, pics[4] = {0, 0, 0, 0}, alg_bytes[4] = {0, 0, 0, 0};
     long long batches = 0, batch_pics = 0;
+    long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
 };
 
 // engine-private state kept inside each Decoder (touched only by the engine thread)

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <cstdlib>
+#include <vector>
 
 using jmamd::Decoder;
 
@@ -59,6 +60,23 @@ __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *
     hipStreamSynchronize(st);
     hipFree(d_job);
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+__attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned char *buf, long len, int passes, unsigned char *out, int out_cap, jm_amddec_handle h) {
+    if (!h || !buf || len < 4 || !out) return -1;
+    // NAL boundaries as find_nalu sees them: a start code is 00 00 01, or 00 00 00 01 (then the NAL starts one byte earlier)
+    std::vector<long> starts;
+    for (long i = 0; i + 3 <= len; i++) if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) { long s0 = (i > 0 && buf[i - 1] == 0) ? i - 1 : i; if (starts.empty() || s0 > starts.back()) starts.push_back(s0); i += 2; }
+    if (starts.empty()) return -1;
+    long frames = 0;
+    for (int p = 0; p < passes; p++)
+        for (size_t k = 0; k < starts.size(); k++) {
+            const long b = starts[k], e = k + 1 < starts.size() ? starts[k + 1] : len;
+            int got = 0;
+            if (D(h)->decode(buf + b, (int)(e - b), &got) != 0) return -2;
+            if (got == 1) { int n = out_cap; if (D(h)->output(out, &n) > 0) frames++; }
+        }
+    return frames;
 }
 
 }  // extern "C"
