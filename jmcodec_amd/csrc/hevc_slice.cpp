@@ -728,10 +728,20 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
 // picture end: 8.7.2.2 - 8.7.2.4 edge flags and boundary strengths, QP map, SAO neighbour masks, motion for temporal prediction
 void HevcPicParser::finish_picture(HevcColMotion *col) {
     const int lc = sps_->log2_ctb;
-    // coding tree blocks no slice delivered: flat grey, exempt from filtering
+    // coding tree blocks no slice delivered (lost / damaged slice segments): the colocated block of the first list-0 reference (zero motion, no
+    // residual), flat grey in a picture without references; exempt from filtering
+    int conceal_slot = -1;
+    for (const SliceInfo &si : slices_) if (si.slot[0][0] >= 0) { conceal_slot = si.slot[0][0]; break; }
     for (int rs = 0; rs < ctb_w_ * ctb_h_; rs++) if (ctb_slice_[rs] < 0) {
         const int x0 = (rs % ctb_w_) << lc, y0 = (rs / ctb_w_) << lc;
         HevcCtb &cj = jobs_->ctbs[rs]; cj.intra_first = (uint32_t)jobs_->itbs.size();
+        if (conceal_slot >= 0) {
+            HevcPu j; memset(&j, 0, sizeof j); j.slot0 = (int8_t)conceal_slot; j.slot1 = -1;
+            for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 16) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 16) {
+                j.x = (uint16_t)x; j.y = (uint16_t)y; j.w = (uint8_t)std::min(16, w_ - x); j.h = (uint8_t)std::min(16, h_ - y);
+                jobs_->pus.push_back(j);
+            }
+        } else
         for (int c = 0; c < 3; c++) for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 8) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 8) {
             // 8x8 luma / 4x4 chroma blocks of the value 128 (PCM-style: no prediction, the "coefficients" are the samples)
             const int sc = c ? 1 : 0, lg = 3 - sc, nn = 1 << lg;

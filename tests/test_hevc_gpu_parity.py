@@ -142,3 +142,15 @@ def test_cra_start_and_end_of_sequence_on_gpu(oracle):
         want, n, _, _ = oracle.decode(s, 1)
         frames, errors = gpu_decode(s)
         assert errors == 0 and len(frames) == n and b"".join(frames) == want
+
+
+def test_resolution_change_between_sequences(oracle):
+    a = streams.generate_hevc(**HEVC_CASES["p_real"])
+    b = streams.generate_hevc(**dict(HEVC_CASES["crop_ctb32"], seed=77))
+    data = a + b + a
+    with jmcodec_amd.JmAmdDec(1, 1, options={"device": 0}) as d:
+        frames = d.decode_stream(data)
+        assert d.stat("errors") == 0
+    # the oracle's convenience call reports one size: compare per sequence
+    want = b"".join(oracle.decode(s, 1)[0] for s in (a, b, a))
+    assert b"".join(frames) == want

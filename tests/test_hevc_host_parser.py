@@ -109,3 +109,15 @@ def test_start_at_cra_and_end_of_sequence(oracle):
         want, ncu = oracle.syntax_digest(s)
         got, cus, n, errors, _ = product_digest(s)
         assert errors == 0 and (got, cus) == (want, ncu) and n == oracle.decode(s, 1)[1]
+
+
+def test_resolution_change_and_repeated_parameter_sets(oracle):
+    """a second coded video sequence with another picture size (new SPS at an IDR picture) and parameter sets re-sent in front of every
+    IRAP picture: frame counts, sizes and syntax must follow the oracle through the switch"""
+    a = streams.generate_hevc(**HEVC_CASES["p_real"])
+    b = streams.generate_hevc(**dict(HEVC_CASES["crop_ctb32"], seed=77))
+    c = streams.generate_hevc(**HEVC_CASES["open_gop"])
+    for data in (a + b, b + a + b, c + a):
+        want, ncu = oracle.syntax_digest(data)
+        got, cus, n, errors, _ = product_digest(data)
+        assert errors == 0 and (got, cus) == (want, ncu) and n == oracle.decode(data, 1)[1]
