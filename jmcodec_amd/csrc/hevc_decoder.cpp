@@ -243,13 +243,13 @@ void Decoder::hevc_parse_task(PicTask *t) {
     static thread_local HevcPicJobs jobs;
     HevcDigest dg = hdigest_; dg.on = want_digest_;
     if (dg.on && !dg.trace && getenv("JM_AMD_DEC_DIGEST_TRACE")) dg.trace = fopen(getenv("JM_AMD_DEC_DIGEST_TRACE"), "w");     // debugging aid: every digest event
-    parser.begin_picture(ht.sps, ht.pps, ht.poc, &jobs, &dg);
+    parser.begin_picture(ht.sps, ht.pps, ht.poc, &jobs, &dg, ht.col_out.get());
     for (auto &s : ht.slices) {
         std::string e = parser.parse_slice(s.sh, s.refs, s.rbsp.data(), s.len);
         if (!e.empty()) { t->error = e; stat_errors_++; }
         std::vector<uint8_t>().swap(s.rbsp);
     }
-    parser.finish_picture(ht.col_out.get());
+    parser.finish_picture();
     if (ht.col_out) ht.col_out->publish();
     if (want_digest_) hdigest_ = dg;
     // pack: every array 16-byte aligned

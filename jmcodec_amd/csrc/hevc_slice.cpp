@@ -40,8 +40,8 @@ inline bool same_motion(const HevcMotion &a, const HevcMotion &b) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
-void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int poc, HevcPicJobs *jobs, HevcDigest *dgst) {
-    sps_ = &sps; pps_ = &pps; poc_ = poc; jobs_ = jobs; dg_ = dgst;
+void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int poc, HevcPicJobs *jobs, HevcDigest *dgst, HevcColMotion *col_out) {
+    sps_ = &sps; pps_ = &pps; poc_ = poc; jobs_ = jobs; dg_ = dgst; col_out_ = col_out; exported_rows_ = 0;
     w_ = sps.width; h_ = sps.height; w4_ = w_ >> 2; h4_ = h_ >> 2; ctb_size_ = 1 << sps.log2_ctb;
     ctb_w_ = (w_ + ctb_size_ - 1) >> sps.log2_ctb; ctb_h_ = (h_ + ctb_size_ - 1) >> sps.log2_ctb;
     const size_t n4 = (size_t)w4_ * h4_, nc = (size_t)ctb_w_ * ctb_h_;
@@ -82,6 +82,12 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     if (layout_bad_) err_ = true;
     jobs->clear();
     jobs->ctbs.assign(nc, HevcCtb());
+    if (col_out_) {
+        HevcColMotion &c = *col_out_;
+        c.w16 = (w_ + 15) >> 4; c.h16 = (h_ + 15) >> 4; c.poc = poc_;
+        const size_t n = (size_t)c.w16 * c.h16;
+        c.mot.resize(n); c.ref_poc.assign(2 * n, 0); c.lt.assign(n, 0); c.intra.assign(n, 1);
+    }
 }
 
 void HevcPicParser::init_contexts() {                                  // 9.3.2.2
@@ -661,7 +667,6 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
     if (err_) return "tile layout does not cover the picture";
     sh_ = &sh; refs_ = &refs;
     if (sh.data_offset >= len) return "slice segment without data";
-    if (refs.col) refs.col->wait();
     const int n_ctb = ctb_w_ * ctb_h_;
     if (!sh.dependent) {
         SliceInfo si; memset(&si, 0, sizeof si);
@@ -691,6 +696,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         const int rx = ctb_rs_ % ctb_w_, ry = ctb_rs_ / ctb_w_, tile = tile_id_[ctb_ts_];
         const bool first_in_tile = ctb_ts_ == 0 || tile_id_[ctb_ts_ - 1] != tile;
         const bool row_start = pps_->wpp && (rx == 0 || tile_id_[rs2ts_[ctb_rs_ - 1]] != tile);
+        if (refs.col && (rx == 0 || first_ctu)) refs.col->wait_rows(std::min((h_ + 15) >> 4, ((ry + 1) << sps_->log2_ctb) >> 4));      // the collocated picture's motion down to this CTB row (its own parse sizes and fills the field: never read it before)
         if (ctb_slice_[ctb_rs_] >= 0) return "coding tree block decoded twice";
         ctb_slice_[ctb_rs_] = sh.slice_addr;
         { HevcCtb &cj = jobs_->ctbs[ctb_rs_]; cj.beta_off = slices_[slice_idx_].beta_off; cj.tc_off = slices_[slice_idx_].tc_off; cj.intra_first = (uint32_t)jobs_->itbs.size(); }
@@ -706,6 +712,8 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         if (!coding_quadtree(rx << sps_->log2_ctb, ry << sps_->log2_ctb, sps_->log2_ctb, 0) || cb_.overrun) return "corrupt slice data";
         jobs_->ctbs[ctb_rs_].intra_count = (uint32_t)jobs_->itbs.size() - jobs_->ctbs[ctb_rs_].intra_first;
         if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) { memcpy(wpp_state_, cb_.state, HEVC_N_CTX); wpp_valid_ = true; }
+        // a finished CTB row (pictures without tiles: rows complete in order) makes its part of the motion field final
+        if (col_out_ && !pps_->tiles && rx == ctb_w_ - 1 && ry * (ctb_size_ >> 4) == exported_rows_) export_motion_rows(exported_rows_, std::min(col_out_->h16, (ry + 1) * (ctb_size_ >> 4)));
         const int end = cb_.terminate();
         ctb_ts_++;
         if (end) break;
@@ -726,7 +734,20 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
 
 // ------------------------------------------------------------------------------------------------------------
 // picture end: 8.7.2.2 - 8.7.2.4 edge flags and boundary strengths, QP map, SAO neighbour masks, motion for temporal prediction
-void HevcPicParser::finish_picture(HevcColMotion *col) {
+void HevcPicParser::export_motion_rows(int r0, int r1) {
+    HevcColMotion &c = *col_out_;
+    for (int y = r0; y < r1; y++) for (int x = 0; x < c.w16; x++) {
+        const int i = i4(x * 16, y * 16); const size_t e = (size_t)y * c.w16 + x;
+        c.intra[e] = pm_[i] != 1; c.mot[e] = mot_[i]; c.lt[e] = 0;
+        size_t k = slice_of_[i]; const SliceInfo &s = slices_[k < slices_.size() ? k : slices_.size() - 1];
+        for (int l = 0; l < 2; l++) if (pm_[i] == 1 && ((mot_[i].pf >> l) & 1)) { c.ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]]; c.lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
+    }
+    exported_rows_ = r1;
+    c.publish_rows(r1);
+}
+
+void HevcPicParser::finish_picture() {
+    HevcColMotion *col = col_out_;
     const int lc = sps_->log2_ctb;
     // coding tree blocks no slice delivered (lost / damaged slice segments): the colocated block of the first list-0 reference (zero motion, no
     // residual), flat grey in a picture without references; exempt from filtering
@@ -806,17 +827,7 @@ void HevcPicParser::finish_picture(HevcColMotion *col) {
             jobs_->ctbs[rs].nb_mask = mask;
         }
     }
-    if (col) {
-        col->w16 = (w_ + 15) >> 4; col->h16 = (h_ + 15) >> 4; col->poc = poc_;
-        const size_t n = (size_t)col->w16 * col->h16;
-        col->mot.resize(n); col->ref_poc.assign(2 * n, 0); col->lt.assign(n, 0); col->intra.resize(n);
-        for (int y = 0; y < col->h16; y++) for (int x = 0; x < col->w16; x++) {
-            const int i = i4(x * 16, y * 16); const size_t e = (size_t)y * col->w16 + x;
-            col->intra[e] = pm_[i] != 1; col->mot[e] = mot_[i];
-            const SliceInfo &s = slice_at(i);
-            for (int l = 0; l < 2; l++) if ((mot_[i].pf >> l) & 1) { col->ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]]; col->lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
-        }
-    }
+    if (col && exported_rows_ < col->h16) export_motion_rows(exported_rows_, col->h16);      // what the row-wise export did not cover (tiles, damaged pictures)
 }
 
 }  // namespace jmamd

@@ -20,12 +20,16 @@ namespace jmamd {
 struct HevcMotion { int16_t mv[2][2]; int8_t ref[2]; uint8_t pf, pad; };      // pf bit 0 = list 0 used, bit 1 = list 1 used
 
 // motion of a decoded picture at 16x16 granularity (8.5.3.2.8); produced by the parse of that picture, consumed by later ones
+// Rows are published as the parse of the picture advances, so a picture that uses it as collocated picture can be parsed a CTB row behind it
+// instead of after it (the temporal candidate of a block never lies below the block's own CTB row, 8.5.3.2.8).
 struct HevcColMotion {
-    std::mutex m; std::condition_variable cv; bool ready = false;
+    std::mutex m; std::condition_variable cv; bool ready = false; int rows_ready = 0;      // rows_ready: 16-sample rows whose entries are final
     int w16 = 0, h16 = 0, poc = 0;
     std::vector<HevcMotion> mot; std::vector<int32_t> ref_poc; std::vector<uint8_t> lt, intra;
-    void publish() { { std::lock_guard<std::mutex> lk(m); ready = true; } cv.notify_all(); }
+    void publish() { { std::lock_guard<std::mutex> lk(m); ready = true; rows_ready = h16; } cv.notify_all(); }
+    void publish_rows(int n) { { std::lock_guard<std::mutex> lk(m); if (n > rows_ready) rows_ready = n; } cv.notify_all(); }
     void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return ready; }); }
+    void wait_rows(int n) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return ready || rows_ready >= n; }); }
 };
 
 struct HevcSliceRefs {            // RefPicList0 / RefPicList1 of one slice (8.3.4)
@@ -46,9 +50,9 @@ struct HevcDigest { bool on = false; uint64_t h = 0xcbf29ce484222325ULL; uint64_
 class HevcPicParser {
 public:
     // one picture: begin, every slice segment in decoding order, finish
-    void begin_picture(const HevcSps &sps, const HevcPps &pps, int poc, HevcPicJobs *jobs, HevcDigest *dg);
+    void begin_picture(const HevcSps &sps, const HevcPps &pps, int poc, HevcPicJobs *jobs, HevcDigest *dg, HevcColMotion *col_out);
     std::string parse_slice(const HevcSliceHeader &sh, const HevcSliceRefs &refs, const uint8_t *rbsp, size_t len);
-    void finish_picture(HevcColMotion *col_out);          // boundary strengths, QP map, motion for temporal prediction
+    void finish_picture();                                // boundary strengths, QP map, the rest of the motion for temporal prediction
 
 private:
     struct SliceInfo { int addr; bool deblock_disabled, lf_across; int8_t beta_off, tc_off; int8_t slot[2][16]; int poc[2][16]; uint8_t is_lt[2][16]; };
@@ -73,7 +77,9 @@ private:
     inline int i4(int x, int y) const { return (y >> 2) * w4_ + (x >> 2); }
 
     const HevcSps *sps_ = nullptr; const HevcPps *pps_ = nullptr; const HevcSliceHeader *sh_ = nullptr; const HevcSliceRefs *refs_ = nullptr;
-    HevcPicJobs *jobs_ = nullptr; HevcDigest *dg_ = nullptr;
+    HevcPicJobs *jobs_ = nullptr; HevcDigest *dg_ = nullptr; HevcColMotion *col_out_ = nullptr;
+    void export_motion_rows(int r0, int r1);               // rows [r0, r1) of the 16x16 motion field -> col_out_
+    int exported_rows_ = 0;
     Cabac cb_;
     uint8_t wpp_state_[CABAC_N_CTX], dep_state_[CABAC_N_CTX]; bool wpp_valid_ = false, dep_valid_ = false;
     int poc_ = 0, w_ = 0, h_ = 0, w4_ = 0, h4_ = 0, ctb_w_ = 0, ctb_h_ = 0, ctb_size_ = 0, tb_w_ = 0;
