@@ -47,6 +47,8 @@ HEVC_CASES = {
     "rps_sps_gop8": dict(width=96, height=80, frames=17, gop=8, num_ref=2, rps_sps=1, mode=1, seed=29),
     "rps_sps_p": dict(width=96, height=80, frames=9, num_ref=3, rps_sps=1, mode=1, seed=30),
     "open_gop": dict(width=96, height=80, frames=20, gop=2, num_ref=2, open_gop=1, intra_period=6, rps_sps=1, seed=31),
+    "tiles_explicit": dict(width=128, height=96, frames=3, tile_cols=3, tile_rows=2, ctb_log2=4, mode=1, seed=34),      # seed & 2: uniform_spacing_flag = 0
+    "poc_wrap": dict(width=64, height=64, frames=70, intra_period=70, gop=2, num_ref=2, seed=36),                          # MaxPicOrderCntLsb = 32 < 70
     "small_tb": dict(width=96, height=80, frames=3, max_tb_log2=3, depth_inter=1, depth_intra=0, mode=1, seed=28),
 }
 

@@ -189,6 +189,7 @@ typedef struct Enc {
     int decode_count;
     uint8_t *dbk[3];
     int lf_across_tiles;
+    int tile_explicit, tile_cb[21], tile_rb[23];                        /* tile boundaries in CTBs; explicit: sent as column widths / row heights (uniform_spacing_flag = 0) */
     RpsSet sps_sets[64]; int n_sps_sets;                               /* short-term reference picture sets carried by the SPS (rps_sps) */
     uint8_t sl4[6][16], sl8[6][64], sl16[6][64], sl32[6][64], dc16[6], dc32[6];   /* coded scaling lists (diagonal order) */
 } Enc;
@@ -1375,7 +1376,11 @@ static void write_pps(Enc *e, BitW *out) {
     bw_put(&w, 1, (uint32_t)p->bypass);
     int tiles = p->tile_cols * p->tile_rows > 1;
     bw_put(&w, 1, (uint32_t)tiles); bw_put(&w, 1, (uint32_t)p->wpp);
-    if (tiles) { bw_ue(&w, (uint32_t)(p->tile_cols - 1)); bw_ue(&w, (uint32_t)(p->tile_rows - 1)); bw_put(&w, 1, 1); bw_put(&w, 1, (uint32_t)e->lf_across_tiles); }
+    if (tiles) {
+        bw_ue(&w, (uint32_t)(p->tile_cols - 1)); bw_ue(&w, (uint32_t)(p->tile_rows - 1)); bw_put(&w, 1, !e->tile_explicit);
+        if (e->tile_explicit) { for (int i = 0; i + 1 < p->tile_cols; i++) bw_ue(&w, (uint32_t)(e->tile_cb[i + 1] - e->tile_cb[i] - 1)); for (int i = 0; i + 1 < p->tile_rows; i++) bw_ue(&w, (uint32_t)(e->tile_rb[i + 1] - e->tile_rb[i] - 1)); }
+        bw_put(&w, 1, (uint32_t)e->lf_across_tiles);
+    }
     bw_put(&w, 1, 1);                                                  /* pps_loop_filter_across_slices_enabled_flag (slices decide) */
     bw_put(&w, 1, 1);                                                  /* deblocking_filter_control_present_flag */
     bw_put(&w, 1, p->deblock == 2); bw_put(&w, 1, p->deblock == 0);
@@ -1538,10 +1543,16 @@ static void store_col_motion(Enc *e) {
     }
 }
 
-static void tables_init(Enc *e) {                                       /* 6.5.1 with uniform tile spacing */
-    const HevcGenParams *p = &e->p; int nc = p->tile_cols, nr = p->tile_rows, cb[21], rb[23];
+static void tables_init(Enc *e) {                                       /* 6.5.1 */
+    const HevcGenParams *p = &e->p; int nc = p->tile_cols, nr = p->tile_rows, *cb = e->tile_cb, *rb = e->tile_rb;
     for (int i = 0; i <= nc; i++) cb[i] = (i * e->ctb_w) / nc;
     for (int i = 0; i <= nr; i++) rb[i] = (i * e->ctb_h) / nr;
+    e->tile_explicit = nc * nr > 1 && (p->seed & 2);
+    if (e->tile_explicit) {                                             /* move the inner boundaries around (every tile keeps at least one CTB) */
+        Rng r = { (uint64_t)p->seed * 31 + 7 };
+        for (int i = 1; i < nc; i++) { int lo = cb[i - 1] + 1, hi = e->ctb_w - (nc - i); cb[i] = lo + rnd_n(&r, hi - lo + 1); }
+        for (int i = 1; i < nr; i++) { int lo = rb[i - 1] + 1, hi = e->ctb_h - (nr - i); rb[i] = lo + rnd_n(&r, hi - lo + 1); }
+    }
     int ts = 0;
     for (int tr = 0; tr < nr; tr++) for (int tc = 0; tc < nc; tc++)
         for (int y = rb[tr]; y < rb[tr + 1]; y++) for (int x = cb[tc]; x < cb[tc + 1]; x++) { int rs = y * e->ctb_w + x; e->rs2ts[rs] = ts; e->ts2rs[ts] = rs; e->tile_of[ts] = tr * nc + tc; ts++; }
