@@ -22,3 +22,5 @@ done
 python3 tools/make_traffic_profile.py gpurun_out/p/hevc_pmc_FETCH_SIZE.csv gpurun_out/p/hevc_pmc_WRITE_SIZE.csv gpurun_out/p/r01_hevc_pmc_traffic.json > /dev/null
 rm -f gpurun_out/p/pmc_*.csv gpurun_out/p/hevc_pmc_*.csv
 for f in gpurun_out/p/*.json; do echo $f; head -c 400 $f; echo; done
+for t in high high_b; do timeout 300 python bench.py --tools $t --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('tools $t', d['value'], d['host_ms_per_picture'], {k:(v['avg_us'], v['pictures_per_launch']) for k,v in d['kernels'].items()})"; done
