@@ -160,11 +160,42 @@ def main():
     pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
     for i in range(S):
         counts[i] = 0
+    def host_cpu():     # CPU seconds of this process, and the container's CPU quota / throttling (cgroup v2), if visible
+        import resource
+        ru = resource.getrusage(resource.RUSAGE_SELF)
+        d = {"cpu_s": ru.ru_utime + ru.ru_stime}
+        try:
+            for ln in open("/sys/fs/cgroup/cpu.stat"):
+                k, v = ln.split()
+                if k in ("nr_throttled", "throttled_usec"):
+                    d[k] = int(v)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            d["quota_cpus"] = None if q == "max" else round(int(q) / int(per), 2)
+        except Exception:
+            pass
+        return d
+    def thread_cpu():   # CPU seconds per thread name (user, system), from /proc
+        tick = os.sysconf("SC_CLK_TCK"); acc = {}
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                f = open(f"/proc/self/task/{tid}/stat").read()
+                name = f[f.index("(") + 1:f.rindex(")")]; rest = f[f.rindex(")") + 2:].split()
+                u, sy = int(rest[11]) / tick, int(rest[12]) / tick
+                a = acc.setdefault(name, [0.0, 0.0, 0]); a[0] += u; a[1] += sy; a[2] += 1
+        except Exception:
+            pass
+        return acc
     sync()
+    tc0 = thread_cpu()
+    hc0 = host_cpu()
     t0 = time.perf_counter()
     batch(K)
     sync()
     dt = time.perf_counter() - t0
+    hc1 = host_cpu()
+    tc1 = thread_cpu()
+    by_thread = {k: {"user_s": round(v[0] - tc0.get(k, [0, 0, 0])[0], 2), "sys_s": round(v[1] - tc0.get(k, [0, 0, 0])[1], 2), "threads": v[2]} for k, v in tc1.items()}
+    by_thread = {k: v for k, v in by_thread.items() if v["user_s"] + v["sys_s"] >= 0.05}
     frames_local = sum(counts)
 
     from jmcodec_amd import shard
@@ -268,6 +299,11 @@ def main():
         "frames": frames_total,
         "decode_errors": int(errors),
         "host_ms_per_picture": host_diag,
+        "host_cpu": {"cpu_s": round(hc1["cpu_s"] - hc0["cpu_s"], 3), "cpus_busy": round((hc1["cpu_s"] - hc0["cpu_s"]) / dt, 2),
+                     "cpu_ms_per_frame": round(1e3 * (hc1["cpu_s"] - hc0["cpu_s"]) / max(frames_local, 1), 4),
+                     "quota_cpus": hc1.get("quota_cpus"), "online_cpus": os.cpu_count(),
+                     "throttled_ms": round((hc1.get("throttled_usec", 0) - hc0.get("throttled_usec", 0)) / 1e3, 1), "by_thread": by_thread,
+                     "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": traffic,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),

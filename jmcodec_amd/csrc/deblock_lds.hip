@@ -9,17 +9,18 @@
 //
 //   k_deblock_prep   fully parallel: boundary strengths (8.7.2.1) and the alpha/beta/tC0 of every edge class
 //                    of every macroblock -> one 64-byte DbRec.  All divergent, table-driven work lives here.
-//   k_deblock_lds    ONE workgroup (16 waves) walks the steps in lockstep, one __syncthreads() per step.
-//                    Waves 0-7 filter luma, waves 8-15 chroma; 16 lanes per macroblock (lane = pixel row
-//                    for vertical edges, = pixel column for horizontal edges), so a whole edge chain of a
+//   k_deblock_band   one 4-wave workgroup per band of 16 macroblock rows walks the steps of its rows in lockstep, one s_barrier per
+//                    step; bands are chained downwards through step counters in device memory.  16 lanes per macroblock (lane =
+//                    pixel row for vertical edges, = pixel column for horizontal edges), so a whole edge chain of a
 //                    macroblock stays in registers.  Everything a neighbour still needs lives in LDS:
 //                      tile[row][x&1]   the macroblock's 16 rows after its own filtering (right 4 columns are
 //                                       the next macroblock's left border)
 //                      ring[row][x&3]   its bottom 4 rows (the macroblock below filters and finally stores them)
-//                    HBM traffic is the algorithmic minimum: every sample is read once (prefetched one step
+//                    HBM traffic is the algorithmic minimum: every sample is read once (prefetched DEPTH steps
 //                    ahead) and written once, as whole 16-byte row segments of a (-4,-4)-shifted 16x16 block.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
 #include "jobs.h"
 #include "kernels.h"
 #include "kernel_common.h"
@@ -95,33 +96,42 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
 // ------------------------------------------------------------------------------------------
 // sample filters on register arrays
 // ------------------------------------------------------------------------------------------
-// s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3
-__device__ __forceinline__ void flt_luma(int *s, int bS, int alpha, int beta, int tc0) {
-    int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
-    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
-    int ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
-    if (bS < 4) {
-        int tc = tc0 + ap + aq;
-        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        s[3] = clip1(p0 + delta); s[4] = clip1(q0 - delta);
-        if (ap) s[2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
-        if (aq) s[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
-    } else {
-        bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
-        if (ap && strong) { s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; s[2] = (p2 + p1 + p0 + q0 + 2) >> 2; s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; }
-        else s[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (aq && strong) { s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; s[5] = (p0 + q0 + q1 + q2 + 2) >> 2; s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3; }
-        else s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+// s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3; bsw = bS | tC0 << 3.  Written without divergent branches: the two filters of 8.7.2.3 / 8.7.2.4
+// are computed for every lane and selected, and the only branches are wave-uniform (nothing to filter / no lane with bS = 4).  The
+// branchy form cost ~10 exec-mask regions and, in the horizontal pass, ~110 register copies at the joins per edge.
+__device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }      // operands are evaluated by the caller: a v_cndmask, never a branch
+__device__ __forceinline__ void flt_luma(int *s, int bsw, int alpha, int beta) {
+    const int bS = bsw & 7, tc0 = bsw >> 3;
+    const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
+    const bool on = ((int)(bS != 0) & (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta)) != 0;
+    if (!__builtin_amdgcn_ballot_w64(on)) return;
+    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    const int tc = tc0 + (int)ap + (int)aq;
+    const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    const bool nrm = ((int)on & (int)(bS < 4)) != 0;
+    const int n_p0 = clip1(p0 + delta), n_q0 = clip1(q0 - delta);
+    const int n_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1), n_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+    int r_p0 = sel(nrm, n_p0, p0), r_q0 = sel(nrm, n_q0, q0), r_p1 = sel(((int)nrm & (int)ap) != 0, n_p1, p1), r_q1 = sel(((int)nrm & (int)aq) != 0, n_q1, q1), r_p2 = p2, r_q2 = q2;
+    const bool st = ((int)on & (int)(bS >= 4)) != 0;
+    if (__builtin_amdgcn_ballot_w64(st)) {
+        const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        const bool sp = ((int)st & (int)ap & (int)strong) != 0, sq = ((int)st & (int)aq & (int)strong) != 0;
+        const int w_p0 = (2 * p1 + p0 + q1 + 2) >> 2, w_q0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        const int s_p0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2, s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        const int s_q0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2, s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        r_p0 = sel(sp, s_p0, sel(st, w_p0, r_p0)); r_p1 = sel(sp, s_p1, r_p1); r_p2 = sel(sp, s_p2, r_p2);
+        r_q0 = sel(sq, s_q0, sel(st, w_q0, r_q0)); r_q1 = sel(sq, s_q1, r_q1); r_q2 = sel(sq, s_q2, r_q2);
     }
+    s[1] = r_p2; s[2] = r_p1; s[3] = r_p0; s[4] = r_q0; s[5] = r_q1; s[6] = r_q2;
 }
 // chroma: p1 p0 q0 q1 by reference
-__device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int bS, int alpha, int beta, int tc0) {
-    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
-    if (bS < 4) {
-        int tc = tc0 + 1;
-        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        p0 = clip1(p0 + delta); q0 = clip1(q0 - delta);
-    } else { int np = (2 * p1 + p0 + q1 + 2) >> 2, nq = (2 * q1 + q0 + p1 + 2) >> 2; p0 = np; q0 = nq; }
+__device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int bsw, int alpha, int beta) {
+    const int bS = bsw & 7, tc = (bsw >> 3) + 1;
+    const bool on = ((int)(bS != 0) & (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta)) != 0;
+    const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int n_p0 = clip1(p0 + delta), n_q0 = clip1(q0 - delta), w_p0 = (2 * p1 + p0 + q1 + 2) >> 2, w_q0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    p0 = sel(on, sel(bS < 4, n_p0, w_p0), p0); q0 = sel(on, sel(bS < 4, n_q0, w_q0), q0);
 }
 
 __device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
@@ -130,11 +140,8 @@ __device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] 
 //   lumaTile  [2][16][16]   = 512 B        chromaTile [2][8][16] = 256 B
 //   lumaRing  [4][4][16]    = 256 B        chromaRing [4][2][16] = 128 B
 // then 64 x 64 B staging for the DbRec of the macroblock each group is working on.
-constexpr int kGroups = 32;              // macroblock rows in flight per plane type: 8 waves x 4 groups
-constexpr int kMaxSlots = 5;             // rows g, g+32, ... g+128 -> pictures up to 160 MB rows (2560 lines)
-
-// Workgroup 0 (luma) and workgroup 1 (chroma) each own a private LDS image laid out the same way:
-// 32 x 64 B DbRec staging, then per macroblock row the tile pair, then per row the ring.
+// Luma and chroma workgroups each own a private LDS image laid out the same way:
+// DbRec staging per group, then per macroblock row the tile pair, then per row the ring.
 struct Lds {
     // Row strides are padded by 16 bytes (4 banks): the four macroblock rows one wave works on would otherwise sit exactly
     // 512 / 256 / 128 bytes apart, i.e. in the same LDS banks, and every byte-column access would be a 4-way bank conflict.
@@ -147,14 +154,31 @@ struct Lds {
     __device__ uint8_t *chroma_ring(int row, int slot) const { return base + hdr + (size_t)mb_h * kCT + (size_t)row * kCR + slot * 32; }
 };
 
+// What a macroblock step needs of the picture, fetched ONCE per workgroup.  The surface pointer is a global (address space 1) pointer:
+// a generic pointer read from PicParams makes every access a FLAT instruction, which counts on lgkmcnt as well as vmcnt, so each
+// wait for an LDS result also waited for the sample prefetches in flight; and reading pp.* inside the step put two dependent
+// global loads on the critical path of every step.
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+struct DbCtx { gbyte *plane; int pitch, mb_w, mb_h; };
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+#define JM_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ T gload(const gbyte *p);
+template <> __device__ __forceinline__ uint4 gload<uint4>(const gbyte *p) { v4u v = *(const JM_GLOBAL v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+template <> __device__ __forceinline__ uint32_t gload<uint32_t>(const gbyte *p) { return *(const JM_GLOBAL uint32_t *)p; }
+__device__ __forceinline__ void gstore(gbyte *p, uint4 v) { v4u t = {v.x, v.y, v.z, v.w}; *(JM_GLOBAL v4u *)p = t; }
+__device__ __forceinline__ void gstore(gbyte *p, uint2 v) { v2u t = {v.x, v.y}; *(JM_GLOBAL v2u *)p = t; }
+__device__ __forceinline__ void gstore(gbyte *p, uint32_t v) { *(JM_GLOBAL uint32_t *)p = v; }
+
 // ------------------------------------------------------------------------------------------
 // luma: one macroblock, 16 lanes (l = 0..15)
 // ------------------------------------------------------------------------------------------
-__device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int l, int group, uint4 own, uint32_t recdw) {
-    uint8_t *tc = lds.luma_tile(row, x & 1), *tp = lds.luma_tile(row, (x - 1) & 1);
-    uint8_t *ring_up = row > 0 ? lds.luma_ring(row - 1, x & 3) : nullptr;
-    uint8_t *ring_up_l = row > 0 ? lds.luma_ring(row - 1, (x - 1) & 3) : nullptr;
-    uint8_t *ring_dn = lds.luma_ring(row, x & 3), *ring_dn_l = lds.luma_ring(row, (x - 1) & 3);
+// row = macroblock row in the picture, lrow = the row's index in the workgroup's LDS image (== row when one workgroup holds the whole plane)
+__device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, int row, int lrow, int l, int group, uint4 own, uint32_t recdw) {
+    uint8_t *tc = lds.luma_tile(lrow, x & 1), *tp = lds.luma_tile(lrow, (x - 1) & 1);
+    uint8_t *ring_up = row > 0 ? lds.luma_ring(lrow - 1, x & 3) : nullptr;
+    uint8_t *ring_up_l = row > 0 ? lds.luma_ring(lrow - 1, (x - 1) & 3) : nullptr;
+    uint8_t *ring_dn = lds.luma_ring(lrow, x & 3), *ring_dn_l = lds.luma_ring(lrow, (x - 1) & 3);
     uint8_t *rec = lds.rec(group);
     if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte luma half of the DbRec
     // this lane's four vertical-edge and four horizontal-edge strengths (bS | tC0 << 3), and the class parameters
@@ -170,10 +194,7 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
 #pragma unroll
       for (int i = 0; i < 20; i++) p[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255; }
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        int bs = vb[e] & 7;
-        if (bs) { const int c = e ? 1 : 0; flt_luma(p + 4 * e, bs, ab[2 * c], ab[2 * c + 1], vb[e] >> 3); }
-    }
+    for (int e = 0; e < 4; e++) { const int c = e ? 1 : 0; flt_luma(p + 4 * e, vb[e], ab[2 * c], ab[2 * c + 1]); }
     uint32_t left_after = pack4(p);
     if (x > 0) *(uint32_t *)(tp + l * 16 + 12) = left_after;
     *(uint4 *)(tc + l * 16) = make_uint4(pack4(p + 4), pack4(p + 8), pack4(p + 12), pack4(p + 16));
@@ -186,10 +207,7 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
 #pragma unroll
     for (int j = 0; j < 16; j++) c[4 + j] = tc[j * 16 + l];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        int bs = hb[e] & 7;
-        if (bs) { const int k = e ? 1 : 2; flt_luma(c + 4 * e, bs, ab[2 * k], ab[2 * k + 1], hb[e] >> 3); }
-    }
+    for (int e = 0; e < 4; e++) { const int k = e ? 1 : 2; flt_luma(c + 4 * e, hb[e], ab[2 * k], ab[2 * k + 1]); }
     if (ring_up) {
 #pragma unroll
         for (int j = 1; j < 4; j++) ring_up[j * 16 + l] = (uint8_t)c[j];
@@ -199,7 +217,7 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
 #pragma unroll
     for (int j = 12; j < 16; j++) { tc[j * 16 + l] = (uint8_t)c[4 + j]; ring_dn[(j - 12) * 16 + l] = (uint8_t)c[4 + j]; }
     // ---- store the final (-4,-4)-shifted 16x16 block: lane -> row R = l - 4 ----
-    uint8_t *dst = pp.surf[pp.cur];
+    gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 16, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
     {
@@ -208,31 +226,31 @@ __device__ void luma_mb(const PicParams &pp, const Lds &lds, int x, int row, int
         if (R < 0) { src = ring_up ? ring_up + (R + 4) * 16 : nullptr; srcl = ring_up_l ? ring_up_l + (R + 4) * 16 + 12 : nullptr; }
         else { src = tc + R * 16; srcl = tp + R * 16 + 12; }
         if (src) {
-            uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+            gbyte *d = dst + (size_t)(y0 + R) * pitch + x0;
             uint4 v = *(const uint4 *)src;
-            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
-            else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
-            if (right) *(uint32_t *)(d + 12) = v.w;
+            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; gstore(d - 4, make_uint4(lf, v.x, v.y, v.z)); }
+            else { gstore(d, make_uint2(v.x, v.y)); gstore(d + 8, v.z); }
+            if (right) gstore(d + 12, v.w);
         }
     }
     if (bottom && l < 4) {
         int R = 12 + l;
-        uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+        gbyte *d = dst + (size_t)(y0 + R) * pitch + x0;
         uint4 v = *(const uint4 *)(tc + R * 16);
-        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
-        else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
-        if (right) *(uint32_t *)(d + 12) = v.w;
+        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); gstore(d - 4, make_uint4(lf, v.x, v.y, v.z)); }
+        else { gstore(d, make_uint2(v.x, v.y)); gstore(d + 8, v.z); }
+        if (right) gstore(d + 12, v.w);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // chroma (NV12 interleaved UV): one macroblock, 16 lanes
 // ------------------------------------------------------------------------------------------
-__device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, int l, int group, uint4 own, uint32_t recdw) {
-    uint8_t *tc = lds.chroma_tile(row, x & 1), *tp = lds.chroma_tile(row, (x - 1) & 1);
-    uint8_t *ring_up = row > 0 ? lds.chroma_ring(row - 1, x & 3) : nullptr;
-    uint8_t *ring_up_l = row > 0 ? lds.chroma_ring(row - 1, (x - 1) & 3) : nullptr;
-    uint8_t *ring_dn = lds.chroma_ring(row, x & 3), *ring_dn_l = lds.chroma_ring(row, (x - 1) & 3);
+__device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x, int row, int lrow, int l, int group, uint4 own, uint32_t recdw) {
+    uint8_t *tc = lds.chroma_tile(lrow, x & 1), *tp = lds.chroma_tile(lrow, (x - 1) & 1);
+    uint8_t *ring_up = row > 0 ? lds.chroma_ring(lrow - 1, x & 3) : nullptr;
+    uint8_t *ring_up_l = row > 0 ? lds.chroma_ring(lrow - 1, (x - 1) & 3) : nullptr;
+    uint8_t *ring_dn = lds.chroma_ring(lrow, x & 3), *ring_dn_l = lds.chroma_ring(lrow, (x - 1) & 3);
     uint8_t *rec = lds.rec(group);
     if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte chroma half of the DbRec
     // ---- vertical edges (chroma columns 0 and 4 <-> luma edges 0 and 2): lane = (plane, chroma row) ----
@@ -249,14 +267,14 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
         int ab[4] = { rec[32 + plane * 6], rec[32 + plane * 6 + 1], rec[32 + plane * 6 + 2], rec[32 + plane * 6 + 3] };
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-            int bs = vb[e >> 1] & 7;
-            if (!bs) continue;
             const int k = e ? 1 : 0;
             int o = 4 * e + plane;                                        // p1 = b[o], p0 = b[o+2], q0 = b[o+4], q1 = b[o+6]
             int p0 = b[o + 2], q0 = b[o + 4];
-            flt_chroma(b[o], p0, q0, b[o + 6], bs, ab[2 * k], ab[2 * k + 1], vb[e >> 1] >> 3);
-            if (e == 0) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
-            else { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
+            flt_chroma(b[o], p0, q0, b[o + 6], vb[e >> 1], ab[2 * k], ab[2 * k + 1]);
+            if (vb[e >> 1] & 7) {
+                if (e == 0) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
+                else { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
+            }
         }
     }
     // left neighbour's bottom rows: columns 12..15 (bytes) of rows 6, 7 after our edge 0
@@ -272,18 +290,16 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
         for (int j = 0; j < 8; j++) c[2 + j] = tc[j * 16 + l];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-            int bs = hb[e >> 1] & 7;
-            if (!bs) continue;
             const int k = e ? 1 : 0;                                      // ab[0..1] top class, ab[2..3] internal
             const int o = 2 * e;                                          // p1 = c[o], p0 = c[o+1], q0 = c[o+2], q1 = c[o+3]
-            flt_chroma(c[o], c[o + 1], c[o + 2], c[o + 3], bs, ab[2 * k], ab[2 * k + 1], hb[e >> 1] >> 3);
+            flt_chroma(c[o], c[o + 1], c[o + 2], c[o + 3], hb[e >> 1], ab[2 * k], ab[2 * k + 1]);
         }
         if (ring_up) ring_up[16 + l] = (uint8_t)c[1];
         tc[l] = (uint8_t)c[2]; tc[3 * 16 + l] = (uint8_t)c[5]; tc[4 * 16 + l] = (uint8_t)c[6];
         ring_dn[l] = (uint8_t)c[8]; ring_dn[16 + l] = (uint8_t)c[9];
     }
     // ---- store the (-2 px, -2 rows)-shifted 8 x 16-byte block: lanes 0..7 -> row R = l - 2 ----
-    uint8_t *dst = pp.surf[pp.cur] + pp.chroma_offset;
+    gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 8, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
     if (l < 8) {
@@ -292,124 +308,148 @@ __device__ void chroma_mb(const PicParams &pp, const Lds &lds, int x, int row, i
         if (R < 0) { src = ring_up ? ring_up + (R + 2) * 16 : nullptr; srcl = ring_up_l ? ring_up_l + (R + 2) * 16 + 12 : nullptr; }
         else { src = tc + R * 16; srcl = tp + R * 16 + 12; }
         if (src) {
-            uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+            gbyte *d = dst + (size_t)(y0 + R) * pitch + x0;
             uint4 v = *(const uint4 *)src;
-            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
-            else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
-            if (right) *(uint32_t *)(d + 12) = v.w;
+            if (x > 0) { uint32_t lf = *(const uint32_t *)srcl; gstore(d - 4, make_uint4(lf, v.x, v.y, v.z)); }
+            else { gstore(d, make_uint2(v.x, v.y)); gstore(d + 8, v.z); }
+            if (right) gstore(d + 12, v.w);
         }
     } else if (bottom && l < 10) {
         int R = 6 + (l - 8);
-        uint8_t *d = dst + (size_t)(y0 + R) * pitch + x0;
+        gbyte *d = dst + (size_t)(y0 + R) * pitch + x0;
         uint4 v = *(const uint4 *)(tc + R * 16);
-        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); *(uint4 *)(d - 4) = make_uint4(lf, v.x, v.y, v.z); }
-        else { *(uint2 *)d = make_uint2(v.x, v.y); *(uint32_t *)(d + 8) = v.z; }
-        if (right) *(uint32_t *)(d + 12) = v.w;
+        if (x > 0) { uint32_t lf = *(const uint32_t *)(tp + R * 16 + 12); gstore(d - 4, make_uint4(lf, v.x, v.y, v.z)); }
+        else { gstore(d, make_uint2(v.x, v.y)); gstore(d + 8, v.z); }
+        if (right) gstore(d + 12, v.w);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// grid = 2 workgroups of 512 threads: block 0 filters luma, block 1 chroma (independent planes, no exchange).
-// 512 threads = 2 waves per SIMD, so each lane may use up to 256 VGPRs: the edge chains never spill.
-// GROUPS 16-lane groups per workgroup (one macroblock row each per slot), NSLOTS rows per group.  (64, 3): 1024 threads = 4 waves
-// per SIMD hide the latency of the dependent filter chains, and at most one macroblock per group is active in a step for pictures
-// up to 64 rows tall / two up to 128 (instead of two / three with 32 groups); needs <= 128 VGPRs.  (32, 5): the 512-thread form.
-__device__ int g_dbg_noload = 0;     // experiment: skip the per-step global loads (timing only, output is wrong)
-// DEPTH = how many steps ahead samples and records are fetched: a step is shorter than a loaded HBM round trip, so with DEPTH 1 every
-// step waited for its own prefetch (0.71 ms without the loads against 1.11 ms with them, 32 x 1080p).
-template <int GROUPS, int NSLOTS, int DEPTH>
-__global__ __launch_bounds__(GROUPS * 16) void k_deblock_lds(const PicParams *pics) {
-    extern __shared__ __align__(16) uint8_t smem[];
+// A plane is cut into bands of kBandRows macroblock rows, one 4-wave workgroup (one wave per SIMD) per band, all bands of all pictures
+// resident at once (the first form of this kernel walked a whole plane with ONE 16-wave workgroup and needed 159 KB of LDS).  A band runs the same steps s = x + 2 * row for its own rows; the only
+// coupling is downwards: the last row of a band hands the bottom four sample rows of each macroblock (after its own filtering, i.e. the
+// state clause 8.7 prescribes when the macroblock below starts) to the first row of the next band.  They travel through the picture
+// surface itself (the band below overwrites them with the final values afterwards) and a per-band step counter in device memory:
+//     band b publishes "steps completed" every `pub` steps (release); band b+1 polls it (acquire) only when the value it last saw does not
+//     cover the step it is about to prefetch for, so in steady state it runs a few steps behind without waiting.
+// Workgroups of a lower band have the higher block index, so whatever a workgroup waits for has been dispatched before it.
+constexpr int kBandRows = 16;
+template <int DEPTH>
+__global__ __launch_bounds__(kBandRows * 16) void k_deblock_band(const PicParams *pics, int *progress, int prog_stride, int pub) {
+    __shared__ __align__(16) uint8_t smem[kBandRows * Lds::kRecStride + (kBandRows + 1) * (Lds::kLT + Lds::kLR)];
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_DEBLOCK_LDS)) return;
-    const DbRec *recs = (const DbRec *)pp.dbrec;
-    Lds lds{smem, pp.mb_h, GROUPS * Lds::kRecStride};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_chroma = blockIdx.x == 1;
-    const int group = wave * 4 + (lane >> 4), l = lane & 15;
+    const int band = blockIdx.x >> 1;
+    const bool is_chroma = blockIdx.x & 1;
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
-    const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
-    const int rows_per_mb = is_chroma ? 8 : 16;
+    const int row0 = band * kBandRows;
+    if (row0 >= mb_h) return;
+    const int rows = min(kBandRows, mb_h - row0);
+    int *prog = progress + (size_t)blockIdx.y * prog_stride + (is_chroma ? kDeblockMaxBands : 0);
+    const gbyte *recs = (const gbyte *)pp.dbrec;
+    Lds lds{smem, kBandRows + 1, kBandRows * Lds::kRecStride};
+    const int group = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int lrow = group + 1;
+    const bool active = group < rows;
+    const int row = row0 + (active ? group : 0);                             // idle groups shadow row0 (loads stay in bounds, nothing is used)
+    gbyte *plane = (gbyte *)(pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0));
+    const DbCtx cx{plane, pitch, mb_w, mb_h};
+    const int rows_per_mb = is_chroma ? 8 : 16, ring_rows = is_chroma ? 2 : 4;
     const int my_row = is_chroma ? (l & 7) : l;
     const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
-    uint4 pre_pix[DEPTH][NSLOTS]; uint32_t pre_rec[DEPTH][NSLOTS];
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) { pre_pix[d][k] = make_uint4(0, 0, 0, 0); pre_rec[d][k] = 0; }
-    const int n_steps = mb_w + 2 * (mb_h - 1);
-    const bool loads_on = !g_dbg_noload;
-    // stage d holds what step (s + d) needs; fill stages 0 .. DEPTH-1 for steps 0 .. DEPTH-1
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            int row = group + GROUPS * k, xn = d - 2 * row;
-            if (row < mb_h && xn >= 0 && xn < mb_w && loads_on) {
-                pre_pix[d][k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
-                pre_rec[d][k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
+    const bool takes_ring = band > 0 && group == 0;                        // first row of a lower band: ring rows come from the band above
+    const bool gives_ring = active && group == rows - 1 && row < mb_h - 1;  // last row of a band that has a band below
+    const int s_begin = 2 * row0, s_end = mb_w - 1 + 2 * (row0 + rows - 1);
+    int known = 0;                                                          // steps the band above is known to have completed
+    // Hand-over protocol without cache maintenance: the ring rows and the counter are written and read with agent-scope relaxed atomics
+    // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
+    // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
+    // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
+    auto wait_above = [&](int need) {
+        if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
+        int spins = 0;
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        asm volatile("" ::: "memory");
+    };
+    const int ring_lanes = ring_rows * 4;                                   // one dword per lane: ring row l >> 2, dword l & 3
+    const int ring_lane = l < ring_lanes ? l : 0;
+    const gbyte *pix_base = plane + (size_t)(row * rows_per_mb + my_row) * pitch;
+    const gbyte *rec_base = recs + (size_t)row * mb_w * sizeof(DbRec) + rec_dw * 4;
+    const gbyte *ring_base = plane + (size_t)(takes_ring ? row * rows_per_mb - ring_rows + (ring_lane >> 2) : 0) * pitch + (ring_lane & 3) * 4;
+    // The loads of a stage are unconditional (clamped coordinates) so that the number of memory operations between a load and its use is
+    // known at compile time: the wait in front of a step is then "all but the younger stages", not "everything".
+    uint4 pre_pix[DEPTH]; uint32_t pre_rec[DEPTH], pre_ring[DEPTH];
+    auto fetch = [&](int d, int s) {
+        int xn = min(max(s - 2 * row, 0), mb_w - 1);
+        pre_pix[d] = gload<uint4>(pix_base + xn * 16);
+        pre_rec[d] = gload<uint32_t>(rec_base + (size_t)xn * sizeof(DbRec));
+        if (band > 0) pre_ring[d] = __hip_atomic_load((const JM_GLOBAL uint32_t *)(ring_base + xn * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // ring rows of macroblock xm of this band's last row -> surface (write-through)
+    auto give = [&](const uint8_t *ring, int xm, int lane0) {
+        int k = l - lane0;
+        if (k < 0 || k >= ring_lanes) return;
+        uint32_t v = *(const uint32_t *)(ring + (k >> 2) * 16 + (k & 3) * 4);
+        __hip_atomic_store((JM_GLOBAL uint32_t *)(plane + (size_t)((row + 1) * rows_per_mb - ring_rows + (k >> 2)) * pitch + xm * 16) + (k & 3), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto step = [&](int s, uint4 own, uint32_t rdw, uint32_t ring) {
+        const int x = s - 2 * row;
+        if (active && x >= 0 && x < mb_w) {
+            if (is_chroma) {
+                if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                chroma_mb(cx, lds, x, row, lrow, l, group, own, rdw);
+                if (gives_ring) {
+                    if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                    if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
+                }
+            } else {
+                if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                luma_mb(cx, lds, x, row, lrow, l, group, own, rdw);
+                if (gives_ring) {
+                    if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                    if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
+                }
             }
         }
-    for (int s = 0; s < n_steps; s++) {
-        // (1) take delivery of stage 0 (fetched DEPTH steps ago).  The empty asm "uses" the registers, so the compiler's s_waitcnt
-        //     for exactly these loads lands HERE, before this step's loads are issued; younger stages stay in flight.
-        uint4 own[NSLOTS]; uint32_t rdw[NSLOTS];
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            own[k] = pre_pix[0][k]; rdw[k] = pre_rec[0][k];
-            asm volatile("" : "+v"(own[k].x), "+v"(own[k].y), "+v"(own[k].z), "+v"(own[k].w), "+v"(rdw[k]));
+        // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough
+        if (gives_ring && ((s + 1 - s_begin) % pub == 0 || s == s_end)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0) __hip_atomic_store(&prog[band], s == s_end ? 0x7fffffff : s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // (2) shift the stages and fetch for step s + DEPTH
-#pragma unroll
-        for (int d = 0; d + 1 < DEPTH; d++)
-#pragma unroll
-            for (int k = 0; k < NSLOTS; k++) { pre_pix[d][k] = pre_pix[d + 1][k]; pre_rec[d][k] = pre_rec[d + 1][k]; }
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            int row = group + GROUPS * k;
-            int xn = s + DEPTH - 2 * row;
-            if (row < mb_h && xn >= 0 && xn < mb_w && loads_on) {
-                pre_pix[DEPTH - 1][k] = *(const uint4 *)(plane_base + (size_t)(row * rows_per_mb + my_row) * pitch + xn * 16);
-                pre_rec[DEPTH - 1][k] = ((const uint32_t *)&recs[row * mb_w + xn])[rec_dw];
-            }
-        }
-        // (3) filter this step's macroblocks out of registers + LDS
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            int row = group + GROUPS * k;
-            int x = s - 2 * row;
-            if (row < mb_h && x >= 0 && x < mb_w) {
-                if (is_chroma) chroma_mb(pp, lds, x, row, l, group, own[k], rdw[k]);
-                else luma_mb(pp, lds, x, row, l, group, own[k], rdw[k]);
-            }
-        }
-        // (4) step barrier: only LDS traffic has to be complete (a __syncthreads() would also drain vmcnt,
-        //     i.e. wait for the prefetches that are in flight)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) pre_ring[d] = 0;
+    wait_above(s_begin + DEPTH);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fetch(d, s_begin + d);
+    // stage j of the unrolled body always lives in the same registers: no copies of registers that still wait for their load
+    for (int s = s_begin; s <= s_end; s += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            if (s + j > s_end) break;
+            uint4 own = pre_pix[j]; uint32_t rdw = pre_rec[j], ring = pre_ring[j];
+            asm volatile("" : "+v"(own.x), "+v"(own.y), "+v"(own.z), "+v"(own.w), "+v"(rdw), "+v"(ring));
+            wait_above(s + j + DEPTH);                // the ring rows of step s + j + DEPTH are final once the band above completed the step before it
+            fetch(j, s + j + DEPTH);
+            step(s + j, own, rdw, ring);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-size_t deblock_lds_bytes(int mb_h) { return 64 * Lds::kRecStride + (size_t)mb_h * (Lds::kLT + Lds::kLR); }      // luma workgroup's need (chroma needs half)
-bool deblock_lds_supported(int mb_w, int mb_h) { return mb_h <= kGroups * kMaxSlots && deblock_lds_bytes(mb_h) <= 160 * 1024 - 1024; }
+bool deblock_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kBandRows * kDeblockMaxBands; }
 
-void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st) {
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void *)k_deblock_lds<32, 5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        hipFuncSetAttribute((const void *)k_deblock_lds<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        hipFuncSetAttribute((const void *)k_deblock_lds<64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        attr_set[dev] = true;
-        if (getenv("JM_AMD_DEC_EXP_NOLOAD")) { int one = 1; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_noload), &one, sizeof one); }
-    }
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, int *progress, hipStream_t st) {
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)
-    static const bool wide = !getenv("JM_AMD_DEC_DEBLOCK_512");
-    static const bool deep = !getenv("JM_AMD_DEC_DEBLOCK_DEPTH1");
-    if (wide && deep && max_mb_h <= 128) hipLaunchKernelGGL((k_deblock_lds<64, 2, 2>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
-    else if (wide) hipLaunchKernelGGL((k_deblock_lds<64, 3, 1>), dim3(2, n), dim3(1024), deblock_lds_bytes(max_mb_h), st, d_pics);
-    else hipLaunchKernelGGL((k_deblock_lds<32, 5, 1>), dim3(2, n), dim3(512), deblock_lds_bytes(max_mb_h), st, d_pics);
+    static const int depth = getenv("JM_AMD_DEC_DEBLOCK_DEPTH") ? atoi(getenv("JM_AMD_DEC_DEBLOCK_DEPTH")) : 3;
+    static const int pub = getenv("JM_AMD_DEC_DEBLOCK_PUB") ? std::max(1, atoi(getenv("JM_AMD_DEC_DEBLOCK_PUB"))) : 2;
+    const int bands = (max_mb_h + kBandRows - 1) / kBandRows;
+    hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kDeblockProgressStride, st);
+    dim3 grid(2 * bands, n), block(kBandRows * 16);
+    if (depth <= 2) hipLaunchKernelGGL((k_deblock_band<2>), grid, block, 0, st, d_pics, progress, kDeblockProgressStride, pub);
+    else if (depth == 3) hipLaunchKernelGGL((k_deblock_band<3>), grid, block, 0, st, d_pics, progress, kDeblockProgressStride, pub);
+    else hipLaunchKernelGGL((k_deblock_band<4>), grid, block, 0, st, d_pics, progress, kDeblockProgressStride, pub);
 }
 
 }  // namespace jmamd

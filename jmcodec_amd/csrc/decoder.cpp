@@ -1,5 +1,6 @@
 // jmcodec_amd/csrc/decoder.cpp -- see decoder.h.
 #include "decoder.h"
+#include <pthread.h>
 #include "engine.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
@@ -27,7 +28,7 @@ struct Pool {
         n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
         if (n < 1) n = 1;
         if (n > 64) n = 64;
-        for (int i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+        for (int i = 0; i < n; i++) threads.emplace_back([this] { pthread_setname_np(pthread_self(), "jm-parse"); run(); });
         for (auto &t : threads) t.detach();
     }
     void run() {

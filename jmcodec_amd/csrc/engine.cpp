@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "hevc_kernels.h"
 #include <hip/hip_runtime_api.h>
+#include <pthread.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -50,7 +51,7 @@ Engine::Engine(int device) : device_(device) {
         }
     }
     ok_ = true;
-    th_ = std::thread([this] { run(); });
+    th_ = std::thread([this] { pthread_setname_np(pthread_self(), "jm-engine"); run(); });
     th_.detach();
 }
 
@@ -161,7 +162,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
-    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, st); b.pmask |= 8; }
+    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, b.d_progress, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);
     hipEventRecord(b.kdone, st);

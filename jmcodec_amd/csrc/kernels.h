@@ -12,7 +12,9 @@ void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);            
 bool intra_lds_supported(int mb_w, int mb_h);
 void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st);
 bool deblock_lds_supported(int mb_w, int mb_h);
-void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, hipStream_t st);   // prep + LDS wavefront
+constexpr int kDeblockMaxBands = 32, kDeblockProgressStride = 2 * kDeblockMaxBands;
+// prep + LDS wavefront; progress: device array of n * kDeblockProgressStride ints (band step counters, cleared by this call)
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, int *progress, hipStream_t st);
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
 // tight I420 (fmt 1) / NV12 (fmt 0) frame in device memory -> ARGB32 in device memory

@@ -42,7 +42,7 @@ void launch_packout(const PackJob *, int, int, int, ihipStream_t *) { abort(); }
 void launch_recon_inter(const PicParams *, int, int, ihipStream_t *) { abort(); }
 void launch_intra_lds(const PicParams *, int, int, ihipStream_t *) { abort(); }
 void launch_recon_intra(const PicParams *, int, ihipStream_t *) { abort(); }
-void launch_deblock_lds(const PicParams *, int, int, int, ihipStream_t *) { abort(); }
+void launch_deblock_lds(const PicParams *, int, int, int, int *, ihipStream_t *) { abort(); }
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 }
 namespace jmamd { void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); } }
