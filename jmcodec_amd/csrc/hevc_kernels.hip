@@ -213,7 +213,9 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         if (threadIdx.x == 0) {
             const int need = cx + 2 < pp.ctb_w ? cx + 2 : pp.ctb_w;
             int spins = 0;
-            while (__hip_atomic_load(&prog[cy - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(4);
+            // relaxed polls: an acquire load invalidates the XCD's L2 on EVERY iteration (the same finding as in deblock_lds.hip); one acquire fence
+            // after the wait is enough
+            while (__hip_atomic_load(&prog[cy - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
         __atomic_thread_fence(__ATOMIC_ACQUIRE);

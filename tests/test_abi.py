@@ -113,5 +113,5 @@ def test_reference_intel_harness_links_against_the_library():
         src = os.path.join(td, "in.h264")
         open(src, "wb").write(golden_stream("ip_fuzz_96x80"))
         env = dict(os.environ, JM_AMD_DEC_PARSE_ONLY="1")
-        r = subprocess.run([exe, src], capture_output=True, text=True, env=env, timeout=60)
+        r = subprocess.run([exe, src], capture_output=True, text=True, env=env, timeout=60, cwd=td)   # the harness opens its hard-coded output name in the cwd
         assert "Frame Count:\t8" in r.stdout, r.stdout + r.stderr
