@@ -132,11 +132,15 @@ struct P {
     const char *err = nullptr;
 
     void locate(int a) {
-        addr = a; mb_x = a % mb_w; mb_y = a / mb_w;
-        auto av = [&](int x, int y) -> int {
-            if (x < 0 || y < 0 || x >= mb_w || y >= cx.mb_h) return -1;
-            int i = y * mb_w + x; return cx.slice_of[i] == slice_num ? i : -1; };
-        nA = av(mb_x - 1, mb_y); nB = av(mb_x, mb_y - 1); nC = av(mb_x + 1, mb_y - 1); nD = av(mb_x - 1, mb_y - 1);
+        if (a == addr + 1 && mb_x + 1 < mb_w) mb_x++; else { mb_x = a % mb_w; mb_y = a / mb_w; }      // raster successor: no division
+        addr = a;
+        const int16_t *so = cx.slice_of.data();
+        const int16_t sn = (int16_t)slice_num;
+        nA = (mb_x > 0 && so[a - 1] == sn) ? a - 1 : -1;
+        if (mb_y > 0) {
+            const int b = a - mb_w;
+            nB = so[b] == sn ? b : -1; nC = (mb_x + 1 < mb_w && so[b + 1] == sn) ? b + 1 : -1; nD = (mb_x > 0 && so[b - 1] == sn) ? b - 1 : -1;
+        } else nB = nC = nD = -1;
         tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16]; mvd = &cx.mvd[(size_t)a * 32];
         mvl[0] = mv; mvl[1] = &cx.mv1[(size_t)a * 32]; refl[0] = ref; refl[1] = &cx.refidx1[(size_t)a * 4]; mvdl[0] = mvd; mvdl[1] = &cx.mvd1[(size_t)a * 32];
     }
@@ -251,6 +255,13 @@ struct P {
         else { px = med(A.mvx, B.mvx, C.mvx); py = med(A.mvy, B.mvy, C.mvy); }
     }
     void set_mv(int bx, int by, int bw, int bh, int x, int y, int l = 0) {
+        if (bw == 4 && bh == 4) {                              // whole macroblock: 16 identical pairs
+            const uint32_t v = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
+            uint32_t *d = (uint32_t *)mvl[l];
+            for (int i = 0; i < 16; i++) d[i] = v;
+            decoded_mask = 0xffff;
+            return;
+        }
         for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvl[l][(j * 4 + i) * 2] = (int16_t)x; mvl[l][(j * 4 + i) * 2 + 1] = (int16_t)y; decoded_mask |= 1u << (j * 4 + i); }
     }
 
