@@ -46,6 +46,12 @@ public:
         uint32_t top = (uint32_t)(cache_ >> 32);
         if (top == 0) { skip(32); error_ = true; return 0; }
         int lz = __builtin_clz(top);
+        if (lz <= 15) {                 // the whole codeword (2 * lz + 1 <= 31 bits) is inside the 32 bits just checked
+            const int len = 2 * lz + 1;
+            uint32_t v = top >> (32 - len);
+            skip(len);
+            return v - 1;
+        }
         skip(lz);                       // now positioned at the leading 1
         if (avail_ < lz + 1) refill();
         uint32_t v = (uint32_t)(cache_ >> (63 - lz));   // lz+1 bits including the leading 1

@@ -734,7 +734,6 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER;
     { int8_t c = -1; for (auto &s : t->slices) if (s.sh.type != SL_I && s.refs.slot[0][0] >= 0) { c = s.refs.slot[0][0]; break; }
       blank.ref[0] = blank.ref[1] = blank.ref[2] = blank.ref[3] = c; }
-    for (int i = 0; i < n_mbs; i++) mbs[i] = blank;
     JobWriter w;
     w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * (big_rec ? kBiRecInt16 / 2 : 16);
     w.coef = coef;
@@ -755,6 +754,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
         if (r.error) { t->error = r.error; stat_errors_++; }
     }
+    for (int i = 0; i < n_mbs; i++) if (scratch.slice_of[i] < 0) mbs[i] = blank;      // only what no slice covered (normally nothing)
     if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)
     t->n_slices = (int)t->slices.size();
     if (t->mf) {                                             // publish this picture's motion for direct prediction in later B pictures

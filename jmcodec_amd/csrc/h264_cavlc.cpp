@@ -162,8 +162,9 @@ struct P {
         return a >= 0 ? a : (b >= 0 ? b : 0);
     }
 
-    // residual_block_cavlc: levels written at dst[map[scan_pos + first]]; returns total_coeff or -1
-    int residual_block(int nCtx, int max_num, int first, int16_t *dst, const uint8_t *map) {
+    // residual_block_cavlc: levels written at dst[map[scan_pos + first]]; returns total_coeff or -1.  dst is zeroed here, and only when the
+    // block has levels (an empty block -- the common case inside a coded 8x8 -- costs the coeff_token lookup and nothing else)
+    __attribute__((always_inline)) inline int residual_block(int nCtx, int max_num, int first, int16_t *dst, const uint8_t *map) {
         uint32_t e;
         if (nCtx < 0) { e = g_cdc[br.peek(8)]; }
         else if (nCtx >= 8) { e = g_tok_flc[br.peek(6)]; }
@@ -179,6 +180,10 @@ struct P {
         int total = (int)(e >> 10), t1 = (e >> 8) & 3;
         if (total == 0) return 0;
         if (total > max_num) return -1;
+        return residual_levels(total, t1, max_num, first, dst, map);
+    }
+    __attribute__((noinline)) int residual_levels(int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) {
+        memset(dst, 0, max_num == 4 ? 8 : 32);
         int level[16];
         int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
         int i = 0;
@@ -631,8 +636,8 @@ struct P {
                 // parse into the stream tail; keep the 16 slots only if the block turns out non-empty
                 if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
                 int16_t *d = out.coef + out.coef_count;
-                memset(d, 0, 32);
                 int n;
+                if (cb) memset(d, 0, 32);
                 if (cb) n = residual_block_ae(i16 ? 1 : 2, by * 4 + bx, cbf_luma_nb(bx, by, true), cbf_luma_nb(bx, by, false), i16 ? 15 : 16, i16 ? 1 : 0, d, kZigzag4, intra);
                 else n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
                 if (n < 0) { if (!err) err = "entropy error (luma block)"; return false; }
@@ -644,8 +649,9 @@ struct P {
         if (cbp & 0x30) {
             for (int pl = 0; pl < 2; pl++) {
                 if (out.coef_count + 4 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
-                int16_t *d = out.coef + out.coef_count; memset(d, 0, 8);
+                int16_t *d = out.coef + out.coef_count;
                 int n;
+                if (cb) memset(d, 0, 8);
                 if (cb) n = residual_block_ae(3, 17 + pl, nA >= 0 ? (int)((cx.cbf[nA] >> (17 + pl)) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> (17 + pl)) & 1) : -1, 4, 0, d, ident, intra);
                 else n = residual_block(-1, 4, 0, d, ident);
                 if (n < 0) { if (!err) err = "entropy error (chroma DC)"; return false; }
@@ -656,9 +662,10 @@ struct P {
             uint32_t cbm = 0;
             for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
                 if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
-                int16_t *d = out.coef + out.coef_count; memset(d, 0, 32);
+                int16_t *d = out.coef + out.coef_count;
                 int n;
                 if (cb) {
+                    memset(d, 0, 32);
                     int bx = k & 1, by = k >> 1, b0 = 19 + pl * 4, fa, fb;
                     if (bx) fa = (int)((cx.cbf[addr] >> (b0 + by * 2)) & 1); else fa = nA >= 0 ? (int)((cx.cbf[nA] >> (b0 + by * 2 + 1)) & 1) : -1;
                     if (by) fb = (int)((cx.cbf[addr] >> (b0 + bx)) & 1); else fb = nB >= 0 ? (int)((cx.cbf[nB] >> (b0 + 2 + bx)) & 1) : -1;
