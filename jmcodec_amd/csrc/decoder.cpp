@@ -26,6 +26,15 @@ struct Pool {
     Pool() {
         const char *e = getenv("JM_AMD_DEC_THREADS");
         n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (!e) {
+            // A container may see every CPU of the machine but own a small CFS quota (cgroup v2 cpu.max: "<quota> <period>"): a worker per
+            // visible CPU then only buys throttling stalls.  Size the pool to the quota, with headroom for workers blocked on job slots.
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                long long q = 0, per = 0; char qs[32] = {0};
+                if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); int lim = (int)((q * 7 / 4 + per - 1) / per); if (lim < 4) lim = 4; if (n > lim) n = lim; }
+                fclose(f);
+            }
+        }
         if (n < 1) n = 1;
         if (n > 64) n = 64;
         for (int i = 0; i < n; i++) threads.emplace_back([this] { pthread_setname_np(pthread_self(), "jm-parse"); run(); });
@@ -960,7 +969,7 @@ int Decoder::output(uint8_t *out, int *out_len) {
     int need = cur_out_->w * cur_out_->h * 3 / 2;
     if (*out_len < need) return -2;
     *out_len = 0;
-    if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);
+    if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
     else if (cur_out_->has_data) { hipSetDevice(device_); if (hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess) return -1; }   // device_output mode: convenience copy
     else memset(out, 0, (size_t)need);
     *out_len = need;
