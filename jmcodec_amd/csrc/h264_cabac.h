@@ -15,6 +15,19 @@
 
 namespace jmamd {
 
+// next state by ((pStateIdx << 1 | valMPS) << 1 | "the bin was the least probable symbol") (Table 9-45 transIdxLps / transIdxMps)
+struct CabacTrans {
+    uint8_t t[256];
+    CabacTrans() : t() {
+        for (int s = 0; s < 128; s++) {
+            const int st = s >> 1, mps = s & 1;
+            t[2 * s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
+            t[2 * s + 1] = (uint8_t)((cabac_trans_lps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
+        }
+    }
+};
+static const CabacTrans kCabacTrans;       // 256 bytes per translation unit, filled before main
+
 struct Cabac {
     uint64_t val = 0; int pos = 0;
     uint32_t range = 510;
@@ -46,25 +59,23 @@ struct Cabac {
     // bits the arithmetic decoder of 9.3.1.2 / 9.3.3.2 has read so far (9 at initialisation + 1 per renormalisation shift)
     inline size_t bits_consumed() const { return (size_t)(ptr - start) * 8 - (size_t)pos; }
 
+    // 9.3.3.2.1, without a branch on the decoded symbol (it is the least predictable branch of the whole parser): `m` is all ones when the
+    // offset lies in the LPS sub-interval and selects offset, range, next state and bin value arithmetically
     inline int decision(int ctx) {
-        uint32_t s = state[ctx], st = s >> 1, mps = s & 1;
-        uint32_t lps = cabac_range_lps[st][(range >> 6) & 3];
-        range -= lps;
-        uint64_t scaled = (uint64_t)range << pos;
-        int bin;
-        if (val < scaled) {                                     // most probable symbol
-            state[ctx] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
-            if (range < 256) { range <<= 1; pos--; }
-            bin = (int)mps;
-        } else {
-            val -= scaled; range = lps;
-            state[ctx] = (uint8_t)((cabac_trans_lps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
-            int sh = __builtin_clz(range) - 23;                 // range in [6, 240] -> shift that brings it back into [256, 511]
-            range <<= sh; pos -= sh;
-            bin = (int)(mps ^ 1);
-        }
+        const uint8_t *const tr = kCabacTrans.t;
+        const uint32_t s = state[ctx];
+        const uint32_t lps = cabac_range_lps[s >> 1][(range >> 6) & 3];
+        const uint32_t rm = range - lps;
+        const uint64_t scaled = (uint64_t)rm << pos;
+        const uint64_t m = (uint64_t)((int64_t)(scaled - val - 1) >> 63);
+        const uint32_t m32 = (uint32_t)m;
+        val -= scaled & m;
+        const uint32_t r = rm ^ ((rm ^ lps) & m32);
+        state[ctx] = tr[2 * s + (m32 & 1)];
+        const int sh = __builtin_clz(r) - 23;                   // MPS: 0 or 1 (range stays >= 128); LPS: range in [6, 240] -> back into [256, 511]
+        range = r << sh; pos -= sh;
         if (pos < 16) refill();
-        return bin;
+        return (int)((s ^ m32) & 1);
     }
     inline int bypass() {
         pos--;

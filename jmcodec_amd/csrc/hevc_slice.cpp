@@ -15,12 +15,22 @@ enum { PART_2Nx2N, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_
 struct ScanTables {
     uint8_t t[3][4][64];
     uint8_t inv[3][4][64];            // position x | y << 3 -> scan index
+    uint8_t sigpat[3][5][16];         // sigCtx pattern term (9.3.4.2.5) by [scanIdx][prevCsbf 0..3, 4 = the 4x4 map][scan position in the sub-block]
     ScanTables() {
         for (int l = 0; l <= 3; l++) {
             int n = 1 << l, k = 0;
             for (int s = 0; s <= 2 * (n - 1); s++) for (int x = 0; x <= s; x++) { int y = s - x; if (x < n && y < n) t[0][l][k++] = (uint8_t)(x | (y << 4)); }
             for (int i = 0; i < n * n; i++) { t[1][l][i] = (uint8_t)((i & (n - 1)) | ((i >> l) << 4)); t[2][l][i] = (uint8_t)((i >> l) | ((i & (n - 1)) << 4)); }
             for (int sidx = 0; sidx < 3; sidx++) for (int i = 0; i < n * n; i++) inv[sidx][l][(t[sidx][l][i] & 15) | ((t[sidx][l][i] >> 4) << 3)] = (uint8_t)i;
+        }
+        static const uint8_t map4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
+        for (int sidx = 0; sidx < 3; sidx++) for (int k = 0; k < 16; k++) {
+            const int xq = t[sidx][2][k] & 15, yq = t[sidx][2][k] >> 4;
+            sigpat[sidx][0][k] = (uint8_t)(xq + yq == 0 ? 2 : (xq + yq < 3 ? 1 : 0));
+            sigpat[sidx][1][k] = (uint8_t)(yq == 0 ? 2 : (yq == 1 ? 1 : 0));
+            sigpat[sidx][2][k] = (uint8_t)(xq == 0 ? 2 : (xq == 1 ? 1 : 0));
+            sigpat[sidx][3][k] = 2;
+            sigpat[sidx][4][k] = map4[(yq << 2) + xq];
         }
     }
 };
@@ -336,17 +346,14 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         int start = 15;
         if (i == last_sb) { start = last_pos - 1; sig = (uint16_t)(1u << last_pos); }
         const int prev = right | (below << 1);
-        for (int k = start; k >= 0; k--) {
-            if (k == 0 && infer_dc) { sig |= 1; break; }
-            const int xq = pos_scan[k] & 15, yq = pos_scan[k] >> 4;
-            int sc;
-            if (log2 == 2) sc = kSigMap4x4[(yq << 2) + xq];
-            else if (k == 0 && i == 0) sc = 0;
-            else {
-                sc = prev == 0 ? (xq + yq == 0 ? 2 : (xq + yq < 3 ? 1 : 0)) : prev == 1 ? (yq == 0 ? 2 : (yq == 1 ? 1 : 0)) : prev == 2 ? (xq == 0 ? 2 : (xq == 1 ? 1 : 0)) : 2;
-                if (c == 0) { if (i > 0) sc += 3; sc += log2 == 3 ? (scan == 0 ? 9 : 15) : 21; } else sc += log2 == 3 ? 9 : 12;
-            }
-            if (cb_.decision(HEVC_CTX_SIG + (c ? 27 + sc : sc))) { sig |= (uint16_t)(1u << k); infer_dc = false; }
+        // sig_coeff_flag context = per-sub-block base + a table term by scan position; only the DC of the whole block is special
+        const uint8_t *pat = kScan.sigpat[scan][log2 == 2 ? 4 : prev];
+        const int sig0 = HEVC_CTX_SIG + (c ? 27 : 0);
+        const int sbase = log2 == 2 ? sig0 : (c == 0 ? HEVC_CTX_SIG + (i > 0 ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21) : HEVC_CTX_SIG + 27 + (log2 == 3 ? 9 : 12));
+        for (int k = start; k >= 1; k--) if (cb_.decision(sbase + pat[k])) { sig |= (uint16_t)(1u << k); infer_dc = false; }
+        if (start >= 0) {
+            if (infer_dc) sig |= 1;
+            else if (cb_.decision((log2 > 2 && i == 0) ? sig0 : sbase + pat[0])) sig |= 1;
         }
         if (!sig) continue;
         int pos[16], np = 0;
