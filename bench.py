@@ -238,7 +238,7 @@ def main():
         else:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc["k_intra_lds"]["traffic_upper"],
-                       "deblock": pmc["k_deblock_lds"]["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
+                       "deblock": pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"traffic_upper": 0}))["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
         if (args.width, args.height) == (1920, 1080):
             traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
     except Exception:

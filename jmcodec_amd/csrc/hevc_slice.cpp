@@ -35,7 +35,6 @@ struct ScanTables {
     }
 };
 const ScanTables kScan;
-const uint8_t kSigMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 
 inline int mv_scale(int mv, int td, int tb) {                         // (8-179) ff.
     td = clip3(-128, 127, td); tb = clip3(-128, 127, tb);

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/p
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/p/gpu_tests_tail.txt
 # H.264 headline: bench line, rocprof kernel stats, PMC traffic
 timeout 400 python bench.py > gpurun_out/p/r01_bench.json 2> gpurun_out/p/r01_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_a -- python3 bench.py --no-cpu-baseline > gpurun_out/p/r01_bench_under_rocprof.json 2>/dev/null
