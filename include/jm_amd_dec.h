@@ -37,7 +37,7 @@ extern "C" {
 typedef void *jm_amddec_handle;
 
 jm_amddec_handle jm_amddec_create_handle(void);
-/* codec_type: 0 = H.264 (1 = H.265 reserved); out_fmt: 0 = NV12, 1 = "YV12" = planar Y,U,V */
+/* codec_type: 0 = H.264, 1 = H.265 / HEVC Main (enum nv_dec.h:37-46); out_fmt: 0 = NV12, 1 = "YV12" = planar Y,U,V */
 int  jm_amddec_init(int codec_type, int out_fmt, char *extra_data, int len, jm_amddec_handle h);
 int  jm_amddec_deinit(jm_amddec_handle h);
 /* in_buf may hold any chunk of an Annex-B stream; (NULL, 0) signals end of stream and then
@@ -77,6 +77,15 @@ int  jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h);
 int  jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h);
 int  jm_amddec_packout_device(const void *d_src, int pitch, int width, int height, int out_fmt,
                               void *d_dst, void *stream);
+/* SURVEY 8f f4 -- the encoder-side pre-processing of the reference (/root/reference/nv_enc/nv_enc.cpp:1022-1079: cuMemcpy2D of the luma plane +
+ * the InterleaveUV kernel; the CPU loop of intel_enc.cpp:316-387) as one HIP kernel, device to device: a tight frame (src_fmt 1 = I420
+ * planar Y,U,V; 0 = tight NV12) becomes a pitch-linear NV12 surface (luma rows at `pitch`, interleaved UV rows from row `height`), the layout an
+ * encoder's input surface has.  width and height must be even, pitch >= width.
+ *   jm_amddec_i420_to_nv12_device: stand-alone (any device frame).  stream: a hipStream_t or NULL.  Returns 0 or -1.
+ *   jm_amddec_output_nv12_pitch_device: the same for the decoder's current display frame -- decode -> encoder surface without touching the host
+ *     (the first half of the transcode loop the reference's README leaves unfinished).  Returns 0, or -1 when no frame is current. */
+int  jm_amddec_i420_to_nv12_device(const void *d_src, int width, int height, int src_fmt, void *d_dst, int pitch, void *stream);
+int  jm_amddec_output_nv12_pitch_device(void *dev_dst, int pitch, jm_amddec_handle h);
 
 /* The hot loop of the reference harness in native code (/root/reference/test_nv_dec/test_nv_dec.cpp:184-250): feed the Annex-B buffer one
  * NAL unit per jm_nvdec_decode_frame call (a NAL = start code + payload up to the next start code, :63-86), fetch a frame with

@@ -996,4 +996,11 @@ int Decoder::stream_info(int *w, int *h) const {
     return 0;
 }
 
+int Decoder::output_nv12_pitch_device(void *dev_dst, int pitch) {
+    if (!cur_out_ || !cur_out_->has_data || !cur_out_->dev || pitch < cur_out_->w) return -1;
+    hipSetDevice(device_);
+    launch_frame_to_nv12_pitch(cur_out_->dev, cur_out_->w, cur_out_->h, out_fmt_, (uint8_t *)dev_dst, pitch, nullptr);
+    return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : -1;
+}
+
 }  // namespace jmamd

@@ -97,6 +97,7 @@ public:
     int  output(uint8_t *out, int *out_len);
     int  output_device(void **dev, int *len);
     int  output_argb_device(void *dev_dst, int pitch);
+    int  output_nv12_pitch_device(void *dev_dst, int pitch);
     int  stream_info(int *w, int *h) const;
     void set_eof(bool e) { eof_flag_ = e; }
     bool is_exit() const { return is_exit_; }

@@ -49,6 +49,12 @@ __attribute__((visibility("default"))) long long jm_amddec_get_stat(jm_amddec_ha
 __attribute__((visibility("default"))) const char *jm_amddec_last_error(jm_amddec_handle h) { return D(h)->last_error(); }
 __attribute__((visibility("default"))) int jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h) { return (h && dev && len) ? D(h)->output_device(dev, len) : -1; }
 __attribute__((visibility("default"))) int jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h) { return (h && dev_dst) ? D(h)->output_argb_device(dev_dst, pitch) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_output_nv12_pitch_device(void *dev_dst, int pitch, jm_amddec_handle h) { return (h && dev_dst) ? D(h)->output_nv12_pitch_device(dev_dst, pitch) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_i420_to_nv12_device(const void *d_src, int width, int height, int src_fmt, void *d_dst, int pitch, void *stream) {
+    if (!d_src || !d_dst || width <= 0 || height <= 0 || (width & 1) || (height & 1) || pitch < width || (src_fmt != 0 && src_fmt != 1)) return -1;
+    jmamd::launch_frame_to_nv12_pitch((const uint8_t *)d_src, width, height, src_fmt, (uint8_t *)d_dst, pitch, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *src, int pitch, int w, int hgt, int fmt, void *dst, void *stream) {
     jmamd::PackJob job{static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), pitch, pitch * hgt, w, hgt, fmt, 0};
     jmamd::PackJob *d_job = nullptr;

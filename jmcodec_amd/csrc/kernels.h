@@ -19,4 +19,5 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
 // tight I420 (fmt 1) / NV12 (fmt 0) frame in device memory -> ARGB32 in device memory
 void launch_frame_to_argb(const uint8_t *d_src, int w, int h, int fmt, uint8_t *d_dst, int dst_pitch, hipStream_t st);
+void launch_frame_to_nv12_pitch(const uint8_t *d_src, int w, int h, int fmt, uint8_t *d_dst, int pitch, hipStream_t st);   // tight I420 / NV12 -> pitch NV12 (encoder input)
 }  // namespace jmamd

@@ -976,6 +976,32 @@ void launch_frame_to_argb(const uint8_t *d_src, int w, int h, int fmt, uint8_t *
     hipLaunchKernelGGL(k_frame_to_argb, dim3((w / 2 + 255) / 256, h), dim3(256), 0, st, d_src, w, h, fmt, d_dst, dst_pitch);
 }
 
+// SURVEY 8f f4 -- the encoder-side pre-processing of the reference as a HIP kernel: tight I420 (or tight NV12) frame -> pitch-linear NV12
+// surface, i.e. the cuMemcpy2D of the luma plane plus the "InterleaveUV" kernel of /root/reference/nv_enc/nv_enc.cpp:1022-1079 (arguments
+// U, V, dst chroma, chroma width / height, source strides, dst stride) in one launch, device to device.  It is the inverse of k_packout.
+// One thread per 4 output bytes of a row (luma rows first, then the h/2 interleaved chroma rows).
+__global__ __launch_bounds__(256) void k_frame_to_nv12_pitch(const uint8_t *src, int w, int h, int fmt, uint8_t *dst, int pitch) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, row = blockIdx.y;
+    if (x >= w) return;
+    uint8_t *o = dst + (size_t)row * pitch + x;
+    uint8_t v[4];
+    if (row < h || fmt == 0) {                                   // luma row, or an already interleaved chroma row: plain copy
+        const uint8_t *i = src + (size_t)row * w + x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = x + k < w ? i[k] : 0;
+    } else {                                                     // chroma row r: bytes 2c, 2c+1 = U[r][c], V[r][c]
+        const int cw = w >> 1, r = row - h;
+        const uint8_t *pu = src + (size_t)w * h + (size_t)r * cw, *pv = pu + (size_t)cw * (h >> 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int c = (x + k) >> 1; v[k] = x + k < w ? (((x + k) & 1) ? pv[c] : pu[c]) : 0; }
+    }
+    if (x + 4 <= w && !(pitch & 3)) *(uint32_t *)o = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    else for (int k = 0; k < 4 && x + k < w; k++) o[k] = v[k];
+}
+void launch_frame_to_nv12_pitch(const uint8_t *d_src, int w, int h, int fmt, uint8_t *d_dst, int pitch, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_to_nv12_pitch, dim3(((w + 3) / 4 + 255) / 256, h + h / 2), dim3(256), 0, st, d_src, w, h, fmt, d_dst, pitch);
+}
+
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st) {
     int chunks = ((max_width + 15) >> 4) * (max_height + (max_height >> 1));
     int blocks = (chunks + 255) / 256;

@@ -227,7 +227,7 @@ def test_packout_kernel_vs_oracle(oracle, w, h, pitch, fmt):
 
 
 def test_4k_picture_size(oracle):
-    """3840x2160 (240 x 135 macroblocks, 5 wavefront slots, 106 KB of LDS in the deblock kernel)."""
+    """3840x2160 (240 x 135 macroblocks: 9 chained bands per plane in the deblock kernel, 5 wavefront slots in the intra kernel)."""
     data = streams.generate(width=3840, height=2160, frames=2, gop=2, seed=0x4A4D0200, level_idc=51)
     want, n, w, h = oracle.decode(data, 1)
     assert (n, w, h) == (2, 3840, 2160)
@@ -390,6 +390,79 @@ def test_device_resident_output_and_argb(oracle):
                 assert count == n
         finally:
             hip.hipFree(d_argb)
+
+
+def _nv12_pitch_restated(frame, w, h, fmt, pitch):
+    """numpy restatement of nv_enc.cpp:1022-1079 (cuMemcpy2D of the luma plane + InterleaveUV): tight I420 / NV12 -> pitch NV12 surface."""
+    out = np.zeros((h + h // 2, pitch), np.uint8)
+    out[:h, :w] = frame[:w * h].reshape(h, w)
+    if fmt == 0:
+        out[h:, :w] = frame[w * h:].reshape(h // 2, w)
+    else:
+        U = frame[w * h:w * h + w * h // 4].reshape(h // 2, w // 2); V = frame[w * h + w * h // 4:].reshape(h // 2, w // 2)
+        out[h:, 0:w:2] = U; out[h:, 1:w:2] = V
+    return out
+
+
+@pytest.mark.parametrize("w,h,pitch", [(16, 16, 16), (90, 70, 131), (1920, 1080, 2048), (3840, 2160, 3840)])
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_encoder_preprocessing_kernel_vs_restatement(w, h, pitch, fmt):
+    """jm_amddec_i420_to_nv12_device against the numpy restatement, including a pitch that is not a multiple of 4."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]; hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L = api.lib()
+    L.jm_amddec_i420_to_nv12_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(w * 31 + h + fmt)
+    frame = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+    rows = h + h // 2
+    d_src, d_dst = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_src), frame.size) == 0 and hip.hipMalloc(C.byref(d_dst), rows * pitch) == 0
+    try:
+        assert hip.hipMemcpy(d_src, frame.ctypes.data_as(C.c_void_p), frame.size, 1) == 0
+        assert hip.hipMemset(d_dst, 0, rows * pitch) == 0
+        assert L.jm_amddec_i420_to_nv12_device(d_src, w, h, fmt, d_dst, pitch, None) == 0
+        got = np.zeros(rows * pitch, np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_dst, got.size, 2) == 0
+        assert np.array_equal(got.reshape(rows, pitch), _nv12_pitch_restated(frame, w, h, fmt, pitch))    # padding bytes stay untouched (zero)
+        assert L.jm_amddec_i420_to_nv12_device(d_src, w + 1, h, fmt, d_dst, pitch, None) == -1 and L.jm_amddec_i420_to_nv12_device(d_src, w, h, fmt, d_dst, w - 1, None) == -1
+    finally:
+        hip.hipFree(d_src); hip.hipFree(d_dst)
+
+
+def test_decode_to_encoder_surface_on_device(oracle):
+    """the decoder's current frame (I420 at init) as a pitch NV12 encoder surface, device to device; it must equal the
+    oracle's NV12 frame of the same stream laid out at that pitch."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]; hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L = api.lib()
+    L.jm_amddec_output_nv12_pitch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    data = golden_stream("high_cabac_fuzz_96x80")
+    want_nv12, n, w, h = oracle.decode(data, 0)
+    fs, pitch, rows = w * h * 3 // 2, 256, h + h // 2
+    d_surf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_surf), rows * pitch) == 0
+    try:
+        with api.JmAmdDec(0, 1, options={"device_output": 1}) as d:
+            assert L.jm_amddec_output_nv12_pitch_device(d_surf, pitch, d.h) == -1          # no frame yet
+            count = 0
+            for nal in api.split_nalus(data) + [None] * 64:
+                if api.jm_nvdec_is_exit(d.h):
+                    break
+                _, got = api.jm_nvdec_decode_frame(nal, len(nal) if nal else 0, d.h)
+                if not got:
+                    continue
+                assert hip.hipMemset(d_surf, 0, rows * pitch) == 0
+                assert L.jm_amddec_output_nv12_pitch_device(d_surf, pitch, d.h) == 0
+                surf = np.zeros(rows * pitch, np.uint8)
+                assert hip.hipMemcpy(surf.ctypes.data_as(C.c_void_p), d_surf, surf.size, 2) == 0
+                ref = np.frombuffer(want_nv12, np.uint8, fs, count * fs)
+                assert np.array_equal(surf.reshape(rows, pitch), _nv12_pitch_restated(ref, w, h, 0, pitch)), f"frame {count}"
+                count += 1
+            assert count == n
+    finally:
+        hip.hipFree(d_surf)
 
 
 def test_resolution_change_between_sequences(oracle):

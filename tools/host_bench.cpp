@@ -36,6 +36,7 @@ void launch_recon_intra(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_deblock_lds(const PicParams *, int, int, int, int *, ihipStream_t *) { abort(); }
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); }
+void launch_frame_to_nv12_pitch(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); }
 void launch_hevc_picture_batch(const HevcPicParams *, int, const HevcBatchDims &, int *, ihipStream_t *, ihipEvent_t **) { abort(); }
 void hevc_kernels_init() {}
 }
