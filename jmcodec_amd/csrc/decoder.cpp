@@ -1,6 +1,7 @@
 // jmcodec_amd/csrc/decoder.cpp -- see decoder.h.
 #include "decoder.h"
 #include <pthread.h>
+#include <time.h>
 #include "engine.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
@@ -148,6 +149,16 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
+    // Where a display frame waits for jm_nvdec_output_frame.  "Fetch": in DEVICE staging, and output() copies it straight into the caller's
+    // buffer with one synchronous DMA (no pinned host slot, no CPU memcpy: that memcpy was 30 % of the host CPU time per frame, and the host
+    // CPU budget is what bounds the rate).  The synchronous copies of a device serialise (~90 us each, ~11 k frames/s),
+    // so only some of the handles use it; the others keep the former scheme -- copy engine -> pinned host slot ahead of time, CPU memcpy in
+    // output() -- which costs CPU instead of time in that queue.  JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.
+    {
+        int fa = 1, fb = 2;                                    // fetch for `fa` of every `fb` handles (JM_AMD_DEC_OUT_FETCH="a/b")
+        if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 1; fb = 2; } }
+        out_fetch_ = out_via_copy_engine_ && !getenv("JM_AMD_DEC_OUT_PINNED") && (handle_index_ % fb) < fa;
+    }
     if (engine_) engine_->set_profile(profile_);
     inited_ = true;
     // optional SPS/PPS given up front (nv_dec.cpp:334-360).  FFmpeg hands test_player either Annex-B parameter sets or, for MP4 /
@@ -289,7 +300,7 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     o->w = disp_w_; o->h = disp_h_;
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!device_output_ && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if (!device_output_ && !out_fetch_ && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
         if ((out_via_copy_engine_ || device_output_) && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
         o->bytes = frame_bytes_;
     }
@@ -970,7 +981,16 @@ int Decoder::output(uint8_t *out, int *out_len) {
     if (*out_len < need) return -2;
     *out_len = 0;
     if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
-    else if (cur_out_->has_data) { hipSetDevice(device_); if (hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess) return -1; }   // device_output mode: convenience copy
+    else if (cur_out_->has_data) {
+        // The frame waits in device staging (fetch mode, or device_output): one synchronous DMA into the caller's buffer.  Plain hipMemcpy
+        // on purpose: the runtime pins the caller's pages (and caches the pinning), runs one copy-engine transfer and the other feeder
+        // threads queue behind it ASLEEP.  Every parallel form measured worse on the 32-stream workload, because waits inside the runtime
+        // spin: hipMemcpyAsync / hipMemcpyWithStream on a stream per handle 6.1-7.4 k frames/s at 2.2-2.6 ms of CPU per frame;
+        // hipHostRegister + hipMemcpyAsync + hipEventSynchronize(hipEventBlockingSync) 4.3 k at 3.6 ms; the same with a sleeping
+        // hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms; this form 10.7-11.4 k at 0.96-1.0 ms.
+        hipSetDevice(device_);
+        if (hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
     else memset(out, 0, (size_t)need);
     *out_len = need;
     return need;

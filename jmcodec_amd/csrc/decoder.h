@@ -154,7 +154,7 @@ private:
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
-    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
     std::string error_;
     bool failed_ = false, inited_ = false;
 
