@@ -356,7 +356,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         }
         if (!sig) continue;
         int pos[16], np = 0;
-        for (int k = 15; k >= 0; k--) if ((sig >> k) & 1) pos[np++] = k;
+        for (uint32_t m = sig; m;) { const int k = 31 - __builtin_clz(m); pos[np++] = k; m &= ~(1u << k); }       // highest scan position first
         int cset = (i == 0 || c) ? 0 : 2;
         if (!first_group && g1ctx == 0) cset++;
         first_group = false; g1ctx = 1;
@@ -407,12 +407,20 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     const bool flat = !sps_->scaling_enabled || (tskip && n > 4);
     const int bd_shift = log2 + 3, ls = hevc_level_scale[qp % 6] << (qp / 6);
     const uint32_t first = (uint32_t)jobs_->coefs.size();
-    for (int k = 0; k < nz_n_; k++) {
-        const int idx = nz_pos_[k];
-        int v = tq_bypass_ ? lev_[idx] : clip3(-32768, 32767, (int)(((int64_t)lev_[idx] * (flat ? 16 : m[idx]) * ls + (1 << (bd_shift - 1))) >> bd_shift));
-        if (v) jobs_->coefs.push_back((uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16));
+    jobs_->coefs.resize(first + (size_t)nz_n_);                      // written in place, trimmed to what survived scaling
+    uint32_t *cw = jobs_->coefs.data() + first;
+    uint32_t count = 0;
+    if (tq_bypass_) {
+        for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx]; if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
+    } else {
+        const int64_t add = (int64_t)1 << (bd_shift - 1);
+        for (int k = 0; k < nz_n_; k++) {
+            const int idx = nz_pos_[k];
+            const int v = clip3(-32768, 32767, (int)(((int64_t)lev_[idx] * (flat ? 16 : m[idx]) * ls + add) >> bd_shift));
+            if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
+        }
     }
-    const uint32_t count = (uint32_t)jobs_->coefs.size() - first;
+    jobs_->coefs.resize(first + count);
     const uint8_t flags = (uint8_t)((tskip ? HTB_TSKIP : 0) | (tq_bypass_ ? HTB_BYPASS : 0) | ((cu_intra_ && c == 0 && n == 4) ? HTB_DST : 0));
     if (intra_tb) { HevcIntraTb &t = jobs_->itbs.back(); t.coef_off = first; t.coef_n = count; t.flags |= flags; }
     else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0; t.coef_off = first; t.coef_n = count; jobs_->tbs.push_back(t); }
