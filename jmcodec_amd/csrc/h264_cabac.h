@@ -104,4 +104,54 @@ struct Cabac {
     }
 };
 
+// The engine's hot variables as LOCALS of the calling function.  Inside `Cabac` they are members next to `state[]`, and every context update
+// is a uint8_t store -- which may alias anything, so the compiler reloads val / pos / range from memory after each bin and the store-to-load
+// forwarding sits on the dependency chain of the arithmetic decoder.  A residual block decodes dozens of bins in a row: it takes a CabacRegs
+// (`CabacRegs r(cb);` ... `r.commit();`), whose scalars never have their address taken and therefore live in registers.  Same arithmetic as above.
+struct CabacRegs {
+    uint64_t val; int pos; uint32_t range; const uint8_t *ptr; const uint8_t *const end; uint8_t *const state; bool overrun; Cabac &home;
+    explicit CabacRegs(Cabac &c) : val(c.val), pos(c.pos), range(c.range), ptr(c.ptr), end(c.end), state(c.state), overrun(c.overrun), home(c) {}
+    inline void commit() { home.val = val; home.pos = pos; home.range = range; home.ptr = ptr; home.overrun = overrun; }
+    inline void refill() {
+        uint32_t w;
+        if (ptr + 4 <= end) { w = ((uint32_t)ptr[0] << 24) | ((uint32_t)ptr[1] << 16) | ((uint32_t)ptr[2] << 8) | ptr[3]; }
+        else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (ptr + i < end ? ptr[i] : 0); if (ptr >= end + 8) overrun = true; }
+        ptr += 4;
+        val = (val << 32) | w; pos += 32;
+    }
+    inline int decision(int ctx) {
+        const uint8_t *const tr = kCabacTrans.t;
+        const uint32_t s = state[ctx];
+        const uint32_t lps = cabac_range_lps[s >> 1][(range >> 6) & 3];
+        const uint32_t rm = range - lps;
+        const uint64_t scaled = (uint64_t)rm << pos;
+        const uint64_t m = (uint64_t)((int64_t)(scaled - val - 1) >> 63);
+        const uint32_t m32 = (uint32_t)m;
+        val -= scaled & m;
+        const uint32_t r = rm ^ ((rm ^ lps) & m32);
+        state[ctx] = tr[2 * s + (m32 & 1)];
+        const int sh = __builtin_clz(r) - 23;
+        range = r << sh; pos -= sh;
+        if (pos < 16) refill();
+        return (int)((s ^ m32) & 1);
+    }
+    inline int bypass() {
+        pos--;
+        const uint64_t scaled = (uint64_t)range << pos;
+        int bin = 0;
+        if (val >= scaled) { val -= scaled; bin = 1; }
+        if (pos < 16) refill();
+        return bin;
+    }
+    inline uint32_t bypass_bits(int n) {
+        if (pos < 16) refill();
+        pos -= n;
+        const uint64_t scaled = (uint64_t)range << pos;
+        const uint64_t q = val / scaled;
+        val -= q * scaled;
+        if (pos < 16) refill();
+        return (uint32_t)q;
+    }
+};
+
 }  // namespace jmamd

@@ -310,16 +310,17 @@ void HevcPicParser::emit_intra_tb(int xp, int yp, int log2, int c, int mode, boo
 bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int yp, bool intra_tb) {
     const int n = 1 << log2;
     int tskip = 0;
-    if (pps_->transform_skip && !tq_bypass_ && log2 == 2) tskip = cb_.decision(HEVC_CTX_TSKIP + (c ? 1 : 0));
+    CabacRegs cb(cb_);                                              // the arithmetic decoder's variables in registers for the whole block (h264_cabac.h)
+    if (pps_->transform_skip && !tq_bypass_ && log2 == 2) tskip = cb.decision(HEVC_CTX_TSKIP + (c ? 1 : 0));
     // last significant coefficient position
     int last[2];
     for (int d = 0; d < 2; d++) {
         const int cmax = 2 * log2 - 1, off = c ? 15 : 3 * (log2 - 2) + ((log2 - 1) >> 2), shf = c ? log2 - 2 : (log2 + 1) >> 2, base = d ? HEVC_CTX_LAST_Y : HEVC_CTX_LAST_X;
         int v = 0;
-        while (v < cmax && cb_.decision(base + off + (v >> shf))) v++;
+        while (v < cmax && cb.decision(base + off + (v >> shf))) v++;
         last[d] = v;
     }
-    for (int d = 0; d < 2; d++) if (last[d] > 3) { int nb = (last[d] >> 1) - 1, s = 0; for (int i = 0; i < nb; i++) s = (s << 1) | cb_.bypass(); last[d] = (1 << nb) * (2 + (last[d] & 1)) + s; }
+    for (int d = 0; d < 2; d++) if (last[d] > 3) { int nb = (last[d] >> 1) - 1, s = 0; for (int i = 0; i < nb; i++) s = (s << 1) | cb.bypass(); last[d] = (1 << nb) * (2 + (last[d] & 1)) + s; }
     int scan = 0;
     if (cu_intra_ && (log2 == 2 || (log2 == 3 && c == 0))) { int pm = c == 0 ? ipm_[i4(x0, y0)] : ipm_c_; if (pm >= 6 && pm <= 14) scan = 2; else if (pm >= 22 && pm <= 30) scan = 1; }
     int lx = last[0], ly = last[1];
@@ -338,7 +339,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         const int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
         const int right = xs < nsb - 1 ? csbf[ys][xs + 1] : 0, below = ys < nsb - 1 ? csbf[ys + 1][xs] : 0;
         bool infer_dc = false;
-        if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)cb_.decision(HEVC_CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)); infer_dc = true; }
+        if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)cb.decision(HEVC_CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)); infer_dc = true; }
         else csbf[ys][xs] = 1;
         if (!csbf[ys][xs]) continue;
         uint16_t sig = 0;                                              // bit k: position k of the sub-block is significant
@@ -349,10 +350,10 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         const uint8_t *pat = kScan.sigpat[scan][log2 == 2 ? 4 : prev];
         const int sig0 = HEVC_CTX_SIG + (c ? 27 : 0);
         const int sbase = log2 == 2 ? sig0 : (c == 0 ? HEVC_CTX_SIG + (i > 0 ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21) : HEVC_CTX_SIG + 27 + (log2 == 3 ? 9 : 12));
-        for (int k = start; k >= 1; k--) if (cb_.decision(sbase + pat[k])) { sig |= (uint16_t)(1u << k); infer_dc = false; }
+        for (int k = start; k >= 1; k--) if (cb.decision(sbase + pat[k])) { sig |= (uint16_t)(1u << k); infer_dc = false; }
         if (start >= 0) {
             if (infer_dc) sig |= 1;
-            else if (cb_.decision((log2 > 2 && i == 0) ? sig0 : sbase + pat[0])) sig |= 1;
+            else if (cb.decision((log2 > 2 && i == 0) ? sig0 : sbase + pat[0])) sig |= 1;
         }
         if (!sig) continue;
         int pos[16], np = 0;
@@ -363,24 +364,24 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         int absv[16], last_g1 = -1;
         for (int m = 0; m < np; m++) absv[m] = 1;
         for (int m = 0; m < np && m < 8; m++) {
-            if (cb_.decision(HEVC_CTX_G1 + cset * 4 + g1ctx + (c ? 16 : 0))) { absv[m] = 2; g1ctx = 0; if (last_g1 < 0) last_g1 = m; }
+            if (cb.decision(HEVC_CTX_G1 + cset * 4 + g1ctx + (c ? 16 : 0))) { absv[m] = 2; g1ctx = 0; if (last_g1 < 0) last_g1 = m; }
             else if (g1ctx > 0 && g1ctx < 3) g1ctx++;
         }
-        if (last_g1 >= 0 && cb_.decision(HEVC_CTX_G2 + cset + (c ? 4 : 0))) absv[last_g1] = 3;
+        if (last_g1 >= 0 && cb.decision(HEVC_CTX_G2 + cset + (c ? 4 : 0))) absv[last_g1] = 3;
         const bool hide = pps_->sign_hiding && !tq_bypass_ && pos[0] - pos[np - 1] > 3;
         const int nsign = np - (hide ? 1 : 0);
-        uint32_t signs = nsign ? cb_.bypass_bits(nsign) << (32 - nsign) : 0;      // first sign in bit 31
+        uint32_t signs = nsign ? cb.bypass_bits(nsign) << (32 - nsign) : 0;      // first sign in bit 31
         int rice = 0, sum = 0;
         for (int m = 0; m < np; m++) {
             const int thr = m < 8 ? (m == last_g1 ? 3 : 2) : 1;
             int a = absv[m];
             if (a == thr) {
                 int q = 0;
-                while (q < 32 && cb_.bypass()) q++;
+                while (q < 32 && cb.bypass()) q++;
                 if (q >= 32) return false;
                 int rem;
-                if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb_.bypass_bits(rice); }
-                else { int nb = q - 3 + rice; if (nb > 30) return false; int s = nb > 16 ? (int)(cb_.bypass_bits(nb - 16) << 16 | cb_.bypass_bits(16)) : (int)cb_.bypass_bits(nb); rem = (((1 << (q - 3)) + 2) << rice) + s; }
+                if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb.bypass_bits(rice); }
+                else { int nb = q - 3 + rice; if (nb > 30) return false; int s = nb > 16 ? (int)(cb.bypass_bits(nb - 16) << 16 | cb.bypass_bits(16)) : (int)cb.bypass_bits(nb); rem = (((1 << (q - 3)) + 2) << rice) + s; }
                 a += rem;
                 if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
             }
@@ -393,6 +394,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
             nz_pos_[nz_n_++] = (uint16_t)idx;
         }
     }
+    cb.commit();                                                    // (the early error returns above abandon the slice: nothing to write back)
     if (cb_.overrun) return false;
     if (dg_->on) {
         dg(0x7000 | (c << 8) | (log2 << 4) | tskip); dg(x0); dg(y0);
