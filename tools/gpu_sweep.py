@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: randomised differential test on a GPU box -- N random generator configurations per codec, decoded through the C ABI
 on cuda:0 and compared bit-exactly with the CPU oracle (which itself must equal the generator's reconstruction).
-    python tools/gpu_sweep.py [n] [seed]"""
+    python tools/gpu_sweep.py [n] [seed] [big]      # big: picture sizes up to 1280x720 (several CTB rows / deblocking bands / XCD bands)"""
 import os
 import random
 import sys
@@ -47,12 +47,17 @@ def h264_params(r):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     oh, o4 = streams.OracleHevc(), streams.Oracle()
     bad = 0
     for codec, name in ((1, "hevc"), (0, "h264")):
         for i in range(n):
             r = random.Random(base * 100003 + i * 7 + codec)
             kw = hevc_params(r) if codec else h264_params(r)
+            if os.environ.get("SWEEP_VERBOSE"):
+                print(name, i, flush=True)
+            if big:
+                kw.update(width=r.choice([416, 640, 854, 1280, 720]), height=r.choice([240, 360, 480, 720, 576]), frames=r.choice([2, 3, 5]))
             with tempfile.NamedTemporaryFile(suffix=".yuv") as tf:
                 data = (streams.generate_hevc if codec else streams.generate)(recon_path=tf.name, **kw)
                 recon = open(tf.name, "rb").read()

@@ -1677,6 +1677,11 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     p->num_ref = CLIP3(1, 4, p->num_ref ? p->num_ref : 1); if (p->gop == 8 && p->num_ref > 2) p->num_ref = 2; if (p->gop >= 1 && p->gop <= 3 && p->num_ref > 2) p->num_ref = 2;
     p->merge_cand = CLIP3(1, 5, p->merge_cand ? p->merge_cand : 5); p->par_mrg = CLIP3(2, p->ctb_log2, p->par_mrg ? p->par_mrg : 2);
     p->tile_cols = MAX(1, p->tile_cols); p->tile_rows = MAX(1, p->tile_rows); if (p->search < 1) p->search = 4;
+    /* the slice table holds 512 entries (dependent slice segments share their parent's): keep independent slices per picture below that */
+    if (p->slice_ctus > 0) {
+        const int cs = 1 << p->ctb_log2, n_ctbs = ((p->width + cs - 1) / cs) * ((p->height + cs - 1) / cs);
+        if ((n_ctbs + p->slice_ctus - 1) / p->slice_ctus > 400) p->slice_ctus = (n_ctbs + 399) / 400;
+    }
     p->dqp = CLIP3(0, 1 + MIN(3, p->ctb_log2 - p->min_cb_log2), p->dqp); p->scaling = CLIP3(0, 3, p->scaling); p->pcm = CLIP3(0, 2, p->pcm); p->deblock = CLIP3(0, 2, p->deblock);
     p->cb_qp_off = CLIP3(-12, 12, p->cb_qp_off); p->cr_qp_off = CLIP3(-12, 12, p->cr_qp_off);
     if (p->gop) p->lt_ref = 0;
