@@ -295,7 +295,7 @@ def main():
         "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) ") + f"{args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
-                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H + memcpy to caller"},
+                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (every second handle: synchronous DMA from device staging; the others: pinned slot + memcpy)"},
         "frames": frames_total,
         "decode_errors": int(errors),
         "host_ms_per_picture": host_diag,
@@ -310,7 +310,7 @@ def main():
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms},
         "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 63.0, "unit": "GB/s",
-                     "note": "tight frames: k_packout -> device staging, copy engine -> pinned host slot (overlaps the next batch); rate = frames/s x frame bytes per GPU"},
+                     "note": "tight frames: k_packout -> device staging, then copy engine -> caller's buffer (or -> pinned host slot ahead of time + memcpy); rate = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
         "roofline_frame": {"alg_bytes_per_frame": int(A), "job_bytes_per_frame": int(J),
