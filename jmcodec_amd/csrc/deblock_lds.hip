@@ -99,13 +99,15 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
 // s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3; bsw = bS | tC0 << 3.  Written without divergent branches: the two filters of 8.7.2.3 / 8.7.2.4
 // are computed for every lane and selected, and the only branches are wave-uniform (nothing to filter / no lane with bS = 4).  The
 // branchy form cost ~10 exec-mask regions and, in the horizontal pass, ~110 register copies at the joins per edge.
+// |a - b| of two samples (0..255, upper bytes zero): one v_sad_u8 instead of sub / neg / max
+__device__ __forceinline__ int adiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
 __device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }      // operands are evaluated by the caller: a v_cndmask, never a branch
 __device__ __forceinline__ void flt_luma(int *s, int bsw, int alpha, int beta) {
     const int bS = bsw & 7, tc0 = bsw >> 3;
     const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
-    const bool on = ((int)(bS != 0) & (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta)) != 0;
+    const bool on = ((int)(bS != 0) & (int)(adiff(p0, q0) < alpha) & (int)(adiff(p1, p0) < beta) & (int)(adiff(q1, q0) < beta)) != 0;
     if (!__builtin_amdgcn_ballot_w64(on)) return;
-    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
     const int tc = tc0 + (int)ap + (int)aq;
     const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
     const int avg = (p0 + q0 + 1) >> 1;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void flt_luma(int *s, int bsw, int alpha, int beta) {
     int r_p0 = sel(nrm, n_p0, p0), r_q0 = sel(nrm, n_q0, q0), r_p1 = sel(((int)nrm & (int)ap) != 0, n_p1, p1), r_q1 = sel(((int)nrm & (int)aq) != 0, n_q1, q1), r_p2 = p2, r_q2 = q2;
     const bool st = ((int)on & (int)(bS >= 4)) != 0;
     if (__builtin_amdgcn_ballot_w64(st)) {
-        const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        const bool strong = adiff(p0, q0) < ((alpha >> 2) + 2);
         const bool sp = ((int)st & (int)ap & (int)strong) != 0, sq = ((int)st & (int)aq & (int)strong) != 0;
         const int w_p0 = (2 * p1 + p0 + q1 + 2) >> 2, w_q0 = (2 * q1 + q0 + p1 + 2) >> 2;
         const int s_p0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2, s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
@@ -128,7 +130,7 @@ __device__ __forceinline__ void flt_luma(int *s, int bsw, int alpha, int beta) {
 // chroma: p1 p0 q0 q1 by reference
 __device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int bsw, int alpha, int beta) {
     const int bS = bsw & 7, tc = (bsw >> 3) + 1;
-    const bool on = ((int)(bS != 0) & (int)(iabs(p0 - q0) < alpha) & (int)(iabs(p1 - p0) < beta) & (int)(iabs(q1 - q0) < beta)) != 0;
+    const bool on = ((int)(bS != 0) & (int)(adiff(p0, q0) < alpha) & (int)(adiff(p1, p0) < beta) & (int)(adiff(q1, q0) < beta)) != 0;
     const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
     const int n_p0 = clip1(p0 + delta), n_q0 = clip1(q0 - delta), w_p0 = (2 * p1 + p0 + q1 + 2) >> 2, w_q0 = (2 * q1 + q0 + p1 + 2) >> 2;
     p0 = sel(on, sel(bS < 4, n_p0, w_p0), p0); q0 = sel(on, sel(bS < 4, n_q0, w_q0), q0);
