@@ -159,7 +159,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     }
     if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
-    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, st); b.pmask |= 4; }
+    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_progress, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
     if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, b.d_progress, st); b.pmask |= 8; }

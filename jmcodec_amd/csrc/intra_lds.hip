@@ -21,8 +21,6 @@
 
 namespace jmamd {
 
-constexpr int kIGroups = 32;
-constexpr int kISlots = 5;
 constexpr int kTS = 28;              // row stride of the luma work tile: corner + 16 + 8 top-right samples
 constexpr int kTileBase = 3904;      // tables, record staging and Intra8x8 edge buffers come first
 
@@ -106,6 +104,16 @@ struct ILds {
     __device__ uint8_t *cring(int row, int slot) const { return base + kTileBase + 32 * 128 + mb_h * 16 + row * 64 + slot * 16; }
 };
 
+// What a macroblock step needs of the picture, read once per workgroup; the plane pointer is a global (address space 1) pointer so that the
+// stores are global_store, not FLAT (see deblock_lds.hip).
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+#define JM_GLOBAL __attribute__((address_space(1)))
+struct ICtx { gbyte *plane; int pitch; };
+__device__ __forceinline__ void gstore4(gbyte *p, uint4 v) { v4u t = {v.x, v.y, v.z, v.w}; *(JM_GLOBAL v4u *)p = t; }
+__device__ __forceinline__ uint4 gload4(const gbyte *p) { v4u v = *(const JM_GLOBAL v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint32_t gload1(const gbyte *p) { return *(const JM_GLOBAL uint32_t *)p; }
+
 // sum over the 16 (or n) lanes of a group
 __device__ __forceinline__ int group_sum16(int v) {
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
@@ -118,10 +126,12 @@ __device__ __forceinline__ int sum4(int v) { v += __shfl_xor(v, 1); v += __shfl_
 // luma, one macroblock, 16 lanes.  res0/res1: this lane's residual row (16 int16); right4/bottom: prefetched
 // samples of an already reconstructed (non-intra) macroblock: columns 12..15 of row l, and the whole row 15.
 // ------------------------------------------------------------------------------------------
-__device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int row, int l, int g,
+// row = macroblock row in the picture (addresses in the surface), lrow = the row's index in the workgroup's LDS image (band-local + 1; index 0
+// holds the bottom rows handed down by the band above)
+__device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, int x, int row, int lrow, int l, int g,
                               uint32_t recdw, uint4 res0, uint4 res1, uint32_t right4, uint4 bottom) {
-    uint8_t *rcol = lds.lrcol(row);
-    uint8_t *ring_dn = lds.lring(row, x & 3);
+    uint8_t *rcol = lds.lrcol(lrow);
+    uint8_t *ring_dn = lds.lring(lrow, x & 3);
     // MbRec through LDS (8 dwords); every lane needs kind / modes / flags / i4 modes
     uint32_t *rec = (uint32_t *)lds.rec(g);
     if (l < 8) rec[l] = recdw;
@@ -134,10 +144,10 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
         return;
     }
     bool availA = flags & MBF_AVAIL_A, availB = flags & MBF_AVAIL_B, availC = flags & MBF_AVAIL_C, availD = flags & MBF_AVAIL_D;
-    uint8_t *dst = pp.surf[pp.cur] + (size_t)(row * 16 + l) * pp.pitch + x * 16;
-    const uint8_t *ring_up = row > 0 ? lds.lring(row - 1, x & 3) : ring_dn;           // only read when availB
-    const uint8_t *ring_ur = row > 0 ? lds.lring(row - 1, (x + 1) & 3) : ring_dn;
-    const uint8_t *ring_ul = row > 0 ? lds.lring(row - 1, (x - 1) & 3) : ring_dn;
+    gbyte *dst = pp.plane + (size_t)(row * 16 + l) * pp.pitch + x * 16;
+    const uint8_t *ring_up = row > 0 ? lds.lring(lrow - 1, x & 3) : ring_dn;           // only read when availB
+    const uint8_t *ring_ur = row > 0 ? lds.lring(lrow - 1, (x + 1) & 3) : ring_dn;
+    const uint8_t *ring_ul = row > 0 ? lds.lring(lrow - 1, (x - 1) & 3) : ring_dn;
     int rs[16];
     { uint32_t w[8] = {res0.x, res0.y, res0.z, res0.w, res1.x, res1.y, res1.z, res1.w};
 #pragma unroll
@@ -290,7 +300,7 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
     }
     uint32_t o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24), o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
     uint32_t o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24), o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
-    *(uint4 *)dst = make_uint4(o0, o1, o2, o3);
+    gstore4(dst, make_uint4(o0, o1, o2, o3));
     rcol[l] = (uint8_t)out[15];
     if (l == 15) *(uint4 *)ring_dn = make_uint4(o0, o1, o2, o3);
 }
@@ -299,10 +309,10 @@ __device__ void intra_luma_mb(const PicParams &pp, const ILds &lds, int x, int r
 // chroma, one macroblock, 16 lanes: lane = (plane, row).  res: 8 int16 of this lane's row; right2/bottom:
 // prefetched samples of an already reconstructed macroblock (UV pair of column 7 in row r; whole row 7).
 // ------------------------------------------------------------------------------------------
-__device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int row, int l, int g,
+__device__ __forceinline__ void intra_chroma_mb(const ICtx &pp, const ILds &lds, int x, int row, int lrow, int l, int g,
                                 uint32_t recdw, uint4 res, uint32_t right2, uint4 bottom) {
-    uint8_t *rcol = lds.crcol(row);                // [8 rows][2 planes]
-    uint8_t *ring_dn = lds.cring(row, x & 3);      // 16 B interleaved bottom row
+    uint8_t *rcol = lds.crcol(lrow);               // [8 rows][2 planes]
+    uint8_t *ring_dn = lds.cring(lrow, x & 3);     // 16 B interleaved bottom row
     uint32_t *rec = (uint32_t *)lds.rec(g);
     if (l < 8) rec[l] = recdw;
     uint32_t r0 = rec[0];
@@ -315,8 +325,8 @@ __device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int
     }
     bool availA = flags & MBF_AVAIL_A, availB = flags & MBF_AVAIL_B;
     int cmode = modes & 3;
-    const uint8_t *ring_up = row > 0 ? lds.cring(row - 1, x & 3) : ring_dn;
-    const uint8_t *ring_ul = row > 0 ? lds.cring(row - 1, (x - 1) & 3) : ring_dn;
+    const uint8_t *ring_up = row > 0 ? lds.cring(lrow - 1, x & 3) : ring_dn;
+    const uint8_t *ring_ul = row > 0 ? lds.cring(lrow - 1, (x - 1) & 3) : ring_dn;
     int rs[8];
     { uint32_t w[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
@@ -365,88 +375,110 @@ __device__ void intra_chroma_mb(const PicParams &pp, const ILds &lds, int x, int
     rcol[r * 2 + plane] = (uint8_t)out[7];
     if (l < 8) {
         uint4 v = *(const uint4 *)(tile + l * 16);
-        *(uint4 *)(pp.surf[pp.cur] + pp.chroma_offset + (size_t)(row * 8 + l) * pp.pitch + x * 16) = v;
+        gstore4(pp.plane + (size_t)(row * 8 + l) * pp.pitch + x * 16, v);
         if (l == 7) *(uint4 *)ring_dn = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// NSLOTS macroblock rows per 16-lane group: 3 covers pictures up to 96 macroblock rows (1080p: 68) with far fewer live prefetch
-// registers (no spills); 5 covers up to 160 rows (4K: 135)
-template <int NSLOTS>
-__global__ __launch_bounds__(512) void k_intra_lds(const PicParams *pics) {
-    extern __shared__ __align__(16) uint8_t smem[];
+// Banded lockstep wavefront, the same construction as k_deblock_band (deblock_lds.hip): a plane is cut into bands of kIBandRows macroblock
+// rows, one 4-wave workgroup per band and plane, every band walks the steps s = x + 2 * row of its own rows.  The only coupling is downwards:
+// the first row of a band predicts from the bottom sample row of the macroblocks above it.  Those 16 bytes per macroblock travel through the
+// picture surface (they are final there anyway) as agent-scope relaxed atomics, behind a per-band step counter in device memory; the band below
+// fetches the row of macroblock x + 2 one step before it needs it.  (The first form walked a whole plane with ONE workgroup: up to five
+// macroblock rows per 16-lane group at 4K, 7 ms for a 4K I picture.)
+constexpr int kIBandRows = 16;
+__global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_intra_band(const PicParams *pics, int *progress, int prog_stride) {
+    __shared__ __align__(16) uint8_t smem[kTileBase + 32 * 992 + (kIBandRows + 1) * 80 + 64];
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_INTRA_LDS)) return;
-    const short *resid = pp.resid;
-    ILds lds{smem, pp.mb_h};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_chroma = blockIdx.x == 1;
-    const int g = wave * 4 + (lane >> 4), l = lane & 15;
+    const int band = blockIdx.x >> 1;
+    const bool is_chroma = blockIdx.x & 1;
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
+    const int row0 = band * kIBandRows;
+    if (row0 >= mb_h) return;
+    const int rows = min(kIBandRows, mb_h - row0);
+    int *prog = progress + (size_t)blockIdx.y * prog_stride + (is_chroma ? kDeblockMaxBands : 0);
+    const gbyte *resid = (const gbyte *)pp.resid;
+    const gbyte *mbs = (const gbyte *)pp.mbs;
+    ILds lds{smem, kIBandRows + 1};
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const bool active = g < rows;
+    const int row = row0 + (active ? g : 0), lrow = g + 1;
     if (threadIdx.x < 144) lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
-    for (int i = threadIdx.x; i < 576; i += 512) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const uint8_t *plane_base = pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0);
+    for (int i = threadIdx.x; i < 576; i += kIBandRows * 16) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
+    gbyte *plane = (gbyte *)(pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0));
+    const ICtx cx{plane, pitch};
     const int rows_per_mb = is_chroma ? 8 : 16, my_row = is_chroma ? (l & 7) : l;
-    uint32_t p_rec[NSLOTS], p_right[NSLOTS]; uint4 p_res0[NSLOTS], p_res1[NSLOTS], p_bot[NSLOTS];
-#pragma unroll
-    for (int k = 0; k < NSLOTS; k++) { p_rec[k] = 0; p_right[k] = 0; p_res0[k] = p_res1[k] = p_bot[k] = make_uint4(0, 0, 0, 0); }
-    const int n_steps = mb_w + 2 * (mb_h - 1);
-    // (a macro, not a lambda: capturing the per-slot arrays by reference kept them in scratch memory)
-#define JM_PREFETCH(k, row, xn) do { \
-        int mb_ = (row) * mb_w + (xn); \
-        p_rec[k] = ((const uint32_t *)&pp.mbs[mb_])[l & 7]; \
-        const uint8_t *px_ = plane_base + (size_t)((row) * rows_per_mb) * pitch + (xn) * 16; \
-        p_right[k] = *(const uint32_t *)(px_ + (size_t)my_row * pitch + 12); \
-        p_bot[k] = *(const uint4 *)(px_ + (size_t)(rows_per_mb - 1) * pitch); \
-        const short *rs_ = resid + (size_t)mb_ * 384; \
-        if (is_chroma) p_res0[k] = *(const uint4 *)(rs_ + 256 + l * 8);               /* plane (l>>3), row (l&7): 8 int16 */ \
-        else { p_res0[k] = *(const uint4 *)(rs_ + l * 16); p_res1[k] = *(const uint4 *)(rs_ + l * 16 + 8); } \
+    const bool takes_ring = band > 0 && g == 0;                             // first row of a lower band
+    const bool gives_ring = active && g == rows - 1 && row < mb_h - 1;       // last row of a band that has a band below
+    const int s_begin = 2 * row0, s_end = mb_w - 1 + 2 * (row0 + rows - 1);
+    // bottom sample row of macroblock xm in the row above this band / in this band's last row: 16 bytes, dword `l` by lane l < 4
+    const gbyte *above = plane + (size_t)(row0 * rows_per_mb - 1) * pitch + (l & 3) * 4;
+    gbyte *below = plane + (size_t)((row + 1) * rows_per_mb - 1) * pitch + (l & 3) * 4;
+    int known = 0;
+    auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
+        if (band == 0 || threadIdx.x >= 64 || known >= need) return;
+        int spins = 0;
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        asm volatile("" ::: "memory");
+    };
+    auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };
+    auto fetch_above = [&](int xm) -> uint32_t { return __hip_atomic_load((const JM_GLOBAL uint32_t *)(above + (size_t)xm * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (band > 0) {
+        // macroblocks 0 and 1 of the row above are final once the band above completed step s_begin - 1
+        wait_above(s_begin);
+        if (takes_ring && l < 8 && (l >> 2) < mb_w) ring0(l >> 2)[l & 3] = fetch_above(l >> 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint32_t p_rec = 0, p_right = 0, p_ring = 0; uint4 p_res0 = make_uint4(0, 0, 0, 0), p_res1 = p_res0, p_bot = p_res0;
+    // (a macro, not a lambda: capturing the uint4 prefetch registers by reference put them in scratch memory)
+#define JM_PREFETCH(s_) do { \
+        const int xn_ = (s_) - 2 * row; \
+        if (active && xn_ >= 0 && xn_ < mb_w) { \
+            const int mb_ = row * mb_w + xn_; \
+            p_rec = gload1(mbs + (size_t)mb_ * sizeof(MbRec) + (l & 7) * 4); \
+            const gbyte *px_ = plane + (size_t)(row * rows_per_mb) * pitch + xn_ * 16; \
+            p_right = gload1(px_ + (size_t)my_row * pitch + 12); \
+            p_bot = gload4(px_ + (size_t)(rows_per_mb - 1) * pitch); \
+            const gbyte *rs_ = resid + (size_t)mb_ * 768; \
+            if (is_chroma) p_res0 = gload4(rs_ + 512 + l * 16);              /* plane (l >> 3), row (l & 7): 8 int16 */ \
+            else { p_res0 = gload4(rs_ + l * 32); p_res1 = gload4(rs_ + l * 32 + 16); } \
+        } \
     } while (0)
-#pragma unroll
-    for (int k = 0; k < NSLOTS; k++) { int row = g + kIGroups * k; if (row == 0) JM_PREFETCH(k, 0, 0); }
-    for (int s = 0; s < n_steps; s++) {
-        uint32_t c_rec[NSLOTS], c_right[NSLOTS]; uint4 c_res0[NSLOTS], c_res1[NSLOTS], c_bot[NSLOTS];
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            c_rec[k] = p_rec[k]; c_right[k] = p_right[k]; c_res0[k] = p_res0[k]; c_res1[k] = p_res1[k]; c_bot[k] = p_bot[k];
-            asm volatile("" : "+v"(c_rec[k]), "+v"(c_right[k]), "+v"(c_res0[k].x), "+v"(c_res0[k].y), "+v"(c_res0[k].z), "+v"(c_res0[k].w),
-                              "+v"(c_res1[k].x), "+v"(c_res1[k].y), "+v"(c_res1[k].z), "+v"(c_res1[k].w),
-                              "+v"(c_bot[k].x), "+v"(c_bot[k].y), "+v"(c_bot[k].z), "+v"(c_bot[k].w));
-        }
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            int row = g + kIGroups * k, xn = s + 1 - 2 * row;
-            if (row < mb_h && xn >= 0 && xn < mb_w) JM_PREFETCH(k, row, xn);
-        }
-#pragma unroll
-        for (int k = 0; k < NSLOTS; k++) {
-            int row = g + kIGroups * k, x = s - 2 * row;
-            if (row < mb_h && x >= 0 && x < mb_w) {
-                if (is_chroma) intra_chroma_mb(pp, lds, x, row, l, g, c_rec[k], c_res0[k], c_right[k], c_bot[k]);
-                else intra_luma_mb(pp, lds, x, row, l, g, c_rec[k], c_res0[k], c_res1[k], c_right[k], c_bot[k]);
+    if (s_begin == 2 * row) JM_PREFETCH(s_begin);
+    for (int s = s_begin; s <= s_end; s++) {
+        const uint32_t c_rec = p_rec, c_right = p_right, c_ring = p_ring; const uint4 c_res0 = p_res0, c_res1 = p_res1, c_bot = p_bot;
+        const int x = s - 2 * row;
+        // the row above: macroblock x + 1 was fetched during the previous step, macroblock x + 2 is fetched now for the next one (it is final
+        // once the band above completed step s, i.e. published s + 1)
+        if (takes_ring && l < 4 && x >= 1 && x + 1 < mb_w) ring0(x + 1)[l] = c_ring;
+        wait_above(s + 1);
+        if (takes_ring && l < 4 && x >= 0 && x + 2 < mb_w) p_ring = fetch_above(x + 2);
+        JM_PREFETCH(s + 1);
+        if (active && x >= 0 && x < mb_w) {
+            if (is_chroma) intra_chroma_mb(cx, lds, x, row, lrow, l, g, c_rec, c_res0, c_right, c_bot);
+            else intra_luma_mb(cx, lds, x, row, lrow, l, g, c_rec, c_res0, c_res1, c_right, c_bot);
+            if (gives_ring) {
+                // hand the bottom row down (write-through), then publish the step; the wave that holds the band's last row wrote it itself
+                if (l < 4) __hip_atomic_store((JM_GLOBAL uint32_t *)(below + (size_t)x * 16), ((const uint32_t *)(is_chroma ? lds.cring(lrow, x & 3) : lds.lring(lrow, x & 3)))[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        if (gives_ring) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0) __hip_atomic_store(&prog[band], s == s_end ? 0x7fffffff : s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef JM_PREFETCH
 }
 
-size_t intra_lds_bytes(int mb_h) { return kTileBase + 32 * 992 + (size_t)mb_h * 80 + 64; }
-bool intra_lds_supported(int mb_w, int mb_h) { return mb_h <= kIGroups * kISlots && intra_lds_bytes(mb_h) <= 150 * 1024; }
+bool intra_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kIBandRows * kDeblockMaxBands; }
 
-void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st) {
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void *)k_intra_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)k_intra_lds<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set[dev] = true;
-    }
-    if (max_mb_h <= 3 * kIGroups) hipLaunchKernelGGL(k_intra_lds<3>, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
-    else hipLaunchKernelGGL(k_intra_lds<5>, dim3(2, n), dim3(512), intra_lds_bytes(max_mb_h), st, d_pics);
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *progress, hipStream_t st) {
+    const int bands = (max_mb_h + kIBandRows - 1) / kIBandRows;
+    (void)hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kDeblockProgressStride, st);
+    hipLaunchKernelGGL(k_intra_band, dim3(2 * bands, n), dim3(kIBandRows * 16), 0, st, d_pics, progress, kDeblockProgressStride);
 }
 
 }  // namespace jmamd

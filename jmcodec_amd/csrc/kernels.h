@@ -10,7 +10,7 @@ void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st);          // spin-wait wavefront (sparse intra, any height)
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);              // spin-wait wavefront (any height)
 bool intra_lds_supported(int mb_w, int mb_h);
-void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, hipStream_t st);
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *progress, hipStream_t st);   // banded wavefront; progress: n * kDeblockProgressStride ints, cleared by this call
 bool deblock_lds_supported(int mb_w, int mb_h);
 constexpr int kDeblockMaxBands = 32, kDeblockProgressStride = 2 * kDeblockMaxBands;
 // prep + LDS wavefront; progress: device array of n * kDeblockProgressStride ints (band step counters, cleared by this call)
