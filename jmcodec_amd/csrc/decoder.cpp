@@ -880,7 +880,9 @@ void Decoder::submit_task(PicTask *t) {
             pp.flat_scaling = flat ? 1 : 0;
         }
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
-        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_);
+        // (Intra8x8 together with constrained_intra_pred takes the spin-wait kernel: the randomised GPU sweep found two streams of that
+        //  combination -- dense intra macroblocks in P / B pictures -- that the LDS wavefront decodes with a few wrong samples; not yet explained)
+        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || (lds_intra8_ && !t->pps.constrained_intra));
         pp.want_intra_resid = lds_intra ? 1 : 0;
         pp.stages = PS_RECON;
         if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;
