@@ -1500,6 +1500,7 @@ static void begin_slice(Enc *e, const PicPlan *pp, const Sched *sc, int addr) {
     s->beta = p->deblock == 2 ? rnd_n(r, 13) - 6 : 0; s->tc = p->deblock == 2 ? rnd_n(r, 13) - 6 : 0;
     s->sao_l = p->sao && rnd_n(r, 8) != 0; s->sao_c = p->sao && rnd_n(r, 8) != 0;
     s->lf_across = rnd_n(r, 4) != 0;
+    if (!(s->sao_l || s->sao_c || !s->deblock_off)) s->lf_across = 1;      /* the flag is then not in the header: inferred = the PPS flag (7.4.7.1) */
     s->max_merge = p->merge_cand;
     if (s->type == 2) return;
     s->n_ref[0] = sc->n[0]; s->n_ref[1] = s->type == 0 ? sc->n[1] : 0;
