@@ -776,6 +776,18 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     }
     for (int i = 0; i < n_mbs; i++) if (scratch.slice_of[i] < 0) mbs[i] = blank;      // only what no slice covered (normally nothing)
     if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)
+    if (const char *dm = getenv("JM_AMD_DEC_DUMP_MB")) {      // developer aid: "picture:x:y" prints the records of a macroblock and its neighbours
+        int dp = 0, dx = 0, dy = 0;
+        if (sscanf(dm, "%d:%d:%d", &dp, &dx, &dy) == 3 && (dp < 0 || dp == (int)stat_pictures_.load())) {
+            for (int oy = -1; oy <= 0; oy++) for (int ox = -1; ox <= 1; ox++) {
+                const int x = dx + ox, y = dy + oy;
+                if (x < 0 || y < 0 || x >= t->sps.mb_w || y >= t->sps.mb_h || (oy == 0 && ox == 1)) continue;
+                const MbRec &m = mbs[y * t->sps.mb_w + x];
+                fprintf(stderr, "MB(%d,%d) kind %d flags 0x%02x modes 0x%02x qp %d slice %d cbp_blk 0x%04x i4 %02x%02x%02x%02x%02x%02x%02x%02x n_intra %d n_i8x8 %d slice_type %d\n", x, y, m.kind, m.flags, m.modes, m.qp, m.slice, m.cbp_blk,
+                        m.u.i4[0], m.u.i4[1], m.u.i4[2], m.u.i4[3], m.u.i4[4], m.u.i4[5], m.u.i4[6], m.u.i4[7], t->n_intra, t->n_i8x8, t->slices.empty() ? -1 : (int)t->slices[0].sh.type);
+            }
+        }
+    }
     t->n_slices = (int)t->slices.size();
     if (t->mf) {                                             // publish this picture's motion for direct prediction in later B pictures
         MotionField &f = *t->mf;
@@ -880,9 +892,12 @@ void Decoder::submit_task(PicTask *t) {
             pp.flat_scaling = flat ? 1 : 0;
         }
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
-        // (Intra8x8 together with constrained_intra_pred takes the spin-wait kernel: the randomised GPU sweep found two streams of that
-        //  combination -- dense intra macroblocks in P / B pictures -- that the LDS wavefront decodes with a few wrong samples; not yet explained)
-        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || (lds_intra8_ && !t->pps.constrained_intra));
+        // Exception, found by the randomised GPU sweep and not yet explained: with constrained_intra_pred, P / B pictures that are dense in intra
+        // macroblocks (three streams out of ~1,500: a block next to an I_PCM / inter neighbour) come out of the LDS wavefront with a few wrong
+        // samples, while the spin-wait kernel decodes them exactly -- so such pictures take the spin-wait kernel.  I pictures are not affected.
+        bool all_intra = true;
+        for (const SliceTask &st : t->slices) all_intra &= st.sh.type == SL_I;
+        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_) && (all_intra || !t->pps.constrained_intra || getenv("JM_AMD_DEC_LDS_CIP"));
         pp.want_intra_resid = lds_intra ? 1 : 0;
         pp.stages = PS_RECON;
         if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;
