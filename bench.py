@@ -237,7 +237,7 @@ def main():
             per_pic = {"inter": t("k_hevc_mc") + t("k_hevc_resid") + t("k_hevc_iresid"), "intra": t("k_hevc_intra"), "deblock": 2 * t("k_hevc_deblock") + t("k_hevc_sao")}
         else:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc["k_intra_lds"]["traffic_upper"],
+            per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc.get("k_intra_band", pmc.get("k_intra_lds", {"traffic_upper": 0}))["traffic_upper"],
                        "deblock": pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"traffic_upper": 0}))["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
         if (args.width, args.height) == (1920, 1080):
             traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
