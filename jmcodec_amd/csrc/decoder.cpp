@@ -892,12 +892,7 @@ void Decoder::submit_task(PicTask *t) {
             pp.flat_scaling = flat ? 1 : 0;
         }
         // dense intra pictures take the lockstep LDS wavefront; a few scattered intra macroblocks the spin-wait one
-        // Exception, found by the randomised GPU sweep and not yet explained: with constrained_intra_pred, P / B pictures that are dense in intra
-        // macroblocks (three streams out of ~1,500: a block next to an I_PCM / inter neighbour) come out of the LDS wavefront with a few wrong
-        // samples, while the spin-wait kernel decodes them exactly -- so such pictures take the spin-wait kernel.  I pictures are not affected.
-        bool all_intra = true;
-        for (const SliceTask &st : t->slices) all_intra &= st.sh.type == SL_I;
-        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_) && (all_intra || !t->pps.constrained_intra || getenv("JM_AMD_DEC_LDS_CIP"));
+        bool lds_intra = use_lds_intra_ && t->n_intra * 16 >= n_mbs && (t->n_i8x8 == 0 || lds_intra8_);
         pp.want_intra_resid = lds_intra ? 1 : 0;
         pp.stages = PS_RECON;
         if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;

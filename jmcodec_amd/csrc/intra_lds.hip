@@ -211,7 +211,8 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
             const int mode = (m0 >> (4 * b8)) & 15;
             uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8;          // corner sample of this block
             // edge path k: 0..7 = p[-1,7]..p[-1,0], 8 = p[-1,-1], 9..24 = p[0..15,-1] (top-right replaced by p[7,-1] when unavailable)
-            auto edge = [&](int k) -> int { return k <= 7 ? org[(8 - k) * kTS] : (k == 8 ? org[0] : org[1 + ((k - 9 > 7 && !c) ? 7 : k - 9)]); };
+            // (samples of unavailable neighbours count as 128: see the Intra4x4 path)
+            auto edge = [&](int k) -> int { return k <= 7 ? (a ? org[(8 - k) * kTS] : 128) : (k == 8 ? (d ? org[0] : 128) : (b ? org[1 + ((k - 9 > 7 && !c) ? 7 : k - 9)] : 128)); };
             raw[l] = (uint8_t)edge(l);
             if (l < 9) raw[16 + l] = (uint8_t)edge(16 + l);
             auto filt = [&](int k) -> int {
@@ -221,6 +222,7 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
                 if (k == 8) { lo = a ? 7 : 8; hi = b ? 9 : 8; }
                 if (k == 9) lo = d ? 8 : 9;
                 if (k == 24) hi = 24;
+                if (k == 8 && !d) return 128;
                 return (raw[lo] + 2 * raw[k] + raw[hi] + 2) >> 2;
             };
             int f1 = filt(l), f2 = l < 9 ? filt(16 + l) : 0;
@@ -290,8 +292,19 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
                 int st = org[1] + org[2] + org[3] + org[4], sl = org[kTS] + org[2 * kTS] + org[3 * kTS] + org[4 * kTS];
                 pred = (a && b) ? (st + sl + 4) >> 3 : (a ? (sl + 2) >> 2 : (b ? (st + 2) >> 2 : 128));
             } else {
-                int v0 = org[off[0]], v1 = org[off[1]], v2 = org[off[2]];
-                pred = kd == 2 ? (v0 + 2 * v1 + v2 + 2) >> 2 : (kd == 1 ? (v1 + v2 + 1) >> 1 : v1);
+                // Samples of a neighbour that is not available count as 128, as in k_recon_intra and the oracle.  A conforming stream never selects a
+                // mode that reads them; the sweep's generator did (constrained_intra_pred: Horizontal-Down next to an inter corner), and the three
+                // decoders have to agree on such a stream too.
+                const bool d = (bx > 0 && by > 0) ? true : (bx > 0 ? availB : (by > 0 ? availA : availD));
+                int v[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    int k = c - 1 + t;
+                    k = k < 1 ? 1 : (k > 13 ? 13 : k);
+                    const bool ok = k <= 4 ? a : (k == 5 ? d : b);
+                    v[t] = ok ? org[off[t]] : 128;
+                }
+                pred = kd == 2 ? (v[0] + 2 * v[1] + v[2] + 2) >> 2 : (kd == 1 ? (v[1] + v[2] + 1) >> 1 : v[1]);
             }
             org[(1 + py) * kTS + 1 + px] = (uint8_t)clip1(pred + rsd[blk]);
         }
