@@ -466,11 +466,12 @@ def test_decode_to_encoder_surface_on_device(oracle):
 
 
 def test_constrained_intra_unavailable_samples_count_as_128(oracle):
-    """Found by tools/gpu_sweep.py: with constrained_intra_pred the generator selects Intra4x4 Horizontal-Down next to an INTER corner neighbour (the
+    """Found by tools/gpu_sweep.py: with constrained_intra_pred the generator selected (then unconditionally, now with nc_corner=1) Intra4x4 Horizontal-Down next to an INTER corner neighbour (the
     sample is not available, so a conforming encoder would not); oracle, generator and the spin-wait kernel count such samples as 128 and the LDS intra
     wavefront has to as well.  The P pictures of this stream are dense enough in intra macroblocks to take the LDS wavefront (three deblocking / intra bands)."""
     kw = dict(width=320, height=520, frames=7, qp=18, gop=4, seed=153603, mode=1, deblock=0, num_ref=3, slices=1, cabac=1, cabac_idc=0, t8x8=1, bframes=2,
-              direct_temporal=0, wp=1, dinf8=0, scaling=0, rplm=1, cip=1, chroma_qp_off=-4, alpha_off=3, beta_off=0, poc_type=0)
+              direct_temporal=0, wp=1, dinf8=0, scaling=0, rplm=1, cip=1, chroma_qp_off=-4, alpha_off=3, beta_off=0, poc_type=0,
+              nc_corner=1)            # the generator's explicit switch for this (non-conforming) choice
     data = streams.generate(**kw)
     want, n, w, h = oracle.decode(data, 1)
     with jmcodec_amd.JmAmdDec(0, 1) as d:

@@ -38,7 +38,8 @@ def h264_params(r):
              qp=r.choice([18, 24, 28, 36, 44]), gop=r.choice([2, 4, 6, 30]),
              seed=r.randrange(1 << 20), mode=r.choice([0, 1, 1]), deblock=r.choice([0, 1, 1, 2]), num_ref=r.randint(1, 4), slices=r.randint(1, 3), cabac=cab, cabac_idc=r.randint(0, 2),
              t8x8=r.randint(0, 1), bframes=b, direct_temporal=r.randint(0, 1), wp=r.choice([0, 0, 1, 2]), dinf8=r.randint(0, 1), scaling=r.choice([0, 0, 1, 2]), rplm=r.choice([0, 0, 1]),
-             cip=r.choice([0, 0, 1]), chroma_qp_off=r.choice([0, 0, -4, 6]), alpha_off=r.choice([0, 0, 3, -3]), beta_off=r.choice([0, 0, -2, 2]), poc_type=r.choice([0, 2]))
+             cip=r.choice([0, 0, 1]), chroma_qp_off=r.choice([0, 0, -4, 6]), alpha_off=r.choice([0, 0, 3, -3]), beta_off=r.choice([0, 0, -2, 2]), poc_type=r.choice([0, 2]),
+             nc_corner=r.choice([0, 0, 0, 1]))
     if not b and r.random() < 0.3:
         a["mmco"] = 1
     return a

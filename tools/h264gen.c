@@ -53,6 +53,8 @@ typedef struct {
     int scaling;                /* 0 flat, 1 scaling lists in the SPS, 2 in the PPS (forces High profile)             */
     int rplm;                   /* 1: random ref_pic_list_modification() in P / B slices (fuzz)                       */
     int mmco;                   /* 1: random memory_management_control_operations, long-term references (P-only streams) */
+    int nc_corner;              /* 1: Intra4x4 modes 4-6 may be chosen although p[-1,-1] is unavailable (NON-CONFORMING; probes the decoders'
+                                   common convention "unavailable samples count as 128", which constrained_intra_pred exposes)   */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -456,6 +458,8 @@ static void store_mv(Enc *e, MbE *m, int bx, int by, int bw, int bh, int mvx, in
 static inline int bX(int blk) { return (blk & 1) + 2 * ((blk >> 2) & 1); }
 static inline int bY(int blk) { return ((blk >> 1) & 1) + 2 * (blk >> 3); }
 /* which Intra4x4 modes are usable for block blk; fills edge arrays */
+static __thread int g_nc_corner;      /* GenParams.nc_corner of the stream being generated */
+static __thread int g_i4_avail_d;     /* p[-1,-1] of the block last given to i4_edges() is available (8.3.1.2: modes 4, 5, 6 need it) */
 static void i4_edges(Enc *e, int mx, int my, int blk, int *T, int *L, int *aA, int *aB) {
     Frame *c = &e->cur; int bx = bX(blk), by = bY(blk);
     uint8_t *d = c->y + (my * 16 + by * 4) * c->sy + mx * 16 + bx * 4; int st = c->sy;
@@ -467,13 +471,16 @@ static void i4_edges(Enc *e, int mx, int my, int blk, int *T, int *L, int *aA, i
     for (int i = 0; i < 4; i++) { T[i] = availB ? d[-st + i] : 128; L[i] = availA ? d[i * st - 1] : 128; }
     for (int i = 4; i < 8; i++) T[i] = (availB && availC) ? d[-st + i] : T[3];
     T[-1] = L[-1] = availD ? d[-st - 1] : 128;
-    *aA = availA; *aB = availB;
+    *aA = availA; *aB = availB; g_i4_avail_d = availD || g_nc_corner;
 }
+/* (with constrained_intra_pred the corner can be the only unavailable neighbour; until round 1 this function did not look at it and the
+   generator wrote non-conforming Horizontal-Down / Diagonal-Down-Right / Vertical-Right blocks, which is how the decoders' handling of
+   unavailable samples came to be compared) */
 static int i4_mode_ok(int mode, int aA, int aB) {
     if (mode == 2) return 1;
     if (mode == 0 || mode == 3 || mode == 7) return aB;
     if (mode == 1 || mode == 8) return aA;
-    return aA && aB;
+    return aA && aB && g_i4_avail_d;
 }
 static void i4_predict(int mode, const int *T, const int *L, int aA, int aB, int *p) {
     switch (mode) {
@@ -2005,6 +2012,7 @@ static void encode_frame(Enc *e, int t, int is_b) {
 
 /* library entry: returns malloc'ed Annex-B stream */
 int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const char *recon_path) {
+    g_nc_corner = gp->nc_corner;
     Enc *e = (Enc *)calloc(1, sizeof(Enc));
     e->p = *gp;
     GenParams *p = &e->p;
@@ -2066,7 +2074,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
