@@ -216,9 +216,11 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             // relaxed polls: an acquire load invalidates the XCD's L2 on EVERY iteration (the same finding as in deblock_lds.hip); one acquire fence
             // after the wait is enough
             while (__hip_atomic_load(&prog[cy - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
+            // ONE acquire for the workgroup: the invalidation acts on the caches (the CU's L1, the XCD's L2), which all four waves share
+            if (!(g_hevc_exp & 8)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
         __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (g_hevc_exp & 8) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __shared__ __align__(16) uint8_t ty[65 * kYS];            // luma tile
     __shared__ __align__(16) uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             *(uint4 *)(cpl + (size_t)y * pp.pitch + 2 * x) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
-    __threadfence();
+    // every wave waits until ITS stores have reached the L2; the release store below (one wave) then writes the L2 back once for all of them
+    if (g_hevc_exp & 8) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     }   // ctb.intra_count
     if (threadIdx.x == 0) __hip_atomic_store(&prog[cy], cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
