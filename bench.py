@@ -295,7 +295,7 @@ def main():
         "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) ") + f"{args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
-                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (every second handle: synchronous DMA from device staging; the others: pinned slot + memcpy)"},
+                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (two of five handles: synchronous DMA from device staging; the others: pinned slot + memcpy)"},
         "frames": frames_total,
         "decode_errors": int(errors),
         "host_ms_per_picture": host_diag,

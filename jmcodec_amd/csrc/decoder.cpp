@@ -155,8 +155,11 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     // so only some of the handles use it; the others keep the former scheme -- copy engine -> pinned host slot ahead of time, CPU memcpy in
     // output() -- which costs CPU instead of time in that queue.  JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.
     {
-        int fa = 1, fb = 2;                                    // fetch for `fa` of every `fb` handles (JM_AMD_DEC_OUT_FETCH="a/b")
-        if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 1; fb = 2; } }
+        // fetch for `fa` of every `fb` handles (JM_AMD_DEC_OUT_FETCH="a/b").  2/5 by measurement, 8 default bench runs per setting on one box: 1/2 is the
+        // fastest when it works (13.4-14.5 k frames/s) but falls into a second regime in 3 runs of 10 (6.8-7.0 k: the fetching streams starve behind the
+        // other handles' asynchronous copies and finish last); 2/5 gave 12.3-13.7 k in 8 of 8, 1/3 12.7-13.6 k with one 10.0 k, 1/4 10.6-12.9 k.
+        int fa = 2, fb = 5;
+        if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 2; fb = 5; } }
         out_fetch_ = out_via_copy_engine_ && !getenv("JM_AMD_DEC_OUT_PINNED") && (handle_index_ % fb) < fa;
     }
     if (engine_) engine_->set_profile(profile_);
