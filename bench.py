@@ -58,7 +58,14 @@ def main():
     os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank % max(n_dev, 1))
     if world > 1 and "JM_AMD_DEC_THREADS" not in os.environ:      # share the host cores between the ranks of this node
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        os.environ["JM_AMD_DEC_THREADS"] = str(max(8, min(64, (os.cpu_count() or 8) // max(local_world, 1))))
+        cpus = os.cpu_count() or 8
+        try:                                                       # a container may own far fewer CPUs than it sees (cgroup v2 quota)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cpus = min(cpus, int(int(q) * 1.75 / int(per) + 0.5))
+        except Exception:
+            pass
+        os.environ["JM_AMD_DEC_THREADS"] = str(max(4, min(64, cpus // max(local_world, 1))))
     red_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
 
     import __graft_entry__ as ge
