@@ -72,7 +72,7 @@ def main():
     if not os.path.exists(os.path.join(ROOT, "jmcodec_amd", "lib", "libjm_amd_dec.so")):
         ge.build()
     import jmcodec_amd
-    from jmcodec_amd import streams
+    from tools import streams
     L = jmcodec_amd.lib()
     if not jmcodec_amd.jm_nvdec_is_hw_support() and not args.parse_only:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")

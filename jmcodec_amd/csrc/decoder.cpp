@@ -46,7 +46,9 @@ struct Pool {
         for (;;) {
             std::pair<Decoder *, PicTask *> job;
             { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); job = q.front(); q.pop_front(); }
-            job.first->parse_task(job.second, scratch);
+            try { job.first->parse_task(job.second, scratch); }
+            catch (const std::exception &e) { job.first->parse_exception(job.second, e.what()); }
+            catch (...) { job.first->parse_exception(job.second, "unknown exception"); }
         }
     }
 };
@@ -75,7 +77,9 @@ Decoder::~Decoder() {
     }
 }
 
-void Decoder::fail(const std::string &msg) {
+void Decoder::fail(const std::string &msg) {            // any thread
+    static std::mutex fm;
+    std::lock_guard<std::mutex> lk(fm);
     if (!failed_) { error_ = msg; fprintf(stderr, "jm_amd_dec: %s\n", msg.c_str()); }
     failed_ = true;
 }
@@ -255,7 +259,9 @@ bool Decoder::gpu_alloc_sequence() {
     size_t n_mbs = (size_t)mb_w_ * mb_h_;
     frame_bytes_ = (size_t)disp_w_ * disp_h_ * 3 / 2;
     // MbRec + worst-case coefficients + motion records (16 vectors; 72 int16 for B / weighted slices) + slice tables
-    job_cap_ = n_mbs * (sizeof(MbRec) + 816 + (seq_.profile_idc == 66 ? 64 : kBiRecInt16 * 2)) + 256 * (sizeof(SliceRec) + (seq_.profile_idc == 66 ? 0 : sizeof(SliceWp))) + 4096;
+    // (always the Main / High layout: a later SPS of the same size may switch profile without re-activation, and a PPS may enable weighted
+    //  prediction under any profile_idc)
+    job_cap_ = n_mbs * (sizeof(MbRec) + 816 + kBiRecInt16 * 2) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096;
     if (codec_ == 1) job_cap_ = n_mbs * 128 + (1u << 20);            // HEVC job lists vary a lot in size: start small, grow on demand (ensure_job_cap)
     if (parse_only_) {
         for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
@@ -421,7 +427,10 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
 // sequence activation, POC, DPB
 // =============================================================================================
 bool Decoder::activate(const SeqParams &sps) {
-    bool changed = !seq_active_ || sps.mb_w != mb_w_ || sps.mb_h != mb_h_;
+    // a new coded video sequence needs new device resources when the coded size changes, and new output slots / stream_info when only the
+    // cropping does (hevc_activate compares the display size too); job buffers are sized for every profile, so a Baseline -> High switch
+    // at the same size needs nothing
+    bool changed = !seq_active_ || sps.mb_w != mb_w_ || sps.mb_h != mb_h_ || sps.disp_w() != disp_w_ || sps.disp_h() != disp_h_;
     seq_ = sps;
     dpb_size_ = sps.dpb_frames();
     // display order == decode order when POC type 2 (8.2.1.3): no bumping delay needed
@@ -459,29 +468,32 @@ int Decoder::compute_poc(const SliceHeader &sh) {                               
     if (s.poc_type == 0) {
         int max_lsb = 1 << s.log2_max_poc_lsb;
         int prev_msb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_msb_, prev_lsb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_lsb_;
-        int msb = prev_msb;
-        if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
-        else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-        if (sh.nal_ref_idc) { prev_poc_msb_ = msb; prev_poc_lsb_ = sh.poc_lsb; }
-        int top = msb + sh.poc_lsb;
-        return std::min(top, top + sh.delta_poc_bottom);
+        long long msb = prev_msb;
+        if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = (long long)prev_msb + max_lsb;
+        else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = (long long)prev_msb - max_lsb;
+        if (msb > (1ll << 30) || msb < -(1ll << 30)) msb = 0;                     // > 2^14 wraps of a 16-bit lsb without an IDR picture: not a real stream
+        if (sh.nal_ref_idc) { prev_poc_msb_ = (int)msb; prev_poc_lsb_ = sh.poc_lsb; }
+        long long top = msb + sh.poc_lsb;
+        return (int)std::min(top, top + sh.delta_poc_bottom);
     }
-    int prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
-    int off = sh.idr ? 0 : (prev_fn > sh.frame_num ? prev_off + max_fn : prev_off);
+    // 64-bit arithmetic: offsets are se(v) of a hostile stream, and sums of them must not overflow (the result is truncated, never UB)
+    long long prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
+    long long off = sh.idr ? 0 : (prev_fn > sh.frame_num ? prev_off + max_fn : prev_off);
+    if (off > (1ll << 40)) off = 0;
     prev_frame_num_offset_ = off;
-    if (s.poc_type == 2) return sh.idr ? 0 : (sh.nal_ref_idc ? 2 * (off + sh.frame_num) : 2 * (off + sh.frame_num) - 1);
-    int abs_fn = s.num_ref_frames_in_poc_cycle ? off + sh.frame_num : 0;
+    if (s.poc_type == 2) return (int)(sh.idr ? 0 : (sh.nal_ref_idc ? 2 * (off + sh.frame_num) : 2 * (off + sh.frame_num) - 1));
+    long long abs_fn = s.num_ref_frames_in_poc_cycle ? off + sh.frame_num : 0;
     if (!sh.nal_ref_idc && abs_fn > 0) abs_fn--;
-    int expected = 0, cycle = 0;
+    long long expected = 0, cycle = 0;
     for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) cycle += s.offset_for_ref_frame[i];
     if (abs_fn > 0) {
-        int cnt = (abs_fn - 1) / s.num_ref_frames_in_poc_cycle, in_cycle = (abs_fn - 1) % s.num_ref_frames_in_poc_cycle;
+        long long cnt = (abs_fn - 1) / s.num_ref_frames_in_poc_cycle; int in_cycle = (int)((abs_fn - 1) % s.num_ref_frames_in_poc_cycle);
         expected = cnt * cycle;
         for (int i = 0; i <= in_cycle; i++) expected += s.offset_for_ref_frame[i];
     }
     if (!sh.nal_ref_idc) expected += s.offset_for_non_ref_pic;
-    int top = expected + sh.delta_poc[0];
-    return std::min(top, top + s.offset_for_top_to_bottom + sh.delta_poc[1]);
+    long long top = expected + sh.delta_poc[0];
+    return (int)std::min(top, top + s.offset_for_top_to_bottom + sh.delta_poc[1]);
 }
 
 void Decoder::flush_dpb(std::vector<int> &out) {
@@ -761,7 +773,12 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     w.mbs = mbs; w.mv_ext = mv_ext_buf.data(); w.mv_ext_cap = (uint32_t)n_mbs * (big_rec ? kBiRecInt16 / 2 : 16);
     w.coef = coef;
     size_t fixed = (size_t)n_mbs * sizeof(MbRec) + 256 * sizeof(SliceRec);
-    w.coef_cap = (uint32_t)((js.cap - fixed - (size_t)n_mbs * (big_rec ? kBiRecInt16 * 2 : 64) - (big_rec ? 256 * sizeof(SliceWp) : 0)) / 2);
+    {   // what is left for coefficients once the motion records and the slices' weight tables have their worst-case room (signed: a buffer that
+        // cannot even hold the fixed part must fail the picture, not wrap into a huge capacity)
+        long long room = (long long)js.cap - (long long)fixed - (long long)n_mbs * (big_rec ? kBiRecInt16 * 2 : 64) - 256ll * (long long)sizeof(SliceWp) - 64;
+        if (room <= 0) { t->error = "job buffer too small for this picture"; stat_errors_++; fail(t->error); room = 0; }
+        w.coef_cap = (uint32_t)(room / 2);
+    }
     SyntaxDigest dg = digest_;
     for (size_t si = 0; si < t->slices.size(); si++) {
         SliceTask &s = t->slices[si];
@@ -807,6 +824,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
     t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count;
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
+    if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++; t->any_wp = false; }
     if (t->any_wp) {
         t->wp_offset = t->upload_bytes;
         for (auto &s : t->slices) { if (!s.has_wp) memset(&s.wp, 0, sizeof s.wp); memcpy(js.host + t->upload_bytes, &s.wp, sizeof(SliceWp)); t->upload_bytes += sizeof(SliceWp); }
@@ -827,6 +845,16 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     submit_ready();
     // last touch of *this by this worker: another worker may already have submitted the task (and the caller may be waiting in the
     // destructor), so the count is dropped and the waiter is woken while the lock is still held
+    { std::lock_guard<std::mutex> lk(mtx_); parse_pending_--; cv_.notify_all(); }
+}
+
+// an exception escaped the entropy decoder of one picture (allocation failure): the handle fails, the pipeline protocol still completes
+void Decoder::parse_exception(PicTask *t, const char *what) {
+    fail(std::string("exception while parsing a picture: ") + what);
+    stat_errors_++;
+    t->error = what;
+    t->state.store(1, std::memory_order_release);
+    submit_ready();
     { std::lock_guard<std::mutex> lk(mtx_); parse_pending_--; cv_.notify_all(); }
 }
 
@@ -915,12 +943,13 @@ void Decoder::submit_task(PicTask *t) {
 }
 
 // called by the engine thread when the batch containing this picture has finished on the device
-void Decoder::on_engine_done(const EnginePic &p) {
+void Decoder::on_engine_done(const EnginePic &p, bool failed) {
+    if (failed) { stat_errors_++; fail("device error: the batch holding this handle's picture did not complete"); }
     {
         std::lock_guard<std::mutex> lk(mtx_);
         if (p.job_slot >= 0) jobs_[p.job_slot].busy = false;
-        for (OutSlot *o : p.slots_before) o->ready = true;
-        for (OutSlot *o : p.slots_after) o->ready = true;
+        for (OutSlot *o : p.slots_before) { o->ready = true; if (failed) o->has_data = false; }
+        for (OutSlot *o : p.slots_after) { o->ready = true; if (failed) o->has_data = false; }
         outstanding_--;
         cv_.notify_all();                  // under the lock: the handle may be destroyed as soon as the count reaches zero
     }

@@ -106,11 +106,13 @@ public:
     int  set_option(const char *key, long long v);
     long long get_stat(const char *key) const;
     void set_device(int d) { device_ = d; }
+    void api_exception(const char *what) { fail(std::string("exception in the decoder: ") + what); }
+    void parse_exception(PicTask *t, const char *what);   // worker-pool: an exception escaped parse_task
 
     // worker-pool entry
     void parse_task(PicTask *t, ParseScratch &scratch);
     // engine completion callback + engine-private per-decoder state
-    void on_engine_done(const struct EnginePic &p);
+    void on_engine_done(const struct EnginePic &p, bool failed = false);
     struct EngineDecoderState &engine_state() { return *eng_state_; }
 
 private:
@@ -156,7 +158,7 @@ private:
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
     std::string error_;
-    bool failed_ = false, inited_ = false;
+    std::atomic<bool> failed_{false}; bool inited_ = false;
 
     // splitter
     std::vector<uint8_t> in_; size_t scan_ = 0; bool have_start_ = false; size_t nal_start_ = 0;
@@ -172,7 +174,7 @@ private:
     int cur_ = -1;
     std::unique_ptr<PicTask> pending_;
     SliceHeader first_sh_;
-    int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0, prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;
+    int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0; long long prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;
     int decode_count_ = 0, max_lt_idx_ = -1;
     uint64_t next_seq_ = 0;
     std::vector<int> carry_out_;               // outputs decided before the next picture starts (IDR flush)

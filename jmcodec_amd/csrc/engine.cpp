@@ -74,13 +74,18 @@ EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     b.pics.clear();
     std::vector<Decoder *> seen;
+    size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
     for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
         Decoder *d = it->dec;
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
         EngineDecoderState &es = d->engine_state();
         bool ok = it->lane() == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        // the pack-job tables hold 2 * kMaxBatch entries each: a picture whose display frames no longer fit waits for the next batch
+        // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
+        if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
         if (!ok) { ++it; continue; }
+        n_pre += it->out_before.size(); n_post += it->out_after.size();
         es.lane = lane_idx; es.inflight++;
         b.pics.push_back(std::move(*it));
         it = pending_.erase(it);
@@ -116,8 +121,8 @@ void Engine::launch(Lane &ln, Batch &b) {
             if (p.uploaded && (!last_upload || p.upload_seq > last_upload->upload_seq)) last_upload = &p;
         }
         if (p.wait_prev_pack) wait_pack = true;
-        for (auto &j : p.out_before) if (b.n_pre < 2 * kMaxBatch) b.h_jobs[b.n_pre++] = j;
-        for (auto &j : p.out_after) if (b.n_post < 2 * kMaxBatch) b.h_jobs[2 * kMaxBatch + b.n_post++] = j;
+        for (auto &j : p.out_before) b.h_jobs[b.n_pre++] = j;                           // form() keeps both tables within 2 * kMaxBatch
+        for (auto &j : p.out_after) b.h_jobs[2 * kMaxBatch + b.n_post++] = j;
         if (!p.out_before.empty() || !p.out_after.empty()) { max_w = std::max(max_w, p.disp_w); max_h = std::max(max_h, p.disp_h); }
         int st = b.h_pics[i].stages;
         if (hevc && p.has_picture) { const int hs = p.hp.stages; if (hs & (HPS_MC | HPS_RESID)) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; } if (hs & HPS_INTRA) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; } if (hs & (HPS_DEBLOCK | HPS_SAO)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; } }
@@ -179,8 +184,8 @@ void Engine::launch(Lane &ln, Batch &b) {
     ln.pack_hist[1] = ln.pack_hist[0]; ln.pack_hist[0] = b.packed;
 }
 
-void Engine::complete(Batch &b) {
-    if (profile_) {
+void Engine::complete(Batch &b, bool failed) {
+    if (profile_ && !failed) {
         std::lock_guard<std::mutex> lk(sm_);
         auto add = [&](int cls, int e0, int e1, bool ran) {
             if (!ran) return;
@@ -192,7 +197,7 @@ void Engine::complete(Batch &b) {
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
-    for (auto &p : b.pics) p.dec->on_engine_done(p);
+    for (auto &p : b.pics) p.dec->on_engine_done(p, failed);
     b.pics.clear();
 }
 
@@ -202,8 +207,13 @@ void Engine::run() {
         bool progressed = false;
         // 1. retire finished batches (oldest first per lane)
         for (auto &ln : lanes_) {
-            while (ln.inflight > 0 && hipEventQuery(ln.ring[ln.tail].done) == hipSuccess) {
-                { auto t0 = std::chrono::steady_clock::now(); complete(ln.ring[ln.tail]); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
+            while (ln.inflight > 0) {
+                // hipErrorNotReady = still running.  Anything else that is not success is a sticky device error (kernel fault, lost device):
+                // the batch is retired as FAILED -- its handles report the error and release their slots -- instead of being polled forever.
+                const hipError_t q = hipEventQuery(ln.ring[ln.tail].done);
+                if (q == hipErrorNotReady) break;
+                if (q != hipSuccess && !device_failed_) { device_failed_ = true; fprintf(stderr, "jm_amd_dec: device %d failed: %s -- every handle on it now returns errors\n", device_, hipGetErrorString(q)); }
+                { auto t0 = std::chrono::steady_clock::now(); complete(ln.ring[ln.tail], q != hipSuccess); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
                 progressed = true;
             }
@@ -217,6 +227,7 @@ void Engine::run() {
             bool have;
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
             if (!have) continue;
+            if (device_failed_) { complete(b, true); progressed = true; continue; }      // nothing can run any more: fail the pictures right away
             { auto t0 = std::chrono::steady_clock::now(); launch(ln, b); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.launch_ns += ns; }
             ln.head = (ln.head + 1) % kBatchRing; ln.inflight++;
             progressed = true;

@@ -94,7 +94,7 @@ private:
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
-    void complete(Batch &b);
+    void complete(Batch &b, bool failed);
 
     int device_;
     ihipStream_t *copy_stream_ = nullptr;
@@ -102,7 +102,7 @@ private:
     Lane lanes_[kLanes];
     std::mutex m_; std::condition_variable cv_;
     std::deque<EnginePic> pending_;
-    bool profile_ = false, ok_ = false;
+    bool profile_ = false, ok_ = false, device_failed_ = false;
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };

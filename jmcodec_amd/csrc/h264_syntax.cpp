@@ -74,36 +74,42 @@ std::string ParamSets::parse_sps(BitReader &br) {
     SeqParams s;
     memset(s.scaling4, 16, sizeof s.scaling4); memset(s.scaling8, 16, sizeof s.scaling8);
     s.profile_idc = br.u(8); s.constraint_flags = br.u(8); s.level_idc = br.u(8);
-    s.id = br.ue();
-    if (s.id > 31) return "sps id out of range";
+    { uint32_t id = br.ue(); if (id > 31) return "sps id out of range"; s.id = (int)id; }
     switch (s.profile_idc) {
     case 100: case 110: case 122: case 244: case 44: case 83: case 86: case 118: case 128: case 138: case 139: case 134: case 135:
-        s.chroma_format_idc = br.ue();
+        { uint32_t cf = br.ue(); if (cf > 3) return "bad chroma_format_idc"; s.chroma_format_idc = (int)cf; }
         if (s.chroma_format_idc == 3) br.u1();
-        s.bit_depth_luma = 8 + br.ue(); s.bit_depth_chroma = 8 + br.ue();
+        { uint32_t bl = br.ue(), bc = br.ue(); if (bl > 6 || bc > 6) return "bad bit depth"; s.bit_depth_luma = 8 + (int)bl; s.bit_depth_chroma = 8 + (int)bc; }
         br.u1();
         s.scaling_matrix_present = br.u1();
         if (s.scaling_matrix_present) read_scaling_matrix(br, s.scaling4, s.scaling8, s.chroma_format_idc != 3 ? 8 : 12, nullptr, nullptr);
         break;
     default: break;
     }
-    s.log2_max_frame_num = 4 + br.ue();
-    s.poc_type = br.ue();
-    if (s.poc_type == 0) s.log2_max_poc_lsb = 4 + br.ue();
+    // every ue() below is range-checked as an unsigned value BEFORE it is narrowed: a crafted SPS may carry 0xFFFFFFFE in any field
+    // (7.4.2.1.1 ranges: log2_max_frame_num_minus4 / log2_max_pic_order_cnt_lsb_minus4 0..12, max_num_ref_frames 0..16)
+    { uint32_t v = br.ue(); if (v > 12) return "log2_max_frame_num out of range"; s.log2_max_frame_num = 4 + (int)v; }
+    { uint32_t v = br.ue(); if (v > 2) return "bad pic_order_cnt_type"; s.poc_type = (int)v; }
+    if (s.poc_type == 0) { uint32_t v = br.ue(); if (v > 12) return "log2_max_pic_order_cnt_lsb out of range"; s.log2_max_poc_lsb = 4 + (int)v; }
     else if (s.poc_type == 1) {
         s.delta_pic_order_always_zero = br.u1();
         s.offset_for_non_ref_pic = br.se(); s.offset_for_top_to_bottom = br.se();
-        s.num_ref_frames_in_poc_cycle = br.ue();
-        if (s.num_ref_frames_in_poc_cycle > 255) return "bad num_ref_frames_in_pic_order_cnt_cycle";
+        { uint32_t v = br.ue(); if (v > 255) return "bad num_ref_frames_in_pic_order_cnt_cycle"; s.num_ref_frames_in_poc_cycle = (int)v; }
         for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) s.offset_for_ref_frame[i] = br.se();
-    } else if (s.poc_type != 2) return "bad pic_order_cnt_type";
-    s.max_num_ref_frames = br.ue();
+    }
+    { uint32_t v = br.ue(); if (v > 16) return "max_num_ref_frames out of range"; s.max_num_ref_frames = (int)v; }
     s.gaps_allowed = br.u1();
-    s.mb_w = br.ue() + 1; s.mb_h = br.ue() + 1;
+    { uint32_t w = br.ue(), h = br.ue(); if (w >= 1024 || h >= 1024) return "picture too large"; s.mb_w = (int)w + 1; s.mb_h = (int)h + 1; }
+    if ((long long)s.mb_w * s.mb_h > 139264) return "picture too large";       // MaxFS of level 6.2 (Table A-1)
     s.frame_mbs_only = br.u1();
     if (!s.frame_mbs_only) br.u1();
     s.direct_8x8_inference = br.u1();
-    if (br.u1()) { s.crop_l = br.ue(); s.crop_r = br.ue(); s.crop_t = br.ue(); s.crop_b = br.ue(); }
+    if (br.u1()) {
+        uint32_t c[4]; for (auto &v : c) v = br.ue();
+        // frame_crop_*_offset in chroma units (4:2:0 -> 2 luma samples, 7.4.2.1.1): the cropped picture must keep at least one sample
+        if (c[0] > 8192 || c[1] > 8192 || c[2] > 8192 || c[3] > 8192 || 2 * (c[0] + c[1]) >= (uint32_t)s.mb_w * 16 || 2 * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
+        s.crop_l = (int)c[0]; s.crop_r = (int)c[1]; s.crop_t = (int)c[2]; s.crop_b = (int)c[3];
+    }
     if (br.u1()) {   // VUI (E.1.1); only the bitstream restriction matters to us
         if (br.u1()) { if (br.u(8) == 255) { br.u(16); br.u(16); } }
         if (br.u1()) br.u1();
@@ -114,12 +120,15 @@ std::string ParamSets::parse_sps(BitReader &br) {
         bool vcl_hrd = br.u1(); if (vcl_hrd) skip_hrd(br);
         if (nal_hrd || vcl_hrd) br.u1();
         br.u1();
-        if (br.u1()) { br.u1(); br.ue(); br.ue(); br.ue(); br.ue(); s.max_num_reorder_frames = br.ue(); s.max_dec_frame_buffering = br.ue(); }
+        if (br.u1()) {
+            br.u1(); br.ue(); br.ue(); br.ue(); br.ue();
+            uint32_t ro = br.ue(), db = br.ue();
+            if (!br.overrun() && ro <= 16 && db <= 16 && ro <= db) { s.max_num_reorder_frames = (int)ro; s.max_dec_frame_buffering = (int)db; }   // out-of-range restriction: ignored (falls back to the level's DPB size)
+        }
     }
     if (br.overrun()) return "SPS truncated";
     if (s.chroma_format_idc != 1 || s.bit_depth_luma != 8 || s.bit_depth_chroma != 8) return "only 8-bit 4:2:0 is supported";
     if (!s.frame_mbs_only) return "interlaced streams are not supported";
-    if (s.mb_w > 1024 || s.mb_h > 1024) return "picture too large";
     s.valid = true;
     sps[s.id] = s;
     return "";
@@ -127,14 +136,16 @@ std::string ParamSets::parse_sps(BitReader &br) {
 
 std::string ParamSets::parse_pps(BitReader &br) {
     PicParamSet p;
-    p.id = br.ue(); p.sps_id = br.ue();
-    if (p.id > 255 || p.sps_id > 31) return "pps/sps id out of range";
+    { uint32_t id = br.ue(), sid = br.ue(); if (id > 255 || sid > 31) return "pps/sps id out of range"; p.id = (int)id; p.sps_id = (int)sid; }
     p.cabac = br.u1(); p.bottom_field_poc_present = br.u1();
     if (br.ue() != 0) return "slice groups (FMO) are not supported";
-    p.num_ref_idx_default[0] = br.ue() + 1; p.num_ref_idx_default[1] = br.ue() + 1;
+    { uint32_t a = br.ue(), b = br.ue(); if (a > 31 || b > 31) return "num_ref_idx_default_active out of range"; p.num_ref_idx_default[0] = (int)a + 1; p.num_ref_idx_default[1] = (int)b + 1; }
     p.weighted_pred = br.u1(); p.weighted_bipred_idc = br.u(2);
-    p.init_qp = 26 + br.se(); br.se();
+    if (p.weighted_bipred_idc > 2) return "bad weighted_bipred_idc";
+    { int q = br.se(); if (q < -26 || q > 25) return "pic_init_qp out of range"; p.init_qp = 26 + q; }
+    br.se();
     p.chroma_qp_off = br.se();
+    if (p.chroma_qp_off < -12 || p.chroma_qp_off > 12) return "chroma_qp_index_offset out of range";
     p.deblock_ctrl_present = br.u1(); p.constrained_intra = br.u1(); p.redundant_pic_cnt_present = br.u1();
     p.second_chroma_qp_off = p.chroma_qp_off;
     const SeqParams *s = sps[p.sps_id].valid ? &sps[p.sps_id] : nullptr;
@@ -149,6 +160,7 @@ std::string ParamSets::parse_pps(BitReader &br) {
             read_scaling_matrix(br, p.scaling4, p.scaling8, 6 + 2 * (int)p.transform8x8, sps_has ? s->scaling4 : nullptr, sps_has ? s->scaling8 : nullptr);
         }
         p.second_chroma_qp_off = br.se();
+        if (p.second_chroma_qp_off < -12 || p.second_chroma_qp_off > 12) return "second_chroma_qp_index_offset out of range";
     }
     if (br.overrun()) return "PPS truncated";
     p.valid = true;
@@ -158,13 +170,12 @@ std::string ParamSets::parse_pps(BitReader &br) {
 
 std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_ref_idc, SliceHeader &sh) const {
     sh.nal_ref_idc = nal_ref_idc; sh.idr = nal_type == 5;
-    sh.first_mb = br.ue();
+    { uint32_t v = br.ue(); if (v >= 139264) return "first_mb_in_slice out of range"; sh.first_mb = (int)v; }
     uint32_t st = br.ue();
     if (st > 9) return "bad slice_type";
     sh.type = st % 5;
     if (sh.type > SL_I) return "SP/SI slices are not supported";
-    sh.pps_id = br.ue();
-    if (sh.pps_id > 255 || !pps[sh.pps_id].valid) return "slice refers to a missing PPS";
+    { uint32_t id = br.ue(); if (id > 255 || !pps[id].valid) return "slice refers to a missing PPS"; sh.pps_id = (int)id; }
     const PicParamSet &p = pps[sh.pps_id];
     if (!sps[p.sps_id].valid) return "slice refers to a missing SPS";
     const SeqParams &s = sps[p.sps_id];
@@ -175,8 +186,11 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if (p.redundant_pic_cnt_present) br.ue();
     if (sh.type == SL_B) sh.direct_spatial_mv_pred = br.u1();
     sh.num_ref_idx[0] = p.num_ref_idx_default[0]; sh.num_ref_idx[1] = p.num_ref_idx_default[1];
-    if (sh.type != SL_I && br.u1()) { sh.num_ref_idx[0] = br.ue() + 1; if (sh.type == SL_B) sh.num_ref_idx[1] = br.ue() + 1; }
-    if (sh.num_ref_idx[0] > 32 || sh.num_ref_idx[1] > 32) return "num_ref_idx_active out of range";
+    if (sh.type != SL_I && br.u1()) {
+        uint32_t a = br.ue(), b = sh.type == SL_B ? br.ue() : 0;
+        if (a > 31 || b > 31) return "num_ref_idx_active out of range";
+        sh.num_ref_idx[0] = (int)a + 1; if (sh.type == SL_B) sh.num_ref_idx[1] = (int)b + 1;
+    }
     if (sh.type != SL_B) sh.num_ref_idx[1] = 0;
     if (sh.type == SL_I) sh.num_ref_idx[0] = 0;
     int lists = sh.type == SL_I ? 0 : (sh.type == SL_B ? 2 : 1);
@@ -191,8 +205,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     }
     if ((p.weighted_pred && sh.type == SL_P) || (p.weighted_bipred_idc == 1 && sh.type == SL_B)) {
         sh.explicit_wp = true;
-        sh.luma_log2_wd = br.ue(); sh.chroma_log2_wd = br.ue();
-        if (sh.luma_log2_wd > 7 || sh.chroma_log2_wd > 7) return "bad weight denominator";
+        { uint32_t a = br.ue(), b = br.ue(); if (a > 7 || b > 7) return "bad weight denominator"; sh.luma_log2_wd = (int)a; sh.chroma_log2_wd = (int)b; }
         for (int l = 0; l < lists; l++) for (int i = 0; i < sh.num_ref_idx[l]; i++) {
             int lw = 1 << sh.luma_log2_wd, lo = 0, cw[2] = {1 << sh.chroma_log2_wd, 1 << sh.chroma_log2_wd}, co[2] = {0, 0};
             if (br.u1()) { lw = br.se(); lo = br.se(); }
@@ -218,13 +231,15 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
             }
         }
     }
-    if (p.cabac && sh.type != SL_I) { sh.cabac_init_idc = (int)br.ue(); if (sh.cabac_init_idc > 2) return "bad cabac_init_idc"; }
-    sh.qp = p.init_qp + br.se();
-    if (sh.qp < 0 || sh.qp > 51) return "slice QP out of range";
+    if (p.cabac && sh.type != SL_I) { uint32_t v = br.ue(); if (v > 2) return "bad cabac_init_idc"; sh.cabac_init_idc = (int)v; }
+    { int d = br.se(); if (d < -51 || d > 51 || p.init_qp + d < 0 || p.init_qp + d > 51) return "slice QP out of range"; sh.qp = p.init_qp + d; }
     if (p.deblock_ctrl_present) {
-        sh.disable_deblock = br.ue();
-        if (sh.disable_deblock > 2) return "bad disable_deblocking_filter_idc";
-        if (sh.disable_deblock != 1) { sh.alpha_off = 2 * br.se(); sh.beta_off = 2 * br.se(); }
+        { uint32_t v = br.ue(); if (v > 2) return "bad disable_deblocking_filter_idc"; sh.disable_deblock = (int)v; }
+        if (sh.disable_deblock != 1) {
+            int a = br.se(), b = br.se();
+            if (a < -6 || a > 6 || b < -6 || b > 6) return "deblocking filter offset out of range";
+            sh.alpha_off = 2 * a; sh.beta_off = 2 * b;
+        }
     }
     if (br.overrun()) return "slice header truncated";
     sh.data_bit_offset = br.bitpos();

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <cstdlib>
+#include <exception>
 #include <vector>
 
 using jmamd::Decoder;
@@ -14,27 +15,36 @@ __attribute__((constructor)) static void jm_amddec_runtime_defaults() { setenv("
 
 #define D(h) (reinterpret_cast<Decoder *>(h))
 
+// No C++ exception may cross the C ABI (a hostile stream must not be able to abort the host application through an allocation
+// failure or a container bound): the entry points that run parser code convert them into the API's error return.
+template <class F> static int guarded(jm_amddec_handle h, F &&f) {
+    try { return f(); }
+    catch (const std::exception &e) { D(h)->api_exception(e.what()); }
+    catch (...) { D(h)->api_exception("unknown exception"); }
+    return -1;
+}
+
 extern "C" {
 
 __attribute__((visibility("default"))) jm_amddec_handle jm_amddec_create_handle(void) { return new Decoder(); }
 __attribute__((visibility("default"))) int jm_amddec_init(int codec_type, int out_fmt, char *extra, int len, jm_amddec_handle h) {
     if (!h) return -1;
-    return D(h)->init(codec_type, out_fmt, reinterpret_cast<const uint8_t *>(extra), len);
+    return guarded(h, [&] { return D(h)->init(codec_type, out_fmt, reinterpret_cast<const uint8_t *>(extra), len); });
 }
 __attribute__((visibility("default"))) int jm_amddec_deinit(jm_amddec_handle h) { delete D(h); return 0; }
 __attribute__((visibility("default"))) int jm_amddec_decode_frame(unsigned char *in_buf, int n, int *got, jm_amddec_handle h) {
     int dummy = 0;
     if (!h) return -1;
-    return D(h)->decode(in_buf, n, got ? got : &dummy);
+    return guarded(h, [&] { return D(h)->decode(in_buf, n, got ? got : &dummy); });
 }
 __attribute__((visibility("default"))) int jm_amddec_poll_frame(int *got, jm_amddec_handle h) {
     int dummy = 0;
     if (!h) return -1;
-    return D(h)->poll(got ? got : &dummy);
+    return guarded(h, [&] { return D(h)->poll(got ? got : &dummy); });
 }
 __attribute__((visibility("default"))) int jm_amddec_output_frame(unsigned char *out, int *out_len, jm_amddec_handle h) {
     if (!h || !out || !out_len) return -1;
-    return D(h)->output(out, out_len);
+    return guarded(h, [&] { return D(h)->output(out, out_len); });
 }
 __attribute__((visibility("default"))) int jm_amddec_stream_info(int *w, int *hh, jm_amddec_handle h) { return D(h)->stream_info(w, hh); }
 __attribute__((visibility("default"))) void jm_amddec_set_eof(int e, jm_amddec_handle h) { D(h)->set_eof(e != 0); }
@@ -79,7 +89,7 @@ __attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned
         for (size_t k = 0; k < starts.size(); k++) {
             const long b = starts[k], e = k + 1 < starts.size() ? starts[k + 1] : len;
             int got = 0;
-            if (D(h)->decode(buf + b, (int)(e - b), &got) != 0) return -2;
+            if (guarded(h, [&] { return D(h)->decode(buf + b, (int)(e - b), &got); }) != 0) return -2;
             if (got == 1) { int n = out_cap; if (D(h)->output(out, &n) > 0) frames++; }
         }
     return frames;

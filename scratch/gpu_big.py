@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import gpu_sweep
 if len(sys.argv) > 3:
     import jmcodec_amd
-    from jmcodec_amd import streams
+    from tools import streams
     codec, base, i = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     r = random.Random(base * 100003 + i * 7 + codec)
     kw = gpu_sweep.hevc_params(r) if codec else gpu_sweep.h264_params(r)

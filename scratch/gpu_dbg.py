@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import jmcodec_amd
-from jmcodec_amd import streams
+from tools import streams
 cfgs = [
  dict(width=320, height=520, frames=7, qp=18, gop=4, seed=153603, mode=1, deblock=0, num_ref=3, slices=1, cabac=1, cabac_idc=0, t8x8=1, bframes=2, direct_temporal=0, wp=1, dinf8=0, scaling=0, rplm=1, cip=1, chroma_qp_off=-4, alpha_off=3, beta_off=0, poc_type=0),
  dict(width=640, height=720, frames=2, qp=18, gop=4, seed=686082, mode=1, deblock=1, num_ref=2, slices=3, cabac=1, cabac_idc=2, t8x8=1, bframes=1, direct_temporal=1, wp=1, dinf8=1, scaling=0, rplm=0, cip=1, chroma_qp_off=-4, alpha_off=-3, beta_off=0, poc_type=0),

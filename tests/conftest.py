@@ -22,5 +22,5 @@ def _built():
 
 @pytest.fixture(scope="session")
 def oracle():
-    from jmcodec_amd import streams
+    from tools import streams
     return streams.Oracle()

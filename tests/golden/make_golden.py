@@ -14,7 +14,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from jmcodec_amd import streams  # noqa: E402
+from tools import streams  # noqa: E402
 
 CASES = {
     "pcm_64x48": dict(width=64, height=48, frames=2, pcm_only=1, gop=2, deblock=0, seed=11),

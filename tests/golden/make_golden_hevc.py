@@ -14,7 +14,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from jmcodec_amd import streams  # noqa: E402
+from tools import streams  # noqa: E402
 
 CASES = {
     "hevc_intra_96x80": dict(width=96, height=80, frames=2, intra_period=1, seed=31),

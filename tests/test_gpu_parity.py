@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import jmcodec_amd
-from jmcodec_amd import api, streams
+from jmcodec_amd import api
+from tools import streams
 from util import ALL_CASES as PARITY_CASES, golden_meta, golden_stream, md5
 
 pytestmark = pytest.mark.gpu

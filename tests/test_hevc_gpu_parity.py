@@ -9,7 +9,7 @@ import threading
 import pytest
 
 import jmcodec_amd
-from jmcodec_amd import streams
+from tools import streams
 from test_hevc_oracle import HEVC_CASES
 from util import GOLDEN, md5
 

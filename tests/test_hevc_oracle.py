@@ -12,7 +12,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from jmcodec_amd import streams
+from tools import streams
 from util import GOLDEN, ROOT, c_array, md5
 
 HEVC_CASES = {

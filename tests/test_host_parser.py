@@ -4,7 +4,8 @@ import random
 
 import pytest
 
-from jmcodec_amd import api, streams
+from jmcodec_amd import api
+from tools import streams
 from util import ALL_CASES as PARITY_CASES, golden_meta, golden_stream
 
 
@@ -145,3 +146,120 @@ def test_resolution_change_between_sequences_host_side():
         frames = d.decode_stream(a + b + c)
         assert [len(f) for f in frames] == [96 * 80 * 3 // 2] * 5 + [176 * 144 * 3 // 2] * 4 + [64 * 48 * 3 // 2] * 3
         assert d.stat("errors") == 0
+
+
+# ---- hostile parameter sets: every ue(v) field is range-checked before it is narrowed ------------------------------
+class _Bits:
+    def __init__(self):
+        self.b = []
+
+    def u(self, n, v):
+        self.b += [(v >> (n - 1 - i)) & 1 for i in range(n)]
+        return self
+
+    def ue(self, v):
+        v += 1
+        n = v.bit_length()
+        return self.u(n - 1, 0).u(n, v)
+
+    def se(self, v):
+        return self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def nal(self, header):
+        bits = self.b + [1]
+        bits += [0] * (-len(bits) % 8)
+        raw = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+        out, z = bytearray(), 0
+        for x in raw:                                   # emulation prevention (7.4.1)
+            if z >= 2 and x <= 3:
+                out.append(3); z = 0
+            out.append(x); z = z + 1 if x == 0 else 0
+        return b"\x00\x00\x00\x01" + bytes([header]) + bytes(out)
+
+
+def _sps(log2_fn=0, poc_type=2, log2_lsb=0, num_ref=1, mb_w1=5, mb_h1=4, crop=None, profile=66, frame_mbs_only=1):
+    b = _Bits().u(8, profile).u(8, 0).u(8, 40).ue(0)
+    b.ue(log2_fn).ue(poc_type)
+    if poc_type == 0:
+        b.ue(log2_lsb)
+    b.ue(num_ref).u(1, 0).ue(mb_w1).ue(mb_h1).u(1, frame_mbs_only)
+    if not frame_mbs_only:
+        b.u(1, 0)
+    b.u(1, 1)
+    if crop:
+        b.u(1, 1)
+        for c in crop:
+            b.ue(c)
+    else:
+        b.u(1, 0)
+    b.u(1, 0)
+    return b.nal(0x67)
+
+
+def _pps(nref0=0, init_qp=0, cqo=0):
+    return _Bits().ue(0).ue(0).u(1, 0).u(1, 0).ue(0).ue(nref0).ue(0).u(1, 0).u(2, 0).se(init_qp).se(0).se(cqo).u(1, 1).u(1, 0).u(1, 0).nal(0x68)
+
+
+def _idr_slice():
+    # first_mb 0, slice_type 7 (I), pps 0, frame_num u(4) 0, idr_pic_id 0, [poc type 2], no_output_of_prior 0, long_term 0, qp_delta 0, deblock idc 1
+    return _Bits().ue(0).ue(7).ue(0).u(4, 0).ue(0).u(1, 0).u(1, 0).se(0).ue(1).u(16, 0xFFFF).nal(0x65)
+
+
+BIG = 0xFFFFFFFE
+HOSTILE_SPS = {
+    "mb_w_wraps_negative": dict(mb_w1=BIG, mb_h1=2),
+    "mb_h_wraps_negative": dict(mb_w1=2, mb_h1=BIG),
+    "both_wrap": dict(mb_w1=0xFFFFFBFF, mb_h1=BIG),
+    "mb_count_too_large": dict(mb_w1=1023, mb_h1=1023),
+    "log2_max_frame_num_60": dict(log2_fn=60),
+    "log2_max_poc_lsb_50": dict(poc_type=0, log2_lsb=50),
+    "poc_type_3": dict(poc_type=3),
+    "num_ref_frames_huge": dict(num_ref=BIG),
+    "crop_huge": dict(crop=(0, BIG, 0, 0)),
+    "crop_eats_picture": dict(crop=(24, 24, 0, 0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HOSTILE_SPS))
+def test_hostile_sps_is_rejected_not_decoded(name):
+    """A crafted ~10-byte SPS must not abort the process (std::length_error), shift by >= 32 or reach the device with a negative pitch:
+    the parameter set is refused, the slice that refers to it fails cleanly and no frame comes out."""
+    data = _sps(**HOSTILE_SPS[name]) + _pps() + _idr_slice()
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        n = d.decode_stream(data, keep=False)
+        assert n == 0
+        assert d.stat("errors") >= 1
+        assert d.stat("coded_width") == 0 and d.stat("coded_height") == 0
+
+
+@pytest.mark.parametrize("kw", [dict(nref0=BIG), dict(nref0=32), dict(init_qp=40), dict(cqo=13), dict(cqo=-13)])
+def test_hostile_pps_is_rejected(kw):
+    data = _sps() + _pps(**kw) + _idr_slice()
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        assert d.decode_stream(data, keep=False) == 0
+        assert d.stat("errors") >= 1
+
+
+def test_well_formed_handwritten_sps_is_accepted():
+    """The same bit writer with in-range values activates a 96x80 sequence (so the rejections above are due to the values, not the writer)."""
+    data = _sps() + _pps() + _idr_slice()
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        d.decode_stream(data, keep=False)
+        assert (d.stat("coded_width"), d.stat("coded_height")) == (96, 80)
+
+
+def test_crop_only_change_at_idr_updates_the_display_size(oracle):
+    """a new SPS that only changes the cropping starts a new sequence as far as frame sizes go."""
+    a = streams.generate(width=96, height=80, frames=2, gop=2, seed=5)
+    b = streams.generate(width=90, height=70, frames=2, gop=2, seed=6)       # same 6x5 macroblocks, cropped to 90x70
+    sizes = []
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+        for nal in api.split_nalus(a + b):
+            _, got = api.jm_nvdec_decode_frame(nal, len(nal), d.h)
+            if got == 1:
+                sizes.append(api.jm_nvdec_stream_info(d.h)); d._pull(None)
+        while not api.jm_nvdec_is_exit(d.h):
+            _, got = api.jm_nvdec_decode_frame(None, 0, d.h)
+            if got == 1:
+                sizes.append(api.jm_nvdec_stream_info(d.h)); d._pull(None)
+    assert sizes == [(96, 80)] * 2 + [(90, 70)] * 2

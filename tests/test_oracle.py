@@ -7,7 +7,8 @@ import tempfile
 import numpy as np
 import pytest
 
-from jmcodec_amd import api, streams
+from jmcodec_amd import api
+from tools import streams
 from util import ALL_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
 
 

@@ -22,7 +22,8 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from jmcodec_amd import api, streams
+    from jmcodec_amd import api
+    from tools import streams
     mine = shard.streams_of_rank(6, rank, world)
     frames = 0
     for sid in mine:

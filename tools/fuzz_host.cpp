@@ -19,7 +19,12 @@ int main(int argc, char **argv) {
     long frames = 0;
     for (int t = 0; t < trials; t++) {
         std::vector<unsigned char> b = base;
-        if (t > 0) { for (int k = 0; k < 1 + t % 6; k++) { size_t p = 30 + rnd() % (b.size() - 30); b[p] ^= (unsigned char)(1u << (rnd() % 8)); } if (t % 4 == 0) b.resize(100 + rnd() % (b.size() - 100)); }
+        if (t > 0 && t % 3 == 2) {
+            // parameter-set trials: the leading SPS / PPS / first slice header (roughly the first 64 bytes) get the damage -- bit flips, and
+            // runs of zero bits that turn a short ue(v) into a 32-bit-class value (the crafted-SPS cases of tests/test_host_parser.py)
+            const size_t lim = b.size() < 64 ? b.size() : 64;
+            for (int k = 0; k < 1 + t % 4; k++) { size_t p = 4 + rnd() % (lim - 4); if (rnd() % 3 == 0) { b[p] = 0; if (p + 1 < lim && rnd() % 2) b[p + 1] = 0; } else b[p] ^= (unsigned char)(1u << (rnd() % 8)); }
+        } else if (t > 0) { for (int k = 0; k < 1 + t % 6; k++) { size_t p = 30 + rnd() % (b.size() - 30); b[p] ^= (unsigned char)(1u << (rnd() % 8)); } if (t % 4 == 0) b.resize(100 + rnd() % (b.size() - 100)); }
         void *h = jm_amddec_create_handle();
         jm_amddec_set_option(h, "parse_only", 1);
         if (t % 2) jm_amddec_set_option(h, "digest", 1);

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import jmcodec_amd
-from jmcodec_amd import streams
+from tools import streams
 
 o = streams.Oracle()
 cases = [

@@ -10,7 +10,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import jmcodec_amd                      # noqa: E402
-from jmcodec_amd import streams         # noqa: E402
+from tools import streams         # noqa: E402
 
 
 def hevc_params(r):
