@@ -23,6 +23,18 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the engine's streams need distinct HW queues (must precede HIP init, incl. torch's)
 
 
+def quota_cpus():
+    """CPUs this container may really use: the cgroup v2 CFS quota when there is one (a box can show 256 CPUs and own 16), else the online count."""
+    cpus = float(os.cpu_count() or 8)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cpus = min(cpus, int(q) / int(per))
+    except Exception:
+        pass
+    return cpus
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -36,6 +48,7 @@ def main():
                     help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P)")
     ap.add_argument("--codec", default="h264", choices=["h264", "hevc"], help="diagnostic: hevc = SURVEY 8d config C3 (HEVC Main, 64x64 CTB, SAO + deblocking, random-access GOP 8) at --width x --height")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the untimed single-stream leg")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
     args = ap.parse_args()
@@ -46,7 +59,9 @@ def main():
 
     import torch
     dist = None
-    backend = os.environ.get("JM_BENCH_BACKEND", "nccl")      # "gloo" lets the multi-process path be exercised on a 1-GPU box
+    # north_star: "independent input streams shard one-per-GPU ... no RCCL" -- the only cross-rank traffic is the barrier and two scalars, so the
+    # process group is gloo (CPU) by default; JM_BENCH_BACKEND=nccl is kept only as a diagnostic
+    backend = os.environ.get("JM_BENCH_BACKEND", "gloo")
     n_dev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
@@ -56,16 +71,9 @@ def main():
         else:
             dist.init_process_group("gloo")
     os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank % max(n_dev, 1))
-    if world > 1 and "JM_AMD_DEC_THREADS" not in os.environ:      # share the host cores between the ranks of this node
+    if world > 1 and "JM_AMD_DEC_THREADS" not in os.environ:      # the ranks of a node share its host cores (parse workers per rank)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        cpus = os.cpu_count() or 8
-        try:                                                       # a container may own far fewer CPUs than it sees (cgroup v2 quota)
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                cpus = min(cpus, int(int(q) * 1.75 / int(per) + 0.5))
-        except Exception:
-            pass
-        os.environ["JM_AMD_DEC_THREADS"] = str(max(4, min(64, cpus // max(local_world, 1))))
+        os.environ["JM_AMD_DEC_THREADS"] = str(max(4, min(64, int(quota_cpus() * 1.75 + 0.5) // max(local_world, 1))))
     red_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
 
     import __graft_entry__ as ge
@@ -77,23 +85,59 @@ def main():
     if not jmcodec_amd.jm_nvdec_is_hw_support() and not args.parse_only:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
 
-    # ---- synthetic input: SURVEY 8d C1, seed = 0x4A4D0000 + 1*256 + stream_id (stream_id = rank) ----
-    cfg = streams.config_c1(stream_id=rank, frames=args.frames, width=args.width, height=args.height)
+    # ---- synthetic input: S DISTINCT streams per rank.  SURVEY 8d C1 / C4: seed = 0x4A4D0000 + 1*256 + stream_id, and the job's S*world streams
+    # shard as stream i -> rank i mod world (jmcodec_amd/shard.py) ----
+    from jmcodec_amd import shard
+    S, F, K, W = args.streams, args.frames, args.steps, args.warmup
+    stream_ids = shard.streams_of_rank(S * world, rank, world)
+    assert len(stream_ids) == S
     tools_desc = "Baseline, I/P-only (CAVLC"
     if args.tools != "baseline":
-        cfg.update(cabac=1, t8x8=1)
         tools_desc = "High, I/P-only (CABAC, 8x8 transform"
     if args.tools == "high_b":
-        cfg.update(bframes=2, num_ref=2, poc_type=0)
         tools_desc = "High, I B B P (CABAC, 8x8 transform"
     if args.codec == "hevc":
-        cfg = streams.config_c3(frames=args.frames, width=args.width, height=args.height, stream_id=rank)
         tools_desc = "Main, random-access GOP 8 (CABAC, 64x64 CTB, SAO"
-        data = streams.generate_hevc(**cfg)
-    else:
-        data = streams.generate(**cfg)
-    nalus = jmcodec_amd.split_nalus(data)
-    S, F, K, W = args.streams, args.frames, args.steps, args.warmup
+
+    def stream_cfg(sid, frames=None):
+        if args.codec == "hevc":
+            return streams.config_c3(frames=frames or F, width=args.width, height=args.height, stream_id=sid)
+        cfg = streams.config_c1(stream_id=sid, frames=frames or F, width=args.width, height=args.height)
+        if args.tools != "baseline":
+            cfg.update(cabac=1, t8x8=1)
+        if args.tools == "high_b":
+            cfg.update(bframes=2, num_ref=2, poc_type=0)
+        return cfg
+
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_threads = max(2, min(32, int(quota_cpus() // max(local_world, 1))))
+
+    def make_stream(sid):
+        """Generated once per box and cached under /tmp (the 1/2/4/8-GPU runs of a scaling sweep share most of their streams)."""
+        import hashlib
+        cfg = stream_cfg(sid)
+        key = hashlib.md5(repr((args.codec, sorted(cfg.items()), os.path.getmtime(os.path.join(ROOT, "tools", "hevcgen.c" if args.codec == "hevc" else "h264gen.c")))).encode()).hexdigest()
+        path = os.path.join(os.environ.get("JM_BENCH_CACHE", "/tmp"), f"jm_bench_{key}.bin")
+        try:
+            with open(path, "rb") as f:
+                return f.read()
+        except OSError:
+            pass
+        d = (streams.generate_hevc if args.codec == "hevc" else streams.generate)(**cfg)
+        try:
+            tmp = path + f".{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(d)
+            os.replace(tmp, path)
+        except OSError:
+            pass
+        return d
+
+    from concurrent.futures import ThreadPoolExecutor      # the generator / oracle are C libraries called through ctypes: the GIL is released
+    tg0 = time.perf_counter()
+    with ThreadPoolExecutor(host_threads) as ex:
+        datas = list(ex.map(make_stream, stream_ids))
+    gen_s = time.perf_counter() - tg0
     mb_w, mb_h = (args.width + 15) // 16, (args.height + 15) // 16
     frame_bytes = args.width * args.height * 3 // 2
 
@@ -118,6 +162,7 @@ def main():
         cnt = 0
         # test_nv_dec's hot loop (one NAL per jm_nvdec_decode_frame call, fetch a frame whenever got_frame == 1) runs in the library:
         # a Python loop would measure the interpreter's per-call overhead and the GIL hand-off between the S feeder threads
+        data = datas[i]
         got_n = L.jm_amddec_feed_annexb(data, len(data), passes, C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
         if got_n < 0:
             raise SystemExit("feed failed: " + L.jm_amddec_last_error(h).decode())
@@ -205,7 +250,6 @@ def main():
     by_thread = {k: v for k, v in by_thread.items() if v["user_s"] + v["sys_s"] >= 0.05}
     frames_local = sum(counts)
 
-    from jmcodec_amd import shard
     frames_total, dt_max = shard.reduce_result(dist, frames_local, dt, device=red_dev)     # SUM of frames, MAX of seconds over ranks
 
     # ---- per-kernel device time: HIP events recorded by the engine on ITS stream around every batched launch, timed region only ----
@@ -220,7 +264,6 @@ def main():
     eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4), "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
-    errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
     threads = L.jm_amddec_get_stat(handles[0], b"threads")
     host_diag = {k: round(sum(L.jm_amddec_get_stat(h, k.encode()) for h in handles) / 1e6 / max(1, sum(L.jm_amddec_get_stat(h, b"pictures") for h in handles)), 4)
                  for k in ("submit_ns", "wait_slot_ns", "parse_ns_i", "parse_ns_p")}   # ms per picture, whole run
@@ -254,36 +297,150 @@ def main():
     A = surf * (p_frac * 2 + (1 - p_frac) * 1) + frame_bytes + J
     kernel_s_per_frame = sum(tot_ns[k] for k in names) * 1e-9 / max(pictures, 1)
 
-    # drain + tear down (outside the timed region)
-    for h in handles:
-        L.jm_amddec_decode_frame(None, 0, C.byref(C.c_int(0)), h)
+    # ---- untimed: prove "+ bit-exact YUV" on the TIMED CONFIGURATION.  One more pass over every handle, all S handles concurrently exactly as in
+    # the timed region (same engine batching, same mix of output routes), every frame MD5'd; the handles are then flushed and closed.  The digests
+    # are compared with the CPU oracle (oracle/, checker only) decoding the first IDR period of the same stream: every handle at N=1, two per
+    # rank otherwise (N ranks share the node's host cores). ----
+    import hashlib
+    is_hevc = args.codec == "hevc"
+
+    def first_period(data):
+        """The stream up to (not including) its second IDR access unit: decodes to the first frames of the full stream's display order."""
+        nal_starts = [k for k in range(len(data) - 3) if data[k] == 0 and data[k + 1] == 0 and data[k + 2] == 1]
+        idr = []
+        for k in nal_starts:
+            b0 = data[k + 3]
+            t = (b0 >> 1) & 63 if is_hevc else b0 & 31
+            if (t in (19, 20)) if is_hevc else (t == 5):
+                first_slice = (data[k + 5] & 0x80) != 0 if is_hevc else (data[k + 4] & 0x80) != 0     # first_slice_segment_in_pic_flag / first_mb_in_slice == 0
+                if first_slice:
+                    idr.append(k)
+        if len(idr) < 2:
+            return data
+        cut = idr[1]
+        # parameter sets that precede the second IDR picture belong to it: cut before them (they follow the previous picture's last slice)
+        prev = [k for k in nal_starts if k < cut]
+        while prev:
+            b0 = data[prev[-1] + 3]
+            t = (b0 >> 1) & 63 if is_hevc else b0 & 31
+            if (t in (32, 33, 34, 35, 39)) if is_hevc else (t in (6, 7, 8, 9)):
+                cut = prev.pop()
+            else:
+                break
+        while cut > 0 and data[cut - 1] == 0:
+            cut -= 1
+        return data[:cut]
+
+    check_digests = [None] * S
+
+    def check_pass(i):
+        h = handles[i]
+        out = C.create_string_buffer(frame_bytes)
+        got, n = C.c_int(0), C.c_int(0)
+        digs = []
+
+        def pull():
+            n.value = frame_bytes
+            if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
+                digs.append(hashlib.md5(out.raw[:n.value]).digest())
+        for nal in jmcodec_amd.split_nalus(datas[i]):
+            L.jm_amddec_decode_frame(C.cast(C.c_char_p(nal), C.c_void_p), len(nal), C.byref(got), h)
+            if got.value == 1:
+                pull()
+        while not L.jm_amddec_is_exit(h):                      # EOS: flush what the DPB still holds, then the handle reports is_exit
+            if L.jm_amddec_decode_frame(None, 0, C.byref(got), h) != 0:
+                break
+            if got.value == 1:
+                pull()
+        check_digests[i] = digs[-F:]                           # frames a reordering DPB still held from the timed passes come out first
+
+    bit_exact, frames_checked, check_note = None, 0, "skipped (--parse-only)"
+    oracle_dt, oracle_frames, oracle_one = 0.0, 0, None
+    if not args.parse_only:
+        ts = [threading.Thread(target=check_pass, args=(i,)) for i in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        orc = streams.OracleHevc() if is_hevc else streams.Oracle()
+        n_oracle = S if world == 1 else min(S, 2)
+        prefixes = [first_period(datas[i]) for i in range(n_oracle)]
+
+        def oracle_digests(pfx):
+            yuv, n, w, h = orc.decode(pfx, 1)
+            fb = w * h * 3 // 2
+            return [hashlib.md5(yuv[k * fb:(k + 1) * fb]).digest() for k in range(n)]
+        want = [None] * n_oracle
+        first = 0
+        if world == 1 and not args.no_cpu_baseline:          # B1: one stream alone on one core
+            c0 = time.perf_counter()
+            want[0] = oracle_digests(prefixes[0])
+            oracle_one = (len(want[0]), time.perf_counter() - c0)
+            first = 1
+        c0 = time.perf_counter()
+        with ThreadPoolExecutor(host_threads) as ex:          # B2: the remaining streams on all the cores this container owns
+            for k, d in zip(range(first, n_oracle), ex.map(oracle_digests, prefixes[first:])):
+                want[k] = d
+        oracle_dt = time.perf_counter() - c0
+        oracle_frames = sum(len(w) for w in want[first:])
+        bit_exact = all(len(check_digests[i]) == F for i in range(S))
+        for i in range(n_oracle):
+            ok = len(want[i]) > 0 and check_digests[i][:len(want[i])] == want[i]
+            bit_exact = bit_exact and ok
+            frames_checked += len(want[i])
+            if not ok:
+                bad = next((k for k in range(min(len(want[i]), len(check_digests[i]))) if want[i][k] != check_digests[i][k]), -1)
+                print(f"bench.py: rank {rank} stream {stream_ids[i]}: decoded frames differ from the CPU oracle (first bad frame {bad}, got {len(check_digests[i])} frames, oracle {len(want[i])})", file=sys.stderr)
+        check_note = (f"one extra pass of all {S} handles concurrently (same batching and output routes as the timed passes), every frame MD5'd; "
+                      f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle; all {S} handles returned {F} frames")
+    errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
+    for i, h in enumerate(handles):
+        if L.jm_amddec_get_stat(h, b"errors"):
+            print(f"bench.py: rank {rank} stream {stream_ids[i]}: {L.jm_amddec_get_stat(h, b'errors')} decode error(s), last: {L.jm_amddec_last_error(h).decode()!r}", file=sys.stderr)
         jmcodec_amd.jm_nvdec_deinit(h)
+
+    # ---- untimed: ONE handle fed exactly like test_nv_dec.cpp:184-250 (the reference harness's own shape: one stream, one thread) ----
+    single = None
+    if world == 1 and not args.parse_only and not args.no_single:
+        h = jmcodec_amd.jm_nvdec_create_handle()
+        if jmcodec_amd.jm_nvdec_init(1 if is_hevc else 0, 1, None, 0, h) == 0:
+            out = C.create_string_buffer(frame_bytes)
+            sp = max(1, min(8, 240 // max(F, 1)))
+            L.jm_amddec_feed_annexb(datas[0], len(datas[0]), 1, C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
+            L.jm_amddec_set_option(h, b"wait_idle", 1)
+            c0 = time.perf_counter()
+            n1 = L.jm_amddec_feed_annexb(datas[0], len(datas[0]), sp, C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
+            L.jm_amddec_set_option(h, b"wait_idle", 1)
+            sdt = time.perf_counter() - c0
+            single = {"value": round(sp * F / sdt, 1), "unit": "frames/s", "frames": sp * F, "frames_returned_in_loop": int(n1),
+                      "note": "one jm_nvdec handle, one feeder thread, NAL-per-call, frame copied into the caller's buffer whenever got_frame == 1 (test_nv_dec.cpp:184-250); untimed extra leg"}
+        jmcodec_amd.jm_nvdec_deinit(h)
+
+    if dist is not None:                                      # every rank must have matched
+        import torch as _t
+        flag = _t.tensor([1.0 if (bit_exact is None or bit_exact) else 0.0, float(frames_checked)], dtype=_t.float64, device=red_dev)
+        mn = flag.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        sm = flag.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        if bit_exact is not None:
+            bit_exact = bool(mn[0].item() > 0.5)
+        frames_checked = int(sm[1].item())
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        if bit_exact is False:
+            raise SystemExit(3)
         return
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the build's own scalar CPU oracle (NOT libmfx: unobtainable),
-        # one core, on a bounded sample of the same workload.
-        o = streams.OracleHevc() if args.codec == "hevc" else streams.Oracle()
-        sample_frames = min(F, 90 if args.codec == "h264" else 16)
-        gen = streams.generate_hevc if args.codec == "hevc" else streams.generate
-        sample = gen(**dict(cfg, frames=sample_frames)) if sample_frames != F else data
-        reps, c0, n_dec = 0, time.perf_counter(), 0
-        while True:
-            _, n, _, _ = o.decode(sample, 1)
-            n_dec += n
-            reps += 1
-            if time.perf_counter() - c0 > 10.0 or reps >= 8:
-                break
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(n_dec / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{reps} x the first {sample_frames} frames of the same {args.width}x{args.height} stream, "
-                         f"build CPU oracle (scalar, spec-literal; not libmfx), {cdt:.1f}s of CPU work",
-               "host_cpus": os.cpu_count()}
+    if world == 1 and not args.no_cpu_baseline and oracle_frames > 0:
+        # CPU baseline = the build's own scalar, spec-literal CPU oracle (NOT the reference's libmfx software path, which does not exist in this
+        # image: BASELINE.md section 4).  B2: one oracle instance per stream on every core the container owns; B1: one instance on one core.
+        cpu = {"value": round(oracle_frames / oracle_dt, 2), "unit": "frames/s", "cores": int(min(host_threads, max(n_oracle - 1, 1))), "kind": "port",
+               "sample": f"first IDR period ({len(want[0])} frames) of {n_oracle - first} of the benchmark's own {args.width}x{args.height} streams, one oracle instance per stream on "
+                         f"{min(host_threads, max(n_oracle - 1, 1))} threads, {oracle_dt:.1f} s wall (build CPU oracle: scalar, spec-literal; not libmfx) -- a label, not a bar",
+               "one_core": {"value": round(oracle_one[0] / oracle_one[1], 2), "unit": "frames/s", "cores": 1, "sample": f"{oracle_one[0]} frames of stream {stream_ids[0]}, {oracle_one[1]:.1f} s"} if oracle_one else None,
+               "host_cpus": os.cpu_count(), "quota_cpus": round(quota_cpus(), 2)}
 
     value = frames_total / dt_max
     line = {
@@ -301,16 +458,20 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) ") + f"{args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
-                   "streams_per_gpu": S, "frames_per_stream_per_step": F, "bitstream_bytes": len(data),
+                   "streams_per_gpu": S, "frames_per_stream_per_step": F, "stream_ids": [stream_ids[0], stream_ids[-1]], "distinct_streams": len(set(datas)),
+                   "bitstream_bytes_per_stream": int(sum(len(d) for d in datas) / S), "stream_generation_s": round(gen_s, 1),
                    "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (two of five handles: synchronous DMA from device staging; the others: pinned slot + memcpy)"},
         "frames": frames_total,
+        "bit_exact": bit_exact, "frames_checked": int(frames_checked), "bit_exact_check": check_note,
         "decode_errors": int(errors),
         "host_ms_per_picture": host_diag,
         "host_cpu": {"cpu_s": round(hc1["cpu_s"] - hc0["cpu_s"], 3), "cpus_busy": round((hc1["cpu_s"] - hc0["cpu_s"]) / dt, 2),
                      "cpu_ms_per_frame": round(1e3 * (hc1["cpu_s"] - hc0["cpu_s"]) / max(frames_local, 1), 4),
                      "quota_cpus": hc1.get("quota_cpus"), "online_cpus": os.cpu_count(),
                      "throttled_ms": round((hc1.get("throttled_usec", 0) - hc0.get("throttled_usec", 0)) / 1e3, 1), "by_thread": by_thread,
-                     "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate"},
+                     "cpu_needed_for_8_gpus": round(8 * (hc1["cpu_s"] - hc0["cpu_s"]) / dt, 1),
+                     "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate; "
+                             "cpu_needed_for_8_gpus = 8 x cpus_busy is what an 8-rank run of this rate would need from the node"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": traffic,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
@@ -326,9 +487,19 @@ def main():
     }
     if cpu is not None:
         line["cpu_baseline"] = cpu
+    if single is not None:
+        line["single_stream"] = single
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    q = hc1.get("quota_cpus") or os.cpu_count()
+    if world > 1 and q and line["host_cpu"]["cpus_busy"] * local_world > 0.95 * q:
+        line["host_cpu"]["oversubscribed"] = True
+        print(f"bench.py: WARNING: {local_world} ranks x {line['host_cpu']['cpus_busy']} busy CPUs meet the node's {q} CPUs -- this run is bound by the host "
+              f"(entropy decode), not by the GPUs; the scaling figure measures the CPU allotment", file=sys.stderr)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if bit_exact is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

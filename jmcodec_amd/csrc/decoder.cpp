@@ -84,6 +84,13 @@ void Decoder::fail(const std::string &msg) {            // any thread
     failed_ = true;
 }
 
+// remembers the most recent non-fatal error text for jm_amddec_last_error (any thread)
+void Decoder::note_error(const std::string &msg) {
+    static std::mutex nm;
+    std::lock_guard<std::mutex> lk(nm);
+    if (!failed_) error_ = msg;
+}
+
 int Decoder::set_option(const char *key, long long v) {
     std::string k(key);
     if (k == "parse_only") parse_only_ = v != 0;
@@ -792,7 +799,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         if (s.has_wp) t->any_wp = true;
         SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr);
         t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
-        if (r.error) { t->error = r.error; stat_errors_++; }
+        if (r.error) { t->error = r.error; stat_errors_++; note_error(std::string("slice data: ") + r.error); }
     }
     for (int i = 0; i < n_mbs; i++) if (scratch.slice_of[i] < 0) mbs[i] = blank;      // only what no slice covered (normally nothing)
     if (want_digest_) digest_ = dg;      // pictures are parsed in order when the digest is requested (sync option)

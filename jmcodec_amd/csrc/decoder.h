@@ -133,6 +133,7 @@ private:
     int  acquire_job_slot();
     int  pop_output(bool block);
     void fail(const std::string &msg);
+    void note_error(const std::string &msg);
     // ---- device side ----
     bool gpu_open();
     bool gpu_alloc_sequence();

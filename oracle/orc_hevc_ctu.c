@@ -573,7 +573,7 @@ static void mc_block(const HPic *ref, int c, int pw, int ph, int xb, int yb, int
 /* 8.5.3.3 decoding process for inter sample prediction of one prediction block */
 static int inter_pred(Sx *s, int xpb, int ypb, int npbw, int npbh, const Cand *m) {
     OrchDec *d = s->d; HSlice *sh = s->sh;
-    static int16_t p[2][64 * 64];
+    static __thread int16_t p[2][64 * 64];
     int wp = (sh->type == H_SLICE_P && s->pps->weighted_pred) || (sh->type == H_SLICE_B && s->pps->weighted_bipred);
     for (int c = 0; c < 3; c++) {
         int sc = c ? 1 : 0, bw = npbw >> sc, bh = npbh >> sc, xb = xpb >> sc, yb = ypb >> sc, pw = d->w >> sc, ph = d->h >> sc;
@@ -954,7 +954,7 @@ static void parse_sao(Sx *s, int rx, int ry) {
 
 /* ------------------------------------------ 7.3.8.1 slice_segment_data ------------------------------------------ */
 int orch_decode_slice_data(OrchDec *d, HSlice *sh, int slice_idx, const uint8_t *rbsp, size_t len) {
-    static Sx sx;
+    static __thread Sx sx;
     Sx *s = &sx;
     memset(s, 0, sizeof *s);
     s->d = d; s->sh = sh; s->sps = d->asps; s->pps = d->apps; s->slice_idx = slice_idx;

@@ -307,7 +307,7 @@ int orch_decode_nal(OrchDec *d, const uint8_t *nal, size_t len) {
     }
     else if (type == 35 || type == 32 || type == 39) { finish_picture(d); }
     else if (type <= 9 || (type >= 16 && type <= 21)) {
-        static HSlice sh;
+        static __thread HSlice sh;
         const HSlice *prev = d->n_slices > 0 && d->pic_started ? &d->slices[d->n_slices - 1] : NULL;
         int first = (int)bits_peek(&b, 1);
         if (first) { finish_picture(d); prev = NULL; }

@@ -115,3 +115,34 @@ def test_reference_intel_harness_links_against_the_library():
         env = dict(os.environ, JM_AMD_DEC_PARSE_ONLY="1")
         r = subprocess.run([exe, src], capture_output=True, text=True, env=env, timeout=60, cwd=td)   # the harness opens its hard-coded output name in the cwd
         assert "Frame Count:\t8" in r.stdout, r.stdout + r.stderr
+
+
+def _harness():
+    return os.path.join(ROOT, "tools", "_build", "test_amd_dec")
+
+
+def test_native_harness_fails_loudly_without_a_gpu(tmp_path):
+    """tools/test_amd_dec (the test_nv_dec counterpart) links the drop-in jm_nvdec_* symbols; with no HIP device it must
+    refuse (exit 3) instead of decoding on the CPU."""
+    import jmcodec_amd
+    if jmcodec_amd.jm_nvdec_is_hw_support():
+        pytest.skip("a GPU is present")
+    from tools import streams
+    p = tmp_path / "s.h264"
+    p.write_bytes(streams.generate(width=96, height=80, frames=4, gop=4))
+    r = subprocess.run([_harness(), str(p)], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+def test_native_harness_loop_in_parse_only_mode(tmp_path):
+    """The harness's sliding-window NAL loop (small window, multi-loop) drives the library's host stages correctly: frame count and
+    the reference's info block format (nv_dec.cpp:666-680)."""
+    from tools import streams
+    p = tmp_path / "s.h264"
+    p.write_bytes(streams.generate(width=96, height=80, frames=5, gop=5, num_ref=2, mode=1))
+    env = dict(os.environ, JM_AMD_DEC_PARSE_ONLY="1")
+    for extra, frames in ((["--chunk", "64"], 5), (["--loops", "3"], 15), ([], 5)):
+        r = subprocess.run([_harness(), str(p), "--no-hw-check"] + extra, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert f"Frame Count:\t{frames}\n" in r.stdout and "Display:\t96 x 80\n" in r.stdout and "Pixel Format:\tYV12\n" in r.stdout
+        assert f"frames fetched = {frames} " in r.stdout

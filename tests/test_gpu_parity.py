@@ -493,3 +493,108 @@ def test_resolution_change_between_sequences(oracle):
         frames = gpu_decode(a + b + c)
         assert [len(f) for f in frames] == [96 * 80 * 3 // 2] * 5 + [320 * 240 * 3 // 2] * 4 + [64 * 48 * 3 // 2] * 6
         assert b"".join(frames) == want
+
+
+# ---- BASELINE configs at their real shape -----------------------------------------------------------
+def _md5_frames(blob, fs):
+    return [md5(blob[i:i + fs]) for i in range(0, len(blob), fs)]
+
+
+@pytest.mark.parametrize("fetch", ["1/2", "0/1", "1/1"])
+def test_c4_slice_8x1080p_concurrent(oracle, fetch, monkeypatch):
+    """BASELINE config C4's per-GPU slice: 8 DISTINCT 1080p Baseline streams (SURVEY 8d seeds, stream_id 0..7) decoded concurrently by 8
+    handles on 8 threads, one IDR period (30 frames) each, every frame compared with the CPU oracle.  JM_AMD_DEC_OUT_FETCH forces the
+    output routes: alternating, all through pinned slots, all fetched from device staging."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("JM_AMD_DEC_OUT_FETCH", fetch)
+    fs = 1920 * 1080 * 3 // 2
+    with ThreadPoolExecutor(8) as ex:
+        datas = list(ex.map(lambda sid: streams.generate(**streams.config_c1(stream_id=sid, frames=30)), range(8)))
+        wants = list(ex.map(lambda d: _md5_frames(oracle.decode(d, 1)[0], fs), datas))
+    assert len(set(datas)) == 8 and all(len(w) == 30 for w in wants)
+    got, errs = [None] * 8, [None] * 8
+
+    def run(i):
+        with api.JmAmdDec(0, 1) as d:
+            got[i] = [md5(f) for f in d.decode_stream(datas[i])]
+            errs[i] = d.stat("errors")
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(8):
+        assert errs[i] == 0
+        assert got[i] == wants[i], f"stream {i}: first differing frame {next(k for k in range(30) if k >= len(got[i]) or got[i][k] != wants[i][k])}"
+
+
+def _decode_digests(data, w, h, codec=0, chunks=None):
+    """Frame MD5s in display order, through the C ABI exactly like test_nv_dec (decode_frame / output_frame)."""
+    digs = []
+    buf = C.create_string_buffer(w * h * 3 // 2)
+    with api.JmAmdDec(codec, 1) as d:
+        def pull():
+            ret, n = api.jm_nvdec_output_frame(buf, len(buf), d.h)
+            assert ret == n == len(buf)
+            digs.append(md5(buf.raw))
+        for nal in (chunks if chunks is not None else api.split_nalus(data)):
+            _, got = api.jm_nvdec_decode_frame(nal, len(nal), d.h)
+            if got:
+                pull()
+        while not api.jm_nvdec_is_exit(d.h):
+            _, got = api.jm_nvdec_decode_frame(None, 0, d.h)
+            if got:
+                pull()
+        assert d.stat("errors") == 0
+        kinds = (d.stat("i_pictures"), d.stat("p_pictures"), d.stat("b_pictures"))
+    return digs, kinds
+
+
+def test_c2_full_length_4k_high_ibbp(oracle):
+    """BASELINE config C2 at its full size AND length: 3840x2160 High (CABAC, 8x8 transform), I B B P with two references, 120 frames
+    (four IDR periods).  The first IDR period is compared with the CPU oracle frame by frame; the whole run through size-independent
+    properties: 120 frames in display order, no errors, and a second decode fed in 64 KiB chunks instead of NAL-per-call gives the
+    same 120 digests (chunking invariance + run-to-run determinism at full batch depth)."""
+    data = streams.generate(**streams.config_c2(frames=120))
+    digs, kinds = _decode_digests(data, 3840, 2160)
+    assert len(digs) == 120 and sum(kinds) == 120 and kinds[0] == 4 and kinds[2] >= 70      # 4 IDR pictures, ~2/3 B pictures
+    nal_starts = [i for i in range(len(data) - 4) if data[i:i + 4] == b"\x00\x00\x00\x01" and (data[i + 4] & 31) == 7]
+    assert len(nal_starts) >= 2                                                              # an SPS before every IDR picture
+    want, n, w, h = oracle.decode(data[:nal_starts[1]], 1)
+    assert (w, h, n) == (3840, 2160, 30)
+    assert digs[:30] == _md5_frames(want, w * h * 3 // 2)
+    digs2, _ = _decode_digests(data, 3840, 2160, chunks=[data[i:i + 65536] for i in range(0, len(data), 65536)])
+    assert digs2 == digs
+    assert len(set(digs)) == 120
+
+
+def test_avcc_on_device(oracle):
+    """SURVEY 8f f2, H.264 half, on the GPU: parameter sets as an avcC record through jm_nvdec_init(extra_data), packets as
+    length-prefixed NAL units (test_player.cpp:221-226 without the mp4toannexb filter) -- same frames as the Annex-B form."""
+    kw = dict(width=320, height=240, frames=12, gop=6, seed=31, cabac=1, t8x8=1, bframes=2, num_ref=2, poc_type=0)
+    data = streams.generate(**kw)
+    want, n, w, h = oracle.decode(data, 1)
+    assert n == 12
+    for ls in (4, 2):
+        rec, packets = api.annexb_to_avcc(data, ls)
+        with api.JmAmdDec(0, 1, extra_data=rec) as d:
+            frames = d.decode_stream(None, chunks=packets)
+            assert d.stat("errors") == 0
+        assert b"".join(frames) == want, f"length_size {ls}"
+
+
+def test_native_harness_on_device(oracle, tmp_path):
+    """tools/test_amd_dec -- the native counterpart of the reference's test_nv_dec main loop (test_nv_dec.cpp:98-268), bound to the
+    drop-in jm_nvdec_* symbols -- RUNS on the GPU: the YUV file it writes equals the oracle's frames, the info block reports them."""
+    import os
+    import subprocess
+    from util import ROOT
+    data = streams.generate(width=320, height=240, frames=9, gop=9, seed=41, cabac=1, bframes=2, num_ref=2, poc_type=0)
+    want, n, w, h = oracle.decode(data, 1)
+    src, dst = tmp_path / "in.h264", tmp_path / "out.yuv"
+    src.write_bytes(data)
+    exe = os.path.join(ROOT, "tools", "_build", "test_amd_dec")
+    r = subprocess.run([exe, str(src), str(dst), "--chunk", "4096"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"Frame Count:\t{n}\n" in r.stdout and f"Display:\t{w} x {h}\n" in r.stdout
+    assert dst.read_bytes() == want
+    r = subprocess.run([exe, str(src), "--fmt", "0", "--loops", "4"], capture_output=True, text=True, timeout=300)     # NV12, looped input
+    assert r.returncode == 0 and f"Frame Count:\t{4 * n}\n" in r.stdout and "Pixel Format:\tNV12\n" in r.stdout

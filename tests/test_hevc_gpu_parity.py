@@ -154,3 +154,19 @@ def test_resolution_change_between_sequences(oracle):
     # the oracle's convenience call reports one size: compare per sequence
     want = b"".join(oracle.decode(s, 1)[0] for s in (a, b, a))
     assert b"".join(frames) == want
+
+
+def test_c3_4k_whole_gop8_pyramid():
+    """BASELINE config C3 at full size with a COMPLETE random-access GOP-8 pyramid: 3840x2160 HEVC Main, 64x64 CTB, SAO + deblocking,
+    17 frames (I, two full B pyramids of depth 3), every frame compared with the HEVC CPU oracle."""
+    data = streams.generate_hevc(**streams.config_c3(frames=17))
+    want, n, w, h = streams.OracleHevc().decode(data, 1)
+    assert (w, h, n) == (3840, 2160, 17)
+    fs = w * h * 3 // 2
+    with jmcodec_amd.JmAmdDec(1, 1) as d:
+        frames = d.decode_stream(data)
+        assert d.stat("errors") == 0
+        assert d.stat("b_pictures") >= 12
+    assert len(frames) == 17
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i} differs from the oracle"

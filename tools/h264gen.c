@@ -293,7 +293,7 @@ static void frame_finish_ref(Frame *f, int W, int H) {
 static int tri(int p) { p &= 1023; int q = p < 512 ? p : 1023 - p; int x = q - 256; return (x * (512 - ABS(x))) >> 8; /* [-256,256] smooth */ }
 static void make_texture(Enc *e) {
     Rng r = { (uint64_t)e->p.seed * 77 + 5 };
-    static int16_t n0[64][64];
+    static __thread int16_t n0[64][64];
     for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++) n0[y][x] = (int16_t)(rnd_n(&r, 65) - 32);
     for (int y = 0; y < 256; y++) for (int x = 0; x < 256; x++) {      /* bilinear-upsampled noise + fine grain */
         int x0 = (x >> 2) & 63, y0 = (y >> 2) & 63, x1 = (x0 + 1) & 63, y1 = (y0 + 1) & 63, fx = x & 3, fy = y & 3;
@@ -543,7 +543,7 @@ static void idct4_add(const int *dq, uint8_t *dst, int st) {
         dst[j] = (uint8_t)CLIP1(dst[j] + r0); dst[st + j] = (uint8_t)CLIP1(dst[st + j] + r1); dst[2 * st + j] = (uint8_t)CLIP1(dst[2 * st + j] + r2); dst[3 * st + j] = (uint8_t)CLIP1(dst[3 * st + j] + r3); }
 }
 /* scaling matrices in effect (8.5.9), raster order: 4x4 lists Intra Y/Cb/Cr, Inter Y/Cb/Cr; 8x8 lists Intra Y, Inter Y */
-static int g_w4[6][16], g_w8[2][64], g_wlist;          /* g_wlist: list used by the block being coded */
+static __thread int g_w4[6][16], g_w8[2][64], g_wlist;          /* g_wlist: list used by the block being coded */
 static inline int dequant_ac(int c, int qp, int k) { int ls = g_w4[g_wlist][k] * norm4[qp % 6][pos_class(k)]; return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
 
 /* ------------------------------ CAVLC writer -------------------------------- */
@@ -772,9 +772,9 @@ static void recon8(const int *lev /*raster*/, int qp, int list, uint8_t *dst, in
     }
 }
 /* forward side: projection on the decoder's (orthogonal) reconstruction basis, computed in floating point per QP */
-static int g_w8_version;
+static __thread int g_w8_version;   /* per thread: bench.py generates streams on several threads */
 static float *basis8(int qp, int list) {
-    static float *tab[2][52]; static int version[2][52];
+    static __thread float *tab[2][52]; static __thread int version[2][52];
     if (tab[list][qp] && version[list][qp] == g_w8_version) return tab[list][qp];
     free(tab[list][qp]);
     float *B = (float *)malloc(sizeof(float) * 64 * 65);
@@ -1098,7 +1098,7 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
         return;
     }
     int aA = intra_ok(e, mb_avail(e, mx - 1, my)), aB = intra_ok(e, mb_avail(e, mx, my - 1)), aD = intra_ok(e, mb_avail(e, mx - 1, my - 1));
-    static MbCode mc; memset(&mc, 0, sizeof mc);
+    static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     /* QP for this MB */
     int dqp = 0;
     if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
@@ -1270,7 +1270,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     /* ---- decide intra vs inter ---- */
     int want_intra = 0, force_intra = -1;
     if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1; force_intra = 7; } }
-    static MbCode mc; memset(&mc, 0, sizeof mc);
+    static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     int try_skip = fuzz && !want_intra && rnd_n(&e->rng, 8) < 2;
     int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {0, 0, 0, 0};
     int mvs[16][2]; memset(mvs, 0, sizeof mvs);
@@ -1500,7 +1500,14 @@ static int temporal_direct_ok(Enc *e, int mx, int my) {
 }
 /* prediction samples of one 4x4 block from one reference (literal, clamped: direct vectors may point anywhere) */
 static void sample4(Enc *e, const Frame *r, int px, int py, int mvx, int mvy, int *yl, int *cu, int *cv) {
-    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
+    {   /* inside the padded half-sample planes the fast fetch gives the same samples (mc_block checks that under H264GEN_CHECK); the literal
+         * form -- ~40 clamped reads per sample -- is only needed for vectors that leave them */
+        const int lim = PAD - 8, x0 = px + (mvx >> 2), y0 = py + (mvy >> 2);
+        if (r->hb && x0 >= -lim && y0 >= -lim && x0 + 4 <= e->W + lim && y0 + 4 <= e->H + lim)
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = qpel_fast(r, x0 + x, y0 + y, mvx & 3, mvy & 3);
+        else
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
+    }
     int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
     for (int pl = 0; pl < 2; pl++) { const uint8_t *rp = pl ? r->v : r->u; int *o = pl ? cv : cu;
         for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
@@ -1616,7 +1623,7 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     int fuzz = e->p.mode == 1, px = mx * 16, py = my * 16;
     int nref[2] = { e->nlist0, e->nlist1 };
     int direct_ok = e->p.direct_temporal ? temporal_direct_ok(e, mx, my) : 1;
-    static MbCode mc; memset(&mc, 0, sizeof mc);
+    static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     /* ---- choose the macroblock type ---- */
     int mbt, sub[4] = {0, 0, 0, 0};
     if (fuzz) {

@@ -348,7 +348,7 @@ static void mc_pred(const Pic *ref, int c, int pw, int ph, int xb, int yb, int b
 }
 /* prediction of one block of plane c into dst (8.5.3.3.4) */
 static void inter_block(Enc *e, const Mot *m, int c, int xp, int yp, int w, int h, uint8_t *dst, int dstride) {
-    static int16_t a[64 * 64], b[64 * 64];
+    static __thread int16_t a[64 * 64], b[64 * 64];
     int sc = c ? 1 : 0, pw = e->W >> sc, ph = e->H >> sc, bw = w >> sc, bh = h >> sc;
     const Slc *s = e->sl;
     if (m->pf & 1) mc_pred(s->ref[0][m->ref[0]], c, pw, ph, xp >> sc, yp >> sc, bw, bh, m->mv[0][0], m->mv[0][1], a);
@@ -645,7 +645,7 @@ typedef struct {
     int16_t lev[64 * 64 * 2]; int n_lev;
     int max_depth, intra_split;
 } Cu;
-static Cu g_cu;
+static __thread Cu g_cu;            /* per thread: bench.py generates streams on several threads */
 
 static int chroma_qp_of(const Enc *e, int qp, int c) { return hg_qpc_tab[CLIP3(0, 57, qp + (c == 1 ? e->p.cb_qp_off : e->p.cr_qp_off))]; }
 static int scan_of(const Enc *e, const Cu *cu, int x0, int y0, int log2, int c) {
@@ -743,7 +743,7 @@ static int qp_pred(const Enc *e, int xcb, int ycb) {
 
 static int sad_block(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h) { int s = 0; for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) s += ABS(a[y * as + x] - b[y * bs + x]); return s; }
 static int sad_mot(Enc *e, const Mot *m, int x, int y, int w, int h) {
-    static uint8_t tmp[64 * 64];
+    static __thread uint8_t tmp[64 * 64];
     inter_block(e, m, 0, x, y, w, h, tmp, w);
     return sad_block(tmp, w, e->src.pl[0] + y * e->src.stride[0] + x, e->src.stride[0], w, h);
 }
