@@ -1,0 +1,88 @@
+// jmcodec_amd/csrc/chain_common.h -- the device-memory protocol that couples consecutive pictures of one stream inside ONE launch (k_chain).
+//
+// Why: a picture's in-loop deblocking is a 254-step dependency chain at 1080p (x + 2y macroblock wavefront, clause 8.7 order) and the
+// next picture's motion compensation reads its output, so one stream alone leaves the GPU idle and tops out near 1 / (chain latency).
+// A chain launch holds up to kMaxChainDepth consecutive pictures of a stream; picture n+1 follows picture n at MACROBLOCK granularity:
+//   * deblocking workgroups publish, per band of 16 macroblock rows and plane, how many wavefront steps are final in memory (`fin`);
+//   * a reconstruction wave of picture n+1 waits until the steps that store the last sample of its reference windows are final;
+//   * reconstruction waves publish each finished macroblock in a per-row bitmap (`bits`), on which picture n+1's own deblocking waits.
+// Everything that crosses workgroups this way is written with write-through stores and read with loads that bypass the non-coherent
+// cache levels (agent-scope relaxed atomics: the 8 XCDs of an MI355X have private L2s, and a 128-byte line fetched for a final sample
+// also holds neighbours that are not final yet).  Acquire / release fences are deliberately not used: at agent scope they write back /
+// invalidate a whole L2.
+// A workgroup only ever waits for workgroups with a lower linear index (earlier picture, or earlier role of the same picture), which the
+// dispatcher has started before it: no deadlock at any occupancy.  Every wait is bounded; a wait that gives up sets the error word.
+// There is no reference counterpart (the reference hands whole pictures to the NVDEC ASIC, nv_dec.cpp:33-41).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jobs.h"
+
+namespace jmamd {
+
+// per-picture block of ints in the batch's chain buffer
+// (the H.264 stage kernels use the same block: one memset per batch clears every counter of every picture)
+constexpr int kChainRing = 0;          // [64]  band step counters of the ring-row hand-over between deblocking bands (deblock_device.h)
+constexpr int kChainFin = 64;          // [64]  steps final in memory: luma bands 0..31, chroma bands 32..63
+constexpr int kChainIntraRing = 128;   // [64]  band step counters of the intra wavefront (intra_lds.hip)
+constexpr int kChainBits = 192;        // [mb_h][kChainRowWords] reconstruction bitmap, bit x of row y = macroblock (x, y) is in memory
+constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4096 samples)
+constexpr int kChainMaxRows = 512;
+constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
+constexpr int kSpinLimit = 1 << 22;    // polls before a wait gives up (seconds; a healthy wait takes microseconds)
+enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8 };
+
+typedef __attribute__((address_space(1))) int gint;
+
+// loads / stores of data that another workgroup of the same launch produces or consumes
+__device__ __forceinline__ int ld_coh(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_coh(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// reference samples: COH = the reference picture may have been written by this launch
+template <bool COH> __device__ __forceinline__ int ld_ref8(const uint8_t *p) {
+    if (COH) return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)*p;
+}
+template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const uint8_t *p) {
+    if (COH) return __hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *(const uint32_t *)p;
+}
+
+// A bounded wait gave up: record it in the batch's error array (pinned HOST memory mapped into the device, one word per picture; the engine
+// reads it when the batch retires and reports a decode error for the handle -- a damaged hand-over is never silent).
+__device__ __forceinline__ void report_wait_timeout(int *err_word, int code) {
+    if (err_word) __hip_atomic_store(err_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct ChainView {
+    int *base;                          // the batch's control buffer (device): kChainStride ints per picture
+    int *err;                           // the batch's error words (host-pinned, device-visible), one per picture
+    __device__ __forceinline__ int *pic(int idx) const { return base + (size_t)idx * kChainStride; }
+
+    // Wait until every sample of the rectangle [.., xmax] x [ymin, ymax] (luma coordinates, already clamped to the picture) of the picture
+    // with chain index `dep` is final.  The final value of sample (px, py) is stored by the deblocking step of macroblock
+    // ((px + 4) >> 4, (py + 4) >> 4) (clamped; deblock_device.h stores (-4,-4)-shifted blocks, chroma the same in its own units), i.e. in
+    // wavefront step X + 2Y of the band that holds row Y.  A rectangle touches at most two bands.  Per lane; dep < 0 = nothing to wait for.
+    // Returns false when the wait gave up.
+    __device__ __forceinline__ bool wait_final(int dep, int xmax, int ymin, int ymax, int mb_w, int mb_h) const {
+        bool pending = dep >= 0;
+        const int *fin = pic(pending ? dep : 0) + kChainFin;
+        const int xs = min((xmax + 4) >> 4, mb_w - 1), yhi = min((ymax + 4) >> 4, mb_h - 1), ylo = min(max((ymin + 4) >> 4, 0), yhi);
+        const int bhi = yhi >> 4, blo = ylo >> 4;
+        const int need_hi = xs + 2 * yhi + 1, need_lo = xs + 2 * (blo * 16 + 15) + 1;
+        int spins = 0;
+        for (;;) {
+            if (pending) {
+                bool ok = ld_coh(fin + bhi) >= need_hi && ld_coh(fin + 32 + bhi) >= need_hi;
+                if (ok && blo != bhi) ok = ld_coh(fin + blo) >= need_lo && ld_coh(fin + 32 + blo) >= need_lo;
+                pending = !ok;
+            }
+            if (!__builtin_amdgcn_ballot_w64(pending)) return true;
+            if (++spins > kSpinLimit) return false;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+};
+
+}  // namespace jmamd

@@ -112,6 +112,7 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "pictures") return stat_pictures_;
     if (k == "job_bytes") return stat_job_bytes_;
     if (k == "errors") return stat_errors_;
+    if (k == "device_wait_errors") return stat_wait_errors_;
     if (k == "intra_mbs") return stat_intra_mbs_;
     if (k == "coef_int16") return stat_coef_;
     if (k == "syntax_digest") return codec_ == 1 ? (long long)hdigest_.h : (long long)digest_.h;
@@ -130,10 +131,10 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "wait_slot_ns") return stat_wait_slot_ns_;
     if (k == "parse_ns_p") return stat_parse_ns_p_;
     if (k.rfind("k_", 0) == 0 || k.rfind("eng_", 0) == 0) {          // engine-wide (all handles on this device), profile option
-        static const char *kn[4] = {"inter", "intra", "deblock", "packout"};
+        static const char *kn[5] = {"inter", "intra", "deblock", "packout", "chain"};
         if (!engine_) return 0;
         EngineStats es = engine_->stats();
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 5; i++) {
             if (k == std::string("k_") + kn[i] + "_ns") return (long long)es.ns[i];
             if (k == std::string("k_") + kn[i] + "_n") return es.launches[i];
             if (k == std::string("k_") + kn[i] + "_pics") return es.pics[i];
@@ -141,6 +142,9 @@ long long Decoder::get_stat(const char *key) const {
         }
         if (k == "eng_batches") return es.batches;
         if (k == "eng_batch_pics") return es.batch_pics;
+        if (k == "eng_chain_batches") return es.chain_batches;
+        if (k == "eng_chain_pics") return es.chain_pics;
+        if (k == "eng_wait_errors") return es.wait_errors;
         if (k == "eng_launch_ns") return es.launch_ns;
         if (k == "eng_complete_ns") return es.complete_ns;
         return -1;
@@ -230,11 +234,11 @@ void Decoder::gpu_free_sequence() {
     if (!gpu_open_) return;
     hipSetDevice(device_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
-    if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
     for (auto &j : jobs_) {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
+        if (j.dbrec) hipFree(j.dbrec);
         if (j.uploaded) hipEventDestroy(j.uploaded);
         j = JobSlot();
     }
@@ -285,9 +289,11 @@ bool Decoder::gpu_alloc_sequence() {
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
     lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
-    if (!HIP_OK(hipMalloc((void **)&dbrec_, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
+    chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
+    if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
+            (codec_ == 0 && !HIP_OK(hipMalloc((void **)&j.dbrec, n_mbs * 96))) ||
             !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
     }
@@ -454,9 +460,8 @@ bool Decoder::activate(const SeqParams &sps) {
         if (gpu_open_) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
-            if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
-            if (resid_) { hipFree(resid_); resid_ = nullptr; }
-            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
+                    if (resid_) { hipFree(resid_); resid_ = nullptr; }
+            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
             free_out_slots(false);
         } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
     }
@@ -525,7 +530,9 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
     // n+1 decodes (the engine overlaps pack-out with the next batch), so prefer one that has "cooled" for a picture.
     int slot = -1, warm = -1;
     bool wait_pack = false;
-    for (int i = 0; i < n_surf_; i++) if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i; break; } if (warm < 0) warm = i; }
+    // Round robin over the free surfaces (starting behind the one chosen last), so that a surface is reused as LATE as possible: the engine
+    // runs consecutive pictures of a stream in one launch only while none of them decodes into a surface an earlier one still reads or displays.
+    for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i; break; } if (warm < 0) warm = i; } }
     if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
     if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
         int best = -1;
@@ -534,7 +541,7 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
         else { carry_out_.push_back(best); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false; dpb_[best].ref = 0; }
         dpb_[best].in_use = false; slot = best; stat_errors_++;
     }
-    cur_ = slot;
+    cur_ = slot; last_surf_ = slot;
     DpbPic &c = dpb_[slot];
     c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
     c.poc = compute_poc(sh);
@@ -902,7 +909,7 @@ void Decoder::submit_task(PicTask *t) {
     ep.dec = this; ep.has_picture = t->has_picture && !parse_only_ && !failed_; ep.job_slot = t->job_slot;
     ep.p_lane = handle_index_ % kPLanes;
     ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
-    for (int s : t->out_before) enqueue_output(s, ep.out_before, ep.slots_before);
+    for (int s : t->out_before) { enqueue_output(s, ep.out_before, ep.slots_before); ep.out_mask |= 1u << s; }
     memset(&ep.pp, 0, sizeof ep.pp);
     if (ep.has_picture && t->hevc) hevc_fill_engine_pic(t, ep);
     else if (ep.has_picture) {
@@ -918,7 +925,7 @@ void Decoder::submit_task(PicTask *t) {
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
-        pp.resid = (int16_t *)resid_; pp.dbrec = dbrec_;
+        pp.resid = (int16_t *)resid_; pp.dbrec = js.dbrec;
         pp.wp = t->any_wp ? (const SliceWp *)(js.dev + t->wp_offset) : nullptr;
         {   // scaling matrices: transmitted in zig-zag order (7.3.2.1.1.1), the kernels index them in raster order
             static const uint8_t zz4[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
@@ -935,6 +942,11 @@ void Decoder::submit_task(PicTask *t) {
         pp.stages = PS_RECON;
         if (t->n_intra > 0) pp.stages |= lds_intra ? PS_INTRA_LDS : PS_INTRA_V1;
         if (t->any_deblock) pp.stages |= use_lds_deblock_ ? PS_DEBLOCK_LDS : PS_DEBLOCK_V1;
+        // Inter pictures without intra macroblocks, deblocked by the LDS wavefront, may run inside the chain kernel (chain.hip) together with
+        // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
+        ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
+        ep.classic_stages = pp.stages;
+        for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];
         // algorithmic bytes of this picture per kernel class
         long long S = (long long)surf_bytes_;
         bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
@@ -943,10 +955,17 @@ void Decoder::submit_task(PicTask *t) {
         ep.alg_bytes[2] = 2 * S;
     }
     ep.alg_bytes[3] = (long long)surf_bytes_ + (long long)frame_bytes_;
-    for (int s : t->out_after) enqueue_output(s, ep.out_after, ep.slots_after);
+    for (int s : t->out_after) { enqueue_output(s, ep.out_after, ep.slots_after); ep.out_mask |= 1u << s; }
     stat_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - st0).count();
     if (parse_only_ || failed_ || !engine_) { on_engine_done(ep); return; }
     engine_->submit(std::move(ep));
+}
+
+// engine thread: a kernel gave up waiting for another workgroup while one of this handle's pictures was decoded (codes: chain_common.h).
+// The picture may be damaged; that is reported, never silent.
+void Decoder::on_device_wait_error(int code) {
+    stat_errors_++; stat_wait_errors_++;
+    note_error("device: a wait between workgroups timed out (code " + std::to_string(code) + "): the picture may be damaged");
 }
 
 // called by the engine thread when the batch containing this picture has finished on the device

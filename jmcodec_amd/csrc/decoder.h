@@ -76,6 +76,7 @@ struct PicTask {
 
 struct JobSlot {                       // one picture's job list: pinned host buffer (parse target) + its device copy
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
+    uint8_t *dbrec = nullptr;          // device scratch of k_deblock_prep for this picture (96 B per macroblock): per slot, because pictures of a chain run concurrently
     ihipEvent_t *uploaded = nullptr;   // recorded behind the H2D copy on the engine's copy stream
     bool busy = false;                 // from dispatch until the engine reports the picture done
 };
@@ -113,6 +114,7 @@ public:
     void parse_task(PicTask *t, ParseScratch &scratch);
     // engine completion callback + engine-private per-decoder state
     void on_engine_done(const struct EnginePic &p, bool failed = false);
+    void on_device_wait_error(int code);       // engine: a kernel's bounded wait gave up while this handle's picture was decoded
     struct EngineDecoderState &engine_state() { return *eng_state_; }
 
 private:
@@ -156,7 +158,8 @@ private:
     OutSlot *alloc_out_slot();
 
     // configuration
-    int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0;
+    int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1;
+    bool chain_ok_ = false;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
     std::string error_;
     std::atomic<bool> failed_{false}; bool inited_ = false;
@@ -195,7 +198,7 @@ private:
     struct EngineDecoderState *eng_state_ = nullptr;
     class Engine *engine_ = nullptr;          // per-device executor (engine.h): the only place device work is issued
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
-    uint8_t *dbrec_ = nullptr; bool use_lds_deblock_ = false;
+    bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
     bool gpu_open_ = false;
@@ -206,7 +209,7 @@ private:
     std::chrono::steady_clock::time_point t0_; bool timer_started_ = false; double elapsed_ms_ = 0;
     char info_[1024];
     std::atomic<long long> stat_parse_ns_i_{0}, stat_parse_ns_p_{0}, stat_submit_ns_{0}, stat_wait_slot_ns_{0};
-    std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0};
+    std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0}, stat_wait_errors_{0};
     SyntaxDigest digest_;
     // HEVC state (front end only unless noted)
     HevcParamSets hps_; HevcSps hsps_; HevcPps hpps_;

@@ -28,6 +28,7 @@ Engine *Engine::get(int device) {
 }
 
 Engine::Engine(int device) : device_(device) {
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
@@ -42,6 +43,10 @@ Engine::Engine(int device) : device_(device) {
             if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * (size_t)kMaxBatch * chain_ctl_ints()) != hipSuccess) return;
+            if (hipHostMalloc((void **)&b.h_err, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) return;
+            if (hipHostGetDevicePointer((void **)&b.d_err, b.h_err, 0) != hipSuccess) return;
+            memset(b.h_err, 0, sizeof(int) * kMaxBatch);
             if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
@@ -70,11 +75,18 @@ void Engine::submit(EnginePic &&p) {
 
 EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 
-// Take the first pending picture of every decoder (arrival order) that belongs to this lane and may run now.
+// Take the first pending picture of every decoder (arrival order) that belongs to this lane and may run now; then, on the lanes of ordinary
+// pictures, extend every decoder's share of the batch by its NEXT pictures as long as they can run inside the chain kernel (chain.hip):
+// consecutive P / B pictures of a stream then share one launch and follow each other at macroblock granularity instead of one per batch.
 bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
-    b.pics.clear();
-    std::vector<Decoder *> seen;
+    b.pics.clear(); b.any_chain = false; b.max_depth = 1;
+    std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
+    auto account = [&](EnginePic &p, EngineDecoderState &es) {
+        if (p.has_picture && p.codec == 0) es.batch_written |= 1u << p.pp.cur;
+        es.batch_read |= p.ref_mask | p.out_mask;
+        n_pre += p.out_before.size(); n_post += p.out_after.size();
+    };
     for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
         Decoder *d = it->dec;
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
@@ -85,24 +97,52 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
         if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
         if (!ok) { ++it; continue; }
-        n_pre += it->out_before.size(); n_post += it->out_after.size();
         es.lane = lane_idx; es.inflight++;
+        es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false;
+        account(*it, es);
+        members.push_back(d);
         b.pics.push_back(std::move(*it));
         it = pending_.erase(it);
     }
+    if (b.pics.empty()) return false;
+    if (lane_idx < kPLanes && chain_depth_ > 1) {
+        // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
+        // many streams -> the batch is already wide, and kMaxBatch bounds it.
+        const int depth_cap = std::min(chain_depth_, std::max(1, kMaxBatch / (int)members.size()));
+        for (int depth = 1; depth < depth_cap; depth++) {
+            bool added = false;
+            for (Decoder *d : members) {
+                EngineDecoderState &es = d->engine_state();
+                if (es.batch_stop || (int)b.pics.size() >= kMaxBatch) continue;
+                auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
+                // the next picture joins only if it runs inside k_chain, packs nothing BEFORE the kernels (such frames may not be decoded yet),
+                // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
+                const bool ok = it != pending_.end() && it->lane() == lane_idx && it->has_picture && it->chain_ok && it->out_before.empty() && !it->wait_prev_pack &&
+                                !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
+                if (!ok) { es.batch_stop = true; continue; }
+                es.inflight++; es.in_batch++;
+                account(*it, es);
+                b.pics.push_back(std::move(*it));
+                pending_.erase(it);
+                b.any_chain = true; added = true;
+            }
+            if (!added) break;
+            b.max_depth = depth + 1;
+        }
+    }
     (void)ln;
-    return !b.pics.empty();
+    return true;
 }
 
 // one batched launch per stage on the lane's in-order stream; pack-out on the lane's second stream
 void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size();
-    int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0, stages = 0;
+    int max_mbs = 0, max_mb_h = 0, max_mb_w = 0, max_w = 0, max_h = 0, stages = 0;
     bool wait_pack = false, any_hevc = false;
     HevcBatchDims hd;
     const EnginePic *last_upload = nullptr;
     b.n_pre = b.n_post = 0; b.pmask = 0;
-    for (int k = 0; k < 4; k++) { b.alg[k] = 0; b.npics[k] = 0; }
+    for (int k = 0; k < 5; k++) { b.alg[k] = 0; b.npics[k] = 0; }
     // pack jobs: [0, n_pre) before the decode kernels, [2*kMaxBatch, 2*kMaxBatch + n_post) after them
     for (int i = 0; i < n; i++) {
         EnginePic &p = b.pics[i];
@@ -110,7 +150,18 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (hevc) { b.h_hpics[i] = p.hp; if (!p.has_picture) b.h_hpics[i].stages = 0; any_hevc = true; }
         b.h_pics[i] = p.pp;
         if (!p.has_picture || hevc) b.h_pics[i].stages = 0;
+        else if (b.any_chain && p.chain_ok) {
+            // this picture runs inside k_chain: its block of the control buffer, and which surfaces are decoded by EARLIER pictures of this launch
+            PicParams &q = b.h_pics[i];
+            q.stages = PS_CHAIN; q.chain_idx = i; q.n_deps = 0;
+            for (int k = 0; k < kMaxSurfaces; k++) q.dep_pic[k] = -1;
+            for (int j = 0; j < i; j++) {
+                const EnginePic &e = b.pics[j];
+                if (e.dec == p.dec && e.has_picture && e.chain_ok && e.codec == 0) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
+            }
+        }
         stages |= b.h_pics[i].stages;
+        if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
         if (hevc && p.has_picture) {
             const HevcPicParams &h = p.hp;
             hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
@@ -129,10 +180,16 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (st & PS_RECON) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
         if (st & (PS_INTRA_LDS | PS_INTRA_V1)) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; }
         if (st & (PS_DEBLOCK_LDS | PS_DEBLOCK_V1)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; }
+        if (st & PS_CHAIN) { b.alg[4] += p.alg_bytes[0] + p.alg_bytes[2]; b.npics[4]++; }
         b.alg[3] += p.alg_bytes[3] * (long long)(p.out_before.size() + p.out_after.size());
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
+    // surfaces this batch displays, per decoder: a later batch that decodes into one of them must wait for this batch's pack-out
+    for (auto &p : b.pics) p.dec->engine_state().displayed[1] = 0;
+    for (auto &p : b.pics) p.dec->engine_state().displayed[1] |= p.out_mask;
+    for (auto &p : b.pics) p.dec->engine_state().displayed[0] = p.dec->engine_state().displayed[1];
     hipStream_t st = ln.stream, pst = ln.pack_stream;
+    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);   // every counter of every picture
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, st);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, st);
@@ -164,12 +221,15 @@ void Engine::launch(Lane &ln, Batch &b) {
     }
     if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
-    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_progress, st); b.pmask |= 4; }
+    if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
-    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mbs, max_mb_h, b.d_progress, st); b.pmask |= 8; }
+    if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) launch_deblock_prep(b.d_pics, n, max_mbs, st);
+    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);
+    // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
+    if (stages & PS_CHAIN) { launch_chain(b.d_pics, n, max_mb_w, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 32; mark(7, st); }
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
     mark(5, pst);
@@ -193,10 +253,14 @@ void Engine::complete(Batch &b, bool failed) {
             if (hipEventElapsedTime(&ms, b.pev[e0], b.pev[e1]) == hipSuccess) { st_.ns[cls] += ms * 1e6; st_.launches[cls]++; }
         };
         add(3, 0, 1, b.pmask & 1); add(0, 1, 2, b.pmask & 2); add(1, 2, 3, b.pmask & 4); add(2, 3, 4, b.pmask & 8); add(3, 5, 6, b.pmask & 16);
-        for (int k = 0; k < 4; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
+        add(4, 4, 7, b.pmask & 32);
+        for (int k = 0; k < 5; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
+        if (b.any_chain) { st_.chain_batches++; st_.chain_pics += (long long)b.pics.size(); }
     }
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
+    // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
+    for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0; std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }
     for (auto &p : b.pics) p.dec->on_engine_done(p, failed);
     b.pics.clear();
 }

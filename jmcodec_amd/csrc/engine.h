@@ -48,19 +48,28 @@ struct EnginePic {
     std::vector<OutSlot *> slots_before, slots_after;
     int mb_w = 0, mb_h = 0, disp_w = 0, disp_h = 0;
     bool wait_prev_pack = false;                    // this picture reuses a surface whose pack-out may still be running
+    // chain launches (chain.hip): the picture may run inside k_chain, i.e. in the same launch as the pictures before it in its stream
+    bool chain_ok = false;
+    int classic_stages = 0;                         // pp.stages when it runs through the stage kernels instead
+    uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
     int lane() const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane); }
 };
 
-struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout
-    double ns[4] = {0, 0, 0, 0}; long long launches[4] = {0, 0, 0, 0}, pics[4] = {0, 0, 0, 0}, alg_bytes[4] = {0, 0, 0, 0};
-    long long batches = 0, batch_pics = 0;
+struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
+    double ns[5] = {0, 0, 0, 0, 0}; long long launches[5] = {0, 0, 0, 0, 0}, pics[5] = {0, 0, 0, 0, 0}, alg_bytes[5] = {0, 0, 0, 0, 0};
+    long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0;
     long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
 };
 
 // engine-private state kept inside each Decoder (touched only by the engine thread)
-struct EngineDecoderState { int lane = -1, inflight = 0; };
+struct EngineDecoderState {
+    int lane = -1, inflight = 0;
+    uint32_t displayed[2] = {0, 0};                 // surfaces displayed by this decoder's pictures in the two most recently formed batches
+    // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
+    int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false;
+};
 
 class Engine {
 public:
@@ -79,11 +88,14 @@ private:
         PicParams *h_pics = nullptr, *d_pics = nullptr;       // pinned host / device, kMaxBatch entries
         HevcPicParams *h_hpics = nullptr, *d_hpics = nullptr; // the same for HEVC batches
         int *d_progress = nullptr;                            // CTB row progress counters of k_hevc_intra
+        int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
+        int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
+        bool any_chain = false; int max_depth = 1;
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
-        long long alg[4] = {0, 0, 0, 0}; int npics[4] = {0, 0, 0, 0};
+        long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
     };
     struct Lane {
         ihipStream_t *stream = nullptr, *pack_stream = nullptr;
@@ -92,6 +104,7 @@ private:
         int head = 0, tail = 0, inflight = 0;
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
+    int chain_depth_ = 8;                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Batch &b, bool failed);

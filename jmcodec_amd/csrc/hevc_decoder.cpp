@@ -86,7 +86,6 @@ bool Decoder::hevc_activate(const HevcSps &sps) {
         if (gpu_open_) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
-            if (dbrec_) { hipFree(dbrec_); dbrec_ = nullptr; }
             if (resid_) { hipFree(resid_); resid_ = nullptr; }
             for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
             free_out_slots(false);

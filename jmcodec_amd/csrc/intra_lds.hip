@@ -18,6 +18,7 @@
 #include "jobs.h"
 #include "kernels.h"
 #include "kernel_common.h"
+#include "chain_common.h"
 
 namespace jmamd {
 
@@ -401,7 +402,7 @@ __device__ __forceinline__ void intra_chroma_mb(const ICtx &pp, const ILds &lds,
 // fetches the row of macroblock x + 2 one step before it needs it.  (The first form walked a whole plane with ONE workgroup: up to five
 // macroblock rows per 16-lane group at 4K, 7 ms for a 4K I picture.)
 constexpr int kIBandRows = 16;
-__global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_intra_band(const PicParams *pics, int *progress, int prog_stride) {
+__global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_intra_band(const PicParams *pics, int *ctl, int *err) {
     __shared__ __align__(16) uint8_t smem[kTileBase + 32 * 992 + (kIBandRows + 1) * 80 + 64];
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_INTRA_LDS)) return;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu
     const int row0 = band * kIBandRows;
     if (row0 >= mb_h) return;
     const int rows = min(kIBandRows, mb_h - row0);
-    int *prog = progress + (size_t)blockIdx.y * prog_stride + (is_chroma ? kDeblockMaxBands : 0);
+    int *prog = ctl + (size_t)blockIdx.y * kChainStride + kChainIntraRing + (is_chroma ? kDeblockMaxBands : 0);     // control block layout: chain_common.h
     const gbyte *resid = (const gbyte *)pp.resid;
     const gbyte *mbs = (const gbyte *)pp.mbs;
     ILds lds{smem, kIBandRows + 1};
@@ -433,7 +434,8 @@ __global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu
     auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
         int spins = 0;
-        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(8);
+        if (known < need && l == 0) report_wait_timeout(err + blockIdx.y, CHAIN_ERR_INTRA_TIMEOUT);       // never silent: the engine reports a decode error
         asm volatile("" ::: "memory");
     };
     auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };
@@ -488,10 +490,10 @@ __global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu
 
 bool intra_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kIBandRows * kDeblockMaxBands; }
 
-void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *progress, hipStream_t st) {
+// ctl must have been cleared for this batch (Engine::launch)
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, hipStream_t st) {
     const int bands = (max_mb_h + kIBandRows - 1) / kIBandRows;
-    (void)hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kDeblockProgressStride, st);
-    hipLaunchKernelGGL(k_intra_band, dim3(2 * bands, n), dim3(kIBandRows * 16), 0, st, d_pics, progress, kDeblockProgressStride);
+    hipLaunchKernelGGL(k_intra_band, dim3(2 * bands, n), dim3(kIBandRows * 16), 0, st, d_pics, ctl, err);
 }
 
 }  // namespace jmamd

@@ -107,11 +107,17 @@ struct PicParams {
     int flat_scaling;             // 1: every weight is 16 (Flat_4x4_16 / Flat_8x8_16): kernels skip the table reads
     uint8_t wscale4[6][16];
     uint8_t wscale8[2][64];
+    // chain launches (chain_common.h): this picture's block in the batch's chain buffer, and for every surface slot the chain index of
+    // the picture of THIS launch that decodes into it (an earlier picture of the same stream), -1 = complete before the launch
+    int chain_idx;
+    int n_deps;                   // number of entries of dep_pic that are >= 0 and referenced by this picture
+    int8_t dep_pic[kMaxSurfaces];
 };
 
 // One launch works on a BATCH of pictures (one per stream): kernels take an array of PicParams in device memory
 // and use blockIdx.y as the picture index.
-enum : int { PS_RECON = 1, PS_INTRA_LDS = 2, PS_INTRA_V1 = 4, PS_DEBLOCK_LDS = 8, PS_DEBLOCK_V1 = 16 };
+enum : int { PS_RECON = 1, PS_INTRA_LDS = 2, PS_INTRA_V1 = 4, PS_DEBLOCK_LDS = 8, PS_DEBLOCK_V1 = 16,
+             PS_CHAIN = 32 };     // PS_CHAIN: reconstruction + deblocking run inside k_chain (only k_deblock_prep of the stage kernels acts on it)
 
 struct PackJob {                  // one display frame to pack out (k_packout, blockIdx.y = job)
     const uint8_t *src; uint8_t *dst;

@@ -10,11 +10,18 @@ void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st);          // spin-wait wavefront (sparse intra, any height)
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);              // spin-wait wavefront (any height)
 bool intra_lds_supported(int mb_w, int mb_h);
-void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *progress, hipStream_t st);   // banded wavefront; progress: n * kDeblockProgressStride ints, cleared by this call
+// ctl: the batch's control buffer, n * kChainStride ints (chain_common.h), cleared once per batch by the caller; err: the batch's error words
+// (one int per picture, host-pinned and device-visible): a kernel whose bounded wait gives up writes a non-zero code there
+void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, hipStream_t st);   // banded wavefront
 bool deblock_lds_supported(int mb_w, int mb_h);
 constexpr int kDeblockMaxBands = 32, kDeblockProgressStride = 2 * kDeblockMaxBands;
-// prep + LDS wavefront; progress: device array of n * kDeblockProgressStride ints (band step counters, cleared by this call)
-void launch_deblock_lds(const PicParams *d_pics, int n, int max_mbs, int max_mb_h, int *progress, hipStream_t st);
+void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_t st);           // boundary strengths -> DbRec (PS_DEBLOCK_LDS or PS_CHAIN pictures)
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, hipStream_t st);   // LDS wavefront (after the prep)
+// chain launch (chain.hip): reconstruction + deblocking of every PS_CHAIN picture of the batch in ONE kernel; pictures of a stream follow each
+// other at macroblock granularity (chain_common.h).  Pictures must be ordered so that a picture's in-launch references have a lower index.
+bool chain_supported(int mb_w, int mb_h);
+void launch_chain(const PicParams *d_pics, int n, int max_mb_w, int max_mb_h, int *ctl, int *err, hipStream_t st);
+int  chain_ctl_ints();                                                                         // kChainStride
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
 // tight I420 (fmt 1) / NV12 (fmt 0) frame in device memory -> ARGB32 in device memory

@@ -13,177 +13,13 @@
 #include "jobs.h"
 #include "kernels.h"
 #include "kernel_common.h"
+#include "recon_device.h"      // ResTile, mb_residual_to_lds, luma_sample, recon_inter_wave (shared with chain.hip)
 
 namespace jmamd {
-
-// LDS residual scratch of one wave: 16x16 luma + 2 x 8x8 chroma, int16
-struct ResTile { short y[256]; short c[2][64]; int t8[256]; };    // t8: row-transformed 8x8 blocks between the two 1-D passes
-
-// 8.5.13 one-dimensional 8-point inverse transform (in place)
-__device__ __forceinline__ void idct8_1d(int *d) {
-    int e0 = d[0] + d[4], e1 = -d[3] + d[5] - d[7] - (d[7] >> 1), e2 = d[0] - d[4], e3 = d[1] + d[7] - d[3] - (d[3] >> 1);
-    int e4 = (d[2] >> 1) - d[6], e5 = -d[1] + d[7] + d[5] + (d[5] >> 1), e6 = d[2] + (d[6] >> 1), e7 = d[3] + d[5] + d[1] + (d[1] >> 1);
-    int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2), f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
-    d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1; d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
-}
-// normAdjust8x8(m, i, j) (8.5.9, v_m0..v_m5), six 6-bit fields per m; LevelScale8x8 = weight * this
-__device__ __forceinline__ int norm_adjust8(int m, int i, int j) {
-    const unsigned long long packed = m == 0 ? 0x6194E0494ull : (m == 1 ? 0x69C5634D6ull : (m == 2 ? 0x7E162A5DAull : (m == 3 ? 0x8636AD65Cull : (m == 4 ? 0x9A87B3720ull : 0xAEE8BA824ull))));
-    int ti = (i & 1) ? 1 : ((i & 2) ? 2 : 0), tj = (j & 1) ? 1 : ((j & 2) ? 2 : 0);
-    int cls = ti == tj ? ti : (ti + tj == 1 ? 3 : (ti + tj == 2 ? 4 : 5));
-    return (int)((packed >> (6 * cls)) & 63);
-}
-
-// Residual of one macroblock into LDS.  Lanes 0..15: luma 4x4 blocks (blkIdx order) -- or lanes 0..31: (8x8 block, row / column)
-// when the macroblock uses the 8x8 transform -- and lanes 32..39: chroma blocks.
-// For MB_I16 the luma DC path (8.5.10) is applied.  Must be called by all 64 lanes of the wave.
-__device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile &rt, int lane) {
-    const short *coef = pp.coef + r.coef_off;
-    int qp = r.qp;
-    int n_luma = __popc((unsigned)r.cbp_blk);
-    int base_luma = r.kind == MB_I16 ? 16 : 0;
-    const bool flat = pp.flat_scaling != 0;
-    const int wl = r.kind == MB_INTER ? 3 : 0;                 // scaling list of this macroblock's luma; chroma lists follow it
-    if (r.modes & MBM_T8X8) {
-        if (lane < 32) {
-            int b8 = lane >> 3, i = lane & 7;
-            bool coded = (r.cbp_blk >> (4 * b8)) & 1;
-            int d[8];
-            if (coded) {
-                const short *c = coef + 16 * __popc((unsigned)r.cbp_blk & ((1u << (4 * b8)) - 1)) + i * 8;
-                int m = qp % 6, s = qp / 6;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { int wgt = flat ? 16 : pp.wscale8[r.kind == MB_INTER ? 1 : 0][i * 8 + k]; int v = c[k] * wgt * norm_adjust8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
-                idct8_1d(d);
-#pragma unroll
-                for (int k = 0; k < 8; k++) rt.t8[b8 * 64 + i * 8 + k] = d[k];
-            }
-            // second pass: lane = (block, column); same wave, LDS keeps program order
-            if (coded) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) d[k] = rt.t8[b8 * 64 + k * 8 + i];
-                idct8_1d(d);
-#pragma unroll
-                for (int k = 0; k < 8; k++) d[k] = (d[k] + 32) >> 6;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) d[k] = 0;
-            }
-            int ox = (b8 & 1) * 8 + i, oy = (b8 >> 1) * 8;
-#pragma unroll
-            for (int k = 0; k < 8; k++) rt.y[(oy + k) * 16 + ox] = (short)d[k];
-        }
-    } else if (lane < 16) {
-        int blk = lane, rpos = blk_to_raster(blk);
-        int d[16];
-        bool coded = (r.cbp_blk >> blk) & 1;
-        if (coded) {
-            const short *c = coef + base_luma + 16 * __popc((unsigned)r.cbp_blk & ((1u << blk) - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qp, k) : dequant4w(c[k], qp, k, pp.wscale4[wl][k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = 0;
-        }
-        bool any = coded;
-        if (r.kind == MB_I16) {
-            // 8.5.10: f = H c H over the 4x4 DC matrix, element (row i, col j) belongs to the block at (x=j, y=i)
-            int c[16], f[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) c[k] = coef[k];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int a = c[4 * i], b = c[4 * i + 1], cc = c[4 * i + 2], e = c[4 * i + 3];
-                f[4 * i] = a + b + cc + e; f[4 * i + 1] = a + b - cc - e; f[4 * i + 2] = a - b - cc + e; f[4 * i + 3] = a - b + cc - e;
-            }
-            int j = rpos & 3, i = rpos >> 2;
-            int a = f[j], b = f[4 + j], cc = f[8 + j], e = f[12 + j];
-            int g = i == 0 ? a + b + cc + e : (i == 1 ? a + b - cc - e : (i == 2 ? a - b - cc + e : a - b + cc - e));
-            int ls0 = flat ? level_scale4(qp % 6, 0) : pp.wscale4[0][0] * norm4(qp % 6, 0), s = qp / 6;
-            d[0] = s >= 6 ? (g * ls0) << (s - 6) : (g * ls0 + (1 << (5 - s))) >> (6 - s);
-            any = true;
-        }
-        if (any) idct4x4(d);
-        int bx = rpos & 3, by = rpos >> 2;
-#pragma unroll
-        for (int k = 0; k < 16; k++) rt.y[(by * 4 + (k >> 2)) * 16 + bx * 4 + (k & 3)] = (short)d[k];
-    }
-    if (lane >= 32 && lane < 40) {
-        int pl = (lane - 32) >> 2, k4 = (lane - 32) & 3;
-        int qpc = chroma_qp(qp, pl ? pp.cr_qp_off : pp.cb_qp_off);
-        const short *cdc = coef + base_luma + 16 * n_luma;
-        int has_cb = (r.flags & MBF_CB_DC) ? 1 : 0, has_cr = (r.flags & MBF_CR_DC) ? 1 : 0;
-        const short *cac = cdc + 4 * (has_cb + has_cr);
-        int d[16];
-        bool coded = (r.cbp_cac >> (lane - 32)) & 1;
-        if (coded) {
-            const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 32)) - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qpc, k) : dequant4w(c[k], qpc, k, pp.wscale4[wl + 1 + pl][k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = 0;
-        }
-        bool has_dc = pl ? has_cr : has_cb;
-        if (has_dc) {
-            const short *c = cdc + (pl ? 4 * has_cb : 0);
-            int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            int f = k4 == 0 ? c0 + c1 + c2 + c3 : (k4 == 1 ? c0 - c1 + c2 - c3 : (k4 == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
-            d[0] = ((f * (flat ? level_scale4(qpc % 6, 0) : pp.wscale4[wl + 1 + pl][0] * norm4(qpc % 6, 0))) << (qpc / 6)) >> 5;
-        } else d[0] = 0;
-        if (coded || has_dc) idct4x4(d);
-        int bx = k4 & 1, by = k4 >> 1;
-#pragma unroll
-        for (int k = 0; k < 16; k++) rt.c[pl][(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)] = (short)d[k];
-    }
-}
-
-// dynamically indexed fields of a MbRec held in registers: select with shifts instead of indexing an array (which would
-// force the record into scratch memory -- 18 MB of extra HBM writes per 1080p picture, measured with WRITE_SIZE)
-__device__ __forceinline__ int rec_ref(const MbRec &r, int b8) {
-    uint32_t w = (uint32_t)(uint8_t)r.ref[0] | ((uint32_t)(uint8_t)r.ref[1] << 8) | ((uint32_t)(uint8_t)r.ref[2] << 16) | ((uint32_t)(uint8_t)r.ref[3] << 24);
-    return (int)(int8_t)(w >> (8 * b8));
-}
-__device__ __forceinline__ void rec_mv8(const MbRec &r, int b8, int &mx, int &my) {
-    uint32_t w0 = (uint16_t)r.u.mv[0][0] | ((uint32_t)(uint16_t)r.u.mv[0][1] << 16), w1 = (uint16_t)r.u.mv[1][0] | ((uint32_t)(uint16_t)r.u.mv[1][1] << 16);
-    uint32_t w2 = (uint16_t)r.u.mv[2][0] | ((uint32_t)(uint16_t)r.u.mv[2][1] << 16), w3 = (uint16_t)r.u.mv[3][0] | ((uint32_t)(uint16_t)r.u.mv[3][1] << 16);
-    uint32_t w = b8 == 0 ? w0 : (b8 == 1 ? w1 : (b8 == 2 ? w2 : w3));
-    mx = (int)(int16_t)(w & 0xffff); my = (int)(int16_t)(w >> 16);
-}
-__device__ __forceinline__ bool mb_has_residual(const MbRec &r) {
-    return r.kind == MB_I16 || r.cbp_blk || r.cbp_cac || (r.flags & (MBF_CB_DC | MBF_CR_DC));
-}
 
 // ------------------------------------------------------------------------------------------
 // k_recon_inter: one wave per macroblock, 4 macroblocks per workgroup
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ref_luma(const uint8_t *s, int pitch, int W, int H, int x, int y) {
-    return s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)];
-}
-// 8.4.2.2.1 luma sample interpolation (literal form)
-__device__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
-#define P(dx, dy) ref_luma(s, pitch, W, H, xi + (dx), yi + (dy))
-#define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
-#define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
-    int G = P(0, 0);
-    if (!fx && !fy) return G;
-    if (!fy) { int b = clip1((HB(0) + 16) >> 5); return fx == 2 ? b : (fx == 1 ? (G + b + 1) >> 1 : (P(1, 0) + b + 1) >> 1); }
-    if (!fx) { int h = clip1((VH(0) + 16) >> 5); return fy == 2 ? h : (fy == 1 ? (G + h + 1) >> 1 : (P(0, 1) + h + 1) >> 1); }
-    if (fx == 2 || fy == 2) {
-        int j = clip1((tap6(HB(-2), HB(-1), HB(0), HB(1), HB(2), HB(3)) + 512) >> 10);
-        if (fx == 2 && fy == 2) return j;
-        if (fx == 2) { int q = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5); return (q + j + 1) >> 1; }
-        int q = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);
-        return (q + j + 1) >> 1;
-    }
-    int bq = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5);   // b or s
-    int hq = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);   // h or m
-    return (bq + hq + 1) >> 1;
-#undef P
-#undef HB
-#undef VH
-}
-
 __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give every XCD one
@@ -191,256 +27,10 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     const int per_xcd = ((int)gridDim.x + 7) >> 3;
     const int blk = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (!(pp.stages & PS_RECON) || blk * 4 >= pp.mb_w * pp.mb_h) return;
-    __shared__ ResTile tiles[4];
-    __shared__ uint32_t outt[4][96];                        // per wave: reconstructed MB, 16 luma rows + 8 interleaved chroma rows of 16 B
-    __shared__ uint32_t wins[4][4][13 * 5 + 3];            // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int n_mbs = pp.mb_w * pp.mb_h;
-    int mb = blk * 4 + wave;
-    bool valid = mb < n_mbs;
-    MbRec r;
-    if (valid) r = pp.mbs[mb]; else { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
-    bool inter = valid && r.kind == MB_INTER;
-    bool intra_res = valid && pp.want_intra_resid && (r.kind == MB_I4 || r.kind == MB_I16);
-    bool has_res = (inter || intra_res) && mb_has_residual(r);
-    const int mbx = valid ? mb % pp.mb_w : 0, mby = valid ? mb / pp.mb_w : 0;
-    const int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
-    // Everything an ordinary inter macroblock reads from its reference pictures depends only on the record, not on the residual:
-    // issue those loads first so that their latency overlaps the coefficient loads and the inverse transform (the kernel is
-    // latency bound: SQ_WAIT_ANY was 65 % of SQ_WAVE_CYCLES with the loads issued where they were consumed).
-    const bool plain = inter && !(r.modes & MBM_BIPRED);
-    bool fast = false;
-    uint32_t wv[5] = {0, 0, 0, 0, 0};                       // this lane's dwords of the 13x13 reference window (fast path)
-    int c_smp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // chroma: the four neighbours of (cx, cy), U then V
-    int c_slot = -1, c_fx = 0, c_fy = 0;
-    if (plain) {
-        {
-            int g = lane >> 4;                              // 8x8 block of this lane in the fast-path mapping
-            int mvx, mvy; rec_mv8(r, g, mvx, mvy);
-            int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2;
-            bool ok = !(r.flags & MBF_MV_EXT) && rec_ref(r, g) >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
-            fast = __all(ok);                               // wave-uniform: the whole macroblock takes one path
-            if (fast) {
-                const uint8_t *ref = pp.surf[rec_ref(r, g)];
-                int l = lane & 15, xa = xi & ~3;
-#pragma unroll
-                for (int t = 0; t < 5; t++) {
-                    int i = l + 16 * t;
-                    if (i < 65) { int row = i / 5, dw = i % 5; wv[t] = *(const uint32_t *)(ref + (size_t)(yi + row) * pitch + xa + dw * 4); }
-                }
-            }
-        }
-        {
-            int cx = lane & 7, cy = lane >> 3;
-            int rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
-            int mvx, mvy;
-            if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
-            else rec_mv8(r, b8, mvx, mvy);
-            c_slot = rec_ref(r, b8); c_fx = mvx & 7; c_fy = mvy & 7;
-            if (c_slot >= 0) {
-                const uint8_t *rc = pp.surf[c_slot] + pp.chroma_offset;
-                int CW = W >> 1, CH = H >> 1;
-                int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3);
-                int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
-                const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
-                c_smp[0] = r0[2 * xa]; c_smp[1] = r0[2 * xb]; c_smp[2] = r1[2 * xa]; c_smp[3] = r1[2 * xb];
-                c_smp[4] = r0[2 * xa + 1]; c_smp[5] = r0[2 * xb + 1]; c_smp[6] = r1[2 * xa + 1]; c_smp[7] = r1[2 * xb + 1];
-            }
-        }
-    }
-    if (has_res) mb_residual_to_lds(pp, r, tiles[wave], lane);
-    // the residual tile is private to this wave and LDS operations of one wave complete in order: no workgroup barrier needed
-    __builtin_amdgcn_wave_barrier();
-    if (!valid) return;
-    if (intra_res) {
-        // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
-        if (lane < 48) {
-            uint4 v = has_res ? *(const uint4 *)((const short *)&tiles[wave] + lane * 8) : make_uint4(0, 0, 0, 0);
-            *(uint4 *)(pp.resid + (size_t)mb * 384 + lane * 8) = v;
-        }
-        return;
-    }
-    uint8_t *dst = pp.surf[pp.cur];
-    uint8_t *dst_c = dst + pp.chroma_offset;
-    uint32_t *ot = outt[wave];
-    if (r.kind == MB_PCM) {
-        const uint8_t *pcm = (const uint8_t *)(pp.coef + r.coef_off);
-        int row = lane >> 2, xq = lane & 3;
-        ot[row * 4 + xq] = pcm[row * 16 + xq * 4] | (pcm[row * 16 + xq * 4 + 1] << 8) | (pcm[row * 16 + xq * 4 + 2] << 16) | (pcm[row * 16 + xq * 4 + 3] << 24);
-        int cx = lane & 7, cy = lane >> 3;
-        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
-    }
-    if (!inter && r.kind != MB_PCM) return;
-    if (inter && (r.modes & MBM_BIPRED)) {
-        // B slices / weighted prediction: one or two references per 8x8, one vector per 4x4, weights of 8.4.2.3.  Literal sampling.
-        const short *rec = pp.mv_ext + (size_t)r.u.mv_ext * 2;
-        const int8_t *tail = (const int8_t *)(rec + 64);
-        const SliceWp *wp = pp.wp ? &pp.wp[r.slice] : nullptr;
-        const int mode = wp ? wp->mode : 0;
-        auto combine = [&](int a, int b, bool use0, bool use1, int i0, int i1, int cmp) -> int {
-            if (use0 && use1) {
-                if (mode == 0) return (a + b + 1) >> 1;
-                int w0, w1, o = 0, lg = 5;
-                if (mode == 1) { w0 = wp->w[0][i0 & 15][cmp]; w1 = wp->w[1][i1 & 15][cmp]; o = (wp->o[0][i0 & 15][cmp] + wp->o[1][i1 & 15][cmp] + 1) >> 1; lg = cmp ? wp->logwd_c : wp->logwd_y; }
-                else { w1 = (int)wp->imp_w1[i0 & 15][i1 & 15] - 64; w0 = 64 - w1; }
-                return clip1(((a * w0 + b * w1 + (1 << lg)) >> (lg + 1)) + o);
-            }
-            if (!use0 && !use1) return 128;
-            int v = use0 ? a : b;
-            if (mode != 1) return v;
-            int l = use0 ? 0 : 1, i = (use0 ? i0 : i1) & 15, lg = cmp ? wp->logwd_c : wp->logwd_y, w = wp->w[l][i][cmp], o = wp->o[l][i][cmp];
-            return clip1((lg >= 1 ? ((v * w + (1 << (lg - 1))) >> lg) : v * w) + o);
-        };
-        {   // luma: lane -> (4x4 block, row)
-            int rb = lane >> 2, row = lane & 3, bx = rb & 3, by = rb >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
-            int s0 = rec_ref(r, b8), s1 = tail[b8], i0 = tail[4 + b8], i1 = tail[8 + b8];
-            int x0 = mbx * 16 + bx * 4, y = mby * 16 + by * 4 + row;
-            int m0x = rec[rb * 2], m0y = rec[rb * 2 + 1], m1x = rec[32 + rb * 2], m1y = rec[32 + rb * 2 + 1];
-            int v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int a = 0, b = 0;
-                if (s0 >= 0) a = luma_sample(pp.surf[s0], pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
-                if (s1 >= 0) b = luma_sample(pp.surf[s1], pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
-                v[k] = combine(a, b, s0 >= 0, s1 >= 0, i0, i1, 0);
-            }
-            if (has_res) { const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]); }
-            ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-        }
-        {   // chroma: lane -> (cx, cy), both planes
-            int cx = lane & 7, cy = lane >> 3, rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
-            int s[2] = { rec_ref(r, b8), tail[b8] }, i0 = tail[4 + b8], i1 = tail[8 + b8];
-            int CW = W >> 1, CH = H >> 1, pu[2] = {0, 0}, pv[2] = {0, 0};
-#pragma unroll
-            for (int l = 0; l < 2; l++) {
-                if (s[l] < 0) continue;
-                int mvx = rec[l * 32 + rb * 2], mvy = rec[l * 32 + rb * 2 + 1];
-                const uint8_t *rc = pp.surf[s[l]] + pp.chroma_offset;
-                int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
-                int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CH - 1, yi), yb = clip3(0, CH - 1, yi + 1);
-                const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
-                int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
-                pu[l] = (w00 * r0[2 * xa] + w01 * r0[2 * xb] + w10 * r1[2 * xa] + w11 * r1[2 * xb] + 32) >> 6;
-                pv[l] = (w00 * r0[2 * xa + 1] + w01 * r0[2 * xb + 1] + w10 * r1[2 * xa + 1] + w11 * r1[2 * xb + 1] + 32) >> 6;
-            }
-            int u = combine(pu[0], pu[1], s[0] >= 0, s[1] >= 0, i0, i1, 1), v = combine(pv[0], pv[1], s[0] >= 0, s[1] >= 0, i0, i1, 2);
-            if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
-            ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
-        }
-    } else if (inter) {
-    // ---- luma ----
-    // Fast path (one MV per 8x8 block, i.e. 16x16 / 16x8 / 8x16 / 8x8 partitions): 16 lanes per 8x8 block stage its
-    // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
-    // The fractional position is uniform inside a block, so the 6-tap paths do not diverge within the 16 lanes.
-    // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
-    if (fast) {
-        int g = lane >> 4, l = lane & 15;
-        int mvx, mvy; rec_mv8(r, g, mvx, mvy);
-        int fx = mvx & 3, fy = mvy & 3;
-        int bx0 = mbx * 16 + (g & 1) * 8;
-        int xi = bx0 + (mvx >> 2) - 2;
-        uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
-        int sh = xi & 3;
-#pragma unroll
-        for (int t = 0; t < 5; t++) { int i = l + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
-        // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
-        int rr = l >> 1, hh = l & 1;
-        // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
-        auto row9 = [&](int wr, int *t) {
-            const uint32_t *p = win + wr * 5 + hh;           // dword containing byte 4hh
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-            uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
-            t[4] = a1 & 255; t[5] = (a1 >> 8) & 255; t[6] = (a1 >> 16) & 255; t[7] = a1 >> 24; t[8] = a2 & 255;
-        };
-        int v[4];
-        if (fy == 0) {
-            int t[9]; row9(rr + 2, t);
-            if (fx == 0) { v[0] = t[2]; v[1] = t[3]; v[2] = t[4]; v[3] = t[5]; }
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int b = clip1((tap6(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5]) + 16) >> 5);
-                    v[k] = fx == 2 ? b : ((fx == 1 ? t[k + 2] : t[k + 3]) + b + 1) >> 1;
-                }
-            }
-        } else {
-            int t[6][9];
-#pragma unroll
-            for (int j = 0; j < 6; j++) row9(rr + j, t[j]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // vertical half samples at column k (h) and k+1 (m); horizontal half samples at row 0 (b) and row 1 (s)
-                int c = k + 2;
-                if (fx == 0) {
-                    int h = clip1((tap6(t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]) + 16) >> 5);
-                    v[k] = fy == 2 ? h : ((fy == 1 ? t[2][c] : t[3][c]) + h + 1) >> 1;
-                } else if (fx == 2 || fy == 2) {
-                    int hb[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) hb[j] = tap6(t[j][k], t[j][k + 1], t[j][k + 2], t[j][k + 3], t[j][k + 4], t[j][k + 5]);
-                    int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
-                    if (fx == 2 && fy == 2) v[k] = jv;
-                    else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                } else {
-                    int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
-                    int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
-                    int hq = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
-                    v[k] = (bq + hq + 1) >> 1;
-                }
-            }
-        }
-        int px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;     // position inside the macroblock
-        if (has_res) {
-            const short *rs = &tiles[wave].y[py * 16 + px];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
-        }
-        ot[py * 4 + (px >> 2)] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-    } else {
-        int rb = lane >> 2, row = lane & 3;
-        int bx = rb & 3, by = rb >> 2;
-        int b8 = (by >> 1) * 2 + (bx >> 1);
-        int mvx, mvy;
-        if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
-        else rec_mv8(r, b8, mvx, mvy);
-        int slot = rec_ref(r, b8);
-        int x0 = mbx * 16 + bx * 4, y = mby * 16 + by * 4 + row;
-        int v[4];
-        if (slot < 0) { v[0] = v[1] = v[2] = v[3] = 128; }
-        else {
-            const uint8_t *ref = pp.surf[slot];
-            int xi = x0 + (mvx >> 2), yi = y + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = luma_sample(ref, pitch, W, H, xi + k, yi, fx, fy);
-        }
-        if (has_res) {
-            const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
-        }
-        ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-    }
-    // ---- chroma: lane -> chroma position (cx, cy), both planes; the four neighbours were loaded up front ----
-    {
-        int cx = lane & 7, cy = lane >> 3;
-        int u, v;
-        if (c_slot < 0) { u = v = 128; }
-        else {
-            int w00 = (8 - c_fx) * (8 - c_fy), w01 = c_fx * (8 - c_fy), w10 = (8 - c_fx) * c_fy, w11 = c_fx * c_fy;
-            u = (w00 * c_smp[0] + w01 * c_smp[1] + w10 * c_smp[2] + w11 * c_smp[3] + 32) >> 6;
-            v = (w00 * c_smp[4] + w01 * c_smp[5] + w10 * c_smp[6] + w11 * c_smp[7] + 32) >> 6;
-        }
-        if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
-        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
-    }
-    }   // inter
-    // ---- store: whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments ----
-    if (lane < 16) *(uint4 *)(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16) = *(const uint4 *)(ot + lane * 4);
-    else if (lane < 24) *(uint4 *)(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16) = *(const uint4 *)(ot + 64 + (lane - 16) * 4);
+    __shared__ ReconLds sm;
+    const int n_mbs = pp.mb_w * pp.mb_h;
+    const int mb = blk * 4 + (int)(threadIdx.x >> 6);
+    recon_inter_wave<false, false>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, nullptr});
 }
 
 // ------------------------------------------------------------------------------------------
