@@ -202,7 +202,7 @@ def main():
 
     if W > 0:
         batch(W)
-    KN = ("inter", "intra", "deblock", "packout")
+    KN = ("inter", "intra", "deblock", "packout", "chain")     # chain = k_chain: reconstruction + deblocking of consecutive pictures in one launch
     def eng():      # engine-wide counters (one engine per device serves every handle)
         return {k: {f: L.jm_amddec_get_stat(handles[0], f"k_{k}_{f}".encode()) for f in ("ns", "n", "pics", "alg_bytes")} for k in KN}
     e0 = eng()
@@ -261,6 +261,7 @@ def main():
     tot_alg = {k: e1[k]["alg_bytes"] - e0[k]["alg_bytes"] for k in names}
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
+    chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"), L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"))   # whole run
     eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4), "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
@@ -274,7 +275,7 @@ def main():
     p_frac = (F - F // 30) / F if F >= 30 else 1.0
     alg = {k: (tot_alg[k] / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     # dominant kernel among the HBM-side stages; k_packout writes to pinned HOST memory, so it is priced against PCIe below
-    dominant = max(("inter", "intra", "deblock"), key=lambda k: tot_ns[k])
+    dominant = max(("inter", "intra", "deblock", "chain"), key=lambda k: tot_ns[k])
     avg_s = {k: (tot_ns[k] * 1e-9 / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     peak = 8000.0
     achieved = alg[dominant] / avg_s[dominant] / 1e9 if avg_s[dominant] > 0 else 0.0
@@ -289,6 +290,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc.get("k_intra_band", pmc.get("k_intra_lds", {"traffic_upper": 0}))["traffic_upper"],
                        "deblock": pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"traffic_upper": 0}))["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
+        per_pic.setdefault("chain", per_pic["inter"] + per_pic["deblock"])
         if (args.width, args.height) == (1920, 1080):
             traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
     except Exception:
@@ -476,7 +478,8 @@ def main():
                      "frac": round(achieved / peak, 6), "traffic": traffic,
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
-        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms},
+        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms,
+                   "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2])},
         "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 63.0, "unit": "GB/s",
                      "note": "tight frames: k_packout -> device staging, then copy engine -> caller's buffer (or -> pinned host slot ahead of time + memcpy); rate = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),

@@ -5,14 +5,19 @@
 // a fixed-function pipeline; here a single stream keeps several pictures in flight on the CUs, because picture n+1's macroblock (x, y) only
 // needs picture n deblocked a few macroblocks beyond (x, y), not the whole picture.
 //
-// grid = (blocks per picture, pictures).  Workgroup roles by blockIdx.x, in dispatch order:
-//   [0, n_recon)            reconstruction, 4 macroblocks per workgroup (one wave each), macroblock rows top to bottom so that workgroups
-//                           retire in the order the deblocking wavefront of the reference picture releases them; inside a row the 8 XCDs
-//                           (workgroup i runs on XCD i mod 8) each take one vertical strip of the picture, so reference windows of
-//                           neighbouring macroblocks meet in one memory channel group (reference loads bypass the L2: see chain_common.h)
-//   [n_recon, n_recon + 2 * bands)   deblocking bands (deblock_device.h), luma and chroma
-// A workgroup only waits for lower block indices: reconstruction for deblocking bands of EARLIER pictures, bands for reconstruction bits of
-// their own picture and for the band above.
+// grid = 1-D, cut into GROUPS of 2 workgroups; groups[g] = picture << 16 | kind << 15 | index says what group g does:
+//   kind 0  reconstruction of 8 consecutive macroblocks of a row (index = row * 32 + segment): 4 macroblocks per workgroup, one wave each
+//   kind 1  deblocking band `index` (deblock_device.h): workgroup 0 of the group luma, workgroup 1 chroma
+// The host orders the work list (Engine::launch).  The dispatcher starts workgroups strictly in index order and a workgroup that waits stays
+// resident, so the order decides what can run:
+//   * all deblocking bands of the launch come first and are resident from the start (Engine::form keeps their number at half of what the GPU
+//     holds at 3 workgroups per CU); a band lives for its whole wavefront and waits for reconstruction bits that are produced later;
+//   * reconstruction groups follow along the pipeline's own time axis: the deblocking wavefront reaches macroblock (x, y) in step x + 2y, so the
+//     segment gets the key  base(picture) + 2 * row + 8 * segment,  base growing by `lag` steps from picture to picture of a stream.  A
+//     reconstruction wave waits for bands (resident) whose own needs have smaller keys, so the waiting group with the smallest key can always
+//     run: no deadlock at any occupancy.  Other orders fill the machine with waiting workgroups: picture-major order held picture n+2 back until
+//     all of picture n+1 was resident (0.5 ms between the pictures of a 1080p chain), row-major order inside a picture did the same to the
+//     lower half of the diagonal wavefront (0.27 ms); 32-macroblock segments with a lag of 24 steps broke the key rule and deadlocked at 4 streams.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "jobs.h"
@@ -25,28 +30,25 @@
 namespace jmamd {
 
 template <int DEPTH>
-__global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, int *err, int n_recon, int blocks_per_row, int pub) {
-    const PicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & PS_CHAIN)) return;
+__global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, int *err, const uint32_t *groups, int pub) {
+    const int g = (int)blockIdx.x >> 1, rem = (int)blockIdx.x & 1;
+    const uint32_t entry = groups[g];
+    const PicParams &pp = pics[entry >> 16];
     const ChainView cv{ctl, err};
-    const int b = (int)blockIdx.x;
-    if (b < n_recon) {
-        const int row = b / blocks_per_row, rem = b - row * blocks_per_row;
-        const int strip_w = (pp.mb_w + 7) >> 3;                               // macroblocks per XCD strip of THIS picture
-        const int j = rem >> 3, xcd = rem & 7, in_strip = j * 4 + (int)(threadIdx.x >> 6);
-        const int x = xcd * strip_w + in_strip;
-        const bool valid = row < pp.mb_h && in_strip < strip_w && x < pp.mb_w;
-        if (row >= pp.mb_h) return;
+    if (!(entry & 0x8000u)) {
+        const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;
+        const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
+        const bool valid = row < pp.mb_h && x < pp.mb_w;
+        if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
         __shared__ ReconLds sm;
         const int mb = valid ? row * pp.mb_w + x : 0;
         // one instantiation for every picture of the launch (with the cached-load variant beside it the kernel needs 196 VGPRs and scratch;
         // this way 165): a picture without references inside the launch passes wait_final at once
         recon_inter_wave<true, true>(pp, mb, valid, sm, cv);
     } else {
-        const int k = b - n_recon;
         __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes];
         int *cpic = cv.pic(pp.chain_idx);
-        deblock_band_body<DEPTH, true>(pp, k >> 1, k & 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
+        deblock_band_body<DEPTH, true>(pp, (int)(entry & 0x7fffu), rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
     }
 }
 
@@ -58,16 +60,14 @@ int chain_ctl_ints() { return kChainStride; }
 
 int deblock_depth(); int deblock_pub();
 
-void launch_chain(const PicParams *d_pics, int n, int max_mb_w, int max_mb_h, int *ctl, int *err, hipStream_t st) {
-    const int strip_w = (max_mb_w + 7) / 8, blocks_per_row = 8 * ((strip_w + 3) / 4);
-    const int n_recon = blocks_per_row * max_mb_h;                            // multiple of 8: block index mod 8 == XCD for every picture
-    const int bands = (max_mb_h + kBandRows - 1) / kBandRows;
-    const int gx = (n_recon + 2 * bands + 7) & ~7;
+int chain_band_rows() { return kBandRows; }
+
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, hipStream_t st) {
     const int depth = deblock_depth(), pub = deblock_pub();
-    dim3 grid(gx, n), block(256);
-    if (depth <= 2) hipLaunchKernelGGL((k_chain<2>), grid, block, 0, st, d_pics, ctl, err, n_recon, blocks_per_row, pub);
-    else if (depth == 3) hipLaunchKernelGGL((k_chain<3>), grid, block, 0, st, d_pics, ctl, err, n_recon, blocks_per_row, pub);
-    else hipLaunchKernelGGL((k_chain<4>), grid, block, 0, st, d_pics, ctl, err, n_recon, blocks_per_row, pub);
+    dim3 grid((unsigned)n_groups * 2u), block(256);
+    if (depth <= 2) hipLaunchKernelGGL((k_chain<2>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);
+    else if (depth == 3) hipLaunchKernelGGL((k_chain<3>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);
+    else hipLaunchKernelGGL((k_chain<4>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);
 }
 
 }  // namespace jmamd

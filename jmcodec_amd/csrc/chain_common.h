@@ -28,8 +28,9 @@ constexpr int kChainIntraRing = 128;   // [64]  band step counters of the intra 
 constexpr int kChainBits = 192;        // [mb_h][kChainRowWords] reconstruction bitmap, bit x of row y = macroblock (x, y) is in memory
 constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4096 samples)
 constexpr int kChainMaxRows = 512;
+constexpr int kChainMaxPics = 64;      // == kMaxBatch (engine.h)
 constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
-constexpr int kSpinLimit = 1 << 22;    // polls before a wait gives up (seconds; a healthy wait takes microseconds)
+constexpr int kSpinLimit = 1 << 20;    // polls before a wait gives up (about a second; a healthy wait takes microseconds)
 enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8 };
 
 typedef __attribute__((address_space(1))) int gint;
@@ -56,9 +57,12 @@ __device__ __forceinline__ void report_wait_timeout(int *err_word, int code) {
 }
 
 struct ChainView {
-    int *base;                          // the batch's control buffer (device): kChainStride ints per picture
+    int *base;                          // the batch's control buffer (device): kChainStride ints per picture, then the launch-wide abort word
     int *err;                           // the batch's error words (host-pinned, device-visible), one per picture
     __device__ __forceinline__ int *pic(int idx) const { return base + (size_t)idx * kChainStride; }
+    // Once one wait of a launch has given up, the launch is damaged anyway: every other wait then gives up as soon as it looks (every 256 polls),
+    // so a broken hand-over costs about one timeout, not one per waiting wave.
+    __device__ __forceinline__ int *abort_word() const { return base + (size_t)kChainMaxPics * kChainStride; }
 
     // Wait until every sample of the rectangle [.., xmax] x [ymin, ymax] (luma coordinates, already clamped to the picture) of the picture
     // with chain index `dep` is final.  The final value of sample (px, py) is stored by the deblocking step of macroblock
@@ -79,7 +83,7 @@ struct ChainView {
                 pending = !ok;
             }
             if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-            if (++spins > kSpinLimit) return false;
+            if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
             __builtin_amdgcn_s_sleep(4);
         }
     }

@@ -298,6 +298,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const bool gives_ring = active && group == rows - 1 && row < mb_h - 1;  // last row of a band that has a band below
     const int s_begin = 2 * row0, s_end = mb_w - 1 + 2 * (row0 + rows - 1);
     int known = 0;                                                          // steps the band above is known to have completed
+    int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;   // launch-wide: a wait of this launch gave up (chain_common.h)
     // Hand-over protocol without cache maintenance: the ring rows and the counter are written and read with agent-scope relaxed atomics
     // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
@@ -305,8 +306,12 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     auto wait_above = [&](int need) {
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
         int spins = 0;
-        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(8);
-        if (known < need && l == 0) report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT);     // the band above never got there: damaged, and SAID so
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
+               !(CHAIN && (spins & 255) == 0 && ld_coh(abort_word))) __builtin_amdgcn_s_sleep(8);
+        if (known < need) {                                                  // the band above never got there: damaged, and SAID so
+            if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT); if (CHAIN) st_coh(abort_word, 1); }
+            known = 0x7fffffff;                                              // do not wait again
+        }
         asm volatile("" ::: "memory");
     };
     // CHAIN: macroblocks of this group's row known to be reconstructed, counted from the left (bits of the row's bitmap words seen so far)
@@ -322,8 +327,12 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
                 if (m & 1) { recon_known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
             }
             if (!__builtin_amdgcn_ballot_w64(pending)) break;
-            if (++spins > kSpinLimit) { if ((threadIdx.x & 63) == 0) report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); break; }
-            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) {
+                if ((threadIdx.x & 63) == 0) { report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); }
+                recon_known = 0x7fffffff;       // damaged and reported: do not wait again
+                break;
+            }
+            if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);      // a band may be resident long before its rows are reconstructed
         }
     };
     const int ring_lanes = ring_rows * 4;                                   // one dword per lane: ring row l >> 2, dword l & 3

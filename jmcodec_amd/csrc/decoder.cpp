@@ -836,7 +836,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     // append mv_ext behind the coefficients (4-byte aligned), then the weighted-prediction tables of the slices
     if (w.coef_count & 1) w.coef[w.coef_count++] = 0;
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
-    t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count;
+    t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count; t->max_mvy = w.max_mvy;
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
     if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++; t->any_wp = false; }
     if (t->any_wp) {
@@ -946,6 +946,7 @@ void Decoder::submit_task(PicTask *t) {
         // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
         ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
         ep.classic_stages = pp.stages;
+        ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];
         // algorithmic bytes of this picture per kernel class
         long long S = (long long)surf_bytes_;

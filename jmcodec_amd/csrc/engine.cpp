@@ -29,6 +29,8 @@ Engine *Engine::get(int device) {
 
 Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
@@ -43,10 +45,12 @@ Engine::Engine(int device) : device_(device) {
             if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
-            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * (size_t)kMaxBatch * chain_ctl_ints()) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + 16)) != hipSuccess) return;   // + the launch-wide abort word
             if (hipHostMalloc((void **)&b.h_err, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) return;
             if (hipHostGetDevicePointer((void **)&b.d_err, b.h_err, 0) != hipSuccess) return;
             memset(b.h_err, 0, sizeof(int) * kMaxBatch);
+            if (hipHostMalloc((void **)&b.h_groups, sizeof(uint32_t) * kMaxChainGroups, hipHostMallocDefault) != hipSuccess) return;
+            if (hipMalloc((void **)&b.d_groups, sizeof(uint32_t) * kMaxChainGroups) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_jobs, sizeof(PackJob) * 4 * kMaxBatch) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
@@ -105,7 +109,12 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         it = pending_.erase(it);
     }
     if (b.pics.empty()) return false;
-    if (lane_idx < kPLanes && chain_depth_ > 1) {
+    // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
+    // workgroups the GPU holds (chain.hip), and its work list must fit the table
+    auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = 2 * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + (p.mb_h + 15) / 16; };
+    int tot_bands = 0, tot_groups = 0;
+    for (auto &p : b.pics) if (p.has_picture && p.chain_ok) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng; }
+    if (lane_idx < kPLanes && chain_depth_ > 1 && (int)members.size() <= chain_max_streams_ && tot_bands <= kMaxChainBands && tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
         const int depth_cap = std::min(chain_depth_, std::max(1, kMaxBatch / (int)members.size()));
@@ -119,7 +128,10 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
                 const bool ok = it != pending_.end() && it->lane() == lane_idx && it->has_picture && it->chain_ok && it->out_before.empty() && !it->wait_prev_pack &&
                                 !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
-                if (!ok) { es.batch_stop = true; continue; }
+                int nb = 0, ng = 0;
+                if (ok) chain_cost(*it, nb, ng);
+                if (!ok || tot_bands + nb > kMaxChainBands || tot_groups + ng > kMaxChainGroups) { es.batch_stop = true; continue; }
+                tot_bands += nb; tot_groups += ng;
                 es.inflight++; es.in_batch++;
                 account(*it, es);
                 b.pics.push_back(std::move(*it));
@@ -189,7 +201,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     for (auto &p : b.pics) p.dec->engine_state().displayed[1] |= p.out_mask;
     for (auto &p : b.pics) p.dec->engine_state().displayed[0] = p.dec->engine_state().displayed[1];
     hipStream_t st = ln.stream, pst = ln.pack_stream;
-    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);   // every counter of every picture
+    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st); hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), st); }   // every counter of every picture, and the abort word
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, st);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, st);
@@ -229,7 +241,40 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);
     // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
-    if (stages & PS_CHAIN) { launch_chain(b.d_pics, n, max_mb_w, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 32; mark(7, st); }
+    if (stages & PS_CHAIN) {
+        // Work list of the chain kernel, ordered along the pipeline's time axis (chain.hip).  The deblocking wavefront of a picture reaches
+        // macroblock (x, y) in step x + 2y; a picture follows the previous picture of its stream `lag` steps behind (plus twice the number of
+        // rows its vectors reach further down than usual, from the parser).  Keys: 8-macroblock segment of row r: base + 2r + 8 * segment;
+        // Every reconstruction dependency then points to a smaller key -- also the
+        // transitive ones through a band to the previous picture's reconstruction (a few macroblocks right of and below the segment itself:
+        // 8 + 1 + 2 (publishing lag) + 3 (prefetch depth) + 2 steps) -- as long as lag > 16: what keeps a full machine from deadlocking.
+        const int band_rows = chain_band_rows();
+        std::vector<int> base_of(n, 0);
+        size_t n_keys = 0;
+        for (int i = 0; i < n; i++) {
+            if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
+            for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) { base_of[i] = base_of[j] + chain_lag_steps_ + 2 * b.pics[i].reach_rows; break; }
+            n_keys = std::max(n_keys, (size_t)(base_of[i] + 2 * b.h_pics[i].mb_h + b.h_pics[i].mb_w + 2));
+        }
+        if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
+        for (size_t k = 0; k < n_keys; k++) group_buckets_[k].clear();
+        for (int i = 0; i < n; i++) {
+            if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
+            const int mb_h = b.h_pics[i].mb_h, segs = (b.h_pics[i].mb_w + 7) / 8, base = base_of[i];
+            for (int r = 0; r < mb_h; r++) {
+                for (int c = 0; c < segs; c++) group_buckets_[base + 2 * r + 8 * c].push_back((uint32_t)i << 16 | (uint32_t)(r * 32 + c));
+            }
+        }
+        // Every deblocking band of the launch goes FIRST (Engine::form keeps their number at half of what the GPU holds): a band lives for its whole
+        // wavefront and waits for reconstruction bits with larger keys, so it must be resident before anything that waits for it is started --
+        // then every reconstruction group only ever waits for workgroups that are resident or done, and the one with the smallest key can always run.
+        int n_groups = 0;
+        for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) for (int bnd = 0; bnd * band_rows < b.h_pics[i].mb_h; bnd++) b.h_groups[n_groups++] = (uint32_t)i << 16 | 0x8000u | (uint32_t)bnd;
+        for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
+        hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
+        launch_chain(b.d_pics, b.d_groups, n_groups, b.d_ctl, b.d_err, st);
+        b.pmask |= 32; mark(7, st);
+    }
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
     mark(5, pst);

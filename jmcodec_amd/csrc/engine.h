@@ -31,6 +31,8 @@ struct OutSlot;
 
 constexpr int kMaxBatch = 64;
 constexpr int kBatchRing = 4;
+constexpr int kMaxChainGroups = 128 * 1024;         // work list of one chain launch (1080p: 1025 groups per picture, 4K: 4059)
+constexpr int kMaxChainBands = 384;                 // deblocking-band workgroups of one chain launch: half of what an MI355X holds at 3 per CU
 constexpr int kPLanes = 1;                          // lanes for ordinary pictures: while one group's batch sits in the serial deblock
                                                     // wavefront (2 CUs per picture) the other group's fully parallel kernels use the idle CUs
 constexpr int kLanes = kPLanes + 2;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures
@@ -52,6 +54,7 @@ struct EnginePic {
     bool chain_ok = false;
     int classic_stages = 0;                         // pp.stages when it runs through the stage kernels instead
     uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
+    int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
     int lane() const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane); }
@@ -91,6 +94,7 @@ private:
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
         bool any_chain = false; int max_depth = 1;
+        uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;
@@ -104,7 +108,9 @@ private:
         int head = 0, tail = 0, inflight = 0;
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
-    int chain_depth_ = 8;                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
+    int chain_max_streams_ = 8;                               // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    int chain_depth_ = 8, chain_lag_steps_ = 24;              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
+    std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Batch &b, bool failed);

@@ -302,6 +302,12 @@ struct P {
     }
     void write_motion(MbRec *r, bool sub8) {
         for (int i = 0; i < 4; i++) r->ref[i] = ref[i] >= 0 ? rf.slot[0][ref[i]] : (int8_t)-1;
+        {   // downward reach of this macroblock's vectors (one vector per 8x8 unless sub-8x8 partitions / a second list exist)
+            int m = out.max_mvy;
+            if (!sub8 && !rf.bipred_rec) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; m = mv[b * 2 + 1] > m ? mv[b * 2 + 1] : m; } }
+            else for (int i = 0; i < 16; i++) { m = mvl[0][i * 2 + 1] > m ? mvl[0][i * 2 + 1] : m; if (rf.bipred_rec) m = mvl[1][i * 2 + 1] > m ? mvl[1][i * 2 + 1] : m; }
+            out.max_mvy = m;
+        }
         if (rf.track_uid) for (int l = 0; l < 2; l++) { int32_t *u = &(l ? cx.uid1 : cx.uid0)[(size_t)addr * 4]; for (int i = 0; i < 4; i++) u[i] = refl[l][i] >= 0 ? rf.uid[l][refl[l][i]] : -1; }
         if (rf.bipred_rec) {                                   // B slice / weighted prediction: full motion record (jobs.h MBM_BIPRED)
             if (out.mv_ext_count + kBiRecInt16 / 2 > out.mv_ext_cap) { err = "mv_ext overflow"; return; }

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kIBandRows * 16) __attribute__((amdgpu_waves_per_eu
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
         int spins = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(8);
-        if (known < need && l == 0) report_wait_timeout(err + blockIdx.y, CHAIN_ERR_INTRA_TIMEOUT);       // never silent: the engine reports a decode error
+        if (known < need) { if (l == 0) report_wait_timeout(err + blockIdx.y, CHAIN_ERR_INTRA_TIMEOUT); known = 0x7fffffff; }   // never silent: the engine reports a decode error (and the band does not wait again)
         asm volatile("" ::: "memory");
     };
     auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };

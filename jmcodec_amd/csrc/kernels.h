@@ -20,7 +20,10 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, 
 // chain launch (chain.hip): reconstruction + deblocking of every PS_CHAIN picture of the batch in ONE kernel; pictures of a stream follow each
 // other at macroblock granularity (chain_common.h).  Pictures must be ordered so that a picture's in-launch references have a lower index.
 bool chain_supported(int mb_w, int mb_h);
-void launch_chain(const PicParams *d_pics, int n, int max_mb_w, int max_mb_h, int *ctl, int *err, hipStream_t st);
+// d_groups: the work list, n_groups entries `picture << 16 | kind << 15 | index` (kind 0: reconstruction of 8 macroblocks, index = row * 32 +
+// segment; kind 1: deblocking band `index`), in the order in which the dispatcher shall start them (chain.hip)
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, hipStream_t st);
+int  chain_band_rows();
 int  chain_ctl_ints();                                                                         // kChainStride
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);
