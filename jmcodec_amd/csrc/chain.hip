@@ -62,8 +62,8 @@ int deblock_depth(); int deblock_pub();
 
 int chain_band_rows() { return kBandRows; }
 
-void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, hipStream_t st) {
-    const int depth = deblock_depth(), pub = deblock_pub();
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, bool debug_stall, hipStream_t st) {
+    const int depth = deblock_depth(), pub = debug_stall ? -1 : deblock_pub();
     dim3 grid((unsigned)n_groups * 2u), block(256);
     if (depth <= 2) hipLaunchKernelGGL((k_chain<2>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);
     else if (depth == 3) hipLaunchKernelGGL((k_chain<3>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);

@@ -382,7 +382,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             }
         }
         // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough
-        if (gives_ring && ((s + 1 - s_begin) % pub == 0 || s == s_end)) {
+        if (gives_ring && pub > 0 && ((s + 1 - s_begin) % pub == 0 || s == s_end)) {        // pub <= 0: debug option "debug_stall" -- the counter never advances
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (l == 0) __hip_atomic_store(&prog[band], s == s_end ? 0x7fffffff : s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

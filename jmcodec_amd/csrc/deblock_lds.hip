@@ -104,8 +104,8 @@ void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)
 }
 // ctl must have been cleared for this batch (Engine::launch does one memset for all H.264 kernels of a batch)
-void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, hipStream_t st) {
-    const int depth = deblock_depth(), pub = deblock_pub();
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, bool debug_stall, hipStream_t st) {
+    const int depth = deblock_depth(), pub = debug_stall ? -1 : deblock_pub();
     const int bands = (max_mb_h + kBandRows - 1) / kBandRows;
     dim3 grid(2 * bands, n), block(kBandRows * 16);
     if (depth <= 2) hipLaunchKernelGGL((k_deblock_band<2>), grid, block, 0, st, d_pics, ctl, pub, err);

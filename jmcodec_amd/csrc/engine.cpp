@@ -77,6 +77,15 @@ void Engine::submit(EnginePic &&p) {
     cv_.notify_one();
 }
 
+bool Engine::set_knob(const std::string &key, long long v) {
+    if (key == "chain_depth") chain_depth_ = (int)std::max(1ll, std::min(v, 16ll));
+    else if (key == "chain_lag") chain_lag_steps_ = (int)std::max(20ll, std::min(v, 1024ll));
+    else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
+    else if (key == "debug_stall") debug_stall_ = v != 0;
+    else return false;
+    return true;
+}
+
 EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 
 // Take the first pending picture of every decoder (arrival order) that belongs to this lane and may run now; then, on the lanes of ordinary
@@ -117,7 +126,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     if (lane_idx < kPLanes && chain_depth_ > 1 && (int)members.size() <= chain_max_streams_ && tot_bands <= kMaxChainBands && tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
-        const int depth_cap = std::min(chain_depth_, std::max(1, kMaxBatch / (int)members.size()));
+        const int depth_cap = std::min(chain_depth_.load(), std::max(1, kMaxBatch / (int)members.size()));
         for (int depth = 1; depth < depth_cap; depth++) {
             bool added = false;
             for (Decoder *d : members) {
@@ -237,7 +246,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
     if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) launch_deblock_prep(b.d_pics, n, max_mbs, st);
-    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 8; }
+    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, debug_stall_, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);
     // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
@@ -272,7 +281,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) for (int bnd = 0; bnd * band_rows < b.h_pics[i].mb_h; bnd++) b.h_groups[n_groups++] = (uint32_t)i << 16 | 0x8000u | (uint32_t)bnd;
         for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
-        launch_chain(b.d_pics, b.d_groups, n_groups, b.d_ctl, b.d_err, st);
+        launch_chain(b.d_pics, b.d_groups, n_groups, b.d_ctl, b.d_err, debug_stall_, st);
         b.pmask |= 32; mark(7, st);
     }
     hipEventRecord(b.kdone, st);

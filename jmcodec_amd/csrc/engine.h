@@ -16,9 +16,11 @@
 #pragma once
 #include "jobs.h"
 #include "hevc_jobs.h"
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -81,6 +83,8 @@ public:
     // async H2D of a parsed job list on the engine's copy stream; records `ev` behind it and returns its sequence number
     unsigned long long upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev);
     void set_profile(bool on) { profile_ = on; }
+    // engine-wide knobs (all handles of the device): "chain_depth", "chain_lag", "chain_streams", "debug_stall"; false = unknown key
+    bool set_knob(const std::string &key, long long v);
     EngineStats stats();
     int device() const { return device_; }
 
@@ -108,8 +112,8 @@ private:
         int head = 0, tail = 0, inflight = 0;
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
-    int chain_max_streams_ = 8;                               // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
-    int chain_depth_ = 8, chain_lag_steps_ = 24;              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
+    std::atomic<int> chain_max_streams_{8};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
@@ -122,6 +126,7 @@ private:
     std::mutex m_; std::condition_variable cv_;
     std::deque<EnginePic> pending_;
     bool profile_ = false, ok_ = false, device_failed_ = false;
+    std::atomic<bool> debug_stall_{false};
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };

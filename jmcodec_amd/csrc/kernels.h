@@ -16,13 +16,14 @@ void launch_intra_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, in
 bool deblock_lds_supported(int mb_w, int mb_h);
 constexpr int kDeblockMaxBands = 32, kDeblockProgressStride = 2 * kDeblockMaxBands;
 void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_t st);           // boundary strengths -> DbRec (PS_DEBLOCK_LDS or PS_CHAIN pictures)
-void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, hipStream_t st);   // LDS wavefront (after the prep)
+// debug_stall: test hook -- the bands never publish their step counters, so every band below the first one runs into its bounded wait
+void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, int *err, bool debug_stall, hipStream_t st);   // LDS wavefront (after the prep)
 // chain launch (chain.hip): reconstruction + deblocking of every PS_CHAIN picture of the batch in ONE kernel; pictures of a stream follow each
 // other at macroblock granularity (chain_common.h).  Pictures must be ordered so that a picture's in-launch references have a lower index.
 bool chain_supported(int mb_w, int mb_h);
 // d_groups: the work list, n_groups entries `picture << 16 | kind << 15 | index` (kind 0: reconstruction of 8 macroblocks, index = row * 32 +
 // segment; kind 1: deblocking band `index`), in the order in which the dispatcher shall start them (chain.hip)
-void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, hipStream_t st);
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, bool debug_stall, hipStream_t st);
 int  chain_band_rows();
 int  chain_ctl_ints();                                                                         // kChainStride
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820

@@ -598,3 +598,74 @@ def test_native_harness_on_device(oracle, tmp_path):
     assert dst.read_bytes() == want
     r = subprocess.run([exe, str(src), "--fmt", "0", "--loops", "4"], capture_output=True, text=True, timeout=300)     # NV12, looped input
     assert r.returncode == 0 and f"Frame Count:\t{4 * n}\n" in r.stdout and "Pixel Format:\tNV12\n" in r.stdout
+
+
+# ---- chain launches (chain.hip): consecutive pictures of one stream in one launch ----------------------------------------------------
+CHAIN_CASES = {
+    # several deblocking bands (more than 16 macroblock rows), several references, sub-8x8 partitions, vectors that point far down
+    "p_multiband_fuzz": dict(width=352, height=416, frames=14, gop=14, mode=1, num_ref=3, seed=201),
+    "p_multiband_real": dict(width=640, height=368, frames=12, gop=12, seed=202, search=12),
+    "b_multiband_cabac": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=2, bframes=2, cabac=1, seed=203, poc_type=0),
+    "wp_slices_nonref": dict(width=320, height=272, frames=12, gop=12, mode=1, num_ref=2, wp=1, slices=3, nonref_period=3, seed=204, poc_type=0),
+    "mmco_deblock_idc2": dict(width=320, height=272, frames=16, gop=16, mode=1, num_ref=3, mmco=1, deblock=2, slices=2, seed=205),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CHAIN_CASES))
+def test_chain_launch_vs_oracle(oracle, name):
+    """One stream decoded with chain launches of depth 1 (off), 3, 8 and 16 and with the tightest / a wide spacing of the pictures in the
+    work list: every variant is bit-exact against the oracle, chains really formed, and no wait between workgroups timed out."""
+    data = streams.generate(**CHAIN_CASES[name])
+    want, n, w, h = oracle.decode(data, 1)
+    for depth, lag in ((1, 24), (3, 20), (8, 24), (16, 64)):
+        with api.JmAmdDec(0, 1) as d:
+            lib = api.lib()
+            assert lib.jm_amddec_set_option(d.h, b"chain_depth", depth) == 0 and lib.jm_amddec_set_option(d.h, b"chain_lag", lag) == 0
+            before = d.stat("eng_chain_pics")
+            # the whole stream in one call: every picture is pending when the engine forms its batches
+            frames = d.decode_stream(None, chunks=[data])
+            assert d.stat("errors") == 0 and d.stat("device_wait_errors") == 0
+            chained = d.stat("eng_chain_pics") - before
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 8); lib.jm_amddec_set_option(d.h, b"chain_lag", 24)
+        assert len(frames) == n
+        assert b"".join(frames) == want, f"{name}: depth {depth} lag {lag} differs from the oracle"
+        assert (chained == 0) if depth == 1 else (chained > 0), (name, depth, chained)
+
+
+def test_chain_launch_1080p_two_gops(oracle):
+    """BASELINE config C1 through chain launches at full size: two IDR periods of one 1080p stream fed in one call (so that every P picture
+    of an IDR period is pending at once), each frame compared with the oracle."""
+    data = streams.generate(**streams.config_c1(stream_id=7, frames=40))
+    want, n, w, h = oracle.decode(data, 1)
+    fs = w * h * 3 // 2
+    with api.JmAmdDec(0, 1) as d:
+        before = d.stat("eng_chain_pics")
+        frames = d.decode_stream(None, chunks=[data])
+        assert d.stat("errors") == 0 and d.stat("eng_chain_pics") - before >= 30
+    assert len(frames) == n == 40
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+
+
+@pytest.mark.parametrize("chain", [0, 1])
+def test_damaged_handover_is_reported_not_silent(chain):
+    """a wait between workgroups that gives up must surface as a decode error.  Debug option "debug_stall" makes the deblocking
+    bands never publish their step counters, so the second band of a picture taller than 16 macroblock rows runs into its bounded wait:
+    the handle reports errors > 0, device_wait_errors > 0 and says so in jm_amddec_last_error -- in the stage kernels and in the chain kernel."""
+    data = streams.generate(width=176, height=288, frames=4, gop=4, seed=77)           # 18 macroblock rows: two bands
+    lib = api.lib()
+    with api.JmAmdDec(0, 1) as d:
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 8 if chain else 1)
+        lib.jm_amddec_set_option(d.h, b"debug_stall", 1)
+        try:
+            frames = d.decode_stream(None, chunks=[data])
+            errs, werrs, msg = d.stat("errors"), d.stat("device_wait_errors"), lib.jm_amddec_last_error(d.h).decode()
+        finally:
+            lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+    assert len(frames) == 4                       # the pipeline still completes
+    assert werrs > 0 and errs >= werrs
+    assert "timed out" in msg
+    with api.JmAmdDec(0, 1) as d:                 # and the engine is healthy afterwards
+        assert b"".join(d.decode_stream(data)) == b"".join(gpu_decode(data))
+        assert d.stat("errors") == 0
