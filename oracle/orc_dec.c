@@ -357,7 +357,7 @@ const char *orc_last_error(const OrcDec *d) { return d->err; }
 /* which coding tools the decoded stream exercised (macroblock / slice counts) */
 const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
-        "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter"};
+        "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }

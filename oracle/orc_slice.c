@@ -1180,7 +1180,15 @@ int orc_decode_slice_data(OrcDec *d, Bits *b) {
             if ((skip ? decode_skip_mb(s) : decode_mb(s)) < 0) { if (!d->err[0]) snprintf(d->err, sizeof d->err, "macroblock %d decode error", addr); rc = -1; break; }
             addr++; d->cur_mb_count++;
             if (b->err) { snprintf(d->err, sizeof d->err, "slice data truncated"); rc = -1; break; }
-            if (orc_cabac_terminate(&s->c)) break;             /* end_of_slice_flag */
+            if (orc_cabac_terminate(&s->c)) {                  /* end_of_slice_flag */
+                /* 9.3.3.2.2.3: the last bit the engine read is rbsp_stop_one_bit, so the slice data ended EXACTLY where the RBSP's trailing bits
+                 * begin: the bit before the read position is 1 and nothing but alignment zeros follows.  One wrong context-table entry,
+                 * binarisation or ctxIdxInc desynchronises the engine long before this point (hard part 1): counted per slice. */
+                size_t p = b->pos; int exact = p > 0 && p <= b->nbits && ((b->p[(p - 1) >> 3] >> (7 - ((p - 1) & 7))) & 1);
+                for (size_t q = p; exact && q < b->nbits; q++) if ((b->p[q >> 3] >> (7 - (q & 7))) & 1) exact = 0;
+                if (exact) d->stats[ORC_ST_EXACT_END]++;
+                break;
+            }
         }
         free(s);
         return rc;
@@ -1205,6 +1213,7 @@ int orc_decode_slice_data(OrcDec *d, Bits *b) {
         addr++; d->cur_mb_count++;
         more = bits_more_rbsp(b);
     }
+    if (rc == 0 && !b->err) d->stats[ORC_ST_EXACT_END]++;    /* CAVLC: the loop ends exactly when only rbsp_trailing_bits remain (7.3.4) */
     if (rc == 0 && b->err) { snprintf(d->err, sizeof d->err, "slice data truncated"); rc = -1; }
     free(s);
     return rc;

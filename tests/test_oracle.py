@@ -121,6 +121,10 @@ def test_thirdparty_high_profile_stream(oracle):
     assert md5(out) == m["md5_i420"]
     t = oracle.tools(data)
     assert t["cabac-slices"] == 36 and t["idc0"] == 34 and "cavlc-slices" not in t
+    # explicit (hard part 1): EVERY slice of the foreign stream ends with end_of_slice_flag on its last macroblock, with the arithmetic
+    # decoder's read position exactly on rbsp_stop_one_bit, and the 36 slices cover every macroblock of the 36 pictures (320x240 = 300 each)
+    assert t["exact-slice-ends"] == 36
+    assert sum(t.get(k, 0) for k in ("I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8")) == 36 * 300
     for k in ("I4x4", "I8x8", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "T8x8-inter"):
         assert t[k] > 50, k
     fs = w * h * 3 // 2

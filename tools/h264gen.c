@@ -55,6 +55,8 @@ typedef struct {
     int mmco;                   /* 1: random memory_management_control_operations, long-term references (P-only streams) */
     int nc_corner;              /* 1: Intra4x4 modes 4-6 may be chosen although p[-1,-1] is unavailable (NON-CONFORMING; probes the decoders'
                                    common convention "unavailable samples count as 128", which constrained_intra_pred exposes)   */
+    int no_intra;               /* 1: fuzz mode codes no intra macroblocks in P / B pictures and no non-IDR I pictures (the random numbers are
+                                   still drawn, so the rest of the stream's decisions do not shift)                              */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -1269,7 +1271,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     int px = mx * 16, py = my * 16, nref = e->nlist0;
     /* ---- decide intra vs inter ---- */
     int want_intra = 0, force_intra = -1;
-    if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1; force_intra = 7; } }
+    if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1; force_intra = 7; } if (e->p.no_intra) want_intra = 0; }
     static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     int try_skip = fuzz && !want_intra && rnd_n(&e->rng, 8) < 2;
     int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {0, 0, 0, 0};
@@ -1628,7 +1630,8 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     int mbt, sub[4] = {0, 0, 0, 0};
     if (fuzz) {
         int k = rnd_n(&e->rng, 24);
-        if (k == 0) { se_begin_mb(e, mx, my, skip_run); encode_intra_mb(e, mx, my, m, rnd_n(&e->rng, 12) == 0 ? 7 : -1); return; }
+        if (k == 0 && !e->p.no_intra) { se_begin_mb(e, mx, my, skip_run); encode_intra_mb(e, mx, my, m, rnd_n(&e->rng, 12) == 0 ? 7 : -1); return; }
+        if (k == 0) k = 6;
         if (k < 6) mbt = 0; else if (k < 11) mbt = 1 + rnd_n(&e->rng, 3); else if (k < 17) mbt = 4 + rnd_n(&e->rng, 18); else mbt = 22;
         if (mbt == 22) for (int i = 0; i < 4; i++) sub[i] = rnd_n(&e->rng, 13);
         if (!direct_ok) { if (mbt == 0) mbt = 3; for (int i = 0; i < 4; i++) if (sub[i] == 0) sub[i] = 3; }
@@ -1809,7 +1812,7 @@ static void encode_frame(Enc *e, int t, int is_b) {
     render_source(e, t);
     if (idr) { e->frame_num = 0; e->nrefs = 0; write_sps_pps(e); }
     e->slice_type = idr ? 2 : (is_b ? 1 : 0);
-    if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0) e->slice_type = 2;   /* occasional non-IDR I picture */
+    if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0 && !p->no_intra) e->slice_type = 2;   /* occasional non-IDR I picture */
     e->cur_poc = 2 * (t % p->gop); e->cur.poc = e->cur_poc;
     const int maxfn = 1 << e->log2_max_fn, curfn = e->frame_num & (maxfn - 1);
     e->cur.frame_num = curfn; e->cur.is_long = 0; e->cur.lt_idx = -1;
@@ -2081,7 +2084,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
