@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the untimed single-stream leg")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
+    ap.add_argument("--device-output", action="store_true", help="diagnostic (profiles/): display frames stay in device memory (jm_amddec_output_frame_device), no D2H copy -- "
+                    "under rocprofv3 the runtime replaces copy-engine transfers by blit kernels, which perturbs the decode kernels")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
     args = ap.parse_args()
 
@@ -147,11 +149,23 @@ def main():
         L.jm_amddec_set_option(h, b"profile", 0 if args.no_profile else 1)   # the engine records HIP events around each batched launch
         if args.parse_only:
             L.jm_amddec_set_option(h, b"parse_only", 1)
+        if args.device_output:
+            L.jm_amddec_set_option(h, b"device_output", 1)
         if jmcodec_amd.jm_nvdec_init(1 if args.codec == "hevc" else 0, 1, None, 0, h) != 0:
             raise SystemExit("init failed: " + L.jm_amddec_last_error(h).decode())
         handles.append(h)
 
     counts = [0] * S
+
+    dev_ptr, dev_len = C.c_void_p(0), C.c_int(0)
+
+    def take(out, n, h):
+        """jm_nvdec_output_frame -- or, with --device-output, the device-resident variant (no copy)."""
+        if args.device_output:
+            p, ln = C.c_void_p(0), C.c_int(0)
+            return L.jm_amddec_output_frame_device(C.byref(p), C.byref(ln), h)
+        n.value = frame_bytes
+        return L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h)
 
     def run_passes(i, passes):
         """test_nv_dec's hot loop: one NAL per jm_nvdec_decode_frame call, pull a frame whenever got_frame == 1."""
@@ -163,7 +177,7 @@ def main():
         # test_nv_dec's hot loop (one NAL per jm_nvdec_decode_frame call, fetch a frame whenever got_frame == 1) runs in the library:
         # a Python loop would measure the interpreter's per-call overhead and the GIL hand-off between the S feeder threads
         data = datas[i]
-        got_n = L.jm_amddec_feed_annexb(data, len(data), passes, C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
+        got_n = L.jm_amddec_feed_annexb(data, len(data), passes, None if args.device_output else C.cast(out, C.POINTER(C.c_ubyte)), frame_bytes, h)
         if got_n < 0:
             raise SystemExit("feed failed: " + L.jm_amddec_last_error(h).decode())
         cnt += got_n
@@ -173,17 +187,14 @@ def main():
         sc = b"\x00\x00\x01\x46\x01\x50" if args.codec == "hevc" else b"\x00\x00\x01\x09\x10"
         for _ in range(2):
             L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
-            if got.value == 1:
-                n.value = frame_bytes
-                if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
-                    cnt += 1
+            if got.value == 1 and take(out, n, h) > 0:
+                cnt += 1
         L.jm_amddec_set_option(h, b"wait_idle", 1)
         while True:
             L.jm_amddec_decode_frame(C.cast(C.c_char_p(sc), C.c_void_p), len(sc), C.byref(got), h)
             if got.value != 1:
                 break
-            n.value = frame_bytes
-            if L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) > 0:
+            if take(out, n, h) > 0:
                 cnt += 1
         counts[i] += cnt
 
@@ -280,19 +291,28 @@ def main():
     peak = 8000.0
     achieved = alg[dominant] / avg_s[dominant] / 1e9 if avg_s[dominant] > 0 else 0.0
     # HBM traffic from PMC counters (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, per picture) x pictures per launch
-    traffic = None
+    traffic = traffic_raw = None
     try:
         if args.codec == "hevc":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hevc_pmc_traffic.json")))["kernels"]
             t = lambda k: pmc[k]["traffic_upper"] if k in pmc else 0
             per_pic = {"inter": t("k_hevc_mc") + t("k_hevc_resid") + t("k_hevc_iresid"), "intra": t("k_hevc_intra"), "deblock": 2 * t("k_hevc_deblock") + t("k_hevc_sao")}
         else:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(p))
+            pmc = json.load(open(pmc_path))["kernels"]
             per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc.get("k_intra_band", pmc.get("k_intra_lds", {"traffic_upper": 0}))["traffic_upper"],
                        "deblock": pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"traffic_upper": 0}))["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
-        per_pic.setdefault("chain", per_pic["inter"] + per_pic["deblock"])
+        per_pic["chain"] = pmc["k_chain"]["traffic_upper"] if "k_chain" in pmc else per_pic["inter"] + per_pic["deblock"]
+        raw_pic = {"inter": pmc["k_recon_inter"]["fetch_raw"] + pmc["k_recon_inter"]["write"]} if args.codec == "h264" else {}
+        if args.codec == "h264":
+            band = pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"fetch_raw": 0, "write": 0}))
+            raw_pic["deblock"] = band["fetch_raw"] + band["write"] + pmc["k_deblock_prep"]["fetch_raw"] + pmc["k_deblock_prep"]["write"]
+            ib = pmc.get("k_intra_band", pmc.get("k_intra_lds", {"fetch_raw": 0, "write": 0}))
+            raw_pic["intra"] = ib["fetch_raw"] + ib["write"]
+            raw_pic["chain"] = (pmc["k_chain"]["fetch_raw"] + pmc["k_chain"]["write"]) if "k_chain" in pmc else raw_pic["inter"] + raw_pic["deblock"]
         if (args.width, args.height) == (1920, 1080):
             traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
+            traffic_raw = int(raw_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1)) if dominant in raw_pic else None
     except Exception:
         traffic = None
     # frame-level contract figure of SURVEY 8(d): A = 1.5*Wc*Hc*(n_ref+1) + 1.5*Wd*Hd + J per frame
@@ -475,7 +495,10 @@ def main():
                      "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate; "
                              "cpu_needed_for_8_gpus = 8 x cpus_busy is what an 8-rank run of this rate would need from the node"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 6), "traffic": traffic,
+                     "frac": round(achieved / peak, 6), "traffic": traffic, "traffic_raw": traffic_raw,
+                     "traffic_note": "HBM bytes per launch from PMC counters (profiles/r02_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, per picture) x "
+                                     "pictures per launch of THIS run; traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced reads, an "
+                                     "upper estimate for these access shapes), traffic_raw = FETCH_SIZE + WRITE_SIZE as counted",
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms,

@@ -90,7 +90,9 @@ int  jm_amddec_output_nv12_pitch_device(void *dev_dst, int pitch, jm_amddec_hand
 /* The hot loop of the reference harness in native code (/root/reference/test_nv_dec/test_nv_dec.cpp:184-250): feed the Annex-B buffer one
  * NAL unit per jm_nvdec_decode_frame call (a NAL = start code + payload up to the next start code, :63-86), fetch a frame with
  * jm_nvdec_output_frame into out_buf whenever got_frame == 1.  `passes` repeats the buffer.  Does not send end of stream (the caller
- * decides when to drain).  Returns the number of frames fetched, < 0 on error.  Exists so that callers in interpreted languages
+* decides when to drain).  out_buf == NULL (with option "device_output"): frames are taken with jm_amddec_output_frame_device instead, i.e. they
+ * stay in device memory and nothing crosses PCIe (profiling: rocprofv3 replaces copy-engine transfers by blit kernels that disturb the decode
+ * kernels).  Returns the number of frames fetched, < 0 on error.  Exists so that callers in interpreted languages
  * (bench.py) measure the library, not their own per-call overhead. */
 long jm_amddec_feed_annexb(const unsigned char *buf, long len, int passes, unsigned char *out_buf, int out_cap, jm_amddec_handle handle);
 

@@ -60,6 +60,7 @@ def lib():
     L.jm_amddec_last_error.argtypes = [vp]
     L.jm_amddec_last_error.restype = cp
     L.jm_amddec_packout_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.jm_amddec_output_frame_device.argtypes = [C.POINTER(C.c_void_p), ip, vp]
     L.jm_amddec_feed_annexb.argtypes = [cp, C.c_long, C.c_int, C.POINTER(C.c_ubyte), C.c_int, vp]
     L.jm_amddec_feed_annexb.restype = C.c_long
     _LIB = L

@@ -315,7 +315,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         asm volatile("" ::: "memory");
     };
     // CHAIN: macroblocks of this group's row known to be reconstructed, counted from the left (bits of the row's bitmap words seen so far)
-    int recon_known = 0;
+    int recon_known = (pp.stages & PS_RECON) ? 0x7fffffff : 0;               // PS_RECON beside PS_CHAIN: reconstructed by the stage kernel before this launch
     const uint32_t *bits_row = CHAIN ? (const uint32_t *)(cpic + kChainBits) + (size_t)row * kChainRowWords : nullptr;
     auto wait_recon = [&](int x) {              // before the unfiltered samples of macroblock (x, row) are fetched; uniform per 16-lane group
         if (!CHAIN) return;

@@ -180,6 +180,10 @@ void Engine::launch(Lane &ln, Batch &b) {
                 const EnginePic &e = b.pics[j];
                 if (e.dec == p.dec && e.has_picture && e.chain_ok && e.codec == 0) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
             }
+            // A picture whose references were all complete before this launch (the first picture of its stream in the batch) is reconstructed
+            // by the stage kernel k_recon_inter, which runs first on the lane's stream: cached reference loads at 5 waves per SIMD instead of
+            // cache-bypassing ones at 3 inside k_chain.  k_chain then only deblocks it (its bands find the reconstruction complete).
+            if (q.n_deps == 0) q.stages |= PS_RECON;
         }
         stages |= b.h_pics[i].stages;
         if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
@@ -201,7 +205,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (st & PS_RECON) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
         if (st & (PS_INTRA_LDS | PS_INTRA_V1)) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; }
         if (st & (PS_DEBLOCK_LDS | PS_DEBLOCK_V1)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; }
-        if (st & PS_CHAIN) { b.alg[4] += p.alg_bytes[0] + p.alg_bytes[2]; b.npics[4]++; }
+        if (st & PS_CHAIN) { b.alg[4] += ((st & PS_RECON) ? 0 : p.alg_bytes[0]) + p.alg_bytes[2]; b.npics[4]++; }
         b.alg[3] += p.alg_bytes[3] * (long long)(p.out_before.size() + p.out_after.size());
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
@@ -268,7 +272,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
         for (size_t k = 0; k < n_keys; k++) group_buckets_[k].clear();
         for (int i = 0; i < n; i++) {
-            if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
+            if (!(b.h_pics[i].stages & PS_CHAIN) || (b.h_pics[i].stages & PS_RECON)) continue;      // (PS_RECON: reconstructed by the stage kernel)
             const int mb_h = b.h_pics[i].mb_h, segs = (b.h_pics[i].mb_w + 7) / 8, base = base_of[i];
             for (int r = 0; r < mb_h; r++) {
                 for (int c = 0; c < segs; c++) group_buckets_[base + 2 * r + 8 * c].push_back((uint32_t)i << 16 | (uint32_t)(r * 32 + c));
@@ -310,8 +314,8 @@ void Engine::complete(Batch &b, bool failed) {
         add(4, 4, 7, b.pmask & 32);
         for (int k = 0; k < 5; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
-        if (b.any_chain) { st_.chain_batches++; st_.chain_pics += (long long)b.pics.size(); }
     }
+    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; for (auto &p : b.pics) st_.chain_pics += p.has_picture && p.chain_ok; }   // (counted with or without profiling)
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
     // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
     for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0; std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }

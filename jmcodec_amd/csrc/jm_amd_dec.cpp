@@ -79,7 +79,7 @@ __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *
 }
 
 __attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned char *buf, long len, int passes, unsigned char *out, int out_cap, jm_amddec_handle h) {
-    if (!h || !buf || len < 4 || !out) return -1;
+    if (!h || !buf || len < 4) return -1;       // out == NULL: frames stay on the device (jm_amddec_output_frame_device), nothing is copied
     // NAL boundaries as find_nalu sees them: a start code is 00 00 01, or 00 00 00 01 (then the NAL starts one byte earlier)
     std::vector<long> starts;
     for (long i = 0; i + 3 <= len; i++) if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) { long s0 = (i > 0 && buf[i - 1] == 0) ? i - 1 : i; if (starts.empty() || s0 > starts.back()) starts.push_back(s0); i += 2; }
@@ -90,7 +90,10 @@ __attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned
             const long b = starts[k], e = k + 1 < starts.size() ? starts[k + 1] : len;
             int got = 0;
             if (guarded(h, [&] { return D(h)->decode(buf + b, (int)(e - b), &got); }) != 0) return -2;
-            if (got == 1) { int n = out_cap; if (D(h)->output(out, &n) > 0) frames++; }
+            if (got == 1) {
+                if (out) { int n = out_cap; if (D(h)->output(out, &n) > 0) frames++; }
+                else { void *dev = nullptr; int n = 0; if (D(h)->output_device(&dev, &n) > 0) frames++; }
+            }
         }
     return frames;
 }
