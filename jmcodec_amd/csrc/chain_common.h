@@ -40,6 +40,20 @@ __device__ __forceinline__ int ld_coh(const int *p) { return __hip_atomic_load(p
 __device__ __forceinline__ uint32_t ld_coh(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Wide write-through stores (16 / 8 bytes per lane, `sc1` = agent scope on gfx950).  The atomic builtins stop at 8 bytes and split a row into dword
+// stores, each of which the memory side handles as its own partial-sector write: WRITE_SIZE showed 68 MB per 1080p picture for k_chain against
+// 6.3 MB of samples.  Inline assembly is safe here: the compiler does not count these stores in its vmcnt bookkeeping, so the waits it inserts for
+// later loads only become more conservative; the waits that matter for the stores themselves are explicit (s_waitcnt vmcnt) in the callers.
+typedef uint32_t jm_v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t jm_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_wt16(void *p, uint4 v) {
+    const jm_v4u t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) void *)p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_wt8(void *p, uint2 v) {
+    const jm_v2u t = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) void *)p), "v"(t) : "memory");
+}
 // reference samples: COH = the reference picture may have been written by this launch
 template <bool COH> __device__ __forceinline__ int ld_ref8(const uint8_t *p) {
     if (COH) return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

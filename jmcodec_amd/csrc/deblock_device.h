@@ -98,11 +98,11 @@ template <> __device__ __forceinline__ uint32_t gload<uint32_t>(const gbyte *p) 
 __device__ __forceinline__ void gstore(gbyte *p, uint4 v) { v4u t = {v.x, v.y, v.z, v.w}; *(JM_GLOBAL v4u *)p = t; }
 __device__ __forceinline__ void gstore(gbyte *p, uint2 v) { v2u t = {v.x, v.y}; *(JM_GLOBAL v2u *)p = t; }
 __device__ __forceinline__ void gstore(gbyte *p, uint32_t v) { *(JM_GLOBAL uint32_t *)p = v; }
-// final samples.  WT (chain launches): dword write-through stores, because the next reader -- the motion compensation of the following picture --
+// final samples.  WT (chain launches): write-through stores (chain_common.h), because the next reader -- the motion compensation of the following picture --
 // may sit on another XCD and reads with cache-bypassing loads as soon as the band's `fin` counter covers the step (chain_common.h)
 __device__ __forceinline__ void gstore_wt(gbyte *p, uint32_t v) { __hip_atomic_store((JM_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (WT) { gstore_wt(p, v.x); gstore_wt(p + 4, v.y); gstore_wt(p + 8, v.z); gstore_wt(p + 12, v.w); } else gstore(p, v); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (WT) { gstore_wt(p, v.x); gstore_wt(p + 4, v.y); } else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (WT) st_wt16((void *)p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (WT) st_wt8((void *)p, v); else gstore(p, v); }
 template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) { if (WT) gstore_wt(p, v); else gstore(p, v); }
 
 // ------------------------------------------------------------------------------------------

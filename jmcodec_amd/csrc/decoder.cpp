@@ -167,18 +167,21 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
-    // Where a display frame waits for jm_nvdec_output_frame.  "Fetch": in DEVICE staging, and output() copies it straight into the caller's
-    // buffer with one synchronous DMA (no pinned host slot, no CPU memcpy: that memcpy was 30 % of the host CPU time per frame, and the host
-    // CPU budget is what bounds the rate).  The synchronous copies of a device serialise (~90 us each, ~11 k frames/s),
-    // so only some of the handles use it; the others keep the former scheme -- copy engine -> pinned host slot ahead of time, CPU memcpy in
-    // output() -- which costs CPU instead of time in that queue.  JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.
+    // Where a display frame waits for jm_nvdec_output_frame.  Every output slot has a device staging buffer (k_packout writes the tight frame
+    // there) and a pinned host buffer.  Per FRAME one of two routes is taken (enqueue_output):
+    //   pinned : a copy engine moves the frame to the pinned slot ahead of time, jm_nvdec_output_frame is one CPU memcpy (0.3 ms of CPU per 1080p frame);
+    //   fetch  : the frame stays in device staging and jm_nvdec_output_frame copies it straight into the caller's buffer with one synchronous DMA
+    //            (no CPU copy, a third of the time in the calling thread -- but the synchronous copies of a device queue behind each other, ~90 us each).
+    // Rule: a frame takes the fetch route when no other thread is inside such a copy at the moment the frame is queued, else the pinned route.  One
+    // stream alone therefore always fetches (its calling thread is what bounds it), many streams settle where the copy queue is busy but never
+    // backed up.  (Round 1 fixed the route per handle, "two of every five handles fetch", tuned for 32 streams on a 16-CPU quota.)
+    // JM_AMD_DEC_OUT_FETCH="a/b" keeps that per-handle form for tests (fetch for `a` of every `b` handles); JM_AMD_DEC_OUT_PINNED=1 = always pinned.
     {
-        // fetch for `fa` of every `fb` handles (JM_AMD_DEC_OUT_FETCH="a/b").  2/5 by measurement, 8 default bench runs per setting on one box: 1/2 is the
-        // fastest when it works (13.4-14.5 k frames/s) but falls into a second regime in 3 runs of 10 (6.8-7.0 k: the fetching streams starve behind the
-        // other handles' asynchronous copies and finish last); 2/5 gave 12.3-13.7 k in 8 of 8, 1/3 12.7-13.6 k with one 10.0 k, 1/4 10.6-12.9 k.
-        int fa = 2, fb = 5;
-        if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 2; fb = 5; } }
-        out_fetch_ = out_via_copy_engine_ && !getenv("JM_AMD_DEC_OUT_PINNED") && (handle_index_ % fb) < fa;
+        out_route_ = 0;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned
+        if (getenv("JM_AMD_DEC_OUT_PINNED") || !out_via_copy_engine_) out_route_ = 2;
+        else if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { int fa = 0, fb = 0; if (sscanf(e, "%d/%d", &fa, &fb) == 2 && fb > 0) out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
+        out_fetch_ = out_route_ == 1;
+        if (const char *e = getenv("JM_AMD_DEC_FETCH_LIMIT")) fetch_limit_ = atoi(e);
     }
     if (engine_) engine_->set_profile(profile_);
     inited_ = true;
@@ -325,7 +328,7 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     o->w = disp_w_; o->h = disp_h_;
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!device_output_ && !out_fetch_ && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if (!device_output_ && out_route_ != 1 && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
         if ((out_via_copy_engine_ || device_output_) && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
         o->bytes = frame_bytes_;
     }
@@ -904,6 +907,8 @@ void Decoder::enqueue_output(int slot, std::vector<PackJob> &jobs, std::vector<O
     jobs.push_back(PackJob{surf_[slot], o->dev ? o->dev : o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, 0});
     slots.push_back(o);
     o->has_data = true;
+    // route of this frame (see Decoder::init): fetch when the device's synchronous-copy queue is idle right now
+    o->fetch = o->dev && (!o->host || (out_route_ == 0 && engine_ && engine_->fetchers() < fetch_limit_));
 }
 
 void Decoder::submit_task(PicTask *t) {
@@ -1054,7 +1059,7 @@ int Decoder::output(uint8_t *out, int *out_len) {
     int need = cur_out_->w * cur_out_->h * 3 / 2;
     if (*out_len < need) return -2;
     *out_len = 0;
-    if (cur_out_->has_data && cur_out_->host) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
+    if (cur_out_->has_data && cur_out_->host && !cur_out_->fetch) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
     else if (cur_out_->has_data) {
         // The frame waits in device staging (fetch mode, or device_output): one synchronous DMA into the caller's buffer.  Plain hipMemcpy
         // on purpose: the runtime pins the caller's pages (and caches the pinning), runs one copy-engine transfer and the other feeder
@@ -1063,7 +1068,10 @@ int Decoder::output(uint8_t *out, int *out_len) {
         // hipHostRegister + hipMemcpyAsync + hipEventSynchronize(hipEventBlockingSync) 4.3 k at 3.6 ms; the same with a sleeping
         // hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms; this form 10.7-11.4 k at 0.96-1.0 ms.
         hipSetDevice(device_);
-        if (hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (engine_) engine_->fetch_begin();
+        const hipError_t ce = hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost);
+        if (engine_) engine_->fetch_end();
+        if (ce != hipSuccess) return -1;
     }
     else memset(out, 0, (size_t)need);
     *out_len = need;

@@ -87,6 +87,7 @@ struct OutSlot {                       // one display frame in pinned host memor
     size_t bytes = 0;
     int w = 0, h = 0;                  // display size of the frame held (a stream may change resolution at an IDR picture)
     bool has_data = false, ready = false;
+    bool fetch = false;                // this frame waits in device staging and jm_nvdec_output_frame copies it with one synchronous DMA (Decoder::init)
 };
 
 class Decoder {
@@ -159,7 +160,7 @@ private:
     OutSlot *alloc_out_slot();
 
     // configuration
-    int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1;
+    int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1, out_route_ = 0, fetch_limit_ = 1;
     bool chain_ok_ = false;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
     std::string error_;

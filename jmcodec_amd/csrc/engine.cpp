@@ -233,7 +233,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     // Pack-out: k_packout writes the tight frames into device staging and a copy engine (SDMA) moves them to the pinned slots.
     // Letting the kernel store into host memory directly saves that hop but its PCIe-bound stores share the L2 / fabric write
     // queues with everything else: k_recon_inter of the next batch ran 4x slower next to it (0.56 -> 2.3 ms for 32 pictures).
-    auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev && o->host) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
+    auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
     if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; for (auto &p : b.pics) copy_out(p.slots_before, st); }
     mark(1, st);
     if (any_hevc && (hd.max_pus || hd.max_tbs || hd.any_intra || hd.any_deblock || hd.any_sao)) {

@@ -83,6 +83,10 @@ public:
     // async H2D of a parsed job list on the engine's copy stream; records `ev` behind it and returns its sequence number
     unsigned long long upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev);
     void set_profile(bool on) { profile_ = on; }
+    // threads currently inside a synchronous device-to-host frame copy (jm_nvdec_output_frame, fetch route): the copies of a device run one after another
+    int  fetchers() const { return fetchers_.load(std::memory_order_relaxed); }
+    void fetch_begin() { fetchers_.fetch_add(1, std::memory_order_relaxed); }
+    void fetch_end() { fetchers_.fetch_sub(1, std::memory_order_relaxed); }
     // engine-wide knobs (all handles of the device): "chain_depth", "chain_lag", "chain_streams", "debug_stall"; false = unknown key
     bool set_knob(const std::string &key, long long v);
     EngineStats stats();
@@ -127,6 +131,7 @@ private:
     std::deque<EnginePic> pending_;
     bool profile_ = false, ok_ = false, device_failed_ = false;
     std::atomic<bool> debug_stall_{false};
+    std::atomic<int> fetchers_{0};
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };

@@ -470,9 +470,8 @@ __device__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconL
     // ---- store: whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments ----
     if (CHAIN) {
         if (lane < 24) {
-            uint32_t *d = (uint32_t *)(lane < 16 ? dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16 : dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16);
-            const uint4 v = *(const uint4 *)(ot + (lane < 16 ? lane * 4 : 64 + (lane - 16) * 4));
-            st_coh(d, v.x); st_coh(d + 1, v.y); st_coh(d + 2, v.z); st_coh(d + 3, v.w);       // write-through: the next reader sits on another XCD
+            uint8_t *d = lane < 16 ? dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16 : dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16;
+            st_wt16(d, *(const uint4 *)(ot + (lane < 16 ? lane * 4 : 64 + (lane - 16) * 4)));       // write-through: the next reader sits on another XCD
         }
         publish();
     } else {
