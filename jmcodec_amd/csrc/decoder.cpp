@@ -167,21 +167,25 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
-    // Where a display frame waits for jm_nvdec_output_frame.  Every output slot has a device staging buffer (k_packout writes the tight frame
-    // there) and a pinned host buffer.  Per FRAME one of two routes is taken (enqueue_output):
-    //   pinned : a copy engine moves the frame to the pinned slot ahead of time, jm_nvdec_output_frame is one CPU memcpy (0.3 ms of CPU per 1080p frame);
-    //   fetch  : the frame stays in device staging and jm_nvdec_output_frame copies it straight into the caller's buffer with one synchronous DMA
-    //            (no CPU copy, a third of the time in the calling thread -- but the synchronous copies of a device queue behind each other, ~90 us each).
-    // Rule: a frame takes the fetch route when no other thread is inside such a copy at the moment the frame is queued, else the pinned route.  One
-    // stream alone therefore always fetches (its calling thread is what bounds it), many streams settle where the copy queue is busy but never
-    // backed up.  (Round 1 fixed the route per handle, "two of every five handles fetch", tuned for 32 streams on a 16-CPU quota.)
-    // JM_AMD_DEC_OUT_FETCH="a/b" keeps that per-handle form for tests (fetch for `a` of every `b` handles); JM_AMD_DEC_OUT_PINNED=1 = always pinned.
+    // Where a display frame waits for jm_nvdec_output_frame.  k_packout writes the tight frame into a device staging buffer of the output slot; then
+    //   pinned : a copy engine moves it to the slot's pinned host buffer ahead of time, jm_nvdec_output_frame is one CPU memcpy (0.3 ms of CPU per 1080p frame);
+    //   fetch  : it stays in device staging and jm_nvdec_output_frame copies it straight into the caller's buffer with one synchronous DMA (no CPU copy:
+    //            that memcpy was 30 % of the host CPU time per frame, and the host CPU budget bounds the rate, DESIGN.md section 6 -- but the synchronous
+    //            copies of a device queue behind each other, ~90 us each, ~11 k frames/s).
+    // Default: the route is fixed per handle, two of every five handles fetch (JM_AMD_DEC_OUT_FETCH="a/b"; round-1 measurements: 1/2 is the fastest when
+    // it works, 13.4-14.5 k frames/s, but 3 runs of 10 fell into a second regime at 6.8-7.0 k; 2/5 gave 12.3-13.7 k in 8 of 8; 1/3 12.7-13.6 k with one
+    // 10.0 k; 1/4 10.6-12.9 k).  JM_AMD_DEC_OUT_FETCH=auto chooses per FRAME instead -- fetch when no other thread is inside such a copy at the moment the
+    // frame is queued (JM_AMD_DEC_FETCH_LIMIT) -- which needs no tuning but measured no better in round 2 (32 streams: 11.7-12.4 k against 12.4 k on the
+    // same box; 8 streams: 9.2 k against 10.0 k), so it is not the default.  JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.
     {
-        out_route_ = 0;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned
+        int fa = 2, fb = 5;
+        out_route_ = 2;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned
+        const char *e = getenv("JM_AMD_DEC_OUT_FETCH");
         if (getenv("JM_AMD_DEC_OUT_PINNED") || !out_via_copy_engine_) out_route_ = 2;
-        else if (const char *e = getenv("JM_AMD_DEC_OUT_FETCH")) { int fa = 0, fb = 0; if (sscanf(e, "%d/%d", &fa, &fb) == 2 && fb > 0) out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
+        else if (e && !strcmp(e, "auto")) out_route_ = 0;
+        else { if (e && (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0)) { fa = 2; fb = 5; } out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
         out_fetch_ = out_route_ == 1;
-        if (const char *e = getenv("JM_AMD_DEC_FETCH_LIMIT")) fetch_limit_ = atoi(e);
+        if (const char *l = getenv("JM_AMD_DEC_FETCH_LIMIT")) fetch_limit_ = atoi(l);
     }
     if (engine_) engine_->set_profile(profile_);
     inited_ = true;
