@@ -264,8 +264,18 @@ __device__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconL
                 int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3);
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
                 const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
+                if (COH && __all(xb == xa + 1 && 2 * xa + 8 <= pitch)) {
+                    // chain launches: the four bytes U V U V at 2 * xa of each row come out of two aligned dwords per row -- cache-bypassing BYTE loads
+                    // are one memory request each (FETCH_SIZE showed 26.9 MB per 1080p picture for k_chain against 4.9 MB for the stage kernels)
+                    const int o = (2 * xa) & ~3, sh = (2 * xa) & 3;
+                    const uint32_t a0 = ld_ref32<true>(r0 + o), a1 = ld_ref32<true>(r0 + o + 4), b0 = ld_ref32<true>(r1 + o), b1 = ld_ref32<true>(r1 + o + 4);
+                    const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
+                    c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
+                    c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
+                } else {
                 c_smp[0] = ld_ref8<COH>(r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(r1 + 2 * xa); c_smp[3] = ld_ref8<COH>(r1 + 2 * xb);
                 c_smp[4] = ld_ref8<COH>(r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(r1 + 2 * xa + 1); c_smp[7] = ld_ref8<COH>(r1 + 2 * xb + 1);
+                }
             }
         }
     }
