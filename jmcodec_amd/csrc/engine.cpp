@@ -176,14 +176,19 @@ void Engine::launch(Lane &ln, Batch &b) {
             PicParams &q = b.h_pics[i];
             q.stages = PS_CHAIN; q.chain_idx = i; q.n_deps = 0;
             for (int k = 0; k < kMaxSurfaces; k++) q.dep_pic[k] = -1;
+            bool refs_in_batch = false;                   // does it reference a picture that ANY kernel of this batch decodes?
             for (int j = 0; j < i; j++) {
                 const EnginePic &e = b.pics[j];
-                if (e.dec == p.dec && e.has_picture && e.chain_ok && e.codec == 0) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
+                if (e.dec != p.dec || !e.has_picture || e.codec != 0) continue;
+                if (p.ref_mask & (1u << e.pp.cur)) refs_in_batch = true;
+                if (e.chain_ok) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
             }
             // A picture whose references were all complete before this launch (the first picture of its stream in the batch) is reconstructed
             // by the stage kernel k_recon_inter, which runs first on the lane's stream: cached reference loads at 5 waves per SIMD instead of
             // cache-bypassing ones at 3 inside k_chain.  k_chain then only deblocks it (its bands find the reconstruction complete).
-            if (q.n_deps == 0) q.stages |= PS_RECON;
+            // (a reference decoded by the STAGE kernels of this batch -- a picture with intra macroblocks in front of the chain -- rules that out
+            // too: k_recon_inter reconstructs all its pictures at once; inside k_chain, which runs after every stage kernel, the order is right)
+            if (!refs_in_batch) q.stages |= PS_RECON;
         }
         stages |= b.h_pics[i].stages;
         if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
