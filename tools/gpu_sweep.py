@@ -39,9 +39,11 @@ def h264_params(r):
              seed=r.randrange(1 << 20), mode=r.choice([0, 1, 1]), deblock=r.choice([0, 1, 1, 2]), num_ref=r.randint(1, 4), slices=r.randint(1, 3), cabac=cab, cabac_idc=r.randint(0, 2),
              t8x8=r.randint(0, 1), bframes=b, direct_temporal=r.randint(0, 1), wp=r.choice([0, 0, 1, 2]), dinf8=r.randint(0, 1), scaling=r.choice([0, 0, 1, 2]), rplm=r.choice([0, 0, 1]),
              cip=r.choice([0, 0, 1]), chroma_qp_off=r.choice([0, 0, -4, 6]), alpha_off=r.choice([0, 0, 3, -3]), beta_off=r.choice([0, 0, -2, 2]), poc_type=r.choice([0, 2]),
-             nc_corner=r.choice([0, 0, 0, 1]))
+             nc_corner=r.choice([0, 0, 0, 1]), no_intra=r.choice([0, 1, 1]), search=r.choice([4, 4, 16, 48]))      # no_intra: pictures that can run in chain launches
     if not b and r.random() < 0.3:
         a["mmco"] = 1
+    if r.random() < 0.4:
+        a["frames"] = r.choice([9, 14, 20])                                                                        # long enough for deep chains
     return a
 
 
@@ -68,10 +70,16 @@ def main():
                 print("ORACLE FAIL", name, kw, e); bad += 1; continue
             if want != recon:
                 print("ORACLE != GENERATOR", name, kw); bad += 1; continue
-            with jmcodec_amd.JmAmdDec(codec, 1, options={"device": 0}) as d:
-                got = b"".join(d.decode_stream(data)); err = d.stat("errors")
-            if got != want or err:
-                print("GPU MISMATCH", name, kw, "errors", err); bad += 1
+            # NAL by NAL (pictures trickle into the engine), and the whole stream in one call with random chain knobs (every picture pending at once:
+            # the engine forms chain launches of consecutive pictures, chain.hip)
+            for whole in (False, True):
+                with jmcodec_amd.JmAmdDec(codec, 1, options={"device": 0}) as d:
+                    if whole:
+                        L = jmcodec_amd.lib()
+                        L.jm_amddec_set_option(d.h, b"chain_depth", r.choice([2, 3, 8, 16])); L.jm_amddec_set_option(d.h, b"chain_lag", r.choice([20, 24, 40]))
+                    got = b"".join(d.decode_stream(None, chunks=[data]) if whole else d.decode_stream(data)); err = d.stat("errors")
+                if got != want or err:
+                    print("GPU MISMATCH", name, "whole" if whole else "nal", kw, "errors", err); bad += 1
         print(name, n, "configurations done, failures so far:", bad, flush=True)
     sys.exit(1 if bad else 0)
 
