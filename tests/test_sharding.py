@@ -51,3 +51,25 @@ def test_two_rank_reduction_gloo():
     assert [r[2] for r in res] == [want_total, want_total]
     assert [r[3] for r in res] == [2.0, 2.0]                     # max over ranks
     assert res[0][1] + res[1][1] == want_total
+
+
+def test_bench_two_ranks_gloo_parse_only():
+    """bench.py itself under the driver's multi-rank launch line (torch.distributed.run, 2 ranks, gloo, no GPU: --parse-only): the S*world distinct
+    streams shard as stream i -> rank i mod world, rank 0 prints ONE JSON line whose frame count is the sum over ranks, the bit-exact flag is reduced."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--parse-only", "--streams", "3", "--frames", "6", "--width", "176", "--height", "144"]
+    env = dict(os.environ, JM_BENCH_CACHE=os.environ.get("TMPDIR", "/tmp"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["frames"] == 2 * 3 * 6 * 2                       # ranks x streams x frames x steps
+    assert d["config"]["stream_ids"] == [0, 4]                # rank 0 of 2: streams 0, 2, 4 of the job's 6
+    assert d["bit_exact"] is None and "cpu_baseline" not in d  # parse-only: no pixels to check; the CPU baseline is an N=1 leg
