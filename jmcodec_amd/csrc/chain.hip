@@ -7,7 +7,8 @@
 //
 // grid = 1-D, cut into GROUPS of 2 workgroups; groups[g] = picture << 16 | kind << 15 | index says what group g does:
 //   kind 0  reconstruction of 8 consecutive macroblocks of a row (index = row * 32 + segment): 4 macroblocks per workgroup, one wave each
-//   kind 1  deblocking band `index` (deblock_device.h): workgroup 0 of the group luma, workgroup 1 chroma
+//   kind 1  band `index & 31`: workgroup 0 of the group luma, workgroup 1 chroma; a deblocking band (deblock_device.h) -- or, index bit 14 set and only in
+//           the k_chain_i variant (chain_intra.hip), a band of the intra wavefront of a picture that is (mostly) intra coded
 // The host orders the work list (Engine::launch).  The dispatcher starts workgroups strictly in index order and a workgroup that waits stays
 // resident, so the order decides what can run:
 //   * all deblocking bands of the launch come first and are resident from the start (Engine::form keeps their number at half of what the GPU
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
     } else {
         __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes];
         int *cpic = cv.pic(pp.chain_idx);
-        deblock_band_body<DEPTH, true>(pp, (int)(entry & 0x7fffu), rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
+        deblock_band_body<DEPTH, true>(pp, (int)(entry & 31u), rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
     }
 }
 
@@ -62,8 +63,13 @@ int deblock_depth(); int deblock_pub();
 
 int chain_band_rows() { return kBandRows; }
 
-void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, bool debug_stall, hipStream_t st) {
+// chain_intra.hip: the variant with the intra role (its own translation unit: the inlining decisions, and with them the register count, of a fused
+// kernel depend on everything else in the module)
+void launch_chain_intra(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, int depth, int pub, hipStream_t st);
+
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st) {
     const int depth = deblock_depth(), pub = debug_stall ? -1 : deblock_pub();
+    if (with_intra) { launch_chain_intra(d_pics, d_groups, n_groups, ctl, err, depth, pub, st); return; }
     dim3 grid((unsigned)n_groups * 2u), block(256);
     if (depth <= 2) hipLaunchKernelGGL((k_chain<2>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);
     else if (depth == 3) hipLaunchKernelGGL((k_chain<3>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);

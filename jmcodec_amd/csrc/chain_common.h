@@ -24,14 +24,15 @@ namespace jmamd {
 // (the H.264 stage kernels use the same block: one memset per batch clears every counter of every picture)
 constexpr int kChainRing = 0;          // [64]  band step counters of the ring-row hand-over between deblocking bands (deblock_device.h)
 constexpr int kChainFin = 64;          // [64]  steps final in memory: luma bands 0..31, chroma bands 32..63
-constexpr int kChainIntraRing = 128;   // [64]  band step counters of the intra wavefront (intra_lds.hip)
-constexpr int kChainBits = 192;        // [mb_h][kChainRowWords] reconstruction bitmap, bit x of row y = macroblock (x, y) is in memory
+constexpr int kChainIntraRing = 128;   // [64]  band step counters of the intra wavefront (intra_device.h)
+constexpr int kChainIntraFin = 192;    // [64]  steps of the intra wavefront whose samples are in memory: luma bands 0..31, chroma bands 32..63
+constexpr int kChainBits = 256;        // [mb_h][kChainRowWords] reconstruction bitmap, bit x of row y = macroblock (x, y) is in memory
 constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4096 samples)
 constexpr int kChainMaxRows = 512;
 constexpr int kChainMaxPics = 64;      // == kMaxBatch (engine.h)
 constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
 constexpr int kSpinLimit = 1 << 20;    // polls before a wait gives up (about a second; a healthy wait takes microseconds)
-enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8 };
+enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16 };
 
 typedef __attribute__((address_space(1))) int gint;
 
@@ -68,6 +69,34 @@ template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const uint8_t *
 // reads it when the batch retires and reports a decode error for the handle -- a damaged hand-over is never silent).
 __device__ __forceinline__ void report_wait_timeout(int *err_word, int code) {
     if (err_word) __hip_atomic_store(err_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Bits of one macroblock row of the reconstruction bitmap as a band workgroup sees them: `known` macroblocks from the left are known to be in memory
+// (the run of set bits found by the last poll), so a band that trails the reconstruction polls once per row.  Uniform per 16-lane group.
+// want = this group needs macroblock x now; returns false when the wait gave up (reported by the caller).
+__device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word) {
+    bool pending = want && x >= known;
+    int spins = 0;
+    for (;;) {
+        if (pending) {
+            const uint32_t m = ld_coh(bits_row + (x >> 5)) >> (x & 31);
+            if (m & 1) { known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
+        }
+        if (!__builtin_amdgcn_ballot_w64(pending)) return true;
+        if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // damaged: do not wait again
+        if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);                // a band may be resident long before its rows are reconstructed
+    }
+}
+// the same for a step counter (`fin` of the intra wavefront): wait until *ctr >= need
+__device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word) {
+    bool pending = want && known < need;
+    int spins = 0;
+    for (;;) {
+        if (pending) { known = ld_coh(ctr); pending = known < need; }
+        if (!__builtin_amdgcn_ballot_w64(pending)) return true;
+        if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
+        if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+    }
 }
 
 struct ChainView {

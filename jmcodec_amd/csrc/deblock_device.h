@@ -276,7 +276,8 @@ constexpr int kDeblockSmemBytes = kBandRows * Lds::kRecStride + (kBandRows + 1) 
 // (kDeblockProgressStride ints).  CHAIN (k_chain): `cpic` = the picture's block of the chain buffer; the unfiltered samples come from
 // reconstruction waves of the same launch (wait for their bits, read with cache-bypassing loads), the final samples are written through
 // and the band publishes in cpic[kChainFin ..] how many of its steps are final in memory.
-template <int DEPTH, bool CHAIN>
+// AFTER_INTRA (k_chain_i only): the picture's unfiltered samples come from an intra wavefront of the same launch (see wait_recon below)
+template <int DEPTH, bool CHAIN, bool AFTER_INTRA = false>
 __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band, bool is_chroma, int *prog_pic, int pub, uint8_t *smem, int *cpic, int *err_word) {
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
     const int row0 = band * kBandRows;
@@ -317,23 +318,20 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // CHAIN: macroblocks of this group's row known to be reconstructed, counted from the left (bits of the row's bitmap words seen so far)
     int recon_known = (pp.stages & PS_RECON) ? 0x7fffffff : 0;               // PS_RECON beside PS_CHAIN: reconstructed by the stage kernel before this launch
     const uint32_t *bits_row = CHAIN ? (const uint32_t *)(cpic + kChainBits) + (size_t)row * kChainRowWords : nullptr;
+    // PS_CHAIN_INTRA: the unfiltered samples come from the picture's intra wavefront (which itself waited for the reconstruction bits).  Intra prediction
+    // reads UNFILTERED neighbours: macroblock (x, row) may be deblocked once the intra wavefront has passed (x + 1, row + 1), i.e. its step s + 3, in the band
+    // that holds row + 1 and in this row's own band (counters `ifin`, published two steps late like `fin`).
+    constexpr bool after_intra = CHAIN && AFTER_INTRA;
+    int ifin_known0 = 0, ifin_known1 = 0;
+    const int *ifin0 = after_intra ? cpic + kChainIntraFin + (is_chroma ? 32 : 0) + (row >> 4) : nullptr;
+    const int *ifin1 = after_intra ? cpic + kChainIntraFin + (is_chroma ? 32 : 0) + (min(row + 1, mb_h - 1) >> 4) : nullptr;
     auto wait_recon = [&](int x) {              // before the unfiltered samples of macroblock (x, row) are fetched; uniform per 16-lane group
         if (!CHAIN) return;
-        bool pending = active && x >= 0 && x < mb_w && x >= recon_known;
-        int spins = 0;
-        for (;;) {
-            if (pending) {
-                const uint32_t m = ld_coh(bits_row + (x >> 5)) >> (x & 31);
-                if (m & 1) { recon_known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
-            }
-            if (!__builtin_amdgcn_ballot_w64(pending)) break;
-            if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) {
-                if ((threadIdx.x & 63) == 0) { report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); }
-                recon_known = 0x7fffffff;       // damaged and reported: do not wait again
-                break;
-            }
-            if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);      // a band may be resident long before its rows are reconstructed
-        }
+        const bool want = active && x >= 0 && x < mb_w;
+        bool ok;
+        if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word) && wait_counter(ifin1, ifin_known1, want, need, abort_word); }
+        else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word);
+        if (!ok && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, after_intra ? CHAIN_ERR_IFIN_TIMEOUT : CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); }
     };
     const int ring_lanes = ring_rows * 4;                                   // one dword per lane: ring row l >> 2, dword l & 3
     const int ring_lane = l < ring_lanes ? l : 0;

@@ -300,6 +300,7 @@ bool Decoder::gpu_alloc_sequence() {
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
     lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
     chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
+    chain_intra_on_ = !getenv("JM_AMD_DEC_NO_CHAIN_INTRA");
     if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
@@ -957,6 +958,7 @@ void Decoder::submit_task(PicTask *t) {
         // Inter pictures without intra macroblocks, deblocked by the LDS wavefront, may run inside the chain kernel (chain.hip) together with
         // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
         ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
+        ep.chain_intra = chain_ok_ && chain_intra_on_ && pp.stages == (PS_RECON | PS_INTRA_LDS | PS_DEBLOCK_LDS);      // e.g. the I picture of an IDR period
         ep.classic_stages = pp.stages;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];

@@ -161,7 +161,7 @@ private:
 
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1, out_route_ = 0, fetch_limit_ = 1;
-    bool chain_ok_ = false;
+    bool chain_ok_ = false, chain_intra_on_ = true;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
     std::string error_;
     std::atomic<bool> failed_{false}; bool inited_ = false;

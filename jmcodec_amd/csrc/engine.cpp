@@ -93,6 +93,14 @@ EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 // consecutive P / B pictures of a stream then share one launch and follow each other at macroblock granularity instead of one per batch.
 bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     b.pics.clear(); b.any_chain = false; b.max_depth = 1;
+    // chain launches are formed while few streams have pictures ready (a wide batch fills the GPU anyway); then the I picture of an IDR period stays on
+    // its stream's ordinary lane, where it becomes the first picture of a chain (k_chain_i), instead of going to the intra lane
+    bool chaining = false;
+    if (chain_depth_ > 1) {
+        std::vector<Decoder *> ds;
+        for (auto &p : pending_) if (p.codec == 0 && std::find(ds.begin(), ds.end(), p.dec) == ds.end()) ds.push_back(p.dec);
+        chaining = !ds.empty() && (int)ds.size() <= chain_max_streams_;
+    }
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
     auto account = [&](EnginePic &p, EngineDecoderState &es) {
@@ -105,13 +113,13 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
         EngineDecoderState &es = d->engine_state();
-        bool ok = it->lane() == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        bool ok = it->lane(chaining) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
         // the pack-job tables hold 2 * kMaxBatch entries each: a picture whose display frames no longer fit waits for the next batch
         // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
         if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
         if (!ok) { ++it; continue; }
         es.lane = lane_idx; es.inflight++;
-        es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false;
+        es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false; es.batch_resid = it->has_picture && it->codec == 0 && (it->pp.stages & (PS_INTRA_LDS | PS_INTRA_V1)) != 0;
         account(*it, es);
         members.push_back(d);
         b.pics.push_back(std::move(*it));
@@ -120,10 +128,11 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     if (b.pics.empty()) return false;
     // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
     // workgroups the GPU holds (chain.hip), and its work list must fit the table
-    auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = 2 * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + (p.mb_h + 15) / 16; };
-    int tot_bands = 0, tot_groups = 0;
-    for (auto &p : b.pics) if (p.has_picture && p.chain_ok) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng; }
-    if (lane_idx < kPLanes && chain_depth_ > 1 && (int)members.size() <= chain_max_streams_ && tot_bands <= kMaxChainBands && tot_groups <= kMaxChainGroups) {
+    auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + 2 * ((p.mb_h + 15) / 16); };
+    int tot_bands = 0, tot_groups = 0; bool any_intra = false;
+    for (auto &p : b.pics) if (p.has_picture && (p.chain_ok || p.chain_intra)) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng; any_intra |= p.chain_intra; }
+    auto band_limit = [&](bool intra) { return intra ? kMaxChainBandsIntra : kMaxChainBands; };
+    if (lane_idx < kPLanes && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) && tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
         const int depth_cap = std::min(chain_depth_.load(), std::max(1, kMaxBatch / (int)members.size()));
@@ -135,12 +144,14 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
                 // the next picture joins only if it runs inside k_chain, packs nothing BEFORE the kernels (such frames may not be decoded yet),
                 // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
-                const bool ok = it != pending_.end() && it->lane() == lane_idx && it->has_picture && it->chain_ok && it->out_before.empty() && !it->wait_prev_pack &&
+                // (a picture with an intra wavefront uses the handle's residual scratch: one such picture per stream and batch)
+                const bool ok = it != pending_.end() && it->lane(true) == lane_idx && it->has_picture && (it->chain_ok || (it->chain_intra && !es.batch_resid)) &&
+                                it->out_before.empty() && !it->wait_prev_pack &&
                                 !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
                 int nb = 0, ng = 0;
                 if (ok) chain_cost(*it, nb, ng);
-                if (!ok || tot_bands + nb > kMaxChainBands || tot_groups + ng > kMaxChainGroups) { es.batch_stop = true; continue; }
-                tot_bands += nb; tot_groups += ng;
+                if (!ok || tot_bands + nb > band_limit(any_intra || it->chain_intra) || tot_groups + ng > kMaxChainGroups) { es.batch_stop = true; continue; }
+                tot_bands += nb; tot_groups += ng; any_intra |= it->chain_intra; es.batch_resid |= it->chain_intra;
                 es.inflight++; es.in_batch++;
                 account(*it, es);
                 b.pics.push_back(std::move(*it));
@@ -171,17 +182,17 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (hevc) { b.h_hpics[i] = p.hp; if (!p.has_picture) b.h_hpics[i].stages = 0; any_hevc = true; }
         b.h_pics[i] = p.pp;
         if (!p.has_picture || hevc) b.h_pics[i].stages = 0;
-        else if (b.any_chain && p.chain_ok) {
+        else if (b.any_chain && (p.chain_ok || p.chain_intra)) {
             // this picture runs inside k_chain: its block of the control buffer, and which surfaces are decoded by EARLIER pictures of this launch
             PicParams &q = b.h_pics[i];
-            q.stages = PS_CHAIN; q.chain_idx = i; q.n_deps = 0;
+            q.stages = PS_CHAIN | (p.chain_intra ? PS_CHAIN_INTRA : 0); q.chain_idx = i; q.n_deps = 0;
             for (int k = 0; k < kMaxSurfaces; k++) q.dep_pic[k] = -1;
             bool refs_in_batch = false;                   // does it reference a picture that ANY kernel of this batch decodes?
             for (int j = 0; j < i; j++) {
                 const EnginePic &e = b.pics[j];
                 if (e.dec != p.dec || !e.has_picture || e.codec != 0) continue;
                 if (p.ref_mask & (1u << e.pp.cur)) refs_in_batch = true;
-                if (e.chain_ok) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
+                if (e.chain_ok || e.chain_intra) { q.dep_pic[e.pp.cur] = (int8_t)j; if (p.ref_mask & (1u << e.pp.cur)) q.n_deps++; }
             }
             // A picture whose references were all complete before this launch (the first picture of its stream in the batch) is reconstructed
             // by the stage kernel k_recon_inter, which runs first on the lane's stream: cached reference loads at 5 waves per SIMD instead of
@@ -210,7 +221,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (st & PS_RECON) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
         if (st & (PS_INTRA_LDS | PS_INTRA_V1)) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; }
         if (st & (PS_DEBLOCK_LDS | PS_DEBLOCK_V1)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; }
-        if (st & PS_CHAIN) { b.alg[4] += ((st & PS_RECON) ? 0 : p.alg_bytes[0]) + p.alg_bytes[2]; b.npics[4]++; }
+        if (st & PS_CHAIN) { b.alg[4] += ((st & PS_RECON) ? 0 : p.alg_bytes[0]) + ((st & PS_CHAIN_INTRA) ? p.alg_bytes[1] : 0) + p.alg_bytes[2]; b.npics[4]++; }
         b.alg[3] += p.alg_bytes[3] * (long long)(p.out_before.size() + p.out_after.size());
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
@@ -287,10 +298,14 @@ void Engine::launch(Lane &ln, Batch &b) {
         // wavefront and waits for reconstruction bits with larger keys, so it must be resident before anything that waits for it is started --
         // then every reconstruction group only ever waits for workgroups that are resident or done, and the one with the smallest key can always run.
         int n_groups = 0;
-        for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) for (int bnd = 0; bnd * band_rows < b.h_pics[i].mb_h; bnd++) b.h_groups[n_groups++] = (uint32_t)i << 16 | 0x8000u | (uint32_t)bnd;
+        bool with_intra = false;
+        for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) for (int bnd = 0; bnd * band_rows < b.h_pics[i].mb_h; bnd++) {
+            if (b.h_pics[i].stages & PS_CHAIN_INTRA) { b.h_groups[n_groups++] = (uint32_t)i << 16 | 0xC000u | (uint32_t)bnd; with_intra = true; }   // band of the intra wavefront
+            b.h_groups[n_groups++] = (uint32_t)i << 16 | 0x8000u | (uint32_t)bnd;
+        }
         for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
-        launch_chain(b.d_pics, b.d_groups, n_groups, b.d_ctl, b.d_err, debug_stall_, st);
+        launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_, st);
         b.pmask |= 32; mark(7, st);
     }
     hipEventRecord(b.kdone, st);
@@ -320,7 +335,7 @@ void Engine::complete(Batch &b, bool failed) {
         for (int k = 0; k < 5; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
-    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; for (auto &p : b.pics) st_.chain_pics += p.has_picture && p.chain_ok; }   // (counted with or without profiling)
+    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }   // (counted with or without profiling)
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
     // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
     for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0; std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }

@@ -34,7 +34,8 @@ struct OutSlot;
 constexpr int kMaxBatch = 64;
 constexpr int kBatchRing = 4;
 constexpr int kMaxChainGroups = 128 * 1024;         // work list of one chain launch (1080p: 1025 groups per picture, 4K: 4059)
-constexpr int kMaxChainBands = 384;                 // deblocking-band workgroups of one chain launch: half of what an MI355X holds at 3 per CU
+constexpr int kMaxChainBands = 384;                 // band workgroups of one chain launch: half of what an MI355X holds at 3 workgroups per CU (k_chain)
+constexpr int kMaxChainBandsIntra = 256;            // ... at 2 per CU (k_chain_i, the variant with the intra role)
 constexpr int kPLanes = 1;                          // lanes for ordinary pictures: while one group's batch sits in the serial deblock
                                                     // wavefront (2 CUs per picture) the other group's fully parallel kernels use the idle CUs
 constexpr int kLanes = kPLanes + 2;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures
@@ -54,12 +55,14 @@ struct EnginePic {
     bool wait_prev_pack = false;                    // this picture reuses a surface whose pack-out may still be running
     // chain launches (chain.hip): the picture may run inside k_chain, i.e. in the same launch as the pictures before it in its stream
     bool chain_ok = false;
+    bool chain_intra = false;                       // a (mostly) intra picture that can run inside k_chain_i with its intra wavefront as a third role (chain_intra.hip)
     int classic_stages = 0;                         // pp.stages when it runs through the stage kernels instead
     uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
     int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
-    int lane() const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS)) ? kPLanes : p_lane); }
+    // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on its stream's ordinary lane
+    int lane(bool chaining = false) const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : p_lane); }
 };
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
@@ -73,7 +76,7 @@ struct EngineDecoderState {
     int lane = -1, inflight = 0;
     uint32_t displayed[2] = {0, 0};                 // surfaces displayed by this decoder's pictures in the two most recently formed batches
     // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
-    int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false;
+    int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false, batch_resid = false;
 };
 
 class Engine {

@@ -117,7 +117,8 @@ struct PicParams {
 // One launch works on a BATCH of pictures (one per stream): kernels take an array of PicParams in device memory
 // and use blockIdx.y as the picture index.
 enum : int { PS_RECON = 1, PS_INTRA_LDS = 2, PS_INTRA_V1 = 4, PS_DEBLOCK_LDS = 8, PS_DEBLOCK_V1 = 16,
-             PS_CHAIN = 32 };     // PS_CHAIN: reconstruction + deblocking run inside k_chain (only k_deblock_prep of the stage kernels acts on it)
+             PS_CHAIN = 32,       // PS_CHAIN: reconstruction + deblocking run inside k_chain (only k_deblock_prep of the stage kernels acts on it)
+             PS_CHAIN_INTRA = 64 };   // with PS_CHAIN: a picture with (mostly) intra macroblocks -- its intra wavefront runs inside k_chain too
 
 struct PackJob {                  // one display frame to pack out (k_packout, blockIdx.y = job)
     const uint8_t *src; uint8_t *dst;

@@ -23,7 +23,7 @@ void launch_deblock_lds(const PicParams *d_pics, int n, int max_mb_h, int *ctl, 
 bool chain_supported(int mb_w, int mb_h);
 // d_groups: the work list, n_groups entries `picture << 16 | kind << 15 | index` (kind 0: reconstruction of 8 macroblocks, index = row * 32 +
 // segment; kind 1: deblocking band `index`), in the order in which the dispatcher shall start them (chain.hip)
-void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, bool debug_stall, hipStream_t st);
+void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st);
 int  chain_band_rows();
 int  chain_ctl_ints();                                                                         // kChainStride
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820

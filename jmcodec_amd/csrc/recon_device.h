@@ -156,7 +156,7 @@ template <bool COH> __device__ __forceinline__ int ref_luma(const uint8_t *s, in
     return ld_ref8<COH>(&s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)]);     // 32-bit index arithmetic (pointer adds here cost 15 VGPRs)
 }
 // 8.4.2.2.1 luma sample interpolation (literal form)
-template <bool COH> __device__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
+template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
 #define P(dx, dy) ref_luma<COH>(s, pitch, W, H, xi + (dx), yi + (dy))
 #define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
 #define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
@@ -193,7 +193,7 @@ struct alignas(16) ReconLds {
 // picture's reconstruction bitmap, on which the deblocking workgroups of this picture wait.
 // COH: the reference loads are the cache-bypassing kind (needed exactly when the picture has references inside the launch, pp.n_deps > 0).
 template <bool CHAIN, bool COH>
-__device__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
+__device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
     ResTile *tiles = sm.tiles;
     uint32_t (*outt)[96] = sm.outt;
     uint32_t (*wins)[4][13 * 5 + 3] = sm.wins;
@@ -294,7 +294,8 @@ __device__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconL
         // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
         if (lane < 48) {
             uint4 v = has_res ? *(const uint4 *)((const short *)&tiles[wave] + lane * 8) : make_uint4(0, 0, 0, 0);
-            *(uint4 *)(pp.resid + (size_t)mb * 384 + lane * 8) = v;
+            if (CHAIN) st_wt16(pp.resid + (size_t)mb * 384 + lane * 8, v);        // read by the intra band of this launch, possibly on another XCD
+            else *(uint4 *)(pp.resid + (size_t)mb * 384 + lane * 8) = v;
         }
         publish();
         return;
