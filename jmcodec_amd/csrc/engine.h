@@ -119,7 +119,7 @@ private:
         int head = 0, tail = 0, inflight = 0;
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
-    std::atomic<int> chain_max_streams_{8};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    std::atomic<int> chain_max_streams_{12};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
