@@ -249,6 +249,7 @@ void Decoder::gpu_free_sequence() {
         if (j.host) hipHostFree(j.host);
         if (j.dev) hipFree(j.dev);
         if (j.dbrec) hipFree(j.dbrec);
+        if (j.resid) hipFree(j.resid);
         if (j.uploaded) hipEventDestroy(j.uploaded);
         j = JobSlot();
     }
@@ -301,10 +302,10 @@ bool Decoder::gpu_alloc_sequence() {
     lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
     chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
     chain_intra_on_ = !getenv("JM_AMD_DEC_NO_CHAIN_INTRA");
-    if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }
+    if (codec_ == 1 && !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }   // HEVC: one per handle (H.264: per job slot)
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
-            (codec_ == 0 && !HIP_OK(hipMalloc((void **)&j.dbrec, n_mbs * 96))) ||
+            (codec_ == 0 && (!HIP_OK(hipMalloc((void **)&j.dbrec, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&j.resid, n_mbs * 768)))) ||
             !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
     }
@@ -472,7 +473,7 @@ bool Decoder::activate(const SeqParams &sps) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
                     if (resid_) { hipFree(resid_); resid_ = nullptr; }
-            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
+            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.resid) hipFree(j.resid); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
             free_out_slots(false);
         } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
     }
@@ -938,7 +939,7 @@ void Decoder::submit_task(PicTask *t) {
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);
         pp.mv_ext = pp.coef + t->coef_count;
-        pp.resid = (int16_t *)resid_; pp.dbrec = js.dbrec;
+        pp.resid = (int16_t *)js.resid; pp.dbrec = js.dbrec;
         pp.wp = t->any_wp ? (const SliceWp *)(js.dev + t->wp_offset) : nullptr;
         {   // scaling matrices: transmitted in zig-zag order (7.3.2.1.1.1), the kernels index them in raster order
             static const uint8_t zz4[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
@@ -958,7 +959,9 @@ void Decoder::submit_task(PicTask *t) {
         // Inter pictures without intra macroblocks, deblocked by the LDS wavefront, may run inside the chain kernel (chain.hip) together with
         // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
         ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
-        ep.chain_intra = chain_ok_ && chain_intra_on_ && pp.stages == (PS_RECON | PS_INTRA_LDS | PS_DEBLOCK_LDS);      // e.g. the I picture of an IDR period
+        // Pictures WITH intra macroblocks -- the I picture of an IDR period, or a P picture with a few of them -- can join too: the intra wavefront then
+        // runs as a third role of the chain kernel (k_chain_i), whatever the share of intra macroblocks (the stage path uses the spin-wait kernel for sparse ones).
+        ep.chain_intra = chain_ok_ && chain_intra_on_ && t->n_intra > 0 && use_lds_intra_ && (t->n_i8x8 == 0 || lds_intra8_) && (pp.stages & PS_DEBLOCK_LDS);
         ep.classic_stages = pp.stages;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];

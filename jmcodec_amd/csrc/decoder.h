@@ -77,6 +77,7 @@ struct PicTask {
 
 struct JobSlot {                       // one picture's job list: pinned host buffer (parse target) + its device copy
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
+    uint8_t *resid = nullptr;          // device scratch: int16 residual of this picture's intra macroblocks (768 B per macroblock), per slot for the same reason
     uint8_t *dbrec = nullptr;          // device scratch of k_deblock_prep for this picture (96 B per macroblock): per slot, because pictures of a chain run concurrently
     ihipEvent_t *uploaded = nullptr;   // recorded behind the H2D copy on the engine's copy stream
     bool busy = false;                 // from dispatch until the engine reports the picture done

@@ -144,8 +144,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
                 // the next picture joins only if it runs inside k_chain, packs nothing BEFORE the kernels (such frames may not be decoded yet),
                 // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
-                // (a picture with an intra wavefront uses the handle's residual scratch: one such picture per stream and batch)
-                const bool ok = it != pending_.end() && it->lane(true) == lane_idx && it->has_picture && (it->chain_ok || (it->chain_intra && !es.batch_resid)) &&
+                const bool ok = it != pending_.end() && it->lane(true) == lane_idx && it->has_picture && (it->chain_ok || it->chain_intra) &&
                                 it->out_before.empty() && !it->wait_prev_pack &&
                                 !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
                 int nb = 0, ng = 0;
@@ -186,6 +185,7 @@ void Engine::launch(Lane &ln, Batch &b) {
             // this picture runs inside k_chain: its block of the control buffer, and which surfaces are decoded by EARLIER pictures of this launch
             PicParams &q = b.h_pics[i];
             q.stages = PS_CHAIN | (p.chain_intra ? PS_CHAIN_INTRA : 0); q.chain_idx = i; q.n_deps = 0;
+            if (p.chain_intra) q.want_intra_resid = 1;      // the intra bands read the residuals from the picture's scratch (the stage path only asks for them when intra is dense)
             for (int k = 0; k < kMaxSurfaces; k++) q.dep_pic[k] = -1;
             bool refs_in_batch = false;                   // does it reference a picture that ANY kernel of this batch decodes?
             for (int j = 0; j < i; j++) {

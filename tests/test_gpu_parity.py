@@ -603,14 +603,18 @@ def test_native_harness_on_device(oracle, tmp_path):
 # ---- chain launches (chain.hip): consecutive pictures of one stream in one launch ----------------------------------------------------
 CHAIN_CASES = {
     # several deblocking bands (more than 16 macroblock rows), several references, sub-8x8 partitions, vectors that point far down
-    # (no_intra: the fuzz generator codes no intra macroblocks in P / B pictures -- pictures with intra macroblocks take the stage kernels)
+    # (no_intra: the fuzz generator codes no intra macroblocks in P / B pictures: chains of the two-role kernel k_chain)
     "p_multiband_fuzz": dict(width=352, height=416, frames=14, gop=14, mode=1, num_ref=3, seed=201, no_intra=1),
     "p_multiband_real": dict(width=640, height=368, frames=12, gop=12, seed=202, search=12),
     "b_multiband_cabac": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=2, bframes=2, cabac=1, seed=203, poc_type=0, no_intra=1),
     "b_temporal_t8x8": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=3, bframes=3, cabac=1, t8x8=1, direct_temporal=1, seed=206, poc_type=0, no_intra=1),
     "wp_slices_nonref": dict(width=320, height=272, frames=12, gop=12, mode=1, num_ref=2, wp=1, slices=3, nonref_period=3, seed=204, poc_type=0, no_intra=1),
     "mmco_deblock_idc2": dict(width=320, height=272, frames=16, gop=16, mode=1, num_ref=3, mmco=1, deblock=2, slices=2, seed=205, no_intra=1),
-    "mixed_intra_breaks_chains": dict(width=320, height=272, frames=16, gop=16, mode=1, num_ref=2, seed=207),
+    # intra macroblocks scattered through P / B pictures, and several IDR periods: those pictures join the chains through the intra role (k_chain_i)
+    "mixed_intra_p": dict(width=320, height=272, frames=16, gop=16, mode=1, num_ref=2, seed=207),
+    "mixed_intra_b_cabac_i8x8": dict(width=352, height=288, frames=14, gop=7, mode=1, num_ref=2, bframes=2, cabac=1, t8x8=1, seed=208, poc_type=0),
+    "idr_every_4_real": dict(width=640, height=368, frames=13, gop=4, seed=209),
+    "cip_mixed_intra": dict(width=320, height=272, frames=12, gop=12, mode=1, num_ref=2, cip=1, seed=210),
 }
 
 
@@ -632,7 +636,7 @@ def test_chain_launch_vs_oracle(oracle, name):
             lib.jm_amddec_set_option(d.h, b"chain_depth", 8); lib.jm_amddec_set_option(d.h, b"chain_lag", 24)
         assert len(frames) == n
         assert b"".join(frames) == want, f"{name}: depth {depth} lag {lag} differs from the oracle"
-        assert (chained == 0) if depth == 1 else (chained > 0 or name == "mixed_intra_breaks_chains"), (name, depth, chained)
+        assert (chained == 0) if depth == 1 else chained > 0, (name, depth, chained)
 
 
 def test_chain_launch_1080p_two_gops(oracle):
