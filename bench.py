@@ -167,8 +167,11 @@ def main():
         n.value = frame_bytes
         return L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h)
 
+    feeder_cpu = [0.0] * S          # CPU seconds of each handle's calling thread (they exit before the per-thread /proc snapshot)
+
     def run_passes(i, passes):
         """test_nv_dec's hot loop: one NAL per jm_nvdec_decode_frame call, pull a frame whenever got_frame == 1."""
+        tc_start = time.thread_time()
         h = handles[i]
         out = C.create_string_buffer(frame_bytes)
         got = C.c_int(0)
@@ -197,6 +200,7 @@ def main():
             if take(out, n, h) > 0:
                 cnt += 1
         counts[i] += cnt
+        feeder_cpu[i] += time.thread_time() - tc_start
 
     def batch(passes):
         ts = [threading.Thread(target=run_passes, args=(i, passes)) for i in range(S)]
@@ -223,6 +227,7 @@ def main():
     pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
     for i in range(S):
         counts[i] = 0
+        feeder_cpu[i] = 0.0
     def host_cpu():     # CPU seconds of this process, and the container's CPU quota / throttling (cgroup v2), if visible
         import resource
         ru = resource.getrusage(resource.RUSAGE_SELF)
@@ -491,6 +496,8 @@ def main():
                      "cpu_ms_per_frame": round(1e3 * (hc1["cpu_s"] - hc0["cpu_s"]) / max(frames_local, 1), 4),
                      "quota_cpus": hc1.get("quota_cpus"), "online_cpus": os.cpu_count(),
                      "throttled_ms": round((hc1.get("throttled_usec", 0) - hc0.get("throttled_usec", 0)) / 1e3, 1), "by_thread": by_thread,
+                     "calling_threads": {"cpu_ms_per_frame": round(1e3 * sum(feeder_cpu) / max(frames_local, 1), 4), "busiest_thread_share_of_wall": round(max(feeder_cpu) / dt, 3),
+                                         "note": "the S threads that call jm_nvdec_decode_frame / jm_nvdec_output_frame (NAL handling, slice headers, DPB, the frame copy); 1.0 = a handle's own thread is what bounds it"},
                      "cpu_needed_for_8_gpus": round(8 * (hc1["cpu_s"] - hc0["cpu_s"]) / dt, 1),
                      "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate; "
                              "cpu_needed_for_8_gpus = 8 x cpus_busy is what an 8-rank run of this rate would need from the node"},
