@@ -31,7 +31,16 @@ constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4
 constexpr int kChainMaxRows = 512;
 constexpr int kChainMaxPics = 64;      // == kMaxBatch (engine.h)
 constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
-constexpr int kSpinLimit = 1 << 20;    // polls before a wait gives up (about a second; a healthy wait takes microseconds)
+constexpr int kSpinLimit = 1 << 20;    // polls before a wait of the STAGE kernels gives up (about a second; a healthy wait takes microseconds)
+// waits of a chain launch are bounded by time: 100 ms of the 100 MHz wall clock (a healthy wait takes micro- to a few milliseconds).  The engine then
+// decodes the launch's pictures again with the stage kernels (Engine::recover), so a timeout costs time, not correctness.
+constexpr uint32_t kWaitTicks = 10u * 1000u * 1000u;
+__device__ __forceinline__ bool wait_expired(int spins, uint32_t &t0) {          // (32 bits of the clock: one register, and differences survive the wrap)
+    if (spins & 63) return false;
+    const uint32_t now = (uint32_t)wall_clock64();
+    if (spins == 64) { t0 = now; return false; }
+    return now - t0 > kWaitTicks;
+}
 enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16 };
 
 typedef __attribute__((address_space(1))) int gint;
@@ -76,25 +85,25 @@ __device__ __forceinline__ void report_wait_timeout(int *err_word, int code) {
 // want = this group needs macroblock x now; returns false when the wait gave up (reported by the caller).
 __device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word) {
     bool pending = want && x >= known;
-    int spins = 0;
+    int spins = 0; uint32_t t0 = 0;
     for (;;) {
         if (pending) {
             const uint32_t m = ld_coh(bits_row + (x >> 5)) >> (x & 31);
             if (m & 1) { known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
         }
         if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // damaged: do not wait again
+        if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // gave up: do not wait again
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);                // a band may be resident long before its rows are reconstructed
     }
 }
 // the same for a step counter (`fin` of the intra wavefront): wait until *ctr >= need
 __device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word) {
     bool pending = want && known < need;
-    int spins = 0;
+    int spins = 0; uint32_t t0 = 0;
     for (;;) {
         if (pending) { known = ld_coh(ctr); pending = known < need; }
         if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
+        if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -118,7 +127,7 @@ struct ChainView {
         const int xs = min((xmax + 4) >> 4, mb_w - 1), yhi = min((ymax + 4) >> 4, mb_h - 1), ylo = min(max((ymin + 4) >> 4, 0), yhi);
         const int bhi = yhi >> 4, blo = ylo >> 4;
         const int need_hi = xs + 2 * yhi + 1, need_lo = xs + 2 * (blo * 16 + 15) + 1;
-        int spins = 0;
+        int spins = 0; uint32_t t0 = 0;
         for (;;) {
             if (pending) {
                 bool ok = ld_coh(fin + bhi) >= need_hi && ld_coh(fin + 32 + bhi) >= need_hi;
@@ -126,7 +135,7 @@ struct ChainView {
                 pending = !ok;
             }
             if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-            if (++spins > kSpinLimit || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
+            if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
             __builtin_amdgcn_s_sleep(4);
         }
     }

@@ -306,9 +306,9 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
     auto wait_above = [&](int need) {
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
-        int spins = 0;
+        int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
-               !(CHAIN && (spins & 255) == 0 && ld_coh(abort_word))) __builtin_amdgcn_s_sleep(8);
+               !(CHAIN && (wait_expired(spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))))) __builtin_amdgcn_s_sleep(8);
         if (known < need) {                                                  // the band above never got there: damaged, and SAID so
             if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT); if (CHAIN) st_coh(abort_word, 1); }
             known = 0x7fffffff;                                              // do not wait again

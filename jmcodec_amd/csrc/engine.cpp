@@ -78,10 +78,11 @@ void Engine::submit(EnginePic &&p) {
 }
 
 bool Engine::set_knob(const std::string &key, long long v) {
+    if (key.rfind("chain_", 0) == 0) chain_block_until_ns_ = 0;            // an explicit setting ends the pause that follows a recovered chain launch
     if (key == "chain_depth") chain_depth_ = (int)std::max(1ll, std::min(v, 16ll));
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max(20ll, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
-    else if (key == "debug_stall") debug_stall_ = v != 0;
+    else if (key == "debug_stall") debug_stall_ = (int)v;
     else return false;
     return true;
 }
@@ -99,7 +100,8 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     if (chain_depth_ > 1) {
         std::vector<Decoder *> ds;
         for (auto &p : pending_) if (p.codec == 0 && std::find(ds.begin(), ds.end(), p.dec) == ds.end()) ds.push_back(p.dec);
-        chaining = !ds.empty() && (int)ds.size() <= chain_max_streams_;
+        chaining = !ds.empty() && (int)ds.size() <= chain_max_streams_ &&
+                   std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() >= chain_block_until_ns_;
     }
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
@@ -229,6 +231,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     for (auto &p : b.pics) p.dec->engine_state().displayed[1] = 0;
     for (auto &p : b.pics) p.dec->engine_state().displayed[1] |= p.out_mask;
     for (auto &p : b.pics) p.dec->engine_state().displayed[0] = p.dec->engine_state().displayed[1];
+    b.max_mbs = max_mbs; b.max_mb_h = max_mb_h; b.max_w = max_w; b.max_h = max_h; b.redo = false;
     hipStream_t st = ln.stream, pst = ln.pack_stream;
     if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st); hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), st); }   // every counter of every picture, and the abort word
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, st);
@@ -266,7 +269,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
     if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) launch_deblock_prep(b.d_pics, n, max_mbs, st);
-    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, debug_stall_, st); b.pmask |= 8; }
+    if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, debug_stall_ == 1, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);
     // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
@@ -305,7 +308,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         }
         for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
-        launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_, st);
+        launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_ != 0, st);
         b.pmask |= 32; mark(7, st);
     }
     hipEventRecord(b.kdone, st);
@@ -322,7 +325,55 @@ void Engine::launch(Lane &ln, Batch &b) {
     ln.pack_hist[1] = ln.pack_hist[0]; ln.pack_hist[0] = b.packed;
 }
 
-void Engine::complete(Batch &b, bool failed) {
+// A wait inside a chain launch gave up: the launch assumed slots that were not there (another process on the GPU, a long kernel of another stream).  Its
+// pictures -- and those of the lane's next batch, which read them -- are decoded again by the stage kernels, one picture per stream at a time, so what
+// the caller gets is still right; chain launches then pause for a while.  Synchronous and slow on purpose: it should never happen on a GPU the engine owns.
+void Engine::recover(Lane &ln, Batch &b) {
+    const int n = (int)b.pics.size();
+    hipStream_t st = ln.stream;
+    hipStreamSynchronize(ln.pack_stream); hipStreamSynchronize(st);
+    std::vector<int> depth(n, 0); int max_depth = 0;
+    for (int i = 0; i < n; i++) { for (int j = 0; j < i; j++) if (b.pics[j].dec == b.pics[i].dec && b.pics[j].has_picture) depth[i]++; max_depth = std::max(max_depth, depth[i]); }
+    for (int d = 0; d <= max_depth; d++) {
+        int stages = 0;
+        for (int i = 0; i < n; i++) {
+            const EnginePic &p = b.pics[i];
+            b.h_pics[i] = p.pp;
+            b.h_pics[i].stages = (p.has_picture && p.codec == 0 && depth[i] == d) ? p.classic_stages : 0;
+            stages |= b.h_pics[i].stages;
+            b.h_err[i] = 0;
+        }
+        if (!stages) continue;
+        hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);
+        hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
+        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, st);
+        if (stages & PS_INTRA_LDS) launch_intra_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, st);
+        if (stages & PS_INTRA_V1) launch_recon_intra(b.d_pics, n, st);
+        if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st); launch_deblock_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, false, st); }
+        if (stages & PS_DEBLOCK_V1) launch_deblock(b.d_pics, n, st);
+        hipStreamSynchronize(st);                              // h_pics is rewritten for the next depth
+    }
+    if (b.n_post) {                                            // the display frames of the batch again, from the pictures as they are now
+        launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, b.max_w, b.max_h, st);
+        for (auto &p : b.pics) for (OutSlot *o : p.slots_after) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+    }
+    { std::lock_guard<std::mutex> lk(sm_); st_.chain_recoveries++; }
+    chain_block_until_ns_ = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() + 30ll * 1000 * 1000 * 1000;
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "jm_amd_dec: device %d: a chain launch ran out of time waiting for workgroups (is the GPU shared?) -- its pictures were decoded again by the stage kernels; chain launches pause for 30 s\n", device_); }
+}
+
+void Engine::complete(Lane &ln, Batch &b, bool failed) {
+    if (!failed && (b.redo || b.any_chain)) {
+        bool wait_err = b.redo;
+        for (size_t i = 0; i < b.pics.size(); i++) wait_err |= b.h_err[i] != 0 && b.any_chain;
+        if (wait_err) {
+            // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
+            if (ln.inflight > 1) { Batch &nx = ln.ring[(ln.tail + 1) % kBatchRing]; hipEventSynchronize(nx.done); nx.redo = true; }
+            recover(ln, b);
+        }
+    }
     if (profile_ && !failed) {
         std::lock_guard<std::mutex> lk(sm_);
         auto add = [&](int cls, int e0, int e1, bool ran) {
@@ -355,7 +406,7 @@ void Engine::run() {
                 const hipError_t q = hipEventQuery(ln.ring[ln.tail].done);
                 if (q == hipErrorNotReady) break;
                 if (q != hipSuccess && !device_failed_) { device_failed_ = true; fprintf(stderr, "jm_amd_dec: device %d failed: %s -- every handle on it now returns errors\n", device_, hipGetErrorString(q)); }
-                { auto t0 = std::chrono::steady_clock::now(); complete(ln.ring[ln.tail], q != hipSuccess); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
+                { auto t0 = std::chrono::steady_clock::now(); complete(ln, ln.ring[ln.tail], q != hipSuccess); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
                 progressed = true;
             }
@@ -369,7 +420,7 @@ void Engine::run() {
             bool have;
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
             if (!have) continue;
-            if (device_failed_) { complete(b, true); progressed = true; continue; }      // nothing can run any more: fail the pictures right away
+            if (device_failed_) { complete(ln, b, true); progressed = true; continue; }      // nothing can run any more: fail the pictures right away
             { auto t0 = std::chrono::steady_clock::now(); launch(ln, b); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.launch_ns += ns; }
             ln.head = (ln.head + 1) % kBatchRing; ln.inflight++;
             progressed = true;

@@ -67,7 +67,7 @@ struct EnginePic {
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
     double ns[5] = {0, 0, 0, 0, 0}; long long launches[5] = {0, 0, 0, 0, 0}, pics[5] = {0, 0, 0, 0, 0}, alg_bytes[5] = {0, 0, 0, 0, 0};
-    long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0;
+    long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0, chain_recoveries = 0;
     long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
 };
 
@@ -104,7 +104,8 @@ private:
         int *d_progress = nullptr;                            // CTB row progress counters of k_hevc_intra
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
-        bool any_chain = false; int max_depth = 1;
+        bool any_chain = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
+        int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
@@ -124,7 +125,8 @@ private:
     std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
-    void complete(Batch &b, bool failed);
+    void complete(Lane &ln, Batch &b, bool failed);
+    void recover(Lane &ln, Batch &b);                         // decode a batch's pictures again with the stage kernels (a chain launch's wait gave up)
 
     int device_;
     ihipStream_t *copy_stream_ = nullptr;
@@ -133,8 +135,9 @@ private:
     std::mutex m_; std::condition_variable cv_;
     std::deque<EnginePic> pending_;
     bool profile_ = false, ok_ = false, device_failed_ = false;
-    std::atomic<bool> debug_stall_{false};
+    std::atomic<int> debug_stall_{0};                         // test hook: 1 = no band publishes its step counter (stage kernels and chain launches), 2 = chain launches only
     std::atomic<int> fetchers_{0};
+    std::atomic<long long> chain_block_until_ns_{0};          // no chain launches before this time (set when one had to be recovered; setting a chain knob clears it)
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };

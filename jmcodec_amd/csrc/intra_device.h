@@ -432,8 +432,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     int known = 0;
     auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
-        int spins = 0;
-        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit) __builtin_amdgcn_s_sleep(8);
+        int spins = 0; uint32_t t0 = 0;
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit && !(CHAIN && wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
         if (known < need) { if (l == 0) report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT); known = 0x7fffffff; }   // never silent: the engine reports a decode error (and the band does not wait again)
         asm volatile("" ::: "memory");
     };

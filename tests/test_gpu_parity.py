@@ -654,15 +654,14 @@ def test_chain_launch_1080p_two_gops(oracle):
         assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
 
 
-@pytest.mark.parametrize("chain", [0, 1])
-def test_damaged_handover_is_reported_not_silent(chain):
+def test_damaged_handover_is_reported_not_silent():
     """a wait between workgroups that gives up must surface as a decode error.  Debug option "debug_stall" makes the deblocking
     bands never publish their step counters, so the second band of a picture taller than 16 macroblock rows runs into its bounded wait:
-    the handle reports errors > 0, device_wait_errors > 0 and says so in jm_amddec_last_error -- in the stage kernels and in the chain kernel."""
+    the handle reports errors > 0, device_wait_errors > 0 and says so in jm_amddec_last_error (stage kernels; chain launches off)."""
     data = streams.generate(width=176, height=288, frames=4, gop=4, seed=77)           # 18 macroblock rows: two bands
     lib = api.lib()
     with api.JmAmdDec(0, 1) as d:
-        lib.jm_amddec_set_option(d.h, b"chain_depth", 8 if chain else 1)
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 1)
         lib.jm_amddec_set_option(d.h, b"debug_stall", 1)
         try:
             frames = d.decode_stream(None, chunks=[data])
@@ -676,3 +675,25 @@ def test_damaged_handover_is_reported_not_silent(chain):
     with api.JmAmdDec(0, 1) as d:                 # and the engine is healthy afterwards
         assert b"".join(d.decode_stream(data)) == b"".join(gpu_decode(data))
         assert d.stat("errors") == 0
+
+
+def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
+    """A chain launch assumes it can keep its bands resident; on a GPU it shares (another process, a long kernel of another stream) a wait inside it
+    can run out of time.  That must cost time, not correctness: the engine decodes the launch's pictures -- and those of the lane's next batch, which
+    read them -- again with the stage kernels.  "debug_stall" = 2 makes the chain launches of this stream fail that way (their bands never publish): the
+    frames still equal the oracle's, no error is reported, and eng_chain_recoveries counts the event."""
+    data = streams.generate(width=352, height=288, frames=12, gop=6, seed=78, num_ref=2)       # 18 macroblock rows, two IDR periods
+    want, n, w, h = oracle.decode(data, 1)
+    lib = api.lib()
+    with api.JmAmdDec(0, 1) as d:
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+        lib.jm_amddec_set_option(d.h, b"debug_stall", 2)           # 2 = chain launches only: the stage kernels that redo the pictures work
+        before = d.stat("eng_chain_recoveries")
+        try:
+            frames = d.decode_stream(None, chunks=[data])
+            errs, rec = d.stat("errors"), d.stat("eng_chain_recoveries") - before
+        finally:
+            lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)     # (also ends the pause of chain launches that follows a recovery)
+    assert len(frames) == n and b"".join(frames) == want
+    assert rec >= 1 and errs == 0
