@@ -443,6 +443,38 @@ def main():
                       "note": "one jm_nvdec handle, one feeder thread, NAL-per-call, frame copied into the caller's buffer whenever got_frame == 1 (test_nv_dec.cpp:184-250); untimed extra leg"}
         jmcodec_amd.jm_nvdec_deinit(h)
 
+    # ---- untimed: the same S streams with DEVICE-RESIDENT output (jm_amddec_output_frame_device: frames stay in HBM, nothing crosses PCIe on the way
+    # out, no frame copy on the CPU) -- the rate the contract calls "inputs and outputs resident in HBM"; `value` above is the PCIe-inclusive one ----
+    dev_leg = None
+    if world == 1 and not args.parse_only and not args.no_single and not args.device_output:
+        hs = []
+        for _ in range(S):
+            h = jmcodec_amd.jm_nvdec_create_handle()
+            L.jm_amddec_set_option(h, b"device_output", 1)
+            if jmcodec_amd.jm_nvdec_init(1 if is_hevc else 0, 1, None, 0, h) == 0:
+                hs.append(h)
+        got_dev = [0] * len(hs)
+
+        def dev_pass(i, passes):
+            got_dev[i] = L.jm_amddec_feed_annexb(datas[i], len(datas[i]), passes, None, frame_bytes, hs[i])
+            L.jm_amddec_set_option(hs[i], b"wait_idle", 1)
+        for passes, timed in ((1, False), (max(1, min(K, 3)), True)):
+            c0 = time.perf_counter()
+            ts = [threading.Thread(target=dev_pass, args=(i, passes)) for i in range(len(hs))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            if n_dev > 0:
+                torch.cuda.synchronize()
+            ddt = time.perf_counter() - c0
+            if timed:
+                dev_leg = {"value": round(len(hs) * F * passes / ddt, 1), "unit": "frames/s", "frames": len(hs) * F * passes,
+                           "note": "untimed extra leg: the same streams, display frames left in device memory (jm_amddec_output_frame_device, SURVEY 8f f3): "
+                                   "no D2H copy, no frame copy on the CPU; host entropy decode and job-list upload still included"}
+        for h in hs:
+            jmcodec_amd.jm_nvdec_deinit(h)
+
     if dist is not None:                                      # every rank must have matched
         import torch as _t
         flag = _t.tensor([1.0 if (bit_exact is None or bit_exact) else 0.0, float(frames_checked)], dtype=_t.float64, device=red_dev)
@@ -522,6 +554,8 @@ def main():
         line["cpu_baseline"] = cpu
     if single is not None:
         line["single_stream"] = single
+    if dev_leg is not None:
+        line["device_resident_output"] = dev_leg
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     q = hc1.get("quota_cpus") or os.cpu_count()
     if world > 1 and q and line["host_cpu"]["cpus_busy"] * local_world > 0.95 * q:
