@@ -36,9 +36,10 @@ Engine::Engine(int device) : device_(device) {
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
     copy_stream_ = c;
     for (auto &ln : lanes_) {
-        hipStream_t s, p;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) return;
-        ln.stream = s; ln.pack_stream = p;
+        hipStream_t s, p, q;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return;
+        ln.stream = s; ln.pack_stream = p; ln.pre_stream = q;
         for (auto &b : ln.ring) {
             if (hipHostMalloc((void **)&b.h_pics, sizeof(PicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
@@ -56,6 +57,7 @@ Engine::Engine(int device) : device_(device) {
             if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.kdone, hipEventDisableTiming) != hipSuccess) return;
             if (hipEventCreateWithFlags(&b.packed, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&b.pre_done, hipEventDisableTiming) != hipSuccess) return;
             for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
         }
     }
@@ -201,7 +203,8 @@ void Engine::launch(Lane &ln, Batch &b) {
             // cache-bypassing ones at 3 inside k_chain.  k_chain then only deblocks it (its bands find the reconstruction complete).
             // (a reference decoded by the STAGE kernels of this batch -- a picture with intra macroblocks in front of the chain -- rules that out
             // too: k_recon_inter reconstructs all its pictures at once; inside k_chain, which runs after every stage kernel, the order is right)
-            if (!refs_in_batch) q.stages |= PS_RECON;
+            static const bool no_hoist = getenv("JM_AMD_DEC_NO_HOIST") != nullptr;      // experiment
+            if (!refs_in_batch && !no_hoist) q.stages |= PS_RECON;
         }
         stages |= b.h_pics[i].stages;
         if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
@@ -233,15 +236,25 @@ void Engine::launch(Lane &ln, Batch &b) {
     for (auto &p : b.pics) p.dec->engine_state().displayed[0] = p.dec->engine_state().displayed[1];
     b.max_mbs = max_mbs; b.max_mb_h = max_mb_h; b.max_w = max_w; b.max_h = max_h; b.redo = false;
     hipStream_t st = ln.stream, pst = ln.pack_stream;
-    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st); hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), st); }   // every counter of every picture, and the abort word
-    if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, st);
-    else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
-    if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, st);
-    if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, st);
+    // What does not depend on the lane's previous batch -- clearing the control blocks, the parameter / pack-job tables, the deblocking pre-pass (it only
+    // reads the job lists) -- is issued on the lane's pre-stream, so it runs WHILE the previous batch's kernels are still busy instead of in the gap behind them.
+    // (This batch's tables were last used four batches ago: the ring guarantees that batch has retired.)
+    hipStream_t ps = any_hevc ? st : ln.pre_stream;
+    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps); hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), ps); }   // every counter of every picture, and the abort word
+    if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, ps);
+    else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, ps);
+    if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, ps);
+    if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, ps);
     // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
     // issued one of this batch covers them all without waiting for uploads of later pictures
     static const bool no_upl_wait = getenv("JM_AMD_DEC_EXP_NOUPLWAIT") != nullptr;   // experiment only
-    if (last_upload && !no_upl_wait) hipStreamWaitEvent(st, last_upload->uploaded, 0);
+    if (last_upload && !no_upl_wait) hipStreamWaitEvent(ps, last_upload->uploaded, 0);
+    bool prep_early = false;
+    if (!any_hevc) {
+        if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) { launch_deblock_prep(b.d_pics, n, max_mbs, ps); prep_early = true; }
+        hipEventRecord(b.pre_done, ps);
+        hipStreamWaitEvent(st, b.pre_done, 0);
+    }
     // Pack-out of batch k runs on its own stream and overlaps the decode kernels of batch k+1 (PCIe writes vs. compute).
     // The decoder never reuses a displayed surface for the very next picture (DPB cooling, decoder.cpp), so the decode
     // kernels of this batch only have to wait for the pack-out launched TWO batches ago.
@@ -268,7 +281,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
     if (!any_hevc) mark(3, st);
-    if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) launch_deblock_prep(b.d_pics, n, max_mbs, st);
+    if ((stages & (PS_DEBLOCK_LDS | PS_CHAIN)) && !prep_early) launch_deblock_prep(b.d_pics, n, max_mbs, st);
     if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, debug_stall_ == 1, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
     if (!any_hevc) mark(4, st);

@@ -108,13 +108,13 @@ private:
         int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
-        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
+        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
     };
     struct Lane {
-        ihipStream_t *stream = nullptr, *pack_stream = nullptr;
+        ihipStream_t *stream = nullptr, *pack_stream = nullptr, *pre_stream = nullptr;   // pre_stream: what a batch can do before the previous batch is complete
         ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // 'packed' events of the two most recently launched batches
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
