@@ -95,6 +95,8 @@ int Decoder::set_option(const char *key, long long v) {
     std::string k(key);
     if (k == "parse_only") parse_only_ = v != 0;
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
+    else if (k == "fast_parse") fast_parse_ = v != 0;        // 0: the general macroblock path only (tests)
+    else if (k == "job_digest") { want_job_digest_ = v != 0; if (want_job_digest_) sync_mode_ = true; }      // tests: FNV-1a over every picture's job list as the device gets it
     else if (k == "sync") sync_mode_ = v != 0;
     else if (k == "device_output") device_output_ = v != 0;        // frames stay in device memory (no D2H); see output_device()
     else if (k == "device") device_ = (int)v;
@@ -119,6 +121,7 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "intra_mbs") return stat_intra_mbs_;
     if (k == "coef_int16") return stat_coef_;
     if (k == "syntax_digest") return codec_ == 1 ? (long long)hdigest_.h : (long long)digest_.h;
+    if (k == "job_digest") return (long long)job_digest_;
     if (k == "digest_mbs") return codec_ == 1 ? (long long)hdigest_.n_cu : (long long)digest_.mbs;
     if (k == "i_pictures") return stat_i_;
     if (k == "p_pictures") return stat_p_;
@@ -817,7 +820,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
         if (s.col) s.col->wait();                            // direct prediction reads RefPicList1[0]'s motion: that picture was dispatched earlier
         if (s.has_wp) t->any_wp = true;
-        SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr);
+        SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr, fast_parse_);
         t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
         if (r.error) { t->error = r.error; stat_errors_++; note_error(std::string("slice data: ") + r.error); }
     }
@@ -851,6 +854,13 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
     t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count; t->max_mvy = w.max_mvy;
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
+    if (want_job_digest_) {                                  // (pictures are parsed in order: sync option)
+        uint64_t h = job_digest_;
+        auto eat = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+        eat(mbs, (size_t)n_mbs * sizeof(MbRec)); eat(srec, t->slices.size() * sizeof(SliceRec)); eat(w.coef, (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4);
+        const int mm = w.max_mvy; eat(&mm, sizeof mm);
+        job_digest_ = h;
+    }
     if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++; t->any_wp = false; }
     if (t->any_wp) {
         t->wp_offset = t->upload_bytes;

@@ -214,6 +214,7 @@ private:
     std::atomic<long long> stat_parse_ns_i_{0}, stat_parse_ns_p_{0}, stat_submit_ns_{0}, stat_wait_slot_ns_{0};
     std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0}, stat_wait_errors_{0};
     SyntaxDigest digest_;
+    bool fast_parse_ = true, want_job_digest_ = false; uint64_t job_digest_ = 1469598103934665603ull;    // option "job_digest" (tests)
     // HEVC state (front end only unless noted)
     HevcParamSets hps_; HevcSps hsps_; HevcPps hpps_;
     int h_poc_tid0_ = 0, h_max_dpb_ = 1, h_reorder_ = 0, extra_surf_ = 0; bool h_first_picture_ = true, h_no_rasl_output_ = false, h_seen_eos_ = false;

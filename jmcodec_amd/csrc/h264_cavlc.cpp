@@ -4,6 +4,7 @@
 #include "h264_cavlc.h"
 #include "h264_cabac.h"
 #include <mutex>
+#include <stddef.h>
 
 namespace jmamd {
 
@@ -52,7 +53,8 @@ static const uint8_t kZigzag8[64] = {
 
 // two-level table for coeff_token: primary on the top 8 bits, secondary on the next 8
 struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ; len 0xFF => sym = subtable number
-static TokTable g_tok[3];
+static TokTable g_tok[4];                           // [3]: nC >= 8, the 6-bit fixed-length code in the same format (fast path)
+static const uint8_t kTokClass[17] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3};
 static uint16_t g_tok_flc[64];                        // nC >= 8: 6-bit FLC
 static uint16_t g_cdc[256];                           // chroma DC token, max 8 bits
 static uint16_t g_tz[15][512];                        // total_zeros, max 9 bits
@@ -84,6 +86,8 @@ void cavlc_init_tables() {
         for (int i = 0; i < 3; i++) build_tok(g_tok[i], kTokLen[i], kTokBits[i]);
         // nC >= 8: 0000 11 -> (0,0); else total_coeff = (code >> 2) + 1, trailing_ones = code & 3
         for (int c = 0; c < 64; c++) { int tc = (c >> 2) + 1, t1 = c & 3; if (c == 3) { tc = 0; t1 = 0; } g_tok_flc[c] = (uint16_t)((4 * tc + t1) << 8 | 6); }
+        memset(g_tok[3].t, 0, sizeof g_tok[3].t);
+        for (int c = 0; c < 256; c++) g_tok[3].t[c] = g_tok_flc[c >> 2];
         memset(g_cdc, 0, sizeof g_cdc);
         for (int s = 0; s < 20; s++) if (kCdcLen[s]) { int l = kCdcLen[s]; uint32_t b = (uint32_t)kCdcBits[s] << (8 - l); for (uint32_t k = 0; k < (1u << (8 - l)); k++) g_cdc[b + k] = (uint16_t)(s << 8 | l); }
         memset(g_tz, 0, sizeof g_tz);
@@ -182,8 +186,19 @@ struct P {
         if (total > max_num) return -1;
         return residual_levels(total, t1, max_num, first, dst, map);
     }
-    __attribute__((noinline)) int residual_levels(int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) {
+    __attribute__((noinline)) int residual_levels(int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) { return levels_of(br, total, t1, max_num, first, dst, map); }
+    // (static, explicit reader: the fast path runs it on a local copy of the reader that lives in registers)
+    __attribute__((always_inline)) static inline int levels_of(BitReader &br, int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) {
         memset(dst, 0, max_num == 4 ? 8 : 32);
+        if (total == 1 && t1 == 1) {                          // the most frequent block by far: one level of +-1
+            const int v = 1 - 2 * (int)br.u1();
+            int z;
+            if (max_num == 4) { const uint8_t e = g_ctz[0][br.peek(3)]; if (!(e & 15)) return -1; br.skip(e & 15); z = e >> 4; }
+            else { const uint16_t e = g_tz[0][br.peek(9)]; if (!(e & 0xff)) return -1; br.skip(e & 0xff); z = e >> 8; }
+            if (z + 1 > max_num) return -1;
+            dst[map[z + first]] = (int16_t)v;
+            return 1;
+        }
         int level[16];
         int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
         int i = 0;
@@ -422,6 +437,156 @@ struct P {
         write_motion(r, false);
         finish_mb(r);
         return err == nullptr;
+    }
+
+
+    // ---- fast path (P slices with CAVLC, one motion record format, no digest): P_Skip and P_L0_16x16 -- 96 % of the macroblocks of a typical
+    // P picture -- without the general partition / list machinery.  Same arrays, same records: any other macroblock type of the slice goes
+    // through macroblock() and the two mix freely.  (tests/test_host_parser.py compares the job lists of both paths.)
+    // motion vector and reference of the 4x4 block r (8x8 quadrant b8) of neighbouring macroblock m; a macroblock that is not there or is intra has
+    // ref -1 and vector 0 (begin_mb clears the vectors of intra macroblocks)
+    struct Nv { int ref, x, y; };
+    inline Nv nbv(int m, int r, int b8) const {
+        if (m < 0) return Nv{-2, 0, 0};                             // -2: not available (8.4.1.3.2), never equal to a reference index
+        const int16_t *q = &cx.mv[(size_t)m * 32 + r * 2];
+        return Nv{cx.refidx[(size_t)m * 4 + b8], q[0], q[1]};
+    }
+    // 8.4.1.3 for a 16x16 partition: neighbours A (left, block 3), B (above, block 12), C (above right, block 12; else D above left, block 15)
+    inline void mvp16(int refi, const Nv &A, const Nv &B, int &px, int &py) const {
+        const Nv C = nC >= 0 ? nbv(nC, 12, 2) : nbv(nD, 15, 3);
+        if (B.ref == -2 && C.ref == -2 && A.ref != -2) { px = A.x; py = A.y; return; }
+        const int ma = A.ref == refi, mb = B.ref == refi, mc = C.ref == refi;
+        if (ma + mb + mc == 1) { const Nv &n = ma ? A : (mb ? B : C); px = n.x; py = n.y; }
+        else { px = med(A.x, B.x, C.x); py = med(A.y, B.y, C.y); }
+    }
+    // the macroblock's record and neighbour state for one vector / one reference index over the whole macroblock
+    // (the record is put together in four 64-bit words and stored once: byte-wise assembly followed by a 32-byte copy stalls on store forwarding)
+    inline void put_inter16(MbRec *r, int refi, int x, int y, uint32_t coef_off, uint32_t flags, uint32_t cbp_blk, uint32_t cbp_cac) {
+        const uint32_t v = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
+        const uint64_t vv = (uint64_t)v << 32 | v;
+        uint64_t *d = (uint64_t *)mv;
+        for (int i = 0; i < 8; i++) d[i] = vv;
+        const uint32_t rr = (uint8_t)refi * 0x01010101u;
+        memcpy(ref, &rr, 4);
+        cx.slice_of[addr] = (int16_t)slice_num;
+        const int my = (int16_t)y;
+        if (my > out.max_mvy) out.max_mvy = my;
+        static_assert(MB_INTER == 0 && offsetof(MbRec, cbp_blk) == 4 && offsetof(MbRec, coef_off) == 8 && offsetof(MbRec, ref) == 12 && offsetof(MbRec, u) == 16, "record layout");
+        uint64_t *q = (uint64_t *)r;
+        q[0] = (uint64_t)(uint8_t)qp << 8 | (uint64_t)(flags | MBF_DECODED) << 24 | (uint64_t)cbp_blk << 32 | (uint64_t)cbp_cac << 48 | (uint64_t)(uint8_t)slice_num << 56;
+        q[1] = (uint64_t)coef_off | (uint64_t)((uint8_t)rf.slot[0][refi] * 0x01010101u) << 32;
+        q[2] = vv; q[3] = vv;
+    }
+    __attribute__((always_inline)) inline void skip_mb_fast() {
+        int px = 0, py = 0;
+        if (nA >= 0 && nB >= 0) {
+            const Nv A = nbv(nA, 3, 1), B = nbv(nB, 12, 2);
+            if (!((A.ref == 0 && !A.x && !A.y) || (B.ref == 0 && !B.x && !B.y))) mvp16(0, A, B, px, py);
+        }
+        memset(tc, 0, 24);
+        cx.info[addr] = 4;
+        put_inter16(&out.mbs[addr], 0, px, py, out.coef_count, 0, 0, 0);
+    }
+    // total_coeff of one block (9.2.1) given the sum s of its left and upper neighbours' counts in the window (64 = not available): both there ->
+    // rounded mean, one -> that one, none -> 0
+    static inline int nc_of(int s) { return s < 64 ? (s + 1) >> 1 : s & 31; }
+    __attribute__((always_inline)) static inline int token_fast(BitReader &br, int nCtx) {                          // coeff_token: total_coeff << 2 | trailing_ones, or -1
+        const TokTable &T = g_tok[kTokClass[nCtx]];
+        const uint32_t v = br.peek(16);
+        uint32_t e = T.t[v >> 8];
+        if ((e & 0xff) == 0xff) e = T.t[256 * (e >> 8) + (v & 0xff)];
+        const int len = e & 0xff;
+        if (len == 0) return -1;
+        br.skip(len);
+        return (int)(e >> 8);
+    }
+    __attribute__((always_inline)) inline bool residual_fast(BitReader &br, int cbp, uint32_t &flags, uint32_t &bits, uint32_t &cbm) {
+        static const uint8_t ident[16] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15};
+        static const uint8_t kWin[16] = {9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36};      // block (decoding order) -> window index (by + 1) * 8 + bx + 1
+        static const uint8_t kRas[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};                 // ... -> raster index by * 4 + bx
+        // window of total_coeff: row 0 / column 0 = the macroblocks above / to the left
+        alignas(8) uint8_t w[5 * 8];
+        const uint8_t *ta = nA >= 0 ? &cx.tc[(size_t)nA * 24] : nullptr, *tb = nB >= 0 ? &cx.tc[(size_t)nB * 24] : nullptr;
+        flags = bits = cbm = 0;
+        memset(tc, 0, 24);
+        if (cbp & 15) {
+            memset(w, 0, sizeof w);
+            if (tb) memcpy(w + 1, tb + 12, 4); else memset(w + 1, 64, 4);
+            for (int j = 0; j < 4; j++) w[8 * (j + 1)] = ta ? ta[4 * j + 3] : 64;
+            for (int b8 = 0; b8 < 4; b8++) {
+                if (!(cbp & (1 << b8))) continue;
+                for (int k = 0; k < 4; k++) {
+                    const int blk = b8 * 4 + k, wi = kWin[blk];
+                    if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                    const int tk = token_fast(br, nc_of(w[wi - 1] + w[wi - 8]));
+                    if (tk < 0) { err = "entropy error (luma block)"; return false; }
+                    if (!tk) continue;
+                    const int total = tk >> 2;
+                    int16_t *d = out.coef + out.coef_count;
+                    if (levels_of(br, total, tk & 3, 16, 0, d, kZigzag4) < 0) { err = "entropy error (luma block)"; return false; }
+                    w[wi] = (uint8_t)total; tc[kRas[blk]] = (uint8_t)total; bits |= 1u << blk; out.coef_count += 16;
+                }
+            }
+        }
+        if (cbp & 0x30) {
+            for (int pl = 0; pl < 2; pl++) {
+                if (out.coef_count + 4 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                int16_t *d = out.coef + out.coef_count;
+                const uint32_t e = g_cdc[br.peek(8)];
+                if (!(e & 0xff)) { err = "entropy error (chroma DC)"; return false; }
+                br.skip((int)(e & 0xff));
+                if (!(e >> 10)) continue;
+                if ((int)(e >> 10) > 4 || levels_of(br, (int)(e >> 10), (int)(e >> 8) & 3, 4, 0, d, ident) < 0) { err = "entropy error (chroma DC)"; return false; }
+                flags |= pl ? MBF_CR_DC : MBF_CB_DC; out.coef_count += 4;
+            }
+        }
+        if (cbp & 0x20) {
+            for (int pl = 0; pl < 2; pl++) {
+                const int o = 16 + 4 * pl;
+                // 3x3 window of the plane: [0] unused, [1] [2] above, [3] [6] left
+                uint8_t c[9];
+                c[1] = tb ? tb[o + 2] : 64; c[2] = tb ? tb[o + 3] : 64; c[3] = ta ? ta[o + 1] : 64; c[6] = ta ? ta[o + 3] : 64;
+                for (int k = 0; k < 4; k++) {
+                    const int ci = 4 + (k >> 1) * 3 + (k & 1);
+                    if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+                    const int tk = token_fast(br, nc_of(c[ci - 1] + c[ci - 3]));
+                    if (tk < 0 || (tk >> 2) > 15) { err = "entropy error (chroma AC)"; return false; }
+                    c[ci] = (uint8_t)(tk >> 2);
+                    if (!tk) continue;
+                    int16_t *d = out.coef + out.coef_count;
+                    if (levels_of(br, tk >> 2, tk & 3, 15, 1, d, kZigzag4) < 0) { err = "entropy error (chroma AC)"; return false; }
+                    tc[o + k] = (uint8_t)(tk >> 2); cbm |= 1u << (4 * pl + k); out.coef_count += 16;
+                }
+            }
+        }
+        return true;
+    }
+    __attribute__((always_inline)) inline bool p16x16_fast(BitReader &br) {
+        int refi = 0;
+        const int nref = sh.num_ref_idx[0];
+        if (nref > 1) { refi = br.te(nref - 1); if (refi >= nref) { err = "ref_idx out of range"; return false; } }
+        int px, py;
+        mvp16(refi, nbv(nA, 3, 1), nbv(nB, 12, 2), px, py);
+        const int dx = br.se(), dy = br.se();
+        const uint32_t code = br.ue();
+        if (code > 47) { err = "bad coded_block_pattern"; return false; }
+        const int cbp = kCbpInter[code];
+        MbRec *r = &out.mbs[addr];
+        cx.info[addr] = 0;
+        if (cbp) {
+            const int dqp = br.se();
+            if (dqp < -26 || dqp > 25) { err = "mb_qp_delta out of range"; return false; }
+            qp += dqp; if (qp < 0) qp += 52; else if (qp > 51) qp -= 52;
+            const uint32_t coef_off = out.coef_count;
+            uint32_t flags, bits, cbm;
+            if (!residual_fast(br, cbp, flags, bits, cbm)) return false;
+            put_inter16(r, refi, px + dx, py + dy, coef_off, flags, bits, cbm);
+        } else {
+            memset(tc, 0, 24);
+            put_inter16(r, refi, px + dx, py + dy, out.coef_count, 0, 0, 0);
+        }
+        if (br.overrun()) { err = "macroblock data truncated"; return false; }
+        return true;
     }
 
     // ---- CABAC syntax elements (9.3.2 binarisation, 9.3.3.1 ctxIdxInc) ------------------------
@@ -696,9 +861,9 @@ struct P {
         return a < b ? a : b;
     }
 
-    bool macroblock(int &n_intra, int &n_i8x8) {
+    bool macroblock(int &n_intra, int &n_i8x8, int type_read = -1) {            // type_read: mb_type when the caller has read it already (CAVLC)
         MbRec *r = begin_mb();
-        uint32_t mb_type = cb ? (uint32_t)ae_mb_type() : br.ue();
+        uint32_t mb_type = type_read >= 0 ? (uint32_t)type_read : (cb ? (uint32_t)ae_mb_type() : br.ue());
         int itype = -1;
         if (sh.type == SL_I) itype = (int)mb_type;
         else if (sh.type == SL_P) { if (mb_type >= 5) itype = (int)mb_type - 5; }
@@ -879,7 +1044,7 @@ struct P {
 
 SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
                                   BitReader &br, int slice_num, const SliceRefs &refs,
-                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest) {
+                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest, bool allow_fast) {
     cavlc_init_tables();
     SliceParseResult res;
     Canon canon;
@@ -906,6 +1071,31 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
             if (cabac.overrun || cabac.bits_consumed() > (size_t)(cabac.end - cabac.start) * 8 + 16) { res.error = "slice data truncated"; return res; }
             if (cabac.terminate()) break;                     // end_of_slice_flag
         }
+        return res;
+    }
+    if (allow_fast && sh.type == SL_P && !digest && !pps.transform8x8 && !refs.bipred_rec && !refs.track_uid) {
+        // P_Skip / P_L0_16x16 through the fast path.  The reader is copied into a local whose address never leaves this loop (everything that
+        // takes it is inlined), so its state lives in registers instead of being reloaded after every byte store into the neighbour arrays.
+        BitReader b = br;
+        bool more = true;
+        while (more) {
+            const uint32_t run = b.ue();
+            if (b.overrun() || run > (uint32_t)(n_mbs - addr)) { res.error = "bad mb_skip_run"; break; }
+            for (uint32_t i = 0; i < run; i++) { p.locate(addr); p.skip_mb_fast(); addr++; }
+            res.mbs_decoded += (int)run;
+            if (run > 0) more = b.more_rbsp_data();
+            if (!more) break;
+            if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; break; }
+            p.locate(addr);
+            const uint32_t mb_type = b.ue();
+            bool ok;
+            if (mb_type == 0) ok = p.p16x16_fast(b);
+            else { br = b; ok = p.macroblock(res.n_intra, res.n_i8x8, (int)(mb_type > 255 ? 255 : mb_type)); b = br; }
+            if (!ok) { res.error = p.err ? p.err : "macroblock error"; break; }
+            addr++; res.mbs_decoded++;
+            more = b.more_rbsp_data();
+        }
+        br = b;
         return res;
     }
     bool more = true;

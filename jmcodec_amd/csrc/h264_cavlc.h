@@ -75,10 +75,10 @@ struct SliceParseResult {
 };
 
 // Parses slice_data() of one slice.  br must be positioned at sh.data_bit_offset with
-// set_end_from_trailing() already called.
+// set_end_from_trailing() already called.  allow_fast = false: every macroblock through the general path (tests compare the two).
 SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, const SliceHeader &sh,
                                   BitReader &br, int slice_num, const SliceRefs &refs,
-                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest);
+                                  ParseScratch &cx, JobWriter &out, SyntaxDigest *digest, bool allow_fast = true);
 
 void cavlc_init_tables();   // idempotent, thread-safe
 

@@ -263,3 +263,35 @@ def test_crop_only_change_at_idr_updates_the_display_size(oracle):
             if got == 1:
                 sizes.append(api.jm_nvdec_stream_info(d.h)); d._pull(None)
     assert sizes == [(96, 80)] * 2 + [(90, 70)] * 2
+
+
+def _job_digest(data, fast):
+    with api.JmAmdDec(0, 1, options={"parse_only": 1, "job_digest": 1, "fast_parse": 1 if fast else 0}) as d:
+        n = d.decode_stream(data, keep=False)
+        return d.stat("job_digest") & (2 ** 64 - 1), n, d.stat("errors"), d.stat("job_bytes")
+
+
+@pytest.mark.parametrize("name", sorted(PARITY_CASES))
+def test_fast_p_slice_path_builds_the_same_job_lists(name):
+    """P_Skip / P_L0_16x16 macroblocks of CAVLC P slices take a shorter route through the parser (h264_cavlc.cpp, `fast`); the syntax digest
+    above always runs the general route, so the two are compared here on what the device gets: records, coefficients, vectors."""
+    data = streams.generate(**PARITY_CASES[name])
+    a, b = _job_digest(data, True), _job_digest(data, False)
+    assert a == b and a[2] == 0 and a[1] == PARITY_CASES[name]["frames"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fast_p_slice_path_on_random_tool_mixes(seed):
+    rng = random.Random(900 + seed)
+    kw = dict(width=rng.choice([48, 96, 176, 320]), height=rng.choice([48, 80, 144, 240]), frames=rng.choice([4, 7, 10]), gop=rng.choice([3, 5, 30]),
+              qp=rng.choice([20, 26, 32, 40]), mode=rng.choice([0, 1]), num_ref=rng.choice([1, 2, 4]), slices=rng.choice([1, 2, 3]), seed=0x5000 + seed,
+              deblock=rng.choice([0, 1, 2]))
+    data = streams.generate(**kw)
+    a, b = _job_digest(data, True), _job_digest(data, False)
+    assert a == b and a[2] == 0 and a[1] == kw["frames"]
+
+
+def test_fast_p_slice_path_full_size():
+    data = streams.generate(**streams.config_c1(stream_id=3, frames=6))
+    a, b = _job_digest(data, True), _job_digest(data, False)
+    assert a == b and a[2] == 0 and a[1] == 6

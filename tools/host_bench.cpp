@@ -10,18 +10,23 @@
 #include <cstring>
 #include <sys/time.h>
 #include <ucontext.h>
+#include <time.h>
+#include <pthread.h>
 
-// JM_HOST_BENCH_PROF=file: a sampling profile of the host half (the image has no perf / gprof-capable toolchain): SIGPROF every 250 us of
-// process CPU time, the interrupted program counter is recorded and written as `offset-in-binary` lines for llvm-addr2line / llvm-symbolizer.
+// JM_HOST_BENCH_PROF=file: a sampling profile of the host half (the image has no perf / gprof-capable toolchain): SIGPROF every 50 us of wall time, the interrupted program counter is recorded and written as `offset-in-binary` lines for llvm-addr2line / llvm-symbolizer.
 static unsigned long *g_pcs; static volatile long g_npc; static const long kMaxPc = 1 << 22;
 static void on_prof(int, siginfo_t *, void *uc) { long i = __atomic_fetch_add(&g_npc, 1, __ATOMIC_RELAXED); if (i < kMaxPc) g_pcs[i] = (unsigned long)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP]; }
 static void prof_start() {
     g_pcs = new unsigned long[kMaxPc];
     struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART; sigaction(SIGPROF, &sa, nullptr);
-    struct itimerval it = {{0, 250}, {0, 250}}; setitimer(ITIMER_PROF, &it, nullptr);
+    // a wall-clock timer (ITIMER_PROF only ticks at CONFIG_HZ); the signal is blocked in the calling thread, so it interrupts the parse workers,
+    // which do all the work in parse-only mode with JM_AMD_DEC_THREADS=1
+    timer_t t; struct sigevent se; memset(&se, 0, sizeof se); se.sigev_notify = SIGEV_SIGNAL; se.sigev_signo = SIGPROF; timer_create(CLOCK_MONOTONIC, &se, &t);
+    struct itimerspec its = {{0, 50000}, {0, 50000}}; timer_settime(t, 0, &its, nullptr);
+    sigset_t m; sigemptyset(&m); sigaddset(&m, SIGPROF); pthread_sigmask(SIG_BLOCK, &m, nullptr);
 }
 static void prof_stop(const char *path) {
-    struct itimerval it = {{0, 0}, {0, 0}}; setitimer(ITIMER_PROF, &it, nullptr);
+    signal(SIGPROF, SIG_IGN);
     unsigned long lo = 0, hi = 0;                                           // the executable's own text mapping
     if (FILE *m = fopen("/proc/self/maps", "r")) { char ln[512]; while (fgets(ln, sizeof ln, m)) { unsigned long a, b, off; char perm[8]; if (sscanf(ln, "%lx-%lx %7s %lx", &a, &b, perm, &off) == 4 && strstr(ln, "host_bench")) { if (!lo || a - off < lo) lo = a - off; if (b > hi) hi = b; } } fclose(m); }
     if (FILE *f = fopen(path, "w")) { long n = g_npc < kMaxPc ? g_npc : kMaxPc; for (long i = 0; i < n; i++) if (g_pcs[i] >= lo && g_pcs[i] < hi) fprintf(f, "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other\n"); fclose(f); }
@@ -36,7 +41,7 @@ int main(int argc, char **argv) {
     if (jm_amddec_init(codec, 1, nullptr, 0, h) != 0) { fprintf(stderr, "init failed\n"); return 1; }
     std::vector<unsigned char> out(64 << 20);
     const char *prof = getenv("JM_HOST_BENCH_PROF");
-    if (prof) prof_start();
+    if (prof) { jm_amddec_feed_annexb(b.data(), (long)b.size(), 1, out.data(), (int)out.size(), h); prof_start(); }      // (the first pass creates the parse workers: they must not inherit the blocked signal)
     auto t0 = std::chrono::steady_clock::now();
     long frames = jm_amddec_feed_annexb(b.data(), (long)b.size(), passes, out.data(), (int)out.size(), h);
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
