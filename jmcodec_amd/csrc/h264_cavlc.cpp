@@ -202,19 +202,27 @@ struct P {
         int level[16];
         int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
         int i = 0;
-        if (t1) { uint32_t s = br.u(t1); for (; i < t1; i++) level[i] = 1 - 2 * (int)((s >> (t1 - 1 - i)) & 1); }
+        {   // trailing_ones_sign_flag x t1: the next three bits give up to three signs (entries past t1 are overwritten below)
+            const uint32_t s3 = br.peek(3);
+            level[0] = 1 - (int)((s3 >> 1) & 2); level[1] = 1 - (int)(s3 & 2); level[2] = 1 - (int)((s3 << 1) & 2);
+            br.skip(t1); i = t1;
+        }
         for (; i < total; i++) {
             uint32_t w = br.peek(32);
             if (w == 0) return -1;
             int prefix = __builtin_clz(w);
-            br.skip(prefix + 1);
-            int code = (prefix < 15 ? prefix : 15) << suffix_len;
-            if (suffix_len > 0 || prefix >= 14) {
+            int code;
+            if (prefix < 14) {                                // prefix, stop bit and suffix (at most 20 bits) are all inside w: one skip
+                code = (prefix << suffix_len) + (int)((w >> (31 - prefix - suffix_len)) & ((1u << suffix_len) - 1));
+                br.skip(prefix + 1 + suffix_len);
+            } else {
+                br.skip(prefix + 1);
+                code = (prefix < 15 ? prefix : 15) << suffix_len;
                 int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
                 if (size > 0) code += (int)br.u(size);
+                if (prefix >= 15 && suffix_len == 0) code += 15;
+                if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
             }
-            if (prefix >= 15 && suffix_len == 0) code += 15;
-            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
             if (i == t1 && t1 < 3) code += 2;
             int lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
             level[i] = lv;
@@ -500,7 +508,8 @@ struct P {
         br.skip(len);
         return (int)(e >> 8);
     }
-    __attribute__((always_inline)) inline bool residual_fast(BitReader &br, int cbp, uint32_t &flags, uint32_t &bits, uint32_t &cbm) {
+    // residual() of a CAVLC macroblock without the 8x8 transform: coded_block_pattern cbp, i16 = Intra16x16 (DC block + 15-level AC blocks)
+    __attribute__((always_inline)) inline bool residual_fast(BitReader &br, int cbp, const bool i16, uint32_t &flags, uint32_t &bits, uint32_t &cbm) {
         static const uint8_t ident[16] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15};
         static const uint8_t kWin[16] = {9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36};      // block (decoding order) -> window index (by + 1) * 8 + bx + 1
         static const uint8_t kRas[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};                 // ... -> raster index by * 4 + bx
@@ -509,10 +518,16 @@ struct P {
         const uint8_t *ta = nA >= 0 ? &cx.tc[(size_t)nA * 24] : nullptr, *tb = nB >= 0 ? &cx.tc[(size_t)nB * 24] : nullptr;
         flags = bits = cbm = 0;
         memset(tc, 0, 24);
-        if (cbp & 15) {
+        if ((cbp & 15) || i16) {
             memset(w, 0, sizeof w);
             if (tb) memcpy(w + 1, tb + 12, 4); else memset(w + 1, 64, 4);
             for (int j = 0; j < 4; j++) w[8 * (j + 1)] = ta ? ta[4 * j + 3] : 64;
+            if (i16) {                                        // Intra16x16 DC levels: always 16 slots in the stream
+                int16_t *d = alloc_coef(16); if (!d) return false;
+                const int tk = token_fast(br, nc_of(w[8] + w[1]));
+                if (tk < 0 || (tk && levels_of(br, tk >> 2, tk & 3, 16, 0, d, kZigzag4) < 0)) { err = "entropy error (Intra16x16 DC)"; return false; }
+            }
+            const int max_num = i16 ? 15 : 16, first = i16 ? 1 : 0;
             for (int b8 = 0; b8 < 4; b8++) {
                 if (!(cbp & (1 << b8))) continue;
                 for (int k = 0; k < 4; k++) {
@@ -523,7 +538,7 @@ struct P {
                     if (!tk) continue;
                     const int total = tk >> 2;
                     int16_t *d = out.coef + out.coef_count;
-                    if (levels_of(br, total, tk & 3, 16, 0, d, kZigzag4) < 0) { err = "entropy error (luma block)"; return false; }
+                    if (total > max_num || levels_of(br, total, tk & 3, max_num, first, d, kZigzag4) < 0) { err = "entropy error (luma block)"; return false; }
                     w[wi] = (uint8_t)total; tc[kRas[blk]] = (uint8_t)total; bits |= 1u << blk; out.coef_count += 16;
                 }
             }
@@ -579,7 +594,7 @@ struct P {
             qp += dqp; if (qp < 0) qp += 52; else if (qp > 51) qp -= 52;
             const uint32_t coef_off = out.coef_count;
             uint32_t flags, bits, cbm;
-            if (!residual_fast(br, cbp, flags, bits, cbm)) return false;
+            if (!residual_fast(br, cbp, false, flags, bits, cbm)) return false;
             put_inter16(r, refi, px + dx, py + dy, coef_off, flags, bits, cbm);
         } else {
             memset(tc, 0, 24);
@@ -1030,7 +1045,14 @@ struct P {
             last_dqp = dqp != 0;
         } else last_dqp = false;
         r->qp = (uint8_t)qp;
-        if (cbp > 0 || i16) { if (!residual(r, cbp, i16, t8, itype >= 0)) return false; }
+        if ((cbp > 0 || i16) && !cb && !t8 && !canon) {
+            BitReader b = br;                                  // (a local copy lives in registers, see parse_slice_data)
+            uint32_t fl, bits, cbm;
+            const bool ok = i16 ? residual_fast(b, cbp, true, fl, bits, cbm) : residual_fast(b, cbp, false, fl, bits, cbm);
+            br = b;
+            if (!ok) return false;
+            r->flags |= (uint8_t)fl; r->cbp_blk = (uint16_t)bits; r->cbp_cac = (uint8_t)cbm;
+        } else if (cbp > 0 || i16) { if (!residual(r, cbp, i16, t8, itype >= 0)) return false; }
         if (err) return false;
         if (cb ? cb->overrun : br.overrun()) { err = "macroblock data truncated"; return false; }
         if (canon && t8) r->kind |= 16;                        // digest only: restored below

@@ -10,7 +10,7 @@ for rec in out.split("\n\n"):
     l = [x for x in rec.split("\n") if x]
     if len(l) < 2: continue
     n += 1
-    outer[l[-2].split("(")[0][-50:]] += 1; inner[l[0].split("(")[0][-50:]] += 1; lines[l[1].split("/")[-1].rsplit(":", 1)[0]] += 1
+    f = lambda t: t.replace("(anonymous namespace)::", "").split("(")[0][-50:]; outer[f(l[-2])] += 1; inner[f(l[0])] += 1; lines[l[1].split("/")[-1].rsplit(":", 1)[0]] += 1
 print(n, "samples")
 for title, c, k in (("function", outer, 14), ("innermost inlined", inner, 24), ("line", lines, 60)):
     print("--", title)
