@@ -223,6 +223,7 @@ def main():
     e0 = eng()
     b0 = (L.jm_amddec_get_stat(handles[0], b"eng_batches"), L.jm_amddec_get_stat(handles[0], b"eng_batch_pics"))
     et0 = (L.jm_amddec_get_stat(handles[0], b"eng_launch_ns"), L.jm_amddec_get_stat(handles[0], b"eng_complete_ns"))
+    fm0 = [L.jm_amddec_get_stat(handles[0], k) for k in (b"eng_forms", b"eng_form_decoders", b"eng_form_pending")]
     jb0 = [L.jm_amddec_get_stat(h, b"job_bytes") for h in handles]
     pic0 = [L.jm_amddec_get_stat(h, b"pictures") for h in handles]
     for i in range(S):
@@ -278,6 +279,11 @@ def main():
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
     chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"), L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"))   # whole run
+    dfr = sum(L.jm_amddec_get_stat(h, b"direct_frames") for h in handles)
+    direct_stat = {"sdma_engines": hex(L.jm_amddec_get_stat(handles[0], b"copy_engines")), "frames_whole_run": int(dfr), "caller_wait_us_per_frame": round(sum(L.jm_amddec_get_stat(h, b"direct_ns") for h in handles) / 1e3 / max(dfr, 1), 1)}
+    fm1 = [L.jm_amddec_get_stat(handles[0], k) for k in (b"eng_forms", b"eng_form_decoders", b"eng_form_pending")]
+    forms = max(1, fm1[0] - fm0[0])
+    form_stat = {"decoders_waiting_per_batch_formed": round((fm1[1] - fm0[1]) / forms, 2), "pictures_waiting_per_batch_formed": round((fm1[2] - fm0[2]) / forms, 2)}   # timed region, ordinary lane
     eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4), "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
@@ -519,7 +525,7 @@ def main():
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "stream_ids": [stream_ids[0], stream_ids[-1]], "distinct_streams": len(set(datas)),
                    "bitstream_bytes_per_stream": int(sum(len(d) for d in datas) / S), "stream_generation_s": round(gen_s, 1),
-                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (two of five handles: synchronous DMA from device staging; the others: pinned slot + memcpy)"},
+                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (one copy-engine transfer per frame from device staging, jmcodec_amd/csrc/host_copy.h)"},
         "frames": frames_total,
         "bit_exact": bit_exact, "frames_checked": int(frames_checked), "bit_exact_check": check_note,
         "decode_errors": int(errors),
@@ -540,10 +546,12 @@ def main():
                                      "upper estimate for these access shapes), traffic_raw = FETCH_SIZE + WRITE_SIZE as counted",
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
-        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms,
+        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms, "formation": form_stat, "direct_output": direct_stat,
                    "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2])},
-        "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 63.0, "unit": "GB/s",
-                     "note": "tight frames: k_packout -> device staging, then copy engine -> caller's buffer (or -> pinned host slot ahead of time + memcpy); rate = frames/s x frame bytes per GPU"},
+        "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 52.5, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 52.5, 4),
+                     "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> caller's buffer); peak = device->host "
+                             "rate measured on this platform with two SDMA engines at once (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 52.5 GB/s = 16.9 k frames/s of 1080p); "
+                             "achieved = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
         "roofline_frame": {"alg_bytes_per_frame": int(A), "job_bytes_per_frame": int(J),

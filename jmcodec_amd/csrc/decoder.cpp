@@ -3,6 +3,7 @@
 #include <pthread.h>
 #include <time.h>
 #include "engine.h"
+#include "host_copy.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
@@ -69,6 +70,7 @@ Decoder::~Decoder() {
     // wait until no worker still references this object
     { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0 && parse_pending_ == 0; }); }
     { std::lock_guard<std::mutex> lk(submit_mtx_); }
+    forget_caller_buffers();
     gpu_close();
     delete eng_state_;
     if (trace_on_ && !trace_.empty()) {
@@ -95,6 +97,7 @@ int Decoder::set_option(const char *key, long long v) {
     std::string k(key);
     if (k == "parse_only") parse_only_ = v != 0;
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
+    else if (k == "display_delay") display_delay_ = (int)std::max(0ll, std::min(v, (long long)kJobSlots - 4));
     else if (k == "fast_parse") fast_parse_ = v != 0;        // 0: the general macroblock path only (tests)
     else if (k == "job_digest") { want_job_digest_ = v != 0; if (want_job_digest_) sync_mode_ = true; }      // tests: FNV-1a over every picture's job list as the device gets it
     else if (k == "sync") sync_mode_ = v != 0;
@@ -117,6 +120,9 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "pictures") return stat_pictures_;
     if (k == "job_bytes") return stat_job_bytes_;
     if (k == "errors") return stat_errors_;
+    if (k == "copy_engines") return copier_ ? (long long)copier_->engine_mask() : 0;      // SDMA engines the direct route uses (bit mask)
+    if (k == "direct_frames") return stat_direct_;
+    if (k == "direct_ns") return stat_direct_ns_;             // ... and the time their callers spent waiting for them             // frames that went out by the "direct" route (one DMA into the caller's registered buffer)
     if (k == "device_wait_errors") return stat_wait_errors_;
     if (k == "intra_mbs") return stat_intra_mbs_;
     if (k == "coef_int16") return stat_coef_;
@@ -147,6 +153,9 @@ long long Decoder::get_stat(const char *key) const {
             if (k == std::string("k_") + kn[i] + "_alg_bytes") return es.alg_bytes[i];
         }
         if (k == "eng_batches") return es.batches;
+        if (k == "eng_forms") return es.forms;
+        if (k == "eng_form_decoders") return es.form_decoders;
+        if (k == "eng_form_pending") return es.form_pending;
         if (k == "eng_batch_pics") return es.batch_pics;
         if (k == "eng_chain_batches") return es.chain_batches;
         if (k == "eng_chain_pics") return es.chain_pics;
@@ -166,29 +175,35 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
     if (codec_type != 0 && codec_type != 1) { fail("only codec_type 0 (H.264) and 1 (HEVC) are implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
+    if (const char *dd = getenv("JM_AMD_DEC_DISPLAY_DELAY")) display_delay_ = std::max(0, std::min(atoi(dd), kJobSlots - 4));
     if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;
     out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
     if (!parse_only_ && !gpu_open()) return -1;
     // Where a display frame waits for jm_nvdec_output_frame.  k_packout writes the tight frame into a device staging buffer of the output slot; then
-    //   pinned : a copy engine moves it to the slot's pinned host buffer ahead of time, jm_nvdec_output_frame is one CPU memcpy (0.3 ms of CPU per 1080p frame);
-    //   fetch  : it stays in device staging and jm_nvdec_output_frame copies it straight into the caller's buffer with one synchronous DMA (no CPU copy:
-    //            that memcpy was 30 % of the host CPU time per frame, and the host CPU budget bounds the rate, DESIGN.md section 6 -- but the synchronous
-    //            copies of a device queue behind each other, ~90 us each, ~11 k frames/s).
-    // Default: the route is fixed per handle, two of every five handles fetch (JM_AMD_DEC_OUT_FETCH="a/b"; round-1 measurements: 1/2 is the fastest when
-    // it works, 13.4-14.5 k frames/s, but 3 runs of 10 fell into a second regime at 6.8-7.0 k; 2/5 gave 12.3-13.7 k in 8 of 8; 1/3 12.7-13.6 k with one
-    // 10.0 k; 1/4 10.6-12.9 k).  JM_AMD_DEC_OUT_FETCH=auto chooses per FRAME instead -- fetch when no other thread is inside such a copy at the moment the
-    // frame is queued (JM_AMD_DEC_FETCH_LIMIT) -- which needs no tuning but measured no better in round 2 (32 streams: 11.7-12.4 k against 12.4 k on the
-    // same box; 8 streams: 9.2 k against 10.0 k), so it is not the default.  JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.
+    //   direct : (default) it stays there, and jm_nvdec_output_frame moves it into the caller's buffer with ONE copy-engine transfer on the ROCr layer
+    //            (host_copy.h): no staging hop, no CPU copy, the caller asleep meanwhile.  With three SDMA engines in turn the PCIe link is what bounds
+    //            the rate: 16.8-17.0 k frames/s of 1080p at 0.63 ms of CPU per frame (32 streams), against 14.7 k at 0.89 ms for the mix below;
+    //   pinned : a copy engine moves it to the slot's pinned host buffer ahead of time, jm_nvdec_output_frame is one CPU memcpy (0.3-0.57 ms of CPU per frame);
+    //   fetch  : it stays in device staging and jm_nvdec_output_frame is a plain synchronous hipMemcpy (the copies of a process queue behind each
+    //            other on the one engine the HIP runtime uses for this direction: 11.7 k frames/s).
+    // JM_AMD_DEC_OUT_FETCH = "direct" | "a/b" (a of every b handles fetch, the rest pinned: the round-1 default was 2/5) | "auto" (per frame: fetch when
+    // no other thread is inside such a copy); JM_AMD_DEC_OUT_PINNED=1 = pinned slots for every handle.  When the ROCr layer cannot be reached the
+    // default falls back to 2/5.
     {
         int fa = 2, fb = 5;
-        out_route_ = 2;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned
         const char *e = getenv("JM_AMD_DEC_OUT_FETCH");
+        out_route_ = 3;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned, 3 direct
         if (getenv("JM_AMD_DEC_OUT_PINNED") || !out_via_copy_engine_) out_route_ = 2;
         else if (e && !strcmp(e, "auto")) out_route_ = 0;
-        else { if (e && (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0)) { fa = 2; fb = 5; } out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
-        out_fetch_ = out_route_ == 1;
+        else if (e && strcmp(e, "direct")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 2; fb = 5; } out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
+        if (out_route_ == 3 && !parse_only_) {
+            copier_ = HostCopier::get(device_);
+            if (copier_) out_sig_ = copier_->new_signal();
+            if (!copier_ || !out_sig_) { copier_ = nullptr; out_route_ = (handle_index_ % 5) < 2 ? 1 : 2; }
+        }
+        out_fetch_ = out_route_ == 1 || out_route_ == 3;
         if (const char *l = getenv("JM_AMD_DEC_FETCH_LIMIT")) fetch_limit_ = atoi(l);
     }
     if (engine_) engine_->set_profile(profile_);
@@ -338,7 +353,7 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     o->w = disp_w_; o->h = disp_h_;
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!device_output_ && out_route_ != 1 && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if (!device_output_ && out_route_ != 1 && out_route_ != 3 && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
         if ((out_via_copy_engine_ || device_output_) && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
         o->bytes = frame_bytes_;
     }
@@ -1019,6 +1034,12 @@ int Decoder::pop_output(bool block) {
     for (;;) {
         if (!ready_.empty()) {
             OutSlot *o = ready_.front();
+            // Display delay (the reference asks its parser for ulMaxDisplayDelay = 2, nv_dec.cpp:341), counted on the INPUT side: while input keeps
+            // coming, a frame is handed out only when display_delay_ pictures of this handle are still on their way (being parsed, waiting for a
+            // batch, on the device) -- the caller answers a withheld frame by feeding the next NAL, so every handle has pictures waiting when the
+            // engine forms a batch, however long its caller stays in jm_nvdec_output_frame.  Finished frames pile up meanwhile: beyond a few, they
+            // go out anyway (they hold output slots).  The end of the stream (block) drains everything.
+            if (!block && outstanding_ < display_delay_ && (int)ready_.size() <= 6) return 0;
             if (!o->ready) { if (!block) return 0; cv_.wait(lk); continue; }
             ready_.pop_front();
             cur_out_ = o;
@@ -1088,14 +1109,43 @@ int Decoder::output(uint8_t *out, int *out_len) {
         // hipHostRegister + hipMemcpyAsync + hipEventSynchronize(hipEventBlockingSync) 4.3 k at 3.6 ms; the same with a sleeping
         // hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms; this form 10.7-11.4 k at 0.96-1.0 ms.
         hipSetDevice(device_);
-        if (engine_) engine_->fetch_begin();
-        const hipError_t ce = hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost);
-        if (engine_) engine_->fetch_end();
-        if (ce != hipSuccess) return -1;
+        // route "direct" (host_copy.h): one copy-engine transfer into the caller's page-locked buffer, this thread asleep meanwhile
+        void *dst = out_route_ == 3 && copier_ ? caller_buffer_locked(out, (size_t)need) : nullptr;
+        const auto c0 = std::chrono::steady_clock::now();
+        if (dst && copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_)) { stat_direct_++; stat_direct_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count(); }
+        else {
+            if (engine_) engine_->fetch_begin();
+            const hipError_t ce = hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost);
+            if (engine_) engine_->fetch_end();
+            if (ce != hipSuccess) return -1;
+        }
     }
     else memset(out, 0, (size_t)need);
     *out_len = need;
     return need;
+}
+
+// The address the copy engines use for the caller's buffer [p, p + n), or nullptr while it is not page-locked.  A buffer is locked the second time
+// it is passed in: a caller that brings a fresh buffer for every frame must not pay a lock per frame.  The driver tracks the address range, not the
+// pages (an munmap / mmap of the same range is followed); everything is unlocked when the handle goes away.
+void *Decoder::caller_buffer_locked(uint8_t *p, size_t n) {
+    for (auto &b : caller_bufs_) if (b.ptr == p && b.n < n) { if (b.locked) copier_->unlock(b.ptr); b = CallerBuf(); }   // the same buffer, now for larger frames
+    for (auto &b : caller_bufs_) if (b.ptr == p && b.n >= n) {
+        if (b.locked) return b.locked;
+        if (++b.seen < 2) return nullptr;
+        b.locked = copier_->lock(p, b.n);
+        if (!b.locked) b.seen = -1000000;                      // (cannot be locked: stop trying)
+        return b.locked;
+    }
+    CallerBuf &b = caller_bufs_[caller_buf_next_++ % kCallerBufs];
+    if (b.locked) copier_->unlock(b.ptr);
+    b = CallerBuf(); b.ptr = p; b.n = n; b.seen = 1;
+    return nullptr;
+}
+void Decoder::forget_caller_buffers() {
+    if (!copier_) return;
+    for (auto &b : caller_bufs_) { if (b.locked) copier_->unlock(b.ptr); b = CallerBuf(); }
+    copier_->free_signal(out_sig_); out_sig_ = 0;
 }
 
 // the current display frame as it sits in device memory (tight NV12 / I420), valid until the next decode call

@@ -130,6 +130,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         it = pending_.erase(it);
     }
     if (b.pics.empty()) return false;
+    if (lane_idx < kPLanes) { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size(); st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
     // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
     // workgroups the GPU holds (chain.hip), and its work list must fit the table
     auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + 2 * ((p.mb_h + 15) / 16); };

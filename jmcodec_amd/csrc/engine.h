@@ -68,6 +68,7 @@ struct EnginePic {
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
     double ns[5] = {0, 0, 0, 0, 0}; long long launches[5] = {0, 0, 0, 0, 0}, pics[5] = {0, 0, 0, 0, 0}, alg_bytes[5] = {0, 0, 0, 0, 0};
     long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0, chain_recoveries = 0;
+    long long forms = 0, form_decoders = 0, form_pending = 0;   // ordinary-lane batches formed; decoders that had a picture waiting then; pictures waiting then
     long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
 };
 
@@ -120,7 +121,7 @@ private:
         int head = 0, tail = 0, inflight = 0;
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
-    std::atomic<int> chain_max_streams_{12};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    std::atomic<int> chain_max_streams_{16};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);

@@ -1,0 +1,134 @@
+// jmcodec_amd/csrc/host_copy.cpp -- see host_copy.h
+#include "host_copy.h"
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <atomic>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include <sys/prctl.h>
+#include <vector>
+
+namespace jmamd {
+
+namespace {
+struct Agents { std::vector<hsa_agent_t> gpus, cpus; };
+hsa_status_t on_agent(hsa_agent_t a, void *p) {
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    Agents *ag = (Agents *)p;
+    if (t == HSA_DEVICE_TYPE_GPU) ag->gpus.push_back(a); else if (t == HSA_DEVICE_TYPE_CPU) ag->cpus.push_back(a);
+    return HSA_STATUS_SUCCESS;
+}
+}  // namespace
+
+HostCopier *HostCopier::get(int dev) {
+    static std::mutex m; static HostCopier *tab[64]; static bool tried[64];
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(m);
+    if (tried[dev]) return tab[dev];
+    tried[dev] = true;
+    if (getenv("JM_AMD_DEC_NO_HSA_COPY")) return nullptr;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;           // (reference-counted: the HIP runtime holds the first reference)
+    Agents ag;
+    hsa_iterate_agents(on_agent, &ag);
+    if (ag.cpus.empty()) return nullptr;
+    // the HSA agent of this HIP device: same PCI location
+    int bus = -1, pdev = -1, dom = -1;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId, dev) != hipSuccess ||
+        hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    HostCopier *c = nullptr;
+    for (hsa_agent_t g : ag.gpus) {
+        uint32_t bdf = 0, d = 0;
+        if (hsa_agent_get_info(g, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) continue;
+        (void)hsa_agent_get_info(g, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &d);
+        if ((int)((bdf >> 8) & 0xff) == bus && (int)((bdf >> 3) & 0x1f) == pdev && (int)d == dom) { c = new HostCopier(); c->gpu_ = g.handle; break; }
+    }
+    if (!c) return nullptr;
+    c->cpu_ = ag.cpus[0].handle;
+    // Which engines?  An MI355X shows sixteen; measured with one packed 1080p frame each (tools/sdma_probe.cpp): four move 47.6 GB/s over PCIe, the
+    // rest serve xGMI and manage 12 GB/s; two or three of the fast ones together fill the link (52.5 GB/s = 16.9 k frames/s).  The engine the HIP
+    // runtime itself prefers for host -> device traffic must be left alone (frames queue behind its work: 11.7 k frames/s with it, 16.9 k without).
+    // So: time one copy on every available engine, keep those within 1.5x of the best, drop the host -> device ones, use up to three in turn.
+    uint32_t avail = 0, h2d = 0, d2h = 0;
+    hsa_agent_t ca{c->cpu_}, ga{c->gpu_};
+    if (hsa_amd_memory_copy_engine_status(ca, ga, &avail) != HSA_STATUS_SUCCESS) avail = 0;
+    if (hsa_amd_memory_get_preferred_copy_engine(ga, ca, &h2d) != HSA_STATUS_SUCCESS) h2d = 0;
+    if (hsa_amd_memory_get_preferred_copy_engine(ca, ga, &d2h) != HSA_STATUS_SUCCESS) d2h = 0;
+    if (const char *ev = getenv("JM_AMD_DEC_COPY_ENGINES")) {     // explicit: comma-separated engine ids (hsa_amd_sdma_engine_id_t bit values)
+        for (const char *q = ev; *q && c->n_engines_ < 4;) { char *end; unsigned long v = strtoul(q, &end, 0); if (end == q) break; if (v && (avail & v)) c->engines_[c->n_engines_++] = (uint32_t)v; q = *end ? end + 1 : end; }
+    } else {
+        const size_t n = 2u << 20;
+        (void)hipSetDevice(dev);
+        void *dsrc = nullptr, *hbuf = nullptr, *hloc = nullptr;
+        hsa_signal_t sg{0};
+        double t[32]; double best = 1e30;
+        for (auto &x : t) x = 1e30;
+        if (hipMalloc(&dsrc, n) == hipSuccess && posix_memalign(&hbuf, 4096, n) == 0 && (hloc = c->lock(hbuf, n)) != nullptr && hsa_signal_create(1, 0, nullptr, &sg) == HSA_STATUS_SUCCESS) {
+            for (int pass = 0; pass < 2; pass++)                  // (the first pass touches the pages and wakes the engines)
+                for (int b = 0; b < 16; b++) {
+                    const uint32_t e = 1u << b;
+                    if (!(avail & e)) continue;
+                    hsa_signal_store_relaxed(sg, 1);
+                    timespec a, z; clock_gettime(CLOCK_MONOTONIC, &a);
+                    if (hsa_amd_memory_async_copy_on_engine(hloc, ca, dsrc, ga, n, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)e, false) != HSA_STATUS_SUCCESS) continue;
+                    while (hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, 100ull * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) >= 1) {}
+                    clock_gettime(CLOCK_MONOTONIC, &z);
+                    if (pass) { t[b] = (z.tv_sec - a.tv_sec) + 1e-9 * (z.tv_nsec - a.tv_nsec); if (t[b] < best) best = t[b]; }
+                }
+        }
+        (void)hipGetLastError();
+        // (engine 0x1 is where the HIP runtime puts its host -> device copies on this platform whatever the preference query says: last choice)
+        for (int b = 1; b < 16 && c->n_engines_ < 3; b++) if (t[b] <= 1.5 * best && !(h2d & (1u << b))) c->engines_[c->n_engines_++] = 1u << b;
+        if (!c->n_engines_ && t[0] <= 1.5 * best) c->engines_[c->n_engines_++] = 1u;
+        if (!c->n_engines_) for (uint32_t e = 1; e && c->n_engines_ < 2; e <<= 1) if (d2h & e) c->engines_[c->n_engines_++] = e;     // (nothing measured: the runtime's recommendation)
+        if (sg.handle) (void)hsa_signal_destroy(sg);
+        if (hloc) c->unlock(hbuf);
+        free(hbuf);
+        if (dsrc) (void)hipFree(dsrc);
+    }
+    if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d: output copies on SDMA engines 0x%x 0x%x 0x%x (available 0x%x, host->device preference 0x%x, device->host preference 0x%x)\n", dev, c->engines_[0], c->engines_[1], c->engines_[2], avail, h2d, d2h);
+    tab[dev] = c;
+    return c;
+}
+
+void *HostCopier::lock(void *p, size_t n) {
+    hsa_agent_t g{gpu_}; void *ap = nullptr;
+    return hsa_amd_memory_lock(p, n, &g, 1, &ap) == HSA_STATUS_SUCCESS ? ap : nullptr;
+}
+void HostCopier::unlock(void *p) { (void)hsa_amd_memory_unlock(p); }
+
+uint64_t HostCopier::new_signal() { hsa_signal_t s; return hsa_signal_create(1, 0, nullptr, &s) == HSA_STATUS_SUCCESS ? s.handle : 0; }
+void HostCopier::free_signal(uint64_t s) { if (s) (void)hsa_signal_destroy(hsa_signal_t{s}); }
+
+bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
+    static std::atomic<unsigned> turn{0};
+    if (!sig) return false;
+    hsa_signal_t s{sig}; hsa_agent_t ca{cpu_}, ga{gpu_};
+    hsa_signal_store_relaxed(s, 1);
+    const uint32_t e = n_engines_ ? engines_[turn.fetch_add(1, std::memory_order_relaxed) % (unsigned)n_engines_] : 0;
+    hsa_status_t st = e ? hsa_amd_memory_async_copy_on_engine(dst, ca, src, ga, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)e, false) : HSA_STATUS_ERROR;
+    if (st != HSA_STATUS_SUCCESS) st = hsa_amd_memory_async_copy(dst, ca, src, ga, n, 0, nullptr, s);      // (engine busy / not selectable: the runtime's own choice)
+    if (st != HSA_STATUS_SUCCESS) return false;
+    // A failed copy sets the signal negative; a healthy one takes ~60 us plus its place in the engine's queue.  The wait is a sleep-and-look loop on the
+    // signal's value (a plain load): hsa_signal_wait spins for ~200 us before it blocks, which is exactly the CPU this route exists to save.
+    static thread_local bool slack_set = false;
+    if (!slack_set) { slack_set = true; prctl(PR_SET_TIMERSLACK, 2000ul, 0, 0, 0); }   // this thread's sleeps end within 2 us of their time (the default slack is 50 us: every look would come ~65 us after the last)
+    struct timespec ts = {0, 40 * 1000};
+    long total_ns = 0;
+    for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute)
+        nanosleep(&ts, nullptr);
+        total_ns += ts.tv_nsec;
+        const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
+        if (v < 1) return v == 0;
+        // the next look comes after a quarter of the time waited so far (at least 15 us, at most 250 us): a lone copy is seen within a few
+        // microseconds of its end, one that queues behind thirty others costs a dozen looks instead of a hundred
+        long next = total_ns / 4; if (next < 15000) next = 15000; if (next > 250000) next = 250000;
+        ts.tv_nsec = next;
+    }
+    return false;
+}
+
+}  // namespace jmamd

@@ -500,11 +500,11 @@ def _md5_frames(blob, fs):
     return [md5(blob[i:i + fs]) for i in range(0, len(blob), fs)]
 
 
-@pytest.mark.parametrize("fetch", ["1/2", "0/1", "1/1"])
+@pytest.mark.parametrize("fetch", ["1/2", "0/1", "1/1", "direct"])
 def test_c4_slice_8x1080p_concurrent(oracle, fetch, monkeypatch):
     """BASELINE config C4's per-GPU slice: 8 DISTINCT 1080p Baseline streams (SURVEY 8d seeds, stream_id 0..7) decoded concurrently by 8
     handles on 8 threads, one IDR period (30 frames) each, every frame compared with the CPU oracle.  JM_AMD_DEC_OUT_FETCH forces the
-    output routes: alternating, all through pinned slots, all fetched from device staging."""
+    output routes: alternating, all through pinned slots, all fetched from device staging, all by DMA into the caller's registered buffer."""
     from concurrent.futures import ThreadPoolExecutor
     monkeypatch.setenv("JM_AMD_DEC_OUT_FETCH", fetch)
     fs = 1920 * 1080 * 3 // 2
@@ -518,6 +518,7 @@ def test_c4_slice_8x1080p_concurrent(oracle, fetch, monkeypatch):
         with api.JmAmdDec(0, 1) as d:
             got[i] = [md5(f) for f in d.decode_stream(datas[i])]
             errs[i] = d.stat("errors")
+            assert fetch != "direct" or d.stat("direct_frames") >= 28          # (the buffer is registered the second time it is seen)
     ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
     [t.start() for t in ts]
     [t.join() for t in ts]
