@@ -70,7 +70,7 @@ Decoder::~Decoder() {
     // wait until no worker still references this object
     { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0 && parse_pending_ == 0; }); }
     { std::lock_guard<std::mutex> lk(submit_mtx_); }
-    forget_caller_buffers();
+    if (copier_) { copier_->free_signal(out_sig_); out_sig_ = 0; }
     gpu_close();
     delete eng_state_;
     if (trace_on_ && !trace_.empty()) {
@@ -1110,9 +1110,13 @@ int Decoder::output(uint8_t *out, int *out_len) {
         // hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms; this form 10.7-11.4 k at 0.96-1.0 ms.
         hipSetDevice(device_);
         // route "direct" (host_copy.h): one copy-engine transfer into the caller's page-locked buffer, this thread asleep meanwhile
-        void *dst = out_route_ == 3 && copier_ ? caller_buffer_locked(out, (size_t)need) : nullptr;
+        // The caller's buffer is page-locked for the duration of this call only (1.4 us per lock / unlock pair measured, tools/sdma_probe.cpp): a lock kept
+        // between calls goes stale when the caller unmaps the buffer and the address range is mapped again (the runtime aborted in that test).
         const auto c0 = std::chrono::steady_clock::now();
-        if (dst && copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_)) { stat_direct_++; stat_direct_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count(); }
+        void *dst = out_route_ == 3 && copier_ ? copier_->lock(out, (size_t)need) : nullptr;
+        const bool went = dst && copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_);
+        if (dst) copier_->unlock(out);
+        if (went) { stat_direct_++; stat_direct_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count(); }
         else {
             if (engine_) engine_->fetch_begin();
             const hipError_t ce = hipMemcpy(out, cur_out_->dev, (size_t)need, hipMemcpyDeviceToHost);
@@ -1123,29 +1127,6 @@ int Decoder::output(uint8_t *out, int *out_len) {
     else memset(out, 0, (size_t)need);
     *out_len = need;
     return need;
-}
-
-// The address the copy engines use for the caller's buffer [p, p + n), or nullptr while it is not page-locked.  A buffer is locked the second time
-// it is passed in: a caller that brings a fresh buffer for every frame must not pay a lock per frame.  The driver tracks the address range, not the
-// pages (an munmap / mmap of the same range is followed); everything is unlocked when the handle goes away.
-void *Decoder::caller_buffer_locked(uint8_t *p, size_t n) {
-    for (auto &b : caller_bufs_) if (b.ptr == p && b.n < n) { if (b.locked) copier_->unlock(b.ptr); b = CallerBuf(); }   // the same buffer, now for larger frames
-    for (auto &b : caller_bufs_) if (b.ptr == p && b.n >= n) {
-        if (b.locked) return b.locked;
-        if (++b.seen < 2) return nullptr;
-        b.locked = copier_->lock(p, b.n);
-        if (!b.locked) b.seen = -1000000;                      // (cannot be locked: stop trying)
-        return b.locked;
-    }
-    CallerBuf &b = caller_bufs_[caller_buf_next_++ % kCallerBufs];
-    if (b.locked) copier_->unlock(b.ptr);
-    b = CallerBuf(); b.ptr = p; b.n = n; b.seen = 1;
-    return nullptr;
-}
-void Decoder::forget_caller_buffers() {
-    if (!copier_) return;
-    for (auto &b : caller_bufs_) { if (b.locked) copier_->unlock(b.ptr); b = CallerBuf(); }
-    copier_->free_signal(out_sig_); out_sig_ = 0;
 }
 
 // the current display frame as it sits in device memory (tight NV12 / I420), valid until the next decode call

@@ -217,14 +217,11 @@ private:
     std::atomic<long long> stat_pictures_{0}, stat_job_bytes_{0}, stat_errors_{0}, stat_intra_mbs_{0}, stat_coef_{0}, stat_wait_errors_{0};
     SyntaxDigest digest_;
     bool fast_parse_ = true, want_job_digest_ = false;
-    // output route "direct" (host_copy.h): buffers the caller has passed to jm_nvdec_output_frame (at most kCallerBufs), page-locked on second sight
-    struct CallerBuf { uint8_t *ptr = nullptr; size_t n = 0; int seen = 0; void *locked = nullptr; };
-    static constexpr int kCallerBufs = 4;
-    CallerBuf caller_bufs_[kCallerBufs]; int caller_buf_next_ = 0; long long stat_direct_ = 0, stat_direct_ns_ = 0;
+    // output route "direct" (host_copy.h)
+    long long stat_direct_ = 0, stat_direct_ns_ = 0;
     HostCopier *copier_ = nullptr; uint64_t out_sig_ = 0;
-    int display_delay_ = 0;                    // frames kept queued behind the one handed out (option "display_delay", JM_AMD_DEC_DISPLAY_DELAY)
-    void *caller_buffer_locked(uint8_t *p, size_t n);
-    void forget_caller_buffers(); uint64_t job_digest_ = 1469598103934665603ull;    // option "job_digest" (tests)
+    int display_delay_ = 0;                    // a frame goes out only while this many pictures of the handle are still on their way (option "display_delay", JM_AMD_DEC_DISPLAY_DELAY)
+    uint64_t job_digest_ = 1469598103934665603ull;    // option "job_digest" (tests)
     // HEVC state (front end only unless noted)
     HevcParamSets hps_; HevcSps hsps_; HevcPps hpps_;
     int h_poc_tid0_ = 0, h_max_dpb_ = 1, h_reorder_ = 0, extra_surf_ = 0; bool h_first_picture_ = true, h_no_rasl_output_ = false, h_seen_eos_ = false;

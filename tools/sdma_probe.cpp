@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 
 static hsa_agent_t g_gpu, g_cpu; static bool g_have_gpu = false, g_have_cpu = false;
 static hsa_status_t on_agent(hsa_agent_t a, void *) {
@@ -63,6 +64,17 @@ int main() {
         wait(0); wait(1);
         double dt = now() - t0; const int frames = 2 + 4 * (reps / 2 - 1);
         printf("engines 0x%02x + 0x%02x: %.1f us per frame, %.1f GB/s\n", es[a], es[b], 1e6 * dt / frames, n * (double)frames / dt / 1e9);
+    }
+    // what page-locking the caller's buffer per call would cost (instead of keeping it locked between calls)
+    {
+        void *p = nullptr, *ap = nullptr; if (posix_memalign(&p, 4096, n)) return 1;
+        memset(p, 1, n);
+        double t0 = now();
+        for (int i = 0; i < reps; i++) { hsa_amd_memory_lock(p, n, &g_gpu, 1, &ap); hsa_amd_memory_unlock(p); }
+        printf("hsa_amd_memory_lock + unlock of %zu bytes: %.1f us per pair\n", n, 1e6 * (now() - t0) / reps);
+        t0 = now();
+        for (int i = 0; i < reps; i++) { hsa_amd_memory_lock(p, n, &g_gpu, 1, &ap); copy(0, 0x2); hsa_signal_store_relaxed(sig[0], 1); hsa_amd_memory_async_copy_on_engine(ap, g_cpu, dev, g_gpu, n, 0, nullptr, sig[0], (hsa_amd_sdma_engine_id_t)0x2, false); wait(0); hsa_amd_memory_unlock(p); }
+        printf("lock + copy + unlock: %.1f us per frame\n", 1e6 * (now() - t0) / reps);
     }
     // the HIP way for comparison
     void *ph = nullptr; hipHostMalloc(&ph, n * 2, hipHostMallocDefault); hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
