@@ -33,7 +33,10 @@ struct Cabac {
     uint32_t range = 510;
     const uint8_t *ptr = nullptr, *start = nullptr, *end = nullptr;
     bool overrun = false;                    // the arithmetic decoder ran past the end of the slice data
-    uint8_t state[CABAC_N_CTX];              // pStateIdx << 1 | valMPS
+    // pStateIdx << 1 | valMPS.  16-bit on purpose: a store through a character type may alias anything, so with uint8_t every context update made the
+    // compiler reload val / pos / range from memory before the next bin (and keep them there); int16 stores cannot alias them.
+    typedef uint16_t State;
+    State state[CABAC_N_CTX];
 
     // 9.3.1.1: context variables from (m, n) and SliceQPY; table 0 = I slices, 1 + cabac_init_idc otherwise
     void init_contexts(int table, int slice_qp) {
@@ -41,7 +44,7 @@ struct Cabac {
         for (int i = 0; i < CABAC_N_CTX; i++) {
             int pre = ((cabac_init_mn[table][i][0] * qp) >> 4) + cabac_init_mn[table][i][1];
             pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
-            state[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)(((pre - 64) << 1) | 1);
+            state[i] = pre <= 63 ? (State)((63 - pre) << 1) : (State)(((pre - 64) << 1) | 1);
         }
     }
     inline void refill() {
@@ -61,7 +64,7 @@ struct Cabac {
 
     // 9.3.3.2.1, without a branch on the decoded symbol (it is the least predictable branch of the whole parser): `m` is all ones when the
     // offset lies in the LPS sub-interval and selects offset, range, next state and bin value arithmetically
-    inline int decision(int ctx) {
+    __attribute__((always_inline)) inline int decision(int ctx) {
         const uint8_t *const tr = kCabacTrans.t;
         const uint32_t s = state[ctx];
         const uint32_t lps = cabac_range_lps[s >> 1][(range >> 6) & 3];
@@ -109,7 +112,7 @@ struct Cabac {
 // forwarding sits on the dependency chain of the arithmetic decoder.  A residual block decodes dozens of bins in a row: it takes a CabacRegs
 // (`CabacRegs r(cb);` ... `r.commit();`), whose scalars never have their address taken and therefore live in registers.  Same arithmetic as above.
 struct CabacRegs {
-    uint64_t val; int pos; uint32_t range; const uint8_t *ptr; const uint8_t *const end; uint8_t *const state; bool overrun; Cabac &home;
+    uint64_t val; int pos; uint32_t range; const uint8_t *ptr; const uint8_t *const end; Cabac::State *const state; bool overrun; Cabac &home;
     explicit CabacRegs(Cabac &c) : val(c.val), pos(c.pos), range(c.range), ptr(c.ptr), end(c.end), state(c.state), overrun(c.overrun), home(c) {}
     inline void commit() { home.val = val; home.pos = pos; home.range = range; home.ptr = ptr; home.overrun = overrun; }
     inline void refill() {

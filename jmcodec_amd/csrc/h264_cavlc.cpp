@@ -734,42 +734,44 @@ struct P {
     // blocks (-1: neighbour macroblock not available)
     int residual_block_ae(int cat, int bit, int fa, int fb, int maxnum, int first, int16_t *dst, const uint8_t *map, bool intra) {
         static const int cbf_off[5] = {0, 4, 8, 12, 16}, sig_off[5] = {0, 15, 29, 44, 47}, abs_off[5] = {0, 10, 20, 30, 39};
+        // the arithmetic decoder's variables in registers for the whole block (h264_cabac.h, CabacRegs): a block is dozens of bins in a row
+        CabacRegs r(*cb);
         if (cat != 5) {
             if (fa < 0) fa = intra; if (fb < 0) fb = intra;
-            if (!cb->decision(85 + cbf_off[cat] + fa + 2 * fb)) return 0;
+            if (!r.decision(85 + cbf_off[cat] + fa + 2 * fb)) { r.commit(); return 0; }
             cx.cbf[addr] |= 1u << bit;
         }
         const int sig_base = cat == 5 ? 402 : 105 + sig_off[cat], last_base = cat == 5 ? 417 : 166 + sig_off[cat];
         const int abs_base = cat == 5 ? 426 : 227 + abs_off[cat];
         uint8_t pos[64]; int n = 0, i;
-        for (i = 0; i < maxnum - 1; i++) {
-            int si = cat == 5 ? cabac_sig8_inc[i] : (cat == 3 ? (i < 2 ? i : 2) : i);
-            if (cb->decision(sig_base + si)) {
-                pos[n++] = (uint8_t)i;
-                int li = cat == 5 ? cabac_last8_inc[i] : (cat == 3 ? (i < 2 ? i : 2) : i);
-                if (cb->decision(last_base + li)) break;
-            }
+        if (cat == 5) {
+            for (i = 0; i < 63; i++) if (r.decision(402 + cabac_sig8_inc[i])) { pos[n++] = (uint8_t)i; if (r.decision(417 + cabac_last8_inc[i])) break; }
+        } else if (cat == 3) {
+            for (i = 0; i < maxnum - 1; i++) { const int si = i < 2 ? i : 2; if (r.decision(sig_base + si)) { pos[n++] = (uint8_t)i; if (r.decision(last_base + si)) break; } }
+        } else {
+            for (i = 0; i < maxnum - 1; i++) if (r.decision(sig_base + i)) { pos[n++] = (uint8_t)i; if (r.decision(last_base + i)) break; }
         }
         if (i == maxnum - 1) pos[n++] = (uint8_t)(maxnum - 1);
         int gt1 = 0, eq1 = 0;
         const int gt1_max = 4 - (cat == 3);
         for (int k = n - 1; k >= 0; k--) {
             int v = 0;
-            if (cb->decision(abs_base + (gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4)))) {
+            if (r.decision(abs_base + (gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4)))) {
                 v = 1;
                 int ctx = abs_base + 5 + (gt1 < gt1_max ? gt1 : gt1_max);
-                while (v < 14 && cb->decision(ctx)) v++;
+                while (v < 14 && r.decision(ctx)) v++;
                 if (v == 14) {
                     int e = 0;
-                    while (cb->bypass()) { v += 1 << e; e++; if (e > 20) { err = "coefficient level out of range"; return -1; } }
-                    while (e--) v += cb->bypass() << e;
+                    while (r.bypass()) { v += 1 << e; e++; if (e > 20) { err = "coefficient level out of range"; return -1; } }    // (the slice is abandoned: nothing to write back)
+                    while (e--) v += r.bypass() << e;
                 }
             }
             int level = v + 1;
             if (level == 1) eq1++; else gt1++;
             if (level > 32767) level = 32767;
-            dst[map[pos[k] + first]] = (int16_t)(cb->bypass() ? -level : level);
+            dst[map[pos[k] + first]] = (int16_t)(r.bypass() ? -level : level);
         }
+        r.commit();
         return n;
     }
     // coded_block_flag of the 4x4 luma block left of / above (bx,by): -1 when the neighbouring macroblock is not available

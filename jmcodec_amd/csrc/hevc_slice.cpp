@@ -104,7 +104,7 @@ void HevcPicParser::init_contexts() {                                  // 9.3.2.
     const int qp = clip3(0, 51, sh_->qp);
     for (int i = 0; i < HEVC_N_CTX; i++) {
         int v = hevc_ctx_init[t][i], pre = clip3(1, 126, ((((v >> 4) * 5 - 45) * qp) >> 4) + ((v & 15) << 3) - 16);
-        cb_.state[i] = pre <= 63 ? (uint8_t)((63 - pre) << 1) : (uint8_t)(((pre - 64) << 1) | 1);
+        cb_.state[i] = pre <= 63 ? (Cabac::State)((63 - pre) << 1) : (Cabac::State)(((pre - 64) << 1) | 1);
     }
 }
 
@@ -702,7 +702,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
     ctb_rs_ = sh.segment_addr; ctb_ts_ = rs2ts_[ctb_rs_];
     if (sh.dependent) {
         if (!dep_valid_) return "dependent slice segment without stored context variables";
-        memcpy(cb_.state, dep_state_, HEVC_N_CTX);
+        memcpy(cb_.state, dep_state_, HEVC_N_CTX * sizeof(Cabac::State));
         qp_prev_ = last_cu_qp_; first_qg_ = false; cu_since_reset_ = false;
     } else { init_contexts(); first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp; }
     qp_y_ = sh.qp; dqp_ = 0; dqp_coded_ = false;
@@ -719,7 +719,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         if (first_in_tile) { if (!first_ctu) init_contexts(); first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp; }
         else if (row_start) {                                           // 9.3.1: synchronisation with the CTB above and to the right
             const int x0 = rx << sps_->log2_ctb, y0 = ry << sps_->log2_ctb;
-            if (wpp_valid_ && avail_zs(x0, y0, x0 + ctb_size_, y0 - ctb_size_)) memcpy(cb_.state, wpp_state_, HEVC_N_CTX);
+            if (wpp_valid_ && avail_zs(x0, y0, x0 + ctb_size_, y0 - ctb_size_)) memcpy(cb_.state, wpp_state_, HEVC_N_CTX * sizeof(Cabac::State));
             else if (!first_ctu) init_contexts();
             first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp;
         }
@@ -727,7 +727,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         parse_sao(ctb_rs_);
         if (!coding_quadtree(rx << sps_->log2_ctb, ry << sps_->log2_ctb, sps_->log2_ctb, 0) || cb_.overrun) return "corrupt slice data";
         jobs_->ctbs[ctb_rs_].intra_count = (uint32_t)jobs_->itbs.size() - jobs_->ctbs[ctb_rs_].intra_first;
-        if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) { memcpy(wpp_state_, cb_.state, HEVC_N_CTX); wpp_valid_ = true; }
+        if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) { memcpy(wpp_state_, cb_.state, HEVC_N_CTX * sizeof(Cabac::State)); wpp_valid_ = true; }
         // a finished CTB row (pictures without tiles: rows complete in order) makes its part of the motion field final
         if (col_out_ && !pps_->tiles && rx == ctb_w_ - 1 && ry * (ctb_size_ >> 4) == exported_rows_) export_motion_rows(exported_rows_, std::min(col_out_->h16, (ry + 1) * (ctb_size_ >> 4)));
         const int end = cb_.terminate();
@@ -744,7 +744,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
             cb_.init_engine(next, cb_.end);
         }
     }
-    if (pps_->dependent_slices) { memcpy(dep_state_, cb_.state, HEVC_N_CTX); dep_valid_ = true; }
+    if (pps_->dependent_slices) { memcpy(dep_state_, cb_.state, HEVC_N_CTX * sizeof(Cabac::State)); dep_valid_ = true; }
     return cb_.overrun ? "corrupt slice data" : "";
 }
 

@@ -81,7 +81,7 @@ private:
     void export_motion_rows(int r0, int r1);               // rows [r0, r1) of the 16x16 motion field -> col_out_
     int exported_rows_ = 0;
     Cabac cb_;
-    uint8_t wpp_state_[CABAC_N_CTX], dep_state_[CABAC_N_CTX]; bool wpp_valid_ = false, dep_valid_ = false;
+    Cabac::State wpp_state_[CABAC_N_CTX], dep_state_[CABAC_N_CTX]; bool wpp_valid_ = false, dep_valid_ = false;
     int poc_ = 0, w_ = 0, h_ = 0, w4_ = 0, h4_ = 0, ctb_w_ = 0, ctb_h_ = 0, ctb_size_ = 0, tb_w_ = 0;
     std::vector<int> rs2ts_, ts2rs_, tile_id_, ctb_slice_;
     std::vector<uint32_t> zs_;                 // MinTbAddrZs
