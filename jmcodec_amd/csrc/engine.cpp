@@ -383,6 +383,7 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         bool wait_err = b.redo;
         for (size_t i = 0; i < b.pics.size(); i++) wait_err |= b.h_err[i] != 0 && b.any_chain;
         if (wait_err) {
+            if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size()); for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n"); }
             // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
             if (ln.inflight > 1) { Batch &nx = ln.ring[(ln.tail + 1) % kBatchRing]; hipEventSynchronize(nx.done); nx.redo = true; }
             recover(ln, b);
