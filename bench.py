@@ -38,7 +38,7 @@ def quota_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("JM_BENCH_STREAMS", "32")))
     ap.add_argument("--frames", type=int, default=60, help="frames per stream per step (multiple of the GOP, 30)")
@@ -548,7 +548,7 @@ def main():
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms, "formation": form_stat, "direct_output": direct_stat,
                    "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2])},
-        "pcie_out": {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 52.5, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 52.5, 4),
+        "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 52.5, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 52.5, 4),
                      "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> caller's buffer); peak = device->host "
                              "rate measured on this platform with two SDMA engines at once (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 52.5 GB/s = 16.9 k frames/s of 1080p); "
                              "achieved = frames/s x frame bytes per GPU"},

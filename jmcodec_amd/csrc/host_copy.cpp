@@ -114,8 +114,11 @@ bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
     if (st != HSA_STATUS_SUCCESS) return false;
     // A failed copy sets the signal negative; a healthy one takes ~60 us plus its place in the engine's queue.  The wait is a sleep-and-look loop on the
     // signal's value (a plain load): hsa_signal_wait spins for ~200 us before it blocks, which is exactly the CPU this route exists to save.
-    static thread_local bool slack_set = false;
-    if (!slack_set) { slack_set = true; prctl(PR_SET_TIMERSLACK, 2000ul, 0, 0, 0); }   // this thread's sleeps end within 2 us of their time (the default slack is 50 us: every look would come ~65 us after the last)
+    // this thread's sleeps must end within a couple of microseconds of their time while it waits here (the default timer slack is 50 us: every look
+    // would come ~65 us after the last); it is the caller's thread, so its own setting is put back afterwards
+    const int old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    prctl(PR_SET_TIMERSLACK, 2000ul, 0, 0, 0);
+    struct Restore { int v; ~Restore() { if (v > 0) prctl(PR_SET_TIMERSLACK, (unsigned long)v, 0, 0, 0); } } restore{old_slack};
     struct timespec ts = {0, 40 * 1000};
     long total_ns = 0;
     for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute)

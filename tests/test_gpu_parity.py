@@ -801,3 +801,13 @@ def test_direct_route_two_handles_one_buffer(oracle):
                 step(k, None)
         assert d0.stat("errors") == 0 and d1.stat("errors") == 0
     assert b"".join(got[0]) == wa and b"".join(got[1]) == wb
+
+
+def test_direct_route_into_pinned_host_memory(oracle):
+    """An application that already page-locked its output buffer with the HIP runtime (hipHostMalloc, here through torch)."""
+    import torch
+    data = streams.generate(**_DIRECT_KW)
+    want = oracle.decode(data, 1)[0]
+    t = torch.empty(320 * 240 * 3 // 2, dtype=torch.uint8, pin_memory=True)
+    frames, (errors, _) = _pull_all(data, 320, 240, lambda i: (t.data_ptr(), t))
+    assert errors == 0 and b"".join(frames) == want
