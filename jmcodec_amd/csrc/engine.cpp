@@ -204,8 +204,8 @@ void Engine::launch(Lane &ln, Batch &b) {
             // cache-bypassing ones at 3 inside k_chain.  k_chain then only deblocks it (its bands find the reconstruction complete).
             // (a reference decoded by the STAGE kernels of this batch -- a picture with intra macroblocks in front of the chain -- rules that out
             // too: k_recon_inter reconstructs all its pictures at once; inside k_chain, which runs after every stage kernel, the order is right)
-            static const bool no_hoist = getenv("JM_AMD_DEC_NO_HOIST") != nullptr;      // experiment
-            if (!refs_in_batch && !no_hoist) q.stages |= PS_RECON;
+            // (measured against reconstructing it inside k_chain: 1 stream 3507 / 3476, 4 streams 8810 / 8315, 8 streams 10157 / 9585 frames/s)
+            if (!refs_in_batch) q.stages |= PS_RECON;
         }
         stages |= b.h_pics[i].stages;
         if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
@@ -248,8 +248,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, ps);
     // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
     // issued one of this batch covers them all without waiting for uploads of later pictures
-    static const bool no_upl_wait = getenv("JM_AMD_DEC_EXP_NOUPLWAIT") != nullptr;   // experiment only
-    if (last_upload && !no_upl_wait) hipStreamWaitEvent(ps, last_upload->uploaded, 0);
+    if (last_upload) hipStreamWaitEvent(ps, last_upload->uploaded, 0);
     bool prep_early = false;
     if (!any_hevc) {
         if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) { launch_deblock_prep(b.d_pics, n, max_mbs, ps); prep_early = true; }

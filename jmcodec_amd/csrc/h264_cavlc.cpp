@@ -55,6 +55,9 @@ static const uint8_t kZigzag8[64] = {
 struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ; len 0xFF => sym = subtable number
 static TokTable g_tok[4];                           // [3]: nC >= 8, the 6-bit fixed-length code in the same format (fast path)
 static const uint8_t kTokClass[17] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3};
+// ... straight from the sum s of the two neighbouring counts in the fast path's window (64 = not available): s < 64 -> nC = (s + 1) >> 1, else nC = s & 31
+struct TokClassOfSum { uint8_t t[129]; TokClassOfSum() { for (int s = 0; s <= 128; s++) { const int nc = s < 64 ? (s + 1) >> 1 : s & 31; t[s] = kTokClass[nc > 16 ? 16 : nc]; } } };
+static const TokClassOfSum kTokClassOfSum;
 static uint16_t g_tok_flc[64];                        // nC >= 8: 6-bit FLC
 static uint16_t g_cdc[256];                           // chroma DC token, max 8 bits
 static uint16_t g_tz[15][512];                        // total_zeros, max 9 bits
@@ -145,6 +148,19 @@ struct P {
             const int b = a - mb_w;
             nB = so[b] == sn ? b : -1; nC = (mb_x + 1 < mb_w && so[b + 1] == sn) ? b + 1 : -1; nD = (mb_x > 0 && so[b - 1] == sn) ? b - 1 : -1;
         } else nB = nC = nD = -1;
+        tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16]; mvd = &cx.mvd[(size_t)a * 32];
+        mvl[0] = mv; mvl[1] = &cx.mv1[(size_t)a * 32]; refl[0] = ref; refl[1] = &cx.refidx1[(size_t)a * 4]; mvdl[0] = mvd; mvdl[1] = &cx.mvd1[(size_t)a * 32];
+    }
+    // the same for the fast loop, which walks a slice's macroblocks in raster order: without FMO a slice is one contiguous run [first, ...), so a
+    // neighbour belongs to this slice exactly when its address is not below the slice's first macroblock (no loads from slice_of)
+    __attribute__((always_inline)) inline void locate_next(int a, int first) {
+        if (a == addr + 1 && mb_x + 1 < mb_w) mb_x++; else { mb_x = a % mb_w; mb_y = a / mb_w; }
+        addr = a;
+        const int b = a - mb_w;
+        nA = (mb_x > 0 && a - 1 >= first) ? a - 1 : -1;
+        nB = b >= first ? b : -1;
+        nC = (mb_x + 1 < mb_w && b + 1 >= first) ? b + 1 : -1;
+        nD = (mb_x > 0 && b - 1 >= first) ? b - 1 : -1;
         tc = &cx.tc[(size_t)a * 24]; mv = &cx.mv[(size_t)a * 32]; ref = &cx.refidx[(size_t)a * 4]; i4m = &cx.i4[(size_t)a * 16]; mvd = &cx.mvd[(size_t)a * 32];
         mvl[0] = mv; mvl[1] = &cx.mv1[(size_t)a * 32]; refl[0] = ref; refl[1] = &cx.refidx1[(size_t)a * 4]; mvdl[0] = mvd; mvdl[1] = &cx.mvd1[(size_t)a * 32];
     }
@@ -498,9 +514,11 @@ struct P {
     // total_coeff of one block (9.2.1) given the sum s of its left and upper neighbours' counts in the window (64 = not available): both there ->
     // rounded mean, one -> that one, none -> 0
     static inline int nc_of(int s) { return s < 64 ? (s + 1) >> 1 : s & 31; }
-    __attribute__((always_inline)) static inline int token_fast(BitReader &br, int nCtx) {                          // coeff_token: total_coeff << 2 | trailing_ones, or -1
-        const TokTable &T = g_tok[kTokClass[nCtx]];
+    __attribute__((always_inline)) static inline int token_fast(BitReader &br, int sum) {                           // coeff_token: total_coeff << 2 | trailing_ones, or -1; sum: see kTokClassOfSum
+        const int cls = kTokClassOfSum.t[sum];
         const uint32_t v = br.peek(16);
+        if (cls == 0 && (v & 0x8000)) { br.skip(1); return 0; }     // nC < 2 and the codeword "1": an empty block (most blocks of a coded 8x8 are)
+        const TokTable &T = g_tok[cls];
         uint32_t e = T.t[v >> 8];
         if ((e & 0xff) == 0xff) e = T.t[256 * (e >> 8) + (v & 0xff)];
         const int len = e & 0xff;
@@ -518,13 +536,16 @@ struct P {
         const uint8_t *ta = nA >= 0 ? &cx.tc[(size_t)nA * 24] : nullptr, *tb = nB >= 0 ? &cx.tc[(size_t)nB * 24] : nullptr;
         flags = bits = cbm = 0;
         memset(tc, 0, 24);
+        // one room check per macroblock: the most this coded_block_pattern can store (16 slots per 4x4 block, 4 per chroma DC block; the Intra16x16 DC
+        // block is allocated -- and checked -- by alloc_coef)
+        if (out.coef_count + (i16 ? 16u : 0u) + 64u * (uint32_t)__builtin_popcount(cbp & 15) + ((cbp & 0x30) ? 8u : 0u) + ((cbp & 0x20) ? 128u : 0u) > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
         if ((cbp & 15) || i16) {
             memset(w, 0, sizeof w);
             if (tb) memcpy(w + 1, tb + 12, 4); else memset(w + 1, 64, 4);
             for (int j = 0; j < 4; j++) w[8 * (j + 1)] = ta ? ta[4 * j + 3] : 64;
             if (i16) {                                        // Intra16x16 DC levels: always 16 slots in the stream
                 int16_t *d = alloc_coef(16); if (!d) return false;
-                const int tk = token_fast(br, nc_of(w[8] + w[1]));
+                const int tk = token_fast(br, w[8] + w[1]);
                 if (tk < 0 || (tk && levels_of(br, tk >> 2, tk & 3, 16, 0, d, kZigzag4) < 0)) { err = "entropy error (Intra16x16 DC)"; return false; }
             }
             const int max_num = i16 ? 15 : 16, first = i16 ? 1 : 0;
@@ -532,8 +553,7 @@ struct P {
                 if (!(cbp & (1 << b8))) continue;
                 for (int k = 0; k < 4; k++) {
                     const int blk = b8 * 4 + k, wi = kWin[blk];
-                    if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
-                    const int tk = token_fast(br, nc_of(w[wi - 1] + w[wi - 8]));
+                    const int tk = token_fast(br, w[wi - 1] + w[wi - 8]);
                     if (tk < 0) { err = "entropy error (luma block)"; return false; }
                     if (!tk) continue;
                     const int total = tk >> 2;
@@ -545,7 +565,6 @@ struct P {
         }
         if (cbp & 0x30) {
             for (int pl = 0; pl < 2; pl++) {
-                if (out.coef_count + 4 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
                 int16_t *d = out.coef + out.coef_count;
                 const uint32_t e = g_cdc[br.peek(8)];
                 if (!(e & 0xff)) { err = "entropy error (chroma DC)"; return false; }
@@ -563,8 +582,7 @@ struct P {
                 c[1] = tb ? tb[o + 2] : 64; c[2] = tb ? tb[o + 3] : 64; c[3] = ta ? ta[o + 1] : 64; c[6] = ta ? ta[o + 3] : 64;
                 for (int k = 0; k < 4; k++) {
                     const int ci = 4 + (k >> 1) * 3 + (k & 1);
-                    if (out.coef_count + 16 > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
-                    const int tk = token_fast(br, nc_of(c[ci - 1] + c[ci - 3]));
+                    const int tk = token_fast(br, c[ci - 1] + c[ci - 3]);
                     if (tk < 0 || (tk >> 2) > 15) { err = "entropy error (chroma AC)"; return false; }
                     c[ci] = (uint8_t)(tk >> 2);
                     if (!tk) continue;
@@ -1105,12 +1123,12 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
         while (more) {
             const uint32_t run = b.ue();
             if (b.overrun() || run > (uint32_t)(n_mbs - addr)) { res.error = "bad mb_skip_run"; break; }
-            for (uint32_t i = 0; i < run; i++) { p.locate(addr); p.skip_mb_fast(); addr++; }
+            for (uint32_t i = 0; i < run; i++) { p.locate_next(addr, sh.first_mb); p.skip_mb_fast(); addr++; }
             res.mbs_decoded += (int)run;
             if (run > 0) more = b.more_rbsp_data();
             if (!more) break;
             if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; break; }
-            p.locate(addr);
+            p.locate_next(addr, sh.first_mb);
             const uint32_t mb_type = b.ue();
             bool ok;
             if (mb_type == 0) ok = p.p16x16_fast(b);
