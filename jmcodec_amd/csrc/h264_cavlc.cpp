@@ -947,12 +947,21 @@ struct P {
                     // Intra8x8PredMode of block b8 in nibble b8
                     r->u.i4[0] = (uint8_t)(i4m[0] | (i4m[2] << 4)); r->u.i4[1] = (uint8_t)(i4m[8] | (i4m[10] << 4));
                 } else {
-                    for (int blk = 0; blk < 16; blk++) {
-                        int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
-                        int pred = pred_intra_mode(bx, by), mode;
-                        if (cb) mode = ae_intra_mode(pred);
-                        else if (br.u1()) mode = pred; else { int rem = (int)br.u(3); mode = rem < pred ? rem : rem + 1; }
-                        i4m[by * 4 + bx] = (uint8_t)mode;
+                    if (cb) {
+                        for (int blk = 0; blk < 16; blk++) {
+                            int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+                            i4m[by * 4 + bx] = (uint8_t)ae_intra_mode(pred_intra_mode(bx, by));
+                        }
+                    } else {
+                        BitReader b = br;                          // (a local copy lives in registers, see parse_slice_data)
+                        for (int blk = 0; blk < 16; blk++) {
+                            int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
+                            int pred = pred_intra_mode(bx, by), mode;
+                            const uint32_t v = b.peek(4);              // prev_intra4x4_pred_mode_flag, then rem_intra4x4_pred_mode (3 bits) when it is 0
+                            if (v & 8) { mode = pred; b.skip(1); } else { const int rem = (int)(v & 7); mode = rem < pred ? rem : rem + 1; b.skip(4); }
+                            i4m[by * 4 + bx] = (uint8_t)mode;
+                        }
+                        br = b;
                     }
                     for (int k = 0; k < 8; k++) r->u.i4[k] = (uint8_t)(i4m[2 * k] | (i4m[2 * k + 1] << 4));
                 }
