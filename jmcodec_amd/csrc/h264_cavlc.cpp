@@ -493,6 +493,13 @@ struct P {
         const uint32_t rr = (uint8_t)refi * 0x01010101u;
         memcpy(ref, &rr, 4);
         cx.slice_of[addr] = (int16_t)slice_num;
+        if (rf.track_uid) {                                       // the stream may hold B pictures: this picture's motion may serve direct prediction later (list 1 unused here)
+            int32_t *u0 = &cx.uid0[(size_t)addr * 4], *u1 = &cx.uid1[(size_t)addr * 4];
+            const int32_t u = rf.uid[0][refi];
+            u0[0] = u0[1] = u0[2] = u0[3] = u; u1[0] = u1[1] = u1[2] = u1[3] = -1;
+            refl[1][0] = refl[1][1] = refl[1][2] = refl[1][3] = -1;
+            cx.direct8[addr] = 0;
+        }
         const int my = (int16_t)y;
         if (my > out.max_mvy) out.max_mvy = my;
         static_assert(MB_INTER == 0 && offsetof(MbRec, cbp_blk) == 4 && offsetof(MbRec, coef_off) == 8 && offsetof(MbRec, ref) == 12 && offsetof(MbRec, u) == 16, "record layout");
@@ -619,6 +626,40 @@ struct P {
             put_inter16(r, refi, px + dx, py + dy, out.coef_count, 0, 0, 0);
         }
         if (br.overrun()) { err = "macroblock data truncated"; return false; }
+        return true;
+    }
+
+    // The same two macroblock types in CABAC slices: the syntax elements go through the general ae_* routines (their contexts come from the neighbour
+    // arrays, which are kept exactly as macroblock() keeps them); what is saved is the partition machinery around them.
+    inline void skip_mb_fast_ae() {
+        skip_mb_fast();
+        cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0; memset(mvd, 0, 32); last_dqp = false;
+    }
+    bool p16x16_fast_ae() {
+        MbRec *r = &out.mbs[addr];
+        cx.info[addr] = 0; cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0;
+        memset(tc, 0, 24);
+        int refi = 0;
+        const int nref = sh.num_ref_idx[0];
+        if (nref > 1) { refi = ae_ref_idx(0, 0, 0); if (err || refi >= nref) { if (!err) err = "ref_idx out of range"; return false; } }
+        int px, py, dx, dy;
+        mvp16(refi, nbv(nA, 3, 1), nbv(nB, 12, 2), px, py);
+        read_mvd(0, 0, 4, 4, dx, dy, 0);
+        if (err) return false;
+        const int cbp = ae_cbp();
+        cx.cbp[addr] = (uint8_t)cbp;
+        bool t8 = false;
+        if ((cbp & 15) && pps.transform8x8) { t8 = ae_t8x8() != 0; if (t8) cx.info[addr] |= 8; }
+        if (cbp) {
+            const int dqp = ae_qp_delta();
+            if (err || dqp < -26 || dqp > 25) { if (!err) err = "mb_qp_delta out of range"; return false; }
+            qp += dqp; if (qp < 0) qp += 52; else if (qp > 51) qp -= 52;
+            last_dqp = dqp != 0;
+        } else last_dqp = false;
+        put_inter16(r, refi, px + dx, py + dy, out.coef_count, 0, 0, 0);
+        if (t8) r->modes |= MBM_T8X8;
+        if (cbp && !residual(r, cbp, false, t8, false)) return false;
+        if (cb->overrun) { err = "macroblock data truncated"; return false; }
         return true;
     }
 
@@ -1111,12 +1152,22 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
         cabac.init_contexts(sh.type == SL_I ? 0 : 1 + sh.cabac_init_idc, sh.qp);
         cabac.init_engine(br.byte_ptr(), br.base() + br.size());
         p.cb = &cabac;
+        const bool fast_ae = allow_fast && sh.type == SL_P && !digest && !refs.bipred_rec;
         for (;;) {
             if (addr >= n_mbs) { res.error = "slice runs past the end of the picture"; return res; }
-            p.locate(addr);
             bool ok;
-            if (sh.type != SL_I && p.ae_mb_skip()) ok = p.skip_mb();
-            else ok = p.macroblock(res.n_intra, res.n_i8x8);
+            if (fast_ae) {                                    // P_Skip / P_L0_16x16 without the partition machinery (see skip_mb_fast_ae)
+                p.locate_next(addr, sh.first_mb);
+                if (p.ae_mb_skip()) { p.skip_mb_fast_ae(); ok = true; }
+                else {
+                    const int mb_type = p.ae_mb_type();
+                    ok = mb_type == 0 ? p.p16x16_fast_ae() : p.macroblock(res.n_intra, res.n_i8x8, mb_type);
+                }
+            } else {
+                p.locate(addr);
+                if (sh.type != SL_I && p.ae_mb_skip()) ok = p.skip_mb();
+                else ok = p.macroblock(res.n_intra, res.n_i8x8);
+            }
             if (!ok) { res.error = p.err ? p.err : "macroblock error"; return res; }
             addr++; res.mbs_decoded++;
             if (cabac.overrun || cabac.bits_consumed() > (size_t)(cabac.end - cabac.start) * 8 + 16) { res.error = "slice data truncated"; return res; }
@@ -1124,7 +1175,7 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
         }
         return res;
     }
-    if (allow_fast && sh.type == SL_P && !digest && !pps.transform8x8 && !refs.bipred_rec && !refs.track_uid) {
+    if (allow_fast && sh.type == SL_P && !digest && !pps.transform8x8 && !refs.bipred_rec) {
         // P_Skip / P_L0_16x16 through the fast path.  The reader is copied into a local whose address never leaves this loop (everything that
         // takes it is inlined), so its state lives in registers instead of being reloaded after every byte store into the neighbour arrays.
         BitReader b = br;
