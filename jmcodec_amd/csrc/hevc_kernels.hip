@@ -37,31 +37,77 @@ __device__ __forceinline__ uint8_t *sample_ptr(uint8_t *surf, const HevcPicParam
 // ------------------------------------------------------------------------------------------------------------
 // 8.5.3.3: motion compensation
 // ------------------------------------------------------------------------------------------------------------
-// 14-bit intermediate prediction of one component block: out[i] for the lane's samples k = lane + 64 * i
-template <int NT>
-__device__ void interp_block(const uint8_t *plane, int pitch, int step, int pw, int ph, int xi, int yi, int bw, int bh, int xf, int yf,
-                             const int8_t *fx, const int8_t *fy, uint8_t *tile, int16_t *hbuf, int lane, int *out) {
-    const int tw = bw + NT - 1, th = bh + NT - 1, off = NT / 2 - 1;
-    __syncthreads();
-    for (int k = lane; k < tw * th; k += 64) {
-        const int r = k / tw, c = k - r * tw;
-        tile[k] = plane[(size_t)clip3(0, ph - 1, yi + r - off) * pitch + clip3(0, pw - 1, xi + c - off) * step];
+// One wavefront per prediction block of at most 16x16 luma samples.  Per reference list: the (w+7) x (h+7) luma window (then the interleaved CbCr
+// window, (w/2+3) x (h/2+3) sample pairs) goes into LDS as ALIGNED DWORDS of 32-byte rows -- 3 load rounds of the wave instead of 9 byte-wise ones --
+// unless it touches the picture border (then byte-wise with clamped coordinates, 8.5.3.3.3.1); separable 8-tap / 4-tap filter through LDS; every
+// lane ends up with four horizontally adjacent samples (luma) or two CbCr pairs (chroma) and stores ONE dword (block positions and widths are
+// multiples of 4).  Cb and Cr share one window load and one store.
+struct HevcMcLds {
+    __align__(16) uint8_t tile[23 * 32];      // window rows of 32 bytes
+    int16_t hbuf[23 * 16];                    // horizontally filtered rows, 16 per row; chroma: Cb rows, then (from 11 * 8) Cr rows of 8
+};
+
+// luma: this lane's four 14-bit intermediates (row my_row, columns 4 * my_q ..) of list-l prediction
+__device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint8_t *ref, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm, int lane, bool mine, int my_row, int my_q, int *out) {
+    const int tw = bw + 7, th = bh + 7, x0 = xi - 3, y0 = yi - 3;
+    int sh = 0;
+    __syncthreads();                                          // (the previous user of tile / hbuf is done)
+    if (x0 >= 0 && y0 >= 0 && x0 + tw <= pp.w && y0 + th <= pp.h && ((x0 + tw + 3) & ~3) <= pp.pitch) {     // (the last dword of a row stays inside the row)
+        sh = x0 & 3;
+        const int ndw = (sh + tw + 3) >> 2;                   // <= 7
+        const uint8_t *base = ref + (size_t)y0 * pp.pitch + (x0 & ~3);
+        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7; if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
+    } else {
+        for (int k = lane; k < tw * th; k += 64) { const int r = k / tw, c = k - r * tw; sm.tile[r * 32 + c] = ref[(size_t)clip3(0, pp.h - 1, y0 + r) * pp.pitch + clip3(0, pp.w - 1, x0 + c)]; }
     }
     __syncthreads();
+    const int8_t *fx = c_lf[xf], *fy = c_lf[yf];
     for (int k = lane; k < bw * th; k += 64) {
         const int r = k / bw, c = k - r * bw;
+        const uint8_t *t = sm.tile + r * 32 + sh + c;
         int v;
-        if (xf) { v = 0; for (int i = 0; i < NT; i++) v += fx[i] * tile[r * tw + c + i]; } else v = tile[r * tw + c + off];
-        hbuf[k] = (int16_t)v;
+        if (xf) { v = 0; for (int i = 0; i < 8; i++) v += fx[i] * t[i]; } else v = t[3];
+        sm.hbuf[r * 16 + c] = (int16_t)v;
     }
     __syncthreads();
+    if (!mine) return;
     for (int i = 0; i < 4; i++) {
-        const int k = lane + 64 * i;
-        if (k >= bw * bh) break;
-        const int r = k / bw, c = k - r * bw;
+        const int16_t *h = sm.hbuf + my_row * 16 + 4 * my_q + i;
         int v;
-        if (yf) { v = 0; for (int j = 0; j < NT; j++) v += fy[j] * hbuf[(r + j) * bw + c]; if (xf) v >>= 6; }
-        else { v = hbuf[(r + off) * bw + c]; if (!xf) v <<= 6; }
+        if (yf) { v = 0; for (int j = 0; j < 8; j++) v += fy[j] * h[j * 16]; if (xf) v >>= 6; }
+        else { v = h[3 * 16]; if (!xf) v <<= 6; }
+        out[i] = v;
+    }
+}
+// chroma: this lane's two CbCr pairs (Cb0, Cr0, Cb1, Cr1 of row my_row, columns 2 * my_q, 2 * my_q + 1)
+__device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const uint8_t *refc, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm, int lane, bool mine, int my_row, int my_q, int *out) {
+    const int tw = bw + 3, th = bh + 3, x0 = xi - 1, y0 = yi - 1, pw = pp.w >> 1, ph = pp.h >> 1;
+    int sh = 0;
+    __syncthreads();
+    if (x0 >= 0 && y0 >= 0 && x0 + tw <= pw && y0 + th <= ph && ((2 * (x0 + tw) + 3) & ~3) <= pp.pitch) {
+        sh = (2 * x0) & 3;
+        const int ndw = (sh + 2 * tw + 3) >> 2;               // <= 6
+        const uint8_t *base = refc + (size_t)y0 * pp.pitch + ((2 * x0) & ~3);
+        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7; if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
+    } else {
+        for (int k = lane; k < 2 * tw * th; k += 64) { const int r = k / (2 * tw), c = k - r * 2 * tw; sm.tile[r * 32 + c] = refc[(size_t)clip3(0, ph - 1, y0 + r) * pp.pitch + 2 * clip3(0, pw - 1, x0 + (c >> 1)) + (c & 1)]; }
+    }
+    __syncthreads();
+    const int8_t *fx = c_cf[xf], *fy = c_cf[yf];
+    for (int k = lane; k < 2 * bw * th; k += 64) {            // both components: k = (r * bw + c) * 2 + comp
+        const int comp = k & 1, rc = k >> 1, r = rc / bw, c = rc - r * bw;
+        const uint8_t *t = sm.tile + r * 32 + sh + 2 * c + comp;
+        int v;
+        if (xf) { v = 0; for (int i = 0; i < 4; i++) v += fx[i] * t[2 * i]; } else v = t[2];
+        sm.hbuf[comp * 88 + r * 8 + c] = (int16_t)v;
+    }
+    __syncthreads();
+    if (!mine) return;
+    for (int i = 0; i < 4; i++) {                              // i = 2 * (column within the pair) + comp
+        const int16_t *h = sm.hbuf + (i & 1) * 88 + my_row * 8 + 2 * my_q + (i >> 1);
+        int v;
+        if (yf) { v = 0; for (int j = 0; j < 4; j++) v += fy[j] * h[j * 8]; if (xf) v >>= 6; }
+        else { v = h[8]; if (!xf) v <<= 6; }
         out[i] = v;
     }
 }
@@ -74,35 +120,52 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
     if (!(pp.stages & HPS_MC) || job >= pp.n_pus) return;
     const HevcPu pu = pp.pus[job];
     const int lane = threadIdx.x;
-    __shared__ uint8_t tile[23 * 23 + 3];
-    __shared__ int16_t hbuf[23 * 16];
+    __shared__ HevcMcLds sm;
     uint8_t *dst = pp.surf[pp.work];
     const HevcWp *wp = pu.wp ? &pp.wps[pu.wp - 1] : nullptr;
     const int both = pu.slot0 >= 0 && pu.slot1 >= 0;
-    for (int c = 0; c < 3; c++) {
-        const int sc = c ? 1 : 0, bw = pu.w >> sc, bh = pu.h >> sc, xb = pu.x >> sc, yb = pu.y >> sc, pw = pp.w >> sc, ph = pp.h >> sc;
-        int p[2][4];
+    // 8.5.3.3.4.2 / 8.5.3.3.4.3: the two 14-bit predictions -> one sample of component c
+    auto weigh = [&](int p0, int p1, int c) -> int {
+        int v;
+        if (!wp) v = both ? (p0 + p1 + 64) >> 7 : ((pu.slot0 >= 0 ? p0 : p1) + 32) >> 6;
+        else {
+            const int ld = wp->log2wd[c ? 1 : 0];
+            if (both) v = (p0 * wp->w[0][pu.ridx0][c] + p1 * wp->w[1][pu.ridx1][c] + ((wp->o[0][pu.ridx0][c] + wp->o[1][pu.ridx1][c] + 1) << ld)) >> (ld + 1);
+            else if (pu.slot0 >= 0) v = ((p0 * wp->w[0][pu.ridx0][c] + (1 << (ld - 1))) >> ld) + wp->o[0][pu.ridx0][c];
+            else v = ((p1 * wp->w[1][pu.ridx1][c] + (1 << (ld - 1))) >> ld) + wp->o[1][pu.ridx1][c];
+        }
+        return clip1(v);
+    };
+    {   // ---- luma: lane -> (row, dword) ----
+        const int bw = pu.w, bh = pu.h, qw = bw >> 2, my_row = lane / qw, my_q = lane - my_row * qw;
+        const bool mine = lane < bh * qw;
+        int p[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int l = 0; l < 2; l++) {
             const int slot = l ? pu.slot1 : pu.slot0;
             if (slot < 0) continue;
             const int mvx = l ? pu.mv1[0] : pu.mv0[0], mvy = l ? pu.mv1[1] : pu.mv0[1];
-            const uint8_t *ref = pp.surf[slot];
-            if (c == 0) interp_block<8>(ref, pp.pitch, 1, pw, ph, xb + (mvx >> 2), yb + (mvy >> 2), bw, bh, mvx & 3, mvy & 3, c_lf[mvx & 3], c_lf[mvy & 3], tile, hbuf, lane, p[l]);
-            else interp_block<4>(ref + pp.chroma_offset + (c - 1), pp.pitch, 2, pw, ph, xb + (mvx >> 3), yb + (mvy >> 3), bw, bh, mvx & 7, mvy & 7, c_cf[mvx & 7], c_cf[mvy & 7], tile, hbuf, lane, p[l]);
+            hevc_mc_luma(pp, pp.surf[slot], pu.x + (mvx >> 2), pu.y + (mvy >> 2), bw, bh, mvx & 3, mvy & 3, sm, lane, mine, my_row, my_q, p[l]);
         }
-        for (int i = 0; i < 4; i++) {
-            const int k = lane + 64 * i;
-            if (k >= bw * bh) break;
-            const int r = k / bw, cc = k - r * bw;
-            int v;
-            if (!wp) v = both ? (p[0][i] + p[1][i] + 64) >> 7 : ((pu.slot0 >= 0 ? p[0][i] : p[1][i]) + 32) >> 6;          // 8.5.3.3.4.2
-            else {                                                                                                     // 8.5.3.3.4.3
-                const int ld = wp->log2wd[c ? 1 : 0];
-                if (both) v = (p[0][i] * wp->w[0][pu.ridx0][c] + p[1][i] * wp->w[1][pu.ridx1][c] + ((wp->o[0][pu.ridx0][c] + wp->o[1][pu.ridx1][c] + 1) << ld)) >> (ld + 1);
-                else if (pu.slot0 >= 0) v = ((p[0][i] * wp->w[0][pu.ridx0][c] + (1 << (ld - 1))) >> ld) + wp->o[0][pu.ridx0][c];
-                else v = ((p[1][i] * wp->w[1][pu.ridx1][c] + (1 << (ld - 1))) >> ld) + wp->o[1][pu.ridx1][c];
-            }
-            *sample_ptr(dst, pp, c, xb + cc, yb + r) = (uint8_t)clip1(v);
+        if (mine) {
+            uint32_t w = 0;
+            for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 0) << (8 * i);
+            *(uint32_t *)(dst + (size_t)(pu.y + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
+        }
+    }
+    {   // ---- chroma, both components: lane -> (row, dword of two CbCr pairs) ----
+        const int bw = pu.w >> 1, bh = pu.h >> 1, qw = bw >> 1, my_row = lane / qw, my_q = lane - my_row * qw;
+        const bool mine = lane < bh * qw;
+        int p[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int l = 0; l < 2; l++) {
+            const int slot = l ? pu.slot1 : pu.slot0;
+            if (slot < 0) continue;
+            const int mvx = l ? pu.mv1[0] : pu.mv0[0], mvy = l ? pu.mv1[1] : pu.mv0[1];
+            hevc_mc_chroma(pp, pp.surf[slot] + pp.chroma_offset, (pu.x >> 1) + (mvx >> 3), (pu.y >> 1) + (mvy >> 3), bw, bh, mvx & 7, mvy & 7, sm, lane, mine, my_row, my_q, p[l]);
+        }
+        if (mine) {
+            uint32_t w = 0;
+            for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 1 + (i & 1)) << (8 * i);
+            *(uint32_t *)(dst + pp.chroma_offset + (size_t)((pu.y >> 1) + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
         }
     }
 }
