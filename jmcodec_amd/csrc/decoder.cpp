@@ -989,6 +989,7 @@ void Decoder::submit_task(PicTask *t) {
         // runs as a third role of the chain kernel (k_chain_i), whatever the share of intra macroblocks (the stage path uses the spin-wait kernel for sparse ones).
         ep.chain_intra = chain_ok_ && chain_intra_on_ && t->n_intra > 0 && use_lds_intra_ && (t->n_i8x8 == 0 || lds_intra8_) && (pp.stages & PS_DEBLOCK_LDS);
         ep.classic_stages = pp.stages;
+        for (auto &sl : t->slices) ep.bipred |= sl.refs.bipred_rec;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];
         // algorithmic bytes of this picture per kernel class

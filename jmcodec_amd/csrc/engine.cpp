@@ -276,7 +276,9 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (hd.any_intra) b.pmask |= 4;
         if (hd.any_deblock || hd.any_sao) b.pmask |= 8;
     }
-    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, st); b.pmask |= 2; }
+    b.any_bipred = false;
+    for (auto &p : b.pics) b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred;
+    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
@@ -359,7 +361,7 @@ void Engine::recover(Lane &ln, Batch &b) {
         if (!stages) continue;
         hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);
         hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
-        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, st);
+        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, st);
         if (stages & PS_INTRA_LDS) launch_intra_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, st);
         if (stages & PS_INTRA_V1) launch_recon_intra(b.d_pics, n, st);
         if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st); launch_deblock_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, false, st); }

@@ -58,6 +58,7 @@ struct EnginePic {
     bool chain_intra = false;                       // a (mostly) intra picture that can run inside k_chain_i with its intra wavefront as a third role (chain_intra.hip)
     int classic_stages = 0;                         // pp.stages when it runs through the stage kernels instead
     uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
+    bool bipred = false;                            // some slice of the picture writes two-list / weighted motion records (B slices, weighted prediction)
     int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
@@ -106,7 +107,7 @@ private:
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
         bool any_chain = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
-        int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0;
+        int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)

@@ -20,6 +20,7 @@ namespace jmamd {
 // ------------------------------------------------------------------------------------------
 // k_recon_inter: one wave per macroblock, 4 macroblocks per workgroup
 // ------------------------------------------------------------------------------------------
+template <bool BIFAST>
 __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give every XCD one
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     __shared__ ReconLds sm;
     const int n_mbs = pp.mb_w * pp.mb_h;
     const int mb = blk * 4 + (int)(threadIdx.x >> 6);
-    recon_inter_wave<false, false>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, nullptr});
+    recon_inter_wave<false, false, BIFAST>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, nullptr});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,9 +538,11 @@ __global__ __launch_bounds__(256) void k_packout(const PackJob *jobs) {
 // ------------------------------------------------------------------------------------------
 // launchers: d_pics / d_jobs are device arrays of n entries; max_* size the grid for the largest picture
 // ------------------------------------------------------------------------------------------
-void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, hipStream_t st) {
     int nblk = ((max_mbs + 3) / 4 + 7) & ~7;              // multiple of 8: the XCD band mapping must be a bijection
-    hipLaunchKernelGGL(k_recon_inter, dim3(nblk, n), dim3(256), 0, st, d_pics);
+    // any_bipred: some picture of the batch has B slices / weighted prediction (two-list motion records): the instantiation with their LDS-window path
+    if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true>), dim3(nblk, n), dim3(256), 0, st, d_pics);
+    else hipLaunchKernelGGL((k_recon_inter<false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
 }
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }

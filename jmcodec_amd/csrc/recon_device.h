@@ -192,7 +192,9 @@ struct alignas(16) ReconLds {
 // samples with loads that bypass the non-coherent cache levels, writes its result through to memory and publishes the macroblock in the
 // picture's reconstruction bitmap, on which the deblocking workgroups of this picture wait.
 // COH: the reference loads are the cache-bypassing kind (needed exactly when the picture has references inside the launch, pp.n_deps > 0).
-template <bool CHAIN, bool COH>
+// BIFAST: macroblocks with two-list / weighted motion records take their luma windows through LDS like P blocks when they can (below).  The stage
+// kernel has an instantiation without it for batches that hold no such picture: the extra code costs 9 VGPRs there (96 -> 105, 5 -> 4 waves per SIMD).
+template <bool CHAIN, bool COH, bool BIFAST = true>
 __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
     ResTile *tiles = sm.tiles;
     uint32_t (*outt)[96] = sm.outt;
@@ -311,6 +313,60 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
     }
     if (!inter && r.kind != MB_PCM) { publish(); return; }
+    // The 8x8 block's 13x13 reference window (this lane's five dwords wv of it, row * 5 + dword == l16 + 16 * t, first byte at offset sh of the row) goes
+    // into the block's LDS window; the lane then filters the four samples 4 * hh .. of row rr (8.4.2.2.1).  The fractional position is uniform inside a
+    // block, so the 6-tap paths do not diverge within its 16 lanes.
+    auto filter_window = [&](uint32_t *win, const uint32_t *wv, int l16, int sh, int fx, int fy, int *v) {
+#pragma unroll
+        for (int t = 0; t < 5; t++) { int i = l16 + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
+        // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
+        const int rr = l16 >> 1, hh = l16 & 1;
+        // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
+        auto row9 = [&](int wr, int *t) {
+            const uint32_t *p = win + wr * 5 + hh;           // dword containing byte 4hh
+            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+            uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
+            t[4] = a1 & 255; t[5] = (a1 >> 8) & 255; t[6] = (a1 >> 16) & 255; t[7] = a1 >> 24; t[8] = a2 & 255;
+        };
+        if (fy == 0) {
+            int t[9]; row9(rr + 2, t);
+            if (fx == 0) { v[0] = t[2]; v[1] = t[3]; v[2] = t[4]; v[3] = t[5]; }
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int b = clip1((tap6(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5]) + 16) >> 5);
+                    v[k] = fx == 2 ? b : ((fx == 1 ? t[k + 2] : t[k + 3]) + b + 1) >> 1;
+                }
+            }
+        } else {
+            int t[6][9];
+#pragma unroll
+            for (int j = 0; j < 6; j++) row9(rr + j, t[j]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // vertical half samples at column k (h) and k+1 (m); horizontal half samples at row 0 (b) and row 1 (s)
+                int c = k + 2;
+                if (fx == 0) {
+                    int h = clip1((tap6(t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]) + 16) >> 5);
+                    v[k] = fy == 2 ? h : ((fy == 1 ? t[2][c] : t[3][c]) + h + 1) >> 1;
+                } else if (fx == 2 || fy == 2) {
+                    int hb[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) hb[j] = tap6(t[j][k], t[j][k + 1], t[j][k + 2], t[j][k + 3], t[j][k + 4], t[j][k + 5]);
+                    int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
+                    if (fx == 2 && fy == 2) v[k] = jv;
+                    else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
+                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
+                } else {
+                    int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
+                    int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
+                    int hq = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
+                    v[k] = (bq + hq + 1) >> 1;
+                }
+            }
+        }
+    };
     if (inter && (r.modes & MBM_BIPRED)) {
         // B slices / weighted prediction: one or two references per 8x8, one vector per 4x4, weights of 8.4.2.3.  Literal sampling.
         const short *rec = pp.mv_ext + (size_t)r.u.mv_ext * 2;
@@ -331,6 +387,52 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             int l = use0 ? 0 : 1, i = (use0 ? i0 : i1) & 15, lg = cmp ? wp->logwd_c : wp->logwd_y, w = wp->w[l][i][cmp], o = wp->o[l][i][cmp];
             return clip1((lg >= 1 ? ((v * w + (1 << (lg - 1))) >> lg) : v * w) + o);
         };
+        // luma.  Fast path: every 8x8 block has ONE vector per list in use (B_16x16 / 16x8 / 8x16, B_8x8 with 8x8 sub-blocks, direct
+        // prediction with direct_8x8_inference) and its 13x13 windows lie inside the picture -- then each list's window goes through LDS exactly like a
+        // P block's (5 dword loads per lane instead of up to 36 byte loads per SAMPLE) and the two predictions are combined per sample.
+        bool bfast = false;
+        if (BIFAST) {
+            const int g = lane >> 4, rb0 = (g >> 1) * 8 + (g & 1) * 2;
+            bool okb = true;
+#pragma unroll
+            for (int L = 0; L < 2; L++) {
+                if ((L ? (int)tail[g] : rec_ref(r, g)) < 0) continue;
+                const short *m = rec + L * 32 + rb0 * 2;
+                const int ax = m[0], ay = m[1];
+                okb = okb && m[2] == ax && m[3] == ay && m[8] == ax && m[9] == ay && m[10] == ax && m[11] == ay;
+                const int xi = mbx * 16 + (g & 1) * 8 + (ax >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (ay >> 2) - 2;
+                okb = okb && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
+            }
+            bfast = __all(okb);
+        }
+        if (BIFAST && bfast) {
+            const int g = lane >> 4, l16 = lane & 15, rb0 = (g >> 1) * 8 + (g & 1) * 2;
+            const int s0 = rec_ref(r, g), s1 = tail[g], i0 = tail[4 + g], i1 = tail[8 + g];
+            uint32_t pa = 0, pb = 0;                               // the two predictions of this lane's four samples, one byte each
+            auto predict = [&](int slot, const short *m) -> uint32_t {
+                const int mvx = m[0], mvy = m[1];
+                const int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2, xa = xi & ~3;
+                const uint8_t *ref = pp.surf[slot];
+                uint32_t w5[5];
+#pragma unroll
+                for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5; w5[t] = ld_ref32<COH>(ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
+                __builtin_amdgcn_wave_barrier();                   // (the block's window in LDS is reused for the second list: its readers are done)
+                int v[4];
+                filter_window(&wins[wave][g][0], w5, l16, xi & 3, mvx & 3, mvy & 3, v);
+                __builtin_amdgcn_wave_barrier();
+                return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            };
+            if (s0 >= 0) pa = predict(s0, rec + rb0 * 2);
+            if (s1 >= 0) pb = predict(s1, rec + 32 + rb0 * 2);
+            const int rr = l16 >> 1, hh = l16 & 1, px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = combine((int)((pa >> (8 * k)) & 255), (int)((pb >> (8 * k)) & 255), s0 >= 0, s1 >= 0, i0, i1, 0);
+            if (has_res) { const short *rs = &tiles[wave].y[py * 16 + px];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]); }
+            ot[py * 4 + (px >> 2)] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        } else
         {   // luma: lane -> (4x4 block, row)
             int rb = lane >> 2, row = lane & 3, bx = rb & 3, by = rb >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
             int s0 = rec_ref(r, b8), s1 = tail[b8], i0 = tail[4 + b8], i1 = tail[8 + b8];
@@ -381,58 +483,9 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         int fx = mvx & 3, fy = mvy & 3;
         int bx0 = mbx * 16 + (g & 1) * 8;
         int xi = bx0 + (mvx >> 2) - 2;
-        uint32_t *win = &wins[wave][g][0];                  // 13 rows x 5 dwords (20 bytes, starting at the aligned address)
-        int sh = xi & 3;
-#pragma unroll
-        for (int t = 0; t < 5; t++) { int i = l + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
-        // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
-        int rr = l >> 1, hh = l & 1;
-        // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
-        auto row9 = [&](int wr, int *t) {
-            const uint32_t *p = win + wr * 5 + hh;           // dword containing byte 4hh
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-            uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
-            t[4] = a1 & 255; t[5] = (a1 >> 8) & 255; t[6] = (a1 >> 16) & 255; t[7] = a1 >> 24; t[8] = a2 & 255;
-        };
         int v[4];
-        if (fy == 0) {
-            int t[9]; row9(rr + 2, t);
-            if (fx == 0) { v[0] = t[2]; v[1] = t[3]; v[2] = t[4]; v[3] = t[5]; }
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int b = clip1((tap6(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5]) + 16) >> 5);
-                    v[k] = fx == 2 ? b : ((fx == 1 ? t[k + 2] : t[k + 3]) + b + 1) >> 1;
-                }
-            }
-        } else {
-            int t[6][9];
-#pragma unroll
-            for (int j = 0; j < 6; j++) row9(rr + j, t[j]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // vertical half samples at column k (h) and k+1 (m); horizontal half samples at row 0 (b) and row 1 (s)
-                int c = k + 2;
-                if (fx == 0) {
-                    int h = clip1((tap6(t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]) + 16) >> 5);
-                    v[k] = fy == 2 ? h : ((fy == 1 ? t[2][c] : t[3][c]) + h + 1) >> 1;
-                } else if (fx == 2 || fy == 2) {
-                    int hb[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) hb[j] = tap6(t[j][k], t[j][k + 1], t[j][k + 2], t[j][k + 3], t[j][k + 4], t[j][k + 5]);
-                    int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
-                    if (fx == 2 && fy == 2) v[k] = jv;
-                    else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                } else {
-                    int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
-                    int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
-                    int hq = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
-                    v[k] = (bq + hq + 1) >> 1;
-                }
-            }
-        }
+        filter_window(&wins[wave][g][0], wv, l, xi & 3, fx, fy, v);
+        const int rr = l >> 1, hh = l & 1;
         int px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;     // position inside the macroblock
         if (has_res) {
             const short *rs = &tiles[wave].y[py * 16 + px];

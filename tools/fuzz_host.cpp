@@ -44,7 +44,7 @@ namespace jmamd {
 bool deblock_lds_supported(int, int) { return true; }
 bool intra_lds_supported(int, int) { return true; }
 void launch_packout(const PackJob *, int, int, int, ihipStream_t *) { abort(); }
-void launch_recon_inter(const PicParams *, int, int, ihipStream_t *) { abort(); }
+void launch_recon_inter(const PicParams *, int, int, bool, ihipStream_t *) { abort(); }
 void launch_intra_lds(const PicParams *, int, int, int *, int *, ihipStream_t *) { abort(); }
 void launch_recon_intra(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_deblock_prep(const PicParams *, int, int, ihipStream_t *) { abort(); }
