@@ -811,3 +811,13 @@ def test_direct_route_into_pinned_host_memory(oracle):
     t = torch.empty(320 * 240 * 3 // 2, dtype=torch.uint8, pin_memory=True)
     frames, (errors, _) = _pull_all(data, 320, 240, lambda i: (t.data_ptr(), t))
     assert errors == 0 and b"".join(frames) == want
+
+
+@pytest.mark.parametrize("delay", [1, 3, 8])
+def test_display_delay_changes_when_frames_come_out_not_what_they_are(oracle, delay):
+    """set_option("display_delay", n) (the reference's ulMaxDisplayDelay, nv_dec.cpp:341): frames are withheld while n pictures are on their way; the end of
+    the stream drains everything -- same frames, same order."""
+    data = streams.generate(width=176, height=144, frames=14, gop=7, qp=28, num_ref=2, seed=0x4D60, bframes=2, poc_type=0, cabac=1)
+    want = oracle.decode(data, 1)[0]
+    frames = gpu_decode(data, display_delay=delay)
+    assert len(frames) == 14 and b"".join(frames) == want
