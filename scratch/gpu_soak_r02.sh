@@ -1,6 +1,6 @@
 # scratch/gpu_soak_r02.sh -- repeated runs of the chained configurations: every line must be bit-exact with zero device wait errors
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/soak
-for i in 1 2 3 4 5 6; do for s in 1 3 8 12; do timeout 120 python bench.py --streams $s --no-cpu-baseline --no-single > gpurun_out/soak/s${s}_$i.json 2>/dev/null || echo "FAIL s$s run $i rc=$?"; done; done
+for i in 1 2 3 4; do for s in 1 3 8 12 16 20; do timeout 120 python bench.py --streams $s --no-cpu-baseline --no-single > gpurun_out/soak/s${s}_$i.json 2>/dev/null || echo "FAIL s$s run $i rc=$?"; done; done
 for i in 1 2 3; do timeout 200 python bench.py --no-cpu-baseline --no-single > gpurun_out/soak/s32_$i.json 2>/dev/null || echo "FAIL s32 run $i"; done
 for t in high high_b; do timeout 120 python bench.py --streams 6 --tools $t --no-cpu-baseline --no-single > gpurun_out/soak/s6_$t.json 2>/dev/null || echo "FAIL $t"; done
 python3 - <<'PY'
