@@ -30,6 +30,7 @@ Engine *Engine::get(int device) {
 Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
+    if (const char *e = getenv("JM_AMD_DEC_LANE_SPLIT")) lane_split_ = atoi(e) != 0;
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
@@ -75,7 +76,15 @@ unsigned long long Engine::upload(uint8_t *dev, const uint8_t *host, size_t n, i
 }
 
 void Engine::submit(EnginePic &&p) {
-    { std::lock_guard<std::mutex> lk(m_); pending_.push_back(std::move(p)); }
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (p.codec == 0) {
+            const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            auto it = std::find_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *, long long> &r) { return r.first == p.dec; });
+            if (it != recent_.end()) it->second = now; else recent_.emplace_back(p.dec, now);
+        }
+        pending_.push_back(std::move(p));
+    }
     cv_.notify_one();
 }
 
@@ -98,12 +107,16 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     b.pics.clear(); b.any_chain = false; b.max_depth = 1;
     // chain launches are formed while few streams have pictures ready (a wide batch fills the GPU anyway); then the I picture of an IDR period stays on
     // its stream's ordinary lane, where it becomes the first picture of a chain (k_chain_i), instead of going to the intra lane
-    bool chaining = false;
-    if (chain_depth_ > 1) {
-        std::vector<Decoder *> ds;
-        for (auto &p : pending_) if (p.codec == 0 && std::find(ds.begin(), ds.end(), p.dec) == ds.end()) ds.push_back(p.dec);
-        chaining = !ds.empty() && (int)ds.size() <= chain_max_streams_ &&
-                   std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() >= chain_block_until_ns_;
+    // The regime follows the number of ACTIVE streams (handles that submitted a picture in the last 50 ms), not the number that happen to have a picture
+    // pending right now: with 20 or 32 streams the pending set dips below the threshold now and then, and a stream may only change lane once its pictures
+    // in flight have retired.  Few streams: chain launches on lane 0.  Many: stage kernels on both ordinary lanes, the streams split by handle parity.
+    bool chaining = false, split = false;
+    {
+        const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *, long long> &r) { return now - r.second > 50ll * 1000 * 1000; }), recent_.end());
+        const int n_active = (int)recent_.size();
+        chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_;
+        split = !chaining && lane_split_ && n_active > chain_max_streams_;
     }
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
@@ -117,7 +130,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
         EngineDecoderState &es = d->engine_state();
-        bool ok = it->lane(chaining) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        bool ok = it->lane(chaining, split) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
         // the pack-job tables hold 2 * kMaxBatch entries each: a picture whose display frames no longer fit waits for the next batch
         // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
         if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
@@ -149,7 +162,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
                 // the next picture joins only if it runs inside k_chain, packs nothing BEFORE the kernels (such frames may not be decoded yet),
                 // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
-                const bool ok = it != pending_.end() && it->lane(true) == lane_idx && it->has_picture && (it->chain_ok || it->chain_intra) &&
+                const bool ok = it != pending_.end() && it->lane(true, false) == lane_idx && it->has_picture && (it->chain_ok || it->chain_intra) &&
                                 it->out_before.empty() && !it->wait_prev_pack &&
                                 !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
                 int nb = 0, ng = 0;

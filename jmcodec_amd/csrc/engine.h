@@ -36,8 +36,10 @@ constexpr int kBatchRing = 4;
 constexpr int kMaxChainGroups = 128 * 1024;         // work list of one chain launch (1080p: 1025 groups per picture, 4K: 4059)
 constexpr int kMaxChainBands = 384;                 // band workgroups of one chain launch: half of what an MI355X holds at 3 workgroups per CU (k_chain)
 constexpr int kMaxChainBandsIntra = 256;            // ... at 2 per CU (k_chain_i, the variant with the intra role)
-constexpr int kPLanes = 1;                          // lanes for ordinary pictures: while one group's batch sits in the serial deblock
-                                                    // wavefront (2 CUs per picture) the other group's fully parallel kernels use the idle CUs
+constexpr int kPLanes = 2;                          // lanes for ordinary pictures.  The second one is an OPTION (JM_AMD_DEC_LANE_SPLIT=1, Engine::form `split`): with many
+                                                    // active streams they are divided between the two lanes by handle parity.  It measured worse in both rounds
+                                                    // (round 2, frames/s with / without: 20 streams 12.6 k / 16.0 k, 32 streams 12.5 k / 16.8 k, device-resident
+                                                    // output 14.2 k / 20.6 k): two half-size batches take as long as one, and their kernels get in each other's way.
 constexpr int kLanes = kPLanes + 2;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures
 constexpr int kHevcLane = kPLanes + 1;
 
@@ -63,7 +65,8 @@ struct EnginePic {
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
     // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on its stream's ordinary lane
-    int lane(bool chaining = false) const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : p_lane); }
+    // split: both ordinary-picture lanes are in use; otherwise everything ordinary runs on lane 0
+    int lane(bool chaining = false, bool split = false) const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : (split ? p_lane : 0)); }
 };
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
@@ -124,6 +127,8 @@ private:
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     std::atomic<int> chain_max_streams_{16};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
+    std::vector<std::pair<Decoder *, long long>> recent_;     // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
+    std::atomic<int> lane_split_{0};                          // 1: two ordinary lanes while more streams are active than chain launches are formed for (JM_AMD_DEC_LANE_SPLIT)
     std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);

@@ -804,12 +804,16 @@ def test_direct_route_two_handles_one_buffer(oracle):
 
 
 def test_direct_route_into_pinned_host_memory(oracle):
-    """An application that already page-locked its output buffer with the HIP runtime (hipHostMalloc, here through torch)."""
-    import torch
+    """An application that already page-locked its output buffer with the HIP runtime (hipHostMalloc)."""
+    hip = C.CDLL("libamdhip64.so")
     data = streams.generate(**_DIRECT_KW)
     want = oracle.decode(data, 1)[0]
-    t = torch.empty(320 * 240 * 3 // 2, dtype=torch.uint8, pin_memory=True)
-    frames, (errors, _) = _pull_all(data, 320, 240, lambda i: (t.data_ptr(), t))
+    ptr = C.c_void_p(0)
+    assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(320 * 240 * 3 // 2), C.c_uint(0)) == 0
+    try:
+        frames, (errors, _) = _pull_all(data, 320, 240, lambda i: (ptr.value, None))
+    finally:
+        hip.hipHostFree(ptr)
     assert errors == 0 and b"".join(frames) == want
 
 
