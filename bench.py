@@ -548,9 +548,9 @@ def main():
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms, "formation": form_stat, "direct_output": direct_stat,
                    "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2])},
-        "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 52.5, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 52.5, 4),
+        "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 54.0, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 54.0, 4),
                      "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> caller's buffer); peak = device->host "
-                             "rate measured on this platform with two SDMA engines at once (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 52.5 GB/s = 16.9 k frames/s of 1080p); "
+                             "rate measured on this platform with three SDMA engines in turn, four copies in flight (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 54.0 GB/s = 17.4 k frames/s of 1080p; two engines 52.5, one 47); "
                              "achieved = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},

@@ -49,7 +49,7 @@ HostCopier *HostCopier::get(int dev) {
     if (!c) return nullptr;
     c->cpu_ = ag.cpus[0].handle;
     // Which engines?  An MI355X shows sixteen; measured with one packed 1080p frame each (tools/sdma_probe.cpp): four move 47.6 GB/s over PCIe, the
-    // rest serve xGMI and manage 12 GB/s; two or three of the fast ones together fill the link (52.5 GB/s = 16.9 k frames/s).  The engine the HIP
+    // rest serve xGMI and manage 12 GB/s; two or three of the fast ones together fill the link (52.5 / 54.0 GB/s = 16.9 / 17.4 k frames/s).  The engine the HIP
     // runtime itself prefers for host -> device traffic must be left alone (frames queue behind its work: 11.7 k frames/s with it, 16.9 k without).
     // So: time one copy on every available engine, keep those within 1.5x of the best, drop the host -> device ones, use up to three in turn.
     uint32_t avail = 0, h2d = 0, d2h = 0;

@@ -65,6 +65,17 @@ int main() {
         double dt = now() - t0; const int frames = 2 + 4 * (reps / 2 - 1);
         printf("engines 0x%02x + 0x%02x: %.1f us per frame, %.1f GB/s\n", es[a], es[b], 1e6 * dt / frames, n * (double)frames / dt / 1e9);
     }
+    // three engines at once (what the product's direct output route does): 0x2, 0x4, 0x8 in turn, four copies in flight
+    if ((mask & 0xe) == 0xe) {
+        const uint32_t e3[3] = {0x2, 0x4, 0x8};
+        double t0 = now();
+        for (int s2 = 0; s2 < 4; s2++) copy(s2, e3[s2 % 3]);
+        int issued = 4;
+        for (int i = 0; i < 3 * reps; i++) { const int s2 = i & 3; wait(s2); if (issued < 3 * reps + 4) { copy(s2, e3[issued % 3]); issued++; } }
+        for (int s2 = 0; s2 < 4; s2++) wait(s2);
+        double dt = now() - t0;
+        printf("engines 0x02 + 0x04 + 0x08 in turn, 4 in flight: %.1f us per frame, %.1f GB/s\n", 1e6 * dt / issued, n * (double)issued / dt / 1e9);
+    }
     // what page-locking the caller's buffer per call would cost (instead of keeping it locked between calls)
     {
         void *p = nullptr, *ap = nullptr; if (posix_memalign(&p, 4096, n)) return 1;
