@@ -280,15 +280,23 @@ def test_fast_p_slice_path_builds_the_same_job_lists(name):
     assert a == b and a[2] == 0 and a[1] == PARITY_CASES[name]["frames"]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(36))
 def test_fast_p_slice_path_on_random_tool_mixes(seed):
+    """CAVLC and CABAC, with and without the 8x8 transform, B pictures (whose direct prediction reads the motion the fast path leaves behind), weighted
+    prediction (takes the general path), constrained intra prediction, several slices and references."""
     rng = random.Random(900 + seed)
+    cabac = rng.choice([0, 0, 1])
+    bframes = rng.choice([0, 0, 2]) if seed % 3 else 0
     kw = dict(width=rng.choice([48, 96, 176, 320]), height=rng.choice([48, 80, 144, 240]), frames=rng.choice([4, 7, 10]), gop=rng.choice([3, 5, 30]),
               qp=rng.choice([20, 26, 32, 40]), mode=rng.choice([0, 1]), num_ref=rng.choice([1, 2, 4]), slices=rng.choice([1, 2, 3]), seed=0x5000 + seed,
-              deblock=rng.choice([0, 1, 2]))
+              deblock=rng.choice([0, 1, 2]), cabac=cabac, cabac_idc=rng.choice([0, 1, 2]) if cabac else 0, t8x8=rng.choice([0, 1]) if (cabac or bframes) else 0,
+              cip=rng.choice([0, 0, 1]), bframes=bframes, poc_type=0 if bframes else 2, direct_temporal=rng.choice([0, 1]) if bframes else 0,
+              wp=rng.choice([0, 0, 1, 2]) if (cabac or bframes) else 0)
+    if bframes:
+        kw["num_ref"] = max(2, kw["num_ref"]); kw["frames"] = 1 + 3 * rng.choice([1, 2, 3]); kw["gop"] = 30
     data = streams.generate(**kw)
     a, b = _job_digest(data, True), _job_digest(data, False)
-    assert a == b and a[2] == 0 and a[1] == kw["frames"]
+    assert a == b and a[2] == 0 and a[1] == kw["frames"], kw
 
 
 def test_fast_p_slice_path_full_size():
