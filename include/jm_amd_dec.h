@@ -54,13 +54,19 @@ int  jm_amddec_is_hw_support(void);
 /* ---- additions (no reference counterpart) ---- */
 /* keys: "device" (before init), "device_output" (before init, see below), "sync" (1 = every call waits for the pipeline; deterministic),
  *       "parse_only" (1 = host bitstream stages only, frames carry no pixels; for host-side tests),
- *       "digest" (1 = accumulate the macroblock syntax digest; implies sync) */
+ *       "digest" (1 = accumulate the macroblock syntax digest; implies sync),
+ *       "display_delay" (n: a frame is handed out only while n pictures of the handle are still on their way -- the reference's ulMaxDisplayDelay,
+ *       nv_dec.cpp:341; default 0), "profile" (1 = time the kernels with events), "wait_idle" (block until every dispatched picture has run),
+ *       engine-wide after init: "chain_depth", "chain_lag", "chain_streams", "debug_stall" (DESIGN.md 4a);
+ *       tests only: "fast_parse" (0 = every macroblock through the general parser path), "job_digest" (1 = digest of the job lists; implies sync) */
 /* like jm_amddec_decode_frame without input: *got_frame = 1 when a display-order frame became ready (never signals end of stream) */
 int  jm_amddec_poll_frame(int *got_frame, jm_amddec_handle h);
 int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
 /* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
  *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",
- *       "threads", "elapsed_us", "display_poc:<n>" */
+ *       "threads", "elapsed_us", "display_poc:<n>", "device_wait_errors", "direct_frames" / "direct_ns" (frames that left by one copy-engine
+ *       transfer into the caller's buffer, and the time their callers waited), "copy_engines" (SDMA engines used for that, bit mask),
+ *       "job_digest", "eng_*" / "k_*" (engine and per-kernel counters, bench.py) */
 long long jm_amddec_get_stat(jm_amddec_handle h, const char *key);
 const char *jm_amddec_last_error(jm_amddec_handle h);
 
