@@ -40,8 +40,9 @@ constexpr int kPLanes = 2;                          // lanes for ordinary pictur
                                                     // active streams they are divided between the two lanes by handle parity.  It measured worse in both rounds
                                                     // (round 2, frames/s with / without: 20 streams 12.6 k / 16.0 k, 32 streams 12.5 k / 16.8 k, device-resident
                                                     // output 14.2 k / 20.6 k): two half-size batches take as long as one, and their kernels get in each other's way.
-constexpr int kLanes = kPLanes + 2;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures
+constexpr int kLanes = kPLanes + 3;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures + one for HEVC I pictures
 constexpr int kHevcLane = kPLanes + 1;
+constexpr int kHevcIntraLane = kPLanes + 2;         // an I picture's CTB-row wavefront (k_hevc_intra, 2-3 ms at 1080p) would hold up every other stream's P / B batch
 
 struct EnginePic {
     Decoder *dec = nullptr;
@@ -66,7 +67,7 @@ struct EnginePic {
     int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
     // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on its stream's ordinary lane
     // split: both ordinary-picture lanes are in use; otherwise everything ordinary runs on lane 0
-    int lane(bool chaining = false, bool split = false) const { return codec == 1 ? kHevcLane : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : (split ? p_lane : 0)); }
+    int lane(bool chaining = false, bool split = false) const { return codec == 1 ? ((has_picture && hp.n_pus == 0 && hp.n_itbs > 0) ? kHevcIntraLane : kHevcLane) : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : (split ? p_lane : 0)); }
 };
 
 struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
