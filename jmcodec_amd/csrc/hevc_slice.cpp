@@ -433,7 +433,16 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
 // 7.3.8.8, 7.3.8.10
 bool HevcPicParser::transform_unit(int x0, int y0, int xb, int yb, int log2, int depth, int blk, int cbf_y, int cbf_cb, int cbf_cr) {
     const int n = 1 << log2;
-    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) { const int i = i4(x, y); if (x == x0) edge_[i] |= 1; if (y == y0) edge_[i] |= 2; cbf_[i] = (uint8_t)cbf_y; }
+    {
+        uint8_t *ed = edge_.data(), *cf = cbf_.data();
+        const int nu = n >> 2;
+        for (int r = 0; r < nu; r++) {
+            const int i = i4(x0, y0 + 4 * r);
+            memset(cf + i, cbf_y, nu);
+            ed[i] |= 1;
+            if (r == 0) for (int k = 0; k < nu; k++) ed[i + k] |= 2;
+        }
+    }
     if ((cbf_y || cbf_cb || cbf_cr) && pps_->cu_qp_delta && !dqp_coded_) {
         int v = 0;
         if (cb_.decision(HEVC_CTX_CU_QP_DELTA)) { v = 1; while (v < 5 && cb_.decision(HEVC_CTX_CU_QP_DELTA + 1)) v++; }
@@ -525,7 +534,16 @@ bool HevcPicParser::prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, i
         }
     }
     for (int l = 0; l < 2; l++) if (((m.pf >> l) & 1) && (m.ref[l] < 0 || m.ref[l] >= sh_->n_ref[l])) return false;
-    for (int y = y0; y < y0 + h; y += 4) for (int x = x0; x < x0 + w; x += 4) { const int i = i4(x, y); mot_[i] = m; if (x == x0) edge_[i] |= 4; if (y == y0) edge_[i] |= 8; }
+    {
+        HevcMotion *mo = mot_.data(); uint8_t *ed = edge_.data();
+        const int nux = w >> 2, nuy = h >> 2;
+        for (int r = 0; r < nuy; r++) {
+            const int i = i4(x0, y0 + 4 * r);
+            for (int k = 0; k < nux; k++) mo[i + k] = m;
+            ed[i] |= 4;
+            if (r == 0) for (int k = 0; k < nux; k++) ed[i + k] |= 8;
+        }
+    }
     if (dg_->on) { dg(0x5000 | (merge << 4) | m.pf); dg(x0); dg(y0); dg(w); dg(h); dg(m.ref[0]); dg(m.ref[1]); dg(m.mv[0][0]); dg(m.mv[0][1]); dg(m.mv[1][0]); dg(m.mv[1][1]); }
     // motion compensation jobs: tiles of at most 16x16 luma samples
     HevcPu j; memset(&j, 0, sizeof j);
@@ -568,11 +586,17 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
         }
     }
     const uint16_t sidx = (uint16_t)slice_idx_;
-    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
-        const int i = i4(x, y);
-        pm_[i] = cu_intra_ ? 2 : 1; skip_[i] = cu_skip_; nofilter_[i] = tq_bypass_; slice_of_[i] = sidx; cbf_[i] = 0; ipm_[i] = 1;
-        edge_[i] = (uint8_t)((x == x0 ? 5 : 0) | (y == y0 ? 10 : 0));
-        memset(&mot_[i], 0, sizeof(HevcMotion)); mot_[i].ref[0] = mot_[i].ref[1] = -1;
+    {   // per-4x4 maps of the coding unit, a row of units at a time (the unit loop with its eight array stores was 7 % of the parse)
+        const int nu = n >> 2;
+        HevcMotion blank; memset(&blank, 0, sizeof blank); blank.ref[0] = blank.ref[1] = -1;
+        uint8_t *pm = pm_.data(), *sk = skip_.data(), *nf = nofilter_.data(), *cf = cbf_.data(), *ip = ipm_.data(), *ed = edge_.data();
+        uint16_t *so = slice_of_.data(); HevcMotion *mo = mot_.data();
+        for (int r = 0; r < nu; r++) {
+            const int i = i4(x0, y0 + 4 * r);
+            memset(pm + i, cu_intra_ ? 2 : 1, nu); memset(sk + i, cu_skip_, nu); memset(nf + i, tq_bypass_, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu);
+            memset(ed + i, r == 0 ? 10 : 0, nu); ed[i] |= 5;
+            for (int k = 0; k < nu; k++) { so[i + k] = sidx; mo[i + k] = blank; }
+        }
     }
     if (dg_->on) { dg(0x4000 | (cu_skip_ << 8) | (cu_intra_ << 7) | (tq_bypass_ << 6) | (part_mode_ << 3) | log2); dg(x0); dg(y0); }
     bool pcm = false, root_cbf = true;
@@ -649,7 +673,7 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             if (!transform_tree(x0, y0, x0, y0, log2, 0, 0, 1, 1)) return false;
         }
     }
-    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) qp_[i4(x, y)] = (int8_t)qp_y_;
+    for (int r = 0; r < (n >> 2); r++) memset(qp_.data() + i4(x0, y0 + 4 * r), (int8_t)qp_y_, n >> 2);
     last_cu_qp_ = qp_y_; cu_since_reset_ = true;
     if (dg_->on) dg(0x4800 | qp_y_);
     return !cb_.overrun;
@@ -672,7 +696,7 @@ bool HevcPicParser::coding_quadtree(int x0, int y0, int log2, int depth) {
         for (int k = 0; k < 4; k++) { const int x = x0 + (k & 1) * hh, y = y0 + (k >> 1) * hh; if (x < w_ && y < h_ && !coding_quadtree(x, y, log2 - 1, depth + 1)) return false; }
         return true;
     }
-    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) depth_[i4(x, y)] = (uint8_t)depth;
+    for (int r = 0; r < (n >> 2); r++) memset(depth_.data() + i4(x0, y0 + 4 * r), depth, n >> 2);
     derive_qp(x0, y0);
     return coding_unit(x0, y0, log2);
 }
