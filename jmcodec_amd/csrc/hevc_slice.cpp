@@ -823,19 +823,27 @@ void HevcPicParser::finish_picture() {
     for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8); jobs_->qp8[(size_t)y * w8 + x] = (uint8_t)((qp_[i] & 63) | (nofilter_[i] ? 128 : 0)); }
     // boundary strengths: bs_v[(y / 4) * (w / 8) + x / 8] for vertical edges at x = 8k, bs_h[(y / 8) * (w / 4) + x / 4] for horizontal edges
     jobs_->bs_v.assign((size_t)w8 * h4_, 0); jobs_->bs_h.assign((size_t)w4_ * h8, 0);
-    auto strength = [&](int xq, int yq, int dir) -> int {
-        const int xp = dir ? xq : xq - 1, yp = dir ? yq - 1 : yq, q = i4(xq, yq), p = i4(xp, yp);
-        const int tu = edge_[q] & (dir ? 2 : 1), pu = edge_[q] & (dir ? 8 : 4);
+    // (raw pointers: the vectors' data pointers would be reloaded after every byte store; one slice and one tile -- the usual case -- needs no boundary tests)
+    const uint8_t *edge = edge_.data(), *pm = pm_.data(), *cbf = cbf_.data(), *nofilter = nofilter_.data();
+    const HevcMotion *mot = mot_.data();
+    const bool one_region = slices_.size() == 1 && pps_->lf_across_tiles;
+    const SliceInfo &s0 = slices_[0];
+    const int w4 = w4_;
+    auto strength = [&](int q, int p, int xq, int yq, int xp, int yp, int dir) -> int {
+        const int tu = edge[q] & (dir ? 2 : 1), pu = edge[q] & (dir ? 8 : 4);
         if (!tu && !pu) return 0;
-        const SliceInfo &sq = slice_at(q), &sp = slice_at(p);
-        if (sq.deblock_disabled) return 0;
-        if (sq.addr != sp.addr && !sq.lf_across) return 0;
-        if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc); if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
-        if (pm_[q] == 2 || pm_[p] == 2) return 2;
-        if (tu && (cbf_[q] || cbf_[p])) return 1;
-        const HevcMotion &a = mot_[q], &b = mot_[p];
+        const SliceInfo *sq = &s0, *sp = &s0;
+        if (!one_region) {
+            sq = &slice_at(q); sp = &slice_at(p);
+            if (sq->addr != sp->addr && !sq->lf_across) return 0;
+            if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc); if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
+        }
+        if (sq->deblock_disabled) return 0;
+        if (pm[q] == 2 || pm[p] == 2) return 2;
+        if (tu && (cbf[q] || cbf[p])) return 1;
+        const HevcMotion &a = mot[q], &b = mot[p];
         int ra[2], rb[2]; const int16_t *va[2], *vb[2]; int na = 0, nb = 0;
-        for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq.slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) { rb[nb] = sp.slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
+        for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq->slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) { rb[nb] = sp->slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
         if (na != nb) return 1;
         auto far = [](const int16_t *u, const int16_t *v) { return std::abs(u[0] - v[0]) >= 4 || std::abs(u[1] - v[1]) >= 4; };
         if (na == 1) return ra[0] != rb[0] || far(va[0], vb[0]);
@@ -845,8 +853,25 @@ void HevcPicParser::finish_picture() {
         return straight && crossed ? (ds && dc) : (straight ? ds : dc);
     };
     if (jobs_->any_deblock) {
-        for (int y = 0; y < h_; y += 4) for (int x = 8; x < w_; x += 8) { if (!(edge_[i4(x, y)] & 5)) continue; int bs = strength(x, y, 0); if (bs) jobs_->bs_v[(size_t)(y >> 2) * w8 + (x >> 3)] = (uint8_t)(bs | (nofilter_[i4(x - 1, y)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
-        for (int y = 8; y < h_; y += 8) for (int x = 0; x < w_; x += 4) { if (!(edge_[i4(x, y)] & 10)) continue; int bs = strength(x, y, 1); if (bs) jobs_->bs_h[(size_t)(y >> 3) * w4_ + (x >> 2)] = (uint8_t)(bs | (nofilter_[i4(x, y - 1)] ? 4 : 0) | (nofilter_[i4(x, y)] ? 8 : 0)); }
+        uint8_t *bsv = jobs_->bs_v.data(), *bsh = jobs_->bs_h.data();
+        for (int y = 0; y < h_; y += 4) {
+            const int row = (y >> 2) * w4;
+            for (int x = 8; x < w_; x += 8) {
+                const int q = row + (x >> 2);
+                if (!(edge[q] & 5)) continue;
+                const int bs = strength(q, q - 1, x, y, x - 1, y, 0);
+                if (bs) bsv[(size_t)(y >> 2) * w8 + (x >> 3)] = (uint8_t)(bs | (nofilter[q - 1] ? 4 : 0) | (nofilter[q] ? 8 : 0));
+            }
+        }
+        for (int y = 8; y < h_; y += 8) {
+            const int row = (y >> 2) * w4;
+            for (int x = 0; x < w_; x += 4) {
+                const int q = row + (x >> 2);
+                if (!(edge[q] & 10)) continue;
+                const int bs = strength(q, q - w4, x, y, x, y - 1, 1);
+                if (bs) bsh[(size_t)(y >> 3) * w4 + (x >> 2)] = (uint8_t)(bs | (nofilter[q - w4] ? 4 : 0) | (nofilter[q] ? 8 : 0));
+            }
+        }
     }
     // SAO: which neighbouring CTBs the edge offset of a CTB may read (8.7.3: slice and tile boundaries)
     if (jobs_->any_sao) {
