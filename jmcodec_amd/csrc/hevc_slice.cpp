@@ -593,8 +593,11 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
         uint16_t *so = slice_of_.data(); HevcMotion *mo = mot_.data();
         for (int r = 0; r < nu; r++) {
             const int i = i4(x0, y0 + 4 * r);
-            memset(pm + i, cu_intra_ ? 2 : 1, nu); memset(sk + i, cu_skip_, nu); memset(nf + i, tq_bypass_, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu);
-            memset(ed + i, r == 0 ? 10 : 0, nu); ed[i] |= 5;
+            const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_, ved = r == 0 ? 10 : 0;
+            if (nu <= 4) {                                      // (8x8 and 16x16 units: a library call per array costs more than the stores)
+                for (int k = 0; k < nu; k++) { pm[i + k] = vpm; sk[i + k] = vsk; nf[i + k] = vnf; cf[i + k] = 0; ip[i + k] = 1; ed[i + k] = ved; }
+            } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu); memset(ed + i, ved, nu); }
+            ed[i] |= 5;
             for (int k = 0; k < nu; k++) { so[i + k] = sidx; mo[i + k] = blank; }
         }
     }
