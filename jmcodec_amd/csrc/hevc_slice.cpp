@@ -333,6 +333,17 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     last_sb = kScan.inv[scan][nsl][(lx >> 2) | ((ly >> 2) << 3)]; last_pos = kScan.inv[scan][2][(lx & 3) | ((ly & 3) << 3)];
     uint8_t csbf[8][8]; memset(csbf, 0, sizeof csbf);
     int g1ctx = 1; bool first_group = true;
+    // 8.6.4.1 scaling.  Without the digest every level is scaled and appended to the coefficient list as it is decoded (`direct`); with it the levels are
+    // first collected in lev_ / nz_pos_ (the digest wants them sorted by position) and scaled afterwards.
+    const int qp = c == 0 ? qp_y_ : hevc_qpc_tab[clip3(0, 57, qp_y_ + (c == 1 ? pps_->cb_qp_off + sh_->cb_qp_off : pps_->cr_qp_off + sh_->cr_qp_off))];
+    const HevcScaling &sf = pps_->scaling_present ? pps_->sf : sps_->sf;
+    const int mat = (cu_intra_ ? 0 : 3) + c;
+    const uint8_t *smat = log2 == 2 ? sf.f4[mat] : log2 == 3 ? sf.f8[mat] : log2 == 4 ? sf.f16[mat] : sf.f32[cu_intra_ ? 0 : 1];
+    const bool flat = !sps_->scaling_enabled || (tskip && n > 4);
+    const int bd_shift = log2 + 3, ls = hevc_level_scale[qp % 6] << (qp / 6);
+    const int64_t sc_add = (int64_t)1 << (bd_shift - 1);
+    const bool direct = !dg_->on;
+    uint32_t dw[32 * 32]; uint32_t dcount = 0;
     for (int k = 0; k < nz_n_; k++) lev_[nz_pos_[k]] = 0;             // lev_ is all zero between calls
     nz_n_ = 0;
     for (int i = last_sb; i >= 0; i--) {
@@ -390,8 +401,11 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
             if (hide && m == np - 1) neg = sum & 1;
             else { neg = signs >> 31; signs <<= 1; }
             const int xq = pos_scan[pos[m]] & 15, yq = pos_scan[pos[m]] >> 4, idx = ((ys << 2) + yq) * n + (xs << 2) + xq;
-            lev_[idx] = (int16_t)clip3(-32768, 32767, neg ? -a : a);
-            nz_pos_[nz_n_++] = (uint16_t)idx;
+            const int lv = clip3(-32768, 32767, neg ? -a : a);
+            if (direct) {
+                const int v = tq_bypass_ ? lv : clip3(-32768, 32767, (int)(((int64_t)lv * (flat ? 16 : smat[idx]) * ls + sc_add) >> bd_shift));
+                if (v) dw[dcount++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
+            } else { lev_[idx] = (int16_t)lv; nz_pos_[nz_n_++] = (uint16_t)idx; }
         }
     }
     cb.commit();                                                    // (the early error returns above abandon the slice: nothing to write back)
@@ -401,28 +415,24 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         std::sort(nz_pos_, nz_pos_ + nz_n_);
         for (int k = 0; k < nz_n_; k++) { dg(nz_pos_[k]); dg(lev_[nz_pos_[k]]); }
     }
-    // 8.6.4.1 scaling -> sparse coefficient list
-    const int qp = c == 0 ? qp_y_ : hevc_qpc_tab[clip3(0, 57, qp_y_ + (c == 1 ? pps_->cb_qp_off + sh_->cb_qp_off : pps_->cr_qp_off + sh_->cr_qp_off))];
-    const HevcScaling &sf = pps_->scaling_present ? pps_->sf : sps_->sf;
-    const int mat = (cu_intra_ ? 0 : 3) + c;
-    const uint8_t *m = log2 == 2 ? sf.f4[mat] : log2 == 3 ? sf.f8[mat] : log2 == 4 ? sf.f16[mat] : sf.f32[cu_intra_ ? 0 : 1];
-    const bool flat = !sps_->scaling_enabled || (tskip && n > 4);
-    const int bd_shift = log2 + 3, ls = hevc_level_scale[qp % 6] << (qp / 6);
+    // 8.6.4.1 scaling -> sparse coefficient list (direct: done level by level above)
     const uint32_t first = (uint32_t)jobs_->coefs.size();
-    jobs_->coefs.resize(first + (size_t)nz_n_);                      // written in place, trimmed to what survived scaling
-    uint32_t *cw = jobs_->coefs.data() + first;
     uint32_t count = 0;
-    if (tq_bypass_) {
-        for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx]; if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
-    } else {
-        const int64_t add = (int64_t)1 << (bd_shift - 1);
-        for (int k = 0; k < nz_n_; k++) {
-            const int idx = nz_pos_[k];
-            const int v = clip3(-32768, 32767, (int)(((int64_t)lev_[idx] * (flat ? 16 : m[idx]) * ls + add) >> bd_shift));
-            if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
+    if (direct) { count = dcount; jobs_->coefs.insert(jobs_->coefs.end(), dw, dw + dcount); }
+    else {
+        jobs_->coefs.resize(first + (size_t)nz_n_);                  // written in place, trimmed to what survived scaling
+        uint32_t *cw = jobs_->coefs.data() + first;
+        if (tq_bypass_) {
+            for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx]; if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
+        } else {
+            for (int k = 0; k < nz_n_; k++) {
+                const int idx = nz_pos_[k];
+                const int v = clip3(-32768, 32767, (int)(((int64_t)lev_[idx] * (flat ? 16 : smat[idx]) * ls + sc_add) >> bd_shift));
+                if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
+            }
         }
+        jobs_->coefs.resize(first + count);
     }
-    jobs_->coefs.resize(first + count);
     const uint8_t flags = (uint8_t)((tskip ? HTB_TSKIP : 0) | (tq_bypass_ ? HTB_BYPASS : 0) | ((cu_intra_ && c == 0 && n == 4) ? HTB_DST : 0));
     if (intra_tb) { HevcIntraTb &t = jobs_->itbs.back(); t.coef_off = first; t.coef_n = count; t.flags |= flags; }
     else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0; t.coef_off = first; t.coef_n = count; jobs_->tbs.push_back(t); }
