@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/soak
 for i in 1 2 3 4; do for s in 1 3 8 12 16 20; do timeout 120 python bench.py --streams $s --no-cpu-baseline --no-single > gpurun_out/soak/s${s}_$i.json 2>/dev/null || echo "FAIL s$s run $i rc=$?"; done; done
 for i in 1 2 3; do timeout 200 python bench.py --no-cpu-baseline --no-single > gpurun_out/soak/s32_$i.json 2>/dev/null || echo "FAIL s32 run $i"; done
+for s in 1 4 16; do timeout 200 python bench.py --codec hevc --streams $s --steps 3 --no-cpu-baseline --no-single > gpurun_out/soak/hevc_s$s.json 2>/dev/null || echo "FAIL hevc $s"; done
 for t in high high_b; do timeout 120 python bench.py --streams 6 --tools $t --no-cpu-baseline --no-single > gpurun_out/soak/s6_$t.json 2>/dev/null || echo "FAIL $t"; done
 python3 - <<'PY'
 import json,glob
