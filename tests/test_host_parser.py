@@ -303,3 +303,17 @@ def test_fast_p_slice_path_full_size():
     data = streams.generate(**streams.config_c1(stream_id=3, frames=6))
     a, b = _job_digest(data, True), _job_digest(data, False)
     assert a == b and a[2] == 0 and a[1] == 6
+
+
+@pytest.mark.parametrize("delay", [0, 2, 6])
+def test_display_delay_holds_frames_back_but_loses_none(delay):
+    """set_option("display_delay", n) mirrors the reference's ulMaxDisplayDelay (nv_dec.cpp:341): while input keeps coming a frame is handed out only
+    when n pictures are still on their way; the end of the stream drains everything, in the same display order."""
+    data = streams.generate(width=96, height=80, frames=12, gop=6, num_ref=2, seed=0x4D61, poc_type=0, nonref_period=3)
+    with api.JmAmdDec(0, 1, options={"parse_only": 1, "display_delay": delay}) as d:
+        n = d.decode_stream(data, keep=False)
+        pocs = [d.stat(f"display_poc:{i}") for i in range(n)]
+    with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d0:
+        n0 = d0.decode_stream(data, keep=False)
+        pocs0 = [d0.stat(f"display_poc:{i}") for i in range(n0)]
+    assert n == n0 == 12 and pocs == pocs0
