@@ -1103,16 +1103,14 @@ int Decoder::output(uint8_t *out, int *out_len) {
     *out_len = 0;
     if (cur_out_->has_data && cur_out_->host && !cur_out_->fetch) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
     else if (cur_out_->has_data) {
-        // The frame waits in device staging (fetch mode, or device_output): one synchronous DMA into the caller's buffer.  Plain hipMemcpy
-        // on purpose: the runtime pins the caller's pages (and caches the pinning), runs one copy-engine transfer and the other feeder
-        // threads queue behind it ASLEEP.  Every parallel form measured worse on the 32-stream workload, because waits inside the runtime
-        // spin: hipMemcpyAsync / hipMemcpyWithStream on a stream per handle 6.1-7.4 k frames/s at 2.2-2.6 ms of CPU per frame;
-        // hipHostRegister + hipMemcpyAsync + hipEventSynchronize(hipEventBlockingSync) 4.3 k at 3.6 ms; the same with a sleeping
-        // hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms; this form 10.7-11.4 k at 0.96-1.0 ms.
-        hipSetDevice(device_);
-        // route "direct" (host_copy.h): one copy-engine transfer into the caller's page-locked buffer, this thread asleep meanwhile
-        // The caller's buffer is page-locked for the duration of this call only (1.4 us per lock / unlock pair measured, tools/sdma_probe.cpp): a lock kept
+        // The frame waits in device staging.  Route "direct" (host_copy.h): one copy-engine transfer into the caller's buffer, this thread asleep
+        // meanwhile.  The buffer is page-locked for the duration of this call only (1.2-1.4 us per lock / unlock pair, tools/sdma_probe.cpp): a lock kept
         // between calls goes stale when the caller unmaps the buffer and the address range is mapped again (the runtime aborted in that test).
+        // Fallback (route "fetch", or no ROCr access): plain synchronous hipMemcpy -- the runtime pins the caller's pages, runs one transfer on the one
+        // engine it uses for this direction, and the other feeder threads queue behind it asleep.  Round 1 measured every parallel HIP form worse on the
+        // 32-stream workload because waits inside the runtime spin: hipMemcpyAsync on a stream per handle 6.1-7.4 k frames/s at 2.2-2.6 ms of CPU per
+        // frame; hipHostRegister + hipMemcpyAsync + blocking event 4.3 k at 3.6 ms; with a sleeping hipEventQuery poll 9.2-11.4 k at 1.1-1.2 ms.
+        hipSetDevice(device_);
         const auto c0 = std::chrono::steady_clock::now();
         void *dst = out_route_ == 3 && copier_ ? copier_->lock(out, (size_t)need) : nullptr;
         const bool went = dst && copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_);

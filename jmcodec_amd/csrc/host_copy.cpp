@@ -121,7 +121,7 @@ bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
     struct Restore { int v; ~Restore() { if (v > 0) prctl(PR_SET_TIMERSLACK, (unsigned long)v, 0, 0, 0); } } restore{old_slack};
     struct timespec ts = {0, 40 * 1000};
     long total_ns = 0;
-    for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute)
+    for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute -- a device that takes longer has hung, and the caller's plain hipMemcpy that follows will say so)
         nanosleep(&ts, nullptr);
         total_ns += ts.tv_nsec;
         const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
