@@ -119,15 +119,20 @@ bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
     const int old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
     prctl(PR_SET_TIMERSLACK, 2000ul, 0, 0, 0);
     struct Restore { int v; ~Restore() { if (v > 0) prctl(PR_SET_TIMERSLACK, (unsigned long)v, 0, 0, 0); } } restore{old_slack};
+    // First sleep: 40 us -- or, when copies have been queueing lately (~1.4 ms each with 32 handles on a saturated link), half of what they took, so that a
+    // copy costs a handful of looks whatever the load; then a quarter of the time waited so far per look (15-250 us).
+    const long typical = typical_wait_ns_.load(std::memory_order_relaxed);
     struct timespec ts = {0, 40 * 1000};
+    if (typical > 400000) ts.tv_nsec = typical / 2 > 5000000 ? 5000000 : typical / 2;      // (only when copies queue: a lone copy must be seen as it ends)
     long total_ns = 0;
     for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute -- a device that takes longer has hung, and the caller's plain hipMemcpy that follows will say so)
         nanosleep(&ts, nullptr);
         total_ns += ts.tv_nsec;
         const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
-        if (v < 1) return v == 0;
-        // the next look comes after a quarter of the time waited so far (at least 15 us, at most 250 us): a lone copy is seen within a few
-        // microseconds of its end, one that queues behind thirty others costs a dozen looks instead of a hundred
+        if (v < 1) {
+            typical_wait_ns_.store((typical * 7 + total_ns) / 8, std::memory_order_relaxed);      // (approximate on purpose: many threads update it)
+            return v == 0;
+        }
         long next = total_ns / 4; if (next < 15000) next = 15000; if (next > 250000) next = 250000;
         ts.tv_nsec = next;
     }

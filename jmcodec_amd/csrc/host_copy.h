@@ -10,6 +10,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace jmamd {
 
@@ -27,6 +28,7 @@ public:
 private:
     HostCopier() {}
     uint64_t gpu_ = 0, cpu_ = 0;                        // hsa_agent_t handles
+    std::atomic<long> typical_wait_ns_{0};              // how long copies have been taking lately, queueing included (sizes the waiter's first sleep)
     uint32_t engines_[4] = {0, 0, 0, 0}; int n_engines_ = 0;   // engine ids used in turn (none: the runtime chooses)
 };
 
