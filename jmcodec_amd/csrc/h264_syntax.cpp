@@ -100,15 +100,21 @@ std::string ParamSets::parse_sps(BitReader &br) {
     { uint32_t v = br.ue(); if (v > 16) return "max_num_ref_frames out of range"; s.max_num_ref_frames = (int)v; }
     s.gaps_allowed = br.u1();
     { uint32_t w = br.ue(), h = br.ue(); if (w >= 1024 || h >= 1024) return "picture too large"; s.mb_w = (int)w + 1; s.mb_h = (int)h + 1; }
-    if ((long long)s.mb_w * s.mb_h > 139264) return "picture too large";       // MaxFS of level 6.2 (Table A-1)
     s.frame_mbs_only = br.u1();
-    if (!s.frame_mbs_only) br.u1();
+    // frame_mbs_only_flag = 0: the stream MAY hold field pictures (PAFF) or, with mb_adaptive_frame_field_flag, field macroblock pairs (MBAFF).
+    // pic_height_in_map_units then counts field macroblock rows: FrameHeightInMbs is twice that (7.4.2.1.1).  Frame pictures of such a stream without
+    // MBAFF are coded exactly like progressive ones and decode here; field pictures are refused where they occur (slice header), MBAFF streams here.
+    if (!s.frame_mbs_only) { s.mbaff = br.u1(); s.mb_h *= 2; }
+    if ((long long)s.mb_w * s.mb_h > 139264) return "picture too large";       // MaxFS of level 6.2 (Table A-1)
     s.direct_8x8_inference = br.u1();
     if (br.u1()) {
         uint32_t c[4]; for (auto &v : c) v = br.ue();
         // frame_crop_*_offset in chroma units (4:2:0 -> 2 luma samples, 7.4.2.1.1): the cropped picture must keep at least one sample
         if (c[0] > 8192 || c[1] > 8192 || c[2] > 8192 || c[3] > 8192 || 2 * (c[0] + c[1]) >= (uint32_t)s.mb_w * 16 || 2 * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
-        s.crop_l = (int)c[0]; s.crop_r = (int)c[1]; s.crop_t = (int)c[2]; s.crop_b = (int)c[3];
+        // (vertical crop units are 2 luma rows of a FRAME, or of a field when frame_mbs_only_flag = 0: CropUnitY = SubHeightC * (2 - frame_mbs_only_flag))
+        const int vy = s.frame_mbs_only ? 1 : 2;
+        if (2 * vy * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
+        s.crop_l = (int)c[0]; s.crop_r = (int)c[1]; s.crop_t = (int)c[2] * vy; s.crop_b = (int)c[3] * vy;
     }
     if (br.u1()) {   // VUI (E.1.1); only the bitstream restriction matters to us
         if (br.u1()) { if (br.u(8) == 255) { br.u(16); br.u(16); } }
@@ -128,7 +134,8 @@ std::string ParamSets::parse_sps(BitReader &br) {
     }
     if (br.overrun()) return "SPS truncated";
     if (s.chroma_format_idc != 1 || s.bit_depth_luma != 8 || s.bit_depth_chroma != 8) return "only 8-bit 4:2:0 is supported";
-    if (!s.frame_mbs_only) return "interlaced streams are not supported";
+    if (!s.frame_mbs_only && s.mbaff) return "interlaced streams with MBAFF are not supported";
+    if (!s.frame_mbs_only && !s.direct_8x8_inference) return "direct_8x8_inference_flag must be 1 when frame_mbs_only_flag is 0";
     s.valid = true;
     sps[s.id] = s;
     return "";
@@ -180,6 +187,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if (!sps[p.sps_id].valid) return "slice refers to a missing SPS";
     const SeqParams &s = sps[p.sps_id];
     sh.frame_num = br.u(s.log2_max_frame_num);
+    if (!s.frame_mbs_only && br.u1()) return "field pictures (PAFF) are not supported";      // field_pic_flag
     if (sh.idr) sh.idr_pic_id = br.ue();
     if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present) sh.delta_poc_bottom = br.se(); }
     else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (p.bottom_field_poc_present) sh.delta_poc[1] = br.se(); }

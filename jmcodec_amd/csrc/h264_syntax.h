@@ -21,7 +21,7 @@ struct SeqParams {
     int max_num_ref_frames = 0;
     bool gaps_allowed = false;
     int mb_w = 0, mb_h = 0;
-    bool frame_mbs_only = true, direct_8x8_inference = false;
+    bool frame_mbs_only = true, mbaff = false, direct_8x8_inference = false;
     int crop_l = 0, crop_r = 0, crop_t = 0, crop_b = 0;
     int max_num_reorder_frames = -1, max_dec_frame_buffering = -1;
     int coded_w() const { return mb_w * 16; }

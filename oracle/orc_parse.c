@@ -101,6 +101,7 @@ int orc_parse_sps(OrcDec *d, Bits *b) {
     if (s.crop) {
         s.crop_left = bits_ue(b); s.crop_right = bits_ue(b);
         s.crop_top = bits_ue(b); s.crop_bottom = bits_ue(b);
+        if (!s.frame_mbs_only) { s.crop_top *= 2; s.crop_bottom *= 2; }     /* CropUnitY = SubHeightC * (2 - frame_mbs_only_flag), 7.4.2.1.1 */
     }
     s.vui_present = bits_u1(b);
     s.max_num_reorder_frames = -1; s.max_dec_frame_buffering = -1;
@@ -124,7 +125,9 @@ int orc_parse_sps(OrcDec *d, Bits *b) {
     if (b->err) ORC_FAIL(d, "SPS truncated");
     if (s.chroma_format_idc != 1 || s.bit_depth_luma != 8 || s.bit_depth_chroma != 8)
         ORC_FAIL(d, "unsupported chroma format / bit depth (8-bit 4:2:0 only)");
-    if (!s.frame_mbs_only) ORC_FAIL(d, "interlaced (field/MBAFF) streams unsupported");
+    /* frame_mbs_only_flag = 0 without MBAFF: frame pictures are coded like progressive ones (decoded); field pictures are refused in the slice header */
+    if (!s.frame_mbs_only && s.mb_aff) ORC_FAIL(d, "interlaced streams with MBAFF unsupported");
+    if (!s.frame_mbs_only && !s.direct_8x8_inference) ORC_FAIL(d, "direct_8x8_inference_flag must be 1 when frame_mbs_only_flag is 0");
     if (s.mb_width > 1024 || s.mb_height > 1024) ORC_FAIL(d, "picture too large");
     s.valid = 1;
     d->sps[s.sps_id] = s;
@@ -185,6 +188,7 @@ int orc_parse_slice_header(OrcDec *d, Bits *b, int nal_unit_type, int nal_ref_id
     if (!d->sps[pps->sps_id].valid) ORC_FAIL(d, "slice refers to missing SPS");
     const Sps *sps = &d->sps[pps->sps_id];
     sh->frame_num = bits_u(b, sps->log2_max_frame_num);
+    if (!sps->frame_mbs_only && bits_u1(b)) ORC_FAIL(d, "field pictures (PAFF) unsupported");      /* field_pic_flag */
     if (sh->idr) sh->idr_pic_id = bits_ue(b);
     if (sps->poc_type == 0) {
         sh->poc_lsb = bits_u(b, sps->log2_max_poc_lsb);

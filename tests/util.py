@@ -107,6 +107,11 @@ B_CASES = {
     "mmco_longterm_rplm_cabac": dict(width=96, height=80, frames=20, gop=10, mode=1, seed=108, mmco=1, rplm=1, num_ref=3, cabac=1, t8x8=1),
     "mmco_two_refs_poc0": dict(width=96, height=80, frames=20, gop=20, mode=1, seed=17, mmco=1, num_ref=2, poc_type=0, slices=2),
     "mmco_one_ref": dict(width=96, height=80, frames=16, gop=16, mode=1, seed=109, mmco=1, num_ref=1),
+    # frame_mbs_only_flag = 0 without MBAFF, every picture a frame picture (field_pic_flag = 0): an interlace-capable stream coded progressively.
+    # pic_height_in_map_units counts field macroblock rows, the vertical crop unit is four luma rows, the slice header carries field_pic_flag
+    "fmo0_cavlc_fuzz": dict(width=96, height=96, frames=8, gop=4, mode=1, num_ref=2, slices=2, seed=110, fmo0=1),
+    "fmo0_cabac_b_crop": dict(width=176, height=156, frames=10, gop=10, mode=1, seed=111, fmo0=1, cabac=1, t8x8=1, bframes=2, num_ref=3),
+    "fmo0_real": dict(width=320, height=256, frames=6, gop=6, seed=112, fmo0=1, cabac=1),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

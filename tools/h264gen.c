@@ -57,6 +57,8 @@ typedef struct {
                                    common convention "unavailable samples count as 128", which constrained_intra_pred exposes)   */
     int no_intra;               /* 1: fuzz mode codes no intra macroblocks in P / B pictures and no non-IDR I pictures (the random numbers are
                                    still drawn, so the rest of the stream's decisions do not shift)                              */
+    int fmo0;                   /* 1: frame_mbs_only_flag = 0 without MBAFF, every picture a FRAME picture (field_pic_flag = 0): an interlace-capable
+                                   stream that happens to be coded progressively.  Needs an even number of macroblock rows; Main profile at least */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -1778,7 +1780,7 @@ static void write_sps_pps(Enc *e) {
     g_w8_version++;
     int high = p->t8x8 || p->scaling;
     if (high) { bw_put(w, 8, 100); bw_put(w, 8, 0); }                  /* High */
-    else if (p->cabac || p->bframes || p->wp) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
+    else if (p->cabac || p->bframes || p->wp || p->fmo0) { bw_put(w, 8, 77); bw_put(w, 8, 0x40); }          /* Main, constraint_set1 */
     else { bw_put(w, 8, 66); bw_put(w, 8, 0xC0); }                        /* Baseline, constraint_set0/1 */
     bw_put(w, 8, p->level_idc);
     bw_ue(w, 0);
@@ -1787,9 +1789,10 @@ static void write_sps_pps(Enc *e) {
     bw_ue(w, p->poc_type);
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
     bw_ue(w, p->num_ref); bw_put(w, 1, 0);
-    bw_ue(w, e->mbw - 1); bw_ue(w, e->mbh - 1);
-    bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)p->dinf8);                    /* frame_mbs_only, direct_8x8_inference */
-    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / 2;
+    bw_ue(w, e->mbw - 1); bw_ue(w, (p->fmo0 ? e->mbh / 2 : e->mbh) - 1);   /* pic_height_in_map_units: field macroblock rows when frame_mbs_only_flag = 0 */
+    if (p->fmo0) { bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 1); }  /* frame_mbs_only_flag 0, mb_adaptive_frame_field_flag 0, direct_8x8_inference_flag 1 */
+    else { bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)p->dinf8); }           /* frame_mbs_only, direct_8x8_inference */
+    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / (p->fmo0 ? 4 : 2);   /* CropUnitY = 2 * (2 - frame_mbs_only_flag) */
     if (cr || cb) { bw_put(w, 1, 1); bw_ue(w, 0); bw_ue(w, cr); bw_ue(w, 0); bw_ue(w, cb); } else bw_put(w, 1, 0);
     bw_put(w, 1, 0);                                                      /* no VUI */
     bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
@@ -1921,6 +1924,7 @@ static void encode_frame(Enc *e, int t, int is_b) {
         bw_ue(w, e->slice_type + ((sl & 1) ? 0 : 5));                     /* alternate slice_type / slice_type+5 spelling */
         bw_ue(w, 0);
         bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
+        if (p->fmo0) bw_put(w, 1, 0);                                      /* field_pic_flag */
         if (idr) bw_ue(w, e->idr_id & 0xffff);
         if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_poc & ((1u << e->poc_lsb_bits) - 1));
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
@@ -2044,6 +2048,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     e->cabac = p->cabac;
     if (p->nonref_period == 1) p->nonref_period = 2;
     e->mbw = (p->width + 15) / 16; e->mbh = (p->height + 15) / 16; e->W = e->mbw * 16; e->H = e->mbh * 16;
+    p->fmo0 = p->fmo0 != 0;
+    if (p->fmo0) { if ((e->mbh & 1) || ((e->H - p->height) & 3)) { free(e); return -1; } p->dinf8 = 1; }
     if (p->slices > e->mbh) p->slices = e->mbh;
     e->log2_max_fn = 4 + (p->seed & 3); e->poc_lsb_bits = 6 + (p->seed & 1) * 2;
     e->rng.s = (uint64_t)p->seed * 0x9E3779B97F4A7C15ull + 12345;
@@ -2084,7 +2090,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
