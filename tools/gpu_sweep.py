@@ -42,6 +42,8 @@ def h264_params(r):
              nc_corner=r.choice([0, 0, 0, 1]), no_intra=r.choice([0, 1, 1]), search=r.choice([4, 4, 16, 48]))      # no_intra: pictures that can run in chain launches
     if not b and r.random() < 0.3:
         a["mmco"] = 1
+    if (cab or b) and r.random() < 0.25 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
+        a.update(fmo0=1, dinf8=1)                                                                                  # interlace-capable stream, frame pictures only
     if r.random() < 0.4:
         a["frames"] = r.choice([9, 14, 20])                                                                        # long enough for deep chains
     return a

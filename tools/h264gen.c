@@ -1763,7 +1763,8 @@ static void write_scaling_matrix(Enc *e, BitW *w, int n_lists) {
         for (int j = 0; j < n; j++) {
             if (j == stop) { bw_se(w, -last <= -128 ? 256 - last : -last); for (int k = j; k < n; k++) eff[i][k] = (uint8_t)last; break; }
             int v = 8 + rnd_n(&r, 41);                                     /* 8..48 */
-            if (j > 0 && rnd_n(&r, 3)) v = CLIP3(8, 48, last + rnd_n(&r, 9) - 4);
+            if (j > 0 && rnd_n(&r, 3)) { const int step = last + rnd_n(&r, 9) - 4; v = CLIP3(8, 48, step); }   /* (CLIP3 is a macro: the draw must not sit inside it -- it used to,
+                                                                                                        and one matrix in ~150 came out with a 0 entry, which ends the list early: both decoders rightly rejected that SPS) */
             int d = v - last; bw_se(w, d);
             eff[i][j] = (uint8_t)v; last = v;
         }
