@@ -173,8 +173,15 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
 // ------------------------------------------------------------------------------------------------------------
 // 8.6.4.2: residual of one transform block from its sparse scaled coefficients; result in res[y * n + x]
 // ------------------------------------------------------------------------------------------------------------
+// The n-point core transform matrix of 8.6.4.2 is rows 0, 32/n, 2 * 32/n, ... of the 32-point matrix, first n columns: tm[j * n + y], n * n bytes (16 for a 4x4
+// block -- the whole 32x32 matrix used to be copied for every block).  The caller synchronises before using it.
+__device__ __forceinline__ void load_transform_matrix(int8_t *tm, int log2, int lane, int nt) {
+    if (log2 == 5) { for (int k = lane; k < 256; k += nt) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k]; return; }
+    const int n = 1 << log2, step = 32 >> log2;
+    for (int k = lane; k < n * n; k += nt) tm[k] = c_trans[(k >> log2) * step][k & (n - 1)];
+}
 // Callers make sure nobody still reads d / res (a barrier since their last use).  Returns the buffer that holds the residual.
-// tm: the 32x32 core transform matrix in LDS; ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the rest).
+// tm: the block's n-point transform matrix in LDS (load_transform_matrix); ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the rest).
 // WAVE: the caller is a single wavefront (LDS operations of one wave execute in order, so a scheduling barrier replaces s_barrier).
 template <bool WAVE>
 __device__ const int16_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, const int8_t *tm, int *ext, int lane, int nt) {
@@ -187,12 +194,12 @@ __device__ const int16_t *residual_block(const uint32_t *coefs, int count, int l
     sync();
     if (flags & HTB_BYPASS) return d;
     if (flags & HTB_TSKIP) { for (int k = lane; k < nn; k += nt) res[k] = (int16_t)(((d[k] << 7) + 2048) >> 12); sync(); return res; }
-    const int step = 32 >> log2, dst = flags & HTB_DST, jmax = ext[0], xw = ext[1] + 1;
+    const int dst = flags & HTB_DST, jmax = ext[0], xw = ext[1] + 1;
     // columns: g[y][x] = clip16((sum_j M[j][y] * d[j][x] + 64) >> 7) for the columns that hold coefficients, kept in res
     for (int k = lane; k < n * xw; k += nt) {
         const int y = k / xw, x = k - y * xw;
         int v = 0;
-        for (int j = 0; j <= jmax; j++) v += (dst ? c_dst[j][y] : tm[j * step * 32 + y]) * d[j * n + x];
+        for (int j = 0; j <= jmax; j++) v += (dst ? c_dst[j][y] : tm[(j << log2) + y]) * d[j * n + x];
         res[y * n + x] = (int16_t)clip3(-32768, 32767, (v + 64) >> 7);
     }
     sync();
@@ -200,7 +207,7 @@ __device__ const int16_t *residual_block(const uint32_t *coefs, int count, int l
     for (int k = lane; k < nn; k += nt) {
         const int y = k >> log2, x = k & (n - 1);
         int v = 0;
-        for (int j = 0; j < xw; j++) v += (dst ? c_dst[j][x] : tm[j * step * 32 + x]) * res[y * n + j];
+        for (int j = 0; j < xw; j++) v += (dst ? c_dst[j][x] : tm[(j << log2) + x]) * res[y * n + j];
         d[k] = (int16_t)((v + 2048) >> 12);
     }
     sync();
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     __shared__ __align__(16) int8_t tm[32 * 32];
     __shared__ int ext[2];
     const int lane = threadIdx.x, n = 1 << tb.log2;
-    for (int k = lane; k < 256; k += 64) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
+    load_transform_matrix(tm, tb.log2, lane, 64);
     const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
     uint8_t *dst = pp.surf[pp.work];
     for (int k = lane; k < n * n; k += 64) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
     __shared__ __align__(16) int8_t tm[32 * 32];
     __shared__ int ext[2];
     const int lane = threadIdx.x, n = 1 << tb.log2;
-    for (int k = lane; k < 256; k += 64) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k];
+    load_transform_matrix(tm, tb.log2, lane, 64);
     const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
     const int pw = tb.plane ? pp.w >> 1 : pp.w;
     int16_t *dst = pp.resid + (tb.plane == 0 ? 0 : (size_t)pp.w * pp.h + (tb.plane == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
