@@ -170,3 +170,33 @@ def test_c3_4k_whole_gop8_pyramid():
     assert len(frames) == 17
     for i, f in enumerate(frames):
         assert f == want[i * fs:(i + 1) * fs], f"frame {i} differs from the oracle"
+
+
+@pytest.mark.gpu
+def test_mixed_codecs_concurrently_all_engine_lanes():
+    """H.264 Baseline, H.264 High with B pictures and HEVC handles decoding at the same time on one device: ordinary lane (chain launches and stage kernels),
+    H.264 intra lane, HEVC lane and HEVC I-picture lane all busy, 18 handles on 18 threads, every frame compared with the oracles."""
+    import threading
+    from util import ALL_CASES
+    o4, oh = streams.Oracle(), streams.OracleHevc()
+    jobs = []
+    for rep in range(2):
+        for name in ("real_qvga", "fuzz_multiref_slices", "b_real_spatial", "b_fuzz_cabac_high", "high_real_qvga", "fmo0_cabac_b_crop"):
+            d = streams.generate(**dict(ALL_CASES[name], seed=ALL_CASES[name].get("seed", 1) + 1000 * rep))
+            jobs.append((0, name, d, o4.decode(d, 1)[0]))
+        for kw in (dict(width=320, height=240, frames=9, gop=8, num_ref=2, seed=0x4D70 + rep, sdh=1), dict(width=176, height=144, frames=17, gop=8, num_ref=3, seed=0x4D80 + rep, mode=1),
+                   dict(width=352, height=288, frames=6, gop=0, num_ref=1, seed=0x4D90 + rep)):
+            d = streams.generate_hevc(**kw)
+            jobs.append((1, "hevc %dx%d" % (kw["width"], kw["height"]), d, oh.decode(d, 1)[0]))
+    got, errs = [None] * len(jobs), [None] * len(jobs)
+
+    def run(i):
+        codec, _, d, _ = jobs[i]
+        with jmcodec_amd.JmAmdDec(codec, 1) as dec:
+            got[i] = b"".join(dec.decode_stream(d))
+            errs[i] = dec.stat("errors")
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i, (codec, name, _, want) in enumerate(jobs):
+        assert errs[i] == 0 and got[i] == want, (codec, name)
