@@ -113,6 +113,7 @@ bool HevcPicParser::avail_zs(int xc, int yc, int xn, int yn) const {
     if (xn < 0 || yn < 0 || xn >= w_ || yn >= h_) return false;
     const int s = sps_->log2_min_tb;
     if (zs_[(size_t)(yn >> s) * tb_w_ + (xn >> s)] > zs_[(size_t)(yc >> s) * tb_w_ + (xc >> s)]) return false;
+    if ((((xn ^ xc) | (yn ^ yc)) >> sps_->log2_ctb) == 0) return true;      // same coding tree block: same slice, same tile
     const int cn = (yn >> sps_->log2_ctb) * ctb_w_ + (xn >> sps_->log2_ctb);
     return ctb_slice_[cn] == sh_->slice_addr && tile_id_[rs2ts_[cn]] == tile_id_[ctb_ts_];
 }
@@ -608,7 +609,8 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
                 for (int k = 0; k < nu; k++) { pm[i + k] = vpm; sk[i + k] = vsk; nf[i + k] = vnf; cf[i + k] = 0; ip[i + k] = 1; ed[i + k] = ved; }
             } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu); memset(ed + i, ved, nu); }
             ed[i] |= 5;
-            for (int k = 0; k < nu; k++) { so[i + k] = sidx; mo[i + k] = blank; }
+            for (int k = 0; k < nu; k++) so[i + k] = sidx;
+            if (cu_intra_) for (int k = 0; k < nu; k++) mo[i + k] = blank;      // (the prediction units of an inter unit cover it and write their own)
         }
     }
     if (dg_->on) { dg(0x4000 | (cu_skip_ << 8) | (cu_intra_ << 7) | (tq_bypass_ << 6) | (part_mode_ << 3) | log2); dg(x0); dg(y0); }
