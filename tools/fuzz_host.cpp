@@ -14,6 +14,7 @@ static std::vector<unsigned char> read_all(const char *p) {
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s stream.h264|stream.h265 [seed] [trials] [codec_type]\n", argv[0]); return 2; }
     std::vector<unsigned char> base = read_all(argv[1]);
+    if (base.size() < 200) { fprintf(stderr, "%s: missing or shorter than 200 bytes\n", argv[1]); return 2; }
     unsigned long long s = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1; int trials = argc > 3 ? atoi(argv[3]) : 100; const int codec = argc > 4 ? atoi(argv[4]) : 0;
     auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(s >> 33); };
     long frames = 0;
