@@ -28,6 +28,23 @@ struct CabacTrans {
 };
 static const CabacTrans kCabacTrans;       // 256 bytes per translation unit, filled before main
 
+// Everything one decision needs from the tables, in ONE 64-bit word per context state (pStateIdx << 1 | valMPS): bytes 0-3 rangeTabLps for the four
+// quantised ranges (Table 9-44), byte 4 the next state after the most probable symbol, byte 5 after the least probable one.  The word's address depends on
+// the state only, so its load is off the dependency chain that links one bin to the next (range -> LPS range -> new range): on that chain the range now
+// picks a byte with a shift instead of a second, range-addressed table load.
+struct CabacRows {
+    uint64_t r[128];
+    CabacRows() : r() {
+        for (int s = 0; s < 128; s++) {
+            uint64_t w = 0;
+            for (int q = 0; q < 4; q++) w |= (uint64_t)cabac_range_lps[s >> 1][q] << (8 * q);
+            w |= (uint64_t)kCabacTrans.t[2 * s] << 32; w |= (uint64_t)kCabacTrans.t[2 * s + 1] << 40;
+            r[s] = w;
+        }
+    }
+};
+static const CabacRows kCabacRows;         // (defined after kCabacTrans in every translation unit: initialised after it)
+
 struct Cabac {
     uint64_t val = 0; int pos = 0;
     uint32_t range = 510;
@@ -65,16 +82,16 @@ struct Cabac {
     // 9.3.3.2.1, without a branch on the decoded symbol (it is the least predictable branch of the whole parser): `m` is all ones when the
     // offset lies in the LPS sub-interval and selects offset, range, next state and bin value arithmetically
     __attribute__((always_inline)) inline int decision(int ctx) {
-        const uint8_t *const tr = kCabacTrans.t;
         const uint32_t s = state[ctx];
-        const uint32_t lps = cabac_range_lps[s >> 1][(range >> 6) & 3];
+        const uint64_t row = kCabacRows.r[s];
+        const uint32_t lps = (uint32_t)(row >> ((range >> 3) & 24)) & 0xff;
         const uint32_t rm = range - lps;
         const uint64_t scaled = (uint64_t)rm << pos;
         const uint64_t m = (uint64_t)((int64_t)(scaled - val - 1) >> 63);
         const uint32_t m32 = (uint32_t)m;
         val -= scaled & m;
         const uint32_t r = rm ^ ((rm ^ lps) & m32);
-        state[ctx] = tr[2 * s + (m32 & 1)];
+        state[ctx] = (Cabac::State)((row >> (32 + (m32 & 8))) & 0xff);
         const int sh = __builtin_clz(r) - 23;                   // MPS: 0 or 1 (range stays >= 128); LPS: range in [6, 240] -> back into [256, 511]
         range = r << sh; pos -= sh;
         if (pos < 16) refill();
@@ -123,17 +140,17 @@ struct CabacRegs {
         val = (val << 32) | w; pos += 32;
     }
     inline int decision(int ctx) {
-        const uint8_t *const tr = kCabacTrans.t;
         const uint32_t s = state[ctx];
-        const uint32_t lps = cabac_range_lps[s >> 1][(range >> 6) & 3];
+        const uint64_t row = kCabacRows.r[s];
+        const uint32_t lps = (uint32_t)(row >> ((range >> 3) & 24)) & 0xff;
         const uint32_t rm = range - lps;
         const uint64_t scaled = (uint64_t)rm << pos;
         const uint64_t m = (uint64_t)((int64_t)(scaled - val - 1) >> 63);
         const uint32_t m32 = (uint32_t)m;
         val -= scaled & m;
         const uint32_t r = rm ^ ((rm ^ lps) & m32);
-        state[ctx] = tr[2 * s + (m32 & 1)];
-        const int sh = __builtin_clz(r) - 23;
+        state[ctx] = (Cabac::State)((row >> (32 + (m32 & 8))) & 0xff);
+        const int sh = __builtin_clz(r) - 23;                   // MPS: 0 or 1 (range stays >= 128); LPS: range in [6, 240] -> back into [256, 511]
         range = r << sh; pos -= sh;
         if (pos < 16) refill();
         return (int)((s ^ m32) & 1);
