@@ -3,6 +3,7 @@
 #include "decoder.h"
 #include "kernels.h"
 #include <hip/hip_runtime_api.h>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <vector>
@@ -12,6 +13,16 @@ using jmamd::Decoder;
 // The engine drives several HIP streams (per lane: decode + pack-out, plus one copy stream) that must map to distinct
 // hardware queues to run concurrently; ROCm's default is 4 queues per process.  Must be set before the runtime initialises.
 __attribute__((constructor)) static void jm_amddec_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+// The host half is compiled for BMI1 / BMI2 / LZCNT (Makefile: the arithmetic decoder's variable shifts and leading-zero counts; every x86 host an
+// MI355X is sold in has them).  A CPU without them gets told so before the first such instruction runs, instead of an illegal-instruction trap.
+__attribute__((constructor(101), target("no-bmi,no-bmi2,no-lzcnt"))) static void jm_amddec_cpu_check() {
+    __builtin_cpu_init();
+    if (!__builtin_cpu_supports("bmi") || !__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("lzcnt")) {
+        fputs("jm_amd_dec: this build needs a CPU with BMI1, BMI2 and LZCNT (rebuild jmcodec_amd/csrc with HOST_ISA= for older hosts)\n", stderr);
+        abort();
+    }
+}
 
 #define D(h) (reinterpret_cast<Decoder *>(h))
 
