@@ -14,3 +14,16 @@ for f in sorted(glob.glob("gpurun_out/check/*.json")):
     h=d["host_cpu"]; r=d["roofline"]
     print(f.split("/")[-1], d["value"], d["bit_exact"], d["decode_errors"], h["cpus_busy"], h["cpu_ms_per_frame"], r["kernel"], r["frac"], (d.get("pcie_out") or {}).get("frac"), (d.get("single_stream") or {}).get("value"), (d.get("cpu_baseline") or {}).get("value"))
 PY
+# the CABAC-bound configurations (host half rebuilt with the packed table rows and BMI2)
+mkdir -p gpurun_out/check
+timeout 300 python bench.py --tools high --no-cpu-baseline --no-single > gpurun_out/check/r02_bench_high.json 2>/dev/null || echo FAIL high
+timeout 300 python bench.py --tools high_b --no-cpu-baseline --no-single > gpurun_out/check/r02_bench_high_b.json 2>/dev/null || echo FAIL high_b
+timeout 500 python bench.py --tools high_b --width 3840 --height 2160 --streams 16 --frames 24 --steps 3 --no-cpu-baseline --no-single > gpurun_out/check/r02_c2_4k.json 2>/dev/null || echo FAIL c2
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/check/r02_*.json")):
+    try: d=json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e: print(f,"ERR",e); continue
+    h=d["host_cpu"]
+    print(f.split("/")[-1], d["value"], d["bit_exact"], d["decode_errors"], h["cpus_busy"], h["cpu_ms_per_frame"])
+PY
