@@ -81,8 +81,8 @@ HostCopier *HostCopier::get(int dev) {
         }
         (void)hipGetLastError();
         // (engine 0x1 is where the HIP runtime puts its host -> device copies on this platform whatever the preference query says: last choice)
-        for (int b = 1; b < 16 && c->n_engines_ < 3; b++) if (t[b] <= 1.5 * best && !(h2d & (1u << b))) c->engines_[c->n_engines_++] = 1u << b;
-        if (!c->n_engines_ && t[0] <= 1.5 * best) c->engines_[c->n_engines_++] = 1u;
+        for (int b = 1; b < 16 && c->n_engines_ < 3; b++) if (t[b] < 1e29 && t[b] <= 1.5 * best && !(h2d & (1u << b))) c->engines_[c->n_engines_++] = 1u << b;      // (1e30 = not measured)
+        if (!c->n_engines_ && t[0] < 1e29 && t[0] <= 1.5 * best) c->engines_[c->n_engines_++] = 1u;
         if (!c->n_engines_) for (uint32_t e = 1; e && c->n_engines_ < 2; e <<= 1) if (d2h & e) c->engines_[c->n_engines_++] = e;     // (nothing measured: the runtime's recommendation)
         if (sg.handle) (void)hsa_signal_destroy(sg);
         if (hloc) c->unlock(hbuf);
