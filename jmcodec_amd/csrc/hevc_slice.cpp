@@ -857,6 +857,7 @@ void HevcPicParser::finish_picture() {
         if (pm[q] == 2 || pm[p] == 2) return 2;
         if (tu && (cbf[q] || cbf[p])) return 1;
         const HevcMotion &a = mot[q], &b = mot[p];
+        if (sq == sp && !memcmp(&a, &b, sizeof a)) return 0;      // the same motion on both sides (a transform edge inside a prediction block, merged neighbours)
         int ra[2], rb[2]; const int16_t *va[2], *vb[2]; int na = 0, nb = 0;
         for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq->slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) { rb[nb] = sp->slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
         if (na != nb) return 1;
