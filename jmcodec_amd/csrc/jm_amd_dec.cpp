@@ -16,6 +16,7 @@ __attribute__((constructor)) static void jm_amddec_runtime_defaults() { setenv("
 
 // The host half is compiled for BMI1 / BMI2 / LZCNT (Makefile: the arithmetic decoder's variable shifts and leading-zero counts; every x86 host an
 // MI355X is sold in has them).  A CPU without them gets told so before the first such instruction runs, instead of an illegal-instruction trap.
+#if defined(__BMI2__) || defined(__BMI__) || defined(__LZCNT__)
 __attribute__((constructor(101), target("no-bmi,no-bmi2,no-lzcnt"))) static void jm_amddec_cpu_check() {
     __builtin_cpu_init();
     if (!__builtin_cpu_supports("bmi") || !__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("lzcnt")) {
@@ -23,6 +24,7 @@ __attribute__((constructor(101), target("no-bmi,no-bmi2,no-lzcnt"))) static void
         abort();
     }
 }
+#endif
 
 #define D(h) (reinterpret_cast<Decoder *>(h))
 
