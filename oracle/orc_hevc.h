@@ -13,7 +13,9 @@
  * image holds no third-party HEVC stream or decoder either, so every table in orc_hevc_tables.h (CABAC context
  * initialisation values, transform matrix, filters, beta/tC) is restated from the published standard without an external
  * check.  What pins it instead: agreement with an independently written encoder's reconstruction loop (tools/hevcgen.c)
- * and structural tests on the tables (tests/test_hevc_*.py).
+ * and structural tests on the tables (tests/test_hevc_*.py), a pcm_sample known answer (all-PCM 8-bit stream: decoded blocks
+ * == payload bytes, tests/test_hevc_oracle.py::test_pcm_known_answer) and a separately typed copy of the 462 initValues
+ * (tests/test_table_provenance.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this code.
  */

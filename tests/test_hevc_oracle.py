@@ -30,6 +30,7 @@ HEVC_CASES = {
     "dqp_depths": dict(width=128, height=96, frames=3, dqp=4, mode=1, seed=11, cb_qp_off=-5, cr_qp_off=7),
     "pcm_bypass": dict(width=96, height=80, frames=3, pcm=1, bypass=1, mode=1, seed=12),
     "pcm_filtered": dict(width=96, height=80, frames=2, pcm=2, mode=1, seed=13),
+    "pcm_only_8bit": dict(width=96, height=80, frames=3, pcm=3, ctb_log2=4, min_cb_log2=4, sao=0, deblock=0, gop=0, num_ref=1, seed=21),   # the known-answer stream below
     "cip": dict(width=96, height=80, frames=4, cip=1, mode=1, seed=14),
     "wp_b": dict(width=96, height=80, frames=7, gop=2, num_ref=2, wp=1, mode=1, seed=15),
     "rplm": dict(width=96, height=80, frames=6, num_ref=3, rplm=1, mode=1, seed=16),
@@ -209,3 +210,37 @@ def test_decoding_from_a_cra_drops_its_rasl_pictures(oracle):
     out2, n2, _, _ = oracle.decode(head + eos + tail, 1)
     n_head = oracle.decode(head, 1)[1]
     assert n2 == n_head + n and out2[n_head * fs:] == out
+
+
+def test_pcm_known_answer(oracle):
+    """A true known answer, independent of the reconstruction code of either decoder: in a stream whose coding units are all pcm_flag = 1 with 8-bit
+    samples, no in-loop filter and 16x16 coding tree blocks, every decoded block must literally be a run of payload bytes of the slice data, in
+    decoding order (7.3.8.7 pcm_sample: luma 16x16, then Cb 8x8, then Cr 8x8)."""
+    import jmcodec_amd
+    from util import unescape
+    w, h, frames = 96, 80, 3
+    data = streams.generate_hevc(**HEVC_CASES["pcm_only_8bit"])
+    out, n, ow, oh = oracle.decode(data, 1)
+    assert (n, ow, oh) == (frames, w, h)
+    slices = []
+    for x in jmcodec_amd.split_nalus(data):
+        nal = x.lstrip(b"\x00")[1:]                    # after the start code
+        if ((nal[0] >> 1) & 63) < 32:                  # VCL NAL units
+            slices.append(unescape(nal[2:]))
+    assert len(slices) == frames
+    fs = w * h * 3 // 2
+    for f, rbsp in enumerate(slices):
+        fr = np.frombuffer(out[f * fs:(f + 1) * fs], np.uint8)
+        Y = fr[:w * h].reshape(h, w); U = fr[w * h:w * h * 5 // 4].reshape(h // 2, w // 2); V = fr[w * h * 5 // 4:].reshape(h // 2, w // 2)
+        pos = 0
+        for cy in range(h // 16):
+            for cx in range(w // 16):
+                payload = (Y[cy * 16:cy * 16 + 16, cx * 16:cx * 16 + 16].tobytes() + U[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8].tobytes()
+                           + V[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8].tobytes())
+                k = rbsp.find(payload, pos)
+                assert k >= 0, (f, cx, cy)
+                # between two payloads: the arithmetic decoder's 9 + 7 initialisation bits, end_of_slice_segment_flag, (cu_skip_flag, pred_mode_flag,) part_mode,
+                # pcm_flag and the alignment bits -- a few bytes; before the first one also the slice segment header
+                assert k - pos <= (24 if (cx, cy) == (0, 0) else 6), (f, cx, cy, k - pos)
+                pos = k + 384
+        assert len(rbsp) - pos <= 4                    # end_of_slice_segment_flag + rbsp_slice_segment_trailing_bits

@@ -849,6 +849,7 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
         if (fuzz) intra = rnd_n(r, 5) == 0;
         else { int act = 0; const uint8_t *sp = e->src.pl[0] + y0 * e->src.stride[0] + x0; for (int y = 0; y < n; y += 2) for (int x = 0; x < n; x += 2) act += ABS(sp[y * e->src.stride[0] + x] - sp[y * e->src.stride[0] + x + 1]); intra = rnd_n(r, 24) == 0 || (act < n * n / 8 && rnd_n(r, 3) == 0); }
     }
+    if (p->pcm == 3) intra = 1;                                         /* known-answer streams: every coding unit I_PCM with 8-bit samples */
     cu->intra = intra;
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
         int i = I4(e, x, y);
@@ -858,11 +859,11 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
         if (y == y0) e->edges[i] |= 10;
     }
     if (intra) {
-        cu->pcm = p->pcm && log2 <= MIN(5, p->ctb_log2) && rnd_n(r, fuzz ? 10 : 40) == 0;
+        cu->pcm = p->pcm && log2 <= MIN(5, p->ctb_log2) && (p->pcm == 3 || rnd_n(r, fuzz ? 10 : 40) == 0);
         cu->part = (!cu->pcm && log2 == p->min_cb_log2 && rnd_n(r, 3) == 0) ? 3 : 0;
         if (cu->pcm) {
-            for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) { int bits = c ? 6 : 7; e->cur->pl[c][y * e->cur->stride[c] + x] = (uint8_t)((e->src.pl[c][y * e->src.stride[c] + x] >> (8 - bits)) << (8 - bits)); } }
-            if (p->pcm == 1) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->nofilt[I4(e, x, y)] = 1;   /* pcm_loop_filter_disabled_flag */
+            for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) { int bits = p->pcm == 3 ? 8 : (c ? 6 : 7); e->cur->pl[c][y * e->cur->stride[c] + x] = (uint8_t)((e->src.pl[c][y * e->src.stride[c] + x] >> (8 - bits)) << (8 - bits)); } }
+            if (p->pcm == 1 || p->pcm == 3) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->nofilt[I4(e, x, y)] = 1;   /* pcm_loop_filter_disabled_flag */
         } else {
             int np = cu->part == 3 ? 2 : 1, pb = n / np;
             cu->intra_split = np == 2;
@@ -955,7 +956,7 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
             if (cu->pcm) {
                 BitW *w = cb->w;
                 while (w->nbits) bw_put(w, 1, 0);                       /* pcm_alignment_zero_bit */
-                for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0, bits = c ? 6 : 7; for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) bw_put(w, bits, (uint32_t)(e->cur->pl[c][y * e->cur->stride[c] + x] >> (8 - bits))); }
+                for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0, bits = p->pcm == 3 ? 8 : (c ? 6 : 7); for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) bw_put(w, bits, (uint32_t)(e->cur->pl[c][y * e->cur->stride[c] + x] >> (8 - bits))); }
                 cab_start(cb, w);
             } else {
                 int np = cu->part == 3 ? 4 : 1;
@@ -1345,7 +1346,7 @@ static void write_sps(Enc *e, BitW *out, int max_dpb, int reorder) {
     bw_put(&w, 1, p->scaling != 0);
     if (p->scaling) { bw_put(&w, 1, p->scaling == 2); if (p->scaling == 2) write_scaling_list_data(e, &w); }
     bw_put(&w, 1, (uint32_t)p->amp); bw_put(&w, 1, (uint32_t)p->sao); bw_put(&w, 1, p->pcm != 0);
-    if (p->pcm) { bw_put(&w, 4, 6); bw_put(&w, 4, 5); bw_ue(&w, (uint32_t)(p->min_cb_log2 - 3)); bw_ue(&w, (uint32_t)(MIN(5, p->ctb_log2) - p->min_cb_log2)); bw_put(&w, 1, p->pcm == 1); }
+    if (p->pcm) { bw_put(&w, 4, p->pcm == 3 ? 7 : 6); bw_put(&w, 4, p->pcm == 3 ? 7 : 5); bw_ue(&w, (uint32_t)(p->min_cb_log2 - 3)); bw_ue(&w, (uint32_t)(MIN(5, p->ctb_log2) - p->min_cb_log2)); bw_put(&w, 1, p->pcm == 1 || p->pcm == 3); }
     bw_ue(&w, (uint32_t)e->n_sps_sets);                                /* short-term reference picture sets (none: every slice header carries its own) */
     for (int i = 0; i < e->n_sps_sets; i++) {
         if (i == 0) { rps_write_explicit(&w, &e->sps_sets[0]); continue; }
@@ -1683,7 +1684,7 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
         const int cs = 1 << p->ctb_log2, n_ctbs = ((p->width + cs - 1) / cs) * ((p->height + cs - 1) / cs);
         if ((n_ctbs + p->slice_ctus - 1) / p->slice_ctus > 400) p->slice_ctus = (n_ctbs + 399) / 400;
     }
-    p->dqp = CLIP3(0, 1 + MIN(3, p->ctb_log2 - p->min_cb_log2), p->dqp); p->scaling = CLIP3(0, 3, p->scaling); p->pcm = CLIP3(0, 2, p->pcm); p->deblock = CLIP3(0, 2, p->deblock);
+    p->dqp = CLIP3(0, 1 + MIN(3, p->ctb_log2 - p->min_cb_log2), p->dqp); p->scaling = CLIP3(0, 3, p->scaling); p->pcm = CLIP3(0, 3, p->pcm); p->deblock = CLIP3(0, 2, p->deblock);
     p->cb_qp_off = CLIP3(-12, 12, p->cb_qp_off); p->cr_qp_off = CLIP3(-12, 12, p->cr_qp_off);
     if (p->gop) p->lt_ref = 0;
     int mcb = 1 << p->min_cb_log2;
