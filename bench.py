@@ -229,6 +229,15 @@ def main():
     for i in range(S):
         counts[i] = 0
         feeder_cpu[i] = 0.0
+    def memtrace(tag):   # JM_BENCH_MEMTRACE=1: resident / locked memory of this rank at the phases of the run (stderr)
+        if not os.environ.get("JM_BENCH_MEMTRACE"):
+            return
+        try:
+            f = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/self/status") if l.startswith(("VmRSS", "VmHWM", "VmLck", "VmPin", "RssAnon", "RssShmem", "RssFile"))}
+            print(f"bench.py: memtrace rank {rank} {tag}: {f}", file=sys.stderr, flush=True)
+        except OSError:
+            pass
+
     def host_cpu():     # CPU seconds of this process, and the container's CPU quota / throttling (cgroup v2), if visible
         import resource
         ru = resource.getrusage(resource.RUSAGE_SELF)
@@ -255,6 +264,7 @@ def main():
             pass
         return acc
     sync()
+    memtrace("handles created, warm-up done")
     tc0 = thread_cpu()
     hc0 = host_cpu()
     t0 = time.perf_counter()
@@ -263,6 +273,7 @@ def main():
     dt = time.perf_counter() - t0
     hc1 = host_cpu()
     tc1 = thread_cpu()
+    memtrace("timed region done")
     by_thread = {k: {"user_s": round(v[0] - tc0.get(k, [0, 0, 0])[0], 2), "sys_s": round(v[1] - tc0.get(k, [0, 0, 0])[1], 2), "threads": v[2]} for k, v in tc1.items()}
     by_thread = {k: v for k, v in by_thread.items() if v["user_s"] + v["sys_s"] >= 0.05}
     frames_local = sum(counts)
@@ -426,6 +437,7 @@ def main():
                 print(f"bench.py: rank {rank} stream {stream_ids[i]}: decoded frames differ from the CPU oracle (first bad frame {bad}, got {len(check_digests[i])} frames, oracle {len(want[i])})", file=sys.stderr)
         check_note = (f"one extra pass of all {S} handles concurrently (same batching and output routes as the timed passes), every frame MD5'd; "
                       f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle; all {S} handles returned {F} frames")
+    memtrace("check pass and oracle done")
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
     for i, h in enumerate(handles):
         if L.jm_amddec_get_stat(h, b"errors"):
@@ -433,6 +445,7 @@ def main():
         jmcodec_amd.jm_nvdec_deinit(h)
 
     # ---- untimed: ONE handle fed exactly like test_nv_dec.cpp:184-250 (the reference harness's own shape: one stream, one thread) ----
+    memtrace("handles released")
     single = None
     if world == 1 and not args.parse_only and not args.no_single:
         h = jmcodec_amd.jm_nvdec_create_handle()
@@ -558,6 +571,20 @@ def main():
                            "end_to_end_GBps": round(value / world * A / 1e9, 3), "end_to_end_frac": round(value / world * A / 1e9 / peak, 6),
                            "kernel_time_GBps": round(A / kernel_s_per_frame / 1e9, 3) if kernel_s_per_frame > 0 else None},
     }
+    # host memory of this rank (pinned job and output buffers of S handles included): what N ranks need from the node's memory allotment
+    try:
+        import resource
+        mem = {"peak_rss_mb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)}
+        for name, key in (("memory.current", "cgroup_current_mb"), ("memory.max", "cgroup_max_mb")):
+            try:
+                v = open("/sys/fs/cgroup/" + name).read().strip()
+                mem[key] = None if v == "max" else round(int(v) / 1048576.0, 1)
+            except (OSError, ValueError):
+                pass
+        mem["needed_for_8_gpus_mb"] = round(8 * mem["peak_rss_mb"], 0)
+        line["host_memory"] = mem
+    except Exception:
+        pass
     if cpu is not None:
         line["cpu_baseline"] = cpu
     if single is not None:
