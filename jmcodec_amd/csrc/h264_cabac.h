@@ -13,6 +13,14 @@
 #include "bitreader.h"
 #include "cabac_tables.h"
 
+// developer diagnostic (make -C tools host_bench HB_FLAGS=-DJM_COUNT_BINS, single-threaded runs): number of bins decoded
+#ifdef JM_COUNT_BINS
+namespace jmamd { extern long g_cabac_bins; }
+#define JM_BIN(n) (jmamd::g_cabac_bins += (n))
+#else
+#define JM_BIN(n) ((void)0)
+#endif
+
 namespace jmamd {
 
 // next state by ((pStateIdx << 1 | valMPS) << 1 | "the bin was the least probable symbol") (Table 9-45 transIdxLps / transIdxMps)
@@ -82,6 +90,7 @@ struct Cabac {
     // 9.3.3.2.1, without a branch on the decoded symbol (it is the least predictable branch of the whole parser): `m` is all ones when the
     // offset lies in the LPS sub-interval and selects offset, range, next state and bin value arithmetically
     __attribute__((always_inline)) inline int decision(int ctx) {
+        JM_BIN(1);
         const uint32_t s = state[ctx];
         const uint64_t row = kCabacRows.r[s];
         const uint32_t lps = (uint32_t)(row >> ((range >> 3) & 24)) & 0xff;
@@ -98,6 +107,7 @@ struct Cabac {
         return (int)((s ^ m32) & 1);
     }
     inline int bypass() {
+        JM_BIN(1);
         pos--;
         uint64_t scaled = (uint64_t)range << pos;
         int bin = 0;
@@ -108,6 +118,7 @@ struct Cabac {
     // n bypass bins at once (1 <= n <= 16), first bin in the most significant bit: the n compare-and-subtract steps of 9.3.3.2.3 are one
     // division of the offset by the (scaled) range
     inline uint32_t bypass_bits(int n) {
+        JM_BIN(n);
         if (pos < 16) refill();
         pos -= n;
         const uint64_t scaled = (uint64_t)range << pos;
@@ -117,6 +128,7 @@ struct Cabac {
         return (uint32_t)q;
     }
     inline int terminate() {
+        JM_BIN(1);
         range -= 2;
         if (val >= ((uint64_t)range << pos)) return 1;          // no renormalisation: parsing of the slice / before I_PCM ends
         if (range < 256) { range <<= 1; pos--; if (pos < 16) refill(); }
@@ -140,6 +152,7 @@ struct CabacRegs {
         val = (val << 32) | w; pos += 32;
     }
     inline int decision(int ctx) {
+        JM_BIN(1);
         const uint32_t s = state[ctx];
         const uint64_t row = kCabacRows.r[s];
         const uint32_t lps = (uint32_t)(row >> ((range >> 3) & 24)) & 0xff;
@@ -156,6 +169,7 @@ struct CabacRegs {
         return (int)((s ^ m32) & 1);
     }
     inline int bypass() {
+        JM_BIN(1);
         pos--;
         const uint64_t scaled = (uint64_t)range << pos;
         int bin = 0;
@@ -164,6 +178,7 @@ struct CabacRegs {
         return bin;
     }
     inline uint32_t bypass_bits(int n) {
+        JM_BIN(n);
         if (pos < 16) refill();
         pos -= n;
         const uint64_t scaled = (uint64_t)range << pos;

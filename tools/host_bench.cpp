@@ -32,6 +32,9 @@ static void prof_stop(const char *path) {
     if (FILE *f = fopen(path, "w")) { long n = g_npc < kMaxPc ? g_npc : kMaxPc; for (long i = 0; i < n; i++) if (g_pcs[i] >= lo && g_pcs[i] < hi) fprintf(f, "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other\n"); fclose(f); }
 }
 
+#ifdef JM_COUNT_BINS
+namespace jmamd { long g_cabac_bins = 0; }
+#endif
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s stream [passes] [codec_type]\n", argv[0]); return 2; }
     std::vector<unsigned char> b; { FILE *f = fopen(argv[1], "rb"); if (!f) return 2; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize(n); if (fread(b.data(), 1, n, f) != (size_t)n) return 2; fclose(f); }
@@ -44,9 +47,17 @@ int main(int argc, char **argv) {
     if (prof) { jm_amddec_feed_annexb(b.data(), (long)b.size(), 1, out.data(), (int)out.size(), h); prof_start(); }      // (the first pass creates the parse workers: they must not inherit the blocked signal)
     auto t0 = std::chrono::steady_clock::now();
     long frames = jm_amddec_feed_annexb(b.data(), (long)b.size(), passes, out.data(), (int)out.size(), h);
+    // drain inside the timed region: every picture fed has then been parsed (the pipeline holds up to two dozen per handle)
+    for (int i = 0, got = 0; i < 100000 && !jm_amddec_is_exit(h); i++) { jm_amddec_decode_frame(nullptr, 0, &got, h); if (got) { int n = (int)out.size(); if (jm_amddec_output_frame(out.data(), &n, h) > 0) frames++; } }
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (prof) prof_stop(prof);
-    printf("%ld frames in %.3f s: %.1f frames/s wall, %.3f ms per frame, %.1f MB/s of bitstream\n", frames, s, frames / s, 1e3 * s / (frames > 0 ? frames : 1), passes * b.size() / s / 1e6);
+    // per PICTURE PARSED (the stat), not per frame returned: a reordering DPB holds frames back across the passes
+    long pics = (long)jm_amddec_get_stat(h, "pictures"); if (pics <= 0) pics = frames > 0 ? frames : 1;
+    if (prof) pics -= pics / (passes + 1);            // (the profiler's warm-up pass is not in the timed region)
+#ifdef JM_COUNT_BINS
+    printf("%.0f bins per picture (all passes; JM_AMD_DEC_THREADS=1 for a meaningful count)\n", (double)jmamd::g_cabac_bins / pics);
+#endif
+    printf("%ld pictures (%ld frames returned) in %.3f s: %.1f pictures/s wall, %.3f ms per picture, %.1f MB/s of bitstream\n", pics, frames, s, pics / s, 1e3 * s / pics, passes * b.size() / s / 1e6);
     jm_amddec_deinit(h);
     return 0;
 }
