@@ -177,10 +177,13 @@ int HevcPicParser::merge_candidates(int xcb, int ycb, int ncb, int xp, int yp, i
         if (k == 1 && part == 1 && (pmode == PART_2NxN || pmode == PART_2NxnU || pmode == PART_2NxnD)) have[k] = false;
         if (have[k]) c[k] = mot_[i4(nx[k], ny[k])];
     }
+    // 8.5.3.2.3: B0 and B2 are compared with B1 whenever B1 is AVAILABLE (availableB1), also when B1 itself was dropped as a duplicate of A1
+    // (availableFlagB1 = 0); only the count of four uses the flags
+    const bool avail_b1 = have[1];
     if (have[1] && have[0] && same_motion(c[1], c[0])) have[1] = false;
-    if (have[2] && have[1] && same_motion(c[2], c[1])) have[2] = false;
+    if (have[2] && avail_b1 && same_motion(c[2], c[1])) have[2] = false;
     if (have[3] && have[0] && same_motion(c[3], c[0])) have[3] = false;
-    if (have[4] && (have[0] + have[1] + have[2] + have[3] == 4 || (have[0] && same_motion(c[4], c[0])) || (have[1] && same_motion(c[4], c[1])))) have[4] = false;
+    if (have[4] && (have[0] + have[1] + have[2] + have[3] == 4 || (have[0] && same_motion(c[4], c[0])) || (avail_b1 && same_motion(c[4], c[1])))) have[4] = false;
     int n = 0;
     for (int k = 0; k < 5; k++) if (have[k]) list[n++] = c[k];
     if (n > want && n <= max) return n;

@@ -424,25 +424,27 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
     int pml = s->pps->log2_par_mrg_level, part_mode = s->part_mode;
     if (pml > 2 && ncbs == 8) { xpb = xcb; ypb = ycb; npbw = npbh = ncbs; part_idx = 0; part_mode = H_PART_2Nx2N; }
     Cand list[6]; int n = 0;
-    Cand a1, b1, b0, a0, b2; int fa1, fb1, fb0, fa0, fb2;
+    Cand a1, b1, b0, a0, b2; int fa1, fb1, fb0, fa0, fb2, vb1;      /* vb1: availableB1 (8.5.3.2.3), fb1: availableFlagB1 (after the comparison with A1) */
 #define SAME_MER(xn, yn) ((xpb >> pml) == ((xn) >> pml) && (ypb >> pml) == ((yn) >> pml))
     { int xn = xpb - 1, yn = ypb + npbh - 1;
       fa1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_Nx2N || part_mode == H_PART_nLx2N || part_mode == H_PART_nRx2N))) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
       if (fa1) { a1 = cand_of(d, xn, yn); list[n++] = a1; } }
     { int xn = xpb + npbw - 1, yn = ypb - 1;
       fb1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_2NxN || part_mode == H_PART_2NxnU || part_mode == H_PART_2NxnD))) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
+      vb1 = fb1;
       if (fb1) { b1 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &b1)) fb1 = 0; else list[n++] = b1; } }
     { int xn = xpb + npbw, yn = ypb - 1;
       fb0 = !SAME_MER(xn, yn) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
-      if (fb0) { b0 = cand_of(d, xn, yn); if (fb1 && cand_same(&b1, &b0)) fb0 = 0; else list[n++] = b0; } }
+      if (fb0) { b0 = cand_of(d, xn, yn); if (vb1 && cand_same(&b1, &b0)) fb0 = 0; else list[n++] = b0; } }
     { int xn = xpb - 1, yn = ypb + npbh;
       fa0 = !SAME_MER(xn, yn) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
       if (fa0) { a0 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &a0)) fa0 = 0; else list[n++] = a0; } }
     { int xn = xpb - 1, yn = ypb - 1;
       fb2 = !SAME_MER(xn, yn) && fa0 + fa1 + fb0 + fb1 != 4 && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
-      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (fb1 && cand_same(&b1, &b2))) fb2 = 0; else list[n++] = b2; } }
+      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (vb1 && cand_same(&b1, &b2))) fb2 = 0; else list[n++] = b2; } }
 #undef SAME_MER
-    /* the availability flags of B1/B0/A0/B2 above follow the spec's wording: a pruned candidate counts as unavailable */
+    /* B0 and B2 are compared with B1 whenever availableB1 is TRUE -- also when B1 was dropped as a duplicate of A1 (availableFlagB1 = 0);
+     * the count of four candidates uses the flags (8.5.3.2.3) */
     if (n < sh->max_merge_cand && sh->temporal_mvp) {
         Cand t; memset(&t, 0, sizeof t); t.ref[0] = t.ref[1] = -1;
         if (temporal_mv(s, xpb, ypb, npbw, npbh, 0, 0, t.mv[0])) { t.pf |= 1; t.ref[0] = 0; }

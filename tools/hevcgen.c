@@ -411,10 +411,12 @@ static int merge_list(Enc *e, int xcb, int ycb, int ncb, int xp, int yp, int w, 
         if (k == 1 && part == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5)) have[k] = 0;      /* 2NxN 2NxnU 2NxnD */
         if (have[k]) c[k] = e->mot[I4(e, nx[k], ny[k])];
     }
+    /* 8.5.3.2.3: B0 / B2 are compared with B1 when B1 is available (availableB1), whether or not B1 itself was pruned against A1 */
+    const int avail_b1 = have[1];
     if (have[1] && have[0] && same_mot(&c[1], &c[0])) have[1] = 0;
-    if (have[2] && have[1] && same_mot(&c[2], &c[1])) have[2] = 0;
+    if (have[2] && avail_b1 && same_mot(&c[2], &c[1])) have[2] = 0;
     if (have[3] && have[0] && same_mot(&c[3], &c[0])) have[3] = 0;
-    if (have[4] && ((have[0] && same_mot(&c[4], &c[0])) || (have[1] && same_mot(&c[4], &c[1])) || have[0] + have[1] + have[2] + have[3] == 4)) have[4] = 0;
+    if (have[4] && ((have[0] && same_mot(&c[4], &c[0])) || (avail_b1 && same_mot(&c[4], &c[1])) || have[0] + have[1] + have[2] + have[3] == 4)) have[4] = 0;
     for (int k = 0; k < 5; k++) if (have[k]) list[n++] = c[k];
     if (n < s->max_merge && s->tmvp) {
         Mot t; memset(&t, 0, sizeof t); t.ref[0] = t.ref[1] = -1;
