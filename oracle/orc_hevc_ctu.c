@@ -435,13 +435,13 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
       if (fb1) { b1 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &b1)) fb1 = 0; else list[n++] = b1; } }
     { int xn = xpb + npbw, yn = ypb - 1;
       fb0 = !SAME_MER(xn, yn) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
-      if (fb0) { b0 = cand_of(d, xn, yn); if (vb1 && cand_same(&b1, &b0)) fb0 = 0; else list[n++] = b0; } }
+      if (fb0) { b0 = cand_of(d, xn, yn); if (vb1 && cand_same(&b1, &b0)) { fb0 = 0; if (!fb1) d->stats[HST_MERGE_VS_PRUNED_B1]++; } else list[n++] = b0; } }
     { int xn = xpb - 1, yn = ypb + npbh;
       fa0 = !SAME_MER(xn, yn) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
       if (fa0) { a0 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &a0)) fa0 = 0; else list[n++] = a0; } }
     { int xn = xpb - 1, yn = ypb - 1;
       fb2 = !SAME_MER(xn, yn) && fa0 + fa1 + fb0 + fb1 != 4 && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
-      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (vb1 && cand_same(&b1, &b2))) fb2 = 0; else list[n++] = b2; } }
+      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (vb1 && cand_same(&b1, &b2))) { fb2 = 0; if (vb1 && !fb1 && !(fa1 && cand_same(&a1, &b2))) d->stats[HST_MERGE_VS_PRUNED_B1]++; } else list[n++] = b2; } }
 #undef SAME_MER
     /* B0 and B2 are compared with B1 whenever availableB1 is TRUE -- also when B1 was dropped as a duplicate of A1 (availableFlagB1 = 0);
      * the count of four candidates uses the flags (8.5.3.2.3) */

@@ -76,7 +76,8 @@ def test_cases_cover_the_tools(oracle):
         for k, v in oracle.tools(streams.generate_hevc(**HEVC_CASES[name])).items():
             seen[k] = seen.get(k, 0) + v
     for tool in ("intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst", "sign_hiding", "transform_skip", "tq_bypass", "pcm",
-                 "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "wpp_rows", "tiles", "dependent_slices", "long_term_ref", "rplm", "b_slices"):
+                 "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "wpp_rows", "tiles", "dependent_slices", "long_term_ref", "rplm", "b_slices",
+                 "merge_b0_b2_vs_pruned_b1"):      # 8.5.3.2.3: B0 / B2 dropped as duplicates of a B1 that is available but was itself pruned against A1 (the case all three programs once misread)
         assert seen.get(tool, 0) > 0, f"no test stream exercises {tool}"
 
 
