@@ -322,31 +322,34 @@ def main():
     avg_s = {k: (tot_ns[k] * 1e-9 / tot_n[k]) if tot_n[k] else 0.0 for k in names}
     peak = 8000.0
     achieved = alg[dominant] / avg_s[dominant] / 1e9 if avg_s[dominant] > 0 else 0.0
-    # HBM traffic from PMC counters (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, per picture) x pictures per launch
+    # HBM traffic from PMC counters: one file per codec / tool set / picture size under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes with ONE
+    # stream, so bytes are per picture; tools/make_traffic_profile.py), scaled by the pictures per launch of THIS run.  No file for the size: null.
     traffic = traffic_raw = None
+    traffic_file = None
     try:
+        tag = f"hevc_{args.width}x{args.height}" if args.codec == "hevc" else f"h264_{args.tools}_{args.width}x{args.height}"
+        cands = [f"r03_pmc_traffic_{tag}.json"]
+        if tag == "h264_baseline_1920x1080":
+            cands.append("r02_pmc_traffic.json")
+        pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in cands) if os.path.exists(p))
+        traffic_file = os.path.relpath(pmc_path, ROOT)
+        pmc = json.load(open(pmc_path))["kernels"]
+        t = lambda k: pmc[k]["traffic_upper"] if k in pmc else 0
+        r = lambda k: (pmc[k]["fetch_raw"] + pmc[k]["write"]) if k in pmc else 0
         if args.codec == "hevc":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hevc_pmc_traffic.json")))["kernels"]
-            t = lambda k: pmc[k]["traffic_upper"] if k in pmc else 0
+            # k_hevc_deblock runs twice per picture (vertical edges, horizontal edges); the file holds the average of its launches
             per_pic = {"inter": t("k_hevc_mc") + t("k_hevc_resid") + t("k_hevc_iresid"), "intra": t("k_hevc_intra"), "deblock": 2 * t("k_hevc_deblock") + t("k_hevc_sao")}
+            raw_pic = {"inter": r("k_hevc_mc") + r("k_hevc_resid") + r("k_hevc_iresid"), "intra": r("k_hevc_intra"), "deblock": 2 * r("k_hevc_deblock") + r("k_hevc_sao")}
         else:
-            pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")) if os.path.exists(p))
-            pmc = json.load(open(pmc_path))["kernels"]
-            per_pic = {"inter": pmc["k_recon_inter"]["traffic_upper"], "intra": pmc.get("k_intra_band", pmc.get("k_intra_lds", {"traffic_upper": 0}))["traffic_upper"],
-                       "deblock": pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"traffic_upper": 0}))["traffic_upper"] + pmc["k_deblock_prep"]["traffic_upper"]}
-        per_pic["chain"] = pmc["k_chain"]["traffic_upper"] if "k_chain" in pmc else per_pic["inter"] + per_pic["deblock"]
-        raw_pic = {"inter": pmc["k_recon_inter"]["fetch_raw"] + pmc["k_recon_inter"]["write"]} if args.codec == "h264" else {}
-        if args.codec == "h264":
-            band = pmc.get("k_deblock_band", pmc.get("k_deblock_lds", {"fetch_raw": 0, "write": 0}))
-            raw_pic["deblock"] = band["fetch_raw"] + band["write"] + pmc["k_deblock_prep"]["fetch_raw"] + pmc["k_deblock_prep"]["write"]
-            ib = pmc.get("k_intra_band", pmc.get("k_intra_lds", {"fetch_raw": 0, "write": 0}))
-            raw_pic["intra"] = ib["fetch_raw"] + ib["write"]
-            raw_pic["chain"] = (pmc["k_chain"]["fetch_raw"] + pmc["k_chain"]["write"]) if "k_chain" in pmc else raw_pic["inter"] + raw_pic["deblock"]
-        if (args.width, args.height) == (1920, 1080):
+            per_pic = {"inter": t("k_recon_inter"), "intra": t("k_intra_band"), "deblock": t("k_deblock_band") + t("k_deblock_prep")}
+            raw_pic = {"inter": r("k_recon_inter"), "intra": r("k_intra_band"), "deblock": r("k_deblock_band") + r("k_deblock_prep")}
+            per_pic["chain"] = pmc["k_chain"]["traffic_upper"] if "k_chain" in pmc else per_pic["inter"] + per_pic["deblock"]
+            raw_pic["chain"] = r("k_chain") if "k_chain" in pmc else raw_pic["inter"] + raw_pic["deblock"]
+        if per_pic.get(dominant):
             traffic = int(per_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
-            traffic_raw = int(raw_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1)) if dominant in raw_pic else None
-    except Exception:
-        traffic = None
+            traffic_raw = int(raw_pic[dominant] * tot_pics[dominant] / max(tot_n[dominant], 1))
+    except (StopIteration, OSError, KeyError, ValueError):
+        traffic = traffic_raw = None
     # frame-level contract figure of SURVEY 8(d): A = 1.5*Wc*Hc*(n_ref+1) + 1.5*Wd*Hd + J per frame
     A = surf * (p_frac * 2 + (1 - p_frac) * 1) + frame_bytes + J
     kernel_s_per_frame = sum(tot_ns[k] for k in names) * 1e-9 / max(pictures, 1)
@@ -358,32 +361,10 @@ def main():
     import hashlib
     is_hevc = args.codec == "hevc"
 
+    idr_period = lambda data, which=0: streams.idr_period(data, which, is_hevc)
+
     def first_period(data):
-        """The stream up to (not including) its second IDR access unit: decodes to the first frames of the full stream's display order."""
-        nal_starts = [k for k in range(len(data) - 3) if data[k] == 0 and data[k + 1] == 0 and data[k + 2] == 1]
-        idr = []
-        for k in nal_starts:
-            b0 = data[k + 3]
-            t = (b0 >> 1) & 63 if is_hevc else b0 & 31
-            if (t in (19, 20)) if is_hevc else (t == 5):
-                first_slice = (data[k + 5] & 0x80) != 0 if is_hevc else (data[k + 4] & 0x80) != 0     # first_slice_segment_in_pic_flag / first_mb_in_slice == 0
-                if first_slice:
-                    idr.append(k)
-        if len(idr) < 2:
-            return data
-        cut = idr[1]
-        # parameter sets that precede the second IDR picture belong to it: cut before them (they follow the previous picture's last slice)
-        prev = [k for k in nal_starts if k < cut]
-        while prev:
-            b0 = data[prev[-1] + 3]
-            t = (b0 >> 1) & 63 if is_hevc else b0 & 31
-            if (t in (32, 33, 34, 35, 39)) if is_hevc else (t in (6, 7, 8, 9)):
-                cut = prev.pop()
-            else:
-                break
-        while cut > 0 and data[cut - 1] == 0:
-            cut -= 1
-        return data[:cut]
+        return idr_period(data, 0)
 
     check_digests = [None] * S
 
@@ -445,8 +426,24 @@ def main():
             if not ok:
                 bad = next((k for k in range(min(len(want[i]), len(check_digests[i]))) if want[i][k] != check_digests[i][k]), -1)
                 print(f"bench.py: rank {rank} stream {stream_ids[i]}: decoded frames differ from the CPU oracle (first bad frame {bad}, got {len(check_digests[i])} frames, oracle {len(want[i])})", file=sys.stderr)
+        # a LATE IDR period too (the last one of the pass: frames F - period .. F - 1) of up to two streams: everything between the first period and the end
+        # of a pass -- DPB reuse over many pictures, surfaces and job slots recycled, chain launches in steady state -- is otherwise only self-consistent
+        n_late, late_note = 0, ""
+        n_periods = 0
+        while idr_period(datas[0], n_periods) is not None:
+            n_periods += 1
+        if n_periods >= 2:
+            for i in range(min(2, n_oracle)):
+                late = oracle_digests(idr_period(datas[i], n_periods - 1))
+                got_late = check_digests[i][F - len(late):] if len(late) else []
+                ok = len(late) > 0 and got_late == late
+                bit_exact = bit_exact and ok
+                frames_checked += len(late); n_late += 1
+                if not ok:
+                    print(f"bench.py: rank {rank} stream {stream_ids[i]}: IDR period {n_periods - 1} differs from the CPU oracle", file=sys.stderr)
+            late_note = f"; the last IDR period (period {n_periods - 1}, frames {F - len(late)}..{F - 1}) of {n_late} handle(s) as well"
         check_note = (f"one extra pass of all {S} handles concurrently (same batching and output routes as the timed passes), every frame MD5'd; "
-                      f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle; all {S} handles returned {F} frames")
+                      f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle{late_note}; all {S} handles returned {F} frames")
     memtrace("check pass and oracle done")
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
     for i, h in enumerate(handles):
@@ -564,7 +561,8 @@ def main():
                              "cpu_needed_for_8_gpus = 8 x cpus_busy is what an 8-rank run of this rate would need from the node"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": traffic, "traffic_raw": traffic_raw,
-                     "traffic_note": "HBM bytes per launch from PMC counters (profiles/r02_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, per picture) x "
+                     "traffic_file": traffic_file,
+                     "traffic_note": "HBM bytes per launch from PMC counters (traffic_file: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this codec / tool set / size, per picture) x "
                                      "pictures per launch of THIS run; traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced reads, an "
                                      "upper estimate for these access shapes), traffic_raw = FETCH_SIZE + WRITE_SIZE as counted",
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),

@@ -118,3 +118,35 @@ def config_c3(frames=120, width=3840, height=2160, stream_id=0):
                 ctb_log2=6, min_cb_log2=3, sao=1, deblock=1, tmvp=1, amp=1, strong_intra=1, depth_inter=2, depth_intra=2, sdh=1)
 
 
+def idr_period(data, which=0, is_hevc=False):
+    """IDR period `which` of the stream as a stream of its own: the parameter sets in front of the first picture, then the access units from the
+    period's IDR picture up to (not including) the next one.  An IDR picture resets the decoding process, so period k decodes to frames
+    k*period .. of the full stream's display order (the generator's GOPs are closed)."""
+    nal_starts = [k for k in range(len(data) - 3) if data[k] == 0 and data[k + 1] == 0 and data[k + 2] == 1]
+    ntype = lambda k: ((data[k + 3] >> 1) & 63) if is_hevc else (data[k + 3] & 31)
+    is_ps = lambda t: (t in (32, 33, 34, 35, 39)) if is_hevc else (t in (6, 7, 8, 9))
+    idr = []
+    for k in nal_starts:
+        t = ntype(k)
+        if (t in (19, 20)) if is_hevc else (t == 5):
+            first_slice = (data[k + 5] & 0x80) != 0 if is_hevc else (data[k + 4] & 0x80) != 0     # first_slice_segment_in_pic_flag / first_mb_in_slice == 0
+            if first_slice:
+                idr.append(k)
+
+    def cut_before(pos):
+        # parameter sets that precede an IDR picture belong to it: cut before them (they follow the previous picture's last slice)
+        prev = [k for k in nal_starts if k < pos]
+        while prev and is_ps(ntype(prev[-1])):
+            pos = prev.pop()
+        while pos > 0 and data[pos - 1] == 0:
+            pos -= 1
+        return pos
+    if which >= len(idr):
+        return None
+    end = cut_before(idr[which + 1]) if which + 1 < len(idr) else len(data)
+    if which == 0:
+        return data[:end]
+    head = data[:next((k for k in nal_starts if not is_ps(ntype(k))), 0)]     # the parameter sets in front of the first picture
+    while head and head[-1:] == b"\x00":
+        head = head[:-1]
+    return head + data[cut_before(idr[which]):end]
