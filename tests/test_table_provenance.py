@@ -15,7 +15,7 @@ import hashlib
 import json
 import os
 
-from util import ROOT, GOLDEN, c_array
+from util import ROOT, GOLDEN, c_array, c_rows
 
 PROD_CABAC = os.path.join(ROOT, "jmcodec_amd", "csrc", "cabac_tables.h")
 ORC_CABAC = os.path.join(ROOT, "oracle", "orc_cabac_tables.h")
@@ -100,35 +100,138 @@ def test_hevc_context_init_values_against_a_separately_typed_copy():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
-# H.264 9.3.1.1, Tables 9-12 .. 9-17: (m, n), typed per ctxIdx range; index 0 = I slices (where defined), 1..3 = cabac_init_idc 0..2
+# H.264: every table of the entropy layer against tests/spec_tables_h264.py (typed per syntax element / per code table, see its header)
 # ---------------------------------------------------------------------------------------------------------------------------------------
-H264_MN_ALL = {   # the same for every slice type / cabac_init_idc
-    0: [(20, -15), (2, 54), (3, 74), (20, -15), (2, 54), (3, 74), (-28, 127), (-23, 104), (-6, 53), (-1, 54), (7, 51)],            # Table 9-12: mb_type (SI prefix / I), ctxIdx 0..10
-    60: [(0, 41), (0, 63), (0, 63), (0, 63), (-9, 83), (4, 86), (0, 97), (-7, 72), (13, 41), (3, 62)],                             # Table 9-17: mb_qp_delta, intra_chroma_pred_mode, prev_intra / rem_intra, ctxIdx 60..69
-}
-H264_MN_IDC = {   # Table 9-13: mb_skip_flag (P), mb_type (P), sub_mb_type (P), ctxIdx 11..23, per cabac_init_idc
-    11: [[(23, 33), (23, 2), (21, 0), (1, 9), (0, 49), (-37, 118), (5, 57), (-13, 78), (-11, 65), (1, 62), (12, 49), (-4, 73), (17, 50)],
-         [(22, 25), (34, 0), (16, 0), (-2, 9), (4, 41), (-29, 118), (2, 65), (-6, 71), (-13, 79), (5, 52), (9, 50), (-3, 70), (10, 54)],
-         [(29, 16), (25, 0), (14, 0), (-10, 51), (-3, 62), (-27, 99), (26, 16), (-4, 85), (-24, 102), (5, 57), (6, 57), (-17, 73), (14, 57)]],
-}
-H264_MN_I = {     # Table 9-18 (I slices): mb_field_decoding_flag 70..72, coded_block_pattern luma 73..76
-    70: [(0, 11), (1, 55), (0, 69), (-17, 127), (-13, 102), (0, 82), (-7, 74)],
-}
+import spec_tables_h264 as spec  # noqa: E402
+
+ORC_TABLES = os.path.join(ROOT, "oracle", "orc_tables.h")
+PROD_CAVLC = os.path.join(ROOT, "jmcodec_amd", "csrc", "h264_cavlc.cpp")
+PROD_SYNTAX = os.path.join(ROOT, "jmcodec_amd", "csrc", "h264_syntax.cpp")
+PROD_KERNEL = os.path.join(ROOT, "jmcodec_amd", "csrc", "kernel_common.h")
+GEN_H264 = os.path.join(ROOT, "tools", "h264gen.c")
+
+
+def _spec_mn_columns():
+    """The separately typed (m, n) pairs as four columns [I, idc 0, idc 1, idc 2] x ctxIdx -> pair or None (not defined for that column)."""
+    cols = [[None] * 460 for _ in range(4)]
+    for table in (spec.CABAC_MN, spec.CABAC_MN_FIELD):
+        for elem, (first, by_col) in table.items():
+            n = {len(v) for v in by_col.values()}
+            assert len(n) == 1, f"{elem}: the columns of one element have one length"
+            for key, vals in by_col.items():
+                for c in (range(4) if key == "all" else [0 if key == "I" else 1 + key]):
+                    for i, mn in enumerate(vals):
+                        assert cols[c][first + i] is None, f"{elem}: ctxIdx {first + i} typed twice"
+                        cols[c][first + i] = mn
+    return cols
+
+
+def test_the_separately_typed_cabac_copy_covers_every_context_exactly_once():
+    cols = _spec_mn_columns()
+    for c in range(4):
+        have = {i for i in range(460) if cols[c][i] is not None}
+        # I slices: no P / B elements (11..59); 276 is end_of_slice_flag (no context variable: decoded with DecodeTerminate)
+        want = (set(range(0, 11)) | set(range(60, 276)) | set(range(277, 436))) if c == 0 else (set(range(0, 276)) | set(range(277, 436)))
+        assert have == want, (c, sorted(have ^ want))
+        for i in have:
+            m, n = cols[c][i]
+            assert -128 <= m <= 127 and -128 <= n <= 127
 
 
 def test_h264_cabac_init_values_against_a_separately_typed_copy():
+    """ALL frame-coded contexts, ctxIdx 0..435 x {I, cabac_init_idc 0, 1, 2}, product and oracle."""
+    cols = _spec_mn_columns()
     for path, name in ((PROD_CABAC, "cabac_init_mn"), (ORC_CABAC, "orc_cabac_init_mn")):
         flat = c_array(path, name)
-        assert len(flat) == 4 * 436 * 2
-        mn = [[(flat[(t * 436 + i) * 2], flat[(t * 436 + i) * 2 + 1]) for i in range(436)] for t in range(4)]
-        for first, vals in H264_MN_ALL.items():
-            for t in range(4):
-                assert mn[t][first:first + len(vals)] == vals, (os.path.basename(path), first, t)
-        for first, per_idc in H264_MN_IDC.items():
-            for idc in range(3):
-                assert mn[1 + idc][first:first + len(per_idc[idc])] == per_idc[idc], (os.path.basename(path), first, idc)
-        for first, vals in H264_MN_I.items():
-            assert mn[0][first:first + len(vals)] == vals, (os.path.basename(path), first)
+        n_ctx = len(flat) // 8
+        assert len(flat) == 4 * n_ctx * 2 and n_ctx in (436, 460)
+        checked = 0
+        for t in range(4):
+            for i in range(n_ctx):
+                want = cols[t][i]
+                got = (flat[(t * n_ctx + i) * 2], flat[(t * n_ctx + i) * 2 + 1])
+                if want is None:
+                    continue
+                if 277 <= i <= 398 and got == (0, 0) and n_ctx == 436:
+                    continue                                   # field-coded contexts not emitted by this build of the table
+                assert got == want, f"{os.path.basename(path)}: ctxIdx {i}, column {('I', 0, 1, 2)[t]}: table has {got}, the separately typed copy {want}"
+                checked += 1
+        # 0..10, 60..275, 399..435 in every column + 11..59 in the three P / B columns; + 122 x 4 once the table holds the field-coded contexts
+        assert checked in (264 + 3 * 313, 264 + 3 * 313 + 4 * 122), checked
+
+
+def test_h264_cabac_8x8_ctxidxinc_tables():
+    for path, pfx in ((PROD_CABAC, "cabac_"), (ORC_CABAC, "orc_cabac_")):
+        assert c_array(path, pfx + "sig8_inc") == spec.SIG8_FRAME
+        assert c_array(path, pfx + "last8_inc") == spec.LAST8
+    assert len(spec.SIG8_FIELD) == 63 and max(spec.SIG8_FIELD) == 14
+
+
+def test_h264_cavlc_code_tables_against_the_bit_strings_of_the_standard():
+    """coeff_token (Table 9-5, all five columns), total_zeros (9-7, 9-8, 9-9a), run_before (9-10): oracle, product, generator."""
+    tok = spec.parse_code_table(spec.COEFF_TOKEN, 5)
+    assert len(tok) == 62
+    for path, ln, bn, ncol in ((ORC_TABLES, "orc_coeff_token_len", "orc_coeff_token_bits", 4), (PROD_CAVLC, "kTokLen", "kTokBits", 3), (GEN_H264, "ct_len", "ct_bits", 4)):
+        lens, bits = c_array(path, ln), c_array(path, bn)
+        assert len(lens) == len(bits) == ncol * 68
+        for col in range(ncol):
+            for tc in range(17):
+                for t1 in range(4):
+                    want = tok.get((t1, tc), [None] * 5)[col]
+                    got = (lens[col * 68 + 4 * tc + t1], bits[col * 68 + 4 * tc + t1])
+                    assert got == (want or (0, 0)), (os.path.basename(path), col, t1, tc, got, want)
+    for path, ln, bn in ((ORC_TABLES, "orc_chroma_dc_token_len", "orc_chroma_dc_token_bits"), (PROD_CAVLC, "kCdcLen", "kCdcBits"), (GEN_H264, "cdc_len", "cdc_bits")):
+        lens, bits = c_array(path, ln), c_array(path, bn)
+        for tc in range(5):
+            for t1 in range(4):
+                want = tok.get((t1, tc), [None] * 5)[4]
+                assert (lens[4 * tc + t1], bits[4 * tc + t1]) == (want or (0, 0)), (os.path.basename(path), t1, tc)
+    tz = spec.parse_code_table(spec.TOTAL_ZEROS_4x4, 15)
+    for path, ln, bn in ((ORC_TABLES, "orc_total_zeros_len", "orc_total_zeros_bits"), (PROD_CAVLC, "kTzLen", "kTzBits"), (GEN_H264, "tz_len", "tz_bits")):
+        lens, bits = c_rows(path, ln, 16), c_rows(path, bn, 16)
+        assert len(lens) == len(bits) == 15
+        for idx in range(15):
+            for z in range(16):
+                want = tz[(z,)][idx]
+                assert (lens[idx][z], bits[idx][z]) == (want or (0, 0)), (os.path.basename(path), idx + 1, z)
+    ctz = spec.parse_code_table(spec.TOTAL_ZEROS_CHROMA_DC, 3)
+    for path, ln, bn in ((ORC_TABLES, "orc_cdc_total_zeros_len", "orc_cdc_total_zeros_bits"), (PROD_CAVLC, "kCtzLen", "kCtzBits"), (GEN_H264, "ctz_len", "ctz_bits")):
+        lens, bits = c_rows(path, ln, 4), c_rows(path, bn, 4)
+        for idx in range(3):
+            for z in range(4):
+                want = ctz[(z,)][idx]
+                assert (lens[idx][z], bits[idx][z]) == (want or (0, 0)), (os.path.basename(path), idx + 1, z)
+    rb = spec.parse_code_table(spec.RUN_BEFORE, 7)
+    for path, ln, bn, rows, width in ((ORC_TABLES, "orc_run_len", "orc_run_bits", 7, 15), (GEN_H264, "rb_len", "rb_bits", 7, 15), (PROD_CAVLC, "kRunLen", "kRunBits", 6, 7)):
+        lens, bits = c_rows(path, ln, width), c_rows(path, bn, width)
+        assert len(lens) == len(bits) == rows
+        for zl in range(rows):
+            for r in range(width):
+                want = rb.get((r,), [None] * 7)[zl]
+                assert (lens[zl][r], bits[zl][r]) == (want or (0, 0)), (os.path.basename(path), zl + 1, r)
+    # zerosLeft > 6 in the product is computed, not tabled: run_before = 7 - (first three bits) or 4 + leading zeros (h264_cavlc.cpp); the column's shape says so
+    for r in range(15):
+        ln, v = rb[(r,)][6]
+        assert (ln, v) == ((3, 7 - r) if r < 7 else (r - 3, 1))
+
+
+def test_h264_mapping_scan_and_filter_tables_against_a_separately_typed_copy():
+    intra, inter = [a for a, _ in spec.CBP_OF_CODENUM], [b for _, b in spec.CBP_OF_CODENUM]
+    assert c_array(ORC_TABLES, "orc_cbp_intra") == c_array(PROD_CAVLC, "kCbpIntra") == c_array(GEN_H264, "cbp_intra_tab") == intra
+    assert c_array(ORC_TABLES, "orc_cbp_inter") == c_array(PROD_CAVLC, "kCbpInter") == c_array(GEN_H264, "cbp_inter_tab") == inter
+    assert c_array(ORC_TABLES, "orc_zigzag4") == c_array(PROD_CAVLC, "kZigzag4") == c_array(GEN_H264, "zz4") == spec.ZIGZAG_4x4
+    assert c_array(ORC_TABLES, "orc_zigzag8") == c_array(PROD_CAVLC, "kZigzag8") == c_array(GEN_H264, "zz8") == spec.ZIGZAG_8x8
+    assert c_array(ORC_TABLES, "orc_alpha") == c_array(PROD_KERNEL, "kAlpha") == c_array(GEN_H264, "alpha_tab") == spec.ALPHA
+    assert c_array(ORC_TABLES, "orc_beta") == c_array(PROD_KERNEL, "kBeta") == c_array(GEN_H264, "beta_tab") == spec.BETA
+    tc0 = [v for row in spec.TC0 for v in row]
+    assert len(spec.TC0) == 52 and c_array(ORC_TABLES, "orc_tc0") == c_array(PROD_KERNEL, "kTc0") == c_array(GEN_H264, "tc0_tab") == tc0
+    assert c_array(ORC_TABLES, "orc_qpc_tab") == c_array(GEN_H264, "qpc_tab") == spec.QPC_30_51
+    assert c_array(ORC_TABLES, "orc_norm4") == c_array(GEN_H264, "norm4") == [v for r in spec.NORM_ADJUST_4x4 for v in r]
+    assert c_array(ORC_TABLES, "orc_norm8") == c_array(GEN_H264, "norm8") == [v for r in spec.NORM_ADJUST_8x8 for v in r]
+    assert c_array(PROD_SYNTAX, "kDef4Intra") == c_array(GEN_H264, "dflt4_intra") == spec.DEFAULT_4x4_INTRA
+    assert c_array(PROD_SYNTAX, "kDef4Inter") == c_array(GEN_H264, "dflt4_inter") == spec.DEFAULT_4x4_INTER
+    assert c_array(PROD_SYNTAX, "kDef8Intra") == c_array(GEN_H264, "dflt8_intra") == spec.DEFAULT_8x8_INTRA
+    assert c_array(PROD_SYNTAX, "kDef8Inter") == c_array(GEN_H264, "dflt8_inter") == spec.DEFAULT_8x8_INTER
 
 
 def test_arithmetic_decoder_tables_against_a_separately_typed_copy():
@@ -142,6 +245,7 @@ def test_arithmetic_decoder_tables_against_a_separately_typed_copy():
         r = c_array(path, rname)
         rows = [r[i * 4:i * 4 + 4] for i in range(64)]
         assert rows[:8] == range_first and rows[60:] == range_last, os.path.basename(path)
+        assert [tuple(r) for r in rows] == spec.RANGE_TAB_LPS, os.path.basename(path)          # all 64 rows
         assert c_array(path, tname) == trans_lps, os.path.basename(path)
 
 

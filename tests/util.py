@@ -39,6 +39,18 @@ def c_array(path, name):
     return [int(x, 0) for x in re.findall(r"-?\b(?:0x[0-9a-fA-F]+|\d+)\b", body)]
 
 
+def c_rows(path, name, width):
+    """A two-dimensional integer array initialiser as a list of rows, each padded with zeros to `width` (C semantics of short inner braces)."""
+    src = open(path).read()
+    m = re.search(r"\b" + re.escape(name) + r"\s*(\[[^\]]*\]\s*)+=\s*\{", src)
+    assert m, f"{name} not found in {path}"
+    i = m.end()
+    body = re.sub(r"/\*.*?\*/", "", src[i:src.index(";", i)], flags=re.S)
+    rows = [[int(x, 0) for x in re.findall(r"-?\b(?:0x[0-9a-fA-F]+|\d+)\b", r)] for r in re.findall(r"\{([^{}]*)\}", body)]
+    assert rows and all(len(r) <= width for r in rows), (name, width)
+    return [r + [0] * (width - len(r)) for r in rows]
+
+
 def unescape(nal):
     out = bytearray()
     z = 0
