@@ -249,6 +249,41 @@ def test_arithmetic_decoder_tables_against_a_separately_typed_copy():
         assert c_array(path, tname) == trans_lps, os.path.basename(path)
 
 
+def test_hevc_constant_tables_against_a_separately_typed_copy():
+    """H.265 transform basis, DST, intra angles, interpolation filters, deblocking and chroma-QP tables: typed here from the standard's tables.
+    The 32x32 transMatrix is BUILT from its 31 distinct magnitudes and the cosine structure it samples (entry (k, n) = the rounded
+    64 * sqrt(2) * cos((2n + 1) k pi / 64), of which the standard lists the integers), not copied as 1024 numbers."""
+    mag = {0: 64, 16: 64, 8: 83, 24: 36, 4: 89, 12: 75, 20: 50, 28: 18, 2: 90, 6: 87, 10: 80, 14: 70, 18: 57, 22: 43, 26: 25, 30: 9,
+           1: 90, 3: 90, 5: 88, 7: 85, 9: 82, 11: 78, 13: 73, 15: 67, 17: 61, 19: 54, 21: 46, 23: 38, 25: 31, 27: 22, 29: 13, 31: 4}
+    want = []
+    for k in range(32):
+        for n in range(32):
+            m = ((2 * n + 1) * k) % 128
+            if m > 64:
+                m = 128 - m
+            want.append(mag[m] if m <= 32 else -mag[64 - m])
+    intra_angle = [0, 0] + [32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32]
+    inv_angle = [0] * 11 + [-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096] + [0] * 9
+    luma = [0, 0, 0, 64, 0, 0, 0, 0, -1, 4, -10, 58, 17, -5, 1, 0, -1, 4, -11, 40, 40, -11, 4, -1, 0, 1, -5, 17, 58, -10, 4, -1]
+    chroma = [0, 64, 0, 0, -2, 58, 10, -2, -4, 54, 16, -2, -6, 46, 28, -4, -4, 36, 36, -4, -4, 28, 46, -6, -2, 16, 54, -4, -2, 10, 58, -2]
+    beta = [0] * 16 + list(range(6, 19)) + list(range(20, 65, 2))
+    tc = [0] * 18 + [1] * 9 + [2] * 4 + [3] * 4 + [4] * 3 + [5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24]
+    qpc = list(range(30)) + [29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37] + [q - 6 for q in range(44, 58)]
+    dst = [29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29]
+    for path, pfx in ((PROD_HEVC, "hevc_"), (ORC_HEVC, None), (GEN_HEVC, None)):
+        src = open(path).read()
+        import re
+
+        def arr(stem):
+            name = next(n for n in (("hevc_" + stem), ("orch_" + stem), ("orc_hevc_" + stem), ("hg_" + stem), ("hevcgen_" + stem)) if re.search(r"\b" + n + r"\s*\[", src))
+            return c_array(path, name)
+        assert arr("trans") == want, os.path.basename(path)
+        assert arr("dst") == dst and arr("intra_angle") == intra_angle and arr("inv_angle") == inv_angle, os.path.basename(path)
+        assert arr("luma_filter") == luma and arr("chroma_filter") == chroma, os.path.basename(path)
+        assert arr("beta_tab") == beta and arr("tc_tab") == tc and arr("qpc_tab") == qpc, os.path.basename(path)
+        assert arr("level_scale") == [40, 45, 51, 57, 64, 72], os.path.basename(path)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 def table_digests():
     """{table: sha256 of its comma-joined integers} for every table of the product headers, with the clause each restates."""
