@@ -510,13 +510,16 @@ int Decoder::compute_poc(const SliceHeader &sh) {                               
     int max_fn = 1 << s.log2_max_frame_num;
     if (s.poc_type == 0) {
         int max_lsb = 1 << s.log2_max_poc_lsb;
-        int prev_msb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_msb_, prev_lsb = (sh.idr || prev_mmco5_) ? 0 : prev_poc_lsb_;
+        // prevPicOrderCntMsb / Lsb are those of the previous REFERENCE picture in decoding order; when it carried operation 5 they are 0 and its
+        // TopFieldOrderCnt after the operation -- dispatch_pending() stores that, and non-reference pictures in between leave it alone (8.2.1.1)
+        int prev_msb = sh.idr ? 0 : prev_poc_msb_, prev_lsb = sh.idr ? 0 : prev_poc_lsb_;
         long long msb = prev_msb;
         if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = (long long)prev_msb + max_lsb;
         else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = (long long)prev_msb - max_lsb;
         if (msb > (1ll << 30) || msb < -(1ll << 30)) msb = 0;                     // > 2^14 wraps of a 16-bit lsb without an IDR picture: not a real stream
         if (sh.nal_ref_idc) { prev_poc_msb_ = (int)msb; prev_poc_lsb_ = sh.poc_lsb; }
         long long top = msb + sh.poc_lsb;
+        cur_top_poc_ = top; cur_bot_poc_ = top + sh.delta_poc_bottom;
         return (int)std::min(top, top + sh.delta_poc_bottom);
     }
     // 64-bit arithmetic: offsets are se(v) of a hostile stream, and sums of them must not overflow (the result is truncated, never UB)
@@ -757,7 +760,10 @@ void Decoder::dispatch_pending() {
     std::unique_ptr<PicTask> t = std::move(pending_);
     mark_current(first_sh_);
     prev_frame_num_ = dpb_[cur_].frame_num;
-    prev_mmco5_ = dpb_[cur_].mmco5;
+    prev_mmco5_ = dpb_[cur_].mmco5;                // types 1 / 2: "the previous picture in decoding order included operation 5" (8.2.1.2, 8.2.1.3)
+    // type 0: tempPicOrderCnt = Min(top, bottom) is subtracted from the picture's order counts (8.2.1); what the following pictures see as
+    // prevPicOrderCntLsb is its TopFieldOrderCnt after that (> 0 when the bottom field lies below the top field)
+    if (dpb_[cur_].mmco5 && seq_.poc_type == 0) { prev_poc_msb_ = 0; prev_poc_lsb_ = (int)(cur_top_poc_ - std::min(cur_top_poc_, cur_bot_poc_)); }
     int poc = dpb_[cur_].poc;
     (void)poc;
     bump_after_current(t->out_after);

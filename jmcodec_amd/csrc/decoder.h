@@ -184,6 +184,7 @@ private:
     std::unique_ptr<PicTask> pending_;
     SliceHeader first_sh_;
     int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0; long long prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;
+    long long cur_top_poc_ = 0, cur_bot_poc_ = 0;   // TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0)
     int decode_count_ = 0, max_lt_idx_ = -1;
     uint64_t next_seq_ = 0;
     std::vector<int> carry_out_;               // outputs decided before the next picture starts (IDR flush)

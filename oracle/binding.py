@@ -50,6 +50,22 @@ class Oracle:
         self.L.orc_free(buf)
         return out, cnt, w.value, h.value
 
+    def display_pocs(self, data):
+        """PicOrderCnt of every output frame, display order (OrcFrame.poc at the moment the frame is handed out)."""
+        class Frame(C.Structure):
+            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c", C.c_int),
+                        ("poc", C.c_int), ("frame_type", C.c_int), ("decode_index", C.c_int)]
+        pocs = []
+        cb = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame))(lambda user, f: pocs.append(f.contents.poc))
+        d = self.L.orc_open(C.cast(cb, C.c_void_p), None)
+        rc = self.L.orc_decode_annexb(d, data, len(data))
+        err = self.L.orc_last_error(d).decode()
+        self.L.orc_flush(d)
+        self.L.orc_close(d)
+        if rc < 0:
+            raise RuntimeError("oracle: " + err)
+        return pocs
+
     def syntax_digest(self, data):
         """(digest, n_macroblocks) of the parsed syntax elements (see oracle/orc_slice.c digest_mb)."""
         d = self.L.orc_open(None, None)
@@ -139,6 +155,22 @@ class OracleHevc:
         err = self.L.orch_last_error(d).decode()
         self.L.orch_flush(d)
         return d, rc, err
+
+    def display_pocs(self, data):
+        """PicOrderCnt of every output frame, display order (OrcFrame.poc at the moment the frame is handed out)."""
+        class Frame(C.Structure):
+            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c", C.c_int),
+                        ("poc", C.c_int), ("frame_type", C.c_int), ("decode_index", C.c_int)]
+        pocs = []
+        cb = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame))(lambda user, f: pocs.append(f.contents.poc))
+        d = self.L.orc_open(C.cast(cb, C.c_void_p), None)
+        rc = self.L.orc_decode_annexb(d, data, len(data))
+        err = self.L.orc_last_error(d).decode()
+        self.L.orc_flush(d)
+        self.L.orc_close(d)
+        if rc < 0:
+            raise RuntimeError("oracle: " + err)
+        return pocs
 
     def syntax_digest(self, data):
         d, rc, err = self._run(data, True)

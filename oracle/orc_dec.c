@@ -103,8 +103,9 @@ static int compute_poc(OrcDec *d, const SliceHdr *sh) {
     int max_frame_num = 1 << s->log2_max_frame_num;
     if (s->poc_type == 0) {
         int max_lsb = 1 << s->log2_max_poc_lsb, prev_msb, prev_lsb;
+        /* prevPicOrderCntMsb / Lsb belong to the previous REFERENCE picture in decoding order (non-reference pictures in between change nothing).
+         * When that picture carried operation 5 they are 0 and its TopFieldOrderCnt after the operation: orc_finish_picture stores exactly that. */
         if (sh->idr) { prev_msb = 0; prev_lsb = 0; }
-        else if (d->prev_ref_has_mmco5) { prev_msb = 0; prev_lsb = 0; /* frame: tempPicOrderCnt of a frame after mmco5 is 0 */ }
         else { prev_msb = d->prev_poc_msb; prev_lsb = d->prev_poc_lsb; }
         int msb;
         if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
@@ -112,6 +113,7 @@ static int compute_poc(OrcDec *d, const SliceHdr *sh) {
         else msb = prev_msb;
         int top = msb + sh->poc_lsb, bot = top + sh->delta_poc_bottom;
         if (sh->nal_ref_idc) { d->prev_poc_msb = msb; d->prev_poc_lsb = sh->poc_lsb; }
+        d->cur_top_poc = top; d->cur_bot_poc = bot;
         return orc_min(top, bot);
     }
     int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset;
@@ -311,8 +313,12 @@ void orc_finish_picture(OrcDec *d) {
     d->prev_frame_num = cur->frame_num;
     d->prev_ref_has_mmco5 = 0;
     if (cur->has_mmco5) {
-        /* 8.2.1: after mmco5 the picture is inferred to have had frame_num 0 and POC relative to itself */
+        /* 7.4.3 / 8.2.1: after operation 5 the picture is inferred to have had frame_num 0, and tempPicOrderCnt = Min(top, bottom) is subtracted
+         * from both of its order counts: PicOrderCnt becomes 0, and for pic_order_cnt_type 0 the NEXT pictures see prevPicOrderCntMsb = 0 and
+         * prevPicOrderCntLsb = its TopFieldOrderCnt after the subtraction (> 0 when the bottom field lies below the top field).  prev_ref_has_mmco5
+         * is the "previous picture" condition of types 1 and 2 (8.2.1.2 / 8.2.1.3: only the picture that follows immediately). */
         d->prev_ref_has_mmco5 = 1; cur->frame_num = 0;
+        if (d->asps->poc_type == 0) { d->prev_poc_msb = 0; d->prev_poc_lsb = d->cur_top_poc - orc_min(d->cur_top_poc, d->cur_bot_poc); }
         Picture *p; while ((p = smallest_poc_waiting(d, cur)) != NULL) emit(d, p);
         cur->poc = 0;
     }

@@ -164,7 +164,7 @@ struct OrcDec {
     int dpb_size;
     int next_pic_id, decode_count;
     /* POC state */
-    int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5;
+    int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5; int cur_top_poc, cur_bot_poc;   /* TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0) */
     /* slice state */
     SliceHdr sh; SliceHdr first_sh;
     int slice_num;

@@ -124,6 +124,15 @@ B_CASES = {
     "fmo0_cavlc_fuzz": dict(width=96, height=96, frames=8, gop=4, mode=1, num_ref=2, slices=2, seed=110, fmo0=1),
     "fmo0_cabac_b_crop": dict(width=176, height=156, frames=10, gop=10, mode=1, seed=111, fmo0=1, cabac=1, t8x8=1, bframes=2, num_ref=3),
     "fmo0_real": dict(width=320, height=256, frames=6, gop=6, seed=112, fmo0=1, cabac=1),
+    # picture order count (8.2.1): type 1 (expected-delta cycle, offset_for_non_ref_pic, delta_pic_order_cnt[0 / 1]), bottom-field deltas
+    # (PicOrderCnt = Min(top, bottom)) in P / B streams, and memory management operation 5 (frame_num and order counts restart) with types 0, 1, 2
+    "poc1_cycle_nonref": dict(width=96, height=80, frames=16, gop=16, mode=1, seed=113, poc_type=1, nonref_period=3, num_ref=2),
+    "poc1_bottom_cabac": dict(width=96, height=80, frames=12, gop=6, mode=1, seed=114, poc_type=1, poc_bottom=1, nonref_period=2, num_ref=3, cabac=1, slices=2),
+    "poc0_bottom_b_temporal": dict(width=96, height=80, frames=13, gop=13, mode=1, seed=115, poc_bottom=1, bframes=2, num_ref=3, direct_temporal=1, cabac=1),
+    "poc0_bottom_b_implicit": dict(width=96, height=80, frames=13, gop=13, mode=1, seed=116, poc_bottom=1, bframes=3, num_ref=3, wp=2),
+    "mmco5_poc0_bottom_nonref": dict(width=64, height=48, frames=70, gop=70, mode=1, seed=2, poc_type=0, poc_bottom=1, nonref_period=2, mmco=2, num_ref=3),
+    "mmco5_poc1": dict(width=96, height=80, frames=24, gop=24, mode=1, seed=117, poc_type=1, poc_bottom=1, nonref_period=3, mmco=2, num_ref=3),
+    "mmco5_poc2_cabac": dict(width=96, height=80, frames=24, gop=24, mode=1, seed=118, poc_type=2, nonref_period=3, mmco=2, num_ref=2, cabac=1),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

@@ -36,7 +36,7 @@ typedef struct {
     int num_ref;                /* max_num_ref_frames 1..4                    */
     int slices;                 /* slices per picture (split by MB rows)      */
     int pcm_only;               /* every MB I_PCM (known-answer streams)      */
-    int poc_type;               /* 0 or 2                                     */
+    int poc_type;               /* 0, 1 or 2 (1: P-only streams; expected-delta cycle, offsets and delta_pic_order_cnt[] drawn from the seed) */
     int nonref_period;          /* >0: every n-th P picture is non-reference  */
     int alpha_off, beta_off;    /* slice_alpha_c0_offset_div2, beta_offset_div2 */
     int chroma_qp_off;
@@ -52,13 +52,16 @@ typedef struct {
     int dinf8;                  /* direct_8x8_inference_flag (default 1 when 0 is passed with bframes == 0) */
     int scaling;                /* 0 flat, 1 scaling lists in the SPS, 2 in the PPS (forces High profile)             */
     int rplm;                   /* 1: random ref_pic_list_modification() in P / B slices (fuzz)                       */
-    int mmco;                   /* 1: random memory_management_control_operations, long-term references (P-only streams) */
+    int mmco;                   /* 1: random memory_management_control_operations, long-term references (P-only streams); 2: also operation 5 now and
+                                   then (all references dropped, frame_num and picture order count restart: 7.4.3, 8.2.1) */
     int nc_corner;              /* 1: Intra4x4 modes 4-6 may be chosen although p[-1,-1] is unavailable (NON-CONFORMING; probes the decoders'
                                    common convention "unavailable samples count as 128", which constrained_intra_pred exposes)   */
     int no_intra;               /* 1: fuzz mode codes no intra macroblocks in P / B pictures and no non-IDR I pictures (the random numbers are
                                    still drawn, so the rest of the stream's decisions do not shift)                              */
     int fmo0;                   /* 1: frame_mbs_only_flag = 0 without MBAFF, every picture a FRAME picture (field_pic_flag = 0): an interlace-capable
                                    stream that happens to be coded progressively.  Needs an even number of macroblock rows; Main profile at least */
+    int poc_bottom;             /* 1: bottom_field_pic_order_in_frame_present_flag = 1 with random delta_pic_order_cnt_bottom / delta_pic_order_cnt[1] in -1..1
+                                   (PicOrderCnt of a frame = Min(top, bottom), 8.2.1) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -242,6 +245,10 @@ typedef struct {
     int slice_id, slice_type, qp_run;
     Frame *list0[5]; int nlist0;
     Frame *list1[5]; int nlist1; int cur_poc;
+    int *pocs;                            /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
+    int poc_base;                         /* display index at which the picture order count restarted (IDR picture, or a picture with operation 5) */
+    int cur_top, delta_bottom, delta0;    /* TopFieldOrderCnt of the current picture; delta_pic_order_cnt_bottom / [1]; delta_pic_order_cnt[0] (type 1) */
+    int t1_cycle, t1_ref[3], t1_nonref, t1_t2b;   /* pic_order_cnt_type 1: cycle of expected deltas, offset_for_non_ref_pic, offset_for_top_to_bottom_field */
     int wlog[2], ww[2][5][3], wo[2][5][3];   /* explicit weighted prediction: log2 denominators (luma, chroma), weight / offset [list][ref][Y,Cb,Cr] */
     uint8_t *recon_buf; int recon_frames;
     int max_lt_idx;                         /* MaxLongTermFrameIdx, -1 = "no long-term frame indices" */
@@ -1789,6 +1796,10 @@ static void write_sps_pps(Enc *e) {
     bw_ue(w, e->log2_max_fn - 4);
     bw_ue(w, p->poc_type);
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
+    if (p->poc_type == 1) {                                               /* delta_pic_order_always_zero_flag 0, offsets, the cycle */
+        bw_put(w, 1, 0); bw_se(w, e->t1_nonref); bw_se(w, e->t1_t2b); bw_ue(w, e->t1_cycle);
+        for (int i = 0; i < e->t1_cycle; i++) bw_se(w, e->t1_ref[i]);
+    }
     bw_ue(w, p->num_ref); bw_put(w, 1, 0);
     bw_ue(w, e->mbw - 1); bw_ue(w, (p->fmo0 ? e->mbh / 2 : e->mbh) - 1);   /* pic_height_in_map_units: field macroblock rows when frame_mbs_only_flag = 0 */
     if (p->fmo0) { bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 1); }  /* frame_mbs_only_flag 0, mb_adaptive_frame_field_flag 0, direct_8x8_inference_flag 1 */
@@ -1798,7 +1809,7 @@ static void write_sps_pps(Enc *e) {
     bw_put(w, 1, 0);                                                      /* no VUI */
     bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
     w->len = 0;
-    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, 0); bw_ue(w, 0);
+    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, (uint32_t)p->poc_bottom); bw_ue(w, 0);   /* ..., bottom_field_pic_order_in_frame_present_flag, one slice group */
     bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
     bw_put(w, 1, (uint32_t)(p->wp == 1)); bw_put(w, 2, (uint32_t)(p->bframes ? p->wp : 0));   /* weighted_pred_flag, weighted_bipred_idc */
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
@@ -1814,10 +1825,16 @@ static void encode_frame(Enc *e, int t, int is_b) {
     int is_ref = !is_b && (idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0));
     if (p->bframes) is_ref = !is_b;
     render_source(e, t);
-    if (idr) { e->frame_num = 0; e->nrefs = 0; write_sps_pps(e); }
+    if (idr) { e->frame_num = 0; e->nrefs = 0; e->poc_base = t; write_sps_pps(e); }
     e->slice_type = idr ? 2 : (is_b ? 1 : 0);
     if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0 && !p->no_intra) e->slice_type = 2;   /* occasional non-IDR I picture */
-    e->cur_poc = 2 * (t % p->gop); e->cur.poc = e->cur_poc;
+    /* 8.2.1: TopFieldOrderCnt counts 2 per picture from the last restart; with poc_bottom the bottom field may lie one below or above, and
+       PicOrderCnt(frame) = Min(top, bottom) is what the lists, direct prediction and the output order see */
+    e->cur_top = 2 * (t - e->poc_base); e->delta_bottom = 0; e->delta0 = 0;
+    if (p->poc_bottom) { e->delta_bottom = rnd_n(&e->rng, 3) - 1; if (idr && e->delta_bottom < 0) e->delta_bottom = 1; }   /* an IDR frame: Min(top, bottom) = 0 (8.2.1) */
+    if (p->poc_type == 1) e->delta0 = rnd_n(&e->rng, 2);
+    e->cur_poc = e->cur_top + MIN(0, e->delta_bottom); e->cur.poc = e->cur_poc;
+    if (e->pocs) e->pocs[t] = e->cur_poc;
     const int maxfn = 1 << e->log2_max_fn, curfn = e->frame_num & (maxfn - 1);
     e->cur.frame_num = curfn; e->cur.is_long = 0; e->cur.lt_idx = -1;
 #define PICNUM(f) ((f)->frame_num > curfn ? (f)->frame_num - maxfn : (f)->frame_num)
@@ -1885,7 +1902,10 @@ static void encode_frame(Enc *e, int t, int is_b) {
             /* the sliding window needs a short-term picture to drop (8.2.5.3): with only long-term pictures in a full buffer the
                stream MUST use memory management operations */
             int must = st_n == 0 && lt_n >= p->num_ref;
-            if (must || rnd_n(&e->rng, 3) == 0) {
+            /* operation 5 alone.  Not on a picture with frame_num 1: the next picture has frame_num 1 again (7.4.3) and could then differ from this
+               one in none of the ways 7.4.1.2.4 lists (same frame_num, both reference pictures, same order-count syntax) */
+            if (p->mmco == 2 && curfn != 1 && rnd_n(&e->rng, 5) == 0) { e->mmco_op[0] = 5; e->mmco_a[0] = e->mmco_b[0] = 0; e->n_mmco = 1; }
+            else if (must || rnd_n(&e->rng, 3) == 0) {
 #define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
 #define DROP_LT(ix) do { for (int q_ = 0; q_ < lt_n; q_++) if (lt_ix[q_] == (ix)) { lt_ix[q_] = lt_ix[--lt_n]; break; } } while (0)
             if (maxlt < 1 && rnd_n(&e->rng, 2)) { ADD_OP(4, 2, 0); maxlt = 1; }
@@ -1927,7 +1947,8 @@ static void encode_frame(Enc *e, int t, int is_b) {
         bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
         if (p->fmo0) bw_put(w, 1, 0);                                      /* field_pic_flag */
         if (idr) bw_ue(w, e->idr_id & 0xffff);
-        if (p->poc_type == 0) bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_poc & ((1u << e->poc_lsb_bits) - 1));
+        if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_top & ((1u << e->poc_lsb_bits) - 1)); if (p->poc_bottom) bw_se(w, e->delta_bottom); }
+        if (p->poc_type == 1) { bw_se(w, e->delta0); if (p->poc_bottom) bw_se(w, e->delta_bottom); }
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); }
         if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); }
@@ -2012,6 +2033,13 @@ static void encode_frame(Enc *e, int t, int is_b) {
                 } else if (o == 2) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == a) { REMOVE_REF(i); break; } }
                 else if (o == 4) { e->max_lt_idx = a - 1; for (int i = e->nrefs - 1; i >= 0; i--) if (e->refs[i].is_long && e->refs[i].lt_idx > e->max_lt_idx) REMOVE_REF(i); }
                 else if (o == 6) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); break; } e->cur.is_long = 1; e->cur.lt_idx = b; }
+                else if (o == 5) {
+                    /* every reference picture is dropped; the picture is inferred to have had frame_num 0 (7.4.3) and its order counts are
+                       reduced by Min(top, bottom) (8.2.1): what follows counts from here */
+                    while (e->nrefs > 0) REMOVE_REF(0);
+                    e->max_lt_idx = -1; e->cur.frame_num = 0; e->cur.poc = 0; e->frame_num = 0; e->poc_base = t;
+                    if (e->pocs) e->pocs[t] = 0;
+                }
             }
         } else if (e->nrefs >= p->num_ref) {                              /* sliding window: drop the oldest short-term picture */
             int old = -1;
@@ -2025,6 +2053,12 @@ static void encode_frame(Enc *e, int t, int is_b) {
     if (idr) e->idr_id++;
 }
 
+/* The picture order counts the encoder MEANT, by display index, of the stream this thread generated last: TopFieldOrderCnt counts 2 per picture from
+   the last IDR picture or operation 5, PicOrderCnt = Min(top, bottom), 0 for a picture that carried operation 5 (8.2.1).  For pic_order_cnt_type 0 a
+   decoder must reconstruct exactly these values from pic_order_cnt_lsb / delta_pic_order_cnt_bottom (tests/test_host_parser.py); types 1 and 2
+   derive other (equally ordered) values.  Returns the number of pictures. */
+static __thread int *g_last_pocs; static __thread int g_last_n;
+int h264gen_last_pocs(int *buf, int max) { for (int i = 0; i < g_last_n && i < max; i++) buf[i] = g_last_pocs[i]; return g_last_n; }
 /* library entry: returns malloc'ed Annex-B stream */
 int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const char *recon_path) {
     g_nc_corner = gp->nc_corner;
@@ -2038,13 +2072,19 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (p->slices < 1) p->slices = 1;
     if (p->search < 1) p->search = 4;
     if (!p->level_idc) p->level_idc = 40;
-    if (p->poc_type != 0) p->poc_type = 2;
+    if (p->poc_type != 0 && p->poc_type != 1) p->poc_type = 2;
+    p->poc_bottom = p->poc_bottom != 0;
     p->scaling = CLIP3(0, 2, p->scaling);
     if (p->bframes) p->mmco = 0;
     e->max_lt_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
     else { p->poc_type = 0; p->nonref_period = 0; if (p->num_ref < 2) p->num_ref = 2; p->dinf8 = p->dinf8 != 0; }
+    /* pic_order_cnt_type 1 (8.2.1.2): reference pictures advance by 8 / 10 / 12 in a cycle of 1..3, a non-reference picture lies 4 above the
+       reference picture before it, top-to-bottom offset -1..1; with delta_pic_order_cnt[0] in 0..1 and the bottom deltas in -1..1 the counts still
+       rise strictly in decoding order, which is the display order of a stream without B pictures */
+    { uint32_t h = (uint32_t)p->seed * 2654435761u; e->t1_cycle = 1 + (int)((h >> 8) % 3); for (int i = 0; i < 3; i++) e->t1_ref[i] = 8 + 2 * (int)((h >> (12 + 4 * i)) % 3);
+      e->t1_nonref = 4; e->t1_t2b = p->poc_bottom ? (int)((h >> 26) % 3) - 1 : 0; }
     p->cabac = p->cabac != 0; p->t8x8 = p->t8x8 != 0; p->cabac_idc = CLIP3(0, 2, p->cabac_idc);
     e->cabac = p->cabac;
     if (p->nonref_period == 1) p->nonref_period = 2;
@@ -2058,6 +2098,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     for (int i = 0; i < 5; i++) frame_alloc(&e->refs[i], e->W, e->H, 1);
     e->mbs = (MbE *)calloc((size_t)e->mbw * e->mbh, sizeof(MbE));
     make_texture(e);
+    e->pocs = (int *)calloc((size_t)p->frames + 1, sizeof(int));
     if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames; e->recon_buf = (uint8_t *)calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
     for (int g0 = 0; g0 < p->frames; g0 += p->gop) {                      /* coding order: every anchor before the B pictures that precede it in display order */
         int g1 = MIN(p->frames, g0 + p->gop), prev = g0;
@@ -2071,6 +2112,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     }
     if (e->recon) { fwrite(e->recon_buf, 1, (size_t)p->frames * ((size_t)p->width * p->height * 3 / 2), e->recon); fclose(e->recon); free(e->recon_buf); }
     *out = e->out.buf; *out_len = e->out.len;
+    free(g_last_pocs); g_last_pocs = e->pocs; g_last_n = p->frames;
     free(e->cur.mf); for (int i = 0; i < 5; i++) free(e->refs[i].mf);
     frame_free(&e->src); frame_free(&e->cur); for (int i = 0; i < 5; i++) frame_free(&e->refs[i]);
     free(e->mbs); free(e->bw.buf); free(e);
@@ -2091,7 +2133,7 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;

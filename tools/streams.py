@@ -18,7 +18,7 @@ class GenParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "width", "height", "frames", "qp", "gop", "seed", "mode", "deblock", "num_ref", "slices",
         "pcm_only", "poc_type", "nonref_period", "alpha_off", "beta_off", "chroma_qp_off", "level_idc",
-        "cip", "search", "cabac", "cabac_idc", "t8x8", "bframes", "direct_temporal", "wp", "dinf8", "scaling", "rplm", "mmco", "nc_corner", "no_intra", "fmo0")]
+        "cip", "search", "cabac", "cabac_idc", "t8x8", "bframes", "direct_temporal", "wp", "dinf8", "scaling", "rplm", "mmco", "nc_corner", "no_intra", "fmo0", "poc_bottom")]
 
 
 def build_tools():
@@ -43,12 +43,12 @@ def _genlib():
 
 def generate(width=64, height=48, frames=4, qp=28, gop=30, seed=0x4A4D0100, mode=0, deblock=1, num_ref=1,
              slices=1, pcm_only=0, poc_type=2, nonref_period=0, alpha_off=0, beta_off=0, chroma_qp_off=0,
-             level_idc=0, cip=0, search=4, cabac=0, cabac_idc=0, t8x8=0, bframes=0, direct_temporal=0, wp=0, dinf8=1, scaling=0, rplm=0, mmco=0, nc_corner=0, no_intra=0, fmo0=0,
+             level_idc=0, cip=0, search=4, cabac=0, cabac_idc=0, t8x8=0, bframes=0, direct_temporal=0, wp=0, dinf8=1, scaling=0, rplm=0, mmco=0, nc_corner=0, no_intra=0, fmo0=0, poc_bottom=0,
              recon_path=None):
     """Returns the Annex-B stream as bytes (optionally writing the encoder's own reconstruction)."""
     p = GenParams(width, height, frames, qp, gop, seed, mode, deblock, num_ref, slices, pcm_only, poc_type,
                   nonref_period, alpha_off, beta_off, chroma_qp_off, level_idc, cip, search, cabac, cabac_idc, t8x8,
-                  bframes, direct_temporal, wp, dinf8, scaling, rplm, mmco, nc_corner, no_intra, fmo0)
+                  bframes, direct_temporal, wp, dinf8, scaling, rplm, mmco, nc_corner, no_intra, fmo0, poc_bottom)
     buf = C.POINTER(C.c_ubyte)()
     n = C.c_size_t(0)
     rc = _genlib().h264gen_generate(C.byref(p), C.byref(buf), C.byref(n), recon_path.encode() if recon_path else None)
@@ -57,6 +57,13 @@ def generate(width=64, height=48, frames=4, qp=28, gop=30, seed=0x4A4D0100, mode
     data = C.string_at(buf, n.value)
     _genlib().h264gen_free(buf)
     return data
+
+
+def last_pocs():
+    """PicOrderCnt per display index as the generator meant it, of the H.264 stream THIS thread generated last (tools/h264gen.c h264gen_last_pocs)."""
+    buf = (C.c_int * 4096)()
+    n = _genlib().h264gen_last_pocs(buf, 4096)
+    return list(buf[:min(n, 4096)])
 
 
 # BASELINE.json configs restated as generator parameters (SURVEY.md 8d); seed = 0x4A4D0000 + config*256 + stream
