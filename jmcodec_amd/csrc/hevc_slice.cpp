@@ -758,7 +758,9 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         if (ctb_slice_[ctb_rs_] >= 0) return "coding tree block decoded twice";
         ctb_slice_[ctb_rs_] = sh.slice_addr;
         { HevcCtb &cj = jobs_->ctbs[ctb_rs_]; cj.beta_off = slices_[slice_idx_].beta_off; cj.tc_off = slices_[slice_idx_].tc_off; cj.intra_first = (uint32_t)jobs_->itbs.size(); }
-        if (first_in_tile) { if (!first_ctu) init_contexts(); first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp; }
+        // 9.3.1: the first CTB of a tile ALWAYS starts from initialised context variables -- also when it opens a dependent slice segment (the
+        // stored variables of the previous segment only apply to a segment that starts inside a tile)
+        if (first_in_tile) { if (!first_ctu || sh.dependent) init_contexts(); first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp; }
         else if (row_start) {                                           // 9.3.1: synchronisation with the CTB above and to the right
             const int x0 = rx << sps_->log2_ctb, y0 = ry << sps_->log2_ctb;
             if (wpp_valid_ && avail_zs(x0, y0, x0 + ctb_size_, y0 - ctb_size_)) memcpy(cb_.state, wpp_state_, HEVC_N_CTX * sizeof(Cabac::State));

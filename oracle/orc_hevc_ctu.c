@@ -979,7 +979,10 @@ int orch_decode_slice_data(OrchDec *d, HSlice *sh, int slice_idx, const uint8_t 
         int first_in_tile = s->ctb_addr_ts == 0 || d->tile_id[s->ctb_addr_ts - 1] != tile;
         int row_start = s->pps->wpp && (rx == 0 || d->tile_id[d->ctb_rs2ts[s->ctb_addr_rs - 1]] != tile);
         d->ctb_slice_addr[s->ctb_addr_rs] = sh->slice_addr; d->ctb_slice_idx[s->ctb_addr_rs] = (int16_t)slice_idx;
-        if (first_in_tile) { if (!first_ctu) cabac_init_ctx(s); s->first_qg = 1; s->qg_started = 0; s->qp_y_prev = sh->slice_qp; }
+        /* 9.3.1: "If the CTU is the first CTU in a tile, the initialization process is invoked" comes BEFORE the dependent-slice-segment case:
+         * a dependent segment that opens a tile does not inherit the previous segment's context variables */
+        if (first_in_tile && first_ctu && sh->dependent) d->stats[HST_DEP_OPENS_TILE]++;
+        if (first_in_tile) { if (!first_ctu || sh->dependent) cabac_init_ctx(s); s->first_qg = 1; s->qg_started = 0; s->qp_y_prev = sh->slice_qp; }
         else if (row_start) {                                           /* 9.3.1: synchronisation with the CTB above right */
             int x0 = rx << s->sps->log2_ctb, y0 = ry << s->sps->log2_ctb;
             int avail_t = avail_zs(s, x0, y0, x0 + d->ctb_size, y0 - d->ctb_size);

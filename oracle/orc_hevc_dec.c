@@ -9,7 +9,7 @@
 
 static const char *kToolNames[HST_N] = { "cu", "intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst",
     "sign_hiding", "transform_skip", "tq_bypass", "pcm", "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "scaling_list", "wpp_rows", "tiles",
-    "dependent_slices", "long_term_ref", "rplm", "strong_intra", "constrained_intra", "slices", "i_slices", "p_slices", "b_slices", "merge_b0_b2_vs_pruned_b1" };
+    "dependent_slices", "long_term_ref", "rplm", "strong_intra", "constrained_intra", "slices", "i_slices", "p_slices", "b_slices", "merge_b0_b2_vs_pruned_b1", "dependent_segment_opens_tile" };
 const char *orch_tool_name(int i) { return i >= 0 && i < HST_N ? kToolNames[i] : NULL; }
 long orch_tool_count(const OrchDec *d, int i) { return i >= 0 && i < HST_N ? d->stats[i] : 0; }
 

@@ -13,7 +13,7 @@ enum { H_SLICE_B = 0, H_SLICE_P = 1, H_SLICE_I = 2 };
 enum { H_PART_2Nx2N, H_PART_2NxN, H_PART_Nx2N, H_PART_NxN, H_PART_2NxnU, H_PART_2NxnD, H_PART_nLx2N, H_PART_nRx2N };
 enum { HST_CU, HST_INTRA_CU, HST_SKIP_CU, HST_MERGE_PU, HST_AMVP_PU, HST_BI_PU, HST_AMP, HST_NXN, HST_TU4, HST_TU8, HST_TU16, HST_TU32, HST_DST,
        HST_SDH, HST_TSKIP, HST_BYPASS, HST_PCM, HST_DQP, HST_SAO_BAND, HST_SAO_EDGE, HST_WP, HST_TMVP, HST_SCALING, HST_WPP_ROWS, HST_TILES,
-       HST_DEP_SLICE, HST_LT_REF, HST_RPLM, HST_STRONG_INTRA, HST_CIP, HST_SLICES, HST_I, HST_P, HST_B, HST_MERGE_VS_PRUNED_B1, HST_N };
+       HST_DEP_SLICE, HST_LT_REF, HST_RPLM, HST_STRONG_INTRA, HST_CIP, HST_SLICES, HST_I, HST_P, HST_B, HST_MERGE_VS_PRUNED_B1, HST_DEP_OPENS_TILE, HST_N };
 
 typedef struct {                 /* short-term reference picture set (7.4.8) */
     int n_neg, n_pos;

@@ -48,6 +48,8 @@ HEVC_CASES = {
     "rps_sps_gop8": dict(width=96, height=80, frames=17, gop=8, num_ref=2, rps_sps=1, mode=1, seed=29),
     "rps_sps_p": dict(width=96, height=80, frames=9, num_ref=3, rps_sps=1, mode=1, seed=30),
     "open_gop": dict(width=96, height=80, frames=20, gop=2, num_ref=2, open_gop=1, intra_period=6, rps_sps=1, seed=31),
+    # dependent slice segments that OPEN a tile: the first CTB of a tile starts from initialised context variables, not from the previous segment's (9.3.1)
+    "tiles_dep_slices": dict(width=128, height=96, frames=3, tile_cols=2, tile_rows=2, slice_ctus=4, dep_slices=1, ctb_log2=4, mode=1, seed=40),
     "tiles_explicit": dict(width=128, height=96, frames=3, tile_cols=3, tile_rows=2, ctb_log2=4, mode=1, seed=34),      # seed & 2: uniform_spacing_flag = 0
     "poc_wrap": dict(width=64, height=64, frames=70, intra_period=70, gop=2, num_ref=2, seed=36),                          # MaxPicOrderCntLsb = 32 < 70
     "small_tb": dict(width=96, height=80, frames=3, max_tb_log2=3, depth_inter=1, depth_intra=0, mode=1, seed=28),
@@ -72,11 +74,12 @@ def test_oracle_equals_generator_reconstruction(oracle, name):
 
 def test_cases_cover_the_tools(oracle):
     seen = {}
-    for name in ("b_gop2", "tskip_sdh", "pcm_bypass", "wp_b", "rplm", "long_term", "wpp", "tiles", "slices_dep", "dqp_depths", "b_gop8", "cip"):
+    for name in ("b_gop2", "tskip_sdh", "pcm_bypass", "wp_b", "rplm", "long_term", "wpp", "tiles", "tiles_dep_slices", "slices_dep", "dqp_depths", "b_gop8", "cip"):
         for k, v in oracle.tools(streams.generate_hevc(**HEVC_CASES[name])).items():
             seen[k] = seen.get(k, 0) + v
     for tool in ("intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst", "sign_hiding", "transform_skip", "tq_bypass", "pcm",
                  "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "wpp_rows", "tiles", "dependent_slices", "long_term_ref", "rplm", "b_slices",
+                 "dependent_segment_opens_tile",   # 9.3.1: initialised contexts, not the stored ones (a second shared misreading, found in round 3)
                  "merge_b0_b2_vs_pruned_b1"):      # 8.5.3.2.3: B0 / B2 dropped as duplicates of a B1 that is available but was itself pruned against A1 (the case all three programs once misread)
         assert seen.get(tool, 0) > 0, f"no test stream exercises {tool}"
 

@@ -1618,7 +1618,8 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
             int first_in_tile = ts == 0 || e->tile_of[ts - 1] != tile;
             int row_start = p->wpp && (rx == 0 || e->tile_of[e->rs2ts[rs - 1]] != tile);
             e->ctb_slice[rs] = e->seg_first_ctb; e->cur_ts = ts;
-            if (first_in_tile) { if (ts != first_ts) cab_init_ctx(cb, init_type, s->qp); e->first_qg = 1; e->qg_open = 0; e->qp_prev = s->qp; }
+            /* the first CTB of a tile starts from initialised contexts, also at the head of a dependent slice segment (9.3.1) */
+            if (first_in_tile) { if (ts != first_ts || dependent) cab_init_ctx(cb, init_type, s->qp); e->first_qg = 1; e->qg_open = 0; e->qp_prev = s->qp; }
             else if (row_start) {
                 int x0 = rx << p->ctb_log2, y0 = ry << p->ctb_log2;
                 if (avail(e, x0, y0, x0 + e->ctb, y0 - e->ctb) && wpp_valid) { memcpy(cb->st, wpp_st, sizeof wpp_st); memcpy(cb->mps, wpp_mps, sizeof wpp_mps); }
