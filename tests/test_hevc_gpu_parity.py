@@ -172,6 +172,31 @@ def test_c3_4k_whole_gop8_pyramid():
         assert f == want[i * fs:(i + 1) * fs], f"frame {i} differs from the oracle"
 
 
+def test_c3_full_length_4k_hevc():
+    """BASELINE config C3 at its full size AND length (120 frames): 3840x2160 HEVC Main, 64x64 CTB, SAO + deblocking, random-access GOP 8,
+    IDR every 32 -- four IDR periods (generated as four closed periods on four threads: a 4K picture costs the generator seconds, and an IDR picture
+    restarts everything anyway).  The first period (32 frames, four complete B pyramids) AND the last one (frames 96..119: surfaces, job slots and
+    collocated-motion fields recycled many times by then) are compared with the CPU oracle frame by frame; the whole run through size-independent
+    properties: 120 frames in display order, no errors, every frame distinct, and a second decode fed in 64 KiB chunks instead of NAL-per-call gives
+    the same 120 digests (chunking invariance + run-to-run determinism with the pictures of a stream parsed concurrently)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from test_gpu_parity import _decode_digests, _md5_frames
+    lengths = (32, 32, 32, 24)
+    with ThreadPoolExecutor(4) as ex:                                     # generator and oracle are C libraries behind ctypes: the GIL is released
+        periods = list(ex.map(lambda k: streams.generate_hevc(**streams.config_c3(frames=lengths[k], stream_id=k)), range(4)))
+        data = b"".join(periods)
+        assert [streams.idr_period(data, k, True) is not None for k in range(5)] == [True] * 4 + [False]
+        wants = {k: ex.submit(lambda k=k: streams.OracleHevc().decode(periods[k], 1)) for k in (0, 3)}
+        digs, kinds = _decode_digests(data, 3840, 2160, codec=1)
+        assert len(digs) == 120 and len(set(digs)) == 120 and sum(kinds) == 120 and kinds[0] == 4 and kinds[2] >= 84   # 4 IDR pictures, 7 of 8 others are B pictures
+        digs2, _ = _decode_digests(data, 3840, 2160, codec=1, chunks=[data[i:i + 65536] for i in range(0, len(data), 65536)])
+        assert digs2 == digs
+        for k, first in ((0, 0), (3, 96)):
+            want, n, w, h = wants[k].result()
+            assert (w, h, n) == (3840, 2160, lengths[k])
+            assert digs[first:first + n] == _md5_frames(want, w * h * 3 // 2), f"IDR period {k} differs from the oracle"
+
+
 @pytest.mark.gpu
 def test_mixed_codecs_concurrently_all_engine_lanes():
     """H.264 Baseline, H.264 High with B pictures and HEVC handles decoding at the same time on one device: ordinary lane (chain launches and stage kernels),
