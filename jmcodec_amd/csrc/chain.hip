@@ -67,6 +67,18 @@ int chain_band_rows() { return kBandRows; }
 // kernel depend on everything else in the module)
 void launch_chain_intra(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, int depth, int pub, hipStream_t st);
 
+int chain_intra_resident_workgroups();
+// workgroups of a chain launch the current device holds at once: k_chain, or (intra) k_chain_i; 0 when the runtime cannot say
+int chain_resident_workgroups(bool intra) {
+    if (intra) return chain_intra_resident_workgroups();
+    int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    const int depth = deblock_depth();
+    hipError_t e = depth <= 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<2>, 256, 0)
+                 : depth == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<3>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<4>, 256, 0);
+    return e == hipSuccess ? per_cu * prop.multiProcessorCount : 0;
+}
+
 void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st) {
     const int depth = deblock_depth(), pub = debug_stall ? -1 : deblock_pub();
     if (with_intra) { launch_chain_intra(d_pics, d_groups, n_groups, ctl, err, depth, pub, st); return; }

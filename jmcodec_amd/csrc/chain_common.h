@@ -41,7 +41,8 @@ __device__ __forceinline__ bool wait_expired(int spins, uint32_t &t0) {         
     if (spins == 64) { t0 = now; return false; }
     return now - t0 > kWaitTicks;
 }
-enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16 };
+enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16,
+               CHAIN_ERR_NOT_RECOVERED = 32 };   // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
 
 typedef __attribute__((address_space(1))) int gint;
 

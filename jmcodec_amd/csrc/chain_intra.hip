@@ -18,6 +18,8 @@
 
 namespace jmamd {
 
+int deblock_depth();
+
 constexpr int kChainISmemBytes = kIntraSmemBytes > kDeblockSmemBytes ? (kIntraSmemBytes > (int)sizeof(ReconLds) ? kIntraSmemBytes : (int)sizeof(ReconLds))
                                                                       : (kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds));
 
@@ -42,6 +44,16 @@ __global__ __launch_bounds__(256) __attribute__((flatten)) void k_chain_i(const 
         else if (pp.stages & PS_CHAIN_INTRA) deblock_band_body<DEPTH, true, true>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
         else deblock_band_body<DEPTH, true, false>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
     }
+}
+
+// workgroups of k_chain_i the current device holds at once (occupancy x compute units, as the runtime reports them for THIS device: a compute
+// partition or a smaller part holds fewer than a whole MI355X); 0 when the query fails
+int chain_intra_resident_workgroups() {
+    int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    const bool d2 = deblock_depth() <= 2;
+    if ((d2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<3>, 256, 0)) != hipSuccess) return 0;
+    return per_cu * prop.multiProcessorCount;
 }
 
 void launch_chain_intra(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, int *ctl, int *err, int depth, int pub, hipStream_t st) {

@@ -80,16 +80,21 @@ Decoder::~Decoder() {
 }
 
 void Decoder::fail(const std::string &msg) {            // any thread
-    static std::mutex fm;
-    std::lock_guard<std::mutex> lk(fm);
+    std::lock_guard<std::mutex> lk(error_m_);
     if (!failed_) { error_ = msg; fprintf(stderr, "jm_amd_dec: %s\n", msg.c_str()); }
     failed_ = true;
+}
+// jm_amddec_last_error: the text is copied under the lock into a buffer only the calling thread's calls replace, so the pointer stays valid while
+// parse workers and the engine thread go on reporting
+const char *Decoder::last_error() {
+    std::lock_guard<std::mutex> lk(error_m_);
+    error_out_ = error_;
+    return error_out_.c_str();
 }
 
 // remembers the most recent non-fatal error text for jm_amddec_last_error (any thread)
 void Decoder::note_error(const std::string &msg) {
-    static std::mutex nm;
-    std::lock_guard<std::mutex> lk(nm);
+    std::lock_guard<std::mutex> lk(error_m_);
     if (!failed_) error_ = msg;
 }
 
@@ -454,12 +459,12 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
     if (type == 7 || type == 8) {
         dispatch_pending();
         std::string e = type == 7 ? ps_.parse_sps(br) : ps_.parse_pps(br);
-        if (!e.empty()) { stat_errors_++; error_ = e; }
+        if (!e.empty()) { stat_errors_++; note_error(e); }
         return;
     }
     SliceHeader sh;
     std::string e = ps_.parse_slice_header(br, type, ref_idc, sh);
-    if (!e.empty()) { stat_errors_++; error_ = e; return; }
+    if (!e.empty()) { stat_errors_++; note_error(e); return; }
     const PicParamSet &pps = ps_.pps[sh.pps_id];
     const SeqParams &sps = ps_.sps[pps.sps_id];
     if (pending_ && !same_picture(first_sh_, sh)) dispatch_pending();
@@ -1119,8 +1124,11 @@ int Decoder::output(uint8_t *out, int *out_len) {
         hipSetDevice(device_);
         const auto c0 = std::chrono::steady_clock::now();
         void *dst = out_route_ == 3 && copier_ ? copier_->lock(out, (size_t)need) : nullptr;
-        const bool went = dst && copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_);
+        const HostCopier::Result cr = dst ? copier_->copy(dst, cur_out_->dev, (size_t)need, out_sig_) : HostCopier::kNotSubmitted;
+        // a transfer that is still queued may write into the caller's pages at any time: they stay locked, nothing else touches them, the handle fails
+        if (cr == HostCopier::kStuck) { fail("device: a frame copy into the caller's buffer never completed (device hung?)"); return -1; }
         if (dst) copier_->unlock(out);
+        const bool went = cr == HostCopier::kDone;
         if (went) { stat_direct_++; stat_direct_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count(); }
         else {
             if (engine_) engine_->fetch_begin();

@@ -108,7 +108,7 @@ public:
     void set_eof(bool e) { eof_flag_ = e; }
     bool is_exit() const { return is_exit_; }
     char *info() { return info_; }
-    const char *last_error() const { return error_.c_str(); }
+    const char *last_error();
     int  set_option(const char *key, long long v);
     long long get_stat(const char *key) const;
     void set_device(int d) { device_ = d; }
@@ -166,7 +166,7 @@ private:
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1, out_route_ = 0, fetch_limit_ = 1;
     bool chain_ok_ = false, chain_intra_on_ = true;
     bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
-    std::string error_;
+    std::string error_, error_out_; std::mutex error_m_;     // error_out_: what last_error() last handed out (see there)
     std::atomic<bool> failed_{false}; bool inited_ = false;
 
     // splitter
@@ -219,7 +219,7 @@ private:
     SyntaxDigest digest_;
     bool fast_parse_ = true, want_job_digest_ = false;
     // output route "direct" (host_copy.h)
-    long long stat_direct_ = 0, stat_direct_ns_ = 0;
+    std::atomic<long long> stat_direct_{0}, stat_direct_ns_{0};
     HostCopier *copier_ = nullptr; uint64_t out_sig_ = 0;
     int display_delay_ = 0;                    // a frame goes out only while this many pictures of the handle are still on their way (option "display_delay", JM_AMD_DEC_DISPLAY_DELAY)
     uint64_t job_digest_ = 1469598103934665603ull;    // option "job_digest" (tests)

@@ -62,6 +62,13 @@ Engine::Engine(int device) : device_(device) {
             for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
         }
     }
+    // The no-deadlock argument of a chain launch (chain.hip) needs its band workgroups -- resident for their whole wavefront -- to leave room for the
+    // reconstruction groups they wait for: at most half of what the device holds.  Taken from the device in use (a compute partition, a smaller part
+    // or a build with other register counts holds fewer than the constants assume); launches whose first pictures do not fit run unchained.
+    { const int r = chain_resident_workgroups(false), ri = chain_resident_workgroups(true);
+      if (r > 0) chain_bands_max_ = std::min(kMaxChainBands, r / 2);
+      if (ri > 0) chain_bands_max_intra_ = std::min(kMaxChainBandsIntra, ri / 2);
+      if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_, chain_bands_max_intra_); }
     ok_ = true;
     th_ = std::thread([this] { pthread_setname_np(pthread_self(), "jm-engine"); run(); });
     th_.detach();
@@ -149,7 +156,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + 2 * ((p.mb_h + 15) / 16); };
     int tot_bands = 0, tot_groups = 0; bool any_intra = false;
     for (auto &p : b.pics) if (p.has_picture && (p.chain_ok || p.chain_intra)) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng; any_intra |= p.chain_intra; }
-    auto band_limit = [&](bool intra) { return intra ? kMaxChainBandsIntra : kMaxChainBands; };
+    auto band_limit = [&](bool intra) { return intra ? chain_bands_max_intra_ : chain_bands_max_; };
     if (lane_idx < kPLanes && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) && tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
@@ -354,12 +361,46 @@ void Engine::launch(Lane &ln, Batch &b) {
 }
 
 // A wait inside a chain launch gave up: the launch assumed slots that were not there (another process on the GPU, a long kernel of another stream).  Its
-// pictures -- and those of the lane's next batch, which read them -- are decoded again by the stage kernels, one picture per stream at a time, so what
-// the caller gets is still right; chain launches then pause for a while.  Synchronous and slow on purpose: it should never happen on a GPU the engine owns.
-void Engine::recover(Lane &ln, Batch &b) {
+// pictures -- and those of the lane's next batch, which read them -- are decoded again by the stage kernels, one picture per stream at a time; chain
+// launches then pause for a while.  Synchronous and slow on purpose: it should never happen on a GPU the engine owns.
+//
+// What the redo may NOT do is claim a clean result it cannot deliver.  The lane's next batch has already run when this batch is recovered, and
+// surfaces are reused round robin: if that batch decoded into a surface this batch's pictures reference from OUTSIDE the batch (an older picture), or
+// into one this batch displays, the redo reads / packs the newer picture.  Such a decoder is "tainted": its pictures of this batch and of the next one
+// keep an error (stat errors, jm_amddec_last_error) instead of being passed off as recovered.  Frames the next batch packed BEFORE its kernels
+// (out_before: they show pictures of this batch) are packed again when it is redone, or tainted when their surfaces are gone.
+void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later) {
     const int n = (int)b.pics.size();
     hipStream_t st = ln.stream;
     hipStreamSynchronize(ln.pack_stream); hipStreamSynchronize(st);
+    auto is_tainted = [&](Decoder *d) { return std::find(ln.tainted.begin(), ln.tainted.end(), d) != ln.tainted.end(); };
+    auto taint = [&](Decoder *d) { if (!is_tainted(d)) ln.tainted.push_back(d); };
+    // 1. which decoders can be redone from intact data
+    for (int i = 0; i < n; i++) {
+        Decoder *d = b.pics[i].dec;
+        bool first = true;
+        for (int j = 0; j < i; j++) first &= b.pics[j].dec != d;
+        if (!first) continue;
+        uint32_t written = 0, ext_refs = 0, shown = 0, shown_before = 0, lw = 0;
+        for (int j = i; j < n; j++) {
+            const EnginePic &p = b.pics[j];
+            if (p.dec != d) continue;
+            ext_refs |= p.ref_mask & ~written;                 // references decoded before this batch
+            shown |= p.out_mask;
+            if (!p.out_before.empty()) shown_before |= p.out_mask;
+            if (p.has_picture && p.codec == 0) written |= 1u << p.pp.cur;
+        }
+        for (auto &e : later) if (e.first == d) lw |= e.second;
+        // b.redo: this batch is the "next batch" of a recovered one -- its own first run may have decoded into surfaces its out_before frames show
+        if ((lw & (ext_refs | shown)) || (b.redo && (written & shown_before))) taint(d);
+    }
+    // 2. frames this batch packed before its kernels showed pictures of the recovered batch: again, from the pictures as they are now
+    if (b.redo && b.n_pre) {
+        launch_packout(b.d_jobs, b.n_pre, b.max_w, b.max_h, st);
+        for (auto &p : b.pics) for (OutSlot *o : p.slots_before) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+    }
+    // 3. the pictures again, one per stream at a time
     std::vector<int> depth(n, 0); int max_depth = 0;
     for (int i = 0; i < n; i++) { for (int j = 0; j < i; j++) if (b.pics[j].dec == b.pics[i].dec && b.pics[j].has_picture) depth[i]++; max_depth = std::max(max_depth, depth[i]); }
     for (int d = 0; d <= max_depth; d++) {
@@ -386,6 +427,8 @@ void Engine::recover(Lane &ln, Batch &b) {
         for (auto &p : b.pics) for (OutSlot *o : p.slots_after) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
     }
+    // 4. what could not be redone from intact data stays an error of its handle (complete() reports the words that are set)
+    for (int i = 0; i < n; i++) if (is_tainted(b.pics[i].dec) && !b.h_err[i]) b.h_err[i] = kErrNotRecovered;
     { std::lock_guard<std::mutex> lk(sm_); st_.chain_recoveries++; }
     chain_block_until_ns_ = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() + 30ll * 1000 * 1000 * 1000;
     static bool said = false;
@@ -399,8 +442,13 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         if (wait_err) {
             if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size()); for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n"); }
             // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
-            if (ln.inflight > 1) { Batch &nx = ln.ring[(ln.tail + 1) % kBatchRing]; hipEventSynchronize(nx.done); nx.redo = true; }
-            recover(ln, b);
+            std::vector<std::pair<Decoder *, uint32_t>> later;     // ... and remember which surfaces it decoded into meanwhile (Engine::recover)
+            if (!b.redo) ln.tainted.clear();                       // (a redo batch inherits the tainted set of the batch it followed)
+            if (ln.inflight > 1) {
+                Batch &nx = ln.ring[(ln.tail + 1) % kBatchRing]; hipEventSynchronize(nx.done); nx.redo = true;
+                for (auto &p : nx.pics) if (p.has_picture && p.codec == 0) later.emplace_back(p.dec, 1u << p.pp.cur);
+            }
+            recover(ln, b, later);
         }
     }
     if (profile_ && !failed) {

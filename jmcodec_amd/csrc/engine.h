@@ -34,12 +34,13 @@ struct OutSlot;
 constexpr int kMaxBatch = 64;
 constexpr int kBatchRing = 4;
 constexpr int kMaxChainGroups = 128 * 1024;         // work list of one chain launch (1080p: 1025 groups per picture, 4K: 4059)
-constexpr int kMaxChainBands = 384;                 // band workgroups of one chain launch: half of what an MI355X holds at 3 workgroups per CU (k_chain)
-constexpr int kMaxChainBandsIntra = 256;            // ... at 2 per CU (k_chain_i, the variant with the intra role)
+constexpr int kMaxChainBands = 384;                 // band workgroups of one chain launch, upper bound: half of what a whole MI355X holds at 3 workgroups per CU (k_chain)
+constexpr int kMaxChainBandsIntra = 256;            // ... at 2 per CU (k_chain_i, the variant with the intra role).  The bounds in use come from the device (Engine::Engine)
 constexpr int kPLanes = 2;                          // lanes for ordinary pictures.  The second one is an OPTION (JM_AMD_DEC_LANE_SPLIT=1, Engine::form `split`): with many
                                                     // active streams they are divided between the two lanes by handle parity.  It measured worse in both rounds
                                                     // (round 2, frames/s with / without: 20 streams 12.6 k / 16.0 k, 32 streams 12.5 k / 16.8 k, device-resident
                                                     // output 14.2 k / 20.6 k): two half-size batches take as long as one, and their kernels get in each other's way.
+constexpr int kErrNotRecovered = 32;                // error word set by Engine::recover (chain_common.h CHAIN_ERR_NOT_RECOVERED; the device sets 1..16)
 constexpr int kLanes = kPLanes + 3;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures + one for HEVC I pictures
 constexpr int kHevcLane = kPLanes + 1;
 constexpr int kHevcIntraLane = kPLanes + 2;         // an I picture's CTB-row wavefront (k_hevc_intra, 2-3 ms at 1080p) would hold up every other stream's P / B batch
@@ -124,9 +125,11 @@ private:
         ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // 'packed' events of the two most recently launched batches
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
+        std::vector<Decoder *> tainted;                        // decoders whose recovered pictures could not be redone from intact references (Engine::recover)
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     std::atomic<int> chain_max_streams_{16};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    int chain_bands_max_ = kMaxChainBands, chain_bands_max_intra_ = kMaxChainBandsIntra;   // half of the workgroups THIS device keeps resident (occupancy x compute units)
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::vector<std::pair<Decoder *, long long>> recent_;     // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
     std::atomic<int> lane_split_{0};                          // 1: two ordinary lanes while more streams are active than chain launches are formed for (JM_AMD_DEC_LANE_SPLIT)
@@ -134,7 +137,9 @@ private:
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Lane &ln, Batch &b, bool failed);
-    void recover(Lane &ln, Batch &b);                         // decode a batch's pictures again with the stage kernels (a chain launch's wait gave up)
+    // decode a batch's pictures again with the stage kernels (a chain launch's wait gave up).  `later` = surfaces the lane's NEXT batch, which has
+    // already run, decoded into, per decoder: a redo that would read one of them cannot be right, and is reported instead of passed off as clean
+    void recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later);
 
     int device_;
     ihipStream_t *copy_stream_ = nullptr;

@@ -47,7 +47,7 @@ void Decoder::hevc_handle_nal(const uint8_t *nal, size_t len) {
     if (!is_slice) {
         hevc_dispatch_pending();
         std::string e = type == 33 ? hps_.parse_sps(br) : hps_.parse_pps(br);
-        if (!e.empty()) { stat_errors_++; error_ = e; }
+        if (!e.empty()) { stat_errors_++; note_error(e); }
         return;
     }
     const bool first = (rbsp[0] & 0x80) != 0;
@@ -56,11 +56,11 @@ void Decoder::hevc_handle_nal(const uint8_t *nal, size_t len) {
     if (h_first_picture_ && !(type >= 16 && type <= 21)) return;      // decoding starts at an IRAP picture
     HevcSliceHeader sh;
     std::string e = hps_.parse_slice_header(br, type, sh, (pending_ && h_have_last_sh_) ? &h_last_sh_ : nullptr);
-    if (!e.empty()) { stat_errors_++; error_ = e; return; }
+    if (!e.empty()) { stat_errors_++; note_error(e); return; }
     if (sh.first_in_pic) { if (!hevc_start_picture(sh, type, tid)) return; }
-    else if (!pending_ || !pending_->hevc) { stat_errors_++; error_ = "slice segment of a picture whose first segment is missing"; return; }
+    else if (!pending_ || !pending_->hevc) { stat_errors_++; note_error("slice segment of a picture whose first segment is missing"); return; }
     HevcTask &ht = *pending_->hevc;
-    if (!ht.slices.empty() && sh.pps_id != ht.slices[0].sh.pps_id) { stat_errors_++; error_ = "slices of one picture refer to different PPSs"; return; }
+    if (!ht.slices.empty() && sh.pps_id != ht.slices[0].sh.pps_id) { stat_errors_++; note_error("slices of one picture refer to different PPSs"); return; }
     if (ht.slices.size() >= 600) { stat_errors_++; return; }
     HevcSliceTask st;
     st.sh = sh;

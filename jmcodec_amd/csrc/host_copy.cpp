@@ -103,15 +103,15 @@ void HostCopier::unlock(void *p) { (void)hsa_amd_memory_unlock(p); }
 uint64_t HostCopier::new_signal() { hsa_signal_t s; return hsa_signal_create(1, 0, nullptr, &s) == HSA_STATUS_SUCCESS ? s.handle : 0; }
 void HostCopier::free_signal(uint64_t s) { if (s) (void)hsa_signal_destroy(hsa_signal_t{s}); }
 
-bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
+HostCopier::Result HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
     static std::atomic<unsigned> turn{0};
-    if (!sig) return false;
+    if (!sig) return kNotSubmitted;
     hsa_signal_t s{sig}; hsa_agent_t ca{cpu_}, ga{gpu_};
     hsa_signal_store_relaxed(s, 1);
     const uint32_t e = n_engines_ ? engines_[turn.fetch_add(1, std::memory_order_relaxed) % (unsigned)n_engines_] : 0;
     hsa_status_t st = e ? hsa_amd_memory_async_copy_on_engine(dst, ca, src, ga, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)e, false) : HSA_STATUS_ERROR;
     if (st != HSA_STATUS_SUCCESS) st = hsa_amd_memory_async_copy(dst, ca, src, ga, n, 0, nullptr, s);      // (engine busy / not selectable: the runtime's own choice)
-    if (st != HSA_STATUS_SUCCESS) return false;
+    if (st != HSA_STATUS_SUCCESS) return kNotSubmitted;
     // A failed copy sets the signal negative; a healthy one takes ~60 us plus its place in the engine's queue.  The wait is a sleep-and-look loop on the
     // signal's value (a plain load): hsa_signal_wait spins for ~200 us before it blocks, which is exactly the CPU this route exists to save.
     // this thread's sleeps must end within a couple of microseconds of their time while it waits here (the default timer slack is 50 us: every look
@@ -131,12 +131,16 @@ bool HostCopier::copy(void *dst, const void *src, size_t n, uint64_t sig) {
         const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
         if (v < 1) {
             typical_wait_ns_.store((typical * 7 + total_ns) / 8, std::memory_order_relaxed);      // (approximate on purpose: many threads update it)
-            return v == 0;
+            return v == 0 ? kDone : kFailed;
         }
         long next = total_ns / 4; if (next < 15000) next = 15000; if (next > 250000) next = 250000;
         ts.tv_nsec = next;
     }
-    return false;
+    // Half a minute and the transfer is still queued: the device has hung.  The engine may yet write into the caller's pages, so "give up and let the
+    // caller copy another way" would race with it (and unlocking the pages under a queued transfer is worse).  One more, blocking, wait -- then say so.
+    const hsa_signal_value_t v = hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, 30ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_BLOCKED);
+    if (v < 1) return v == 0 ? kDone : kFailed;
+    return kStuck;
 }
 
 }  // namespace jmamd

@@ -20,8 +20,13 @@ public:
     // page-lock [p, p + n) for the device; returns the address the copy engines use for it, nullptr on failure
     void *lock(void *p, size_t n);
     void  unlock(void *p);
-    // device -> locked host memory, blocking (asleep) until the bytes are there; sig = handle from new_signal(); false on any failure
-    bool  copy(void *locked_dst, const void *dev_src, size_t n, uint64_t sig);
+    // device -> locked host memory, blocking (asleep) until the bytes are there; sig = handle from new_signal().
+    //   kDone          the bytes are in the buffer
+    //   kNotSubmitted  nothing was queued (no signal, the runtime refused): the caller may take another route into the same buffer
+    //   kFailed        the transfer ended with an error (signal below 0): it is OVER, the buffer may be unlocked / written by another route
+    //   kStuck         the transfer was queued and never completed: it may still write into the buffer -- the caller must neither unlock nor reuse it
+    enum Result { kDone = 0, kNotSubmitted = 1, kFailed = 2, kStuck = 3 };
+    Result copy(void *locked_dst, const void *dev_src, size_t n, uint64_t sig);
     uint64_t new_signal();
     uint32_t engine_mask() const { uint32_t m = 0; for (int i = 0; i < n_engines_; i++) m |= engines_[i]; return m; }
     void  free_signal(uint64_t sig);

@@ -25,6 +25,7 @@ bool chain_supported(int mb_w, int mb_h);
 // segment; kind 1: deblocking band `index`), in the order in which the dispatcher shall start them (chain.hip)
 void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st);
 int  chain_band_rows();
+int  chain_resident_workgroups(bool intra);   // workgroups of k_chain / k_chain_i the CURRENT device keeps resident (0: unknown); the engine bounds a launch's bands by half of it
 int  chain_ctl_ints();                                                                         // kChainStride
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);

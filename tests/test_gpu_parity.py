@@ -700,6 +700,31 @@ def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
     assert rec >= 1 and errs == 0
 
 
+@pytest.mark.parametrize("kw", [dict(num_ref=4, frames=48, gop=24), dict(num_ref=3, frames=39, gop=13, bframes=2, cabac=1, poc_type=0), dict(num_ref=1, frames=40, gop=20)])
+def test_recovered_chain_launches_are_never_silently_wrong(oracle, kw):
+    """when a chain launch is recovered, the lane's NEXT batch has already run and may have decoded into surfaces the redo needs (18
+    surfaces round robin, depth-8 chains, several references) or that an IDR / flush displays.  The engine now checks that per decoder: either the redo
+    reads intact data -- then every frame equals the oracle's and no error is reported -- or the handle REPORTS errors for what it could not redo.  What
+    may not happen is a wrong frame with errors == 0."""
+    data = streams.generate(width=352, height=288, seed=0x4D91, mode=1, **kw)
+    want, n, w, h = oracle.decode(data, 1)
+    fs = w * h * 3 // 2
+    lib = api.lib()
+    with api.JmAmdDec(0, 1) as d:
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+        lib.jm_amddec_set_option(d.h, b"debug_stall", 2)
+        before = d.stat("eng_chain_recoveries")
+        try:
+            frames = d.decode_stream(None, chunks=[data])               # one chunk: the parser runs far ahead, chains are as deep as they get
+            errs, rec = d.stat("errors"), d.stat("eng_chain_recoveries") - before
+        finally:
+            lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+    assert len(frames) == n and rec >= 1
+    wrong = [i for i in range(n) if frames[i] != want[i * fs:(i + 1) * fs]]
+    assert not wrong or errs > 0, f"frames {wrong[:8]} differ from the oracle after a recovery and the handle reports no error"
+
+
 # ---- the "direct" output route (host_copy.cpp): whatever the caller does with its buffers, the bytes are the oracle's -----------------------
 def _pull_all(data, w, h, next_buffer, after_frame=None):
     """test_nv_dec's loop with the caller's buffer chosen per frame by next_buffer(i) -> (address, keepalive)."""
