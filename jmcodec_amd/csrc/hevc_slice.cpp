@@ -618,7 +618,15 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
     }
     if (dg_->on) { dg(0x4000 | (cu_skip_ << 8) | (cu_intra_ << 7) | (tq_bypass_ << 6) | (part_mode_ << 3) | log2); dg(x0); dg(y0); }
     bool pcm = false, root_cbf = true;
-    if (cu_skip_) { if (!prediction_unit(x0, y0, n, x0, y0, n, n, 0)) return false; }
+    // a prediction unit that gives up (reference index out of range, data overrun) leaves part of the unit without motion of its own: blank the whole
+    // unit, so that the picture -- which is still submitted, with its error counted -- carries no stale vectors or unchecked reference indices into
+    // the strengths, the collocated field or the motion jobs
+    auto drop_inter_cu = [&]() {
+        HevcMotion none; memset(&none, 0, sizeof none); none.ref[0] = none.ref[1] = -1;
+        for (int r = 0; r < (n >> 2); r++) for (int k = 0; k < (n >> 2); k++) { const int i = i4(x0, y0 + 4 * r) + k; mot_[i] = none; pm_[i] = 2; }
+        return false;
+    };
+    if (cu_skip_) { if (!prediction_unit(x0, y0, n, x0, y0, n, n, 0)) return drop_inter_cu(); }
     else if (cu_intra_) {
         jobs_->n_intra_cu++;
         if (part_mode_ == PART_2Nx2N && sps_->pcm && log2 >= sps_->log2_min_pcm && log2 <= sps_->log2_max_pcm) pcm = cb_.terminate();
@@ -681,7 +689,7 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
         case PART_nRx2N: h[0] = h[1] = n; w[0] = 3 * n / 4; w[1] = n / 4; xs[1] = x0 + 3 * n / 4; ys[1] = y0; break;
         default: np = 4; for (int k = 0; k < 4; k++) { w[k] = h[k] = n / 2; xs[k] = x0 + (k & 1) * n / 2; ys[k] = y0 + (k >> 1) * n / 2; } break;
         }
-        for (int k = 0; k < np; k++) if (!prediction_unit(x0, y0, n, xs[k], ys[k], w[k], h[k], k)) return false;
+        for (int k = 0; k < np; k++) if (!prediction_unit(x0, y0, n, xs[k], ys[k], w[k], h[k], k)) return drop_inter_cu();
     }
     if (cb_.overrun) return false;
     if (!pcm && !cu_skip_) {
