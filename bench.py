@@ -446,6 +446,9 @@ def main():
                       f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle{late_note}; all {S} handles returned {F} frames")
     memtrace("check pass and oracle done")
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
+    job_slot_mb = round(sum(L.jm_amddec_get_stat(h, b"job_slot_bytes") for h in handles) / 1048576.0, 1)      # page-locked job buffers of all handles, as grown
+    job_regrown = int(sum(L.jm_amddec_get_stat(h, b"job_regrown") for h in handles))
+    numa_node = int(L.jm_amddec_get_stat(handles[0], b"numa_node"))
     for i, h in enumerate(handles):
         if L.jm_amddec_get_stat(h, b"errors"):
             print(f"bench.py: rank {rank} stream {stream_ids[i]}: {L.jm_amddec_get_stat(h, b'errors')} decode error(s), last: {L.jm_amddec_last_error(h).decode()!r}", file=sys.stderr)
@@ -590,9 +593,23 @@ def main():
             except (OSError, ValueError):
                 pass
         mem["needed_for_8_gpus_mb"] = round(8 * mem["peak_rss_mb"], 0)
+        mem["job_slots_mb"] = job_slot_mb
+        mem["job_slots_grown"] = job_regrown
+        mem["note"] = "peak_rss_mb includes the Python / torch runtime and the untimed oracle check; job_slots_mb = page-locked job buffers of this rank's handles (grown on demand from ordinary-picture size)"
         line["host_memory"] = mem
     except Exception:
         pass
+    # what bounds this rank's rate: the PCIe link (frames leave at >= 90 % of the measured device->host rate), the host CPU allotment (the process keeps
+    # >= 90 % of its quota busy), or neither -- then the device side (engine lanes / kernels) is what is left
+    q_cpus = hc1.get("quota_cpus") or os.cpu_count()
+    if line["pcie_out"] and line["pcie_out"]["frac"] >= 0.9:
+        bound = "pcie"
+    elif q_cpus and line["host_cpu"]["cpus_busy"] >= 0.9 * q_cpus / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))):
+        bound = "host_cpu_quota"
+    else:
+        bound = "gpu"
+    line["scaling_bound"] = bound
+    line["numa_node"] = numa_node
     if cpu is not None:
         line["cpu_baseline"] = cpu
     if single is not None:

@@ -112,6 +112,7 @@ public:
     int  set_option(const char *key, long long v);
     long long get_stat(const char *key) const;
     void set_device(int d) { device_ = d; }
+    int  numa_node() const { return numa_node_; }   // NUMA node of this handle's GPU (-1: unknown / one-node host): which parse pool it uses
     void api_exception(const char *what) { fail(std::string("exception in the decoder: ") + what); }
     void parse_exception(PicTask *t, const char *what);   // worker-pool: an exception escaped parse_task
 
@@ -155,7 +156,7 @@ private:
     void hevc_bump(std::vector<int> &out, bool all, bool use_fullness);
     void hevc_parse_task(PicTask *t);
     void hevc_fill_engine_pic(PicTask *t, struct EnginePic &ep);
-    bool ensure_job_cap(JobSlot &js, size_t bytes);
+    bool ensure_job_cap(JobSlot &js, size_t bytes, size_t keep = 0);
     void gpu_close();
     void submit_ready();
     void submit_task(PicTask *t);
@@ -184,6 +185,7 @@ private:
     std::unique_ptr<PicTask> pending_;
     SliceHeader first_sh_;
     int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0; long long prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;
+    int numa_node_ = -1;
     long long cur_top_poc_ = 0, cur_bot_poc_ = 0;   // TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0)
     int decode_count_ = 0, max_lt_idx_ = -1;
     uint64_t next_seq_ = 0;
@@ -206,7 +208,9 @@ private:
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
-    int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0;
+    int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
+    std::atomic<size_t> job_hint_{0};           // what the biggest H.264 picture so far needed (+ a quarter): later slots are grown to it before their parse
+    std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;
 
     // status / stats
@@ -236,6 +240,6 @@ private:
 
 // process-wide parse worker pool
 void pool_submit(Decoder *d, PicTask *t);
-int  pool_threads();
+int  pool_threads(int numa_node);
 
 }  // namespace jmamd

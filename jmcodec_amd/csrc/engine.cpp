@@ -3,6 +3,7 @@
 #include "decoder.h"
 #include "kernels.h"
 #include "hevc_kernels.h"
+#include "numa.h"
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <algorithm>
@@ -70,7 +71,8 @@ Engine::Engine(int device) : device_(device) {
       if (ri > 0) chain_bands_max_intra_ = std::min(kMaxChainBandsIntra, ri / 2);
       if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_, chain_bands_max_intra_); }
     ok_ = true;
-    th_ = std::thread([this] { pthread_setname_np(pthread_self(), "jm-engine"); run(); });
+    numa_node_ = numa_node_of_device(device_, true);
+    th_ = std::thread([this] { pthread_setname_np(pthread_self(), "jm-engine"); numa_bind_this_thread(numa_node_); run(); });
     th_.detach();
 }
 

@@ -141,7 +141,7 @@ private:
     // already run, decoded into, per decoder: a redo that would read one of them cannot be right, and is reported instead of passed off as clean
     void recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later);
 
-    int device_;
+    int device_, numa_node_ = -1;
     ihipStream_t *copy_stream_ = nullptr;
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];

@@ -13,13 +13,15 @@
 
 namespace jmamd {
 
-bool Decoder::ensure_job_cap(JobSlot &js, size_t bytes) {
+// keep = bytes at the start of the old host buffer that the new one must hold (0: the contents are rebuilt anyway)
+bool Decoder::ensure_job_cap(JobSlot &js, size_t bytes, size_t keep) {
     if (bytes <= js.cap) return true;
-    size_t cap = bytes + bytes / 2 + 4096;
+    size_t cap = codec_ == 1 ? bytes + bytes / 2 + 4096 : bytes;      // (the H.264 caller chooses its own head room)
     if (parse_only_ || !gpu_open_) { uint8_t *p = (uint8_t *)realloc(js.host, cap); if (!p) return false; js.host = p; js.cap = cap; return true; }
     hipSetDevice(device_);
     uint8_t *h = nullptr, *d = nullptr;
     if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d, cap) != hipSuccess) { if (h) hipHostFree(h); return false; }
+    if (keep && js.host) memcpy(h, js.host, std::min(keep, js.cap));
     // the slot belongs to the picture being parsed: nothing on the device refers to the old buffers any more (see acquire_job_slot)
     if (js.host) hipHostFree(js.host);
     if (js.dev) hipFree(js.dev);

@@ -47,7 +47,12 @@ HostCopier *HostCopier::get(int dev) {
         if ((int)((bdf >> 8) & 0xff) == bus && (int)((bdf >> 3) & 0x1f) == pdev && (int)d == dom) { c = new HostCopier(); c->gpu_ = g.handle; break; }
     }
     if (!c) return nullptr;
-    c->cpu_ = ag.cpus[0].handle;
+    // the CPU agent whose memory the frames land in: the one nearest to this GPU (its NUMA node), not whichever the runtime lists first
+    { hsa_agent_t near{0};
+      if (hsa_agent_get_info(hsa_agent_t{c->gpu_}, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NEAREST_CPU, &near) == HSA_STATUS_SUCCESS && near.handle) {
+          bool known = false; for (hsa_agent_t a : ag.cpus) known |= a.handle == near.handle;
+          c->cpu_ = known ? near.handle : ag.cpus[0].handle;
+      } else c->cpu_ = ag.cpus[0].handle; }
     // Which engines?  An MI355X shows sixteen; measured with one packed 1080p frame each (tools/sdma_probe.cpp): four move 47.6 GB/s over PCIe, the
     // rest serve xGMI and manage 12 GB/s; two or three of the fast ones together fill the link (52.5 / 54.0 GB/s = 16.9 / 17.4 k frames/s).  The engine the HIP
     // runtime itself prefers for host -> device traffic must be left alone (frames queue behind its work: 11.7 k frames/s with it, 16.9 k without).

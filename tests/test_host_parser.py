@@ -353,3 +353,45 @@ def test_display_delay_holds_frames_back_but_loses_none(delay):
         n0 = d0.decode_stream(data, keep=False)
         pocs0 = [d0.stat(f"display_poc:{i}") for i in range(n0)]
     assert n == n0 == 12 and pocs == pocs0
+
+
+@pytest.mark.parametrize("kw", [dict(width=352, height=288, frames=8, gop=4, qp=10, seed=0x4D92, num_ref=2),
+                                dict(width=320, height=240, frames=9, gop=9, qp=12, seed=0x4D93, cabac=1, t8x8=1, bframes=2, poc_type=0, wp=1, mode=1)])
+def test_job_slots_grow_on_demand_and_build_the_same_job_lists(kw, monkeypatch):
+    """Job slots start at what an ordinary picture needs and grow when a picture does not fit (it is parsed again into a bigger slot; motion records and
+    weight tables that do not fit behind the levels move the slot's contents): low-QP streams outgrow the starting size several times over.  The job
+    lists the device would get -- and the syntax digest, which must not see the abandoned attempts -- equal those of worst-case slots."""
+    data = streams.generate(**kw)
+
+    def run():
+        with api.JmAmdDec(0, 1, options={"parse_only": 1, "job_digest": 1, "digest": 1}) as d:
+            n = len(d.decode_stream(data))
+            return (d.stat("job_digest") & (2 ** 64 - 1), d.stat("syntax_digest") & (2 ** 64 - 1), n, d.stat("errors"), d.stat("job_bytes")), d.stat("job_regrown"), d.stat("job_slot_bytes")
+    small, regrown, slot_bytes = run()
+    monkeypatch.setenv("JM_AMD_DEC_JOB_WORST_CASE", "1")
+    worst, regrown_w, slot_bytes_w = run()
+    assert small == worst and small[3] == 0 and small[2] == kw["frames"]
+    assert regrown >= 1 and regrown_w == 0
+    assert slot_bytes < slot_bytes_w
+
+
+def test_parse_pools_per_numa_node_in_the_many_gpus_one_process_mode(oracle, monkeypatch):
+    """The drop-in mode 'one process, handles round robin over every GPU': handles of GPUs on different NUMA nodes use different parse pools (workers on the
+    node's CPUs, page-locked job buffers from its memory).  No GPU here: JM_AMD_DEC_FAKE_NUMA places two parse-only 'devices' on two nodes; both handles
+    decode concurrently through their own pool and build the oracle's syntax."""
+    import threading
+    monkeypatch.setenv("JM_AMD_DEC_FAKE_NUMA", "0:0,1:1")
+    monkeypatch.delenv("JM_AMD_DEC_DEVICE", raising=False)
+    data = streams.generate(width=176, height=144, frames=12, gop=6, mode=1, num_ref=2, seed=0x4D94, cabac=1)
+    want = oracle.syntax_digest(data)
+    got = {}
+
+    def run(dev):
+        with api.JmAmdDec(0, 1, options={"device": dev, "parse_only": 1, "digest": 1}) as d:
+            n = len(d.decode_stream(data))
+            got[dev] = (d.stat("syntax_digest") & (2 ** 64 - 1), d.stat("digest_mbs"), n, d.stat("errors"), d.stat("numa_node"), d.stat("threads"))
+    ts = [threading.Thread(target=run, args=(dev,)) for dev in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for dev in (0, 1):
+        assert got[dev][:4] == (want[0], want[1], 12, 0) and got[dev][4] == dev and got[dev][5] >= 1
