@@ -54,6 +54,7 @@ bool chain_supported(int, int) { return true; }
 int chain_ctl_ints() { return 1; }
 void launch_chain(const PicParams *, const uint32_t *, int, bool, int *, int *, bool, ihipStream_t *) { abort(); }
 int chain_band_rows() { return 16; }
+int chain_resident_workgroups(bool) { return 0; }
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 }
 namespace jmamd { void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); }
