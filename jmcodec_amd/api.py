@@ -13,7 +13,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libjm_amd_dec.so")
+    # JM_AMD_DEC_LIB: developer aid (timing experiments with alternative builds of the library); the product is lib/libjm_amd_dec.so
+    return os.environ.get("JM_AMD_DEC_LIB") or os.path.join(_HERE, "lib", "libjm_amd_dec.so")
 
 
 def build(force=False):

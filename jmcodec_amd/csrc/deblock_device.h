@@ -8,6 +8,9 @@
 #include "kernel_common.h"
 #include "chain_common.h"
 
+#ifndef JM_DBG_DEBLOCK
+#define JM_DBG_DEBLOCK 0          // timing experiments only (scratch/gpu_dbg_deblock.sh); results are wrong when set
+#endif
 namespace jmamd {
 
 struct DbRec {                 // 96 bytes per macroblock: 48 for the luma workgroup, 48 for the chroma workgroup
@@ -29,30 +32,56 @@ static_assert(sizeof(DbRec) == 96, "DbRec must be 96 bytes");
 // |a - b| of two samples (0..255, upper bytes zero): one v_sad_u8 instead of sub / neg / max
 __device__ __forceinline__ int adiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
 __device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }      // operands are evaluated by the caller: a v_cndmask, never a branch
-__device__ __forceinline__ void flt_luma(int *s, int bsw, int alpha, int beta) {
+// ---- the luma edge filter on PACKED 16-bit pairs (round 3) ----
+// One 32-bit register holds the sample i of the p side in its low half and the sample i of the q side in its high half: A = (p0 | q0 << 16),
+// B = (p1 | q1), C = (p2 | q2), D = (p3 | q3).  The two sides of 8.7.2.3 / 8.7.2.4 are mirror images, so every side-wise quantity (|p1 - p0| and
+// |q1 - q0|, ap and aq, p1' and q1', the strong filter's three outputs per side) is ONE v_pk_* instruction instead of two scalar ones, conditions
+// become masks ((x - limit) >> 15 per half) and selects become bitwise blends: ~60 vector instructions for the normal filter where the scalar
+// form needed ~100, and no int <-> bool conversions.  Same arithmetic, value for value (tests: every deblocking case against the oracle).
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ uint32_t as_u(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 splat(int v) { return as_s2((uint32_t)v | ((uint32_t)v << 16)); }      // 0 <= v < 65536
+__device__ __forceinline__ s2 swp(s2 v) { const uint32_t u = as_u(v); return as_s2(__builtin_amdgcn_alignbit(u, u, 16)); }
+__device__ __forceinline__ s2 pabs(s2 v) { return __builtin_elementwise_max(v, -v); }
+__device__ __forceinline__ s2 pmin(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 blend(uint32_t m, s2 a, s2 b) { return as_s2((as_u(a) & m) | (as_u(b) & ~m)); }      // m: all ones / all zeros per half
+// v_perm_b32: byte k of the result = byte sel[k] of {hi, lo} (0..3 = lo, 4..7 = hi, 0x0c = zero)
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// A, B, C are updated in place (D = p3 | q3 is only read); bsw = bS | tC0 << 3
+__device__ __forceinline__ void flt_luma(s2 &A, s2 &B, s2 &C, const s2 D, int bsw, int alpha, int beta) {
+    if (JM_DBG_DEBLOCK & 64) return;
     const int bS = bsw & 7, tc0 = bsw >> 3;
-    const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
-    const bool on = ((int)(bS != 0) & (int)(adiff(p0, q0) < alpha) & (int)(adiff(p1, p0) < beta) & (int)(adiff(q1, q0) < beta)) != 0;
-    if (!__builtin_amdgcn_ballot_w64(on)) return;
-    const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
-    const int tc = tc0 + (int)ap + (int)aq;
-    const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-    const int avg = (p0 + q0 + 1) >> 1;
-    const bool nrm = ((int)on & (int)(bS < 4)) != 0;
-    const int n_p0 = clip1(p0 + delta), n_q0 = clip1(q0 - delta);
-    const int n_p1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1), n_q1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
-    int r_p0 = sel(nrm, n_p0, p0), r_q0 = sel(nrm, n_q0, q0), r_p1 = sel(((int)nrm & (int)ap) != 0, n_p1, p1), r_q1 = sel(((int)nrm & (int)aq) != 0, n_q1, q1), r_p2 = p2, r_q2 = q2;
-    const bool st = ((int)on & (int)(bS >= 4)) != 0;
-    if (__builtin_amdgcn_ballot_w64(st)) {
-        const bool strong = adiff(p0, q0) < ((alpha >> 2) + 2);
-        const bool sp = ((int)st & (int)ap & (int)strong) != 0, sq = ((int)st & (int)aq & (int)strong) != 0;
-        const int w_p0 = (2 * p1 + p0 + q1 + 2) >> 2, w_q0 = (2 * q1 + q0 + p1 + 2) >> 2;
-        const int s_p0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2, s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-        const int s_q0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2, s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-        r_p0 = sel(sp, s_p0, sel(st, w_p0, r_p0)); r_p1 = sel(sp, s_p1, r_p1); r_p2 = sel(sp, s_p2, r_p2);
-        r_q0 = sel(sq, s_q0, sel(st, w_q0, r_q0)); r_q1 = sel(sq, s_q1, r_q1); r_q2 = sel(sq, s_q2, r_q2);
+    const s2 As = swp(A), Bs = swp(B);
+    const s2 beta2 = splat(beta);
+    const s2 d10 = pabs(B - A), dpq = pabs(As - A);                       // (|p1 - p0| , |q1 - q0|), |p0 - q0| in both halves
+    const s2 m10 = (d10 - beta2) >> 15, mpq = (dpq - splat(alpha)) >> 15;
+    const uint32_t on = as_u(m10) & as_u(swp(m10)) & as_u(mpq) & (bS ? 0xffffffffu : 0u);      // filterSamplesFlag, the same in both halves
+    if (!__builtin_amdgcn_ballot_w64(on != 0)) return;
+    const s2 m20 = (pabs(C - A) - beta2) >> 15;                           // (ap , aq) as masks
+    const int tc = tc0 + (int)(as_u(m20) & 1u) + (int)(as_u(m20) >> 31);
+    const s2 t = ((As - A) << 2) + (B - Bs) + splat(4);                    // low half: ((q0 - p0) << 2) + (p1 - q1) + 4
+    const int dl = clip3(-tc, tc, (int)(short)(as_u(t) & 0xffffu) >> 3);
+    const s2 dd = as_s2(((uint32_t)dl & 0xffffu) | ((uint32_t)(-dl) << 16));       // (+delta , -delta)
+    const s2 nA = pmin(pmax(A + dd, splat(0)), splat(255));
+    const s2 avg = as_s2((as_u(A + As + splat(1)) >> 1) & 0x7fff7fffu);     // (p0 + q0 + 1) >> 1 in both halves
+    const s2 tcs = splat(tc0);
+    const s2 tt = pmin(pmax((C + avg - (B << 1)) >> 1, -tcs), tcs);
+    const s2 nB = B + as_s2(as_u(tt) & as_u(m20));                        // p1' only with ap, q1' only with aq
+    const uint32_t nrm = on & (bS < 4 ? 0xffffffffu : 0u);
+    s2 rA = blend(nrm, nA, A), rB = blend(nrm, nB, B), rC = C;
+    const uint32_t st = on & (bS >= 4 ? 0xffffffffu : 0u);
+    if (__builtin_amdgcn_ballot_w64(st != 0)) {
+        const s2 msg = (dpq - splat((alpha >> 2) + 2)) >> 15;
+        const uint32_t sm = st & as_u(m20) & as_u(msg);                    // the strong filter, per side
+        const s2 S0 = (C + ((B + A + As) << 1) + Bs + splat(4)) >> 3;
+        const s2 S1 = (C + B + A + As + splat(2)) >> 2;
+        const s2 S2 = ((D << 1) + C + (C << 1) + B + A + As + splat(4)) >> 3;
+        const s2 W0 = ((B << 1) + A + Bs + splat(2)) >> 2;
+        rA = blend(sm, S0, blend(st, W0, rA)); rB = blend(sm, S1, rB); rC = blend(sm, S2, rC);
     }
-    s[1] = r_p2; s[2] = r_p1; s[3] = r_p0; s[4] = r_q0; s[5] = r_q1; s[6] = r_q2;
+    A = rA; B = rB; C = rC;
 }
 // chroma: p1 p0 q0 q1 by reference
 __device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int bsw, int alpha, int beta) {
@@ -63,7 +92,6 @@ __device__ __forceinline__ void flt_chroma(int p1, int &p0, int &q0, int q1, int
     p0 = sel(on, sel(bS < 4, n_p0, w_p0), p0); q0 = sel(on, sel(bS < 4, n_q0, w_q0), q0);
 }
 
-__device__ __forceinline__ uint32_t pack4(const int *v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
 
 // LDS layout (dynamic): per macroblock row
 //   lumaTile  [2][16][16]   = 512 B        chromaTile [2][8][16] = 256 B
@@ -125,34 +153,59 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
     for (int i = 0; i < 6; i++) ab[i] = rec[32 + i];
     // ---- vertical edges: lane = pixel row l ----
     uint32_t left = x > 0 ? *(const uint32_t *)(tp + l * 16 + 12) : 0;
-    int p[20];
-    { uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
+    // The row's 20 samples x[-4 .. 15] arrive as five dwords.  Edge e pairs x[4e - 1 - i] with x[4e + i]: one v_perm_b32 per pair -- the p side of
+    // edge 0 from the left neighbour's dword, that of a later edge from the HIGH halves the previous edge left behind (its q side, filtered).
+    uint32_t left_after, row_after[4];
+    {
+        const uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
+        s2 A = as_s2(perm(w[1], w[0], 0x0c040c03)), B = as_s2(perm(w[1], w[0], 0x0c050c02)), C = as_s2(perm(w[1], w[0], 0x0c060c01)), D = as_s2(perm(w[1], w[0], 0x0c070c00));
 #pragma unroll
-      for (int i = 0; i < 20; i++) p[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255; }
-#pragma unroll
-    for (int e = 0; e < 4; e++) { const int c = e ? 1 : 0; flt_luma(p + 4 * e, vb[e], ab[2 * c], ab[2 * c + 1]); }
-    uint32_t left_after = pack4(p);
+        for (int e = 0; e < 4; e++) {
+            if (e) {
+                const s2 pA = A, pB = B, pC = C, pD = D;
+                A = as_s2(perm(w[e + 1], as_u(pD), 0x0c040c02)); B = as_s2(perm(w[e + 1], as_u(pC), 0x0c050c02));
+                C = as_s2(perm(w[e + 1], as_u(pB), 0x0c060c02)); D = as_s2(perm(w[e + 1], as_u(pA), 0x0c070c02));
+            }
+            const int c = e ? 1 : 0;
+            flt_luma(A, B, C, D, vb[e], ab[2 * c], ab[2 * c + 1]);
+            // x[4e - 4 .. 4e - 1] are final for this pass: the low halves of D, C, B, A
+            const uint32_t o = perm(as_u(C), as_u(D), 0x0c0c0400) | perm(as_u(A), as_u(B), 0x04000c0c);
+            if (e == 0) left_after = o; else row_after[e - 1] = o;
+        }
+        row_after[3] = perm(as_u(B), as_u(A), 0x0c0c0602) | perm(as_u(D), as_u(C), 0x06020c0c);      // x[12 .. 15]: the high halves of edge 3
+    }
     if (x > 0) *(uint32_t *)(tp + l * 16 + 12) = left_after;
-    *(uint4 *)(tc + l * 16) = make_uint4(pack4(p + 4), pack4(p + 8), pack4(p + 12), pack4(p + 16));
+    *(uint4 *)(tc + l * 16) = make_uint4(row_after[0], row_after[1], row_after[2], row_after[3]);
     // the left neighbour's bottom rows (its ring slot) get our edge-0 result for columns 12..15
     if (x > 0 && l >= 12) *(uint32_t *)(ring_dn_l + (l - 12) * 16 + 12) = left_after;
     // ---- horizontal edges: lane = pixel column l ----
-    int c[20];
+    {
+        uint32_t c[20];
+        c[0] = c[1] = c[2] = c[3] = 0;
+        if (ring_up) { c[0] = ring_up[l]; c[1] = ring_up[16 + l]; c[2] = ring_up[32 + l]; c[3] = ring_up[48 + l]; }      // (one region, not four)
 #pragma unroll
-    for (int j = 0; j < 4; j++) c[j] = ring_up ? ring_up[j * 16 + l] : 0;
+        for (int j = 0; j < 16; j++) c[4 + j] = tc[j * 16 + l];
+        s2 A = as_s2(c[3] | (c[4] << 16)), B = as_s2(c[2] | (c[5] << 16)), C = as_s2(c[1] | (c[6] << 16)), D = as_s2(c[0] | (c[7] << 16));
 #pragma unroll
-    for (int j = 0; j < 16; j++) c[4 + j] = tc[j * 16 + l];
-#pragma unroll
-    for (int e = 0; e < 4; e++) { const int k = e ? 1 : 2; flt_luma(c + 4 * e, hb[e], ab[2 * k], ab[2 * k + 1]); }
-    if (ring_up) {
-#pragma unroll
-        for (int j = 1; j < 4; j++) ring_up[j * 16 + l] = (uint8_t)c[j];
+        for (int e = 0; e < 4; e++) {
+            if (e) {
+                const s2 pA = A, pB = B, pC = C, pD = D;
+                A = as_s2(perm(c[4 * e + 4], as_u(pD), 0x0c040c02)); B = as_s2(perm(c[4 * e + 5], as_u(pC), 0x0c040c02));
+                C = as_s2(perm(c[4 * e + 6], as_u(pB), 0x0c040c02)); D = as_s2(perm(c[4 * e + 7], as_u(pA), 0x0c040c02));
+            }
+            const int k = e ? 1 : 2;
+            flt_luma(A, B, C, D, hb[e], ab[2 * k], ab[2 * k + 1]);
+            // rows 4e - 4 .. 4e - 1 of the column are final: the low halves of D, C, B, A (row 4e - 4 = p3 is never changed by this edge)
+            if (e == 0) { if (ring_up) { ring_up[1 * 16 + l] = (uint8_t)as_u(C); ring_up[2 * 16 + l] = (uint8_t)as_u(B); ring_up[3 * 16 + l] = (uint8_t)as_u(A); } }
+            else { const int r = 4 * e - 4; tc[r * 16 + l] = (uint8_t)as_u(D); tc[(r + 1) * 16 + l] = (uint8_t)as_u(C); tc[(r + 2) * 16 + l] = (uint8_t)as_u(B); tc[(r + 3) * 16 + l] = (uint8_t)as_u(A); }
+        }
+        // rows 12 .. 15: the high halves of edge 3 -- into the tile and, as the rows the macroblock below starts from, into this row's ring slot
+        const uint8_t r12 = (uint8_t)(as_u(A) >> 16), r13 = (uint8_t)(as_u(B) >> 16), r14 = (uint8_t)(as_u(C) >> 16), r15 = (uint8_t)(as_u(D) >> 16);
+        tc[12 * 16 + l] = r12; tc[13 * 16 + l] = r13; tc[14 * 16 + l] = r14; tc[15 * 16 + l] = r15;
+        ring_dn[0 * 16 + l] = r12; ring_dn[1 * 16 + l] = r13; ring_dn[2 * 16 + l] = r14; ring_dn[3 * 16 + l] = r15;
     }
-#pragma unroll
-    for (int j = 0; j < 12; j++) tc[j * 16 + l] = (uint8_t)c[4 + j];
-#pragma unroll
-    for (int j = 12; j < 16; j++) { tc[j * 16 + l] = (uint8_t)c[4 + j]; ring_dn[(j - 12) * 16 + l] = (uint8_t)c[4 + j]; }
     // ---- store the final (-4,-4)-shifted 16x16 block: lane -> row R = l - 4 ----
+    if (JM_DBG_DEBLOCK & 32) return;
     gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 16, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
@@ -192,26 +245,25 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
     if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte chroma half of the DbRec
     // ---- vertical edges (chroma columns 0 and 4 <-> luma edges 0 and 2): lane = (plane, chroma row) ----
     {
-        int plane = l >> 3, r = l & 7;
+        const int plane = l >> 3, r = l & 7;
         // `own` of lane l is row (l & 7) of the macroblock (both lane halves prefetch the same 16 bytes)
-        uint32_t left = x > 0 ? *(const uint32_t *)(tp + r * 16 + 12) : 0;
+        const uint32_t left = x > 0 ? *(const uint32_t *)(tp + r * 16 + 12) : 0;
         if (plane == 0) *(uint4 *)(tc + r * 16) = own;
-        uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
-        int b[20];
-#pragma unroll
-        for (int i = 0; i < 20; i++) b[i] = (w[i >> 2] >> ((i & 3) * 8)) & 255;
-        int vb[2] = { rec[plane * 16 + (r >> 1)], rec[plane * 16 + 4 + (r >> 1)] };
-        int ab[4] = { rec[32 + plane * 6], rec[32 + plane * 6 + 1], rec[32 + plane * 6 + 2], rec[32 + plane * 6 + 3] };
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            const int k = e ? 1 : 0;
-            int o = 4 * e + plane;                                        // p1 = b[o], p0 = b[o+2], q0 = b[o+4], q1 = b[o+6]
-            int p0 = b[o + 2], q0 = b[o + 4];
-            flt_chroma(b[o], p0, q0, b[o + 6], vb[e >> 1], ab[2 * k], ab[2 * k + 1]);
-            if (vb[e >> 1] & 7) {
-                if (e == 0) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
-                else { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
-            }
+        // Cb and Cr bytes alternate: sample k of this lane's plane in a dword is byte 2k + plane -- taken with a shift by 8 * plane.  (Indexing an
+        // unpacked register array with the run-time `plane` made the compiler build every access as a chain of twenty compares and selects:
+        // about a thousand instructions per step, three quarters of this workgroup's code.)
+        const int s0 = plane * 8, s1 = s0 + 16;
+        const int vb[2] = { rec[plane * 16 + (r >> 1)], rec[plane * 16 + 4 + (r >> 1)] };
+        const int ab[4] = { rec[32 + plane * 6], rec[32 + plane * 6 + 1], rec[32 + plane * 6 + 2], rec[32 + plane * 6 + 3] };
+        {   // edge 0: p1 p0 | q0 q1 = left dword samples 0, 1 | own.x samples 0, 1
+            int p0 = (int)(left >> s1) & 255, q0 = (int)(own.x >> s0) & 255;
+            flt_chroma((int)(left >> s0) & 255, p0, q0, (int)(own.x >> s1) & 255, vb[0], ab[0], ab[1]);
+            if (vb[0] & 7) { tp[r * 16 + 14 + plane] = (uint8_t)p0; tc[r * 16 + plane] = (uint8_t)q0; }
+        }
+        {   // edge 2 (chroma column 4): own.y samples 0, 1 | own.z samples 0, 1
+            int p0 = (int)(own.y >> s1) & 255, q0 = (int)(own.z >> s0) & 255;
+            flt_chroma((int)(own.y >> s0) & 255, p0, q0, (int)(own.z >> s1) & 255, vb[1], ab[2], ab[3]);
+            if (vb[1] & 7) { tc[r * 16 + 6 + plane] = (uint8_t)p0; tc[r * 16 + 8 + plane] = (uint8_t)q0; }
         }
     }
     // left neighbour's bottom rows: columns 12..15 (bytes) of rows 6, 7 after our edge 0
@@ -236,6 +288,7 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
         ring_dn[l] = (uint8_t)c[8]; ring_dn[16 + l] = (uint8_t)c[9];
     }
     // ---- store the (-2 px, -2 rows)-shifted 8 x 16-byte block: lanes 0..7 -> row R = l - 2 ----
+    if (JM_DBG_DEBLOCK & 32) return;
     gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 8, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
@@ -271,7 +324,32 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
 //     cover the step it is about to prefetch for, so in steady state it runs a few steps behind without waiting.
 // Workgroups of a lower band have the higher block index, so whatever a workgroup waits for has been dispatched before it.
 constexpr int kBandRows = 16;
-constexpr int kDeblockSmemBytes = kBandRows * Lds::kRecStride + (kBandRows + 1) * (Lds::kLT + Lds::kLR);
+constexpr int kDeblockSmemMain = kBandRows * Lds::kRecStride + (kBandRows + 1) * (Lds::kLT + Lds::kLR);
+// Per wave and prefetch stage, the inputs of one step as the LDS-DMA loads deliver them (lane-linear): 64 x 16 B of samples, 64 x 4 B of DbRec
+// dwords, 64 x 4 B of ring-row dwords from the band above.
+constexpr int kStageBytes = 1024 + 256 + 256, kDeblockMaxDepth = 4;
+constexpr int kDeblockSmemBytes = kDeblockSmemMain + (kBandRows / 4) * kDeblockMaxDepth * kStageBytes;
+
+// ---- LDS-DMA loads issued from inline assembly (round 3) ----
+// What bounded a step of this kernel was not its arithmetic (switching the filters off changed nothing) but the memory waits hipcc places: with the
+// step's conditional stores between a prefetch and its use it cannot count the operations in flight, so every step began with s_waitcnt vmcnt(0 / 1)
+// -- a full round trip to memory for the stores issued a moment ago -- and the per-step barrier handed the slowest wave's wait to all four
+// (profiles/README.md: 2.7 us per step; the same pipeline with counted waits: 0.64 us in scratch/exp/glds_probe.hip).  A load that writes LDS directly
+// has no register destination the compiler could touch early, so it can be issued from inline assembly, invisible to hipcc's bookkeeping, and
+// retired by a COUNTED s_waitcnt of our own: the operations of a wave retire in order, and between a stage's loads and their use every wave issues
+// at least the loads of the younger stages, whatever it stores in between.  M0 (the LDS destination base) is saved and restored around the load
+// (cdna_hip_programming.md, inline assembly, LDS-DMA recipe).  The destination is wave-uniform base + lane x size.
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
+template <bool COHERENT> __device__ __forceinline__ void glds16(const gbyte *g, uint32_t lds_byte_addr) {
+    unsigned keep;
+    if (COHERENT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+}
+template <bool COHERENT> __device__ __forceinline__ void glds4(const gbyte *g, uint32_t lds_byte_addr) {
+    unsigned keep;
+    if (COHERENT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+}
 // One 256-thread workgroup deblocks band `band` of one plane of picture pp.  prog = the picture's band step counters of the ring-row hand-over
 // (kDeblockProgressStride ints).  CHAIN (k_chain): `cpic` = the picture's block of the chain buffer; the unfiltered samples come from
 // reconstruction waves of the same launch (wait for their bits, read with cache-bypassing loads), the final samples are written through
@@ -282,6 +360,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
     const int row0 = band * kBandRows;
     if (row0 >= mb_h) return;
+    if ((JM_DBG_DEBLOCK & 1) && is_chroma) return;
+    if ((JM_DBG_DEBLOCK & 2) && !is_chroma) return;
     const int rows = min(kBandRows, mb_h - row0);
     int *prog = prog_pic + (is_chroma ? kDeblockMaxBands : 0);
     const gbyte *recs = (const gbyte *)pp.dbrec;
@@ -305,6 +385,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
     auto wait_above = [&](int need) {
+        if (JM_DBG_DEBLOCK & 16) return;
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
         int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
@@ -338,20 +419,18 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const gbyte *pix_base = plane + (size_t)(row * rows_per_mb + my_row) * pitch;
     const gbyte *rec_base = recs + (size_t)row * mb_w * sizeof(DbRec) + rec_dw * 4;
     const gbyte *ring_base = plane + (size_t)(takes_ring ? row * rows_per_mb - ring_rows + (ring_lane >> 2) : 0) * pitch + (ring_lane & 3) * 4;
-    // The loads of a stage are unconditional (clamped coordinates) so that the number of memory operations between a load and its use is
-    // known at compile time: the wait in front of a step is then "all but the younger stages", not "everything".
-    uint4 pre_pix[DEPTH]; uint32_t pre_rec[DEPTH], pre_ring[DEPTH];
+    // The loads of a stage are unconditional (clamped coordinates; band 0 "loads" ring dwords it never uses): every wave issues exactly three
+    // LDS-DMA loads per step, which is what makes the counted waits below exact enough.
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wl = (int)(threadIdx.x & 63);
+    uint8_t *stage = smem + kDeblockSmemMain + wave * (kDeblockMaxDepth * kStageBytes);
+    const uint32_t stage_lds = lds_addr_of(stage);
     auto fetch = [&](int d, int s) {
         int xn = min(max(s - 2 * row, 0), mb_w - 1);
-        if (CHAIN) {
-            wait_recon(s - 2 * row);            // (steps outside the row load a clamped position whose data is never used: nothing to wait for)
-            const JM_GLOBAL uint64_t *q = (const JM_GLOBAL uint64_t *)(pix_base + xn * 16);
-            const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pre_pix[d] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-        } else
-        pre_pix[d] = gload<uint4>(pix_base + xn * 16);
-        pre_rec[d] = gload<uint32_t>(rec_base + (size_t)xn * sizeof(DbRec));
-        if (band > 0) pre_ring[d] = __hip_atomic_load((const JM_GLOBAL uint32_t *)(ring_base + xn * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CHAIN) wait_recon(s - 2 * row);     // (steps outside the row load a clamped position whose data is never used: nothing to wait for)
+        const uint32_t slot = stage_lds + (uint32_t)d * kStageBytes;
+        glds16<CHAIN>(pix_base + xn * 16, slot);                                        // CHAIN: reconstructed in this launch -> coherent load
+        glds4<false>(rec_base + (size_t)xn * sizeof(DbRec), slot + 1024);
+        glds4<true>(band > 0 ? ring_base + xn * 16 : rec_base, slot + 1280);
     };
     // ring rows of macroblock xm of this band's last row -> surface (write-through)
     auto give = [&](const uint8_t *ring, int xm, int lane0) {
@@ -366,45 +445,55 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             if (is_chroma) {
                 if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
                 chroma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring) {
+                if (gives_ring && !(JM_DBG_DEBLOCK & 8)) {
                     if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
                     if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
                 }
             } else {
                 if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
                 luma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring) {
+                if (gives_ring && !(JM_DBG_DEBLOCK & 8)) {
                     if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
                     if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
                 }
             }
         }
-        // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough
-        if (gives_ring && pub > 0 && ((s + 1 - s_begin) % pub == 0 || s == s_end)) {        // pub <= 0: debug option "debug_stall" -- the counter never advances
+        // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough -- and not by draining
+        // the wave: it has issued the three loads of each of the last kPubLag steps since the ring stores of step s - kPubLag (the loads of a step go
+        // out before its stores), operations retire in order, so "at most 3 * kPubLag outstanding" proves those stores acknowledged.  The band below
+        // sees the counter kPubLag steps late; it runs some thirty steps behind anyway.
+        constexpr int kPubLag = 3;
+        if (!(JM_DBG_DEBLOCK & 8) && gives_ring && pub > 0 && s - kPubLag >= s_begin && ((s - kPubLag + 1 - s_begin) % pub == 0)) {      // pub <= 0: debug option "debug_stall" -- the counter never advances
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPubLag) : "memory");
+            if (l == 0) __hip_atomic_store(&prog[band], s - kPubLag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (gives_ring && pub > 0 && s == s_end) {                                           // the band's last step: everything, then "done"
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (l == 0) __hip_atomic_store(&prog[band], s == s_end ? 0x7fffffff : s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0) __hip_atomic_store(&prog[band], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (CHAIN) {
-            // `fin`: steps whose final samples are in memory, published two steps late.  Every wave has issued at least four memory
-            // operations since its stores of step s - 2 (the prefetches of two steps), and a wave's operations retire in order, so "at most four
-            // outstanding" means those stores have been acknowledged -- without draining the prefetches that were just issued.
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // `fin`: how many steps have their final samples in memory, published two steps late by the same counting argument: every wave has issued
+            // the six loads of the steps s - 1 and s since its stores of step s - 2.
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        { if (JM_DBG_DEBLOCK & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
     };
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) pre_ring[d] = 0;
+    static_assert(DEPTH >= 2 && DEPTH <= kDeblockMaxDepth, "prefetch depth");
     wait_above(s_begin + DEPTH);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, s_begin + d);
-    // stage j of the unrolled body always lives in the same registers: no copies of registers that still wait for their load
     for (int s = s_begin; s <= s_end; s += DEPTH) {
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             if (s + j > s_end) break;
-            uint4 own = pre_pix[j]; uint32_t rdw = pre_rec[j], ring = pre_ring[j];
-            asm volatile("" : "+v"(own.x), "+v"(own.y), "+v"(own.z), "+v"(own.w), "+v"(rdw), "+v"(ring));
+            // the loads of this stage were issued DEPTH steps ago; since then the wave has issued at least the 3 * (DEPTH - 1) loads of the younger
+            // stages (plus whatever it stored): in-order retirement makes "at most that many outstanding" sufficient
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (DEPTH - 1)) : "memory");
+            const uint8_t *sl = stage + j * kStageBytes;
+            const uint4 own = *(const uint4 *)(sl + wl * 16);
+            const uint32_t rdw = *(const uint32_t *)(sl + 1024 + wl * 4), ring = *(const uint32_t *)(sl + 1280 + wl * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is read before its next load is even issued
             wait_above(s + j + DEPTH);                // the ring rows of step s + j + DEPTH are final once the band above completed the step before it
             fetch(j, s + j + DEPTH);
             step(s + j, own, rdw, ring);

@@ -138,7 +138,7 @@ private:
     void flush_dpb(std::vector<int> &out);
     void push_task(std::unique_ptr<PicTask> t);
     bool activate(const SeqParams &sps);
-    int  acquire_job_slot();
+    int  acquire_job_slot(bool big = false);
     int  pop_output(bool block);
     void fail(const std::string &msg);
     void note_error(const std::string &msg);
@@ -209,7 +209,7 @@ private:
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
-    std::atomic<size_t> job_hint_{0};           // what the biggest H.264 picture so far needed (+ a quarter): later slots are grown to it before their parse
+    std::atomic<size_t> job_hint_{0}, job_hint_i_{0};   // (job_hint_i_: the same for I pictures)           // what the biggest H.264 picture so far needed (+ a quarter): later slots are grown to it before their parse
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;
 
