@@ -291,19 +291,26 @@ bool Decoder::gpu_open() {
     return true;
 }
 
+// job slots and the big buffers they borrow: device build (page-locked + device copies) or parse-only build (plain memory).  Nothing is in flight.
+void Decoder::free_job_buffers() {
+    for (auto &j : jobs_) {
+        if (j.big >= 0) { j.host = j.own_host; j.dev = j.own_dev; j.big = -1; }       // (a borrowed buffer is freed with the others below)
+        if (gpu_open_ && !parse_only_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.resid) hipFree(j.resid); if (j.uploaded) hipEventDestroy(j.uploaded); }
+        else free(j.host);
+        j = JobSlot();
+    }
+    for (auto &b : big_) {
+        if (gpu_open_ && !parse_only_) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); } else free(b.host);
+        b = BigJobBuf();
+    }
+}
+
 void Decoder::gpu_free_sequence() {
     if (!gpu_open_) return;
     hipSetDevice(device_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
-    for (auto &j : jobs_) {
-        if (j.host) hipHostFree(j.host);
-        if (j.dev) hipFree(j.dev);
-        if (j.dbrec) hipFree(j.dbrec);
-        if (j.resid) hipFree(j.resid);
-        if (j.uploaded) hipEventDestroy(j.uploaded);
-        j = JobSlot();
-    }
+    free_job_buffers();
     free_out_slots(true);
 }
 // releases output slots: every one (teardown) or only those the application is not waiting for (resolution change: frames of the
@@ -335,16 +342,19 @@ bool Decoder::gpu_alloc_sequence() {
     // (always the Main / High layout: a later SPS of the same size may switch profile without re-activation, and a PPS may enable weighted
     //  prediction under any profile_idc)
     job_cap_max_ = n_mbs * (sizeof(MbRec) + 816 + kBiRecInt16 * 2) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096;
-    // Slots start at what an ordinary picture needs -- the fixed records plus 128 bytes per macroblock of levels and motion (config C1 measures
-    // 0.63 MB per 1080p picture, an I picture about three times that) -- and grow on demand up to the worst case above: a picture that does not fit
-    // is parsed again into a bigger buffer (parse_task), and job_hint_ makes the later slots big enough beforehand.  24 worst-case slots were
-    // 195 MB of page-locked memory per 1080p handle (14 GB for the bench's 32 handles: VERDICT r2 weak 11); this way a handle settles near 50 MB.
+    // The 24 slots are sized for an ordinary picture -- the fixed records plus 128 bytes per macroblock of levels and motion (config C1 measures
+    // 0.63 MB per 1080p picture) -- and three worst-case buffers per handle are LENT to I pictures, which need several times that
+    // (acquire_job_slot).  Nothing is allocated while pictures are in flight: hipHostMalloc / hipFree cost milliseconds and synchronise the device,
+    // and one stream's chain of pictures stalls for every one of them (a first version grew slots on demand: single stream 4.0 k -> 3.1 k frames/s).
+    // A P / B picture that outgrows its slot all the same is parsed again into a grown slot (parse_task): rare, and then the slot stays bigger.
+    // 24 worst-case slots were 195 MB of page-locked memory per 1080p handle (14 GB for the bench's 32 handles: VERDICT r2 weak 11); now 55 MB.
     job_cap_ = std::min(job_cap_max_, n_mbs * (sizeof(MbRec) + 128) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096);
     if (getenv("JM_AMD_DEC_JOB_WORST_CASE")) job_cap_ = job_cap_max_;
-    job_hint_ = 0; job_hint_i_ = 0;
     if (codec_ == 1) job_cap_ = n_mbs * 128 + (1u << 20);            // HEVC job lists vary a lot in size: start small, grow on demand (ensure_job_cap)
+    const bool lend_big = codec_ == 0 && job_cap_ < job_cap_max_;
     if (parse_only_) {
         for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
+        if (lend_big) for (auto &b : big_) b.host = (uint8_t *)malloc(job_cap_max_);
         return true;
     }
     hipSetDevice(device_);
@@ -368,6 +378,7 @@ bool Decoder::gpu_alloc_sequence() {
             !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
     }
+    if (lend_big) for (auto &b : big_) if (!HIP_OK(hipHostMalloc((void **)&b.host, job_cap_max_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&b.dev, job_cap_max_))) { fail("job buffer allocation failed"); return false; }
     // output slots: allocate the steady-state population now (hipHostMalloc costs milliseconds and serialises
     // inside the runtime; it must never happen while pictures are in flight)
     {
@@ -532,9 +543,9 @@ bool Decoder::activate(const SeqParams &sps) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
                     if (resid_) { hipFree(resid_); resid_ = nullptr; }
-            for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.resid) hipFree(j.resid); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
+            free_job_buffers();
             free_out_slots(false);
-        } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
+        } else free_job_buffers();
     }
     mb_w_ = sps.mb_w; mb_h_ = sps.mb_h; disp_w_ = sps.disp_w(); disp_h_ = sps.disp_h();
     n_surf_ = 18;                                  // 16 (max DPB) + current + one spare; also covers later SPSs with a larger DPB
@@ -812,14 +823,24 @@ void Decoder::dispatch_pending() {
     push_task(std::move(t));
 }
 
-// big: the picture is an I picture -- several times the job list of a P / B picture.  It takes the BIGGEST free slot and the others the smallest, so the
-// two or three slots that I pictures have grown keep serving them and the rest stay at P-picture size (best fit: ~45 MB of page-locked job memory
-// per 1080p handle instead of every slot growing to I-picture size as the pictures rotate through them).
+// big: the picture is an I picture -- several times the job list of a P / B picture.  It borrows one of the handle's worst-case buffers for as long as
+// it holds the slot.  Pictures are dispatched in decoding order, so whoever holds the buffers now completes without this picture: waiting is safe.
 int Decoder::acquire_job_slot(bool big) {
     auto w0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(mtx_);
-    int got = -1;
-    cv_.wait(lk, [&] { got = -1; for (int i = 0; i < kJobSlots; i++) if (!jobs_[i].busy && (got < 0 || (big ? jobs_[i].cap > jobs_[got].cap : jobs_[i].cap < jobs_[got].cap))) got = i; return got >= 0; });
+    const bool lend = big && codec_ == 0 && big_[0].host != nullptr;
+    int got = -1, bg = -1;
+    cv_.wait(lk, [&] {
+        got = bg = -1;
+        for (int i = 0; i < kJobSlots && got < 0; i++) if (!jobs_[i].busy) got = i;
+        if (lend) for (int i = 0; i < kBigJobBufs && bg < 0; i++) if (!big_[i].busy) bg = i;
+        return got >= 0 && (!lend || bg >= 0);
+    });
+    if (lend) {
+        JobSlot &j = jobs_[got];
+        j.own_host = j.host; j.own_dev = j.dev; j.own_cap = j.cap;
+        j.host = big_[bg].host; j.dev = big_[bg].dev; j.cap = job_cap_max_; j.big = bg; big_[bg].busy = true;
+    }
     jobs_[got].busy = true;
     stat_wait_slot_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
     return got;
@@ -857,11 +878,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     mv_ext_buf.resize((size_t)n_mbs * (big_rec ? kBiRecInt16 : 32));
     const size_t fixed = (size_t)n_mbs * sizeof(MbRec) + 256 * sizeof(SliceRec);
     // The slot may be smaller than the worst-case picture (gpu_alloc_sequence).  Levels are written in place, so a picture that outgrows its slot is
-    // parsed AGAIN into a bigger one (twice the size, at least what the biggest picture so far needed, at most the worst case): rare by construction,
-    // because job_hint_ sizes the slots of later pictures beforehand.
-    const bool i_pic = !t->slices.empty() && t->slices[0].sh.type == SL_I;
-    std::atomic<size_t> &job_hint = i_pic ? job_hint_i_ : job_hint_;      // I pictures and the others size their slots separately (acquire_job_slot)
-    { const size_t hint = job_hint.load(std::memory_order_relaxed); if (hint > js.cap && !ensure_job_cap(js, std::min(hint, job_cap_max_))) fail("job buffer allocation failed"); }
+    // parsed AGAIN into a bigger one (twice the size, at most the worst case): rare -- I pictures borrow worst-case buffers (acquire_job_slot).
     MbRec *mbs = nullptr; SliceRec *srec = nullptr; int16_t *coef = nullptr;
     MbRec blank; memset(&blank, 0, sizeof blank); blank.kind = MB_INTER;
     // default record = concealment for macroblocks no slice delivers (lost / damaged slices): copy the colocated macroblock of the
@@ -900,7 +917,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
             if (r.error) { t->error = r.error; if (!first_error) first_error = r.error; overflow |= strcmp(r.error, "coefficient buffer overflow") == 0; }
         }
         if (overflow && js.cap < job_cap_max_ && attempt < 6 && !failed_) {
-            const size_t want = std::min(job_cap_max_, std::max(js.cap * 2, job_hint.load(std::memory_order_relaxed)));
+            const size_t want = std::min(job_cap_max_, js.cap * 2);
             if (ensure_job_cap(js, want)) { stat_job_regrown_++; continue; }
         }
         if (!t->error.empty()) { stat_errors_++; note_error(std::string("slice data: ") + t->error); }
@@ -940,9 +957,6 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
             if (!ensure_job_cap(js, std::min(need + need / 4, std::max(job_cap_max_, need)), fixed + (size_t)w.coef_count * 2)) fail("job buffer allocation failed");
             else { mbs = (MbRec *)js.host; srec = (SliceRec *)(js.host + (size_t)n_mbs * sizeof(MbRec)); coef = (int16_t *)(srec + 256); w.mbs = mbs; w.coef = coef; stat_job_regrown_++; }
         }
-        size_t hint = job_hint.load(std::memory_order_relaxed);
-        const size_t mine = std::min(job_cap_max_, need + need / 4);          // a quarter of head room: the next picture of this kind should fit at once
-        while (mine > hint && !job_hint.compare_exchange_weak(hint, mine, std::memory_order_relaxed)) {}
     }
     if (failed_) { w.mv_ext_count = 0; }
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
@@ -1097,7 +1111,11 @@ void Decoder::on_engine_done(const EnginePic &p, bool failed) {
     if (failed) { stat_errors_++; fail("device error: the batch holding this handle's picture did not complete"); }
     {
         std::lock_guard<std::mutex> lk(mtx_);
-        if (p.job_slot >= 0) jobs_[p.job_slot].busy = false;
+        if (p.job_slot >= 0) {
+            JobSlot &j = jobs_[p.job_slot];
+            if (j.big >= 0) { big_[j.big].busy = false; j.host = j.own_host; j.dev = j.own_dev; j.cap = j.own_cap; j.big = -1; }     // the borrowed I-picture buffer goes back
+            j.busy = false;
+        }
         for (OutSlot *o : p.slots_before) { o->ready = true; if (failed) o->has_data = false; }
         for (OutSlot *o : p.slots_after) { o->ready = true; if (failed) o->has_data = false; }
         outstanding_--;

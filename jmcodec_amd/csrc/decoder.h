@@ -81,7 +81,11 @@ struct JobSlot {                       // one picture's job list: pinned host bu
     uint8_t *dbrec = nullptr;          // device scratch of k_deblock_prep for this picture (96 B per macroblock): per slot, because pictures of a chain run concurrently
     ihipEvent_t *uploaded = nullptr;   // recorded behind the H2D copy on the engine's copy stream
     bool busy = false;                 // from dispatch until the engine reports the picture done
+    int big = -1;                      // >= 0: host / dev / cap are those of borrowed big buffer `big` (an I picture); the slot's own are kept below
+    uint8_t *own_host = nullptr, *own_dev = nullptr; size_t own_cap = 0;
 };
+constexpr int kBigJobBufs = 3;         // worst-case-sized job buffers per H.264 handle, lent to I pictures (one in thirty pictures of config C1; two in flight at most)
+struct BigJobBuf { uint8_t *host = nullptr, *dev = nullptr; bool busy = false; };
 struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
     uint8_t *host = nullptr;
     uint8_t *dev = nullptr;            // device staging of the packed frame (copy-engine mode, see Engine::launch)
@@ -197,6 +201,8 @@ private:
     std::deque<std::unique_ptr<PicTask>> inflight_;
     std::mutex submit_mtx_;
     JobSlot jobs_[kJobSlots];
+    BigJobBuf big_[kBigJobBufs];               // see acquire_job_slot
+    void free_job_buffers();
     std::deque<OutSlot *> ready_;              // display order
     std::vector<OutSlot *> free_out_, all_out_;
     OutSlot *cur_out_ = nullptr;
@@ -209,7 +215,6 @@ private:
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
-    std::atomic<size_t> job_hint_{0}, job_hint_i_{0};   // (job_hint_i_: the same for I pictures)           // what the biggest H.264 picture so far needed (+ a quarter): later slots are grown to it before their parse
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;
 

@@ -16,6 +16,7 @@ namespace jmamd {
 // keep = bytes at the start of the old host buffer that the new one must hold (0: the contents are rebuilt anyway)
 bool Decoder::ensure_job_cap(JobSlot &js, size_t bytes, size_t keep) {
     if (bytes <= js.cap) return true;
+    if (js.big >= 0) return false;                                     // a borrowed worst-case buffer: nothing bigger exists
     size_t cap = codec_ == 1 ? bytes + bytes / 2 + 4096 : bytes;      // (the H.264 caller chooses its own head room)
     if (parse_only_ || !gpu_open_) { uint8_t *p = (uint8_t *)realloc(js.host, cap); if (!p) return false; js.host = p; js.cap = cap; return true; }
     hipSetDevice(device_);
