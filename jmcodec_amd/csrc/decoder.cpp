@@ -310,6 +310,7 @@ void Decoder::gpu_free_sequence() {
     hipSetDevice(device_);
     for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
+    for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
     free_job_buffers();
     free_out_slots(true);
 }
@@ -370,7 +371,10 @@ bool Decoder::gpu_alloc_sequence() {
     lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
     chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
     chain_intra_on_ = !getenv("JM_AMD_DEC_NO_CHAIN_INTRA");
-    if (codec_ == 1 && !HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768))) { fail("hipMalloc(scratch) failed"); return false; }   // HEVC: one per handle (H.264: per job slot)
+    if (codec_ == 1) {                               // HEVC: kHevcWorkSets residual scratches and pre-SAO work surfaces per handle (H.264: a scratch per job slot)
+        if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768 * kHevcWorkSets))) { fail("hipMalloc(scratch) failed"); return false; }
+        for (auto &w : hevc_work_) { if (!HIP_OK(hipMalloc((void **)&w, surf_bytes_))) { fail("hipMalloc(work surface) failed"); return false; } hipMemset(w, 128, surf_bytes_); }
+    }
     NumaPreferred on_gpu_node(numa_node_);          // the page-locked job buffers (and output slots) of this handle: memory of the GPU's node
     for (auto &j : jobs_) {
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
@@ -543,6 +547,8 @@ bool Decoder::activate(const SeqParams &sps) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
                     if (resid_) { hipFree(resid_); resid_ = nullptr; }
+                    for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+    for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
             free_job_buffers();
             free_out_slots(false);
         } else free_job_buffers();

@@ -84,6 +84,7 @@ struct JobSlot {                       // one picture's job list: pinned host bu
     int big = -1;                      // >= 0: host / dev / cap are those of borrowed big buffer `big` (an I picture); the slot's own are kept below
     uint8_t *own_host = nullptr, *own_dev = nullptr; size_t own_cap = 0;
 };
+constexpr int kHevcWorkSets = 4;       // HEVC pictures of one handle that may share a batch (independent B pictures of a pyramid): each needs its own pre-SAO work surface and residual scratch
 constexpr int kBigJobBufs = 3;         // worst-case-sized job buffers per H.264 handle, lent to I pictures (one in thirty pictures of config C1; two in flight at most)
 struct BigJobBuf { uint8_t *host = nullptr, *dev = nullptr; bool busy = false; };
 struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
@@ -214,6 +215,7 @@ private:
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
+    uint8_t *hevc_work_[kHevcWorkSets] = {nullptr, nullptr, nullptr, nullptr}; unsigned hevc_work_rr_ = 0;   // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;

@@ -130,7 +130,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
     auto account = [&](EnginePic &p, EngineDecoderState &es) {
-        if (p.has_picture && p.codec == 0) es.batch_written |= 1u << p.pp.cur;
+        if (p.has_picture) es.batch_written |= 1u << (p.codec == 0 ? p.pp.cur : p.hp.cur);
         es.batch_read |= p.ref_mask | p.out_mask;
         n_pre += p.out_before.size(); n_post += p.out_after.size();
     };
@@ -188,6 +188,26 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             b.max_depth = depth + 1;
         }
     }
+    // HEVC (both HEVC lanes): further pictures of a member decoder join the batch as long as each is INDEPENDENT of the decoder's pictures already in
+    // it -- it references none of the surfaces they decode into, decodes into none they read or display, and packs nothing before the kernels.  That is
+    // the shape of a random-access pyramid: after the anchor and the middle B picture, the B pictures of a level do not depend on each other.  A
+    // single stream then runs two to four pictures per launch instead of one (its rate was one kernel sequence per picture: 1.25 k frames/s at
+    // 1080p).  At most kHevcWorkSets pictures per decoder: each needs its own pre-SAO work surface and residual scratch (hevc_decoder.cpp).
+    if (lane_idx == kHevcLane || lane_idx == kHevcIntraLane) {
+        for (Decoder *d : members) {
+            EngineDecoderState &es = d->engine_state();
+            while (es.in_batch < kHevcWorkSets && (int)b.pics.size() < kMaxBatch) {
+                auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
+                if (it == pending_.end() || !it->has_picture || it->codec != 1 || it->lane(false, false) != lane_idx || !it->out_before.empty() || it->wait_prev_pack) break;
+                if ((it->ref_mask & es.batch_written) || ((1u << it->hp.cur) & (es.batch_written | es.batch_read)) || n_post + it->out_after.size() > (size_t)2 * kMaxBatch) break;
+                es.inflight++; es.in_batch++;
+                es.batch_written |= 1u << it->hp.cur;
+                account(*it, es);
+                b.pics.push_back(std::move(*it));
+                pending_.erase(it);
+            }
+        }
+    }
     (void)ln;
     return true;
 }
@@ -230,7 +250,9 @@ void Engine::launch(Lane &ln, Batch &b) {
             if (!refs_in_batch) q.stages |= PS_RECON;
         }
         stages |= b.h_pics[i].stages;
-        if (p.has_picture && !hevc) { max_mb_w = std::max(max_mb_w, p.mb_w); if ((1u << p.pp.cur) & p.dec->engine_state().displayed[0]) wait_pack = true; }
+        if (p.has_picture && !hevc) max_mb_w = std::max(max_mb_w, p.mb_w);
+        // a surface this decoder's pictures of the PREVIOUS batch display may still be read by that batch's pack-out (it runs beside this batch's kernels)
+        if (p.has_picture && ((1u << (hevc ? p.hp.cur : p.pp.cur)) & p.dec->engine_state().displayed[0])) wait_pack = true;
         if (hevc && p.has_picture) {
             const HevcPicParams &h = p.hp;
             hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);

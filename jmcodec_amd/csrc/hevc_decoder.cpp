@@ -90,12 +90,13 @@ bool Decoder::hevc_activate(const HevcSps &sps) {
             hipSetDevice(device_);
             for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
             if (resid_) { hipFree(resid_); resid_ = nullptr; }
+            for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
             for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
             free_out_slots(false);
         } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
     }
     mb_w_ = mbw; mb_h_ = mbh; disp_w_ = sps.disp_w(); disp_h_ = sps.disp_h();
-    n_surf_ = 18; extra_surf_ = 1;                 // 16 (max DPB) + current + one spare, plus the pre-SAO work surface
+    n_surf_ = 18; extra_surf_ = 0;                 // 16 (max DPB) + current + one spare (the pre-SAO work surfaces are separate: hevc_work_)
     for (auto &d : dpb_) d = DpbPic();
     seq_.profile_idc = 100;                        // sizes the shared job buffers (gpu_alloc_sequence)
     if (!gpu_alloc_sequence()) return false;
@@ -177,7 +178,7 @@ bool Decoder::hevc_start_picture(const HevcSliceHeader &sh, int nal_type, int ti
     pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack;
     pending_->out_before = std::move(carry_out_); carry_out_.clear();
     pending_->hevc = std::make_unique<HevcTask>();
-    pending_->hevc->sps = sps; pending_->hevc->pps = pps; pending_->hevc->poc = poc; pending_->hevc->col_out = c.hcol; pending_->hevc->work_slot = n_surf_;
+    pending_->hevc->sps = sps; pending_->hevc->pps = pps; pending_->hevc->poc = poc; pending_->hevc->col_out = c.hcol; pending_->hevc->work_slot = (int)(hevc_work_rr_++ % kHevcWorkSets);
     first_sh_ = SliceHeader(); first_sh_.type = sh.type == HSL_I ? SL_I : (sh.type == HSL_B ? SL_B : SL_P);
     if (sh.type == HSL_I) stat_i_++; else if (sh.type == HSL_B) stat_b_++; else stat_p_++;
     return true;
@@ -291,12 +292,15 @@ void Decoder::hevc_fill_engine_pic(PicTask *t, EnginePic &ep) {
     hp.w = ht.sps.width; hp.h = ht.sps.height; hp.pitch = pitch_; hp.chroma_offset = chroma_off_;
     hp.ctb_log2 = ht.sps.log2_ctb; hp.ctb_w = (hp.w + (1 << hp.ctb_log2) - 1) >> hp.ctb_log2; hp.ctb_h = (hp.h + (1 << hp.ctb_log2) - 1) >> hp.ctb_log2;
     hp.w8 = hp.w >> 3; hp.cb_qp_off = ht.pps.cb_qp_off; hp.cr_qp_off = ht.pps.cr_qp_off; hp.strong_intra = ht.sps.strong_intra;
-    hp.cur = t->cur_slot; hp.work = ht.any_sao ? ht.work_slot : t->cur_slot;
+    hp.cur = t->cur_slot; hp.work = ht.work_slot;
+    hp.work_surf = ht.any_sao ? hevc_work_[ht.work_slot] : surf_[t->cur_slot];
     for (int i = 0; i < kMaxSurfaces; i++) hp.surf[i] = surf_[i];
     hp.ctbs = (const HevcCtb *)(js.dev + ht.off_ctbs); hp.qp8 = js.dev + ht.off_qp8; hp.bs_v = js.dev + ht.off_bsv; hp.bs_h = js.dev + ht.off_bsh;
     hp.pus = (const HevcPu *)(js.dev + ht.off_pus); hp.n_pus = ht.n_pus; hp.tbs = (const HevcTb *)(js.dev + ht.off_tbs); hp.n_tbs = ht.n_tbs;
-    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs); hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)resid_;
+    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs); hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)(resid_ + (size_t)ht.work_slot * ((size_t)mb_w_ * mb_h_ * 768));
     hp.stages = (ht.n_pus ? HPS_MC : 0) | (ht.n_tbs ? HPS_RESID : 0) | (ht.n_itbs ? HPS_INTRA : 0) | (ht.any_deblock ? HPS_DEBLOCK : 0) | (ht.any_sao ? HPS_SAO : 0);
+    // which surfaces the picture reads: lets the engine put INDEPENDENT pictures of this handle (the B pictures of one pyramid level) into one batch
+    for (const auto &sl : ht.slices) for (int l = 0; l < 2; l++) for (int i = 0; i < sl.sh.n_ref[l] && i < 16; i++) if (sl.refs.slot[l][i] >= 0 && sl.refs.slot[l][i] < 32) ep.ref_mask |= 1u << sl.refs.slot[l][i];
     const long long S = (long long)surf_bytes_;
     ep.alg_bytes[0] = (ht.n_pus ? 2 * S : 0) + (long long)t->upload_bytes; ep.alg_bytes[1] = ht.n_itbs ? S : 0; ep.alg_bytes[2] = (ht.any_deblock ? 2 * S : 0) + (ht.any_sao ? 2 * S : 0);
 }

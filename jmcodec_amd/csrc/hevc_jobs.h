@@ -70,8 +70,9 @@ struct HevcPicParams {
     int cb_qp_off, cr_qp_off;     // pps_cb_qp_offset / pps_cr_qp_offset (chroma deblocking)
     int strong_intra;
     int stages;                   // HPS_*
-    int cur, work;                // surface the finished picture lands in / surface reconstruction and deblocking run in (== cur without SAO)
+    int cur, work;                // surface the finished picture lands in / (diagnostic) index of the work set
     uint8_t *surf[kMaxSurfaces];
+    uint8_t *work_surf;           // surface reconstruction and deblocking run in: surf[cur] without SAO, else one of the handle's pre-SAO work surfaces
     const HevcCtb *ctbs;
     const uint8_t *qp8, *bs_v, *bs_h;
     const HevcPu *pus; int n_pus;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
     const HevcPu pu = pp.pus[job];
     const int lane = threadIdx.x;
     __shared__ HevcMcLds sm;
-    uint8_t *dst = pp.surf[pp.work];
+    uint8_t *dst = pp.work_surf;
     const HevcWp *wp = pu.wp ? &pp.wps[pu.wp - 1] : nullptr;
     const int both = pu.slot0 >= 0 && pu.slot1 >= 0;
     // 8.5.3.3.4.2 / 8.5.3.3.4.3: the two 14-bit predictions -> one sample of component c
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     const int lane = threadIdx.x, n = 1 << tb.log2;
     load_transform_matrix(tm, tb.log2, lane, 64);
     const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
-    uint8_t *dst = pp.surf[pp.work];
+    uint8_t *dst = pp.work_surf;
     for (int k = lane; k < n * n; k += 64) {
         const int y = k >> tb.log2, x = k & (n - 1);
         uint8_t *p = sample_ptr(dst, pp, tb.plane, tb.x + x, tb.y + y);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     __shared__ int16_t refa_[3][32 * 3 + 8];    // main reference of the angular modes, index 0 at refa[32]
     __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records and residual (k_hevc_iresid), fetched once: the block loop touches no global memory
     int lane = threadIdx.x, nt = kIntraThreads;
-    uint8_t *surf = pp.surf[pp.work];
+    uint8_t *surf = pp.work_surf;
     const int cs = 1 << pp.ctb_log2, x0 = cx << pp.ctb_log2, y0 = cy << pp.ctb_log2;
     const int n_tbs = (int)ctb.intra_count;
     const bool tbs_in_lds = n_tbs <= kIntraMaxTbs;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const HevcPicParams *pics,
     const int xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
     const int qpq = pp.qp8[(y >> 3) * pp.w8 + (x >> 3)] & 63, qpp = pp.qp8[(yp >> 3) * pp.w8 + (xp >> 3)] & 63, qpl = (qpq + qpp + 1) >> 1;
     const HevcCtb &cq = pp.ctbs[(y >> pp.ctb_log2) * pp.ctb_w + (x >> pp.ctb_log2)];
-    uint8_t *surf = pp.surf[pp.work];
+    uint8_t *surf = pp.work_surf;
     {
         const int beta = c_beta[clip3(0, 51, qpl + 2 * cq.beta_off)], tc = c_tc[clip3(0, 53, qpl + 2 * (bs - 1) + 2 * cq.tc_off)];
         const int across = dir ? pp.pitch : 1, along = dir ? 1 : pp.pitch;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_hevc_sao(const HevcPicParams *pics) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= pw * ph) return;
     const int x = idx % pw, y = idx / pw, xl = x << sc, yl = y << sc;
-    const uint8_t *src = pp.surf[pp.work]; uint8_t *dst = pp.surf[pp.cur];
+    const uint8_t *src = pp.work_surf; uint8_t *dst = pp.surf[pp.cur];
     const int v = *sample_ptr((uint8_t *)src, pp, c, x, y);
     const int cxb = xl >> pp.ctb_log2, cyb = yl >> pp.ctb_log2;
     const HevcCtb &ctb = pp.ctbs[cyb * pp.ctb_w + cxb];

@@ -197,6 +197,32 @@ def test_c3_full_length_4k_hevc():
             assert digs[first:first + n] == _md5_frames(want, w * h * 3 // 2), f"IDR period {k} differs from the oracle"
 
 
+def test_independent_pictures_of_a_stream_share_a_launch(oracle):
+    """Round 3: the engine puts INDEPENDENT pictures of one HEVC handle -- the B pictures of one level of a random-access pyramid -- into one batch
+    (each with its own pre-SAO work surface and residual scratch).  Eight handles decode GOP-8 pyramids concurrently, every frame of every handle is
+    compared with the oracle, twice over: a picture that decodes into a surface the previous batch still packs out, or shares a work surface with a
+    batch mate, shows up as a wrong frame here (the first form of the change corrupted a displayed frame at 16 streams)."""
+    datas = [streams.generate_hevc(**streams.config_c3(frames=25, width=640, height=368, stream_id=40 + i)) for i in range(8)]
+    wants = [oracle.decode(d, 1) for d in datas]
+    for rep in range(2):
+        got, errs, ppb = [None] * 8, [None] * 8, [None] * 8
+
+        def run(i):
+            with jmcodec_amd.JmAmdDec(1, 1) as dec:
+                b0 = (dec.stat("eng_batches"), dec.stat("eng_batch_pics"))
+                got[i] = dec.decode_stream(datas[i] * 2)                     # two IDR periods back to back
+                errs[i] = dec.stat("errors")
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for i in range(8):
+            want, n, w, h = wants[i]
+            fs = w * h * 3 // 2
+            assert errs[i] == 0 and len(got[i]) == 2 * n
+            for k, f in enumerate(got[i]):
+                assert f == want[(k % n) * fs:(k % n + 1) * fs], f"pass {rep}, handle {i}: frame {k} differs from the oracle"
+
+
 @pytest.mark.gpu
 def test_mixed_codecs_concurrently_all_engine_lanes():
     """H.264 Baseline, H.264 High with B pictures and HEVC handles decoding at the same time on one device: ordinary lane (chain launches and stage kernels),
