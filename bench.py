@@ -299,7 +299,8 @@ def main():
     tot_alg = {k: e1[k]["alg_bytes"] - e0[k]["alg_bytes"] for k in names}
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
-    chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"), L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"))   # whole run
+    chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"), L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"),
+                  L.jm_amddec_get_stat(handles[0], b"eng_chain_recoveries"), L.jm_amddec_get_stat(handles[0], b"eng_gpu_shared"))   # whole run
     dfr = sum(L.jm_amddec_get_stat(h, b"direct_frames") for h in handles)
     direct_stat = {"sdma_engines": hex(L.jm_amddec_get_stat(handles[0], b"copy_engines")), "frames_whole_run": int(dfr), "caller_wait_us_per_frame": round(sum(L.jm_amddec_get_stat(h, b"direct_ns") for h in handles) / 1e3 / max(dfr, 1), 1)}
     fm1 = [L.jm_amddec_get_stat(handles[0], k) for k in (b"eng_forms", b"eng_form_decoders", b"eng_form_pending")]
@@ -571,7 +572,8 @@ def main():
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms, "formation": form_stat, "direct_output": direct_stat,
-                   "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2])},
+                   "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2]),
+                   "chain_recoveries_whole_run": int(chain_stat[3]), "gpu_shared_with_another_process": bool(chain_stat[4])},
         "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 54.0, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 54.0, 4),
                      "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> caller's buffer); peak = device->host "
                              "rate measured on this platform with three SDMA engines in turn, four copies in flight (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 54.0 GB/s = 17.4 k frames/s of 1080p; two engines 52.5, one 47); "

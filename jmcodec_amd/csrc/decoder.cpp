@@ -191,6 +191,7 @@ long long Decoder::get_stat(const char *key) const {
         if (k == "eng_chain_pics") return es.chain_pics;
         if (k == "eng_wait_errors") return es.wait_errors;
         if (k == "eng_chain_recoveries") return es.chain_recoveries;
+        if (k == "eng_gpu_shared") return engine_->gpu_shared() ? 1 : 0;
         if (k == "eng_launch_ns") return es.launch_ns;
         if (k == "eng_complete_ns") return es.complete_ns;
         return -1;

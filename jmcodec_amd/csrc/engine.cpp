@@ -72,6 +72,7 @@ Engine::Engine(int device) : device_(device) {
       if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_, chain_bands_max_intra_); }
     ok_ = true;
     numa_node_ = numa_node_of_device(device_, true);
+    kfd_gpu_id_ = getenv("JM_AMD_DEC_IGNORE_SHARED_GPU") ? 0 : kfd_gpu_id_of_device(device_);
     th_ = std::thread([this] { pthread_setname_np(pthread_self(), "jm-engine"); numa_bind_this_thread(numa_node_); run(); });
     th_.detach();
 }
@@ -124,7 +125,16 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
         recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *, long long> &r) { return now - r.second > 50ll * 1000 * 1000; }), recent_.end());
         const int n_active = (int)recent_.size();
-        chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_;
+        // A chain launch needs the whole GPU (its waits assume its bands stay resident, chain.hip).  When another process has compute queues on this
+        // device -- a second rank of the same job, another tenant -- no chain launches are formed at all, instead of letting them time out against the
+        // other process's kernels and decoding their pictures again (Engine::recover: correct, but every such launch costs 100 ms).
+        if (kfd_gpu_id_ && now - shared_checked_ns_ > 1000ll * 1000 * 1000) {
+            shared_checked_ns_ = now;
+            const bool sh = kfd_gpu_has_other_users(kfd_gpu_id_);
+            if (sh != gpu_shared_) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_, sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
+            gpu_shared_ = sh;
+        }
+        chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
         split = !chaining && lane_split_ && n_active > chain_max_streams_;
     }
     std::vector<Decoder *> seen, members;

@@ -101,6 +101,7 @@ public:
     bool set_knob(const std::string &key, long long v);
     EngineStats stats();
     int device() const { return device_; }
+    bool gpu_shared() const { return gpu_shared_; }      // another process has compute queues on this GPU (no chain launches then)
 
 private:
     explicit Engine(int device);
@@ -142,6 +143,7 @@ private:
     void recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later);
 
     int device_, numa_node_ = -1;
+    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; long long shared_checked_ns_ = 0;   // another process has queues on this GPU (checked about once a second): no chain launches
     ihipStream_t *copy_stream_ = nullptr;
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];

@@ -1,6 +1,7 @@
 // jmcodec_amd/csrc/numa.cpp -- see numa.h.
 #include "numa.h"
 #include <hip/hip_runtime_api.h>
+#include <dirent.h>
 #include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -70,5 +71,68 @@ NumaPreferred::NumaPreferred(int node) {
     on = syscall(SYS_set_mempolicy, 1, mask, (unsigned long)(sizeof mask * 8)) == 0;
 }
 NumaPreferred::~NumaPreferred() { if (on) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0ul); }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+static bool read_small(const char *path, char *buf, size_t n) {
+    FILE *fp = fopen(path, "r");
+    if (!fp) return false;
+    const size_t got = fread(buf, 1, n - 1, fp);
+    fclose(fp);
+    buf[got] = 0;
+    return got > 0;
+}
+
+unsigned kfd_gpu_id_of_device(int dev) {
+    int bus = -1, pdev = -1, dom = -1;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId, dev) != hipSuccess ||
+        hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const unsigned want_loc = ((unsigned)bus << 8) | ((unsigned)pdev << 3);
+    unsigned only = 0; int n_readable = 0;
+    for (int node = 0; node < 256; node++) {
+        char path[128], buf[4096];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", node);
+        if (!read_small(path, buf, sizeof buf)) { if (node > 64) break; continue; }         // (a container sees the nodes of other tenants' GPUs as unreadable)
+        const unsigned id = (unsigned)strtoul(buf, nullptr, 10);
+        if (!id) continue;                                                               // CPU node
+        only = id; n_readable++;
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+        if (!read_small(path, buf, sizeof buf)) continue;
+        unsigned loc = ~0u, domain = 0;
+        if (const char *p = strstr(buf, "location_id ")) loc = (unsigned)strtoul(p + 12, nullptr, 10);
+        if (const char *p = strstr(buf, "domain ")) domain = (unsigned)strtoul(p + 7, nullptr, 10);
+        if (loc == want_loc && (int)domain == dom) return id;
+    }
+    return n_readable == 1 ? only : 0;                                                   // one GPU visible: it is the one
+}
+
+// The directory names are process ids of the HOST's pid namespace: inside a container getpid() names nothing there, so "a process other than this
+// one" cannot be told by id.  Counted instead: processes with at least one compute queue (type != 1: SDMA queues belong to copies) on the GPU.  This
+// process is one of them -- the engine creates its streams before the first check -- so two or more means company.
+bool kfd_gpu_has_other_users(unsigned gpu_id) {
+    if (!gpu_id) return false;
+    DIR *d = opendir("/sys/class/kfd/kfd/proc");
+    if (!d) return false;
+    int users = 0;
+    while (struct dirent *e = readdir(d)) {
+        char *end; (void)strtol(e->d_name, &end, 10);
+        if (end == e->d_name || *end) continue;
+        char qdir[160]; snprintf(qdir, sizeof qdir, "/sys/class/kfd/kfd/proc/%s/queues", e->d_name);
+        DIR *q = opendir(qdir);
+        if (!q) continue;
+        bool here = false;
+        while (struct dirent *f = readdir(q)) {
+            if (f->d_name[0] == '.') continue;
+            char path[256], buf[32]; snprintf(path, sizeof path, "%s/%s/gpuid", qdir, f->d_name);
+            if (!read_small(path, buf, sizeof buf) || (unsigned)strtoul(buf, nullptr, 10) != gpu_id) continue;
+            snprintf(path, sizeof path, "%s/%s/type", qdir, f->d_name);
+            if (read_small(path, buf, sizeof buf) && strtoul(buf, nullptr, 10) == 1) continue;       // an SDMA queue
+            here = true; break;
+        }
+        closedir(q);
+        users += here;
+    }
+    closedir(d);
+    return users >= 2;
+}
 
 }  // namespace jmamd

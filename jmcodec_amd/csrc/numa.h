@@ -17,4 +17,11 @@ bool numa_bind_this_thread(int node);
 // while alive, page allocations of the calling thread prefer `node` (set_mempolicy MPOL_PREFERRED): hipHostMalloc pins pages where they are first placed
 struct NumaPreferred { explicit NumaPreferred(int node); ~NumaPreferred(); bool on = false; };
 
+// ---- who else is on the GPU (KFD sysfs) ----
+// The KFD driver's id of HIP device `dev` (/sys/class/kfd/kfd/topology/nodes/*/gpu_id, matched by PCI location); 0 when it cannot be told.
+unsigned kfd_gpu_id_of_device(int dev);
+// true when two or more processes (this one included) have compute queues on that GPU (/sys/class/kfd/kfd/proc/<pid>/queues/*/gpuid): the engine then forms no
+// chain launches -- their no-deadlock argument needs the whole GPU (chain.hip); two processes on one device made them time out and be decoded again
+bool kfd_gpu_has_other_users(unsigned gpu_id);
+
 }  // namespace jmamd
