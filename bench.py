@@ -46,11 +46,13 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tools", default="baseline", choices=["baseline", "high", "high_b"],
                     help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P)")
-    ap.add_argument("--codec", default="h264", choices=["h264", "hevc"], help="diagnostic: hevc = SURVEY 8d config C3 (HEVC Main, 64x64 CTB, SAO + deblocking, random-access GOP 8) at --width x --height")
+    ap.add_argument("--codec", default="h264", choices=["h264", "hevc"], help="diagnostic: hevc = SURVEY 8d config C3 (HEVC Main, 64x64 CTB, SAO + "
+        "deblocking, random-access GOP 8) at --width x --height")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the untimed single-stream leg")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: do not record per-kernel HIP events")
-    ap.add_argument("--device-output", action="store_true", help="diagnostic (profiles/): display frames stay in device memory (jm_amddec_output_frame_device), no D2H copy -- "
+    ap.add_argument("--device-output", action="store_true", help="diagnostic (profiles/): display frames stay in device memory "
+        "(jm_amddec_output_frame_device), no D2H copy -- "
                     "under rocprofv3 the runtime replaces copy-engine transfers by blit kernels, which perturbs the decode kernels")
     ap.add_argument("--parse-only", action="store_true", help="diagnostic: host stages only (no device work, frames carry no pixels)")
     args = ap.parse_args()
@@ -118,7 +120,8 @@ def main():
         """Generated once per box and cached under /tmp (the 1/2/4/8-GPU runs of a scaling sweep share most of their streams)."""
         import hashlib
         cfg = stream_cfg(sid)
-        key = hashlib.md5(repr((args.codec, sorted(cfg.items()), os.path.getmtime(os.path.join(ROOT, "tools", "hevcgen.c" if args.codec == "hevc" else "h264gen.c")))).encode()).hexdigest()
+        key = hashlib.md5(repr((args.codec, sorted(cfg.items()), os.path.getmtime(os.path.join(ROOT, "tools",
+            "hevcgen.c" if args.codec == "hevc" else "h264gen.c")))).encode()).hexdigest()
         path = os.path.join(os.environ.get("JM_BENCH_CACHE", "/tmp"), f"jm_bench_{key}.bin")
         try:
             with open(path, "rb") as f:
@@ -150,7 +153,8 @@ def main():
         if mm != "max" and not args.parse_only:
             need = local_world * (S * 0.2e9 * max(1.0, args.width * args.height / (1920.0 * 1080.0)) + 3e9)
             if need > 0.9 * int(mm):
-                print(f"bench.py: WARNING: {local_world} rank(s) x {S} handles want about {need / 1e9:.0f} GB of host memory, the container allows {int(mm) / 1e9:.0f} GB", file=sys.stderr, flush=True)
+                print(f"bench.py: WARNING: {local_world} rank(s) x {S} handles want about {need / 1e9:.0f} GB of host memory, the container allows "
+                    f"{int(mm) / 1e9:.0f} GB", file=sys.stderr, flush=True)
     except (OSError, ValueError):
         pass
     handles = []
@@ -243,7 +247,8 @@ def main():
         if not os.environ.get("JM_BENCH_MEMTRACE"):
             return
         try:
-            f = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/self/status") if l.startswith(("VmRSS", "VmHWM", "VmLck", "VmPin", "RssAnon", "RssShmem", "RssFile"))}
+            f = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/self/status") if l.startswith(("VmRSS", "VmHWM", "VmLck", "VmPin", "RssAnon",
+                "RssShmem", "RssFile"))}
             print(f"bench.py: memtrace rank {rank} {tag}: {f}", file=sys.stderr, flush=True)
         except OSError:
             pass
@@ -284,7 +289,8 @@ def main():
     hc1 = host_cpu()
     tc1 = thread_cpu()
     memtrace("timed region done")
-    by_thread = {k: {"user_s": round(v[0] - tc0.get(k, [0, 0, 0])[0], 2), "sys_s": round(v[1] - tc0.get(k, [0, 0, 0])[1], 2), "threads": v[2]} for k, v in tc1.items()}
+    by_thread = {k: {"user_s": round(v[0] - tc0.get(k, [0, 0, 0])[0], 2), "sys_s": round(v[1] - tc0.get(k, [0, 0, 0])[1], 2), "threads": v[2]} for k,
+        v in tc1.items()}
     by_thread = {k: v for k, v in by_thread.items() if v["user_s"] + v["sys_s"] >= 0.05}
     frames_local = sum(counts)
 
@@ -299,18 +305,23 @@ def main():
     tot_alg = {k: e1[k]["alg_bytes"] - e0[k]["alg_bytes"] for k in names}
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
-    chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"), L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"),
+    chain_stat = (L.jm_amddec_get_stat(handles[0], b"eng_chain_batches"), L.jm_amddec_get_stat(handles[0], b"eng_chain_pics"),
+        L.jm_amddec_get_stat(handles[0], b"eng_wait_errors"),
                   L.jm_amddec_get_stat(handles[0], b"eng_chain_recoveries"), L.jm_amddec_get_stat(handles[0], b"eng_gpu_shared"))   # whole run
     dfr = sum(L.jm_amddec_get_stat(h, b"direct_frames") for h in handles)
-    direct_stat = {"sdma_engines": hex(L.jm_amddec_get_stat(handles[0], b"copy_engines")), "frames_whole_run": int(dfr), "caller_wait_us_per_frame": round(sum(L.jm_amddec_get_stat(h, b"direct_ns") for h in handles) / 1e3 / max(dfr, 1), 1)}
+    direct_stat = {"sdma_engines": hex(L.jm_amddec_get_stat(handles[0], b"copy_engines")), "frames_whole_run": int(dfr),
+        "caller_wait_us_per_frame": round(sum(L.jm_amddec_get_stat(h, b"direct_ns") for h in handles) / 1e3 / max(dfr, 1), 1)}
     fm1 = [L.jm_amddec_get_stat(handles[0], k) for k in (b"eng_forms", b"eng_form_decoders", b"eng_form_pending")]
     forms = max(1, fm1[0] - fm0[0])
-    form_stat = {"decoders_waiting_per_batch_formed": round((fm1[1] - fm0[1]) / forms, 2), "pictures_waiting_per_batch_formed": round((fm1[2] - fm0[2]) / forms, 2)}   # timed region, ordinary lane
-    eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4), "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
+    form_stat = {"decoders_waiting_per_batch_formed": round((fm1[1] - fm0[1]) / forms, 2),
+        "pictures_waiting_per_batch_formed": round((fm1[2] - fm0[2]) / forms, 2)}   # timed region, ordinary lane
+    eng_thread_ms = {"launch_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_launch_ns") - et0[0]) / 1e6 / max(batches, 1), 4),
+        "retire_per_batch": round((L.jm_amddec_get_stat(handles[0], b"eng_complete_ns") - et0[1]) / 1e6 / max(batches, 1), 4)}
     job_bytes = sum(L.jm_amddec_get_stat(h, b"job_bytes") - jb0[i] for i, h in enumerate(handles))
     pictures = sum(L.jm_amddec_get_stat(h, b"pictures") - pic0[i] for i, h in enumerate(handles))
     threads = L.jm_amddec_get_stat(handles[0], b"threads")
-    host_diag = {k: round(sum(L.jm_amddec_get_stat(h, k.encode()) for h in handles) / 1e6 / max(1, sum(L.jm_amddec_get_stat(h, b"pictures") for h in handles)), 4)
+    host_diag = {k: round(sum(L.jm_amddec_get_stat(h, k.encode()) for h in handles) / 1e6 / max(1, sum(L.jm_amddec_get_stat(h,
+        b"pictures") for h in handles)), 4)
                  for k in ("submit_ns", "wait_slot_ns", "parse_ns_i", "parse_ns_p")}   # ms per picture, whole run
 
     # algorithmic bytes per launch: summed by the engine over the pictures each batched launch processed
@@ -339,8 +350,10 @@ def main():
         r = lambda k: (pmc[k]["fetch_raw"] + pmc[k]["write"]) if k in pmc else 0
         if args.codec == "hevc":
             # k_hevc_deblock runs twice per picture (vertical edges, horizontal edges); the file holds the average of its launches
-            per_pic = {"inter": t("k_hevc_mc") + t("k_hevc_resid") + t("k_hevc_iresid"), "intra": t("k_hevc_intra"), "deblock": 2 * t("k_hevc_deblock") + t("k_hevc_sao")}
-            raw_pic = {"inter": r("k_hevc_mc") + r("k_hevc_resid") + r("k_hevc_iresid"), "intra": r("k_hevc_intra"), "deblock": 2 * r("k_hevc_deblock") + r("k_hevc_sao")}
+            per_pic = {"inter": t("k_hevc_mc") + t("k_hevc_resid") + t("k_hevc_iresid"), "intra": t("k_hevc_intra"),
+                "deblock": 2 * t("k_hevc_deblock") + t("k_hevc_sao")}
+            raw_pic = {"inter": r("k_hevc_mc") + r("k_hevc_resid") + r("k_hevc_iresid"), "intra": r("k_hevc_intra"),
+                "deblock": 2 * r("k_hevc_deblock") + r("k_hevc_sao")}
         else:
             per_pic = {"inter": t("k_recon_inter"), "intra": t("k_intra_band"), "deblock": t("k_deblock_band") + t("k_deblock_prep")}
             raw_pic = {"inter": r("k_recon_inter"), "intra": r("k_intra_band"), "deblock": r("k_deblock_band") + r("k_deblock_prep")}
@@ -426,7 +439,8 @@ def main():
             frames_checked += len(want[i])
             if not ok:
                 bad = next((k for k in range(min(len(want[i]), len(check_digests[i]))) if want[i][k] != check_digests[i][k]), -1)
-                print(f"bench.py: rank {rank} stream {stream_ids[i]}: decoded frames differ from the CPU oracle (first bad frame {bad}, got {len(check_digests[i])} frames, oracle {len(want[i])})", file=sys.stderr)
+                print(f"bench.py: rank {rank} stream {stream_ids[i]}: decoded frames differ from the CPU oracle (first bad frame {bad}, got "
+                    f"{len(check_digests[i])} frames, oracle {len(want[i])})", file=sys.stderr)
         # a LATE IDR period too (the last one of the pass: frames F - period .. F - 1) of up to two streams: everything between the first period and the end
         # of a pass -- DPB reuse over many pictures, surfaces and job slots recycled, chain launches in steady state -- is otherwise only self-consistent
         n_late, late_note = 0, ""
@@ -444,7 +458,8 @@ def main():
                     print(f"bench.py: rank {rank} stream {stream_ids[i]}: IDR period {n_periods - 1} differs from the CPU oracle", file=sys.stderr)
             late_note = f"; the last IDR period (period {n_periods - 1}, frames {F - len(late)}..{F - 1}) of {n_late} handle(s) as well"
         check_note = (f"one extra pass of all {S} handles concurrently (same batching and output routes as the timed passes), every frame MD5'd; "
-                      f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle{late_note}; all {S} handles returned {F} frames")
+                      f"first IDR period ({len(want[0])} frames) of {n_oracle} handle(s) per rank compared with the CPU oracle{late_note}; all {S} handles "
+                      f"returned {F} frames")
     memtrace("check pass and oracle done")
     errors = sum(L.jm_amddec_get_stat(h, b"errors") for h in handles)
     job_slot_mb = round(sum(L.jm_amddec_get_stat(h, b"job_slot_bytes") for h in handles) / 1048576.0, 1)      # page-locked job buffers of all handles, as grown
@@ -452,7 +467,8 @@ def main():
     numa_node = int(L.jm_amddec_get_stat(handles[0], b"numa_node"))
     for i, h in enumerate(handles):
         if L.jm_amddec_get_stat(h, b"errors"):
-            print(f"bench.py: rank {rank} stream {stream_ids[i]}: {L.jm_amddec_get_stat(h, b'errors')} decode error(s), last: {L.jm_amddec_last_error(h).decode()!r}", file=sys.stderr)
+            print(f"bench.py: rank {rank} stream {stream_ids[i]}: {L.jm_amddec_get_stat(h, b'errors')} decode error(s), last: "
+                f"{L.jm_amddec_last_error(h).decode()!r}", file=sys.stderr)
         jmcodec_amd.jm_nvdec_deinit(h)
 
     # ---- untimed: ONE handle fed exactly like test_nv_dec.cpp:184-250 (the reference harness's own shape: one stream, one thread) ----
@@ -470,7 +486,8 @@ def main():
             L.jm_amddec_set_option(h, b"wait_idle", 1)
             sdt = time.perf_counter() - c0
             single = {"value": round(sp * F / sdt, 1), "unit": "frames/s", "frames": sp * F, "frames_returned_in_loop": int(n1),
-                      "note": "one jm_nvdec handle, one feeder thread, NAL-per-call, frame copied into the caller's buffer whenever got_frame == 1 (test_nv_dec.cpp:184-250); untimed extra leg"}
+                      "note": "one jm_nvdec handle, one feeder thread, NAL-per-call, frame copied into the caller's buffer whenever got_frame == 1 "
+                      "(test_nv_dec.cpp:184-250); untimed extra leg"}
         jmcodec_amd.jm_nvdec_deinit(h)
 
     # ---- untimed: the same S streams with DEVICE-RESIDENT output (jm_amddec_output_frame_device: frames stay in HBM, nothing crosses PCIe on the way
@@ -526,14 +543,18 @@ def main():
         # CPU baseline = the build's own scalar, spec-literal CPU oracle (NOT the reference's libmfx software path, which does not exist in this
         # image: BASELINE.md section 4).  B2: one oracle instance per stream on every core the container owns; B1: one instance on one core.
         cpu = {"value": round(oracle_frames / oracle_dt, 2), "unit": "frames/s", "cores": int(min(host_threads, max(n_oracle - 1, 1))), "kind": "port",
-               "sample": f"first IDR period ({len(want[0])} frames) of {n_oracle - first} of the benchmark's own {args.width}x{args.height} streams, one oracle instance per stream on "
-                         f"{min(host_threads, max(n_oracle - 1, 1))} threads, {oracle_dt:.1f} s wall (build CPU oracle: scalar, spec-literal; not libmfx) -- a label, not a bar",
-               "one_core": {"value": round(oracle_one[0] / oracle_one[1], 2), "unit": "frames/s", "cores": 1, "sample": f"{oracle_one[0]} frames of stream {stream_ids[0]}, {oracle_one[1]:.1f} s"} if oracle_one else None,
+               "sample": f"first IDR period ({len(want[0])} frames) of {n_oracle - first} of the benchmark's own {args.width}x{args.height} streams, one "
+               f"oracle instance per stream on "
+                         f"{min(host_threads, max(n_oracle - 1, 1))} threads, {oracle_dt:.1f} s wall (build CPU oracle: scalar, spec-literal; not libmfx) -- "
+                         f"a label, not a bar",
+               "one_core": {"value": round(oracle_one[0] / oracle_one[1], 2), "unit": "frames/s", "cores": 1, "sample": f"{oracle_one[0]} frames of stream "
+               f"{stream_ids[0]}, {oracle_one[1]:.1f} s"} if oracle_one else None,
                "host_cpus": os.cpu_count(), "quota_cpus": round(quota_cpus(), 2)}
 
     value = frames_total / dt_max
     line = {
-        "metric": "decoded frames/sec @1080p H.264 + bit-exact YUV" if args.codec == "h264" else f"decoded frames/sec HEVC {args.width}x{args.height} (diagnostic, SURVEY 8d C3)",
+        "metric": "decoded frames/sec @1080p H.264 + bit-exact YUV" if args.codec == "h264" else f"decoded frames/sec HEVC {args.width}x{args.height} "
+        f"(diagnostic, SURVEY 8d C3)",
         "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -545,11 +566,13 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP 28, deblock on) ") + f"{args.width}x{args.height}, "
+        "config": {"workload": (f"HEVC {tools_desc} + deblocking, IDR every 32, QP 32) " if args.codec == "hevc" else f"H.264 {tools_desc}, IDR every 30, QP "
+        f"28, deblock on) ") + f"{args.width}x{args.height}, "
                                f"{S} independent streams per GPU x {F} frames per step, NAL-per-call via jm_nvdec_* API, I420 out",
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "stream_ids": [stream_ids[0], stream_ids[-1]], "distinct_streams": len(set(datas)),
                    "bitstream_bytes_per_stream": int(sum(len(d) for d in datas) / S), "stream_generation_s": round(gen_s, 1),
-                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (one copy-engine transfer per frame from device staging, jmcodec_amd/csrc/host_copy.h)"},
+                   "host_parse_threads": int(threads), "includes": "host entropy decode + H2D + kernels + packout + D2H into the caller's buffer (one "
+                   "copy-engine transfer per frame from device staging, jmcodec_amd/csrc/host_copy.h)"},
         "frames": frames_total,
         "bit_exact": bit_exact, "frames_checked": int(frames_checked), "bit_exact_check": check_note,
         "decode_errors": int(errors),
@@ -558,25 +581,33 @@ def main():
                      "cpu_ms_per_frame": round(1e3 * (hc1["cpu_s"] - hc0["cpu_s"]) / max(frames_local, 1), 4),
                      "quota_cpus": hc1.get("quota_cpus"), "online_cpus": os.cpu_count(),
                      "throttled_ms": round((hc1.get("throttled_usec", 0) - hc0.get("throttled_usec", 0)) / 1e3, 1), "by_thread": by_thread,
-                     "calling_threads": {"cpu_ms_per_frame": round(1e3 * sum(feeder_cpu) / max(frames_local, 1), 4), "busiest_thread_share_of_wall": round(max(feeder_cpu) / dt, 3),
-                                         "note": "the S threads that call jm_nvdec_decode_frame / jm_nvdec_output_frame (NAL handling, slice headers, DPB, the frame copy); 1.0 = a handle's own thread is what bounds it"},
+                     "calling_threads": {"cpu_ms_per_frame": round(1e3 * sum(feeder_cpu) / max(frames_local, 1), 4),
+                     "busiest_thread_share_of_wall": round(max(feeder_cpu) / dt, 3),
+                                         "note": "the S threads that call jm_nvdec_decode_frame / jm_nvdec_output_frame (NAL handling, slice headers, DPB, "
+                                         "the frame copy); 1.0 = a handle's own thread is what bounds it"},
                      "cpu_needed_for_8_gpus": round(8 * (hc1["cpu_s"] - hc0["cpu_s"]) / dt, 1),
                      "note": "rank 0, timed region; when cpus_busy sits at quota_cpus the host half (entropy decode) bounds the rate; "
                              "cpu_needed_for_8_gpus = 8 x cpus_busy is what an 8-rank run of this rate would need from the node"},
         "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 6), "traffic": traffic, "traffic_raw": traffic_raw,
                      "traffic_file": traffic_file,
-                     "traffic_note": "HBM bytes per launch from PMC counters (traffic_file: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this codec / tool set / size, per picture) x "
-                                     "pictures per launch of THIS run; traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide coalesced reads, an "
+                     "traffic_note": "HBM bytes per launch from PMC counters (traffic_file: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this codec / "
+                     "tool set / size, per picture) x "
+                                     "pictures per launch of THIS run; traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for wide "
+                                     "coalesced reads, an "
                                      "upper estimate for these access shapes), traffic_raw = FETCH_SIZE + WRITE_SIZE as counted",
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
-        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms, "formation": form_stat, "direct_output": direct_stat,
+        "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms,
+        "formation": form_stat, "direct_output": direct_stat,
                    "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2]),
                    "chain_recoveries_whole_run": int(chain_stat[3]), "gpu_shared_with_another_process": bool(chain_stat[4])},
-        "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 54.0, "unit": "GB/s", "frac": round(value / world * frame_bytes / 1e9 / 54.0, 4),
-                     "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> caller's buffer); peak = device->host "
-                             "rate measured on this platform with three SDMA engines in turn, four copies in flight (tools/sdma_probe.cpp, profiles/r02_sdma_probe.txt: 54.0 GB/s = 17.4 k frames/s of 1080p; two engines 52.5, one 47); "
+        "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 54.0, "unit": "GB/s",
+        "frac": round(value / world * frame_bytes / 1e9 / 54.0, 4),
+                     "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> "
+                     "caller's buffer); peak = device->host "
+                             "rate measured on this platform with three SDMA engines in turn, four copies in flight (tools/sdma_probe.cpp, "
+                             "profiles/r02_sdma_probe.txt: 54.0 GB/s = 17.4 k frames/s of 1080p; two engines 52.5, one 47); "
                              "achieved = frames/s x frame bytes per GPU"},
         "kernels": {("k_" + k): {"launches": int(tot_n[k]), "avg_us": round(avg_s[k] * 1e6, 2), "pictures_per_launch": round(tot_pics[k] / max(tot_n[k], 1), 2),
                                  "alg_GBps": round(alg[k] / avg_s[k] / 1e9, 2) if avg_s[k] > 0 else None} for k in names},
@@ -597,7 +628,8 @@ def main():
         mem["needed_for_8_gpus_mb"] = round(8 * mem["peak_rss_mb"], 0)
         mem["job_slots_mb"] = job_slot_mb
         mem["job_slots_grown"] = job_regrown
-        mem["note"] = "peak_rss_mb includes the Python / torch runtime and the untimed oracle check; job_slots_mb = page-locked job buffers of this rank's handles (grown on demand from ordinary-picture size)"
+        mem["note"] = ("peak_rss_mb includes the Python / torch runtime and the untimed oracle check; job_slots_mb = page-locked job buffers of this "
+                       "rank's handles (ordinary-picture size; three worst-case buffers per handle are lent to I pictures)")
         line["host_memory"] = mem
     except Exception:
         pass

@@ -75,7 +75,8 @@ int chain_resident_workgroups(bool intra) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     const int depth = deblock_depth();
     hipError_t e = depth <= 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<2>, 256, 0)
-                 : depth == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<3>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<4>, 256, 0);
+                 : depth == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<3>, 256,
+                     0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<4>, 256, 0);
     return e == hipSuccess ? per_cu * prop.multiProcessorCount : 0;
 }
 

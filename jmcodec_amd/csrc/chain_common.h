@@ -42,7 +42,8 @@ __device__ __forceinline__ bool wait_expired(int spins, uint32_t &t0) {         
     return now - t0 > kWaitTicks;
 }
 enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16,
-               CHAIN_ERR_NOT_RECOVERED = 32 };   // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
+               // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
+               CHAIN_ERR_NOT_RECOVERED = 32 };
 
 typedef __attribute__((address_space(1))) int gint;
 
@@ -94,7 +95,8 @@ __device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &know
         }
         if (!__builtin_amdgcn_ballot_w64(pending)) return true;
         if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // gave up: do not wait again
-        if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);                // a band may be resident long before its rows are reconstructed
+        // a band may be resident long before its rows are reconstructed
+        if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
     }
 }
 // the same for a step counter (`fin` of the intra wavefront): wait until *ctr >= need

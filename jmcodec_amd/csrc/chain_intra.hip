@@ -52,7 +52,8 @@ int chain_intra_resident_workgroups() {
     int per_cu = 0, dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     const bool d2 = deblock_depth() <= 2;
-    if ((d2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<3>, 256, 0)) != hipSuccess) return 0;
+    if ((d2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_i<3>,
+        256, 0)) != hipSuccess) return 0;
     return per_cu * prop.multiProcessorCount;
 }
 

@@ -8,9 +8,6 @@
 #include "kernel_common.h"
 #include "chain_common.h"
 
-#ifndef JM_DBG_DEBLOCK
-#define JM_DBG_DEBLOCK 0          // timing experiments only (scratch/gpu_dbg_deblock.sh); results are wrong when set
-#endif
 namespace jmamd {
 
 struct DbRec {                 // 96 bytes per macroblock: 48 for the luma workgroup, 48 for the chroma workgroup
@@ -51,7 +48,6 @@ __device__ __forceinline__ s2 blend(uint32_t m, s2 a, s2 b) { return as_s2((as_u
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 // A, B, C are updated in place (D = p3 | q3 is only read); bsw = bS | tC0 << 3
 __device__ __forceinline__ void flt_luma(s2 &A, s2 &B, s2 &C, const s2 D, int bsw, int alpha, int beta) {
-    if (JM_DBG_DEBLOCK & 64) return;
     const int bS = bsw & 7, tc0 = bsw >> 3;
     const s2 As = swp(A), Bs = swp(B);
     const s2 beta2 = splat(beta);
@@ -158,7 +154,8 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
     uint32_t left_after, row_after[4];
     {
         const uint32_t w[5] = {left, own.x, own.y, own.z, own.w};
-        s2 A = as_s2(perm(w[1], w[0], 0x0c040c03)), B = as_s2(perm(w[1], w[0], 0x0c050c02)), C = as_s2(perm(w[1], w[0], 0x0c060c01)), D = as_s2(perm(w[1], w[0], 0x0c070c00));
+        s2 A = as_s2(perm(w[1], w[0], 0x0c040c03)), B = as_s2(perm(w[1], w[0], 0x0c050c02)), C = as_s2(perm(w[1], w[0], 0x0c060c01)),
+            D = as_s2(perm(w[1], w[0], 0x0c070c00));
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             if (e) {
@@ -196,8 +193,10 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
             const int k = e ? 1 : 2;
             flt_luma(A, B, C, D, hb[e], ab[2 * k], ab[2 * k + 1]);
             // rows 4e - 4 .. 4e - 1 of the column are final: the low halves of D, C, B, A (row 4e - 4 = p3 is never changed by this edge)
-            if (e == 0) { if (ring_up) { ring_up[1 * 16 + l] = (uint8_t)as_u(C); ring_up[2 * 16 + l] = (uint8_t)as_u(B); ring_up[3 * 16 + l] = (uint8_t)as_u(A); } }
-            else { const int r = 4 * e - 4; tc[r * 16 + l] = (uint8_t)as_u(D); tc[(r + 1) * 16 + l] = (uint8_t)as_u(C); tc[(r + 2) * 16 + l] = (uint8_t)as_u(B); tc[(r + 3) * 16 + l] = (uint8_t)as_u(A); }
+            if (e == 0) { if (ring_up) { ring_up[1 * 16 + l] = (uint8_t)as_u(C); ring_up[2 * 16 + l] = (uint8_t)as_u(B);
+                ring_up[3 * 16 + l] = (uint8_t)as_u(A); } }
+            else { const int r = 4 * e - 4; tc[r * 16 + l] = (uint8_t)as_u(D); tc[(r + 1) * 16 + l] = (uint8_t)as_u(C);
+                tc[(r + 2) * 16 + l] = (uint8_t)as_u(B); tc[(r + 3) * 16 + l] = (uint8_t)as_u(A); }
         }
         // rows 12 .. 15: the high halves of edge 3 -- into the tile and, as the rows the macroblock below starts from, into this row's ring slot
         const uint8_t r12 = (uint8_t)(as_u(A) >> 16), r13 = (uint8_t)(as_u(B) >> 16), r14 = (uint8_t)(as_u(C) >> 16), r15 = (uint8_t)(as_u(D) >> 16);
@@ -205,7 +204,6 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
         ring_dn[0 * 16 + l] = r12; ring_dn[1 * 16 + l] = r13; ring_dn[2 * 16 + l] = r14; ring_dn[3 * 16 + l] = r15;
     }
     // ---- store the final (-4,-4)-shifted 16x16 block: lane -> row R = l - 4 ----
-    if (JM_DBG_DEBLOCK & 32) return;
     gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 16, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
@@ -288,7 +286,6 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
         ring_dn[l] = (uint8_t)c[8]; ring_dn[16 + l] = (uint8_t)c[9];
     }
     // ---- store the (-2 px, -2 rows)-shifted 8 x 16-byte block: lanes 0..7 -> row R = l - 2 ----
-    if (JM_DBG_DEBLOCK & 32) return;
     gbyte *dst = pp.plane;
     int x0 = x * 16, y0 = row * 8, pitch = pp.pitch;
     bool right = x == pp.mb_w - 1, bottom = row == pp.mb_h - 1;
@@ -316,7 +313,8 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
 
 // ------------------------------------------------------------------------------------------
 // A plane is cut into bands of kBandRows macroblock rows, one 4-wave workgroup (one wave per SIMD) per band, all bands of all pictures
-// resident at once (the first form of this kernel walked a whole plane with ONE 16-wave workgroup and needed 159 KB of LDS).  A band runs the same steps s = x + 2 * row for its own rows; the only
+// resident at once (the first form of this kernel walked a whole plane with ONE 16-wave workgroup and needed 159 KB of LDS). A band runs the same steps s = x +
+// 2 * row for its own rows; the only
 // coupling is downwards: the last row of a band hands the bottom four sample rows of each macroblock (after its own filtering, i.e. the
 // state clause 8.7 prescribes when the macroblock below starts) to the first row of the next band.  They travel through the picture
 // surface itself (the band below overwrites them with the final values afterwards) and a per-band step counter in device memory:
@@ -342,13 +340,19 @@ constexpr int kDeblockSmemBytes = kDeblockSmemMain + (kBandRows / 4) * kDeblockM
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
 template <bool COHERENT> __device__ __forceinline__ void glds16(const gbyte *g, uint32_t lds_byte_addr) {
     unsigned keep;
-    if (COHERENT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
-    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    if (COHERENT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g),
+        "s"(lds_byte_addr) : "memory");
 }
 template <bool COHERENT> __device__ __forceinline__ void glds4(const gbyte *g, uint32_t lds_byte_addr) {
     unsigned keep;
-    if (COHERENT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
-    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    if (COHERENT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g),
+        "s"(lds_byte_addr) : "memory");
 }
 // One 256-thread workgroup deblocks band `band` of one plane of picture pp.  prog = the picture's band step counters of the ring-row hand-over
 // (kDeblockProgressStride ints).  CHAIN (k_chain): `cpic` = the picture's block of the chain buffer; the unfiltered samples come from
@@ -356,12 +360,11 @@ template <bool COHERENT> __device__ __forceinline__ void glds4(const gbyte *g, u
 // and the band publishes in cpic[kChainFin ..] how many of its steps are final in memory.
 // AFTER_INTRA (k_chain_i only): the picture's unfiltered samples come from an intra wavefront of the same launch (see wait_recon below)
 template <int DEPTH, bool CHAIN, bool AFTER_INTRA = false>
-__device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band, bool is_chroma, int *prog_pic, int pub, uint8_t *smem, int *cpic, int *err_word) {
+__device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band, bool is_chroma, int *prog_pic, int pub, uint8_t *smem, int *cpic,
+    int *err_word) {
     const int mb_w = pp.mb_w, mb_h = pp.mb_h, pitch = pp.pitch;
     const int row0 = band * kBandRows;
     if (row0 >= mb_h) return;
-    if ((JM_DBG_DEBLOCK & 1) && is_chroma) return;
-    if ((JM_DBG_DEBLOCK & 2) && !is_chroma) return;
     const int rows = min(kBandRows, mb_h - row0);
     int *prog = prog_pic + (is_chroma ? kDeblockMaxBands : 0);
     const gbyte *recs = (const gbyte *)pp.dbrec;
@@ -379,13 +382,13 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const bool gives_ring = active && group == rows - 1 && row < mb_h - 1;  // last row of a band that has a band below
     const int s_begin = 2 * row0, s_end = mb_w - 1 + 2 * (row0 + rows - 1);
     int known = 0;                                                          // steps the band above is known to have completed
-    int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;   // launch-wide: a wait of this launch gave up (chain_common.h)
+    // launch-wide: a wait of this launch gave up (chain_common.h)
+    int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
     // Hand-over protocol without cache maintenance: the ring rows and the counter are written and read with agent-scope relaxed atomics
     // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
     auto wait_above = [&](int need) {
-        if (JM_DBG_DEBLOCK & 16) return;
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
         int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
@@ -410,9 +413,11 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         if (!CHAIN) return;
         const bool want = active && x >= 0 && x < mb_w;
         bool ok;
-        if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word) && wait_counter(ifin1, ifin_known1, want, need, abort_word); }
+        if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word) &&
+            wait_counter(ifin1, ifin_known1, want, need, abort_word); }
         else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word);
-        if (!ok && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, after_intra ? CHAIN_ERR_IFIN_TIMEOUT : CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); }
+        if (!ok && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, after_intra ? CHAIN_ERR_IFIN_TIMEOUT : CHAIN_ERR_BITS_TIMEOUT);
+            st_coh(abort_word, 1); }
     };
     const int ring_lanes = ring_rows * 4;                                   // one dword per lane: ring row l >> 2, dword l & 3
     const int ring_lane = l < ring_lanes ? l : 0;
@@ -437,7 +442,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         int k = l - lane0;
         if (k < 0 || k >= ring_lanes) return;
         uint32_t v = *(const uint32_t *)(ring + (k >> 2) * 16 + (k & 3) * 4);
-        __hip_atomic_store((JM_GLOBAL uint32_t *)(plane + (size_t)((row + 1) * rows_per_mb - ring_rows + (k >> 2)) * pitch + xm * 16) + (k & 3), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((JM_GLOBAL uint32_t *)(plane + (size_t)((row + 1) * rows_per_mb - ring_rows + (k >> 2)) * pitch + xm * 16) + (k & 3), v,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto step = [&](int s, uint4 own, uint32_t rdw, uint32_t ring) {
         const int x = s - 2 * row;
@@ -445,14 +451,14 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             if (is_chroma) {
                 if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
                 chroma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring && !(JM_DBG_DEBLOCK & 8)) {
+                if (gives_ring) {
                     if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
                     if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
                 }
             } else {
                 if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
                 luma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring && !(JM_DBG_DEBLOCK & 8)) {
+                if (gives_ring) {
                     if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
                     if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
                 }
@@ -463,7 +469,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         // out before its stores), operations retire in order, so "at most 3 * kPubLag outstanding" proves those stores acknowledged.  The band below
         // sees the counter kPubLag steps late; it runs some thirty steps behind anyway.
         constexpr int kPubLag = 3;
-        if (!(JM_DBG_DEBLOCK & 8) && gives_ring && pub > 0 && s - kPubLag >= s_begin && ((s - kPubLag + 1 - s_begin) % pub == 0)) {      // pub <= 0: debug option "debug_stall" -- the counter never advances
+        // pub <= 0: debug option "debug_stall" -- the counter never advances
+        if (gives_ring && pub > 0 && s - kPubLag >= s_begin && ((s - kPubLag + 1 - s_begin) % pub == 0)) {
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPubLag) : "memory");
             if (l == 0) __hip_atomic_store(&prog[band], s - kPubLag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -475,9 +482,10 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             // `fin`: how many steps have their final samples in memory, published two steps late by the same counting argument: every wave has issued
             // the six loads of the steps s - 1 and s since its stores of step s - 2.
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
         } else
-        { if (JM_DBG_DEBLOCK & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     static_assert(DEPTH >= 2 && DEPTH <= kDeblockMaxDepth, "prefetch depth");
     wait_above(s_begin + DEPTH);

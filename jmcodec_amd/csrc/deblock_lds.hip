@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kBandRows * 16) void k_deblock_band(const PicParams
     __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes];
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_DEBLOCK_LDS)) return;
-    deblock_band_body<DEPTH, false>(pp, blockIdx.x >> 1, blockIdx.x & 1, ctl + (size_t)blockIdx.y * kChainStride + kChainRing, pub, smem, nullptr, err + blockIdx.y);
+    deblock_band_body<DEPTH, false>(pp, blockIdx.x >> 1, blockIdx.x & 1, ctl + (size_t)blockIdx.y * kChainStride + kChainRing, pub, smem, nullptr,
+        err + blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------

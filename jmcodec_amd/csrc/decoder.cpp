@@ -34,7 +34,8 @@ int thread_budget() {
         // visible CPU then only buys throttling stalls.  Size the pool to the quota, with headroom for workers blocked on job slots.
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long q = 0, per = 0; char qs[32] = {0};
-            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); int lim = (int)((q * 7 / 4 + per - 1) / per); if (lim < 4) lim = 4; if (n > lim) n = lim; }
+            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); int lim = (int)((q * 7 / 4 + per - 1) / per);
+                if (lim < 4) lim = 4; if (n > lim) n = lim; }
             fclose(f);
         }
     }
@@ -47,7 +48,8 @@ struct Pool {
     int n = 0, node = -1; bool bound = false;
     Pool(int node_, int n_) : n(n_), node(node_) {
         bound = !numa_cpus_of_node(node).empty();
-        for (int i = 0; i < n; i++) threads.emplace_back([this] { pthread_setname_np(pthread_self(), "jm-parse"); if (bound) numa_bind_this_thread(node); run(); });
+        for (int i = 0; i < n; i++) threads.emplace_back([this] { pthread_setname_np(pthread_self(),
+            "jm-parse"); if (bound) numa_bind_this_thread(node); run(); });
         for (auto &t : threads) t.detach();
     }
     void run() {
@@ -80,7 +82,8 @@ std::atomic<int> g_handle_counter{0};
 std::atomic<int> g_handle_index{0};
 }  // namespace
 
-void pool_submit(Decoder *d, PicTask *t) { Pool &p = pool_of_node(d->numa_node()); { std::lock_guard<std::mutex> lk(p.m); p.q.emplace_back(d, t); } p.cv.notify_one(); }
+void pool_submit(Decoder *d, PicTask *t) { Pool &p = pool_of_node(d->numa_node()); { std::lock_guard<std::mutex> lk(p.m); p.q.emplace_back(d, t); }
+    p.cv.notify_one(); }
 int pool_threads(int node) { return pool_of_node(node).n; }
 
 // =============================================================================================
@@ -97,7 +100,12 @@ Decoder::~Decoder() {
     delete eng_state_;
     if (trace_on_ && !trace_.empty()) {
         char name[256]; snprintf(name, sizeof name, "%s.%p.csv", getenv("JM_AMD_DEC_TRACE"), (void *)this);
-        if (FILE *f = fopen(name, "w")) { fprintf(f, "seq,is_i,dispatch,parsed,submit0,submit1\n"); for (auto &r : trace_) fprintf(f, "%llu,%d,%lld,%lld,%lld,%lld\n", (unsigned long long)r.seq, r.is_i, r.t_dispatch, r.t_parsed, r.t_submit0, r.t_submit1); fclose(f); }
+        if (FILE *f = fopen(name, "w")) {
+            fprintf(f, "seq,is_i,dispatch,parsed,submit0,submit1\n");
+            for (auto &r : trace_)
+                fprintf(f, "%llu,%d,%lld,%lld,%lld,%lld\n", (unsigned long long)r.seq, r.is_i, r.t_dispatch, r.t_parsed, r.t_submit0, r.t_submit1);
+            fclose(f);
+        }
     }
 }
 
@@ -126,7 +134,8 @@ int Decoder::set_option(const char *key, long long v) {
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
     else if (k == "display_delay") display_delay_ = (int)std::max(0ll, std::min(v, (long long)kJobSlots - 4));
     else if (k == "fast_parse") fast_parse_ = v != 0;        // 0: the general macroblock path only (tests)
-    else if (k == "job_digest") { want_job_digest_ = v != 0; if (want_job_digest_) sync_mode_ = true; }      // tests: FNV-1a over every picture's job list as the device gets it
+    // tests: FNV-1a over every picture's job list as the device gets it
+    else if (k == "job_digest") { want_job_digest_ = v != 0; if (want_job_digest_) sync_mode_ = true; }
     else if (k == "sync") sync_mode_ = v != 0;
     else if (k == "device_output") device_output_ = v != 0;        // frames stay in device memory (no D2H); see output_device()
     else if (k == "device") device_ = (int)v;
@@ -151,7 +160,8 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "errors") return stat_errors_;
     if (k == "copy_engines") return copier_ ? (long long)copier_->engine_mask() : 0;      // SDMA engines the direct route uses (bit mask)
     if (k == "direct_frames") return stat_direct_;
-    if (k == "direct_ns") return stat_direct_ns_;             // ... and the time their callers spent waiting for them             // frames that went out by the "direct" route (one DMA into the caller's registered buffer)
+    // ... and the time their callers spent waiting for them // frames that went out by the "direct" route (one DMA into the caller's registered buffer)
+    if (k == "direct_ns") return stat_direct_ns_;
     if (k == "device_wait_errors") return stat_wait_errors_;
     if (k == "intra_mbs") return stat_intra_mbs_;
     if (k == "coef_int16") return stat_coef_;
@@ -211,7 +221,8 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
     cavlc_init_tables();
-    if (parse_only_) numa_node_ = numa_node_of_device(device_ < 0 ? 0 : device_, false);      // (no HIP call: only the test override can place a parse-only handle)
+    // (no HIP call: only the test override can place a parse-only handle)
+    if (parse_only_) numa_node_ = numa_node_of_device(device_ < 0 ? 0 : device_, false);
     if (!parse_only_ && !gpu_open()) return -1;
     // Where a display frame waits for jm_nvdec_output_frame.  k_packout writes the tight frame into a device staging buffer of the output slot; then
     //   direct : (default) it stays there, and jm_nvdec_output_frame moves it into the caller's buffer with ONE copy-engine transfer on the ROCr layer
@@ -229,7 +240,8 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
         out_route_ = 3;                                                     // 0 auto (per frame), 1 always fetch, 2 always pinned, 3 direct
         if (getenv("JM_AMD_DEC_OUT_PINNED") || !out_via_copy_engine_) out_route_ = 2;
         else if (e && !strcmp(e, "auto")) out_route_ = 0;
-        else if (e && strcmp(e, "direct")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 2; fb = 5; } out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
+        else if (e && strcmp(e, "direct")) { if (sscanf(e, "%d/%d", &fa, &fb) != 2 || fb <= 0) { fa = 2; fb = 5; }
+            out_route_ = (handle_index_ % fb) < fa ? 1 : 2; }
         if (out_route_ == 3 && !parse_only_) {
             copier_ = HostCopier::get(device_);
             if (copier_) out_sig_ = copier_->new_signal();
@@ -296,7 +308,8 @@ bool Decoder::gpu_open() {
 void Decoder::free_job_buffers() {
     for (auto &j : jobs_) {
         if (j.big >= 0) { j.host = j.own_host; j.dev = j.own_dev; j.big = -1; }       // (a borrowed buffer is freed with the others below)
-        if (gpu_open_ && !parse_only_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec); if (j.resid) hipFree(j.resid); if (j.uploaded) hipEventDestroy(j.uploaded); }
+        if (gpu_open_ && !parse_only_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.dbrec) hipFree(j.dbrec);
+            if (j.resid) hipFree(j.resid); if (j.uploaded) hipEventDestroy(j.uploaded); }
         else free(j.host);
         j = JobSlot();
     }
@@ -372,9 +385,11 @@ bool Decoder::gpu_alloc_sequence() {
     lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
     chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
     chain_intra_on_ = !getenv("JM_AMD_DEC_NO_CHAIN_INTRA");
-    if (codec_ == 1) {                               // HEVC: kHevcWorkSets residual scratches and pre-SAO work surfaces per handle (H.264: a scratch per job slot)
+    // HEVC: kHevcWorkSets residual scratches and pre-SAO work surfaces per handle (H.264: a scratch per job slot)
+    if (codec_ == 1) {
         if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768 * kHevcWorkSets))) { fail("hipMalloc(scratch) failed"); return false; }
-        for (auto &w : hevc_work_) { if (!HIP_OK(hipMalloc((void **)&w, surf_bytes_))) { fail("hipMalloc(work surface) failed"); return false; } hipMemset(w, 128, surf_bytes_); }
+        for (auto &w : hevc_work_) { if (!HIP_OK(hipMalloc((void **)&w, surf_bytes_))) { fail("hipMalloc(work surface) failed"); return false; }
+            hipMemset(w, 128, surf_bytes_); }
     }
     NumaPreferred on_gpu_node(numa_node_);          // the page-locked job buffers (and output slots) of this handle: memory of the GPU's node
     for (auto &j : jobs_) {
@@ -383,7 +398,8 @@ bool Decoder::gpu_alloc_sequence() {
             !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
         j.cap = job_cap_;
     }
-    if (lend_big) for (auto &b : big_) if (!HIP_OK(hipHostMalloc((void **)&b.host, job_cap_max_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&b.dev, job_cap_max_))) { fail("job buffer allocation failed"); return false; }
+    if (lend_big) for (auto &b : big_) if (!HIP_OK(hipHostMalloc((void **)&b.host, job_cap_max_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&b.dev,
+        job_cap_max_))) { fail("job buffer allocation failed"); return false; }
     // output slots: allocate the steady-state population now (hipHostMalloc costs milliseconds and serialises
     // inside the runtime; it must never happen while pictures are in flight)
     {
@@ -409,7 +425,8 @@ OutSlot *Decoder::alloc_out_slot() {   // mtx_ held
     o->w = disp_w_; o->h = disp_h_;
     if (!parse_only_) {
         hipSetDevice(device_);
-        if (!device_output_ && out_route_ != 1 && out_route_ != 3 && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_, hipHostMallocDefault))) fail("output buffer allocation failed");
+        if (!device_output_ && out_route_ != 1 && out_route_ != 3 && !HIP_OK(hipHostMalloc((void **)&o->host, frame_bytes_,
+            hipHostMallocDefault))) fail("output buffer allocation failed");
         if ((out_via_copy_engine_ || device_output_) && !HIP_OK(hipMalloc((void **)&o->dev, frame_bytes_))) fail("output staging allocation failed");
         o->bytes = frame_bytes_;
     }
@@ -426,7 +443,8 @@ void Decoder::feed(const uint8_t *buf, size_t len) {
         // (a 4-byte length of 256..511 reads 00 00 01 xx, so the first bytes alone cannot tell the two forms apart: the packet is
         //  length-prefixed exactly when its length fields chain to its end)
         bool prefixed = false;
-        { size_t o = 0; while (o + (size_t)avcc_len_size_ <= len) { size_t l = 0; for (int i = 0; i < avcc_len_size_; i++) l = (l << 8) | buf[o + i]; o += (size_t)avcc_len_size_; if (l == 0 || l > len - o) { o = len + 1; break; } o += l; } prefixed = o == len; }
+        { size_t o = 0; while (o + (size_t)avcc_len_size_ <= len) { size_t l = 0; for (int i = 0; i < avcc_len_size_; i++) l = (l << 8) | buf[o + i];
+            o += (size_t)avcc_len_size_; if (l == 0 || l > len - o) { o = len + 1; break; } o += l; } prefixed = o == len; }
         if (prefixed) {
             size_t o = 0;
             while (o + (size_t)avcc_len_size_ <= len) {
@@ -601,7 +619,8 @@ int Decoder::compute_poc(const SliceHeader &sh) {                               
 }
 
 void Decoder::flush_dpb(std::vector<int> &out) {
-    if (codec_ == 1) { for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0; hevc_bump(out, true, true); for (int i = 0; i < n_surf_; i++) if (i != cur_ && !dpb_[i].wait_output) dpb_[i].in_use = false; return; }
+    if (codec_ == 1) { for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0; hevc_bump(out, true, true);
+        for (int i = 0; i < n_surf_; i++) if (i != cur_ && !dpb_[i].wait_output) dpb_[i].in_use = false; return; }
     for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
     for (;;) {
         int best = -1;
@@ -624,7 +643,8 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
     bool wait_pack = false;
     // Round robin over the free surfaces (starting behind the one chosen last), so that a surface is reused as LATE as possible: the engine
     // runs consecutive pictures of a stream in one launch only while none of them decodes into a surface an earlier one still reads or displays.
-    for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i; break; } if (warm < 0) warm = i; } }
+    for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i;
+        break; } if (warm < 0) warm = i; } }
     if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
     if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
         int best = -1;
@@ -729,7 +749,8 @@ void Decoder::build_ref_lists(const SliceHeader &sh, SliceTask &task) {
                 int w1 = 32;
                 if (rf.slot[0][i] >= 0 && rf.slot[1][j] >= 0 && !rf.is_long[0][i] && !rf.is_long[1][j]) {
                     int tb = std::clamp(rf.cur_poc - rf.poc[0][i], -128, 127), td = std::clamp(rf.poc[1][j] - rf.poc[0][i], -128, 127);
-                    if (td != 0) { int tx = (16384 + std::abs(td / 2)) / td, dsf = std::clamp((tb * tx + 32) >> 6, -1024, 1023) >> 2; if (dsf >= -64 && dsf <= 128) w1 = dsf; }
+                    if (td != 0) { int tx = (16384 + std::abs(td / 2)) / td, dsf = std::clamp((tb * tx + 32) >> 6, -1024, 1023) >> 2;
+                        if (dsf >= -64 && dsf <= 128) w1 = dsf; }
                 }
                 wp.imp_w1[i][j] = (uint8_t)(64 + w1);
             }
@@ -754,7 +775,8 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
         if (sh.long_term_reference) { cur.ref = 2; cur.lt_idx = 0; max_lt_idx_ = 0; } else { cur.ref = 1; max_lt_idx_ = -1; }
         return;
     }
-    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1) { p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; } }
+    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1) {
+        p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; } }
     bool made_long = false;
     if (sh.adaptive_marking) {
         for (int k = 0; k < sh.n_mark; k++) {
@@ -772,7 +794,8 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
                 case 6: if (p.ref == 2 && p.lt_idx == (int)m.b) p.ref = 0; break;
                 }
             }
-            if (m.op == 3) for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1 && p.pic_num == pic_num_x) { p.ref = 2; p.lt_idx = (int)m.b; } }
+            if (m.op == 3) for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1 && p.pic_num == pic_num_x) {
+                p.ref = 2; p.lt_idx = (int)m.b; } }
             if (m.op == 4) max_lt_idx_ = (int)m.a - 1;
             if (m.op == 5) { max_lt_idx_ = -1; cur.mmco5 = true; }
             if (m.op == 6) { cur.ref = 2; cur.lt_idx = (int)m.b; made_long = true; }
@@ -794,10 +817,23 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
 // display order (the YUV file only records ORDER; nv_dec.cpp:341 ulMaxDisplayDelay=2 only adds latency)
 void Decoder::bump_after_current(std::vector<int> &out) {
     DpbPic &cur = dpb_[cur_];
-    auto smallest = [&](int exclude) { int b = -1; for (int i = 0; i < n_surf_; i++) if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i; return b; };
-    if (cur.mmco5) { int b; while ((b = smallest(cur_)) >= 0) { out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; dpb_[b].out_at = decode_count_ - 1; } cur.poc = 0; cur.frame_num = 0; }
+    auto smallest = [&](int exclude) {
+        int b = -1;
+        for (int i = 0; i < n_surf_; i++)
+            if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i;
+        return b;
+    };
+    if (cur.mmco5) {
+        int b;
+        while ((b = smallest(cur_)) >= 0) {
+            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false;
+            dpb_[b].out_at = decode_count_ - 1;
+        }
+        cur.poc = 0; cur.frame_num = 0;
+    }
     int w = smallest(cur_);
-    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.out_at = decode_count_ - 1; cur.in_use = false; }
+    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.out_at = decode_count_ - 1;
+        cur.in_use = false; }
     else {
         cur.wait_output = true;
         for (;;) {
@@ -911,7 +947,8 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         const char *first_error = nullptr; bool overflow = false;
         for (size_t si = 0; si < t->slices.size(); si++) {
             SliceTask &s = t->slices[si];
-            srec[si].alpha_off = (int8_t)s.sh.alpha_off; srec[si].beta_off = (int8_t)s.sh.beta_off; srec[si].disable = (uint8_t)s.sh.disable_deblock; srec[si].pad = 0;
+            srec[si].alpha_off = (int8_t)s.sh.alpha_off; srec[si].beta_off = (int8_t)s.sh.beta_off; srec[si].disable = (uint8_t)s.sh.disable_deblock;
+            srec[si].pad = 0;
             if (s.sh.disable_deblock != 1) t->any_deblock = true;
             BitReader br(s.rbsp.data(), s.rbsp_len);
             br.set_end_from_trailing();
@@ -939,8 +976,10 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
                 const int x = dx + ox, y = dy + oy;
                 if (x < 0 || y < 0 || x >= t->sps.mb_w || y >= t->sps.mb_h || (oy == 0 && ox == 1)) continue;
                 const MbRec &m = mbs[y * t->sps.mb_w + x];
-                fprintf(stderr, "MB(%d,%d) kind %d flags 0x%02x modes 0x%02x qp %d slice %d cbp_blk 0x%04x i4 %02x%02x%02x%02x%02x%02x%02x%02x n_intra %d n_i8x8 %d slice_type %d\n", x, y, m.kind, m.flags, m.modes, m.qp, m.slice, m.cbp_blk,
-                        m.u.i4[0], m.u.i4[1], m.u.i4[2], m.u.i4[3], m.u.i4[4], m.u.i4[5], m.u.i4[6], m.u.i4[7], t->n_intra, t->n_i8x8, t->slices.empty() ? -1 : (int)t->slices[0].sh.type);
+                fprintf(stderr, "MB(%d,%d) kind %d flags 0x%02x modes 0x%02x qp %d slice %d cbp_blk 0x%04x i4 %02x%02x%02x%02x%02x%02x%02x%02x "
+                        "n_intra %d n_i8x8 %d slice_type %d\n", x, y, m.kind, m.flags, m.modes, m.qp, m.slice, m.cbp_blk,
+                        m.u.i4[0], m.u.i4[1], m.u.i4[2], m.u.i4[3], m.u.i4[4], m.u.i4[5], m.u.i4[6], m.u.i4[7], t->n_intra, t->n_i8x8,
+                            t->slices.empty() ? -1 : (int)t->slices[0].sh.type);
             }
         }
     }
@@ -961,8 +1000,10 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     {
         const size_t need = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4 + (t->any_wp ? t->slices.size() * sizeof(SliceWp) : 0) + 64;
         if (need > js.cap) {
-            if (!ensure_job_cap(js, std::min(need + need / 4, std::max(job_cap_max_, need)), fixed + (size_t)w.coef_count * 2)) fail("job buffer allocation failed");
-            else { mbs = (MbRec *)js.host; srec = (SliceRec *)(js.host + (size_t)n_mbs * sizeof(MbRec)); coef = (int16_t *)(srec + 256); w.mbs = mbs; w.coef = coef; stat_job_regrown_++; }
+            if (!ensure_job_cap(js, std::min(need + need / 4, std::max(job_cap_max_, need)),
+                fixed + (size_t)w.coef_count * 2)) fail("job buffer allocation failed");
+            else { mbs = (MbRec *)js.host; srec = (SliceRec *)(js.host + (size_t)n_mbs * sizeof(MbRec)); coef = (int16_t *)(srec + 256); w.mbs = mbs;
+                w.coef = coef; stat_job_regrown_++; }
         }
     }
     if (failed_) { w.mv_ext_count = 0; }
@@ -972,14 +1013,17 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     if (want_job_digest_) {                                  // (pictures are parsed in order: sync option)
         uint64_t h = job_digest_;
         auto eat = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
-        eat(mbs, (size_t)n_mbs * sizeof(MbRec)); eat(srec, t->slices.size() * sizeof(SliceRec)); eat(w.coef, (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4);
+        eat(mbs, (size_t)n_mbs * sizeof(MbRec)); eat(srec, t->slices.size() * sizeof(SliceRec));
+        eat(w.coef, (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4);
         const int mm = w.max_mvy; eat(&mm, sizeof mm);
         job_digest_ = h;
     }
-    if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++; t->any_wp = false; }
+    if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++;
+        t->any_wp = false; }
     if (t->any_wp) {
         t->wp_offset = t->upload_bytes;
-        for (auto &s : t->slices) { if (!s.has_wp) memset(&s.wp, 0, sizeof s.wp); memcpy(js.host + t->upload_bytes, &s.wp, sizeof(SliceWp)); t->upload_bytes += sizeof(SliceWp); }
+        for (auto &s : t->slices) { if (!s.has_wp) memset(&s.wp, 0, sizeof s.wp); memcpy(js.host + t->upload_bytes, &s.wp, sizeof(SliceWp));
+            t->upload_bytes += sizeof(SliceWp); }
     }
     stat_pictures_++; stat_job_bytes_ += (long long)t->upload_bytes; stat_intra_mbs_ += t->n_intra; stat_coef_ += w.coef_count;
     for (auto &s : t->slices) { std::vector<uint8_t>().swap(s.rbsp); }
@@ -1025,7 +1069,8 @@ void Decoder::submit_ready() {
         }
         long long ts0 = now_ns();
         submit_task(t.get());
-        if (trace_on_ && t->has_picture) trace_.push_back(TraceRec{t->seq, t->t_dispatch, t->t_parsed, ts0, now_ns(), (!t->slices.empty() && t->slices[0].sh.type == SL_I) ? 1 : 0});
+        if (trace_on_ && t->has_picture) trace_.push_back(TraceRec{t->seq, t->t_dispatch, t->t_parsed, ts0, now_ns(), (!t->slices.empty() &&
+            t->slices[0].sh.type == SL_I) ? 1 : 0});
     }
 }
 
@@ -1047,7 +1092,6 @@ void Decoder::submit_task(PicTask *t) {
     auto st0 = std::chrono::steady_clock::now();
     EnginePic ep;
     ep.dec = this; ep.has_picture = t->has_picture && !parse_only_ && !failed_; ep.job_slot = t->job_slot;
-    ep.p_lane = handle_index_ % kPLanes;
     ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
     for (int s : t->out_before) { enqueue_output(s, ep.out_before, ep.slots_before); ep.out_mask |= 1u << s; }
     memset(&ep.pp, 0, sizeof ep.pp);
@@ -1069,8 +1113,10 @@ void Decoder::submit_task(PicTask *t) {
         pp.wp = t->any_wp ? (const SliceWp *)(js.dev + t->wp_offset) : nullptr;
         {   // scaling matrices: transmitted in zig-zag order (7.3.2.1.1.1), the kernels index them in raster order
             static const uint8_t zz4[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
-            static const uint8_t zz8[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            static const uint8_t zz8[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+                28,
+                                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47,
+                                                55, 62, 63};
             bool flat = true;
             for (int i = 0; i < 6; i++) for (int k = 0; k < 16; k++) { pp.wscale4[i][zz4[k]] = t->pps.scaling4[i][k]; flat &= t->pps.scaling4[i][k] == 16; }
             for (int i = 0; i < 2; i++) for (int k = 0; k < 64; k++) { pp.wscale8[i][zz8[k]] = t->pps.scaling8[i][k]; flat &= t->pps.scaling8[i][k] == 16; }
@@ -1086,12 +1132,14 @@ void Decoder::submit_task(PicTask *t) {
         // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
         ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
         // Pictures WITH intra macroblocks -- the I picture of an IDR period, or a P picture with a few of them -- can join too: the intra wavefront then
-        // runs as a third role of the chain kernel (k_chain_i), whatever the share of intra macroblocks (the stage path uses the spin-wait kernel for sparse ones).
+        // runs as a third role of the chain kernel (k_chain_i), whatever the share of intra macroblocks (the stage path uses the spin-wait kernel for sparse
+        // ones).
         ep.chain_intra = chain_ok_ && chain_intra_on_ && t->n_intra > 0 && use_lds_intra_ && (t->n_i8x8 == 0 || lds_intra8_) && (pp.stages & PS_DEBLOCK_LDS);
         ep.classic_stages = pp.stages;
         for (auto &sl : t->slices) ep.bipred |= sl.refs.bipred_rec;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
-        for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |= 1u << sl.refs.slot[l][i];
+        for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |=
+            1u << sl.refs.slot[l][i];
         // algorithmic bytes of this picture per kernel class
         long long S = (long long)surf_bytes_;
         bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
@@ -1120,7 +1168,8 @@ void Decoder::on_engine_done(const EnginePic &p, bool failed) {
         std::lock_guard<std::mutex> lk(mtx_);
         if (p.job_slot >= 0) {
             JobSlot &j = jobs_[p.job_slot];
-            if (j.big >= 0) { big_[j.big].busy = false; j.host = j.own_host; j.dev = j.own_dev; j.cap = j.own_cap; j.big = -1; }     // the borrowed I-picture buffer goes back
+            // the borrowed I-picture buffer goes back
+            if (j.big >= 0) { big_[j.big].busy = false; j.host = j.own_host; j.dev = j.own_dev; j.cap = j.own_cap; j.big = -1; }
             j.busy = false;
         }
         for (OutSlot *o : p.slots_before) { o->ready = true; if (failed) o->has_data = false; }
@@ -1205,7 +1254,8 @@ int Decoder::output(uint8_t *out, int *out_len) {
     int need = cur_out_->w * cur_out_->h * 3 / 2;
     if (*out_len < need) return -2;
     *out_len = 0;
-    if (cur_out_->has_data && cur_out_->host && !cur_out_->fetch) memcpy(out, cur_out_->host, (size_t)need);     // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
+    // (streaming stores were slower than glibc's copy on Zen 5: 10.4 k vs 11.4 k frames/s)
+    if (cur_out_->has_data && cur_out_->host && !cur_out_->fetch) memcpy(out, cur_out_->host, (size_t)need);
     else if (cur_out_->has_data) {
         // The frame waits in device staging.  Route "direct" (host_copy.h): one copy-engine transfer into the caller's buffer, this thread asleep
         // meanwhile.  The buffer is page-locked for the duration of this call only (1.2-1.4 us per lock / unlock pair, tools/sdma_probe.cpp): a lock kept

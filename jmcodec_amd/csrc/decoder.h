@@ -77,15 +77,19 @@ struct PicTask {
 
 struct JobSlot {                       // one picture's job list: pinned host buffer (parse target) + its device copy
     uint8_t *host = nullptr, *dev = nullptr; size_t cap = 0;
-    uint8_t *resid = nullptr;          // device scratch: int16 residual of this picture's intra macroblocks (768 B per macroblock), per slot for the same reason
-    uint8_t *dbrec = nullptr;          // device scratch of k_deblock_prep for this picture (96 B per macroblock): per slot, because pictures of a chain run concurrently
+    // device scratch: int16 residual of this picture's intra macroblocks (768 B per macroblock), per slot for the same reason
+    uint8_t *resid = nullptr;
+    // device scratch of k_deblock_prep for this picture (96 B per macroblock): per slot, because pictures of a chain run concurrently
+    uint8_t *dbrec = nullptr;
     ihipEvent_t *uploaded = nullptr;   // recorded behind the H2D copy on the engine's copy stream
     bool busy = false;                 // from dispatch until the engine reports the picture done
     int big = -1;                      // >= 0: host / dev / cap are those of borrowed big buffer `big` (an I picture); the slot's own are kept below
     uint8_t *own_host = nullptr, *own_dev = nullptr; size_t own_cap = 0;
 };
-constexpr int kHevcWorkSets = 4;       // HEVC pictures of one handle that may share a batch (independent B pictures of a pyramid): each needs its own pre-SAO work surface and residual scratch
-constexpr int kBigJobBufs = 3;         // worst-case-sized job buffers per H.264 handle, lent to I pictures (one in thirty pictures of config C1; two in flight at most)
+// HEVC pictures of one handle that may share a batch (independent B pictures of a pyramid): each needs its own pre-SAO work surface and residual scratch
+constexpr int kHevcWorkSets = 4;
+// worst-case-sized job buffers per H.264 handle, lent to I pictures (one in thirty pictures of config C1; two in flight at most)
+constexpr int kBigJobBufs = 3;
 struct BigJobBuf { uint8_t *host = nullptr, *dev = nullptr; bool busy = false; };
 struct OutSlot {                       // one display frame in pinned host memory, written by k_packout
     uint8_t *host = nullptr;
@@ -171,7 +175,8 @@ private:
     // configuration
     int codec_ = 0, out_fmt_ = 1, device_ = -1, handle_index_ = 0, last_surf_ = -1, out_route_ = 0, fetch_limit_ = 1;
     bool chain_ok_ = false, chain_intra_on_ = true;
-    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false, out_fetch_ = true;
+    bool parse_only_ = false, want_digest_ = false, sync_mode_ = false, profile_ = false, out_via_copy_engine_ = true, device_output_ = false,
+        out_fetch_ = true;
     std::string error_, error_out_; std::mutex error_m_;     // error_out_: what last_error() last handed out (see there)
     std::atomic<bool> failed_{false}; bool inited_ = false;
 
@@ -215,7 +220,8 @@ private:
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
-    uint8_t *hevc_work_[kHevcWorkSets] = {nullptr, nullptr, nullptr, nullptr}; unsigned hevc_work_rr_ = 0;   // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)
+    // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)
+    uint8_t *hevc_work_[kHevcWorkSets] = {nullptr, nullptr, nullptr, nullptr}; unsigned hevc_work_rr_ = 0;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;
@@ -232,7 +238,8 @@ private:
     // output route "direct" (host_copy.h)
     std::atomic<long long> stat_direct_{0}, stat_direct_ns_{0};
     HostCopier *copier_ = nullptr; uint64_t out_sig_ = 0;
-    int display_delay_ = 0;                    // a frame goes out only while this many pictures of the handle are still on their way (option "display_delay", JM_AMD_DEC_DISPLAY_DELAY)
+    // a frame goes out only while this many pictures of the handle are still on their way (option "display_delay", JM_AMD_DEC_DISPLAY_DELAY)
+    int display_delay_ = 0;
     uint64_t job_digest_ = 1469598103934665603ull;    // option "job_digest" (tests)
     // HEVC state (front end only unless noted)
     HevcParamSets hps_; HevcSps hsps_; HevcPps hpps_;

@@ -31,7 +31,6 @@ Engine *Engine::get(int device) {
 Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
-    if (const char *e = getenv("JM_AMD_DEC_LANE_SPLIT")) lane_split_ = atoi(e) != 0;
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
@@ -69,7 +68,9 @@ Engine::Engine(int device) : device_(device) {
     { const int r = chain_resident_workgroups(false), ri = chain_resident_workgroups(true);
       if (r > 0) chain_bands_max_ = std::min(kMaxChainBands, r / 2);
       if (ri > 0) chain_bands_max_intra_ = std::min(kMaxChainBandsIntra, ri / 2);
-      if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_, chain_bands_max_intra_); }
+      if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr,
+          "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_,
+          chain_bands_max_intra_); }
     ok_ = true;
     numa_node_ = numa_node_of_device(device_, true);
     kfd_gpu_id_ = getenv("JM_AMD_DEC_IGNORE_SHARED_GPU") ? 0 : kfd_gpu_id_of_device(device_);
@@ -119,11 +120,12 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     // its stream's ordinary lane, where it becomes the first picture of a chain (k_chain_i), instead of going to the intra lane
     // The regime follows the number of ACTIVE streams (handles that submitted a picture in the last 50 ms), not the number that happen to have a picture
     // pending right now: with 20 or 32 streams the pending set dips below the threshold now and then, and a stream may only change lane once its pictures
-    // in flight have retired.  Few streams: chain launches on lane 0.  Many: stage kernels on both ordinary lanes, the streams split by handle parity.
-    bool chaining = false, split = false;
+    // in flight have retired.  Few streams: chain launches.  Many: stage kernels, one batch across all streams.
+    bool chaining = false;
     {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *, long long> &r) { return now - r.second > 50ll * 1000 * 1000; }), recent_.end());
+        recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *,
+            long long> &r) { return now - r.second > 50ll * 1000 * 1000; }), recent_.end());
         const int n_active = (int)recent_.size();
         // A chain launch needs the whole GPU (its waits assume its bands stay resident, chain.hip).  When another process has compute queues on this
         // device -- a second rank of the same job, another tenant -- no chain launches are formed at all, instead of letting them time out against the
@@ -131,11 +133,11 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         if (kfd_gpu_id_ && now - shared_checked_ns_ > 1000ll * 1000 * 1000) {
             shared_checked_ns_ = now;
             const bool sh = kfd_gpu_has_other_users(kfd_gpu_id_);
-            if (sh != gpu_shared_) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_, sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
+            if (sh != gpu_shared_) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_,
+                sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
             gpu_shared_ = sh;
         }
         chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
-        split = !chaining && lane_split_ && n_active > chain_max_streams_;
     }
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
@@ -149,27 +151,31 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
         EngineDecoderState &es = d->engine_state();
-        bool ok = it->lane(chaining, split) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        bool ok = it->lane(chaining) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
         // the pack-job tables hold 2 * kMaxBatch entries each: a picture whose display frames no longer fit waits for the next batch
         // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
         if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
         if (!ok) { ++it; continue; }
         es.lane = lane_idx; es.inflight++;
-        es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false; es.batch_resid = it->has_picture && it->codec == 0 && (it->pp.stages & (PS_INTRA_LDS | PS_INTRA_V1)) != 0;
+        es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false;
+        es.batch_resid = it->has_picture && it->codec == 0 && (it->pp.stages & (PS_INTRA_LDS | PS_INTRA_V1)) != 0;
         account(*it, es);
         members.push_back(d);
         b.pics.push_back(std::move(*it));
         it = pending_.erase(it);
     }
     if (b.pics.empty()) return false;
-    if (lane_idx < kPLanes) { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size(); st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
+    if (lane_idx == kOrdinaryLane) { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size();
+        st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
     // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
     // workgroups the GPU holds (chain.hip), and its work list must fit the table
-    auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16); groups = p.mb_h * ((p.mb_w + 7) / 8) + 2 * ((p.mb_h + 15) / 16); };
+    auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16);
+        groups = p.mb_h * ((p.mb_w + 7) / 8) + 2 * ((p.mb_h + 15) / 16); };
     int tot_bands = 0, tot_groups = 0; bool any_intra = false;
-    for (auto &p : b.pics) if (p.has_picture && (p.chain_ok || p.chain_intra)) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng; any_intra |= p.chain_intra; }
+    for (auto &p : b.pics) if (p.has_picture && (p.chain_ok || p.chain_intra)) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng;
+        any_intra |= p.chain_intra; }
     auto band_limit = [&](bool intra) { return intra ? chain_bands_max_intra_ : chain_bands_max_; };
-    if (lane_idx < kPLanes && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) && tot_groups <= kMaxChainGroups) {
+    if (lane_idx == kOrdinaryLane && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) && tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
         const int depth_cap = std::min(chain_depth_.load(), std::max(1, kMaxBatch / (int)members.size()));
@@ -181,7 +187,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
                 // the next picture joins only if it runs inside k_chain, packs nothing BEFORE the kernels (such frames may not be decoded yet),
                 // and decodes into a surface that no earlier picture of this decoder in the batch writes, references or displays
-                const bool ok = it != pending_.end() && it->lane(true, false) == lane_idx && it->has_picture && (it->chain_ok || it->chain_intra) &&
+                const bool ok = it != pending_.end() && it->lane(true) == lane_idx && it->has_picture && (it->chain_ok || it->chain_intra) &&
                                 it->out_before.empty() && !it->wait_prev_pack &&
                                 !((1u << it->pp.cur) & (es.batch_written | es.batch_read)) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch;
                 int nb = 0, ng = 0;
@@ -208,8 +214,10 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             EngineDecoderState &es = d->engine_state();
             while (es.in_batch < kHevcWorkSets && (int)b.pics.size() < kMaxBatch) {
                 auto it = std::find_if(pending_.begin(), pending_.end(), [&](const EnginePic &p) { return p.dec == d; });
-                if (it == pending_.end() || !it->has_picture || it->codec != 1 || it->lane(false, false) != lane_idx || !it->out_before.empty() || it->wait_prev_pack) break;
-                if ((it->ref_mask & es.batch_written) || ((1u << it->hp.cur) & (es.batch_written | es.batch_read)) || n_post + it->out_after.size() > (size_t)2 * kMaxBatch) break;
+                if (it == pending_.end() || !it->has_picture || it->codec != 1 || it->lane(false) != lane_idx || !it->out_before.empty() ||
+                    it->wait_prev_pack) break;
+                if ((it->ref_mask & es.batch_written) || ((1u << it->hp.cur) & (es.batch_written | es.batch_read)) ||
+                    n_post + it->out_after.size() > (size_t)2 * kMaxBatch) break;
                 es.inflight++; es.in_batch++;
                 es.batch_written |= 1u << it->hp.cur;
                 account(*it, es);
@@ -242,7 +250,8 @@ void Engine::launch(Lane &ln, Batch &b) {
             // this picture runs inside k_chain: its block of the control buffer, and which surfaces are decoded by EARLIER pictures of this launch
             PicParams &q = b.h_pics[i];
             q.stages = PS_CHAIN | (p.chain_intra ? PS_CHAIN_INTRA : 0); q.chain_idx = i; q.n_deps = 0;
-            if (p.chain_intra) q.want_intra_resid = 1;      // the intra bands read the residuals from the picture's scratch (the stage path only asks for them when intra is dense)
+            // the intra bands read the residuals from the picture's scratch (the stage path only asks for them when intra is dense)
+            if (p.chain_intra) q.want_intra_resid = 1;
             for (int k = 0; k < kMaxSurfaces; k++) q.dep_pic[k] = -1;
             bool refs_in_batch = false;                   // does it reference a picture that ANY kernel of this batch decodes?
             for (int j = 0; j < i; j++) {
@@ -265,8 +274,10 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (p.has_picture && ((1u << (hevc ? p.hp.cur : p.pp.cur)) & p.dec->engine_state().displayed[0])) wait_pack = true;
         if (hevc && p.has_picture) {
             const HevcPicParams &h = p.hp;
-            hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs); hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
-            hd.max_w = std::max(hd.max_w, h.w); hd.max_h = std::max(hd.max_h, h.h); hd.any_intra |= (h.stages & HPS_INTRA) != 0; hd.any_deblock |= (h.stages & HPS_DEBLOCK) != 0; hd.any_sao |= (h.stages & HPS_SAO) != 0;
+            hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs);
+            hd.max_ctb_w = std::max(hd.max_ctb_w, h.ctb_w); hd.max_ctb_h = std::max(hd.max_ctb_h, h.ctb_h);
+            hd.max_w = std::max(hd.max_w, h.w); hd.max_h = std::max(hd.max_h, h.h); hd.any_intra |= (h.stages & HPS_INTRA) != 0;
+            hd.any_deblock |= (h.stages & HPS_DEBLOCK) != 0; hd.any_sao |= (h.stages & HPS_SAO) != 0;
         }
         if (p.has_picture) {
             max_mbs = std::max(max_mbs, p.mb_w * p.mb_h); max_mb_h = std::max(max_mb_h, p.mb_h);
@@ -277,7 +288,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         for (auto &j : p.out_after) b.h_jobs[2 * kMaxBatch + b.n_post++] = j;
         if (!p.out_before.empty() || !p.out_after.empty()) { max_w = std::max(max_w, p.disp_w); max_h = std::max(max_h, p.disp_h); }
         int st = b.h_pics[i].stages;
-        if (hevc && p.has_picture) { const int hs = p.hp.stages; if (hs & (HPS_MC | HPS_RESID)) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; } if (hs & HPS_INTRA) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; } if (hs & (HPS_DEBLOCK | HPS_SAO)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; } }
+        if (hevc && p.has_picture) { const int hs = p.hp.stages; if (hs & (HPS_MC | HPS_RESID)) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
+            if (hs & HPS_INTRA) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; } if (hs & (HPS_DEBLOCK | HPS_SAO)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; } }
         if (st & PS_RECON) { b.alg[0] += p.alg_bytes[0]; b.npics[0]++; }
         if (st & (PS_INTRA_LDS | PS_INTRA_V1)) { b.alg[1] += p.alg_bytes[1]; b.npics[1]++; }
         if (st & (PS_DEBLOCK_LDS | PS_DEBLOCK_V1)) { b.alg[2] += p.alg_bytes[2]; b.npics[2]++; }
@@ -292,10 +304,13 @@ void Engine::launch(Lane &ln, Batch &b) {
     b.max_mbs = max_mbs; b.max_mb_h = max_mb_h; b.max_w = max_w; b.max_h = max_h; b.redo = false;
     hipStream_t st = ln.stream, pst = ln.pack_stream;
     // What does not depend on the lane's previous batch -- clearing the control blocks, the parameter / pack-job tables, the deblocking pre-pass (it only
-    // reads the job lists) -- is issued on the lane's pre-stream, so it runs WHILE the previous batch's kernels are still busy instead of in the gap behind them.
+    // reads the job lists) -- is issued on the lane's pre-stream, so it runs WHILE the previous batch's kernels are still busy instead of in the gap behind
+    // them.
     // (This batch's tables were last used four batches ago: the ring guarantees that batch has retired.)
     hipStream_t ps = any_hevc ? st : ln.pre_stream;
-    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps); hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), ps); }   // every counter of every picture, and the abort word
+    // every counter of every picture, and the abort word
+    if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps);
+        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), ps); }
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, ps);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, ps);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, ps);
@@ -319,7 +334,8 @@ void Engine::launch(Lane &ln, Batch &b) {
     // Pack-out: k_packout writes the tight frames into device staging and a copy engine (SDMA) moves them to the pinned slots.
     // Letting the kernel store into host memory directly saves that hop but its PCIe-bound stores share the L2 / fabric write
     // queues with everything else: k_recon_inter of the next batch ran 4x slower next to it (0.56 -> 2.3 ms for 32 pictures).
-    auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
+    auto copy_out = [&](const std::vector<OutSlot *> &slots, hipStream_t s) { for (OutSlot *o : slots) if (o->dev && o->host &&
+        !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, s); };
     if (b.n_pre) { launch_packout(b.d_jobs, b.n_pre, max_w, max_h, st); b.pmask |= 1; for (auto &p : b.pics) copy_out(p.slots_before, st); }
     mark(1, st);
     if (any_hevc && (hd.max_pus || hd.max_tbs || hd.any_intra || hd.any_deblock || hd.any_sao)) {
@@ -354,7 +370,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         size_t n_keys = 0;
         for (int i = 0; i < n; i++) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
-            for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) { base_of[i] = base_of[j] + chain_lag_steps_ + 2 * b.pics[i].reach_rows; break; }
+            for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
+                base_of[i] = base_of[j] + chain_lag_steps_ + 2 * b.pics[i].reach_rows; break; }
             n_keys = std::max(n_keys, (size_t)(base_of[i] + 2 * b.h_pics[i].mb_h + b.h_pics[i].mb_w + 2));
         }
         if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
@@ -372,7 +389,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         int n_groups = 0;
         bool with_intra = false;
         for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) for (int bnd = 0; bnd * band_rows < b.h_pics[i].mb_h; bnd++) {
-            if (b.h_pics[i].stages & PS_CHAIN_INTRA) { b.h_groups[n_groups++] = (uint32_t)i << 16 | 0xC000u | (uint32_t)bnd; with_intra = true; }   // band of the intra wavefront
+            // band of the intra wavefront
+            if (b.h_pics[i].stages & PS_CHAIN_INTRA) { b.h_groups[n_groups++] = (uint32_t)i << 16 | 0xC000u | (uint32_t)bnd; with_intra = true; }
             b.h_groups[n_groups++] = (uint32_t)i << 16 | 0x8000u | (uint32_t)bnd;
         }
         for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
@@ -431,12 +449,14 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
     // 2. frames this batch packed before its kernels showed pictures of the recovered batch: again, from the pictures as they are now
     if (b.redo && b.n_pre) {
         launch_packout(b.d_jobs, b.n_pre, b.max_w, b.max_h, st);
-        for (auto &p : b.pics) for (OutSlot *o : p.slots_before) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st);
+        for (auto &p : b.pics) for (OutSlot *o : p.slots_before) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes,
+            hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
     }
     // 3. the pictures again, one per stream at a time
     std::vector<int> depth(n, 0); int max_depth = 0;
-    for (int i = 0; i < n; i++) { for (int j = 0; j < i; j++) if (b.pics[j].dec == b.pics[i].dec && b.pics[j].has_picture) depth[i]++; max_depth = std::max(max_depth, depth[i]); }
+    for (int i = 0; i < n; i++) { for (int j = 0; j < i; j++) if (b.pics[j].dec == b.pics[i].dec && b.pics[j].has_picture) depth[i]++;
+        max_depth = std::max(max_depth, depth[i]); }
     for (int d = 0; d <= max_depth; d++) {
         int stages = 0;
         for (int i = 0; i < n; i++) {
@@ -452,21 +472,27 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
         if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, st);
         if (stages & PS_INTRA_LDS) launch_intra_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, st);
         if (stages & PS_INTRA_V1) launch_recon_intra(b.d_pics, n, st);
-        if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st); launch_deblock_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, false, st); }
+        if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st);
+            launch_deblock_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, false, st); }
         if (stages & PS_DEBLOCK_V1) launch_deblock(b.d_pics, n, st);
         hipStreamSynchronize(st);                              // h_pics is rewritten for the next depth
     }
     if (b.n_post) {                                            // the display frames of the batch again, from the pictures as they are now
         launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, b.max_w, b.max_h, st);
-        for (auto &p : b.pics) for (OutSlot *o : p.slots_after) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, st);
+        for (auto &p : b.pics) for (OutSlot *o : p.slots_after) if (o->dev && o->host && !o->fetch) hipMemcpyAsync(o->host, o->dev, o->bytes,
+            hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
     }
     // 4. what could not be redone from intact data stays an error of its handle (complete() reports the words that are set)
     for (int i = 0; i < n; i++) if (is_tainted(b.pics[i].dec) && !b.h_err[i]) b.h_err[i] = kErrNotRecovered;
     { std::lock_guard<std::mutex> lk(sm_); st_.chain_recoveries++; }
-    chain_block_until_ns_ = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() + 30ll * 1000 * 1000 * 1000;
+    const auto since_epoch = std::chrono::steady_clock::now().time_since_epoch();
+    chain_block_until_ns_ = std::chrono::duration_cast<std::chrono::nanoseconds>(since_epoch).count() + 30ll * 1000 * 1000 * 1000;
     static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "jm_amd_dec: device %d: a chain launch ran out of time waiting for workgroups (is the GPU shared?) -- its pictures were decoded again by the stage kernels; chain launches pause for 30 s\n", device_); }
+    if (!said) { said = true;
+        fprintf(stderr, "jm_amd_dec: device %d: a chain launch ran out of time waiting for workgroups (is the GPU shared?) -- its pictures were decoded "
+                "again by the stage kernels; chain launches pause for 30 s\n", device_);
+    }
 }
 
 void Engine::complete(Lane &ln, Batch &b, bool failed) {
@@ -474,7 +500,8 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         bool wait_err = b.redo;
         for (size_t i = 0; i < b.pics.size(); i++) wait_err |= b.h_err[i] != 0 && b.any_chain;
         if (wait_err) {
-            if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size()); for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n"); }
+            if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size());
+                for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n"); }
             // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
             std::vector<std::pair<Decoder *, uint32_t>> later;     // ... and remember which surfaces it decoded into meanwhile (Engine::recover)
             if (!b.redo) ln.tainted.clear();                       // (a redo batch inherits the tainted set of the batch it followed)
@@ -497,10 +524,13 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         for (int k = 0; k < 5; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
-    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }   // (counted with or without profiling)
+    // (counted with or without profiling)
+    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++;
+        for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
     // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
-    for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0; std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }
+    for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0;
+        std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }
     for (auto &p : b.pics) p.dec->on_engine_done(p, failed);
     b.pics.clear();
 }
@@ -516,8 +546,11 @@ void Engine::run() {
                 // the batch is retired as FAILED -- its handles report the error and release their slots -- instead of being polled forever.
                 const hipError_t q = hipEventQuery(ln.ring[ln.tail].done);
                 if (q == hipErrorNotReady) break;
-                if (q != hipSuccess && !device_failed_) { device_failed_ = true; fprintf(stderr, "jm_amd_dec: device %d failed: %s -- every handle on it now returns errors\n", device_, hipGetErrorString(q)); }
-                { auto t0 = std::chrono::steady_clock::now(); complete(ln, ln.ring[ln.tail], q != hipSuccess); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
+                if (q != hipSuccess && !device_failed_) { device_failed_ = true;
+                    fprintf(stderr, "jm_amd_dec: device %d failed: %s -- every handle on it now returns errors\n", device_, hipGetErrorString(q)); }
+                { auto t0 = std::chrono::steady_clock::now(); complete(ln, ln.ring[ln.tail], q != hipSuccess);
+                    long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                    std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
                 progressed = true;
             }
@@ -532,7 +565,9 @@ void Engine::run() {
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
             if (!have) continue;
             if (device_failed_) { complete(ln, b, true); progressed = true; continue; }      // nothing can run any more: fail the pictures right away
-            { auto t0 = std::chrono::steady_clock::now(); launch(ln, b); long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(sm_); st_.launch_ns += ns; }
+            { auto t0 = std::chrono::steady_clock::now(); launch(ln, b);
+                long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                std::lock_guard<std::mutex> lk(sm_); st_.launch_ns += ns; }
             ln.head = (ln.head + 1) % kBatchRing; ln.inflight++;
             progressed = true;
         }

@@ -7,9 +7,8 @@
 // and issues ONE batched launch per stage with blockIdx.y = picture.  A 32-stream batch is 32x the work per launch at
 // the same latency.
 //
-// Lanes, each an in-order HIP stream with its own pack-out stream: lanes 0..kPLanes-1 take ordinary pictures (P, sparse
-// intra; decoders are split between them), the last lane pictures whose macroblocks are mostly intra (I pictures:
-// +3 ms of intra wavefront).  Without the split
+// Lanes, each an in-order HIP stream with its own pack-out stream: lane 0 takes ordinary H.264 pictures (P, B, sparse intra), lane 1 those whose
+// macroblocks are mostly intra (I pictures: +3 ms of intra wavefront), lanes 2 / 3 the same two classes of HEVC pictures.  Without the separate lanes
 // one I picture would hold up every other stream's round.  A decoder may only change lane when its previous pictures
 // have completed, so decode order per stream is preserved by stream order inside a lane.
 // There is no reference counterpart: the reference drives one NVDEC session synchronously (nv_dec.cpp:33-41).
@@ -34,16 +33,20 @@ struct OutSlot;
 constexpr int kMaxBatch = 64;
 constexpr int kBatchRing = 4;
 constexpr int kMaxChainGroups = 128 * 1024;         // work list of one chain launch (1080p: 1025 groups per picture, 4K: 4059)
-constexpr int kMaxChainBands = 384;                 // band workgroups of one chain launch, upper bound: half of what a whole MI355X holds at 3 workgroups per CU (k_chain)
-constexpr int kMaxChainBandsIntra = 256;            // ... at 2 per CU (k_chain_i, the variant with the intra role).  The bounds in use come from the device (Engine::Engine)
-constexpr int kPLanes = 2;                          // lanes for ordinary pictures.  The second one is an OPTION (JM_AMD_DEC_LANE_SPLIT=1, Engine::form `split`): with many
-                                                    // active streams they are divided between the two lanes by handle parity.  It measured worse in both rounds
-                                                    // (round 2, frames/s with / without: 20 streams 12.6 k / 16.0 k, 32 streams 12.5 k / 16.8 k, device-resident
-                                                    // output 14.2 k / 20.6 k): two half-size batches take as long as one, and their kernels get in each other's way.
+// band workgroups of one chain launch, upper bound: half of what a whole MI355X holds at 3 workgroups per CU (k_chain)
+constexpr int kMaxChainBands = 384;
+// ... at 2 per CU (k_chain_i, the variant with the intra role). The bounds in use come from the device (Engine::Engine)
+constexpr int kMaxChainBandsIntra = 256;
+// Lane 0 takes ordinary pictures.  (Rounds 1-2 carried an optional second ordinary lane with the streams divided by handle parity; it measured worse
+// every time -- 32 streams 12.5 k against 16.8 k frames/s: two half-size batches take as long as one and their kernels get in each other's way --
+// and was removed in round 3.)
+constexpr int kOrdinaryLane = 0;
+constexpr int kIntraLane = 1;                       // intra-dense H.264 pictures
 constexpr int kErrNotRecovered = 32;                // error word set by Engine::recover (chain_common.h CHAIN_ERR_NOT_RECOVERED; the device sets 1..16)
-constexpr int kLanes = kPLanes + 3;                 // + one lane for intra-dense H.264 pictures + one for HEVC pictures + one for HEVC I pictures
-constexpr int kHevcLane = kPLanes + 1;
-constexpr int kHevcIntraLane = kPLanes + 2;         // an I picture's CTB-row wavefront (k_hevc_intra, 2-3 ms at 1080p) would hold up every other stream's P / B batch
+constexpr int kLanes = 4;                           // ordinary, intra-dense H.264, HEVC, HEVC I pictures
+constexpr int kHevcLane = 2;
+// an I picture's CTB-row wavefront (k_hevc_intra, 2-3 ms at 1080p) would hold up every other stream's P / B batch
+constexpr int kHevcIntraLane = 3;
 
 struct EnginePic {
     Decoder *dec = nullptr;
@@ -59,19 +62,22 @@ struct EnginePic {
     bool wait_prev_pack = false;                    // this picture reuses a surface whose pack-out may still be running
     // chain launches (chain.hip): the picture may run inside k_chain, i.e. in the same launch as the pictures before it in its stream
     bool chain_ok = false;
-    bool chain_intra = false;                       // a (mostly) intra picture that can run inside k_chain_i with its intra wavefront as a third role (chain_intra.hip)
+    // a (mostly) intra picture that can run inside k_chain_i with its intra wavefront as a third role (chain_intra.hip)
+    bool chain_intra = false;
     int classic_stages = 0;                         // pp.stages when it runs through the stage kernels instead
     uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
     bool bipred = false;                            // some slice of the picture writes two-list / weighted motion records (B slices, weighted prediction)
     int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
-    int p_lane = 0;                                 // which of the ordinary-picture lanes this decoder uses (decoder index modulo)
-    // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on its stream's ordinary lane
-    // split: both ordinary-picture lanes are in use; otherwise everything ordinary runs on lane 0
-    int lane(bool chaining = false, bool split = false) const { return codec == 1 ? ((has_picture && hp.n_pus == 0 && hp.n_itbs > 0) ? kHevcIntraLane : kHevcLane) : ((has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kPLanes : (split ? p_lane : 0)); }
+    // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on the ordinary lane
+    int lane(bool chaining = false) const {
+        if (codec == 1) return (has_picture && hp.n_pus == 0 && hp.n_itbs > 0) ? kHevcIntraLane : kHevcLane;
+        return (has_picture && (pp.stages & PS_INTRA_LDS) && !(chaining && chain_intra)) ? kIntraLane : kOrdinaryLane;
+    }
 };
 
-struct EngineStats {                                // per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
+// per kernel class: 0 recon_inter, 1 intra, 2 deblock (prep+lds), 3 packout, 4 chain (k_chain: recon + deblock)
+struct EngineStats {
     double ns[5] = {0, 0, 0, 0, 0}; long long launches[5] = {0, 0, 0, 0, 0}, pics[5] = {0, 0, 0, 0, 0}, alg_bytes[5] = {0, 0, 0, 0, 0};
     long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0, chain_recoveries = 0;
     long long forms = 0, form_decoders = 0, form_pending = 0;   // ordinary-lane batches formed; decoders that had a picture waiting then; pictures waiting then
@@ -116,25 +122,31 @@ private:
         int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
-        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[8] = {nullptr};   // packed: surfaces were read by k_packout (before the copies)
+        // packed: surfaces were read by k_packout (before the copies)
+        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[8] = {nullptr};
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
     };
     struct Lane {
-        ihipStream_t *stream = nullptr, *pack_stream = nullptr, *pre_stream = nullptr;   // pre_stream: what a batch can do before the previous batch is complete
+        // pre_stream: what a batch can do before the previous batch is complete
+        ihipStream_t *stream = nullptr, *pack_stream = nullptr, *pre_stream = nullptr;
         ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // 'packed' events of the two most recently launched batches
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
         std::vector<Decoder *> tainted;                        // decoders whose recovered pictures could not be redone from intact references (Engine::recover)
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
-    std::atomic<int> chain_max_streams_{16};                              // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
-    int chain_bands_max_ = kMaxChainBands, chain_bands_max_intra_ = kMaxChainBandsIntra;   // half of the workgroups THIS device keeps resident (occupancy x compute units)
-    std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};              // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
-    std::vector<std::pair<Decoder *, long long>> recent_;     // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
-    std::atomic<int> lane_split_{0};                          // 1: two ordinary lanes while more streams are active than chain launches are formed for (JM_AMD_DEC_LANE_SPLIT)
-    std::vector<std::vector<uint32_t>> group_buckets_;        // scratch of launch()                                     // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
+    // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
+    std::atomic<int> chain_max_streams_{16};
+    // half of the workgroups THIS device keeps resident (occupancy x compute units)
+    int chain_bands_max_ = kMaxChainBands, chain_bands_max_intra_ = kMaxChainBandsIntra;
+    // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
+    std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};
+    // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
+    std::vector<std::pair<Decoder *, long long>> recent_;
+    // scratch of launch() // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
+    std::vector<std::vector<uint32_t>> group_buckets_;
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Lane &ln, Batch &b, bool failed);
@@ -143,16 +155,19 @@ private:
     void recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later);
 
     int device_, numa_node_ = -1;
-    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; long long shared_checked_ns_ = 0;   // another process has queues on this GPU (checked about once a second): no chain launches
+    // another process has queues on this GPU (checked about once a second): no chain launches
+    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; long long shared_checked_ns_ = 0;
     ihipStream_t *copy_stream_ = nullptr;
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];
     std::mutex m_; std::condition_variable cv_;
     std::deque<EnginePic> pending_;
     bool profile_ = false, ok_ = false, device_failed_ = false;
-    std::atomic<int> debug_stall_{0};                         // test hook: 1 = no band publishes its step counter (stage kernels and chain launches), 2 = chain launches only
+    // test hook: 1 = no band publishes its step counter (stage kernels and chain launches), 2 = chain launches only
+    std::atomic<int> debug_stall_{0};
     std::atomic<int> fetchers_{0};
-    std::atomic<long long> chain_block_until_ns_{0};          // no chain launches before this time (set when one had to be recovered; setting a chain knob clears it)
+    // no chain launches before this time (set when one had to be recovered; setting a chain knob clears it)
+    std::atomic<long long> chain_block_until_ns_{0};
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };

@@ -75,7 +75,8 @@ struct Cabac {
     inline void refill() {
         uint32_t w;
         if (ptr + 4 <= end) { w = ((uint32_t)ptr[0] << 24) | ((uint32_t)ptr[1] << 16) | ((uint32_t)ptr[2] << 8) | ptr[3]; }
-        else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (ptr + i < end ? ptr[i] : 0); if (ptr >= end + 8) overrun = true; }   // a few bytes of look-ahead past the end are normal
+        // a few bytes of look-ahead past the end are normal
+        else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (ptr + i < end ? ptr[i] : 0); if (ptr >= end + 8) overrun = true; }
         ptr += 4;
         val = (val << 32) | w; pos += 32;
     }

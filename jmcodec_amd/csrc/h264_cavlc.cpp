@@ -43,8 +43,10 @@ static const uint8_t kCtzLen[3][4] = { {1,2,3,3},{1,2,2,0},{1,1,0,0} };
 static const uint8_t kCtzBits[3][4] = { {1,1,1,0},{1,1,0,0},{1,0,0,0} };
 static const uint8_t kRunLen[6][7] = { {1,1,0,0,0,0,0},{1,2,2,0,0,0,0},{2,2,2,2,0,0,0},{2,2,2,3,3,0,0},{2,2,3,3,3,3,0},{2,3,3,3,3,3,3} };
 static const uint8_t kRunBits[6][7] = { {1,0,0,0,0,0,0},{1,1,0,0,0,0,0},{3,2,1,0,0,0,0},{3,2,1,1,0,0,0},{3,2,3,2,1,0,0},{3,0,1,3,2,5,4} };
-static const uint8_t kCbpIntra[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
-static const uint8_t kCbpInter[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
+static const uint8_t kCbpIntra[48] = {
+    47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
+static const uint8_t kCbpInter[48] = {
+    0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
 static const uint8_t kZigzag4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
 // zig-zag scan of a luma block coded with the large transform, frame macroblocks (8.5.7): scan position -> raster index
 static const uint8_t kZigzag8[64] = {
@@ -56,7 +58,8 @@ struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ;
 static TokTable g_tok[4];                           // [3]: nC >= 8, the 6-bit fixed-length code in the same format (fast path)
 static const uint8_t kTokClass[17] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3};
 // ... straight from the sum s of the two neighbouring counts in the fast path's window (64 = not available): s < 64 -> nC = (s + 1) >> 1, else nC = s & 31
-struct TokClassOfSum { uint8_t t[129]; TokClassOfSum() { for (int s = 0; s <= 128; s++) { const int nc = s < 64 ? (s + 1) >> 1 : s & 31; t[s] = kTokClass[nc > 16 ? 16 : nc]; } } };
+struct TokClassOfSum { uint8_t t[129]; TokClassOfSum() { for (int s = 0; s <= 128; s++) { const int nc = s < 64 ? (s + 1) >> 1 : s & 31;
+    t[s] = kTokClass[nc > 16 ? 16 : nc]; } } };
 static const TokClassOfSum kTokClassOfSum;
 static uint16_t g_tok_flc[64];                        // nC >= 8: 6-bit FLC
 static uint16_t g_cdc[256];                           // chroma DC token, max 8 bits
@@ -92,13 +95,17 @@ void cavlc_init_tables() {
         memset(g_tok[3].t, 0, sizeof g_tok[3].t);
         for (int c = 0; c < 256; c++) g_tok[3].t[c] = g_tok_flc[c >> 2];
         memset(g_cdc, 0, sizeof g_cdc);
-        for (int s = 0; s < 20; s++) if (kCdcLen[s]) { int l = kCdcLen[s]; uint32_t b = (uint32_t)kCdcBits[s] << (8 - l); for (uint32_t k = 0; k < (1u << (8 - l)); k++) g_cdc[b + k] = (uint16_t)(s << 8 | l); }
+        for (int s = 0; s < 20; s++) if (kCdcLen[s]) { int l = kCdcLen[s]; uint32_t b = (uint32_t)kCdcBits[s] << (8 - l);
+            for (uint32_t k = 0; k < (1u << (8 - l)); k++) g_cdc[b + k] = (uint16_t)(s << 8 | l); }
         memset(g_tz, 0, sizeof g_tz);
-        for (int t = 0; t < 15; t++) for (int z = 0; z < 16 - t; z++) { int l = kTzLen[t][z]; uint32_t b = (uint32_t)kTzBits[t][z] << (9 - l); for (uint32_t k = 0; k < (1u << (9 - l)); k++) g_tz[t][b + k] = (uint16_t)(z << 8 | l); }
+        for (int t = 0; t < 15; t++) for (int z = 0; z < 16 - t; z++) { int l = kTzLen[t][z]; uint32_t b = (uint32_t)kTzBits[t][z] << (9 - l);
+            for (uint32_t k = 0; k < (1u << (9 - l)); k++) g_tz[t][b + k] = (uint16_t)(z << 8 | l); }
         memset(g_ctz, 0, sizeof g_ctz);
-        for (int t = 0; t < 3; t++) for (int z = 0; z < 4 - t; z++) { int l = kCtzLen[t][z]; uint32_t b = (uint32_t)kCtzBits[t][z] << (3 - l); for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_ctz[t][b + k] = (uint8_t)(z << 4 | l); }
+        for (int t = 0; t < 3; t++) for (int z = 0; z < 4 - t; z++) { int l = kCtzLen[t][z]; uint32_t b = (uint32_t)kCtzBits[t][z] << (3 - l);
+            for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_ctz[t][b + k] = (uint8_t)(z << 4 | l); }
         memset(g_run, 0, sizeof g_run);
-        for (int t = 0; t < 6; t++) for (int r = 0; r <= t + 1; r++) { int l = kRunLen[t][r]; uint32_t b = (uint32_t)kRunBits[t][r] << (3 - l); for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_run[t][b + k] = (uint8_t)(r << 4 | l); }
+        for (int t = 0; t < 6; t++) for (int r = 0; r <= t + 1; r++) { int l = kRunLen[t][r]; uint32_t b = (uint32_t)kRunBits[t][r] << (3 - l);
+            for (uint32_t k = 0; k < (1u << (3 - l)); k++) g_run[t][b + k] = (uint8_t)(r << 4 | l); }
     });
 }
 
@@ -116,7 +123,8 @@ void ParseScratch::begin_picture() { std::fill(slice_of.begin(), slice_of.end(),
 namespace {
 
 struct Canon {                     // canonical per-MB serialisation for SyntaxDigest
-    uint32_t addr; uint8_t kind /* | 16 when transform_size_8x8_flag: luma[] then holds 4 x 64 levels */, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4]; int16_t mv[16][2];
+    uint32_t addr; uint8_t kind /* | 16 when transform_size_8x8_flag: luma[] then holds 4 x 64 levels */, qp, cmode, i16mode; uint8_t i4[16]; int8_t ref[4];
+    int16_t mv[16][2];
     int16_t i16dc[16], luma[16][16], cdc[2][4], cac[2][4][16];
     int8_t ref1[4]; int16_t mv1[16][2];          // list 1 (B slices)
 };
@@ -202,7 +210,8 @@ struct P {
         if (total > max_num) return -1;
         return residual_levels(total, t1, max_num, first, dst, map);
     }
-    __attribute__((noinline)) int residual_levels(int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) { return levels_of(br, total, t1, max_num, first, dst, map); }
+    __attribute__((noinline)) int residual_levels(int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) {
+        return levels_of(br, total, t1, max_num, first, dst, map); }
     // (static, explicit reader: the fast path runs it on a local copy of the reader that lives in registers)
     __attribute__((always_inline)) static inline int levels_of(BitReader &br, int total, int t1, int max_num, int first, int16_t *dst, const uint8_t *map) {
         memset(dst, 0, max_num == 4 ? 8 : 32);
@@ -291,8 +300,10 @@ struct P {
     void predict(int bx, int by, int bw, int refi, int shape, int part, int &px, int &py, int l = 0) const {
         Nb A = nb(bx - 1, by, l), B = nb(bx, by - 1, l), C = nb(bx + bw, by - 1, l);
         if (!C.avail) C = nb(bx - 1, by - 1, l);
-        if (shape == 1) { if (part == 0) { if (B.ref == refi) { px = B.mvx; py = B.mvy; return; } } else if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } }
-        else if (shape == 2) { if (part == 0) { if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } } else if (C.ref == refi) { px = C.mvx; py = C.mvy; return; } }
+        if (shape == 1) { if (part == 0) { if (B.ref == refi) { px = B.mvx; py = B.mvy; return; } } else if (A.ref == refi) { px = A.mvx; py = A.mvy; return; }
+            }
+        else if (shape == 2) { if (part == 0) { if (A.ref == refi) { px = A.mvx; py = A.mvy; return; } } else if (C.ref == refi) { px = C.mvx; py = C.mvy;
+            return; } }
         if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
         int ma = A.ref == refi, mb = B.ref == refi, mc = C.ref == refi;
         if (ma + mb + mc == 1) { const Nb &n = ma ? A : (mb ? B : C); px = n.mvx; py = n.mvy; }
@@ -306,7 +317,8 @@ struct P {
             decoded_mask = 0xffff;
             return;
         }
-        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvl[l][(j * 4 + i) * 2] = (int16_t)x; mvl[l][(j * 4 + i) * 2 + 1] = (int16_t)y; decoded_mask |= 1u << (j * 4 + i); }
+        for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) { mvl[l][(j * 4 + i) * 2] = (int16_t)x; mvl[l][(j * 4 + i) * 2 + 1] = (int16_t)y;
+            decoded_mask |= 1u << (j * 4 + i); }
     }
 
     // ---- macroblock start / finish -------------------------------------------------------
@@ -318,9 +330,11 @@ struct P {
         cx.slice_of[addr] = (int16_t)slice_num;
         memset(tc, 0, 24); ref[0] = ref[1] = ref[2] = ref[3] = -1; memset(mv, 0, 64); memset(i4m, 2, 16);
         cx.info[addr] = 0; decoded_mask = 0;
-        if (sh.type == SL_B || rf.track_uid) { refl[1][0] = refl[1][1] = refl[1][2] = refl[1][3] = -1; memset(mvl[1], 0, 64); memset(mvdl[1], 0, 32); cx.direct8[addr] = 0; }
+        if (sh.type == SL_B || rf.track_uid) { refl[1][0] = refl[1][1] = refl[1][2] = refl[1][3] = -1; memset(mvl[1], 0, 64); memset(mvdl[1], 0, 32);
+            cx.direct8[addr] = 0; }
         if (cb) { cx.cbp[addr] = 0; cx.cmode[addr] = 0; cx.cbf[addr] = 0; memset(mvd, 0, 32); }
-        if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1; canon->ref1[0] = canon->ref1[1] = canon->ref1[2] = canon->ref1[3] = -1; }
+        if (canon) { memset(canon, 0, sizeof *canon); canon->addr = (uint32_t)addr; canon->ref[0] = canon->ref[1] = canon->ref[2] = canon->ref[3] = -1;
+            canon->ref1[0] = canon->ref1[1] = canon->ref1[2] = canon->ref1[3] = -1; }
         return r;
     }
     void finish_mb(const MbRec *r) {
@@ -344,17 +358,20 @@ struct P {
         {   // downward reach of this macroblock's vectors (one vector per 8x8 unless sub-8x8 partitions / a second list exist)
             int m = out.max_mvy;
             if (!sub8 && !rf.bipred_rec) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; m = mv[b * 2 + 1] > m ? mv[b * 2 + 1] : m; } }
-            else for (int i = 0; i < 16; i++) { m = mvl[0][i * 2 + 1] > m ? mvl[0][i * 2 + 1] : m; if (rf.bipred_rec) m = mvl[1][i * 2 + 1] > m ? mvl[1][i * 2 + 1] : m; }
+            else for (int i = 0; i < 16; i++) { m = mvl[0][i * 2 + 1] > m ? mvl[0][i * 2 + 1] : m;
+                if (rf.bipred_rec) m = mvl[1][i * 2 + 1] > m ? mvl[1][i * 2 + 1] : m; }
             out.max_mvy = m;
         }
-        if (rf.track_uid) for (int l = 0; l < 2; l++) { int32_t *u = &(l ? cx.uid1 : cx.uid0)[(size_t)addr * 4]; for (int i = 0; i < 4; i++) u[i] = refl[l][i] >= 0 ? rf.uid[l][refl[l][i]] : -1; }
+        if (rf.track_uid) for (int l = 0; l < 2; l++) { int32_t *u = &(l ? cx.uid1 : cx.uid0)[(size_t)addr * 4];
+            for (int i = 0; i < 4; i++) u[i] = refl[l][i] >= 0 ? rf.uid[l][refl[l][i]] : -1; }
         if (rf.bipred_rec) {                                   // B slice / weighted prediction: full motion record (jobs.h MBM_BIPRED)
             if (out.mv_ext_count + kBiRecInt16 / 2 > out.mv_ext_cap) { err = "mv_ext overflow"; return; }
             r->modes |= MBM_BIPRED; r->u.mv_ext = out.mv_ext_count;
             int16_t *d = out.mv_ext + (size_t)out.mv_ext_count * 2;
             memcpy(d, mvl[0], 64); memcpy(d + 32, mvl[1], 64);
             int8_t *t = (int8_t *)(d + 64);
-            for (int i = 0; i < 4; i++) { t[i] = refl[1][i] >= 0 ? rf.slot[1][refl[1][i]] : (int8_t)-1; t[4 + i] = ref[i]; t[8 + i] = refl[1][i]; t[12 + i] = 0; }
+            for (int i = 0; i < 4; i++) { t[i] = refl[1][i] >= 0 ? rf.slot[1][refl[1][i]] : (int8_t)-1; t[4 + i] = ref[i]; t[8 + i] = refl[1][i];
+                t[12 + i] = 0; }
             out.mv_ext_count += kBiRecInt16 / 2;
             return;
         }
@@ -438,7 +455,8 @@ struct P {
         cx.direct8[addr] |= (uint8_t)mask;
         return true;
     }
-    void mark8(int q) { int bx = (q & 1) * 2, by = (q >> 1) * 2; decoded_mask |= (1u << (by * 4 + bx)) | (1u << (by * 4 + bx + 1)) | (1u << (by * 4 + bx + 4)) | (1u << (by * 4 + bx + 5)); }
+    void mark8(int q) { int bx = (q & 1) * 2, by = (q >> 1) * 2;
+        decoded_mask |= (1u << (by * 4 + bx)) | (1u << (by * 4 + bx + 1)) | (1u << (by * 4 + bx + 4)) | (1u << (by * 4 + bx + 5)); }
 
     bool skip_mb() {
         MbRec *r = begin_mb();
@@ -493,7 +511,8 @@ struct P {
         const uint32_t rr = (uint8_t)refi * 0x01010101u;
         memcpy(ref, &rr, 4);
         cx.slice_of[addr] = (int16_t)slice_num;
-        if (rf.track_uid) {                                       // the stream may hold B pictures: this picture's motion may serve direct prediction later (list 1 unused here)
+        // the stream may hold B pictures: this picture's motion may serve direct prediction later (list 1 unused here)
+        if (rf.track_uid) {
             int32_t *u0 = &cx.uid0[(size_t)addr * 4], *u1 = &cx.uid1[(size_t)addr * 4];
             const int32_t u = rf.uid[0][refi];
             u0[0] = u0[1] = u0[2] = u0[3] = u; u1[0] = u1[1] = u1[2] = u1[3] = -1;
@@ -502,9 +521,11 @@ struct P {
         }
         const int my = (int16_t)y;
         if (my > out.max_mvy) out.max_mvy = my;
-        static_assert(MB_INTER == 0 && offsetof(MbRec, cbp_blk) == 4 && offsetof(MbRec, coef_off) == 8 && offsetof(MbRec, ref) == 12 && offsetof(MbRec, u) == 16, "record layout");
+        static_assert(MB_INTER == 0 && offsetof(MbRec, cbp_blk) == 4 && offsetof(MbRec, coef_off) == 8 && offsetof(MbRec, ref) == 12 && offsetof(MbRec,
+            u) == 16, "record layout");
         uint64_t *q = (uint64_t *)r;
-        q[0] = (uint64_t)(uint8_t)qp << 8 | (uint64_t)(flags | MBF_DECODED) << 24 | (uint64_t)cbp_blk << 32 | (uint64_t)cbp_cac << 48 | (uint64_t)(uint8_t)slice_num << 56;
+        q[0] = (uint64_t)(uint8_t)qp << 8 | (uint64_t)(flags | MBF_DECODED) << 24 | (uint64_t)cbp_blk << 32 | (uint64_t)cbp_cac << 48 |
+            (uint64_t)(uint8_t)slice_num << 56;
         q[1] = (uint64_t)coef_off | (uint64_t)((uint8_t)rf.slot[0][refi] * 0x01010101u) << 32;
         q[2] = vv; q[3] = vv;
     }
@@ -521,7 +542,8 @@ struct P {
     // total_coeff of one block (9.2.1) given the sum s of its left and upper neighbours' counts in the window (64 = not available): both there ->
     // rounded mean, one -> that one, none -> 0
     static inline int nc_of(int s) { return s < 64 ? (s + 1) >> 1 : s & 31; }
-    __attribute__((always_inline)) static inline int token_fast(BitReader &br, int sum) {                           // coeff_token: total_coeff << 2 | trailing_ones, or -1; sum: see kTokClassOfSum
+    // coeff_token: total_coeff << 2 | trailing_ones, or -1; sum: see kTokClassOfSum
+    __attribute__((always_inline)) static inline int token_fast(BitReader &br, int sum) {
         const int cls = kTokClassOfSum.t[sum];
         const uint32_t v = br.peek(16);
         if (cls == 0 && (v & 0x8000)) { br.skip(1); return 0; }     // nC < 2 and the codeword "1": an empty block (most blocks of a coded 8x8 are)
@@ -536,7 +558,8 @@ struct P {
     // residual() of a CAVLC macroblock without the 8x8 transform: coded_block_pattern cbp, i16 = Intra16x16 (DC block + 15-level AC blocks)
     __attribute__((always_inline)) inline bool residual_fast(BitReader &br, int cbp, const bool i16, uint32_t &flags, uint32_t &bits, uint32_t &cbm) {
         static const uint8_t ident[16] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15};
-        static const uint8_t kWin[16] = {9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36};      // block (decoding order) -> window index (by + 1) * 8 + bx + 1
+        // block (decoding order) -> window index (by + 1) * 8 + bx + 1
+        static const uint8_t kWin[16] = {9, 10, 17, 18, 11, 12, 19, 20, 25, 26, 33, 34, 27, 28, 35, 36};
         static const uint8_t kRas[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};                 // ... -> raster index by * 4 + bx
         // window of total_coeff: row 0 / column 0 = the macroblocks above / to the left
         alignas(8) uint8_t w[5 * 8];
@@ -545,7 +568,8 @@ struct P {
         memset(tc, 0, 24);
         // one room check per macroblock: the most this coded_block_pattern can store (16 slots per 4x4 block, 4 per chroma DC block; the Intra16x16 DC
         // block is allocated -- and checked -- by alloc_coef)
-        if (out.coef_count + (i16 ? 16u : 0u) + 64u * (uint32_t)__builtin_popcount(cbp & 15) + ((cbp & 0x30) ? 8u : 0u) + ((cbp & 0x20) ? 128u : 0u) > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
+        const uint32_t need = (i16 ? 16u : 0u) + 64u * (uint32_t)__builtin_popcount(cbp & 15) + ((cbp & 0x30) ? 8u : 0u) + ((cbp & 0x20) ? 128u : 0u);
+        if (out.coef_count + need > out.coef_cap) { err = "coefficient buffer overflow"; return false; }
         if ((cbp & 15) || i16) {
             memset(w, 0, sizeof w);
             if (tb) memcpy(w + 1, tb + 12, 4); else memset(w + 1, 64, 4);
@@ -577,7 +601,8 @@ struct P {
                 if (!(e & 0xff)) { err = "entropy error (chroma DC)"; return false; }
                 br.skip((int)(e & 0xff));
                 if (!(e >> 10)) continue;
-                if ((int)(e >> 10) > 4 || levels_of(br, (int)(e >> 10), (int)(e >> 8) & 3, 4, 0, d, ident) < 0) { err = "entropy error (chroma DC)"; return false; }
+                if ((int)(e >> 10) > 4 || levels_of(br, (int)(e >> 10), (int)(e >> 8) & 3, 4, 0, d, ident) < 0) { err = "entropy error (chroma DC)";
+                    return false; }
                 flags |= pl ? MBF_CR_DC : MBF_CB_DC; out.coef_count += 4;
             }
         }
@@ -806,7 +831,8 @@ struct P {
         if (cat == 5) {
             for (i = 0; i < 63; i++) if (r.decision(402 + cabac_sig8_inc[i])) { pos[n++] = (uint8_t)i; if (r.decision(417 + cabac_last8_inc[i])) break; }
         } else if (cat == 3) {
-            for (i = 0; i < maxnum - 1; i++) { const int si = i < 2 ? i : 2; if (r.decision(sig_base + si)) { pos[n++] = (uint8_t)i; if (r.decision(last_base + si)) break; } }
+            for (i = 0; i < maxnum - 1; i++) { const int si = i < 2 ? i : 2; if (r.decision(sig_base + si)) { pos[n++] = (uint8_t)i;
+                if (r.decision(last_base + si)) break; } }
         } else {
             for (i = 0; i < maxnum - 1; i++) if (r.decision(sig_base + i)) { pos[n++] = (uint8_t)i; if (r.decision(last_base + i)) break; }
         }
@@ -821,7 +847,8 @@ struct P {
                 while (v < 14 && r.decision(ctx)) v++;
                 if (v == 14) {
                     int e = 0;
-                    while (r.bypass()) { v += 1 << e; e++; if (e > 20) { err = "coefficient level out of range"; return -1; } }    // (the slice is abandoned: nothing to write back)
+                    // (the slice is abandoned: nothing to write back)
+                    while (r.bypass()) { v += 1 << e; e++; if (e > 20) { err = "coefficient level out of range"; return -1; } }
                     while (e--) v += r.bypass() << e;
                 }
             }
@@ -846,7 +873,8 @@ struct P {
         if (i16) {
             int16_t *d = alloc_coef(16); if (!d) return false;
             int n;
-            if (cb) n = residual_block_ae(0, 16, nA >= 0 ? (int)((cx.cbf[nA] >> 16) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> 16) & 1) : -1, 16, 0, d, kZigzag4, intra);
+            if (cb) n = residual_block_ae(0, 16, nA >= 0 ? (int)((cx.cbf[nA] >> 16) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> 16) & 1) : -1, 16, 0, d,
+                kZigzag4, intra);
             else n = residual_block(nc_luma(0, 0), 16, 0, d, kZigzag4);
             if (n < 0) { if (!err) err = "entropy error (Intra16x16 DC)"; return false; }
             if (canon) memcpy(canon->i16dc, d, 32);
@@ -885,7 +913,8 @@ struct P {
                 int16_t *d = out.coef + out.coef_count;
                 int n;
                 if (cb) memset(d, 0, 32);
-                if (cb) n = residual_block_ae(i16 ? 1 : 2, by * 4 + bx, cbf_luma_nb(bx, by, true), cbf_luma_nb(bx, by, false), i16 ? 15 : 16, i16 ? 1 : 0, d, kZigzag4, intra);
+                if (cb) n = residual_block_ae(i16 ? 1 : 2, by * 4 + bx, cbf_luma_nb(bx, by, true), cbf_luma_nb(bx, by, false), i16 ? 15 : 16, i16 ? 1 : 0, d,
+                    kZigzag4, intra);
                 else n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
                 if (n < 0) { if (!err) err = "entropy error (luma block)"; return false; }
                 tc[by * 4 + bx] = (uint8_t)n;
@@ -899,7 +928,8 @@ struct P {
                 int16_t *d = out.coef + out.coef_count;
                 int n;
                 if (cb) memset(d, 0, 8);
-                if (cb) n = residual_block_ae(3, 17 + pl, nA >= 0 ? (int)((cx.cbf[nA] >> (17 + pl)) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> (17 + pl)) & 1) : -1, 4, 0, d, ident, intra);
+                if (cb) n = residual_block_ae(3, 17 + pl, nA >= 0 ? (int)((cx.cbf[nA] >> (17 + pl)) & 1) : -1,
+                    nB >= 0 ? (int)((cx.cbf[nB] >> (17 + pl)) & 1) : -1, 4, 0, d, ident, intra);
                 else n = residual_block(-1, 4, 0, d, ident);
                 if (n < 0) { if (!err) err = "entropy error (chroma DC)"; return false; }
                 if (n) { r->flags |= pl ? MBF_CR_DC : MBF_CB_DC; out.coef_count += 4; if (canon) memcpy(canon->cdc[pl], d, 8); }
@@ -1045,7 +1075,8 @@ struct P {
                         if (!(pred[p] == 2 || pred[p] == l)) continue;
                         int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0, bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
                         rf_[l][p] = 0;
-                        if (nref > 1) { rf_[l][p] = cb ? ae_ref_idx(bx, by, l) : br.te(nref - 1); if (rf_[l][p] >= nref) { err = "ref_idx out of range"; return false; } }
+                        if (nref > 1) { rf_[l][p] = cb ? ae_ref_idx(bx, by, l) : br.te(nref - 1); if (rf_[l][p] >= nref) { err = "ref_idx out of range";
+                            return false; } }
                         for (int j = by; j < by + bh; j += 2) for (int i = bx; i < bx + bw; i += 2) refl[l][(j >> 1) * 2 + (i >> 1)] = (int8_t)rf_[l][p];
                     }
                 }
@@ -1053,7 +1084,8 @@ struct P {
                     decoded_mask = 0;
                     for (int p = 0; p < np; p++) {
                         int bx = shape == 2 ? p * 2 : 0, by = shape == 1 ? p * 2 : 0, bw = shape == 2 ? 2 : 4, bh = shape == 1 ? 2 : 4;
-                        if (rf_[l][p] < 0) { for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) decoded_mask |= 1u << (j * 4 + i); continue; }
+                        if (rf_[l][p] < 0) { for (int j = by; j < by + bh; j++) for (int i = bx; i < bx + bw; i++) decoded_mask |= 1u << (j * 4 + i); continue;
+                            }
                         int px, py, dx, dy; predict(bx, by, bw, rf_[l][p], shape, p, px, py, l);
                         read_mvd(bx, by, bw, bh, dx, dy, l);
                         set_mv(bx, by, bw, bh, px + dx, py + dy, l);
@@ -1074,7 +1106,8 @@ struct P {
                     for (int i = 0; i < 4; i++) {
                         if (!(pred[i] == 2 || pred[i] == l)) continue;
                         rf_[l][i] = 0;
-                        if (nref > 1 && !(!is_b && mb_type == 4)) { rf_[l][i] = cb ? ae_ref_idx((i & 1) * 2, (i >> 1) * 2, l) : br.te(nref - 1); if (rf_[l][i] >= nref) { err = "ref_idx out of range"; return false; } }
+                        if (nref > 1 && !(!is_b && mb_type == 4)) { rf_[l][i] = cb ? ae_ref_idx((i & 1) * 2, (i >> 1) * 2, l) : br.te(nref - 1);
+                            if (rf_[l][i] >= nref) { err = "ref_idx out of range"; return false; } }
                         refl[l][i] = (int8_t)rf_[l][i];
                     }
                 }

@@ -110,7 +110,8 @@ std::string ParamSets::parse_sps(BitReader &br) {
     if (br.u1()) {
         uint32_t c[4]; for (auto &v : c) v = br.ue();
         // frame_crop_*_offset in chroma units (4:2:0 -> 2 luma samples, 7.4.2.1.1): the cropped picture must keep at least one sample
-        if (c[0] > 8192 || c[1] > 8192 || c[2] > 8192 || c[3] > 8192 || 2 * (c[0] + c[1]) >= (uint32_t)s.mb_w * 16 || 2 * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
+        if (c[0] > 8192 || c[1] > 8192 || c[2] > 8192 || c[3] > 8192 || 2 * (c[0] + c[1]) >= (uint32_t)s.mb_w * 16 ||
+            2 * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
         // (vertical crop units are 2 luma rows of a FRAME, or of a field when frame_mbs_only_flag = 0: CropUnitY = SubHeightC * (2 - frame_mbs_only_flag))
         const int vy = s.frame_mbs_only ? 1 : 2;
         if (2 * vy * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
@@ -129,7 +130,8 @@ std::string ParamSets::parse_sps(BitReader &br) {
         if (br.u1()) {
             br.u1(); br.ue(); br.ue(); br.ue(); br.ue();
             uint32_t ro = br.ue(), db = br.ue();
-            if (!br.overrun() && ro <= 16 && db <= 16 && ro <= db) { s.max_num_reorder_frames = (int)ro; s.max_dec_frame_buffering = (int)db; }   // out-of-range restriction: ignored (falls back to the level's DPB size)
+            // out-of-range restriction: ignored (falls back to the level's DPB size)
+            if (!br.overrun() && ro <= 16 && db <= 16 && ro <= db) { s.max_num_reorder_frames = (int)ro; s.max_dec_frame_buffering = (int)db; }
         }
     }
     if (br.overrun()) return "SPS truncated";
@@ -146,7 +148,8 @@ std::string ParamSets::parse_pps(BitReader &br) {
     { uint32_t id = br.ue(), sid = br.ue(); if (id > 255 || sid > 31) return "pps/sps id out of range"; p.id = (int)id; p.sps_id = (int)sid; }
     p.cabac = br.u1(); p.bottom_field_poc_present = br.u1();
     if (br.ue() != 0) return "slice groups (FMO) are not supported";
-    { uint32_t a = br.ue(), b = br.ue(); if (a > 31 || b > 31) return "num_ref_idx_default_active out of range"; p.num_ref_idx_default[0] = (int)a + 1; p.num_ref_idx_default[1] = (int)b + 1; }
+    { uint32_t a = br.ue(), b = br.ue(); if (a > 31 || b > 31) return "num_ref_idx_default_active out of range"; p.num_ref_idx_default[0] = (int)a + 1;
+        p.num_ref_idx_default[1] = (int)b + 1; }
     p.weighted_pred = br.u1(); p.weighted_bipred_idc = br.u(2);
     if (p.weighted_bipred_idc > 2) return "bad weighted_bipred_idc";
     { int q = br.se(); if (q < -26 || q > 25) return "pic_init_qp out of range"; p.init_qp = 26 + q; }
@@ -218,9 +221,12 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
             int lw = 1 << sh.luma_log2_wd, lo = 0, cw[2] = {1 << sh.chroma_log2_wd, 1 << sh.chroma_log2_wd}, co[2] = {0, 0};
             if (br.u1()) { lw = br.se(); lo = br.se(); }
             if (br.u1()) for (int j = 0; j < 2; j++) { cw[j] = br.se(); co[j] = br.se(); }
-            if (lw < -128 || lw > 127 || lo < -128 || lo > 127 || cw[0] < -128 || cw[0] > 127 || cw[1] < -128 || cw[1] > 127 || co[0] < -128 || co[0] > 127 || co[1] < -128 || co[1] > 127) return "weight out of range";
-            if (lw != (1 << sh.luma_log2_wd) || lo != 0 || cw[0] != (1 << sh.chroma_log2_wd) || cw[1] != cw[0] || co[0] != 0 || co[1] != 0) sh.wp_nondefault = true;
-            sh.luma_w[l][i] = (int16_t)lw; sh.luma_o[l][i] = (int16_t)lo; for (int j = 0; j < 2; j++) { sh.chroma_w[l][i][j] = (int16_t)cw[j]; sh.chroma_o[l][i][j] = (int16_t)co[j]; }
+            if (lw < -128 || lw > 127 || lo < -128 || lo > 127 || cw[0] < -128 || cw[0] > 127 || cw[1] < -128 || cw[1] > 127 || co[0] < -128 || co[0] > 127 ||
+                co[1] < -128 || co[1] > 127) return "weight out of range";
+            if (lw != (1 << sh.luma_log2_wd) || lo != 0 || cw[0] != (1 << sh.chroma_log2_wd) || cw[1] != cw[0] || co[0] != 0 ||
+                co[1] != 0) sh.wp_nondefault = true;
+            sh.luma_w[l][i] = (int16_t)lw; sh.luma_o[l][i] = (int16_t)lo;
+            for (int j = 0; j < 2; j++) { sh.chroma_w[l][i][j] = (int16_t)cw[j]; sh.chroma_o[l][i][j] = (int16_t)co[j]; }
         }
     }
     if (nal_ref_idc) {

@@ -21,7 +21,8 @@ bool Decoder::ensure_job_cap(JobSlot &js, size_t bytes, size_t keep) {
     if (parse_only_ || !gpu_open_) { uint8_t *p = (uint8_t *)realloc(js.host, cap); if (!p) return false; js.host = p; js.cap = cap; return true; }
     hipSetDevice(device_);
     uint8_t *h = nullptr, *d = nullptr;
-    if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d, cap) != hipSuccess) { if (h) hipHostFree(h); return false; }
+    if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d, cap) != hipSuccess) { if (h) hipHostFree(h);
+        return false; }
     if (keep && js.host) memcpy(h, js.host, std::min(keep, js.cap));
     // the slot belongs to the picture being parsed: nothing on the device refers to the old buffers any more (see acquire_job_slot)
     if (js.host) hipHostFree(js.host);
@@ -40,7 +41,8 @@ void Decoder::hevc_handle_nal(const uint8_t *nal, size_t len) {
         if (type == 32 || type == 35 || type == 39) hevc_dispatch_pending();            // VPS, AUD, prefix SEI: a new access unit starts
         if (type == 36 || type == 37) {                                              // end of sequence / bitstream: everything decoded so far is output
             hevc_dispatch_pending(); h_seen_eos_ = true;
-            if (seq_active_) { for (int i = 0; i < n_surf_; i++) dpb_[i].ref = 0; hevc_bump(carry_out_, true, true); for (int i = 0; i < n_surf_; i++) if (!dpb_[i].wait_output) dpb_[i].in_use = false; }
+            if (seq_active_) { for (int i = 0; i < n_surf_; i++) dpb_[i].ref = 0; hevc_bump(carry_out_, true, true);
+                for (int i = 0; i < n_surf_; i++) if (!dpb_[i].wait_output) dpb_[i].in_use = false; }
         }
         return;
     }
@@ -78,7 +80,8 @@ void Decoder::hevc_handle_nal(const uint8_t *nal, size_t len) {
 
 bool Decoder::hevc_activate(const HevcSps &sps) {
     const int mbw = (sps.width + 15) / 16, mbh = (sps.height + 15) / 16;
-    const bool changed = !seq_active_ || mbw != mb_w_ || mbh != mb_h_ || sps.width != hsps_.width || sps.height != hsps_.height || sps.disp_w() != disp_w_ || sps.disp_h() != disp_h_;
+    const bool changed = !seq_active_ || mbw != mb_w_ || mbh != mb_h_ || sps.width != hsps_.width || sps.height != hsps_.height || sps.disp_w() != disp_w_ ||
+        sps.disp_h() != disp_h_;
     h_max_dpb_ = sps.max_dec_pic_buffering; h_reorder_ = sps.max_num_reorder;
     if (!changed) return true;
     if (seq_active_) {
@@ -109,7 +112,8 @@ bool Decoder::hevc_activate(const HevcSps &sps) {
 void Decoder::hevc_bump(std::vector<int> &out, bool all, bool use_fullness) {
     for (;;) {
         int n_out = 0, full = 0, best = -1;
-        for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && i != cur_) { full++; if (dpb_[i].wait_output) { n_out++; if (best < 0 || dpb_[i].poc < dpb_[best].poc) best = i; } }
+        for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && i != cur_) { full++; if (dpb_[i].wait_output) { n_out++;
+            if (best < 0 || dpb_[i].poc < dpb_[best].poc) best = i; } }
         if (best < 0 || !(all || n_out > h_reorder_ || (use_fullness && full >= h_max_dpb_))) break;
         out.push_back(best); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc); dpb_[best].out_at = decode_count_ - 1;
         if (!dpb_[best].ref) dpb_[best].in_use = false;
@@ -178,7 +182,8 @@ bool Decoder::hevc_start_picture(const HevcSliceHeader &sh, int nal_type, int ti
     pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack;
     pending_->out_before = std::move(carry_out_); carry_out_.clear();
     pending_->hevc = std::make_unique<HevcTask>();
-    pending_->hevc->sps = sps; pending_->hevc->pps = pps; pending_->hevc->poc = poc; pending_->hevc->col_out = c.hcol; pending_->hevc->work_slot = (int)(hevc_work_rr_++ % kHevcWorkSets);
+    pending_->hevc->sps = sps; pending_->hevc->pps = pps; pending_->hevc->poc = poc; pending_->hevc->col_out = c.hcol;
+    pending_->hevc->work_slot = (int)(hevc_work_rr_++ % kHevcWorkSets);
     first_sh_ = SliceHeader(); first_sh_.type = sh.type == HSL_I ? SL_I : (sh.type == HSL_B ? SL_B : SL_P);
     if (sh.type == HSL_I) stat_i_++; else if (sh.type == HSL_B) stat_b_++; else stat_p_++;
     return true;
@@ -188,7 +193,8 @@ bool Decoder::hevc_start_picture(const HevcSliceHeader &sh, int nal_type, int ti
 bool Decoder::hevc_build_refs(const HevcSliceHeader &sh, HevcSliceRefs &rf) {
     const int max_lsb = 1 << hsps_.log2_max_poc_lsb, poc = dpb_[cur_].poc;
     int before[16], after[16], lt[32], nb = 0, na = 0, nl = 0;
-    auto find_st = [&](int want) { for (int k = 0; k < n_surf_; k++) if (k != cur_ && dpb_[k].in_use && dpb_[k].ref == 1 && dpb_[k].poc == want) return k; return -1; };
+    auto find_st = [&](int want) { for (int k = 0; k < n_surf_; k++) if (k != cur_ && dpb_[k].in_use && dpb_[k].ref == 1 && dpb_[k].poc == want) return k;
+        return -1; };
     auto missing = [&](int want, int ref) {       // 8.3.3: a grey stand-in (conformant streams never get here after the first IRAP)
         for (int k = 0; k < n_surf_; k++) if (k != cur_ && !dpb_[k].in_use) {
             dpb_[k] = DpbPic(); dpb_[k].in_use = true; dpb_[k].ref = ref; dpb_[k].poc = want; dpb_[k].decode_idx = -1;
@@ -197,12 +203,15 @@ bool Decoder::hevc_build_refs(const HevcSliceHeader &sh, HevcSliceRefs &rf) {
         }
         return -1;
     };
-    for (int i = 0; i < sh.rps.n_neg; i++) if (sh.rps.used[0][i]) { int k = find_st(poc + sh.rps.d[0][i]); if (k < 0) k = missing(poc + sh.rps.d[0][i], 1); if (k < 0) return false; before[nb++] = k; }
-    for (int i = 0; i < sh.rps.n_pos; i++) if (sh.rps.used[1][i]) { int k = find_st(poc + sh.rps.d[1][i]); if (k < 0) k = missing(poc + sh.rps.d[1][i], 1); if (k < 0) return false; after[na++] = k; }
+    for (int i = 0; i < sh.rps.n_neg; i++) if (sh.rps.used[0][i]) { int k = find_st(poc + sh.rps.d[0][i]); if (k < 0) k = missing(poc + sh.rps.d[0][i], 1);
+        if (k < 0) return false; before[nb++] = k; }
+    for (int i = 0; i < sh.rps.n_pos; i++) if (sh.rps.used[1][i]) { int k = find_st(poc + sh.rps.d[1][i]); if (k < 0) k = missing(poc + sh.rps.d[1][i], 1);
+        if (k < 0) return false; after[na++] = k; }
     for (int i = 0; i < sh.n_lt; i++) if (sh.lt_used[i]) {
         const int want = sh.lt_msb[i] ? (poc & ~(max_lsb - 1)) + sh.lt_poc[i] : sh.lt_poc[i];
         int k = -1;
-        for (int j = 0; j < n_surf_ && k < 0; j++) if (j != cur_ && dpb_[j].in_use && dpb_[j].ref && (sh.lt_msb[i] ? dpb_[j].poc == want : (dpb_[j].poc & (max_lsb - 1)) == want)) k = j;
+        for (int j = 0; j < n_surf_ && k < 0; j++) if (j != cur_ && dpb_[j].in_use && dpb_[j].ref &&
+            (sh.lt_msb[i] ? dpb_[j].poc == want : (dpb_[j].poc & (max_lsb - 1)) == want)) k = j;
         if (k < 0) k = missing(want, 2);
         if (k < 0) return false;
         dpb_[k].ref = 2; lt[nl++] = k;
@@ -217,7 +226,8 @@ bool Decoder::hevc_build_refs(const HevcSliceHeader &sh, HevcSliceRefs &rf) {
             for (int i = 0; i < (l ? nb : na) && n < want; i++) tmp[n++] = l ? before[i] : after[i];
             for (int i = 0; i < nl && n < want; i++) tmp[n++] = lt[i];
         }
-        for (int i = 0; i < sh.n_ref[l]; i++) { const int k = sh.rplm[l] ? tmp[sh.list_entry[l][i]] : tmp[i]; rf.slot[l][i] = (int8_t)k; rf.poc[l][i] = dpb_[k].poc; rf.is_lt[l][i] = dpb_[k].ref == 2; }
+        for (int i = 0; i < sh.n_ref[l]; i++) { const int k = sh.rplm[l] ? tmp[sh.list_entry[l][i]] : tmp[i]; rf.slot[l][i] = (int8_t)k;
+            rf.poc[l][i] = dpb_[k].poc; rf.is_lt[l][i] = dpb_[k].ref == 2; }
     }
     rf.col.reset();
     if (sh.temporal_mvp) { const int k = rf.slot[(sh.type == HSL_B && !sh.col_from_l0) ? 1 : 0][sh.col_ref_idx]; if (k >= 0) rf.col = dpb_[k].hcol; }
@@ -245,7 +255,8 @@ void Decoder::hevc_parse_task(PicTask *t) {
     static thread_local HevcPicParser parser;
     static thread_local HevcPicJobs jobs;
     HevcDigest dg = hdigest_; dg.on = want_digest_;
-    if (dg.on && !dg.trace && getenv("JM_AMD_DEC_DIGEST_TRACE")) dg.trace = fopen(getenv("JM_AMD_DEC_DIGEST_TRACE"), "w");     // debugging aid: every digest event
+    // debugging aid: every digest event
+    if (dg.on && !dg.trace && getenv("JM_AMD_DEC_DIGEST_TRACE")) dg.trace = fopen(getenv("JM_AMD_DEC_DIGEST_TRACE"), "w");
     parser.begin_picture(ht.sps, ht.pps, ht.poc, &jobs, &dg, ht.col_out.get());
     for (auto &s : ht.slices) {
         std::string e = parser.parse_slice(s.sh, s.refs, s.rbsp.data(), s.len);
@@ -258,17 +269,23 @@ void Decoder::hevc_parse_task(PicTask *t) {
     // pack: every array 16-byte aligned
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return o; };
-    ht.off_ctbs = place(jobs.ctbs.size() * sizeof(HevcCtb)); ht.off_qp8 = place(jobs.qp8.size()); ht.off_bsv = place(jobs.bs_v.size()); ht.off_bsh = place(jobs.bs_h.size());
-    ht.off_pus = place(jobs.pus.size() * sizeof(HevcPu)); ht.off_tbs = place(jobs.tbs.size() * sizeof(HevcTb)); ht.off_itbs = place(jobs.itbs.size() * sizeof(HevcIntraTb));
+    ht.off_ctbs = place(jobs.ctbs.size() * sizeof(HevcCtb)); ht.off_qp8 = place(jobs.qp8.size()); ht.off_bsv = place(jobs.bs_v.size());
+    ht.off_bsh = place(jobs.bs_h.size());
+    ht.off_pus = place(jobs.pus.size() * sizeof(HevcPu)); ht.off_tbs = place(jobs.tbs.size() * sizeof(HevcTb));
+    ht.off_itbs = place(jobs.itbs.size() * sizeof(HevcIntraTb));
     ht.off_coefs = place(jobs.coefs.size() * 4); ht.off_wps = place(jobs.wps.size() * sizeof(HevcWp));
-    ht.n_pus = (int)jobs.pus.size(); ht.n_tbs = (int)jobs.tbs.size(); ht.n_itbs = (int)jobs.itbs.size(); ht.any_sao = jobs.any_sao; ht.any_deblock = jobs.any_deblock;
+    ht.n_pus = (int)jobs.pus.size(); ht.n_tbs = (int)jobs.tbs.size(); ht.n_itbs = (int)jobs.itbs.size(); ht.any_sao = jobs.any_sao;
+    ht.any_deblock = jobs.any_deblock;
     t->n_intra = jobs.n_intra_cu; t->any_deblock = jobs.any_deblock; t->n_slices = (int)ht.slices.size();
     if (!ensure_job_cap(js, off + 64)) { fail("job buffer allocation failed"); }
     else {
         auto put = [&](size_t o, const void *p, size_t bytes) { if (bytes) memcpy(js.host + o, p, bytes); };
-        put(ht.off_ctbs, jobs.ctbs.data(), jobs.ctbs.size() * sizeof(HevcCtb)); put(ht.off_qp8, jobs.qp8.data(), jobs.qp8.size()); put(ht.off_bsv, jobs.bs_v.data(), jobs.bs_v.size());
-        put(ht.off_bsh, jobs.bs_h.data(), jobs.bs_h.size()); put(ht.off_pus, jobs.pus.data(), jobs.pus.size() * sizeof(HevcPu)); put(ht.off_tbs, jobs.tbs.data(), jobs.tbs.size() * sizeof(HevcTb));
-        put(ht.off_itbs, jobs.itbs.data(), jobs.itbs.size() * sizeof(HevcIntraTb)); put(ht.off_coefs, jobs.coefs.data(), jobs.coefs.size() * 4); put(ht.off_wps, jobs.wps.data(), jobs.wps.size() * sizeof(HevcWp));
+        put(ht.off_ctbs, jobs.ctbs.data(), jobs.ctbs.size() * sizeof(HevcCtb)); put(ht.off_qp8, jobs.qp8.data(), jobs.qp8.size());
+        put(ht.off_bsv, jobs.bs_v.data(), jobs.bs_v.size());
+        put(ht.off_bsh, jobs.bs_h.data(), jobs.bs_h.size()); put(ht.off_pus, jobs.pus.data(), jobs.pus.size() * sizeof(HevcPu));
+        put(ht.off_tbs, jobs.tbs.data(), jobs.tbs.size() * sizeof(HevcTb));
+        put(ht.off_itbs, jobs.itbs.data(), jobs.itbs.size() * sizeof(HevcIntraTb)); put(ht.off_coefs, jobs.coefs.data(), jobs.coefs.size() * 4);
+        put(ht.off_wps, jobs.wps.data(), jobs.wps.size() * sizeof(HevcWp));
         t->upload_bytes = off;
         stat_pictures_++; stat_job_bytes_ += (long long)off; stat_intra_mbs_ += jobs.n_intra_cu; stat_coef_ += (long long)jobs.coefs.size();
         if (!parse_only_ && !failed_) t->upload_seq = engine_->upload(js.dev, js.host, off, js.uploaded);
@@ -297,12 +314,16 @@ void Decoder::hevc_fill_engine_pic(PicTask *t, EnginePic &ep) {
     for (int i = 0; i < kMaxSurfaces; i++) hp.surf[i] = surf_[i];
     hp.ctbs = (const HevcCtb *)(js.dev + ht.off_ctbs); hp.qp8 = js.dev + ht.off_qp8; hp.bs_v = js.dev + ht.off_bsv; hp.bs_h = js.dev + ht.off_bsh;
     hp.pus = (const HevcPu *)(js.dev + ht.off_pus); hp.n_pus = ht.n_pus; hp.tbs = (const HevcTb *)(js.dev + ht.off_tbs); hp.n_tbs = ht.n_tbs;
-    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs); hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)(resid_ + (size_t)ht.work_slot * ((size_t)mb_w_ * mb_h_ * 768));
-    hp.stages = (ht.n_pus ? HPS_MC : 0) | (ht.n_tbs ? HPS_RESID : 0) | (ht.n_itbs ? HPS_INTRA : 0) | (ht.any_deblock ? HPS_DEBLOCK : 0) | (ht.any_sao ? HPS_SAO : 0);
+    hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs);
+    hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)(resid_ + (size_t)ht.work_slot * ((size_t)mb_w_ * mb_h_ * 768));
+    hp.stages = (ht.n_pus ? HPS_MC : 0) | (ht.n_tbs ? HPS_RESID : 0) | (ht.n_itbs ? HPS_INTRA : 0) | (ht.any_deblock ? HPS_DEBLOCK : 0) |
+        (ht.any_sao ? HPS_SAO : 0);
     // which surfaces the picture reads: lets the engine put INDEPENDENT pictures of this handle (the B pictures of one pyramid level) into one batch
-    for (const auto &sl : ht.slices) for (int l = 0; l < 2; l++) for (int i = 0; i < sl.sh.n_ref[l] && i < 16; i++) if (sl.refs.slot[l][i] >= 0 && sl.refs.slot[l][i] < 32) ep.ref_mask |= 1u << sl.refs.slot[l][i];
+    for (const auto &sl : ht.slices) for (int l = 0; l < 2; l++) for (int i = 0; i < sl.sh.n_ref[l] && i < 16; i++) if (sl.refs.slot[l][i] >= 0 &&
+        sl.refs.slot[l][i] < 32) ep.ref_mask |= 1u << sl.refs.slot[l][i];
     const long long S = (long long)surf_bytes_;
-    ep.alg_bytes[0] = (ht.n_pus ? 2 * S : 0) + (long long)t->upload_bytes; ep.alg_bytes[1] = ht.n_itbs ? S : 0; ep.alg_bytes[2] = (ht.any_deblock ? 2 * S : 0) + (ht.any_sao ? 2 * S : 0);
+    ep.alg_bytes[0] = (ht.n_pus ? 2 * S : 0) + (long long)t->upload_bytes; ep.alg_bytes[1] = ht.n_itbs ? S : 0;
+    ep.alg_bytes[2] = (ht.any_deblock ? 2 * S : 0) + (ht.any_sao ? 2 * S : 0);
 }
 
 }  // namespace jmamd

@@ -4,7 +4,8 @@
 #include "hevc_jobs.h"
 
 namespace jmamd {
-struct HevcBatchDims { int max_pus = 0, max_tbs = 0, max_itbs = 0, max_ctb_w = 0, max_ctb_h = 0, max_w = 0, max_h = 0; bool any_intra = false, any_deblock = false, any_sao = false; };
+struct HevcBatchDims { int max_pus = 0, max_tbs = 0, max_itbs = 0, max_ctb_w = 0, max_ctb_h = 0, max_w = 0, max_h = 0;
+    bool any_intra = false, any_deblock = false, any_sao = false; };
 // marks (optional, 4 events): before MC, after residual, after intra, after the loop filters
 constexpr int kHevcProgressStride = 544;      // CTB rows per picture the progress array provides for (8192 / 16 + slack)
 // progress: device array of n * kHevcProgressStride ints (row progress counters of k_hevc_intra, cleared by this call)

@@ -48,7 +48,8 @@ struct HevcMcLds {
 };
 
 // luma: this lane's four 14-bit intermediates (row my_row, columns 4 * my_q ..) of list-l prediction
-__device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint8_t *ref, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm, int lane, bool mine, int my_row, int my_q, int *out) {
+__device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint8_t *ref, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm,
+    int lane, bool mine, int my_row, int my_q, int *out) {
     const int tw = bw + 7, th = bh + 7, x0 = xi - 3, y0 = yi - 3;
     int sh = 0;
     __syncthreads();                                          // (the previous user of tile / hbuf is done)
@@ -56,9 +57,11 @@ __device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint
         sh = x0 & 3;
         const int ndw = (sh + tw + 3) >> 2;                   // <= 7
         const uint8_t *base = ref + (size_t)y0 * pp.pitch + (x0 & ~3);
-        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7; if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
+        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
+            if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
     } else {
-        for (int k = lane; k < tw * th; k += 64) { const int r = k / tw, c = k - r * tw; sm.tile[r * 32 + c] = ref[(size_t)clip3(0, pp.h - 1, y0 + r) * pp.pitch + clip3(0, pp.w - 1, x0 + c)]; }
+        for (int k = lane; k < tw * th; k += 64) { const int r = k / tw, c = k - r * tw;
+            sm.tile[r * 32 + c] = ref[(size_t)clip3(0, pp.h - 1, y0 + r) * pp.pitch + clip3(0, pp.w - 1, x0 + c)]; }
     }
     __syncthreads();
     const int8_t *fx = c_lf[xf], *fy = c_lf[yf];
@@ -80,7 +83,8 @@ __device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint
     }
 }
 // chroma: this lane's two CbCr pairs (Cb0, Cr0, Cb1, Cr1 of row my_row, columns 2 * my_q, 2 * my_q + 1)
-__device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const uint8_t *refc, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm, int lane, bool mine, int my_row, int my_q, int *out) {
+__device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const uint8_t *refc, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm,
+    int lane, bool mine, int my_row, int my_q, int *out) {
     const int tw = bw + 3, th = bh + 3, x0 = xi - 1, y0 = yi - 1, pw = pp.w >> 1, ph = pp.h >> 1;
     int sh = 0;
     __syncthreads();
@@ -88,9 +92,11 @@ __device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const ui
         sh = (2 * x0) & 3;
         const int ndw = (sh + 2 * tw + 3) >> 2;               // <= 6
         const uint8_t *base = refc + (size_t)y0 * pp.pitch + ((2 * x0) & ~3);
-        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7; if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
+        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
+            if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
     } else {
-        for (int k = lane; k < 2 * tw * th; k += 64) { const int r = k / (2 * tw), c = k - r * 2 * tw; sm.tile[r * 32 + c] = refc[(size_t)clip3(0, ph - 1, y0 + r) * pp.pitch + 2 * clip3(0, pw - 1, x0 + (c >> 1)) + (c & 1)]; }
+        for (int k = lane; k < 2 * tw * th; k += 64) { const int r = k / (2 * tw), c = k - r * 2 * tw;
+            sm.tile[r * 32 + c] = refc[(size_t)clip3(0, ph - 1, y0 + r) * pp.pitch + 2 * clip3(0, pw - 1, x0 + (c >> 1)) + (c & 1)]; }
     }
     __syncthreads();
     const int8_t *fx = c_cf[xf], *fy = c_cf[yf];
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
             const int slot = l ? pu.slot1 : pu.slot0;
             if (slot < 0) continue;
             const int mvx = l ? pu.mv1[0] : pu.mv0[0], mvy = l ? pu.mv1[1] : pu.mv0[1];
-            hevc_mc_chroma(pp, pp.surf[slot] + pp.chroma_offset, (pu.x >> 1) + (mvx >> 3), (pu.y >> 1) + (mvy >> 3), bw, bh, mvx & 7, mvy & 7, sm, lane, mine, my_row, my_q, p[l]);
+            hevc_mc_chroma(pp, pp.surf[slot] + pp.chroma_offset, (pu.x >> 1) + (mvx >> 3), (pu.y >> 1) + (mvy >> 3), bw, bh, mvx & 7, mvy & 7, sm, lane, mine,
+                my_row, my_q, p[l]);
         }
         if (mine) {
             uint32_t w = 0;
@@ -181,16 +188,19 @@ __device__ __forceinline__ void load_transform_matrix(int8_t *tm, int log2, int 
     for (int k = lane; k < n * n; k += nt) tm[k] = c_trans[(k >> log2) * step][k & (n - 1)];
 }
 // Callers make sure nobody still reads d / res (a barrier since their last use).  Returns the buffer that holds the residual.
-// tm: the block's n-point transform matrix in LDS (load_transform_matrix); ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the rest).
+// tm: the block's n-point transform matrix in LDS (load_transform_matrix); ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the
+// rest).
 // WAVE: the caller is a single wavefront (LDS operations of one wave execute in order, so a scheduling barrier replaces s_barrier).
 template <bool WAVE>
-__device__ const int16_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, const int8_t *tm, int *ext, int lane, int nt) {
+__device__ const int16_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, const int8_t *tm, int *ext, int lane,
+    int nt) {
     auto sync = [] { if (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
     const int n = 1 << log2, nn = n * n;
     for (int k = lane; k < nn; k += nt) d[k] = 0;
     if (lane < 2) ext[lane] = 0;
     sync();
-    for (int k = lane; k < count; k += nt) { const uint32_t e = coefs[k]; const int pos = e & 1023; d[pos] = (int16_t)(e >> 16); atomicMax(&ext[0], pos >> log2); atomicMax(&ext[1], pos & (n - 1)); }
+    for (int k = lane; k < count; k += nt) { const uint32_t e = coefs[k]; const int pos = e & 1023; d[pos] = (int16_t)(e >> 16);
+        atomicMax(&ext[0], pos >> log2); atomicMax(&ext[1], pos & (n - 1)); }
     sync();
     if (flags & HTB_BYPASS) return d;
     if (flags & HTB_TSKIP) { for (int k = lane; k < nn; k += nt) res[k] = (int16_t)(((d[k] << 7) + 2048) >> 12); sync(); return res; }
@@ -254,10 +264,12 @@ __global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
 // ------------------------------------------------------------------------------------------------------------
 // 8.4.4.2: intra prediction (+ residual) of the intra blocks of one coding tree block, in decoding order
 // ------------------------------------------------------------------------------------------------------------
-__device__ int g_hevc_exp = 0;                  // experiments (timing only, wrong output): 1 no block loop, 2 no waiting on the row above, 4 no tile load / store
+// experiments (timing only, wrong output): 1 no block loop, 2 no waiting on the row above, 4 no tile load / store
+__device__ int g_hevc_exp = 0;
 constexpr int kIntraThreads = 256;
 constexpr int kYS = 160, kCS = 80;              // LDS row strides of the luma / chroma tiles
-constexpr int kYO = 16, kCO = 8;                // column of the CTB's first sample inside a tile row (the left neighbour column sits just before): keeps 16- / 8-byte accesses aligned
+// column of the CTB's first sample inside a tile row (the left neighbour column sits just before): keeps 16- / 8-byte accesses aligned
+constexpr int kYO = 16, kCO = 8;
 constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 blocks (+ PCM planes)
 
 // The coding tree block lives in LDS while its intra blocks are reconstructed: tile row 0 / column 0 hold the samples above / left
@@ -284,7 +296,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // With one counter per row "everything up to cx + 2 of the row above" chained every intra block of a picture to ALL intra blocks up and to the
     // left of it -- ~0.5 ms per P / B picture with a handful of intra blocks, and what bounded one HEVC stream (k_hevc_intra 571 us of 737 us per picture).
     int need = 0;
-    if (cy > 0 && !(exp_ & 2)) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 && col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_count) need = col + 1;
+    if (cy > 0 && !(exp_ & 2)) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 &&
+        col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_count) need = col + 1;
     if (need) {
         if (threadIdx.x == 0) {
             int spins = 0;
@@ -319,8 +332,10 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             const int r = k / q, g = k - r * q, y = y0 + r;
             if (y < pp.h && x0 + 16 * g < pp.w) *(uint4 *)&ty[(r + 1) * kYS + kYO + 16 * g] = *(const uint4 *)(surf + (size_t)y * pp.pitch + x0 + 16 * g);
         }
-        if (y0 > 0) for (int k = lane; k < 2 * q; k += nt) if (x0 + 16 * k < pp.w) *(uint4 *)&ty[kYO + 16 * k] = *(const uint4 *)(surf + (size_t)(y0 - 1) * pp.pitch + x0 + 16 * k);
-        if (x0 > 0) for (int k = lane; k <= cs; k += nt) { const int y = y0 + k - 1; if (y >= 0 && y < pp.h) ty[k * kYS + kYO - 1] = surf[(size_t)y * pp.pitch + x0 - 1]; }
+        if (y0 > 0) for (int k = lane; k < 2 * q; k += nt) if (x0 + 16 * k < pp.w) *(uint4 *)&ty[kYO + 16 * k] =
+            *(const uint4 *)(surf + (size_t)(y0 - 1) * pp.pitch + x0 + 16 * k);
+        if (x0 > 0) for (int k = lane; k <= cs; k += nt) { const int y = y0 + k - 1;
+            if (y >= 0 && y < pp.h) ty[k * kYS + kYO - 1] = surf[(size_t)y * pp.pitch + x0 - 1]; }
         const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1, qc = cs >> 4;      // a 16-byte group holds 8 Cb/Cr pairs
         const uint8_t *cpl = surf + pp.chroma_offset;
         for (int k = lane; k < (hc + 1) * 2 * qc; k += nt) {            // rows -1 .. hc-1; row -1 spans two CTB widths
@@ -334,7 +349,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                 cr[h2] = (a >> 8 & 255) | ((a >> 24) << 8) | ((b >> 8 & 255) << 16) | ((b >> 24) << 24); }
             *(uint2 *)&tc[0][r * kCS + kCO + 8 * g] = make_uint2(cb[0], cb[1]); *(uint2 *)&tc[1][r * kCS + kCO + 8 * g] = make_uint2(cr[0], cr[1]);
         }
-        if (x0 > 0) for (int k = lane; k <= hc; k += nt) { const int y = yc0 + k - 1; if (y >= 0 && y < ph) { const uint8_t *p = cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1); tc[0][k * kCS + kCO - 1] = p[0]; tc[1][k * kCS + kCO - 1] = p[1]; } }
+        if (x0 > 0) for (int k = lane; k <= hc; k += nt) { const int y = yc0 + k - 1; if (y >= 0 && y < ph) {
+            const uint8_t *p = cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1); tc[0][k * kCS + kCO - 1] = p[0]; tc[1][k * kCS + kCO - 1] = p[1]; } }
     }
     __syncthreads();
     // ---- block loop: the three colour planes are independent, so wavefront w runs the blocks of plane w on its own (wave-synchronous:
@@ -354,7 +370,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         const int lx = tb.x - (c ? x0 >> 1 : x0) + (c ? kCO : kYO), ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
         // the block's residual (k_hevc_iresid) is fetched now and used at the end: its latency hides behind the prediction
         int rv[16];
-        if (tb.coef_n) for (int i = 0; i < 16; i++) { const int k = lane + 64 * i; if (k < n * n) rv[i] = rplane[(size_t)(tb.y + (k >> log2)) * rpw + tb.x + (k & (n - 1))]; }
+        if (tb.coef_n) for (int i = 0; i < 16; i++) { const int k = lane + 64 * i;
+            if (k < n * n) rv[i] = rplane[(size_t)(tb.y + (k >> log2)) * rpw + tb.x + (k & (n - 1))]; }
         const int16_t *e = edge[0];
         if (!pcm) {
             // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
@@ -371,7 +388,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                     int src = i;
                     if (!((mask >> sgm) & 1)) {
                         const uint64_t below = mask & ((1ull << sgm) - 1);
-                        if (below) { const int t = 63 - __clzll((long long)below); src = t < U ? t * unit + unit - 1 : (t == U ? 2 * n : 2 * n + 1 + (t - U - 1) * unit + unit - 1); }
+                        if (below) { const int t = 63 - __clzll((long long)below);
+                            src = t < U ? t * unit + unit - 1 : (t == U ? 2 * n : 2 * n + 1 + (t - U - 1) * unit + unit - 1); }
                         else { const int f = __ffsll((long long)mask) - 1; src = f < U ? f * unit : (f == U ? 2 * n : 2 * n + 1 + (f - U - 1) * unit); }
                     }
                     if (src < 2 * n) v = tile[(ly + 2 * n - 1 - src) * ts + lx - 1];
@@ -385,11 +403,13 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             if (c == 0 && tb.mode != 1 && n > 4) {
                 const int dv = iabs(tb.mode - 26), dh = iabs(tb.mode - 10), md = dv < dh ? dv : dh, thr = n == 8 ? 7 : (n == 16 ? 1 : 0);
                 if (md > thr) {
-                    const bool strong = pp.strong_intra && n == 32 && iabs(edge[0][64] + edge[0][128] - 2 * edge[0][96]) < 8 && iabs(edge[0][64] + edge[0][0] - 2 * edge[0][32]) < 8;
+                    const bool strong = pp.strong_intra && n == 32 && iabs(edge[0][64] + edge[0][128] - 2 * edge[0][96]) < 8 &&
+                        iabs(edge[0][64] + edge[0][0] - 2 * edge[0][32]) < 8;
                     for (int i = lane; i <= N; i += nt) {
                         int v;
                         if (i == 0 || i == N) v = edge[0][i];
-                        else if (strong) v = i == 64 ? edge[0][64] : (i < 64 ? (i * edge[0][64] + (64 - i) * edge[0][0] + 32) >> 6 : ((128 - i) * edge[0][64] + (i - 64) * edge[0][128] + 32) >> 6);
+                        else if (strong) v = i == 64 ? edge[0][64] :
+                            (i < 64 ? (i * edge[0][64] + (64 - i) * edge[0][0] + 32) >> 6 : ((128 - i) * edge[0][64] + (i - 64) * edge[0][128] + 32) >> 6);
                         else v = (edge[0][i - 1] + 2 * edge[0][i] + edge[0][i + 1] + 2) >> 2;
                         edge[1][i] = (int16_t)v;
                     }
@@ -423,7 +443,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             else if (tb.mode == 0) v = ((n - 1 - x) * L[-y] + (x + 1) * T[n] + (n - 1 - y) * T[x] + (y + 1) * L[-n] + n) >> (log2 + 1);
             else if (tb.mode == 1) {
                 v = dc;
-                if (c == 0 && n < 32) { if (x == 0 && y == 0) v = (L[0] + 2 * dc + T[0] + 2) >> 2; else if (y == 0) v = (T[x] + 3 * dc + 2) >> 2; else if (x == 0) v = (L[-y] + 3 * dc + 2) >> 2; }
+                if (c == 0 && n < 32) { if (x == 0 && y == 0) v = (L[0] + 2 * dc + T[0] + 2) >> 2; else if (y == 0) v = (T[x] + 3 * dc + 2) >> 2;
+                    else if (x == 0) v = (L[-y] + 3 * dc + 2) >> 2; }
             } else {
                 const int a = vert ? y : x, b = vert ? x : y, pos = (a + 1) * ang, idx = pos >> 5, fr = pos & 31;
                 v = fr ? ((32 - fr) * ref[b + idx + 1] + fr * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
@@ -492,23 +513,32 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const HevcPicParams *pics,
         uint8_t *q = surf + (size_t)y * pp.pitch + x;
         int s[4][8];                                                    // s[line][0..7] = p3 p2 p1 p0 q0 q1 q2 q3
         for (int k = 0; k < 4; k++) for (int i = 0; i < 8; i++) s[k][i] = q[k * along + (i - 4) * across];
-        const int dp0 = iabs(s[0][1] - 2 * s[0][2] + s[0][3]), dp3 = iabs(s[3][1] - 2 * s[3][2] + s[3][3]), dq0 = iabs(s[0][6] - 2 * s[0][5] + s[0][4]), dq3 = iabs(s[3][6] - 2 * s[3][5] + s[3][4]);
+        const int dp0 = iabs(s[0][1] - 2 * s[0][2] + s[0][3]), dp3 = iabs(s[3][1] - 2 * s[3][2] + s[3][3]), dq0 = iabs(s[0][6] - 2 * s[0][5] + s[0][4]),
+            dq3 = iabs(s[3][6] - 2 * s[3][5] + s[3][4]);
         if (dp0 + dq0 + dp3 + dq3 < beta) {
             bool strong = true;
-            for (int k = 0; k < 4; k += 3) { const int dk = k ? dp3 + dq3 : dp0 + dq0; if (!(2 * dk < (beta >> 2) && iabs(s[k][0] - s[k][3]) + iabs(s[k][4] - s[k][7]) < (beta >> 3) && iabs(s[k][3] - s[k][4]) < ((5 * tc + 1) >> 1))) strong = false; }
+            for (int k = 0; k < 4; k += 3) { const int dk = k ? dp3 + dq3 : dp0 + dq0;
+                if (!(2 * dk < (beta >> 2) && iabs(s[k][0] - s[k][3]) + iabs(s[k][4] - s[k][7]) < (beta >> 3) &&
+                iabs(s[k][3] - s[k][4]) < ((5 * tc + 1) >> 1))) strong = false; }
             const int side = (beta + (beta >> 1)) >> 3; const bool mp = dp0 + dp3 < side, mq = dq0 + dq3 < side;
             for (int k = 0; k < 4; k++) {
                 const int p3 = s[k][0], p2 = s[k][1], p1 = s[k][2], p0 = s[k][3], q0 = s[k][4], q1 = s[k][5], q2 = s[k][6], q3 = s[k][7];
                 uint8_t *l = q + k * along;
                 if (strong) {
-                    if (!keep_p) { l[-across] = (uint8_t)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3); l[-2 * across] = (uint8_t)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2); l[-3 * across] = (uint8_t)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
-                    if (!keep_q) { l[0] = (uint8_t)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3); l[across] = (uint8_t)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2); l[2 * across] = (uint8_t)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3); }
+                    if (!keep_p) { l[-across] = (uint8_t)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+                        l[-2 * across] = (uint8_t)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+                        l[-3 * across] = (uint8_t)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
+                    if (!keep_q) { l[0] = (uint8_t)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+                        l[across] = (uint8_t)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+                        l[2 * across] = (uint8_t)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3); }
                 } else {
                     int dl = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
                     if (iabs(dl) >= 10 * tc) continue;
                     dl = clip3(-tc, tc, dl);
-                    if (!keep_p) { l[-across] = (uint8_t)clip1(p0 + dl); if (mp) l[-2 * across] = (uint8_t)clip1(p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + dl) >> 1)); }
-                    if (!keep_q) { l[0] = (uint8_t)clip1(q0 - dl); if (mq) l[across] = (uint8_t)clip1(q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - dl) >> 1)); }
+                    if (!keep_p) { l[-across] = (uint8_t)clip1(p0 + dl); if (mp) l[-2 * across] = (uint8_t)clip1(p1 + clip3(-(tc >> 1), tc >> 1,
+                        (((p2 + p0 + 1) >> 1) - p1 + dl) >> 1)); }
+                    if (!keep_q) { l[0] = (uint8_t)clip1(q0 - dl); if (mq) l[across] = (uint8_t)clip1(q1 + clip3(-(tc >> 1), tc >> 1,
+                        (((q2 + q0 + 1) >> 1) - q1 - dl) >> 1)); }
                 }
             }
         }
@@ -519,8 +549,10 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const HevcPicParams *pics,
         for (int c = 1; c < 3; c++) {
             const int qpc = c_qpc[clip3(0, 57, qpl + (c == 1 ? pp.cb_qp_off : pp.cr_qp_off))], tc = c_tc[clip3(0, 53, qpc + 2 + 2 * cq.tc_off)];
             for (int k = 0; k < 4; k++) {
-                uint8_t *p1 = sample_ptr(surf, pp, c, dir ? xc + k : xc - 2, dir ? yc - 2 : yc + k), *p0 = sample_ptr(surf, pp, c, dir ? xc + k : xc - 1, dir ? yc - 1 : yc + k);
-                uint8_t *q0 = sample_ptr(surf, pp, c, dir ? xc + k : xc, dir ? yc : yc + k), *q1 = sample_ptr(surf, pp, c, dir ? xc + k : xc + 1, dir ? yc + 1 : yc + k);
+                uint8_t *p1 = sample_ptr(surf, pp, c, dir ? xc + k : xc - 2, dir ? yc - 2 : yc + k),
+                    *p0 = sample_ptr(surf, pp, c, dir ? xc + k : xc - 1, dir ? yc - 1 : yc + k);
+                uint8_t *q0 = sample_ptr(surf, pp, c, dir ? xc + k : xc, dir ? yc : yc + k),
+                    *q1 = sample_ptr(surf, pp, c, dir ? xc + k : xc + 1, dir ? yc + 1 : yc + k);
                 const int dl = clip3(-tc, tc, (((*q0 - *p0) << 2) + *p1 - *q1 + 4) >> 3), np = clip1(*p0 + dl), nq = clip1(*q0 - dl);
                 if (!keep_p) *p0 = (uint8_t)np;
                 if (!keep_q) *q0 = (uint8_t)nq;
@@ -548,7 +580,8 @@ __global__ __launch_bounds__(256) void k_hevc_sao(const HevcPicParams *pics) {
     if (type && !(pp.qp8[(yl >> 3) * pp.w8 + (xl >> 3)] & 128)) {
         if (type == 1) { const int k = ((v >> 3) - ctb.sao_pos[c]) & 31; if (k < 4) add = ctb.sao_off[c][k]; }
         else {
-            const int cls = ctb.sao_pos[c], dx = cls == 1 ? 0 : (cls == 3 ? -1 : 1), dy = cls == 0 ? 0 : 1;      // second neighbour; the first is its mirror image
+            // second neighbour; the first is its mirror image
+            const int cls = ctb.sao_pos[c], dx = cls == 1 ? 0 : (cls == 3 ? -1 : 1), dy = cls == 0 ? 0 : 1;
             const int xa = x - dx, ya = y - dy, xb = x + dx, yb = y + dy;
             bool okk = xa >= 0 && xb >= 0 && xa < pw && xb < pw && ya >= 0 && yb < ph;
             if (okk) {
@@ -578,7 +611,8 @@ static void upload_tables() {
     hipMemcpyToSymbol(HIP_SYMBOL(c_trans), hevc_trans, sizeof c_trans); hipMemcpyToSymbol(HIP_SYMBOL(c_dst), hevc_dst, sizeof c_dst);
     hipMemcpyToSymbol(HIP_SYMBOL(c_lf), hevc_luma_filter, sizeof c_lf); hipMemcpyToSymbol(HIP_SYMBOL(c_cf), hevc_chroma_filter, sizeof c_cf);
     hipMemcpyToSymbol(HIP_SYMBOL(c_angle), hevc_intra_angle, sizeof c_angle); hipMemcpyToSymbol(HIP_SYMBOL(c_inv_angle), hevc_inv_angle, sizeof c_inv_angle);
-    hipMemcpyToSymbol(HIP_SYMBOL(c_beta), hevc_beta_tab, sizeof c_beta); hipMemcpyToSymbol(HIP_SYMBOL(c_tc), hevc_tc_tab, sizeof c_tc); hipMemcpyToSymbol(HIP_SYMBOL(c_qpc), hevc_qpc_tab, sizeof c_qpc);
+    hipMemcpyToSymbol(HIP_SYMBOL(c_beta), hevc_beta_tab, sizeof c_beta); hipMemcpyToSymbol(HIP_SYMBOL(c_tc), hevc_tc_tab, sizeof c_tc);
+    hipMemcpyToSymbol(HIP_SYMBOL(c_qpc), hevc_qpc_tab, sizeof c_qpc);
     if (getenv("JM_AMD_DEC_EXP_HEVC")) { int v = atoi(getenv("JM_AMD_DEC_EXP_HEVC")); hipMemcpyToSymbol(HIP_SYMBOL(g_hevc_exp), &v, sizeof v); }
     done[dev] = true;
 }

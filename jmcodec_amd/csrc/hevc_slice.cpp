@@ -20,7 +20,8 @@ struct ScanTables {
         for (int l = 0; l <= 3; l++) {
             int n = 1 << l, k = 0;
             for (int s = 0; s <= 2 * (n - 1); s++) for (int x = 0; x <= s; x++) { int y = s - x; if (x < n && y < n) t[0][l][k++] = (uint8_t)(x | (y << 4)); }
-            for (int i = 0; i < n * n; i++) { t[1][l][i] = (uint8_t)((i & (n - 1)) | ((i >> l) << 4)); t[2][l][i] = (uint8_t)((i >> l) | ((i & (n - 1)) << 4)); }
+            for (int i = 0; i < n * n; i++) { t[1][l][i] = (uint8_t)((i & (n - 1)) | ((i >> l) << 4)); t[2][l][i] = (uint8_t)((i >> l) | ((i & (n - 1)) << 4));
+                }
             for (int sidx = 0; sidx < 3; sidx++) for (int i = 0; i < n * n; i++) inv[sidx][l][(t[sidx][l][i] & 15) | ((t[sidx][l][i] >> 4) << 3)] = (uint8_t)i;
         }
         static const uint8_t map4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
@@ -64,7 +65,8 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     ctb_slice_.assign(nc, -1);
     slices_.clear(); wpp_valid_ = dep_valid_ = false; last_cu_qp_ = 26; err_ = false;
     // 6.5.1 raster <-> tile scan and 6.5.2 z-scan order: only when the layout changed
-    uint64_t key = ((uint64_t)w_ << 48) ^ ((uint64_t)h_ << 32) ^ ((uint64_t)sps.log2_ctb << 28) ^ ((uint64_t)sps.log2_min_tb << 24) ^ ((uint64_t)pps.tile_cols << 16) ^ ((uint64_t)pps.tile_rows << 8) ^ (pps.uniform ? 1 : 0);
+    uint64_t key = ((uint64_t)w_ << 48) ^ ((uint64_t)h_ << 32) ^ ((uint64_t)sps.log2_ctb << 28) ^ ((uint64_t)sps.log2_min_tb << 24) ^
+        ((uint64_t)pps.tile_cols << 16) ^ ((uint64_t)pps.tile_rows << 8) ^ (pps.uniform ? 1 : 0);
     if (!pps.uniform) for (int i = 0; i < 20; i++) key = key * 1099511628211ULL + (uint64_t)(pps.col_w[i % 20] * 131 + pps.row_h[i % 22]);
     if (key != layout_key_ || rs2ts_.size() != nc) {
     layout_key_ = key;
@@ -77,7 +79,8 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     colb[nc_t] = ctb_w_; rowb[nr_t] = ctb_h_;
     int ts = 0;
     for (int tr = 0; tr < nr_t; tr++) for (int tc = 0; tc < nc_t; tc++)
-        for (int y = rowb[tr]; y < rowb[tr + 1]; y++) for (int x = colb[tc]; x < colb[tc + 1]; x++) { int rs = y * ctb_w_ + x; rs2ts_[rs] = ts; ts2rs_[ts] = rs; tile_id_[ts] = tr * nc_t + tc; ts++; }
+        for (int y = rowb[tr]; y < rowb[tr + 1]; y++) for (int x = colb[tc]; x < colb[tc + 1]; x++) { int rs = y * ctb_w_ + x; rs2ts_[rs] = ts;
+            ts2rs_[ts] = rs; tile_id_[ts] = tr * nc_t + tc; ts++; }
     layout_bad_ = ts != (int)nc;                                       // tile boundaries that do not cover the picture
     const int sh = sps.log2_ctb - sps.log2_min_tb;
     tb_w_ = ctb_w_ << sh;
@@ -193,7 +196,8 @@ int HevcPicParser::merge_candidates(int xcb, int ycb, int ncb, int xp, int yp, i
     if (have[1] && have[0] && same_motion(c[1], c[0])) have[1] = false;
     if (have[2] && avail_b1 && same_motion(c[2], c[1])) have[2] = false;
     if (have[3] && have[0] && same_motion(c[3], c[0])) have[3] = false;
-    if (have[4] && (have[0] + have[1] + have[2] + have[3] == 4 || (have[0] && same_motion(c[4], c[0])) || (avail_b1 && same_motion(c[4], c[1])))) have[4] = false;
+    if (have[4] && (have[0] + have[1] + have[2] + have[3] == 4 || (have[0] && same_motion(c[4], c[0])) || (avail_b1 && same_motion(c[4],
+        c[1])))) have[4] = false;
     int n = 0;
     for (int k = 0; k < 5; k++) if (have[k]) list[n++] = c[k];
     if (n > want && n <= max) return n;
@@ -234,7 +238,8 @@ void HevcPicParser::amvp(int xcb, int ycb, int ncb, int xp, int yp, int w, int h
     for (int k = 0; k < 3; k++) okb[k] = avail_pb(xcb, ycb, ncb, xp, yp, w, h, part, bx[k], by[k]);
     // neighbours lie in the current slice (6.4.1), so their reference indices refer to this slice's lists
     auto same_ref = [&](const HevcMotion &m, int16_t *mv) {
-        for (int t = 0; t < 2; t++) { int l = t ? !X : X; if (((m.pf >> l) & 1) && refs_->poc[l][m.ref[l]] == tp) { mv[0] = m.mv[l][0]; mv[1] = m.mv[l][1]; return true; } }
+        for (int t = 0; t < 2; t++) { int l = t ? !X : X; if (((m.pf >> l) & 1) && refs_->poc[l][m.ref[l]] == tp) { mv[0] = m.mv[l][0]; mv[1] = m.mv[l][1];
+            return true; } }
         return false;
     };
     auto scaled_ref = [&](const HevcMotion &m, int16_t *mv) {
@@ -272,7 +277,8 @@ void HevcPicParser::parse_sao(int rs) {
     const int rx = rs % ctb_w_, ry = rs / ctb_w_;
     bool left = false, up = false;
     if (rx > 0 && ctb_slice_[rs - 1] == sh_->slice_addr && tile_id_[rs2ts_[rs - 1]] == tile_id_[ctb_ts_]) left = cb_.decision(HEVC_CTX_SAO_MERGE);
-    if (!left && ry > 0 && ctb_slice_[rs - ctb_w_] == sh_->slice_addr && tile_id_[rs2ts_[rs - ctb_w_]] == tile_id_[ctb_ts_]) up = cb_.decision(HEVC_CTX_SAO_MERGE);
+    if (!left && ry > 0 && ctb_slice_[rs - ctb_w_] == sh_->slice_addr &&
+        tile_id_[rs2ts_[rs - ctb_w_]] == tile_id_[ctb_ts_]) up = cb_.decision(HEVC_CTX_SAO_MERGE);
     if (left || up) {
         const HevcCtb &s = jobs_->ctbs[left ? rs - 1 : rs - ctb_w_];
         memcpy(o.sao_type, s.sao_type, 3); memcpy(o.sao_pos, s.sao_pos, 3); memcpy(o.sao_off, s.sao_off, 12);
@@ -296,7 +302,8 @@ void HevcPicParser::parse_sao(int rs) {
     if (!sh_->sao_luma) o.sao_type[0] = 0;
     if (!sh_->sao_chroma) o.sao_type[1] = o.sao_type[2] = 0;
     if (o.sao_type[0] | o.sao_type[1] | o.sao_type[2]) jobs_->any_sao = true;
-    if (dg_->on) for (int c = 0; c < 3; c++) { dg(0x6000 | (c << 8) | (o.sao_type[c] << 6) | o.sao_pos[c] * (o.sao_type[c] != 0)); if (o.sao_type[c]) for (int i = 0; i < 4; i++) dg(o.sao_off[c][i]); }
+    if (dg_->on) for (int c = 0; c < 3; c++) { dg(0x6000 | (c << 8) | (o.sao_type[c] << 6) | o.sao_pos[c] * (o.sao_type[c] != 0));
+        if (o.sao_type[c]) for (int i = 0; i < 4; i++) dg(o.sao_off[c][i]); }
 }
 
 // intra transform block record; xp/yp in samples of plane c
@@ -329,14 +336,17 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     // last significant coefficient position
     int last[2];
     for (int d = 0; d < 2; d++) {
-        const int cmax = 2 * log2 - 1, off = c ? 15 : 3 * (log2 - 2) + ((log2 - 1) >> 2), shf = c ? log2 - 2 : (log2 + 1) >> 2, base = d ? HEVC_CTX_LAST_Y : HEVC_CTX_LAST_X;
+        const int cmax = 2 * log2 - 1, off = c ? 15 : 3 * (log2 - 2) + ((log2 - 1) >> 2), shf = c ? log2 - 2 : (log2 + 1) >> 2,
+            base = d ? HEVC_CTX_LAST_Y : HEVC_CTX_LAST_X;
         int v = 0;
         while (v < cmax && cb.decision(base + off + (v >> shf))) v++;
         last[d] = v;
     }
-    for (int d = 0; d < 2; d++) if (last[d] > 3) { int nb = (last[d] >> 1) - 1, s = 0; for (int i = 0; i < nb; i++) s = (s << 1) | cb.bypass(); last[d] = (1 << nb) * (2 + (last[d] & 1)) + s; }
+    for (int d = 0; d < 2; d++) if (last[d] > 3) { int nb = (last[d] >> 1) - 1, s = 0; for (int i = 0; i < nb; i++) s = (s << 1) | cb.bypass();
+        last[d] = (1 << nb) * (2 + (last[d] & 1)) + s; }
     int scan = 0;
-    if (cu_intra_ && (log2 == 2 || (log2 == 3 && c == 0))) { int pm = c == 0 ? ipm_[i4(x0, y0)] : ipm_c_; if (pm >= 6 && pm <= 14) scan = 2; else if (pm >= 22 && pm <= 30) scan = 1; }
+    if (cu_intra_ && (log2 == 2 || (log2 == 3 && c == 0))) { int pm = c == 0 ? ipm_[i4(x0, y0)] : ipm_c_; if (pm >= 6 && pm <= 14) scan = 2;
+        else if (pm >= 22 && pm <= 30) scan = 1; }
     int lx = last[0], ly = last[1];
     if (scan == 2) std::swap(lx, ly);
     if (lx >= n || ly >= n) return false;
@@ -374,7 +384,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         // sig_coeff_flag context = per-sub-block base + a table term by scan position; only the DC of the whole block is special
         const uint8_t *pat = kScan.sigpat[scan][log2 == 2 ? 4 : prev];
         const int sig0 = HEVC_CTX_SIG + (c ? 27 : 0);
-        const int sbase = log2 == 2 ? sig0 : (c == 0 ? HEVC_CTX_SIG + (i > 0 ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21) : HEVC_CTX_SIG + 27 + (log2 == 3 ? 9 : 12));
+        const int sbase = log2 == 2 ? sig0 :
+            (c == 0 ? HEVC_CTX_SIG + (i > 0 ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21) : HEVC_CTX_SIG + 27 + (log2 == 3 ? 9 : 12));
         for (int k = start; k >= 1; k--) if (cb.decision(sbase + pat[k])) { sig |= (uint16_t)(1u << k); infer_dc = false; }
         if (start >= 0) {
             if (infer_dc) sig |= 1;
@@ -406,7 +417,9 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
                 if (q >= 32) return false;
                 int rem;
                 if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb.bypass_bits(rice); }
-                else { int nb = q - 3 + rice; if (nb > 30) return false; int s = nb > 16 ? (int)(cb.bypass_bits(nb - 16) << 16 | cb.bypass_bits(16)) : (int)cb.bypass_bits(nb); rem = (((1 << (q - 3)) + 2) << rice) + s; }
+                else { int nb = q - 3 + rice; if (nb > 30) return false;
+                    int s = nb > 16 ? (int)(cb.bypass_bits(nb - 16) << 16 | cb.bypass_bits(16)) : (int)cb.bypass_bits(nb);
+                    rem = (((1 << (q - 3)) + 2) << rice) + s; }
                 a += rem;
                 if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
             }
@@ -437,7 +450,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         jobs_->coefs.resize(first + (size_t)nz_n_);                  // written in place, trimmed to what survived scaling
         uint32_t *cw = jobs_->coefs.data() + first;
         if (tq_bypass_) {
-            for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx]; if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
+            for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx];
+                if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
         } else {
             for (int k = 0; k < nz_n_; k++) {
                 const int idx = nz_pos_[k];
@@ -449,7 +463,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     }
     const uint8_t flags = (uint8_t)((tskip ? HTB_TSKIP : 0) | (tq_bypass_ ? HTB_BYPASS : 0) | ((cu_intra_ && c == 0 && n == 4) ? HTB_DST : 0));
     if (intra_tb) { HevcIntraTb &t = jobs_->itbs.back(); t.coef_off = first; t.coef_n = count; t.flags |= flags; }
-    else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0; t.coef_off = first; t.coef_n = count; jobs_->tbs.push_back(t); }
+    else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0;
+        t.coef_off = first; t.coef_n = count; jobs_->tbs.push_back(t); }
     return true;
 }
 
@@ -470,7 +485,8 @@ bool HevcPicParser::transform_unit(int x0, int y0, int xb, int yb, int log2, int
     if ((cbf_y || cbf_cb || cbf_cr) && pps_->cu_qp_delta && !dqp_coded_) {
         int v = 0;
         if (cb_.decision(HEVC_CTX_CU_QP_DELTA)) { v = 1; while (v < 5 && cb_.decision(HEVC_CTX_CU_QP_DELTA + 1)) v++; }
-        if (v == 5) { int k = 0, a = 0; while (cb_.bypass()) { a += 1 << k; if (++k > 16) return false; } for (int b = k - 1; b >= 0; b--) a += cb_.bypass() << b; v += a; }
+        if (v == 5) { int k = 0, a = 0; while (cb_.bypass()) { a += 1 << k; if (++k > 16) return false; }
+            for (int b = k - 1; b >= 0; b--) a += cb_.bypass() << b; v += a; }
         if (v && cb_.bypass()) v = -v;
         if (v < -26 || v > 25) return false;
         dqp_coded_ = true; dqp_ = v;
@@ -493,7 +509,8 @@ bool HevcPicParser::transform_unit(int x0, int y0, int xb, int yb, int log2, int
 }
 bool HevcPicParser::transform_tree(int x0, int y0, int xb, int yb, int log2, int depth, int blk, int pcb, int pcr) {
     bool split;
-    if (log2 <= sps_->log2_max_tb && log2 > sps_->log2_min_tb && depth < max_tr_depth_ && !(intra_split_ && depth == 0)) split = cb_.decision(HEVC_CTX_SPLIT_TF + 5 - log2);
+    if (log2 <= sps_->log2_max_tb && log2 > sps_->log2_min_tb && depth < max_tr_depth_ && !(intra_split_ &&
+        depth == 0)) split = cb_.decision(HEVC_CTX_SPLIT_TF + 5 - log2);
     else split = log2 > sps_->log2_max_tb || (intra_split_ && depth == 0) || (sps_->depth_inter == 0 && !cu_intra_ && part_mode_ != PART_2Nx2N && depth == 0);
     int ccb = pcb, ccr = pcr;
     if (log2 > 2) { ccb = pcb ? cb_.decision(HEVC_CTX_CBF_CBCR + depth) : 0; ccr = pcr ? cb_.decision(HEVC_CTX_CBF_CBCR + depth) : 0; }
@@ -531,7 +548,8 @@ bool HevcPicParser::prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, i
         for (int l = 0; l < 2; l++) {
             if (idc == (l ? 0 : 1)) continue;
             int ri = 0;
-            if (sh_->n_ref[l] > 1) { const int cmax = sh_->n_ref[l] - 1; while (ri < cmax && (ri < 2 ? cb_.decision(HEVC_CTX_REF_IDX + ri) : cb_.bypass())) ri++; }
+            if (sh_->n_ref[l] > 1) { const int cmax = sh_->n_ref[l] - 1;
+                while (ri < cmax && (ri < 2 ? cb_.decision(HEVC_CTX_REF_IDX + ri) : cb_.bypass())) ri++; }
             m.ref[l] = (int8_t)ri; m.pf |= (uint8_t)(1 << l);
             if (!(l == 1 && sh_->mvd_l1_zero && idc == 2)) {
                 int g0[2], g1[2] = {0, 0};
@@ -542,7 +560,8 @@ bool HevcPicParser::prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, i
                     int v = 0;
                     if (g0[d]) {
                         v = 1;
-                        if (g1[d]) { int k = 1, a = 0; while (cb_.bypass()) { a += 1 << k; if (++k > 17) return false; } for (int b = k - 1; b >= 0; b--) a += cb_.bypass() << b; v = a + 2; }
+                        if (g1[d]) { int k = 1, a = 0; while (cb_.bypass()) { a += 1 << k; if (++k > 17) return false; }
+                            for (int b = k - 1; b >= 0; b--) a += cb_.bypass() << b; v = a + 2; }
                         if (cb_.bypass()) v = -v;
                     }
                     if (v < -32768 || v > 32767) return false;
@@ -568,7 +587,8 @@ bool HevcPicParser::prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, i
             if (r == 0) for (int k = 0; k < nux; k++) ed[i + k] |= 8;
         }
     }
-    if (dg_->on) { dg(0x5000 | (merge << 4) | m.pf); dg(x0); dg(y0); dg(w); dg(h); dg(m.ref[0]); dg(m.ref[1]); dg(m.mv[0][0]); dg(m.mv[0][1]); dg(m.mv[1][0]); dg(m.mv[1][1]); }
+    if (dg_->on) { dg(0x5000 | (merge << 4) | m.pf); dg(x0); dg(y0); dg(w); dg(h); dg(m.ref[0]); dg(m.ref[1]); dg(m.mv[0][0]); dg(m.mv[0][1]); dg(m.mv[1][0]);
+        dg(m.mv[1][1]); }
     // motion compensation jobs: tiles of at most 16x16 luma samples
     HevcPu j; memset(&j, 0, sizeof j);
     j.slot0 = (m.pf & 1) ? refs_->slot[0][m.ref[0]] : -1; j.slot1 = (m.pf & 2) ? refs_->slot[1][m.ref[1]] : -1;
@@ -620,7 +640,8 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_, ved = r == 0 ? 10 : 0;
             if (nu <= 4) {                                      // (8x8 and 16x16 units: a library call per array costs more than the stores)
                 for (int k = 0; k < nu; k++) { pm[i + k] = vpm; sk[i + k] = vsk; nf[i + k] = vnf; cf[i + k] = 0; ip[i + k] = 1; ed[i + k] = ved; }
-            } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu); memset(ed + i, ved, nu); }
+            } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu);
+                memset(ed + i, ved, nu); }
             ed[i] |= 5;
             for (int k = 0; k < nu; k++) so[i + k] = sidx;
             if (cu_intra_) for (int k = 0; k < nu; k++) mo[i + k] = blank;      // (the prediction units of an inter unit cover it and write their own)
@@ -648,8 +669,10 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             for (int c = 0; c < 3; c++) {
                 const int sc = c ? 1 : 0, nn = n >> sc, bits = c ? sps_->pcm_bits_c : sps_->pcm_bits_y, lg = log2 - sc;
                 HevcIntraTb t; memset(&t, 0, sizeof t);
-                t.x = (uint16_t)(x0 >> sc); t.y = (uint16_t)(y0 >> sc); t.log2 = (uint8_t)lg; t.plane = (uint8_t)c; t.mode = kHevcModePcm; t.flags = HTB_BYPASS; t.coef_off = (uint32_t)jobs_->coefs.size();
-                for (int k = 0; k < nn * nn; k++) { int v = (int)br.u(bits); if (dg_->on) dg(v); v <<= 8 - bits; if (v) jobs_->coefs.push_back((uint32_t)k | ((uint32_t)v << 16)); }
+                t.x = (uint16_t)(x0 >> sc); t.y = (uint16_t)(y0 >> sc); t.log2 = (uint8_t)lg; t.plane = (uint8_t)c; t.mode = kHevcModePcm; t.flags = HTB_BYPASS;
+                t.coef_off = (uint32_t)jobs_->coefs.size();
+                for (int k = 0; k < nn * nn; k++) { int v = (int)br.u(bits); if (dg_->on) dg(v); v <<= 8 - bits;
+                    if (v) jobs_->coefs.push_back((uint32_t)k | ((uint32_t)v << 16)); }
                 t.coef_n = (uint32_t)jobs_->coefs.size() - t.coef_off;
                 jobs_->itbs.push_back(t);
             }
@@ -667,12 +690,15 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             for (int k = 0; k < np * np; k++) {
                 const int xp = x0 + (k & 1) * pb, yp = y0 + (k >> 1) * pb;
                 int idx;
-                if (prev_flag[k]) { idx = 0; while (idx < 2 && cb_.bypass()) idx++; } else { idx = 0; for (int b = 0; b < 5; b++) idx = (idx << 1) | cb_.bypass(); }
+                if (prev_flag[k]) { idx = 0; while (idx < 2 && cb_.bypass()) idx++; } else { idx = 0;
+                    for (int b = 0; b < 5; b++) idx = (idx << 1) | cb_.bypass(); }
                 int a = 1, b = 1;                                       // 8.4.2
                 if (avail_zs(xp, yp, xp - 1, yp) && pm_[i4(xp - 1, yp)] == 2) a = ipm_[i4(xp - 1, yp)];
-                if (((yp - 1) >> sps_->log2_ctb) == (yp >> sps_->log2_ctb) && avail_zs(xp, yp, xp, yp - 1) && pm_[i4(xp, yp - 1)] == 2) b = ipm_[i4(xp, yp - 1)];
+                if (((yp - 1) >> sps_->log2_ctb) == (yp >> sps_->log2_ctb) && avail_zs(xp, yp, xp, yp - 1) && pm_[i4(xp, yp - 1)] == 2) b = ipm_[i4(xp,
+                    yp - 1)];
                 int cand[3];
-                if (a == b) { if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; } else { cand[0] = a; cand[1] = 2 + ((a + 29) & 31); cand[2] = 2 + ((a - 1) & 31); } }
+                if (a == b) { if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; } else { cand[0] = a; cand[1] = 2 + ((a + 29) & 31);
+                    cand[2] = 2 + ((a - 1) & 31); } }
                 else { cand[0] = a; cand[1] = b; cand[2] = (a && b) ? 0 : ((a != 1 && b != 1) ? 1 : 26); }
                 int mode;
                 if (prev_flag[k]) mode = cand[idx];
@@ -729,7 +755,8 @@ bool HevcPicParser::coding_quadtree(int x0, int y0, int log2, int depth) {
     }
     if (split) {
         const int hh = n >> 1;
-        for (int k = 0; k < 4; k++) { const int x = x0 + (k & 1) * hh, y = y0 + (k >> 1) * hh; if (x < w_ && y < h_ && !coding_quadtree(x, y, log2 - 1, depth + 1)) return false; }
+        for (int k = 0; k < 4; k++) { const int x = x0 + (k & 1) * hh, y = y0 + (k >> 1) * hh;
+            if (x < w_ && y < h_ && !coding_quadtree(x, y, log2 - 1, depth + 1)) return false; }
         return true;
     }
     for (int r = 0; r < (n >> 2); r++) memset(depth_.data() + i4(x0, y0 + 4 * r), depth, n >> 2);
@@ -746,7 +773,8 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
     const int n_ctb = ctb_w_ * ctb_h_;
     if (!sh.dependent) {
         SliceInfo si; memset(&si, 0, sizeof si);
-        si.addr = sh.slice_addr; si.deblock_disabled = sh.deblock_disabled; si.lf_across = sh.lf_across_slices; si.beta_off = (int8_t)sh.beta_off; si.tc_off = (int8_t)sh.tc_off;
+        si.addr = sh.slice_addr; si.deblock_disabled = sh.deblock_disabled; si.lf_across = sh.lf_across_slices; si.beta_off = (int8_t)sh.beta_off;
+        si.tc_off = (int8_t)sh.tc_off;
         memcpy(si.slot, refs.slot, sizeof si.slot); memcpy(si.poc, refs.poc, sizeof si.poc); memcpy(si.is_lt, refs.is_lt, sizeof si.is_lt);
         slices_.push_back(si);
         wp_index_ = 0;
@@ -772,10 +800,12 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         const int rx = ctb_rs_ % ctb_w_, ry = ctb_rs_ / ctb_w_, tile = tile_id_[ctb_ts_];
         const bool first_in_tile = ctb_ts_ == 0 || tile_id_[ctb_ts_ - 1] != tile;
         const bool row_start = pps_->wpp && (rx == 0 || tile_id_[rs2ts_[ctb_rs_ - 1]] != tile);
-        if (refs.col && (rx == 0 || first_ctu)) refs.col->wait_rows(std::min((h_ + 15) >> 4, ((ry + 1) << sps_->log2_ctb) >> 4));      // the collocated picture's motion down to this CTB row (its own parse sizes and fills the field: never read it before)
+        // the collocated picture's motion down to this CTB row (its own parse sizes and fills the field: never read it before)
+        if (refs.col && (rx == 0 || first_ctu)) refs.col->wait_rows(std::min((h_ + 15) >> 4, ((ry + 1) << sps_->log2_ctb) >> 4));
         if (ctb_slice_[ctb_rs_] >= 0) return "coding tree block decoded twice";
         ctb_slice_[ctb_rs_] = sh.slice_addr;
-        { HevcCtb &cj = jobs_->ctbs[ctb_rs_]; cj.beta_off = slices_[slice_idx_].beta_off; cj.tc_off = slices_[slice_idx_].tc_off; cj.intra_first = (uint32_t)jobs_->itbs.size(); }
+        { HevcCtb &cj = jobs_->ctbs[ctb_rs_]; cj.beta_off = slices_[slice_idx_].beta_off; cj.tc_off = slices_[slice_idx_].tc_off;
+            cj.intra_first = (uint32_t)jobs_->itbs.size(); }
         // 9.3.1: the first CTB of a tile ALWAYS starts from initialised context variables -- also when it opens a dependent slice segment (the
         // stored variables of the previous segment only apply to a segment that starts inside a tile)
         if (first_in_tile) { if (!first_ctu || sh.dependent) init_contexts(); first_qg_ = true; cu_since_reset_ = false; qp_prev_ = sh.qp; }
@@ -789,9 +819,11 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         parse_sao(ctb_rs_);
         if (!coding_quadtree(rx << sps_->log2_ctb, ry << sps_->log2_ctb, sps_->log2_ctb, 0) || cb_.overrun) return "corrupt slice data";
         jobs_->ctbs[ctb_rs_].intra_count = (uint32_t)jobs_->itbs.size() - jobs_->ctbs[ctb_rs_].intra_first;
-        if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) { memcpy(wpp_state_, cb_.state, HEVC_N_CTX * sizeof(Cabac::State)); wpp_valid_ = true; }
+        if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) {
+            memcpy(wpp_state_, cb_.state, HEVC_N_CTX * sizeof(Cabac::State)); wpp_valid_ = true; }
         // a finished CTB row (pictures without tiles: rows complete in order) makes its part of the motion field final
-        if (col_out_ && !pps_->tiles && rx == ctb_w_ - 1 && ry * (ctb_size_ >> 4) == exported_rows_) export_motion_rows(exported_rows_, std::min(col_out_->h16, (ry + 1) * (ctb_size_ >> 4)));
+        if (col_out_ && !pps_->tiles && rx == ctb_w_ - 1 && ry * (ctb_size_ >> 4) == exported_rows_) export_motion_rows(exported_rows_, std::min(col_out_->h16,
+            (ry + 1) * (ctb_size_ >> 4)));
         const int end = cb_.terminate();
         ctb_ts_++;
         if (end) break;
@@ -818,7 +850,8 @@ void HevcPicParser::export_motion_rows(int r0, int r1) {
         const int i = i4(x * 16, y * 16); const size_t e = (size_t)y * c.w16 + x;
         c.intra[e] = pm_[i] != 1; c.mot[e] = mot_[i]; c.lt[e] = 0;
         size_t k = slice_of_[i]; const SliceInfo &s = slices_[k < slices_.size() ? k : slices_.size() - 1];
-        for (int l = 0; l < 2; l++) if (pm_[i] == 1 && ((mot_[i].pf >> l) & 1)) { c.ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]]; c.lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
+        for (int l = 0; l < 2; l++) if (pm_[i] == 1 && ((mot_[i].pf >> l) & 1)) { c.ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]];
+            c.lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
     }
     exported_rows_ = r1;
     c.publish_rows(r1);
@@ -845,20 +878,23 @@ void HevcPicParser::finish_picture() {
             // 8x8 luma / 4x4 chroma blocks of the value 128 (PCM-style: no prediction, the "coefficients" are the samples)
             const int sc = c ? 1 : 0, lg = 3 - sc, nn = 1 << lg;
             HevcIntraTb t; memset(&t, 0, sizeof t);
-            t.x = (uint16_t)(x >> sc); t.y = (uint16_t)(y >> sc); t.log2 = (uint8_t)lg; t.plane = (uint8_t)c; t.mode = kHevcModePcm; t.flags = HTB_BYPASS; t.coef_off = (uint32_t)jobs_->coefs.size();
+            t.x = (uint16_t)(x >> sc); t.y = (uint16_t)(y >> sc); t.log2 = (uint8_t)lg; t.plane = (uint8_t)c; t.mode = kHevcModePcm; t.flags = HTB_BYPASS;
+            t.coef_off = (uint32_t)jobs_->coefs.size();
             for (int k = 0; k < nn * nn; k++) jobs_->coefs.push_back((uint32_t)k | (128u << 16));
             t.coef_n = (uint32_t)(nn * nn);
             jobs_->itbs.push_back(t);
         }
         cj.intra_count = (uint32_t)jobs_->itbs.size() - cj.intra_first;
-        for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y); pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; slice_of_[i] = 0; }
+        for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y);
+            pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; slice_of_[i] = 0; }
     }
     if (slices_.empty()) { SliceInfo si; memset(&si, 0, sizeof si); si.deblock_disabled = true; slices_.push_back(si); }
     // (after a damaged slice a unit may hold the slice index of an earlier picture: clamp)
     auto slice_at = [&](int i) -> const SliceInfo & { size_t k = slice_of_[i]; return slices_[k < slices_.size() ? k : slices_.size() - 1]; };
     const int w8 = w_ >> 3, h8 = h_ >> 3;
     jobs_->qp8.resize((size_t)w8 * h8);
-    for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8); jobs_->qp8[(size_t)y * w8 + x] = (uint8_t)((qp_[i] & 63) | (nofilter_[i] ? 128 : 0)); }
+    for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8);
+        jobs_->qp8[(size_t)y * w8 + x] = (uint8_t)((qp_[i] & 63) | (nofilter_[i] ? 128 : 0)); }
     // boundary strengths: bs_v[(y / 4) * (w / 8) + x / 8] for vertical edges at x = 8k, bs_h[(y / 8) * (w / 4) + x / 4] for horizontal edges
     jobs_->bs_v.assign((size_t)w8 * h4_, 0); jobs_->bs_h.assign((size_t)w4_ * h8, 0);
     // (raw pointers: the vectors' data pointers would be reloaded after every byte store; one slice and one tile -- the usual case -- needs no boundary tests)
@@ -874,15 +910,18 @@ void HevcPicParser::finish_picture() {
         if (!one_region) {
             sq = &slice_at(q); sp = &slice_at(p);
             if (sq->addr != sp->addr && !sq->lf_across) return 0;
-            if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc); if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
+            if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc);
+                if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
         }
         if (sq->deblock_disabled) return 0;
         if (pm[q] == 2 || pm[p] == 2) return 2;
         if (tu && (cbf[q] || cbf[p])) return 1;
         const HevcMotion &a = mot[q], &b = mot[p];
-        if (sq == sp && !memcmp(&a, &b, sizeof a)) return 0;      // the same motion on both sides (a transform edge inside a prediction block, merged neighbours)
+        // the same motion on both sides (a transform edge inside a prediction block, merged neighbours)
+        if (sq == sp && !memcmp(&a, &b, sizeof a)) return 0;
         int ra[2], rb[2]; const int16_t *va[2], *vb[2]; int na = 0, nb = 0;
-        for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq->slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) { rb[nb] = sp->slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
+        for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq->slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) {
+            rb[nb] = sp->slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
         if (na != nb) return 1;
         auto far = [](const int16_t *u, const int16_t *v) { return std::abs(u[0] - v[0]) >= 4 || std::abs(u[1] - v[1]) >= 4; };
         if (na == 1) return ra[0] != rb[0] || far(va[0], vb[0]);

@@ -42,7 +42,8 @@ struct HevcPicJobs {
     std::vector<HevcCtb> ctbs; std::vector<uint8_t> qp8, bs_v, bs_h;
     std::vector<HevcPu> pus; std::vector<HevcTb> tbs; std::vector<HevcIntraTb> itbs; std::vector<uint32_t> coefs; std::vector<HevcWp> wps;
     bool any_sao = false, any_deblock = false; int n_intra_cu = 0;
-    void clear() { ctbs.clear(); qp8.clear(); bs_v.clear(); bs_h.clear(); pus.clear(); tbs.clear(); itbs.clear(); coefs.clear(); wps.clear(); any_sao = any_deblock = false; n_intra_cu = 0; }
+    void clear() { ctbs.clear(); qp8.clear(); bs_v.clear(); bs_h.clear(); pus.clear(); tbs.clear(); itbs.clear(); coefs.clear(); wps.clear();
+        any_sao = any_deblock = false; n_intra_cu = 0; }
 };
 
 struct HevcDigest { bool on = false; uint64_t h = 0xcbf29ce484222325ULL; uint64_t n_cu = 0; FILE *trace = nullptr; };
@@ -73,7 +74,8 @@ private:
     void amvp(int xcb, int ycb, int ncb, int xp, int yp, int w, int h, int part, int X, int ridx, int flag, int16_t out[2]);
     bool temporal(int xp, int yp, int w, int h, int X, int ridx, int16_t mv[2]);
     void init_contexts();
-    inline void dg(int v) { if (dg_->on && dg_->trace) fprintf(dg_->trace, "D %d\n", v); if (dg_->on) for (int i = 0; i < 4; i++) { dg_->h ^= (uint8_t)((uint32_t)v >> (8 * i)); dg_->h *= 0x100000001b3ULL; } }
+    inline void dg(int v) { if (dg_->on && dg_->trace) fprintf(dg_->trace, "D %d\n", v); if (dg_->on) for (int i = 0; i < 4; i++) {
+        dg_->h ^= (uint8_t)((uint32_t)v >> (8 * i)); dg_->h *= 0x100000001b3ULL; } }
     inline int i4(int x, int y) const { return (y >> 2) * w4_ + (x >> 2); }
 
     const HevcSps *sps_ = nullptr; const HevcPps *pps_ = nullptr; const HevcSliceHeader *sh_ = nullptr; const HevcSliceRefs *refs_ = nullptr;
@@ -85,7 +87,8 @@ private:
     int poc_ = 0, w_ = 0, h_ = 0, w4_ = 0, h4_ = 0, ctb_w_ = 0, ctb_h_ = 0, ctb_size_ = 0, tb_w_ = 0;
     std::vector<int> rs2ts_, ts2rs_, tile_id_, ctb_slice_;
     std::vector<uint32_t> zs_;                 // MinTbAddrZs
-    std::vector<uint8_t> pm_, skip_, depth_, ipm_, nofilter_, edge_, cbf_; std::vector<int8_t> qp_; std::vector<HevcMotion> mot_; std::vector<uint16_t> slice_of_;
+    std::vector<uint8_t> pm_, skip_, depth_, ipm_, nofilter_, edge_, cbf_; std::vector<int8_t> qp_; std::vector<HevcMotion> mot_;
+    std::vector<uint16_t> slice_of_;
     std::vector<SliceInfo> slices_;
     int slice_idx_ = 0, ctb_rs_ = 0, ctb_ts_ = 0;
     // CU state

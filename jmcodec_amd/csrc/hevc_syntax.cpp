@@ -49,12 +49,15 @@ bool parse_scaling_list_data(BitReader &br, HevcScaling &sf) {          // 7.3.4
             if (!br.u1()) {
                 uint32_t delta = br.ue();
                 if (delta > (uint32_t)k) return false;
-                if (delta == 0) { if (size == 0) memset(c.l[0][m], 16, 16); else memcpy(c.l[size][m], hevc_scaling_default[size == 3 ? k : (m >= 3)], 64); c.dc[size][m] = 16; }
-                else { int rm = size == 3 ? 3 * (k - (int)delta) : m - (int)delta; memmove(c.l[size][m], c.l[size][rm], (size_t)n); c.dc[size][m] = c.dc[size][rm]; }
+                if (delta == 0) { if (size == 0) memset(c.l[0][m], 16, 16); else memcpy(c.l[size][m], hevc_scaling_default[size == 3 ? k : (m >= 3)], 64);
+                    c.dc[size][m] = 16; }
+                else { int rm = size == 3 ? 3 * (k - (int)delta) : m - (int)delta; memmove(c.l[size][m], c.l[size][rm], (size_t)n);
+                    c.dc[size][m] = c.dc[size][rm]; }
             } else {
                 int next = 8;
                 if (size > 1) { int v = br.se(); if (v < -7 || v > 247) return false; next = v + 8; c.dc[size][m] = (uint8_t)next; }
-                for (int i = 0; i < n; i++) { int d = br.se(); if (d < -128 || d > 127) return false; next = (next + d + 256) & 255; c.l[size][m][i] = (uint8_t)next; }
+                for (int i = 0; i < n; i++) { int d = br.se(); if (d < -128 || d > 127) return false; next = (next + d + 256) & 255;
+                    c.l[size][m][i] = (uint8_t)next; }
             }
         }
     }
@@ -87,13 +90,15 @@ bool parse_rps(BitReader &br, HevcRps &out, int idx, int n_sps, const HevcRps *k
         // candidate deltas of the reference set in increasing order of POC: positives reversed ... no: walk the spec's three loops
         auto push = [&](int list, int &n, int dp, bool u) { if (n >= 16) return false; out.d[list][n] = (int16_t)dp; out.used[list][n] = u; n++; return true; };
         int n = 0;
-        for (int j = ref.n_pos - 1; j >= 0; j--) { int dp = ref.d[1][j] + drps; if (dp < 0 && keep[ref.n_neg + j] && !push(0, n, dp, used[ref.n_neg + j])) return false; }
+        for (int j = ref.n_pos - 1; j >= 0; j--) { int dp = ref.d[1][j] + drps; if (dp < 0 && keep[ref.n_neg + j] && !push(0, n, dp,
+            used[ref.n_neg + j])) return false; }
         if (drps < 0 && keep[total] && !push(0, n, drps, used[total])) return false;
         for (int j = 0; j < ref.n_neg; j++) { int dp = ref.d[0][j] + drps; if (dp < 0 && keep[j] && !push(0, n, dp, used[j])) return false; }
         out.n_neg = n; n = 0;
         for (int j = ref.n_neg - 1; j >= 0; j--) { int dp = ref.d[0][j] + drps; if (dp > 0 && keep[j] && !push(1, n, dp, used[j])) return false; }
         if (drps > 0 && keep[total] && !push(1, n, drps, used[total])) return false;
-        for (int j = 0; j < ref.n_pos; j++) { int dp = ref.d[1][j] + drps; if (dp > 0 && keep[ref.n_neg + j] && !push(1, n, dp, used[ref.n_neg + j])) return false; }
+        for (int j = 0; j < ref.n_pos; j++) { int dp = ref.d[1][j] + drps; if (dp > 0 && keep[ref.n_neg + j] && !push(1, n, dp,
+            used[ref.n_neg + j])) return false; }
         out.n_pos = n;
     } else {
         uint32_t a = br.ue(), b = br.ue();
@@ -133,10 +138,12 @@ std::string HevcParamSets::parse_sps(BitReader &br) {
     s.log2_min_cb = (int)br.ue() + 3; s.log2_ctb = s.log2_min_cb + (int)br.ue();
     s.log2_min_tb = (int)br.ue() + 2; s.log2_max_tb = s.log2_min_tb + (int)br.ue();
     s.depth_inter = (int)br.ue(); s.depth_intra = (int)br.ue();
-    if (br.overrun() || s.log2_ctb < 4 || s.log2_ctb > 6 || s.log2_min_cb > s.log2_ctb || s.log2_min_tb >= s.log2_min_cb || s.log2_max_tb > 5 || s.log2_max_tb > s.log2_ctb ||
+    if (br.overrun() || s.log2_ctb < 4 || s.log2_ctb > 6 || s.log2_min_cb > s.log2_ctb || s.log2_min_tb >= s.log2_min_cb || s.log2_max_tb > 5 ||
+        s.log2_max_tb > s.log2_ctb ||
         s.depth_inter > s.log2_ctb - s.log2_min_tb || s.depth_intra > s.log2_ctb - s.log2_min_tb) return "SPS: block size parameters out of range";
     const int mcb = (1 << s.log2_min_cb) - 1;
-    if (s.width <= 0 || s.height <= 0 || s.width > 8192 || s.height > 8192 || (s.width & mcb) || (s.height & mcb)) return "SPS: picture size is not a multiple of the minimum coding block";
+    if (s.width <= 0 || s.height <= 0 || s.width > 8192 || s.height > 8192 || (s.width & mcb) ||
+        (s.height & mcb)) return "SPS: picture size is not a multiple of the minimum coding block";
     if (2 * (s.conf[0] + s.conf[1]) >= s.width || 2 * (s.conf[2] + s.conf[3]) >= s.height) return "SPS: conformance window larger than the picture";
     s.scaling_enabled = br.u1();
     s.sf.set_default();
@@ -146,7 +153,8 @@ std::string HevcParamSets::parse_sps(BitReader &br) {
         s.pcm_bits_y = (int)br.u(4) + 1; s.pcm_bits_c = (int)br.u(4) + 1;
         s.log2_min_pcm = (int)br.ue() + 3; s.log2_max_pcm = s.log2_min_pcm + (int)br.ue();
         s.pcm_loop_filter_disabled = br.u1();
-        if (s.pcm_bits_y > 8 || s.pcm_bits_c > 8 || s.log2_min_pcm < s.log2_min_cb || s.log2_max_pcm > 5 || s.log2_max_pcm > s.log2_ctb) return "SPS: PCM parameters out of range";
+        if (s.pcm_bits_y > 8 || s.pcm_bits_c > 8 || s.log2_min_pcm < s.log2_min_cb || s.log2_max_pcm > 5 ||
+            s.log2_max_pcm > s.log2_ctb) return "SPS: PCM parameters out of range";
     }
     s.n_rps = (int)br.ue();
     if (s.n_rps > 64) return "SPS: too many short-term reference picture sets";
@@ -183,7 +191,8 @@ std::string HevcParamSets::parse_pps(BitReader &br) {
         p.tile_cols = (int)br.ue() + 1; p.tile_rows = (int)br.ue() + 1;
         if (p.tile_cols > 20 || p.tile_rows > 22) return "PPS: too many tiles";
         p.uniform = br.u1();
-        if (!p.uniform) { for (int i = 0; i + 1 < p.tile_cols; i++) p.col_w[i] = (int)br.ue() + 1; for (int i = 0; i + 1 < p.tile_rows; i++) p.row_h[i] = (int)br.ue() + 1; }
+        if (!p.uniform) { for (int i = 0; i + 1 < p.tile_cols; i++) p.col_w[i] = (int)br.ue() + 1;
+            for (int i = 0; i + 1 < p.tile_rows; i++) p.row_h[i] = (int)br.ue() + 1; }
         p.lf_across_tiles = br.u1();
     }
     p.lf_across_slices = br.u1();
@@ -197,8 +206,10 @@ std::string HevcParamSets::parse_pps(BitReader &br) {
     p.log2_par_mrg = (int)br.ue() + 2;
     p.sh_extension = br.u1();
     if (br.overrun()) return "PPS truncated";
-    if (p.n_ref_default[0] > 15 || p.n_ref_default[1] > 15 || p.init_qp < 0 || p.init_qp > 51 || p.cb_qp_off < -12 || p.cb_qp_off > 12 || p.cr_qp_off < -12 || p.cr_qp_off > 12 ||
-        p.beta_off < -6 || p.beta_off > 6 || p.tc_off < -6 || p.tc_off > 6 || p.diff_cu_qp_delta_depth > 3 || p.log2_par_mrg > 6) return "PPS: parameter out of range";
+    if (p.n_ref_default[0] > 15 || p.n_ref_default[1] > 15 || p.init_qp < 0 || p.init_qp > 51 || p.cb_qp_off < -12 || p.cb_qp_off > 12 || p.cr_qp_off < -12 ||
+        p.cr_qp_off > 12 ||
+        p.beta_off < -6 || p.beta_off > 6 || p.tc_off < -6 || p.tc_off > 6 || p.diff_cu_qp_delta_depth > 3 ||
+            p.log2_par_mrg > 6) return "PPS: parameter out of range";
     p.valid = true;
     pps[id] = p;
     return "";
@@ -247,7 +258,8 @@ std::string HevcParamSets::parse_slice_header(BitReader &br, int nal_type, HevcS
                 int cycle_acc = 0;
                 for (int i = 0; i < sh.n_lt; i++) {
                     int lsb;
-                    if (i < from_sps) { int k = sp.n_lt > 1 ? (int)br.u(ceil_log2(sp.n_lt)) : 0; if (k >= sp.n_lt) return "lt_idx_sps out of range"; lsb = sp.lt_lsb[k]; sh.lt_used[i] = sp.lt_used[k]; }
+                    if (i < from_sps) { int k = sp.n_lt > 1 ? (int)br.u(ceil_log2(sp.n_lt)) : 0; if (k >= sp.n_lt) return "lt_idx_sps out of range";
+                        lsb = sp.lt_lsb[k]; sh.lt_used[i] = sp.lt_used[k]; }
                     else { lsb = (int)br.u(sp.log2_max_poc_lsb); sh.lt_used[i] = (uint8_t)br.u1(); }
                     sh.lt_msb[i] = (uint8_t)br.u1();
                     if (i == 0 || i == from_sps) cycle_acc = 0;                       // (7-52)
@@ -270,7 +282,8 @@ std::string HevcParamSets::parse_slice_header(BitReader &br, int nal_type, HevcS
                 const int nb = ceil_log2(total);
                 for (int l = 0; l < (sh.type == HSL_B ? 2 : 1); l++) {
                     sh.rplm[l] = br.u1();
-                    if (sh.rplm[l]) for (int i = 0; i < sh.n_ref[l]; i++) { uint32_t e = br.u(nb); if ((int)e >= total) return "list_entry out of range"; sh.list_entry[l][i] = (uint8_t)e; }
+                    if (sh.rplm[l]) for (int i = 0; i < sh.n_ref[l]; i++) { uint32_t e = br.u(nb); if ((int)e >= total) return "list_entry out of range";
+                        sh.list_entry[l][i] = (uint8_t)e; }
                 }
             }
             if (sh.type == HSL_B) sh.mvd_l1_zero = br.u1();
@@ -289,7 +302,8 @@ std::string HevcParamSets::parse_slice_header(BitReader &br, int nal_type, HevcS
                     for (int i = 0; i < sh.n_ref[l]; i++) fc[i] = br.u1();
                     for (int i = 0; i < sh.n_ref[l]; i++) {
                         for (int c = 0; c < 3; c++) { sh.wp_w[l][i][c] = (int16_t)(1 << sh.wp_denom[c ? 1 : 0]); sh.wp_o[l][i][c] = 0; }
-                        if (fy[i]) { int dw = br.se(), o = br.se(); if (dw < -128 || dw > 127 || o < -128 || o > 127) return "bad pred_weight_table"; sh.wp_w[l][i][0] = (int16_t)(sh.wp_w[l][i][0] + dw); sh.wp_o[l][i][0] = (int16_t)o; }
+                        if (fy[i]) { int dw = br.se(), o = br.se(); if (dw < -128 || dw > 127 || o < -128 || o > 127) return "bad pred_weight_table";
+                            sh.wp_w[l][i][0] = (int16_t)(sh.wp_w[l][i][0] + dw); sh.wp_o[l][i][0] = (int16_t)o; }
                         if (fc[i]) for (int c = 1; c < 3; c++) {
                             int dw = br.se(), dofs = br.se();
                             if (dw < -128 || dw > 127 || dofs < -512 || dofs > 511) return "bad pred_weight_table";
@@ -309,7 +323,8 @@ std::string HevcParamSets::parse_slice_header(BitReader &br, int nal_type, HevcS
         sh.deblock_disabled = pp.deblock_disabled; sh.beta_off = pp.beta_off; sh.tc_off = pp.tc_off;
         if (pp.deblock_override && br.u1()) {
             sh.deblock_disabled = br.u1();
-            if (!sh.deblock_disabled) { sh.beta_off = br.se(); sh.tc_off = br.se(); if (sh.beta_off < -6 || sh.beta_off > 6 || sh.tc_off < -6 || sh.tc_off > 6) return "slice deblocking offsets out of range"; }
+            if (!sh.deblock_disabled) { sh.beta_off = br.se(); sh.tc_off = br.se();
+                if (sh.beta_off < -6 || sh.beta_off > 6 || sh.tc_off < -6 || sh.tc_off > 6) return "slice deblocking offsets out of range"; }
         }
         sh.lf_across_slices = pp.lf_across_slices;
         if (pp.lf_across_slices && (sh.sao_luma || sh.sao_chroma || !sh.deblock_disabled)) sh.lf_across_slices = br.u1();

@@ -37,7 +37,8 @@ HostCopier *HostCopier::get(int dev) {
     if (ag.cpus.empty()) return nullptr;
     // the HSA agent of this HIP device: same PCI location
     int bus = -1, pdev = -1, dom = -1;
-    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId, dev) != hipSuccess ||
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId,
+        dev) != hipSuccess ||
         hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     HostCopier *c = nullptr;
     for (hsa_agent_t g : ag.gpus) {
@@ -63,7 +64,8 @@ HostCopier *HostCopier::get(int dev) {
     if (hsa_amd_memory_get_preferred_copy_engine(ga, ca, &h2d) != HSA_STATUS_SUCCESS) h2d = 0;
     if (hsa_amd_memory_get_preferred_copy_engine(ca, ga, &d2h) != HSA_STATUS_SUCCESS) d2h = 0;
     if (const char *ev = getenv("JM_AMD_DEC_COPY_ENGINES")) {     // explicit: comma-separated engine ids (hsa_amd_sdma_engine_id_t bit values)
-        for (const char *q = ev; *q && c->n_engines_ < 4;) { char *end; unsigned long v = strtoul(q, &end, 0); if (end == q) break; if (v && (avail & v)) c->engines_[c->n_engines_++] = (uint32_t)v; q = *end ? end + 1 : end; }
+        for (const char *q = ev; *q && c->n_engines_ < 4;) { char *end; unsigned long v = strtoul(q, &end, 0); if (end == q) break;
+            if (v && (avail & v)) c->engines_[c->n_engines_++] = (uint32_t)v; q = *end ? end + 1 : end; }
     } else {
         const size_t n = 2u << 20;
         (void)hipSetDevice(dev);
@@ -71,14 +73,16 @@ HostCopier *HostCopier::get(int dev) {
         hsa_signal_t sg{0};
         double t[32]; double best = 1e30;
         for (auto &x : t) x = 1e30;
-        if (hipMalloc(&dsrc, n) == hipSuccess && posix_memalign(&hbuf, 4096, n) == 0 && (hloc = c->lock(hbuf, n)) != nullptr && hsa_signal_create(1, 0, nullptr, &sg) == HSA_STATUS_SUCCESS) {
+        if (hipMalloc(&dsrc, n) == hipSuccess && posix_memalign(&hbuf, 4096, n) == 0 && (hloc = c->lock(hbuf, n)) != nullptr && hsa_signal_create(1, 0,
+            nullptr, &sg) == HSA_STATUS_SUCCESS) {
             for (int pass = 0; pass < 2; pass++)                  // (the first pass touches the pages and wakes the engines)
                 for (int b = 0; b < 16; b++) {
                     const uint32_t e = 1u << b;
                     if (!(avail & e)) continue;
                     hsa_signal_store_relaxed(sg, 1);
                     timespec a, z; clock_gettime(CLOCK_MONOTONIC, &a);
-                    if (hsa_amd_memory_async_copy_on_engine(hloc, ca, dsrc, ga, n, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)e, false) != HSA_STATUS_SUCCESS) continue;
+                    if (hsa_amd_memory_async_copy_on_engine(hloc, ca, dsrc, ga, n, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)e,
+                        false) != HSA_STATUS_SUCCESS) continue;
                     while (hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, 100ull * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) >= 1) {}
                     clock_gettime(CLOCK_MONOTONIC, &z);
                     if (pass) { t[b] = (z.tv_sec - a.tv_sec) + 1e-9 * (z.tv_nsec - a.tv_nsec); if (t[b] < best) best = t[b]; }
@@ -86,15 +90,19 @@ HostCopier *HostCopier::get(int dev) {
         }
         (void)hipGetLastError();
         // (engine 0x1 is where the HIP runtime puts its host -> device copies on this platform whatever the preference query says: last choice)
-        for (int b = 1; b < 16 && c->n_engines_ < 3; b++) if (t[b] < 1e29 && t[b] <= 1.5 * best && !(h2d & (1u << b))) c->engines_[c->n_engines_++] = 1u << b;      // (1e30 = not measured)
+        // (1e30 = not measured)
+        for (int b = 1; b < 16 && c->n_engines_ < 3; b++) if (t[b] < 1e29 && t[b] <= 1.5 * best && !(h2d & (1u << b))) c->engines_[c->n_engines_++] = 1u << b;
         if (!c->n_engines_ && t[0] < 1e29 && t[0] <= 1.5 * best) c->engines_[c->n_engines_++] = 1u;
-        if (!c->n_engines_) for (uint32_t e = 1; e && c->n_engines_ < 2; e <<= 1) if (d2h & e) c->engines_[c->n_engines_++] = e;     // (nothing measured: the runtime's recommendation)
+        // (nothing measured: the runtime's recommendation)
+        if (!c->n_engines_) for (uint32_t e = 1; e && c->n_engines_ < 2; e <<= 1) if (d2h & e) c->engines_[c->n_engines_++] = e;
         if (sg.handle) (void)hsa_signal_destroy(sg);
         if (hloc) c->unlock(hbuf);
         free(hbuf);
         if (dsrc) (void)hipFree(dsrc);
     }
-    if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: device %d: output copies on SDMA engines 0x%x 0x%x 0x%x (available 0x%x, host->device preference 0x%x, device->host preference 0x%x)\n", dev, c->engines_[0], c->engines_[1], c->engines_[2], avail, h2d, d2h);
+    if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr,
+        "jm_amd_dec: device %d: output copies on SDMA engines 0x%x 0x%x 0x%x (available 0x%x, host->device preference 0x%x, device->host preference 0x%x)\n",
+        dev, c->engines_[0], c->engines_[1], c->engines_[2], avail, h2d, d2h);
     tab[dev] = c;
     return c;
 }
@@ -115,7 +123,8 @@ HostCopier::Result HostCopier::copy(void *dst, const void *src, size_t n, uint64
     hsa_signal_store_relaxed(s, 1);
     const uint32_t e = n_engines_ ? engines_[turn.fetch_add(1, std::memory_order_relaxed) % (unsigned)n_engines_] : 0;
     hsa_status_t st = e ? hsa_amd_memory_async_copy_on_engine(dst, ca, src, ga, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)e, false) : HSA_STATUS_ERROR;
-    if (st != HSA_STATUS_SUCCESS) st = hsa_amd_memory_async_copy(dst, ca, src, ga, n, 0, nullptr, s);      // (engine busy / not selectable: the runtime's own choice)
+    // (engine busy / not selectable: the runtime's own choice)
+    if (st != HSA_STATUS_SUCCESS) st = hsa_amd_memory_async_copy(dst, ca, src, ga, n, 0, nullptr, s);
     if (st != HSA_STATUS_SUCCESS) return kNotSubmitted;
     // A failed copy sets the signal negative; a healthy one takes ~60 us plus its place in the engine's queue.  The wait is a sleep-and-look loop on the
     // signal's value (a plain load): hsa_signal_wait spins for ~200 us before it blocks, which is exactly the CPU this route exists to save.
@@ -130,7 +139,8 @@ HostCopier::Result HostCopier::copy(void *dst, const void *src, size_t n, uint64
     struct timespec ts = {0, 40 * 1000};
     if (typical > 400000) ts.tv_nsec = typical / 2 > 5000000 ? 5000000 : typical / 2;      // (only when copies queue: a lone copy must be seen as it ends)
     long total_ns = 0;
-    for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {      // (bounded: half a minute -- a device that takes longer has hung, and the caller's plain hipMemcpy that follows will say so)
+    // (bounded: half a minute -- a device that takes longer has hung, and the caller's plain hipMemcpy that follows will say so)
+    for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {
         nanosleep(&ts, nullptr);
         total_ns += ts.tv_nsec;
         const hsa_signal_value_t v = hsa_signal_load_scacquire(s);

@@ -2,9 +2,11 @@
 //
 // jm_nvdec_output_frame hands the frame over in a host buffer the caller owns (nv_dec.cpp:750-828 copies device -> host there, then repacks on
 // the CPU).  Here the repack already happened on the device (k_packout), so what is left is 3.1 MB per 1080p frame over PCIe -- and that link is
-// the hard ceiling of the host-output rate: 54.0 GB/s measured = 17.4 k frames/s (tools/sdma_probe.cpp: three SDMA engines in turn; two 52.5, one alone 47 GB/s).
+// the hard ceiling of the host-output rate: 54.0 GB/s measured = 17.4 k frames/s (tools/sdma_probe.cpp: three SDMA engines in turn; two 52.5, one alone 47
+// GB/s).
 // The HIP runtime sends every device-to-host copy of a process to one engine and its waits either spin or need a poll loop; this goes to the ROCr
-// layer underneath instead: the caller's buffer is page-locked for the call (hsa_amd_memory_lock, 1.4 us), the copy is put on one of the two PCIe-capable engines
+// layer underneath instead: the caller's buffer is page-locked for the call (hsa_amd_memory_lock, 1.4 us), the copy is put on one of the two PCIe-capable
+// engines
 // in turn (hsa_amd_memory_async_copy_on_engine) and the calling thread sleeps on the completion signal (interrupt wait, no CPU) -- no staging copy,
 // no CPU memcpy (the pinned route costs 0.3-0.57 ms of CPU per frame for it), no helper thread.
 #pragma once

@@ -100,14 +100,17 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define JM_GLOBAL __attribute__((address_space(1)))
 struct ICtx { gbyte *plane; int pitch; };
 __device__ __forceinline__ void gstore4(gbyte *p, uint4 v) { v4u t = {v.x, v.y, v.z, v.w}; *(JM_GLOBAL v4u *)p = t; }
-template <bool WT> __device__ __forceinline__ void istore4(gbyte *p, uint4 v) { if (WT) st_wt16((void *)p, v); else gstore4(p, v); }   // WT: chain launches (chain_common.h)
+// WT: chain launches (chain_common.h)
+template <bool WT> __device__ __forceinline__ void istore4(gbyte *p, uint4 v) { if (WT) st_wt16((void *)p, v); else gstore4(p, v); }
 // cache-bypassing loads (chain launches): 8-byte relaxed agent-scope atomics
 __device__ __forceinline__ uint4 gload4_coh(const gbyte *p) {
     const JM_GLOBAL uint64_t *q = (const JM_GLOBAL uint64_t *)p;
-    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+        b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
-__device__ __forceinline__ uint32_t gload1_coh(const gbyte *p) { return __hip_atomic_load((const JM_GLOBAL uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t gload1_coh(const gbyte *p) { return __hip_atomic_load((const JM_GLOBAL uint32_t *)p, __ATOMIC_RELAXED,
+    __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint4 gload4(const gbyte *p) { v4u v = *(const JM_GLOBAL v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint32_t gload1(const gbyte *p) { return *(const JM_GLOBAL uint32_t *)p; }
 
@@ -210,7 +213,8 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
             uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8;          // corner sample of this block
             // edge path k: 0..7 = p[-1,7]..p[-1,0], 8 = p[-1,-1], 9..24 = p[0..15,-1] (top-right replaced by p[7,-1] when unavailable)
             // (samples of unavailable neighbours count as 128: see the Intra4x4 path)
-            auto edge = [&](int k) -> int { return k <= 7 ? (a ? org[(8 - k) * kTS] : 128) : (k == 8 ? (d ? org[0] : 128) : (b ? org[1 + ((k - 9 > 7 && !c) ? 7 : k - 9)] : 128)); };
+            auto edge = [&](int k) -> int { return k <= 7 ? (a ? org[(8 - k) * kTS] : 128) : (k == 8 ? (d ? org[0] : 128) : (b ? org[1 + ((k - 9 > 7 &&
+                !c) ? 7 : k - 9)] : 128)); };
             raw[l] = (uint8_t)edge(l);
             if (l < 9) raw[16 + l] = (uint8_t)edge(16 + l);
             auto filt = [&](int k) -> int {
@@ -433,12 +437,15 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
         int spins = 0; uint32_t t0 = 0;
-        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit && !(CHAIN && wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
-        if (known < need) { if (l == 0) report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT); known = 0x7fffffff; }   // never silent: the engine reports a decode error (and the band does not wait again)
+        while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit && !(CHAIN &&
+            wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
+        // never silent: the engine reports a decode error (and the band does not wait again)
+        if (known < need) { if (l == 0) report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT); known = 0x7fffffff; }
         asm volatile("" ::: "memory");
     };
     auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };
-    auto fetch_above = [&](int xm) -> uint32_t { return __hip_atomic_load((const JM_GLOBAL uint32_t *)(above + (size_t)xm * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto fetch_above = [&](int xm) -> uint32_t { return __hip_atomic_load((const JM_GLOBAL uint32_t *)(above + (size_t)xm * 16), __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT); };
     if (band > 0) {
         // macroblocks 0 and 1 of the row above are final once the band above completed step s_begin - 1
         wait_above(s_begin);
@@ -447,7 +454,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // CHAIN: the residual of an intra macroblock / the samples of a macroblock that is not intra are written by a reconstruction wave of this launch
     int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
-    int recon_known = (pp.stages & PS_RECON) ? 0x7fffffff : 0;               // PS_RECON beside PS_CHAIN: residuals / samples come from the stage kernel, complete before this launch
+    // PS_RECON beside PS_CHAIN: residuals / samples come from the stage kernel, complete before this launch
+    int recon_known = (pp.stages & PS_RECON) ? 0x7fffffff : 0;
     const uint32_t *bits_row = CHAIN ? (const uint32_t *)(cpic + kChainBits) + (size_t)row * kChainRowWords : nullptr;
     const int wave = threadIdx.x >> 6;
     const int wave_first = 2 * (row0 + 4 * wave), wave_last = 2 * (row0 + min(4 * wave + 3, rows - 1)) + mb_w - 1;   // steps in which this wave has work
@@ -455,7 +463,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     // (a macro, not a lambda: capturing the uint4 prefetch registers by reference put them in scratch memory)
 #define JM_PREFETCH(s_) do { \
         const int xn_ = (s_) - 2 * row; \
-        if (CHAIN && !wait_row_bit(bits_row, recon_known, active && xn_ >= 0 && xn_ < mb_w, xn_, abort_word) && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); } \
+        if (CHAIN && !wait_row_bit(bits_row, recon_known, active && xn_ >= 0 && xn_ < mb_w, xn_, abort_word) && (threadIdx.x & 63) == 0) { \
+            report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); } \
         if (active && xn_ >= 0 && xn_ < mb_w) { \
             const int mb_ = row * mb_w + xn_; \
             p_rec = gload1(mbs + (size_t)mb_ * sizeof(MbRec) + (l & 7) * 4); \
@@ -489,7 +498,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
             else intra_luma_mb<CHAIN>(cx, lds, x, row, lrow, l, g, c_rec, c_res0, c_res1, c_right, c_bot);
             if (gives_ring) {
                 // hand the bottom row down (write-through), then publish the step; the wave that holds the band's last row wrote it itself
-                if (l < 4) __hip_atomic_store((JM_GLOBAL uint32_t *)(below + (size_t)x * 16), ((const uint32_t *)(is_chroma ? lds.cring(lrow, x & 3) : lds.lring(lrow, x & 3)))[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l < 4) __hip_atomic_store((JM_GLOBAL uint32_t *)(below + (size_t)x * 16), ((const uint32_t *)(is_chroma ? lds.cring(lrow,
+                    x & 3) : lds.lring(lrow, x & 3)))[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (gives_ring) {
@@ -502,7 +512,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
             // acknowledged; in the first / last steps of its rows it waits for everything.
             if (s >= wave_first && s + 1 <= wave_last) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainIntraFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainIntraFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
         } else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }

@@ -70,10 +70,14 @@ __attribute__((visibility("default"))) int jm_amddec_is_hw_support(void) {      
 __attribute__((visibility("default"))) int jm_amddec_set_option(jm_amddec_handle h, const char *key, long long v) { return D(h)->set_option(key, v); }
 __attribute__((visibility("default"))) long long jm_amddec_get_stat(jm_amddec_handle h, const char *key) { return D(h)->get_stat(key); }
 __attribute__((visibility("default"))) const char *jm_amddec_last_error(jm_amddec_handle h) { return D(h)->last_error(); }
-__attribute__((visibility("default"))) int jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h) { return (h && dev && len) ? D(h)->output_device(dev, len) : -1; }
-__attribute__((visibility("default"))) int jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h) { return (h && dev_dst) ? D(h)->output_argb_device(dev_dst, pitch) : -1; }
-__attribute__((visibility("default"))) int jm_amddec_output_nv12_pitch_device(void *dev_dst, int pitch, jm_amddec_handle h) { return (h && dev_dst) ? D(h)->output_nv12_pitch_device(dev_dst, pitch) : -1; }
-__attribute__((visibility("default"))) int jm_amddec_i420_to_nv12_device(const void *d_src, int width, int height, int src_fmt, void *d_dst, int pitch, void *stream) {
+__attribute__((visibility("default"))) int jm_amddec_output_frame_device(void **dev, int *len, jm_amddec_handle h) {
+    return (h && dev && len) ? D(h)->output_device(dev, len) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_output_argb_device(void *dev_dst, int pitch, jm_amddec_handle h) {
+    return (h && dev_dst) ? D(h)->output_argb_device(dev_dst, pitch) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_output_nv12_pitch_device(void *dev_dst, int pitch, jm_amddec_handle h) {
+    return (h && dev_dst) ? D(h)->output_nv12_pitch_device(dev_dst, pitch) : -1; }
+__attribute__((visibility("default"))) int jm_amddec_i420_to_nv12_device(const void *d_src, int width, int height, int src_fmt, void *d_dst, int pitch,
+    void *stream) {
     if (!d_src || !d_dst || width <= 0 || height <= 0 || (width & 1) || (height & 1) || pitch < width || (src_fmt != 0 && src_fmt != 1)) return -1;
     jmamd::launch_frame_to_nv12_pitch((const uint8_t *)d_src, width, height, src_fmt, (uint8_t *)d_dst, pitch, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -91,11 +95,13 @@ __attribute__((visibility("default"))) int jm_amddec_packout_device(const void *
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-__attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned char *buf, long len, int passes, unsigned char *out, int out_cap, jm_amddec_handle h) {
+__attribute__((visibility("default"))) long jm_amddec_feed_annexb(const unsigned char *buf, long len, int passes, unsigned char *out, int out_cap,
+    jm_amddec_handle h) {
     if (!h || !buf || len < 4) return -1;       // out == NULL: frames stay on the device (jm_amddec_output_frame_device), nothing is copied
     // NAL boundaries as find_nalu sees them: a start code is 00 00 01, or 00 00 00 01 (then the NAL starts one byte earlier)
     std::vector<long> starts;
-    for (long i = 0; i + 3 <= len; i++) if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) { long s0 = (i > 0 && buf[i - 1] == 0) ? i - 1 : i; if (starts.empty() || s0 > starts.back()) starts.push_back(s0); i += 2; }
+    for (long i = 0; i + 3 <= len; i++) if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) { long s0 = (i > 0 && buf[i - 1] == 0) ? i - 1 : i;
+        if (starts.empty() || s0 > starts.back()) starts.push_back(s0); i += 2; }
     if (starts.empty()) return -1;
     long frames = 0;
     for (int p = 0; p < passes; p++)

@@ -69,7 +69,8 @@ JM_EXPORT int jm_amdintel_output_frame(unsigned char *out_buf, int *out_len, jm_
     if (!h || !out_len) return -1;
     Ctx *c = C(h);
     std::lock_guard<std::mutex> lk(c->m);
-    if (c->inited && c->fifo.empty()) { int got = 0; if (c->eof) jm_amddec_decode_frame(nullptr, 0, &got, c->dec); else jm_amddec_poll_frame(&got, c->dec); c->collect(got); }
+    if (c->inited && c->fifo.empty()) { int got = 0; if (c->eof) jm_amddec_decode_frame(nullptr, 0, &got, c->dec); else jm_amddec_poll_frame(&got, c->dec);
+        c->collect(got); }
     if (c->fifo.empty() || c->cb) { *out_len = 0; return -1; }
     std::vector<unsigned char> &f = c->fifo.front();
     if (!out_buf) { *out_len = (int)f.size(); return 0; }                 // size query (jm_intel_dec.h:74)
@@ -113,12 +114,16 @@ typedef int (*HANDLE_YUV_CALLBACK)(unsigned char *out_buf, int out_len, void *us
 JM_EXPORT handle_inteldec jm_intel_dec_create_handle() { return jm_amdintel_create_handle(); }
 JM_EXPORT int jm_intel_dec_init(int codec_type, int out_fmt, handle_inteldec handle) { return jm_amdintel_init(codec_type, out_fmt, handle); }
 JM_EXPORT int jm_intel_dec_deinit(handle_inteldec handle) { return jm_amdintel_deinit(handle); }
-JM_EXPORT int jm_intel_dec_set_yuv_callback(void *user_data, HANDLE_YUV_CALLBACK callback, handle_inteldec handle) { return jm_amdintel_set_yuv_callback(user_data, callback, handle); }
-JM_EXPORT int jm_intel_dec_input_data(unsigned char *in_buf, int in_data_len, handle_inteldec handle) { return jm_amdintel_input_data(in_buf, in_data_len, handle); }
-JM_EXPORT int jm_intel_dec_output_frame(unsigned char *out_buf, int *out_len, handle_inteldec handle) { return jm_amdintel_output_frame(out_buf, out_len, handle); }
+JM_EXPORT int jm_intel_dec_set_yuv_callback(void *user_data, HANDLE_YUV_CALLBACK callback, handle_inteldec handle) {
+    return jm_amdintel_set_yuv_callback(user_data, callback, handle); }
+JM_EXPORT int jm_intel_dec_input_data(unsigned char *in_buf, int in_data_len, handle_inteldec handle) {
+    return jm_amdintel_input_data(in_buf, in_data_len, handle); }
+JM_EXPORT int jm_intel_dec_output_frame(unsigned char *out_buf, int *out_len, handle_inteldec handle) {
+    return jm_amdintel_output_frame(out_buf, out_len, handle); }
 JM_EXPORT int jm_intel_dec_set_eof(int is_eof, handle_inteldec handle) { return jm_amdintel_set_eof(is_eof, handle); }
 JM_EXPORT char *jm_intel_dec_info(handle_inteldec handle) { return jm_amdintel_info(handle); }
-JM_EXPORT int jm_intel_get_stream_info(int *width, int *height, float *frame_rate, handle_inteldec handle) { return jm_amdintel_get_stream_info(width, height, frame_rate, handle); }
+JM_EXPORT int jm_intel_get_stream_info(int *width, int *height, float *frame_rate, handle_inteldec handle) {
+    return jm_amdintel_get_stream_info(width, height, frame_rate, handle); }
 JM_EXPORT bool jm_intel_dec_need_more_data(handle_inteldec handle) { return jm_amdintel_need_more_data(handle) != 0; }
 JM_EXPORT int jm_intel_dec_free_buf_len(handle_inteldec handle) { return jm_amdintel_free_buf_len(handle); }
 JM_EXPORT bool jm_intel_dec_is_exit(handle_inteldec handle) { return jm_amdintel_is_exit(handle) != 0; }

@@ -125,7 +125,8 @@ __device__ void intra8x8_block(IntraTile &t, const ResTile &rt, int b8, int mode
     // same wave: LDS keeps program order
     if (lane == 0) {
         int c = raw[0], t0 = raw[1], l0 = raw[17];
-        fe[0] = (uint8_t)(!availD ? 128 : ((availA && availB) ? (t0 + 2 * c + l0 + 2) >> 2 : (availB ? (3 * c + t0 + 2) >> 2 : (availA ? (3 * c + l0 + 2) >> 2 : c))));
+        fe[0] = (uint8_t)(!availD ? 128 : ((availA &&
+            availB) ? (t0 + 2 * c + l0 + 2) >> 2 : (availB ? (3 * c + t0 + 2) >> 2 : (availA ? (3 * c + l0 + 2) >> 2 : c))));
     } else if (lane <= 16) {
         int k = lane - 1, c = raw[lane];
         int lo = k == 0 ? (availD ? raw[0] : c) : raw[lane - 1], hi = k == 15 ? c : raw[lane + 1];
@@ -204,8 +205,10 @@ __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, 
         if (lane < 25) { int x = clip3(0, W - 1, x0 - 1 + lane), y = clip3(0, H - 1, y0 - 1); t.y[0][lane] = dst[(size_t)y * pitch + x]; }
         else if (lane >= 32 && lane < 48) { int i = lane - 32; int x = clip3(0, W - 1, x0 - 1); t.y[1 + i][0] = dst[(size_t)(y0 + i) * pitch + x]; }
         int cx0 = mbx * 8, cy0 = mby * 8, CW = W >> 1, CH = H >> 1;
-        if (lane < 18) { int pl = lane / 9, i = lane % 9; int x = clip3(0, CW - 1, cx0 - 1 + i), y = clip3(0, CH - 1, cy0 - 1); t.c[pl][0][i] = dst_c[(size_t)y * pitch + 2 * x + pl]; }
-        else if (lane >= 32 && lane < 48) { int pl = (lane - 32) >> 3, i = (lane - 32) & 7; int x = clip3(0, CW - 1, cx0 - 1); t.c[pl][1 + i][0] = dst_c[(size_t)(cy0 + i) * pitch + 2 * x + pl]; }
+        if (lane < 18) { int pl = lane / 9, i = lane % 9; int x = clip3(0, CW - 1, cx0 - 1 + i), y = clip3(0, CH - 1, cy0 - 1);
+            t.c[pl][0][i] = dst_c[(size_t)y * pitch + 2 * x + pl]; }
+        else if (lane >= 32 && lane < 48) { int pl = (lane - 32) >> 3, i = (lane - 32) & 7; int x = clip3(0, CW - 1, cx0 - 1);
+            t.c[pl][1 + i][0] = dst_c[(size_t)(cy0 + i) * pitch + 2 * x + pl]; }
     }
     // ---- luma ----
     if (r.kind == MB_I4 && (r.modes & MBM_T8X8)) {
@@ -324,9 +327,11 @@ __device__ __forceinline__ void filter_luma(int *s, int bS, int alpha, int beta,
         if (aq) s[5] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
     } else {
         bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
-        if (ap && strong) { s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; s[2] = (p2 + p1 + p0 + q0 + 2) >> 2; s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; }
+        if (ap && strong) { s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; s[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
+            s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3; }
         else s[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (aq && strong) { s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; s[5] = (p0 + q0 + q1 + q2 + 2) >> 2; s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3; }
+        if (aq && strong) { s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; s[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
+            s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3; }
         else s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
     }
 }

@@ -24,7 +24,8 @@ int numa_node_of_device(int dev, bool query_hip) {
     }
     if (!query_hip) return -1;
     int bus = -1, pdev = -1, dom = -1;
-    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId, dev) != hipSuccess ||
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId,
+        dev) != hipSuccess ||
         hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
     char path[128];
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node", dom, bus, pdev);
@@ -84,7 +85,8 @@ static bool read_small(const char *path, char *buf, size_t n) {
 
 unsigned kfd_gpu_id_of_device(int dev) {
     int bus = -1, pdev = -1, dom = -1;
-    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId, dev) != hipSuccess ||
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev) != hipSuccess || hipDeviceGetAttribute(&pdev, hipDeviceAttributePciDeviceId,
+        dev) != hipSuccess ||
         hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
     const unsigned want_loc = ((unsigned)bus << 8) | ((unsigned)pdev << 3);
     unsigned only = 0; int n_readable = 0;

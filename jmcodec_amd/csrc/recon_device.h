@@ -23,7 +23,8 @@ __device__ __forceinline__ void idct8_1d(int *d) {
 }
 // normAdjust8x8(m, i, j) (8.5.9, v_m0..v_m5), six 6-bit fields per m; LevelScale8x8 = weight * this
 __device__ __forceinline__ int norm_adjust8(int m, int i, int j) {
-    const unsigned long long packed = m == 0 ? 0x6194E0494ull : (m == 1 ? 0x69C5634D6ull : (m == 2 ? 0x7E162A5DAull : (m == 3 ? 0x8636AD65Cull : (m == 4 ? 0x9A87B3720ull : 0xAEE8BA824ull))));
+    const unsigned long long packed = m == 0 ? 0x6194E0494ull :
+        (m == 1 ? 0x69C5634D6ull : (m == 2 ? 0x7E162A5DAull : (m == 3 ? 0x8636AD65Cull : (m == 4 ? 0x9A87B3720ull : 0xAEE8BA824ull))));
     int ti = (i & 1) ? 1 : ((i & 2) ? 2 : 0), tj = (j & 1) ? 1 : ((j & 2) ? 2 : 0);
     int cls = ti == tj ? ti : (ti + tj == 1 ? 3 : (ti + tj == 2 ? 4 : 5));
     return (int)((packed >> (6 * cls)) & 63);
@@ -48,7 +49,8 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
                 const short *c = coef + 16 * __popc((unsigned)r.cbp_blk & ((1u << (4 * b8)) - 1)) + i * 8;
                 int m = qp % 6, s = qp / 6;
 #pragma unroll
-                for (int k = 0; k < 8; k++) { int wgt = flat ? 16 : pp.wscale8[r.kind == MB_INTER ? 1 : 0][i * 8 + k]; int v = c[k] * wgt * norm_adjust8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
+                for (int k = 0; k < 8; k++) { int wgt = flat ? 16 : pp.wscale8[r.kind == MB_INTER ? 1 : 0][i * 8 + k];
+                    int v = c[k] * wgt * norm_adjust8(m, i, k); d[k] = s >= 6 ? v << (s - 6) : (v + (1 << (5 - s))) >> (6 - s); }
                 idct8_1d(d);
 #pragma unroll
                 for (int k = 0; k < 8; k++) rt.t8[b8 * 64 + i * 8 + k] = d[k];
@@ -275,8 +277,10 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                     c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
                     c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
                 } else {
-                c_smp[0] = ld_ref8<COH>(r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(r1 + 2 * xa); c_smp[3] = ld_ref8<COH>(r1 + 2 * xb);
-                c_smp[4] = ld_ref8<COH>(r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(r1 + 2 * xa + 1); c_smp[7] = ld_ref8<COH>(r1 + 2 * xb + 1);
+                c_smp[0] = ld_ref8<COH>(r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(r1 + 2 * xa);
+                c_smp[3] = ld_ref8<COH>(r1 + 2 * xb);
+                c_smp[4] = ld_ref8<COH>(r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(r1 + 2 * xa + 1);
+                c_smp[7] = ld_ref8<COH>(r1 + 2 * xb + 1);
                 }
             }
         }
@@ -290,7 +294,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     auto publish = [&]() {
         if (!CHAIN) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_or((uint32_t *)(cv.pic(pp.chain_idx) + kChainBits) + mby * kChainRowWords + (mbx >> 5), 1u << (mbx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_or((uint32_t *)(cv.pic(pp.chain_idx) + kChainBits) + mby * kChainRowWords + (mbx >> 5), 1u << (mbx & 31),
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (intra_res) {
         // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
@@ -357,7 +362,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                     int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
                     if (fx == 2 && fy == 2) v[k] = jv;
                     else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
+                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
+                        v[k] = (q + jv + 1) >> 1; }
                 } else {
                     int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
                     int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
@@ -377,7 +383,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             if (use0 && use1) {
                 if (mode == 0) return (a + b + 1) >> 1;
                 int w0, w1, o = 0, lg = 5;
-                if (mode == 1) { w0 = wp->w[0][i0 & 15][cmp]; w1 = wp->w[1][i1 & 15][cmp]; o = (wp->o[0][i0 & 15][cmp] + wp->o[1][i1 & 15][cmp] + 1) >> 1; lg = cmp ? wp->logwd_c : wp->logwd_y; }
+                if (mode == 1) { w0 = wp->w[0][i0 & 15][cmp]; w1 = wp->w[1][i1 & 15][cmp]; o = (wp->o[0][i0 & 15][cmp] + wp->o[1][i1 & 15][cmp] + 1) >> 1;
+                    lg = cmp ? wp->logwd_c : wp->logwd_y; }
                 else { w1 = (int)wp->imp_w1[i0 & 15][i1 & 15] - 64; w0 = 64 - w1; }
                 return clip1(((a * w0 + b * w1 + (1 << lg)) >> (lg + 1)) + o);
             }
@@ -415,7 +422,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 const uint8_t *ref = pp.surf[slot];
                 uint32_t w5[5];
 #pragma unroll
-                for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5; w5[t] = ld_ref32<COH>(ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
+                for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5;
+                    w5[t] = ld_ref32<COH>(ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
                 __builtin_amdgcn_wave_barrier();                   // (the block's window in LDS is reused for the second list: its readers are done)
                 int v[4];
                 filter_window(&wins[wave][g][0], w5, l16, xi & 3, mvx & 3, mvy & 3, v);
@@ -464,8 +472,10 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
                 const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
                 int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
-                pu[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa) + w01 * ld_ref8<COH>(r0 + 2 * xb) + w10 * ld_ref8<COH>(r1 + 2 * xa) + w11 * ld_ref8<COH>(r1 + 2 * xb) + 32) >> 6;
-                pv[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa + 1) + w01 * ld_ref8<COH>(r0 + 2 * xb + 1) + w10 * ld_ref8<COH>(r1 + 2 * xa + 1) + w11 * ld_ref8<COH>(r1 + 2 * xb + 1) + 32) >> 6;
+                pu[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa) + w01 * ld_ref8<COH>(r0 + 2 * xb) +
+                         w10 * ld_ref8<COH>(r1 + 2 * xa) + w11 * ld_ref8<COH>(r1 + 2 * xb) + 32) >> 6;
+                pv[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa + 1) + w01 * ld_ref8<COH>(r0 + 2 * xb + 1) +
+                         w10 * ld_ref8<COH>(r1 + 2 * xa + 1) + w11 * ld_ref8<COH>(r1 + 2 * xb + 1) + 32) >> 6;
             }
             int u = combine(pu[0], pu[1], s[0] >= 0, s[1] >= 0, i0, i1, 1), v = combine(pv[0], pv[1], s[0] >= 0, s[1] >= 0, i0, i1, 2);
             if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }

@@ -53,7 +53,8 @@ class Oracle:
     def display_pocs(self, data):
         """PicOrderCnt of every output frame, display order (OrcFrame.poc at the moment the frame is handed out)."""
         class Frame(C.Structure):
-            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c", C.c_int),
+            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c",
+                C.c_int),
                         ("poc", C.c_int), ("frame_type", C.c_int), ("decode_index", C.c_int)]
         pocs = []
         cb = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame))(lambda user, f: pocs.append(f.contents.poc))
@@ -118,7 +119,8 @@ class OracleHevc:
         if not os.path.exists(p):
             build_oracle()
         L = C.CDLL(p)
-        L.orch_decode_stream_to_buffer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orch_decode_stream_to_buffer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t),
+            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orch_free.argtypes = [C.c_void_p]
         L.orch_open.restype = C.c_void_p
         L.orch_open.argtypes = [C.c_void_p, C.c_void_p]
@@ -159,7 +161,8 @@ class OracleHevc:
     def display_pocs(self, data):
         """PicOrderCnt of every output frame, display order (OrcFrame.poc at the moment the frame is handed out)."""
         class Frame(C.Structure):
-            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c", C.c_int),
+            _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c",
+                C.c_int),
                         ("poc", C.c_int), ("frame_type", C.c_int), ("decode_index", C.c_int)]
         pocs = []
         cb = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame))(lambda user, f: pocs.append(f.contents.poc))

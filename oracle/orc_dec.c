@@ -190,7 +190,8 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
         } else if (p->is_ref == 2) { p->long_term_pic_num = p->long_term_frame_idx; lt[nlt++] = p; }
     }
     for (int i = 0; i < nst; i++) for (int j = i + 1; j < nst; j++) if (st[j]->pic_num > st[i]->pic_num) { Picture *t = st[i]; st[i] = st[j]; st[j] = t; }
-    for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_pic_num < lt[i]->long_term_pic_num) { Picture *t = lt[i]; lt[i] = lt[j]; lt[j] = t; }
+    for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_pic_num < lt[i]->long_term_pic_num) { Picture *t = lt[i];
+        lt[i] = lt[j]; lt[j] = t; }
     int nlists = sh->slice_type == SLICE_B ? 2 : 1;
     Picture *init[2][34]; int ninit[2] = {0, 0};
     memset(init, 0, sizeof init);
@@ -199,8 +200,10 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
     } else {                                               /* 8.2.4.2.3: by POC distance around the current picture */
         Picture *before[ORC_MAX_DPB + 1], *after[ORC_MAX_DPB + 1]; int nb = 0, na = 0;
         for (int i = 0; i < nst; i++) { if (st[i]->poc < d->cur->poc) before[nb++] = st[i]; else after[na++] = st[i]; }
-        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j]; before[j] = t; }
-        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j]; after[j] = t; }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j];
+            before[j] = t; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j];
+            after[j] = t; }
         for (int i = 0; i < nb; i++) init[0][ninit[0]++] = before[i];
         for (int i = 0; i < na; i++) init[0][ninit[0]++] = after[i];
         for (int i = 0; i < na; i++) init[1][ninit[1]++] = after[i];

@@ -40,7 +40,8 @@ static void cabac_init_ctx(Sx *s) {                                     /* 9.3.2
 }
 static void cabac_init_engine(Sx *s) { s->range = 510; s->offset = bits_u(&s->b, 9); }      /* 9.3.2.5 */
 static FILE *g_trace; static int g_trace_init;
-#define TRACE(...) do { if (!g_trace_init) { g_trace_init = 1; if (getenv("ORCH_TRACE")) g_trace = fopen(getenv("ORCH_TRACE"), "w"); } if (g_trace) fprintf(g_trace, __VA_ARGS__); } while (0)
+#define TRACE(...) do { if (!g_trace_init) { g_trace_init = 1; if (getenv("ORCH_TRACE")) g_trace = fopen(getenv("ORCH_TRACE"), "w"); } \
+        if (g_trace) fprintf(g_trace, __VA_ARGS__); } while (0)
 static void dg_trace(int v) { TRACE("D %d\n", v); }
 static int ae_(Sx *s, int ctx);
 static int ae(Sx *s, int ctx) { int b = ae_(s, ctx); TRACE("c%d %d\n", ctx, b); return b; }
@@ -142,11 +143,13 @@ static void intra_pred(Sx *s, int x0, int y0, int log2, int c, int mode) {
             if (s->sps->strong_intra_smoothing && n == 32 && abs(top[0] + top[64] - 2 * top[32]) < 8 && abs(left[0] + left[64] - 2 * left[32]) < 8) {
                 d->stats[HST_STRONG_INTRA]++;
                 fl_[0] = ft_[0] = top[0];
-                for (int i = 0; i < 63; i++) { fl_[i + 1] = ((63 - i) * left[0] + (i + 1) * left[64] + 32) >> 6; ft_[i + 1] = ((63 - i) * top[0] + (i + 1) * top[64] + 32) >> 6; }
+                for (int i = 0; i < 63; i++) { fl_[i + 1] = ((63 - i) * left[0] + (i + 1) * left[64] + 32) >> 6;
+                    ft_[i + 1] = ((63 - i) * top[0] + (i + 1) * top[64] + 32) >> 6; }
                 fl_[64] = left[64]; ft_[64] = top[64];
             } else {
                 fl_[0] = ft_[0] = (left[1] + 2 * left[0] + top[1] + 2) >> 2;
-                for (int i = 1; i < 2 * n; i++) { fl_[i] = (left[i + 1] + 2 * left[i] + left[i - 1] + 2) >> 2; ft_[i] = (top[i + 1] + 2 * top[i] + top[i - 1] + 2) >> 2; }
+                for (int i = 1; i < 2 * n; i++) { fl_[i] = (left[i + 1] + 2 * left[i] + left[i - 1] + 2) >> 2;
+                    ft_[i] = (top[i + 1] + 2 * top[i] + top[i - 1] + 2) >> 2; }
                 fl_[2 * n] = left[2 * n]; ft_[2 * n] = top[2 * n];
             }
             left = fl_; top = ft_;
@@ -177,7 +180,8 @@ static void intra_pred(Sx *s, int x0, int y0, int log2, int c, int mode) {
             else for (int x = n + 1; x <= 2 * n; x++) ref[x] = PT(x - 1);
             for (int y = 0; y < n; y++) {
                 int idx = ((y + 1) * ang) >> 5, f = ((y + 1) * ang) & 31;
-                for (int x = 0; x < n; x++) dst[y * stride + x] = (uint8_t)(f ? ((32 - f) * ref[x + idx + 1] + f * ref[x + idx + 2] + 16) >> 5 : ref[x + idx + 1]);
+                for (int x = 0; x < n; x++) dst[y * stride + x] =
+                    (uint8_t)(f ? ((32 - f) * ref[x + idx + 1] + f * ref[x + idx + 2] + 16) >> 5 : ref[x + idx + 1]);
             }
             if (mode == 26 && c == 0 && n < 32) for (int y = 0; y < n; y++) dst[y * stride] = (uint8_t)h_clip1(PT(0) + ((PL(y) - PL(-1)) >> 1));
         } else {
@@ -186,7 +190,8 @@ static void intra_pred(Sx *s, int x0, int y0, int log2, int c, int mode) {
             else for (int x = n + 1; x <= 2 * n; x++) ref[x] = PL(x - 1);
             for (int x = 0; x < n; x++) {
                 int idx = ((x + 1) * ang) >> 5, f = ((x + 1) * ang) & 31;
-                for (int y = 0; y < n; y++) dst[y * stride + x] = (uint8_t)(f ? ((32 - f) * ref[y + idx + 1] + f * ref[y + idx + 2] + 16) >> 5 : ref[y + idx + 1]);
+                for (int y = 0; y < n; y++) dst[y * stride + x] =
+                    (uint8_t)(f ? ((32 - f) * ref[y + idx + 1] + f * ref[y + idx + 2] + 16) >> 5 : ref[y + idx + 1]);
             }
             if (mode == 10 && c == 0 && n < 32) for (int x = 0; x < n; x++) dst[x] = (uint8_t)h_clip1(PL(0) + ((PT(x) - PT(-1)) >> 1));
         }
@@ -368,7 +373,8 @@ static int residual_coding(Sx *s, int x0, int y0, int log2, int c, int *tskip_ou
 
 /* ------------------------------------------ 8.5 inter prediction ------------------------------------------ */
 typedef struct { int16_t mv[2][2]; int8_t ref[2]; uint8_t pf; } Cand;
-static Cand cand_of(const OrchDec *d, int x, int y) { const HMotion *m = &d->mot[I4(d, x, y)]; Cand c; memcpy(c.mv, m->mv, sizeof c.mv); c.ref[0] = m->ref_idx[0]; c.ref[1] = m->ref_idx[1]; c.pf = m->pred_flag; return c; }
+static Cand cand_of(const OrchDec *d, int x, int y) { const HMotion *m = &d->mot[I4(d, x, y)]; Cand c; memcpy(c.mv, m->mv, sizeof c.mv);
+    c.ref[0] = m->ref_idx[0]; c.ref[1] = m->ref_idx[1]; c.pf = m->pred_flag; return c; }
 static int cand_same(const Cand *a, const Cand *b) {
     if (a->pf != b->pf) return 0;
     for (int l = 0; l < 2; l++) if (a->pf & (1 << l)) { if (a->ref[l] != b->ref[l] || a->mv[l][0] != b->mv[l][0] || a->mv[l][1] != b->mv[l][1]) return 0; }
@@ -403,7 +409,7 @@ static int temporal_mv(Sx *s, int xpb, int ypb, int npbw, int npbh, int X, int r
         if (!(cm->pred_flag & 1)) lc = 1;
         else if (!(cm->pred_flag & 2)) lc = 0;
         else {
-            int no_backward = 1;                                        /* NoBackwardPredFlag: DiffPicOrderCnt(aPic, currPic) <= 0 for every reference picture */
+            int no_backward = 1; /* NoBackwardPredFlag: DiffPicOrderCnt(aPic, currPic) <= 0 for every reference picture */
             for (int l = 0; l < 2; l++) for (int i = 0; i < sh->n_ref[l]; i++) if (sh->ref_poc[l][i] > d->cur->poc) no_backward = 0;
             lc = no_backward ? X : sh->collocated_from_l0;
         }
@@ -427,10 +433,12 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
     Cand a1, b1, b0, a0, b2; int fa1, fb1, fb0, fa0, fb2, vb1;      /* vb1: availableB1 (8.5.3.2.3), fb1: availableFlagB1 (after the comparison with A1) */
 #define SAME_MER(xn, yn) ((xpb >> pml) == ((xn) >> pml) && (ypb >> pml) == ((yn) >> pml))
     { int xn = xpb - 1, yn = ypb + npbh - 1;
-      fa1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_Nx2N || part_mode == H_PART_nLx2N || part_mode == H_PART_nRx2N))) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
+      fa1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_Nx2N || part_mode == H_PART_nLx2N || part_mode == H_PART_nRx2N))) &&
+          avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
       if (fa1) { a1 = cand_of(d, xn, yn); list[n++] = a1; } }
     { int xn = xpb + npbw - 1, yn = ypb - 1;
-      fb1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_2NxN || part_mode == H_PART_2NxnU || part_mode == H_PART_2NxnD))) && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
+      fb1 = !(SAME_MER(xn, yn) || (part_idx == 1 && (part_mode == H_PART_2NxN || part_mode == H_PART_2NxnU || part_mode == H_PART_2NxnD))) &&
+          avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
       vb1 = fb1;
       if (fb1) { b1 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &b1)) fb1 = 0; else list[n++] = b1; } }
     { int xn = xpb + npbw, yn = ypb - 1;
@@ -441,7 +449,8 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
       if (fa0) { a0 = cand_of(d, xn, yn); if (fa1 && cand_same(&a1, &a0)) fa0 = 0; else list[n++] = a0; } }
     { int xn = xpb - 1, yn = ypb - 1;
       fb2 = !SAME_MER(xn, yn) && fa0 + fa1 + fb0 + fb1 != 4 && avail_pb(s, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xn, yn);
-      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (vb1 && cand_same(&b1, &b2))) { fb2 = 0; if (vb1 && !fb1 && !(fa1 && cand_same(&a1, &b2))) d->stats[HST_MERGE_VS_PRUNED_B1]++; } else list[n++] = b2; } }
+      if (fb2) { b2 = cand_of(d, xn, yn); if ((fa1 && cand_same(&a1, &b2)) || (vb1 && cand_same(&b1, &b2))) { fb2 = 0;
+          if (vb1 && !fb1 && !(fa1 && cand_same(&a1, &b2))) d->stats[HST_MERGE_VS_PRUNED_B1]++; } else list[n++] = b2; } }
 #undef SAME_MER
     /* B0 and B2 are compared with B1 whenever availableB1 is TRUE -- also when B1 was dropped as a duplicate of A1 (availableFlagB1 = 0);
      * the count of four candidates uses the flags (8.5.3.2.3) */
@@ -457,8 +466,10 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
         int n_orig = n;
         for (int k = 0; k < n_orig * (n_orig - 1) && n < sh->max_merge_cand; k++) {
             const Cand *c0 = &list[i0[k]], *c1 = &list[i1[k]];
-            if ((c0->pf & 1) && (c1->pf & 2) && (sh->ref_poc[0][c0->ref[0]] != sh->ref_poc[1][c1->ref[1]] || c0->mv[0][0] != c1->mv[1][0] || c0->mv[0][1] != c1->mv[1][1])) {
-                Cand t; t.pf = 3; t.ref[0] = c0->ref[0]; t.ref[1] = c1->ref[1]; t.mv[0][0] = c0->mv[0][0]; t.mv[0][1] = c0->mv[0][1]; t.mv[1][0] = c1->mv[1][0]; t.mv[1][1] = c1->mv[1][1];
+            if ((c0->pf & 1) && (c1->pf & 2) && (sh->ref_poc[0][c0->ref[0]] != sh->ref_poc[1][c1->ref[1]] || c0->mv[0][0] != c1->mv[1][0] ||
+                c0->mv[0][1] != c1->mv[1][1])) {
+                Cand t; t.pf = 3; t.ref[0] = c0->ref[0]; t.ref[1] = c1->ref[1]; t.mv[0][0] = c0->mv[0][0]; t.mv[0][1] = c0->mv[0][1]; t.mv[1][0] = c1->mv[1][0];
+                t.mv[1][1] = c1->mv[1][1];
                 list[n++] = t;
             }
         }
@@ -466,7 +477,8 @@ static Cand merge_cand(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int 
     { int num_ref = sh->type == H_SLICE_P ? sh->n_ref[0] : (sh->n_ref[0] < sh->n_ref[1] ? sh->n_ref[0] : sh->n_ref[1]);     /* 8.5.3.2.5 zero candidates */
       for (int z = 0; n < sh->max_merge_cand; z++) {
           Cand t; memset(&t, 0, sizeof t);
-          t.pf = sh->type == H_SLICE_P ? 1 : 3; t.ref[0] = (int8_t)(z < num_ref ? z : 0); t.ref[1] = (int8_t)(sh->type == H_SLICE_P ? -1 : (z < num_ref ? z : 0));
+          t.pf = sh->type == H_SLICE_P ? 1 : 3; t.ref[0] = (int8_t)(z < num_ref ? z : 0);
+          t.ref[1] = (int8_t)(sh->type == H_SLICE_P ? -1 : (z < num_ref ? z : 0));
           list[n++] = t;
       } }
     Cand r = list[merge_idx];
@@ -500,7 +512,8 @@ static void amvp(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, 
         if (l >= 0) {
             fa = 1; mva[0] = m->mv[l][0]; mva[1] = m->mv[l][1];
             int rp = ns->ref_poc[l][m->ref_idx[l]];
-            if (!ns->ref_is_lt[l][m->ref_idx[l]] && !tlt) { int td = d->cur->poc - rp, tb = d->cur->poc - tpoc; if (td != tb && td != 0) { mva[0] = (int16_t)mv_scale(mva[0], td, tb); mva[1] = (int16_t)mv_scale(mva[1], td, tb); } }
+            if (!ns->ref_is_lt[l][m->ref_idx[l]] && !tlt) { int td = d->cur->poc - rp, tb = d->cur->poc - tpoc; if (td != tb && td != 0) {
+                mva[0] = (int16_t)mv_scale(mva[0], td, tb); mva[1] = (int16_t)mv_scale(mva[1], td, tb); } }
         }
     }
     for (int k = 0; k < 3 && !fb; k++) if (avb[k]) {
@@ -521,7 +534,8 @@ static void amvp(Sx *s, int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, 
             if (l >= 0) {
                 fb = 1; mvb[0] = m->mv[l][0]; mvb[1] = m->mv[l][1];
                 int rp = ns->ref_poc[l][m->ref_idx[l]];
-                if (!ns->ref_is_lt[l][m->ref_idx[l]] && !tlt) { int td = d->cur->poc - rp, tb = d->cur->poc - tpoc; if (td != tb && td != 0) { mvb[0] = (int16_t)mv_scale(mvb[0], td, tb); mvb[1] = (int16_t)mv_scale(mvb[1], td, tb); } }
+                if (!ns->ref_is_lt[l][m->ref_idx[l]] && !tlt) { int td = d->cur->poc - rp, tb = d->cur->poc - tpoc; if (td != tb && td != 0) {
+                    mvb[0] = (int16_t)mv_scale(mvb[0], td, tb); mvb[1] = (int16_t)mv_scale(mvb[1], td, tb); } }
             }
         }
     }
@@ -675,7 +689,8 @@ static int prediction_unit(Sx *s, int xcb, int ycb, int ncbs, int x0, int y0, in
         if (x == x0) d->edge[I4(d, x, y)] |= 4;
         if (y == y0) d->edge[I4(d, x, y)] |= 8;
     }
-    if (d->digest_on) { dg(d, 0x5000 | (merge << 4) | m.pf); dg(d, x0); dg(d, y0); dg(d, w); dg(d, h); dg(d, m.ref[0]); dg(d, m.ref[1]); dg(d, m.mv[0][0]); dg(d, m.mv[0][1]); dg(d, m.mv[1][0]); dg(d, m.mv[1][1]); }
+    if (d->digest_on) { dg(d, 0x5000 | (merge << 4) | m.pf); dg(d, x0); dg(d, y0); dg(d, w); dg(d, h); dg(d, m.ref[0]); dg(d, m.ref[1]); dg(d, m.mv[0][0]);
+        dg(d, m.mv[0][1]); dg(d, m.mv[1][0]); dg(d, m.mv[1][1]); }
     return inter_pred(s, x0, y0, w, h, &m);
 }
 
@@ -687,8 +702,10 @@ static void derive_qp(Sx *s, int xcb, int ycb) {
     int prev = s->first_qg ? s->sh->slice_qp : s->qp_y_prev;
     int a = prev, b = prev;
     int ctb_mask = ~((1 << s->sps->log2_ctb) - 1);
-    if (avail_zs(s, xcb, ycb, xqg - 1, yqg) && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && (yqg & ctb_mask) == (ycb & ctb_mask)) a = d->qp_y[I4(d, xqg - 1, yqg)];
-    if (avail_zs(s, xcb, ycb, xqg, yqg - 1) && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && (xqg & ctb_mask) == (xcb & ctb_mask)) b = d->qp_y[I4(d, xqg, yqg - 1)];
+    if (avail_zs(s, xcb, ycb, xqg - 1, yqg) && ((xqg - 1) & ctb_mask) == (xqg & ctb_mask) && (yqg & ctb_mask) == (ycb & ctb_mask)) a = d->qp_y[I4(d, xqg - 1,
+        yqg)];
+    if (avail_zs(s, xcb, ycb, xqg, yqg - 1) && ((yqg - 1) & ctb_mask) == (yqg & ctb_mask) && (xqg & ctb_mask) == (xcb & ctb_mask)) b = d->qp_y[I4(d, xqg,
+        yqg - 1)];
     int pred = (a + b + 1) >> 1;
     s->qp_y = ((pred + s->dqp + 52) % 52);
 }
@@ -729,19 +746,22 @@ static int transform_unit(Sx *s, int x0, int y0, int xbase, int ybase, int log2,
     if (log2 > 2) {
         for (int c = 1; c < 3; c++) {
             if (s->cu_intra) intra_pred(s, x0 >> 1, y0 >> 1, log2 - 1, c, s->ipm_c);
-            if (c == 1 ? cbf_cb : cbf_cr) { if (residual_coding(s, x0, y0, log2 - 1, c, &tskip) < 0) return -1; residual_add(s, x0 >> 1, y0 >> 1, log2 - 1, c, tskip, chroma_qp(s, c)); }
+            if (c == 1 ? cbf_cb : cbf_cr) { if (residual_coding(s, x0, y0, log2 - 1, c, &tskip) < 0) return -1;
+                residual_add(s, x0 >> 1, y0 >> 1, log2 - 1, c, tskip, chroma_qp(s, c)); }
         }
     } else if (blk == 3) {
         for (int c = 1; c < 3; c++) {
             if (s->cu_intra) intra_pred(s, xbase >> 1, ybase >> 1, 2, c, s->ipm_c);
-            if (c == 1 ? cbf_cb : cbf_cr) { if (residual_coding(s, xbase, ybase, 2, c, &tskip) < 0) return -1; residual_add(s, xbase >> 1, ybase >> 1, 2, c, tskip, chroma_qp(s, c)); }
+            if (c == 1 ? cbf_cb : cbf_cr) { if (residual_coding(s, xbase, ybase, 2, c, &tskip) < 0) return -1;
+                residual_add(s, xbase >> 1, ybase >> 1, 2, c, tskip, chroma_qp(s, c)); }
         }
     }
     return 0;
 }
 static int transform_tree(Sx *s, int x0, int y0, int xbase, int ybase, int log2, int depth, int blk, int pcbf_cb, int pcbf_cr) {
     int split;
-    if (log2 <= s->sps->log2_max_tb && log2 > s->sps->log2_min_tb && depth < s->max_tr_depth && !(s->intra_split && depth == 0)) split = ae(s, ORCH_CTX_SPLIT_TF + 5 - log2);
+    if (log2 <= s->sps->log2_max_tb && log2 > s->sps->log2_min_tb && depth < s->max_tr_depth && !(s->intra_split && depth == 0)) split = ae(s,
+        ORCH_CTX_SPLIT_TF + 5 - log2);
     else {
         int inter_split = s->sps->max_th_depth_inter == 0 && !s->cu_intra && s->part_mode != H_PART_2Nx2N && depth == 0;
         split = log2 > s->sps->log2_max_tb || (s->intra_split && depth == 0) || inter_split;
@@ -795,7 +815,8 @@ static int coding_unit(Sx *s, int x0, int y0, int log2) {
     /* CU-level maps that the syntax below (and later CUs) read */
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
         int i = I4(d, x, y);
-        d->pred_mode[i] = (uint8_t)(s->cu_intra ? 2 : 1); d->skip_flag[i] = (uint8_t)s->cu_skip; d->nofilter[i] = (uint8_t)s->tq_bypass; d->slice_of4[i] = (int16_t)s->slice_idx;
+        d->pred_mode[i] = (uint8_t)(s->cu_intra ? 2 : 1); d->skip_flag[i] = (uint8_t)s->cu_skip; d->nofilter[i] = (uint8_t)s->tq_bypass;
+        d->slice_of4[i] = (int16_t)s->slice_idx;
         d->edge[i] = 0; d->cbf[i] = 0; d->ipm[i] = 1;
         memset(&d->mot[i], 0, sizeof d->mot[i]); d->mot[i].ref_idx[0] = d->mot[i].ref_idx[1] = -1;
         if (x == x0) d->edge[i] |= 1 | 4;
@@ -812,7 +833,8 @@ static int coding_unit(Sx *s, int x0, int y0, int log2) {
             for (int c = 0; c < 3; c++) {
                 int sc = c ? 1 : 0, nn = n >> sc, bits = c ? sps->pcm_bits_c : sps->pcm_bits_y;
                 uint8_t *dst = d->cur->pl[c] + (y0 >> sc) * d->cur->stride[c] + (x0 >> sc);
-                for (int y = 0; y < nn; y++) for (int x = 0; x < nn; x++) { int v = (int)bits_u(&s->b, bits); dst[y * d->cur->stride[c] + x] = (uint8_t)(v << (8 - bits)); if (d->digest_on) dg(d, v); }
+                for (int y = 0; y < nn; y++) for (int x = 0; x < nn; x++) { int v = (int)bits_u(&s->b, bits);
+                    dst[y * d->cur->stride[c] + x] = (uint8_t)(v << (8 - bits)); if (d->digest_on) dg(d, v); }
             }
             cabac_init_engine(s);
             if (sps->pcm_loop_filter_disabled) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) d->nofilter[I4(d, x, y)] = 1;
@@ -829,9 +851,11 @@ static int coding_unit(Sx *s, int x0, int y0, int log2) {
                 /* 8.4.2 derivation of the luma intra prediction mode */
                 int ca = 1, cb = 1;
                 if (avail_zs(s, xp, yp, xp - 1, yp) && d->pred_mode[I4(d, xp - 1, yp)] == 2) ca = d->ipm[I4(d, xp - 1, yp)];
-                if (avail_zs(s, xp, yp, xp, yp - 1) && d->pred_mode[I4(d, xp, yp - 1)] == 2 && yp - 1 >= ((yp >> sps->log2_ctb) << sps->log2_ctb)) cb = d->ipm[I4(d, xp, yp - 1)];
+                if (avail_zs(s, xp, yp, xp, yp - 1) && d->pred_mode[I4(d, xp, yp - 1)] == 2 &&
+                    yp - 1 >= ((yp >> sps->log2_ctb) << sps->log2_ctb)) cb = d->ipm[I4(d, xp, yp - 1)];
                 int cand[3];
-                if (ca == cb) { if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; } else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); } }
+                if (ca == cb) { if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; } else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32);
+                    cand[2] = 2 + ((ca - 2 + 1) % 32); } }
                 else { cand[0] = ca; cand[1] = cb; cand[2] = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26); }
                 int mode;
                 if (prev_flag[k]) mode = cand[idx];
@@ -863,7 +887,8 @@ static int coding_unit(Sx *s, int x0, int y0, int log2) {
         case H_PART_2NxnD: w[0] = w[1] = n; h[0] = n * 3 / 4; h[1] = n / 4; xs[1] = x0; ys[1] = y0 + n * 3 / 4; break;
         case H_PART_nLx2N: h[0] = h[1] = n; w[0] = n / 4; w[1] = n * 3 / 4; xs[1] = x0 + n / 4; ys[1] = y0; break;
         case H_PART_nRx2N: h[0] = h[1] = n; w[0] = n * 3 / 4; w[1] = n / 4; xs[1] = x0 + n * 3 / 4; ys[1] = y0; break;
-        default: np = 4; for (int k = 0; k < 4; k++) { w[k] = h[k] = n / 2; xs[k] = x0 + (k & 1) * n / 2; ys[k] = y0 + (k >> 1) * n / 2; } d->stats[HST_NXN]++; break;
+        default: np = 4; for (int k = 0; k < 4; k++) { w[k] = h[k] = n / 2; xs[k] = x0 + (k & 1) * n / 2; ys[k] = y0 + (k >> 1) * n / 2; } d->stats[HST_NXN]++;
+        break;
         }
         for (int k = 0; k < np; k++) if (prediction_unit(s, x0, y0, n, xs[k], ys[k], w[k], h[k], k) < 0) return -1;
     }
@@ -919,7 +944,8 @@ static void parse_sao(Sx *s, int rx, int ry) {
     if (!sh->sao_luma && !sh->sao_chroma) return;
     int merge_left = 0, merge_up = 0;
     if (rx > 0) {
-        int left_in_slice = d->ctb_slice_addr[s->ctb_addr_rs - 1] == sh->slice_addr, left_in_tile = d->tile_id[d->ctb_rs2ts[s->ctb_addr_rs - 1]] == d->tile_id[s->ctb_addr_ts];
+        int left_in_slice = d->ctb_slice_addr[s->ctb_addr_rs - 1] == sh->slice_addr,
+            left_in_tile = d->tile_id[d->ctb_rs2ts[s->ctb_addr_rs - 1]] == d->tile_id[s->ctb_addr_ts];
         if (left_in_slice && left_in_tile) merge_left = ae(s, ORCH_CTX_SAO_MERGE);
     }
     if (ry > 0 && !merge_left) {
@@ -951,7 +977,8 @@ static void parse_sao(Sx *s, int rx, int ry) {
     /* components whose slice flag is off are not filtered even when the parameters were merged from a neighbour */
     if (!sh->sao_luma) o->type[0] = 0;
     if (!sh->sao_chroma) o->type[1] = o->type[2] = 0;
-    if (d->digest_on) for (int c = 0; c < 3; c++) { dg(d, 0x6000 | (c << 8) | (o->type[c] << 6) | (o->type[c] == 1 ? o->band_pos[c] : o->eo_class[c])); if (o->type[c]) for (int i = 0; i < 4; i++) dg(d, o->off[c][i]); }
+    if (d->digest_on) for (int c = 0; c < 3; c++) { dg(d, 0x6000 | (c << 8) | (o->type[c] << 6) | (o->type[c] == 1 ? o->band_pos[c] : o->eo_class[c]));
+        if (o->type[c]) for (int i = 0; i < 4; i++) dg(d, o->off[c][i]); }
 }
 
 /* ------------------------------------------ 7.3.8.1 slice_segment_data ------------------------------------------ */

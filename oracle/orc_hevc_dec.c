@@ -9,7 +9,8 @@
 
 static const char *kToolNames[HST_N] = { "cu", "intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst",
     "sign_hiding", "transform_skip", "tq_bypass", "pcm", "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "scaling_list", "wpp_rows", "tiles",
-    "dependent_slices", "long_term_ref", "rplm", "strong_intra", "constrained_intra", "slices", "i_slices", "p_slices", "b_slices", "merge_b0_b2_vs_pruned_b1", "dependent_segment_opens_tile" };
+    "dependent_slices", "long_term_ref", "rplm", "strong_intra", "constrained_intra", "slices", "i_slices", "p_slices", "b_slices", "merge_b0_b2_vs_pruned_b1",
+        "dependent_segment_opens_tile" };
 const char *orch_tool_name(int i) { return i >= 0 && i < HST_N ? kToolNames[i] : NULL; }
 long orch_tool_count(const OrchDec *d, int i) { return i >= 0 && i < HST_N ? d->stats[i] : 0; }
 
@@ -19,14 +20,18 @@ OrchDec *orch_open(orch_frame_cb cb, void *user) {
     d->cb = cb; d->user = user; d->first_picture = 1; d->digest = 0xcbf29ce484222325ULL;
     return d;
 }
-static void free_pic(HPic *p) { for (int c = 0; c < 3; c++) free(p->pl[c]); free(p->col_mv); free(p->col_ref_poc); free(p->col_ref_lt); free(p->col_intra); memset(p, 0, sizeof *p); }
+static void free_pic(HPic *p) { for (int c = 0; c < 3; c++) free(p->pl[c]); free(p->col_mv); free(p->col_ref_poc); free(p->col_ref_lt); free(p->col_intra);
+    memset(p, 0, sizeof *p); }
 static void free_sequence(OrchDec *d) {
     for (int i = 0; i < H_MAX_DPB; i++) free_pic(&d->dpb[i]);
-    free(d->pred_mode); free(d->skip_flag); free(d->ct_depth); free(d->ipm); free(d->nofilter); free(d->qp_y); free(d->edge); free(d->cbf); free(d->mot); free(d->slice_of4);
-    free(d->ctb_slice_addr); free(d->ctb_slice_idx); free(d->sao); free(d->ctb_rs2ts); free(d->ctb_ts2rs); free(d->tile_id); free(d->col_bd); free(d->row_bd); free(d->min_tb_zs);
+    free(d->pred_mode); free(d->skip_flag); free(d->ct_depth); free(d->ipm); free(d->nofilter); free(d->qp_y); free(d->edge); free(d->cbf); free(d->mot);
+    free(d->slice_of4);
+    free(d->ctb_slice_addr); free(d->ctb_slice_idx); free(d->sao); free(d->ctb_rs2ts); free(d->ctb_ts2rs); free(d->tile_id); free(d->col_bd); free(d->row_bd);
+    free(d->min_tb_zs);
     for (int c = 0; c < 3; c++) { free(d->deblocked[c]); d->deblocked[c] = NULL; }
     d->pred_mode = d->skip_flag = d->ct_depth = d->ipm = d->nofilter = d->edge = d->cbf = NULL; d->qp_y = NULL; d->mot = NULL; d->slice_of4 = NULL;
-    d->ctb_slice_addr = NULL; d->ctb_slice_idx = NULL; d->sao = NULL; d->ctb_rs2ts = d->ctb_ts2rs = d->tile_id = d->col_bd = d->row_bd = NULL; d->min_tb_zs = NULL;
+    d->ctb_slice_addr = NULL; d->ctb_slice_idx = NULL; d->sao = NULL; d->ctb_rs2ts = d->ctb_ts2rs = d->tile_id = d->col_bd = d->row_bd = NULL;
+    d->min_tb_zs = NULL;
     d->cur = NULL;
 }
 void orch_close(OrchDec *d) { if (!d) return; free_sequence(d); free(d); }
@@ -57,12 +62,14 @@ static void emit(OrchDec *d, HPic *p) {
 }
 static int bump(OrchDec *d) {
     HPic *best = NULL;
-    for (int i = 0; i < H_MAX_DPB; i++) { HPic *p = &d->dpb[i]; if (p->in_use && p != d->cur && p->needed_for_output && (!best || p->poc < best->poc)) best = p; }
+    for (int i = 0; i < H_MAX_DPB; i++) { HPic *p = &d->dpb[i]; if (p->in_use && p != d->cur && p->needed_for_output && (!best ||
+        p->poc < best->poc)) best = p; }
     if (!best) return 0;
     emit(d, best);
     return 1;
 }
-static void release_unused(OrchDec *d) { for (int i = 0; i < H_MAX_DPB; i++) { HPic *p = &d->dpb[i]; if (p->in_use && p != d->cur && !p->is_ref && !p->needed_for_output) p->in_use = 0; } }
+static void release_unused(OrchDec *d) { for (int i = 0; i < H_MAX_DPB; i++) { HPic *p = &d->dpb[i];
+    if (p->in_use && p != d->cur && !p->is_ref && !p->needed_for_output) p->in_use = 0; } }
 
 /* ------------------------------ sequence activation ------------------------------ */
 static int activate(OrchDec *d, const HSps *sps, const HPps *pps) {
@@ -75,15 +82,18 @@ static int activate(OrchDec *d, const HSps *sps, const HPps *pps) {
         d->w4 = d->w >> 2; d->h4 = d->h >> 2;
         size_t n4 = (size_t)d->w4 * (size_t)d->h4, nc = (size_t)d->ctb_w * (size_t)d->ctb_h;
         d->pred_mode = calloc(n4, 1); d->skip_flag = calloc(n4, 1); d->ct_depth = calloc(n4, 1); d->ipm = calloc(n4, 1); d->nofilter = calloc(n4, 1);
-        d->qp_y = calloc(n4, 1); d->edge = calloc(n4, 1); d->cbf = calloc(n4, 1); d->mot = calloc(n4, sizeof(HMotion)); d->slice_of4 = calloc(n4, sizeof(int16_t));
+        d->qp_y = calloc(n4, 1); d->edge = calloc(n4, 1); d->cbf = calloc(n4, 1); d->mot = calloc(n4, sizeof(HMotion));
+        d->slice_of4 = calloc(n4, sizeof(int16_t));
         d->ctb_slice_addr = calloc(nc, sizeof(int)); d->ctb_slice_idx = calloc(nc, sizeof(int16_t)); d->sao = calloc(nc, sizeof(HSao));
         d->ctb_rs2ts = calloc(nc, sizeof(int)); d->ctb_ts2rs = calloc(nc, sizeof(int)); d->tile_id = calloc(nc, sizeof(int));
         d->col_bd = calloc(32, sizeof(int)); d->row_bd = calloc(32, sizeof(int));
         d->tb_w = d->ctb_w << (sps->log2_ctb - sps->log2_min_tb); d->tb_h = d->ctb_h << (sps->log2_ctb - sps->log2_min_tb);
         d->min_tb_zs = calloc((size_t)d->tb_w * (size_t)d->tb_h, sizeof(uint32_t));
         for (int c = 0; c < 3; c++) d->deblocked[c] = malloc((size_t)(d->w >> (c ? 1 : 0)) * (size_t)(d->h >> (c ? 1 : 0)));
-        if (!d->pred_mode || !d->skip_flag || !d->ct_depth || !d->ipm || !d->nofilter || !d->qp_y || !d->edge || !d->cbf || !d->mot || !d->slice_of4 || !d->ctb_slice_addr ||
-            !d->ctb_slice_idx || !d->sao || !d->ctb_rs2ts || !d->ctb_ts2rs || !d->tile_id || !d->col_bd || !d->row_bd || !d->min_tb_zs || !d->deblocked[0] || !d->deblocked[1] || !d->deblocked[2])
+        if (!d->pred_mode || !d->skip_flag || !d->ct_depth || !d->ipm || !d->nofilter || !d->qp_y || !d->edge || !d->cbf || !d->mot || !d->slice_of4 ||
+            !d->ctb_slice_addr ||
+            !d->ctb_slice_idx || !d->sao || !d->ctb_rs2ts || !d->ctb_ts2rs || !d->tile_id || !d->col_bd || !d->row_bd || !d->min_tb_zs || !d->deblocked[0] ||
+                !d->deblocked[1] || !d->deblocked[2])
             H_FAIL(d, "out of memory");
     }
     d->asps = sps; d->apps = pps;
@@ -91,10 +101,15 @@ static int activate(OrchDec *d, const HSps *sps, const HPps *pps) {
     int nc_ = pps->n_tile_cols, nr_ = pps->n_tile_rows;
     if (nc_ > d->ctb_w || nr_ > d->ctb_h) H_FAIL(d, "more tiles than CTBs");
     int colw[20], rowh[22];
-    if (pps->uniform_spacing) { for (int i = 0; i < nc_; i++) colw[i] = ((i + 1) * d->ctb_w) / nc_ - (i * d->ctb_w) / nc_; for (int i = 0; i < nr_; i++) rowh[i] = ((i + 1) * d->ctb_h) / nr_ - (i * d->ctb_h) / nr_; }
+    if (pps->uniform_spacing) { for (int i = 0; i < nc_; i++) colw[i] = ((i + 1) * d->ctb_w) / nc_ - (i * d->ctb_w) / nc_;
+        for (int i = 0; i < nr_; i++) rowh[i] = ((i + 1) * d->ctb_h) / nr_ - (i * d->ctb_h) / nr_; }
     else {
-        int sum = 0; for (int i = 0; i < nc_ - 1; i++) { colw[i] = pps->col_w[i]; sum += colw[i]; } if (sum >= d->ctb_w) H_FAIL(d, "tile columns wider than the picture"); colw[nc_ - 1] = d->ctb_w - sum;
-        sum = 0; for (int i = 0; i < nr_ - 1; i++) { rowh[i] = pps->row_h[i]; sum += rowh[i]; } if (sum >= d->ctb_h) H_FAIL(d, "tile rows taller than the picture"); rowh[nr_ - 1] = d->ctb_h - sum;
+        int sum = 0;
+        for (int i = 0; i < nc_ - 1; i++) { colw[i] = pps->col_w[i]; sum += colw[i]; } if (sum >= d->ctb_w) H_FAIL(d, "tile columns wider than the picture");
+        colw[nc_ - 1] = d->ctb_w - sum;
+        sum = 0;
+        for (int i = 0; i < nr_ - 1; i++) { rowh[i] = pps->row_h[i]; sum += rowh[i]; } if (sum >= d->ctb_h) H_FAIL(d, "tile rows taller than the picture");
+        rowh[nr_ - 1] = d->ctb_h - sum;
     }
     d->col_bd[0] = 0; for (int i = 0; i < nc_; i++) d->col_bd[i + 1] = d->col_bd[i] + colw[i];
     d->row_bd[0] = 0; for (int i = 0; i < nr_; i++) d->row_bd[i + 1] = d->row_bd[i] + rowh[i];
@@ -144,8 +159,11 @@ static void finish_picture(OrchDec *d) {
     /* macroblocks... coding tree blocks no slice delivered: grey */
     for (int rs = 0; rs < d->ctb_w * d->ctb_h; rs++) if (d->ctb_slice_addr[rs] < 0) {
         int x0 = (rs % d->ctb_w) * d->ctb_size, y0 = (rs / d->ctb_w) * d->ctb_size;
-        for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; for (int y = y0 >> sc; y < ((y0 + d->ctb_size) >> sc) && y < (d->h >> sc); y++) for (int x = x0 >> sc; x < ((x0 + d->ctb_size) >> sc) && x < (d->w >> sc); x++) p->pl[c][y * p->stride[c] + x] = 128; }
-        for (int y = y0; y < y0 + d->ctb_size && y < d->h; y += 4) for (int x = x0; x < x0 + d->ctb_size && x < d->w; x += 4) { int i = (y >> 2) * d->w4 + (x >> 2); d->pred_mode[i] = 2; d->edge[i] = 0; d->nofilter[i] = 1; d->slice_of4[i] = 0; d->qp_y[i] = 26; }
+        for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0;
+            for (int y = y0 >> sc; y < ((y0 + d->ctb_size) >> sc) && y < (d->h >> sc); y++) for (int x = x0 >> sc; x < ((x0 + d->ctb_size) >> sc) &&
+            x < (d->w >> sc); x++) p->pl[c][y * p->stride[c] + x] = 128; }
+        for (int y = y0; y < y0 + d->ctb_size && y < d->h; y += 4) for (int x = x0; x < x0 + d->ctb_size && x < d->w; x += 4) {
+            int i = (y >> 2) * d->w4 + (x >> 2); d->pred_mode[i] = 2; d->edge[i] = 0; d->nofilter[i] = 1; d->slice_of4[i] = 0; d->qp_y[i] = 26; }
     }
     orch_deblock_picture(d);
     orch_sao_picture(d);
@@ -156,7 +174,8 @@ static void finish_picture(OrchDec *d) {
         p->col_mv[e] = d->mot[i4];
         const HSlice *sl = &d->slices[d->slice_of4[i4]];
         p->col_ref_lt[e] = 0;
-        for (int l = 0; l < 2; l++) if (d->mot[i4].pred_flag >> l & 1) { p->col_ref_poc[e * 2 + l] = sl->ref_poc[l][d->mot[i4].ref_idx[l]]; p->col_ref_lt[e] |= (uint8_t)(sl->ref_is_lt[l][d->mot[i4].ref_idx[l]] << l); }
+        for (int l = 0; l < 2; l++) if (d->mot[i4].pred_flag >> l & 1) { p->col_ref_poc[e * 2 + l] = sl->ref_poc[l][d->mot[i4].ref_idx[l]];
+            p->col_ref_lt[e] |= (uint8_t)(sl->ref_is_lt[l][d->mot[i4].ref_idx[l]] << l); }
     }
     /* C.5.2.3: "additional bumping" */
     if (p->pic_output) p->needed_for_output = 1;
@@ -260,8 +279,10 @@ static int build_ref_lists(OrchDec *d, HSlice *sh) {
     const HSps *sps = d->asps;
     int max_lsb = 1 << sps->log2_max_poc_lsb, poc = d->cur->poc;
     HPic *before[16], *after[16], *ltc[32]; int nb = 0, na = 0, nl = 0;
-    for (int i = 0; i < sh->st_rps.n_neg; i++) if (sh->st_rps.used[0][i]) { int want = poc + sh->st_rps.dpoc[0][i]; HPic *p = find_ref(d, want, 0, 0, 0); if (!p) p = make_missing(d, want, 0); if (!p) H_FAIL(d, "no room for a missing reference picture"); before[nb++] = p; }
-    for (int i = 0; i < sh->st_rps.n_pos; i++) if (sh->st_rps.used[1][i]) { int want = poc + sh->st_rps.dpoc[1][i]; HPic *p = find_ref(d, want, 0, 0, 0); if (!p) p = make_missing(d, want, 0); if (!p) H_FAIL(d, "no room for a missing reference picture"); after[na++] = p; }
+    for (int i = 0; i < sh->st_rps.n_neg; i++) if (sh->st_rps.used[0][i]) { int want = poc + sh->st_rps.dpoc[0][i]; HPic *p = find_ref(d, want, 0, 0, 0);
+        if (!p) p = make_missing(d, want, 0); if (!p) H_FAIL(d, "no room for a missing reference picture"); before[nb++] = p; }
+    for (int i = 0; i < sh->st_rps.n_pos; i++) if (sh->st_rps.used[1][i]) { int want = poc + sh->st_rps.dpoc[1][i]; HPic *p = find_ref(d, want, 0, 0, 0);
+        if (!p) p = make_missing(d, want, 0); if (!p) H_FAIL(d, "no room for a missing reference picture"); after[na++] = p; }
     for (int i = 0; i < sh->n_lt; i++) if (sh->lt_used[i]) {
         int want = sh->lt_msb_present[i] ? (poc & ~(max_lsb - 1)) + sh->lt_poc[i] : sh->lt_poc[i];
         HPic *p = find_ref(d, want, 1, !sh->lt_msb_present[i], max_lsb);
@@ -302,7 +323,8 @@ int orch_decode_nal(OrchDec *d, const uint8_t *nal, size_t len) {
     int rc = 0;
     if (type == 33) { finish_picture(d); rc = orch_parse_sps(d, &b); }
     else if (type == 34) { finish_picture(d); rc = orch_parse_pps(d, &b); }
-    else if (type == 36 || type == 37) {                               /* end of sequence / bitstream: everything decoded so far is output (as at the end of the stream) */
+    else if (type == 36 || type == 37) {
+        /* end of sequence / bitstream: everything decoded so far is output (as at the end of the stream) */
         finish_picture(d); while (bump(d)) {} for (int i = 0; i < H_MAX_DPB; i++) d->dpb[i].is_ref = 0; release_unused(d); d->seen_eos = 1;
     }
     else if (type == 35 || type == 32 || type == 39) { finish_picture(d); }
@@ -311,10 +333,12 @@ int orch_decode_nal(OrchDec *d, const uint8_t *nal, size_t len) {
         const HSlice *prev = d->n_slices > 0 && d->pic_started ? &d->slices[d->n_slices - 1] : NULL;
         int first = (int)bits_peek(&b, 1);
         if (first) { finish_picture(d); prev = NULL; }
-        if ((type == 8 || type == 9) && d->no_rasl_output) { free(rbsp); return 0; }      /* RASL pictures of a CRA that starts the stream are not decoded (8.1.3) */
+        if ((type == 8 || type == 9) && d->no_rasl_output) { free(rbsp); return 0; }
+            /* RASL pictures of a CRA that starts the stream are not decoded (8.1.3) */
         if (d->first_picture && !(type >= 16 && type <= 21)) { free(rbsp); return 0; }    /* decoding starts at an IRAP picture */
         rc = orch_parse_slice_header(d, &b, type, &sh, prev);
-        if (rc == 0 && !sh.first_in_pic && !d->pic_started) { snprintf(d->err, sizeof d->err, "slice segment of a picture whose first segment is missing"); rc = -1; }
+        if (rc == 0 && !sh.first_in_pic && !d->pic_started) { snprintf(d->err, sizeof d->err, "slice segment of a picture whose first segment is missing");
+            rc = -1; }
         if (rc == 0 && sh.first_in_pic) rc = start_picture(d, &sh, type, tid);
         if (rc == 0 && d->apps != &d->pps[sh.pps_id]) { snprintf(d->err, sizeof d->err, "slices of one picture refer to different PPSs"); rc = -1; }
         if (rc == 0 && d->n_slices >= H_MAX_SLICES) { snprintf(d->err, sizeof d->err, "too many slice segments"); rc = -1; }
@@ -322,7 +346,8 @@ int orch_decode_nal(OrchDec *d, const uint8_t *nal, size_t len) {
             int idx = d->n_slices++;
             d->slices[idx] = sh;
             HSlice *s = &d->slices[idx];
-            if (s->dependent) { memcpy(s->ref_poc, prev->ref_poc, sizeof s->ref_poc); memcpy(s->ref_is_lt, prev->ref_is_lt, sizeof s->ref_is_lt); memcpy(s->ref_dpb, prev->ref_dpb, sizeof s->ref_dpb); }
+            if (s->dependent) { memcpy(s->ref_poc, prev->ref_poc, sizeof s->ref_poc); memcpy(s->ref_is_lt, prev->ref_is_lt, sizeof s->ref_is_lt);
+                memcpy(s->ref_dpb, prev->ref_dpb, sizeof s->ref_dpb); }
             else {
                 memset(s->ref_dpb, -1, sizeof s->ref_dpb);
                 if (s->type != H_SLICE_I) rc = build_ref_lists(d, s);
@@ -339,11 +364,13 @@ int orch_decode_annexb(OrchDec *d, const uint8_t *buf, size_t len) {
     size_t i = 0, start = (size_t)-1; int count = 0;
     while (i + 3 <= len) {
         if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) {
-            if (start != (size_t)-1) { size_t e = i; while (e > start && buf[e - 1] == 0) e--; if (orch_decode_nal(d, buf + start, e - start) < 0) return -1; count++; }
+            if (start != (size_t)-1) { size_t e = i; while (e > start && buf[e - 1] == 0) e--; if (orch_decode_nal(d, buf + start, e - start) < 0) return -1;
+                count++; }
             start = i + 3; i += 3;
         } else i++;
     }
-    if (start != (size_t)-1 && start < len) { size_t e = len; while (e > start && buf[e - 1] == 0) e--; if (orch_decode_nal(d, buf + start, e - start) < 0) return -1; count++; }
+    if (start != (size_t)-1 && start < len) { size_t e = len; while (e > start && buf[e - 1] == 0) e--;
+        if (orch_decode_nal(d, buf + start, e - start) < 0) return -1; count++; }
     return count;
 }
 void orch_flush(OrchDec *d) { finish_picture(d); while (bump(d)) {} release_unused(d); }
@@ -353,7 +380,8 @@ typedef struct { uint8_t *buf; size_t len, cap; int fmt, n, w, h, oom; } Sink;
 static void sink_cb(void *u, const OrchFrame *f) {
     Sink *s = u;
     size_t need = (size_t)f->width * (size_t)f->height * 3 / 2;
-    if (s->len + need > s->cap) { size_t nc = s->cap ? s->cap * 2 : need * 4; while (nc < s->len + need) nc *= 2; uint8_t *nb = realloc(s->buf, nc); if (!nb) { s->oom = 1; return; } s->buf = nb; s->cap = nc; }
+    if (s->len + need > s->cap) { size_t nc = s->cap ? s->cap * 2 : need * 4; while (nc < s->len + need) nc *= 2; uint8_t *nb = realloc(s->buf, nc); if (!nb) {
+        s->oom = 1; return; } s->buf = nb; s->cap = nc; }
     uint8_t *o = s->buf + s->len;
     for (int y = 0; y < f->height; y++) memcpy(o + (size_t)y * (size_t)f->width, f->y + (size_t)y * (size_t)f->stride_y, (size_t)f->width);
     o += (size_t)f->width * (size_t)f->height;
@@ -362,7 +390,9 @@ static void sink_cb(void *u, const OrchFrame *f) {
         for (int y = 0; y < ch; y++) memcpy(o + (size_t)y * (size_t)cw, f->u + (size_t)y * (size_t)f->stride_c, (size_t)cw);
         o += (size_t)cw * (size_t)ch;
         for (int y = 0; y < ch; y++) memcpy(o + (size_t)y * (size_t)cw, f->v + (size_t)y * (size_t)f->stride_c, (size_t)cw);
-    } else for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) { o[(size_t)y * (size_t)f->width + 2 * (size_t)x] = f->u[(size_t)y * (size_t)f->stride_c + (size_t)x]; o[(size_t)y * (size_t)f->width + 2 * (size_t)x + 1] = f->v[(size_t)y * (size_t)f->stride_c + (size_t)x]; }
+    } else for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) {
+        o[(size_t)y * (size_t)f->width + 2 * (size_t)x] = f->u[(size_t)y * (size_t)f->stride_c + (size_t)x];
+        o[(size_t)y * (size_t)f->width + 2 * (size_t)x + 1] = f->v[(size_t)y * (size_t)f->stride_c + (size_t)x]; }
     s->len += need; s->n++; s->w = f->width; s->h = f->height;
 }
 int orch_decode_stream_to_buffer(const uint8_t *buf, size_t len, int out_fmt, uint8_t **out, size_t *out_len, int *w, int *h) {
@@ -372,7 +402,8 @@ int orch_decode_stream_to_buffer(const uint8_t *buf, size_t len, int out_fmt, ui
     int rc = orch_decode_annexb(d, buf, len);
     if (rc < 0) fprintf(stderr, "orch: %s\n", orch_last_error(d));
     orch_flush(d);
-    if (getenv("ORC_STATS")) { fprintf(stderr, "orch tools:"); for (int i = 0; i < HST_N; i++) if (d->stats[i]) fprintf(stderr, " %s=%ld", kToolNames[i], d->stats[i]); fprintf(stderr, "\n"); }
+    if (getenv("ORC_STATS")) { fprintf(stderr, "orch tools:"); for (int i = 0; i < HST_N; i++) if (d->stats[i]) fprintf(stderr, " %s=%ld", kToolNames[i],
+        d->stats[i]); fprintf(stderr, "\n"); }
     orch_close(d);
     if (rc < 0 || s.oom) { free(s.buf); return -1; }
     *out = s.buf; *out_len = s.len; if (w) *w = s.w; if (h) *h = s.h;

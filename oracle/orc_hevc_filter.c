@@ -111,7 +111,8 @@ void orch_deblock_picture(OrchDec *d) {
             int xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
             const HSlice *sq = slice_at(d, x, y);
             int qp = (d->qp_y[I4(d, x, y)] + d->qp_y[I4(d, xp, yp)] + 1) >> 1;
-            luma_segment(pic->pl[0] + y * pic->stride[0] + x, dir ? pic->stride[0] : 1, dir ? 1 : pic->stride[0], bs, qp, sq->beta_offset_div2, sq->tc_offset_div2,
+            luma_segment(pic->pl[0] + y * pic->stride[0] + x, dir ? pic->stride[0] : 1, dir ? 1 : pic->stride[0], bs, qp, sq->beta_offset_div2,
+                sq->tc_offset_div2,
                          d->nofilter[I4(d, xp, yp)], d->nofilter[I4(d, x, y)]);
         }
         /* chroma: edges on the 8x8 chroma sample grid, bS == 2 only, four chroma lines per unit (bS taken at the unit's first line) */
@@ -124,7 +125,8 @@ void orch_deblock_picture(OrchDec *d) {
                 int xp = dir ? xl : xl - 1, yp = dir ? yl - 1 : yl;
                 const HSlice *sq = slice_at(d, xl, yl);
                 int qpi = ((d->qp_y[I4(d, xl, yl)] + d->qp_y[I4(d, xp, yp)] + 1) >> 1) + off;
-                chroma_segment(pic->pl[c] + y * pic->stride[c] + x, dir ? pic->stride[c] : 1, dir ? 1 : pic->stride[c], orch_qpc_tab[h_clip3(0, 57, qpi)], sq->tc_offset_div2,
+                chroma_segment(pic->pl[c] + y * pic->stride[c] + x, dir ? pic->stride[c] : 1, dir ? 1 : pic->stride[c], orch_qpc_tab[h_clip3(0, 57, qpi)],
+                    sq->tc_offset_div2,
                                d->nofilter[I4(d, xp, yp)], d->nofilter[I4(d, xl, yl)]);
             }
         }
@@ -163,7 +165,8 @@ void orch_sao_picture(OrchDec *d) {
                         int xnl = xn << sc, ynl = yn << sc;
                         const HSlice *sn = slice_at(d, xnl, ynl), *scur = slice_at(d, xl, yl);
                         if (sn->slice_addr != scur->slice_addr) {
-                            int n_first = d->min_tb_zs[(ynl >> d->asps->log2_min_tb) * d->tb_w + (xnl >> d->asps->log2_min_tb)] < d->min_tb_zs[(yl >> d->asps->log2_min_tb) * d->tb_w + (xl >> d->asps->log2_min_tb)];
+                            int n_first = d->min_tb_zs[(ynl >> d->asps->log2_min_tb) * d->tb_w + (xnl >> d->asps->log2_min_tb)] <
+                                d->min_tb_zs[(yl >> d->asps->log2_min_tb) * d->tb_w + (xl >> d->asps->log2_min_tb)];
                             if (n_first ? !scur->lf_across_slices : !sn->lf_across_slices) { skip = 1; break; }
                         }
                         if (!d->apps->lf_across_tiles) {

@@ -35,7 +35,8 @@ static void expand_lists(const CodedLists *c, ScalingFactors *sf) {
 static void default_lists(CodedLists *c) {
     memset(c->l4, 16, sizeof c->l4);
     for (int m = 0; m < 6; m++) {
-        memcpy(c->l8[m], orch_scaling_default[m >= 3], 64); memcpy(c->l16[m], orch_scaling_default[m >= 3], 64); memcpy(c->l32[m], orch_scaling_default[m >= 3], 64);
+        memcpy(c->l8[m], orch_scaling_default[m >= 3], 64); memcpy(c->l16[m], orch_scaling_default[m >= 3], 64);
+        memcpy(c->l32[m], orch_scaling_default[m >= 3], 64);
         c->dc16[m] = c->dc32[m] = 16;
     }
 }
@@ -66,7 +67,8 @@ static int parse_scaling_list_data(Bits *b, ScalingFactors *sf) {
             } else {
                 int next = 8;
                 if (size_id > 1) { int v = bits_se(b); if (v < -7 || v > 247) return -1; next = v + 8; *dc = (uint8_t)next; }
-                for (int i = 0; i < n; i++) { int dl = bits_se(b); if (dl < -128 || dl > 127) return -1; next = (next + dl + 256) % 256; list[i] = (uint8_t)next; }
+                for (int i = 0; i < n; i++) { int dl = bits_se(b); if (dl < -128 || dl > 127) return -1; next = (next + dl + 256) % 256;
+                    list[i] = (uint8_t)next; }
             }
         }
     }
@@ -102,14 +104,18 @@ static int parse_st_rps(Bits *b, StRps *out, int idx, int n_sps, const StRps *se
         uint8_t used[33], use_delta[33];
         for (int j = 0; j <= n_ref; j++) { used[j] = (uint8_t)bits_u1(b); use_delta[j] = 1; if (!used[j]) use_delta[j] = (uint8_t)bits_u1(b); }
         int i = 0;
-        for (int j = ref->n_pos - 1; j >= 0; j--) { int dp = ref->dpoc[1][j] + drps; if (dp < 0 && use_delta[ref->n_neg + j]) { if (i >= 16) return -1; out->dpoc[0][i] = dp; out->used[0][i++] = used[ref->n_neg + j]; } }
+        for (int j = ref->n_pos - 1; j >= 0; j--) { int dp = ref->dpoc[1][j] + drps; if (dp < 0 && use_delta[ref->n_neg + j]) { if (i >= 16) return -1;
+            out->dpoc[0][i] = dp; out->used[0][i++] = used[ref->n_neg + j]; } }
         if (drps < 0 && use_delta[n_ref]) { if (i >= 16) return -1; out->dpoc[0][i] = drps; out->used[0][i++] = used[n_ref]; }
-        for (int j = 0; j < ref->n_neg; j++) { int dp = ref->dpoc[0][j] + drps; if (dp < 0 && use_delta[j]) { if (i >= 16) return -1; out->dpoc[0][i] = dp; out->used[0][i++] = used[j]; } }
+        for (int j = 0; j < ref->n_neg; j++) { int dp = ref->dpoc[0][j] + drps; if (dp < 0 && use_delta[j]) { if (i >= 16) return -1; out->dpoc[0][i] = dp;
+            out->used[0][i++] = used[j]; } }
         out->n_neg = i;
         i = 0;
-        for (int j = ref->n_neg - 1; j >= 0; j--) { int dp = ref->dpoc[0][j] + drps; if (dp > 0 && use_delta[j]) { if (i >= 16) return -1; out->dpoc[1][i] = dp; out->used[1][i++] = used[j]; } }
+        for (int j = ref->n_neg - 1; j >= 0; j--) { int dp = ref->dpoc[0][j] + drps; if (dp > 0 && use_delta[j]) { if (i >= 16) return -1;
+            out->dpoc[1][i] = dp; out->used[1][i++] = used[j]; } }
         if (drps > 0 && use_delta[n_ref]) { if (i >= 16) return -1; out->dpoc[1][i] = drps; out->used[1][i++] = used[n_ref]; }
-        for (int j = 0; j < ref->n_pos; j++) { int dp = ref->dpoc[1][j] + drps; if (dp > 0 && use_delta[ref->n_neg + j]) { if (i >= 16) return -1; out->dpoc[1][i] = dp; out->used[1][i++] = used[ref->n_neg + j]; } }
+        for (int j = 0; j < ref->n_pos; j++) { int dp = ref->dpoc[1][j] + drps; if (dp > 0 && use_delta[ref->n_neg + j]) { if (i >= 16) return -1;
+            out->dpoc[1][i] = dp; out->used[1][i++] = used[ref->n_neg + j]; } }
         out->n_pos = i;
     } else {
         unsigned nn = bits_ue(b), np = bits_ue(b);
@@ -146,27 +152,32 @@ int orch_parse_sps(OrchDec *d, Bits *b) {
         s.max_dec_pic_buffering[i] = (int)bits_ue(b) + 1; s.max_num_reorder[i] = (int)bits_ue(b); s.max_latency_increase[i] = (int)bits_ue(b);
         if (s.max_dec_pic_buffering[i] > 16 || s.max_num_reorder[i] > s.max_dec_pic_buffering[i] - 1) H_FAIL(d, "SPS: DPB parameters out of range");
     }
-    if (!info_present) for (int i = 0; i < s.max_sub_layers - 1; i++) { s.max_dec_pic_buffering[i] = s.max_dec_pic_buffering[s.max_sub_layers - 1]; s.max_num_reorder[i] = s.max_num_reorder[s.max_sub_layers - 1]; s.max_latency_increase[i] = s.max_latency_increase[s.max_sub_layers - 1]; }
+    if (!info_present) for (int i = 0; i < s.max_sub_layers - 1; i++) { s.max_dec_pic_buffering[i] = s.max_dec_pic_buffering[s.max_sub_layers - 1];
+        s.max_num_reorder[i] = s.max_num_reorder[s.max_sub_layers - 1]; s.max_latency_increase[i] = s.max_latency_increase[s.max_sub_layers - 1]; }
     s.log2_min_cb = (int)bits_ue(b) + 3;
     s.log2_ctb = s.log2_min_cb + (int)bits_ue(b);
     s.log2_min_tb = (int)bits_ue(b) + 2;
     s.log2_max_tb = s.log2_min_tb + (int)bits_ue(b);
     s.max_th_depth_inter = (int)bits_ue(b); s.max_th_depth_intra = (int)bits_ue(b);
-    if (b->err || s.log2_ctb < 4 || s.log2_ctb > 6 || s.log2_min_cb > s.log2_ctb || s.log2_min_tb >= s.log2_min_cb || s.log2_max_tb > 5 || s.log2_max_tb > s.log2_ctb ||
+    if (b->err || s.log2_ctb < 4 || s.log2_ctb > 6 || s.log2_min_cb > s.log2_ctb || s.log2_min_tb >= s.log2_min_cb || s.log2_max_tb > 5 ||
+        s.log2_max_tb > s.log2_ctb ||
         s.max_th_depth_inter > s.log2_ctb - s.log2_min_tb || s.max_th_depth_intra > s.log2_ctb - s.log2_min_tb)
         H_FAIL(d, "SPS: block size parameters out of range");
     if (s.width <= 0 || s.height <= 0 || s.width > 8192 || s.height > 8192 || (s.width & ((1 << s.log2_min_cb) - 1)) || (s.height & ((1 << s.log2_min_cb) - 1)))
         H_FAIL(d, "SPS: picture size %dx%d not a multiple of the minimum coding block", s.width, s.height);
-    if (2 * (s.conf_win[0] + s.conf_win[1]) >= s.width || 2 * (s.conf_win[2] + s.conf_win[3]) >= s.height) H_FAIL(d, "SPS: conformance window larger than the picture");
+    if (2 * (s.conf_win[0] + s.conf_win[1]) >= s.width || 2 * (s.conf_win[2] + s.conf_win[3]) >= s.height) H_FAIL(d,
+        "SPS: conformance window larger than the picture");
     s.scaling_list_enabled = (int)bits_u1(b);
     orch_default_scaling(&s.sf);
-    if (s.scaling_list_enabled) { s.sps_scaling_present = (int)bits_u1(b); if (s.sps_scaling_present && parse_scaling_list_data(b, &s.sf) < 0) H_FAIL(d, "SPS: bad scaling_list_data"); }
+    if (s.scaling_list_enabled) { s.sps_scaling_present = (int)bits_u1(b); if (s.sps_scaling_present && parse_scaling_list_data(b, &s.sf) < 0) H_FAIL(d,
+        "SPS: bad scaling_list_data"); }
     s.amp = (int)bits_u1(b); s.sao = (int)bits_u1(b); s.pcm = (int)bits_u1(b);
     if (s.pcm) {
         s.pcm_bits_y = (int)bits_u(b, 4) + 1; s.pcm_bits_c = (int)bits_u(b, 4) + 1;
         s.log2_min_pcm = (int)bits_ue(b) + 3; s.log2_max_pcm = s.log2_min_pcm + (int)bits_ue(b);
         s.pcm_loop_filter_disabled = (int)bits_u1(b);
-        if (s.pcm_bits_y > 8 || s.pcm_bits_c > 8 || s.log2_min_pcm < s.log2_min_cb || s.log2_max_pcm > 5 || s.log2_max_pcm > s.log2_ctb) H_FAIL(d, "SPS: PCM parameters out of range");
+        if (s.pcm_bits_y > 8 || s.pcm_bits_c > 8 || s.log2_min_pcm < s.log2_min_cb || s.log2_max_pcm > 5 || s.log2_max_pcm > s.log2_ctb) H_FAIL(d,
+            "SPS: PCM parameters out of range");
     }
     s.n_st_rps = (int)bits_ue(b);
     if (s.n_st_rps > 64) H_FAIL(d, "SPS: too many short-term RPS");
@@ -224,8 +235,10 @@ int orch_parse_pps(OrchDec *d, Bits *b) {
     p.log2_par_mrg_level = (int)bits_ue(b) + 2;
     p.sh_extension = (int)bits_u1(b);
     if (b->err) H_FAIL(d, "PPS truncated");
-    if (p.n_ref_default[0] > 15 || p.n_ref_default[1] > 15 || p.init_qp < 0 || p.init_qp > 51 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12 ||
-        p.beta_offset_div2 < -6 || p.beta_offset_div2 > 6 || p.tc_offset_div2 < -6 || p.tc_offset_div2 > 6 || p.diff_cu_qp_delta_depth > 3 || p.log2_par_mrg_level > 6)
+    if (p.n_ref_default[0] > 15 || p.n_ref_default[1] > 15 || p.init_qp < 0 || p.init_qp > 51 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 ||
+        p.cr_qp_offset < -12 || p.cr_qp_offset > 12 ||
+        p.beta_offset_div2 < -6 || p.beta_offset_div2 > 6 || p.tc_offset_div2 < -6 || p.tc_offset_div2 > 6 || p.diff_cu_qp_delta_depth > 3 ||
+            p.log2_par_mrg_level > 6)
         H_FAIL(d, "PPS: parameter out of range");
     p.valid = 1;
     if (d->apps == &d->pps[id] && d->pic_started) H_FAIL(d, "PPS %u re-sent inside a picture", id);
@@ -237,7 +250,9 @@ int orch_parse_pps(OrchDec *d, Bits *b) {
 static int parse_pwt(Bits *b, HSlice *sh) {
     sh->wp_log2_denom_l = (int)bits_ue(b);
     sh->wp_log2_denom_c = sh->wp_log2_denom_l + bits_se(b);
-    if (sh->wp_log2_denom_l > 7 || sh->wp_log2_denom_c < 0 || sh->wp_log2_denom_c > 7) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt denom %d %d type %d nref %d %d\n", sh->wp_log2_denom_l, sh->wp_log2_denom_c, sh->type, sh->n_ref[0], sh->n_ref[1]); return -1; }
+    if (sh->wp_log2_denom_l > 7 || sh->wp_log2_denom_c < 0 || sh->wp_log2_denom_c > 7) {
+        if (getenv("ORCH_DBG")) fprintf(stderr, "pwt denom %d %d type %d nref %d %d\n", sh->wp_log2_denom_l, sh->wp_log2_denom_c, sh->type, sh->n_ref[0],
+        sh->n_ref[1]); return -1; }
     for (int l = 0; l < (sh->type == H_SLICE_B ? 2 : 1); l++) {
         uint8_t lf[16], cf[16];
         for (int i = 0; i < sh->n_ref[l]; i++) lf[i] = (uint8_t)bits_u1(b);
@@ -247,12 +262,15 @@ static int parse_pwt(Bits *b, HSlice *sh) {
             sh->wp_w[l][i][1] = sh->wp_w[l][i][2] = (int16_t)(1 << sh->wp_log2_denom_c); sh->wp_o[l][i][1] = sh->wp_o[l][i][2] = 0;
             if (lf[i]) {
                 int dw = bits_se(b), o = bits_se(b);
-                if (dw < -128 || dw > 127 || o < -128 || o > 127) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt luma l%d i%d dw %d o %d denom %d %d nref %d %d\n", l, i, dw, o, sh->wp_log2_denom_l, sh->wp_log2_denom_c, sh->n_ref[0], sh->n_ref[1]); return -1; }
+                if (dw < -128 || dw > 127 || o < -128 || o > 127) {
+                    if (getenv("ORCH_DBG")) fprintf(stderr, "pwt luma l%d i%d dw %d o %d denom %d %d nref %d %d\n", l, i, dw, o, sh->wp_log2_denom_l,
+                    sh->wp_log2_denom_c, sh->n_ref[0], sh->n_ref[1]); return -1; }
                 sh->wp_w[l][i][0] = (int16_t)(sh->wp_w[l][i][0] + dw); sh->wp_o[l][i][0] = (int16_t)o;
             }
             if (cf[i]) for (int j = 1; j < 3; j++) {
                 int dw = bits_se(b), dofs = bits_se(b);
-                if (dw < -128 || dw > 127 || dofs < -512 || dofs > 511) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt chroma l%d i%d j%d dw %d dofs %d\n", l, i, j, dw, dofs); return -1; }
+                if (dw < -128 || dw > 127 || dofs < -512 || dofs > 511) { if (getenv("ORCH_DBG")) fprintf(stderr, "pwt chroma l%d i%d j%d dw %d dofs %d\n", l,
+                    i, j, dw, dofs); return -1; }
                 int w = (1 << sh->wp_log2_denom_c) + dw;
                 sh->wp_w[l][i][j] = (int16_t)w;
                 sh->wp_o[l][i][j] = (int16_t)h_clip3(-128, 127, (128 + dofs) - ((128 * w) >> sh->wp_log2_denom_c));
@@ -299,7 +317,8 @@ int orch_parse_slice_header(OrchDec *d, Bits *b, int nal_type, HSlice *sh, const
         if (nal_type != 19 && nal_type != 20) {
             sh->poc_lsb = (int)bits_u(b, sps->log2_max_poc_lsb);
             sh->st_rps_sps_flag = (int)bits_u1(b);
-            if (!sh->st_rps_sps_flag) { if (parse_st_rps(b, &sh->st_rps, sps->n_st_rps, sps->n_st_rps, sps->st_rps) < 0) H_FAIL(d, "bad st_ref_pic_set in slice header"); }
+            if (!sh->st_rps_sps_flag) { if (parse_st_rps(b, &sh->st_rps, sps->n_st_rps, sps->n_st_rps, sps->st_rps) < 0) H_FAIL(d,
+                "bad st_ref_pic_set in slice header"); }
             else {
                 if (sps->n_st_rps == 0) H_FAIL(d, "short_term_ref_pic_set_sps_flag without SPS sets");
                 if (sps->n_st_rps > 1) sh->st_rps_idx = (int)bits_u(b, h_ceil_log2(sps->n_st_rps));
@@ -315,13 +334,16 @@ int orch_parse_slice_header(OrchDec *d, Bits *b, int nal_type, HSlice *sh, const
                 int prev_msb = 0;
                 for (int i = 0; i < sh->n_lt; i++) {
                     int lsb;
-                    if (i < n_sps) { int idx = sps->n_lt_sps > 1 ? (int)bits_u(b, h_ceil_log2(sps->n_lt_sps)) : 0; if (idx >= sps->n_lt_sps) H_FAIL(d, "lt_idx_sps out of range"); lsb = sps->lt_poc_lsb[idx]; sh->lt_used[i] = sps->lt_used[idx]; }
+                    if (i < n_sps) { int idx = sps->n_lt_sps > 1 ? (int)bits_u(b, h_ceil_log2(sps->n_lt_sps)) : 0;
+                        if (idx >= sps->n_lt_sps) H_FAIL(d, "lt_idx_sps out of range"); lsb = sps->lt_poc_lsb[idx]; sh->lt_used[i] = sps->lt_used[idx]; }
                     else { lsb = (int)bits_u(b, sps->log2_max_poc_lsb); sh->lt_used[i] = (uint8_t)bits_u1(b); }
                     sh->lt_msb_present[i] = (uint8_t)bits_u1(b);
                     int cycle = 0;
-                    if (sh->lt_msb_present[i]) { cycle = (int)bits_ue(b); if (i != 0 && i != n_sps) cycle += prev_msb; prev_msb = cycle; }   /* DeltaPocMsbCycleLt (7-52) */
+                    if (sh->lt_msb_present[i]) { cycle = (int)bits_ue(b); if (i != 0 && i != n_sps) cycle += prev_msb; prev_msb = cycle; }
+                        /* DeltaPocMsbCycleLt (7-52) */
                     else if (i == 0 || i == n_sps) prev_msb = 0;
-                    sh->lt_poc[i] = sh->lt_msb_present[i] ? -(cycle << sps->log2_max_poc_lsb) + lsb : lsb;   /* resolved against the current POC in orc_hevc_dec.c */
+                    sh->lt_poc[i] = sh->lt_msb_present[i] ? -(cycle << sps->log2_max_poc_lsb) + lsb : lsb;
+                    /* resolved against the current POC in orc_hevc_dec.c */
                 }
             }
             if (sps->temporal_mvp) sh->temporal_mvp = (int)bits_u1(b);
@@ -343,7 +365,8 @@ int orch_parse_slice_header(OrchDec *d, Bits *b, int nal_type, HSlice *sh, const
                 int nb = h_ceil_log2(n_total);
                 for (int l = 0; l < (sh->type == H_SLICE_B ? 2 : 1); l++) {
                     sh->rplm_flag[l] = (int)bits_u1(b);
-                    if (sh->rplm_flag[l]) for (int i = 0; i < sh->n_ref[l]; i++) { sh->list_entry[l][i] = (int)bits_u(b, nb); if (sh->list_entry[l][i] >= n_total) H_FAIL(d, "list_entry out of range"); }
+                    if (sh->rplm_flag[l]) for (int i = 0; i < sh->n_ref[l]; i++) { sh->list_entry[l][i] = (int)bits_u(b, nb);
+                        if (sh->list_entry[l][i] >= n_total) H_FAIL(d, "list_entry out of range"); }
                 }
             }
             if (sh->type == H_SLICE_B) sh->mvd_l1_zero = (int)bits_u1(b);
@@ -353,20 +376,23 @@ int orch_parse_slice_header(OrchDec *d, Bits *b, int nal_type, HSlice *sh, const
                 if ((sh->collocated_from_l0 && sh->n_ref[0] > 1) || (!sh->collocated_from_l0 && sh->n_ref[1] > 1)) sh->collocated_ref_idx = (int)bits_ue(b);
                 if (sh->collocated_ref_idx >= sh->n_ref[sh->collocated_from_l0 ? 0 : 1]) H_FAIL(d, "collocated_ref_idx out of range");
             }
-            if ((pps->weighted_pred && sh->type == H_SLICE_P) || (pps->weighted_bipred && sh->type == H_SLICE_B)) if (parse_pwt(b, sh) < 0) H_FAIL(d, "bad pred_weight_table");
+            if ((pps->weighted_pred && sh->type == H_SLICE_P) || (pps->weighted_bipred && sh->type == H_SLICE_B)) if (parse_pwt(b, sh) < 0) H_FAIL(d,
+                "bad pred_weight_table");
             sh->max_merge_cand = 5 - (int)bits_ue(b);
             if (sh->max_merge_cand < 1 || sh->max_merge_cand > 5) H_FAIL(d, "five_minus_max_num_merge_cand out of range");
         }
         sh->qp_delta = bits_se(b);
         if (pps->slice_chroma_qp_offsets) { sh->cb_qp_offset = bits_se(b); sh->cr_qp_offset = bits_se(b); }
-        if (sh->cb_qp_offset < -12 || sh->cb_qp_offset > 12 || sh->cr_qp_offset < -12 || sh->cr_qp_offset > 12) H_FAIL(d, "slice chroma QP offset out of range");
+        if (sh->cb_qp_offset < -12 || sh->cb_qp_offset > 12 || sh->cr_qp_offset < -12 || sh->cr_qp_offset > 12) H_FAIL(d,
+            "slice chroma QP offset out of range");
         int override = 0;
         if (pps->deblock_override) override = (int)bits_u1(b);
         sh->deblock_disabled = pps->deblock_disabled; sh->beta_offset_div2 = pps->beta_offset_div2; sh->tc_offset_div2 = pps->tc_offset_div2;
         if (override) {
             sh->deblock_disabled = (int)bits_u1(b);
             if (!sh->deblock_disabled) { sh->beta_offset_div2 = bits_se(b); sh->tc_offset_div2 = bits_se(b); }
-            if (sh->beta_offset_div2 < -6 || sh->beta_offset_div2 > 6 || sh->tc_offset_div2 < -6 || sh->tc_offset_div2 > 6) H_FAIL(d, "slice deblocking offsets out of range");
+            if (sh->beta_offset_div2 < -6 || sh->beta_offset_div2 > 6 || sh->tc_offset_div2 < -6 || sh->tc_offset_div2 > 6) H_FAIL(d,
+                "slice deblocking offsets out of range");
         }
         sh->lf_across_slices = pps->lf_across_slices;
         if (pps->lf_across_slices && (sh->sao_luma || sh->sao_chroma || !sh->deblock_disabled)) sh->lf_across_slices = (int)bits_u1(b);
@@ -378,9 +404,11 @@ int orch_parse_slice_header(OrchDec *d, Bits *b, int nal_type, HSlice *sh, const
         unsigned n = bits_ue(b);
         if (n > (unsigned)(ctb_w * ctb_h)) H_FAIL(d, "num_entry_point_offsets out of range");
         sh->n_entry = (int)n;
-        if (n > 0) { int len = (int)bits_ue(b) + 1; if (len > 32) H_FAIL(d, "offset_len_minus1 out of range"); for (unsigned i = 0; i < n; i++) bits_u(b, len); }
+        if (n > 0) { int len = (int)bits_ue(b) + 1; if (len > 32) H_FAIL(d, "offset_len_minus1 out of range"); for (unsigned i = 0; i < n; i++) bits_u(b, len);
+            }
     }
-    if (pps->sh_extension) { unsigned n = bits_ue(b); if (n > 256) H_FAIL(d, "slice header extension too long"); for (unsigned i = 0; i < n; i++) bits_u(b, 8); }
+    if (pps->sh_extension) { unsigned n = bits_ue(b); if (n > 256) H_FAIL(d, "slice header extension too long"); for (unsigned i = 0; i < n; i++) bits_u(b, 8);
+        }
     /* byte_alignment() */
     if (!bits_u1(b)) H_FAIL(d, "slice header: alignment bit missing");
     while (b->pos & 7) bits_u1(b);

@@ -164,7 +164,8 @@ struct OrcDec {
     int dpb_size;
     int next_pic_id, decode_count;
     /* POC state */
-    int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5; int cur_top_poc, cur_bot_poc;   /* TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0) */
+    int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5; int cur_top_poc, cur_bot_poc;
+    /* TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0) */
     /* slice state */
     SliceHdr sh; SliceHdr first_sh;
     int slice_num;
@@ -193,7 +194,8 @@ int  orc_build_ref_lists(OrcDec *d, const SliceHdr *sh);
 void orc_output_all(OrcDec *d);
 
 enum { ORC_ST_I4, ORC_ST_I8, ORC_ST_I16, ORC_ST_PCM, ORC_ST_PSKIP, ORC_ST_P16, ORC_ST_P16x8, ORC_ST_P8x16, ORC_ST_P8x8, ORC_ST_SUB_SMALL,
-       ORC_ST_T8_INTER, ORC_ST_CABAC_SLICES, ORC_ST_CAVLC_SLICES, ORC_ST_IDC0, ORC_ST_IDC1, ORC_ST_IDC2, ORC_ST_MULTIREF, ORC_ST_BSKIP, ORC_ST_BDIRECT, ORC_ST_BINTER, ORC_ST_EXACT_END, ORC_ST_N };
+       ORC_ST_T8_INTER, ORC_ST_CABAC_SLICES, ORC_ST_CAVLC_SLICES, ORC_ST_IDC0, ORC_ST_IDC1, ORC_ST_IDC2, ORC_ST_MULTIREF, ORC_ST_BSKIP, ORC_ST_BDIRECT,
+           ORC_ST_BINTER, ORC_ST_EXACT_END, ORC_ST_N };
 
 #define ORC_FAIL(d, ...) do { snprintf((d)->err, sizeof((d)->err), __VA_ARGS__); return -1; } while (0)
 

@@ -500,7 +500,8 @@ static int inter_recon(Sl *s) {
         for (int l = 0; l < 2; l++) {
             ri[l] = mb->ref_idx[l][b8];
             if (ri[l] < 0) continue;
-            if (ri[l] >= d->ref_count[l] || !d->ref_list[l][ri[l]]) { snprintf(d->err, sizeof d->err, "missing reference picture (list %d ref_idx %d)", l, ri[l]); return -1; }
+            if (ri[l] >= d->ref_count[l] || !d->ref_list[l][ri[l]]) { snprintf(d->err, sizeof d->err, "missing reference picture (list %d ref_idx %d)", l,
+                ri[l]); return -1; }
             ref[l] = d->ref_list[l][ri[l]];
             mb->ref_pic_id[l][b8] = ref[l]->id;
         }
@@ -513,9 +514,12 @@ static int inter_recon(Sl *s) {
                 int m = mode, w0 = 32, w1 = 32;
                 if (m == 2) { implicit_weights(d, ref[0], ref[1], &w0, &w1); }
                 if (m == 1) {
-                    weight_samples(oy, y[0], y[1], 16, 1, sh->luma_log2_wd, sh->luma_weight[0][ri[0]], sh->luma_weight[1][ri[1]], sh->luma_offset[0][ri[0]], sh->luma_offset[1][ri[1]]);
-                    weight_samples(ou, cu[0], cu[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][0], sh->chroma_weight[1][ri[1]][0], sh->chroma_offset[0][ri[0]][0], sh->chroma_offset[1][ri[1]][0]);
-                    weight_samples(ov, cv[0], cv[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][1], sh->chroma_weight[1][ri[1]][1], sh->chroma_offset[0][ri[0]][1], sh->chroma_offset[1][ri[1]][1]);
+                    weight_samples(oy, y[0], y[1], 16, 1, sh->luma_log2_wd, sh->luma_weight[0][ri[0]], sh->luma_weight[1][ri[1]], sh->luma_offset[0][ri[0]],
+                        sh->luma_offset[1][ri[1]]);
+                    weight_samples(ou, cu[0], cu[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][0], sh->chroma_weight[1][ri[1]][0],
+                        sh->chroma_offset[0][ri[0]][0], sh->chroma_offset[1][ri[1]][0]);
+                    weight_samples(ov, cv[0], cv[1], 4, 1, sh->chroma_log2_wd, sh->chroma_weight[0][ri[0]][1], sh->chroma_weight[1][ri[1]][1],
+                        sh->chroma_offset[0][ri[0]][1], sh->chroma_offset[1][ri[1]][1]);
                 } else {
                     weight_samples(oy, y[0], y[1], 16, m, 5, w0, w1, 0, 0);
                     weight_samples(ou, cu[0], cu[1], 4, m, 5, w0, w1, 0, 0);
@@ -919,7 +923,8 @@ static int decode_mb(Sl *s) {
     if (is_intra_type == 25) {             /* I_PCM, 7.3.5 */
         mb->is_intra = 1; mb->is_pcm = 1;
         s->d->stats[ORC_ST_PCM]++;
-        if (cab) b->pos = (b->pos + 7) & ~(size_t)7;   /* the 9 bits read ahead end exactly with the last bit of the encoder's flush (9.3.4.5): only the pcm_alignment_zero_bits remain */
+        if (cab) b->pos = (b->pos + 7) & ~(size_t)7;
+        /* the 9 bits read ahead end exactly with the last bit of the encoder's flush (9.3.4.5): only the pcm_alignment_zero_bits remain */
         else while (!bits_aligned(b)) if (bits_u1(b)) { snprintf(s->d->err, sizeof s->d->err, "pcm_alignment_zero_bit != 0"); return -1; }
         for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) dy[y * pic->stride_y + x] = (uint8_t)bits_u(b, 8);
         for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) du[y * pic->stride_c + x] = (uint8_t)bits_u(b, 8);
@@ -947,7 +952,8 @@ static int decode_mb(Sl *s) {
                 if (cab) { int rem = orc_cabac_intra_pred_mode(s); mode = rem < 0 ? pred : (rem < pred ? rem : rem + 1); }
                 else if (bits_u1(b)) mode = pred;
                 else { int rem = bits_u(b, 3); mode = rem < pred ? rem : rem + 1; }
-                if (mb->t8x8) { mb->i4mode[by * 4 + bx] = mb->i4mode[by * 4 + bx + 1] = mb->i4mode[by * 4 + bx + 4] = mb->i4mode[by * 4 + bx + 5] = (uint8_t)mode; }
+                if (mb->t8x8) { mb->i4mode[by * 4 + bx] = mb->i4mode[by * 4 + bx + 1] = mb->i4mode[by * 4 + bx + 4] = mb->i4mode[by * 4 + bx + 5] =
+                    (uint8_t)mode; }
                 else mb->i4mode[by * 4 + bx] = (uint8_t)mode;
             }
         } else {                           /* I_16x16: Table 7-11 */
@@ -1019,7 +1025,8 @@ static int decode_mb(Sl *s) {
                 for (int i = 0; i < 4; i++) {
                     if (!(pred[i] == 2 || pred[i] == l)) continue;
                     refs[l][i] = 0;
-                    if (nref > 1 && !(!is_b && mb_type == 4)) { refs[l][i] = rd_ref_idx(s, l, (i & 1) * 2, (i >> 1) * 2, nref); if (refs[l][i] < 0 || refs[l][i] >= nref) return -1; }
+                    if (nref > 1 && !(!is_b && mb_type == 4)) { refs[l][i] = rd_ref_idx(s, l, (i & 1) * 2, (i >> 1) * 2, nref);
+                        if (refs[l][i] < 0 || refs[l][i] >= nref) return -1; }
                     mb->ref_idx[l][i] = (int8_t)refs[l][i];
                 }
             }
@@ -1098,7 +1105,8 @@ static int decode_mb(Sl *s) {
             }
         }
     } else if (mb->is_i16) {
-        if (pred16x16(s, s->i16_pred_mode, dy, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra16x16 mode needs unavailable neighbour"); return -1; }
+        if (pred16x16(s, s->i16_pred_mode, dy, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra16x16 mode needs unavailable neighbour");
+            return -1; }
         const uint8_t *list = s->pps->scaling4[0];
         /* 8.5.10: 4x4 luma DC Hadamard + scaling */
         int f[16], g[16];
@@ -1125,7 +1133,8 @@ static int decode_mb(Sl *s) {
         for (int b8 = 0; b8 < 4; b8++) {
             uint8_t *dst = dy + (b8 >> 1) * 8 * pic->stride_y + (b8 & 1) * 8;
             int mode = mb->i4mode[(b8 >> 1) * 8 + (b8 & 1) * 2];
-            if (pred8x8l(s, b8, mode, dst, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra8x8 mode %d needs unavailable neighbour", mode); return -1; }
+            if (pred8x8l(s, b8, mode, dst, pic->stride_y) < 0) { snprintf(s->d->err, sizeof s->d->err, "Intra8x8 mode %d needs unavailable neighbour", mode);
+                return -1; }
             if (cbp & (1 << b8)) recon8x8(s, b8, s->pps->scaling8[0], qp, dst, pic->stride_y);
         }
     } else {                               /* Intra 4x4: predict + residual per block in decode order */
@@ -1177,7 +1186,8 @@ int orc_decode_slice_data(OrcDec *d, Bits *b) {
             if (addr >= n_mbs) { snprintf(d->err, sizeof d->err, "slice runs past the end of the picture"); rc = -1; break; }
             s->mb_addr = addr; s->mb_x = addr % d->mb_w; s->mb_y = addr / d->mb_w; s->mb = &s->pic->mbs[addr];
             int skip = d->sh.slice_type != SLICE_I ? orc_cabac_mb_skip_flag(s) : 0;
-            if ((skip ? decode_skip_mb(s) : decode_mb(s)) < 0) { if (!d->err[0]) snprintf(d->err, sizeof d->err, "macroblock %d decode error", addr); rc = -1; break; }
+            if ((skip ? decode_skip_mb(s) : decode_mb(s)) < 0) { if (!d->err[0]) snprintf(d->err, sizeof d->err, "macroblock %d decode error", addr); rc = -1;
+                break; }
             addr++; d->cur_mb_count++;
             if (b->err) { snprintf(d->err, sizeof d->err, "slice data truncated"); rc = -1; break; }
             if (orc_cabac_terminate(&s->c)) {                  /* end_of_slice_flag */

@@ -303,7 +303,8 @@ def test_intel_push_pull_api(oracle):
     L = jmcodec_amd.lib()
     vp = C.c_void_p
     L.jm_amdintel_create_handle.restype = vp
-    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int), vp]),
+    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int),
+        vp]),
                    ("set_eof", [C.c_int, vp]), ("need_more_data", [vp]), ("free_buf_len", [vp]), ("is_exit", [vp]), ("info", [vp]),
                    ("set_yuv_callback", [vp, vp, vp])):
         getattr(L, "jm_amdintel_" + fn).argtypes = at
@@ -386,7 +387,8 @@ def test_device_resident_output_and_argb(oracle):
                     D = U.astype(np.int32).repeat(2, 0).repeat(2, 1) - 128; E = V.astype(np.int32).repeat(2, 0).repeat(2, 1) - 128
                     c = 298 * (Y - 16) + 128
                     R, G, B = np.clip((c + 409 * E) >> 8, 0, 255), np.clip((c - 100 * D - 208 * E) >> 8, 0, 255), np.clip((c + 516 * D) >> 8, 0, 255)
-                    assert np.array_equal(argb[:, :, 0], B) and np.array_equal(argb[:, :, 1], G) and np.array_equal(argb[:, :, 2], R) and (argb[:, :, 3] == 255).all()
+                    assert np.array_equal(argb[:, :, 0], B) and np.array_equal(argb[:, :, 1], G) and np.array_equal(argb[:, :, 2], R) and (argb[:, :,
+                        3] == 255).all()
                     count += 1
                 assert count == n
         finally:
@@ -426,7 +428,8 @@ def test_encoder_preprocessing_kernel_vs_restatement(w, h, pitch, fmt):
         got = np.zeros(rows * pitch, np.uint8)
         assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d_dst, got.size, 2) == 0
         assert np.array_equal(got.reshape(rows, pitch), _nv12_pitch_restated(frame, w, h, fmt, pitch))    # padding bytes stay untouched (zero)
-        assert L.jm_amddec_i420_to_nv12_device(d_src, w + 1, h, fmt, d_dst, pitch, None) == -1 and L.jm_amddec_i420_to_nv12_device(d_src, w, h, fmt, d_dst, w - 1, None) == -1
+        assert L.jm_amddec_i420_to_nv12_device(d_src, w + 1, h, fmt, d_dst, pitch, None) == -1 and L.jm_amddec_i420_to_nv12_device(d_src, w, h, fmt, d_dst,
+            w - 1, None) == -1
     finally:
         hip.hipFree(d_src); hip.hipFree(d_dst)
 
@@ -467,9 +470,10 @@ def test_decode_to_encoder_surface_on_device(oracle):
 
 
 def test_constrained_intra_unavailable_samples_count_as_128(oracle):
-    """Found by tools/gpu_sweep.py: with constrained_intra_pred the generator selected (then unconditionally, now with nc_corner=1) Intra4x4 Horizontal-Down next to an INTER corner neighbour (the
-    sample is not available, so a conforming encoder would not); oracle, generator and the spin-wait kernel count such samples as 128 and the LDS intra
-    wavefront has to as well.  The P pictures of this stream are dense enough in intra macroblocks to take the LDS wavefront (three deblocking / intra bands)."""
+    """Found by tools/gpu_sweep.py: with constrained_intra_pred the generator selected (then unconditionally, now with nc_corner=1) Intra4x4 Horizontal-Down
+    next to an INTER corner neighbour (the sample is not available, so a conforming encoder would not); oracle, generator and the spin-wait kernel count
+    such samples as 128 and the LDS intra wavefront has to as well.  The P pictures of this stream are dense enough in intra macroblocks to take the LDS
+    wavefront (three deblocking / intra bands)."""
     kw = dict(width=320, height=520, frames=7, qp=18, gop=4, seed=153603, mode=1, deblock=0, num_ref=3, slices=1, cabac=1, cabac_idc=0, t8x8=1, bframes=2,
               direct_temporal=0, wp=1, dinf8=0, scaling=0, rplm=1, cip=1, chroma_qp_off=-4, alpha_off=3, beta_off=0, poc_type=0,
               nc_corner=1)            # the generator's explicit switch for this (non-conforming) choice
@@ -608,7 +612,8 @@ CHAIN_CASES = {
     "p_multiband_fuzz": dict(width=352, height=416, frames=14, gop=14, mode=1, num_ref=3, seed=201, no_intra=1),
     "p_multiband_real": dict(width=640, height=368, frames=12, gop=12, seed=202, search=12),
     "b_multiband_cabac": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=2, bframes=2, cabac=1, seed=203, poc_type=0, no_intra=1),
-    "b_temporal_t8x8": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=3, bframes=3, cabac=1, t8x8=1, direct_temporal=1, seed=206, poc_type=0, no_intra=1),
+    "b_temporal_t8x8": dict(width=352, height=288, frames=13, gop=13, mode=1, num_ref=3, bframes=3, cabac=1, t8x8=1, direct_temporal=1, seed=206, poc_type=0,
+    no_intra=1),
     "wp_slices_nonref": dict(width=320, height=272, frames=12, gop=12, mode=1, num_ref=2, wp=1, slices=3, nonref_period=3, seed=204, poc_type=0, no_intra=1),
     "mmco_deblock_idc2": dict(width=320, height=272, frames=16, gop=16, mode=1, num_ref=3, mmco=1, deblock=2, slices=2, seed=205, no_intra=1),
     # intra macroblocks scattered through P / B pictures, and several IDR periods: those pictures join the chains through the intra role (k_chain_i)
@@ -700,7 +705,8 @@ def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
     assert rec >= 1 and errs == 0
 
 
-@pytest.mark.parametrize("kw", [dict(num_ref=4, frames=48, gop=24), dict(num_ref=3, frames=39, gop=13, bframes=2, cabac=1, poc_type=0), dict(num_ref=1, frames=40, gop=20)])
+@pytest.mark.parametrize("kw", [dict(num_ref=4, frames=48, gop=24), dict(num_ref=3, frames=39, gop=13, bframes=2, cabac=1, poc_type=0), dict(num_ref=1,
+    frames=40, gop=20)])
 def test_recovered_chain_launches_are_never_silently_wrong(oracle, kw):
     """when a chain launch is recovered, the lane's NEXT batch has already run and may have decoded into surfaces the redo needs (18
     surfaces round robin, depth-8 chains, several references) or that an IDR / flush displays.  The engine now checks that per decoder: either the redo

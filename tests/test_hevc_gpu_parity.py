@@ -101,7 +101,8 @@ def test_hevc_through_the_intel_push_pull_api_and_hvcc(oracle):
     L = jmcodec_amd.lib()
     vp = C.c_void_p
     L.jm_amdintel_create_handle.restype = vp
-    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int), vp]),
+    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int),
+        vp]),
                    ("set_eof", [C.c_int, vp]), ("need_more_data", [vp]), ("free_buf_len", [vp]), ("is_exit", [vp])):
         getattr(L, "jm_amdintel_" + fn).argtypes = at
     data = streams.generate_hevc(**HEVC_CASES["b_gop8"])
@@ -188,7 +189,8 @@ def test_c3_full_length_4k_hevc():
         assert [streams.idr_period(data, k, True) is not None for k in range(5)] == [True] * 4 + [False]
         wants = {k: ex.submit(lambda k=k: streams.OracleHevc().decode(periods[k], 1)) for k in (0, 3)}
         digs, kinds = _decode_digests(data, 3840, 2160, codec=1)
-        assert len(digs) == 120 and len(set(digs)) == 120 and sum(kinds) == 120 and kinds[0] == 4 and kinds[2] >= 70   # 4 IDR pictures; of the others about two in three are B pictures (the anchors of the GOP-8 pyramids are P)
+        # 4 IDR pictures; of the others about two in three are B pictures (the anchors of the GOP-8 pyramids are P)
+        assert len(digs) == 120 and len(set(digs)) == 120 and sum(kinds) == 120 and kinds[0] == 4 and kinds[2] >= 70
         digs2, _ = _decode_digests(data, 3840, 2160, codec=1, chunks=[data[i:i + 65536] for i in range(0, len(data), 65536)])
         assert digs2 == digs
         for k, first in ((0, 0), (3, 96)):
@@ -235,7 +237,8 @@ def test_mixed_codecs_concurrently_all_engine_lanes():
         for name in ("real_qvga", "fuzz_multiref_slices", "b_real_spatial", "b_fuzz_cabac_high", "high_real_qvga", "fmo0_cabac_b_crop"):
             d = streams.generate(**dict(ALL_CASES[name], seed=ALL_CASES[name].get("seed", 1) + 1000 * rep))
             jobs.append((0, name, d, o4.decode(d, 1)[0]))
-        for kw in (dict(width=320, height=240, frames=9, gop=8, num_ref=2, seed=0x4D70 + rep, sdh=1), dict(width=176, height=144, frames=17, gop=8, num_ref=3, seed=0x4D80 + rep, mode=1),
+        for kw in (dict(width=320, height=240, frames=9, gop=8, num_ref=2, seed=0x4D70 + rep, sdh=1), dict(width=176, height=144, frames=17, gop=8, num_ref=3,
+            seed=0x4D80 + rep, mode=1),
                    dict(width=352, height=288, frames=6, gop=0, num_ref=1, seed=0x4D90 + rep)):
             d = streams.generate_hevc(**kw)
             jobs.append((1, "hevc %dx%d" % (kw["width"], kw["height"]), d, oh.decode(d, 1)[0]))

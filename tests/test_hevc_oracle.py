@@ -30,7 +30,8 @@ HEVC_CASES = {
     "dqp_depths": dict(width=128, height=96, frames=3, dqp=4, mode=1, seed=11, cb_qp_off=-5, cr_qp_off=7),
     "pcm_bypass": dict(width=96, height=80, frames=3, pcm=1, bypass=1, mode=1, seed=12),
     "pcm_filtered": dict(width=96, height=80, frames=2, pcm=2, mode=1, seed=13),
-    "pcm_only_8bit": dict(width=96, height=80, frames=3, pcm=3, ctb_log2=4, min_cb_log2=4, sao=0, deblock=0, gop=0, num_ref=1, seed=21),   # the known-answer stream below
+    "pcm_only_8bit": dict(width=96, height=80, frames=3, pcm=3, ctb_log2=4, min_cb_log2=4, sao=0, deblock=0, gop=0, num_ref=1, seed=21),
+    # the known-answer stream below
     "cip": dict(width=96, height=80, frames=4, cip=1, mode=1, seed=14),
     "wp_b": dict(width=96, height=80, frames=7, gop=2, num_ref=2, wp=1, mode=1, seed=15),
     "rplm": dict(width=96, height=80, frames=6, num_ref=3, rplm=1, mode=1, seed=16),
@@ -74,13 +75,16 @@ def test_oracle_equals_generator_reconstruction(oracle, name):
 
 def test_cases_cover_the_tools(oracle):
     seen = {}
-    for name in ("b_gop2", "tskip_sdh", "pcm_bypass", "wp_b", "rplm", "long_term", "wpp", "tiles", "tiles_dep_slices", "slices_dep", "dqp_depths", "b_gop8", "cip"):
+    for name in ("b_gop2", "tskip_sdh", "pcm_bypass", "wp_b", "rplm", "long_term", "wpp", "tiles", "tiles_dep_slices", "slices_dep", "dqp_depths", "b_gop8",
+        "cip"):
         for k, v in oracle.tools(streams.generate_hevc(**HEVC_CASES[name])).items():
             seen[k] = seen.get(k, 0) + v
-    for tool in ("intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst", "sign_hiding", "transform_skip", "tq_bypass", "pcm",
+    for tool in ("intra_cu", "skip_cu", "merge_pu", "amvp_pu", "bi_pu", "amp", "nxn", "tu4", "tu8", "tu16", "tu32", "dst", "sign_hiding", "transform_skip",
+        "tq_bypass", "pcm",
                  "cu_qp_delta", "sao_band", "sao_edge", "weighted_pred", "tmvp", "wpp_rows", "tiles", "dependent_slices", "long_term_ref", "rplm", "b_slices",
                  "dependent_segment_opens_tile",   # 9.3.1: initialised contexts, not the stored ones (a second shared misreading, found in round 3)
-                 "merge_b0_b2_vs_pruned_b1"):      # 8.5.3.2.3: B0 / B2 dropped as duplicates of a B1 that is available but was itself pruned against A1 (the case all three programs once misread)
+                 # 8.5.3.2.3: B0 / B2 dropped as duplicates of a B1 that is available but was itself pruned against A1 (all three programs once misread it)
+                 "merge_b0_b2_vs_pruned_b1"):
         assert seen.get(tool, 0) > 0, f"no test stream exercises {tool}"
 
 
@@ -154,7 +158,8 @@ def test_filters_and_loop_filter_tables():
     for k in range(1, 8):
         assert (cf[k] == cf[8 - k][::-1]).all()
     beta, tc = c_array(TABLES, "orch_beta_tab"), c_array(TABLES, "orch_tc_tab")
-    assert len(beta) == 52 and len(tc) == 54 and beta == sorted(beta) and tc == sorted(tc) and beta[15] == 0 and beta[16] == 6 and beta[51] == 64 and tc[17] == 0 and tc[18] == 1 and tc[53] == 24
+    assert len(beta) == 52 and len(tc) == 54 and beta == sorted(beta) and tc == sorted(tc)
+    assert beta[15] == 0 and beta[16] == 6 and beta[51] == 64 and tc[17] == 0 and tc[18] == 1 and tc[53] == 24
     qpc = c_array(TABLES, "orch_qpc_tab")
     assert qpc[:30] == list(range(30)) and qpc[43] == 37 and qpc[44] == 38 and qpc[57] == 51 and qpc == sorted(qpc)
     ang = c_array(TABLES, "orch_intra_angle")
@@ -172,7 +177,8 @@ def test_cabac_tables_shape_and_identity_between_copies():
         assert c_array(path, prefix + "ctx_init") == init.ravel().tolist()
         assert c_array(path, prefix + "trans") == c_array(TABLES, "orch_trans")
     h264 = os.path.join(ROOT, "oracle", "orc_cabac_tables.h")
-    assert c_array(TABLES, "orch_range_lps") == c_array(h264, "orc_cabac_range_lps") and c_array(TABLES, "orch_trans_lps") == c_array(h264, "orc_cabac_trans_lps")
+    assert c_array(TABLES, "orch_range_lps") == c_array(h264, "orc_cabac_range_lps") and c_array(TABLES, "orch_trans_lps") == c_array(h264,
+        "orc_cabac_trans_lps")
 
 
 def nal_types(data):
@@ -243,7 +249,8 @@ def test_pcm_known_answer(oracle):
                            + V[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8].tobytes())
                 k = rbsp.find(payload, pos)
                 assert k >= 0, (f, cx, cy)
-                # between two payloads: the arithmetic decoder's 9 + 7 initialisation bits, end_of_slice_segment_flag, (cu_skip_flag, pred_mode_flag,) part_mode,
+                # between two payloads: the arithmetic decoder's 9 + 7 initialisation bits, end_of_slice_segment_flag, (cu_skip_flag, pred_mode_flag,)
+                # part_mode,
                 # pcm_flag and the alignment bits -- a few bytes; before the first one also the slice segment header
                 assert k - pos <= (24 if (cx, cy) == (0, 0) else 6), (f, cx, cy, k - pos)
                 pos = k + 384

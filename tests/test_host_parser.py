@@ -133,7 +133,8 @@ def test_api_protocol_and_info_block():
         frames += got
     assert frames == 6
     info = api.jm_nvdec_show_dec_info(h)
-    assert re.fullmatch(r"=+\nCodec:\t\tH\.264\nDisplay:\t96 x 80\nPixel Format:\tYV12\nFrame Count:\t6\nElapsed Time:\t\d+ ms\nDecode FPS:\t[\d.]+ fps\n=+\n", info), info
+    assert re.fullmatch(r"=+\nCodec:\t\tH\.264\nDisplay:\t96 x 80\nPixel Format:\tYV12\nFrame Count:\t6\nElapsed Time:\t\d+ ms\nDecode FPS:\t[\d.]+ "
+        r"fps\n=+\n", info), info
     # once EOS was sent further input is ignored (nv_dec.cpp:374-375)
     ret, got = api.jm_nvdec_decode_frame(data, len(data), h)
     assert (ret, got) == (0, 0)
@@ -366,7 +367,8 @@ def test_job_slots_grow_on_demand_and_build_the_same_job_lists(kw, monkeypatch):
     def run():
         with api.JmAmdDec(0, 1, options={"parse_only": 1, "job_digest": 1, "digest": 1}) as d:
             n = len(d.decode_stream(data))
-            return (d.stat("job_digest") & (2 ** 64 - 1), d.stat("syntax_digest") & (2 ** 64 - 1), n, d.stat("errors"), d.stat("job_bytes")), d.stat("job_regrown"), d.stat("job_slot_bytes")
+            return (d.stat("job_digest") & (2 ** 64 - 1), d.stat("syntax_digest") & (2 ** 64 - 1), n, d.stat("errors"),
+                d.stat("job_bytes")), d.stat("job_regrown"), d.stat("job_slot_bytes")
     small, regrown, slot_bytes = run()
     monkeypatch.setenv("JM_AMD_DEC_JOB_WORST_CASE", "1")
     worst, regrown_w, slot_bytes_w = run()

@@ -62,7 +62,8 @@ def test_bench_two_ranks_gloo_parse_only():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--parse-only", "--streams", "3", "--frames", "6", "--width", "176", "--height", "144"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--parse-only", "--streams", "3", "--frames", "6", "--width",
+           "176", "--height", "144"]
     env = dict(os.environ, JM_BENCH_CACHE=os.environ.get("TMPDIR", "/tmp"))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -171,7 +171,8 @@ def test_h264_cavlc_code_tables_against_the_bit_strings_of_the_standard():
     """coeff_token (Table 9-5, all five columns), total_zeros (9-7, 9-8, 9-9a), run_before (9-10): oracle, product, generator."""
     tok = spec.parse_code_table(spec.COEFF_TOKEN, 5)
     assert len(tok) == 62
-    for path, ln, bn, ncol in ((ORC_TABLES, "orc_coeff_token_len", "orc_coeff_token_bits", 4), (PROD_CAVLC, "kTokLen", "kTokBits", 3), (GEN_H264, "ct_len", "ct_bits", 4)):
+    for path, ln, bn, ncol in ((ORC_TABLES, "orc_coeff_token_len", "orc_coeff_token_bits", 4), (PROD_CAVLC, "kTokLen", "kTokBits", 3), (GEN_H264, "ct_len",
+        "ct_bits", 4)):
         lens, bits = c_array(path, ln), c_array(path, bn)
         assert len(lens) == len(bits) == ncol * 68
         for col in range(ncol):
@@ -180,7 +181,8 @@ def test_h264_cavlc_code_tables_against_the_bit_strings_of_the_standard():
                     want = tok.get((t1, tc), [None] * 5)[col]
                     got = (lens[col * 68 + 4 * tc + t1], bits[col * 68 + 4 * tc + t1])
                     assert got == (want or (0, 0)), (os.path.basename(path), col, t1, tc, got, want)
-    for path, ln, bn in ((ORC_TABLES, "orc_chroma_dc_token_len", "orc_chroma_dc_token_bits"), (PROD_CAVLC, "kCdcLen", "kCdcBits"), (GEN_H264, "cdc_len", "cdc_bits")):
+    for path, ln, bn in ((ORC_TABLES, "orc_chroma_dc_token_len", "orc_chroma_dc_token_bits"), (PROD_CAVLC, "kCdcLen", "kCdcBits"), (GEN_H264, "cdc_len",
+        "cdc_bits")):
         lens, bits = c_array(path, ln), c_array(path, bn)
         for tc in range(5):
             for t1 in range(4):
@@ -195,21 +197,24 @@ def test_h264_cavlc_code_tables_against_the_bit_strings_of_the_standard():
                 want = tz[(z,)][idx]
                 assert (lens[idx][z], bits[idx][z]) == (want or (0, 0)), (os.path.basename(path), idx + 1, z)
     ctz = spec.parse_code_table(spec.TOTAL_ZEROS_CHROMA_DC, 3)
-    for path, ln, bn in ((ORC_TABLES, "orc_cdc_total_zeros_len", "orc_cdc_total_zeros_bits"), (PROD_CAVLC, "kCtzLen", "kCtzBits"), (GEN_H264, "ctz_len", "ctz_bits")):
+    for path, ln, bn in ((ORC_TABLES, "orc_cdc_total_zeros_len", "orc_cdc_total_zeros_bits"), (PROD_CAVLC, "kCtzLen", "kCtzBits"), (GEN_H264, "ctz_len",
+        "ctz_bits")):
         lens, bits = c_rows(path, ln, 4), c_rows(path, bn, 4)
         for idx in range(3):
             for z in range(4):
                 want = ctz[(z,)][idx]
                 assert (lens[idx][z], bits[idx][z]) == (want or (0, 0)), (os.path.basename(path), idx + 1, z)
     rb = spec.parse_code_table(spec.RUN_BEFORE, 7)
-    for path, ln, bn, rows, width in ((ORC_TABLES, "orc_run_len", "orc_run_bits", 7, 15), (GEN_H264, "rb_len", "rb_bits", 7, 15), (PROD_CAVLC, "kRunLen", "kRunBits", 6, 7)):
+    for path, ln, bn, rows, width in ((ORC_TABLES, "orc_run_len", "orc_run_bits", 7, 15), (GEN_H264, "rb_len", "rb_bits", 7, 15), (PROD_CAVLC, "kRunLen",
+        "kRunBits", 6, 7)):
         lens, bits = c_rows(path, ln, width), c_rows(path, bn, width)
         assert len(lens) == len(bits) == rows
         for zl in range(rows):
             for r in range(width):
                 want = rb.get((r,), [None] * 7)[zl]
                 assert (lens[zl][r], bits[zl][r]) == (want or (0, 0)), (os.path.basename(path), zl + 1, r)
-    # zerosLeft > 6 in the product is computed, not tabled: run_before = 7 - (first three bits) or 4 + leading zeros (h264_cavlc.cpp); the column's shape says so
+    # zerosLeft > 6 in the product is computed, not tabled: run_before = 7 - (first three bits) or 4 + leading zeros (h264_cavlc.cpp);
+    # the column's shape says so
     for r in range(15):
         ln, v = rb[(r,)][6]
         assert (ln, v) == ((3, 7 - r) if r < 7 else (r - 3, 1))
@@ -236,7 +241,8 @@ def test_h264_mapping_scan_and_filter_tables_against_a_separately_typed_copy():
 
 def test_arithmetic_decoder_tables_against_a_separately_typed_copy():
     """rangeTabLPS (first and last rows) and transIdxLPS: H.264 Tables 9-44 / 9-45, H.265 Tables 9-46 / 9-47 (the same engine)."""
-    range_first = [[128, 176, 208, 240], [128, 167, 197, 227], [128, 158, 187, 216], [123, 150, 178, 205], [116, 142, 169, 195], [111, 135, 160, 185], [105, 128, 152, 175], [100, 122, 144, 166]]
+    range_first = [[128, 176, 208, 240], [128, 167, 197, 227], [128, 158, 187, 216], [123, 150, 178, 205], [116, 142, 169, 195], [111, 135, 160, 185], [105,
+        128, 152, 175], [100, 122, 144, 166]]
     range_last = [[6, 8, 9, 11], [6, 7, 9, 10], [6, 7, 8, 9], [2, 2, 2, 2]]
     trans_lps = [0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
                  24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63]
@@ -275,7 +281,8 @@ def test_hevc_constant_tables_against_a_separately_typed_copy():
         import re
 
         def arr(stem):
-            name = next(n for n in (("hevc_" + stem), ("orch_" + stem), ("orc_hevc_" + stem), ("hg_" + stem), ("hevcgen_" + stem)) if re.search(r"\b" + n + r"\s*\[", src))
+            name = next(n for n in (("hevc_" + stem), ("orch_" + stem), ("orc_hevc_" + stem), ("hg_" + stem),
+                ("hevcgen_" + stem)) if re.search(r"\b" + n + r"\s*\[", src))
             return c_array(path, name)
         assert arr("trans") == want, os.path.basename(path)
         assert arr("dst") == dst and arr("intra_angle") == intra_angle and arr("inv_angle") == inv_angle, os.path.basename(path)

@@ -85,7 +85,8 @@ PARITY_CASES = {
     "cabac_pcm": dict(width=48, height=32, frames=2, pcm_only=1, gop=2, cabac=1, seed=3),
     "cabac_real": dict(width=176, height=144, frames=6, gop=6, seed=21, cabac=1),
     "cabac_fuzz_idc1_multiref": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=3, slices=2, seed=84, cabac=1, cabac_idc=1),
-    "cabac_fuzz_idc2_cip": dict(width=96, height=80, frames=8, gop=8, mode=1, num_ref=2, slices=3, seed=85, cabac=1, cabac_idc=2, cip=1, deblock=2, chroma_qp_off=2),
+    "cabac_fuzz_idc2_cip": dict(width=96, height=80, frames=8, gop=8, mode=1, num_ref=2, slices=3, seed=85, cabac=1, cabac_idc=2, cip=1, deblock=2,
+    chroma_qp_off=2),
     "high_cabac_fuzz": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=2, seed=86, cabac=1, t8x8=1),
     "high_cavlc_fuzz": dict(width=96, height=80, frames=8, gop=4, mode=1, num_ref=2, seed=87, t8x8=1, poc_type=0),
     "high_real_qvga": dict(width=320, height=240, frames=8, gop=8, seed=22, cabac=1, t8x8=1, qp=30),
@@ -101,7 +102,8 @@ B_CASES = {
     "b_real_temporal_cabac": dict(width=176, height=144, frames=10, gop=10, seed=92, bframes=2, direct_temporal=1, cabac=1),
     "b_fuzz_cavlc": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=93, bframes=2, num_ref=3),
     "b_fuzz_cabac_high": dict(width=96, height=80, frames=12, gop=6, mode=1, seed=94, bframes=3, num_ref=4, cabac=1, t8x8=1, slices=2),
-    "b_fuzz_temporal_noinf8": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=95, bframes=2, num_ref=3, direct_temporal=1, dinf8=0, cabac=1, cabac_idc=1),
+    "b_fuzz_temporal_noinf8": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=95, bframes=2, num_ref=3, direct_temporal=1, dinf8=0, cabac=1,
+    cabac_idc=1),
     "b_fuzz_spatial_noinf8": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=96, bframes=1, dinf8=0, deblock=2, slices=3, cip=1),
     "b_fuzz_implicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=97, bframes=2, num_ref=3, wp=2, cabac=1, cabac_idc=2),
     "b_fuzz_explicit_wp": dict(width=96, height=80, frames=10, gop=10, mode=1, seed=98, bframes=2, num_ref=2, wp=1, t8x8=1),

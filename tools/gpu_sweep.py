@@ -15,12 +15,18 @@ from tools import streams         # noqa: E402
 
 def hevc_params(r):
     ctb = r.choice([4, 5, 6])
-    a = dict(width=r.choice([64, 96, 120, 176, 200, 130, 320]), height=r.choice([64, 80, 96, 144, 66, 240]), frames=r.choice([2, 3, 5, 9, 17]), qp=r.choice([18, 26, 32, 38, 44]),
-             seed=r.randrange(1 << 20), gop=r.choice([0, 0, 1, 2, 3, 8]), num_ref=r.choice([1, 2, 3, 4]), ctb_log2=ctb, mode=r.choice([0, 1, 1]), amp=r.randint(0, 1), sao=r.randint(0, 1),
-             deblock=r.choice([0, 1, 1, 2]), tskip=r.randint(0, 1), sdh=r.randint(0, 1), dqp=r.choice([0, 0, 1, 2, 3, 4]), pcm=r.choice([0, 0, 1, 2]), bypass=r.choice([0, 0, 1]),
-             cip=r.choice([0, 0, 1]), tmvp=r.randint(0, 1), wp=r.choice([0, 0, 1]), rplm=r.choice([0, 0, 1]), scaling=r.choice([0, 0, 1, 2, 3]), wpp=r.choice([0, 0, 1]),
-             min_cb_log2=r.choice([3, 3, min(4, ctb)]), max_tb_log2=r.choice([5, 5, 4, 3]), depth_inter=r.randint(0, 3), depth_intra=r.randint(0, 3), strong_intra=r.randint(0, 1),
-             merge_cand=r.randint(1, 5), cabac_init=r.choice([0, 1, 2]), par_mrg=r.choice([2, 2, 3, 4, 5]), intra_period=r.choice([4, 8, 32]), cb_qp_off=r.choice([0, 0, -3, 5]),
+    a = dict(width=r.choice([64, 96, 120, 176, 200, 130, 320]), height=r.choice([64, 80, 96, 144, 66, 240]), frames=r.choice([2, 3, 5, 9, 17]),
+        qp=r.choice([18, 26, 32, 38, 44]),
+             seed=r.randrange(1 << 20), gop=r.choice([0, 0, 1, 2, 3, 8]), num_ref=r.choice([1, 2, 3, 4]), ctb_log2=ctb, mode=r.choice([0, 1, 1]),
+             amp=r.randint(0, 1), sao=r.randint(0, 1),
+             deblock=r.choice([0, 1, 1, 2]), tskip=r.randint(0, 1), sdh=r.randint(0, 1), dqp=r.choice([0, 0, 1, 2, 3, 4]), pcm=r.choice([0, 0, 1, 2]),
+             bypass=r.choice([0, 0, 1]),
+             cip=r.choice([0, 0, 1]), tmvp=r.randint(0, 1), wp=r.choice([0, 0, 1]), rplm=r.choice([0, 0, 1]), scaling=r.choice([0, 0, 1, 2, 3]),
+             wpp=r.choice([0, 0, 1]),
+             min_cb_log2=r.choice([3, 3, min(4, ctb)]), max_tb_log2=r.choice([5, 5, 4, 3]), depth_inter=r.randint(0, 3), depth_intra=r.randint(0, 3),
+             strong_intra=r.randint(0, 1),
+             merge_cand=r.randint(1, 5), cabac_init=r.choice([0, 1, 2]), par_mrg=r.choice([2, 2, 3, 4, 5]), intra_period=r.choice([4, 8, 32]),
+             cb_qp_off=r.choice([0, 0, -3, 5]),
              cr_qp_off=r.choice([0, 0, 4, -6]), rps_sps=r.randint(0, 1), open_gop=r.choice([0, 0, 1]))
     if r.random() < 0.25:
         a.update(tile_cols=r.randint(1, 3), tile_rows=r.randint(1, 3))
@@ -34,16 +40,21 @@ def hevc_params(r):
 def h264_params(r):
     cab = r.randint(0, 1)
     b = r.choice([0, 0, 1, 2, 3]) if cab or r.random() < 0.5 else 0
-    a = dict(width=r.choice([64, 96, 90, 176, 200, 320]), height=r.choice([48, 80, 70, 144, 240, 272, 400, 520]), frames=r.choice([2, 4, 7, 12]),      # > 256 rows: several deblocking bands
+    a = dict(width=r.choice([64, 96, 90, 176, 200, 320]), height=r.choice([48, 80, 70, 144, 240, 272, 400, 520]), frames=r.choice([2, 4, 7, 12]),
+        # > 256 rows: several deblocking bands
              qp=r.choice([18, 24, 28, 36, 44]), gop=r.choice([2, 4, 6, 30]),
-             seed=r.randrange(1 << 20), mode=r.choice([0, 1, 1]), deblock=r.choice([0, 1, 1, 2]), num_ref=r.randint(1, 4), slices=r.randint(1, 3), cabac=cab, cabac_idc=r.randint(0, 2),
-             t8x8=r.randint(0, 1), bframes=b, direct_temporal=r.randint(0, 1), wp=r.choice([0, 0, 1, 2]), dinf8=r.randint(0, 1), scaling=r.choice([0, 0, 1, 2]), rplm=r.choice([0, 0, 1]),
-             cip=r.choice([0, 0, 1]), chroma_qp_off=r.choice([0, 0, -4, 6]), alpha_off=r.choice([0, 0, 3, -3]), beta_off=r.choice([0, 0, -2, 2]), poc_type=r.choice([0, 2]),
-             nc_corner=r.choice([0, 0, 0, 1]), no_intra=r.choice([0, 1, 1]), search=r.choice([4, 4, 16, 48]))      # no_intra: pictures that can run in chain launches
+             seed=r.randrange(1 << 20), mode=r.choice([0, 1, 1]), deblock=r.choice([0, 1, 1, 2]), num_ref=r.randint(1, 4), slices=r.randint(1, 3), cabac=cab,
+             cabac_idc=r.randint(0, 2),
+             t8x8=r.randint(0, 1), bframes=b, direct_temporal=r.randint(0, 1), wp=r.choice([0, 0, 1, 2]), dinf8=r.randint(0, 1), scaling=r.choice([0, 0, 1,
+             2]), rplm=r.choice([0, 0, 1]),
+             cip=r.choice([0, 0, 1]), chroma_qp_off=r.choice([0, 0, -4, 6]), alpha_off=r.choice([0, 0, 3, -3]), beta_off=r.choice([0, 0, -2, 2]),
+             poc_type=r.choice([0, 2]),
+             nc_corner=r.choice([0, 0, 0, 1]), no_intra=r.choice([0, 1, 1]), search=r.choice([4, 4, 16,
+             48]))      # no_intra: pictures that can run in chain launches
     if not b and r.random() < 0.3:
         a["mmco"] = 1
     if (cab or b) and r.random() < 0.25 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
-        a.update(fmo0=1, dinf8=1)                                                                                  # interlace-capable stream, frame pictures only
+        a.update(fmo0=1, dinf8=1)                                                                           # interlace-capable stream, frame pictures only
     if r.random() < 0.4:
         a["frames"] = r.choice([9, 14, 20])                                                                        # long enough for deep chains
     return a

@@ -199,14 +199,18 @@ static const uint8_t rb_len[7][15] = {
  {1,1},{1,2,2},{2,2,2,2},{2,2,2,3,3},{2,2,3,3,3,3},{2,3,3,3,3,3,3},{3,3,3,3,3,3,3,4,5,6,7,8,9,10,11} };
 static const uint8_t rb_bits[7][15] = {
  {1,0},{1,1,0},{3,2,1,0},{3,2,1,1,0},{3,2,3,2,1,0},{3,0,1,3,2,5,4},{7,6,5,4,3,2,1,1,1,1,1,1,1,1,1} };
-static const uint8_t cbp_intra_tab[48] = { 47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
-static const uint8_t cbp_inter_tab[48] = { 0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
+static const uint8_t cbp_intra_tab[48] = {
+    47,31,15,0,23,27,29,30,7,11,13,14,39,43,45,46,16,3,5,10,12,19,21,26,28,35,37,42,44,1,2,4,8,17,18,20,24,6,9,22,25,32,33,34,36,40,38,41 };
+static const uint8_t cbp_inter_tab[48] = {
+    0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
 static const uint8_t zz4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
 static const uint8_t qpc_tab[22] = {29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39};
 static const int norm4[6][3] = { {10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23} };
 static const int quant_mf[6][3] = { {13107,5243,8066},{11916,4660,7490},{10082,4194,6554},{9362,3647,5825},{8192,3355,5243},{7282,2893,4559} };
-static const uint8_t alpha_tab[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
-static const uint8_t beta_tab[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
+static const uint8_t alpha_tab[52] = {
+    0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,32,36,40,45,50,56,63,71,80,90,101,113,127,144,162,182,203,226,255,255 };
+static const uint8_t beta_tab[52] = {
+    0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13,14,14,15,15,16,16,17,17,18,18 };
 static const uint8_t tc0_tab[52][3] = {
  {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
  {0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},
@@ -245,7 +249,7 @@ typedef struct {
     int slice_id, slice_type, qp_run;
     Frame *list0[5]; int nlist0;
     Frame *list1[5]; int nlist1; int cur_poc;
-    int *pocs;                            /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
+    int *pocs; /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
     int poc_base;                         /* display index at which the picture order count restarted (IDR picture, or a picture with operation 5) */
     int cur_top, delta_bottom, delta0;    /* TopFieldOrderCnt of the current picture; delta_pic_order_cnt_bottom / [1]; delta_pic_order_cnt[0] (type 1) */
     int t1_cycle, t1_ref[3], t1_nonref, t1_t2b;   /* pic_order_cnt_type 1: cycle of expected deltas, offset_for_non_ref_pic, offset_for_top_to_bottom_field */
@@ -278,7 +282,8 @@ static void frame_alloc(Frame *f, int W, int H, int hp) {
 static void frame_free(Frame *f) { free(f->by); free(f->bu); free(f->bv); free(f->bhb); free(f->bhh); free(f->bhj); }
 static void pad_plane(uint8_t *o, int stride, int w, int h, int pad) {
     for (int y = 0; y < h; y++) { memset(o + y * stride - pad, o[y * stride], pad); memset(o + y * stride + w, o[y * stride + w - 1], pad); }
-    for (int y = 1; y <= pad; y++) { memcpy(o - y * stride - pad, o - pad, w + 2 * pad); memcpy(o + (h - 1 + y) * stride - pad, o + (h - 1) * stride - pad, w + 2 * pad); }
+    for (int y = 1; y <= pad; y++) { memcpy(o - y * stride - pad, o - pad, w + 2 * pad);
+        memcpy(o + (h - 1 + y) * stride - pad, o + (h - 1) * stride - pad, w + 2 * pad); }
 }
 static inline int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 /* pad the reconstructed frame and build the three half-sample planes used by motion search */
@@ -411,7 +416,8 @@ static void mc_block(Enc *e, const Frame *r, int px, int py, int w, int h, int m
     static int check = -1; if (check < 0) check = getenv("H264GEN_CHECK") != NULL;
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
         int v = qpel_fast(r, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
-        if (check && v != luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3)) { fprintf(stderr, "h264gen: fast/literal MC mismatch\n"); abort(); }
+        if (check && v != luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3)) {
+            fprintf(stderr, "h264gen: fast/literal MC mismatch\n"); abort(); }
         c->y[(py + y) * c->sy + px + x] = (uint8_t)v;
     }
     int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
@@ -419,7 +425,8 @@ static void mc_block(Enc *e, const Frame *r, int px, int py, int w, int h, int m
         const uint8_t *rp = pl ? r->v : r->u; uint8_t *dp = pl ? c->v : c->u;
         for (int y = 0; y < h / 2; y++) for (int x = 0; x < w / 2; x++) {
             int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
-            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1), D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
+            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1),
+                D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
             dp[(py / 2 + y) * c->sc + px / 2 + x] = (uint8_t)(((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6);
         }
     }
@@ -447,8 +454,10 @@ static int med3(int a, int b, int c) { return a + b + c - MAX(a, MAX(b, c)) - MI
 static void pred_mv(Enc *e, int mx, int my, MbE *cur, int bx, int by, int bw, int ref, int shape, int part, int out[2]) {
     Nbr A = nbr_get(e, mx, my, cur, bx - 1, by), B = nbr_get(e, mx, my, cur, bx, by - 1), C = nbr_get(e, mx, my, cur, bx + bw, by - 1);
     if (!C.avail) C = nbr_get(e, mx, my, cur, bx - 1, by - 1);
-    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } }
-    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0]; out[1] = C.mv[1]; return; } }
+    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0];
+        out[1] = A.mv[1]; return; } }
+    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0];
+        out[1] = C.mv[1]; return; } }
     if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
     int ma = A.ref == ref, mb = B.ref == ref, mc = C.ref == ref;
     if (ma + mb + mc == 1) { Nbr *n = ma ? &A : (mb ? &B : &C); out[0] = n->mv[0]; out[1] = n->mv[1]; }
@@ -462,7 +471,8 @@ static void skip_mv(Enc *e, int mx, int my, MbE *cur, int out[2]) {
     pred_mv(e, mx, my, cur, 0, 0, 4, 0, 0, 0, out);
 }
 static void store_mv(Enc *e, MbE *m, int bx, int by, int bw, int bh, int mvx, int mvy) {
-    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mv[y * 4 + x][0] = (int16_t)mvx; m->mv[y * 4 + x][1] = (int16_t)mvy; e->decoded_mask |= 1 << (y * 4 + x); }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mv[y * 4 + x][0] = (int16_t)mvx; m->mv[y * 4 + x][1] = (int16_t)mvy;
+        e->decoded_mask |= 1 << (y * 4 + x); }
 }
 
 /* ------------------------------ intra prediction ---------------------------- */
@@ -475,7 +485,8 @@ static void i4_edges(Enc *e, int mx, int my, int blk, int *T, int *L, int *aA, i
     Frame *c = &e->cur; int bx = bX(blk), by = bY(blk);
     uint8_t *d = c->y + (my * 16 + by * 4) * c->sy + mx * 16 + bx * 4; int st = c->sy;
     int availA = bx > 0 || intra_ok(e, mb_avail(e, mx - 1, my)), availB = by > 0 || intra_ok(e, mb_avail(e, mx, my - 1));
-    int availD = (bx > 0 && by > 0) ? 1 : (bx > 0 ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by > 0 ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e, mb_avail(e, mx - 1, my - 1))));
+    int availD = (bx > 0 && by > 0) ? 1 : (bx > 0 ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by > 0 ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e,
+        mb_avail(e, mx - 1, my - 1))));
     int availC;
     if (by == 0) availC = intra_ok(e, bx < 3 ? mb_avail(e, mx, my - 1) : mb_avail(e, mx + 1, my - 1));
     else availC = !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
@@ -497,17 +508,26 @@ static void i4_predict(int mode, const int *T, const int *L, int aA, int aB, int
     switch (mode) {
     case 0: for (int k = 0; k < 16; k++) p[k] = T[k & 3]; break;
     case 1: for (int k = 0; k < 16; k++) p[k] = L[k >> 2]; break;
-    case 2: { int dc = aA && aB ? (T[0] + T[1] + T[2] + T[3] + L[0] + L[1] + L[2] + L[3] + 4) >> 3 : aA ? (L[0] + L[1] + L[2] + L[3] + 2) >> 2 : aB ? (T[0] + T[1] + T[2] + T[3] + 2) >> 2 : 128;
+    case 2: { int dc = aA && aB ? (T[0] + T[1] + T[2] + T[3] + L[0] + L[1] + L[2] + L[3] + 4) >> 3 : aA ? (L[0] + L[1] + L[2] + L[3] + 2) >> 2 : aB ?
+        (T[0] + T[1] + T[2] + T[3] + 2) >> 2 : 128;
         for (int k = 0; k < 16; k++) p[k] = dc; break; }
-    case 3: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = (x == 3 && y == 3) ? (T[6] + 3 * T[7] + 2) >> 2 : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2; break;
-    case 4: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ? (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 : (T[0] + 2 * T[-1] + L[0] + 2) >> 2; break;
+    case 3: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = (x == 3 &&
+        y == 3) ? (T[6] + 3 * T[7] + 2) >> 2 : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2;
+    break;
+    case 4: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) p[y * 4 + x] = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ?
+        (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 : (T[0] + 2 * T[-1] + L[0] + 2) >> 2;
+    break;
     case 5: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = 2 * x - y, i = x - (y >> 1);
-            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (L[y - 1] + 2 * L[y - 2] + L[y - 3] + 2) >> 2; } break;
+            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ?
+                (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (L[y - 1] + 2 * L[y - 2] + L[y - 3] + 2) >> 2; } break;
     case 6: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = 2 * y - x, i = y - (x >> 1);
-            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (T[x - 1] + 2 * T[x - 2] + T[x - 3] + 2) >> 2; } break;
-    case 7: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int i = x + (y >> 1); p[y * 4 + x] = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1; } break;
+            p[y * 4 + x] = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ?
+                (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (T[x - 1] + 2 * T[x - 2] + T[x - 3] + 2) >> 2; } break;
+    case 7: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int i = x + (y >> 1);
+        p[y * 4 + x] = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1; } break;
     default: for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { int z = x + 2 * y, i = y + (x >> 1);
-            p[y * 4 + x] = z > 5 ? L[3] : z == 5 ? (L[2] + 3 * L[3] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 : (L[i] + L[i + 1] + 1) >> 1; } break;
+            p[y * 4 + x] = z > 5 ? L[3] : z == 5 ? (L[2] + 3 * L[3] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 :
+                (L[i] + L[i + 1] + 1) >> 1; } break;
     }
 }
 /* n x n block prediction for Intra16x16 (n=16, modes V,H,DC,Plane) and chroma (n=8, modes DC,H,V,Plane mapped by caller) */
@@ -516,7 +536,8 @@ static void big_predict(const uint8_t *d, int st, int n, int kind /*0 V 1 H 2 DC
     else if (kind == 1) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) p[y * n + x] = d[y * st - 1]; }
     else if (kind == 3) {
         int Hh = 0, V = 0, h2 = n / 2;
-        for (int k = 0; k < h2; k++) { Hh += (k + 1) * (d[-st + h2 + k] - d[-st + h2 - 2 - k]); V += (k + 1) * (d[(h2 + k) * st - 1] - d[(h2 - 2 - k) * st - 1]); }
+        for (int k = 0; k < h2; k++) { Hh += (k + 1) * (d[-st + h2 + k] - d[-st + h2 - 2 - k]);
+            V += (k + 1) * (d[(h2 + k) * st - 1] - d[(h2 - 2 - k) * st - 1]); }
         int a = 16 * (d[(n - 1) * st - 1] + d[-st + n - 1]);
         int b = n == 16 ? (5 * Hh + 32) >> 6 : (34 * Hh + 32) >> 6, c = n == 16 ? (5 * V + 32) >> 6 : (34 * V + 32) >> 6;
         for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) p[y * n + x] = CLIP1((a + b * (x - (h2 - 1)) + c * (y - (h2 - 1)) + 16) >> 5);
@@ -551,11 +572,13 @@ static void idct4_add(const int *dq, uint8_t *dst, int st) {
         f[4 * i] = e0 + e3; f[4 * i + 1] = e1 + e2; f[4 * i + 2] = e1 - e2; f[4 * i + 3] = e0 - e3; }
     for (int j = 0; j < 4; j++) { int g0 = f[j] + f[8 + j], g1 = f[j] - f[8 + j], g2 = (f[4 + j] >> 1) - f[12 + j], g3 = f[4 + j] + (f[12 + j] >> 1);
         int r0 = (g0 + g3 + 32) >> 6, r1 = (g1 + g2 + 32) >> 6, r2 = (g1 - g2 + 32) >> 6, r3 = (g0 - g3 + 32) >> 6;
-        dst[j] = (uint8_t)CLIP1(dst[j] + r0); dst[st + j] = (uint8_t)CLIP1(dst[st + j] + r1); dst[2 * st + j] = (uint8_t)CLIP1(dst[2 * st + j] + r2); dst[3 * st + j] = (uint8_t)CLIP1(dst[3 * st + j] + r3); }
+        dst[j] = (uint8_t)CLIP1(dst[j] + r0); dst[st + j] = (uint8_t)CLIP1(dst[st + j] + r1); dst[2 * st + j] = (uint8_t)CLIP1(dst[2 * st + j] + r2);
+            dst[3 * st + j] = (uint8_t)CLIP1(dst[3 * st + j] + r3); }
 }
 /* scaling matrices in effect (8.5.9), raster order: 4x4 lists Intra Y/Cb/Cr, Inter Y/Cb/Cr; 8x8 lists Intra Y, Inter Y */
 static __thread int g_w4[6][16], g_w8[2][64], g_wlist;          /* g_wlist: list used by the block being coded */
-static inline int dequant_ac(int c, int qp, int k) { int ls = g_w4[g_wlist][k] * norm4[qp % 6][pos_class(k)]; return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
+static inline int dequant_ac(int c, int qp, int k) { int ls = g_w4[g_wlist][k] * norm4[qp % 6][pos_class(k)];
+    return qp >= 24 ? (c * ls) << (qp / 6 - 4) : (c * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6); }
 
 /* ------------------------------ CAVLC writer -------------------------------- */
 static void put_level_code(BitW *w, int code, int sl) {
@@ -644,7 +667,8 @@ static int code_luma4(Enc *e, int px, int py, int qp, int intra, int *levels /*r
 
 /* chroma residual for one plane; pred in cur. fills cdc/cac; returns flags: bit0 dc nonzero, bit1 ac nonzero */
 static int code_chroma(Enc *e, int mx, int my, int pl, int qpc, int intra, MbCode *mc) {
-    Frame *c = &e->cur, *s = &e->src; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8; const uint8_t *sp = (pl ? s->v : s->u) + my * 8 * s->sc + mx * 8;
+    Frame *c = &e->cur, *s = &e->src; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
+    const uint8_t *sp = (pl ? s->v : s->u) + my * 8 * s->sc + mx * 8;
     int w[4][16], dcs[4], flags = 0;
     int shift = 15 + qpc / 6, f = (1 << shift) / (intra ? 3 : 6);
     for (int k = 0; k < 4; k++) {
@@ -652,10 +676,12 @@ static int code_chroma(Enc *e, int mx, int my, int pl, int qpc, int intra, MbCod
         for (int i = 0; i < 16; i++) x[i] = sp[(oy + (i >> 2)) * s->sc + ox + (i & 3)] - cp[(oy + (i >> 2)) * c->sc + ox + (i & 3)];
         fdct4(x, w[k]); dcs[k] = w[k][0];
         mc->cac[pl][k][0] = 0;
-        for (int i = 1; i < 16; i++) { mc->cac[pl][k][i] = quant1(w[k][i], quant_mf[qpc % 6][pos_class(i)] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][i], f, shift); if (mc->cac[pl][k][i]) flags |= 2; }
+        for (int i = 1; i < 16; i++) { mc->cac[pl][k][i] = quant1(w[k][i], quant_mf[qpc % 6][pos_class(i)] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][i], f, shift);
+            if (mc->cac[pl][k][i]) flags |= 2; }
     }
     int h[4] = { dcs[0] + dcs[1] + dcs[2] + dcs[3], dcs[0] - dcs[1] + dcs[2] - dcs[3], dcs[0] + dcs[1] - dcs[2] - dcs[3], dcs[0] - dcs[1] - dcs[2] + dcs[3] };
-    for (int k = 0; k < 4; k++) { mc->cdc[pl][k] = quant1(h[k], quant_mf[qpc % 6][0] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][0], 2 * f, shift + 1); if (mc->cdc[pl][k]) flags |= 1; }
+    for (int k = 0; k < 4; k++) { mc->cdc[pl][k] = quant1(h[k], quant_mf[qpc % 6][0] * 16 / g_w4[(intra ? 0 : 3) + 1 + pl][0], 2 * f, shift + 1);
+        if (mc->cdc[pl][k]) flags |= 1; }
     return flags;
 }
 static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *mc, int use_dc, int use_ac) {
@@ -697,9 +723,11 @@ static void db_luma(uint8_t *q, int s, int bS, int a, int b, int ia) {
     int ap = ABS(p2 - p0) < b, aq = ABS(q2 - q0) < b;
     if (bS == 4) {
         int small = ABS(p0 - q0) < (a >> 2) + 2;
-        if (ap && small) { int p3 = q[-4 * s]; q[-s] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3); q[-2 * s] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2); q[-3 * s] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
+        if (ap && small) { int p3 = q[-4 * s]; q[-s] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            q[-2 * s] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2); q[-3 * s] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
         else q[-s] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
-        if (aq && small) { int q3 = q[3 * s]; q[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3); q[s] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2); q[2 * s] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3); }
+        if (aq && small) { int q3 = q[3 * s]; q[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3); q[s] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+            q[2 * s] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3); }
         else q[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
     } else {
         int t0 = tc0_tab[ia][bS - 1], tc = t0 + ap + aq;
@@ -713,7 +741,8 @@ static void db_chroma(uint8_t *q, int s, int bS, int a, int b, int ia) {
     int p0 = q[-s], p1 = q[-2 * s], q0 = q[0], q1 = q[s];
     if (ABS(p0 - q0) >= a || ABS(p1 - p0) >= b || ABS(q1 - q0) >= b) return;
     if (bS == 4) { q[-s] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2); q[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2); }
-    else { int tc = tc0_tab[ia][bS - 1] + 1, dl = CLIP3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3); q[-s] = (uint8_t)CLIP1(p0 + dl); q[0] = (uint8_t)CLIP1(q0 - dl); }
+    else { int tc = tc0_tab[ia][bS - 1] + 1, dl = CLIP3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3); q[-s] = (uint8_t)CLIP1(p0 + dl);
+        q[0] = (uint8_t)CLIP1(q0 - dl); }
 }
 static void deblock_frame(Enc *e) {
     Frame *c = &e->cur;
@@ -723,9 +752,11 @@ static void deblock_frame(Enc *e) {
         for (int dir = 0; dir < 2; dir++) for (int ed = 0; ed < 4; ed++) {
             const MbE *p = q;
             if ((ed & 1) && q->t8) continue;                /* 8x8 transform: only 8x8 block edges are filtered */
-            if (ed == 0) { int nx = mx - !dir, ny = my - dir; if (nx < 0 || ny < 0) continue; p = &e->mbs[ny * e->mbw + nx]; if (q->dis_db == 2 && p->slice != q->slice) continue; }
+            if (ed == 0) { int nx = mx - !dir, ny = my - dir; if (nx < 0 || ny < 0) continue; p = &e->mbs[ny * e->mbw + nx];
+                if (q->dis_db == 2 && p->slice != q->slice) continue; }
             int bs[4], any = 0;
-            for (int k = 0; k < 4; k++) { int bq = dir ? ed * 4 + k : k * 4 + ed; int bp = ed ? (dir ? bq - 4 : bq - 1) : (dir ? 12 + k : k * 4 + 3); bs[k] = edge_bs(p, bp, q, bq, ed == 0); any |= bs[k]; }
+            for (int k = 0; k < 4; k++) { int bq = dir ? ed * 4 + k : k * 4 + ed; int bp = ed ? (dir ? bq - 4 : bq - 1) : (dir ? 12 + k : k * 4 + 3);
+                bs[k] = edge_bs(p, bp, q, bq, ed == 0); any |= bs[k]; }
             if (!any) continue;
             int qa = (p->qp + q->qp + 1) >> 1, ia = CLIP3(0, 51, qa + q->a_off), ib = CLIP3(0, 51, qa + q->b_off);
             for (int i = 0; i < 16; i++) if (bs[i >> 2]) {
@@ -774,7 +805,8 @@ static void inv8_1d(const int *in, int *out) {
 }
 static void recon8(const int *lev /*raster*/, int qp, int list, uint8_t *dst, int st) {
     int d[64], g[64], col[8], o[8];
-    for (int k = 0; k < 64; k++) { int ls = g_w8[list][k] * norm8[qp % 6][cls8(k >> 3, k & 7)]; d[k] = qp >= 36 ? (lev[k] * ls) << (qp / 6 - 6) : (lev[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6); }
+    for (int k = 0; k < 64; k++) { int ls = g_w8[list][k] * norm8[qp % 6][cls8(k >> 3, k & 7)];
+        d[k] = qp >= 36 ? (lev[k] * ls) << (qp / 6 - 6) : (lev[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6); }
     for (int i = 0; i < 8; i++) inv8_1d(d + 8 * i, g + 8 * i);
     for (int j = 0; j < 8; j++) {
         for (int i = 0; i < 8; i++) col[i] = g[8 * i + j];
@@ -799,7 +831,8 @@ static float *basis8(int qp, int list) {
                 for (int i = 0; i < 8; i++) in[i] = pass ? src[8 * i + r] : src[8 * r + i];
                 a[0] = in[0] + in[4]; a[1] = -in[3] + in[5] - in[7] - in[7] / 2; a[2] = in[0] - in[4]; a[3] = in[1] + in[7] - in[3] - in[3] / 2;
                 a[4] = in[2] / 2 - in[6]; a[5] = -in[1] + in[7] + in[5] + in[5] / 2; a[6] = in[2] + in[6] / 2; a[7] = in[3] + in[5] + in[1] + in[1] / 2;
-                b[0] = a[0] + a[6]; b[1] = a[1] + a[7] / 4; b[2] = a[2] + a[4]; b[3] = a[3] + a[5] / 4; b[4] = a[2] - a[4]; b[5] = a[3] / 4 - a[5]; b[6] = a[0] - a[6]; b[7] = a[7] - a[1] / 4;
+                b[0] = a[0] + a[6]; b[1] = a[1] + a[7] / 4; b[2] = a[2] + a[4]; b[3] = a[3] + a[5] / 4; b[4] = a[2] - a[4]; b[5] = a[3] / 4 - a[5];
+                b[6] = a[0] - a[6]; b[7] = a[7] - a[1] / 4;
                 double o[8] = { b[0] + b[7], b[2] + b[5], b[4] + b[3], b[6] + b[1], b[6] - b[1], b[4] - b[3], b[2] - b[5], b[0] - b[7] };
                 for (int i = 0; i < 8; i++) { if (pass) d[8 * i + r] = o[i]; else g[8 * r + i] = o[i]; }
             }
@@ -831,7 +864,8 @@ static void i8_edges(Enc *e, int mx, int my, int b8, int *T /*[-1..15]*/, int *L
     Frame *c = &e->cur; int bx = b8 & 1, by = b8 >> 1;
     uint8_t *d = c->y + (my * 16 + by * 8) * c->sy + mx * 16 + bx * 8; int st = c->sy;
     int availA = bx || intra_ok(e, mb_avail(e, mx - 1, my)), availB = by || intra_ok(e, mb_avail(e, mx, my - 1));
-    int availD = (bx && by) ? 1 : (bx ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e, mb_avail(e, mx - 1, my - 1))));
+    int availD = (bx && by) ? 1 : (bx ? intra_ok(e, mb_avail(e, mx, my - 1)) : (by ? intra_ok(e, mb_avail(e, mx - 1, my)) : intra_ok(e, mb_avail(e, mx - 1,
+        my - 1))));
     int availC = b8 == 0 ? intra_ok(e, mb_avail(e, mx, my - 1)) : (b8 == 1 ? intra_ok(e, mb_avail(e, mx + 1, my - 1)) : b8 == 2);
     int rt[17], rl[9], *t = rt + 1, *l = rl + 1;
     for (int i = 0; i < 16; i++) t[i] = availB ? d[-st + ((i >= 8 && !availC) ? 7 : i)] : 128;
@@ -863,15 +897,20 @@ static void i8_predict(int mode, const int *T, const int *L, int aA, int aB, int
         int v;
         if (mode == 0) v = T[x];
         else if (mode == 1) v = L[y];
-        else if (mode == 2) { int s1 = 0, s2 = 0; for (int i = 0; i < 8; i++) { s1 += T[i]; s2 += L[i]; } v = aA && aB ? (s1 + s2 + 8) >> 4 : aA ? (s2 + 4) >> 3 : aB ? (s1 + 4) >> 3 : 128; }
+        else if (mode == 2) { int s1 = 0, s2 = 0; for (int i = 0; i < 8; i++) { s1 += T[i]; s2 += L[i]; }
+            v = aA && aB ? (s1 + s2 + 8) >> 4 : aA ? (s2 + 4) >> 3 : aB ? (s1 + 4) >> 3 : 128; }
         else if (mode == 3) v = (x == 7 && y == 7) ? (T[14] + 3 * T[15] + 2) >> 2 : (T[x + y] + 2 * T[x + y + 1] + T[x + y + 2] + 2) >> 2;
-        else if (mode == 4) v = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ? (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 : (T[0] + 2 * T[-1] + L[0] + 2) >> 2;
+        else if (mode == 4) v = x > y ? (T[x - y - 2] + 2 * T[x - y - 1] + T[x - y] + 2) >> 2 : x < y ? (L[y - x - 2] + 2 * L[y - x - 1] + L[y - x] + 2) >> 2 :
+            (T[0] + 2 * T[-1] + L[0] + 2) >> 2;
         else if (mode == 5) { int z = 2 * x - y, i = x - (y >> 1);
-            v = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (L[y - 2 * x - 1] + 2 * L[y - 2 * x - 2] + L[y - 2 * x - 3] + 2) >> 2; }
+            v = z >= 0 ? ((z & 1) ? (T[i - 2] + 2 * T[i - 1] + T[i] + 2) >> 2 : (T[i - 1] + T[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 :
+                (L[y - 2 * x - 1] + 2 * L[y - 2 * x - 2] + L[y - 2 * x - 3] + 2) >> 2; }
         else if (mode == 6) { int z = 2 * y - x, i = y - (x >> 1);
-            v = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 : (T[x - 2 * y - 1] + 2 * T[x - 2 * y - 2] + T[x - 2 * y - 3] + 2) >> 2; }
+            v = z >= 0 ? ((z & 1) ? (L[i - 2] + 2 * L[i - 1] + L[i] + 2) >> 2 : (L[i - 1] + L[i] + 1) >> 1) : z == -1 ? (L[0] + 2 * T[-1] + T[0] + 2) >> 2 :
+                (T[x - 2 * y - 1] + 2 * T[x - 2 * y - 2] + T[x - 2 * y - 3] + 2) >> 2; }
         else if (mode == 7) { int i = x + (y >> 1); v = (y & 1) ? (T[i] + 2 * T[i + 1] + T[i + 2] + 2) >> 2 : (T[i] + T[i + 1] + 1) >> 1; }
-        else { int z = x + 2 * y, i = y + (x >> 1); v = z > 13 ? L[7] : z == 13 ? (L[6] + 3 * L[7] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 : (L[i] + L[i + 1] + 1) >> 1; }
+        else { int z = x + 2 * y, i = y + (x >> 1);
+            v = z > 13 ? L[7] : z == 13 ? (L[6] + 3 * L[7] + 2) >> 2 : (z & 1) ? (L[i] + 2 * L[i + 1] + L[i + 2] + 2) >> 2 : (L[i] + L[i + 1] + 1) >> 1; }
         p[y * 8 + x] = v;
     }
 }
@@ -933,7 +972,8 @@ static void se_sub_mb_type(Enc *e, int st) {
 static void se_ref_idx(Enc *e, int mx, int my, MbE *m, int bx, int by, int nref, int v) {
     if (!e->cabac) { bw_te(&e->bw, nref - 1, v); return; }
     int inc = 0;
-    for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r); if (n && !n->intra && n->ref[(r >> 3) * 2 + ((r & 3) >> 1)] > 0) inc += k == 0 ? 1 : 2; }
+    for (int k = 0; k < 2; k++) { int r; MbE *n = nb4(e, mx, my, m, bx, by, k == 0, &r);
+        if (n && !n->intra && n->ref[(r >> 3) * 2 + ((r & 3) >> 1)] > 0) inc += k == 0 ? 1 : 2; }
     int ctx = 54 + inc;
     for (int i = 0; i < v; i++) { cab_enc(&e->cab, ctx, 1); ctx = 54 + (i == 0 ? 4 : 5); }
     cab_enc(&e->cab, ctx, 0);
@@ -951,7 +991,8 @@ static void se_mvd(Enc *e, int mx, int my, MbE *m, int bx, int by, int bw, int b
         if (a >= 9) cab_ueg(c, a - 9, 3);
         cab_byp(c, d < 0);
     }
-    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mvd[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255); m->mvd[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { m->mvd[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255);
+        m->mvd[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
 }
 static void se_t8_flag(Enc *e, int mx, int my, int v) {
     if (!e->cabac) { bw_put(&e->bw, 1, (uint32_t)v); return; }
@@ -959,7 +1000,8 @@ static void se_t8_flag(Enc *e, int mx, int my, int v) {
     cab_enc(&e->cab, 399 + (a && a->t8) + (b && b->t8), v);
 }
 static void se_intra_mode(Enc *e, int pred, int mode) {
-    if (!e->cabac) { if (mode == pred) bw_put(&e->bw, 1, 1); else { bw_put(&e->bw, 1, 0); bw_put(&e->bw, 3, (uint32_t)(mode < pred ? mode : mode - 1)); } return; }
+    if (!e->cabac) { if (mode == pred) bw_put(&e->bw, 1, 1); else { bw_put(&e->bw, 1, 0); bw_put(&e->bw, 3, (uint32_t)(mode < pred ? mode : mode - 1)); }
+        return; }
     CabEnc *c = &e->cab;
     cab_enc(c, 68, mode == pred);
     if (mode != pred) { int rem = mode < pred ? mode : mode - 1; cab_enc(c, 69, rem & 1); cab_enc(c, 69, (rem >> 1) & 1); cab_enc(c, 69, rem >> 2); }
@@ -971,7 +1013,8 @@ static void se_chroma_mode(Enc *e, int mx, int my, int cm) {
     if (cm > 0) { cab_enc(c, 67, cm > 1); if (cm > 1) cab_enc(c, 67, cm > 2); }
 }
 static void se_cbp(Enc *e, int mx, int my, int cbp, int intra) {
-    if (!e->cabac) { const uint8_t *tab = intra ? cbp_intra_tab : cbp_inter_tab; int code = 0; for (int i = 0; i < 48; i++) if (tab[i] == cbp) code = i; bw_ue(&e->bw, code); return; }
+    if (!e->cabac) { const uint8_t *tab = intra ? cbp_intra_tab : cbp_inter_tab; int code = 0; for (int i = 0; i < 48; i++) if (tab[i] == cbp) code = i;
+        bw_ue(&e->bw, code); return; }
     MbE *a = mb_avail(e, mx - 1, my), *b = mb_avail(e, mx, my - 1); CabEnc *c = &e->cab;
     for (int b8 = 0; b8 < 4; b8++) {
         int ca = (b8 & 1) ? !((cbp >> (b8 - 1)) & 1) : (a ? !((a->cbp >> (b8 + 1)) & 1) : 0);
@@ -1050,9 +1093,12 @@ static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) 
         for (int k = 0; k < 4; k++) {
             int blk = b8 * 4 + k, bx = bX(blk), by = bY(blk), r = by * 4 + bx, n, fa = -1, fb = -1;
             if (!(mc->cbp & (1 << b8))) { m->tc[r] = 0; continue; }
-            if (e->cabac) { int q; MbE *nn = nb4(e, mx, my, m, bx, by, 1, &q); if (nn) fa = (int)((nn->cbf >> q) & 1); nn = nb4(e, mx, my, m, bx, by, 0, &q); if (nn) fb = (int)((nn->cbf >> q) & 1); }
-            if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]]; n = e->cabac ? cab_block(e, m, 1, r, fa, fb, sc, 15) : write_block(w, sc, 15, nC_luma(e, mx, my, m, bx, by)); }
-            else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; n = e->cabac ? cab_block(e, m, 2, r, fa, fb, sc, 16) : write_block(w, sc, 16, nC_luma(e, mx, my, m, bx, by)); }
+            if (e->cabac) { int q; MbE *nn = nb4(e, mx, my, m, bx, by, 1, &q); if (nn) fa = (int)((nn->cbf >> q) & 1); nn = nb4(e, mx, my, m, bx, by, 0, &q);
+                if (nn) fb = (int)((nn->cbf >> q) & 1); }
+            if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]];
+                n = e->cabac ? cab_block(e, m, 1, r, fa, fb, sc, 15) : write_block(w, sc, 15, nC_luma(e, mx, my, m, bx, by)); }
+            else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; n = e->cabac ? cab_block(e, m, 2, r, fa, fb, sc, 16) : write_block(w, sc, 16,
+                nC_luma(e, mx, my, m, bx, by)); }
             m->tc[r] = (uint8_t)n;
             if (n) m->nzmask |= (uint16_t)(1u << r);
         }
@@ -1100,9 +1146,11 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
         m->pcm = 1; m->qp = 0; m->qpc[0] = m->qpc[1] = (uint8_t)chroma_qp_of(e, 0);
         se_mb_type_intra(e, mx, my, 25);                      /* CABAC: the terminate bin flushes the arithmetic code (9.3.4.5) */
         while (w->nbits) bw_put(w, 1, 0);
-        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) { int v = s->y[(my * 16 + y) * s->sy + mx * 16 + x]; dy[y * c->sy + x] = (uint8_t)v; bw_put(w, 8, v); }
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) { int v = s->y[(my * 16 + y) * s->sy + mx * 16 + x]; dy[y * c->sy + x] = (uint8_t)v;
+            bw_put(w, 8, v); }
         for (int pl = 0; pl < 2; pl++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
-            int v = (pl ? s->v : s->u)[(my * 8 + y) * s->sc + mx * 8 + x]; (pl ? c->v : c->u)[(my * 8 + y) * c->sc + mx * 8 + x] = (uint8_t)v; bw_put(w, 8, v); }
+            int v = (pl ? s->v : s->u)[(my * 8 + y) * s->sc + mx * 8 + x]; (pl ? c->v : c->u)[(my * 8 + y) * c->sc + mx * 8 + x] = (uint8_t)v; bw_put(w, 8, v);
+                }
         memset(m->tc, 16, 24);
         m->cbp = 0x2f; m->cbf = 0x7FFFFFF; e->last_dqp = 0;
         if (e->cabac) cab_start(&e->cab, w);
@@ -1118,7 +1166,8 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
     int best16 = -1, best16sad = 1 << 30, p16[256];
     { int cand[4], nc = 0; cand[nc++] = 2; if (aB) cand[nc++] = 0; if (aA) cand[nc++] = 1; if (aA && aB && aD) cand[nc++] = 3;
       if (fuzz) { best16 = cand[rnd_n(&e->rng, nc)]; }
-      else for (int i = 0; i < nc; i++) { big_predict(dy, c->sy, 16, cand[i], aA, aB, p16); int sd = sad16_pred(e, mx, my, p16); if (sd < best16sad) { best16sad = sd; best16 = cand[i]; } } }
+      else for (int i = 0; i < nc; i++) { big_predict(dy, c->sy, 16, cand[i], aA, aB, p16); int sd = sad16_pred(e, mx, my, p16); if (sd < best16sad) {
+          best16sad = sd; best16 = cand[i]; } } }
     /* ---- decide I4x4 vs I16x16 ---- */
     int use_i4;
     if (force == 5) use_i4 = 1; else if (force == 6) use_i4 = 0;
@@ -1186,19 +1235,24 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
             int x[16]; int px = mx * 16 + (r & 3) * 4, py = my * 16 + (r >> 2) * 4;
             for (int k = 0; k < 16; k++) x[k] = s->y[(py + (k >> 2)) * s->sy + px + (k & 3)] - c->y[(py + (k >> 2)) * c->sy + px + (k & 3)];
             fdct4(x, wblk[r]); dcw[r] = wblk[r][0]; mc.luma[r][0] = 0;
-            for (int k = 1; k < 16; k++) { mc.luma[r][k] = quant1(wblk[r][k], quant_mf[qp % 6][pos_class(k)] * 16 / g_w4[0][k], f, shift); any_ac |= mc.luma[r][k] != 0; }
+            for (int k = 1; k < 16; k++) { mc.luma[r][k] = quant1(wblk[r][k], quant_mf[qp % 6][pos_class(k)] * 16 / g_w4[0][k], f, shift);
+                any_ac |= mc.luma[r][k] != 0; }
         }
         /* forward 4x4 Hadamard of the DCs, /2, quantise */
         int t[16], h[16];
-        for (int i = 0; i < 4; i++) { int *r = dcw + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
-        for (int j = 0; j < 4; j++) { h[j] = (t[j] + t[4 + j] + t[8 + j] + t[12 + j]) >> 1; h[4 + j] = (t[j] + t[4 + j] - t[8 + j] - t[12 + j]) >> 1; h[8 + j] = (t[j] - t[4 + j] - t[8 + j] + t[12 + j]) >> 1; h[12 + j] = (t[j] - t[4 + j] + t[8 + j] - t[12 + j]) >> 1; }
+        for (int i = 0; i < 4; i++) { int *r = dcw + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3];
+            t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
+        for (int j = 0; j < 4; j++) { h[j] = (t[j] + t[4 + j] + t[8 + j] + t[12 + j]) >> 1; h[4 + j] = (t[j] + t[4 + j] - t[8 + j] - t[12 + j]) >> 1;
+            h[8 + j] = (t[j] - t[4 + j] - t[8 + j] + t[12 + j]) >> 1; h[12 + j] = (t[j] - t[4 + j] + t[8 + j] - t[12 + j]) >> 1; }
         for (int k = 0; k < 16; k++) mc.dc16[k] = quant1(h[k], quant_mf[qp % 6][0] * 16 / g_w4[0][0], 2 * f, shift + 1);
         if (!any_ac) for (int r = 0; r < 16; r++) for (int k = 1; k < 16; k++) mc.luma[r][k] = 0;
         cbp_l = any_ac ? 15 : 0;
         /* reconstruct: inverse Hadamard + scaling of DCs (8.5.10) */
         int g[16]; const int *cq = mc.dc16;
-        for (int i = 0; i < 4; i++) { const int *r = cq + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3]; t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
-        for (int j = 0; j < 4; j++) { g[j] = t[j] + t[4 + j] + t[8 + j] + t[12 + j]; g[4 + j] = t[j] + t[4 + j] - t[8 + j] - t[12 + j]; g[8 + j] = t[j] - t[4 + j] - t[8 + j] + t[12 + j]; g[12 + j] = t[j] - t[4 + j] + t[8 + j] - t[12 + j]; }
+        for (int i = 0; i < 4; i++) { const int *r = cq + 4 * i; t[4 * i] = r[0] + r[1] + r[2] + r[3]; t[4 * i + 1] = r[0] + r[1] - r[2] - r[3];
+            t[4 * i + 2] = r[0] - r[1] - r[2] + r[3]; t[4 * i + 3] = r[0] - r[1] + r[2] - r[3]; }
+        for (int j = 0; j < 4; j++) { g[j] = t[j] + t[4 + j] + t[8 + j] + t[12 + j]; g[4 + j] = t[j] + t[4 + j] - t[8 + j] - t[12 + j];
+            g[8 + j] = t[j] - t[4 + j] - t[8 + j] + t[12 + j]; g[12 + j] = t[j] - t[4 + j] + t[8 + j] - t[12 + j]; }
         int ls0 = g_w4[0][0] * norm4[qp % 6][0]; g_wlist = 0;
         for (int r = 0; r < 16; r++) {
             int dq[16];
@@ -1212,10 +1266,12 @@ static void encode_intra_mb(Enc *e, int mx, int my, MbE *m, int force /*-1 auto,
     if (fuzz) cmode = cand[rnd_n(&e->rng, nc)];
     else { int bests = 1 << 30; for (int i = 0; i < nc; i++) { int sd = 0, pu[64], pv[64], kind = cand[i] == 0 ? 2 : cand[i] == 1 ? 1 : cand[i] == 2 ? 0 : 3;
             big_predict(c->u + my * 8 * c->sc + mx * 8, c->sc, 8, kind, aA, aB, pu); big_predict(c->v + my * 8 * c->sc + mx * 8, c->sc, 8, kind, aA, aB, pv);
-            for (int k = 0; k < 64; k++) sd += ABS(s->u[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pu[k]) + ABS(s->v[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pv[k]);
+            for (int k = 0; k < 64; k++) sd +=
+                ABS(s->u[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pu[k]) + ABS(s->v[(my * 8 + (k >> 3)) * s->sc + mx * 8 + (k & 7)] - pv[k]);
             if (sd < bests) { bests = sd; cmode = cand[i]; } } }
     int qpc = chroma_qp_of(e, qp), cflags = 0;
-    for (int pl = 0; pl < 2; pl++) { int pc[64], kind = cmode == 0 ? 2 : cmode == 1 ? 1 : cmode == 2 ? 0 : 3; uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
+    for (int pl = 0; pl < 2; pl++) { int pc[64], kind = cmode == 0 ? 2 : cmode == 1 ? 1 : cmode == 2 ? 0 : 3;
+        uint8_t *cp = (pl ? c->v : c->u) + my * 8 * c->sc + mx * 8;
         big_predict(cp, c->sc, 8, kind, aA, aB, pc); for (int k = 0; k < 64; k++) cp[(k >> 3) * c->sc + (k & 7)] = (uint8_t)pc[k]; }
     for (int pl = 0; pl < 2; pl++) cflags |= code_chroma(e, mx, my, pl, qpc, 1, &mc);
     int cbp_c = (cflags & 2) ? 2 : (cflags & 1) ? 1 : 0;
@@ -1244,21 +1300,27 @@ static MvRes search_block(Enc *e, const Frame *r, int px, int py, int w, int h, 
     }
     int cands[3][2] = { { mvp[0] & ~3, mvp[1] & ~3 }, { 0, 0 }, { cx & ~3, cy & ~3 } };
     for (int i = 0; i < 3; i++) { int mx = cands[i][0], my = cands[i][1]; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
-        int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; } }
+        int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx;
+            best.mvy = my; best.cost = c; } }
     if (best.cost == 1 << 30) { best.mvx = best.mvy = 0; best.cost = sad_inter(e, r, px, py, w, h, 0, 0); }
-    best.mvx &= ~3; best.mvy &= ~3; best.cost = sad_inter(e, r, px, py, w, h, best.mvx, best.mvy) + lambda * (mv_bits(best.mvx - mvp[0]) + mv_bits(best.mvy - mvp[1]));
-    { int c = sad_inter(e, r, px, py, w, h, mvp[0], mvp[1]); if (mv_legal(e, px, py, w, h, mvp[0], mvp[1]) && c <= best.cost) { MvRes q = { mvp[0], mvp[1], c }; qbest = q; have_q = 1; } }
+    best.mvx &= ~3; best.mvy &= ~3;
+    best.cost = sad_inter(e, r, px, py, w, h, best.mvx, best.mvy) + lambda * (mv_bits(best.mvx - mvp[0]) + mv_bits(best.mvy - mvp[1]));
+    { int c = sad_inter(e, r, px, py, w, h, mvp[0], mvp[1]); if (mv_legal(e, px, py, w, h, mvp[0], mvp[1]) && c <= best.cost) { MvRes q = {
+        mvp[0], mvp[1], c }; qbest = q; have_q = 1; } }
     for (int step = range; step >= 1; step >>= 1) {          /* integer: shrinking-step pattern search */
         int improved = 1;
         while (improved) { improved = 0; int bx = best.mvx, by = best.mvy;
             static const int dx[8] = { -1, 1, 0, 0, -1, 1, -1, 1 }, dy[8] = { 0, 0, -1, 1, -1, -1, 1, 1 };
             for (int k = 0; k < 8; k++) { int mx = bx + dx[k] * step * 4, my = by + dy[k] * step * 4; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
-                int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; improved = 1; } } }
+                int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx;
+                    best.mvy = my; best.cost = c; improved = 1; } } }
     }
     for (int step = 2; step >= 1; step--) {                  /* half then quarter */
         int bx = best.mvx, by = best.mvy;
-        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) { if (!dx && !dy) continue; int mx = bx + dx * step, my = by + dy * step; if (!mv_legal(e, px, py, w, h, mx, my)) continue;
-            int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx; best.mvy = my; best.cost = c; } }
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) { if (!dx && !dy) continue; int mx = bx + dx * step, my = by + dy * step;
+            if (!mv_legal(e, px, py, w, h, mx, my)) continue;
+            int c = sad_inter(e, r, px, py, w, h, mx, my) + lambda * (mv_bits(mx - mvp[0]) + mv_bits(my - mvp[1])); if (c < best.cost) { best.mvx = mx;
+                best.mvy = my; best.cost = c; } }
     }
     if (have_q && qbest.cost <= best.cost) return qbest;
     return best;
@@ -1280,7 +1342,8 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     int px = mx * 16, py = my * 16, nref = e->nlist0;
     /* ---- decide intra vs inter ---- */
     int want_intra = 0, force_intra = -1;
-    if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1; force_intra = 7; } if (e->p.no_intra) want_intra = 0; }
+    if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1;
+        force_intra = 7; } if (e->p.no_intra) want_intra = 0; }
     static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     int try_skip = fuzz && !want_intra && rnd_n(&e->rng, 8) < 2;
     int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {0, 0, 0, 0};
@@ -1302,22 +1365,26 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
             if (r16.cost > 16 * 16 * 4) {
                 /* try an 8x8 split around the 16x16 vector */
                 MvRes r8[4]; int tot = 0, c8[2] = { r16.mvx, r16.mvy };
-                for (int i = 0; i < 4; i++) { r8[i] = search_block(e, e->list0[0], px + (i & 1) * 8, py + (i >> 1) * 8, 8, 8, c8, r16.mvx, r16.mvy, 2); tot += r8[i].cost; }
+                for (int i = 0; i < 4; i++) { r8[i] = search_block(e, e->list0[0], px + (i & 1) * 8, py + (i >> 1) * 8, 8, 8, c8, r16.mvx, r16.mvy, 2);
+                    tot += r8[i].cost; }
                 if (tot + 16 * 12 < r16.cost) {
                     int same_h = r8[0].mvx == r8[1].mvx && r8[0].mvy == r8[1].mvy && r8[2].mvx == r8[3].mvx && r8[2].mvy == r8[3].mvy;
                     int same_v = r8[0].mvx == r8[2].mvx && r8[0].mvy == r8[2].mvy && r8[1].mvx == r8[3].mvx && r8[1].mvy == r8[3].mvy;
                     type = same_h ? 1 : same_v ? 2 : 3;
                     for (int i = 0; i < 4; i++) {
                         int bx = (i & 1) * 2, by = (i >> 1) * 2;
-                        for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r8[i].mvx; mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r8[i].mvy; }
+                        for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r8[i].mvx;
+                            mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r8[i].mvy; }
                         if (type == 3 && r8[i].cost > 8 * 8 * 6) {     /* 4x4 split of a still-poor 8x8 */
                             int c4[2] = { r8[i].mvx, r8[i].mvy }, t4 = 0; MvRes r4[4];
-                            for (int k = 0; k < 4; k++) { r4[k] = search_block(e, e->list0[0], px + bx * 4 + (k & 1) * 4, py + by * 4 + (k >> 1) * 4, 4, 4, c4, c4[0], c4[1], 1); t4 += r4[k].cost; }
+                            for (int k = 0; k < 4; k++) { r4[k] = search_block(e, e->list0[0], px + bx * 4 + (k & 1) * 4, py + by * 4 + (k >> 1) * 4, 4, 4, c4,
+                                c4[0], c4[1], 1); t4 += r4[k].cost; }
                             if (t4 + 40 < r8[i].cost) {
                                 int sh = r4[0].mvx == r4[1].mvx && r4[0].mvy == r4[1].mvy && r4[2].mvx == r4[3].mvx && r4[2].mvy == r4[3].mvy;
                                 int sv = r4[0].mvx == r4[2].mvx && r4[0].mvy == r4[2].mvy && r4[1].mvx == r4[3].mvx && r4[1].mvy == r4[3].mvy;
                                 sub[i] = sh ? 1 : sv ? 2 : 3;
-                                for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r4[k].mvx; mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r4[k].mvy; }
+                                for (int k = 0; k < 4; k++) { mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][0] = r4[k].mvx;
+                                    mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r4[k].mvy; }
                             }
                         }
                     }
@@ -1356,7 +1423,8 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
         }
     } else {
         for (int i = 0; i < 4; i++) {
-            int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i], nsp = st == 0 ? 1 : st == 3 ? 4 : 2, bw = (st == 0 || st == 1) ? 2 : 1, bh = (st == 0 || st == 2) ? 2 : 1;
+            int ox = (i & 1) * 2, oy = (i >> 1) * 2, st = sub[i], nsp = st == 0 ? 1 : st == 3 ? 4 : 2, bw = (st == 0 || st == 1) ? 2 : 1,
+                bh = (st == 0 || st == 2) ? 2 : 1;
             for (int p = 0; p < nsp; p++) {
                 int bx = ox + (st == 1 ? 0 : st == 2 ? p : (p & 1)), by = oy + (st == 1 ? p : st == 2 ? 0 : (p >> 1)), mvp[2], mv[2];
                 pred_mv(e, mx, my, m, bx, by, bw, refs[i], 0, 0, mvp);
@@ -1369,7 +1437,8 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     }
     for (int i = 0; i < 4; i++) m->refid[i] = e->list0[refs[i]]->id;
     /* ---- prediction + residual ---- */
-    for (int k = 0; k < 16; k++) mc_block(e, e->list0[refs[(k >> 3) * 2 + ((k & 3) >> 1)]], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, m->mv[k][0], m->mv[k][1]);
+    for (int k = 0; k < 16; k++) mc_block(e, e->list0[refs[(k >> 3) * 2 + ((k & 3) >> 1)]], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, m->mv[k][0],
+        m->mv[k][1]);
     if (e->p.wp == 1) mc_mb(e, mx, my, m);                               /* explicit weighted prediction (8.4.2.3) */
     int dqp = 0;
     if (fuzz && rnd_n(&e->rng, 6) == 0) dqp = rnd_n(&e->rng, 9) - 4;
@@ -1378,7 +1447,8 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     int t8_ok = e->p.t8x8 && (type != 3 || (sub[0] | sub[1] | sub[2] | sub[3]) == 0);     /* noSubMbPartSizeLessThan8x8Flag */
     int use_t8 = t8_ok && (fuzz ? rnd_n(&e->rng, 2) : 1);
     if (!try_skip && use_t8) { for (int b8 = 0; b8 < 4; b8++) if (code_luma8(e, px + (b8 & 1) * 8, py + (b8 >> 1) * 8, qp, 0, mc.luma8[b8])) cbp_l |= 1 << b8; }
-    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk);
+        if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
     if (!cbp_l) use_t8 = 0;
     mc.t8 = use_t8;
     int qpc = chroma_qp_of(e, qp), cflags = 0;
@@ -1435,15 +1505,18 @@ static Nbr nbr_get_l(Enc *e, int mx, int my, MbE *cur, int l, int bx, int by) {
 static void pred_mv_l(Enc *e, int mx, int my, MbE *cur, int l, int bx, int by, int bw, int ref, int shape, int part, int out[2]) {
     Nbr A = nbr_get_l(e, mx, my, cur, l, bx - 1, by), B = nbr_get_l(e, mx, my, cur, l, bx, by - 1), C = nbr_get_l(e, mx, my, cur, l, bx + bw, by - 1);
     if (!C.avail) C = nbr_get_l(e, mx, my, cur, l, bx - 1, by - 1);
-    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } }
-    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0]; out[1] = C.mv[1]; return; } }
+    if (shape == 1) { if (part == 0 && B.ref == ref) { out[0] = B.mv[0]; out[1] = B.mv[1]; return; } if (part == 1 && A.ref == ref) { out[0] = A.mv[0];
+        out[1] = A.mv[1]; return; } }
+    if (shape == 2) { if (part == 0 && A.ref == ref) { out[0] = A.mv[0]; out[1] = A.mv[1]; return; } if (part == 1 && C.ref == ref) { out[0] = C.mv[0];
+        out[1] = C.mv[1]; return; } }
     if (!B.avail && !C.avail && A.avail) { B = A; C = A; }
     int ma = A.ref == ref, mb = B.ref == ref, mc = C.ref == ref;
     if (ma + mb + mc == 1) { Nbr *n = ma ? &A : (mb ? &B : &C); out[0] = n->mv[0]; out[1] = n->mv[1]; }
     else { out[0] = med3(A.mv[0], B.mv[0], C.mv[0]); out[1] = med3(A.mv[1], B.mv[1], C.mv[1]); }
 }
 static void store_mv_l(Enc *e, MbE *m, int l, int bx, int by, int bw, int bh, int mvx, int mvy) {
-    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { mb_mv(m, l)[y * 4 + x][0] = (int16_t)mvx; mb_mv(m, l)[y * 4 + x][1] = (int16_t)mvy; e->decoded_mask |= 1 << (y * 4 + x); }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { mb_mv(m, l)[y * 4 + x][0] = (int16_t)mvx; mb_mv(m, l)[y * 4 + x][1] = (int16_t)mvy;
+        e->decoded_mask |= 1 << (y * 4 + x); }
 }
 /* colocated motion (8.4.1.2.1) of 4x4 block r in the first picture of list 1 */
 static void col_motion(Enc *e, int mx, int my, int r, int *refidx, int mv[2], int *refid) {
@@ -1517,12 +1590,14 @@ static void sample4(Enc *e, const Frame *r, int px, int py, int mvx, int mvy, in
         if (r->hb && x0 >= -lim && y0 >= -lim && x0 + 4 <= e->W + lim && y0 + 4 <= e->H + lim)
             for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = qpel_fast(r, x0 + x, y0 + y, mvx & 3, mvy & 3);
         else
-            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2), mvx & 3, mvy & 3);
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2),
+                mvx & 3, mvy & 3);
     }
     int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
     for (int pl = 0; pl < 2; pl++) { const uint8_t *rp = pl ? r->v : r->u; int *o = pl ? cv : cu;
         for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
-            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1), D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
+            int A = refpx(rp, r->sc, cw, ch, xi, yi), B = refpx(rp, r->sc, cw, ch, xi + 1, yi), C = refpx(rp, r->sc, cw, ch, xi, yi + 1),
+                D = refpx(rp, r->sc, cw, ch, xi + 1, yi + 1);
             o[y * 2 + x] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6; } }
 }
 /* 8.4.2.3 for one colour component cmp (0 Y, 1 Cb, 2 Cr) of a block predicted from list entries r0 / r1 (-1 = unused) */
@@ -1538,7 +1613,8 @@ static void weigh(Enc *e, int cmp, int r0, int r1, const int *a, const int *b, i
                 else {
                     int td = CLIP3(-128, 127, e->list1[r1]->poc - e->list0[r0]->poc), tb = CLIP3(-128, 127, e->cur_poc - e->list0[r0]->poc);
                     w0 = w1 = 32;
-                    if (td != 0) { int tx = (16384 + ABS(td / 2)) / td, sc = CLIP3(-1024, 1023, (tb * tx + 32) >> 6) >> 2; if (sc >= -64 && sc <= 128) { w1 = sc; w0 = 64 - sc; } }
+                    if (td != 0) { int tx = (16384 + ABS(td / 2)) / td, sc = CLIP3(-1024, 1023, (tb * tx + 32) >> 6) >> 2; if (sc >= -64 && sc <= 128) {
+                        w1 = sc; w0 = 64 - sc; } }
                 }
                 v = CLIP1(((a[i] * w0 + b[i] * w1 + (1 << sh)) >> (sh + 1)) + o);
             }
@@ -1560,7 +1636,8 @@ static void mc_mb(Enc *e, int mx, int my, MbE *m) {
         if (r1 >= 0) sample4(e, e->list1[r1], px, py, m->mv1[r][0], m->mv1[r][1], y1, u1, v1);
         weigh(e, 0, r0, r1, y0, y1, 16, oy); weigh(e, 1, r0, r1, u0, u1, 4, ou); weigh(e, 2, r0, r1, v0, v1, 4, ov);
         for (int i = 0; i < 16; i++) c->y[(py + (i >> 2)) * c->sy + px + (i & 3)] = (uint8_t)oy[i];
-        for (int i = 0; i < 4; i++) { c->u[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ou[i]; c->v[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ov[i]; }
+        for (int i = 0; i < 4; i++) { c->u[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ou[i];
+            c->v[(py / 2 + (i >> 1)) * c->sc + px / 2 + (i & 1)] = (uint8_t)ov[i]; }
     }
 }
 static int sad_mb(Enc *e, int mx, int my) {
@@ -1623,7 +1700,8 @@ static void se_mvd_l(Enc *e, int mx, int my, MbE *m, int l, int bx, int by, int 
         if (a >= 9) cab_ueg(c, a - 9, 3);
         cab_byp(c, d < 0);
     }
-    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { (l ? m->mvd1 : m->mvd)[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255); (l ? m->mvd1 : m->mvd)[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
+    for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { (l ? m->mvd1 : m->mvd)[y * 4 + x][0] = (uint8_t)MIN(ABS(dx), 255);
+        (l ? m->mvd1 : m->mvd)[y * 4 + x][1] = (uint8_t)MIN(ABS(dy), 255); }
 }
 
 typedef struct { int bx, by, bw, bh, pred /*0 L0 1 L1 2 Bi 3 direct*/, shape, part, q; } BPart;
@@ -1658,7 +1736,8 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
         if (direct_ok) { b_direct(e, mx, my, m, 15); mc_mb(e, mx, my, m); cost[0] = sad_mb(e, mx, my) - 64; } else cost[0] = 1 << 30;
         mb_init(e, m);
         for (int i = 0; i < 4; i++) { m->ref[i] = 0; m->ref1[i] = 0; }
-        for (int r = 0; r < 16; r++) { m->mv[r][0] = (int16_t)r16[0][0]; m->mv[r][1] = (int16_t)r16[0][1]; m->mv1[r][0] = (int16_t)r16[1][0]; m->mv1[r][1] = (int16_t)r16[1][1]; }
+        for (int r = 0; r < 16; r++) { m->mv[r][0] = (int16_t)r16[0][0]; m->mv[r][1] = (int16_t)r16[0][1]; m->mv1[r][0] = (int16_t)r16[1][0];
+            m->mv1[r][1] = (int16_t)r16[1][1]; }
         mc_mb(e, mx, my, m); cost[3] = sad_mb(e, mx, my) + 32;
         mb_init(e, m);
         for (int i = 0; i < 4; i++) if (cost[i] < best) { best = cost[i]; cand = i; }
@@ -1669,12 +1748,14 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     /* ---- partitions in syntax order ---- */
     if (mbt == 0) { dmask = 15; m->bdirect16 = 1; }
     else if (mbt <= 3) { BPart p = {0, 0, 4, 4, mbt - 1, 0, 0, 0}; parts[np++] = p; }
-    else if (mbt <= 21) { int sh = (mbt & 1) ? 2 : 1; for (int i = 0; i < 2; i++) { BPart p = { sh == 2 ? i * 2 : 0, sh == 1 ? i * 2 : 0, sh == 2 ? 2 : 4, sh == 1 ? 2 : 4, pair[(mbt - 4) >> 1][i], sh, i, 0 }; parts[np++] = p; } }
+    else if (mbt <= 21) { int sh = (mbt & 1) ? 2 : 1; for (int i = 0; i < 2; i++) { BPart p = {
+        sh == 2 ? i * 2 : 0, sh == 1 ? i * 2 : 0, sh == 2 ? 2 : 4, sh == 1 ? 2 : 4, pair[(mbt - 4) >> 1][i], sh, i, 0 }; parts[np++] = p; } }
     else for (int q = 0; q < 4; q++) {
         int pr = sub_pred[sub[q]], sp = sub_shape[sub[q]], ox = (q & 1) * 2, oy = (q >> 1) * 2;
         if (pr == 3) { dmask |= 1 << q; BPart p = {ox, oy, 2, 2, 3, 0, 0, q}; parts[np++] = p; continue; }
         int n = sp == 0 ? 1 : sp == 3 ? 4 : 2, bw = (sp == 0 || sp == 1) ? 2 : 1, bh = (sp == 0 || sp == 2) ? 2 : 1;
-        for (int i = 0; i < n; i++) { BPart p = { ox + (sp == 1 ? 0 : sp == 2 ? i : (i & 1)), oy + (sp == 1 ? i : sp == 2 ? 0 : (i >> 1)), bw, bh, pr, 0, 0, q }; parts[np++] = p; }
+        for (int i = 0; i < n; i++) { BPart p = { ox + (sp == 1 ? 0 : sp == 2 ? i : (i & 1)), oy + (sp == 1 ? i : sp == 2 ? 0 : (i >> 1)), bw, bh, pr, 0, 0,
+            q }; parts[np++] = p; }
     }
     if (dmask) b_direct(e, mx, my, m, dmask);
     /* reference indices */
@@ -1692,10 +1773,12 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
         e->decoded_mask = 0;
         for (int i = 0; i < np; i++) {
             BPart *p = &parts[i];
-            if (refs[l][i] < 0) { for (int y = p->by; y < p->by + p->bh; y++) for (int x = p->bx; x < p->bx + p->bw; x++) e->decoded_mask |= 1 << (y * 4 + x); continue; }
+            if (refs[l][i] < 0) { for (int y = p->by; y < p->by + p->bh; y++) for (int x = p->bx; x < p->bx + p->bw; x++) e->decoded_mask |= 1 << (y * 4 + x);
+                continue; }
             int mvp[2], mv[2];
             pred_mv_l(e, mx, my, m, l, p->bx, p->by, p->bw, refs[l][i], p->shape, p->part, mvp);
-            if (fuzz) random_mv(e, px + p->bx * 4, py + p->by * 4, p->bw * 4, p->bh * 4, mvp, mv); else { mv[0] = want[l][p->by * 4 + p->bx][0]; mv[1] = want[l][p->by * 4 + p->bx][1]; }
+            if (fuzz) random_mv(e, px + p->bx * 4, py + p->by * 4, p->bw * 4, p->bh * 4, mvp, mv);
+            else { mv[0] = want[l][p->by * 4 + p->bx][0]; mv[1] = want[l][p->by * 4 + p->bx][1]; }
             mvd[l][i][0] = mv[0] - mvp[0]; mvd[l][i][1] = mv[1] - mvp[1];
             store_mv_l(e, m, l, p->bx, p->by, p->bw, p->bh, mv[0], mv[1]);
         }
@@ -1712,7 +1795,8 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     if (mbt == 0 && !e->p.dinf8) small = 1;
     int t8_ok = e->p.t8x8 && !small, use_t8 = t8_ok && (fuzz ? rnd_n(&e->rng, 2) : 1), cbp_l = 0;
     if (!try_skip && use_t8) { for (int b8 = 0; b8 < 4; b8++) if (code_luma8(e, px + (b8 & 1) * 8, py + (b8 >> 1) * 8, qp, 0, mc.luma8[b8])) cbp_l |= 1 << b8; }
-    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk); if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
+    else if (!try_skip) for (int blk = 0; blk < 16; blk++) { int bx = bX(blk), by = bY(blk);
+        if (code_luma4(e, px + bx * 4, py + by * 4, qp, 0, mc.luma[by * 4 + bx])) cbp_l |= 1 << (blk >> 2); }
     if (!cbp_l) use_t8 = 0;
     mc.t8 = use_t8;
     int qpc = chroma_qp_of(e, qp), cflags = 0;
@@ -1735,7 +1819,8 @@ static void encode_b_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
         if (mbt == 22 && i > 0 && parts[i - 1].q == p->q) continue;       /* ref_idx once per sub-macroblock */
         se_ref_idx_l(e, mx, my, m, l, mbt == 22 ? (p->q & 1) * 2 : p->bx, mbt == 22 ? (p->q >> 1) * 2 : p->by, nref[l], refs[l][i]);
     }
-    for (int l = 0; l < 2; l++) for (int i = 0; i < np; i++) if (refs[l][i] >= 0) se_mvd_l(e, mx, my, m, l, parts[i].bx, parts[i].by, parts[i].bw, parts[i].bh, mvd[l][i][0], mvd[l][i][1]);
+    for (int l = 0; l < 2; l++) for (int i = 0; i < np; i++) if (refs[l][i] >= 0) se_mvd_l(e, mx, my, m, l, parts[i].bx, parts[i].by, parts[i].bw, parts[i].bh,
+        mvd[l][i][0], mvd[l][i][1]);
     se_cbp(e, mx, my, mc.cbp, 0); m->cbp = (uint8_t)mc.cbp;
     if (cbp_l && t8_ok) se_t8_flag(e, mx, my, use_t8);
     m->t8 = (uint8_t)use_t8;
@@ -1770,8 +1855,11 @@ static void write_scaling_matrix(Enc *e, BitW *w, int n_lists) {
         for (int j = 0; j < n; j++) {
             if (j == stop) { bw_se(w, -last <= -128 ? 256 - last : -last); for (int k = j; k < n; k++) eff[i][k] = (uint8_t)last; break; }
             int v = 8 + rnd_n(&r, 41);                                     /* 8..48 */
-            if (j > 0 && rnd_n(&r, 3)) { const int step = last + rnd_n(&r, 9) - 4; v = CLIP3(8, 48, step); }   /* (CLIP3 is a macro: the draw must not sit inside it -- it used to,
-                                                                                                        and one matrix in ~150 came out with a 0 entry, which ends the list early: both decoders rightly rejected that SPS) */
+            if (j > 0 && rnd_n(&r, 3)) { const int step = last + rnd_n(&r, 9) - 4; v = CLIP3(8, 48, step); }
+                /* (CLIP3 is a macro: the draw must not sit inside it -- it used to,
+                                                                                                        and one matrix in ~150 came out with a 0 entry,
+                                                                                                            which ends the list early:
+                                                                                                            both decoders rightly rejected that SPS) */
             int d = v - last; bw_se(w, d);
             eff[i][j] = (uint8_t)v; last = v;
         }
@@ -1792,7 +1880,8 @@ static void write_sps_pps(Enc *e) {
     else { bw_put(w, 8, 66); bw_put(w, 8, 0xC0); }                        /* Baseline, constraint_set0/1 */
     bw_put(w, 8, p->level_idc);
     bw_ue(w, 0);
-    if (high) { bw_ue(w, 1); bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, (uint32_t)(p->scaling == 1)); if (p->scaling == 1) write_scaling_matrix(e, w, 8); }   /* 4:2:0, 8 bit, no bypass, scaling matrix */
+    if (high) { bw_ue(w, 1); bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, 0); bw_put(w, 1, (uint32_t)(p->scaling == 1));
+        if (p->scaling == 1) write_scaling_matrix(e, w, 8); }   /* 4:2:0, 8 bit, no bypass, scaling matrix */
     bw_ue(w, e->log2_max_fn - 4);
     bw_ue(w, p->poc_type);
     if (p->poc_type == 0) bw_ue(w, e->poc_lsb_bits - 4);
@@ -1802,19 +1891,22 @@ static void write_sps_pps(Enc *e) {
     }
     bw_ue(w, p->num_ref); bw_put(w, 1, 0);
     bw_ue(w, e->mbw - 1); bw_ue(w, (p->fmo0 ? e->mbh / 2 : e->mbh) - 1);   /* pic_height_in_map_units: field macroblock rows when frame_mbs_only_flag = 0 */
-    if (p->fmo0) { bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 1); }  /* frame_mbs_only_flag 0, mb_adaptive_frame_field_flag 0, direct_8x8_inference_flag 1 */
+    if (p->fmo0) { bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 1); }  /* frame_mbs_only_flag 0, mb_adaptive_frame_field_flag 0,
+        direct_8x8_inference_flag 1 */
     else { bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)p->dinf8); }           /* frame_mbs_only, direct_8x8_inference */
     int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / (p->fmo0 ? 4 : 2);   /* CropUnitY = 2 * (2 - frame_mbs_only_flag) */
     if (cr || cb) { bw_put(w, 1, 1); bw_ue(w, 0); bw_ue(w, cr); bw_ue(w, 0); bw_ue(w, cb); } else bw_put(w, 1, 0);
     bw_put(w, 1, 0);                                                      /* no VUI */
     bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
     w->len = 0;
-    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, (uint32_t)p->poc_bottom); bw_ue(w, 0);   /* ..., bottom_field_pic_order_in_frame_present_flag, one slice group */
+    bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, (uint32_t)p->poc_bottom); bw_ue(w, 0);
+    /* ..., bottom_field_pic_order_in_frame_present_flag, one slice group */
     bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
     bw_put(w, 1, (uint32_t)(p->wp == 1)); bw_put(w, 2, (uint32_t)(p->bframes ? p->wp : 0));   /* weighted_pred_flag, weighted_bipred_idc */
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
     bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
-    if (high) { bw_put(w, 1, (uint32_t)p->t8x8); bw_put(w, 1, (uint32_t)(p->scaling == 2)); if (p->scaling == 2) write_scaling_matrix(e, w, 6 + 2 * p->t8x8); bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, scaling matrix, second_chroma_qp_index_offset */
+    if (high) { bw_put(w, 1, (uint32_t)p->t8x8); bw_put(w, 1, (uint32_t)(p->scaling == 2)); if (p->scaling == 2) write_scaling_matrix(e, w, 6 + 2 * p->t8x8);
+        bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
 }
 
@@ -1831,7 +1923,8 @@ static void encode_frame(Enc *e, int t, int is_b) {
     /* 8.2.1: TopFieldOrderCnt counts 2 per picture from the last restart; with poc_bottom the bottom field may lie one below or above, and
        PicOrderCnt(frame) = Min(top, bottom) is what the lists, direct prediction and the output order see */
     e->cur_top = 2 * (t - e->poc_base); e->delta_bottom = 0; e->delta0 = 0;
-    if (p->poc_bottom) { e->delta_bottom = rnd_n(&e->rng, 3) - 1; if (idr && e->delta_bottom < 0) e->delta_bottom = 1; }   /* an IDR frame: Min(top, bottom) = 0 (8.2.1) */
+    if (p->poc_bottom) { e->delta_bottom = rnd_n(&e->rng, 3) - 1; if (idr && e->delta_bottom < 0) e->delta_bottom = 1; }
+        /* an IDR frame: Min(top, bottom) = 0 (8.2.1) */
     if (p->poc_type == 1) e->delta0 = rnd_n(&e->rng, 2);
     e->cur_poc = e->cur_top + MIN(0, e->delta_bottom); e->cur.poc = e->cur_poc;
     if (e->pocs) e->pocs[t] = e->cur_poc;
@@ -1853,14 +1946,17 @@ static void encode_frame(Enc *e, int t, int is_b) {
         /* 8.2.4.2.3: list 0 = earlier pictures by descending POC then later ones ascending; list 1 the other way round */
         Frame *before[5], *after[5]; int nb = 0, na = 0, n = MIN(e->nrefs, p->num_ref);
         for (int i = 0; i < n; i++) { if (e->refs[i].poc < e->cur_poc) before[nb++] = &e->refs[i]; else after[na++] = &e->refs[i]; }
-        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Frame *x = before[i]; before[i] = before[j]; before[j] = x; }
-        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Frame *x = after[i]; after[i] = after[j]; after[j] = x; }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Frame *x = before[i]; before[i] = before[j];
+            before[j] = x; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Frame *x = after[i]; after[i] = after[j];
+            after[j] = x; }
         e->nlist0 = e->nlist1 = 0;
         for (int i = 0; i < nb; i++) e->list0[e->nlist0++] = before[i];
         for (int i = 0; i < na; i++) e->list0[e->nlist0++] = after[i];
         for (int i = 0; i < na; i++) e->list1[e->nlist1++] = after[i];
         for (int i = 0; i < nb; i++) e->list1[e->nlist1++] = before[i];
-        if (e->nlist1 > 1) { int same = 1; for (int i = 0; i < e->nlist0; i++) if (e->list0[i] != e->list1[i]) same = 0; if (same) { Frame *x = e->list1[0]; e->list1[0] = e->list1[1]; e->list1[1] = x; } }
+        if (e->nlist1 > 1) { int same = 1; for (int i = 0; i < e->nlist0; i++) if (e->list0[i] != e->list1[i]) same = 0; if (same) { Frame *x = e->list1[0];
+            e->list1[0] = e->list1[1]; e->list1[1] = x; } }
         for (int i = 0; i < e->nlist0; i++) init[0][ninit[0]++] = e->list0[i];
         for (int i = 0; i < e->nlist1; i++) init[1][ninit[1]++] = e->list1[i];
         if (p->mode == 1) { e->nlist0 = 1 + rnd_n(&e->rng, e->nlist0); e->nlist1 = 1 + rnd_n(&e->rng, e->nlist1); }   /* num_ref_idx_active override */
@@ -1909,13 +2005,15 @@ static void encode_frame(Enc *e, int t, int is_b) {
 #define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
 #define DROP_LT(ix) do { for (int q_ = 0; q_ < lt_n; q_++) if (lt_ix[q_] == (ix)) { lt_ix[q_] = lt_ix[--lt_n]; break; } } while (0)
             if (maxlt < 1 && rnd_n(&e->rng, 2)) { ADD_OP(4, 2, 0); maxlt = 1; }
-            if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1); ADD_OP(3, curfn - st_fn[k] - 1, ix); DROP_LT(ix); lt_ix[lt_n++] = ix; st_fn[k] = st_fn[--st_n]; }
+            if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1);
+                ADD_OP(3, curfn - st_fn[k] - 1, ix); DROP_LT(ix); lt_ix[lt_n++] = ix; st_fn[k] = st_fn[--st_n]; }
             if (st_n > 0 && rnd_n(&e->rng, 3) == 0) { int k = rnd_n(&e->rng, st_n); ADD_OP(1, curfn - st_fn[k] - 1, 0); st_fn[k] = st_fn[--st_n]; }
             if (lt_n > 0 && rnd_n(&e->rng, 4) == 0) { int k = rnd_n(&e->rng, lt_n); ADD_OP(2, lt_ix[k], 0); lt_ix[k] = lt_ix[--lt_n]; }
             if (maxlt >= 0 && rnd_n(&e->rng, 4) == 0) { int ix = rnd_n(&e->rng, maxlt + 1); ADD_OP(6, 0, ix); DROP_LT(ix); cur_long = 1; }
             (void)cur_long;
             while (st_n + lt_n + 1 > p->num_ref) {                       /* room for the current picture */
-                if (st_n > 0) { int k = 0; for (int i = 1; i < st_n; i++) if (st_fn[i] < st_fn[k]) k = i; ADD_OP(1, curfn - st_fn[k] - 1, 0); st_fn[k] = st_fn[--st_n]; }
+                if (st_n > 0) { int k = 0; for (int i = 1; i < st_n; i++) if (st_fn[i] < st_fn[k]) k = i; ADD_OP(1, curfn - st_fn[k] - 1, 0);
+                    st_fn[k] = st_fn[--st_n]; }
                 else { ADD_OP(2, lt_ix[0], 0); lt_ix[0] = lt_ix[--lt_n]; }
             }
             }
@@ -1932,7 +2030,9 @@ static void encode_frame(Enc *e, int t, int is_b) {
             e->ww[l][i][c] = one; e->wo[l][i][c] = 0;
             if (rnd_n(&e->rng, 3)) { e->ww[l][i][c] = one + rnd_n(&e->rng, one / 2 + 1) - one / 4; e->wo[l][i][c] = rnd_n(&e->rng, 13) - 6; }
         }
-        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) if (e->ww[l][i][1] == (1 << e->wlog[1]) && e->wo[l][i][1] == 0 && (e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0)) e->wo[l][i][1] = 1;   /* one chroma flag covers Cb and Cr */
+        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) if (e->ww[l][i][1] == (1 << e->wlog[1]) && e->wo[l][i][1] == 0 &&
+            (e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0)) e->wo[l][i][1] = 1;
+        /* one chroma flag covers Cb and Cr */
     }
     e->cur.id = e->next_id++;
     int mbs_total = e->mbw * e->mbh, rows_per = (e->mbh + p->slices - 1) / p->slices;
@@ -1947,7 +2047,8 @@ static void encode_frame(Enc *e, int t, int is_b) {
         bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
         if (p->fmo0) bw_put(w, 1, 0);                                      /* field_pic_flag */
         if (idr) bw_ue(w, e->idr_id & 0xffff);
-        if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_top & ((1u << e->poc_lsb_bits) - 1)); if (p->poc_bottom) bw_se(w, e->delta_bottom); }
+        if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_top & ((1u << e->poc_lsb_bits) - 1)); if (p->poc_bottom) bw_se(w, e->delta_bottom);
+            }
         if (p->poc_type == 1) { bw_se(w, e->delta0); if (p->poc_bottom) bw_se(w, e->delta_bottom); }
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); }
@@ -1968,7 +2069,8 @@ static void encode_frame(Enc *e, int t, int is_b) {
         if (is_ref) {                                                     /* dec_ref_pic_marking() */
             if (idr) { bw_put(w, 1, 0); bw_put(w, 1, (uint32_t)e->idr_long); }
             else { bw_put(w, 1, (uint32_t)(e->n_mmco > 0));
-                for (int k = 0; k < e->n_mmco; k++) { int o = e->mmco_op[k]; bw_ue(w, o); if (o == 1 || o == 3) bw_ue(w, e->mmco_a[k]); if (o == 2) bw_ue(w, e->mmco_a[k]); if (o == 3 || o == 6) bw_ue(w, e->mmco_b[k]); if (o == 4) bw_ue(w, e->mmco_a[k]); }
+                for (int k = 0; k < e->n_mmco; k++) { int o = e->mmco_op[k]; bw_ue(w, o); if (o == 1 || o == 3) bw_ue(w, e->mmco_a[k]);
+                    if (o == 2) bw_ue(w, e->mmco_a[k]); if (o == 3 || o == 6) bw_ue(w, e->mmco_b[k]); if (o == 4) bw_ue(w, e->mmco_a[k]); }
                 if (e->n_mmco) bw_ue(w, 0); }
         }
         if (e->cabac && e->slice_type != 2) bw_ue(w, p->cabac_idc);
@@ -1999,11 +2101,18 @@ static void encode_frame(Enc *e, int t, int is_b) {
     if (p->deblock != 0) deblock_frame(e);
     if (getenv("H264GEN_STATS")) {
         double se = 0; int cnt[6] = {0}, nzmv = 0, qmv = 0;
-        for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x]; se += d * d; }
-        for (int i = 0; i < mbs_total; i++) { MbE *m = &e->mbs[i]; cnt[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)]++; if (!m->intra) for (int k = 0; k < 16; k++) { nzmv += m->mv[k][0] || m->mv[k][1]; qmv += (m->mv[k][0] & 3) || (m->mv[k][1] & 3); } }
+        for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x];
+            se += d * d; }
+        for (int i = 0; i < mbs_total; i++) { MbE *m = &e->mbs[i]; cnt[m->intra ? (m->pcm ? 3 : (m->i16 ? 2 : 1)) : (m->skip ? 4 : 0)]++;
+            if (!m->intra) for (int k = 0; k < 16; k++) { nzmv += m->mv[k][0] || m->mv[k][1]; qmv += (m->mv[k][0] & 3) || (m->mv[k][1] & 3); } }
         double mse = se / (p->width * p->height);
-        if (e->n_mmco || e->n_mod[0] || e->n_mod[1]) { fprintf(stderr, "  frame %d fn %d:", t, e->frame_num); for (int k = 0; k < e->n_mmco; k++) fprintf(stderr, " mmco%d(%d,%d)", e->mmco_op[k], e->mmco_a[k], e->mmco_b[k]); for (int l = 0; l < 2; l++) for (int k = 0; k < e->n_mod[l]; k++) fprintf(stderr, " mod%d(%d,%d)", l, e->mod_idc[l][k], e->mod_val[l][k]); fprintf(stderr, " list0:"); for (int i = 0; i < e->nlist0; i++) fprintf(stderr, " %s%d", e->list0[i]->is_long ? "L" : "fn", e->list0[i]->is_long ? e->list0[i]->lt_idx : e->list0[i]->frame_num); fprintf(stderr, "\n"); }
-        fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t, idr ? 'I' : (e->slice_type == 2 ? 'i' : (is_b ? 'B' : 'P')), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
+        if (e->n_mmco || e->n_mod[0] || e->n_mod[1]) { fprintf(stderr, "  frame %d fn %d:", t, e->frame_num);
+            for (int k = 0; k < e->n_mmco; k++) fprintf(stderr, " mmco%d(%d,%d)", e->mmco_op[k], e->mmco_a[k], e->mmco_b[k]);
+            for (int l = 0; l < 2; l++) for (int k = 0; k < e->n_mod[l]; k++) fprintf(stderr, " mod%d(%d,%d)", l, e->mod_idc[l][k], e->mod_val[l][k]);
+            fprintf(stderr, " list0:"); for (int i = 0; i < e->nlist0; i++) fprintf(stderr, " %s%d", e->list0[i]->is_long ? "L" : "fn",
+            e->list0[i]->is_long ? e->list0[i]->lt_idx : e->list0[i]->frame_num); fprintf(stderr, "\n"); }
+        fprintf(stderr, "frame %d type %c ref %d mse %.2f inter %d i4 %d i16 %d pcm %d skip %d nzmv4x4 %d qpelmv4x4 %d bytes %zu\n", t,
+            idr ? 'I' : (e->slice_type == 2 ? 'i' : (is_b ? 'B' : 'P')), is_ref, mse, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], nzmv, qmv, e->out.len);
     }
     if (e->recon_buf && t < e->recon_frames) {                           /* display order */
         uint8_t *o = e->recon_buf + (size_t)t * (p->width * p->height * 3 / 2);
@@ -2018,7 +2127,9 @@ static void encode_frame(Enc *e, int t, int is_b) {
         if (!e->cur.mf) e->cur.mf = malloc(sizeof(MbE) * (size_t)mbs_total);
         memcpy(e->cur.mf, e->mbs, sizeof(MbE) * (size_t)mbs_total);
         /* 8.2.5 marking; e->refs[] is the set of reference frames, refs[nrefs..4] + cur are free frame stores */
-#define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; for (int q_ = (i_); q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; e->nrefs--; e->refs[e->nrefs] = t_; } while (0)
+#define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; \
+        for (int q_ = (i_); q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; \
+        e->nrefs--; e->refs[e->nrefs] = t_; } while (0)
         if (idr) { e->max_lt_idx = e->idr_long ? 0 : -1; e->cur.is_long = e->idr_long; e->cur.lt_idx = e->idr_long ? 0 : -1; }
         else if (e->n_mmco) {
             for (int k = 0; k < e->n_mmco; k++) {
@@ -2028,11 +2139,14 @@ static void encode_frame(Enc *e, int t, int is_b) {
                     for (int i = 0; i < e->nrefs; i++) if (!e->refs[i].is_long && PICNUM(&e->refs[i]) == pn) found = i;
                     if (found < 0) { fprintf(stderr, "h264gen: MMCO names a missing picture\n"); abort(); }
                     if (o == 1) REMOVE_REF(found);
-                    else { for (int i = 0; i < e->nrefs; i++) if (i != found && e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); if (i < found) found--; break; }
+                    else { for (int i = 0; i < e->nrefs; i++) if (i != found && e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i);
+                        if (i < found) found--; break; }
                            e->refs[found].is_long = 1; e->refs[found].lt_idx = b; }
                 } else if (o == 2) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == a) { REMOVE_REF(i); break; } }
-                else if (o == 4) { e->max_lt_idx = a - 1; for (int i = e->nrefs - 1; i >= 0; i--) if (e->refs[i].is_long && e->refs[i].lt_idx > e->max_lt_idx) REMOVE_REF(i); }
-                else if (o == 6) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); break; } e->cur.is_long = 1; e->cur.lt_idx = b; }
+                else if (o == 4) { e->max_lt_idx = a - 1; for (int i = e->nrefs - 1; i >= 0; i--) if (e->refs[i].is_long &&
+                    e->refs[i].lt_idx > e->max_lt_idx) REMOVE_REF(i); }
+                else if (o == 6) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long && e->refs[i].lt_idx == b) { REMOVE_REF(i); break; }
+                    e->cur.is_long = 1; e->cur.lt_idx = b; }
                 else if (o == 5) {
                     /* every reference picture is dropped; the picture is inferred to have had frame_num 0 (7.4.3) and its order counts are
                        reduced by Min(top, bottom) (8.2.1): what follows counts from here */
@@ -2083,7 +2197,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     /* pic_order_cnt_type 1 (8.2.1.2): reference pictures advance by 8 / 10 / 12 in a cycle of 1..3, a non-reference picture lies 4 above the
        reference picture before it, top-to-bottom offset -1..1; with delta_pic_order_cnt[0] in 0..1 and the bottom deltas in -1..1 the counts still
        rise strictly in decoding order, which is the display order of a stream without B pictures */
-    { uint32_t h = (uint32_t)p->seed * 2654435761u; e->t1_cycle = 1 + (int)((h >> 8) % 3); for (int i = 0; i < 3; i++) e->t1_ref[i] = 8 + 2 * (int)((h >> (12 + 4 * i)) % 3);
+    { uint32_t h = (uint32_t)p->seed * 2654435761u; e->t1_cycle = 1 + (int)((h >> 8) % 3);
+        for (int i = 0; i < 3; i++) e->t1_ref[i] = 8 + 2 * (int)((h >> (12 + 4 * i)) % 3);
       e->t1_nonref = 4; e->t1_t2b = p->poc_bottom ? (int)((h >> 26) % 3) - 1 : 0; }
     p->cabac = p->cabac != 0; p->t8x8 = p->t8x8 != 0; p->cabac_idc = CLIP3(0, 2, p->cabac_idc);
     e->cabac = p->cabac;
@@ -2099,8 +2214,10 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     e->mbs = (MbE *)calloc((size_t)e->mbw * e->mbh, sizeof(MbE));
     make_texture(e);
     e->pocs = (int *)calloc((size_t)p->frames + 1, sizeof(int));
-    if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames; e->recon_buf = (uint8_t *)calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
-    for (int g0 = 0; g0 < p->frames; g0 += p->gop) {                      /* coding order: every anchor before the B pictures that precede it in display order */
+    if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames;
+        e->recon_buf = (uint8_t *)calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
+    for (int g0 = 0; g0 < p->frames; g0 += p->gop) {
+        /* coding order: every anchor before the B pictures that precede it in display order */
         int g1 = MIN(p->frames, g0 + p->gop), prev = g0;
         encode_frame(e, g0, 0);
         while (prev + 1 < g1) {
@@ -2123,7 +2240,8 @@ void h264gen_free(void *p) { free(p); }
 #ifndef H264GEN_NO_MAIN
 int main(int argc, char **argv) {
     GenParams p; memset(&p, 0, sizeof p);
-    p.width = 1920; p.height = 1080; p.frames = 30; p.qp = 28; p.gop = 30; p.seed = 0x4A4D0100; p.deblock = 1; p.num_ref = 1; p.slices = 1; p.search = 4; p.dinf8 = 1;
+    p.width = 1920; p.height = 1080; p.frames = 30; p.qp = 28; p.gop = 30; p.seed = 0x4A4D0100; p.deblock = 1; p.num_ref = 1; p.slices = 1; p.search = 4;
+    p.dinf8 = 1;
     const char *outp = NULL, *recon = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i]; const char *v = i + 1 < argc ? argv[i + 1] : "0";
@@ -2133,12 +2251,15 @@ int main(int argc, char **argv) {
         OPT("--poc-type", poc_type) OPT("--nonref", nonref_period) OPT("--alpha", alpha_off) OPT("--beta", beta_off)
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
-        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm", rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom)
+        OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm",
+            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
     }
-    if (!outp) { fprintf(stderr, "usage: h264gen [--width W --height H --frames N --qp Q --gop G --seed S --mode 0|1 --deblock 0|1|2 --refs N --slices N --pcm 1 ...] -o out.h264 [--recon recon.yuv]\n"); return 2; }
+    if (!outp) { fprintf(stderr,
+        "usage: h264gen [--width W --height H --frames N --qp Q --gop G --seed S --mode 0|1 --deblock 0|1|2 --refs N --slices N --pcm 1 ...] "
+        "-o out.h264 [--recon recon.yuv]\n"); return 2; }
     uint8_t *buf; size_t len;
     if (h264gen_generate(&p, &buf, &len, recon) < 0) { fprintf(stderr, "bad parameters\n"); return 1; }
     FILE *f = fopen(outp, "wb"); fwrite(buf, 1, len, f); fclose(f);

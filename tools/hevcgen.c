@@ -50,7 +50,8 @@ typedef struct {
     int rps_sps;                /* 1: reference picture sets live in the SPS (inter RPS prediction where expressible) */
     int cb_qp_off, cr_qp_off;
     int search;                 /* integer search range (mode 0)                                            */
-    int open_gop;               /* 1: intra periods after the first start with a CRA picture whose leading B pictures are RASL (gop 1..3, period a multiple of gop + 1); parameter sets are repeated there */
+    int open_gop; /* 1: intra periods after the first start with a CRA picture whose leading B pictures are RASL (gop 1..3, period a multiple of gop + 1);
+    parameter sets are repeated there */
 } HevcGenParams;
 
 /* ------------------------------ RNG ------------------------------ */
@@ -60,7 +61,8 @@ static int rnd_n(Rng *r, int n) { return (int)(rnd(r) % (uint32_t)n); }
 
 /* ------------------------------ bit writer ------------------------------ */
 typedef struct { uint8_t *buf; size_t cap, len; uint32_t cur; int nbits; } BitW;
-static void bw_reserve(BitW *w, size_t extra) { if (w->len + extra > w->cap) { w->cap = (w->len + extra) * 2 + 1024; w->buf = (uint8_t *)realloc(w->buf, w->cap); } }
+static void bw_reserve(BitW *w, size_t extra) { if (w->len + extra > w->cap) { w->cap = (w->len + extra) * 2 + 1024;
+    w->buf = (uint8_t *)realloc(w->buf, w->cap); } }
 static void bw_put(BitW *w, int n, uint32_t v) {
     for (int i = n - 1; i >= 0; i--) {
         w->cur = (w->cur << 1) | ((v >> i) & 1);
@@ -118,7 +120,8 @@ static void cab_renorm(Cab *c) {
     }
 }
 static FILE *g_trace; static int g_trace_init;
-#define TRACE(...) do { if (!g_trace_init) { g_trace_init = 1; if (getenv("HG_TRACE")) g_trace = fopen(getenv("HG_TRACE"), "w"); } if (g_trace) fprintf(g_trace, __VA_ARGS__); } while (0)
+#define TRACE(...) do { if (!g_trace_init) { g_trace_init = 1; if (getenv("HG_TRACE")) g_trace = fopen(getenv("HG_TRACE"), "w"); } \
+        if (g_trace) fprintf(g_trace, __VA_ARGS__); } while (0)
 static void cab_enc(Cab *c, int ctx, int bin) {
     TRACE("c%d %d\n", ctx, bin);
     uint32_t lps = hg_range_lps[c->st[ctx]][(c->range >> 6) & 3];
@@ -189,7 +192,7 @@ typedef struct Enc {
     int decode_count;
     uint8_t *dbk[3];
     int lf_across_tiles;
-    int tile_explicit, tile_cb[21], tile_rb[23];                        /* tile boundaries in CTBs; explicit: sent as column widths / row heights (uniform_spacing_flag = 0) */
+    int tile_explicit, tile_cb[21], tile_rb[23]; /* tile boundaries in CTBs; explicit: sent as column widths / row heights (uniform_spacing_flag = 0) */
     RpsSet sps_sets[64]; int n_sps_sets;                               /* short-term reference picture sets carried by the SPS (rps_sps) */
     uint8_t sl4[6][16], sl8[6][64], sl16[6][64], sl32[6][64], dc16[6], dc32[6];   /* coded scaling lists (diagonal order) */
 } Enc;
@@ -198,7 +201,8 @@ typedef struct Enc {
 static void pic_alloc(Enc *e, Pic *p) {
     for (int c = 0; c < 3; c++) { p->stride[c] = e->W >> (c ? 1 : 0); p->pl[c] = (uint8_t *)calloc((size_t)p->stride[c], (size_t)(e->H >> (c ? 1 : 0))); }
     size_t n = (size_t)((e->W + 15) >> 4) * (size_t)((e->H + 15) >> 4);
-    p->col = (Mot *)calloc(n, sizeof(Mot)); p->col_poc = (int *)calloc(n * 2, sizeof(int)); p->col_lt = (uint8_t *)calloc(n, 1); p->col_intra = (uint8_t *)calloc(n, 1);
+    p->col = (Mot *)calloc(n, sizeof(Mot)); p->col_poc = (int *)calloc(n * 2, sizeof(int)); p->col_lt = (uint8_t *)calloc(n, 1);
+    p->col_intra = (uint8_t *)calloc(n, 1);
 }
 
 /* ------------------------------ procedural content ------------------------------ */
@@ -270,7 +274,8 @@ static void intra_edges(Enc *e, int x0, int y0, int n, int c, int *r) {
         a = avail(e, xl, yl, xx << sc, yl - 1); if (a && cip && e->pm[I4(e, xx << sc, yl - 1)] != 2) a = 0;
         for (int k = 0; k < unit; k++) { ok[2 * n + 1 + i + k] = (uint8_t)a; if (a) r[2 * n + 1 + i + k] = pl[(y0 - 1) * st + x0 + i + k]; }
     }
-    { int a = avail(e, xl, yl, xl - 1, yl - 1); if (a && cip && e->pm[I4(e, xl - 1, yl - 1)] != 2) a = 0; ok[2 * n] = (uint8_t)a; if (a) r[2 * n] = pl[(y0 - 1) * st + x0 - 1]; }
+    { int a = avail(e, xl, yl, xl - 1, yl - 1); if (a && cip && e->pm[I4(e, xl - 1, yl - 1)] != 2) a = 0; ok[2 * n] = (uint8_t)a;
+        if (a) r[2 * n] = pl[(y0 - 1) * st + x0 - 1]; }
     int first = -1;
     for (int i = 0; i <= 4 * n; i++) if (ok[i]) { first = i; break; }
     if (first < 0) { for (int i = 0; i <= 4 * n; i++) r[i] = 128; return; }
@@ -358,7 +363,8 @@ static void inter_block(Enc *e, const Mot *m, int c, int xp, int yp, int w, int 
         if (!s->wp_on) v = m->pf == 3 ? (a[i] + b[i] + 64) >> 7 : (a[i] + 32) >> 6;
         else {
             int ld = s->wp_denom[c ? 1 : 0] + 6;
-            if (m->pf == 3) v = (a[i] * s->wp_w[0][m->ref[0]][c] + b[i] * s->wp_w[1][m->ref[1]][c] + ((s->wp_o[0][m->ref[0]][c] + s->wp_o[1][m->ref[1]][c] + 1) << ld)) >> (ld + 1);
+            if (m->pf == 3)
+                v = (a[i] * s->wp_w[0][m->ref[0]][c] + b[i] * s->wp_w[1][m->ref[1]][c] + ((s->wp_o[0][m->ref[0]][c] + s->wp_o[1][m->ref[1]][c] + 1) << ld)) >> (ld + 1);
             else { int l = m->pf == 1 ? 0 : 1; v = ((a[i] * s->wp_w[l][m->ref[l]][c] + (1 << (ld - 1))) >> ld) + s->wp_o[l][m->ref[l]][c]; }
         }
         dst[y * dstride + x] = (uint8_t)CLIP1(v);
@@ -389,7 +395,8 @@ static int temporal_cand(Enc *e, int xp, int yp, int w, int h, int X, int ridx, 
         const Mot *cm = &col->col[ce];
         int l;
         if (!(cm->pf & 1)) l = 1; else if (!(cm->pf & 2)) l = 0;
-        else { int nb = 1; for (int k = 0; k < 2; k++) for (int i = 0; i < s->n_ref[k]; i++) if (s->ref_poc[k][i] > e->cur->poc) nb = 0; l = nb ? X : s->col_l0; }
+        else { int nb = 1; for (int k = 0; k < 2; k++) for (int i = 0; i < s->n_ref[k]; i++) if (s->ref_poc[k][i] > e->cur->poc) nb = 0;
+            l = nb ? X : s->col_l0; }
         int lt = (col->col_lt[ce] >> l) & 1;
         if (lt != s->ref_lt[X][ridx]) continue;
         int cd = col->poc - col->col_poc[ce * 2 + l], bd = e->cur->poc - s->ref_poc[X][ridx];
@@ -432,12 +439,14 @@ static int merge_list(Enc *e, int xcb, int ycb, int ncb, int xp, int yp, int w, 
             const Mot *p = &list[a0[k]], *q = &list[a1[k]];
             if (!(p->pf & 1) || !(q->pf & 2)) continue;
             if (s->ref[0][p->ref[0]] == s->ref[1][q->ref[1]] && p->mv[0][0] == q->mv[1][0] && p->mv[0][1] == q->mv[1][1]) continue;
-            Mot t; t.pf = 3; t.ref[0] = p->ref[0]; t.ref[1] = q->ref[1]; t.mv[0][0] = p->mv[0][0]; t.mv[0][1] = p->mv[0][1]; t.mv[1][0] = q->mv[1][0]; t.mv[1][1] = q->mv[1][1];
+            Mot t; t.pf = 3; t.ref[0] = p->ref[0]; t.ref[1] = q->ref[1]; t.mv[0][0] = p->mv[0][0]; t.mv[0][1] = p->mv[0][1]; t.mv[1][0] = q->mv[1][0];
+            t.mv[1][1] = q->mv[1][1];
             list[n++] = t;
         }
     }
     int nr = s->type == 1 ? s->n_ref[0] : MIN(s->n_ref[0], s->n_ref[1]);
-    for (int z = 0; n < s->max_merge; z++) { Mot t; memset(&t, 0, sizeof t); t.pf = s->type == 1 ? 1 : 3; t.ref[0] = (int8_t)(z < nr ? z : 0); t.ref[1] = (int8_t)(s->type == 1 ? -1 : (z < nr ? z : 0)); list[n++] = t; }
+    for (int z = 0; n < s->max_merge; z++) { Mot t; memset(&t, 0, sizeof t); t.pf = s->type == 1 ? 1 : 3; t.ref[0] = (int8_t)(z < nr ? z : 0);
+        t.ref[1] = (int8_t)(s->type == 1 ? -1 : (z < nr ? z : 0)); list[n++] = t; }
     return n;
 }
 static void merge_fixup(Mot *m, int w, int h) {                        /* 8x4 / 4x8 blocks are never bi-predicted */
@@ -457,11 +466,13 @@ static void amvp_list(Enc *e, int xcb, int ycb, int ncb, int xp, int yp, int w, 
         for (int t = 0; t < 2 && !gotA; t++) { int l = t ? !X : X; if (!((m->pf >> l) & 1)) continue;
             int rp = ns->ref_poc[l][m->ref[l]], rl = ns->ref_lt[l][m->ref[l]];
             if (!scaled ? rp == tp : rl == tl) { gotA = 1; A[0] = m->mv[l][0]; A[1] = m->mv[l][1];
-                if (scaled && !rl && !tl && cur - rp != cur - tp && cur != rp) { A[0] = (int16_t)scale_mv(A[0], cur - rp, cur - tp); A[1] = (int16_t)scale_mv(A[1], cur - rp, cur - tp); } } }
+                if (scaled && !rl && !tl && cur - rp != cur - tp && cur != rp) { A[0] = (int16_t)scale_mv(A[0], cur - rp, cur - tp);
+                    A[1] = (int16_t)scale_mv(A[1], cur - rp, cur - tp); } } }
     }
     for (int k = 0; k < 3 && !gotB; k++) if (okB[k]) {
         const Mot *m = &e->mot[I4(e, bx[k], by[k])]; const Slc *ns = &e->slices[e->slice_of[I4(e, bx[k], by[k])]];
-        for (int t = 0; t < 2 && !gotB; t++) { int l = t ? !X : X; if (((m->pf >> l) & 1) && ns->ref_poc[l][m->ref[l]] == tp) { gotB = 1; B[0] = m->mv[l][0]; B[1] = m->mv[l][1]; } }
+        for (int t = 0; t < 2 && !gotB; t++) { int l = t ? !X : X; if (((m->pf >> l) & 1) && ns->ref_poc[l][m->ref[l]] == tp) { gotB = 1; B[0] = m->mv[l][0];
+            B[1] = m->mv[l][1]; } }
     }
     if (!okA[0] && !okA[1]) {
         if (gotB) { gotA = 1; A[0] = B[0]; A[1] = B[1]; }
@@ -471,7 +482,8 @@ static void amvp_list(Enc *e, int xcb, int ycb, int ncb, int xp, int yp, int w, 
             for (int t = 0; t < 2 && !gotB; t++) { int l = t ? !X : X; if (!((m->pf >> l) & 1)) continue;
                 int rp = ns->ref_poc[l][m->ref[l]], rl = ns->ref_lt[l][m->ref[l]];
                 if (rl == tl) { gotB = 1; B[0] = m->mv[l][0]; B[1] = m->mv[l][1];
-                    if (!rl && !tl && rp != tp && cur != rp) { B[0] = (int16_t)scale_mv(B[0], cur - rp, cur - tp); B[1] = (int16_t)scale_mv(B[1], cur - rp, cur - tp); } } }
+                    if (!rl && !tl && rp != tp && cur != rp) { B[0] = (int16_t)scale_mv(B[0], cur - rp, cur - tp);
+                        B[1] = (int16_t)scale_mv(B[1], cur - rp, cur - tp); } } }
         }
     }
     int n = 0;
@@ -508,7 +520,8 @@ static void inv_residual(const Enc *e, const int16_t *lev, int *res, int log2, i
     int d[32 * 32], shift = log2 + 3, scale = hg_level_scale[qp % 6] << (qp / 6);
     const uint8_t *m = e->sf[log2 - 2][log2 == 5 ? (intra ? 0 : 1) : (intra ? 0 : 3) + c];
     int flat = !e->sf_on || (tskip && n > 4);
-    for (int i = 0; i < n * n; i++) d[i] = lev[i] ? CLIP3(-32768, 32767, (int)(((int64_t)lev[i] * (flat ? 16 : m[i]) * scale + (1 << (shift - 1))) >> shift)) : 0;
+    for (int i = 0; i < n * n; i++) d[i] = lev[i] ? CLIP3(-32768, 32767,
+        (int)(((int64_t)lev[i] * (flat ? 16 : m[i]) * scale + (1 << (shift - 1))) >> shift)) : 0;
     if (tskip) { for (int i = 0; i < n * n; i++) res[i] = ((d[i] << 7) + 2048) >> 12; return; }
     int dst = intra && c == 0 && n == 4, g[32 * 32];
     for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) {          /* vertical stage: sample y of column x */
@@ -539,7 +552,8 @@ static void scan_xy(int idx, int log2, int i, int *x, int *y) {
     if (idx == 1) { *x = i & (n - 1); *y = i >> log2; return; }
     if (idx == 2) { *x = i >> log2; *y = i & (n - 1); return; }
     int k = 0;
-    for (int s = 0; s < 2 * n - 1; s++) for (int xx = 0; xx <= s; xx++) { int yy = s - xx; if (xx < n && yy < n) { if (k == i) { *x = xx; *y = yy; return; } k++; } }
+    for (int s = 0; s < 2 * n - 1; s++) for (int xx = 0; xx <= s; xx++) { int yy = s - xx; if (xx < n && yy < n) { if (k == i) { *x = xx; *y = yy; return; }
+        k++; } }
 }
 static void put_last_prefix(Cab *cb, int base, int log2, int c, int v) {
     int cmax = 2 * log2 - 1, off = c ? 15 : 3 * (log2 - 2) + ((log2 - 1) >> 2), sh = c ? log2 - 2 : (log2 + 1) >> 2;
@@ -549,7 +563,8 @@ static void put_last_prefix(Cab *cb, int base, int log2, int c, int v) {
 static void last_split(int pos, int *prefix, int *suffix, int *nbits) {
     if (pos < 4) { *prefix = pos; *nbits = 0; *suffix = 0; return; }
     int p = 4;
-    for (;; p++) { int nb = (p >> 1) - 1, base = (1 << nb) * (2 + (p & 1)); if (pos >= base && pos < base + (1 << nb)) { *prefix = p; *nbits = nb; *suffix = pos - base; return; } }
+    for (;; p++) { int nb = (p >> 1) - 1, base = (1 << nb) * (2 + (p & 1)); if (pos >= base && pos < base + (1 << nb)) { *prefix = p; *nbits = nb;
+        *suffix = pos - base; return; } }
 }
 /* make the levels of one transform block expressible and (with sign hiding) parity-consistent; returns 1 when any level is non-zero */
 static int shape_levels(const Enc *e, int16_t *lev, int log2, int scan, int bypass) {
@@ -559,7 +574,8 @@ static int shape_levels(const Enc *e, int16_t *lev, int log2, int scan, int bypa
     for (int sb = 0; sb < nsb; sb++) {
         int xs, ys, first = -1, last = -1, sum = 0, xp, yp;
         scan_xy(scan, log2 - 2, sb, &xs, &ys);
-        for (int k = 0; k < 16; k++) { scan_xy(scan, 2, k, &xp, &yp); int v = lev[((ys << 2) + yp) * n + (xs << 2) + xp]; if (v) { if (first < 0) first = k; last = k; sum += ABS(v); } }
+        for (int k = 0; k < 16; k++) { scan_xy(scan, 2, k, &xp, &yp); int v = lev[((ys << 2) + yp) * n + (xs << 2) + xp]; if (v) { if (first < 0) first = k;
+            last = k; sum += ABS(v); } }
         if (first < 0 || last - first <= 3) continue;
         scan_xy(scan, 2, first, &xp, &yp);                             /* lowest scan position = the coefficient whose sign is hidden */
         int16_t *f = &lev[((ys << 2) + yp) * n + (xs << 2) + xp];
@@ -575,7 +591,8 @@ static void write_residual(Enc *e, const int16_t *lev, int log2, int c, int scan
     Cab *cb = &e->cab; int n = 1 << log2, nsl = log2 - 2, nsb = 1 << nsl;
     if (e->p.tskip && !bypass && log2 == 2) cab_enc(cb, HG_CTX_TSKIP + (c ? 1 : 0), tskip);
     int last_sb = -1, last_pos = -1, xs, ys, xp, yp;
-    for (int sb = nsb * nsb - 1; sb >= 0 && last_sb < 0; sb--) { scan_xy(scan, nsl, sb, &xs, &ys); for (int k = 15; k >= 0; k--) { scan_xy(scan, 2, k, &xp, &yp); if (lev[((ys << 2) + yp) * n + (xs << 2) + xp]) { last_sb = sb; last_pos = k; break; } } }
+    for (int sb = nsb * nsb - 1; sb >= 0 && last_sb < 0; sb--) { scan_xy(scan, nsl, sb, &xs, &ys); for (int k = 15; k >= 0; k--) {
+        scan_xy(scan, 2, k, &xp, &yp); if (lev[((ys << 2) + yp) * n + (xs << 2) + xp]) { last_sb = sb; last_pos = k; break; } } }
     scan_xy(scan, nsl, last_sb, &xs, &ys); scan_xy(scan, 2, last_pos, &xp, &yp);
     int lx = (xs << 2) + xp, ly = (ys << 2) + yp;
     if (scan == 2) { int t = lx; lx = ly; ly = t; }
@@ -602,7 +619,8 @@ static void write_residual(Enc *e, const int16_t *lev, int log2, int c, int scan
             if (log2 == 2) { static const uint8_t map[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8}; sc = map[(yc << 2) + xc]; }
             else if (xc + yc == 0) sc = 0;
             else {
-                sc = prev == 0 ? (xp + yp == 0 ? 2 : (xp + yp < 3 ? 1 : 0)) : prev == 1 ? (yp == 0 ? 2 : (yp == 1 ? 1 : 0)) : prev == 2 ? (xp == 0 ? 2 : (xp == 1 ? 1 : 0)) : 2;
+                sc = prev == 0 ? (xp + yp == 0 ? 2 : (xp + yp < 3 ? 1 : 0)) : prev == 1 ? (yp == 0 ? 2 : (yp == 1 ? 1 : 0)) : prev == 2 ?
+                    (xp == 0 ? 2 : (xp == 1 ? 1 : 0)) : 2;
                 if (c == 0) { if (xs + ys > 0) sc += 3; sc += log2 == 3 ? (scan == 0 ? 9 : 15) : 21; } else sc += log2 == 3 ? 9 : 12;
             }
             cab_enc(cb, HG_CTX_SIG + (c ? 27 + sc : sc), v16[k] != 0);
@@ -689,17 +707,21 @@ static int decide_tt(Enc *e, Cu *cu, int x0, int y0, int xb, int yb, int log2, i
     memset(t, 0, sizeof *t); t->x = x0; t->y = y0; t->log2 = log2; t->depth = depth; t->blk = blk; t->xb = xb; t->yb = yb;
     const HevcGenParams *p = &e->p;
     int inter_split = p->depth_inter == 0 && !cu->intra && cu->part != 0 && depth == 0;
-    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) t->split = rnd_n(&e->rng, p->mode ? 2 : 5) == 0;
+    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) t->split = rnd_n(&e->rng,
+        p->mode ? 2 : 5) == 0;
     else t->split = log2 > p->max_tb_log2 || (cu->intra_split && depth == 0) || inter_split;
     if (t->split) {
         int h = 1 << (log2 - 1);
-        for (int k = 0; k < 4; k++) { int ch = decide_tt(e, cu, x0 + (k & 1) * h, y0 + (k >> 1) * h, x0, y0, log2 - 1, depth + 1, k); t = &cu->tu[id]; t->child[k] = ch; }
-        for (int k = 0; k < 4; k++) { const Tu *c = &cu->tu[t->child[k]]; t->cbf[0] |= c->cbf[0]; if (log2 > 3) { t->cbf[1] |= c->cbf[1]; t->cbf[2] |= c->cbf[2]; } }
+        for (int k = 0; k < 4; k++) { int ch = decide_tt(e, cu, x0 + (k & 1) * h, y0 + (k >> 1) * h, x0, y0, log2 - 1, depth + 1, k); t = &cu->tu[id];
+            t->child[k] = ch; }
+        for (int k = 0; k < 4; k++) { const Tu *c = &cu->tu[t->child[k]]; t->cbf[0] |= c->cbf[0]; if (log2 > 3) { t->cbf[1] |= c->cbf[1];
+            t->cbf[2] |= c->cbf[2]; } }
         if (log2 == 3) { const Tu *c3 = &cu->tu[t->child[3]]; t->cbf[1] = c3->cbf[1]; t->cbf[2] = c3->cbf[2]; }
         return id;
     }
     int n = 1 << log2;
-    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) { if (x == x0) e->edges[I4(e, x, y)] |= 1; if (y == y0) e->edges[I4(e, x, y)] |= 2; }
+    for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) { if (x == x0) e->edges[I4(e, x, y)] |= 1;
+        if (y == y0) e->edges[I4(e, x, y)] |= 2; }
     t->cbf[0] = code_tb(e, cu, t, x0, y0, log2, 0, x0, y0);
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->cbf[I4(e, x, y)] = (uint8_t)t->cbf[0];
     if (log2 > 2) for (int c = 1; c < 3; c++) t->cbf[c] = code_tb(e, cu, t, x0 >> 1, y0 >> 1, log2 - 1, c, x0, y0);
@@ -709,7 +731,8 @@ static int decide_tt(Enc *e, Cu *cu, int x0, int y0, int xb, int yb, int log2, i
 static void write_tt(Enc *e, Cu *cu, int id, int pcb, int pcr) {
     Tu *t = &cu->tu[id]; Cab *cb = &e->cab; const HevcGenParams *p = &e->p;
     int log2 = t->log2, depth = t->depth;
-    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) cab_enc(cb, HG_CTX_SPLIT_TF + 5 - log2, t->split);
+    if (log2 <= p->max_tb_log2 && log2 > p->min_tb_log2 && depth < cu->max_depth && !(cu->intra_split && depth == 0)) cab_enc(cb, HG_CTX_SPLIT_TF + 5 - log2,
+        t->split);
     int ccb = pcb, ccr = pcr;
     if (log2 > 2) {
         /* a split 8x8 node carries the chroma of its four 4x4 children; deeper nodes the OR over their subtree */
@@ -724,13 +747,16 @@ static void write_tt(Enc *e, Cu *cu, int id, int pcb, int pcr) {
         if (p->dqp && !e->dqp_coded) {
             int v = e->dqp_val, a = ABS(v);
             cab_enc(cb, HG_CTX_CU_QP_DELTA, a > 0);
-            if (a > 0) { for (int i = 1; i < MIN(a, 5); i++) cab_enc(cb, HG_CTX_CU_QP_DELTA + 1, 1); if (a < 5) cab_enc(cb, HG_CTX_CU_QP_DELTA + 1, 0); else cab_egk(cb, 0, (uint32_t)(a - 5)); cab_byp(cb, v < 0); }
+            if (a > 0) { for (int i = 1; i < MIN(a, 5); i++) cab_enc(cb, HG_CTX_CU_QP_DELTA + 1, 1); if (a < 5) cab_enc(cb, HG_CTX_CU_QP_DELTA + 1, 0);
+                else cab_egk(cb, 0, (uint32_t)(a - 5)); cab_byp(cb, v < 0); }
             e->dqp_coded = 1;
         }
     }
     if (cbf_y) write_residual(e, t->lev[0], log2, 0, scan_of(e, cu, t->x, t->y, log2, 0), t->tskip[0], cu->bypass);
-    if (log2 > 2) { for (int c = 1; c < 3; c++) if (c == 1 ? ccb : ccr) write_residual(e, t->lev[c], log2 - 1, c, scan_of(e, cu, t->x, t->y, log2 - 1, c), t->tskip[c], cu->bypass); }
-    else if (t->blk == 3) { for (int c = 1; c < 3; c++) if (c == 1 ? ccb : ccr) write_residual(e, t->lev[c], 2, c, scan_of(e, cu, t->xb, t->yb, 2, c), t->tskip[c], cu->bypass); }
+    if (log2 > 2) { for (int c = 1; c < 3; c++) if (c == 1 ? ccb : ccr) write_residual(e, t->lev[c], log2 - 1, c, scan_of(e, cu, t->x, t->y, log2 - 1, c),
+        t->tskip[c], cu->bypass); }
+    else if (t->blk == 3) { for (int c = 1; c < 3; c++) if (c == 1 ? ccb : ccr) write_residual(e, t->lev[c], 2, c, scan_of(e, cu, t->xb, t->yb, 2, c),
+        t->tskip[c], cu->bypass); }
 }
 
 /* 8.6.1 prediction of the luma QP for the quantisation group that holds (xcb, ycb) */
@@ -743,14 +769,16 @@ static int qp_pred(const Enc *e, int xcb, int ycb) {
     return (a + b + 1) >> 1;
 }
 
-static int sad_block(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h) { int s = 0; for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) s += ABS(a[y * as + x] - b[y * bs + x]); return s; }
+static int sad_block(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h) { int s = 0;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) s += ABS(a[y * as + x] - b[y * bs + x]); return s; }
 static int sad_mot(Enc *e, const Mot *m, int x, int y, int w, int h) {
     static __thread uint8_t tmp[64 * 64];
     inter_block(e, m, 0, x, y, w, h, tmp, w);
     return sad_block(tmp, w, e->src.pl[0] + y * e->src.stride[0] + x, e->src.stride[0], w, h);
 }
 static void store_motion(Enc *e, const Mot *m, int x0, int y0, int w, int h) {
-    for (int y = y0; y < y0 + h; y += 4) for (int x = x0; x < x0 + w; x += 4) { e->mot[I4(e, x, y)] = *m; if (x == x0) e->edges[I4(e, x, y)] |= 4; if (y == y0) e->edges[I4(e, x, y)] |= 8; }
+    for (int y = y0; y < y0 + h; y += 4) for (int x = x0; x < x0 + w; x += 4) { e->mot[I4(e, x, y)] = *m; if (x == x0) e->edges[I4(e, x, y)] |= 4;
+        if (y == y0) e->edges[I4(e, x, y)] |= 8; }
 }
 /* choose the motion of one prediction unit and store it */
 static void decide_pu(Enc *e, Cu *cu, Pu *pu, int part_idx, int force_merge) {
@@ -758,7 +786,8 @@ static void decide_pu(Enc *e, Cu *cu, Pu *pu, int part_idx, int force_merge) {
     Mot list[6]; int n = merge_list(e, cu->x, cu->y, 1 << cu->log2, pu->x, pu->y, pu->w, pu->h, part_idx, cu->part, list);
     int best_merge = 0, best_cost = 1 << 30;
     if (fuzz) best_merge = rnd_n(r, n);
-    else for (int i = 0; i < n; i++) { Mot t = list[i]; merge_fixup(&t, pu->w, pu->h); int c = sad_mot(e, &t, pu->x, pu->y, pu->w, pu->h) + 8 * i; if (c < best_cost) { best_cost = c; best_merge = i; } }
+    else for (int i = 0; i < n; i++) { Mot t = list[i]; merge_fixup(&t, pu->w, pu->h); int c = sad_mot(e, &t, pu->x, pu->y, pu->w, pu->h) + 8 * i;
+        if (c < best_cost) { best_cost = c; best_merge = i; } }
     int use_merge = force_merge || (fuzz ? rnd_n(r, 2) : 0);
     Mot am; memset(&am, 0, sizeof am); am.ref[0] = am.ref[1] = -1;
     if (!force_merge) {
@@ -773,17 +802,21 @@ static void decide_pu(Enc *e, Cu *cu, Pu *pu, int part_idx, int force_merge) {
             int16_t cand[2][2]; amvp_list(e, cu->x, cu->y, 1 << cu->log2, pu->x, pu->y, pu->w, pu->h, part_idx, l, ri, cand);
             pu->ref[l] = ri; am.ref[l] = (int8_t)ri; am.pf |= (uint8_t)(1 << l);
             int16_t mv[2];
-            if (fuzz) { int k = rnd_n(r, 2); pu->mvp[l] = k; int big = rnd_n(r, 16) == 0; for (int d = 0; d < 2; d++) { int t = cand[k][d] + (big ? rnd_n(r, 1025) - 512 : rnd_n(r, 33) - 16); mv[d] = (int16_t)CLIP3(-2048, 2047, t); }; }
+            if (fuzz) { int k = rnd_n(r, 2); pu->mvp[l] = k; int big = rnd_n(r, 16) == 0; for (int d = 0; d < 2; d++) {
+                int t = cand[k][d] + (big ? rnd_n(r, 1025) - 512 : rnd_n(r, 33) - 16); mv[d] = (int16_t)CLIP3(-2048, 2047, t); }; }
             else {
                 /* true motion of the panning texture relative to the reference, plus a small search */
                 int dpoc = e->cur->poc - s->ref_poc[l][ri], gx = 0, gy = 0;
-                { int t0 = e->cur->poc, t1 = t0 - dpoc; gx = ((64 + (t1 * 3) % 96) - (64 + (t0 * 3) % 96)) * 4; gy = ((64 + (t1 * 2) % 64) - (64 + (t0 * 2) % 64)) * 4; }
+                { int t0 = e->cur->poc, t1 = t0 - dpoc; gx = ((64 + (t1 * 3) % 96) - (64 + (t0 * 3) % 96)) * 4;
+                    gy = ((64 + (t1 * 2) % 64) - (64 + (t0 * 2) % 64)) * 4; }
                 int bestc = 1 << 30; int16_t bmv[2] = {0, 0};
                 for (int k = 0; k < 6; k++) {
                     Mot t; memset(&t, 0, sizeof t); t.pf = (uint8_t)(1 << l); t.ref[l] = (int8_t)ri; t.ref[!l] = -1;
                     int16_t tv[2];
-                    if (k == 0) { tv[0] = (int16_t)gx; tv[1] = (int16_t)gy; } else if (k == 1) { tv[0] = cand[0][0]; tv[1] = cand[0][1]; } else if (k == 2) { tv[0] = cand[1][0]; tv[1] = cand[1][1]; }
-                    else { tv[0] = (int16_t)(gx + rnd_n(r, 4 * e->p.search + 1) - 2 * e->p.search); tv[1] = (int16_t)(gy + rnd_n(r, 4 * e->p.search + 1) - 2 * e->p.search); }
+                    if (k == 0) { tv[0] = (int16_t)gx; tv[1] = (int16_t)gy; } else if (k == 1) { tv[0] = cand[0][0]; tv[1] = cand[0][1]; } else if (k == 2) {
+                        tv[0] = cand[1][0]; tv[1] = cand[1][1]; }
+                    else { tv[0] = (int16_t)(gx + rnd_n(r, 4 * e->p.search + 1) - 2 * e->p.search);
+                        tv[1] = (int16_t)(gy + rnd_n(r, 4 * e->p.search + 1) - 2 * e->p.search); }
                     tv[0] = (int16_t)CLIP3(-2048, 2047, tv[0]); tv[1] = (int16_t)CLIP3(-2048, 2047, tv[1]);
                     t.mv[l][0] = tv[0]; t.mv[l][1] = tv[1];
                     int c = sad_mot(e, &t, pu->x, pu->y, pu->w, pu->h);
@@ -807,7 +840,8 @@ static void write_pu(Enc *e, const Cu *cu, const Pu *pu) {
     Cab *cb = &e->cab; const Slc *s = e->sl;
     if (!cu->skip) cab_enc(cb, HG_CTX_MERGE_FLAG, pu->merge);
     if (pu->merge) {
-        if (s->max_merge > 1) { cab_enc(cb, HG_CTX_MERGE_IDX, pu->merge_idx > 0); for (int i = 1; i < s->max_merge - 1 && i <= pu->merge_idx; i++) cab_byp(cb, pu->merge_idx > i); }
+        if (s->max_merge > 1) { cab_enc(cb, HG_CTX_MERGE_IDX, pu->merge_idx > 0);
+            for (int i = 1; i < s->max_merge - 1 && i <= pu->merge_idx; i++) cab_byp(cb, pu->merge_idx > i); }
         return;
     }
     if (s->type == 0) {
@@ -816,7 +850,8 @@ static void write_pu(Enc *e, const Cu *cu, const Pu *pu) {
     }
     for (int l = 0; l < 2; l++) {
         if (pu->idc == (l ? 0 : 1)) continue;
-        if (s->n_ref[l] > 1) { int cmax = s->n_ref[l] - 1; for (int i = 0; i < cmax && i <= pu->ref[l]; i++) { int b = pu->ref[l] > i; if (i < 2) cab_enc(cb, HG_CTX_REF_IDX + i, b); else cab_byp(cb, b); } }
+        if (s->n_ref[l] > 1) { int cmax = s->n_ref[l] - 1; for (int i = 0; i < cmax && i <= pu->ref[l]; i++) { int b = pu->ref[l] > i;
+            if (i < 2) cab_enc(cb, HG_CTX_REF_IDX + i, b); else cab_byp(cb, b); } }
         if (!(l == 1 && s->mvd_l1_zero && pu->idc == 2)) {
             int ax = ABS(pu->mvd[l][0]), ay = ABS(pu->mvd[l][1]);
             cab_enc(cb, HG_CTX_MVD_G0, ax > 0); cab_enc(cb, HG_CTX_MVD_G0, ay > 0);
@@ -849,13 +884,16 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
     int intra = s->type == 2;
     if (!intra) {
         if (fuzz) intra = rnd_n(r, 5) == 0;
-        else { int act = 0; const uint8_t *sp = e->src.pl[0] + y0 * e->src.stride[0] + x0; for (int y = 0; y < n; y += 2) for (int x = 0; x < n; x += 2) act += ABS(sp[y * e->src.stride[0] + x] - sp[y * e->src.stride[0] + x + 1]); intra = rnd_n(r, 24) == 0 || (act < n * n / 8 && rnd_n(r, 3) == 0); }
+        else { int act = 0; const uint8_t *sp = e->src.pl[0] + y0 * e->src.stride[0] + x0;
+            for (int y = 0; y < n; y += 2) for (int x = 0; x < n; x += 2) act += ABS(sp[y * e->src.stride[0] + x] - sp[y * e->src.stride[0] + x + 1]);
+            intra = rnd_n(r, 24) == 0 || (act < n * n / 8 && rnd_n(r, 3) == 0); }
     }
     if (p->pcm == 3) intra = 1;                                         /* known-answer streams: every coding unit I_PCM with 8-bit samples */
     cu->intra = intra;
     for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
         int i = I4(e, x, y);
-        e->pm[i] = (uint8_t)(intra ? 2 : 1); e->skip[i] = 0; e->nofilt[i] = (uint8_t)cu->bypass; e->slice_of[i] = (int16_t)(e->sl - e->slices); e->edges[i] = 0; e->cbf[i] = 0; e->ipm[i] = 1;
+        e->pm[i] = (uint8_t)(intra ? 2 : 1); e->skip[i] = 0; e->nofilt[i] = (uint8_t)cu->bypass; e->slice_of[i] = (int16_t)(e->sl - e->slices); e->edges[i] = 0;
+        e->cbf[i] = 0; e->ipm[i] = 1;
         memset(&e->mot[i], 0, sizeof(Mot)); e->mot[i].ref[0] = e->mot[i].ref[1] = -1;
         if (x == x0) e->edges[i] |= 5;
         if (y == y0) e->edges[i] |= 10;
@@ -864,8 +902,11 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
         cu->pcm = p->pcm && log2 <= MIN(5, p->ctb_log2) && (p->pcm == 3 || rnd_n(r, fuzz ? 10 : 40) == 0);
         cu->part = (!cu->pcm && log2 == p->min_cb_log2 && rnd_n(r, 3) == 0) ? 3 : 0;
         if (cu->pcm) {
-            for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) { int bits = p->pcm == 3 ? 8 : (c ? 6 : 7); e->cur->pl[c][y * e->cur->stride[c] + x] = (uint8_t)((e->src.pl[c][y * e->src.stride[c] + x] >> (8 - bits)) << (8 - bits)); } }
-            if (p->pcm == 1 || p->pcm == 3) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->nofilt[I4(e, x, y)] = 1;   /* pcm_loop_filter_disabled_flag */
+            for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) {
+                int bits = p->pcm == 3 ? 8 : (c ? 6 : 7);
+                e->cur->pl[c][y * e->cur->stride[c] + x] = (uint8_t)((e->src.pl[c][y * e->src.stride[c] + x] >> (8 - bits)) << (8 - bits)); } }
+            if (p->pcm == 1 || p->pcm == 3) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) e->nofilt[I4(e, x, y)] = 1;
+            /* pcm_loop_filter_disabled_flag */
         } else {
             int np = cu->part == 3 ? 2 : 1, pb = n / np;
             cu->intra_split = np == 2;
@@ -876,13 +917,16 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
                 else {                                                  /* SAD over a handful of modes predicted from the real neighbours */
                     static uint8_t tmp[64 * 64]; int tryl[7] = {0, 1, 26, 10, cand[0], 2 + rnd_n(r, 33), 2 + rnd_n(r, 33)}, best = 1 << 30; mode = 0;
                     int pl = MIN(pb, 32) == pb ? log2 - (np == 2) : 5;
-                    if (pb <= 32) for (int t = 0; t < 7; t++) { intra_predict(e, xp, yp, pl, 0, tryl[t], tmp, pb); int c = sad_block(tmp, pb, e->src.pl[0] + yp * e->src.stride[0] + xp, e->src.stride[0], pb, pb); if (c < best) { best = c; mode = tryl[t]; } }
+                    if (pb <= 32) for (int t = 0; t < 7; t++) { intra_predict(e, xp, yp, pl, 0, tryl[t], tmp, pb);
+                        int c = sad_block(tmp, pb, e->src.pl[0] + yp * e->src.stride[0] + xp, e->src.stride[0], pb, pb); if (c < best) { best = c;
+                        mode = tryl[t]; } }
                     else mode = tryl[rnd_n(r, 7)];
                 }
                 cu->ipm[k] = mode;
                 int mi = -1; for (int i = 0; i < 3; i++) if (cand[i] == mode) mi = i;
                 cu->prev_flag[k] = mi >= 0; cu->mpm_idx[k] = mi;
-                if (mi < 0) { int srt[3] = {cand[0], cand[1], cand[2]}, t; if (srt[0] > srt[1]) { t = srt[0]; srt[0] = srt[1]; srt[1] = t; } if (srt[0] > srt[2]) { t = srt[0]; srt[0] = srt[2]; srt[2] = t; } if (srt[1] > srt[2]) { t = srt[1]; srt[1] = srt[2]; srt[2] = t; }
+                if (mi < 0) { int srt[3] = {cand[0], cand[1], cand[2]}, t; if (srt[0] > srt[1]) { t = srt[0]; srt[0] = srt[1]; srt[1] = t; }
+                    if (srt[0] > srt[2]) { t = srt[0]; srt[0] = srt[2]; srt[2] = t; } if (srt[1] > srt[2]) { t = srt[1]; srt[1] = srt[2]; srt[2] = t; }
                     int rem = mode; for (int i = 2; i >= 0; i--) if (rem > srt[i]) rem--; cu->rem[k] = rem; }
                 for (int y = yp; y < yp + pb; y += 4) for (int x = xp; x < xp + pb; x += 4) e->ipm[I4(e, x, y)] = (uint8_t)mode;
             }
@@ -911,16 +955,20 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
         }
         cu->n_pu = np;
         int try_skip = part == 0 && rnd_n(r, fuzz ? 4 : 3) == 0;
-        for (int k = 0; k < np; k++) { Pu *pu = &cu->pu[k]; memset(pu, 0, sizeof *pu); pu->x = xs[k]; pu->y = ys[k]; pu->w = w[k]; pu->h = h[k]; decide_pu(e, cu, pu, k, try_skip); }
-        for (int k = 0; k < np; k++) for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0; inter_block(e, &cu->pu[k].m, c, xs[k], ys[k], w[k], h[k], e->cur->pl[c] + (ys[k] >> sc) * e->cur->stride[c] + (xs[k] >> sc), e->cur->stride[c]); }
-        if (try_skip && (fuzz ? rnd_n(r, 2) : sad_block(e->cur->pl[0] + y0 * e->cur->stride[0] + x0, e->cur->stride[0], e->src.pl[0] + y0 * e->src.stride[0] + x0, e->src.stride[0], n, n) < n * n * 3)) cu->skip = 1;
+        for (int k = 0; k < np; k++) { Pu *pu = &cu->pu[k]; memset(pu, 0, sizeof *pu); pu->x = xs[k]; pu->y = ys[k]; pu->w = w[k]; pu->h = h[k];
+            decide_pu(e, cu, pu, k, try_skip); }
+        for (int k = 0; k < np; k++) for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0;
+            inter_block(e, &cu->pu[k].m, c, xs[k], ys[k], w[k], h[k], e->cur->pl[c] + (ys[k] >> sc) * e->cur->stride[c] + (xs[k] >> sc), e->cur->stride[c]); }
+        if (try_skip && (fuzz ? rnd_n(r, 2) : sad_block(e->cur->pl[0] + y0 * e->cur->stride[0] + x0, e->cur->stride[0],
+            e->src.pl[0] + y0 * e->src.stride[0] + x0, e->src.stride[0], n, n) < n * n * 3)) cu->skip = 1;
     }
     if (!cu->pcm && !cu->skip) {
         cu->max_depth = cu->intra ? p->depth_intra + cu->intra_split : p->depth_inter;
         cu->root = decide_tt(e, cu, x0, y0, x0, y0, log2, 0, 0);
         const Tu *rt = &cu->tu[cu->root];
         cu->root_cbf = rt->cbf[0] | rt->cbf[1] | rt->cbf[2];
-        if (!cu->intra && !cu->root_cbf && cu->part == 0 && cu->pu[0].merge) cu->skip = 1;      /* a 2Nx2N merge CU without residual can only be sent as a skipped CU */
+        if (!cu->intra && !cu->root_cbf && cu->part == 0 && cu->pu[0].merge) cu->skip = 1;
+        /* a 2Nx2N merge CU without residual can only be sent as a skipped CU */
     }
     if (cu->skip) for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) { e->skip[I4(e, x, y)] = 1; e->cbf[I4(e, x, y)] = 0; }
     /* QpY of the CU: the delta only exists when it could be sent */
@@ -942,7 +990,8 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
             else {
                 cab_enc(cb, HG_CTX_PART_MODE, pm == 0);
                 if (pm != 0) {
-                    if (log2 == p->min_cb_log2) { cab_enc(cb, HG_CTX_PART_MODE + 1, pm == 1); if (pm != 1 && log2 > 3) cab_enc(cb, HG_CTX_PART_MODE + 2, pm == 2); }
+                    if (log2 == p->min_cb_log2) { cab_enc(cb, HG_CTX_PART_MODE + 1, pm == 1);
+                        if (pm != 1 && log2 > 3) cab_enc(cb, HG_CTX_PART_MODE + 2, pm == 2); }
                     else if (!p->amp) cab_enc(cb, HG_CTX_PART_MODE + 1, pm == 1);
                     else {
                         int hor = pm == 1 || pm == 4 || pm == 5;
@@ -958,12 +1007,15 @@ static void encode_cu(Enc *e, int x0, int y0, int log2) {
             if (cu->pcm) {
                 BitW *w = cb->w;
                 while (w->nbits) bw_put(w, 1, 0);                       /* pcm_alignment_zero_bit */
-                for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0, bits = p->pcm == 3 ? 8 : (c ? 6 : 7); for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) bw_put(w, bits, (uint32_t)(e->cur->pl[c][y * e->cur->stride[c] + x] >> (8 - bits))); }
+                for (int c = 0; c < 3; c++) { int sc = c ? 1 : 0, bits = p->pcm == 3 ? 8 : (c ? 6 : 7);
+                    for (int y = y0 >> sc; y < (y0 + n) >> sc; y++) for (int x = x0 >> sc; x < (x0 + n) >> sc; x++) bw_put(w, bits,
+                    (uint32_t)(e->cur->pl[c][y * e->cur->stride[c] + x] >> (8 - bits))); }
                 cab_start(cb, w);
             } else {
                 int np = cu->part == 3 ? 4 : 1;
                 for (int k = 0; k < np; k++) cab_enc(cb, HG_CTX_PREV_INTRA, cu->prev_flag[k]);
-                for (int k = 0; k < np; k++) { if (cu->prev_flag[k]) { cab_byp(cb, cu->mpm_idx[k] > 0); if (cu->mpm_idx[k] > 0) cab_byp(cb, cu->mpm_idx[k] > 1); } else cab_byp_n(cb, 5, (uint32_t)cu->rem[k]); }
+                for (int k = 0; k < np; k++) { if (cu->prev_flag[k]) { cab_byp(cb, cu->mpm_idx[k] > 0);
+                    if (cu->mpm_idx[k] > 0) cab_byp(cb, cu->mpm_idx[k] > 1); } else cab_byp_n(cb, 5, (uint32_t)cu->rem[k]); }
                 cab_enc(cb, HG_CTX_INTRA_CHROMA, cu->chroma_idx != 4);
                 if (cu->chroma_idx != 4) cab_byp_n(cb, 2, (uint32_t)cu->chroma_idx);
             }
@@ -993,7 +1045,8 @@ static void encode_cqt(Enc *e, int x0, int y0, int log2, int depth) {
         int inc = (avail(e, x0, y0, x0 - 1, y0) && e->depth[I4(e, x0 - 1, y0)] > depth) + (avail(e, x0, y0, x0, y0 - 1) && e->depth[I4(e, x0, y0 - 1)] > depth);
         cab_enc(&e->cab, HG_CTX_SPLIT_CU + inc, split);
     } else split = log2 > p->min_cb_log2;
-    if (p->dqp && log2 >= p->ctb_log2 - (p->dqp - 1)) { e->dqp_coded = 0; e->dqp_val = 0; if (e->qg_open) { e->qp_prev = e->last_cu_qp; e->first_qg = 0; } }   /* qg_open: a coding unit was coded since the last reset */
+    if (p->dqp && log2 >= p->ctb_log2 - (p->dqp - 1)) { e->dqp_coded = 0; e->dqp_val = 0; if (e->qg_open) { e->qp_prev = e->last_cu_qp; e->first_qg = 0; } }
+        /* qg_open: a coding unit was coded since the last reset */
     if (split) {
         int h = n >> 1;
         for (int k = 0; k < 4; k++) { int x = x0 + (k & 1) * h, y = y0 + (k >> 1) * h; if (x < e->W && y < e->H) encode_cqt(e, x, y, log2 - 1, depth + 1); }
@@ -1019,7 +1072,8 @@ static void encode_sao(Enc *e, int rs) {
         else o->type[2] = o->type[1];
         if (!o->type[c]) continue;
         int big = e->p.mode == 1 && rnd_n(r, 4) == 0;
-        for (int i = 0; i < 4; i++) { int a = big ? rnd_n(r, 8) : rnd_n(r, 3); for (int k = 0; k < a; k++) cab_byp(cb, 1); if (a < 7) cab_byp(cb, 0); o->off[c][i] = a; }
+        for (int i = 0; i < 4; i++) { int a = big ? rnd_n(r, 8) : rnd_n(r, 3); for (int k = 0; k < a; k++) cab_byp(cb, 1); if (a < 7) cab_byp(cb, 0);
+            o->off[c][i] = a; }
         if (o->type[c] == 1) {
             for (int i = 0; i < 4; i++) if (o->off[c][i]) { int neg = rnd_n(r, 2); cab_byp(cb, neg); if (neg) o->off[c][i] = -o->off[c][i]; }
             o->band[c] = rnd_n(r, 32); cab_byp_n(cb, 5, (uint32_t)o->band[c]);
@@ -1040,12 +1094,14 @@ static int strength(const Enc *e, int xq, int yq, int vertical) {      /* bS of 
     const Slc *sq = &e->slices[e->slice_of[q]], *sp = &e->slices[e->slice_of[p]];
     if (sq->deblock_off) return 0;
     if (sq->addr != sp->addr && !sq->lf_across) return 0;
-    { int cl = e->p.ctb_log2, cq = (yq >> cl) * e->ctb_w + (xq >> cl), cp = (yp >> cl) * e->ctb_w + (xp >> cl); if (e->tile_of[e->rs2ts[cq]] != e->tile_of[e->rs2ts[cp]] && !e->lf_across_tiles) return 0; }
+    { int cl = e->p.ctb_log2, cq = (yq >> cl) * e->ctb_w + (xq >> cl), cp = (yp >> cl) * e->ctb_w + (xp >> cl);
+        if (e->tile_of[e->rs2ts[cq]] != e->tile_of[e->rs2ts[cp]] && !e->lf_across_tiles) return 0; }
     if (e->pm[q] == 2 || e->pm[p] == 2) return 2;
     if (is_tu && (e->cbf[q] || e->cbf[p])) return 1;
     const Mot *a = &e->mot[q], *b = &e->mot[p];
     const Pic *ra[2] = {0, 0}, *rb[2] = {0, 0}; const int16_t *va[2] = {0, 0}, *vb[2] = {0, 0}; int na = 0, nb = 0;
-    for (int l = 0; l < 2; l++) { if ((a->pf >> l) & 1) { ra[na] = sq->ref[l][a->ref[l]]; va[na++] = a->mv[l]; } if ((b->pf >> l) & 1) { rb[nb] = sp->ref[l][b->ref[l]]; vb[nb++] = b->mv[l]; } }
+    for (int l = 0; l < 2; l++) { if ((a->pf >> l) & 1) { ra[na] = sq->ref[l][a->ref[l]]; va[na++] = a->mv[l]; } if ((b->pf >> l) & 1) {
+        rb[nb] = sp->ref[l][b->ref[l]]; vb[nb++] = b->mv[l]; } }
     if (na != nb) return 1;
 #define DIFF4(u, v) (ABS((u)[0] - (v)[0]) > 3 || ABS((u)[1] - (v)[1]) > 3)
     if (na == 1) return ra[0] != rb[0] || DIFF4(va[0], vb[0]);
@@ -1072,25 +1128,34 @@ static void deblock_picture(Enc *e) {
             uint8_t *q = pic->pl[0] + y * st + x;
             int keep_p = e->nofilt[I4(e, xp, yp)], keep_q = e->nofilt[I4(e, x, y)];
             int d2[2][2];                                               /* second differences of lines 0 and 3, p side / q side */
-            for (int k = 0; k < 2; k++) { const uint8_t *l = q + 3 * k * along; d2[k][0] = ABS(l[-3 * across] - 2 * l[-2 * across] + l[-across]); d2[k][1] = ABS(l[2 * across] - 2 * l[across] + l[0]); }
+            for (int k = 0; k < 2; k++) { const uint8_t *l = q + 3 * k * along; d2[k][0] = ABS(l[-3 * across] - 2 * l[-2 * across] + l[-across]);
+                d2[k][1] = ABS(l[2 * across] - 2 * l[across] + l[0]); }
             int d0 = d2[0][0] + d2[0][1], d3 = d2[1][0] + d2[1][1];
             if (d0 + d3 >= beta) continue;
             int strong = 1;
             for (int k = 0; k < 2; k++) { const uint8_t *l = q + 3 * k * along; int dk = k ? d3 : d0;
-                if (!(2 * dk < (beta >> 2) && ABS(l[-4 * across] - l[-across]) + ABS(l[0] - l[3 * across]) < (beta >> 3) && ABS(l[-across] - l[0]) < ((5 * tc + 1) >> 1))) strong = 0; }
+                if (!(2 * dk < (beta >> 2) && ABS(l[-4 * across] - l[-across]) + ABS(l[0] - l[3 * across]) < (beta >> 3) &&
+                    ABS(l[-across] - l[0]) < ((5 * tc + 1) >> 1))) strong = 0; }
             int side_thr = (beta + (beta >> 1)) >> 3, mod_p1 = d2[0][0] + d2[1][0] < side_thr, mod_q1 = d2[0][1] + d2[1][1] < side_thr;
             for (int k = 0; k < 4; k++) {
                 uint8_t *l = q + k * along;
-                int p3 = l[-4 * across], p2 = l[-3 * across], p1 = l[-2 * across], p0 = l[-across], q0 = l[0], q1 = l[across], q2 = l[2 * across], q3 = l[3 * across];
+                int p3 = l[-4 * across], p2 = l[-3 * across], p1 = l[-2 * across], p0 = l[-across], q0 = l[0], q1 = l[across], q2 = l[2 * across],
+                    q3 = l[3 * across];
                 if (strong) {
-                    if (!keep_p) { l[-across] = (uint8_t)CLIP3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3); l[-2 * across] = (uint8_t)CLIP3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2); l[-3 * across] = (uint8_t)CLIP3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
-                    if (!keep_q) { l[0] = (uint8_t)CLIP3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3); l[across] = (uint8_t)CLIP3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2); l[2 * across] = (uint8_t)CLIP3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3); }
+                    if (!keep_p) { l[-across] = (uint8_t)CLIP3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+                        l[-2 * across] = (uint8_t)CLIP3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+                        l[-3 * across] = (uint8_t)CLIP3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3); }
+                    if (!keep_q) { l[0] = (uint8_t)CLIP3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+                        l[across] = (uint8_t)CLIP3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+                        l[2 * across] = (uint8_t)CLIP3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3); }
                 } else {
                     int dl = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
                     if (ABS(dl) >= 10 * tc) continue;
                     dl = CLIP3(-tc, tc, dl);
-                    if (!keep_p) { l[-across] = (uint8_t)CLIP1(p0 + dl); if (mod_p1) l[-2 * across] = (uint8_t)CLIP1(p1 + CLIP3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + dl) >> 1)); }
-                    if (!keep_q) { l[0] = (uint8_t)CLIP1(q0 - dl); if (mod_q1) l[across] = (uint8_t)CLIP1(q1 + CLIP3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - dl) >> 1)); }
+                    if (!keep_p) { l[-across] = (uint8_t)CLIP1(p0 + dl); if (mod_p1) l[-2 * across] = (uint8_t)CLIP1(p1 + CLIP3(-(tc >> 1), tc >> 1,
+                        (((p2 + p0 + 1) >> 1) - p1 + dl) >> 1)); }
+                    if (!keep_q) { l[0] = (uint8_t)CLIP1(q0 - dl); if (mod_q1) l[across] = (uint8_t)CLIP1(q1 + CLIP3(-(tc >> 1), tc >> 1,
+                        (((q2 + q0 + 1) >> 1) - q1 - dl) >> 1)); }
                 }
             }
         }
@@ -1138,9 +1203,11 @@ static void sao_picture(Enc *e) {
                     for (int k = 0; k < 2; k++) {
                         int xn = (k ? xb : xa) << sc, yn = (k ? yb : ya) << sc, xc = x << sc, yc = y << sc;
                         const Slc *sn = &e->slices[e->slice_of[I4(e, xn, yn)]], *sc_ = &e->slices[e->slice_of[I4(e, xc, yc)]];
-                        if (sn->addr != sc_->addr) { int earlier = zrank(e, xn, yn) < zrank(e, xc, yc); if (earlier ? !sc_->lf_across : !sn->lf_across) bad = 1; }
+                        if (sn->addr != sc_->addr) { int earlier = zrank(e, xn, yn) < zrank(e, xc, yc);
+                            if (earlier ? !sc_->lf_across : !sn->lf_across) bad = 1; }
                         int cl = e->p.ctb_log2;
-                        if (e->tile_of[e->rs2ts[(yn >> cl) * e->ctb_w + (xn >> cl)]] != e->tile_of[e->rs2ts[(yc >> cl) * e->ctb_w + (xc >> cl)]] && !e->lf_across_tiles) bad = 1;
+                        if (e->tile_of[e->rs2ts[(yn >> cl) * e->ctb_w + (xn >> cl)]] != e->tile_of[e->rs2ts[(yc >> cl) * e->ctb_w + (xc >> cl)]] &&
+                            !e->lf_across_tiles) bad = 1;
                     }
                     if (bad) continue;
                     int a = e->dbk[c][ya * st + xa], b = e->dbk[c][yb * st + xb], sgn = SIGN(v - a) + SIGN(v - b);
@@ -1153,10 +1220,12 @@ static void sao_picture(Enc *e) {
 }
 
 /* ------------------------------ scaling lists (7.3.4 / 7.4.5) ------------------------------ */
-static void diag_order(int n, int *xs, int *ys) { int k = 0; for (int s = 0; s < 2 * n - 1; s++) for (int x = 0; x <= s; x++) { int y = s - x; if (x < n && y < n) { xs[k] = x; ys[k] = y; k++; } } }
+static void diag_order(int n, int *xs, int *ys) { int k = 0; for (int s = 0; s < 2 * n - 1; s++) for (int x = 0; x <= s; x++) { int y = s - x;
+    if (x < n && y < n) { xs[k] = x; ys[k] = y; k++; } } }
 static void lists_default(Enc *e) {
     memset(e->sl4, 16, sizeof e->sl4);
-    for (int m = 0; m < 6; m++) { memcpy(e->sl8[m], hg_scaling_default[m >= 3], 64); memcpy(e->sl16[m], hg_scaling_default[m >= 3], 64); memcpy(e->sl32[m], hg_scaling_default[m >= 3], 64); e->dc16[m] = e->dc32[m] = 16; }
+    for (int m = 0; m < 6; m++) { memcpy(e->sl8[m], hg_scaling_default[m >= 3], 64); memcpy(e->sl16[m], hg_scaling_default[m >= 3], 64);
+        memcpy(e->sl32[m], hg_scaling_default[m >= 3], 64); e->dc16[m] = e->dc32[m] = 16; }
 }
 static void lists_expand(Enc *e) {
     int x4[16], y4[16], x8[64], y8[64]; diag_order(4, x4, y4); diag_order(8, x8, y8);
@@ -1183,12 +1252,15 @@ static void write_scaling_list_data(Enc *e, BitW *w) {
             int delta = rnd_n(r, k + 1);
             bw_put(w, 1, 0); bw_ue(w, (uint32_t)delta);
             if (delta == 0) { if (size == 0) memset(list, 16, 16); else memcpy(list, hg_scaling_default[size == 3 ? k : (m >= 3)], 64); if (dc) *dc = 16; }
-            else { int rm = size == 3 ? 3 * (k - delta) : m - delta; const uint8_t *src = size == 0 ? e->sl4[rm] : size == 1 ? e->sl8[rm] : size == 2 ? e->sl16[rm] : e->sl32[rm]; memmove(list, src, (size_t)n); if (dc) *dc = size == 2 ? e->dc16[rm] : e->dc32[rm]; }
+            else { int rm = size == 3 ? 3 * (k - delta) : m - delta;
+                const uint8_t *src = size == 0 ? e->sl4[rm] : size == 1 ? e->sl8[rm] : size == 2 ? e->sl16[rm] : e->sl32[rm]; memmove(list, src, (size_t)n);
+                if (dc) *dc = size == 2 ? e->dc16[rm] : e->dc32[rm]; }
         } else {
             bw_put(w, 1, 1);
             int next = 8;
             if (size > 1) { int d = 4 + rnd_n(r, 60); bw_se(w, d - 8); next = d; *dc = (uint8_t)d; }
-            for (int i = 0; i < n; i++) { int v = choice == 1 ? 8 + i / 2 + rnd_n(r, 9) : 1 + rnd_n(r, 255); int dl = v - next; if (dl > 127) dl -= 256; if (dl < -128) dl += 256; bw_se(w, dl); next = v; list[i] = (uint8_t)v; }
+            for (int i = 0; i < n; i++) { int v = choice == 1 ? 8 + i / 2 + rnd_n(r, 9) : 1 + rnd_n(r, 255); int dl = v - next; if (dl > 127) dl -= 256;
+                if (dl < -128) dl += 256; bw_se(w, dl); next = v; list[i] = (uint8_t)v; }
         }
     }
 }
@@ -1226,7 +1298,8 @@ static void plan_sequence(const HevcGenParams *p, Sched *sc, int *count) {
             }
             s = &sc[n++]; memset(s, 0, sizeof *s); s->t = a; s->type = 1; s->is_ref = 1;
             for (int k = 0; k < p->num_ref && k < 4; k++) if (anchors[k] >= 0) s->l[0][s->n[0]++] = anchors[k];
-            if (p->lt_ref && p->gop == 0 && a >= t0 + 3 && s->n[0] < 4) { int dup = 0; for (int k = 0; k < s->n[0]; k++) dup |= s->l[0][k] == t0; if (!dup) { s->l[0][s->n[0]++] = t0; s->lt = 1; } }
+            if (p->lt_ref && p->gop == 0 && a >= t0 + 3 && s->n[0] < 4) { int dup = 0; for (int k = 0; k < s->n[0]; k++) dup |= s->l[0][k] == t0; if (!dup) {
+                s->l[0][s->n[0]++] = t0; s->lt = 1; } }
             int prev = anchors[0];
             for (int k = 3; k > 0; k--) anchors[k] = anchors[k - 1];
             anchors[0] = a;
@@ -1237,10 +1310,12 @@ static void plan_sequence(const HevcGenParams *p, Sched *sc, int *count) {
                 s->l[1][s->n[1]++] = a; if (p->num_ref > 1) s->l[1][s->n[1]++] = prev;
             } else if (p->gop == 8) {
                 static const int off[7] = {4, 2, 1, 3, 6, 5, 7}, isref[7] = {1, 1, 0, 0, 1, 0, 0};
-                static const int l0[7][2] = {{0, -1}, {0, -1}, {0, -1}, {2, 0}, {4, 0}, {4, 0}, {6, 4}}, l1[7][2] = {{8, -1}, {4, 8}, {2, 4}, {4, 8}, {8, -1}, {6, 8}, {8, -1}};
+                static const int l0[7][2] = {{0, -1}, {0, -1}, {0, -1}, {2, 0}, {4, 0}, {4, 0}, {6, 4}}, l1[7][2] = {{8, -1}, {4, 8}, {2, 4}, {4, 8}, {8, -1},
+                    {6, 8}, {8, -1}};
                 for (int k = 0; k < 7; k++) {
                     s = &sc[n++]; memset(s, 0, sizeof *s); s->t = prev + off[k]; s->type = 0; s->is_ref = isref[k];
-                    for (int j = 0; j < 2; j++) { if (l0[k][j] >= 0 && (j == 0 || p->num_ref > 1)) s->l[0][s->n[0]++] = prev + l0[k][j]; if (l1[k][j] >= 0 && (j == 0 || p->num_ref > 1)) s->l[1][s->n[1]++] = prev + l1[k][j]; }
+                    for (int j = 0; j < 2; j++) { if (l0[k][j] >= 0 && (j == 0 || p->num_ref > 1)) s->l[0][s->n[0]++] = prev + l0[k][j];
+                        if (l1[k][j] >= 0 && (j == 0 || p->num_ref > 1)) s->l[1][s->n[1]++] = prev + l1[k][j]; }
                 }
             }
         }
@@ -1261,7 +1336,9 @@ static void plan_rps(const Sched *sched, int n_sched, int idx, RpsSet *o) {
         int d = sched[j].poc - sc->poc;
         if ((pass == 0 ? -d : d) != dist) continue;
         int needed = 0, used = 0;
-        for (int k = idx; k < n_sched && !sched[k].idr; k++) for (int l = 0; l < 2; l++) for (int i = 0; i < sched[k].n[l]; i++) if (sched[k].l[l][i] == sched[j].t) { needed = 1; if (k == idx) used = 1; }
+        for (int k = idx; k < n_sched &&
+            !sched[k].idr; k++) for (int l = 0; l < 2; l++) for (int i = 0; i < sched[k].n[l];
+            i++) if (sched[k].l[l][i] == sched[j].t) { needed = 1; if (k == idx) used = 1; }
         if (!needed) continue;
         if (pass == 0) { o->dneg[o->n_neg] = d; o->uneg[o->n_neg++] = used; } else { o->dpos[o->n_pos] = d; o->upos[o->n_pos++] = used; }
     }
@@ -1295,7 +1372,8 @@ static int rps_write_inter(BitW *w, const RpsSet *t, const RpsSet *r) {
         /* derive exactly as a decoder would (the order of the result matters) and compare */
         RpsSet o; memset(&o, 0, sizeof o);
         int i = 0;
-        for (int j = r->n_pos - 1; j >= 0; j--) { int dp = r->dpos[j] + d; if (dp < 0 && keep[r->n_neg + j]) { o.dneg[i] = dp; o.uneg[i++] = used[r->n_neg + j]; } }
+        for (int j = r->n_pos - 1; j >= 0; j--) { int dp = r->dpos[j] + d; if (dp < 0 && keep[r->n_neg + j]) { o.dneg[i] = dp;
+            o.uneg[i++] = used[r->n_neg + j]; } }
         if (d < 0 && keep[nr]) { o.dneg[i] = d; o.uneg[i++] = used[nr]; }
         for (int j = 0; j < r->n_neg; j++) { int dp = r->dneg[j] + d; if (dp < 0 && keep[j]) { o.dneg[i] = dp; o.uneg[i++] = used[j]; } }
         o.n_neg = i; i = 0;
@@ -1348,14 +1426,16 @@ static void write_sps(Enc *e, BitW *out, int max_dpb, int reorder) {
     bw_put(&w, 1, p->scaling != 0);
     if (p->scaling) { bw_put(&w, 1, p->scaling == 2); if (p->scaling == 2) write_scaling_list_data(e, &w); }
     bw_put(&w, 1, (uint32_t)p->amp); bw_put(&w, 1, (uint32_t)p->sao); bw_put(&w, 1, p->pcm != 0);
-    if (p->pcm) { bw_put(&w, 4, p->pcm == 3 ? 7 : 6); bw_put(&w, 4, p->pcm == 3 ? 7 : 5); bw_ue(&w, (uint32_t)(p->min_cb_log2 - 3)); bw_ue(&w, (uint32_t)(MIN(5, p->ctb_log2) - p->min_cb_log2)); bw_put(&w, 1, p->pcm == 1 || p->pcm == 3); }
+    if (p->pcm) { bw_put(&w, 4, p->pcm == 3 ? 7 : 6); bw_put(&w, 4, p->pcm == 3 ? 7 : 5); bw_ue(&w, (uint32_t)(p->min_cb_log2 - 3));
+        bw_ue(&w, (uint32_t)(MIN(5, p->ctb_log2) - p->min_cb_log2)); bw_put(&w, 1, p->pcm == 1 || p->pcm == 3); }
     bw_ue(&w, (uint32_t)e->n_sps_sets);                                /* short-term reference picture sets (none: every slice header carries its own) */
     for (int i = 0; i < e->n_sps_sets; i++) {
         if (i == 0) { rps_write_explicit(&w, &e->sps_sets[0]); continue; }
         BitW t; memset(&t, 0, sizeof t);                                /* try inter prediction from the previous set (7.3.7) */
         size_t len0 = w.len; int nb0 = w.nbits; uint32_t cur0 = w.cur;
         bw_put(&w, 1, 1);
-        if (!rps_write_inter(&w, &e->sps_sets[i], &e->sps_sets[i - 1])) { w.len = len0; w.nbits = nb0; w.cur = cur0; bw_put(&w, 1, 0); rps_write_explicit(&w, &e->sps_sets[i]); }
+        if (!rps_write_inter(&w, &e->sps_sets[i], &e->sps_sets[i - 1])) { w.len = len0; w.nbits = nb0; w.cur = cur0; bw_put(&w, 1, 0);
+            rps_write_explicit(&w, &e->sps_sets[i]); }
         (void)t;
     }
     bw_put(&w, 1, (uint32_t)p->lt_ref);
@@ -1381,7 +1461,8 @@ static void write_pps(Enc *e, BitW *out) {
     bw_put(&w, 1, (uint32_t)tiles); bw_put(&w, 1, (uint32_t)p->wpp);
     if (tiles) {
         bw_ue(&w, (uint32_t)(p->tile_cols - 1)); bw_ue(&w, (uint32_t)(p->tile_rows - 1)); bw_put(&w, 1, !e->tile_explicit);
-        if (e->tile_explicit) { for (int i = 0; i + 1 < p->tile_cols; i++) bw_ue(&w, (uint32_t)(e->tile_cb[i + 1] - e->tile_cb[i] - 1)); for (int i = 0; i + 1 < p->tile_rows; i++) bw_ue(&w, (uint32_t)(e->tile_rb[i + 1] - e->tile_rb[i] - 1)); }
+        if (e->tile_explicit) { for (int i = 0; i + 1 < p->tile_cols; i++) bw_ue(&w, (uint32_t)(e->tile_cb[i + 1] - e->tile_cb[i] - 1));
+            for (int i = 0; i + 1 < p->tile_rows; i++) bw_ue(&w, (uint32_t)(e->tile_rb[i + 1] - e->tile_rb[i] - 1)); }
         bw_put(&w, 1, (uint32_t)e->lf_across_tiles);
     }
     bw_put(&w, 1, 1);                                                  /* pps_loop_filter_across_slices_enabled_flag (slices decide) */
@@ -1405,11 +1486,15 @@ typedef struct {                 /* picture-level decisions shared by its slices
     int n_total;
 } PicPlan;
 
-static Pic *find_poc(Enc *e, int poc) { for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref && e->dpb[i].poc == poc) return &e->dpb[i]; return NULL; }
+static Pic *find_poc(Enc *e, int poc) { for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref && e->dpb[i].poc == poc) return &e->dpb[i];
+    return NULL; }
 
 static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int first, int dependent, int seg_addr, const size_t *sizes, int n_entry) {
     const HevcGenParams *p = &e->p;
-    if (getenv("HG_DBG")) fprintf(stderr, "SH type %d poc %d nref %d %d tmvp %d col %d %d mvdl1z %d cabac_init %d wp %d denom %d %d rpsneg %d pos %d nl %d ntotal %d\n", s->type, pp->poc, s->n_ref[0], s->n_ref[1], s->tmvp, s->col_l0, s->col_idx, s->mvd_l1_zero, s->cabac_init, s->wp_on, s->wp_denom[0], s->wp_denom[1], pp->n_neg, pp->n_pos, pp->nl, pp->n_total);
+    if (getenv("HG_DBG")) fprintf(stderr,
+        "SH type %d poc %d nref %d %d tmvp %d col %d %d mvdl1z %d cabac_init %d wp %d denom %d %d rpsneg %d pos %d nl %d ntotal %d\n", s->type, pp->poc,
+        s->n_ref[0], s->n_ref[1], s->tmvp, s->col_l0, s->col_idx, s->mvd_l1_zero, s->cabac_init, s->wp_on, s->wp_denom[0], s->wp_denom[1], pp->n_neg,
+        pp->n_pos, pp->nl, pp->n_total);
     bw_put(w, 1, (uint32_t)first);
     if (pp->nal >= 16 && pp->nal <= 23) bw_put(w, 1, 0);
     bw_ue(w, 0);
@@ -1446,7 +1531,8 @@ static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int f
             }
             if (p->lt_ref) {
                 bw_ue(w, (uint32_t)pp->nl);
-                for (int i = 0; i < pp->nl; i++) { bw_put(w, e->poc_bits, (uint32_t)pp->lt_poc_lsb[i]); bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)pp->lt_msb[i]); if (pp->lt_msb[i]) bw_ue(w, (uint32_t)pp->lt_cycle[i]); }
+                for (int i = 0; i < pp->nl; i++) { bw_put(w, e->poc_bits, (uint32_t)pp->lt_poc_lsb[i]); bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)pp->lt_msb[i]);
+                    if (pp->lt_msb[i]) bw_ue(w, (uint32_t)pp->lt_cycle[i]); }
             }
             if (p->tmvp) bw_put(w, 1, (uint32_t)s->tmvp);
         }
@@ -1464,16 +1550,21 @@ static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int f
             }
             if (s->type == 0) bw_put(w, 1, (uint32_t)s->mvd_l1_zero);
             if (p->cabac_init) bw_put(w, 1, (uint32_t)s->cabac_init);
-            if (s->tmvp) { if (s->type == 0) bw_put(w, 1, (uint32_t)s->col_l0); if ((s->col_l0 ? s->n_ref[0] : s->n_ref[1]) > 1) bw_ue(w, (uint32_t)s->col_idx); }
+            if (s->tmvp) { if (s->type == 0) bw_put(w, 1, (uint32_t)s->col_l0); if ((s->col_l0 ? s->n_ref[0] : s->n_ref[1]) > 1) bw_ue(w,
+                (uint32_t)s->col_idx); }
             if (p->wp) {
                 bw_ue(w, (uint32_t)s->wp_denom[0]); bw_se(w, s->wp_denom[1] - s->wp_denom[0]);
                 for (int l = 0; l < (s->type == 0 ? 2 : 1); l++) {
                     for (int i = 0; i < s->n_ref[l]; i++) bw_put(w, 1, s->wp_w[l][i][0] != (1 << s->wp_denom[0]) || s->wp_o[l][i][0] != 0);
-                    for (int i = 0; i < s->n_ref[l]; i++) bw_put(w, 1, s->wp_w[l][i][1] != (1 << s->wp_denom[1]) || s->wp_o[l][i][1] != 0 || s->wp_w[l][i][2] != (1 << s->wp_denom[1]) || s->wp_o[l][i][2] != 0);
+                    for (int i = 0; i < s->n_ref[l]; i++) bw_put(w, 1, s->wp_w[l][i][1] != (1 << s->wp_denom[1]) || s->wp_o[l][i][1] != 0 ||
+                        s->wp_w[l][i][2] != (1 << s->wp_denom[1]) || s->wp_o[l][i][2] != 0);
                     for (int i = 0; i < s->n_ref[l]; i++) {
-                        if (s->wp_w[l][i][0] != (1 << s->wp_denom[0]) || s->wp_o[l][i][0] != 0) { bw_se(w, s->wp_w[l][i][0] - (1 << s->wp_denom[0])); bw_se(w, s->wp_o[l][i][0]); }
-                        if (s->wp_w[l][i][1] != (1 << s->wp_denom[1]) || s->wp_o[l][i][1] != 0 || s->wp_w[l][i][2] != (1 << s->wp_denom[1]) || s->wp_o[l][i][2] != 0)
-                            for (int c = 1; c < 3; c++) { int wgt = s->wp_w[l][i][c]; bw_se(w, wgt - (1 << s->wp_denom[1])); bw_se(w, s->wp_o[l][i][c] - 128 + ((128 * wgt) >> s->wp_denom[1])); }
+                        if (s->wp_w[l][i][0] != (1 << s->wp_denom[0]) || s->wp_o[l][i][0] != 0) { bw_se(w, s->wp_w[l][i][0] - (1 << s->wp_denom[0]));
+                            bw_se(w, s->wp_o[l][i][0]); }
+                        if (s->wp_w[l][i][1] != (1 << s->wp_denom[1]) || s->wp_o[l][i][1] != 0 || s->wp_w[l][i][2] != (1 << s->wp_denom[1]) ||
+                            s->wp_o[l][i][2] != 0)
+                            for (int c = 1; c < 3; c++) { int wgt = s->wp_w[l][i][c]; bw_se(w, wgt - (1 << s->wp_denom[1]));
+                                bw_se(w, s->wp_o[l][i][c] - 128 + ((128 * wgt) >> s->wp_denom[1])); }
                     }
                 }
             }
@@ -1489,7 +1580,8 @@ static void write_slice_header(Enc *e, BitW *w, const PicPlan *pp, Slc *s, int f
     }
     if (p->wpp || p->tile_cols * p->tile_rows > 1) {
         bw_ue(w, (uint32_t)n_entry);
-        if (n_entry > 0) { size_t mx = 1; for (int i = 0; i < n_entry; i++) if (sizes[i] > mx) mx = sizes[i]; int len = 1; while (((size_t)1 << len) < mx) len++; bw_ue(w, (uint32_t)(len - 1)); for (int i = 0; i < n_entry; i++) bw_put(w, len, (uint32_t)(sizes[i] - 1)); }
+        if (n_entry > 0) { size_t mx = 1; for (int i = 0; i < n_entry; i++) if (sizes[i] > mx) mx = sizes[i]; int len = 1;
+            while (((size_t)1 << len) < mx) len++; bw_ue(w, (uint32_t)(len - 1)); for (int i = 0; i < n_entry; i++) bw_put(w, len, (uint32_t)(sizes[i] - 1)); }
     }
     bw_put(w, 1, 1); while (w->nbits) bw_put(w, 1, 0);                /* byte_alignment() */
 }
@@ -1507,7 +1599,8 @@ static void begin_slice(Enc *e, const PicPlan *pp, const Sched *sc, int addr) {
     s->max_merge = p->merge_cand;
     if (s->type == 2) return;
     s->n_ref[0] = sc->n[0]; s->n_ref[1] = s->type == 0 ? sc->n[1] : 0;
-    if (p->mode == 1 && rnd_n(r, 3) == 0) { s->n_ref[0] = 1 + rnd_n(r, MIN(4, 2 * pp->n_total)); if (s->type == 0) s->n_ref[1] = 1 + rnd_n(r, MIN(4, 2 * pp->n_total)); }
+    if (p->mode == 1 && rnd_n(r, 3) == 0) { s->n_ref[0] = 1 + rnd_n(r, MIN(4, 2 * pp->n_total));
+        if (s->type == 0) s->n_ref[1] = 1 + rnd_n(r, MIN(4, 2 * pp->n_total)); }
     for (int l = 0; l < (s->type == 0 ? 2 : 1); l++) {
         Pic *tmp[32]; int n = 0, want = MAX(s->n_ref[l], pp->n_total);
         while (n < want) {
@@ -1543,7 +1636,8 @@ static void store_col_motion(Enc *e) {
     for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) {
         int i = I4(e, x * 16, y * 16), k = y * cw + x; const Slc *s = &e->slices[e->slice_of[i]];
         p->col_intra[k] = e->pm[i] != 1; p->col[k] = e->mot[i]; p->col_lt[k] = 0;
-        for (int l = 0; l < 2; l++) if ((e->mot[i].pf >> l) & 1) { p->col_poc[2 * k + l] = s->ref_poc[l][e->mot[i].ref[l]]; p->col_lt[k] |= (uint8_t)(s->ref_lt[l][e->mot[i].ref[l]] << l); }
+        for (int l = 0; l < 2; l++) if ((e->mot[i].pf >> l) & 1) { p->col_poc[2 * k + l] = s->ref_poc[l][e->mot[i].ref[l]];
+            p->col_lt[k] |= (uint8_t)(s->ref_lt[l][e->mot[i].ref[l]] << l); }
     }
 }
 
@@ -1559,7 +1653,8 @@ static void tables_init(Enc *e) {                                       /* 6.5.1
     }
     int ts = 0;
     for (int tr = 0; tr < nr; tr++) for (int tc = 0; tc < nc; tc++)
-        for (int y = rb[tr]; y < rb[tr + 1]; y++) for (int x = cb[tc]; x < cb[tc + 1]; x++) { int rs = y * e->ctb_w + x; e->rs2ts[rs] = ts; e->ts2rs[ts] = rs; e->tile_of[ts] = tr * nc + tc; ts++; }
+        for (int y = rb[tr]; y < rb[tr + 1]; y++) for (int x = cb[tc]; x < cb[tc + 1]; x++) { int rs = y * e->ctb_w + x; e->rs2ts[rs] = ts; e->ts2rs[ts] = rs;
+            e->tile_of[ts] = tr * nc + tc; ts++; }
 }
 
 static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, int idx) {
@@ -1572,8 +1667,10 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
     if (!sc->idr) {
         RpsSet rs; plan_rps(sched, n_sched, idx, &rs);
         pp.n_neg = rs.n_neg; pp.n_pos = rs.n_pos;
-        for (int i = 0; i < rs.n_neg; i++) { pp.dneg[i] = rs.dneg[i]; pp.uneg[i] = rs.uneg[i]; if (rs.uneg[i]) pp.before[pp.nb++] = find_poc(e, sc->poc + rs.dneg[i]); }
-        for (int i = 0; i < rs.n_pos; i++) { pp.dpos[i] = rs.dpos[i]; pp.upos[i] = rs.upos[i]; if (rs.upos[i]) pp.after[pp.na++] = find_poc(e, sc->poc + rs.dpos[i]); }
+        for (int i = 0; i < rs.n_neg; i++) { pp.dneg[i] = rs.dneg[i]; pp.uneg[i] = rs.uneg[i];
+            if (rs.uneg[i]) pp.before[pp.nb++] = find_poc(e, sc->poc + rs.dneg[i]); }
+        for (int i = 0; i < rs.n_pos; i++) { pp.dpos[i] = rs.dpos[i]; pp.upos[i] = rs.upos[i];
+            if (rs.upos[i]) pp.after[pp.na++] = find_poc(e, sc->poc + rs.dpos[i]); }
         if (sc->lt) {                                                   /* the IDR picture of the period serves as a long-term reference */
             Pic *pic = find_poc(e, sched[period0].poc);
             int max = 1 << e->poc_bits;
@@ -1583,8 +1680,11 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
             pp.lt_cycle[pp.nl] = ((sc->poc & ~(max - 1)) - (pic->poc & ~(max - 1))) >> e->poc_bits; pp.nl++;
         }
         /* pictures that fell out of the set are no longer references */
-        for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 1) { int keep = 0; for (int k = 0; k < pp.n_neg; k++) keep |= e->dpb[i].poc == sc->poc + pp.dneg[k]; for (int k = 0; k < pp.n_pos; k++) keep |= e->dpb[i].poc == sc->poc + pp.dpos[k]; if (!keep) e->dpb[i].is_ref = 0; }
-        for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 2) { int keep = 0; for (int k = 0; k < pp.nl; k++) keep |= pp.ltc[k] == &e->dpb[i]; if (!keep) e->dpb[i].is_ref = 0; }
+        for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 1) { int keep = 0;
+            for (int k = 0; k < pp.n_neg; k++) keep |= e->dpb[i].poc == sc->poc + pp.dneg[k];
+            for (int k = 0; k < pp.n_pos; k++) keep |= e->dpb[i].poc == sc->poc + pp.dpos[k]; if (!keep) e->dpb[i].is_ref = 0; }
+        for (int i = 0; i < 10; i++) if (e->dpb[i].used && e->dpb[i].is_ref == 2) { int keep = 0;
+            for (int k = 0; k < pp.nl; k++) keep |= pp.ltc[k] == &e->dpb[i]; if (!keep) e->dpb[i].is_ref = 0; }
         pp.n_total = pp.nb + pp.na + pp.nl;
     }
     Pic *cur = NULL;
@@ -1622,13 +1722,15 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
             if (first_in_tile) { if (ts != first_ts || dependent) cab_init_ctx(cb, init_type, s->qp); e->first_qg = 1; e->qg_open = 0; e->qp_prev = s->qp; }
             else if (row_start) {
                 int x0 = rx << p->ctb_log2, y0 = ry << p->ctb_log2;
-                if (avail(e, x0, y0, x0 + e->ctb, y0 - e->ctb) && wpp_valid) { memcpy(cb->st, wpp_st, sizeof wpp_st); memcpy(cb->mps, wpp_mps, sizeof wpp_mps); }
+                if (avail(e, x0, y0, x0 + e->ctb, y0 - e->ctb) && wpp_valid) { memcpy(cb->st, wpp_st, sizeof wpp_st); memcpy(cb->mps, wpp_mps, sizeof wpp_mps);
+                    }
                 else if (ts != first_ts) cab_init_ctx(cb, init_type, s->qp);
                 e->first_qg = 1; e->qg_open = 0; e->qp_prev = s->qp;
             }
             encode_sao(e, rs);
             encode_cqt(e, rx << p->ctb_log2, ry << p->ctb_log2, p->ctb_log2, 0);
-            if (p->wpp && (rx == 1 || (rs > 1 && rx > 1 && e->tile_of[e->rs2ts[rs - 2]] != tile))) { memcpy(wpp_st, cb->st, sizeof wpp_st); memcpy(wpp_mps, cb->mps, sizeof wpp_mps); wpp_valid = 1; }
+            if (p->wpp && (rx == 1 || (rs > 1 && rx > 1 && e->tile_of[e->rs2ts[rs - 2]] != tile))) { memcpy(wpp_st, cb->st, sizeof wpp_st);
+                memcpy(wpp_mps, cb->mps, sizeof wpp_mps); wpp_valid = 1; }
             ts++;
             int end = ts >= n_ctb;
             if (!end && slice_ctus > 0 && !tiles && ts - first_ts >= slice_ctus) end = 1;
@@ -1647,7 +1749,8 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
         size_t sizes[600]; int n_entry = n_marks;
         { BitW tmp; memset(&tmp, 0, sizeof tmp); size_t mk[601]; for (int i = 0; i < n_marks; i++) mk[i] = marks[i];
           int zeros = 0, mi = 0; size_t pos = 0, prev = 0;
-          for (size_t i = 0; i < data.len; i++) { while (mi < n_marks && mk[mi] == i) { sizes[mi] = pos - prev; prev = pos; mi++; } if (zeros >= 2 && data.buf[i] <= 3) { pos++; zeros = 0; } pos++; zeros = data.buf[i] == 0 ? zeros + 1 : 0; }
+          for (size_t i = 0; i < data.len; i++) { while (mi < n_marks && mk[mi] == i) { sizes[mi] = pos - prev; prev = pos; mi++; }
+              if (zeros >= 2 && data.buf[i] <= 3) { pos++; zeros = 0; } pos++; zeros = data.buf[i] == 0 ? zeros + 1 : 0; }
           (void)tmp; }
         BitW nal; memset(&nal, 0, sizeof nal);
         write_slice_header(e, &nal, &pp, s, first_ts == 0, dependent, seg_addr, sizes, n_entry);
@@ -1665,7 +1768,8 @@ static void encode_picture(Enc *e, BitW *out, const Sched *sched, int n_sched, i
         uint8_t *o = e->recon_buf + (size_t)sc->t * ((size_t)p->width * p->height * 3 / 2);
         for (int y = 0; y < p->height; y++) memcpy(o + (size_t)y * p->width, cur->pl[0] + (size_t)y * cur->stride[0], (size_t)p->width);
         o += (size_t)p->width * p->height;
-        for (int c = 1; c < 3; c++) { for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), cur->pl[c] + (size_t)y * cur->stride[c], (size_t)(p->width / 2)); o += (size_t)(p->width / 2) * (p->height / 2); }
+        for (int c = 1; c < 3; c++) { for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), cur->pl[c] + (size_t)y * cur->stride[c],
+            (size_t)(p->width / 2)); o += (size_t)(p->width / 2) * (p->height / 2); }
     }
 }
 
@@ -1675,11 +1779,13 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     e->p = *gp; HevcGenParams *p = &e->p;
     if (p->width < 16 || p->height < 16 || (p->width & 1) || (p->height & 1) || p->frames < 1) { free(e); return -1; }
     p->ctb_log2 = CLIP3(4, 6, p->ctb_log2 ? p->ctb_log2 : 6); p->min_cb_log2 = CLIP3(3, p->ctb_log2, p->min_cb_log2 ? p->min_cb_log2 : 3);
-    p->min_tb_log2 = CLIP3(2, p->min_cb_log2 - 1, p->min_tb_log2 ? p->min_tb_log2 : 2); p->max_tb_log2 = CLIP3(p->min_tb_log2, MIN(5, p->ctb_log2), p->max_tb_log2 ? p->max_tb_log2 : 5);
+    p->min_tb_log2 = CLIP3(2, p->min_cb_log2 - 1, p->min_tb_log2 ? p->min_tb_log2 : 2);
+    p->max_tb_log2 = CLIP3(p->min_tb_log2, MIN(5, p->ctb_log2), p->max_tb_log2 ? p->max_tb_log2 : 5);
     p->depth_inter = CLIP3(0, p->ctb_log2 - p->min_tb_log2, p->depth_inter); p->depth_intra = CLIP3(0, p->ctb_log2 - p->min_tb_log2, p->depth_intra);
     p->qp = CLIP3(4, 48, p->qp ? p->qp : 32); if (p->intra_period < 1) p->intra_period = 32;
     if (!(p->gop == 0 || p->gop == 8 || (p->gop >= 1 && p->gop <= 3))) p->gop = 0;
-    p->num_ref = CLIP3(1, 4, p->num_ref ? p->num_ref : 1); if (p->gop == 8 && p->num_ref > 2) p->num_ref = 2; if (p->gop >= 1 && p->gop <= 3 && p->num_ref > 2) p->num_ref = 2;
+    p->num_ref = CLIP3(1, 4, p->num_ref ? p->num_ref : 1); if (p->gop == 8 && p->num_ref > 2) p->num_ref = 2;
+    if (p->gop >= 1 && p->gop <= 3 && p->num_ref > 2) p->num_ref = 2;
     p->merge_cand = CLIP3(1, 5, p->merge_cand ? p->merge_cand : 5); p->par_mrg = CLIP3(2, p->ctb_log2, p->par_mrg ? p->par_mrg : 2);
     p->tile_cols = MAX(1, p->tile_cols); p->tile_rows = MAX(1, p->tile_rows); if (p->search < 1) p->search = 4;
     /* the slice table holds 512 entries (dependent slice segments share their parent's): keep independent slices per picture below that */
@@ -1687,7 +1793,8 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
         const int cs = 1 << p->ctb_log2, n_ctbs = ((p->width + cs - 1) / cs) * ((p->height + cs - 1) / cs);
         if ((n_ctbs + p->slice_ctus - 1) / p->slice_ctus > 400) p->slice_ctus = (n_ctbs + 399) / 400;
     }
-    p->dqp = CLIP3(0, 1 + MIN(3, p->ctb_log2 - p->min_cb_log2), p->dqp); p->scaling = CLIP3(0, 3, p->scaling); p->pcm = CLIP3(0, 3, p->pcm); p->deblock = CLIP3(0, 2, p->deblock);
+    p->dqp = CLIP3(0, 1 + MIN(3, p->ctb_log2 - p->min_cb_log2), p->dqp); p->scaling = CLIP3(0, 3, p->scaling); p->pcm = CLIP3(0, 3, p->pcm);
+    p->deblock = CLIP3(0, 2, p->deblock);
     p->cb_qp_off = CLIP3(-12, 12, p->cb_qp_off); p->cr_qp_off = CLIP3(-12, 12, p->cr_qp_off);
     if (p->gop) p->lt_ref = 0;
     int mcb = 1 << p->min_cb_log2;
@@ -1702,20 +1809,24 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     basis_init();
     pic_alloc(e, &e->src); for (int i = 0; i < 10; i++) pic_alloc(e, &e->dpb[i]);
     size_t n4 = (size_t)e->w4 * e->h4, nc = (size_t)e->ctb_w * e->ctb_h;
-    e->pm = calloc(n4, 1); e->skip = calloc(n4, 1); e->depth = calloc(n4, 1); e->ipm = calloc(n4, 1); e->nofilt = calloc(n4, 1); e->edges = calloc(n4, 1); e->cbf = calloc(n4, 1);
+    e->pm = calloc(n4, 1); e->skip = calloc(n4, 1); e->depth = calloc(n4, 1); e->ipm = calloc(n4, 1); e->nofilt = calloc(n4, 1); e->edges = calloc(n4, 1);
+    e->cbf = calloc(n4, 1);
     e->qpmap = calloc(n4, 1); e->mot = calloc(n4, sizeof(Mot)); e->slice_of = calloc(n4, sizeof(int16_t));
-    e->ctb_slice = calloc(nc, sizeof(int)); e->rs2ts = calloc(nc, sizeof(int)); e->ts2rs = calloc(nc, sizeof(int)); e->tile_of = calloc(nc, sizeof(int)); e->sao = calloc(nc, sizeof(Sao));
+    e->ctb_slice = calloc(nc, sizeof(int)); e->rs2ts = calloc(nc, sizeof(int)); e->ts2rs = calloc(nc, sizeof(int)); e->tile_of = calloc(nc, sizeof(int));
+    e->sao = calloc(nc, sizeof(Sao));
     for (int c = 0; c < 3; c++) e->dbk[c] = malloc((size_t)(e->W >> (c ? 1 : 0)) * (size_t)(e->H >> (c ? 1 : 0)));
     tables_init(e);
     make_texture(e);
-    if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames; e->recon_buf = calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
+    if (recon_path) { e->recon = fopen(recon_path, "wb"); e->recon_frames = p->frames;
+        e->recon_buf = calloc((size_t)p->frames, (size_t)p->width * p->height * 3 / 2); }
     Sched *sched = calloc((size_t)p->frames + 16, sizeof(Sched)); int n_sched = 0;
     plan_sequence(p, sched, &n_sched);
     int reorder = p->gop == 8 ? 3 : (p->gop ? 1 : 0), keep_max = p->gop == 8 ? 5 : p->num_ref + (p->gop ? 1 : 0) + (p->lt_ref ? 1 : 0);
     int max_dpb = MIN(16, keep_max + reorder + 1);
     BitW outw; memset(&outw, 0, sizeof outw);
     lists_default(e); lists_expand(e); e->sf_on = p->scaling != 0;
-    if (p->rps_sps && !p->lt_ref) {                                     /* the distinct reference picture sets of the plan go into the SPS (some are left out on purpose) */
+    if (p->rps_sps && !p->lt_ref) {
+        /* the distinct reference picture sets of the plan go into the SPS (some are left out on purpose) */
         for (int i = 0; i < n_sched && e->n_sps_sets < 64; i++) {
             if (sched[i].idr) continue;
             RpsSet t; plan_rps(sched, n_sched, i, &t);
@@ -1729,7 +1840,8 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     size_t ps_len = outw.len;
     if (p->scaling >= 2) lists_expand(e);
     for (int i = 0; i < n_sched; i++) {
-        if (sched[i].cra) { uint8_t *copy = (uint8_t *)malloc(ps_len); memcpy(copy, outw.buf, ps_len); bw_bytes(&outw, copy, ps_len); free(copy); }   /* parameter sets again: decoding may start here */
+        if (sched[i].cra) { uint8_t *copy = (uint8_t *)malloc(ps_len); memcpy(copy, outw.buf, ps_len); bw_bytes(&outw, copy, ps_len); free(copy); }
+            /* parameter sets again: decoding may start here */
         encode_picture(e, &outw, sched, n_sched, i);
     }
     if (e->recon) { fwrite(e->recon_buf, 1, (size_t)p->frames * ((size_t)p->width * p->height * 3 / 2), e->recon); fclose(e->recon); }
@@ -1743,22 +1855,31 @@ void hevcgen_free(void *p) { free(p); }
 #ifndef HEVCGEN_LIB
 int main(int argc, char **argv) {
     HevcGenParams p; memset(&p, 0, sizeof p);
-    p.width = 176; p.height = 144; p.frames = 8; p.qp = 32; p.seed = 1; p.intra_period = 32; p.deblock = 1; p.sao = 1; p.tmvp = 1; p.amp = 1; p.strong_intra = 1; p.depth_inter = 2; p.depth_intra = 2;
+    p.width = 176; p.height = 144; p.frames = 8; p.qp = 32; p.seed = 1; p.intra_period = 32; p.deblock = 1; p.sao = 1; p.tmvp = 1; p.amp = 1;
+    p.strong_intra = 1; p.depth_inter = 2; p.depth_intra = 2;
     const char *outp = NULL, *recon = NULL;
-    struct { const char *name; int *v; } opts[] = { {"--width", &p.width}, {"--height", &p.height}, {"--frames", &p.frames}, {"--qp", &p.qp}, {"--seed", &p.seed}, {"--intra-period", &p.intra_period},
-        {"--gop", &p.gop}, {"--refs", &p.num_ref}, {"--ctb", &p.ctb_log2}, {"--min-cb", &p.min_cb_log2}, {"--max-tb", &p.max_tb_log2}, {"--min-tb", &p.min_tb_log2}, {"--depth-inter", &p.depth_inter},
-        {"--depth-intra", &p.depth_intra}, {"--mode", &p.mode}, {"--amp", &p.amp}, {"--sao", &p.sao}, {"--deblock", &p.deblock}, {"--tskip", &p.tskip}, {"--sdh", &p.sdh}, {"--dqp", &p.dqp}, {"--pcm", &p.pcm},
-        {"--bypass", &p.bypass}, {"--cip", &p.cip}, {"--strong-intra", &p.strong_intra}, {"--tmvp", &p.tmvp}, {"--wp", &p.wp}, {"--rplm", &p.rplm}, {"--lt-ref", &p.lt_ref}, {"--scaling", &p.scaling},
-        {"--wpp", &p.wpp}, {"--tile-cols", &p.tile_cols}, {"--tile-rows", &p.tile_rows}, {"--slice-ctus", &p.slice_ctus}, {"--dep-slices", &p.dep_slices}, {"--merge-cand", &p.merge_cand},
-        {"--cabac-init", &p.cabac_init}, {"--par-mrg", &p.par_mrg}, {"--cb-qp-off", &p.cb_qp_off}, {"--cr-qp-off", &p.cr_qp_off}, {"--search", &p.search}, {"--rps-sps", &p.rps_sps}, {"--open-gop", &p.open_gop} };
+    struct { const char *name; int *v; } opts[] = { {"--width", &p.width}, {"--height", &p.height}, {"--frames", &p.frames}, {"--qp", &p.qp}, {"--seed",
+        &p.seed}, {"--intra-period", &p.intra_period},
+        {"--gop", &p.gop}, {"--refs", &p.num_ref}, {"--ctb", &p.ctb_log2}, {"--min-cb", &p.min_cb_log2}, {"--max-tb", &p.max_tb_log2}, {"--min-tb",
+            &p.min_tb_log2}, {"--depth-inter", &p.depth_inter},
+        {"--depth-intra", &p.depth_intra}, {"--mode", &p.mode}, {"--amp", &p.amp}, {"--sao", &p.sao}, {"--deblock", &p.deblock}, {"--tskip", &p.tskip},
+            {"--sdh", &p.sdh}, {"--dqp", &p.dqp}, {"--pcm", &p.pcm},
+        {"--bypass", &p.bypass}, {"--cip", &p.cip}, {"--strong-intra", &p.strong_intra}, {"--tmvp", &p.tmvp}, {"--wp", &p.wp}, {"--rplm", &p.rplm},
+            {"--lt-ref", &p.lt_ref}, {"--scaling", &p.scaling},
+        {"--wpp", &p.wpp}, {"--tile-cols", &p.tile_cols}, {"--tile-rows", &p.tile_rows}, {"--slice-ctus", &p.slice_ctus}, {"--dep-slices", &p.dep_slices},
+            {"--merge-cand", &p.merge_cand},
+        {"--cabac-init", &p.cabac_init}, {"--par-mrg", &p.par_mrg}, {"--cb-qp-off", &p.cb_qp_off}, {"--cr-qp-off", &p.cr_qp_off}, {"--search", &p.search},
+            {"--rps-sps", &p.rps_sps}, {"--open-gop", &p.open_gop} };
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-o") && i + 1 < argc) { outp = argv[++i]; continue; }
         if (!strcmp(argv[i], "--recon") && i + 1 < argc) { recon = argv[++i]; continue; }
         int ok = 0;
-        for (size_t k = 0; k < sizeof opts / sizeof opts[0]; k++) if (!strcmp(argv[i], opts[k].name) && i + 1 < argc) { *opts[k].v = (int)strtol(argv[++i], NULL, 0); ok = 1; break; }
+        for (size_t k = 0; k < sizeof opts / sizeof opts[0]; k++) if (!strcmp(argv[i], opts[k].name) && i + 1 < argc) {
+            *opts[k].v = (int)strtol(argv[++i], NULL, 0); ok = 1; break; }
         if (!ok) { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
-    if (!outp) { fprintf(stderr, "usage: hevcgen [--width W --height H --frames N --qp Q --seed S --gop 0|1|2|3|8 ...] -o out.h265 [--recon recon.yuv]\n"); return 2; }
+    if (!outp) { fprintf(stderr, "usage: hevcgen [--width W --height H --frames N --qp Q --seed S --gop 0|1|2|3|8 ...] -o out.h265 [--recon recon.yuv]\n");
+        return 2; }
     uint8_t *buf; size_t len;
     if (hevcgen_generate(&p, &buf, &len, recon) < 0) { fprintf(stderr, "bad parameters\n"); return 1; }
     FILE *f = fopen(outp, "wb"); fwrite(buf, 1, len, f); fclose(f);

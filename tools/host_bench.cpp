@@ -13,9 +13,11 @@
 #include <time.h>
 #include <pthread.h>
 
-// JM_HOST_BENCH_PROF=file: a sampling profile of the host half (the image has no perf / gprof-capable toolchain): SIGPROF every 50 us of wall time, the interrupted program counter is recorded and written as `offset-in-binary` lines for llvm-addr2line / llvm-symbolizer.
+// JM_HOST_BENCH_PROF=file: a sampling profile of the host half (the image has no perf / gprof-capable toolchain): SIGPROF every 50 us of wall time, the
+// interrupted program counter is recorded and written as `offset-in-binary` lines for llvm-addr2line / llvm-symbolizer.
 static unsigned long *g_pcs; static volatile long g_npc; static const long kMaxPc = 1 << 22;
-static void on_prof(int, siginfo_t *, void *uc) { long i = __atomic_fetch_add(&g_npc, 1, __ATOMIC_RELAXED); if (i < kMaxPc) g_pcs[i] = (unsigned long)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP]; }
+static void on_prof(int, siginfo_t *, void *uc) { long i = __atomic_fetch_add(&g_npc, 1, __ATOMIC_RELAXED);
+    if (i < kMaxPc) g_pcs[i] = (unsigned long)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP]; }
 static void prof_start() {
     g_pcs = new unsigned long[kMaxPc];
     struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART; sigaction(SIGPROF, &sa, nullptr);
@@ -28,8 +30,11 @@ static void prof_start() {
 static void prof_stop(const char *path) {
     signal(SIGPROF, SIG_IGN);
     unsigned long lo = 0, hi = 0;                                           // the executable's own text mapping
-    if (FILE *m = fopen("/proc/self/maps", "r")) { char ln[512]; while (fgets(ln, sizeof ln, m)) { unsigned long a, b, off; char perm[8]; if (sscanf(ln, "%lx-%lx %7s %lx", &a, &b, perm, &off) == 4 && strstr(ln, "host_bench")) { if (!lo || a - off < lo) lo = a - off; if (b > hi) hi = b; } } fclose(m); }
-    if (FILE *f = fopen(path, "w")) { long n = g_npc < kMaxPc ? g_npc : kMaxPc; for (long i = 0; i < n; i++) if (g_pcs[i] >= lo && g_pcs[i] < hi) fprintf(f, "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other\n"); fclose(f); }
+    if (FILE *m = fopen("/proc/self/maps", "r")) { char ln[512]; while (fgets(ln, sizeof ln, m)) { unsigned long a, b, off; char perm[8];
+        if (sscanf(ln, "%lx-%lx %7s %lx", &a, &b, perm, &off) == 4 && strstr(ln, "host_bench")) { if (!lo || a - off < lo) lo = a - off; if (b > hi) hi = b; }
+        } fclose(m); }
+    if (FILE *f = fopen(path, "w")) { long n = g_npc < kMaxPc ? g_npc : kMaxPc; for (long i = 0; i < n; i++) if (g_pcs[i] >= lo && g_pcs[i] < hi) fprintf(f,
+        "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other\n"); fclose(f); }
 }
 
 #ifdef JM_COUNT_BINS
@@ -37,18 +42,22 @@ namespace jmamd { long g_cabac_bins = 0; }
 #endif
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s stream [passes] [codec_type]\n", argv[0]); return 2; }
-    std::vector<unsigned char> b; { FILE *f = fopen(argv[1], "rb"); if (!f) return 2; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize(n); if (fread(b.data(), 1, n, f) != (size_t)n) return 2; fclose(f); }
+    std::vector<unsigned char> b;
+    { FILE *f = fopen(argv[1], "rb"); if (!f) return 2; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize(n);
+        if (fread(b.data(), 1, n, f) != (size_t)n) return 2; fclose(f); }
     const int passes = argc > 2 ? atoi(argv[2]) : 3, codec = argc > 3 ? atoi(argv[3]) : 0;
     void *h = jm_amddec_create_handle();
     jm_amddec_set_option(h, "parse_only", 1);
     if (jm_amddec_init(codec, 1, nullptr, 0, h) != 0) { fprintf(stderr, "init failed\n"); return 1; }
     std::vector<unsigned char> out(64 << 20);
     const char *prof = getenv("JM_HOST_BENCH_PROF");
-    if (prof) { jm_amddec_feed_annexb(b.data(), (long)b.size(), 1, out.data(), (int)out.size(), h); prof_start(); }      // (the first pass creates the parse workers: they must not inherit the blocked signal)
+    // (the first pass creates the parse workers: they must not inherit the blocked signal)
+    if (prof) { jm_amddec_feed_annexb(b.data(), (long)b.size(), 1, out.data(), (int)out.size(), h); prof_start(); }
     auto t0 = std::chrono::steady_clock::now();
     long frames = jm_amddec_feed_annexb(b.data(), (long)b.size(), passes, out.data(), (int)out.size(), h);
     // drain inside the timed region: every picture fed has then been parsed (the pipeline holds up to two dozen per handle)
-    for (int i = 0, got = 0; i < 100000 && !jm_amddec_is_exit(h); i++) { jm_amddec_decode_frame(nullptr, 0, &got, h); if (got) { int n = (int)out.size(); if (jm_amddec_output_frame(out.data(), &n, h) > 0) frames++; } }
+    for (int i = 0, got = 0; i < 100000 && !jm_amddec_is_exit(h); i++) { jm_amddec_decode_frame(nullptr, 0, &got, h); if (got) { int n = (int)out.size();
+        if (jm_amddec_output_frame(out.data(), &n, h) > 0) frames++; } }
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (prof) prof_stop(prof);
     // per PICTURE PARSED (the stat), not per frame returned: a reordering DPB holds frames back across the passes
@@ -57,7 +66,8 @@ int main(int argc, char **argv) {
 #ifdef JM_COUNT_BINS
     printf("%.0f bins per picture (all passes; JM_AMD_DEC_THREADS=1 for a meaningful count)\n", (double)jmamd::g_cabac_bins / pics);
 #endif
-    printf("%ld pictures (%ld frames returned) in %.3f s: %.1f pictures/s wall, %.3f ms per picture, %.1f MB/s of bitstream\n", pics, frames, s, pics / s, 1e3 * s / pics, passes * b.size() / s / 1e6);
+    printf("%ld pictures (%ld frames returned) in %.3f s: %.1f pictures/s wall, %.3f ms per picture, %.1f MB/s of bitstream\n", pics, frames, s, pics / s,
+        1e3 * s / pics, passes * b.size() / s / 1e6);
     jm_amddec_deinit(h);
     return 0;
 }

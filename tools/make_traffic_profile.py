@@ -49,21 +49,26 @@ def main():
         pics_timed = kc["launches"] * kc["pictures_per_launch"]      # timed region only; the profile also holds the warm-up pass: same stream, same count
         if "k_chain" in cf and pics_timed > 0:
             n_launch = cf["k_chain"][1]
-            pics = pics_timed * a.chain_scale                         # pictures through k_chain in the whole profile = timed x (passes in profile / timed passes)
-            chain = {"fetch_raw": round(cf["k_chain"][0] * n_launch / pics), "write": round(cw["k_chain"][0] * cw["k_chain"][1] / pics), "launches": n_launch, "pictures": round(pics, 1)}
+            pics = pics_timed * a.chain_scale                      # pictures through k_chain in the whole profile = timed x (passes in profile / timed passes)
+            chain = {"fetch_raw": round(cf["k_chain"][0] * n_launch / pics), "write": round(cw["k_chain"][0] * cw["k_chain"][1] / pics), "launches": n_launch,
+                "pictures": round(pics, 1)}
             chain["fetch_corrected_upper"] = 2 * chain["fetch_raw"]
             chain["traffic_upper"] = chain["fetch_corrected_upper"] + chain["write"]
     mb_w, mb_h = (a.width + 15) // 16, (a.height + 15) // 16
-    out = {"how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per launch, so bytes "
-                  f"are per {a.width}x{a.height} picture (averaged over the launches of the kernel, i.e. over the run's picture types). Counter unit KB (x1024). "
-                  "FETCH_SIZE is the raw value; MI355X_MICROARCH.md says it reads 1/2 of the bytes for wide (16 B/lane) coalesced streams and is uncalibrated for "
+    out = {"how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per launch, so "
+        f"bytes "
+                  f"are per {a.width}x{a.height} picture (averaged over the launches of the kernel, i.e. over the run's picture types). Counter unit KB "
+                  f"(x1024). "
+                  "FETCH_SIZE is the raw value; MI355X_MICROARCH.md says it reads 1/2 of the bytes for wide (16 B/lane) coalesced streams and is uncalibrated "
+                  "for "
                   "other widths, so fetch_corrected = 2 x raw is an upper estimate here.",
            "width": a.width, "height": a.height, "surface_bytes_S": mb_w * mb_h * 384, "kernels": {}}
     for k in sorted(fetch):
         if not k.startswith("k_"):
             continue
         f, w = fetch[k][0], write.get(k, (0, 0))[0]
-        out["kernels"][k] = {"fetch_raw": round(f), "fetch_corrected_upper": round(2 * f), "write": round(w), "traffic_upper": round(2 * f + w), "launches": fetch[k][1]}
+        out["kernels"][k] = {"fetch_raw": round(f), "fetch_corrected_upper": round(2 * f), "write": round(w), "traffic_upper": round(2 * f + w),
+            "launches": fetch[k][1]}
     if chain:
         out["kernels"]["k_chain"] = chain
         out["how_chain"] = "k_chain: the same two passes with chain launches on (default), bytes of all k_chain dispatches / pictures decoded through k_chain"

@@ -39,7 +39,8 @@ int main() {
     hsa_signal_t sig[4]; for (auto &s : sig) hsa_signal_create(1, 0, nullptr, &s);
     auto copy = [&](int slot, uint32_t engine) {
         hsa_signal_store_relaxed(sig[slot], 1);
-        return engine ? hsa_amd_memory_async_copy_on_engine(hostg[slot], g_cpu, (char *)dev + n * slot, g_gpu, n, 0, nullptr, sig[slot], (hsa_amd_sdma_engine_id_t)engine, false)
+        return engine ? hsa_amd_memory_async_copy_on_engine(hostg[slot], g_cpu, (char *)dev + n * slot, g_gpu, n, 0, nullptr, sig[slot],
+            (hsa_amd_sdma_engine_id_t)engine, false)
                       : hsa_amd_memory_async_copy(hostg[slot], g_cpu, (char *)dev + n * slot, g_gpu, n, 0, nullptr, sig[slot]);
     };
     auto wait = [&](int slot) { while (hsa_signal_wait_scacquire(sig[slot], HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_BLOCKED) >= 1) {} };
@@ -84,7 +85,9 @@ int main() {
         for (int i = 0; i < reps; i++) { hsa_amd_memory_lock(p, n, &g_gpu, 1, &ap); hsa_amd_memory_unlock(p); }
         printf("hsa_amd_memory_lock + unlock of %zu bytes: %.1f us per pair\n", n, 1e6 * (now() - t0) / reps);
         t0 = now();
-        for (int i = 0; i < reps; i++) { hsa_amd_memory_lock(p, n, &g_gpu, 1, &ap); copy(0, 0x2); hsa_signal_store_relaxed(sig[0], 1); hsa_amd_memory_async_copy_on_engine(ap, g_cpu, dev, g_gpu, n, 0, nullptr, sig[0], (hsa_amd_sdma_engine_id_t)0x2, false); wait(0); hsa_amd_memory_unlock(p); }
+        for (int i = 0; i < reps; i++) { hsa_amd_memory_lock(p, n, &g_gpu, 1, &ap); copy(0, 0x2); hsa_signal_store_relaxed(sig[0], 1);
+            hsa_amd_memory_async_copy_on_engine(ap, g_cpu, dev, g_gpu, n, 0, nullptr, sig[0], (hsa_amd_sdma_engine_id_t)0x2, false); wait(0);
+            hsa_amd_memory_unlock(p); }
         printf("lock + copy + unlock: %.1f us per frame\n", 1e6 * (now() - t0) / reps);
     }
     // the HIP way for comparison

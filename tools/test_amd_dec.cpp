@@ -45,7 +45,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--fmt") && i + 1 < argc) fmt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--loops") && i + 1 < argc) loops = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--chunk") && i + 1 < argc) chunk = atol(argv[++i]);
-        else if (!strcmp(argv[i], "--no-hw-check")) hw_check = false;      // host-side tests: with JM_AMD_DEC_PARSE_ONLY=1 the library runs its bitstream stages only
+        // host-side tests: with JM_AMD_DEC_PARSE_ONLY=1 the library runs its bitstream stages only
+        else if (!strcmp(argv[i], "--no-hw-check")) hw_check = false;
         else if (!in_path) in_path = argv[i];
         else if (!out_path) out_path = argv[i];
     }
@@ -83,7 +84,8 @@ int main(int argc, char **argv) {
             }
             if (end > 0) {
                 nalu_count++;
-                if (jm_nvdec_decode_frame(in_buf.data(), (int)end, &got_frame, dec) != 0) { fprintf(stderr, "test_amd_dec: jm_nvdec_decode_frame failed\n"); return 5; }
+                if (jm_nvdec_decode_frame(in_buf.data(), (int)end, &got_frame, dec) != 0) { fprintf(stderr, "test_amd_dec: jm_nvdec_decode_frame failed\n");
+                    return 5; }
                 if (got_frame == 1) fetch();
                 memmove(in_buf.data(), in_buf.data() + end, (size_t)(buf_len - end));
                 buf_len -= end;

@@ -37,4 +37,5 @@ for q, ks in byq.items():
         gaps[key][0] += g; gaps[key][1] += 1; gaps[key][2] = max(gaps[key][2], g); gl[key].append(g)
 print("gaps within a queue (avg us, max us, count):")
 for k, (t, c, m) in sorted(gaps.items(), key=lambda x: -x[1][0])[:12]:
-    v = sorted(gl[k]); print("  %-40s avg %8.1f p50 %8.1f p90 %8.1f max %9.1f n %d" % (k, t / c / 1e3, v[len(v) // 2] / 1e3, v[len(v) * 9 // 10] / 1e3, m / 1e3, c))
+    v = sorted(gl[k]); print("  %-40s avg %8.1f p50 %8.1f p90 %8.1f max %9.1f n %d" % (k, t / c / 1e3, v[len(v) // 2] / 1e3, v[len(v) * 9 // 10] / 1e3,
+        m / 1e3, c))

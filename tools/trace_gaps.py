@@ -2,7 +2,8 @@
 For every batched k_deblock_lds launch (grid y = pictures) prints what happened until the next k_recon_inter of the same queue."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r['Queue_Id'], int(r['Grid_Size_Y']) if 'Grid_Size_Y' in r else 0) for r in rows)
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r['Queue_Id'],
+    int(r['Grid_Size_Y']) if 'Grid_Size_Y' in r else 0) for r in rows)
 byq = collections.defaultdict(list)
 for e in ev:
     byq[e[3]].append(e)
@@ -17,7 +18,8 @@ for q, lst in byq.items():
     if gaps:
         gaps_sorted = sorted(gaps)
         print("   gaps between consecutive kernels (us): median %.1f p90 %.1f max %.1f sum %.1f ms of %.1f ms" % (
-            gaps_sorted[len(gaps) // 2], gaps_sorted[int(len(gaps) * .9)], gaps_sorted[-1], sum(g for g in gaps if g > 0) / 1e3, (lst[-1][1] - lst[0][0]) / 1e6))
+            gaps_sorted[len(gaps) // 2], gaps_sorted[int(len(gaps) * .9)], gaps_sorted[-1], sum(g for g in gaps if g > 0) / 1e3,
+            (lst[-1][1] - lst[0][0]) / 1e6))
         for k, v in durs.items():
             v.sort(); print("   %-26s n=%d median %.1f us" % (k, len(v), v[len(v) // 2]))
 

@@ -1,7 +1,8 @@
 """Developer script: print a window of the kernel timeline (all queues) around full batches."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ts = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-16:], r['Queue_Id'], r['Grid_Size_X'], r['Grid_Size_Y']) for r in rows]
+ts = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-16:], r['Queue_Id'], r['Grid_Size_X'],
+    r['Grid_Size_Y']) for r in rows]
 ts.sort()
 t0 = ts[0][0]
 idx = [i for i, t in enumerate(ts) if 'packout' in t[2] and t[1] - t[0] > 800000]
