@@ -100,7 +100,8 @@ void Engine::submit(EnginePic &&p) {
 }
 
 bool Engine::set_knob(const std::string &key, long long v) {
-    if (key.rfind("chain_", 0) == 0) chain_block_until_ns_ = 0;            // an explicit setting ends the pause that follows a recovered chain launch
+    // an explicit setting ends the pause that follows a recovered chain launch, and has the next batch look again whether the GPU is shared
+    if (key.rfind("chain_", 0) == 0) { chain_block_until_ns_ = 0; shared_checked_ns_ = 0; }
     if (key == "chain_depth") chain_depth_ = (int)std::max(1ll, std::min(v, 16ll));
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max(20ll, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
@@ -130,7 +131,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         // A chain launch needs the whole GPU (its waits assume its bands stay resident, chain.hip).  When another process has compute queues on this
         // device -- a second rank of the same job, another tenant -- no chain launches are formed at all, instead of letting them time out against the
         // other process's kernels and decoding their pictures again (Engine::recover: correct, but every such launch costs 100 ms).
-        if (kfd_gpu_id_ && now - shared_checked_ns_ > 1000ll * 1000 * 1000) {
+        if (kfd_gpu_id_ && now - shared_checked_ns_.load() > (gpu_shared_ ? 200ll : 1000ll) * 1000 * 1000) {
             shared_checked_ns_ = now;
             const bool sh = kfd_gpu_has_other_users(kfd_gpu_id_);
             if (sh != gpu_shared_) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_,

@@ -156,7 +156,7 @@ private:
 
     int device_, numa_node_ = -1;
     // another process has queues on this GPU (checked about once a second): no chain launches
-    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; long long shared_checked_ns_ = 0;
+    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; std::atomic<long long> shared_checked_ns_{0};
     ihipStream_t *copy_stream_ = nullptr;
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];
