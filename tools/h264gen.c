@@ -62,6 +62,9 @@ typedef struct {
                                    stream that happens to be coded progressively.  Needs an even number of macroblock rows; Main profile at least */
     int poc_bottom;             /* 1: bottom_field_pic_order_in_frame_present_flag = 1 with random delta_pic_order_cnt_bottom / delta_pic_order_cnt[1] in -1..1
                                    (PicOrderCnt of a frame = Min(top, bottom), 8.2.1) */
+    int paff;                   /* picture-adaptive frame / field coding (implies fmo0; P-only streams): 1 = every I / P picture is coded either as a frame
+                                   or as two field pictures (first field of either parity), drawn per picture; 2 = every picture as two fields.  With
+                                   CABAC the 8x8 transform is switched off (the contexts 436..459 of field-coded 8x8 blocks are not pinned, SPEC_AUDIT.md) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -204,6 +207,8 @@ static const uint8_t cbp_intra_tab[48] = {
 static const uint8_t cbp_inter_tab[48] = {
     0,16,1,2,4,8,32,3,5,10,12,15,47,7,11,13,14,6,9,31,35,37,42,44,33,34,36,40,39,43,45,46,17,18,20,24,19,21,26,28,23,27,29,30,22,25,38,41 };
 static const uint8_t zz4[16] = {0,1,4,8,5,2,3,6,9,12,13,10,7,11,14,15};
+/* field scan (Table 8-2, raster index = 4 * y + x): down the columns first */
+static const uint8_t fs4[16] = {0,4,1,8,12,5,9,13,2,6,10,14,3,7,11,15};
 static const uint8_t qpc_tab[22] = {29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39};
 static const int norm4[6][3] = { {10,16,13},{11,18,14},{13,20,16},{14,23,18},{16,25,20},{18,29,23} };
 static const int quant_mf[6][3] = { {13107,5243,8066},{11916,4660,7490},{10082,4194,6554},{9362,3647,5825},{8192,3355,5243},{7282,2893,4559} };
@@ -218,7 +223,7 @@ static const uint8_t tc0_tab[52][3] = {
  {9,12,18},{10,13,20},{11,15,23},{13,17,25} };
 
 /* ------------------------------ frames ------------------------------------- */
-typedef struct {
+typedef struct FrameS {
     uint8_t *y, *u, *v;            /* origin pointers inside padded buffers      */
     uint8_t *by, *bu, *bv;
     int sy, sc;                    /* strides                                    */
@@ -227,6 +232,12 @@ typedef struct {
     int frame_num, poc, id;
     int is_long, lt_idx;           /* long-term reference with LongTermFrameIdx lt_idx */
     void *mf;                      /* MbE[] motion field of the picture (colocated data for direct prediction) */
+    /* PAFF streams: every frame store also keeps its two fields as pictures of half the height (own padding, own half-sample planes): field
+       pictures are coded exactly like frames of that size, against reference FIELDS; frame pictures against the woven frames */
+    struct FrameS *fld;            /* [2]: top, bottom */
+    uint8_t fmark[2];              /* marking of each field of the store: 0 not a reference, 1 short-term, 2 long-term */
+    int fpoc[2];                   /* TopFieldOrderCnt, BottomFieldOrderCnt */
+    int parity;                    /* of a field picture: 0 top, 1 bottom */
 } Frame;
 
 typedef struct {
@@ -247,13 +258,16 @@ typedef struct {
     BitW bw; Out out;
     int frame_num, idr_id, log2_max_fn, poc_lsb_bits;
     int slice_id, slice_type, qp_run;
-    Frame *list0[5]; int nlist0;
-    Frame *list1[5]; int nlist1; int cur_poc;
+    Frame *list0[16]; int nlist0;
+    Frame *list1[16]; int nlist1; int cur_poc;
+    Frame fsrc; int cur_store_id;         /* PAFF: the source field being coded; id of the frame store the first field of the current frame opened */
+    int field, second;                    /* the picture being coded: 0 frame, 1 top field, 2 bottom field; it is the second field of its frame */
+    const uint8_t *scan4, *scan8;         /* zig-zag or field scan (8.5.6 / 8.5.7) */
     int *pocs; /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
     int poc_base;                         /* display index at which the picture order count restarted (IDR picture, or a picture with operation 5) */
     int cur_top, delta_bottom, delta0;    /* TopFieldOrderCnt of the current picture; delta_pic_order_cnt_bottom / [1]; delta_pic_order_cnt[0] (type 1) */
     int t1_cycle, t1_ref[3], t1_nonref, t1_t2b;   /* pic_order_cnt_type 1: cycle of expected deltas, offset_for_non_ref_pic, offset_for_top_to_bottom_field */
-    int wlog[2], ww[2][5][3], wo[2][5][3];   /* explicit weighted prediction: log2 denominators (luma, chroma), weight / offset [list][ref][Y,Cb,Cr] */
+    int wlog[2], ww[2][16][3], wo[2][16][3];   /* explicit weighted prediction: log2 denominators (luma, chroma), weight / offset [list][ref][Y,Cb,Cr] */
     uint8_t *recon_buf; int recon_frames;
     int max_lt_idx;                         /* MaxLongTermFrameIdx, -1 = "no long-term frame indices" */
     int n_mod[2], mod_idc[2][8], mod_val[2][8];   /* ref_pic_list_modification of the current picture */
@@ -420,6 +434,9 @@ static void mc_block(Enc *e, const Frame *r, int px, int py, int w, int h, int m
             fprintf(stderr, "h264gen: fast/literal MC mismatch\n"); abort(); }
         c->y[(py + y) * c->sy + px + x] = (uint8_t)v;
     }
+    /* 8.4.1.4: a field that predicts from a field of the other parity shifts the chroma vector by a quarter chroma sample (Table 8-9): the chroma
+       lines of the two parities lie a quarter of a field line apart relative to the luma lines */
+    if (e->field) mvy += r->parity == (e->field - 1) ? 0 : (r->parity ? -2 : 2);
     int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
     for (int pl = 0; pl < 2; pl++) {
         const uint8_t *rp = pl ? r->v : r->u; uint8_t *dp = pl ? c->v : c->u;
@@ -699,9 +716,13 @@ static void recon_chroma(Enc *e, int mx, int my, int pl, int qpc, const MbCode *
 }
 
 /* ------------------------------ deblocking (own implementation) --------------- */
-static int mv_far(const int16_t *a, const int16_t *b) { return ABS(a[0] - b[0]) >= 4 || ABS(a[1] - b[1]) >= 4; }
+/* 8.7.2.1: vectors differ by a whole luma FRAME sample or more; in a field picture a vertical difference of 4 quarter frame samples is 2 quarter field
+   samples */
+static __thread int g_mvy_limit = 4;
+static int mv_far(const int16_t *a, const int16_t *b) { return ABS(a[0] - b[0]) >= 4 || ABS(a[1] - b[1]) >= g_mvy_limit; }
+/* mbedge: 0 inner edge, 1 macroblock edge, 2 horizontal macroblock edge of a field picture (8.7.2.1: bS 4 needs frame macroblocks or a vertical edge) */
 static int edge_bs(const MbE *p, int bp, const MbE *q, int bq, int mbedge) {
-    if (p->intra || q->intra) return mbedge ? 4 : 3;
+    if (p->intra || q->intra) return mbedge == 1 ? 4 : 3;
     if (((p->nzmask >> bp) & 1) || ((q->nzmask >> bq) & 1)) return 2;
     int pq = (bp >> 3) * 2 + ((bp & 3) >> 1), qq = (bq >> 3) * 2 + ((bq & 3) >> 1);
     /* reference pictures actually used by each side (as a set of at most two), with their vectors */
@@ -746,6 +767,7 @@ static void db_chroma(uint8_t *q, int s, int bS, int a, int b, int ia) {
 }
 static void deblock_frame(Enc *e) {
     Frame *c = &e->cur;
+    g_mvy_limit = e->field ? 2 : 4;
     for (int my = 0; my < e->mbh; my++) for (int mx = 0; mx < e->mbw; mx++) {
         MbE *q = &e->mbs[my * e->mbw + mx];
         if (q->dis_db == 1) continue;
@@ -756,7 +778,7 @@ static void deblock_frame(Enc *e) {
                 if (q->dis_db == 2 && p->slice != q->slice) continue; }
             int bs[4], any = 0;
             for (int k = 0; k < 4; k++) { int bq = dir ? ed * 4 + k : k * 4 + ed; int bp = ed ? (dir ? bq - 4 : bq - 1) : (dir ? 12 + k : k * 4 + 3);
-                bs[k] = edge_bs(p, bp, q, bq, ed == 0); any |= bs[k]; }
+                bs[k] = edge_bs(p, bp, q, bq, ed == 0 ? (dir && e->field ? 2 : 1) : 0); any |= bs[k]; }
             if (!any) continue;
             int qa = (p->qp + q->qp + 1) >> 1, ia = CLIP3(0, 51, qa + q->a_off), ib = CLIP3(0, 51, qa + q->b_off);
             for (int i = 0; i < 16; i++) if (bs[i >> 2]) {
@@ -786,6 +808,9 @@ static int sad16_pred(Enc *e, int mx, int my, const int *p) {
 /* ------------------------------ 8x8 transform (own implementation) ---------- */
 static const uint8_t zz8[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,
     35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
+/* 8x8 field scan (Table 8-3, raster index = 8 * y + x) */
+static const uint8_t fs8[64] = { 0,8,16,1,9,24,32,17, 2,25,40,48,56,33,10,3, 18,41,49,57,26,11,4,19, 34,42,50,58,27,12,5,20,
+    35,43,51,59,28,13,6,21, 36,44,52,60,29,14,22,37, 45,53,61,30,7,15,38,46, 54,62,23,31,39,47,55,63 };
 static const int norm8[6][6] = { {20,18,32,19,25,24},{22,19,35,21,28,26},{26,23,42,24,33,31},{28,25,45,26,35,33},{32,28,51,30,40,38},{36,32,58,34,46,43} };
 static int cls8(int i, int j) {
     int a = (i & 1) ? 1 : ((i & 3) ? 2 : 0), b = (j & 1) ? 1 : ((j & 3) ? 2 : 0);
@@ -1043,7 +1068,10 @@ static int cab_block(Enc *e, MbE *m, int cat, int bit, int fa, int fb, const int
         if (!n) return 0;
         m->cbf |= 1u << bit;
     }
-    int sb = cat == 5 ? 402 : 105 + sig_off[cat], lb = cat == 5 ? 417 : 166 + sig_off[cat], ab = cat == 5 ? 426 : 227 + abs_off[cat];
+    /* significant_coeff_flag / last_significant_coeff_flag have a second set of contexts for field-coded blocks (Table 9-34: 277.. / 338..) */
+    int sb = cat == 5 ? 402 : (e->field ? 277 : 105) + sig_off[cat], lb = cat == 5 ? 417 : (e->field ? 338 : 166) + sig_off[cat];
+    int ab = cat == 5 ? 426 : 227 + abs_off[cat];
+    if (cat == 5 && e->field) { fprintf(stderr, "h264gen: field-coded 8x8 block with CABAC\n"); abort(); }
     for (int i = 0; i < maxnum - 1; i++) {
         int si = cat == 5 ? orc_cabac_sig8_inc[i] : cat == 3 ? MIN(i, 2) : i, li = cat == 5 ? orc_cabac_last8_inc[i] : cat == 3 ? MIN(i, 2) : i;
         cab_enc(c, sb + si, coef[i] != 0);
@@ -1069,7 +1097,7 @@ static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) 
     BitW *w = &e->bw; int sc[64];
     MbE *mA = mb_avail(e, mx - 1, my), *mB = mb_avail(e, mx, my - 1);
     if (mc->type == 6) {
-        for (int i = 0; i < 16; i++) sc[i] = mc->dc16[zz4[i]];
+        for (int i = 0; i < 16; i++) sc[i] = mc->dc16[e->scan4[i]];
         if (e->cabac) cab_block(e, m, 0, 16, mA ? (int)((mA->cbf >> 16) & 1) : -1, mB ? (int)((mB->cbf >> 16) & 1) : -1, sc, 16);
         else write_block(w, sc, 16, nC_luma(e, mx, my, m, 0, 0));
     }
@@ -1078,12 +1106,12 @@ static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) 
             int ox = (b8 & 1) * 2, oy = (b8 >> 1) * 2, total = 0;
             if (!(mc->cbp & (1 << b8))) { for (int k = 0; k < 4; k++) m->tc[(oy + (k >> 1)) * 4 + ox + (k & 1)] = 0; continue; }
             if (e->cabac) {
-                for (int i = 0; i < 64; i++) sc[i] = mc->luma8[b8][zz8[i]];
+                for (int i = 0; i < 64; i++) sc[i] = mc->luma8[b8][e->scan8[i]];
                 total = cab_block(e, m, 5, -1, 0, 0, sc, 64);
                 for (int k = 0; k < 4; k++) { int r = (oy + (k >> 1)) * 4 + ox + (k & 1); m->tc[r] = (uint8_t)MIN(total, 16); m->cbf |= 1u << r; }
             } else for (int k = 0; k < 4; k++) {
                 int bx = ox + (k & 1), by = oy + (k >> 1);
-                for (int i = 0; i < 16; i++) sc[i] = mc->luma8[b8][zz8[4 * i + k]];
+                for (int i = 0; i < 16; i++) sc[i] = mc->luma8[b8][e->scan8[4 * i + k]];
                 int n = write_block(w, sc, 16, nC_luma(e, mx, my, m, bx, by));
                 m->tc[by * 4 + bx] = (uint8_t)n; total += n;
             }
@@ -1095,9 +1123,9 @@ static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) 
             if (!(mc->cbp & (1 << b8))) { m->tc[r] = 0; continue; }
             if (e->cabac) { int q; MbE *nn = nb4(e, mx, my, m, bx, by, 1, &q); if (nn) fa = (int)((nn->cbf >> q) & 1); nn = nb4(e, mx, my, m, bx, by, 0, &q);
                 if (nn) fb = (int)((nn->cbf >> q) & 1); }
-            if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][zz4[i + 1]];
+            if (mc->type == 6) { for (int i = 0; i < 15; i++) sc[i] = mc->luma[r][e->scan4[i + 1]];
                 n = e->cabac ? cab_block(e, m, 1, r, fa, fb, sc, 15) : write_block(w, sc, 15, nC_luma(e, mx, my, m, bx, by)); }
-            else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][zz4[i]]; n = e->cabac ? cab_block(e, m, 2, r, fa, fb, sc, 16) : write_block(w, sc, 16,
+            else { for (int i = 0; i < 16; i++) sc[i] = mc->luma[r][e->scan4[i]]; n = e->cabac ? cab_block(e, m, 2, r, fa, fb, sc, 16) : write_block(w, sc, 16,
                 nC_luma(e, mx, my, m, bx, by)); }
             m->tc[r] = (uint8_t)n;
             if (n) m->nzmask |= (uint16_t)(1u << r);
@@ -1109,7 +1137,7 @@ static void write_mb_residual(Enc *e, int mx, int my, MbE *m, const MbCode *mc) 
     }
     for (int pl = 0; pl < 2; pl++) for (int k = 0; k < 4; k++) {
         if (!(mc->cbp & 0x20)) { m->tc[16 + 4 * pl + k] = 0; continue; }
-        for (int i = 0; i < 15; i++) sc[i] = mc->cac[pl][k][zz4[i + 1]];
+        for (int i = 0; i < 15; i++) sc[i] = mc->cac[pl][k][e->scan4[i + 1]];
         if (e->cabac) {
             int bx = k & 1, by = k >> 1, b0 = 19 + pl * 4, fa, fb;
             if (bx) fa = (int)((m->cbf >> (b0 + by * 2)) & 1); else fa = mA ? (int)((mA->cbf >> (b0 + by * 2 + 1)) & 1) : -1;
@@ -1593,6 +1621,7 @@ static void sample4(Enc *e, const Frame *r, int px, int py, int mvx, int mvy, in
             for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) yl[y * 4 + x] = luma_sample(r, e->W, e->H, px + x + (mvx >> 2), py + y + (mvy >> 2),
                 mvx & 3, mvy & 3);
     }
+    if (e->field) mvy += r->parity == (e->field - 1) ? 0 : (r->parity ? -2 : 2);       /* Table 8-9, as in mc_block */
     int cw = e->W / 2, ch = e->H / 2, fx = mvx & 7, fy = mvy & 7;
     for (int pl = 0; pl < 2; pl++) { const uint8_t *rp = pl ? r->v : r->u; int *o = pl ? cv : cu;
         for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { int xi = px / 2 + x + (mvx >> 3), yi = py / 2 + y + (mvy >> 3);
@@ -1910,32 +1939,106 @@ static void write_sps_pps(Enc *e) {
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
 }
 
-/* t = display index; kind: 0 P (or IDR/I when t starts a GOP), 1 B (non-reference, coded after its following anchor) */
-static void encode_frame(Enc *e, int t, int is_b) {
+/* copy the lines of one parity of a frame into a field picture / back (the field pictures are pictures of half the height) */
+static void field_copy(Frame *frm, Frame *fld, int par, int W, int H, int to_field) {
+    for (int y = 0; y < H / 2; y++) {
+        uint8_t *a = frm->y + (2 * y + par) * frm->sy, *b = fld->y + y * fld->sy;
+        if (to_field) memcpy(b, a, W); else memcpy(a, b, W);
+    }
+    for (int pl = 0; pl < 2; pl++) for (int y = 0; y < H / 4; y++) {
+        uint8_t *a = (pl ? frm->v : frm->u) + (2 * y + par) * frm->sc, *b = (pl ? fld->v : fld->u) + y * fld->sc;
+        if (to_field) memcpy(b, a, W / 2); else memcpy(a, b, W / 2);
+    }
+}
+/* 8.2.4.2.5: the fields of an ordered list of frame stores, alternating in parity and starting with the parity of the current field; a store whose
+   field of the wanted parity is not marked `mark` is passed over, and when one parity runs out the rest of the other follows in order */
+static int alternate_fields(Frame **stores, int n, int mark, int par, Frame **out, int cnt) {
+    int c[2] = {0, 0}, q = par;
+    for (;;) {
+        while (c[q] < n && stores[c[q]]->fmark[q] != mark) c[q]++;
+        if (c[q] < n) { out[cnt++] = &stores[c[q]]->fld[q]; c[q]++; }
+        else { int o = q ^ 1; while (c[o] < n && stores[c[o]]->fmark[o] != mark) c[o]++; if (c[o] >= n) break; }
+        q ^= 1;
+    }
+    return cnt;
+}
+
+/* t = display index; is_b: a B picture (non-reference, coded after its following anchor), otherwise P (or IDR / I when t starts a GOP);
+   field: 0 = a frame picture, 1 / 2 = the top / bottom field of the frame as a picture of its own; second: it is the second field of its frame */
+static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
     GenParams *p = &e->p; BitW *w = &e->bw;
-    int idr = !is_b && (t % p->gop) == 0;
-    int is_ref = !is_b && (idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0));
+    /* an IDR frame coded as two fields: the first field is the IDR picture, the second a P (or I) field that can only see the first (7.4.1.2.4) */
+    int idr = !is_b && (t % p->gop) == 0 && !second, after_idr = second && (t % p->gop) == 0;
+    int is_ref = !is_b && (idr || after_idr || !(p->nonref_period > 0 && (t % p->gop) % p->nonref_period == p->nonref_period - 1 && (t + 1) % p->gop != 0));
     if (p->bframes) is_ref = !is_b;
-    render_source(e, t);
+    e->field = field; e->second = second;
+    e->scan4 = field ? fs4 : zz4; e->scan8 = field ? fs8 : zz8;
+    const int par = field ? field - 1 : 0;
+    if (!second) render_source(e, t);
     if (idr) { e->frame_num = 0; e->nrefs = 0; e->poc_base = t; write_sps_pps(e); }
+    /* the store of the frame being coded: a frame, or the first field of a non-reference frame, is coded into e->cur; the second field of a reference
+       frame into the store its first field already opened (e->refs[cur_store]) */
+    int cur_store = -1;
+    if (second && is_ref) { for (int i = 0; i < e->nrefs; i++) if (e->refs[i].id == e->cur_store_id) cur_store = i;
+        if (cur_store < 0) { fprintf(stderr, "h264gen: the first field's store is gone\n"); abort(); } }
+    Frame full_src = e->src, spare_cur = e->cur, full_cur = cur_store >= 0 ? e->refs[cur_store] : e->cur;
+    if (field) {
+        /* from here to the end of the picture the encoder sees a picture of half the height */
+        field_copy(&full_src, &e->fsrc, par, e->W, e->H, 1);
+        e->src = e->fsrc; e->cur = full_cur.fld[par]; e->cur.parity = par;
+        e->H /= 2; e->mbh /= 2;
+    }
     e->slice_type = idr ? 2 : (is_b ? 1 : 0);
     if (!idr && !is_b && p->mode == 1 && rnd_n(&e->rng, 12) == 0 && !p->no_intra) e->slice_type = 2;   /* occasional non-IDR I picture */
     /* 8.2.1: TopFieldOrderCnt counts 2 per picture from the last restart; with poc_bottom the bottom field may lie one below or above, and
-       PicOrderCnt(frame) = Min(top, bottom) is what the lists, direct prediction and the output order see */
-    e->cur_top = 2 * (t - e->poc_base); e->delta_bottom = 0; e->delta0 = 0;
-    if (p->poc_bottom) { e->delta_bottom = rnd_n(&e->rng, 3) - 1; if (idr && e->delta_bottom < 0) e->delta_bottom = 1; }
-        /* an IDR frame: Min(top, bottom) = 0 (8.2.1) */
+       PicOrderCnt(frame) = Min(top, bottom) is what the lists, direct prediction and the output order see.  Of two field pictures the first has the
+       frame's count, the second lies one above */
+    if (!second) {
+        e->cur_top = 2 * (t - e->poc_base); e->delta_bottom = 0; e->delta0 = 0;
+        if (p->poc_bottom && !field) { e->delta_bottom = rnd_n(&e->rng, 3) - 1; if (idr && e->delta_bottom < 0) e->delta_bottom = 1; }
+            /* an IDR frame: Min(top, bottom) = 0 (8.2.1) */
+        if (field) { e->delta_bottom = field == 1 ? 1 : -1; if (field == 2) e->cur_top += 1; }      /* bottom first: top = count + 1, bottom = count */
+        e->cur_poc = e->cur_top + MIN(0, e->delta_bottom);
+        if (e->pocs) e->pocs[t] = e->cur_poc;
+    }
     if (p->poc_type == 1) e->delta0 = rnd_n(&e->rng, 2);
-    e->cur_poc = e->cur_top + MIN(0, e->delta_bottom); e->cur.poc = e->cur_poc;
-    if (e->pocs) e->pocs[t] = e->cur_poc;
+    const int field_poc = field == 2 ? e->cur_top + e->delta_bottom : e->cur_top;       /* the count this picture's slice headers carry (type 0) */
+    e->cur.poc = field ? field_poc : e->cur_poc;
     const int maxfn = 1 << e->log2_max_fn, curfn = e->frame_num & (maxfn - 1);
     e->cur.frame_num = curfn; e->cur.is_long = 0; e->cur.lt_idx = -1;
 #define PICNUM(f) ((f)->frame_num > curfn ? (f)->frame_num - maxfn : (f)->frame_num)
-    Frame *init[2][5]; int ninit[2] = {0, 0};
-    if (!is_b) {
+    /* 8.2.4.1: picture numbers.  In a field picture every reference FIELD has one: twice the frame's number, plus one for a field of the current parity */
+#define PN(f) (field ? 2 * PICNUM(f) + ((f)->parity == par) : PICNUM(f))
+#define LPN(f) (field ? 2 * (f)->lt_idx + ((f)->parity == par) : (f)->lt_idx)
+    const int cur_pn = field ? 2 * curfn + 1 : curfn, max_pn = field ? 2 * maxfn : maxfn;
+    Frame *init[2][16]; int ninit[2] = {0, 0};
+    if (field) {
+        /* 8.2.4.2.2 + 8.2.4.2.5 (P field): frame stores with any field marked short-term by descending FrameNumWrap -- the store of the first field
+           of this frame among them, at the front --, then those with a long-term field by ascending LongTermFrameIdx; from each list the fields */
+        Frame *sh[6], *lg[6]; int ns = 0, nl = 0;
+        for (int i = 0; i < e->nrefs; i++) {
+            Frame *s = &e->refs[i];
+            for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; }
+            if (s->fmark[0] == 1 || s->fmark[1] == 1) sh[ns++] = s;
+            if (s->fmark[0] == 2 || s->fmark[1] == 2) lg[nl++] = s;
+        }
+        for (int i = 0; i < ns; i++) for (int j = i + 1; j < ns; j++) if (PICNUM(sh[j]) > PICNUM(sh[i])) { Frame *x = sh[i]; sh[i] = sh[j]; sh[j] = x; }
+        for (int i = 0; i < nl; i++) for (int j = i + 1; j < nl; j++) if (lg[j]->lt_idx < lg[i]->lt_idx) { Frame *x = lg[i]; lg[i] = lg[j]; lg[j] = x; }
+        ninit[0] = alternate_fields(sh, ns, 1, par, init[0], 0);
+        ninit[0] = alternate_fields(lg, nl, 2, par, init[0], ninit[0]);
+        e->nlist0 = MIN(ninit[0], 2 * p->num_ref); e->nlist1 = 0;
+        if (p->mode == 1 && e->nlist0 > 1 && rnd_n(&e->rng, 3) == 0) e->nlist0 = 1 + rnd_n(&e->rng, e->nlist0);      /* num_ref_idx_active override */
+        for (int i = 0; i < e->nlist0; i++) e->list0[i] = init[0][i];
+        if (e->nlist0 == 0 && e->slice_type == 0) e->slice_type = 2;
+    } else if (!is_b) {
         /* 8.2.4.2.1: short-term references by descending PicNum (most recent first), then long-term by ascending LongTermPicNum */
         Frame *sh[5], *lg[5]; int ns = 0, nl = 0;
-        for (int i = 0; i < e->nrefs; i++) { if (e->refs[i].is_long) lg[nl++] = &e->refs[i]; else sh[ns++] = &e->refs[i]; }
+        for (int i = 0; i < e->nrefs; i++) {
+            if (p->paff && e->refs[i].fmark[0] != e->refs[i].fmark[1]) continue;      /* a frame needs both of its fields to be a reference frame */
+            if (e->refs[i].is_long) lg[nl++] = &e->refs[i]; else sh[ns++] = &e->refs[i];
+        }
+        if (ns + nl == 0 && e->slice_type == 0) e->slice_type = 2;
         for (int i = 0; i < ns; i++) for (int j = i + 1; j < ns; j++) if (PICNUM(sh[j]) > PICNUM(sh[i])) { Frame *x = sh[i]; sh[i] = sh[j]; sh[j] = x; }
         for (int i = 0; i < nl; i++) for (int j = i + 1; j < nl; j++) if (lg[j]->lt_idx < lg[i]->lt_idx) { Frame *x = lg[i]; lg[i] = lg[j]; lg[j] = x; }
         for (int i = 0; i < ns; i++) init[0][ninit[0]++] = sh[i];
@@ -1966,16 +2069,16 @@ static void encode_frame(Enc *e, int t, int is_b) {
     if (p->rplm && e->slice_type != 2) for (int l = 0; l < (is_b ? 2 : 1); l++) {
         int nact = l ? e->nlist1 : e->nlist0;
         if (nact < 1 || rnd_n(&e->rng, 2)) continue;
-        Frame *list[8]; for (int i = 0; i < 8; i++) list[i] = i < ninit[l] && i < nact ? init[l][i] : NULL;
-        int m = 1 + rnd_n(&e->rng, MIN(nact, 3)), pred = curfn, idx = 0;
+        Frame *list[20]; for (int i = 0; i < 20; i++) list[i] = i < ninit[l] && i < nact ? init[l][i] : NULL;
+        int m = 1 + rnd_n(&e->rng, MIN(nact, 3)), pred = cur_pn, idx = 0;
         for (int k = 0; k < m; k++) {
             Frame *tg = init[l][rnd_n(&e->rng, ninit[l])];
-            if (tg->is_long) { e->mod_idc[l][k] = 2; e->mod_val[l][k] = tg->lt_idx; }
+            if (tg->is_long) { e->mod_idc[l][k] = 2; e->mod_val[l][k] = LPN(tg); }
             else {
-                int pn = PICNUM(tg), nowrap = pn < 0 ? pn + maxfn : pn, diff = nowrap - pred;
+                int pn = PN(tg), nowrap = pn < 0 ? pn + max_pn : pn, diff = nowrap - pred;
                 if (diff > 0) { e->mod_idc[l][k] = 1; e->mod_val[l][k] = diff - 1; }
                 else if (diff < 0) { e->mod_idc[l][k] = 0; e->mod_val[l][k] = -diff - 1; }
-                else { e->mod_idc[l][k] = 0; e->mod_val[l][k] = maxfn - 1; }            /* a full turn lands on the same PicNum */
+                else { e->mod_idc[l][k] = 0; e->mod_val[l][k] = max_pn - 1; }           /* a full turn lands on the same PicNum */
                 pred = nowrap;
             }
             for (int c = nact; c > idx; c--) list[c] = list[c - 1];
@@ -1990,7 +2093,36 @@ static void encode_frame(Enc *e, int t, int is_b) {
     }
     /* 8.2.5: marking of this picture (decided before the slices are written; applied after the picture is coded) */
     e->n_mmco = 0; e->idr_long = 0;
-    if (p->mmco && is_ref && !is_b) {
+    int half_stores = 0;            /* PAFF: frame stores of which only one field is (still) a reference; no frame picture number names them */
+    if (p->paff) for (int i = 0; i < e->nrefs; i++) half_stores += e->refs[i].fmark[0] != e->refs[i].fmark[1];
+    if (p->mmco && is_ref && !is_b && field) {
+        /* Field pictures (8.2.5.4 with field picture numbers): now and then one reference FIELD is dropped (operation 1), or every field of one frame
+           store (operation 1 per short-term field, operation 2 per long-term field).  The first field of a frame needs a free frame store and, with
+           operations present, gets no sliding window: stores are dropped until there is one.  (Operations 3, 4, 6 and 5 appear in the frame
+           pictures of the stream only.) */
+        uint8_t sim[5][2]; int n_used = 0;
+        for (int i = 0; i < e->nrefs; i++) { sim[i][0] = e->refs[i].fmark[0]; sim[i][1] = e->refs[i].fmark[1]; n_used += sim[i][0] || sim[i][1]; }
+        int any_short = 0; for (int i = 0; i < e->nrefs; i++) if (i != cur_store) any_short |= sim[i][0] == 1 || sim[i][1] == 1;
+        const int must = !idr && !second && !any_short && n_used >= p->num_ref;
+#define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
+#define DROP_FIELD(i_, q_) do { Frame *f_ = &e->refs[i_].fld[q_]; if (sim[i_][q_] == 1) ADD_OP(1, cur_pn - PN(f_) - 1, 0); else ADD_OP(2, LPN(f_), 0); \
+        sim[i_][q_] = 0; } while (0)
+        if (!idr && (must || rnd_n(&e->rng, 3) == 0)) {
+            int cand[10][2], nc = 0;
+            for (int i = 0; i < e->nrefs; i++) if (i != cur_store) for (int q = 0; q < 2; q++) if (sim[i][q] == 1) { cand[nc][0] = i; cand[nc][1] = q; nc++; }
+            if (nc > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, nc); DROP_FIELD(cand[k][0], cand[k][1]); }
+            else if (nc > 0 && rnd_n(&e->rng, 2)) { int i = cand[rnd_n(&e->rng, nc)][0]; for (int q = 0; q < 2; q++) if (sim[i][q]) DROP_FIELD(i, q); }
+            if (!second) for (;;) {                                      /* room for the store this field opens */
+                int used = 0, old = -1;
+                for (int i = 0; i < e->nrefs; i++) if (sim[i][0] || sim[i][1]) { used++;
+                    if (old < 0 || ((sim[old][0] == 2 || sim[old][1] == 2) && sim[i][0] != 2 && sim[i][1] != 2) ||
+                        (((sim[old][0] == 2 || sim[old][1] == 2) == (sim[i][0] == 2 || sim[i][1] == 2)) && PICNUM(&e->refs[i]) < PICNUM(&e->refs[old]))) old = i; }
+                if (used + 1 <= p->num_ref) break;
+                for (int q = 0; q < 2; q++) if (sim[old][q]) DROP_FIELD(old, q);
+            }
+            if (e->n_mmco == 0 && must) { fprintf(stderr, "h264gen: no way to make room\n"); abort(); }
+        }
+    } else if (p->mmco && is_ref && !is_b && !(half_stores && !idr)) {
         if (idr) e->idr_long = rnd_n(&e->rng, 3) == 0;
         else {
             int st_fn[5], st_n = 0, lt_ix[5], lt_n = 0, maxlt = e->max_lt_idx, cur_long = 0;      /* simulated state */
@@ -2002,7 +2134,6 @@ static void encode_frame(Enc *e, int t, int is_b) {
                one in none of the ways 7.4.1.2.4 lists (same frame_num, both reference pictures, same order-count syntax) */
             if (p->mmco == 2 && curfn != 1 && rnd_n(&e->rng, 5) == 0) { e->mmco_op[0] = 5; e->mmco_a[0] = e->mmco_b[0] = 0; e->n_mmco = 1; }
             else if (must || rnd_n(&e->rng, 3) == 0) {
-#define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
 #define DROP_LT(ix) do { for (int q_ = 0; q_ < lt_n; q_++) if (lt_ix[q_] == (ix)) { lt_ix[q_] = lt_ix[--lt_n]; break; } } while (0)
             if (maxlt < 1 && rnd_n(&e->rng, 2)) { ADD_OP(4, 2, 0); maxlt = 1; }
             if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1);
@@ -2021,20 +2152,22 @@ static void encode_frame(Enc *e, int t, int is_b) {
     }
     /* explicit weights of this picture (8.4.2.3); the same table is sent in every slice */
     e->wlog[0] = 5; e->wlog[1] = 5;
-    for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) for (int c = 0; c < 3; c++) { e->ww[l][i][c] = 32; e->wo[l][i][c] = 0; }
+    const int nwp = e->field ? 16 : 5;           /* entries of the weight tables drawn (a field list holds up to twice as many entries) */
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) { e->ww[l][i][c] = 32; e->wo[l][i][c] = 0; }
     int use_wp = (e->slice_type == 0 && p->wp == 1) || (e->slice_type == 1 && p->wp == 1);
     if (use_wp) {
         e->wlog[0] = 3 + rnd_n(&e->rng, 4); e->wlog[1] = 2 + rnd_n(&e->rng, 4);
-        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) for (int c = 0; c < 3; c++) {
+        for (int l = 0; l < 2; l++) for (int i = 0; i < nwp; i++) for (int c = 0; c < 3; c++) {
             int one = 1 << e->wlog[c != 0];
             e->ww[l][i][c] = one; e->wo[l][i][c] = 0;
             if (rnd_n(&e->rng, 3)) { e->ww[l][i][c] = one + rnd_n(&e->rng, one / 2 + 1) - one / 4; e->wo[l][i][c] = rnd_n(&e->rng, 13) - 6; }
         }
-        for (int l = 0; l < 2; l++) for (int i = 0; i < 5; i++) if (e->ww[l][i][1] == (1 << e->wlog[1]) && e->wo[l][i][1] == 0 &&
+        for (int l = 0; l < 2; l++) for (int i = 0; i < nwp; i++) if (e->ww[l][i][1] == (1 << e->wlog[1]) && e->wo[l][i][1] == 0 &&
             (e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0)) e->wo[l][i][1] = 1;
         /* one chroma flag covers Cb and Cr */
     }
-    e->cur.id = e->next_id++;
+    if (!field) e->cur.id = e->next_id++;
+    else { if (!second) full_cur.id = e->next_id++; e->cur.id = (1 << 20) + 2 * full_cur.id + par; }
     int mbs_total = e->mbw * e->mbh, rows_per = (e->mbh + p->slices - 1) / p->slices;
     for (int i = 0; i < mbs_total; i++) e->mbs[i].slice = -1;
     for (int sl = 0, first_row = 0; first_row < e->mbh; sl++, first_row += rows_per) {
@@ -2045,11 +2178,12 @@ static void encode_frame(Enc *e, int t, int is_b) {
         bw_ue(w, e->slice_type + ((sl & 1) ? 0 : 5));                     /* alternate slice_type / slice_type+5 spelling */
         bw_ue(w, 0);
         bw_put(w, e->log2_max_fn, e->frame_num & ((1 << e->log2_max_fn) - 1));
-        if (p->fmo0) bw_put(w, 1, 0);                                      /* field_pic_flag */
+        if (p->fmo0) { bw_put(w, 1, (uint32_t)(field != 0)); if (field) bw_put(w, 1, (uint32_t)(field == 2)); }    /* field_pic_flag, bottom_field_flag */
         if (idr) bw_ue(w, e->idr_id & 0xffff);
-        if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)e->cur_top & ((1u << e->poc_lsb_bits) - 1)); if (p->poc_bottom) bw_se(w, e->delta_bottom);
-            }
-        if (p->poc_type == 1) { bw_se(w, e->delta0); if (p->poc_bottom) bw_se(w, e->delta_bottom); }
+        /* a field carries its own count; delta_pic_order_cnt_bottom / delta_pic_order_cnt[1] belong to frames (7.3.3) */
+        if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)(field ? field_poc : e->cur_top) & ((1u << e->poc_lsb_bits) - 1));
+            if (p->poc_bottom && !field) bw_se(w, e->delta_bottom); }
+        if (p->poc_type == 1) { bw_se(w, e->delta0); if (p->poc_bottom && !field) bw_se(w, e->delta_bottom); }
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); }
         if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); }
@@ -2099,6 +2233,74 @@ static void encode_frame(Enc *e, int t, int is_b) {
         out_nal(&e->out, is_ref ? (idr ? 3 : 2) : 0, idr ? 5 : 1, w, sl == 0);
     }
     if (p->deblock != 0) deblock_frame(e);
+#define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; \
+        for (int q_ = (i_); q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; \
+        e->nrefs--; e->refs[e->nrefs] = t_; } while (0)
+    if (field) {
+        /* ---- end of a field picture ---- */
+        if (getenv("H264GEN_STATS")) {
+            fprintf(stderr, "frame %d %s field (%s) type %c ref %d fn %d list0:", t, field == 1 ? "top" : "bottom", second ? "second" : "first",
+                    idr ? 'I' : (e->slice_type == 2 ? 'i' : 'P'), is_ref, curfn);
+            for (int i = 0; i < e->nlist0; i++) fprintf(stderr, " %s%d%c", e->list0[i]->is_long ? "L" : "fn", e->list0[i]->is_long ? e->list0[i]->lt_idx :
+                e->list0[i]->frame_num, e->list0[i]->parity ? 'b' : 't');
+            for (int k = 0; k < e->n_mmco; k++) fprintf(stderr, " mmco%d(%d)", e->mmco_op[k], e->mmco_a[k]);
+            fprintf(stderr, " bytes %zu\n", e->out.len);
+        }
+        if (is_ref) frame_finish_ref(&e->cur, e->W, e->H);
+        full_cur.fld[par] = e->cur; e->src = full_src; e->H *= 2; e->mbh *= 2;
+        full_cur.fpoc[par] = field_poc;
+        if (is_ref) {
+            /* 8.2.5 for a reference field.  The store of the first field is not in e->refs yet; that of the second is e->refs[cur_store] */
+            if (cur_store >= 0) e->refs[cur_store] = full_cur;
+            if (e->n_mmco) {
+                for (int k = 0; k < e->n_mmco; k++) {
+                    int o = e->mmco_op[k], a = e->mmco_a[k], hit = 0;
+                    for (int i = 0; i < e->nrefs && !hit; i++) for (int q = 0; q < 2 && !hit; q++) {
+                        Frame *f = &e->refs[i].fld[q];
+                        if ((o == 1 && e->refs[i].fmark[q] == 1 && PN(f) == cur_pn - (a + 1)) || (o == 2 && e->refs[i].fmark[q] == 2 && LPN(f) == a)) {
+                            e->refs[i].fmark[q] = 0; hit = 1;
+                            if (!e->refs[i].fmark[0] && !e->refs[i].fmark[1]) { if (i == cur_store) abort(); REMOVE_REF(i); if (cur_store > i) cur_store--; }
+                        }
+                    }
+                    if (!hit) { fprintf(stderr, "h264gen: field MMCO names a missing picture\n"); abort(); }
+                }
+            } else if (!second && !idr && e->nrefs >= p->num_ref) {       /* sliding window (8.2.5.3); never for the second field of a reference frame */
+                int old = -1;
+                for (int i = 0; i < e->nrefs; i++) if ((e->refs[i].fmark[0] == 1 || e->refs[i].fmark[1] == 1) && (old < 0 ||
+                    PICNUM(&e->refs[i]) < PICNUM(&e->refs[old]))) old = i;
+                if (old < 0) { fprintf(stderr, "h264gen: sliding window without a short-term picture\n"); abort(); }
+                REMOVE_REF(old);
+            }
+            if (!second) {
+                if (idr) e->max_lt_idx = -1;
+                if (e->nrefs >= p->num_ref) { fprintf(stderr, "h264gen: no free frame store for a field\n"); abort(); }
+                full_cur.frame_num = curfn; full_cur.is_long = 0; full_cur.lt_idx = -1; full_cur.fmark[par] = 1; full_cur.fmark[par ^ 1] = 0;
+                e->cur_store_id = full_cur.id;
+                Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = full_cur; e->cur = t_; e->nrefs++;
+            } else {
+                Frame *s = &e->refs[cur_store];
+                s->fmark[par] = 1; s->poc = MIN(s->fpoc[0], s->fpoc[1]);
+                for (int q = 0; q < 2; q++) field_copy(s, &s->fld[q], q, e->W, e->H, 0);
+                frame_finish_ref(s, e->W, e->H);
+                e->frame_num++;
+                e->cur = spare_cur;
+            }
+        } else {
+            e->cur = full_cur;
+            if (second) for (int q = 0; q < 2; q++) field_copy(&e->cur, &e->cur.fld[q], q, e->W, e->H, 0);
+        }
+        if (second && e->recon_buf && t < e->recon_frames) {
+            const Frame *s = is_ref ? &e->refs[cur_store] : &e->cur;
+            uint8_t *o = e->recon_buf + (size_t)t * (p->width * p->height * 3 / 2);
+            for (int y = 0; y < p->height; y++) memcpy(o + (size_t)y * p->width, s->y + y * s->sy, p->width);
+            o += (size_t)p->width * p->height;
+            for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), s->u + y * s->sc, p->width / 2);
+            o += (size_t)(p->width / 2) * (p->height / 2);
+            for (int y = 0; y < p->height / 2; y++) memcpy(o + (size_t)y * (p->width / 2), s->v + y * s->sc, p->width / 2);
+        }
+        if (idr) e->idr_id++;
+        return;
+    }
     if (getenv("H264GEN_STATS")) {
         double se = 0; int cnt[6] = {0}, nzmv = 0, qmv = 0;
         for (int y = 0; y < p->height; y++) for (int x = 0; x < p->width; x++) { int d = e->src.y[y * e->src.sy + x] - e->cur.y[y * e->cur.sy + x];
@@ -2127,9 +2329,6 @@ static void encode_frame(Enc *e, int t, int is_b) {
         if (!e->cur.mf) e->cur.mf = malloc(sizeof(MbE) * (size_t)mbs_total);
         memcpy(e->cur.mf, e->mbs, sizeof(MbE) * (size_t)mbs_total);
         /* 8.2.5 marking; e->refs[] is the set of reference frames, refs[nrefs..4] + cur are free frame stores */
-#define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; \
-        for (int q_ = (i_); q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; \
-        e->nrefs--; e->refs[e->nrefs] = t_; } while (0)
         if (idr) { e->max_lt_idx = e->idr_long ? 0 : -1; e->cur.is_long = e->idr_long; e->cur.lt_idx = e->idr_long ? 0 : -1; }
         else if (e->n_mmco) {
             for (int k = 0; k < e->n_mmco; k++) {
@@ -2161,10 +2360,26 @@ static void encode_frame(Enc *e, int t, int is_b) {
             if (old < 0) old = 0;
             REMOVE_REF(old);
         }
+        if (p->paff) {
+            /* the frame's two fields as pictures of their own, for the field pictures that follow */
+            for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long) e->refs[i].fmark[0] = e->refs[i].fmark[1] = 2;
+            e->cur.fmark[0] = e->cur.fmark[1] = e->cur.is_long ? 2 : 1;
+            e->cur.fpoc[0] = e->cur.poc - MIN(0, e->delta_bottom); e->cur.fpoc[1] = e->cur.fpoc[0] + e->delta_bottom;
+            for (int q = 0; q < 2; q++) { field_copy(&e->cur, &e->cur.fld[q], q, e->W, e->H, 1); frame_finish_ref(&e->cur.fld[q], e->W, e->H / 2); }
+        }
         { Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = e->cur; e->cur = t_; e->nrefs++; }
         e->frame_num++;
     }
     if (idr) e->idr_id++;
+}
+
+/* one frame of the stream: a frame picture, or (PAFF) two field pictures -- the first of either parity */
+static void encode_frame(Enc *e, int t, int is_b) {
+    int as_fields = !is_b && e->p.paff && (e->p.paff == 2 || rnd_n(&e->rng, 2));
+    if (!as_fields) { encode_picture(e, t, is_b, 0, 0); return; }
+    int first = 1 + rnd_n(&e->rng, 2);
+    encode_picture(e, t, 0, first, 0);
+    encode_picture(e, t, 0, 3 - first, 1);
 }
 
 /* The picture order counts the encoder MEANT, by display index, of the stream this thread generated last: TopFieldOrderCnt counts 2 per picture from
@@ -2189,6 +2404,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     if (p->poc_type != 0 && p->poc_type != 1) p->poc_type = 2;
     p->poc_bottom = p->poc_bottom != 0;
     p->scaling = CLIP3(0, 2, p->scaling);
+    p->paff = CLIP3(0, 2, p->paff);
+    if (p->paff) { p->fmo0 = 1; p->bframes = 0; if (p->cabac) p->t8x8 = 0; if (p->wp == 2) p->wp = 0; }
     if (p->bframes) p->mmco = 0;
     e->max_lt_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
@@ -2211,6 +2428,11 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     e->rng.s = (uint64_t)p->seed * 0x9E3779B97F4A7C15ull + 12345;
     frame_alloc(&e->src, e->W, e->H, 0); frame_alloc(&e->cur, e->W, e->H, 1);
     for (int i = 0; i < 5; i++) frame_alloc(&e->refs[i], e->W, e->H, 1);
+    if (p->paff) {
+        frame_alloc(&e->fsrc, e->W, e->H / 2, 0);
+        for (int i = 0; i < 6; i++) { Frame *f = i < 5 ? &e->refs[i] : &e->cur; f->fld = (Frame *)calloc(2, sizeof(Frame));
+            for (int q = 0; q < 2; q++) frame_alloc(&f->fld[q], e->W, e->H / 2, 1); }
+    }
     e->mbs = (MbE *)calloc((size_t)e->mbw * e->mbh, sizeof(MbE));
     make_texture(e);
     e->pocs = (int *)calloc((size_t)p->frames + 1, sizeof(int));
@@ -2231,6 +2453,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     *out = e->out.buf; *out_len = e->out.len;
     free(g_last_pocs); g_last_pocs = e->pocs; g_last_n = p->frames;
     free(e->cur.mf); for (int i = 0; i < 5; i++) free(e->refs[i].mf);
+    if (p->paff) { frame_free(&e->fsrc);
+        for (int i = 0; i < 6; i++) { Frame *f = i < 5 ? &e->refs[i] : &e->cur; for (int q = 0; q < 2; q++) frame_free(&f->fld[q]); free(f->fld); } }
     frame_free(&e->src); frame_free(&e->cur); for (int i = 0; i < 5; i++) frame_free(&e->refs[i]);
     free(e->mbs); free(e->bw.buf); free(e);
     return 0;
@@ -2252,7 +2476,7 @@ int main(int argc, char **argv) {
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
         OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm",
-            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom)
+            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
