@@ -262,7 +262,11 @@ int orc_cabac_residual_block(Sl *s, int cat, int idx, int16_t *coef, int maxnum)
         if (!decision(c, 85 + cbf_off[cat] + fa + 2 * fb)) return 0;
         mb->cbf |= 1u << bit;
     }
-    int sig_base = cat == 5 ? 402 : 105 + sig_off[cat], last_base = cat == 5 ? 417 : 166 + sig_off[cat];
+    /* Table 9-34: significant_coeff_flag / last_significant_coeff_flag of field-coded blocks have their own contexts, 277.. / 338.. (the
+     * 8x8 blocks' 436.. / 451.. are not in the tables: their initial values are not pinned, tests/SPEC_AUDIT.md, and such streams are refused) */
+    const int fld = s->d->field_pic;
+    if (fld && cat == 5) { snprintf(s->d->err, sizeof s->d->err, "CABAC residual of a field-coded 8x8 block unsupported"); return -1; }
+    int sig_base = cat == 5 ? 402 : (fld ? 277 : 105) + sig_off[cat], last_base = cat == 5 ? 417 : (fld ? 338 : 166) + sig_off[cat];
     int abs_base = cat == 5 ? 426 : 227 + abs_off[cat];
     uint8_t sig[64];
     int num = maxnum, i;

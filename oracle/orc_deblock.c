@@ -9,9 +9,13 @@
 #include "orc_tables.h"
 
 /* 8.7.2.1 boundary strength between 4x4 luma blocks p (in MB mp, raster bp)
- * and q (in MB mq, raster bq); mb_edge = edge lies on a macroblock boundary */
-static int bs_of(const MbInfo *mp, int bp, const MbInfo *mq, int bq, int mb_edge) {
-    if (mp->is_intra || mq->is_intra) return mb_edge ? 4 : 3;
+ * and q (in MB mq, raster bq); mb_edge = edge lies on a macroblock boundary.
+ * field = the picture is a field picture, horizontal = the edge is a horizontal one: the value 4 is for frame macroblocks and for the vertical edges
+ * of field macroblocks -- an intra macroblock edge that runs horizontally through a field gets 3; and the vertical vector difference that counts as
+ * "one frame sample" is 2 quarter FIELD samples. */
+static int bs_of(OrcDec *d, const MbInfo *mp, int bp, const MbInfo *mq, int bq, int mb_edge, int field, int horizontal) {
+    if (mp->is_intra || mq->is_intra) { if (mb_edge && field && horizontal) d->stats[ORC_ST_FIELD_BS3]++; return mb_edge && !(field && horizontal) ? 4 : 3; }
+    const int vlimit = field ? 2 : 4;
     int nzp, nzq;
     if (mp->t8x8) { int o = ((bp >> 3) * 2 + ((bp & 3) >> 1)); o = (o >> 1) * 8 + (o & 1) * 2;
         nzp = mp->total_coeff[o] | mp->total_coeff[o + 1] | mp->total_coeff[o + 4] | mp->total_coeff[o + 5]; }
@@ -25,7 +29,7 @@ static int bs_of(const MbInfo *mp, int bp, const MbInfo *mq, int bq, int mb_edge
     int p0 = mp->ref_idx[0][pb8] >= 0 ? mp->ref_pic_id[0][pb8] : -1, p1 = mp->ref_idx[1][pb8] >= 0 ? mp->ref_pic_id[1][pb8] : -1;
     int q0 = mq->ref_idx[0][qb8] >= 0 ? mq->ref_pic_id[0][qb8] : -1, q1 = mq->ref_idx[1][qb8] >= 0 ? mq->ref_pic_id[1][qb8] : -1;
     const int16_t *pm0 = mp->mv[0][bp], *pm1 = mp->mv[1][bp], *qm0 = mq->mv[0][bq], *qm1 = mq->mv[1][bq];
-#define FAR(a, b) (orc_abs((a)[0] - (b)[0]) >= 4 || orc_abs((a)[1] - (b)[1]) >= 4)
+#define FAR(a, b) (orc_abs((a)[0] - (b)[0]) >= 4 || (orc_abs((a)[1] - (b)[1]) >= vlimit && (orc_abs((a)[1] - (b)[1]) >= 4 || ++d->stats[ORC_ST_FIELD_MVY])))
     int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
     if (np != nq) return 1;
     if (np == 1) {
@@ -101,7 +105,7 @@ void orc_deblock_picture(OrcDec *d, Picture *pic) {
                 for (int k = 0; k < 4; k++) {
                     int bq = dir == 0 ? k * 4 + e : e * 4 + k;
                     int bp = e == 0 ? (dir == 0 ? k * 4 + 3 : 12 + k) : (dir == 0 ? bq - 1 : bq - 4);
-                    bS[k] = bs_of(mp, bp, mq, bq, e == 0);
+                    bS[k] = bs_of(d, mp, bp, mq, bq, e == 0, pic->is_field, dir == 1);
                 }
                 if (!(bS[0] | bS[1] | bS[2] | bS[3])) continue;
                 /* luma */

@@ -31,8 +31,16 @@ static void free_pictures(OrcDec *d) {
         free(d->dpb[i].y); free(d->dpb[i].u); free(d->dpb[i].v); free(d->dpb[i].mbs);
         memset(&d->dpb[i], 0, sizeof d->dpb[i]);
     }
-    d->cur = NULL;
+    d->cur = d->cur_store = d->pending = NULL;
 }
+
+/* is_ref of a frame store from the marking of its two fields (see Picture) */
+void orc_sync_ref(Picture *p) {
+    p->is_ref = (p->fmark[0] == 1 && p->fmark[1] == 1) ? 1 : (p->fmark[0] == 2 && p->fmark[1] == 2) ? 2 : (p->fmark[0] || p->fmark[1]) ? 3 : 0;
+}
+static void set_ref(Picture *p, int v) { p->fmark[0] = p->fmark[1] = v; p->is_ref = v; }      /* both fields of a store at once */
+static int any_short(const Picture *p) { return p->fmark[0] == 1 || p->fmark[1] == 1; }
+static int any_long(const Picture *p) { return p->fmark[0] == 2 || p->fmark[1] == 2; }
 
 static void emit(OrcDec *d, Picture *p) {
     const Sps *s = d->asps;
@@ -52,7 +60,7 @@ static Picture *smallest_poc_waiting(OrcDec *d, const Picture *exclude) {
     Picture *best = NULL;
     for (int i = 0; i <= ORC_MAX_DPB; i++) {
         Picture *p = &d->dpb[i];
-        if (!p->in_use || p == exclude || !p->needed_for_output) continue;
+        if (!p->in_use || p == exclude || !p->needed_for_output || p->waiting_second) continue;
         if (!best || p->poc < best->poc) best = p;
     }
     return best;
@@ -60,12 +68,12 @@ static Picture *smallest_poc_waiting(OrcDec *d, const Picture *exclude) {
 static void release_unused(OrcDec *d) {
     for (int i = 0; i <= ORC_MAX_DPB; i++) {
         Picture *p = &d->dpb[i];
-        if (p->in_use && p != d->cur && !p->is_ref && !p->needed_for_output) p->in_use = 0;
+        if (p->in_use && p != d->cur_store && p != d->pending && !p->is_ref && !p->needed_for_output) p->in_use = 0;
     }
 }
 void orc_output_all(OrcDec *d) {
     Picture *p;
-    while ((p = smallest_poc_waiting(d, d->cur)) != NULL) emit(d, p);
+    while ((p = smallest_poc_waiting(d, d->cur_store)) != NULL) emit(d, p);
     release_unused(d);
 }
 
@@ -97,56 +105,90 @@ static int activate(OrcDec *d, const Sps *sps, const Pps *pps) {
     return 0;
 }
 
-/* 8.2.1 decoding process for picture order count (frames only) */
-static int compute_poc(OrcDec *d, const SliceHdr *sh) {
+/* 8.2.1 decoding process for picture order count: TopFieldOrderCnt and / or BottomFieldOrderCnt of the current frame or field into fpoc[] of its
+ * store; returns PicOrderCnt of the picture (a frame: Min(top, bottom); a field: its own) */
+static int compute_poc(OrcDec *d, const SliceHdr *sh, Picture *store) {
     const Sps *s = d->asps;
     int max_frame_num = 1 << s->log2_max_frame_num;
+    int top = 0, bot = 0;
     if (s->poc_type == 0) {
         int max_lsb = 1 << s->log2_max_poc_lsb, prev_msb, prev_lsb;
-        /* prevPicOrderCntMsb / Lsb belong to the previous REFERENCE picture in decoding order (non-reference pictures in between change nothing).
-         * When that picture carried operation 5 they are 0 and its TopFieldOrderCnt after the operation: orc_finish_picture stores exactly that. */
+        /* prevPicOrderCntMsb / Lsb belong to the previous REFERENCE picture in decoding order (non-reference pictures in between change nothing; the
+         * first field of a reference frame is that picture for its second field).  When that picture carried operation 5 they are 0 and its
+         * TopFieldOrderCnt after the operation: orc_finish_picture stores exactly that. */
         if (sh->idr) { prev_msb = 0; prev_lsb = 0; }
         else { prev_msb = d->prev_poc_msb; prev_lsb = d->prev_poc_lsb; }
         int msb;
         if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
         else if (sh->poc_lsb > prev_lsb && sh->poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
         else msb = prev_msb;
-        int top = msb + sh->poc_lsb, bot = top + sh->delta_poc_bottom;
+        /* 8.2.1.1: a frame or a top field: TopFieldOrderCnt = msb + lsb; a frame's bottom field lies delta_pic_order_cnt_bottom from it, a bottom
+         * field picture has BottomFieldOrderCnt = msb + lsb */
+        top = bot = msb + sh->poc_lsb;
+        if (!sh->field_pic) bot = top + sh->delta_poc_bottom;
         if (sh->nal_ref_idc) { d->prev_poc_msb = msb; d->prev_poc_lsb = sh->poc_lsb; }
-        d->cur_top_poc = top; d->cur_bot_poc = bot;
-        return orc_min(top, bot);
+    } else {
+        int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset;
+        int prev_fn = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num;
+        int off = sh->idr ? 0 : (prev_fn > sh->frame_num ? prev_off + max_frame_num : prev_off);
+        d->prev_frame_num_offset = off;
+        if (s->poc_type == 2) {
+            /* 8.2.1.3: both fields of a frame -- coded as a frame or as two fields -- get the same count */
+            top = bot = sh->idr ? 0 : (sh->nal_ref_idc ? 2 * (off + sh->frame_num) : 2 * (off + sh->frame_num) - 1);
+        } else {
+            int abs_fn = s->num_ref_frames_in_poc_cycle ? off + sh->frame_num : 0;
+            if (!sh->nal_ref_idc && abs_fn > 0) abs_fn--;
+            int expected = 0, cycle_sum = 0;
+            for (int i = 0; i < s->num_ref_frames_in_poc_cycle; i++) cycle_sum += s->offset_for_ref_frame[i];
+            if (abs_fn > 0) {
+                int cnt = (abs_fn - 1) / s->num_ref_frames_in_poc_cycle, in_cycle = (abs_fn - 1) % s->num_ref_frames_in_poc_cycle;
+                expected = cnt * cycle_sum;
+                for (int i = 0; i <= in_cycle; i++) expected += s->offset_for_ref_frame[i];
+            }
+            if (!sh->nal_ref_idc) expected += s->offset_for_non_ref_pic;
+            /* 8.2.1.2: frame: top = expected + delta[0], bottom = top + offset_for_top_to_bottom_field + delta[1]; a bottom FIELD picture:
+             * expected + offset_for_top_to_bottom_field + delta[0] */
+            top = expected + sh->delta_poc[0];
+            bot = sh->field_pic ? expected + s->offset_for_top_to_bottom + sh->delta_poc[0] : top + s->offset_for_top_to_bottom + sh->delta_poc[1];
+        }
     }
-    int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset;
-    int prev_fn = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num;
-    int off = sh->idr ? 0 : (prev_fn > sh->frame_num ? prev_off + max_frame_num : prev_off);
-    d->prev_frame_num_offset = off;
-    if (s->poc_type == 2) {
-        if (sh->idr) return 0;
-        return sh->nal_ref_idc ? 2 * (off + sh->frame_num) : 2 * (off + sh->frame_num) - 1;
-    }
-    /* type 1 */
-    int abs_fn = s->num_ref_frames_in_poc_cycle ? off + sh->frame_num : 0;
-    if (!sh->nal_ref_idc && abs_fn > 0) abs_fn--;
-    int expected = 0, cycle_sum = 0;
-    for (int i = 0; i < s->num_ref_frames_in_poc_cycle; i++) cycle_sum += s->offset_for_ref_frame[i];
-    if (abs_fn > 0) {
-        int cnt = (abs_fn - 1) / s->num_ref_frames_in_poc_cycle, in_cycle = (abs_fn - 1) % s->num_ref_frames_in_poc_cycle;
-        expected = cnt * cycle_sum;
-        for (int i = 0; i <= in_cycle; i++) expected += s->offset_for_ref_frame[i];
-    }
-    if (!sh->nal_ref_idc) expected += s->offset_for_non_ref_pic;
-    int top = expected + sh->delta_poc[0], bot = top + s->offset_for_top_to_bottom + sh->delta_poc[1];
-    return orc_min(top, bot);
+    d->cur_top_poc = top; d->cur_bot_poc = bot;
+    if (!sh->field_pic) { store->fpoc[0] = top; store->fpoc[1] = bot; return orc_min(top, bot); }
+    store->fpoc[sh->bottom_field] = sh->bottom_field ? bot : top;
+    return store->fpoc[sh->bottom_field];
 }
+
+/* the view of field `par` of a store: the same samples, every second line (see Picture) */
+static Picture *field_view(OrcDec *d, Picture *s, int par) {
+    Picture *v = &d->fview[s - d->dpb][par];
+    int half = d->mb_w * (d->asps->mb_height / 2);
+    *v = *s;
+    v->y = s->y + par * s->stride_y; v->u = s->u + par * s->stride_c; v->v = s->v + par * s->stride_c;
+    v->stride_y = 2 * s->stride_y; v->stride_c = 2 * s->stride_c;
+    v->mbs = s->mbs + par * half;
+    v->is_field = 1; v->parity = par; v->store = s;
+    v->is_ref = s->fmark[par]; v->poc = s->fpoc[par];
+    v->id = 0x40000000 + 2 * s->id + par;       /* its own identity: two fields of one frame are different reference pictures (8.7.2.1) */
+    return v;
+}
+
+static void store_done(OrcDec *d, Picture *cur);
 
 int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
     const Pps *pps = &d->pps[sh->pps_id];
     const Sps *sps = &d->sps[pps->sps_id];
+    /* 3.30 / 7.4.1.2.4: this picture is the SECOND field of the frame whose first field came just before it -- opposite parity, the same frame_num,
+     * not an IDR picture, and a reference field exactly if the first one is */
+    Picture *pend = d->pending;
+    int second = pend && sh->field_pic && !sh->idr && pend->waiting_second && pend->frame_num == sh->frame_num &&
+                 pend->have == (sh->bottom_field ? 1 : 2) && pend->first_was_ref == (sh->nal_ref_idc != 0) && sps == d->asps;
+    if (pend && !second) { pend->waiting_second = 0; d->pending = NULL; d->stats[ORC_ST_LONE_FIELD]++; store_done(d, pend); }   /* a field that stays alone */
+    if (sh->field_pic && sh->slice_type == SLICE_B) ORC_FAIL(d, "B field pictures unsupported");
     if (sh->idr || !d->asps) {
         /* new coded video sequence: output everything that is waiting (no_output_of_prior_pics
          * would discard instead; the reference's CUVID parser displays them, so do we) */
         if (d->asps) {
-            for (int i = 0; i <= ORC_MAX_DPB; i++) d->dpb[i].is_ref = 0;
+            for (int i = 0; i <= ORC_MAX_DPB; i++) set_ref(&d->dpb[i], 0);
             orc_output_all(d);
         }
         if (activate(d, sps, pps) < 0) return -1;
@@ -154,23 +196,115 @@ int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
         if (sps != d->asps && (sps->mb_width != d->mb_w || sps->mb_height != d->mb_h)) ORC_FAIL(d, "SPS change without IDR");
         d->asps = sps; d->apps = pps;
     }
-    release_unused(d);
     Picture *cur = NULL;
-    for (int i = 0; i <= ORC_MAX_DPB; i++) if (!d->dpb[i].in_use) { cur = &d->dpb[i]; break; }
-    if (!cur) ORC_FAIL(d, "DPB overflow (no free picture)");
-    cur->in_use = 1; cur->is_ref = 0; cur->needed_for_output = 0; cur->has_mmco5 = 0;
-    cur->id = d->next_pic_id++; cur->decode_index = d->decode_count++;
-    cur->frame_num = sh->frame_num; cur->is_idr = sh->idr; cur->long_term_frame_idx = -1;
-    cur->frame_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? 1 : 2);
-    cur->poc = compute_poc(d, sh);
-    int n = d->mb_w * d->mb_h;
-    for (int i = 0; i < n; i++) cur->mbs[i].slice_num = -1;
-    /* missing macroblocks stay visible as mid-grey rather than stale data */
-    memset(cur->y, 128, (size_t)d->width * d->height);
-    memset(cur->u, 128, (size_t)d->width * d->height / 4);
-    memset(cur->v, 128, (size_t)d->width * d->height / 4);
-    d->cur = cur; d->cur_mb_count = 0; d->slice_num = 0;
+    if (second) cur = pend;
+    else {
+        release_unused(d);
+        for (int i = 0; i <= ORC_MAX_DPB; i++) if (!d->dpb[i].in_use) { cur = &d->dpb[i]; break; }
+        if (!cur) ORC_FAIL(d, "DPB overflow (no free picture)");
+        cur->in_use = 1; set_ref(cur, 0); cur->needed_for_output = 0; cur->has_mmco5 = 0; cur->have = 0; cur->waiting_second = 0;
+        cur->id = d->next_pic_id++; cur->decode_index = d->decode_count++;
+        cur->frame_num = sh->frame_num; cur->is_idr = sh->idr; cur->long_term_frame_idx = -1;
+        cur->frame_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? 1 : 2);
+        cur->first_was_ref = sh->nal_ref_idc != 0;
+        cur->is_field = 0; cur->store = cur;
+        int n = d->mb_w * d->mb_h;
+        for (int i = 0; i < n; i++) cur->mbs[i].slice_num = -1;
+        /* missing macroblocks stay visible as mid-grey rather than stale data */
+        memset(cur->y, 128, (size_t)d->width * d->height);
+        memset(cur->u, 128, (size_t)d->width * d->height / 4);
+        memset(cur->v, 128, (size_t)d->width * d->height / 4);
+    }
+    int poc = compute_poc(d, sh, cur);
+    if (!second) cur->poc = poc;
+    d->cur_store = cur; d->cur = cur; d->cur_mb_count = 0; d->slice_num = 0;
+    d->field_pic = sh->field_pic; d->cur_parity = sh->bottom_field; d->is_second_field = second;
+    if (sh->field_pic) {
+        d->stats[ORC_ST_FIELD_PICS]++; d->stats[ORC_ST_SECOND_FIELDS] += second;
+        /* from here to orc_finish_picture the decoder works on a picture of half the height */
+        d->cur = field_view(d, cur, sh->bottom_field);
+        d->mb_h = sps->mb_height / 2; d->height = d->mb_h * 16;
+    }
     d->first_sh = *sh;
+    return 0;
+}
+
+/* 8.2.4.2.5: the fields of an ordered list of frame stores, alternating in parity and beginning with the parity of the current field.  A store whose
+ * field of the wanted parity is not marked `mark` is passed over; when one parity has run out the remaining fields of the other follow in order. */
+static int alternate_fields(OrcDec *d, Picture **stores, int n, int mark, int par, Picture **out, int cnt, int max) {
+    int c[2] = {0, 0}, q = par;
+    for (;;) {
+        while (c[q] < n && stores[c[q]]->fmark[q] != mark) c[q]++;
+        if (c[q] < n) { if (cnt < max) out[cnt++] = &d->fview[stores[c[q]] - d->dpb][q]; c[q]++; }
+        else { int o = q ^ 1; while (c[o] < n && stores[c[o]]->fmark[o] != mark) c[o]++; if (c[o] >= n) break; }
+        q ^= 1;
+    }
+    return cnt;
+}
+
+/* 8.2.4.1 (field picture numbers) + 8.2.4.2.2 / 8.2.4.2.5 + 8.2.4.3 for a P field */
+static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
+    const int par = sh->bottom_field, max_frame_num = 1 << d->asps->log2_max_frame_num;
+    Picture *st[ORC_MAX_DPB + 1], *lt[ORC_MAX_DPB + 1]; int nst = 0, nlt = 0;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *s = &d->dpb[i];
+        if (!s->in_use) continue;
+        /* the store of the current frame takes part with its first field (8.2.4.2.2: "when the current field is the second field of a complementary
+         * field pair and the first field is marked as used for short-term reference, the first field is included") */
+        s->frame_num_wrap = s->frame_num > sh->frame_num ? s->frame_num - max_frame_num : s->frame_num;
+        for (int q = 0; q < 2; q++) {
+            Picture *v = field_view(d, s, q);
+            if (s == d->cur_store && q == par) { v->is_ref = 0; continue; }
+            /* 8.2.4.1: PicNum = 2 * FrameNumWrap + 1 for a field of the parity of the current field, 2 * FrameNumWrap for the other;
+             * LongTermPicNum likewise from LongTermFrameIdx */
+            v->pic_num = 2 * s->frame_num_wrap + (q == par);
+            v->long_term_pic_num = 2 * s->long_term_frame_idx + (q == par);
+        }
+        int m0 = s->fmark[0], m1 = s->fmark[1];
+        if (s == d->cur_store) { if (par) m1 = 0; else m0 = 0; }
+        if (m0 == 1 || m1 == 1) st[nst++] = s;
+        if (m0 == 2 || m1 == 2) lt[nlt++] = s;
+    }
+    for (int i = 0; i < nst; i++) for (int j = i + 1; j < nst; j++) if (st[j]->frame_num_wrap > st[i]->frame_num_wrap) { Picture *t = st[i]; st[i] = st[j];
+        st[j] = t; }
+    for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_frame_idx < lt[i]->long_term_frame_idx) { Picture *t = lt[i];
+        lt[i] = lt[j]; lt[j] = t; }
+    Picture *list[35]; memset(list, 0, sizeof list);
+    /* the current field's own store must not offer the current field itself: its mark is still 0 while it is decoded */
+    int n = alternate_fields(d, st, nst, 1, par, list, 0, 33);
+    n = alternate_fields(d, lt, nlt, 2, par, list, n, 33);
+    const int nact = sh->num_ref_idx[0];
+    for (int i = nact; i < 35; i++) list[i] = NULL;
+    if (d->slice_num == 0) { for (int i = 0; i < nact && list[i]; i++) if (list[i]->is_ref == 2) { d->stats[ORC_ST_FIELD_LONG]++; break; }
+        d->stats[ORC_ST_FIELD_RPLM] += sh->rplm_flag[0]; }
+    if (sh->rplm_flag[0]) {
+        const int cur_pic_num = 2 * sh->frame_num + 1, max_pic_num = 2 * max_frame_num;
+        int pred = cur_pic_num, idx = 0;
+        for (int k = 0; k < sh->n_rplm[0]; k++) {
+            const RplmOp *op = &sh->rplm[0][k];
+            Picture *target = NULL;
+            if (op->idc < 2) {
+                int nowrap;
+                if (op->idc == 0) { nowrap = pred - (op->val + 1); if (nowrap < 0) nowrap += max_pic_num; }
+                else { nowrap = pred + (op->val + 1); if (nowrap >= max_pic_num) nowrap -= max_pic_num; }
+                pred = nowrap;
+                int pic_num = nowrap > cur_pic_num ? nowrap - max_pic_num : nowrap;
+                for (int i = 0; i < nst; i++) for (int q = 0; q < 2; q++) { Picture *v = &d->fview[st[i] - d->dpb][q];
+                    if (v->is_ref == 1 && v->pic_num == pic_num) target = v; }
+            } else {
+                for (int i = 0; i < nlt; i++) for (int q = 0; q < 2; q++) { Picture *v = &d->fview[lt[i] - d->dpb][q];
+                    if (v->is_ref == 2 && v->long_term_pic_num == op->val) target = v; }
+            }
+            if (!target) ORC_FAIL(d, "ref_pic_list_modification names a missing field");
+            if (idx >= nact) ORC_FAIL(d, "too many ref_pic_list_modification operations");
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+        }
+    }
+    for (int i = 0; i < nact && i < 33; i++) d->ref_list[0][i] = list[i];
+    d->ref_count[0] = nact;
     return 0;
 }
 
@@ -179,11 +313,13 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
     d->ref_count[0] = d->ref_count[1] = 0;
     memset(d->ref_list, 0, sizeof d->ref_list);
     if (sh->slice_type == SLICE_I) return 0;
+    if (sh->field_pic) return build_field_lists(d, sh);
     int max_frame_num = 1 << d->asps->log2_max_frame_num;
     Picture *st[ORC_MAX_DPB + 1], *lt[ORC_MAX_DPB + 1]; int nst = 0, nlt = 0;
     for (int i = 0; i <= ORC_MAX_DPB; i++) {
         Picture *p = &d->dpb[i];
         if (!p->in_use || p == d->cur) continue;
+        if (p->is_ref == 3 && d->slice_num == 0) d->stats[ORC_ST_HALF_STORE]++;
         if (p->is_ref == 1) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
             p->pic_num = p->frame_num_wrap; st[nst++] = p;
@@ -248,27 +384,28 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
     return 0;
 }
 
-/* 8.2.5 decoded reference picture marking */
-static void mark_current(OrcDec *d) {
-    Picture *cur = d->cur; const SliceHdr *sh = &d->first_sh;
+/* 8.2.5 decoded reference picture marking of a FRAME picture */
+static int mark_current(OrcDec *d) {
+    Picture *cur = d->cur_store; const SliceHdr *sh = &d->first_sh;
     int max_frame_num = 1 << d->asps->log2_max_frame_num;
-    if (!sh->nal_ref_idc) return;
+    if (!sh->nal_ref_idc) return 0;
     if (sh->idr) {
-        for (int i = 0; i <= ORC_MAX_DPB; i++) if (&d->dpb[i] != cur) d->dpb[i].is_ref = 0;
-        if (sh->long_term_reference_flag) { cur->is_ref = 2; cur->long_term_frame_idx = 0; d->max_long_term_frame_idx = 0; }
-        else { cur->is_ref = 1; d->max_long_term_frame_idx = -1; }
-        return;
+        for (int i = 0; i <= ORC_MAX_DPB; i++) if (&d->dpb[i] != cur) set_ref(&d->dpb[i], 0);
+        if (sh->long_term_reference_flag) { set_ref(cur, 2); cur->long_term_frame_idx = 0; d->max_long_term_frame_idx = 0; }
+        else { set_ref(cur, 1); d->max_long_term_frame_idx = -1; }
+        return 0;
     }
     /* refresh PicNum of short-term pictures relative to the current frame_num */
     for (int i = 0; i <= ORC_MAX_DPB; i++) {
         Picture *p = &d->dpb[i];
-        if (p->in_use && p != cur && p->is_ref == 1) {
+        if (p->in_use && p != cur && any_short(p)) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
             p->pic_num = p->frame_num_wrap;
         }
     }
     int made_long = 0;
     if (sh->adaptive_marking) {
+        /* a frame picture names FRAMES: stores with both fields marked the same way (is_ref 1 / 2; 8.2.4.1) */
         for (int k = 0; k < sh->n_mmco; k++) {
             const Mmco *m = &sh->mmco[k];
             int pic_num_x = sh->frame_num - (m->diff_pic_nums_minus1 + 1);
@@ -276,57 +413,100 @@ static void mark_current(OrcDec *d) {
                 Picture *p = &d->dpb[i];
                 if (!p->in_use || p == cur) continue;
                 switch (m->op) {
-                case 1: if (p->is_ref == 1 && p->pic_num == pic_num_x) p->is_ref = 0; break;
-                case 2: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_pic_num) p->is_ref = 0; break;
+                case 1: if (p->is_ref == 1 && p->pic_num == pic_num_x) set_ref(p, 0); break;
+                case 2: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_pic_num) set_ref(p, 0); break;
                 case 3:
-                    if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx && !(p->pic_num == pic_num_x && 0)) p->is_ref = 0;
+                    if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx && !(p->pic_num == pic_num_x && 0)) set_ref(p, 0);
                     break;
-                case 4: if (p->is_ref == 2 && p->long_term_frame_idx > m->max_long_term_frame_idx_plus1 - 1) p->is_ref = 0; break;
-                case 5: p->is_ref = 0; break;
-                case 6: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx) p->is_ref = 0; break;
+                case 4: if (any_long(p) && p->long_term_frame_idx > m->max_long_term_frame_idx_plus1 - 1) set_ref(p, 0); break;
+                case 5: set_ref(p, 0); break;
+                case 6: if (p->is_ref == 2 && p->long_term_frame_idx == m->long_term_frame_idx) set_ref(p, 0); break;
                 }
             }
             if (m->op == 3)
                 for (int i = 0; i <= ORC_MAX_DPB; i++) {
                     Picture *p = &d->dpb[i];
-                    if (p->in_use && p != cur && p->is_ref == 1 && p->pic_num == pic_num_x) { p->is_ref = 2; p->long_term_frame_idx = m->long_term_frame_idx; }
+                    if (p->in_use && p != cur && p->is_ref == 1 && p->pic_num == pic_num_x) { set_ref(p, 2); p->long_term_frame_idx = m->long_term_frame_idx; }
                 }
             if (m->op == 4) d->max_long_term_frame_idx = m->max_long_term_frame_idx_plus1 - 1;
             if (m->op == 5) { d->max_long_term_frame_idx = -1; cur->has_mmco5 = 1; }
-            if (m->op == 6) { cur->is_ref = 2; cur->long_term_frame_idx = m->long_term_frame_idx; made_long = 1; }
+            if (m->op == 6) { set_ref(cur, 2); cur->long_term_frame_idx = m->long_term_frame_idx; made_long = 1; }
         }
     } else {
+        /* 8.2.5.3: numShortTerm + numLongTerm count frames, complementary field pairs and single fields in which ANY field is so marked */
         int nst = 0, nlt = 0; Picture *oldest = NULL;
         for (int i = 0; i <= ORC_MAX_DPB; i++) {
             Picture *p = &d->dpb[i];
             if (!p->in_use || p == cur) continue;
-            if (p->is_ref == 1) { nst++; if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p; }
-            else if (p->is_ref == 2) nlt++;
+            if (any_short(p)) { nst++; if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p; }
+            else if (any_long(p)) nlt++;
         }
-        if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) oldest->is_ref = 0;
+        if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) set_ref(oldest, 0);
     }
-    if (!made_long) cur->is_ref = 1;
+    if (!made_long) set_ref(cur, 1);
+    return 0;
 }
 
-void orc_finish_picture(OrcDec *d) {
-    Picture *cur = d->cur;
-    if (!cur) return;
-    orc_deblock_picture(d, cur);
-    mark_current(d);
-    d->prev_frame_num = cur->frame_num;
-    d->prev_ref_has_mmco5 = 0;
-    if (cur->has_mmco5) {
-        /* 7.4.3 / 8.2.1: after operation 5 the picture is inferred to have had frame_num 0, and tempPicOrderCnt = Min(top, bottom) is subtracted
-         * from both of its order counts: PicOrderCnt becomes 0, and for pic_order_cnt_type 0 the NEXT pictures see prevPicOrderCntMsb = 0 and
-         * prevPicOrderCntLsb = its TopFieldOrderCnt after the subtraction (> 0 when the bottom field lies below the top field).  prev_ref_has_mmco5
-         * is the "previous picture" condition of types 1 and 2 (8.2.1.2 / 8.2.1.3: only the picture that follows immediately). */
-        d->prev_ref_has_mmco5 = 1; cur->frame_num = 0;
-        if (d->asps->poc_type == 0) { d->prev_poc_msb = 0; d->prev_poc_lsb = d->cur_top_poc - orc_min(d->cur_top_poc, d->cur_bot_poc); }
-        Picture *p; while ((p = smallest_poc_waiting(d, cur)) != NULL) emit(d, p);
-        cur->poc = 0;
+/* 8.2.5 for a FIELD picture: field picture numbers (8.2.4.1); the sliding window leaves the second field of a reference frame alone (8.2.5.3) */
+static int mark_current_field(OrcDec *d) {
+    Picture *cur = d->cur_store; const SliceHdr *sh = &d->first_sh;
+    const int par = sh->bottom_field, max_frame_num = 1 << d->asps->log2_max_frame_num;
+    if (!sh->nal_ref_idc) return 0;
+    if (sh->idr) {
+        for (int i = 0; i <= ORC_MAX_DPB; i++) if (&d->dpb[i] != cur) set_ref(&d->dpb[i], 0);
+        cur->fmark[par] = sh->long_term_reference_flag ? 2 : 1; cur->fmark[par ^ 1] = 0;
+        cur->long_term_frame_idx = sh->long_term_reference_flag ? 0 : -1; d->max_long_term_frame_idx = sh->long_term_reference_flag ? 0 : -1;
+        orc_sync_ref(cur);
+        return 0;
     }
-    /* C.4.5.2 / C.4.5.3 */
-    d->cur = NULL;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (p->in_use) p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
+    }
+    if (sh->adaptive_marking) {
+        const int cur_pic_num = 2 * sh->frame_num + 1;
+        for (int k = 0; k < sh->n_mmco; k++) {
+            const Mmco *m = &sh->mmco[k];
+            const int pic_num_x = cur_pic_num - (m->diff_pic_nums_minus1 + 1);
+            if (m->op == 3 || m->op == 5 || m->op == 6) ORC_FAIL(d, "memory management operation %d in a field picture unsupported", m->op);
+            for (int i = 0; i <= ORC_MAX_DPB; i++) {
+                Picture *p = &d->dpb[i];
+                if (!p->in_use) continue;
+                for (int q = 0; q < 2; q++) {
+                    if (p == cur && q == par) continue;
+                    const int pic_num = 2 * p->frame_num_wrap + (q == par), lt_pic_num = 2 * p->long_term_frame_idx + (q == par);
+                    if (m->op == 1 && p->fmark[q] == 1 && pic_num == pic_num_x) { p->fmark[q] = 0; d->stats[ORC_ST_FIELD_MMCO]++; }
+                    if (m->op == 2 && p->fmark[q] == 2 && lt_pic_num == m->long_term_pic_num) p->fmark[q] = 0;
+                    if (m->op == 4 && p->fmark[q] == 2 && p->long_term_frame_idx > m->max_long_term_frame_idx_plus1 - 1) p->fmark[q] = 0;
+                }
+                orc_sync_ref(p);
+            }
+            if (m->op == 4) d->max_long_term_frame_idx = m->max_long_term_frame_idx_plus1 - 1;
+        }
+    } else if (!(d->is_second_field && cur->fmark[par ^ 1] == 1)) {
+        int nst = 0, nlt = 0; Picture *oldest = NULL;
+        for (int i = 0; i <= ORC_MAX_DPB; i++) {
+            Picture *p = &d->dpb[i];
+            if (!p->in_use || p == cur) continue;
+            if (any_short(p)) { nst++; if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p; }
+            else if (any_long(p)) nlt++;
+        }
+        if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) { set_ref(oldest, 0); d->stats[ORC_ST_FIELD_WINDOW]++; }
+    }
+    cur->fmark[par] = 1;
+    orc_sync_ref(cur);
+    return 0;
+}
+
+/* C.4.5.2 / C.4.5.3 for a frame store that is complete: a frame, both fields of a frame, or a field whose partner did not come */
+static void store_done(OrcDec *d, Picture *cur) {
+    if (cur->have != 3) {
+        /* a single field: the lines of the missing parity repeat the decoded ones */
+        const int par = cur->have == 2, h = d->asps->mb_height * 16;
+        for (int y = par; y < h; y += 2) memcpy(cur->y + (size_t)(y ^ 1) * cur->stride_y, cur->y + (size_t)y * cur->stride_y, (size_t)d->width);
+        for (int y = par; y < h / 2; y += 2) { memcpy(cur->u + (size_t)(y ^ 1) * cur->stride_c, cur->u + (size_t)y * cur->stride_c, (size_t)d->width / 2);
+            memcpy(cur->v + (size_t)(y ^ 1) * cur->stride_c, cur->v + (size_t)y * cur->stride_c, (size_t)d->width / 2); }
+    }
     Picture *w = smallest_poc_waiting(d, cur);
     if (!cur->is_ref && (!w || w->poc > cur->poc)) { cur->needed_for_output = 1; emit(d, cur); cur->in_use = 0; release_unused(d); return; }
     cur->needed_for_output = 1;
@@ -341,9 +521,51 @@ void orc_finish_picture(OrcDec *d) {
     release_unused(d);
 }
 
+void orc_finish_picture(OrcDec *d) {
+    Picture *cur = d->cur_store;
+    if (!cur) return;
+    orc_deblock_picture(d, d->cur);
+    if (d->field_pic) {
+        if (mark_current_field(d) < 0) d->sticky_fail = 1;
+        const int par = d->cur_parity;
+        d->mb_h = d->asps->mb_height; d->height = d->mb_h * 16;
+        d->prev_frame_num = cur->frame_num; d->prev_ref_has_mmco5 = 0;
+        cur->have |= 1 << par;
+        d->cur = d->cur_store = NULL; d->field_pic = 0;
+        if (!d->is_second_field) {
+            /* the first field of a frame: the store waits for the other one (orc_start_picture decides whether what comes next is that) */
+            cur->waiting_second = 1; cur->needed_for_output = 1; d->pending = cur;
+            return;
+        }
+        cur->waiting_second = 0; d->pending = NULL;
+        cur->poc = orc_min(cur->fpoc[0], cur->fpoc[1]);                 /* 8.2.1: PicOrderCnt of a complementary field pair */
+        store_done(d, cur);
+        return;
+    }
+    cur->have = 3;
+    mark_current(d);
+    d->prev_frame_num = cur->frame_num;
+    d->prev_ref_has_mmco5 = 0;
+    if (cur->has_mmco5) {
+        /* 7.4.3 / 8.2.1: after operation 5 the picture is inferred to have had frame_num 0, and tempPicOrderCnt = Min(top, bottom) is subtracted
+         * from both of its order counts: PicOrderCnt becomes 0, and for pic_order_cnt_type 0 the NEXT pictures see prevPicOrderCntMsb = 0 and
+         * prevPicOrderCntLsb = its TopFieldOrderCnt after the subtraction (> 0 when the bottom field lies below the top field).  prev_ref_has_mmco5
+         * is the "previous picture" condition of types 1 and 2 (8.2.1.2 / 8.2.1.3: only the picture that follows immediately). */
+        d->prev_ref_has_mmco5 = 1; cur->frame_num = 0;
+        const int tmp = orc_min(cur->fpoc[0], cur->fpoc[1]);
+        if (d->asps->poc_type == 0) { d->prev_poc_msb = 0; d->prev_poc_lsb = cur->fpoc[0] - tmp; }
+        Picture *p; while ((p = smallest_poc_waiting(d, cur)) != NULL) emit(d, p);
+        cur->fpoc[0] -= tmp; cur->fpoc[1] -= tmp;
+        cur->poc = 0;
+    }
+    d->cur = d->cur_store = NULL;
+    store_done(d, cur);
+}
+
 /* ------------------------------- NAL layer ------------------------------- */
 static int same_picture(const SliceHdr *a, const SliceHdr *b) {       /* 7.4.1.2.4 */
     if (a->frame_num != b->frame_num || a->pps_id != b->pps_id) return 0;
+    if (a->field_pic != b->field_pic || a->bottom_field != b->bottom_field) return 0;
     if ((a->nal_ref_idc == 0) != (b->nal_ref_idc == 0)) return 0;
     if (a->poc_lsb != b->poc_lsb || a->delta_poc_bottom != b->delta_poc_bottom) return 0;
     if (a->delta_poc[0] != b->delta_poc[0] || a->delta_poc[1] != b->delta_poc[1]) return 0;
@@ -366,7 +588,9 @@ const char *orc_last_error(const OrcDec *d) { return d->err; }
 /* which coding tools the decoded stream exercised (macroblock / slice counts) */
 const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
-        "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends"};
+        "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
+        "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }
@@ -388,6 +612,7 @@ int orc_stream_info(const OrcDec *d, int *dw, int *dh, int *cw, int *ch) {
 
 int orc_decode_nal(OrcDec *d, const uint8_t *nal, size_t len) {
     if (len < 1) return 0;
+    if (d->sticky_fail) return -1;
     d->err[0] = 0;
     if (nal[0] & 0x80) ORC_FAIL(d, "forbidden_zero_bit set");
     int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
@@ -409,7 +634,7 @@ int orc_decode_nal(OrcDec *d, const uint8_t *nal, size_t len) {
         if (!d->cur) { if (orc_start_picture(d, &sh) < 0) return -1; }
         else d->slice_num++;
         d->sh = sh;
-        if (sh.first_mb >= d->mb_w * d->mb_h) ORC_FAIL(d, "first_mb_in_slice out of range");
+        if (sh.first_mb >= d->mb_w * d->mb_h) ORC_FAIL(d, "first_mb_in_slice out of range");      /* (mb_h: of the field, in a field picture) */
         if (orc_build_ref_lists(d, &sh) < 0) return -1;
         return orc_decode_slice_data(d, &b);
     }
@@ -440,7 +665,8 @@ int orc_decode_annexb(OrcDec *d, const uint8_t *buf, size_t len) {
 
 void orc_flush(OrcDec *d) {
     if (d->cur) orc_finish_picture(d);
-    for (int i = 0; i <= ORC_MAX_DPB; i++) d->dpb[i].is_ref = 0;
+    if (d->pending) { Picture *p = d->pending; p->waiting_second = 0; d->pending = NULL; store_done(d, p); }
+    for (int i = 0; i <= ORC_MAX_DPB; i++) set_ref(&d->dpb[i], 0);
     if (d->asps) orc_output_all(d);
 }
 

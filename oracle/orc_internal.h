@@ -105,6 +105,7 @@ typedef struct { int op, diff_pic_nums_minus1, long_term_pic_num, long_term_fram
 
 typedef struct {
     int first_mb, slice_type, pps_id, frame_num, idr_pic_id;
+    int field_pic, bottom_field;      /* field_pic_flag, bottom_field_flag: the picture is one field of a frame, decoded as a picture of half the height */
     int poc_lsb, delta_poc_bottom, delta_poc[2];
     int redundant_pic_cnt, direct_spatial_mv_pred;
     int num_ref_idx[2];
@@ -149,6 +150,17 @@ typedef struct Picture {
     int id;              /* unique increasing identity */
     int frame_type, decode_index, is_idr;
     int has_mmco5;
+    /* Interlace (PAFF).  A Picture in the DPB is a FRAME STORE (C.4.5): a frame, or one or two field pictures of the same frame.  Each field carries
+     * its own marking and order count; is_ref is derived from them (orc_sync_ref): 1 / 2 = BOTH fields short- / long-term, i.e. a reference frame in
+     * the sense of 8.2.4.2.1; 3 = some field is a reference, which only field pictures can use but which keeps the store occupied. */
+    int fmark[2];        /* per field (top, bottom): 0 not a reference, 1 short-term, 2 long-term */
+    int fpoc[2];         /* TopFieldOrderCnt, BottomFieldOrderCnt */
+    int have;            /* bit 0 / bit 1: the top / bottom field has been decoded (a frame picture decodes both) */
+    int waiting_second;  /* holds a first field whose second field may follow as the next picture */
+    int first_was_ref;   /* nal_ref_idc != 0 of that first field (3.30: reference fields pair with reference fields) */
+    /* FIELD VIEW (OrcDec.fview): the lines of one parity of a store as a picture of half the height and twice the stride -- what a field picture
+     * is decoded into and predicts from.  is_ref, poc, pic_num, long_term_pic_num of a view are the FIELD's (8.2.4.1). */
+    int is_field, parity; struct Picture *store;
 } Picture;
 
 #define ORC_MAX_DPB 17
@@ -160,7 +172,12 @@ struct OrcDec {
     const Sps *asps; const Pps *apps;   /* active */
     int mb_w, mb_h, width, height;
     Picture dpb[ORC_MAX_DPB + 1];
-    Picture *cur;
+    Picture fview[ORC_MAX_DPB + 1][2];
+    Picture *cur;         /* what the slices decode into: the frame store itself, or the view of the field being decoded */
+    Picture *cur_store;   /* the frame store of the current picture */
+    Picture *pending;     /* the store that holds a first field and waits for the second */
+    int sticky_fail;      /* a picture ended in something unsupported: every later call fails */
+    int field_pic, cur_parity, is_second_field;     /* the current picture is a field picture (mb_h / height are the FIELD's while it is decoded) */
     int dpb_size;
     int next_pic_id, decode_count;
     /* POC state */
@@ -176,7 +193,7 @@ struct OrcDec {
     int last_poc_out;
     uint8_t *outbuf; /* crop scratch */
     int digest_on; uint64_t digest; uint64_t digest_mbs;
-    long stats[24];       /* ORC_ST_* tool-usage counters (which coding tools a stream exercised) */
+    long stats[40];       /* ORC_ST_* tool-usage counters (which coding tools a stream exercised) */
 };
 
 /* orc_parse.c */
@@ -191,11 +208,18 @@ void orc_deblock_picture(OrcDec *d, Picture *pic);
 int  orc_start_picture(OrcDec *d, const SliceHdr *sh);
 void orc_finish_picture(OrcDec *d);
 int  orc_build_ref_lists(OrcDec *d, const SliceHdr *sh);
+void orc_sync_ref(Picture *p);
 void orc_output_all(OrcDec *d);
 
 enum { ORC_ST_I4, ORC_ST_I8, ORC_ST_I16, ORC_ST_PCM, ORC_ST_PSKIP, ORC_ST_P16, ORC_ST_P16x8, ORC_ST_P8x16, ORC_ST_P8x8, ORC_ST_SUB_SMALL,
        ORC_ST_T8_INTER, ORC_ST_CABAC_SLICES, ORC_ST_CAVLC_SLICES, ORC_ST_IDC0, ORC_ST_IDC1, ORC_ST_IDC2, ORC_ST_MULTIREF, ORC_ST_BSKIP, ORC_ST_BDIRECT,
-           ORC_ST_BINTER, ORC_ST_EXACT_END, ORC_ST_N };
+           ORC_ST_BINTER, ORC_ST_EXACT_END,
+       /* interlace: field pictures, second fields, 4x4 blocks predicted from a field of the other parity, memory management operations / list
+          modifications / sliding-window removals in field pictures, long-term fields in a field's list, frame pictures that met a store with one
+          reference field only, intra macroblock edges that got bS 3 because they run horizontally through a field, vector pairs whose vertical
+          difference of 2 or 3 counted only because of the field rule, fields that stayed without partner */
+       ORC_ST_FIELD_PICS, ORC_ST_SECOND_FIELDS, ORC_ST_CROSS_PARITY, ORC_ST_FIELD_MMCO, ORC_ST_FIELD_RPLM, ORC_ST_FIELD_WINDOW, ORC_ST_FIELD_LONG,
+       ORC_ST_HALF_STORE, ORC_ST_FIELD_BS3, ORC_ST_FIELD_MVY, ORC_ST_LONE_FIELD, ORC_ST_N };
 
 #define ORC_FAIL(d, ...) do { snprintf((d)->err, sizeof((d)->err), __VA_ARGS__); return -1; } while (0)
 

@@ -125,7 +125,7 @@ int orc_parse_sps(OrcDec *d, Bits *b) {
     if (b->err) ORC_FAIL(d, "SPS truncated");
     if (s.chroma_format_idc != 1 || s.bit_depth_luma != 8 || s.bit_depth_chroma != 8)
         ORC_FAIL(d, "unsupported chroma format / bit depth (8-bit 4:2:0 only)");
-    /* frame_mbs_only_flag = 0 without MBAFF: frame pictures are coded like progressive ones (decoded); field pictures are refused in the slice header */
+    /* frame_mbs_only_flag = 0 without MBAFF: every picture is a frame or a field picture (PAFF) */
     if (!s.frame_mbs_only && s.mb_aff) ORC_FAIL(d, "interlaced streams with MBAFF unsupported");
     if (!s.frame_mbs_only && !s.direct_8x8_inference) ORC_FAIL(d, "direct_8x8_inference_flag must be 1 when frame_mbs_only_flag is 0");
     if (s.mb_width > 1024 || s.mb_height > 1024) ORC_FAIL(d, "picture too large");
@@ -188,14 +188,15 @@ int orc_parse_slice_header(OrcDec *d, Bits *b, int nal_unit_type, int nal_ref_id
     if (!d->sps[pps->sps_id].valid) ORC_FAIL(d, "slice refers to missing SPS");
     const Sps *sps = &d->sps[pps->sps_id];
     sh->frame_num = bits_u(b, sps->log2_max_frame_num);
-    if (!sps->frame_mbs_only && bits_u1(b)) ORC_FAIL(d, "field pictures (PAFF) unsupported");      /* field_pic_flag */
+    if (!sps->frame_mbs_only) { sh->field_pic = bits_u1(b); if (sh->field_pic) sh->bottom_field = bits_u1(b); }     /* 7.3.3: field_pic_flag, bottom_field_flag */
     if (sh->idr) sh->idr_pic_id = bits_ue(b);
+    /* the counts of the OTHER field (delta_pic_order_cnt_bottom, delta_pic_order_cnt[1]) are sent with frames only */
     if (sps->poc_type == 0) {
         sh->poc_lsb = bits_u(b, sps->log2_max_poc_lsb);
-        if (pps->bottom_field_pic_order_present) sh->delta_poc_bottom = bits_se(b);
+        if (pps->bottom_field_pic_order_present && !sh->field_pic) sh->delta_poc_bottom = bits_se(b);
     } else if (sps->poc_type == 1 && !sps->delta_pic_order_always_zero) {
         sh->delta_poc[0] = bits_se(b);
-        if (pps->bottom_field_pic_order_present) sh->delta_poc[1] = bits_se(b);
+        if (pps->bottom_field_pic_order_present && !sh->field_pic) sh->delta_poc[1] = bits_se(b);
     }
     if (pps->redundant_pic_cnt_present) sh->redundant_pic_cnt = bits_ue(b);
     if (sh->slice_type == SLICE_B) sh->direct_spatial_mv_pred = bits_u1(b);
@@ -206,7 +207,8 @@ int orc_parse_slice_header(OrcDec *d, Bits *b, int nal_unit_type, int nal_ref_id
             sh->num_ref_idx[0] = bits_ue(b) + 1;
             if (sh->slice_type == SLICE_B) sh->num_ref_idx[1] = bits_ue(b) + 1;
         }
-        if (sh->num_ref_idx[0] > 32 || sh->num_ref_idx[1] > 32) ORC_FAIL(d, "num_ref_idx out of range");
+        /* 7.4.3: at most 16 entries in a frame's list, 32 in a field's */
+        if (sh->num_ref_idx[0] > (sh->field_pic ? 32 : 16) || sh->num_ref_idx[1] > (sh->field_pic ? 32 : 16)) ORC_FAIL(d, "num_ref_idx out of range");
     }
     if (sh->slice_type != SLICE_B) sh->num_ref_idx[1] = 0;
     if (sh->slice_type == SLICE_I) sh->num_ref_idx[0] = 0;

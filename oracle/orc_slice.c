@@ -121,10 +121,12 @@ static inline int blk_y(int blk) { return ((blk >> 1) & 1) + 2 * (blk >> 3); }
 static int parse_residual(Sl *s, int cbp) {
     MbInfo *mb = s->mb;
     int16_t tmp[16];
+    /* 8.5.6 / 8.5.7: the macroblocks of a field picture are field macroblocks: field scan */
+    const uint8_t *z4 = s->d->field_pic ? orc_fieldscan4 : orc_zigzag4, *z8 = s->d->field_pic ? orc_fieldscan8 : orc_zigzag8;
     if (mb->is_i16) {
         int n = residual_block_cavlc(s, nc_luma(s, 0, 0), 16, tmp);
         if (n < 0) return -1;
-        for (int i = 0; i < 16; i++) s->i16dc[orc_zigzag4[i]] = tmp[i];
+        for (int i = 0; i < 16; i++) s->i16dc[z4[i]] = tmp[i];
     }
     for (int b8 = 0; b8 < 4; b8++) {
         for (int k = 0; k < 4; k++) {
@@ -134,14 +136,14 @@ static int parse_residual(Sl *s, int cbp) {
             if (mb->is_i16) {
                 n = residual_block_cavlc(s, nC, 15, tmp);
                 if (n < 0) return -1;
-                for (int i = 0; i < 15; i++) s->luma[r][orc_zigzag4[i + 1]] = tmp[i];
+                for (int i = 0; i < 15; i++) s->luma[r][z4[i + 1]] = tmp[i];
             } else {
                 n = residual_block_cavlc(s, nC, 16, tmp);
                 if (n < 0) return -1;
                 if (mb->t8x8) {   /* 7.3.5.3.2: 4x4 block k carries 8x8 scan positions 4*i+k */
-                    for (int i = 0; i < 16; i++) s->luma8[b8][orc_zigzag8[4 * i + k]] = tmp[i];
+                    for (int i = 0; i < 16; i++) s->luma8[b8][z8[4 * i + k]] = tmp[i];
                 } else
-                    for (int i = 0; i < 16; i++) s->luma[r][orc_zigzag4[i]] = tmp[i];
+                    for (int i = 0; i < 16; i++) s->luma[r][z4[i]] = tmp[i];
             }
             mb->total_coeff[r] = (uint8_t)n;
         }
@@ -155,7 +157,7 @@ static int parse_residual(Sl *s, int cbp) {
             if (!(cbp & 0x20)) { mb->total_coeff[16 + 4 * pl + k] = 0; continue; }
             int n = residual_block_cavlc(s, nc_chroma(s, pl, k & 1, k >> 1), 15, tmp);
             if (n < 0) return -1;
-            for (int i = 0; i < 15; i++) s->cac[pl][k][orc_zigzag4[i + 1]] = tmp[i];
+            for (int i = 0; i < 15; i++) s->cac[pl][k][z4[i + 1]] = tmp[i];
             mb->total_coeff[16 + 4 * pl + k] = (uint8_t)n;
         }
     return 0;
@@ -461,6 +463,9 @@ static void pred_block(Sl *s, const Picture *ref, int px, int py, int mvx, int m
     for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
         yl[y * 4 + x] = luma_sample(ref, W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
     int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
+    /* 8.4.1.4, Table 8-9: in a field the chroma vector's vertical component is the luma one, minus 2 (units of 1/8 chroma sample) when a top field
+     * predicts from a bottom field, plus 2 when a bottom field predicts from a top field */
+    if (d->field_pic && ref->is_field && ref->parity != d->cur_parity) { mvy += d->cur_parity ? 2 : -2; d->stats[ORC_ST_CROSS_PARITY]++; }
     for (int pl = 0; pl < 2; pl++) {
         const uint8_t *rp = pl ? ref->v : ref->u; int *o = pl ? cv : cu;
         for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
@@ -846,16 +851,17 @@ static void rd_mvd(Sl *s, int list, int bx, int by, int bw, int bh, int mvd[2]) 
 static int parse_residual_cabac(Sl *s, int cbp) {
     MbInfo *mb = s->mb;
     int16_t tmp[64];
+    const uint8_t *z4 = s->d->field_pic ? orc_fieldscan4 : orc_zigzag4, *z8 = s->d->field_pic ? orc_fieldscan8 : orc_zigzag8;
     if (mb->is_i16) {
         if (orc_cabac_residual_block(s, 0, 0, tmp, 16) < 0) return -1;
-        for (int i = 0; i < 16; i++) s->i16dc[orc_zigzag4[i]] = tmp[i];
+        for (int i = 0; i < 16; i++) s->i16dc[z4[i]] = tmp[i];
     }
     for (int b8 = 0; b8 < 4; b8++) {
         if (!(cbp & (1 << b8))) continue;
         if (mb->t8x8) {
             int n = orc_cabac_residual_block(s, 5, b8, tmp, 64);
             if (n < 0) return -1;
-            for (int i = 0; i < 64; i++) s->luma8[b8][orc_zigzag8[i]] = tmp[i];
+            for (int i = 0; i < 64; i++) s->luma8[b8][z8[i]] = tmp[i];
             for (int k = 0; k < 4; k++) {
                 int r = ((b8 >> 1) * 2 + (k >> 1)) * 4 + (b8 & 1) * 2 + (k & 1);
                 mb->total_coeff[r] = (uint8_t)orc_min(n, 16);
@@ -868,11 +874,11 @@ static int parse_residual_cabac(Sl *s, int cbp) {
             if (mb->is_i16) {
                 n = orc_cabac_residual_block(s, 1, r, tmp, 15);
                 if (n < 0) return -1;
-                for (int i = 0; i < 15; i++) s->luma[r][orc_zigzag4[i + 1]] = tmp[i];
+                for (int i = 0; i < 15; i++) s->luma[r][z4[i + 1]] = tmp[i];
             } else {
                 n = orc_cabac_residual_block(s, 2, r, tmp, 16);
                 if (n < 0) return -1;
-                for (int i = 0; i < 16; i++) s->luma[r][orc_zigzag4[i]] = tmp[i];
+                for (int i = 0; i < 16; i++) s->luma[r][z4[i]] = tmp[i];
             }
             mb->total_coeff[r] = (uint8_t)n;
         }
@@ -885,7 +891,7 @@ static int parse_residual_cabac(Sl *s, int cbp) {
             for (int k = 0; k < 4; k++) {
                 int n = orc_cabac_residual_block(s, 4, pl * 4 + k, tmp, 15);
                 if (n < 0) return -1;
-                for (int i = 0; i < 15; i++) s->cac[pl][k][orc_zigzag4[i + 1]] = tmp[i];
+                for (int i = 0; i < 15; i++) s->cac[pl][k][z4[i + 1]] = tmp[i];
                 mb->total_coeff[16 + 4 * pl + k] = (uint8_t)n;
             }
     return 0;

@@ -9,7 +9,7 @@ import pytest
 
 from jmcodec_amd import api
 from tools import streams
-from util import ALL_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
+from util import ALL_CASES, PAFF_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
 
 
 def _recon(kw):
@@ -25,6 +25,44 @@ def test_oracle_equals_generator_reconstruction(oracle, name):
     assert n == ALL_CASES[name]["frames"]
     assert (w, h) == (ALL_CASES[name]["width"], ALL_CASES[name]["height"])
     assert out == recon
+
+
+@pytest.mark.parametrize("name", sorted(PAFF_CASES))
+def test_oracle_equals_generator_reconstruction_of_field_pictures(oracle, name):
+    """The generator codes a field as a picture of its own in buffers of half the height; the oracle decodes it through views of twice the stride into
+    the frame.  Their agreement covers the addressing; the rules both follow are listed clause by clause in tests/SPEC_AUDIT.md."""
+    data, recon = _recon(PAFF_CASES[name])
+    out, n, w, h = oracle.decode(data, 1)
+    assert n == PAFF_CASES[name]["frames"] and (w, h) == (PAFF_CASES[name]["width"], PAFF_CASES[name]["height"])
+    assert out == recon
+
+
+def test_field_picture_streams_exercise_the_field_rules(oracle):
+    seen = {}
+    for name in sorted(PAFF_CASES):
+        for k, v in oracle.tools(streams.generate(**PAFF_CASES[name])).items():
+            seen[k] = seen.get(k, 0) + v
+    for tool in ("field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
+                 "half-marked-stores", "field-bS3", "field-mvy-limit"):
+        assert seen.get(tool, 0) > 0, f"no field-picture stream exercises {tool}"
+    assert seen["second-fields"] * 2 == seen["field-pictures"] and "lone-fields" not in seen
+
+
+def test_a_field_without_partner_is_shown_with_its_lines_repeated(oracle):
+    """The second field of the last frame is cut off: the frame comes out with every line of the decoded field twice (orc_dec.c store_done)."""
+    import numpy as np
+    kw = dict(width=64, height=64, frames=3, gop=3, seed=210, paff=2)
+    data = streams.generate(**kw)
+    full, n, w, h = oracle.decode(data, 1)
+    starts = [i for i in range(len(data) - 4) if data[i:i + 4] == b"\0\0\0\1" or (data[i:i + 3] == b"\0\0\1" and data[i - 1:i] != b"\0")]
+    cut, n2, _, _ = oracle.decode(data[:starts[-1]], 1)
+    assert n == n2 == 3
+    fs = w * h * 3 // 2
+    assert cut[:2 * fs] == full[:2 * fs] and cut[2 * fs:] != full[2 * fs:]
+    y = np.frombuffer(cut[2 * fs:2 * fs + w * h], np.uint8).reshape(h, w)
+    assert (y[0::2] == y[1::2]).all()
+    yf = np.frombuffer(full[2 * fs:2 * fs + w * h], np.uint8).reshape(h, w)
+    assert (y[0::2] == yf[0::2]).all() or (y[1::2] == yf[1::2]).all()
 
 
 def test_ipcm_known_answer(oracle):

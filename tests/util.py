@@ -136,5 +136,19 @@ B_CASES = {
     "mmco5_poc1": dict(width=96, height=80, frames=24, gop=24, mode=1, seed=117, poc_type=1, poc_bottom=1, nonref_period=3, mmco=2, num_ref=3),
     "mmco5_poc2_cabac": dict(width=96, height=80, frames=24, gop=24, mode=1, seed=118, poc_type=2, nonref_period=3, mmco=2, num_ref=2, cabac=1),
 }
+# Interlace, picture-adaptive (P-only streams): every I / P picture a frame or two field pictures (paff=1), or always two fields (paff=2); the first field of
+# either parity.  Field scans, field contexts, alternating-parity lists, field picture numbers in list modification and marking, the sliding window
+# across first / second fields, frame pictures that meet half-marked stores, explicit weights by field index, all three order-count types.
+PAFF_CASES = {
+    "paff_fields_cavlc": dict(width=96, height=96, frames=8, gop=8, seed=201, paff=2, num_ref=2),
+    "paff_fields_cabac": dict(width=96, height=96, frames=8, gop=8, seed=202, paff=2, num_ref=2, cabac=1, cabac_idc=1),
+    "paff_adaptive_fuzz": dict(width=96, height=64, frames=14, gop=9, mode=1, seed=206, paff=1, num_ref=3, slices=2, rplm=1, mmco=1),
+    "paff_adaptive_fuzz_cabac_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=204, paff=1, num_ref=4, cabac=1, rplm=1, mmco=2, wp=1, poc_type=0,
+                                        nonref_period=3),
+    "paff_poc1_t8x8_scaling": dict(width=96, height=96, frames=12, gop=12, mode=1, seed=205, paff=1, num_ref=3, t8x8=1, scaling=1, poc_type=1, poc_bottom=1, deblock=2,
+                                   slices=3, chroma_qp_off=-3, alpha_off=2, beta_off=-2),
+    "paff_poc2_cip_crop": dict(width=90, height=88, frames=10, gop=5, mode=1, seed=206, paff=2, num_ref=2, cip=1, poc_type=2, cabac=1, cabac_idc=2),
+    "paff_real_qvga": dict(width=320, height=224, frames=6, gop=6, seed=207, paff=1, num_ref=2, cabac=1),
+}
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)
