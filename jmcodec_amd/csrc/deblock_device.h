@@ -373,7 +373,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const int lrow = group + 1;
     const bool active = group < rows;
     const int row = row0 + (active ? group : 0);                             // idle groups shadow row0 (loads stay in bounds, nothing is used)
-    gbyte *plane = (gbyte *)(pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0));
+    gbyte *plane = (gbyte *)(cur_plane(pp) + (is_chroma ? pp.chroma_offset : 0));
     const DbCtx cx{plane, pitch, mb_w, mb_h};
     const int rows_per_mb = is_chroma ? 8 : 16, ring_rows = is_chroma ? 2 : 4;
     const int my_row = is_chroma ? (l & 7) : l;

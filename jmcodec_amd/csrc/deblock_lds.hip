@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void k_deblock_prep(const PicParams *pics) {
     else if (e == 0) {
         bool have = dir == 0 ? has_left : has_top;
         const MbW pn = select_mbw(dir == 0, pl, pt);
-        bs = have ? boundary_strength(pp, pn, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true) : 0;
-    } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
+        bs = have ? boundary_strength(pp, pn, dir == 0 ? k * 4 + 3 : 12 + k, q, rq, true, dir == 1) : 0;
+    } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false, dir == 1);
     if ((e & 1) && (mbw_modes(q) & MBM_T8X8)) bs = 0;      // 8.7: with the 8x8 transform only the 8x8 block edges are filtered (chroma uses e = 0, 2)
     // edge class of this lane: 0 left MB edge, 1 internal, 2 top MB edge; qPp is the neighbour's QP on MB edges
     int cls = e ? 1 : (dir ? 2 : 0);

@@ -506,6 +506,7 @@ void Decoder::flush_stream() {
 
 static bool same_picture(const SliceHeader &a, const SliceHeader &b) {      // 7.4.1.2.4
     if (a.frame_num != b.frame_num || a.pps_id != b.pps_id) return false;
+    if (a.field_pic != b.field_pic || a.bottom_field != b.bottom_field) return false;
     if ((a.nal_ref_idc == 0) != (b.nal_ref_idc == 0)) return false;
     if (a.poc_lsb != b.poc_lsb || a.delta_poc_bottom != b.delta_poc_bottom) return false;
     if (a.delta_poc[0] != b.delta_poc[0] || a.delta_poc[1] != b.delta_poc[1]) return false;
@@ -581,90 +582,193 @@ bool Decoder::activate(const SeqParams &sps) {
     return true;
 }
 
-int Decoder::compute_poc(const SliceHeader &sh) {                                   // 8.2.1
+// 8.2.1: TopFieldOrderCnt and / or BottomFieldOrderCnt of the current frame or field (into fpoc[] of its store); returns PicOrderCnt of the picture:
+// Min(top, bottom) of a frame, a field's own count
+int Decoder::compute_poc(const SliceHeader &sh, DpbPic &store) {
     const SeqParams &s = seq_;
     int max_fn = 1 << s.log2_max_frame_num;
+    long long top = 0, bot = 0;
     if (s.poc_type == 0) {
         int max_lsb = 1 << s.log2_max_poc_lsb;
-        // prevPicOrderCntMsb / Lsb are those of the previous REFERENCE picture in decoding order; when it carried operation 5 they are 0 and its
-        // TopFieldOrderCnt after the operation -- dispatch_pending() stores that, and non-reference pictures in between leave it alone (8.2.1.1)
+        // prevPicOrderCntMsb / Lsb are those of the previous REFERENCE picture in decoding order (for the second field of a reference frame: its first
+        // field); when it carried operation 5 they are 0 and its TopFieldOrderCnt after the operation -- dispatch_pending() stores that, and
+        // non-reference pictures in between leave it alone (8.2.1.1)
         int prev_msb = sh.idr ? 0 : prev_poc_msb_, prev_lsb = sh.idr ? 0 : prev_poc_lsb_;
         long long msb = prev_msb;
         if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = (long long)prev_msb + max_lsb;
         else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = (long long)prev_msb - max_lsb;
         if (msb > (1ll << 30) || msb < -(1ll << 30)) msb = 0;                     // > 2^14 wraps of a 16-bit lsb without an IDR picture: not a real stream
         if (sh.nal_ref_idc) { prev_poc_msb_ = (int)msb; prev_poc_lsb_ = sh.poc_lsb; }
-        long long top = msb + sh.poc_lsb;
-        cur_top_poc_ = top; cur_bot_poc_ = top + sh.delta_poc_bottom;
-        return (int)std::min(top, top + sh.delta_poc_bottom);
+        // a frame or a top field: TopFieldOrderCnt = msb + lsb, and a frame's bottom field lies delta_pic_order_cnt_bottom from it; a bottom field
+        // picture: BottomFieldOrderCnt = msb + lsb
+        top = bot = msb + sh.poc_lsb;
+        if (!sh.field_pic) bot = top + sh.delta_poc_bottom;
+    } else {
+        // 64-bit arithmetic: offsets are se(v) of a hostile stream, and sums of them must not overflow (the result is truncated, never UB)
+        long long prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
+        long long off = sh.idr ? 0 : (prev_fn > sh.frame_num ? prev_off + max_fn : prev_off);
+        if (off > (1ll << 40)) off = 0;
+        prev_frame_num_offset_ = off;
+        if (s.poc_type == 2) top = bot = sh.idr ? 0 : (sh.nal_ref_idc ? 2 * (off + sh.frame_num) : 2 * (off + sh.frame_num) - 1);
+        else {
+            long long abs_fn = s.num_ref_frames_in_poc_cycle ? off + sh.frame_num : 0;
+            if (!sh.nal_ref_idc && abs_fn > 0) abs_fn--;
+            long long expected = 0, cycle = 0;
+            for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) cycle += s.offset_for_ref_frame[i];
+            if (abs_fn > 0) {
+                long long cnt = (abs_fn - 1) / s.num_ref_frames_in_poc_cycle; int in_cycle = (int)((abs_fn - 1) % s.num_ref_frames_in_poc_cycle);
+                expected = cnt * cycle;
+                for (int i = 0; i <= in_cycle; i++) expected += s.offset_for_ref_frame[i];
+            }
+            if (!sh.nal_ref_idc) expected += s.offset_for_non_ref_pic;
+            // 8.2.1.2: a bottom FIELD picture: expected + offset_for_top_to_bottom_field + delta_pic_order_cnt[0]
+            top = expected + sh.delta_poc[0];
+            bot = sh.field_pic ? expected + s.offset_for_top_to_bottom + sh.delta_poc[0] : top + s.offset_for_top_to_bottom + sh.delta_poc[1];
+        }
     }
-    // 64-bit arithmetic: offsets are se(v) of a hostile stream, and sums of them must not overflow (the result is truncated, never UB)
-    long long prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
-    long long off = sh.idr ? 0 : (prev_fn > sh.frame_num ? prev_off + max_fn : prev_off);
-    if (off > (1ll << 40)) off = 0;
-    prev_frame_num_offset_ = off;
-    if (s.poc_type == 2) return (int)(sh.idr ? 0 : (sh.nal_ref_idc ? 2 * (off + sh.frame_num) : 2 * (off + sh.frame_num) - 1));
-    long long abs_fn = s.num_ref_frames_in_poc_cycle ? off + sh.frame_num : 0;
-    if (!sh.nal_ref_idc && abs_fn > 0) abs_fn--;
-    long long expected = 0, cycle = 0;
-    for (int i = 0; i < s.num_ref_frames_in_poc_cycle; i++) cycle += s.offset_for_ref_frame[i];
-    if (abs_fn > 0) {
-        long long cnt = (abs_fn - 1) / s.num_ref_frames_in_poc_cycle; int in_cycle = (int)((abs_fn - 1) % s.num_ref_frames_in_poc_cycle);
-        expected = cnt * cycle;
-        for (int i = 0; i <= in_cycle; i++) expected += s.offset_for_ref_frame[i];
-    }
-    if (!sh.nal_ref_idc) expected += s.offset_for_non_ref_pic;
-    long long top = expected + sh.delta_poc[0];
-    return (int)std::min(top, top + s.offset_for_top_to_bottom + sh.delta_poc[1]);
+    cur_top_poc_ = top; cur_bot_poc_ = bot;
+    if (!sh.field_pic) { store.fpoc[0] = (int)top; store.fpoc[1] = (int)bot; return (int)std::min(top, bot); }
+    store.fpoc[sh.bottom_field] = (int)(sh.bottom_field ? bot : top);
+    return store.fpoc[sh.bottom_field];
 }
 
 void Decoder::flush_dpb(std::vector<int> &out) {
     if (codec_ == 1) { for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0; hevc_bump(out, true, true);
         for (int i = 0; i < n_surf_; i++) if (i != cur_ && !dpb_[i].wait_output) dpb_[i].in_use = false; return; }
-    for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
+    if (pending_first_ >= 0) { const int pf = pending_first_; pending_first_ = -1; dpb_[pf].waiting_second = false; store_done(pf, out); }
+    for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].set_ref(0);
     for (;;) {
         int best = -1;
         for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
         if (best < 0) break;
-        out.push_back(best); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc); dpb_[best].out_at = decode_count_ - 1;
+        out.push_back(best | dpb_[best].lone << 8); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc); dpb_[best].out_at = decode_count_ - 1;
     }
     for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
 }
 
 bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const PicParamSet &pps) {
+    // 3.30 / 7.4.1.2.4: is this the SECOND field of the frame whose first field was the picture before it?  Opposite parity, the same frame_num, not an
+    // IDR picture, and a reference field exactly if the first one is.  A first field that does not get its partner is complete as it stands.
+    const int pf = pending_first_;
+    const bool second = pf >= 0 && sh.field_pic && !sh.idr && dpb_[pf].waiting_second && dpb_[pf].frame_num == sh.frame_num &&
+                        dpb_[pf].have == (sh.bottom_field ? 1 : 2) && dpb_[pf].first_was_ref == (sh.nal_ref_idc != 0) && seq_active_ &&
+                        sps.mb_w == mb_w_ && sps.mb_h == mb_h_;
+    if (pf >= 0 && !second) { pending_first_ = -1; dpb_[pf].waiting_second = false; stat_lone_fields_++; store_done(pf, carry_out_); }
     if (sh.idr || !seq_active_) {
         // pfnSequenceCallback moment (nv_dec.cpp:23-30): a new coded video sequence starts.
         if (seq_active_) flush_dpb(carry_out_);
         if (!activate(sps)) return false;
     } else if (sps.mb_w != mb_w_ || sps.mb_h != mb_h_) { stat_errors_++; return false; }
-    // Surface for the new picture.  A surface that was displayed after picture n is still being packed out while picture
-    // n+1 decodes (the engine overlaps pack-out with the next batch), so prefer one that has "cooled" for a picture.
-    int slot = -1, warm = -1;
+    int slot = -1;
     bool wait_pack = false;
-    // Round robin over the free surfaces (starting behind the one chosen last), so that a surface is reused as LATE as possible: the engine
-    // runs consecutive pictures of a stream in one launch only while none of them decodes into a surface an earlier one still reads or displays.
-    for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i;
-        break; } if (warm < 0) warm = i; } }
-    if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
-    if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
-        int best = -1;
-        for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
-        if (best < 0) { for (int i = 0; i < n_surf_; i++) if (best < 0 || dpb_[i].frame_num_wrap < dpb_[best].frame_num_wrap) best = i; dpb_[best].ref = 0; }
-        else { carry_out_.push_back(best); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false; dpb_[best].ref = 0; }
-        dpb_[best].in_use = false; slot = best; stat_errors_++;
+    if (second) slot = pf;
+    else {
+        // Surface for the new picture.  A surface that was displayed after picture n is still being packed out while picture
+        // n+1 decodes (the engine overlaps pack-out with the next batch), so prefer one that has "cooled" for a picture.
+        int warm = -1;
+        // Round robin over the free surfaces (starting behind the one chosen last), so that a surface is reused as LATE as possible: the engine
+        // runs consecutive pictures of a stream in one launch only while none of them decodes into a surface an earlier one still reads or displays.
+        for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i;
+            break; } if (warm < 0) warm = i; } }
+        if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
+        if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
+            int best = -1;
+            for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
+            if (best < 0) { for (int i = 0; i < n_surf_; i++) if (best < 0 || dpb_[i].frame_num_wrap < dpb_[best].frame_num_wrap) best = i;
+                dpb_[best].set_ref(0); }
+            else { carry_out_.push_back(best | dpb_[best].lone << 8); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false; dpb_[best].set_ref(0); }
+            dpb_[best].in_use = false; slot = best; stat_errors_++;
+        }
+        last_surf_ = slot;
+        DpbPic &c = dpb_[slot];
+        c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
+        c.first_was_ref = sh.nal_ref_idc != 0; c.coded_as_fields = sh.field_pic;
+        if (sps.profile_idc != 66 && sh.nal_ref_idc && !sh.field_pic) c.mf = std::make_shared<MotionField>();   // a later B picture may use this one as its
+                                                                                                              // colocated picture
     }
-    cur_ = slot; last_surf_ = slot;
+    cur_ = slot;
     DpbPic &c = dpb_[slot];
-    c = DpbPic(); c.in_use = true; c.frame_num = sh.frame_num; c.decode_idx = decode_count_++;
-    c.poc = compute_poc(sh);
-    if (sps.profile_idc != 66 && sh.nal_ref_idc) c.mf = std::make_shared<MotionField>();   // a later B picture may use this one as its colocated picture
+    const int poc = compute_poc(sh, c);
+    if (!second) c.poc = poc;
+    cur_field_ = sh.field_pic ? 1 + (int)sh.bottom_field : 0; cur_second_ = second;
     pending_ = std::make_unique<PicTask>();
-    pending_->mf = c.mf;
+    pending_->mf = sh.field_pic ? nullptr : c.mf;
     pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack; pending_->sps = sps; pending_->pps = pps;
+    pending_->field = cur_field_;
+    if (sh.field_pic) { pending_->sps.mb_h = sps.mb_h / 2; stat_field_pics_++; }      // from here on the picture is one of half the height
     pending_->out_before = std::move(carry_out_); carry_out_.clear();
     first_sh_ = sh;
     if (sh.type == SL_I) stat_i_++; else if (sh.type == SL_B) stat_b_++; else stat_p_++;
     return true;
+}
+
+// 8.2.4.2.5: the fields of an ordered list of frame stores, alternating in parity and beginning with the parity of the current field; a store whose field
+// of the wanted parity is not marked `mark` is passed over, and when one parity has run out the rest of the other follows.  Entries: slot | parity << 5.
+static int alternate_fields(const DpbPic *dpb, const int *stores, int n, int mark, int par, int cur_slot, int *out, int cnt, int max) {
+    auto marked = [&](int i, int q) { return !(stores[i] == cur_slot && q == par) && dpb[stores[i]].fmark[q] == mark; };
+    int c[2] = {0, 0}, q = par;
+    for (;;) {
+        while (c[q] < n && !marked(c[q], q)) c[q]++;
+        if (c[q] < n) { if (cnt < max) out[cnt++] = stores[c[q]] | q << 5; c[q]++; }
+        else { const int o = q ^ 1; while (c[o] < n && !marked(c[o], o)) c[o]++; if (c[o] >= n) break; }
+        q ^= 1;
+    }
+    return cnt;
+}
+
+// 8.2.4.1 (field picture numbers), 8.2.4.2.2 + 8.2.4.2.5, 8.2.4.3 for the P slices of a field picture.  A list entry names a FIELD: the surface slot
+// of its frame store with the parity in bit 5 (jobs.h MbRec.ref; kernels take the lines of that parity).
+void Decoder::build_field_ref_lists(const SliceHeader &sh, SliceTask &task) {
+    SliceRefs &rf = task.refs;
+    const int par = sh.bottom_field, max_fn = 1 << seq_.log2_max_frame_num;
+    rf.cur_poc = dpb_[cur_].fpoc[par];
+    int st[kMaxSurfaces], lt[kMaxSurfaces], nst = 0, nlt = 0;
+    for (int i = 0; i < n_surf_; i++) {
+        DpbPic &p = dpb_[i];
+        if (!p.in_use) continue;
+        p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num;
+        // the store of the current frame takes part with its FIRST field (8.2.4.2.2)
+        const int m0 = (i == cur_ && par == 0) ? 0 : p.fmark[0], m1 = (i == cur_ && par == 1) ? 0 : p.fmark[1];
+        if (m0 == 1 || m1 == 1) st[nst++] = i;
+        if (m0 == 2 || m1 == 2) lt[nlt++] = i;
+    }
+    std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].frame_num_wrap > dpb_[b].frame_num_wrap; });
+    std::sort(lt, lt + nlt, [&](int a, int b) { return dpb_[a].lt_idx < dpb_[b].lt_idx; });
+    int list[35];
+    for (int &v : list) v = -1;
+    int n = alternate_fields(dpb_, st, nst, 1, par, cur_, list, 0, 33);
+    n = alternate_fields(dpb_, lt, nlt, 2, par, cur_, list, n, 33);
+    const int nact = sh.num_ref_idx[0];
+    for (int i = nact; i < 35; i++) list[i] = -1;
+    // PicNum = 2 * FrameNumWrap + 1 for a field of the current parity, 2 * FrameNumWrap for the other; LongTermPicNum the same from LongTermFrameIdx
+    auto pic_num = [&](int e) { return 2 * dpb_[e & 31].frame_num_wrap + (((e >> 5) & 1) == par); };
+    auto lt_pic_num = [&](int e) { return 2 * dpb_[e & 31].lt_idx + (((e >> 5) & 1) == par); };
+    const int cur_pic_num = 2 * sh.frame_num + 1, max_pic_num = 2 * max_fn;
+    int pred = cur_pic_num, idx = 0;
+    for (int k = 0; k < sh.n_mod[0]; k++) {
+        const RefMod &m = sh.mod[0][k];
+        int target = -1;
+        if (m.idc < 2) {
+            int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
+            if (nowrap < 0) nowrap += max_pic_num;
+            if (nowrap >= max_pic_num) nowrap -= max_pic_num;
+            pred = nowrap;
+            const int want = nowrap > cur_pic_num ? nowrap - max_pic_num : nowrap;
+            for (int i = 0; i < nst; i++) for (int q = 0; q < 2; q++) { const int e = st[i] | q << 5;
+                if (!(st[i] == cur_ && q == par) && dpb_[st[i]].fmark[q] == 1 && pic_num(e) == want) target = e; }
+        } else for (int i = 0; i < nlt; i++) for (int q = 0; q < 2; q++) { const int e = lt[i] | q << 5;
+            if (!(lt[i] == cur_ && q == par) && dpb_[lt[i]].fmark[q] == 2 && lt_pic_num(e) == (int)m.val) target = e; }
+        if (target < 0 || idx >= nact) { stat_errors_++; break; }
+        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+        list[idx++] = target;
+        int nidx = idx;
+        for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+    }
+    for (int i = 0; i < nact && i < 32; i++) {
+        rf.slot[0][i] = (int8_t)list[i];
+        if (list[i] >= 0) { const DpbPic &p = dpb_[list[i] & 31]; const int q = (list[i] >> 5) & 1;
+            rf.uid[0][i] = 2 * p.decode_idx + q; rf.poc[0][i] = p.fpoc[q]; rf.is_long[0][i] = p.fmark[q] == 2; }
+    }
 }
 
 // 8.2.4.2 + 8.2.4.3: RefPicList0 / RefPicList1 of a slice, expressed as surface slots (+ what direct / weighted prediction need)
@@ -675,6 +779,40 @@ void Decoder::build_ref_lists(const SliceHeader &sh, SliceTask &task) {
     rf.track_uid = seq_.profile_idc != 66;                   // Baseline has no B slices: nothing will ever ask for this picture's motion
     rf.bipred_rec = sh.type == SL_B || sh.explicit_wp;
     if (sh.type == SL_I) return;
+    if (sh.field_pic) build_field_ref_lists(sh, task);
+    else build_frame_ref_lists(sh, task);
+    // weighted prediction tables (8.4.2.3)
+    const PicParamSet &pps = ps_.pps[sh.pps_id];
+    const int nlists = sh.type == SL_B ? 2 : 1;
+    int mode = sh.type == SL_P ? (sh.explicit_wp ? 1 : 0) : pps.weighted_bipred_idc;
+    task.has_wp = mode != 0;
+    if (task.has_wp) {
+        if (mode == 1 && (sh.num_ref_idx[0] > 16 || sh.num_ref_idx[1] > 16)) { stat_errors_++; fail("explicit weighted prediction with more than 16 list entries"); }
+        SliceWp &wp = task.wp;
+        memset(&wp, 0, sizeof wp);
+        wp.mode = (uint8_t)mode; wp.logwd_y = (uint8_t)sh.luma_log2_wd; wp.logwd_c = (uint8_t)sh.chroma_log2_wd;
+        if (mode == 1) {
+            for (int l = 0; l < nlists; l++) for (int i = 0; i < 16 && i < sh.num_ref_idx[l]; i++) {
+                wp.w[l][i][0] = (int8_t)sh.luma_w[l][i]; wp.o[l][i][0] = (int8_t)sh.luma_o[l][i];
+                for (int c = 0; c < 2; c++) { wp.w[l][i][1 + c] = (int8_t)sh.chroma_w[l][i][c]; wp.o[l][i][1 + c] = (int8_t)sh.chroma_o[l][i][c]; }
+            }
+        } else {
+            for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
+                int w1 = 32;
+                if (rf.slot[0][i] >= 0 && rf.slot[1][j] >= 0 && !rf.is_long[0][i] && !rf.is_long[1][j]) {
+                    int tb = std::clamp(rf.cur_poc - rf.poc[0][i], -128, 127), td = std::clamp(rf.poc[1][j] - rf.poc[0][i], -128, 127);
+                    if (td != 0) { int tx = (16384 + std::abs(td / 2)) / td, dsf = std::clamp((tb * tx + 32) >> 6, -1024, 1023) >> 2;
+                        if (dsf >= -64 && dsf <= 128) w1 = dsf; }
+                }
+                wp.imp_w1[i][j] = (uint8_t)(64 + w1);
+            }
+        }
+    }
+}
+
+// 8.2.4.2.1 / 8.2.4.2.3 + 8.2.4.3 for the slices of a FRAME picture: reference frames are the stores with both fields marked (DpbPic.ref 1 / 2)
+void Decoder::build_frame_ref_lists(const SliceHeader &sh, SliceTask &task) {
+    SliceRefs &rf = task.refs;
     int max_fn = 1 << seq_.log2_max_frame_num;
     int st[kMaxSurfaces], lt[kMaxSurfaces], nst = 0, nlt = 0;
     for (int i = 0; i < n_surf_; i++) {
@@ -730,31 +868,9 @@ void Decoder::build_ref_lists(const SliceHeader &sh, SliceTask &task) {
             if (list[i] >= 0) { rf.uid[l][i] = dpb_[list[i]].decode_idx; rf.poc[l][i] = dpb_[list[i]].poc; rf.is_long[l][i] = dpb_[list[i]].ref == 2; }
         }
     }
-    if (sh.type == SL_B && rf.slot[1][0] >= 0) { task.col = dpb_[rf.slot[1][0]].mf; rf.col = task.col.get(); }
-    // weighted prediction tables (8.4.2.3)
-    const PicParamSet &pps = ps_.pps[sh.pps_id];
-    int mode = sh.type == SL_P ? (sh.explicit_wp ? 1 : 0) : pps.weighted_bipred_idc;
-    task.has_wp = mode != 0;
-    if (task.has_wp) {
-        SliceWp &wp = task.wp;
-        memset(&wp, 0, sizeof wp);
-        wp.mode = (uint8_t)mode; wp.logwd_y = (uint8_t)sh.luma_log2_wd; wp.logwd_c = (uint8_t)sh.chroma_log2_wd;
-        if (mode == 1) {
-            for (int l = 0; l < nlists; l++) for (int i = 0; i < 16 && i < sh.num_ref_idx[l]; i++) {
-                wp.w[l][i][0] = (int8_t)sh.luma_w[l][i]; wp.o[l][i][0] = (int8_t)sh.luma_o[l][i];
-                for (int c = 0; c < 2; c++) { wp.w[l][i][1 + c] = (int8_t)sh.chroma_w[l][i][c]; wp.o[l][i][1 + c] = (int8_t)sh.chroma_o[l][i][c]; }
-            }
-        } else {
-            for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
-                int w1 = 32;
-                if (rf.slot[0][i] >= 0 && rf.slot[1][j] >= 0 && !rf.is_long[0][i] && !rf.is_long[1][j]) {
-                    int tb = std::clamp(rf.cur_poc - rf.poc[0][i], -128, 127), td = std::clamp(rf.poc[1][j] - rf.poc[0][i], -128, 127);
-                    if (td != 0) { int tx = (16384 + std::abs(td / 2)) / td, dsf = std::clamp((tb * tx + 32) >> 6, -1024, 1023) >> 2;
-                        if (dsf >= -64 && dsf <= 128) w1 = dsf; }
-                }
-                wp.imp_w1[i][j] = (uint8_t)(64 + w1);
-            }
-        }
+    if (sh.type == SL_B && rf.slot[1][0] >= 0) {
+        if (dpb_[rf.slot[1][0]].coded_as_fields) { stat_errors_++; fail("direct prediction from a picture coded as two fields is not supported"); return; }
+        task.col = dpb_[rf.slot[1][0]].mf; rf.col = task.col.get();
     }
 }
 
@@ -766,19 +882,20 @@ void Decoder::add_slice(const SliceHeader &sh, std::vector<uint8_t> &&rbsp, size
     build_ref_lists(sh, s);
 }
 
-void Decoder::mark_current(const SliceHeader &sh) {                                 // 8.2.5
+void Decoder::mark_current(const SliceHeader &sh) {                                 // 8.2.5, frame picture
     DpbPic &cur = dpb_[cur_];
     if (!sh.nal_ref_idc) return;
     int max_fn = 1 << seq_.log2_max_frame_num;
     if (sh.idr) {
-        for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].ref = 0;
-        if (sh.long_term_reference) { cur.ref = 2; cur.lt_idx = 0; max_lt_idx_ = 0; } else { cur.ref = 1; max_lt_idx_ = -1; }
+        for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].set_ref(0);
+        if (sh.long_term_reference) { cur.set_ref(2); cur.lt_idx = 0; max_lt_idx_ = 0; } else { cur.set_ref(1); max_lt_idx_ = -1; }
         return;
     }
-    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1) {
+    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.any_short()) {
         p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; p.pic_num = p.frame_num_wrap; } }
     bool made_long = false;
     if (sh.adaptive_marking) {
+        // a frame picture names FRAMES: stores with both fields marked the same way (ref 1 / 2; 8.2.4.1)
         for (int k = 0; k < sh.n_mark; k++) {
             const MarkOp &m = sh.mark[k];
             int pic_num_x = sh.frame_num - (int)(m.a + 1);
@@ -786,54 +903,105 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
                 DpbPic &p = dpb_[i];
                 if (!p.in_use || i == cur_) continue;
                 switch (m.op) {
-                case 1: if (p.ref == 1 && p.pic_num == pic_num_x) p.ref = 0; break;
-                case 2: if (p.ref == 2 && p.lt_idx == (int)m.a) p.ref = 0; break;
-                case 3: if (p.ref == 2 && p.lt_idx == (int)m.b) p.ref = 0; break;
-                case 4: if (p.ref == 2 && p.lt_idx > (int)m.a - 1) p.ref = 0; break;
-                case 5: p.ref = 0; break;
-                case 6: if (p.ref == 2 && p.lt_idx == (int)m.b) p.ref = 0; break;
+                case 1: if (p.ref == 1 && p.pic_num == pic_num_x) p.set_ref(0); break;
+                case 2: if (p.ref == 2 && p.lt_idx == (int)m.a) p.set_ref(0); break;
+                case 3: if (p.ref == 2 && p.lt_idx == (int)m.b) p.set_ref(0); break;
+                case 4: if (p.any_long() && p.lt_idx > (int)m.a - 1) p.set_ref(0); break;
+                case 5: p.set_ref(0); break;
+                case 6: if (p.ref == 2 && p.lt_idx == (int)m.b) p.set_ref(0); break;
                 }
             }
             if (m.op == 3) for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use && i != cur_ && p.ref == 1 && p.pic_num == pic_num_x) {
-                p.ref = 2; p.lt_idx = (int)m.b; } }
+                p.set_ref(2); p.lt_idx = (int)m.b; } }
             if (m.op == 4) max_lt_idx_ = (int)m.a - 1;
             if (m.op == 5) { max_lt_idx_ = -1; cur.mmco5 = true; }
-            if (m.op == 6) { cur.ref = 2; cur.lt_idx = (int)m.b; made_long = true; }
+            if (m.op == 6) { cur.set_ref(2); cur.lt_idx = (int)m.b; made_long = true; }
         }
     } else {
+        // 8.2.5.3: the count is of frames, complementary field pairs and single fields in which ANY field is marked
         int nst = 0, nlt = 0, oldest = -1;
         for (int i = 0; i < n_surf_; i++) {
             DpbPic &p = dpb_[i];
             if (!p.in_use || i == cur_) continue;
-            if (p.ref == 1) { nst++; if (oldest < 0 || p.frame_num_wrap < dpb_[oldest].frame_num_wrap) oldest = i; }
-            else if (p.ref == 2) nlt++;
+            if (p.any_short()) { nst++; if (oldest < 0 || p.frame_num_wrap < dpb_[oldest].frame_num_wrap) oldest = i; }
+            else if (p.any_long()) nlt++;
         }
-        if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].ref = 0;
+        if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].set_ref(0);
     }
-    if (!made_long) cur.ref = 1;
+    if (!made_long) cur.set_ref(1);
 }
 
-// C.4.5.2 / C.4.5.3 with the display delay of the reference replaced by the minimum that keeps
-// display order (the YUV file only records ORDER; nv_dec.cpp:341 ulMaxDisplayDelay=2 only adds latency)
-void Decoder::bump_after_current(std::vector<int> &out) {
+// 8.2.5 for a FIELD picture: operations name fields by their field picture numbers (8.2.4.1); the sliding window leaves the second field of a reference
+// frame alone (8.2.5.3).  Operations 3, 5 and 6 in a field picture are not supported: the handle fails.
+void Decoder::mark_current_field(const SliceHeader &sh) {
     DpbPic &cur = dpb_[cur_];
+    const int par = sh.bottom_field, max_fn = 1 << seq_.log2_max_frame_num;
+    if (!sh.nal_ref_idc) return;
+    if (sh.idr) {
+        for (int i = 0; i < n_surf_; i++) if (i != cur_) dpb_[i].set_ref(0);
+        cur.fmark[par] = sh.long_term_reference ? 2 : 1; cur.fmark[par ^ 1] = 0; cur.sync_ref();
+        cur.lt_idx = sh.long_term_reference ? 0 : -1; max_lt_idx_ = sh.long_term_reference ? 0 : -1;
+        return;
+    }
+    for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use) p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; }
+    if (sh.adaptive_marking) {
+        const int cur_pic_num = 2 * sh.frame_num + 1;
+        for (int k = 0; k < sh.n_mark; k++) {
+            const MarkOp &m = sh.mark[k];
+            if (m.op == 3 || m.op == 5 || m.op == 6) { stat_errors_++; fail("memory management operation 3, 5 or 6 in a field picture is not supported"); return; }
+            const int pic_num_x = cur_pic_num - (int)(m.a + 1);
+            for (int i = 0; i < n_surf_; i++) {
+                DpbPic &p = dpb_[i];
+                if (!p.in_use) continue;
+                for (int q = 0; q < 2; q++) {
+                    if (i == cur_ && q == par) continue;
+                    const int same = q == par;
+                    if (m.op == 1 && p.fmark[q] == 1 && 2 * p.frame_num_wrap + same == pic_num_x) p.fmark[q] = 0;
+                    if (m.op == 2 && p.fmark[q] == 2 && 2 * p.lt_idx + same == (int)m.a) p.fmark[q] = 0;
+                    if (m.op == 4 && p.fmark[q] == 2 && p.lt_idx > (int)m.a - 1) p.fmark[q] = 0;
+                }
+                p.sync_ref();
+            }
+            if (m.op == 4) max_lt_idx_ = (int)m.a - 1;
+        }
+    } else if (!(cur_second_ && cur.fmark[par ^ 1] == 1)) {
+        int nst = 0, nlt = 0, oldest = -1;
+        for (int i = 0; i < n_surf_; i++) {
+            DpbPic &p = dpb_[i];
+            if (!p.in_use || i == cur_) continue;
+            if (p.any_short()) { nst++; if (oldest < 0 || p.frame_num_wrap < dpb_[oldest].frame_num_wrap) oldest = i; }
+            else if (p.any_long()) nlt++;
+        }
+        if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].set_ref(0);
+    }
+    cur.fmark[par] = 1; cur.sync_ref();
+}
+
+// C.4.5.2 / C.4.5.3 for a frame store that is complete -- a frame, both fields of a frame, or a field whose partner did not come --, with the display
+// delay of the reference replaced by the minimum that keeps display order (the YUV file only records ORDER; nv_dec.cpp:341 ulMaxDisplayDelay=2
+// only adds latency)
+void Decoder::store_done(int slot, std::vector<int> &out) {
+    DpbPic &cur = dpb_[slot];
     auto smallest = [&](int exclude) {
         int b = -1;
         for (int i = 0; i < n_surf_; i++)
-            if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i;
+            if (i != exclude && dpb_[i].in_use && dpb_[i].wait_output && !dpb_[i].waiting_second && (b < 0 || dpb_[i].poc < dpb_[b].poc)) b = i;
         return b;
     };
     if (cur.mmco5) {
         int b;
-        while ((b = smallest(cur_)) >= 0) {
-            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false;
+        while ((b = smallest(slot)) >= 0) {
+            out.push_back(b | dpb_[b].lone << 8); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false;
             dpb_[b].out_at = decode_count_ - 1;
         }
+        const int tmp = std::min(cur.fpoc[0], cur.fpoc[1]);
+        cur.fpoc[0] -= tmp; cur.fpoc[1] -= tmp;
         cur.poc = 0; cur.frame_num = 0;
     }
-    int w = smallest(cur_);
-    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(cur_); display_pocs_.push_back(cur.poc); cur.out_at = decode_count_ - 1;
-        cur.in_use = false; }
+    int w = smallest(slot);
+    cur.lone = cur.have == 3 || codec_ == 1 ? 0 : cur.have;
+    if (!cur.ref && (w < 0 || dpb_[w].poc > cur.poc)) { out.push_back(slot | cur.lone << 8); display_pocs_.push_back(cur.poc); cur.out_at = decode_count_ - 1;
+        cur.in_use = false; cur.wait_output = false; }
     else {
         cur.wait_output = true;
         for (;;) {
@@ -842,26 +1010,43 @@ void Decoder::bump_after_current(std::vector<int> &out) {
             if (used <= dpb_size_ && waiting <= reorder_depth_) break;
             int b = smallest(-1);
             if (b < 0) break;
-            out.push_back(b); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; dpb_[b].out_at = decode_count_ - 1;
+            out.push_back(b | dpb_[b].lone << 8); display_pocs_.push_back(dpb_[b].poc); dpb_[b].wait_output = false; dpb_[b].out_at = decode_count_ - 1;
         }
     }
-    for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
+    for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && i != pending_first_ && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
 }
 
 void Decoder::dispatch_pending() {
     if (codec_ == 1) { hevc_dispatch_pending(); return; }
     if (!pending_) return;
     std::unique_ptr<PicTask> t = std::move(pending_);
-    mark_current(first_sh_);
-    prev_frame_num_ = dpb_[cur_].frame_num;
-    prev_mmco5_ = dpb_[cur_].mmco5;                // types 1 / 2: "the previous picture in decoding order included operation 5" (8.2.1.2, 8.2.1.3)
-    // type 0: tempPicOrderCnt = Min(top, bottom) is subtracted from the picture's order counts (8.2.1); what the following pictures see as
-    // prevPicOrderCntLsb is its TopFieldOrderCnt after that (> 0 when the bottom field lies below the top field)
-    if (dpb_[cur_].mmco5 && seq_.poc_type == 0) { prev_poc_msb_ = 0; prev_poc_lsb_ = (int)(cur_top_poc_ - std::min(cur_top_poc_, cur_bot_poc_)); }
-    int poc = dpb_[cur_].poc;
-    (void)poc;
-    bump_after_current(t->out_after);
-    cur_ = -1;
+    DpbPic &cur = dpb_[cur_];
+    const int slot = cur_;
+    if (cur_field_) {
+        const int par = cur_field_ - 1;
+        mark_current_field(first_sh_);
+        prev_frame_num_ = cur.frame_num; prev_mmco5_ = false;
+        cur.have |= 1 << par;
+        cur_ = -1;
+        if (!cur_second_) {
+            // the first field of a frame: the store waits for the other one (start_picture decides whether the next picture is that)
+            cur.waiting_second = true; cur.wait_output = true; pending_first_ = slot;
+        } else {
+            cur.waiting_second = false; pending_first_ = -1;
+            cur.poc = std::min(cur.fpoc[0], cur.fpoc[1]);                        // 8.2.1: PicOrderCnt of a complementary field pair
+            store_done(slot, t->out_after);
+        }
+    } else {
+        cur.have = 3;
+        mark_current(first_sh_);
+        prev_frame_num_ = cur.frame_num;
+        prev_mmco5_ = cur.mmco5;                   // types 1 / 2: "the previous picture in decoding order included operation 5" (8.2.1.2, 8.2.1.3)
+        // type 0: tempPicOrderCnt = Min(top, bottom) is subtracted from the picture's order counts (8.2.1); what the following pictures see as
+        // prevPicOrderCntLsb is its TopFieldOrderCnt after that (> 0 when the bottom field lies below the top field)
+        if (cur.mmco5 && seq_.poc_type == 0) { prev_poc_msb_ = 0; prev_poc_lsb_ = cur.fpoc[0] - std::min(cur.fpoc[0], cur.fpoc[1]); }
+        cur_ = -1;
+        store_done(slot, t->out_after);
+    }
     t->job_slot = acquire_job_slot(first_sh_.type == SL_I);
     push_task(std::move(t));
 }
@@ -956,7 +1141,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
             if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
             if (s.col) s.col->wait();                            // direct prediction reads RefPicList1[0]'s motion: that picture was dispatched earlier
             if (s.has_wp) t->any_wp = true;
-            SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr, fast_parse_);
+            SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr, fast_parse_ && !t->field);
             t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
             if (r.error) { t->error = r.error; if (!first_error) first_error = r.error; overflow |= strcmp(r.error, "coefficient buffer overflow") == 0; }
         }
@@ -1075,13 +1260,15 @@ void Decoder::submit_ready() {
 }
 
 // a display frame leaves the DPB: reserve an output slot (display order) and describe the pack-out for the engine
-void Decoder::enqueue_output(int slot, std::vector<PackJob> &jobs, std::vector<OutSlot *> &slots) {
+void Decoder::enqueue_output(int slot_and_lone, std::vector<PackJob> &jobs, std::vector<OutSlot *> &slots) {
+    const int slot = slot_and_lone & 255, lone = slot_and_lone >> 8;       // store_done: bits 8.. = the one field that was decoded, if only one was
     OutSlot *o;
     { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
     if (parse_only_ || failed_) { std::lock_guard<std::mutex> lk(mtx_); o->ready = true; return; }
     // k_packout packs the tight frame into device staging and a copy engine moves it to the pinned slot -- or, in direct mode,
     // the kernel stores straight into the pinned host slot (see Engine::launch for why the copy engine is the default)
-    jobs.push_back(PackJob{surf_[slot], o->dev ? o->dev : o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, 0});
+    // (a frame of which only one field was decoded is shown with that field's lines repeated: PackJob.lone_field)
+    jobs.push_back(PackJob{surf_[slot], o->dev ? o->dev : o->host, pitch_, chroma_off_, disp_w_, disp_h_, out_fmt_, lone});
     slots.push_back(o);
     o->has_data = true;
     // route of this frame (see Decoder::init): fetch when the device's synchronous-copy queue is idle right now
@@ -1093,7 +1280,7 @@ void Decoder::submit_task(PicTask *t) {
     EnginePic ep;
     ep.dec = this; ep.has_picture = t->has_picture && !parse_only_ && !failed_; ep.job_slot = t->job_slot;
     ep.mb_w = mb_w_; ep.mb_h = mb_h_; ep.disp_w = disp_w_; ep.disp_h = disp_h_; ep.wait_prev_pack = t->wait_prev_pack;
-    for (int s : t->out_before) { enqueue_output(s, ep.out_before, ep.slots_before); ep.out_mask |= 1u << s; }
+    for (int s : t->out_before) { enqueue_output(s, ep.out_before, ep.slots_before); ep.out_mask |= 1u << (s & 255); }
     memset(&ep.pp, 0, sizeof ep.pp);
     if (ep.has_picture && t->hevc) hevc_fill_engine_pic(t, ep);
     else if (ep.has_picture) {
@@ -1101,7 +1288,9 @@ void Decoder::submit_task(PicTask *t) {
         const int n_mbs = t->sps.mb_w * t->sps.mb_h;
         PicParams &pp = ep.pp;
         ep.uploaded = js.uploaded; ep.upload_seq = t->upload_seq;
-        pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = pitch_; pp.chroma_offset = chroma_off_;
+        // a field picture: the lines of one parity of the surface, as a picture of half the height and twice the pitch (kernel_common.h field_base)
+        pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = t->field ? 2 * pitch_ : pitch_; pp.chroma_offset = chroma_off_; pp.field = t->field;
+        ep.mb_h = t->sps.mb_h;
         pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
         pp.n_slices = t->n_slices; pp.cur = t->cur_slot;
         for (int i = 0; i < kMaxSurfaces; i++) pp.surf[i] = surf_[i];
@@ -1130,16 +1319,17 @@ void Decoder::submit_task(PicTask *t) {
         if (t->any_deblock) pp.stages |= use_lds_deblock_ ? PS_DEBLOCK_LDS : PS_DEBLOCK_V1;
         // Inter pictures without intra macroblocks, deblocked by the LDS wavefront, may run inside the chain kernel (chain.hip) together with
         // the pictures that follow them in this stream; the engine decides per batch.  What the engine needs to see hazards: the surfaces read.
-        ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0;
+        ep.chain_ok = chain_ok_ && pp.stages == (PS_RECON | PS_DEBLOCK_LDS) && t->n_intra == 0 && !t->field;
         // Pictures WITH intra macroblocks -- the I picture of an IDR period, or a P picture with a few of them -- can join too: the intra wavefront then
         // runs as a third role of the chain kernel (k_chain_i), whatever the share of intra macroblocks (the stage path uses the spin-wait kernel for sparse
         // ones).
-        ep.chain_intra = chain_ok_ && chain_intra_on_ && t->n_intra > 0 && use_lds_intra_ && (t->n_i8x8 == 0 || lds_intra8_) && (pp.stages & PS_DEBLOCK_LDS);
+        ep.chain_intra = chain_ok_ && chain_intra_on_ && t->n_intra > 0 && use_lds_intra_ && (t->n_i8x8 == 0 || lds_intra8_) && (pp.stages & PS_DEBLOCK_LDS) &&
+                         !t->field;
         ep.classic_stages = pp.stages;
         for (auto &sl : t->slices) ep.bipred |= sl.refs.bipred_rec;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |=
-            1u << sl.refs.slot[l][i];
+            1u << (sl.refs.slot[l][i] & 31);
         // algorithmic bytes of this picture per kernel class
         long long S = (long long)surf_bytes_;
         bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
@@ -1148,7 +1338,7 @@ void Decoder::submit_task(PicTask *t) {
         ep.alg_bytes[2] = 2 * S;
     }
     ep.alg_bytes[3] = (long long)surf_bytes_ + (long long)frame_bytes_;
-    for (int s : t->out_after) { enqueue_output(s, ep.out_after, ep.slots_after); ep.out_mask |= 1u << s; }
+    for (int s : t->out_after) { enqueue_output(s, ep.out_after, ep.slots_after); ep.out_mask |= 1u << (s & 255); }
     stat_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - st0).count();
     if (parse_only_ || failed_ || !engine_) { on_engine_done(ep); return; }
     engine_->submit(std::move(ep));

@@ -26,8 +26,19 @@ namespace jmamd {
 
 constexpr int kJobSlots = 24;   // pictures in flight per handle (parse + device); deep enough to hide an I picture's entropy decode behind a GOP of device work
 
-struct DpbPic {
-    bool in_use = false; int ref = 0;          // 0 none, 1 short-term, 2 long-term
+struct DpbPic {                                // one frame store (C.4.5): a frame, or the one or two field pictures of a frame
+    bool in_use = false;
+    // marking.  fmark[]: each field (top, bottom): 0 not a reference, 1 short-term, 2 long-term.  ref is derived (sync_ref): 1 / 2 = BOTH fields so,
+    // i.e. a reference FRAME in the sense of 8.2.4.2.1; 3 = some field is a reference (field pictures can use it, and the store stays occupied)
+    int ref = 0; int fmark[2] = {0, 0};
+    int fpoc[2] = {0, 0};                      // TopFieldOrderCnt, BottomFieldOrderCnt
+    int have = 0;                              // bit 0 / 1: top / bottom field decoded (a frame picture: both)
+    bool waiting_second = false, first_was_ref = false, coded_as_fields = false;
+    int lone = 0;                              // set when the store is complete: 1 / 2 = only its top / bottom field was decoded
+    void set_ref(int v) { fmark[0] = fmark[1] = v; ref = v; }
+    void sync_ref() { ref = (fmark[0] == 1 && fmark[1] == 1) ? 1 : (fmark[0] == 2 && fmark[1] == 2) ? 2 : (fmark[0] || fmark[1]) ? 3 : 0; }
+    bool any_short() const { return fmark[0] == 1 || fmark[1] == 1; }
+    bool any_long() const { return fmark[0] == 2 || fmark[1] == 2; }
     bool wait_output = false;
     int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
     int decode_idx = 0; bool mmco5 = false;
@@ -59,6 +70,7 @@ struct PicTask {
     uint64_t seq = 0;
     bool has_picture = false;
     int cur_slot = -1, job_slot = -1;
+    int field = 0;                             // 0 frame picture, 1 / 2 top / bottom field picture (sps.mb_h is then the FIELD's)
     std::shared_ptr<MotionField> mf;           // this picture's motion field (reference pictures of streams that may hold B pictures)
     SeqParams sps; PicParamSet pps;
     std::vector<SliceTask> slices;
@@ -142,7 +154,11 @@ private:
     void dispatch_pending();
     void build_ref_lists(const SliceHeader &sh, SliceTask &st);
     void mark_current(const SliceHeader &sh);
-    int  compute_poc(const SliceHeader &sh);
+    int  compute_poc(const SliceHeader &sh, DpbPic &store);
+    void build_field_ref_lists(const SliceHeader &sh, SliceTask &task);
+    void build_frame_ref_lists(const SliceHeader &sh, SliceTask &task);
+    void mark_current_field(const SliceHeader &sh);
+    void store_done(int slot, std::vector<int> &out);
     void bump_after_current(std::vector<int> &out);
     void flush_dpb(std::vector<int> &out);
     void push_task(std::unique_ptr<PicTask> t);
@@ -192,6 +208,9 @@ private:
     // DPB / picture state (front end only)
     DpbPic dpb_[kMaxSurfaces];
     int cur_ = -1;
+    int cur_field_ = 0; bool cur_second_ = false;   // the current picture: 0 frame, 1 top field, 2 bottom field; the second field of its frame
+    int pending_first_ = -1;                        // the frame store that holds a first field and waits for the second
+    std::atomic<long long> stat_field_pics_{0}, stat_lone_fields_{0};
     std::unique_ptr<PicTask> pending_;
     SliceHeader first_sh_;
     int prev_poc_msb_ = 0, prev_poc_lsb_ = 0, prev_frame_num_ = 0; long long prev_frame_num_offset_ = 0; bool prev_mmco5_ = false;

@@ -53,6 +53,20 @@ static const uint8_t kZigzag8[64] = {
     0, 1, 8,16, 9, 2, 3,10, 17,24,32,25,18,11, 4, 5, 12,19,26,33,40,48,41,34, 27,20,13, 6, 7,14,21,28,
    35,42,49,56,57,50,43,36, 29,22,15,23,30,37,44,51, 58,59,52,45,38,31,39,46, 53,60,61,54,47,55,62,63 };
 
+// Field scans (Table 8-2 / Table 8-3): the coefficients of a field macroblock run down the columns first.  Built from the (column, row) pairs of the
+// tables -- two digits per scan position -- into the same "scan position -> raster index" form as the zig-zag tables above.
+struct FieldScans {
+    uint8_t s4[16], s8[64];
+    FieldScans() {
+        static const char *xy4 = "00 01 10 02 03 11 12 13 20 21 22 23 30 31 32 33";
+        static const char *xy8 = "00 01 02 10 11 03 04 12 20 13 05 06 07 14 21 30 22 15 16 17 23 31 40 32 24 25 26 27 33 41 50 42 "
+                                 "34 35 36 37 43 51 60 52 44 45 46 47 53 61 62 54 55 56 57 63 70 71 64 65 66 67 72 73 74 75 76 77";
+        for (int i = 0; i < 16; i++) s4[i] = (uint8_t)((xy4[3 * i + 1] - '0') * 4 + (xy4[3 * i] - '0'));
+        for (int i = 0; i < 64; i++) s8[i] = (uint8_t)((xy8[3 * i + 1] - '0') * 8 + (xy8[3 * i] - '0'));
+    }
+};
+static const FieldScans kFieldScan;
+
 // two-level table for coeff_token: primary on the top 8 bits, secondary on the next 8
 struct TokTable { uint16_t t[256 * 24]; };           // entry = sym << 8 | len ; len 0xFF => sym = subtable number
 static TokTable g_tok[4];                           // [3]: nC >= 8, the 6-bit fixed-length code in the same format (fast path)
@@ -142,6 +156,9 @@ struct P {
     uint32_t decoded_mask = 0;
     Canon *canon = nullptr;
     Cabac *cb = nullptr;                 // non-null: entropy_coding_mode_flag = 1
+    // a field picture (PAFF): every macroblock is a field macroblock -- field scans (8.5.6, 8.5.7) and the field contexts of significant_coeff_flag /
+    // last_significant_coeff_flag (Table 9-34: 277.. / 338.. instead of 105.. / 166..)
+    const uint8_t *zz4 = kZigzag4, *zz8 = kZigzag8; int fld_ctx = 0;
     bool last_dqp = false;               // mb_qp_delta of the previous macroblock in decoding order != 0
     uint8_t *mvd = nullptr;              // |mvd| per 4x4 and component of the current macroblock (CABAC ctxIdxInc)
     const char *err = nullptr;
@@ -577,7 +594,7 @@ struct P {
             if (i16) {                                        // Intra16x16 DC levels: always 16 slots in the stream
                 int16_t *d = alloc_coef(16); if (!d) return false;
                 const int tk = token_fast(br, w[8] + w[1]);
-                if (tk < 0 || (tk && levels_of(br, tk >> 2, tk & 3, 16, 0, d, kZigzag4) < 0)) { err = "entropy error (Intra16x16 DC)"; return false; }
+                if (tk < 0 || (tk && levels_of(br, tk >> 2, tk & 3, 16, 0, d, zz4) < 0)) { err = "entropy error (Intra16x16 DC)"; return false; }
             }
             const int max_num = i16 ? 15 : 16, first = i16 ? 1 : 0;
             for (int b8 = 0; b8 < 4; b8++) {
@@ -589,7 +606,7 @@ struct P {
                     if (!tk) continue;
                     const int total = tk >> 2;
                     int16_t *d = out.coef + out.coef_count;
-                    if (total > max_num || levels_of(br, total, tk & 3, max_num, first, d, kZigzag4) < 0) { err = "entropy error (luma block)"; return false; }
+                    if (total > max_num || levels_of(br, total, tk & 3, max_num, first, d, zz4) < 0) { err = "entropy error (luma block)"; return false; }
                     w[wi] = (uint8_t)total; tc[kRas[blk]] = (uint8_t)total; bits |= 1u << blk; out.coef_count += 16;
                 }
             }
@@ -619,7 +636,7 @@ struct P {
                     c[ci] = (uint8_t)(tk >> 2);
                     if (!tk) continue;
                     int16_t *d = out.coef + out.coef_count;
-                    if (levels_of(br, tk >> 2, tk & 3, 15, 1, d, kZigzag4) < 0) { err = "entropy error (chroma AC)"; return false; }
+                    if (levels_of(br, tk >> 2, tk & 3, 15, 1, d, zz4) < 0) { err = "entropy error (chroma AC)"; return false; }
                     tc[o + k] = (uint8_t)(tk >> 2); cbm |= 1u << (4 * pl + k); out.coef_count += 16;
                 }
             }
@@ -825,7 +842,8 @@ struct P {
             if (!r.decision(85 + cbf_off[cat] + fa + 2 * fb)) { r.commit(); return 0; }
             cx.cbf[addr] |= 1u << bit;
         }
-        const int sig_base = cat == 5 ? 402 : 105 + sig_off[cat], last_base = cat == 5 ? 417 : 166 + sig_off[cat];
+        if (cat == 5 && fld_ctx) { err = "CABAC residual of a field-coded 8x8 block is not supported"; r.commit(); return -1; }
+        const int sig_base = cat == 5 ? 402 : 105 + fld_ctx + sig_off[cat], last_base = cat == 5 ? 417 : 166 + fld_ctx + sig_off[cat];
         const int abs_base = cat == 5 ? 426 : 227 + abs_off[cat];
         uint8_t pos[64]; int n = 0, i;
         if (cat == 5) {
@@ -874,8 +892,8 @@ struct P {
             int16_t *d = alloc_coef(16); if (!d) return false;
             int n;
             if (cb) n = residual_block_ae(0, 16, nA >= 0 ? (int)((cx.cbf[nA] >> 16) & 1) : -1, nB >= 0 ? (int)((cx.cbf[nB] >> 16) & 1) : -1, 16, 0, d,
-                kZigzag4, intra);
-            else n = residual_block(nc_luma(0, 0), 16, 0, d, kZigzag4);
+                zz4, intra);
+            else n = residual_block(nc_luma(0, 0), 16, 0, d, zz4);
             if (n < 0) { if (!err) err = "entropy error (Intra16x16 DC)"; return false; }
             if (canon) memcpy(canon->i16dc, d, 32);
         }
@@ -888,7 +906,7 @@ struct P {
                 memset(d, 0, 128);
                 int ox = (b8 & 1) * 2, oy = (b8 >> 1) * 2, total = 0;
                 if (cb) {
-                    total = residual_block_ae(5, -1, 0, 0, 64, 0, d, kZigzag8, intra);
+                    total = residual_block_ae(5, -1, 0, 0, 64, 0, d, zz8, intra);
                     if (total < 0) return false;
                     // 7.4.5.3.3: coded_block_flag of an 8x8 luma block is inferred to be 1 (4:2:0)
                     for (int k = 0; k < 4; k++) cx.cbf[addr] |= 1u << ((oy + (k >> 1)) * 4 + ox + (k & 1));
@@ -899,7 +917,7 @@ struct P {
                         int n = residual_block(nc_luma(bx, by), 16, 0, tmp, ident);
                         if (n < 0) { err = "CAVLC error (luma 8x8 block)"; return false; }
                         tc[by * 4 + bx] = (uint8_t)n; total += n;
-                        for (int i = 0; i < 16; i++) if (tmp[i]) d[kZigzag8[4 * i + k]] = tmp[i];
+                        for (int i = 0; i < 16; i++) if (tmp[i]) d[zz8[4 * i + k]] = tmp[i];
                     }
                 }
                 if (total) { bits |= 15u << (4 * b8); out.coef_count += 64; if (canon) memcpy(&canon->luma[0][0] + 64 * b8, d, 128); }
@@ -914,8 +932,8 @@ struct P {
                 int n;
                 if (cb) memset(d, 0, 32);
                 if (cb) n = residual_block_ae(i16 ? 1 : 2, by * 4 + bx, cbf_luma_nb(bx, by, true), cbf_luma_nb(bx, by, false), i16 ? 15 : 16, i16 ? 1 : 0, d,
-                    kZigzag4, intra);
-                else n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, kZigzag4) : residual_block(nc_luma(bx, by), 16, 0, d, kZigzag4);
+                    zz4, intra);
+                else n = i16 ? residual_block(nc_luma(bx, by), 15, 1, d, zz4) : residual_block(nc_luma(bx, by), 16, 0, d, zz4);
                 if (n < 0) { if (!err) err = "entropy error (luma block)"; return false; }
                 tc[by * 4 + bx] = (uint8_t)n;
                 if (n) { bits |= 1u << blk; out.coef_count += 16; if (canon) memcpy(canon->luma[by * 4 + bx], d, 32); }
@@ -946,8 +964,8 @@ struct P {
                     int bx = k & 1, by = k >> 1, b0 = 19 + pl * 4, fa, fb;
                     if (bx) fa = (int)((cx.cbf[addr] >> (b0 + by * 2)) & 1); else fa = nA >= 0 ? (int)((cx.cbf[nA] >> (b0 + by * 2 + 1)) & 1) : -1;
                     if (by) fb = (int)((cx.cbf[addr] >> (b0 + bx)) & 1); else fb = nB >= 0 ? (int)((cx.cbf[nB] >> (b0 + 2 + bx)) & 1) : -1;
-                    n = residual_block_ae(4, b0 + k, fa, fb, 15, 1, d, kZigzag4, intra);
-                } else n = residual_block(nc_chroma(pl, k & 1, k >> 1), 15, 1, d, kZigzag4);
+                    n = residual_block_ae(4, b0 + k, fa, fb, 15, 1, d, zz4, intra);
+                } else n = residual_block(nc_chroma(pl, k & 1, k >> 1), 15, 1, d, zz4);
                 if (n < 0) { if (!err) err = "entropy error (chroma AC)"; return false; }
                 tc[16 + 4 * pl + k] = (uint8_t)n;
                 if (n) { cbm |= 1u << (4 * pl + k); out.coef_count += 16; if (canon) memcpy(canon->cac[pl][k], d, 32); }
@@ -1176,6 +1194,7 @@ SliceParseResult parse_slice_data(const SeqParams &sps, const PicParamSet &pps, 
     P p{sps, pps, sh, br, cx, out, digest, slice_num, refs, sps.mb_w};
     p.qp = sh.qp;
     p.canon = digest ? &canon : nullptr;
+    if (sh.field_pic) { p.zz4 = kFieldScan.s4; p.zz8 = kFieldScan.s8; p.fld_ctx = 277 - 105; allow_fast = false; }
     int n_mbs = sps.mb_w * sps.mb_h, addr = sh.first_mb;
     if (pps.cabac) {
         static thread_local Cabac cabac;

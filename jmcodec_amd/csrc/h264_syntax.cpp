@@ -103,7 +103,7 @@ std::string ParamSets::parse_sps(BitReader &br) {
     s.frame_mbs_only = br.u1();
     // frame_mbs_only_flag = 0: the stream MAY hold field pictures (PAFF) or, with mb_adaptive_frame_field_flag, field macroblock pairs (MBAFF).
     // pic_height_in_map_units then counts field macroblock rows: FrameHeightInMbs is twice that (7.4.2.1.1).  Frame pictures of such a stream without
-    // MBAFF are coded exactly like progressive ones and decode here; field pictures are refused where they occur (slice header), MBAFF streams here.
+    // MBAFF are coded exactly like progressive ones; field pictures decode as pictures of half the height (decoder.cpp); MBAFF streams are refused here.
     if (!s.frame_mbs_only) { s.mbaff = br.u1(); s.mb_h *= 2; }
     if ((long long)s.mb_w * s.mb_h > 139264) return "picture too large";       // MaxFS of level 6.2 (Table A-1)
     s.direct_8x8_inference = br.u1();
@@ -190,16 +190,19 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if (!sps[p.sps_id].valid) return "slice refers to a missing SPS";
     const SeqParams &s = sps[p.sps_id];
     sh.frame_num = br.u(s.log2_max_frame_num);
-    if (!s.frame_mbs_only && br.u1()) return "field pictures (PAFF) are not supported";      // field_pic_flag
+    if (!s.frame_mbs_only) { sh.field_pic = br.u1(); if (sh.field_pic) sh.bottom_field = br.u1(); }      // field_pic_flag, bottom_field_flag
+    if (sh.field_pic && sh.type == SL_B) return "B field pictures are not supported";
     if (sh.idr) sh.idr_pic_id = br.ue();
-    if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present) sh.delta_poc_bottom = br.se(); }
-    else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se(); if (p.bottom_field_poc_present) sh.delta_poc[1] = br.se(); }
+    // the order count of the OTHER field (delta_pic_order_cnt_bottom, delta_pic_order_cnt[1]) is only sent with frames (7.3.3)
+    if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present && !sh.field_pic) sh.delta_poc_bottom = br.se(); }
+    else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se();
+        if (p.bottom_field_poc_present && !sh.field_pic) sh.delta_poc[1] = br.se(); }
     if (p.redundant_pic_cnt_present) br.ue();
     if (sh.type == SL_B) sh.direct_spatial_mv_pred = br.u1();
     sh.num_ref_idx[0] = p.num_ref_idx_default[0]; sh.num_ref_idx[1] = p.num_ref_idx_default[1];
     if (sh.type != SL_I && br.u1()) {
         uint32_t a = br.ue(), b = sh.type == SL_B ? br.ue() : 0;
-        if (a > 31 || b > 31) return "num_ref_idx_active out of range";
+        if (a > (sh.field_pic ? 31u : 15u) || b > (sh.field_pic ? 31u : 15u)) return "num_ref_idx_active out of range";      // 7.4.3
         sh.num_ref_idx[0] = (int)a + 1; if (sh.type == SL_B) sh.num_ref_idx[1] = (int)b + 1;
     }
     if (sh.type != SL_B) sh.num_ref_idx[1] = 0;

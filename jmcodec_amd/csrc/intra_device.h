@@ -424,7 +424,7 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     const int row = row0 + (active ? g : 0), lrow = g + 1;
     if (threadIdx.x < 144) lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
     for (int i = threadIdx.x; i < 576; i += kIBandRows * 16) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
-    gbyte *plane = (gbyte *)(pp.surf[pp.cur] + (is_chroma ? pp.chroma_offset : 0));
+    gbyte *plane = (gbyte *)(cur_plane(pp) + (is_chroma ? pp.chroma_offset : 0));
     const ICtx cx{plane, pitch};
     const int rows_per_mb = is_chroma ? 8 : 16, my_row = is_chroma ? (l & 7) : l;
     const bool takes_ring = band > 0 && g == 0;                             // first row of a lower band

@@ -49,7 +49,7 @@ struct MbRec {            // 32 bytes
     uint8_t  cbp_cac;     // bits 0-3 Cb AC blocks, 4-7 Cr AC blocks
     uint8_t  slice;       // index into SliceRec[]
     uint32_t coef_off;    // first int16 of this macroblock in coef[]
-    int8_t   ref[4];      // DPB surface slot per 8x8 (inter), -1 otherwise
+    int8_t   ref[4];      // DPB surface slot per 8x8 (inter), -1 otherwise; in a field picture bit 5 = parity of the reference FIELD (bits 0-4 the slot)
     union {
         int16_t  mv[4][2];    // one MV per 8x8 (quarter-sample units)
         uint8_t  i4[8];       // Intra4x4PredMode, two per byte (low nibble = even raster index);
@@ -87,7 +87,8 @@ static_assert(sizeof(SliceWp) == 4 + 96 + 96 + 256, "SliceWp layout");
 constexpr int kMaxSurfaces = 20;
 
 struct PicParams {
-    int mb_w, mb_h;
+    int mb_w, mb_h;               // of the picture: a field picture has half the frame's rows
+    int field;                    // 0 frame picture; 1 / 2: top / bottom field picture -- the lines of that parity of surf[cur], pitch = 2 x the surface's
     int pitch;                    // bytes per luma row == bytes per interleaved chroma row
     int chroma_offset;            // byte offset of the UV plane inside a surface = pitch * coded_h
     int cb_qp_off, cr_qp_off;     // chroma_qp_index_offset, second_chroma_qp_index_offset
@@ -122,7 +123,8 @@ enum : int { PS_RECON = 1, PS_INTRA_LDS = 2, PS_INTRA_V1 = 4, PS_DEBLOCK_LDS = 8
 
 struct PackJob {                  // one display frame to pack out (k_packout, blockIdx.y = job)
     const uint8_t *src; uint8_t *dst;
-    int pitch, chroma_offset, width, height, out_fmt, pad;
+    int pitch, chroma_offset, width, height, out_fmt;
+    int lone_field;               // 0; 1 / 2: only the top / bottom field of the frame was decoded -- its lines are shown twice
 };
 
 }  // namespace jmamd

@@ -5,6 +5,15 @@
 
 namespace jmamd {
 
+// Field pictures (PicParams.field != 0): the picture is the lines of one parity of its surface -- pitch is twice the surface's, and a reference entry
+// (MbRec.ref, the slot1 bytes of a motion record) carries the parity of the reference FIELD in bit 5.  In a frame picture both reduce to surf[slot].
+__device__ __forceinline__ const uint8_t *ref_plane(const PicParams &pp, int slot) { return pp.surf[slot & 31] + ((slot & 32) ? (pp.pitch >> 1) : 0); }
+__device__ __forceinline__ uint8_t *cur_plane(const PicParams &pp) { return pp.surf[pp.cur] + (pp.field == 2 ? (pp.pitch >> 1) : 0); }
+// 8.4.1.4, Table 8-9: the vertical chroma vector of a field that predicts from a field of the other parity: -2 (top from bottom) / +2 (bottom from top)
+__device__ __forceinline__ int chroma_mvy_offset(const PicParams &pp, int slot) {
+    return pp.field == 0 || ((slot >> 5) & 1) == pp.field - 1 ? 0 : (pp.field == 2 ? 2 : -2);
+}
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
@@ -120,20 +129,23 @@ __device__ __forceinline__ void mbw_motion(const PicParams &pp, const MbW &m, in
     } else mbw_mv(pp, m, rpos, x0, y0);
 }
 // 8.7.2.1 boundary strength between 4x4 luma blocks rp (in macroblock p) and rq (in macroblock q), raster indices
-__device__ __forceinline__ int boundary_strength(const PicParams &pp, const MbW &p, int rp, const MbW &q, int rq, bool mb_edge) {
-    if (mbw_kind(p) != MB_INTER || mbw_kind(q) != MB_INTER) return mb_edge ? 4 : 3;
+// horizontal: the edge runs horizontally.  In a field picture (8.7.2.1) an intra macroblock edge gets 4 only when it is vertical, and the vertical vector
+// difference that counts as one FRAME sample is 2 quarter field samples.
+__device__ __forceinline__ int boundary_strength(const PicParams &pp, const MbW &p, int rp, const MbW &q, int rq, bool mb_edge, bool horizontal) {
+    if (mbw_kind(p) != MB_INTER || mbw_kind(q) != MB_INTER) return mb_edge && !(pp.field && horizontal) ? 4 : 3;
+    const int vlim = pp.field ? 2 : 4;
     if (((mbw_cbp_blk(p) >> raster_to_blk(rp)) & 1) || ((mbw_cbp_blk(q) >> raster_to_blk(rq)) & 1)) return 2;
     if (!((mbw_modes(p) | mbw_modes(q)) & MBM_BIPRED)) {       // one list on both sides (P slices)
         if (mbw_ref(p, (rp >> 3) * 2 + ((rp & 3) >> 1)) != mbw_ref(q, (rq >> 3) * 2 + ((rq & 3) >> 1))) return 1;
         int px, py, qx, qy; mbw_mv(pp, p, rp, px, py); mbw_mv(pp, q, rq, qx, qy);
-        return (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) ? 1 : 0;
+        return (iabs(px - qx) >= 4 || iabs(py - qy) >= vlim) ? 1 : 0;
     }
     // B slices: compare the SETS of reference pictures and the vectors that go with them
     int p0, p1, q0, q1, px0, py0, px1, py1, qx0, qy0, qx1, qy1;
     mbw_motion(pp, p, rp, p0, p1, px0, py0, px1, py1); mbw_motion(pp, q, rq, q0, q1, qx0, qy0, qx1, qy1);
     int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
     if (np != nq) return 1;
-    auto far = [](int ax, int ay, int bx, int by) { return iabs(ax - bx) >= 4 || iabs(ay - by) >= 4; };
+    auto far = [vlim](int ax, int ay, int bx, int by) { return iabs(ax - bx) >= 4 || iabs(ay - by) >= vlim; };
     if (np == 1) {
         bool pl1 = p0 < 0, ql1 = q0 < 0;
         if ((pl1 ? p1 : p0) != (ql1 ? q1 : q0)) return 1;

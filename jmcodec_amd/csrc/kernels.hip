@@ -193,7 +193,7 @@ __device__ __forceinline__ int plane_pred(const uint8_t *tile, int stride, int n
 
 __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, IntraTile &t, ResTile &rt, int lane) {
     int pitch = pp.pitch, W = pp.mb_w * 16, H = pp.mb_h * 16;
-    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst = cur_plane(pp);
     uint8_t *dst_c = dst + pp.chroma_offset;
     bool availA = r.flags & MBF_AVAIL_A, availB = r.flags & MBF_AVAIL_B, availC = r.flags & MBF_AVAIL_C, availD = r.flags & MBF_AVAIL_D;
     // ---- residual (zeros when absent) ----
@@ -355,7 +355,7 @@ struct DbTile {
 
 __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, const DbTables &tb, int lane) {
     int pitch = pp.pitch, mbw = pp.mb_w;
-    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst = cur_plane(pp);
     uint8_t *dst_c = dst + pp.chroma_offset;
     const MbW q = load_mbw(&pp.mbs[mby * mbw + mbx]);
     const SliceRec sl = pp.slices[mbw_slice(q)];
@@ -372,8 +372,8 @@ __device__ void deblock_mb(const PicParams &pp, int mbx, int mby, DbTile &t, con
         if (e == 0) {
             bool have = dir == 0 ? has_left : has_top;
             if (!have) bs = 0;
-            else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, select_mbw(dir == 0, pl_, pt_), rp, q, rq, true); }
-        } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false);
+            else { int rp = dir == 0 ? k * 4 + 3 : 12 + k; bs = boundary_strength(pp, select_mbw(dir == 0, pl_, pt_), rp, q, rq, true, dir == 1); }
+        } else bs = boundary_strength(pp, q, dir == 0 ? rq - 1 : rq - 4, q, rq, false, dir == 1);
         if ((e & 1) && (mbw_modes(q) & MBM_T8X8)) bs = 0;    // 8x8 transform: inner 4x4 edges are not filtered
         t.bs[dir][e][k] = (uint8_t)bs;
     }
@@ -515,7 +515,9 @@ __global__ __launch_bounds__(256) void k_packout(const PackJob *jobs) {
         bool chroma = i >= luma_chunks;
         int j = chroma ? i - luma_chunks : i;
         int row = j / chunks_per_row, x = (j % chunks_per_row) * 16;
-        const uint8_t *s = src + (chroma ? chroma_offset : 0) + (size_t)row * pitch + x;
+        // (a frame of which only one field was decoded: every row shows the line of that parity of its line pair)
+        const int srow = jb.lone_field ? ((row & ~1) | (jb.lone_field - 1)) : row;
+        const uint8_t *s = src + (chroma ? chroma_offset : 0) + (size_t)srow * pitch + x;
         int n = width - x < 16 ? width - x : 16;
         if (!chroma || out_fmt == 0) {
             uint8_t *d = dst + (chroma ? (size_t)width * height : 0) + (size_t)row * width + x;

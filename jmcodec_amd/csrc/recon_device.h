@@ -233,7 +233,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 slot = rec_ref(r, b8);
             }
         }
-        const int dep = slot >= 0 ? (int)pp.dep_pic[slot] : -1;
+        const int dep = slot >= 0 ? (int)pp.dep_pic[slot & 31] : -1;
         const int x0 = mbx * 16 + bx * 4 + (mvx >> 2), y0 = mby * 16 + by * 4 + (mvy >> 2);
         const bool ok = cv.wait_final(dep, clip3(0, W - 1, x0 + 6), clip3(0, H - 1, y0 - 2), clip3(0, H - 1, y0 + 6), pp.mb_w, pp.mb_h);
         if (!ok && lane == 0) report_wait_timeout(cv.err + pp.chain_idx, CHAIN_ERR_FIN_TIMEOUT);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             bool ok = !(r.flags & MBF_MV_EXT) && rec_ref(r, g) >= 0 && xi >= 0 && yi >= 0 && xi + 13 <= W && yi + 13 <= H;
             fast = __all(ok);                               // wave-uniform: the whole macroblock takes one path
             if (fast) {
-                const uint8_t *ref = pp.surf[rec_ref(r, g)];
+                const uint8_t *ref = ref_plane(pp, rec_ref(r, g));
                 int l = lane & 15, xa = xi & ~3;
 #pragma unroll
                 for (int t = 0; t < 5; t++) {
@@ -261,9 +261,11 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             int mvx, mvy;
             if (r.flags & MBF_MV_EXT) { const short *m = pp.mv_ext + ((size_t)r.u.mv_ext + rb) * 2; mvx = m[0]; mvy = m[1]; }
             else rec_mv8(r, b8, mvx, mvy);
-            c_slot = rec_ref(r, b8); c_fx = mvx & 7; c_fy = mvy & 7;
+            c_slot = rec_ref(r, b8);
+            if (c_slot >= 0) mvy += chroma_mvy_offset(pp, c_slot);
+            c_fx = mvx & 7; c_fy = mvy & 7;
             if (c_slot >= 0) {
-                const uint8_t *rc = pp.surf[c_slot] + pp.chroma_offset;
+                const uint8_t *rc = ref_plane(pp, c_slot) + pp.chroma_offset;
                 int CW = W >> 1, CHh = H >> 1;
                 int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3);
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
@@ -307,7 +309,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         publish();
         return;
     }
-    uint8_t *dst = pp.surf[pp.cur];
+    uint8_t *dst = cur_plane(pp);
     uint8_t *dst_c = dst + pp.chroma_offset;
     uint32_t *ot = outt[wave];
     if (r.kind == MB_PCM) {
@@ -419,7 +421,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             auto predict = [&](int slot, const short *m) -> uint32_t {
                 const int mvx = m[0], mvy = m[1];
                 const int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2, xa = xi & ~3;
-                const uint8_t *ref = pp.surf[slot];
+                const uint8_t *ref = ref_plane(pp, slot);
                 uint32_t w5[5];
 #pragma unroll
                 for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5;
@@ -450,8 +452,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int a = 0, b = 0;
-                if (s0 >= 0) a = luma_sample<COH>(pp.surf[s0], pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
-                if (s1 >= 0) b = luma_sample<COH>(pp.surf[s1], pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
+                if (s0 >= 0) a = luma_sample<COH>(ref_plane(pp, s0), pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
+                if (s1 >= 0) b = luma_sample<COH>(ref_plane(pp, s1), pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
                 v[k] = combine(a, b, s0 >= 0, s1 >= 0, i0, i1, 0);
             }
             if (has_res) { const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
@@ -466,8 +468,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
 #pragma unroll
             for (int l = 0; l < 2; l++) {
                 if (s[l] < 0) continue;
-                int mvx = rec[l * 32 + rb * 2], mvy = rec[l * 32 + rb * 2 + 1];
-                const uint8_t *rc = pp.surf[s[l]] + pp.chroma_offset;
+                int mvx = rec[l * 32 + rb * 2], mvy = rec[l * 32 + rb * 2 + 1] + chroma_mvy_offset(pp, s[l]);
+                const uint8_t *rc = ref_plane(pp, s[l]) + pp.chroma_offset;
                 int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
                 const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
@@ -515,7 +517,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         int v[4];
         if (slot < 0) { v[0] = v[1] = v[2] = v[3] = 128; }
         else {
-            const uint8_t *ref = pp.surf[slot];
+            const uint8_t *ref = ref_plane(pp, slot);
             int xi = x0 + (mvx >> 2), yi = y + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = luma_sample<COH>(ref, pitch, W, H, xi + k, yi, fx, fy);

@@ -152,3 +152,4 @@ PAFF_CASES = {
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)
+ALL_CASES.update(PAFF_CASES)
