@@ -69,6 +69,55 @@ def test_full_size_1080p_baseline(oracle):
         assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
 
 
+def test_full_size_1080i_field_pictures(oracle):
+    """Interlace at full size: 1920x1080 in a 1920x1088 surface (34 macroblock rows per field), Main profile CABAC, every picture a frame or two field
+    pictures; three deblocking bands per field."""
+    data = streams.generate(width=1920, height=1080, frames=8, gop=8, seed=301, paff=1, num_ref=2, cabac=1, qp=30, search=8)
+    want, n, w, h = oracle.decode(data, 1)
+    assert (w, h, n) == (1920, 1080, 8)
+    tools = oracle.tools(data)
+    assert tools.get("field-pictures", 0) >= 4 and tools.get("cross-parity-blocks", 0) > 0
+    frames = gpu_decode(data)
+    fs = w * h * 3 // 2
+    assert len(frames) == n
+    for i, f in enumerate(frames):
+        assert f == want[i * fs:(i + 1) * fs], f"frame {i}: " + first_diff(f, want[i * fs:(i + 1) * fs], w, h)
+
+
+def test_a_field_without_partner_on_device(oracle):
+    """The second field of the last frame never arrives: the frame is shown with the lines of the decoded field repeated (k_packout lone_field), as the
+    oracle shows it; and a stream that goes on with a FRAME after a lone field keeps decoding."""
+    kw = dict(width=96, height=64, frames=4, gop=4, seed=302, paff=2, num_ref=2)
+    data = streams.generate(**kw)
+    starts = [i for i in range(len(data) - 4) if data[i:i + 4] == b"\0\0\0\1" or (data[i:i + 3] == b"\0\0\1" and data[i - 1:i] != b"\0")]
+    cut = data[:starts[-1]]
+    want, n, w, h = oracle.decode(cut, 1)
+    assert n == 4 and oracle.tools(cut).get("lone-fields", 0) == 0          # (the oracle counts a lone field when the NEXT picture starts; here the stream ends)
+    assert b"".join(gpu_decode(cut)) == want
+    # the same, followed by another coded video sequence: the lone field is completed when the IDR picture starts
+    both = cut + streams.generate(**dict(kw, seed=303, paff=1))
+    want2, n2, _, _ = oracle.decode(both, 1)
+    assert n2 == 8 and oracle.tools(both).get("lone-fields", 0) == 1
+    assert b"".join(gpu_decode(both)) == want2
+
+
+def test_field_picture_streams_beside_progressive_ones(oracle):
+    """Field pictures, frame pictures of interlace-capable streams and progressive streams in the same batches."""
+    cases = ["paff_adaptive_fuzz", "real_qvga", "paff_fields_cabac", "fuzz_multiref_slices", "paff_poc1_t8x8_scaling", "paff_real_qvga"]
+    datas = [streams.generate(**PARITY_CASES[c]) for c in cases]
+    wants = [oracle.decode(d, 1)[0] for d in datas]
+    got = [None] * len(cases)
+
+    def run(i):
+        got[i] = b"".join(gpu_decode(datas[i]))
+    for _ in range(3):
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for i in range(len(cases)):
+            assert got[i] == wants[i], cases[i]
+
+
 def test_full_size_1080p_high_cabac(oracle):
     """1920x1080 High profile: CABAC, 8x8 transform, Intra8x8 (the tools of BASELINE config 2 that I/P streams use)."""
     kw = streams.config_c1(frames=5)
