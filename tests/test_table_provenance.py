@@ -14,6 +14,7 @@ Two independent checks live here:
 import hashlib
 import json
 import os
+import re
 
 from util import ROOT, GOLDEN, c_array, c_rows
 
@@ -218,6 +219,32 @@ def test_h264_cavlc_code_tables_against_the_bit_strings_of_the_standard():
     for r in range(15):
         ln, v = rb[(r,)][6]
         assert (ln, v) == ((3, 7 - r) if r < 7 else (r - 3, 1))
+
+
+def test_field_scans_in_four_notations():
+    """Generator: raster indices; oracle: F4(x, y) / F8(x, y) macros; product: digit pairs "xy"; here: the columns of the figures.  All four must describe
+    the same permutation."""
+    def from_columns(cols):
+        n = len(cols)
+        out = [None] * (n * n)
+        for x, col in enumerate(cols):
+            for y, idx in enumerate(col):
+                out[idx] = y * n + x
+        assert sorted(out) == list(range(n * n))
+        return out
+    want4, want8 = from_columns(spec.FIELD_SCAN_4x4_COLUMNS), from_columns(spec.FIELD_SCAN_8x8_COLUMNS)
+    assert c_array(GEN_H264, "fs4") == want4 and c_array(GEN_H264, "fs8") == want8
+    src = open(ORC_TABLES).read()
+    for name, n, want in (("orc_fieldscan4", 4, want4), ("orc_fieldscan8", 8, want8)):
+        body = src[src.index(name):]
+        body = body[:body.index("};")]
+        got = [int(y) * n + int(x) for x, y in re.findall(r"F%d\((\d),\s*(\d)\)" % n, body)]
+        assert got == want, name
+    src = open(PROD_CAVLC).read()
+    for name, n, want in (("xy4", 4, want4), ("xy8", 8, want8)):
+        m = re.search(r"\*%s = ((?:\s*\"[0-9 ]+\")+);" % name, src)
+        pairs = "".join(re.findall(r'"([0-9 ]+)"', m.group(1))).split()
+        assert [int(p[1]) * n + int(p[0]) for p in pairs] == want, name
 
 
 def test_h264_mapping_scan_and_filter_tables_against_a_separately_typed_copy():
