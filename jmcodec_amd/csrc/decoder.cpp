@@ -692,7 +692,8 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
     if (!second) c.poc = poc;
     cur_field_ = sh.field_pic ? 1 + (int)sh.bottom_field : 0; cur_second_ = second;
     pending_ = std::make_unique<PicTask>();
-    pending_->mf = sh.field_pic ? nullptr : c.mf;
+    if (sh.field_pic && seq_.profile_idc != 66 && sh.nal_ref_idc) c.mf_fld[sh.bottom_field] = std::make_shared<MotionField>();
+    pending_->mf = sh.field_pic ? c.mf_fld[sh.bottom_field] : c.mf;
     pending_->has_picture = true; pending_->cur_slot = slot; pending_->wait_prev_pack = wait_pack; pending_->sps = sps; pending_->pps = pps;
     pending_->field = cur_field_;
     if (sh.field_pic) { pending_->sps.mb_h = sps.mb_h / 2; stat_field_pics_++; }      // from here on the picture is one of half the height
@@ -734,40 +735,62 @@ void Decoder::build_field_ref_lists(const SliceHeader &sh, SliceTask &task) {
     }
     std::sort(st, st + nst, [&](int a, int b) { return dpb_[a].frame_num_wrap > dpb_[b].frame_num_wrap; });
     std::sort(lt, lt + nlt, [&](int a, int b) { return dpb_[a].lt_idx < dpb_[b].lt_idx; });
-    int list[35];
-    for (int &v : list) v = -1;
-    int n = alternate_fields(dpb_, st, nst, 1, par, cur_, list, 0, 33);
-    n = alternate_fields(dpb_, lt, nlt, 2, par, cur_, list, n, 33);
-    const int nact = sh.num_ref_idx[0];
-    for (int i = nact; i < 35; i++) list[i] = -1;
+    const int nlists = sh.type == SL_B ? 2 : 1;
+    int lists[2][35], ninit[2] = {0, 0};
+    for (auto &row : lists) for (int &v : row) v = -1;
+    if (nlists == 1) ninit[0] = alternate_fields(dpb_, st, nst, 1, par, cur_, lists[0], 0, 33);
+    else {
+        // 8.2.4.2.4: short-term stores by PicOrderCnt around the count of the current FIELD -- list 0: those not above it, descending, then the others
+        // ascending; list 1 the other way round.  PicOrderCnt of a store: of the frame / field pair (Min of its fields) or of its only field (DpbPic.poc)
+        int ord[2][kMaxSurfaces], nb = 0, na = 0, before[kMaxSurfaces], after[kMaxSurfaces];
+        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].poc <= rf.cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        std::sort(before, before + nb, [&](int a, int b) { return dpb_[a].poc > dpb_[b].poc; });
+        std::sort(after, after + na, [&](int a, int b) { return dpb_[a].poc < dpb_[b].poc; });
+        for (int i = 0; i < nb; i++) { ord[0][i] = before[i]; ord[1][na + i] = before[i]; }
+        for (int i = 0; i < na; i++) { ord[0][nb + i] = after[i]; ord[1][i] = after[i]; }
+        for (int l = 0; l < 2; l++) ninit[l] = alternate_fields(dpb_, ord[l], nst, 1, par, cur_, lists[l], 0, 33);
+    }
+    for (int l = 0; l < nlists; l++) ninit[l] = alternate_fields(dpb_, lt, nlt, 2, par, cur_, lists[l], ninit[l], 33);
+    if (nlists == 2 && ninit[1] > 1 && ninit[0] == ninit[1] && std::equal(lists[0], lists[0] + ninit[0], lists[1])) std::swap(lists[1][0], lists[1][1]);
     // PicNum = 2 * FrameNumWrap + 1 for a field of the current parity, 2 * FrameNumWrap for the other; LongTermPicNum the same from LongTermFrameIdx
     auto pic_num = [&](int e) { return 2 * dpb_[e & 31].frame_num_wrap + (((e >> 5) & 1) == par); };
     auto lt_pic_num = [&](int e) { return 2 * dpb_[e & 31].lt_idx + (((e >> 5) & 1) == par); };
     const int cur_pic_num = 2 * sh.frame_num + 1, max_pic_num = 2 * max_fn;
-    int pred = cur_pic_num, idx = 0;
-    for (int k = 0; k < sh.n_mod[0]; k++) {
-        const RefMod &m = sh.mod[0][k];
-        int target = -1;
-        if (m.idc < 2) {
-            int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
-            if (nowrap < 0) nowrap += max_pic_num;
-            if (nowrap >= max_pic_num) nowrap -= max_pic_num;
-            pred = nowrap;
-            const int want = nowrap > cur_pic_num ? nowrap - max_pic_num : nowrap;
-            for (int i = 0; i < nst; i++) for (int q = 0; q < 2; q++) { const int e = st[i] | q << 5;
-                if (!(st[i] == cur_ && q == par) && dpb_[st[i]].fmark[q] == 1 && pic_num(e) == want) target = e; }
-        } else for (int i = 0; i < nlt; i++) for (int q = 0; q < 2; q++) { const int e = lt[i] | q << 5;
-            if (!(lt[i] == cur_ && q == par) && dpb_[lt[i]].fmark[q] == 2 && lt_pic_num(e) == (int)m.val) target = e; }
-        if (target < 0 || idx >= nact) { stat_errors_++; break; }
-        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
-        list[idx++] = target;
-        int nidx = idx;
-        for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+    for (int l = 0; l < nlists; l++) {
+        int *list = lists[l];
+        const int nact = sh.num_ref_idx[l];
+        for (int i = nact; i < 35; i++) list[i] = -1;
+        int pred = cur_pic_num, idx = 0;
+        for (int k = 0; k < sh.n_mod[l]; k++) {
+            const RefMod &m = sh.mod[l][k];
+            int target = -1;
+            if (m.idc < 2) {
+                int nowrap = m.idc == 0 ? pred - (int)(m.val + 1) : pred + (int)(m.val + 1);
+                if (nowrap < 0) nowrap += max_pic_num;
+                if (nowrap >= max_pic_num) nowrap -= max_pic_num;
+                pred = nowrap;
+                const int want = nowrap > cur_pic_num ? nowrap - max_pic_num : nowrap;
+                for (int i = 0; i < nst; i++) for (int q = 0; q < 2; q++) { const int e = st[i] | q << 5;
+                    if (!(st[i] == cur_ && q == par) && dpb_[st[i]].fmark[q] == 1 && pic_num(e) == want) target = e; }
+            } else for (int i = 0; i < nlt; i++) for (int q = 0; q < 2; q++) { const int e = lt[i] | q << 5;
+                if (!(lt[i] == cur_ && q == par) && dpb_[lt[i]].fmark[q] == 2 && lt_pic_num(e) == (int)m.val) target = e; }
+            if (target < 0 || idx >= nact) { stat_errors_++; break; }
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
+        }
+        for (int i = 0; i < nact && i < 32; i++) {
+            rf.slot[l][i] = (int8_t)list[i];
+            if (list[i] >= 0) { const DpbPic &p = dpb_[list[i] & 31]; const int q = (list[i] >> 5) & 1;
+                rf.uid[l][i] = 2 * p.decode_idx + q; rf.poc[l][i] = p.fpoc[q]; rf.is_long[l][i] = p.fmark[q] == 2; }
+        }
     }
-    for (int i = 0; i < nact && i < 32; i++) {
-        rf.slot[0][i] = (int8_t)list[i];
-        if (list[i] >= 0) { const DpbPic &p = dpb_[list[i] & 31]; const int q = (list[i] >> 5) & 1;
-            rf.uid[0][i] = 2 * p.decode_idx + q; rf.poc[0][i] = p.fpoc[q]; rf.is_long[0][i] = p.fmark[q] == 2; }
+    if (nlists == 2 && rf.slot[1][0] >= 0) {
+        // 8.4.1.2.1: the colocated field must come from a picture that was itself coded as a field (One_To_One); a field of a FRAME picture is not supported
+        const DpbPic &c = dpb_[rf.slot[1][0] & 31];
+        if (!c.coded_as_fields) { stat_errors_++; fail("direct prediction of a field from a frame picture is not supported"); return; }
+        task.col = c.mf_fld[(rf.slot[1][0] >> 5) & 1]; rf.col = task.col.get();
     }
 }
 

@@ -42,7 +42,8 @@ struct DpbPic {                                // one frame store (C.4.5): a fra
     bool wait_output = false;
     int poc = 0, frame_num = 0, frame_num_wrap = 0, pic_num = 0, lt_idx = -1;
     int decode_idx = 0; bool mmco5 = false;
-    std::shared_ptr<MotionField> mf;
+    std::shared_ptr<MotionField> mf;           // motion of the FRAME picture (colocated data of later B frames)
+    std::shared_ptr<MotionField> mf_fld[2];    // ... of the field pictures that filled the store (colocated data of later B fields)
     std::shared_ptr<HevcColMotion> hcol;       // HEVC: motion of this picture for temporal prediction
     int out_at = -100;                         // decode index of the picture after which this surface was displayed (cooling)
 };

@@ -191,7 +191,6 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     const SeqParams &s = sps[p.sps_id];
     sh.frame_num = br.u(s.log2_max_frame_num);
     if (!s.frame_mbs_only) { sh.field_pic = br.u1(); if (sh.field_pic) sh.bottom_field = br.u1(); }      // field_pic_flag, bottom_field_flag
-    if (sh.field_pic && sh.type == SL_B) return "B field pictures are not supported";
     if (sh.idr) sh.idr_pic_id = br.ue();
     // the order count of the OTHER field (delta_pic_order_cnt_bottom, delta_pic_order_cnt[1]) is only sent with frames (7.3.3)
     if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present && !sh.field_pic) sh.delta_poc_bottom = br.se(); }

@@ -183,7 +183,6 @@ int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
     int second = pend && sh->field_pic && !sh->idr && pend->waiting_second && pend->frame_num == sh->frame_num &&
                  pend->have == (sh->bottom_field ? 1 : 2) && pend->first_was_ref == (sh->nal_ref_idc != 0) && sps == d->asps;
     if (pend && !second) { pend->waiting_second = 0; d->pending = NULL; d->stats[ORC_ST_LONE_FIELD]++; store_done(d, pend); }   /* a field that stays alone */
-    if (sh->field_pic && sh->slice_type == SLICE_B) ORC_FAIL(d, "B field pictures unsupported");
     if (sh->idr || !d->asps) {
         /* new coded video sequence: output everything that is waiting (no_output_of_prior_pics
          * would discard instead; the reference's CUVID parser displays them, so do we) */
@@ -206,7 +205,7 @@ int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
         cur->id = d->next_pic_id++; cur->decode_index = d->decode_count++;
         cur->frame_num = sh->frame_num; cur->is_idr = sh->idr; cur->long_term_frame_idx = -1;
         cur->frame_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? 1 : 2);
-        cur->first_was_ref = sh->nal_ref_idc != 0;
+        cur->first_was_ref = sh->nal_ref_idc != 0; cur->coded_fields = sh->field_pic;
         cur->is_field = 0; cur->store = cur;
         int n = d->mb_w * d->mb_h;
         for (int i = 0; i < n; i++) cur->mbs[i].slice_num = -1;
@@ -242,9 +241,10 @@ static int alternate_fields(OrcDec *d, Picture **stores, int n, int mark, int pa
     return cnt;
 }
 
-/* 8.2.4.1 (field picture numbers) + 8.2.4.2.2 / 8.2.4.2.5 + 8.2.4.3 for a P field */
+/* 8.2.4.1 (field picture numbers) + 8.2.4.2.2 / 8.2.4.2.4 / 8.2.4.2.5 + 8.2.4.3 for the P or B slices of a field */
 static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
     const int par = sh->bottom_field, max_frame_num = 1 << d->asps->log2_max_frame_num;
+    const int nlists = sh->slice_type == SLICE_B ? 2 : 1;
     Picture *st[ORC_MAX_DPB + 1], *lt[ORC_MAX_DPB + 1]; int nst = 0, nlt = 0;
     for (int i = 0; i <= ORC_MAX_DPB; i++) {
         Picture *s = &d->dpb[i];
@@ -269,19 +269,43 @@ static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
         st[j] = t; }
     for (int i = 0; i < nlt; i++) for (int j = i + 1; j < nlt; j++) if (lt[j]->long_term_frame_idx < lt[i]->long_term_frame_idx) { Picture *t = lt[i];
         lt[i] = lt[j]; lt[j] = t; }
-    Picture *list[35]; memset(list, 0, sizeof list);
-    /* the current field's own store must not offer the current field itself: its mark is still 0 while it is decoded */
-    int n = alternate_fields(d, st, nst, 1, par, list, 0, 33);
-    n = alternate_fields(d, lt, nlt, 2, par, list, n, 33);
-    const int nact = sh->num_ref_idx[0];
+    Picture *lists[2][35]; memset(lists, 0, sizeof lists);
+    int ninit[2] = {0, 0};
+    if (nlists == 1) {
+        /* (the current field's own store offers its FIRST field only: the mark of the field being decoded is still 0) */
+        ninit[0] = alternate_fields(d, st, nst, 1, par, lists[0], 0, 33);
+    } else {
+        /* 8.2.4.2.4: the short-term stores by PicOrderCnt around the count of the current FIELD: list 0 takes those not above it in descending order,
+         * then the others ascending; list 1 the other way round.  PicOrderCnt of a store: of the frame / complementary field pair (Min of its fields)
+         * or of its only field. */
+        Picture *ord[2][ORC_MAX_DPB + 1], *before[ORC_MAX_DPB + 1], *after[ORC_MAX_DPB + 1]; int nb = 0, na = 0;
+        const int cur_poc = d->cur_store->fpoc[par];
+        for (int i = 0; i < nst; i++) { if (st[i]->poc <= cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j];
+            before[j] = t; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j];
+            after[j] = t; }
+        for (int i = 0; i < nb; i++) { ord[0][i] = before[i]; ord[1][na + i] = before[i]; }
+        for (int i = 0; i < na; i++) { ord[0][nb + i] = after[i]; ord[1][i] = after[i]; }
+        for (int l = 0; l < 2; l++) ninit[l] = alternate_fields(d, ord[l], nst, 1, par, lists[l], 0, 33);
+    }
+    for (int l = 0; l < nlists; l++) ninit[l] = alternate_fields(d, lt, nlt, 2, par, lists[l], ninit[l], 33);
+    if (nlists == 2 && ninit[1] > 1 && ninit[0] == ninit[1]) {
+        int same = 1;
+        for (int i = 0; i < ninit[0]; i++) if (lists[0][i] != lists[1][i]) same = 0;
+        if (same) { Picture *t = lists[1][0]; lists[1][0] = lists[1][1]; lists[1][1] = t; }
+    }
+    for (int l = 0; l < nlists; l++) {
+    Picture **list = lists[l];
+    const int nact = sh->num_ref_idx[l];
     for (int i = nact; i < 35; i++) list[i] = NULL;
     if (d->slice_num == 0) { for (int i = 0; i < nact && list[i]; i++) if (list[i]->is_ref == 2) { d->stats[ORC_ST_FIELD_LONG]++; break; }
-        d->stats[ORC_ST_FIELD_RPLM] += sh->rplm_flag[0]; }
-    if (sh->rplm_flag[0]) {
+        d->stats[ORC_ST_FIELD_RPLM] += sh->rplm_flag[l]; }
+    if (sh->rplm_flag[l]) {
         const int cur_pic_num = 2 * sh->frame_num + 1, max_pic_num = 2 * max_frame_num;
         int pred = cur_pic_num, idx = 0;
-        for (int k = 0; k < sh->n_rplm[0]; k++) {
-            const RplmOp *op = &sh->rplm[0][k];
+        for (int k = 0; k < sh->n_rplm[l]; k++) {
+            const RplmOp *op = &sh->rplm[l][k];
             Picture *target = NULL;
             if (op->idc < 2) {
                 int nowrap;
@@ -303,8 +327,13 @@ static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
             for (int c = idx; c <= nact; c++) if (list[c] != target) list[nidx++] = list[c];
         }
     }
-    for (int i = 0; i < nact && i < 33; i++) d->ref_list[0][i] = list[i];
-    d->ref_count[0] = nact;
+    for (int i = 0; i < nact && i < 33; i++) d->ref_list[l][i] = list[i];
+    d->ref_count[l] = nact;
+    }
+    /* 8.4.1.2.1: the colocated field must come from a picture that was itself coded as a field (vertMvScale One_To_One); a field of a FRAME picture
+     * (Frm_To_Fld) is not supported */
+    if (nlists == 2 && d->ref_list[1][0] && !d->ref_list[1][0]->store->coded_fields) ORC_FAIL(d, "direct prediction of a field from a frame picture unsupported");
+    if (nlists == 2) d->stats[ORC_ST_B_FIELDS] += d->slice_num == 0;
     return 0;
 }
 
@@ -351,6 +380,7 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
         for (int i = 0; i < ninit[0]; i++) if (init[0][i] != init[1][i]) same = 0;
         if (same) { Picture *t = init[1][0]; init[1][0] = init[1][1]; init[1][1] = t; }
     }
+    if (nlists == 2 && init[1][0] == NULL) { /* nothing to check */ }
     for (int l = 0; l < nlists; l++) {
         Picture **list = init[l];
         int nact = sh->num_ref_idx[l];
@@ -381,6 +411,8 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
         for (int i = 0; i < nact; i++) d->ref_list[l][i] = list[i];
         d->ref_count[l] = nact;
     }
+    /* 8.4.1.2.1: a frame whose colocated picture is a complementary field pair (Fld_To_Frm) is not supported */
+    if (nlists == 2 && d->ref_list[1][0] && d->ref_list[1][0]->coded_fields) ORC_FAIL(d, "direct prediction of a frame from a field pair unsupported");
     return 0;
 }
 
@@ -590,7 +622,7 @@ const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
         "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
         "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields"};
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }

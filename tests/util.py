@@ -149,6 +149,11 @@ PAFF_CASES = {
                                    slices=3, chroma_qp_off=-3, alpha_off=2, beta_off=-2),
     "paff_poc2_cip_crop": dict(width=90, height=88, frames=10, gop=5, mode=1, seed=206, paff=2, num_ref=2, cip=1, poc_type=2, cabac=1, cabac_idc=2),
     "paff_real_qvga": dict(width=320, height=224, frames=6, gop=6, seed=207, paff=1, num_ref=2, cabac=1),
+    # B field pictures (every picture of the stream two fields: the colocated field of a B field is then always a field picture, 8.4.1.2.1 One_To_One)
+    "paff_b_spatial": dict(width=96, height=96, frames=10, gop=10, mode=1, seed=211, paff=2, bframes=2, num_ref=3, slices=2),
+    "paff_b_temporal_cabac": dict(width=96, height=64, frames=13, gop=13, mode=1, seed=212, paff=2, bframes=3, num_ref=3, cabac=1, direct_temporal=1, rplm=1),
+    "paff_b_implicit_wp_t8x8": dict(width=80, height=96, frames=10, gop=10, mode=1, seed=213, paff=2, bframes=2, num_ref=4, wp=2, t8x8=1, direct_temporal=1),
+    "paff_b_explicit_wp_real": dict(width=176, height=160, frames=7, gop=7, seed=214, paff=2, bframes=1, num_ref=2, wp=1, cabac=1, cabac_idc=2),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

@@ -62,8 +62,9 @@ typedef struct {
                                    stream that happens to be coded progressively.  Needs an even number of macroblock rows; Main profile at least */
     int poc_bottom;             /* 1: bottom_field_pic_order_in_frame_present_flag = 1 with random delta_pic_order_cnt_bottom / delta_pic_order_cnt[1] in -1..1
                                    (PicOrderCnt of a frame = Min(top, bottom), 8.2.1) */
-    int paff;                   /* picture-adaptive frame / field coding (implies fmo0; P-only streams): 1 = every I / P picture is coded either as a frame
-                                   or as two field pictures (first field of either parity), drawn per picture; 2 = every picture as two fields.  With
+    int paff;                   /* picture-adaptive frame / field coding (implies fmo0): 1 = every I / P picture is coded either as a frame or as two field
+                                   pictures (first field of either parity), drawn per picture (P-only streams); 2 = every picture as two fields (B
+                                   pictures allowed).  With
                                    CABAC the 8x8 transform is switched off (the contexts 436..459 of field-coded 8x8 blocks are not pinned, SPEC_AUDIT.md) */
 } GenParams;
 
@@ -2003,7 +2004,8 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
     }
     if (p->poc_type == 1) e->delta0 = rnd_n(&e->rng, 2);
     const int field_poc = field == 2 ? e->cur_top + e->delta_bottom : e->cur_top;       /* the count this picture's slice headers carry (type 0) */
-    e->cur.poc = field ? field_poc : e->cur_poc;
+    if (field) e->cur_poc = field_poc;          /* what direct prediction and implicit weights measure distances from (8.4.1.2.3, 8.4.2.3.1) */
+    e->cur.poc = e->cur_poc;
     const int maxfn = 1 << e->log2_max_fn, curfn = e->frame_num & (maxfn - 1);
     e->cur.frame_num = curfn; e->cur.is_long = 0; e->cur.lt_idx = -1;
 #define PICNUM(f) ((f)->frame_num > curfn ? (f)->frame_num - maxfn : (f)->frame_num)
@@ -2012,7 +2014,32 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
 #define LPN(f) (field ? 2 * (f)->lt_idx + ((f)->parity == par) : (f)->lt_idx)
     const int cur_pn = field ? 2 * curfn + 1 : curfn, max_pn = field ? 2 * maxfn : maxfn;
     Frame *init[2][16]; int ninit[2] = {0, 0};
-    if (field) {
+    if (field && is_b) {
+        /* 8.2.4.2.4 + 8.2.4.2.5 (B field): frame stores by PicOrderCnt around the current FIELD's count -- list 0: those not above it, descending,
+           then the others ascending; list 1 the other way round --, long-term stores behind; from each ordered list the fields, alternating in
+           parity.  (All pictures of a stream with B pictures are field pairs here, so every store has both fields marked.) */
+        Frame *before[6], *after[6], *ord[2][6]; int nb = 0, na = 0;
+        for (int i = 0; i < e->nrefs; i++) {
+            Frame *s = &e->refs[i];
+            for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; }
+            if (s->fmark[0] != 1 && s->fmark[1] != 1) continue;
+            if (s->poc <= e->cur_poc) before[nb++] = s; else after[na++] = s;
+        }
+        for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Frame *x = before[i]; before[i] = before[j];
+            before[j] = x; }
+        for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Frame *x = after[i]; after[i] = after[j];
+            after[j] = x; }
+        for (int i = 0; i < nb; i++) { ord[0][i] = before[i]; ord[1][na + i] = before[i]; }
+        for (int i = 0; i < na; i++) { ord[0][nb + i] = after[i]; ord[1][i] = after[i]; }
+        for (int l = 0; l < 2; l++) ninit[l] = alternate_fields(ord[l], nb + na, 1, par, init[l], 0);
+        if (ninit[1] > 1 && ninit[0] == ninit[1]) { int same = 1; for (int i = 0; i < ninit[0]; i++) if (init[0][i] != init[1][i]) same = 0;
+            if (same) { Frame *x = init[1][0]; init[1][0] = init[1][1]; init[1][1] = x; } }
+        e->nlist0 = MIN(ninit[0], 2 * p->num_ref); e->nlist1 = MIN(ninit[1], 2 * p->num_ref);
+        if (p->mode == 1) { e->nlist0 = 1 + rnd_n(&e->rng, e->nlist0); e->nlist1 = 1 + rnd_n(&e->rng, e->nlist1); }   /* num_ref_idx_active override */
+        for (int i = 0; i < e->nlist0; i++) e->list0[i] = init[0][i];
+        for (int i = 0; i < e->nlist1; i++) e->list1[i] = init[1][i];
+    } else if (field) {
         /* 8.2.4.2.2 + 8.2.4.2.5 (P field): frame stores with any field marked short-term by descending FrameNumWrap -- the store of the first field
            of this frame among them, at the front --, then those with a long-term field by ascending LongTermFrameIdx; from each list the fields */
         Frame *sh[6], *lg[6]; int ns = 0, nl = 0;
@@ -2246,7 +2273,13 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             for (int k = 0; k < e->n_mmco; k++) fprintf(stderr, " mmco%d(%d)", e->mmco_op[k], e->mmco_a[k]);
             fprintf(stderr, " bytes %zu\n", e->out.len);
         }
-        if (is_ref) frame_finish_ref(&e->cur, e->W, e->H);
+        if (is_ref) {
+            frame_finish_ref(&e->cur, e->W, e->H);
+            if (p->bframes) {                               /* the field's motion, colocated data of later B fields */
+                if (!e->cur.mf) e->cur.mf = malloc(sizeof(MbE) * (size_t)mbs_total);
+                memcpy(e->cur.mf, e->mbs, sizeof(MbE) * (size_t)mbs_total);
+            }
+        }
         full_cur.fld[par] = e->cur; e->src = full_src; e->H *= 2; e->mbh *= 2;
         full_cur.fpoc[par] = field_poc;
         if (is_ref) {
@@ -2275,6 +2308,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
                 if (idr) e->max_lt_idx = -1;
                 if (e->nrefs >= p->num_ref) { fprintf(stderr, "h264gen: no free frame store for a field\n"); abort(); }
                 full_cur.frame_num = curfn; full_cur.is_long = 0; full_cur.lt_idx = -1; full_cur.fmark[par] = 1; full_cur.fmark[par ^ 1] = 0;
+                full_cur.poc = field_poc;
                 e->cur_store_id = full_cur.id;
                 Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = full_cur; e->cur = t_; e->nrefs++;
             } else {
@@ -2375,11 +2409,11 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
 
 /* one frame of the stream: a frame picture, or (PAFF) two field pictures -- the first of either parity */
 static void encode_frame(Enc *e, int t, int is_b) {
-    int as_fields = !is_b && e->p.paff && (e->p.paff == 2 || rnd_n(&e->rng, 2));
+    int as_fields = e->p.paff && (e->p.paff == 2 || (!is_b && rnd_n(&e->rng, 2)));
     if (!as_fields) { encode_picture(e, t, is_b, 0, 0); return; }
     int first = 1 + rnd_n(&e->rng, 2);
-    encode_picture(e, t, 0, first, 0);
-    encode_picture(e, t, 0, 3 - first, 1);
+    encode_picture(e, t, is_b, first, 0);
+    encode_picture(e, t, is_b, 3 - first, 1);
 }
 
 /* The picture order counts the encoder MEANT, by display index, of the stream this thread generated last: TopFieldOrderCnt counts 2 per picture from
@@ -2405,7 +2439,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     p->poc_bottom = p->poc_bottom != 0;
     p->scaling = CLIP3(0, 2, p->scaling);
     p->paff = CLIP3(0, 2, p->paff);
-    if (p->paff) { p->fmo0 = 1; p->bframes = 0; if (p->cabac) p->t8x8 = 0; if (p->wp == 2) p->wp = 0; }
+    /* B pictures in a PAFF stream: only when EVERY picture is a field pair (colocated data of a field then always come from a field picture) */
+    if (p->paff) { p->fmo0 = 1; if (p->paff != 2) p->bframes = 0; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
     if (p->bframes) p->mmco = 0;
     e->max_lt_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
@@ -2454,7 +2489,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     free(g_last_pocs); g_last_pocs = e->pocs; g_last_n = p->frames;
     free(e->cur.mf); for (int i = 0; i < 5; i++) free(e->refs[i].mf);
     if (p->paff) { frame_free(&e->fsrc);
-        for (int i = 0; i < 6; i++) { Frame *f = i < 5 ? &e->refs[i] : &e->cur; for (int q = 0; q < 2; q++) frame_free(&f->fld[q]); free(f->fld); } }
+        for (int i = 0; i < 6; i++) { Frame *f = i < 5 ? &e->refs[i] : &e->cur; for (int q = 0; q < 2; q++) { free(f->fld[q].mf); frame_free(&f->fld[q]); }
+            free(f->fld); } }
     frame_free(&e->src); frame_free(&e->cur); for (int i = 0; i < 5; i++) frame_free(&e->refs[i]);
     free(e->mbs); free(e->bw.buf); free(e);
     return 0;
