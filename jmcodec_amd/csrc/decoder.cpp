@@ -344,7 +344,7 @@ void Decoder::free_out_slots(bool all) {
     if (all) { ready_.clear(); cur_out_ = nullptr; }
 }
 void Decoder::gpu_close() {
-    if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); for (auto &j : jobs_) { free(j.host); j.host = nullptr; } return; }
+    if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); free_job_buffers(); return; }      // (parse-only handles: plain malloc)
     gpu_free_sequence();
     gpu_open_ = false;
 }
