@@ -14,6 +14,7 @@
 #include "hevc_jobs.h"
 #include "hevc_kernels.h"
 #include "hevc_tables.h"
+#include "chain_common.h"
 #include <cstdlib>
 
 namespace jmamd {
@@ -236,6 +237,20 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     load_transform_matrix(tm, tb.log2, lane, 64);
     const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
     uint8_t *dst = pp.work_surf;
+    if (tb.plane == 0) {
+        // luma: four samples of a row per lane, one dword read and one dword written (block positions and sizes are multiples of 4)
+        const int qn = n >> 2;
+        for (int k = lane; k < n * qn; k += 64) {
+            const int y = k / qn, xq = k - y * qn;
+            uint32_t *p = (uint32_t *)(dst + (size_t)(tb.y + y) * pp.pitch + tb.x + 4 * xq);
+            const uint32_t v = *p; const int16_t *rr = r + y * n + 4 * xq;
+            *p = (uint32_t)clip1((int)(v & 255) + rr[0]) | (uint32_t)clip1((int)(v >> 8 & 255) + rr[1]) << 8 | (uint32_t)clip1((int)(v >> 16 & 255) + rr[2]) << 16 |
+                 (uint32_t)clip1((int)(v >> 24) + rr[3]) << 24;
+        }
+        return;
+    }
+    // chroma: Cb and Cr of a block are interleaved in memory and belong to two transform blocks (two workgroups): byte accesses, nothing wider can be
+    // read-modified-written without racing with the other component
     for (int k = lane; k < n * n; k += 64) {
         const int y = k >> tb.log2, x = k & (n - 1);
         uint8_t *p = sample_ptr(dst, pp, tb.plane, tb.x + x, tb.y + y);
@@ -264,8 +279,6 @@ __global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
 // ------------------------------------------------------------------------------------------------------------
 // 8.4.4.2: intra prediction (+ residual) of the intra blocks of one coding tree block, in decoding order
 // ------------------------------------------------------------------------------------------------------------
-// experiments (timing only, wrong output): 1 no block loop, 2 no waiting on the row above, 4 no tile load / store
-__device__ int g_hevc_exp = 0;
 constexpr int kIntraThreads = 256;
 constexpr int kYS = 160, kCS = 80;              // LDS row strides of the luma / chroma tiles
 // column of the CTB's first sample inside a tile row (the left neighbour column sits just before): keeps 16- / 8-byte accesses aligned
@@ -276,88 +289,126 @@ constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 b
 // of the CTB (row 0 continues over the CTB to the right: above-right neighbours), so every neighbour a block may use (8.4.4.2.2) is
 // an LDS read, whether it was produced by this CTB's earlier blocks, by the inter kernels or by a CTB of an earlier diagonal.
 //
-// One workgroup per CTB row walks its row left to right; CTB (x, y) may start when row y - 1 has finished x + 2 CTBs (its above and
-// above-right neighbours).  Progress counters in device memory carry that dependency between workgroups: row y only ever waits for
-// row y - 1, whose workgroup has the smaller block index and is therefore already running or finished -- no deadlock whatever the
-// occupancy.  (A launch per wavefront diagonal, the first version, cost the sum of the slowest CTB of every diagonal: 23 ms for a
-// batch of 4K pictures; this form follows the real dependency chain.)
+// One workgroup per CTB row walks the CTBs of its row THAT HOLD INTRA BLOCKS, left to right (the others were final before the launch);
+// CTB (x, y) may start when the CTBs above it that hold intra blocks -- left, straight, right -- are done.  Progress counters in device
+// memory carry that dependency between workgroups: row y only ever waits for row y - 1, whose workgroup has the smaller block index and
+// is therefore already running or finished -- no deadlock whatever the occupancy.  (A launch per wavefront diagonal, the first version,
+// cost the sum of the slowest CTB of every diagonal: 23 ms for a batch of 4K pictures; this form follows the real dependency chain.)
+//
+// What lies ON that chain (round 3; it was everything: 9-10 us per CTB, 550 us for a P picture with scattered intra blocks): the wait for the
+// row above, the load of the row of samples above the CTB, the block loop, the store of the CTB's BOTTOM row and the release of the
+// counter.  Off the chain: the CTB's own samples (they were final before the launch: fetched into registers while the previous CTB is
+// worked on), its left column (out of the previous tile when that was the neighbour), and the store of the rest of the tile (after the
+// counter is released; the next CTB's tile is filled from registers, so the stores drain meanwhile).
 __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParams *pics, int *progress, int prog_stride) {
     const HevcPicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & HPS_INTRA)) return;
     const int cy = blockIdx.x;
     if (cy >= pp.ctb_h) return;
     int *prog = progress + (size_t)blockIdx.y * prog_stride;
-    for (int cx = 0; cx < pp.ctb_w; cx++) {
-    const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
-    if (!ctb.intra_count) continue;                              // nothing to predict here: its samples were final before this kernel started
-    {
-    const int exp_ = g_hevc_exp;
-    // Wait only for the coding tree blocks above (left, straight, right) that themselves hold intra blocks: the others were final before the launch.
-    // With one counter per row "everything up to cx + 2 of the row above" chained every intra block of a picture to ALL intra blocks up and to the
-    // left of it -- ~0.5 ms per P / B picture with a handful of intra blocks, and what bounded one HEVC stream (k_hevc_intra 571 us of 737 us per picture).
-    int need = 0;
-    if (cy > 0 && !(exp_ & 2)) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 &&
-        col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_count) need = col + 1;
-    if (need) {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            // relaxed polls: an acquire load invalidates the XCD's L2 on EVERY iteration (the same finding as in deblock_lds.hip); one acquire fence
-            // after the wait is enough
-            while (__hip_atomic_load(&prog[cy - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(8);
-            // ONE acquire for the workgroup: the invalidation acts on the caches (the CU's L1, the XCD's L2), which all four waves share
-            if (!(g_hevc_exp & 8)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        }
-        __syncthreads();
-        if (g_hevc_exp & 8) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
     __shared__ __align__(16) uint8_t ty[65 * kYS];            // luma tile
     __shared__ __align__(16) uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
     // per colour plane (= per wavefront of the block loop):
     __shared__ int16_t edge_[3][2][132];        // [0] raw, [1] filtered: 0 .. 2n-1 left column bottom-to-top, 2n corner, 2n+1 .. 4n top row left-to-right
     __shared__ int16_t refa_[3][32 * 3 + 8];    // main reference of the angular modes, index 0 at refa[32]
-    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records and residual (k_hevc_iresid), fetched once: the block loop touches no global memory
-    int lane = threadIdx.x, nt = kIntraThreads;
+    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records, fetched once: the block loop touches no global memory but the residual
     uint8_t *surf = pp.work_surf;
-    const int cs = 1 << pp.ctb_log2, x0 = cx << pp.ctb_log2, y0 = cy << pp.ctb_log2;
+    uint8_t *cpl = surf + pp.chroma_offset;
+    const int cs = 1 << pp.ctb_log2, y0 = cy << pp.ctb_log2, hc = cs >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1;
+    const int q = cs >> 4;                                     // 16-byte groups per luma row of the CTB (and per interleaved chroma row)
+    const int tid = threadIdx.x;
+    // this thread's share of a CTB body: luma group (row yr, group yg), chroma group (row cr, group cg) -- at most one each (64x64: 256 + 128 groups)
+    const int yr = tid / q, yg = tid - yr * q, cr = tid / q, cg = tid - cr * q;
+    const bool y_mine = tid < cs * q, c_mine = tid < hc * q;
+    struct Pre { uint4 y, c; uint32_t ly, lc; };
+    auto de_interleave = [](const uint4 v, uint2 &cb, uint2 &crv) {
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        uint32_t b2[2], r2[2];
+        for (int h2 = 0; h2 < 2; h2++) { const uint32_t a = w4[2 * h2], b = w4[2 * h2 + 1];
+            b2[h2] = (a & 255) | ((a >> 16 & 255) << 8) | ((b & 255) << 16) | ((b >> 16 & 255) << 24);
+            r2[h2] = (a >> 8 & 255) | ((a >> 24) << 8) | ((b >> 8 & 255) << 16) | ((b >> 24) << 24); }
+        cb = make_uint2(b2[0], b2[1]); crv = make_uint2(r2[0], r2[1]);
+    };
+    auto interleave = [](const uint2 cb, const uint2 crv) {
+        const uint32_t bw[2] = {cb.x, cb.y}, rw[2] = {crv.x, crv.y};
+        uint32_t o[4];
+        for (int h2 = 0; h2 < 2; h2++) {
+            o[2 * h2] = (bw[h2] & 255) | ((rw[h2] & 255) << 8) | ((bw[h2] >> 8 & 255) << 16) | ((rw[h2] >> 8 & 255) << 24);
+            o[2 * h2 + 1] = (bw[h2] >> 16 & 255) | ((rw[h2] >> 16 & 255) << 8) | ((bw[h2] >> 24) << 16) | ((rw[h2] >> 24) << 24);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    // the CTB's own samples and its left column, as they are in memory now (final for everything this kernel does not write)
+    auto prefetch = [&](int cxn, Pre &pre) {
+        const int x0 = cxn << pp.ctb_log2, xc0 = x0 >> 1;
+        pre.y = pre.c = make_uint4(0, 0, 0, 0); pre.ly = pre.lc = 0;
+        if (y_mine && y0 + yr < pp.h && x0 + 16 * yg < pp.w) pre.y = *(const uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg);
+        if (c_mine && yc0 + cr < ph && xc0 + 8 * cg < pw) pre.c = *(const uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg));
+        if (x0 > 0 && tid <= cs) { const int y = y0 + tid - 1; if (y >= 0 && y < pp.h) pre.ly = surf[(size_t)y * pp.pitch + x0 - 1]; }
+        if (x0 > 0 && tid <= hc) { const int y = yc0 + tid - 1; if (y >= 0 && y < ph) pre.lc = *(const uint16_t *)(cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1)); }
+    };
+    auto next_intra = [&](int from) { int c = from; while (c < pp.ctb_w && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
+    int cx = next_intra(0), prev_cx = -2;
+    Pre pre;
+    if (cx < pp.ctb_w) prefetch(cx, pre);
+    while (cx < pp.ctb_w) {
+    const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
+    const int x0 = cx << pp.ctb_log2, xc0 = x0 >> 1;
+    // ---- the left column out of the previous tile, when that CTB was the left neighbour (its samples may still be on their way to memory) ----
+    uint32_t keep_ly = pre.ly, keep_lc = pre.lc;
+    if (prev_cx == cx - 1) {
+        if (tid <= cs) keep_ly = ty[tid * kYS + kYO + cs - 1];
+        if (tid <= hc) keep_lc = (uint32_t)tc[0][tid * kCS + kCO + hc - 1] | (uint32_t)tc[1][tid * kCS + kCO + hc - 1] << 8;
+    }
+    // ---- wait only for the coding tree blocks above (left, straight, right) that themselves hold intra blocks: the others were final before the launch
+    //      (one counter per row "everything up to cx + 2 of the row above" chained every intra block of a picture to ALL intra blocks up and to the left) ----
+    int need = 0;
+    // ... and of those only the ones whose intra blocks reach their bottom row (HevcCtb.intra_bottom): in a P / B picture with scattered intra blocks that
+    // leaves few waits at all, and the rows of the picture run side by side instead of as a wavefront
+    if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 && col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_bottom) need = col + 1;
+    if (need && tid == 0) {
+        int spins = 0;
+        // Relaxed polls and NO fence: what the row above hands over -- its bottom rows -- is written through (st_wt16) before the counter moves, and
+        // read below with loads that go past the caches, exactly as the rows of an H.264 chain launch hand over their samples (chain_common.h).  An
+        // acquire / release pair here made every CTB invalidate and write back the XCD's L2.
+        while (ld_coh(&prog[cy - 1]) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();                                              // (also: everybody is done with the previous tile)
     const int n_tbs = (int)ctb.intra_count;
     const bool tbs_in_lds = n_tbs <= kIntraMaxTbs;
     if (tbs_in_lds) {
         const uint32_t *src = (const uint32_t *)(pp.itbs + ctb.intra_first); uint32_t *dstw = (uint32_t *)s_tbs;      // 20-byte records, 4-byte aligned
-        for (int k = lane; k < n_tbs * 5; k += nt) dstw[k] = src[k];
+        for (int k = tid; k < n_tbs * 5; k += kIntraThreads) dstw[k] = src[k];
     }
-    // ---- load: CTB body with 16-byte accesses, the row above (two CTB widths), the column to the left ----
-    if (!(exp_ & 4)) {
-        const int q = cs >> 4;                                          // 16-byte groups per CTB row
-        for (int k = lane; k < cs * q; k += nt) {                       // 64x64: one group per thread
-            const int r = k / q, g = k - r * q, y = y0 + r;
-            if (y < pp.h && x0 + 16 * g < pp.w) *(uint4 *)&ty[(r + 1) * kYS + kYO + 16 * g] = *(const uint4 *)(surf + (size_t)y * pp.pitch + x0 + 16 * g);
-        }
-        if (y0 > 0) for (int k = lane; k < 2 * q; k += nt) if (x0 + 16 * k < pp.w) *(uint4 *)&ty[kYO + 16 * k] =
-            *(const uint4 *)(surf + (size_t)(y0 - 1) * pp.pitch + x0 + 16 * k);
-        if (x0 > 0) for (int k = lane; k <= cs; k += nt) { const int y = y0 + k - 1;
-            if (y >= 0 && y < pp.h) ty[k * kYS + kYO - 1] = surf[(size_t)y * pp.pitch + x0 - 1]; }
-        const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1, qc = cs >> 4;      // a 16-byte group holds 8 Cb/Cr pairs
-        const uint8_t *cpl = surf + pp.chroma_offset;
-        for (int k = lane; k < (hc + 1) * 2 * qc; k += nt) {            // rows -1 .. hc-1; row -1 spans two CTB widths
-            const int r = k / (2 * qc), g = k - r * 2 * qc, y = yc0 + r - 1, x = xc0 + 8 * g;
-            if ((r > 0 && g >= qc) || y < 0 || y >= ph || x >= pw) continue;
-            const uint4 v = *(const uint4 *)(cpl + (size_t)y * pp.pitch + 2 * x);
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-            uint32_t cb[2], cr[2];
-            for (int h2 = 0; h2 < 2; h2++) { const uint32_t a = w4[2 * h2], b = w4[2 * h2 + 1];
-                cb[h2] = (a & 255) | ((a >> 16 & 255) << 8) | ((b & 255) << 16) | ((b >> 16 & 255) << 24);
-                cr[h2] = (a >> 8 & 255) | ((a >> 24) << 8) | ((b >> 8 & 255) << 16) | ((b >> 24) << 24); }
-            *(uint2 *)&tc[0][r * kCS + kCO + 8 * g] = make_uint2(cb[0], cb[1]); *(uint2 *)&tc[1][r * kCS + kCO + 8 * g] = make_uint2(cr[0], cr[1]);
-        }
-        if (x0 > 0) for (int k = lane; k <= hc; k += nt) { const int y = yc0 + k - 1; if (y >= 0 && y < ph) {
-            const uint8_t *p = cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1); tc[0][k * kCS + kCO - 1] = p[0]; tc[1][k * kCS + kCO - 1] = p[1]; } }
+    // ---- the row above (two CTB widths): the one load on the dependency chain ----
+    auto ld16_coh = [](const uint8_t *p) {
+        const unsigned long long a = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 b = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    };
+    if (y0 > 0 && tid < 2 * q && x0 + 16 * tid < pp.w) *(uint4 *)&ty[kYO + 16 * tid] = ld16_coh(surf + (size_t)(y0 - 1) * pp.pitch + x0 + 16 * tid);
+    if (yc0 > 0 && tid >= 64 && tid < 64 + 2 * q && xc0 + 8 * (tid - 64) < pw) {
+        uint2 cb, crv; de_interleave(ld16_coh(cpl + (size_t)(yc0 - 1) * pp.pitch + 2 * (xc0 + 8 * (tid - 64))), cb, crv);
+        *(uint2 *)&tc[0][kCO + 8 * (tid - 64)] = cb; *(uint2 *)&tc[1][kCO + 8 * (tid - 64)] = crv;
     }
+    // (the corner above-left belongs to a CTB of the row above: it, too, may only be read now)
+    if (tid == 128 && x0 > 0 && y0 > 0) keep_ly = (uint32_t)ld_ref8<true>(surf + (size_t)(y0 - 1) * pp.pitch + x0 - 1);
+    if (tid == 129 && x0 > 0 && yc0 > 0) { const uint8_t *pc = cpl + (size_t)(yc0 - 1) * pp.pitch + 2 * (xc0 - 1);
+        keep_lc = (uint32_t)ld_ref8<true>(pc) | (uint32_t)ld_ref8<true>(pc + 1) << 8; }
+    // ---- body and left column from the registers ----
+    if (y_mine) *(uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg] = pre.y;
+    if (c_mine) { uint2 cb, crv; de_interleave(pre.c, cb, crv); *(uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg] = cb; *(uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg] = crv; }
+    if (x0 > 0 && tid >= 1 && tid <= cs) ty[tid * kYS + kYO - 1] = (uint8_t)keep_ly;
+    if (x0 > 0 && tid >= 1 && tid <= hc) { tc[0][tid * kCS + kCO - 1] = (uint8_t)keep_lc; tc[1][tid * kCS + kCO - 1] = (uint8_t)(keep_lc >> 8); }
+    if (tid == 128 && x0 > 0 && y0 > 0) ty[kYO - 1] = (uint8_t)keep_ly;
+    if (tid == 129 && x0 > 0 && yc0 > 0) { tc[0][kCO - 1] = (uint8_t)keep_lc; tc[1][kCO - 1] = (uint8_t)(keep_lc >> 8); }
     __syncthreads();
+    int lane, nt;
     // ---- block loop: the three colour planes are independent, so wavefront w runs the blocks of plane w on its own (wave-synchronous:
     //      no s_barrier, the phases of a block only cost LDS latency) ----
     const int wave = threadIdx.x >> 6;
     lane = threadIdx.x & 63; nt = 64;
-    if (wave < 3 && !(exp_ & 1)) {
+    if (wave < 3) {
     int16_t (*edge)[132] = edge_[wave]; int16_t *refa = refa_[wave];
     const int rpw = wave ? pp.w >> 1 : pp.w;
     const int16_t *rplane = pp.resid + (wave == 0 ? 0 : (size_t)pp.w * pp.h + (wave == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
@@ -457,36 +508,22 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     }
     }   // wave < 3
     __syncthreads();
-    lane = threadIdx.x; nt = kIntraThreads;
-    // ---- store the CTB (its intra blocks changed; the other samples are written back unchanged) ----
-    if (!(exp_ & 4)) {
-        const int q = cs >> 4;
-        for (int k = lane; k < cs * q; k += nt) {
-            const int r = k / q, g = k - r * q, y = y0 + r;
-            if (y < pp.h && x0 + 16 * g < pp.w) *(uint4 *)(surf + (size_t)y * pp.pitch + x0 + 16 * g) = *(const uint4 *)&ty[(r + 1) * kYS + kYO + 16 * g];
-        }
-        const int hc = cs >> 1, xc0 = x0 >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1, qc = cs >> 4;
-        uint8_t *cpl = surf + pp.chroma_offset;
-        for (int k = lane; k < hc * qc; k += nt) {
-            const int r = k / qc, g = k - r * qc, y = yc0 + r, x = xc0 + 8 * g;
-            if (y >= ph || x >= pw) continue;
-            const uint2 cb = *(const uint2 *)&tc[0][(r + 1) * kCS + kCO + 8 * g], cr = *(const uint2 *)&tc[1][(r + 1) * kCS + kCO + 8 * g];
-            const uint32_t bw[2] = {cb.x, cb.y}, rw[2] = {cr.x, cr.y};
-            uint32_t o[4];
-            for (int h2 = 0; h2 < 2; h2++) {
-                o[2 * h2] = (bw[h2] & 255) | ((rw[h2] & 255) << 8) | ((bw[h2] >> 8 & 255) << 16) | ((rw[h2] >> 8 & 255) << 24);
-                o[2 * h2 + 1] = (bw[h2] >> 16 & 255) | ((rw[h2] >> 16 & 255) << 8) | ((bw[h2] >> 24) << 16) | ((rw[h2] >> 24) << 24);
-            }
-            *(uint4 *)(cpl + (size_t)y * pp.pitch + 2 * x) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    // every wave waits until ITS stores have reached the L2; the release store below (one wave) then writes the L2 back once for all of them
-    if (g_hevc_exp & 8) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    }
-    // (only blocks with intra content are ever waited for, so only they publish)
-    if (threadIdx.x == 0) __hip_atomic_store(&prog[cy], cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }   // cx
+    // ---- the bottom row of the CTB first: it is all the row below needs of this CTB; then the counter ----
+    if (tid < q) { const int y = y0 + cs - 1; if (y < pp.h && x0 + 16 * tid < pp.w) st_wt16(surf + (size_t)y * pp.pitch + x0 + 16 * tid, *(const uint4 *)&ty[cs * kYS + kYO + 16 * tid]); }
+    else if (tid < 2 * q) { const int g = tid - q, y = yc0 + hc - 1, x = xc0 + 8 * g;
+        if (y < ph && x < pw) st_wt16(cpl + (size_t)y * pp.pitch + 2 * x, interleave(*(const uint2 *)&tc[0][hc * kCS + kCO + 8 * g], *(const uint2 *)&tc[1][hc * kCS + kCO + 8 * g])); }
+    // (wave 0 holds every one of those write-through stores: once they are complete the counter may move)
+    if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) st_coh(&prog[cy], cx + 1);
+    // ---- the rest of the tile (its intra blocks changed; the other samples are written back unchanged), off the chain ----
+    if (y_mine && yr < cs - 1 && y0 + yr < pp.h && x0 + 16 * yg < pp.w) *(uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg) = *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg];
+    if (c_mine && cr < hc - 1 && yc0 + cr < ph && xc0 + 8 * cg < pw)
+        *(uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg)) = interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg], *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]);
+    // rows of a CTB that reaches below the picture: the "bottom row" above lay outside, the last rows inside were written just now -- nobody waits for them
+    prev_cx = cx;
+    cx = next_intra(cx + 1);
+    if (cx < pp.ctb_w) prefetch(cx, pre);
+    }   // CTBs of the row
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -613,7 +650,6 @@ static void upload_tables() {
     hipMemcpyToSymbol(HIP_SYMBOL(c_angle), hevc_intra_angle, sizeof c_angle); hipMemcpyToSymbol(HIP_SYMBOL(c_inv_angle), hevc_inv_angle, sizeof c_inv_angle);
     hipMemcpyToSymbol(HIP_SYMBOL(c_beta), hevc_beta_tab, sizeof c_beta); hipMemcpyToSymbol(HIP_SYMBOL(c_tc), hevc_tc_tab, sizeof c_tc);
     hipMemcpyToSymbol(HIP_SYMBOL(c_qpc), hevc_qpc_tab, sizeof c_qpc);
-    if (getenv("JM_AMD_DEC_EXP_HEVC")) { int v = atoi(getenv("JM_AMD_DEC_EXP_HEVC")); hipMemcpyToSymbol(HIP_SYMBOL(g_hevc_exp), &v, sizeof v); }
     done[dev] = true;
 }
 void hevc_kernels_init() { upload_tables(); }

@@ -742,6 +742,19 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
 }
 
 // 7.3.8.4
+// HevcCtb.intra_bottom: does an intra block of the CTB reach the CTB's (or the picture's) bottom row?  Only then do the CTBs below read samples that
+// k_hevc_intra reconstructs here -- everything else they see of this CTB was final before that kernel started, and they need not wait for it.
+void HevcPicParser::note_intra_bottom(int rs) {
+    HevcCtb &cj = jobs_->ctbs[rs];
+    const int y_end = std::min(h_, ((rs / ctb_w_) + 1) << sps_->log2_ctb);
+    cj.intra_bottom = 0;
+    for (uint32_t i = 0; i < cj.intra_count && !cj.intra_bottom; i++) {
+        const HevcIntraTb &t = jobs_->itbs[cj.intra_first + i];
+        const int sc = t.plane ? 1 : 0;
+        if ((int)t.y + (1 << t.log2) >= (y_end >> sc)) cj.intra_bottom = 1;
+    }
+}
+
 bool HevcPicParser::coding_quadtree(int x0, int y0, int log2, int depth) {
     const int n = 1 << log2;
     bool split;
@@ -819,6 +832,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         parse_sao(ctb_rs_);
         if (!coding_quadtree(rx << sps_->log2_ctb, ry << sps_->log2_ctb, sps_->log2_ctb, 0) || cb_.overrun) return "corrupt slice data";
         jobs_->ctbs[ctb_rs_].intra_count = (uint32_t)jobs_->itbs.size() - jobs_->ctbs[ctb_rs_].intra_first;
+        note_intra_bottom(ctb_rs_);
         if (pps_->wpp && (rx == 1 || (ctb_rs_ > 1 && rx > 1 && tile_id_[rs2ts_[ctb_rs_ - 2]] != tile))) {
             memcpy(wpp_state_, cb_.state, HEVC_N_CTX * sizeof(Cabac::State)); wpp_valid_ = true; }
         // a finished CTB row (pictures without tiles: rows complete in order) makes its part of the motion field final
@@ -885,6 +899,7 @@ void HevcPicParser::finish_picture() {
             jobs_->itbs.push_back(t);
         }
         cj.intra_count = (uint32_t)jobs_->itbs.size() - cj.intra_first;
+        note_intra_bottom(rs);
         for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y);
             pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; slice_of_[i] = 0; }
     }

@@ -59,6 +59,7 @@ private:
     struct SliceInfo { int addr; bool deblock_disabled, lf_across; int8_t beta_off, tc_off; int8_t slot[2][16]; int poc[2][16]; uint8_t is_lt[2][16]; };
     // ---- syntax ----
     void parse_sao(int rs);
+    void note_intra_bottom(int rs);
     bool coding_quadtree(int x0, int y0, int log2, int depth);
     bool coding_unit(int x0, int y0, int log2);
     bool prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, int w, int h, int part_idx);
