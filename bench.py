@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--frames", type=int, default=60, help="frames per stream per step (multiple of the GOP, 30)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--tools", default="baseline", choices=["baseline", "high", "high_b"],
-                    help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P)")
+    ap.add_argument("--tools", default="baseline", choices=["baseline", "high", "high_b", "paff", "paff_b"],
+                    help="diagnostic: coding tools of the synthetic stream (default = BASELINE config 1; high = CABAC + 8x8 transform; high_b = + I B B P; "
+                         "paff = interlaced Main profile, every I / P picture a frame or two field pictures; paff_b = field pairs throughout, I B B P)")
     ap.add_argument("--codec", default="h264", choices=["h264", "hevc"], help="diagnostic: hevc = SURVEY 8d config C3 (HEVC Main, 64x64 CTB, SAO + "
         "deblocking, random-access GOP 8) at --width x --height")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +101,10 @@ def main():
         tools_desc = "High, I/P-only (CABAC, 8x8 transform"
     if args.tools == "high_b":
         tools_desc = "High, I B B P (CABAC, 8x8 transform"
+    if args.tools == "paff":
+        tools_desc = "Main interlaced, I/P frame or field-pair pictures (PAFF, CABAC"
+    if args.tools == "paff_b":
+        tools_desc = "Main interlaced, field pairs, I B B P (PAFF, CABAC"
     if args.codec == "hevc":
         tools_desc = "Main, random-access GOP 8 (CABAC, 64x64 CTB, SAO"
 
@@ -107,10 +112,14 @@ def main():
         if args.codec == "hevc":
             return streams.config_c3(frames=frames or F, width=args.width, height=args.height, stream_id=sid)
         cfg = streams.config_c1(stream_id=sid, frames=frames or F, width=args.width, height=args.height)
-        if args.tools != "baseline":
+        if args.tools in ("high", "high_b"):
             cfg.update(cabac=1, t8x8=1)
         if args.tools == "high_b":
             cfg.update(bframes=2, num_ref=2, poc_type=0)
+        if args.tools == "paff":
+            cfg.update(cabac=1, paff=1, num_ref=2, poc_type=0)
+        if args.tools == "paff_b":
+            cfg.update(cabac=1, paff=2, bframes=2, num_ref=2, poc_type=0)
         return cfg
 
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))

@@ -788,9 +788,11 @@ void Decoder::build_field_ref_lists(const SliceHeader &sh, SliceTask &task) {
     }
     if (nlists == 2 && rf.slot[1][0] >= 0) {
         // 8.4.1.2.1: the colocated field must come from a picture that was itself coded as a field (One_To_One); a field of a FRAME picture is not supported
+        // 8.4.1.2.1: the colocated field's motion -- its own when it was coded as a field picture, otherwise that of the FRAME picture (Frm_To_Fld)
         const DpbPic &c = dpb_[rf.slot[1][0] & 31];
-        if (!c.coded_as_fields) { stat_errors_++; fail("direct prediction of a field from a frame picture is not supported"); return; }
-        task.col = c.mf_fld[(rf.slot[1][0] >> 5) & 1]; rf.col = task.col.get();
+        if (c.coded_as_fields) task.col = c.mf_fld[(rf.slot[1][0] >> 5) & 1];
+        else { task.col = c.mf; rf.col_mode = 1; rf.cur_parity = par; }
+        rf.col = task.col.get();
     }
 }
 
@@ -888,12 +890,18 @@ void Decoder::build_frame_ref_lists(const SliceHeader &sh, SliceTask &task) {
         }
         for (int i = 0; i < nact && i < 32; i++) {
             rf.slot[l][i] = (int8_t)list[i];
-            if (list[i] >= 0) { rf.uid[l][i] = dpb_[list[i]].decode_idx; rf.poc[l][i] = dpb_[list[i]].poc; rf.is_long[l][i] = dpb_[list[i]].ref == 2; }
+            if (list[i] >= 0) { rf.uid[l][i] = 2 * dpb_[list[i]].decode_idx; rf.poc[l][i] = dpb_[list[i]].poc; rf.is_long[l][i] = dpb_[list[i]].ref == 2; }
         }
     }
     if (sh.type == SL_B && rf.slot[1][0] >= 0) {
-        if (dpb_[rf.slot[1][0]].coded_as_fields) { stat_errors_++; fail("direct prediction from a picture coded as two fields is not supported"); return; }
-        task.col = dpb_[rf.slot[1][0]].mf; rf.col = task.col.get();
+        const DpbPic &c = dpb_[rf.slot[1][0]];
+        if (c.coded_as_fields) {
+            // 8.4.1.2.1: RefPicList1[0] is a complementary field pair: the motion of the field nearer in order count (the top field only when strictly nearer)
+            const int q = std::abs(c.fpoc[0] - rf.cur_poc) < std::abs(c.fpoc[1] - rf.cur_poc) ? 0 : 1;
+            task.col = c.mf_fld[q]; rf.col_mode = 2;
+            if (c.have != 3 || !task.col) { stat_errors_++; note_error("colocated field pair incomplete"); task.col.reset(); }
+        } else task.col = c.mf;
+        rf.col = task.col.get();
     }
 }
 

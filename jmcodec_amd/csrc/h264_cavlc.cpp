@@ -402,15 +402,27 @@ struct P {
 
     // ---- direct prediction (8.4.1.2) of the 8x8 quadrants in mask -------------------------------------
     static int min_pos(int a, int b) { return (a >= 0 && b >= 0) ? (a < b ? a : b) : (a > b ? a : b); }
+    // motion that goes with block r of the current macroblock in the colocated picture (8.4.1.2.1).  The vertical vector is returned as stored; the
+    // identity of the referenced picture in the CURRENT picture's terms (Frm_To_Fld: the field of the current parity of that frame; Fld_To_Frm: the frame
+    // that holds that field)
     void col_block(int r, int &refc, int &mx, int &my, int32_t &uid) const {
         const MotionField &c = *rf.col;
+        size_t a = (size_t)addr;
+        if (rf.col_mode == 1) {                                    // mbAddrCol6, yM = (2 * yCol) % 16
+            const int yCol = (r >> 2) * 4, xCol = (r & 3) * 4;
+            a = (size_t)(2 * mb_y + yCol / 8) * mb_w + mb_x; r = (((2 * yCol) % 16) >> 2) * 4 + (xCol >> 2);
+        } else if (rf.col_mode == 2) {                             // mbAddrCol7, yM = 8 * (mb_y % 2) + 4 * (yCol / 8)
+            const int yCol = (r >> 2) * 4, xCol = (r & 3) * 4, yM = 8 * (mb_y % 2) + 4 * (yCol / 8);
+            a = (size_t)(mb_y / 2) * mb_w + mb_x; r = (yM >> 2) * 4 + (xCol >> 2);
+        }
         refc = -1; mx = my = 0; uid = -1;
-        if (c.intra[addr]) return;
+        if (a >= c.intra.size() || c.intra[a]) return;
         int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
-        int l = c.ref[0][(size_t)addr * 4 + b8] >= 0 ? 0 : 1;
-        refc = c.ref[l][(size_t)addr * 4 + b8];
+        int l = c.ref[0][a * 4 + b8] >= 0 ? 0 : 1;
+        refc = c.ref[l][a * 4 + b8];
         if (refc < 0) return;
-        mx = c.mv[l][(size_t)addr * 32 + r * 2]; my = c.mv[l][(size_t)addr * 32 + r * 2 + 1]; uid = c.uid[l][(size_t)addr * 4 + b8];
+        mx = c.mv[l][a * 32 + r * 2]; my = c.mv[l][a * 32 + r * 2 + 1]; uid = c.uid[l][a * 4 + b8];
+        if (rf.col_mode == 1) uid = (uid & ~1) | rf.cur_parity; else if (rf.col_mode == 2) uid &= ~1;
     }
     bool direct_pred(int mask) {
         if (!rf.col || rf.slot[1][0] < 0) { err = "direct prediction without RefPicList1[0]"; return false; }
@@ -449,6 +461,7 @@ struct P {
                     int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
                     int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cmx, cmy, r0 = 0; int32_t uid;
                     col_block(rc, refc, cmx, cmy, uid);
+                    if (rf.col_mode == 1) cmy = cmy / 2; else if (rf.col_mode == 2) cmy *= 2;      // 8.4.1.2.3: Frm_To_Fld ("/" towards zero), Fld_To_Frm
                     if (refc >= 0) {
                         r0 = -1;
                         for (int i = 0; i < sh.num_ref_idx[0]; i++) if (rf.slot[0][i] >= 0 && rf.uid[0][i] == uid) { r0 = i; break; }

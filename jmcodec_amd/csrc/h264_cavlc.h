@@ -59,6 +59,10 @@ struct SliceRefs {
     uint8_t is_long[2][32];
     int32_t cur_poc = 0;
     const MotionField *col = nullptr;   // motion of RefPicList1[0] (B slices)
+    // 8.4.1.2.1, Table 8-8 (no MBAFF): 0 = colocated picture coded like the current one (One_To_One); 1 = the current picture is a FIELD, `col` is the motion
+    // of the FRAME picture that holds RefPicList1[0] (Frm_To_Fld); 2 = the current picture is a FRAME, `col` is the motion of the field of the
+    // complementary field pair RefPicList1[0] that is nearer in order count (Fld_To_Frm).  uids: 2 x decode index of the store (+ parity for a field)
+    int col_mode = 0, cur_parity = 0;
     bool track_uid = false;        // the stream may contain B pictures: remember which picture every block refers to
     bool bipred_rec = false;       // every inter macroblock of this slice uses the MBM_BIPRED motion record (B slice / weighted prediction)
 };

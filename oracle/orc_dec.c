@@ -330,9 +330,7 @@ static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
     for (int i = 0; i < nact && i < 33; i++) d->ref_list[l][i] = list[i];
     d->ref_count[l] = nact;
     }
-    /* 8.4.1.2.1: the colocated field must come from a picture that was itself coded as a field (vertMvScale One_To_One); a field of a FRAME picture
-     * (Frm_To_Fld) is not supported */
-    if (nlists == 2 && d->ref_list[1][0] && !d->ref_list[1][0]->store->coded_fields) ORC_FAIL(d, "direct prediction of a field from a frame picture unsupported");
+    if (nlists == 2 && d->ref_list[1][0] && !d->asps->direct_8x8_inference) ORC_FAIL(d, "field pictures need direct_8x8_inference_flag");
     if (nlists == 2) d->stats[ORC_ST_B_FIELDS] += d->slice_num == 0;
     return 0;
 }
@@ -411,8 +409,8 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
         for (int i = 0; i < nact; i++) d->ref_list[l][i] = list[i];
         d->ref_count[l] = nact;
     }
-    /* 8.4.1.2.1: a frame whose colocated picture is a complementary field pair (Fld_To_Frm) is not supported */
-    if (nlists == 2 && d->ref_list[1][0] && d->ref_list[1][0]->coded_fields) ORC_FAIL(d, "direct prediction of a frame from a field pair unsupported");
+    /* 8.4.1.2.1 Fld_To_Frm needs both fields of the colocated pair */
+    if (nlists == 2 && d->ref_list[1][0] && d->ref_list[1][0]->coded_fields && d->ref_list[1][0]->have != 3) ORC_FAIL(d, "colocated field pair incomplete");
     return 0;
 }
 
@@ -622,7 +620,7 @@ const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
         "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
         "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures"};
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }

@@ -549,16 +549,38 @@ static int inter_recon(Sl *s) {
 
 /* ----------------------------- direct prediction (8.4.1.2) ---------------- */
 static int min_positive(int a, int b) { return (a >= 0 && b >= 0) ? orc_min(a, b) : orc_max(a, b); }
-/* colocated 4x4 block (8.4.1.2.1, frame pictures): motion of block r of the same macroblock in RefPicList1[0] */
-static void colocated(Sl *s, int r, int *ref_col, int mv_col[2], int *ref_pic_col) {
-    const Picture *col = s->d->ref_list[1][0];
-    const MbInfo *m = &col->mbs[s->mb_addr];
-    int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
+/* Colocated 4x4 block (8.4.1.2.1): the motion that goes with block r of the current macroblock in RefPicList1[0].  Tables 8-6 and 8-8 without MBAFF:
+ *   picture and colocated picture coded alike (frame / frame, field / field picture): the same macroblock, the same block (vertMvScale One_To_One);
+ *   a FIELD picture whose RefPicList1[0] is a field of a FRAME picture (Frm_To_Fld): mbAddrCol6 = 2 * W * (CurrMbAddr / W) + CurrMbAddr % W + W * (yCol / 8)
+ *     in the frame, yM = (2 * yCol) % 16;
+ *   a FRAME picture whose RefPicList1[0] is a complementary field pair (Fld_To_Frm): the field nearer in order count (the top one only when strictly
+ *     nearer), mbAddrCol7 = W * (CurrMbAddr / (2 * W)) + CurrMbAddr % W, yM = 8 * ((CurrMbAddr / W) % 2) + 4 * (yCol / 8).
+ * (xCol, yCol) = position of block r; the mixed cases only occur with direct_8x8_inference_flag = 1, so r is a corner block.
+ * *vscale: 0 / 1 (Frm_To_Fld) / 2 (Fld_To_Frm); *ref_pic_col: the identity of the referenced picture IN THE CURRENT PICTURE'S TERMS -- the field of the
+ * current parity of the referenced frame (1), the frame of the referenced field (2) (8.4.1.2.3). */
+static void colocated(Sl *s, int r, int *ref_col, int mv_col[2], int *ref_pic_col, int *vscale) {
+    OrcDec *d = s->d;
+    const Picture *l1 = d->ref_list[1][0], *st = l1->store ? l1->store : l1;
+    const int W = d->mb_w, xCol = (r & 3) * 4, yCol = (r >> 2) * 4;
+    const MbInfo *m; int rb = r;
+    *vscale = 0;
+    if (d->field_pic && !st->coded_fields) {
+        m = &st->mbs[(2 * s->mb_y + yCol / 8) * W + s->mb_x];
+        rb = (((2 * yCol) % 16) >> 2) * 4 + (xCol >> 2); *vscale = 1;
+    } else if (!d->field_pic && st->coded_fields) {
+        const int q = orc_abs(st->fpoc[0] - d->cur->poc) < orc_abs(st->fpoc[1] - d->cur->poc) ? 0 : 1;
+        const int yM = 8 * (s->mb_y % 2) + 4 * (yCol / 8);
+        m = &st->mbs[q * (W * (d->asps->mb_height / 2)) + (s->mb_y / 2) * W + s->mb_x];
+        rb = (yM >> 2) * 4 + (xCol >> 2); *vscale = 2;
+    } else m = &l1->mbs[s->mb_addr];
+    int b8 = (rb >> 3) * 2 + ((rb & 3) >> 1);
     *ref_col = -1; mv_col[0] = mv_col[1] = 0; *ref_pic_col = -1;
     if (m->is_intra || m->slice_num < 0) return;
     int l = m->ref_idx[0][b8] >= 0 ? 0 : 1;
     if (m->ref_idx[l][b8] < 0) return;
-    *ref_col = m->ref_idx[l][b8]; mv_col[0] = m->mv[l][r][0]; mv_col[1] = m->mv[l][r][1]; *ref_pic_col = m->ref_pic_id[l][b8];
+    *ref_col = m->ref_idx[l][b8]; mv_col[0] = m->mv[l][rb][0]; mv_col[1] = m->mv[l][rb][1]; *ref_pic_col = m->ref_pic_id[l][b8];
+    if (*vscale == 1) *ref_pic_col = 0x40000000 + 2 * *ref_pic_col + d->cur_parity;
+    if (*vscale == 2) *ref_pic_col = (*ref_pic_col - 0x40000000) >> 1;
 }
 /* derive refIdx / mv of the 8x8 quadrants in `mask` (bit b8) by direct prediction; marks them in direct8 */
 static int direct_pred(Sl *s, int mask) {
@@ -586,8 +608,9 @@ static int direct_pred(Sl *s, int mask) {
             for (int k = 0; k < 4; k++) {
                 int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1), r = by * 4 + bx;
                 int rc = inf8 ? ((b8 >> 1) * 3) * 4 + (b8 & 1) * 3 : r;       /* corner block of the quadrant when direct_8x8_inference */
-                int ref_col, mv_col[2], pid;
-                colocated(s, rc, &ref_col, mv_col, &pid);
+                int ref_col, mv_col[2], pid, vs;
+                colocated(s, rc, &ref_col, mv_col, &pid, &vs);          /* (colZeroFlag: the vectors as stored, whatever vertMvScale is) */
+                d->stats[ORC_ST_DIRECT_MIXED] += vs != 0;
                 int col_zero = col_short && ref_col == 0 && mv_col[0] >= -1 && mv_col[0] <= 1 && mv_col[1] >= -1 && mv_col[1] <= 1;
                 for (int l = 0; l < 2; l++) {
                     int z = zero || ref[l] < 0 || (ref[l] == 0 && col_zero);
@@ -601,8 +624,10 @@ static int direct_pred(Sl *s, int mask) {
             for (int k = 0; k < 4; k++) {
                 int bx = (b8 & 1) * 2 + (k & 1), by = (b8 >> 1) * 2 + (k >> 1), r = by * 4 + bx;
                 int rc = inf8 ? ((b8 >> 1) * 3) * 4 + (b8 & 1) * 3 : r;
-                int ref_col, mv_col[2], pid, ref0 = 0;
-                colocated(s, rc, &ref_col, mv_col, &pid);
+                int ref_col, mv_col[2], pid, ref0 = 0, vs;
+                colocated(s, rc, &ref_col, mv_col, &pid, &vs);
+                if (vs == 1) mv_col[1] = mv_col[1] / 2; else if (vs == 2) mv_col[1] *= 2;      /* 8.4.1.2.3 ("/": towards zero) */
+                d->stats[ORC_ST_DIRECT_MIXED] += vs != 0;
                 if (ref_col >= 0) {
                     ref0 = -1;
                     for (int i = 0; i < d->ref_count[0]; i++) if (d->ref_list[0][i] && d->ref_list[0][i]->id == pid) { ref0 = i; break; }

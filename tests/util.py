@@ -154,6 +154,12 @@ PAFF_CASES = {
     "paff_b_temporal_cabac": dict(width=96, height=64, frames=13, gop=13, mode=1, seed=212, paff=2, bframes=3, num_ref=3, cabac=1, direct_temporal=1, rplm=1),
     "paff_b_implicit_wp_t8x8": dict(width=80, height=96, frames=10, gop=10, mode=1, seed=213, paff=2, bframes=2, num_ref=4, wp=2, t8x8=1, direct_temporal=1),
     "paff_b_explicit_wp_real": dict(width=176, height=160, frames=7, gop=7, seed=214, paff=2, bframes=1, num_ref=2, wp=1, cabac=1, cabac_idc=2),
+    # frame and field pictures mixed around B pictures: the colocated picture of a B field may be a frame picture (Frm_To_Fld), that of a B frame a field
+    # pair (Fld_To_Frm) -- 8.4.1.2.1 Tables 8-6 / 8-8, vertical vectors halved / doubled in temporal direct prediction
+    "paff_mixed_b_spatial": dict(width=96, height=96, frames=13, gop=13, mode=1, seed=215, paff=1, bframes=2, num_ref=3, slices=2),
+    "paff_mixed_b_temporal_cabac": dict(width=96, height=64, frames=13, gop=13, mode=1, seed=216, paff=1, bframes=3, num_ref=3, cabac=1, direct_temporal=1, rplm=1),
+    "paff_mixed_b_implicit_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=217, paff=1, bframes=2, num_ref=4, wp=2, t8x8=1, direct_temporal=1),
+    "paff_mixed_b_real": dict(width=176, height=160, frames=10, gop=10, seed=218, paff=1, bframes=2, num_ref=2, cabac=1),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

@@ -56,7 +56,7 @@ def h264_params(r):
     if (cab or b) and r.random() < 0.25 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
         a.update(fmo0=1, dinf8=1)                                                                           # interlace-capable stream, frame pictures only
     if b and r.random() < 0.3 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
-        a.update(paff=2, dinf8=1)                                                                                    # B field pictures
+        a.update(paff=r.choice([1, 2]), dinf8=1)                                                                                    # B field pictures
         if a["cabac"]:
             a["t8x8"] = 0
     if not b and r.random() < 0.3 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:

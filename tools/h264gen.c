@@ -239,6 +239,8 @@ typedef struct FrameS {
     uint8_t fmark[2];              /* marking of each field of the store: 0 not a reference, 1 short-term, 2 long-term */
     int fpoc[2];                   /* TopFieldOrderCnt, BottomFieldOrderCnt */
     int parity;                    /* of a field picture: 0 top, 1 bottom */
+    int coded_fields;              /* the store was coded as two field pictures (its motion is kept per field, fld[].mf), not as a frame picture (mf) */
+    void *store_mf; int store_fields, store_id;   /* of a field: the frame picture's motion, coding and id of its store (refreshed when lists are built) */
 } Frame;
 
 typedef struct {
@@ -1547,14 +1549,32 @@ static void store_mv_l(Enc *e, MbE *m, int l, int bx, int by, int bw, int bh, in
     for (int y = by; y < by + bh; y++) for (int x = bx; x < bx + bw; x++) { mb_mv(m, l)[y * 4 + x][0] = (int16_t)mvx; mb_mv(m, l)[y * 4 + x][1] = (int16_t)mvy;
         e->decoded_mask |= 1 << (y * 4 + x); }
 }
-/* colocated motion (8.4.1.2.1) of 4x4 block r in the first picture of list 1 */
-static void col_motion(Enc *e, int mx, int my, int r, int *refidx, int mv[2], int *refid) {
-    const MbE *cm = &((const MbE *)e->list1[0]->mf)[my * e->mbw + mx];
-    int b8 = (r >> 3) * 2 + ((r & 3) >> 1);
+/* colocated motion (8.4.1.2.1, Tables 8-6 / 8-8) of 4x4 block r of the current macroblock in the first picture of list 1.
+   *vscale: 0 = the colocated picture is coded like the current one (One_To_One); 1 = a field picture takes the motion of a FRAME picture (Frm_To_Fld:
+   the field macroblock covers two frame macroblocks, vertical vectors are halved for temporal prediction); 2 = a frame picture takes the motion of one
+   FIELD of a field pair -- the one nearer in order count -- (Fld_To_Frm: vertical vectors doubled).  Only with direct_8x8_inference (r a corner block).
+   *refid names the referenced picture in the current picture's terms: the field of the current parity of that frame (1), the frame of that field (2). */
+static void col_motion(Enc *e, int mx, int my, int r, int *refidx, int mv[2], int *refid, int *vscale) {
+    const Frame *l1 = e->list1[0];
+    const MbE *cm; int rb = r;
+    *vscale = 0;
+    if (e->field && !l1->store_fields) {                      /* FLD x FRM */
+        const int yCol = (r >> 2) * 4, xCol = (r & 3) * 4, yM = (2 * yCol) % 16;
+        cm = &((const MbE *)l1->store_mf)[(2 * my + yCol / 8) * e->mbw + mx];
+        rb = (yM >> 2) * 4 + (xCol >> 2); *vscale = 1;
+    } else if (!e->field && l1->coded_fields) {               /* FRM x FLD */
+        const int yCol = (r >> 2) * 4, xCol = (r & 3) * 4, yM = 8 * (my % 2) + 4 * (yCol / 8);
+        const int q = ABS(l1->fpoc[0] - e->cur_poc) < ABS(l1->fpoc[1] - e->cur_poc) ? 0 : 1;
+        cm = &((const MbE *)l1->fld[q].mf)[(my / 2) * e->mbw + mx];
+        rb = (yM >> 2) * 4 + (xCol >> 2); *vscale = 2;
+    } else cm = &((const MbE *)l1->mf)[my * e->mbw + mx];
+    int b8 = (rb >> 3) * 2 + ((rb & 3) >> 1);
     *refidx = -1; mv[0] = mv[1] = 0; *refid = -1;
     if (cm->intra) return;
-    if (cm->ref[b8] >= 0) { *refidx = cm->ref[b8]; mv[0] = cm->mv[r][0]; mv[1] = cm->mv[r][1]; *refid = cm->refid[b8]; }
-    else if (cm->ref1[b8] >= 0) { *refidx = cm->ref1[b8]; mv[0] = cm->mv1[r][0]; mv[1] = cm->mv1[r][1]; *refid = cm->refid1[b8]; }
+    if (cm->ref[b8] >= 0) { *refidx = cm->ref[b8]; mv[0] = cm->mv[rb][0]; mv[1] = cm->mv[rb][1]; *refid = cm->refid[b8]; }
+    else if (cm->ref1[b8] >= 0) { *refidx = cm->ref1[b8]; mv[0] = cm->mv1[rb][0]; mv[1] = cm->mv1[rb][1]; *refid = cm->refid1[b8]; }
+    if (*refid >= 0 && *vscale == 1) *refid = (1 << 20) + 2 * *refid + (e->field - 1);
+    if (*refid >= 0 && *vscale == 2) *refid = (*refid - (1 << 20)) >> 1;
 }
 /* 8.4.1.2.2 / 8.4.1.2.3: fill refs and motion vectors of the 8x8 quadrants in mask */
 static void b_direct(Enc *e, int mx, int my, MbE *m, int mask) {
@@ -1576,8 +1596,8 @@ static void b_direct(Enc *e, int mx, int my, MbE *m, int mask) {
             m->ref[q] = (int8_t)ref[0]; m->ref1[q] = (int8_t)ref[1];
             for (int k = 0; k < 4; k++) {
                 int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
-                int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid;
-                col_motion(e, mx, my, rc, &cref, cmv, &cid);
+                int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid, vs;
+                col_motion(e, mx, my, rc, &cref, cmv, &cid, &vs);      /* (colZeroFlag looks at the vectors as they are stored: no vertical scaling) */
                 int still = cref == 0 && ABS(cmv[0]) <= 1 && ABS(cmv[1]) <= 1;     /* colZeroFlag (the list-1 picture is never long-term here) */
                 for (int l = 0; l < 2; l++) {
                     int zero = both_missing || ref[l] < 0 || (ref[l] == 0 && still);
@@ -1588,8 +1608,9 @@ static void b_direct(Enc *e, int mx, int my, MbE *m, int mask) {
     } else {
         for (int q = 0; q < 4; q++) if (mask & (1 << q)) for (int k = 0; k < 4; k++) {
             int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
-            int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid, r0 = 0;
-            col_motion(e, mx, my, rc, &cref, cmv, &cid);
+            int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, cref, cmv[2], cid, r0 = 0, vs;
+            col_motion(e, mx, my, rc, &cref, cmv, &cid, &vs);
+            if (vs == 1) cmv[1] = cmv[1] / 2; else if (vs == 2) cmv[1] *= 2;     /* 8.4.1.2.3: Frm_To_Fld / Fld_To_Frm */
             if (cref >= 0) { r0 = 0; for (int i = e->nlist0 - 1; i >= 0; i--) if (e->list0[i]->id == cid) r0 = i; }
             int pd = e->list1[0]->poc - e->list0[r0]->poc, pb = e->cur_poc - e->list0[r0]->poc;
             int td = CLIP3(-128, 127, pd), tb = CLIP3(-128, 127, pb), v0[2], v1[2];
@@ -1606,7 +1627,7 @@ static void b_direct(Enc *e, int mx, int my, MbE *m, int mask) {
 }
 /* temporal direct needs the colocated block's reference in list 0; the generator only emits it when that holds for every block */
 static int temporal_direct_ok(Enc *e, int mx, int my) {
-    for (int r = 0; r < 16; r++) { int cref, cmv[2], cid, found = 0; col_motion(e, mx, my, r, &cref, cmv, &cid); if (cref < 0) continue;
+    for (int r = 0; r < 16; r++) { int cref, cmv[2], cid, found = 0, vs; col_motion(e, mx, my, r, &cref, cmv, &cid, &vs); if (cref < 0) continue;
         for (int i = 0; i < e->nlist0; i++) if (e->list0[i]->id == cid) found = 1;
         if (!found) return 0; }
     return 1;
@@ -2022,7 +2043,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         for (int i = 0; i < e->nrefs; i++) {
             Frame *s = &e->refs[i];
             for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
-                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; }
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; }
             if (s->fmark[0] != 1 && s->fmark[1] != 1) continue;
             if (s->poc <= e->cur_poc) before[nb++] = s; else after[na++] = s;
         }
@@ -2046,7 +2067,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         for (int i = 0; i < e->nrefs; i++) {
             Frame *s = &e->refs[i];
             for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
-                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; }
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; }
             if (s->fmark[0] == 1 || s->fmark[1] == 1) sh[ns++] = s;
             if (s->fmark[0] == 2 || s->fmark[1] == 2) lg[nl++] = s;
         }
@@ -2308,7 +2329,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
                 if (idr) e->max_lt_idx = -1;
                 if (e->nrefs >= p->num_ref) { fprintf(stderr, "h264gen: no free frame store for a field\n"); abort(); }
                 full_cur.frame_num = curfn; full_cur.is_long = 0; full_cur.lt_idx = -1; full_cur.fmark[par] = 1; full_cur.fmark[par ^ 1] = 0;
-                full_cur.poc = field_poc;
+                full_cur.poc = field_poc; full_cur.coded_fields = 1;
                 e->cur_store_id = full_cur.id;
                 Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = full_cur; e->cur = t_; e->nrefs++;
             } else {
@@ -2397,7 +2418,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         if (p->paff) {
             /* the frame's two fields as pictures of their own, for the field pictures that follow */
             for (int i = 0; i < e->nrefs; i++) if (e->refs[i].is_long) e->refs[i].fmark[0] = e->refs[i].fmark[1] = 2;
-            e->cur.fmark[0] = e->cur.fmark[1] = e->cur.is_long ? 2 : 1;
+            e->cur.fmark[0] = e->cur.fmark[1] = e->cur.is_long ? 2 : 1; e->cur.coded_fields = 0;
             e->cur.fpoc[0] = e->cur.poc - MIN(0, e->delta_bottom); e->cur.fpoc[1] = e->cur.fpoc[0] + e->delta_bottom;
             for (int q = 0; q < 2; q++) { field_copy(&e->cur, &e->cur.fld[q], q, e->W, e->H, 1); frame_finish_ref(&e->cur.fld[q], e->W, e->H / 2); }
         }
@@ -2409,7 +2430,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
 
 /* one frame of the stream: a frame picture, or (PAFF) two field pictures -- the first of either parity */
 static void encode_frame(Enc *e, int t, int is_b) {
-    int as_fields = e->p.paff && (e->p.paff == 2 || (!is_b && rnd_n(&e->rng, 2)));
+    int as_fields = e->p.paff && (e->p.paff == 2 || rnd_n(&e->rng, 2));
     if (!as_fields) { encode_picture(e, t, is_b, 0, 0); return; }
     int first = 1 + rnd_n(&e->rng, 2);
     encode_picture(e, t, is_b, first, 0);
@@ -2439,8 +2460,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     p->poc_bottom = p->poc_bottom != 0;
     p->scaling = CLIP3(0, 2, p->scaling);
     p->paff = CLIP3(0, 2, p->paff);
-    /* B pictures in a PAFF stream: only when EVERY picture is a field pair (colocated data of a field then always come from a field picture) */
-    if (p->paff) { p->fmo0 = 1; if (p->paff != 2) p->bframes = 0; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
+    if (p->paff) { p->fmo0 = 1; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
     if (p->bframes) p->mmco = 0;
     e->max_lt_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
