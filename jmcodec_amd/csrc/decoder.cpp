@@ -963,7 +963,7 @@ void Decoder::mark_current(const SliceHeader &sh) {                             
 }
 
 // 8.2.5 for a FIELD picture: operations name fields by their field picture numbers (8.2.4.1); the sliding window leaves the second field of a reference
-// frame alone (8.2.5.3).  Operations 3, 5 and 6 in a field picture are not supported: the handle fails.
+// frame alone (8.2.5.3).  Operation 5 in a field picture is not supported: the handle fails.
 void Decoder::mark_current_field(const SliceHeader &sh) {
     DpbPic &cur = dpb_[cur_];
     const int par = sh.bottom_field, max_fn = 1 << seq_.log2_max_frame_num;
@@ -975,12 +975,27 @@ void Decoder::mark_current_field(const SliceHeader &sh) {
         return;
     }
     for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i]; if (p.in_use) p.frame_num_wrap = p.frame_num > sh.frame_num ? p.frame_num - max_fn : p.frame_num; }
+    bool made_long = false;
     if (sh.adaptive_marking) {
         const int cur_pic_num = 2 * sh.frame_num + 1;
         for (int k = 0; k < sh.n_mark; k++) {
             const MarkOp &m = sh.mark[k];
-            if (m.op == 3 || m.op == 5 || m.op == 6) { stat_errors_++; fail("memory management operation 3, 5 or 6 in a field picture is not supported"); return; }
+            if (m.op == 5) { stat_errors_++; fail("memory management operation 5 in a field picture is not supported"); return; }
             const int pic_num_x = cur_pic_num - (int)(m.a + 1);
+            if (m.op == 3 || m.op == 6) {
+                // 8.2.5.4.3 / 8.2.5.4.6: a field -- the one picNumX names, or the current one -- becomes long-term with LongTermFrameIdx m.b.  Whoever holds
+                // that index loses it first, except the other field of the SAME frame (the two fields of a long-term pair share their index)
+                int owner = m.op == 6 ? cur_ : -1, owner_q = par;
+                if (m.op == 3) for (int i = 0; i < n_surf_; i++) { const DpbPic &p = dpb_[i]; if (!p.in_use) continue;
+                    for (int q = 0; q < 2; q++) if (!(i == cur_ && q == par) && p.fmark[q] == 1 && 2 * p.frame_num_wrap + (q == par) == pic_num_x) {
+                        owner = i; owner_q = q; } }
+                if (owner < 0) { stat_errors_++; continue; }
+                for (int i = 0; i < n_surf_; i++) { DpbPic &p = dpb_[i];
+                    if (p.in_use && i != owner && p.lt_idx == (int)m.b) { for (int q = 0; q < 2; q++) if (p.fmark[q] == 2) p.fmark[q] = 0; p.sync_ref(); } }
+                dpb_[owner].lt_idx = (int)m.b;
+                if (m.op == 3) { dpb_[owner].fmark[owner_q] = 2; dpb_[owner].sync_ref(); } else made_long = true;
+                continue;
+            }
             for (int i = 0; i < n_surf_; i++) {
                 DpbPic &p = dpb_[i];
                 if (!p.in_use) continue;
@@ -1005,7 +1020,7 @@ void Decoder::mark_current_field(const SliceHeader &sh) {
         }
         if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].set_ref(0);
     }
-    cur.fmark[par] = 1; cur.sync_ref();
+    cur.fmark[par] = made_long ? 2 : 1; cur.sync_ref();
 }
 
 // C.4.5.2 / C.4.5.3 for a frame store that is complete -- a frame, both fields of a frame, or a field whose partner did not come --, with the display

@@ -493,12 +493,29 @@ static int mark_current_field(OrcDec *d) {
         Picture *p = &d->dpb[i];
         if (p->in_use) p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_frame_num : p->frame_num;
     }
+    int made_long = 0;
     if (sh->adaptive_marking) {
         const int cur_pic_num = 2 * sh->frame_num + 1;
         for (int k = 0; k < sh->n_mmco; k++) {
             const Mmco *m = &sh->mmco[k];
             const int pic_num_x = cur_pic_num - (m->diff_pic_nums_minus1 + 1);
-            if (m->op == 3 || m->op == 5 || m->op == 6) ORC_FAIL(d, "memory management operation %d in a field picture unsupported", m->op);
+            if (m->op == 5) ORC_FAIL(d, "memory management operation 5 in a field picture unsupported");
+            if (m->op == 3 || m->op == 6) {
+                /* 8.2.5.4.3 / 8.2.5.4.6: a field becomes long-term with LongTermFrameIdx idx.  The index is first taken away from whoever holds it --
+                 * except from the other field of the SAME frame (the two fields of a long-term pair share their index) */
+                Picture *owner = m->op == 6 ? cur : NULL; int owner_q = m->op == 6 ? par : -1;
+                if (m->op == 3) for (int i = 0; i <= ORC_MAX_DPB; i++) { Picture *p = &d->dpb[i]; if (!p->in_use) continue;
+                    for (int q = 0; q < 2; q++) if (!(p == cur && q == par) && p->fmark[q] == 1 && 2 * p->frame_num_wrap + (q == par) == pic_num_x) {
+                        owner = p; owner_q = q; } }
+                if (!owner) ORC_FAIL(d, "operation 3 names a missing field");
+                for (int i = 0; i <= ORC_MAX_DPB; i++) { Picture *p = &d->dpb[i];
+                    if (p->in_use && p != owner && p->long_term_frame_idx == m->long_term_frame_idx) { for (int q = 0; q < 2; q++) if (p->fmark[q] == 2) p->fmark[q] = 0;
+                        orc_sync_ref(p); } }
+                owner->long_term_frame_idx = m->long_term_frame_idx;
+                if (m->op == 3) { owner->fmark[owner_q] = 2; orc_sync_ref(owner); } else made_long = 1;
+                d->stats[ORC_ST_FIELD_LONG_OPS]++;
+                continue;
+            }
             for (int i = 0; i <= ORC_MAX_DPB; i++) {
                 Picture *p = &d->dpb[i];
                 if (!p->in_use) continue;
@@ -523,7 +540,7 @@ static int mark_current_field(OrcDec *d) {
         }
         if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) { set_ref(oldest, 0); d->stats[ORC_ST_FIELD_WINDOW]++; }
     }
-    cur->fmark[par] = 1;
+    cur->fmark[par] = made_long ? 2 : 1;
     orc_sync_ref(cur);
     return 0;
 }
@@ -620,7 +637,7 @@ const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
         "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
         "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed"};
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed", "field-long-term-ops"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }

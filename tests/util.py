@@ -142,7 +142,7 @@ B_CASES = {
 PAFF_CASES = {
     "paff_fields_cavlc": dict(width=96, height=96, frames=8, gop=8, seed=201, paff=2, num_ref=2),
     "paff_fields_cabac": dict(width=96, height=96, frames=8, gop=8, seed=202, paff=2, num_ref=2, cabac=1, cabac_idc=1),
-    "paff_adaptive_fuzz": dict(width=96, height=64, frames=14, gop=9, mode=1, seed=206, paff=1, num_ref=3, slices=2, rplm=1, mmco=1),
+    "paff_adaptive_fuzz": dict(width=96, height=64, frames=14, gop=9, mode=1, seed=204, paff=1, num_ref=3, slices=2, rplm=1, mmco=1),
     "paff_adaptive_fuzz_cabac_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=204, paff=1, num_ref=4, cabac=1, rplm=1, mmco=2, wp=1, poc_type=0,
                                         nonref_period=3),
     "paff_poc1_t8x8_scaling": dict(width=96, height=96, frames=12, gop=12, mode=1, seed=205, paff=1, num_ref=3, t8x8=1, scaling=1, poc_type=1, poc_bottom=1, deblock=2,

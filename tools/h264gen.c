@@ -263,6 +263,7 @@ typedef struct {
     int slice_id, slice_type, qp_run;
     Frame *list0[16]; int nlist0;
     Frame *list1[16]; int nlist1; int cur_poc;
+    int pending_long_idx;                 /* PAFF: LongTermFrameIdx the first field of the current frame took by operation 6 (-1: none): the second follows */
     Frame fsrc; int cur_store_id;         /* PAFF: the source field being coded; id of the frame store the first field of the current frame opened */
     int field, second;                    /* the picture being coded: 0 frame, 1 top field, 2 bottom field; it is the second field of its frame */
     const uint8_t *scan4, *scan8;         /* zig-zag or field scan (8.5.6 / 8.5.7) */
@@ -2146,16 +2147,42 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
     if (p->mmco && is_ref && !is_b && field) {
         /* Field pictures (8.2.5.4 with field picture numbers): now and then one reference FIELD is dropped (operation 1), or every field of one frame
            store (operation 1 per short-term field, operation 2 per long-term field).  The first field of a frame needs a free frame store and, with
-           operations present, gets no sliding window: stores are dropped until there is one.  (Operations 3, 4, 6 and 5 appear in the frame
-           pictures of the stream only.) */
-        uint8_t sim[5][2]; int n_used = 0;
-        for (int i = 0; i < e->nrefs; i++) { sim[i][0] = e->refs[i].fmark[0]; sim[i][1] = e->refs[i].fmark[1]; n_used += sim[i][0] || sim[i][1]; }
+           operations present, gets no sliding window: stores are dropped until there is one.  Long-term fields: both fields of a store are turned
+           long-term by two operations 3 with the same LongTermFrameIdx (the second must not free the index the first just took: 8.2.5.4.3), or the
+           current field by operation 6 -- then the second field of the frame follows with the same index --, after operation 4 has allowed indices.
+           (Operation 5 appears in the frame pictures of the stream only.) */
+        uint8_t sim[5][2]; int n_used = 0, sim_lt[5], maxlt = e->max_lt_idx;
+        for (int i = 0; i < e->nrefs; i++) { sim[i][0] = e->refs[i].fmark[0]; sim[i][1] = e->refs[i].fmark[1]; n_used += sim[i][0] || sim[i][1];
+            sim_lt[i] = e->refs[i].lt_idx; }
         int any_short = 0; for (int i = 0; i < e->nrefs; i++) if (i != cur_store) any_short |= sim[i][0] == 1 || sim[i][1] == 1;
         const int must = !idr && !second && !any_short && n_used >= p->num_ref;
 #define ADD_OP(o, a_, b_) do { e->mmco_op[e->n_mmco] = (o); e->mmco_a[e->n_mmco] = (a_); e->mmco_b[e->n_mmco] = (b_); e->n_mmco++; } while (0)
-#define DROP_FIELD(i_, q_) do { Frame *f_ = &e->refs[i_].fld[q_]; if (sim[i_][q_] == 1) ADD_OP(1, cur_pn - PN(f_) - 1, 0); else ADD_OP(2, LPN(f_), 0); \
+#define DROP_FIELD(i_, q_) do { Frame *f_ = &e->refs[i_].fld[q_]; if (sim[i_][q_] == 1) ADD_OP(1, cur_pn - PN(f_) - 1, 0); \
+        else ADD_OP(2, 2 * sim_lt[i_] + ((q_) == par), 0);      /* (the index may be one an earlier operation of this picture assigned) */ \
         sim[i_][q_] = 0; } while (0)
-        if (!idr && (must || rnd_n(&e->rng, 3) == 0)) {
+        const int follow_long = second && e->pending_long_idx >= 0;
+        if (!second) e->pending_long_idx = -1;
+#define FREE_IDX(ix_, keep_) do { for (int j_ = 0; j_ < e->nrefs; j_++) if (j_ != (keep_) && sim_lt[j_] == (ix_)) for (int q_ = 0; q_ < 2; q_++) \
+        if (sim[j_][q_] == 2) sim[j_][q_] = 0; } while (0)
+        if (follow_long) { ADD_OP(6, 0, e->pending_long_idx); }          /* (the index is the first field's: nothing else holds it) */
+        if (!idr && (must || follow_long || rnd_n(&e->rng, 3) == 0)) {
+            if (!follow_long && p->mmco && rnd_n(&e->rng, 3) == 0) {
+                /* a store with two short-term fields becomes a long-term pair */
+                int full[5], nf = 0;
+                for (int i = 0; i < e->nrefs; i++) if (i != cur_store && sim[i][0] == 1 && sim[i][1] == 1) full[nf++] = i;
+                if (nf > 0) {
+                    if (maxlt < 1) { ADD_OP(4, 2, 0); maxlt = 1; }
+                    const int i = full[rnd_n(&e->rng, nf)], ix = rnd_n(&e->rng, maxlt + 1);
+                    FREE_IDX(ix, i);
+                    for (int q = 0; q < 2; q++) { ADD_OP(3, cur_pn - PN(&e->refs[i].fld[q]) - 1, ix); sim[i][q] = 2; }
+                    sim_lt[i] = ix;
+                }
+            } else if (!follow_long && !second && p->mmco && rnd_n(&e->rng, 4) == 0) {
+                if (maxlt < 1) { ADD_OP(4, 2, 0); maxlt = 1; }
+                const int ix = rnd_n(&e->rng, maxlt + 1);
+                FREE_IDX(ix, -1);
+                ADD_OP(6, 0, ix); e->pending_long_idx = ix;
+            }
             int cand[10][2], nc = 0;
             for (int i = 0; i < e->nrefs; i++) if (i != cur_store) for (int q = 0; q < 2; q++) if (sim[i][q] == 1) { cand[nc][0] = i; cand[nc][1] = q; nc++; }
             if (nc > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, nc); DROP_FIELD(cand[k][0], cand[k][1]); }
@@ -2308,15 +2335,32 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             if (cur_store >= 0) e->refs[cur_store] = full_cur;
             if (e->n_mmco) {
                 for (int k = 0; k < e->n_mmco; k++) {
-                    int o = e->mmco_op[k], a = e->mmco_a[k], hit = 0;
+                    int o = e->mmco_op[k], a = e->mmco_a[k], b = e->mmco_b[k], hit = 0;
+                    if (o == 4) { e->max_lt_idx = a - 1; for (int i = 0; i < e->nrefs; i++) for (int q = 0; q < 2; q++) if (e->refs[i].fmark[q] == 2 &&
+                        e->refs[i].lt_idx > e->max_lt_idx) e->refs[i].fmark[q] = 0; continue; }
+                    if (o == 3 || o == 6) {
+                        /* the index is taken away from every long-term field that is not the partner of the field that gets it (8.2.5.4.3 / 8.2.5.4.6) */
+                        int owner = cur_store;                                           /* operation 6: the store of the current frame (-1: not open yet) */
+                        if (o == 3) { owner = -1; for (int i = 0; i < e->nrefs; i++) for (int q = 0; q < 2; q++) if (e->refs[i].fmark[q] == 1 &&
+                            PN(&e->refs[i].fld[q]) == cur_pn - (a + 1)) { owner = i; e->refs[i].fmark[q] = 2; hit = 1; }
+                            if (!hit) { fprintf(stderr, "h264gen: operation 3 names a missing field\n"); abort(); } }
+                        for (int i = 0; i < e->nrefs; i++) if (i != owner && e->refs[i].lt_idx == b) for (int q = 0; q < 2; q++) if (e->refs[i].fmark[q] == 2)
+                            e->refs[i].fmark[q] = 0;
+                        if (o == 3) e->refs[owner].lt_idx = b;
+                        continue;
+                    }
                     for (int i = 0; i < e->nrefs && !hit; i++) for (int q = 0; q < 2 && !hit; q++) {
                         Frame *f = &e->refs[i].fld[q];
-                        if ((o == 1 && e->refs[i].fmark[q] == 1 && PN(f) == cur_pn - (a + 1)) || (o == 2 && e->refs[i].fmark[q] == 2 && LPN(f) == a)) {
+                        if ((o == 1 && e->refs[i].fmark[q] == 1 && PN(f) == cur_pn - (a + 1)) || (o == 2 && e->refs[i].fmark[q] == 2 && 2 * e->refs[i].lt_idx + (q == par) == a)) {
                             e->refs[i].fmark[q] = 0; hit = 1;
                             if (!e->refs[i].fmark[0] && !e->refs[i].fmark[1]) { if (i == cur_store) abort(); REMOVE_REF(i); if (cur_store > i) cur_store--; }
                         }
                     }
                     if (!hit) { fprintf(stderr, "h264gen: field MMCO names a missing picture\n"); abort(); }
+                }
+                for (int i = e->nrefs - 1; i >= 0; i--) {                    /* stores left without a reference field go; whole long-term pairs are frames */
+                    if (!e->refs[i].fmark[0] && !e->refs[i].fmark[1]) { if (i == cur_store) abort(); REMOVE_REF(i); if (cur_store > i) cur_store--; continue; }
+                    e->refs[i].is_long = e->refs[i].fmark[0] == 2 && e->refs[i].fmark[1] == 2;
                 }
             } else if (!second && !idr && e->nrefs >= p->num_ref) {       /* sliding window (8.2.5.3); never for the second field of a reference frame */
                 int old = -1;
@@ -2328,13 +2372,15 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             if (!second) {
                 if (idr) e->max_lt_idx = -1;
                 if (e->nrefs >= p->num_ref) { fprintf(stderr, "h264gen: no free frame store for a field\n"); abort(); }
-                full_cur.frame_num = curfn; full_cur.is_long = 0; full_cur.lt_idx = -1; full_cur.fmark[par] = 1; full_cur.fmark[par ^ 1] = 0;
+                full_cur.frame_num = curfn; full_cur.is_long = 0; full_cur.lt_idx = e->pending_long_idx;
+                full_cur.fmark[par] = e->pending_long_idx >= 0 ? 2 : 1; full_cur.fmark[par ^ 1] = 0;
                 full_cur.poc = field_poc; full_cur.coded_fields = 1;
                 e->cur_store_id = full_cur.id;
                 Frame t_ = e->refs[e->nrefs]; e->refs[e->nrefs] = full_cur; e->cur = t_; e->nrefs++;
             } else {
                 Frame *s = &e->refs[cur_store];
-                s->fmark[par] = 1; s->poc = MIN(s->fpoc[0], s->fpoc[1]);
+                s->fmark[par] = e->pending_long_idx >= 0 ? 2 : 1; s->is_long = s->fmark[0] == 2 && s->fmark[1] == 2; s->poc = MIN(s->fpoc[0], s->fpoc[1]);
+                e->pending_long_idx = -1;
                 for (int q = 0; q < 2; q++) field_copy(s, &s->fld[q], q, e->W, e->H, 0);
                 frame_finish_ref(s, e->W, e->H);
                 e->frame_num++;
@@ -2462,7 +2508,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     p->paff = CLIP3(0, 2, p->paff);
     if (p->paff) { p->fmo0 = 1; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
     if (p->bframes) p->mmco = 0;
-    e->max_lt_idx = -1;
+    e->max_lt_idx = -1; e->pending_long_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
     else { p->poc_type = 0; p->nonref_period = 0; if (p->num_ref < 2) p->num_ref = 2; p->dinf8 = p->dinf8 != 0; }
