@@ -24,7 +24,8 @@ struct HevcCtb {                  // 32 bytes
     int8_t   sao_off[3][4];
     int8_t   beta_off, tc_off;    // slice_beta_offset_div2 / slice_tc_offset_div2 of the CTB's slice
     uint8_t  nb_mask;             // bit k set: SAO edge offset may use samples of neighbouring CTB k (L, R, T, B, TL, TR, BL, BR)
-    uint8_t  intra_bottom;        // some intra block of the CTB reaches its bottom row: the CTBs below (left, straight, right) read what it reconstructs
+    uint8_t  intra_edge;          // bit 0: some intra block of the CTB reaches its bottom row -- the CTBs below (left, straight, right) read what k_hevc_intra
+                                  // reconstructs there; bit 1: ... its right column -- the CTB to the right does
     uint32_t intra_first, intra_count;
 };
 static_assert(sizeof(HevcCtb) == 32, "HevcCtb layout");

@@ -303,8 +303,13 @@ constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 b
 __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParams *pics, int *progress, int prog_stride) {
     const HevcPicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & HPS_INTRA)) return;
-    const int cy = blockIdx.x;
+    // Each CTB row is cut into kHevcIntraSegs runs of CTBs, one workgroup each (block index = row * segments + segment: whatever a workgroup waits
+    // for -- CTBs of the row above, the last CTB of the run to its left -- has a smaller block index).  A run publishes "my CTBs up to column c are done"
+    // in its own counter.  Where intra blocks are scattered (P / B pictures) few CTBs wait for anything, and the runs of a row work side by side.
+    const int cy = (int)blockIdx.x / kHevcIntraSegs, seg = (int)blockIdx.x % kHevcIntraSegs;
     if (cy >= pp.ctb_h) return;
+    const int seg_w = (pp.ctb_w + kHevcIntraSegs - 1) / kHevcIntraSegs, c0 = seg * seg_w, c1 = min(pp.ctb_w, c0 + seg_w);
+    if (c0 >= c1) return;
     int *prog = progress + (size_t)blockIdx.y * prog_stride;
     __shared__ __align__(16) uint8_t ty[65 * kYS];            // luma tile
     __shared__ __align__(16) uint8_t tc[2][33 * kCS];         // Cb, Cr tiles
@@ -347,11 +352,11 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         if (x0 > 0 && tid <= cs) { const int y = y0 + tid - 1; if (y >= 0 && y < pp.h) pre.ly = surf[(size_t)y * pp.pitch + x0 - 1]; }
         if (x0 > 0 && tid <= hc) { const int y = yc0 + tid - 1; if (y >= 0 && y < ph) pre.lc = *(const uint16_t *)(cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1)); }
     };
-    auto next_intra = [&](int from) { int c = from; while (c < pp.ctb_w && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
-    int cx = next_intra(0), prev_cx = -2;
+    auto next_intra = [&](int from) { int c = from; while (c < c1 && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
+    int cx = next_intra(c0), prev_cx = -2;
     Pre pre;
-    if (cx < pp.ctb_w) prefetch(cx, pre);
-    while (cx < pp.ctb_w) {
+    if (cx < c1) prefetch(cx, pre);
+    while (cx < c1) {
     const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
     const int x0 = cx << pp.ctb_log2, xc0 = x0 >> 1;
     // ---- the left column out of the previous tile, when that CTB was the left neighbour (its samples may still be on their way to memory) ----
@@ -362,16 +367,23 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     }
     // ---- wait only for the coding tree blocks above (left, straight, right) that themselves hold intra blocks: the others were final before the launch
     //      (one counter per row "everything up to cx + 2 of the row above" chained every intra block of a picture to ALL intra blocks up and to the left) ----
-    int need = 0;
-    // ... and of those only the ones whose intra blocks reach their bottom row (HevcCtb.intra_bottom): in a P / B picture with scattered intra blocks that
-    // leaves few waits at all, and the rows of the picture run side by side instead of as a wavefront
-    if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 && col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_bottom) need = col + 1;
-    if (need && tid == 0) {
-        int spins = 0;
-        // Relaxed polls and NO fence: what the row above hands over -- its bottom rows -- is written through (st_wt16) before the counter moves, and
-        // read below with loads that go past the caches, exactly as the rows of an H.264 chain launch hand over their samples (chain_common.h).  An
-        // acquire / release pair here made every CTB invalidate and write back the XCD's L2.
-        while (ld_coh(&prog[cy - 1]) < need && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
+    // ... and of those only the ones whose intra blocks reach their bottom row (HevcCtb.intra_edge): in a P / B picture with scattered intra blocks that
+    // leaves few waits at all, and the rows of the picture run side by side instead of as a wavefront.  The CTB to the left matters when it belongs to the
+    // run before this one and its intra blocks reach its right column.
+    int need[kHevcIntraSegs + 1];
+    for (int &v : need) v = 0;
+    if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 && col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_edge & 1) need[col / seg_w] = col + 1;
+    const bool left_run = cx == c0 && cx > 0 && (pp.ctbs[cy * pp.ctb_w + cx - 1].intra_edge & 2);
+    if (left_run) need[kHevcIntraSegs] = cx;
+    if (tid == 0) {
+        // Relaxed polls and NO fence: what is handed over -- bottom rows, the last tile of a run -- is written through (st_wt16) before the counter moves,
+        // and read with loads that go past the caches, exactly as the rows of an H.264 chain launch hand over their samples (chain_common.h).  An acquire /
+        // release pair here made every CTB invalidate and write back the XCD's L2.
+        for (int s = 0; s <= kHevcIntraSegs; s++) if (need[s]) {
+            const int *ctr = s < kHevcIntraSegs ? &prog[(cy - 1) * kHevcIntraSegs + s] : &prog[cy * kHevcIntraSegs + seg - 1];
+            int spins = 0;
+            while (ld_coh(ctr) < need[s] && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(2);
+        }
     }
     __syncthreads();                                              // (also: everybody is done with the previous tile)
     const int n_tbs = (int)ctb.intra_count;
@@ -390,6 +402,11 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     if (yc0 > 0 && tid >= 64 && tid < 64 + 2 * q && xc0 + 8 * (tid - 64) < pw) {
         uint2 cb, crv; de_interleave(ld16_coh(cpl + (size_t)(yc0 - 1) * pp.pitch + 2 * (xc0 + 8 * (tid - 64))), cb, crv);
         *(uint2 *)&tc[0][kCO + 8 * (tid - 64)] = cb; *(uint2 *)&tc[1][kCO + 8 * (tid - 64)] = crv;
+    }
+    if (left_run) {                                               // the left column was written by another workgroup of this launch
+        if (tid >= 1 && tid <= cs && y0 + tid - 1 < pp.h) keep_ly = (uint32_t)ld_ref8<true>(surf + (size_t)(y0 + tid - 1) * pp.pitch + x0 - 1);
+        if (tid >= 1 && tid <= hc && yc0 + tid - 1 < ph) { const uint8_t *pc = cpl + (size_t)(yc0 + tid - 1) * pp.pitch + 2 * (xc0 - 1);
+            keep_lc = (uint32_t)ld_ref8<true>(pc) | (uint32_t)ld_ref8<true>(pc + 1) << 8; }
     }
     // (the corner above-left belongs to a CTB of the row above: it, too, may only be read now)
     if (tid == 128 && x0 > 0 && y0 > 0) keep_ly = (uint32_t)ld_ref8<true>(surf + (size_t)(y0 - 1) * pp.pitch + x0 - 1);
@@ -508,21 +525,32 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     }
     }   // wave < 3
     __syncthreads();
+    // ---- the last CTB of a run whose intra blocks reach its right column: the next run reads that column -- the whole tile is written through ----
+    const bool wt_all = (ctb.intra_edge & 2) && cx == c1 - 1 && c1 < pp.ctb_w;
+    if (wt_all) {
+        if (y_mine && y0 + yr < pp.h && x0 + 16 * yg < pp.w) st_wt16(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg, *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg]);
+        if (c_mine && yc0 + cr < ph && xc0 + 8 * cg < pw)
+            st_wt16(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg), interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg], *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_coh(&prog[cy * kHevcIntraSegs + seg], cx + 1);
+    } else {
     // ---- the bottom row of the CTB first: it is all the row below needs of this CTB; then the counter ----
     if (tid < q) { const int y = y0 + cs - 1; if (y < pp.h && x0 + 16 * tid < pp.w) st_wt16(surf + (size_t)y * pp.pitch + x0 + 16 * tid, *(const uint4 *)&ty[cs * kYS + kYO + 16 * tid]); }
     else if (tid < 2 * q) { const int g = tid - q, y = yc0 + hc - 1, x = xc0 + 8 * g;
         if (y < ph && x < pw) st_wt16(cpl + (size_t)y * pp.pitch + 2 * x, interleave(*(const uint2 *)&tc[0][hc * kCS + kCO + 8 * g], *(const uint2 *)&tc[1][hc * kCS + kCO + 8 * g])); }
     // (wave 0 holds every one of those write-through stores: once they are complete the counter may move)
     if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) st_coh(&prog[cy], cx + 1);
+    if (tid == 0) st_coh(&prog[cy * kHevcIntraSegs + seg], cx + 1);
     // ---- the rest of the tile (its intra blocks changed; the other samples are written back unchanged), off the chain ----
     if (y_mine && yr < cs - 1 && y0 + yr < pp.h && x0 + 16 * yg < pp.w) *(uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg) = *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg];
     if (c_mine && cr < hc - 1 && yc0 + cr < ph && xc0 + 8 * cg < pw)
         *(uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg)) = interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg], *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]);
+    }
     // rows of a CTB that reaches below the picture: the "bottom row" above lay outside, the last rows inside were written just now -- nobody waits for them
     prev_cx = cx;
     cx = next_intra(cx + 1);
-    if (cx < pp.ctb_w) prefetch(cx, pre);
+    if (cx < c1) prefetch(cx, pre);
     }   // CTBs of the row
 }
 
@@ -663,7 +691,7 @@ void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBat
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
         hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kHevcProgressStride, st);
-        hipLaunchKernelGGL(k_hevc_intra, dim3(m.max_ctb_h, n), dim3(kIntraThreads), 0, st, d_pics, progress, kHevcProgressStride);
+        hipLaunchKernelGGL(k_hevc_intra, dim3(m.max_ctb_h * kHevcIntraSegs, n), dim3(kIntraThreads), 0, st, d_pics, progress, kHevcProgressStride);
     }
     if (marks) hipEventRecord(marks[2], st);
     if (m.any_deblock) {

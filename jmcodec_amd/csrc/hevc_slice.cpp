@@ -742,16 +742,18 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
 }
 
 // 7.3.8.4
-// HevcCtb.intra_bottom: does an intra block of the CTB reach the CTB's (or the picture's) bottom row?  Only then do the CTBs below read samples that
-// k_hevc_intra reconstructs here -- everything else they see of this CTB was final before that kernel started, and they need not wait for it.
+// HevcCtb.intra_edge: does an intra block of the CTB reach the CTB's (or the picture's) bottom row / right column?  Only then do the CTBs below / the CTB to
+// the right read samples that k_hevc_intra reconstructs here -- everything else they see of this CTB was final before that kernel started, and they need
+// not wait for it.
 void HevcPicParser::note_intra_bottom(int rs) {
     HevcCtb &cj = jobs_->ctbs[rs];
-    const int y_end = std::min(h_, ((rs / ctb_w_) + 1) << sps_->log2_ctb);
-    cj.intra_bottom = 0;
-    for (uint32_t i = 0; i < cj.intra_count && !cj.intra_bottom; i++) {
+    const int y_end = std::min(h_, ((rs / ctb_w_) + 1) << sps_->log2_ctb), x_end = std::min(w_, ((rs % ctb_w_) + 1) << sps_->log2_ctb);
+    cj.intra_edge = 0;
+    for (uint32_t i = 0; i < cj.intra_count && cj.intra_edge != 3; i++) {
         const HevcIntraTb &t = jobs_->itbs[cj.intra_first + i];
         const int sc = t.plane ? 1 : 0;
-        if ((int)t.y + (1 << t.log2) >= (y_end >> sc)) cj.intra_bottom = 1;
+        if ((int)t.y + (1 << t.log2) >= (y_end >> sc)) cj.intra_edge |= 1;
+        if ((int)t.x + (1 << t.log2) >= (x_end >> sc)) cj.intra_edge |= 2;
     }
 }
 

@@ -329,6 +329,33 @@ def test_corrupt_streams_do_not_crash_or_hang():
                     assert len(f) == 96 * 80 * 3 // 2
 
 
+def test_corrupt_field_picture_streams_do_not_crash_or_hang():
+    """The same for interlaced streams: damaged field pictures (lost second fields, parities that do not pair, broken marking operations, B fields whose
+    colocated field never arrived) must neither crash nor dead-lock; every frame that comes out has the stream's size."""
+    bases = [streams.generate(**PARITY_CASES[c]) for c in ("paff_adaptive_fuzz", "paff_adaptive_fuzz_cabac_wp", "paff_mixed_b_temporal_cabac", "paff_b_spatial")]
+    sizes = [(PARITY_CASES[c]["width"], PARITY_CASES[c]["height"]) for c in ("paff_adaptive_fuzz", "paff_adaptive_fuzz_cabac_wp", "paff_mixed_b_temporal_cabac",
+                                                                            "paff_b_spatial")]
+    rng = np.random.default_rng(11)
+    for base, (w, h) in zip(bases, sizes):
+        for trial in range(12):
+            b = bytearray(base)
+            for _ in range(1 + trial % 4):
+                p = int(rng.integers(40, len(b)))
+                b[p] ^= 1 << int(rng.integers(0, 8))
+            if trial % 3 == 0:
+                b = b[:int(rng.integers(100, len(b)))]
+            if trial % 4 == 1:                                  # drop one NAL unit out of the middle (often a whole field)
+                st = [i for i in range(len(b) - 4) if b[i:i + 4] == b"\0\0\0\1" or (b[i:i + 3] == b"\0\0\1" and b[i - 1:i] != b"\0")]
+                if len(st) > 6:
+                    k = int(rng.integers(3, len(st) - 2))
+                    b = b[:st[k]] + b[st[k + 1]:]
+            with api.JmAmdDec(0, 1) as d:
+                frames = d.decode_stream(bytes(b))
+                assert len(frames) <= 16
+                for f in frames:
+                    assert len(f) == w * h * 3 // 2
+
+
 def test_thirdparty_high_profile_stream(oracle):
     """High profile (CABAC, 8x8 transform, Intra8x8) on the device: bit-exact with the oracle on the third-party clip."""
     import json, os
