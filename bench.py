@@ -298,6 +298,8 @@ def main():
     hc1 = host_cpu()
     tc1 = thread_cpu()
     memtrace("timed region done")
+    import resource as _res
+    peak_rss_timed_mb = round(_res.getrusage(_res.RUSAGE_SELF).ru_maxrss / 1024.0, 1)     # high-water mark up to here: handles, streams, the timed passes
     by_thread = {k: {"user_s": round(v[0] - tc0.get(k, [0, 0, 0])[0], 2), "sys_s": round(v[1] - tc0.get(k, [0, 0, 0])[1], 2), "threads": v[2]} for k,
         v in tc1.items()}
     by_thread = {k: v for k, v in by_thread.items() if v["user_s"] + v["sys_s"] >= 0.05}
@@ -634,10 +636,13 @@ def main():
                 mem[key] = None if v == "max" else round(int(v) / 1048576.0, 1)
             except (OSError, ValueError):
                 pass
-        mem["needed_for_8_gpus_mb"] = round(8 * mem["peak_rss_mb"], 0)
+        mem["peak_rss_timed_region_mb"] = peak_rss_timed_mb
+        mem["needed_for_8_gpus_mb"] = round(8 * peak_rss_timed_mb, 0)
         mem["job_slots_mb"] = job_slot_mb
         mem["job_slots_grown"] = job_regrown
-        mem["note"] = ("peak_rss_mb includes the Python / torch runtime and the untimed oracle check; job_slots_mb = page-locked job buffers of this "
+        mem["note"] = ("peak_rss_mb includes the untimed check pass and the CPU oracle; peak_rss_timed_region_mb is the high-water mark when the timed region "
+                       "ends (Python / torch runtime, the bitstreams, the handles) and what needed_for_8_gpus_mb multiplies; job_slots_mb = page-locked job "
+                       "buffers of this "
                        "rank's handles (ordinary-picture size; three worst-case buffers per handle are lent to I pictures)")
         line["host_memory"] = mem
     except Exception:
