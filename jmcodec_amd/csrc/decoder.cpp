@@ -152,6 +152,9 @@ int Decoder::set_option(const char *key, long long v) {
 }
 long long Decoder::get_stat(const char *key) const {
     std::string k(key);
+    if (k == "inferred_frames") return stat_inferred_frames_.load();
+    if (k == "field_pictures") return stat_field_pics_.load();
+    if (k == "lone_fields") return stat_lone_fields_.load();
     if (k == "frames") return num_frames_;
     if (k == "pictures") return stat_pictures_;
     if (k == "job_bytes") return stat_job_bytes_;
@@ -646,6 +649,40 @@ void Decoder::flush_dpb(std::vector<int> &out) {
     for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
 }
 
+// 8.2.5.2: a frame_num that no picture carried stands for a frame that was not sent (gaps_in_frame_num_value_allowed_flag; otherwise lost pictures, counted
+// as an error).  The frame is inferred: the sliding window runs as for any reference frame without marking operations, and the frame stays in the buffer as
+// a short-term reference "non-existing" -- it is in the reference lists, never displayed, and nothing may predict from it.  The order-count state of types
+// 1 and 2 follows the frame numbers.
+void Decoder::infer_frame(int fn) {
+    const int max_fn = 1 << seq_.log2_max_frame_num;
+    int nst = 0, nlt = 0, oldest = -1;
+    for (int i = 0; i < n_surf_; i++) {
+        DpbPic &p = dpb_[i];
+        if (!p.in_use) continue;
+        p.frame_num_wrap = p.frame_num > fn ? p.frame_num - max_fn : p.frame_num;
+        if (p.any_short()) { nst++; if (oldest < 0 || p.frame_num_wrap < dpb_[oldest].frame_num_wrap) oldest = i; }
+        else if (p.any_long()) nlt++;
+    }
+    if (nst + nlt >= std::max(seq_.max_num_ref_frames, 1) && oldest >= 0) dpb_[oldest].set_ref(0);
+    int slot = -1;
+    for (;;) {
+        for (int i = 0; i < n_surf_; i++) if (dpb_[i].in_use && i != pending_first_ && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
+        for (int k = 1; k <= n_surf_ && slot < 0; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) slot = i; }
+        if (slot >= 0) break;
+        int best = -1;                                      // C.4.5.3: no empty frame buffer -> the picture first in output order goes
+        for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && !dpb_[i].waiting_second && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
+        if (best < 0) { stat_errors_++; return; }
+        carry_out_.push_back(best | dpb_[best].lone << 8); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false;
+        dpb_[best].out_at = decode_count_ - 1;
+    }
+    DpbPic &c = dpb_[slot];
+    c = DpbPic(); c.in_use = true; c.set_ref(1); c.frame_num = fn; c.decode_idx = decode_count_++; c.have = 3; c.non_existing = true;
+    const long long prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
+    prev_frame_num_offset_ = prev_fn > fn ? prev_off + max_fn : prev_off; prev_frame_num_ = fn; prev_mmco5_ = false;
+    prev_ref_frame_num_ = fn;
+    stat_inferred_frames_++;
+}
+
 bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const PicParamSet &pps) {
     // 3.30 / 7.4.1.2.4: is this the SECOND field of the frame whose first field was the picture before it?  Opposite parity, the same frame_num, not an
     // IDR picture, and a reference field exactly if the first one is.  A first field that does not get its partner is complete as it stands.
@@ -659,6 +696,15 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
         if (seq_active_) flush_dpb(carry_out_);
         if (!activate(sps)) return false;
     } else if (sps.mb_w != mb_w_ || sps.mb_h != mb_h_) { stat_errors_++; return false; }
+    if (!second && !sh.idr && decode_count_ > 0) {
+        // 7.4.3: frame_num is PrevRefFrameNum or the one after it; anything else is a gap (a stream that STARTS without an IDR picture has no gap yet)
+        const int max_fn = 1 << seq_.log2_max_frame_num;
+        if (sh.frame_num != prev_ref_frame_num_ && sh.frame_num != (prev_ref_frame_num_ + 1) % max_fn) {
+            if (!seq_.gaps_allowed) stat_errors_++;
+            int guard = 0;
+            for (int fn = (prev_ref_frame_num_ + 1) % max_fn; fn != sh.frame_num && guard < max_fn; fn = (fn + 1) % max_fn, guard++) infer_frame(fn);
+        }
+    }
     int slot = -1;
     bool wait_pack = false;
     if (second) slot = pf;
@@ -671,13 +717,19 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
         for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i;
             break; } if (warm < 0) warm = i; } }
         if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
-        if (slot < 0) {                      // non-conformant stream: force room by displaying the oldest picture
+        while (slot < 0) {
+            // C.4.5.3: no empty frame buffer -> the pictures first in output order go until one is free (frames inferred from gaps in frame_num take buffers
+            // without passing through the output process, so this happens in conforming streams too)
             int best = -1;
-            for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
-            if (best < 0) { for (int i = 0; i < n_surf_; i++) if (best < 0 || dpb_[i].frame_num_wrap < dpb_[best].frame_num_wrap) best = i;
-                dpb_[best].set_ref(0); }
-            else { carry_out_.push_back(best | dpb_[best].lone << 8); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false; dpb_[best].set_ref(0); }
-            dpb_[best].in_use = false; slot = best; stat_errors_++;
+            for (int i = 0; i < n_surf_; i++) if (dpb_[i].wait_output && !dpb_[i].waiting_second && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
+            if (best < 0) {                  // nothing left to display, every buffer a reference: non-conformant stream -- the oldest reference goes
+                for (int i = 0; i < n_surf_; i++) if (best < 0 || dpb_[i].frame_num_wrap < dpb_[best].frame_num_wrap) best = i;
+                dpb_[best].set_ref(0); dpb_[best].in_use = false; slot = best; stat_errors_++;
+                break;
+            }
+            carry_out_.push_back(best | dpb_[best].lone << 8); display_pocs_.push_back(dpb_[best].poc); dpb_[best].wait_output = false;
+            dpb_[best].out_at = decode_count_ - 1;
+            if (!dpb_[best].ref) { dpb_[best].in_use = false; slot = best; wait_pack = true; }
         }
         last_surf_ = slot;
         DpbPic &c = dpb_[slot];
@@ -1072,6 +1124,7 @@ void Decoder::dispatch_pending() {
         const int par = cur_field_ - 1;
         mark_current_field(first_sh_);
         prev_frame_num_ = cur.frame_num; prev_mmco5_ = false;
+        if (first_sh_.nal_ref_idc) prev_ref_frame_num_ = cur.frame_num;
         cur.have |= 1 << par;
         cur_ = -1;
         if (!cur_second_) {
@@ -1086,6 +1139,7 @@ void Decoder::dispatch_pending() {
         cur.have = 3;
         mark_current(first_sh_);
         prev_frame_num_ = cur.frame_num;
+        if (first_sh_.nal_ref_idc) prev_ref_frame_num_ = cur.mmco5 ? 0 : cur.frame_num;
         prev_mmco5_ = cur.mmco5;                   // types 1 / 2: "the previous picture in decoding order included operation 5" (8.2.1.2, 8.2.1.3)
         // type 0: tempPicOrderCnt = Min(top, bottom) is subtracted from the picture's order counts (8.2.1); what the following pictures see as
         // prevPicOrderCntLsb is its TopFieldOrderCnt after that (> 0 when the bottom field lies below the top field)

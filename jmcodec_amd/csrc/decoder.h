@@ -34,6 +34,7 @@ struct DpbPic {                                // one frame store (C.4.5): a fra
     int fpoc[2] = {0, 0};                      // TopFieldOrderCnt, BottomFieldOrderCnt
     int have = 0;                              // bit 0 / 1: top / bottom field decoded (a frame picture: both)
     bool waiting_second = false, first_was_ref = false, coded_as_fields = false;
+    bool non_existing = false;                 // a frame inferred from a gap in frame_num (8.2.5.2): a short-term reference without samples, never displayed
     int lone = 0;                              // set when the store is complete: 1 / 2 = only its top / bottom field was decoded
     void set_ref(int v) { fmark[0] = fmark[1] = v; ref = v; }
     void sync_ref() { ref = (fmark[0] == 1 && fmark[1] == 1) ? 1 : (fmark[0] == 2 && fmark[1] == 2) ? 2 : (fmark[0] || fmark[1]) ? 3 : 0; }
@@ -160,6 +161,7 @@ private:
     void build_frame_ref_lists(const SliceHeader &sh, SliceTask &task);
     void mark_current_field(const SliceHeader &sh);
     void store_done(int slot, std::vector<int> &out);
+    void infer_frame(int frame_num);
     void bump_after_current(std::vector<int> &out);
     void flush_dpb(std::vector<int> &out);
     void push_task(std::unique_ptr<PicTask> t);
@@ -210,6 +212,8 @@ private:
     DpbPic dpb_[kMaxSurfaces];
     int cur_ = -1;
     int cur_field_ = 0; bool cur_second_ = false;   // the current picture: 0 frame, 1 top field, 2 bottom field; the second field of its frame
+    int prev_ref_frame_num_ = 0;                    // PrevRefFrameNum (7.4.3)
+    std::atomic<long long> stat_inferred_frames_{0};
     int pending_first_ = -1;                        // the frame store that holds a first field and waits for the second
     std::atomic<long long> stat_field_pics_{0}, stat_lone_fields_{0};
     std::unique_ptr<PicTask> pending_;

@@ -174,6 +174,44 @@ static Picture *field_view(OrcDec *d, Picture *s, int par) {
 
 static void store_done(OrcDec *d, Picture *cur);
 
+/* a free frame buffer; C.4.5.3: when there is none, the pictures first in output order go until there is (frames inferred from gaps in frame_num take
+ * buffers without passing through the output process) */
+static Picture *take_free_picture(OrcDec *d) {
+    release_unused(d);
+    for (;;) {
+        for (int i = 0; i <= ORC_MAX_DPB; i++) if (!d->dpb[i].in_use) return &d->dpb[i];
+        Picture *w = smallest_poc_waiting(d, NULL);
+        if (!w) return NULL;
+        emit(d, w); release_unused(d);
+    }
+}
+
+/* 8.2.5.2: a frame_num that no picture carried stands for a frame that was not sent.  The frame is inferred: the sliding window runs as for any reference
+ * frame without marking operations, and the frame stays in the buffer as a short-term reference "non-existing" -- in the lists, never output, and not to
+ * be predicted from.  The order-count state of types 1 and 2 follows the frame numbers. */
+static int infer_frame(OrcDec *d, int fn) {
+    const int max_frame_num = 1 << d->asps->log2_max_frame_num;
+    int nst = 0, nlt = 0; Picture *oldest = NULL;
+    for (int i = 0; i <= ORC_MAX_DPB; i++) {
+        Picture *p = &d->dpb[i];
+        if (!p->in_use) continue;
+        p->frame_num_wrap = p->frame_num > fn ? p->frame_num - max_frame_num : p->frame_num;
+        if (any_short(p)) { nst++; if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p; }
+        else if (any_long(p)) nlt++;
+    }
+    if (nst + nlt >= orc_max(d->asps->max_num_ref_frames, 1) && oldest) set_ref(oldest, 0);
+    Picture *f = take_free_picture(d);
+    if (!f) ORC_FAIL(d, "DPB overflow (no room for an inferred frame)");
+    f->in_use = 1; set_ref(f, 1); f->needed_for_output = 0; f->has_mmco5 = 0; f->have = 3; f->waiting_second = 0; f->non_existing = 1; f->coded_fields = 0;
+    f->id = d->next_pic_id++; f->frame_num = fn; f->is_idr = 0; f->long_term_frame_idx = -1; f->poc = f->fpoc[0] = f->fpoc[1] = 0; f->is_field = 0; f->store = f;
+    { const int n = d->mb_w * d->asps->mb_height; for (int i = 0; i < n; i++) f->mbs[i].slice_num = -1; }
+    const int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset, prev_fn = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num;
+    d->prev_frame_num_offset = prev_fn > fn ? prev_off + max_frame_num : prev_off; d->prev_frame_num = fn; d->prev_ref_has_mmco5 = 0;
+    d->prev_ref_frame_num = fn;
+    d->stats[ORC_ST_INFERRED_FRAMES]++;
+    return 0;
+}
+
 int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
     const Pps *pps = &d->pps[sh->pps_id];
     const Sps *sps = &d->sps[pps->sps_id];
@@ -195,17 +233,22 @@ int orc_start_picture(OrcDec *d, const SliceHdr *sh) {
         if (sps != d->asps && (sps->mb_width != d->mb_w || sps->mb_height != d->mb_h)) ORC_FAIL(d, "SPS change without IDR");
         d->asps = sps; d->apps = pps;
     }
+    if (!second && !sh->idr && d->decode_count > 0) {
+        /* 7.4.3: frame_num is PrevRefFrameNum or the one after it; anything else is a gap (gaps_in_frame_num_value_allowed_flag, or lost pictures) */
+        const int max_frame_num = 1 << sps->log2_max_frame_num;
+        if (sh->frame_num != d->prev_ref_frame_num && sh->frame_num != (d->prev_ref_frame_num + 1) % max_frame_num)
+            for (int fn = (d->prev_ref_frame_num + 1) % max_frame_num; fn != sh->frame_num; fn = (fn + 1) % max_frame_num) if (infer_frame(d, fn) < 0) return -1;
+    }
     Picture *cur = NULL;
     if (second) cur = pend;
     else {
-        release_unused(d);
-        for (int i = 0; i <= ORC_MAX_DPB; i++) if (!d->dpb[i].in_use) { cur = &d->dpb[i]; break; }
+        cur = take_free_picture(d);
         if (!cur) ORC_FAIL(d, "DPB overflow (no free picture)");
         cur->in_use = 1; set_ref(cur, 0); cur->needed_for_output = 0; cur->has_mmco5 = 0; cur->have = 0; cur->waiting_second = 0;
         cur->id = d->next_pic_id++; cur->decode_index = d->decode_count++;
         cur->frame_num = sh->frame_num; cur->is_idr = sh->idr; cur->long_term_frame_idx = -1;
         cur->frame_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? 1 : 2);
-        cur->first_was_ref = sh->nal_ref_idc != 0; cur->coded_fields = sh->field_pic;
+        cur->first_was_ref = sh->nal_ref_idc != 0; cur->coded_fields = sh->field_pic; cur->non_existing = 0;
         cur->is_field = 0; cur->store = cur;
         int n = d->mb_w * d->mb_h;
         for (int i = 0; i < n; i++) cur->mbs[i].slice_num = -1;
@@ -577,6 +620,7 @@ void orc_finish_picture(OrcDec *d) {
         const int par = d->cur_parity;
         d->mb_h = d->asps->mb_height; d->height = d->mb_h * 16;
         d->prev_frame_num = cur->frame_num; d->prev_ref_has_mmco5 = 0;
+        if (d->first_sh.nal_ref_idc) d->prev_ref_frame_num = cur->frame_num;
         cur->have |= 1 << par;
         d->cur = d->cur_store = NULL; d->field_pic = 0;
         if (!d->is_second_field) {
@@ -593,6 +637,7 @@ void orc_finish_picture(OrcDec *d) {
     mark_current(d);
     d->prev_frame_num = cur->frame_num;
     d->prev_ref_has_mmco5 = 0;
+    if (d->first_sh.nal_ref_idc) d->prev_ref_frame_num = cur->has_mmco5 ? 0 : cur->frame_num;
     if (cur->has_mmco5) {
         /* 7.4.3 / 8.2.1: after operation 5 the picture is inferred to have had frame_num 0, and tempPicOrderCnt = Min(top, bottom) is subtracted
          * from both of its order counts: PicOrderCnt becomes 0, and for pic_order_cnt_type 0 the NEXT pictures see prevPicOrderCntMsb = 0 and
@@ -637,7 +682,7 @@ const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
         "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
         "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed", "field-long-term-ops"};
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed", "field-long-term-ops", "inferred-frames"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }

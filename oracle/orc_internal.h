@@ -158,6 +158,7 @@ typedef struct Picture {
     int have;            /* bit 0 / bit 1: the top / bottom field has been decoded (a frame picture decodes both) */
     int waiting_second;  /* holds a first field whose second field may follow as the next picture */
     int first_was_ref;   /* nal_ref_idc != 0 of that first field (3.30: reference fields pair with reference fields) */
+    int non_existing;    /* a frame inferred from a gap in frame_num (8.2.5.2): a short-term reference without samples, never output */
     int coded_fields;    /* the store was filled by field pictures (its MbInfo are two field arrays), not by a frame picture */
     /* FIELD VIEW (OrcDec.fview): the lines of one parity of a store as a picture of half the height and twice the stride -- what a field picture
      * is decoded into and predicts from.  is_ref, poc, pic_num, long_term_pic_num of a view are the FIELD's (8.2.4.1). */
@@ -183,6 +184,7 @@ struct OrcDec {
     int next_pic_id, decode_count;
     /* POC state */
     int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5; int cur_top_poc, cur_bot_poc;
+    int prev_ref_frame_num;   /* PrevRefFrameNum (7.4.3): frame_num of the previous reference picture (0 after an IDR picture or operation 5) */
     /* TopFieldOrderCnt / BottomFieldOrderCnt of the current picture (pic_order_cnt_type 0) */
     /* slice state */
     SliceHdr sh; SliceHdr first_sh;
@@ -220,7 +222,7 @@ enum { ORC_ST_I4, ORC_ST_I8, ORC_ST_I16, ORC_ST_PCM, ORC_ST_PSKIP, ORC_ST_P16, O
           reference field only, intra macroblock edges that got bS 3 because they run horizontally through a field, vector pairs whose vertical
           difference of 2 or 3 counted only because of the field rule, fields that stayed without partner */
        ORC_ST_FIELD_PICS, ORC_ST_SECOND_FIELDS, ORC_ST_CROSS_PARITY, ORC_ST_FIELD_MMCO, ORC_ST_FIELD_RPLM, ORC_ST_FIELD_WINDOW, ORC_ST_FIELD_LONG,
-       ORC_ST_HALF_STORE, ORC_ST_FIELD_BS3, ORC_ST_FIELD_MVY, ORC_ST_LONE_FIELD, ORC_ST_B_FIELDS, ORC_ST_DIRECT_MIXED, ORC_ST_FIELD_LONG_OPS, ORC_ST_N };
+       ORC_ST_HALF_STORE, ORC_ST_FIELD_BS3, ORC_ST_FIELD_MVY, ORC_ST_LONE_FIELD, ORC_ST_B_FIELDS, ORC_ST_DIRECT_MIXED, ORC_ST_FIELD_LONG_OPS, ORC_ST_INFERRED_FRAMES, ORC_ST_N };
 
 #define ORC_FAIL(d, ...) do { snprintf((d)->err, sizeof((d)->err), __VA_ARGS__); return -1; } while (0)
 

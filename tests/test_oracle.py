@@ -9,7 +9,7 @@ import pytest
 
 from jmcodec_amd import api
 from tools import streams
-from util import ALL_CASES, PAFF_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
+from util import ALL_CASES, GAPS_CASES, PAFF_CASES, PARITY_CASES, golden_meta, golden_stream, md5, unescape
 
 
 def _recon(kw):
@@ -46,6 +46,15 @@ def test_field_picture_streams_exercise_the_field_rules(oracle):
                  "half-marked-stores", "field-bS3", "field-mvy-limit", "b-field-pictures", "B_Direct", "B_Skip", "direct-frame-field-mixed", "field-long-term-ops"):
         assert seen.get(tool, 0) > 0, f"no field-picture stream exercises {tool}"
     assert seen["second-fields"] * 2 == seen["field-pictures"] and "lone-fields" not in seen
+
+
+def test_gap_streams_make_the_decoder_infer_frames(oracle):
+    """8.2.5.2: every gaps case really skips frame_num values, and references beyond index 0 are used (so a decoder that ignored the inferred frames would
+    pick the wrong pictures)."""
+    for name in sorted(GAPS_CASES):
+        t = oracle.tools(streams.generate(**GAPS_CASES[name]))
+        assert t.get("inferred-frames", 0) > 0, name
+    assert sum(oracle.tools(streams.generate(**GAPS_CASES[n])).get("ref>0", 0) for n in GAPS_CASES) > 0
 
 
 def test_a_field_without_partner_is_shown_with_its_lines_repeated(oracle):

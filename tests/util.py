@@ -161,6 +161,15 @@ PAFF_CASES = {
     "paff_mixed_b_implicit_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=217, paff=1, bframes=2, num_ref=4, wp=2, t8x8=1, direct_temporal=1),
     "paff_mixed_b_real": dict(width=176, height=160, frames=10, gop=10, seed=218, paff=1, bframes=2, num_ref=2, cabac=1),
 }
+# gaps_in_frame_num_value_allowed_flag = 1 and frame_num values that no picture carries (8.2.5.2): the decoder infers the frames that were not sent -- they pass
+# through the sliding window (older pictures leave earlier than they otherwise would) and sit in the initial lists, shifting the indices of the real ones
+GAPS_CASES = {
+    "gaps_fuzz_multiref": dict(width=96, height=80, frames=20, gop=20, mode=1, num_ref=3, seed=221, gaps=1, rplm=1),
+    "gaps_mmco_cabac_poc1": dict(width=96, height=80, frames=24, gop=12, mode=1, num_ref=3, seed=222, gaps=1, mmco=1, cabac=1, poc_type=1),
+    "gaps_real_nonref_poc2": dict(width=128, height=96, frames=16, gop=16, seed=223, gaps=1, num_ref=2, nonref_period=3, poc_type=2),
+    "gaps_paff_cabac": dict(width=96, height=96, frames=16, gop=16, mode=1, seed=224, gaps=1, paff=1, num_ref=3, cabac=1),
+}
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)
 ALL_CASES.update(PAFF_CASES)
+ALL_CASES.update(GAPS_CASES)

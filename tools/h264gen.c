@@ -66,6 +66,9 @@ typedef struct {
                                    pictures (first field of either parity), drawn per picture (P-only streams); 2 = every picture as two fields (B
                                    pictures allowed).  With
                                    CABAC the 8x8 transform is switched off (the contexts 436..459 of field-coded 8x8 blocks are not pinned, SPEC_AUDIT.md) */
+    int gaps;                   /* 1: gaps_in_frame_num_value_allowed_flag = 1 and, now and then, one or two frame_num values are skipped before a P picture
+                                   (P-only streams): the decoder must infer frames that were never sent (8.2.5.2) -- they pass through the sliding window,
+                                   push older pictures out and sit in the reference lists, where nothing may predict from them */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -239,6 +242,7 @@ typedef struct FrameS {
     uint8_t fmark[2];              /* marking of each field of the store: 0 not a reference, 1 short-term, 2 long-term */
     int fpoc[2];                   /* TopFieldOrderCnt, BottomFieldOrderCnt */
     int parity;                    /* of a field picture: 0 top, 1 bottom */
+    int nonexist;                  /* a frame the decoder has to infer from a gap in frame_num (8.2.5.2): a short-term reference with no samples */
     int coded_fields;              /* the store was coded as two field pictures (its motion is kept per field, fld[].mf), not as a frame picture (mf) */
     void *store_mf; int store_fields, store_id;   /* of a field: the frame picture's motion, coding and id of its store (refreshed when lists are built) */
 } Frame;
@@ -267,6 +271,8 @@ typedef struct {
     Frame fsrc; int cur_store_id;         /* PAFF: the source field being coded; id of the frame store the first field of the current frame opened */
     int field, second;                    /* the picture being coded: 0 frame, 1 top field, 2 bottom field; it is the second field of its frame */
     const uint8_t *scan4, *scan8;         /* zig-zag or field scan (8.5.6 / 8.5.7) */
+    int after_op5;                        /* the previous picture carried operation 5 */
+    int usable[16], n_usable;             /* the entries of list 0 that exist (gaps in frame_num leave entries nothing may predict from) */
     int *pocs; /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
     int poc_base;                         /* display index at which the picture order count restarted (IDR picture, or a picture with operation 5) */
     int cur_top, delta_bottom, delta0;    /* TopFieldOrderCnt of the current picture; delta_pic_order_cnt_bottom / [1]; delta_pic_order_cnt[0] (type 1) */
@@ -1372,32 +1378,35 @@ static void mc_mb(Enc *e, int mx, int my, MbE *m);
 static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
     Frame *c = &e->cur; BitW *w = &e->bw; int fuzz = e->p.mode == 1;
     int px = mx * 16, py = my * 16, nref = e->nlist0;
+    const int r0 = e->n_usable ? e->usable[0] : 0;                      /* the first entry of list 0 that exists (gaps in frame_num: GenParams.gaps) */
     /* ---- decide intra vs inter ---- */
     int want_intra = 0, force_intra = -1;
     if (fuzz) { int k = rnd_n(&e->rng, 16); if (k == 0) { want_intra = 1; force_intra = -1; } else if (k == 1 && rnd_n(&e->rng, 4) == 0) { want_intra = 1;
         force_intra = 7; } if (e->p.no_intra) want_intra = 0; }
     static __thread MbCode mc; memset(&mc, 0, sizeof mc);
     int try_skip = fuzz && !want_intra && rnd_n(&e->rng, 8) < 2;
-    int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {0, 0, 0, 0};
+    if (r0 != 0) try_skip = 0;                                           /* P_Skip predicts from entry 0 */
+    int type = 0, sub[4] = {0, 0, 0, 0}, refs[4] = {r0, r0, r0, r0};
     int mvs[16][2]; memset(mvs, 0, sizeof mvs);
     int skipmv[2]; skip_mv(e, mx, my, m, skipmv);
     if (!want_intra) {
         if (fuzz) {
             type = rnd_n(&e->rng, 4);
-            for (int i = 0; i < 4; i++) { sub[i] = rnd_n(&e->rng, 4); refs[i] = nref > 1 ? rnd_n(&e->rng, nref) : 0; }
+            for (int i = 0; i < 4; i++) { sub[i] = rnd_n(&e->rng, 4); refs[i] = nref > 1 ? rnd_n(&e->rng, nref) : 0;
+                if (e->n_usable < e->nlist0) refs[i] = e->usable[refs[i] % e->n_usable]; }
             if (type == 0) refs[1] = refs[2] = refs[3] = refs[0];
             else if (type == 1) { refs[1] = refs[0]; refs[3] = refs[2]; }
             else if (type == 2) { refs[2] = refs[0]; refs[3] = refs[1]; }
             if (try_skip) { type = 0; refs[0] = refs[1] = refs[2] = refs[3] = 0; }
         } else {
-            int mvp[2]; pred_mv(e, mx, my, m, 0, 0, 4, 0, 0, 0, mvp);
-            MvRes r16 = search_block(e, e->list0[0], px, py, 16, 16, mvp, skipmv[0], skipmv[1], e->p.search);
+            int mvp[2]; pred_mv(e, mx, my, m, 0, 0, 4, r0, 0, 0, mvp);
+            MvRes r16 = search_block(e, e->list0[r0], px, py, 16, 16, mvp, skipmv[0], skipmv[1], e->p.search);
             for (int k = 0; k < 16; k++) { mvs[k][0] = r16.mvx; mvs[k][1] = r16.mvy; }
             type = 0;
             if (r16.cost > 16 * 16 * 4) {
                 /* try an 8x8 split around the 16x16 vector */
                 MvRes r8[4]; int tot = 0, c8[2] = { r16.mvx, r16.mvy };
-                for (int i = 0; i < 4; i++) { r8[i] = search_block(e, e->list0[0], px + (i & 1) * 8, py + (i >> 1) * 8, 8, 8, c8, r16.mvx, r16.mvy, 2);
+                for (int i = 0; i < 4; i++) { r8[i] = search_block(e, e->list0[r0], px + (i & 1) * 8, py + (i >> 1) * 8, 8, 8, c8, r16.mvx, r16.mvy, 2);
                     tot += r8[i].cost; }
                 if (tot + 16 * 12 < r16.cost) {
                     int same_h = r8[0].mvx == r8[1].mvx && r8[0].mvy == r8[1].mvy && r8[2].mvx == r8[3].mvx && r8[2].mvy == r8[3].mvy;
@@ -1409,7 +1418,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
                             mvs[(by + (k >> 1)) * 4 + bx + (k & 1)][1] = r8[i].mvy; }
                         if (type == 3 && r8[i].cost > 8 * 8 * 6) {     /* 4x4 split of a still-poor 8x8 */
                             int c4[2] = { r8[i].mvx, r8[i].mvy }, t4 = 0; MvRes r4[4];
-                            for (int k = 0; k < 4; k++) { r4[k] = search_block(e, e->list0[0], px + bx * 4 + (k & 1) * 4, py + by * 4 + (k >> 1) * 4, 4, 4, c4,
+                            for (int k = 0; k < 4; k++) { r4[k] = search_block(e, e->list0[r0], px + bx * 4 + (k & 1) * 4, py + by * 4 + (k >> 1) * 4, 4, 4, c4,
                                 c4[0], c4[1], 1); t4 += r4[k].cost; }
                             if (t4 + 40 < r8[i].cost) {
                                 int sh = r4[0].mvx == r4[1].mvx && r4[0].mvy == r4[1].mvy && r4[2].mvx == r4[3].mvx && r4[2].mvy == r4[3].mvy;
@@ -1424,7 +1433,7 @@ static void encode_p_mb(Enc *e, int mx, int my, MbE *m, int *skip_run) {
             }
             /* intra fallback when inter prediction is poor */
             int best_cost = 0;
-            for (int k = 0; k < 16; k++) best_cost += sad_inter(e, e->list0[0], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, mvs[k][0], mvs[k][1]);
+            for (int k = 0; k < 16; k++) best_cost += sad_inter(e, e->list0[r0], px + (k & 3) * 4, py + (k >> 2) * 4, 4, 4, mvs[k][0], mvs[k][1]);
             if (best_cost > 16 * 16 * 10) {
                 int aA = intra_ok(e, mb_avail(e, mx - 1, my)), aB = intra_ok(e, mb_avail(e, mx, my - 1)), p16[256];
                 big_predict(c->y + py * c->sy + px, c->sy, 16, 2, aA, aB, p16);
@@ -1941,7 +1950,7 @@ static void write_sps_pps(Enc *e) {
         bw_put(w, 1, 0); bw_se(w, e->t1_nonref); bw_se(w, e->t1_t2b); bw_ue(w, e->t1_cycle);
         for (int i = 0; i < e->t1_cycle; i++) bw_se(w, e->t1_ref[i]);
     }
-    bw_ue(w, p->num_ref); bw_put(w, 1, 0);
+    bw_ue(w, p->num_ref); bw_put(w, 1, (uint32_t)(p->gaps != 0));      /* max_num_ref_frames, gaps_in_frame_num_value_allowed_flag */
     bw_ue(w, e->mbw - 1); bw_ue(w, (p->fmo0 ? e->mbh / 2 : e->mbh) - 1);   /* pic_height_in_map_units: field macroblock rows when frame_mbs_only_flag = 0 */
     if (p->fmo0) { bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 1); }  /* frame_mbs_only_flag 0, mb_adaptive_frame_field_flag 0,
         direct_8x8_inference_flag 1 */
@@ -1999,6 +2008,31 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
     const int par = field ? field - 1 : 0;
     if (!second) render_source(e, t);
     if (idr) { e->frame_num = 0; e->nrefs = 0; e->poc_base = t; write_sps_pps(e); }
+    /* (not right after operation 5: that picture's frame_num counts as 0 afterwards, the next one has 1 -- with a gap it could repeat the very frame_num
+       and order count the operation-5 picture was sent with, and 7.4.1.2.4 could not tell the two apart) */
+    const int gap_ok = !e->after_op5;
+    if (!second) e->after_op5 = 0;
+    if (p->gaps && !idr && !is_b && !second && gap_ok && e->nrefs > 0 && rnd_n(&e->rng, 4) == 0) {
+        /* 8.2.5.2: one or two frame_num values are left out.  For each of them the decoder infers a frame: the sliding window runs as for any
+           reference frame, and the frame stays in the buffer as a short-term reference without samples */
+        const int mfn = 1 << e->log2_max_fn;
+        for (int k = 1 + rnd_n(&e->rng, 2); k > 0; k--) {
+            const int fn = e->frame_num & (mfn - 1);
+            if (e->nrefs >= p->num_ref) {
+                int old = -1;
+#define WRAP_(f) ((f)->frame_num > fn ? (f)->frame_num - mfn : (f)->frame_num)
+                for (int i = 0; i < e->nrefs; i++) if ((p->paff ? e->refs[i].fmark[0] == 1 || e->refs[i].fmark[1] == 1 : !e->refs[i].is_long) &&
+                    (old < 0 || WRAP_(&e->refs[i]) < WRAP_(&e->refs[old]))) old = i;
+#undef WRAP_
+                if (old < 0) break;                                        /* only long-term pictures left: the window has nothing to drop */
+                { Frame t_ = e->refs[old]; for (int q_ = old; q_ + 1 < e->nrefs; q_++) e->refs[q_] = e->refs[q_ + 1]; e->nrefs--; e->refs[e->nrefs] = t_; }
+            }
+            Frame *f = &e->refs[e->nrefs++];
+            f->frame_num = fn; f->is_long = 0; f->lt_idx = -1; f->nonexist = 1; f->fmark[0] = f->fmark[1] = 1; f->coded_fields = 0; f->id = e->next_id++;
+            f->poc = f->fpoc[0] = f->fpoc[1] = 0;
+            e->frame_num++;
+        }
+    }
     /* the store of the frame being coded: a frame, or the first field of a non-reference frame, is coded into e->cur; the second field of a reference
        frame into the store its first field already opened (e->refs[cur_store]) */
     int cur_store = -1;
@@ -2044,7 +2078,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         for (int i = 0; i < e->nrefs; i++) {
             Frame *s = &e->refs[i];
             for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
-                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; }
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; f->nonexist = s->nonexist; }
             if (s->fmark[0] != 1 && s->fmark[1] != 1) continue;
             if (s->poc <= e->cur_poc) before[nb++] = s; else after[na++] = s;
         }
@@ -2068,7 +2102,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         for (int i = 0; i < e->nrefs; i++) {
             Frame *s = &e->refs[i];
             for (int q = 0; q < 2; q++) { Frame *f = &s->fld[q]; f->frame_num = s->frame_num; f->is_long = s->fmark[q] == 2; f->lt_idx = s->lt_idx; f->parity = q;
-                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; }
+                f->poc = s->fpoc[q]; f->id = (1 << 20) + 2 * s->id + q; f->store_mf = s->mf; f->store_fields = s->coded_fields; f->store_id = s->id; f->nonexist = s->nonexist; }
             if (s->fmark[0] == 1 || s->fmark[1] == 1) sh[ns++] = s;
             if (s->fmark[0] == 2 || s->fmark[1] == 2) lg[nl++] = s;
         }
@@ -2122,6 +2156,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         int m = 1 + rnd_n(&e->rng, MIN(nact, 3)), pred = cur_pn, idx = 0;
         for (int k = 0; k < m; k++) {
             Frame *tg = init[l][rnd_n(&e->rng, ninit[l])];
+            if (tg->nonexist) { m = k; break; }                          /* (a frame that was never sent is not named) */
             if (tg->is_long) { e->mod_idc[l][k] = 2; e->mod_val[l][k] = LPN(tg); }
             else {
                 int pn = PN(tg), nowrap = pn < 0 ? pn + max_pn : pn, diff = nowrap - pred;
@@ -2140,6 +2175,9 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         for (int i = 0; i < nact; i++) if (list[i]) { (l ? e->list1 : e->list0)[cnt++] = list[i]; } else break;
         if (l) e->nlist1 = cnt; else e->nlist0 = cnt;
     }
+    e->n_usable = 0;
+    for (int i = 0; i < e->nlist0 && i < 16; i++) if (!(field ? e->list0[i]->nonexist : e->list0[i]->nonexist)) e->usable[e->n_usable++] = i;
+    if (e->slice_type == 0 && e->n_usable == 0) e->slice_type = 2;      /* nothing to predict from */
     /* 8.2.5: marking of this picture (decided before the slices are written; applied after the picture is coded) */
     e->n_mmco = 0; e->idr_long = 0;
     int half_stores = 0;            /* PAFF: frame stores of which only one field is (still) a reference; no frame picture number names them */
@@ -2169,7 +2207,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             if (!follow_long && p->mmco && rnd_n(&e->rng, 3) == 0) {
                 /* a store with two short-term fields becomes a long-term pair */
                 int full[5], nf = 0;
-                for (int i = 0; i < e->nrefs; i++) if (i != cur_store && sim[i][0] == 1 && sim[i][1] == 1) full[nf++] = i;
+                for (int i = 0; i < e->nrefs; i++) if (i != cur_store && sim[i][0] == 1 && sim[i][1] == 1 && !e->refs[i].nonexist) full[nf++] = i;
                 if (nf > 0) {
                     if (maxlt < 1) { ADD_OP(4, 2, 0); maxlt = 1; }
                     const int i = full[rnd_n(&e->rng, nf)], ix = rnd_n(&e->rng, maxlt + 1);
@@ -2211,8 +2249,9 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             else if (must || rnd_n(&e->rng, 3) == 0) {
 #define DROP_LT(ix) do { for (int q_ = 0; q_ < lt_n; q_++) if (lt_ix[q_] == (ix)) { lt_ix[q_] = lt_ix[--lt_n]; break; } } while (0)
             if (maxlt < 1 && rnd_n(&e->rng, 2)) { ADD_OP(4, 2, 0); maxlt = 1; }
-            if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1);
-                ADD_OP(3, curfn - st_fn[k] - 1, ix); DROP_LT(ix); lt_ix[lt_n++] = ix; st_fn[k] = st_fn[--st_n]; }
+            if (maxlt >= 0 && st_n > 0 && rnd_n(&e->rng, 2)) { int k = rnd_n(&e->rng, st_n), ix = rnd_n(&e->rng, maxlt + 1), ne = 0;
+                for (int i = 0; i < e->nrefs; i++) if (!e->refs[i].is_long && e->refs[i].nonexist && PICNUM(&e->refs[i]) == st_fn[k]) ne = 1;
+                if (!ne) { ADD_OP(3, curfn - st_fn[k] - 1, ix); DROP_LT(ix); lt_ix[lt_n++] = ix; st_fn[k] = st_fn[--st_n]; } }   /* (never a frame that was not sent) */
             if (st_n > 0 && rnd_n(&e->rng, 3) == 0) { int k = rnd_n(&e->rng, st_n); ADD_OP(1, curfn - st_fn[k] - 1, 0); st_fn[k] = st_fn[--st_n]; }
             if (lt_n > 0 && rnd_n(&e->rng, 4) == 0) { int k = rnd_n(&e->rng, lt_n); ADD_OP(2, lt_ix[k], 0); lt_ix[k] = lt_ix[--lt_n]; }
             if (maxlt >= 0 && rnd_n(&e->rng, 4) == 0) { int ix = rnd_n(&e->rng, maxlt + 1); ADD_OP(6, 0, ix); DROP_LT(ix); cur_long = 1; }
@@ -2241,8 +2280,8 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
             (e->ww[l][i][2] != (1 << e->wlog[1]) || e->wo[l][i][2] != 0)) e->wo[l][i][1] = 1;
         /* one chroma flag covers Cb and Cr */
     }
-    if (!field) e->cur.id = e->next_id++;
-    else { if (!second) full_cur.id = e->next_id++; e->cur.id = (1 << 20) + 2 * full_cur.id + par; }
+    if (!field) { e->cur.id = e->next_id++; e->cur.nonexist = 0; }
+    else { if (!second) { full_cur.id = e->next_id++; full_cur.nonexist = 0; } e->cur.id = (1 << 20) + 2 * full_cur.id + par; e->cur.nonexist = 0; }
     int mbs_total = e->mbw * e->mbh, rows_per = (e->mbh + p->slices - 1) / p->slices;
     for (int i = 0; i < mbs_total; i++) e->mbs[i].slice = -1;
     for (int sl = 0, first_row = 0; first_row < e->mbh; sl++, first_row += rows_per) {
@@ -2451,7 +2490,7 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
                     /* every reference picture is dropped; the picture is inferred to have had frame_num 0 (7.4.3) and its order counts are
                        reduced by Min(top, bottom) (8.2.1): what follows counts from here */
                     while (e->nrefs > 0) REMOVE_REF(0);
-                    e->max_lt_idx = -1; e->cur.frame_num = 0; e->cur.poc = 0; e->frame_num = 0; e->poc_base = t;
+                    e->max_lt_idx = -1; e->cur.frame_num = 0; e->cur.poc = 0; e->frame_num = 0; e->poc_base = t; e->after_op5 = 1;
                     if (e->pocs) e->pocs[t] = 0;
                 }
             }
@@ -2507,7 +2546,8 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     p->scaling = CLIP3(0, 2, p->scaling);
     p->paff = CLIP3(0, 2, p->paff);
     if (p->paff) { p->fmo0 = 1; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
-    if (p->bframes) p->mmco = 0;
+    if (p->bframes) { p->mmco = 0; p->gaps = 0; }
+    p->gaps = p->gaps != 0;
     e->max_lt_idx = -1; e->pending_long_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
@@ -2578,7 +2618,7 @@ int main(int argc, char **argv) {
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
         OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm",
-            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff)
+            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff) OPT("--gaps", gaps)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
