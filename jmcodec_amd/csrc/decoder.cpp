@@ -153,6 +153,7 @@ int Decoder::set_option(const char *key, long long v) {
 long long Decoder::get_stat(const char *key) const {
     std::string k(key);
     if (k == "inferred_frames") return stat_inferred_frames_.load();
+    if (k == "redundant_slices") return stat_redundant_slices_.load();
     if (k == "field_pictures") return stat_field_pics_.load();
     if (k == "lone_fields") return stat_lone_fields_.load();
     if (k == "frames") return num_frames_;
@@ -538,6 +539,9 @@ void Decoder::handle_nal(const uint8_t *nal, size_t len) {
     SliceHeader sh;
     std::string e = ps_.parse_slice_header(br, type, ref_idc, sh);
     if (!e.empty()) { stat_errors_++; note_error(e); return; }
+    // a redundant coded picture repeats (part of) the primary one for the case that it was lost; the primary picture is what is decoded (7.4.3: "the
+    // decoding process ... of redundant coded pictures is not specified"), its redundant copies are dropped
+    if (sh.redundant_pic_cnt > 0) { stat_redundant_slices_++; return; }
     const PicParamSet &pps = ps_.pps[sh.pps_id];
     const SeqParams &sps = ps_.sps[pps.sps_id];
     if (pending_ && !same_picture(first_sh_, sh)) dispatch_pending();

@@ -213,7 +213,7 @@ private:
     int cur_ = -1;
     int cur_field_ = 0; bool cur_second_ = false;   // the current picture: 0 frame, 1 top field, 2 bottom field; the second field of its frame
     int prev_ref_frame_num_ = 0;                    // PrevRefFrameNum (7.4.3)
-    std::atomic<long long> stat_inferred_frames_{0};
+    std::atomic<long long> stat_inferred_frames_{0}, stat_redundant_slices_{0};
     int pending_first_ = -1;                        // the frame store that holds a first field and waits for the second
     std::atomic<long long> stat_field_pics_{0}, stat_lone_fields_{0};
     std::unique_ptr<PicTask> pending_;

@@ -196,7 +196,7 @@ std::string ParamSets::parse_slice_header(BitReader &br, int nal_type, int nal_r
     if (s.poc_type == 0) { sh.poc_lsb = br.u(s.log2_max_poc_lsb); if (p.bottom_field_poc_present && !sh.field_pic) sh.delta_poc_bottom = br.se(); }
     else if (s.poc_type == 1 && !s.delta_pic_order_always_zero) { sh.delta_poc[0] = br.se();
         if (p.bottom_field_poc_present && !sh.field_pic) sh.delta_poc[1] = br.se(); }
-    if (p.redundant_pic_cnt_present) br.ue();
+    if (p.redundant_pic_cnt_present) { const uint32_t r = br.ue(); if (r > 127) return "redundant_pic_cnt out of range"; sh.redundant_pic_cnt = (int)r; }
     if (sh.type == SL_B) sh.direct_spatial_mv_pred = br.u1();
     sh.num_ref_idx[0] = p.num_ref_idx_default[0]; sh.num_ref_idx[1] = p.num_ref_idx_default[1];
     if (sh.type != SL_I && br.u1()) {

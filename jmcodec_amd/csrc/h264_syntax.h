@@ -52,6 +52,7 @@ struct MarkOp { uint8_t op; uint32_t a, b; };      // a: diff_pic_nums_minus1 / 
 struct SliceHeader {
     int nal_ref_idc = 0; bool idr = false;
     int first_mb = 0, type = SL_I, pps_id = 0, frame_num = 0, idr_pic_id = 0;
+    int redundant_pic_cnt = 0;                          // > 0: a slice of a redundant coded picture (7.4.3): dropped (decoder.cpp handle_nal)
     bool field_pic = false, bottom_field = false;      // the picture is ONE FIELD of a frame (PAFF), decoded as a picture of half the height
     int poc_lsb = 0, delta_poc_bottom = 0, delta_poc[2] = {0, 0};
     int num_ref_idx[2] = {0, 0};

@@ -682,7 +682,7 @@ const char *orc_tool_name(int i) {
     static const char *nm[ORC_ST_N] = {"I4x4", "I8x8", "I16x16", "I_PCM", "P_Skip", "P16x16", "P16x8", "P8x16", "P8x8", "sub<8x8", "T8x8-inter",
         "cabac-slices", "cavlc-slices", "idc0", "idc1", "idc2", "ref>0", "B_Skip", "B_Direct", "B-inter", "exact-slice-ends",
         "field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed", "field-long-term-ops", "inferred-frames"};
+        "half-marked-stores", "field-bS3", "field-mvy-limit", "lone-fields", "b-field-pictures", "direct-frame-field-mixed", "field-long-term-ops", "inferred-frames", "redundant-slices-dropped"};
     return i >= 0 && i < ORC_ST_N ? nm[i] : NULL;
 }
 long orc_tool_count(const OrcDec *d, int i) { return i >= 0 && i < ORC_ST_N ? d->stats[i] : 0; }
@@ -722,6 +722,7 @@ int orc_decode_nal(OrcDec *d, const uint8_t *nal, size_t len) {
     case 1: case 5: {
         SliceHdr sh;
         if (orc_parse_slice_header(d, &b, type, ref_idc, &sh) < 0) return -1;
+        if (sh.redundant_pic_cnt > 0) { d->stats[ORC_ST_REDUNDANT]++; return 0; }      /* 7.4.3: redundant coded pictures are not decoded */
         if (d->cur && !same_picture(&d->first_sh, &sh)) orc_finish_picture(d);
         if (!d->cur) { if (orc_start_picture(d, &sh) < 0) return -1; }
         else d->slice_num++;

@@ -222,7 +222,7 @@ enum { ORC_ST_I4, ORC_ST_I8, ORC_ST_I16, ORC_ST_PCM, ORC_ST_PSKIP, ORC_ST_P16, O
           reference field only, intra macroblock edges that got bS 3 because they run horizontally through a field, vector pairs whose vertical
           difference of 2 or 3 counted only because of the field rule, fields that stayed without partner */
        ORC_ST_FIELD_PICS, ORC_ST_SECOND_FIELDS, ORC_ST_CROSS_PARITY, ORC_ST_FIELD_MMCO, ORC_ST_FIELD_RPLM, ORC_ST_FIELD_WINDOW, ORC_ST_FIELD_LONG,
-       ORC_ST_HALF_STORE, ORC_ST_FIELD_BS3, ORC_ST_FIELD_MVY, ORC_ST_LONE_FIELD, ORC_ST_B_FIELDS, ORC_ST_DIRECT_MIXED, ORC_ST_FIELD_LONG_OPS, ORC_ST_INFERRED_FRAMES, ORC_ST_N };
+       ORC_ST_HALF_STORE, ORC_ST_FIELD_BS3, ORC_ST_FIELD_MVY, ORC_ST_LONE_FIELD, ORC_ST_B_FIELDS, ORC_ST_DIRECT_MIXED, ORC_ST_FIELD_LONG_OPS, ORC_ST_INFERRED_FRAMES, ORC_ST_REDUNDANT, ORC_ST_N };
 
 #define ORC_FAIL(d, ...) do { snprintf((d)->err, sizeof((d)->err), __VA_ARGS__); return -1; } while (0)
 

@@ -329,6 +329,16 @@ def test_corrupt_streams_do_not_crash_or_hang():
                     assert len(f) == 96 * 80 * 3 // 2
 
 
+def test_arbitrary_slice_order_on_device(oracle):
+    """Baseline's arbitrary slice order: the slices of every picture rearranged; same frames as the oracle's (job lists are per macroblock, the kernels
+    never see slice order)."""
+    from test_oracle import reorder_slices
+    data = streams.generate(width=176, height=144, frames=6, gop=6, mode=1, num_ref=2, slices=3, seed=78)
+    want = oracle.decode(data, 1)[0]
+    for order in ((2, 0, 1), (1, 2, 0)):
+        assert b"".join(gpu_decode(reorder_slices(data, order))) == want, order
+
+
 def test_corrupt_field_picture_streams_do_not_crash_or_hang():
     """The same for interlaced streams: damaged field pictures (lost second fields, parities that do not pair, broken marking operations, B fields whose
     colocated field never arrived) must neither crash nor dead-lock; every frame that comes out has the stream's size."""

@@ -168,6 +168,9 @@ GAPS_CASES = {
     "gaps_mmco_cabac_poc1": dict(width=96, height=80, frames=24, gop=12, mode=1, num_ref=3, seed=222, gaps=1, mmco=1, cabac=1, poc_type=1),
     "gaps_real_nonref_poc2": dict(width=128, height=96, frames=16, gop=16, seed=223, gaps=1, num_ref=2, nonref_period=3, poc_type=2),
     "gaps_paff_cabac": dict(width=96, height=96, frames=16, gop=16, mode=1, seed=224, gaps=1, paff=1, num_ref=3, cabac=1),
+    # redundant_pic_cnt_present_flag = 1 with slices of redundant coded pictures behind the primary ones (their payload is not slice data): dropped
+    "redundant_slices_baseline": dict(width=96, height=80, frames=8, gop=8, mode=1, num_ref=2, slices=2, seed=225, redundant=1),
+    "redundant_slices_cabac_b": dict(width=96, height=80, frames=9, gop=9, mode=1, num_ref=2, seed=226, redundant=1, cabac=1, bframes=2, gaps=0),
 }
 ALL_CASES = dict(PARITY_CASES)
 ALL_CASES.update(B_CASES)

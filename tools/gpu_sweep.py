@@ -63,6 +63,8 @@ def h264_params(r):
         a.update(paff=r.choice([1, 2]), poc_type=r.choice([0, 1, 2]), poc_bottom=r.randint(0, 1), nonref_period=r.choice([0, 0, 3]))      # field pictures
         if a.get("mmco"):
             a["mmco"] = r.choice([1, 2])
+    if r.random() < 0.15:
+        a["redundant"] = 1                                                                                            # slices of redundant coded pictures
     if not b and r.random() < 0.25:
         a["gaps"] = 1                                                                                                 # frame_num values nobody sends (8.2.5.2)
     if r.random() < 0.4:

@@ -69,6 +69,9 @@ typedef struct {
     int gaps;                   /* 1: gaps_in_frame_num_value_allowed_flag = 1 and, now and then, one or two frame_num values are skipped before a P picture
                                    (P-only streams): the decoder must infer frames that were never sent (8.2.5.2) -- they pass through the sliding window,
                                    push older pictures out and sit in the reference lists, where nothing may predict from them */
+    int redundant;              /* 1: redundant_pic_cnt_present_flag = 1; behind the slices of a picture now and then a slice of a REDUNDANT coded picture
+                                   (redundant_pic_cnt 1 or 2: the header of the picture's first slice, then bits that are not slice data) -- a decoder
+                                   decodes the primary picture and must leave these alone (Baseline tool) */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -96,6 +99,10 @@ static void bw_se(BitW *w, int v) { bw_ue(w, v > 0 ? (uint32_t)(2 * v - 1) : (ui
 static void bw_te(BitW *w, int range_max, int v) { if (range_max > 1) bw_ue(w, v); else bw_put(w, 1, !v); }
 static void bw_trailing(BitW *w) { bw_put(w, 1, 1); while (w->nbits) bw_put(w, 1, 0); }
 static int bw_bitpos(const BitW *w) { return (int)w->len * 8 + w->nbits; }
+static int bw_bit_at(const BitW *w, int pos) {                      /* bit `pos` of what has been written so far */
+    if (pos < (int)w->len * 8) return (w->buf[pos >> 3] >> (7 - (pos & 7))) & 1;
+    return (int)(w->cur >> (w->nbits - 1 - (pos - (int)w->len * 8))) & 1;
+}
 
 /* ---------------- CABAC encoder (9.3.4) ------------------------------------- */
 #include "../oracle/orc_cabac_tables.h"     /* context init (m,n), rangeTabLPS, transIdxLPS: data tables shared with the oracle */
@@ -272,6 +279,7 @@ typedef struct {
     int field, second;                    /* the picture being coded: 0 frame, 1 top field, 2 bottom field; it is the second field of its frame */
     const uint8_t *scan4, *scan8;         /* zig-zag or field scan (8.5.6 / 8.5.7) */
     int after_op5;                        /* the previous picture carried operation 5 */
+    uint8_t hdr_copy[256]; int hdr_bits, hdr_rpc;     /* redundant pictures: header bits of the current picture's first slice, position of redundant_pic_cnt */
     int usable[16], n_usable;             /* the entries of list 0 that exist (gaps in frame_num leave entries nothing may predict from) */
     int *pocs; /* PicOrderCnt of every picture by display index as the ENCODER means it (after operation 5: 0); see h264gen_last_pocs */
     int poc_base;                         /* display index at which the picture order count restarted (IDR picture, or a picture with operation 5) */
@@ -1965,7 +1973,8 @@ static void write_sps_pps(Enc *e) {
     bw_ue(w, p->num_ref - 1); bw_ue(w, 0);
     bw_put(w, 1, (uint32_t)(p->wp == 1)); bw_put(w, 2, (uint32_t)(p->bframes ? p->wp : 0));   /* weighted_pred_flag, weighted_bipred_idc */
     bw_se(w, p->qp - 26); bw_se(w, 0); bw_se(w, p->chroma_qp_off);
-    bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, 0);
+    bw_put(w, 1, 1); bw_put(w, 1, p->cip); bw_put(w, 1, (uint32_t)(p->redundant != 0));      /* deblocking_filter_control_present, constrained_intra_pred,
+        redundant_pic_cnt_present */
     if (high) { bw_put(w, 1, (uint32_t)p->t8x8); bw_put(w, 1, (uint32_t)(p->scaling == 2)); if (p->scaling == 2) write_scaling_matrix(e, w, 6 + 2 * p->t8x8);
         bw_se(w, p->chroma_qp_off); }   /* transform_8x8_mode, scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(w); out_nal(&e->out, 3, 8, w, 1);
@@ -2298,6 +2307,8 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         if (p->poc_type == 0) { bw_put(w, e->poc_lsb_bits, (uint32_t)(field ? field_poc : e->cur_top) & ((1u << e->poc_lsb_bits) - 1));
             if (p->poc_bottom && !field) bw_se(w, e->delta_bottom); }
         if (p->poc_type == 1) { bw_se(w, e->delta0); if (p->poc_bottom && !field) bw_se(w, e->delta_bottom); }
+        int rpc_bit = -1;
+        if (p->redundant) { rpc_bit = bw_bitpos(w); bw_ue(w, 0); }                              /* redundant_pic_cnt */
         if (e->slice_type == 1) bw_put(w, 1, (uint32_t)!p->direct_temporal);                  /* direct_spatial_mv_pred_flag */
         if (e->slice_type == 0) { int ovr = e->nlist0 != p->num_ref; bw_put(w, 1, ovr); if (ovr) bw_ue(w, e->nlist0 - 1); }
         if (e->slice_type == 1) { bw_put(w, 1, 1); bw_ue(w, e->nlist0 - 1); bw_ue(w, e->nlist1 - 1); }
@@ -2325,6 +2336,12 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         bw_se(w, 0);                                                      /* slice_qp_delta */
         int idc = p->deblock == 1 ? 0 : (p->deblock == 0 ? 1 : 2);
         bw_ue(w, idc); if (idc != 1) { bw_se(w, p->alpha_off); bw_se(w, p->beta_off); }
+        if (p->redundant && sl == 0) {
+            /* the header of the picture's first slice, bit by bit, for the slice of a redundant coded picture that may follow the picture (below) */
+            e->hdr_bits = MIN(bw_bitpos(w), (int)sizeof e->hdr_copy * 8); e->hdr_rpc = rpc_bit;
+            memset(e->hdr_copy, 0, sizeof e->hdr_copy);
+            for (int i = 0; i < e->hdr_bits; i++) if (bw_bit_at(w, i)) e->hdr_copy[i >> 3] |= (uint8_t)(0x80 >> (i & 7));
+        }
         int skip_run = e->slice_type != 2 ? 0 : -1;
         if (e->cabac) {
             while (w->nbits) bw_put(w, 1, 1);                             /* cabac_alignment_one_bit */
@@ -2345,6 +2362,17 @@ static void encode_picture(Enc *e, int t, int is_b, int field, int second) {
         if (e->cabac) { while (w->nbits) bw_put(w, 1, 0); }              /* the flush ended with the rbsp_stop_one_bit */
         else { if (skip_run > 0) bw_ue(w, skip_run); bw_trailing(w); }
         out_nal(&e->out, is_ref ? (idr ? 3 : 2) : 0, idr ? 5 : 1, w, sl == 0);
+    }
+    if (p->redundant && e->hdr_rpc >= 0 && rnd_n(&e->rng, 2) == 0) {
+        /* a slice of a redundant coded picture (7.4.1.2.4: behind the primary picture's slices, same access unit): the first slice's header with
+           redundant_pic_cnt = 1 or 2, and a payload that is NOT slice data -- whoever tries to decode it ends up with a different picture */
+        w->len = 0; w->nbits = 0; w->cur = 0;
+        for (int i = 0; i < e->hdr_rpc; i++) bw_put(w, 1, (uint32_t)((e->hdr_copy[i >> 3] >> (7 - (i & 7))) & 1));
+        bw_ue(w, 1 + (uint32_t)rnd_n(&e->rng, 2));
+        for (int i = e->hdr_rpc + 1; i < e->hdr_bits; i++) bw_put(w, 1, (uint32_t)((e->hdr_copy[i >> 3] >> (7 - (i & 7))) & 1));
+        for (int i = 0, n = 4 + rnd_n(&e->rng, 24); i < n; i++) bw_put(w, 8, 1 + (uint32_t)rnd_n(&e->rng, 254));
+        bw_trailing(w);
+        out_nal(&e->out, is_ref ? (idr ? 3 : 2) : 0, idr ? 5 : 1, w, 0);
     }
     if (p->deblock != 0) deblock_frame(e);
 #define REMOVE_REF(i_) do { Frame t_ = e->refs[i_]; \
@@ -2547,7 +2575,7 @@ int h264gen_generate(const GenParams *gp, uint8_t **out, size_t *out_len, const 
     p->paff = CLIP3(0, 2, p->paff);
     if (p->paff) { p->fmo0 = 1; if (p->cabac) p->t8x8 = 0; if (p->wp == 2 && !p->bframes) p->wp = 0; }
     if (p->bframes) { p->mmco = 0; p->gaps = 0; }
-    p->gaps = p->gaps != 0;
+    p->gaps = p->gaps != 0; p->redundant = p->redundant != 0;
     e->max_lt_idx = -1; e->pending_long_idx = -1;
     p->bframes = CLIP3(0, 3, p->bframes); p->wp = CLIP3(0, 2, p->wp); p->direct_temporal = p->direct_temporal != 0;
     if (!p->bframes) { if (p->wp == 2) p->wp = 0; p->dinf8 = 1; }
@@ -2618,7 +2646,7 @@ int main(int argc, char **argv) {
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
         OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm",
-            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff) OPT("--gaps", gaps)
+            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff) OPT("--gaps", gaps) OPT("--redundant", redundant)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;
