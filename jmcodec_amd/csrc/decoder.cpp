@@ -299,12 +299,15 @@ bool Decoder::gpu_open() {
         device_ = e ? atoi(e) : (g_handle_counter++ % n);
     }
     if (device_ >= n) device_ %= n;
+    mem_trace("handle: before hipSetDevice");
     if (!HIP_OK(hipSetDevice(device_))) { fail("hipSetDevice failed"); return false; }
+    mem_trace("handle: hipSetDevice");
     handle_index_ = g_handle_index++;
     numa_node_ = numa_node_of_device(device_, true);
     engine_ = Engine::get(device_);
     if (!engine_) { fail("could not start the device engine (stream / buffer creation failed)"); return false; }
     gpu_open_ = true;
+    mem_trace("handle: engine ready");
     return true;
 }
 

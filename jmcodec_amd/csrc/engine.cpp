@@ -28,7 +28,17 @@ Engine *Engine::get(int device) {
     return g_engines[device];
 }
 
+// developer aid (JM_AMD_DEC_MEMTRACE=1): resident memory of the process at the steps of engine / handle set-up
+void mem_trace(const char *tag) {
+    static const bool on = getenv("JM_AMD_DEC_MEMTRACE") != nullptr;
+    if (!on) return;
+    long pages = 0, res = 0;
+    if (FILE *f = fopen("/proc/self/statm", "r")) { if (fscanf(f, "%ld %ld", &pages, &res) != 2) res = 0; fclose(f); }
+    fprintf(stderr, "jm_amd_dec: memtrace %-44s %8.1f MB resident\n", tag, res * 4096.0 / 1e6);
+}
+
 Engine::Engine(int device) : device_(device) {
+    mem_trace("engine: start");
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
@@ -36,11 +46,13 @@ Engine::Engine(int device) : device_(device) {
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
     copy_stream_ = c;
+    mem_trace("engine: copy stream");
     for (auto &ln : lanes_) {
         hipStream_t s, p, q;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return;
         ln.stream = s; ln.pack_stream = p; ln.pre_stream = q;
+        mem_trace("engine: lane streams");
         for (auto &b : ln.ring) {
             if (hipHostMalloc((void **)&b.h_pics, sizeof(PicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_pics, sizeof(PicParams) * kMaxBatch) != hipSuccess) return;
@@ -62,6 +74,7 @@ Engine::Engine(int device) : device_(device) {
             for (auto &e : b.pev) if (hipEventCreate(&e) != hipSuccess) return;
         }
     }
+    mem_trace("engine: lane buffers");
     // The no-deadlock argument of a chain launch (chain.hip) needs its band workgroups -- resident for their whole wavefront -- to leave room for the
     // reconstruction groups they wait for: at most half of what the device holds.  Taken from the device in use (a compute partition, a smaller part
     // or a build with other register counts holds fewer than the constants assume); launches whose first pictures do not fit run unchained.
@@ -71,6 +84,7 @@ Engine::Engine(int device) : device_(device) {
       if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr,
           "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_,
           chain_bands_max_intra_); }
+    mem_trace("engine: occupancy queries");
     ok_ = true;
     numa_node_ = numa_node_of_device(device_, true);
     kfd_gpu_id_ = getenv("JM_AMD_DEC_IGNORE_SHARED_GPU") ? 0 : kfd_gpu_id_of_device(device_);

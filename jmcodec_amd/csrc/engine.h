@@ -92,6 +92,8 @@ struct EngineDecoderState {
     int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false, batch_resid = false;
 };
 
+void mem_trace(const char *tag);      // developer aid: JM_AMD_DEC_MEMTRACE=1 prints the process's resident memory at set-up steps (engine.cpp)
+
 class Engine {
 public:
     static Engine *get(int device);                 // creates the engine (and its thread) on first use; nullptr on HIP failure

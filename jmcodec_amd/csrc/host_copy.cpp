@@ -57,7 +57,10 @@ HostCopier *HostCopier::get(int dev) {
     // Which engines?  An MI355X shows sixteen; measured with one packed 1080p frame each (tools/sdma_probe.cpp): four move 47.6 GB/s over PCIe, the
     // rest serve xGMI and manage 12 GB/s; two or three of the fast ones together fill the link (52.5 / 54.0 GB/s = 16.9 / 17.4 k frames/s).  The engine the HIP
     // runtime itself prefers for host -> device traffic must be left alone (frames queue behind its work: 11.7 k frames/s with it, 16.9 k without).
-    // So: time one copy on every available engine, keep those within 1.5x of the best, drop the host -> device ones, use up to three in turn.
+    // So: time one copy on an engine after the other, keep those within 1.5x of the best, drop the host -> device ones, use up to three in turn.
+    // NOT on every engine: the runtime builds a queue per engine it is asked to use and keeps it -- about 190 MB of resident host memory each, 3 GB
+    // for all sixteen (round 3, JM_AMD_DEC_MEMTRACE).  The engines the runtime itself recommends for this direction come first; the search stops
+    // once three engines within 1.5x of the best are known and a slower one has been seen (or six engines were tried).
     uint32_t avail = 0, h2d = 0, d2h = 0;
     hsa_agent_t ca{c->cpu_}, ga{c->gpu_};
     if (hsa_amd_memory_copy_engine_status(ca, ga, &avail) != HSA_STATUS_SUCCESS) avail = 0;
@@ -75,18 +78,28 @@ HostCopier *HostCopier::get(int dev) {
         for (auto &x : t) x = 1e30;
         if (hipMalloc(&dsrc, n) == hipSuccess && posix_memalign(&hbuf, 4096, n) == 0 && (hloc = c->lock(hbuf, n)) != nullptr && hsa_signal_create(1, 0,
             nullptr, &sg) == HSA_STATUS_SUCCESS) {
-            for (int pass = 0; pass < 2; pass++)                  // (the first pass touches the pages and wakes the engines)
-                for (int b = 0; b < 16; b++) {
-                    const uint32_t e = 1u << b;
-                    if (!(avail & e)) continue;
+            int order[16], n_order = 0;
+            for (int b = 1; b < 16; b++) if (d2h & (1u << b)) order[n_order++] = b;            // the runtime's recommendation first
+            for (int b = 1; b < 16; b++) if (!(d2h & (1u << b))) order[n_order++] = b;
+            order[n_order++] = 0;                                                               // (engine 0x1: the runtime's host -> device engine, last choice)
+            int tried = 0; bool slower_seen = false;
+            for (int k = 0; k < n_order; k++) {
+                const int b = order[k]; const uint32_t e = 1u << b;
+                if (!(avail & e) || (h2d & e)) continue;
+                for (int pass = 0; pass < 2; pass++) {            // (the first copy touches the pages and wakes the engine)
                     hsa_signal_store_relaxed(sg, 1);
                     timespec a, z; clock_gettime(CLOCK_MONOTONIC, &a);
                     if (hsa_amd_memory_async_copy_on_engine(hloc, ca, dsrc, ga, n, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)e,
-                        false) != HSA_STATUS_SUCCESS) continue;
+                        false) != HSA_STATUS_SUCCESS) break;
                     while (hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, 100ull * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) >= 1) {}
                     clock_gettime(CLOCK_MONOTONIC, &z);
                     if (pass) { t[b] = (z.tv_sec - a.tv_sec) + 1e-9 * (z.tv_nsec - a.tv_nsec); if (t[b] < best) best = t[b]; }
                 }
+                tried++;
+                int good = 0;
+                for (int j = 0; j < 16; j++) { if (t[j] < 1e29 && t[j] <= 1.5 * best) good++; else if (t[j] < 1e29) slower_seen = true; }
+                if (good >= 3 && (slower_seen || tried >= 6)) break;
+            }
         }
         (void)hipGetLastError();
         // (engine 0x1 is where the HIP runtime puts its host -> device copies on this platform whatever the preference query says: last choice)
