@@ -42,6 +42,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_LINGER")) chain_linger_streams_ = std::max(0, atoi(e));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
@@ -153,6 +154,17 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             gpu_shared_ = sh;
         }
         chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
+        // One or two streams: a chain launch is as long as what its stream(s) fed while the previous launch ran.  Queueing a SECOND launch behind a running one
+        // as soon as a picture or two are there splits that supply into a short launch and a long one, and a short chain costs nearly what a long one costs
+        // (the first picture's wavefront, ~0.7 ms at 1080p).  So while a launch is in flight the next one is only formed when it would be a full chain;
+        // otherwise it waits until the lane is idle and takes everything that has arrived by then (two streams 6.4 k -> 7.2 k frames/s; one stream within
+        // the noise: its caller's loop, not the chain length, is what bounds it.  Forming the next launch when the running one is four fifths through, to
+        // hide the host's turnaround, was tried and lost the gain again: measured, not kept).
+        if (lane_idx == kOrdinaryLane && chaining && n_active <= chain_linger_streams_ && ln.inflight > 0) {
+            int n = 0;
+            for (const EnginePic &p : pending_) if (p.codec == 0 && p.has_picture && p.lane(true) == lane_idx) n++;
+            if (n < chain_depth_ * n_active) return false;
+        }
     }
     std::vector<Decoder *> seen, members;
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels

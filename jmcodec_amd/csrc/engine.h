@@ -170,6 +170,7 @@ private:
     std::atomic<int> fetchers_{0};
     // no chain launches before this time (set when one had to be recovered; setting a chain knob clears it)
     std::atomic<long long> chain_block_until_ns_{0};
+    int chain_linger_streams_ = 2;                  // up to this many active streams the next chain launch waits for the running one (Engine::form)
     std::mutex sm_; EngineStats st_;
     std::thread th_;
 };
