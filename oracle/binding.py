@@ -163,16 +163,16 @@ class OracleHevc:
         class Frame(C.Structure):
             _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c",
                 C.c_int),
-                        ("poc", C.c_int), ("frame_type", C.c_int), ("decode_index", C.c_int)]
+                        ("poc", C.c_int), ("slice_type", C.c_int), ("decode_index", C.c_int)]
         pocs = []
         cb = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame))(lambda user, f: pocs.append(f.contents.poc))
-        d = self.L.orc_open(C.cast(cb, C.c_void_p), None)
-        rc = self.L.orc_decode_annexb(d, data, len(data))
-        err = self.L.orc_last_error(d).decode()
-        self.L.orc_flush(d)
-        self.L.orc_close(d)
+        d = self.L.orch_open(C.cast(cb, C.c_void_p), None)
+        rc = self.L.orch_decode_annexb(d, data, len(data))
+        err = self.L.orch_last_error(d).decode()
+        self.L.orch_flush(d)
+        self.L.orch_close(d)
         if rc < 0:
-            raise RuntimeError("oracle: " + err)
+            raise RuntimeError("HEVC oracle: " + err)
         return pocs
 
     def syntax_digest(self, data):

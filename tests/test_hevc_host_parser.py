@@ -66,6 +66,17 @@ def test_display_order_is_poc_order():
     assert pocs == sorted(pocs) and len(set(pocs)) == n == 17
 
 
+@pytest.mark.parametrize("name", sorted(HEVC_CASES))
+def test_display_order_equals_the_oracles(oracle, name):
+    """C.5.2 bumping: the product hands the pictures out in the order, and with the PicOrderCntVal, the oracle does -- over every test stream
+    (open GOPs with skipped RASL pictures, long-term references, several coded video sequences)."""
+    data = streams.generate_hevc(**HEVC_CASES[name])
+    want = oracle.display_pocs(data)
+    with jmcodec_amd.JmAmdDec(1, 1, options=OPTS) as d:
+        n = d.decode_stream(data, keep=False)
+        assert [d.stat(f"display_poc:{i}") for i in range(n)] == want
+
+
 def test_corrupt_streams_do_not_crash():
     data = streams.generate_hevc(**HEVC_CASES["b_gop2"])
     rng = np.random.default_rng(11)
