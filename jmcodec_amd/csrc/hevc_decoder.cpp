@@ -287,6 +287,15 @@ void Decoder::hevc_parse_task(PicTask *t) {
         put(ht.off_itbs, jobs.itbs.data(), jobs.itbs.size() * sizeof(HevcIntraTb)); put(ht.off_coefs, jobs.coefs.data(), jobs.coefs.size() * 4);
         put(ht.off_wps, jobs.wps.data(), jobs.wps.size() * sizeof(HevcWp));
         t->upload_bytes = off;
+        if (want_job_digest_) {                              // tests (pictures are parsed in order: sync option): the arrays as the device gets them
+            uint64_t h = job_digest_;
+            auto eat = [&](size_t o, size_t n) { const uint8_t *b = js.host + o; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+            eat(ht.off_ctbs, jobs.ctbs.size() * sizeof(HevcCtb)); eat(ht.off_qp8, jobs.qp8.size()); eat(ht.off_bsv, jobs.bs_v.size());
+            eat(ht.off_bsh, jobs.bs_h.size()); eat(ht.off_pus, jobs.pus.size() * sizeof(HevcPu)); eat(ht.off_tbs, jobs.tbs.size() * sizeof(HevcTb));
+            eat(ht.off_itbs, jobs.itbs.size() * sizeof(HevcIntraTb)); eat(ht.off_coefs, jobs.coefs.size() * 4);
+            eat(ht.off_wps, jobs.wps.size() * sizeof(HevcWp));
+            job_digest_ = h;
+        }
         stat_pictures_++; stat_job_bytes_ += (long long)off; stat_intra_mbs_ += jobs.n_intra_cu; stat_coef_ += (long long)jobs.coefs.size();
         if (!parse_only_ && !failed_) t->upload_seq = engine_->upload(js.dev, js.host, off, js.uploaded);
     }

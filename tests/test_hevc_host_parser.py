@@ -77,6 +77,19 @@ def test_display_order_equals_the_oracles(oracle, name):
         assert [d.stat(f"display_poc:{i}") for i in range(n)] == want
 
 
+@pytest.mark.parametrize("name", sorted(HEVC_CASES))
+def test_job_lists_are_the_ones_the_gpu_tests_confirmed(name):
+    """The job lists (coding tree block records, strengths, motion jobs, transform blocks, scaled coefficients) of every test stream, byte for byte
+    as they were when the GPU parity tests last confirmed the kernels' output for them (tools/make_hevc_job_digests.py): a change of the host parser
+    that is made and timed without a GPU cannot alter what the device receives.  With the syntax digest on, the coefficients of a block are listed
+    by position instead of scan order -- the same set."""
+    want = json.load(open(os.path.join(GOLDEN, "hevc_job_digests.json")))[name]
+    data = streams.generate_hevc(**HEVC_CASES[name])
+    with jmcodec_amd.JmAmdDec(1, 1, options={"parse_only": 1, "job_digest": 1}) as d:
+        n = d.decode_stream(data, keep=False)
+        assert n > 0 and "%016x" % (d.stat("job_digest") & (2 ** 64 - 1)) == want
+
+
 def test_corrupt_streams_do_not_crash():
     data = streams.generate_hevc(**HEVC_CASES["b_gop2"])
     rng = np.random.default_rng(11)
