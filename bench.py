@@ -78,7 +78,7 @@ def main():
     os.environ["JM_AMD_DEC_DEVICE"] = str(local_rank % max(n_dev, 1))
     if world > 1 and "JM_AMD_DEC_THREADS" not in os.environ:      # the ranks of a node share its host cores (parse workers per rank)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        os.environ["JM_AMD_DEC_THREADS"] = str(max(4, min(64, int(quota_cpus() * 1.75 + 0.5) // max(local_world, 1))))
+        os.environ["JM_AMD_DEC_THREADS"] = str(max(4, min(64, int(quota_cpus() * 1.25 + 0.5) // max(local_world, 1))))
     red_dev = "cuda" if (world > 1 and backend == "nccl") else "cpu"
 
     import __graft_entry__ as ge

@@ -22,7 +22,7 @@ namespace jmamd {
 // =============================================================================================
 // A handle's pictures are entropy-decoded on the node of its GPU: the workers run on that node's CPUs and the page-locked job buffers they fill
 // (and grow) come from its memory, so a job list crosses the socket interconnect neither on its way into the buffer nor on its way to the device.
-// The process-wide thread budget (the CFS quota x 1.75, or JM_AMD_DEC_THREADS) is what ONE pool gets when the process drives one device
+// The process-wide thread budget (the CFS quota x 1.25, or JM_AMD_DEC_THREADS) is what ONE pool gets when the process drives one device
 // (JM_AMD_DEC_DEVICE: a rank of bench.py, a process per GPU); in the drop-in "one process, handles round robin over every GPU" mode each node's
 // pool gets the share of the budget that corresponds to its CPUs.
 namespace {
@@ -31,10 +31,13 @@ int thread_budget() {
     int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     if (!e) {
         // A container may see every CPU of the machine but own a small CFS quota (cgroup v2 cpu.max: "<quota> <period>"): a worker per
-        // visible CPU then only buys throttling stalls.  Size the pool to the quota, with headroom for workers blocked on job slots.
+        // visible CPU then only buys throttling stalls.  Size the pool to the quota, with a quarter more for workers blocked on job slots or on
+        // the collocated picture's motion: measured on a 16-CPU quota (scratch/gpu_threads.sh, frames/s with 16 / 20 / 28 workers) HEVC 1080p
+        // 3.98 / 4.29 / 3.85 k, High 9.9 / 8.6 / 8.3 k, High + B 7.5 / 8.3 / 7.1 k, 4K High + B 1.21 / 1.32 / 1.33 k -- with 28 (x 1.75, the
+        // former rule) the kernel throttled the process for seconds per second and a picture cost 15-25 % more CPU time.
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long q = 0, per = 0; char qs[32] = {0};
-            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); int lim = (int)((q * 7 / 4 + per - 1) / per);
+            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); int lim = (int)((q * 5 / 4 + per - 1) / per);
                 if (lim < 4) lim = 4; if (n > lim) n = lim; }
             fclose(f);
         }

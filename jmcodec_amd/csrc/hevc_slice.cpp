@@ -36,6 +36,8 @@ struct ScanTables {
     }
 };
 const ScanTables kScan;
+struct Flat16 { uint8_t v[32 * 32]; Flat16() { memset(v, 16, sizeof v); } };     // m[x][y] = 16 (7.3.4: scaling lists off, transform skip of a larger block)
+const Flat16 kFlat16;
 
 inline int mv_scale(int mv, int td, int tb) {                         // (8-179) ff.
     td = clip3(-128, 127, td); tb = clip3(-128, 127, tb);
@@ -327,14 +329,89 @@ void HevcPicParser::emit_intra_tb(int xp, int yp, int log2, int c, int mode, boo
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The entropy-coded part of one 4x4 sub-block (7.3.8.11 from sig_coeff_flag to coeff_abs_level_remaining; 9.3.3.11, 9.3.4.2.5 - 9.3.4.2.7) as a function of
+// its own: its loops carry the arithmetic decoder's variables from bin to bin, and inside residual_coding -- next to the block's positions, scaling and
+// output variables -- the compiler kept them on the stack (55 instructions per significance bin).  Nothing here branches on a decoded bin except the loop
+// ends: the greater-than-1 flags of the first eight coefficients are collected in a bit mask, which also says who carries a remaining level.
+namespace {
+struct SubBlock {
+    // in
+    uint32_t sig;                  // the last significant position of the block, when it lies in this sub-block
+    int start;                     // first scan position to decode a flag for (downwards; -1: none)
+    bool infer_dc;                 // the sub-block is coded and not the first or last one: position 0 is significant when no other position is
+    const uint8_t *pat;            // context increment of sig_coeff_flag by scan position
+    int sig_ctx, dc_ctx, cset_base;
+    bool chroma, first_group, sign_hiding;
+    // in / out
+    int g1ctx;                     // greater1Ctx at the end of the previous coded sub-block
+    // out
+    int np;                        // significant coefficients; m = 0 .. np - 1 counts them in decoding order (highest scan position first)
+    uint32_t g1, g2, signs;        // bit m: coefficient m is greater than 1 / than 2; signs: coefficient 0 in bit 31, a hidden sign reads as 0
+    bool hide;
+    int remv[16];                  // coeff_abs_level_remaining by m (0 where none is coded)
+};
+__attribute__((noinline)) bool decode_sub_block(Cabac &home, SubBlock &sb) {
+    CabacRegs cb(home);
+    uint32_t sig = sb.sig;
+    {
+        const uint8_t *pat = sb.pat; const int ctx = sb.sig_ctx;
+        for (int k = sb.start; k >= 1; k--) sig |= (uint32_t)cb.decision(ctx + pat[k]) << k;
+        if (sb.start >= 0) {
+            if (sb.infer_dc && !sig) sig = 1;
+            else sig |= (uint32_t)cb.decision(sb.dc_ctx);
+        }
+    }
+    sb.sig = sig;
+    if (!sig) { cb.commit(); return true; }
+    const int np = __builtin_popcount(sig), n8 = np < 8 ? np : 8;
+    int cset = sb.cset_base;
+    if (!sb.first_group && sb.g1ctx == 0) cset++;
+    uint32_t g1 = 0, g1ctx = 1;
+    const int g1base = HEVC_CTX_G1 + cset * 4 + (sb.chroma ? 16 : 0);
+    for (int m = 0; m < n8; m++) {
+        const uint32_t b = (uint32_t)cb.decision(g1base + (int)g1ctx);
+        g1 |= b << m;
+        g1ctx = (g1ctx + ((g1ctx - 1) < 2u)) & (b - 1);             // 1 -> 2 -> 3 while the flags are 0, 0 from the first 1 on
+    }
+    uint32_t g2 = 0;                                                // the greater-than-2 flag belongs to the first coefficient greater than 1
+    if (g1 && cb.decision(HEVC_CTX_G2 + cset + (sb.chroma ? 4 : 0))) g2 = g1 & (0u - g1);
+    // a remaining level follows when the flags could not say more: base level 3 for the coefficient with the greater-than-2 flag, 2 for the others of
+    // the first eight, 1 from the ninth on
+    uint32_t rem_mask = (g1 & (g1 - 1)) | g2 | (((1u << np) - 1) & ~0xffu);
+    const int hi_pos = 31 - __builtin_clz(sig), lo_pos = __builtin_ctz(sig);
+    const bool hide = sb.sign_hiding && hi_pos - lo_pos > 3;
+    const int nsign = np - (hide ? 1 : 0);
+    sb.signs = nsign ? cb.bypass_bits(nsign) << (32 - nsign) : 0;
+    memset(sb.remv, 0, sizeof sb.remv);
+    for (int rice = 0; rem_mask;) {
+        const int m = __builtin_ctz(rem_mask); rem_mask &= rem_mask - 1;
+        const int q = cb.unary(32);
+        if (q >= 32) return false;
+        int rem;
+        if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb.bypass_bits(rice); }
+        else { const int nb = q - 3 + rice; if (nb > 30) return false;
+            const int s = nb > 16 ? (int)(cb.bypass_bits(nb - 16) << 16 | cb.bypass_bits(16)) : (int)cb.bypass_bits(nb);
+            rem = (((1 << (q - 3)) + 2) << rice) + s; }
+        sb.remv[m] = rem;
+        const int a = 1 + (int)((g1 >> m) & 1) + (int)((g2 >> m) & 1) + rem;
+        if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
+    }
+    sb.np = np; sb.g1 = g1; sb.g2 = g2; sb.hide = hide; sb.g1ctx = (int)g1ctx;
+    cb.commit();                                                    // (the error returns above abandon the slice: nothing to write back)
+    return true;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
 // 7.3.8.11 residual_coding; (x0, y0) luma position for the digest, (xp, yp) position in plane c.  Appends the scaled coefficients.
 bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int yp, bool intra_tb) {
     const int n = 1 << log2;
     int tskip = 0;
-    CabacRegs cb(cb_);                                              // the arithmetic decoder's variables in registers for the whole block (h264_cabac.h)
-    if (pps_->transform_skip && !tq_bypass_ && log2 == 2) tskip = cb.decision(HEVC_CTX_TSKIP + (c ? 1 : 0));
     // last significant coefficient position
     int last[2];
+    {
+    CabacRegs cb(cb_);                                              // the arithmetic decoder's variables in registers (h264_cabac.h)
+    if (pps_->transform_skip && !tq_bypass_ && log2 == 2) tskip = cb.decision(HEVC_CTX_TSKIP + (c ? 1 : 0));
     for (int d = 0; d < 2; d++) {
         const int cmax = 2 * log2 - 1, off = c ? 15 : 3 * (log2 - 2) + ((log2 - 1) >> 2), shf = c ? log2 - 2 : (log2 + 1) >> 2,
             base = d ? HEVC_CTX_LAST_Y : HEVC_CTX_LAST_X;
@@ -344,6 +421,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     }
     for (int d = 0; d < 2; d++) if (last[d] > 3) { int nb = (last[d] >> 1) - 1, s = 0; for (int i = 0; i < nb; i++) s = (s << 1) | cb.bypass();
         last[d] = (1 << nb) * (2 + (last[d] & 1)) + s; }
+    cb.commit();
+    }
     int scan = 0;
     if (cu_intra_ && (log2 == 2 || (log2 == 3 && c == 0))) { int pm = c == 0 ? ipm_[i4(x0, y0)] : ipm_c_; if (pm >= 6 && pm <= 14) scan = 2;
         else if (pm >= 22 && pm <= 30) scan = 1; }
@@ -364,6 +443,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     const int mat = (cu_intra_ ? 0 : 3) + c;
     const uint8_t *smat = log2 == 2 ? sf.f4[mat] : log2 == 3 ? sf.f8[mat] : log2 == 4 ? sf.f16[mat] : sf.f32[cu_intra_ ? 0 : 1];
     const bool flat = !sps_->scaling_enabled || (tskip && n > 4);
+    const uint8_t *smul = flat ? kFlat16.v : smat;
     const int bd_shift = log2 + 3, ls = hevc_level_scale[qp % 6] << (qp / 6);
     const int64_t sc_add = (int64_t)1 << (bd_shift - 1);
     const bool direct = !dg_->on;
@@ -374,7 +454,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         const int xs = sb_scan[i] & 15, ys = sb_scan[i] >> 4;
         const int right = xs < nsb - 1 ? csbf[ys][xs + 1] : 0, below = ys < nsb - 1 ? csbf[ys + 1][xs] : 0;
         bool infer_dc = false;
-        if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)cb.decision(HEVC_CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)); infer_dc = true; }
+        if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)cb_.decision(HEVC_CTX_CSBF + ((right | below) ? 1 : 0) + (c ? 2 : 0)); infer_dc = true; }
         else csbf[ys][xs] = 1;
         if (!csbf[ys][xs]) continue;
         uint16_t sig = 0;                                              // bit k: position k of the sub-block is significant
@@ -386,56 +466,31 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
         const int sig0 = HEVC_CTX_SIG + (c ? 27 : 0);
         const int sbase = log2 == 2 ? sig0 :
             (c == 0 ? HEVC_CTX_SIG + (i > 0 ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21) : HEVC_CTX_SIG + 27 + (log2 == 3 ? 9 : 12));
-        for (int k = start; k >= 1; k--) if (cb.decision(sbase + pat[k])) { sig |= (uint16_t)(1u << k); infer_dc = false; }
-        if (start >= 0) {
-            if (infer_dc) sig |= 1;
-            else if (cb.decision((log2 > 2 && i == 0) ? sig0 : sbase + pat[0])) sig |= 1;
-        }
+        SubBlock sb;
+        sb.sig = sig; sb.start = start; sb.infer_dc = infer_dc; sb.pat = pat; sb.sig_ctx = sbase; sb.dc_ctx = (log2 > 2 && i == 0) ? sig0 : sbase + pat[0];
+        sb.cset_base = ((i == 0 || c) ? 0 : 2); sb.chroma = c != 0; sb.g1ctx = g1ctx; sb.first_group = first_group;
+        sb.sign_hiding = pps_->sign_hiding && !tq_bypass_;
+        if (!decode_sub_block(cb_, sb)) return false;
+        sig = (uint16_t)sb.sig;
         if (!sig) continue;
-        int pos[16], np = 0;
-        for (uint32_t m = sig; m;) { const int k = 31 - __builtin_clz(m); pos[np++] = k; m &= ~(1u << k); }       // highest scan position first
-        int cset = (i == 0 || c) ? 0 : 2;
-        if (!first_group && g1ctx == 0) cset++;
-        first_group = false; g1ctx = 1;
-        int absv[16], last_g1 = -1;
-        for (int m = 0; m < np; m++) absv[m] = 1;
-        for (int m = 0; m < np && m < 8; m++) {
-            if (cb.decision(HEVC_CTX_G1 + cset * 4 + g1ctx + (c ? 16 : 0))) { absv[m] = 2; g1ctx = 0; if (last_g1 < 0) last_g1 = m; }
-            else if (g1ctx > 0 && g1ctx < 3) g1ctx++;
-        }
-        if (last_g1 >= 0 && cb.decision(HEVC_CTX_G2 + cset + (c ? 4 : 0))) absv[last_g1] = 3;
-        const bool hide = pps_->sign_hiding && !tq_bypass_ && pos[0] - pos[np - 1] > 3;
-        const int nsign = np - (hide ? 1 : 0);
-        uint32_t signs = nsign ? cb.bypass_bits(nsign) << (32 - nsign) : 0;      // first sign in bit 31
-        int rice = 0, sum = 0;
+        first_group = false; g1ctx = sb.g1ctx;
+        const int np = sb.np; const uint32_t g1 = sb.g1, g2 = sb.g2; uint32_t signs = sb.signs; const bool hide = sb.hide; const int *remv = sb.remv;
+        const int sb_base = ((ys << 2) << log2) + (xs << 2), hidden = hide ? np - 1 : 99;
+        int sum = 0;
+        uint32_t left = sig;
         for (int m = 0; m < np; m++) {
-            const int thr = m < 8 ? (m == last_g1 ? 3 : 2) : 1;
-            int a = absv[m];
-            if (a == thr) {
-                int q = 0;
-                while (q < 32 && cb.bypass()) q++;
-                if (q >= 32) return false;
-                int rem;
-                if (q < 4) { rem = q << rice; if (rice) rem |= (int)cb.bypass_bits(rice); }
-                else { int nb = q - 3 + rice; if (nb > 30) return false;
-                    int s = nb > 16 ? (int)(cb.bypass_bits(nb - 16) << 16 | cb.bypass_bits(16)) : (int)cb.bypass_bits(nb);
-                    rem = (((1 << (q - 3)) + 2) << rice) + s; }
-                a += rem;
-                if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
-            }
+            const int k = 31 - __builtin_clz(left); left ^= 1u << k;
+            const int a = 1 + (int)((g1 >> m) & 1) + (int)((g2 >> m) & 1) + remv[m];
             sum += a;
-            bool neg;
-            if (hide && m == np - 1) neg = sum & 1;
-            else { neg = signs >> 31; signs <<= 1; }
-            const int xq = pos_scan[pos[m]] & 15, yq = pos_scan[pos[m]] >> 4, idx = ((ys << 2) + yq) * n + (xs << 2) + xq;
-            const int lv = clip3(-32768, 32767, neg ? -a : a);
+            const int neg = (int)(signs >> 31) | ((m == hidden) & sum & 1); signs <<= 1;       // 9.3.4.3.6: the hidden sign is the parity of the sum
+            const int idx = sb_base + ((pos_scan[k] >> 4) << log2) + (pos_scan[k] & 15);
+            const int lv = clip3(-32768, 32767, (a ^ -neg) + neg);
             if (direct) {
-                const int v = tq_bypass_ ? lv : clip3(-32768, 32767, (int)(((int64_t)lv * (flat ? 16 : smat[idx]) * ls + sc_add) >> bd_shift));
-                if (v) dw[dcount++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
+                const int v = tq_bypass_ ? lv : clip3(-32768, 32767, (int)(((int64_t)lv * smul[idx] * ls + sc_add) >> bd_shift));
+                dw[dcount] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); dcount += v != 0;
             } else { lev_[idx] = (int16_t)lv; nz_pos_[nz_n_++] = (uint16_t)idx; }
         }
     }
-    cb.commit();                                                    // (the early error returns above abandon the slice: nothing to write back)
     if (cb_.overrun) return false;
     if (dg_->on) {
         dg(0x7000 | (c << 8) | (log2 << 4) | tskip); dg(x0); dg(y0);

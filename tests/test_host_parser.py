@@ -1,5 +1,6 @@
 """Host side of the product (no GPU needed): Annex-B splitting, header parsing, DPB / display order and the CAVLC
 job builder, compared with the CPU oracle through the macroblock syntax digest (parse_only mode produces no pixels)."""
+import os
 import random
 
 import pytest
@@ -92,6 +93,20 @@ def test_order_counts_of_types_1_and_2_rise_in_display_order(oracle, poc_type):
     assert len(restarts) >= 3, "the stream holds pictures with operation 5"
     for a, b in zip(restarts, restarts[1:] + [60]):
         assert got[a] == 0 and all(got[i] < got[i + 1] for i in range(a, b - 1)), (a, b, got[a:b])
+
+
+def test_cabac_engine_shortcuts_equal_the_bin_by_bin_decoder(tmp_path):
+    """n bypass bins as one reciprocal multiplication, a unary prefix by counting leading zeros (h264_cabac.h): a C++ check against the
+    one-bin-at-a-time operations of 9.3.3.2.3 (tests/cabac_engine_check.cpp)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ is missing")
+    exe = str(tmp_path / "cabac_engine_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cabac_engine_check.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mbmi", "-mbmi2", "-mlzcnt", "-o", exe, src])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
 def test_empty_and_garbage_input():
