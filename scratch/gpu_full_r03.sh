@@ -8,4 +8,6 @@ timeout 300 python bench.py --streams 8 --no-cpu-baseline > gpurun_out/p3/r03_be
 timeout 300 python bench.py --tools high --no-cpu-baseline --no-single > gpurun_out/p3/r03_bench_high.json 2>/dev/null
 timeout 300 python bench.py --tools high_b --no-cpu-baseline --no-single > gpurun_out/p3/r03_bench_high_b.json 2>/dev/null
 timeout 300 python bench.py --codec hevc --streams 1 --frames 32 --steps 3 --no-cpu-baseline > gpurun_out/p3/r03_hevc_bench_s1.json 2>/dev/null
+timeout 300 python bench.py --tools paff --no-cpu-baseline --no-single > gpurun_out/p3/r03_bench_paff.json 2>/dev/null
+timeout 300 python bench.py --tools paff_b --no-cpu-baseline --no-single > gpurun_out/p3/r03_bench_paff_b.json 2>/dev/null
 bash scratch/gpu_prof_r03.sh r03
