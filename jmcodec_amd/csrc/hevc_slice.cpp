@@ -62,9 +62,9 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     // coding tree blocks that no slice delivered.
     if (pm_.size() != n4) {
         pm_.assign(n4, 0); skip_.assign(n4, 0); depth_.assign(n4, 0); ipm_.assign(n4, 1); nofilter_.assign(n4, 0); edge_.assign(n4, 0); cbf_.assign(n4, 0);
-        qp_.assign(n4, 26); mot_.assign(n4, HevcMotion()); slice_of_.assign(n4, 0);
+        qp_.assign(n4, 26); mot_.assign(n4, HevcMotion());
     }
-    ctb_slice_.assign(nc, -1);
+    ctb_slice_.assign(nc, -1); ctb_sidx_.assign(nc, 0);
     slices_.clear(); wpp_valid_ = dep_valid_ = false; last_cu_qp_ = 26; err_ = false;
     // 6.5.1 raster <-> tile scan and 6.5.2 z-scan order: only when the layout changed
     uint64_t key = ((uint64_t)w_ << 48) ^ ((uint64_t)h_ << 32) ^ ((uint64_t)sps.log2_ctb << 28) ^ ((uint64_t)sps.log2_min_tb << 24) ^
@@ -447,7 +447,7 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     const int bd_shift = log2 + 3, ls = hevc_level_scale[qp % 6] << (qp / 6);
     const int64_t sc_add = (int64_t)1 << (bd_shift - 1);
     const bool direct = !dg_->on;
-    uint32_t dw[32 * 32]; uint32_t dcount = 0;
+    uint32_t *const dw = jobs_->coefs.tail((size_t)n * n); uint32_t dcount = 0;      // the block's coefficients are written where they stay
     for (int k = 0; k < nz_n_; k++) lev_[nz_pos_[k]] = 0;             // lev_ is all zero between calls
     nz_n_ = 0;
     for (int i = last_sb; i >= 0; i--) {
@@ -500,10 +500,9 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     // 8.6.4.1 scaling -> sparse coefficient list (direct: done level by level above)
     const uint32_t first = (uint32_t)jobs_->coefs.size();
     uint32_t count = 0;
-    if (direct) { count = dcount; jobs_->coefs.insert(jobs_->coefs.end(), dw, dw + dcount); }
+    if (direct) count = dcount;
     else {
-        jobs_->coefs.resize(first + (size_t)nz_n_);                  // written in place, trimmed to what survived scaling
-        uint32_t *cw = jobs_->coefs.data() + first;
+        uint32_t *cw = dw;                                           // trimmed to what survived scaling
         if (tq_bypass_) {
             for (int k = 0; k < nz_n_; k++) { const int idx = nz_pos_[k], v = lev_[idx];
                 if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16); }
@@ -514,8 +513,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
                 if (v) cw[count++] = (uint32_t)idx | ((uint32_t)(uint16_t)(int16_t)v << 16);
             }
         }
-        jobs_->coefs.resize(first + count);
     }
+    jobs_->coefs.take(count);
     const uint8_t flags = (uint8_t)((tskip ? HTB_TSKIP : 0) | (tq_bypass_ ? HTB_BYPASS : 0) | ((cu_intra_ && c == 0 && n == 4) ? HTB_DST : 0));
     if (intra_tb) { HevcIntraTb &t = jobs_->itbs.back(); t.coef_off = first; t.coef_n = count; t.flags |= flags; }
     else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0;
@@ -684,12 +683,11 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             }
         }
     }
-    const uint16_t sidx = (uint16_t)slice_idx_;
     {   // per-4x4 maps of the coding unit, a row of units at a time (the unit loop with its eight array stores was 7 % of the parse)
         const int nu = n >> 2;
         HevcMotion blank; memset(&blank, 0, sizeof blank); blank.ref[0] = blank.ref[1] = -1;
         uint8_t *pm = pm_.data(), *sk = skip_.data(), *nf = nofilter_.data(), *cf = cbf_.data(), *ip = ipm_.data(), *ed = edge_.data();
-        uint16_t *so = slice_of_.data(); HevcMotion *mo = mot_.data();
+        HevcMotion *mo = mot_.data();
         for (int r = 0; r < nu; r++) {
             const int i = i4(x0, y0 + 4 * r);
             const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_, ved = r == 0 ? 10 : 0;
@@ -698,7 +696,6 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu);
                 memset(ed + i, ved, nu); }
             ed[i] |= 5;
-            for (int k = 0; k < nu; k++) so[i + k] = sidx;
             if (cu_intra_) for (int k = 0; k < nu; k++) mo[i + k] = blank;      // (the prediction units of an inter unit cover it and write their own)
         }
     }
@@ -873,7 +870,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
         // the collocated picture's motion down to this CTB row (its own parse sizes and fills the field: never read it before)
         if (refs.col && (rx == 0 || first_ctu)) refs.col->wait_rows(std::min((h_ + 15) >> 4, ((ry + 1) << sps_->log2_ctb) >> 4));
         if (ctb_slice_[ctb_rs_] >= 0) return "coding tree block decoded twice";
-        ctb_slice_[ctb_rs_] = sh.slice_addr;
+        ctb_slice_[ctb_rs_] = sh.slice_addr; ctb_sidx_[ctb_rs_] = (uint16_t)slice_idx_;
         { HevcCtb &cj = jobs_->ctbs[ctb_rs_]; cj.beta_off = slices_[slice_idx_].beta_off; cj.tc_off = slices_[slice_idx_].tc_off;
             cj.intra_first = (uint32_t)jobs_->itbs.size(); }
         // 9.3.1: the first CTB of a tile ALWAYS starts from initialised context variables -- also when it opens a dependent slice segment (the
@@ -920,7 +917,7 @@ void HevcPicParser::export_motion_rows(int r0, int r1) {
     for (int y = r0; y < r1; y++) for (int x = 0; x < c.w16; x++) {
         const int i = i4(x * 16, y * 16); const size_t e = (size_t)y * c.w16 + x;
         c.intra[e] = pm_[i] != 1; c.mot[e] = mot_[i]; c.lt[e] = 0;
-        size_t k = slice_of_[i]; const SliceInfo &s = slices_[k < slices_.size() ? k : slices_.size() - 1];
+        const SliceInfo &s = slices_[ctb_sidx_[((y * 16) >> sps_->log2_ctb) * ctb_w_ + ((x * 16) >> sps_->log2_ctb)]];
         for (int l = 0; l < 2; l++) if (pm_[i] == 1 && ((mot_[i].pf >> l) & 1)) { c.ref_poc[2 * e + l] = s.poc[l][mot_[i].ref[l]];
             c.lt[e] |= (uint8_t)(s.is_lt[l][mot_[i].ref[l]] << l); }
     }
@@ -958,11 +955,11 @@ void HevcPicParser::finish_picture() {
         cj.intra_count = (uint32_t)jobs_->itbs.size() - cj.intra_first;
         note_intra_bottom(rs);
         for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y);
-            pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; slice_of_[i] = 0; }
+            pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; }
     }
     if (slices_.empty()) { SliceInfo si; memset(&si, 0, sizeof si); si.deblock_disabled = true; slices_.push_back(si); }
-    // (after a damaged slice a unit may hold the slice index of an earlier picture: clamp)
-    auto slice_at = [&](int i) -> const SliceInfo & { size_t k = slice_of_[i]; return slices_[k < slices_.size() ? k : slices_.size() - 1]; };
+    // the slice of a sample position: slice segments start at coding tree blocks (blocks no slice delivered read as slice 0)
+    auto slice_at = [&](int x, int y) -> const SliceInfo & { return slices_[ctb_sidx_[(y >> lc) * ctb_w_ + (x >> lc)]]; };
     const int w8 = w_ >> 3, h8 = h_ >> 3;
     jobs_->qp8.resize((size_t)w8 * h8);
     for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8);
@@ -980,7 +977,7 @@ void HevcPicParser::finish_picture() {
         if (!tu && !pu) return 0;
         const SliceInfo *sq = &s0, *sp = &s0;
         if (!one_region) {
-            sq = &slice_at(q); sp = &slice_at(p);
+            sq = &slice_at(xq, yq); sp = &slice_at(xp, yp);
             if (sq->addr != sp->addr && !sq->lf_across) return 0;
             if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc);
                 if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
@@ -1036,12 +1033,12 @@ void HevcPicParser::finish_picture() {
         static const int dx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, dy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
         for (int rs = 0; rs < ctb_w_ * ctb_h_; rs++) {
             const int cx = rs % ctb_w_, cy = rs / ctb_w_; uint8_t mask = 0;
-            const SliceInfo &sc = slice_at(i4(cx << lc, cy << lc));
+            const SliceInfo &sc = slices_[ctb_sidx_[rs]];
             for (int k = 0; k < 8; k++) {
                 const int nx = cx + dx[k], ny = cy + dy[k];
                 if (nx < 0 || ny < 0 || nx >= ctb_w_ || ny >= ctb_h_) continue;
                 const int nrs = ny * ctb_w_ + nx;
-                const SliceInfo &sn = slice_at(i4(nx << lc, ny << lc));
+                const SliceInfo &sn = slices_[ctb_sidx_[nrs]];
                 bool ok = true;
                 if (sn.addr != sc.addr) ok = rs2ts_[nrs] < rs2ts_[rs] ? sc.lf_across : sn.lf_across;
                 if (ok && !pps_->lf_across_tiles && tile_id_[rs2ts_[nrs]] != tile_id_[rs2ts_[rs]]) ok = false;

@@ -38,9 +38,31 @@ struct HevcSliceRefs {            // RefPicList0 / RefPicList1 of one slice (8.3
     std::shared_ptr<HevcColMotion> col;       // motion of the collocated picture (slice_temporal_mvp_enabled_flag)
 };
 
+// A growing array of plain records for the lists the parser appends to ten thousand times per picture: push_back is a compare and a store (no
+// exception paths, no value-initialisation), and `tail(n)` hands out room for n more records that `take(k)` then keeps the first k of -- a transform
+// block's coefficients are written where they stay.  The storage lives as long as the object (thread-local in the parse workers): no allocation after
+// the first pictures.
+template <class T> struct PodList {
+    T *p = nullptr; size_t n = 0, cap = 0;
+    PodList() = default; PodList(const PodList &) = delete; PodList &operator=(const PodList &) = delete;
+    ~PodList() { free(p); }
+    size_t size() const { return n; }
+    T *data() { return p; } const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; }
+    void clear() { n = 0; }
+    T *tail(size_t more) {
+        if (n + more > cap) { size_t c = cap ? cap : 4096; while (c < n + more) c *= 2; T *q = (T *)realloc(p, c * sizeof(T)); if (!q) throw std::bad_alloc();
+            p = q; cap = c; }
+        return p + n;
+    }
+    void take(size_t k) { n += k; }
+    void push_back(const T &v) { *tail(1) = v; n++; }
+};
+
 struct HevcPicJobs {
     std::vector<HevcCtb> ctbs; std::vector<uint8_t> qp8, bs_v, bs_h;
-    std::vector<HevcPu> pus; std::vector<HevcTb> tbs; std::vector<HevcIntraTb> itbs; std::vector<uint32_t> coefs; std::vector<HevcWp> wps;
+    PodList<HevcPu> pus; PodList<HevcTb> tbs; PodList<HevcIntraTb> itbs; PodList<uint32_t> coefs; std::vector<HevcWp> wps;
     bool any_sao = false, any_deblock = false; int n_intra_cu = 0;
     void clear() { ctbs.clear(); qp8.clear(); bs_v.clear(); bs_h.clear(); pus.clear(); tbs.clear(); itbs.clear(); coefs.clear(); wps.clear();
         any_sao = any_deblock = false; n_intra_cu = 0; }
@@ -89,7 +111,7 @@ private:
     std::vector<int> rs2ts_, ts2rs_, tile_id_, ctb_slice_;
     std::vector<uint32_t> zs_;                 // MinTbAddrZs
     std::vector<uint8_t> pm_, skip_, depth_, ipm_, nofilter_, edge_, cbf_; std::vector<int8_t> qp_; std::vector<HevcMotion> mot_;
-    std::vector<uint16_t> slice_of_;
+    std::vector<uint16_t> ctb_sidx_;                      // index into slices_ by coding tree block (raster scan)
     std::vector<SliceInfo> slices_;
     int slice_idx_ = 0, ctb_rs_ = 0, ctb_ts_ = 0;
     // CU state
