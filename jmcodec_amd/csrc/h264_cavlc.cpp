@@ -443,11 +443,27 @@ struct P {
             for (int q = 0; q < 4; q++) {
                 if (!(mask & (1 << q))) continue;
                 refl[0][q] = (int8_t)rr[0]; refl[1][q] = (int8_t)rr[1];
+                bool col_zero = false;
+                if (inf8) {
+                    // direct_8x8_inference: the four blocks of the quadrant share the corner block of the colocated macroblock and therefore one vector
+                    // per list -- two rows of two (x, y) pairs, stored as two 64-bit words
+                    int refc, cx_, cy_; int32_t uid;
+                    col_block((q >> 1) * 12 + (q & 1) * 3, refc, cx_, cy_, uid);
+                    col_zero = col_short && refc == 0 && cx_ >= -1 && cx_ <= 1 && cy_ >= -1 && cy_ <= 1;
+                    const int r0 = (q >> 1) * 8 + (q & 1) * 2;
+                    for (int l = 0; l < 2; l++) {
+                        const bool z = zero || rr[l] < 0 || (rr[l] == 0 && col_zero);
+                        const uint32_t v = z ? 0u : ((uint32_t)(uint16_t)(int16_t)mvp[l][0] | (uint32_t)(uint16_t)(int16_t)mvp[l][1] << 16);
+                        const uint64_t two = (uint64_t)v | (uint64_t)v << 32;
+                        memcpy(mvl[l] + r0 * 2, &two, 8); memcpy(mvl[l] + (r0 + 4) * 2, &two, 8);
+                    }
+                    continue;
+                }
                 for (int k = 0; k < 4; k++) {
                     int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
-                    int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cx_, cy_; int32_t uid;
-                    col_block(rc, refc, cx_, cy_, uid);
-                    bool col_zero = col_short && refc == 0 && cx_ >= -1 && cx_ <= 1 && cy_ >= -1 && cy_ <= 1;
+                    int refc, cx_, cy_; int32_t uid;
+                    col_block(r, refc, cx_, cy_, uid);
+                    col_zero = col_short && refc == 0 && cx_ >= -1 && cx_ <= 1 && cy_ >= -1 && cy_ <= 1;
                     for (int l = 0; l < 2; l++) {
                         bool z = zero || rr[l] < 0 || (rr[l] == 0 && col_zero);
                         mvl[l][r * 2] = (int16_t)(z ? 0 : mvp[l][0]); mvl[l][r * 2 + 1] = (int16_t)(z ? 0 : mvp[l][1]);
@@ -457,9 +473,15 @@ struct P {
         } else {
             for (int q = 0; q < 4; q++) {
                 if (!(mask & (1 << q))) continue;
+                int m0x = 0, m0y = 0, m1x = 0, m1y = 0, r0 = 0;
                 for (int k = 0; k < 4; k++) {
                     int r = ((q >> 1) * 2 + (k >> 1)) * 4 + (q & 1) * 2 + (k & 1);
-                    int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cmx, cmy, r0 = 0; int32_t uid;
+                    if (k > 0 && inf8) {                               // the quadrant's one colocated block: the vectors of block 0 again
+                        mvl[0][r * 2] = (int16_t)m0x; mvl[0][r * 2 + 1] = (int16_t)m0y; mvl[1][r * 2] = (int16_t)m1x; mvl[1][r * 2 + 1] = (int16_t)m1y;
+                        continue;
+                    }
+                    int rc = inf8 ? (q >> 1) * 12 + (q & 1) * 3 : r, refc, cmx, cmy; int32_t uid;
+                    r0 = 0;
                     col_block(rc, refc, cmx, cmy, uid);
                     if (rf.col_mode == 1) cmy = cmy / 2; else if (rf.col_mode == 2) cmy *= 2;      // 8.4.1.2.3: Frm_To_Fld ("/" towards zero), Fld_To_Frm
                     if (refc >= 0) {
@@ -470,7 +492,6 @@ struct P {
                     if (rf.slot[0][r0] < 0) { err = "temporal direct without its list-0 reference"; return false; }
                     int tb = rf.cur_poc - rf.poc[0][r0], td = rf.poc[1][0] - rf.poc[0][r0];
                     tb = tb < -128 ? -128 : (tb > 127 ? 127 : tb); td = td < -128 ? -128 : (td > 127 ? 127 : td);
-                    int m0x, m0y, m1x, m1y;
                     if (rf.is_long[0][r0] || td == 0) { m0x = cmx; m0y = cmy; m1x = m1y = 0; }
                     else {
                         int tx = (16384 + (td < 0 ? -td : td) / 2) / td, dsf = (tb * tx + 32) >> 6;
@@ -826,16 +847,18 @@ struct P {
     int ae_cbp() {
         int cbp = 0;
         int ca4 = nA >= 0 ? cx.cbp[nA] : -1, cb4 = nB >= 0 ? cx.cbp[nB] : -1;
+        CabacRegs r(*cb);                                       // five to six bins, each context chosen by the bins before it
         for (int b8 = 0; b8 < 4; b8++) {
             int a = (b8 & 1) ? !((cbp >> (b8 - 1)) & 1) : (ca4 >= 0 ? !((ca4 >> (b8 + 1)) & 1) : 0);
             int b = (b8 & 2) ? !((cbp >> (b8 - 2)) & 1) : (cb4 >= 0 ? !((cb4 >> (b8 + 2)) & 1) : 0);
-            cbp |= cb->decision(73 + a + 2 * b) << b8;
+            cbp |= r.decision(73 + a + 2 * b) << b8;
         }
         int a = ca4 >= 0 && (ca4 >> 4) != 0, b = cb4 >= 0 && (cb4 >> 4) != 0;
-        if (cb->decision(77 + a + 2 * b)) {
+        if (r.decision(77 + a + 2 * b)) {
             a = ca4 >= 0 && (ca4 >> 4) == 2; b = cb4 >= 0 && (cb4 >> 4) == 2;
-            cbp |= (1 + cb->decision(77 + 4 + a + 2 * b)) << 4;
+            cbp |= (1 + r.decision(77 + 4 + a + 2 * b)) << 4;
         }
+        r.commit();
         return cbp;
     }
     int ae_qp_delta() {
