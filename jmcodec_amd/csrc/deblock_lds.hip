@@ -98,8 +98,8 @@ __global__ __launch_bounds__(kBandRows * 16) void k_deblock_band(const PicParams
 // ------------------------------------------------------------------------------------------
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kBandRows * kDeblockMaxBands; }
 
-int deblock_depth() { static const int depth = getenv("JM_AMD_DEC_DEBLOCK_DEPTH") ? atoi(getenv("JM_AMD_DEC_DEBLOCK_DEPTH")) : 3; return depth; }
-int deblock_pub() { static const int pub = getenv("JM_AMD_DEC_DEBLOCK_PUB") ? std::max(1, atoi(getenv("JM_AMD_DEC_DEBLOCK_PUB"))) : 2; return pub; }
+int deblock_depth() { return 3; }
+int deblock_pub() { return 2; }
 
 void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)

@@ -428,11 +428,10 @@ void Engine::launch(Lane &ln, Batch &b) {
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
     mark(5, pst);
-    static const bool no_pack = getenv("JM_AMD_DEC_EXP_NOPACK") != nullptr;           // experiment only: frames are not written
-    if (b.n_post && !no_pack) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pst); b.pmask |= 16; }
+    if (b.n_post) { launch_packout(b.d_jobs + 2 * kMaxBatch, b.n_post, max_w, max_h, pst); b.pmask |= 16; }
     mark(6, pst);
     hipEventRecord(b.packed, pst);                            // from here on the displayed surfaces may be decoded into again
-    if (!no_pack) for (auto &p : b.pics) copy_out(p.slots_after, pst);
+    for (auto &p : b.pics) copy_out(p.slots_after, pst);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) fprintf(stderr, "jm_amd_dec: kernel launch failed: %s\n", hipGetErrorString(le));
     hipEventRecord(b.done, pst);

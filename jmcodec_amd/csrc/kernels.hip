@@ -607,7 +607,7 @@ void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height,
     int blocks = (chunks + 255) / 256;
     // The destination is pinned HOST memory: the kernel is PCIe-bound (~55 GB/s), not CU-bound.  A small grid is enough to
     // keep the link full and leaves the CUs to the decode kernels of the next batch that run concurrently.
-    static const int total = getenv("JM_AMD_DEC_PACK_WGS") ? atoi(getenv("JM_AMD_DEC_PACK_WGS")) : 160;
+    const int total = 160;
     int cap = total / (n > 0 ? n : 1);
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
