@@ -800,7 +800,9 @@ struct P {
     int ae_t8x8() { return cb->decision(399 + (nA >= 0 && (cx.info[nA] & 8)) + (nB >= 0 && (cx.info[nB] & 8))); }
     int ae_intra_mode(int pred) {
         if (cb->decision(68)) return pred;
-        int rem = cb->decision(69); rem |= cb->decision(69) << 1; rem |= cb->decision(69) << 2;
+        CabacRegs r(*cb);
+        int rem = r.decision(69); rem |= r.decision(69) << 1; rem |= r.decision(69) << 2;
+        r.commit();
         return rem < pred ? rem : rem + 1;
     }
     int ae_chroma_mode() {
@@ -827,14 +829,17 @@ struct P {
         for (int k = 0; k < 2; k++) { int r, m = nb4(bx, by, k == 0, r); if (m >= 0) sum += (l ? cx.mvd1 : cx.mvd)[(size_t)m * 32 + r * 2 + comp]; }
         int base = comp ? 47 : 40;
         if (!cb->decision(base + (sum < 3 ? 0 : (sum > 32 ? 2 : 1)))) return 0;
+        CabacRegs r(*cb);                                       // the rest of the prefix, the suffix and the sign: three bins at least
         int v = 1, ctx = 3;
-        while (v < 9 && cb->decision(base + ctx)) { v++; if (ctx < 6) ctx++; }
+        while (v < 9 && r.decision(base + ctx)) { v++; if (ctx < 6) ctx++; }
         if (v == 9) {
             int k = 3;
-            while (cb->bypass()) { v += 1 << k; k++; if (k > 24) { err = "mvd out of range"; return 0; } }
-            while (k--) v += cb->bypass() << k;
+            while (r.bypass()) { v += 1 << k; k++; if (k > 24) { err = "mvd out of range"; r.commit(); return 0; } }
+            while (k--) v += r.bypass() << k;
         }
-        return cb->bypass() ? -v : v;
+        const int neg = r.bypass();
+        r.commit();
+        return neg ? -v : v;
     }
     void read_mvd(int bx, int by, int bw, int bh, int &dx, int &dy, int l = 0) {
         if (!cb) { dx = br.se(); dy = br.se(); return; }
