@@ -849,7 +849,6 @@ void Decoder::build_field_ref_lists(const SliceHeader &sh, SliceTask &task) {
         }
     }
     if (nlists == 2 && rf.slot[1][0] >= 0) {
-        // 8.4.1.2.1: the colocated field must come from a picture that was itself coded as a field (One_To_One); a field of a FRAME picture is not supported
         // 8.4.1.2.1: the colocated field's motion -- its own when it was coded as a field picture, otherwise that of the FRAME picture (Frm_To_Fld)
         const DpbPic &c = dpb_[rf.slot[1][0] & 31];
         if (c.coded_as_fields) task.col = c.mf_fld[(rf.slot[1][0] >> 5) & 1];
