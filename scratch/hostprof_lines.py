@@ -9,7 +9,8 @@ lo = hi = None
 for i, l in enumerate(lines):
     if len(l) == 3 and fn in l[2] and l[1] in "tT" and lo is None:
         lo = int(l[0], 16); hi = next(int(m[0], 16) for m in lines[i + 1:] if len(m) == 3 and int(m[0], 16) > lo)
-dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", "-l", "--start-address=" + hex(lo), "--stop-address=" + hex(hi), binary],
+dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", "-l", "--start-address=" + hex(lo), "--stop-address=" + hex(hi),
+    binary],
     capture_output=True, text=True).stdout
 per = collections.Counter(); cur = "?"
 for l in dis.splitlines():

@@ -92,7 +92,8 @@ def test_a_field_without_partner_on_device(oracle):
     starts = [i for i in range(len(data) - 4) if data[i:i + 4] == b"\0\0\0\1" or (data[i:i + 3] == b"\0\0\1" and data[i - 1:i] != b"\0")]
     cut = data[:starts[-1]]
     want, n, w, h = oracle.decode(cut, 1)
-    assert n == 4 and oracle.tools(cut).get("lone-fields", 0) == 0          # (the oracle counts a lone field when the NEXT picture starts; here the stream ends)
+    assert n == 4 and oracle.tools(cut).get("lone-fields",
+        0) == 0          # (the oracle counts a lone field when the NEXT picture starts; here the stream ends)
     assert b"".join(gpu_decode(cut)) == want
     # the same, followed by another coded video sequence: the lone field is completed when the IDR picture starts
     both = cut + streams.generate(**dict(kw, seed=303, paff=1))
@@ -342,7 +343,8 @@ def test_arbitrary_slice_order_on_device(oracle):
 def test_corrupt_field_picture_streams_do_not_crash_or_hang():
     """The same for interlaced streams: damaged field pictures (lost second fields, parities that do not pair, broken marking operations, B fields whose
     colocated field never arrived) must neither crash nor dead-lock; every frame that comes out has the stream's size."""
-    bases = [streams.generate(**PARITY_CASES[c]) for c in ("paff_adaptive_fuzz", "paff_adaptive_fuzz_cabac_wp", "paff_mixed_b_temporal_cabac", "paff_b_spatial")]
+    bases = [streams.generate(**PARITY_CASES[c]) for c in ("paff_adaptive_fuzz", "paff_adaptive_fuzz_cabac_wp", "paff_mixed_b_temporal_cabac",
+        "paff_b_spatial")]
     sizes = [(PARITY_CASES[c]["width"], PARITY_CASES[c]["height"]) for c in ("paff_adaptive_fuzz", "paff_adaptive_fuzz_cabac_wp", "paff_mixed_b_temporal_cabac",
                                                                             "paff_b_spatial")]
     rng = np.random.default_rng(11)

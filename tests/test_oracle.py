@@ -43,7 +43,8 @@ def test_field_picture_streams_exercise_the_field_rules(oracle):
         for k, v in oracle.tools(streams.generate(**PAFF_CASES[name])).items():
             seen[k] = seen.get(k, 0) + v
     for tool in ("field-pictures", "second-fields", "cross-parity-blocks", "field-mmco", "field-rplm", "field-sliding-window", "field-long-term",
-                 "half-marked-stores", "field-bS3", "field-mvy-limit", "b-field-pictures", "B_Direct", "B_Skip", "direct-frame-field-mixed", "field-long-term-ops"):
+                 "half-marked-stores", "field-bS3", "field-mvy-limit", "b-field-pictures", "B_Direct", "B_Skip", "direct-frame-field-mixed",
+                 "field-long-term-ops"):
         assert seen.get(tool, 0) > 0, f"no field-picture stream exercises {tool}"
     assert seen["second-fields"] * 2 == seen["field-pictures"] and "lone-fields" not in seen
 

@@ -145,7 +145,8 @@ PAFF_CASES = {
     "paff_adaptive_fuzz": dict(width=96, height=64, frames=14, gop=9, mode=1, seed=204, paff=1, num_ref=3, slices=2, rplm=1, mmco=1),
     "paff_adaptive_fuzz_cabac_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=204, paff=1, num_ref=4, cabac=1, rplm=1, mmco=2, wp=1, poc_type=0,
                                         nonref_period=3),
-    "paff_poc1_t8x8_scaling": dict(width=96, height=96, frames=12, gop=12, mode=1, seed=205, paff=1, num_ref=3, t8x8=1, scaling=1, poc_type=1, poc_bottom=1, deblock=2,
+    "paff_poc1_t8x8_scaling": dict(width=96, height=96, frames=12, gop=12, mode=1, seed=205, paff=1, num_ref=3, t8x8=1, scaling=1, poc_type=1, poc_bottom=1,
+    deblock=2,
                                    slices=3, chroma_qp_off=-3, alpha_off=2, beta_off=-2),
     "paff_poc2_cip_crop": dict(width=90, height=88, frames=10, gop=5, mode=1, seed=206, paff=2, num_ref=2, cip=1, poc_type=2, cabac=1, cabac_idc=2),
     "paff_real_qvga": dict(width=320, height=224, frames=6, gop=6, seed=207, paff=1, num_ref=2, cabac=1),
@@ -157,7 +158,8 @@ PAFF_CASES = {
     # frame and field pictures mixed around B pictures: the colocated picture of a B field may be a frame picture (Frm_To_Fld), that of a B frame a field
     # pair (Fld_To_Frm) -- 8.4.1.2.1 Tables 8-6 / 8-8, vertical vectors halved / doubled in temporal direct prediction
     "paff_mixed_b_spatial": dict(width=96, height=96, frames=13, gop=13, mode=1, seed=215, paff=1, bframes=2, num_ref=3, slices=2),
-    "paff_mixed_b_temporal_cabac": dict(width=96, height=64, frames=13, gop=13, mode=1, seed=216, paff=1, bframes=3, num_ref=3, cabac=1, direct_temporal=1, rplm=1),
+    "paff_mixed_b_temporal_cabac": dict(width=96, height=64, frames=13, gop=13, mode=1, seed=216, paff=1, bframes=3, num_ref=3, cabac=1, direct_temporal=1,
+    rplm=1),
     "paff_mixed_b_implicit_wp": dict(width=80, height=96, frames=14, gop=7, mode=1, seed=217, paff=1, bframes=2, num_ref=4, wp=2, t8x8=1, direct_temporal=1),
     "paff_mixed_b_real": dict(width=176, height=160, frames=10, gop=10, seed=218, paff=1, bframes=2, num_ref=2, cabac=1),
 }
