@@ -106,8 +106,10 @@ void Engine::submit(EnginePic &&p) {
         std::lock_guard<std::mutex> lk(m_);
         if (p.codec == 0) {
             const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            auto it = std::find_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *, long long> &r) { return r.first == p.dec; });
-            if (it != recent_.end()) it->second = now; else recent_.emplace_back(p.dec, now);
+            auto it = std::find_if(recent_.begin(), recent_.end(), [&](const Recent &r) { return r.dec == p.dec; });
+            if (it == recent_.end()) { recent_.push_back(Recent{p.dec, now, 0}); it = recent_.end() - 1; }
+            it->t = now;
+            if (p.has_picture) it->mbs = p.mb_w * p.mb_h;
         }
         pending_.push_back(std::move(p));
     }
@@ -140,8 +142,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     bool chaining = false;
     {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const std::pair<Decoder *,
-            long long> &r) { return now - r.second > 50ll * 1000 * 1000; }), recent_.end());
+        recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const Recent &r) { return now - r.t > 50ll * 1000 * 1000; }), recent_.end());
         const int n_active = (int)recent_.size();
         // A chain launch needs the whole GPU (its waits assume its bands stay resident, chain.hip).  When another process has compute queues on this
         // device -- a second rank of the same job, another tenant -- no chain launches are formed at all, instead of letting them time out against the
@@ -153,7 +154,11 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
             gpu_shared_ = sh;
         }
-        chaining = chain_depth_ > 1 && n_active > 0 && n_active <= chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
+        // "few streams" is meant in 1080p streams: a 4K stream fills the stage kernels like four of them.  (C2, 16 streams of 4K: the stage kernels run at the
+        // chains' rate, 2.4-2.5 k against 2.3-2.6 k frames/s -- and the first chain launch of such a run sometimes gave up)
+        double load = 0;
+        for (const Recent &r : recent_) load += std::max(1.0, r.mbs / 8160.0);
+        chaining = chain_depth_ > 1 && n_active > 0 && load <= (double)chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
         // One or two streams: a chain launch is as long as what its stream(s) fed while the previous launch ran.  Queueing a SECOND launch behind a running one
         // as soon as a picture or two are there splits that supply into a short launch and a long one, and a short chain costs nearly what a long one costs
         // (the first picture's wavefront, ~0.7 ms at 1080p).  So while a launch is in flight the next one is only formed when it would be a full chain;

@@ -146,7 +146,8 @@ private:
     // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};
     // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
-    std::vector<std::pair<Decoder *, long long>> recent_;
+    struct Recent { Decoder *dec; long long t; int mbs; };      // (dec is only compared, never dereferenced: the handle may be gone)
+    std::vector<Recent> recent_;
     // scratch of launch() // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     std::vector<std::vector<uint32_t>> group_buckets_;
     void launch(Lane &ln, Batch &b);
