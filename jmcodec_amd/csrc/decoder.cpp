@@ -373,7 +373,13 @@ bool Decoder::gpu_alloc_sequence() {
     // and one stream's chain of pictures stalls for every one of them (a first version grew slots on demand: single stream 4.0 k -> 3.1 k frames/s).
     // A P / B picture that outgrows its slot all the same is parsed again into a grown slot (parse_task): rare, and then the slot stays bigger.
     // 24 worst-case slots were 195 MB of page-locked memory per 1080p handle (14 GB for the bench's 32 handles: VERDICT r2 weak 11); now 55 MB.
-    job_cap_ = std::min(job_cap_max_, n_mbs * (sizeof(MbRec) + 128) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096);
+    // High streams get 320 bytes per macroblock: their P / B pictures average 125 (High I/P, CABAC + 8x8 transform, QP 28) to 195 bytes (with B
+    // pictures: a 144-byte motion record per bi-predicted macroblock) -- with the Baseline allowance every second picture of such a stream was parsed twice
+    // and its slot re-allocated mid-stream (`job_slots_grown` 344 / 760 in a bench run of High / High + B: 0.2 ms of kernel time per picture in the
+    // parse workers, 10.9 -> 9.6 k frames/s against round 2's worst-case slots on the same box).
+    // (Main / Extended: 224 -- B pictures, no 8x8 transform.)
+    const size_t per_mb = seq_.profile_idc == 66 ? 128 : (seq_.profile_idc < 100 ? 224 : 320);
+    job_cap_ = std::min(job_cap_max_, n_mbs * (sizeof(MbRec) + per_mb) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096);
     if (getenv("JM_AMD_DEC_JOB_WORST_CASE")) job_cap_ = job_cap_max_;
     if (codec_ == 1) job_cap_ = n_mbs * 128 + (1u << 20);            // HEVC job lists vary a lot in size: start small, grow on demand (ensure_job_cap)
     const bool lend_big = codec_ == 0 && job_cap_ < job_cap_max_;
