@@ -1,9 +1,8 @@
-# job slot allowance for Main / High streams: grow events, kernel time of the parse workers and rate (one box; the round-2 tree beside it)
+# job slot allowance for Main / High streams: grow events, kernel time of the parse workers and rate, lines written as profiles/r03_* files
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/sl
-for cfg in high high_b paff paff_b; do python bench.py --tools $cfg --steps 3 --no-cpu-baseline --no-single > gpurun_out/sl/r3_$cfg.json 2>/dev/null; done
+for cfg in high high_b paff paff_b; do python bench.py --tools $cfg --no-cpu-baseline --no-single > gpurun_out/sl/r3_$cfg.json 2>/dev/null; done
 python bench.py --tools high_b --width 3840 --height 2160 --streams 16 --frames 24 --steps 3 --no-cpu-baseline --no-single > gpurun_out/sl/r3_c2.json 2>/dev/null
 python bench.py --no-cpu-baseline > gpurun_out/sl/r3_default.json 2>/dev/null
-for cfg in high high_b; do ( cd scratch/_r2 && JM_AMD_DEC_THREADS=20 python bench.py --tools $cfg --steps 3 --no-cpu-baseline --no-single > ../../gpurun_out/sl/r2_$cfg.json 2>/dev/null ); done
 python - <<'PY'
 import json, glob, os
 for f in sorted(glob.glob('gpurun_out/sl/*.json')):
