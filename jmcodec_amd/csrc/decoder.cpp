@@ -50,7 +50,10 @@ struct Pool {
     std::vector<std::thread> threads;
     int n = 0, node = -1; bool bound = false;
     Pool(int node_, int n_) : n(n_), node(node_) {
-        bound = !numa_cpus_of_node(node).empty();
+        // The workers are bound to the node's CPUs only when this process may use enough of them: in a cpuset-restricted container that owns a couple
+        // of CPUs on that node and more elsewhere, binding would pile all n workers onto those few.  Enough = the pool's share of the CPU
+        // quota (n is quota x 1.25), at least half the pool.
+        bound = (int)numa_cpus_of_node(node).size() >= std::max(2, (n * 4 / 5 + 1) / 2);
         for (int i = 0; i < n; i++) threads.emplace_back([this] { pthread_setname_np(pthread_self(),
             "jm-parse"); if (bound) numa_bind_this_thread(node); run(); });
         for (auto &t : threads) t.detach();
@@ -206,6 +209,7 @@ long long Decoder::get_stat(const char *key) const {
         if (k == "eng_batch_pics") return es.batch_pics;
         if (k == "eng_chain_batches") return es.chain_batches;
         if (k == "eng_chain_pics") return es.chain_pics;
+        if (k == "eng_chain_i_batches") return es.chain_i_batches;
         if (k == "eng_wait_errors") return es.wait_errors;
         if (k == "eng_chain_recoveries") return es.chain_recoveries;
         if (k == "eng_gpu_shared") return engine_->gpu_shared() ? 1 : 0;
@@ -1167,19 +1171,23 @@ void Decoder::dispatch_pending() {
 }
 
 // big: the picture is an I picture -- several times the job list of a P / B picture.  It borrows one of the handle's worst-case buffers for as long as
-// it holds the slot.  Pictures are dispatched in decoding order, so whoever holds the buffers now completes without this picture: waiting is safe.
+// it holds the slot, WHEN one is free.  It never waits for one (an all-intra or short-GOP stream had its pipeline depth cut from
+// kJobSlots to kBigJobBufs that way, and the P / B pictures behind a waiting I picture could not be dispatched): without a free big buffer it takes
+// the roomiest free ordinary slot, which parse_task grows on overflow -- straight to the size the handle's I pictures have shown so far (i_job_peak_) --
+// and which stays that size; ordinary pictures take the SMALLEST free slot, so grown slots collect where the next I pictures find them.  An intra-only
+// stream therefore settles into kJobSlots slots of I-picture size after a handful of grow events (stat job_regrown) instead of running three deep.
 int Decoder::acquire_job_slot(bool big) {
     auto w0 = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(mtx_);
     const bool lend = big && codec_ == 0 && big_[0].host != nullptr;
     int got = -1, bg = -1;
     cv_.wait(lk, [&] {
-        got = bg = -1;
-        for (int i = 0; i < kJobSlots && got < 0; i++) if (!jobs_[i].busy) got = i;
-        if (lend) for (int i = 0; i < kBigJobBufs && bg < 0; i++) if (!big_[i].busy) bg = i;
-        return got >= 0 && (!lend || bg >= 0);
+        got = -1;
+        for (int i = 0; i < kJobSlots; i++) if (!jobs_[i].busy && (got < 0 || (big ? jobs_[i].cap > jobs_[got].cap : jobs_[i].cap < jobs_[got].cap))) got = i;
+        return got >= 0;
     });
-    if (lend) {
+    if (lend && jobs_[got].cap < job_cap_max_) for (int i = 0; i < kBigJobBufs && bg < 0; i++) if (!big_[i].busy) bg = i;
+    if (bg >= 0) {
         JobSlot &j = jobs_[got];
         j.own_host = j.host; j.own_dev = j.dev; j.own_cap = j.cap;
         j.host = big_[bg].host; j.dev = big_[bg].dev; j.cap = job_cap_max_; j.big = bg; big_[bg].busy = true;
@@ -1261,7 +1269,9 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
             if (r.error) { t->error = r.error; if (!first_error) first_error = r.error; overflow |= strcmp(r.error, "coefficient buffer overflow") == 0; }
         }
         if (overflow && js.cap < job_cap_max_ && attempt < 6 && !failed_) {
-            const size_t want = std::min(job_cap_max_, js.cap * 2);
+            // twice the size -- or, for an I picture in an ordinary slot (no worst-case buffer was free), what this handle's I pictures needed so far
+            const bool i_pic = !t->slices.empty() && t->slices[0].sh.type == SL_I;
+            const size_t want = std::min(job_cap_max_, std::max(js.cap * 2, i_pic ? i_job_peak_.load() * 5 / 4 : (size_t)0));
             if (ensure_job_cap(js, want)) { stat_job_regrown_++; continue; }
         }
         if (!t->error.empty()) { stat_errors_++; note_error(std::string("slice data: ") + t->error); }
@@ -1335,6 +1345,7 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
         long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
         bool is_i = !t->slices.empty() && t->slices[0].sh.type == SL_I;
         (is_i ? stat_parse_ns_i_ : stat_parse_ns_p_) += ns;
+        if (is_i) { size_t pk = i_job_peak_.load(); while (t->upload_bytes + 4096 > pk && !i_job_peak_.compare_exchange_weak(pk, t->upload_bytes + 4096)) {} }
     }
     t->t_parsed = now_ns();
     t->state.store(1, std::memory_order_release);

@@ -247,6 +247,7 @@ private:
     // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)
     uint8_t *hevc_work_[kHevcWorkSets] = {nullptr, nullptr, nullptr, nullptr}; unsigned hevc_work_rr_ = 0;
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
+    std::atomic<size_t> i_job_peak_{0};            // largest job list of an I picture of this handle so far (+ slack): what a slot grows to for the next one
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)
     bool gpu_open_ = false;
 

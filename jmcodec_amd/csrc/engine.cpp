@@ -133,7 +133,7 @@ EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
 // pictures, extend every decoder's share of the batch by its NEXT pictures as long as they can run inside the chain kernel (chain.hip):
 // consecutive P / B pictures of a stream then share one launch and follow each other at macroblock granularity instead of one per batch.
 bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
-    b.pics.clear(); b.any_chain = false; b.max_depth = 1;
+    b.pics.clear(); b.any_chain = false; b.chain_with_intra = false; b.max_depth = 1;
     // chain launches are formed while few streams have pictures ready (a wide batch fills the GPU anyway); then the I picture of an IDR period stays on
     // its stream's ordinary lane, where it becomes the first picture of a chain (k_chain_i), instead of going to the intra lane
     // The regime follows the number of ACTIVE streams (handles that submitted a picture in the last 50 ms), not the number that happen to have a picture
@@ -146,19 +146,13 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         const int n_active = (int)recent_.size();
         // A chain launch needs the whole GPU (its waits assume its bands stay resident, chain.hip).  When another process has compute queues on this
         // device -- a second rank of the same job, another tenant -- no chain launches are formed at all, instead of letting them time out against the
-        // other process's kernels and decoding their pictures again (Engine::recover: correct, but every such launch costs 100 ms).
-        if (kfd_gpu_id_ && now - shared_checked_ns_.load() > (gpu_shared_ ? 200ll : 1000ll) * 1000 * 1000) {
-            shared_checked_ns_ = now;
-            const bool sh = kfd_gpu_has_other_users(kfd_gpu_id_);
-            if (sh != gpu_shared_) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_,
-                sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
-            gpu_shared_ = sh;
-        }
+        // other process's kernels and decoding their pictures again (Engine::recover: correct, but every such launch costs 100 ms).  The look itself
+        // (a walk through KFD's sysfs) happens on the engine thread OUTSIDE m_ (Engine::look_for_other_users): submit() never waits for it.
         // "few streams" is meant in 1080p streams: a 4K stream fills the stage kernels like four of them.  (C2, 16 streams of 4K: the stage kernels run at the
         // chains' rate, 2.4-2.5 k against 2.3-2.6 k frames/s -- and the first chain launch of such a run sometimes gave up)
         double load = 0;
         for (const Recent &r : recent_) load += std::max(1.0, r.mbs / 8160.0);
-        chaining = chain_depth_ > 1 && n_active > 0 && load <= (double)chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_;
+        chaining = chain_depth_ > 1 && n_active > 0 && load <= (double)chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_.load(std::memory_order_relaxed);
         // One or two streams: a chain launch is as long as what its stream(s) fed while the previous launch ran.  Queueing a SECOND launch behind a running one
         // as soon as a picture or two are there splits that supply into a short launch and a long one, and a short chain costs nearly what a long one costs
         // (the first picture's wavefront, ~0.7 ms at 1080p).  So while a launch is in flight the next one is only formed when it would be a full chain;
@@ -428,6 +422,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         for (size_t k = 0; k < n_keys; k++) for (uint32_t e : group_buckets_[k]) b.h_groups[n_groups++] = e;
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
         launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_ != 0, st);
+        b.chain_with_intra = with_intra;
         b.pmask |= 32; mark(7, st);
     }
     hipEventRecord(b.kdone, st);
@@ -556,7 +551,7 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
     // (counted with or without profiling)
-    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++;
+    if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; st_.chain_i_batches += b.chain_with_intra;
         for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
     // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
@@ -564,6 +559,21 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }
     for (auto &p : b.pics) p.dec->on_engine_done(p, failed);
     b.pics.clear();
+}
+
+// about once a second (every 200 ms while the GPU is shared, and at once after a chain knob was set): does another process have compute queues on this GPU?
+// Engine thread only, no lock held.  A point-in-time sample: a process that arrives between two looks can still make a chain launch give up, which
+// recover() then repairs.
+void Engine::look_for_other_users() {
+    if (!kfd_gpu_id_) return;
+    const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const bool was = gpu_shared_.load(std::memory_order_relaxed);
+    if (now - shared_checked_ns_.load() <= (was ? 200ll : 1000ll) * 1000 * 1000) return;
+    shared_checked_ns_ = now;
+    const bool sh = kfd_gpu_has_other_users(kfd_gpu_id_);
+    if (sh != was) fprintf(stderr, "jm_amd_dec: device %d: %s -- chain launches %s\n", device_,
+        sh ? "another process has compute queues on this GPU" : "the GPU is no longer shared", sh ? "off" : "on again");
+    gpu_shared_.store(sh, std::memory_order_relaxed);
 }
 
 void Engine::run() {
@@ -593,6 +603,7 @@ void Engine::run() {
             if (ln.inflight >= max_inflight) continue;
             Batch &b = ln.ring[ln.head];
             bool have;
+            if (li == kOrdinaryLane) { bool any; { std::lock_guard<std::mutex> lk(m_); any = !pending_.empty(); } if (any) look_for_other_users(); }
             { std::lock_guard<std::mutex> lk(m_); have = !pending_.empty() && form(ln, li, b); }
             if (!have) continue;
             if (device_failed_) { complete(ln, b, true); progressed = true; continue; }      // nothing can run any more: fail the pictures right away

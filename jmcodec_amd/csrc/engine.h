@@ -80,6 +80,7 @@ struct EnginePic {
 struct EngineStats {
     double ns[5] = {0, 0, 0, 0, 0}; long long launches[5] = {0, 0, 0, 0, 0}, pics[5] = {0, 0, 0, 0, 0}, alg_bytes[5] = {0, 0, 0, 0, 0};
     long long batches = 0, batch_pics = 0, chain_batches = 0, chain_pics = 0, wait_errors = 0, chain_recoveries = 0;
+    long long chain_i_batches = 0;                  // chain launches that ran k_chain_i (the variant with the intra role); the others ran k_chain
     long long forms = 0, form_decoders = 0, form_pending = 0;   // ordinary-lane batches formed; decoders that had a picture waiting then; pictures waiting then
     long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
 };
@@ -109,7 +110,7 @@ public:
     bool set_knob(const std::string &key, long long v);
     EngineStats stats();
     int device() const { return device_; }
-    bool gpu_shared() const { return gpu_shared_; }      // another process has compute queues on this GPU (no chain launches then)
+    bool gpu_shared() const { return gpu_shared_.load(std::memory_order_relaxed); }      // another process has compute queues on this GPU (no chain launches then)
 
 private:
     explicit Engine(int device);
@@ -120,7 +121,7 @@ private:
         int *d_progress = nullptr;                            // CTB row progress counters of k_hevc_intra
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
-        bool any_chain = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
+        bool any_chain = false, chain_with_intra = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
         int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
@@ -159,7 +160,8 @@ private:
 
     int device_, numa_node_ = -1;
     // another process has queues on this GPU (checked about once a second): no chain launches
-    unsigned kfd_gpu_id_ = 0; bool gpu_shared_ = false; std::atomic<long long> shared_checked_ns_{0};
+    unsigned kfd_gpu_id_ = 0; std::atomic<bool> gpu_shared_{false}; std::atomic<long long> shared_checked_ns_{0};
+    void look_for_other_users();                    // engine thread, no lock held
     ihipStream_t *copy_stream_ = nullptr;
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];

@@ -98,7 +98,7 @@ HostCopier *HostCopier::get(int dev) {
                 tried++;
                 int good = 0;
                 for (int j = 0; j < 16; j++) { if (t[j] < 1e29 && t[j] <= 1.5 * best) good++; else if (t[j] < 1e29) slower_seen = true; }
-                if (good >= 3 && (slower_seen || tried >= 6)) break;
+                if ((good >= 3 && slower_seen) || tried >= 6) break;      // three good ones and a slower one seen, or six engines tried: stop (every engine ever used keeps a ~190 MB queue)
             }
         }
         (void)hipGetLastError();

@@ -64,14 +64,24 @@ bool numa_bind_this_thread(int node) {
     return sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
-// set_mempolicy without libnuma: mode 1 = MPOL_PREFERRED, 0 = MPOL_DEFAULT
+// set_mempolicy / get_mempolicy without libnuma: mode 1 = MPOL_PREFERRED.  The constructor runs on the APPLICATION's thread (gpu_alloc_sequence), so the
+// policy that thread had -- a membind or interleave set by the application or by numactl -- is read first and put back by the destructor;
+// when it cannot be read, nothing is changed at all.
 NumaPreferred::NumaPreferred(int node) {
     if (node < 0 || node >= 1024 || numa_cpus_of_node(node).empty()) return;
+    memset(old_mask, 0, sizeof old_mask);
+    if (syscall(SYS_get_mempolicy, &old_mode, old_mask, (unsigned long)(sizeof old_mask * 8), nullptr, 0ul) != 0) return;
     unsigned long mask[16]; memset(mask, 0, sizeof mask);
     mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
     on = syscall(SYS_set_mempolicy, 1, mask, (unsigned long)(sizeof mask * 8)) == 0;
 }
-NumaPreferred::~NumaPreferred() { if (on) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0ul); }
+NumaPreferred::~NumaPreferred() {
+    if (!on) return;
+    bool any = false;
+    for (unsigned long w : old_mask) any |= w != 0;
+    if (syscall(SYS_set_mempolicy, old_mode, any ? old_mask : nullptr, any ? (unsigned long)(sizeof old_mask * 8) : 0ul) != 0)
+        (void)syscall(SYS_set_mempolicy, 0, nullptr, 0ul);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
 static bool read_small(const char *path, char *buf, size_t n) {

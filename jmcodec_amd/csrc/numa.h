@@ -15,7 +15,8 @@ std::vector<int> numa_cpus_of_node(int node);
 // bind the calling thread to the node's CPUs; false (and no change) when the node or its CPUs are unknown
 bool numa_bind_this_thread(int node);
 // while alive, page allocations of the calling thread prefer `node` (set_mempolicy MPOL_PREFERRED): hipHostMalloc pins pages where they are first placed
-struct NumaPreferred { explicit NumaPreferred(int node); ~NumaPreferred(); bool on = false; };
+// the policy the thread had before (whatever the application or numactl set) is restored when the object dies
+struct NumaPreferred { explicit NumaPreferred(int node); ~NumaPreferred(); bool on = false; int old_mode = 0; unsigned long old_mask[16]; };
 
 // ---- who else is on the GPU (KFD sysfs) ----
 // The KFD driver's id of HIP device `dev` (/sys/class/kfd/kfd/topology/nodes/*/gpu_id, matched by PCI location); 0 when it cannot be told.

@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """Evidence lines of the GPU suite (which chain kernels really ran): printed even with -q, so the driver's record shows them."""
+    try:
+        import util
+    except ImportError:
+        return
+    for line in util.SESSION_NOTES:
+        terminalreporter.write_line("jm_amd_dec: " + line)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Build the product library, the generator and the oracle once per session (CPU only: hipcc cross-compiles)."""

@@ -412,3 +412,21 @@ def test_parse_pools_per_numa_node_in_the_many_gpus_one_process_mode(oracle, mon
     [t.join() for t in ts]
     for dev in (0, 1):
         assert got[dev][:4] == (want[0], want[1], 12, 0) and got[dev][4] == dev and got[dev][5] >= 1
+
+
+def test_all_intra_stream_is_not_held_to_the_lent_worst_case_buffers(monkeypatch):
+    """every picture of an intra-only stream is an I picture.  Three worst-case job buffers per handle are lent to I pictures; a
+    picture that finds none free must not wait for one (the pipeline would run three deep and block the feeding thread) -- it takes an ordinary slot,
+    which grows to I-picture size once and stays that size.  Fed in one chunk so that many pictures are in flight at once: every frame comes out, no
+    error, the job bytes equal those of worst-case slots, and the slots grew a bounded number of times (not once per picture)."""
+    data = streams.generate(width=352, height=288, frames=60, gop=1, qp=14, seed=0x4D95)
+
+    def run():
+        with api.JmAmdDec(0, 1, options={"parse_only": 1}) as d:
+            n = len(d.decode_stream(None, chunks=[data]))
+            return n, d.stat("errors"), d.stat("job_bytes"), d.stat("job_regrown"), d.stat("i_pictures")
+    n, errors, job_bytes, regrown, n_i = run()
+    monkeypatch.setenv("JM_AMD_DEC_JOB_WORST_CASE", "1")
+    n_w, errors_w, job_bytes_w, regrown_w, _ = run()
+    assert (n, errors, job_bytes) == (60, 0, job_bytes_w) and (n_w, errors_w, regrown_w) == (60, 0, 0) and n_i == 60
+    assert 1 <= regrown <= 2 * 24, regrown          # at most a grow event or two per job slot (24 slots), whatever the number of pictures

@@ -6,6 +6,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLDEN = os.path.join(HERE, "golden")
+SESSION_NOTES = []      # lines a test wants in the terminal summary whatever the verbosity (conftest.py prints them)
 
 
 def golden_meta():
