@@ -74,3 +74,33 @@ def test_bench_two_ranks_gloo_parse_only():
     assert d["frames"] == 2 * 3 * 6 * 2                       # ranks x streams x frames x steps
     assert d["config"]["stream_ids"] == [0, 4]                # rank 0 of 2: streams 0, 2, 4 of the job's 6
     assert d["bit_exact"] is None and "cpu_baseline" not in d  # parse-only: no pixels to check; the CPU baseline is an N=1 leg
+
+
+def test_bench_extra_legs_parse_only(tmp_path):
+    """the default bench invocation appends untimed legs for the other BASELINE configurations -- c4_slice (8 x 1080p Baseline), c2_4k (16 x 4K
+    High I B B P), c3_4k (16 x 4K HEVC) -- each a compact object with its own bit-exact flag and roofline block.  Here: the same code path at a toy size
+    without a GPU (--parse-only, JM_BENCH_TEST_LEGS): one JSON line, the headline keys unchanged, the three legs present with the promised fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--parse-only", "--streams", "2", "--frames", "8", "--width", "176",
+           "--height", "144"]
+    env = dict(os.environ, JM_BENCH_CACHE=str(tmp_path), JM_BENCH_TEST_LEGS="176x144")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["frames"] == 2 * 8 and d["n_gpus"] == 1
+    want = {"c4_slice": ("H.264 Baseline", 60), "c2_4k": ("H.264 High, I B B P", 24), "c3_4k": ("HEVC Main", 16)}
+    for key, (tools, frames) in want.items():
+        leg = d[key]
+        assert "error" not in leg, leg
+        assert leg["workload"].startswith(tools) and f"x {frames} frames per step" in leg["workload"]
+        assert leg["value"] > 0 and leg["decode_errors"] == 0
+        for k in ("bit_exact", "frames_checked", "scaling_bound", "roofline", "host_cpu", "engine", "kernels"):
+            assert k in leg
+        for k in ("kernel", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_us"):
+            assert k in leg["roofline"]
+        assert "cpu_ms_per_frame" in leg["host_cpu"]
