@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
         const int mb = valid ? row * pp.mb_w + x : 0;
         // one instantiation for every picture of the launch (with the cached-load variant beside it the kernel needs 196 VGPRs and scratch;
         // this way 165): a picture without references inside the launch passes wait_final at once
-        recon_inter_wave<true, true>(pp, mb, valid, sm, cv);
+        recon_inter_wave<true, true, true, false>(pp, mb, valid, sm, cv);
     } else {
         __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes];
         int *cpic = cv.pic(pp.chain_idx);

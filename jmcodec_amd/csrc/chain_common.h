@@ -45,6 +45,19 @@ enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RI
                // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
                CHAIN_ERR_NOT_RECOVERED = 32 };
 
+// Steps between a macroblock row and the row below it (round 4).  Clause 8.7 orders the macroblocks in raster order, and within one the vertical edges (V)
+// before the horizontal edges (H).  Which filters touch the same samples: V(x, y) the macroblock and columns 12..15 of (x - 1, y); H(x, y) the macroblock and rows
+// 12..15 of (x, y - 1).  So V(x, y) needs H(x - 1, y) and nothing of the row above, and H(x, y) needs V(x, y) and -- for columns 13..15 of those four rows, which
+// the left edge of (x + 1, y - 1) changes -- V(x + 1, y - 1), but NOT H(x + 1, y - 1).  Rounds 1-3 ran whole macroblocks per step, which needs two steps
+// between rows (s = x + 2y: 254 steps at 1080p, 508 at 4K).  With the step cut into a V phase and an H phase by a second barrier, (x + 1, y - 1) and (x, y)
+// share a step: s = x + y, 187 steps at 1080p (-26 %), 374 at 4K, every filter still sees exactly the samples raster order would give it (no two filters
+// that touch a common sample change their order).  JM_DEBLOCK_ROW_LAG=2 builds the old schedule (A/B runs).
+#ifndef JM_DEBLOCK_ROW_LAG
+#define JM_DEBLOCK_ROW_LAG 1
+#endif
+constexpr int kRowLag = JM_DEBLOCK_ROW_LAG;
+static_assert(kRowLag == 1 || kRowLag == 2, "row lag of the deblocking wavefront");
+
 typedef __attribute__((address_space(1))) int gint;
 
 // loads / stores of data that another workgroup of the same launch produces or consumes
@@ -124,12 +137,13 @@ struct ChainView {
     // ((px + 4) >> 4, (py + 4) >> 4) (clamped; deblock_device.h stores (-4,-4)-shifted blocks, chroma the same in its own units), i.e. in
     // wavefront step X + 2Y of the band that holds row Y.  A rectangle touches at most two bands.  Per lane; dep < 0 = nothing to wait for.
     // Returns false when the wait gave up.
-    __device__ __forceinline__ bool wait_final(int dep, int xmax, int ymin, int ymax, int mb_w, int mb_h) const {
+    // row_lag = steps between a macroblock row and the next in the deblocking wavefront (deblock_device.h kRowLag): macroblock (X, Y) is step X + row_lag * Y
+    __device__ __forceinline__ bool wait_final(int dep, int xmax, int ymin, int ymax, int mb_w, int mb_h, int row_lag) const {
         bool pending = dep >= 0;
         const int *fin = pic(pending ? dep : 0) + kChainFin;
         const int xs = min((xmax + 4) >> 4, mb_w - 1), yhi = min((ymax + 4) >> 4, mb_h - 1), ylo = min(max((ymin + 4) >> 4, 0), yhi);
         const int bhi = yhi >> 4, blo = ylo >> 4;
-        const int need_hi = xs + 2 * yhi + 1, need_lo = xs + 2 * (blo * 16 + 15) + 1;
+        const int need_hi = xs + row_lag * yhi + 1, need_lo = xs + row_lag * (blo * 16 + 15) + 1;
         int spins = 0; uint32_t t0 = 0;
         for (;;) {
             if (pending) {

@@ -24,7 +24,7 @@ constexpr int kChainISmemBytes = kIntraSmemBytes > kDeblockSmemBytes ? (kIntraSm
                                                                       : (kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds));
 
 template <int DEPTH>
-__global__ __launch_bounds__(256) __attribute__((flatten)) void k_chain_i(const PicParams *pics, int *ctl, int *err, const uint32_t *groups, int pub) {
+__global__ __launch_bounds__(256, 3) __attribute__((flatten)) void k_chain_i(const PicParams *pics, int *ctl, int *err, const uint32_t *groups, int pub) {
     // one LDS block for whichever role this workgroup has (separate static arrays would add up to 65 KB)
     __shared__ __align__(16) uint8_t smem[kChainISmemBytes];
     const int g = (int)blockIdx.x >> 1, rem = (int)blockIdx.x & 1;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) __attribute__((flatten)) void k_chain_i(const 
         const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
-        recon_inter_wave<true, true>(pp, valid ? row * pp.mb_w + x : 0, valid, *reinterpret_cast<ReconLds *>(smem), cv);
+        recon_inter_wave<true, true, true, false>(pp, valid ? row * pp.mb_w + x : 0, valid, *reinterpret_cast<ReconLds *>(smem), cv);
     } else {
         int *cpic = cv.pic(pp.chain_idx);
         const int band = (int)(entry & 31u);

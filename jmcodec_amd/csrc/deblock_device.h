@@ -133,20 +133,23 @@ template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) 
 // luma: one macroblock, 16 lanes (l = 0..15)
 // ------------------------------------------------------------------------------------------
 // row = macroblock row in the picture, lrow = the row's index in the workgroup's LDS image (== row when one workgroup holds the whole plane)
-template <bool WT>
+// PHASE: 0 = the whole macroblock; 1 = its vertical edges only (kRowLag 1: every row of the band does this part of its step, then a barrier);
+// 2 = horizontal edges + the final store
+template <bool WT, int PHASE = 0>
 __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, int row, int lrow, int l, int group, uint4 own, uint32_t recdw) {
     uint8_t *tc = lds.luma_tile(lrow, x & 1), *tp = lds.luma_tile(lrow, (x - 1) & 1);
     uint8_t *ring_up = row > 0 ? lds.luma_ring(lrow - 1, x & 3) : nullptr;
     uint8_t *ring_up_l = row > 0 ? lds.luma_ring(lrow - 1, (x - 1) & 3) : nullptr;
     uint8_t *ring_dn = lds.luma_ring(lrow, x & 3), *ring_dn_l = lds.luma_ring(lrow, (x - 1) & 3);
     uint8_t *rec = lds.rec(group);
-    if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte luma half of the DbRec
+    if (PHASE != 2 && l < 12) ((uint32_t *)rec)[l] = recdw;   // 48-byte luma half of the DbRec
     // this lane's four vertical-edge and four horizontal-edge strengths (bS | tC0 << 3), and the class parameters
     int vb[4], hb[4], ab[6];
 #pragma unroll
-    for (int e = 0; e < 4; e++) { vb[e] = rec[e * 4 + (l >> 2)]; hb[e] = rec[16 + e * 4 + (l >> 2)]; }
+    for (int e = 0; e < 4; e++) { if (PHASE != 2) vb[e] = rec[e * 4 + (l >> 2)]; if (PHASE != 1) hb[e] = rec[16 + e * 4 + (l >> 2)]; }
 #pragma unroll
     for (int i = 0; i < 6; i++) ab[i] = rec[32 + i];
+    if (PHASE != 2) {
     // ---- vertical edges: lane = pixel row l ----
     uint32_t left = x > 0 ? *(const uint32_t *)(tp + l * 16 + 12) : 0;
     // The row's 20 samples x[-4 .. 15] arrive as five dwords.  Edge e pairs x[4e - 1 - i] with x[4e + i]: one v_perm_b32 per pair -- the p side of
@@ -175,6 +178,8 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
     *(uint4 *)(tc + l * 16) = make_uint4(row_after[0], row_after[1], row_after[2], row_after[3]);
     // the left neighbour's bottom rows (its ring slot) get our edge-0 result for columns 12..15
     if (x > 0 && l >= 12) *(uint32_t *)(ring_dn_l + (l - 12) * 16 + 12) = left_after;
+    }
+    if (PHASE == 1) return;
     // ---- horizontal edges: lane = pixel column l ----
     {
         uint32_t c[20];
@@ -233,16 +238,16 @@ __device__ __forceinline__ void luma_mb(const DbCtx &pp, const Lds &lds, int x, 
 // ------------------------------------------------------------------------------------------
 // chroma (NV12 interleaved UV): one macroblock, 16 lanes
 // ------------------------------------------------------------------------------------------
-template <bool WT>
+template <bool WT, int PHASE = 0>
 __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x, int row, int lrow, int l, int group, uint4 own, uint32_t recdw) {
     uint8_t *tc = lds.chroma_tile(lrow, x & 1), *tp = lds.chroma_tile(lrow, (x - 1) & 1);
     uint8_t *ring_up = row > 0 ? lds.chroma_ring(lrow - 1, x & 3) : nullptr;
     uint8_t *ring_up_l = row > 0 ? lds.chroma_ring(lrow - 1, (x - 1) & 3) : nullptr;
     uint8_t *ring_dn = lds.chroma_ring(lrow, x & 3), *ring_dn_l = lds.chroma_ring(lrow, (x - 1) & 3);
     uint8_t *rec = lds.rec(group);
-    if (l < 12) ((uint32_t *)rec)[l] = recdw;                 // 48-byte chroma half of the DbRec
+    if (PHASE != 2 && l < 12) ((uint32_t *)rec)[l] = recdw;   // 48-byte chroma half of the DbRec
     // ---- vertical edges (chroma columns 0 and 4 <-> luma edges 0 and 2): lane = (plane, chroma row) ----
-    {
+    if (PHASE != 2) {
         const int plane = l >> 3, r = l & 7;
         // `own` of lane l is row (l & 7) of the macroblock (both lane halves prefetch the same 16 bytes)
         const uint32_t left = x > 0 ? *(const uint32_t *)(tp + r * 16 + 12) : 0;
@@ -265,7 +270,8 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
         }
     }
     // left neighbour's bottom rows: columns 12..15 (bytes) of rows 6, 7 after our edge 0
-    if (x > 0 && l < 2) *(uint32_t *)(ring_dn_l + l * 16 + 12) = *(const uint32_t *)(tp + (6 + l) * 16 + 12);
+    if (PHASE != 2 && x > 0 && l < 2) *(uint32_t *)(ring_dn_l + l * 16 + 12) = *(const uint32_t *)(tp + (6 + l) * 16 + 12);
+    if (PHASE == 1) return;
     // ---- horizontal edges (chroma rows 0 and 4): lane = interleaved byte column ----
     {
         int plane = l & 1;
@@ -322,6 +328,7 @@ __device__ __forceinline__ void chroma_mb(const DbCtx &pp, const Lds &lds, int x
 //     cover the step it is about to prefetch for, so in steady state it runs a few steps behind without waiting.
 // Workgroups of a lower band have the higher block index, so whatever a workgroup waits for has been dispatched before it.
 constexpr int kBandRows = 16;
+// kRowLag (chain_common.h): steps between a macroblock row and the row below it -- 1 since round 4 (a step = V phase | barrier | H phase)
 constexpr int kDeblockSmemMain = kBandRows * Lds::kRecStride + (kBandRows + 1) * (Lds::kLT + Lds::kLR);
 // Per wave and prefetch stage, the inputs of one step as the LDS-DMA loads deliver them (lane-linear): 64 x 16 B of samples, 64 x 4 B of DbRec
 // dwords, 64 x 4 B of ring-row dwords from the band above.
@@ -380,7 +387,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
     const bool takes_ring = band > 0 && group == 0;                        // first row of a lower band: ring rows come from the band above
     const bool gives_ring = active && group == rows - 1 && row < mb_h - 1;  // last row of a band that has a band below
-    const int s_begin = 2 * row0, s_end = mb_w - 1 + 2 * (row0 + rows - 1);
+    const int s_begin = kRowLag * row0, s_end = mb_w - 1 + kRowLag * (row0 + rows - 1);
     int known = 0;                                                          // steps the band above is known to have completed
     // launch-wide: a wait of this launch gave up (chain_common.h)
     int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
@@ -430,8 +437,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     uint8_t *stage = smem + kDeblockSmemMain + wave * (kDeblockMaxDepth * kStageBytes);
     const uint32_t stage_lds = lds_addr_of(stage);
     auto fetch = [&](int d, int s) {
-        int xn = min(max(s - 2 * row, 0), mb_w - 1);
-        if (CHAIN) wait_recon(s - 2 * row);     // (steps outside the row load a clamped position whose data is never used: nothing to wait for)
+        int xn = min(max(s - kRowLag * row, 0), mb_w - 1);
+        if (CHAIN) wait_recon(s - kRowLag * row);     // (steps outside the row load a clamped position whose data is never used: nothing to wait for)
         const uint32_t slot = stage_lds + (uint32_t)d * kStageBytes;
         glds16<CHAIN>(pix_base + xn * 16, slot);                                        // CHAIN: reconstructed in this launch -> coherent load
         glds4<false>(rec_base + (size_t)xn * sizeof(DbRec), slot + 1024);
@@ -446,22 +453,33 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto step = [&](int s, uint4 own, uint32_t rdw, uint32_t ring) {
-        const int x = s - 2 * row;
-        if (active && x >= 0 && x < mb_w) {
+        const int x = s - kRowLag * row;
+        const bool work = active && x >= 0 && x < mb_w;
+        constexpr int kFirst = kRowLag == 1 ? 1 : 0;                        // kRowLag 1: vertical edges | barrier | horizontal edges + store
+        if (work) {
             if (is_chroma) {
                 if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
-                chroma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring) {
-                    if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
-                    if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
-                }
+                chroma_mb<CHAIN, kFirst>(cx, lds, x, row, lrow, l, group, own, rdw);
             } else {
                 if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
-                luma_mb<CHAIN>(cx, lds, x, row, lrow, l, group, own, rdw);
-                if (gives_ring) {
-                    if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
-                    if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
-                }
+                luma_mb<CHAIN, kFirst>(cx, lds, x, row, lrow, l, group, own, rdw);
+            }
+        }
+        if (kRowLag == 1) {
+            // the row above ran V(x + 1, row - 1) in this very step: its left edge changed columns 13..15 of the ring rows H(x, row) starts from
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (work) {
+                if (is_chroma) chroma_mb<CHAIN, 2>(cx, lds, x, row, lrow, l, group, own, rdw);
+                else luma_mb<CHAIN, 2>(cx, lds, x, row, lrow, l, group, own, rdw);
+            }
+        }
+        if (work && gives_ring) {
+            if (is_chroma) {
+                if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
+            } else {
+                if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
             }
         }
         // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough -- and not by draining
@@ -488,7 +506,10 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     static_assert(DEPTH >= 2 && DEPTH <= kDeblockMaxDepth, "prefetch depth");
-    wait_above(s_begin + DEPTH);
+    // the ring rows a step starts from are final once the band above has completed the step before it (kRowLag 2) / that very step (kRowLag 1: its last
+    // row runs V(x + 1) in the step in which this band's first row runs H(x))
+    constexpr int kAbove = 2 - kRowLag;
+    wait_above(s_begin + DEPTH + kAbove);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, s_begin + d);
     for (int s = s_begin; s <= s_end; s += DEPTH) {
@@ -502,7 +523,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             const uint4 own = *(const uint4 *)(sl + wl * 16);
             const uint32_t rdw = *(const uint32_t *)(sl + 1024 + wl * 4), ring = *(const uint32_t *)(sl + 1280 + wl * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is read before its next load is even issued
-            wait_above(s + j + DEPTH);                // the ring rows of step s + j + DEPTH are final once the band above completed the step before it
+            wait_above(s + j + DEPTH + kAbove);      // the ring rows of step s + j + DEPTH: see above
             fetch(j, s + j + DEPTH);
             step(s + j, own, rdw, ring);
         }

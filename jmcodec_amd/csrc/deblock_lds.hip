@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kBandRows * 16) void k_deblock_band(const PicParams
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kBandRows * kDeblockMaxBands; }
 
 int deblock_depth() { return 3; }
+int deblock_row_lag() { return kRowLag; }     // steps between macroblock rows of the deblocking wavefront (Engine::launch orders chain work lists by it)
 int deblock_pub() { return 2; }
 
 void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {

@@ -1318,14 +1318,14 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
     }
     if (failed_) { w.mv_ext_count = 0; }
     memcpy(w.coef + w.coef_count, mv_ext_buf.data(), (size_t)w.mv_ext_count * 4);
-    t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count; t->max_mvy = w.max_mvy;
+    t->coef_count = w.coef_count; t->mv_ext_count = w.mv_ext_count; t->max_mvy = w.max_mvy; t->max_mvx = w.max_mvx;
     t->upload_bytes = fixed + (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4;
     if (want_job_digest_) {                                  // (pictures are parsed in order: sync option)
         uint64_t h = job_digest_;
         auto eat = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
         eat(mbs, (size_t)n_mbs * sizeof(MbRec)); eat(srec, t->slices.size() * sizeof(SliceRec));
         eat(w.coef, (size_t)w.coef_count * 2 + (size_t)w.mv_ext_count * 4);
-        const int mm = w.max_mvy; eat(&mm, sizeof mm);
+        const int mm = w.max_mvy, mmx = w.max_mvx; eat(&mm, sizeof mm); eat(&mmx, sizeof mmx);
         job_digest_ = h;
     }
     if (t->any_wp && t->upload_bytes + t->slices.size() * sizeof(SliceWp) > js.cap) { t->error = "job buffer overflow (weight tables)"; stat_errors_++;
@@ -1454,6 +1454,7 @@ void Decoder::submit_task(PicTask *t) {
         ep.classic_stages = pp.stages;
         for (auto &sl : t->slices) ep.bipred |= sl.refs.bipred_rec;
         ep.reach_rows = ((t->max_mvy >> 2) + 15) / 16;      // macroblock rows below a macroblock that its reference windows can touch beyond the usual one
+        ep.reach_cols = ((t->max_mvx >> 2) + 15) / 16;      // ... and macroblocks to its right
         for (auto &sl : t->slices) for (int l = 0; l < 2; l++) for (int i = 0; i < 32; i++) if (sl.refs.slot[l][i] >= 0) ep.ref_mask |=
             1u << (sl.refs.slot[l][i] & 31);
         // algorithmic bytes of this picture per kernel class

@@ -83,7 +83,7 @@ struct PicTask {
     std::atomic<int> state{0};                 // 0 queued, 1 parsed
     int n_intra = 0, n_i8x8 = 0, n_slices = 0; bool any_deblock = false;
     uint32_t coef_count = 0, mv_ext_count = 0; size_t upload_bytes = 0, wp_offset = 0; bool any_wp = false;
-    int max_mvy = 0;                           // largest downward vertical vector component (quarter samples)
+    int max_mvy = 0, max_mvx = 0;              // largest downward / rightward vector component (quarter samples): spacing of chain launches
     unsigned long long upload_seq = 0;
     std::string error;
     long long t_dispatch = 0, t_parsed = 0;    // host steady-clock ns (JM_AMD_DEC_TRACE)

@@ -372,9 +372,9 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (hd.any_intra) b.pmask |= 4;
         if (hd.any_deblock || hd.any_sao) b.pmask |= 8;
     }
-    b.any_bipred = false;
-    for (auto &p : b.pics) b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred;
-    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, st); b.pmask |= 2; }
+    b.any_bipred = b.any_field = false;
+    for (auto &p : b.pics) { b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred; b.any_field |= p.has_picture && p.codec == 0 && p.pp.field != 0; }
+    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, b.any_field, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
@@ -386,19 +386,36 @@ void Engine::launch(Lane &ln, Batch &b) {
     // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
     if (stages & PS_CHAIN) {
         // Work list of the chain kernel, ordered along the pipeline's time axis (chain.hip).  The deblocking wavefront of a picture reaches
-        // macroblock (x, y) in step x + 2y; a picture follows the previous picture of its stream `lag` steps behind (plus twice the number of
-        // rows its vectors reach further down than usual, from the parser).  Keys: 8-macroblock segment of row r: base + 2r + 8 * segment;
-        // Every reconstruction dependency then points to a smaller key -- also the
-        // transitive ones through a band to the previous picture's reconstruction (a few macroblocks right of and below the segment itself:
-        // 8 + 1 + 2 (publishing lag) + 3 (prefetch depth) + 2 steps) -- as long as lag > 16: what keeps a full machine from deadlocking.
-        const int band_rows = chain_band_rows();
+        // macroblock (x, y) in step x + L * y (L = deblock_row_lag(), 1 since round 4); the band that holds row y trails the band above it by about
+        // kBandLag steps (prefetch depth + publishing lag of the ring-row hand-over, deblock_device.h); a picture follows the previous picture of
+        // its stream `lag` steps behind, plus what its vectors reach beyond the usual window: L steps per macroblock row further DOWN and one step per
+        // macroblock further RIGHT (both from the parser; rounds 2-3 counted only the rows, so a stream with long rightward vectors could break the
+        // rule below).  Key of the 8-macroblock segment c of row r:
+        //     base(picture) + L * r + 8 * c + kBandLag * (r / band_rows)
+        // i.e. (an upper bound of) the step in which the picture's OWN deblocking wants the segment.  Rule: every dependency of a reconstruction
+        // group points to a smaller key.  Direct ones: the reference samples of macroblock (x, r) are final after step (x + 1 + reach_x) + L * (r +
+        // 1 + reach_y) of the previous picture, published 2 steps late.  Transitive ones: to run that step the band has prefetched 3 steps ahead,
+        // i.e. it has waited for the reconstruction bits of every macroblock (x', y') of its rows with x' + L * y' up to that step + 3 -- and the
+        // band ABOVE it has run kBandLag steps further, the one above that 2 * kBandLag, ...: exactly the term the key carries, so the bound holds
+        // at every band level (rounds 2-3 had no such term: with nine bands at 4K the bound was off by up to 8 * 7 steps for the lowest band).
+        // With 8c <= x' the previous picture's groups involved have keys <= base' + x + L * r + L + 8 + kBandLag * band, this group's key is
+        // >= base' + lag + x - 7 + L * r + kBandLag * band: smaller whenever lag > L + 15.  That is what keeps a full machine from deadlocking:
+        // the unfinished group with the smallest key is resident (in-order dispatch per XCD) and waits only for finished groups and resident bands.
+        // A launch that holds a picture with the intra role (k_chain_i) keeps L = 2 in its keys: that picture's deblocking follows its intra wavefront,
+        // which advances as x + 2y (intra prediction needs the macroblock above right COMPLETE), so its reconstruction groups are wanted in that order;
+        // keys built for x + 2y also bound the dependencies of a wavefront that runs as x + y (x' + 2y' <= x' + y' + Y).
+        bool launch_has_intra = false;
+        for (int i = 0; i < n; i++) launch_has_intra |= (b.h_pics[i].stages & PS_CHAIN_INTRA) != 0;
+        const int band_rows = chain_band_rows(), L = launch_has_intra ? 2 : deblock_row_lag();
+        constexpr int kBandLag = 8;
         std::vector<int> base_of(n, 0);
         size_t n_keys = 0;
         for (int i = 0; i < n; i++) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
             for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
-                base_of[i] = base_of[j] + chain_lag_steps_ + 2 * b.pics[i].reach_rows; break; }
-            n_keys = std::max(n_keys, (size_t)(base_of[i] + 2 * b.h_pics[i].mb_h + b.h_pics[i].mb_w + 2));
+                base_of[i] = base_of[j] + chain_lag_steps_ + L * b.pics[i].reach_rows + b.pics[i].reach_cols + kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
+                break; }
+            n_keys = std::max(n_keys, (size_t)(base_of[i] + L * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
         }
         if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
         for (size_t k = 0; k < n_keys; k++) group_buckets_[k].clear();
@@ -406,7 +423,8 @@ void Engine::launch(Lane &ln, Batch &b) {
             if (!(b.h_pics[i].stages & PS_CHAIN) || (b.h_pics[i].stages & PS_RECON)) continue;      // (PS_RECON: reconstructed by the stage kernel)
             const int mb_h = b.h_pics[i].mb_h, segs = (b.h_pics[i].mb_w + 7) / 8, base = base_of[i];
             for (int r = 0; r < mb_h; r++) {
-                for (int c = 0; c < segs; c++) group_buckets_[base + 2 * r + 8 * c].push_back((uint32_t)i << 16 | (uint32_t)(r * 32 + c));
+                const int kr = base + L * r + kBandLag * (r / band_rows);
+                for (int c = 0; c < segs; c++) group_buckets_[kr + 8 * c].push_back((uint32_t)i << 16 | (uint32_t)(r * 32 + c));
             }
         }
         // Every deblocking band of the launch goes FIRST (Engine::form keeps their number at half of what the GPU holds): a band lives for its whole
@@ -495,7 +513,7 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
         if (!stages) continue;
         hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);
         hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
-        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, st);
+        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, b.any_field, st);
         if (stages & PS_INTRA_LDS) launch_intra_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, st);
         if (stages & PS_INTRA_V1) launch_recon_intra(b.d_pics, n, st);
         if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st);

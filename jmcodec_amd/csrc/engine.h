@@ -68,6 +68,7 @@ struct EnginePic {
     uint32_t ref_mask = 0, out_mask = 0;            // surface slots this picture reads as references / displays (pack-out reads them)
     bool bipred = false;                            // some slice of the picture writes two-list / weighted motion records (B slices, weighted prediction)
     int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
+    int reach_cols = 0;                             // ... and how many macroblocks further right (both space the pictures of a chain launch, Engine::launch)
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
     // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on the ordinary lane
     int lane(bool chaining = false) const {
@@ -122,7 +123,7 @@ private:
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
         bool any_chain = false, chain_with_intra = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
-        int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false;
+        int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false, any_field = false;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         // packed: surfaces were read by k_packout (before the copies)

@@ -373,11 +373,12 @@ struct P {
     void write_motion(MbRec *r, bool sub8) {
         for (int i = 0; i < 4; i++) r->ref[i] = ref[i] >= 0 ? rf.slot[0][ref[i]] : (int8_t)-1;
         {   // downward reach of this macroblock's vectors (one vector per 8x8 unless sub-8x8 partitions / a second list exist)
-            int m = out.max_mvy;
-            if (!sub8 && !rf.bipred_rec) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; m = mv[b * 2 + 1] > m ? mv[b * 2 + 1] : m; } }
-            else for (int i = 0; i < 16; i++) { m = mvl[0][i * 2 + 1] > m ? mvl[0][i * 2 + 1] : m;
-                if (rf.bipred_rec) m = mvl[1][i * 2 + 1] > m ? mvl[1][i * 2 + 1] : m; }
-            out.max_mvy = m;
+            int m = out.max_mvy, mx = out.max_mvx;
+            if (!sub8 && !rf.bipred_rec) { for (int i = 0; i < 4; i++) { int b = (i >> 1) * 8 + (i & 1) * 2; m = mv[b * 2 + 1] > m ? mv[b * 2 + 1] : m;
+                mx = mv[b * 2] > mx ? mv[b * 2] : mx; } }
+            else for (int i = 0; i < 16; i++) { m = mvl[0][i * 2 + 1] > m ? mvl[0][i * 2 + 1] : m; mx = mvl[0][i * 2] > mx ? mvl[0][i * 2] : mx;
+                if (rf.bipred_rec) { m = mvl[1][i * 2 + 1] > m ? mvl[1][i * 2 + 1] : m; mx = mvl[1][i * 2] > mx ? mvl[1][i * 2] : mx; } }
+            out.max_mvy = m; out.max_mvx = mx;
         }
         if (rf.track_uid) for (int l = 0; l < 2; l++) { int32_t *u = &(l ? cx.uid1 : cx.uid0)[(size_t)addr * 4];
             for (int i = 0; i < 4; i++) u[i] = refl[l][i] >= 0 ? rf.uid[l][refl[l][i]] : -1; }
@@ -570,8 +571,9 @@ struct P {
             refl[1][0] = refl[1][1] = refl[1][2] = refl[1][3] = -1;
             cx.direct8[addr] = 0;
         }
-        const int my = (int16_t)y;
+        const int my = (int16_t)y, mx = (int16_t)x;
         if (my > out.max_mvy) out.max_mvy = my;
+        if (mx > out.max_mvx) out.max_mvx = mx;
         static_assert(MB_INTER == 0 && offsetof(MbRec, cbp_blk) == 4 && offsetof(MbRec, coef_off) == 8 && offsetof(MbRec, ref) == 12 && offsetof(MbRec,
             u) == 16, "record layout");
         uint64_t *q = (uint64_t *)r;

@@ -17,6 +17,7 @@ struct JobWriter {
     MbRec   *mbs = nullptr;
     int16_t *mv_ext = nullptr;  uint32_t mv_ext_count = 0, mv_ext_cap = 0;   // in MVs (int16 pairs)
     int16_t *coef = nullptr;    uint32_t coef_count = 0, coef_cap = 0;       // in int16
+    int max_mvx = 0;            // largest rightward horizontal vector component (quarter samples, >= 0), for the same purpose
     int max_mvy = 0;            // largest downward vertical vector component of the picture (quarter samples, >= 0): how far below a macroblock
                                 // its reference windows can reach -- the engine spaces the pictures of a chain launch accordingly (engine.cpp)
 };

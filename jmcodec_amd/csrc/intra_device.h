@@ -10,8 +10,13 @@
 
 namespace jmamd {
 
-constexpr int kTS = 28;              // row stride of the luma work tile: corner + 16 + 8 top-right samples
-constexpr int kTileBase = 3904;      // tables, record staging and Intra8x8 edge buffers come first
+// The luma work tile of a macroblock: 17 rows of kTS bytes.  Row 0 = the sample row above the macroblock, rows 1..16 = its own.  In a row the
+// neighbour column (left sample / corner) sits at byte kTO, the 16 samples at kTO + 1 .. kTO + 16 -- i.e. at dword-aligned offsets 4 .. 19, so the four
+// samples above a 4x4 block, the four above right and a whole reconstructed row are aligned dword reads (round 4) -- and up to 8 samples above right
+// (Intra8x8) behind them.
+constexpr int kTS = 28, kTO = 3;
+constexpr int kI4SelBase = 3904;     // Intra4x4 selector table (i4_sel_entry): 9 modes x 16 pixels x 8 bytes
+constexpr int kTileBase = 3904 + 1152;   // tables, record staging and Intra8x8 edge buffers come first
 
 // (c, kind) of Intra4x4 mode `mode` for pixel (x, y); kind 0 copy P[c], 1 two-tap (P[c]+P[c+1]+1)>>1,
 // 2 three-tap (P[c-1]+2P[c]+P[c+1]+2)>>2, 3 DC.  Edge path index: 0 L3' 1 L3 2 L2 3 L1 4 L0 5 TL 6..13 T0..T7 14 T7'
@@ -42,6 +47,21 @@ __device__ __forceinline__ int i4_table_entry(int mode, int x, int y) {
         break; }
     }
     return c | (kind << 4);
+}
+
+// Round 4: the same table as byte selectors for v_perm_b32.  A lane holds the 15-entry edge path of its block in four registers P0..P3 (entry k = byte
+// k); its three taps are the entries c - 1, c, c + 1 (entries 0 and 14 duplicate 1 and 13, which is the clamping of 8.3.1.2).  selA takes them out of
+// P1:P0 (entries 0..7), selB out of P3:P2 (entries 8..15); a selector byte 0x0c yields zero, so the OR of the two v_perm results has tap t in byte t.
+// Byte 3 of selA carries `kind` (it selects some byte of P0 into byte 3 of the result, which is never looked at).
+__device__ __forceinline__ uint2 i4_sel_entry(int mode, int x, int y) {
+    const int e = i4_table_entry(mode, x, y), c = e & 15, kind = e >> 4;
+    uint32_t a = (uint32_t)kind << 24, b = 0x0c000000u;
+    for (int t = 0; t < 3; t++) {
+        const int k = kind == 3 ? 1 : c - 1 + t;                    // (DC reads no tap)
+        a |= (uint32_t)(k < 8 ? k : 0x0c) << (8 * t);
+        b |= (uint32_t)(k >= 8 ? k - 8 : 0x0c) << (8 * t);
+    }
+    return make_uint2(a, b);
 }
 
 // Same idea for Intra8x8 on the FILTERED 25-entry edge path  L7..L0 (0..7)  TL (8)  T0..T15 (9..24): entry = c | kind << 5
@@ -82,6 +102,7 @@ struct ILds {
     __device__ uint8_t *rec(int g) const { return base + 256 + g * 32; }                          // MbRec staging, 32 groups
     __device__ uint8_t *i8tab() const { return base + 1280; }                                     // 576 B
     __device__ uint8_t *e8(int g) const { return base + 1856 + g * 64; }                          // Intra8x8: raw [32] + filtered [32] edge path
+    __device__ uint8_t *i4sel() const { return base + kI4SelBase; }                               // 1152 B: uint2 per (mode, pixel)
     // luma: tile[17][kTS] per group (476 -> 480), residual [16][16] int16 per group (512)
     __device__ uint8_t *ltile(int g) const { return base + kTileBase + g * 480; }
     __device__ short *lres(int g) const { return (short *)(base + kTileBase + 32 * 480 + g * 512); }
@@ -154,8 +175,9 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
 #pragma unroll
       for (int i = 0; i < 16; i++) rs[i] = (int)(short)(w[i >> 1] >> ((i & 1) * 16)); }
     int left = rcol[l], corner = ring_ul[15];
-    int out[16];
+    uint32_t o0, o1, o2, o3;                                      // this lane's reconstructed row
     if (kind == MB_I16) {
+        int out[16];
         int mode = (modes >> 2) & 3;
         uint4 tv = *(const uint4 *)ring_up;
         int T[16];
@@ -189,6 +211,8 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) out[i] = clip1(out[i] + rs[i]);
+        o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
+        o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24); o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
     } else if (modes & MBM_T8X8) {
         // ---- Intra8x8 (8.3.2): four 8x8 blocks in order; per block the 25 reference samples are gathered and filtered
         //      (8.3.2.2.1) into LDS by the 16 lanes, then every lane predicts 4 pixels of one row from the (c, kind) table ----
@@ -196,10 +220,10 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
         short *res = lds.lres(g);
         uint8_t *raw = lds.e8(g), *fe = raw + 32;
         *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
-        tile[(1 + l) * kTS] = (uint8_t)left;
-        tile[1 + l] = ring_up[l];
-        if (l < 8) tile[17 + l] = ring_ur[l];
-        if (l == 0) tile[0] = (uint8_t)corner;
+        tile[(1 + l) * kTS + kTO] = (uint8_t)left;
+        tile[kTO + 1 + l] = ring_up[l];
+        if (l < 8) tile[kTO + 17 + l] = ring_ur[l];
+        if (l == 0) tile[kTO] = (uint8_t)corner;
         const uint8_t *tab8 = lds.i8tab();
         const uint32_t m0 = rec[4];                                   // Intra8x8PredMode of block b in nibble b
         const int y8 = l >> 1, x8 = (l & 1) * 4;
@@ -210,7 +234,7 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
             const bool d = (bx8 && by8) ? true : (bx8 ? availB : (by8 ? availA : availD));
             const bool c = b8 == 0 ? availB : (b8 == 1 ? availC : b8 == 2);
             const int mode = (m0 >> (4 * b8)) & 15;
-            uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8;          // corner sample of this block
+            uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8 + kTO;    // corner sample of this block
             // edge path k: 0..7 = p[-1,7]..p[-1,0], 8 = p[-1,-1], 9..24 = p[0..15,-1] (top-right replaced by p[7,-1] when unavailable)
             // (samples of unavailable neighbours count as 128: see the Intra4x4 path)
             auto edge = [&](int k) -> int { return k <= 7 ? (a ? org[(8 - k) * kTS] : 128) : (k == 8 ? (d ? org[0] : 128) : (b ? org[1 + ((k - 9 > 7 &&
@@ -249,74 +273,72 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
                 org[(1 + y8) * kTS + 1 + x8 + j] = (uint8_t)clip1(pred + res[(by8 * 8 + y8) * 16 + bx8 * 8 + x8 + j]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * kTS + 1 + i];
+        { const uint32_t *rw = (const uint32_t *)(tile + (1 + l) * kTS + kTO + 1); o0 = rw[0]; o1 = rw[1]; o2 = rw[2]; o3 = rw[3]; }
     } else {
-        // ---- Intra4x4: work tile in LDS: tile[0] = row above (col 0 corner, 1..16, 17..20 top-right), col 0 = left ----
+        // ---- Intra4x4: work tile in LDS (layout: kTS / kTO above) ----
+        // Round 4.  The sixteen blocks are a dependency chain (each predicts from the blocks before it), and rounds 1-3 spent most of a step here:
+        // per block three CONDITIONAL byte loads (each its own exec-mask region with its own wait: three LDS round trips in a row), eight more for
+        // the DC sum and the address arithmetic of the edge path.  Now a lane fetches its block's whole edge path with seven unconditional aligned
+        // dword loads (ONE wait), puts it into four registers and takes its three taps out with two v_perm_b32 whose selectors come from a table
+        // (i4_sel_entry); availability is a substitution on the path (unavailable -> 128, no samples above right -> the last one above repeated),
+        // decided at compile time for the inner blocks; sums of four samples are one v_sad_u8.
         uint8_t *tile = lds.ltile(g);
         short *res = lds.lres(g);
         *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
-        tile[(1 + l) * kTS] = (uint8_t)left;
-        tile[1 + l] = ring_up[l];
-        if (l < 4) tile[17 + l] = ring_ur[l];
-        if (l == 0) tile[0] = (uint8_t)corner;
-        const uint8_t *tab = lds.i4tab();
+        tile[(1 + l) * kTS + kTO] = (uint8_t)left;
+        if (l < 4) ((uint32_t *)(tile + kTO + 1))[l] = ((const uint32_t *)ring_up)[l];
+        if (l == 4) *(uint32_t *)(tile + kTO + 17) = *(const uint32_t *)ring_ur;
+        if (l == 0) tile[kTO] = (uint8_t)corner;
+        const uint2 *sel = (const uint2 *)lds.i4sel();
         uint32_t m0 = rec[4], m1 = rec[5];                         // u.i4[8]: two 4-bit modes per byte, raster order
         int px = l & 3, py = l >> 2;
-        // everything that does not depend on earlier blocks is fetched up front: table entries and this lane's residuals
-        int ent[16], rsd[16];
+        // everything that does not depend on earlier blocks is fetched up front: selectors and this lane's residuals (two per register)
+        uint32_t selA[16], selB[16], rsd2[8];
 #pragma unroll
         for (int blk = 0; blk < 16; blk++) {
             const int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3), rpos = by * 4 + bx;
             int mode = ((rpos < 8 ? m0 : m1) >> ((rpos & 7) * 4)) & 15;
-            ent[blk] = tab[mode * 16 + l];
-            rsd[blk] = res[(by * 4 + py) * 16 + bx * 4 + px];
+            mode = mode > 8 ? 8 : mode;                              // (a damaged record must not index beyond the table)
+            const uint2 e = sel[mode * 16 + l];
+            selA[blk] = e.x; selB[blk] = e.y;
+            const uint32_t r = (uint16_t)res[(by * 4 + py) * 16 + bx * 4 + px];
+            if (blk & 1) rsd2[blk >> 1] |= r << 16; else rsd2[blk >> 1] = r;
         }
 #pragma unroll
         for (int blk = 0; blk < 16; blk++) {
             const int bx = (blk & 1) + 2 * ((blk >> 2) & 1), by = ((blk >> 1) & 1) + 2 * (blk >> 3);
             const bool a = bx > 0 || availA, b = by > 0 || availB;
             const bool cavail = by == 0 ? (bx < 3 ? availB : availC) : !(bx == 3 || blk == 3 || blk == 11 || blk == 7 || blk == 13 || blk == 15);
-            const int c = ent[blk] & 15, kd = ent[blk] >> 4;
-            uint8_t *org = tile + (by * 4) * kTS + bx * 4;    // corner sample of this block
-            // offset of edge-path entry k relative to org: k<=4 left column (row 5-k), k==5 corner, k>=6 row above
-            int off[3];
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                int k = c - 1 + t;
-                k = k < 1 ? 1 : (k > 13 ? 13 : k);
-                int xx = k - 6;
-                if (!cavail && xx > 3) xx = 3;
-                off[t] = k <= 4 ? (5 - k) * kTS : (k == 5 ? 0 : 1 + xx);
-            }
-            int pred;
-            if (kd == 3) {
-                int st = org[1] + org[2] + org[3] + org[4], sl = org[kTS] + org[2 * kTS] + org[3 * kTS] + org[4 * kTS];
-                pred = (a && b) ? (st + sl + 4) >> 3 : (a ? (sl + 2) >> 2 : (b ? (st + 2) >> 2 : 128));
-            } else {
-                // Samples of a neighbour that is not available count as 128, as in k_recon_intra and the oracle.  A conforming stream never selects a
-                // mode that reads them; the sweep's generator did (constrained_intra_pred: Horizontal-Down next to an inter corner), and the three
-                // decoders have to agree on such a stream too.
-                const bool d = (bx > 0 && by > 0) ? true : (bx > 0 ? availB : (by > 0 ? availA : availD));
-                int v[3];
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    int k = c - 1 + t;
-                    k = k < 1 ? 1 : (k > 13 ? 13 : k);
-                    const bool ok = k <= 4 ? a : (k == 5 ? d : b);
-                    v[t] = ok ? org[off[t]] : 128;
-                }
-                pred = kd == 2 ? (v[0] + 2 * v[1] + v[2] + 2) >> 2 : (kd == 1 ? (v[1] + v[2] + 1) >> 1 : v[1]);
-            }
-            org[(1 + py) * kTS + 1 + px] = (uint8_t)clip1(pred + rsd[blk]);
+            // Samples of a neighbour that is not available count as 128, as in k_recon_intra and the oracle.  A conforming stream never selects a
+            // mode that reads them; the sweep's generator did (constrained_intra_pred: Horizontal-Down next to an inter corner), and the three
+            // decoders have to agree on such a stream too.
+            const bool d = (bx > 0 && by > 0) ? true : (bx > 0 ? availB : (by > 0 ? availA : availD));
+            const uint8_t *org = tile + (by * 4) * kTS + bx * 4;      // the dword whose last byte is the block's corner sample; the row above follows
+            const uint32_t wTL = *(const uint32_t *)org, wT = *(const uint32_t *)(org + 4), wTR = *(const uint32_t *)(org + 8);
+            const uint32_t w0 = *(const uint32_t *)(org + kTS), w1 = *(const uint32_t *)(org + 2 * kTS), w2 = *(const uint32_t *)(org + 3 * kTS),
+                w3 = *(const uint32_t *)(org + 4 * kTS);              // byte 3 = the left neighbour of the block's rows 0..3
+            const uint32_t k128 = 0x80808080u;
+            const uint32_t T = b ? wT : k128;
+            const uint32_t TR = b ? (cavail ? wTR : __builtin_amdgcn_perm(0u, wT, 0x03030303u)) : k128;
+            // P0 = L3 L3 L2 L1 | P1 = L0 TL T0 T1 | P2 = T2 T3 T4 T5 | P3 = T6 T7 T7 -
+            uint32_t P0 = __builtin_amdgcn_perm(w1, __builtin_amdgcn_perm(w2, w3, 0x0c070303u), 0x07020100u);
+            P0 = a ? P0 : k128;
+            const uint32_t lt = __builtin_amdgcn_perm(d ? wTL : k128, a ? w0 : k128, 0x0c0c0703u);          // L0 TL - -
+            const uint32_t P1 = lt | (T << 16);
+            const uint32_t P2 = __builtin_amdgcn_alignbyte(TR, T, 2), P3 = __builtin_amdgcn_perm(0u, TR, 0x0c030302u);
+            const uint32_t X = __builtin_amdgcn_perm(P1, P0, selA[blk]) | __builtin_amdgcn_perm(P3, P2, selB[blk]);
+            const int v0 = (int)(X & 255u), v1 = (int)((X >> 8) & 255u), v2 = (int)((X >> 16) & 255u), kd = (int)(selA[blk] >> 24);
+            const int st = (int)__builtin_amdgcn_sad_u8(T, 0u, 0u), sl = (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(lt, P0, 0x04030201u), 0u, 0u);
+            const int dc = (a && b) ? (st + sl + 4) >> 3 : (a ? (sl + 2) >> 2 : (b ? (st + 2) >> 2 : 128));
+            const int p3 = (v0 + 2 * v1 + v2 + 2) >> 2, p2 = (v1 + v2 + 1) >> 1;
+            const int pred = kd == 3 ? dc : (kd == 2 ? p3 : (kd == 1 ? p2 : v1));
+            const int r = (int)(short)(rsd2[blk >> 1] >> (16 * (blk & 1)));
+            tile[(by * 4 + 1 + py) * kTS + kTO + 1 + bx * 4 + px] = (uint8_t)clip1(pred + r);
         }
-#pragma unroll
-        for (int i = 0; i < 16; i++) out[i] = tile[(1 + l) * kTS + 1 + i];
+        { const uint32_t *rw = (const uint32_t *)(tile + (1 + l) * kTS + kTO + 1); o0 = rw[0]; o1 = rw[1]; o2 = rw[2]; o3 = rw[3]; }
     }
-    uint32_t o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24), o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
-    uint32_t o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24), o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
     istore4<WT>(dst, make_uint4(o0, o1, o2, o3));
-    rcol[l] = (uint8_t)out[15];
+    rcol[l] = (uint8_t)(o3 >> 24);
     if (l == 15) *(uint4 *)ring_dn = make_uint4(o0, o1, o2, o3);
 }
 
@@ -422,7 +444,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const bool active = g < rows;
     const int row = row0 + (active ? g : 0), lrow = g + 1;
-    if (threadIdx.x < 144) lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
+    if (threadIdx.x < 144) { lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
+        ((uint2 *)lds.i4sel())[threadIdx.x] = i4_sel_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3); }
     for (int i = threadIdx.x; i < 576; i += kIBandRows * 16) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
     gbyte *plane = (gbyte *)(cur_plane(pp) + (is_chroma ? pp.chroma_offset : 0));
     const ICtx cx{plane, pitch};

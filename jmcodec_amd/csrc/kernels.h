@@ -6,7 +6,7 @@
 #include "jobs.h"
 
 namespace jmamd {
-void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, hipStream_t st);
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, bool any_field, hipStream_t st);
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st);          // spin-wait wavefront (sparse intra, any height)
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);              // spin-wait wavefront (any height)
 bool intra_lds_supported(int mb_w, int mb_h);
@@ -26,6 +26,7 @@ bool chain_supported(int mb_w, int mb_h);
 // segment; kind 1: deblocking band `index`), in the order in which the dispatcher shall start them (chain.hip)
 void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st);
 int  chain_band_rows();
+int  deblock_row_lag();        // steps between macroblock rows of the deblocking wavefront (chain_common.h kRowLag)
 // workgroups of k_chain / k_chain_i the CURRENT device keeps resident (0: unknown); the engine bounds a launch's bands by half of it
 int  chain_resident_workgroups(bool intra);
 int  chain_ctl_ints();                                                                         // kChainStride

@@ -196,8 +196,13 @@ struct alignas(16) ReconLds {
 // COH: the reference loads are the cache-bypassing kind (needed exactly when the picture has references inside the launch, pp.n_deps > 0).
 // BIFAST: macroblocks with two-list / weighted motion records take their luma windows through LDS like P blocks when they can (below).  The stage
 // kernel has an instantiation without it for batches that hold no such picture: the extra code costs 9 VGPRs there (96 -> 105, 5 -> 4 waves per SIMD).
-template <bool CHAIN, bool COH, bool BIFAST = true>
+// FIELD = false: no picture of the launch is a field picture -- a reference entry is a plain surface index and the picture its whole surface (round 4:
+// what the frame-only kernels of round 2 compiled to; k_recon_inter<false> needs its 96 registers for five waves per SIMD, kernels.hip)
+template <bool CHAIN, bool COH, bool BIFAST = true, bool FIELD = true>
 __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
+    auto ref_plane = [&](const PicParams &q, int slot) -> const uint8_t * { return FIELD ? jmamd::ref_plane(q, slot) : q.surf[slot]; };
+    auto chroma_mvy_offset = [&](const PicParams &q, int slot) -> int { return FIELD ? jmamd::chroma_mvy_offset(q, slot) : 0; };
+    auto cur_plane = [&](const PicParams &q) -> uint8_t * { return FIELD ? jmamd::cur_plane(q) : q.surf[q.cur]; };
     ResTile *tiles = sm.tiles;
     uint32_t (*outt)[96] = sm.outt;
     uint32_t (*wins)[4][13 * 5 + 3] = sm.wins;
@@ -235,7 +240,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         }
         const int dep = slot >= 0 ? (int)pp.dep_pic[slot & 31] : -1;
         const int x0 = mbx * 16 + bx * 4 + (mvx >> 2), y0 = mby * 16 + by * 4 + (mvy >> 2);
-        const bool ok = cv.wait_final(dep, clip3(0, W - 1, x0 + 6), clip3(0, H - 1, y0 - 2), clip3(0, H - 1, y0 + 6), pp.mb_w, pp.mb_h);
+        const bool ok = cv.wait_final(dep, clip3(0, W - 1, x0 + 6), clip3(0, H - 1, y0 - 2), clip3(0, H - 1, y0 + 6), pp.mb_w, pp.mb_h, kRowLag);
         if (!ok && lane == 0) report_wait_timeout(cv.err + pp.chain_idx, CHAIN_ERR_FIN_TIMEOUT);
     }
     if (plain) {
