@@ -36,20 +36,27 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
     const uint32_t entry = groups[g];
     const PicParams &pp = pics[entry >> 16];
     const ChainView cv{ctl, err};
+    // ONE LDS block for whichever role the workgroup has: two static arrays add up (52.5 KB: three workgroups per CU by LDS alone), and since round 4
+    // the kernel's 119 registers allow four
+    __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)];
+    cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;
         const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
-        __shared__ ReconLds sm;
+        cv.census(ChainView::CENSUS_RECON_STARTED);
+        ReconLds &sm = *reinterpret_cast<ReconLds *>(smem);
         const int mb = valid ? row * pp.mb_w + x : 0;
         // one instantiation for every picture of the launch (with the cached-load variant beside it the kernel needs 196 VGPRs and scratch;
         // this way 165): a picture without references inside the launch passes wait_final at once
         recon_inter_wave<true, true, true, false>(pp, mb, valid, sm, cv);
+        cv.census(ChainView::CENSUS_RECON_DONE);
     } else {
-        __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes];
+        cv.census(ChainView::CENSUS_BAND_STARTED);
         int *cpic = cv.pic(pp.chain_idx);
         deblock_band_body<DEPTH, true>(pp, (int)(entry & 31u), rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
+        cv.census(ChainView::CENSUS_BAND_DONE);
     }
 }
 

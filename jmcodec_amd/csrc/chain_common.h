@@ -50,8 +50,9 @@ enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RI
 // 12..15 of (x, y - 1).  So V(x, y) needs H(x - 1, y) and nothing of the row above, and H(x, y) needs V(x, y) and -- for columns 13..15 of those four rows, which
 // the left edge of (x + 1, y - 1) changes -- V(x + 1, y - 1), but NOT H(x + 1, y - 1).  Rounds 1-3 ran whole macroblocks per step, which needs two steps
 // between rows (s = x + 2y: 254 steps at 1080p, 508 at 4K).  With the step cut into a V phase and an H phase by a second barrier, (x + 1, y - 1) and (x, y)
-// share a step: s = x + y, 187 steps at 1080p (-26 %), 374 at 4K, every filter still sees exactly the samples raster order would give it (no two filters
-// that touch a common sample change their order).  JM_DEBLOCK_ROW_LAG=2 builds the old schedule (A/B runs).
+// share a step: s = x + y, 188 steps at 1080p (-26 %), 375 at 4K, every filter still sees exactly the samples raster order would give it (no two filters
+// that touch a common sample change their order).  As built (deblock_device.h `step`): step s of row y = H + store of macroblock s - 1 - y, then V of
+// macroblock s - y, ONE barrier per step; the final samples of macroblock (X, Y) are therefore stored in step X + Y + 1.  JM_DEBLOCK_ROW_LAG=2 builds the old schedule (A/B runs).
 #ifndef JM_DEBLOCK_ROW_LAG
 #define JM_DEBLOCK_ROW_LAG 1
 #endif
@@ -79,13 +80,28 @@ __device__ __forceinline__ void st_wt8(void *p, uint2 v) {
     const jm_v2u t = {v.x, v.y};
     asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"((__attribute__((address_space(1))) void *)p), "v"(t) : "memory");
 }
-// reference samples: COH = the reference picture may have been written by this launch
-template <bool COH> __device__ __forceinline__ int ld_ref8(const uint8_t *p) {
-    if (COH) return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// reference samples: COH = the reference picture may have been written by this launch -- `sc1` loads, which every level that is not coherent across the
+// XCDs passes through.  Round 4: NOT the atomic builtins any more.  An atomic load can neither be merged nor moved, and with 36 of them per sample in the
+// literal path and a dozen per lane in the window paths the reconstruction role of the chain kernels needed 146 registers against the 96 of the same
+// code with plain loads -- which made k_chain a 3-waves-per-SIMD kernel, and its reconstruction waves (a latency-bound role: they wait for other
+// workgroups and for uncached loads) are what bounds 2..16 streams.  Now they are ordinary buffer loads with the sc1 policy bit (aux 16 on gfx940+):
+// same instruction on the memory side (buffer_load_* ... sc1), freely scheduled by the compiler, and addressed by a 32-bit offset into ONE descriptor
+// over the handle's surface block (PicParams.surf_base; jobs.h) instead of a 64-bit pointer per load: 101 / 108 registers.  What ordered the atomic loads
+// behind the polls of wait_final -- the data dependency on the counter -- is kept by a compiler barrier there (the hardware issues in program order).
+struct RefBuf {
+    __amdgpu_buffer_rsrc_t rsrc; const uint8_t *base;
+    __device__ __forceinline__ explicit RefBuf(const uint8_t *b) : rsrc(__builtin_amdgcn_make_buffer_rsrc((void *)b, 0, -1, 0x00020000)), base(b) {}
+    __device__ __forceinline__ int off(const uint8_t *p) const { return (int)((uint32_t)(uintptr_t)p - (uint32_t)(uintptr_t)base); }
+};
+constexpr int kAuxSc1 = 16;
+// a single coherent byte through a plain pointer (hevc_kernels.hip: a few edge samples per coding tree block)
+__device__ __forceinline__ int ld_coh8(const uint8_t *p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COH> __device__ __forceinline__ int ld_ref8(const RefBuf &rb, const uint8_t *p) {
+    if (COH) return (int)__builtin_amdgcn_raw_buffer_load_b8(rb.rsrc, rb.off(p), 0, kAuxSc1);
     return (int)*p;
 }
-template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const uint8_t *p) {
-    if (COH) return __hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const RefBuf &rb, const uint8_t *p) {
+    if (COH) return __builtin_amdgcn_raw_buffer_load_b32(rb.rsrc, rb.off(p), 0, kAuxSc1);
     return *(const uint32_t *)p;
 }
 
@@ -131,6 +147,14 @@ struct ChainView {
     // Once one wait of a launch has given up, the launch is damaged anyway: every other wait then gives up as soon as it looks (every 256 polls),
     // so a broken hand-over costs about one timeout, not one per waiting wave.
     __device__ __forceinline__ int *abort_word() const { return base + (size_t)kChainMaxPics * kChainStride; }
+    // Census of the launch (round 4, what a give-up is diagnosed with: Engine::dump_chain_state): behind the abort word, workgroups started / finished
+    // per role and the highest work-list index started.  No-return atomics, one per workgroup: nothing waits for them.
+    enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5 };
+    __device__ __forceinline__ void census(int what, int value = 1) const {
+        if (threadIdx.x != 0) return;
+        if (what == CENSUS_MAX_GROUP) (void)__hip_atomic_fetch_max(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else (void)__hip_atomic_fetch_add(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // Wait until every sample of the rectangle [.., xmax] x [ymin, ymax] (luma coordinates, already clamped to the picture) of the picture
     // with chain index `dep` is final.  The final value of sample (px, py) is stored by the deblocking step of macroblock
@@ -143,7 +167,8 @@ struct ChainView {
         const int *fin = pic(pending ? dep : 0) + kChainFin;
         const int xs = min((xmax + 4) >> 4, mb_w - 1), yhi = min((ymax + 4) >> 4, mb_h - 1), ylo = min(max((ymin + 4) >> 4, 0), yhi);
         const int bhi = yhi >> 4, blo = ylo >> 4;
-        const int need_hi = xs + row_lag * yhi + 1, need_lo = xs + row_lag * (blo * 16 + 15) + 1;
+        const int store_lag = row_lag == 1 ? 1 : 0;                // one row per step: macroblock (X, Y) is stored in step X + Y + 1 (deblock_device.h)
+        const int need_hi = xs + row_lag * yhi + 1 + store_lag, need_lo = xs + row_lag * (blo * 16 + 15) + 1 + store_lag;
         int spins = 0; uint32_t t0 = 0;
         for (;;) {
             if (pending) {
@@ -151,7 +176,7 @@ struct ChainView {
                 if (ok && blo != bhi) ok = ld_coh(fin + blo) >= need_lo && ld_coh(fin + 32 + blo) >= need_lo;
                 pending = !ok;
             }
-            if (!__builtin_amdgcn_ballot_w64(pending)) return true;
+            if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }      // (nothing that reads the picture moves above the polls)
             if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
             __builtin_amdgcn_s_sleep(4);
         }

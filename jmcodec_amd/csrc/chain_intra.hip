@@ -31,18 +31,23 @@ __global__ __launch_bounds__(256, 3) __attribute__((flatten)) void k_chain_i(con
     const uint32_t entry = groups[g];
     const PicParams &pp = pics[entry >> 16];
     const ChainView cv{ctl, err};
+    cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;
         const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
+        cv.census(ChainView::CENSUS_RECON_STARTED);
         recon_inter_wave<true, true, true, false>(pp, valid ? row * pp.mb_w + x : 0, valid, *reinterpret_cast<ReconLds *>(smem), cv);
+        cv.census(ChainView::CENSUS_RECON_DONE);
     } else {
+        cv.census(ChainView::CENSUS_BAND_STARTED);
         int *cpic = cv.pic(pp.chain_idx);
         const int band = (int)(entry & 31u);
         if (entry & 0x4000u) intra_band_body<true>(pp, band, rem == 1, cpic + kChainIntraRing, smem, cpic, err + pp.chain_idx);
         else if (pp.stages & PS_CHAIN_INTRA) deblock_band_body<DEPTH, true, true>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
         else deblock_band_body<DEPTH, true, false>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
+        cv.census(ChainView::CENSUS_BAND_DONE);
     }
 }
 

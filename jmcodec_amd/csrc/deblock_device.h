@@ -387,7 +387,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     const int rec_dw = (is_chroma ? 12 : 0) + (l < 12 ? l : 0);
     const bool takes_ring = band > 0 && group == 0;                        // first row of a lower band: ring rows come from the band above
     const bool gives_ring = active && group == rows - 1 && row < mb_h - 1;  // last row of a band that has a band below
-    const int s_begin = kRowLag * row0, s_end = mb_w - 1 + kRowLag * (row0 + rows - 1);
+    // (kRowLag 1: one more step, the H + store of the last macroblock of the band's last row)
+    const int s_begin = kRowLag * row0, s_end = mb_w - 1 + kRowLag * (row0 + rows - 1) + (kRowLag == 1 ? 1 : 0);
     int known = 0;                                                          // steps the band above is known to have completed
     // launch-wide: a wait of this launch gave up (chain_common.h)
     int *abort_word = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
@@ -453,33 +454,48 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto step = [&](int s, uint4 own, uint32_t rdw, uint32_t ring) {
-        const int x = s - kRowLag * row;
-        const bool work = active && x >= 0 && x < mb_w;
-        constexpr int kFirst = kRowLag == 1 ? 1 : 0;                        // kRowLag 1: vertical edges | barrier | horizontal edges + store
-        if (work) {
-            if (is_chroma) {
-                if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
-                chroma_mb<CHAIN, kFirst>(cx, lds, x, row, lrow, l, group, own, rdw);
-            } else {
-                if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
-                luma_mb<CHAIN, kFirst>(cx, lds, x, row, lrow, l, group, own, rdw);
-            }
-        }
         if (kRowLag == 1) {
-            // the row above ran V(x + 1, row - 1) in this very step: its left edge changed columns 13..15 of the ring rows H(x, row) starts from
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (work) {
-                if (is_chroma) chroma_mb<CHAIN, 2>(cx, lds, x, row, lrow, l, group, own, rdw);
-                else luma_mb<CHAIN, 2>(cx, lds, x, row, lrow, l, group, own, rdw);
+            // One barrier per step, and one row per step (chain_common.h kRowLag): the step is NOT "macroblock x" but "H + store of macroblock x - 1, then V
+            // of macroblock x" of every row.  H(x - 1, row) needs V(x, row - 1) -- the left edge of the macroblock above right changes columns 13..15 of
+            // the ring rows it starts from -- and that ran in the PREVIOUS step of the row above (row - 1 is one macroblock ahead), i.e. behind the
+            // barrier that ended it; V(x, row) follows H(x - 1, row) in program order.  (The first version of the one-row schedule ran V | barrier | H
+            // inside a step: two barriers, each paying the slowest of the four waves -- 3.0 us per step against 2.6.)
+            const int xv = s - row, xh = xv - 1;
+            if (active && xh >= 0 && xh < mb_w) {
+                if (is_chroma) { chroma_mb<CHAIN, 2>(cx, lds, xh, row, lrow, l, group, own, rdw);
+                    if (gives_ring && xh == mb_w - 1) give(lds.chroma_ring(lrow, xh & 3), xh, 8); }
+                else { luma_mb<CHAIN, 2>(cx, lds, xh, row, lrow, l, group, own, rdw);
+                    if (gives_ring && xh == mb_w - 1) give(lds.luma_ring(lrow, xh & 3), xh, 0); }
             }
-        }
-        if (work && gives_ring) {
-            if (is_chroma) {
-                if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
-                if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
-            } else {
-                if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
-                if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
+            if (active && xv >= 0 && xv < mb_w) {
+                if (is_chroma) {
+                    if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, xv & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                    chroma_mb<CHAIN, 1>(cx, lds, xv, row, lrow, l, group, own, rdw);
+                    if (gives_ring && xv > 0) give(lds.chroma_ring(lrow, (xv - 1) & 3), xv - 1, 0);
+                } else {
+                    if (takes_ring) *(uint32_t *)(lds.luma_ring(0, xv & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                    luma_mb<CHAIN, 1>(cx, lds, xv, row, lrow, l, group, own, rdw);
+                    if (gives_ring && xv > 0) give(lds.luma_ring(lrow, (xv - 1) & 3), xv - 1, 0);
+                }
+            }
+        } else {
+            const int x = s - kRowLag * row;
+            if (active && x >= 0 && x < mb_w) {
+                if (is_chroma) {
+                    if (takes_ring && l < ring_lanes) *(uint32_t *)(lds.chroma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                    chroma_mb<CHAIN, 0>(cx, lds, x, row, lrow, l, group, own, rdw);
+                    if (gives_ring) {
+                        if (x > 0) give(lds.chroma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                        if (x == mb_w - 1) give(lds.chroma_ring(lrow, x & 3), x, 8);
+                    }
+                } else {
+                    if (takes_ring) *(uint32_t *)(lds.luma_ring(0, x & 3) + (l >> 2) * 16 + (l & 3) * 4) = ring;
+                    luma_mb<CHAIN, 0>(cx, lds, x, row, lrow, l, group, own, rdw);
+                    if (gives_ring) {
+                        if (x > 0) give(lds.luma_ring(lrow, (x - 1) & 3), x - 1, 0);
+                        if (x == mb_w - 1) give(lds.luma_ring(lrow, x & 3), x, 0);
+                    }
+                }
             }
         }
         // publish: the wave that holds the band's last row wrote the ring rows itself, so waiting for ITS stores is enough -- and not by draining

@@ -333,10 +333,16 @@ void Decoder::free_job_buffers() {
     }
 }
 
+void Decoder::free_surfaces() {
+    if (surf_block_) hipFree(surf_block_);
+    surf_block_ = nullptr;
+    for (auto &p : surf_) p = nullptr;
+}
+
 void Decoder::gpu_free_sequence() {
     if (!gpu_open_) return;
     hipSetDevice(device_);
-    for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+    free_surfaces();
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
     free_job_buffers();
@@ -396,9 +402,11 @@ bool Decoder::gpu_alloc_sequence() {
     pitch_ = (mb_w_ * 16 + 127) & ~127;
     chroma_off_ = pitch_ * mb_h_ * 16;
     surf_bytes_ = (size_t)pitch_ * mb_h_ * 16 * 3 / 2;
-    for (int i = 0; i < n_surf_ + extra_surf_; i++) {
-        if (!HIP_OK(hipMalloc((void **)&surf_[i], surf_bytes_))) { fail("hipMalloc(surface) failed"); return false; }
-        hipMemset(surf_[i], 128, surf_bytes_);
+    {   // every surface in one allocation (256-byte aligned strides): a picture's references then lie within one 32-bit offset range
+        const size_t stride = (surf_bytes_ + 255) & ~(size_t)255, n = (size_t)(n_surf_ + extra_surf_);
+        if (!HIP_OK(hipMalloc((void **)&surf_block_, stride * n))) { fail("hipMalloc(surfaces) failed"); return false; }
+        hipMemset(surf_block_, 128, stride * n);
+        for (size_t i = 0; i < n; i++) surf_[i] = surf_block_ + i * stride;
     }
     use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
     use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
@@ -588,7 +596,7 @@ bool Decoder::activate(const SeqParams &sps) {
         // nothing is in flight any more, so surfaces, job rings and scratch are rebuilt; frames already decoded keep their slots
         if (gpu_open_) {
             hipSetDevice(device_);
-            for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+            free_surfaces();
                     if (resid_) { hipFree(resid_); resid_ = nullptr; }
                     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
@@ -1420,6 +1428,7 @@ void Decoder::submit_task(PicTask *t) {
         pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
         pp.n_slices = t->n_slices; pp.cur = t->cur_slot;
         for (int i = 0; i < kMaxSurfaces; i++) pp.surf[i] = surf_[i];
+        pp.surf_base = surf_block_;
         pp.mbs = (const MbRec *)js.dev;
         pp.slices = (const SliceRec *)(js.dev + (size_t)n_mbs * sizeof(MbRec));
         pp.coef = (const int16_t *)(pp.slices + 256);

@@ -242,6 +242,9 @@ private:
     struct EngineDecoderState *eng_state_ = nullptr;
     class Engine *engine_ = nullptr;          // per-device executor (engine.h): the only place device work is issued
     uint8_t *surf_[kMaxSurfaces] = {nullptr};
+    uint8_t *surf_block_ = nullptr;            // ONE device allocation holds every surface (surf_[i] = block + i * stride): the chain kernels address all of
+                                               // a picture's references through one buffer descriptor (recon_device.h RefBuf)
+    void free_surfaces();
     bool use_lds_deblock_ = false;
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)

@@ -336,7 +336,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     hipStream_t ps = any_hevc ? st : ln.pre_stream;
     // every counter of every picture, and the abort word
     if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps);
-        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, sizeof(int), ps); }
+        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, 16 * sizeof(int), ps); }      // abort word + census (chain_common.h)
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, ps);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, ps);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, ps);
@@ -539,13 +539,45 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
     }
 }
 
+// JM_AMD_DEC_VERBOSE: what a chain launch that gave up looked like when it ended -- the census of its workgroups, and per picture
+// the step counters of every band and how far the reconstruction bitmap got.  Read after the launch has retired; `redo` batches reuse the buffer.
+void Engine::dump_chain_state(Batch &b) {
+    const int n = (int)b.pics.size(), stride = chain_ctl_ints();
+    std::vector<int> ctl((size_t)kMaxBatch * stride + 16);
+    if (hipMemcpy(ctl.data(), b.d_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int *lw = ctl.data() + (size_t)kMaxBatch * stride;
+    int n_band_wgs = 0, n_recon_groups = 0;
+    for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) { const int bands = (b.h_pics[i].mb_h + 15) / 16;
+        n_band_wgs += ((b.h_pics[i].stages & PS_CHAIN_INTRA) ? 4 : 2) * bands;
+        if (!(b.h_pics[i].stages & PS_RECON)) n_recon_groups += b.h_pics[i].mb_h * ((b.h_pics[i].mb_w + 7) / 8); }
+    fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | band workgroups started %d done %d of %d | "
+        "highest work-list index started %d | band budget %d / %d\n", lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_,
+        chain_bands_max_intra_);
+    for (int i = 0; i < n; i++) {
+        const PicParams &q = b.h_pics[i];
+        if (!(q.stages & PS_CHAIN)) continue;
+        const int *c = ctl.data() + (size_t)i * stride;
+        const int bands = (q.mb_h + 15) / 16;
+        fprintf(stderr, "  picture %2d dec %p %dx%d stages 0x%x%s deps %d err %d reach %d/%d |", i, (void *)b.pics[i].dec, q.mb_w, q.mb_h, q.stages,
+            (q.stages & PS_RECON) ? " (reconstructed before the launch)" : "", q.n_deps, b.h_err[i], b.pics[i].reach_rows, b.pics[i].reach_cols);
+        for (int k = 0; k < bands; k++) fprintf(stderr, " b%d ring %d/%d fin %d/%d", k, c[0 + k], c[32 + k], c[64 + k], c[64 + 32 + k]);
+        if (q.stages & PS_CHAIN_INTRA) for (int k = 0; k < bands; k++) fprintf(stderr, " i%d ring %d/%d ifin %d/%d", k, c[128 + k], c[128 + 32 + k], c[192 + k],
+            c[192 + 32 + k]);
+        int full = 0, first_open = -1, first_open_bits = 0;
+        for (int r = 0; r < q.mb_h; r++) { int cnt = 0; for (int w = 0; w < 8; w++) cnt += __builtin_popcount((unsigned)c[256 + r * 8 + w]);
+            if (cnt >= q.mb_w) full++; else if (first_open < 0) { first_open = r; first_open_bits = cnt; } }
+        fprintf(stderr, " | bitmap: %d of %d rows complete, first open row %d has %d of %d\n", full, q.mb_h, first_open, first_open_bits, q.mb_w);
+    }
+}
+
 void Engine::complete(Lane &ln, Batch &b, bool failed) {
     if (!failed && (b.redo || b.any_chain)) {
         bool wait_err = b.redo;
         for (size_t i = 0; i < b.pics.size(); i++) wait_err |= b.h_err[i] != 0 && b.any_chain;
         if (wait_err) {
             if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size());
-                for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n"); }
+                for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n");
+                dump_chain_state(b); }
             // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
             std::vector<std::pair<Decoder *, uint32_t>> later;     // ... and remember which surfaces it decoded into meanwhile (Engine::recover)
             if (!b.redo) ln.tainted.clear();                       // (a redo batch inherits the tainted set of the batch it followed)

@@ -155,6 +155,7 @@ private:
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Lane &ln, Batch &b, bool failed);
+    void dump_chain_state(Batch &b);                         // JM_AMD_DEC_VERBOSE: counters of a chain launch that gave up
     // decode a batch's pictures again with the stage kernels (a chain launch's wait gave up).  `later` = surfaces the lane's NEXT batch, which has
     // already run, decoded into, per decoder: a redo that would read one of them cannot be right, and is reported instead of passed off as clean
     void recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, uint32_t>> &later);

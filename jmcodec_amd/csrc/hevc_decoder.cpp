@@ -91,7 +91,7 @@ bool Decoder::hevc_activate(const HevcSps &sps) {
         { std::unique_lock<std::mutex> lk(mtx_); cv_.wait(lk, [&] { return outstanding_ == 0 && parse_pending_ == 0; }); }
         if (gpu_open_) {
             hipSetDevice(device_);
-            for (int i = 0; i < kMaxSurfaces; i++) if (surf_[i]) { hipFree(surf_[i]); surf_[i] = nullptr; }
+            free_surfaces();
             if (resid_) { hipFree(resid_); resid_ = nullptr; }
             for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
             for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }

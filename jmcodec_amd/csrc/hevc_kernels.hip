@@ -404,14 +404,14 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         *(uint2 *)&tc[0][kCO + 8 * (tid - 64)] = cb; *(uint2 *)&tc[1][kCO + 8 * (tid - 64)] = crv;
     }
     if (left_run) {                                               // the left column was written by another workgroup of this launch
-        if (tid >= 1 && tid <= cs && y0 + tid - 1 < pp.h) keep_ly = (uint32_t)ld_ref8<true>(surf + (size_t)(y0 + tid - 1) * pp.pitch + x0 - 1);
+        if (tid >= 1 && tid <= cs && y0 + tid - 1 < pp.h) keep_ly = (uint32_t)ld_coh8(surf + (size_t)(y0 + tid - 1) * pp.pitch + x0 - 1);
         if (tid >= 1 && tid <= hc && yc0 + tid - 1 < ph) { const uint8_t *pc = cpl + (size_t)(yc0 + tid - 1) * pp.pitch + 2 * (xc0 - 1);
-            keep_lc = (uint32_t)ld_ref8<true>(pc) | (uint32_t)ld_ref8<true>(pc + 1) << 8; }
+            keep_lc = (uint32_t)ld_coh8(pc) | (uint32_t)ld_coh8(pc + 1) << 8; }
     }
     // (the corner above-left belongs to a CTB of the row above: it, too, may only be read now)
-    if (tid == 128 && x0 > 0 && y0 > 0) keep_ly = (uint32_t)ld_ref8<true>(surf + (size_t)(y0 - 1) * pp.pitch + x0 - 1);
+    if (tid == 128 && x0 > 0 && y0 > 0) keep_ly = (uint32_t)ld_coh8(surf + (size_t)(y0 - 1) * pp.pitch + x0 - 1);
     if (tid == 129 && x0 > 0 && yc0 > 0) { const uint8_t *pc = cpl + (size_t)(yc0 - 1) * pp.pitch + 2 * (xc0 - 1);
-        keep_lc = (uint32_t)ld_ref8<true>(pc) | (uint32_t)ld_ref8<true>(pc + 1) << 8; }
+        keep_lc = (uint32_t)ld_coh8(pc) | (uint32_t)ld_coh8(pc + 1) << 8; }
     // ---- body and left column from the registers ----
     if (y_mine) *(uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg] = pre.y;
     if (c_mine) { uint2 cb, crv; de_interleave(pre.c, cb, crv); *(uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg] = cb; *(uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg] = crv; }

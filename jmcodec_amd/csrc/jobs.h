@@ -95,6 +95,7 @@ struct PicParams {
     int n_slices;
     int cur;                      // surface slot being written
     uint8_t *surf[kMaxSurfaces];  // device pointers of the DPB surfaces
+    uint8_t *surf_base;           // the one allocation that holds them all (every surf[i] lies within 2^31 bytes above it)
     const MbRec *mbs;
     const SliceRec *slices;
     const int16_t *mv_ext;

@@ -154,12 +154,13 @@ __device__ __forceinline__ bool mb_has_residual(const MbRec &r) {
 // ------------------------------------------------------------------------------------------
 // k_recon_inter: one wave per macroblock, 4 macroblocks per workgroup
 // ------------------------------------------------------------------------------------------
-template <bool COH> __device__ __forceinline__ int ref_luma(const uint8_t *s, int pitch, int W, int H, int x, int y) {
-    return ld_ref8<COH>(&s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)]);     // 32-bit index arithmetic (pointer adds here cost 15 VGPRs)
+template <bool COH> __device__ __forceinline__ int ref_luma(const RefBuf &rb, const uint8_t *s, int pitch, int W, int H, int x, int y) {
+    return ld_ref8<COH>(rb, &s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)]);     // 32-bit index arithmetic (pointer adds here cost 15 VGPRs)
 }
 // 8.4.2.2.1 luma sample interpolation (literal form)
-template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
-#define P(dx, dy) ref_luma<COH>(s, pitch, W, H, xi + (dx), yi + (dy))
+template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_base, const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
+    const RefBuf rb(surf_base);
+#define P(dx, dy) ref_luma<COH>(rb, s, pitch, W, H, xi + (dx), yi + (dy))
 #define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
 #define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
     int G = P(0, 0);
@@ -203,6 +204,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     auto ref_plane = [&](const PicParams &q, int slot) -> const uint8_t * { return FIELD ? jmamd::ref_plane(q, slot) : q.surf[slot]; };
     auto chroma_mvy_offset = [&](const PicParams &q, int slot) -> int { return FIELD ? jmamd::chroma_mvy_offset(q, slot) : 0; };
     auto cur_plane = [&](const PicParams &q) -> uint8_t * { return FIELD ? jmamd::cur_plane(q) : q.surf[q.cur]; };
+    const RefBuf refbuf(pp.surf_base);                           // the coherent reference loads of chain launches (chain_common.h)
     ResTile *tiles = sm.tiles;
     uint32_t (*outt)[96] = sm.outt;
     uint32_t (*wins)[4][13 * 5 + 3] = sm.wins;
@@ -256,7 +258,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
 #pragma unroll
                 for (int t = 0; t < 5; t++) {
                     int i = l + 16 * t;
-                    if (i < 65) { int row = i / 5, dw = i % 5; wv[t] = ld_ref32<COH>(ref + (size_t)(yi + row) * pitch + xa + dw * 4); }
+                    if (i < 65) { int row = i / 5, dw = i % 5; wv[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + row) * pitch + xa + dw * 4); }
                 }
             }
         }
@@ -279,15 +281,15 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                     // chain launches: the four bytes U V U V at 2 * xa of each row come out of two aligned dwords per row -- cache-bypassing BYTE loads
                     // are one memory request each (FETCH_SIZE showed 26.9 MB per 1080p picture for k_chain against 4.9 MB for the stage kernels)
                     const int o = (2 * xa) & ~3, sh = (2 * xa) & 3;
-                    const uint32_t a0 = ld_ref32<true>(r0 + o), a1 = ld_ref32<true>(r0 + o + 4), b0 = ld_ref32<true>(r1 + o), b1 = ld_ref32<true>(r1 + o + 4);
+                    const uint32_t a0 = ld_ref32<true>(refbuf, r0 + o), a1 = ld_ref32<true>(refbuf, r0 + o + 4), b0 = ld_ref32<true>(refbuf, r1 + o), b1 = ld_ref32<true>(refbuf, r1 + o + 4);
                     const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
                     c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
                     c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
                 } else {
-                c_smp[0] = ld_ref8<COH>(r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(r1 + 2 * xa);
-                c_smp[3] = ld_ref8<COH>(r1 + 2 * xb);
-                c_smp[4] = ld_ref8<COH>(r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(r1 + 2 * xa + 1);
-                c_smp[7] = ld_ref8<COH>(r1 + 2 * xb + 1);
+                c_smp[0] = ld_ref8<COH>(refbuf, r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(refbuf, r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(refbuf, r1 + 2 * xa);
+                c_smp[3] = ld_ref8<COH>(refbuf, r1 + 2 * xb);
+                c_smp[4] = ld_ref8<COH>(refbuf, r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(refbuf, r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(refbuf, r1 + 2 * xa + 1);
+                c_smp[7] = ld_ref8<COH>(refbuf, r1 + 2 * xb + 1);
                 }
             }
         }
@@ -430,7 +432,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 uint32_t w5[5];
 #pragma unroll
                 for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5;
-                    w5[t] = ld_ref32<COH>(ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
+                    w5[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
                 __builtin_amdgcn_wave_barrier();                   // (the block's window in LDS is reused for the second list: its readers are done)
                 int v[4];
                 filter_window(&wins[wave][g][0], w5, l16, xi & 3, mvx & 3, mvy & 3, v);
@@ -457,8 +459,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int a = 0, b = 0;
-                if (s0 >= 0) a = luma_sample<COH>(ref_plane(pp, s0), pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
-                if (s1 >= 0) b = luma_sample<COH>(ref_plane(pp, s1), pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
+                if (s0 >= 0) a = luma_sample<COH>(pp.surf_base, ref_plane(pp, s0), pitch, W, H, x0 + k + (m0x >> 2), y + (m0y >> 2), m0x & 3, m0y & 3);
+                if (s1 >= 0) b = luma_sample<COH>(pp.surf_base, ref_plane(pp, s1), pitch, W, H, x0 + k + (m1x >> 2), y + (m1y >> 2), m1x & 3, m1y & 3);
                 v[k] = combine(a, b, s0 >= 0, s1 >= 0, i0, i1, 0);
             }
             if (has_res) { const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
@@ -479,10 +481,10 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
                 const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
                 int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
-                pu[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa) + w01 * ld_ref8<COH>(r0 + 2 * xb) +
-                         w10 * ld_ref8<COH>(r1 + 2 * xa) + w11 * ld_ref8<COH>(r1 + 2 * xb) + 32) >> 6;
-                pv[l] = (w00 * ld_ref8<COH>(r0 + 2 * xa + 1) + w01 * ld_ref8<COH>(r0 + 2 * xb + 1) +
-                         w10 * ld_ref8<COH>(r1 + 2 * xa + 1) + w11 * ld_ref8<COH>(r1 + 2 * xb + 1) + 32) >> 6;
+                pu[l] = (w00 * ld_ref8<COH>(refbuf, r0 + 2 * xa) + w01 * ld_ref8<COH>(refbuf, r0 + 2 * xb) +
+                         w10 * ld_ref8<COH>(refbuf, r1 + 2 * xa) + w11 * ld_ref8<COH>(refbuf, r1 + 2 * xb) + 32) >> 6;
+                pv[l] = (w00 * ld_ref8<COH>(refbuf, r0 + 2 * xa + 1) + w01 * ld_ref8<COH>(refbuf, r0 + 2 * xb + 1) +
+                         w10 * ld_ref8<COH>(refbuf, r1 + 2 * xa + 1) + w11 * ld_ref8<COH>(refbuf, r1 + 2 * xb + 1) + 32) >> 6;
             }
             int u = combine(pu[0], pu[1], s[0] >= 0, s[1] >= 0, i0, i1, 1), v = combine(pv[0], pv[1], s[0] >= 0, s[1] >= 0, i0, i1, 2);
             if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
@@ -525,7 +527,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             const uint8_t *ref = ref_plane(pp, slot);
             int xi = x0 + (mvx >> 2), yi = y + (mvy >> 2), fx = mvx & 3, fy = mvy & 3;
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = luma_sample<COH>(ref, pitch, W, H, xi + k, yi, fx, fy);
+            for (int k = 0; k < 4; k++) v[k] = luma_sample<COH>(pp.surf_base, ref, pitch, W, H, xi + k, yi, fx, fy);
         }
         if (has_res) {
             const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];

@@ -79,7 +79,7 @@ namespace jmamd {
 bool deblock_lds_supported(int, int) { return true; }
 bool intra_lds_supported(int, int) { return true; }
 void launch_packout(const PackJob *, int, int, int, ihipStream_t *) { abort(); }
-void launch_recon_inter(const PicParams *, int, int, bool, ihipStream_t *) { abort(); }
+void launch_recon_inter(const PicParams *, int, int, bool, bool, ihipStream_t *) { abort(); }
 void launch_intra_lds(const PicParams *, int, int, int *, int *, ihipStream_t *) { abort(); }
 void launch_recon_intra(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_deblock_prep(const PicParams *, int, int, ihipStream_t *) { abort(); }
@@ -88,6 +88,7 @@ bool chain_supported(int, int) { return true; }
 int chain_ctl_ints() { return 1; }
 void launch_chain(const PicParams *, const uint32_t *, int, bool, int *, int *, bool, ihipStream_t *) { abort(); }
 int chain_band_rows() { return 16; }
+int deblock_row_lag() { return 1; }
 int chain_resident_workgroups(bool) { return 0; }
 void launch_deblock(const PicParams *, int, ihipStream_t *) { abort(); }
 void launch_frame_to_argb(const uint8_t *, int, int, int, uint8_t *, int, ihipStream_t *) { abort(); }
