@@ -705,8 +705,15 @@ void Decoder::infer_frame(int fn) {
     }
     DpbPic &c = dpb_[slot];
     c = DpbPic(); c.in_use = true; c.set_ref(1); c.frame_num = fn; c.decode_idx = decode_count_++; c.have = 3; c.non_existing = true;
-    const long long prev_off = prev_mmco5_ ? 0 : prev_frame_num_offset_, prev_fn = prev_mmco5_ ? 0 : prev_frame_num_;
-    prev_frame_num_offset_ = prev_fn > fn ? prev_off + max_fn : prev_off; prev_frame_num_ = fn; prev_mmco5_ = false;
+    if (seq_.poc_type != 0) {
+        // 8.2.5.2 (second reading, round 4): with pic_order_cnt_type 1 / 2 the inferred frame GETS order counts -- 8.2.1 as for a reference frame whose
+        // delta_pic_order_cnt[] are 0 -- and takes its place by them in the initial lists of later B slices (rounds 1-3 left them 0; only the
+        // FrameNumOffset state was carried on, which is all a P-only stream can see).  compute_poc also moves prevFrameNumOffset.
+        SliceHeader ih{}; ih.idr = false; ih.nal_ref_idc = 1; ih.frame_num = fn; ih.field_pic = false; ih.bottom_field = false;
+        ih.delta_poc[0] = ih.delta_poc[1] = 0;
+        c.poc = compute_poc(ih, c);
+    }
+    prev_frame_num_ = fn; prev_mmco5_ = false;
     prev_ref_frame_num_ = fn;
     stat_inferred_frames_++;
 }
@@ -934,7 +941,10 @@ void Decoder::build_frame_ref_lists(const SliceHeader &sh, SliceTask &task) {
         for (int i = 0; i < nst && ninit[0] < 33; i++) init[0][ninit[0]++] = st[i];
     } else {                                                // 8.2.4.2.3: by POC around the current picture
         int before[kMaxSurfaces], after[kMaxSurfaces], nb = 0, na = 0, cp = dpb_[cur_].poc;
-        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].poc < cp) before[nb++] = st[i]; else after[na++] = st[i]; }
+        // (with pic_order_cnt_type 0 a frame inferred from a gap in frame_num has no order count: it is left out of the initial lists of a B slice;
+        //  with types 1 / 2 it has one, infer_frame)
+        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].non_existing && seq_.poc_type == 0) continue;
+            if (dpb_[st[i]].poc < cp) before[nb++] = st[i]; else after[na++] = st[i]; }
         std::sort(before, before + nb, [&](int a, int b) { return dpb_[a].poc > dpb_[b].poc; });
         std::sort(after, after + na, [&](int a, int b) { return dpb_[a].poc < dpb_[b].poc; });
         for (int i = 0; i < nb; i++) init[0][ninit[0]++] = before[i];

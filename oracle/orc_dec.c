@@ -205,8 +205,13 @@ static int infer_frame(OrcDec *d, int fn) {
     f->in_use = 1; set_ref(f, 1); f->needed_for_output = 0; f->has_mmco5 = 0; f->have = 3; f->waiting_second = 0; f->non_existing = 1; f->coded_fields = 0;
     f->id = d->next_pic_id++; f->frame_num = fn; f->is_idr = 0; f->long_term_frame_idx = -1; f->poc = f->fpoc[0] = f->fpoc[1] = 0; f->is_field = 0; f->store = f;
     { const int n = d->mb_w * d->asps->mb_height; for (int i = 0; i < n; i++) f->mbs[i].slice_num = -1; }
-    const int prev_off = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num_offset, prev_fn = d->prev_ref_has_mmco5 ? 0 : d->prev_frame_num;
-    d->prev_frame_num_offset = prev_fn > fn ? prev_off + max_frame_num : prev_off; d->prev_frame_num = fn; d->prev_ref_has_mmco5 = 0;
+    if (d->asps->poc_type != 0) {
+        /* 8.2.5.2, second reading (round 4): with pic_order_cnt_type 1 / 2 the inferred frame gets its order counts by 8.2.1, as a reference frame whose
+         * delta_pic_order_cnt[] are 0 (this also moves prevFrameNumOffset); a later B slice sorts it into its initial lists by them */
+        SliceHdr ih; memset(&ih, 0, sizeof ih); ih.nal_ref_idc = 1; ih.frame_num = fn;
+        f->poc = compute_poc(d, &ih, f);
+    }
+    d->prev_frame_num = fn; d->prev_ref_has_mmco5 = 0;
     d->prev_ref_frame_num = fn;
     d->stats[ORC_ST_INFERRED_FRAMES]++;
     return 0;
@@ -405,7 +410,9 @@ int orc_build_ref_lists(OrcDec *d, const SliceHdr *sh) {
         for (int i = 0; i < nst && ninit[0] < 33; i++) init[0][ninit[0]++] = st[i];
     } else {                                               /* 8.2.4.2.3: by POC distance around the current picture */
         Picture *before[ORC_MAX_DPB + 1], *after[ORC_MAX_DPB + 1]; int nb = 0, na = 0;
-        for (int i = 0; i < nst; i++) { if (st[i]->poc < d->cur->poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        /* (a frame inferred from a gap in frame_num has no order count when pic_order_cnt_type is 0: it is not in the initial lists of a B slice) */
+        for (int i = 0; i < nst; i++) { if (st[i]->non_existing && d->asps->poc_type == 0) continue;
+            if (st[i]->poc < d->cur->poc) before[nb++] = st[i]; else after[na++] = st[i]; }
         for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j];
             before[j] = t; }
         for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j];

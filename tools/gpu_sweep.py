@@ -53,6 +53,11 @@ def h264_params(r):
              48]))      # no_intra: pictures that can run in chain launches
     if not b and r.random() < 0.3:
         a["mmco"] = 1
+    if not b and r.random() < 0.3:
+        # round 4: memory management operation 5, pic_order_cnt_type 1 (with a bottom-field offset and non-reference pictures in
+        # the cycle) and long-term references TOGETHER, in frame streams too -- the combinations the three shared deviations of round 3 hid in
+        a.update(mmco=2, poc_type=r.choice([0, 1, 1, 2]), poc_bottom=r.randint(0, 1), nonref_period=r.choice([0, 2, 3]), num_ref=r.randint(2, 4),
+                 frames=r.choice([14, 20, 30]), gop=r.choice([10, 30]))
     if (cab or b) and r.random() < 0.25 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
         a.update(fmo0=1, dinf8=1)                                                                           # interlace-capable stream, frame pictures only
     if b and r.random() < 0.3 and ((a["height"] + 15) // 16) % 2 == 0 and (((a["height"] + 15) // 16) * 16 - a["height"]) % 4 == 0:
