@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--command", default="python3 bench.py --steps 1 --warmup 1 --frames 30 --streams 1 --no-cpu-baseline")
+    # environment of the profiled run, written IN FRONT of rocprofv3 in the recipe (behind the `--` it would be the program rocprofv3 tries to
+    # start, and `-- env VAR=1 python3 ...` is an exec hop behind an initialised GPU, which this pool forbids under --pmc)
+    ap.add_argument("--env", default="", help='e.g. "JM_AMD_DEC_CHAIN_DEPTH=1"')
     ap.add_argument("--chain-fetch")
     ap.add_argument("--chain-write")
     ap.add_argument("--chain-line")
@@ -48,14 +51,17 @@ def main():
         kc = line["kernels"]["k_chain"]
         pics_timed = kc["launches"] * kc["pictures_per_launch"]      # timed region only; the profile also holds the warm-up pass: same stream, same count
         if "k_chain" in cf and pics_timed > 0:
-            n_launch = cf["k_chain"][1]
+            # (both chain kernels: launches that hold a picture with intra macroblocks run k_chain_i, and the line counts the pictures of both)
+            tot = lambda d: sum(d[k][0] * d[k][1] for k in ("k_chain", "k_chain_i") if k in d)
+            n_launch = sum(cf[k][1] for k in ("k_chain", "k_chain_i") if k in cf)
             pics = pics_timed * a.chain_scale                      # pictures through k_chain in the whole profile = timed x (passes in profile / timed passes)
-            chain = {"fetch_raw": round(cf["k_chain"][0] * n_launch / pics), "write": round(cw["k_chain"][0] * cw["k_chain"][1] / pics), "launches": n_launch,
+            chain = {"fetch_raw": round(tot(cf) / pics), "write": round(tot(cw) / pics), "launches": n_launch,
                 "pictures": round(pics, 1)}
             chain["fetch_corrected_upper"] = 2 * chain["fetch_raw"]
             chain["traffic_upper"] = chain["fetch_corrected_upper"] + chain["write"]
     mb_w, mb_h = (a.width + 15) // 16, (a.height + 15) // 16
-    out = {"how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per launch, so "
+    env = (a.env.strip() + " ") if a.env.strip() else ""
+    out = {"how": f"{env}rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per launch, so "
         f"bytes "
                   f"are per {a.width}x{a.height} picture (averaged over the launches of the kernel, i.e. over the run's picture types). Counter unit KB "
                   f"(x1024). "
