@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
     const int g = (int)blockIdx.x >> 1, rem = (int)blockIdx.x & 1;
     const uint32_t entry = groups[g];
     const PicParams &pp = pics[entry >> 16];
-    const ChainView cv{ctl, err};
+    const bool census_on = pub > 0 && (pub & 0x10000) != 0;
+    if (pub > 0) pub &= 0xffff;
+    ChainView cv{ctl, err}; cv.census_on = census_on;
     // ONE LDS block for whichever role the workgroup has: two static arrays add up (52.5 KB: three workgroups per CU by LDS alone), and since round 4
     // the kernel's 119 registers allow four
     __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)];
@@ -88,7 +90,8 @@ int chain_resident_workgroups(bool intra) {
 }
 
 void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st) {
-    const int depth = deblock_depth(), pub = debug_stall ? -1 : deblock_pub();
+    static const bool census = getenv("JM_AMD_DEC_VERBOSE") != nullptr;      // diagnostic launches count their workgroups (chain_common.h)
+    const int depth = deblock_depth(), pub = debug_stall ? -1 : (deblock_pub() | (census ? 0x10000 : 0));
     if (with_intra) { launch_chain_intra(d_pics, d_groups, n_groups, ctl, err, depth, pub, st); return; }
     dim3 grid((unsigned)n_groups * 2u), block(256);
     if (depth <= 2) hipLaunchKernelGGL((k_chain<2>), grid, block, 0, st, d_pics, ctl, err, d_groups, pub);

@@ -148,10 +148,13 @@ struct ChainView {
     // so a broken hand-over costs about one timeout, not one per waiting wave.
     __device__ __forceinline__ int *abort_word() const { return base + (size_t)kChainMaxPics * kChainStride; }
     // Census of the launch (round 4, what a give-up is diagnosed with: Engine::dump_chain_state): behind the abort word, workgroups started / finished
-    // per role and the highest work-list index started.  No-return atomics, one per workgroup: nothing waits for them.
+    // per role and the highest work-list index started.  Only in diagnostic launches (JM_AMD_DEC_VERBOSE; `on` comes with the kernel's `pub` argument):
+    // three atomics per workgroup on ONE cache line are 180 k of them in a 2 ms launch of eight streams -- the rate at which a single address saturates
+    // -- and a wave's loads retire behind its own older atomics: switched on for every launch they cost 8 / 16 streams 11 % / 9 % of their rate.
     enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5 };
+    bool census_on = false;
     __device__ __forceinline__ void census(int what, int value = 1) const {
-        if (threadIdx.x != 0) return;
+        if (!census_on || threadIdx.x != 0) return;
         if (what == CENSUS_MAX_GROUP) (void)__hip_atomic_fetch_max(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else (void)__hip_atomic_fetch_add(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256, 3) __attribute__((flatten)) void k_chain_i(con
     const int g = (int)blockIdx.x >> 1, rem = (int)blockIdx.x & 1;
     const uint32_t entry = groups[g];
     const PicParams &pp = pics[entry >> 16];
-    const ChainView cv{ctl, err};
+    const bool census_on = pub > 0 && (pub & 0x10000) != 0;
+    if (pub > 0) pub &= 0xffff;
+    ChainView cv{ctl, err}; cv.census_on = census_on;
     cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;

@@ -152,6 +152,26 @@ HostCopier::Result HostCopier::copy(void *dst, const void *src, size_t n, uint64
     struct timespec ts = {0, 40 * 1000};
     if (typical > 400000) ts.tv_nsec = typical / 2 > 5000000 ? 5000000 : typical / 2;      // (only when copies queue: a lone copy must be seen as it ends)
     long total_ns = 0;
+    if (typical <= 400000) {
+        // Copies are NOT queueing (one or a few callers: the reference harness's own shape): the transfer ends a known time after it was queued -- one
+        // engine moves 47 bytes per nanosecond (tools/sdma_probe.cpp) -- so sleep until shortly before that and then LOOK, without sleeping, for a few
+        // tens of microseconds.  The sleep-and-look loop below saw a 66 us copy of a 1080p frame after 85-105 us (every look is a system call and a
+        // timer); one stream spends a quarter of its caller's time per frame in here (round 4: +10 % on the single-stream rate).  A copy that is not
+        // done by then (the engine was busy after all) falls through to the sleeping loop; with many callers `typical` is large and this is skipped.
+        const long expect_ns = (long)((double)n / 47.0);
+        ts.tv_nsec = expect_ns > 27000 ? expect_ns - 12000 : 15000;
+        nanosleep(&ts, nullptr);
+        struct timespec a, z; clock_gettime(CLOCK_MONOTONIC, &a);
+        for (;;) {
+            const hsa_signal_value_t v = hsa_signal_load_scacquire(s);
+            clock_gettime(CLOCK_MONOTONIC, &z);
+            const long spun = (z.tv_sec - a.tv_sec) * 1000000000l + (z.tv_nsec - a.tv_nsec);
+            if (v < 1) { typical_wait_ns_.store((typical * 7 + ts.tv_nsec + spun) / 8, std::memory_order_relaxed); return v == 0 ? kDone : kFailed; }
+            if (spun > 50000) { total_ns = ts.tv_nsec + spun; break; }
+            __builtin_ia32_pause();
+        }
+        ts.tv_nsec = 15000;
+    }
     // (bounded: half a minute -- a device that takes longer has hung, and the caller's plain hipMemcpy that follows will say so)
     for (int i = 0; i < 400000 && total_ns < 30l * 1000 * 1000 * 1000; i++) {
         nanosleep(&ts, nullptr);
