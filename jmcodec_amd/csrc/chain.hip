@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
     ChainView cv{ctl, err}; cv.census_on = census_on;
     // ONE LDS block for whichever role the workgroup has: two static arrays add up (52.5 KB: three workgroups per CU by LDS alone), and since round 4
     // the kernel's 119 registers allow four
-    __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)];
+#ifndef JM_CHAIN_LDS_PAD
+#define JM_CHAIN_LDS_PAD 0          // A/B builds: extra LDS per workgroup (14000 -> three workgroups per CU again)
+#endif
+    __shared__ __align__(16) uint8_t smem[(kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)) + JM_CHAIN_LDS_PAD];
     cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;
@@ -90,7 +93,7 @@ int chain_resident_workgroups(bool intra) {
 }
 
 void launch_chain(const PicParams *d_pics, const uint32_t *d_groups, int n_groups, bool with_intra, int *ctl, int *err, bool debug_stall, hipStream_t st) {
-    static const bool census = getenv("JM_AMD_DEC_VERBOSE") != nullptr;      // diagnostic launches count their workgroups (chain_common.h)
+    static const bool census = getenv("JM_AMD_DEC_CENSUS") != nullptr;       // diagnostic launches count their workgroups (chain_common.h)
     const int depth = deblock_depth(), pub = debug_stall ? -1 : (deblock_pub() | (census ? 0x10000 : 0));
     if (with_intra) { launch_chain_intra(d_pics, d_groups, n_groups, ctl, err, depth, pub, st); return; }
     dim3 grid((unsigned)n_groups * 2u), block(256);

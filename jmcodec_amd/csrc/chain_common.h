@@ -148,7 +148,7 @@ struct ChainView {
     // so a broken hand-over costs about one timeout, not one per waiting wave.
     __device__ __forceinline__ int *abort_word() const { return base + (size_t)kChainMaxPics * kChainStride; }
     // Census of the launch (round 4, what a give-up is diagnosed with: Engine::dump_chain_state): behind the abort word, workgroups started / finished
-    // per role and the highest work-list index started.  Only in diagnostic launches (JM_AMD_DEC_VERBOSE; `on` comes with the kernel's `pub` argument):
+    // per role and the highest work-list index started.  Only in diagnostic launches (JM_AMD_DEC_CENSUS; `on` comes with the kernel's `pub` argument):
     // three atomics per workgroup on ONE cache line are 180 k of them in a 2 ms launch of eight streams -- the rate at which a single address saturates
     // -- and a wave's loads retire behind its own older atomics: switched on for every launch they cost 8 / 16 streams 11 % / 9 % of their rate.
     enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5 };

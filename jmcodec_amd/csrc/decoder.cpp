@@ -305,12 +305,15 @@ bool Decoder::gpu_open() {
         const char *e = getenv("JM_AMD_DEC_DEVICE");
         device_ = e ? atoi(e) : (g_handle_counter++ % n);
     }
+    // (the test override JM_AMD_DEC_FAKE_NUMA is keyed by the device index the CALLER named: "device 1" on a one-GPU box is device 0 again, but keeps the
+    //  node the override gives device 1 -- the many-GPUs-in-one-process mode, two parse pools and all, on real hardware with one GPU)
+    const int named_device = device_;
     if (device_ >= n) device_ %= n;
     mem_trace("handle: before hipSetDevice");
     if (!HIP_OK(hipSetDevice(device_))) { fail("hipSetDevice failed"); return false; }
     mem_trace("handle: hipSetDevice");
     handle_index_ = g_handle_index++;
-    numa_node_ = numa_node_of_device(device_, true);
+    numa_node_ = numa_node_of_device(getenv("JM_AMD_DEC_FAKE_NUMA") ? named_device : device_, true);
     engine_ = Engine::get(device_);
     if (!engine_) { fail("could not start the device engine (stream / buffer creation failed)"); return false; }
     gpu_open_ = true;

@@ -414,6 +414,11 @@ void Engine::launch(Lane &ln, Batch &b) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
             for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
                 base_of[i] = base_of[j] + chain_lag_steps_ + L * b.pics[i].reach_rows + b.pics[i].reach_cols + kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
+                // Behind a picture with the intra role: its deblocking bands move in lockstep over 16 rows at ONE row per step, but each row is gated by the
+                // intra wavefront, which needs TWO steps per row -- so a band's step S waits for intra step S + 4 + (its last row), up to 15 rows' worth more
+                // than the x + 2y keys of that picture's own groups allow for.  (Found on paper after chain launches of 4 / 8 streams gave up with the
+                // one-row deblocking schedule: profiles/r04_ab4_chain.json.)  One I picture per IDR period: the extra spacing costs nothing measurable.
+                if (b.h_pics[j].stages & PS_CHAIN_INTRA) base_of[i] += band_rows + 8;
                 break; }
             n_keys = std::max(n_keys, (size_t)(base_of[i] + L * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
         }

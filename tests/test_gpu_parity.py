@@ -997,6 +997,28 @@ def test_all_intra_stream_on_device(oracle):
     assert len(frames) == n == 48 and b"".join(frames) == want
 
 
+def test_many_gpus_in_one_process_mode_on_the_device(oracle, monkeypatch):
+    """the drop-in mode 'one process, handles round robin over every GPU' on real hardware.  The box has one GPU, so two handles name
+    devices 0 and 1 (device 1 wraps to the GPU) and JM_AMD_DEC_FAKE_NUMA puts them on two NUMA nodes: two parse pools (one per node), page-locked job buffers
+    allocated under each node's policy, both handles decoding concurrently through ONE engine -- frames bit-exact, each handle on its node."""
+    monkeypatch.setenv("JM_AMD_DEC_FAKE_NUMA", "0:0,1:1")
+    monkeypatch.delenv("JM_AMD_DEC_DEVICE", raising=False)
+    data = [streams.generate(width=352, height=288, frames=24, gop=12, mode=1, num_ref=2, seed=0x4D97 + k, cabac=k) for k in (0, 1)]
+    want = [oracle.decode(d, 1)[0] for d in data]
+    got, info = {}, {}
+
+    def run(dev):
+        with api.JmAmdDec(0, 1, options={"device": dev}) as d:
+            got[dev] = b"".join(d.decode_stream(data[dev]))
+            info[dev] = (d.stat("numa_node"), d.stat("device"), d.stat("threads"), d.stat("errors"))
+    ts = [threading.Thread(target=run, args=(dev,)) for dev in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for dev in (0, 1):
+        assert got[dev] == want[dev], f"handle on device {dev}"
+        assert info[dev][0] == dev and info[dev][1] == 0 and info[dev][2] >= 1 and info[dev][3] == 0, info
+
+
 # ---- closing test of this file (pytest runs a file's tests in definition order): were the chain kernels exercised at all? ---------------------------
 def test_zz_chain_kernels_ran_in_this_session():
     """1-16-stream callers (config C4's 8 streams per GPU, the reference harness's single stream) run on k_chain and
