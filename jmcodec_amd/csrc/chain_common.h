@@ -111,10 +111,19 @@ __device__ __forceinline__ void report_wait_timeout(int *err_word, int code) {
     if (err_word) __hip_atomic_store(err_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The FIRST wait of a launch that runs out of time (not the ones that follow the abort word) leaves a record behind the abort word: which wait, of which
+// picture, where, what it needed and what it saw -- when the launch retires every counter is complete again (after the abort the waits let go), so this
+// is the only trace of where a launch was stuck (Engine::dump_chain_state prints it).  launch = the abort word's address.
+__device__ __forceinline__ void record_first_giveup(int *launch, int code, int pic, int where, int need, int seen0, int seen1) {
+    if (__hip_atomic_fetch_add(launch + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    launch[9] = code; launch[10] = pic; launch[11] = where; launch[12] = need; launch[13] = seen0; launch[14] = seen1;
+}
+
 // Bits of one macroblock row of the reconstruction bitmap as a band workgroup sees them: `known` macroblocks from the left are known to be in memory
 // (the run of set bits found by the last poll), so a band that trails the reconstruction polls once per row.  Uniform per 16-lane group.
 // want = this group needs macroblock x now; returns false when the wait gave up (reported by the caller).
-__device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word) {
+// tag = picture << 16 | row (for the record of the first give-up)
+__device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word, int tag = 0) {
     bool pending = want && x >= known;
     int spins = 0; uint32_t t0 = 0;
     for (;;) {
@@ -123,19 +132,24 @@ __device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &know
             if (m & 1) { known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
         }
         if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // gave up: do not wait again
+        const bool expired = wait_expired(++spins, t0);
+        if (expired && pending) record_first_giveup(abort_word, CHAIN_ERR_BITS_TIMEOUT, tag >> 16, (tag & 0xffff) << 16 | (x & 0xffff), x, known,
+            (int)ld_coh(bits_row + (x >> 5)));
+        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // gave up: do not wait again
         // a band may be resident long before its rows are reconstructed
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
     }
 }
 // the same for a step counter (`fin` of the intra wavefront): wait until *ctr >= need
-__device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word) {
+__device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word, int tag = 0) {
     bool pending = want && known < need;
     int spins = 0; uint32_t t0 = 0;
     for (;;) {
         if (pending) { known = ld_coh(ctr); pending = known < need; }
         if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
+        const bool expired = wait_expired(++spins, t0);
+        if (expired && pending) record_first_giveup(abort_word, CHAIN_ERR_IFIN_TIMEOUT, tag >> 16, tag & 0xffff, need, known, 0);
+        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -180,7 +194,10 @@ struct ChainView {
                 pending = !ok;
             }
             if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }      // (nothing that reads the picture moves above the polls)
-            if (wait_expired(++spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
+            const bool expired = wait_expired(++spins, t0);
+            if (expired && pending) record_first_giveup(abort_word(), CHAIN_ERR_FIN_TIMEOUT, dep, bhi << 16 | (xs & 0xffff), need_hi, ld_coh(fin + bhi),
+                ld_coh(fin + 32 + bhi));
+            if (expired || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
             __builtin_amdgcn_s_sleep(4);
         }
     }

@@ -402,7 +402,11 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
                !(CHAIN && (wait_expired(spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))))) __builtin_amdgcn_s_sleep(8);
         if (known < need) {                                                  // the band above never got there: damaged, and SAID so
-            if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT); if (CHAIN) st_coh(abort_word, 1); }
+            if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT);
+                if (CHAIN) {
+                    if (!ld_coh(abort_word)) record_first_giveup(abort_word, CHAIN_ERR_RING_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0), need, known, 0);
+                    st_coh(abort_word, 1);
+                } }
             known = 0x7fffffff;                                              // do not wait again
         }
         asm volatile("" ::: "memory");
@@ -421,9 +425,10 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         if (!CHAIN) return;
         const bool want = active && x >= 0 && x < mb_w;
         bool ok;
-        if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word) &&
-            wait_counter(ifin1, ifin_known1, want, need, abort_word); }
-        else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word);
+        const int tag = pp.chain_idx << 16 | (row & 0xffff);
+        if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word, tag) &&
+            wait_counter(ifin1, ifin_known1, want, need, abort_word, tag); }
+        else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word, tag);
         if (!ok && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, after_intra ? CHAIN_ERR_IFIN_TIMEOUT : CHAIN_ERR_BITS_TIMEOUT);
             st_coh(abort_word, 1); }
     };

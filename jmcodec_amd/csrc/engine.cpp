@@ -41,7 +41,7 @@ Engine::Engine(int device) : device_(device) {
     mem_trace("engine: start");
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
-    if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(20, std::min(atoi(e), 1024));
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(kMinChainLag, std::min(atoi(e), 1024));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LINGER")) chain_linger_streams_ = std::max(0, atoi(e));
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
@@ -120,7 +120,7 @@ bool Engine::set_knob(const std::string &key, long long v) {
     // an explicit setting ends the pause that follows a recovered chain launch, and has the next batch look again whether the GPU is shared
     if (key.rfind("chain_", 0) == 0) { chain_block_until_ns_ = 0; shared_checked_ns_ = 0; }
     if (key == "chain_depth") chain_depth_ = (int)std::max(1ll, std::min(v, 16ll));
-    else if (key == "chain_lag") chain_lag_steps_ = (int)std::max(20ll, std::min(v, 1024ll));
+    else if (key == "chain_lag") chain_lag_steps_ = (int)std::max((long long)kMinChainLag, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
     else if (key == "debug_stall") debug_stall_ = (int)v;
     else return false;
@@ -408,12 +408,15 @@ void Engine::launch(Lane &ln, Batch &b) {
         for (int i = 0; i < n; i++) launch_has_intra |= (b.h_pics[i].stages & PS_CHAIN_INTRA) != 0;
         const int band_rows = chain_band_rows(), L = launch_has_intra ? 2 : deblock_row_lag();
         constexpr int kBandLag = 8;
+#ifndef JM_CHAIN_KEY_MARGIN
+#define JM_CHAIN_KEY_MARGIN 0          // A/B builds: extra keys between consecutive pictures of a chain, beyond chain_lag
+#endif
         std::vector<int> base_of(n, 0);
         size_t n_keys = 0;
         for (int i = 0; i < n; i++) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
             for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
-                base_of[i] = base_of[j] + chain_lag_steps_ + L * b.pics[i].reach_rows + b.pics[i].reach_cols + kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
+                base_of[i] = base_of[j] + chain_lag_steps_ + JM_CHAIN_KEY_MARGIN + L * b.pics[i].reach_rows + b.pics[i].reach_cols + kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
                 // Behind a picture with the intra role: its deblocking bands move in lockstep over 16 rows at ONE row per step, but each row is gated by the
                 // intra wavefront, which needs TWO steps per row -- so a band's step S waits for intra step S + 4 + (its last row), up to 15 rows' worth more
                 // than the x + 2y keys of that picture's own groups allow for.  (Found on paper after chain launches of 4 / 8 streams gave up with the
@@ -558,6 +561,9 @@ void Engine::dump_chain_state(Batch &b) {
     fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | band workgroups started %d done %d of %d | "
         "highest work-list index started %d | band budget %d / %d\n", lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_,
         chain_bands_max_intra_);
+    if (lw[8]) fprintf(stderr, "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
+        "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
+        "the row = intra band; ring: band << 16 | chroma) needed %d saw %d / %d\n", lw[8], lw[9], lw[10], (unsigned)lw[11], lw[12], lw[13], lw[14]);
     for (int i = 0; i < n; i++) {
         const PicParams &q = b.h_pics[i];
         if (!(q.stages & PS_CHAIN)) continue;

@@ -40,6 +40,9 @@ constexpr int kMaxChainBandsIntra = 256;
 // Lane 0 takes ordinary pictures.  (Rounds 1-2 carried an optional second ordinary lane with the streams divided by handle parity; it measured worse
 // every time -- 32 streams 12.5 k against 16.8 k frames/s: two half-size batches take as long as one and their kernels get in each other's way --
 // and was removed in round 3.)
+// smallest spacing of consecutive pictures of a chain in the work list: the rule of Engine::launch (every dependency has a smaller key) needs
+// lag > 15 + kBandLag, so the knob cannot go below it
+constexpr int kMinChainLag = 24;
 constexpr int kOrdinaryLane = 0;
 constexpr int kIntraLane = 1;                       // intra-dense H.264 pictures
 constexpr int kErrNotRecovered = 32;                // error word set by Engine::recover (chain_common.h CHAIN_ERR_NOT_RECOVERED; the device sets 1..16)

@@ -457,13 +457,16 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     const gbyte *above = plane + (size_t)(row0 * rows_per_mb - 1) * pitch + (l & 3) * 4;
     gbyte *below = plane + (size_t)((row + 1) * rows_per_mb - 1) * pitch + (l & 3) * 4;
     int known = 0;
+    int *abort_word_ = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
     auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
         int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit && !(CHAIN &&
             wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
         // never silent: the engine reports a decode error (and the band does not wait again)
-        if (known < need) { if (l == 0) report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT); known = 0x7fffffff; }
+        if (known < need) { if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT);
+            if (CHAIN && abort_word_ && !ld_coh(abort_word_)) record_first_giveup(abort_word_, CHAIN_ERR_INTRA_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0),
+                need, known, 0); } known = 0x7fffffff; }
         asm volatile("" ::: "memory");
     };
     auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };
@@ -486,7 +489,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     // (a macro, not a lambda: capturing the uint4 prefetch registers by reference put them in scratch memory)
 #define JM_PREFETCH(s_) do { \
         const int xn_ = (s_) - 2 * row; \
-        if (CHAIN && !wait_row_bit(bits_row, recon_known, active && xn_ >= 0 && xn_ < mb_w, xn_, abort_word) && (threadIdx.x & 63) == 0) { \
+        if (CHAIN && !wait_row_bit(bits_row, recon_known, active && xn_ >= 0 && xn_ < mb_w, xn_, abort_word, pp.chain_idx << 16 | 0x8000 | (row & 0x7fff)) && \
+            (threadIdx.x & 63) == 0) { \
             report_wait_timeout(err_word, CHAIN_ERR_BITS_TIMEOUT); st_coh(abort_word, 1); } \
         if (active && xn_ >= 0 && xn_ < mb_w) { \
             const int mb_ = row * mb_w + xn_; \
