@@ -399,31 +399,33 @@ void Engine::launch(Lane &ln, Batch &b) {
         // band ABOVE it has run kBandLag steps further, the one above that 2 * kBandLag, ...: exactly the term the key carries, so the bound holds
         // at every band level (rounds 2-3 had no such term: with nine bands at 4K the bound was off by up to 8 * 7 steps for the lowest band).
         // With 8c <= x' the previous picture's groups involved have keys <= base' + x + L * r + L + 8 + kBandLag * band, this group's key is
-        // >= base' + lag + x - 7 + L * r + kBandLag * band: smaller whenever lag > L + 15.  That is what keeps a full machine from deadlocking:
+        // >= base' + lag + x - 7 + L * r + kBandLag * band: smaller whenever lag > L + 16 (one step more since the final store of a macroblock moved
+        // behind the next one's vertical edges).  That is what keeps a full machine from deadlocking:
         // the unfinished group with the smallest key is resident (in-order dispatch per XCD) and waits only for finished groups and resident bands.
-        // A launch that holds a picture with the intra role (k_chain_i) keeps L = 2 in its keys: that picture's deblocking follows its intra wavefront,
-        // which advances as x + 2y (intra prediction needs the macroblock above right COMPLETE), so its reconstruction groups are wanted in that order;
-        // keys built for x + 2y also bound the dependencies of a wavefront that runs as x + y (x' + 2y' <= x' + y' + Y).
-        bool launch_has_intra = false;
-        for (int i = 0; i < n; i++) launch_has_intra |= (b.h_pics[i].stages & PS_CHAIN_INTRA) != 0;
-        const int band_rows = chain_band_rows(), L = launch_has_intra ? 2 : deblock_row_lag();
-        constexpr int kBandLag = 8;
+        // The SLOPE of a picture's keys is the pace of whatever consumes its reconstruction: one step per macroblock row for a picture that is only deblocked
+        // (deblock_row_lag()), two for a picture with the intra role (its intra wavefront needs the macroblock above right COMPLETE: x + 2y).  Rounds 2-3 and the
+        // first form of round 4 gave a whole launch ONE slope (2 as soon as it held an intra-role picture): with one-row deblocking that puts a band's needs up
+        // to 14 keys beyond a dependent group's own key -- the band moves as a unit over 16 rows -- and chain launches of 4 / 8 streams gave up in 3 runs of 10
+        // (profiles/r04_ab6_first_giveup.json).  tools/chain_keys.py checks the rule by brute force for every macroblock of a picture (it found both numbers):
+        //   deblock-only picture -> deblock-only successor: largest needed key = key - 1 (holds; + kKeySlack for comfort);
+        //   intra-role picture (slope 2, its one-row deblocking bands gated by a two-row intra wavefront) -> any successor: the successor starts
+        //   mb_h + kIntraExtra keys later (needed: > mb_h + 7 at 1080p, > mb_h + 4 at 4K).  One such picture per IDR period: nothing measurable.
+        const int band_rows = chain_band_rows(), L = deblock_row_lag();
+        constexpr int kBandLag = 8, kKeySlack = 2, kIntraExtra = 24;
 #ifndef JM_CHAIN_KEY_MARGIN
 #define JM_CHAIN_KEY_MARGIN 0          // A/B builds: extra keys between consecutive pictures of a chain, beyond chain_lag
 #endif
-        std::vector<int> base_of(n, 0);
+        std::vector<int> base_of(n, 0), slope_of(n, L);
         size_t n_keys = 0;
         for (int i = 0; i < n; i++) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
+            slope_of[i] = (b.h_pics[i].stages & PS_CHAIN_INTRA) ? 2 : L;
             for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
-                base_of[i] = base_of[j] + chain_lag_steps_ + JM_CHAIN_KEY_MARGIN + L * b.pics[i].reach_rows + b.pics[i].reach_cols + kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
-                // Behind a picture with the intra role: its deblocking bands move in lockstep over 16 rows at ONE row per step, but each row is gated by the
-                // intra wavefront, which needs TWO steps per row -- so a band's step S waits for intra step S + 4 + (its last row), up to 15 rows' worth more
-                // than the x + 2y keys of that picture's own groups allow for.  (Found on paper after chain launches of 4 / 8 streams gave up with the
-                // one-row deblocking schedule: profiles/r04_ab4_chain.json.)  One I picture per IDR period: the extra spacing costs nothing measurable.
-                if (b.h_pics[j].stages & PS_CHAIN_INTRA) base_of[i] += band_rows + 8;
+                base_of[i] = base_of[j] + chain_lag_steps_ + kKeySlack + JM_CHAIN_KEY_MARGIN + slope_of[i] * b.pics[i].reach_rows + b.pics[i].reach_cols +
+                             kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
+                if (b.h_pics[j].stages & PS_CHAIN_INTRA) base_of[i] += b.h_pics[j].mb_h + kIntraExtra;
                 break; }
-            n_keys = std::max(n_keys, (size_t)(base_of[i] + L * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
+            n_keys = std::max(n_keys, (size_t)(base_of[i] + slope_of[i] * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
         }
         if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
         for (size_t k = 0; k < n_keys; k++) group_buckets_[k].clear();
@@ -431,7 +433,7 @@ void Engine::launch(Lane &ln, Batch &b) {
             if (!(b.h_pics[i].stages & PS_CHAIN) || (b.h_pics[i].stages & PS_RECON)) continue;      // (PS_RECON: reconstructed by the stage kernel)
             const int mb_h = b.h_pics[i].mb_h, segs = (b.h_pics[i].mb_w + 7) / 8, base = base_of[i];
             for (int r = 0; r < mb_h; r++) {
-                const int kr = base + L * r + kBandLag * (r / band_rows);
+                const int kr = base + slope_of[i] * r + kBandLag * (r / band_rows);
                 for (int c = 0; c < segs; c++) group_buckets_[kr + 8 * c].push_back((uint32_t)i << 16 | (uint32_t)(r * 32 + c));
             }
         }
