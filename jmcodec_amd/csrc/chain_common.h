@@ -10,8 +10,23 @@
 // cache levels (agent-scope relaxed atomics: the 8 XCDs of an MI355X have private L2s, and a 128-byte line fetched for a final sample
 // also holds neighbours that are not final yet).  Acquire / release fences are deliberately not used: at agent scope they write back /
 // invalidate a whole L2.
-// A workgroup only ever waits for workgroups with a lower linear index (earlier picture, or earlier role of the same picture), which the
-// dispatcher has started before it: no deadlock at any occupancy.  Every wait is bounded; a wait that gives up sets the error word.
+// THE INVARIANT (who may wait on whom, and why the waited-on workgroup is resident; round 4 wrote it down after two parked give-ups were traced to it):
+//   1. There is ONE chain launch per device at a time (the ordinary lane's in-order stream), and its band workgroups -- deblocking bands, intra bands
+//      -- come first in the grid and number at most half of what the device holds (Engine::form, chain_resident_workgroups): the dispatcher starts
+//      workgroups in grid order per XCD and a waiting workgroup keeps its slot, so every band is resident before the first reconstruction group that
+//      could wait for it, and stays for its whole wavefront.  (Two chain lanes at once -- tried in round 2 -- break exactly this: neither launch's
+//      bands are guaranteed slots.)
+//   2. A band waits only for (a) the band above it in the same picture (resident, 1.), (b) reconstruction bits of its own picture.
+//   3. A reconstruction group waits only for `fin` of bands (resident) of EARLIER pictures of its stream.
+//   4. The work list is sorted by a key such that everything a group depends on -- through 3., then 2.(b) of those bands and, through 2.(a), of the bands
+//      above them -- has a SMALLER key (Engine::launch builds the keys; tools/chain_keys.py restates every wait of this file, deblock_device.h and
+//      intra_device.h and checks the rule by brute force; tests/test_chain_keys.py).  Hence the unfinished group with the smallest key is resident --
+//      everything before it in its XCD's order has finished or is a band -- and all it waits for is finished or resident: it runs.  No deadlock at any
+//      occupancy, PROVIDED the keys are right: round 3's keys ignored that a band trails the band above it by ~7 steps (nine bands at 4K: the first
+//      chain launch of a C2 run gave up in one run of three), and round 4's first one-row schedule kept one key slope per launch (launches of 4 / 8
+//      streams gave up in three runs of ten).  Both were found as VIOLATIONS OF 4., not as mysteries.
+// Every wait is still bounded (100 ms); a wait that gives up sets the error word and the abort word, records itself (record_first_giveup), and the
+// engine decodes the launch's pictures again with the stage kernels (Engine::recover): a wrong key costs time, never a wrong frame.
 // There is no reference counterpart (the reference hands whole pictures to the NVDEC ASIC, nv_dec.cpp:33-41).
 #pragma once
 #include <hip/hip_runtime.h>
