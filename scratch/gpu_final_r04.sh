@@ -8,6 +8,7 @@ timeout 1500 python tools/gpu_sweep.py 200 42 > gpurun_out/f4/sweep_b.log 2>&1; 
 timeout 900 python tools/gpu_sweep.py 30 43 big > gpurun_out/f4/sweep_big.log 2>&1; tail -2 gpurun_out/f4/sweep_big.log
 bash scratch/gpu_prof_r04.sh r04 > gpurun_out/f4/prof.log 2>&1; tail -30 gpurun_out/f4/prof.log | cut -c1-260
 for s in 1 8; do timeout 300 python bench.py --streams $s --no-extra --no-cpu-baseline --no-single > gpurun_out/f4/r04_bench_s$s.json 2>/dev/null; done
+for t in high high_b; do timeout 300 python bench.py --tools $t --no-extra --no-cpu-baseline --no-single > gpurun_out/f4/r04_bench_$t.json 2>/dev/null; done
 C2="--tools high_b --width 3840 --height 2160 --streams 16 --frames 24 --steps 3 --no-extra --no-cpu-baseline --no-single"
 for i in 7 8 9 10; do JM_AMD_DEC_CHAIN_STREAMS=64 JM_AMD_DEC_VERBOSE=1 timeout 300 python bench.py $C2 > gpurun_out/f4/c2_chain_$i.json 2> gpurun_out/f4/c2_chain_$i.err; done
 python - <<'PY'

@@ -19,7 +19,7 @@ import sys
 from functools import lru_cache
 
 BR = 16                                   # kBandRows
-DEPTH, PUB, KPUBLAG = 3, 2, 3             # deblock_depth(), deblock_pub(), kPubLag
+DEPTH, PUB, KPUBLAG = 2, 2, 3             # deblock_depth(), deblock_pub(), kPubLag
 ROW_LAG = 1                               # kRowLag (one macroblock row per deblocking step)
 K_BAND_LAG, KEY_SLACK, INTRA_EXTRA, CHAIN_LAG = 8, 2, 24, 24
 
