@@ -61,13 +61,16 @@ enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RI
                CHAIN_ERR_NOT_RECOVERED = 32 };
 
 // Steps between a macroblock row and the row below it (round 4).  Clause 8.7 orders the macroblocks in raster order, and within one the vertical edges (V)
-// before the horizontal edges (H).  Which filters touch the same samples: V(x, y) the macroblock and columns 12..15 of (x - 1, y); H(x, y) the macroblock and rows
-// 12..15 of (x, y - 1).  So V(x, y) needs H(x - 1, y) and nothing of the row above, and H(x, y) needs V(x, y) and -- for columns 13..15 of those four rows, which
+// before the horizontal edges (H). Which filters touch the same samples: V(x, y) the macroblock and columns 12..15 of (x - 1, y); H(x, y) the macroblock and
+// rows
+// 12..15 of (x, y - 1). So V(x, y) needs H(x - 1, y) and nothing of the row above, and H(x, y) needs V(x, y) and -- for columns 13..15 of those four rows,
+// which
 // the left edge of (x + 1, y - 1) changes -- V(x + 1, y - 1), but NOT H(x + 1, y - 1).  Rounds 1-3 ran whole macroblocks per step, which needs two steps
 // between rows (s = x + 2y: 254 steps at 1080p, 508 at 4K).  With the step cut into a V phase and an H phase by a second barrier, (x + 1, y - 1) and (x, y)
 // share a step: s = x + y, 188 steps at 1080p (-26 %), 375 at 4K, every filter still sees exactly the samples raster order would give it (no two filters
 // that touch a common sample change their order).  As built (deblock_device.h `step`): step s of row y = H + store of macroblock s - 1 - y, then V of
-// macroblock s - y, ONE barrier per step; the final samples of macroblock (X, Y) are therefore stored in step X + Y + 1.  JM_DEBLOCK_ROW_LAG=2 builds the old schedule (A/B runs).
+// macroblock s - y, ONE barrier per step; the final samples of macroblock (X, Y) are therefore stored in step X + Y + 1. JM_DEBLOCK_ROW_LAG=2 builds the old
+// schedule (A/B runs).
 #ifndef JM_DEBLOCK_ROW_LAG
 #define JM_DEBLOCK_ROW_LAG 1
 #endif
@@ -208,7 +211,8 @@ struct ChainView {
                 if (ok && blo != bhi) ok = ld_coh(fin + blo) >= need_lo && ld_coh(fin + 32 + blo) >= need_lo;
                 pending = !ok;
             }
-            if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }      // (nothing that reads the picture moves above the polls)
+            // (nothing that reads the picture moves above the polls)
+            if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }
             const bool expired = wait_expired(++spins, t0);
             if (expired && pending) record_first_giveup(abort_word(), CHAIN_ERR_FIN_TIMEOUT, dep, bhi << 16 | (xs & 0xffff), need_hi, ld_coh(fin + bhi),
                 ld_coh(fin + 32 + bhi));

@@ -404,7 +404,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         if (known < need) {                                                  // the band above never got there: damaged, and SAID so
             if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT);
                 if (CHAIN) {
-                    if (!ld_coh(abort_word)) record_first_giveup(abort_word, CHAIN_ERR_RING_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0), need, known, 0);
+                    if (!ld_coh(abort_word)) record_first_giveup(abort_word, CHAIN_ERR_RING_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0), need,
+                        known, 0);
                     st_coh(abort_word, 1);
                 } }
             known = 0x7fffffff;                                              // do not wait again

@@ -100,7 +100,8 @@ bool deblock_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kBan
 
 // (A/B builds: make EXTRA="-DJM_DEBLOCK_DEPTH=4 -DJM_DEBLOCK_PUB=1" OUT=../lib_dbg_x OBJ=../lib_dbg_x/obj)
 #ifndef JM_DEBLOCK_DEPTH
-#define JM_DEBLOCK_DEPTH 2          // round 4: 2 measured 2 % faster than 3 (609-614 against 624-627 us per launch), 4 1 % slower (profiles/r04_ab7_chain_fixed.json)
+// round 4: 2 measured 2 % faster than 3 (609-614 against 624-627 us per launch), 4 1 % slower (profiles/r04_ab7_chain_fixed.json)
+#define JM_DEBLOCK_DEPTH 2
 #endif
 #ifndef JM_DEBLOCK_PUB
 #define JM_DEBLOCK_PUB 2

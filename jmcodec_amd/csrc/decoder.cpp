@@ -675,7 +675,8 @@ void Decoder::flush_dpb(std::vector<int> &out) {
         int best = -1;
         for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && dpb_[i].wait_output && (best < 0 || dpb_[i].poc < dpb_[best].poc)) best = i;
         if (best < 0) break;
-        out.push_back(best | dpb_[best].lone << 8); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc); dpb_[best].out_at = decode_count_ - 1;
+        out.push_back(best | dpb_[best].lone << 8); dpb_[best].wait_output = false; display_pocs_.push_back(dpb_[best].poc);
+        dpb_[best].out_at = decode_count_ - 1;
     }
     for (int i = 0; i < n_surf_; i++) if (i != cur_ && dpb_[i].in_use && !dpb_[i].ref && !dpb_[i].wait_output) dpb_[i].in_use = false;
 }
@@ -752,7 +753,8 @@ bool Decoder::start_picture(const SliceHeader &sh, const SeqParams &sps, const P
         int warm = -1;
         // Round robin over the free surfaces (starting behind the one chosen last), so that a surface is reused as LATE as possible: the engine
         // runs consecutive pictures of a stream in one launch only while none of them decodes into a surface an earlier one still reads or displays.
-        for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) { slot = i;
+        for (int k = 1; k <= n_surf_; k++) { const int i = (last_surf_ + k) % n_surf_; if (!dpb_[i].in_use) { if (decode_count_ >= dpb_[i].out_at + 2) {
+            slot = i;
             break; } if (warm < 0) warm = i; } }
         if (slot < 0 && warm >= 0) { slot = warm; wait_pack = true; }
         while (slot < 0) {
@@ -901,7 +903,8 @@ void Decoder::build_ref_lists(const SliceHeader &sh, SliceTask &task) {
     int mode = sh.type == SL_P ? (sh.explicit_wp ? 1 : 0) : pps.weighted_bipred_idc;
     task.has_wp = mode != 0;
     if (task.has_wp) {
-        if (mode == 1 && (sh.num_ref_idx[0] > 16 || sh.num_ref_idx[1] > 16)) { stat_errors_++; fail("explicit weighted prediction with more than 16 list entries"); }
+        if (mode == 1 && (sh.num_ref_idx[0] > 16 || sh.num_ref_idx[1] > 16)) { stat_errors_++;
+            fail("explicit weighted prediction with more than 16 list entries"); }
         SliceWp &wp = task.wp;
         memset(&wp, 0, sizeof wp);
         wp.mode = (uint8_t)mode; wp.logwd_y = (uint8_t)sh.luma_log2_wd; wp.logwd_c = (uint8_t)sh.chroma_log2_wd;
@@ -1285,7 +1288,8 @@ void Decoder::parse_task(PicTask *t, ParseScratch &scratch) {
             if (s.sh.first_mb >= n_mbs) { t->error = "first_mb_in_slice out of range"; continue; }
             if (s.col) s.col->wait();                            // direct prediction reads RefPicList1[0]'s motion: that picture was dispatched earlier
             if (s.has_wp) t->any_wp = true;
-            SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr, fast_parse_ && !t->field);
+            SliceParseResult r = parse_slice_data(t->sps, t->pps, s.sh, br, (int)si, s.refs, scratch, w, want_digest_ ? &dg : nullptr, fast_parse_ &&
+                !t->field);
             t->n_intra += r.n_intra; t->n_i8x8 += r.n_i8x8;
             if (r.error) { t->error = r.error; if (!first_error) first_error = r.error; overflow |= strcmp(r.error, "coefficient buffer overflow") == 0; }
         }

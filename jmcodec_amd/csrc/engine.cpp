@@ -152,7 +152,8 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         // chains' rate, 2.4-2.5 k against 2.3-2.6 k frames/s -- and the first chain launch of such a run sometimes gave up)
         double load = 0;
         for (const Recent &r : recent_) load += std::max(1.0, r.mbs / 8160.0);
-        chaining = chain_depth_ > 1 && n_active > 0 && load <= (double)chain_max_streams_ && now >= chain_block_until_ns_ && !gpu_shared_.load(std::memory_order_relaxed);
+        chaining = chain_depth_ > 1 && n_active > 0 && load <= (double)chain_max_streams_ && now >= chain_block_until_ns_ &&
+            !gpu_shared_.load(std::memory_order_relaxed);
         // One or two streams: a chain launch is as long as what its stream(s) fed while the previous launch ran.  Queueing a SECOND launch behind a running one
         // as soon as a picture or two are there splits that supply into a short launch and a long one, and a short chain costs nearly what a long one costs
         // (the first picture's wavefront, ~0.7 ms at 1080p).  So while a launch is in flight the next one is only formed when it would be a full chain;
@@ -201,7 +202,8 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     for (auto &p : b.pics) if (p.has_picture && (p.chain_ok || p.chain_intra)) { int nb, ng; chain_cost(p, nb, ng); tot_bands += nb; tot_groups += ng;
         any_intra |= p.chain_intra; }
     auto band_limit = [&](bool intra) { return intra ? chain_bands_max_intra_ : chain_bands_max_; };
-    if (lane_idx == kOrdinaryLane && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) && tot_groups <= kMaxChainGroups) {
+    if (lane_idx == kOrdinaryLane && chaining && (int)members.size() <= chain_max_streams_ && tot_bands <= band_limit(any_intra) &&
+        tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
         const int depth_cap = std::min(chain_depth_.load(), std::max(1, kMaxBatch / (int)members.size()));
@@ -403,7 +405,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         // behind the next one's vertical edges).  That is what keeps a full machine from deadlocking:
         // the unfinished group with the smallest key is resident (in-order dispatch per XCD) and waits only for finished groups and resident bands.
         // The SLOPE of a picture's keys is the pace of whatever consumes its reconstruction: one step per macroblock row for a picture that is only deblocked
-        // (deblock_row_lag()), two for a picture with the intra role (its intra wavefront needs the macroblock above right COMPLETE: x + 2y).  Rounds 2-3 and the
+        // (deblock_row_lag()), two for a picture with the intra role (its intra wavefront needs the macroblock above right COMPLETE: x + 2y). Rounds 2-3 and
+        // the
         // first form of round 4 gave a whole launch ONE slope (2 as soon as it held an intra-role picture): with one-row deblocking that puts a band's needs up
         // to 14 keys beyond a dependent group's own key -- the band moves as a unit over 16 rows -- and chain launches of 4 / 8 streams gave up in 3 runs of 10
         // (profiles/r04_ab6_first_giveup.json).  tools/chain_keys.py checks the rule by brute force for every macroblock of a picture (it found both numbers):
@@ -425,7 +428,8 @@ void Engine::launch(Lane &ln, Batch &b) {
                              kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
                 if (b.h_pics[j].stages & PS_CHAIN_INTRA) base_of[i] += b.h_pics[j].mb_h + kIntraExtra;
                 break; }
-            n_keys = std::max(n_keys, (size_t)(base_of[i] + slope_of[i] * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
+            n_keys = std::max(n_keys,
+                (size_t)(base_of[i] + slope_of[i] * b.h_pics[i].mb_h + b.h_pics[i].mb_w + kBandLag * (b.h_pics[i].mb_h / band_rows + 1) + 2));
         }
         if (group_buckets_.size() < n_keys) group_buckets_.resize(n_keys);
         for (size_t k = 0; k < n_keys; k++) group_buckets_[k].clear();
@@ -571,10 +575,11 @@ void Engine::dump_chain_state(Batch &b) {
     for (int i = 0; i < n; i++) if (b.h_pics[i].stages & PS_CHAIN) { const int bands = (b.h_pics[i].mb_h + 15) / 16;
         n_band_wgs += ((b.h_pics[i].stages & PS_CHAIN_INTRA) ? 4 : 2) * bands;
         if (!(b.h_pics[i].stages & PS_RECON)) n_recon_groups += b.h_pics[i].mb_h * ((b.h_pics[i].mb_w + 7) / 8); }
-    fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | band workgroups started %d done %d of %d | "
-        "highest work-list index started %d | band budget %d / %d\n", lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_,
+    fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | "
+        "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n", lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_,
         chain_bands_max_intra_);
-    if (lw[8]) fprintf(stderr, "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
+    if (lw[8]) fprintf(stderr,
+        "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
         "the row = intra band; ring: band << 16 | chroma) needed %d saw %d / %d\n", lw[8], lw[9], lw[10], (unsigned)lw[11], lw[12], lw[13], lw[14]);
     for (int i = 0; i < n; i++) {

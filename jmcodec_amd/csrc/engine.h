@@ -114,7 +114,8 @@ public:
     bool set_knob(const std::string &key, long long v);
     EngineStats stats();
     int device() const { return device_; }
-    bool gpu_shared() const { return gpu_shared_.load(std::memory_order_relaxed); }      // another process has compute queues on this GPU (no chain launches then)
+    // another process has compute queues on this GPU (no chain launches then)
+    bool gpu_shared() const { return gpu_shared_.load(std::memory_order_relaxed); }
 
 private:
     explicit Engine(int device);
@@ -125,7 +126,8 @@ private:
         int *d_progress = nullptr;                            // CTB row progress counters of k_hevc_intra
         int *d_ctl = nullptr;                                 // H.264: kMaxBatch control blocks (chain_common.h), cleared once per batch
         int *h_err = nullptr, *d_err = nullptr;               // error words, one per picture: pinned host memory and its device address
-        bool any_chain = false, chain_with_intra = false, redo = false; int max_depth = 1;   // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
+        // redo: an earlier batch of the lane was recovered, this one read its (then damaged) output
+        bool any_chain = false, chain_with_intra = false, redo = false; int max_depth = 1;
         int max_mbs = 0, max_mb_h = 0, max_w = 0, max_h = 0; bool any_bipred = false, any_field = false;
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries

@@ -81,7 +81,8 @@ HostCopier *HostCopier::get(int dev) {
             int order[16], n_order = 0;
             for (int b = 1; b < 16; b++) if (d2h & (1u << b)) order[n_order++] = b;            // the runtime's recommendation first
             for (int b = 1; b < 16; b++) if (!(d2h & (1u << b))) order[n_order++] = b;
-            order[n_order++] = 0;                                                               // (engine 0x1: the runtime's host -> device engine, last choice)
+            // (engine 0x1: the runtime's host -> device engine, last choice)
+            order[n_order++] = 0;
             int tried = 0; bool slower_seen = false;
             for (int k = 0; k < n_order; k++) {
                 const int b = order[k]; const uint32_t e = 1u << b;
@@ -98,7 +99,8 @@ HostCopier *HostCopier::get(int dev) {
                 tried++;
                 int good = 0;
                 for (int j = 0; j < 16; j++) { if (t[j] < 1e29 && t[j] <= 1.5 * best) good++; else if (t[j] < 1e29) slower_seen = true; }
-                if ((good >= 3 && slower_seen) || tried >= 6) break;      // three good ones and a slower one seen, or six engines tried: stop (every engine ever used keeps a ~190 MB queue)
+                // three good ones and a slower one seen, or six engines tried: stop (every engine ever used keeps a ~190 MB queue)
+                if ((good >= 3 && slower_seen) || tried >= 6) break;
             }
         }
         (void)hipGetLastError();

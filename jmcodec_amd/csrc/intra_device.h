@@ -465,7 +465,8 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
             wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
         // never silent: the engine reports a decode error (and the band does not wait again)
         if (known < need) { if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT);
-            if (CHAIN && abort_word_ && !ld_coh(abort_word_)) record_first_giveup(abort_word_, CHAIN_ERR_INTRA_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0),
+            if (CHAIN && abort_word_ && !ld_coh(abort_word_)) record_first_giveup(abort_word_, CHAIN_ERR_INTRA_TIMEOUT, pp.chain_idx,
+                band << 16 | (is_chroma ? 1 : 0),
                 need, known, 0); } known = 0x7fffffff; }
         asm volatile("" ::: "memory");
     };

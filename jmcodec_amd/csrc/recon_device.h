@@ -158,7 +158,8 @@ template <bool COH> __device__ __forceinline__ int ref_luma(const RefBuf &rb, co
     return ld_ref8<COH>(rb, &s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)]);     // 32-bit index arithmetic (pointer adds here cost 15 VGPRs)
 }
 // 8.4.2.2.1 luma sample interpolation (literal form)
-template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_base, const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx, int fy) {
+template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_base, const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx,
+    int fy) {
     const RefBuf rb(surf_base);
 #define P(dx, dy) ref_luma<COH>(rb, s, pitch, W, H, xi + (dx), yi + (dy))
 #define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
@@ -281,14 +282,16 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                     // chain launches: the four bytes U V U V at 2 * xa of each row come out of two aligned dwords per row -- cache-bypassing BYTE loads
                     // are one memory request each (FETCH_SIZE showed 26.9 MB per 1080p picture for k_chain against 4.9 MB for the stage kernels)
                     const int o = (2 * xa) & ~3, sh = (2 * xa) & 3;
-                    const uint32_t a0 = ld_ref32<true>(refbuf, r0 + o), a1 = ld_ref32<true>(refbuf, r0 + o + 4), b0 = ld_ref32<true>(refbuf, r1 + o), b1 = ld_ref32<true>(refbuf, r1 + o + 4);
+                    const uint32_t a0 = ld_ref32<true>(refbuf, r0 + o), a1 = ld_ref32<true>(refbuf, r0 + o + 4), b0 = ld_ref32<true>(refbuf, r1 + o),
+                        b1 = ld_ref32<true>(refbuf, r1 + o + 4);
                     const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
                     c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
                     c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
                 } else {
                 c_smp[0] = ld_ref8<COH>(refbuf, r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(refbuf, r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(refbuf, r1 + 2 * xa);
                 c_smp[3] = ld_ref8<COH>(refbuf, r1 + 2 * xb);
-                c_smp[4] = ld_ref8<COH>(refbuf, r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(refbuf, r0 + 2 * xb + 1); c_smp[6] = ld_ref8<COH>(refbuf, r1 + 2 * xa + 1);
+                c_smp[4] = ld_ref8<COH>(refbuf, r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(refbuf, r0 + 2 * xb + 1);
+                c_smp[6] = ld_ref8<COH>(refbuf, r1 + 2 * xa + 1);
                 c_smp[7] = ld_ref8<COH>(refbuf, r1 + 2 * xb + 1);
                 }
             }
