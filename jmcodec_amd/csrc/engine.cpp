@@ -576,8 +576,8 @@ void Engine::dump_chain_state(Batch &b) {
         n_band_wgs += ((b.h_pics[i].stages & PS_CHAIN_INTRA) ? 4 : 2) * bands;
         if (!(b.h_pics[i].stages & PS_RECON)) n_recon_groups += b.h_pics[i].mb_h * ((b.h_pics[i].mb_w + 7) / 8); }
     fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | "
-        "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n", lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_,
-        chain_bands_max_intra_);
+        "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n",
+        lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_, chain_bands_max_intra_);
     if (lw[8]) fprintf(stderr,
         "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
