@@ -74,6 +74,9 @@ enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RI
 #ifndef JM_DEBLOCK_ROW_LAG
 #define JM_DEBLOCK_ROW_LAG 1
 #endif
+#ifndef JM_DEBLOCK_ASYNC_POLL
+#define JM_DEBLOCK_ASYNC_POLL 0       // A/B builds: the band above's step counter travels with the prefetch stage (deblock_device.h)
+#endif
 constexpr int kRowLag = JM_DEBLOCK_ROW_LAG;
 static_assert(kRowLag == 1 || kRowLag == 2, "row lag of the deblocking wavefront");
 

@@ -396,8 +396,11 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
+    int sampled = 0;                                                        // JM_DEBLOCK_ASYNC_POLL: the counter of the band above as the last stage delivered it
     auto wait_above = [&](int need) {
-        if (band == 0 || threadIdx.x >= 64 || known >= need) return;        // wave 0 holds group 0
+        if (band == 0 || threadIdx.x >= 64) return;                          // wave 0 holds group 0
+        if (sampled > known) known = sampled;
+        if (known >= need) return;
         int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
                !(CHAIN && (wait_expired(spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))))) __builtin_amdgcn_s_sleep(8);
@@ -449,7 +452,14 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         const uint32_t slot = stage_lds + (uint32_t)d * kStageBytes;
         glds16<CHAIN>(pix_base + xn * 16, slot);                                        // CHAIN: reconstructed in this launch -> coherent load
         glds4<false>(rec_base + (size_t)xn * sizeof(DbRec), slot + 1024);
+#if JM_DEBLOCK_ASYNC_POLL
+        // the last lane of wave 0 (its ring dword is a dummy: only group 0 takes ring rows) fetches the step counter of the band above instead: the sample
+        // arrives with the stage, DEPTH steps later, and wait_above looks at it before it polls -- the poll's round trip (a load that bypasses the caches) then
+        // lies beside the steps' work instead of in front of every second step of every band but the first
+        glds4<true>(band > 0 ? (threadIdx.x == 63 ? (const gbyte *)(prog + band - 1) : ring_base + xn * 16) : rec_base, slot + 1280);
+#else
         glds4<true>(band > 0 ? ring_base + xn * 16 : rec_base, slot + 1280);
+#endif
     };
     // ring rows of macroblock xm of this band's last row -> surface (write-through)
     auto give = [&](const uint8_t *ring, int xm, int lane0) {
@@ -545,6 +555,9 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             const uint4 own = *(const uint4 *)(sl + wl * 16);
             const uint32_t rdw = *(const uint32_t *)(sl + 1024 + wl * 4), ring = *(const uint32_t *)(sl + 1280 + wl * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is read before its next load is even issued
+#if JM_DEBLOCK_ASYNC_POLL
+            if (band > 0 && threadIdx.x < 64) sampled = __builtin_amdgcn_readlane((int)ring, 63);
+#endif
             wait_above(s + j + DEPTH + kAbove);      // the ring rows of step s + j + DEPTH: see above
             fetch(j, s + j + DEPTH);
             step(s + j, own, rdw, ring);
