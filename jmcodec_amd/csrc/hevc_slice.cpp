@@ -36,6 +36,18 @@ struct ScanTables {
     }
 };
 const ScanTables kScan;
+// A run of per-4x4 map entries of one value, n = 1 .. 16 units (a row of a coding / transform unit).  The library's memset costs more than the stores at
+// these sizes (its masked-store path for n < 32 was 4 % of the parse): the power-of-two sizes, which is all a quadtree produces, are inline stores.
+static inline void fill_units(void *p, int v, int n) {
+    switch (n) {
+    case 1: *(uint8_t *)p = (uint8_t)v; break;
+    case 2: memset(p, v, 2); break;
+    case 4: memset(p, v, 4); break;
+    case 8: memset(p, v, 8); break;
+    case 16: memset(p, v, 16); break;
+    default: memset(p, v, (size_t)n); break;
+    }
+}
 struct Flat16 { uint8_t v[32 * 32]; Flat16() { memset(v, 16, sizeof v); } };     // m[x][y] = 16 (7.3.4: scaling lists off, transform skip of a larger block)
 const Flat16 kFlat16;
 
@@ -531,7 +543,7 @@ bool HevcPicParser::transform_unit(int x0, int y0, int xb, int yb, int log2, int
         const int nu = n >> 2;
         for (int r = 0; r < nu; r++) {
             const int i = i4(x0, y0 + 4 * r);
-            memset(cf + i, cbf_y, nu);
+            fill_units(cf + i, cbf_y, nu);
             ed[i] |= 1;
             if (r == 0) for (int k = 0; k < nu; k++) ed[i + k] |= 2;
         }
@@ -691,10 +703,8 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
         for (int r = 0; r < nu; r++) {
             const int i = i4(x0, y0 + 4 * r);
             const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_, ved = r == 0 ? 10 : 0;
-            if (nu <= 4) {                                      // (8x8 and 16x16 units: a library call per array costs more than the stores)
-                for (int k = 0; k < nu; k++) { pm[i + k] = vpm; sk[i + k] = vsk; nf[i + k] = vnf; cf[i + k] = 0; ip[i + k] = 1; ed[i + k] = ved; }
-            } else { memset(pm + i, vpm, nu); memset(sk + i, vsk, nu); memset(nf + i, vnf, nu); memset(cf + i, 0, nu); memset(ip + i, 1, nu);
-                memset(ed + i, ved, nu); }
+            fill_units(pm + i, vpm, nu); fill_units(sk + i, vsk, nu); fill_units(nf + i, vnf, nu); fill_units(cf + i, 0, nu); fill_units(ip + i, 1, nu);
+            fill_units(ed + i, ved, nu);
             ed[i] |= 5;
             if (cu_intra_) for (int k = 0; k < nu; k++) mo[i + k] = blank;      // (the prediction units of an inter unit cover it and write their own)
         }
@@ -787,7 +797,7 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
             if (!transform_tree(x0, y0, x0, y0, log2, 0, 0, 1, 1)) return false;
         }
     }
-    for (int r = 0; r < (n >> 2); r++) memset(qp_.data() + i4(x0, y0 + 4 * r), (int8_t)qp_y_, n >> 2);
+    for (int r = 0; r < (n >> 2); r++) fill_units(qp_.data() + i4(x0, y0 + 4 * r), (int8_t)qp_y_, n >> 2);
     last_cu_qp_ = qp_y_; cu_since_reset_ = true;
     if (dg_->on) dg(0x4800 | qp_y_);
     return !cb_.overrun;
@@ -826,7 +836,7 @@ bool HevcPicParser::coding_quadtree(int x0, int y0, int log2, int depth) {
             if (x < w_ && y < h_ && !coding_quadtree(x, y, log2 - 1, depth + 1)) return false; }
         return true;
     }
-    for (int r = 0; r < (n >> 2); r++) memset(depth_.data() + i4(x0, y0 + 4 * r), depth, n >> 2);
+    for (int r = 0; r < (n >> 2); r++) fill_units(depth_.data() + i4(x0, y0 + 4 * r), depth, n >> 2);
     derive_qp(x0, y0);
     return coding_unit(x0, y0, log2);
 }

@@ -184,6 +184,7 @@ template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_
 }
 
 // LDS of one 4-wave workgroup of the inter reconstruction
+constexpr int kUniChroma = 136;          // dword offset of the chroma window behind the 21 x 6 luma window in wins[wave] (uni path)
 struct alignas(16) ReconLds {
     ResTile tiles[4];
     uint32_t outt[4][96];                        // per wave: reconstructed MB, 16 luma rows + 8 interleaved chroma rows of 16 B
@@ -246,7 +247,41 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         const bool ok = cv.wait_final(dep, clip3(0, W - 1, x0 + 6), clip3(0, H - 1, y0 - 2), clip3(0, H - 1, y0 + 6), pp.mb_w, pp.mb_h, kRowLag);
         if (!ok && lane == 0) report_wait_timeout(cv.err + pp.chain_idx, CHAIN_ERR_FIN_TIMEOUT);
     }
-    if (plain) {
+    // Round 4: ONE window per macroblock when its four 8x8 blocks share a vector and a reference (P_Skip, P_L0_16x16: 96 % of the macroblocks of config
+    // C1): 21 rows of 6 aligned dwords for luma and 9 rows of 5 for the interleaved chroma, three loads per lane instead of nine -- the four 13x13 windows
+    // overlap by half, and the chroma path fetched four bytes per sample pair (1 KB per macroblock).  In chain launches these loads bypass the caches, so
+    // the bytes are real traffic: ~2.8 KB per macroblock before, ~1.2 KB now (profiles/r04_pmc_traffic_*).  `uni` is wave-uniform (the record is).
+    bool uni = false;
+    uint32_t cw = 0;                                        // this lane's dword of the chroma window (uni path)
+    int c_sh = 0;                                           // byte offset of chroma sample 0 in its window row
+    if (plain && !(r.flags & MBF_MV_EXT) && rec_ref(r, 0) >= 0) {
+        const uint32_t m0 = (uint16_t)r.u.mv[0][0] | ((uint32_t)(uint16_t)r.u.mv[0][1] << 16);
+        bool same = true;
+#pragma unroll
+        for (int i = 1; i < 4; i++) same &= ((uint16_t)r.u.mv[i][0] | ((uint32_t)(uint16_t)r.u.mv[i][1] << 16)) == m0 && r.ref[i] == r.ref[0];
+        if (same) {
+            int mvx = (int16_t)(m0 & 0xffff), mvy = (int16_t)(m0 >> 16);
+            const int slot = rec_ref(r, 0);
+            const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
+            const int cmvy = mvy + chroma_mvy_offset(pp, slot);
+            const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (cmvy >> 3);
+            uni = xi >= 0 && yi >= 0 && xi + 21 <= W && yi + 21 <= H && cxi >= 0 && cyi >= 0 && cxi + 9 <= (W >> 1) && cyi + 9 <= (H >> 1) &&
+                  ((2 * cxi) & ~3) + 20 <= pitch;
+            if (uni) {
+                const uint8_t *ref = ref_plane(pp, slot);
+                const int xa = xi & ~3;
+#pragma unroll
+                for (int t = 0; t < 2; t++) { const int i = lane + 64 * t;
+                    if (i < 126) wv[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + i / 6) * pitch + xa + (i % 6) * 4); }
+                const uint8_t *rc = ref + pp.chroma_offset;
+                const int ca = (2 * cxi) & ~3;
+                c_sh = (2 * cxi) & 3;
+                if (lane < 45) cw = ld_ref32<COH>(refbuf, rc + (size_t)(cyi + lane / 5) * pitch + ca + (lane % 5) * 4);
+                c_slot = slot; c_fx = mvx & 7; c_fy = cmvy & 7;
+            }
+        }
+    }
+    if (plain && !uni) {
         {
             int g = lane >> 4;                              // 8x8 block of this lane in the fast-path mapping
             int mvx, mvy; rec_mv8(r, g, mvx, mvy);
@@ -333,14 +368,18 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     // The 8x8 block's 13x13 reference window (this lane's five dwords wv of it, row * 5 + dword == l16 + 16 * t, first byte at offset sh of the row) goes
     // into the block's LDS window; the lane then filters the four samples 4 * hh .. of row rr (8.4.2.2.1).  The fractional position is uniform inside a
     // block, so the 6-tap paths do not diverge within its 16 lanes.
-    auto filter_window = [&](uint32_t *win, const uint32_t *wv, int l16, int sh, int fx, int fy, int *v) {
+    // stride = dwords per window row: 5 (the block's own 13x13 window, stored here from wv) or 6 (the macroblock's 21x21 window, already in LDS: `win` then
+    // points at the block's corner inside it and wv is null)
+    auto filter_window = [&](uint32_t *win, const uint32_t *wv, int l16, int sh, int fx, int fy, int *v, const int stride = 5) {
+        if (wv) {
 #pragma unroll
         for (int t = 0; t < 5; t++) { int i = l16 + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
+        }
         // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
         const int rr = l16 >> 1, hh = l16 & 1;
         // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
         auto row9 = [&](int wr, int *t) {
-            const uint32_t *p = win + wr * 5 + hh;           // dword containing byte 4hh
+            const uint32_t *p = win + wr * stride + hh;      // dword containing byte 4hh
             uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
             uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
             t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
@@ -499,13 +538,21 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
     // The fractional position is uniform inside a block, so the 6-tap paths do not diverge within the 16 lanes.
     // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
-    if (fast) {
+    if (fast || uni) {
         int g = lane >> 4, l = lane & 15;
         int mvx, mvy; rec_mv8(r, g, mvx, mvy);
         int fx = mvx & 3, fy = mvy & 3;
         int bx0 = mbx * 16 + (g & 1) * 8;
         int xi = bx0 + (mvx >> 2) - 2;
         int v[4];
+        if (uni) {
+            // the macroblock's window: 21 rows x 6 dwords (+ the chroma window behind it), written by all 64 lanes, read back by the same wave
+            uint32_t *w16 = &wins[wave][0][0];
+            if (lane < 62) { w16[lane] = wv[0]; w16[lane + 64] = wv[1]; } else w16[lane] = wv[0];
+            if (lane < 45) w16[kUniChroma + lane] = cw;
+            __builtin_amdgcn_wave_barrier();
+            filter_window(w16 + (g >> 1) * 8 * 6 + (g & 1) * 2, nullptr, l, xi & 3, fx, fy, v, 6);
+        } else
         filter_window(&wins[wave][g][0], wv, l, xi & 3, fx, fy, v);
         const int rr = l >> 1, hh = l & 1;
         int px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;     // position inside the macroblock
@@ -543,6 +590,15 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     {
         int cx = lane & 7, cy = lane >> 3;
         int u, v;
+        if (uni) {
+            // U V U V at byte c_sh + 2 * cx of window rows cy and cy + 1 (5 dwords per row): two dwords per row, aligned by byte
+            const uint32_t *cwn = &wins[wave][0][0] + kUniChroma;
+            const int o = (c_sh + 2 * cx) >> 2, sh = (c_sh + 2 * cx) & 3;
+            const uint32_t a0 = cwn[cy * 5 + o], a1 = cwn[cy * 5 + o + 1], b0 = cwn[(cy + 1) * 5 + o], b1 = cwn[(cy + 1) * 5 + o + 1];
+            const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
+            c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
+            c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
+        }
         if (c_slot < 0) { u = v = 128; }
         else {
             int w00 = (8 - c_fx) * (8 - c_fy), w01 = c_fx * (8 - c_fy), w10 = (8 - c_fx) * c_fy, w11 = c_fx * c_fy;

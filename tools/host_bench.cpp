@@ -34,7 +34,11 @@ static void prof_stop(const char *path) {
         if (sscanf(ln, "%lx-%lx %7s %lx", &a, &b, perm, &off) == 4 && strstr(ln, "host_bench")) { if (!lo || a - off < lo) lo = a - off; if (b > hi) hi = b; }
         } fclose(m); }
     if (FILE *f = fopen(path, "w")) { long n = g_npc < kMaxPc ? g_npc : kMaxPc; for (long i = 0; i < n; i++) if (g_pcs[i] >= lo && g_pcs[i] < hi) fprintf(f,
-        "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other\n"); fclose(f); }
+        "0x%lx\n", g_pcs[i] - lo); else fprintf(f, "other 0x%lx\n", g_pcs[i]); fclose(f); }
+    // (the samples outside the executable -- libc, libstdc++, the kernel's entry stubs -- carry their absolute address; the mappings go beside them)
+    { char mp[600]; snprintf(mp, sizeof mp, "%s.maps", path); FILE *o = fopen(mp, "w"), *m = fopen("/proc/self/maps", "r"); char ln[512];
+      if (o && m) while (fgets(ln, sizeof ln, m)) if (strstr(ln, " r-xp ")) fputs(ln, o);
+      if (o) fclose(o); if (m) fclose(m); }
 }
 
 #ifdef JM_COUNT_BINS
