@@ -207,12 +207,22 @@ struct ChainView {
         const int bhi = yhi >> 4, blo = ylo >> 4;
         const int store_lag = row_lag == 1 ? 1 : 0;                // one row per step: macroblock (X, Y) is stored in step X + Y + 1 (deblock_device.h)
         const int need_hi = xs + row_lag * yhi + 1 + store_lag, need_lo = xs + row_lag * (blo * 16 + 15) + 1 + store_lag;
+        // Polls cost: a waiting wave that looks every 0.2 us is two or three uncached 64-byte fetches per microsecond, and a chain launch keeps thousands of
+        // waves waiting (one stream: the whole device waits for ONE picture's bands) -- hundreds of GB/s of fetches onto a handful of counter lines, in
+        // front of the stores that move those counters.  The counters are step numbers, so a wave knows how far away its samples are: it naps
+        // kNapPerStep for every step still missing (a deblocking step takes >= 2.3 us, a band that has not started begins at step row_lag * 16 * band;
+        // napping 0.75 us per step never oversleeps), at most 63 in a row, and looks again.  Waits that are nearly over poll as before.
+        constexpr int kNapSlack = 3, kTopNap = 32;                  // naps in a row: at most 2 * kTopNap - 1 (47 us)
+        const int first_hi = row_lag * 16 * bhi, first_lo = row_lag * 16 * blo;
         int spins = 0; uint32_t t0 = 0;
         for (;;) {
+            int missing = 0;                                        // steps until the rectangle is final, as far as the last look could tell
             if (pending) {
-                bool ok = ld_coh(fin + bhi) >= need_hi && ld_coh(fin + 32 + bhi) >= need_hi;
-                if (ok && blo != bhi) ok = ld_coh(fin + blo) >= need_lo && ld_coh(fin + 32 + blo) >= need_lo;
-                pending = !ok;
+                missing = need_hi - max(ld_coh(fin + bhi), first_hi);
+                if (missing <= 0) missing = need_hi - max(ld_coh(fin + 32 + bhi), first_hi);
+                if (missing <= 0 && blo != bhi) { missing = need_lo - max(ld_coh(fin + blo), first_lo);
+                    if (missing <= 0) missing = need_lo - max(ld_coh(fin + 32 + blo), first_lo); }
+                pending = missing > 0;
             }
             // (nothing that reads the picture moves above the polls)
             if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }
@@ -220,6 +230,10 @@ struct ChainView {
             if (expired && pending) record_first_giveup(abort_word(), CHAIN_ERR_FIN_TIMEOUT, dep, bhi << 16 | (xs & 0xffff), need_hi, ld_coh(fin + bhi),
                 ld_coh(fin + 32 + bhi));
             if (expired || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
+            // the wave goes on when its LAST lane is served: nap by the largest number of missing steps (bit by bit: seven ballots)
+            int naps = 0;
+            for (int t = kTopNap; t; t >>= 1) if (__builtin_amdgcn_ballot_w64(pending && missing - kNapSlack >= naps + t)) naps += t;
+            for (int i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(28);       // 28 x 64 cycles: 0.75 us at 2.4 GHz
             __builtin_amdgcn_s_sleep(4);
         }
     }

@@ -189,6 +189,7 @@ struct alignas(16) ReconLds {
     ResTile tiles[4];
     uint32_t outt[4][96];                        // per wave: reconstructed MB, 16 luma rows + 8 interleaved chroma rows of 16 B
     uint32_t wins[4][4][13 * 5 + 3];             // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
+    uint32_t fate[4];                            // chain launches: what became of each wave's macroblock (the store tail of recon_inter_wave)
 };
 
 // One wave reconstructs macroblock `mb` (mbx, mby) of picture pp.  CHAIN = false: the stage kernel (every reference picture was complete
@@ -335,15 +336,15 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     if (has_res) mb_residual_to_lds(pp, r, tiles[wave], lane);
     // the residual tile is private to this wave and LDS operations of one wave complete in order: no workgroup barrier needed
     __builtin_amdgcn_wave_barrier();
-    if (!valid) return;
-    // chain launches: the macroblock's samples are in memory -> set its bit in the picture's reconstruction bitmap (all lanes' stores
-    // were issued by this wave, so waiting for the wave's own stores is enough)
-    auto publish = [&]() {
-        if (!CHAIN) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_or((uint32_t *)(cv.pic(pp.chain_idx) + kChainBits) + mby * kChainRowWords + (mbx >> 5), 1u << (mbx & 31),
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    uint8_t *dst = cur_plane(pp);
+    uint8_t *dst_c = dst + pp.chroma_offset;
+    uint32_t *ot = outt[wave];
+    // what the tail below does with this wave's macroblock: nothing (no macroblock), publish it in the picture's reconstruction bitmap (chain launches;
+    // what it had to write is in memory), or store its samples out of `ot` first
+    enum : uint32_t { FATE_NONE = 0, FATE_PUBLISH = 1, FATE_STORE = 2 };
+    uint32_t fate = FATE_NONE;
+    do {
+    if (!valid) break;
     if (intra_res) {
         // residual of an intra macroblock for k_intra_lds: 384 int16 (Y 16x16, Cb 8x8, Cr 8x8), zeros when nothing is coded
         if (lane < 48) {
@@ -351,12 +352,10 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             if (CHAIN) st_wt16(pp.resid + (size_t)mb * 384 + lane * 8, v);        // read by the intra band of this launch, possibly on another XCD
             else *(uint4 *)(pp.resid + (size_t)mb * 384 + lane * 8) = v;
         }
-        publish();
-        return;
+        if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (this wave's own stores: in memory before the bit is)
+        fate = FATE_PUBLISH;
+        break;
     }
-    uint8_t *dst = cur_plane(pp);
-    uint8_t *dst_c = dst + pp.chroma_offset;
-    uint32_t *ot = outt[wave];
     if (r.kind == MB_PCM) {
         const uint8_t *pcm = (const uint8_t *)(pp.coef + r.coef_off);
         int row = lane >> 2, xq = lane & 3;
@@ -364,7 +363,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         int cx = lane & 7, cy = lane >> 3;
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
     }
-    if (!inter && r.kind != MB_PCM) { publish(); return; }
+    if (!inter && r.kind != MB_PCM) { fate = FATE_PUBLISH; break; }
     // The 8x8 block's 13x13 reference window (this lane's five dwords wv of it, row * 5 + dword == l16 + 16 * t, first byte at offset sh of the row) goes
     // into the block's LDS window; the lane then filters the four samples 4 * hh .. of row rr (8.4.2.2.1).  The fractional position is uniform inside a
     // block, so the 6-tap paths do not diverge within its 16 lanes.
@@ -609,14 +608,30 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
     }
     }   // inter
-    // ---- store: whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments ----
+    fate = FATE_STORE;
+    } while (0);
+    // ---- store ----
     if (CHAIN) {
-        if (lane < 24) {
-            uint8_t *d = lane < 16 ? dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16 : dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16;
-            st_wt16(d, *(const uint4 *)(ot + (lane < 16 ? lane * 4 : 64 + (lane - 16) * 4)));       // write-through: the next reader sits on another XCD
+        // The four waves of a workgroup hold four macroblocks side by side (x a multiple of 4: 64 bytes of every row, 64-byte aligned).  Stored wave by
+        // wave, every write-through row was a 16-byte piece of a line of its own (WRITE_SIZE: 22 MB per 1080p picture for 4.7 MB of samples); wave 0
+        // stores all four out of the shared LDS tile instead, four neighbouring lanes a whole 64-byte segment, and publishes the four macroblocks with
+        // ONE atomic once its stores are in memory (wave 0's macroblock always exists: the chain kernels drop a workgroup whose first one does not).
+        if (lane == 0) sm.fate[wave] = fate;
+        __syncthreads();
+        if (wave == 0) {
+            const int piece = lane & 3, row = lane >> 2;
+            const uint32_t f = sm.fate[piece];
+            if (f == FATE_STORE) {
+                st_wt16(dst + (size_t)(mby * 16 + row) * pitch + (mbx + piece) * 16, *(const uint4 *)(outt[piece] + row * 4));
+                if (lane < 32) st_wt16(dst_c + (size_t)(mby * 8 + row) * pitch + (mbx + piece) * 16, *(const uint4 *)(outt[piece] + 64 + row * 4));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t bits = (uint32_t)(__builtin_amdgcn_ballot_w64(lane < 4 && f != FATE_NONE) & 15u) << (mbx & 31);
+            if (lane == 0 && bits) __hip_atomic_fetch_or((uint32_t *)(cv.pic(pp.chain_idx) + kChainBits) + mby * kChainRowWords + (mbx >> 5), bits,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        publish();
-    } else {
+    } else if (fate == FATE_STORE) {
+        // whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments
         if (lane < 16) *(uint4 *)(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16) = *(const uint4 *)(ot + lane * 4);
         else if (lane < 24) *(uint4 *)(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16) = *(const uint4 *)(ot + 64 + (lane - 16) * 4);
     }
