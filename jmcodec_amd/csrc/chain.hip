@@ -50,18 +50,20 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
         const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
-        cv.census(ChainView::CENSUS_RECON_STARTED);
+        cv.census(ChainView::CENSUS_RECON_STARTED); cv.stamp(pp.chain_idx, ChainView::STAMP_RECON_FIRST);
+        const uint32_t tr0 = census_on ? (uint32_t)wall_clock64() : 0u;
         ReconLds &sm = *reinterpret_cast<ReconLds *>(smem);
         const int mb = valid ? row * pp.mb_w + x : 0;
         // one instantiation for every picture of the launch (with the cached-load variant beside it the kernel needs 196 VGPRs and scratch;
         // this way 165): a picture without references inside the launch passes wait_final at once
         recon_inter_wave<true, true, true, false>(pp, mb, valid, sm, cv);
-        cv.census(ChainView::CENSUS_RECON_DONE);
+        cv.census(ChainView::CENSUS_RECON_DONE); cv.stamp(pp.chain_idx, ChainView::STAMP_RECON_LAST);
+        if (census_on) cv.census(ChainView::CENSUS_RECON_TICKS, (int)((uint32_t)wall_clock64() - tr0));
     } else {
-        cv.census(ChainView::CENSUS_BAND_STARTED);
+        cv.census(ChainView::CENSUS_BAND_STARTED); cv.stamp(pp.chain_idx, ChainView::STAMP_BAND_FIRST);
         int *cpic = cv.pic(pp.chain_idx);
         deblock_band_body<DEPTH, true>(pp, (int)(entry & 31u), rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
-        cv.census(ChainView::CENSUS_BAND_DONE);
+        cv.census(ChainView::CENSUS_BAND_DONE); cv.stamp(pp.chain_idx, ChainView::STAMP_BAND_LAST);
     }
 }
 
@@ -70,6 +72,7 @@ bool chain_supported(int mb_w, int mb_h) {
     return !off && mb_w > 0 && mb_w <= 32 * kChainRowWords && mb_h <= kChainMaxRows && deblock_lds_supported(mb_w, mb_h);
 }
 int chain_ctl_ints() { return kChainStride; }
+int chain_tail_ints() { return kChainTail; }
 
 int deblock_depth(); int deblock_pub();
 

@@ -46,6 +46,9 @@ constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4
 constexpr int kChainMaxRows = 512;
 constexpr int kChainMaxPics = 64;      // == kMaxBatch (engine.h)
 constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
+// behind the pictures' blocks: the launch-wide abort word, the census and the record of the first give-up (16 ints), then four time stamps per picture
+// (diagnostic launches: ChainView::stamp)
+constexpr int kChainTail = 16 + 4 * kChainMaxPics;
 constexpr int kSpinLimit = 1 << 20;    // polls before a wait of the STAGE kernels gives up (about a second; a healthy wait takes microseconds)
 // waits of a chain launch are bounded by time: 100 ms of the 100 MHz wall clock (a healthy wait takes micro- to a few milliseconds).  The engine then
 // decodes the launch's pictures again with the stage kernels (Engine::recover), so a timeout costs time, not correctness.
@@ -186,12 +189,21 @@ struct ChainView {
     // per role and the highest work-list index started.  Only in diagnostic launches (JM_AMD_DEC_CENSUS; `on` comes with the kernel's `pub` argument):
     // three atomics per workgroup on ONE cache line are 180 k of them in a 2 ms launch of eight streams -- the rate at which a single address saturates
     // -- and a wave's loads retire behind its own older atomics: switched on for every launch they cost 8 / 16 streams 11 % / 9 % of their rate.
-    enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5 };
+    enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5,
+                 CENSUS_WAIT_TICKS = 6, CENSUS_RECON_TICKS = 7 };    // 100 MHz ticks wave 0 of the reconstruction workgroups spent in wait_final / in all
     bool census_on = false;
     __device__ __forceinline__ void census(int what, int value = 1) const {
         if (!census_on || threadIdx.x != 0) return;
         if (what == CENSUS_MAX_GROUP) (void)__hip_atomic_fetch_max(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else (void)__hip_atomic_fetch_add(abort_word() + what, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Time line of a diagnostic launch (JM_AMD_DEC_CENSUS; printed with JM_AMD_DEC_CHAIN_TIMELINE, Engine::dump_chain_state): per picture the first start
+    // and the last end of its reconstruction workgroups and of its bands, in ticks of the 100 MHz clock.  "First" is kept as the maximum of 2^30 - t.
+    enum : int { STAMP_RECON_FIRST = 0, STAMP_RECON_LAST = 1, STAMP_BAND_FIRST = 2, STAMP_BAND_LAST = 3 };
+    __device__ __forceinline__ void stamp(int pic_idx, int which) const {
+        if (!census_on || threadIdx.x != 0) return;
+        const int t = (int)((uint32_t)wall_clock64() & 0x3fffffffu);
+        (void)__hip_atomic_fetch_max(abort_word() + 16 + 4 * pic_idx + which, (which & 1) ? t : 0x40000000 - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // Wait until every sample of the rectangle [.., xmax] x [ymin, ymax] (luma coordinates, already clamped to the picture) of the picture
@@ -218,10 +230,11 @@ struct ChainView {
         for (;;) {
             int missing = 0;                                        // steps until the rectangle is final, as far as the last look could tell
             if (pending) {
-                missing = need_hi - max(ld_coh(fin + bhi), first_hi);
-                if (missing <= 0) missing = need_hi - max(ld_coh(fin + 32 + bhi), first_hi);
-                if (missing <= 0 && blo != bhi) { missing = need_lo - max(ld_coh(fin + blo), first_lo);
-                    if (missing <= 0) missing = need_lo - max(ld_coh(fin + 32 + blo), first_lo); }
+                // (the luma and the chroma counter in one round trip: a reconstruction workgroup lives ~25 us, and a look that passes is the common case)
+                const int fy = ld_coh(fin + bhi), fc = ld_coh(fin + 32 + bhi);
+                missing = need_hi - max(min(fy, fc), first_hi);
+                if (missing <= 0 && blo != bhi) { const int gy = ld_coh(fin + blo), gc = ld_coh(fin + 32 + blo);
+                    missing = need_lo - max(min(gy, gc), first_lo); }
                 pending = missing > 0;
             }
             // (nothing that reads the picture moves above the polls)

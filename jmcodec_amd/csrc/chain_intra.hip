@@ -39,17 +39,19 @@ __global__ __launch_bounds__(256, 3) __attribute__((flatten)) void k_chain_i(con
         const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
-        cv.census(ChainView::CENSUS_RECON_STARTED);
+        cv.census(ChainView::CENSUS_RECON_STARTED); cv.stamp(pp.chain_idx, ChainView::STAMP_RECON_FIRST);
+        const uint32_t tr0 = census_on ? (uint32_t)wall_clock64() : 0u;
         recon_inter_wave<true, true, true, false>(pp, valid ? row * pp.mb_w + x : 0, valid, *reinterpret_cast<ReconLds *>(smem), cv);
-        cv.census(ChainView::CENSUS_RECON_DONE);
+        cv.census(ChainView::CENSUS_RECON_DONE); cv.stamp(pp.chain_idx, ChainView::STAMP_RECON_LAST);
+        if (census_on) cv.census(ChainView::CENSUS_RECON_TICKS, (int)((uint32_t)wall_clock64() - tr0));
     } else {
-        cv.census(ChainView::CENSUS_BAND_STARTED);
+        cv.census(ChainView::CENSUS_BAND_STARTED); cv.stamp(pp.chain_idx, ChainView::STAMP_BAND_FIRST);
         int *cpic = cv.pic(pp.chain_idx);
         const int band = (int)(entry & 31u);
         if (entry & 0x4000u) intra_band_body<true>(pp, band, rem == 1, cpic + kChainIntraRing, smem, cpic, err + pp.chain_idx);
         else if (pp.stages & PS_CHAIN_INTRA) deblock_band_body<DEPTH, true, true>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
         else deblock_band_body<DEPTH, true, false>(pp, band, rem == 1, cpic + kChainRing, pub, smem, cpic, err + pp.chain_idx);
-        cv.census(ChainView::CENSUS_BAND_DONE);
+        cv.census(ChainView::CENSUS_BAND_DONE); cv.stamp(pp.chain_idx, ChainView::STAMP_BAND_LAST);
     }
 }
 

@@ -60,7 +60,7 @@ Engine::Engine(int device) : device_(device) {
             if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
-            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + 16)) != hipSuccess) return;   // + the launch-wide abort word
+            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + chain_tail_ints())) != hipSuccess) return;   // + the launch-wide tail (chain_common.h)
             if (hipHostMalloc((void **)&b.h_err, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) return;
             if (hipHostGetDevicePointer((void **)&b.d_err, b.h_err, 0) != hipSuccess) return;
             memset(b.h_err, 0, sizeof(int) * kMaxBatch);
@@ -338,7 +338,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     hipStream_t ps = any_hevc ? st : ln.pre_stream;
     // every counter of every picture, and the abort word
     if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps);
-        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, 16 * sizeof(int), ps); }      // abort word + census (chain_common.h)
+        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, chain_tail_ints() * sizeof(int), ps); }      // abort word, census, time stamps
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, ps);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, ps);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, ps);
@@ -568,7 +568,7 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
 // the step counters of every band and how far the reconstruction bitmap got.  Read after the launch has retired; `redo` batches reuse the buffer.
 void Engine::dump_chain_state(Batch &b) {
     const int n = (int)b.pics.size(), stride = chain_ctl_ints();
-    std::vector<int> ctl((size_t)kMaxBatch * stride + 16);
+    std::vector<int> ctl((size_t)kMaxBatch * stride + chain_tail_ints());
     if (hipMemcpy(ctl.data(), b.d_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
     const int *lw = ctl.data() + (size_t)kMaxBatch * stride;
     int n_band_wgs = 0, n_recon_groups = 0;
@@ -578,6 +578,7 @@ void Engine::dump_chain_state(Batch &b) {
     fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | "
         "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n",
         lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_, chain_bands_max_intra_);
+    if (lw[2] > 0) fprintf(stderr, "  reconstruction workgroups: %.2f us each on average, of which %.2f us in wait_final (wave 0)\n", 0.01 * lw[7] / lw[2], 0.01 * lw[6] / lw[2]);
     if (lw[8]) fprintf(stderr,
         "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
@@ -596,6 +597,15 @@ void Engine::dump_chain_state(Batch &b) {
         for (int r = 0; r < q.mb_h; r++) { int cnt = 0; for (int w = 0; w < 8; w++) cnt += __builtin_popcount((unsigned)c[256 + r * 8 + w]);
             if (cnt >= q.mb_w) full++; else if (first_open < 0) { first_open = r; first_open_bits = cnt; } }
         fprintf(stderr, " | bitmap: %d of %d rows complete, first open row %d has %d of %d\n", full, q.mb_h, first_open, first_open_bits, q.mb_w);
+    }
+    // time line (diagnostic launches, JM_AMD_DEC_CENSUS): per picture, microseconds after the launch's first stamp
+    const int *ts = lw + 16;
+    int t0 = 0x7fffffff;
+    for (int i = 0; i < n; i++) for (int k = 0; k < 4; k += 2) if (ts[4 * i + k]) t0 = std::min(t0, 0x40000000 - ts[4 * i + k]);
+    if (t0 != 0x7fffffff) for (int i = 0; i < n; i++) {
+        if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
+        auto us = [&](int k) { const int v = ts[4 * i + k]; return v ? ((k & 1) ? v - t0 : 0x40000000 - v - t0) * 0.01 : -1.0; };
+        fprintf(stderr, "  time line picture %2d dec %p: reconstruction %.1f .. %.1f us, bands %.1f .. %.1f us\n", i, (void *)b.pics[i].dec, us(0), us(1), us(2), us(3));
     }
 }
 
@@ -630,6 +640,8 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
     }
     // (counted with or without profiling)
+    if (b.any_chain && !failed) { static const bool timeline = getenv("JM_AMD_DEC_CHAIN_TIMELINE") != nullptr;
+        if (timeline) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures\n", b.pics.size()); dump_chain_state(b); } }
     if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; st_.chain_i_batches += b.chain_with_intra;
         for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }
     { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }

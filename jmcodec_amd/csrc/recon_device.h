@@ -245,7 +245,9 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         }
         const int dep = slot >= 0 ? (int)pp.dep_pic[slot & 31] : -1;
         const int x0 = mbx * 16 + bx * 4 + (mvx >> 2), y0 = mby * 16 + by * 4 + (mvy >> 2);
+        const uint32_t tw0 = cv.census_on ? (uint32_t)wall_clock64() : 0u;
         const bool ok = cv.wait_final(dep, clip3(0, W - 1, x0 + 6), clip3(0, H - 1, y0 - 2), clip3(0, H - 1, y0 + 6), pp.mb_w, pp.mb_h, kRowLag);
+        if (cv.census_on) cv.census(ChainView::CENSUS_WAIT_TICKS, (int)((uint32_t)wall_clock64() - tw0));
         if (!ok && lane == 0) report_wait_timeout(cv.err + pp.chain_idx, CHAIN_ERR_FIN_TIMEOUT);
     }
     // Round 4: ONE window per macroblock when its four 8x8 blocks share a vector and a reference (P_Skip, P_L0_16x16: 96 % of the macroblocks of config

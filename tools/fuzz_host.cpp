@@ -56,6 +56,7 @@ void launch_deblock_prep(const PicParams *, int, int, ihipStream_t *) { abort();
 void launch_deblock_lds(const PicParams *, int, int, int *, int *, bool, ihipStream_t *) { abort(); }
 bool chain_supported(int, int) { return true; }
 int chain_ctl_ints() { return 1; }
+int chain_tail_ints() { return 16; }
 void launch_chain(const PicParams *, const uint32_t *, int, bool, int *, int *, bool, ihipStream_t *) { abort(); }
 int chain_band_rows() { return 16; }
 int deblock_row_lag() { return 1; }
