@@ -1,6 +1,7 @@
 """Parity tests proper (-m gpu): the HIP decode path, driven through the C ABI exactly like the reference harness
 drives jm_nvdec_* (test_nv_dec.cpp:163-259), must be BIT-EXACT against the CPU oracle / the committed golden vectors."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -1017,6 +1018,37 @@ def test_many_gpus_in_one_process_mode_on_the_device(oracle, monkeypatch):
     for dev in (0, 1):
         assert got[dev] == want[dev], f"handle on device {dev}"
         assert info[dev][0] == dev and info[dev][1] == 0 and info[dev][2] >= 1 and info[dev][3] == 0, info
+
+
+def test_diagnostic_chain_launches_are_bit_exact_and_print_a_time_line(oracle, tmp_path):
+    """Round 4: JM_AMD_DEC_CENSUS turns every chain launch into a diagnostic one (workgroup census, time stamps per picture, wait ticks) and
+    JM_AMD_DEC_CHAIN_TIMELINE prints them when the launch retires (Engine::dump_chain_state).  Both are read once per process, hence the child process:
+    one stream of 24 frames must decode bit-exactly with them on, and the child reports how many chain launches it saw and their time lines."""
+    import subprocess, sys
+    data = streams.generate(width=352, height=288, frames=24, gop=12, mode=1, num_ref=1, seed=0x71AE)
+    want = oracle.decode(data, 1)[0]
+    src, dst = tmp_path / "in.h264", tmp_path / "out.yuv"
+    src.write_bytes(data)
+    child = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from jmcodec_amd import api\n"
+        f"data = open({str(src)!r}, 'rb').read()\n"
+        "with api.JmAmdDec(0, 1) as d:\n"
+        "    out = b''.join(d.decode_stream(data))\n"
+        "    print('chains', d.stat('eng_chain_batches'), 'shared', d.stat('eng_gpu_shared'), 'errors', d.stat('errors'))\n"
+        f"open({str(dst)!r}, 'wb').write(out)\n")
+    env = dict(os.environ, JM_AMD_DEC_CENSUS="1", JM_AMD_DEC_CHAIN_TIMELINE="1")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert dst.read_bytes() == want
+    words = r.stdout.split()
+    chains, shared = int(words[words.index("chains") + 1]), int(words[words.index("shared") + 1])
+    assert int(words[words.index("errors") + 1]) == 0
+    if chains == 0 and shared:
+        pytest.skip("GPU shared with another process: no chain launch formed in the child")
+    assert chains >= 1, r.stdout
+    assert r.stderr.count("chain launch of") == chains and "time line picture" in r.stderr and "reconstruction workgroups:" in r.stderr, r.stderr[-2000:]
 
 
 # ---- closing test of this file (pytest runs a file's tests in definition order): were the chain kernels exercised at all? ---------------------------
