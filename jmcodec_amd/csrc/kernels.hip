@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
 // (left neighbour is the same wave; top, top-left and top-right are covered by the count).
 // ------------------------------------------------------------------------------------------
 constexpr int kWaves = 16;
+// k_recon_intra runs eight: a workgroup of 16 waves is four per SIMD, i.e. 128 registers each, and the kernel then spilled 63 of them (368 bytes of scratch);
+// with two waves per SIMD it keeps everything in registers.  It only sees pictures with a few scattered intra macroblocks (decoder.cpp).
+constexpr int kIntraWaves = 8;
 constexpr int kMaxRows = 512;
 
 __device__ __forceinline__ void wait_row(volatile int *progress, int row, int need) {
@@ -284,18 +287,18 @@ __device__ void intra_mb(const PicParams &pp, const MbRec &r, int mbx, int mby, 
     }
 }
 
-__global__ __launch_bounds__(kWaves * 64) void k_recon_intra(const PicParams *pics) {
+__global__ __launch_bounds__(kIntraWaves * 64) void k_recon_intra(const PicParams *pics) {
     const PicParams &pp = pics[blockIdx.y];
     if (!(pp.stages & PS_INTRA_V1)) return;
     __shared__ volatile int progress[kMaxRows];
-    __shared__ IntraTile tiles[kWaves];
-    __shared__ ResTile res[kWaves];
+    __shared__ IntraTile tiles[kIntraWaves];
+    __shared__ ResTile res[kIntraWaves];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < kMaxRows; i += blockDim.x) progress[i] = 0;
     __syncthreads();
     // progress[row] = x of the first macroblock of the row that is NOT yet reconstructed; inter / I_PCM
     // macroblocks were finished by k_recon_inter, so only Intra4x4 / Intra16x16 ones hold the count back.
-    for (int row = wave; row < pp.mb_h; row += kWaves) {
+    for (int row = wave; row < pp.mb_h; row += kIntraWaves) {
         const MbRec *recs = pp.mbs + (size_t)row * pp.mb_w;
         for (int c0 = 0; c0 < pp.mb_w; c0 += 64) {
             int x = c0 + lane;
@@ -558,7 +561,7 @@ void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bi
     else if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
     else hipLaunchKernelGGL((k_recon_inter<false, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
 }
-void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
+void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kIntraWaves * 64), 0, st, d_pics); }
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
 // Tight I420 / NV12 frame -> 32-bit ARGB (bytes B, G, R, A), BT.601 limited range, the conversion the reference left behind
 // "#if 0" (nv_dec.h:98-107, nv_dec.cpp:244-265).  One thread per pixel pair.
