@@ -3,9 +3,9 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/f4
 timeout 1500 python -m pytest tests -m gpu -q -rs > gpurun_out/f4/gputests.log 2>&1; tail -4 gpurun_out/f4/gputests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1500 python tools/gpu_sweep.py 200 41 > gpurun_out/f4/sweep_a.log 2>&1; tail -2 gpurun_out/f4/sweep_a.log
-timeout 1500 python tools/gpu_sweep.py 200 42 > gpurun_out/f4/sweep_b.log 2>&1; tail -2 gpurun_out/f4/sweep_b.log
-timeout 900 python tools/gpu_sweep.py 30 43 big > gpurun_out/f4/sweep_big.log 2>&1; tail -2 gpurun_out/f4/sweep_big.log
+timeout 1500 python tools/gpu_sweep.py 200 61 > gpurun_out/f4/sweep_a.log 2>&1; tail -2 gpurun_out/f4/sweep_a.log
+timeout 1500 python tools/gpu_sweep.py 200 62 > gpurun_out/f4/sweep_b.log 2>&1; tail -2 gpurun_out/f4/sweep_b.log
+timeout 900 python tools/gpu_sweep.py 30 63 big > gpurun_out/f4/sweep_big.log 2>&1; tail -2 gpurun_out/f4/sweep_big.log
 bash scratch/gpu_prof_r04.sh r04 > gpurun_out/f4/prof.log 2>&1; tail -30 gpurun_out/f4/prof.log | cut -c1-260
 for s in 1 8; do timeout 300 python bench.py --streams $s --no-extra --no-cpu-baseline --no-single > gpurun_out/f4/r04_bench_s$s.json 2>/dev/null; done
 for t in high high_b; do timeout 300 python bench.py --tools $t --no-extra --no-cpu-baseline --no-single > gpurun_out/f4/r04_bench_$t.json 2>/dev/null; done
