@@ -125,9 +125,14 @@ __device__ __forceinline__ void gstore(gbyte *p, uint32_t v) { *(JM_GLOBAL uint3
 // final samples.  WT (chain launches): write-through stores (chain_common.h), because the next reader -- the motion compensation of the following picture --
 // may sit on another XCD and reads with cache-bypassing loads as soon as the band's `fin` counter covers the step (chain_common.h)
 __device__ __forceinline__ void gstore_wt(gbyte *p, uint32_t v) { __hip_atomic_store((JM_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (WT) st_wt16((void *)p, v); else gstore(p, v); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (WT) st_wt8((void *)p, v); else gstore(p, v); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) { if (WT) gstore_wt(p, v); else gstore(p, v); }
+#ifdef JM_EXP_NO_WT_DEBLOCK     // measurement only (results may be wrong): what do the write-through stores cost a deblocking step?
+#define JM_WT_ON(WT) false
+#else
+#define JM_WT_ON(WT) (WT)
+#endif
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (JM_WT_ON(WT)) st_wt16((void *)p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (JM_WT_ON(WT)) st_wt8((void *)p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) { if (JM_WT_ON(WT)) gstore_wt(p, v); else gstore(p, v); }
 
 // ------------------------------------------------------------------------------------------
 // luma: one macroblock, 16 lanes (l = 0..15)
@@ -531,7 +536,11 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         if (CHAIN) {
             // `fin`: how many steps have their final samples in memory, published two steps late by the same counting argument: every wave has issued
             // the six loads of the steps s - 1 and s since its stores of step s - 2.
+#ifdef JM_EXP_NO_FIN_WAIT        // measurement only (results may be wrong): what does the counted wait in front of the `fin` counter cost per step?
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);
         } else
