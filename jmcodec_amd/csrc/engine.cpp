@@ -578,7 +578,7 @@ void Engine::dump_chain_state(Batch &b) {
     fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | "
         "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n",
         lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_, chain_bands_max_intra_);
-    if (lw[2] > 0) fprintf(stderr, "  reconstruction workgroups: %.2f us each on average, of which %.2f us in wait_final (wave 0)\n", 0.01 * lw[7] / lw[2], 0.01 * lw[6] / lw[2]);
+    if (lw[2] > 0) fprintf(stderr, "  reconstruction workgroups: %.2f us each on average, of which %.2f us in wait_final (wave 0)\n", 0.01 * (double)(unsigned)lw[7] / lw[2], 0.01 * (double)(unsigned)lw[6] / lw[2]);      // (sums of ticks: read as unsigned, a large launch passes 2^31)
     if (lw[8]) fprintf(stderr,
         "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
