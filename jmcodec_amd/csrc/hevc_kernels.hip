@@ -230,6 +230,12 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD-aware, see k_hevc_mc
     if (!(pp.stages & HPS_RESID) || job >= pp.n_tbs) return;
     const HevcTb tb = pp.tbs[job];
+    // Cb and Cr of a transform unit are interleaved in memory and are two entries of the list, one behind the other when both are coded (transform_unit()
+    // emits c = 1, then c = 2).  The Cb workgroup takes its Cr partner along, so the pair leaves as whole dwords (Cb Cr Cb Cr) instead of byte-wise
+    // read-modify-writes of two workgroups on the same lines; a component whose partner is not coded does the same with a zero residual for the other half
+    // (nobody else writes those bytes: blocks are disjoint, and the motion compensation ran in an earlier kernel).
+    auto same_place = [](const HevcTb &a, const HevcTb &b) { return a.x == b.x && a.y == b.y && a.log2 == b.log2; };
+    if (tb.plane == 2 && job > 0) { const HevcTb prev = pp.tbs[job - 1]; if (prev.plane == 1 && same_place(prev, tb)) return; }     // done by its Cb partner
     __shared__ int16_t d[32 * 32], res[32 * 32];
     __shared__ __align__(16) int8_t tm[32 * 32];
     __shared__ int ext[2];
@@ -249,12 +255,22 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
         }
         return;
     }
-    // chroma: Cb and Cr of a block are interleaved in memory and belong to two transform blocks (two workgroups): byte accesses, nothing wider can be
-    // read-modified-written without racing with the other component
-    for (int k = lane; k < n * n; k += 64) {
-        const int y = k >> tb.log2, x = k & (n - 1);
-        uint8_t *p = sample_ptr(dst, pp, tb.plane, tb.x + x, tb.y + y);
-        *p = (uint8_t)clip1(*p + r[k]);
+    // chroma (blocks of at most 16x16: the upper halves of d / res hold the partner's block)
+    const int16_t *rb = tb.plane == 1 ? r : nullptr, *rr2 = tb.plane == 2 ? r : nullptr;
+    if (tb.plane == 1 && job + 1 < pp.n_tbs) {
+        const HevcTb nx = pp.tbs[job + 1];
+        if (nx.plane == 2 && same_place(tb, nx))
+            rr2 = residual_block<false>(pp.coefs + nx.coef_off, (int)nx.coef_n, nx.log2, nx.flags, d + 512, res + 512, tm, ext, lane, 64);
+    }
+    const int hn = n >> 1;
+    for (int k = lane; k < n * hn; k += 64) {                         // two sample pairs per lane: Cb0 Cr0 Cb1 Cr1
+        const int y = k / hn, xq = k - y * hn;
+        uint32_t *p = (uint32_t *)(dst + pp.chroma_offset + (size_t)(tb.y + y) * pp.pitch + 2 * (tb.x + 2 * xq));
+        const uint32_t v = *p;
+        const int o = y * n + 2 * xq;
+        const int b0 = rb ? rb[o] : 0, b1 = rb ? rb[o + 1] : 0, c0 = rr2 ? rr2[o] : 0, c1 = rr2 ? rr2[o + 1] : 0;
+        *p = (uint32_t)clip1((int)(v & 255) + b0) | (uint32_t)clip1((int)(v >> 8 & 255) + c0) << 8 | (uint32_t)clip1((int)(v >> 16 & 255) + b1) << 16 |
+             (uint32_t)clip1((int)(v >> 24) + c1) << 24;
     }
 }
 
