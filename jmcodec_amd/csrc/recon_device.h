@@ -250,10 +250,11 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         if (cv.census_on) cv.census(ChainView::CENSUS_WAIT_TICKS, (int)((uint32_t)wall_clock64() - tw0));
         if (!ok && lane == 0) report_wait_timeout(cv.err + pp.chain_idx, CHAIN_ERR_FIN_TIMEOUT);
     }
-    // Round 4: ONE window per macroblock when its four 8x8 blocks share a vector and a reference (P_Skip, P_L0_16x16: 96 % of the macroblocks of config
-    // C1): 21 rows of 6 aligned dwords for luma and 9 rows of 5 for the interleaved chroma, three loads per lane instead of nine -- the four 13x13 windows
-    // overlap by half, and the chroma path fetched four bytes per sample pair (1 KB per macroblock).  In chain launches these loads bypass the caches, so
-    // the bytes are real traffic: ~2.8 KB per macroblock before, ~1.2 KB now (profiles/r04_pmc_traffic_*).  `uni` is wave-uniform (the record is).
+    // Round 4: ONE window per macroblock when its four 8x8 blocks share a vector and a reference (P_Skip, P_L0_16x16: 97 % of the inter macroblocks of
+    // config C1): 21 rows of 6 aligned dwords for luma and 9 rows of 5 for the interleaved chroma, three loads per lane instead of nine -- the four 13x13
+    // windows overlap by half, and the chroma path fetched four bytes per sample pair.  Measured (profiles/r04_ab9_one_window.json): k_recon_inter 534 ->
+    // 504 us per launch; the bytes the chain kernels fetch from memory moved by 3 % only (what they are: profiles/r04_pmc_chain_l2_requests.txt).
+    // `uni` is wave-uniform (the record is).
     bool uni = false;
     uint32_t cw = 0;                                        // this lane's dword of the chroma window (uni path)
     int c_sh = 0;                                           // byte offset of chroma sample 0 in its window row
