@@ -219,11 +219,12 @@ struct ChainView {
         const int bhi = yhi >> 4, blo = ylo >> 4;
         const int store_lag = row_lag == 1 ? 1 : 0;                // one row per step: macroblock (X, Y) is stored in step X + Y + 1 (deblock_device.h)
         const int need_hi = xs + row_lag * yhi + 1 + store_lag, need_lo = xs + row_lag * (blo * 16 + 15) + 1 + store_lag;
-        // Polls cost: a waiting wave that looks every 0.2 us is two or three uncached 64-byte fetches per microsecond, and a chain launch keeps thousands of
-        // waves waiting (one stream: the whole device waits for ONE picture's bands) -- hundreds of GB/s of fetches onto a handful of counter lines, in
-        // front of the stores that move those counters.  The counters are step numbers, so a wave knows how far away its samples are: it naps
-        // kNapPerStep for every step still missing (a deblocking step takes >= 2.3 us, a band that has not started begins at step row_lag * 16 * band;
-        // napping 0.75 us per step never oversleeps), at most 63 in a row, and looks again.  Waits that are nearly over poll as before.
+        // Polls cost: a waiting wave that looks every 0.2 us sends two or three L2 requests per microsecond, and a chain launch keeps thousands of waves
+        // waiting (one stream: the whole device waits for ONE picture's bands) -- all onto a handful of counter lines, in front of the stores that move
+        // those counters.  The counters are step numbers, so a wave knows how far away its samples are: it naps 0.75 us for every step still missing (a
+        // deblocking step takes >= 2.3 us, a band that has not started begins at step row_lag * 16 * band: it never oversleeps), at most 63 naps in a
+        // row, and looks again.  Waits that are nearly over poll as before.  (4 / 8 streams +4 %, profiles/r04_ab10_wait_naps.json; the bytes fetched
+        // from MEMORY did not change: the polls hit in the L2.)
         constexpr int kNapSlack = 3, kTopNap = 32;                  // naps in a row: at most 2 * kTopNap - 1 (47 us)
         const int first_hi = row_lag * 16 * bhi, first_lo = row_lag * 16 * blo;
         int spins = 0; uint32_t t0 = 0;
