@@ -401,7 +401,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
-    int sampled = 0;                                                        // JM_DEBLOCK_ASYNC_POLL: the counter of the band above as the last stage delivered it
+    // JM_DEBLOCK_ASYNC_POLL: the counter of the band above as the last stage delivered it
+    int sampled = 0;
     auto wait_above = [&](int need) {
         if (band == 0 || threadIdx.x >= 64) return;                          // wave 0 holds group 0
         if (sampled > known) known = sampled;

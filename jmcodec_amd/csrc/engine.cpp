@@ -60,7 +60,8 @@ Engine::Engine(int device) : device_(device) {
             if (hipHostMalloc((void **)&b.h_hpics, sizeof(HevcPicParams) * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_hpics, sizeof(HevcPicParams) * kMaxBatch) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
-            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + chain_tail_ints())) != hipSuccess) return;   // + the launch-wide tail (chain_common.h)
+            // + the launch-wide tail (chain_common.h)
+            if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + chain_tail_ints())) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_err, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) return;
             if (hipHostGetDevicePointer((void **)&b.d_err, b.h_err, 0) != hipSuccess) return;
             memset(b.h_err, 0, sizeof(int) * kMaxBatch);
@@ -578,7 +579,9 @@ void Engine::dump_chain_state(Batch &b) {
     fprintf(stderr, "  census: abort %d | reconstruction workgroups started %d done %d (work list: %d groups x 2, some empty) | "
         "band workgroups started %d done %d of %d | highest work-list index started %d | band budget %d / %d\n",
         lw[0], lw[1], lw[2], n_recon_groups, lw[3], lw[4], n_band_wgs, lw[5], chain_bands_max_, chain_bands_max_intra_);
-    if (lw[2] > 0) fprintf(stderr, "  reconstruction workgroups: %.2f us each on average, of which %.2f us in wait_final (wave 0)\n", 0.01 * (double)(unsigned)lw[7] / lw[2], 0.01 * (double)(unsigned)lw[6] / lw[2]);      // (sums of ticks: read as unsigned, a large launch passes 2^31)
+    // (sums of ticks: read as unsigned, a large launch passes 2^31)
+    if (lw[2] > 0) fprintf(stderr, "  reconstruction workgroups: %.2f us each on average, of which %.2f us in wait_final (wave 0)\n",
+        0.01 * (double)(unsigned)lw[7] / lw[2], 0.01 * (double)(unsigned)lw[6] / lw[2]);
     if (lw[8]) fprintf(stderr,
         "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
@@ -605,7 +608,8 @@ void Engine::dump_chain_state(Batch &b) {
     if (t0 != 0x7fffffff) for (int i = 0; i < n; i++) {
         if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
         auto us = [&](int k) { const int v = ts[4 * i + k]; return v ? ((k & 1) ? v - t0 : 0x40000000 - v - t0) * 0.01 : -1.0; };
-        fprintf(stderr, "  time line picture %2d dec %p: reconstruction %.1f .. %.1f us, bands %.1f .. %.1f us\n", i, (void *)b.pics[i].dec, us(0), us(1), us(2), us(3));
+        fprintf(stderr, "  time line picture %2d dec %p: reconstruction %.1f .. %.1f us, bands %.1f .. %.1f us\n", i, (void *)b.pics[i].dec, us(0), us(1),
+            us(2), us(3));
     }
 }
 

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
             const int y = k / qn, xq = k - y * qn;
             uint32_t *p = (uint32_t *)(dst + (size_t)(tb.y + y) * pp.pitch + tb.x + 4 * xq);
             const uint32_t v = *p; const int16_t *rr = r + y * n + 4 * xq;
-            *p = (uint32_t)clip1((int)(v & 255) + rr[0]) | (uint32_t)clip1((int)(v >> 8 & 255) + rr[1]) << 8 | (uint32_t)clip1((int)(v >> 16 & 255) + rr[2]) << 16 |
+            *p = (uint32_t)clip1((int)(v & 255) + rr[0]) | (uint32_t)clip1((int)(v >> 8 & 255) + rr[1]) << 8 |
+                 (uint32_t)clip1((int)(v >> 16 & 255) + rr[2]) << 16 |
                  (uint32_t)clip1((int)(v >> 24) + rr[3]) << 24;
         }
         return;
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         if (y_mine && y0 + yr < pp.h && x0 + 16 * yg < pp.w) pre.y = *(const uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg);
         if (c_mine && yc0 + cr < ph && xc0 + 8 * cg < pw) pre.c = *(const uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg));
         if (x0 > 0 && tid <= cs) { const int y = y0 + tid - 1; if (y >= 0 && y < pp.h) pre.ly = surf[(size_t)y * pp.pitch + x0 - 1]; }
-        if (x0 > 0 && tid <= hc) { const int y = yc0 + tid - 1; if (y >= 0 && y < ph) pre.lc = *(const uint16_t *)(cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1)); }
+        if (x0 > 0 && tid <= hc) { const int y = yc0 + tid - 1; if (y >= 0 && y < ph) pre.lc = *(const uint16_t *)(cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1));
+            }
     };
     auto next_intra = [&](int from) { int c = from; while (c < c1 && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
     int cx = next_intra(c0), prev_cx = -2;
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // run before this one and its intra blocks reach its right column.
     int need[kHevcIntraSegs + 1];
     for (int &v : need) v = 0;
-    if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 && col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_edge & 1) need[col / seg_w] = col + 1;
+    if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 &&
+        col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_edge & 1) need[col / seg_w] = col + 1;
     const bool left_run = cx == c0 && cx > 0 && (pp.ctbs[cy * pp.ctb_w + cx - 1].intra_edge & 2);
     if (left_run) need[kHevcIntraSegs] = cx;
     if (tid == 0) {
@@ -430,7 +433,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         keep_lc = (uint32_t)ld_coh8(pc) | (uint32_t)ld_coh8(pc + 1) << 8; }
     // ---- body and left column from the registers ----
     if (y_mine) *(uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg] = pre.y;
-    if (c_mine) { uint2 cb, crv; de_interleave(pre.c, cb, crv); *(uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg] = cb; *(uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg] = crv; }
+    if (c_mine) { uint2 cb, crv; de_interleave(pre.c, cb, crv); *(uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg] = cb;
+        *(uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg] = crv; }
     if (x0 > 0 && tid >= 1 && tid <= cs) ty[tid * kYS + kYO - 1] = (uint8_t)keep_ly;
     if (x0 > 0 && tid >= 1 && tid <= hc) { tc[0][tid * kCS + kCO - 1] = (uint8_t)keep_lc; tc[1][tid * kCS + kCO - 1] = (uint8_t)(keep_lc >> 8); }
     if (tid == 128 && x0 > 0 && y0 > 0) ty[kYO - 1] = (uint8_t)keep_ly;
@@ -544,24 +548,30 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // ---- the last CTB of a run whose intra blocks reach its right column: the next run reads that column -- the whole tile is written through ----
     const bool wt_all = (ctb.intra_edge & 2) && cx == c1 - 1 && c1 < pp.ctb_w;
     if (wt_all) {
-        if (y_mine && y0 + yr < pp.h && x0 + 16 * yg < pp.w) st_wt16(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg, *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg]);
+        if (y_mine && y0 + yr < pp.h && x0 + 16 * yg < pp.w) st_wt16(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg,
+            *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg]);
         if (c_mine && yc0 + cr < ph && xc0 + 8 * cg < pw)
-            st_wt16(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg), interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg], *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]));
+            st_wt16(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg), interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg],
+                *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) st_coh(&prog[cy * kHevcIntraSegs + seg], cx + 1);
     } else {
     // ---- the bottom row of the CTB first: it is all the row below needs of this CTB; then the counter ----
-    if (tid < q) { const int y = y0 + cs - 1; if (y < pp.h && x0 + 16 * tid < pp.w) st_wt16(surf + (size_t)y * pp.pitch + x0 + 16 * tid, *(const uint4 *)&ty[cs * kYS + kYO + 16 * tid]); }
+    if (tid < q) { const int y = y0 + cs - 1; if (y < pp.h && x0 + 16 * tid < pp.w) st_wt16(surf + (size_t)y * pp.pitch + x0 + 16 * tid,
+        *(const uint4 *)&ty[cs * kYS + kYO + 16 * tid]); }
     else if (tid < 2 * q) { const int g = tid - q, y = yc0 + hc - 1, x = xc0 + 8 * g;
-        if (y < ph && x < pw) st_wt16(cpl + (size_t)y * pp.pitch + 2 * x, interleave(*(const uint2 *)&tc[0][hc * kCS + kCO + 8 * g], *(const uint2 *)&tc[1][hc * kCS + kCO + 8 * g])); }
+        if (y < ph && x < pw) st_wt16(cpl + (size_t)y * pp.pitch + 2 * x, interleave(*(const uint2 *)&tc[0][hc * kCS + kCO + 8 * g],
+            *(const uint2 *)&tc[1][hc * kCS + kCO + 8 * g])); }
     // (wave 0 holds every one of those write-through stores: once they are complete the counter may move)
     if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) st_coh(&prog[cy * kHevcIntraSegs + seg], cx + 1);
     // ---- the rest of the tile (its intra blocks changed; the other samples are written back unchanged), off the chain ----
-    if (y_mine && yr < cs - 1 && y0 + yr < pp.h && x0 + 16 * yg < pp.w) *(uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg) = *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg];
+    if (y_mine && yr < cs - 1 && y0 + yr < pp.h &&
+        x0 + 16 * yg < pp.w) *(uint4 *)(surf + (size_t)(y0 + yr) * pp.pitch + x0 + 16 * yg) = *(const uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg];
     if (c_mine && cr < hc - 1 && yc0 + cr < ph && xc0 + 8 * cg < pw)
-        *(uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg)) = interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg], *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]);
+        *(uint4 *)(cpl + (size_t)(yc0 + cr) * pp.pitch + 2 * (xc0 + 8 * cg)) = interleave(*(const uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg],
+            *(const uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg]);
     }
     // rows of a CTB that reaches below the picture: the "bottom row" above lay outside, the last rows inside were written just now -- nobody waits for them
     prev_cx = cx;

@@ -561,7 +561,8 @@ void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bi
     else if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
     else hipLaunchKernelGGL((k_recon_inter<false, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
 }
-void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kIntraWaves * 64), 0, st, d_pics); }
+void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kIntraWaves * 64), 0, st, d_pics);
+    }
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_deblock, dim3(1, n), dim3(kWaves * 64), 0, st, d_pics); }
 // Tight I420 / NV12 frame -> 32-bit ARGB (bytes B, G, R, A), BT.601 limited range, the conversion the reference left behind
 // "#if 0" (nv_dec.h:98-107, nv_dec.cpp:244-265).  One thread per pixel pair.

@@ -1048,7 +1048,8 @@ def test_diagnostic_chain_launches_are_bit_exact_and_print_a_time_line(oracle, t
     chains, shared = int(words[words.index("chains") + 1]), int(words[words.index("shared") + 1])
     assert int(words[words.index("errors") + 1]) == 0
     assert chains >= 1 and shared == 0, r.stdout
-    assert r.stderr.count("chain launch of") == chains and "time line picture" in r.stderr and "reconstruction workgroups:" in r.stderr, r.stderr[-2000:]
+    assert r.stderr.count("chain launch of") == chains, r.stderr[-2000:]
+    assert "time line picture" in r.stderr and "reconstruction workgroups:" in r.stderr, r.stderr[-2000:]
 
 
 # ---- closing test of this file (pytest runs a file's tests in definition order): were the chain kernels exercised at all? ---------------------------
