@@ -1064,7 +1064,8 @@ def test_zz_chain_kernels_ran_in_this_session():
         total, with_intra, pics = d.stat("eng_chain_batches"), d.stat("eng_chain_i_batches"), d.stat("eng_chain_pics")
         rec, shared = d.stat("eng_chain_recoveries"), d.stat("eng_gpu_shared")
     util.SESSION_NOTES.append(f"chain launches in this session: k_chain {total - with_intra}, k_chain_i {with_intra} ({pics} pictures; {rec} recovered on "
-                              f"purpose by the debug_stall tests); GPU seen unshared in {sum(_GPU_OURS_SEEN)} of {len(_GPU_OURS_SEEN)} looks, shared now: {shared}")
+                              f"purpose by the debug_stall tests); GPU seen unshared in {sum(_GPU_OURS_SEEN)} of {len(_GPU_OURS_SEEN)} looks, "
+                              f"shared now: {shared}")
     if not _GPU_OURS_SEEN:
         pytest.skip("no chain test ran in this session (test selection)")
     if not any(_GPU_OURS_SEEN):

@@ -61,7 +61,8 @@ def main():
             chain["traffic_upper"] = chain["fetch_corrected_upper"] + chain["write"]
     mb_w, mb_h = (a.width + 15) // 16, (a.height + 15) // 16
     env = (a.env.strip() + " ") if a.env.strip() else ""
-    out = {"how": f"{env}rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per launch, so "
+    out = {"how": f"{env}rocprofv3 --kernel-trace --pmc FETCH_SIZE (and a separate pass --pmc WRITE_SIZE) -- {a.command}; ONE stream, one picture per "
+                  f"launch, so "
         f"bytes "
                   f"are per {a.width}x{a.height} picture (averaged over the launches of the kernel, i.e. over the run's picture types). Counter unit KB "
                   f"(x1024). "
