@@ -79,8 +79,7 @@ def test_bench_two_ranks_gloo_parse_only():
 def test_bench_extra_legs_parse_only(tmp_path):
     """the default bench invocation appends untimed legs for the other BASELINE configurations -- c4_slice (8 x 1080p Baseline), c2_4k
     (16 x 4K High I B B P), c3_4k (16 x 4K HEVC) -- each a compact object with its own bit-exact flag and roofline block.  Here: the same code path at a toy
-    size
-    without a GPU (--parse-only, JM_BENCH_TEST_LEGS): one JSON line, the headline keys unchanged, the three legs present with the promised fields."""
+    size without a GPU (--parse-only, JM_BENCH_TEST_LEGS): one JSON line, the headline keys unchanged, the three legs present with the promised fields."""
     import json
     import subprocess
     import sys
