@@ -120,13 +120,25 @@ struct RefBuf {
 constexpr int kAuxSc1 = 16;
 // a single coherent byte through a plain pointer (hevc_kernels.hip: a few edge samples per coding tree block)
 __device__ __forceinline__ int ld_coh8(const uint8_t *p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (the plain loads go through address-space-1 pointers: a generic pointer makes them FLAT instructions, which count on lgkmcnt as well as vmcnt, so every
+// wait for an LDS result would also wait for the reference loads in flight)
+#define JM_GLOBAL_AS __attribute__((address_space(1)))
 template <bool COH> __device__ __forceinline__ int ld_ref8(const RefBuf &rb, const uint8_t *p) {
     if (COH) return (int)__builtin_amdgcn_raw_buffer_load_b8(rb.rsrc, rb.off(p), 0, kAuxSc1);
-    return (int)*p;
+    return (int)*(const JM_GLOBAL_AS uint8_t *)p;
+}
+template <bool COH> __device__ __forceinline__ uint32_t ld_ref16(const RefBuf &rb, const uint8_t *p) {        // p even
+    if (COH) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rb.rsrc, rb.off(p), 0, kAuxSc1);
+    return *(const JM_GLOBAL_AS uint16_t *)p;
 }
 template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const RefBuf &rb, const uint8_t *p) {
     if (COH) return __builtin_amdgcn_raw_buffer_load_b32(rb.rsrc, rb.off(p), 0, kAuxSc1);
-    return *(const uint32_t *)p;
+    return *(const JM_GLOBAL_AS uint32_t *)p;
+}
+// the same with a wave-uniform plane address and a 32-bit byte offset per lane (scalar base + vector offset: no 64-bit address arithmetic per lane)
+template <bool COH> __device__ __forceinline__ uint32_t ld_ref32(const RefBuf &rb, const uint8_t *plane, uint32_t off) {
+    if (COH) return __builtin_amdgcn_raw_buffer_load_b32(rb.rsrc, rb.off(plane) + (int)off, 0, kAuxSc1);
+    return *(const JM_GLOBAL_AS uint32_t *)((const JM_GLOBAL_AS uint8_t *)plane + off);
 }
 
 // A bounded wait gave up: record it in the batch's error array (pinned HOST memory mapped into the device, one word per picture; the engine

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 3) __attribute__((flatten)) void k_chain_i(con
     cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;
-        const int x = seg * 8 + rem * 4 + (int)(threadIdx.x >> 6);
+        const int x = seg * 8 + rem * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and known to be (recon_device.h)
         const bool valid = row < pp.mb_h && x < pp.mb_w;
         if (row >= pp.mb_h || seg * 8 + rem * 4 >= pp.mb_w) return;
         cv.census(ChainView::CENSUS_RECON_STARTED); cv.stamp(pp.chain_idx, ChainView::STAMP_RECON_FIRST);

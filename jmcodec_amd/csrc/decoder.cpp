@@ -1440,7 +1440,9 @@ void Decoder::submit_task(PicTask *t) {
         PicParams &pp = ep.pp;
         ep.uploaded = js.uploaded; ep.upload_seq = t->upload_seq;
         // a field picture: the lines of one parity of the surface, as a picture of half the height and twice the pitch (kernel_common.h field_base)
-        pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.pitch = t->field ? 2 * pitch_ : pitch_; pp.chroma_offset = chroma_off_; pp.field = t->field;
+        pp.mb_w = t->sps.mb_w; pp.mb_h = t->sps.mb_h; pp.mb_w_magic = (uint32_t)(((1ull << 32) + (uint32_t)pp.mb_w - 1) / (uint32_t)pp.mb_w);     // (0 for mb_w == 1, jobs.h)
+        pp.surf_stride = (uint32_t)(surf_[1] - surf_[0]);
+        pp.pitch = t->field ? 2 * pitch_ : pitch_; pp.chroma_offset = chroma_off_; pp.field = t->field;
         ep.mb_h = t->sps.mb_h;
         pp.cb_qp_off = t->pps.chroma_qp_off; pp.cr_qp_off = t->pps.second_chroma_qp_off;
         pp.n_slices = t->n_slices; pp.cur = t->cur_slot;

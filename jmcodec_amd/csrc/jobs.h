@@ -45,7 +45,7 @@ struct MbRec {            // 32 bytes
     uint8_t  qp;          // QP_Y of the macroblock (0 for I_PCM: 8.7.2.2)
     uint8_t  modes;       // bits 0-1 intra_chroma_pred_mode, bits 2-3 Intra16x16PredMode, bit 4 MBM_T8X8
     uint8_t  flags;       // MBF_*
-    uint16_t cbp_blk;     // bit r set: luma 4x4 block r (raster) has coded levels
+    uint16_t cbp_blk;     // bit b set: luma 4x4 block b (blkIdx, i.e. coding order) has coded levels
     uint8_t  cbp_cac;     // bits 0-3 Cb AC blocks, 4-7 Cr AC blocks
     uint8_t  slice;       // index into SliceRec[]
     uint32_t coef_off;    // first int16 of this macroblock in coef[]
@@ -88,6 +88,9 @@ constexpr int kMaxSurfaces = 20;
 
 struct PicParams {
     int mb_w, mb_h;               // of the picture: a field picture has half the frame's rows
+    uint32_t mb_w_magic;          // ceil(2^32 / mb_w): macroblock address / mb_w == mulhi(address, magic) for every address of a picture (address * mb_w < 2^32);
+                                  // 0 when mb_w == 1 (2^32 does not fit): the row is the address
+    uint32_t surf_stride;         // surf[i] == surf_base + i * surf_stride (one allocation, decoder.cpp): a kernel that knows the slot needs no pointer load
     int field;                    // 0 frame picture; 1 / 2: top / bottom field picture -- the lines of that parity of surf[cur], pitch = 2 x the surface's
     int pitch;                    // bytes per luma row == bytes per interleaved chroma row
     int chroma_offset;            // byte offset of the UV plane inside a surface = pitch * coded_h

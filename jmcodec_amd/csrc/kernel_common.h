@@ -88,6 +88,21 @@ __device__ __forceinline__ void idct4x4(int *d) {
 __device__ __forceinline__ int blk_to_raster(int blk) { return ((((blk >> 1) & 1) + 2 * (blk >> 3)) << 2) | ((blk & 1) + 2 * ((blk >> 2) & 1)); }
 __device__ __forceinline__ int raster_to_blk(int r) { int bx = r & 3, by = r >> 2; return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
 
+// loads / stores through address-space-1 pointers (global_* instructions, vmcnt only; a generic pointer gives FLAT instructions that also count on lgkmcnt)
+typedef uint32_t jm_g2u __attribute__((ext_vector_type(2)));
+typedef uint32_t jm_g4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 gld_u2(const void *p) { const jm_g2u v = *(const __attribute__((address_space(1))) jm_g2u *)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void gst_u4(void *p, uint4 v) { const jm_g4u t = {v.x, v.y, v.z, v.w}; *(__attribute__((address_space(1))) jm_g4u *)p = t; }
+
+// A MbRec read at a wave-uniform address: scalar loads (constant address space), the record stays in scalar registers and every condition on it is a
+// scalar branch.  The job list is written by the host before the launch, never by a kernel.
+struct MbWords { uint32_t w[8]; };       // w[3] = ref[0..3], w[4..7] = mv[0..3] (x | y << 16)
+__device__ __forceinline__ MbWords load_mbrec_uniform(const MbRec *p) {
+    typedef uint32_t v8u __attribute__((ext_vector_type(8)));
+    const v8u v = *(const __attribute__((address_space(4))) v8u *)(uintptr_t)p;
+    return __builtin_bit_cast(MbWords, v);
+}
+
 // A MbRec as eight dwords in registers.  All dynamically indexed fields are extracted with shifts / selects so the
 // record never has to live in scratch memory.
 struct MbW { uint32_t w[8]; };

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     if (!(pp.stages & PS_RECON) || blk * 4 >= pp.mb_w * pp.mb_h) return;
     __shared__ ReconLds sm;
     const int n_mbs = pp.mb_w * pp.mb_h;
-    const int mb = blk * 4 + (int)(threadIdx.x >> 6);
+    const int mb = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform, and known to be (recon_device.h)
     recon_inter_wave<false, false, BIFAST, FIELD>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, nullptr});
 }
 

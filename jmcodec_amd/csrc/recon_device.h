@@ -8,6 +8,7 @@
 #include "jobs.h"
 #include "kernel_common.h"
 #include "chain_common.h"
+#include "mc_packed.h"
 
 namespace jmamd {
 
@@ -30,8 +31,8 @@ __device__ __forceinline__ int norm_adjust8(int m, int i, int j) {
     return (int)((packed >> (6 * cls)) & 63);
 }
 
-// Residual of one macroblock into LDS.  Lanes 0..15: luma 4x4 blocks (blkIdx order) -- or lanes 0..31: (8x8 block, row / column)
-// when the macroblock uses the 8x8 transform -- and lanes 32..39: chroma blocks.
+// Residual of one macroblock into LDS.  Luma: four lanes per 4x4 block (blkIdx order) -- or lanes 0..31: (8x8 block, row / column)
+// when the macroblock uses the 8x8 transform; then lanes 0..31: the eight chroma blocks, four lanes each.
 // For MB_I16 the luma DC path (8.5.10) is applied.  Must be called by all 64 lanes of the wave.
 __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile &rt, int lane) {
     const short *coef = pp.coef + r.coef_off;
@@ -70,68 +71,104 @@ __device__ void mb_residual_to_lds(const PicParams &pp, const MbRec &r, ResTile 
 #pragma unroll
             for (int k = 0; k < 8; k++) rt.y[(oy + k) * 16 + ox] = (short)d[k];
         }
-    } else if (lane < 16) {
-        int blk = lane, rpos = blk_to_raster(blk);
-        int d[16];
-        bool coded = (r.cbp_blk >> blk) & 1;
+    } else {
+        // Round 5: FOUR lanes per 4x4 block (lane -> block lane >> 2 in coding order, row q of the block), all 64 lanes busy.  Rounds 1-4 gave a block to
+        // ONE lane (16 lanes busy, 16 two-byte loads, the whole 2-D transform and 16 two-byte LDS stores in that lane): ~200 wave-instructions for the
+        // luma blocks and as many again for the eight chroma blocks on 8 lanes.  A lane now loads its row with one 8-byte load, scales it, runs the row
+        // pass of 8.5.12.2 on it, hands the four 32-bit intermediates to the block's other lanes through LDS (rt.t8, unused without the 8x8 transform)
+        // and runs the column pass on column q.
+        const int blk = lane >> 2, q = lane & 3, rpos = blk_to_raster(blk), bx = rpos & 3, by = rpos >> 2;
+        const bool coded = (r.cbp_blk >> blk) & 1;
+        int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         if (coded) {
-            const short *c = coef + base_luma + 16 * __popc((unsigned)r.cbp_blk & ((1u << blk) - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qp, k) : dequant4w(c[k], qp, k, pp.wscale4[wl][k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = 0;
+            const short *c = coef + base_luma + 16 * __popc((unsigned)r.cbp_blk & ((1u << blk) - 1)) + 4 * q;
+            const uint2 cw = gld_u2(c);                                               // (coef_off and every block size are multiples of four levels)
+            const int c0 = (int)(short)(cw.x & 0xffffu), c1 = (int)cw.x >> 16, c2 = (int)(short)(cw.y & 0xffffu), c3 = (int)cw.y >> 16;
+            if (flat) {
+                // LevelScale4x4 = 16 * normAdjust4x4: 8.5.12.1 then gives exactly c * (normAdjust << (qP / 6)) for every qP (no rounding term survives)
+                const int s = qp / 6, m = qp % 6;
+                const int me = ((q & 1) ? norm4(m, 2) : norm4(m, 0)) << s, mo = ((q & 1) ? norm4(m, 1) : norm4(m, 2)) << s;
+                d0 = c0 * me; d1 = c1 * mo; d2 = c2 * me; d3 = c3 * mo;
+            } else {
+                const uint8_t *w4 = &pp.wscale4[wl][4 * q];
+                d0 = dequant4w(c0, qp, 4 * q, w4[0]); d1 = dequant4w(c1, qp, 4 * q + 1, w4[1]); d2 = dequant4w(c2, qp, 4 * q + 2, w4[2]);
+                d3 = dequant4w(c3, qp, 4 * q + 3, w4[3]);
+            }
         }
         bool any = coded;
         if (r.kind == MB_I16) {
-            // 8.5.10: f = H c H over the 4x4 DC matrix, element (row i, col j) belongs to the block at (x=j, y=i)
-            int c[16], f[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) c[k] = coef[k];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int a = c[4 * i], b = c[4 * i + 1], cc = c[4 * i + 2], e = c[4 * i + 3];
-                f[4 * i] = a + b + cc + e; f[4 * i + 1] = a + b - cc - e; f[4 * i + 2] = a - b - cc + e; f[4 * i + 3] = a - b + cc - e;
-            }
-            int j = rpos & 3, i = rpos >> 2;
-            int a = f[j], b = f[4 + j], cc = f[8 + j], e = f[12 + j];
-            int g = i == 0 ? a + b + cc + e : (i == 1 ? a + b - cc - e : (i == 2 ? a - b - cc + e : a - b + cc - e));
+            // 8.5.10: f = H c H over the 4x4 DC matrix (H the symmetric Hadamard matrix rows ++++ ++-- +--+ +-+-); element (row by, column bx) belongs to
+            // this lane's block.  f[by][bx] = sum over rows q of H[by][q] * (c[q][.] . H[.][bx]): lane q of the block takes row q of c (one 8-byte load) and
+            // the four lanes add their terms across the quad (two DPP adds) -- not 16 loads and the whole matrix in every lane.
+            const uint2 v = gld_u2(coef + 4 * q);
+            const int a = (int)(short)(v.x & 0xffffu), b = (int)v.x >> 16, cc = (int)(short)(v.y & 0xffffu), e = (int)v.y >> 16;
+            const int t = bx == 0 ? a + b + cc + e : (bx == 1 ? a + b - cc - e : (bx == 2 ? a - b - cc + e : a - b + cc - e));
+            const bool neg = by == 0 ? false : (by == 1 ? q >= 2 : (by == 2 ? (q == 1 || q == 2) : (q & 1) != 0));
+            int g = neg ? -t : t;
+            g += __builtin_amdgcn_update_dpp(0, g, 0xB1, 0xf, 0xf, false);          // quad_perm [1 0 3 2]
+            g += __builtin_amdgcn_update_dpp(0, g, 0x4E, 0xf, 0xf, false);          // quad_perm [2 3 0 1]
             int ls0 = flat ? level_scale4(qp % 6, 0) : pp.wscale4[0][0] * norm4(qp % 6, 0), s = qp / 6;
-            d[0] = s >= 6 ? (g * ls0) << (s - 6) : (g * ls0 + (1 << (5 - s))) >> (6 - s);
+            const int dc = s >= 6 ? (g * ls0) << (s - 6) : (g * ls0 + (1 << (5 - s))) >> (6 - s);
+            if (q == 0) d0 = dc;
             any = true;
         }
-        if (any) idct4x4(d);
-        int bx = rpos & 3, by = rpos >> 2;
-#pragma unroll
-        for (int k = 0; k < 16; k++) rt.y[(by * 4 + (k >> 2)) * 16 + bx * 4 + (k & 3)] = (short)d[k];
+        if (any) {
+            int *t = &rt.t8[blk * 16];
+            {   // rows first (8.5.12.2): this lane's row q
+                const int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+                *(int4 *)(t + 4 * q) = make_int4(e0 + e3, e1 + e2, e1 - e2, e0 - e3);
+            }
+            __builtin_amdgcn_wave_barrier();          // (the four lanes of a block are in one wave, whose LDS operations complete in order)
+            const int a = t[q], b = t[4 + q], c = t[8 + q], e = t[12 + q];
+            const int g0 = a + c, g1 = a - c, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+            short *y = &rt.y[by * 64 + bx * 4 + q];
+            y[0] = (short)((g0 + g3 + 32) >> 6); y[16] = (short)((g1 + g2 + 32) >> 6); y[32] = (short)((g1 - g2 + 32) >> 6); y[48] = (short)((g0 - g3 + 32) >> 6);
+        } else *(uint2 *)&rt.y[(by * 4 + q) * 16 + bx * 4] = make_uint2(0u, 0u);
     }
-    if (lane >= 32 && lane < 40) {
-        int pl = (lane - 32) >> 2, k4 = (lane - 32) & 3;
-        int qpc = chroma_qp(qp, pl ? pp.cr_qp_off : pp.cb_qp_off);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) {
+        // chroma: four lanes per block again -- lane -> (plane, block k4 of the plane, row q)
+        const int cb8 = lane >> 2, q = lane & 3, pl = cb8 >> 2, k4 = cb8 & 3, bx = k4 & 1, by = k4 >> 1;
+        const int qpc = chroma_qp(qp, pl ? pp.cr_qp_off : pp.cb_qp_off);
         const short *cdc = coef + base_luma + 16 * n_luma;
-        int has_cb = (r.flags & MBF_CB_DC) ? 1 : 0, has_cr = (r.flags & MBF_CR_DC) ? 1 : 0;
+        const int has_cb = (r.flags & MBF_CB_DC) ? 1 : 0, has_cr = (r.flags & MBF_CR_DC) ? 1 : 0;
         const short *cac = cdc + 4 * (has_cb + has_cr);
-        int d[16];
-        bool coded = (r.cbp_cac >> (lane - 32)) & 1;
+        const bool coded = (r.cbp_cac >> cb8) & 1;
+        int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         if (coded) {
-            const short *c = cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << (lane - 32)) - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = flat ? dequant4(c[k], qpc, k) : dequant4w(c[k], qpc, k, pp.wscale4[wl + 1 + pl][k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = 0;
+            const uint2 cw = gld_u2(cac + 16 * __popc((unsigned)r.cbp_cac & ((1u << cb8) - 1)) + 4 * q);
+            const int c0 = (int)(short)(cw.x & 0xffffu), c1 = (int)cw.x >> 16, c2 = (int)(short)(cw.y & 0xffffu), c3 = (int)cw.y >> 16;
+            if (flat) {
+                const int s = qpc / 6, m = qpc % 6;
+                const int me = ((q & 1) ? norm4(m, 2) : norm4(m, 0)) << s, mo = ((q & 1) ? norm4(m, 1) : norm4(m, 2)) << s;
+                d0 = c0 * me; d1 = c1 * mo; d2 = c2 * me; d3 = c3 * mo;
+            } else {
+                const uint8_t *w4 = &pp.wscale4[wl + 1 + pl][4 * q];
+                d0 = dequant4w(c0, qpc, 4 * q, w4[0]); d1 = dequant4w(c1, qpc, 4 * q + 1, w4[1]); d2 = dequant4w(c2, qpc, 4 * q + 2, w4[2]);
+                d3 = dequant4w(c3, qpc, 4 * q + 3, w4[3]);
+            }
         }
-        bool has_dc = pl ? has_cr : has_cb;
+        const bool has_dc = pl ? has_cr : has_cb;
+        if (q == 0) d0 = 0;                                                          // (level [0] of an AC block is unused: the DC comes from the 2x2 matrix)
         if (has_dc) {
-            const short *c = cdc + (pl ? 4 * has_cb : 0);
-            int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            int f = k4 == 0 ? c0 + c1 + c2 + c3 : (k4 == 1 ? c0 - c1 + c2 - c3 : (k4 == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
-            d[0] = ((f * (flat ? level_scale4(qpc % 6, 0) : pp.wscale4[wl + 1 + pl][0] * norm4(qpc % 6, 0))) << (qpc / 6)) >> 5;
-        } else d[0] = 0;
-        if (coded || has_dc) idct4x4(d);
-        int bx = k4 & 1, by = k4 >> 1;
-#pragma unroll
-        for (int k = 0; k < 16; k++) rt.c[pl][(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)] = (short)d[k];
+            const uint2 v = gld_u2(cdc + (pl ? 4 * has_cb : 0));
+            const int c0 = (int)(short)(v.x & 0xffffu), c1 = (int)v.x >> 16, c2 = (int)(short)(v.y & 0xffffu), c3 = (int)v.y >> 16;
+            const int f = k4 == 0 ? c0 + c1 + c2 + c3 : (k4 == 1 ? c0 - c1 + c2 - c3 : (k4 == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
+            const int dc = ((f * (flat ? level_scale4(qpc % 6, 0) : pp.wscale4[wl + 1 + pl][0] * norm4(qpc % 6, 0))) << (qpc / 6)) >> 5;
+            if (q == 0) d0 = dc;
+        }
+        if (coded || has_dc) {
+            int *t = &rt.t8[cb8 * 16];
+            {
+                const int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+                *(int4 *)(t + 4 * q) = make_int4(e0 + e3, e1 + e2, e1 - e2, e0 - e3);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int a = t[q], b = t[4 + q], c = t[8 + q], e = t[12 + q];
+            const int g0 = a + c, g1 = a - c, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+            short *y = &rt.c[pl][by * 32 + bx * 4 + q];
+            y[0] = (short)((g0 + g3 + 32) >> 6); y[8] = (short)((g1 + g2 + 32) >> 6); y[16] = (short)((g1 - g2 + 32) >> 6); y[24] = (short)((g0 - g3 + 32) >> 6);
+        } else *(uint2 *)&rt.c[pl][(by * 4 + q) * 8 + bx * 4] = make_uint2(0u, 0u);
     }
 }
 
@@ -157,30 +194,36 @@ __device__ __forceinline__ bool mb_has_residual(const MbRec &r) {
 template <bool COH> __device__ __forceinline__ int ref_luma(const RefBuf &rb, const uint8_t *s, int pitch, int W, int H, int x, int y) {
     return ld_ref8<COH>(rb, &s[clip3(0, H - 1, y) * pitch + clip3(0, W - 1, x)]);     // 32-bit index arithmetic (pointer adds here cost 15 VGPRs)
 }
-// 8.4.2.2.1 luma sample interpolation (literal form)
+// 8.4.2.2.1 luma sample interpolation for ONE sample, with coordinate clamping (windows that leave the picture, sub-8x8 partitions, missing windows).
+// Round 5: one rolled loop over the six rows -- every position is made of G, H, M and the six-tap sums b1 (this row / the row below), h1 (this column / the
+// next) and j1, all of which fall out of one pass; the literal form held 36 samples in flight and its 71 registers, added to what is live across the
+// call, decided the register count (and the occupancy) of the whole kernel.
 template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_base, const uint8_t *s, int pitch, int W, int H, int xi, int yi, int fx,
     int fy) {
     const RefBuf rb(surf_base);
-#define P(dx, dy) ref_luma<COH>(rb, s, pitch, W, H, xi + (dx), yi + (dy))
-#define HB(dy) tap6(P(-2, dy), P(-1, dy), P(0, dy), P(1, dy), P(2, dy), P(3, dy))
-#define VH(dx) tap6(P(dx, -2), P(dx, -1), P(dx, 0), P(dx, 1), P(dx, 2), P(dx, 3))
-    int G = P(0, 0);
-    if (!fx && !fy) return G;
-    if (!fy) { int b = clip1((HB(0) + 16) >> 5); return fx == 2 ? b : (fx == 1 ? (G + b + 1) >> 1 : (P(1, 0) + b + 1) >> 1); }
-    if (!fx) { int h = clip1((VH(0) + 16) >> 5); return fy == 2 ? h : (fy == 1 ? (G + h + 1) >> 1 : (P(0, 1) + h + 1) >> 1); }
-    if (fx == 2 || fy == 2) {
-        int j = clip1((tap6(HB(-2), HB(-1), HB(0), HB(1), HB(2), HB(3)) + 512) >> 10);
-        if (fx == 2 && fy == 2) return j;
-        if (fx == 2) { int q = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5); return (q + j + 1) >> 1; }
-        int q = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);
-        return (q + j + 1) >> 1;
+    int G = 0, Hs = 0, M = 0, b0 = 0, b1 = 0, h0 = 0, h1 = 0, j1 = 0;
+#pragma unroll 1
+    for (int j = 0; j < 6; j++) {
+        const int y = yi + j - 2;
+        const int p0 = ref_luma<COH>(rb, s, pitch, W, H, xi - 2, y), p1 = ref_luma<COH>(rb, s, pitch, W, H, xi - 1, y), p2 = ref_luma<COH>(rb, s, pitch, W, H, xi, y);
+        const int p3 = ref_luma<COH>(rb, s, pitch, W, H, xi + 1, y), p4 = ref_luma<COH>(rb, s, pitch, W, H, xi + 2, y), p5 = ref_luma<COH>(rb, s, pitch, W, H, xi + 3, y);
+        const int hb = tap6(p0, p1, p2, p3, p4, p5);
+        const int tap = (j == 0 || j == 5) ? 1 : ((j == 1 || j == 4) ? -5 : 20);
+        j1 += tap * hb; h0 += tap * p2; h1 += tap * p3;
+        if (j == 2) { G = p2; Hs = p3; b0 = hb; }
+        if (j == 3) { M = p2; b1 = hb; }
     }
-    int bq = fy == 1 ? clip1((HB(0) + 16) >> 5) : clip1((HB(1) + 16) >> 5);   // b or s
-    int hq = fx == 1 ? clip1((VH(0) + 16) >> 5) : clip1((VH(1) + 16) >> 5);   // h or m
-    return (bq + hq + 1) >> 1;
-#undef P
-#undef HB
-#undef VH
+    if (!fx && !fy) return G;
+    const int b = clip1(((fy == 3 ? b1 : b0) + 16) >> 5);          // b, or s = b of the row below
+    const int h = clip1(((fx == 3 ? h1 : h0) + 16) >> 5);          // h, or m = h of the next column
+    if (!fy) return fx == 2 ? b : (((fx == 1 ? G : Hs) + b + 1) >> 1);
+    if (!fx) return fy == 2 ? h : (((fy == 1 ? G : M) + h + 1) >> 1);
+    if (fx == 2 || fy == 2) {
+        const int jj = clip1((j1 + 512) >> 10);
+        if (fx == 2 && fy == 2) return jj;
+        return ((fx == 2 ? b : h) + jj + 1) >> 1;
+    }
+    return (b + h + 1) >> 1;
 }
 
 // LDS of one 4-wave workgroup of the inter reconstruction
@@ -204,28 +247,39 @@ struct alignas(16) ReconLds {
 // what the frame-only kernels of round 2 compiled to; k_recon_inter<false> needs its 96 registers for five waves per SIMD, kernels.hip)
 template <bool CHAIN, bool COH, bool BIFAST = true, bool FIELD = true>
 __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
-    auto ref_plane = [&](const PicParams &q, int slot) -> const uint8_t * { return FIELD ? jmamd::ref_plane(q, slot) : q.surf[slot]; };
+    // (frame pictures: the surface's address by arithmetic -- q.surf[slot] is a load that depends on the record, one more round trip in front of the window loads)
+    auto ref_plane = [&](const PicParams &q, int slot) -> const uint8_t * { return FIELD ? jmamd::ref_plane(q, slot) : q.surf_base + (size_t)slot * q.surf_stride; };
     auto chroma_mvy_offset = [&](const PicParams &q, int slot) -> int { return FIELD ? jmamd::chroma_mvy_offset(q, slot) : 0; };
-    auto cur_plane = [&](const PicParams &q) -> uint8_t * { return FIELD ? jmamd::cur_plane(q) : q.surf[q.cur]; };
+    auto cur_plane = [&](const PicParams &q) -> uint8_t * { return FIELD ? jmamd::cur_plane(q) : q.surf_base + (size_t)q.cur * q.surf_stride; };
     const RefBuf refbuf(pp.surf_base);                           // the coherent reference loads of chain launches (chain_common.h)
     ResTile *tiles = sm.tiles;
     uint32_t (*outt)[96] = sm.outt;
     uint32_t (*wins)[4][13 * 5 + 3] = sm.wins;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    MbRec r;
-    if (valid) r = pp.mbs[mb]; else { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
+    // Round 5: `mb` and `valid` are wave-uniform AND the compiler is told so (the callers pass them through v_readfirstlane): the record comes in with
+    // scalar loads and stays in scalar registers, every branch on it is a scalar branch.  Before, the record sat in vector registers, each of the ~40
+    // conditions on it cost an exec-mask save / restore pair (SQ_INSTS_SALU: 289 per macroblock) and mb % mb_w / mb / mb_w ran as two 25-instruction
+    // reciprocal sequences per lane.
+    if (!CHAIN && !valid) return;                               // (the stage kernel has no workgroup barrier behind this point)
+    const MbWords rw = load_mbrec_uniform(pp.mbs + (valid ? mb : 0));
+    MbRec r = __builtin_bit_cast(MbRec, rw);
+    if (!valid) { r.kind = MB_I4; r.cbp_blk = 0; r.cbp_cac = 0; r.flags = 0; }
     bool inter = valid && r.kind == MB_INTER;
     bool intra_res = valid && pp.want_intra_resid && (r.kind == MB_I4 || r.kind == MB_I16);
     bool has_res = (inter || intra_res) && mb_has_residual(r);
-    const int mbx = valid ? mb % pp.mb_w : 0, mby = valid ? mb / pp.mb_w : 0;
+    const int mby = valid ? (pp.mb_w_magic ? (int)__umulhi((uint32_t)mb, pp.mb_w_magic) : mb) : 0, mbx = valid ? mb - mby * pp.mb_w : 0;   // mb / mb_w (jobs.h)
     const int W = pp.mb_w * 16, H = pp.mb_h * 16, pitch = pp.pitch;
     // Everything an ordinary inter macroblock reads from its reference pictures depends only on the record, not on the residual:
     // issue those loads first so that their latency overlaps the coefficient loads and the inverse transform (the kernel is
     // latency bound: SQ_WAIT_ANY was 65 % of SQ_WAVE_CYCLES with the loads issued where they were consumed).
-    const bool plain = inter && !(r.modes & MBM_BIPRED);
+    // BIFAST = false: NO picture of the launch has two-list / weighted motion records (Engine: any_bipred; the parser sets MBM_BIPRED only in slices that
+    // have them), so that instantiation is compiled without their code -- round 5: it was the register high-water mark of every instantiation (97 against
+    // 70 without it: five waves per SIMD against seven)
+    const bool bipred = BIFAST && inter && (r.modes & MBM_BIPRED);
+    const bool plain = inter && !bipred;
     bool fast = false;
     uint32_t wv[5] = {0, 0, 0, 0, 0};                       // this lane's dwords of the 13x13 reference window (fast path)
-    int c_smp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // chroma: the four neighbours of (cx, cy), U then V
+    uint32_t c_wa = 0, c_wb = 0;                            // chroma: the four neighbours of (cx, cy) as U V U V of its row and of the row below
     int c_slot = -1, c_fx = 0, c_fy = 0;
     if (CHAIN && COH) {
         // lane -> (4x4 block rb, list): the samples that block's prediction can touch (13x13-style window: -2 .. +3 around the block, which
@@ -233,7 +287,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         const int rb = lane >> 2, list = (lane >> 1) & 1, bx = rb & 3, by = rb >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
         int slot = -1, mvx = 0, mvy = 0;
         if (inter) {
-            if (r.modes & MBM_BIPRED) {
+            if (bipred) {
                 const short *rec = pp.mv_ext + (size_t)r.u.mv_ext * 2;
                 mvx = rec[list * 32 + rb * 2]; mvy = rec[list * 32 + rb * 2 + 1];
                 slot = list ? ((const int8_t *)(rec + 64))[b8] : rec_ref(r, b8);
@@ -258,30 +312,35 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     bool uni = false;
     uint32_t cw = 0;                                        // this lane's dword of the chroma window (uni path)
     int c_sh = 0;                                           // byte offset of chroma sample 0 in its window row
+    int u_fx = 0, u_fy = 0, u_sh = 0;                       // uni path: the luma vector's fraction and the byte offset of window column 0 in its dword
     if (plain && !(r.flags & MBF_MV_EXT) && rec_ref(r, 0) >= 0) {
-        const uint32_t m0 = (uint16_t)r.u.mv[0][0] | ((uint32_t)(uint16_t)r.u.mv[0][1] << 16);
-        bool same = true;
-#pragma unroll
-        for (int i = 1; i < 4; i++) same &= ((uint16_t)r.u.mv[i][0] | ((uint32_t)(uint16_t)r.u.mv[i][1] << 16)) == m0 && r.ref[i] == r.ref[0];
+        // (the record as dwords: four vectors and the four reference bytes compared with a handful of scalar operations, not field by field)
+        const uint32_t m0 = rw.w[4], refs = rw.w[3];
+        const bool same = ((rw.w[5] ^ m0) | (rw.w[6] ^ m0) | (rw.w[7] ^ m0) | (refs ^ ((refs & 255u) * 0x01010101u))) == 0;
         if (same) {
             int mvx = (int16_t)(m0 & 0xffff), mvy = (int16_t)(m0 >> 16);
             const int slot = rec_ref(r, 0);
             const int xi = mbx * 16 + (mvx >> 2) - 2, yi = mby * 16 + (mvy >> 2) - 2;
             const int cmvy = mvy + chroma_mvy_offset(pp, slot);
             const int cxi = mbx * 8 + (mvx >> 3), cyi = mby * 8 + (cmvy >> 3);
-            uni = xi >= 0 && yi >= 0 && xi + 21 <= W && yi + 21 <= H && cxi >= 0 && cyi >= 0 && cxi + 9 <= (W >> 1) && cyi + 9 <= (H >> 1) &&
-                  ((2 * cxi) & ~3) + 20 <= pitch;
+            // the luma window inside the picture; in a frame picture that puts the chroma window (half the vector, 9 x 9 samples) inside as well:
+            // cxi == (xi + 2) >> 1 >= 1 and cxi + 9 <= (W - 19) / 2 + 9 < W / 2, rows alike, and its five dwords end at most at byte W <= pitch
+            uni = W >= 21 && H >= 21 && (unsigned)xi <= (unsigned)(W - 21) && (unsigned)yi <= (unsigned)(H - 21);
+            if (FIELD) uni = uni && cyi >= 0 && cyi + 9 <= (H >> 1);                            // (the chroma vector of a cross-parity reference is shifted by 2)
             if (uni) {
                 const uint8_t *ref = ref_plane(pp, slot);
                 const int xa = xi & ~3;
 #pragma unroll
-                for (int t = 0; t < 2; t++) { const int i = lane + 64 * t;
-                    if (i < 126) wv[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + i / 6) * pitch + xa + (i % 6) * 4); }
+                // (unconditional loads -- lanes past the window's end fetch its last dword again: a load under `if (i < 126)` came out as its own block
+                // with its own s_waitcnt vmcnt(0), i.e. the two loads of a lane were two memory round trips one after the other)
+                for (int t = 0; t < 2; t++) { const int i = min(lane + 64 * t, 125);
+                    wv[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + i / 6) * pitch + xa + (i % 6) * 4)); }
                 const uint8_t *rc = ref + pp.chroma_offset;
                 const int ca = (2 * cxi) & ~3;
                 c_sh = (2 * cxi) & 3;
-                if (lane < 45) cw = ld_ref32<COH>(refbuf, rc + (size_t)(cyi + lane / 5) * pitch + ca + (lane % 5) * 4);
+                { const int i = min(lane, 44); cw = ld_ref32<COH>(refbuf, rc, (uint32_t)((cyi + i / 5) * pitch + ca + (i % 5) * 4)); }
                 c_slot = slot; c_fx = mvx & 7; c_fy = cmvy & 7;
+                u_fx = mvx & 3; u_fy = mvy & 3; u_sh = xi & 3;
             }
         }
     }
@@ -297,8 +356,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 int l = lane & 15, xa = xi & ~3;
 #pragma unroll
                 for (int t = 0; t < 5; t++) {
-                    int i = l + 16 * t;
-                    if (i < 65) { int row = i / 5, dw = i % 5; wv[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + row) * pitch + xa + dw * 4); }
+                    const int i = min(l + 16 * t, 64), row = i / 5, dw = i % 5;
+                    wv[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + row) * pitch + xa + dw * 4));
                 }
             }
         }
@@ -323,15 +382,11 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                     const int o = (2 * xa) & ~3, sh = (2 * xa) & 3;
                     const uint32_t a0 = ld_ref32<true>(refbuf, r0 + o), a1 = ld_ref32<true>(refbuf, r0 + o + 4), b0 = ld_ref32<true>(refbuf, r1 + o),
                         b1 = ld_ref32<true>(refbuf, r1 + o + 4);
-                    const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
-                    c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
-                    c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
+                    c_wa = __builtin_amdgcn_alignbyte(a1, a0, sh); c_wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
                 } else {
-                c_smp[0] = ld_ref8<COH>(refbuf, r0 + 2 * xa); c_smp[1] = ld_ref8<COH>(refbuf, r0 + 2 * xb); c_smp[2] = ld_ref8<COH>(refbuf, r1 + 2 * xa);
-                c_smp[3] = ld_ref8<COH>(refbuf, r1 + 2 * xb);
-                c_smp[4] = ld_ref8<COH>(refbuf, r0 + 2 * xa + 1); c_smp[5] = ld_ref8<COH>(refbuf, r0 + 2 * xb + 1);
-                c_smp[6] = ld_ref8<COH>(refbuf, r1 + 2 * xa + 1);
-                c_smp[7] = ld_ref8<COH>(refbuf, r1 + 2 * xb + 1);
+                    // a U V pair per 16-bit load (the pair starts at an even byte); xa / xb are clamped separately at the picture's edge
+                    c_wa = ld_ref16<COH>(refbuf, r0 + 2 * xa) | ld_ref16<COH>(refbuf, r0 + 2 * xb) << 16;
+                    c_wb = ld_ref16<COH>(refbuf, r1 + 2 * xa) | ld_ref16<COH>(refbuf, r1 + 2 * xb) << 16;
                 }
             }
         }
@@ -367,66 +422,15 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(pcm[256 + cy * 8 + cx] | (pcm[320 + cy * 8 + cx] << 8));
     }
     if (!inter && r.kind != MB_PCM) { fate = FATE_PUBLISH; break; }
-    // The 8x8 block's 13x13 reference window (this lane's five dwords wv of it, row * 5 + dword == l16 + 16 * t, first byte at offset sh of the row) goes
-    // into the block's LDS window; the lane then filters the four samples 4 * hh .. of row rr (8.4.2.2.1).  The fractional position is uniform inside a
-    // block, so the 6-tap paths do not diverge within its 16 lanes.
-    // stride = dwords per window row: 5 (the block's own 13x13 window, stored here from wv) or 6 (the macroblock's 21x21 window, already in LDS: `win` then
-    // points at the block's corner inside it and wv is null)
-    auto filter_window = [&](uint32_t *win, const uint32_t *wv, int l16, int sh, int fx, int fy, int *v, const int stride = 5) {
-        if (wv) {
+    // Luma prediction from a window in LDS: pk::mc_luma4 (mc_packed.h).  The windows hold the samples ^ 0x80 (signed bytes for v_dot4_i32_i8); a lane
+    // filters four neighbouring samples of one row; the fractional position is uniform inside an 8x8 block (and inside the macroblock on the one-window
+    // path), so the six-tap paths do not diverge within a block's 16 lanes.
+    // stage_window: this lane's five dwords of a block's 13x13 window (row * 5 + dword == l16 + 16 * t) into the block's LDS window
+    auto stage_window = [&](uint32_t *win, const uint32_t *w5, int l16) {
 #pragma unroll
-        for (int t = 0; t < 5; t++) { int i = l16 + 16 * t; if (i < 65) win[i] = wv[t]; }      // row * 5 + dw == i
-        }
-        // lane -> row rr (0..7) of the block, pixels 4*hh .. 4*hh+3 ; window row of sample row y is y + 2, column x is x + 2 + sh
-        const int rr = l16 >> 1, hh = l16 & 1;
-        // 9 bytes [4hh+sh .. 4hh+sh+8] of window row wr -> t[0..8] ; sample x of this lane's k-th pixel = t[k+2]
-        auto row9 = [&](int wr, int *t) {
-            const uint32_t *p = win + wr * stride + hh;      // dword containing byte 4hh
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-            uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            t[0] = a0 & 255; t[1] = (a0 >> 8) & 255; t[2] = (a0 >> 16) & 255; t[3] = a0 >> 24;
-            t[4] = a1 & 255; t[5] = (a1 >> 8) & 255; t[6] = (a1 >> 16) & 255; t[7] = a1 >> 24; t[8] = a2 & 255;
-        };
-        if (fy == 0) {
-            int t[9]; row9(rr + 2, t);
-            if (fx == 0) { v[0] = t[2]; v[1] = t[3]; v[2] = t[4]; v[3] = t[5]; }
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int b = clip1((tap6(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5]) + 16) >> 5);
-                    v[k] = fx == 2 ? b : ((fx == 1 ? t[k + 2] : t[k + 3]) + b + 1) >> 1;
-                }
-            }
-        } else {
-            int t[6][9];
-#pragma unroll
-            for (int j = 0; j < 6; j++) row9(rr + j, t[j]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // vertical half samples at column k (h) and k+1 (m); horizontal half samples at row 0 (b) and row 1 (s)
-                int c = k + 2;
-                if (fx == 0) {
-                    int h = clip1((tap6(t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]) + 16) >> 5);
-                    v[k] = fy == 2 ? h : ((fy == 1 ? t[2][c] : t[3][c]) + h + 1) >> 1;
-                } else if (fx == 2 || fy == 2) {
-                    int hb[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) hb[j] = tap6(t[j][k], t[j][k + 1], t[j][k + 2], t[j][k + 3], t[j][k + 4], t[j][k + 5]);
-                    int jv = clip1((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
-                    if (fx == 2 && fy == 2) v[k] = jv;
-                    else if (fx == 2) { int q = clip1(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5); v[k] = (q + jv + 1) >> 1; }
-                    else { int cc = fx == 1 ? c : c + 1; int q = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
-                        v[k] = (q + jv + 1) >> 1; }
-                } else {
-                    int wr = fy == 1 ? 2 : 3, cc = fx == 1 ? c : c + 1;
-                    int bq = clip1((tap6(t[wr][k], t[wr][k + 1], t[wr][k + 2], t[wr][k + 3], t[wr][k + 4], t[wr][k + 5]) + 16) >> 5);
-                    int hq = clip1((tap6(t[0][cc], t[1][cc], t[2][cc], t[3][cc], t[4][cc], t[5][cc]) + 16) >> 5);
-                    v[k] = (bq + hq + 1) >> 1;
-                }
-            }
-        }
+        for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; if (i < 65) win[i] = w5[t] ^ pk::kSign; }
     };
-    if (inter && (r.modes & MBM_BIPRED)) {
+    if (bipred) {
         // B slices / weighted prediction: one or two references per 8x8, one vector per 4x4, weights of 8.4.2.3.  Literal sampling.
         const short *rec = pp.mv_ext + (size_t)r.u.mv_ext * 2;
         const int8_t *tail = (const int8_t *)(rec + 64);
@@ -475,24 +479,28 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
                 const uint8_t *ref = ref_plane(pp, slot);
                 uint32_t w5[5];
 #pragma unroll
-                for (int t = 0; t < 5; t++) { const int i = l16 + 16 * t; w5[t] = 0; if (i < 65) { const int row = i / 5, dw = i % 5;
-                    w5[t] = ld_ref32<COH>(refbuf, ref + (size_t)(yi + row) * pitch + xa + dw * 4); } }
+                for (int t = 0; t < 5; t++) { const int i = min(l16 + 16 * t, 64), row = i / 5, dw = i % 5;
+                    w5[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + row) * pitch + xa + dw * 4)); }
                 __builtin_amdgcn_wave_barrier();                   // (the block's window in LDS is reused for the second list: its readers are done)
-                int v[4];
-                filter_window(&wins[wave][g][0], w5, l16, xi & 3, mvx & 3, mvy & 3, v);
+                stage_window(&wins[wave][g][0], w5, l16);
                 __builtin_amdgcn_wave_barrier();
-                return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+                const uint32_t pv = pk::mc_luma4(&wins[wave][g][0], 5, l16 >> 1, 4 * (l16 & 1) + (xi & 3), mvx & 3, mvy & 3);
+                __builtin_amdgcn_wave_barrier();
+                return pv;
             };
             if (s0 >= 0) pa = predict(s0, rec + rb0 * 2);
             if (s1 >= 0) pb = predict(s1, rec + 32 + rb0 * 2);
             const int rr = l16 >> 1, hh = l16 & 1, px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;
-            int v[4];
+            uint32_t pred;
+            if (mode == 0) pred = s0 >= 0 ? (s1 >= 0 ? pk::lerp(pa, pb, pk::kOnes) : pa) : (s1 >= 0 ? pb : pk::kSign);   // default: the rounded average, or the one list
+            else {
+                int v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = combine((int)((pa >> (8 * k)) & 255), (int)((pb >> (8 * k)) & 255), s0 >= 0, s1 >= 0, i0, i1, 0);
-            if (has_res) { const short *rs = &tiles[wave].y[py * 16 + px];
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]); }
-            ot[py * 4 + (px >> 2)] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                for (int k = 0; k < 4; k++) v[k] = combine((int)((pa >> (8 * k)) & 255), (int)((pb >> (8 * k)) & 255), s0 >= 0, s1 >= 0, i0, i1, 0);
+                pred = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            }
+            if (has_res) { const uint2 rs = *(const uint2 *)&tiles[wave].y[py * 16 + px]; pred = pk::add_residual4(pred, rs.x, rs.y); }
+            ot[py * 4 + (px >> 2)] = pred;
         } else
         {   // luma: lane -> (4x4 block, row)
             int rb = lane >> 2, row = lane & 3, bx = rb & 3, by = rb >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
@@ -540,30 +548,26 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     // 13x13 reference window in LDS with aligned dword loads, then every lane filters 4 pixels of one row out of LDS.
     // The fractional position is uniform inside a block, so the 6-tap paths do not diverge within the 16 lanes.
     // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
-    if (fast || uni) {
-        int g = lane >> 4, l = lane & 15;
+    uint32_t pred;                                              // this lane's four luma samples (px .. px + 3, py) of the macroblock
+    int px, py;
+    if (uni) {
+        // the macroblock's window: 21 rows x 6 dwords (+ the chroma window behind it), written by all 64 lanes, read back by the same wave;
+        // lane -> row lane >> 2, samples 4 * (lane & 3) ..: the output tile and the residual are then walked linearly
+        uint32_t *w16 = &wins[wave][0][0];
+        if (lane < 62) { w16[lane] = wv[0] ^ pk::kSign; w16[lane + 64] = wv[1] ^ pk::kSign; } else w16[lane] = wv[0] ^ pk::kSign;
+        if (lane < 45) w16[kUniChroma + lane] = cw;
+        __builtin_amdgcn_wave_barrier();
+        py = lane >> 2; px = (lane & 3) * 4;
+        pred = pk::mc_luma4(w16, 6, py, px + u_sh, u_fx, u_fy);
+    } else if (fast) {
+        const int g = lane >> 4, l = lane & 15;
         int mvx, mvy; rec_mv8(r, g, mvx, mvy);
-        int fx = mvx & 3, fy = mvy & 3;
-        int bx0 = mbx * 16 + (g & 1) * 8;
-        int xi = bx0 + (mvx >> 2) - 2;
-        int v[4];
-        if (uni) {
-            // the macroblock's window: 21 rows x 6 dwords (+ the chroma window behind it), written by all 64 lanes, read back by the same wave
-            uint32_t *w16 = &wins[wave][0][0];
-            if (lane < 62) { w16[lane] = wv[0]; w16[lane + 64] = wv[1]; } else w16[lane] = wv[0];
-            if (lane < 45) w16[kUniChroma + lane] = cw;
-            __builtin_amdgcn_wave_barrier();
-            filter_window(w16 + (g >> 1) * 8 * 6 + (g & 1) * 2, nullptr, l, xi & 3, fx, fy, v, 6);
-        } else
-        filter_window(&wins[wave][g][0], wv, l, xi & 3, fx, fy, v);
+        const int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2;
+        stage_window(&wins[wave][g][0], wv, l);
+        __builtin_amdgcn_wave_barrier();
         const int rr = l >> 1, hh = l & 1;
-        int px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;     // position inside the macroblock
-        if (has_res) {
-            const short *rs = &tiles[wave].y[py * 16 + px];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
-        }
-        ot[py * 4 + (px >> 2)] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        px = (g & 1) * 8 + hh * 4; py = (g >> 1) * 8 + rr;         // position inside the macroblock
+        pred = pk::mc_luma4(&wins[wave][g][0], 5, rr, 4 * hh + (xi & 3), mvx & 3, mvy & 3);
     } else {
         int rb = lane >> 2, row = lane & 3;
         int bx = rb & 3, by = rb >> 2;
@@ -581,34 +585,25 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = luma_sample<COH>(pp.surf_base, ref, pitch, W, H, xi + k, yi, fx, fy);
         }
-        if (has_res) {
-            const short *rs = &tiles[wave].y[(by * 4 + row) * 16 + bx * 4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = clip1(v[k] + rs[k]);
-        }
-        ot[(by * 4 + row) * 4 + bx] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        px = bx * 4; py = by * 4 + row;
+        pred = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     }
+    if (has_res) { const uint2 rs = *(const uint2 *)&tiles[wave].y[py * 16 + px]; pred = pk::add_residual4(pred, rs.x, rs.y); }
+    ot[py * 4 + (px >> 2)] = pred;
     // ---- chroma: lane -> chroma position (cx, cy), both planes; the four neighbours were loaded up front ----
     {
-        int cx = lane & 7, cy = lane >> 3;
-        int u, v;
+        const int cx = lane & 7, cy = lane >> 3;
         if (uni) {
             // U V U V at byte c_sh + 2 * cx of window rows cy and cy + 1 (5 dwords per row): two dwords per row, aligned by byte
             const uint32_t *cwn = &wins[wave][0][0] + kUniChroma;
             const int o = (c_sh + 2 * cx) >> 2, sh = (c_sh + 2 * cx) & 3;
             const uint32_t a0 = cwn[cy * 5 + o], a1 = cwn[cy * 5 + o + 1], b0 = cwn[(cy + 1) * 5 + o], b1 = cwn[(cy + 1) * 5 + o + 1];
-            const uint32_t wa = __builtin_amdgcn_alignbyte(a1, a0, sh), wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
-            c_smp[0] = wa & 255; c_smp[4] = (wa >> 8) & 255; c_smp[1] = (wa >> 16) & 255; c_smp[5] = wa >> 24;
-            c_smp[2] = wb & 255; c_smp[6] = (wb >> 8) & 255; c_smp[3] = (wb >> 16) & 255; c_smp[7] = wb >> 24;
+            c_wa = __builtin_amdgcn_alignbyte(a1, a0, sh); c_wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
         }
-        if (c_slot < 0) { u = v = 128; }
-        else {
-            int w00 = (8 - c_fx) * (8 - c_fy), w01 = c_fx * (8 - c_fy), w10 = (8 - c_fx) * c_fy, w11 = c_fx * c_fy;
-            u = (w00 * c_smp[0] + w01 * c_smp[1] + w10 * c_smp[2] + w11 * c_smp[3] + 32) >> 6;
-            v = (w00 * c_smp[4] + w01 * c_smp[5] + w10 * c_smp[6] + w11 * c_smp[7] + 32) >> 6;
-        }
-        if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
-        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
+        // 8.4.2.2.2: one v_dot4 per plane with the weights (8 - x)(8 - y), x (8 - y), (8 - x) y, x y
+        uint32_t uv = c_slot < 0 ? 0x8080u : pk::mc_chroma_uv(c_wa, c_wb, pk::chroma_weights(c_fx, c_fy));
+        if (has_res) uv = pk::add_residual_uv(uv, tiles[wave].c[0][cy * 8 + cx], tiles[wave].c[1][cy * 8 + cx]);
+        ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)uv;
     }
     }   // inter
     fate = FATE_STORE;
@@ -635,8 +630,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         }
     } else if (fate == FATE_STORE) {
         // whole 16-byte rows (lanes 0..15 luma, 16..23 interleaved chroma), so that HBM sees full segments
-        if (lane < 16) *(uint4 *)(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16) = *(const uint4 *)(ot + lane * 4);
-        else if (lane < 24) *(uint4 *)(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16) = *(const uint4 *)(ot + 64 + (lane - 16) * 4);
+        if (lane < 16) gst_u4(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16, *(const uint4 *)(ot + lane * 4));
+        else if (lane < 24) gst_u4(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16, *(const uint4 *)(ot + 64 + (lane - 16) * 4));
     }
 }
 
