@@ -67,14 +67,18 @@ def main():
         # are unchanged; each leg is a full measure() of its own (fresh handles, warm-up, timed steps, bit-exact check against the oracle) reduced to a
         # compact object.  Only in the default invocation (N = 1, the headline workload): diagnostics and multi-rank runs skip them. ----
         if ctx["world"] == 1 and default_workload(args) and not args.no_extra:
+            # (the measured headline must survive whatever a leg does -- it goes to stderr before the legs start, and a leg that raises ANYTHING
+            # becomes an {"error": ...} entry of the one JSON line instead of taking the line with it)
+            print("bench.py: headline before the extra legs (repeated in the final line): " +
+                  json.dumps({k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "bit_exact") if k in line}), file=sys.stderr, flush=True)
             for key, over in EXTRA_LEGS:
                 t0 = time.perf_counter()
                 try:
                     leg = measure(leg_args(args, over), ctx)
                     line[key] = compact_leg(leg, time.perf_counter() - t0)
-                except SystemExit as e:          # a leg that cannot run (memory, a failed init) must not take the headline line with it
-                    line[key] = {"error": str(e)}
-                    print(f"bench.py: extra leg {key} failed: {e}", file=sys.stderr, flush=True)
+                except (SystemExit, Exception) as e:      # a leg that cannot run (memory, a failed init, a bug in the leg's own code)
+                    line[key] = {"error": f"{type(e).__name__}: {e}"}
+                    print(f"bench.py: extra leg {key} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -40,10 +40,7 @@ __global__ __launch_bounds__(256) void k_chain(const PicParams *pics, int *ctl, 
     ChainView cv{ctl, err}; cv.census_on = census_on;
     // ONE LDS block for whichever role the workgroup has: two static arrays add up (52.5 KB: three workgroups per CU by LDS alone), and since round 4
     // the kernel's 119 registers allow four
-#ifndef JM_CHAIN_LDS_PAD
-#define JM_CHAIN_LDS_PAD 0          // A/B builds: extra LDS per workgroup (14000 -> three workgroups per CU again)
-#endif
-    __shared__ __align__(16) uint8_t smem[(kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)) + JM_CHAIN_LDS_PAD];
+    __shared__ __align__(16) uint8_t smem[kDeblockSmemBytes > (int)sizeof(ReconLds) ? kDeblockSmemBytes : (int)sizeof(ReconLds)];
     cv.census(ChainView::CENSUS_MAX_GROUP, g);
     if (!(entry & 0x8000u)) {
         const int row = (int)(entry & 0x7fffu) >> 5, seg = (int)entry & 31;

@@ -72,15 +72,8 @@ enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RI
 // between rows (s = x + 2y: 254 steps at 1080p, 508 at 4K).  With the step cut into a V phase and an H phase by a second barrier, (x + 1, y - 1) and (x, y)
 // share a step: s = x + y, 188 steps at 1080p (-26 %), 375 at 4K, every filter still sees exactly the samples raster order would give it (no two filters
 // that touch a common sample change their order).  As built (deblock_device.h `step`): step s of row y = H + store of macroblock s - 1 - y, then V of
-// macroblock s - y, ONE barrier per step; the final samples of macroblock (X, Y) are therefore stored in step X + Y + 1. JM_DEBLOCK_ROW_LAG=2 builds the old
-// schedule (A/B runs).
-#ifndef JM_DEBLOCK_ROW_LAG
-#define JM_DEBLOCK_ROW_LAG 1
-#endif
-#ifndef JM_DEBLOCK_ASYNC_POLL
-#define JM_DEBLOCK_ASYNC_POLL 0       // A/B builds: the band above's step counter travels with the prefetch stage (deblock_device.h)
-#endif
-constexpr int kRowLag = JM_DEBLOCK_ROW_LAG;
+// macroblock s - y, ONE barrier per step; the final samples of macroblock (X, Y) are therefore stored in step X + Y + 1.
+constexpr int kRowLag = 1;
 static_assert(kRowLag == 1 || kRowLag == 2, "row lag of the deblocking wavefront");
 
 typedef __attribute__((address_space(1))) int gint;

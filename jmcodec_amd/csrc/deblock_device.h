@@ -125,14 +125,9 @@ __device__ __forceinline__ void gstore(gbyte *p, uint32_t v) { *(JM_GLOBAL uint3
 // final samples.  WT (chain launches): write-through stores (chain_common.h), because the next reader -- the motion compensation of the following picture --
 // may sit on another XCD and reads with cache-bypassing loads as soon as the band's `fin` counter covers the step (chain_common.h)
 __device__ __forceinline__ void gstore_wt(gbyte *p, uint32_t v) { __hip_atomic_store((JM_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#ifdef JM_EXP_NO_WT_DEBLOCK     // measurement only (results may be wrong): what do the write-through stores cost a deblocking step?
-#define JM_WT_ON(WT) false
-#else
-#define JM_WT_ON(WT) (WT)
-#endif
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (JM_WT_ON(WT)) st_wt16((void *)p, v); else gstore(p, v); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (JM_WT_ON(WT)) st_wt8((void *)p, v); else gstore(p, v); }
-template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) { if (JM_WT_ON(WT)) gstore_wt(p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint4 v) { if (WT) st_wt16((void *)p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint2 v) { if (WT) st_wt8((void *)p, v); else gstore(p, v); }
+template <bool WT> __device__ __forceinline__ void fstore(gbyte *p, uint32_t v) { if (WT) gstore_wt(p, v); else gstore(p, v); }
 
 // ------------------------------------------------------------------------------------------
 // luma: one macroblock, 16 lanes (l = 0..15)
@@ -401,11 +396,8 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     // (write-through stores / loads that bypass the non-coherent cache levels), ordered by a plain s_waitcnt on the writer's side and by the
     // data dependency on the counter on the reader's side.  Acquire / release at agent scope would write back and invalidate the whole
     // L2 of the XCD on every poll (measured: 2.8 ms per launch with one release per step).
-    // JM_DEBLOCK_ASYNC_POLL: the counter of the band above as the last stage delivered it
-    int sampled = 0;
     auto wait_above = [&](int need) {
         if (band == 0 || threadIdx.x >= 64) return;                          // wave 0 holds group 0
-        if (sampled > known) known = sampled;
         if (known >= need) return;
         int spins = 0; uint32_t t0 = 0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
@@ -458,14 +450,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         const uint32_t slot = stage_lds + (uint32_t)d * kStageBytes;
         glds16<CHAIN>(pix_base + xn * 16, slot);                                        // CHAIN: reconstructed in this launch -> coherent load
         glds4<false>(rec_base + (size_t)xn * sizeof(DbRec), slot + 1024);
-#if JM_DEBLOCK_ASYNC_POLL
-        // the last lane of wave 0 (its ring dword is a dummy: only group 0 takes ring rows) fetches the step counter of the band above instead: the sample
-        // arrives with the stage, DEPTH steps later, and wait_above looks at it before it polls -- the poll's round trip (a load that bypasses the caches) then
-        // lies beside the steps' work instead of in front of every second step of every band but the first
-        glds4<true>(band > 0 ? (threadIdx.x == 63 ? (const gbyte *)(prog + band - 1) : ring_base + xn * 16) : rec_base, slot + 1280);
-#else
         glds4<true>(band > 0 ? ring_base + xn * 16 : rec_base, slot + 1280);
-#endif
     };
     // ring rows of macroblock xm of this band's last row -> surface (write-through)
     auto give = [&](const uint8_t *ring, int xm, int lane0) {
@@ -537,11 +522,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         if (CHAIN) {
             // `fin`: how many steps have their final samples in memory, published two steps late by the same counting argument: every wave has issued
             // the six loads of the steps s - 1 and s since its stores of step s - 2.
-#ifdef JM_EXP_NO_FIN_WAIT        // measurement only (results may be wrong): what does the counted wait in front of the `fin` counter cost per step?
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
             if (threadIdx.x == 0 && s - 1 > s_begin) __hip_atomic_store(cpic + kChainFin + (is_chroma ? 32 : 0) + band, s - 1, __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);
         } else
@@ -565,9 +546,6 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
             const uint4 own = *(const uint4 *)(sl + wl * 16);
             const uint32_t rdw = *(const uint32_t *)(sl + 1024 + wl * 4), ring = *(const uint32_t *)(sl + 1280 + wl * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is read before its next load is even issued
-#if JM_DEBLOCK_ASYNC_POLL
-            if (band > 0 && threadIdx.x < 64) sampled = __builtin_amdgcn_readlane((int)ring, 63);
-#endif
             wait_above(s + j + DEPTH + kAbove);      // the ring rows of step s + j + DEPTH: see above
             fetch(j, s + j + DEPTH);
             step(s + j, own, rdw, ring);

@@ -411,9 +411,11 @@ bool Decoder::gpu_alloc_sequence() {
         hipMemset(surf_block_, 128, stride * n);
         for (size_t i = 0; i < n; i++) surf_[i] = surf_block_ + i * stride;
     }
-    use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_DEBLOCK_V1");
-    use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_) && !getenv("JM_AMD_DEC_INTRA_V1");
-    lds_intra8_ = !getenv("JM_AMD_DEC_INTRA8_V1");      // Intra8x8 in the LDS wavefront (the spin-wait kernel stays available for comparison)
+    // the banded LDS wavefronts hold pictures of up to 512 macroblock rows (16 rows x 32 bands); the one-workgroup spin-wait kernels k_deblock / k_recon_intra
+    // remain for taller ones (a legal H.264 picture may have up to 1,055 rows), k_recon_intra also for P / B pictures with a few scattered intra macroblocks
+    use_lds_deblock_ = deblock_lds_supported(mb_w_, mb_h_);
+    use_lds_intra_ = intra_lds_supported(mb_w_, mb_h_);
+    lds_intra8_ = true;
     chain_ok_ = codec_ == 0 && use_lds_deblock_ && chain_supported(mb_w_, mb_h_);
     chain_intra_on_ = !getenv("JM_AMD_DEC_NO_CHAIN_INTRA");
     // HEVC: kHevcWorkSets residual scratches and pre-SAO work surfaces per handle (H.264: a scratch per job slot)
@@ -835,7 +837,9 @@ void Decoder::build_field_ref_lists(const SliceHeader &sh, SliceTask &task) {
         // 8.2.4.2.4: short-term stores by PicOrderCnt around the count of the current FIELD -- list 0: those not above it, descending, then the others
         // ascending; list 1 the other way round.  PicOrderCnt of a store: of the frame / field pair (Min of its fields) or of its only field (DpbPic.poc)
         int ord[2][kMaxSurfaces], nb = 0, na = 0, before[kMaxSurfaces], after[kMaxSurfaces];
-        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].poc <= rf.cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        // (pic_order_cnt_type 0: a frame inferred from a gap in frame_num has no order count and is left out, as in the frame lists of 8.2.4.2.3)
+        for (int i = 0; i < nst; i++) { if (dpb_[st[i]].non_existing && seq_.poc_type == 0) continue;
+            if (dpb_[st[i]].poc <= rf.cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
         std::sort(before, before + nb, [&](int a, int b) { return dpb_[a].poc > dpb_[b].poc; });
         std::sort(after, after + na, [&](int a, int b) { return dpb_[a].poc < dpb_[b].poc; });
         for (int i = 0; i < nb; i++) { ord[0][i] = before[i]; ord[1][na + i] = before[i]; }

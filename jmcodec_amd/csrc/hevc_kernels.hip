@@ -333,7 +333,13 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // per colour plane (= per wavefront of the block loop):
     __shared__ int16_t edge_[3][2][132];        // [0] raw, [1] filtered: 0 .. 2n-1 left column bottom-to-top, 2n corner, 2n+1 .. 4n top row left-to-right
     __shared__ int16_t refa_[3][32 * 3 + 8];    // main reference of the angular modes, index 0 at refa[32]
-    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records, fetched once: the block loop touches no global memory but the residual
+    __shared__ HevcIntraTb s_tbs[kIntraMaxTbs];  // the CTB's block records, fetched once: the block loop touches no global memory at all (round 5)
+    // Round 5: the CTB's residual (k_hevc_iresid's planar int16 scratch) travels with the CTB's samples -- fetched into registers while the PREVIOUS CTB is
+    // worked on, put into LDS when this one starts.  Before, every block began with its own residual loads and ended waiting for them: one memory round
+    // trip per block on the dependency chain of the picture (~19 luma blocks per 64x64 CTB of an I picture).
+    __shared__ uint16_t s_list[3][kIntraMaxTbs];   // per colour plane: the indices of its blocks in s_tbs, in decoding order
+    __shared__ __align__(16) int16_t tr_y[64 * 64];
+    __shared__ __align__(16) int16_t tr_c[2][32 * 32];
     uint8_t *surf = pp.work_surf;
     uint8_t *cpl = surf + pp.chroma_offset;
     const int cs = 1 << pp.ctb_log2, y0 = cy << pp.ctb_log2, hc = cs >> 1, yc0 = y0 >> 1, pw = pp.w >> 1, ph = pp.h >> 1;
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // this thread's share of a CTB body: luma group (row yr, group yg), chroma group (row cr, group cg) -- at most one each (64x64: 256 + 128 groups)
     const int yr = tid / q, yg = tid - yr * q, cr = tid / q, cg = tid - cr * q;
     const bool y_mine = tid < cs * q, c_mine = tid < hc * q;
-    struct Pre { uint4 y, c; uint32_t ly, lc; };
+    struct Pre { uint4 y, c; uint32_t ly, lc; uint4 ry[2]; uint2 rc[2]; };
     auto de_interleave = [](const uint4 v, uint2 &cb, uint2 &crv) {
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
         uint32_t b2[2], r2[2];
@@ -369,6 +375,16 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         if (x0 > 0 && tid <= cs) { const int y = y0 + tid - 1; if (y >= 0 && y < pp.h) pre.ly = surf[(size_t)y * pp.pitch + x0 - 1]; }
         if (x0 > 0 && tid <= hc) { const int y = yc0 + tid - 1; if (y >= 0 && y < ph) pre.lc = *(const uint16_t *)(cpl + (size_t)y * pp.pitch + 2 * (xc0 - 1));
             }
+        // residual: luma 64 rows x 8 pieces of 8 int16 (two pieces per thread), chroma 2 planes x 32 rows x 4 pieces (one per thread, as two 8-byte loads:
+        // a chroma row starts at a multiple of 8 bytes only)
+        for (int t = 0; t < 2; t++) { const int pc = tid + 256 * t, row = pc >> 3, sg = pc & 7;
+            pre.ry[t] = make_uint4(0, 0, 0, 0);
+            if (row < cs && 8 * sg < cs && y0 + row < pp.h && x0 + 8 * sg < pp.w) pre.ry[t] = *(const uint4 *)(pp.resid + (size_t)(y0 + row) * pp.w + x0 + 8 * sg); }
+        { const int pl = tid >> 7, row = (tid & 127) >> 2, sg = tid & 3;
+            pre.rc[0] = pre.rc[1] = make_uint2(0, 0);
+            if (row < hc && 8 * sg < hc && yc0 + row < ph && xc0 + 8 * sg < pw) {
+                const int16_t *src = pp.resid + (size_t)pp.w * pp.h + (pl ? (size_t)pw * ph : 0) + (size_t)(yc0 + row) * pw + xc0 + 8 * sg;
+                pre.rc[0] = *(const uint2 *)src; pre.rc[1] = *(const uint2 *)(src + 4); } }
     };
     auto next_intra = [&](int from) { int c = from; while (c < c1 && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
     int cx = next_intra(c0), prev_cx = -2;
@@ -435,6 +451,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     if (y_mine) *(uint4 *)&ty[(yr + 1) * kYS + kYO + 16 * yg] = pre.y;
     if (c_mine) { uint2 cb, crv; de_interleave(pre.c, cb, crv); *(uint2 *)&tc[0][(cr + 1) * kCS + kCO + 8 * cg] = cb;
         *(uint2 *)&tc[1][(cr + 1) * kCS + kCO + 8 * cg] = crv; }
+    for (int t = 0; t < 2; t++) { const int pc = tid + 256 * t; *(uint4 *)&tr_y[(pc >> 3) * 64 + 8 * (pc & 7)] = pre.ry[t]; }
+    { int16_t *d = &tr_c[tid >> 7][((tid & 127) >> 2) * 32 + 8 * (tid & 3)]; *(uint2 *)d = pre.rc[0]; *(uint2 *)(d + 4) = pre.rc[1]; }
     if (x0 > 0 && tid >= 1 && tid <= cs) ty[tid * kYS + kYO - 1] = (uint8_t)keep_ly;
     if (x0 > 0 && tid >= 1 && tid <= hc) { tc[0][tid * kCS + kCO - 1] = (uint8_t)keep_lc; tc[1][tid * kCS + kCO - 1] = (uint8_t)(keep_lc >> 8); }
     if (tid == 128 && x0 > 0 && y0 > 0) ty[kYO - 1] = (uint8_t)keep_ly;
@@ -447,26 +465,35 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     lane = threadIdx.x & 63; nt = 64;
     if (wave < 3) {
     int16_t (*edge)[132] = edge_[wave]; int16_t *refa = refa_[wave];
-    const int rpw = wave ? pp.w >> 1 : pp.w;
-    const int16_t *rplane = pp.resid + (wave == 0 ? 0 : (size_t)pp.w * pp.h + (wave == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
-    for (int ti = 0; ti < n_tbs; ti++) {
+    const int16_t *rtile = wave ? tr_c[wave - 1] : tr_y; const int rts = wave ? 32 : 64;      // the CTB's residual in LDS
+    // this plane's blocks: a wave used to walk the CTB's whole list and skip the other planes' records (one LDS round trip each: ~46 per CTB of an I picture
+    // for ~19 luma blocks); it now compacts the indices of its own blocks once (ballot + prefix count)
+    int n_mine = 0;
+    if (tbs_in_lds) {
+        for (int b0 = 0; b0 < n_tbs; b0 += 64) {
+            const int idx = b0 + lane;
+            const bool mine = idx < n_tbs && s_tbs[idx].plane == wave;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if (mine) s_list[wave][n_mine + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)idx;
+            n_mine += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int tj = 0; tj < (tbs_in_lds ? n_mine : n_tbs); tj++) {
+        const int ti = tbs_in_lds ? (int)s_list[wave][tj] : tj;
         const HevcIntraTb tb = tbs_in_lds ? s_tbs[ti] : pp.itbs[ctb.intra_first + ti];
         if (tb.plane != wave) continue;
         const int log2 = tb.log2, n = 1 << log2, c = tb.plane, N = 4 * n, unit = c ? 2 : 4;
         const bool pcm = tb.mode == kHevcModePcm;
         uint8_t *tile = c ? tc[c - 1] : ty; const int ts = c ? kCS : kYS;
         const int lx = tb.x - (c ? x0 >> 1 : x0) + (c ? kCO : kYO), ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
-        // the block's residual (k_hevc_iresid) is fetched now and used at the end: its latency hides behind the prediction
-        int rv[16];
-        if (tb.coef_n) for (int i = 0; i < 16; i++) { const int k = lane + 64 * i;
-            if (k < n * n) rv[i] = rplane[(size_t)(tb.y + (k >> log2)) * rpw + tb.x + (k & (n - 1))]; }
+        const int16_t *rblk = rtile + (tb.y - (c ? y0 >> 1 : y0)) * rts + tb.x - (c ? x0 >> 1 : x0);      // the block's residual (k_hevc_iresid)
         const int16_t *e = edge[0];
         if (!pcm) {
             // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
             //      samples, so the substitute of an unavailable entry is found with bit scans over a mask of <= 33 segments ----
             const int U = 2 * n / unit;
-            uint64_t mask = 0;
-            for (int j = 0; j < U; j++) if ((tb.avail >> (U - 1 - j)) & 1) mask |= 1ull << j;
+            uint64_t mask = __brev(tb.avail << (32 - U));                // left units bottom to top: bit j = avail bit U - 1 - j (U <= 16)
             if (tb.flags & HTB_CORNER) mask |= 1ull << U;
             mask |= (uint64_t)((tb.avail >> 16) & ((1u << U) - 1)) << (U + 1);
             for (int i = lane; i <= N; i += nt) {
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                 v = fr ? ((32 - fr) * ref[b + idx + 1] + fr * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
                 if (c == 0 && n < 32 && ang == 0 && b == 0) v = clip1((vert ? T[0] : L[0]) + (((vert ? L[-a] : T[a]) - T[-1]) >> 1));
             }
-            if (tb.coef_n) v = clip1(v + rv[i]);
+            if (tb.coef_n) v = clip1(v + rblk[y * rts + x]);
             tile[(ly + y) * ts + lx + x] = (uint8_t)v;
         }
         __builtin_amdgcn_wave_barrier();

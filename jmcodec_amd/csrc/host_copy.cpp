@@ -99,8 +99,9 @@ HostCopier *HostCopier::get(int dev) {
                 tried++;
                 int good = 0;
                 for (int j = 0; j < 16; j++) { if (t[j] < 1e29 && t[j] <= 1.5 * best) good++; else if (t[j] < 1e29) slower_seen = true; }
-                // three good ones and a slower one seen, or six engines tried: stop (every engine ever used keeps a ~190 MB queue)
-                if ((good >= 3 && slower_seen) || tried >= 6) break;
+                // three good ones and a slower one seen: stop; after six engines stop as soon as three good ones are known (every engine ever used keeps
+                // a ~190 MB queue) -- but a box whose first six are busy or slow keeps looking until three are found or the list ends
+                if (good >= 3 && (slower_seen || tried >= 6)) break;
             }
         }
         (void)hipGetLastError();
@@ -115,6 +116,8 @@ HostCopier *HostCopier::get(int dev) {
         free(hbuf);
         if (dsrc) (void)hipFree(dsrc);
     }
+    if (c->n_engines_ < 3) fprintf(stderr, "jm_amd_dec: device %d: only %d copy engine(s) accepted for the output copies (host output of many streams will be "
+        "slower than the link)\n", dev, c->n_engines_);
     if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr,
         "jm_amd_dec: device %d: output copies on SDMA engines 0x%x 0x%x 0x%x (available 0x%x, host->device preference 0x%x, device->host preference 0x%x)\n",
         dev, c->engines_[0], c->engines_[1], c->engines_[2], avail, h2d, d2h);
@@ -169,7 +172,7 @@ HostCopier::Result HostCopier::copy(void *dst, const void *src, size_t n, uint64
             clock_gettime(CLOCK_MONOTONIC, &z);
             const long spun = (z.tv_sec - a.tv_sec) * 1000000000l + (z.tv_nsec - a.tv_nsec);
             if (v < 1) { typical_wait_ns_.store((typical * 7 + ts.tv_nsec + spun) / 8, std::memory_order_relaxed); return v == 0 ? kDone : kFailed; }
-            if (spun > 50000) { total_ns = ts.tv_nsec + spun; break; }
+            if (spun > 25000) { total_ns = ts.tv_nsec + spun; break; }      // (25 us at most: a CPU is burnt while looking -- many one-stream processes on a tight quota)
             __builtin_ia32_pause();
         }
         ts.tv_nsec = 15000;

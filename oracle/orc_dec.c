@@ -328,7 +328,9 @@ static int build_field_lists(OrcDec *d, const SliceHdr *sh) {
          * or of its only field. */
         Picture *ord[2][ORC_MAX_DPB + 1], *before[ORC_MAX_DPB + 1], *after[ORC_MAX_DPB + 1]; int nb = 0, na = 0;
         const int cur_poc = d->cur_store->fpoc[par];
-        for (int i = 0; i < nst; i++) { if (st[i]->poc <= cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
+        /* (pic_order_cnt_type 0: frames inferred from a gap in frame_num carry no order count and stay out, as in 8.2.4.2.3) */
+        for (int i = 0; i < nst; i++) { if (st[i]->non_existing && d->asps->poc_type == 0) continue;
+            if (st[i]->poc <= cur_poc) before[nb++] = st[i]; else after[na++] = st[i]; }
         for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) if (before[j]->poc > before[i]->poc) { Picture *t = before[i]; before[i] = before[j];
             before[j] = t; }
         for (int i = 0; i < na; i++) for (int j = i + 1; j < na; j++) if (after[j]->poc < after[i]->poc) { Picture *t = after[i]; after[i] = after[j];

@@ -2,7 +2,7 @@
 inlined function and per source line.  usage: python scratch/hostprof.py samples.txt [binary]"""
 import collections, subprocess, sys
 path = sys.argv[1]; binary = sys.argv[2] if len(sys.argv) > 2 else "tools/_build/host_bench"
-addrs = [hex(int(l, 16) + 0x200000) for l in open(path) if l.strip() != "other"]
+addrs = [hex(int(l, 16) + 0x200000) for l in open(path) if not l.startswith("other")]
 out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + binary, "-f", "-C", "-i"], input="\n".join(addrs), capture_output=True,
     text=True).stdout
 outer, inner, lines = collections.Counter(), collections.Counter(), collections.Counter()

@@ -104,3 +104,30 @@ def test_bench_extra_legs_parse_only(tmp_path):
         for k in ("kernel", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_us"):
             assert k in leg["roofline"]
         assert "cpu_ms_per_frame" in leg["host_cpu"]
+
+
+def test_bench_eight_ranks_gloo_parse_only():
+    """BASELINE config 5 at its real SHAPE on a host without a GPU: bench.py under the driver's launch line with 8 ranks (gloo, --parse-only), 8 streams per
+    rank -- 64 distinct streams, stream i -> rank i mod 8 (the reference is single-device, nv_dec/nv_dec.cpp:209), LOCAL_WORLD_SIZE 8 divides the
+    parse pool, rank 0 prints ONE JSON line whose frame count is the sum over the eight ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--parse-only", "--streams", "8", "--frames", "4", "--width",
+           "64", "--height", "48"]
+    env = dict(os.environ, JM_BENCH_CACHE=os.environ.get("TMPDIR", "/tmp"), OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["frames"] == 8 * 8 * 4                            # ranks x streams x frames x steps
+    assert d["config"]["stream_ids"] == [0, 56]                # rank 0 of 8: streams 0, 8, .., 56 of the job's 64
+    assert d["config"]["streams_per_gpu"] == 8
+    # the parse pool of a rank is its share of the node's CPUs: quota x 1.25 / LOCAL_WORLD_SIZE workers, never fewer than four (bench.py setup_process)
+    import bench
+    assert d["config"]["host_parse_threads"] == max(4, min(64, int(bench.quota_cpus() * 1.25 + 0.5) // 8))

@@ -33,7 +33,7 @@ def constants_in_sources(root):
     com = open(f"{root}/jmcodec_amd/csrc/chain_common.h").read()
     g = lambda pat, s: int(re.search(pat, s).group(1))
     return dict(BR=g(r"constexpr int kBandRows = (\d+);", deb), DEPTH=g(r"#define JM_DEBLOCK_DEPTH (\d+)", lds), PUB=g(r"#define JM_DEBLOCK_PUB (\d+)", lds),
-                KPUBLAG=g(r"constexpr int kPubLag = (\d+);", deb), ROW_LAG=g(r"#define JM_DEBLOCK_ROW_LAG (\d+)", com),
+                KPUBLAG=g(r"constexpr int kPubLag = (\d+);", deb), ROW_LAG=g(r"constexpr int kRowLag = (\d+);", com),
                 K_BAND_LAG=g(r"constexpr int kBandLag = (\d+),", eng), KEY_SLACK=g(r"kKeySlack = (\d+),", eng), INTRA_EXTRA=g(r"kIntraExtra = (\d+);", eng),
                 CHAIN_LAG=g(r"constexpr int kMinChainLag = (\d+);", engh))
 
