@@ -293,6 +293,15 @@ __global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
     for (int k = lane; k < n * n; k += 64) dst[(size_t)(tb.y + (k >> tb.log2)) * pw + tb.x + (k & (n - 1))] = r[k];
 }
 
+// sum of v over the 64 lanes of the wave, as a wave-uniform value: four DPP adds give every lane the total of its row of 16, four v_readlane add the rows
+__device__ __forceinline__ int wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);          // quad_perm [1 0 3 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);          // quad_perm [2 3 0 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);         // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);         // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 8.4.4.2: intra prediction (+ residual) of the intra blocks of one coding tree block, in decoding order
 // ------------------------------------------------------------------------------------------------------------
@@ -457,6 +466,11 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     if (x0 > 0 && tid >= 1 && tid <= hc) { tc[0][tid * kCS + kCO - 1] = (uint8_t)keep_lc; tc[1][tid * kCS + kCO - 1] = (uint8_t)(keep_lc >> 8); }
     if (tid == 128 && x0 > 0 && y0 > 0) ty[kYO - 1] = (uint8_t)keep_ly;
     if (tid == 129 && x0 > 0 && yc0 > 0) { tc[0][kCO - 1] = (uint8_t)keep_lc; tc[1][kCO - 1] = (uint8_t)(keep_lc >> 8); }
+    // Round 5: the NEXT coding tree block of the run is looked up and fetched here, in front of the block loop (everything fetched was final before the
+    // launch, the registers of `pre` are free again): its loads land while this CTB's blocks are predicted.  At the end of the iteration, where round 4 had
+    // them, the lookup and the issue cost 3 us per CTB on the picture's dependency chain (probe) and the first use of `pre` waited for memory.
+    const int next_cx = next_intra(cx + 1);
+    if (next_cx < c1) prefetch(next_cx, pre);
     __syncthreads();
     int lane, nt;
     // ---- block loop: the three colour planes are independent, so wavefront w runs the blocks of plane w on its own (wave-synchronous:
@@ -479,11 +493,25 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         }
         __builtin_amdgcn_wave_barrier();
     }
-    for (int tj = 0; tj < (tbs_in_lds ? n_mine : n_tbs); tj++) {
+    // (the NEXT block's record is fetched while this one is predicted: the index list and the record are two dependent LDS round trips)
+    const int n_loop = tbs_in_lds ? n_mine : n_tbs;
+    auto fetch_tb = [&](int tj) -> HevcIntraTb {
+        if (tj >= n_loop) return HevcIntraTb{};
         const int ti = tbs_in_lds ? (int)s_list[wave][tj] : tj;
-        const HevcIntraTb tb = tbs_in_lds ? s_tbs[ti] : pp.itbs[ctb.intra_first + ti];
+        return tbs_in_lds ? s_tbs[ti] : pp.itbs[ctb.intra_first + ti];
+    };
+    HevcIntraTb tv_next = fetch_tb(0);
+    for (int tj = 0; tj < n_loop; tj++) {
+        // the record is the same for every lane: through v_readfirstlane into scalar registers, so that everything that depends on the block's size and
+        // mode only -- loop bounds, the mode dispatch, the tile addresses -- is scalar code and scalar branches (round 5; before, each of those was
+        // an exec-mask region of vector compares on the dependency chain of the picture)
+        HevcIntraTb tb;
+        { uint32_t w[5]; __builtin_memcpy(w, &tv_next, 20);
+          for (int i = 0; i < 5; i++) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
+          __builtin_memcpy(&tb, w, 20); }
+        tv_next = fetch_tb(tj + 1);
         if (tb.plane != wave) continue;
-        const int log2 = tb.log2, n = 1 << log2, c = tb.plane, N = 4 * n, unit = c ? 2 : 4;
+        const int log2 = tb.log2, n = 1 << log2, c = wave, N = 4 * n, unit = c ? 2 : 4, ush = c ? 1 : 2;
         const bool pcm = tb.mode == kHevcModePcm;
         uint8_t *tile = c ? tc[c - 1] : ty; const int ts = c ? kCS : kYS;
         const int lx = tb.x - (c ? x0 >> 1 : x0) + (c ? kCO : kYO), ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
@@ -492,16 +520,17 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         if (!pcm) {
             // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
             //      samples, so the substitute of an unavailable entry is found with bit scans over a mask of <= 33 segments ----
-            const int U = 2 * n / unit;
+            const int U = (2 * n) >> ush;
             uint64_t mask = __brev(tb.avail << (32 - U));                // left units bottom to top: bit j = avail bit U - 1 - j (U <= 16)
             if (tb.flags & HTB_CORNER) mask |= 1ull << U;
             mask |= (uint64_t)((tb.avail >> 16) & ((1u << U) - 1)) << (U + 1);
+            const bool full = mask == ((2ull << (2 * U)) - 1);
             for (int i = lane; i <= N; i += nt) {
                 int v = 128;
                 if (mask) {
-                    const int sgm = i < 2 * n ? i / unit : (i == 2 * n ? U : U + 1 + (i - 2 * n - 1) / unit);
+                    const int sgm = i < 2 * n ? i >> ush : (i == 2 * n ? U : U + 1 + ((i - 2 * n - 1) >> ush));
                     int src = i;
-                    if (!((mask >> sgm) & 1)) {
+                    if (!full && !((mask >> sgm) & 1)) {                 // (full: every neighbour is available -- the usual case inside an I picture)
                         const uint64_t below = mask & ((1ull << sgm) - 1);
                         if (below) { const int t = 63 - __clzll((long long)below);
                             src = t < U ? t * unit + unit - 1 : (t == U ? 2 * n : 2 * n + 1 + (t - U - 1) * unit + unit - 1); }
@@ -536,7 +565,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         const int16_t *L = e + 2 * n - 1, *T = e + 2 * n + 1;      // L[-y] = left sample of row y, T[x] = top sample of column x, T[-1] = corner
         int ang = 0; bool vert = false;
         int dc = 0;
-        if (!pcm && tb.mode == 1) { int s = n; for (int i = 0; i < n; i++) s += L[-i] + T[i]; dc = s >> (log2 + 1); }
+        if (!pcm && tb.mode == 1) dc = (n + wave_sum(lane < n ? L[-lane] + T[lane] : 0)) >> (log2 + 1);      // (n <= 32: one entry of each edge per lane)
         if (!pcm && tb.mode >= 2) {
             ang = c_angle[tb.mode]; vert = tb.mode >= 18;
             const int inv = c_inv_angle[tb.mode], lo = ang < 0 ? (n * ang) >> 5 : 0;
@@ -549,24 +578,55 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             __builtin_amdgcn_wave_barrier();
         }
         const int16_t *ref = refa + 32;
-        for (int i = 0; i < 16; i++) {
+        // Round 5: a lane predicts FOUR neighbouring samples of a row and stores them as one dword (block positions are multiples of 4 in the tile).  A
+        // 32x32 block is 4 rounds of the wave instead of 16, each round's LDS reads (references, residual) are in flight together -- the byte-wise stores of
+        // the one-sample form may alias anything, so the compiler kept every round's reads behind the previous round's store: one LDS round trip per round
+        // on the dependency chain (probe: the prediction loop was half of a block's 2.9 us).
+        const int qsh = log2 - 2, nq = n << qsh, iters = (nq + 63) >> 6;      // quads per row = n / 4; n == 4: four lanes of one round
+#pragma unroll 1
+        for (int i = 0; i < iters; i++) {
             const int k = lane + 64 * i;
-            if (k >= n * n) break;
-            const int y = k >> log2, x = k & (n - 1);
-            int v;
-            if (pcm) v = 0;
-            else if (tb.mode == 0) v = ((n - 1 - x) * L[-y] + (x + 1) * T[n] + (n - 1 - y) * T[x] + (y + 1) * L[-n] + n) >> (log2 + 1);
-            else if (tb.mode == 1) {
-                v = dc;
-                if (c == 0 && n < 32) { if (x == 0 && y == 0) v = (L[0] + 2 * dc + T[0] + 2) >> 2; else if (y == 0) v = (T[x] + 3 * dc + 2) >> 2;
-                    else if (x == 0) v = (L[-y] + 3 * dc + 2) >> 2; }
+            if (k >= nq) break;
+            const int y = k >> qsh, x = (k & ((1 << qsh) - 1)) << 2;
+            int v[4];
+            if (pcm) { v[0] = v[1] = v[2] = v[3] = 0; }
+            else if (tb.mode == 0) {
+                const int ly_ = L[-y], tn = T[n], ln = L[-n];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = ((n - 1 - (x + j)) * ly_ + (x + j + 1) * tn + (n - 1 - y) * T[x + j] + (y + 1) * ln + n) >> (log2 + 1);
+            } else if (tb.mode == 1) {
+                v[0] = v[1] = v[2] = v[3] = dc;
+                if (c == 0 && n < 32) {
+                    if (y == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] = (T[x + j] + 3 * dc + 2) >> 2;
+                        if (x == 0) v[0] = (L[0] + 2 * dc + T[0] + 2) >> 2;
+                    } else if (x == 0) v[0] = (L[-y] + 3 * dc + 2) >> 2;
+                }
+            } else if (vert) {
+                // the row's offset and fraction are shared by its samples: five neighbouring references for four samples
+                const int pos = (y + 1) * ang, idx = pos >> 5, fr = pos & 31;
+                const int16_t *rp = ref + x + idx + 1;
+                const int r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
+                if (fr) { v[0] = ((32 - fr) * r0 + fr * r1 + 16) >> 5; v[1] = ((32 - fr) * r1 + fr * r2 + 16) >> 5; v[2] = ((32 - fr) * r2 + fr * r3 + 16) >> 5;
+                    v[3] = ((32 - fr) * r3 + fr * r4 + 16) >> 5; }
+                else { v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; }
+                if (c == 0 && n < 32 && ang == 0 && x == 0) v[0] = clip1(T[0] + ((L[-y] - T[-1]) >> 1));
             } else {
-                const int a = vert ? y : x, b = vert ? x : y, pos = (a + 1) * ang, idx = pos >> 5, fr = pos & 31;
-                v = fr ? ((32 - fr) * ref[b + idx + 1] + fr * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
-                if (c == 0 && n < 32 && ang == 0 && b == 0) v = clip1((vert ? T[0] : L[0]) + (((vert ? L[-a] : T[a]) - T[-1]) >> 1));
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int pos = (x + j + 1) * ang, idx = pos >> 5, fr = pos & 31;
+                    v[j] = fr ? ((32 - fr) * ref[y + idx + 1] + fr * ref[y + idx + 2] + 16) >> 5 : ref[y + idx + 1];
+                }
+                if (c == 0 && n < 32 && ang == 0 && y == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = clip1(L[0] + ((T[x + j] - T[-1]) >> 1));
+                }
             }
-            if (tb.coef_n) v = clip1(v + rblk[y * rts + x]);
-            tile[(ly + y) * ts + lx + x] = (uint8_t)v;
+            if (tb.coef_n) { const uint2 rr = *(const uint2 *)(rblk + y * rts + x);
+                v[0] = clip1(v[0] + (int)(short)(rr.x & 0xffffu)); v[1] = clip1(v[1] + ((int)rr.x >> 16)); v[2] = clip1(v[2] + (int)(short)(rr.y & 0xffffu));
+                v[3] = clip1(v[3] + ((int)rr.y >> 16)); }
+            *(uint32_t *)&tile[(ly + y) * ts + lx + x] = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -602,8 +662,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     }
     // rows of a CTB that reaches below the picture: the "bottom row" above lay outside, the last rows inside were written just now -- nobody waits for them
     prev_cx = cx;
-    cx = next_intra(cx + 1);
-    if (cx < c1) prefetch(cx, pre);
+    cx = next_cx;
     }   // CTBs of the row
 }
 

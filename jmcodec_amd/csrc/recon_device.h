@@ -523,22 +523,28 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         {   // chroma: lane -> (cx, cy), both planes
             int cx = lane & 7, cy = lane >> 3, rb = (cy >> 1) * 4 + (cx >> 1), b8 = (cy >> 2) * 2 + (cx >> 2);
             int s[2] = { rec_ref(r, b8), tail[b8] }, i0 = tail[4 + b8], i1 = tail[8 + b8];
-            int CW = W >> 1, CHh = H >> 1, pu[2] = {0, 0}, pv[2] = {0, 0};
+            // (round 5: a U V pair per 16-bit load and one v_dot4 per plane and list, as in the one-list paths -- the byte-wise form issued sixteen loads per lane)
+            int CW = W >> 1, CHh = H >> 1;
+            uint32_t puv[2] = {0, 0};                                   // per list: U | V << 8
 #pragma unroll
             for (int l = 0; l < 2; l++) {
                 if (s[l] < 0) continue;
-                int mvx = rec[l * 32 + rb * 2], mvy = rec[l * 32 + rb * 2 + 1] + chroma_mvy_offset(pp, s[l]);
+                const uint32_t mvw = *(const uint32_t *)(rec + l * 32 + rb * 2);
+                int mvx = (int16_t)(mvw & 0xffffu), mvy = (int)mvw >> 16;
+                mvy += chroma_mvy_offset(pp, s[l]);
                 const uint8_t *rc = ref_plane(pp, s[l]) + pp.chroma_offset;
                 int xi = mbx * 8 + cx + (mvx >> 3), yi = mby * 8 + cy + (mvy >> 3), fx = mvx & 7, fy = mvy & 7;
                 int xa = clip3(0, CW - 1, xi), xb = clip3(0, CW - 1, xi + 1), ya = clip3(0, CHh - 1, yi), yb = clip3(0, CHh - 1, yi + 1);
                 const uint8_t *r0 = rc + (size_t)ya * pitch, *r1 = rc + (size_t)yb * pitch;
-                int w00 = (8 - fx) * (8 - fy), w01 = fx * (8 - fy), w10 = (8 - fx) * fy, w11 = fx * fy;
-                pu[l] = (w00 * ld_ref8<COH>(refbuf, r0 + 2 * xa) + w01 * ld_ref8<COH>(refbuf, r0 + 2 * xb) +
-                         w10 * ld_ref8<COH>(refbuf, r1 + 2 * xa) + w11 * ld_ref8<COH>(refbuf, r1 + 2 * xb) + 32) >> 6;
-                pv[l] = (w00 * ld_ref8<COH>(refbuf, r0 + 2 * xa + 1) + w01 * ld_ref8<COH>(refbuf, r0 + 2 * xb + 1) +
-                         w10 * ld_ref8<COH>(refbuf, r1 + 2 * xa + 1) + w11 * ld_ref8<COH>(refbuf, r1 + 2 * xb + 1) + 32) >> 6;
+                const uint32_t wa = ld_ref16<COH>(refbuf, r0 + 2 * xa) | ld_ref16<COH>(refbuf, r0 + 2 * xb) << 16;
+                const uint32_t wb = ld_ref16<COH>(refbuf, r1 + 2 * xa) | ld_ref16<COH>(refbuf, r1 + 2 * xb) << 16;
+                puv[l] = pk::mc_chroma_uv(wa, wb, pk::chroma_weights(fx, fy));
             }
-            int u = combine(pu[0], pu[1], s[0] >= 0, s[1] >= 0, i0, i1, 1), v = combine(pv[0], pv[1], s[0] >= 0, s[1] >= 0, i0, i1, 2);
+            int u, v;
+            if (mode == 0) { const uint32_t uv = s[0] >= 0 ? (s[1] >= 0 ? pk::lerp(puv[0], puv[1], pk::kOnes) : puv[0]) : (s[1] >= 0 ? puv[1] : 0x8080u);
+                u = (int)(uv & 255u); v = (int)((uv >> 8) & 255u); }
+            else { u = combine((int)(puv[0] & 255u), (int)(puv[1] & 255u), s[0] >= 0, s[1] >= 0, i0, i1, 1);
+                v = combine((int)((puv[0] >> 8) & 255u), (int)((puv[1] >> 8) & 255u), s[0] >= 0, s[1] >= 0, i0, i1, 2); }
             if (has_res) { u = clip1(u + tiles[wave].c[0][cy * 8 + cx]); v = clip1(v + tiles[wave].c[1][cy * 8 + cx]); }
             ((uint16_t *)(ot + 64))[cy * 8 + cx] = (uint16_t)(u | (v << 8));
         }
