@@ -309,6 +309,7 @@ constexpr int kIntraThreads = 256;
 constexpr int kYS = 160, kCS = 80;              // LDS row strides of the luma / chroma tiles
 // column of the CTB's first sample inside a tile row (the left neighbour column sits just before): keeps 16- / 8-byte accesses aligned
 constexpr int kYO = 16, kCO = 8;
+constexpr int kIntraMaxRun = (8192 / 16 + kHevcIntraSegs - 1) / kHevcIntraSegs;      // CTBs of a run: a CTB row of the widest picture / segments
 constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 blocks (+ PCM planes)
 
 // The coding tree block lives in LDS while its intra blocks are reconstructed: tile row 0 / column 0 hold the samples above / left
@@ -327,7 +328,11 @@ constexpr int kIntraMaxTbs = 448;               // 64x64 CTB: <= 256 + 128 4x4 b
 // worked on), its left column (out of the previous tile when that was the neighbour), and the store of the rest of the tile (after the
 // counter is released; the next CTB's tile is filled from registers, so the stores drain meanwhile).
 __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParams *pics, int *progress, int prog_stride) {
-    const HevcPicParams &pp = pics[blockIdx.y];
+    // The picture's parameters through a CONSTANT-address-space reference: scalar loads the compiler may hoist and reuse.  Through the generic reference of
+    // rounds 1-4 every `pp.x` after a store was a vector load from memory followed by s_waitcnt vmcnt(0) -- one of them (`pp.strong_intra`) in the filter
+    // decision of every block, i.e. a memory round trip per block on the picture's dependency chain (round 5, found with wall-clock probes in the kernel).
+    typedef const __attribute__((address_space(4))) HevcPicParams ConstPic;
+    ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
     if (!(pp.stages & HPS_INTRA)) return;
     // Each CTB row is cut into kHevcIntraSegs runs of CTBs, one workgroup each (block index = row * segments + segment: whatever a workgroup waits
     // for -- CTBs of the row above, the last CTB of the run to its left -- has a smaller block index).  A run publishes "my CTBs up to column c are done"
@@ -346,6 +351,10 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // Round 5: the CTB's residual (k_hevc_iresid's planar int16 scratch) travels with the CTB's samples -- fetched into registers while the PREVIOUS CTB is
     // worked on, put into LDS when this one starts.  Before, every block began with its own residual loads and ended waiting for them: one memory round
     // trip per block on the dependency chain of the picture (~19 luma blocks per 64x64 CTB of an I picture).
+    __shared__ int16_t s_angle[35], s_inv_angle[35];   // intraPredAngle / invAngle by mode (Tables 8-4 / 8-5): LDS copies -- the __constant__ arrays are reached
+                                                       // with vector loads from memory, another round trip per angular block
+    __shared__ HevcCtb s_ctb[kIntraMaxRun];
+    __shared__ uint8_t s_edge_above[kIntraMaxRun + 4];
     __shared__ uint16_t s_list[3][kIntraMaxTbs];   // per colour plane: the indices of its blocks in s_tbs, in decoding order
     __shared__ __align__(16) int16_t tr_y[64 * 64];
     __shared__ __align__(16) int16_t tr_c[2][32 * 32];
@@ -395,12 +404,20 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                 const int16_t *src = pp.resid + (size_t)pp.w * pp.h + (pl ? (size_t)pw * ph : 0) + (size_t)(yc0 + row) * pw + xc0 + 8 * sg;
                 pre.rc[0] = *(const uint2 *)src; pre.rc[1] = *(const uint2 *)(src + 4); } }
     };
-    auto next_intra = [&](int from) { int c = from; while (c < c1 && !pp.ctbs[cy * pp.ctb_w + c].intra_count) c++; return c; };
+    if (tid < 35) { s_angle[tid] = c_angle[tid]; s_inv_angle[tid] = c_inv_angle[tid]; }
+    // the run's CTB records and the `intra_edge` flags around it (row above: columns c0 - 1 .. c1; this row: c0 - 1), once: the CTB loop looked them up in
+    // memory one dependent load at a time -- which CTB is next, its record, whom it waits for
+    for (int k = tid; k < (c1 - c0) * 8; k += kIntraThreads) ((uint32_t *)s_ctb)[k] = ((const uint32_t *)(pp.ctbs + cy * pp.ctb_w + c0))[k];
+    if (tid < c1 - c0 + 2) { const int col = c0 - 1 + tid;
+        s_edge_above[tid] = (cy > 0 && col >= 0 && col < pp.ctb_w) ? pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_edge : (uint8_t)0; }
+    if (tid == kIntraThreads - 1) s_edge_above[kIntraMaxRun + 2] = c0 > 0 ? pp.ctbs[cy * pp.ctb_w + c0 - 1].intra_edge : (uint8_t)0;
+    __syncthreads();
+    auto next_intra = [&](int from) { int c = from; while (c < c1 && !s_ctb[c - c0].intra_count) c++; return c; };
     int cx = next_intra(c0), prev_cx = -2;
     Pre pre;
     if (cx < c1) prefetch(cx, pre);
     while (cx < c1) {
-    const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];
+    const HevcCtb ctb = s_ctb[cx - c0];
     const int x0 = cx << pp.ctb_log2, xc0 = x0 >> 1;
     // ---- the left column out of the previous tile, when that CTB was the left neighbour (its samples may still be on their way to memory) ----
     uint32_t keep_ly = pre.ly, keep_lc = pre.lc;
@@ -416,8 +433,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     int need[kHevcIntraSegs + 1];
     for (int &v : need) v = 0;
     if (cy > 0) for (int col = cx > 0 ? cx - 1 : 0; col <= cx + 1 &&
-        col < pp.ctb_w; col++) if (pp.ctbs[(cy - 1) * pp.ctb_w + col].intra_edge & 1) need[col / seg_w] = col + 1;
-    const bool left_run = cx == c0 && cx > 0 && (pp.ctbs[cy * pp.ctb_w + cx - 1].intra_edge & 2);
+        col < pp.ctb_w; col++) if (s_edge_above[col - (c0 - 1)] & 1) need[col / seg_w] = col + 1;
+    const bool left_run = cx == c0 && cx > 0 && (s_edge_above[kIntraMaxRun + 2] & 2);
     if (left_run) need[kHevcIntraSegs] = cx;
     if (tid == 0) {
         // Relaxed polls and NO fence: what is handed over -- bottom rows, the last tile of a run -- is written through (st_wt16) before the counter moves,
@@ -567,17 +584,23 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         int dc = 0;
         if (!pcm && tb.mode == 1) dc = (n + wave_sum(lane < n ? L[-lane] + T[lane] : 0)) >> (log2 + 1);      // (n <= 32: one entry of each edge per lane)
         if (!pcm && tb.mode >= 2) {
-            ang = c_angle[tb.mode]; vert = tb.mode >= 18;
-            const int inv = c_inv_angle[tb.mode], lo = ang < 0 ? (n * ang) >> 5 : 0;
-            for (int i = lo + lane; i <= 2 * n; i += nt) {
-                int v;
-                if (i >= 0) v = vert ? T[i - 1] : L[-(i - 1)];
-                else { const int k = (i * inv + 128) >> 8; v = vert ? L[-(k - 1)] : T[k - 1]; }
-                refa[32 + i] = (int16_t)v;
+            ang = s_angle[tb.mode]; vert = tb.mode >= 18;
+            // the main reference array ref[] of 8.4.4.2.6 is the edge itself when the angle is not negative (ref[i] = T[i - 1] resp. L[-(i - 1)], i >= 0):
+            // only negative angles, which extend it below index 0 with projected samples of the other edge, build it in LDS (round 5)
+            if (ang < 0) {
+                const int inv = s_inv_angle[tb.mode], lo = (n * ang) >> 5;
+                for (int i = lo + lane; i <= 2 * n; i += nt) {
+                    int v;
+                    if (i >= 0) v = vert ? T[i - 1] : L[-(i - 1)];
+                    else { const int k = (i * inv + 128) >> 8; v = vert ? L[-(k - 1)] : T[k - 1]; }
+                    refa[32 + i] = (int16_t)v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
-        const int16_t *ref = refa + 32;
+        // ref[i] == rbase[rs * i]
+        const int16_t *rbase = ang < 0 ? refa + 32 : (vert ? T - 1 : L + 1);
+        const int rs = (ang < 0 || vert) ? 1 : -1;
         // Round 5: a lane predicts FOUR neighbouring samples of a row and stores them as one dword (block positions are multiples of 4 in the tile).  A
         // 32x32 block is 4 rounds of the wave instead of 16, each round's LDS reads (references, residual) are in flight together -- the byte-wise stores of
         // the one-sample form may alias anything, so the compiler kept every round's reads behind the previous round's store: one LDS round trip per round
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             } else if (vert) {
                 // the row's offset and fraction are shared by its samples: five neighbouring references for four samples
                 const int pos = (y + 1) * ang, idx = pos >> 5, fr = pos & 31;
-                const int16_t *rp = ref + x + idx + 1;
+                const int16_t *rp = rbase + x + idx + 1;                     // (vertical modes: rs == 1)
                 const int r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4];
                 if (fr) { v[0] = ((32 - fr) * r0 + fr * r1 + 16) >> 5; v[1] = ((32 - fr) * r1 + fr * r2 + 16) >> 5; v[2] = ((32 - fr) * r2 + fr * r3 + 16) >> 5;
                     v[3] = ((32 - fr) * r3 + fr * r4 + 16) >> 5; }
@@ -616,7 +639,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int pos = (x + j + 1) * ang, idx = pos >> 5, fr = pos & 31;
-                    v[j] = fr ? ((32 - fr) * ref[y + idx + 1] + fr * ref[y + idx + 2] + 16) >> 5 : ref[y + idx + 1];
+                    const int r0 = rbase[rs * (y + idx + 1)], r1 = rbase[rs * (y + idx + 2)];
+                    v[j] = fr ? ((32 - fr) * r0 + fr * r1 + 16) >> 5 : r0;
                 }
                 if (c == 0 && n < 32 && ang == 0 && y == 0) {
 #pragma unroll
