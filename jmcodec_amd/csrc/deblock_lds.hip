@@ -98,17 +98,12 @@ __global__ __launch_bounds__(kBandRows * 16) void k_deblock_band(const PicParams
 // ------------------------------------------------------------------------------------------
 bool deblock_lds_supported(int mb_w, int mb_h) { return mb_w > 0 && mb_h <= kBandRows * kDeblockMaxBands; }
 
-// (A/B builds: make EXTRA="-DJM_DEBLOCK_DEPTH=4 -DJM_DEBLOCK_PUB=1" OUT=../lib_dbg_x OBJ=../lib_dbg_x/obj)
-#ifndef JM_DEBLOCK_DEPTH
-// round 4: 2 measured 2 % faster than 3 (609-614 against 624-627 us per launch), 4 1 % slower (profiles/r04_ab7_chain_fixed.json)
-#define JM_DEBLOCK_DEPTH 2
-#endif
-#ifndef JM_DEBLOCK_PUB
-#define JM_DEBLOCK_PUB 2
-#endif
-int deblock_depth() { return JM_DEBLOCK_DEPTH; }
+// prefetch depth of the band kernels (steps in flight): 2 measured 2 % faster than 3 (609-614 against 624-627 us per launch), 4 1 % slower
+// (profiles/r04_ab7_chain_fixed.json); kDeblockPub: the band publishes its step counter every second step
+constexpr int kDeblockDepth = 2, kDeblockPub = 2;
+int deblock_depth() { return kDeblockDepth; }
 int deblock_row_lag() { return kRowLag; }     // steps between macroblock rows of the deblocking wavefront (Engine::launch orders chain work lists by it)
-int deblock_pub() { return JM_DEBLOCK_PUB; }
+int deblock_pub() { return kDeblockPub; }
 
 void launch_deblock_prep(const PicParams *d_pics, int n, int max_mbs, hipStream_t st) {
     hipLaunchKernelGGL(k_deblock_prep, dim3(((max_mbs + 7) / 8 + 7) & ~7, n), dim3(256), 0, st, d_pics);   // multiple of 8 (XCD bands)

@@ -416,16 +416,13 @@ void Engine::launch(Lane &ln, Batch &b) {
         //   mb_h + kIntraExtra keys later (needed: > mb_h + 7 at 1080p, > mb_h + 4 at 4K).  One such picture per IDR period: nothing measurable.
         const int band_rows = chain_band_rows(), L = deblock_row_lag();
         constexpr int kBandLag = 8, kKeySlack = 2, kIntraExtra = 24;
-#ifndef JM_CHAIN_KEY_MARGIN
-#define JM_CHAIN_KEY_MARGIN 0          // A/B builds: extra keys between consecutive pictures of a chain, beyond chain_lag
-#endif
         std::vector<int> base_of(n, 0), slope_of(n, L);
         size_t n_keys = 0;
         for (int i = 0; i < n; i++) {
             if (!(b.h_pics[i].stages & PS_CHAIN)) continue;
             slope_of[i] = (b.h_pics[i].stages & PS_CHAIN_INTRA) ? 2 : L;
             for (int j = i - 1; j >= 0; j--) if (b.pics[j].dec == b.pics[i].dec && (b.h_pics[j].stages & PS_CHAIN)) {
-                base_of[i] = base_of[j] + chain_lag_steps_ + kKeySlack + JM_CHAIN_KEY_MARGIN + slope_of[i] * b.pics[i].reach_rows + b.pics[i].reach_cols +
+                base_of[i] = base_of[j] + chain_lag_steps_ + kKeySlack + slope_of[i] * b.pics[i].reach_rows + b.pics[i].reach_cols +
                              kBandLag * ((b.pics[i].reach_rows + 1) / band_rows);
                 if (b.h_pics[j].stages & PS_CHAIN_INTRA) base_of[i] += b.h_pics[j].mb_h + kIntraExtra;
                 break; }

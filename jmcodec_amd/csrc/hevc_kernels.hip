@@ -553,9 +553,9 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                             src = t < U ? t * unit + unit - 1 : (t == U ? 2 * n : 2 * n + 1 + (t - U - 1) * unit + unit - 1); }
                         else { const int f = __ffsll((long long)mask) - 1; src = f < U ? f * unit : (f == U ? 2 * n : 2 * n + 1 + (f - U - 1) * unit); }
                     }
-                    if (src < 2 * n) v = tile[(ly + 2 * n - 1 - src) * ts + lx - 1];
-                    else if (src == 2 * n) v = tile[(ly - 1) * ts + lx - 1];
-                    else v = tile[(ly - 1) * ts + lx + src - 2 * n - 1];
+                    // entry src: left column bottom to top (src < 2n), corner (2n), top row left to right -- one read at (row, column), no branches
+                    const int d = src - 2 * n, trow = d < 0 ? ly - 1 - d : ly - 1, tcol = d <= 0 ? lx - 1 : lx - 1 + d;
+                    v = tile[trow * ts + tcol];
                 }
                 edge[0][i] = (int16_t)v;
             }

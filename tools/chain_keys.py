@@ -32,7 +32,7 @@ def constants_in_sources(root):
     lds = open(f"{root}/jmcodec_amd/csrc/deblock_lds.hip").read()
     com = open(f"{root}/jmcodec_amd/csrc/chain_common.h").read()
     g = lambda pat, s: int(re.search(pat, s).group(1))
-    return dict(BR=g(r"constexpr int kBandRows = (\d+);", deb), DEPTH=g(r"#define JM_DEBLOCK_DEPTH (\d+)", lds), PUB=g(r"#define JM_DEBLOCK_PUB (\d+)", lds),
+    return dict(BR=g(r"constexpr int kBandRows = (\d+);", deb), DEPTH=g(r"constexpr int kDeblockDepth = (\d+),", lds), PUB=g(r"kDeblockPub = (\d+);", lds),
                 KPUBLAG=g(r"constexpr int kPubLag = (\d+);", deb), ROW_LAG=g(r"constexpr int kRowLag = (\d+);", com),
                 K_BAND_LAG=g(r"constexpr int kBandLag = (\d+),", eng), KEY_SLACK=g(r"kKeySlack = (\d+),", eng), INTRA_EXTRA=g(r"kIntraExtra = (\d+);", eng),
                 CHAIN_LAG=g(r"constexpr int kMinChainLag = (\d+);", engh))
