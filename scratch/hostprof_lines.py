@@ -2,7 +2,7 @@
 optimised function under line 0).  usage: python scratch/hostprof_lines.py samples.txt function-substring [binary]"""
 import collections, subprocess, sys
 path, fn = sys.argv[1], sys.argv[2]; binary = sys.argv[3] if len(sys.argv) > 3 else "tools/_build/host_bench"
-addrs = [int(l, 16) + 0x200000 for l in open(path) if l.strip() != "other"]
+addrs = [int(l, 16) + 0x200000 for l in open(path) if not l.startswith("other")]
 c = collections.Counter(addrs)
 lines = [l.split(None, 2) for l in subprocess.run(["nm", "-C", "--defined-only", "-n", binary], capture_output=True, text=True).stdout.splitlines()]
 lo = hi = None
