@@ -534,6 +534,7 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
         const int lx = tb.x - (c ? x0 >> 1 : x0) + (c ? kCO : kYO), ly = tb.y - (c ? y0 >> 1 : y0) + 1;     // block origin inside the tile
         const int16_t *rblk = rtile + (tb.y - (c ? y0 >> 1 : y0)) * rts + tb.x - (c ? x0 >> 1 : x0);      // the block's residual (k_hevc_iresid)
         const int16_t *e = edge[0];
+        int dc_fused = 0; bool have_dc = false;
         if (!pcm) {
             // ---- neighbouring samples with substitution (8.4.4.2.2), every entry on its own lane: availability comes in units of 4 luma
             //      samples, so the substitute of an unavailable entry is found with bit scans over a mask of <= 33 segments ----
@@ -542,6 +543,34 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             if (tb.flags & HTB_CORNER) mask |= 1ull << U;
             mask |= (uint64_t)((tb.avail >> 16) & ((1u << U) - 1)) << (U + 1);
             const bool full = mask == ((2ull << (2 * U)) - 1);
+            if (full) {
+                // Every neighbour is available (the usual case inside an I picture): no substitution, so the smoothing filter (8.4.4.2.3) and the DC sum need
+                // not wait for a gathered copy of the edge -- a lane reads entry i and its two neighbours straight from the tile.  One phase (and one LDS
+                // round trip on the block's dependency chain) instead of gather -> barrier -> filter -> barrier -> DC sum (round 5).
+                auto raw = [&](int j) -> int { const int d = j - 2 * n, trow = d < 0 ? ly - 1 - d : ly - 1, tcol = d <= 0 ? lx - 1 : lx - 1 + d;
+                    return tile[trow * ts + tcol]; };
+                bool filt = false, strong = false;
+                if (c == 0 && tb.mode != 1 && n > 4) {
+                    const int dv = iabs(tb.mode - 26), dh = iabs(tb.mode - 10), md = dv < dh ? dv : dh, thr = n == 8 ? 7 : (n == 16 ? 1 : 0);
+                    filt = md > thr;
+                }
+                int e0 = 0, e64 = 0, e128 = 0;
+                if (filt && n == 32 && pp.strong_intra) { e0 = raw(0); e64 = raw(64); e128 = raw(128);
+                    strong = iabs(e64 + e128 - 2 * raw(96)) < 8 && iabs(e64 + e0 - 2 * raw(32)) < 8; }
+                int dcp = 0;
+                for (int i = lane; i <= N; i += nt) {
+                    const int v1 = raw(i);
+                    int v = v1;
+                    if (filt && i != 0 && i != N) {
+                        if (strong) v = i == 64 ? e64 : (i < 64 ? (i * e64 + (64 - i) * e0 + 32) >> 6 : ((128 - i) * e64 + (i - 64) * e128 + 32) >> 6);
+                        else v = (raw(i - 1) + 2 * v1 + raw(i + 1) + 2) >> 2;
+                    }
+                    if ((i >= n && i < 2 * n) || (i > 2 * n && i <= 3 * n)) dcp += v1;      // L[0 .. n-1] and T[0 .. n-1] (used by DC, which is never smoothed)
+                    edge[0][i] = (int16_t)v;
+                }
+                if (tb.mode == 1) { dc_fused = (n + wave_sum(dcp)) >> (log2 + 1); have_dc = true; }
+                __builtin_amdgcn_wave_barrier();
+            } else {
             for (int i = lane; i <= N; i += nt) {
                 int v = 128;
                 if (mask) {
@@ -578,11 +607,12 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            }   // !full
         }
         const int16_t *L = e + 2 * n - 1, *T = e + 2 * n + 1;      // L[-y] = left sample of row y, T[x] = top sample of column x, T[-1] = corner
         int ang = 0; bool vert = false;
         int dc = 0;
-        if (!pcm && tb.mode == 1) dc = (n + wave_sum(lane < n ? L[-lane] + T[lane] : 0)) >> (log2 + 1);      // (n <= 32: one entry of each edge per lane)
+        if (!pcm && tb.mode == 1) dc = have_dc ? dc_fused : (n + wave_sum(lane < n ? L[-lane] + T[lane] : 0)) >> (log2 + 1);   // (n <= 32: one entry of each edge per lane)
         if (!pcm && tb.mode >= 2) {
             ang = s_angle[tb.mode]; vert = tb.mode >= 18;
             // the main reference array ref[] of 8.4.4.2.6 is the edge itself when the angle is not negative (ref[i] = T[i - 1] resp. L[-(i - 1)], i >= 0):

@@ -473,23 +473,31 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             const int g = lane >> 4, l16 = lane & 15, rb0 = (g >> 1) * 8 + (g & 1) * 2;
             const int s0 = rec_ref(r, g), s1 = tail[g], i0 = tail[4 + g], i1 = tail[8 + g];
             uint32_t pa = 0, pb = 0;                               // the two predictions of this lane's four samples, one byte each
-            auto predict = [&](int slot, const short *m) -> uint32_t {
-                const int mvx = m[0], mvy = m[1];
+            // (round 5: BOTH lists' windows are fetched before either is filtered -- one memory round trip for the macroblock instead of two in a row)
+            struct Win { uint32_t w5[5]; int sh, fx, fy; };
+            auto fetch = [&](int slot, const short *m, Win &wn) {
+                const uint32_t mvw = *(const uint32_t *)m;
+                const int mvx = (int16_t)(mvw & 0xffffu), mvy = (int)mvw >> 16;
                 const int xi = mbx * 16 + (g & 1) * 8 + (mvx >> 2) - 2, yi = mby * 16 + (g >> 1) * 8 + (mvy >> 2) - 2, xa = xi & ~3;
                 const uint8_t *ref = ref_plane(pp, slot);
-                uint32_t w5[5];
 #pragma unroll
                 for (int t = 0; t < 5; t++) { const int i = min(l16 + 16 * t, 64), row = i / 5, dw = i % 5;
-                    w5[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + row) * pitch + xa + dw * 4)); }
+                    wn.w5[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + row) * pitch + xa + dw * 4)); }
+                wn.sh = xi & 3; wn.fx = mvx & 3; wn.fy = mvy & 3;
+            };
+            auto filter = [&](const Win &wn) -> uint32_t {
                 __builtin_amdgcn_wave_barrier();                   // (the block's window in LDS is reused for the second list: its readers are done)
-                stage_window(&wins[wave][g][0], w5, l16);
+                stage_window(&wins[wave][g][0], wn.w5, l16);
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t pv = pk::mc_luma4(&wins[wave][g][0], 5, l16 >> 1, 4 * (l16 & 1) + (xi & 3), mvx & 3, mvy & 3);
+                const uint32_t pv = pk::mc_luma4(&wins[wave][g][0], 5, l16 >> 1, 4 * (l16 & 1) + wn.sh, wn.fx, wn.fy);
                 __builtin_amdgcn_wave_barrier();
                 return pv;
             };
-            if (s0 >= 0) pa = predict(s0, rec + rb0 * 2);
-            if (s1 >= 0) pb = predict(s1, rec + 32 + rb0 * 2);
+            Win wa, wb;
+            if (s0 >= 0) fetch(s0, rec + rb0 * 2, wa);
+            if (s1 >= 0) fetch(s1, rec + 32 + rb0 * 2, wb);
+            if (s0 >= 0) pa = filter(wa);
+            if (s1 >= 0) pb = filter(wb);
             const int rr = l16 >> 1, hh = l16 & 1, px = (g & 1) * 8 + hh * 4, py = (g >> 1) * 8 + rr;
             uint32_t pred;
             if (mode == 0) pred = s0 >= 0 ? (s1 >= 0 ? pk::lerp(pa, pb, pk::kOnes) : pa) : (s1 >= 0 ? pb : pk::kSign);   // default: the rounded average, or the one list

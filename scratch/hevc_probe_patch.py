@@ -12,10 +12,10 @@ rep('__constant__ uint8_t c_beta[52], c_tc[54], c_qpc[58];', '''__constant__ uin
 __device__ unsigned long long g_probe[32];
 #define PROBE(i, t0) do { if (threadIdx.x == 0) { unsigned long long t1_ = wall_clock64(); atomicAdd(&g_probe[i], t1_ - (t0)); (t0) = t1_; } } while (0)''')
 rep('''    while (cx < c1) {
-    const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];''', '''    unsigned long long tp = wall_clock64();
+    const HevcCtb ctb = s_ctb[cx - c0];''', '''    unsigned long long tp = wall_clock64();
     while (cx < c1) {
     PROBE(0, tp);
-    const HevcCtb ctb = pp.ctbs[cy * pp.ctb_w + cx];''')
+    const HevcCtb ctb = s_ctb[cx - c0];''')
 rep('''    __syncthreads();                                              // (also: everybody is done with the previous tile)
     const int n_tbs = (int)ctb.intra_count;''', '''    __syncthreads();                                              // (also: everybody is done with the previous tile)
     PROBE(1, tp);
@@ -45,8 +45,8 @@ rep('''            __builtin_amdgcn_wave_barrier();
             // ---- filtering (8.4.4.2.3) ----''')
 rep('''        const int16_t *L = e + 2 * n - 1, *T = e + 2 * n + 1;''', '''        PROBE(10, tq);
         const int16_t *L = e + 2 * n - 1, *T = e + 2 * n + 1;''')
-rep('''        const int16_t *ref = refa + 32;''', '''        PROBE(11, tq);
-        const int16_t *ref = refa + 32;''')
+rep('''        // ref[i] == rbase[rs * i]''', '''        PROBE(11, tq);
+        // ref[i] == rbase[rs * i]''')
 rep('''        __builtin_amdgcn_wave_barrier();
     }
     }   // wave < 3''', '''        __builtin_amdgcn_wave_barrier();
