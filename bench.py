@@ -429,7 +429,7 @@ def measure(args, ctx):
     traffic_file = None
     try:
         tag = f"hevc_{args.width}x{args.height}" if args.codec == "hevc" else f"h264_{args.tools}_{args.width}x{args.height}"
-        cands = [f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json"]
+        cands = [f"r05_pmc_traffic_{tag}.json", f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json"]
         if tag == "h264_baseline_1920x1080":
             cands.append("r02_pmc_traffic.json")
         pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in cands) if os.path.exists(p))

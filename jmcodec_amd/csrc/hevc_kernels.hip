@@ -366,7 +366,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     // this thread's share of a CTB body: luma group (row yr, group yg), chroma group (row cr, group cg) -- at most one each (64x64: 256 + 128 groups)
     const int yr = tid / q, yg = tid - yr * q, cr = tid / q, cg = tid - cr * q;
     const bool y_mine = tid < cs * q, c_mine = tid < hc * q;
-    struct Pre { uint4 y, c; uint32_t ly, lc; uint4 ry[2]; uint2 rc[2]; };
+    // tb[]: the first 3 x 256 dwords of the CTB's block records (153 of the 20-byte records; CTBs with more fetch the rest when they start)
+    struct Pre { uint4 y, c; uint32_t ly, lc; uint4 ry[2]; uint2 rc[2]; uint32_t tb[3]; };
     auto de_interleave = [](const uint4 v, uint2 &cb, uint2 &crv) {
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
         uint32_t b2[2], r2[2];
@@ -403,6 +404,8 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
             if (row < hc && 8 * sg < hc && yc0 + row < ph && xc0 + 8 * sg < pw) {
                 const int16_t *src = pp.resid + (size_t)pp.w * pp.h + (pl ? (size_t)pw * ph : 0) + (size_t)(yc0 + row) * pw + xc0 + 8 * sg;
                 pre.rc[0] = *(const uint2 *)src; pre.rc[1] = *(const uint2 *)(src + 4); } }
+        { const HevcCtb &cn = s_ctb[cxn - c0]; const int nd = (int)cn.intra_count * 5; const uint32_t *src = (const uint32_t *)(pp.itbs + cn.intra_first);
+            for (int t = 0; t < 3; t++) { const int k = tid + kIntraThreads * t; pre.tb[t] = (cn.intra_count <= (uint32_t)kIntraMaxTbs && k < nd) ? src[k] : 0u; } }
     };
     if (tid < 35) { s_angle[tid] = c_angle[tid]; s_inv_angle[tid] = c_inv_angle[tid]; }
     // the run's CTB records and the `intra_edge` flags around it (row above: columns c0 - 1 .. c1; this row: c0 - 1), once: the CTB loop looked them up in
@@ -450,8 +453,10 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
     const int n_tbs = (int)ctb.intra_count;
     const bool tbs_in_lds = n_tbs <= kIntraMaxTbs;
     if (tbs_in_lds) {
+        // (the records came with the CTB's prefetch -- `pre.tb`, 3 dwords per thread --; only a CTB with more than 153 blocks fetches the rest here)
         const uint32_t *src = (const uint32_t *)(pp.itbs + ctb.intra_first); uint32_t *dstw = (uint32_t *)s_tbs;      // 20-byte records, 4-byte aligned
-        for (int k = tid; k < n_tbs * 5; k += kIntraThreads) dstw[k] = src[k];
+        for (int t = 0; t < 3; t++) { const int k = tid + kIntraThreads * t; if (k < n_tbs * 5) dstw[k] = pre.tb[t]; }
+        for (int k = tid + 3 * kIntraThreads; k < n_tbs * 5; k += kIntraThreads) dstw[k] = src[k];
     }
     // ---- the row above (two CTB widths): the one load on the dependency chain ----
     auto ld16_coh = [](const uint8_t *p) {
