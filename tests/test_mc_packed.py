@@ -118,3 +118,17 @@ def test_lerp_is_the_rounded_average(lib):
         a, b = (int(v) for v in rng.integers(0, 2 ** 32, size=2, dtype=np.uint64))
         got = lib.mcp_lerp(a, b)
         assert [(got >> (8 * k)) & 255 for k in range(4)] == [((((a >> (8 * k)) & 255) + ((b >> (8 * k)) & 255) + 1) >> 1) for k in range(4)]
+
+
+def test_macroblock_row_by_multiplication():
+    """k_recon_inter takes the macroblock row as mulhi(address, ceil(2^32 / mb_w)) (PicParams.mb_w_magic, decoder.cpp; 0 stands for mb_w == 1).  The parser
+    admits pictures of up to 1024 x 1024 macroblocks (h264_syntax.cpp); the identity must hold for every address of every such picture."""
+    for mb_w in range(2, 1025):
+        magic = ((1 << 32) + mb_w - 1) // mb_w
+        assert magic < (1 << 32)
+        n = np.arange(0, mb_w * 1024, dtype=np.uint64)
+        # the addresses of whole pictures: first / last of each row are the critical ones, but all are cheap enough at a stride
+        step = 1 if mb_w < 64 else 7
+        n = np.concatenate([n[::step], np.arange(mb_w - 1, mb_w * 1024, mb_w, dtype=np.uint64), np.arange(0, mb_w * 1024, mb_w, dtype=np.uint64)])
+        assert np.array_equal((n * np.uint64(magic)) >> np.uint64(32), n // np.uint64(mb_w)), mb_w
+    assert (((1 << 32) + 1 - 1) // 1) & 0xffffffff == 0                 # mb_w == 1: the 32-bit field reads 0, the kernel then takes row = address
