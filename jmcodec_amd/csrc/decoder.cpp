@@ -348,6 +348,7 @@ void Decoder::gpu_free_sequence() {
     free_surfaces();
     if (resid_) { hipFree(resid_); resid_ = nullptr; }
     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+    if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
     free_job_buffers();
     free_out_slots(true);
 }
@@ -423,6 +424,14 @@ bool Decoder::gpu_alloc_sequence() {
         if (!HIP_OK(hipMalloc((void **)&resid_, n_mbs * 768 * kHevcWorkSets))) { fail("hipMalloc(scratch) failed"); return false; }
         for (auto &w : hevc_work_) { if (!HIP_OK(hipMalloc((void **)&w, surf_bytes_))) { fail("hipMalloc(work surface) failed"); return false; }
             hipMemset(w, 128, surf_bytes_); }
+        {   // boundary strengths on the device: pu_map (4 B per 4x4 cell), four flag planes (1 B each), bs_v, bs_h -- every part 256-byte aligned
+            const size_t cells = (size_t)mb_w_ * 4 * mb_h_ * 4, al = 255;
+            hevc_bs_off_[0] = 0; hevc_bs_off_[1] = (cells * 4 + al) & ~al; hevc_bs_off_[2] = hevc_bs_off_[1] + ((cells * 4 + al) & ~al);
+            hevc_bs_off_[3] = hevc_bs_off_[2] + ((cells / 2 + al) & ~al);                     // bs_v: (w / 8) x (h / 4) = cells / 2; bs_h the same
+            hevc_bs_set_bytes_ = hevc_bs_off_[3] + ((cells / 2 + al) & ~al);
+            if (!HIP_OK(hipMalloc((void **)&hevc_bs_, hevc_bs_set_bytes_ * kHevcWorkSets))) { fail("hipMalloc(strength maps) failed"); return false; }
+            hipMemset(hevc_bs_, 0, hevc_bs_set_bytes_ * kHevcWorkSets);
+        }
     }
     NumaPreferred on_gpu_node(numa_node_);          // the page-locked job buffers (and output slots) of this handle: memory of the GPU's node
     for (auto &j : jobs_) {
@@ -604,7 +613,9 @@ bool Decoder::activate(const SeqParams &sps) {
             free_surfaces();
                     if (resid_) { hipFree(resid_); resid_ = nullptr; }
                     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+    if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
     for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+    if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
             free_job_buffers();
             free_out_slots(false);
         } else free_job_buffers();

@@ -64,7 +64,7 @@ struct HevcTask {
     HevcSps sps; HevcPps pps; int poc = 0, work_slot = -1;
     std::vector<HevcSliceTask> slices;
     std::shared_ptr<HevcColMotion> col_out;
-    size_t off_ctbs = 0, off_qp8 = 0, off_bsv = 0, off_bsh = 0, off_pus = 0, off_tbs = 0, off_itbs = 0, off_coefs = 0, off_wps = 0;
+    size_t off_ctbs = 0, off_qp8 = 0, off_pus = 0, off_tbs = 0, off_itbs = 0, off_coefs = 0, off_wps = 0;
     int n_pus = 0, n_tbs = 0, n_itbs = 0; bool any_sao = false, any_deblock = false;
 };
 
@@ -249,6 +249,8 @@ private:
     uint8_t *resid_ = nullptr; bool use_lds_intra_ = false; bool lds_intra8_ = false;
     // HEVC: pre-SAO work surfaces (resid_ holds as many residual scratches)
     uint8_t *hevc_work_[kHevcWorkSets] = {nullptr, nullptr, nullptr, nullptr}; unsigned hevc_work_rr_ = 0;
+    // HEVC boundary strengths on the device (round 5): per work set the 4x4-cell maps and the strength arrays (hevc_jobs.h HevcPicParams)
+    uint8_t *hevc_bs_ = nullptr; size_t hevc_bs_set_bytes_ = 0, hevc_bs_off_[4] = {0, 0, 0, 0};
     int pitch_ = 0, chroma_off_ = 0; size_t surf_bytes_ = 0, frame_bytes_ = 0, job_cap_ = 0, job_cap_max_ = 0;
     std::atomic<size_t> i_job_peak_{0};            // largest job list of an I picture of this handle so far (+ slack): what a slot grows to for the next one
     std::atomic<long long> stat_job_regrown_{0};   // job slots grown (a few per handle while the slots reach their working size)

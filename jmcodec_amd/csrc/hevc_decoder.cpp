@@ -94,6 +94,7 @@ bool Decoder::hevc_activate(const HevcSps &sps) {
             free_surfaces();
             if (resid_) { hipFree(resid_); resid_ = nullptr; }
             for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+            if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
             for (auto &j : jobs_) { if (j.host) hipHostFree(j.host); if (j.dev) hipFree(j.dev); if (j.uploaded) hipEventDestroy(j.uploaded); j = JobSlot(); }
             free_out_slots(false);
         } else for (auto &j : jobs_) { free(j.host); j = JobSlot(); }
@@ -269,8 +270,7 @@ void Decoder::hevc_parse_task(PicTask *t) {
     // pack: every array 16-byte aligned
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return o; };
-    ht.off_ctbs = place(jobs.ctbs.size() * sizeof(HevcCtb)); ht.off_qp8 = place(jobs.qp8.size()); ht.off_bsv = place(jobs.bs_v.size());
-    ht.off_bsh = place(jobs.bs_h.size());
+    ht.off_ctbs = place(jobs.ctbs.size() * sizeof(HevcCtb)); ht.off_qp8 = place(jobs.qp8.size());
     ht.off_pus = place(jobs.pus.size() * sizeof(HevcPu)); ht.off_tbs = place(jobs.tbs.size() * sizeof(HevcTb));
     ht.off_itbs = place(jobs.itbs.size() * sizeof(HevcIntraTb));
     ht.off_coefs = place(jobs.coefs.size() * 4); ht.off_wps = place(jobs.wps.size() * sizeof(HevcWp));
@@ -281,8 +281,7 @@ void Decoder::hevc_parse_task(PicTask *t) {
     else {
         auto put = [&](size_t o, const void *p, size_t bytes) { if (bytes) memcpy(js.host + o, p, bytes); };
         put(ht.off_ctbs, jobs.ctbs.data(), jobs.ctbs.size() * sizeof(HevcCtb)); put(ht.off_qp8, jobs.qp8.data(), jobs.qp8.size());
-        put(ht.off_bsv, jobs.bs_v.data(), jobs.bs_v.size());
-        put(ht.off_bsh, jobs.bs_h.data(), jobs.bs_h.size()); put(ht.off_pus, jobs.pus.data(), jobs.pus.size() * sizeof(HevcPu));
+        put(ht.off_pus, jobs.pus.data(), jobs.pus.size() * sizeof(HevcPu));
         put(ht.off_tbs, jobs.tbs.data(), jobs.tbs.size() * sizeof(HevcTb));
         put(ht.off_itbs, jobs.itbs.data(), jobs.itbs.size() * sizeof(HevcIntraTb)); put(ht.off_coefs, jobs.coefs.data(), jobs.coefs.size() * 4);
         put(ht.off_wps, jobs.wps.data(), jobs.wps.size() * sizeof(HevcWp));
@@ -290,8 +289,8 @@ void Decoder::hevc_parse_task(PicTask *t) {
         if (want_job_digest_) {                              // tests (pictures are parsed in order: sync option): the arrays as the device gets them
             uint64_t h = job_digest_;
             auto eat = [&](size_t o, size_t n) { const uint8_t *b = js.host + o; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
-            eat(ht.off_ctbs, jobs.ctbs.size() * sizeof(HevcCtb)); eat(ht.off_qp8, jobs.qp8.size()); eat(ht.off_bsv, jobs.bs_v.size());
-            eat(ht.off_bsh, jobs.bs_h.size()); eat(ht.off_pus, jobs.pus.size() * sizeof(HevcPu)); eat(ht.off_tbs, jobs.tbs.size() * sizeof(HevcTb));
+            eat(ht.off_ctbs, jobs.ctbs.size() * sizeof(HevcCtb)); eat(ht.off_qp8, jobs.qp8.size());
+            eat(ht.off_pus, jobs.pus.size() * sizeof(HevcPu)); eat(ht.off_tbs, jobs.tbs.size() * sizeof(HevcTb));
             eat(ht.off_itbs, jobs.itbs.size() * sizeof(HevcIntraTb)); eat(ht.off_coefs, jobs.coefs.size() * 4);
             eat(ht.off_wps, jobs.wps.size() * sizeof(HevcWp));
             job_digest_ = h;
@@ -321,7 +320,9 @@ void Decoder::hevc_fill_engine_pic(PicTask *t, EnginePic &ep) {
     hp.cur = t->cur_slot; hp.work = ht.work_slot;
     hp.work_surf = ht.any_sao ? hevc_work_[ht.work_slot] : surf_[t->cur_slot];
     for (int i = 0; i < kMaxSurfaces; i++) hp.surf[i] = surf_[i];
-    hp.ctbs = (const HevcCtb *)(js.dev + ht.off_ctbs); hp.qp8 = js.dev + ht.off_qp8; hp.bs_v = js.dev + ht.off_bsv; hp.bs_h = js.dev + ht.off_bsh;
+    hp.ctbs = (const HevcCtb *)(js.dev + ht.off_ctbs); hp.qp8 = js.dev + ht.off_qp8;
+    { uint8_t *set = hevc_bs_ + (size_t)ht.work_slot * hevc_bs_set_bytes_;
+      hp.pu_map = (uint32_t *)(set + hevc_bs_off_[0]); hp.cell_flags = set + hevc_bs_off_[1]; hp.bs_v = set + hevc_bs_off_[2]; hp.bs_h = set + hevc_bs_off_[3]; }
     hp.pus = (const HevcPu *)(js.dev + ht.off_pus); hp.n_pus = ht.n_pus; hp.tbs = (const HevcTb *)(js.dev + ht.off_tbs); hp.n_tbs = ht.n_tbs;
     hp.itbs = (const HevcIntraTb *)(js.dev + ht.off_itbs); hp.n_itbs = ht.n_itbs; hp.coefs = (const uint32_t *)(js.dev + ht.off_coefs);
     hp.wps = (const HevcWp *)(js.dev + ht.off_wps); hp.resid = (int16_t *)(resid_ + (size_t)ht.work_slot * ((size_t)mb_w_ * mb_h_ * 768));

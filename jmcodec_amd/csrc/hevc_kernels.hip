@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
     const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD-aware, see k_hevc_mc
     if (!(pp.stages & HPS_RESID) || job >= pp.n_tbs) return;
     const HevcTb tb = pp.tbs[job];
+    if (!tb.coef_n) return;                                           // (a luma block whose levels all scaled to zero: listed for the boundary strengths only)
     // Cb and Cr of a transform unit are interleaved in memory and are two entries of the list, one behind the other when both are coded (transform_unit()
     // emits c = 1, then c = 2).  The Cb workgroup takes its Cr partner along, so the pair leaves as whole dwords (Cb Cr Cb Cr) instead of byte-wise
     // read-modify-writes of two workgroups on the same lines; a component whose partner is not coded does the same with a zero residual for the other half
@@ -726,6 +727,103 @@ __global__ __launch_bounds__(kIntraThreads) void k_hevc_intra(const HevcPicParam
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// 8.7.2.3 / 8.7.2.4: which edges are filtered and how strongly -- on the device since round 5 (the host spent 9 % of its parse time per picture on it)
+// ------------------------------------------------------------------------------------------------------------
+// The job lists already say everything the derivation needs: where the prediction blocks lie and what their motion is (HevcPu), where the intra blocks lie
+// (HevcIntraTb, luma entries) and where the luma transform blocks with cbf_luma = 1 lie (HevcTb, luma entries).  k_hevc_bs_raster paints them into maps of
+// 4x4 cells; k_hevc_bs reads the maps per 4-sample edge segment of the 8x8 grid and writes bs_v / bs_h in the layout k_hevc_deblock has always read:
+//   an edge exists where a painted block ends (flag planes 2 / 3: the left / top edge of a cell is the edge of an intra or coded block -- painted on the
+//   block's own first column / row AND on the cells behind its last ones) or where two different prediction blocks meet;
+//   bS 2: p0 or q0 intra; 1: a transform edge with coefficients on either side, or different motion (8.7.2.4); else 0.
+// (The lists hold prediction blocks cut into pieces of at most 16x16 and no transform blocks without coefficients: edges between pieces of one
+// prediction block compare equal motion and give 0, and a transform edge between two blocks without coefficients inside one prediction block gives 0 by
+// the clause itself.)  What the lists cannot say is in HevcCtb.db_flags.  All plain stores of the value 1 / of a block's own index: no atomics needed.
+__global__ __launch_bounds__(256) void k_hevc_bs_clear(const HevcPicParams *pics) {
+    typedef const __attribute__((address_space(4))) HevcPicParams ConstPic;
+    ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
+    if (!(pp.stages & HPS_DEBLOCK)) return;
+    const int n16 = ((pp.w >> 2) * (pp.h >> 2)) >> 2;                // 4 planes x cells bytes = cells / 4 uint4
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) ((uint4 *)pp.cell_flags)[i] = make_uint4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void k_hevc_bs_raster(const HevcPicParams *pics) {
+    typedef const __attribute__((address_space(4))) HevcPicParams ConstPic;
+    ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
+    if (!(pp.stages & HPS_DEBLOCK)) return;
+    const int w4 = pp.w >> 2, h4 = pp.h >> 2, cells = w4 * h4;
+    uint8_t *f_intra = pp.cell_flags, *f_cbf = f_intra + cells, *f_l = f_cbf + cells, *f_t = f_l + cells;
+    uint32_t *pu_map = pp.pu_map;
+    const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int i = gid; i < pp.n_pus; i += stride) {
+        const HevcPu pu = pp.pus[i];
+        const int cx0 = pu.x >> 2, cy0 = pu.y >> 2, nx = pu.w >> 2, ny = pu.h >> 2;
+        for (int r = 0; r < ny; r++) for (int k = 0; k < nx; k++) pu_map[(cy0 + r) * w4 + cx0 + k] = (uint32_t)i;
+    }
+    auto mark = [&](int x, int y, int n, uint8_t *own) {
+        const int cx0 = x >> 2, cy0 = y >> 2, nu = n >> 2;
+        for (int r = 0; r < nu; r++) {
+            uint8_t *o = own + (cy0 + r) * w4 + cx0;
+            for (int k = 0; k < nu; k++) o[k] = 1;
+            f_l[(cy0 + r) * w4 + cx0] = 1;
+            if (cx0 + nu < w4) f_l[(cy0 + r) * w4 + cx0 + nu] = 1;
+        }
+        for (int k = 0; k < nu; k++) { f_t[cy0 * w4 + cx0 + k] = 1; if (cy0 + nu < h4) f_t[(cy0 + nu) * w4 + cx0 + k] = 1; }
+    };
+    for (int i = gid; i < pp.n_itbs; i += stride) { const HevcIntraTb tb = pp.itbs[i]; if (tb.plane == 0) mark(tb.x, tb.y, 1 << tb.log2, f_intra); }
+    for (int i = gid; i < pp.n_tbs; i += stride) { const HevcTb tb = pp.tbs[i]; if (tb.plane == 0) mark(tb.x, tb.y, 1 << tb.log2, f_cbf); }
+}
+// blockIdx.z = direction: 0 vertical edges (x = 8k, one entry per 4 rows), 1 horizontal edges (y = 8k, one entry per 4 columns)
+__global__ __launch_bounds__(256) void k_hevc_bs(const HevcPicParams *pics) {
+    typedef const __attribute__((address_space(4))) HevcPicParams ConstPic;
+    ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
+    if (!(pp.stages & HPS_DEBLOCK)) return;
+    const int dir = (int)blockIdx.z;
+    const int w8 = pp.w >> 3, w4 = pp.w >> 2, h4 = pp.h >> 2, h8 = pp.h >> 3, cells = w4 * h4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int x, y;
+    if (dir == 0) { if (idx >= w8 * h4) return; x = (idx % w8) * 8; y = (idx / w8) * 4; }
+    else { if (idx >= w4 * h8) return; x = (idx % w4) * 4; y = (idx / w4) * 8; }
+    uint8_t *out = dir ? pp.bs_h + idx : pp.bs_v + idx;
+    int bs = 0;
+    do {
+        if (dir ? y == 0 : x == 0) break;                             // picture boundary
+        const int lg = pp.ctb_log2, cs = 1 << lg, xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
+        const int fq = pp.ctbs[(y >> lg) * pp.ctb_w + (x >> lg)].db_flags, fp = pp.ctbs[(yp >> lg) * pp.ctb_w + (xp >> lg)].db_flags;
+        if (fq & (HDB_DISABLED | HDB_CONCEALED)) break;
+        if (((dir ? y : x) & (cs - 1)) == 0 && (fq & (dir ? HDB_NO_TOP : HDB_NO_LEFT))) break;
+        const uint8_t *f_intra = pp.cell_flags, *f_cbf = f_intra + cells, *f_edge = f_intra + (dir ? 3 : 2) * cells;
+        const int q = (y >> 2) * w4 + (x >> 2), p = dir ? q - w4 : q - 1;
+        const bool iq = f_intra[q] != 0, ip_cell = f_intra[p] != 0, ip = ip_cell || (fp & HDB_CONCEALED);
+        const bool tu = f_edge[q] != 0;
+        uint32_t ia = 0, ib = 0;
+        if (!iq && !ip_cell) { ia = pp.pu_map[q]; ib = pp.pu_map[p]; }
+        if (!tu && ia == ib) break;                                   // no transform edge, and the same prediction block (or one of them intra: tu is set then)
+        if (iq || ip) { bs = 2; break; }
+        if (tu && (f_cbf[q] || f_cbf[p])) { bs = 1; break; }
+        if (ia == ib) break;
+        const HevcPu a = pp.pus[ia], b = pp.pus[ib];
+        const int na = (a.slot0 >= 0) + (a.slot1 >= 0), nb = (b.slot0 >= 0) + (b.slot1 >= 0);
+        if (na != nb) { bs = 1; break; }
+        auto far = [](const int16_t *u, const int16_t *v) { return iabs(u[0] - v[0]) >= 4 || iabs(u[1] - v[1]) >= 4; };
+        if (na == 1) {
+            const int ra = a.slot0 >= 0 ? a.slot0 : a.slot1, rb = b.slot0 >= 0 ? b.slot0 : b.slot1;
+            const int16_t *va = a.slot0 >= 0 ? a.mv0 : a.mv1, *vb = b.slot0 >= 0 ? b.mv0 : b.mv1;
+            bs = (ra != rb || far(va, vb)) ? 1 : 0;
+            break;
+        }
+        const bool straight = a.slot0 == b.slot0 && a.slot1 == b.slot1, crossed = a.slot0 == b.slot1 && a.slot1 == b.slot0;
+        if (!straight && !crossed) { bs = 1; break; }
+        const bool ds = far(a.mv0, b.mv0) || far(a.mv1, b.mv1), dc = far(a.mv0, b.mv1) || far(a.mv1, b.mv0);
+        bs = (straight && crossed ? (ds && dc) : (straight ? ds : dc)) ? 1 : 0;
+    } while (0);
+    if (bs) {
+        const int xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
+        if (pp.qp8[(yp >> 3) * pp.w8 + (xp >> 3)] & 128) bs |= 4;     // samples of the p side / the q side are exempt from the loop filters
+        if (pp.qp8[(y >> 3) * pp.w8 + (x >> 3)] & 128) bs |= 8;
+    }
+    *out = (uint8_t)bs;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // 8.7.2.5: deblocking, one lane per 4-sample edge segment.  dir 0: vertical edges (filter across x), dir 1: horizontal edges
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hevc_deblock(const HevcPicParams *pics, int dir) {
@@ -917,6 +1015,12 @@ void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBat
     }
     if (marks) hipEventRecord(marks[2], st);
     if (m.any_deblock) {
+        // boundary strengths (k_hevc_bs_*): the maps are painted from the job lists, the strengths read the maps -- three small launches in front of the filter
+        const int cells = (m.max_w >> 2) * (m.max_h >> 2), entries = m.max_pus > m.max_tbs ? (m.max_pus > m.max_itbs ? m.max_pus : m.max_itbs)
+            : (m.max_tbs > m.max_itbs ? m.max_tbs : m.max_itbs);
+        hipLaunchKernelGGL(k_hevc_bs_clear, dim3((cells / 4 + 255) / 256, n), dim3(256), 0, st, d_pics);
+        hipLaunchKernelGGL(k_hevc_bs_raster, dim3((entries + 255) / 256 > 0 ? (entries + 255) / 256 : 1, n), dim3(256), 0, st, d_pics);
+        hipLaunchKernelGGL(k_hevc_bs, dim3((cells / 2 + 255) / 256, n, 2), dim3(256), 0, st, d_pics);
         hipLaunchKernelGGL(k_hevc_deblock, dim3(((m.max_w >> 3) * (m.max_h >> 2) + 255) / 256, n), dim3(256), 0, st, d_pics, 0);
         hipLaunchKernelGGL(k_hevc_deblock, dim3(((m.max_w >> 2) * (m.max_h >> 3) + 255) / 256, n), dim3(256), 0, st, d_pics, 1);
     }

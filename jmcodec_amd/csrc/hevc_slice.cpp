@@ -73,7 +73,7 @@ void HevcPicParser::begin_picture(const HevcSps &sps, const HevcPps &pps, int po
     // units this picture has already decoded, and coding_unit() rewrites every map for all units of the CU; finish_picture() fills in
     // coding tree blocks that no slice delivered.
     if (pm_.size() != n4) {
-        pm_.assign(n4, 0); skip_.assign(n4, 0); depth_.assign(n4, 0); ipm_.assign(n4, 1); nofilter_.assign(n4, 0); edge_.assign(n4, 0); cbf_.assign(n4, 0);
+        pm_.assign(n4, 0); skip_.assign(n4, 0); depth_.assign(n4, 0); ipm_.assign(n4, 1); nofilter_.assign(n4, 0);
         qp_.assign(n4, 26); mot_.assign(n4, HevcMotion());
     }
     ctb_slice_.assign(nc, -1); ctb_sidx_.assign(nc, 0);
@@ -529,7 +529,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
     jobs_->coefs.take(count);
     const uint8_t flags = (uint8_t)((tskip ? HTB_TSKIP : 0) | (tq_bypass_ ? HTB_BYPASS : 0) | ((cu_intra_ && c == 0 && n == 4) ? HTB_DST : 0));
     if (intra_tb) { HevcIntraTb &t = jobs_->itbs.back(); t.coef_off = first; t.coef_n = count; t.flags |= flags; }
-    else if (count) { HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0;
+    else if (count || c == 0) {                                     // (a luma block with cbf_luma = 1 is listed even when no level survived the scaling: bS, hevc_jobs.h)
+        HevcTb t; t.x = (uint16_t)xp; t.y = (uint16_t)yp; t.log2 = (uint8_t)log2; t.plane = (uint8_t)c; t.flags = flags; t.pad = 0;
         t.coef_off = first; t.coef_n = count; jobs_->tbs.push_back(t); }
     return true;
 }
@@ -537,17 +538,8 @@ bool HevcPicParser::residual_coding(int x0, int y0, int log2, int c, int xp, int
 // ------------------------------------------------------------------------------------------------------------
 // 7.3.8.8, 7.3.8.10
 bool HevcPicParser::transform_unit(int x0, int y0, int xb, int yb, int log2, int depth, int blk, int cbf_y, int cbf_cb, int cbf_cr) {
-    const int n = 1 << log2;
-    {
-        uint8_t *ed = edge_.data(), *cf = cbf_.data();
-        const int nu = n >> 2;
-        for (int r = 0; r < nu; r++) {
-            const int i = i4(x0, y0 + 4 * r);
-            fill_units(cf + i, cbf_y, nu);
-            ed[i] |= 1;
-            if (r == 0) for (int k = 0; k < nu; k++) ed[i + k] |= 2;
-        }
-    }
+    // (rounds 1-4 kept per-4x4 maps of transform / prediction edges and cbf_luma here for the boundary strengths: the device derives them from the job
+    // lists now, hevc_kernels.hip k_hevc_bs_raster)
     if ((cbf_y || cbf_cb || cbf_cr) && pps_->cu_qp_delta && !dqp_coded_) {
         int v = 0;
         if (cb_.decision(HEVC_CTX_CU_QP_DELTA)) { v = 1; while (v < 5 && cb_.decision(HEVC_CTX_CU_QP_DELTA + 1)) v++; }
@@ -644,13 +636,11 @@ bool HevcPicParser::prediction_unit(int xcb, int ycb, int ncb, int x0, int y0, i
     }
     for (int l = 0; l < 2; l++) if (((m.pf >> l) & 1) && (m.ref[l] < 0 || m.ref[l] >= sh_->n_ref[l])) return false;
     {
-        HevcMotion *mo = mot_.data(); uint8_t *ed = edge_.data();
+        HevcMotion *mo = mot_.data();
         const int nux = w >> 2, nuy = h >> 2;
         for (int r = 0; r < nuy; r++) {
             const int i = i4(x0, y0 + 4 * r);
             for (int k = 0; k < nux; k++) mo[i + k] = m;
-            ed[i] |= 4;
-            if (r == 0) for (int k = 0; k < nux; k++) ed[i + k] |= 8;
         }
     }
     if (dg_->on) { dg(0x5000 | (merge << 4) | m.pf); dg(x0); dg(y0); dg(w); dg(h); dg(m.ref[0]); dg(m.ref[1]); dg(m.mv[0][0]); dg(m.mv[0][1]); dg(m.mv[1][0]);
@@ -698,14 +688,12 @@ bool HevcPicParser::coding_unit(int x0, int y0, int log2) {
     {   // per-4x4 maps of the coding unit, a row of units at a time (the unit loop with its eight array stores was 7 % of the parse)
         const int nu = n >> 2;
         HevcMotion blank; memset(&blank, 0, sizeof blank); blank.ref[0] = blank.ref[1] = -1;
-        uint8_t *pm = pm_.data(), *sk = skip_.data(), *nf = nofilter_.data(), *cf = cbf_.data(), *ip = ipm_.data(), *ed = edge_.data();
+        uint8_t *pm = pm_.data(), *sk = skip_.data(), *nf = nofilter_.data(), *ip = ipm_.data();
         HevcMotion *mo = mot_.data();
         for (int r = 0; r < nu; r++) {
             const int i = i4(x0, y0 + 4 * r);
-            const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_, ved = r == 0 ? 10 : 0;
-            fill_units(pm + i, vpm, nu); fill_units(sk + i, vsk, nu); fill_units(nf + i, vnf, nu); fill_units(cf + i, 0, nu); fill_units(ip + i, 1, nu);
-            fill_units(ed + i, ved, nu);
-            ed[i] |= 5;
+            const uint8_t vpm = cu_intra_ ? 2 : 1, vsk = cu_skip_, vnf = tq_bypass_;
+            fill_units(pm + i, vpm, nu); fill_units(sk + i, vsk, nu); fill_units(nf + i, vnf, nu); fill_units(ip + i, 1, nu);
             if (cu_intra_) for (int k = 0; k < nu; k++) mo[i + k] = blank;      // (the prediction units of an inter unit cover it and write their own)
         }
     }
@@ -965,77 +953,30 @@ void HevcPicParser::finish_picture() {
         cj.intra_count = (uint32_t)jobs_->itbs.size() - cj.intra_first;
         note_intra_bottom(rs);
         for (int y = y0; y < std::min(h_, y0 + ctb_size_); y += 4) for (int x = x0; x < std::min(w_, x0 + ctb_size_); x += 4) { const int i = i4(x, y);
-            pm_[i] = 2; edge_[i] = 0; nofilter_[i] = 1; qp_[i] = 26; }
+            pm_[i] = 2; nofilter_[i] = 1; qp_[i] = 26; }
     }
     if (slices_.empty()) { SliceInfo si; memset(&si, 0, sizeof si); si.deblock_disabled = true; slices_.push_back(si); }
-    // the slice of a sample position: slice segments start at coding tree blocks (blocks no slice delivered read as slice 0)
-    auto slice_at = [&](int x, int y) -> const SliceInfo & { return slices_[ctb_sidx_[(y >> lc) * ctb_w_ + (x >> lc)]]; };
     const int w8 = w_ >> 3, h8 = h_ >> 3;
     jobs_->qp8.resize((size_t)w8 * h8);
     for (int y = 0; y < h8; y++) for (int x = 0; x < w8; x++) { const int i = i4(x * 8, y * 8);
         jobs_->qp8[(size_t)y * w8 + x] = (uint8_t)((qp_[i] & 63) | (nofilter_[i] ? 128 : 0)); }
-    // boundary strengths: bs_v[(y / 4) * (w / 8) + x / 8] for vertical edges at x = 8k, bs_h[(y / 8) * (w / 4) + x / 4] for horizontal edges
-    jobs_->bs_v.assign((size_t)w8 * h4_, 0); jobs_->bs_h.assign((size_t)w4_ * h8, 0);
-    // (raw pointers: the vectors' data pointers would be reloaded after every byte store; one slice and one tile -- the usual case -- needs no boundary tests)
-    const uint8_t *edge = edge_.data(), *pm = pm_.data(), *cbf = cbf_.data(), *nofilter = nofilter_.data();
-    const HevcMotion *mot = mot_.data();
-    const bool one_region = slices_.size() == 1 && pps_->lf_across_tiles;
-    const SliceInfo &s0 = slices_[0];
-    const int w4 = w4_;
-    auto strength = [&](int q, int p, int xq, int yq, int xp, int yp, int dir) -> int {
-        const int tu = edge[q] & (dir ? 2 : 1), pu = edge[q] & (dir ? 8 : 4);
-        if (!tu && !pu) return 0;
-        const SliceInfo *sq = &s0, *sp = &s0;
-        if (!one_region) {
-            sq = &slice_at(xq, yq); sp = &slice_at(xp, yp);
-            if (sq->addr != sp->addr && !sq->lf_across) return 0;
-            if (!pps_->lf_across_tiles) { const int cq = (yq >> lc) * ctb_w_ + (xq >> lc), cp = (yp >> lc) * ctb_w_ + (xp >> lc);
-                if (tile_id_[rs2ts_[cq]] != tile_id_[rs2ts_[cp]]) return 0; }
-        }
-        if (sq->deblock_disabled) return 0;
-        if (pm[q] == 2 || pm[p] == 2) return 2;
-        if (tu && (cbf[q] || cbf[p])) return 1;
-        const HevcMotion &a = mot[q], &b = mot[p];
-        // the same motion on both sides (a transform edge inside a prediction block, merged neighbours)
-        if (sq == sp && !memcmp(&a, &b, sizeof a)) return 0;
-        int ra[2], rb[2]; const int16_t *va[2], *vb[2]; int na = 0, nb = 0;
-        for (int l = 0; l < 2; l++) { if ((a.pf >> l) & 1) { ra[na] = sq->slot[l][a.ref[l]]; va[na++] = a.mv[l]; } if ((b.pf >> l) & 1) {
-            rb[nb] = sp->slot[l][b.ref[l]]; vb[nb++] = b.mv[l]; } }
-        if (na != nb) return 1;
-        auto far = [](const int16_t *u, const int16_t *v) { return std::abs(u[0] - v[0]) >= 4 || std::abs(u[1] - v[1]) >= 4; };
-        if (na == 1) return ra[0] != rb[0] || far(va[0], vb[0]);
-        const bool straight = ra[0] == rb[0] && ra[1] == rb[1], crossed = ra[0] == rb[1] && ra[1] == rb[0];
-        if (!straight && !crossed) return 1;
-        const bool ds = far(va[0], vb[0]) || far(va[1], vb[1]), dc = far(va[0], vb[1]) || far(va[1], vb[0]);
-        return straight && crossed ? (ds && dc) : (straight ? ds : dc);
-    };
+    // Deblocking (8.7.2): the boundary strengths are derived on the device (k_hevc_bs_raster / k_hevc_bs, round 5) from the prediction blocks, intra blocks
+    // and coded transform blocks of the job lists; what they cannot know -- the slice's deblocking switch, slice / tile boundaries that must not be filtered
+    // across (8.7.2.3: the left / top edge of a slice takes the flag of the slice that holds q0), concealed CTBs -- goes into HevcCtb.db_flags.
     if (jobs_->any_deblock) {
-        uint8_t *bsv = jobs_->bs_v.data(), *bsh = jobs_->bs_h.data();
-        // The edge flags are scanned eight 4x4 units at a time: with 64x64 coding tree blocks most units lie inside a block and carry no edge
-        // (the unit-by-unit walk over all 130 k units of a 1080p picture was most of this function's 8 % of the parse).
-        auto word = [&](int q, int n_units, uint64_t mask) { uint64_t v = 0; memcpy(&v, edge + q, (size_t)(n_units < 8 ? n_units : 8)); return v & mask; };
-        for (int y = 0; y < h_; y += 4) {
-            const int row = (y >> 2) * w4;
-            for (int u0 = 0; u0 < w4; u0 += 8) {                          // units u0 .. u0 + 7; vertical edges on the 8-sample grid: the even ones
-                for (uint64_t v = word(row + u0, w4 - u0, 0x0005000500050005ull); v;) {
-                    const int k = __builtin_ctzll(v) >> 3; v &= ~(0xffull << (8 * k));
-                    const int x = (u0 + k) << 2, q = row + u0 + k;
-                    if (x == 0) continue;
-                    const int bs = strength(q, q - 1, x, y, x - 1, y, 0);
-                    if (bs) bsv[(size_t)(y >> 2) * w8 + (x >> 3)] = (uint8_t)(bs | (nofilter[q - 1] ? 4 : 0) | (nofilter[q] ? 8 : 0));
-                }
-            }
-        }
-        for (int y = 8; y < h_; y += 8) {
-            const int row = (y >> 2) * w4;
-            for (int u0 = 0; u0 < w4; u0 += 8) {
-                for (uint64_t v = word(row + u0, w4 - u0, 0x0a0a0a0a0a0a0a0aull); v;) {
-                    const int k = __builtin_ctzll(v) >> 3; v &= ~(0xffull << (8 * k));
-                    const int x = (u0 + k) << 2, q = row + u0 + k;
-                    const int bs = strength(q, q - w4, x, y, x, y - 1, 1);
-                    if (bs) bsh[(size_t)(y >> 3) * w4 + (x >> 2)] = (uint8_t)(bs | (nofilter[q - w4] ? 4 : 0) | (nofilter[q] ? 8 : 0));
-                }
-            }
+        for (int rs = 0; rs < ctb_w_ * ctb_h_; rs++) {
+            const SliceInfo &sq = slices_[ctb_sidx_[rs]];
+            uint8_t f = 0;
+            if (sq.deblock_disabled) f |= HDB_DISABLED;
+            if (ctb_slice_[rs] < 0) f |= HDB_CONCEALED;
+            auto blocked = [&](int nrs) {
+                const SliceInfo &sp = slices_[ctb_sidx_[nrs]];
+                if (sq.addr != sp.addr && !sq.lf_across) return true;
+                return !pps_->lf_across_tiles && tile_id_[rs2ts_[rs]] != tile_id_[rs2ts_[nrs]];
+            };
+            if (rs % ctb_w_ > 0 && blocked(rs - 1)) f |= HDB_NO_LEFT;
+            if (rs >= ctb_w_ && blocked(rs - ctb_w_)) f |= HDB_NO_TOP;
+            jobs_->ctbs[rs].db_flags = f;
         }
     }
     // SAO: which neighbouring CTBs the edge offset of a CTB may read (8.7.3: slice and tile boundaries)

@@ -61,10 +61,10 @@ template <class T> struct PodList {
 };
 
 struct HevcPicJobs {
-    std::vector<HevcCtb> ctbs; std::vector<uint8_t> qp8, bs_v, bs_h;
+    std::vector<HevcCtb> ctbs; std::vector<uint8_t> qp8;
     PodList<HevcPu> pus; PodList<HevcTb> tbs; PodList<HevcIntraTb> itbs; PodList<uint32_t> coefs; std::vector<HevcWp> wps;
     bool any_sao = false, any_deblock = false; int n_intra_cu = 0;
-    void clear() { ctbs.clear(); qp8.clear(); bs_v.clear(); bs_h.clear(); pus.clear(); tbs.clear(); itbs.clear(); coefs.clear(); wps.clear();
+    void clear() { ctbs.clear(); qp8.clear(); pus.clear(); tbs.clear(); itbs.clear(); coefs.clear(); wps.clear();
         any_sao = any_deblock = false; n_intra_cu = 0; }
 };
 
@@ -110,7 +110,7 @@ private:
     int poc_ = 0, w_ = 0, h_ = 0, w4_ = 0, h4_ = 0, ctb_w_ = 0, ctb_h_ = 0, ctb_size_ = 0, tb_w_ = 0;
     std::vector<int> rs2ts_, ts2rs_, tile_id_, ctb_slice_;
     std::vector<uint32_t> zs_;                 // MinTbAddrZs
-    std::vector<uint8_t> pm_, skip_, depth_, ipm_, nofilter_, edge_, cbf_; std::vector<int8_t> qp_; std::vector<HevcMotion> mot_;
+    std::vector<uint8_t> pm_, skip_, depth_, ipm_, nofilter_; std::vector<int8_t> qp_; std::vector<HevcMotion> mot_;
     std::vector<uint16_t> ctb_sidx_;                      // index into slices_ by coding tree block (raster scan)
     std::vector<SliceInfo> slices_;
     int slice_idx_ = 0, ctb_rs_ = 0, ctb_ts_ = 0;
