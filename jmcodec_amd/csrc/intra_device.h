@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include "kernel_common.h"
 #include "chain_common.h"
+#include "intra8_packed.h"
 
 namespace jmamd {
 
@@ -16,7 +17,8 @@ namespace jmamd {
 // (Intra8x8) behind them.
 constexpr int kTS = 28, kTO = 3;
 constexpr int kI4SelBase = 3904;     // Intra4x4 selector table (i4_sel_entry): 9 modes x 16 pixels x 8 bytes
-constexpr int kTileBase = 3904 + 1152;   // tables, record staging and Intra8x8 edge buffers come first
+constexpr int kI8SelBase = 3904 + 1152;  // Intra8x8 selector table (intra8_packed.h pk::I8Sel): 9 modes x 16 lanes x 64 bytes
+constexpr int kTileBase = kI8SelBase + 9 * 16 * 64;   // tables and record staging come first
 
 // (c, kind) of Intra4x4 mode `mode` for pixel (x, y); kind 0 copy P[c], 1 two-tap (P[c]+P[c+1]+1)>>1,
 // 2 three-tap (P[c-1]+2P[c]+P[c+1]+2)>>2, 3 DC.  Edge path index: 0 L3' 1 L3 2 L2 3 L1 4 L0 5 TL 6..13 T0..T7 14 T7'
@@ -64,44 +66,14 @@ __device__ __forceinline__ uint2 i4_sel_entry(int mode, int x, int y) {
     return make_uint2(a, b);
 }
 
-// Same idea for Intra8x8 on the FILTERED 25-entry edge path  L7..L0 (0..7)  TL (8)  T0..T15 (9..24): entry = c | kind << 5
-__device__ __forceinline__ int i8_table_entry(int mode, int x, int y) {
-    int c = 0, kind = 0;
-    switch (mode) {
-    case 0: c = 9 + x; break;
-    case 1: c = 7 - y; break;
-    case 2: kind = 3; break;
-    case 3: c = 10 + x + y; kind = 2; break;
-    case 4: c = 8 + x - y; kind = 2; break;
-    case 5: { int z = 2 * x - y, i = x - (y >> 1);
-        if (z >= 0) { c = 8 + i; kind = (z & 1) ? 2 : 1; }
-        else if (z == -1) { c = 8; kind = 2; }
-        else { c = 9 - y + 2 * x; kind = 2; }
-        break; }
-    case 6: { int z = 2 * y - x, i = y - (x >> 1);
-        if (z >= 0) { if (z & 1) { c = 8 - i; kind = 2; } else { c = 7 - i; kind = 1; } }
-        else if (z == -1) { c = 8; kind = 2; }
-        else { c = 7 + x - 2 * y; kind = 2; }
-        break; }
-    case 7: { int i = x + (y >> 1); if (y & 1) { c = 10 + i; kind = 2; } else { c = 9 + i; kind = 1; } break; }
-    default: { int z = x + 2 * y, i = y + (x >> 1);
-        if (z > 13) { c = 0; kind = 0; }
-        else if (z == 13) { c = 0; kind = 2; }
-        else if (z & 1) { c = 6 - i; kind = 2; }
-        else { c = 6 - i; kind = 1; }
-        break; }
-    }
-    return c | (kind << 5);
-}
-
 // LDS image of one workgroup
 struct ILds {
     uint8_t *base; int mb_h;
     // common
     __device__ uint8_t *i4tab() const { return base; }                                            // 144 B
     __device__ uint8_t *rec(int g) const { return base + 256 + g * 32; }                          // MbRec staging, 32 groups
-    __device__ uint8_t *i8tab() const { return base + 1280; }                                     // 576 B
-    __device__ uint8_t *e8(int g) const { return base + 1856 + g * 64; }                          // Intra8x8: raw [32] + filtered [32] edge path
+    // (bytes 1280 .. 3903 held the Intra8x8 byte table and per-group edge buffers of rounds 1-4; the path lives in registers now)
+    __device__ uint8_t *i8sel() const { return base + kI8SelBase; }                               // 9216 B: pk::I8Sel per (mode, lane)
     __device__ uint8_t *i4sel() const { return base + kI4SelBase; }                               // 1152 B: uint2 per (mode, pixel)
     // luma: tile[17][kTS] per group (476 -> 480), residual [16][16] int16 per group (512)
     __device__ uint8_t *ltile(int g) const { return base + kTileBase + g * 480; }
@@ -214,17 +186,17 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
         o0 = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24); o1 = out[4] | (out[5] << 8) | (out[6] << 16) | (out[7] << 24);
         o2 = out[8] | (out[9] << 8) | (out[10] << 16) | (out[11] << 24); o3 = out[12] | (out[13] << 8) | (out[14] << 16) | (out[15] << 24);
     } else if (modes & MBM_T8X8) {
-        // ---- Intra8x8 (8.3.2): four 8x8 blocks in order; per block the 25 reference samples are gathered and filtered
-        //      (8.3.2.2.1) into LDS by the 16 lanes, then every lane predicts 4 pixels of one row from the (c, kind) table ----
+        // ---- Intra8x8 (8.3.2): four 8x8 blocks in order.  Round 5 (intra8_packed.h): a lane reads the block's surroundings from the work tile with thirteen
+        //      unconditional dword loads, keeps the filtered reference path (8.3.2.2.1) in seven registers and takes the taps of its four samples (one row
+        //      segment of the block) out with v_perm_b32 selectors from a table by (mode, lane): one LDS round trip per block where there were five ----
         uint8_t *tile = lds.ltile(g);
         short *res = lds.lres(g);
-        uint8_t *raw = lds.e8(g), *fe = raw + 32;
         *(uint4 *)(res + l * 16) = res0; *(uint4 *)(res + l * 16 + 8) = res1;
         tile[(1 + l) * kTS + kTO] = (uint8_t)left;
-        tile[kTO + 1 + l] = ring_up[l];
-        if (l < 8) tile[kTO + 17 + l] = ring_ur[l];
+        if (l < 4) ((uint32_t *)(tile + kTO + 1))[l] = ((const uint32_t *)ring_up)[l];
+        if (l == 4 || l == 5) ((uint32_t *)(tile + kTO + 17))[l - 4] = ((const uint32_t *)ring_ur)[l - 4];
         if (l == 0) tile[kTO] = (uint8_t)corner;
-        const uint8_t *tab8 = lds.i8tab();
+        const pk::I8Sel *seltab = (const pk::I8Sel *)lds.i8sel();
         const uint32_t m0 = rec[4];                                   // Intra8x8PredMode of block b in nibble b
         const int y8 = l >> 1, x8 = (l & 1) * 4;
 #pragma nounroll
@@ -233,45 +205,26 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
             const bool a = bx8 || availA, b = by8 || availB;
             const bool d = (bx8 && by8) ? true : (bx8 ? availB : (by8 ? availA : availD));
             const bool c = b8 == 0 ? availB : (b8 == 1 ? availC : b8 == 2);
-            const int mode = (m0 >> (4 * b8)) & 15;
-            uint8_t *org = tile + (by8 * 8) * kTS + bx8 * 8 + kTO;    // corner sample of this block
-            // edge path k: 0..7 = p[-1,7]..p[-1,0], 8 = p[-1,-1], 9..24 = p[0..15,-1] (top-right replaced by p[7,-1] when unavailable)
-            // (samples of unavailable neighbours count as 128: see the Intra4x4 path)
-            auto edge = [&](int k) -> int { return k <= 7 ? (a ? org[(8 - k) * kTS] : 128) : (k == 8 ? (d ? org[0] : 128) : (b ? org[1 + ((k - 9 > 7 &&
-                !c) ? 7 : k - 9)] : 128)); };
-            raw[l] = (uint8_t)edge(l);
-            if (l < 9) raw[16 + l] = (uint8_t)edge(16 + l);
-            auto filt = [&](int k) -> int {
-                int lo = k - 1, hi = k + 1;
-                if (k == 0) lo = 0;
-                if (k == 7) hi = d ? 8 : 7;
-                if (k == 8) { lo = a ? 7 : 8; hi = b ? 9 : 8; }
-                if (k == 9) lo = d ? 8 : 9;
-                if (k == 24) hi = 24;
-                if (k == 8 && !d) return 128;
-                return (raw[lo] + 2 * raw[k] + raw[hi] + 2) >> 2;
-            };
-            int f1 = filt(l), f2 = l < 9 ? filt(16 + l) : 0;
-            fe[l] = (uint8_t)f1;
-            if (l < 9) fe[16 + l] = (uint8_t)f2;
-            int dc = 0;
-            if (mode == 2) {
-                int st = 0, sl = 0;
+            int mode = (m0 >> (4 * b8)) & 15;
+            mode = mode > 8 ? 8 : mode;                              // (a damaged record must not index beyond the table)
+            const uint4 *sp = (const uint4 *)&seltab[mode * 16 + l];
+            const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            const uint8_t *row0 = tile + (by8 * 8) * kTS + bx8 * 8;   // the dword whose last byte is the block's corner sample; the row above follows
+            pk::I8Edge e;
+            e.tl = *(const uint32_t *)row0; e.t0 = *(const uint32_t *)(row0 + 4); e.t1 = *(const uint32_t *)(row0 + 8); e.r0 = *(const uint32_t *)(row0 + 12);
+            e.r1 = *(const uint32_t *)(row0 + 16);
 #pragma unroll
-                for (int i = 0; i < 8; i++) { sl += fe[i]; st += fe[9 + i]; }
-                dc = (a && b) ? (st + sl + 8) >> 4 : (a ? (sl + 4) >> 3 : (b ? (st + 4) >> 3 : 128));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ent = tab8[mode * 64 + y8 * 8 + x8 + j], cc = ent & 31, kd = ent >> 5;
-                int pred;
-                if (kd == 3) pred = dc;
-                else {
-                    int v0 = fe[cc > 0 ? cc - 1 : 0], v1 = fe[cc], v2 = fe[cc < 24 ? cc + 1 : 24];
-                    pred = kd == 2 ? (v0 + 2 * v1 + v2 + 2) >> 2 : (kd == 1 ? (v1 + v2 + 1) >> 1 : v1);
-                }
-                org[(1 + y8) * kTS + 1 + x8 + j] = (uint8_t)clip1(pred + res[(by8 * 8 + y8) * 16 + bx8 * 8 + x8 + j]);
-            }
+            for (int i = 0; i < 8; i++) e.l[i] = *(const uint32_t *)(row0 + (1 + i) * kTS);      // byte 3 = the left neighbour of the block's row i
+            uint32_t F[7];
+            pk::i8_filtered_path(e, a, b, c, d, F);
+            const int dc = pk::i8_dc(F, a, b);
+            pk::I8Sel sel;
+            sel.s[0][0] = s0.x; sel.s[0][1] = s0.y; sel.s[0][2] = s0.z; sel.s[0][3] = s0.w; sel.s[1][0] = s1.x; sel.s[1][1] = s1.y; sel.s[1][2] = s1.z;
+            sel.s[1][3] = s1.w; sel.s[2][0] = s2.x; sel.s[2][1] = s2.y; sel.s[2][2] = s2.z; sel.s[2][3] = s2.w; sel.m1 = s3.x; sel.m2 = s3.y; sel.m3 = s3.z;
+            sel.pad = 0;
+            const uint32_t pred = pk::i8_predict4(F, sel, dc);
+            const uint2 r = *(const uint2 *)(res + (by8 * 8 + y8) * 16 + bx8 * 8 + x8);       // (issued with the loads above: one wait)
+            *(uint32_t *)(tile + (by8 * 8 + 1 + y8) * kTS + kTO + 1 + bx8 * 8 + x8) = pk::add_residual4(pred, r.x, r.y);
         }
         { const uint32_t *rw = (const uint32_t *)(tile + (1 + l) * kTS + kTO + 1); o0 = rw[0]; o1 = rw[1]; o2 = rw[2]; o3 = rw[3]; }
     } else {
@@ -446,7 +399,7 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     const int row = row0 + (active ? g : 0), lrow = g + 1;
     if (threadIdx.x < 144) { lds.i4tab()[threadIdx.x] = (uint8_t)i4_table_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3);
         ((uint2 *)lds.i4sel())[threadIdx.x] = i4_sel_entry(threadIdx.x >> 4, threadIdx.x & 3, (threadIdx.x >> 2) & 3); }
-    for (int i = threadIdx.x; i < 576; i += kIBandRows * 16) lds.i8tab()[i] = (uint8_t)i8_table_entry(i >> 6, i & 7, (i >> 3) & 7);
+    if (!is_chroma && threadIdx.x < 144) ((pk::I8Sel *)lds.i8sel())[threadIdx.x] = pk::i8_sel_entry(threadIdx.x >> 4, threadIdx.x & 15);
     gbyte *plane = (gbyte *)(cur_plane(pp) + (is_chroma ? pp.chroma_offset : 0));
     const ICtx cx{plane, pitch};
     const int rows_per_mb = is_chroma ? 8 : 16, my_row = is_chroma ? (l & 7) : l;
