@@ -199,7 +199,7 @@ __device__ __forceinline__ void intra_luma_mb(const ICtx &pp, const ILds &lds, i
         const pk::I8Sel *seltab = (const pk::I8Sel *)lds.i8sel();
         const uint32_t m0 = rec[4];                                   // Intra8x8PredMode of block b in nibble b
         const int y8 = l >> 1, x8 = (l & 1) * 4;
-#pragma nounroll
+#pragma unroll
         for (int b8 = 0; b8 < 4; b8++) {
             const int bx8 = b8 & 1, by8 = b8 >> 1;
             const bool a = bx8 || availA, b = by8 || availB;
