@@ -321,6 +321,47 @@ void HevcPicParser::parse_sao(int rs) {
 }
 
 // intra transform block record; xp/yp in samples of plane c
+// 6.4.1 for the neighbours of an intra block, all at once.  Inside the block's own coding tree block the answer depends on nothing but the positions (z-scan
+// order): a table by (block size, position in the CTB) built once per CTB size holds, for the 4-sample units down the left edge and along the top edge, who
+// precedes the block.  Units in a neighbouring CTB are available when that CTB is (same slice, same tile, decoded: four flags per CTB, looked up once per CTB),
+// units below the CTB / to its right never are, units outside the picture are cut off by count.  (One avail_zs() call per unit -- up to 33 per block -- was
+// ~5 % of the parse.)
+namespace {
+struct IntraNb { uint16_t left, top; };                                // bit i: unit i down the left edge / along the top edge precedes the block, same CTB
+struct IntraNbTable {
+    IntraNb t[3][4][16 * 16];                                          // [log2_ctb - 4][log2 of the block's size in units][uy * U + ux]
+    IntraNbTable() {
+        for (int lc = 4; lc <= 6; lc++) { const int U = 1 << (lc - 2);
+            for (int si = 0; si < 4; si++) { const int units = 2 << si;
+                for (int uy = 0; uy < U; uy++) for (int ux = 0; ux < U; ux++) {
+                    IntraNb e = {0, 0}; const uint32_t cur = zorder4((uint32_t)ux, (uint32_t)uy);
+                    for (int i = 0; i < units && i < 16; i++) {
+                        if (ux > 0 && uy + i < U && zorder4((uint32_t)(ux - 1), (uint32_t)(uy + i)) <= cur) e.left |= (uint16_t)(1u << i);
+                        if (uy > 0 && ux + i < U && zorder4((uint32_t)(ux + i), (uint32_t)(uy - 1)) <= cur) e.top |= (uint16_t)(1u << i);
+                    }
+                    t[lc - 4][si][uy * U + ux] = e;
+                } } }
+    }
+};
+const IntraNbTable kIntraNb;
+inline uint32_t low_bits(int n) { return n >= 32 ? 0xffffffffu : (1u << (n < 0 ? 0 : n)) - 1u; }
+}  // namespace
+
+// which of the four neighbouring coding tree blocks the current one may predict from (6.4.1: decoded, same slice, same tile): bit 0 left, 1 above, 2 above right,
+// 3 above left
+int HevcPicParser::ctb_neighbours() {
+    if (nbf_rs_ == ctb_rs_) return nbf_;
+    const int cx = ctb_rs_ % ctb_w_, cy = ctb_rs_ / ctb_w_;
+    auto ok = [&](int cn) { return ctb_slice_[cn] == sh_->slice_addr && rs2ts_[cn] < ctb_ts_ && tile_id_[rs2ts_[cn]] == tile_id_[ctb_ts_]; };
+    int f = 0;
+    if (cx > 0 && ok(ctb_rs_ - 1)) f |= 1;
+    if (cy > 0 && ok(ctb_rs_ - ctb_w_)) f |= 2;
+    if (cy > 0 && cx + 1 < ctb_w_ && ok(ctb_rs_ - ctb_w_ + 1)) f |= 4;
+    if (cy > 0 && cx > 0 && ok(ctb_rs_ - ctb_w_ - 1)) f |= 8;
+    nbf_rs_ = ctb_rs_; nbf_ = f;
+    return f;
+}
+
 void HevcPicParser::emit_intra_tb(int xp, int yp, int log2, int c, int mode, bool with_coefs) {
     HevcIntraTb t; memset(&t, 0, sizeof t);
     const int n = 1 << log2, sc = c ? 1 : 0, xl = xp << sc, yl = yp << sc, unit = 4;
@@ -328,12 +369,35 @@ void HevcPicParser::emit_intra_tb(int xp, int yp, int log2, int c, int mode, boo
     if (mode != kHevcModePcm) {
         const bool cip = pps_->constrained_intra;
         const int units = (2 * n << sc) / unit;                       // 4-luma-sample units along each of the two edges
-        for (int i = 0; i < units; i++) {
-            int yy = yl + i * unit, xx = xl + i * unit;
-            if (avail_zs(xl, yl, xl - 1, yy) && (!cip || pm_[i4(xl - 1, yy)] == 2)) t.avail |= 1u << i;
-            if (avail_zs(xl, yl, xx, yl - 1) && (!cip || pm_[i4(xx, yl - 1)] == 2)) t.avail |= 1u << (16 + i);
+        const int lc = sps_->log2_ctb, si = log2 + sc - 2;
+        if (!cip && lc >= 4 && lc <= 6 && si >= 0 && si <= 3) {
+            const int U = 1 << (lc - 2), cm = (1 << lc) - 1, ux = (xl & cm) >> 2, uy = (yl & cm) >> 2, nb = ctb_neighbours();
+            const IntraNb e = kIntraNb.t[lc - 4][si][uy * U + ux];
+            uint32_t left = e.left, top = e.top;
+            if (ux == 0 && (nb & 1)) left |= low_bits(std::min(units, U - uy));                   // the CTB to the left (the one below it is never decoded yet)
+            if (uy == 0) {
+                const int inside = std::min(units, U - ux);
+                if (nb & 2) top |= low_bits(inside);                                               // the CTB above
+                if ((nb & 4) && units > inside) top |= low_bits(units) & ~low_bits(inside);        // ... and the one above right
+            }
+            left &= low_bits(std::min(units, (h_ - yl + 3) >> 2));                                  // units below / right of the picture
+            top &= low_bits(std::min(units, (w_ - xl + 3) >> 2));
+            t.avail = left | top << 16;
+            if ((ux > 0 && uy > 0) || (ux == 0 && uy == 0 ? (nb & 8) : ux == 0 ? (nb & 1) : (nb & 2))) t.flags |= HTB_CORNER;
+#ifdef JM_CHECK_INTRA_NB                                               // developer cross-check against the unit-by-unit form (tools/host_bench with HB_FLAGS)
+            { uint32_t av = 0; bool corner = avail_zs(xl, yl, xl - 1, yl - 1);
+              for (int i = 0; i < units; i++) { if (avail_zs(xl, yl, xl - 1, yl + i * unit)) av |= 1u << i; if (avail_zs(xl, yl, xl + i * unit, yl - 1)) av |= 1u << (16 + i); }
+              if (av != t.avail || corner != ((t.flags & HTB_CORNER) != 0)) { fprintf(stderr, "intra neighbours differ at (%d, %d) log2 %d plane %d: %08x / %08x\n",
+                  xl, yl, log2, c, t.avail, av); abort(); } }
+#endif
+        } else {
+            for (int i = 0; i < units; i++) {
+                int yy = yl + i * unit, xx = xl + i * unit;
+                if (avail_zs(xl, yl, xl - 1, yy) && (!cip || pm_[i4(xl - 1, yy)] == 2)) t.avail |= 1u << i;
+                if (avail_zs(xl, yl, xx, yl - 1) && (!cip || pm_[i4(xx, yl - 1)] == 2)) t.avail |= 1u << (16 + i);
+            }
+            if (avail_zs(xl, yl, xl - 1, yl - 1) && (!cip || pm_[i4(xl - 1, yl - 1)] == 2)) t.flags |= HTB_CORNER;
         }
-        if (avail_zs(xl, yl, xl - 1, yl - 1) && (!cip || pm_[i4(xl - 1, yl - 1)] == 2)) t.flags |= HTB_CORNER;
     }
     t.coef_off = (uint32_t)jobs_->coefs.size();
     (void)with_coefs;
@@ -852,7 +916,7 @@ std::string HevcPicParser::parse_slice(const HevcSliceHeader &sh, const HevcSlic
     } else if (slices_.empty()) return "dependent slice segment without a slice";
     slice_idx_ = (int)slices_.size() - 1;
     if (!sh.deblock_disabled) jobs_->any_deblock = true;
-    ctb_rs_ = sh.segment_addr; ctb_ts_ = rs2ts_[ctb_rs_];
+    ctb_rs_ = sh.segment_addr; ctb_ts_ = rs2ts_[ctb_rs_]; nbf_rs_ = -1;
     if (sh.dependent) {
         if (!dep_valid_) return "dependent slice segment without stored context variables";
         memcpy(cb_.state, dep_state_, HEVC_N_CTX * sizeof(Cabac::State));

@@ -91,6 +91,7 @@ private:
     void emit_intra_tb(int xp, int yp, int log2, int c, int mode, bool with_coefs);
     // ---- derivations ----
     bool avail_zs(int xc, int yc, int xn, int yn) const;
+    int ctb_neighbours();
     bool avail_pb(int xcb, int ycb, int ncb, int xp, int yp, int w, int h, int part, int xn, int yn) const;
     void derive_qp(int xcb, int ycb);
     int merge_candidates(int xcb, int ycb, int ncb, int xp, int yp, int w, int h, int part, int want, HevcMotion *list);
@@ -114,6 +115,7 @@ private:
     std::vector<uint16_t> ctb_sidx_;                      // index into slices_ by coding tree block (raster scan)
     std::vector<SliceInfo> slices_;
     int slice_idx_ = 0, ctb_rs_ = 0, ctb_ts_ = 0;
+    int nbf_rs_ = -1, nbf_ = 0;                                      // ctb_neighbours(): the CTB the flags were looked up for
     // CU state
     int qp_y_ = 0, qp_prev_ = 0, last_cu_qp_ = 0, dqp_ = 0; bool dqp_coded_ = false, first_qg_ = true, cu_since_reset_ = false;
     bool cu_intra_ = false, cu_skip_ = false, tq_bypass_ = false, intra_split_ = false, last_merge_ = false;
