@@ -595,6 +595,7 @@ def measure(args, ctx):
             got_dev[i] = L.jm_amddec_feed_annexb(datas[i], len(datas[i]), passes, None, frame_bytes, hs[i])
             L.jm_amddec_set_option(hs[i], b"wait_idle", 1)
         for passes, timed in ((1, False), (max(1, min(K, 8)), True)):      # (three passes were 0.27 s: a tenth of it pipeline fill and drain)
+            dhc0 = host_cpu()
             c0 = time.perf_counter()
             ts = [threading.Thread(target=dev_pass, args=(i, passes)) for i in range(len(hs))]
             for t in ts:
@@ -605,7 +606,14 @@ def measure(args, ctx):
                 torch.cuda.synchronize()
             ddt = time.perf_counter() - c0
             if timed:
+                dhc1 = host_cpu()
+                d_busy = (dhc1["cpu_s"] - dhc0["cpu_s"]) / ddt
+                d_quota = dhc1.get("quota_cpus") or os.cpu_count()
                 dev_leg = {"value": round(len(hs) * F * passes / ddt, 1), "unit": "frames/s", "frames": len(hs) * F * passes,
+                           "host_cpu": {"cpu_ms_per_frame": round(1e3 * (dhc1["cpu_s"] - dhc0["cpu_s"]) / max(len(hs) * F * passes, 1), 4),
+                                        "cpus_busy": round(d_busy, 2), "quota_cpus": d_quota},
+                           # (no link in the way here: the host's entropy decode -- >= 90 % of the CPU allotment busy -- or the device)
+                           "scaling_bound": "host_cpu_quota" if d_quota and d_busy >= 0.9 * d_quota else "gpu",
                            "note": "untimed extra leg: the same streams, display frames left in device memory (jm_amddec_output_frame_device, SURVEY 8f f3): "
                                    "no D2H copy, no frame copy on the CPU; host entropy decode and job-list upload still included"}
         for h in hs:
