@@ -225,5 +225,32 @@ JM_HD uint32_t add_residual_uv(uint32_t uv, int ru, int rv) {
     return sat_pk_u8(pk_add_sat(perm(0u, uv, 0x0c010c00u), ((uint32_t)ru & 0xffffu) | ((uint32_t)rv << 16))) & 0xffffu;
 }
 
+// ---- one reference window for the four macroblocks of a chain workgroup (recon_device.h, "quad" path) ----
+// Each macroblock says what its own one-window fetch would be: vote[w] = { reference slot or -1, xi, yi, 2 * cxi, cyi } -- the first luma sample of its 21 x 21
+// window, the first byte / row of its 9-row chroma window (interleaved U V).  The shared window starts at (x0, y0) / (cx0, cy0), x0 and cx0 dword-aligned, and
+// holds nrow x ndw dwords of luma, ncrow x ncdw of chroma, in rows of kQuadStride dwords.  ok: all four take the one-window path from the same picture and
+// everything a macroblock reads of a row (pk::row12: four dwords from the dword of byte 12 + offset at most) lies inside a row of kQuadStride dwords.
+constexpr int kQuadStride = 27, kQuadRows = 32, kQuadChromaRows = 16;
+struct QuadGeom { bool ok; int x0, y0, nrow, ndw, cx0, cy0, ncrow, ncdw; };
+JM_HD QuadGeom quad_geometry(const int (*vote)[8]) {
+    int x0 = 1 << 30, x1 = 0, y0 = 1 << 30, y1 = 0, cx0 = 1 << 30, cx1 = 0, cy0 = 1 << 30, cy1 = 0; bool all = true;
+    for (int w = 0; w < 4; w++) {
+        const int sl = vote[w][0], a = vote[w][1], b = vote[w][2], c = vote[w][3], d = vote[w][4];
+        all = all && sl >= 0 && sl == vote[0][0];
+        x0 = a < x0 ? a : x0; x1 = a > x1 ? a : x1; y0 = b < y0 ? b : y0; y1 = b > y1 ? b : y1;
+        cx0 = c < cx0 ? c : cx0; cx1 = c > cx1 ? c : cx1; cy0 = d < cy0 ? d : cy0; cy1 = d > cy1 ? d : cy1;
+    }
+    x0 &= ~3; cx0 &= ~3;
+    QuadGeom g;
+    g.ok = all && x1 - x0 + 28 <= kQuadStride * 4 && y1 - y0 + 21 <= kQuadRows && cx1 - cx0 + 24 <= kQuadStride * 4 && cy1 - cy0 + 9 <= kQuadChromaRows;
+    g.x0 = x0; g.y0 = y0; g.nrow = y1 - y0 + 21; g.ndw = (x1 - x0 + 21 + 3) >> 2; g.cx0 = cx0; g.cy0 = cy0; g.ncrow = cy1 - cy0 + 9; g.ncdw = (cx1 - cx0 + 18 + 3) >> 2;
+    return g;
+}
+// the four interleaved chroma bytes U V U V at byte offset `off` of window rows r and r + 1 (`stride` dwords per row): what mc_chroma_uv takes
+JM_HD void chroma_pairs(const uint32_t *win, int stride, int r, int off, uint32_t &wa, uint32_t &wb) {
+    const int o = off >> 2; const uint32_t sh = (uint32_t)off & 3u;
+    wa = alignbyte(win[r * stride + o + 1], win[r * stride + o], sh); wb = alignbyte(win[(r + 1) * stride + o + 1], win[(r + 1) * stride + o], sh);
+}
+
 }  // namespace pk
 }  // namespace jmamd

@@ -228,11 +228,20 @@ template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_
 
 // LDS of one 4-wave workgroup of the inter reconstruction
 constexpr int kUniChroma = 136;          // dword offset of the chroma window behind the 21 x 6 luma window in wins[wave] (uni path)
+// Chain launches, "quad" path (round 5): when the four macroblocks of a workgroup all take the one-window path from the same reference picture with vectors
+// that lie close together, the workgroup fetches ONE window for the four of them -- kQRows rows of kQStride dwords of luma, kQCRows of chroma -- instead of four
+// overlapping ones (coherent loads are served from memory in 64-byte requests whoever read the line before: four private 24-byte rows cost 5.2 requests, one
+// shared 72-byte row 2.1; profiles/r05_chain_quad_fetch.txt).
+constexpr int kQStride = pk::kQuadStride, kQRows = pk::kQuadRows, kQCRows = pk::kQuadChromaRows;      // (mc_packed.h: quad_geometry, host-tested)
 struct alignas(16) ReconLds {
     ResTile tiles[4];
     uint32_t outt[4][96];                        // per wave: reconstructed MB, 16 luma rows + 8 interleaved chroma rows of 16 B
-    uint32_t wins[4][4][13 * 5 + 3];             // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
+    union {
+        uint32_t wins[4][4][13 * 5 + 3];         // per wave, per 8x8 block: 13 rows x 5 dwords of reference window
+        struct { uint32_t qwin[kQRows * kQStride]; uint32_t qcwin[kQCRows * kQStride]; };      // the workgroup's shared window (quad path)
+    };
     uint32_t fate[4];                            // chain launches: what became of each wave's macroblock (the store tail of recon_inter_wave)
+    int vote[4][8];                              // chain launches: each wave's one-window parameters (reference slot or -1, xi, yi, 2 * cxi, cyi)
 };
 
 // One wave reconstructs macroblock `mb` (mbx, mby) of picture pp.  CHAIN = false: the stage kernel (every reference picture was complete
@@ -313,6 +322,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     uint32_t cw = 0;                                        // this lane's dword of the chroma window (uni path)
     int c_sh = 0;                                           // byte offset of chroma sample 0 in its window row
     int u_fx = 0, u_fy = 0, u_sh = 0;                       // uni path: the luma vector's fraction and the byte offset of window column 0 in its dword
+    int u_xi = 0, u_yi = 0, u_cx2 = 0, u_cyi = 0;           // uni path: first sample of the luma window, first byte / row of the chroma window
+    int qv_rows = 0, qv_dws = 0, qc_rows = 0, qc_dws = 0;   // quad path: extent of the shared windows
     if (plain && !(r.flags & MBF_MV_EXT) && rec_ref(r, 0) >= 0) {
         // (the record as dwords: four vectors and the four reference bytes compared with a handful of scalar operations, not field by field)
         const uint32_t m0 = rw.w[4], refs = rw.w[3];
@@ -328,21 +339,50 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             uni = W >= 21 && H >= 21 && (unsigned)xi <= (unsigned)(W - 21) && (unsigned)yi <= (unsigned)(H - 21);
             if (FIELD) uni = uni && cyi >= 0 && cyi + 9 <= (H >> 1);                            // (the chroma vector of a cross-parity reference is shifted by 2)
             if (uni) {
-                const uint8_t *ref = ref_plane(pp, slot);
-                const int xa = xi & ~3;
-#pragma unroll
-                // (unconditional loads -- lanes past the window's end fetch its last dword again: a load under `if (i < 126)` came out as its own block
-                // with its own s_waitcnt vmcnt(0), i.e. the two loads of a lane were two memory round trips one after the other)
-                for (int t = 0; t < 2; t++) { const int i = min(lane + 64 * t, 125);
-                    wv[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((yi + i / 6) * pitch + xa + (i % 6) * 4)); }
-                const uint8_t *rc = ref + pp.chroma_offset;
-                const int ca = (2 * cxi) & ~3;
+                u_xi = xi; u_yi = yi; u_cx2 = 2 * cxi; u_cyi = cyi;
                 c_sh = (2 * cxi) & 3;
-                { const int i = min(lane, 44); cw = ld_ref32<COH>(refbuf, rc, (uint32_t)((cyi + i / 5) * pitch + ca + (i % 5) * 4)); }
                 c_slot = slot; c_fx = mvx & 7; c_fy = cmvy & 7;
                 u_fx = mvx & 3; u_fy = mvy & 3; u_sh = xi & 3;
             }
         }
+    }
+    // Chain launches: can the workgroup's four macroblocks share one window?  Every wave says what its window would be; all four decide alike.
+    bool quad = false;
+    int q_row = 0, q_crow = 0;                              // quad path: this macroblock's first row in the shared luma / chroma window
+    uint32_t qv[4] = {0, 0, 0, 0}, qc[2] = {0, 0};          // quad path: this lane's dwords of the shared windows
+    if (CHAIN && COH) {
+        if (lane == 0) { sm.vote[wave][0] = uni ? c_slot : -1; sm.vote[wave][1] = u_xi; sm.vote[wave][2] = u_yi; sm.vote[wave][3] = u_cx2; sm.vote[wave][4] = u_cyi; }
+        __syncthreads();
+        const pk::QuadGeom qg = pk::quad_geometry(sm.vote);
+        quad = qg.ok;
+        const int x0 = qg.x0, y0 = qg.y0, cx0 = qg.cx0, cy0 = qg.cy0;
+        if (quad) {
+            // rows wave * 2 + (lane >> 5) + 8 k of the shared window, dword lane & 31 of the row: unconditional loads (clamped), stored where they belong below
+            const uint8_t *ref = ref_plane(pp, c_slot);
+            const int nrow = qg.nrow, ndw = qg.ndw, ncrow = qg.ncrow, ncdw = qg.ncdw;
+            const int sub = wave * 2 + (lane >> 5), dwi = lane & 31;
+#pragma unroll
+            for (int k = 0; k < 4; k++) qv[k] = ld_ref32<COH>(refbuf, ref, (uint32_t)((y0 + min(sub + 8 * k, nrow - 1)) * pitch + x0 + min(dwi, ndw - 1) * 4));
+            const uint8_t *rc = ref + pp.chroma_offset;
+#pragma unroll
+            for (int k = 0; k < 2; k++) qc[k] = ld_ref32<COH>(refbuf, rc, (uint32_t)((cy0 + min(sub + 8 * k, ncrow - 1)) * pitch + cx0 + min(dwi, ncdw - 1) * 4));
+            q_row = u_yi - y0; q_crow = u_cyi - cy0;
+            u_sh = u_xi - x0; c_sh = u_cx2 - cx0;           // byte offsets of this macroblock's first sample in a row of the shared windows
+            // (what the stores below need: the window's extent, in registers the loop above already holds)
+            qv_rows = nrow; qv_dws = ndw; qc_rows = ncrow; qc_dws = ncdw;
+        }
+    }
+    if (uni && !quad) {
+        const uint8_t *ref = ref_plane(pp, c_slot);
+        const int xa = u_xi & ~3;
+#pragma unroll
+        // (unconditional loads -- lanes past the window's end fetch its last dword again: a load under `if (i < 126)` came out as its own block
+        // with its own s_waitcnt vmcnt(0), i.e. the two loads of a lane were two memory round trips one after the other)
+        for (int t = 0; t < 2; t++) { const int i = min(lane + 64 * t, 125);
+            wv[t] = ld_ref32<COH>(refbuf, ref, (uint32_t)((u_yi + i / 6) * pitch + xa + (i % 6) * 4)); }
+        const uint8_t *rc = ref + pp.chroma_offset;
+        const int ca = u_cx2 & ~3;
+        { const int i = min(lane, 44); cw = ld_ref32<COH>(refbuf, rc, (uint32_t)((u_cyi + i / 5) * pitch + ca + (i % 5) * 4)); }
     }
     if (plain && !uni) {
         {
@@ -564,7 +604,17 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     // Slow path (sub-8x8 partitions, windows touching the picture border, missing reference): literal per-sample taps.
     uint32_t pred;                                              // this lane's four luma samples (px .. px + 3, py) of the macroblock
     int px, py;
-    if (uni) {
+    if (CHAIN && COH && quad) {
+        // the workgroup's shared window (every wave of the workgroup is here: `quad` is the same for all four)
+        const int sub = wave * 2 + (lane >> 5), dwi = lane & 31;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (sub + 8 * k < qv_rows && dwi < qv_dws) sm.qwin[(sub + 8 * k) * kQStride + dwi] = qv[k] ^ pk::kSign;
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (sub + 8 * k < qc_rows && dwi < qc_dws) sm.qcwin[(sub + 8 * k) * kQStride + dwi] = qc[k];
+        __syncthreads();
+        py = lane >> 2; px = (lane & 3) * 4;
+        pred = pk::mc_luma4(sm.qwin, kQStride, py + q_row, px + u_sh, u_fx, u_fy);
+    } else if (uni) {
         // the macroblock's window: 21 rows x 6 dwords (+ the chroma window behind it), written by all 64 lanes, read back by the same wave;
         // lane -> row lane >> 2, samples 4 * (lane & 3) ..: the output tile and the residual are then walked linearly
         uint32_t *w16 = &wins[wave][0][0];
@@ -608,11 +658,11 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     {
         const int cx = lane & 7, cy = lane >> 3;
         if (uni) {
-            // U V U V at byte c_sh + 2 * cx of window rows cy and cy + 1 (5 dwords per row): two dwords per row, aligned by byte
-            const uint32_t *cwn = &wins[wave][0][0] + kUniChroma;
-            const int o = (c_sh + 2 * cx) >> 2, sh = (c_sh + 2 * cx) & 3;
-            const uint32_t a0 = cwn[cy * 5 + o], a1 = cwn[cy * 5 + o + 1], b0 = cwn[(cy + 1) * 5 + o], b1 = cwn[(cy + 1) * 5 + o + 1];
-            c_wa = __builtin_amdgcn_alignbyte(a1, a0, sh); c_wb = __builtin_amdgcn_alignbyte(b1, b0, sh);
+            // U V U V at byte c_sh + 2 * cx of window rows cy and cy + 1 (5 dwords per row; the shared window: kQStride): two dwords per row, aligned by byte
+            const bool q = CHAIN && COH && quad;
+            const uint32_t *cwn = q ? sm.qcwin + q_crow * kQStride : &wins[wave][0][0] + kUniChroma;
+            const int cs = q ? kQStride : 5;
+            pk::chroma_pairs(cwn, cs, cy, c_sh + 2 * cx, c_wa, c_wb);
         }
         // 8.4.2.2.2: one v_dot4 per plane with the weights (8 - x)(8 - y), x (8 - y), (8 - x) y, x y
         uint32_t uv = c_slot < 0 ? 0x8080u : pk::mc_chroma_uv(c_wa, c_wb, pk::chroma_weights(c_fx, c_fy));
