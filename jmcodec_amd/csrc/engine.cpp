@@ -1,5 +1,6 @@
 // jmcodec_amd/csrc/engine.cpp -- see engine.h.
 #include "engine.h"
+#include "chain_order.h"
 #include "decoder.h"
 #include "kernels.h"
 #include "hevc_kernels.h"
@@ -452,25 +453,9 @@ void Engine::launch(Lane &ln, Batch &b) {
         // (The invariant of chain_common.h is established by construction here -- Engine::form keeps the bands within their budget, base_of is built from
         // kMinChainLag / kKeySlack above -- and checked independently by tools/chain_keys.py, which restates every device wait and tests the keys by brute
         // force, tests/test_chain_keys.py.  A run-time re-check against the same constants, as round 4 had here, could never fire: ADVICE r4.)
-        // Groups of ONE key are independent of each other, so their order inside the bucket is free -- and decides on which XCD a group runs: work-list entry g
-        // becomes workgroups 2g, 2g + 1, which the dispatcher hands to XCDs (2g) % 8 and (2g + 1) % 8.  Each XCD has its own L2: in plain key order the groups that
-        // read one stretch of a reference picture (the same 8-macroblock column in neighbouring rows; their windows overlap by 5 of 21 rows) were spread over all
-        // eight, and every L2 fetched the rows again (k_chain fetched 4 x its algorithmic bytes).  So: column c of a picture goes to XCD pair (c + picture) % 4
-        // whenever the bucket has such a group left for the position at hand, else whatever it has most of (no padding entries: the key rule only orders
-        // buckets, and within a bucket every order is as good as any other for it).
-        for (size_t k = 0; k < n_keys; k++) {
-            std::vector<uint32_t> &bk = group_buckets_[k];
-            if (bk.size() < 2 || !xcd_group_order_) { for (uint32_t e : bk) b.h_groups[n_groups++] = e; continue; }
-            uint32_t *q[4]; int qn[4] = {0, 0, 0, 0}, qi[4] = {0, 0, 0, 0};
-            if (bucket_tmp_.size() < 4 * bk.size()) bucket_tmp_.resize(4 * bk.size());
-            for (int j = 0; j < 4; j++) q[j] = bucket_tmp_.data() + (size_t)j * bk.size();
-            for (uint32_t e : bk) { const int j = (int)((e & 31u) + (e >> 16)) & 3; q[j][qn[j]++] = e; }
-            for (size_t left = bk.size(); left; left--) {
-                int j = n_groups & 3;
-                if (qi[j] == qn[j]) { int best = 0; for (int t = 1; t < 4; t++) if (qn[t] - qi[t] > qn[best] - qi[best]) best = t; j = best; }
-                b.h_groups[n_groups++] = q[j][qi[j]++];
-            }
-        }
+        // Groups of ONE key are independent of each other: inside a bucket they are dealt so that a picture's 8-macroblock column always runs on the same XCD pair
+        // (chain_order.h; the key rule orders buckets only and does not see it)
+        for (size_t k = 0; k < n_keys; k++) append_bucket_by_xcd(group_buckets_[k].data(), group_buckets_[k].size(), b.h_groups, n_groups, bucket_tmp_);
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
         launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_ != 0, st);
         b.chain_with_intra = with_intra;

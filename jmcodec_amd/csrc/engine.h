@@ -157,8 +157,7 @@ private:
     std::vector<Recent> recent_;
     // scratch of launch() // pictures of one stream per launch at most (JM_AMD_DEC_CHAIN_DEPTH; 1 = off)
     std::vector<std::vector<uint32_t>> group_buckets_;
-    std::vector<uint32_t> bucket_tmp_;
-    bool xcd_group_order_ = true;                                      // Engine::launch: groups of one key ordered by the XCD their column belongs to
+    std::vector<uint32_t> bucket_tmp_;                                 // scratch of append_bucket_by_xcd (chain_order.h)
     void launch(Lane &ln, Batch &b);
     void launch_hevc(Lane &ln, Batch &b);
     void complete(Lane &ln, Batch &b, bool failed);

@@ -11,6 +11,8 @@ The model restates, macroblock by macroblock, what the device code waits for:
     prefetches up to step s + DEPTH, and after the band above has published step s + DEPTH + kAbove (published kPubLag steps late, every `pub` steps);
   * with the intra role (`k_chain_i`), the band is gated by P's intra wavefront instead (x + 2y steps, `intra_device.h`), which waits for the bits.
 Keys and spacing are the engine's (`key()`, `spacing()` below mirror Engine::launch; tests/test_chain_keys.py checks that the constants agree).
+The rule orders BUCKETS of equal key; inside a bucket the engine is free (round 5: groups dealt by XCD, jmcodec_amd/csrc/chain_order.h -- a permutation of the
+bucket, tests/test_chain_order.py).
 
     python3 tools/chain_keys.py [mb_w mb_h]        # prints, per case, (largest needed key of P) - (key of the dependent group): must be < 0
 """
