@@ -453,8 +453,8 @@ void Engine::launch(Lane &ln, Batch &b) {
         // (The invariant of chain_common.h is established by construction here -- Engine::form keeps the bands within their budget, base_of is built from
         // kMinChainLag / kKeySlack above -- and checked independently by tools/chain_keys.py, which restates every device wait and tests the keys by brute
         // force, tests/test_chain_keys.py.  A run-time re-check against the same constants, as round 4 had here, could never fire: ADVICE r4.)
-        // Groups of ONE key are independent of each other: inside a bucket they are dealt so that a picture's 8-macroblock column always runs on the same XCD pair
-        // (chain_order.h; the key rule orders buckets only and does not see it)
+        // Groups of ONE key are independent of each other: inside a bucket they are dealt so that a picture's 8-macroblock column always runs on the same XCD
+        // pair (chain_order.h; the key rule orders buckets only and does not see it)
         for (size_t k = 0; k < n_keys; k++) append_bucket_by_xcd(group_buckets_[k].data(), group_buckets_[k].size(), b.h_groups, n_groups, bucket_tmp_);
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
         launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_ != 0, st);

@@ -347,8 +347,8 @@ const IntraNbTable kIntraNb;
 inline uint32_t low_bits(int n) { return n >= 32 ? 0xffffffffu : (1u << (n < 0 ? 0 : n)) - 1u; }
 }  // namespace
 
-// which of the four neighbouring coding tree blocks the current one may predict from (6.4.1: decoded, same slice, same tile): bit 0 left, 1 above, 2 above right,
-// 3 above left
+// which of the four neighbouring coding tree blocks the current one may predict from (6.4.1: decoded, same slice, same tile): bit 0 left, 1 above, 2 above
+// right, 3 above left
 int HevcPicParser::ctb_neighbours() {
     if (nbf_rs_ == ctb_rs_) return nbf_;
     const int cx = ctb_rs_ % ctb_w_, cy = ctb_rs_ / ctb_w_;
@@ -386,9 +386,10 @@ void HevcPicParser::emit_intra_tb(int xp, int yp, int log2, int c, int mode, boo
             if ((ux > 0 && uy > 0) || (ux == 0 && uy == 0 ? (nb & 8) : ux == 0 ? (nb & 1) : (nb & 2))) t.flags |= HTB_CORNER;
 #ifdef JM_CHECK_INTRA_NB                                               // developer cross-check against the unit-by-unit form (tools/host_bench with HB_FLAGS)
             { uint32_t av = 0; bool corner = avail_zs(xl, yl, xl - 1, yl - 1);
-              for (int i = 0; i < units; i++) { if (avail_zs(xl, yl, xl - 1, yl + i * unit)) av |= 1u << i; if (avail_zs(xl, yl, xl + i * unit, yl - 1)) av |= 1u << (16 + i); }
-              if (av != t.avail || corner != ((t.flags & HTB_CORNER) != 0)) { fprintf(stderr, "intra neighbours differ at (%d, %d) log2 %d plane %d: %08x / %08x\n",
-                  xl, yl, log2, c, t.avail, av); abort(); } }
+              for (int i = 0; i < units; i++) { if (avail_zs(xl, yl, xl - 1, yl + i * unit)) av |= 1u << i;
+                  if (avail_zs(xl, yl, xl + i * unit, yl - 1)) av |= 1u << (16 + i); }
+              if (av != t.avail || corner != ((t.flags & HTB_CORNER) != 0)) {
+                  fprintf(stderr, "intra neighbours differ at (%d, %d) log2 %d plane %d: %08x / %08x\n", xl, yl, log2, c, t.avail, av); abort(); } }
 #endif
         } else {
             for (int i = 0; i < units; i++) {

@@ -243,7 +243,8 @@ JM_HD QuadGeom quad_geometry(const int (*vote)[8]) {
     x0 &= ~3; cx0 &= ~3;
     QuadGeom g;
     g.ok = all && x1 - x0 + 28 <= kQuadStride * 4 && y1 - y0 + 21 <= kQuadRows && cx1 - cx0 + 24 <= kQuadStride * 4 && cy1 - cy0 + 9 <= kQuadChromaRows;
-    g.x0 = x0; g.y0 = y0; g.nrow = y1 - y0 + 21; g.ndw = (x1 - x0 + 21 + 3) >> 2; g.cx0 = cx0; g.cy0 = cy0; g.ncrow = cy1 - cy0 + 9; g.ncdw = (cx1 - cx0 + 18 + 3) >> 2;
+    g.x0 = x0; g.y0 = y0; g.nrow = y1 - y0 + 21; g.ndw = (x1 - x0 + 21 + 3) >> 2;
+    g.cx0 = cx0; g.cy0 = cy0; g.ncrow = cy1 - cy0 + 9; g.ncdw = (cx1 - cx0 + 18 + 3) >> 2;
     return g;
 }
 // the four interleaved chroma bytes U V U V at byte offset `off` of window rows r and r + 1 (`stride` dwords per row): what mc_chroma_uv takes

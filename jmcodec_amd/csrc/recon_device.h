@@ -229,8 +229,8 @@ template <bool COH> __device__ __noinline__ int luma_sample(const uint8_t *surf_
 // LDS of one 4-wave workgroup of the inter reconstruction
 constexpr int kUniChroma = 136;          // dword offset of the chroma window behind the 21 x 6 luma window in wins[wave] (uni path)
 // Chain launches, "quad" path (round 5): when the four macroblocks of a workgroup all take the one-window path from the same reference picture with vectors
-// that lie close together, the workgroup fetches ONE window for the four of them -- kQRows rows of kQStride dwords of luma, kQCRows of chroma -- instead of four
-// overlapping ones (coherent loads are served from memory in 64-byte requests whoever read the line before: four private 24-byte rows cost 5.2 requests, one
+// that lie close together, the workgroup fetches ONE window for the four of them -- kQRows rows of kQStride dwords of luma, kQCRows of chroma -- instead of
+// four overlapping ones (coherent loads are served from memory in 64-byte requests whoever read the line before: four private 24-byte rows cost 5.2 requests, one
 // shared 72-byte row 2.1; profiles/r05_chain_quad_fetch.txt).
 constexpr int kQStride = pk::kQuadStride, kQRows = pk::kQuadRows, kQCRows = pk::kQuadChromaRows;      // (mc_packed.h: quad_geometry, host-tested)
 struct alignas(16) ReconLds {
@@ -351,7 +351,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     int q_row = 0, q_crow = 0;                              // quad path: this macroblock's first row in the shared luma / chroma window
     uint32_t qv[4] = {0, 0, 0, 0}, qc[2] = {0, 0};          // quad path: this lane's dwords of the shared windows
     if (CHAIN && COH) {
-        if (lane == 0) { sm.vote[wave][0] = uni ? c_slot : -1; sm.vote[wave][1] = u_xi; sm.vote[wave][2] = u_yi; sm.vote[wave][3] = u_cx2; sm.vote[wave][4] = u_cyi; }
+        if (lane == 0) { int *v = sm.vote[wave]; v[0] = uni ? c_slot : -1; v[1] = u_xi; v[2] = u_yi; v[3] = u_cx2; v[4] = u_cyi; }
         __syncthreads();
         const pk::QuadGeom qg = pk::quad_geometry(sm.vote);
         quad = qg.ok;
@@ -365,7 +365,8 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             for (int k = 0; k < 4; k++) qv[k] = ld_ref32<COH>(refbuf, ref, (uint32_t)((y0 + min(sub + 8 * k, nrow - 1)) * pitch + x0 + min(dwi, ndw - 1) * 4));
             const uint8_t *rc = ref + pp.chroma_offset;
 #pragma unroll
-            for (int k = 0; k < 2; k++) qc[k] = ld_ref32<COH>(refbuf, rc, (uint32_t)((cy0 + min(sub + 8 * k, ncrow - 1)) * pitch + cx0 + min(dwi, ncdw - 1) * 4));
+            for (int k = 0; k < 2; k++)
+                qc[k] = ld_ref32<COH>(refbuf, rc, (uint32_t)((cy0 + min(sub + 8 * k, ncrow - 1)) * pitch + cx0 + min(dwi, ncdw - 1) * 4));
             q_row = u_yi - y0; q_crow = u_cyi - cy0;
             u_sh = u_xi - x0; c_sh = u_cx2 - cx0;           // byte offsets of this macroblock's first sample in a row of the shared windows
             // (what the stores below need: the window's extent, in registers the loop above already holds)

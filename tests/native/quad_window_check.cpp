@@ -14,7 +14,8 @@ int qw_check(const uint8_t *pic, int pitch, int chroma_offset, const int *votes,
     for (int w = 0; w < 4; w++) for (int k = 0; k < 5; k++) vote[w][k] = votes[w * 5 + k];
     const QuadGeom g = quad_geometry(vote);
     if (!g.ok) return 0;
-    auto ld = [&](const uint8_t *plane, int off) { return (uint32_t)plane[off] | (uint32_t)plane[off + 1] << 8 | (uint32_t)plane[off + 2] << 16 | (uint32_t)plane[off + 3] << 24; };
+    auto ld = [&](const uint8_t *plane, int off) {
+        return (uint32_t)plane[off] | (uint32_t)plane[off + 1] << 8 | (uint32_t)plane[off + 2] << 16 | (uint32_t)plane[off + 3] << 24; };
     std::vector<uint32_t> qwin(kQuadRows * kQuadStride), qcwin(kQuadChromaRows * kQuadStride);
     for (size_t i = 0; i < qwin.size(); i++) qwin[i] = noise * (uint32_t)(2654435761u + i * 40503u);
     for (size_t i = 0; i < qcwin.size(); i++) qcwin[i] = noise * (uint32_t)(97u + i * 7919u);
@@ -33,7 +34,8 @@ int qw_check(const uint8_t *pic, int pitch, int chroma_offset, const int *votes,
         }
     }
     for (int w = 0; w < 4; w++) {
-        const int xi = vote[w][1], yi = vote[w][2], cx2 = vote[w][3], cyi = vote[w][4], fx = frac[w * 4], fy = frac[w * 4 + 1], cfx = frac[w * 4 + 2], cfy = frac[w * 4 + 3];
+        const int xi = vote[w][1], yi = vote[w][2], cx2 = vote[w][3], cyi = vote[w][4];
+        const int fx = frac[w * 4], fy = frac[w * 4 + 1], cfx = frac[w * 4 + 2], cfy = frac[w * 4 + 3];
         // the private windows of the one-window path: 21 rows x 6 dwords from xi & ~3, 9 rows x 5 dwords from cx2 & ~3 (the rest: noise)
         uint32_t w16[21 * 6 + 8], cw[9 * 5 + 4];
         for (int i = 0; i < 21 * 6 + 8; i++) w16[i] = noise * (uint32_t)(31u + i);
