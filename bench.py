@@ -123,7 +123,8 @@ def compact_leg(l, wall_s):
                                              "pictures_per_launch")},
             "kernels": {k: {"avg_us": v["avg_us"], "pictures_per_launch": v["pictures_per_launch"]} for k, v in l["kernels"].items() if v["launches"]},
             "host_cpu": {"cpu_ms_per_frame": l["host_cpu"]["cpu_ms_per_frame"], "cpus_busy": l["host_cpu"]["cpus_busy"]},
-            "engine": {k: l["engine"][k] for k in ("chain_batches", "chain_i_batches", "chain_recoveries", "device_wait_errors", "pictures_per_batch")},
+            "engine": {k: l["engine"][k] for k in ("chain_batches", "chain_i_batches", "chain_recoveries", "device_wait_errors", "pictures_per_batch",
+                                                      "chain_launches_with_clock_gaps")},
             "stream_generation_s": l["config"]["stream_generation_s"], "leg_wall_s": round(wall_s, 1)}
 
 
@@ -314,14 +315,35 @@ def measure(args, ctx):
         if dist is not None:
             dist.barrier()
 
-    CS = (b"eng_chain_batches", b"eng_chain_pics", b"eng_wait_errors", b"eng_chain_recoveries", b"eng_chain_i_batches")
+    CS = (b"eng_chain_batches", b"eng_chain_pics", b"eng_wait_errors", b"eng_chain_recoveries", b"eng_chain_i_batches", b"eng_wait_gap_launches")
     cs0 = [L.jm_amddec_get_stat(handles[0], k) for k in CS]      # the engine is process-wide: counters of THIS measure() = differences
     if W > 0:
         batch(W)
     KN = ("inter", "intra", "deblock", "packout", "chain")     # chain = k_chain: reconstruction + deblocking of consecutive pictures in one launch
     def eng():      # engine-wide counters (one engine per device serves every handle)
         return {k: {f: L.jm_amddec_get_stat(handles[0], f"k_{k}_{f}".encode()) for f in ("ns", "n", "pics", "alg_bytes")} for k in KN}
+    LK = [b"eng_rej_other_lane", b"eng_rej_cross_lane", b"eng_rej_tables", b"eng_early_intra", b"eng_blocked_ns", b"eng_blocked_n", b"eng_forms"] + \
+         [f"eng_lane{i}_{f}".encode() for i in range(4) for f in ("busy_ns", "gap_ns", "batches", "pics")]
+    def lanes_now(h=None):
+        return {k.decode(): L.jm_amddec_get_stat(h or handles[0], k) for k in LK}
+    def lanes_report(a, b_, wall_s):
+        """Engine lanes between two snapshots: how full the ordinary lane's batches were and why not fuller, and how busy each lane's stream was."""
+        d = {k: b_[k] - a[k] for k in a}
+        forms = max(d["eng_forms"], 1)
+        names = ("ordinary", "intra", "hevc", "hevc_intra")
+        out = {"left_out_per_ordinary_batch": {"oldest_picture_is_for_another_lane": round(d["eng_rej_other_lane"] / forms, 2),
+                                               "earlier_pictures_on_another_lane": round(d["eng_rej_cross_lane"] / forms, 2),
+                                               "pack_tables_full": round(d["eng_rej_tables"] / forms, 2)},
+               "intra_pictures_launched_ahead_of_their_turn": int(d["eng_early_intra"]),
+               "left_out_ms_per_occasion": round(d["eng_blocked_ns"] / 1e6 / max(d["eng_blocked_n"], 1), 3), "left_out_occasions": int(d["eng_blocked_n"])}
+        for i, nm in enumerate(names):
+            if d[f"eng_lane{i}_batches"]:
+                out[nm] = {"batches": int(d[f"eng_lane{i}_batches"]), "pictures_per_batch": round(d[f"eng_lane{i}_pics"] / d[f"eng_lane{i}_batches"], 2),
+                           "busy_frac": round(d[f"eng_lane{i}_busy_ns"] / 1e9 / wall_s, 3), "idle_between_batches_frac": round(d[f"eng_lane{i}_gap_ns"] / 1e9 / wall_s, 3),
+                           "kernel_ms_per_batch": round(d[f"eng_lane{i}_busy_ns"] / 1e6 / d[f"eng_lane{i}_batches"], 3)}
+        return out
     e0 = eng()
+    ln0 = lanes_now()
     b0 = (L.jm_amddec_get_stat(handles[0], b"eng_batches"), L.jm_amddec_get_stat(handles[0], b"eng_batch_pics"))
     et0 = (L.jm_amddec_get_stat(handles[0], b"eng_launch_ns"), L.jm_amddec_get_stat(handles[0], b"eng_complete_ns"))
     fm0 = [L.jm_amddec_get_stat(handles[0], k) for k in (b"eng_forms", b"eng_form_decoders", b"eng_form_pending")]
@@ -388,6 +410,7 @@ def measure(args, ctx):
     # ---- per-kernel device time: HIP events recorded by the engine on ITS stream around every batched launch, timed region only ----
     names = KN
     e1 = eng()
+    lanes_timed = lanes_report(ln0, lanes_now(), dt)
     tot_ns = {k: e1[k]["ns"] - e0[k]["ns"] for k in names}
     tot_n = {k: e1[k]["n"] - e0[k]["n"] for k in names}
     tot_pics = {k: e1[k]["pics"] - e0[k]["pics"] for k in names}
@@ -395,8 +418,9 @@ def measure(args, ctx):
     batches = L.jm_amddec_get_stat(handles[0], b"eng_batches") - b0[0]
     batch_pics = L.jm_amddec_get_stat(handles[0], b"eng_batch_pics") - b0[1]
     cs1 = [L.jm_amddec_get_stat(handles[0], k) for k in CS]
+    gap_max_us = L.jm_amddec_get_stat(handles[0], b"eng_wait_gap_max_us")
     chain_stat = (cs1[0] - cs0[0], cs1[1] - cs0[1], cs1[2] - cs0[2], cs1[3] - cs0[3], L.jm_amddec_get_stat(handles[0], b"eng_gpu_shared"),
-                  cs1[4] - cs0[4])   # warm-up + timed region of this configuration
+                  cs1[4] - cs0[4], cs1[5] - cs0[5])   # warm-up + timed region of this configuration
     dfr = sum(L.jm_amddec_get_stat(h, b"direct_frames") for h in handles)
     direct_stat = {"sdma_engines": hex(L.jm_amddec_get_stat(handles[0], b"copy_engines")), "frames_whole_run": int(dfr),
         "caller_wait_us_per_frame": round(sum(L.jm_amddec_get_stat(h, b"direct_ns") for h in handles) / 1e3 / max(dfr, 1), 1)}
@@ -579,6 +603,46 @@ def measure(args, ctx):
                       "(test_nv_dec.cpp:184-250); untimed extra leg"}
         jmcodec_amd.jm_nvdec_deinit(h)
 
+    # ---- untimed: BASELINE config 0's call shape -- ONE handle of the push / pull API (jm_intel_dec_*), driven by the loop of test_intel_dec.cpp:64-102
+    # in native code (jm_amdintel_run_pushpull): input_data in pushes of free_buf_len = 1 MB while need_more_data, one output_frame into the caller's
+    # buffer per turn, set_eof when the input ran out, until is_exit.  A first copy of the stream is pushed through the same handle untimed (allocations,
+    # first launches), like the single-stream leg. ----
+    c0_leg = None
+    if world == 1 and not args.parse_only and not args.no_single:
+        h = L.jm_amdintel_create_handle()
+        if L.jm_amdintel_init(1 if is_hevc else 0, 1, h) == 0:
+            out = (C.c_ubyte * frame_bytes)()
+            sp = max(1, min(8, 240 // max(F, 1)))
+            d0 = datas[0]
+            base = C.cast(C.c_char_p(d0), C.c_void_p).value
+            pos, n, warm = 0, C.c_int(0), 0
+            while pos < len(d0):                                   # warm-up: the reference loop without the end of stream
+                if L.jm_amdintel_need_more_data(h):
+                    k = min(L.jm_amdintel_free_buf_len(h), len(d0) - pos)
+                    L.jm_amdintel_input_data(base + pos, k, h); pos += k
+                n.value = frame_bytes
+                if L.jm_amdintel_output_frame(C.cast(out, C.c_void_p), C.byref(n), h) == 0:
+                    warm += 1
+            L.jm_amddec_set_option(L.jm_amdintel_decoder(h), b"wait_idle", 1)
+            timed = d0 * sp
+            c_0 = time.perf_counter()
+            n1 = L.jm_amdintel_run_pushpull(timed, len(timed), out, frame_bytes, h)
+            cdt = time.perf_counter() - c_0
+            last_ok = None
+            if check_digests[0]:
+                last_ok = hashlib.md5(bytes(out)).digest() == check_digests[0][-1]      # the last frame of the stream sits in the caller's buffer
+            c0_leg = {"value": round(sp * F / cdt, 1), "unit": "frames/s", "frames": sp * F, "frames_returned": int(n1 + warm), "frames_expected": (sp + 1) * F,
+                  "push_bytes": int(L.jm_amdintel_free_buf_len(h)), "bitstream_bytes_per_frame": int(len(d0) / max(F, 1)),
+                  "last_frame_equals_checked_pass": last_ok,
+                  "vs_single_stream": round(sp * F / cdt / single["value"], 3) if single and single["value"] else None,
+                  "decode_errors": int(L.jm_amddec_get_stat(L.jm_amdintel_decoder(h), b"errors")),
+                  "note": "BASELINE config 0's shape (test_intel_dec.cpp:64-102): one jm_intel_dec handle, one thread, pushes of free_buf_len, one "
+                          "output_frame per loop turn into the caller's buffer (one copy-engine transfer per frame); untimed extra leg"}
+            if last_ok is False or n1 + warm != (sp + 1) * F:
+                bit_exact = False
+                print(f"bench.py: c0_pushpull: {n1 + warm} frames of {(sp + 1) * F}, last frame matches: {last_ok}", file=sys.stderr)
+        L.jm_amdintel_deinit(h)
+
     # ---- untimed: the same S streams with DEVICE-RESIDENT output (jm_amddec_output_frame_device: frames stay in HBM, nothing crosses PCIe on the way
     # out, no frame copy on the CPU) -- the rate the contract calls "inputs and outputs resident in HBM"; `value` above is the PCIe-inclusive one ----
     dev_leg = None
@@ -596,6 +660,7 @@ def measure(args, ctx):
             L.jm_amddec_set_option(hs[i], b"wait_idle", 1)
         for passes, timed in ((1, False), (max(1, min(K, 8)), True)):      # (three passes were 0.27 s: a tenth of it pipeline fill and drain)
             dhc0 = host_cpu()
+            dl0 = lanes_now(hs[0]) if hs else None
             c0 = time.perf_counter()
             ts = [threading.Thread(target=dev_pass, args=(i, passes)) for i in range(len(hs))]
             for t in ts:
@@ -609,11 +674,16 @@ def measure(args, ctx):
                 dhc1 = host_cpu()
                 d_busy = (dhc1["cpu_s"] - dhc0["cpu_s"]) / ddt
                 d_quota = dhc1.get("quota_cpus") or os.cpu_count()
+                d_lanes = lanes_report(dl0, lanes_now(hs[0]), ddt) if dl0 else {}
+                # what bounds it, from measurements instead of by elimination: the host when its CPU allotment is used up; else the
+                # device when the busiest lane's stream has kernels on it for >= 85 % of the wall time; else the pipeline in between (batches not formed in time)
+                lane_busy = max([v["busy_frac"] for v in d_lanes.values() if isinstance(v, dict) and "busy_frac" in v] or [0.0])
+                d_bound = "host_cpu_quota" if d_quota and d_busy >= 0.9 * d_quota else ("gpu" if lane_busy >= 0.85 else "engine_pipeline")
                 dev_leg = {"value": round(len(hs) * F * passes / ddt, 1), "unit": "frames/s", "frames": len(hs) * F * passes,
                            "host_cpu": {"cpu_ms_per_frame": round(1e3 * (dhc1["cpu_s"] - dhc0["cpu_s"]) / max(len(hs) * F * passes, 1), 4),
                                         "cpus_busy": round(d_busy, 2), "quota_cpus": d_quota},
                            # (no link in the way here: the host's entropy decode -- >= 90 % of the CPU allotment busy -- or the device)
-                           "scaling_bound": "host_cpu_quota" if d_quota and d_busy >= 0.9 * d_quota else "gpu",
+                           "scaling_bound": d_bound, "busiest_lane_busy_frac": lane_busy, "lanes": d_lanes,
                            "note": "untimed extra leg: the same streams, display frames left in device memory (jm_amddec_output_frame_device, SURVEY 8f f3): "
                                    "no D2H copy, no frame copy on the CPU; host entropy decode and job-list upload still included"}
         for h in hs:
@@ -693,10 +763,13 @@ def measure(args, ctx):
                      "alg_bytes_per_launch": int(alg[dominant]), "avg_launch_us": round(avg_s[dominant] * 1e6, 2),
                      "launches": int(tot_n[dominant]), "pictures_per_launch": round(tot_pics[dominant] / max(tot_n[dominant], 1), 2)},
         "engine": {"batches": int(batches), "pictures_per_batch": round(batch_pics / max(batches, 1), 2), "engine_thread_ms": eng_thread_ms,
-        "formation": form_stat, "direct_output": direct_stat,
+        "formation": form_stat, "lanes": lanes_timed, "direct_output": direct_stat,
                    "chain_batches_whole_run": int(chain_stat[0]), "chain_pictures_whole_run": int(chain_stat[1]), "device_wait_errors": int(chain_stat[2]),
                    "chain_recoveries_whole_run": int(chain_stat[3]), "gpu_shared_with_another_process": bool(chain_stat[4]),
-                   "chain_batches": int(chain_stat[0]), "chain_i_batches": int(chain_stat[5]), "chain_recoveries": int(chain_stat[3])},
+                   "chain_batches": int(chain_stat[0]), "chain_i_batches": int(chain_stat[5]), "chain_recoveries": int(chain_stat[3]),
+                   # chain launches whose waits saw the wall clock jump by more than 5 ms between two looks: their waves were not run meanwhile (the timers
+                   # leave such gaps out: chain_common.h WaitClock); the longest jump any launch of this process saw
+                   "chain_launches_with_clock_gaps": int(chain_stat[6]), "longest_clock_gap_us_whole_process": int(gap_max_us)},
         "pcie_out": None if args.device_output else {"bound": "pcie", "achieved": round(value / world * frame_bytes / 1e9, 2), "peak": 54.0, "unit": "GB/s",
         "frac": round(value / world * frame_bytes / 1e9 / 54.0, 4),
                      "note": "what bounds the rate WITH host output: every frame crosses the link once (k_packout -> device staging -> copy engine -> "
@@ -746,6 +819,8 @@ def measure(args, ctx):
         line["cpu_baseline"] = cpu
     if single is not None:
         line["single_stream"] = single
+    if c0_leg is not None:
+        line["c0_pushpull"] = c0_leg
     if dev_leg is not None:
         line["device_resident_output"] = dev_leg
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))

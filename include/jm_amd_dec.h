@@ -61,10 +61,16 @@ int  jm_amddec_is_hw_support(void);
  *       tests only: "fast_parse" (0 = every macroblock through the general parser path), "job_digest" (1 = digest of the job lists; implies sync) */
 /* like jm_amddec_decode_frame without input: *got_frame = 1 when a display-order frame became ready (never signals end of stream) */
 int  jm_amddec_poll_frame(int *got_frame, jm_amddec_handle h);
+/* jm_amddec_poll_frame that sleeps up to timeout_us microseconds for a frame whose picture is still being decoded (returns at once when nothing is on its way) */
+int  jm_amddec_wait_frame(int *got_frame, int timeout_us, jm_amddec_handle h);
+/* input without taking a frame: the push half of the reference's push / pull API (intel_dec_put_input_data, /root/reference/intel_dec/intel_dec.cpp:189-234).
+ * The frame signalled by an earlier got_frame = 1 stays current until the next jm_amddec_decode_frame / jm_amddec_poll_frame call.  0, or -1 on error. */
+int  jm_amddec_push_data(unsigned char *in_buf, int in_data_len, jm_amddec_handle h);
 int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
 /* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
  *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",
- *       "threads", "elapsed_us", "display_poc:<n>", "device_wait_errors", "direct_frames" / "direct_ns" (frames that left by one copy-engine
+ *       "threads", "elapsed_us", "display_poc:<n>", "fps_num" / "fps_den" (frame rate from the VUI timing information, 0 / 0 = not transmitted),
+ *       "frames_waiting" (display frames decided and not yet made current by a decode / poll call), "device_wait_errors", "direct_frames" / "direct_ns" (frames that left by one copy-engine
  *       transfer into the caller's buffer, and the time their callers waited), "copy_engines" (SDMA engines used for that, bit mask),
  *       "job_digest", "eng_*" / "k_*" (engine and per-kernel counters, bench.py) */
 long long jm_amddec_get_stat(jm_amddec_handle h, const char *key);

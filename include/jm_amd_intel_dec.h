@@ -45,6 +45,13 @@ int   jm_amdintel_free_buf_len(jm_amdintel_handle h);
 int   jm_amdintel_is_exit(jm_amdintel_handle h);
 int   jm_amdintel_is_hw_support(void);
 
+/* addition (no reference counterpart): the push / pull loop of /root/reference/test_intel_dec/test_intel_dec.cpp:64-102 in native code over a whole
+ * Annex-B buffer -- input_data in chunks of free_buf_len while need_more_data, set_eof when the input ran out, one output_frame into out_buf per
+ * turn, until is_exit.  Returns the number of frames fetched, < 0 on error.  For callers in interpreted languages (bench.py). */
+/* the jm_amd_dec.h handle behind a push / pull handle: options before init (jm_amddec_set_option), statistics (jm_amddec_get_stat), jm_amddec_last_error */
+void *jm_amdintel_decoder(jm_amdintel_handle h);
+long  jm_amdintel_run_pushpull(const unsigned char *buf, long len, unsigned char *out_buf, int out_cap, jm_amdintel_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,27 @@ def lib():
     L.jm_amddec_output_frame_device.argtypes = [C.POINTER(C.c_void_p), ip, vp]
     L.jm_amddec_feed_annexb.argtypes = [cp, C.c_long, C.c_int, C.POINTER(C.c_ubyte), C.c_int, vp]
     L.jm_amddec_feed_annexb.restype = C.c_long
+    L.jm_amddec_poll_frame.argtypes = [ip, vp]
+    L.jm_amddec_wait_frame.argtypes = [ip, C.c_int, vp]
+    L.jm_amddec_push_data.argtypes = [vp, C.c_int, vp]
+    # push / pull API (include/jm_amd_intel_dec.h <- /root/reference/intel_dec/jm_intel_dec.h:29-122)
+    L.jm_amdintel_create_handle.restype = vp
+    L.jm_amdintel_init.argtypes = [C.c_int, C.c_int, vp]
+    L.jm_amdintel_deinit.argtypes = [vp]
+    L.jm_amdintel_set_yuv_callback.argtypes = [vp, vp, vp]
+    L.jm_amdintel_input_data.argtypes = [vp, C.c_int, vp]
+    L.jm_amdintel_output_frame.argtypes = [vp, ip, vp]
+    L.jm_amdintel_set_eof.argtypes = [C.c_int, vp]
+    L.jm_amdintel_info.argtypes = [vp]
+    L.jm_amdintel_info.restype = cp
+    L.jm_amdintel_get_stream_info.argtypes = [ip, ip, C.POINTER(C.c_float), vp]
+    L.jm_amdintel_need_more_data.argtypes = [vp]
+    L.jm_amdintel_free_buf_len.argtypes = [vp]
+    L.jm_amdintel_is_exit.argtypes = [vp]
+    L.jm_amdintel_run_pushpull.argtypes = [cp, C.c_long, C.POINTER(C.c_ubyte), C.c_int, vp]
+    L.jm_amdintel_run_pushpull.restype = C.c_long
+    L.jm_amdintel_decoder.argtypes = [vp]
+    L.jm_amdintel_decoder.restype = vp
     _LIB = L
     return L
 
@@ -252,3 +273,123 @@ class JmAmdDec:
 
     def __exit__(self, *a):
         self.close()
+
+
+# ---- the reference's push / pull API (intel_dec/jm_intel_dec.h:29-122), same names and argument order ----
+YUV_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_void_p)     # HANDLE_YUV_CALLBACK, jm_intel_dec.h:20
+
+
+def jm_intel_is_hw_support():
+    return bool(lib().jm_amdintel_is_hw_support())
+
+
+def jm_intel_dec_create_handle():
+    return lib().jm_amdintel_create_handle()
+
+
+def jm_intel_dec_init(codec_type, out_fmt, handle):
+    return lib().jm_amdintel_init(codec_type, out_fmt, handle)
+
+
+def jm_intel_dec_deinit(handle):
+    return lib().jm_amdintel_deinit(handle)
+
+
+def jm_intel_dec_set_yuv_callback(user_data, callback, handle):
+    """callback: a YUV_CALLBACK instance (the caller keeps it alive) or None."""
+    return lib().jm_amdintel_set_yuv_callback(user_data, C.cast(callback, C.c_void_p) if callback else None, handle)
+
+
+def jm_intel_dec_input_data(in_buf, in_data_len, handle):
+    """in_buf: bytes or a ctypes buffer / address.  Returns the bytes accepted (> 0) or < 0."""
+    if isinstance(in_buf, (bytes, bytearray)):
+        in_buf = C.cast(C.c_char_p(bytes(in_buf)), C.c_void_p)
+    return lib().jm_amdintel_input_data(in_buf, in_data_len, handle)
+
+
+def jm_intel_dec_output_frame(out_buf, out_len, handle):
+    """out_buf: writable ctypes buffer or None (size query); out_len: its capacity.  Returns (ret, bytes): ret 0 = a frame was copied,
+    -1 = none ready, -2 = buffer too small (jm_intel_dec.h:69-78)."""
+    n = C.c_int(out_len)
+    ret = lib().jm_amdintel_output_frame(C.cast(out_buf, C.c_void_p) if out_buf is not None else None, C.byref(n), handle)
+    return ret, n.value
+
+
+def jm_intel_dec_set_eof(is_eof, handle):
+    return lib().jm_amdintel_set_eof(int(is_eof), handle)
+
+
+def jm_intel_dec_info(handle):
+    s = lib().jm_amdintel_info(handle)
+    return s.decode() if s else ""
+
+
+def jm_intel_get_stream_info(handle):
+    """Returns (ret, width, height, frame_rate)."""
+    w, h, f = C.c_int(0), C.c_int(0), C.c_float(0.0)
+    ret = lib().jm_amdintel_get_stream_info(C.byref(w), C.byref(h), C.byref(f), handle)
+    return ret, w.value, h.value, f.value
+
+
+def jm_intel_dec_need_more_data(handle):
+    return bool(lib().jm_amdintel_need_more_data(handle))
+
+
+def jm_intel_dec_free_buf_len(handle):
+    return lib().jm_amdintel_free_buf_len(handle)
+
+
+def jm_intel_dec_is_exit(handle):
+    return bool(lib().jm_amdintel_is_exit(handle))
+
+
+def intel_push_pull(data, codec_type=0, out_fmt=1, callback=False, max_push=None, on_frame=None, options=None):
+    """The loop of /root/reference/test_intel_dec/test_intel_dec.cpp:64-102 over an Annex-B buffer: while not is_exit: if need_more_data and input is
+    left, input_data(min(free_buf_len, remaining)) -- set_eof when it ran out; then one output_frame.  Frames go to ``on_frame(bytes)`` (default: a
+    list that is returned), through output_frame or -- callback=True -- through the YUV callback.  Returns (frames, info string, stream info tuple,
+    largest single push)."""
+    frames = []
+    sink = on_frame or frames.append
+    cb = YUV_CALLBACK(lambda p, n, u: sink(C.string_at(p, n)) or 0)
+    h = jm_intel_dec_create_handle()
+    for k, v in (options or {}).items():
+        lib().jm_amddec_set_option(lib().jm_amdintel_decoder(h), k.encode(), int(v))
+    if jm_intel_dec_init(codec_type, out_fmt, h) != 0:
+        jm_intel_dec_deinit(h)
+        raise RuntimeError("jm_intel_dec_init failed")
+    try:
+        if callback:
+            jm_intel_dec_set_yuv_callback(None, cb, h)
+        data = bytes(data)
+        mv = memoryview(data)
+        base = C.cast(C.c_char_p(data), C.c_void_p).value
+        out = C.create_string_buffer(20 << 20)                       # the harness's 20 MB output buffer, test_intel_dec.cpp:50
+        pos, is_eof, biggest, guard, sinfo = 0, False, 0, 0, None
+        while not jm_intel_dec_is_exit(h):
+            guard += 1
+            if guard > 50_000_000:
+                raise RuntimeError("push / pull loop does not terminate")
+            if jm_intel_dec_need_more_data(h) and not is_eof:
+                k = min(jm_intel_dec_free_buf_len(h), len(mv) - pos)
+                if max_push:
+                    k = min(k, max_push)
+                if k == 0:
+                    is_eof = True
+                    jm_intel_dec_set_eof(1, h)
+                else:
+                    if jm_intel_dec_input_data(base + pos, k, h) != k:
+                        raise RuntimeError("jm_intel_dec_input_data failed")
+                    pos += k
+                    biggest = max(biggest, k)
+            ret, n = jm_intel_dec_output_frame(out, len(out), h)
+            if ret == 0:
+                if callback:
+                    raise RuntimeError("output_frame handed out a frame although a callback is set")
+                sink(C.string_at(out, n))
+                if sinfo is None:
+                    sinfo = jm_intel_get_stream_info(h)
+        if sinfo is None:
+            sinfo = jm_intel_get_stream_info(h)
+        return frames, jm_intel_dec_info(h), sinfo, biggest
+    finally:
+        jm_intel_dec_deinit(h)

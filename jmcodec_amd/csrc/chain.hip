@@ -70,6 +70,8 @@ bool chain_supported(int mb_w, int mb_h) {
 }
 int chain_ctl_ints() { return kChainStride; }
 int chain_tail_ints() { return kChainTail; }
+int chain_tail_head_ints() { return kChainTailHead; }
+int chain_tail_wait_limit() { return kTailWaitLimit; }
 
 int deblock_depth(); int deblock_pub();
 

@@ -25,7 +25,7 @@
 //      occupancy, PROVIDED the keys are right: round 3's keys ignored that a band trails the band above it by ~7 steps (nine bands at 4K: the first
 //      chain launch of a C2 run gave up in one run of three), and round 4's first one-row schedule kept one key slope per launch (launches of 4 / 8
 //      streams gave up in three runs of ten).  Both were found as VIOLATIONS OF 4., not as mysteries.
-// Every wait is still bounded (100 ms); a wait that gives up sets the error word and the abort word, records itself (record_first_giveup), and the
+// Every wait is still bounded (by the time its wave spent waiting: WaitClock below); a wait that gives up sets the error word and the abort word, records itself (record_first_giveup), and the
 // engine decodes the launch's pictures again with the stage kernels (Engine::recover): a wrong key costs time, never a wrong frame.
 // There is no reference counterpart (the reference hands whole pictures to the NVDEC ASIC, nv_dec.cpp:33-41).
 #pragma once
@@ -46,18 +46,49 @@ constexpr int kChainRowWords = 8;      // pictures up to 256 macroblocks wide (4
 constexpr int kChainMaxRows = 512;
 constexpr int kChainMaxPics = 64;      // == kMaxBatch (engine.h)
 constexpr int kChainStride = kChainBits + kChainMaxRows * kChainRowWords;
-// behind the pictures' blocks: the launch-wide abort word, the census and the record of the first give-up (16 ints), then four time stamps per picture
-// (diagnostic launches: ChainView::stamp)
-constexpr int kChainTail = 16 + 4 * kChainMaxPics;
+// behind the pictures' blocks: the launch-wide abort word, the census, the record of the first give-up and the launch's wait limit (32 ints, layout below),
+// then four time stamps per picture (diagnostic launches: ChainView::stamp)
+constexpr int kChainTailHead = 32;
+constexpr int kChainTail = kChainTailHead + 4 * kChainMaxPics;
+// words of the tail head: [0] abort, [1..7] census (ChainView), [8] give-ups, [9..14] record of the first give-up (record_first_giveup),
+// [15] wait limit of this launch in 100 MHz ticks (written by the host, Engine::launch; 0 = kWaitTicks), [16..21] second half of the record:
+// what an atomic read-modify-write of the counter returned when the wait gave up (the value at the point of coherence, beside what the polls saw), the waiter's
+// XCC_ID and HW_ID1 registers, its number of looks, the clock gaps its timer had skipped and the largest of them
+constexpr int kTailWaitLimit = 15, kTailRmw = 16, kTailXcc = 17, kTailHwId = 18, kTailSpins = 19, kTailGaps = 20, kTailGapMax = 21;
 constexpr int kSpinLimit = 1 << 20;    // polls before a wait of the STAGE kernels gives up (about a second; a healthy wait takes microseconds)
-// waits of a chain launch are bounded by time: 100 ms of the 100 MHz wall clock (a healthy wait takes micro- to a few milliseconds).  The engine then
-// decodes the launch's pictures again with the stage kernels (Engine::recover), so a timeout costs time, not correctness.
-constexpr uint32_t kWaitTicks = 10u * 1000u * 1000u;
-__device__ __forceinline__ bool wait_expired(int spins, uint32_t &t0) {          // (32 bits of the clock: one register, and differences survive the wrap)
+// Waits of a chain launch are bounded by TIME THE WAVE SPENT WAITING, in ticks of the 100 MHz wall clock.  The limit comes with the launch (tail word
+// kTailWaitLimit): about ten times the longest healthy wait -- a band is resident from the launch's first microsecond and may wait for the launch's last
+// reconstruction group, so the longest healthy wait is the launch itself: 1.3-2.1 ms at 1080p (profiles/r04_chain_timeline.txt), more for bigger
+// pictures and deeper chains (Engine::launch scales it).  Rounds 2-5 used a flat 100 ms of WALL time.  Round 5's two unexplained give-ups (2 of 41,800
+// launches, profiles/r05_chain_soak.txt: a band one step short of what its neighbour needed, nothing in the code that could stall it) fit a timer that
+// keeps running while its wave does not: when a queue is taken off the device for a while (the kernel driver evicts a process's queues when it
+// revalidates user pages or moves memory -- and every jm_nvdec_output_frame call page-locks and releases the caller's buffer), every wave of the launch
+// stands still, the clock does not, and the first wave to wake up finds its time used up with the counter exactly where a healthy run would have it.
+// So the timer now measures waiting, not absence: the clock is read every 64 looks, 64 looks take at most ~3 ms (wait_final's naps), and a jump of
+// more than kGapTicks between two readings is time the wave was not run -- it is taken out of the wait and recorded (WaitClock::gaps, the launch's
+// evidence words: Engine::complete counts them, profiles/r06_chain_soak.txt).  A give-up then means what it says: the wave looked for `limit` of its own
+// running time and the counter did not move.  The engine decodes the launch's pictures again with the stage kernels (Engine::recover) either way: a timeout
+// costs time, not correctness.
+constexpr uint32_t kWaitTicks = 2u * 1000u * 1000u;      // 20 ms: the default when the host wrote no limit
+constexpr uint32_t kGapTicks = 500u * 1000u;             // 5 ms between two clock readings of a waiting wave: it was not run
+struct WaitClock { uint32_t t0 = 0, last = 0, limit = 0, gaps = 0, gap_max = 0; };
+// launch = the launch's abort word (tail word 0), nullptr outside chain launches
+__device__ __forceinline__ bool wait_expired(int spins, WaitClock &c, const int *launch) {          // (32 bits of the clock: differences survive the wrap)
     if (spins & 63) return false;
     const uint32_t now = (uint32_t)wall_clock64();
-    if (spins == 64) { t0 = now; return false; }
-    return now - t0 > kWaitTicks;
+    if (spins == 64) { c.t0 = c.last = now;
+        const uint32_t lim = launch ? (uint32_t)__hip_atomic_load(launch + kTailWaitLimit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        c.limit = lim ? lim : kWaitTicks; return false; }
+    const uint32_t d = now - c.last;
+    c.last = now;
+    if (d > kGapTicks) { c.t0 += d; c.gaps++; c.gap_max = d > c.gap_max ? d : c.gap_max; }
+    return now - c.t0 > c.limit;
+}
+// a wait that saw clock gaps leaves them in the batch's evidence words (host-pinned, behind the error words: plain stores, the last writer wins --
+// evidence, not accounting).  evid = err + kChainMaxPics
+__device__ __forceinline__ void note_gaps(const WaitClock &c, int *evid) {
+    if (c.gaps && evid) { __hip_atomic_store(evid, (int)c.gaps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(evid + 1, (int)c.gap_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16,
                // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
@@ -147,38 +178,50 @@ __device__ __forceinline__ void record_first_giveup(int *launch, int code, int p
     if (__hip_atomic_fetch_add(launch + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     launch[9] = code; launch[10] = pic; launch[11] = where; launch[12] = need; launch[13] = seen0; launch[14] = seen1;
 }
+// ... and the second half: `ctr` = the counter (or bitmap word) the wait polled, read once more by an atomic read-modify-write -- performed where the
+// device's memory is coherent, so it cannot be served by a stale line: a value that differs from what the polls saw means "published, not seen";
+// the same value means the producer really stood there.  Plus where the waiter ran and what its timer went through.
+__device__ __forceinline__ void record_giveup_evidence(int *launch, const int *ctr, int spins, const WaitClock &c) {
+    if (__hip_atomic_load(launch + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 || launch[kTailSpins]) return;      // the first give-up only
+    launch[kTailRmw] = ctr ? __hip_atomic_fetch_or(const_cast<int *>(ctr), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    launch[kTailXcc] = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);       // XCC_ID[3:0] (hardware register 20 on gfx940+)
+    launch[kTailHwId] = (int)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 23);     // HW_ID1: wave, SIMD, CU, shader array, shader engine
+    launch[kTailSpins] = spins; launch[kTailGaps] = (int)c.gaps; launch[kTailGapMax] = (int)c.gap_max;
+}
 
 // Bits of one macroblock row of the reconstruction bitmap as a band workgroup sees them: `known` macroblocks from the left are known to be in memory
 // (the run of set bits found by the last poll), so a band that trails the reconstruction polls once per row.  Uniform per 16-lane group.
 // want = this group needs macroblock x now; returns false when the wait gave up (reported by the caller).
 // tag = picture << 16 | row (for the record of the first give-up)
-__device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word, int tag = 0) {
+__device__ __forceinline__ bool wait_row_bit(const uint32_t *bits_row, int &known, bool want, int x, int *abort_word, int tag = 0, int *evid = nullptr) {
     bool pending = want && x >= known;
-    int spins = 0; uint32_t t0 = 0;
+    int spins = 0; WaitClock t0;
     for (;;) {
         if (pending) {
             const uint32_t m = ld_coh(bits_row + (x >> 5)) >> (x & 31);
             if (m & 1) { known = x + (m == 0xffffffffu ? 32 : __builtin_ctz(~m)); pending = false; }   // the run of set bits that starts at x
         }
-        if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        const bool expired = wait_expired(++spins, t0);
-        if (expired && pending) record_first_giveup(abort_word, CHAIN_ERR_BITS_TIMEOUT, tag >> 16, (tag & 0xffff) << 16 | (x & 0xffff), x, known,
+        if (!__builtin_amdgcn_ballot_w64(pending)) { note_gaps(t0, evid); return true; }
+        const bool expired = wait_expired(++spins, t0, abort_word);
+        if (expired && pending) { record_first_giveup(abort_word, CHAIN_ERR_BITS_TIMEOUT, tag >> 16, (tag & 0xffff) << 16 | (x & 0xffff), x, known,
             (int)ld_coh(bits_row + (x >> 5)));
-        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }   // gave up: do not wait again
+            record_giveup_evidence(abort_word, (const int *)(bits_row + (x >> 5)), spins, t0); }
+        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { note_gaps(t0, evid); known = 0x7fffffff; return false; }   // gave up: do not wait again
         // a band may be resident long before its rows are reconstructed
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
     }
 }
 // the same for a step counter (`fin` of the intra wavefront): wait until *ctr >= need
-__device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word, int tag = 0) {
+__device__ __forceinline__ bool wait_counter(const int *ctr, int &known, bool want, int need, int *abort_word, int tag = 0, int *evid = nullptr) {
     bool pending = want && known < need;
-    int spins = 0; uint32_t t0 = 0;
+    int spins = 0; WaitClock t0;
     for (;;) {
         if (pending) { known = ld_coh(ctr); pending = known < need; }
-        if (!__builtin_amdgcn_ballot_w64(pending)) return true;
-        const bool expired = wait_expired(++spins, t0);
-        if (expired && pending) record_first_giveup(abort_word, CHAIN_ERR_IFIN_TIMEOUT, tag >> 16, tag & 0xffff, need, known, 0);
-        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { known = 0x7fffffff; return false; }
+        if (!__builtin_amdgcn_ballot_w64(pending)) { note_gaps(t0, evid); return true; }
+        const bool expired = wait_expired(++spins, t0, abort_word);
+        if (expired && pending) { record_first_giveup(abort_word, CHAIN_ERR_IFIN_TIMEOUT, tag >> 16, tag & 0xffff, need, known, 0);
+            record_giveup_evidence(abort_word, ctr, spins, t0); }
+        if (expired || ((spins & 255) == 0 && ld_coh(abort_word))) { note_gaps(t0, evid); known = 0x7fffffff; return false; }
         if (spins < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -208,7 +251,7 @@ struct ChainView {
     __device__ __forceinline__ void stamp(int pic_idx, int which) const {
         if (!census_on || threadIdx.x != 0) return;
         const int t = (int)((uint32_t)wall_clock64() & 0x3fffffffu);
-        (void)__hip_atomic_fetch_max(abort_word() + 16 + 4 * pic_idx + which, (which & 1) ? t : 0x40000000 - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_max(abort_word() + kChainTailHead + 4 * pic_idx + which, (which & 1) ? t : 0x40000000 - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // Wait until every sample of the rectangle [.., xmax] x [ymin, ymax] (luma coordinates, already clamped to the picture) of the picture
@@ -232,7 +275,7 @@ struct ChainView {
         // from MEMORY did not change: the polls hit in the L2.)
         constexpr int kNapSlack = 3, kTopNap = 32;                  // naps in a row: at most 2 * kTopNap - 1 (47 us)
         const int first_hi = row_lag * 16 * bhi, first_lo = row_lag * 16 * blo;
-        int spins = 0; uint32_t t0 = 0;
+        int spins = 0; WaitClock t0;
         for (;;) {
             int missing = 0;                                        // steps until the rectangle is final, as far as the last look could tell
             if (pending) {
@@ -244,11 +287,13 @@ struct ChainView {
                 pending = missing > 0;
             }
             // (nothing that reads the picture moves above the polls)
-            if (!__builtin_amdgcn_ballot_w64(pending)) { asm volatile("" ::: "memory"); return true; }
-            const bool expired = wait_expired(++spins, t0);
-            if (expired && pending) record_first_giveup(abort_word(), CHAIN_ERR_FIN_TIMEOUT, dep, bhi << 16 | (xs & 0xffff), need_hi, ld_coh(fin + bhi),
+            if (!__builtin_amdgcn_ballot_w64(pending)) { note_gaps(t0, err ? err + kChainMaxPics : nullptr); asm volatile("" ::: "memory"); return true; }
+            const bool expired = wait_expired(++spins, t0, abort_word());
+            if (expired && pending) { record_first_giveup(abort_word(), CHAIN_ERR_FIN_TIMEOUT, dep, bhi << 16 | (xs & 0xffff), need_hi, ld_coh(fin + bhi),
                 ld_coh(fin + 32 + bhi));
-            if (expired || ((spins & 255) == 0 && ld_coh(abort_word()))) { st_coh(abort_word(), 1); return false; }
+                record_giveup_evidence(abort_word(), fin + bhi, spins, t0); }
+            if (expired || ((spins & 255) == 0 && ld_coh(abort_word()))) { note_gaps(t0, err ? err + kChainMaxPics : nullptr); st_coh(abort_word(), 1);
+                return false; }
             // the wave goes on when its LAST lane is served: nap by the largest number of missing steps (bit by bit: seven ballots)
             int naps = 0;
             for (int t = kTopNap; t; t >>= 1) if (__builtin_amdgcn_ballot_w64(pending && missing - kNapSlack >= naps + t)) naps += t;

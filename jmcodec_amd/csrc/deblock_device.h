@@ -399,14 +399,16 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
     auto wait_above = [&](int need) {
         if (band == 0 || threadIdx.x >= 64) return;                          // wave 0 holds group 0
         if (known >= need) return;
-        int spins = 0; uint32_t t0 = 0;
+        int spins = 0; WaitClock t0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit &&
-               !(CHAIN && (wait_expired(spins, t0) || ((spins & 255) == 0 && ld_coh(abort_word))))) __builtin_amdgcn_s_sleep(8);
+               !(CHAIN && (wait_expired(spins, t0, abort_word) || ((spins & 255) == 0 && ld_coh(abort_word))))) __builtin_amdgcn_s_sleep(8);
+        if (CHAIN && l == 0) note_gaps(t0, err_word ? err_word - pp.chain_idx + kChainMaxPics : nullptr);
         if (known < need) {                                                  // the band above never got there: damaged, and SAID so
             if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_RING_TIMEOUT);
                 if (CHAIN) {
-                    if (!ld_coh(abort_word)) record_first_giveup(abort_word, CHAIN_ERR_RING_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0), need,
+                    if (!ld_coh(abort_word)) { record_first_giveup(abort_word, CHAIN_ERR_RING_TIMEOUT, pp.chain_idx, band << 16 | (is_chroma ? 1 : 0), need,
                         known, 0);
+                        record_giveup_evidence(abort_word, &prog[band - 1], spins, t0); }
                     st_coh(abort_word, 1);
                 } }
             known = 0x7fffffff;                                              // do not wait again
@@ -430,7 +432,7 @@ __device__ __forceinline__ void deblock_band_body(const PicParams &pp, int band,
         const int tag = pp.chain_idx << 16 | (row & 0xffff);
         if (after_intra) { const int need = x + 2 * row + 4; ok = wait_counter(ifin0, ifin_known0, want, need, abort_word, tag) &&
             wait_counter(ifin1, ifin_known1, want, need, abort_word, tag); }
-        else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word, tag);
+        else ok = wait_row_bit(bits_row, recon_known, want, x, abort_word, tag, err_word ? err_word - pp.chain_idx + kChainMaxPics : nullptr);
         if (!ok && (threadIdx.x & 63) == 0) { report_wait_timeout(err_word, after_intra ? CHAIN_ERR_IFIN_TIMEOUT : CHAIN_ERR_BITS_TIMEOUT);
             st_coh(abort_word, 1); }
     };

@@ -181,6 +181,11 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "i_pictures") return stat_i_;
     if (k == "p_pictures") return stat_p_;
     if (k == "b_pictures") return stat_b_;
+    // frame rate of the active sequence as a fraction (VUI timing information; 0 / 0 when the stream carries none): H.264 counts FIELD ticks (E.2.1)
+    if (k == "fps_num") return codec_ == 1 ? (long long)hsps_.time_scale : (long long)seq_.time_scale;
+    if (k == "fps_den") return codec_ == 1 ? (long long)hsps_.num_units_in_tick : 2ll * seq_.num_units_in_tick;
+    // display frames decided and not yet made current by a decode / poll call (finished or still on the device)
+    if (k == "frames_waiting") { std::lock_guard<std::mutex> lk(const_cast<std::mutex &>(mtx_)); return (long long)ready_.size(); }
     if (k == "coded_width") return mb_w_ * 16;
     if (k == "coded_height") return mb_h_ * 16;
     if (k == "pitch") return pitch_;
@@ -214,6 +219,21 @@ long long Decoder::get_stat(const char *key) const {
         if (k == "eng_chain_recoveries") return es.chain_recoveries;
         if (k == "eng_gpu_shared") return engine_->gpu_shared() ? 1 : 0;
         if (k == "eng_launch_ns") return es.launch_ns;
+        if (k == "eng_wait_gap_launches") return es.wait_gap_launches;
+        if (k == "eng_wait_gap_max_us") return es.wait_gap_max_ticks / 100;
+        if (k == "eng_rej_other_lane") return es.rej_other_lane;
+        if (k == "eng_rej_cross_lane") return es.rej_cross_lane;
+        if (k == "eng_rej_tables") return es.rej_tables;
+        if (k == "eng_early_intra") return es.early_intra;
+        if (k == "eng_blocked_ns") return es.blocked_ns;
+        if (k == "eng_blocked_n") return es.blocked_n;
+        for (int i = 0; i < 4; i++) {
+            const std::string l = std::to_string(i);
+            if (k == "eng_lane" + l + "_busy_ns") return (long long)es.lane_busy_ns[i];
+            if (k == "eng_lane" + l + "_gap_ns") return (long long)es.lane_gap_ns[i];
+            if (k == "eng_lane" + l + "_batches") return es.lane_batches[i];
+            if (k == "eng_lane" + l + "_pics") return es.lane_pics[i];
+        }
         if (k == "eng_complete_ns") return es.complete_ns;
         return -1;
     }
@@ -1542,9 +1562,12 @@ void Decoder::on_engine_done(const EnginePic &p, bool failed) {
 // =============================================================================================
 // API-level flow: nvdec_decode_frame (nv_dec.cpp:481-494) = feed packet, then pop <= 1 display frame
 // =============================================================================================
-int Decoder::pop_output(bool block) {
+int Decoder::pop_output(bool block, int wait_us) {
     std::unique_lock<std::mutex> lk(mtx_);
     if (cur_out_) { free_out_.push_back(cur_out_); cur_out_ = nullptr; }
+    // wait_us > 0 (poll with a bounded wait): sleep until the frame at the head of the display queue has its samples, but no longer than that
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us > 0 ? wait_us : 0);
+    auto nap = [&] { return wait_us > 0 && cv_.wait_until(lk, deadline) != std::cv_status::timeout; };
     for (;;) {
         if (!ready_.empty()) {
             OutSlot *o = ready_.front();
@@ -1554,21 +1577,30 @@ int Decoder::pop_output(bool block) {
             // engine forms a batch, however long its caller stays in jm_nvdec_output_frame.  Finished frames pile up meanwhile: beyond a few, they
             // go out anyway (they hold output slots).  The end of the stream (block) drains everything.
             if (!block && outstanding_ < display_delay_ && (int)ready_.size() <= 6) return 0;
-            if (!o->ready) { if (!block) return 0; cv_.wait(lk); continue; }
+            if (!o->ready) { if (!block) { if (nap()) continue; return 0; } cv_.wait(lk); continue; }
             ready_.pop_front();
             cur_out_ = o;
             return 1;
         }
-        if (!block || outstanding_ == 0) return 0;
+        if (outstanding_ == 0) return 0;
+        if (!block) { if (nap()) continue; return 0; }
         cv_.wait(lk);
     }
 }
 
-int Decoder::poll(int *got_frame) {
+int Decoder::poll(int *got_frame, int wait_us) {
     *got_frame = 0;
     if (!inited_ || failed_) return -1;
-    *got_frame = pop_output(false);
+    *got_frame = pop_output(false, wait_us);
     return 0;
+}
+
+// Input without taking a frame (the push half of the push / pull API, intel_dec.cpp:189-234 intel_dec_put_input_data): the frame a caller has not
+// fetched yet stays current.  Frames are taken with poll() / output().
+int Decoder::push(const uint8_t *buf, int len) {
+    if (!inited_ || failed_ || !buf || len <= 0) return -1;
+    if (!eos_sent_ && !eof_flag_) feed(buf, (size_t)len);
+    return failed_ ? -1 : 0;
 }
 
 int Decoder::decode(const uint8_t *buf, int len, int *got_frame) {

@@ -122,7 +122,8 @@ public:
     ~Decoder();
     int  init(int codec_type, int out_fmt, const uint8_t *extra, int len);
     int  decode(const uint8_t *buf, int len, int *got_frame);
-    int  poll(int *got_frame);                 // pop a finished display frame without feeding input
+    int  poll(int *got_frame, int wait_us = 0); // pop a finished display frame without feeding input (wait_us > 0: wait that long for one that is on its way)
+    int  push(const uint8_t *buf, int len);    // feed input without popping a frame (the current frame stays current)
     int  output(uint8_t *out, int *out_len);
     int  output_device(void **dev, int *len);
     int  output_argb_device(void *dev_dst, int pitch);
@@ -167,7 +168,7 @@ private:
     void push_task(std::unique_ptr<PicTask> t);
     bool activate(const SeqParams &sps);
     int  acquire_job_slot(bool big = false);
-    int  pop_output(bool block);
+    int  pop_output(bool block, int wait_us = 0);
     void fail(const std::string &msg);
     void note_error(const std::string &msg);
     // ---- device side ----

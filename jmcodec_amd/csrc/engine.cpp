@@ -15,6 +15,13 @@
 
 namespace jmamd {
 
+// developer aid (JM_AMD_DEC_LANE_TRACE=<max lines>): the lanes' time line on stderr -- batches launched / retired, pictures launched ahead of their turn,
+// decoders left out of an ordinary batch and what held them (profiles/r06_lane_trace.txt)
+static long g_lane_trace = getenv("JM_AMD_DEC_LANE_TRACE") ? atol(getenv("JM_AMD_DEC_LANE_TRACE")) : 0;
+static double trace_ms() { static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+#define LANE_TRACE(...) do { if (g_lane_trace > 0) { g_lane_trace--; fprintf(stderr, "lane-trace %9.3f " , trace_ms()); fprintf(stderr, __VA_ARGS__); } } while (0)
+
 static std::mutex g_engines_m;
 static Engine *g_engines[64] = {nullptr};
 
@@ -44,6 +51,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(kMinChainLag, std::min(atoi(e), 1024));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LINGER")) chain_linger_streams_ = std::max(0, atoi(e));
+    if (const char *e = getenv("JM_AMD_DEC_CROSS_LANE")) cross_lane_ = atoi(e) != 0;
+    if (const char *e = getenv("JM_AMD_DEC_EARLY_INTRA")) early_intra_ = atoi(e) != 0;
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
@@ -63,9 +72,10 @@ Engine::Engine(int device) : device_(device) {
             if (hipMalloc((void **)&b.d_progress, sizeof(int) * kMaxBatch * kHevcProgressStride) != hipSuccess) return;
             // + the launch-wide tail (chain_common.h)
             if (hipMalloc((void **)&b.d_ctl, sizeof(int) * ((size_t)kMaxBatch * chain_ctl_ints() + chain_tail_ints())) != hipSuccess) return;
-            if (hipHostMalloc((void **)&b.h_err, sizeof(int) * kMaxBatch, hipHostMallocMapped) != hipSuccess) return;
+            // error words, one per picture, then two evidence words of the batch (clock gaps its waits saw: chain_common.h note_gaps)
+            if (hipHostMalloc((void **)&b.h_err, sizeof(int) * (kMaxBatch + 4), hipHostMallocMapped) != hipSuccess) return;
             if (hipHostGetDevicePointer((void **)&b.d_err, b.h_err, 0) != hipSuccess) return;
-            memset(b.h_err, 0, sizeof(int) * kMaxBatch);
+            memset(b.h_err, 0, sizeof(int) * (kMaxBatch + 4));
             if (hipHostMalloc((void **)&b.h_groups, sizeof(uint32_t) * kMaxChainGroups, hipHostMallocDefault) != hipSuccess) return;
             if (hipMalloc((void **)&b.d_groups, sizeof(uint32_t) * kMaxChainGroups) != hipSuccess) return;
             if (hipHostMalloc((void **)&b.h_jobs, sizeof(PackJob) * 4 * kMaxBatch, hipHostMallocDefault) != hipSuccess) return;
@@ -113,7 +123,9 @@ void Engine::submit(EnginePic &&p) {
             it->t = now;
             if (p.has_picture) it->mbs = p.mb_w * p.mb_h;
         }
+        p.seq = p.dec->engine_state().next_seq++;
         pending_.push_back(std::move(p));
+        pending_gen_++;
     }
     cv_.notify_one();
 }
@@ -130,6 +142,31 @@ bool Engine::set_knob(const std::string &key, long long v) {
 }
 
 EngineStats Engine::stats() { std::lock_guard<std::mutex> lk(sm_); return st_; }
+
+// m_ held.  Lanes other than `lane_idx`: is the device done (decode kernels AND the pack-out that reads the surfaces: event `packed`) with every picture of d
+// that comes before `seq` in decode order?  Pictures of the lane itself are ordered by its stream.
+bool Engine::others_done(Decoder *d, int lane_idx, unsigned long long seq) {
+    for (int li = 0; li < kLanes; li++) {
+        if (li == lane_idx) continue;
+        Lane &o = lanes_[li];
+        for (int k = 0; k < o.inflight; k++) {
+            Batch &ob = o.ring[(o.tail + k) % kBatchRing];
+            bool mine = false;
+            for (auto &p : ob.pics) if (p.dec == d && p.seq < seq) { mine = true; break; }
+            if (mine && hipEventQuery(ob.packed) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+    }
+    return true;
+}
+
+// m_ held: every surface the pictures of d that are in flight (any lane) decode into, reference or display
+void Engine::inflight_masks(Decoder *d, uint32_t &touched) {
+    touched = 0;
+    for (auto &o : lanes_) for (int k = 0; k < o.inflight; k++) for (auto &p : o.ring[(o.tail + k) % kBatchRing].pics) if (p.dec == d) {
+        touched |= p.ref_mask | p.out_mask;
+        if (p.has_picture) touched |= 1u << (p.codec == 0 ? p.pp.cur : p.hp.cur);
+    }
+}
 
 // Take the first pending picture of every decoder (arrival order) that belongs to this lane and may run now; then, on the lanes of ordinary
 // pictures, extend every decoder's share of the batch by its NEXT pictures as long as they can run inside the chain kernel (chain.hip):
@@ -169,6 +206,8 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         }
     }
     std::vector<Decoder *> seen, members;
+    const bool relaxed = cross_lane_ && !chaining;
+    const long long now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     size_t n_pre = 0, n_post = 0;                       // display frames the batch packs out before / after its decode kernels
     auto account = [&](EnginePic &p, EngineDecoderState &es) {
         if (p.has_picture) es.batch_written |= 1u << (p.codec == 0 ? p.pp.cur : p.hp.cur);
@@ -180,12 +219,34 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
         EngineDecoderState &es = d->engine_state();
-        bool ok = it->lane(chaining) == lane_idx && (es.inflight == 0 || es.lane == lane_idx);
+        // Decode order per stream: pictures of one lane follow each other on the lane's stream.  A picture whose decoder still has EARLIER pictures in
+        // flight on another lane waits for them: until round 5 for the host to have retired them (the batch's last copy, the engine thread's turn, every
+        // handle's completion callback); now until the device is done with them (one event query per such batch) -- a stream's I picture left it out of 30 %
+        // of the ordinary batches (profiles/r06_lane_fill.txt).  Chain launches keep the strict rule: Engine::recover reasons about one lane at a time.
+        int why = 0;
+        if (it->lane(chaining) != lane_idx) why = 1;
+        else if (es.inflight > es.lane_inflight[lane_idx] && !(relaxed && others_done(d, lane_idx, it->seq))) why = 2;
         // the pack-job tables hold 2 * kMaxBatch entries each: a picture whose display frames no longer fit waits for the next batch
         // (a flush or an IDR picture can release a whole DPB at once: up to 16 frames from one handle)
-        if (ok && (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch)) ok = false;
-        if (!ok) { ++it; continue; }
-        es.lane = lane_idx; es.inflight++;
+        else if (n_pre + it->out_before.size() > (size_t)2 * kMaxBatch || n_post + it->out_after.size() > (size_t)2 * kMaxBatch) why = 3;
+        if (why) {
+            if (lane_idx == kOrdinaryLane && it->codec == 0) { std::lock_guard<std::mutex> lk(sm_);
+                (why == 1 ? st_.rej_other_lane : why == 2 ? st_.rej_cross_lane : st_.rej_tables)++;
+                if (!es.blocked_since) { es.blocked_since = now_ns;
+                    if (g_lane_trace > 0) {
+                        LANE_TRACE("left-out dec %p seq %llu why %d inflight %d (lane0 %d lane1 %d)\n", (void *)d, it->seq, why, es.inflight, es.lane_inflight[0],
+                            es.lane_inflight[1]);
+                        for (int li = 0; li < kLanes; li++) for (int k = 0; k < lanes_[li].inflight; k++) { Batch &ob = lanes_[li].ring[(lanes_[li].tail + k) % kBatchRing];
+                            for (auto &p : ob.pics) if (p.dec == d) LANE_TRACE("    in flight: lane %d batch %llu seq %llu kdone %d packed %d done %d\n", li, ob.serial, p.seq,
+                                (int)hipEventQuery(ob.kdone), (int)hipEventQuery(ob.packed), (int)hipEventQuery(ob.done)); }
+                        (void)hipGetLastError();
+                    } } }
+            ++it; continue;
+        }
+        if (lane_idx == kOrdinaryLane && es.blocked_since) { std::lock_guard<std::mutex> lk(sm_); st_.blocked_ns += now_ns - es.blocked_since; st_.blocked_n++;
+            LANE_TRACE("rejoined dec %p seq %llu after %.3f ms\n", (void *)d, it->seq, (now_ns - es.blocked_since) * 1e-6);
+            es.blocked_since = 0; }
+        es.lane = lane_idx; es.inflight++; es.lane_inflight[lane_idx]++;
         es.in_batch = 1; es.batch_written = es.batch_read = 0; es.batch_stop = false;
         es.batch_resid = it->has_picture && it->codec == 0 && (it->pp.stages & (PS_INTRA_LDS | PS_INTRA_V1)) != 0;
         account(*it, es);
@@ -193,7 +254,44 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         b.pics.push_back(std::move(*it));
         it = pending_.erase(it);
     }
+    // Intra-only pictures ahead of their turn (round 6).  An IDR / I picture references nothing: all that ties it to the pictures before it in its stream is
+    // the surface it decodes into.  With many streams the engine is what the streams wait for -- a decoder has some twenty parsed pictures pending -- so the
+    // I picture of the NEXT IDR period is here long before its turn, and its turn used to cost its stream three to four batch times (wait for its P
+    // pictures to retire, run alone on the intra lane, retire, rejoin).  It is launched as soon as it is seen when no earlier picture of its decoder,
+    // pending or in flight, decodes into, references or displays its surface, it packs nothing before its kernels and displays at most itself.  Frames
+    // still leave in display order (the handle's queue was filled at submit time); the P picture behind it waits for it like for any picture on another lane.
+    if (lane_idx == kIntraLane && early_intra_ && !chaining && early_scanned_gen_ != pending_gen_) {
+        struct Scan { Decoder *d; uint32_t touched; bool closed; };
+        std::vector<Scan> scans;
+        for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
+            Decoder *d = it->dec;
+            auto sc = std::find_if(scans.begin(), scans.end(), [&](const Scan &x) { return x.d == d; });
+            if (sc == scans.end()) { scans.push_back(Scan{d, 0u, std::find(members.begin(), members.end(), d) != members.end()}); sc = scans.end() - 1; }
+            const uint32_t own = it->has_picture ? 1u << (it->codec == 0 ? it->pp.cur : it->hp.cur) : 0u;
+            if (!sc->closed && it->codec == 0 && it->has_picture && it->lane(false) == kIntraLane && it->ref_mask == 0 && it->out_before.empty() &&
+                !it->wait_prev_pack && !(it->out_mask & ~own) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch) {
+                sc->closed = true;                          // only a decoder's first intra picture is looked at
+                uint32_t infl; inflight_masks(d, infl);
+                if (!(own & (sc->touched | infl))) {
+                    EngineDecoderState &es = d->engine_state();
+                    es.inflight++; es.lane_inflight[lane_idx]++;
+                    if (g_lane_trace > 0) { unsigned long long head = it->seq; int npend = 0;
+                        for (auto &q : pending_) if (q.dec == d) { if (q.seq < head) head = q.seq; npend++; }
+                        LANE_TRACE("early dec %p seq %llu ahead of %llu (%d pending)\n", (void *)d, it->seq, head, npend); }
+                    n_post += it->out_after.size();
+                    b.pics.push_back(std::move(*it));
+                    it = pending_.erase(it);
+                    { std::lock_guard<std::mutex> lk(sm_); st_.early_intra++; }
+                    continue;
+                }
+            }
+            sc->touched |= it->ref_mask | it->out_mask | own;
+            ++it;
+        }
+        early_scanned_gen_ = pending_gen_;                  // (taking a picture bumps the generation below: the next look then scans again)
+    }
     if (b.pics.empty()) return false;
+    pending_gen_++;
     if (lane_idx == kOrdinaryLane) { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size();
         st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
     // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
@@ -224,7 +322,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 if (ok) chain_cost(*it, nb, ng);
                 if (!ok || tot_bands + nb > band_limit(any_intra || it->chain_intra) || tot_groups + ng > kMaxChainGroups) { es.batch_stop = true; continue; }
                 tot_bands += nb; tot_groups += ng; any_intra |= it->chain_intra; es.batch_resid |= it->chain_intra;
-                es.inflight++; es.in_batch++;
+                es.inflight++; es.lane_inflight[lane_idx]++; es.in_batch++;
                 account(*it, es);
                 b.pics.push_back(std::move(*it));
                 pending_.erase(it);
@@ -248,7 +346,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                     it->wait_prev_pack) break;
                 if ((it->ref_mask & es.batch_written) || ((1u << it->hp.cur) & (es.batch_written | es.batch_read)) ||
                     n_post + it->out_after.size() > (size_t)2 * kMaxBatch) break;
-                es.inflight++; es.in_batch++;
+                es.inflight++; es.lane_inflight[lane_idx]++; es.in_batch++;
                 es.batch_written |= 1u << it->hp.cur;
                 account(*it, es);
                 b.pics.push_back(std::move(*it));
@@ -262,7 +360,9 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
 
 // one batched launch per stage on the lane's in-order stream; pack-out on the lane's second stream
 void Engine::launch(Lane &ln, Batch &b) {
-    const int n = (int)b.pics.size();
+    const int n = (int)b.pics.size(), li = (int)(&ln - lanes_);
+    b.serial = ++ln.launched; b.last_ev = -1;
+    LANE_TRACE("launch lane %d batch %llu pics %d\n", li, b.serial, n);
     int max_mbs = 0, max_mb_h = 0, max_mb_w = 0, max_w = 0, max_h = 0, stages = 0;
     bool wait_pack = false, any_hevc = false;
     HevcBatchDims hd;
@@ -301,7 +401,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         stages |= b.h_pics[i].stages;
         if (p.has_picture && !hevc) max_mb_w = std::max(max_mb_w, p.mb_w);
         // a surface this decoder's pictures of the PREVIOUS batch display may still be read by that batch's pack-out (it runs beside this batch's kernels)
-        if (p.has_picture && ((1u << (hevc ? p.hp.cur : p.pp.cur)) & p.dec->engine_state().displayed[0])) wait_pack = true;
+        if (p.has_picture && ((1u << (hevc ? p.hp.cur : p.pp.cur)) & p.dec->engine_state().displayed[li])) wait_pack = true;
         if (hevc && p.has_picture) {
             const HevcPicParams &h = p.hp;
             hd.max_pus = std::max(hd.max_pus, h.n_pus); hd.max_tbs = std::max(hd.max_tbs, h.n_tbs); hd.max_itbs = std::max(hd.max_itbs, h.n_itbs);
@@ -328,9 +428,9 @@ void Engine::launch(Lane &ln, Batch &b) {
         b.npics[3] += (int)(p.out_before.size() + p.out_after.size());
     }
     // surfaces this batch displays, per decoder: a later batch that decodes into one of them must wait for this batch's pack-out
-    for (auto &p : b.pics) p.dec->engine_state().displayed[1] = 0;
-    for (auto &p : b.pics) p.dec->engine_state().displayed[1] |= p.out_mask;
-    for (auto &p : b.pics) p.dec->engine_state().displayed[0] = p.dec->engine_state().displayed[1];
+    // (per lane: pictures of a decoder on different lanes are kept apart by Engine::form)
+    for (auto &p : b.pics) p.dec->engine_state().displayed[li] = 0;
+    for (auto &p : b.pics) p.dec->engine_state().displayed[li] |= p.out_mask;
     b.max_mbs = max_mbs; b.max_mb_h = max_mb_h; b.max_w = max_w; b.max_h = max_h; b.redo = false;
     hipStream_t st = ln.stream, pst = ln.pack_stream;
     // What does not depend on the lane's previous batch -- clearing the control blocks, the parameter / pack-job tables, the deblocking pre-pass (it only
@@ -340,7 +440,15 @@ void Engine::launch(Lane &ln, Batch &b) {
     hipStream_t ps = any_hevc ? st : ln.pre_stream;
     // every counter of every picture, and the abort word
     if (!any_hevc && (stages & (PS_INTRA_LDS | PS_DEBLOCK_LDS | PS_CHAIN))) { hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), ps);
-        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, chain_tail_ints() * sizeof(int), ps); }      // abort word, census, time stamps
+        hipMemsetAsync(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), 0, chain_tail_ints() * sizeof(int), ps);        // abort word, census, time stamps
+        // the launch's wait limit (chain_common.h): ten times the longest healthy wait, which is the launch itself -- about 0.25 ms per picture of a stream's
+        // chain at 1080p (1.3-2.1 ms for 8 pictures, profiles/r04_chain_timeline.txt), in proportion to the picture size; never below 10 ms, never above 100
+        if (stages & PS_CHAIN) {
+            const double launch_ms = 0.25 * b.max_depth * std::max(1.0, max_mbs / 8160.0) + 0.8;
+            const unsigned ticks = (unsigned)(std::min(100.0, std::max(10.0, 10.0 * launch_ms)) * 100000.0);
+            static const unsigned forced = getenv("JM_AMD_DEC_CHAIN_WAIT_MS") ? (unsigned)(atof(getenv("JM_AMD_DEC_CHAIN_WAIT_MS")) * 100000.0) : 0u;
+            hipMemsetD32Async((hipDeviceptr_t)(b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints() + chain_tail_wait_limit()), (int)(forced ? forced : ticks), 1, ps);
+        } }
     if (any_hevc) hipMemcpyAsync(b.d_hpics, b.h_hpics, sizeof(HevcPicParams) * n, hipMemcpyHostToDevice, ps);
     else hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, ps);
     if (b.n_pre) hipMemcpyAsync(b.d_jobs, b.h_jobs, sizeof(PackJob) * b.n_pre, hipMemcpyHostToDevice, ps);
@@ -375,6 +483,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         if (hd.max_pus || hd.max_tbs) b.pmask |= 2;
         if (hd.any_intra) b.pmask |= 4;
         if (hd.any_deblock || hd.any_sao) b.pmask |= 8;
+        b.last_ev = 4;
     }
     b.any_bipred = b.any_field = false;
     for (auto &p : b.pics) { b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred; b.any_field |= p.has_picture && p.codec == 0 && p.pp.field != 0; }
@@ -386,7 +495,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     if ((stages & (PS_DEBLOCK_LDS | PS_CHAIN)) && !prep_early) launch_deblock_prep(b.d_pics, n, max_mbs, st);
     if (stages & PS_DEBLOCK_LDS) { launch_deblock_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, debug_stall_ == 1, st); b.pmask |= 8; }
     if (stages & PS_DEBLOCK_V1) { launch_deblock(b.d_pics, n, st); b.pmask |= 8; }
-    if (!any_hevc) mark(4, st);
+    if (!any_hevc) { mark(4, st); b.last_ev = 4; }
     // pictures that run inside the chain kernel: reconstruction + deblocking of all of them, consecutive pictures of a stream pipelined
     if (stages & PS_CHAIN) {
         // Work list of the chain kernel, ordered along the pipeline's time axis (chain.hip).  The deblocking wavefront of a picture reaches
@@ -459,7 +568,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         hipMemcpyAsync(b.d_groups, b.h_groups, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyHostToDevice, st);
         launch_chain(b.d_pics, b.d_groups, n_groups, with_intra, b.d_ctl, b.d_err, debug_stall_ != 0, st);
         b.chain_with_intra = with_intra;
-        b.pmask |= 32; mark(7, st);
+        b.pmask |= 32; mark(7, st); b.last_ev = 7;
     }
     hipEventRecord(b.kdone, st);
     hipStreamWaitEvent(pst, b.kdone, 0);
@@ -578,6 +687,12 @@ void Engine::dump_chain_state(Batch &b) {
         "  FIRST give-up (of %d): code %d (1 fin: reconstruction waits for the deblocking of picture `pic`; 2 bits: a deblocking band of `pic` waits "
         "for its reconstruction; 4 ring; 8 intra ring; 16 ifin) pic %d where 0x%x (fin: band << 16 | macroblock column; bits: row << 16 | column, bit 31 of "
         "the row = intra band; ring: band << 16 | chroma) needed %d saw %d / %d\n", lw[8], lw[9], lw[10], (unsigned)lw[11], lw[12], lw[13], lw[14]);
+    // the second half of the record (round 6): what decides between "the producer stood still" and "its publication was not seen", and where the waiter ran
+    if (lw[8]) fprintf(stderr,
+        "  ... the same counter read by an atomic read-modify-write when the wait gave up: %d (equal to what the polls saw = the producer stood there; larger = "
+        "published and not seen) | waiter: XCC %d, HW_ID1 0x%08x (wave %d SIMD %d CU %d SA %d SE %d), %d looks | its timer skipped %d clock gap(s), the longest "
+        "%.2f ms | wait limit of the launch %.1f ms\n", lw[16], lw[17] & 15, (unsigned)lw[18], lw[18] & 31, (lw[18] >> 8) & 3, (lw[18] >> 10) & 15,
+        (lw[18] >> 16) & 1, (lw[18] >> 18) & 7, lw[19], lw[20], lw[21] * 1e-5, lw[15] * 1e-5);
     for (int i = 0; i < n; i++) {
         const PicParams &q = b.h_pics[i];
         if (!(q.stages & PS_CHAIN)) continue;
@@ -594,7 +709,7 @@ void Engine::dump_chain_state(Batch &b) {
         fprintf(stderr, " | bitmap: %d of %d rows complete, first open row %d has %d of %d\n", full, q.mb_h, first_open, first_open_bits, q.mb_w);
     }
     // time line (diagnostic launches, JM_AMD_DEC_CENSUS): per picture, microseconds after the launch's first stamp
-    const int *ts = lw + 16;
+    const int *ts = lw + chain_tail_head_ints();
     int t0 = 0x7fffffff;
     for (int i = 0; i < n; i++) for (int k = 0; k < 4; k += 2) if (ts[4 * i + k]) t0 = std::min(t0, 0x40000000 - ts[4 * i + k]);
     if (t0 != 0x7fffffff) for (int i = 0; i < n; i++) {
@@ -606,11 +721,16 @@ void Engine::dump_chain_state(Batch &b) {
 }
 
 void Engine::complete(Lane &ln, Batch &b, bool failed) {
+    LANE_TRACE("retire lane %d batch %llu pics %zu\n", (int)(&ln - lanes_), b.serial, b.pics.size());
     if (!failed && (b.redo || b.any_chain)) {
         bool wait_err = b.redo;
         for (size_t i = 0; i < b.pics.size(); i++) wait_err |= b.h_err[i] != 0 && b.any_chain;
         if (wait_err) {
-            if (getenv("JM_AMD_DEC_VERBOSE")) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up; codes:", b.pics.size());
+            // the full state of the first give-ups of a process goes to stderr whatever the verbosity (a give-up nobody can explain
+            // afterwards is worth nothing); JM_AMD_DEC_VERBOSE prints all of them
+            static std::atomic<int> dumped{0};
+            if (getenv("JM_AMD_DEC_VERBOSE") || (!b.redo && dumped.fetch_add(1) < 4)) {
+                fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures gave up%s; codes:", b.pics.size(), b.redo ? " (redo of the batch behind one that did)" : "");
                 for (size_t i = 0; i < b.pics.size(); i++) fprintf(stderr, " %d", b.h_err[i]); fprintf(stderr, "\n");
                 dump_chain_state(b); }
             // the lane's next batch (already launched) decoded from this batch's damaged pictures: let it finish, it is redone when it retires
@@ -634,13 +754,31 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
         add(4, 4, 7, b.pmask & 32);
         for (int k = 0; k < 5; k++) { st_.pics[k] += b.npics[k]; st_.alg_bytes[k] += b.alg[k]; }
         st_.batches++; st_.batch_pics += (long long)b.pics.size();
+        // the lane's time line: how long this batch's kernels held the lane's stream, and how long the stream sat idle since the previous batch's last kernel
+        const int li = (int)(&ln - lanes_);
+        st_.lane_batches[li]++; st_.lane_pics[li] += (long long)b.pics.size();
+        if (b.last_ev >= 0) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, b.pev[0], b.pev[b.last_ev]) == hipSuccess) st_.lane_busy_ns[li] += ms * 1e6;
+            const Batch &pb = ln.ring[(ln.tail + kBatchRing - 1) % kBatchRing];       // (its events are recorded again three launches from now at the earliest)
+            if (pb.serial + 1 == b.serial && pb.last_ev >= 0 && hipEventElapsedTime(&ms, pb.pev[pb.last_ev], b.pev[0]) == hipSuccess && ms > 0)
+                st_.lane_gap_ns[li] += ms * 1e6;
+        }
+        (void)hipGetLastError();
     }
     // (counted with or without profiling)
     if (b.any_chain && !failed) { static const bool timeline = getenv("JM_AMD_DEC_CHAIN_TIMELINE") != nullptr;
         if (timeline) { fprintf(stderr, "jm_amd_dec: chain launch of %zu pictures\n", b.pics.size()); dump_chain_state(b); } }
+    // clock gaps the launch's waits saw (chain_common.h WaitClock): time its waves were not run -- evidence, counted per launch
+    if (b.h_err[kMaxBatch]) { std::lock_guard<std::mutex> lk(sm_); st_.wait_gap_launches++; st_.wait_gap_max_ticks = std::max(st_.wait_gap_max_ticks,
+        (long long)(unsigned)b.h_err[kMaxBatch + 1]);
+        if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: a chain launch's waits saw %d clock gap(s), the longest %.2f ms: its waves were not run meanwhile\n",
+            b.h_err[kMaxBatch], (unsigned)b.h_err[kMaxBatch + 1] * 1e-5);
+        b.h_err[kMaxBatch] = b.h_err[kMaxBatch + 1] = 0; }
     if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; st_.chain_i_batches += b.chain_with_intra;
         for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }
-    { std::lock_guard<std::mutex> lk(m_); for (auto &p : b.pics) p.dec->engine_state().inflight--; }
+    { std::lock_guard<std::mutex> lk(m_); const int li = (int)(&ln - lanes_);
+      for (auto &p : b.pics) { p.dec->engine_state().inflight--; p.dec->engine_state().lane_inflight[li]--; } pending_gen_++; }
     // a kernel whose bounded wait gave up (damaged hand-over between workgroups) left a code in the picture's error word: the handle reports it
     for (size_t i = 0; i < b.pics.size(); i++) if (b.h_err[i]) { b.pics[i].dec->on_device_wait_error(b.h_err[i]); b.h_err[i] = 0;
         std::lock_guard<std::mutex> lk(sm_); st_.wait_errors++; }

@@ -73,6 +73,7 @@ struct EnginePic {
     int reach_rows = 0;                             // how many macroblock rows further down than usual its vectors reach into the reference pictures
     int reach_cols = 0;                             // ... and how many macroblocks further right (both space the pictures of a chain launch, Engine::launch)
     long long alg_bytes[4] = {0, 0, 0, 0};          // algorithmic bytes of this picture per kernel class (recon, intra, deblock, packout)
+    unsigned long long seq = 0;                     // position in its decoder's decode order (Engine::submit)
     // chaining: the engine currently forms chain launches -- an intra picture that can join one stays on the ordinary lane
     int lane(bool chaining = false) const {
         if (codec == 1) return (has_picture && hp.n_pus == 0 && hp.n_itbs > 0) ? kHevcIntraLane : kHevcLane;
@@ -87,12 +88,23 @@ struct EngineStats {
     long long chain_i_batches = 0;                  // chain launches that ran k_chain_i (the variant with the intra role); the others ran k_chain
     long long forms = 0, form_decoders = 0, form_pending = 0;   // ordinary-lane batches formed; decoders that had a picture waiting then; pictures waiting then
     long long launch_ns = 0, complete_ns = 0;      // engine thread time spent issuing a batch / retiring it
+    // why a decoder with a picture waiting was left out when an ordinary-lane batch was formed (round 6): its oldest picture belongs to another lane (an
+    // I picture); it is an ordinary picture but the decoder still has pictures on another lane; the pack-job tables were full
+    long long rej_other_lane = 0, rej_cross_lane = 0, rej_tables = 0;
+    long long wait_gap_launches = 0, wait_gap_max_ticks = 0;   // chain launches whose waits saw the clock jump (their waves were not run meanwhile), longest jump
+    long long early_intra = 0;                     // intra pictures launched ahead of their stream's earlier pictures (Engine::form)
+    long long blocked_ns = 0, blocked_n = 0;       // time decoders spent left out of ordinary batches between two of their pictures joining one, and how often
+    // per lane, from the profile events: time between a batch's first and last kernel, time its stream sat idle before it, batches and pictures
+    double lane_busy_ns[4] = {0, 0, 0, 0}, lane_gap_ns[4] = {0, 0, 0, 0}; long long lane_batches[4] = {0, 0, 0, 0}, lane_pics[4] = {0, 0, 0, 0};
 };
 
 // engine-private state kept inside each Decoder (touched only by the engine thread)
 struct EngineDecoderState {
-    int lane = -1, inflight = 0;
-    uint32_t displayed[2] = {0, 0};                 // surfaces displayed by this decoder's pictures in the two most recently formed batches
+    int lane = -1, inflight = 0;                    // lane of the decoder's most recent in-order picture; pictures in flight (all lanes)
+    int lane_inflight[4] = {0, 0, 0, 0};            // ... per lane
+    uint32_t displayed[4] = {0, 0, 0, 0};           // per lane: surfaces displayed by this decoder's pictures in the lane's most recently launched batch
+    unsigned long long next_seq = 0;                // decode-order numbering of the decoder's pictures (Engine::submit, m_)
+    long long blocked_since = 0;                    // diagnostic: when an ordinary-lane batch first left this decoder out (0: not left out)
     // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
     int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false, batch_resid = false;
 };
@@ -136,6 +148,8 @@ private:
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
+        int last_ev = -1;                                     // index of the profile event behind the batch's last decode kernel
+        unsigned long long serial = 0;                        // position of the batch in its lane's sequence of launches
     };
     struct Lane {
         // pre_stream: what a batch can do before the previous batch is complete
@@ -143,9 +157,17 @@ private:
         ihipEvent_t *pack_hist[2] = {nullptr, nullptr};        // 'packed' events of the two most recently launched batches
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
+        unsigned long long launched = 0;                       // batches launched on this lane so far
         std::vector<Decoder *> tainted;                        // decoders whose recovered pictures could not be redone from intact references (Engine::recover)
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
+    // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
+    // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
+    bool cross_lane_ = true, early_intra_ = true;
+    unsigned long long pending_gen_ = 0, early_scanned_gen_ = ~0ull;      // m_: bumped whenever pending_ or the set of pictures in flight changes
+    // m_ held: the device has finished every picture of d earlier in decode order than `seq` that is in flight on another lane
+    bool others_done(Decoder *d, int lane_idx, unsigned long long seq);
+    void inflight_masks(Decoder *d, uint32_t &touched);       // m_ held: surfaces d's pictures in flight read, write or display
     // chains only while at most this many streams have pictures ready (JM_AMD_DEC_CHAIN_STREAMS): a wide batch fills the GPU anyway
     std::atomic<int> chain_max_streams_{16};
     // half of the workgroups THIS device keeps resident (occupancy x compute units)

@@ -117,12 +117,12 @@ std::string ParamSets::parse_sps(BitReader &br) {
         if (2 * vy * (c[2] + c[3]) >= (uint32_t)s.mb_h * 16) return "frame cropping larger than the picture";
         s.crop_l = (int)c[0]; s.crop_r = (int)c[1]; s.crop_t = (int)c[2] * vy; s.crop_b = (int)c[3] * vy;
     }
-    if (br.u1()) {   // VUI (E.1.1); only the bitstream restriction matters to us
+    if (br.u1()) {   // VUI (E.1.1): the bitstream restriction sizes the DPB; the timing information is what jm_intel_get_stream_info reports
         if (br.u1()) { if (br.u(8) == 255) { br.u(16); br.u(16); } }
         if (br.u1()) br.u1();
         if (br.u1()) { br.u(3); br.u1(); if (br.u1()) { br.u(8); br.u(8); br.u(8); } }
         if (br.u1()) { br.ue(); br.ue(); }
-        if (br.u1()) { br.u(32); br.u(32); br.u1(); }
+        if (br.u1()) { s.num_units_in_tick = br.u(32); s.time_scale = br.u(32); s.fixed_frame_rate = br.u1(); }   // timing_info_present_flag
         bool nal_hrd = br.u1(); if (nal_hrd) skip_hrd(br);
         bool vcl_hrd = br.u1(); if (vcl_hrd) skip_hrd(br);
         if (nal_hrd || vcl_hrd) br.u1();

@@ -24,6 +24,9 @@ struct SeqParams {
     bool frame_mbs_only = true, mbaff = false, direct_8x8_inference = false;
     int crop_l = 0, crop_r = 0, crop_t = 0, crop_b = 0;
     int max_num_reorder_frames = -1, max_dec_frame_buffering = -1;
+    // VUI timing_info (E.2.1): a field lasts num_units_in_tick / time_scale seconds, so the frame rate is time_scale / (2 * num_units_in_tick) --
+    // what Media SDK's DecodeHeader puts into FrameRateExtN / FrameRateExtD and the reference divides (intel_dec.cpp:975-990).  0 / 0 = not transmitted.
+    uint32_t num_units_in_tick = 0, time_scale = 0; bool fixed_frame_rate = false;
     int coded_w() const { return mb_w * 16; }
     int coded_h() const { return mb_h * 16; }
     // nv_dec.cpp:513-519: target size = display_area right-left x bottom-top (origin forced to 0,0)

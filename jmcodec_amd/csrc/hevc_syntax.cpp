@@ -168,6 +168,17 @@ std::string HevcParamSets::parse_sps(BitReader &br) {
     s.temporal_mvp = br.u1(); s.strong_intra = br.u1();
     if (br.overrun()) return "SPS truncated";
     s.valid = true;                    // VUI and extensions do not influence decoding
+    // vui_parameters() (E.2.1) up to vui_timing_info: the picture rate jm_intel_get_stream_info reports (intel_dec.cpp:975-990).  Best effort: a VUI that
+    // runs off the end of the NAL unit leaves the rate unknown and the SPS valid.
+    if (br.u1()) {
+        if (br.u1()) { if (br.u(8) == 255) { br.u(16); br.u(16); } }                             // aspect ratio
+        if (br.u1()) br.u1();                                                                   // overscan
+        if (br.u1()) { br.u(3); br.u1(); if (br.u1()) { br.u(8); br.u(8); br.u(8); } }          // video signal type
+        if (br.u1()) { br.ue(); br.ue(); }                                                      // chroma sample location
+        br.u1(); br.u1(); br.u1();                                                              // neutral chroma, field_seq, frame_field_info
+        if (br.u1()) { br.ue(); br.ue(); br.ue(); br.ue(); }                                    // default display window
+        if (br.u1()) { const uint32_t tick = br.u(32), scale = br.u(32); if (!br.overrun()) { s.num_units_in_tick = tick; s.time_scale = scale; } }
+    }
     sps[id] = s;
     return "";
 }

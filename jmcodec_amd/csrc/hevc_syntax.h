@@ -30,6 +30,7 @@ struct HevcSps {
     int n_rps = 0; HevcRps rps[65];
     bool long_term_present = false; int n_lt = 0; uint16_t lt_lsb[32]; uint8_t lt_used[32];
     bool temporal_mvp = false, strong_intra = false;
+    uint32_t num_units_in_tick = 0, time_scale = 0;    // vui_timing_info (E.3.1): a picture lasts num_units_in_tick / time_scale seconds; 0 = not transmitted
     // nv_dec.cpp:513-519: target size = display area size, origin forced to (0,0)
     int disp_w() const { return width - 2 * (conf[0] + conf[1]); }
     int disp_h() const { return height - 2 * (conf[2] + conf[3]); }

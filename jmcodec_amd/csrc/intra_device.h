@@ -413,14 +413,16 @@ __device__ __forceinline__ void intra_band_body(const PicParams &pp, int band, b
     int *abort_word_ = CHAIN ? cpic - (size_t)pp.chain_idx * kChainStride + (size_t)kChainMaxPics * kChainStride : nullptr;
     auto wait_above = [&](int need) {                                       // (protocol: see k_deblock_band)
         if (band == 0 || threadIdx.x >= 64 || known >= need) return;
-        int spins = 0; uint32_t t0 = 0;
+        int spins = 0; WaitClock t0;
         while ((known = __hip_atomic_load(&prog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need && ++spins < kSpinLimit && !(CHAIN &&
-            wait_expired(spins, t0))) __builtin_amdgcn_s_sleep(8);
+            wait_expired(spins, t0, abort_word_))) __builtin_amdgcn_s_sleep(8);
+        if (CHAIN && l == 0) note_gaps(t0, err_word ? err_word - pp.chain_idx + kChainMaxPics : nullptr);
         // never silent: the engine reports a decode error (and the band does not wait again)
         if (known < need) { if (l == 0) { report_wait_timeout(err_word, CHAIN_ERR_INTRA_TIMEOUT);
-            if (CHAIN && abort_word_ && !ld_coh(abort_word_)) record_first_giveup(abort_word_, CHAIN_ERR_INTRA_TIMEOUT, pp.chain_idx,
+            if (CHAIN && abort_word_ && !ld_coh(abort_word_)) { record_first_giveup(abort_word_, CHAIN_ERR_INTRA_TIMEOUT, pp.chain_idx,
                 band << 16 | (is_chroma ? 1 : 0),
-                need, known, 0); } known = 0x7fffffff; }
+                need, known, 0);
+                record_giveup_evidence(abort_word_, &prog[band - 1], spins, t0); } } known = 0x7fffffff; }
         asm volatile("" ::: "memory");
     };
     auto ring0 = [&](int xm) -> uint32_t * { return (uint32_t *)(is_chroma ? lds.cring(0, xm & 3) : lds.lring(0, xm & 3)); };

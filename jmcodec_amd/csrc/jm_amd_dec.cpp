@@ -55,6 +55,15 @@ __attribute__((visibility("default"))) int jm_amddec_poll_frame(int *got, jm_amd
     if (!h) return -1;
     return guarded(h, [&] { return D(h)->poll(got ? got : &dummy); });
 }
+__attribute__((visibility("default"))) int jm_amddec_wait_frame(int *got, int timeout_us, jm_amddec_handle h) {
+    int dummy = 0;
+    if (!h) return -1;
+    return guarded(h, [&] { return D(h)->poll(got ? got : &dummy, timeout_us); });
+}
+__attribute__((visibility("default"))) int jm_amddec_push_data(unsigned char *in_buf, int n, jm_amddec_handle h) {
+    if (!h) return -1;
+    return guarded(h, [&] { return D(h)->push(in_buf, n); });
+}
 __attribute__((visibility("default"))) int jm_amddec_output_frame(unsigned char *out, int *out_len, jm_amddec_handle h) {
     if (!h || !out || !out_len) return -1;
     return guarded(h, [&] { return D(h)->output(out, out_len); });

@@ -30,6 +30,7 @@ int  deblock_row_lag();        // steps between macroblock rows of the deblockin
 // workgroups of k_chain / k_chain_i the CURRENT device keeps resident (0: unknown); the engine bounds a launch's bands by half of it
 int  chain_resident_workgroups(bool intra);
 int  chain_ctl_ints();                                                                         // kChainStride
+int  chain_tail_head_ints(); int chain_tail_wait_limit();                                           // kChainTailHead, kTailWaitLimit (chain_common.h)
 int  chain_tail_ints();                                                                        // kChainTail: ints behind the pictures' blocks
 // pitch-linear NV12 surface -> tight frame (out_fmt 0 = NV12, 1 = I420 order), nv_dec.cpp:782-820
 void launch_packout(const PackJob *d_jobs, int n, int max_width, int max_height, hipStream_t st);

@@ -72,6 +72,8 @@ typedef struct {
     int redundant;              /* 1: redundant_pic_cnt_present_flag = 1; behind the slices of a picture now and then a slice of a REDUNDANT coded picture
                                    (redundant_pic_cnt 1 or 2: the header of the picture's first slice, then bits that are not slice data) -- a decoder
                                    decodes the primary picture and must leave these alone (Baseline tool) */
+    int vui_fps;                /* > 0: the SPS carries VUI timing_info (num_units_in_tick 1, time_scale 2 * vui_fps, fixed_frame_rate_flag 1) and an
+                                   aspect ratio -- nothing in it influences decoding; jm_intel_get_stream_info reports the frame rate from it */
 } GenParams;
 
 /* ------------------------------ RNG --------------------------------------- */
@@ -1965,7 +1967,14 @@ static void write_sps_pps(Enc *e) {
     else { bw_put(w, 1, 1); bw_put(w, 1, (uint32_t)p->dinf8); }           /* frame_mbs_only, direct_8x8_inference */
     int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / (p->fmo0 ? 4 : 2);   /* CropUnitY = 2 * (2 - frame_mbs_only_flag) */
     if (cr || cb) { bw_put(w, 1, 1); bw_ue(w, 0); bw_ue(w, cr); bw_ue(w, 0); bw_ue(w, cb); } else bw_put(w, 1, 0);
-    bw_put(w, 1, 0);                                                      /* no VUI */
+    if (p->vui_fps > 0) {                                                 /* vui_parameters() (E.1.1) */
+        bw_put(w, 1, 1);
+        bw_put(w, 1, 1); bw_put(w, 8, 1);                                 /* aspect_ratio_info_present_flag, aspect_ratio_idc 1 (square) */
+        bw_put(w, 1, 0); bw_put(w, 1, 0); bw_put(w, 1, 0);                /* no overscan info, video signal type, chroma location */
+        bw_put(w, 1, 1); bw_put(w, 32, 1); bw_put(w, 32, 2u * (uint32_t)p->vui_fps); bw_put(w, 1, 1);   /* timing_info: tick, time_scale, fixed rate */
+        bw_put(w, 1, 0); bw_put(w, 1, 0);                                 /* no NAL / VCL HRD parameters */
+        bw_put(w, 1, 0); bw_put(w, 1, 0);                                 /* pic_struct_present_flag, bitstream_restriction_flag */
+    } else bw_put(w, 1, 0);                                               /* no VUI */
     bw_trailing(w); out_nal(&e->out, 3, 7, w, 1);
     w->len = 0;
     bw_ue(w, 0); bw_ue(w, 0); bw_put(w, 1, (uint32_t)(p->cabac != 0)); bw_put(w, 1, (uint32_t)p->poc_bottom); bw_ue(w, 0);
@@ -2646,7 +2655,7 @@ int main(int argc, char **argv) {
         OPT("--cqp", chroma_qp_off) OPT("--level", level_idc) OPT("--cip", cip) OPT("--search", search)
         OPT("--cabac", cabac) OPT("--cabac-idc", cabac_idc) OPT("--t8x8", t8x8)
         OPT("--bframes", bframes) OPT("--direct-temporal", direct_temporal) OPT("--wp", wp) OPT("--dinf8", dinf8) OPT("--scaling", scaling) OPT("--rplm",
-            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff) OPT("--gaps", gaps) OPT("--redundant", redundant)
+            rplm) OPT("--mmco", mmco) OPT("--nc-corner", nc_corner) OPT("--no-intra", no_intra) OPT("--fmo0", fmo0) OPT("--poc-bottom", poc_bottom) OPT("--paff", paff) OPT("--gaps", gaps) OPT("--redundant", redundant) OPT("--vui-fps", vui_fps)
         if (!strcmp(a, "-o")) { outp = v; i++; continue; }
         if (!strcmp(a, "--recon")) { recon = v; i++; continue; }
         fprintf(stderr, "unknown option %s\n", a); return 2;

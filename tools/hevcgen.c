@@ -52,6 +52,7 @@ typedef struct {
     int search;                 /* integer search range (mode 0)                                            */
     int open_gop; /* 1: intra periods after the first start with a CRA picture whose leading B pictures are RASL (gop 1..3, period a multiple of gop + 1);
     parameter sets are repeated there */
+    int vui_fps;                /* > 0: the SPS carries vui_parameters() with vui_timing_info (num_units_in_tick 1, time_scale vui_fps); no effect on decoding */
 } HevcGenParams;
 
 /* ------------------------------ RNG ------------------------------ */
@@ -1441,7 +1442,17 @@ static void write_sps(Enc *e, BitW *out, int max_dpb, int reorder) {
     bw_put(&w, 1, (uint32_t)p->lt_ref);
     if (p->lt_ref) bw_ue(&w, 0);
     bw_put(&w, 1, (uint32_t)p->tmvp); bw_put(&w, 1, (uint32_t)p->strong_intra);
-    bw_put(&w, 1, 0); bw_put(&w, 1, 0);                               /* no VUI, no extension */
+    if (p->vui_fps > 0) {                                             /* vui_parameters() (E.2.1) */
+        bw_put(&w, 1, 1);
+        bw_put(&w, 1, 1); bw_put(&w, 8, 1);                           /* aspect_ratio_info_present_flag, aspect_ratio_idc 1 */
+        bw_put(&w, 1, 0); bw_put(&w, 1, 0); bw_put(&w, 1, 0);         /* overscan, video signal type, chroma location: absent */
+        bw_put(&w, 1, 0); bw_put(&w, 1, 0); bw_put(&w, 1, 0);         /* neutral_chroma_indication, field_seq, frame_field_info_present */
+        bw_put(&w, 1, 0);                                             /* default_display_window_flag */
+        bw_put(&w, 1, 1); bw_put(&w, 32, 1); bw_put(&w, 32, (uint32_t)p->vui_fps);     /* vui_timing_info: num_units_in_tick, time_scale */
+        bw_put(&w, 1, 0); bw_put(&w, 1, 0);                           /* poc_proportional_to_timing, vui_hrd_parameters_present */
+        bw_put(&w, 1, 0);                                             /* bitstream_restriction_flag */
+    } else bw_put(&w, 1, 0);                                          /* no VUI */
+    bw_put(&w, 1, 0);                                                 /* no extension */
     bw_trailing(&w);
     write_nal(out, 33, 0, w.buf, w.len, NULL, 0); free(w.buf);
 }
@@ -1869,7 +1880,7 @@ int main(int argc, char **argv) {
         {"--wpp", &p.wpp}, {"--tile-cols", &p.tile_cols}, {"--tile-rows", &p.tile_rows}, {"--slice-ctus", &p.slice_ctus}, {"--dep-slices", &p.dep_slices},
             {"--merge-cand", &p.merge_cand},
         {"--cabac-init", &p.cabac_init}, {"--par-mrg", &p.par_mrg}, {"--cb-qp-off", &p.cb_qp_off}, {"--cr-qp-off", &p.cr_qp_off}, {"--search", &p.search},
-            {"--rps-sps", &p.rps_sps}, {"--open-gop", &p.open_gop} };
+            {"--rps-sps", &p.rps_sps}, {"--open-gop", &p.open_gop}, {"--vui-fps", &p.vui_fps} };
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-o") && i + 1 < argc) { outp = argv[++i]; continue; }
         if (!strcmp(argv[i], "--recon") && i + 1 < argc) { recon = argv[++i]; continue; }

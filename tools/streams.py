@@ -19,7 +19,7 @@ class GenParams(C.Structure):
         "width", "height", "frames", "qp", "gop", "seed", "mode", "deblock", "num_ref", "slices",
         "pcm_only", "poc_type", "nonref_period", "alpha_off", "beta_off", "chroma_qp_off", "level_idc",
         "cip", "search", "cabac", "cabac_idc", "t8x8", "bframes", "direct_temporal", "wp", "dinf8", "scaling", "rplm", "mmco", "nc_corner", "no_intra",
-        "fmo0", "poc_bottom", "paff", "gaps", "redundant")]
+        "fmo0", "poc_bottom", "paff", "gaps", "redundant", "vui_fps")]
 
 
 def build_tools():
@@ -45,12 +45,12 @@ def _genlib():
 def generate(width=64, height=48, frames=4, qp=28, gop=30, seed=0x4A4D0100, mode=0, deblock=1, num_ref=1,
              slices=1, pcm_only=0, poc_type=2, nonref_period=0, alpha_off=0, beta_off=0, chroma_qp_off=0,
              level_idc=0, cip=0, search=4, cabac=0, cabac_idc=0, t8x8=0, bframes=0, direct_temporal=0, wp=0, dinf8=1, scaling=0, rplm=0, mmco=0, nc_corner=0,
-             no_intra=0, fmo0=0, poc_bottom=0, paff=0, gaps=0, redundant=0,
+             no_intra=0, fmo0=0, poc_bottom=0, paff=0, gaps=0, redundant=0, vui_fps=0,
              recon_path=None):
     """Returns the Annex-B stream as bytes (optionally writing the encoder's own reconstruction)."""
     p = GenParams(width, height, frames, qp, gop, seed, mode, deblock, num_ref, slices, pcm_only, poc_type,
                   nonref_period, alpha_off, beta_off, chroma_qp_off, level_idc, cip, search, cabac, cabac_idc, t8x8,
-                  bframes, direct_temporal, wp, dinf8, scaling, rplm, mmco, nc_corner, no_intra, fmo0, poc_bottom, paff, gaps, redundant)
+                  bframes, direct_temporal, wp, dinf8, scaling, rplm, mmco, nc_corner, no_intra, fmo0, poc_bottom, paff, gaps, redundant, vui_fps)
     buf = C.POINTER(C.c_ubyte)()
     n = C.c_size_t(0)
     rc = _genlib().h264gen_generate(C.byref(p), C.byref(buf), C.byref(n), recon_path.encode() if recon_path else None)
@@ -86,7 +86,7 @@ def config_c2(stream_id=0, frames=120, width=3840, height=2160):
 HEVC_FIELDS = ("width", "height", "frames", "qp", "seed", "intra_period", "gop", "num_ref", "ctb_log2", "min_cb_log2", "max_tb_log2", "min_tb_log2",
                "depth_inter", "depth_intra", "mode", "amp", "sao", "deblock", "tskip", "sdh", "dqp", "pcm", "bypass", "cip", "strong_intra", "tmvp", "wp",
                "rplm", "lt_ref", "scaling", "wpp", "tile_cols", "tile_rows", "slice_ctus", "dep_slices", "merge_cand", "cabac_init", "par_mrg", "rps_sps",
-               "cb_qp_off", "cr_qp_off", "search", "open_gop")
+               "cb_qp_off", "cr_qp_off", "search", "open_gop", "vui_fps")
 
 
 class HevcGenParams(C.Structure):
