@@ -138,7 +138,8 @@ int Decoder::set_option(const char *key, long long v) {
     std::string k(key);
     if (k == "parse_only") parse_only_ = v != 0;
     else if (k == "digest") { want_digest_ = v != 0; if (want_digest_) sync_mode_ = true; }
-    else if (k == "display_delay") display_delay_ = (int)std::max(0ll, std::min(v, (long long)kJobSlots - 4));
+    else if (k == "display_delay") display_delay_ = (int)std::max(0ll, std::min(v, (long long)n_jobs_ - 4));
+    else if (k == "job_slots") { if (inited_) return -1; n_jobs_ = (int)std::max(8ll, std::min(v, (long long)kMaxJobSlots)); n_jobs_set_ = true; }
     else if (k == "fast_parse") fast_parse_ = v != 0;        // 0: the general macroblock path only (tests)
     // tests: FNV-1a over every picture's job list as the device gets it
     else if (k == "job_digest") { want_job_digest_ = v != 0; if (want_job_digest_) sync_mode_ = true; }
@@ -186,6 +187,8 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "fps_den") return codec_ == 1 ? (long long)hsps_.num_units_in_tick : 2ll * seq_.num_units_in_tick;
     // display frames decided and not yet made current by a decode / poll call (finished or still on the device)
     if (k == "frames_waiting") { std::lock_guard<std::mutex> lk(const_cast<std::mutex &>(mtx_)); return (long long)ready_.size(); }
+    // pictures dispatched (being parsed, waiting for the engine, on the device) whose completion the handle has not seen yet
+    if (k == "pictures_in_flight") { std::lock_guard<std::mutex> lk(const_cast<std::mutex &>(mtx_)); return (long long)outstanding_; }
     if (k == "coded_width") return mb_w_ * 16;
     if (k == "coded_height") return mb_h_ * 16;
     if (k == "pitch") return pitch_;
@@ -247,7 +250,8 @@ int Decoder::init(int codec_type, int out_fmt, const uint8_t *extra, int len) {
     codec_ = codec_type; out_fmt_ = out_fmt ? 1 : 0;
     if (codec_type != 0 && codec_type != 1) { fail("only codec_type 0 (H.264) and 1 (HEVC) are implemented"); return -1; }
     if (getenv("JM_AMD_DEC_SYNC")) sync_mode_ = true;
-    if (const char *dd = getenv("JM_AMD_DEC_DISPLAY_DELAY")) display_delay_ = std::max(0, std::min(atoi(dd), kJobSlots - 4));
+    if (const char *js = getenv("JM_AMD_DEC_JOB_SLOTS")) { n_jobs_ = std::max(8, std::min(atoi(js), kMaxJobSlots)); n_jobs_set_ = true; }
+    if (const char *dd = getenv("JM_AMD_DEC_DISPLAY_DELAY")) display_delay_ = std::max(0, std::min(atoi(dd), n_jobs_ - 4));
     if (getenv("JM_AMD_DEC_PARSE_ONLY")) parse_only_ = true;
     out_via_copy_engine_ = !getenv("JM_AMD_DEC_OUT_DIRECT");
     if (getenv("JM_AMD_DEC_DEVICE_OUTPUT")) device_output_ = true;      // host-side tests of callers that cannot reach set_option (jm_intel_dec_* facade)
@@ -416,9 +420,10 @@ bool Decoder::gpu_alloc_sequence() {
     job_cap_ = std::min(job_cap_max_, n_mbs * (sizeof(MbRec) + per_mb) + 256 * (sizeof(SliceRec) + sizeof(SliceWp)) + 4096);
     if (getenv("JM_AMD_DEC_JOB_WORST_CASE")) job_cap_ = job_cap_max_;
     if (codec_ == 1) job_cap_ = n_mbs * 128 + (1u << 20);            // HEVC job lists vary a lot in size: start small, grow on demand (ensure_job_cap)
+    if (!n_jobs_set_) n_jobs_ = codec_ == 0 && n_mbs <= 8704 ? kJobSlotsSmall : kJobSlots;      // (decoder.h)
     const bool lend_big = codec_ == 0 && job_cap_ < job_cap_max_;
     if (parse_only_) {
-        for (auto &j : jobs_) { j.host = (uint8_t *)malloc(job_cap_); j.cap = job_cap_; }
+        for (int i = 0; i < n_jobs_; i++) { jobs_[i].host = (uint8_t *)malloc(job_cap_); jobs_[i].cap = job_cap_; }
         if (lend_big) for (auto &b : big_) b.host = (uint8_t *)malloc(job_cap_max_);
         return true;
     }
@@ -454,7 +459,8 @@ bool Decoder::gpu_alloc_sequence() {
         }
     }
     NumaPreferred on_gpu_node(numa_node_);          // the page-locked job buffers (and output slots) of this handle: memory of the GPU's node
-    for (auto &j : jobs_) {
+    for (int ji = 0; ji < n_jobs_; ji++) {
+        JobSlot &j = jobs_[ji];
         if (!HIP_OK(hipHostMalloc((void **)&j.host, job_cap_, hipHostMallocDefault)) || !HIP_OK(hipMalloc((void **)&j.dev, job_cap_)) ||
             (codec_ == 0 && (!HIP_OK(hipMalloc((void **)&j.dbrec, n_mbs * 96)) || !HIP_OK(hipMalloc((void **)&j.resid, n_mbs * 768)))) ||
             !HIP_OK(hipEventCreateWithFlags(&j.uploaded, hipEventDisableTiming))) { fail("job buffer allocation failed"); return false; }
@@ -467,7 +473,7 @@ bool Decoder::gpu_alloc_sequence() {
     {
         std::lock_guard<std::mutex> lk(mtx_);
         std::vector<OutSlot *> tmp;
-        for (int i = 0; i < kJobSlots + 4; i++) tmp.push_back(alloc_out_slot());
+        for (int i = 0; i < n_jobs_ + 4; i++) tmp.push_back(alloc_out_slot());
         for (OutSlot *o : tmp) free_out_.push_back(o);
     }
     return !failed_;
@@ -1242,7 +1248,7 @@ int Decoder::acquire_job_slot(bool big) {
     int got = -1, bg = -1;
     cv_.wait(lk, [&] {
         got = -1;
-        for (int i = 0; i < kJobSlots; i++) if (!jobs_[i].busy && (got < 0 || (big ? jobs_[i].cap > jobs_[got].cap : jobs_[i].cap < jobs_[got].cap))) got = i;
+        for (int i = 0; i < n_jobs_; i++) if (!jobs_[i].busy && (got < 0 || (big ? jobs_[i].cap > jobs_[got].cap : jobs_[i].cap < jobs_[got].cap))) got = i;
         return got >= 0;
     });
     if (lend && jobs_[got].cap < job_cap_max_) for (int i = 0; i < kBigJobBufs && bg < 0; i++) if (!big_[i].busy) bg = i;

@@ -24,7 +24,12 @@ struct ihipStream_t; struct ihipEvent_t;
 
 namespace jmamd {
 
+constexpr int kMaxJobSlots = 64;  // upper bound of the option "job_slots" / JM_AMD_DEC_JOB_SLOTS
 constexpr int kJobSlots = 24;   // pictures in flight per handle (parse + device); deep enough to hide an I picture's entropy decode behind a GOP of device work
+// H.264 streams up to 1080p: one stream alone is fed by what fits into its slots -- a chain launch holds n pictures while the next n are parsed, and a launch
+// costs ~0.85 ms plus ~0.1 ms per picture, so n decides its rate: 24 slots -> 6.8 pictures per launch, 4.5 k frames/s; 40 slots (and chains of up to 16) ->
+// 14.6 per launch, 6.6 k (profiles/r06_single_stream_slots.txt).  1.3 MB of page-locked memory per slot at 1080p Baseline
+constexpr int kJobSlotsSmall = 40;
 
 struct DpbPic {                                // one frame store (C.4.5): a frame, or the one or two field pictures of a frame
     bool in_use = false;
@@ -231,7 +236,8 @@ private:
     std::condition_variable cv_;
     std::deque<std::unique_ptr<PicTask>> inflight_;
     std::mutex submit_mtx_;
-    JobSlot jobs_[kJobSlots];
+    JobSlot jobs_[kMaxJobSlots]; int n_jobs_ = kJobSlots;      // the first n_jobs_ are in use (option "job_slots", before init)
+    bool n_jobs_set_ = false;                                  // ... chosen by the caller; else by picture size (gpu_alloc_sequence)
     BigJobBuf big_[kBigJobBufs];               // see acquire_job_slot
     void free_job_buffers();
     std::deque<OutSlot *> ready_;              // display order

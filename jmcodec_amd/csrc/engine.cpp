@@ -47,7 +47,7 @@ void mem_trace(const char *tag) {
 
 Engine::Engine(int device) : device_(device) {
     mem_trace("engine: start");
-    if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) chain_depth_ = std::max(1, std::min(atoi(e), 16));
+    if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) { chain_depth_ = std::max(1, std::min(atoi(e), 16)); chain_depth_few_ = chain_depth_.load(); }
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(kMinChainLag, std::min(atoi(e), 1024));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LINGER")) chain_linger_streams_ = std::max(0, atoi(e));
@@ -133,7 +133,7 @@ void Engine::submit(EnginePic &&p) {
 bool Engine::set_knob(const std::string &key, long long v) {
     // an explicit setting ends the pause that follows a recovered chain launch, and has the next batch look again whether the GPU is shared
     if (key.rfind("chain_", 0) == 0) { chain_block_until_ns_ = 0; shared_checked_ns_ = 0; }
-    if (key == "chain_depth") chain_depth_ = (int)std::max(1ll, std::min(v, 16ll));
+    if (key == "chain_depth") { chain_depth_ = (int)std::max(1ll, std::min(v, 16ll)); chain_depth_few_ = chain_depth_.load(); }
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max((long long)kMinChainLag, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
     else if (key == "debug_stall") debug_stall_ = (int)v;
@@ -179,6 +179,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     // pending right now: with 20 or 32 streams the pending set dips below the threshold now and then, and a stream may only change lane once its pictures
     // in flight have retired.  Few streams: chain launches.  Many: stage kernels, one batch across all streams.
     bool chaining = false;
+    int depth_now = chain_depth_;
     {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
         recent_.erase(std::remove_if(recent_.begin(), recent_.end(), [&](const Recent &r) { return now - r.t > 50ll * 1000 * 1000; }), recent_.end());
@@ -199,10 +200,12 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         // otherwise it waits until the lane is idle and takes everything that has arrived by then (two streams 6.4 k -> 7.2 k frames/s; one stream within
         // the noise: its caller's loop, not the chain length, is what bounds it.  Forming the next launch when the running one is four fifths through, to
         // hide the host's turnaround, was tried and lost the gain again: measured, not kept).
+        // one or two streams: chains of up to chain_depth_few_ pictures (a launch costs ~0.85 ms + ~0.1 ms per picture: engine.h)
+        depth_now = n_active <= chain_linger_streams_ ? std::max(chain_depth_.load(), chain_depth_few_.load()) : chain_depth_.load();
         if (lane_idx == kOrdinaryLane && chaining && n_active <= chain_linger_streams_ && ln.inflight > 0) {
             int n = 0;
             for (const EnginePic &p : pending_) if (p.codec == 0 && p.has_picture && p.lane(true) == lane_idx) n++;
-            if (n < chain_depth_ * n_active) return false;
+            if (n < depth_now * n_active) return false;
         }
     }
     std::vector<Decoder *> seen, members;
@@ -260,33 +263,51 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     // pictures to retire, run alone on the intra lane, retire, rejoin).  It is launched as soon as it is seen when no earlier picture of its decoder,
     // pending or in flight, decodes into, references or displays its surface, it packs nothing before its kernels and displays at most itself.  Frames
     // still leave in display order (the handle's queue was filled at submit time); the P picture behind it waits for it like for any picture on another lane.
-    if (lane_idx == kIntraLane && early_intra_ && !chaining && early_scanned_gen_ != pending_gen_) {
-        struct Scan { Decoder *d; uint32_t touched; bool closed; };
-        std::vector<Scan> scans;
-        for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
+    // The look costs a walk over everything pending (some twenty pictures per decoder, under m_, which every submitting thread needs): at most every
+    // 250 us -- an intra batch holds the lane for ~1.8 ms -- and only when something changed.  (The first version looked on every turn of the engine loop
+    // with a quadratic walk: the engine thread sat in it, the feeders queued for m_, 27 k -> 16-20 k frames/s: profiles/r06_lane_fill.txt.)
+    if (lane_idx == kIntraLane && early_intra_ && !chaining && early_scanned_gen_ != pending_gen_ && now_ns - early_scan_ns_ > 250 * 1000) {
+        early_scan_ns_ = now_ns;
+        const unsigned long long tag = ++early_scan_tag_;
+        std::vector<std::deque<EnginePic>::iterator> cand;
+        bool near_turn = false;
+        for (auto it = pending_.begin(); it != pending_.end(); ++it) {
             Decoder *d = it->dec;
-            auto sc = std::find_if(scans.begin(), scans.end(), [&](const Scan &x) { return x.d == d; });
-            if (sc == scans.end()) { scans.push_back(Scan{d, 0u, std::find(members.begin(), members.end(), d) != members.end()}); sc = scans.end() - 1; }
+            EngineDecoderState &es = d->engine_state();
+            if (es.scan_tag != tag) { es.scan_tag = tag; es.scan_touched = 0; es.scan_ahead = 0;
+                es.scan_closed = std::find(members.begin(), members.end(), d) != members.end(); }
             const uint32_t own = it->has_picture ? 1u << (it->codec == 0 ? it->pp.cur : it->hp.cur) : 0u;
-            if (!sc->closed && it->codec == 0 && it->has_picture && it->lane(false) == kIntraLane && it->ref_mask == 0 && it->out_before.empty() &&
-                !it->wait_prev_pack && !(it->out_mask & ~own) && n_post + it->out_after.size() <= (size_t)2 * kMaxBatch) {
-                sc->closed = true;                          // only a decoder's first intra picture is looked at
+            if (!es.scan_closed && it->codec == 0 && it->has_picture && it->lane(false) == kIntraLane && it->ref_mask == 0 && it->out_before.empty() &&
+                !it->wait_prev_pack && !(it->out_mask & ~own)) {
+                es.scan_closed = true;                      // only a decoder's first intra picture is looked at
                 uint32_t infl; inflight_masks(d, infl);
-                if (!(own & (sc->touched | infl))) {
-                    EngineDecoderState &es = d->engine_state();
-                    es.inflight++; es.lane_inflight[lane_idx]++;
-                    if (g_lane_trace > 0) { unsigned long long head = it->seq; int npend = 0;
-                        for (auto &q : pending_) if (q.dec == d) { if (q.seq < head) head = q.seq; npend++; }
-                        LANE_TRACE("early dec %p seq %llu ahead of %llu (%d pending)\n", (void *)d, it->seq, head, npend); }
-                    n_post += it->out_after.size();
-                    b.pics.push_back(std::move(*it));
-                    it = pending_.erase(it);
-                    { std::lock_guard<std::mutex> lk(sm_); st_.early_intra++; }
-                    continue;
-                }
+                // (its job list must have LANDED: the copy stream carries every handle's uploads -- 18 GB/s at 27 k frames/s, the I pictures of all streams
+                //  within a few milliseconds of each other -- and runs some milliseconds behind at times; a picture launched the moment it is parsed makes
+                //  the lane's stream wait for its upload, and with it every other picture of the batch.  In-order pictures were uploaded twenty pictures ago)
+                const bool landed = !it->uploaded || hipEventQuery(it->uploaded) == hipSuccess;
+                if (!landed) (void)hipGetLastError();
+                if (landed && !(own & (es.scan_touched | infl))) { cand.push_back(it); near_turn |= es.scan_ahead <= 8; }
             }
-            sc->touched |= it->ref_mask | it->out_mask | own;
-            ++it;
+            es.scan_touched |= it->ref_mask | it->out_mask | own;
+            es.scan_ahead++;
+        }
+        // an intra batch costs the lane the same 1.8 ms whatever it holds, and its kernels run beside the ordinary lane's: few, full batches.  The pictures
+        // found go now when there are enough of them, or when one of them is about to have its turn anyway; else they wait for company
+        if ((int)cand.size() >= 4 || near_turn || !b.pics.empty()) {      // (or a batch is formed anyway: they go along)
+            // (taken back to front, by position: erasing from a deque invalidates iterators)
+            std::vector<size_t> pos;
+            for (auto &c : cand) pos.push_back((size_t)(c - pending_.begin()));
+            for (size_t k = pos.size(); k-- > 0 && (int)b.pics.size() < kMaxBatch;) {
+                auto it = pending_.begin() + (std::ptrdiff_t)pos[k];
+                if (n_post + it->out_after.size() > (size_t)2 * kMaxBatch) continue;
+                EngineDecoderState &es = it->dec->engine_state();
+                es.inflight++; es.lane_inflight[lane_idx]++;
+                LANE_TRACE("early dec %p seq %llu\n", (void *)it->dec, it->seq);
+                n_post += it->out_after.size();
+                b.pics.push_back(std::move(*it));
+                pending_.erase(it);
+                { std::lock_guard<std::mutex> lk(sm_); st_.early_intra++; }
+            }
         }
         early_scanned_gen_ = pending_gen_;                  // (taking a picture bumps the generation below: the next look then scans again)
     }
@@ -306,7 +327,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         tot_groups <= kMaxChainGroups) {
         // Depth: few streams -> long chains (a lone stream is bound by the latency of the deblocking wavefront, which chains overlap);
         // many streams -> the batch is already wide, and kMaxBatch bounds it.
-        const int depth_cap = std::min(chain_depth_.load(), std::max(1, kMaxBatch / (int)members.size()));
+        const int depth_cap = std::min(depth_now, std::max(1, kMaxBatch / (int)members.size()));
         for (int depth = 1; depth < depth_cap; depth++) {
             bool added = false;
             for (Decoder *d : members) {
@@ -825,7 +846,10 @@ void Engine::run() {
         for (int li = 0; li < kLanes; li++) {
             Lane &ln = lanes_[li];
             static const int max_inflight = getenv("JM_AMD_DEC_INFLIGHT") ? atoi(getenv("JM_AMD_DEC_INFLIGHT")) : 2;
-            if (ln.inflight >= max_inflight) continue;
+            // the intra lane takes one batch at a time while intra pictures may run ahead of their turn: a second batch behind a running one would only fix its
+            // membership early (it could not start sooner), and an intra batch costs the lane the same 1.8 ms whether it holds two pictures or twenty --
+            // formed when the lane falls idle it takes everything that has become ready meanwhile (r06: 276 batches of 2.3 -> see profiles/r06_lane_fill.txt)
+            if (ln.inflight >= (li == kIntraLane && early_intra_ ? 1 : max_inflight)) continue;
             Batch &b = ln.ring[ln.head];
             bool have;
             if (li == kOrdinaryLane) { bool any; { std::lock_guard<std::mutex> lk(m_); any = !pending_.empty(); } if (any) look_for_other_users(); }

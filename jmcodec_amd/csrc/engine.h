@@ -104,6 +104,7 @@ struct EngineDecoderState {
     int lane_inflight[4] = {0, 0, 0, 0};            // ... per lane
     uint32_t displayed[4] = {0, 0, 0, 0};           // per lane: surfaces displayed by this decoder's pictures in the lane's most recently launched batch
     unsigned long long next_seq = 0;                // decode-order numbering of the decoder's pictures (Engine::submit, m_)
+    unsigned long long scan_tag = 0; uint32_t scan_touched = 0; int scan_ahead = 0; bool scan_closed = false;   // scratch of the look for intra pictures (Engine::form)
     long long blocked_since = 0;                    // diagnostic: when an ordinary-lane batch first left this decoder out (0: not left out)
     // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
     int in_batch = 0; uint32_t batch_written = 0, batch_read = 0; bool batch_chain = false, batch_stop = false, batch_resid = false;
@@ -164,6 +165,7 @@ private:
     // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
     // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
     bool cross_lane_ = true, early_intra_ = true;
+    long long early_scan_ns_ = 0; unsigned long long early_scan_tag_ = 0;
     unsigned long long pending_gen_ = 0, early_scanned_gen_ = ~0ull;      // m_: bumped whenever pending_ or the set of pictures in flight changes
     // m_ held: the device has finished every picture of d earlier in decode order than `seq` that is in flight on another lane
     bool others_done(Decoder *d, int lane_idx, unsigned long long seq);
@@ -174,6 +176,7 @@ private:
     int chain_bands_max_ = kMaxChainBands, chain_bands_max_intra_ = kMaxChainBandsIntra;
     // chain_lag_steps_: spacing of consecutive pictures of a chain in the work list, in wavefront steps (JM_AMD_DEC_CHAIN_LAG)
     std::atomic<int> chain_depth_{8}, chain_lag_steps_{24};
+    std::atomic<int> chain_depth_few_{16};          // ... with one or two active streams (an explicit chain_depth sets both)
     // H.264 decoders that submitted a picture lately (time of the last one): how many streams are active (m_)
     struct Recent { Decoder *dec; long long t; int mbs; };      // (dec is only compared, never dereferenced: the handle may be gone)
     std::vector<Recent> recent_;

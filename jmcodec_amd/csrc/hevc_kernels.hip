@@ -14,13 +14,13 @@
 #include "hevc_jobs.h"
 #include "hevc_kernels.h"
 #include "hevc_tables.h"
+#include "hevc_mc_packed.h"
+#include "hevc_resid_packed.h"
 #include "chain_common.h"
 #include <cstdlib>
 
 namespace jmamd {
 
-__constant__ int8_t c_trans[32][32];
-__constant__ int8_t c_dst[4][4];
 __constant__ int8_t c_lf[4][8];
 __constant__ int8_t c_cf[8][4];
 __constant__ int8_t c_angle[35];
@@ -38,109 +38,104 @@ __device__ __forceinline__ uint8_t *sample_ptr(uint8_t *surf, const HevcPicParam
 // ------------------------------------------------------------------------------------------------------------
 // 8.5.3.3: motion compensation
 // ------------------------------------------------------------------------------------------------------------
-// One wavefront per prediction block of at most 16x16 luma samples.  Per reference list: the (w+7) x (h+7) luma window (then the interleaved CbCr
-// window, (w/2+3) x (h/2+3) sample pairs) goes into LDS as ALIGNED DWORDS of 32-byte rows -- 3 load rounds of the wave instead of 9 byte-wise ones --
-// unless it touches the picture border (then byte-wise with clamped coordinates, 8.5.3.3.3.1); separable 8-tap / 4-tap filter through LDS; every
-// lane ends up with four horizontally adjacent samples (luma) or two CbCr pairs (chroma) and stores ONE dword (block positions and widths are
-// multiples of 4).  Cb and Cr share one window load and one store.
+// One WAVEFRONT per prediction block of at most 16x16 luma samples, four of them to a workgroup (round 6; until round 5 one 64-thread workgroup per block
+// and plain integer filters: 29.7 M VALU wave-instructions per 4K picture).  The sample arithmetic is hevc_mc_packed.h.  Per reference list:
+//   window  the (w+7) x (h+7) luma window (then the interleaved CbCr window, (w/2+3) x (h/2+3) pairs) goes into the wave's LDS tile as ALIGNED DWORDS of
+//           32-byte rows, samples XOR 0x80 -- unless it touches the picture border (then byte-wise with clamped coordinates, 8.5.3.3.3.1);
+//   pass 1  a lane takes two window rows and four columns: horizontal sums by v_dot4, packed into 16-bit row pairs, stored column-major (one round);
+//   pass 2  a lane takes one row and four columns (luma) / two CbCr pairs (chroma) of the block: five (three) v_dot2 per sample down the column strings;
+// every lane ends up with four 14-bit intermediates and stores ONE dword (block positions and widths are multiples of 4).  Cb and Cr share one window load
+// and one store.  The wave's LDS operations execute in order, so a compiler barrier stands where a workgroup would need s_barrier.
+using hpk::kMcRowDw; using hpk::kMcTileDw; using hpk::kMcColDw;
 struct HevcMcLds {
-    __align__(16) uint8_t tile[23 * 32];      // window rows of 32 bytes
-    int16_t hbuf[23 * 16];                    // horizontally filtered rows, 16 per row; chroma: Cb rows, then (from 11 * 8) Cr rows of 8
+    uint32_t tile[kMcTileDw];
+    uint32_t hcol[16 * kMcColDw];              // [column][row pair]
 };
+__constant__ uint32_t c_lh[4][2];              // hpk::luma_taps_h
+__constant__ uint32_t c_lv[4][2][5];           // hpk::luma_taps_v [fraction][row parity]
+__constant__ uint32_t c_ch[8];                 // hpk::chroma_taps_h
+__constant__ uint32_t c_cv[8][2][3];           // hpk::chroma_taps_v
 
-// luma: this lane's four 14-bit intermediates (row my_row, columns 4 * my_q ..) of list-l prediction
+// the window of one list into the tile.  row_bytes: bytes of a window row (luma tw, chroma 2 * tw); x0b: byte column of its first sample in the plane row;
+// inside: it lies within the plane (and the last dword of a row within the pitch).  Returns the byte offset of the first sample in a tile row.
+__device__ __forceinline__ int mc_fill_tile(const uint8_t *plane, int pitch, int x0b, int y0, int row_bytes, int th, bool inside, int pw_b, int ph, int step,
+    uint32_t *tile, int lane) {
+    if (inside) {
+        const int sh = x0b & 3, ndw = (sh + row_bytes + 3) >> 2;          // <= 7
+        const uint8_t *base = plane + (size_t)y0 * pitch + (x0b & ~3);
+        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
+            if (d < ndw) tile[r * kMcRowDw + d] = *(const uint32_t *)(base + (size_t)r * pitch + 4 * d) ^ 0x80808080u; }
+        return sh;
+    }
+    // border: byte-wise, coordinates clamped per sample (chroma: per CbCr pair, step 2)
+    for (int k = lane; k < th * 8; k += 64) {
+        const int r = k >> 3, d = k & 7;
+        if (4 * d >= row_bytes) continue;
+        const uint8_t *row = plane + (size_t)clip3(0, ph - 1, y0 + r) * pitch;
+        uint32_t w = 0;
+        for (int i = 0; i < 4; i++) { const int xb = x0b + 4 * d + i; const int xs = clip3(0, pw_b - step, xb & ~(step - 1)) + (xb & (step - 1));
+            w |= (uint32_t)row[xs] << (8 * i); }
+        tile[r * kMcRowDw + d] = w ^ 0x80808080u;
+    }
+    return 0;
+}
+
+// luma: this lane's four 14-bit intermediates (row my_row, columns 4 * my_q ..) of one list's prediction
 __device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint8_t *ref, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm,
     int lane, bool mine, int my_row, int my_q, int *out) {
-    const int tw = bw + 7, th = bh + 7, x0 = xi - 3, y0 = yi - 3;
-    int sh = 0;
-    __syncthreads();                                          // (the previous user of tile / hbuf is done)
-    if (x0 >= 0 && y0 >= 0 && x0 + tw <= pp.w && y0 + th <= pp.h && ((x0 + tw + 3) & ~3) <= pp.pitch) {     // (the last dword of a row stays inside the row)
-        sh = x0 & 3;
-        const int ndw = (sh + tw + 3) >> 2;                   // <= 7
-        const uint8_t *base = ref + (size_t)y0 * pp.pitch + (x0 & ~3);
-        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
-            if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
-    } else {
-        for (int k = lane; k < tw * th; k += 64) { const int r = k / tw, c = k - r * tw;
-            sm.tile[r * 32 + c] = ref[(size_t)clip3(0, pp.h - 1, y0 + r) * pp.pitch + clip3(0, pp.w - 1, x0 + c)]; }
-    }
-    __syncthreads();
-    const int8_t *fx = c_lf[xf], *fy = c_lf[yf];
-    for (int k = lane; k < bw * th; k += 64) {
-        const int r = k / bw, c = k - r * bw;
-        const uint8_t *t = sm.tile + r * 32 + sh + c;
-        int v;
-        if (xf) { v = 0; for (int i = 0; i < 8; i++) v += fx[i] * t[i]; } else v = t[3];
-        sm.hbuf[r * 16 + c] = (int16_t)v;
-    }
-    __syncthreads();
+    const int tw = bw + 7, th = bh + 7, x0 = xi - 3, y0 = yi - 3, qw = bw >> 2;
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + tw <= pp.w && y0 + th <= pp.h && ((x0 + tw + 3) & ~3) <= pp.pitch;
+    __builtin_amdgcn_wave_barrier();                              // (the previous user of the tile is done: same wave, in order)
+    const int sh = mc_fill_tile(ref, pp.pitch, x0, y0, tw, th, inside, pp.w, pp.h, 1, sm.tile, lane);
+    __builtin_amdgcn_wave_barrier();
+    hpk::mc_pass1<false>(sm.tile, sh, qw, th, lane, c_lh[xf][0], c_lh[xf][1], sm.hcol);       // lane -> (row pair, column quad); at most 12 x 4 tasks
+    __builtin_amdgcn_wave_barrier();
     if (!mine) return;
-    for (int i = 0; i < 4; i++) {
-        const int16_t *h = sm.hbuf + my_row * 16 + 4 * my_q + i;
-        int v;
-        if (yf) { v = 0; for (int j = 0; j < 8; j++) v += fy[j] * h[j * 16]; if (xf) v >>= 6; }
-        else { v = h[3 * 16]; if (!xf) v <<= 6; }
-        out[i] = v;
-    }
+    uint32_t tp[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) tp[k] = c_lv[yf][my_row & 1][k];
+    hpk::mc_pass2<false>(sm.hcol, my_row, my_q, tp, xf != 0, yf != 0, out);                   // rows my_row .. my_row + 7 of the intermediates, down four columns
 }
-// chroma: this lane's two CbCr pairs (Cb0, Cr0, Cb1, Cr1 of row my_row, columns 2 * my_q, 2 * my_q + 1)
+// chroma: this lane's two CbCr pairs (Cb0, Cr0, Cb1, Cr1 of row my_row, pair columns 2 * my_q, 2 * my_q + 1)
 __device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const uint8_t *refc, int xi, int yi, int bw, int bh, int xf, int yf, HevcMcLds &sm,
     int lane, bool mine, int my_row, int my_q, int *out) {
-    const int tw = bw + 3, th = bh + 3, x0 = xi - 1, y0 = yi - 1, pw = pp.w >> 1, ph = pp.h >> 1;
-    int sh = 0;
-    __syncthreads();
-    if (x0 >= 0 && y0 >= 0 && x0 + tw <= pw && y0 + th <= ph && ((2 * (x0 + tw) + 3) & ~3) <= pp.pitch) {
-        sh = (2 * x0) & 3;
-        const int ndw = (sh + 2 * tw + 3) >> 2;               // <= 6
-        const uint8_t *base = refc + (size_t)y0 * pp.pitch + ((2 * x0) & ~3);
-        for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
-            if (d < ndw) ((uint32_t *)sm.tile)[r * 8 + d] = *(const uint32_t *)(base + (size_t)r * pp.pitch + 4 * d); }
-    } else {
-        for (int k = lane; k < 2 * tw * th; k += 64) { const int r = k / (2 * tw), c = k - r * 2 * tw;
-            sm.tile[r * 32 + c] = refc[(size_t)clip3(0, ph - 1, y0 + r) * pp.pitch + 2 * clip3(0, pw - 1, x0 + (c >> 1)) + (c & 1)]; }
-    }
-    __syncthreads();
-    const int8_t *fx = c_cf[xf], *fy = c_cf[yf];
-    for (int k = lane; k < 2 * bw * th; k += 64) {            // both components: k = (r * bw + c) * 2 + comp
-        const int comp = k & 1, rc = k >> 1, r = rc / bw, c = rc - r * bw;
-        const uint8_t *t = sm.tile + r * 32 + sh + 2 * c + comp;
-        int v;
-        if (xf) { v = 0; for (int i = 0; i < 4; i++) v += fx[i] * t[2 * i]; } else v = t[2];
-        sm.hbuf[comp * 88 + r * 8 + c] = (int16_t)v;
-    }
-    __syncthreads();
+    const int tw = bw + 3, th = bh + 3, x0 = xi - 1, y0 = yi - 1, pw = pp.w >> 1, ph = pp.h >> 1, qw = bw >> 1;
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + tw <= pw && y0 + th <= ph && ((2 * (x0 + tw) + 3) & ~3) <= pp.pitch;
+    __builtin_amdgcn_wave_barrier();
+    const int sh = mc_fill_tile(refc, pp.pitch, 2 * x0, y0, 2 * tw, th, inside, 2 * pw, ph, 2, sm.tile, lane);
+    __builtin_amdgcn_wave_barrier();
+    // pass 1: lane -> (row pair, two CbCr pairs); the intermediates' "columns" are the bytes of the interleaved output row: Cb0 Cr0 Cb1 Cr1 ..
+    hpk::mc_pass1<true>(sm.tile, sh, qw, th, lane, c_ch[xf], 0u, sm.hcol);
+    __builtin_amdgcn_wave_barrier();
     if (!mine) return;
-    for (int i = 0; i < 4; i++) {                              // i = 2 * (column within the pair) + comp
-        const int16_t *h = sm.hbuf + (i & 1) * 88 + my_row * 8 + 2 * my_q + (i >> 1);
-        int v;
-        if (yf) { v = 0; for (int j = 0; j < 4; j++) v += fy[j] * h[j * 8]; if (xf) v >>= 6; }
-        else { v = h[8]; if (!xf) v <<= 6; }
-        out[i] = v;
-    }
+    uint32_t tp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tp[k] = c_cv[yf][my_row & 1][k];
+    hpk::mc_pass2<true>(sm.hcol, my_row, my_q, tp, xf != 0, yf != 0, out);                    // out[i]: byte i of the output dword = Cb0 Cr0 Cb1 Cr1
 }
 
-__global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
+constexpr int kMcWaves = 4;
+__global__ __launch_bounds__(64 * kMcWaves) void k_hevc_mc(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
     // XCD-aware: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); give every XCD one contiguous run of blocks
     // (blocks are in decoding order, i.e. spatially coherent), so that a reference window is fetched into one L2 instead of eight
-    const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (!(pp.stages & HPS_MC) || job >= pp.n_pus) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int per_xcd = ((int)gridDim.x + 7) >> 3, job = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * kMcWaves + wave;
+    if (!(pp.stages & HPS_MC) || job >= pp.n_pus) return;      // (no workgroup barrier below: a wave may leave alone)
     const HevcPu pu = pp.pus[job];
-    const int lane = threadIdx.x;
-    __shared__ HevcMcLds sm;
+    const int lane = (int)(threadIdx.x & 63);
+    __shared__ HevcMcLds sm_all[kMcWaves];
+    HevcMcLds &sm = sm_all[wave];
     uint8_t *dst = pp.work_surf;
     const HevcWp *wp = pu.wp ? &pp.wps[pu.wp - 1] : nullptr;
-    const int both = pu.slot0 >= 0 && pu.slot1 >= 0;
-    // 8.5.3.3.4.2 / 8.5.3.3.4.3: the two 14-bit predictions -> one sample of component c
+    const bool both = pu.slot0 >= 0 && pu.slot1 >= 0;
+    // 8.5.3.3.4.3 (explicit weights): the two 14-bit predictions -> one sample of component c.  Default weights: hpk::weigh_default4
     auto weigh = [&](int p0, int p1, int c) -> int {
         int v;
-        if (!wp) v = both ? (p0 + p1 + 64) >> 7 : ((pu.slot0 >= 0 ? p0 : p1) + 32) >> 6;
-        else {
-            const int ld = wp->log2wd[c ? 1 : 0];
-            if (both) v = (p0 * wp->w[0][pu.ridx0][c] + p1 * wp->w[1][pu.ridx1][c] + ((wp->o[0][pu.ridx0][c] + wp->o[1][pu.ridx1][c] + 1) << ld)) >> (ld + 1);
-            else if (pu.slot0 >= 0) v = ((p0 * wp->w[0][pu.ridx0][c] + (1 << (ld - 1))) >> ld) + wp->o[0][pu.ridx0][c];
-            else v = ((p1 * wp->w[1][pu.ridx1][c] + (1 << (ld - 1))) >> ld) + wp->o[1][pu.ridx1][c];
-        }
+        const int ld = wp->log2wd[c ? 1 : 0];
+        if (both) v = (p0 * wp->w[0][pu.ridx0][c] + p1 * wp->w[1][pu.ridx1][c] + ((wp->o[0][pu.ridx0][c] + wp->o[1][pu.ridx1][c] + 1) << ld)) >> (ld + 1);
+        else if (pu.slot0 >= 0) v = ((p0 * wp->w[0][pu.ridx0][c] + (1 << (ld - 1))) >> ld) + wp->o[0][pu.ridx0][c];
+        else v = ((p1 * wp->w[1][pu.ridx1][c] + (1 << (ld - 1))) >> ld) + wp->o[1][pu.ridx1][c];
         return clip1(v);
     };
     {   // ---- luma: lane -> (row, dword) ----
@@ -155,7 +150,8 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
         }
         if (mine) {
             uint32_t w = 0;
-            for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 0) << (8 * i);
+            if (!wp) w = both ? hpk::weigh_default4(p[0], p[1], true) : hpk::weigh_default4(pu.slot0 >= 0 ? p[0] : p[1], p[1], false);
+            else for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 0) << (8 * i);
             *(uint32_t *)(dst + (size_t)(pu.y + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
         }
     }
@@ -172,126 +168,139 @@ __global__ __launch_bounds__(64) void k_hevc_mc(const HevcPicParams *pics) {
         }
         if (mine) {
             uint32_t w = 0;
-            for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 1 + (i & 1)) << (8 * i);
+            if (!wp) w = both ? hpk::weigh_default4(p[0], p[1], true) : hpk::weigh_default4(pu.slot0 >= 0 ? p[0] : p[1], p[1], false);
+            else for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 1 + (i & 1)) << (8 * i);
             *(uint32_t *)(dst + pp.chroma_offset + (size_t)((pu.y >> 1) + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// 8.6.4.2: residual of one transform block from its sparse scaled coefficients; result in res[y * n + x]
+// 8.6.4.2: residual of one transform block from its sparse scaled coefficients
 // ------------------------------------------------------------------------------------------------------------
-// The n-point core transform matrix of 8.6.4.2 is rows 0, 32/n, 2 * 32/n, ... of the 32-point matrix, first n columns: tm[j * n + y], n * n bytes (16 for a 4x4
-// block -- the whole 32x32 matrix used to be copied for every block).  The caller synchronises before using it.
-__device__ __forceinline__ void load_transform_matrix(int8_t *tm, int log2, int lane, int nt) {
-    if (log2 == 5) { for (int k = lane; k < 256; k += nt) ((uint32_t *)tm)[k] = ((const uint32_t *)&c_trans[0][0])[k]; return; }
-    const int n = 1 << log2, step = 32 >> log2;
-    for (int k = lane; k < n * n; k += nt) tm[k] = c_trans[(k >> log2) * step][k & (n - 1)];
+// Round 6 (hevc_resid_packed.h): one WAVE per transform block, four waves to a workgroup, every wave takes kResidPerWave consecutive blocks of the list; the
+// matrices of all sizes sit in LDS once per workgroup as 16-bit pairs; both stages are v_dot2_i32_i16 sums over the row pairs / column pairs that hold
+// coefficients.  (Until round 5: one 64-thread workgroup per block, the block's matrix copied to LDS per block, byte-wise multiply-adds.)
+constexpr int kResidWaves = 4, kResidPerWave = 8;
+constexpr int kResidBufDw = 512;                       // one wave's coefficient pairs (16 x 32) / intermediate (32 x 16 dwords)
+__device__ uint32_t g_resid_pairs[hrp::kPairDw];       // hrp::build_pair_table, uploaded once per device
+struct HevcResidLds {
+    uint32_t mp[hrp::kPairDw];
+    uint32_t dp[kResidWaves][kResidBufDw];
+    uint32_t g[kResidWaves][kResidBufDw];
+};
+// largest value of v over the wave, wave-uniform (v >= 0)
+__device__ __forceinline__ int wave_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));         // quad_perm [1 0 3 2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));         // quad_perm [2 3 0 1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));        // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));        // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-// Callers make sure nobody still reads d / res (a barrier since their last use).  Returns the buffer that holds the residual.
-// tm: the block's n-point transform matrix in LDS (load_transform_matrix); ext: two LDS ints (largest row / column that holds a coefficient: the sums skip the
-// rest).
-// WAVE: the caller is a single wavefront (LDS operations of one wave execute in order, so a scheduling barrier replaces s_barrier).
-template <bool WAVE>
-__device__ const int16_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, int16_t *d, int16_t *res, const int8_t *tm, int *ext, int lane,
-    int nt) {
-    auto sync = [] { if (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
+// The residual of one block, by ONE wave (its LDS operations execute in order: a compiler barrier stands where a workgroup would need s_barrier).
+// Returns the residual as dwords of two neighbouring samples (x | x + 1 << 16), n / 2 per row -- in dp, or in g for transform-skip / bypass blocks.
+__device__ __forceinline__ const uint32_t *residual_block(const uint32_t *coefs, int count, int log2, int flags, uint32_t *dp, uint32_t *g, const uint32_t *mp,
+    int lane) {
     const int n = 1 << log2, nn = n * n;
-    for (int k = lane; k < nn; k += nt) d[k] = 0;
-    if (lane < 2) ext[lane] = 0;
-    sync();
-    for (int k = lane; k < count; k += nt) { const uint32_t e = coefs[k]; const int pos = e & 1023; d[pos] = (int16_t)(e >> 16);
-        atomicMax(&ext[0], pos >> log2); atomicMax(&ext[1], pos & (n - 1)); }
-    sync();
-    if (flags & HTB_BYPASS) return d;
-    if (flags & HTB_TSKIP) { for (int k = lane; k < nn; k += nt) res[k] = (int16_t)(((d[k] << 7) + 2048) >> 12); sync(); return res; }
-    const int dst = flags & HTB_DST, jmax = ext[0], xw = ext[1] + 1;
-    // columns: g[y][x] = clip16((sum_j M[j][y] * d[j][x] + 64) >> 7) for the columns that hold coefficients, kept in res
-    for (int k = lane; k < n * xw; k += nt) {
-        const int y = k / xw, x = k - y * xw;
-        int v = 0;
-        for (int j = 0; j <= jmax; j++) v += (dst ? c_dst[j][y] : tm[(j << log2) + y]) * d[j * n + x];
-        res[y * n + x] = (int16_t)clip3(-32768, 32767, (v + 64) >> 7);
+    const uint32_t e0 = lane < count ? coefs[lane] : 0u;                          // (most blocks hold fewer than 64 coefficients: one load serves both walks)
+    __builtin_amdgcn_wave_barrier();
+    if (flags & (HTB_BYPASS | HTB_TSKIP)) {
+        for (int k = lane; k < (nn >> 1); k += 64) g[k] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int16_t *r16 = (int16_t *)g;
+        for (int k = lane; k < count; k += 64) { const uint32_t e = k < 64 ? e0 : coefs[k]; const int v = (int16_t)(e >> 16);
+            r16[e & 1023u] = (int16_t)((flags & HTB_BYPASS) ? v : hrp::tskip_value(v)); }
+        __builtin_amdgcn_wave_barrier();
+        return g;
     }
-    sync();
-    // rows: r[y][x] = (sum_k M[k][x] * g[y][k] + 2048) >> 12, into d
-    for (int k = lane; k < nn; k += nt) {
-        const int y = k >> log2, x = k & (n - 1);
-        int v = 0;
-        for (int j = 0; j < xw; j++) v += (dst ? c_dst[j][x] : tm[(j << log2) + x]) * res[y * n + j];
-        d[k] = (int16_t)((v + 2048) >> 12);
-    }
-    sync();
-    return d;
+    // which row pairs and columns hold coefficients
+    int mj = 0, mx = 0;
+    for (int k = lane; k < count; k += 64) { const uint32_t e = k < 64 ? e0 : coefs[k]; const int pos = (int)(e & 1023u);
+        mj = max(mj, pos >> log2); mx = max(mx, pos & (n - 1)); }
+    const int jpmax = wave_max(mj) >> 1, cw = min(hrp::pad_cols(wave_max(mx) + 1), n), lcw = hrp::log2_of(cw);
+    for (int k = lane; k < ((jpmax + 1) << log2); k += 64) dp[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int16_t *d16 = (int16_t *)dp;
+    for (int k = lane; k < count; k += 64) { const uint32_t e = k < 64 ? e0 : coefs[k]; const int pos = (int)(e & 1023u);
+        d16[hrp::pair_slot(pos >> log2, pos & (n - 1), log2)] = (int16_t)(e >> 16); }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t *mp_n = mp + hrp::pair_off(log2, (flags & HTB_DST) != 0);
+    int16_t *g16 = (int16_t *)g;
+    for (int t = lane; t < (n << lcw); t += 64) { int gi; const int v = hrp::col_task(t, log2, lcw, jpmax, mp_n, dp, gi); g16[gi] = (int16_t)v; }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < (nn >> 1); t += 64) dp[t] = hrp::row_task(t, log2, cw >> 1, mp_n, g);        // (the second stage reads g only: dp is free again)
+    __builtin_amdgcn_wave_barrier();
+    return dp;
 }
 
-__global__ __launch_bounds__(64) void k_hevc_resid(const HevcPicParams *pics) {
+__global__ __launch_bounds__(64 * kResidWaves) void k_hevc_resid(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
-    const int per_xcd = ((int)gridDim.x + 7) >> 3, job = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD-aware, see k_hevc_mc
-    if (!(pp.stages & HPS_RESID) || job >= pp.n_tbs) return;
-    const HevcTb tb = pp.tbs[job];
-    if (!tb.coef_n) return;                                           // (a luma block whose levels all scaled to zero: listed for the boundary strengths only)
+    const int per_xcd = ((int)gridDim.x + 7) >> 3, wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);      // XCD-aware, see k_hevc_mc
+    if (!(pp.stages & HPS_RESID) || wg * (kResidWaves * kResidPerWave) >= pp.n_tbs) return;
+    __shared__ HevcResidLds sm;
+    for (int k = threadIdx.x; k < hrp::kPairDw; k += 64 * kResidWaves) sm.mp[k] = g_resid_pairs[k];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    uint32_t *dp = sm.dp[wave], *g = sm.g[wave];
+    uint8_t *dst = pp.work_surf;
     // Cb and Cr of a transform unit are interleaved in memory and are two entries of the list, one behind the other when both are coded (transform_unit()
-    // emits c = 1, then c = 2).  The Cb workgroup takes its Cr partner along, so the pair leaves as whole dwords (Cb Cr Cb Cr) instead of byte-wise
-    // read-modify-writes of two workgroups on the same lines; a component whose partner is not coded does the same with a zero residual for the other half
+    // emits c = 1, then c = 2).  The Cb wave takes its Cr partner along, so the pair leaves as whole dwords (Cb Cr Cb Cr) instead of byte-wise
+    // read-modify-writes of two waves on the same lines; a component whose partner is not coded does the same with a zero residual for the other half
     // (nobody else writes those bytes: blocks are disjoint, and the motion compensation ran in an earlier kernel).
     auto same_place = [](const HevcTb &a, const HevcTb &b) { return a.x == b.x && a.y == b.y && a.log2 == b.log2; };
-    if (tb.plane == 2 && job > 0) { const HevcTb prev = pp.tbs[job - 1]; if (prev.plane == 1 && same_place(prev, tb)) return; }     // done by its Cb partner
-    __shared__ int16_t d[32 * 32], res[32 * 32];
-    __shared__ __align__(16) int8_t tm[32 * 32];
-    __shared__ int ext[2];
-    const int lane = threadIdx.x, n = 1 << tb.log2;
-    load_transform_matrix(tm, tb.log2, lane, 64);
-    const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
-    uint8_t *dst = pp.work_surf;
-    if (tb.plane == 0) {
-        // luma: four samples of a row per lane, one dword read and one dword written (block positions and sizes are multiples of 4)
-        const int qn = n >> 2;
-        for (int k = lane; k < n * qn; k += 64) {
-            const int y = k / qn, xq = k - y * qn;
-            uint32_t *p = (uint32_t *)(dst + (size_t)(tb.y + y) * pp.pitch + tb.x + 4 * xq);
-            const uint32_t v = *p; const int16_t *rr = r + y * n + 4 * xq;
-            *p = (uint32_t)clip1((int)(v & 255) + rr[0]) | (uint32_t)clip1((int)(v >> 8 & 255) + rr[1]) << 8 |
-                 (uint32_t)clip1((int)(v >> 16 & 255) + rr[2]) << 16 |
-                 (uint32_t)clip1((int)(v >> 24) + rr[3]) << 24;
+    const int first = (wg * kResidWaves + wave) * kResidPerWave;
+    for (int job = first; job < first + kResidPerWave && job < pp.n_tbs; job++) {
+        const HevcTb tb = pp.tbs[job];
+        if (!tb.coef_n) continue;                                     // (a luma block whose levels all scaled to zero: listed for the boundary strengths only)
+        if (tb.plane == 2 && job > 0) { const HevcTb prev = pp.tbs[job - 1]; if (prev.plane == 1 && same_place(prev, tb)) continue; }   // done by its Cb partner
+        const int n = 1 << tb.log2, hn = n >> 1;
+        const uint32_t *r = residual_block(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, dp, g, sm.mp, lane);
+        if (tb.plane == 0) {
+            // luma: four samples of a row per lane, one dword read and one dword written (block positions and sizes are multiples of 4)
+            for (int k = lane; k < (n << (tb.log2 - 2)); k += 64) {
+                const int y = k >> (tb.log2 - 2), xq = k & ((n >> 2) - 1);
+                uint32_t *p = (uint32_t *)(dst + (size_t)(tb.y + y) * pp.pitch + tb.x + 4 * xq);
+                *p = pk::add_residual4(*p, r[y * hn + 2 * xq], r[y * hn + 2 * xq + 1]);
+            }
+            continue;
         }
-        return;
-    }
-    // chroma (blocks of at most 16x16: the upper halves of d / res hold the partner's block)
-    const int16_t *rb = tb.plane == 1 ? r : nullptr, *rr2 = tb.plane == 2 ? r : nullptr;
-    if (tb.plane == 1 && job + 1 < pp.n_tbs) {
-        const HevcTb nx = pp.tbs[job + 1];
-        if (nx.plane == 2 && same_place(tb, nx))
-            rr2 = residual_block<false>(pp.coefs + nx.coef_off, (int)nx.coef_n, nx.log2, nx.flags, d + 512, res + 512, tm, ext, lane, 64);
-    }
-    const int hn = n >> 1;
-    for (int k = lane; k < n * hn; k += 64) {                         // two sample pairs per lane: Cb0 Cr0 Cb1 Cr1
-        const int y = k / hn, xq = k - y * hn;
-        uint32_t *p = (uint32_t *)(dst + pp.chroma_offset + (size_t)(tb.y + y) * pp.pitch + 2 * (tb.x + 2 * xq));
-        const uint32_t v = *p;
-        const int o = y * n + 2 * xq;
-        const int b0 = rb ? rb[o] : 0, b1 = rb ? rb[o + 1] : 0, c0 = rr2 ? rr2[o] : 0, c1 = rr2 ? rr2[o + 1] : 0;
-        *p = (uint32_t)clip1((int)(v & 255) + b0) | (uint32_t)clip1((int)(v >> 8 & 255) + c0) << 8 | (uint32_t)clip1((int)(v >> 16 & 255) + b1) << 16 |
-             (uint32_t)clip1((int)(v >> 24) + c1) << 24;
+        // chroma (blocks of at most 16x16: the upper halves of the wave's buffers hold the partner's block)
+        const uint32_t *rb = tb.plane == 1 ? r : nullptr, *rr2 = tb.plane == 2 ? r : nullptr;
+        if (tb.plane == 1 && job + 1 < pp.n_tbs) {
+            const HevcTb nx = pp.tbs[job + 1];
+            if (nx.plane == 2 && same_place(tb, nx))
+                rr2 = residual_block(pp.coefs + nx.coef_off, (int)nx.coef_n, nx.log2, nx.flags, dp + kResidBufDw / 2, g + kResidBufDw / 2, sm.mp, lane);
+        }
+        for (int k = lane; k < (n << (tb.log2 - 1)); k += 64) {       // two sample pairs per lane: Cb0 Cr0 Cb1 Cr1
+            const int y = k >> (tb.log2 - 1), xq = k & (hn - 1);
+            uint32_t *p = (uint32_t *)(dst + pp.chroma_offset + (size_t)(tb.y + y) * pp.pitch + 2 * (tb.x + 2 * xq));
+            const uint32_t b = rb ? rb[y * hn + xq] : 0u, c = rr2 ? rr2[y * hn + xq] : 0u;
+            *p = pk::add_residual4(*p, pk::perm(c, b, 0x05040100u), pk::perm(c, b, 0x07060302u));
+        }
     }
 }
 
 // residual of the intra blocks, computed ahead of the (sequential) intra pass: it does not depend on the prediction.  Planar int16
 // scratch: Y (w x h), Cb, Cr.
-__global__ __launch_bounds__(64) void k_hevc_iresid(const HevcPicParams *pics) {
+__global__ __launch_bounds__(64 * kResidWaves) void k_hevc_iresid(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & HPS_INTRA) || (int)blockIdx.x >= pp.n_itbs) return;
-    const HevcIntraTb tb = pp.itbs[blockIdx.x];
-    if (!tb.coef_n) return;
-    __shared__ int16_t d[32 * 32], res[32 * 32];
-    __shared__ __align__(16) int8_t tm[32 * 32];
-    __shared__ int ext[2];
-    const int lane = threadIdx.x, n = 1 << tb.log2;
-    load_transform_matrix(tm, tb.log2, lane, 64);
-    const int16_t *r = residual_block<false>(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, d, res, tm, ext, lane, 64);
-    const int pw = tb.plane ? pp.w >> 1 : pp.w;
-    int16_t *dst = pp.resid + (tb.plane == 0 ? 0 : (size_t)pp.w * pp.h + (tb.plane == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
-    for (int k = lane; k < n * n; k += 64) dst[(size_t)(tb.y + (k >> tb.log2)) * pw + tb.x + (k & (n - 1))] = r[k];
+    if (!(pp.stages & HPS_INTRA) || (int)blockIdx.x * (kResidWaves * kResidPerWave) >= pp.n_itbs) return;
+    __shared__ HevcResidLds sm;
+    for (int k = threadIdx.x; k < hrp::kPairDw; k += 64 * kResidWaves) sm.mp[k] = g_resid_pairs[k];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int first = ((int)blockIdx.x * kResidWaves + wave) * kResidPerWave;
+    for (int job = first; job < first + kResidPerWave && job < pp.n_itbs; job++) {
+        const HevcIntraTb tb = pp.itbs[job];
+        if (!tb.coef_n) continue;
+        const int n = 1 << tb.log2, hn = n >> 1;
+        const uint32_t *r = residual_block(pp.coefs + tb.coef_off, (int)tb.coef_n, tb.log2, tb.flags, sm.dp[wave], sm.g[wave], sm.mp, lane);
+        const int pw = tb.plane ? pp.w >> 1 : pp.w;
+        int16_t *dst = pp.resid + (tb.plane == 0 ? 0 : (size_t)pp.w * pp.h + (tb.plane == 2 ? (size_t)(pp.w >> 1) * (pp.h >> 1) : 0));
+        // (block positions are multiples of 4 and plane widths even: a pair of samples is an aligned dword of the scratch)
+        for (int k = lane; k < (n << (tb.log2 - 1)); k += 64) { const int y = k >> (tb.log2 - 1), xp = k & (hn - 1);
+            *(uint32_t *)(dst + (size_t)(tb.y + y) * pw + tb.x + 2 * xp) = r[k]; }
+    }
 }
 
 // sum of v over the 64 lanes of the wave, as a wave-uniform value: four DPP adds give every lane the total of its row of 16, four v_readlane add the rows
@@ -993,11 +1002,22 @@ static void upload_tables() {
     static bool done[64] = {false};
     int dev = 0; hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || done[dev]) return;
-    hipMemcpyToSymbol(HIP_SYMBOL(c_trans), hevc_trans, sizeof c_trans); hipMemcpyToSymbol(HIP_SYMBOL(c_dst), hevc_dst, sizeof c_dst);
     hipMemcpyToSymbol(HIP_SYMBOL(c_lf), hevc_luma_filter, sizeof c_lf); hipMemcpyToSymbol(HIP_SYMBOL(c_cf), hevc_chroma_filter, sizeof c_cf);
     hipMemcpyToSymbol(HIP_SYMBOL(c_angle), hevc_intra_angle, sizeof c_angle); hipMemcpyToSymbol(HIP_SYMBOL(c_inv_angle), hevc_inv_angle, sizeof c_inv_angle);
     hipMemcpyToSymbol(HIP_SYMBOL(c_beta), hevc_beta_tab, sizeof c_beta); hipMemcpyToSymbol(HIP_SYMBOL(c_tc), hevc_tc_tab, sizeof c_tc);
     hipMemcpyToSymbol(HIP_SYMBOL(c_qpc), hevc_qpc_tab, sizeof c_qpc);
+    {   // the transform matrices as 16-bit pairs (hevc_resid_packed.h)
+        static uint32_t mp[hrp::kPairDw];
+        hrp::build_pair_table(hevc_trans, hevc_dst, mp);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_resid_pairs), mp, sizeof mp);
+    }
+    {   // the interpolation taps in the forms hevc_mc_packed.h works with
+        uint32_t lh[4][2], lv[4][2][5], ch[8], cv[8][2][3];
+        for (int f = 0; f < 4; f++) { hpk::luma_taps_h(f, lh[f][0], lh[f][1]); hpk::luma_taps_v(f, false, lv[f][0]); hpk::luma_taps_v(f, true, lv[f][1]); }
+        for (int f = 0; f < 8; f++) { ch[f] = hpk::chroma_taps_h(f); hpk::chroma_taps_v(f, false, cv[f][0]); hpk::chroma_taps_v(f, true, cv[f][1]); }
+        hipMemcpyToSymbol(HIP_SYMBOL(c_lh), lh, sizeof lh); hipMemcpyToSymbol(HIP_SYMBOL(c_lv), lv, sizeof lv);
+        hipMemcpyToSymbol(HIP_SYMBOL(c_ch), ch, sizeof ch); hipMemcpyToSymbol(HIP_SYMBOL(c_cv), cv, sizeof cv);
+    }
     done[dev] = true;
 }
 void hevc_kernels_init() { upload_tables(); }
@@ -1005,9 +1025,10 @@ void hevc_kernels_init() { upload_tables(); }
 void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBatchDims &m, int *progress, hipStream_t st, hipEvent_t *marks) {
     upload_tables();
     if (marks) hipEventRecord(marks[0], st);
-    if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3((m.max_pus + 7) & ~7, n), dim3(64), 0, st, d_pics);
-    if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3((m.max_tbs + 7) & ~7, n), dim3(64), 0, st, d_pics);
-    if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3(m.max_itbs, n), dim3(64), 0, st, d_pics);
+    if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3(((m.max_pus + kMcWaves - 1) / kMcWaves + 7) & ~7, n), dim3(64 * kMcWaves), 0, st, d_pics);
+    constexpr int per_wg = kResidWaves * kResidPerWave;
+    if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3(((m.max_tbs + per_wg - 1) / per_wg + 7) & ~7, n), dim3(64 * kResidWaves), 0, st, d_pics);
+    if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3((m.max_itbs + per_wg - 1) / per_wg, n), dim3(64 * kResidWaves), 0, st, d_pics);
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
         hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kHevcProgressStride, st);

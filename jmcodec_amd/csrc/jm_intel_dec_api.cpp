@@ -5,9 +5,12 @@
 //   input_data   = jm_amddec_push_data (the whole chunk is parsed and dispatched at once; a frame the caller has not fetched yet stays current);
 //   output_frame = take the next finished display frame and let the decoder put it into the CALLER'S buffer with its one copy-engine transfer --
 //                  one copy per frame, the same as jm_nvdec_output_frame (round 5 had three: device -> a scratch buffer -> a fresh vector -> the caller);
-//   need_more_data turns false while kFramesHigh display frames wait for the caller, so a caller following test_intel_dec.cpp:78-102 (one
-//                  output_frame per loop turn, up to free_buf_len bytes of input per turn) cannot run ahead of its own consumption; while it is held
-//                  off, output_frame sleeps up to kWaitUs for the frame that is on its way instead of returning -1 into a spinning loop.
+//   need_more_data is true while the decoder runs low on work -- fewer than kPicturesLow pictures on their way through parse and device -- and fewer than
+//                  kFramesHigh display frames wait for the caller: a caller following test_intel_dec.cpp:78-102 (one output_frame per loop turn, up to
+//                  free_buf_len bytes of input per turn -- some 45 pictures of the 1080p C1 stream) keeps the pipeline fed without running far ahead of its
+//                  own consumption; while it is held off, output_frame sleeps up to kWaitUs for the frame that is on its way instead of returning -1 into a
+//                  spinning loop.  (A first version looked at the waiting frames only, 16 of them: the caller then pushed when its OUTPUT ran low, which is
+//                  when the pipeline had long run dry -- 0.80 of the NAL-per-call rate.)
 #include "../../include/jm_amd_dec.h"
 #include "../../include/jm_amd_intel_dec.h"
 #include <mutex>
@@ -18,7 +21,8 @@
 
 namespace {
 constexpr int kInputChunk = 1 << 20;      // what free_buf_len reports (the reference's buffer starts at 1 MB, intel_dec.h)
-constexpr long long kFramesHigh = 16;     // display frames waiting for the caller before input is held off (two chain launches of 8 pictures)
+constexpr long long kFramesHigh = 64;     // display frames waiting for the caller: more than that and input is held off whatever the pipeline holds
+constexpr long long kPicturesLow = 24;    // pictures on their way (parse, engine, device): fewer than that and the decoder wants input
 constexpr int kWaitUs = 2000;             // longest sleep of output_frame for a frame that is being decoded, while input is held off
 struct Ctx {
     jm_amddec_handle dec = nullptr;
@@ -28,7 +32,7 @@ struct Ctx {
     bool eof = false, inited = false;
     bool have = false;                    // the decoder holds a current frame that nobody fetched yet
     long long waiting() { return jm_amddec_get_stat(dec, "frames_waiting") + (have ? 1 : 0); }
-    bool held_off() { return !cb && waiting() >= kFramesHigh; }
+    bool held_off() { return !cb && (waiting() >= kFramesHigh || jm_amddec_get_stat(dec, "pictures_in_flight") >= kPicturesLow); }
     // make the next finished display frame current (m held).  After set_eof the decoder drains: it blocks until the next frame is there or none is left.
     bool take(int wait_us) {
         if (have || !inited) return have;

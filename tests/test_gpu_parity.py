@@ -389,45 +389,12 @@ def test_intel_push_pull_api(oracle):
     """jm_intel_dec_* facade driven like test_intel_dec.cpp:78-102: push chunks while need_more_data, pull frames,
     set_eof, run until is_exit.  Frames must equal the oracle's, in display order; then the same through the YUV callback."""
     from util import B_CASES
-    L = jmcodec_amd.lib()
-    vp = C.c_void_p
-    L.jm_amdintel_create_handle.restype = vp
-    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int),
-        vp]),
-                   ("set_eof", [C.c_int, vp]), ("need_more_data", [vp]), ("free_buf_len", [vp]), ("is_exit", [vp]), ("info", [vp]),
-                   ("set_yuv_callback", [vp, vp, vp])):
-        getattr(L, "jm_amdintel_" + fn).argtypes = at
-    L.jm_amdintel_info.restype = C.c_char_p
     data = streams.generate(**B_CASES["b_fuzz_cabac_high"])
     want, n, w, h = oracle.decode(data, 1)
-    fs = w * h * 3 // 2
     for use_cb in (False, True):
-        got = []
-        CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_ubyte), C.c_int, vp)
-        cb = CB(lambda p, ln, u: got.append(C.string_at(p, ln)) or 0)
-        hd = L.jm_amdintel_create_handle()
-        assert L.jm_amdintel_init(0, 1, hd) == 0
-        if use_cb:
-            L.jm_amdintel_set_yuv_callback(None, C.cast(cb, vp), hd)
-        out = C.create_string_buffer(fs)
-        pos, eof, guard = 0, False, 0
-        while not L.jm_amdintel_is_exit(hd):
-            guard += 1
-            assert guard < 100000
-            if L.jm_amdintel_need_more_data(hd) and not eof:
-                k = min(L.jm_amdintel_free_buf_len(hd), 777, len(data) - pos)
-                if k == 0:
-                    eof = True
-                    L.jm_amdintel_set_eof(1, hd)
-                else:
-                    assert L.jm_amdintel_input_data(data[pos:pos + k], k, hd) == k
-                    pos += k
-            ln = C.c_int(fs)
-            if L.jm_amdintel_output_frame(out, C.byref(ln), hd) == 0:
-                assert not use_cb
-                got.append(out.raw[:ln.value])
-        assert b"Frame Count:\t%d" % n in L.jm_amdintel_info(hd)
-        L.jm_amdintel_deinit(hd)
+        got, info, sinfo, biggest = api.intel_push_pull(data, callback=use_cb, max_push=777)      # arbitrary small chunks: NAL units cut anywhere
+        assert biggest == 777 and sinfo[:3] == (0, w, h)
+        assert "Frame Count:\t%d" % n in info
         assert len(got) == n
         assert b"".join(got) == want
 

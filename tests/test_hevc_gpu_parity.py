@@ -97,36 +97,11 @@ def test_corrupt_hevc_streams_do_not_hang():
 
 def test_hevc_through_the_intel_push_pull_api_and_hvcc(oracle):
     """jm_intel_dec_init(1, ...) (codec enum jm_intel_dec.h:33) over the same engine, fed in arbitrary chunks; and hvcC + length-prefixed packets"""
-    import ctypes as C
-    L = jmcodec_amd.lib()
-    vp = C.c_void_p
-    L.jm_amdintel_create_handle.restype = vp
-    for fn, at in (("init", [C.c_int, C.c_int, vp]), ("deinit", [vp]), ("input_data", [C.c_char_p, C.c_int, vp]), ("output_frame", [vp, C.POINTER(C.c_int),
-        vp]),
-                   ("set_eof", [C.c_int, vp]), ("need_more_data", [vp]), ("free_buf_len", [vp]), ("is_exit", [vp])):
-        getattr(L, "jm_amdintel_" + fn).argtypes = at
+    from jmcodec_amd import api
     data = streams.generate_hevc(**HEVC_CASES["b_gop8"])
     want, n, w, h = oracle.decode(data, 1)
-    fs = w * h * 3 // 2
-    hd = L.jm_amdintel_create_handle()
-    assert L.jm_amdintel_init(1, 1, hd) == 0
-    out = C.create_string_buffer(fs)
-    got, pos, eof, guard = [], 0, False, 0
-    while not L.jm_amdintel_is_exit(hd):
-        guard += 1
-        assert guard < 100000
-        if L.jm_amdintel_need_more_data(hd) and not eof:
-            k = min(L.jm_amdintel_free_buf_len(hd), 1500, len(data) - pos)
-            if k == 0:
-                eof = True
-                L.jm_amdintel_set_eof(1, hd)
-            else:
-                assert L.jm_amdintel_input_data(data[pos:pos + k], k, hd) == k
-                pos += k
-        ln = C.c_int(fs)
-        if L.jm_amdintel_output_frame(out, C.byref(ln), hd) == 0:
-            got.append(out.raw[:ln.value])
-    L.jm_amdintel_deinit(hd)
+    got, info, sinfo, biggest = api.intel_push_pull(data, codec_type=1, max_push=1500)      # the reference loop in pushes of at most 1,500 bytes
+    assert biggest == 1500 and sinfo[:3] == (0, w, h)
     assert len(got) == n and b"".join(got) == want
     from jmcodec_amd import api
     rec, packets = api.annexb_to_hvcc(data)
