@@ -57,7 +57,9 @@ int  jm_amddec_is_hw_support(void);
  *       "digest" (1 = accumulate the macroblock syntax digest; implies sync),
  *       "display_delay" (n: a frame is handed out only while n pictures of the handle are still on their way -- the reference's ulMaxDisplayDelay,
  *       nv_dec.cpp:341; default 0), "profile" (1 = time the kernels with events), "wait_idle" (block until every dispatched picture has run),
- *       engine-wide after init: "chain_depth", "chain_lag", "chain_streams", "debug_stall" (DESIGN.md 4a);
+ *       engine-wide after init: "chain_depth" (pictures of one stream per chain launch; 0 = the defaults: 8, and 16 while one or two streams are active),
+ *       "chain_lag", "chain_streams", "debug_stall" (DESIGN.md 4b); before init: "job_slots" (pictures in flight per handle, 8..64; default 40 for H.264 up
+ *       to 1080p, else 24);
  *       tests only: "fast_parse" (0 = every macroblock through the general parser path), "job_digest" (1 = digest of the job lists; implies sync) */
 /* like jm_amddec_decode_frame without input: *got_frame = 1 when a display-order frame became ready (never signals end of stream) */
 int  jm_amddec_poll_frame(int *got_frame, jm_amddec_handle h);
@@ -66,6 +68,10 @@ int  jm_amddec_wait_frame(int *got_frame, int timeout_us, jm_amddec_handle h);
 /* input without taking a frame: the push half of the reference's push / pull API (intel_dec_put_input_data, /root/reference/intel_dec/intel_dec.cpp:189-234).
  * The frame signalled by an earlier got_frame = 1 stays current until the next jm_amddec_decode_frame / jm_amddec_poll_frame call.  0, or -1 on error. */
 int  jm_amddec_push_data(unsigned char *in_buf, int in_data_len, jm_amddec_handle h);
+/* end of stream without taking a frame (what jm_amddec_decode_frame(NULL, 0) does before it hands out a frame); drain with jm_amddec_decode_frame(NULL, 0)
+ * afterwards.  jm_amddec_push_data / jm_amddec_push_eos may run on another thread than jm_amddec_poll_frame / _wait_frame / _output_frame: the facade of
+ * the push / pull API feeds from a worker thread, as the reference's does (intel_dec.cpp:46-81) */
+int  jm_amddec_push_eos(jm_amddec_handle h);
 int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
 /* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
  *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",

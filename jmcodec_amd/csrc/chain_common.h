@@ -53,7 +53,7 @@ constexpr int kChainTail = kChainTailHead + 4 * kChainMaxPics;
 // words of the tail head: [0] abort, [1..7] census (ChainView), [8] give-ups, [9..14] record of the first give-up (record_first_giveup),
 // [15] wait limit of this launch in 100 MHz ticks (written by the host, Engine::launch; 0 = kWaitTicks), [16..21] second half of the record:
 // what an atomic read-modify-write of the counter returned when the wait gave up (the value at the point of coherence, beside what the polls saw), the waiter's
-// XCC_ID and HW_ID1 registers, its number of looks, the clock gaps its timer had skipped and the largest of them
+// XCC_ID and HW_ID1 registers, its number of looks, the clock gaps its timer had skipped and the largest of them; [22..23] census of the reference windows
 constexpr int kTailWaitLimit = 15, kTailRmw = 16, kTailXcc = 17, kTailHwId = 18, kTailSpins = 19, kTailGaps = 20, kTailGapMax = 21;
 constexpr int kSpinLimit = 1 << 20;    // polls before a wait of the STAGE kernels gives up (about a second; a healthy wait takes microseconds)
 // Waits of a chain launch are bounded by TIME THE WAVE SPENT WAITING, in ticks of the 100 MHz wall clock.  The limit comes with the launch (tail word
@@ -92,7 +92,9 @@ __device__ __forceinline__ void note_gaps(const WaitClock &c, int *evid) {
 }
 enum : int { CHAIN_ERR_FIN_TIMEOUT = 1, CHAIN_ERR_BITS_TIMEOUT = 2, CHAIN_ERR_RING_TIMEOUT = 4, CHAIN_ERR_INTRA_TIMEOUT = 8, CHAIN_ERR_IFIN_TIMEOUT = 16,
                // host side (Engine::recover): the pictures of a timed-out chain launch could not be decoded again from intact references
-               CHAIN_ERR_NOT_RECOVERED = 32 };
+               CHAIN_ERR_NOT_RECOVERED = 32,
+               // a kernel instantiation met a motion record it was compiled without (k_recon_inter<HAS_BI = false> and a two-list record: ADVICE r5)
+               CHAIN_ERR_BAD_RECORD = 64 };
 
 // Steps between a macroblock row and the row below it (round 4).  Clause 8.7 orders the macroblocks in raster order, and within one the vertical edges (V)
 // before the horizontal edges (H). Which filters touch the same samples: V(x, y) the macroblock and columns 12..15 of (x - 1, y); H(x, y) the macroblock and
@@ -238,7 +240,9 @@ struct ChainView {
     // three atomics per workgroup on ONE cache line are 180 k of them in a 2 ms launch of eight streams -- the rate at which a single address saturates
     // -- and a wave's loads retire behind its own older atomics: switched on for every launch they cost 8 / 16 streams 11 % / 9 % of their rate.
     enum : int { CENSUS_RECON_STARTED = 1, CENSUS_RECON_DONE = 2, CENSUS_BAND_STARTED = 3, CENSUS_BAND_DONE = 4, CENSUS_MAX_GROUP = 5,
-                 CENSUS_WAIT_TICKS = 6, CENSUS_RECON_TICKS = 7 };    // 100 MHz ticks wave 0 of the reconstruction workgroups spent in wait_final / in all
+                 CENSUS_WAIT_TICKS = 6, CENSUS_RECON_TICKS = 7,
+                 // reconstruction workgroups that fetched ONE shared reference window for their four macroblocks / whose macroblocks fetched their own (recon_device.h)
+                 CENSUS_QUAD = 22, CENSUS_PRIVATE = 23 };    // 100 MHz ticks wave 0 of the reconstruction workgroups spent in wait_final / in all
     bool census_on = false;
     __device__ __forceinline__ void census(int what, int value = 1) const {
         if (!census_on || threadIdx.x != 0) return;

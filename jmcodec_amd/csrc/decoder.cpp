@@ -224,6 +224,8 @@ long long Decoder::get_stat(const char *key) const {
         if (k == "eng_launch_ns") return es.launch_ns;
         if (k == "eng_wait_gap_launches") return es.wait_gap_launches;
         if (k == "eng_wait_gap_max_us") return es.wait_gap_max_ticks / 100;
+        if (k == "eng_quad_windows") return es.quad_windows;
+        if (k == "eng_private_windows") return es.private_windows;
         if (k == "eng_rej_other_lane") return es.rej_other_lane;
         if (k == "eng_rej_cross_lane") return es.rej_cross_lane;
         if (k == "eng_rej_tables") return es.rej_tables;
@@ -637,11 +639,9 @@ bool Decoder::activate(const SeqParams &sps) {
         if (gpu_open_) {
             hipSetDevice(device_);
             free_surfaces();
-                    if (resid_) { hipFree(resid_); resid_ = nullptr; }
-                    for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
-    if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
-    for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
-    if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
+            if (resid_) { hipFree(resid_); resid_ = nullptr; }
+            for (auto &w : hevc_work_) if (w) { hipFree(w); w = nullptr; }
+            if (hevc_bs_) { hipFree(hevc_bs_); hevc_bs_ = nullptr; }
             free_job_buffers();
             free_out_slots(false);
         } else free_job_buffers();
@@ -1544,7 +1544,8 @@ void Decoder::submit_task(PicTask *t) {
 // The picture may be damaged; that is reported, never silent.
 void Decoder::on_device_wait_error(int code) {
     stat_errors_++; stat_wait_errors_++;
-    note_error("device: a wait between workgroups timed out (code " + std::to_string(code) + "): the picture may be damaged");
+    if (code & 64) note_error("device: a kernel met a motion record it was compiled without (code " + std::to_string(code) + "): the picture is damaged");
+    else note_error("device: a wait between workgroups timed out (code " + std::to_string(code) + "): the picture may be damaged");
 }
 
 // called by the engine thread when the batch containing this picture has finished on the device
@@ -1606,6 +1607,14 @@ int Decoder::poll(int *got_frame, int wait_us) {
 int Decoder::push(const uint8_t *buf, int len) {
     if (!inited_ || failed_ || !buf || len <= 0) return -1;
     if (!eos_sent_ && !eof_flag_) feed(buf, (size_t)len);
+    return failed_ ? -1 : 0;
+}
+
+// End of stream without taking a frame (the push / pull facade's feeder thread): what decode(NULL, 0) does before it pops.  The caller then drains with
+// decode(NULL, 0), which finds the end already sent.
+int Decoder::push_eos() {
+    if (!inited_ || failed_) return -1;
+    if (!eos_sent_) { flush_stream(); eos_sent_ = true; }
     return failed_ ? -1 : 0;
 }
 

@@ -129,6 +129,7 @@ public:
     int  decode(const uint8_t *buf, int len, int *got_frame);
     int  poll(int *got_frame, int wait_us = 0); // pop a finished display frame without feeding input (wait_us > 0: wait that long for one that is on its way)
     int  push(const uint8_t *buf, int len);    // feed input without popping a frame (the current frame stays current)
+    int  push_eos();                           // end of stream without popping a frame
     int  output(uint8_t *out, int *out_len);
     int  output_device(void **dev, int *len);
     int  output_argb_device(void *dev_dst, int pitch);
@@ -264,7 +265,8 @@ private:
     bool gpu_open_ = false;
 
     // status / stats
-    bool eof_flag_ = false, eos_sent_ = false, is_exit_ = false;
+    bool eof_flag_ = false, is_exit_ = false;
+    std::atomic<bool> eos_sent_{false};        // (set by the thread that feeds, read by the thread that takes frames: jm_amddec_push_eos)
     uint32_t num_frames_ = 0;
     std::chrono::steady_clock::time_point t0_; bool timer_started_ = false; double elapsed_ms_ = 0;
     char info_[1024];

@@ -46,6 +46,7 @@ void mem_trace(const char *tag) {
 }
 
 Engine::Engine(int device) : device_(device) {
+    (void)trace_ms();                                 // (the diagnostic clock starts with the first engine)
     mem_trace("engine: start");
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_DEPTH")) { chain_depth_ = std::max(1, std::min(atoi(e), 16)); chain_depth_few_ = chain_depth_.load(); }
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_STREAMS")) chain_max_streams_ = std::max(0, atoi(e));
@@ -88,6 +89,21 @@ Engine::Engine(int device) : device_(device) {
         }
     }
     mem_trace("engine: lane buffers");
+    // Every stream gets its hardware queue NOW (the runtime creates a queue when a stream is first used).  Creating a queue makes the kernel driver rebuild the
+    // process's run list, and for that it takes every running queue off the device and puts it back -- waves and all: 24-33 ms during which a chain launch
+    // stands still (seen as clock gaps by its waits, once per process in a quarter of the soak runs: profiles/r06_chain_soak.txt).  With the old wall-clock
+    // timers a few of those inside one wait were a give-up.  JM_AMD_DEC_LAZY_QUEUES=1 keeps the old behaviour (A/B).
+    if (!getenv("JM_AMD_DEC_LAZY_QUEUES")) {
+        int *d_word = nullptr;
+        if (hipMalloc((void **)&d_word, 256) == hipSuccess) {
+            hipMemsetAsync(d_word, 0, 4, copy_stream_);
+            for (auto &ln : lanes_) { hipMemsetAsync(d_word + 4, 0, 4, ln.stream); hipMemsetAsync(d_word + 8, 0, 4, ln.pack_stream);
+                hipMemsetAsync(d_word + 12, 0, 4, ln.pre_stream); }
+            hipDeviceSynchronize();
+            hipFree(d_word);
+        }
+        (void)hipGetLastError();
+    }
     // The no-deadlock argument of a chain launch (chain.hip) needs its band workgroups -- resident for their whole wavefront -- to leave room for the
     // reconstruction groups they wait for: at most half of what the device holds.  Taken from the device in use (a compute partition, a smaller part
     // or a build with other register counts holds fewer than the constants assume); launches whose first pictures do not fit run unchained.
@@ -133,7 +149,8 @@ void Engine::submit(EnginePic &&p) {
 bool Engine::set_knob(const std::string &key, long long v) {
     // an explicit setting ends the pause that follows a recovered chain launch, and has the next batch look again whether the GPU is shared
     if (key.rfind("chain_", 0) == 0) { chain_block_until_ns_ = 0; shared_checked_ns_ = 0; }
-    if (key == "chain_depth") { chain_depth_ = (int)std::max(1ll, std::min(v, 16ll)); chain_depth_few_ = chain_depth_.load(); }
+    if (key == "chain_depth") { if (v <= 0) { chain_depth_ = 8; chain_depth_few_ = 16; }      // 0: the defaults (8; 16 with one or two active streams)
+        else { chain_depth_ = (int)std::min(v, 16ll); chain_depth_few_ = chain_depth_.load(); } }
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max((long long)kMinChainLag, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
     else if (key == "debug_stall") debug_stall_ = (int)v;
@@ -270,7 +287,6 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         early_scan_ns_ = now_ns;
         const unsigned long long tag = ++early_scan_tag_;
         std::vector<std::deque<EnginePic>::iterator> cand;
-        bool near_turn = false;
         for (auto it = pending_.begin(); it != pending_.end(); ++it) {
             Decoder *d = it->dec;
             EngineDecoderState &es = d->engine_state();
@@ -286,14 +302,18 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 //  the lane's stream wait for its upload, and with it every other picture of the batch.  In-order pictures were uploaded twenty pictures ago)
                 const bool landed = !it->uploaded || hipEventQuery(it->uploaded) == hipSuccess;
                 if (!landed) (void)hipGetLastError();
-                if (landed && !(own & (es.scan_touched | infl))) { cand.push_back(it); near_turn |= es.scan_ahead <= 8; }
+                // ... and only a picture that is still far from its turn: that is the case when the ENGINE is what its stream waits for (some twenty
+                // pictures pending per decoder), and then an early launch saves the stream its stall.  With shallow queues (host- or PCIe-bound
+                // callers) the picture would go a batch or two early at best, in more and smaller intra batches than its turn would have formed:
+                // measured -2 % on the host-output headline (profiles/r06_lane_fill.txt), so those take their turn as before
+                if (landed && es.scan_ahead >= kEarlyIntraAhead && !(own & (es.scan_touched | infl))) cand.push_back(it);
             }
             es.scan_touched |= it->ref_mask | it->out_mask | own;
             es.scan_ahead++;
         }
-        // an intra batch costs the lane the same 1.8 ms whatever it holds, and its kernels run beside the ordinary lane's: few, full batches.  The pictures
-        // found go now when there are enough of them, or when one of them is about to have its turn anyway; else they wait for company
-        if ((int)cand.size() >= 4 || near_turn || !b.pics.empty()) {      // (or a batch is formed anyway: they go along)
+        // (an intra batch costs the lane the same 1.8 ms whatever it holds: the lane takes one batch at a time while this is on, Engine::run, so whatever
+        //  became ready while the previous one ran goes together)
+        if (!cand.empty()) {
             // (taken back to front, by position: erasing from a deque invalidates iterators)
             std::vector<size_t> pos;
             for (auto &c : cand) pos.push_back((size_t)(c - pending_.begin()));
@@ -508,7 +528,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     }
     b.any_bipred = b.any_field = false;
     for (auto &p : b.pics) { b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred; b.any_field |= p.has_picture && p.codec == 0 && p.pp.field != 0; }
-    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, b.any_field, st); b.pmask |= 2; }
+    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, b.any_field, b.d_err, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
@@ -661,7 +681,7 @@ void Engine::recover(Lane &ln, Batch &b, const std::vector<std::pair<Decoder *, 
         if (!stages) continue;
         hipMemsetAsync(b.d_ctl, 0, sizeof(int) * (size_t)n * chain_ctl_ints(), st);
         hipMemcpyAsync(b.d_pics, b.h_pics, sizeof(PicParams) * n, hipMemcpyHostToDevice, st);
-        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, b.any_field, st);
+        if (stages & PS_RECON) launch_recon_inter(b.d_pics, n, b.max_mbs, b.any_bipred, b.any_field, b.d_err, st);
         if (stages & PS_INTRA_LDS) launch_intra_lds(b.d_pics, n, b.max_mb_h, b.d_ctl, b.d_err, st);
         if (stages & PS_INTRA_V1) launch_recon_intra(b.d_pics, n, st);
         if (stages & PS_DEBLOCK_LDS) { launch_deblock_prep(b.d_pics, n, b.max_mbs, st);
@@ -793,9 +813,16 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
     // clock gaps the launch's waits saw (chain_common.h WaitClock): time its waves were not run -- evidence, counted per launch
     if (b.h_err[kMaxBatch]) { std::lock_guard<std::mutex> lk(sm_); st_.wait_gap_launches++; st_.wait_gap_max_ticks = std::max(st_.wait_gap_max_ticks,
         (long long)(unsigned)b.h_err[kMaxBatch + 1]);
-        if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: a chain launch's waits saw %d clock gap(s), the longest %.2f ms: its waves were not run meanwhile\n",
-            b.h_err[kMaxBatch], (unsigned)b.h_err[kMaxBatch + 1] * 1e-5);
+        if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: a chain launch's waits saw %d clock gap(s), the longest %.2f ms: its waves were not run meanwhile "
+            "(chain launch %lld of this process, batch %llu of its lane, %.1f ms after the engine's first trace point)\n",
+            b.h_err[kMaxBatch], (unsigned)b.h_err[kMaxBatch + 1] * 1e-5, st_.chain_batches + 1, b.serial, trace_ms());
         b.h_err[kMaxBatch] = b.h_err[kMaxBatch + 1] = 0; }
+    // diagnostic launches (JM_AMD_DEC_CENSUS): how many reconstruction workgroups shared one reference window (tests: the quad path really ran)
+    if (b.any_chain && !failed) { static const bool census = getenv("JM_AMD_DEC_CENSUS") != nullptr;
+        if (census) { int tail[32];
+            if (hipMemcpy(tail, b.d_ctl + (size_t)kMaxBatch * chain_ctl_ints(), sizeof tail, hipMemcpyDeviceToHost) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(sm_); st_.quad_windows += tail[22]; st_.private_windows += tail[23]; }
+            else (void)hipGetLastError(); } }
     if (b.any_chain && !failed) { std::lock_guard<std::mutex> lk(sm_); st_.chain_batches++; st_.chain_i_batches += b.chain_with_intra;
         for (auto &p : b.pics) st_.chain_pics += p.has_picture && (p.chain_ok || p.chain_intra); }
     { std::lock_guard<std::mutex> lk(m_); const int li = (int)(&ln - lanes_);

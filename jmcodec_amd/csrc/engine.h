@@ -50,6 +50,7 @@ constexpr int kLanes = 4;                           // ordinary, intra-dense H.2
 constexpr int kHevcLane = 2;
 // an I picture's CTB-row wavefront (k_hevc_intra, 2-3 ms at 1080p) would hold up every other stream's P / B batch
 constexpr int kHevcIntraLane = 3;
+constexpr int kEarlyIntraAhead = 10;               // an intra picture runs ahead of its turn only with at least this many earlier pictures of its stream pending
 
 struct EnginePic {
     Decoder *dec = nullptr;
@@ -92,6 +93,7 @@ struct EngineStats {
     // I picture); it is an ordinary picture but the decoder still has pictures on another lane; the pack-job tables were full
     long long rej_other_lane = 0, rej_cross_lane = 0, rej_tables = 0;
     long long wait_gap_launches = 0, wait_gap_max_ticks = 0;   // chain launches whose waits saw the clock jump (their waves were not run meanwhile), longest jump
+    long long quad_windows = 0, private_windows = 0;   // JM_AMD_DEC_CENSUS: reconstruction workgroups of chain launches with one shared / four private reference windows
     long long early_intra = 0;                     // intra pictures launched ahead of their stream's earlier pictures (Engine::form)
     long long blocked_ns = 0, blocked_n = 0;       // time decoders spent left out of ordinary batches between two of their pictures joining one, and how often
     // per lane, from the profile events: time between a batch's first and last kernel, time its stream sat idle before it, batches and pictures

@@ -64,14 +64,14 @@ __device__ __forceinline__ int mc_fill_tile(const uint8_t *plane, int pitch, int
         const int sh = x0b & 3, ndw = (sh + row_bytes + 3) >> 2;          // <= 7
         const uint8_t *base = plane + (size_t)y0 * pitch + (x0b & ~3);
         for (int k = lane; k < th * 8; k += 64) { const int r = k >> 3, d = k & 7;
-            if (d < ndw) tile[r * kMcRowDw + d] = *(const uint32_t *)(base + (size_t)r * pitch + 4 * d) ^ 0x80808080u; }
+            if (d < ndw) tile[r * kMcRowDw + d] = *(const JM_GLOBAL_AS uint32_t *)(base + (size_t)r * pitch + 4 * d) ^ 0x80808080u; }
         return sh;
     }
     // border: byte-wise, coordinates clamped per sample (chroma: per CbCr pair, step 2)
     for (int k = lane; k < th * 8; k += 64) {
         const int r = k >> 3, d = k & 7;
         if (4 * d >= row_bytes) continue;
-        const uint8_t *row = plane + (size_t)clip3(0, ph - 1, y0 + r) * pitch;
+        const JM_GLOBAL_AS uint8_t *row = (const JM_GLOBAL_AS uint8_t *)plane + (size_t)clip3(0, ph - 1, y0 + r) * pitch;
         uint32_t w = 0;
         for (int i = 0; i < 4; i++) { const int xb = x0b + 4 * d + i; const int xs = clip3(0, pw_b - step, xb & ~(step - 1)) + (xb & (step - 1));
             w |= (uint32_t)row[xs] << (8 * i); }
@@ -93,7 +93,7 @@ __device__ __forceinline__ void hevc_mc_luma(const HevcPicParams &pp, const uint
     if (!mine) return;
     uint32_t tp[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) tp[k] = c_lv[yf][my_row & 1][k];
+    for (int k = 0; k < 5; k++) { const uint32_t te = c_lv[yf][0][k], to = c_lv[yf][1][k]; tp[k] = (my_row & 1) ? to : te; }      // (scalar loads + a select)
     hpk::mc_pass2<false>(sm.hcol, my_row, my_q, tp, xf != 0, yf != 0, out);                   // rows my_row .. my_row + 7 of the intermediates, down four columns
 }
 // chroma: this lane's two CbCr pairs (Cb0, Cr0, Cb1, Cr1 of row my_row, pair columns 2 * my_q, 2 * my_q + 1)
@@ -110,7 +110,7 @@ __device__ __forceinline__ void hevc_mc_chroma(const HevcPicParams &pp, const ui
     if (!mine) return;
     uint32_t tp[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) tp[k] = c_cv[yf][my_row & 1][k];
+    for (int k = 0; k < 3; k++) { const uint32_t te = c_cv[yf][0][k], to = c_cv[yf][1][k]; tp[k] = (my_row & 1) ? to : te; }
     hpk::mc_pass2<true>(sm.hcol, my_row, my_q, tp, xf != 0, yf != 0, out);                    // out[i]: byte i of the output dword = Cb0 Cr0 Cb1 Cr1
 }
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * kMcWaves) void k_hevc_mc(const HevcPicParams *
         return clip1(v);
     };
     {   // ---- luma: lane -> (row, dword) ----
-        const int bw = pu.w, bh = pu.h, qw = bw >> 2, my_row = lane / qw, my_q = lane - my_row * qw;
+        const int bw = pu.w, bh = pu.h, qw = bw >> 2, my_row = hpk::div_qw(lane, qw), my_q = lane - my_row * qw;
         const bool mine = lane < bh * qw;
         int p[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int l = 0; l < 2; l++) {
@@ -152,11 +152,11 @@ __global__ __launch_bounds__(64 * kMcWaves) void k_hevc_mc(const HevcPicParams *
             uint32_t w = 0;
             if (!wp) w = both ? hpk::weigh_default4(p[0], p[1], true) : hpk::weigh_default4(pu.slot0 >= 0 ? p[0] : p[1], p[1], false);
             else for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 0) << (8 * i);
-            *(uint32_t *)(dst + (size_t)(pu.y + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
+            *(JM_GLOBAL_AS uint32_t *)(dst + (size_t)(pu.y + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
         }
     }
     {   // ---- chroma, both components: lane -> (row, dword of two CbCr pairs) ----
-        const int bw = pu.w >> 1, bh = pu.h >> 1, qw = bw >> 1, my_row = lane / qw, my_q = lane - my_row * qw;
+        const int bw = pu.w >> 1, bh = pu.h >> 1, qw = bw >> 1, my_row = hpk::div_qw(lane, qw), my_q = lane - my_row * qw;
         const bool mine = lane < bh * qw;
         int p[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int l = 0; l < 2; l++) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * kMcWaves) void k_hevc_mc(const HevcPicParams *
             uint32_t w = 0;
             if (!wp) w = both ? hpk::weigh_default4(p[0], p[1], true) : hpk::weigh_default4(pu.slot0 >= 0 ? p[0] : p[1], p[1], false);
             else for (int i = 0; i < 4; i++) w |= (uint32_t)weigh(p[0][i], p[1][i], 1 + (i & 1)) << (8 * i);
-            *(uint32_t *)(dst + pp.chroma_offset + (size_t)((pu.y >> 1) + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
+            *(JM_GLOBAL_AS uint32_t *)(dst + pp.chroma_offset + (size_t)((pu.y >> 1) + my_row) * pp.pitch + pu.x + 4 * my_q) = w;
         }
     }
 }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * kMcWaves) void k_hevc_mc(const HevcPicParams *
 // Round 6 (hevc_resid_packed.h): one WAVE per transform block, four waves to a workgroup, every wave takes kResidPerWave consecutive blocks of the list; the
 // matrices of all sizes sit in LDS once per workgroup as 16-bit pairs; both stages are v_dot2_i32_i16 sums over the row pairs / column pairs that hold
 // coefficients.  (Until round 5: one 64-thread workgroup per block, the block's matrix copied to LDS per block, byte-wise multiply-adds.)
-constexpr int kResidWaves = 4, kResidPerWave = 8;
+constexpr int kResidWaves = 4, kResidPerWave = 8, kIresidPerWave = 2;
 constexpr int kResidBufDw = 512;                       // one wave's coefficient pairs (16 x 32) / intermediate (32 x 16 dwords)
 __device__ uint32_t g_resid_pairs[hrp::kPairDw];       // hrp::build_pair_table, uploaded once per device
 struct HevcResidLds {
@@ -284,13 +284,14 @@ __global__ __launch_bounds__(64 * kResidWaves) void k_hevc_resid(const HevcPicPa
 // scratch: Y (w x h), Cb, Cr.
 __global__ __launch_bounds__(64 * kResidWaves) void k_hevc_iresid(const HevcPicParams *pics) {
     const HevcPicParams &pp = pics[blockIdx.y];
-    if (!(pp.stages & HPS_INTRA) || (int)blockIdx.x * (kResidWaves * kResidPerWave) >= pp.n_itbs) return;
+    // (kIresidPerWave: an I picture's blocks are few and large -- 10 k per 4K picture -- so fewer per wave than in k_hevc_resid keeps the machine covered)
+    if (!(pp.stages & HPS_INTRA) || (int)blockIdx.x * (kResidWaves * kIresidPerWave) >= pp.n_itbs) return;
     __shared__ HevcResidLds sm;
     for (int k = threadIdx.x; k < hrp::kPairDw; k += 64 * kResidWaves) sm.mp[k] = g_resid_pairs[k];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-    const int first = ((int)blockIdx.x * kResidWaves + wave) * kResidPerWave;
-    for (int job = first; job < first + kResidPerWave && job < pp.n_itbs; job++) {
+    const int first = ((int)blockIdx.x * kResidWaves + wave) * kIresidPerWave;
+    for (int job = first; job < first + kIresidPerWave && job < pp.n_itbs; job++) {
         const HevcIntraTb tb = pp.itbs[job];
         if (!tb.coef_n) continue;
         const int n = 1 << tb.log2, hn = n >> 1;
@@ -1028,7 +1029,8 @@ void launch_hevc_picture_batch(const HevcPicParams *d_pics, int n, const HevcBat
     if (m.max_pus > 0) hipLaunchKernelGGL(k_hevc_mc, dim3(((m.max_pus + kMcWaves - 1) / kMcWaves + 7) & ~7, n), dim3(64 * kMcWaves), 0, st, d_pics);
     constexpr int per_wg = kResidWaves * kResidPerWave;
     if (m.max_tbs > 0) hipLaunchKernelGGL(k_hevc_resid, dim3(((m.max_tbs + per_wg - 1) / per_wg + 7) & ~7, n), dim3(64 * kResidWaves), 0, st, d_pics);
-    if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3((m.max_itbs + per_wg - 1) / per_wg, n), dim3(64 * kResidWaves), 0, st, d_pics);
+    constexpr int iper_wg = kResidWaves * kIresidPerWave;
+    if (m.any_intra && m.max_itbs > 0) hipLaunchKernelGGL(k_hevc_iresid, dim3((m.max_itbs + iper_wg - 1) / iper_wg, n), dim3(64 * kResidWaves), 0, st, d_pics);
     if (marks) hipEventRecord(marks[1], st);
     if (m.any_intra) {
         hipMemsetAsync(progress, 0, sizeof(int) * (size_t)n * kHevcProgressStride, st);

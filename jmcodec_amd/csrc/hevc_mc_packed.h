@@ -117,8 +117,10 @@ constexpr int kMcColDw = 13;                   // column string of the intermedi
 // pass 1: lane -> (row pair, output dword q of the row): rows 2 * rp and 2 * rp + 1 of the window, the four intermediate columns 4 * q .. 4 * q + 3.
 // tile: samples ^ 0x80, rows of kMcRowDw dwords, the window's first sample at byte `sh` of a row; qw: output dwords per row; th: window rows.
 // CHROMA: the row is interleaved Cb Cr and the four columns are Cb Cr Cb Cr of two pairs (ta = the four taps, tb unused)
+// lane / qw for lane < 64 and qw = 1..4 (output dwords per row: blocks are 4, 8, 12 or 16 samples wide) without an integer division (some thirty instructions)
+JM_HD int div_qw(int lane, int qw) { return (lane * (qw == 1 ? 256 : (qw == 2 ? 128 : (qw == 3 ? 86 : 64)))) >> 8; }
 template <bool CHROMA> JM_HD void mc_pass1(const uint32_t *tile, int sh, int qw, int th, int lane, uint32_t ta, uint32_t tb, uint32_t *hcol) {
-    const int rp = lane / qw, q = lane - rp * qw;
+    const int rp = div_qw(lane, qw), q = lane - rp * qw;
     if (rp * 2 >= th) return;
     const uint32_t *r0 = tile + (2 * rp) * kMcRowDw + ((sh + 4 * q) >> 2), *r1 = r0 + kMcRowDw;
     const uint32_t s = (uint32_t)(sh + 4 * q) & 3u;

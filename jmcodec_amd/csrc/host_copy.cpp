@@ -100,8 +100,9 @@ HostCopier *HostCopier::get(int dev) {
                 int good = 0;
                 for (int j = 0; j < 16; j++) { if (t[j] < 1e29 && t[j] <= 1.5 * best) good++; else if (t[j] < 1e29) slower_seen = true; }
                 // three good ones and a slower one seen: stop; after six engines stop as soon as three good ones are known (every engine ever used keeps
-                // a ~190 MB queue) -- but a box whose first six are busy or slow keeps looking until three are found or the list ends
-                if (good >= 3 && (slower_seen || tried >= 6)) break;
+                // a ~190 MB queue) -- a box whose first six are busy or slow keeps looking until three are found, but never past ten engines:
+                // ten queues are 2 GB per device, and a box that has not shown three good engines by then will not
+                if ((good >= 3 && (slower_seen || tried >= 6)) || tried >= 10) break;
             }
         }
         (void)hipGetLastError();
@@ -117,7 +118,7 @@ HostCopier *HostCopier::get(int dev) {
         if (dsrc) (void)hipFree(dsrc);
     }
     if (c->n_engines_ < 3) fprintf(stderr, "jm_amd_dec: device %d: only %d copy engine(s) accepted for the output copies (host output of many streams will be "
-        "slower than the link)\n", dev, c->n_engines_);
+        "slower than the link; engines available 0x%x)\n", dev, c->n_engines_, avail);
     if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr,
         "jm_amd_dec: device %d: output copies on SDMA engines 0x%x 0x%x 0x%x (available 0x%x, host->device preference 0x%x, device->host preference 0x%x)\n",
         dev, c->engines_[0], c->engines_[1], c->engines_[2], avail, h2d, d2h);

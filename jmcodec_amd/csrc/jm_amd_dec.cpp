@@ -64,6 +64,10 @@ __attribute__((visibility("default"))) int jm_amddec_push_data(unsigned char *in
     if (!h) return -1;
     return guarded(h, [&] { return D(h)->push(in_buf, n); });
 }
+__attribute__((visibility("default"))) int jm_amddec_push_eos(jm_amddec_handle h) {
+    if (!h) return -1;
+    return guarded(h, [&] { return D(h)->push_eos(); });
+}
 __attribute__((visibility("default"))) int jm_amddec_output_frame(unsigned char *out, int *out_len, jm_amddec_handle h) {
     if (!h || !out || !out_len) return -1;
     return guarded(h, [&] { return D(h)->output(out, out_len); });

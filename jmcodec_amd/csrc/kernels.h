@@ -6,7 +6,7 @@
 #include "jobs.h"
 
 namespace jmamd {
-void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, bool any_field, hipStream_t st);
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, bool any_field, int *d_err, hipStream_t st);
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st);          // spin-wait wavefront (sparse intra, any height)
 void launch_deblock(const PicParams *d_pics, int n, hipStream_t st);              // spin-wait wavefront (any height)
 bool intra_lds_supported(int mb_w, int mb_h);

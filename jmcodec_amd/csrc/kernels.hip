@@ -24,8 +24,8 @@ namespace jmamd {
 // plumbing (parity bit of a reference entry, chroma vector offset) had taken it to 100, i.e. to four waves: +10 % per picture and most of the round's
 // 3-5 % loss on the default bench (profiles/r04_ab_r2_vs_r3.json: the round-2 library beside round 3's on one box).  Batches without a field picture --
 // all of them in progressive streams -- now run an instantiation compiled without that plumbing (FIELD = false).
-template <bool BIFAST, bool FIELD>
-__global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
+template <bool HAS_BI, bool FIELD>
+__global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics, int *err) {
     const PicParams &pp = pics[blockIdx.y];
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give every XCD one
     // contiguous band of the picture; neighbouring macroblocks, whose reference windows overlap, then share an L2.
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_recon_inter(const PicParams *pics) {
     __shared__ ReconLds sm;
     const int n_mbs = pp.mb_w * pp.mb_h;
     const int mb = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform, and known to be (recon_device.h)
-    recon_inter_wave<false, false, BIFAST, FIELD>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, nullptr});
+    recon_inter_wave<false, false, HAS_BI, FIELD>(pp, mb, mb < n_mbs, sm, ChainView{nullptr, err});      // (err: one word per picture of the batch)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -552,14 +552,14 @@ __global__ __launch_bounds__(256) void k_packout(const PackJob *jobs) {
 // ------------------------------------------------------------------------------------------
 // launchers: d_pics / d_jobs are device arrays of n entries; max_* size the grid for the largest picture
 // ------------------------------------------------------------------------------------------
-void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, bool any_field, hipStream_t st) {
+void launch_recon_inter(const PicParams *d_pics, int n, int max_mbs, bool any_bipred, bool any_field, int *d_err, hipStream_t st) {
     int nblk = ((max_mbs + 3) / 4 + 7) & ~7;              // multiple of 8: the XCD band mapping must be a bijection
     // any_bipred: some picture of the batch has B slices / weighted prediction (two-list motion records): the instantiation with their LDS-window path
     // any_field: some picture of the batch is a field picture (interlaced streams)
-    if (any_field) { if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, true>), dim3(nblk, n), dim3(256), 0, st, d_pics);
-        else hipLaunchKernelGGL((k_recon_inter<false, true>), dim3(nblk, n), dim3(256), 0, st, d_pics); }
-    else if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
-    else hipLaunchKernelGGL((k_recon_inter<false, false>), dim3(nblk, n), dim3(256), 0, st, d_pics);
+    if (any_field) { if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, true>), dim3(nblk, n), dim3(256), 0, st, d_pics, d_err);
+        else hipLaunchKernelGGL((k_recon_inter<false, true>), dim3(nblk, n), dim3(256), 0, st, d_pics, d_err); }
+    else if (any_bipred) hipLaunchKernelGGL((k_recon_inter<true, false>), dim3(nblk, n), dim3(256), 0, st, d_pics, d_err);
+    else hipLaunchKernelGGL((k_recon_inter<false, false>), dim3(nblk, n), dim3(256), 0, st, d_pics, d_err);
 }
 void launch_recon_intra(const PicParams *d_pics, int n, hipStream_t st) { hipLaunchKernelGGL(k_recon_intra, dim3(1, n), dim3(kIntraWaves * 64), 0, st, d_pics);
     }

@@ -250,11 +250,11 @@ struct alignas(16) ReconLds {
 // samples with loads that bypass the non-coherent cache levels, writes its result through to memory and publishes the macroblock in the
 // picture's reconstruction bitmap, on which the deblocking workgroups of this picture wait.
 // COH: the reference loads are the cache-bypassing kind (needed exactly when the picture has references inside the launch, pp.n_deps > 0).
-// BIFAST: macroblocks with two-list / weighted motion records take their luma windows through LDS like P blocks when they can (below).  The stage
+// HAS_BI: macroblocks with two-list / weighted motion records take their luma windows through LDS like P blocks when they can (below).  The stage
 // kernel has an instantiation without it for batches that hold no such picture: the extra code costs 9 VGPRs there (96 -> 105, 5 -> 4 waves per SIMD).
 // FIELD = false: no picture of the launch is a field picture -- a reference entry is a plain surface index and the picture its whole surface (round 4:
 // what the frame-only kernels of round 2 compiled to; k_recon_inter<false> needs its 96 registers for five waves per SIMD, kernels.hip)
-template <bool CHAIN, bool COH, bool BIFAST = true, bool FIELD = true>
+template <bool CHAIN, bool COH, bool HAS_BI = true, bool FIELD = true>
 __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bool valid, ReconLds &sm, const ChainView &cv) {
     // (frame pictures: the surface's address by arithmetic -- q.surf[slot] is a load that depends on the record, one more round trip in front of the window loads)
     auto ref_plane = [&](const PicParams &q, int slot) -> const uint8_t * { return FIELD ? jmamd::ref_plane(q, slot) : q.surf_base + (size_t)slot * q.surf_stride; };
@@ -281,10 +281,13 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     // Everything an ordinary inter macroblock reads from its reference pictures depends only on the record, not on the residual:
     // issue those loads first so that their latency overlaps the coefficient loads and the inverse transform (the kernel is
     // latency bound: SQ_WAIT_ANY was 65 % of SQ_WAVE_CYCLES with the loads issued where they were consumed).
-    // BIFAST = false: NO picture of the launch has two-list / weighted motion records (Engine: any_bipred; the parser sets MBM_BIPRED only in slices that
+    // HAS_BI = false: NO picture of the launch has two-list / weighted motion records (Engine: any_bipred; the parser sets MBM_BIPRED only in slices that
     // have them), so that instantiation is compiled without their code -- round 5: it was the register high-water mark of every instantiation (97 against
     // 70 without it: five waves per SIMD against seven)
-    const bool bipred = BIFAST && inter && (r.modes & MBM_BIPRED);
+    const bool bipred = HAS_BI && inter && (r.modes & MBM_BIPRED);
+    // (an instantiation without the two-list code that meets such a record all the same -- a future producer that breaks the invariant above -- says so
+    //  through the picture's error word instead of decoding the record as a plain one; the picture is then reported as damaged, never silently wrong)
+    if (!HAS_BI && inter && (r.modes & MBM_BIPRED) && cv.err && (threadIdx.x & 63) == 0) report_wait_timeout(cv.err + blockIdx.y, CHAIN_ERR_BAD_RECORD);
     const bool plain = inter && !bipred;
     bool fast = false;
     uint32_t wv[5] = {0, 0, 0, 0, 0};                       // this lane's dwords of the 13x13 reference window (fast path)
@@ -355,6 +358,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         __syncthreads();
         const pk::QuadGeom qg = pk::quad_geometry(sm.vote);
         quad = qg.ok;
+        cv.census(quad ? ChainView::CENSUS_QUAD : ChainView::CENSUS_PRIVATE);      // (diagnostic launches only: JM_AMD_DEC_CENSUS)
         const int x0 = qg.x0, y0 = qg.y0, cx0 = qg.cx0, cy0 = qg.cy0;
         if (quad) {
             // rows wave * 2 + (lane >> 5) + 8 k of the shared window, dword lane & 31 of the row: unconditional loads (clamped), stored where they belong below
@@ -496,7 +500,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         // prediction with direct_8x8_inference) and its 13x13 windows lie inside the picture -- then each list's window goes through LDS exactly like a
         // P block's (5 dword loads per lane instead of up to 36 byte loads per SAMPLE) and the two predictions are combined per sample.
         bool bfast = false;
-        if (BIFAST) {
+        if (HAS_BI) {
             const int g = lane >> 4, rb0 = (g >> 1) * 8 + (g & 1) * 2;
             bool okb = true;
 #pragma unroll
@@ -510,7 +514,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
             }
             bfast = __all(okb);
         }
-        if (BIFAST && bfast) {
+        if (HAS_BI && bfast) {
             const int g = lane >> 4, l16 = lane & 15, rb0 = (g >> 1) * 8 + (g & 1) * 2;
             const int s0 = rec_ref(r, g), s1 = tail[g], i0 = tail[4 + g], i1 = tail[8 + g];
             uint32_t pa = 0, pb = 0;                               // the two predictions of this lane's four samples, one byte each

@@ -690,7 +690,7 @@ def _wait_until_the_gpu_is_ours():
     tiny = streams.generate(width=64, height=48, frames=2, gop=2)
     for _ in range(100):
         with api.JmAmdDec(0, 1) as d:
-            api.lib().jm_amddec_set_option(d.h, b"chain_depth", 8)       # a chain option makes the next batch look again
+            api.lib().jm_amddec_set_option(d.h, b"chain_depth", 0)       # a chain option makes the next batch look again
             d.decode_stream(None, chunks=[tiny])
             if d.stat("eng_gpu_shared") == 0:
                 _GPU_OURS_SEEN.append(True)
@@ -723,7 +723,7 @@ def test_chain_launch_vs_oracle(oracle, name):
             frames = d.decode_stream(None, chunks=[data])
             assert d.stat("errors") == 0 and d.stat("device_wait_errors") == 0
             chained = d.stat("eng_chain_pics") - before
-            lib.jm_amddec_set_option(d.h, b"chain_depth", 8); lib.jm_amddec_set_option(d.h, b"chain_lag", 24)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 0); lib.jm_amddec_set_option(d.h, b"chain_lag", 24)
         assert len(frames) == n
         assert b"".join(frames) == want, f"{name}: depth {depth} lag {lag} differs from the oracle"
         assert chained == 0 or depth > 1, (name, depth, chained)
@@ -764,7 +764,7 @@ def test_damaged_handover_is_reported_not_silent():
             errs, werrs, msg = d.stat("errors"), d.stat("device_wait_errors"), lib.jm_amddec_last_error(d.h).decode()
         finally:
             lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
-            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 0)
     assert len(frames) == 4                       # the pipeline still completes
     assert werrs > 0 and errs >= werrs
     assert "timed out" in msg
@@ -783,7 +783,7 @@ def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
     lib = api.lib()
     ours = _wait_until_the_gpu_is_ours()
     with api.JmAmdDec(0, 1) as d:
-        lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 0)
         lib.jm_amddec_set_option(d.h, b"debug_stall", 2)           # 2 = chain launches only: the stage kernels that redo the pictures work
         before = d.stat("eng_chain_recoveries")
         try:
@@ -791,7 +791,7 @@ def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
             errs, rec = d.stat("errors"), d.stat("eng_chain_recoveries") - before
         finally:
             lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
-            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)     # (also ends the pause of chain launches that follows a recovery)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 0)     # (also ends the pause of chain launches that follows a recovery)
     assert len(frames) == n and b"".join(frames) == want and errs == 0
     assert rec >= 1 or not ours, "debug_stall 2 did not make a chain launch give up on a GPU the engine owns"
     _chains_must_have_formed(ours, "the recovery path")
@@ -810,7 +810,7 @@ def test_recovered_chain_launches_are_never_silently_wrong(oracle, kw):
     lib = api.lib()
     ours = _wait_until_the_gpu_is_ours()
     with api.JmAmdDec(0, 1) as d:
-        lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 0)
         lib.jm_amddec_set_option(d.h, b"debug_stall", 2)
         before = d.stat("eng_chain_recoveries")
         try:
@@ -818,7 +818,7 @@ def test_recovered_chain_launches_are_never_silently_wrong(oracle, kw):
             errs, rec = d.stat("errors"), d.stat("eng_chain_recoveries") - before
         finally:
             lib.jm_amddec_set_option(d.h, b"debug_stall", 0)
-            lib.jm_amddec_set_option(d.h, b"chain_depth", 8)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 0)
     assert len(frames) == n
     wrong = [i for i in range(n) if frames[i] != want[i * fs:(i + 1) * fs]]
     assert not wrong or errs > 0, f"frames {wrong[:8]} differ from the oracle after a recovery and the handle reports no error"
@@ -1017,6 +1017,61 @@ def test_diagnostic_chain_launches_are_bit_exact_and_print_a_time_line(oracle, t
     assert chains >= 1 and shared == 0, r.stdout
     assert r.stderr.count("chain launch of") == chains, r.stderr[-2000:]
     assert "time line picture" in r.stderr and "reconstruction workgroups:" in r.stderr, r.stderr[-2000:]
+
+
+_QUAD_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from jmcodec_amd import api
+from tools import streams
+out = {}
+orc = streams.Oracle()
+# search: the generator's integer search range = how far apart the vectors of neighbouring macroblocks can lie.  4: a workgroup's four macroblocks nearly
+# always share a window; 24 / 48: many groups sit at the bounds of pk::quad_geometry (vectors ~29 samples / 11 rows apart) or beyond; small pictures: every
+# window touches a picture border now and then (the one-window path, and with it the shared window, is then refused per macroblock)
+# (mode 1 = random decisions: a fifth of its vectors up to 80 samples long, most macroblocks in several partitions -- those never take the one-window path)
+for name, kw in (("near", dict(width=640, height=368, frames=24, gop=24, seed=311, search=4)),
+                 ("bounds", dict(width=640, height=368, frames=24, gop=24, seed=312, search=24)),
+                 ("far", dict(width=352, height=288, frames=24, gop=24, seed=313, search=48)),
+                 ("fuzz", dict(width=352, height=288, frames=24, gop=24, seed=315, mode=1, no_intra=1, num_ref=2)),
+                 ("borders", dict(width=96, height=80, frames=24, gop=24, seed=314, search=16))):
+    data = streams.generate(**kw)
+    want, n, w, h = orc.decode(data, 1)
+    with api.JmAmdDec(0, 1) as d:
+        q0, p0, c0 = d.stat("eng_quad_windows"), d.stat("eng_private_windows"), d.stat("eng_chain_pics")
+        frames = d.decode_stream(None, chunks=[data])
+        out[name] = dict(equal=b"".join(frames) == want, frames=len(frames), n=n, errors=d.stat("errors"), quad=d.stat("eng_quad_windows") - q0,
+                         private=d.stat("eng_private_windows") - p0, chained=d.stat("eng_chain_pics") - c0, shared=d.stat("eng_gpu_shared"))
+print("QUAD " + json.dumps(out))
+"""
+
+
+def test_shared_reference_window_path_ran_and_is_bit_exact(tmp_path):
+    """the "quad" path of the chain kernels -- ONE reference window for the four macroblocks of a reconstruction workgroup, a
+    data-dependent vote through LDS (recon_device.h) -- must be PROVEN to run on the GPU, not assumed: a diagnostic run (JM_AMD_DEC_CENSUS, its own
+    process: the switch is read once) counts the workgroups that shared a window and those that did not, on streams whose vectors lie close together, at
+    the bounds of pk::quad_geometry, far apart and against picture borders.  Every stream must equal the oracle; the first must take the shared path,
+    the wide-range ones both paths."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    ours = _wait_until_the_gpu_is_ours()
+    src = tmp_path / "quad.py"
+    src.write_text(_QUAD_SCRIPT)
+    r = subprocess.run([sys.executable, str(src), ROOT], capture_output=True, text=True, timeout=900, env=dict(os.environ, JM_AMD_DEC_CENSUS="1"))
+    line = next((l for l in r.stdout.splitlines() if l.startswith("QUAD ")), None)
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[5:])
+    for name, v in res.items():
+        assert v["equal"] and v["frames"] == v["n"] and v["errors"] == 0, (name, v)
+    if not ours or any(v["shared"] for v in res.values()) or not any(v["chained"] for v in res.values()):
+        pytest.skip("no chain launch formed (GPU shared): the census has nothing to count")
+    import util
+    util.SESSION_NOTES.append("shared reference windows (quad path) / private windows per stream: " +
+                              ", ".join(f"{k} {v['quad']} / {v['private']}" for k, v in res.items()))
+    assert res["near"]["quad"] > 0 and res["bounds"]["quad"] > 0, (res["near"], res["bounds"])          # the shared window really was fetched
+    assert res["fuzz"]["private"] > 0 and res["borders"]["private"] > 0, (res["fuzz"], res["borders"])  # ... and refused where it must be
 
 
 # ---- closing test of this file (pytest runs a file's tests in definition order): were the chain kernels exercised at all? ---------------------------

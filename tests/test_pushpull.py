@@ -70,47 +70,61 @@ def test_push_pull_loop_host_side_with_whole_buffer_pushes():
     assert "Frame Count:\t120" in info and "Display:\t176 x 144" in info
 
 
-def test_input_is_held_off_while_frames_wait():
-    """need_more_data turns false while kFramesHigh (64) display frames wait for the caller (or kPicturesLow pictures are still on their way through the
-    pipeline: not in this host-only run, where a picture is done as soon as it is parsed), and true again once they are fetched."""
-    data = streams.generate(width=96, height=80, frames=120, gop=40, seed=3)
-    nal = api.split_nalus(data)
+def test_input_buffer_and_feeder_hold_off():
+    """The facade's input side (jm_intel_dec_api.cpp): input_data copies into a 1 MB buffer that a feeder thread hands to the decoder; need_more_data /
+    free_buf_len describe that buffer (intel_dec.cpp:343-360); the feeder stops while 64 display frames wait for the caller, so a caller that does not
+    fetch cannot make the decoder run through the whole stream; size query and a too-small buffer leave the frame where it is."""
+    import time
+    data = streams.generate(width=96, height=80, frames=300, gop=30, seed=3)
+    L = api.lib()
     h = api.jm_intel_dec_create_handle()
-    api.lib().jm_amddec_set_option(api.lib().jm_amdintel_decoder(h), b"parse_only", 1)
+    dec = L.jm_amdintel_decoder(h)
+    L.jm_amddec_set_option(dec, b"parse_only", 1)
     assert api.jm_intel_dec_init(0, 1, h) == 0
-    assert api.jm_intel_dec_need_more_data(h)
-    pushed = 0
-    while api.jm_intel_dec_need_more_data(h) and pushed < len(nal):
-        assert api.jm_intel_dec_input_data(nal[pushed], len(nal[pushed]), h) == len(nal[pushed])
-        pushed += 1
-    dec = api.lib().jm_amdintel_decoder(h)
-    api.lib().jm_amddec_set_option(dec, b"wait_idle", 1)     # pictures are parsed by worker threads: let what was pushed arrive in the display queue
-    waiting = api.lib().jm_amddec_get_stat(dec, b"frames_waiting")      # none is current yet
-    assert pushed < len(nal) and 64 <= waiting <= pushed, (pushed, waiting)
-    assert not api.jm_intel_dec_need_more_data(h)
+    assert api.jm_intel_dec_need_more_data(h) and api.jm_intel_dec_free_buf_len(h) == MB
+    assert 64 * 1024 < len(data) < MB // 2                                       # more than one of the feeder's 64 KB pieces
+    assert api.jm_intel_dec_input_data(data, len(data), h) == len(data)        # one push of the whole stream: accepted at once
+    for _ in range(2000):                                                        # the feeder works through it until 64 frames wait
+        if L.jm_amddec_get_stat(dec, b"frames_waiting") >= 64:
+            break
+        time.sleep(0.001)
+    time.sleep(0.05)
+    waiting, pics = L.jm_amddec_get_stat(dec, b"frames_waiting"), L.jm_amddec_get_stat(dec, b"pictures")
+    assert 64 <= waiting < 300 and pics < 300, (waiting, pics)                   # held back: a 64 KB piece beyond the limit at most
+    assert api.jm_intel_dec_free_buf_len(h) < MB                                 # ... with input still in the buffer
     out = C.create_string_buffer(96 * 80 * 3 // 2)
     # a size query and a too-small buffer leave the frame where it is (jm_intel_dec.h:69-78, intel_dec.cpp:266-270)
     assert api.jm_intel_dec_output_frame(None, 0, h) == (0, len(out))
     assert api.jm_intel_dec_output_frame(out, 10, h) == (-2, 0)
-    assert api.lib().jm_amddec_get_stat(dec, b"frames_waiting") == waiting - 1     # + the current one
-    assert not api.jm_intel_dec_need_more_data(h)
-    got = 0
-    while not api.jm_intel_dec_need_more_data(h):            # input stays held off until fewer than 64 frames wait
-        assert api.jm_intel_dec_output_frame(out, len(out), h) == (0, len(out))
-        got += 1
-    assert got == waiting - 63 and api.lib().jm_amddec_get_stat(dec, b"frames_waiting") == 63
-    # two pushes in a row without a pull in between lose nothing
-    for n in nal[pushed:]:
-        api.jm_intel_dec_input_data(n, len(n), h)
+    assert api.jm_intel_dec_output_frame(out, len(out), h) == (0, len(out))
+    got = 1
     api.jm_intel_dec_set_eof(1, h)
     assert not api.jm_intel_dec_need_more_data(h)
-    assert api.jm_intel_dec_input_data(nal[0], len(nal[0]), h) < 0        # input after end of stream is refused
+    assert api.jm_intel_dec_input_data(data[:100], 100, h) < 0                   # input after end of stream is refused
+    guard = 0
     while not api.jm_intel_dec_is_exit(h):
+        guard += 1
+        assert guard < 10_000_000
         if api.jm_intel_dec_output_frame(out, len(out), h)[0] == 0:
             got += 1
-    assert got == 120
-    assert "Frame Count:\t120" in api.jm_intel_dec_info(h)
+    assert got == 300
+    assert "Frame Count:\t300" in api.jm_intel_dec_info(h)
     api.jm_intel_dec_deinit(h)
+
+
+def test_deinit_with_input_still_buffered():
+    """A handle closed in the middle of everything: input buffered, the feeder waiting for the caller, frames never fetched."""
+    data = streams.generate(width=96, height=80, frames=200, gop=40, seed=4)
+    for fetch in (0, 3):
+        h = api.jm_intel_dec_create_handle()
+        api.lib().jm_amddec_set_option(api.lib().jm_amdintel_decoder(h), b"parse_only", 1)
+        assert api.jm_intel_dec_init(0, 1, h) == 0
+        assert api.jm_intel_dec_input_data(data, len(data), h) == len(data)
+        out = C.create_string_buffer(96 * 80 * 3 // 2)
+        for _ in range(fetch):
+            while api.jm_intel_dec_output_frame(out, len(out), h)[0] != 0:
+                pass
+        assert api.jm_intel_dec_deinit(h) == 0
 
 
 def test_native_push_pull_loop_host_side():
