@@ -268,12 +268,16 @@ def measure(args, ctx):
         return L.jm_amddec_output_frame(C.cast(out, C.c_void_p), C.byref(n), h)
 
     feeder_cpu = [0.0] * S          # CPU seconds of each handle's calling thread (they exit before the per-thread /proc snapshot)
+    out_bufs = [C.create_string_buffer(frame_bytes) for _ in range(S)]
 
     def run_passes(i, passes):
         """test_nv_dec's hot loop: one NAL per jm_nvdec_decode_frame call, pull a frame whenever got_frame == 1."""
         tc_start = time.thread_time()
         h = handles[i]
-        out = C.create_string_buffer(frame_bytes)
+        # one output buffer per handle for the whole run, as the reference harness has (test_nv_dec.cpp:107-110).  JM_BENCH_FRESH_BUFFERS=1: a new one per
+        # pass, freed when the pass ends (rounds 1-5; the munmap of a buffer that the output route had page-locked is suspected of taking the process's
+        # queues off the device for ~25 ms: profiles/r06_chain_soak.txt)
+        out = C.create_string_buffer(frame_bytes) if os.environ.get("JM_BENCH_FRESH_BUFFERS") else out_bufs[i]
         got = C.c_int(0)
         n = C.c_int(0)
         cnt = 0
@@ -453,7 +457,7 @@ def measure(args, ctx):
     traffic_file = None
     try:
         tag = f"hevc_{args.width}x{args.height}" if args.codec == "hevc" else f"h264_{args.tools}_{args.width}x{args.height}"
-        cands = [f"r05_pmc_traffic_{tag}.json", f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json"]
+        cands = [f"r06_pmc_traffic_{tag}.json", f"r05_pmc_traffic_{tag}.json", f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json"]
         if tag == "h264_baseline_1920x1080":
             cands.append("r02_pmc_traffic.json")
         pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in cands) if os.path.exists(p))

@@ -61,14 +61,15 @@ constexpr int kSpinLimit = 1 << 20;    // polls before a wait of the STAGE kerne
 // reconstruction group, so the longest healthy wait is the launch itself: 1.3-2.1 ms at 1080p (profiles/r04_chain_timeline.txt), more for bigger
 // pictures and deeper chains (Engine::launch scales it).  Rounds 2-5 used a flat 100 ms of WALL time.  Round 5's two unexplained give-ups (2 of 41,800
 // launches, profiles/r05_chain_soak.txt: a band one step short of what its neighbour needed, nothing in the code that could stall it) fit a timer that
-// keeps running while its wave does not: when a queue is taken off the device for a while (the kernel driver evicts a process's queues when it
-// revalidates user pages or moves memory -- and every jm_nvdec_output_frame call page-locks and releases the caller's buffer), every wave of the launch
-// stands still, the clock does not, and the first wave to wake up finds its time used up with the counter exactly where a healthy run would have it.
-// So the timer now measures waiting, not absence: the clock is read every 64 looks, 64 looks take at most ~3 ms (wait_final's naps), and a jump of
-// more than kGapTicks between two readings is time the wave was not run -- it is taken out of the wait and recorded (WaitClock::gaps, the launch's
-// evidence words: Engine::complete counts them, profiles/r06_chain_soak.txt).  A give-up then means what it says: the wave looked for `limit` of its own
-// running time and the counter did not move.  The engine decodes the launch's pictures again with the stage kernels (Engine::recover) either way: a timeout
-// costs time, not correctness.
+// keeps running while its wave does not -- and round 6 SAW that happen: in each of three soaks of ~13,700 launches several launches had a wait whose
+// clock jumped by 23-33 ms between two looks (profiles/r06_chain_soak.txt), typically once per run, when the load on the device drops at the end of a
+// pass.  Every wave of the launch stands still that long while the clock does not; the first wave to wake up finds its time used up with the counter exactly
+// where a healthy run would have it.  (Not queue creation, not the freeing of output buffers: both were tried; what is left -- clock / power state
+// changes of the device, the driver's scheduler -- cannot be observed or changed by an ordinary user of this pool.)  The timers do not need to know:
+// they measure waiting, not absence.  The clock is read every 64 looks, 64 looks take at most ~3 ms (wait_final's naps), and a jump of more than
+// kGapTicks between two readings is time the wave was not run -- it is taken out of the wait and recorded (WaitClock::gaps, the launch's evidence words:
+// Engine::complete counts them).  A give-up then means what it says: the wave looked for `limit` of its own running time and the counter did not move.
+// The engine decodes the launch's pictures again with the stage kernels (Engine::recover) either way: a timeout costs time, not correctness.
 constexpr uint32_t kWaitTicks = 2u * 1000u * 1000u;      // 20 ms: the default when the host wrote no limit
 constexpr uint32_t kGapTicks = 500u * 1000u;             // 5 ms between two clock readings of a waiting wave: it was not run
 struct WaitClock { uint32_t t0 = 0, last = 0, limit = 0, gaps = 0, gap_max = 0; };

@@ -89,21 +89,6 @@ Engine::Engine(int device) : device_(device) {
         }
     }
     mem_trace("engine: lane buffers");
-    // Every stream gets its hardware queue NOW (the runtime creates a queue when a stream is first used).  Creating a queue makes the kernel driver rebuild the
-    // process's run list, and for that it takes every running queue off the device and puts it back -- waves and all: 24-33 ms during which a chain launch
-    // stands still (seen as clock gaps by its waits, once per process in a quarter of the soak runs: profiles/r06_chain_soak.txt).  With the old wall-clock
-    // timers a few of those inside one wait were a give-up.  JM_AMD_DEC_LAZY_QUEUES=1 keeps the old behaviour (A/B).
-    if (!getenv("JM_AMD_DEC_LAZY_QUEUES")) {
-        int *d_word = nullptr;
-        if (hipMalloc((void **)&d_word, 256) == hipSuccess) {
-            hipMemsetAsync(d_word, 0, 4, copy_stream_);
-            for (auto &ln : lanes_) { hipMemsetAsync(d_word + 4, 0, 4, ln.stream); hipMemsetAsync(d_word + 8, 0, 4, ln.pack_stream);
-                hipMemsetAsync(d_word + 12, 0, 4, ln.pre_stream); }
-            hipDeviceSynchronize();
-            hipFree(d_word);
-        }
-        (void)hipGetLastError();
-    }
     // The no-deadlock argument of a chain launch (chain.hip) needs its band workgroups -- resident for their whole wavefront -- to leave room for the
     // reconstruction groups they wait for: at most half of what the device holds.  Taken from the device in use (a compute partition, a smaller part
     // or a build with other register counts holds fewer than the constants assume); launches whose first pictures do not fit run unchained.
@@ -814,8 +799,9 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
     if (b.h_err[kMaxBatch]) { std::lock_guard<std::mutex> lk(sm_); st_.wait_gap_launches++; st_.wait_gap_max_ticks = std::max(st_.wait_gap_max_ticks,
         (long long)(unsigned)b.h_err[kMaxBatch + 1]);
         if (getenv("JM_AMD_DEC_VERBOSE")) fprintf(stderr, "jm_amd_dec: a chain launch's waits saw %d clock gap(s), the longest %.2f ms: its waves were not run meanwhile "
-            "(chain launch %lld of this process, batch %llu of its lane, %.1f ms after the engine's first trace point)\n",
-            b.h_err[kMaxBatch], (unsigned)b.h_err[kMaxBatch + 1] * 1e-5, st_.chain_batches + 1, b.serial, trace_ms());
+            "(chain launch %lld of this process, batch %llu of its lane, %.1f ms after the engine's first trace point, CLOCK_MONOTONIC %.3f s when it retired)\n",
+            b.h_err[kMaxBatch], (unsigned)b.h_err[kMaxBatch + 1] * 1e-5, st_.chain_batches + 1, b.serial, trace_ms(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
         b.h_err[kMaxBatch] = b.h_err[kMaxBatch + 1] = 0; }
     // diagnostic launches (JM_AMD_DEC_CENSUS): how many reconstruction workgroups shared one reference window (tests: the quad path really ran)
     if (b.any_chain && !failed) { static const bool census = getenv("JM_AMD_DEC_CENSUS") != nullptr;

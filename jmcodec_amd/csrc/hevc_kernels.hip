@@ -16,6 +16,7 @@
 #include "hevc_tables.h"
 #include "hevc_mc_packed.h"
 #include "hevc_resid_packed.h"
+#include "hevc_bs.h"
 #include "chain_common.h"
 #include <cstdlib>
 
@@ -759,27 +760,11 @@ __global__ __launch_bounds__(256) void k_hevc_bs_raster(const HevcPicParams *pic
     typedef const __attribute__((address_space(4))) HevcPicParams ConstPic;
     ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
     if (!(pp.stages & HPS_DEBLOCK)) return;
-    const int w4 = pp.w >> 2, h4 = pp.h >> 2, cells = w4 * h4;
-    uint8_t *f_intra = pp.cell_flags, *f_cbf = f_intra + cells, *f_l = f_cbf + cells, *f_t = f_l + cells;
-    uint32_t *pu_map = pp.pu_map;
+    const hbs::Maps m = hbs::maps_of(pp.w, pp.h, pp.pu_map, pp.cell_flags);
     const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-    for (int i = gid; i < pp.n_pus; i += stride) {
-        const HevcPu pu = pp.pus[i];
-        const int cx0 = pu.x >> 2, cy0 = pu.y >> 2, nx = pu.w >> 2, ny = pu.h >> 2;
-        for (int r = 0; r < ny; r++) for (int k = 0; k < nx; k++) pu_map[(cy0 + r) * w4 + cx0 + k] = (uint32_t)i;
-    }
-    auto mark = [&](int x, int y, int n, uint8_t *own) {
-        const int cx0 = x >> 2, cy0 = y >> 2, nu = n >> 2;
-        for (int r = 0; r < nu; r++) {
-            uint8_t *o = own + (cy0 + r) * w4 + cx0;
-            for (int k = 0; k < nu; k++) o[k] = 1;
-            f_l[(cy0 + r) * w4 + cx0] = 1;
-            if (cx0 + nu < w4) f_l[(cy0 + r) * w4 + cx0 + nu] = 1;
-        }
-        for (int k = 0; k < nu; k++) { f_t[cy0 * w4 + cx0 + k] = 1; if (cy0 + nu < h4) f_t[(cy0 + nu) * w4 + cx0 + k] = 1; }
-    };
-    for (int i = gid; i < pp.n_itbs; i += stride) { const HevcIntraTb tb = pp.itbs[i]; if (tb.plane == 0) mark(tb.x, tb.y, 1 << tb.log2, f_intra); }
-    for (int i = gid; i < pp.n_tbs; i += stride) { const HevcTb tb = pp.tbs[i]; if (tb.plane == 0) mark(tb.x, tb.y, 1 << tb.log2, f_cbf); }
+    for (int i = gid; i < pp.n_pus; i += stride) hbs::paint_pu(m, i, pp.pus[i]);
+    for (int i = gid; i < pp.n_itbs; i += stride) { const HevcIntraTb tb = pp.itbs[i]; if (tb.plane == 0) hbs::mark(m, tb.x, tb.y, 1 << tb.log2, m.f_intra); }
+    for (int i = gid; i < pp.n_tbs; i += stride) { const HevcTb tb = pp.tbs[i]; if (tb.plane == 0) hbs::mark(m, tb.x, tb.y, 1 << tb.log2, m.f_cbf); }
 }
 // blockIdx.z = direction: 0 vertical edges (x = 8k, one entry per 4 rows), 1 horizontal edges (y = 8k, one entry per 4 columns)
 __global__ __launch_bounds__(256) void k_hevc_bs(const HevcPicParams *pics) {
@@ -787,50 +772,13 @@ __global__ __launch_bounds__(256) void k_hevc_bs(const HevcPicParams *pics) {
     ConstPic &pp = *(ConstPic *)(uintptr_t)(pics + blockIdx.y);
     if (!(pp.stages & HPS_DEBLOCK)) return;
     const int dir = (int)blockIdx.z;
-    const int w8 = pp.w >> 3, w4 = pp.w >> 2, h4 = pp.h >> 2, h8 = pp.h >> 3, cells = w4 * h4;
+    const int w8 = pp.w >> 3, w4 = pp.w >> 2, h4 = pp.h >> 2, h8 = pp.h >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     int x, y;
     if (dir == 0) { if (idx >= w8 * h4) return; x = (idx % w8) * 8; y = (idx / w8) * 4; }
     else { if (idx >= w4 * h8) return; x = (idx % w4) * 4; y = (idx / w4) * 8; }
-    uint8_t *out = dir ? pp.bs_h + idx : pp.bs_v + idx;
-    int bs = 0;
-    do {
-        if (dir ? y == 0 : x == 0) break;                             // picture boundary
-        const int lg = pp.ctb_log2, cs = 1 << lg, xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
-        const int fq = pp.ctbs[(y >> lg) * pp.ctb_w + (x >> lg)].db_flags, fp = pp.ctbs[(yp >> lg) * pp.ctb_w + (xp >> lg)].db_flags;
-        if (fq & (HDB_DISABLED | HDB_CONCEALED)) break;
-        if (((dir ? y : x) & (cs - 1)) == 0 && (fq & (dir ? HDB_NO_TOP : HDB_NO_LEFT))) break;
-        const uint8_t *f_intra = pp.cell_flags, *f_cbf = f_intra + cells, *f_edge = f_intra + (dir ? 3 : 2) * cells;
-        const int q = (y >> 2) * w4 + (x >> 2), p = dir ? q - w4 : q - 1;
-        const bool iq = f_intra[q] != 0, ip_cell = f_intra[p] != 0, ip = ip_cell || (fp & HDB_CONCEALED);
-        const bool tu = f_edge[q] != 0;
-        uint32_t ia = 0, ib = 0;
-        if (!iq && !ip_cell) { ia = pp.pu_map[q]; ib = pp.pu_map[p]; }
-        if (!tu && ia == ib) break;                                   // no transform edge, and the same prediction block (or one of them intra: tu is set then)
-        if (iq || ip) { bs = 2; break; }
-        if (tu && (f_cbf[q] || f_cbf[p])) { bs = 1; break; }
-        if (ia == ib) break;
-        const HevcPu a = pp.pus[ia], b = pp.pus[ib];
-        const int na = (a.slot0 >= 0) + (a.slot1 >= 0), nb = (b.slot0 >= 0) + (b.slot1 >= 0);
-        if (na != nb) { bs = 1; break; }
-        auto far = [](const int16_t *u, const int16_t *v) { return iabs(u[0] - v[0]) >= 4 || iabs(u[1] - v[1]) >= 4; };
-        if (na == 1) {
-            const int ra = a.slot0 >= 0 ? a.slot0 : a.slot1, rb = b.slot0 >= 0 ? b.slot0 : b.slot1;
-            const int16_t *va = a.slot0 >= 0 ? a.mv0 : a.mv1, *vb = b.slot0 >= 0 ? b.mv0 : b.mv1;
-            bs = (ra != rb || far(va, vb)) ? 1 : 0;
-            break;
-        }
-        const bool straight = a.slot0 == b.slot0 && a.slot1 == b.slot1, crossed = a.slot0 == b.slot1 && a.slot1 == b.slot0;
-        if (!straight && !crossed) { bs = 1; break; }
-        const bool ds = far(a.mv0, b.mv0) || far(a.mv1, b.mv1), dc = far(a.mv0, b.mv1) || far(a.mv1, b.mv0);
-        bs = (straight && crossed ? (ds && dc) : (straight ? ds : dc)) ? 1 : 0;
-    } while (0);
-    if (bs) {
-        const int xp = dir ? x : x - 1, yp = dir ? y - 1 : y;
-        if (pp.qp8[(yp >> 3) * pp.w8 + (xp >> 3)] & 128) bs |= 4;     // samples of the p side / the q side are exempt from the loop filters
-        if (pp.qp8[(y >> 3) * pp.w8 + (x >> 3)] & 128) bs |= 8;
-    }
-    *out = (uint8_t)bs;
+    const hbs::Maps m = hbs::maps_of(pp.w, pp.h, pp.pu_map, pp.cell_flags);
+    (dir ? pp.bs_h : pp.bs_v)[idx] = (uint8_t)hbs::edge_strength(m, dir, x, y, pp.ctb_log2, pp.ctb_w, pp.ctbs, pp.pus, pp.qp8, pp.w8);
 }
 
 // ------------------------------------------------------------------------------------------------------------
