@@ -139,6 +139,7 @@ bool Engine::set_knob(const std::string &key, long long v) {
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max((long long)kMinChainLag, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
     else if (key == "debug_stall") debug_stall_ = (int)v;
+    else if (key == "early_intra_ahead") early_intra_ahead_ = (int)std::max(1ll, std::min(v, 64ll));      // (tests: 1 = run ahead whenever the hazards allow)
     else return false;
     return true;
 }
@@ -291,7 +292,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 // pictures pending per decoder), and then an early launch saves the stream its stall.  With shallow queues (host- or PCIe-bound
                 // callers) the picture would go a batch or two early at best, in more and smaller intra batches than its turn would have formed:
                 // measured -2 % on the host-output headline (profiles/r06_lane_fill.txt), so those take their turn as before
-                if (landed && es.scan_ahead >= kEarlyIntraAhead && !(own & (es.scan_touched | infl))) cand.push_back(it);
+                if (landed && es.scan_ahead >= early_intra_ahead_.load() && !(own & (es.scan_touched | infl))) cand.push_back(it);
             }
             es.scan_touched |= it->ref_mask | it->out_mask | own;
             es.scan_ahead++;
