@@ -656,6 +656,7 @@ def measure(args, ctx):
             h = jmcodec_amd.jm_nvdec_create_handle()
             L.jm_amddec_set_option(h, b"device_output", 1)
             if jmcodec_amd.jm_nvdec_init(1 if is_hevc else 0, 1, None, 0, h) == 0:
+                L.jm_amddec_set_option(h, b"profile", 0 if args.no_profile else 1)   # (the engine's switch follows the handle that set it last: without this the lanes below read 0)
                 hs.append(h)
         got_dev = [0] * len(hs)
 
@@ -682,7 +683,7 @@ def measure(args, ctx):
                 # what bounds it, from measurements instead of by elimination: the host when its CPU allotment is used up; else the
                 # device when the busiest lane's stream has kernels on it for >= 85 % of the wall time; else the pipeline in between (batches not formed in time)
                 lane_busy = max([v["busy_frac"] for v in d_lanes.values() if isinstance(v, dict) and "busy_frac" in v] or [0.0])
-                d_bound = "host_cpu_quota" if d_quota and d_busy >= 0.9 * d_quota else ("gpu" if lane_busy >= 0.85 else "engine_pipeline")
+                d_bound = "host_cpu_quota" if d_quota and d_busy >= 0.9 * d_quota else ("gpu" if lane_busy >= 0.85 else ("engine_pipeline" if lane_busy > 0 else "lanes_unmeasured"))
                 dev_leg = {"value": round(len(hs) * F * passes / ddt, 1), "unit": "frames/s", "frames": len(hs) * F * passes,
                            "host_cpu": {"cpu_ms_per_frame": round(1e3 * (dhc1["cpu_s"] - dhc0["cpu_s"]) / max(len(hs) * F * passes, 1), 4),
                                         "cpus_busy": round(d_busy, 2), "quota_cpus": d_quota},

@@ -269,7 +269,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     // The look costs a walk over everything pending (some twenty pictures per decoder, under m_, which every submitting thread needs): at most every
     // 250 us -- an intra batch holds the lane for ~1.8 ms -- and only when something changed.  (The first version looked on every turn of the engine loop
     // with a quadratic walk: the engine thread sat in it, the feeders queued for m_, 27 k -> 16-20 k frames/s: profiles/r06_lane_fill.txt.)
-    if (lane_idx == kIntraLane && early_intra_ && !chaining && early_scanned_gen_ != pending_gen_ && now_ns - early_scan_ns_ > 250 * 1000) {
+    if (lane_idx == kIntraLane && early_intra_ && deep_queues_ && !chaining && early_scanned_gen_ != pending_gen_ && now_ns - early_scan_ns_ > 250 * 1000) {
         early_scan_ns_ = now_ns;
         const unsigned long long tag = ++early_scan_tag_;
         std::vector<std::deque<EnginePic>::iterator> cand;
@@ -319,8 +319,15 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
     }
     if (b.pics.empty()) return false;
     pending_gen_++;
-    if (lane_idx == kOrdinaryLane) { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size();
-        st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
+    if (lane_idx == kOrdinaryLane) {
+        { std::lock_guard<std::mutex> lk(sm_); st_.forms++; st_.form_decoders += (long long)seen.size(); st_.form_pending += (long long)(pending_.size() + b.pics.size()); }
+        // Is the ENGINE what the streams wait for?  Then a decoder has many parsed pictures pending (its job slots: up to 40); callers bound by the host's entropy
+        // decode or by the PCIe link keep about ten.  With hysteresis: the intra pictures' early launches and the one-batch-at-a-time intra lane are for deep
+        // queues only -- with shallow ones they made more, smaller batches on both lanes (18.5 instead of 25 pictures per ordinary batch, 2.1 instead of 3.2 per
+        // intra batch in the PCIe-bound headline: profiles/r06_lane_fill.txt section 5), which costs no frames there but is waste all the same.
+        const size_t depth = (pending_.size() + b.pics.size()) / std::max<size_t>(1, seen.size());
+        if (depth >= 16) deep_queues_ = true; else if (depth <= 8) deep_queues_ = false;
+    }
     // bounds of a chain launch: its deblocking bands (2 workgroups each, resident for their whole wavefront) must stay well below the number of
     // workgroups the GPU holds (chain.hip), and its work list must fit the table
     auto chain_cost = [&](const EnginePic &p, int &bands, int &groups) { bands = (p.chain_intra ? 4 : 2) * ((p.mb_h + 15) / 16);
@@ -860,10 +867,10 @@ void Engine::run() {
         for (int li = 0; li < kLanes; li++) {
             Lane &ln = lanes_[li];
             static const int max_inflight = getenv("JM_AMD_DEC_INFLIGHT") ? atoi(getenv("JM_AMD_DEC_INFLIGHT")) : 2;
-            // the intra lane takes one batch at a time while intra pictures may run ahead of their turn: a second batch behind a running one would only fix its
+            // the intra lane takes one batch at a time while intra pictures may run ahead of their turn (deep queues): a second batch behind a running one would only fix its
             // membership early (it could not start sooner), and an intra batch costs the lane the same 1.8 ms whether it holds two pictures or twenty --
             // formed when the lane falls idle it takes everything that has become ready meanwhile (r06: 276 batches of 2.3 -> see profiles/r06_lane_fill.txt)
-            if (ln.inflight >= (li == kIntraLane && early_intra_ ? 1 : max_inflight)) continue;
+            if (ln.inflight >= (li == kIntraLane && early_intra_ && deep_queues_ ? 1 : max_inflight)) continue;
             Batch &b = ln.ring[ln.head];
             bool have;
             if (li == kOrdinaryLane) { bool any; { std::lock_guard<std::mutex> lk(m_); any = !pending_.empty(); } if (any) look_for_other_users(); }

@@ -167,6 +167,7 @@ private:
     // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
     // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
     bool cross_lane_ = true, early_intra_ = true;
+    bool deep_queues_ = false;                      // engine thread: the decoders have many parsed pictures pending -- the engine is what they wait for (Engine::form)
     std::atomic<int> early_intra_ahead_{kEarlyIntraAhead};     // knob "early_intra_ahead" (tests)
     long long early_scan_ns_ = 0; unsigned long long early_scan_tag_ = 0;
     unsigned long long pending_gen_ = 0, early_scanned_gen_ = ~0ull;      // m_: bumped whenever pending_ or the set of pictures in flight changes

@@ -52,6 +52,7 @@ struct Ctx {
                 chunk = std::move(inq.front()); inq.pop_front();
             }
             for (size_t o = 0; o < chunk.size() && !feed_failed;) {
+                { std::lock_guard<std::mutex> lk(im); if (stop) return; }          // (deinit in the middle of a chunk)
                 // (frames nobody fetches hold output slots: wait for the caller rather than decode the whole stream into memory)
                 while (!cb && jm_amddec_get_stat(dec, "frames_waiting") >= kFramesHigh) {
                     std::unique_lock<std::mutex> lk(im);
