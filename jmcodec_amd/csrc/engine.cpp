@@ -1,5 +1,6 @@
 // jmcodec_amd/csrc/engine.cpp -- see engine.h.
 #include "engine.h"
+#include <sys/prctl.h>
 #include "chain_order.h"
 #include "decoder.h"
 #include "kernels.h"
@@ -845,6 +846,9 @@ void Engine::look_for_other_users() {
 
 void Engine::run() {
     hipSetDevice(device_);
+    // this thread's sleeps are its polling period (step 3 below: 20 us while batches are in flight); with the default timer slack of 50 us a 20 us sleep
+    // takes ~75, which is how late the end of a batch was noticed on average -- per chain launch of a lone stream, whose next launch waits for exactly that
+    prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);
     for (;;) {
         bool progressed = false;
         // 1. retire finished batches (oldest first per lane)
