@@ -126,6 +126,7 @@ void Engine::submit(EnginePic &&p) {
             if (p.has_picture) it->mbs = p.mb_w * p.mb_h;
         }
         p.seq = p.dec->engine_state().next_seq++;
+        if (p.dec->engine_state().n_pending++ == 0) decoders_pending_++;
         pending_.push_back(std::move(p));
         pending_gen_++;
     }
@@ -221,7 +222,11 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         es.batch_read |= p.ref_mask | p.out_mask;
         n_pre += p.out_before.size(); n_post += p.out_after.size();
     };
-    for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch;) {
+    // (the walk ends once every decoder that has pictures pending has been seen: with the engine as the bottleneck some 1,100 pictures are pending at 32 streams,
+    //  the decoders' oldest ones among the first hundred or two -- and this runs under m_, which every submitting thread needs, on every turn of the engine loop)
+    const size_t n_dec_pending = (size_t)decoders_pending_;
+    auto took = [&](EngineDecoderState &es) { if (--es.n_pending == 0) decoders_pending_--; };
+    for (auto it = pending_.begin(); it != pending_.end() && (int)b.pics.size() < kMaxBatch && seen.size() < n_dec_pending;) {
         Decoder *d = it->dec;
         if (std::find(seen.begin(), seen.end(), d) != seen.end()) { ++it; continue; }
         seen.push_back(d);                              // only a decoder's OLDEST pending picture is a candidate
@@ -258,6 +263,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
         es.batch_resid = it->has_picture && it->codec == 0 && (it->pp.stages & (PS_INTRA_LDS | PS_INTRA_V1)) != 0;
         account(*it, es);
         members.push_back(d);
+        took(es);
         b.pics.push_back(std::move(*it));
         it = pending_.erase(it);
     }
@@ -311,6 +317,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 es.inflight++; es.lane_inflight[lane_idx]++;
                 LANE_TRACE("early dec %p seq %llu\n", (void *)it->dec, it->seq);
                 n_post += it->out_after.size();
+                took(es);
                 b.pics.push_back(std::move(*it));
                 pending_.erase(it);
                 { std::lock_guard<std::mutex> lk(sm_); st_.early_intra++; }
@@ -359,6 +366,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 tot_bands += nb; tot_groups += ng; any_intra |= it->chain_intra; es.batch_resid |= it->chain_intra;
                 es.inflight++; es.lane_inflight[lane_idx]++; es.in_batch++;
                 account(*it, es);
+                took(es);
                 b.pics.push_back(std::move(*it));
                 pending_.erase(it);
                 b.any_chain = true; added = true;
@@ -384,6 +392,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 es.inflight++; es.lane_inflight[lane_idx]++; es.in_batch++;
                 es.batch_written |= 1u << it->hp.cur;
                 account(*it, es);
+                took(es);
                 b.pics.push_back(std::move(*it));
                 pending_.erase(it);
             }
@@ -846,9 +855,10 @@ void Engine::look_for_other_users() {
 
 void Engine::run() {
     hipSetDevice(device_);
-    // this thread's sleeps are its polling period (step 3 below: 20 us while batches are in flight); with the default timer slack of 50 us a 20 us sleep
-    // takes ~75, which is how late the end of a batch was noticed on average -- per chain launch of a lone stream, whose next launch waits for exactly that
-    prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);
+    // This thread's sleeps are its polling period (step 3 below: 20 us while batches are in flight; with the default timer slack of 50 us such a sleep takes ~75).
+    // A 1 us slack was tried (JM_AMD_DEC_TIMER_SLACK_NS=1000): the end of a batch is noticed 50 us sooner, but the loop then takes m_ three times as often --
+    // one stream and eight streams unchanged, 32 device-resident streams rather worse (profiles/r06_engine_loop.txt).  Default: the slack is left alone.
+    { const char *e = getenv("JM_AMD_DEC_TIMER_SLACK_NS"); const unsigned long ns = e ? strtoul(e, nullptr, 10) : 0ul; if (ns) prctl(PR_SET_TIMERSLACK, ns, 0, 0, 0); }
     for (;;) {
         bool progressed = false;
         // 1. retire finished batches (oldest first per lane)

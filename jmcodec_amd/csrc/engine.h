@@ -106,6 +106,7 @@ struct EngineDecoderState {
     int lane_inflight[4] = {0, 0, 0, 0};            // ... per lane
     uint32_t displayed[4] = {0, 0, 0, 0};           // per lane: surfaces displayed by this decoder's pictures in the lane's most recently launched batch
     unsigned long long next_seq = 0;                // decode-order numbering of the decoder's pictures (Engine::submit, m_)
+    int n_pending = 0;                              // the decoder's pictures in Engine::pending_ (m_)
     unsigned long long scan_tag = 0; uint32_t scan_touched = 0; int scan_ahead = 0; bool scan_closed = false;   // scratch of the look for intra pictures (Engine::form)
     long long blocked_since = 0;                    // diagnostic: when an ordinary-lane batch first left this decoder out (0: not left out)
     // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
@@ -167,6 +168,7 @@ private:
     // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
     // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
     bool cross_lane_ = true, early_intra_ = true;
+    int decoders_pending_ = 0;                      // under m_: decoders with pictures in pending_ (EngineDecoderState::n_pending)
     bool deep_queues_ = false;                      // engine thread: the decoders have many parsed pictures pending -- the engine is what they wait for (Engine::form)
     std::atomic<int> early_intra_ahead_{kEarlyIntraAhead};     // knob "early_intra_ahead" (tests)
     long long early_scan_ns_ = 0; unsigned long long early_scan_tag_ = 0;
