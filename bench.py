@@ -327,7 +327,7 @@ def measure(args, ctx):
     def eng():      # engine-wide counters (one engine per device serves every handle)
         return {k: {f: L.jm_amddec_get_stat(handles[0], f"k_{k}_{f}".encode()) for f in ("ns", "n", "pics", "alg_bytes")} for k in KN}
     LK = [b"eng_rej_other_lane", b"eng_rej_cross_lane", b"eng_rej_tables", b"eng_early_intra", b"eng_blocked_ns", b"eng_blocked_n", b"eng_forms"] + \
-         [f"eng_lane{i}_{f}".encode() for i in range(4) for f in ("busy_ns", "gap_ns", "batches", "pics")]
+         [f"eng_lane{i}_{f}".encode() for i in range(4) for f in ("busy_ns", "gap_ns", "batches", "pics", "upwait_ns", "prewait_ns", "dry")]
     def lanes_now(h=None):
         return {k.decode(): L.jm_amddec_get_stat(h or handles[0], k) for k in LK}
     def lanes_report(a, b_, wall_s):
@@ -344,7 +344,12 @@ def measure(args, ctx):
             if d[f"eng_lane{i}_batches"]:
                 out[nm] = {"batches": int(d[f"eng_lane{i}_batches"]), "pictures_per_batch": round(d[f"eng_lane{i}_pics"] / d[f"eng_lane{i}_batches"], 2),
                            "busy_frac": round(d[f"eng_lane{i}_busy_ns"] / 1e9 / wall_s, 3), "idle_between_batches_frac": round(d[f"eng_lane{i}_gap_ns"] / 1e9 / wall_s, 3),
-                           "kernel_ms_per_batch": round(d[f"eng_lane{i}_busy_ns"] / 1e6 / d[f"eng_lane{i}_batches"], 3)}
+                           "kernel_ms_per_batch": round(d[f"eng_lane{i}_busy_ns"] / 1e6 / d[f"eng_lane{i}_batches"], 3),
+                           # where the idle time went (H.264 lanes): the batch's job lists had not landed / its pre-pass had not finished when the previous
+                           # batch ended (fractions of wall time, the second includes the first); batches launched after the previous one had already ended
+                           "idle_waiting_for_job_lists_frac": round(d[f"eng_lane{i}_upwait_ns"] / 1e9 / wall_s, 3),
+                           "idle_waiting_for_pre_pass_frac": round(d[f"eng_lane{i}_prewait_ns"] / 1e9 / wall_s, 3),
+                           "batches_launched_after_the_lane_ran_dry": int(d[f"eng_lane{i}_dry"])}
         return out
     e0 = eng()
     ln0 = lanes_now()
@@ -809,15 +814,18 @@ def measure(args, ctx):
         line["host_memory"] = mem
     except Exception:
         pass
-    # what bounds this rank's rate: the PCIe link (frames leave at >= 90 % of the measured device->host rate), the host CPU allotment (the process keeps
-    # >= 90 % of its quota busy), or neither -- then the device side (engine lanes / kernels) is what is left
+    # what bounds this rank's rate, from three measured utilisations instead of by elimination: the PCIe link (frames leave at this fraction of the measured
+    # device->host rate), the host CPU allotment (share of the quota the process keeps busy), the device (share of the wall time the busiest engine lane's
+    # stream has kernels on it).  The highest one names the bound when it is >= 0.85; when nothing is that busy the pipeline in between is (batches formed late,
+    # uploads, callers): "engine_pipeline".
     q_cpus = hc1.get("quota_cpus") or os.cpu_count()
-    if line["pcie_out"] and line["pcie_out"]["frac"] >= 0.9:
-        bound = "pcie"
-    elif q_cpus and line["host_cpu"]["cpus_busy"] >= 0.9 * q_cpus / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))):
-        bound = "host_cpu_quota"
-    else:
-        bound = "gpu"
+    util = {"pcie": line["pcie_out"]["frac"] if line["pcie_out"] else None,
+            "host_cpu_quota": round(line["host_cpu"]["cpus_busy"] / (q_cpus / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))), 3) if q_cpus else None,
+            "gpu": max([v["busy_frac"] for v in lanes_timed.values() if isinstance(v, dict) and "busy_frac" in v] or [None], key=lambda x: -1 if x is None else x)}
+    known = {k: v for k, v in util.items() if v is not None}
+    top = max(known, key=known.get) if known else None
+    bound = top if top is not None and known[top] >= 0.85 else ("engine_pipeline" if known else None)
+    line["bound_utilisation"] = util
     line["scaling_bound"] = bound
     line["numa_node"] = numa_node
     if cpu is not None:

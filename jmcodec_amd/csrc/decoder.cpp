@@ -147,7 +147,7 @@ int Decoder::set_option(const char *key, long long v) {
     else if (k == "device_output") device_output_ = v != 0;        // frames stay in device memory (no D2H); see output_device()
     else if (k == "device") device_ = (int)v;
     else if (k == "profile") { profile_ = v != 0; if (engine_) engine_->set_profile(profile_); }
-    else if (k.rfind("chain_", 0) == 0 || k == "debug_stall" || k == "early_intra_ahead") {    // engine-wide knobs (every handle of the device), after init
+    else if (k.rfind("chain_", 0) == 0 || k == "debug_stall" || k == "debug_no_bi" || k == "early_intra_ahead") {    // engine-wide knobs (every handle of the device), after init
         if (!engine_ || !engine_->set_knob(k, v)) return -1;
     }
     else if (k == "wait_idle") {      // block until every dispatched picture has been executed by the device (no flush)
@@ -236,6 +236,9 @@ long long Decoder::get_stat(const char *key) const {
             const std::string l = std::to_string(i);
             if (k == "eng_lane" + l + "_busy_ns") return (long long)es.lane_busy_ns[i];
             if (k == "eng_lane" + l + "_gap_ns") return (long long)es.lane_gap_ns[i];
+            if (k == "eng_lane" + l + "_upwait_ns") return (long long)es.lane_upwait_ns[i];
+            if (k == "eng_lane" + l + "_prewait_ns") return (long long)es.lane_prewait_ns[i];
+            if (k == "eng_lane" + l + "_dry") return es.lane_dry[i];
             if (k == "eng_lane" + l + "_batches") return es.lane_batches[i];
             if (k == "eng_lane" + l + "_pics") return es.lane_pics[i];
         }

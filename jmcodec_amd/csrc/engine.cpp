@@ -54,11 +54,14 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LAG")) chain_lag_steps_ = std::max(kMinChainLag, std::min(atoi(e), 1024));
     if (const char *e = getenv("JM_AMD_DEC_CHAIN_LINGER")) chain_linger_streams_ = std::max(0, atoi(e));
     if (const char *e = getenv("JM_AMD_DEC_CROSS_LANE")) cross_lane_ = atoi(e) != 0;
+    if (const char *e = getenv("JM_AMD_DEC_FILL_LINGER_US")) fill_linger_ns_ = std::max(0, atoi(e)) * 1000ll;
     if (const char *e = getenv("JM_AMD_DEC_EARLY_INTRA")) early_intra_ = atoi(e) != 0;
     if (hipSetDevice(device_) != hipSuccess) return;
     hipStream_t c;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
-    copy_stream_ = c;
+    copy_stream_ = c; copy_streams_[0] = c;
+    if (const char *e = getenv("JM_AMD_DEC_COPY_STREAMS")) n_copy_ = std::max(1, std::min(atoi(e), 4));
+    for (int k = 1; k < n_copy_; k++) if (hipStreamCreateWithFlags(&copy_streams_[k], hipStreamNonBlocking) != hipSuccess) return;
     mem_trace("engine: copy stream");
     for (auto &ln : lanes_) {
         hipStream_t s, p, q;
@@ -110,9 +113,11 @@ Engine::Engine(int device) : device_(device) {
 unsigned long long Engine::upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev) {
     std::lock_guard<std::mutex> lk(um_);              // keeps (copy, event, sequence number) consistent with stream order
     hipSetDevice(device_);
-    hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, copy_stream_);
-    hipEventRecord(ev, copy_stream_);
-    return ++upload_seq_;
+    const unsigned long long seq = ++upload_seq_;
+    hipStream_t cs = copy_streams_[seq % (unsigned)n_copy_];
+    hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, cs);
+    hipEventRecord(ev, cs);
+    return seq;
 }
 
 void Engine::submit(EnginePic &&p) {
@@ -141,6 +146,7 @@ bool Engine::set_knob(const std::string &key, long long v) {
     else if (key == "chain_lag") chain_lag_steps_ = (int)std::max((long long)kMinChainLag, std::min(v, 1024ll));
     else if (key == "chain_streams") chain_max_streams_ = (int)std::max(0ll, v);
     else if (key == "debug_stall") debug_stall_ = (int)v;
+    else if (key == "debug_no_bi") debug_no_bi_ = (int)v;          // test aid: launch k_recon_inter WITHOUT its two-list code whatever the batch holds (the kernel must say so)
     else if (key == "early_intra_ahead") early_intra_ahead_ = (int)std::max(1ll, std::min(v, 64ll));      // (tests: 1 = run ahead whenever the hazards allow)
     else return false;
     return true;
@@ -212,6 +218,17 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             for (const EnginePic &p : pending_) if (p.codec == 0 && p.has_picture && p.lane(true) == lane_idx) n++;
             if (n < depth_now * n_active) return false;
         }
+    }
+    // Stage batches: `k_recon_inter` + `k_deblock` hold the lane for ~0.93 ms whatever the batch holds, so a batch should hold a picture of EVERY stream.  While a
+    // batch is running, the next one is not formed the moment the ring has room but when every active stream has something pending -- or fill_linger_ns_ after the
+    // running batch started, whichever comes first: it could not start before the running one ends anyway.  With deep queues (the engine is the bottleneck)
+    // everyone is there at once and nothing changes; with shallow ones (callers that wait for the PCIe link or for their parser) a batch formed at once held
+    // what had arrived since the last one: 16 pictures of 32 streams, the lane 88 % busy with half-empty launches at the same frame rate
+    // (profiles/r06_copy_streams.txt).  An idle lane never waits.
+    if (lane_idx == kOrdinaryLane && !chaining && ln.inflight > 0 && fill_linger_ns_ > 0) {
+        const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        // (the batch that is running now started when it was launched onto an idle lane, or when the one before it ended -- which the engine sees as its retirement)
+        if ((int)recent_.size() > decoders_pending_ && now - std::max(ln.last_launch_ns, ln.last_retire_ns) < fill_linger_ns_) return false;
     }
     std::vector<Decoder *> seen, members;
     const bool relaxed = cross_lane_ && !chaining;
@@ -406,11 +423,17 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
 void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size(), li = (int)(&ln - lanes_);
     b.serial = ++ln.launched; b.last_ev = -1;
+    ln.last_launch_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (profile_) {       // diagnostic: did the lane run dry -- had its previous batch's kernels already ended when this one is launched?
+        const Batch &pb = ln.ring[(ln.head + kBatchRing - 1) % kBatchRing];
+        if (pb.serial + 1 == b.serial && pb.kdone) { const bool ended = hipEventQuery(pb.kdone) == hipSuccess; (void)hipGetLastError();
+            if (ended) { std::lock_guard<std::mutex> lk(sm_); st_.lane_dry[li]++; } }
+    }
     LANE_TRACE("launch lane %d batch %llu pics %d\n", li, b.serial, n);
     int max_mbs = 0, max_mb_h = 0, max_mb_w = 0, max_w = 0, max_h = 0, stages = 0;
     bool wait_pack = false, any_hevc = false;
     HevcBatchDims hd;
-    const EnginePic *last_upload = nullptr;
+    const EnginePic *last_upload[4] = {nullptr, nullptr, nullptr, nullptr};      // per copy stream (upload k went to stream k % n_copy_)
     b.n_pre = b.n_post = 0; b.pmask = 0;
     for (int k = 0; k < 5; k++) { b.alg[k] = 0; b.npics[k] = 0; }
     // pack jobs: [0, n_pre) before the decode kernels, [2*kMaxBatch, 2*kMaxBatch + n_post) after them
@@ -455,7 +478,7 @@ void Engine::launch(Lane &ln, Batch &b) {
         }
         if (p.has_picture) {
             max_mbs = std::max(max_mbs, p.mb_w * p.mb_h); max_mb_h = std::max(max_mb_h, p.mb_h);
-            if (p.uploaded && (!last_upload || p.upload_seq > last_upload->upload_seq)) last_upload = &p;
+            if (p.uploaded) { const EnginePic *&lu = last_upload[p.upload_seq % (unsigned)n_copy_]; if (!lu || p.upload_seq > lu->upload_seq) lu = &p; }
         }
         if (p.wait_prev_pack) wait_pack = true;
         for (auto &j : p.out_before) b.h_jobs[b.n_pre++] = j;                           // form() keeps both tables within 2 * kMaxBatch
@@ -499,10 +522,12 @@ void Engine::launch(Lane &ln, Batch &b) {
     if (b.n_post) hipMemcpyAsync(b.d_jobs + 2 * kMaxBatch, b.h_jobs + 2 * kMaxBatch, sizeof(PackJob) * b.n_post, hipMemcpyHostToDevice, ps);
     // job lists were copied on the (in-order) copy stream when the pictures were parsed: waiting for the most recently
     // issued one of this batch covers them all without waiting for uploads of later pictures
-    if (last_upload) hipStreamWaitEvent(ps, last_upload->uploaded, 0);
+    for (const EnginePic *lu : last_upload) if (lu) hipStreamWaitEvent(ps, lu->uploaded, 0);
+    if (profile_ && !any_hevc) hipEventRecord(b.pev[8], ps);
     bool prep_early = false;
     if (!any_hevc) {
         if (stages & (PS_DEBLOCK_LDS | PS_CHAIN)) { launch_deblock_prep(b.d_pics, n, max_mbs, ps); prep_early = true; }
+        if (profile_) hipEventRecord(b.pev[9], ps);
         hipEventRecord(b.pre_done, ps);
         hipStreamWaitEvent(st, b.pre_done, 0);
     }
@@ -531,7 +556,7 @@ void Engine::launch(Lane &ln, Batch &b) {
     }
     b.any_bipred = b.any_field = false;
     for (auto &p : b.pics) { b.any_bipred |= p.has_picture && p.codec == 0 && p.bipred; b.any_field |= p.has_picture && p.codec == 0 && p.pp.field != 0; }
-    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred, b.any_field, b.d_err, st); b.pmask |= 2; }
+    if (stages & PS_RECON) { launch_recon_inter(b.d_pics, n, max_mbs, b.any_bipred && !debug_no_bi_, b.any_field, b.d_err, st); b.pmask |= 2; }
     if (!any_hevc) mark(2, st);
     if (stages & PS_INTRA_LDS) { launch_intra_lds(b.d_pics, n, max_mb_h, b.d_ctl, b.d_err, st); b.pmask |= 4; }
     if (stages & PS_INTRA_V1) { launch_recon_intra(b.d_pics, n, st); b.pmask |= 4; }
@@ -805,8 +830,13 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, b.pev[0], b.pev[b.last_ev]) == hipSuccess) st_.lane_busy_ns[li] += ms * 1e6;
             const Batch &pb = ln.ring[(ln.tail + kBatchRing - 1) % kBatchRing];       // (its events are recorded again three launches from now at the earliest)
-            if (pb.serial + 1 == b.serial && pb.last_ev >= 0 && hipEventElapsedTime(&ms, pb.pev[pb.last_ev], b.pev[0]) == hipSuccess && ms > 0)
+            if (pb.serial + 1 == b.serial && pb.last_ev >= 0 && hipEventElapsedTime(&ms, pb.pev[pb.last_ev], b.pev[0]) == hipSuccess && ms > 0) {
                 st_.lane_gap_ns[li] += ms * 1e6;
+                float mu = 0, mp = 0;
+                const bool h264 = !b.pics.empty() && b.pics[0].codec == 0;       // (the two pre-stream events are recorded for H.264 batches)
+                if (h264 && hipEventElapsedTime(&mu, pb.pev[pb.last_ev], b.pev[8]) == hipSuccess && mu > 0) st_.lane_upwait_ns[li] += std::min(mu, ms) * 1e6;
+                if (h264 && hipEventElapsedTime(&mp, pb.pev[pb.last_ev], b.pev[9]) == hipSuccess && mp > 0) st_.lane_prewait_ns[li] += std::min(mp, ms) * 1e6;
+            }
         }
         (void)hipGetLastError();
     }
@@ -874,6 +904,7 @@ void Engine::run() {
                     long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                     std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
+                ln.last_retire_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
                 progressed = true;
             }
         }

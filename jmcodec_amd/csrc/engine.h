@@ -97,6 +97,9 @@ struct EngineStats {
     long long early_intra = 0;                     // intra pictures launched ahead of their stream's earlier pictures (Engine::form)
     long long blocked_ns = 0, blocked_n = 0;       // time decoders spent left out of ordinary batches between two of their pictures joining one, and how often
     // per lane, from the profile events: time between a batch's first and last kernel, time its stream sat idle before it, batches and pictures
+    // where a lane's idle time between two batches went (diagnostic, profile mode): this batch's job lists had not all landed when the previous batch ended /
+    // its pre-pass (tables, deblocking pre-pass on the pre-stream) had not finished / it was only launched after the previous batch had ended (count)
+    double lane_upwait_ns[4] = {0, 0, 0, 0}, lane_prewait_ns[4] = {0, 0, 0, 0}; long long lane_dry[4] = {0, 0, 0, 0};
     double lane_busy_ns[4] = {0, 0, 0, 0}, lane_gap_ns[4] = {0, 0, 0, 0}; long long lane_batches[4] = {0, 0, 0, 0}, lane_pics[4] = {0, 0, 0, 0};
 };
 
@@ -148,7 +151,7 @@ private:
         uint32_t *h_groups = nullptr, *d_groups = nullptr;     // work list of k_chain (chain.hip), kMaxChainGroups entries
         PackJob *h_jobs = nullptr, *d_jobs = nullptr;         // 4 * kMaxBatch entries
         // packed: surfaces were read by k_packout (before the copies)
-        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[8] = {nullptr};
+        ihipEvent_t *done = nullptr, *kdone = nullptr, *packed = nullptr, *pre_done = nullptr, *pev[10] = {nullptr};
         std::vector<EnginePic> pics;
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
@@ -162,12 +165,14 @@ private:
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
         unsigned long long launched = 0;                       // batches launched on this lane so far
+        long long last_launch_ns = 0, last_retire_ns = 0;      // when the lane's most recent batch was launched / when one last retired (steady clock)
         std::vector<Decoder *> tainted;                        // decoders whose recovered pictures could not be redone from intact references (Engine::recover)
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
     // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
     bool cross_lane_ = true, early_intra_ = true;
+    long long fill_linger_ns_ = 600 * 1000;         // Engine::form: how long the ordinary lane's NEXT batch may wait for the streams that have nothing pending yet (JM_AMD_DEC_FILL_LINGER_US)
     int decoders_pending_ = 0;                      // under m_: decoders with pictures in pending_ (EngineDecoderState::n_pending)
     bool deep_queues_ = false;                      // engine thread: the decoders have many parsed pictures pending -- the engine is what they wait for (Engine::form)
     std::atomic<int> early_intra_ahead_{kEarlyIntraAhead};     // knob "early_intra_ahead" (tests)
@@ -201,7 +206,8 @@ private:
     // another process has queues on this GPU (checked about once a second): no chain launches
     unsigned kfd_gpu_id_ = 0; std::atomic<bool> gpu_shared_{false}; std::atomic<long long> shared_checked_ns_{0};
     void look_for_other_users();                    // engine thread, no lock held
-    ihipStream_t *copy_stream_ = nullptr;
+    ihipStream_t *copy_stream_ = nullptr;           // job-list uploads (Engine::upload); copy_streams_[0]
+    ihipStream_t *copy_streams_[4] = {nullptr, nullptr, nullptr, nullptr}; int n_copy_ = 2;     // upload k goes to stream k % n_copy_ (JM_AMD_DEC_COPY_STREAMS)
     std::mutex um_; unsigned long long upload_seq_ = 0;
     Lane lanes_[kLanes];
     std::mutex m_; std::condition_variable cv_;
@@ -209,6 +215,7 @@ private:
     bool profile_ = false, ok_ = false, device_failed_ = false;
     // test hook: 1 = no band publishes its step counter (stage kernels and chain launches), 2 = chain launches only
     std::atomic<int> debug_stall_{0};
+    std::atomic<int> debug_no_bi_{0};
     std::atomic<int> fetchers_{0};
     // no chain launches before this time (set when one had to be recovered; setting a chain knob clears it)
     std::atomic<long long> chain_block_until_ns_{0};

@@ -287,7 +287,9 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
     const bool bipred = HAS_BI && inter && (r.modes & MBM_BIPRED);
     // (an instantiation without the two-list code that meets such a record all the same -- a future producer that breaks the invariant above -- says so
     //  through the picture's error word instead of decoding the record as a plain one; the picture is then reported as damaged, never silently wrong)
-    if (!HAS_BI && inter && (r.modes & MBM_BIPRED) && cv.err && (threadIdx.x & 63) == 0) report_wait_timeout(cv.err + blockIdx.y, CHAIN_ERR_BAD_RECORD);
+    // (reported at the END of the wave's work: a store to memory the compiler knows nothing about, placed here, turned every later scalar load of the picture's
+    //  parameters and of the record into a vector load -- + 5 % vector instructions per macroblock, profiles/r06_sq_counters_c1.json)
+    const bool bad_record = !HAS_BI && inter && (r.modes & MBM_BIPRED);
     const bool plain = inter && !bipred;
     bool fast = false;
     uint32_t wv[5] = {0, 0, 0, 0, 0};                       // this lane's dwords of the 13x13 reference window (fast path)
@@ -702,6 +704,7 @@ __device__ __forceinline__ void recon_inter_wave(const PicParams &pp, int mb, bo
         if (lane < 16) gst_u4(dst + (size_t)(mby * 16 + lane) * pitch + mbx * 16, *(const uint4 *)(ot + lane * 4));
         else if (lane < 24) gst_u4(dst_c + (size_t)(mby * 8 + lane - 16) * pitch + mbx * 16, *(const uint4 *)(ot + 64 + (lane - 16) * 4));
     }
+    if (bad_record && cv.err && lane == 0) report_wait_timeout(cv.err + blockIdx.y, CHAIN_ERR_BAD_RECORD);
 }
 
 }  // namespace jmamd

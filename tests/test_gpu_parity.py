@@ -854,6 +854,29 @@ def test_damaged_handover_is_reported_not_silent():
         assert d.stat("errors") == 0
 
 
+def test_kernel_without_two_list_code_says_so_when_it_meets_a_two_list_record():
+    """k_recon_inter<HAS_BI = false> -- the instantiation for batches that hold no B / weighted picture -- must not decode a two-list record as a
+    plain one if a future producer ever hands it one.  Debug option "debug_no_bi" launches that instantiation whatever the batch holds: on a stream with B
+    pictures the handle reports errors, device_wait_errors and names the cause; without the option the same handle type decodes the stream cleanly."""
+    data = streams.generate(width=320, height=240, frames=9, gop=9, seed=41, cabac=1, bframes=2, num_ref=2, poc_type=0)
+    lib = api.lib()
+    with api.JmAmdDec(0, 1) as d:
+        lib.jm_amddec_set_option(d.h, b"chain_depth", 1)
+        lib.jm_amddec_set_option(d.h, b"debug_no_bi", 1)
+        try:
+            frames = d.decode_stream(None, chunks=[data])
+            errs, werrs, msg = d.stat("errors"), d.stat("device_wait_errors"), lib.jm_amddec_last_error(d.h).decode()
+        finally:
+            lib.jm_amddec_set_option(d.h, b"debug_no_bi", 0)
+            lib.jm_amddec_set_option(d.h, b"chain_depth", 0)
+    assert len(frames) == 9                       # the pipeline still completes
+    assert werrs > 0 and errs >= werrs
+    assert "compiled without" in msg, msg
+    with api.JmAmdDec(0, 1) as d:                 # and the engine is healthy afterwards
+        assert b"".join(d.decode_stream(data)) == b"".join(gpu_decode(data))
+        assert d.stat("errors") == 0
+
+
 def test_chain_launch_that_runs_out_of_time_is_decoded_again(oracle):
     """A chain launch assumes it can keep its bands resident; on a GPU it shares (another process, a long kernel of another stream) a wait inside it
     can run out of time.  That must cost time, not correctness: the engine decodes the launch's pictures -- and those of the lane's next batch, which
