@@ -394,7 +394,7 @@ void Decoder::free_out_slots(bool all) {
         delete o;
     }
     all_out_ = keep; free_out_.clear();
-    if (all) { ready_.clear(); cur_out_ = nullptr; }
+    if (all) { ready_.clear(); done_unfetched_ = 0; cur_out_ = nullptr; }
 }
 void Decoder::gpu_close() {
     if (!gpu_open_) { for (OutSlot *o : all_out_) delete o; all_out_.clear(); free_job_buffers(); return; }      // (parse-only handles: plain malloc)
@@ -1459,7 +1459,7 @@ void Decoder::enqueue_output(int slot_and_lone, std::vector<PackJob> &jobs, std:
     const int slot = slot_and_lone & 255, lone = slot_and_lone >> 8;       // store_done: bits 8.. = the one field that was decoded, if only one was
     OutSlot *o;
     { std::lock_guard<std::mutex> lk(mtx_); o = alloc_out_slot(); ready_.push_back(o); num_frames_++; }   // nv_dec.cpp:48 num_frames++
-    if (parse_only_ || failed_) { std::lock_guard<std::mutex> lk(mtx_); o->ready = true; return; }
+    if (parse_only_ || failed_) { std::lock_guard<std::mutex> lk(mtx_); o->ready = true; done_unfetched_++; return; }
     // k_packout packs the tight frame into device staging and a copy engine moves it to the pinned slot -- or, in direct mode,
     // the kernel stores straight into the pinned host slot (see Engine::launch for why the copy engine is the default)
     // (a frame of which only one field was decoded is shown with that field's lines repeated: PackJob.lone_field)
@@ -1564,6 +1564,7 @@ void Decoder::on_engine_done(const EnginePic &p, bool failed) {
         }
         for (OutSlot *o : p.slots_before) { o->ready = true; if (failed) o->has_data = false; }
         for (OutSlot *o : p.slots_after) { o->ready = true; if (failed) o->has_data = false; }
+        done_unfetched_ += (int)(p.slots_before.size() + p.slots_after.size());
         outstanding_--;
         cv_.notify_all();                  // under the lock: the handle may be destroyed as soon as the count reaches zero
     }
@@ -1588,7 +1589,7 @@ int Decoder::pop_output(bool block, int wait_us) {
             // go out anyway (they hold output slots).  The end of the stream (block) drains everything.
             if (!block && outstanding_ < display_delay_ && (int)ready_.size() <= 6) return 0;
             if (!o->ready) { if (!block) { if (nap()) continue; return 0; } cv_.wait(lk); continue; }
-            ready_.pop_front();
+            ready_.pop_front(); done_unfetched_--;
             cur_out_ = o;
             return 1;
         }

@@ -152,6 +152,8 @@ public:
     void on_engine_done(const struct EnginePic &p, bool failed = false);
     void on_device_wait_error(int code);       // engine: a kernel's bounded wait gave up while this handle's picture was decoded
     struct EngineDecoderState &engine_state() { return *eng_state_; }
+    // display frames that are decoded and packed and that the caller has not fetched yet (the engine asks: is this handle's next picture urgent?)
+    int frames_done_unfetched() const { return done_unfetched_.load(std::memory_order_relaxed); }
 
 private:
     // ---- front end (caller thread) ----
@@ -242,6 +244,7 @@ private:
     BigJobBuf big_[kBigJobBufs];               // see acquire_job_slot
     void free_job_buffers();
     std::deque<OutSlot *> ready_;              // display order
+    std::atomic<int> done_unfetched_{0};       // entries of ready_ whose samples are there (OutSlot::ready)
     std::vector<OutSlot *> free_out_, all_out_;
     OutSlot *cur_out_ = nullptr;
     int outstanding_ = 0, parse_pending_ = 0;                      // tasks pushed and not yet submitted

@@ -219,16 +219,51 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             if (n < depth_now * n_active) return false;
         }
     }
-    // Stage batches: `k_recon_inter` + `k_deblock` hold the lane for ~0.93 ms whatever the batch holds, so a batch should hold a picture of EVERY stream.  While a
-    // batch is running, the next one is not formed the moment the ring has room but when every active stream has something pending -- or fill_linger_ns_ after the
-    // running batch started, whichever comes first: it could not start before the running one ends anyway.  With deep queues (the engine is the bottleneck)
-    // everyone is there at once and nothing changes; with shallow ones (callers that wait for the PCIe link or for their parser) a batch formed at once held
-    // what had arrived since the last one: 16 pictures of 32 streams, the lane 88 % busy with half-empty launches at the same frame rate
-    // (profiles/r06_copy_streams.txt).  An idle lane never waits.
-    if (lane_idx == kOrdinaryLane && !chaining && ln.inflight > 0 && fill_linger_ns_ > 0) {
+    // Stage batches: `k_recon_inter` + `k_deblock` hold the lane for ~0.93 ms whatever the batch holds, so a batch should hold a picture of EVERY stream.  With deep
+    // queues (the engine is the bottleneck) everyone is there at once.  With shallow ones a batch formed the moment something is pending holds what arrived since
+    // the last one -- 16 pictures of 32 streams at 16.5 k frames/s, the lane 88 % busy with half-empty launches (profiles/r06_copy_streams.txt).  So a batch
+    // waits for the streams that have nothing pending yet -- but only while nobody is in a hurry: a picture is URGENT when its handle has no decoded frame left
+    // that its caller has not fetched (a caller that waits for the PCIe link has a frame or two in hand: its next picture can wait a millisecond; a caller that
+    // waits for its parser or for the engine has none: its picture goes at once).  At most fill_linger_ns_ after the first picture could have gone.
+    if (lane_idx == kOrdinaryLane && !chaining && fill_linger_ns_ > 0 && (int)recent_.size() > decoders_pending_) {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        // (the batch that is running now started when it was launched onto an idle lane, or when the one before it ended -- which the engine sees as its retirement)
-        if ((int)recent_.size() > decoders_pending_ && now - std::max(ln.last_launch_ns, ln.last_retire_ns) < fill_linger_ns_) return false;
+        if (!ln.wait_since_ns) ln.wait_since_ns = now;
+        if (now - ln.wait_since_ns < fill_linger_ns_) {
+            bool urgent = false; size_t n_seen = 0; const size_t n_dec = (size_t)decoders_pending_;
+            scan_tag_form_++;
+            for (auto it = pending_.begin(); it != pending_.end() && n_seen < n_dec && !urgent; ++it) {
+                EngineDecoderState &es = it->dec->engine_state();
+                if (es.form_tag == scan_tag_form_) continue;            // only a decoder's oldest pending picture counts
+                es.form_tag = scan_tag_form_; n_seen++;
+                if (it->lane(false) != lane_idx || es.inflight > es.lane_inflight[lane_idx]) continue;      // (not for this batch anyway)
+                urgent = it->dec->frames_done_unfetched() < 1;
+            }
+            if (!urgent) return false;
+        }
+    }
+    if (lane_idx == kOrdinaryLane) ln.wait_since_ns = 0;
+    // The intra lane alike: `k_recon_inter` + `k_intra_band` + `k_deblock` hold it for ~1.8 ms whether the batch holds one I picture or ten, and with shallow queues
+    // I pictures come one at a time (32 streams, one in 30 pictures: one every 1.8 ms).  While nobody is in a hurry a batch waits for the fourth.
+    // (Deep queues: the early launches above all; chain launches keep their I pictures on the ordinary lane.)
+    if (lane_idx == kIntraLane && !chaining && !deep_queues_ && fill_linger_ns_ > 0) {
+        const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (!ln.wait_since_ns || now - ln.wait_since_ns < fill_linger_ns_) {
+            bool urgent = false; int n_elig = 0; size_t n_seen = 0; const size_t n_dec = (size_t)decoders_pending_;
+            scan_tag_form_++;
+            for (auto it = pending_.begin(); it != pending_.end() && n_seen < n_dec && !urgent && n_elig < 4; ++it) {
+                EngineDecoderState &es = it->dec->engine_state();
+                if (es.form_tag == scan_tag_form_) continue;
+                es.form_tag = scan_tag_form_; n_seen++;
+                if (it->codec != 0 || it->lane(false) != lane_idx) continue;
+                if (es.inflight > es.lane_inflight[lane_idx] && !(cross_lane_ && others_done(it->dec, lane_idx, it->seq))) continue;
+                n_elig++;
+                urgent = it->dec->frames_done_unfetched() < 1;
+            }
+            if (n_elig == 0) return false;
+            if (!ln.wait_since_ns) ln.wait_since_ns = now;
+            if (n_elig < 4 && !urgent && now - ln.wait_since_ns < fill_linger_ns_) return false;
+        }
+        ln.wait_since_ns = 0;
     }
     std::vector<Decoder *> seen, members;
     const bool relaxed = cross_lane_ && !chaining;
@@ -423,7 +458,6 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
 void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size(), li = (int)(&ln - lanes_);
     b.serial = ++ln.launched; b.last_ev = -1;
-    ln.last_launch_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (profile_) {       // diagnostic: did the lane run dry -- had its previous batch's kernels already ended when this one is launched?
         const Batch &pb = ln.ring[(ln.head + kBatchRing - 1) % kBatchRing];
         if (pb.serial + 1 == b.serial && pb.kdone) { const bool ended = hipEventQuery(pb.kdone) == hipSuccess; (void)hipGetLastError();
@@ -904,7 +938,6 @@ void Engine::run() {
                     long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                     std::lock_guard<std::mutex> lk(sm_); st_.complete_ns += ns; }
                 ln.tail = (ln.tail + 1) % kBatchRing; ln.inflight--;
-                ln.last_retire_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
                 progressed = true;
             }
         }

@@ -110,6 +110,7 @@ struct EngineDecoderState {
     uint32_t displayed[4] = {0, 0, 0, 0};           // per lane: surfaces displayed by this decoder's pictures in the lane's most recently launched batch
     unsigned long long next_seq = 0;                // decode-order numbering of the decoder's pictures (Engine::submit, m_)
     int n_pending = 0;                              // the decoder's pictures in Engine::pending_ (m_)
+    unsigned long long form_tag = 0;                // scratch of Engine::form's look for urgent pictures
     unsigned long long scan_tag = 0; uint32_t scan_touched = 0; int scan_ahead = 0; bool scan_closed = false;   // scratch of the look for intra pictures (Engine::form)
     long long blocked_since = 0;                    // diagnostic: when an ordinary-lane batch first left this decoder out (0: not left out)
     // scratch of Engine::form (one batch at a time): what the decoder's pictures already in the batch write / read
@@ -165,14 +166,15 @@ private:
         Batch ring[kBatchRing];
         int head = 0, tail = 0, inflight = 0;
         unsigned long long launched = 0;                       // batches launched on this lane so far
-        long long last_launch_ns = 0, last_retire_ns = 0;      // when the lane's most recent batch was launched / when one last retired (steady clock)
+        long long wait_since_ns = 0;                           // Engine::form: since when the lane's next batch has been waiting for the streams that have nothing pending (0: not waiting)
         std::vector<Decoder *> tainted;                        // decoders whose recovered pictures could not be redone from intact references (Engine::recover)
     };
     bool form(Lane &ln, int lane_idx, Batch &b);              // m_ held
     // Round 6 (Engine::form): cross_lane_ -- a decoder changes lane as soon as the DEVICE is done with its pictures on the other lane (event query), not when
     // the host has retired them; early_intra_ -- an intra-only picture runs ahead of its stream's earlier pictures when nothing they touch is its surface
     bool cross_lane_ = true, early_intra_ = true;
-    long long fill_linger_ns_ = 600 * 1000;         // Engine::form: how long the ordinary lane's NEXT batch may wait for the streams that have nothing pending yet (JM_AMD_DEC_FILL_LINGER_US)
+    long long fill_linger_ns_ = 4000 * 1000;        // Engine::form: how long the ordinary lane's next stage batch may wait for the streams that have nothing pending yet, while no picture is urgent (JM_AMD_DEC_FILL_LINGER_US)
+    unsigned long long scan_tag_form_ = 0;
     int decoders_pending_ = 0;                      // under m_: decoders with pictures in pending_ (EngineDecoderState::n_pending)
     bool deep_queues_ = false;                      // engine thread: the decoders have many parsed pictures pending -- the engine is what they wait for (Engine::form)
     std::atomic<int> early_intra_ahead_{kEarlyIntraAhead};     // knob "early_intra_ahead" (tests)

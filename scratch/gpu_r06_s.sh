@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6: the fill linger on both stage lanes (ordinary: every stream; intra: four pictures; nobody urgent): 0 / 2000 / 4000 us.  Two copy streams.
+mkdir -p gpurun_out/s; O=gpurun_out/s
+for i in 1 2 3 4; do
+  for l in 0 2000 4000; do
+    JM_AMD_DEC_FILL_LINGER_US=$l python bench.py --no-extra --no-cpu-baseline --no-single > $O/host_l${l}_$i.json 2> $O/host_l${l}_$i.err
+  done
+done
+for i in 1 2; do
+  for l in 0 4000; do
+    JM_AMD_DEC_FILL_LINGER_US=$l python bench.py --tools high --no-extra --no-cpu-baseline --no-single > $O/high_l${l}_$i.json 2> $O/high_l${l}_$i.err
+    JM_AMD_DEC_FILL_LINGER_US=$l python bench.py --device-output --no-extra --no-cpu-baseline --no-single --steps 10 > $O/dev_l${l}_$i.json 2> $O/dev_l${l}_$i.err
+    JM_AMD_DEC_FILL_LINGER_US=$l python bench.py --tools high_b --width 3840 --height 2160 --streams 16 --frames 24 --steps 3 --no-extra --no-cpu-baseline --no-single > $O/c2_l${l}_$i.json 2> $O/c2_l${l}_$i.err
+  done
+done
+python - <<'PY'
+import json, glob, os
+for f in sorted(glob.glob('gpurun_out/s/*.json')):
+    try: d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e: print(os.path.basename(f), 'NO LINE'); continue
+    e = d["engine"]; ln = e.get("lanes", {}); o = ln.get("ordinary", {}); it = ln.get("intra", {}); r = d["roofline"]
+    print(os.path.basename(f), d["value"], d["bit_exact"], d["scaling_bound"], "cpus", d["host_cpu"]["cpus_busy"], "ord", o.get("pictures_per_batch"), "busy", o.get("busy_frac"),
+          "of", o.get("batches"), "intra", it.get("batches"), it.get("pictures_per_batch"), it.get("busy_frac"), "roofline", r["kernel"], r["frac"], r["pictures_per_launch"], "pcie", (d.get("pcie_out") or {}).get("frac"))
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pushpull.py -m gpu -q -x 2>&1 | tail -3
