@@ -110,10 +110,11 @@ Engine::Engine(int device) : device_(device) {
     th_.detach();
 }
 
-unsigned long long Engine::upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev) {
+unsigned long long Engine::upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev, bool spread) {
     std::lock_guard<std::mutex> lk(um_);              // keeps (copy, event, sequence number) consistent with stream order
     hipSetDevice(device_);
-    const unsigned long long seq = ++upload_seq_;
+    unsigned long long seq = ++upload_seq_;
+    if (!spread) while (seq % (unsigned)n_copy_) seq = ++upload_seq_;      // (the stream is seq mod n_copy_: Engine::launch finds it again from the number)
     hipStream_t cs = copy_streams_[seq % (unsigned)n_copy_];
     hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, cs);
     hipEventRecord(ev, cs);
@@ -458,9 +459,11 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
 void Engine::launch(Lane &ln, Batch &b) {
     const int n = (int)b.pics.size(), li = (int)(&ln - lanes_);
     b.serial = ++ln.launched; b.last_ev = -1;
+    b.launched_dry = false;
     if (profile_) {       // diagnostic: did the lane run dry -- had its previous batch's kernels already ended when this one is launched?
         const Batch &pb = ln.ring[(ln.head + kBatchRing - 1) % kBatchRing];
         if (pb.serial + 1 == b.serial && pb.kdone) { const bool ended = hipEventQuery(pb.kdone) == hipSuccess; (void)hipGetLastError();
+            b.launched_dry = ended;
             if (ended) { std::lock_guard<std::mutex> lk(sm_); st_.lane_dry[li]++; } }
     }
     LANE_TRACE("launch lane %d batch %llu pics %d\n", li, b.serial, n);
@@ -868,8 +871,9 @@ void Engine::complete(Lane &ln, Batch &b, bool failed) {
                 st_.lane_gap_ns[li] += ms * 1e6;
                 float mu = 0, mp = 0;
                 const bool h264 = !b.pics.empty() && b.pics[0].codec == 0;       // (the two pre-stream events are recorded for H.264 batches)
-                if (h264 && hipEventElapsedTime(&mu, pb.pev[pb.last_ev], b.pev[8]) == hipSuccess && mu > 0) st_.lane_upwait_ns[li] += std::min(mu, ms) * 1e6;
-                if (h264 && hipEventElapsedTime(&mp, pb.pev[pb.last_ev], b.pev[9]) == hipSuccess && mp > 0) st_.lane_prewait_ns[li] += std::min(mp, ms) * 1e6;
+                // (a batch launched onto a lane that had already run dry waited for nothing: the idle time before it is the lane's, not its uploads')
+                if (h264 && !b.launched_dry && hipEventElapsedTime(&mu, pb.pev[pb.last_ev], b.pev[8]) == hipSuccess && mu > 0) st_.lane_upwait_ns[li] += std::min(mu, ms) * 1e6;
+                if (h264 && !b.launched_dry && hipEventElapsedTime(&mp, pb.pev[pb.last_ev], b.pev[9]) == hipSuccess && mp > 0) st_.lane_prewait_ns[li] += std::min(mp, ms) * 1e6;
             }
         }
         (void)hipGetLastError();

@@ -124,7 +124,9 @@ public:
     static Engine *get(int device);                 // creates the engine (and its thread) on first use; nullptr on HIP failure
     void submit(EnginePic &&p);                     // decode order per decoder; thread-safe
     // async H2D of a parsed job list on the engine's copy stream; records `ev` behind it and returns its sequence number
-    unsigned long long upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev);
+    // spread = false: always copy stream 0 (HEVC: its few, large job lists gained nothing from a second stream and its parse threads paid 5-12 % more CPU
+    // per frame for it, profiles/r06_copy_streams.txt)
+    unsigned long long upload(uint8_t *dev, const uint8_t *host, size_t n, ihipEvent_t *ev, bool spread = true);
     void set_profile(bool on) { profile_ = on; }
     // threads currently inside a synchronous device-to-host frame copy (jm_nvdec_output_frame, fetch route): the copies of a device run one after another
     int  fetchers() const { return fetchers_.load(std::memory_order_relaxed); }
@@ -157,6 +159,7 @@ private:
         int n_pre = 0, n_post = 0; unsigned pmask = 0;
         long long alg[5] = {0, 0, 0, 0, 0}; int npics[5] = {0, 0, 0, 0, 0};
         int last_ev = -1;                                     // index of the profile event behind the batch's last decode kernel
+        bool launched_dry = false;                            // diagnostic: the lane's previous batch had already ended when this one was launched
         unsigned long long serial = 0;                        // position of the batch in its lane's sequence of launches
     };
     struct Lane {

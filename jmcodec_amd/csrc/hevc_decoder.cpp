@@ -296,7 +296,7 @@ void Decoder::hevc_parse_task(PicTask *t) {
             job_digest_ = h;
         }
         stat_pictures_++; stat_job_bytes_ += (long long)off; stat_intra_mbs_ += jobs.n_intra_cu; stat_coef_ += (long long)jobs.coefs.size();
-        if (!parse_only_ && !failed_) t->upload_seq = engine_->upload(js.dev, js.host, off, js.uploaded);
+        if (!parse_only_ && !failed_) t->upload_seq = engine_->upload(js.dev, js.host, off, js.uploaded, false);
     }
     {
         long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pt0).count();
