@@ -61,7 +61,6 @@ Engine::Engine(int device) : device_(device) {
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
     copy_stream_ = c; copy_streams_[0] = c;
     if (const char *e = getenv("JM_AMD_DEC_COPY_STREAMS")) n_copy_ = std::max(1, std::min(atoi(e), 4));
-    for (int k = 1; k < n_copy_; k++) if (hipStreamCreateWithFlags(&copy_streams_[k], hipStreamNonBlocking) != hipSuccess) return;
     mem_trace("engine: copy stream");
     for (auto &ln : lanes_) {
         hipStream_t s, p, q;
@@ -103,6 +102,10 @@ Engine::Engine(int device) : device_(device) {
           "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_,
           chain_bands_max_intra_); }
     mem_trace("engine: occupancy queries");
+    // The further copy streams are created LAST: the runtime deals streams to its hardware queues in the order they are created, and a second copy stream created
+    // beside the first moved every lane's streams to other queues -- the HEVC lane's kernels onto the queue of copy stream 0, behind that codec's multi-megabyte
+    // uploads: C3 and C2 -8 % with the stream merely existing (profiles/r06_copy_streams.txt).
+    for (int k = 1; k < n_copy_; k++) if (hipStreamCreateWithFlags(&copy_streams_[k], hipStreamNonBlocking) != hipSuccess) return;
     ok_ = true;
     numa_node_ = numa_node_of_device(device_, true);
     kfd_gpu_id_ = getenv("JM_AMD_DEC_IGNORE_SHARED_GPU") ? 0 : kfd_gpu_id_of_device(device_);
