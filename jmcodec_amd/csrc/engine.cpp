@@ -57,10 +57,18 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = getenv("JM_AMD_DEC_FILL_LINGER_US")) fill_linger_ns_ = std::max(0, atoi(e)) * 1000ll;
     if (const char *e = getenv("JM_AMD_DEC_EARLY_INTRA")) early_intra_ = atoi(e) != 0;
     if (hipSetDevice(device_) != hipSuccess) return;
-    hipStream_t c;
-    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return;
-    copy_stream_ = c; copy_streams_[0] = c;
+    // The copy streams (job-list uploads) get a stream priority of their own: the runtime keeps a separate pool of hardware queues per priority, so an upload
+    // never shares a queue with a lane's kernels -- which streams share one is otherwise decided by the order in which the runtime first sees them, and this round
+    // met both outcomes by accident (a second copy stream created beside the first: C3 / C2 -8 %; created last: 8 streams -19 %; profiles/r06_copy_streams.txt).
     if (const char *e = getenv("JM_AMD_DEC_COPY_STREAMS")) n_copy_ = std::max(1, std::min(atoi(e), 4));
+    int prio_lo = 0, prio_hi = 0, copy_prio = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // (numerically lower = higher priority)
+    { const char *e = getenv("JM_AMD_DEC_COPY_PRIORITY"); const int want = e ? atoi(e) : 1;      // 1 = high (default), 0 = the lanes' own, -1 = low
+      copy_prio = want > 0 ? prio_hi : (want < 0 ? prio_lo : 0); }
+    for (int k = 0; k < n_copy_; k++) if (hipStreamCreateWithPriority(&copy_streams_[k], hipStreamNonBlocking, copy_prio) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipStreamCreateWithFlags(&copy_streams_[k], hipStreamNonBlocking) != hipSuccess) return; }
+    copy_stream_ = copy_streams_[0];
     mem_trace("engine: copy stream");
     for (auto &ln : lanes_) {
         hipStream_t s, p, q;
@@ -102,10 +110,6 @@ Engine::Engine(int device) : device_(device) {
           "jm_amd_dec: device %d holds %d / %d chain workgroups (plain / with the intra role): band budget %d / %d\n", device_, r, ri, chain_bands_max_,
           chain_bands_max_intra_); }
     mem_trace("engine: occupancy queries");
-    // The further copy streams are created LAST: the runtime deals streams to its hardware queues in the order they are created, and a second copy stream created
-    // beside the first moved every lane's streams to other queues -- the HEVC lane's kernels onto the queue of copy stream 0, behind that codec's multi-megabyte
-    // uploads: C3 and C2 -8 % with the stream merely existing (profiles/r06_copy_streams.txt).
-    for (int k = 1; k < n_copy_; k++) if (hipStreamCreateWithFlags(&copy_streams_[k], hipStreamNonBlocking) != hipSuccess) return;
     ok_ = true;
     numa_node_ = numa_node_of_device(device_, true);
     kfd_gpu_id_ = getenv("JM_AMD_DEC_IGNORE_SHARED_GPU") ? 0 : kfd_gpu_id_of_device(device_);
