@@ -76,7 +76,7 @@ int  jm_amddec_set_option(jm_amddec_handle h, const char *key, long long value);
 /* keys: "frames", "pictures", "job_bytes", "errors", "intra_mbs", "coef_int16", "syntax_digest",
  *       "digest_mbs", "i_pictures", "p_pictures", "coded_width", "coded_height", "pitch", "device",
  *       "threads", "elapsed_us", "display_poc:<n>", "fps_num" / "fps_den" (frame rate from the VUI timing information, 0 / 0 = not transmitted),
- *       "frames_waiting" (display frames decided and not yet made current by a decode / poll call), "device_wait_errors", "direct_frames" / "direct_ns" (frames that left by one copy-engine
+ *       "frames_waiting" (display frames decided and not yet made current by a decode / poll call), "frames_done_unfetched" (those of them whose samples are there), "device_wait_errors", "direct_frames" / "direct_ns" (frames that left by one copy-engine
  *       transfer into the caller's buffer, and the time their callers waited), "copy_engines" (SDMA engines used for that, bit mask),
  *       "job_digest", "eng_*" / "k_*" (engine and per-kernel counters, bench.py) */
 long long jm_amddec_get_stat(jm_amddec_handle h, const char *key);

@@ -186,6 +186,7 @@ long long Decoder::get_stat(const char *key) const {
     if (k == "fps_num") return codec_ == 1 ? (long long)hsps_.time_scale : (long long)seq_.time_scale;
     if (k == "fps_den") return codec_ == 1 ? (long long)hsps_.num_units_in_tick : 2ll * seq_.num_units_in_tick;
     // display frames decided and not yet made current by a decode / poll call (finished or still on the device)
+    if (k == "frames_done_unfetched") return (long long)frames_done_unfetched();
     if (k == "frames_waiting") { std::lock_guard<std::mutex> lk(const_cast<std::mutex &>(mtx_)); return (long long)ready_.size(); }
     // pictures dispatched (being parsed, waiting for the engine, on the device) whose completion the handle has not seen yet
     if (k == "pictures_in_flight") { std::lock_guard<std::mutex> lk(const_cast<std::mutex &>(mtx_)); return (long long)outstanding_; }

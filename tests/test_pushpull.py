@@ -91,6 +91,8 @@ def test_input_buffer_and_feeder_hold_off():
     time.sleep(0.05)
     waiting, pics = L.jm_amddec_get_stat(dec, b"frames_waiting"), L.jm_amddec_get_stat(dec, b"pictures")
     assert 64 <= waiting < 300 and pics < 300, (waiting, pics)                   # held back: a 64 KB piece beyond the limit at most
+    # (the engine's urgency rule reads this count: display frames whose samples are there and that nobody has fetched -- in parse-only mode every queued frame)
+    assert L.jm_amddec_get_stat(dec, b"frames_done_unfetched") == waiting
     assert api.jm_intel_dec_free_buf_len(h) < MB                                 # ... with input still in the buffer
     out = C.create_string_buffer(96 * 80 * 3 // 2)
     # a size query and a too-small buffer leave the frame where it is (jm_intel_dec.h:69-78, intel_dec.cpp:266-270)
@@ -108,6 +110,7 @@ def test_input_buffer_and_feeder_hold_off():
         if api.jm_intel_dec_output_frame(out, len(out), h)[0] == 0:
             got += 1
     assert got == 300
+    assert L.jm_amddec_get_stat(dec, b"frames_done_unfetched") == 0
     assert "Frame Count:\t300" in api.jm_intel_dec_info(h)
     api.jm_intel_dec_deinit(h)
 
