@@ -246,7 +246,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
                 if (it->lane(false) != lane_idx || es.inflight > es.lane_inflight[lane_idx]) continue;      // (not for this batch anyway)
                 urgent = it->dec->frames_done_unfetched() < 1;
             }
-            if (!urgent) return false;
+            if (!urgent) { lingered_ = true; return false; }
         }
     }
     if (lane_idx == kOrdinaryLane) ln.wait_since_ns = 0;
@@ -269,7 +269,7 @@ bool Engine::form(Lane &ln, int lane_idx, Batch &b) {
             }
             if (n_elig == 0) return false;
             if (!ln.wait_since_ns) ln.wait_since_ns = now;
-            if (n_elig < 4 && !urgent && now - ln.wait_since_ns < fill_linger_ns_) return false;
+            if (n_elig < 4 && !urgent && now - ln.wait_since_ns < fill_linger_ns_) { lingered_ = true; return false; }
         }
         ln.wait_since_ns = 0;
     }
@@ -953,6 +953,7 @@ void Engine::run() {
             }
         }
         // 2. launch: at most two batches queued per lane, so that while they run new pictures pile up and batches stay full
+        lingered_ = false;
         for (int li = 0; li < kLanes; li++) {
             Lane &ln = lanes_[li];
             static const int max_inflight = getenv("JM_AMD_DEC_INFLIGHT") ? atoi(getenv("JM_AMD_DEC_INFLIGHT")) : 2;
@@ -976,7 +977,9 @@ void Engine::run() {
         // 3. nothing to do right now
         bool busy = false;
         for (auto &ln : lanes_) busy |= ln.inflight > 0;
-        if (busy) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        // (a batch that waits for its missing streams -- Engine::form's fill linger -- is looked at again after a nap, not in a spin under m_: with pictures pending
+        //  the wait below returns at once)
+        if (busy || lingered_) std::this_thread::sleep_for(std::chrono::microseconds(20));
         else { std::unique_lock<std::mutex> lk(m_); cv_.wait_for(lk, std::chrono::milliseconds(2), [&] { return !pending_.empty(); }); }
     }
 }

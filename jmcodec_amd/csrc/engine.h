@@ -178,6 +178,7 @@ private:
     bool cross_lane_ = true, early_intra_ = true;
     long long fill_linger_ns_ = 4000 * 1000;        // Engine::form: how long the ordinary lane's next stage batch may wait for the streams that have nothing pending yet, while no picture is urgent (JM_AMD_DEC_FILL_LINGER_US)
     unsigned long long scan_tag_form_ = 0;
+    bool lingered_ = false;                         // engine thread: this turn of the loop a batch was held back by the fill linger
     int decoders_pending_ = 0;                      // under m_: decoders with pictures in pending_ (EngineDecoderState::n_pending)
     bool deep_queues_ = false;                      // engine thread: the decoders have many parsed pictures pending -- the engine is what they wait for (Engine::form)
     std::atomic<int> early_intra_ahead_{kEarlyIntraAhead};     // knob "early_intra_ahead" (tests)
