@@ -50,7 +50,7 @@ def main():
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     bad = 0
-    with Pool(workers) as pool:
+    with Pool(workers, maxtasksperchild=2000) as pool:       # (bounds whatever a native library of the tool chain might keep per call)
         for codec, name in ((1, "hevc"), (0, "h264")):
             for res in pool.imap_unordered(one, [(codec, base, i) for i in range(n)], chunksize=4):
                 if res:

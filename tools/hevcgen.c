@@ -1858,6 +1858,15 @@ int hevcgen_generate(const HevcGenParams *gp, uint8_t **out, size_t *out_len, co
     if (e->recon) { fwrite(e->recon_buf, 1, (size_t)p->frames * ((size_t)p->width * p->height * 3 / 2), e->recon); fclose(e->recon); }
     *out = outw.buf; *out_len = outw.len;
     free(sched);
+    /* everything the encoder allocated (a sweep of 50,000 streams in one process kept 0.7 MB of it per call) */
+    {
+        Pic *pics[11]; pics[0] = &e->src; for (int i = 0; i < 10; i++) pics[1 + i] = &e->dpb[i];
+        for (int i = 0; i < 11; i++) { for (int c = 0; c < 3; c++) free(pics[i]->pl[c]); free(pics[i]->col); free(pics[i]->col_poc); free(pics[i]->col_lt); free(pics[i]->col_intra); }
+        free(e->pm); free(e->skip); free(e->depth); free(e->ipm); free(e->nofilt); free(e->edges); free(e->cbf); free(e->qpmap); free(e->mot); free(e->slice_of);
+        free(e->ctb_slice); free(e->rs2ts); free(e->ts2rs); free(e->tile_of); free(e->sao);
+        for (int c = 0; c < 3; c++) free(e->dbk[c]);
+        free(e->tex); free(e->recon_buf); free(e);
+    }
     return 0;
 }
 
