@@ -8,4 +8,4 @@ from tools import cpu_sweep
 @pytest.mark.parametrize("codec", [0, 1])
 def test_a_few_random_configurations(codec):
     for i in range(4):
-        assert cpu_sweep.one((codec, 77, i)) is None
+        assert cpu_sweep.one((codec, 77, i, False)) is None

@@ -4,7 +4,7 @@
   * the generator's own reconstruction must equal the oracle's decoded output byte for byte (two independently structured reconstructions);
   * the product's host parser (parse-only handle) must deliver the same number of frames without errors, and its per-element syntax digest must equal the
     oracle's (a third implementation of the syntax layer: final motion vectors, modes, QPs, coefficient levels).
-    python tools/cpu_sweep.py [n] [seed] [workers]"""
+    python tools/cpu_sweep.py [n] [seed] [workers] [big]      # big: picture sizes up to 1280x720, 2 - 5 frames"""
 import os
 import random
 import sys
@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 
 def one(job):
-    codec, base, i = job
+    codec, base, i, big = job
     import jmcodec_amd
     from jmcodec_amd import api
     from tools import streams
@@ -24,6 +24,8 @@ def one(job):
     r = random.Random(base * 100003 + i * 7 + codec)
     kw = hevc_params(r) if codec else h264_params(r)
     name = "hevc" if codec else "h264"
+    if big:
+        kw.update(width=r.choice([416, 640, 854, 1280, 720]), height=r.choice([240, 360, 480, 720, 576]), frames=r.choice([2, 3, 5]))
     with tempfile.NamedTemporaryFile(suffix=".yuv") as tf:
         data = (streams.generate_hevc if codec else streams.generate)(recon_path=tf.name, **kw)
         recon = open(tf.name, "rb").read()
@@ -49,10 +51,11 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    big = len(sys.argv) > 4 and sys.argv[4] == "big"
     bad = 0
     with Pool(workers, maxtasksperchild=2000) as pool:       # (bounds whatever a native library of the tool chain might keep per call)
         for codec, name in ((1, "hevc"), (0, "h264")):
-            for res in pool.imap_unordered(one, [(codec, base, i) for i in range(n)], chunksize=4):
+            for res in pool.imap_unordered(one, [(codec, base, i, big) for i in range(n)], chunksize=4):
                 if res:
                     print(res, flush=True); bad += 1
             print(name, n, "configurations done, failures so far:", bad, flush=True)
